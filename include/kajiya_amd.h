@@ -1,0 +1,274 @@
+/*
+ * kajiya_amd.h — C-ABI drop-in boundary for the MI355X-native ReSTIR-GI hot path.
+ *
+ * Every entry point replaces one pass-level method of the reference's Rust
+ * renderer (`/root/reference/crates/lib/kajiya/src/...`, cited per function).
+ * Plain pointers and sizes only: no C++ / torch types cross this boundary.
+ *
+ * Conventions
+ *   - Every function returns KjStatus (0 = OK). `kj_last_error()` returns a
+ *     thread-local message for the last failure. Nothing unwinds.
+ *   - All image arguments are DEVICE pointers to linear, row-major, tightly
+ *     packed surfaces in the texel format named in the comment (the formats are
+ *     the reference's Vulkan formats; they are part of the algorithm).
+ *   - All launches are asynchronous on the caller's `stream` (a hipStream_t
+ *     passed as void*); no host synchronisation happens inside render calls.
+ *   - Temporal (ping-pong) state lives inside the Kj* handles, mirroring
+ *     `PingPongTemporalResource` (renderers/mod.rs:73-103).
+ */
+#ifndef KAJIYA_AMD_H
+#define KAJIYA_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t KjStatus;
+enum {
+    KJ_OK = 0,
+    KJ_ERR_INVALID_ARGUMENT = 1,
+    KJ_ERR_HIP = 2,
+    KJ_ERR_OUT_OF_MEMORY = 3,
+    KJ_ERR_NOT_COMMITTED = 4,
+    KJ_ERR_UNSUPPORTED = 5
+};
+
+/* ------------------------------------------------------------------------ */
+/* Frame constants: bit-compatible with the reference's 1216-byte UBO        */
+/* (rust-shaders-shared/src/frame_constants.rs:13-37, view_constants.rs:4-23,*/
+/*  assets/shaders/inc/frame_constants.hlsl:8-82). Matrices are column-major */
+/* (glam::Mat4 memory order): m[c*4 + r].                                    */
+/* ------------------------------------------------------------------------ */
+typedef struct KjViewConstants {
+    float view_to_clip[16];
+    float clip_to_view[16];
+    float view_to_sample[16];
+    float sample_to_view[16];
+    float world_to_view[16];
+    float view_to_world[16];
+    float clip_to_prev_clip[16];
+    float prev_view_to_prev_clip[16];
+    float prev_clip_to_prev_view[16];
+    float prev_world_to_prev_view[16];
+    float prev_view_to_prev_world[16];
+    float sample_offset_pixels[2];
+    float sample_offset_clip[2];
+} KjViewConstants;
+
+typedef struct KjIrcacheCascadeConstants {
+    int32_t origin[4];
+    int32_t voxels_scrolled_this_frame[4];
+} KjIrcacheCascadeConstants;
+
+typedef struct KjRenderOverrides {
+    uint32_t flags;
+    float material_roughness_scale;
+    uint32_t pad0, pad1;
+} KjRenderOverrides;
+
+enum {
+    KJ_OVERRIDE_FORCE_FACE_NORMALS = 1u << 0,
+    KJ_OVERRIDE_NO_NORMAL_MAPS = 1u << 1,
+    KJ_OVERRIDE_FLIP_NORMAL_MAP_YZ = 1u << 2,
+    KJ_OVERRIDE_NO_METAL = 1u << 3
+};
+
+#define KJ_IRCACHE_CASCADE_COUNT 12
+
+typedef struct KjFrameConstants {
+    KjViewConstants view_constants;
+    float sun_direction[4];
+    uint32_t frame_index;
+    float delta_time_seconds;
+    float sun_angular_radius_cos;
+    uint32_t triangle_light_count;
+    float sun_color_multiplier[4];
+    float sky_ambient[4];
+    float pre_exposure;
+    float pre_exposure_prev;
+    float pre_exposure_delta;
+    float pad0;
+    KjRenderOverrides render_overrides;
+    float ircache_grid_center[4];
+    KjIrcacheCascadeConstants ircache_cascades[KJ_IRCACHE_CASCADE_COUNT];
+} KjFrameConstants; /* sizeof == 1216 */
+
+/* ------------------------------------------------------------------------ */
+/* Scene data: the reference's packed mesh layout                            */
+/* (kajiya-asset/src/mesh.rs:75-84,447-459; world_renderer.rs:43-54,604-776) */
+/* ------------------------------------------------------------------------ */
+typedef struct KjPackedVertex {
+    float pos[3];
+    uint32_t normal; /* 11:10:11 unorm of n*0.5+0.5, x in the low bits */
+} KjPackedVertex;
+
+typedef struct KjMeshMaterial { /* 152 bytes, inc/mesh.hlsl:49-59; kajiya-asset mesh.rs:75-84 */
+    float base_color_mult[4];
+    uint32_t maps[4]; /* normal, spec, albedo, emissive — indices into KjMeshDesc.maps */
+    float roughness_mult;
+    float metalness_factor;
+    float emissive[3];
+    uint32_t flags;
+    float map_transforms[24];
+} KjMeshMaterial;
+
+#define KJ_MESH_MATERIAL_FLAG_EMISSIVE_USED_AS_LIGHT 1u
+
+/* A material map. Round 1 supports the reference's `MeshMaterialMap::Placeholder`
+ * (a 1x1 RGBA8 image, mesh.rs:60-66) and full RGBA8 images with a mip chain. */
+typedef struct KjMaterialMap {
+    uint8_t placeholder_rgba[4];
+    const uint8_t* image_rgba8; /* NULL => placeholder; else width*height*4 bytes (host) */
+    uint32_t width, height;
+} KjMaterialMap;
+
+typedef struct KjMeshDesc {
+    const KjPackedVertex* verts;
+    uint32_t vertex_count;
+    const float* uvs;            /* 2 per vertex, or NULL (zeros) */
+    const float* tangents;       /* 4 per vertex, or NULL */
+    const float* colors;         /* 4 per vertex, or NULL (mesh.vertex_aux_offset == 0) */
+    const uint32_t* material_ids;/* 1 per vertex, or NULL (zeros) */
+    const uint32_t* indices;
+    uint32_t index_count;
+    const KjMeshMaterial* materials;
+    uint32_t material_count;
+    const KjMaterialMap* maps;
+    uint32_t map_count;
+    uint32_t use_lights;         /* AddMeshOptions::use_lights, world_renderer.rs:325-339 */
+} KjMeshDesc;
+
+typedef struct KjTriangleLight { /* 48 bytes: 3 verts + radiance (world_renderer.rs:107-112) */
+    float verts[9];
+    float radiance[3];
+} KjTriangleLight;
+
+typedef struct KjDevice KjDevice;
+typedef struct KjScene KjScene;
+typedef struct KjRtdgi KjRtdgi;
+typedef struct KjIrcache KjIrcache;
+typedef struct KjTaa KjTaa;
+typedef struct KjReprojection KjReprojection;
+
+const char* kj_last_error(void);
+uint32_t kj_abi_version(void);
+
+/* RenderBackend / WorldRenderer::new analogue (default_world_renderer.rs:14-58):
+ * picks the HIP device, builds the BRDF-FG LUT (bindless #0, lut/brdf_fg.hlsl),
+ * and takes the 256x256 RGBA8 blue-noise table (bindless #1, host pointer,
+ * 262144 bytes). */
+KjStatus kj_device_create(int32_t hip_device_ordinal, const uint8_t* blue_noise_rgba8_256, KjDevice** out);
+void kj_device_destroy(KjDevice* dev);
+/* Device pointer to the 64x64 RGBA16F BRDF FG LUT (for tests). */
+KjStatus kj_device_brdf_lut(KjDevice* dev, const void** out_dev_ptr);
+
+/* WorldRenderer::{add_mesh, add_instance, set_instance_transform, remove_instance}
+ * (world_renderer.rs:604,778,800,815). Transforms are row-major 3x4 affine. */
+KjStatus kj_scene_create(KjDevice* dev, KjScene** out);
+void kj_scene_destroy(KjScene* scene);
+KjStatus kj_scene_add_mesh(KjScene* scene, const KjMeshDesc* desc, uint32_t* out_mesh);
+KjStatus kj_scene_add_instance(KjScene* scene, uint32_t mesh, const float transform3x4[12], uint32_t* out_instance);
+KjStatus kj_scene_set_instance_transform(KjScene* scene, uint32_t instance, const float transform3x4[12]);
+KjStatus kj_scene_set_instance_emissive_multiplier(KjScene* scene, uint32_t instance, float v);
+KjStatus kj_scene_remove_instance(KjScene* scene, uint32_t instance);
+/* build_ray_tracing_top_level_acceleration + prepare_top_level_acceleration
+ * (world_renderer.rs:836,865): builds the software LBVH over all instances
+ * (replaces BLAS/TLAS) and uploads the scene tables. */
+KjStatus kj_scene_commit(KjScene* scene, void* stream);
+/* Number of world-space triangle lights after commit (frame_constants.triangle_light_count). */
+KjStatus kj_scene_triangle_light_count(KjScene* scene, uint32_t* out);
+KjStatus kj_scene_stats(KjScene* scene, uint32_t* out_tri_count, uint32_t* out_node_count, uint64_t* out_bvh_bytes);
+
+/* prepare_frame_constants (world_renderer.rs:1001-1108): upload this frame's UBO. */
+KjStatus kj_frame_begin(KjDevice* dev, const KjFrameConstants* fc, void* stream);
+
+/* Ray "ISA" exposed for tests and for other subsystems (inc/rt.hlsl:58-137):
+ * rays = float4 origin+tmin, float4 dir+tmax (32 B/ray); hits = {t, u, v, prim}
+ * with t = FLT_MAX on miss; any-hit variant writes 1 byte per ray. */
+KjStatus kj_trace_closest(KjScene* scene, const void* rays, void* hits, uint32_t count, uint32_t cull_back_faces, void* stream);
+KjStatus kj_trace_any(KjScene* scene, const void* rays, void* out_u8, uint32_t count, void* stream);
+
+/* G-buffer stand-in for raster_meshes (renderers/raster_meshes.rs; packing as in
+ * raster_simple_ps.hlsl:126-137): primary rays through the jittered camera.
+ * Outputs: geometric_normal A2R10G10B10_UNORM (u32), gbuffer RGBA32F-as-uint4,
+ * depth R32F (reverse-Z, 0 = sky), velocity RGBA16F. Test/bench input generator. */
+KjStatus kj_raster_gbuffer(KjDevice* dev, KjScene* scene, uint32_t width, uint32_t height,
+                           void* geometric_normal, void* gbuffer, void* depth, void* velocity, void* stream);
+
+/* sky::render_sky_cube / sky::convolve_cube (renderers/sky.rs:4-36): RGBA16F cubes,
+ * 6 faces x width x width. */
+KjStatus kj_sky_cube_render(KjDevice* dev, void* out_cube64, void* stream);
+KjStatus kj_sky_cube_convolve(KjDevice* dev, const void* cube64, void* out_cube16, void* stream);
+
+typedef struct KjGbufferDepth { /* renderers/mod.rs:31-71 */
+    const void* geometric_normal; /* A2R10G10B10_UNORM_PACK32 */
+    const void* gbuffer;          /* R32G32B32A32 (4 packed dwords, inc/gbuffer.hlsl:51-64) */
+    const void* depth;            /* R32F */
+    uint32_t width, height;
+} KjGbufferDepth;
+
+/* calculate_reprojection_map (renderers/reprojection.rs:6-52). The handle owns the
+ * `reprojection.prev_depth` temporal. Output RGBA16_SNORM, full res. */
+KjStatus kj_reprojection_create(KjDevice* dev, KjReprojection** out);
+void kj_reprojection_destroy(KjReprojection* r);
+KjStatus kj_calculate_reprojection_map(KjReprojection* r, const KjGbufferDepth* gbuffer_depth,
+                                       const void* velocity, const void** out_reprojection_map, void* stream);
+
+/* RtdgiRenderer (renderers/rtdgi.rs:11-46). */
+KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out);
+void kj_rtdgi_destroy(KjRtdgi* r);
+KjStatus kj_rtdgi_set_options(KjRtdgi* r, uint32_t spatial_reuse_pass_count, uint32_t use_raytraced_reservoir_visibility);
+
+/* RtdgiRenderer::reproject (rtdgi.rs:143-170). */
+KjStatus kj_rtdgi_reproject(KjRtdgi* r, const void* reprojection_map, uint32_t width, uint32_t height, void* stream);
+
+/* Pass bits for kj_rtdgi_render's pass_mask (data-flow order, rtdgi.rs:189-553). */
+enum {
+    KJ_RTDGI_PASS_EXTRACT_HALF = 1u << 0,   /* extract ssao/2, view normal/2, depth/2 */
+    KJ_RTDGI_PASS_VALIDATE = 1u << 1,
+    KJ_RTDGI_PASS_TRACE = 1u << 2,
+    KJ_RTDGI_PASS_VALIDITY_INTEGRATE = 1u << 3,
+    KJ_RTDGI_PASS_RESTIR_TEMPORAL = 1u << 4,
+    KJ_RTDGI_PASS_RESTIR_SPATIAL = 1u << 5,
+    KJ_RTDGI_PASS_RESTIR_RESOLVE = 1u << 6,
+    KJ_RTDGI_PASS_TEMPORAL_FILTER = 1u << 7,
+    KJ_RTDGI_PASS_SPATIAL_FILTER = 1u << 8,
+    KJ_RTDGI_PASS_ALL = 0x1ffu
+};
+
+typedef struct KjRtdgiRenderParams {
+    KjGbufferDepth gbuffer_depth;
+    const void* reprojection_map;  /* RGBA16_SNORM full res */
+    const void* sky_cube;          /* convolved 6x16x16 RGBA16F (world_render_passes.rs:150) */
+    uint32_t sky_cube_width;
+    KjScene* scene;                /* tlas + bindless set */
+    KjIrcache* ircache;            /* may be NULL: lookups return 0 (config 1) */
+    const void* ssao_tex;          /* R8_UNORM full res */
+    uint32_t pass_mask;            /* KJ_RTDGI_PASS_ALL for the product path */
+} KjRtdgiRenderParams;
+
+typedef struct KjRtdgiOutput { /* RtdgiOutput / RtdgiCandidates, rtdgi.rs:53-62 */
+    const void* screen_irradiance_tex;  /* RGBA16F full res */
+    const void* candidate_radiance_tex; /* RGBA16F half res */
+    const void* candidate_normal_tex;   /* RGBA8_SNORM half res */
+    const void* candidate_hit_tex;      /* RGBA16F half res */
+} KjRtdgiOutput;
+
+/* RtdgiRenderer::render (rtdgi.rs:173-554). */
+KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* params, KjRtdgiOutput* out, void* stream);
+
+/* Render-graph debug hook analogue (kajiya-rg/src/graph.rs:124-145): access any
+ * named surface of the renderer (names are the reference's temporal keys /
+ * variable names, e.g. "rtdgi.radiance:history", "candidate_radiance_tex").
+ * `kj_rtdgi_surface` returns the device pointer and byte size. */
+KjStatus kj_rtdgi_surface(KjRtdgi* r, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
+/* Ray counters of the last kj_rtdgi_render (closest-hit rays, any-hit rays). */
+KjStatus kj_rtdgi_ray_counts(KjRtdgi* r, uint64_t* out_closest, uint64_t* out_any);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAJIYA_AMD_H */

@@ -1,0 +1,206 @@
+// ORACLE (test infrastructure): C entry points for ctypes. Only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+// The product (kajiya_amd/) never links, imports or calls it.
+#include "okj_rtdgi.hpp"
+#include <cstdio>
+#include <chrono>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace okj;
+
+extern "C" {
+
+// ---- known-answer helpers
+uint32_t okj_hash1(uint32_t x) { return hash1(x); }
+uint32_t okj_hash_combine2(uint32_t x, uint32_t y) { return hash_combine2(x, y); }
+uint32_t okj_hash3(uint32_t x, uint32_t y, uint32_t z) { return hash3(x, y, z); }
+float okj_uint_to_u01_float(uint32_t h) { return uint_to_u01_float(h); }
+uint32_t okj_pack_normal_11_10_11(float x, float y, float z) { return pack_normal_11_10_11(f3{x, y, z}); }
+void okj_unpack_normal_11_10_11(uint32_t p, float* out) { f3 n = unpack_normal_11_10_11(p); out[0] = n.x; out[1] = n.y; out[2] = n.z; }
+uint32_t okj_pack_color_888(float r, float g, float b) { return pack_color_888(f3{r, g, b}); }
+void okj_unpack_color_888(uint32_t p, float* out) { f3 c = unpack_color_888(p); out[0] = c.x; out[1] = c.y; out[2] = c.z; }
+uint32_t okj_float3_to_rgb9e5(float r, float g, float b) { return float3_to_rgb9e5(f3{r, g, b}); }
+void okj_rgb9e5_to_float3(uint32_t p, float* out) { f3 c = rgb9e5_to_float3(p); out[0] = c.x; out[1] = c.y; out[2] = c.z; }
+uint16_t okj_f32_to_f16(float f) { return f32_to_f16(f); }
+float okj_f16_to_f32(uint16_t h) { return f16_to_f32(h); }
+void okj_r2_sequence(uint32_t i, float* out) { f2 r = r2_sequence(i); out[0] = r.x; out[1] = r.y; }
+void okj_reservoir_roundtrip(uint32_t payload, float M, float W, uint32_t* out_raw, float* out_mw) {
+    Reservoir1spp r; r.payload = payload; r.M = M; r.W = W;
+    u2 raw = r.as_raw();
+    out_raw[0] = raw.x; out_raw[1] = raw.y;
+    Reservoir1spp q = Reservoir1spp::from_raw(raw);
+    out_mw[0] = q.M; out_mw[1] = q.W;
+}
+void okj_gbuffer_roundtrip(const float* albedo, const float* normal, float roughness, float metalness, const float* emissive,
+                           uint32_t* out_packed, float* out_unpacked /*11*/) {
+    GbufferData g;
+    g.albedo = f3{albedo[0], albedo[1], albedo[2]};
+    g.normal = f3{normal[0], normal[1], normal[2]};
+    g.roughness = roughness; g.metalness = metalness;
+    g.emissive = f3{emissive[0], emissive[1], emissive[2]};
+    u4 p = gbuffer_pack(g);
+    out_packed[0] = p.x; out_packed[1] = p.y; out_packed[2] = p.z; out_packed[3] = p.w;
+    GbufferData u = gbuffer_unpack(p);
+    float o[11] = {u.albedo.x, u.albedo.y, u.albedo.z, u.normal.x, u.normal.y, u.normal.z, u.roughness, u.metalness, u.emissive.x, u.emissive.y, u.emissive.z};
+    memcpy(out_unpacked, o, sizeof(o));
+}
+// RIS estimate of integral of f(x)=x^2 on [0,1] with uniform candidates, target p_hat=f
+// (reservoir unbiasedness check; inc/reservoir.hlsl:47-97)
+double okj_ris_estimate(uint32_t n_candidates, uint32_t n_trials, uint32_t seed) {
+    double acc = 0;
+    for (uint32_t t = 0; t < n_trials; ++t) {
+        uint32_t rng = hash2(seed, t);
+        Reservoir1spp r; StreamState ss;
+        float xs = 0;
+        for (uint32_t i = 0; i < n_candidates; ++i) {
+            float x = uint_to_u01_float(hash1_mut(rng));
+            float p_hat = x * x;
+            Reservoir1spp c; c.M = 1; c.W = 1; // candidate from pdf 1 => W = 1/pdf
+            if (i == 0) { r.init_with_stream(p_hat, 1.0f, ss, i); xs = x; }
+            else if (r.update_with_stream(c, p_hat, 1.0f, ss, i, rng)) xs = x;
+        }
+        r.finish_stream(ss);
+        acc += double(xs * xs) * double(r.W);
+    }
+    return acc / n_trials;
+}
+
+void okj_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int okj_get_max_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+// ---- LUT / sky
+void okj_brdf_fg_lut(void* out) { build_brdf_fg_lut((h4*)out); }
+void okj_sky_cube_render(const KjFrameConstants* fc, void* out64) { render_sky_cube(*fc, (h4*)out64, 64); }
+void okj_sky_cube_convolve(const void* in64, void* out16) { convolve_sky_cube((const h4*)in64, 64, (h4*)out16, 16); }
+void okj_sample_cube(const void* cube, int width, const float* dir, float* out) {
+    f4 v = sample_cube_rgba16f((const h4*)cube, width, f3{dir[0], dir[1], dir[2]});
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+void okj_sun_color(const KjFrameConstants* fc, float* out) {
+    f3 c = sun_color_in_direction(*fc, sun_direction(*fc));
+    out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+void okj_layered_brdf_eval(const void* fg_lut, const float* albedo, float roughness, float metalness, const float* wo, const float* wi, float* out) {
+    GbufferData g; g.albedo = f3{albedo[0], albedo[1], albedo[2]}; g.roughness = roughness; g.metalness = metalness;
+    LayeredBrdf b = LayeredBrdf::from_gbuffer_ndotv((const h4*)fg_lut, g, wo[2]);
+    f3 v = b.evaluate(f3{wo[0], wo[1], wo[2]}, f3{wi[0], wi[1], wi[2]});
+    out[0] = v.x; out[1] = v.y; out[2] = v.z;
+}
+
+// ---- scene
+void* okj_scene_create() { return new Scene(); }
+void okj_scene_destroy(void* s) { delete (Scene*)s; }
+uint32_t okj_scene_add_mesh(void* s, const KjMeshDesc* d) { return ((Scene*)s)->add_mesh(*d); }
+uint32_t okj_scene_add_instance(void* s, uint32_t mesh, const float* xf) { return ((Scene*)s)->add_instance(mesh, xf); }
+void okj_scene_set_instance_transform(void* s, uint32_t inst, const float* xf) { memcpy(((Scene*)s)->instances[inst].xform, xf, 48); }
+void okj_scene_commit(void* s) { ((Scene*)s)->commit(); }
+void okj_scene_use_bvh(void* s, int v) { ((Scene*)s)->use_bvh = v != 0; }
+uint32_t okj_scene_triangle_count(void* s) { return uint32_t(((Scene*)s)->tris.size()); }
+uint32_t okj_scene_triangle_light_count(void* s) { return uint32_t(((Scene*)s)->triangle_lights.size()); }
+// rays: {ox,oy,oz,tmin, dx,dy,dz,tmax}; hits: {t,u,v,asfloat(tri)}
+void okj_trace_closest(void* s, const float* rays, float* hits, uint32_t count, int cull_back, int brute) {
+    const Scene& sc = *(Scene*)s;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < int64_t(count); ++i) {
+        const float* r = rays + i * 8;
+        Ray ray{f3{r[0], r[1], r[2]}, r[3], f3{r[4], r[5], r[6]}, r[7]};
+        Hit h = brute ? sc.trace_closest_brute(ray, cull_back != 0) : sc.trace_closest(ray, cull_back != 0);
+        hits[i * 4 + 0] = h.t; hits[i * 4 + 1] = h.u; hits[i * 4 + 2] = h.v; hits[i * 4 + 3] = asfloat(h.tri);
+    }
+}
+void okj_trace_any(void* s, const float* rays, uint8_t* out, uint32_t count) {
+    const Scene& sc = *(Scene*)s;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < int64_t(count); ++i) {
+        const float* r = rays + i * 8;
+        Ray ray{f3{r[0], r[1], r[2]}, r[3], f3{r[4], r[5], r[6]}, r[7]};
+        out[i] = sc.trace_any(ray) ? 1 : 0;
+    }
+}
+// world-space triangle i -> (inst, prim), for mapping product hits onto oracle triangle ids
+void okj_scene_tri_ids(void* s, uint32_t* out_inst_prim) {
+    const Scene& sc = *(Scene*)s;
+    for (size_t i = 0; i < sc.tris.size(); ++i) { out_inst_prim[i * 2] = sc.tris[i].inst; out_inst_prim[i * 2 + 1] = sc.tris[i].prim; }
+}
+
+void okj_raster_gbuffer(void* s, const KjFrameConstants* fc, uint32_t W, uint32_t H, void* geometric_normal, void* gbuffer, void* depth, void* velocity) {
+    raster_gbuffer(*(Scene*)s, *fc, W, H, ImgU32(geometric_normal, W, H), ImgU4(gbuffer, W, H), ImgR32F(depth, W, H), ImgRGBA16F(velocity, W, H));
+}
+void okj_calculate_reprojection_map(const KjFrameConstants* fc, uint32_t W, uint32_t H, const void* depth, const void* geometric_normal,
+                                    const void* prev_depth, const void* velocity, void* out) {
+    calculate_reprojection_map(*fc, W, H, ImgR32F((void*)depth, W, H), ImgU32((void*)geometric_normal, W, H), ImgR32F((void*)prev_depth, W, H),
+                               ImgRGBA16F((void*)velocity, W, H), ImgRGBA16S(out, W, H));
+}
+
+// ---- rtdgi
+struct OkjRtdgi {
+    Rtdgi r;
+    std::vector<uint8_t> blue_noise;
+    std::vector<h4> brdf_lut;
+};
+void* okj_rtdgi_create(const uint8_t* blue_noise_rgba8_256, const void* brdf_fg_lut /* may be NULL => computed */) {
+    OkjRtdgi* o = new OkjRtdgi();
+    o->blue_noise.assign(blue_noise_rgba8_256, blue_noise_rgba8_256 + 256 * 256 * 4);
+    o->brdf_lut.resize(64 * 64);
+    if (brdf_fg_lut) memcpy(o->brdf_lut.data(), brdf_fg_lut, 64 * 64 * 8);
+    else build_brdf_fg_lut(o->brdf_lut.data());
+    return o;
+}
+void okj_rtdgi_destroy(void* p) { delete (OkjRtdgi*)p; }
+void okj_rtdgi_set_options(void* p, uint32_t spatial_reuse_pass_count) { ((OkjRtdgi*)p)->r.spatial_reuse_pass_count = spatial_reuse_pass_count; }
+void okj_rtdgi_reproject(void* p, const KjFrameConstants* fc, const void* reprojection_map, uint32_t W, uint32_t H) {
+    ((OkjRtdgi*)p)->r.reproject(*fc, ImgRGBA16S((void*)reprojection_map, W, H), W, H);
+}
+// params hold HOST pointers here; params->scene is an okj scene handle.
+void okj_rtdgi_render(void* p, const KjFrameConstants* fc, const KjRtdgiRenderParams* params, KjRtdgiOutput* out) {
+    OkjRtdgi* o = (OkjRtdgi*)p;
+    RtdgiInputs in;
+    const int W = params->gbuffer_depth.width, H = params->gbuffer_depth.height;
+    in.W = W; in.H = H;
+    in.geometric_normal = ImgU32((void*)params->gbuffer_depth.geometric_normal, W, H);
+    in.gbuffer = ImgU4((void*)params->gbuffer_depth.gbuffer, W, H);
+    in.depth = ImgR32F((void*)params->gbuffer_depth.depth, W, H);
+    in.reprojection_map = ImgRGBA16S((void*)params->reprojection_map, W, H);
+    in.sky_cube = (const h4*)params->sky_cube;
+    in.sky_cube_width = params->sky_cube_width;
+    in.scene = (const Scene*)params->scene;
+    in.ssao = ImgR8((void*)params->ssao_tex, W, H);
+    in.blue_noise = o->blue_noise.data();
+    in.brdf_fg_lut = o->brdf_lut.data();
+    Rtdgi::Output r = o->r.render(*fc, in, params->pass_mask);
+    if (out) {
+        out->screen_irradiance_tex = r.screen_irradiance_tex.p;
+        out->candidate_radiance_tex = r.candidate_radiance_tex.p;
+        out->candidate_normal_tex = r.candidate_normal_tex.p;
+        out->candidate_hit_tex = r.candidate_hit_tex.p;
+    }
+}
+int okj_rtdgi_surface(void* p, const char* name, void** out_ptr, uint64_t* out_bytes) {
+    OkjRtdgi* o = (OkjRtdgi*)p;
+    auto it = o->r.surf.find(name);
+    if (it == o->r.surf.end()) return 1;
+    *out_ptr = it->second.data();
+    *out_bytes = it->second.size();
+    return 0;
+}
+void okj_rtdgi_ray_counts(void* p, uint64_t* closest, uint64_t* any) {
+    OkjRtdgi* o = (OkjRtdgi*)p;
+    *closest = o->r.rays_closest.load();
+    *any = o->r.rays_any.load();
+}
+
+} // extern "C"

@@ -1,0 +1,203 @@
+"""ORACLE (test infrastructure): ctypes loader + a frame driver for the CPU restatement.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from kajiya_amd.abi import (KjFrameConstants, KjMeshDesc, KjRtdgiRenderParams, KjRtdgiOutput, KJ_RTDGI_PASS)  # noqa: E402
+from kajiya_amd import scenes as kscenes  # noqa: E402
+
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(HERE, "liboracle_kajiya.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.okj_hash1.restype = C.c_uint32; L.okj_hash1.argtypes = [C.c_uint32]
+        L.okj_hash_combine2.restype = C.c_uint32; L.okj_hash_combine2.argtypes = [C.c_uint32, C.c_uint32]
+        L.okj_hash3.restype = C.c_uint32; L.okj_hash3.argtypes = [C.c_uint32] * 3
+        L.okj_uint_to_u01_float.restype = C.c_float; L.okj_uint_to_u01_float.argtypes = [C.c_uint32]
+        L.okj_pack_normal_11_10_11.restype = C.c_uint32; L.okj_pack_normal_11_10_11.argtypes = [C.c_float] * 3
+        L.okj_pack_color_888.restype = C.c_uint32; L.okj_pack_color_888.argtypes = [C.c_float] * 3
+        L.okj_float3_to_rgb9e5.restype = C.c_uint32; L.okj_float3_to_rgb9e5.argtypes = [C.c_float] * 3
+        L.okj_f32_to_f16.restype = C.c_uint16; L.okj_f32_to_f16.argtypes = [C.c_float]
+        L.okj_f16_to_f32.restype = C.c_float; L.okj_f16_to_f32.argtypes = [C.c_uint16]
+        L.okj_ris_estimate.restype = C.c_double; L.okj_ris_estimate.argtypes = [C.c_uint32] * 3
+        L.okj_scene_create.restype = C.c_void_p
+        L.okj_scene_destroy.argtypes = [C.c_void_p]
+        L.okj_scene_add_mesh.restype = C.c_uint32; L.okj_scene_add_mesh.argtypes = [C.c_void_p, C.POINTER(KjMeshDesc)]
+        L.okj_scene_add_instance.restype = C.c_uint32; L.okj_scene_add_instance.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.okj_scene_set_instance_transform.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.okj_scene_commit.argtypes = [C.c_void_p]
+        L.okj_scene_use_bvh.argtypes = [C.c_void_p, C.c_int]
+        L.okj_scene_triangle_count.restype = C.c_uint32; L.okj_scene_triangle_count.argtypes = [C.c_void_p]
+        L.okj_scene_triangle_light_count.restype = C.c_uint32; L.okj_scene_triangle_light_count.argtypes = [C.c_void_p]
+        L.okj_scene_tri_ids.argtypes = [C.c_void_p, C.c_void_p]
+        L.okj_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
+        L.okj_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.okj_raster_gbuffer.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_uint32, C.c_uint32] + [C.c_void_p] * 4
+        L.okj_calculate_reprojection_map.argtypes = [C.POINTER(KjFrameConstants), C.c_uint32, C.c_uint32] + [C.c_void_p] * 5
+        L.okj_brdf_fg_lut.argtypes = [C.c_void_p]
+        L.okj_sky_cube_render.argtypes = [C.POINTER(KjFrameConstants), C.c_void_p]
+        L.okj_sky_cube_convolve.argtypes = [C.c_void_p, C.c_void_p]
+        L.okj_sample_cube.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.okj_sun_color.argtypes = [C.POINTER(KjFrameConstants), C.c_void_p]
+        L.okj_rtdgi_create.restype = C.c_void_p; L.okj_rtdgi_create.argtypes = [C.c_void_p, C.c_void_p]
+        L.okj_rtdgi_destroy.argtypes = [C.c_void_p]
+        L.okj_rtdgi_set_options.argtypes = [C.c_void_p, C.c_uint32]
+        L.okj_rtdgi_reproject.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_uint32]
+        L.okj_rtdgi_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.POINTER(KjRtdgiRenderParams), C.POINTER(KjRtdgiOutput)]
+        L.okj_rtdgi_surface.restype = C.c_int
+        L.okj_rtdgi_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.okj_rtdgi_ray_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.okj_set_threads.argtypes = [C.c_int]
+        L.okj_get_max_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def blue_noise():
+    return np.fromfile(os.path.join(kscenes.GOLDEN_DIR, "bluenoise_256_rgba8.bin"), dtype=np.uint8)
+
+
+_BRDF_LUT = None
+
+
+def brdf_lut():
+    global _BRDF_LUT
+    if _BRDF_LUT is None:
+        out = np.zeros((64, 64, 4), np.uint16)
+        lib().okj_brdf_fg_lut(out.ctypes.data)
+        _BRDF_LUT = out
+    return _BRDF_LUT
+
+
+class OracleScene:
+    def __init__(self, desc: kscenes.SceneDesc, use_lights=False):
+        L = lib()
+        self.h = L.okj_scene_create()
+        self._keep = []
+        for m in desc.meshes:
+            d, keep = m.pack(use_lights)
+            self._keep.append(keep)
+            L.okj_scene_add_mesh(self.h, C.byref(d))
+        for mi, xf in desc.instances:
+            L.okj_scene_add_instance(self.h, mi, xf.ctypes.data)
+        L.okj_scene_commit(self.h)
+        self.triangle_count = L.okj_scene_triangle_count(self.h)
+        self.triangle_light_count = L.okj_scene_triangle_light_count(self.h)
+
+    def trace_closest(self, rays, cull_back=False, brute=False):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.zeros((len(rays), 4), np.float32)
+        lib().okj_trace_closest(self.h, rays.ctypes.data, hits.ctypes.data, len(rays), int(cull_back), int(brute))
+        return hits
+
+    def trace_any(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(len(rays), np.uint8)
+        lib().okj_trace_any(self.h, rays.ctypes.data, out.ctypes.data, len(rays))
+        return out
+
+    def tri_ids(self):
+        out = np.zeros((self.triangle_count, 2), np.uint32)
+        lib().okj_scene_tri_ids(self.h, out.ctypes.data)
+        return out
+
+    def __del__(self):
+        try:
+            lib().okj_scene_destroy(self.h)
+        except Exception:
+            pass
+
+
+class OraclePipeline:
+    """CPU restatement of one frame of the hot path (world_render_passes.rs:13-292, the subset in
+    scope): sky cubes -> G-buffer stand-in -> reprojection map -> rtdgi.reproject -> rtdgi.render."""
+
+    def __init__(self, scene: OracleScene, width, height):
+        L = lib()
+        self.L = L
+        self.scene = scene
+        self.W, self.H = width, height
+        self.bn = blue_noise()
+        self.rtdgi = L.okj_rtdgi_create(self.bn.ctypes.data, brdf_lut().ctypes.data)
+        W, H = width, height
+        self.geometric_normal = np.zeros((H, W), np.uint32)
+        self.gbuffer = np.zeros((H, W, 4), np.uint32)
+        self.depth = np.zeros((H, W), np.float32)
+        self.velocity = np.zeros((H, W, 4), np.uint16)
+        self.prev_depth = np.zeros((H, W), np.float32)
+        self.reprojection_map = np.zeros((H, W, 4), np.int16)
+        self.ssao = np.full((H, W), 255, np.uint8)
+        self.sky64 = np.zeros((6, 64, 64, 4), np.uint16)
+        self.sky16 = np.zeros((6, 16, 16, 4), np.uint16)
+        self._sky_key = None
+        self.out = KjRtdgiOutput()
+
+    def render_inputs(self, fc):
+        L = self.L
+        key = bytes(fc.sun_direction) + bytes(fc.sun_color_multiplier) + bytes(fc.sky_ambient) + bytes(C.c_float(fc.pre_exposure))
+        if key != self._sky_key:
+            L.okj_sky_cube_render(C.byref(fc), self.sky64.ctypes.data)
+            L.okj_sky_cube_convolve(self.sky64.ctypes.data, self.sky16.ctypes.data)
+            self._sky_key = key
+        L.okj_raster_gbuffer(self.scene.h, C.byref(fc), self.W, self.H, self.geometric_normal.ctypes.data,
+                             self.gbuffer.ctypes.data, self.depth.ctypes.data, self.velocity.ctypes.data)
+
+    def reprojection(self, fc):
+        self.L.okj_calculate_reprojection_map(C.byref(fc), self.W, self.H, self.depth.ctypes.data, self.geometric_normal.ctypes.data,
+                                              self.prev_depth.ctypes.data, self.velocity.ctypes.data, self.reprojection_map.ctypes.data)
+        self.prev_depth[...] = self.depth  # "copy depth" pass (renderers/reprojection.rs:37-49)
+
+    def params(self, pass_mask=KJ_RTDGI_PASS["ALL"]):
+        p = KjRtdgiRenderParams()
+        p.gbuffer_depth.geometric_normal = self.geometric_normal.ctypes.data
+        p.gbuffer_depth.gbuffer = self.gbuffer.ctypes.data
+        p.gbuffer_depth.depth = self.depth.ctypes.data
+        p.gbuffer_depth.width, p.gbuffer_depth.height = self.W, self.H
+        p.reprojection_map = self.reprojection_map.ctypes.data
+        p.sky_cube = self.sky16.ctypes.data
+        p.sky_cube_width = 16
+        p.scene = self.scene.h
+        p.ircache = None
+        p.ssao_tex = self.ssao.ctypes.data
+        p.pass_mask = pass_mask
+        return p
+
+    def rtdgi_frame(self, fc, pass_mask=KJ_RTDGI_PASS["ALL"]):
+        self.L.okj_rtdgi_reproject(self.rtdgi, C.byref(fc), self.reprojection_map.ctypes.data, self.W, self.H)
+        p = self.params(pass_mask)
+        self.L.okj_rtdgi_render(self.rtdgi, C.byref(fc), C.byref(p), C.byref(self.out))
+
+    def frame(self, fc):
+        self.render_inputs(fc)
+        self.reprojection(fc)
+        self.rtdgi_frame(fc)
+
+    def surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        if self.L.okj_rtdgi_surface(self.rtdgi, name.encode(), C.byref(ptr), C.byref(n)) != 0:
+            raise KeyError(name)
+        buf = (C.c_uint8 * n.value).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def ray_counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.L.okj_rtdgi_ray_counts(self.rtdgi, C.byref(a), C.byref(b))
+        return a.value, b.value
