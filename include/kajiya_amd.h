@@ -236,7 +236,10 @@ enum {
     KJ_RTDGI_PASS_RESTIR_RESOLVE = 1u << 6,
     KJ_RTDGI_PASS_TEMPORAL_FILTER = 1u << 7,
     KJ_RTDGI_PASS_SPATIAL_FILTER = 1u << 8,
-    KJ_RTDGI_PASS_ALL = 0x1ffu
+    KJ_RTDGI_PASS_ALL = 0x1ffu,
+    /* Debug: re-use the previous call's ping-pong assignment instead of advancing it, so a frame can be
+     * executed pass by pass (render-graph debug hook analogue). Never set on the product path. */
+    KJ_RTDGI_PASS_KEEP_TEMPORALS = 1u << 31
 };
 
 typedef struct KjRtdgiRenderParams {

@@ -1,0 +1,284 @@
+// KjDevice + frame prologue kernels for gfx950:
+//   BRDF FG LUT (lut/brdf_fg.hlsl), sky cube + convolution (sky/comp_cube.hlsl,
+//   convolve_cube.hlsl), primary-ray G-buffer stand-in (raster_simple_ps.hlsl:126-137
+//   packing), reprojection map (calculate_reprojection_map.hlsl:17-142) and the
+//   raw ray-query entry points (inc/rt.hlsl:58-137).
+#include "kj_host.hpp"
+#include "kj_scene.hpp"
+
+using namespace kj;
+
+namespace kj { SceneView scene_view(const KjScene& s); }
+
+// ------------------------------------------------------------------ LUT / sun / sky
+__global__ void k_brdf_fg_lut(uint2* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= 64 || y >= 64) return;
+    const float ndotv = (float(x) / 63.0f) * (1.0f - 1e-3f) + 1e-3f;
+    const float roughness = fmaxf(1e-5f, float(y) / 63.0f);
+    out[y * 64 + x] = pack_rgba16f(v4(integrate_brdf_fg(roughness, ndotv), 0.0f));
+}
+__global__ void k_sun_color(const FrameConstants* __restrict__ fc, float4* __restrict__ out) {
+    const V3 c = sun_color_in_direction(*fc, sun_direction(*fc));
+    *out = make_float4(c.x, c.y, c.z, 0.0f);
+}
+__global__ void k_sky_cube(const FrameConstants* __restrict__ fc, uint2* __restrict__ out, int width) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, face = blockIdx.z;
+    if (x >= width || y >= width) return;
+    const V3 dir = cube_face_dir(face, V2{(x + 0.5f) / float(width), (y + 0.5f) / float(width)});
+    const V3 c = atmosphere_default(*fc, dir, sun_direction(*fc));
+    out[(size_t(face) * width + y) * width + x] = pack_rgba16f(v4(c, 1.0f));
+}
+// one wave per output texel: 512 cone samples, 8 per lane, wave-reduced
+__global__ void __launch_bounds__(64) k_convolve_cube(const uint2* __restrict__ in, int in_width, uint2* __restrict__ out, int width) {
+    const int texel = blockIdx.x;
+    const int face = texel / (width * width), y = (texel / width) % width, x = texel % width;
+    const V3 output_dir = cube_face_dir(face, V2{(x + 0.5f) / float(width), (y + 0.5f) / float(width)});
+    const Basis basis = build_orthonormal_basis(output_dir);
+    V4 acc = v4(0.0f);
+    for (uint32_t i = threadIdx.x; i < 512u; i += 64u) {
+        const V3 input_dir = to_world(basis, uniform_sample_cone(hammersley(i, 512u), 0.99f));
+        acc += sample_cube_rgba16f(in, in_width, input_dir);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+        acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+    }
+    if (threadIdx.x == 0) out[texel] = pack_rgba16f(acc / 512.0f);
+}
+
+// ------------------------------------------------------------------ G-buffer stand-in
+__global__ void __launch_bounds__(64) k_raster_gbuffer(const FrameConstants* __restrict__ fcp, SceneView sc, int W, int H, uint32_t* __restrict__ geometric_normal,
+                                                        uint4* __restrict__ gbuffer, float* __restrict__ depth, uint2* __restrict__ velocity) {
+    extern __shared__ uint32_t lds_stack[];
+    const int x = blockIdx.x * 8 + (threadIdx.x & 7), y = blockIdx.y * 8 + (threadIdx.x >> 3);
+    if (x >= W || y >= H) return;
+    const FrameConstants& fc = *fcp;
+    const V2 uv = get_uv(float(x), float(y), tex_size4(W, H));
+    const ViewRay vr = view_ray_from_uv(fc, uv);
+    const RayHit h = bvh_trace<false>(sc.bvh, vr.origin_ws, vr.dir_ws, 0.0f, FLT_MAX, false, lds_stack + threadIdx.x, 64);
+    const size_t idx = size_t(y) * W + x;
+    if (h.slot == 0xffffffffu) {
+        geometric_normal[idx] = 0; gbuffer[idx] = make_uint4(0, 0, 0, 0); depth[idx] = 0.0f; velocity[idx] = make_uint2(0, 0);
+        return;
+    }
+    const float4* __restrict__ tp = (const float4*)sc.bvh.tris + size_t(h.slot) * 3;
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    V3 gn_ws = normalize(cross(V3{b.x - a.x, b.y - a.y, b.z - a.z}, V3{c.x - a.x, c.y - a.y, c.z - a.z}));
+    if (dot(gn_ws, vr.dir_ws) > 0) gn_ws = -gn_ws;
+    const V3 gn_vs = normalize(direction_world_to_view(fc, gn_ws));
+    const V3 pos = mad_nc(vr.origin_ws, vr.dir_ws, h.t);
+    const V3 cs = position_world_to_sample(fc, pos);
+    geometric_normal[idx] = pack_a2r10g10b10(gn_vs * 0.5f + 0.5f);
+    gbuffer[idx] = shade_gbuffer_hit(sc, fc, vr.dir_ws, h, 0);
+    depth[idx] = cs.z;
+    velocity[idx] = make_uint2(0, 0);
+}
+
+// ------------------------------------------------------------------ reprojection map
+__global__ void __launch_bounds__(64) k_reprojection_map(const FrameConstants* __restrict__ fcp, int W, int H, const float* __restrict__ depth_p,
+                                                          const uint32_t* __restrict__ gn_p, const float* __restrict__ prev_depth_p,
+                                                          const uint2* __restrict__ velocity_p, uint2* __restrict__ out_p) {
+    const int x = blockIdx.x * 8 + (threadIdx.x & 7), y = blockIdx.y * 8 + (threadIdx.x >> 3);
+    if (x >= W || y >= H) return;
+    const FrameConstants& fc = *fcp;
+    const KjViewConstants& vc = fc.view_constants;
+    const size_t idx = size_t(y) * W + x;
+    const V2 uv = get_uv(float(x), float(y), tex_size4(W, H));
+    auto store = [&](V4 v) {
+        out_p[idx] = make_uint2(uint32_t(uint16_t(to_snorm16(v.x))) | (uint32_t(uint16_t(to_snorm16(v.y))) << 16),
+                                uint32_t(uint16_t(to_snorm16(v.z))) | (uint32_t(uint16_t(to_snorm16(v.w))) << 16));
+    };
+    const float depth = depth_p[idx];
+    const V2 cs = uv_to_cs(uv);
+    if (depth == 0.0f) {
+        const V4 pos_vs = mul44(vc.clip_to_view, V4{cs.x, cs.y, 0.0f, 1.0f});
+        const V4 prev_pcs = mul44(vc.clip_to_prev_clip, mul44(vc.view_to_clip, pos_vs));
+        const V2 uv_diff = cs_to_uv(V2{prev_pcs.x, prev_pcs.y}) - uv;
+        store(V4{uv_diff.x, uv_diff.y, 0, 0});
+        return;
+    }
+    const V3 normal_vs = unpack_a2r10g10b10(gn_p[idx]) * 2.0f - 1.0f;
+    const V3 normal_pvs = xyz(mul44(vc.prev_clip_to_prev_view, mul44(vc.clip_to_prev_clip, mul44(vc.view_to_clip, v4(normal_vs, 0)))));
+    const V4 pos_vs = mul44(vc.clip_to_view, V4{cs.x, cs.y, depth, 1.0f});
+    const float dist_to_point = -(pos_vs.z / pos_vs.w);
+    V4 prev_vs = pos_vs / pos_vs.w;
+    const V4 vel = unpack_rgba16f(velocity_p[idx]);
+    prev_vs.x += vel.x; prev_vs.y += vel.y; prev_vs.z += vel.z;
+    const V4 prev_pcs = mul44(vc.clip_to_prev_clip, mul44(vc.view_to_clip, prev_vs));
+    V2 prev_uv = cs_to_uv(V2{prev_pcs.x / prev_pcs.w, prev_pcs.y / prev_pcs.w});
+    V2 uv_diff = prev_uv - uv;
+    uv_diff = V2{floorf(uv_diff.x * 32767.0f + 0.5f) / 32767.0f, floorf(uv_diff.y * 32767.0f + 0.5f) / 32767.0f};
+    prev_uv = uv + uv_diff;
+    V4 prev_pvs = mul44(vc.prev_clip_to_prev_view, prev_pcs);
+    prev_pvs = prev_pvs / prev_pvs.w;
+    const float plane_dist_prev_dz = fminf(-0.2f, normal_vs.z);
+    const V2 bp = prev_uv * V2{float(W), float(H)} - 0.5f;
+    const int ox = int(truncf(bp.x)), oy = int(truncf(bp.y));
+    const Img<float> pdimg = img<float>(prev_depth_p, W, H);
+    const V4 prev_depth{pdimg.ldc(ox, oy), pdimg.ldc(ox + 1, oy), pdimg.ldc(ox, oy + 1), pdimg.ldc(ox + 1, oy + 1)};
+    const float m43 = -vc.prev_clip_to_prev_view[11];
+    const V4 pvz{1.0f / (prev_depth.x * m43), 1.0f / (prev_depth.y * m43), 1.0f / (prev_depth.z * m43), 1.0f / (prev_depth.w * m43)};
+    const V4 qd{fabsf(plane_dist_prev_dz * (pvz.x - prev_pvs.z)), fabsf(plane_dist_prev_dz * (pvz.y - prev_pvs.z)),
+                fabsf(plane_dist_prev_dz * (pvz.z - prev_pvs.z)), fabsf(plane_dist_prev_dz * (pvz.w - prev_pvs.z))};
+    const float acceptance_threshold = 0.001f * (1080.0f / float(H));
+    const V3 pos_vs_norm = normalize(xyz(pos_vs) / pos_vs.w);
+    const float ndotv = dot(normal_vs, pos_vs_norm);
+    const float prev_ndotv = dot(normal_pvs, normalize(xyz(prev_pvs)));
+    const float thr = acceptance_threshold * dist_to_point / -ndotv;
+    V4 qv{stepf(qd.x, thr), stepf(qd.y, thr), stepf(qd.z, thr), stepf(qd.w, thr)};
+    qv.x *= pdimg.inb(ox, oy) ? 1.0f : 0.0f;
+    qv.y *= pdimg.inb(ox + 1, oy) ? 1.0f : 0.0f;
+    qv.z *= pdimg.inb(ox, oy + 1) ? 1.0f : 0.0f;
+    qv.w *= pdimg.inb(ox + 1, oy + 1) ? 1.0f : 0.0f;
+    const float validity = dot(qv, V4{1, 2, 4, 8}) / 15.0f;
+    float accuracy = smoothstep(0.8f, 0.95f, prev_ndotv / ndotv);
+    if (saturate(prev_uv.x) != prev_uv.x || saturate(prev_uv.y) != prev_uv.y) accuracy = -1;
+    store(V4{uv_diff.x, uv_diff.y, validity, accuracy});
+}
+
+// ------------------------------------------------------------------ raw ray queries
+__global__ void __launch_bounds__(64) k_trace_closest(SceneView sc, const float4* __restrict__ rays, float4* __restrict__ hits, uint32_t count, int cull_back) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    const float4 a = rays[i * 2], b = rays[i * 2 + 1];
+    const RayHit h = bvh_trace<false>(sc.bvh, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, a.w, b.w, cull_back != 0, lds_stack + threadIdx.x, 64);
+    hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.world_id));
+}
+__global__ void __launch_bounds__(64) k_trace_any(SceneView sc, const float4* __restrict__ rays, uint8_t* __restrict__ out, uint32_t count) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    const float4 a = rays[i * 2], b = rays[i * 2 + 1];
+    out[i] = bvh_trace<true>(sc.bvh, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, a.w, b.w, false, lds_stack + threadIdx.x, 64).slot != 0xffffffffu ? 1 : 0;
+}
+
+#define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
+
+extern "C" {
+
+KjStatus kj_device_create(int32_t ordinal, const uint8_t* blue_noise_rgba8_256, KjDevice** out) {
+    KJ_REQUIRE(out && blue_noise_rgba8_256, "null argument");
+    int n = 0;
+    KJ_TRY_HIP(hipGetDeviceCount(&n));
+    if (ordinal < 0 || ordinal >= n) { set_last_error("HIP device %d not available (%d devices)", ordinal, n); return KJ_ERR_HIP; }
+    KJ_TRY_HIP(hipSetDevice(ordinal));
+    KjDevice* d = new KjDevice();
+    d->ordinal = ordinal;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ordinal) == hipSuccess) d->num_cus = uint32_t(prop.multiProcessorCount);
+    KjStatus st = KJ_OK;
+    do {
+        if (d->blue_noise.upload(blue_noise_rgba8_256, 256 * 256 * 4) != hipSuccess) { st = KJ_ERR_OUT_OF_MEMORY; break; }
+        if (d->brdf_fg_lut.alloc(64 * 64 * 8) != hipSuccess) { st = KJ_ERR_OUT_OF_MEMORY; break; }
+        if (d->frame_constants.alloc(sizeof(KjFrameConstants) * KjDevice::FC_RING) != hipSuccess) { st = KJ_ERR_OUT_OF_MEMORY; break; }
+        if (d->sun_color.alloc(16 * KjDevice::FC_RING) != hipSuccess) { st = KJ_ERR_OUT_OF_MEMORY; break; }
+        hipLaunchKernelGGL(k_brdf_fg_lut, dim3(8, 8), dim3(8, 8), 0, 0, (uint2*)d->brdf_fg_lut.p);
+        if (hipDeviceSynchronize() != hipSuccess) { st = KJ_ERR_HIP; break; }
+    } while (0);
+    if (st != KJ_OK) { set_last_error("kj_device_create failed: %s", hipGetErrorString(hipGetLastError())); delete d; return st; }
+    *out = d;
+    return KJ_OK;
+}
+void kj_device_destroy(KjDevice* dev) { delete dev; }
+KjStatus kj_device_brdf_lut(KjDevice* dev, const void** out) {
+    KJ_REQUIRE(dev && out, "null argument");
+    *out = dev->brdf_fg_lut.p;
+    return KJ_OK;
+}
+
+KjStatus kj_frame_begin(KjDevice* dev, const KjFrameConstants* fc, void* stream_) {
+    KJ_REQUIRE(dev && fc, "null argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    dev->fc_slot = (dev->fc_slot + 1) % KjDevice::FC_RING;
+    dev->fc_host = *fc;
+    KjFrameConstants* dst = (KjFrameConstants*)dev->frame_constants.p + dev->fc_slot;
+    KJ_TRY_HIP(hipMemcpyAsync(dst, fc, sizeof(KjFrameConstants), hipMemcpyHostToDevice, stream));
+    dev->fc_dev = dst;
+    hipLaunchKernelGGL(k_sun_color, dim3(1), dim3(1), 0, stream, dst, (float4*)dev->sun_color.p + dev->fc_slot);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+
+KjStatus kj_sky_cube_render(KjDevice* dev, void* out_cube64, void* stream) {
+    KJ_REQUIRE(dev && out_cube64 && dev->fc_dev, "null argument / kj_frame_begin not called");
+    hipLaunchKernelGGL(k_sky_cube, dim3(8, 8, 6), dim3(8, 8), 0, (hipStream_t)stream, dev->fc_dev, (uint2*)out_cube64, 64);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+KjStatus kj_sky_cube_convolve(KjDevice* dev, const void* cube64, void* out_cube16, void* stream) {
+    KJ_REQUIRE(dev && cube64 && out_cube16, "null argument");
+    hipLaunchKernelGGL(k_convolve_cube, dim3(6 * 16 * 16), dim3(64), 0, (hipStream_t)stream, (const uint2*)cube64, 64, (uint2*)out_cube16, 16);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+
+KjStatus kj_raster_gbuffer(KjDevice* dev, KjScene* scene, uint32_t W, uint32_t H, void* geometric_normal, void* gbuffer, void* depth, void* velocity, void* stream) {
+    KJ_REQUIRE(dev && scene && geometric_normal && gbuffer && depth && velocity && dev->fc_dev, "null argument / kj_frame_begin not called");
+    if (!scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
+    const SceneView sv = scene_view(*scene);
+    hipLaunchKernelGGL(k_raster_gbuffer, dim3((W + 7) / 8, (H + 7) / 8), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, dev->fc_dev, sv, int(W), int(H),
+                       (uint32_t*)geometric_normal, (uint4*)gbuffer, (float*)depth, (uint2*)velocity);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+
+KjStatus kj_trace_closest(KjScene* scene, const void* rays, void* hits, uint32_t count, uint32_t cull_back_faces, void* stream) {
+    KJ_REQUIRE(scene && rays && hits, "null argument");
+    if (!scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
+    if (count == 0) return KJ_OK;
+    const SceneView sv = scene_view(*scene);
+    hipLaunchKernelGGL(k_trace_closest, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (float4*)hits, count, int(cull_back_faces));
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+KjStatus kj_trace_any(KjScene* scene, const void* rays, void* out_u8, uint32_t count, void* stream) {
+    KJ_REQUIRE(scene && rays && out_u8, "null argument");
+    if (!scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
+    if (count == 0) return KJ_OK;
+    const SceneView sv = scene_view(*scene);
+    hipLaunchKernelGGL(k_trace_any, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+
+// ---- reprojection
+}  // extern "C"
+
+struct KjReprojection {
+    KjDevice* dev = nullptr;
+    kj::DevBuf prev_depth, output;
+    uint32_t W = 0, H = 0;
+};
+
+extern "C" {
+
+KjStatus kj_reprojection_create(KjDevice* dev, KjReprojection** out) {
+    KJ_REQUIRE(dev && out, "null argument");
+    KjReprojection* r = new KjReprojection();
+    r->dev = dev;
+    *out = r;
+    return KJ_OK;
+}
+void kj_reprojection_destroy(KjReprojection* r) { delete r; }
+
+KjStatus kj_calculate_reprojection_map(KjReprojection* r, const KjGbufferDepth* gd, const void* velocity, const void** out_map, void* stream_) {
+    KJ_REQUIRE(r && gd && velocity && out_map && r->dev->fc_dev, "null argument / kj_frame_begin not called");
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint32_t W = gd->width, H = gd->height;
+    if (W != r->W || H != r->H) {
+        KJ_TRY_HIP(r->prev_depth.alloc(size_t(W) * H * 4, stream));  // temporal "reprojection.prev_depth", zero-initialised
+        KJ_TRY_HIP(r->output.alloc(size_t(W) * H * 8, stream));
+        r->W = W; r->H = H;
+    }
+    hipLaunchKernelGGL(k_reprojection_map, dim3((W + 7) / 8, (H + 7) / 8), dim3(64), 0, stream, r->dev->fc_dev, int(W), int(H), (const float*)gd->depth,
+                       (const uint32_t*)gd->geometric_normal, (const float*)r->prev_depth.p, (const uint2*)velocity, (uint2*)r->output.p);
+    KJ_CHECK_LAUNCH();
+    // "copy depth" pass (renderers/reprojection.rs:37-49)
+    KJ_TRY_HIP(hipMemcpyAsync(r->prev_depth.p, gd->depth, size_t(W) * H * 4, hipMemcpyDeviceToDevice, stream));
+    *out_map = r->output.p;
+    return KJ_OK;
+}
+
+}  // extern "C"

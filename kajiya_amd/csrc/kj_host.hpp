@@ -1,0 +1,87 @@
+// Host-side objects behind the C-ABI handles (include/kajiya_amd.h).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/kajiya_amd.h"
+#include "kj_scene_types.hpp"
+
+namespace kj {
+
+void set_last_error(const char* fmt, ...);
+
+#define KJ_TRY_HIP(expr)                                                                              \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            kj::set_last_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return KJ_ERR_HIP;                                                                        \
+        }                                                                                             \
+    } while (0)
+#define KJ_REQUIRE(cond, msg)                                            \
+    do {                                                                 \
+        if (!(cond)) {                                                   \
+            kj::set_last_error("%s:%d: %s", __FILE__, __LINE__, msg);    \
+            return KJ_ERR_INVALID_ARGUMENT;                              \
+        }                                                                \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    // (re)allocate, zero-filled
+    hipError_t alloc(size_t n, hipStream_t s = nullptr) {
+        if (n == bytes && p) return hipSuccess;
+        release();
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        bytes = n;
+        return hipMemsetAsync(p, 0, n, s);
+    }
+    hipError_t upload(const void* src, size_t n, hipStream_t s = nullptr) {
+        hipError_t e = alloc(n, s);
+        if (e != hipSuccess || n == 0) return e;
+        return hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, s);
+    }
+};
+
+} // namespace kj
+
+struct KjDevice {
+    int ordinal = 0;
+    kj::DevBuf blue_noise;      // 256x256 RGBA8
+    kj::DevBuf brdf_fg_lut;     // 64x64 RGBA16F
+    kj::DevBuf frame_constants; // ring of KjFrameConstants
+    uint32_t fc_slot = 0;
+    static const uint32_t FC_RING = 16;
+    KjFrameConstants fc_host{};           // last uploaded
+    const KjFrameConstants* fc_dev = nullptr;
+    kj::DevBuf sun_color;                 // float4: SUN_COLOR hoisted per frame (inc/sun.hlsl:21-33)
+    uint32_t num_cus = 256;
+};
+
+struct KjScene {
+    KjDevice* dev = nullptr;
+    // host-side tables (the reference keeps these in one 1 GiB vertex buffer + mesh buffer)
+    std::vector<uint8_t> vertex_buffer;
+    std::vector<kj::GpuMesh> meshes;
+    std::vector<std::vector<KjTriangleLight>> mesh_lights;
+    struct Inst { uint32_t mesh; float xform[12]; float emissive_multiplier; bool alive; };
+    std::vector<Inst> instances;
+    std::vector<float> map_colors; // 4 per map
+    // committed device state
+    bool committed = false;
+    kj::DevBuf d_vertex_buffer, d_meshes, d_instances, d_map_colors, d_lights, d_nodes, d_tris;
+    uint32_t light_count = 0, tri_count = 0, node_count = 0, bvh_root = 0, bvh_max_depth = 0;
+    kj::SceneView view() const;
+};

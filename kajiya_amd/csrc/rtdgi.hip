@@ -1,0 +1,1045 @@
+// RtdgiRenderer for gfx950: one HIP kernel per reference pass (renderers/rtdgi.rs:143-554,
+// assets/shaders/rtdgi/*.hlsl), 8x8 pixel tile = one wave64, neighbour exchange by
+// __shfl_xor, software BVH traversal instead of TraceRay. Host orchestration mirrors
+// RtdgiRenderer::{reproject,render} including the ping-pong temporal resources.
+#include "kj_host.hpp"
+#include "kj_scene.hpp"
+
+using namespace kj;
+namespace kj { SceneView scene_view(const KjScene& s); }
+
+#define SKY_DIST 1e4f
+#define RESTIR_TEMPORAL_M_CLAMP 20.0f
+#define RESTIR_RESERVOIR_W_CLAMP 10.0f
+#define SSGI_NEAR_FIELD_RADIUS 80.0f
+#define ROUGHNESS_BIAS 0.5f
+
+typedef Img<uint2> ImgH4;     // RGBA16F
+typedef Img<uint32_t> ImgU32; // RGBA8_SNORM / RG16F / A2R10G10B10
+typedef Img<float> ImgF32;
+typedef Img<uint4> ImgU4;
+typedef Img<uint2> ImgU2;     // RG32UI (reservoirs) and RGBA16_SNORM share the 8-byte texel
+typedef Img<uint8_t> ImgR8;
+typedef Img<int8_t> ImgR8S;
+typedef Img<float4> ImgF4;
+
+#define TILE_XY(W_, H_)                                                   \
+    const int lane = threadIdx.x;                                         \
+    const int x = int(blockIdx.x) * 8 + (lane & 7), y = int(blockIdx.y) * 8 + (lane >> 3); \
+    const bool in_image = x < (W_) && y < (H_);
+
+// ------------------------------------------------------------------ reservoirs (inc/reservoir.hlsl:6-98)
+struct StreamState { float p_q_sel, M_sum; };
+struct Reservoir1spp {
+    float w_sum; uint32_t payload; float M, W;
+    KJ_D static Reservoir1spp create() { return Reservoir1spp{0, 0, 0, 0}; }
+    KJ_D static Reservoir1spp from_raw(uint2 raw) { V2 mw = unpack_2x16f_uint(raw.y); return Reservoir1spp{0, raw.x, mw.x, mw.y}; }
+    KJ_D uint2 as_raw() const { return make_uint2(payload, pack_2x16f_uint(M, fmaxf(0.0f, W))); }
+    KJ_D bool update(float w, uint32_t sample_payload, uint32_t& rng) {
+        w_sum += w;
+        M += 1;
+        const float dart = uint_to_u01_float(hash1_mut(rng));
+        const float prob = w / w_sum;
+        if (prob >= dart) { payload = sample_payload; return true; }
+        return false;
+    }
+    KJ_D bool update_with_stream(const Reservoir1spp& r, float p_q, float weight, StreamState& ss, uint32_t sample_payload, uint32_t& rng) {
+        ss.M_sum += r.M;
+        if (update(p_q * weight * r.W * r.M, sample_payload, rng)) { ss.p_q_sel = p_q; return true; }
+        return false;
+    }
+    KJ_D void init_with_stream(float p_q, float weight, StreamState& ss, uint32_t sample_payload) {
+        payload = sample_payload;
+        w_sum = p_q * weight;
+        M = weight != 0 ? 1.0f : 0.0f;
+        W = weight;
+        ss.p_q_sel = p_q;
+        ss.M_sum = M;
+    }
+    KJ_D void finish_stream(const StreamState& ss) {
+        M = ss.M_sum;
+        W = w_sum / (fmaxf(1e-8f, M * ss.p_q_sel));
+    }
+};
+// rtdgi_common.hlsl:12-39
+struct TemporalReservoirOutput {
+    float depth; V3 ray_hit_offset_ws; float luminance; V3 hit_normal_ws;
+    KJ_D static TemporalReservoirOutput from_raw(uint4 raw) {
+        V2 a = unpack_2x16f_uint(raw.y), b = unpack_2x16f_uint(raw.z);
+        return TemporalReservoirOutput{asfloat(raw.x), V3{a.x, a.y, b.x}, b.y, unpack_normal_11_10_11(raw.w)};
+    }
+    KJ_D uint4 as_raw() const {
+        return make_uint4(asuint(depth), pack_2x16f_uint(ray_hit_offset_ws.x, ray_hit_offset_ws.y), pack_2x16f_uint(ray_hit_offset_ws.z, luminance),
+                          pack_normal_11_10_11(hit_normal_ws));
+    }
+};
+
+// ------------------------------------------------------------------ extract_half_res_{gbuffer_view_normal_rgba8,depth,ssao}.hlsl (fused)
+__global__ void __launch_bounds__(64) k_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgR8 ssao, ImgU32 half_view_normal,
+                                                      ImgF32 half_depth, ImgR8S half_ssao) {
+    TILE_XY(half_depth.w, half_depth.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int sx = x * 2 + off.x, sy = y * 2 + off.y;
+    const V3 normal_ws = unpack_normal_11_10_11_no_normalize(gbuffer.ld(sx, sy).y);
+    const V3 normal_vs = normalize(xyz(mul44(fc.view_constants.world_to_view, v4(normal_ws, 0))));
+    half_view_normal.st(x, y, pack_rgba8_snorm(v4(normal_vs, 1.0f)));
+    half_depth.st(x, y, depth.ld(sx, sy));
+    half_ssao.st(x, y, to_snorm8(from_unorm8(ssao.ld(sx, sy))));
+}
+
+// ------------------------------------------------------------------ fullres_reproject.hlsl:29-76
+KJ_D V4 cubic_hermite(V4 A, V4 B, V4 C, V4 D, float t) {  // inc/curve.hlsl:4-13
+    const float t2 = t * t, t3 = t * t * t;
+    const V4 a = -A / 2.0f + (3.0f * B) / 2.0f - (3.0f * C) / 2.0f + D / 2.0f;
+    const V4 b = A - (5.0f * B) / 2.0f + 2.0f * C - D / 2.0f;
+    const V4 c = -A / 2.0f + C / 2.0f;
+    return a * t3 + b * t2 + c * t + B;
+}
+__global__ void __launch_bounds__(64) k_fullres_reproject(ImgH4 input_tex, ImgU2 reprojection_tex, ImgH4 output_tex) {
+    const int W = output_tex.w, H = output_tex.h;
+    TILE_XY(W, H)
+    if (!in_image) return;
+    const V4 ts = tex_size4(W, H);
+    const V2 uv = get_uv(float(x), float(y), ts);
+    const V4 reproj = ld_reproj(reprojection_tex, x, y);
+    const V2 prev_uv = uv + V2{reproj.x, reproj.y};
+    const uint32_t quad_valid = uint32_t(reproj.z * 15.0f + 0.5f);
+    V4 history = v4(0.0f);
+    if (quad_valid == 15) {
+        // GatherBlue(sampler_nnc, uv + 0.5*sign(prev_uv)*texel): validity of the 2x2 footprint
+        const V2 guv = uv + 0.5f * V2{float((prev_uv.x > 0) - (prev_uv.x < 0)), float((prev_uv.y > 0) - (prev_uv.y < 0))} * V2{ts.z, ts.w};
+        const int ox = int(floorf(guv.x * float(W) - 0.5f)), oy = int(floorf(guv.y * float(H) - 0.5f));
+        bool all_valid = true;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int sx = min(max(ox + dx, 0), W - 1), sy = min(max(oy + dy, 0), H - 1);
+                all_valid = all_valid && (uint32_t(ld_reproj(reprojection_tex, sx, sy).z * 15.0f + 0.5f) == 15u);
+            }
+        if (all_valid) {
+            const V2 pixel = prev_uv * V2{float(W), float(H)} + 0.5f;
+            const V2 frc{frac(pixel.x), frac(pixel.y)};
+            const int ipx = int(pixel.x) - 1, ipy = int(pixel.y) - 1;
+            V4 rows[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rows[j] = cubic_hermite(ld4(input_tex, ipx - 1, ipy - 1 + j), ld4(input_tex, ipx, ipy - 1 + j), ld4(input_tex, ipx + 1, ipy - 1 + j),
+                                        ld4(input_tex, ipx + 2, ipy - 1 + j), frc.x);
+            history = vmax(v4(0.0f), cubic_hermite(rows[0], rows[1], rows[2], rows[3], frc.y));
+        } else {
+            history = sample_bilinear_clamp_rgba16f(input_tex.p, W, H, prev_uv);
+        }
+    } else if (quad_valid != 0) {
+        const V4 qv{(quad_valid & 1) ? 1.0f : 0.0f, (quad_valid & 2) ? 1.0f : 0.0f, (quad_valid & 4) ? 1.0f : 0.0f, (quad_valid & 8) ? 1.0f : 0.0f};
+        const V2 bp = prev_uv * V2{float(W), float(H)} - 0.5f;
+        const int ox = int(truncf(bp.x)), oy = int(truncf(bp.y));
+        const V2 bw{frac(bp.x), frac(bp.y)};
+        V4 w{(1.0f - bw.x) * (1.0f - bw.y), bw.x * (1.0f - bw.y), (1.0f - bw.x) * bw.y, bw.x * bw.y};
+        w = w * qv;
+        const float wsum = dot(w, v4(1.0f));
+        if (wsum > 1e-5f) {
+            const V4 r = ld4(input_tex, ox, oy) * w.x + ld4(input_tex, ox + 1, oy) * w.y + ld4(input_tex, ox, oy + 1) * w.z + ld4(input_tex, ox + 1, oy + 1) * w.w;
+            history = r * (1.0f / wsum);
+        }
+    }
+    st4(output_tex, x, y, history);
+}
+
+// ------------------------------------------------------------------ diffuse_trace_common.inc.hlsl:38-221
+struct TraceCtx {
+    const FrameConstants* __restrict__ fc;
+    SceneView sc;
+    ImgF32 depth;                 // full res
+    ImgH4 reprojected_gi;         // full res
+    const uint2* __restrict__ sky_cube; int sky_cube_width;
+    const uint32_t* __restrict__ blue_noise;
+    const uint2* __restrict__ brdf_fg_lut;
+    const float4* __restrict__ sun_color;
+    unsigned long long* __restrict__ ray_counters;  // [0]=closest, [1]=any
+};
+struct TraceResult { V3 out_value; V3 hit_normal_ws; float hit_t; float pdf; bool is_hit; };
+
+KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
+    const unsigned long long m = __ballot(active);
+    if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counters[which], (unsigned long long)__popcll(m));
+}
+
+KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3 normal_ws, uint32_t& rng, V3 ray_o, V3 ray_d, float ray_tmax, uint32_t* stack) {
+    const FrameConstants& fc = *c.fc;
+    V3 total_radiance = v3(0.0f);
+    V3 hit_normal_ws = -ray_d;
+    float hit_t = ray_tmax;
+    const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, ray_d) * 2 * KJ_PI));
+    count_rays(c.ray_counters, 0, true);
+    const GbufferPathVertex primary_hit = gbuffer_raytrace(c.sc, fc, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, 64);
+    if (primary_hit.is_hit) {
+        hit_t = primary_hit.ray_t;
+        GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);
+        hit_normal_ws = gbuffer.normal;
+        const V3 hit_cs = position_world_to_sample(fc, primary_hit.position);
+        const V2 hit_uv = cs_to_uv(V2{hit_cs.x, hit_cs.y});
+        const float screen_depth = sample_nearest_clamp(c.depth, hit_uv);
+        bool is_on_screen = fabsf(hit_cs.x) < 1.0f && fabsf(hit_cs.y) < 1.0f && inverse_depth_relative_diff(hit_cs.z, screen_depth) < 5e-3f;
+        V4 reprojected_radiance = v4(0.0f);
+        if (is_on_screen) {
+            reprojected_radiance = unpack_rgba16f(sample_nearest_clamp(c.reprojected_gi, hit_uv)) * fc.pre_exposure_delta;
+            is_on_screen = reprojected_radiance.w > 0;
+        }
+        gbuffer.roughness = lerp(gbuffer.roughness, 1.0f, ROUGHNESS_BIAS);
+        const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
+        const V3 wo = to_local(tangent_to_world, -ray_d);
+        const LayeredBrdf brdf = layered_brdf_from_gbuffer_ndotv(c.brdf_fg_lut, gbuffer, wo.z);
+        const float4 sc4 = *c.sun_color;
+        const V3 sun_radiance{sc4.x, sc4.y, sc4.z};
+        if (sun_radiance.x != 0 || sun_radiance.y != 0 || sun_radiance.z != 0) {
+            const V4 bn = blue_noise_for_pixel(c.blue_noise, px, py, rng);
+            const V3 to_light_norm = sample_sun_direction(fc, V2{bn.x, bn.y}, false);
+            count_rays(c.ray_counters, 1, true);
+            const bool is_shadowed = rt_is_shadowed(c.sc, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, 64);
+            const V3 wi = to_local(tangent_to_world, to_light_norm);
+            const V3 brdf_value = layered_brdf_evaluate(brdf, wo, wi) * fmaxf(0.0f, wi.z);
+            total_radiance += brdf_value * (is_shadowed ? v3(0.0f) : sun_radiance);
+        }
+        total_radiance += gbuffer.emissive;
+        if (is_on_screen) {
+            total_radiance += xyz(reprojected_radiance) * gbuffer.albedo;
+        } else {
+            V2 urand;
+            urand.x = uint_to_u01_float(hash1_mut(rng));
+            urand.y = uint_to_u01_float(hash1_mut(rng));
+            const uint32_t nl = min(fc.triangle_light_count, c.sc.light_count);
+            for (uint32_t li = 0; li < nl; ++li) {
+                const KjTriangleLight tl = c.sc.lights[li];
+                const V3 v0{tl.verts[0], tl.verts[1], tl.verts[2]}, v1{tl.verts[3], tl.verts[4], tl.verts[5]}, v2{tl.verts[6], tl.verts[7], tl.verts[8]};
+                const LightSampleArea ls = sample_triangle_light(v0, v1 - v0, v2 - v0, urand);
+                const V3 to_light_ws = ls.pos - primary_hit.position;
+                const float dist2 = dot(to_light_ws, to_light_ws);
+                const V3 to_light_norm_ws = to_light_ws * (1.0f / sqrtf(dist2));
+                const float to_psa_metric = fmaxf(0.0f, dot(to_light_norm_ws, gbuffer.normal)) * fmaxf(0.0f, dot(to_light_norm_ws, -ls.normal)) / dist2;
+                if (to_psa_metric > 0.0f) {
+                    count_rays(c.ray_counters, 1, true);
+                    const bool is_shadowed = rt_is_shadowed(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, 64);
+                    const V3 bounce_albedo = lerp(gbuffer.albedo, v3(1.0f), 0.04f);
+                    const V3 brdf_value = bounce_albedo * to_psa_metric / KJ_PI;
+                    if (!is_shadowed) total_radiance += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * brdf_value / ls.pdf;
+                }
+            }
+            // USE_IRCACHE: no irradiance cache bound in this build => lookup contributes 0 (BASELINE config 1)
+        }
+    } else {
+        total_radiance += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
+    }
+    return TraceResult{total_radiance, hit_normal_ws, hit_t, pdf, primary_hit.is_hit};
+}
+
+// ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111
+__global__ void __launch_bounds__(64) k_rtdgi_validate(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
+                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex) {
+    extern __shared__ uint32_t lds_stack[];
+    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    if (0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y)) { invalidity_out_tex.st(x, y, to_unorm8(1.0f)); return; }
+    float invalidity = 0.0f;
+    if (is_rtdgi_validation_frame(fc.frame_index)) {
+        const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
+        const float4 ro = ray_orig_history_tex.ld(x, y);
+        const V3 prev_ray_orig{ro.x, ro.y, ro.z};
+        const V3 prev_hit_pos = xyz(ld4(reservoir_ray_history_tex, x, y)) + prev_ray_orig;
+        const V4 prev_radiance_packed = ld4(irradiance_history_tex, x, y);
+        const V3 prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
+        uint32_t rng = hash3(uint32_t(x), uint32_t(y), 0);
+        const TraceResult result = trace_candidate(c, x, y, normal_ws, rng, prev_ray_orig, normalize(prev_hit_pos - prev_ray_orig), SKY_DIST, lds_stack + lane);
+        const V3 new_radiance = vmax(v3(0.0f), result.out_value);
+        const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
+        invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
+        const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
+        if (fabsf(result.hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
+            st4(irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
+            Reservoir1spp r = Reservoir1spp::from_raw(reservoir_tex.ld(x, y));
+            const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
+            r.M *= clampf(lum_old / fmaxf(1e-8f, lum_new), 0.03f, 1.0f);
+            r.W *= clampf(lum_old / fmaxf(1e-8f, lum_new) * 10.0f, 0.01f, 1.0f);
+            reservoir_tex.st(x, y, r.as_raw());
+        }
+    }
+    invalidity_out_tex.st(x, y, to_unorm8(invalidity));
+}
+
+// ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24
+__global__ void __launch_bounds__(64) k_rtdgi_trace(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
+                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex) {
+    extern __shared__ uint32_t lds_stack[];
+    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+    const float depth = c.depth.ld(hx, hy);
+    if (0.0f == depth) {
+        st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
+        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
+        invalidity_out_tex.st(x, y, 0);
+        return;
+    }
+    const V4 gts = tex_size4(c.depth.w, c.depth.h);
+    const V2 uv = get_uv(float(hx), float(hy), gts);
+    const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
+    const float near_field_fade_out_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
+    const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
+    {
+        const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
+        const Basis tangent_to_world = build_orthonormal_basis(normal_ws);
+        const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, fc.frame_index);
+        const V3 outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
+        const V3 origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
+        uint32_t rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u);
+        TraceResult result = trace_candidate(c, x, y, normal_ws, rng, origin, outgoing_dir, tracing_frame ? SKY_DIST : near_field_fade_out_end, lds_stack + lane);
+        if (!tracing_frame && !result.is_hit) { result.out_value = v3(0.0f); result.hit_t = SKY_DIST; }
+        const V3 hit_offset_ws = outgoing_dir * result.hit_t;
+        const float cos_theta = dot(normalize(outgoing_dir - vr.dir_ws), normal_ws);
+        st4(candidate_irradiance_out_tex, x, y, v4(result.out_value, 1.0f - cos_theta));
+        st4(candidate_hit_out_tex, x, y, v4(hit_offset_ws, result.pdf * (tracing_frame ? 1.0f : -1.0f)));
+        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, result.hit_normal_ws), 0)));
+    }
+    const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
+    const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
+    invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
+}
+
+// ------------------------------------------------------------------ temporal_validity_integrate.hlsl:21-119
+// WaveReadLaneAt(v, lane^k) inside the 8x8 group == __shfl_xor(v, k) on wave64.
+__global__ void __launch_bounds__(64) k_validity_integrate(const FrameConstants* __restrict__ fcp, ImgR8 input_tex, ImgU32 history_tex /*RG16F*/, ImgU2 reprojection_tex,
+                                                            ImgF32 half_depth_tex, ImgU32 output_tex /*RG16F*/, int W, int H) {
+    TILE_XY(output_tex.w, output_tex.h)
+    (void)in_image;  // lanes outside the image still take part in the shuffles (loads return 0)
+    const FrameConstants& fc = *fcp;
+    V2 invalid_blurred{0, 0};
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+            const float w = exp2f(-0.1f * float(dx * dx + dy * dy));
+            invalid_blurred += V2{from_unorm8(input_tex.ld(x + dx, y + dy)), 1.0f} * w;
+        }
+    invalid_blurred = invalid_blurred / invalid_blurred.y;
+    float ib = invalid_blurred.x;
+    ib = lerp(ib, __shfl_xor(ib, 2), 0.5f);
+    ib = lerp(ib, __shfl_xor(ib, 16), 0.5f);
+    ib = smoothstep(0.0f, 1.0f, ib);
+    const float center_depth = half_depth_tex.ld(x, y);
+    float edge = 1;
+    for (int oy = 0; oy <= 2; ++oy)
+        for (int ox = 1; ox <= 2; ++ox) {
+            const V4 reproj = ld_reproj(reprojection_tex, x * 2 + ox, y * 2 + oy);
+            const float sample_depth = half_depth_tex.ld(x + ox / 2, y + oy / 2);
+            if (reproj.w < 0 || inverse_depth_relative_diff(center_depth, sample_depth) > 0.1f) { edge = 0; break; }
+            edge *= (reproj.z == 0 && sample_depth != 0) ? 1.0f : 0.0f;
+        }
+    edge = fmaxf(edge, __shfl_xor(edge, 1));
+    edge = fmaxf(edge, __shfl_xor(edge, 8));
+    ib = saturate(ib + edge);
+    const V4 reproj = ld_reproj(reprojection_tex, x * 2, y * 2);
+    const V2 reproj_px{float(x) + float(W) * reproj.x / 2 + 0.5f, float(y) + float(H) * reproj.y / 2 + 0.5f};
+    float history = 0;
+    const float ang_off = uint_to_u01_float(hash3(uint32_t(x), uint32_t(y), fc.frame_index)) * KJ_PI * 2;
+    for (uint32_t si = 0; si < 8u; ++si) {
+        const float ang = (float(si) + ang_off) * KJ_GOLDEN_ANGLE;
+        const float radius = float(si) * 1.0f;
+        const V2 so = V2{cosf(ang), sinf(ang)} * radius;
+        history += ld2h(history_tex, int(reproj_px.x + so.x), int(reproj_px.y + so.y)).x;
+    }
+    history /= 8;
+    st2h(output_tex, x, y, V2{fmaxf(history * 0.75f, ib), from_unorm8(input_tex.ld(x, y))});
+}
+
+// ------------------------------------------------------------------ restir_temporal.hlsl:83-422
+struct RestirTemporalArgs {
+    const FrameConstants* __restrict__ fc;
+    ImgF32 depth_tex; ImgU32 half_view_normal_tex; ImgH4 candidate_radiance_tex; ImgU32 candidate_normal_tex; ImgH4 candidate_hit_tex;
+    ImgH4 radiance_history_tex; ImgF4 ray_orig_history_tex; ImgH4 ray_history_tex; ImgU2 reservoir_history_tex; ImgU2 reprojection_tex;
+    ImgH4 hit_normal_history_tex; ImgH4 candidate_history_tex; ImgU32 rt_invalidity_tex;
+    ImgH4 radiance_out_tex; ImgF4 ray_orig_output_tex; ImgH4 ray_output_tex; ImgH4 hit_normal_output_tex; ImgU2 reservoir_out_tex;
+    ImgH4 candidate_out_tex; ImgU4 temporal_reservoir_packed_tex;
+};
+__global__ void __launch_bounds__(64) k_restir_temporal(RestirTemporalArgs a) {
+    TILE_XY(a.reservoir_out_tex.w, a.reservoir_out_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *a.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+    const float depth = a.depth_tex.ld(hx, hy);
+    if (0.0f == depth) {
+        st4(a.radiance_out_tex, x, y, V4{0, 0, 0, -SKY_DIST});
+        st4(a.hit_normal_output_tex, x, y, v4(0.0f));
+        a.reservoir_out_tex.st(x, y, make_uint2(0, 0));
+        return;
+    }
+    const V4 gts = tex_size4(a.depth_tex.w, a.depth_tex.h);
+    const V2 uv = get_uv(float(hx), float(hy), gts);
+    const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
+    const V3 normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, x, y);
+    const V3 normal_ws = direction_view_to_world(fc, normal_vs);
+    const V3 refl_ray_origin_ws = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
+    const V3 hit_offset_ws = xyz(ld4(a.candidate_hit_tex, x, y));
+    V3 outgoing_dir = normalize(hit_offset_ws);
+    uint32_t rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index);
+    V3 radiance_sel = v3(0.0f), ray_orig_sel_ws = v3(0.0f), ray_hit_sel_ws = v3(1.0f), hit_normal_sel = v3(1.0f);
+    StreamState stream_state{0, 0};
+    Reservoir1spp reservoir = Reservoir1spp::create();
+    const uint32_t reservoir_payload = uint32_t(x) | (uint32_t(y) << 16);
+    const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
+    if (tracing_frame) {
+        const float hit_t = length(hit_offset_ws);
+        const V3 out_value = xyz(ld4(a.candidate_radiance_tex, x, y));
+        const float p_q = 1.0f * fmaxf(0.0f, sRGB_to_luminance(out_value)) * stepf(0.0f, dot(outgoing_dir, normal_ws));
+        radiance_sel = out_value;
+        ray_orig_sel_ws = refl_ray_origin_ws;
+        ray_hit_sel_ws = refl_ray_origin_ws + outgoing_dir * hit_t;
+        hit_normal_sel = direction_view_to_world(fc, ld_nrm_snorm8(a.candidate_normal_tex, x, y));
+        reservoir.init_with_stream(p_q, 1.0f, stream_state, reservoir_payload);
+        const float rl = lerp(ld4(a.candidate_history_tex, x, y).y, sqrtf(hit_t), 0.05f);
+        st4(a.candidate_out_tex, x, y, V4{sqrtf(hit_t), rl, 0, 0});
+    }
+    const float rt_invalidity = sqrtf(saturate(ld2h(a.rt_invalidity_tex, x, y).y));
+    float center_M = 0;
+    const uint32_t fi = fc.frame_index;
+    // xor_seq[frame&3] = {(3,3),(2,1),(1,2),(3,3)} ; offsets[4] = {(-1,-1),(1,1),(-1,1),(1,-1)}
+    const uint32_t pxv_x = (fi & 3u) == 1u ? 2u : ((fi & 3u) == 2u ? 1u : 3u);
+    const uint32_t pxv_y = (fi & 3u) == 1u ? 1u : ((fi & 3u) == 2u ? 2u : 3u);
+    for (uint32_t sample_i = 0; sample_i < 5u && stream_state.M_sum < 1.25f * RESTIR_TEMPORAL_M_CLAMP; ++sample_i) {
+        I2 rpx_offset{0, 0};
+        if (sample_i != 0) {
+            const uint32_t ia = fi & 3u, ib = (sample_i + (fi ^ 1u)) & 3u;
+            auto ofs = [](uint32_t i) { return I2{(i == 1u || i == 3u) ? 1 : -1, (i == 1u || i == 2u) ? 1 : -1}; };
+            const I2 oa = ofs(ia), ob = ofs(ib);
+            rpx_offset = I2{oa.x + ob.x, oa.y + ob.y};
+            if (rpx_offset.x == 0 && rpx_offset.y == 0) continue;
+        }
+        const V4 reproj = ld_reproj(a.reprojection_tex, hx + rpx_offset.x * 2, hy + rpx_offset.y * 2);
+        const V2 base = sample_i == 0 ? V2{float(x), float(y)} : V2{float(uint32_t(x + rpx_offset.x) ^ pxv_x), float(uint32_t(y + rpx_offset.y) ^ pxv_y)};
+        const int prx = f2i_sat(floorf(base.x + gts.x * reproj.x * 0.5f + 0.0f + 0.5f)), pry = f2i_sat(floorf(base.y + gts.y * reproj.y * 0.5f + 0.0f + 0.5f));
+        const I2 rpx{wrap_add(prx, rpx_offset.x), wrap_add(pry, rpx_offset.y)};
+        const int pnx = f2i_sat(floorf(base.x + 0.5f)), pny = f2i_sat(floorf(base.y + 0.5f));
+        const I2 neighbor_px{wrap_add(pnx, rpx_offset.x), wrap_add(pny, rpx_offset.y)};
+        const int nhx = wrap_mul2_add(neighbor_px.x, off.x), nhy = wrap_mul2_add(neighbor_px.y, off.y);
+        Reservoir1spp r = Reservoir1spp::from_raw(a.reservoir_history_tex.ld(rpx.x, rpx.y));
+        const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
+        float relevance = 1;
+        const float sample_depth = a.depth_tex.ld(nhx, nhy);
+        const float4 pro = a.ray_orig_history_tex.ld(spx_x, spx_y);
+        const V3 prev_ray_orig{pro.x, pro.y, pro.z};
+        if (length(prev_ray_orig - refl_ray_origin_ws) > 0.1f * -vr.hit_vs.z) continue;
+        if (0 == sample_depth) continue;
+        if (reproj.z == 0) continue;
+        relevance *= 1 - smoothstep(0.0f, 0.1f, inverse_depth_relative_diff(depth, sample_depth));
+        const V3 sample_normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, neighbor_px.x, neighbor_px.y);
+        const float normal_similarity_dot = fmaxf(0.0f, dot(sample_normal_vs, normal_vs));
+        if (sample_i != 0 && normal_similarity_dot < 0.2f) continue;
+        relevance *= powf(normal_similarity_dot, 4.0f);
+        const V4 rh = ld4(a.ray_history_tex, spx_x, spx_y);
+        const V3 sample_hit_ws = xyz(rh) + prev_ray_orig;
+        const float prev_dist = rh.w;
+        const V4 hn = ld4(a.hit_normal_history_tex, spx_x, spx_y);
+        const V4 sample_hit_normal_ws_dot{hn.x * 2 - 1, hn.y * 2 - 1, hn.z * 2 - 1, hn.w};
+        const V3 dir_to_sample_hit_unnorm = sample_hit_ws - refl_ray_origin_ws;
+        const float dist_to_sample_hit = length(dir_to_sample_hit_unnorm);
+        const V3 dir_to_sample_hit = normalize(dir_to_sample_hit_unnorm);
+        const float center_to_hit_vis = -dot(xyz(sample_hit_normal_ws_dot), dir_to_sample_hit);
+        const V4 prev_rad = ld4(a.radiance_history_tex, spx_x, spx_y) * V4{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
+        r.M = fmaxf(0.0f, fminf(r.M, exp2f(log2f(RESTIR_TEMPORAL_M_CLAMP) * (1.0f - rt_invalidity))));
+        const float p_q = 1 * fmaxf(0.0f, sRGB_to_luminance(xyz(prev_rad))) * stepf(0.0f, dot(dir_to_sample_hit, normal_ws));
+        float jacobian = 1;
+        jacobian *= clampf(prev_dist / dist_to_sample_hit, 1e-4f, 1e4f);
+        jacobian *= jacobian;
+        jacobian *= clampf(center_to_hit_vis / sample_hit_normal_ws_dot.w, 0.0f, 1e4f);
+        r.M *= relevance;
+        if (0 == sample_i) center_M = r.M;
+        if (reservoir.update_with_stream(r, p_q, jacobian * 1.0f, stream_state, reservoir_payload, rng)) {
+            outgoing_dir = dir_to_sample_hit;
+            radiance_sel = xyz(prev_rad);
+            ray_orig_sel_ws = prev_ray_orig;
+            ray_hit_sel_ws = sample_hit_ws;
+            hit_normal_sel = xyz(sample_hit_normal_ws_dot);
+        }
+    }
+    reservoir.finish_stream(stream_state);
+    reservoir.W = fminf(reservoir.W, RESTIR_RESERVOIR_W_CLAMP);
+    reservoir.M = center_M + 0.5f;
+    const V4 hit_normal_ws_dot = v4(hit_normal_sel, -dot(hit_normal_sel, outgoing_dir));
+    st4(a.radiance_out_tex, x, y, v4(radiance_sel, dot(normal_ws, outgoing_dir)));
+    a.ray_orig_output_tex.st(x, y, make_float4(ray_orig_sel_ws.x, ray_orig_sel_ws.y, ray_orig_sel_ws.z, 0.0f));
+    st4(a.hit_normal_output_tex, x, y, V4{hit_normal_ws_dot.x * 0.5f + 0.5f, hit_normal_ws_dot.y * 0.5f + 0.5f, hit_normal_ws_dot.z * 0.5f + 0.5f, hit_normal_ws_dot.w});
+    st4(a.ray_output_tex, x, y, v4(ray_hit_sel_ws - ray_orig_sel_ws, length(ray_hit_sel_ws - refl_ray_origin_ws)));
+    a.reservoir_out_tex.st(x, y, reservoir.as_raw());
+    TemporalReservoirOutput rp;
+    rp.depth = depth;
+    rp.ray_hit_offset_ws = ray_hit_sel_ws - vr.hit_ws;
+    rp.luminance = fmaxf(0.0f, sRGB_to_luminance(radiance_sel));
+    rp.hit_normal_ws = xyz(hit_normal_ws_dot);
+    a.temporal_reservoir_packed_tex.st(x, y, rp.as_raw());
+}
+
+// ------------------------------------------------------------------ occlusion_raymarch.hlsl:75-146 (half-res depth, no colour bounce)
+KJ_D void occlusion_raymarch(const FrameConstants& fc, V2 start_uv, V3 start_cs, V3 end_ws, int max_sample_count, const ImgF32& half_depth, int W, int H, float& visibility) {
+    const V2 fullres{float(W), float(H)}, halfres{float(half_depth.w), float(half_depth.h)};
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const V3 end_cs = position_world_to_clip(fc, end_ws);
+    const V2 len_px = (cs_to_uv(V2{end_cs.x, end_cs.y}) - start_uv) * halfres;
+    const int k_count = min(max_sample_count, int(floorf(length(len_px) / 2.0f)));
+    const float Z_LAYER_THICKNESS = 0.05f;
+    const float depth_step_per_z = (end_cs.z - start_cs.z) / length(V2{end_cs.x, end_cs.y} - V2{start_cs.x, start_cs.y});
+    const float t_step = 1.0f / float(k_count);
+    float t = 0.5f * t_step;
+    for (int k = 0; k < k_count; ++k) {
+        const V3 interp_cs = lerp(start_cs, end_cs, t);
+        const V2 uv_at = cs_to_uv(V2{interp_cs.x, interp_cs.y});
+        const V2 fp{floorf(uv_at.x * fullres.x - float(off.x)), floorf(uv_at.y * fullres.y - float(off.y))};
+        const uint32_t ux = fp.x > 0 ? uint32_t(fp.x) : 0u, uy = fp.y > 0 ? uint32_t(fp.y) : 0u;
+        const uint32_t pxi = (ux & ~1u) + uint32_t(off.x), pyi = (uy & ~1u) + uint32_t(off.y);
+        const float depth_at = half_depth.ld(int(pxi >> 1u), int(pyi >> 1u));
+        const V2 qcs = uv_to_cs(V2{(float(pxi) + 0.5f) / fullres.x, (float(pyi) + 0.5f) / fullres.y});
+        const float biased_z = start_cs.z + depth_step_per_z * length(qcs - V2{start_cs.x, start_cs.y});
+        if (depth_at > biased_z) {
+            const float depth_diff = inverse_depth_relative_diff(interp_cs.z, depth_at);
+            visibility *= 1 - smoothstep(Z_LAYER_THICKNESS, Z_LAYER_THICKNESS * 0.5f, depth_diff);
+        }
+        t += t_step;
+    }
+}
+
+// ------------------------------------------------------------------ restir_spatial.hlsl:48-372
+KJ_D float normal_inluence_nonlinearity(float x, float b) { return x < -b ? 0.0f : (x + b) * (x + b) / (4 * b); }
+__global__ void __launch_bounds__(64) k_restir_spatial(const FrameConstants* __restrict__ fcp, ImgU2 reservoir_input_tex, ImgU32 half_view_normal_tex, ImgF32 half_depth_tex,
+                                                        ImgR8S half_ssao_tex, ImgU4 temporal_reservoir_packed_tex, ImgU2 reservoir_output_tex, int W, int H,
+                                                        uint32_t spatial_reuse_pass_idx, uint32_t perform_occlusion_raymarch, uint32_t occlusion_raymarch_importance_only) {
+    const int hw = reservoir_output_tex.w, hh = reservoir_output_tex.h;
+    TILE_XY(hw, hh)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const V4 gts = tex_size4(W, H);
+    const float depth = half_depth_tex.ld(x, y);
+    uint32_t rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index + spatial_reuse_pass_idx * 123u);
+    const V2 uv = get_uv(float(x * 2 + off.x), float(y * 2 + off.y), gts);
+    const ViewRay vr = view_ray_from_uv_and_depth(fc, uv, depth);
+    const V3 center_normal_vs = ld_nrm_snorm8(half_view_normal_tex, x, y);
+    const V3 center_normal_ws = direction_view_to_world(fc, center_normal_vs);
+    const float center_depth = depth;
+    const float center_ssao = from_snorm8(half_ssao_tex.ld(x, y));
+    StreamState stream_state{0, 0};
+    Reservoir1spp reservoir = Reservoir1spp::create();
+    const float sample_radius_offset = uint_to_u01_float(hash1_mut(rng));
+    const Reservoir1spp center_r = Reservoir1spp::from_raw(reservoir_input_tex.ld(x, y));
+    float kernel_tightness = 1.0f - center_ssao;
+    const float MAX_INPUT_M_IN_PASS = spatial_reuse_pass_idx == 0 ? RESTIR_TEMPORAL_M_CLAMP : RESTIR_TEMPORAL_M_CLAMP * 8.0f;
+    kernel_tightness = lerp(kernel_tightness, 1.0f, 0.5f * smoothstep(MAX_INPUT_M_IN_PASS * 0.5f, MAX_INPUT_M_IN_PASS, center_r.M));
+    float max_kernel_radius = spatial_reuse_pass_idx == 0 ? lerp(32.0f, 12.0f, kernel_tightness) : lerp(16.0f, 6.0f, kernel_tightness);
+    if (spatial_reuse_pass_idx >= 2) max_kernel_radius = 8;
+    const V2 dist_to_edge_xy = vmin(V2{float(x), float(y)}, V2{float(hw) - float(x), float(hh) - float(y)});
+    const float allow_edge_overstep = center_r.M < 10 ? 100.0f : 1.25f;
+    const V2 kernel_radius = vmin(V2{max_kernel_radius, max_kernel_radius}, dist_to_edge_xy * allow_edge_overstep);
+    const uint32_t sample_count = spatial_reuse_pass_idx == 0 ? 8u : 5u;
+    const uint32_t shift = spatial_reuse_pass_idx == 0 ? 3u : 2u;
+    const float ang_offset = uint_to_u01_float(hash3(uint32_t(x) >> shift, uint32_t(y) >> shift, fc.frame_index * 2u + spatial_reuse_pass_idx)) * KJ_PI * 2;
+    for (uint32_t sample_i = 0; sample_i < sample_count; ++sample_i) {
+        const float ang = (float(sample_i) + ang_offset) * KJ_GOLDEN_ANGLE;
+        const V2 radius = 0 == sample_i ? V2{0, 0} : (powf((float(sample_i) + sample_radius_offset) / float(sample_count), 0.5f) * kernel_radius);
+        const I2 rpx_offset{int(cosf(ang) * radius.x), int(sinf(ang) * radius.y)};
+        const bool is_center_sample = sample_i == 0;
+        const I2 rpx{x + rpx_offset.x, y + rpx_offset.y};
+        const uint2 reservoir_raw = reservoir_input_tex.ld(rpx.x, rpx.y);
+        if (0 == reservoir_raw.x) continue;
+        Reservoir1spp r = Reservoir1spp::from_raw(reservoir_raw);
+        r.M = fminf(r.M, 500.0f);
+        const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
+        const TemporalReservoirOutput spx_packed = TemporalReservoirOutput::from_raw(temporal_reservoir_packed_tex.ld(spx_x, spx_y));
+        float visibility = 1, relevance = 1;
+        const V3 sample_normal_vs = ld_nrm_snorm8(half_view_normal_tex, rpx.x, rpx.y);
+        const float normal_similarity_dot = dot(sample_normal_vs, center_normal_vs);
+        relevance *= normal_inluence_nonlinearity(normal_similarity_dot, 0.5f) / normal_inluence_nonlinearity(1.0f, 0.5f);
+        const float sample_ssao = from_snorm8(half_ssao_tex.ld(rpx.x, rpx.y));
+        relevance *= 1 - fabsf(sample_ssao - center_ssao);
+        const V2 rpx_uv = get_uv(float(rpx.x * 2 + off.x), float(rpx.y * 2 + off.y), gts);
+        const float rpx_depth = half_depth_tex.ld(rpx.x, rpx.y);
+        if (rpx_depth == 0.0f) continue;
+        const ViewRay rpx_ray = view_ray_from_uv_and_depth(fc, rpx_uv, rpx_depth);
+        const V2 spx_uv = get_uv(float(spx_x * 2 + off.x), float(spx_y * 2 + off.y), gts);
+        const ViewRay spx_ray = view_ray_from_uv_and_depth(fc, spx_uv, spx_packed.depth);
+        const V3 sample_hit_ws = spx_packed.ray_hit_offset_ws + spx_ray.hit_ws;
+        const V3 reused_unnorm = sample_hit_ws - rpx_ray.hit_ws;
+        const float reused_dist = length(reused_unnorm);
+        const V3 reused_dir = reused_unnorm / reused_dist;
+        const V3 dir_unnorm = sample_hit_ws - vr.hit_ws;
+        const float dist_to_sample_hit = length(dir_unnorm);
+        const V3 dir_to_sample_hit = normalize(dir_unnorm);
+        if (!is_center_sample) {
+            const float depth_diff = fabsf(fmaxf(0.3f, center_normal_vs.z) * (center_depth / rpx_depth - 1.0f));
+            relevance *= 1 - smoothstep(0.0f, spatial_reuse_pass_idx == 0 ? 0.15f : 0.1f, depth_diff);
+        }
+        if (perform_occlusion_raymarch) {
+            const float surface_offset_len = length(view_ray_from_uv_and_depth(fc, spx_uv, depth).hit_vs - vr.hit_vs);
+            const V3 march_dir = sample_hit_ws - vr.hit_ws;
+            const V3 end_ws = vr.hit_ws + march_dir * fminf(1.0f, 3.0f * surface_offset_len / length(march_dir));
+            occlusion_raymarch(fc, uv, vr.hit_cs, end_ws, 6, half_depth_tex, W, H, visibility);
+        }
+        const float center_to_hit_vis = -dot(spx_packed.hit_normal_ws, dir_to_sample_hit);
+        const float reused_to_hit_vis = -dot(spx_packed.hit_normal_ws, reused_dir);
+        float p_q = 1;
+        p_q *= spx_packed.luminance;
+        p_q *= fmaxf(0.0f, dot(dir_to_sample_hit, center_normal_ws));
+        float jacobian = 1;
+        jacobian *= reused_dist / dist_to_sample_hit;
+        jacobian *= jacobian;
+        jacobian *= clampf(center_to_hit_vis / reused_to_hit_vis, 0.0f, 1e4f);
+        jacobian = sqrtf(jacobian);
+        if (is_center_sample) jacobian = 1;
+        if (!(p_q >= 0)) continue;
+        r.M *= relevance;
+        if (occlusion_raymarch_importance_only) { p_q *= lerp(0.25f, 1.0f, visibility); visibility = 1; }
+        reservoir.update_with_stream(r, p_q, visibility * jacobian, stream_state, r.payload, rng);
+    }
+    reservoir.finish_stream(stream_state);
+    reservoir.W = fminf(reservoir.W, RESTIR_RESERVOIR_W_CLAMP);
+    reservoir_output_tex.st(x, y, reservoir.as_raw());
+}
+
+// ------------------------------------------------------------------ restir_resolve.hlsl:42-205
+KJ_D float ggx_ndf_unnorm(float a2, float cos_theta) { const float d = cos_theta * cos_theta * (a2 - 1.0f) + 1.0f; return a2 / (d * d); }
+struct ResolveArgs {
+    const FrameConstants* __restrict__ fc;
+    ImgH4 radiance_tex; ImgU2 reservoir_input_tex; ImgU4 gbuffer_tex; ImgF32 depth_tex; ImgU32 half_view_normal_tex; ImgF32 half_depth_tex; ImgR8 ssao_tex;
+    ImgH4 candidate_radiance_tex; ImgH4 candidate_hit_tex; ImgU4 temporal_reservoir_packed_tex; ImgH4 irradiance_output_tex;
+    const uint32_t* __restrict__ blue_noise;
+};
+__global__ void __launch_bounds__(64) k_restir_resolve(ResolveArgs a) {
+    const int W = a.irradiance_output_tex.w, H = a.irradiance_output_tex.h;
+    TILE_XY(W, H)
+    if (!in_image) return;
+    const FrameConstants& fc = *a.fc;
+    const float depth = a.depth_tex.ld(x, y);
+    if (0 == depth) { st4(a.irradiance_output_tex, x, y, v4(0.0f)); return; }
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const V4 gts = tex_size4(W, H);
+    const V2 uv = get_uv(float(x), float(y), gts);
+    const ViewRay vr = view_ray_from_uv_and_depth(fc, uv, depth);
+    const GbufferData gbuffer = gbuffer_unpack(a.gbuffer_tex.ld(x, y));
+    const V3 center_normal_ws = gbuffer.normal;
+    const V3 center_normal_vs = direction_world_to_view(fc, center_normal_ws);
+    const float center_depth = depth;
+    const float center_ssao = from_unorm8(a.ssao_tex.ld(x, y));
+    const uint32_t frame_hash = hash1(fc.frame_index);
+    const uint32_t px_idx_in_quad = (((uint32_t(x) & 1u) | (uint32_t(y) & 1u) * 2u) + frame_hash) & 3u;
+    const float blue_x = blue_noise_for_pixel(a.blue_noise, x, y, fc.frame_index).x * KJ_TAU;
+    const float near_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
+    const float near_start = near_end * 0.5f;
+    const float near_field_influence = center_ssao;
+    V3 total_irradiance = v3(0.0f);
+    bool sharpen_gi_kernel = false;
+    {
+        float w_sum = 0;
+        V3 weighted = v3(0.0f);
+        for (uint32_t si = 0; si < 4u; ++si) {
+            const float ang = (float(si) + blue_x) * KJ_GOLDEN_ANGLE + (float(px_idx_in_quad) / 4.0f) * KJ_TAU;
+            const float radius = powf(float(si), 0.666f) * 1.0f + 0.4f;
+            const V2 rpo = V2{cosf(ang), sinf(ang)} * radius;
+            const int rx = int(floorf(float(x) * 0.5f + rpo.x)), ry = int(floorf(float(y) * 0.5f + rpo.y));
+            const V2 rpx_uv = get_uv(float(rx * 2 + off.x), float(ry * 2 + off.y), gts);
+            const float rpx_depth = a.half_depth_tex.ld(rx, ry);
+            const ViewRay rpx_ray = view_ray_from_uv_and_depth(fc, rpx_uv, rpx_depth);
+            const V3 hit_ws = xyz(ld4(a.candidate_hit_tex, rx, ry)) + rpx_ray.hit_ws;
+            const V3 sample_offset = hit_ws - vr.hit_ws;
+            const float sample_dist = length(sample_offset);
+            const V3 sample_dir = sample_offset / sample_dist;
+            const float geometric_term = 2 * fmaxf(0.0f, dot(center_normal_ws, sample_dir));
+            const float atten = smoothstep(near_end, near_start, sample_dist);
+            sharpen_gi_kernel |= atten > 0.9f;
+            V3 contribution = xyz(ld4(a.candidate_radiance_tex, rx, ry)) * geometric_term;
+            contribution *= lerp(0.0f, atten, near_field_influence);
+            const V3 sample_normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, rx, ry);
+            float w = 1;
+            w *= ggx_ndf_unnorm(0.01f, saturate(dot(center_normal_vs, sample_normal_vs)));
+            w *= exp2f(-200.0f * fabsf(center_normal_vs.z * (center_depth / rpx_depth - 1.0f)));
+            weighted += contribution * w;
+            w_sum += w;
+        }
+        total_irradiance += weighted / fmaxf(1e-20f, w_sum);
+    }
+    {
+        float w_sum = 0;
+        V3 weighted = v3(0.0f);
+        const float kernel_scale = sharpen_gi_kernel ? 0.5f : 1.0f;
+        for (uint32_t si = 0; si < 4u; ++si) {
+            const float ang = (float(si) + blue_x) * KJ_GOLDEN_ANGLE + (float(px_idx_in_quad) / 4.0f) * KJ_TAU;
+            const float radius = powf(float(si), 0.666f) * 1.0f * kernel_scale + 0.4f * kernel_scale;
+            const V2 rpo = V2{cosf(ang), sinf(ang)} * radius;
+            const int rx = int(floorf(float(x) * 0.5f + rpo.x)), ry = int(floorf(float(y) * 0.5f + rpo.y));
+            const Reservoir1spp r = Reservoir1spp::from_raw(a.reservoir_input_tex.ld(rx, ry));
+            const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
+            const TemporalReservoirOutput spx_packed = TemporalReservoirOutput::from_raw(a.temporal_reservoir_packed_tex.ld(spx_x, spx_y));
+            const V2 spx_uv = get_uv(float(spx_x * 2 + off.x), float(spx_y * 2 + off.y), gts);
+            const ViewRay spx_ray = view_ray_from_uv_and_depth(fc, spx_uv, spx_packed.depth);
+            const float rpx_depth = a.half_depth_tex.ld(rx, ry);
+            const V3 hit_ws = spx_packed.ray_hit_offset_ws + spx_ray.hit_ws;
+            const V3 sample_offset = hit_ws - vr.hit_ws;
+            const float sample_dist = length(sample_offset);
+            const V3 sample_dir = sample_offset / sample_dist;
+            const float geometric_term = 2 * fmaxf(0.0f, dot(center_normal_ws, sample_dir));
+            V3 radiance = xyz(ld4(a.radiance_tex, spx_x, spx_y));
+            radiance *= lerp(1.0f, smoothstep(near_start, near_end, sample_dist), near_field_influence);
+            const V3 contribution = radiance * geometric_term * r.W;
+            const V3 sample_normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, spx_x, spx_y);
+            const float sample_ssao = from_unorm8(a.ssao_tex.ld(rx * 2 + off.x, ry * 2 + off.y));
+            float w = 1;
+            w *= ggx_ndf_unnorm(0.01f, saturate(dot(center_normal_vs, sample_normal_vs)));
+            w *= exp2f(-200.0f * fabsf(center_normal_vs.z * (center_depth / rpx_depth - 1.0f)));
+            w *= exp2f(-20.0f * fabsf(center_ssao - sample_ssao));
+            weighted += contribution * w;
+            w_sum += w;
+        }
+        total_irradiance += weighted / fmaxf(1e-20f, w_sum);
+    }
+    st4(a.irradiance_output_tex, x, y, v4(total_irradiance, 1));
+}
+
+// ------------------------------------------------------------------ temporal_filter.hlsl:39-252
+__global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgH4 history_tex, ImgU32 variance_history_tex /*RG16F*/,
+                                                         ImgU2 reprojection_tex, ImgU32 rt_history_invalidity_tex /*RG16F half*/, ImgH4 output_tex, ImgH4 history_output_tex,
+                                                         ImgU32 variance_history_output_tex) {
+    const int W = output_tex.w, H = output_tex.h;
+    TILE_XY(W, H)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const V2 uv = get_uv(float(x), float(y), tex_size4(W, H));
+    const V4 center = linear_rgb_to_crunched_luma_chroma(ld4(input_tex, x, y));
+    const V4 reproj = ld_reproj(reprojection_tex, x, y);
+    const V4 history_mult{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
+    const V4 history = linear_rgb_to_crunched_luma_chroma(ld4(history_tex, x, y) * history_mult);
+    V4 vsum = v4(0.0f), vsum2 = v4(0.0f);
+    float wsum = 0, hist_diff = 0, hist_vsum = 0, hist_vsum2 = 0;
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+            const V4 neigh = linear_rgb_to_crunched_luma_chroma(ld4(input_tex, x + dx, y + dy));
+            const V4 hist_neigh = linear_rgb_to_crunched_luma_chroma(ld4(history_tex, x + dx, y + dy) * history_mult);
+            const float neigh_luma = neigh.x, hist_luma = hist_neigh.x;
+            const float w = expf(-3.0f * float(dx * dx + dy * dy) / float((2 + 1.) * (2 + 1.)));
+            vsum += neigh * w;
+            vsum2 += neigh * neigh * w;
+            wsum += w;
+            hist_diff += fabsf(neigh_luma - hist_luma) / fmaxf(1e-5f, neigh_luma + hist_luma) * w;
+            hist_vsum += hist_luma * w;
+            hist_vsum2 += hist_luma * hist_luma * w;
+        }
+    const V4 ex = vsum / wsum, ex2 = vsum2 / wsum;
+    const V4 dev = vsqrt(vmax(v4(0.0f), ex2 - ex * ex));
+    hist_vsum /= wsum;
+    const V2 moments_history = sample_bilinear_clamp_rg16f(variance_history_tex.p, W, H, uv + V2{reproj.x, reproj.y}) *
+                               V2{fc.pre_exposure_delta, fc.pre_exposure_delta * fc.pre_exposure_delta};
+    const float center_luma = center.x + (hist_vsum - ex.x);
+    const V2 mo = lerp(moments_history, V2{center_luma, center_luma * center_luma}, 0.25f);
+    st2h(variance_history_output_tex, x, y, V2{fmaxf(0.0f, mo.x), fmaxf(0.0f, mo.y)});
+    const float center_temporal_dev = sqrtf(fmaxf(0.0f, moments_history.y - moments_history.x * moments_history.x));
+    const float temporal_change = fabsf(hist_vsum - ex.x) / fmaxf(1e-8f, hist_vsum + ex.x);
+    const float rt_invalid = saturate(sqrtf(ld2h(rt_history_invalidity_tex, x / 2, y / 2).x) * 4);
+    const float current_sample_count = history.w;
+    float clamp_box_size = 1 * lerp(0.25f, 2.0f, 1.0f - rt_invalid) * lerp(0.333f, 1.0f, saturate(reproj.w)) * 2;
+    clamp_box_size = fmaxf(clamp_box_size, 0.5f);
+    const V4 nmin = center - dev * clamp_box_size, nmax = center + dev * clamp_box_size;
+    const V3 clamped_history = vclamp(xyz(history), xyz(nmin), xyz(nmax));
+    const float variance_adjusted_temporal_change = smoothstep(0.1f, 1.0f, 0.05f * temporal_change / center_temporal_dev);
+    float max_sample_count = 32;
+    max_sample_count = lerp(max_sample_count, 4.0f, variance_adjusted_temporal_change);
+    max_sample_count *= lerp(1.0f, 0.5f, rt_invalid);
+    const V3 res = lerp(clamped_history, xyz(center), 1.0f / (1.0f + fminf(max_sample_count, current_sample_count)));
+    const float output_sample_count = fminf(current_sample_count, max_sample_count) + 1;
+    const V4 output = crunched_luma_chroma_to_linear_rgb(v4(res, output_sample_count));
+    st4(history_output_tex, x, y, output);
+    st4(output_tex, x, y, v4(xyz(output), saturate(output_sample_count * lerp(1.0f, 0.5f, rt_invalid) * smoothstep(0.3f, 0.0f, temporal_change) / 32.0f)));
+}
+
+// ------------------------------------------------------------------ spatial_filter.hlsl:34-101
+KJ_D V3 crunch(V3 v) { return v * (1.0f / (max3(v.x, v.y, v.z) + 1.0f)); }
+KJ_D V3 uncrunch(V3 v) { return v * (1.0f / (1.0f - max3(v.x, v.y, v.z))); }
+__global__ void __launch_bounds__(64) k_spatial_filter(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgF32 depth_tex, ImgR8 ssao_tex, ImgU32 geometric_normal_tex, ImgH4 output_tex) {
+    TILE_XY(output_tex.w, output_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const V4 c = ld4(input_tex, x, y);
+    const float center_validity = c.w;
+    const V3 center_value = xyz(c);
+    if (center_validity == 1) { st4(output_tex, x, y, v4(center_value, 1.0f)); return; }
+    const float center_depth = depth_tex.ld(x, y);
+    const float center_ssao = from_unorm8(ssao_tex.ld(x, y));
+    const V3 center_normal_vs = unpack_a2r10g10b10(geometric_normal_tex.ld(x, y)) * 2.0f - 1.0f;
+    const float ang_off = float((fc.frame_index * 23u) % 32u) * KJ_TAU + interleaved_gradient_noise(x, y) * KJ_PI;
+    const uint32_t MAX_SAMPLE_COUNT = 8;
+    const float MAX_RADIUS_PX = sqrtf(lerp(16.0f * 16.0f, 2.0f * 2.0f, center_validity));
+    const float KERNEL_SHARPNESS = 0.666f;
+    const uint32_t sample_count = min(max(uint32_t(exp2f(4.0f * square(1.0f - center_validity))), 2u), MAX_SAMPLE_COUNT);
+    V4 sum = v4(crunch(center_value), 1);
+    const float RADIUS_SAMPLE_MULT = MAX_RADIUS_PX / powf(float(MAX_SAMPLE_COUNT - 1), KERNEL_SHARPNESS);
+    for (uint32_t si = 1; si < MAX_SAMPLE_COUNT; ++si) {
+        const float ang = (float(si) + ang_off) * KJ_GOLDEN_ANGLE;
+        const float radius = powf(float(si), KERNEL_SHARPNESS) * RADIUS_SAMPLE_MULT;
+        const V2 so = V2{cosf(ang), sinf(ang)} * radius;
+        const int sx = int(float(x) + so.x), sy = int(float(y) + so.y);
+        const float sample_depth = depth_tex.ld(sx, sy);
+        if (sample_depth != 0 && si < sample_count) {
+            const V3 sample_val = xyz(ld4(input_tex, sx, sy));
+            const float sample_ssao = from_unorm8(ssao_tex.ld(sx, sy));
+            float wt = 1;
+            wt *= exp2f(-100.0f * fabsf(center_normal_vs.z * (center_depth / sample_depth - 1.0f)));
+            wt *= exp2f(-20.0f * fabsf(sample_ssao - center_ssao));
+            sum += v4(crunch(sample_val), 1.0f) * wt;
+        }
+    }
+    const float norm_factor = 1.0f / fmaxf(1e-5f, sum.w);
+    st4(output_tex, x, y, v4(uncrunch(xyz(sum) * norm_factor), 1.0f));
+}
+
+// ================================================================== host side
+struct KjRtdgi {
+    KjDevice* dev = nullptr;
+    uint32_t spatial_reuse_pass_count = 2;      // rtdgi.rs:43-44
+    bool use_raytraced_reservoir_visibility = false;
+    int W = 0, H = 0, hw = 0, hh = 0;
+    std::map<std::string, kj::DevBuf> surf;
+    bool flip[8] = {false, false, false, false, false, false, false, false};
+    bool temporal2_flip = false;
+    void* temporal_output_tex = nullptr;        // ReprojectedRtdgi (rtdgi.rs:48-51)
+    void* reprojected_history_tex = nullptr;
+    kj::DevBuf ray_counters;                    // 2 x u64
+    hipError_t err = hipSuccess;
+
+    void* get(const std::string& name, size_t bytes, hipStream_t s) {
+        kj::DevBuf& b = surf[name];
+        if (b.bytes != bytes) { hipError_t e = b.alloc(bytes, s); if (e != hipSuccess) err = e; }
+        return b.p;
+    }
+    // PingPongTemporalResource::get_output_and_history (renderers/mod.rs:85-102)
+    void pingpong(const char* key, int idx, size_t bytes, hipStream_t s, void*& output, void*& history) {
+        std::string a = std::string(key) + ":0", b = std::string(key) + ":1";
+        if (flip[idx]) std::swap(a, b);
+        output = get(a, bytes, s);
+        history = get(b, bytes, s);
+        flip[idx] = !flip[idx];
+    }
+    void resize(int W_, int H_) {
+        if (W == W_ && H == H_) return;
+        W = W_; H = H_; hw = (W + 1) / 2; hh = (H + 1) / 2;  // ImageDesc::half_res
+        surf.clear();
+    }
+};
+
+#define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
+
+extern "C" {
+
+KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
+    KJ_REQUIRE(dev && out, "null argument");
+    KjRtdgi* r = new KjRtdgi();
+    r->dev = dev;
+    if (r->ray_counters.alloc(16) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
+    *out = r;
+    return KJ_OK;
+}
+void kj_rtdgi_destroy(KjRtdgi* r) { delete r; }
+KjStatus kj_rtdgi_set_options(KjRtdgi* r, uint32_t spatial_reuse_pass_count, uint32_t use_raytraced_reservoir_visibility) {
+    KJ_REQUIRE(r, "null argument");
+    if (use_raytraced_reservoir_visibility) { set_last_error("restir_check (ray-traced reservoir visibility) is not implemented; the reference default is off (rtdgi.rs:43)"); return KJ_ERR_UNSUPPORTED; }
+    r->spatial_reuse_pass_count = spatial_reuse_pass_count;
+    return KJ_OK;
+}
+
+KjStatus kj_rtdgi_reproject(KjRtdgi* r, const void* reprojection_map, uint32_t width, uint32_t height, void* stream_) {
+    KJ_REQUIRE(r && reprojection_map && width && height, "null argument");
+    hipStream_t s = (hipStream_t)stream_;
+    r->resize(int(width), int(height));
+    const int W = r->W, H = r->H;
+    std::string a = "rtdgi.temporal2:0", b = "rtdgi.temporal2:1";
+    if (r->temporal2_flip) std::swap(a, b);
+    r->temporal_output_tex = r->get(a, size_t(W) * H * 8, s);
+    void* history = r->get(b, size_t(W) * H * 8, s);
+    r->temporal2_flip = !r->temporal2_flip;
+    r->reprojected_history_tex = r->get("reprojected_history_tex", size_t(W) * H * 8, s);
+    KJ_TRY_HIP(r->err);
+    hipLaunchKernelGGL(k_fullres_reproject, dim3((W + 7) / 8, (H + 7) / 8), dim3(64), 0, s, img<uint2>(history, W, H), img<uint2>(reprojection_map, W, H),
+                       img<uint2>(r->reprojected_history_tex, W, H));
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+
+KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput* out, void* stream_) {
+    KJ_REQUIRE(r && p, "null argument");
+    KJ_REQUIRE(p->scene && p->reprojection_map && p->sky_cube && p->ssao_tex && p->gbuffer_depth.depth && p->gbuffer_depth.gbuffer && p->gbuffer_depth.geometric_normal, "missing input");
+    KJ_REQUIRE(int(p->gbuffer_depth.width) == r->W && int(p->gbuffer_depth.height) == r->H && r->reprojected_history_tex, "kj_rtdgi_reproject must run first with the same extent");
+    KJ_REQUIRE(r->dev->fc_dev, "kj_frame_begin not called");
+    if (!p->scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
+    if (p->ircache) { set_last_error("irradiance cache binding is not implemented yet"); return KJ_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream_;
+    const int W = r->W, H = r->H, hw = r->hw, hh = r->hh;
+    const FrameConstants* fc = r->dev->fc_dev;
+    const uint32_t mask = p->pass_mask;
+    if (mask & KJ_RTDGI_PASS_KEEP_TEMPORALS) for (bool& f : r->flip) f = !f;
+    const dim3 gh((hw + 7) / 8, (hh + 7) / 8), gf((W + 7) / 8, (H + 7) / 8), blk(64);
+    const size_t HB = size_t(hw) * hh, FB = size_t(W) * H;
+
+    const ImgU4 gbuffer = img<uint4>(p->gbuffer_depth.gbuffer, W, H);
+    const ImgF32 depth = img<float>(p->gbuffer_depth.depth, W, H);
+    const ImgU32 geometric_normal = img<uint32_t>(p->gbuffer_depth.geometric_normal, W, H);
+    const ImgR8 ssao = img<uint8_t>(p->ssao_tex, W, H);
+    const ImgU2 reprojection = img<uint2>(p->reprojection_map, W, H);
+
+    void* half_ssao = r->get("half_ssao_tex", HB, s);
+    void* half_view_normal = r->get("half_view_normal_tex", HB * 4, s);
+    void* half_depth = r->get("half_depth_tex", HB * 4, s);
+    void *hit_normal_out, *hit_normal_hist; r->pingpong("rtdgi.hit_normal", 0, HB * 8, s, hit_normal_out, hit_normal_hist);
+    void *candidate_out, *candidate_hist;   r->pingpong("rtdgi.candidate", 1, HB * 8, s, candidate_out, candidate_hist);
+    void* candidate_radiance = r->get("candidate_radiance_tex", HB * 8, s);
+    void* candidate_normal = r->get("candidate_normal_tex", HB * 4, s);
+    void* candidate_hit = r->get("candidate_hit_tex", HB * 8, s);
+    void* temporal_reservoir_packed = r->get("temporal_reservoir_packed_tex", HB * 16, s);
+    void *invalidity_out, *invalidity_hist; r->pingpong("rtdgi.invalidity", 2, HB * 4, s, invalidity_out, invalidity_hist);
+    void *radiance_out, *radiance_hist;     r->pingpong("rtdgi.radiance", 3, HB * 8, s, radiance_out, radiance_hist);
+    void *ray_orig_out, *ray_orig_hist;     r->pingpong("rtdgi.ray_orig", 4, HB * 16, s, ray_orig_out, ray_orig_hist);
+    void *ray_out, *ray_hist;               r->pingpong("rtdgi.ray", 5, HB * 8, s, ray_out, ray_hist);
+    void* validity_pre = r->get("rt_history_validity_pre_input_tex", HB, s);
+    void *reservoir_out, *reservoir_hist;   r->pingpong("rtdgi.reservoir", 6, HB * 8, s, reservoir_out, reservoir_hist);
+    void* validity_in = r->get("rt_history_validity_input_tex", HB, s);
+    void* reservoir_tex0 = r->get("reservoir_output_tex0", HB * 8, s);
+    void* reservoir_tex1 = r->get("reservoir_output_tex1", HB * 8, s);
+    void* irradiance = r->get("irradiance_output_tex", FB * 8, s);
+    void *variance_out, *variance_hist;     r->pingpong("rtdgi.temporal2_var", 7, FB * 4, s, variance_out, variance_hist);
+    void* temporal_filtered = r->get("temporal_filtered_tex", FB * 8, s);
+    void* spatial_filtered = r->get("spatial_filtered_tex", FB * 8, s);
+    KJ_TRY_HIP(r->err);
+    KJ_TRY_HIP(hipMemsetAsync(r->ray_counters.p, 0, 16, s));
+
+    TraceCtx tc;
+    tc.fc = fc;
+    tc.sc = scene_view(*p->scene);
+    tc.depth = depth;
+    tc.reprojected_gi = img<uint2>(r->reprojected_history_tex, W, H);
+    tc.sky_cube = (const uint2*)p->sky_cube;
+    tc.sky_cube_width = int(p->sky_cube_width);
+    tc.blue_noise = (const uint32_t*)r->dev->blue_noise.p;
+    tc.brdf_fg_lut = (const uint2*)r->dev->brdf_fg_lut.p;
+    tc.sun_color = (const float4*)r->dev->sun_color.p + r->dev->fc_slot;
+    tc.ray_counters = (unsigned long long*)r->ray_counters.p;
+    const size_t trace_lds = size_t(tc.sc.bvh.stack_entries) * 64 * 4;
+    KJ_REQUIRE(trace_lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");
+
+    if (mask & KJ_RTDGI_PASS_EXTRACT_HALF) {
+        hipLaunchKernelGGL(k_extract_half, gh, blk, 0, s, fc, gbuffer, depth, ssao, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), img<int8_t>(half_ssao, hw, hh));
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & KJ_RTDGI_PASS_VALIDATE) {
+        hipLaunchKernelGGL(k_rtdgi_validate, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+                           img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh));
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & KJ_RTDGI_PASS_TRACE) {
+        hipLaunchKernelGGL(k_rtdgi_trace, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh));
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & KJ_RTDGI_PASS_VALIDITY_INTEGRATE) {
+        hipLaunchKernelGGL(k_validity_integrate, gh, blk, 0, s, fc, img<uint8_t>(validity_in, hw, hh), img<uint32_t>(invalidity_hist, hw, hh), reprojection,
+                           img<float>(half_depth, hw, hh), img<uint32_t>(invalidity_out, hw, hh), W, H);
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & KJ_RTDGI_PASS_RESTIR_TEMPORAL) {
+        RestirTemporalArgs a;
+        a.fc = fc; a.depth_tex = depth;
+        a.half_view_normal_tex = img<uint32_t>(half_view_normal, hw, hh);
+        a.candidate_radiance_tex = img<uint2>(candidate_radiance, hw, hh);
+        a.candidate_normal_tex = img<uint32_t>(candidate_normal, hw, hh);
+        a.candidate_hit_tex = img<uint2>(candidate_hit, hw, hh);
+        a.radiance_history_tex = img<uint2>(radiance_hist, hw, hh);
+        a.ray_orig_history_tex = img<float4>(ray_orig_hist, hw, hh);
+        a.ray_history_tex = img<uint2>(ray_hist, hw, hh);
+        a.reservoir_history_tex = img<uint2>(reservoir_hist, hw, hh);
+        a.reprojection_tex = reprojection;
+        a.hit_normal_history_tex = img<uint2>(hit_normal_hist, hw, hh);
+        a.candidate_history_tex = img<uint2>(candidate_hist, hw, hh);
+        a.rt_invalidity_tex = img<uint32_t>(invalidity_out, hw, hh);
+        a.radiance_out_tex = img<uint2>(radiance_out, hw, hh);
+        a.ray_orig_output_tex = img<float4>(ray_orig_out, hw, hh);
+        a.ray_output_tex = img<uint2>(ray_out, hw, hh);
+        a.hit_normal_output_tex = img<uint2>(hit_normal_out, hw, hh);
+        a.reservoir_out_tex = img<uint2>(reservoir_out, hw, hh);
+        a.candidate_out_tex = img<uint2>(candidate_out, hw, hh);
+        a.temporal_reservoir_packed_tex = img<uint4>(temporal_reservoir_packed, hw, hh);
+        hipLaunchKernelGGL(k_restir_temporal, gh, blk, 0, s, a);
+        KJ_CHECK_LAUNCH();
+    }
+    void* reservoir_input = reservoir_out;
+    for (uint32_t i = 0; i < r->spatial_reuse_pass_count; ++i) {
+        const uint32_t perform_occlusion_raymarch = (i + 1 == r->spatial_reuse_pass_count) ? 1u : 0u;
+        if (mask & KJ_RTDGI_PASS_RESTIR_SPATIAL) {
+            hipLaunchKernelGGL(k_restir_spatial, gh, blk, 0, s, fc, img<uint2>(reservoir_input, hw, hh), img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh),
+                               img<int8_t>(half_ssao, hw, hh), img<uint4>(temporal_reservoir_packed, hw, hh), img<uint2>(reservoir_tex0, hw, hh), W, H, i, perform_occlusion_raymarch, 0u);
+            KJ_CHECK_LAUNCH();
+        }
+        std::swap(reservoir_tex0, reservoir_tex1);
+        reservoir_input = reservoir_tex1;
+    }
+    if (mask & KJ_RTDGI_PASS_RESTIR_RESOLVE) {
+        ResolveArgs a;
+        a.fc = fc;
+        a.radiance_tex = img<uint2>(radiance_out, hw, hh);
+        a.reservoir_input_tex = img<uint2>(reservoir_input, hw, hh);
+        a.gbuffer_tex = gbuffer; a.depth_tex = depth;
+        a.half_view_normal_tex = img<uint32_t>(half_view_normal, hw, hh);
+        a.half_depth_tex = img<float>(half_depth, hw, hh);
+        a.ssao_tex = ssao;
+        a.candidate_radiance_tex = img<uint2>(candidate_radiance, hw, hh);
+        a.candidate_hit_tex = img<uint2>(candidate_hit, hw, hh);
+        a.temporal_reservoir_packed_tex = img<uint4>(temporal_reservoir_packed, hw, hh);
+        a.irradiance_output_tex = img<uint2>(irradiance, W, H);
+        a.blue_noise = (const uint32_t*)r->dev->blue_noise.p;
+        hipLaunchKernelGGL(k_restir_resolve, gf, blk, 0, s, a);
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & KJ_RTDGI_PASS_TEMPORAL_FILTER) {
+        hipLaunchKernelGGL(k_temporal_filter, gf, blk, 0, s, fc, img<uint2>(irradiance, W, H), img<uint2>(r->reprojected_history_tex, W, H), img<uint32_t>(variance_hist, W, H),
+                           reprojection, img<uint32_t>(invalidity_out, hw, hh), img<uint2>(temporal_filtered, W, H), img<uint2>(r->temporal_output_tex, W, H),
+                           img<uint32_t>(variance_out, W, H));
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & KJ_RTDGI_PASS_SPATIAL_FILTER) {
+        hipLaunchKernelGGL(k_spatial_filter, gf, blk, 0, s, fc, img<uint2>(temporal_filtered, W, H), depth, ssao, geometric_normal, img<uint2>(spatial_filtered, W, H));
+        KJ_CHECK_LAUNCH();
+    }
+    if (out) {
+        out->screen_irradiance_tex = spatial_filtered;
+        out->candidate_radiance_tex = candidate_radiance;
+        out->candidate_normal_tex = candidate_normal;
+        out->candidate_hit_tex = candidate_hit;
+    }
+    return KJ_OK;
+}
+
+KjStatus kj_rtdgi_surface(KjRtdgi* r, const char* name, void** out_dev_ptr, uint64_t* out_bytes) {
+    KJ_REQUIRE(r && name && out_dev_ptr && out_bytes, "null argument");
+    auto it = r->surf.find(name);
+    if (it == r->surf.end()) { set_last_error("no rtdgi surface named '%s'", name); return KJ_ERR_INVALID_ARGUMENT; }
+    *out_dev_ptr = it->second.p;
+    *out_bytes = it->second.bytes;
+    return KJ_OK;
+}
+KjStatus kj_rtdgi_ray_counts(KjRtdgi* r, uint64_t* out_closest, uint64_t* out_any) {
+    KJ_REQUIRE(r && out_closest && out_any, "null argument");
+    uint64_t v[2];
+    KJ_TRY_HIP(hipMemcpy(v, r->ray_counters.p, 16, hipMemcpyDeviceToHost));
+    *out_closest = v[0]; *out_any = v[1];
+    return KJ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,323 @@
+// KjScene: WorldRenderer's scene state for the GI path (world_renderer.rs:604-911):
+// mesh upload into one byte-addressed vertex buffer + GpuMesh table, instances,
+// triangle lights, and — replacing the driver's BLAS/TLAS — a host-built LBVH
+// (63-bit Morton codes, top-down split at the highest differing bit, <=4 tris
+// per leaf) uploaded as 64-byte two-box nodes and 48-byte leaf-ordered triangles.
+// Plain C++ (no device code); compiled with -ffp-contract=off so the instance
+// transform of vertices rounds exactly like the oracle's.
+#include "kj_host.hpp"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <numeric>
+
+namespace kj {
+
+static thread_local char g_last_error[1024] = "";
+void set_last_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+struct Aabb {
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    void grow(const float* p) { for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], p[k]); mx[k] = std::max(mx[k], p[k]); } }
+    void grow(const Aabb& o) { for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], o.mn[k]); mx[k] = std::max(mx[k], o.mx[k]); } }
+};
+
+static inline uint64_t expand21(uint64_t v) {
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+struct LbvhBuilder {
+    const std::vector<BvhTri>& tris;       // Morton-sorted
+    const std::vector<uint64_t>& codes;    // sorted
+    std::vector<BvhNode> nodes;
+    uint32_t max_depth = 0;
+
+    LbvhBuilder(const std::vector<BvhTri>& t, const std::vector<uint64_t>& c) : tris(t), codes(c) {}
+
+    static Aabb tri_bounds(const BvhTri& t) { Aabb b; b.grow(t.v0); b.grow(t.v1); b.grow(t.v2); return b; }
+
+    uint32_t find_split(uint32_t first, uint32_t last) const {
+        const uint64_t a = codes[first], b = codes[last];
+        if (a == b) return (first + last) >> 1;
+        const int common = __builtin_clzll(a ^ b);
+        // largest index in [first,last) sharing more than `common` leading bits with `a`
+        uint32_t split = first, step = last - first;
+        do {
+            step = (step + 1) >> 1;
+            const uint32_t ns = split + step;
+            if (ns < last) {
+                const uint64_t x = codes[ns] ^ a;
+                const int cp = x ? __builtin_clzll(x) : 64;
+                if (cp > common) split = ns;
+            }
+        } while (step > 1);
+        return split;
+    }
+
+    // returns child reference; fills `box`
+    uint32_t build(uint32_t first, uint32_t last, uint32_t depth, Aabb& box) {
+        max_depth = std::max(max_depth, depth);
+        const uint32_t count = last - first + 1;
+        if (count <= KJ_BVH_MAX_LEAF_TRIS) {
+            for (uint32_t i = first; i <= last; ++i) box.grow(tri_bounds(tris[i]));
+            return KJ_BVH_LEAF | ((count - 1) << 28) | first;
+        }
+        const uint32_t split = find_split(first, last);
+        const uint32_t idx = uint32_t(nodes.size());
+        nodes.push_back(BvhNode{});
+        Aabb lb, rb;
+        const uint32_t l = build(first, split, depth + 1, lb);
+        const uint32_t r = build(split + 1, last, depth + 1, rb);
+        BvhNode& n = nodes[idx];
+        for (int k = 0; k < 3; ++k) { n.lmin[k] = lb.mn[k]; n.lmax[k] = lb.mx[k]; n.rmin[k] = rb.mn[k]; n.rmax[k] = rb.mx[k]; }
+        n.left = l; n.right = r; n.pad0 = n.pad1 = 0;
+        box.grow(lb); box.grow(rb);
+        return idx;
+    }
+};
+
+SceneView scene_view(const KjScene& s) {
+    SceneView v{};
+    v.vertex_buffer = (const uint8_t*)s.d_vertex_buffer.p;
+    v.meshes = (const GpuMesh*)s.d_meshes.p;
+    v.instances = (const GpuInstance*)s.d_instances.p;
+    v.map_colors = (const F4*)s.d_map_colors.p;
+    v.lights = (const KjTriangleLight*)s.d_lights.p;
+    v.light_count = s.light_count;
+    v.bvh.nodes = (const F4*)s.d_nodes.p;
+    v.bvh.tris = (const F4*)s.d_tris.p;
+    v.bvh.root = s.bvh_root;
+    v.bvh.stack_entries = s.bvh_max_depth + 2;
+    return v;
+}
+
+} // namespace kj
+
+kj::SceneView KjScene::view() const { return kj::scene_view(*this); }
+
+using namespace kj;
+
+template <typename T> static uint32_t vb_append(std::vector<uint8_t>& vb, const T* data, size_t count) {
+    size_t off = (vb.size() + 63) & ~size_t(63);
+    vb.resize(off + sizeof(T) * count);
+    if (count) memcpy(vb.data() + off, data, sizeof(T) * count);
+    return uint32_t(off);
+}
+
+extern "C" {
+
+const char* kj_last_error(void) { return kj::g_last_error; }
+uint32_t kj_abi_version(void) { return 1; }
+
+KjStatus kj_scene_create(KjDevice* dev, KjScene** out) {
+    KJ_REQUIRE(dev && out, "null argument");
+    KjScene* s = new KjScene();
+    s->dev = dev;
+    s->vertex_buffer.resize(64, 0);  // offset 0 stays unused: `vertex_aux_offset != 0` means "has colours"
+    *out = s;
+    return KJ_OK;
+}
+void kj_scene_destroy(KjScene* scene) { delete scene; }
+
+KjStatus kj_scene_add_mesh(KjScene* s, const KjMeshDesc* d, uint32_t* out_mesh) {
+    KJ_REQUIRE(s && d && out_mesh, "null argument");
+    KJ_REQUIRE(d->verts && d->indices && d->materials && d->maps, "mesh streams missing");
+    KJ_REQUIRE(d->index_count >= 3 && d->index_count % 3 == 0, "mesh must not be empty (world_renderer.rs:706-711)");
+    for (uint32_t i = 0; i < d->map_count; ++i)
+        if (d->maps[i].image_rgba8) { set_last_error("image material maps are not supported yet (placeholders only)"); return KJ_ERR_UNSUPPORTED; }
+    for (uint32_t i = 0; i < d->index_count; ++i) KJ_REQUIRE(d->indices[i] < d->vertex_count, "index out of range");
+    std::vector<KjMeshMaterial> mats(d->materials, d->materials + d->material_count);
+    const uint32_t map_base = uint32_t(s->map_colors.size() / 4);
+    for (uint32_t i = 0; i < d->map_count; ++i)
+        for (int k = 0; k < 4; ++k) s->map_colors.push_back(float(d->maps[i].placeholder_rgba[k]) / 255.0f);
+    for (auto& m : mats) {
+        for (int k = 0; k < 4; ++k) { KJ_REQUIRE(m.maps[k] < d->map_count, "material map index out of range"); m.maps[k] += map_base; }
+        if (d->use_lights) m.flags |= KJ_MESH_MATERIAL_FLAG_EMISSIVE_USED_AS_LIGHT;
+    }
+    std::vector<float> uvs(size_t(d->vertex_count) * 2, 0.0f);
+    if (d->uvs) memcpy(uvs.data(), d->uvs, uvs.size() * 4);
+    std::vector<uint32_t> mids(d->vertex_count, 0);
+    if (d->material_ids) memcpy(mids.data(), d->material_ids, size_t(d->vertex_count) * 4);
+    for (uint32_t v : mids) KJ_REQUIRE(v < d->material_count, "material id out of range");
+    GpuMesh m{};
+    std::vector<uint8_t>& vb = s->vertex_buffer;
+    m.index_offset = vb_append(vb, d->indices, d->index_count);
+    m.vertex_core_offset = vb_append(vb, d->verts, d->vertex_count);
+    m.vertex_uv_offset = vb_append(vb, uvs.data(), uvs.size());
+    m.vertex_mat_offset = vb_append(vb, mids.data(), mids.size());
+    m.vertex_aux_offset = d->colors ? vb_append(vb, d->colors, size_t(d->vertex_count) * 4) : 0;
+    m.vertex_tangent_offset = d->tangents ? vb_append(vb, d->tangents, size_t(d->vertex_count) * 4) : 0;
+    m.mat_data_offset = vb_append(vb, mats.data(), mats.size());
+    m.index_count = d->index_count;
+    s->meshes.push_back(m);
+    // emissive triangles -> TriangleLight list (world_renderer.rs:741-773)
+    std::vector<KjTriangleLight> lights;
+    if (d->use_lights) {
+        for (uint32_t i = 0; i + 2 < d->index_count; i += 3) {
+            const KjMeshMaterial& mat = d->materials[mids[d->indices[i]]];
+            if (!(mat.emissive[0] > 0 || mat.emissive[1] > 0 || mat.emissive[2] > 0)) continue;
+            KjTriangleLight l;
+            for (int k = 0; k < 3; ++k) memcpy(&l.verts[k * 3], d->verts[d->indices[i + k]].pos, 12);
+            memcpy(l.radiance, mat.emissive, 12);
+            lights.push_back(l);
+        }
+    }
+    s->mesh_lights.push_back(std::move(lights));
+    s->committed = false;
+    *out_mesh = uint32_t(s->meshes.size() - 1);
+    return KJ_OK;
+}
+
+KjStatus kj_scene_add_instance(KjScene* s, uint32_t mesh, const float* xf, uint32_t* out_instance) {
+    KJ_REQUIRE(s && xf && out_instance, "null argument");
+    KJ_REQUIRE(mesh < s->meshes.size(), "bad mesh handle");
+    KjScene::Inst i{};
+    i.mesh = mesh;
+    memcpy(i.xform, xf, 48);
+    i.emissive_multiplier = 1.0f;
+    i.alive = true;
+    s->instances.push_back(i);
+    s->committed = false;
+    *out_instance = uint32_t(s->instances.size() - 1);
+    return KJ_OK;
+}
+KjStatus kj_scene_set_instance_transform(KjScene* s, uint32_t instance, const float* xf) {
+    KJ_REQUIRE(s && xf && instance < s->instances.size() && s->instances[instance].alive, "bad instance handle");
+    memcpy(s->instances[instance].xform, xf, 48);
+    s->committed = false;
+    return KJ_OK;
+}
+KjStatus kj_scene_set_instance_emissive_multiplier(KjScene* s, uint32_t instance, float v) {
+    KJ_REQUIRE(s && instance < s->instances.size() && s->instances[instance].alive, "bad instance handle");
+    s->instances[instance].emissive_multiplier = v;
+    s->committed = false;
+    return KJ_OK;
+}
+KjStatus kj_scene_remove_instance(KjScene* s, uint32_t instance) {
+    KJ_REQUIRE(s && instance < s->instances.size() && s->instances[instance].alive, "bad instance handle");
+    s->instances[instance].alive = false;
+    s->committed = false;
+    return KJ_OK;
+}
+
+KjStatus kj_scene_commit(KjScene* s, void* stream_) {
+    KJ_REQUIRE(s, "null scene");
+    hipStream_t stream = (hipStream_t)stream_;
+    KJ_TRY_HIP(hipSetDevice(s->dev->ordinal));
+    // 1. flatten instances into world space (same arithmetic as the oracle: row-major 3x4 times point)
+    std::vector<BvhTri> wt;
+    std::vector<KjTriangleLight> lights;
+    std::vector<GpuInstance> ginst(s->instances.size());
+    for (uint32_t ii = 0; ii < s->instances.size(); ++ii) {
+        const KjScene::Inst& inst = s->instances[ii];
+        GpuInstance& g = ginst[ii];
+        memcpy(g.xform, inst.xform, 48);
+        g.mesh = inst.mesh; g.emissive_multiplier = inst.emissive_multiplier; g.pad0 = g.pad1 = 0;
+        if (!inst.alive) continue;
+        const GpuMesh& m = s->meshes[inst.mesh];
+        const float* x = inst.xform;
+        auto xf_point = [&](const float* p, float* o) {
+            o[0] = x[0] * p[0] + x[1] * p[1] + x[2] * p[2] + x[3];
+            o[1] = x[4] * p[0] + x[5] * p[1] + x[6] * p[2] + x[7];
+            o[2] = x[8] * p[0] + x[9] * p[1] + x[10] * p[2] + x[11];
+        };
+        for (uint32_t p = 0; p < m.index_count / 3; ++p) {
+            BvhTri t{};
+            float* dst[3] = {t.v0, t.v1, t.v2};
+            for (int k = 0; k < 3; ++k) {
+                uint32_t idx;
+                memcpy(&idx, s->vertex_buffer.data() + m.index_offset + (p * 3 + k) * 4, 4);
+                xf_point((const float*)(s->vertex_buffer.data() + m.vertex_core_offset + size_t(idx) * 16), dst[k]);
+            }
+            t.world_id = uint32_t(wt.size());
+            t.inst = ii; t.prim = p;
+            wt.push_back(t);
+        }
+        for (const KjTriangleLight& l : s->mesh_lights[inst.mesh]) {  // TriangleLight::transform, scale_radiance
+            KjTriangleLight w = l;
+            for (int k = 0; k < 3; ++k) xf_point(&l.verts[k * 3], &w.verts[k * 3]);
+            for (int k = 0; k < 3; ++k) w.radiance[k] = l.radiance[k] * inst.emissive_multiplier;
+            lights.push_back(w);
+        }
+    }
+    KJ_REQUIRE(!wt.empty(), "scene has no triangles");
+    KJ_REQUIRE(wt.size() < (1u << 28), "too many triangles for 28-bit leaf references");
+    // 2. Morton codes of centroids, sort
+    Aabb cb;
+    std::vector<float> cen(wt.size() * 3);
+    for (size_t i = 0; i < wt.size(); ++i) {
+        for (int k = 0; k < 3; ++k) cen[i * 3 + k] = (wt[i].v0[k] + wt[i].v1[k] + wt[i].v2[k]) * (1.0f / 3.0f);
+        cb.grow(&cen[i * 3]);
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> keys(wt.size());
+    double inv[3];
+    for (int k = 0; k < 3; ++k) inv[k] = cb.mx[k] > cb.mn[k] ? 2097151.0 / double(cb.mx[k] - cb.mn[k]) : 0.0;
+    for (size_t i = 0; i < wt.size(); ++i) {
+        uint64_t q[3];
+        for (int k = 0; k < 3; ++k) q[k] = uint64_t(std::min(2097151.0, std::max(0.0, (double(cen[i * 3 + k]) - cb.mn[k]) * inv[k])));
+        keys[i] = {(expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]), uint32_t(i)};
+    }
+    std::sort(keys.begin(), keys.end());
+    std::vector<BvhTri> sorted(wt.size());
+    std::vector<uint64_t> codes(wt.size());
+    for (size_t i = 0; i < wt.size(); ++i) { sorted[i] = wt[keys[i].second]; codes[i] = keys[i].first; }
+    // 3. hierarchy
+    LbvhBuilder b(sorted, codes);
+    b.nodes.reserve(wt.size());
+    Aabb root_box;
+    uint32_t root = b.build(0, uint32_t(sorted.size() - 1), 0, root_box);
+    if (root & KJ_BVH_LEAF) {  // tiny scene: wrap the single leaf in a node whose right child is an empty box
+        BvhNode n{};
+        for (int k = 0; k < 3; ++k) { n.lmin[k] = root_box.mn[k]; n.lmax[k] = root_box.mx[k]; n.rmin[k] = FLT_MAX; n.rmax[k] = FLT_MAX; }  // unreachable box: both slab planes at +inf
+        n.left = root; n.right = root;
+        b.nodes.push_back(n);
+        root = uint32_t(b.nodes.size() - 1);
+        b.max_depth = 1;
+    }
+    s->tri_count = uint32_t(sorted.size());
+    s->node_count = uint32_t(b.nodes.size());
+    s->bvh_root = root;
+    s->bvh_max_depth = b.max_depth;
+    s->light_count = uint32_t(lights.size());
+    // 4. upload
+    KJ_TRY_HIP(s->d_vertex_buffer.upload(s->vertex_buffer.data(), s->vertex_buffer.size(), stream));
+    KJ_TRY_HIP(s->d_meshes.upload(s->meshes.data(), s->meshes.size() * sizeof(GpuMesh), stream));
+    KJ_TRY_HIP(s->d_instances.upload(ginst.data(), ginst.size() * sizeof(GpuInstance), stream));
+    KJ_TRY_HIP(s->d_map_colors.upload(s->map_colors.data(), s->map_colors.size() * 4, stream));
+    if (lights.empty()) lights.push_back(KjTriangleLight{});
+    KJ_TRY_HIP(s->d_lights.upload(lights.data(), lights.size() * sizeof(KjTriangleLight), stream));
+    KJ_TRY_HIP(s->d_nodes.upload(b.nodes.data(), b.nodes.size() * sizeof(BvhNode), stream));
+    KJ_TRY_HIP(s->d_tris.upload(sorted.data(), sorted.size() * sizeof(BvhTri), stream));
+    KJ_TRY_HIP(hipStreamSynchronize(stream));  // host vectors go out of scope
+    s->committed = true;
+    return KJ_OK;
+}
+
+KjStatus kj_scene_triangle_light_count(KjScene* s, uint32_t* out) {
+    KJ_REQUIRE(s && out, "null argument");
+    if (!s->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
+    *out = s->light_count;
+    return KJ_OK;
+}
+KjStatus kj_scene_stats(KjScene* s, uint32_t* out_tri_count, uint32_t* out_node_count, uint64_t* out_bvh_bytes) {
+    KJ_REQUIRE(s, "null scene");
+    if (!s->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
+    if (out_tri_count) *out_tri_count = s->tri_count;
+    if (out_node_count) *out_node_count = s->node_count;
+    if (out_bvh_bytes) *out_bvh_bytes = uint64_t(s->node_count) * sizeof(BvhNode) + uint64_t(s->tri_count) * sizeof(BvhTri);
+    return KJ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,28 @@
+import os
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import okj_py
+    okj_py.lib()
+    return okj_py
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """The product library on cuda:0. Fails (does not skip) if the HIP extension is missing."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from kajiya_amd import lib
+    lib.load()
+    return lib

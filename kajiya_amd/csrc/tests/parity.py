@@ -1,0 +1,83 @@
+"""Surface decoding + comparison helpers shared by the parity tests."""
+import numpy as np
+
+# name prefix -> (format, channels). Ping-pong names carry a ":0"/":1" suffix.
+FORMATS = {
+    "rtdgi.radiance": "rgba16f", "rtdgi.ray_orig": "rgba32f", "rtdgi.ray": "rgba16f", "rtdgi.candidate": "rgba16f",
+    "rtdgi.hit_normal": "rgba16f", "rtdgi.temporal2_var": "rg16f", "rtdgi.temporal2": "rgba16f", "rtdgi.invalidity": "rg16f",
+    "rtdgi.reservoir": "reservoir", "reservoir_output_tex0": "reservoir", "reservoir_output_tex1": "reservoir",
+    "candidate_radiance_tex": "rgba16f", "candidate_hit_tex": "rgba16f", "candidate_normal_tex": "rgba8s",
+    "temporal_reservoir_packed_tex": "trp", "rt_history_validity_pre_input_tex": "r8", "rt_history_validity_input_tex": "r8",
+    "half_ssao_tex": "r8s", "half_view_normal_tex": "rgba8s", "half_depth_tex": "r32f",
+    "reprojected_history_tex": "rgba16f", "irradiance_output_tex": "rgba16f", "temporal_filtered_tex": "rgba16f",
+    "spatial_filtered_tex": "rgba16f",
+}
+FULL_RES = {"rtdgi.temporal2_var", "rtdgi.temporal2", "reprojected_history_tex", "irradiance_output_tex", "temporal_filtered_tex", "spatial_filtered_tex"}
+BYTES_PER_TEXEL = {"rgba16f": 8, "rgba32f": 16, "rg16f": 4, "reservoir": 8, "rgba8s": 4, "trp": 16, "r8": 1, "r8s": 1, "r32f": 4}
+
+
+def base_name(name):
+    return name.split(":")[0]
+
+
+def fmt_of(name):
+    return FORMATS[base_name(name)]
+
+
+def unpack_11_10_11(p):
+    x = (p & 2047).astype(np.float32) / 2047.0
+    y = ((p >> 11) & 1023).astype(np.float32) / 1023.0
+    z = ((p >> 21) & 2047).astype(np.float32) / 2047.0
+    return np.stack([x, y, z], -1) * 2 - 1
+
+
+def decode(raw_u8, fmt):
+    """raw bytes (numpy uint8, flat) -> float32 array [..., C] for comparison."""
+    raw = np.ascontiguousarray(raw_u8).reshape(-1)
+    if fmt == "rgba16f":
+        return raw.view(np.float16).astype(np.float32).reshape(-1, 4)
+    if fmt == "rg16f":
+        return raw.view(np.float16).astype(np.float32).reshape(-1, 2)
+    if fmt == "rgba32f":
+        return raw.view(np.float32).reshape(-1, 4)
+    if fmt == "r32f":
+        return raw.view(np.float32).reshape(-1, 1)
+    if fmt == "r8":
+        return (raw.astype(np.float32) / 255.0).reshape(-1, 1)
+    if fmt == "r8s":
+        return np.maximum(raw.view(np.int8).astype(np.float32) / 127.0, -1).reshape(-1, 1)
+    if fmt == "rgba8s":
+        return np.maximum(raw.view(np.int8).astype(np.float32) / 127.0, -1).reshape(-1, 4)
+    if fmt == "reservoir":
+        u = raw.view(np.uint32).reshape(-1, 2)
+        mw = u[:, 1:2].copy().view(np.float16).astype(np.float32).reshape(-1, 2)
+        px = (u[:, 0] & 0xffff).astype(np.float32)
+        py = (u[:, 0] >> 16).astype(np.float32)
+        return np.stack([px, py, mw[:, 0], mw[:, 1]], -1)
+    if fmt == "trp":
+        u = raw.view(np.uint32).reshape(-1, 4)
+        depth = u[:, 0:1].copy().view(np.float32)
+        a = u[:, 1:2].copy().view(np.float16).astype(np.float32).reshape(-1, 2)
+        b = u[:, 2:3].copy().view(np.float16).astype(np.float32).reshape(-1, 2)
+        n = unpack_11_10_11(u[:, 3])
+        return np.concatenate([depth, a, b, n], -1)
+    raise KeyError(fmt)
+
+
+def compare(a_raw, b_raw, fmt, atol=0.0):
+    """Returns dict(rel_l2, mismatch_frac, max_abs, n). NaN==NaN and inf==inf count as equal."""
+    a, b = decode(a_raw, fmt).astype(np.float64), decode(b_raw, fmt).astype(np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    both_nan = np.isnan(a) & np.isnan(b)
+    same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+    ok = both_nan | same_inf
+    fin = np.isfinite(a) & np.isfinite(b)
+    bad_class = ~(ok | fin)  # one side non-finite, the other not (or different inf)
+    d = np.where(fin, a - b, 0.0)
+    ref = np.where(fin, b, 0.0)
+    num, den = np.sqrt((d * d).sum()), np.sqrt((ref * ref).sum())
+    tol = atol + 1e-3 * np.abs(ref)
+    mism = ((np.abs(d) > tol) & fin) | bad_class
+    texel_mism = mism.any(axis=-1)
+    return dict(rel_l2=float(num / den) if den > 0 else float(num), mismatch_frac=float(texel_mism.mean()),
+                max_abs=float(np.abs(d).max()) if d.size else 0.0, n=int(a.shape[0]), bad_class=int(bad_class.sum()))

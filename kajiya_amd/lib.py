@@ -1,0 +1,286 @@
+"""ctypes binding of libkajiya_amd.so (the C-ABI in include/kajiya_amd.h) and a thin
+frame driver that mirrors the in-scope part of `prepare_render_graph_standard`
+(crates/lib/kajiya/src/world_render_passes.rs:13-292).
+
+The HIP library is the only compute path: if it cannot be loaded this module raises —
+there is no CPU fallback. torch is used only for device memory and streams.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from .abi import (KjFrameConstants, KjMeshDesc, KjGbufferDepth, KjRtdgiRenderParams, KjRtdgiOutput, KJ_RTDGI_PASS)
+from . import scenes as kscenes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkajiya_amd.so")
+
+EXPORTS = [
+    "kj_last_error", "kj_abi_version", "kj_device_create", "kj_device_destroy", "kj_device_brdf_lut",
+    "kj_scene_create", "kj_scene_destroy", "kj_scene_add_mesh", "kj_scene_add_instance", "kj_scene_set_instance_transform",
+    "kj_scene_set_instance_emissive_multiplier", "kj_scene_remove_instance", "kj_scene_commit", "kj_scene_triangle_light_count",
+    "kj_scene_stats", "kj_frame_begin", "kj_trace_closest", "kj_trace_any", "kj_raster_gbuffer", "kj_sky_cube_render",
+    "kj_sky_cube_convolve", "kj_reprojection_create", "kj_reprojection_destroy", "kj_calculate_reprojection_map",
+    "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_render",
+    "kj_rtdgi_surface", "kj_rtdgi_ray_counts",
+]
+
+_LIB = None
+
+
+class KjError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library. Fails loudly when it is missing (no fallback path exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise KjError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(kajiya_amd has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+    L.kj_last_error.restype = C.c_char_p
+    L.kj_abi_version.restype = u32
+    sig = {
+        "kj_device_create": [i32, vp, C.POINTER(vp)],
+        "kj_device_brdf_lut": [vp, C.POINTER(vp)],
+        "kj_scene_create": [vp, C.POINTER(vp)],
+        "kj_scene_add_mesh": [vp, C.POINTER(KjMeshDesc), C.POINTER(u32)],
+        "kj_scene_add_instance": [vp, u32, vp, C.POINTER(u32)],
+        "kj_scene_set_instance_transform": [vp, u32, vp],
+        "kj_scene_set_instance_emissive_multiplier": [vp, u32, C.c_float],
+        "kj_scene_remove_instance": [vp, u32],
+        "kj_scene_commit": [vp, vp],
+        "kj_scene_triangle_light_count": [vp, C.POINTER(u32)],
+        "kj_scene_stats": [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64)],
+        "kj_frame_begin": [vp, C.POINTER(KjFrameConstants), vp],
+        "kj_trace_closest": [vp, vp, vp, u32, u32, vp],
+        "kj_trace_any": [vp, vp, vp, u32, vp],
+        "kj_raster_gbuffer": [vp, vp, u32, u32, vp, vp, vp, vp, vp],
+        "kj_sky_cube_render": [vp, vp, vp],
+        "kj_sky_cube_convolve": [vp, vp, vp, vp],
+        "kj_reprojection_create": [vp, C.POINTER(vp)],
+        "kj_calculate_reprojection_map": [vp, C.POINTER(KjGbufferDepth), vp, C.POINTER(vp), vp],
+        "kj_rtdgi_create": [vp, C.POINTER(vp)],
+        "kj_rtdgi_set_options": [vp, u32, u32],
+        "kj_rtdgi_reproject": [vp, vp, u32, u32, vp],
+        "kj_rtdgi_render": [vp, C.POINTER(KjRtdgiRenderParams), C.POINTER(KjRtdgiOutput), vp],
+        "kj_rtdgi_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
+        "kj_rtdgi_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = i32
+    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy"):
+        f = getattr(L, name)
+        f.argtypes = [vp]
+        f.restype = None
+    _LIB = L
+    return L
+
+
+def check(status):
+    if status != 0:
+        raise KjError(f"kajiya_amd status {status}: {load().kj_last_error().decode()}")
+
+
+def _stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Device:
+    def __init__(self, ordinal=0, blue_noise=None):
+        L = load()
+        if blue_noise is None:
+            blue_noise = np.fromfile(os.path.join(kscenes.GOLDEN_DIR, "bluenoise_256_rgba8.bin"), dtype=np.uint8)
+        self._bn = np.ascontiguousarray(blue_noise, np.uint8)
+        assert self._bn.size == 256 * 256 * 4
+        self.h = C.c_void_p()
+        check(L.kj_device_create(ordinal, self._bn.ctypes.data, C.byref(self.h)))
+
+    def frame_begin(self, fc):
+        check(load().kj_frame_begin(self.h, C.byref(fc), _stream_ptr()))
+
+    def brdf_lut_ptr(self):
+        p = C.c_void_p()
+        check(load().kj_device_brdf_lut(self.h, C.byref(p)))
+        return p.value
+
+    def __del__(self):
+        try:
+            load().kj_device_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Scene:
+    """WorldRenderer scene state: add_mesh / add_instance / commit (builds the software LBVH)."""
+
+    def __init__(self, dev: Device, desc: kscenes.SceneDesc = None, use_lights=False):
+        L = load()
+        self.dev = dev
+        self.h = C.c_void_p()
+        check(L.kj_scene_create(dev.h, C.byref(self.h)))
+        self._keep = []
+        if desc is not None:
+            for m in desc.meshes:
+                self.add_mesh(m, use_lights)
+            for mi, xf in desc.instances:
+                self.add_instance(mi, xf)
+            self.commit()
+
+    def add_mesh(self, mesh: kscenes.TriangleMesh, use_lights=False):
+        d, keep = mesh.pack(use_lights)
+        self._keep.append(keep)
+        out = C.c_uint32()
+        check(load().kj_scene_add_mesh(self.h, C.byref(d), C.byref(out)))
+        return out.value
+
+    def add_instance(self, mesh_idx, xform3x4):
+        xf = np.ascontiguousarray(xform3x4, np.float32)
+        out = C.c_uint32()
+        check(load().kj_scene_add_instance(self.h, mesh_idx, xf.ctypes.data, C.byref(out)))
+        return out.value
+
+    def commit(self):
+        check(load().kj_scene_commit(self.h, _stream_ptr()))
+
+    def stats(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        check(load().kj_scene_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(triangles=a.value, nodes=b.value, bvh_bytes=c.value)
+
+    @property
+    def triangle_light_count(self):
+        out = C.c_uint32()
+        check(load().kj_scene_triangle_light_count(self.h, C.byref(out)))
+        return out.value
+
+    def trace_closest(self, rays_dev, count, cull_back=False):
+        import torch
+        hits = torch.empty((count, 4), dtype=torch.float32, device=rays_dev.device)
+        check(load().kj_trace_closest(self.h, rays_dev.data_ptr(), hits.data_ptr(), count, int(cull_back), _stream_ptr()))
+        return hits
+
+    def trace_any(self, rays_dev, count):
+        import torch
+        out = torch.empty((count,), dtype=torch.uint8, device=rays_dev.device)
+        check(load().kj_trace_any(self.h, rays_dev.data_ptr(), out.data_ptr(), count, _stream_ptr()))
+        return out
+
+    def __del__(self):
+        try:
+            load().kj_scene_destroy(self.h)
+        except Exception:
+            pass
+
+
+class GpuPipeline:
+    """One frame of the hot path on the GPU: sky cubes -> G-buffer stand-in -> reprojection map ->
+    RtdgiRenderer::reproject -> RtdgiRenderer::render. All buffers stay resident in HBM."""
+
+    def __init__(self, dev: Device, scene: Scene, width, height, device="cuda:0"):
+        import torch
+        self.torch = torch
+        L = load()
+        self.L, self.dev, self.scene = L, dev, scene
+        self.W, self.H = width, height
+        W, H = width, height
+        t = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+        self.geometric_normal = t((H, W), torch.int32)
+        self.gbuffer = t((H, W, 4), torch.int32)
+        self.depth = t((H, W), torch.float32)
+        self.velocity = t((H, W, 4), torch.int16)
+        self.ssao = torch.full((H, W), 255, dtype=torch.uint8, device=device)
+        self.sky64 = t((6, 64, 64, 4), torch.int16)
+        self.sky16 = t((6, 16, 16, 4), torch.int16)
+        self._sky_key = None
+        self.reproj = C.c_void_p()
+        check(L.kj_reprojection_create(dev.h, C.byref(self.reproj)))
+        self.rtdgi = C.c_void_p()
+        check(L.kj_rtdgi_create(dev.h, C.byref(self.rtdgi)))
+        self.reprojection_map_ptr = C.c_void_p()
+        self.out = KjRtdgiOutput()
+
+    def gbuffer_depth(self):
+        g = KjGbufferDepth()
+        g.geometric_normal = self.geometric_normal.data_ptr()
+        g.gbuffer = self.gbuffer.data_ptr()
+        g.depth = self.depth.data_ptr()
+        g.width, g.height = self.W, self.H
+        return g
+
+    def render_inputs(self, fc):
+        L, s = self.L, _stream_ptr()
+        self.dev.frame_begin(fc)
+        key = bytes(fc.sun_direction) + bytes(fc.sun_color_multiplier) + bytes(fc.sky_ambient) + bytes(C.c_float(fc.pre_exposure))
+        if key != self._sky_key:
+            check(L.kj_sky_cube_render(self.dev.h, self.sky64.data_ptr(), s))
+            check(L.kj_sky_cube_convolve(self.dev.h, self.sky64.data_ptr(), self.sky16.data_ptr(), s))
+            self._sky_key = key
+        check(L.kj_raster_gbuffer(self.dev.h, self.scene.h, self.W, self.H, self.geometric_normal.data_ptr(), self.gbuffer.data_ptr(),
+                                  self.depth.data_ptr(), self.velocity.data_ptr(), s))
+
+    def reprojection(self):
+        g = self.gbuffer_depth()
+        check(self.L.kj_calculate_reprojection_map(self.reproj, C.byref(g), self.velocity.data_ptr(), C.byref(self.reprojection_map_ptr), _stream_ptr()))
+
+    def params(self, pass_mask=KJ_RTDGI_PASS["ALL"]):
+        p = KjRtdgiRenderParams()
+        p.gbuffer_depth = self.gbuffer_depth()
+        p.reprojection_map = self.reprojection_map_ptr
+        p.sky_cube = self.sky16.data_ptr()
+        p.sky_cube_width = 16
+        p.scene = self.scene.h
+        p.ircache = None
+        p.ssao_tex = self.ssao.data_ptr()
+        p.pass_mask = pass_mask
+        return p
+
+    def rtdgi_frame(self, pass_mask=KJ_RTDGI_PASS["ALL"]):
+        """The GI frame proper (what `gi_frame_ms` times): rtdgi.reproject + rtdgi.render."""
+        s = _stream_ptr()
+        check(self.L.kj_rtdgi_reproject(self.rtdgi, self.reprojection_map_ptr, self.W, self.H, s))
+        p = self.params(pass_mask)
+        check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+
+    def frame(self, fc):
+        self.render_inputs(fc)
+        self.reprojection()
+        self.rtdgi_frame()
+
+    def surface(self, name, dtype, shape):
+        """Wrap a named renderer surface as a torch tensor (no copy)."""
+        torch = self.torch
+        ptr, n = C.c_void_p(), C.c_uint64()
+        check(self.L.kj_rtdgi_surface(self.rtdgi, name.encode(), C.byref(ptr), C.byref(n)))
+        return tensor_from_ptr(ptr.value, n.value, dtype, shape)
+
+    def ray_counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self.L.kj_rtdgi_ray_counts(self.rtdgi, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def __del__(self):
+        try:
+            self.L.kj_rtdgi_destroy(self.rtdgi)
+            self.L.kj_reprojection_destroy(self.reproj)
+        except Exception:
+            pass
+
+
+class _CudaArrayView:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+
+def tensor_from_ptr(ptr, nbytes, dtype, shape):
+    """Device pointer -> torch tensor view (via __cuda_array_interface__)."""
+    import torch
+    t = torch.as_tensor(_CudaArrayView(ptr, nbytes), device="cuda")
+    return t.view(dtype).reshape(shape)

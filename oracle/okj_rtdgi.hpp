@@ -920,6 +920,7 @@ struct Rtdgi {
     Output render(const FrameConstants& fc, const RtdgiInputs& in, uint32_t pass_mask = KJ_RTDGI_PASS_ALL) {
         sun_color = sun_color_in_direction(fc, sun_direction(fc));
         rays_closest = 0; rays_any = 0;
+        if (pass_mask & KJ_RTDGI_PASS_KEEP_TEMPORALS) for (bool& f : flip) f = !f;
         ImgR8S half_ssao_tex = get<int8_t>("half_ssao_tex", hw, hh);
         ImgU32 half_view_normal_tex = get<uint32_t>("half_view_normal_tex", hw, hh);
         ImgR32F half_depth_tex = get<float>("half_depth_tex", hw, hh);
