@@ -139,6 +139,16 @@ KJ_HD float inverse_depth_relative_diff(float primary_depth, float secondary_dep
     return fabsf(fmaxf(1e-20f, primary_depth) / fmaxf(1e-20f, secondary_depth) - 1.0f);
 }
 
+// sin/cos of a spiral-tap angle with the range reduction of v_sin_f32/v_cos_f32 (angle in revolutions,
+// fract) — what HLSL sin/cos lower to on the reference's GPUs; keeps ~500 rad arguments well-defined.
+KJ_HD V2 cos_sin_turns(float ang) {
+#pragma clang fp contract(off)
+    float t = ang * 0.15915494309189535f;
+    t = t - floorf(t);
+    const float a = t * KJ_TAU;
+    return V2{cosf(a), sinf(a)};
+}
+
 // ---- RNG (inc/hash.hlsl:7-55, inc/quasi_random.hlsl:6-24)
 KJ_HD uint32_t hash1(uint32_t x) {
     x += (x << 10u); x ^= (x >> 6u); x += (x << 3u); x ^= (x >> 11u); x += (x << 15u);
@@ -156,8 +166,15 @@ KJ_HD uint32_t hash_combine2(uint32_t x, uint32_t y) {
 KJ_HD uint32_t hash2(uint32_t x, uint32_t y) { return hash_combine2(x, hash1(y)); }
 KJ_HD uint32_t hash3(uint32_t x, uint32_t y, uint32_t z) { return hash_combine2(x, hash2(y, z)); }
 KJ_HD float uint_to_u01_float(uint32_t h) { return asfloat((h & 0x007FFFFFu) | 0x3F800000u) - 1.0f; }
+// frac() amplifies last-bit differences here, so this is evaluated without FMA contraction
+// (every product rounds, as in the literal HLSL expression).
 KJ_HD float interleaved_gradient_noise(uint32_t px, uint32_t py) {
-    return frac(52.9829189f * frac(0.06711056f * float(px) + 0.00583715f * float(py)));
+#pragma clang fp contract(off)
+    const float a = 0.06711056f * float(px), b = 0.00583715f * float(py);
+    const float s = a + b;
+    const float f = s - floorf(s);
+    const float m = 52.9829189f * f;
+    return m - floorf(m);
 }
 KJ_HD float radical_inverse_vdc(uint32_t bits) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -173,9 +190,12 @@ KJ_HD float radical_inverse_vdc(uint32_t bits) {
 }
 KJ_HD V2 hammersley(uint32_t i, uint32_t n) { return V2{float(i + 1) / float(n), radical_inverse_vdc(i + 1)}; }
 KJ_HD V2 r2_sequence(uint32_t i) {
+#pragma clang fp contract(off)
     const float a1 = 1.0f / KJ_PLASTIC;
     const float a2 = 1.0f / (KJ_PLASTIC * KJ_PLASTIC);
-    return V2{frac(a1 * float(i) + 0.5f), frac(a2 * float(i) + 0.5f)};
+    const float x = a1 * float(i), y = a2 * float(i);
+    const float xs = x + 0.5f, ys = y + 0.5f;
+    return V2{xs - floorf(xs), ys - floorf(ys)};
 }
 // inc/blue_noise.hlsl:8-15; tex = 256x256 RGBA8 packed as one u32 per texel
 KJ_D V4 blue_noise_for_pixel(const uint32_t* __restrict__ tex, uint32_t px, uint32_t py, uint32_t n) {

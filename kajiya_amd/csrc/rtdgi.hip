@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(64) k_validity_integrate(const FrameConstants*
     for (uint32_t si = 0; si < 8u; ++si) {
         const float ang = (float(si) + ang_off) * KJ_GOLDEN_ANGLE;
         const float radius = float(si) * 1.0f;
-        const V2 so = V2{cosf(ang), sinf(ang)} * radius;
+        const V2 so = cos_sin_turns(ang) * radius;
         history += ld2h(history_tex, int(reproj_px.x + so.x), int(reproj_px.y + so.y)).x;
     }
     history /= 8;
@@ -549,7 +549,8 @@ __global__ void __launch_bounds__(64) k_restir_spatial(const FrameConstants* __r
     for (uint32_t sample_i = 0; sample_i < sample_count; ++sample_i) {
         const float ang = (float(sample_i) + ang_offset) * KJ_GOLDEN_ANGLE;
         const V2 radius = 0 == sample_i ? V2{0, 0} : (powf((float(sample_i) + sample_radius_offset) / float(sample_count), 0.5f) * kernel_radius);
-        const I2 rpx_offset{int(cosf(ang) * radius.x), int(sinf(ang) * radius.y)};
+        const V2 cs_ang = cos_sin_turns(ang);
+        const I2 rpx_offset{int(cs_ang.x * radius.x), int(cs_ang.y * radius.y)};
         const bool is_center_sample = sample_i == 0;
         const I2 rpx{x + rpx_offset.x, y + rpx_offset.y};
         const uint2 reservoir_raw = reservoir_input_tex.ld(rpx.x, rpx.y);
@@ -646,7 +647,7 @@ __global__ void __launch_bounds__(64) k_restir_resolve(ResolveArgs a) {
         for (uint32_t si = 0; si < 4u; ++si) {
             const float ang = (float(si) + blue_x) * KJ_GOLDEN_ANGLE + (float(px_idx_in_quad) / 4.0f) * KJ_TAU;
             const float radius = powf(float(si), 0.666f) * 1.0f + 0.4f;
-            const V2 rpo = V2{cosf(ang), sinf(ang)} * radius;
+            const V2 rpo = cos_sin_turns(ang) * radius;
             const int rx = int(floorf(float(x) * 0.5f + rpo.x)), ry = int(floorf(float(y) * 0.5f + rpo.y));
             const V2 rpx_uv = get_uv(float(rx * 2 + off.x), float(ry * 2 + off.y), gts);
             const float rpx_depth = a.half_depth_tex.ld(rx, ry);
@@ -676,7 +677,7 @@ __global__ void __launch_bounds__(64) k_restir_resolve(ResolveArgs a) {
         for (uint32_t si = 0; si < 4u; ++si) {
             const float ang = (float(si) + blue_x) * KJ_GOLDEN_ANGLE + (float(px_idx_in_quad) / 4.0f) * KJ_TAU;
             const float radius = powf(float(si), 0.666f) * 1.0f * kernel_scale + 0.4f * kernel_scale;
-            const V2 rpo = V2{cosf(ang), sinf(ang)} * radius;
+            const V2 rpo = cos_sin_turns(ang) * radius;
             const int rx = int(floorf(float(x) * 0.5f + rpo.x)), ry = int(floorf(float(y) * 0.5f + rpo.y));
             const Reservoir1spp r = Reservoir1spp::from_raw(a.reservoir_input_tex.ld(rx, ry));
             const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
@@ -787,7 +788,7 @@ __global__ void __launch_bounds__(64) k_spatial_filter(const FrameConstants* __r
     for (uint32_t si = 1; si < MAX_SAMPLE_COUNT; ++si) {
         const float ang = (float(si) + ang_off) * KJ_GOLDEN_ANGLE;
         const float radius = powf(float(si), KERNEL_SHARPNESS) * RADIUS_SAMPLE_MULT;
-        const V2 so = V2{cosf(ang), sinf(ang)} * radius;
+        const V2 so = cos_sin_turns(ang) * radius;
         const int sx = int(float(x) + so.x), sy = int(float(y) + so.y);
         const float sample_depth = depth_tex.ld(sx, sy);
         if (sample_depth != 0 && si < sample_count) {

@@ -89,6 +89,8 @@ static inline f3 vsqrt(f3 a) { return f3{sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
 static inline f4 vsqrt(f4 a) { return f4{sqrtf(a.x), sqrtf(a.y), sqrtf(a.z), sqrtf(a.w)}; }
 static inline f3 vclamp(f3 v, f3 a, f3 b) { return vmin(vmax(v, a), b); }
 
+static const float M_PI_F = 3.14159265358979323846f;
+static const float M_TAU_F = 6.28318530717958647692f;
 // float -> int32 conversion with the GPU's saturating behaviour (v_cvt_i32_f32); NaN -> 0
 static inline int f2i_sat(float f) {
     if (!(f == f)) return 0;
@@ -101,8 +103,6 @@ static inline int wrap_mul2_add(int a, int b) { return int(uint32_t(a) * 2u + ui
 static inline uint32_t asuint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float asfloat(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-static const float M_PI_F = 3.14159265358979323846f;
-static const float M_TAU_F = 6.28318530717958647692f;
 static const float M_FRAC_1_PI_F = 0.318309886183790671537767526745028724f;
 static const float M_PLASTIC_F = 1.32471795724474602596f;
 static const float GOLDEN_ANGLE = 2.39996323f;
@@ -155,6 +155,17 @@ static inline f3 uniform_sample_hemisphere(f2 urand) {
 }
 static inline float inverse_depth_relative_diff(float primary_depth, float secondary_depth) {
     return fabsf(fmaxf(1e-20f, primary_depth) / fmaxf(1e-20f, secondary_depth) - 1.0f);
+}
+
+// sin/cos of a spiral-tap angle. The reference ran on GCN/RDNA hardware where HLSL sin/cos lower to
+// v_sin_f32/v_cos_f32, which take the angle in revolutions (x * 1/2pi, fract). We restate that range
+// reduction explicitly so the large angles of the denoiser kernels (up to ~500 rad in
+// rtdgi/spatial_filter.hlsl:58) do not depend on a libm's argument reduction.
+static inline f2 cos_sin_turns(float ang) {
+    float t = ang * 0.15915494309189535f;
+    t = t - floorf(t);
+    const float a = t * M_TAU_F;
+    return f2{cosf(a), sinf(a)};
 }
 
 // ------------------------------------------------------------------ hash (inc/hash.hlsl:7-55)

@@ -427,7 +427,7 @@ struct Rtdgi {
                     for (uint32_t si = 0; si < uint32_t(sample_count); ++si) {
                         float ang = (float(si) + ang_off) * GOLDEN_ANGLE;
                         float radius = float(si) * 1.0f;
-                        f2 so = f2{cosf(ang), sinf(ang)} * radius;
+                        f2 so = cos_sin_turns(ang) * radius;
                         const int sx = int(reproj_px.x + so.x), sy = int(reproj_px.y + so.y);
                         history += ld2(history_tex, sx, sy).x;
                     }
@@ -644,7 +644,8 @@ struct Rtdgi {
                 for (uint32_t sample_i = 0; sample_i < sample_count; ++sample_i) {
                     float ang = (float(sample_i) + ang_offset) * GOLDEN_ANGLE;
                     f2 radius = 0 == sample_i ? f2{0, 0} : (powf((float(sample_i) + sample_radius_offset) / float(sample_count), 0.5f) * kernel_radius);
-                    const i2 rpx_offset{int(cosf(ang) * radius.x), int(sinf(ang) * radius.y)};
+                    const f2 cs_ang = cos_sin_turns(ang);
+                    const i2 rpx_offset{int(cs_ang.x * radius.x), int(cs_ang.y * radius.y)};
                     const bool is_center_sample = sample_i == 0;
                     const i2 rpx{x + rpx_offset.x, y + rpx_offset.y};
                     const u2 reservoir_raw = reservoir_input_tex.ld(rpx.x, rpx.y);
@@ -749,7 +750,7 @@ struct Rtdgi {
                     for (uint32_t sample_i = 0; sample_i < 4; ++sample_i) {
                         const float ang = (float(sample_i) + blue.x) * GOLDEN_ANGLE + (float(px_idx_in_quad) / 4.0f) * M_TAU_F;
                         const float radius = powf(float(sample_i), 0.666f) * 1.0f + 0.4f;
-                        const f2 rpo = f2{cosf(ang), sinf(ang)} * radius;
+                        const f2 rpo = cos_sin_turns(ang) * radius;
                         const int rx = int(floorf(float(x) * 0.5f + rpo.x)), ry = int(floorf(float(y) * 0.5f + rpo.y));
                         const f2 rpx_uv = get_uv(float(rx * 2 + off.x), float(ry * 2 + off.y), gbuffer_tex_size);
                         const float rpx_depth = half_depth_tex.ld(rx, ry);
@@ -779,7 +780,7 @@ struct Rtdgi {
                     for (uint32_t sample_i = 0; sample_i < 4; ++sample_i) {
                         const float ang = (float(sample_i) + blue.x) * GOLDEN_ANGLE + (float(px_idx_in_quad) / 4.0f) * M_TAU_F;
                         const float radius = powf(float(sample_i), 0.666f) * 1.0f * kernel_scale + 0.4f * kernel_scale;
-                        const f2 rpo = f2{cosf(ang), sinf(ang)} * radius;
+                        const f2 rpo = cos_sin_turns(ang) * radius;
                         const int rx = int(floorf(float(x) * 0.5f + rpo.x)), ry = int(floorf(float(y) * 0.5f + rpo.y));
                         Reservoir1spp r = Reservoir1spp::from_raw(reservoir_input_tex.ld(rx, ry));
                         const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
@@ -896,7 +897,7 @@ struct Rtdgi {
                 for (uint32_t sample_i = 1; sample_i < MAX_SAMPLE_COUNT; ++sample_i) {
                     const float ang = (float(sample_i) + ang_off) * GOLDEN_ANGLE;
                     float radius = powf(float(sample_i), KERNEL_SHARPNESS) * RADIUS_SAMPLE_MULT;
-                    f2 so = f2{cosf(ang), sinf(ang)} * radius;
+                    f2 so = cos_sin_turns(ang) * radius;
                     // int2 sample_px = px + sample_offset : uint2 + float2 -> float2 -> int2 (truncation)
                     const int sx = int(float(x) + so.x), sy = int(float(y) + so.y);
                     const float sample_depth = in.depth.ld(sx, sy);
