@@ -268,6 +268,16 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* params, KjRtdgiO
  * variable names, e.g. "rtdgi.radiance:history", "candidate_radiance_tex").
  * `kj_rtdgi_surface` returns the device pointer and byte size. */
 KjStatus kj_rtdgi_surface(KjRtdgi* r, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
+/* Per-pass GPU timestamps (the reference scopes every render-graph pass with a timestamp query,
+ * kajiya-rg/src/graph.rs:941-944) and instrumented traversal counters. Scope order:
+ * reproject, extract, validate, trace, validity integrate, restir temporal, spatial 0, spatial 1,
+ * resolve, temporal filter, spatial filter. `count_traversal` switches the trace kernels to the
+ * instrumented build (nodes visited / triangles tested per ray type) — never timed. */
+#define KJ_RTDGI_NUM_SCOPES 11
+KjStatus kj_rtdgi_set_profiling(KjRtdgi* r, uint32_t enable_pass_timers, uint32_t count_traversal);
+KjStatus kj_rtdgi_pass_times_ms(KjRtdgi* r, float* out_ms, uint32_t count);
+/* out[6] = closest rays, any-hit rays, nodes (closest), tris (closest), nodes (any), tris (any) */
+KjStatus kj_rtdgi_traversal_counts(KjRtdgi* r, uint64_t out[6]);
 /* Ray counters of the last kj_rtdgi_render (closest-hit rays, any-hit rays). */
 KjStatus kj_rtdgi_ray_counts(KjRtdgi* r, uint64_t* out_closest, uint64_t* out_any);
 

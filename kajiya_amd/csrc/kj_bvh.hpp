@@ -72,10 +72,16 @@ KJ_D bool intersect_tri(V3 o, V3 d, float tmin, float tmax, const float4 a, cons
 }
 
 // stack: LDS base for this lane; entries at stack[level * stride]
-template <bool ANY_HIT>
-KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bool cull_back, uint32_t* stack, uint32_t stride) {
+struct TraverseStats { uint32_t nodes, tris; };
+
+template <bool ANY_HIT, bool STATS = false>
+KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bool cull_back, uint32_t* stack, uint32_t stride, TraverseStats* stats = nullptr) {
     RayHit h;
     h.t = FLT_MAX; h.u = 0; h.v = 0; h.slot = 0xffffffffu; h.world_id = 0xffffffffu;
+    // Rays with a non-finite origin or direction are misses (the reference's validation pass issues such
+    // rays for pixels without history; a hardware traversal unit rejects every box for them). Without
+    // this, NaN slabs pass the fmin/fmax test and the whole tree is walked.
+    if (!(fabsf(o.x) <= FLT_MAX && fabsf(o.y) <= FLT_MAX && fabsf(o.z) <= FLT_MAX && fabsf(d.x) <= FLT_MAX && fabsf(d.y) <= FLT_MAX && fabsf(d.z) <= FLT_MAX)) return h;
     const float eps = 1e-20f;
     const V3 inv_d{1.0f / (fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x), 1.0f / (fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y),
                    1.0f / (fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z)};
@@ -86,6 +92,7 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
         if (!(cur & KJ_BVH_LEAF)) {
             const float4* __restrict__ n = (const float4*)bvh.nodes + size_t(cur) * 4;
             const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if (STATS) stats->nodes++;
             const float tlimit = ANY_HIT ? tmax : fminf(h.t, tmax);
             // left box
             float t0x = (n0.x - o.x) * inv_d.x, t1x = (n1.x - o.x) * inv_d.x;
@@ -120,6 +127,7 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
             for (uint32_t i = 0; i < count; ++i) {
                 const float4* __restrict__ tp = (const float4*)bvh.tris + size_t(first + i) * 3;
                 const float4 a = tp[0], b = tp[1], c = tp[2];
+                if (STATS) stats->tris++;
                 if (intersect_tri(o, d, tmin, tmax, a, b, c, first + i, cull_back, h)) {
                     if (ANY_HIT) return h;
                 }

@@ -73,10 +73,11 @@ KJ_D uint4 shade_gbuffer_hit(const SceneView& sc, const FrameConstants& fc, V3 r
 }
 
 // GbufferRaytrace::trace (inc/rt.hlsl:112-137)
+template <bool STATS = false>
 KJ_D GbufferPathVertex gbuffer_raytrace(const SceneView& sc, const FrameConstants& fc, V3 o, V3 d, float tmin, float tmax, uint32_t path_length,
-                                        bool cull_back_faces, uint32_t* stack, uint32_t stride) {
+                                        bool cull_back_faces, uint32_t* stack, uint32_t stride, TraverseStats* stats = nullptr) {
     GbufferPathVertex res;
-    const RayHit h = bvh_trace<false>(sc.bvh, o, d, tmin, tmax, cull_back_faces, stack, stride);
+    const RayHit h = bvh_trace<false, STATS>(sc.bvh, o, d, tmin, tmax, cull_back_faces, stack, stride, stats);
     res.is_hit = h.slot != 0xffffffffu;
     res.ray_t = h.t;
     if (res.is_hit) {
@@ -89,8 +90,9 @@ KJ_D GbufferPathVertex gbuffer_raytrace(const SceneView& sc, const FrameConstant
     return res;
 }
 // rt_is_shadowed (inc/rt.hlsl:58-70)
-KJ_D bool rt_is_shadowed(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t* stack, uint32_t stride) {
-    return bvh_trace<true>(sc.bvh, o, d, tmin, tmax, false, stack, stride).slot != 0xffffffffu;
+template <bool STATS = false>
+KJ_D bool rt_is_shadowed(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t* stack, uint32_t stride, TraverseStats* stats = nullptr) {
+    return bvh_trace<true, STATS>(sc.bvh, o, d, tmin, tmax, false, stack, stride, stats).slot != 0xffffffffu;
 }
 #endif
 

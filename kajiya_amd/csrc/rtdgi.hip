@@ -158,7 +158,7 @@ struct TraceCtx {
     const uint32_t* __restrict__ blue_noise;
     const uint2* __restrict__ brdf_fg_lut;
     const float4* __restrict__ sun_color;
-    unsigned long long* __restrict__ ray_counters;  // [0]=closest, [1]=any
+    unsigned long long* __restrict__ ray_counters;  // [0]=closest rays, [1]=any-hit rays, [2..5]=nodes/tris visited (closest, any) in STATS builds
 };
 struct TraceResult { V3 out_value; V3 hit_normal_ws; float hit_t; float pdf; bool is_hit; };
 
@@ -167,6 +167,7 @@ KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
     if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counters[which], (unsigned long long)__popcll(m));
 }
 
+template <bool STATS>
 KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3 normal_ws, uint32_t& rng, V3 ray_o, V3 ray_d, float ray_tmax, uint32_t* stack) {
     const FrameConstants& fc = *c.fc;
     V3 total_radiance = v3(0.0f);
@@ -174,7 +175,8 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
     float hit_t = ray_tmax;
     const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, ray_d) * 2 * KJ_PI));
     count_rays(c.ray_counters, 0, true);
-    const GbufferPathVertex primary_hit = gbuffer_raytrace(c.sc, fc, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, 64);
+    TraverseStats st_closest{0, 0}, st_any{0, 0};
+    const GbufferPathVertex primary_hit = gbuffer_raytrace<STATS>(c.sc, fc, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, 64, &st_closest);
     if (primary_hit.is_hit) {
         hit_t = primary_hit.ray_t;
         GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);
@@ -198,7 +200,7 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
             const V4 bn = blue_noise_for_pixel(c.blue_noise, px, py, rng);
             const V3 to_light_norm = sample_sun_direction(fc, V2{bn.x, bn.y}, false);
             count_rays(c.ray_counters, 1, true);
-            const bool is_shadowed = rt_is_shadowed(c.sc, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, 64);
+            const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, 64, &st_any);
             const V3 wi = to_local(tangent_to_world, to_light_norm);
             const V3 brdf_value = layered_brdf_evaluate(brdf, wo, wi) * fmaxf(0.0f, wi.z);
             total_radiance += brdf_value * (is_shadowed ? v3(0.0f) : sun_radiance);
@@ -221,7 +223,7 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
                 const float to_psa_metric = fmaxf(0.0f, dot(to_light_norm_ws, gbuffer.normal)) * fmaxf(0.0f, dot(to_light_norm_ws, -ls.normal)) / dist2;
                 if (to_psa_metric > 0.0f) {
                     count_rays(c.ray_counters, 1, true);
-                    const bool is_shadowed = rt_is_shadowed(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, 64);
+                    const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, 64, &st_any);
                     const V3 bounce_albedo = lerp(gbuffer.albedo, v3(1.0f), 0.04f);
                     const V3 brdf_value = bounce_albedo * to_psa_metric / KJ_PI;
                     if (!is_shadowed) total_radiance += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * brdf_value / ls.pdf;
@@ -232,10 +234,17 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
     } else {
         total_radiance += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
     }
+    if (STATS) {  // instrumentation build only: traversal work per ray type (SURVEY 8d "measured by the instrumented kernel")
+        atomicAdd(&c.ray_counters[2], (unsigned long long)st_closest.nodes);
+        atomicAdd(&c.ray_counters[3], (unsigned long long)st_closest.tris);
+        atomicAdd(&c.ray_counters[4], (unsigned long long)st_any.nodes);
+        atomicAdd(&c.ray_counters[5], (unsigned long long)st_any.tris);
+    }
     return TraceResult{total_radiance, hit_normal_ws, hit_t, pdf, primary_hit.is_hit};
 }
 
 // ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111
+template <bool STATS>
 __global__ void __launch_bounds__(64) k_rtdgi_validate(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
                                                         ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex) {
     extern __shared__ uint32_t lds_stack[];
@@ -253,7 +262,7 @@ __global__ void __launch_bounds__(64) k_rtdgi_validate(TraceCtx c, ImgU32 half_v
         const V4 prev_radiance_packed = ld4(irradiance_history_tex, x, y);
         const V3 prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
         uint32_t rng = hash3(uint32_t(x), uint32_t(y), 0);
-        const TraceResult result = trace_candidate(c, x, y, normal_ws, rng, prev_ray_orig, normalize(prev_hit_pos - prev_ray_orig), SKY_DIST, lds_stack + lane);
+        const TraceResult result = trace_candidate<STATS>(c, x, y, normal_ws, rng, prev_ray_orig, normalize(prev_hit_pos - prev_ray_orig), SKY_DIST, lds_stack + lane);
         const V3 new_radiance = vmax(v3(0.0f), result.out_value);
         const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
         invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
@@ -271,6 +280,7 @@ __global__ void __launch_bounds__(64) k_rtdgi_validate(TraceCtx c, ImgU32 half_v
 }
 
 // ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24
+template <bool STATS>
 __global__ void __launch_bounds__(64) k_rtdgi_trace(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
                                                      ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex) {
     extern __shared__ uint32_t lds_stack[];
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(64) k_rtdgi_trace(TraceCtx c, ImgU32 half_view
         const V3 outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
         const V3 origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
         uint32_t rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u);
-        TraceResult result = trace_candidate(c, x, y, normal_ws, rng, origin, outgoing_dir, tracing_frame ? SKY_DIST : near_field_fade_out_end, lds_stack + lane);
+        TraceResult result = trace_candidate<STATS>(c, x, y, normal_ws, rng, origin, outgoing_dir, tracing_frame ? SKY_DIST : near_field_fade_out_end, lds_stack + lane);
         if (!tracing_frame && !result.is_hit) { result.out_value = v3(0.0f); result.hit_t = SKY_DIST; }
         const V3 hit_offset_ws = outgoing_dir * result.hit_t;
         const float cos_theta = dot(normalize(outgoing_dir - vr.dir_ws), normal_ws);
@@ -815,7 +825,13 @@ struct KjRtdgi {
     bool temporal2_flip = false;
     void* temporal_output_tex = nullptr;        // ReprojectedRtdgi (rtdgi.rs:48-51)
     void* reprojected_history_tex = nullptr;
-    kj::DevBuf ray_counters;                    // 2 x u64
+    kj::DevBuf ray_counters;                    // 6 x u64
+    bool profiling = false;                     // per-pass GPU timestamps (gpu-profiler scopes, kajiya-rg/src/graph.rs:941-944)
+    bool count_traversal = false;               // instrumented trace kernels
+    static const int NUM_SCOPES = 11;
+    hipEvent_t ev[NUM_SCOPES][2] = {};
+    bool ev_valid[NUM_SCOPES] = {};
+    bool ev_created = false;
     hipError_t err = hipSuccess;
 
     void* get(const std::string& name, size_t bytes, hipStream_t s) {
@@ -839,6 +855,8 @@ struct KjRtdgi {
 };
 
 #define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
+#define SCOPE_BEGIN(i) do { if (r->profiling) { KJ_TRY_HIP(hipEventRecord(r->ev[i][0], s)); } } while (0)
+#define SCOPE_END(i) do { if (r->profiling) { KJ_TRY_HIP(hipEventRecord(r->ev[i][1], s)); r->ev_valid[i] = true; } } while (0)
 
 extern "C" {
 
@@ -846,7 +864,7 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     KJ_REQUIRE(dev && out, "null argument");
     KjRtdgi* r = new KjRtdgi();
     r->dev = dev;
-    if (r->ray_counters.alloc(16) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
+    if (r->ray_counters.alloc(48) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
     *out = r;
     return KJ_OK;
 }
@@ -870,9 +888,11 @@ KjStatus kj_rtdgi_reproject(KjRtdgi* r, const void* reprojection_map, uint32_t w
     r->temporal2_flip = !r->temporal2_flip;
     r->reprojected_history_tex = r->get("reprojected_history_tex", size_t(W) * H * 8, s);
     KJ_TRY_HIP(r->err);
+    SCOPE_BEGIN(0);
     hipLaunchKernelGGL(k_fullres_reproject, dim3((W + 7) / 8, (H + 7) / 8), dim3(64), 0, s, img<uint2>(history, W, H), img<uint2>(reprojection_map, W, H),
                        img<uint2>(r->reprojected_history_tex, W, H));
     KJ_CHECK_LAUNCH();
+    SCOPE_END(0);
     return KJ_OK;
 }
 
@@ -920,7 +940,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     void* temporal_filtered = r->get("temporal_filtered_tex", FB * 8, s);
     void* spatial_filtered = r->get("spatial_filtered_tex", FB * 8, s);
     KJ_TRY_HIP(r->err);
-    KJ_TRY_HIP(hipMemsetAsync(r->ray_counters.p, 0, 16, s));
+    KJ_TRY_HIP(hipMemsetAsync(r->ray_counters.p, 0, 48, s));
 
     TraceCtx tc;
     tc.fc = fc;
@@ -937,23 +957,31 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     KJ_REQUIRE(trace_lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");
 
     if (mask & KJ_RTDGI_PASS_EXTRACT_HALF) {
+        SCOPE_BEGIN(1);
         hipLaunchKernelGGL(k_extract_half, gh, blk, 0, s, fc, gbuffer, depth, ssao, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), img<int8_t>(half_ssao, hw, hh));
         KJ_CHECK_LAUNCH();
+        SCOPE_END(1);
     }
     if (mask & KJ_RTDGI_PASS_VALIDATE) {
-        hipLaunchKernelGGL(k_rtdgi_validate, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+        SCOPE_BEGIN(2);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate<true> : k_rtdgi_validate<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
                            img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh));
         KJ_CHECK_LAUNCH();
+        SCOPE_END(2);
     }
     if (mask & KJ_RTDGI_PASS_TRACE) {
-        hipLaunchKernelGGL(k_rtdgi_trace, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+        SCOPE_BEGIN(3);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace<true> : k_rtdgi_trace<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
                            img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh));
         KJ_CHECK_LAUNCH();
+        SCOPE_END(3);
     }
     if (mask & KJ_RTDGI_PASS_VALIDITY_INTEGRATE) {
+        SCOPE_BEGIN(4);
         hipLaunchKernelGGL(k_validity_integrate, gh, blk, 0, s, fc, img<uint8_t>(validity_in, hw, hh), img<uint32_t>(invalidity_hist, hw, hh), reprojection,
                            img<float>(half_depth, hw, hh), img<uint32_t>(invalidity_out, hw, hh), W, H);
         KJ_CHECK_LAUNCH();
+        SCOPE_END(4);
     }
     if (mask & KJ_RTDGI_PASS_RESTIR_TEMPORAL) {
         RestirTemporalArgs a;
@@ -977,16 +1005,20 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         a.reservoir_out_tex = img<uint2>(reservoir_out, hw, hh);
         a.candidate_out_tex = img<uint2>(candidate_out, hw, hh);
         a.temporal_reservoir_packed_tex = img<uint4>(temporal_reservoir_packed, hw, hh);
+        SCOPE_BEGIN(5);
         hipLaunchKernelGGL(k_restir_temporal, gh, blk, 0, s, a);
         KJ_CHECK_LAUNCH();
+        SCOPE_END(5);
     }
     void* reservoir_input = reservoir_out;
     for (uint32_t i = 0; i < r->spatial_reuse_pass_count; ++i) {
         const uint32_t perform_occlusion_raymarch = (i + 1 == r->spatial_reuse_pass_count) ? 1u : 0u;
         if (mask & KJ_RTDGI_PASS_RESTIR_SPATIAL) {
+            SCOPE_BEGIN((6 + (i ? 1 : 0)));
             hipLaunchKernelGGL(k_restir_spatial, gh, blk, 0, s, fc, img<uint2>(reservoir_input, hw, hh), img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh),
                                img<int8_t>(half_ssao, hw, hh), img<uint4>(temporal_reservoir_packed, hw, hh), img<uint2>(reservoir_tex0, hw, hh), W, H, i, perform_occlusion_raymarch, 0u);
             KJ_CHECK_LAUNCH();
+            SCOPE_END((6 + (i ? 1 : 0)));
         }
         std::swap(reservoir_tex0, reservoir_tex1);
         reservoir_input = reservoir_tex1;
@@ -1005,18 +1037,24 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         a.temporal_reservoir_packed_tex = img<uint4>(temporal_reservoir_packed, hw, hh);
         a.irradiance_output_tex = img<uint2>(irradiance, W, H);
         a.blue_noise = (const uint32_t*)r->dev->blue_noise.p;
+        SCOPE_BEGIN(8);
         hipLaunchKernelGGL(k_restir_resolve, gf, blk, 0, s, a);
         KJ_CHECK_LAUNCH();
+        SCOPE_END(8);
     }
     if (mask & KJ_RTDGI_PASS_TEMPORAL_FILTER) {
+        SCOPE_BEGIN(9);
         hipLaunchKernelGGL(k_temporal_filter, gf, blk, 0, s, fc, img<uint2>(irradiance, W, H), img<uint2>(r->reprojected_history_tex, W, H), img<uint32_t>(variance_hist, W, H),
                            reprojection, img<uint32_t>(invalidity_out, hw, hh), img<uint2>(temporal_filtered, W, H), img<uint2>(r->temporal_output_tex, W, H),
                            img<uint32_t>(variance_out, W, H));
         KJ_CHECK_LAUNCH();
+        SCOPE_END(9);
     }
     if (mask & KJ_RTDGI_PASS_SPATIAL_FILTER) {
+        SCOPE_BEGIN(10);
         hipLaunchKernelGGL(k_spatial_filter, gf, blk, 0, s, fc, img<uint2>(temporal_filtered, W, H), depth, ssao, geometric_normal, img<uint2>(spatial_filtered, W, H));
         KJ_CHECK_LAUNCH();
+        SCOPE_END(10);
     }
     if (out) {
         out->screen_irradiance_tex = spatial_filtered;
@@ -1029,6 +1067,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
 
 KjStatus kj_rtdgi_surface(KjRtdgi* r, const char* name, void** out_dev_ptr, uint64_t* out_bytes) {
     KJ_REQUIRE(r && name && out_dev_ptr && out_bytes, "null argument");
+    if (strcmp(name, "ray_counters") == 0) { *out_dev_ptr = r->ray_counters.p; *out_bytes = r->ray_counters.bytes; return KJ_OK; }
     auto it = r->surf.find(name);
     if (it == r->surf.end()) { set_last_error("no rtdgi surface named '%s'", name); return KJ_ERR_INVALID_ARGUMENT; }
     *out_dev_ptr = it->second.p;
@@ -1040,6 +1079,30 @@ KjStatus kj_rtdgi_ray_counts(KjRtdgi* r, uint64_t* out_closest, uint64_t* out_an
     uint64_t v[2];
     KJ_TRY_HIP(hipMemcpy(v, r->ray_counters.p, 16, hipMemcpyDeviceToHost));
     *out_closest = v[0]; *out_any = v[1];
+    return KJ_OK;
+}
+KjStatus kj_rtdgi_set_profiling(KjRtdgi* r, uint32_t enable_pass_timers, uint32_t count_traversal) {
+    KJ_REQUIRE(r, "null argument");
+    if (enable_pass_timers && !r->ev_created) {
+        for (int i = 0; i < KjRtdgi::NUM_SCOPES; ++i)
+            for (int k = 0; k < 2; ++k) KJ_TRY_HIP(hipEventCreate(&r->ev[i][k]));
+        r->ev_created = true;
+    }
+    r->profiling = enable_pass_timers != 0;
+    r->count_traversal = count_traversal != 0;
+    return KJ_OK;
+}
+KjStatus kj_rtdgi_pass_times_ms(KjRtdgi* r, float* out_ms, uint32_t count) {
+    KJ_REQUIRE(r && out_ms && count >= (uint32_t)KjRtdgi::NUM_SCOPES, "need room for KJ_RTDGI_NUM_SCOPES floats");
+    for (int i = 0; i < KjRtdgi::NUM_SCOPES; ++i) {
+        out_ms[i] = 0.0f;
+        if (r->ev_valid[i]) KJ_TRY_HIP(hipEventElapsedTime(&out_ms[i], r->ev[i][0], r->ev[i][1]));
+    }
+    return KJ_OK;
+}
+KjStatus kj_rtdgi_traversal_counts(KjRtdgi* r, uint64_t out[6]) {
+    KJ_REQUIRE(r && out, "null argument");
+    KJ_TRY_HIP(hipMemcpy(out, r->ray_counters.p, 48, hipMemcpyDeviceToHost));
     return KJ_OK;
 }
 

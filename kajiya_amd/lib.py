@@ -22,7 +22,7 @@ EXPORTS = [
     "kj_scene_stats", "kj_frame_begin", "kj_trace_closest", "kj_trace_any", "kj_raster_gbuffer", "kj_sky_cube_render",
     "kj_sky_cube_convolve", "kj_reprojection_create", "kj_reprojection_destroy", "kj_calculate_reprojection_map",
     "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_render",
-    "kj_rtdgi_surface", "kj_rtdgi_ray_counts",
+    "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
 ]
 
 _LIB = None
@@ -70,6 +70,9 @@ def load():
         "kj_rtdgi_render": [vp, C.POINTER(KjRtdgiRenderParams), C.POINTER(KjRtdgiOutput), vp],
         "kj_rtdgi_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_rtdgi_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+        "kj_rtdgi_set_profiling": [vp, u32, u32],
+        "kj_rtdgi_pass_times_ms": [vp, C.POINTER(C.c_float), u32],
+        "kj_rtdgi_traversal_counts": [vp, C.POINTER(C.c_uint64)],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -265,6 +268,22 @@ class GpuPipeline:
         a, b = C.c_uint64(), C.c_uint64()
         check(self.L.kj_rtdgi_ray_counts(self.rtdgi, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    PASS_NAMES = ["rtdgi reproject", "extract half", "rtdgi validate", "rtdgi trace", "validity integrate", "restir temporal",
+                  "restir spatial 0", "restir spatial 1", "restir resolve", "rtdgi temporal", "rtdgi spatial"]
+
+    def set_profiling(self, pass_timers=True, count_traversal=False):
+        check(self.L.kj_rtdgi_set_profiling(self.rtdgi, int(pass_timers), int(count_traversal)))
+
+    def pass_times_ms(self):
+        buf = (C.c_float * 11)()
+        check(self.L.kj_rtdgi_pass_times_ms(self.rtdgi, buf, 11))
+        return list(buf)
+
+    def traversal_counts(self):
+        buf = (C.c_uint64 * 6)()
+        check(self.L.kj_rtdgi_traversal_counts(self.rtdgi, buf))
+        return dict(zip(["closest_rays", "any_rays", "closest_nodes", "closest_tris", "any_nodes", "any_tris"], list(buf)))
 
     def __del__(self):
         try:

@@ -247,14 +247,20 @@ struct Scene {
         return tnear <= tfar * 1.0000004f + 1e-30f || !(tnear == tnear) || !(tfar == tfar);
     }
 
+    // Non-finite rays are misses (see header note; the reference issues them from zero history).
+    static bool ray_finite(const Ray& r) {
+        return fabsf(r.o.x) <= FLT_MAX && fabsf(r.o.y) <= FLT_MAX && fabsf(r.o.z) <= FLT_MAX && fabsf(r.d.x) <= FLT_MAX && fabsf(r.d.y) <= FLT_MAX && fabsf(r.d.z) <= FLT_MAX;
+    }
     Hit trace_closest_brute(const Ray& r, bool cull_back = false) const {
         Hit h;
+        if (!ray_finite(r)) return h;
         for (uint32_t i = 0; i < tris.size(); ++i) intersect_tri(r, tris[i], i, cull_back, h);
         return h;
     }
     Hit trace_closest(const Ray& r, bool cull_back = false) const {
         if (!use_bvh || nodes.empty()) return trace_closest_brute(r, cull_back);
         Hit h;
+        if (!ray_finite(r)) return h;
         f3 inv_d{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
         uint32_t stack[128]; int sp = 0;
         stack[sp++] = 0;
@@ -272,6 +278,7 @@ struct Scene {
         return h;
     }
     bool trace_any(const Ray& r) const {
+        if (!ray_finite(r)) return false;
         if (!use_bvh || nodes.empty()) {
             Hit h;
             for (uint32_t i = 0; i < tris.size(); ++i) if (intersect_tri(r, tris[i], i, false, h)) return true;

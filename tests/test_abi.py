@@ -1,0 +1,65 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/kajiya_amd.h declares; struct layouts match the reference's; error paths report, not crash."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "kajiya_amd.h")).read()
+    return sorted(set(re.findall(r"\b(kj_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from kajiya_amd import lib
+    L = lib.load()
+    names = _declared()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(lib.EXPORTS) <= set(names)
+    assert L.kj_abi_version() == 1
+
+
+def test_struct_layouts():
+    from kajiya_amd import abi
+    assert C.sizeof(abi.KjFrameConstants) == 1216      # frame_constants.rs:13-37
+    assert C.sizeof(abi.KjViewConstants) == 11 * 64 + 16
+    assert abi.KjFrameConstants.frame_index.offset == 736
+    assert abi.KjFrameConstants.ircache_cascades.offset == 832
+    assert C.sizeof(abi.KjMeshMaterial) == 152
+    assert C.sizeof(abi.KjPackedVertex) == 16
+
+
+def test_error_reporting_without_gpu():
+    """No compute calls: only argument validation paths (must not touch a device)."""
+    from kajiya_amd import lib
+    L = lib.load()
+    out = C.c_void_p()
+    st = L.kj_scene_create(None, C.byref(out))
+    assert st != 0 and b"null" in L.kj_last_error()
+    st = L.kj_rtdgi_render(None, None, None, None)
+    assert st != 0
+
+
+def test_frame_constants_builder():
+    import numpy as np
+    from kajiya_amd import frame
+    fs = frame.FrameState((1920, 1080))
+    cam = frame.CameraMatrices((1.0, 2.0, 3.0), np.eye(3), 52.0, 1920 / 1080)
+    fc = fs.prepare_frame_constants(cam)
+    v2c = np.array(fc.view_constants.view_to_clip[:]).reshape(4, 4).T
+    c2v = np.array(fc.view_constants.clip_to_view[:]).reshape(4, 4).T
+    assert np.allclose(v2c @ c2v, np.eye(4), atol=1e-5)
+    assert abs(c2v[3, 2] - 1.0 / 0.01) < 1e-3                      # clip_to_view._43 = 1/znear (camera.rs:112-117)
+    w2v = np.array(fc.view_constants.world_to_view[:]).reshape(4, 4).T
+    v2w = np.array(fc.view_constants.view_to_world[:]).reshape(4, 4).T
+    assert np.allclose(w2v @ v2w, np.eye(4), atol=1e-5)
+    # jitter = halton(2,3)[0] - 0.5 = (0, -1/6)  (world_renderer.rs:425-428)
+    assert abs(fc.view_constants.sample_offset_pixels[0] - 0.0) < 1e-7
+    assert abs(fc.view_constants.sample_offset_pixels[1] - (1.0 / 3.0 - 0.5)) < 1e-6
+    # first frame: prev == current => clip_to_prev_clip == identity
+    c2p = np.array(fc.view_constants.clip_to_prev_clip[:]).reshape(4, 4).T
+    assert np.allclose(c2p, np.eye(4), atol=1e-4)
