@@ -248,7 +248,7 @@ typedef struct KjRtdgiRenderParams {
     const void* sky_cube;          /* convolved 6x16x16 RGBA16F (world_render_passes.rs:150) */
     uint32_t sky_cube_width;
     KjScene* scene;                /* tlas + bindless set */
-    KjIrcache* ircache;            /* may be NULL: lookups return 0 (config 1) */
+    KjIrcache* ircache;            /* &mut IrcacheRenderState; NULL => lookups return 0 (BASELINE config 1) */
     const void* ssao_tex;          /* R8_UNORM full res */
     uint32_t pass_mask;            /* KJ_RTDGI_PASS_ALL for the product path */
 } KjRtdgiRenderParams;
@@ -280,6 +280,29 @@ KjStatus kj_rtdgi_pass_times_ms(KjRtdgi* r, float* out_ms, uint32_t count);
 KjStatus kj_rtdgi_traversal_counts(KjRtdgi* r, uint64_t out[6]);
 /* Ray counters of the last kj_rtdgi_render (closest-hit rays, any-hit rays). */
 KjStatus kj_rtdgi_ray_counts(KjRtdgi* r, uint64_t* out_closest, uint64_t* out_any);
+
+/* ------------------------------------------------------------------------ */
+/* Irradiance cache: IrcacheRenderer / IrcacheRenderState (renderers/ircache.rs) */
+/* ------------------------------------------------------------------------ */
+KjStatus kj_ircache_create(KjDevice* dev, KjIrcache** out);
+void kj_ircache_destroy(KjIrcache* c);
+/* IrcacheRenderer::update_eye_position (ircache.rs:126-141) and ::constants/::grid_center (:143-162):
+ * the host calls these while building the frame constants (world_renderer.rs:1061-1069). */
+KjStatus kj_ircache_update_eye_position(KjIrcache* c, const float eye[3]);
+KjStatus kj_ircache_constants(KjIrcache* c, KjFrameConstants* fc_inout);
+KjStatus kj_ircache_set_enable_scroll(KjIrcache* c, uint32_t enable);
+/* IrcacheRenderer::prepare (ircache.rs:168-350): [clear pool | scroll cascades], age, prefix scan, compact. */
+KjStatus kj_ircache_prepare(KjIrcache* c, void* stream);
+/* IrcacheRenderState::trace_irradiance (ircache.rs:360-481): dispatch args, reset, accessibility rays,
+ * validation rays, irradiance rays. `sky_cube` is the convolved cube (world_render_passes.rs:113-121). */
+KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* sky_cube, uint32_t sky_cube_width, void* stream);
+/* IrcacheRenderState::sum_up_irradiance_for_sampling (ircache.rs:487-506). */
+KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream);
+/* Debug access to the persistent buffers by the reference's names without the "ircache." prefix
+ * ("meta", "grid_meta", "entry_cell", "spatial", "irradiance", "aux", "life", "pool",
+ *  "entry_indirection", "reposition_proposal", "reposition_proposal_count"). */
+KjStatus kj_ircache_buffer(KjIrcache* c, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
+KjStatus kj_ircache_ray_counts(KjIrcache* c, uint64_t* out_closest, uint64_t* out_any);
 
 #ifdef __cplusplus
 }

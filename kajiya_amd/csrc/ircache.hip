@@ -1,0 +1,490 @@
+// IrcacheRenderer / IrcacheRenderState for gfx950 (renderers/ircache.rs:92-506, assets/shaders/ircache/*.hlsl,
+// prefix_scan/*). Maintenance kernels are grid-stride over entries/cells; the 64 Ki-element prefix scan is
+// one 1024-thread workgroup in LDS (the reference launches a 1 Mi-element three-pass scan, prefix_scan.rs:10-38);
+// ray kernels use the same software BVH traversal as rtdgi with a grid sized to the chip instead of the
+// reference's MAX_ENTRIES*4 launch with early-out (ircache.rs:416-476).
+#include "kj_host.hpp"
+#include "kj_scene.hpp"
+#include "kj_ircache.hpp"
+#include "kj_reservoir.hpp"
+
+using namespace kj;
+namespace kj { SceneView scene_view(const KjScene& s); }
+
+// ------------------------------------------------------------------ maintenance
+__global__ void k_irc_clear_pool(uint32_t* __restrict__ pool, uint32_t* __restrict__ life) {  // clear_ircache_pool.hlsl
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < IRC_MAX_ENTRIES) { pool[i] = i; life[i] = IRC_LIFE_RECYCLED; }
+}
+// scroll_cascades.hlsl:13-69 — one thread per destination cell
+__global__ void __launch_bounds__(256) k_irc_scroll_cascades(const FrameConstants* __restrict__ fc, const uint2* __restrict__ src, uint2* __restrict__ dst,
+                                                              uint32_t* __restrict__ entry_cell, float4* __restrict__ irradiance, uint32_t* __restrict__ life,
+                                                              uint32_t* __restrict__ pool, uint32_t* __restrict__ meta) {
+    const uint32_t dst_cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dst_cell >= IRC_MAX_GRID_CELLS) return;
+    const uint32_t x = dst_cell & 31u, y = (dst_cell >> 5) & 31u, z = (dst_cell >> 10) & 31u, cascade = dst_cell >> 15;
+    const int32_t* sb = fc->ircache_cascades[cascade].voxels_scrolled_this_frame;
+    const uint32_t bx = uint32_t(int(x) - sb[0]), by = uint32_t(int(y) - sb[1]), bz = uint32_t(int(z) - sb[2]);
+    if (!(bx < 32u && by < 32u && bz < 32u)) {
+        const uint2 m = src[dst_cell];  // deallocate_cell
+        if (m.y & IRC_META_OCCUPIED) {
+            const uint32_t entry_idx = m.x;
+            life[entry_idx] = IRC_LIFE_RECYCLED;
+            for (int i = 0; i < 3; ++i) irradiance[entry_idx * 3 + i] = make_float4(0, 0, 0, 0);
+            const uint32_t c = atomicAdd(&meta[IRC_META_ALLOC_COUNT], 0xffffffffu);
+            pool[c - 1u] = entry_idx;
+        }
+    }
+    const uint32_t sx = uint32_t(int(x) + sb[0]), sy = uint32_t(int(y) + sb[1]), sz = uint32_t(int(z) + sb[2]);
+    if (sx < 32u && sy < 32u && sz < 32u) {
+        const uint2 cm = src[irc_cell_idx(sx, sy, sz, cascade)];
+        dst[dst_cell] = cm;
+        if (cm.y & IRC_META_OCCUPIED) entry_cell[cm.x] = dst_cell;
+    } else {
+        dst[dst_cell] = make_uint2(0, 0);
+    }
+}
+// age_ircache_entries.hlsl:22-94 (+ prepare_age_dispatch_args.hlsl: the reference dispatches ceil(entry_count/64) groups)
+__global__ void __launch_bounds__(256) k_irc_age(IrcacheView ic, uint32_t* __restrict__ occupancy) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= IRC_MAX_ENTRIES) return;
+    const uint32_t total_entry_count = ic.meta[IRC_META_ENTRY_COUNT];
+    const uint32_t dispatched = ((total_entry_count + 63u) / 64u) * 64u;
+    if (e >= dispatched) { occupancy[e] = 0; return; }
+    if (e < total_entry_count) {
+        const uint32_t l = ic.life[e];
+        if (l != IRC_LIFE_RECYCLED) {
+            const uint32_t new_age = l + 1u;
+            if (irc_life_valid(new_age)) {
+                ic.life[e] = new_age;
+                atomicAnd(&ic.grid_meta[ic.entry_cell[e]].y, ~IRC_META_JUST_ALLOCATED);
+            } else {
+                ic.life[e] = IRC_LIFE_RECYCLED;
+                for (int i = 0; i < 3; ++i) ic.irradiance[e * 3 + i] = make_float4(0, 0, 0, 0);
+                const uint32_t c = atomicAdd(&ic.meta[IRC_META_ALLOC_COUNT], 0xffffffffu);
+                ic.pool[c - 1u] = e;
+                atomicAnd(&ic.grid_meta[ic.entry_cell[e]].y, ~(IRC_META_OCCUPIED | IRC_META_JUST_ALLOCATED));
+            }
+        }
+        ic.spatial[e] = ic.reposition_proposal[e];
+        ic.reposition_proposal_count[e] = 0;
+    } else {
+        ic.spatial[e] = make_float4(0, 0, 0, 0);
+    }
+    occupancy[e] = (e < total_entry_count && irc_life_valid(ic.life[e])) ? 1u : 0u;
+}
+// inclusive prefix scan over 64 Ki u32 in one workgroup (prefix_scan/*.hlsl semantics)
+__global__ void __launch_bounds__(1024) k_irc_scan(uint32_t* __restrict__ data) {
+    __shared__ uint32_t partial[1024];
+    const uint32_t t = threadIdx.x;
+    uint4 v[16];
+    uint32_t run = 0;
+    uint4* p = (uint4*)data + t * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uint4 a = p[i];
+        a.x += run; a.y += a.x; a.z += a.y; a.w += a.z; run = a.w;
+        v[i] = a;
+    }
+    partial[t] = run;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = t >= off ? partial[t - off] : 0u;
+        __syncthreads();
+        partial[t] += add;
+        __syncthreads();
+    }
+    const uint32_t base = t ? partial[t - 1] : 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { uint4 a = v[i]; a.x += base; a.y += base; a.z += base; a.w += base; p[i] = a; }
+}
+// ircache_compact_entries.hlsl
+__global__ void __launch_bounds__(256) k_irc_compact(const uint32_t* __restrict__ meta, const uint32_t* __restrict__ life, const uint32_t* __restrict__ occupancy,
+                                                      uint32_t* __restrict__ indirection) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= IRC_MAX_ENTRIES) return;
+    if (e < meta[IRC_META_ENTRY_COUNT] && irc_life_valid(life[e])) indirection[occupancy[e]] = e;
+}
+// prepare_trace_dispatch_args.hlsl
+__global__ void k_irc_prepare_trace(uint32_t* __restrict__ meta) { meta[IRC_META_TRACING_ALLOC_COUNT] = meta[IRC_META_ALLOC_COUNT]; }
+// reset_entry.hlsl: one wave per entry (64 float4 of aux = one wave-wide store)
+__global__ void __launch_bounds__(64) k_irc_reset(IrcacheView ic) {
+    const uint32_t alloc_count = ic.meta[IRC_META_TRACING_ALLOC_COUNT];
+    for (uint32_t d = blockIdx.x; d < alloc_count; d += gridDim.x) {
+        const uint32_t entry_idx = ic.entry_indirection[d];
+        const float4 i0 = ic.irradiance[entry_idx * 3];
+        if (i0.x == 0.0f && i0.y == 0.0f && i0.z == 0.0f && i0.w == 0.0f) ic.aux[size_t(entry_idx) * IRC_AUX_STRIDE + threadIdx.x] = make_float4(0, 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------ ray passes
+struct IrcTraceCtx {
+    const FrameConstants* __restrict__ fc;
+    SceneView sc;
+    IrcacheView ic;
+    const uint2* __restrict__ sky_cube; int sky_cube_width;
+    const uint2* __restrict__ brdf_fg_lut;
+    const float4* __restrict__ sun_color;
+    unsigned long long* __restrict__ ray_counters;
+};
+KJ_D void irc_count_rays(unsigned long long* counters, int which) {
+    const unsigned long long m = __ballot(true);
+    if ((__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counters[which], (unsigned long long)__popcll(m));
+}
+// trace_accessibility.rgen.hlsl:21-66
+__global__ void __launch_bounds__(64) k_irc_trace_accessibility(IrcTraceCtx c) {
+    extern __shared__ uint32_t lds_stack[];
+    const IrcacheView& ic = c.ic;
+    const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_OCTA_DIMS2;
+    for (uint32_t d = blockIdx.x * 64u + threadIdx.x; d < total; d += gridDim.x * 64u) {
+        const uint32_t entry_idx = ic.entry_indirection[d / IRC_OCTA_DIMS2];
+        const uint32_t octa_idx = d % IRC_OCTA_DIMS2;
+        if (!irc_life_valid(ic.life[entry_idx])) continue;
+        const IrcVertex entry = irc_unpack_vertex(ic.spatial[entry_idx]);
+        const size_t output_idx = size_t(entry_idx) * IRC_AUX_STRIDE + octa_idx;
+        const float4 r0 = ic.aux[output_idx];
+        Reservoir1spp r = Reservoir1spp::from_raw(make_uint2(asuint(r0.x), asuint(r0.y)));
+        const IrcVertex prev_entry = irc_unpack_vertex(ic.aux[output_idx + IRC_OCTA_DIMS2 * 2]);
+        irc_count_rays(c.ray_counters, 1);
+        if (rt_is_shadowed(c.sc, entry.position, prev_entry.position - entry.position, 0.001f, 0.999f, lds_stack + threadIdx.x, 64)) {
+            r.M *= 0.8f;
+            const uint2 raw = r.as_raw();
+            float2* dst = (float2*)&ic.aux[output_idx];
+            *dst = make_float2(asfloat(raw.x), asfloat(raw.y));
+        }
+    }
+}
+
+struct IrcTraceResult { V3 incident_radiance, direction, hit_pos; };
+// ircache_trace_common.inc.hlsl:37-227 (MAX_PATH_LENGTH = 1)
+KJ_D IrcTraceResult ircache_trace(const IrcTraceCtx& c, const IrcVertex& entry, uint32_t sample_params, uint32_t life, uint32_t* stack) {
+    const FrameConstants& fc = *c.fc;
+    uint32_t rng = hash1(sample_params >> 4u);
+    const V3 ray_o = entry.position, ray_d = irc_sample_direction(sample_params);
+    IrcTraceResult result;
+    result.direction = ray_d;
+    result.hit_pos = v3(0.0f);
+    V3 irradiance_sum = v3(0.0f);
+    irc_count_rays(c.ray_counters, 0);
+    const GbufferPathVertex primary_hit = gbuffer_raytrace(c.sc, fc, ray_o, ray_d, 0.0f, FLT_MAX, 1, false, stack, 64);
+    if (primary_hit.is_hit) {
+        result.hit_pos = primary_hit.position;
+        const V3 to_light_norm = sun_direction(fc);
+        irc_count_rays(c.ray_counters, 1);
+        const bool is_shadowed = rt_is_shadowed(c.sc, primary_hit.position, to_light_norm, 1e-4f, FLT_MAX, stack, 64);
+        const GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);
+        const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
+        const V3 wi = to_local(tangent_to_world, to_light_norm);
+        V3 wo = to_local(tangent_to_world, -ray_d);
+        if (wo.z < 0.0f) { wo.z *= -0.25f; wo = normalize(wo); }
+        LayeredBrdf brdf = layered_brdf_from_gbuffer_ndotv(c.brdf_fg_lut, gbuffer, wo.z);
+        brdf.roughness = lerp(brdf.roughness, 1.0f, 0.5f);  // FIREFLY_SUPPRESSION with roughness_bias = 0.5
+        const V3 brdf_value = layered_brdf_evaluate_directional_light(brdf, wo, wi);
+        const float4 sc4 = *c.sun_color;
+        const V3 light_radiance = is_shadowed ? v3(0.0f) : V3{sc4.x, sc4.y, sc4.z};
+        irradiance_sum += brdf_value * light_radiance * fmaxf(0.0f, wi.z);
+        irradiance_sum += gbuffer.emissive;
+        if (fc.triangle_light_count > 0 && c.sc.light_count > 0) {
+            const float light_selection_pmf = 1.0f / float(fc.triangle_light_count);
+            const uint32_t light_idx = hash1_mut(rng) % fc.triangle_light_count;
+            V2 urand;
+            urand.x = uint_to_u01_float(hash1_mut(rng));
+            urand.y = uint_to_u01_float(hash1_mut(rng));
+            const KjTriangleLight tl = c.sc.lights[min(light_idx, c.sc.light_count - 1u)];
+            const V3 v0{tl.verts[0], tl.verts[1], tl.verts[2]}, v1{tl.verts[3], tl.verts[4], tl.verts[5]}, v2{tl.verts[6], tl.verts[7], tl.verts[8]};
+            const LightSampleArea ls = sample_triangle_light(v0, v1 - v0, v2 - v0, urand);
+            const V3 to_light_ws = ls.pos - primary_hit.position;
+            const float dist2 = dot(to_light_ws, to_light_ws);
+            const V3 to_light_norm_ws = to_light_ws * (1.0f / sqrtf(dist2));
+            const float to_psa_metric = fmaxf(0.0f, dot(to_light_norm_ws, gbuffer.normal)) * fmaxf(0.0f, dot(to_light_norm_ws, -ls.normal)) / dist2;
+            if (to_psa_metric > 0.0f) {
+                const V3 wi2 = to_local(tangent_to_world, to_light_norm_ws);
+                irc_count_rays(c.ray_counters, 1);
+                const bool sh = rt_is_shadowed(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, 64);
+                if (!sh) irradiance_sum += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * layered_brdf_evaluate(brdf, wo, wi2) / ls.pdf * to_psa_metric / light_selection_pmf;
+            }
+        }
+        irradiance_sum += ircache_lookup<true>(c.ic, fc, entry.position, primary_hit.position, gbuffer.normal, 1u + life / IRC_LIFE_PER_RANK, rng) * gbuffer.albedo;
+    } else {
+        result.hit_pos = ray_o + ray_d * 1000.0f;
+        irradiance_sum += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
+    }
+    result.incident_radiance = irradiance_sum;
+    return result;
+}
+// ircache_validate.rgen.hlsl:44-131
+__global__ void __launch_bounds__(64) k_irc_validate(IrcTraceCtx c) {
+    extern __shared__ uint32_t lds_stack[];
+    const IrcacheView& ic = c.ic;
+    const FrameConstants& fc = *c.fc;
+    const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_VALIDATION_SAMPLES_PER_FRAME;
+    for (uint32_t d = blockIdx.x * 64u + threadIdx.x; d < total; d += gridDim.x * 64u) {
+        const uint32_t entry_idx = ic.entry_indirection[d / IRC_VALIDATION_SAMPLES_PER_FRAME];
+        const uint32_t sample_idx = d % IRC_VALIDATION_SAMPLES_PER_FRAME;
+        const uint32_t life = ic.life[entry_idx];
+        const uint32_t sp = irc_sample_params(IRC_VALIDATION_SAMPLES_PER_FRAME, entry_idx, sample_idx, fc.frame_index);
+        const size_t output_idx = size_t(entry_idx) * IRC_AUX_STRIDE + (sp % IRC_OCTA_DIMS2);
+        const float4 r0 = ic.aux[output_idx];
+        Reservoir1spp r = Reservoir1spp::from_raw(make_uint2(asuint(r0.x), asuint(r0.y)));
+        if (r.M > 0) {
+            float4 pv = ic.aux[output_idx + IRC_OCTA_DIMS2];
+            pv.x *= fc.pre_exposure_delta; pv.y *= fc.pre_exposure_delta; pv.z *= fc.pre_exposure_delta;
+            const IrcVertex prev_entry = irc_unpack_vertex(ic.aux[output_idx + IRC_OCTA_DIMS2 * 2]);
+            const IrcTraceResult prev_traced = ircache_trace(c, prev_entry, r.payload, life, lds_stack + threadIdx.x);
+            const float limiter = lerp(0.5f, 1.0f, smoothstep(-0.1f, 0.0f, dot(prev_traced.direction, prev_entry.normal)));
+            const V3 a = prev_traced.incident_radiance * limiter;
+            const V3 b{pv.x, pv.y, pv.z};
+            const V3 dist3 = vabs(a - b) / (a + b);
+            const float dist = fmaxf(dist3.x, fmaxf(dist3.y, dist3.z));
+            const float invalidity = smoothstep(0.1f, 0.5f, dist);
+            r.M = fmaxf(0.0f, fminf(r.M, exp2f(log2f(float(IRC_RESTIR_M_CLAMP)) * (1.0f - invalidity))));
+            const uint2 raw = r.as_raw();
+            float2* dst = (float2*)&ic.aux[output_idx];
+            *dst = make_float2(asfloat(raw.x), asfloat(raw.y));
+            ic.aux[output_idx + IRC_OCTA_DIMS2] = make_float4(a.x, a.y, a.z, pv.w);
+        }
+    }
+}
+// trace_irradiance.rgen.hlsl:44-145
+__global__ void __launch_bounds__(64) k_irc_trace_irradiance(IrcTraceCtx c) {
+    extern __shared__ uint32_t lds_stack[];
+    const IrcacheView& ic = c.ic;
+    const FrameConstants& fc = *c.fc;
+    const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME;
+    for (uint32_t d = blockIdx.x * 64u + threadIdx.x; d < total; d += gridDim.x * 64u) {
+        const uint32_t entry_idx = ic.entry_indirection[d / IRC_SAMPLES_PER_FRAME];
+        const uint32_t sample_idx = d % IRC_SAMPLES_PER_FRAME;
+        const uint32_t life = ic.life[entry_idx];
+        const float4 packed_entry = ic.spatial[entry_idx];
+        const IrcVertex entry = irc_unpack_vertex(packed_entry);
+        uint32_t rng = hash1(hash1(entry_idx) + fc.frame_index);
+        const uint32_t sp = irc_sample_params(IRC_SAMPLES_PER_FRAME, entry_idx, sample_idx, fc.frame_index);
+        const IrcTraceResult traced = ircache_trace(c, entry, sp, life, lds_stack + threadIdx.x);
+        const float limiter = lerp(0.5f, 1.0f, smoothstep(-0.1f, 0.0f, dot(traced.direction, entry.normal)));
+        const V3 new_value = traced.incident_radiance * limiter;
+        StreamState stream_state{0, 0};
+        Reservoir1spp reservoir = Reservoir1spp::create();
+        reservoir.init_with_stream(sRGB_to_luminance(new_value), 1.0f, stream_state, sp);
+        const size_t output_idx = size_t(entry_idx) * IRC_AUX_STRIDE + (sp % IRC_OCTA_DIMS2);
+        float4 pv = ic.aux[output_idx + IRC_OCTA_DIMS2];
+        const V3 prev_value{pv.x * fc.pre_exposure_delta, pv.y * fc.pre_exposure_delta, pv.z * fc.pre_exposure_delta};
+        V3 val_sel = new_value;
+        bool selected_new = true;
+        {
+            const float4 r0 = ic.aux[output_idx];
+            Reservoir1spp r = Reservoir1spp::from_raw(make_uint2(asuint(r0.x), asuint(r0.y)));
+            if (r.M > 0) {
+                r.M = fminf(r.M, 30.0f);
+                if (reservoir.update_with_stream(r, sRGB_to_luminance(prev_value), 1.0f, stream_state, r.payload, rng)) {
+                    val_sel = prev_value;
+                    selected_new = false;
+                }
+            }
+        }
+        reservoir.finish_stream(stream_state);
+        const uint2 raw = reservoir.as_raw();
+        float2* dst = (float2*)&ic.aux[output_idx];
+        *dst = make_float2(asfloat(raw.x), asfloat(raw.y));
+        ic.aux[output_idx + IRC_OCTA_DIMS2] = make_float4(val_sel.x, val_sel.y, val_sel.z, reservoir.W);
+        if (selected_new) ic.aux[output_idx + IRC_OCTA_DIMS2 * 2] = packed_entry;
+    }
+}
+// sum_up_irradiance.hlsl:34-89 — 16 lanes per entry (one per octahedral cell), shuffle-reduced
+__global__ void __launch_bounds__(64) k_irc_sum_up(const FrameConstants* __restrict__ fcp, IrcacheView ic) {
+    const uint32_t alloc_count = ic.meta[IRC_META_TRACING_ALLOC_COUNT];
+    const uint32_t sub = threadIdx.x >> 4, octa_idx = threadIdx.x & 15u;
+    for (uint32_t d0 = blockIdx.x * 4u; d0 < alloc_count; d0 += gridDim.x * 4u) {
+        const uint32_t d = d0 + sub;
+        const bool active = d < alloc_count;
+        const uint32_t entry_idx = active ? ic.entry_indirection[d] : 0u;
+        float4 sh[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+        float valid = 0;
+        if (active) {
+            const uint32_t payload = asuint(ic.aux[size_t(entry_idx) * IRC_AUX_STRIDE + octa_idx].x);
+            const V3 dir = irc_sample_direction(payload);
+            const float4 contrib = ic.aux[size_t(entry_idx) * IRC_AUX_STRIDE + IRC_OCTA_DIMS2 + octa_idx];
+            const V3 radiance = V3{contrib.x, contrib.y, contrib.z} * contrib.w;
+            const float4 basis = make_float4(0.282095f * 4.0f, dir.x * 0.488603f * 4.0f, dir.y * 0.488603f * 4.0f, dir.z * 0.488603f * 4.0f);
+            const float rad[3] = {radiance.x, radiance.y, radiance.z};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sh[k] = make_float4(basis.x * rad[k], basis.y * rad[k], basis.z * rad[k], basis.w * rad[k]);
+            valid = contrib.w > 0 ? 1.0f : 0.0f;
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                sh[k].x += __shfl_xor(sh[k].x, off); sh[k].y += __shfl_xor(sh[k].y, off);
+                sh[k].z += __shfl_xor(sh[k].z, off); sh[k].w += __shfl_xor(sh[k].w, off);
+            }
+            valid += __shfl_xor(valid, off);
+        }
+        if (active && octa_idx < 3u) {
+            const float scale = 1.0f / fmaxf(1.0f, valid);
+            const float4 s = sh[octa_idx];
+            const V4 new_value = V4{s.x, s.y, s.z, s.w} * scale;
+            const float4 pvf = ic.irradiance[entry_idx * 3u + octa_idx];
+            V4 prev_value = V4{pvf.x, pvf.y, pvf.z, pvf.w} * fcp->pre_exposure_delta;
+            if (!(prev_value.x != 0.0f || prev_value.y != 0.0f || prev_value.z != 0.0f || prev_value.w != 0.0f)) prev_value = new_value;
+            const V4 b = lerp(prev_value, new_value, 0.25f);
+            ic.irradiance[entry_idx * 3u + octa_idx] = make_float4(b.x, b.y, b.z, b.w);
+        }
+    }
+}
+
+// ================================================================== host
+#include "kj_ircache_host.hpp"
+
+IrcacheView KjIrcache::view() const {
+    IrcacheView v;
+    v.meta = (uint32_t*)meta.p;
+    v.grid_meta = (uint2*)grid_meta[cur].p;
+    v.entry_cell = (uint32_t*)entry_cell.p;
+    v.spatial = (float4*)spatial.p;
+    v.irradiance = (float4*)irradiance.p;
+    v.aux = (float4*)aux.p;
+    v.life = (uint32_t*)life.p;
+    v.pool = (uint32_t*)pool.p;
+    v.reposition_proposal = (float4*)reposition_proposal.p;
+    v.reposition_proposal_count = (uint32_t*)reposition_proposal_count.p;
+    v.entry_indirection = (const uint32_t*)entry_indirection.p;
+    return v;
+}
+
+#define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
+
+extern "C" {
+
+KjStatus kj_ircache_create(KjDevice* dev, KjIrcache** out) {
+    KJ_REQUIRE(dev && out, "null argument");
+    KjIrcache* c = new KjIrcache();
+    c->dev = dev;
+    hipError_t e = hipSuccess;
+    auto A = [&](kj::DevBuf& b, size_t n) { if (e == hipSuccess) e = b.alloc(n); };
+    A(c->meta, 32); A(c->grid_meta[0], size_t(IRC_MAX_GRID_CELLS) * 8); A(c->grid_meta[1], size_t(IRC_MAX_GRID_CELLS) * 8);
+    A(c->entry_cell, IRC_MAX_ENTRIES * 4); A(c->spatial, IRC_MAX_ENTRIES * 16); A(c->irradiance, size_t(IRC_MAX_ENTRIES) * 48);
+    A(c->aux, size_t(IRC_MAX_ENTRIES) * 64 * 16); A(c->life, IRC_MAX_ENTRIES * 4); A(c->pool, IRC_MAX_ENTRIES * 4);
+    A(c->entry_indirection, (IRC_MAX_ENTRIES + 64) * 4); A(c->reposition_proposal, IRC_MAX_ENTRIES * 16);
+    A(c->reposition_proposal_count, IRC_MAX_ENTRIES * 4); A(c->occupancy, IRC_MAX_ENTRIES * 4); A(c->ray_counters, 16);
+    if (e != hipSuccess) { delete c; set_last_error("ircache allocation failed: %s", hipGetErrorString(e)); return KJ_ERR_OUT_OF_MEMORY; }
+    *out = c;
+    return KJ_OK;
+}
+void kj_ircache_destroy(KjIrcache* c) { delete c; }
+
+// IrcacheRenderer::update_eye_position (ircache.rs:126-141)
+KjStatus kj_ircache_update_eye_position(KjIrcache* c, const float eye[3]) {
+    KJ_REQUIRE(c && eye, "null argument");
+    if (!c->enable_scroll) return KJ_OK;
+    for (int k = 0; k < 3; ++k) c->grid_center[k] = eye[k];
+    for (int cs = 0; cs < 12; ++cs) {
+        const float cell_diameter = IRC_GRID_CELL_DIAMETER * float(1 << cs);
+        for (int k = 0; k < 3; ++k) {
+            c->prev_scroll[cs][k] = c->cur_scroll[cs][k];
+            c->cur_scroll[cs][k] = int(floorf(eye[k] / cell_diameter)) - int(IRC_CASCADE_SIZE) / 2;
+        }
+    }
+    return KJ_OK;
+}
+// IrcacheRenderer::constants + grid_center (ircache.rs:143-162): fills the ircache members of the frame constants
+KjStatus kj_ircache_constants(KjIrcache* c, KjFrameConstants* fc) {
+    KJ_REQUIRE(c && fc, "null argument");
+    for (int k = 0; k < 3; ++k) fc->ircache_grid_center[k] = c->grid_center[k];
+    fc->ircache_grid_center[3] = 1.0f;
+    for (int cs = 0; cs < 12; ++cs)
+        for (int k = 0; k < 4; ++k) {
+            fc->ircache_cascades[cs].origin[k] = k < 3 ? c->cur_scroll[cs][k] : 0;
+            fc->ircache_cascades[cs].voxels_scrolled_this_frame[k] = k < 3 ? c->cur_scroll[cs][k] - c->prev_scroll[cs][k] : 0;
+        }
+    return KJ_OK;
+}
+KjStatus kj_ircache_set_enable_scroll(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->enable_scroll = enable != 0; return KJ_OK; }
+
+// IrcacheRenderer::prepare (ircache.rs:168-350)
+KjStatus kj_ircache_prepare(KjIrcache* c, void* stream_) {
+    KJ_REQUIRE(c && c->dev->fc_dev, "null argument / kj_frame_begin not called");
+    hipStream_t s = (hipStream_t)stream_;
+    int a = 0, b = 1;
+    if (c->parity == 1) std::swap(a, b);
+    if (!c->initialized) {
+        hipLaunchKernelGGL(k_irc_clear_pool, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, (uint32_t*)c->pool.p, (uint32_t*)c->life.p);
+        KJ_CHECK_LAUNCH();
+        c->initialized = true;
+    } else {
+        hipLaunchKernelGGL(k_irc_scroll_cascades, dim3(IRC_MAX_GRID_CELLS / 256), dim3(256), 0, s, c->dev->fc_dev, (const uint2*)c->grid_meta[a].p, (uint2*)c->grid_meta[b].p,
+                           (uint32_t*)c->entry_cell.p, (float4*)c->irradiance.p, (uint32_t*)c->life.p, (uint32_t*)c->pool.p, (uint32_t*)c->meta.p);
+        KJ_CHECK_LAUNCH();
+        std::swap(a, b);
+        c->parity = (c->parity + 1) % 2;
+    }
+    c->cur = a;
+    const IrcacheView v = c->view();
+    hipLaunchKernelGGL(k_irc_age, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, v, (uint32_t*)c->occupancy.p);
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_irc_scan, dim3(1), dim3(1024), 0, s, (uint32_t*)c->occupancy.p);
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_irc_compact, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, (const uint32_t*)c->meta.p, (const uint32_t*)c->life.p, (const uint32_t*)c->occupancy.p,
+                       (uint32_t*)c->entry_indirection.p);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+
+// IrcacheRenderState::trace_irradiance (ircache.rs:360-481): args, reset, accessibility, validate, trace
+KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* sky_cube, uint32_t sky_cube_width, void* stream_) {
+    KJ_REQUIRE(c && scene && sky_cube && c->dev->fc_dev, "null argument / kj_frame_begin not called");
+    if (!scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
+    hipStream_t s = (hipStream_t)stream_;
+    IrcTraceCtx tc;
+    tc.fc = c->dev->fc_dev;
+    tc.sc = scene_view(*scene);
+    tc.ic = c->view();
+    tc.sky_cube = (const uint2*)sky_cube; tc.sky_cube_width = int(sky_cube_width);
+    tc.brdf_fg_lut = (const uint2*)c->dev->brdf_fg_lut.p;
+    tc.sun_color = (const float4*)c->dev->sun_color.p + c->dev->fc_slot;
+    tc.ray_counters = (unsigned long long*)c->ray_counters.p;
+    const size_t lds = size_t(tc.sc.bvh.stack_entries) * 64 * 4;
+    KJ_REQUIRE(lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");
+    const uint32_t grid = c->dev->num_cus * 8;
+    KJ_TRY_HIP(hipMemsetAsync(c->ray_counters.p, 0, 16, s));
+    hipLaunchKernelGGL(k_irc_prepare_trace, dim3(1), dim3(1), 0, s, (uint32_t*)c->meta.p);
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_irc_reset, dim3(grid), dim3(64), 0, s, tc.ic);
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_irc_trace_accessibility, dim3(grid), dim3(64), lds, s, tc);
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_irc_validate, dim3(grid), dim3(64), lds, s, tc);
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_irc_trace_irradiance, dim3(grid), dim3(64), lds, s, tc);
+    KJ_CHECK_LAUNCH();
+    c->pending_irradiance_sum = true;
+    return KJ_OK;
+}
+// IrcacheRenderState::sum_up_irradiance_for_sampling (ircache.rs:487-506)
+KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream_) {
+    KJ_REQUIRE(c && c->dev->fc_dev, "null argument");
+    KJ_REQUIRE(c->pending_irradiance_sum, "trace_irradiance must run first (ircache.rs:492 assert)");
+    hipLaunchKernelGGL(k_irc_sum_up, dim3(c->dev->num_cus * 4), dim3(64), 0, (hipStream_t)stream_, c->dev->fc_dev, c->view());
+    KJ_CHECK_LAUNCH();
+    c->pending_irradiance_sum = false;
+    return KJ_OK;
+}
+KjStatus kj_ircache_buffer(KjIrcache* c, const char* name, void** out_dev_ptr, uint64_t* out_bytes) {
+    KJ_REQUIRE(c && name && out_dev_ptr && out_bytes, "null argument");
+    struct { const char* n; kj::DevBuf* b; } tbl[] = {
+        {"meta", &c->meta}, {"grid_meta", &c->grid_meta[c->cur]}, {"entry_cell", &c->entry_cell}, {"spatial", &c->spatial}, {"irradiance", &c->irradiance},
+        {"aux", &c->aux}, {"life", &c->life}, {"pool", &c->pool}, {"entry_indirection", &c->entry_indirection},
+        {"reposition_proposal", &c->reposition_proposal}, {"reposition_proposal_count", &c->reposition_proposal_count}, {"ray_counters", &c->ray_counters}};
+    for (auto& t : tbl)
+        if (strcmp(t.n, name) == 0) { *out_dev_ptr = t.b->p; *out_bytes = t.b->bytes; return KJ_OK; }
+    set_last_error("no ircache buffer named '%s'", name);
+    return KJ_ERR_INVALID_ARGUMENT;
+}
+KjStatus kj_ircache_ray_counts(KjIrcache* c, uint64_t* out_closest, uint64_t* out_any) {
+    KJ_REQUIRE(c && out_closest && out_any, "null argument");
+    uint64_t v[2];
+    KJ_TRY_HIP(hipMemcpy(v, c->ray_counters.p, 16, hipMemcpyDeviceToHost));
+    *out_closest = v[0]; *out_any = v[1];
+    return KJ_OK;
+}
+
+}  // extern "C"

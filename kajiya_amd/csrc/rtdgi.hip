@@ -4,6 +4,9 @@
 // RtdgiRenderer::{reproject,render} including the ping-pong temporal resources.
 #include "kj_host.hpp"
 #include "kj_scene.hpp"
+#include "kj_reservoir.hpp"
+#include "kj_ircache.hpp"
+#include "kj_ircache_host.hpp"
 
 using namespace kj;
 namespace kj { SceneView scene_view(const KjScene& s); }
@@ -27,52 +30,6 @@ typedef Img<float4> ImgF4;
     const int lane = threadIdx.x;                                         \
     const int x = int(blockIdx.x) * 8 + (lane & 7), y = int(blockIdx.y) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < (H_);
-
-// ------------------------------------------------------------------ reservoirs (inc/reservoir.hlsl:6-98)
-struct StreamState { float p_q_sel, M_sum; };
-struct Reservoir1spp {
-    float w_sum; uint32_t payload; float M, W;
-    KJ_D static Reservoir1spp create() { return Reservoir1spp{0, 0, 0, 0}; }
-    KJ_D static Reservoir1spp from_raw(uint2 raw) { V2 mw = unpack_2x16f_uint(raw.y); return Reservoir1spp{0, raw.x, mw.x, mw.y}; }
-    KJ_D uint2 as_raw() const { return make_uint2(payload, pack_2x16f_uint(M, fmaxf(0.0f, W))); }
-    KJ_D bool update(float w, uint32_t sample_payload, uint32_t& rng) {
-        w_sum += w;
-        M += 1;
-        const float dart = uint_to_u01_float(hash1_mut(rng));
-        const float prob = w / w_sum;
-        if (prob >= dart) { payload = sample_payload; return true; }
-        return false;
-    }
-    KJ_D bool update_with_stream(const Reservoir1spp& r, float p_q, float weight, StreamState& ss, uint32_t sample_payload, uint32_t& rng) {
-        ss.M_sum += r.M;
-        if (update(p_q * weight * r.W * r.M, sample_payload, rng)) { ss.p_q_sel = p_q; return true; }
-        return false;
-    }
-    KJ_D void init_with_stream(float p_q, float weight, StreamState& ss, uint32_t sample_payload) {
-        payload = sample_payload;
-        w_sum = p_q * weight;
-        M = weight != 0 ? 1.0f : 0.0f;
-        W = weight;
-        ss.p_q_sel = p_q;
-        ss.M_sum = M;
-    }
-    KJ_D void finish_stream(const StreamState& ss) {
-        M = ss.M_sum;
-        W = w_sum / (fmaxf(1e-8f, M * ss.p_q_sel));
-    }
-};
-// rtdgi_common.hlsl:12-39
-struct TemporalReservoirOutput {
-    float depth; V3 ray_hit_offset_ws; float luminance; V3 hit_normal_ws;
-    KJ_D static TemporalReservoirOutput from_raw(uint4 raw) {
-        V2 a = unpack_2x16f_uint(raw.y), b = unpack_2x16f_uint(raw.z);
-        return TemporalReservoirOutput{asfloat(raw.x), V3{a.x, a.y, b.x}, b.y, unpack_normal_11_10_11(raw.w)};
-    }
-    KJ_D uint4 as_raw() const {
-        return make_uint4(asuint(depth), pack_2x16f_uint(ray_hit_offset_ws.x, ray_hit_offset_ws.y), pack_2x16f_uint(ray_hit_offset_ws.z, luminance),
-                          pack_normal_11_10_11(hit_normal_ws));
-    }
-};
 
 // ------------------------------------------------------------------ extract_half_res_{gbuffer_view_normal_rgba8,depth,ssao}.hlsl (fused)
 __global__ void __launch_bounds__(64) k_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgR8 ssao, ImgU32 half_view_normal,
@@ -158,6 +115,7 @@ struct TraceCtx {
     const uint32_t* __restrict__ blue_noise;
     const uint2* __restrict__ brdf_fg_lut;
     const float4* __restrict__ sun_color;
+    IrcacheView irc; bool has_ircache;              // IrcacheRenderState bound via bind_mut (rtdgi.rs:321,350)
     unsigned long long* __restrict__ ray_counters;  // [0]=closest rays, [1]=any-hit rays, [2..5]=nodes/tris visited (closest, any) in STATS builds
 };
 struct TraceResult { V3 out_value; V3 hit_normal_ws; float hit_t; float pdf; bool is_hit; };
@@ -229,7 +187,10 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
                     if (!is_shadowed) total_radiance += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * brdf_value / ls.pdf;
                 }
             }
-            // USE_IRCACHE: no irradiance cache bound in this build => lookup contributes 0 (BASELINE config 1)
+            if (c.has_ircache) {  // USE_IRCACHE (diffuse_trace_common.inc.hlsl:189-198); unbound => contributes 0 (BASELINE config 1)
+                const V3 gi = ircache_lookup<false>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng);
+                total_radiance += gi * gbuffer.albedo;
+            }
         }
     } else {
         total_radiance += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
@@ -902,7 +863,6 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     KJ_REQUIRE(int(p->gbuffer_depth.width) == r->W && int(p->gbuffer_depth.height) == r->H && r->reprojected_history_tex, "kj_rtdgi_reproject must run first with the same extent");
     KJ_REQUIRE(r->dev->fc_dev, "kj_frame_begin not called");
     if (!p->scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
-    if (p->ircache) { set_last_error("irradiance cache binding is not implemented yet"); return KJ_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream_;
     const int W = r->W, H = r->H, hw = r->hw, hh = r->hh;
     const FrameConstants* fc = r->dev->fc_dev;
@@ -952,6 +912,8 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     tc.blue_noise = (const uint32_t*)r->dev->blue_noise.p;
     tc.brdf_fg_lut = (const uint2*)r->dev->brdf_fg_lut.p;
     tc.sun_color = (const float4*)r->dev->sun_color.p + r->dev->fc_slot;
+    tc.has_ircache = p->ircache != nullptr;
+    if (p->ircache) { KJ_REQUIRE(!p->ircache->pending_irradiance_sum, "ircache sum-up pending (ircache.rs:67 assert)"); tc.irc = p->ircache->view(); } else { memset(&tc.irc, 0, sizeof(tc.irc)); }
     tc.ray_counters = (unsigned long long*)r->ray_counters.p;
     const size_t trace_lds = size_t(tc.sc.bvh.stack_entries) * 64 * 4;
     KJ_REQUIRE(trace_lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");

@@ -93,10 +93,31 @@ class FrameState:
         self.triangle_light_count = 0
         self.pre_exposure = 1.0
         self.ircache_grid_center = (0.0, 0.0, 0.0, 1.0)
-        self.ircache_cascades = None  # optional list of 12 (origin[4], scrolled[4])
+        self.ircache_cascades = None  # list of 12 (origin[4], scrolled[4]) once the ircache is enabled
+        # IrcacheRenderer host state (renderers/ircache.rs:92-158)
+        self.ircache_enabled = False
+        self._irc_cur = np.zeros((12, 3), np.int32)
+        self._irc_prev = np.zeros((12, 3), np.int32)
+
+    def ircache_update_eye_position(self, eye):
+        """IrcacheRenderer::update_eye_position + constants (ircache.rs:126-158), f32 arithmetic."""
+        eye = np.asarray(eye, np.float32)
+        self.ircache_grid_center = (float(eye[0]), float(eye[1]), float(eye[2]), 1.0)
+        casc = []
+        for c in range(12):
+            cell_diameter = np.float32(0.16 * 0.125) * np.float32(1 << c)
+            center = np.floor(eye / cell_diameter).astype(np.int32)
+            origin = center - np.int32(16)
+            self._irc_prev[c] = self._irc_cur[c]
+            self._irc_cur[c] = origin
+            casc.append((list(origin) + [0], list(self._irc_cur[c] - self._irc_prev[c]) + [0]))
+        self.ircache_cascades = casc
 
     def prepare_frame_constants(self, cam: CameraMatrices, delta_time_seconds=1.0 / 60.0) -> KjFrameConstants:
         prev = self.prev_camera or cam
+        if self.ircache_enabled:
+            # world_renderer.rs:1061-1069: update_eye_position(view_constants.eye_position()) before the constants are pushed
+            self.ircache_update_eye_position(cam.view_to_world[:3, 3])
         fc = KjFrameConstants()
         vc = fc.view_constants
         f32 = np.float32

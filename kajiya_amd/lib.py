@@ -23,6 +23,8 @@ EXPORTS = [
     "kj_sky_cube_convolve", "kj_reprojection_create", "kj_reprojection_destroy", "kj_calculate_reprojection_map",
     "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_render",
     "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
+    "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
+    "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts",
 ]
 
 _LIB = None
@@ -73,12 +75,21 @@ def load():
         "kj_rtdgi_set_profiling": [vp, u32, u32],
         "kj_rtdgi_pass_times_ms": [vp, C.POINTER(C.c_float), u32],
         "kj_rtdgi_traversal_counts": [vp, C.POINTER(C.c_uint64)],
+        "kj_ircache_create": [vp, C.POINTER(vp)],
+        "kj_ircache_update_eye_position": [vp, vp],
+        "kj_ircache_constants": [vp, C.POINTER(KjFrameConstants)],
+        "kj_ircache_set_enable_scroll": [vp, u32],
+        "kj_ircache_prepare": [vp, vp],
+        "kj_ircache_trace_irradiance": [vp, vp, vp, u32, vp],
+        "kj_ircache_sum_up_irradiance_for_sampling": [vp, vp],
+        "kj_ircache_buffer": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
+        "kj_ircache_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     }
     for name, args in sig.items():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = i32
-    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy"):
+    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy"):
         f = getattr(L, name)
         f.argtypes = [vp]
         f.restype = None
@@ -187,7 +198,7 @@ class GpuPipeline:
     """One frame of the hot path on the GPU: sky cubes -> G-buffer stand-in -> reprojection map ->
     RtdgiRenderer::reproject -> RtdgiRenderer::render. All buffers stay resident in HBM."""
 
-    def __init__(self, dev: Device, scene: Scene, width, height, device="cuda:0"):
+    def __init__(self, dev: Device, scene: Scene, width, height, device="cuda:0", use_ircache=False):
         import torch
         self.torch = torch
         L = load()
@@ -209,6 +220,10 @@ class GpuPipeline:
         check(L.kj_rtdgi_create(dev.h, C.byref(self.rtdgi)))
         self.reprojection_map_ptr = C.c_void_p()
         self.out = KjRtdgiOutput()
+        self.ircache = None
+        if use_ircache:
+            self.ircache = C.c_void_p()
+            check(L.kj_ircache_create(dev.h, C.byref(self.ircache)))
 
     def gbuffer_depth(self):
         g = KjGbufferDepth()
@@ -240,7 +255,7 @@ class GpuPipeline:
         p.sky_cube = self.sky16.data_ptr()
         p.sky_cube_width = 16
         p.scene = self.scene.h
-        p.ircache = None
+        p.ircache = self.ircache
         p.ssao_tex = self.ssao.data_ptr()
         p.pass_mask = pass_mask
         return p
@@ -252,10 +267,33 @@ class GpuPipeline:
         p = self.params(pass_mask)
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
 
+    def gi_frame(self, pass_mask=KJ_RTDGI_PASS["ALL"]):
+        """The GI frame in world_render_passes.rs order: ircache.prepare, trace_irradiance (:99,113-121),
+        rtdgi.reproject (:129), ircache sum-up (:138-140), rtdgi.render (:145-163)."""
+        s = _stream_ptr()
+        if self.ircache:
+            check(self.L.kj_ircache_prepare(self.ircache, s))
+            check(self.L.kj_ircache_trace_irradiance(self.ircache, self.scene.h, self.sky16.data_ptr(), 16, s))
+        check(self.L.kj_rtdgi_reproject(self.rtdgi, self.reprojection_map_ptr, self.W, self.H, s))
+        if self.ircache:
+            check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
+        p = self.params(pass_mask)
+        check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+
     def frame(self, fc):
         self.render_inputs(fc)
         self.reprojection()
-        self.rtdgi_frame()
+        self.gi_frame()
+
+    def ircache_buffer(self, name, dtype):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        check(self.L.kj_ircache_buffer(self.ircache, name.encode(), C.byref(ptr), C.byref(n)))
+        return tensor_from_ptr(ptr.value, n.value, dtype, (-1,))
+
+    def ircache_ray_counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self.L.kj_ircache_ray_counts(self.ircache, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def surface(self, name, dtype, shape):
         """Wrap a named renderer surface as a torch tensor (no copy)."""
@@ -289,6 +327,8 @@ class GpuPipeline:
         try:
             self.L.kj_rtdgi_destroy(self.rtdgi)
             self.L.kj_reprojection_destroy(self.reproj)
+            if self.ircache:
+                self.L.kj_ircache_destroy(self.ircache)
         except Exception:
             pass
 

@@ -2,6 +2,7 @@
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
 // The product (kajiya_amd/) never links, imports or calls it.
 #include "okj_rtdgi.hpp"
+#include "okj_ircache_trace.hpp"
 #include <cstdio>
 #include <chrono>
 #ifdef _OPENMP
@@ -181,6 +182,11 @@ void okj_rtdgi_render(void* p, const KjFrameConstants* fc, const KjRtdgiRenderPa
     in.ssao = ImgR8((void*)params->ssao_tex, W, H);
     in.blue_noise = o->blue_noise.data();
     in.brdf_fg_lut = o->brdf_lut.data();
+    if (params->ircache) {
+        Ircache* ic = (Ircache*)params->ircache;
+        const KjFrameConstants* fcp = fc;
+        in.ircache_lookup = [ic, fcp](f3 from, f3 pt, f3 n, uint32_t rank, uint32_t& rng) { return ic->lookup(*fcp, from, pt, n, rank, rng, false); };
+    }
     Rtdgi::Output r = o->r.render(*fc, in, params->pass_mask);
     if (out) {
         out->screen_irradiance_tex = r.screen_irradiance_tex.p;
@@ -201,6 +207,52 @@ void okj_rtdgi_ray_counts(void* p, uint64_t* closest, uint64_t* any) {
     OkjRtdgi* o = (OkjRtdgi*)p;
     *closest = o->r.rays_closest.load();
     *any = o->r.rays_any.load();
+}
+
+
+// ---- ircache (IrcacheRenderer / IrcacheRenderState)
+struct OkjIrcache {
+    Ircache ic;
+    std::vector<h4> brdf_lut;
+};
+void* okj_ircache_create(const void* brdf_fg_lut) {
+    OkjIrcache* o = new OkjIrcache();
+    o->brdf_lut.resize(64 * 64);
+    if (brdf_fg_lut) memcpy(o->brdf_lut.data(), brdf_fg_lut, 64 * 64 * 8);
+    else build_brdf_fg_lut(o->brdf_lut.data());
+    return o;
+}
+void okj_ircache_destroy(void* p) { delete (OkjIrcache*)p; }
+void* okj_ircache_core(void* p) { return &((OkjIrcache*)p)->ic; }   // value for KjRtdgiRenderParams.ircache
+void okj_ircache_update_eye_position(void* p, const float* eye) { ((OkjIrcache*)p)->ic.update_eye_position(f3{eye[0], eye[1], eye[2]}); }
+void okj_ircache_constants(void* p, KjFrameConstants* fc) { ((OkjIrcache*)p)->ic.constants(*fc); }
+void okj_ircache_prepare(void* p, const KjFrameConstants* fc) { ((OkjIrcache*)p)->ic.prepare(*fc); }
+void okj_ircache_trace_irradiance(void* p, const KjFrameConstants* fc, void* scene, const void* sky_cube, int sky_cube_width) {
+    OkjIrcache* o = (OkjIrcache*)p;
+    IrcacheTraceInputs in;
+    in.scene = (const Scene*)scene; in.sky_cube = (const h4*)sky_cube; in.sky_cube_width = sky_cube_width; in.brdf_fg_lut = o->brdf_lut.data();
+    const f3 sun_color = sun_color_in_direction(*fc, sun_direction(*fc));
+    o->ic.rays_closest = 0; o->ic.rays_any = 0;
+    IrcacheTracer::prepare_and_reset(o->ic);
+    IrcacheTracer::trace_accessibility(o->ic, in);
+    IrcacheTracer::validate(o->ic, *fc, in, sun_color);
+    IrcacheTracer::trace_irradiance(o->ic, *fc, in, sun_color);
+}
+void okj_ircache_sum_up(void* p, const KjFrameConstants* fc) { IrcacheTracer::sum_up(((OkjIrcache*)p)->ic, *fc); }
+int okj_ircache_buffer(void* p, const char* name, void** out_ptr, uint64_t* out_bytes) {
+    Ircache& ic = ((OkjIrcache*)p)->ic;
+    std::string n(name);
+#define OKJ_BUF(nm, vec) if (n == nm) { *out_ptr = (void*)(vec).data(); *out_bytes = (vec).size() * sizeof((vec)[0]); return 0; }
+    OKJ_BUF("meta", ic.meta) OKJ_BUF("grid_meta", ic.grid_meta[ic.cur]) OKJ_BUF("entry_cell", ic.entry_cell) OKJ_BUF("spatial", ic.spatial)
+    OKJ_BUF("irradiance", ic.irradiance) OKJ_BUF("aux", ic.aux) OKJ_BUF("life", ic.life) OKJ_BUF("pool", ic.pool)
+    OKJ_BUF("entry_indirection", ic.entry_indirection) OKJ_BUF("reposition_proposal", ic.reposition_proposal)
+    OKJ_BUF("reposition_proposal_count", ic.reposition_proposal_count)
+#undef OKJ_BUF
+    return 1;
+}
+void okj_ircache_ray_counts(void* p, uint64_t* closest, uint64_t* any) {
+    Ircache& ic = ((OkjIrcache*)p)->ic;
+    *closest = ic.rays_closest.load(); *any = ic.rays_any.load();
 }
 
 } // extern "C"

@@ -65,6 +65,17 @@ def lib():
         L.okj_rtdgi_surface.restype = C.c_int
         L.okj_rtdgi_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_rtdgi_ray_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.okj_ircache_create.restype = C.c_void_p; L.okj_ircache_create.argtypes = [C.c_void_p]
+        L.okj_ircache_destroy.argtypes = [C.c_void_p]
+        L.okj_ircache_core.restype = C.c_void_p; L.okj_ircache_core.argtypes = [C.c_void_p]
+        L.okj_ircache_update_eye_position.argtypes = [C.c_void_p, C.c_void_p]
+        L.okj_ircache_constants.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants)]
+        L.okj_ircache_prepare.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants)]
+        L.okj_ircache_trace_irradiance.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_int]
+        L.okj_ircache_sum_up.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants)]
+        L.okj_ircache_buffer.restype = C.c_int
+        L.okj_ircache_buffer.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.okj_ircache_ray_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.okj_set_threads.argtypes = [C.c_int]
         L.okj_get_max_threads.restype = C.c_int
         _LIB = L
@@ -130,11 +141,12 @@ class OraclePipeline:
     """CPU restatement of one frame of the hot path (world_render_passes.rs:13-292, the subset in
     scope): sky cubes -> G-buffer stand-in -> reprojection map -> rtdgi.reproject -> rtdgi.render."""
 
-    def __init__(self, scene: OracleScene, width, height):
+    def __init__(self, scene: OracleScene, width, height, use_ircache=False):
         L = lib()
         self.L = L
         self.scene = scene
         self.W, self.H = width, height
+        self.ircache = L.okj_ircache_create(brdf_lut().ctypes.data) if use_ircache else None
         self.bn = blue_noise()
         self.rtdgi = L.okj_rtdgi_create(self.bn.ctypes.data, brdf_lut().ctypes.data)
         W, H = width, height
@@ -175,7 +187,7 @@ class OraclePipeline:
         p.sky_cube = self.sky16.ctypes.data
         p.sky_cube_width = 16
         p.scene = self.scene.h
-        p.ircache = None
+        p.ircache = self.L.okj_ircache_core(self.ircache) if self.ircache else None
         p.ssao_tex = self.ssao.ctypes.data
         p.pass_mask = pass_mask
         return p
@@ -185,10 +197,41 @@ class OraclePipeline:
         p = self.params(pass_mask)
         self.L.okj_rtdgi_render(self.rtdgi, C.byref(fc), C.byref(p), C.byref(self.out))
 
+    def ircache_prepare_and_trace(self, fc):
+        """ircache.prepare + trace_irradiance (world_render_passes.rs:99,113-121)."""
+        self.L.okj_ircache_prepare(self.ircache, C.byref(fc))
+        self.L.okj_ircache_trace_irradiance(self.ircache, C.byref(fc), self.scene.h, self.sky16.ctypes.data, 16)
+
+    def ircache_sum_up(self, fc):
+        self.L.okj_ircache_sum_up(self.ircache, C.byref(fc))
+
+    def gi_frame(self, fc, pass_mask=KJ_RTDGI_PASS["ALL"]):
+        """The GI frame in world_render_passes.rs order: ircache prepare/trace, rtdgi.reproject,
+        ircache sum-up (deliberately delayed, :138-140), rtdgi.render."""
+        if self.ircache:
+            self.ircache_prepare_and_trace(fc)
+        self.L.okj_rtdgi_reproject(self.rtdgi, C.byref(fc), self.reprojection_map.ctypes.data, self.W, self.H)
+        if self.ircache:
+            self.ircache_sum_up(fc)
+        p = self.params(pass_mask)
+        self.L.okj_rtdgi_render(self.rtdgi, C.byref(fc), C.byref(p), C.byref(self.out))
+
     def frame(self, fc):
         self.render_inputs(fc)
         self.reprojection(fc)
-        self.rtdgi_frame(fc)
+        self.gi_frame(fc)
+
+    def ircache_buffer(self, name, dtype):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        if self.L.okj_ircache_buffer(self.ircache, name.encode(), C.byref(ptr), C.byref(n)) != 0:
+            raise KeyError(name)
+        buf = (C.c_uint8 * n.value).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype)
+
+    def ircache_ray_counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.L.okj_ircache_ray_counts(self.ircache, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def surface(self, name, dtype, shape):
         ptr, n = C.c_void_p(), C.c_uint64()

@@ -29,3 +29,8 @@ def gpu():
     from kajiya_amd import lib
     lib.load()
     return lib
+
+
+@pytest.fixture(scope="session")
+def device(gpu):
+    return gpu.Device(0)

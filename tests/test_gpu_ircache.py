@@ -1,0 +1,140 @@
+"""GPU parity for the irradiance cache. The cache is order-dependent in the reference (lock-free allocation,
+last-writer-wins votes: docs/gi-overview.md:296), so entry indices differ between runs. Deterministic pieces are
+compared exactly on identical state; the full cache is compared structurally (per grid cell) and statistically."""
+import ctypes as C
+import numpy as np
+import pytest
+
+import parity as P
+import test_gpu_parity as T
+
+pytestmark = pytest.mark.gpu
+
+BUFS = {"meta": np.uint32, "grid_meta": np.uint32, "entry_cell": np.uint32, "spatial": np.float32, "irradiance": np.float32, "aux": np.float32,
+        "life": np.uint32, "pool": np.uint32, "entry_indirection": np.uint32, "reposition_proposal": np.float32, "reposition_proposal_count": np.uint32}
+
+
+def _frames(W, H, n, use_ircache=True):
+    from kajiya_amd import frame
+    fs = frame.FrameState((W, H))
+    fs.ircache_enabled = use_ircache
+    out = []
+    for i in range(n):
+        out.append(fs.prepare_frame_constants(frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.02)))
+        fs.retire_frame()
+    return out
+
+
+def _upload_ircache(op, gp, torch):
+    for name, dt in BUFS.items():
+        src = op.ircache_buffer(name, np.uint8)
+        dst = gp.ircache_buffer(name, torch.uint8)
+        n = min(src.size, dst.numel())
+        dst[:n].copy_(torch.from_numpy(src[:n].copy()))
+
+
+def test_ircache_maintenance_and_sum_are_exact_on_identical_state(gpu, oracle, device):
+    """scroll/age/scan/compact and the SH sum-up are deterministic given the same state (single-threaded oracle
+    order == any GPU order up to the free-list permutation): run the oracle for several frames, upload its
+    state, run one prepare() on both, compare."""
+    import torch
+    from kajiya_amd import scenes
+    W = H = 128
+    desc = scenes.cornell_box()
+    oracle.lib().okj_set_threads(1)
+    try:
+        op = oracle.OraclePipeline(oracle.OracleScene(desc), W, H, use_ircache=True)
+        gp = gpu.GpuPipeline(device, gpu.Scene(device, desc), W, H, use_ircache=True)
+        fcs = _frames(W, H, 8)
+        for fc in fcs[:6]:
+            op.frame(fc)
+        # GPU: run one frame to initialise, then overwrite its state with the oracle's
+        gp.frame(fcs[0])
+        torch.cuda.synchronize()
+        gp_parity_fix = op  # noqa
+        _upload_ircache(op, gp, torch)
+        # both: next frame's prepare (scroll with the camera move, age, scan, compact)
+        fc = fcs[6]
+        op.render_inputs(fc)
+        gp.dev.frame_begin(fc)
+        op.L.okj_ircache_prepare(op.ircache, C.byref(fc))
+        # the GPU handle's ping-pong parity must match the oracle's: both ran the same number of prepare() calls? no -> align by
+        # comparing against whichever grid buffer is live: kj_ircache_buffer("grid_meta") returns the live one on both sides.
+        gpu.check(gp.L.kj_ircache_prepare(gp.ircache, None))
+        torch.cuda.synchronize()
+        for name in ("meta", "entry_cell", "life", "spatial", "irradiance", "reposition_proposal_count"):
+            a = op.ircache_buffer(name, np.uint8)
+            b = gp.ircache_buffer(name, torch.uint8).cpu().numpy()
+            n = min(a.size, b.size)
+            assert np.array_equal(a[:n], b[:n]), name
+        gm_a = op.ircache_buffer("grid_meta", np.uint32).reshape(-1, 2)
+        gm_b = gp.ircache_buffer("grid_meta", torch.int32).cpu().numpy().view(np.uint32).reshape(-1, 2)
+        assert np.array_equal(gm_a, gm_b)
+        meta = op.ircache_buffer("meta", np.uint32)
+        alloc = int(meta[3])
+        assert alloc > 50
+        # free list: same set of free entries (order may differ)
+        pa = op.ircache_buffer("pool", np.uint32)[alloc:]
+        pb = gp.ircache_buffer("pool", torch.int32).cpu().numpy().view(np.uint32)[alloc:]
+        assert np.array_equal(np.sort(pa), np.sort(pb))
+        # compaction: same set of live entries in [1..alloc] (inclusive-scan off-by-one of the reference is preserved)
+        ia = op.ircache_buffer("entry_indirection", np.uint32)[1:alloc + 1]
+        ib = gp.ircache_buffer("entry_indirection", torch.int32).cpu().numpy().view(np.uint32)[1:alloc + 1]
+        assert np.array_equal(ia, ib)
+        # trace + sum-up on identical state: rays are deterministic per entry; lookups may allocate in different order,
+        # so compare the SH of entries that existed before this frame
+        op.L.okj_ircache_trace_irradiance(op.ircache, C.byref(fc), op.scene.h, op.sky16.ctypes.data, 16)
+        gp.sky16.copy_(torch.from_numpy(op.sky16.view(np.int16)))
+        gpu.check(gp.L.kj_ircache_trace_irradiance(gp.ircache, gp.scene.h, gp.sky16.data_ptr(), 16, None))
+        op.L.okj_ircache_sum_up(op.ircache, C.byref(fc))
+        gpu.check(gp.L.kj_ircache_sum_up_irradiance_for_sampling(gp.ircache, None))
+        torch.cuda.synchronize()
+        oc, oa = op.ircache_ray_counts(); gc, ga = gp.ircache_ray_counts()
+        assert oc == gc and abs(oa - ga) <= 0.01 * oa + 4, (oc, oa, gc, ga)
+        irr_a = op.ircache_buffer("irradiance", np.float32).reshape(-1, 12)
+        irr_b = gp.ircache_buffer("irradiance", torch.float32).cpu().numpy().reshape(-1, 12)
+        live = ia
+        num = np.sqrt(((irr_a[live] - irr_b[live]) ** 2).sum()); den = np.sqrt((irr_a[live] ** 2).sum())
+        print("ircache SH rel-L2 on identical state:", num / den, "entries", len(live))
+        assert num / den < 2e-2
+    finally:
+        oracle.lib().okj_set_threads(oracle.lib().okj_get_max_threads())
+
+
+def test_ircache_free_running_structure_and_statistics(gpu, oracle, device):
+    """Independent 20-frame runs: the set of occupied grid cells and the mean cached irradiance agree."""
+    import torch
+    from kajiya_amd import scenes
+    W = H = 160
+    desc = scenes.cornell_box()
+    op = oracle.OraclePipeline(oracle.OracleScene(desc), W, H, use_ircache=True)
+    gp = gpu.GpuPipeline(device, gpu.Scene(device, desc), W, H, use_ircache=True)
+    for fc in _frames(W, H, 20):
+        op.frame(fc)
+        gp.frame(fc)
+    torch.cuda.synchronize()
+    gm_a = op.ircache_buffer("grid_meta", np.uint32).reshape(-1, 2)
+    gm_b = gp.ircache_buffer("grid_meta", torch.int32).cpu().numpy().view(np.uint32).reshape(-1, 2)
+    occ_a, occ_b = (gm_a[:, 1] & 1) != 0, (gm_b[:, 1] & 1) != 0
+    inter, union = (occ_a & occ_b).sum(), (occ_a | occ_b).sum()
+    print("ircache occupied cells: oracle", occ_a.sum(), "gpu", occ_b.sum(), "IoU", inter / union)
+    assert occ_a.sum() > 100 and inter / union > 0.9
+    irr_a = op.ircache_buffer("irradiance", np.float32).reshape(-1, 3, 4)
+    irr_b = gp.ircache_buffer("irradiance", torch.float32).cpu().numpy().reshape(-1, 3, 4)
+    both = np.nonzero(occ_a & occ_b)[0]
+    l0_a = irr_a[gm_a[both, 0]][:, :, 0]; l0_b = irr_b[gm_b[both, 0]][:, :, 0]
+    ma, mb = l0_a.mean(axis=0), l0_b.mean(axis=0)
+    print("mean SH L0 per channel: oracle", ma, "gpu", mb)
+    assert np.allclose(ma, mb, rtol=0.12, atol=2e-3)  # statistical: both runs are racy (OpenMP / GPU atomics)
+    # per-cell values are independent noisy ReSTIR estimates (4 rays/entry/frame, 0.25 blend): require strong
+    # correlation and a bounded mean absolute deviation rather than equality
+    per_cell = np.abs(l0_a - l0_b).mean() / (np.abs(l0_a).mean() + 1e-6)
+    corr = np.corrcoef(l0_a.sum(axis=1), l0_b.sum(axis=1))[0, 1]
+    print("per-cell mean abs diff / mean:", per_cell, "correlation:", corr)
+    assert per_cell < 0.45 and corr > 0.85
+    # and the GI image with the cache bound agrees within the free-running bar
+    ref = op.surface("spatial_filtered_tex", np.uint8, (-1,))
+    got = gp.surface("spatial_filtered_tex", torch.uint8, (-1,)).cpu().numpy()
+    r = P.compare(got, ref, "rgba16f")
+    print("free-running GI with ircache:", r)
+    assert r["rel_l2"] < 5e-2

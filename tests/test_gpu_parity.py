@@ -39,11 +39,6 @@ def _random_rays(rng, n, lo, hi):
     return rays
 
 
-@pytest.fixture(scope="module")
-def device(gpu):
-    return gpu.Device(0)
-
-
 def _scenes():
     from kajiya_amd import scenes
     return {"cornell": scenes.cornell_box(), "city20k": scenes.procedural_city(target_tris=20000, seed=7, n_instances=24)}
