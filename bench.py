@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — GI-frame throughput of the MI355X-native ReSTIR-GI hot path.
 
-A "step" is one GI frame (RtdgiRenderer::reproject + RtdgiRenderer::render, i.e. every rtdgi pass from
-`rtdgi reproject` to `rtdgi spatial`) over one frame's inputs, which are generated beforehand and stay
+A "step" is one GI frame (IrcacheRenderer::prepare + trace_irradiance + sum-up, RtdgiRenderer::reproject + render:
+every pass from `scroll cascades` to `rtdgi spatial`) over one frame's inputs, which are generated beforehand and stay
 resident in HBM (G-buffer, depth, normals, velocity, reprojection map, sky cube, BVH).
 
 Workload (BASELINE.json configs[1] stand-in): procedural "city" scene, ~1.0 M triangles,
@@ -54,6 +54,7 @@ def make_scene(name, tris):
 def frame_constants_list(W, H, n, cam_args, phase=0.0):
     from kajiya_amd import frame
     fs = frame.FrameState((W, H))
+    fs.ircache_enabled = True
     out = []
     for i in range(n):
         out.append(fs.prepare_frame_constants(frame.orbit_camera(i, (W, H), phase=phase, **cam_args)))
@@ -68,7 +69,7 @@ def cpu_baseline(desc, cam_args, cores):
     t_build = time.time()
     osc = okj_py.OracleScene(desc)
     t_build = time.time() - t_build
-    op = okj_py.OraclePipeline(osc, W, H)
+    op = okj_py.OraclePipeline(osc, W, H, use_ircache=True)
     okj_py.lib().okj_set_threads(cores)
     fcs = frame_constants_list(W, H, frames, cam_args)
     rays, t_gi = 0, 0.0
@@ -76,12 +77,13 @@ def cpu_baseline(desc, cam_args, cores):
         op.render_inputs(fc)
         op.reprojection(fc)
         t0 = time.time()
-        op.rtdgi_frame(fc)
+        op.gi_frame(fc)
         t_gi += time.time() - t0
         a, b = op.ray_counts()
-        rays += a + b
+        c, d = op.ircache_ray_counts()
+        rays += a + b + c + d
     return {"value": round(rays / t_gi / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"oracle rtdgi (all passes), same scene+camera, {frames} frames at {W}x{H} ({rays} rays in {t_gi:.2f} s; "
+            "sample": f"oracle ircache + rtdgi (all passes), same scene+camera, {frames} frames at {W}x{H} ({rays} rays in {t_gi:.2f} s; "
                       f"oracle BVH build {t_build:.1f} s not counted)",
             "gi_frame_ms_at_sample_res": round(1e3 * t_gi / frames, 2)}
 
@@ -105,7 +107,7 @@ def main():
     dev = lib.Device(local_rank)
     scene = lib.Scene(dev, desc)
     stats = scene.stats()
-    gp = lib.GpuPipeline(dev, scene, W, H, device=f"cuda:{local_rank}")
+    gp = lib.GpuPipeline(dev, scene, W, H, device=f"cuda:{local_rank}", use_ircache=True)
 
     # ---- pre-generate the inputs of every frame (resident in HBM before the timed region)
     n_frames = Wm + K + args.profile_frames + 3
@@ -124,11 +126,13 @@ def main():
         gp.geometric_normal, gp.gbuffer, gp.depth = gn, gb, d
         gp.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
         dev.frame_begin(fcs[i])
-        gp.rtdgi_frame()
+        gp.gi_frame()
 
     step(0)  # allocates surfaces
     gp_counters = lib.tensor_from_ptr(*_counter_ptr(gp, lib), torch.int64, (6,))
+    irc_counters = gp.ircache_buffer("ray_counters", torch.int64)
     ray_log = torch.zeros((n_frames, 6), dtype=torch.int64, device=f"cuda:{local_rank}")
+    irc_log = torch.zeros((n_frames, 2), dtype=torch.int64, device=f"cuda:{local_rank}")
     for i in range(1, Wm):
         step(i)
 
@@ -142,6 +146,7 @@ def main():
     for i in range(Wm, Wm + K):
         step(i)
         ray_log[i].copy_(gp_counters, non_blocking=True)  # 48-byte device-to-device copy on the same stream
+        irc_log[i].copy_(irc_counters, non_blocking=True)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -150,7 +155,8 @@ def main():
         elapsed = float(t.item())
     rays_closest = int(ray_log[Wm:Wm + K, 0].sum().item())
     rays_any = int(ray_log[Wm:Wm + K, 1].sum().item())
-    total_rays = rays_closest + rays_any
+    irc_rays = int(irc_log[Wm:Wm + K].sum().item())
+    total_rays = rays_closest + rays_any + irc_rays
     if world > 1:
         t = torch.tensor([total_rays], dtype=torch.int64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -214,9 +220,9 @@ def main():
         "gi_frame_ms": round(ms_per_step, 4), "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{scene_label}, {W}x{H}, rtdgi: reproject+validate+trace+validity+temporal ReSTIR+2x spatial ReSTIR+"
-                               "resolve+temporal+spatial denoise; irradiance cache and TAA not in this build",
+                               "resolve+temporal+spatial denoise, irradiance cache (scroll/age/compact, accessibility+validate+trace rays, SH sum); TAA not in this build",
                    "triangles": stats["triangles"], "bvh_nodes": stats["nodes"], "bvh_bytes": stats["bvh_bytes"],
-                   "rays_per_frame": round(total_rays / K, 1), "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (screen-tile split not in this build)"},
+                   "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (screen-tile split not in this build)"},
         "pass_ms": {n: round(v, 4) for n, v in zip(lib.GpuPipeline.PASS_NAMES, pass_ms)},
         "roofline": roofline,
     }

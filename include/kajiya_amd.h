@@ -304,6 +304,21 @@ KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream);
 KjStatus kj_ircache_buffer(KjIrcache* c, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 KjStatus kj_ircache_ray_counts(KjIrcache* c, uint64_t* out_closest, uint64_t* out_any);
 
+/* ------------------------------------------------------------------------ */
+/* TAA / temporal super-resolution: TaaRenderer (renderers/taa.rs:41-191)     */
+/* ------------------------------------------------------------------------ */
+typedef struct KjTaaOutput { /* TaaOutput, taa.rs:30-33 */
+    const void* temporal_out;    /* RGBA16F output res, a = accumulated coverage ("taa" temporal) */
+    const void* this_frame_out;  /* RGBA16F output res */
+} KjTaaOutput;
+KjStatus kj_taa_create(KjDevice* dev, KjTaa** out);
+void kj_taa_destroy(KjTaa* t);
+/* TaaRenderer::render(rg, input_tex, reprojection_map, depth_tex, output_extent). input_tex RGBA16F,
+ * reprojection_map RGBA16_SNORM and depth R32F are at the input (render) extent. */
+KjStatus kj_taa_render(KjTaa* t, const void* input_tex, uint32_t input_width, uint32_t input_height, const void* reprojection_map,
+                       const void* depth_tex, uint32_t output_width, uint32_t output_height, KjTaaOutput* out, void* stream);
+KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
+
 #ifdef __cplusplus
 }
 #endif

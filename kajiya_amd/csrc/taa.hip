@@ -1,0 +1,422 @@
+// TaaRenderer for gfx950 (renderers/taa.rs:41-191; assets/shaders/taa/*.hlsl, inc/unjitter_taa.hlsl,
+// inc/image.hlsl). Seven kernels as in the reference; 8x8 tile = one wave64 (the velocity-dilation vote
+// uses __shfl_xor like WaveReadLaneAt in reproject_history.hlsl:80-82).
+#include "kj_host.hpp"
+#include "kj_shading.hpp"
+
+using namespace kj;
+
+typedef Img<uint2> ImgH4;      // RGBA16F (and RGBA16_SNORM)
+typedef Img<uint32_t> ImgH2;   // RG16F
+typedef Img<uint16_t> ImgH1;   // R16F
+typedef Img<float> ImgF32;
+
+#define TILE_XY(W_, H_)                                                                          \
+    const int lane = threadIdx.x;                                                                \
+    const int x = int(blockIdx.x) * 8 + (lane & 7), y = int(blockIdx.y) * 8 + (lane >> 3);     \
+    const bool in_image = x < (W_) && y < (H_);
+
+// taa_common.hlsl (TAA_NONLINEARITY_TYPE 1, TAA_COLOR_MAPPING_MODE 1)
+KJ_D V3 taa_decode_rgb(V3 v) { const float m = max3(v.x, v.y, v.z); return v * sqrtf(fmaxf(0.0f, m)) / fmaxf(1e-20f, m); }
+KJ_D V3 taa_encode_rgb(V3 v) { const float m = max3(v.x, v.y, v.z); return v * (m * m) / fmaxf(1e-20f, m); }
+KJ_D float ld1h(const ImgH1& i, int x, int y) { return f16_to_f32(i.ld(x, y)); }
+
+// image_sample_catmull_rom_5tap (inc/image.hlsl:88-172); the history remap (decode_rgb * pre_exposure_delta) is applied per tap
+KJ_D V4 taa_history_tap(const ImgH4& tex, V2 uv, float ped) {
+    const V4 v = sample_bilinear_clamp_rgba16f(tex.p, tex.w, tex.h, uv);
+    return v4(taa_decode_rgb(xyz(v) * ped), v.w);
+}
+KJ_D V4 catmull_rom_5tap_history(const ImgH4& tex, V2 uv, V2 tex_size, float ped) {
+    const V2 sample_pos = uv * tex_size;
+    const V2 tex_pos1{floorf(sample_pos.x - 0.5f) + 0.5f, floorf(sample_pos.y - 0.5f) + 0.5f};
+    const V2 f = sample_pos - tex_pos1;
+    const V2 w0 = f * (-0.5f + f * (1.0f - 0.5f * f));
+    const V2 w1 = 1.0f + f * f * (-2.5f + 1.5f * f);
+    const V2 w2 = f * (0.5f + f * (2.0f - 1.5f * f));
+    const V2 w3 = f * f * (-0.5f + 0.5f * f);
+    const V2 w12 = w1 + w2;
+    const V2 offset12 = w2 / (w1 + w2);
+    const V2 p0 = (tex_pos1 - 1.0f) / tex_size, p3 = (tex_pos1 + 2.0f) / tex_size, p12 = (tex_pos1 + offset12) / tex_size;
+    V4 result = v4(0.0f);
+    result += taa_history_tap(tex, V2{p12.x, p0.y}, ped) * (w12.x * w0.y);
+    result += taa_history_tap(tex, V2{p0.x, p12.y}, ped) * (w0.x * w12.y);
+    result += taa_history_tap(tex, V2{p12.x, p12.y}, ped) * (w12.x * w12.y);
+    result += taa_history_tap(tex, V2{p3.x, p12.y}, ped) * (w3.x * w12.y);
+    result += taa_history_tap(tex, V2{p12.x, p3.y}, ped) * (w12.x * w3.y);
+    return result / (w12.x * w0.y + w0.x * w12.y + w12.x * w12.y + w3.x * w12.y + w12.x * w3.y);
+}
+
+// reproject_history.hlsl:42-129
+__global__ void __launch_bounds__(64) k_taa_reproject(const FrameConstants* __restrict__ fc, ImgH4 history_tex, ImgH4 reprojection_tex, ImgF32 depth_tex, ImgH4 output_tex,
+                                                       ImgH2 closest_velocity_output, int IW, int IH) {
+    const int OW = output_tex.w, OH = output_tex.h;
+    TILE_XY(OW, OH)
+    (void)in_image;  // all 64 lanes take part in the vote; stores are bounds-checked
+    const V4 its = tex_size4(IW, IH), ots = tex_size4(OW, OH);
+    const V2 scale{its.x / ots.x, its.y / ots.y};
+    const int rx = int(uint32_t((float(x) + 0.5f) * scale.x)), ry = int(uint32_t((float(y) + 0.5f) * scale.y));
+    V2 vmn, vmx;
+    {
+        V4 r = ld_reproj(reprojection_tex, rx - 1, ry - 1); vmn = vmx = V2{r.x, r.y};
+        r = ld_reproj(reprojection_tex, rx + 1, ry - 1); vmn = vmin(vmn, V2{r.x, r.y}); vmx = V2{fmaxf(vmx.x, r.x), fmaxf(vmx.y, r.y)};
+        r = ld_reproj(reprojection_tex, rx - 1, ry + 1); vmn = vmin(vmn, V2{r.x, r.y}); vmx = V2{fmaxf(vmx.x, r.x), fmaxf(vmx.y, r.y)};
+        r = ld_reproj(reprojection_tex, rx + 1, ry + 1); vmn = vmin(vmn, V2{r.x, r.y}); vmx = V2{fmaxf(vmx.x, r.x), fmaxf(vmx.y, r.y)};
+    }
+    const V2 d = vmx - vmn, s = vmx + vmn;
+    int should_dilate = (d.x > 0.1f * fmaxf(its.z, fabsf(s.x)) || d.y > 0.1f * fmaxf(its.w, fabsf(s.y))) ? 1 : 0;
+    should_dilate |= __shfl_xor(should_dilate, 2);
+    should_dilate |= __shfl_xor(should_dilate, 16);
+    int cx = rx, cy = ry;
+    if (should_dilate) {
+        float reproj_depth = depth_tex.ld(rx, ry);
+        for (int oy = -1; oy <= 1; ++oy)
+            for (int ox = -1; ox <= 1; ++ox) {
+                const float dd = depth_tex.ld(rx + ox, ry + oy);
+                if (dd > reproj_depth) { reproj_depth = dd; cx = rx + ox; cy = ry + oy; }
+            }
+    }
+    const V4 rr = ld_reproj(reprojection_tex, cx, cy);
+    const V2 reproj_xy{rr.x, rr.y};
+    st2h(closest_velocity_output, x, y, reproj_xy);
+    const V2 uv = get_uv(float(x), float(y), ots);
+    const V4 hp = catmull_rom_5tap_history(history_tex, uv + reproj_xy, V2{ots.x, ots.y}, fc->pre_exposure_delta);
+    st4(output_tex, x, y, v4(xyz(hp), fmaxf(0.0f, hp.w)));
+}
+
+// filter_input.hlsl:33-88
+struct FilteredInput { V3 clamped_ex, var; };
+KJ_D FilteredInput filter_input_inner(const ImgH4& input_tex, const ImgF32& depth_tex, int px, int py, float center_depth, float luma_cutoff, float depth_scale) {
+    V3 iex = v3(0.0f), iex2 = v3(0.0f), clamped_iex = v3(0.0f);
+    float iwsum = 0, clamped_iwsum = 0;
+#pragma unroll
+    for (int yy = -1; yy <= 1; ++yy)
+#pragma unroll
+        for (int xx = -1; xx <= 1; ++xx) {
+            const float distance_w = expf(-0.8f * float(xx * xx + yy * yy));
+            const V3 s = sRGB_to_YCbCr(taa_decode_rgb(xyz(ld4(input_tex, px + xx, py + yy))));
+            const float depth = depth_tex.ld(px + xx, py + yy);
+            float w = 1;
+            w *= exp2f(-fminf(16.0f, depth_scale * inverse_depth_relative_diff(center_depth, depth)));
+            w *= distance_w;
+            w *= powf(saturate(luma_cutoff / s.x), 8.0f);
+            clamped_iwsum += w;
+            clamped_iex += s * w;
+            iwsum += 1;
+            iex += s;
+            iex2 += s * s;
+        }
+    clamped_iex = clamped_iex / clamped_iwsum;
+    iex = iex / iwsum;
+    iex2 = iex2 / iwsum;
+    return FilteredInput{clamped_iex, vmax(v3(0.0f), iex2 - iex * iex)};
+}
+__global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32 depth_tex, ImgH4 output_tex, ImgH4 dev_output_tex) {
+    TILE_XY(output_tex.w, output_tex.h)
+    if (!in_image) return;
+    const float center_depth = depth_tex.ld(x, y);
+    const FilteredInput a = filter_input_inner(input_tex, depth_tex, x, y, center_depth, 1e10f, 200.0f);
+    const FilteredInput b = filter_input_inner(input_tex, depth_tex, x, y, center_depth, a.clamped_ex.x * 1.001f, 200.0f);
+    st4(output_tex, x, y, v4(b.clamped_ex, 0.0f));
+    st4(dev_output_tex, x, y, v4(vsqrt(a.var), 0.0f));
+}
+
+// filter_history.hlsl:15-61
+KJ_D V3 fh_filter_input(const ImgH4& input_tex, V2 uv, float luma_cutoff, int k) {
+    V3 iex = v3(0.0f);
+    float iwsum = 0;
+    const int sx = int(floorf(uv.x * float(input_tex.w) + 1e-3f)), sy = int(floorf(uv.y * float(input_tex.h) + 1e-3f));
+    for (int yy = -k; yy <= k; ++yy)
+        for (int xx = -k; xx <= k; ++xx) {
+            const float distance_w = expf(-(0.8f / float(k * k)) * float(xx * xx + yy * yy));
+            const V3 s = sRGB_to_YCbCr(xyz(ld4(input_tex, sx + xx, sy + yy)));
+            const float w = distance_w * powf(saturate(luma_cutoff / s.x), 8.0f);
+            iwsum += w;
+            iex += s * w;
+        }
+    return iex / iwsum;
+}
+__global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_history, ImgH4 output_tex) {
+    TILE_XY(output_tex.w, output_tex.h)
+    if (!in_image) return;
+    const int k = (float(reprojected_history.w) / float(output_tex.w) > 1.75f) ? 2 : 1;
+    const V2 uv = get_uv(float(x), float(y), tex_size4(output_tex.w, output_tex.h));
+    const float filtered_luma = fh_filter_input(reprojected_history, uv, 1e10f, k).x;
+    st4(output_tex, x, y, v4(fh_filter_input(reprojected_history, uv, filtered_luma * 1.001f, k), 0.0f));
+}
+
+// input_prob.hlsl:50-108
+__global__ void __launch_bounds__(64) k_taa_input_prob(const FrameConstants* __restrict__ fc, ImgH4 filtered_input_tex, ImgH4 filtered_input_dev_tex, ImgH4 filtered_history_tex,
+                                                        ImgH4 reprojection_tex, ImgH4 smooth_var_history_tex, ImgH2 velocity_history_tex, ImgH1 output_tex) {
+    const int IW = output_tex.w, IH = output_tex.h;
+    TILE_XY(IW, IH)
+    if (!in_image) return;
+    const V4 its = tex_size4(IW, IH);
+    V3 ivar = v3(0.0f);
+#pragma unroll
+    for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+        for (int ox = -1; ox <= 1; ++ox) ivar = vmax(ivar, xyz(ld4(filtered_input_dev_tex, x + ox * 2, y + oy * 2)));
+    ivar = ivar * ivar;
+    const V2 input_uv{(float(x) + fc->view_constants.sample_offset_pixels[0]) * its.z, (float(y) + fc->view_constants.sample_offset_pixels[1]) * its.w};
+    const V4 closest_history = unpack_rgba16f(sample_nearest_clamp(filtered_history_tex, input_uv));
+    const V4 rp = ld_reproj(reprojection_tex, x, y);
+    const V2 huv = input_uv + V2{rp.x, rp.y};
+    const V3 closest_smooth_var = xyz(sample_bilinear_clamp_rgba16f(smooth_var_history_tex.p, smooth_var_history_tex.w, smooth_var_history_tex.h, huv));
+    const V2 closest_vel = sample_bilinear_clamp_rg16f(velocity_history_tex.p, velocity_history_tex.w, velocity_history_tex.h, huv) * fc->delta_time_seconds;
+    const V3 combined_var = vmin(closest_smooth_var, ivar * 10.0f);
+    float input_prob = 0;
+#pragma unroll
+    for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+        for (int ox = -1; ox <= 1; ++ox) {
+            const V3 idiff = xyz(ld4(filtered_input_tex, x + ox, y + oy)) - xyz(closest_history);
+            const V4 rv = ld_reproj(reprojection_tex, x + ox, y + oy);
+            const V2 q{(rv.x - closest_vel.x) / fmaxf(1.0f, fabsf(rv.x + closest_vel.x)), (rv.y - closest_vel.y) / fmaxf(1.0f, fabsf(rv.y + closest_vel.y))};
+            const float prob = exp2f(-1.0f * length(idiff * idiff / vmax(v3(1e-6f), combined_var)) - 1000.0f * length(q));
+            input_prob = fmaxf(input_prob, prob);
+        }
+    output_tex.st(x, y, f32_to_f16(input_prob));
+}
+// filter_prob.hlsl, filter_prob2.hlsl
+__global__ void __launch_bounds__(64) k_taa_filter_prob(ImgH1 input_tex, ImgH1 output_tex) {
+    TILE_XY(output_tex.w, output_tex.h)
+    if (!in_image) return;
+    float prob = ld1h(input_tex, x, y);
+#pragma unroll
+    for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+        for (int ox = -1; ox <= 1; ++ox) prob = fmaxf(prob, ld1h(input_tex, x + ox, y + oy));
+    output_tex.st(x, y, f32_to_f16(prob));
+}
+__global__ void __launch_bounds__(64) k_taa_filter_prob2(ImgH1 input_tex, ImgH1 output_tex) {
+    TILE_XY(output_tex.w, output_tex.h)
+    if (!in_image) return;
+    V2 weighted{0, 0};
+#pragma unroll
+    for (int oy = -2; oy <= 2; ++oy)
+#pragma unroll
+        for (int ox = -2; ox <= 2; ++ox) weighted += V2{exp2f(-clampf(10.0f * ld1h(input_tex, x + ox * 2, y + oy * 2), 0.0f, 100.0f)), 1.0f};
+    output_tex.st(x, y, f32_to_f16(fmaxf(0.0f, -1.0f / 10.0f * log2f(1e-30f + weighted.x / weighted.y))));
+}
+
+// inc/unjitter_taa.hlsl:58-125 (kernel half width 1)
+struct Unjittered { V4 color; float coverage; V3 ex, ex2; };
+KJ_D Unjittered sample_image_unjitter_taa(const ImgH4& img, int opx, int opy, V2 out_size, V2 sample_offset_pixels, float kernel_scale) {
+    const V2 scale = V2{float(img.w), float(img.h)} / out_size;
+    const int bx = int((float(opx) + 0.5f) * scale.x), by = int((float(opy) + 0.5f) * scale.y);
+    const V2 dst_sample_loc{float(opx) + 0.5f, float(opy) + 0.5f};
+    const V2 base_src_sample_loc = V2{float(bx) + 0.5f + sample_offset_pixels.x, float(by) + 0.5f - sample_offset_pixels.y} / scale;
+    V4 res = v4(0.0f);
+    V3 ex = v3(0.0f), ex2 = v3(0.0f);
+    float dev_wt_sum = 0, wt_sum = 0;
+#pragma unroll
+    for (int yy = -1; yy <= 1; ++yy)
+#pragma unroll
+        for (int xx = -1; xx <= 1; ++xx) {
+            const V2 src_sample_loc = base_src_sample_loc + V2{float(xx), float(yy)} / scale;
+            const V3 col = sRGB_to_YCbCr(taa_decode_rgb(xyz(ld4(img, bx + xx, by + yy))));
+            const V2 o = (src_sample_loc - dst_sample_loc) * kernel_scale;
+            const float dist2 = dot(o, o);
+            const float dev_wt = exp2f(-dist2 * scale.x);
+            const float wt = exp2f(-10.0f * dist2 * scale.x);
+            res += v4(col, 1.0f) * wt;
+            wt_sum += wt;
+            ex += col * dev_wt;
+            ex2 += col * col * dev_wt;
+            dev_wt_sum += dev_wt;
+        }
+    return Unjittered{res, wt_sum, ex / dev_wt_sum, ex2 / dev_wt_sum};
+}
+
+// taa.hlsl:94-338
+struct TaaArgs {
+    const FrameConstants* __restrict__ fc;
+    ImgH4 input_tex, history_tex, reprojection_tex; ImgH2 closest_velocity_tex, velocity_history_tex; ImgH4 smooth_var_history_tex; ImgH1 input_prob_tex;
+    ImgH4 temporal_output_tex, output_tex, smooth_var_output_tex; ImgH2 velocity_output_tex;
+};
+__global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
+    const int OW = a.temporal_output_tex.w, OH = a.temporal_output_tex.h;
+    TILE_XY(OW, OH)
+    if (!in_image) return;
+    const FrameConstants& fc = *a.fc;
+    const V4 ots = tex_size4(OW, OH);
+    const V2 frac_{float(a.input_tex.w) / float(OW), float(a.input_tex.h) / float(OH)};
+    const V2 sop{fc.view_constants.sample_offset_pixels[0], fc.view_constants.sample_offset_pixels[1]};
+    const int rx = int(uint32_t((float(x) + 0.5f) * frac_.x)), ry = int(uint32_t((float(y) + 0.5f) * frac_.y));
+    const V2 uv = get_uv(float(x), float(y), ots);
+    const V4 history_packed = ld4(a.history_tex, x, y);
+    V3 history = xyz(history_packed);
+    float history_coverage = fmaxf(0.0f, history_packed.w);
+    V4 csum = v4(0.0f); float wsum = 0;
+#pragma unroll
+    for (int oy = -2; oy <= 2; ++oy)
+#pragma unroll
+        for (int ox = -2; ox <= 2; ++ox) {
+            const float w = expf(-float(ox * ox + oy * oy));
+            csum += ld4(a.history_tex, x + ox, y + oy) * w;
+            wsum += w;
+        }
+    const V4 bhistory_packed = csum / wsum;
+    V3 bhistory = xyz(bhistory_packed);
+    const float bhistory_coverage = bhistory_packed.w;
+    history = sRGB_to_YCbCr(history);
+    bhistory = sRGB_to_YCbCr(bhistory);
+    const V4 reproj = ld_reproj(a.reprojection_tex, rx, ry);
+    const V2 reproj_xy = ld2h(a.closest_velocity_tex, x, y);
+    const Unjittered center_sample = sample_image_unjitter_taa(a.input_tex, x, y, V2{ots.x, ots.y}, sop, 1.0f);
+    const Unjittered bcenter_sample = sample_image_unjitter_taa(a.input_tex, x, y, V2{ots.x, ots.y}, sop, 0.333f);
+    float coverage = center_sample.coverage;
+    V3 center = xyz(center_sample.color);
+    const V3 bcenter = xyz(bcenter_sample.color) / bcenter_sample.coverage;
+    history = lerp(history, bcenter, saturate(1.0f - history_coverage));
+    bhistory = lerp(bhistory, bcenter, saturate(1.0f - bhistory_coverage));
+    const float input_prob = ld1h(a.input_prob_tex, rx, ry);
+    const V3 ex = center_sample.ex, ex2 = center_sample.ex2;
+    const V3 var = vmax(v3(0.0f), ex2 - ex * ex);
+    const V3 prev_var = v3(sample_bilinear_clamp_rgba16f(a.smooth_var_history_tex.p, OW, OH, uv + reproj_xy).x);
+    const V2 vel_now = reproj_xy / fc.delta_time_seconds;
+    const V2 vel_prev = sample_bilinear_clamp_rg16f(a.velocity_history_tex.p, OW, OH, uv + reproj_xy);
+    const V2 vq{(vel_now.x - vel_prev.x) / fmaxf(1.0f, fabsf(vel_now.x + vel_prev.x)), (vel_now.y - vel_prev.y) / fmaxf(1.0f, fabsf(vel_now.y + vel_prev.y))};
+    const float var_blend = saturate(0.3f + 0.7f * (1 - reproj.z) + length(vq));
+    V3 smooth_var = vmax(var, lerp(prev_var, var, var_blend));
+    smooth_var = lerp(var, smooth_var, saturate(input_prob));
+    const V3 input_dev = vsqrt(var);
+    V3 clamped_history;
+    {
+        const float box_n_deviations = lerp(0.8f, 3.0f, input_prob);
+        const V3 nmin = ex - input_dev * box_n_deviations, nmax = ex + input_dev * box_n_deviations;
+        const V3 clamped_bhistory = vclamp(bhistory, nmin, nmax);
+        const float clamping_event = length(vmax(v3(0.0f), vmax(bhistory - nmax, nmin - bhistory)) / vmax(v3(0.01f), ex));
+        const V3 outlier3 = vmax(v3(0.0f), vmax(nmin - history, history - nmax) / (0.1f + vmax(vmax(vabs(history), vabs(ex)), v3(1e-5f))));
+        const V3 boutlier3 = vmax(v3(0.0f), vmax(nmin - bhistory, bhistory - nmax) / (0.1f + vmax(vmax(vabs(bhistory), vabs(ex)), v3(1e-5f))));
+        const float outlier = fmaxf(outlier3.x, fmaxf(outlier3.y, outlier3.z));
+        const float boutlier = fmaxf(boutlier3.x, fmaxf(boutlier3.y, boutlier3.z));
+        const V2 huv = uv + reproj_xy;
+        const bool history_valid = huv.x == saturate(huv.x) && huv.y == saturate(huv.y);
+        if (history_valid) {
+            const float non_disoccluding_outliers = fmaxf(0.0f, outlier - boutlier) * 10;
+            const V3 unclamped_history_detail = history - clamped_bhistory;
+            const float temporal_clamping_detail = fabsf(unclamped_history_detail.x / fmaxf(1e-3f, input_dev.x)) * 0.05f;
+            const float temporal_stability = saturate(1 - temporal_clamping_detail);
+            const float allow_unclamped_detail = saturate(non_disoccluding_outliers) * temporal_stability;
+            V3 history_detail = history - bhistory;
+            history_detail = lerp(history_detail, unclamped_history_detail, allow_unclamped_detail);
+            const float initial_bclamp_amount = saturate(dot(clamped_bhistory - bhistory, bcenter - bhistory) /
+                                                         fmaxf(1e-5f, length(clamped_bhistory - bhistory) * length(bcenter - bhistory)));
+            const float keep_detail = 1 - saturate(initial_bclamp_amount) * (1 - allow_unclamped_detail);
+            history_detail *= keep_detail;
+            clamped_history = clamped_bhistory + history_detail;
+            if (frac_.x < 1.0f) history_coverage *= lerp(lerp(0.0f, 0.9f, keep_detail), 1.0f, saturate(10 * clamping_event));
+        } else {
+            clamped_history = clamped_bhistory;
+            coverage = 1;
+            center = bcenter;
+            history_coverage = 0;
+        }
+        clamped_history = lerp(clamped_history, history, smoothstep(0.5f, 1.0f, input_prob));
+    }
+    float total_coverage = fmaxf(1e-5f, history_coverage + coverage);
+    V3 temporal_result = (clamped_history * history_coverage + center) / total_coverage;
+    total_coverage = fminf(fmaxf(2.0f, 8.0f / (frac_.x * frac_.y)), total_coverage);
+    st4(a.smooth_var_output_tex, x, y, v4(smooth_var, 0.0f));
+    temporal_result = vmax(v3(0.0f), taa_encode_rgb(YCbCr_to_sRGB(temporal_result)));
+    st4(a.temporal_output_tex, x, y, v4(temporal_result, total_coverage));
+    st4(a.output_tex, x, y, v4(temporal_result, 0.0f));
+    st2h(a.velocity_output_tex, x, y, reproj_xy / fc.delta_time_seconds);
+}
+
+// ================================================================== host
+struct KjTaa {
+    KjDevice* dev = nullptr;
+    int IW = 0, IH = 0, OW = 0, OH = 0;
+    std::map<std::string, kj::DevBuf> surf;
+    bool flip[3] = {false, false, false};
+    hipError_t err = hipSuccess;
+    void* get(const std::string& name, size_t bytes, hipStream_t s) {
+        kj::DevBuf& b = surf[name];
+        if (b.bytes != bytes) { hipError_t e = b.alloc(bytes, s); if (e != hipSuccess) err = e; }
+        return b.p;
+    }
+    void pingpong(const char* key, int idx, size_t bytes, hipStream_t s, void*& output, void*& history) {
+        std::string a = std::string(key) + ":0", b = std::string(key) + ":1";
+        if (flip[idx]) std::swap(a, b);
+        output = get(a, bytes, s);
+        history = get(b, bytes, s);
+        flip[idx] = !flip[idx];
+    }
+};
+
+#define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
+
+extern "C" {
+
+KjStatus kj_taa_create(KjDevice* dev, KjTaa** out) {
+    KJ_REQUIRE(dev && out, "null argument");
+    KjTaa* t = new KjTaa();
+    t->dev = dev;
+    *out = t;
+    return KJ_OK;
+}
+void kj_taa_destroy(KjTaa* t) { delete t; }
+
+// TaaRenderer::render (taa.rs:41-191)
+KjStatus kj_taa_render(KjTaa* t, const void* input_tex, uint32_t input_width, uint32_t input_height, const void* reprojection_map, const void* depth_tex,
+                       uint32_t output_width, uint32_t output_height, KjTaaOutput* out, void* stream_) {
+    KJ_REQUIRE(t && input_tex && reprojection_map && depth_tex && out && input_width && input_height && output_width && output_height, "null argument");
+    KJ_REQUIRE(t->dev->fc_dev, "kj_frame_begin not called");
+    hipStream_t s = (hipStream_t)stream_;
+    const int IW = int(input_width), IH = int(input_height), OW = int(output_width), OH = int(output_height);
+    if (IW != t->IW || IH != t->IH || OW != t->OW || OH != t->OH) { t->surf.clear(); t->IW = IW; t->IH = IH; t->OW = OW; t->OH = OH; }
+    const FrameConstants* fc = t->dev->fc_dev;
+    const size_t OB = size_t(OW) * OH, IB = size_t(IW) * IH;
+    const dim3 go((OW + 7) / 8, (OH + 7) / 8), gi((IW + 7) / 8, (IH + 7) / 8), blk(64);
+    void *temporal_out, *history; t->pingpong("taa", 0, OB * 8, s, temporal_out, history);
+    void *vel_out, *vel_hist;     t->pingpong("taa.velocity", 1, OB * 4, s, vel_out, vel_hist);
+    void* reprojected_history = t->get("reprojected_history_img", OB * 8, s);
+    void* closest_velocity = t->get("closest_velocity_img", OB * 4, s);
+    void *sv_out, *sv_hist;       t->pingpong("taa.smooth_var", 2, OB * 8, s, sv_out, sv_hist);
+    void* filtered_input = t->get("filtered_input_img", IB * 8, s);
+    void* filtered_input_dev = t->get("filtered_input_deviation_img", IB * 8, s);
+    void* filtered_history = t->get("filtered_history_img", IB * 8, s);
+    void* input_prob = t->get("input_prob_img", IB * 2, s);
+    void* prob1 = t->get("prob_filtered1_img", IB * 2, s);
+    void* prob2 = t->get("prob_filtered2_img", IB * 2, s);
+    void* this_frame = t->get("this_frame_output_img", OB * 8, s);
+    KJ_TRY_HIP(t->err);
+    const ImgH4 input = img<uint2>(input_tex, IW, IH), reproj = img<uint2>(reprojection_map, IW, IH);
+    const ImgF32 depth = img<float>(depth_tex, IW, IH);
+    hipLaunchKernelGGL(k_taa_reproject, go, blk, 0, s, fc, img<uint2>(history, OW, OH), reproj, depth, img<uint2>(reprojected_history, OW, OH), img<uint32_t>(closest_velocity, OW, OH), IW, IH);
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_taa_filter_input, gi, blk, 0, s, input, depth, img<uint2>(filtered_input, IW, IH), img<uint2>(filtered_input_dev, IW, IH));
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_taa_filter_history, gi, blk, 0, s, img<uint2>(reprojected_history, OW, OH), img<uint2>(filtered_history, IW, IH));
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_taa_input_prob, gi, blk, 0, s, fc, img<uint2>(filtered_input, IW, IH), img<uint2>(filtered_input_dev, IW, IH), img<uint2>(filtered_history, IW, IH), reproj,
+                       img<uint2>(sv_hist, OW, OH), img<uint32_t>(vel_hist, OW, OH), img<uint16_t>(input_prob, IW, IH));
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_taa_filter_prob, gi, blk, 0, s, img<uint16_t>(input_prob, IW, IH), img<uint16_t>(prob1, IW, IH));
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_taa_filter_prob2, gi, blk, 0, s, img<uint16_t>(prob1, IW, IH), img<uint16_t>(prob2, IW, IH));
+    KJ_CHECK_LAUNCH();
+    TaaArgs a;
+    a.fc = fc; a.input_tex = input; a.history_tex = img<uint2>(reprojected_history, OW, OH); a.reprojection_tex = reproj;
+    a.closest_velocity_tex = img<uint32_t>(closest_velocity, OW, OH); a.velocity_history_tex = img<uint32_t>(vel_hist, OW, OH);
+    a.smooth_var_history_tex = img<uint2>(sv_hist, OW, OH); a.input_prob_tex = img<uint16_t>(prob2, IW, IH);
+    a.temporal_output_tex = img<uint2>(temporal_out, OW, OH); a.output_tex = img<uint2>(this_frame, OW, OH);
+    a.smooth_var_output_tex = img<uint2>(sv_out, OW, OH); a.velocity_output_tex = img<uint32_t>(vel_out, OW, OH);
+    hipLaunchKernelGGL(k_taa, go, blk, 0, s, a);
+    KJ_CHECK_LAUNCH();
+    out->temporal_out = temporal_out;
+    out->this_frame_out = this_frame;
+    return KJ_OK;
+}
+KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t* out_bytes) {
+    KJ_REQUIRE(t && name && out_dev_ptr && out_bytes, "null argument");
+    auto it = t->surf.find(name);
+    if (it == t->surf.end()) { set_last_error("no taa surface named '%s'", name); return KJ_ERR_INVALID_ARGUMENT; }
+    *out_dev_ptr = it->second.p;
+    *out_bytes = it->second.bytes;
+    return KJ_OK;
+}
+
+}  // extern "C"

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import numpy as np
 
-from .abi import (KjFrameConstants, KjMeshDesc, KjGbufferDepth, KjRtdgiRenderParams, KjRtdgiOutput, KJ_RTDGI_PASS)
+from .abi import (KjFrameConstants, KjMeshDesc, KjGbufferDepth, KjRtdgiRenderParams, KjRtdgiOutput, KjTaaOutput, KJ_RTDGI_PASS)
 from . import scenes as kscenes
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -25,6 +25,7 @@ EXPORTS = [
     "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
     "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts",
+    "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_surface",
 ]
 
 _LIB = None
@@ -84,12 +85,15 @@ def load():
         "kj_ircache_sum_up_irradiance_for_sampling": [vp, vp],
         "kj_ircache_buffer": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_ircache_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+        "kj_taa_create": [vp, C.POINTER(vp)],
+        "kj_taa_render": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp],
+        "kj_taa_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
     }
     for name, args in sig.items():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = i32
-    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy"):
+    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy"):
         f = getattr(L, name)
         f.argtypes = [vp]
         f.restype = None
@@ -220,6 +224,9 @@ class GpuPipeline:
         check(L.kj_rtdgi_create(dev.h, C.byref(self.rtdgi)))
         self.reprojection_map_ptr = C.c_void_p()
         self.out = KjRtdgiOutput()
+        self.taa = C.c_void_p()
+        check(L.kj_taa_create(dev.h, C.byref(self.taa)))
+        self.taa_out = KjTaaOutput()
         self.ircache = None
         if use_ircache:
             self.ircache = C.c_void_p()
@@ -280,6 +287,17 @@ class GpuPipeline:
         p = self.params(pass_mask)
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
 
+    def taa_frame(self, input_ptr=None, out_extent=None):
+        """TaaRenderer::render on `input_ptr` (default: this frame's rtdgi screen_irradiance_tex)."""
+        ow, oh = out_extent or (self.W, self.H)
+        inp = input_ptr if input_ptr is not None else self.out.screen_irradiance_tex
+        check(self.L.kj_taa_render(self.taa, inp, self.W, self.H, self.reprojection_map_ptr, self.depth.data_ptr(), ow, oh, C.byref(self.taa_out), _stream_ptr()))
+
+    def taa_surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        check(self.L.kj_taa_surface(self.taa, name.encode(), C.byref(ptr), C.byref(n)))
+        return tensor_from_ptr(ptr.value, n.value, dtype, shape)
+
     def frame(self, fc):
         self.render_inputs(fc)
         self.reprojection()
@@ -329,6 +347,7 @@ class GpuPipeline:
             self.L.kj_reprojection_destroy(self.reproj)
             if self.ircache:
                 self.L.kj_ircache_destroy(self.ircache)
+            self.L.kj_taa_destroy(self.taa)
         except Exception:
             pass
 

@@ -3,6 +3,7 @@
 // The product (kajiya_amd/) never links, imports or calls it.
 #include "okj_rtdgi.hpp"
 #include "okj_ircache_trace.hpp"
+#include "okj_taa.hpp"
 #include <cstdio>
 #include <chrono>
 #ifdef _OPENMP
@@ -253,6 +254,27 @@ int okj_ircache_buffer(void* p, const char* name, void** out_ptr, uint64_t* out_
 void okj_ircache_ray_counts(void* p, uint64_t* closest, uint64_t* any) {
     Ircache& ic = ((OkjIrcache*)p)->ic;
     *closest = ic.rays_closest.load(); *any = ic.rays_any.load();
+}
+
+// ---- taa (TaaRenderer)
+void* okj_taa_create() { return new Taa(); }
+void okj_taa_destroy(void* p) { delete (Taa*)p; }
+// returns this_frame_out; *temporal_out receives the temporal output pointer
+const void* okj_taa_render(void* p, const KjFrameConstants* fc, const void* input_tex, uint32_t in_w, uint32_t in_h, const void* reprojection_map,
+                           const void* depth_tex, uint32_t out_w, uint32_t out_h, const void** temporal_out) {
+    Taa* t = (Taa*)p;
+    ImgRGBA16F tout;
+    ImgRGBA16F r = t->render(*fc, ImgRGBA16F((void*)input_tex, in_w, in_h), ImgRGBA16S((void*)reprojection_map, in_w, in_h), ImgR32F((void*)depth_tex, in_w, in_h), out_w, out_h, &tout);
+    if (temporal_out) *temporal_out = tout.p;
+    return r.p;
+}
+int okj_taa_surface(void* p, const char* name, void** out_ptr, uint64_t* out_bytes) {
+    Taa* t = (Taa*)p;
+    auto it = t->surf.find(name);
+    if (it == t->surf.end()) return 1;
+    *out_ptr = it->second.data();
+    *out_bytes = it->second.size();
+    return 0;
 }
 
 } // extern "C"

@@ -76,6 +76,12 @@ def lib():
         L.okj_ircache_buffer.restype = C.c_int
         L.okj_ircache_buffer.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_ircache_ray_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.okj_taa_create.restype = C.c_void_p
+        L.okj_taa_destroy.argtypes = [C.c_void_p]
+        L.okj_taa_render.restype = C.c_void_p
+        L.okj_taa_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.okj_taa_surface.restype = C.c_int
+        L.okj_taa_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_set_threads.argtypes = [C.c_int]
         L.okj_get_max_threads.restype = C.c_int
         _LIB = L
@@ -215,6 +221,23 @@ class OraclePipeline:
             self.ircache_sum_up(fc)
         p = self.params(pass_mask)
         self.L.okj_rtdgi_render(self.rtdgi, C.byref(fc), C.byref(p), C.byref(self.out))
+
+    def taa_frame(self, fc, input_ptr=None, out_extent=None):
+        """TaaRenderer::render on `input_ptr` (default: this frame's rtdgi screen_irradiance_tex)."""
+        if not hasattr(self, "taa"):
+            self.taa = self.L.okj_taa_create()
+        ow, oh = out_extent or (self.W, self.H)
+        inp = input_ptr if input_ptr is not None else self.out.screen_irradiance_tex
+        tout = C.c_void_p()
+        r = self.L.okj_taa_render(self.taa, C.byref(fc), inp, self.W, self.H, self.reprojection_map.ctypes.data, self.depth.ctypes.data, ow, oh, C.byref(tout))
+        return r, tout.value
+
+    def taa_surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        if self.L.okj_taa_surface(self.taa, name.encode(), C.byref(ptr), C.byref(n)) != 0:
+            raise KeyError(name)
+        buf = (C.c_uint8 * n.value).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def frame(self, fc):
         self.render_inputs(fc)

@@ -1,0 +1,56 @@
+"""GPU parity for TAA (TaaRenderer::render): every frame both implementations receive the SAME input image,
+reprojection map and depth (the oracle's); all TAA surfaces are compared per frame."""
+import ctypes as C
+import numpy as np
+import pytest
+
+import parity as P
+import test_gpu_parity as T
+
+pytestmark = pytest.mark.gpu
+
+TAA_SURFACES = {"taa:0": "rgba16f", "taa:1": "rgba16f", "taa.velocity:0": "rg16f", "taa.velocity:1": "rg16f", "taa.smooth_var:0": "rgba16f", "taa.smooth_var:1": "rgba16f",
+                "reprojected_history_img": "rgba16f", "closest_velocity_img": "rg16f", "filtered_input_img": "rgba16f", "filtered_input_deviation_img": "rgba16f",
+                "filtered_history_img": "rgba16f", "input_prob_img": "r16f", "prob_filtered1_img": "r16f", "prob_filtered2_img": "r16f", "this_frame_output_img": "rgba16f"}
+
+
+def _decode_r16f(raw):
+    return raw.view(np.float16).astype(np.float32).reshape(-1, 1)
+
+
+@pytest.mark.parametrize("scene_name,W,H", [("cornell", 192, 160), ("city20k", 256, 144)])
+def test_taa_per_frame_parity(gpu, oracle, device, scene_name, W, H):
+    import torch
+    desc = T._scenes()[scene_name]
+    op, gp = T._make_pipelines(gpu, oracle, device, desc, W, H)
+    fcs = T._frame_constants(W, H, 8, "cornell" if scene_name == "cornell" else "city")
+    repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    inp_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    worst = 0.0
+    for fi, fc in enumerate(fcs):
+        op.frame(fc)                       # oracle: inputs + reprojection + rtdgi
+        op.taa_frame(fc)
+        gp.dev.frame_begin(fc)
+        gp.depth.copy_(torch.from_numpy(op.depth))
+        repro_dev.copy_(torch.from_numpy(op.reprojection_map))
+        gp.reprojection_map_ptr = C.c_void_p(repro_dev.data_ptr())
+        inp_dev.copy_(torch.from_numpy(op.surface("spatial_filtered_tex", np.int16, (H, W, 4))))
+        gp.taa_frame(input_ptr=inp_dev.data_ptr())
+        torch.cuda.synchronize()
+        for name, fmt in TAA_SURFACES.items():
+            if name == "filtered_history_img" and fi < 2:
+                # filter_history.hlsl:37 divides by the history luma; on the first frames the history is sparse and the
+                # Catmull-Rom negative lobe yields 0 vs -6e-8 (FMA contraction), i.e. weight 1 vs 0: ill-conditioned in
+                # the reference itself, not an implementation difference. Dense history (frame >= 2) is compared.
+                continue
+            ref = op.taa_surface(name, np.uint8, (-1,))
+            got = gp.taa_surface(name, torch.uint8, (-1,)).cpu().numpy()
+            if fmt == "r16f":
+                a, b = _decode_r16f(got).astype(np.float64), _decode_r16f(ref).astype(np.float64)
+                rel = float(np.sqrt(((a - b) ** 2).sum()) / max(1e-12, np.sqrt((b ** 2).sum())))
+                r = {"rel_l2": rel, "mismatch_frac": float((np.abs(a - b) > 1e-3 + 1e-3 * np.abs(b)).mean())}
+            else:
+                r = P.compare(got, ref, fmt)
+            worst = max(worst, r["rel_l2"])
+            assert r["rel_l2"] <= 1e-3 or r["mismatch_frac"] <= 2e-3, f"frame {fi} {name}: {r}"
+    print(f"TAA worst per-surface rel-L2 over {len(fcs)} free-running frames ({scene_name}): {worst:.2e}")
