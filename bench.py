@@ -2,7 +2,7 @@
 """bench.py — GI-frame throughput of the MI355X-native ReSTIR-GI hot path.
 
 A "step" is one GI frame (IrcacheRenderer::prepare + trace_irradiance + sum-up, RtdgiRenderer::reproject + render:
-every pass from `scroll cascades` to `rtdgi spatial`) over one frame's inputs, which are generated beforehand and stay
+every pass from `scroll cascades` to `rtdgi spatial`, then TaaRenderer::render) over one frame's inputs, which are generated beforehand and stay
 resident in HBM (G-buffer, depth, normals, velocity, reprojection map, sky cube, BVH).
 
 Workload (BASELINE.json configs[1] stand-in): procedural "city" scene, ~1.0 M triangles,
@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--scene", default="city", choices=["city", "ruins", "cornell"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=12)
+    ap.add_argument("--virtual-ranks", type=int, default=0, help="debug: run the N-way screen-tile split on ONE GPU (LocalComm)")
+    ap.add_argument("--motion-halo", type=int, default=16, help="rows of history exchanged beyond the stencil (>= max |screen motion| per frame)")
     return ap.parse_args()
 
 
@@ -65,7 +67,7 @@ def frame_constants_list(W, H, n, cam_args, phase=0.0):
 def cpu_baseline(desc, cam_args, cores):
     """Oracle (CPU restatement, kind='port') on a bounded sample of the same scene/camera."""
     from oracle import okj_py
-    W, H, frames = 640, 360, 6
+    W, H, frames = 1920, 1080, 20   # the bench workload itself, fewer frames (~10-30 s of CPU work on 16+ cores)
     t_build = time.time()
     osc = okj_py.OracleScene(desc)
     t_build = time.time() - t_build
@@ -108,10 +110,25 @@ def main():
     scene = lib.Scene(dev, desc)
     stats = scene.stats()
     gp = lib.GpuPipeline(dev, scene, W, H, device=f"cuda:{local_rank}", use_ircache=True)
+    # ---- N > 1: screen-tile split of the SAME frame (strong scaling): one strip per rank, halo exchange over RCCL
+    split = None
+    nsplit = world if world > 1 else args.virtual_ranks
+    if nsplit > 1:
+        from kajiya_amd import multigpu
+        if world > 1:
+            split_pipes = {rank: gp}
+            comm = multigpu.DistComm(dist, rank, world)
+        else:
+            split_pipes = {0: gp}
+            for r in range(1, nsplit):
+                split_pipes[r] = lib.GpuPipeline(dev, scene, W, H, device=f"cuda:{local_rank}", use_ircache=True)
+            comm = multigpu.LocalComm(nsplit)
+        split = multigpu.SplitRtdgi(comm, split_pipes, W, H, motion_halo=args.motion_halo)
+    single = split is None
 
-    # ---- pre-generate the inputs of every frame (resident in HBM before the timed region)
-    n_frames = Wm + K + args.profile_frames + 3
-    fcs = frame_constants_list(W, H, n_frames, cam_args, phase=0.35 * rank)
+    # ---- pre-generate the inputs of every frame (resident in HBM before the timed region; replicated on every rank)
+    n_frames = Wm + K + (args.profile_frames + 3 if single else 0)
+    fcs = frame_constants_list(W, H, n_frames, cam_args)
     inputs = []
     for fc in fcs:
         gp.render_inputs(fc)
@@ -123,14 +140,23 @@ def main():
 
     def step(i):
         gn, gb, d, rp = inputs[i]
-        gp.geometric_normal, gp.gbuffer, gp.depth = gn, gb, d
-        gp.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
         dev.frame_begin(fcs[i])
-        gp.gi_frame()
+        if single:
+            gp.geometric_normal, gp.gbuffer, gp.depth = gn, gb, d
+            gp.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+            gp.gi_frame()
+            gp.taa_frame()   # TaaRenderer::render on the GI output (the reference feeds it the lit image; same kernels, same bytes)
+        else:
+            for q in split.pipes.values():
+                q.geometric_normal, q.gbuffer, q.depth = gn, gb, d
+                q.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+            split.gi_frame()
+            split.taa_frame()
 
     step(0)  # allocates surfaces
-    gp_counters = lib.tensor_from_ptr(*_counter_ptr(gp, lib), torch.int64, (6,))
-    irc_counters = gp.ircache_buffer("ray_counters", torch.int64)
+    all_pipes = [gp] if single else list(split.pipes.values())
+    gp_counters = [lib.tensor_from_ptr(*_counter_ptr(q, lib), torch.int64, (6,)) for q in all_pipes]
+    irc_counters = [q.ircache_buffer("ray_counters", torch.int64) for q in all_pipes]
     ray_log = torch.zeros((n_frames, 6), dtype=torch.int64, device=f"cuda:{local_rank}")
     irc_log = torch.zeros((n_frames, 2), dtype=torch.int64, device=f"cuda:{local_rank}")
     for i in range(1, Wm):
@@ -145,8 +171,11 @@ def main():
     t0 = time.perf_counter()
     for i in range(Wm, Wm + K):
         step(i)
-        ray_log[i].copy_(gp_counters, non_blocking=True)  # 48-byte device-to-device copy on the same stream
-        irc_log[i].copy_(irc_counters, non_blocking=True)
+        ray_log[i].copy_(gp_counters[0], non_blocking=True)  # 48-byte device-to-device copy on the same stream
+        irc_log[i].copy_(irc_counters[0], non_blocking=True)
+        for c_, ic_ in zip(gp_counters[1:], irc_counters[1:]):   # virtual ranks only
+            ray_log[i] += c_
+            irc_log[i] += ic_
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -156,78 +185,119 @@ def main():
     rays_closest = int(ray_log[Wm:Wm + K, 0].sum().item())
     rays_any = int(ray_log[Wm:Wm + K, 1].sum().item())
     irc_rays = int(irc_log[Wm:Wm + K].sum().item())
-    total_rays = rays_closest + rays_any + irc_rays
     if world > 1:
-        t = torch.tensor([total_rays], dtype=torch.int64, device=f"cuda:{local_rank}")
+        t = torch.tensor([rays_closest, rays_any, irc_rays], dtype=torch.int64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total_rays_all = int(t.item())
-    else:
-        total_rays_all = total_rays
+        rays_closest, rays_any, irc_rays = (int(v) for v in t.tolist())
+    if nsplit > 1:
+        # every rank keeps its own replica of the irradiance cache (fed by its strip's rays only); replicas overlap, so
+        # their rays are counted as ONE cache's worth (mean over ranks) -- conservative for `value`.
+        irc_rays //= nsplit
+    total_rays = total_rays_all = rays_closest + rays_any + irc_rays
 
-    # ---- per-pass GPU timestamps (HIP events on the launch stream), after the timed region
-    gp.set_profiling(True, False)
-    pass_ms = [0.0] * 11
-    trace_ms_list = []
-    base = Wm + K
-    for i in range(base, base + args.profile_frames):
-        step(i)
-        torch.cuda.synchronize()
-        t = gp.pass_times_ms()
-        pass_ms = [a + b for a, b in zip(pass_ms, t)]
-        trace_ms_list.append(t[3])
-    pass_ms = [p / max(1, args.profile_frames) for p in pass_ms]
-    gp.set_profiling(False, False)
-    # ---- instrumented traversal counters (3 frames: one validation + two tracing frames)
-    gp.set_profiling(False, True)
-    trav = None
-    for i in range(base + args.profile_frames, base + args.profile_frames + 3):
-        step(i)
-        torch.cuda.synchronize()
-        c = gp.traversal_counts()
-        trav = c if trav is None else {k: trav[k] + c[k] for k in c}
-    gp.set_profiling(False, False)
+    seg, pass_ms, roofline = None, None, None
+    if single:
+        # ---- per-pass GPU timestamps (HIP events on the launch stream), after the timed region
+        gp.set_profiling(True, False)
+        pass_ms = [0.0] * 11
+        trace_ms_list = []
+        base = Wm + K
+        for i in range(base, base + args.profile_frames):
+            step(i)
+            torch.cuda.synchronize()
+            t = gp.pass_times_ms()
+            pass_ms = [a + b for a, b in zip(pass_ms, t)]
+            trace_ms_list.append(t[3])
+        pass_ms = [p / max(1, args.profile_frames) for p in pass_ms]
+        gp.set_profiling(False, False)
+        # ---- segment timers (torch events on the launch stream): ircache / rtdgi / taa
+        seg = {"ircache": 0.0, "rtdgi": 0.0, "taa": 0.0}
+        nseg = 6
+        for i in range(base, base + nseg):   # replays inputs of already-used frames: timing only
+            gn, gb, d, rp = inputs[i]
+            gp.geometric_normal, gp.gbuffer, gp.depth = gn, gb, d
+            gp.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+            dev.frame_begin(fcs[i])
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            s_ = lib._stream_ptr()
+            ev[0].record()
+            lib.check(gp.L.kj_ircache_prepare(gp.ircache, s_))
+            lib.check(gp.L.kj_ircache_trace_irradiance(gp.ircache, gp.scene.h, gp.sky16.data_ptr(), 16, s_))
+            ev[1].record()
+            lib.check(gp.L.kj_rtdgi_reproject(gp.rtdgi, gp.reprojection_map_ptr, W, H, s_))
+            ev[2].record()
+            lib.check(gp.L.kj_ircache_sum_up_irradiance_for_sampling(gp.ircache, s_))
+            ev[3].record()
+            p_ = gp.params()
+            lib.check(gp.L.kj_rtdgi_render(gp.rtdgi, C.byref(p_), C.byref(gp.out), s_))
+            ev[4].record()
+            gp.taa_frame()
+            ev5 = torch.cuda.Event(enable_timing=True); ev5.record()
+            torch.cuda.synchronize()
+            seg["ircache"] += ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])
+            seg["rtdgi"] += ev[1].elapsed_time(ev[2]) + ev[3].elapsed_time(ev[4])
+            seg["taa"] += ev[4].elapsed_time(ev5)
+        seg = {k: round(v / nseg, 4) for k, v in seg.items()}
+        # ---- instrumented traversal counters (3 frames: one validation + two tracing frames)
+        gp.set_profiling(False, True)
+        trav = None
+        for i in range(base + args.profile_frames, base + args.profile_frames + 3):
+            step(i)
+            torch.cuda.synchronize()
+            c = gp.traversal_counts()
+            trav = c if trav is None else {k: trav[k] + c[k] for k in c}
+        gp.set_profiling(False, False)
 
-    hw, hh = (W + 1) // 2, (H + 1) // 2
-    # dominant kernel: pick by measured time
-    dom = max(range(11), key=lambda k: pass_ms[k])
-    dom_name = lib.GpuPipeline.PASS_NAMES[dom]
-    # algorithmic bytes of `rtdgi trace` per launch: 38 B/half-res px of surface I/O
-    #   + per ray: nodes visited x 64 B + triangles tested x 48 B (instrumented) + 232 B hit shading per closest hit
-    nodes_per_closest = trav["closest_nodes"] / max(1, trav["closest_rays"])
-    tris_per_closest = trav["closest_tris"] / max(1, trav["closest_rays"])
-    nodes_per_any = trav["any_nodes"] / max(1, trav["any_rays"])
-    tris_per_any = trav["any_tris"] / max(1, trav["any_rays"])
-    # rays issued by the trace kernel per frame ~ measured split: trace issues (hw*hh non-sky) closest + shadow rays;
-    # use the per-frame average of the timed region minus the validate kernel's share (1/3 of frames run validate).
-    closest_per_frame = rays_closest / K
-    any_per_frame = rays_any / K
-    trace_share = 1.0 / (1.0 + 1.0 / 3.0)  # validate kernel traces the same count on every 3rd frame
-    bytes_per_closest = nodes_per_closest * 64 + tris_per_closest * 48 + 232
-    bytes_per_any = nodes_per_any * 64 + tris_per_any * 48
-    trace_bytes = hw * hh * 38 + trace_share * (closest_per_frame * bytes_per_closest + any_per_frame * bytes_per_any)
-    trace_ms = pass_ms[3]
-    achieved = trace_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-    roofline = {"kernel": "k_rtdgi_trace", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "avg_launch_ms": round(trace_ms, 4), "algorithmic_bytes_per_launch": int(trace_bytes),
-                "nodes_per_closest_ray": round(nodes_per_closest, 2), "tris_per_closest_ray": round(tris_per_closest, 2),
-                "nodes_per_any_ray": round(nodes_per_any, 2), "tris_per_any_ray": round(tris_per_any, 2),
-                "dominant_by_time": dom_name}
+        hw, hh = (W + 1) // 2, (H + 1) // 2
+        # dominant kernel: pick by measured time
+        dom = max(range(11), key=lambda k: pass_ms[k])
+        dom_name = lib.GpuPipeline.PASS_NAMES[dom]
+        # algorithmic bytes of `rtdgi trace` per launch: 38 B/half-res px of surface I/O
+        #   + per ray: nodes visited x 64 B + triangles tested x 48 B (instrumented) + 232 B hit shading per closest hit
+        nodes_per_closest = trav["closest_nodes"] / max(1, trav["closest_rays"])
+        tris_per_closest = trav["closest_tris"] / max(1, trav["closest_rays"])
+        nodes_per_any = trav["any_nodes"] / max(1, trav["any_rays"])
+        tris_per_any = trav["any_tris"] / max(1, trav["any_rays"])
+        # rays issued by the trace kernel per frame ~ measured split: trace issues (hw*hh non-sky) closest + shadow rays;
+        # use the per-frame average of the timed region minus the validate kernel's share (1/3 of frames run validate).
+        closest_per_frame = rays_closest / K
+        any_per_frame = rays_any / K
+        trace_share = 1.0 / (1.0 + 1.0 / 3.0)  # validate kernel traces the same count on every 3rd frame
+        bytes_per_closest = nodes_per_closest * 64 + tris_per_closest * 48 + 232
+        bytes_per_any = nodes_per_any * 64 + tris_per_any * 48
+        trace_bytes = hw * hh * 38 + trace_share * (closest_per_frame * bytes_per_closest + any_per_frame * bytes_per_any)
+        trace_ms = pass_ms[3]
+        achieved = trace_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        roofline = {"kernel": "k_rtdgi_trace", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_ms": round(trace_ms, 4), "algorithmic_bytes_per_launch": int(trace_bytes),
+                    "nodes_per_closest_ray": round(nodes_per_closest, 2), "tris_per_closest_ray": round(tris_per_closest, 2),
+                    "nodes_per_any_ray": round(nodes_per_any, 2), "tris_per_any_ray": round(tris_per_any, 2),
+                    "dominant_by_time": dom_name}
 
     ms_per_step = 1e3 * elapsed / K
     out = {
         "metric": "gi_mrays_per_s", "value": round(total_rays_all / elapsed / 1e6, 3), "unit": "Mrays/s",
         "gi_frame_ms": round(ms_per_step, 4), "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{scene_label}, {W}x{H}, rtdgi: reproject+validate+trace+validity+temporal ReSTIR+2x spatial ReSTIR+"
-                               "resolve+temporal+spatial denoise, irradiance cache (scroll/age/compact, accessibility+validate+trace rays, SH sum); TAA not in this build",
+                               "resolve+temporal+spatial denoise, irradiance cache (scroll/age/compact, accessibility+validate+trace rays, SH sum), TAA (7 passes) on the GI output",
                    "triangles": stats["triangles"], "bvh_nodes": stats["nodes"], "bvh_bytes": stats["bvh_bytes"],
-                   "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (screen-tile split not in this build)"},
-        "pass_ms": {n: round(v, 4) for n, v in zip(lib.GpuPipeline.PASS_NAMES, pass_ms)},
+                   "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": "single GPU" if nsplit <= 1 else f"{nsplit}-way screen-tile split (16-row-aligned strips; halo exchange + temporal2 all-gather over "
+                                  + ("RCCL P2P" if world > 1 else "virtual ranks on one GPU") + f"; motion halo {args.motion_halo} rows; irradiance cache replicated per rank)"},
+        "segment_ms": seg,
+        "pass_ms": {n: round(v, 4) for n, v in zip(lib.GpuPipeline.PASS_NAMES, pass_ms)} if pass_ms else None,
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:  # respect a cgroup CPU quota: oversubscribed OpenMP threads spin and distort the baseline
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                cores = max(1, min(cores, int(int(q) / int(per))))
+        except Exception:
+            pass
+        cores = min(cores, 64)
         out["cpu_baseline"] = cpu_baseline(desc, cam_args, cores)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -251,6 +251,11 @@ typedef struct KjRtdgiRenderParams {
     KjIrcache* ircache;            /* &mut IrcacheRenderState; NULL => lookups return 0 (BASELINE config 1) */
     const void* ssao_tex;          /* R8_UNORM full res */
     uint32_t pass_mask;            /* KJ_RTDGI_PASS_ALL for the product path */
+    /* Screen-tile split (multi-GPU): process only full-res rows [row_begin, row_end) (16-aligned; half-res
+     * passes use [row_begin/2, row_end/2)). 0,0 = whole image. Reads reach outside the range; the caller
+     * exchanges halos between passes (kajiya_amd/multigpu.py). */
+    uint32_t row_begin, row_end;
+    uint32_t spatial_pass_select;  /* 0 = run every spatial reuse pass; k>0 = only pass k-1 (halo exchange between passes) */
 } KjRtdgiRenderParams;
 
 typedef struct KjRtdgiOutput { /* RtdgiOutput / RtdgiCandidates, rtdgi.rs:53-62 */
@@ -317,6 +322,12 @@ void kj_taa_destroy(KjTaa* t);
  * reprojection_map RGBA16_SNORM and depth R32F are at the input (render) extent. */
 KjStatus kj_taa_render(KjTaa* t, const void* input_tex, uint32_t input_width, uint32_t input_height, const void* reprojection_map,
                        const void* depth_tex, uint32_t output_width, uint32_t output_height, KjTaaOutput* out, void* stream);
+/* Strip / pass-by-pass variant used by the screen-tile split (kajiya_amd/multigpu.py). pass_mask bits 0..6 =
+ * reproject, filter input, filter history, input prob, prob filter, prob filter2, taa; bit 31 = keep the
+ * previous call's ping-pong assignment. Rows are 8-aligned and need input extent == output extent. */
+KjStatus kj_taa_render_rows(KjTaa* t, const void* input_tex, uint32_t input_width, uint32_t input_height, const void* reprojection_map,
+                            const void* depth_tex, uint32_t output_width, uint32_t output_height, KjTaaOutput* out, void* stream,
+                            uint32_t pass_mask, uint32_t row_begin, uint32_t row_end);
 KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 
 #ifdef __cplusplus

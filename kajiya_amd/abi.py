@@ -78,6 +78,7 @@ class KjRtdgiRenderParams(C.Structure):
         ("ircache", C.c_void_p),
         ("ssao_tex", C.c_void_p),
         ("pass_mask", c_u32),
+        ("row_begin", c_u32), ("row_end", c_u32), ("spatial_pass_select", c_u32),
     ]
 
 

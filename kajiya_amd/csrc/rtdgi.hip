@@ -26,14 +26,16 @@ typedef Img<uint8_t> ImgR8;
 typedef Img<int8_t> ImgR8S;
 typedef Img<float4> ImgF4;
 
+// Row-range aware tile mapping: a launch covers image rows [row0, row1) of the kernel's own resolution
+// (row0 a multiple of 8) so the same kernels serve the screen-tile split across GPUs.
 #define TILE_XY(W_, H_)                                                   \
     const int lane = threadIdx.x;                                         \
-    const int x = int(blockIdx.x) * 8 + (lane & 7), y = int(blockIdx.y) * 8 + (lane >> 3); \
-    const bool in_image = x < (W_) && y < (H_);
+    const int x = int(blockIdx.x) * 8 + (lane & 7), y = row0 + int(blockIdx.y) * 8 + (lane >> 3); \
+    const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
 // ------------------------------------------------------------------ extract_half_res_{gbuffer_view_normal_rgba8,depth,ssao}.hlsl (fused)
 __global__ void __launch_bounds__(64) k_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgR8 ssao, ImgU32 half_view_normal,
-                                                      ImgF32 half_depth, ImgR8S half_ssao) {
+                                                      ImgF32 half_depth, ImgR8S half_ssao, int row0, int row1) {
     TILE_XY(half_depth.w, half_depth.h)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
@@ -54,7 +56,7 @@ KJ_D V4 cubic_hermite(V4 A, V4 B, V4 C, V4 D, float t) {  // inc/curve.hlsl:4-13
     const V4 c = -A / 2.0f + C / 2.0f;
     return a * t3 + b * t2 + c * t + B;
 }
-__global__ void __launch_bounds__(64) k_fullres_reproject(ImgH4 input_tex, ImgU2 reprojection_tex, ImgH4 output_tex) {
+__global__ void __launch_bounds__(64) k_fullres_reproject(ImgH4 input_tex, ImgU2 reprojection_tex, ImgH4 output_tex, int row0, int row1) {
     const int W = output_tex.w, H = output_tex.h;
     TILE_XY(W, H)
     if (!in_image) return;
@@ -207,7 +209,7 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
 // ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111
 template <bool STATS>
 __global__ void __launch_bounds__(64) k_rtdgi_validate(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
-                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex) {
+                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
     extern __shared__ uint32_t lds_stack[];
     TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
     if (!in_image) return;
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(64) k_rtdgi_validate(TraceCtx c, ImgU32 half_v
 // ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24
 template <bool STATS>
 __global__ void __launch_bounds__(64) k_rtdgi_trace(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
-                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex) {
+                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
     extern __shared__ uint32_t lds_stack[];
     TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
     if (!in_image) return;
@@ -285,9 +287,8 @@ __global__ void __launch_bounds__(64) k_rtdgi_trace(TraceCtx c, ImgU32 half_view
 // ------------------------------------------------------------------ temporal_validity_integrate.hlsl:21-119
 // WaveReadLaneAt(v, lane^k) inside the 8x8 group == __shfl_xor(v, k) on wave64.
 __global__ void __launch_bounds__(64) k_validity_integrate(const FrameConstants* __restrict__ fcp, ImgR8 input_tex, ImgU32 history_tex /*RG16F*/, ImgU2 reprojection_tex,
-                                                            ImgF32 half_depth_tex, ImgU32 output_tex /*RG16F*/, int W, int H) {
+                                                            ImgF32 half_depth_tex, ImgU32 output_tex /*RG16F*/, int W, int H, int row0, int row1) {
     TILE_XY(output_tex.w, output_tex.h)
-    (void)in_image;  // lanes outside the image still take part in the shuffles (loads return 0)
     const FrameConstants& fc = *fcp;
     V2 invalid_blurred{0, 0};
 #pragma unroll
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(64) k_validity_integrate(const FrameConstants*
         history += ld2h(history_tex, int(reproj_px.x + so.x), int(reproj_px.y + so.y)).x;
     }
     history /= 8;
-    st2h(output_tex, x, y, V2{fmaxf(history * 0.75f, ib), from_unorm8(input_tex.ld(x, y))});
+    if (in_image) st2h(output_tex, x, y, V2{fmaxf(history * 0.75f, ib), from_unorm8(input_tex.ld(x, y))});
 }
 
 // ------------------------------------------------------------------ restir_temporal.hlsl:83-422
@@ -336,8 +337,10 @@ struct RestirTemporalArgs {
     ImgH4 hit_normal_history_tex; ImgH4 candidate_history_tex; ImgU32 rt_invalidity_tex;
     ImgH4 radiance_out_tex; ImgF4 ray_orig_output_tex; ImgH4 ray_output_tex; ImgH4 hit_normal_output_tex; ImgU2 reservoir_out_tex;
     ImgH4 candidate_out_tex; ImgU4 temporal_reservoir_packed_tex;
+    int row0, row1;
 };
 __global__ void __launch_bounds__(64) k_restir_temporal(RestirTemporalArgs a) {
+    const int row0 = a.row0, row1 = a.row1;
     TILE_XY(a.reservoir_out_tex.w, a.reservoir_out_tex.h)
     if (!in_image) return;
     const FrameConstants& fc = *a.fc;
@@ -487,7 +490,7 @@ KJ_D void occlusion_raymarch(const FrameConstants& fc, V2 start_uv, V3 start_cs,
 KJ_D float normal_inluence_nonlinearity(float x, float b) { return x < -b ? 0.0f : (x + b) * (x + b) / (4 * b); }
 __global__ void __launch_bounds__(64) k_restir_spatial(const FrameConstants* __restrict__ fcp, ImgU2 reservoir_input_tex, ImgU32 half_view_normal_tex, ImgF32 half_depth_tex,
                                                         ImgR8S half_ssao_tex, ImgU4 temporal_reservoir_packed_tex, ImgU2 reservoir_output_tex, int W, int H,
-                                                        uint32_t spatial_reuse_pass_idx, uint32_t perform_occlusion_raymarch, uint32_t occlusion_raymarch_importance_only) {
+                                                        uint32_t spatial_reuse_pass_idx, uint32_t perform_occlusion_raymarch, uint32_t occlusion_raymarch_importance_only, int row0, int row1) {
     const int hw = reservoir_output_tex.w, hh = reservoir_output_tex.h;
     TILE_XY(hw, hh)
     if (!in_image) return;
@@ -587,8 +590,10 @@ struct ResolveArgs {
     ImgH4 radiance_tex; ImgU2 reservoir_input_tex; ImgU4 gbuffer_tex; ImgF32 depth_tex; ImgU32 half_view_normal_tex; ImgF32 half_depth_tex; ImgR8 ssao_tex;
     ImgH4 candidate_radiance_tex; ImgH4 candidate_hit_tex; ImgU4 temporal_reservoir_packed_tex; ImgH4 irradiance_output_tex;
     const uint32_t* __restrict__ blue_noise;
+    int row0, row1;
 };
 __global__ void __launch_bounds__(64) k_restir_resolve(ResolveArgs a) {
+    const int row0 = a.row0, row1 = a.row1;
     const int W = a.irradiance_output_tex.w, H = a.irradiance_output_tex.h;
     TILE_XY(W, H)
     if (!in_image) return;
@@ -681,7 +686,7 @@ __global__ void __launch_bounds__(64) k_restir_resolve(ResolveArgs a) {
 // ------------------------------------------------------------------ temporal_filter.hlsl:39-252
 __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgH4 history_tex, ImgU32 variance_history_tex /*RG16F*/,
                                                          ImgU2 reprojection_tex, ImgU32 rt_history_invalidity_tex /*RG16F half*/, ImgH4 output_tex, ImgH4 history_output_tex,
-                                                         ImgU32 variance_history_output_tex) {
+                                                         ImgU32 variance_history_output_tex, int row0, int row1) {
     const int W = output_tex.w, H = output_tex.h;
     TILE_XY(W, H)
     if (!in_image) return;
@@ -738,7 +743,7 @@ __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __
 // ------------------------------------------------------------------ spatial_filter.hlsl:34-101
 KJ_D V3 crunch(V3 v) { return v * (1.0f / (max3(v.x, v.y, v.z) + 1.0f)); }
 KJ_D V3 uncrunch(V3 v) { return v * (1.0f / (1.0f - max3(v.x, v.y, v.z))); }
-__global__ void __launch_bounds__(64) k_spatial_filter(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgF32 depth_tex, ImgR8 ssao_tex, ImgU32 geometric_normal_tex, ImgH4 output_tex) {
+__global__ void __launch_bounds__(64) k_spatial_filter(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgF32 depth_tex, ImgR8 ssao_tex, ImgU32 geometric_normal_tex, ImgH4 output_tex, int row0, int row1) {
     TILE_XY(output_tex.w, output_tex.h)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
@@ -851,7 +856,7 @@ KjStatus kj_rtdgi_reproject(KjRtdgi* r, const void* reprojection_map, uint32_t w
     KJ_TRY_HIP(r->err);
     SCOPE_BEGIN(0);
     hipLaunchKernelGGL(k_fullres_reproject, dim3((W + 7) / 8, (H + 7) / 8), dim3(64), 0, s, img<uint2>(history, W, H), img<uint2>(reprojection_map, W, H),
-                       img<uint2>(r->reprojected_history_tex, W, H));
+                       img<uint2>(r->reprojected_history_tex, W, H), 0, H);
     KJ_CHECK_LAUNCH();
     SCOPE_END(0);
     return KJ_OK;
@@ -868,7 +873,14 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     const FrameConstants* fc = r->dev->fc_dev;
     const uint32_t mask = p->pass_mask;
     if (mask & KJ_RTDGI_PASS_KEEP_TEMPORALS) for (bool& f : r->flip) f = !f;
-    const dim3 gh((hw + 7) / 8, (hh + 7) / 8), gf((W + 7) / 8, (H + 7) / 8), blk(64);
+    // rows of this call (screen-tile split): full-res [fr0, fr1), half-res [hr0, hr1); 0,0 = whole image
+    int fr0 = 0, fr1 = H;
+    if (p->row_end > p->row_begin) {
+        KJ_REQUIRE(p->row_begin % 16 == 0 && (p->row_end % 16 == 0 || int(p->row_end) == H) && int(p->row_end) <= H, "row range must be 16-aligned (8x8 half-res tiles)");
+        fr0 = int(p->row_begin); fr1 = int(p->row_end);
+    }
+    const int hr0 = fr0 / 2, hr1 = fr1 == H ? hh : fr1 / 2;
+    const dim3 gh((hw + 7) / 8, (hr1 - hr0 + 7) / 8), gf((W + 7) / 8, (fr1 - fr0 + 7) / 8), blk(64);
     const size_t HB = size_t(hw) * hh, FB = size_t(W) * H;
 
     const ImgU4 gbuffer = img<uint4>(p->gbuffer_depth.gbuffer, W, H);
@@ -900,7 +912,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     void* temporal_filtered = r->get("temporal_filtered_tex", FB * 8, s);
     void* spatial_filtered = r->get("spatial_filtered_tex", FB * 8, s);
     KJ_TRY_HIP(r->err);
-    KJ_TRY_HIP(hipMemsetAsync(r->ray_counters.p, 0, 48, s));
+    if (!(p->pass_mask & KJ_RTDGI_PASS_KEEP_TEMPORALS)) KJ_TRY_HIP(hipMemsetAsync(r->ray_counters.p, 0, 48, s));  // per frame; pass-by-pass calls accumulate
 
     TraceCtx tc;
     tc.fc = fc;
@@ -920,28 +932,28 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
 
     if (mask & KJ_RTDGI_PASS_EXTRACT_HALF) {
         SCOPE_BEGIN(1);
-        hipLaunchKernelGGL(k_extract_half, gh, blk, 0, s, fc, gbuffer, depth, ssao, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), img<int8_t>(half_ssao, hw, hh));
+        hipLaunchKernelGGL(k_extract_half, gh, blk, 0, s, fc, gbuffer, depth, ssao, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), img<int8_t>(half_ssao, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(1);
     }
     if (mask & KJ_RTDGI_PASS_VALIDATE) {
         SCOPE_BEGIN(2);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate<true> : k_rtdgi_validate<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
-                           img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh));
+                           img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(2);
     }
     if (mask & KJ_RTDGI_PASS_TRACE) {
         SCOPE_BEGIN(3);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace<true> : k_rtdgi_trace<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
-                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh));
+                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
     }
     if (mask & KJ_RTDGI_PASS_VALIDITY_INTEGRATE) {
         SCOPE_BEGIN(4);
         hipLaunchKernelGGL(k_validity_integrate, gh, blk, 0, s, fc, img<uint8_t>(validity_in, hw, hh), img<uint32_t>(invalidity_hist, hw, hh), reprojection,
-                           img<float>(half_depth, hw, hh), img<uint32_t>(invalidity_out, hw, hh), W, H);
+                           img<float>(half_depth, hw, hh), img<uint32_t>(invalidity_out, hw, hh), W, H, hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(4);
     }
@@ -968,6 +980,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         a.candidate_out_tex = img<uint2>(candidate_out, hw, hh);
         a.temporal_reservoir_packed_tex = img<uint4>(temporal_reservoir_packed, hw, hh);
         SCOPE_BEGIN(5);
+        a.row0 = hr0; a.row1 = hr1;
         hipLaunchKernelGGL(k_restir_temporal, gh, blk, 0, s, a);
         KJ_CHECK_LAUNCH();
         SCOPE_END(5);
@@ -975,10 +988,10 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     void* reservoir_input = reservoir_out;
     for (uint32_t i = 0; i < r->spatial_reuse_pass_count; ++i) {
         const uint32_t perform_occlusion_raymarch = (i + 1 == r->spatial_reuse_pass_count) ? 1u : 0u;
-        if (mask & KJ_RTDGI_PASS_RESTIR_SPATIAL) {
+        if ((mask & KJ_RTDGI_PASS_RESTIR_SPATIAL) && (p->spatial_pass_select == 0 || p->spatial_pass_select == i + 1)) {
             SCOPE_BEGIN((6 + (i ? 1 : 0)));
             hipLaunchKernelGGL(k_restir_spatial, gh, blk, 0, s, fc, img<uint2>(reservoir_input, hw, hh), img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh),
-                               img<int8_t>(half_ssao, hw, hh), img<uint4>(temporal_reservoir_packed, hw, hh), img<uint2>(reservoir_tex0, hw, hh), W, H, i, perform_occlusion_raymarch, 0u);
+                               img<int8_t>(half_ssao, hw, hh), img<uint4>(temporal_reservoir_packed, hw, hh), img<uint2>(reservoir_tex0, hw, hh), W, H, i, perform_occlusion_raymarch, 0u, hr0, hr1);
             KJ_CHECK_LAUNCH();
             SCOPE_END((6 + (i ? 1 : 0)));
         }
@@ -1000,6 +1013,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         a.irradiance_output_tex = img<uint2>(irradiance, W, H);
         a.blue_noise = (const uint32_t*)r->dev->blue_noise.p;
         SCOPE_BEGIN(8);
+        a.row0 = fr0; a.row1 = fr1;
         hipLaunchKernelGGL(k_restir_resolve, gf, blk, 0, s, a);
         KJ_CHECK_LAUNCH();
         SCOPE_END(8);
@@ -1008,13 +1022,13 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         SCOPE_BEGIN(9);
         hipLaunchKernelGGL(k_temporal_filter, gf, blk, 0, s, fc, img<uint2>(irradiance, W, H), img<uint2>(r->reprojected_history_tex, W, H), img<uint32_t>(variance_hist, W, H),
                            reprojection, img<uint32_t>(invalidity_out, hw, hh), img<uint2>(temporal_filtered, W, H), img<uint2>(r->temporal_output_tex, W, H),
-                           img<uint32_t>(variance_out, W, H));
+                           img<uint32_t>(variance_out, W, H), fr0, fr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(9);
     }
     if (mask & KJ_RTDGI_PASS_SPATIAL_FILTER) {
         SCOPE_BEGIN(10);
-        hipLaunchKernelGGL(k_spatial_filter, gf, blk, 0, s, fc, img<uint2>(temporal_filtered, W, H), depth, ssao, geometric_normal, img<uint2>(spatial_filtered, W, H));
+        hipLaunchKernelGGL(k_spatial_filter, gf, blk, 0, s, fc, img<uint2>(temporal_filtered, W, H), depth, ssao, geometric_normal, img<uint2>(spatial_filtered, W, H), fr0, fr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(10);
     }

@@ -11,10 +11,11 @@ typedef Img<uint32_t> ImgH2;   // RG16F
 typedef Img<uint16_t> ImgH1;   // R16F
 typedef Img<float> ImgF32;
 
+// Row-range aware tile mapping (see rtdgi.hip): rows [row0, row1) of the kernel's own resolution.
 #define TILE_XY(W_, H_)                                                                          \
     const int lane = threadIdx.x;                                                                \
-    const int x = int(blockIdx.x) * 8 + (lane & 7), y = int(blockIdx.y) * 8 + (lane >> 3);     \
-    const bool in_image = x < (W_) && y < (H_);
+    const int x = int(blockIdx.x) * 8 + (lane & 7), y = row0 + int(blockIdx.y) * 8 + (lane >> 3); \
+    const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
 // taa_common.hlsl (TAA_NONLINEARITY_TYPE 1, TAA_COLOR_MAPPING_MODE 1)
 KJ_D V3 taa_decode_rgb(V3 v) { const float m = max3(v.x, v.y, v.z); return v * sqrtf(fmaxf(0.0f, m)) / fmaxf(1e-20f, m); }
@@ -48,10 +49,9 @@ KJ_D V4 catmull_rom_5tap_history(const ImgH4& tex, V2 uv, V2 tex_size, float ped
 
 // reproject_history.hlsl:42-129
 __global__ void __launch_bounds__(64) k_taa_reproject(const FrameConstants* __restrict__ fc, ImgH4 history_tex, ImgH4 reprojection_tex, ImgF32 depth_tex, ImgH4 output_tex,
-                                                       ImgH2 closest_velocity_output, int IW, int IH) {
+                                                       ImgH2 closest_velocity_output, int IW, int IH, int row0, int row1) {
     const int OW = output_tex.w, OH = output_tex.h;
     TILE_XY(OW, OH)
-    (void)in_image;  // all 64 lanes take part in the vote; stores are bounds-checked
     const V4 its = tex_size4(IW, IH), ots = tex_size4(OW, OH);
     const V2 scale{its.x / ots.x, its.y / ots.y};
     const int rx = int(uint32_t((float(x) + 0.5f) * scale.x)), ry = int(uint32_t((float(y) + 0.5f) * scale.y));
@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(64) k_taa_reproject(const FrameConstants* __re
     }
     const V4 rr = ld_reproj(reprojection_tex, cx, cy);
     const V2 reproj_xy{rr.x, rr.y};
+    if (!in_image) return;  // after the wave vote
     st2h(closest_velocity_output, x, y, reproj_xy);
     const V2 uv = get_uv(float(x), float(y), ots);
     const V4 hp = catmull_rom_5tap_history(history_tex, uv + reproj_xy, V2{ots.x, ots.y}, fc->pre_exposure_delta);
@@ -110,7 +111,7 @@ KJ_D FilteredInput filter_input_inner(const ImgH4& input_tex, const ImgF32& dept
     iex2 = iex2 / iwsum;
     return FilteredInput{clamped_iex, vmax(v3(0.0f), iex2 - iex * iex)};
 }
-__global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32 depth_tex, ImgH4 output_tex, ImgH4 dev_output_tex) {
+__global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32 depth_tex, ImgH4 output_tex, ImgH4 dev_output_tex, int row0, int row1) {
     TILE_XY(output_tex.w, output_tex.h)
     if (!in_image) return;
     const float center_depth = depth_tex.ld(x, y);
@@ -135,7 +136,7 @@ KJ_D V3 fh_filter_input(const ImgH4& input_tex, V2 uv, float luma_cutoff, int k)
         }
     return iex / iwsum;
 }
-__global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_history, ImgH4 output_tex) {
+__global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_history, ImgH4 output_tex, int row0, int row1) {
     TILE_XY(output_tex.w, output_tex.h)
     if (!in_image) return;
     const int k = (float(reprojected_history.w) / float(output_tex.w) > 1.75f) ? 2 : 1;
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_his
 
 // input_prob.hlsl:50-108
 __global__ void __launch_bounds__(64) k_taa_input_prob(const FrameConstants* __restrict__ fc, ImgH4 filtered_input_tex, ImgH4 filtered_input_dev_tex, ImgH4 filtered_history_tex,
-                                                        ImgH4 reprojection_tex, ImgH4 smooth_var_history_tex, ImgH2 velocity_history_tex, ImgH1 output_tex) {
+                                                        ImgH4 reprojection_tex, ImgH4 smooth_var_history_tex, ImgH2 velocity_history_tex, ImgH1 output_tex, int row0, int row1) {
     const int IW = output_tex.w, IH = output_tex.h;
     TILE_XY(IW, IH)
     if (!in_image) return;
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(64) k_taa_input_prob(const FrameConstants* __r
     output_tex.st(x, y, f32_to_f16(input_prob));
 }
 // filter_prob.hlsl, filter_prob2.hlsl
-__global__ void __launch_bounds__(64) k_taa_filter_prob(ImgH1 input_tex, ImgH1 output_tex) {
+__global__ void __launch_bounds__(64) k_taa_filter_prob(ImgH1 input_tex, ImgH1 output_tex, int row0, int row1) {
     TILE_XY(output_tex.w, output_tex.h)
     if (!in_image) return;
     float prob = ld1h(input_tex, x, y);
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(64) k_taa_filter_prob(ImgH1 input_tex, ImgH1 o
         for (int ox = -1; ox <= 1; ++ox) prob = fmaxf(prob, ld1h(input_tex, x + ox, y + oy));
     output_tex.st(x, y, f32_to_f16(prob));
 }
-__global__ void __launch_bounds__(64) k_taa_filter_prob2(ImgH1 input_tex, ImgH1 output_tex) {
+__global__ void __launch_bounds__(64) k_taa_filter_prob2(ImgH1 input_tex, ImgH1 output_tex, int row0, int row1) {
     TILE_XY(output_tex.w, output_tex.h)
     if (!in_image) return;
     V2 weighted{0, 0};
@@ -233,8 +234,10 @@ struct TaaArgs {
     const FrameConstants* __restrict__ fc;
     ImgH4 input_tex, history_tex, reprojection_tex; ImgH2 closest_velocity_tex, velocity_history_tex; ImgH4 smooth_var_history_tex; ImgH1 input_prob_tex;
     ImgH4 temporal_output_tex, output_tex, smooth_var_output_tex; ImgH2 velocity_output_tex;
+    int row0, row1;
 };
 __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
+    const int row0 = a.row0, row1 = a.row1;
     const int OW = a.temporal_output_tex.w, OH = a.temporal_output_tex.h;
     TILE_XY(OW, OH)
     if (!in_image) return;
@@ -360,8 +363,8 @@ KjStatus kj_taa_create(KjDevice* dev, KjTaa** out) {
 void kj_taa_destroy(KjTaa* t) { delete t; }
 
 // TaaRenderer::render (taa.rs:41-191)
-KjStatus kj_taa_render(KjTaa* t, const void* input_tex, uint32_t input_width, uint32_t input_height, const void* reprojection_map, const void* depth_tex,
-                       uint32_t output_width, uint32_t output_height, KjTaaOutput* out, void* stream_) {
+static KjStatus taa_render_impl(KjTaa* t, const void* input_tex, uint32_t input_width, uint32_t input_height, const void* reprojection_map, const void* depth_tex,
+                                uint32_t output_width, uint32_t output_height, KjTaaOutput* out, void* stream_, uint32_t mask, uint32_t row_begin, uint32_t row_end) {
     KJ_REQUIRE(t && input_tex && reprojection_map && depth_tex && out && input_width && input_height && output_width && output_height, "null argument");
     KJ_REQUIRE(t->dev->fc_dev, "kj_frame_begin not called");
     hipStream_t s = (hipStream_t)stream_;
@@ -369,7 +372,14 @@ KjStatus kj_taa_render(KjTaa* t, const void* input_tex, uint32_t input_width, ui
     if (IW != t->IW || IH != t->IH || OW != t->OW || OH != t->OH) { t->surf.clear(); t->IW = IW; t->IH = IH; t->OW = OW; t->OH = OH; }
     const FrameConstants* fc = t->dev->fc_dev;
     const size_t OB = size_t(OW) * OH, IB = size_t(IW) * IH;
-    const dim3 go((OW + 7) / 8, (OH + 7) / 8), gi((IW + 7) / 8, (IH + 7) / 8), blk(64);
+    if (mask & 0x80000000u) for (bool& f : t->flip) f = !f;  // KEEP_TEMPORALS: same ping-pong assignment as the previous call
+    int or0 = 0, or1 = OH;
+    if (row_end > row_begin) {
+        KJ_REQUIRE(IW == OW && IH == OH, "row ranges need input extent == output extent");
+        KJ_REQUIRE(row_begin % 8 == 0 && (row_end % 8 == 0 || int(row_end) == OH) && int(row_end) <= OH, "row range must be 8-aligned");
+        or0 = int(row_begin); or1 = int(row_end);
+    }
+    const int ir0 = or0, ir1 = or1;
     void *temporal_out, *history; t->pingpong("taa", 0, OB * 8, s, temporal_out, history);
     void *vel_out, *vel_hist;     t->pingpong("taa.velocity", 1, OB * 4, s, vel_out, vel_hist);
     void* reprojected_history = t->get("reprojected_history_img", OB * 8, s);
@@ -383,32 +393,58 @@ KjStatus kj_taa_render(KjTaa* t, const void* input_tex, uint32_t input_width, ui
     void* prob2 = t->get("prob_filtered2_img", IB * 2, s);
     void* this_frame = t->get("this_frame_output_img", OB * 8, s);
     KJ_TRY_HIP(t->err);
+    const dim3 go((OW + 7) / 8, (or1 - or0 + 7) / 8), gi((IW + 7) / 8, (ir1 - ir0 + 7) / 8), blk(64);
     const ImgH4 input = img<uint2>(input_tex, IW, IH), reproj = img<uint2>(reprojection_map, IW, IH);
     const ImgF32 depth = img<float>(depth_tex, IW, IH);
-    hipLaunchKernelGGL(k_taa_reproject, go, blk, 0, s, fc, img<uint2>(history, OW, OH), reproj, depth, img<uint2>(reprojected_history, OW, OH), img<uint32_t>(closest_velocity, OW, OH), IW, IH);
-    KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_taa_filter_input, gi, blk, 0, s, input, depth, img<uint2>(filtered_input, IW, IH), img<uint2>(filtered_input_dev, IW, IH));
-    KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_taa_filter_history, gi, blk, 0, s, img<uint2>(reprojected_history, OW, OH), img<uint2>(filtered_history, IW, IH));
-    KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_taa_input_prob, gi, blk, 0, s, fc, img<uint2>(filtered_input, IW, IH), img<uint2>(filtered_input_dev, IW, IH), img<uint2>(filtered_history, IW, IH), reproj,
-                       img<uint2>(sv_hist, OW, OH), img<uint32_t>(vel_hist, OW, OH), img<uint16_t>(input_prob, IW, IH));
-    KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_taa_filter_prob, gi, blk, 0, s, img<uint16_t>(input_prob, IW, IH), img<uint16_t>(prob1, IW, IH));
-    KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_taa_filter_prob2, gi, blk, 0, s, img<uint16_t>(prob1, IW, IH), img<uint16_t>(prob2, IW, IH));
-    KJ_CHECK_LAUNCH();
+    if (mask & 1u) {
+        hipLaunchKernelGGL(k_taa_reproject, go, blk, 0, s, fc, img<uint2>(history, OW, OH), reproj, depth, img<uint2>(reprojected_history, OW, OH), img<uint32_t>(closest_velocity, OW, OH), IW, IH, or0, or1);
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & 2u) {
+        hipLaunchKernelGGL(k_taa_filter_input, gi, blk, 0, s, input, depth, img<uint2>(filtered_input, IW, IH), img<uint2>(filtered_input_dev, IW, IH), ir0, ir1);
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & 4u) {
+        hipLaunchKernelGGL(k_taa_filter_history, gi, blk, 0, s, img<uint2>(reprojected_history, OW, OH), img<uint2>(filtered_history, IW, IH), ir0, ir1);
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & 8u) {
+        hipLaunchKernelGGL(k_taa_input_prob, gi, blk, 0, s, fc, img<uint2>(filtered_input, IW, IH), img<uint2>(filtered_input_dev, IW, IH), img<uint2>(filtered_history, IW, IH), reproj,
+                       img<uint2>(sv_hist, OW, OH), img<uint32_t>(vel_hist, OW, OH), img<uint16_t>(input_prob, IW, IH), ir0, ir1);
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & 16u) {
+        hipLaunchKernelGGL(k_taa_filter_prob, gi, blk, 0, s, img<uint16_t>(input_prob, IW, IH), img<uint16_t>(prob1, IW, IH), ir0, ir1);
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & 32u) {
+        hipLaunchKernelGGL(k_taa_filter_prob2, gi, blk, 0, s, img<uint16_t>(prob1, IW, IH), img<uint16_t>(prob2, IW, IH), ir0, ir1);
+        KJ_CHECK_LAUNCH();
+    }
     TaaArgs a;
     a.fc = fc; a.input_tex = input; a.history_tex = img<uint2>(reprojected_history, OW, OH); a.reprojection_tex = reproj;
     a.closest_velocity_tex = img<uint32_t>(closest_velocity, OW, OH); a.velocity_history_tex = img<uint32_t>(vel_hist, OW, OH);
     a.smooth_var_history_tex = img<uint2>(sv_hist, OW, OH); a.input_prob_tex = img<uint16_t>(prob2, IW, IH);
     a.temporal_output_tex = img<uint2>(temporal_out, OW, OH); a.output_tex = img<uint2>(this_frame, OW, OH);
     a.smooth_var_output_tex = img<uint2>(sv_out, OW, OH); a.velocity_output_tex = img<uint32_t>(vel_out, OW, OH);
-    hipLaunchKernelGGL(k_taa, go, blk, 0, s, a);
-    KJ_CHECK_LAUNCH();
+    a.row0 = or0; a.row1 = or1;
+    if (mask & 64u) {
+        hipLaunchKernelGGL(k_taa, go, blk, 0, s, a);
+        KJ_CHECK_LAUNCH();
+    }
     out->temporal_out = temporal_out;
     out->this_frame_out = this_frame;
     return KJ_OK;
+}
+KjStatus kj_taa_render(KjTaa* t, const void* input_tex, uint32_t input_width, uint32_t input_height, const void* reprojection_map, const void* depth_tex,
+                       uint32_t output_width, uint32_t output_height, KjTaaOutput* out, void* stream) {
+    return taa_render_impl(t, input_tex, input_width, input_height, reprojection_map, depth_tex, output_width, output_height, out, stream, 127u, 0, 0);
+}
+// Pass-by-pass / strip variant for the screen-tile split: pass_mask bits 0..6 = reproject, filter input, filter history,
+// input prob, prob filter, prob filter2, taa; bit 31 = keep the previous call's ping-pong assignment.
+KjStatus kj_taa_render_rows(KjTaa* t, const void* input_tex, uint32_t input_width, uint32_t input_height, const void* reprojection_map, const void* depth_tex,
+                            uint32_t output_width, uint32_t output_height, KjTaaOutput* out, void* stream, uint32_t pass_mask, uint32_t row_begin, uint32_t row_end) {
+    return taa_render_impl(t, input_tex, input_width, input_height, reprojection_map, depth_tex, output_width, output_height, out, stream, pass_mask, row_begin, row_end);
 }
 KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t* out_bytes) {
     KJ_REQUIRE(t && name && out_dev_ptr && out_bytes, "null argument");

@@ -25,7 +25,7 @@ EXPORTS = [
     "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
     "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts",
-    "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_surface",
+    "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface",
 ]
 
 _LIB = None
@@ -88,6 +88,7 @@ def load():
         "kj_taa_create": [vp, C.POINTER(vp)],
         "kj_taa_render": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp],
         "kj_taa_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
+        "kj_taa_render_rows": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp, u32, u32, u32],
     }
     for name, args in sig.items():
         f = getattr(L, name)

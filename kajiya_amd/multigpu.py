@@ -1,0 +1,234 @@
+"""Screen-tile split of the rtdgi frame across GPUs (BASELINE north_star: "partition across the
+GPUs of one node by screen-space tile with a halo exchange of reservoirs/history over RCCL/xGMI").
+
+One process per GPU. The full-res image is cut into horizontal strips aligned to 16 rows (so 8x8 half-res
+tiles never straddle a cut). Every rank keeps full-size surfaces but runs each pass only on its own rows
+(`KjRtdgiRenderParams.row_begin/row_end`); between passes the rows a consumer pass can reach are fetched
+from their owners:
+
+  * last frame's denoised GI (`rtdgi.temporal2`, + its variance) is ALL-GATHERED: the trace pass reads it at the
+    hit point's screen position, anywhere on screen (diffuse_trace_common.inc.hlsl:85-107);
+  * everything else is a bounded HALO: motion+4 rows of the five reservoir histories before the temporal
+    pass, 51 half-res rows of {reservoir, packed reservoir, radiance} after it (spatial 32 + 16, resolve 3;
+    restir_spatial.hlsl:89-97, restir_resolve.hlsl:89-96), 16 / 3 rows between the spatial passes, 2 / 16
+    full-res rows around the denoiser stencils.
+
+Inputs (G-buffer, depth, reprojection map, sky, BVH) are replicated, as is the world-space irradiance cache
+(each rank updates its replica from its own strip's rays; replicas therefore differ at noise level — with the
+cache unbound the split is bit-identical to the single-GPU frame, which tests/test_gpu_multigpu.py checks).
+
+Communication backends: `DistComm` = torch.distributed point-to-point (backend "nccl" = RCCL over xGMI, or
+"gloo" on CPU for the tests); `LocalComm` = N virtual ranks inside one process (single-GPU emulation used by
+the exactness test).
+"""
+import ctypes as C
+import numpy as np
+
+from .abi import KJ_RTDGI_PASS
+from . import lib as klib
+
+KEEP = 1 << 31
+
+# surface name -> (bytes per texel, resolution: "h" half / "f" full)
+SURF = {
+    "rtdgi.reservoir": (8, "h"), "rtdgi.ray_orig": (16, "h"), "rtdgi.ray": (8, "h"), "rtdgi.radiance": (8, "h"), "rtdgi.hit_normal": (8, "h"),
+    "rtdgi.invalidity": (4, "h"), "rtdgi.candidate": (8, "h"), "rtdgi.temporal2": (8, "f"), "rtdgi.temporal2_var": (4, "f"),
+    "rt_history_validity_pre_input_tex": (1, "h"), "rt_history_validity_input_tex": (1, "h"), "candidate_radiance_tex": (8, "h"),
+    "candidate_hit_tex": (8, "h"), "temporal_reservoir_packed_tex": (16, "h"), "reservoir_output_tex0": (8, "h"), "reservoir_output_tex1": (8, "h"),
+    "irradiance_output_tex": (8, "f"), "temporal_filtered_tex": (8, "f"), "spatial_filtered_tex": (8, "f"),
+}
+# TaaRenderer surfaces (all full-res; input extent == output extent in the split path)
+TAA_SURF = {"taa": 8, "taa.velocity": 4, "taa.smooth_var": 8, "this_frame_output_img": 8}
+
+
+def plan_strips(height, n):
+    """Full-res row ranges [(r0, r1)] per rank: 16-aligned cuts, as even as possible."""
+    units = (height + 15) // 16
+    base, extra = divmod(units, n)
+    out, u = [], 0
+    for r in range(n):
+        cnt = base + (1 if r < extra else 0)
+        r0, r1 = min(u * 16, height), min((u + cnt) * 16, height)
+        out.append((r0, r1))
+        u += cnt
+    assert out[-1][1] == height and all(b > a for a, b in out), out
+    return out
+
+
+def half_rows(r0, r1, height):
+    hh = (height + 1) // 2
+    return r0 // 2, (hh if r1 == height else r1 // 2)
+
+
+def transfers(strips, halo, res, height):
+    """[(src_rank, dst_rank, row0, row1)] in the surface's own resolution so that every rank holds rows
+    [own0 - halo, own1 + halo) after the exchange (halo=None: all rows = all-gather)."""
+    n = len(strips)
+    own = [half_rows(a, b, height) if res == "h" else (a, b) for a, b in strips]
+    total = (height + 1) // 2 if res == "h" else height
+    out = []
+    for dst in range(n):
+        lo = 0 if halo is None else max(0, own[dst][0] - halo)
+        hi = total if halo is None else min(total, own[dst][1] + halo)
+        for src in range(n):
+            if src == dst:
+                continue
+            a, b = max(lo, own[src][0]), min(hi, own[src][1])
+            if b > a:
+                out.append((src, dst, a, b))
+    return out
+
+
+class LocalComm:
+    """N virtual ranks in one process: transfers are device-to-device copies. For the single-GPU exactness test."""
+
+    def __init__(self, n):
+        self.n = n
+        self.ranks = list(range(n))
+
+    def run(self, xfers, get_rows):
+        # snapshot sources first so that in-place updates of one rank cannot leak into another's copy
+        staged = [(dst, a, b, get_rows(src, a, b).clone()) for (src, dst, a, b) in xfers]
+        for dst, a, b, data in staged:
+            get_rows(dst, a, b).copy_(data)
+
+
+class DistComm:
+    """torch.distributed point-to-point exchange (NCCL = RCCL on ROCm; gloo for CPU tests)."""
+
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.n = dist, rank, world
+        self.ranks = [rank]
+
+    def run(self, xfers, get_rows):
+        ops = []
+        for (src, dst, a, b) in xfers:
+            if src == self.rank:
+                ops.append(self.dist.P2POp(self.dist.isend, get_rows(src, a, b), dst))
+            elif dst == self.rank:
+                ops.append(self.dist.P2POp(self.dist.irecv, get_rows(dst, a, b), src))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+
+
+class SplitRtdgi:
+    """Drives RtdgiRenderer::{reproject,render} strip by strip with halo exchanges.
+    `pipes`: {rank: GpuPipeline} for the ranks living in this process (one for DistComm, N for LocalComm)."""
+
+    def __init__(self, comm, pipes, width, height, motion_halo=8):
+        self.comm, self.pipes = comm, pipes
+        self.W, self.H = width, height
+        self.strips = plan_strips(height, comm.n)
+        self.motion_halo = motion_halo
+        self.frame = 0
+        self.taa_frames = 0
+
+    # -- helpers
+    def _rows_view(self, rank, name, a, b):
+        import torch
+        gp = self.pipes[rank]
+        if name.startswith("TAA/"):
+            return gp.taa_surface(name[4:], torch.uint8, (self.H, self.W * TAA_SURF[name[4:].split(":")[0]]))[a:b]
+        bpt, res = SURF[name.split(":")[0]]
+        w = (self.W + 1) // 2 if res == "h" else self.W
+        h = (self.H + 1) // 2 if res == "h" else self.H
+        t = gp.surface(name, torch.uint8, (h, w * bpt))
+        return t[a:b]
+
+    def _exchange(self, items):
+        """items: [(surface name, halo rows or None)] -- ONE batched exchange for all of them (a single RCCL group:
+        both ends enumerate (item, dst, src) in the same order, so per-pair send/recv order matches)."""
+        xfers = []
+        for name, halo in items:
+            res = "f" if name.startswith("TAA/") else SURF[name.split(":")[0]][1]
+            xfers += [(src, dst, (name, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H)]
+        self.comm.run(xfers, lambda r, na, b: self._rows_view(r, na[0], na[1], b))
+
+    def _render(self, rank, mask, rows=None, spatial_select=0):
+        gp = self.pipes[rank]
+        p = gp.params(mask)
+        if rows is not None:
+            p.row_begin, p.row_end = rows
+        p.spatial_pass_select = spatial_select
+        klib.check(gp.L.kj_rtdgi_render(gp.rtdgi, C.byref(p), C.byref(gp.out), klib._stream_ptr()))
+
+    def gi_frame(self):
+        """One rtdgi frame (ircache per rank, if bound, runs through GpuPipeline's own calls before this)."""
+        P = KJ_RTDGI_PASS
+        out_sfx, hist_sfx = f":{self.frame % 2}", f":{1 - self.frame % 2}"
+        M = self.motion_halo
+        R = self.comm.ranks
+        if self.frame > 0:
+            self._exchange([("rtdgi.temporal2" + hist_sfx, None), ("rtdgi.temporal2_var" + hist_sfx, None)])
+        for r in R:
+            gp = self.pipes[r]
+            s = klib._stream_ptr()
+            if gp.ircache:
+                klib.check(gp.L.kj_ircache_prepare(gp.ircache, s))
+                klib.check(gp.L.kj_ircache_trace_irradiance(gp.ircache, gp.scene.h, gp.sky16.data_ptr(), 16, s))
+            klib.check(gp.L.kj_rtdgi_reproject(gp.rtdgi, gp.reprojection_map_ptr, self.W, self.H, s))
+            if gp.ircache:
+                klib.check(gp.L.kj_ircache_sum_up_irradiance_for_sampling(gp.ircache, s))
+            self._render(r, P["EXTRACT_HALF"])                                   # replicated inputs: full frame, cheap
+            self._render(r, P["VALIDATE"] | KEEP, self.strips[r])
+        if self.frame > 0:
+            self._exchange([(n + hist_sfx, M + 4) for n in ("rtdgi.reservoir", "rtdgi.ray_orig", "rtdgi.ray", "rtdgi.radiance", "rtdgi.hit_normal")]
+                           + [("rtdgi.invalidity" + hist_sfx, M + 8)])
+        self._exchange([("rt_history_validity_pre_input_tex", M + 1)])
+        for r in R:
+            self._render(r, P["TRACE"] | KEEP, self.strips[r])
+        self._exchange([("rt_history_validity_input_tex", 2), ("candidate_radiance_tex", 3), ("candidate_hit_tex", 3)])
+        for r in R:
+            self._render(r, P["VALIDITY_INTEGRATE"] | KEEP, self.strips[r])
+            self._render(r, P["RESTIR_TEMPORAL"] | KEEP, self.strips[r])
+        self._exchange([("rtdgi.reservoir" + out_sfx, 32), ("temporal_reservoir_packed_tex", 51), ("rtdgi.radiance" + out_sfx, 51)])
+        for r in R:
+            self._render(r, P["RESTIR_SPATIAL"] | KEEP, self.strips[r], spatial_select=1)
+        self._exchange([("reservoir_output_tex0", 16)])
+        for r in R:
+            self._render(r, P["RESTIR_SPATIAL"] | KEEP, self.strips[r], spatial_select=2)
+        self._exchange([("reservoir_output_tex1", 3)])
+        for r in R:
+            self._render(r, P["RESTIR_RESOLVE"] | KEEP, self.strips[r])
+        self._exchange([("irradiance_output_tex", 2)])
+        for r in R:
+            self._render(r, P["TEMPORAL_FILTER"] | KEEP, self.strips[r])
+        self._exchange([("temporal_filtered_tex", 16)])
+        for r in R:
+            self._render(r, P["SPATIAL_FILTER"] | KEEP, self.strips[r])
+        self.frame += 1
+
+    def taa_frame(self):
+        """TaaRenderer::render on this frame's GI image, strip by strip. ONE exchange (the three histories and the
+        input's halo); the intermediate images are over-computed on up to 32 extra rows per side (8-row tile
+        granularity) instead of being exchanged: prob_filter2 reaches +-4 rows of prob_filter, that +-1 of input_prob,
+        that +-1 of the filtered history / input and +-2 of the input deviation, those +-1 of the reprojected history /
+        input (taa/*.hlsl)."""
+        import torch
+        M = self.motion_halo
+        gi_out = "spatial_filtered_tex"
+        hist_sfx = f":{1 - self.taa_frames % 2}"
+        items = [(gi_out, 1 + 24)]                          # filter_input runs on +-24 rows
+        if self.taa_frames > 0:
+            items += [("TAA/taa" + hist_sfx, M + 4 + 32), ("TAA/taa.velocity" + hist_sfx, M + 2 + 16), ("TAA/taa.smooth_var" + hist_sfx, M + 2 + 16)]
+        self._exchange(items)
+        for r in self.comm.ranks:
+            gp = self.pipes[r]
+            r0, r1 = self.strips[r]
+            inp = gp.surface(gi_out, torch.uint8, (self.H, self.W * 8)).data_ptr()
+
+            def run(mask, grow, keep=True):
+                a, b = max(0, r0 - grow), min(self.H, r1 + grow)
+                klib.check(gp.L.kj_taa_render_rows(gp.taa, inp, self.W, self.H, gp.reprojection_map_ptr, gp.depth.data_ptr(), self.W, self.H,
+                                                   C.byref(gp.taa_out), klib._stream_ptr(), mask | (KEEP if keep else 0), a, b))
+            run(1, 32, keep=False)         # reproject history (5-tap Catmull-Rom around uv + motion)
+            run(2 | 4, 24)                 # filter input (+-1 input), filter history (+-1 reprojected history)
+            run(8, 16)                     # input prob (+-2 deviation, +-1 filtered input / history)
+            run(16, 8)                     # prob filter (+-1)
+            run(32 | 64, 0)                # prob filter 2 (+-4), taa (+-2 reprojected history, +-1 input)
+        self.taa_frames += 1
+
+    def gather_output(self, name="spatial_filtered_tex"):
+        """Assemble the full image from every rank's own rows (result collection; not part of the timed frame)."""
+        self._exchange([(name, None)])

@@ -1,0 +1,79 @@
+"""N>1 path on CPU: two processes over `gloo` run DistComm's halo exchange / all-gather on strip-owned images
+(the same call SplitRtdgi makes between passes, with host tensors standing in for the renderer surfaces)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, H, W, q):
+    import torch
+    import torch.distributed as dist
+    from kajiya_amd import multigpu
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = multigpu.DistComm(dist, rank, world)
+        strips = multigpu.plan_strips(H, world)
+        g = torch.Generator().manual_seed(1234)
+        results = {}
+        for res, bpt, halo in (("h", 8, 51), ("f", 8, 2), ("f", 4, None), ("h", 1, 9)):
+            hh = (H + 1) // 2 if res == "h" else H
+            ww = ((W + 1) // 2 if res == "h" else W) * bpt
+            truth = torch.randint(0, 256, (hh, ww), dtype=torch.uint8, generator=g)   # same on both ranks (same seed)
+            own = multigpu.half_rows(*strips[rank], H) if res == "h" else strips[rank]
+            mine = torch.full_like(truth, 0xEE if rank == 0 else 0x77)
+            mine[own[0]:own[1]] = truth[own[0]:own[1]]
+            comm.run(multigpu.transfers(strips, halo, res, H), lambda r, a, b: mine[a:b])
+            lo = 0 if halo is None else max(0, own[0] - halo)
+            hi = hh if halo is None else min(hh, own[1] + halo)
+            ok = bool((mine[lo:hi] == truth[lo:hi]).all())
+            # rows outside the halo must be untouched
+            outside = torch.cat([mine[:lo], mine[hi:]])
+            ok_out = bool((outside == (0xEE if rank == 0 else 0x77)).all()) if outside.numel() else True
+            results[(res, bpt, halo)] = (ok, ok_out)
+        dist.barrier()
+        q.put((rank, results))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_distcomm_halo_exchange_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    H, W = 208, 96
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, H, W, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in got) == [0, 1]
+    for rank, results in got:
+        for key, (ok, ok_out) in results.items():
+            assert ok, f"rank {rank}: halo rows wrong for {key}"
+            assert ok_out, f"rank {rank}: rows outside the halo were written for {key}"
+
+
+def test_transfer_plan_is_symmetric_and_minimal():
+    from kajiya_amd import multigpu
+    st = multigpu.plan_strips(1080, 8)
+    x = multigpu.transfers(st, 16, "f", 1080)
+    # with a 16-row halo and >=128-row strips every rank only talks to its neighbours
+    assert all(abs(s - d) == 1 for s, d, _, _ in x)
+    assert sum(b - a for _, _, a, b in x) == 16 * 2 * 7
+    xa = multigpu.transfers(st, None, "f", 1080)
+    assert sum(b - a for _, _, a, b in xa) == 1080 * 7
