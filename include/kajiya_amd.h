@@ -330,6 +330,23 @@ KjStatus kj_taa_render_rows(KjTaa* t, const void* input_tex, uint32_t input_widt
                             uint32_t pass_mask, uint32_t row_begin, uint32_t row_end);
 KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 
+/* ---------------------------------------------------------------------------
+ * Reference path tracer — the convergence oracle of the GI path
+ *   reference_path_trace(rg, &mut output_img, bindless_set, tlas)   renderers/reference.rs:8-26
+ *   rt/reference_path_trace.rgen.hlsl:75-377 (16-segment eye paths, sun NEE with soft shadows, one triangle
+ *   light per vertex, Russian roulette from the 4th vertex, Gaussian pixel filter, firefly suppression)
+ * `output` is the persistent RGBA32F accumulation image (rgb = running mean, a = sample count; the reference's
+ * "refpt.accum" temporal); each call adds one sample per pixel with the rng seeded from frame_index.
+ * first_bounce_mode: 0 = as shipped; 1 = the shader's INDIRECT_ONLY switch; 2 = indirect light through a white
+ * Lambert first bounce (the quantity rtdgi's irradiance output estimates; used by the convergence test).
+ * interleave_count/index: 8x8 tiles are dealt round-robin to `count` ranks and this call renders tiles with
+ * tile % count == index (BASELINE config 5: pixel-interleaved multi-GPU split; sum the images at the end).
+ * ray_counter_dev: optional device u64 that receives += rays traced.
+ * --------------------------------------------------------------------------- */
+KjStatus kj_reference_path_trace(KjDevice* dev, const KjScene* scene, void* output, uint32_t width, uint32_t height,
+                                 uint32_t first_bounce_mode, uint32_t interleave_count, uint32_t interleave_index,
+                                 uint64_t* ray_counter_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

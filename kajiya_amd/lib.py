@@ -25,7 +25,7 @@ EXPORTS = [
     "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
     "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts",
-    "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface",
+    "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
 ]
 
 _LIB = None
@@ -88,6 +88,7 @@ def load():
         "kj_taa_create": [vp, C.POINTER(vp)],
         "kj_taa_render": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp],
         "kj_taa_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
+        "kj_reference_path_trace": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp],
         "kj_taa_render_rows": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp, u32, u32, u32],
     }
     for name, args in sig.items():
@@ -293,6 +294,12 @@ class GpuPipeline:
         ow, oh = out_extent or (self.W, self.H)
         inp = input_ptr if input_ptr is not None else self.out.screen_irradiance_tex
         check(self.L.kj_taa_render(self.taa, inp, self.W, self.H, self.reprojection_map_ptr, self.depth.data_ptr(), ow, oh, C.byref(self.taa_out), _stream_ptr()))
+
+    def reference_path_trace(self, accum, first_bounce_mode=0, interleave=(1, 0), ray_counter=None):
+        """reference_path_trace (reference.rs:8-26): one more sample per pixel into `accum` (H, W, 4) float32 cuda tensor."""
+        assert accum.dtype == self.torch.float32 and accum.is_contiguous() and tuple(accum.shape) == (self.H, self.W, 4)
+        check(self.L.kj_reference_path_trace(self.dev.h, self.scene.h, accum.data_ptr(), self.W, self.H, first_bounce_mode, interleave[0], interleave[1],
+                                             ray_counter.data_ptr() if ray_counter is not None else None, _stream_ptr()))
 
     def taa_surface(self, name, dtype, shape):
         ptr, n = C.c_void_p(), C.c_uint64()

@@ -4,6 +4,7 @@
 #include "okj_rtdgi.hpp"
 #include "okj_ircache_trace.hpp"
 #include "okj_taa.hpp"
+#include "okj_reference_pt.hpp"
 #include <cstdio>
 #include <chrono>
 #ifdef _OPENMP
@@ -275,6 +276,20 @@ int okj_taa_surface(void* p, const char* name, void** out_ptr, uint64_t* out_byt
     *out_ptr = it->second.data();
     *out_bytes = it->second.size();
     return 0;
+}
+
+// reference_path_trace (reference.rs:8-26): accumulates one sample per pixel into `output` (RGBA32F). Returns the ray count.
+uint64_t okj_reference_path_trace(const void* scene, const KjFrameConstants* fc, const void* brdf_fg_lut, void* output, uint32_t w, uint32_t h, int first_bounce_mode) {
+    static std::vector<h4> lut;
+    ReferencePtInputs in;
+    in.scene = (const Scene*)scene;
+    if (brdf_fg_lut) in.brdf_fg_lut = (const h4*)brdf_fg_lut;
+    else {
+        if (lut.empty()) { lut.resize(64 * 64); build_brdf_fg_lut(lut.data()); }
+        in.brdf_fg_lut = lut.data();
+    }
+    in.first_bounce_mode = first_bounce_mode;
+    return reference_path_trace(*(const FrameConstants*)fc, in, (f4*)output, w, h);
 }
 
 } // extern "C"

@@ -82,6 +82,8 @@ def lib():
         L.okj_taa_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.okj_taa_surface.restype = C.c_int
         L.okj_taa_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.okj_reference_path_trace.restype = C.c_uint64
+        L.okj_reference_path_trace.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
         L.okj_set_threads.argtypes = [C.c_int]
         L.okj_get_max_threads.restype = C.c_int
         _LIB = L
@@ -102,6 +104,13 @@ def brdf_lut():
         lib().okj_brdf_fg_lut(out.ctypes.data)
         _BRDF_LUT = out
     return _BRDF_LUT
+
+
+def reference_path_trace(scene, fc, output, first_bounce_mode=0):
+    """reference.rs:8-26: accumulate one sample/pixel into `output` (H, W, 4) float32. Returns the number of rays traced."""
+    assert output.dtype == np.float32 and output.flags["C_CONTIGUOUS"] and output.shape[2] == 4
+    h, w = output.shape[:2]
+    return lib().okj_reference_path_trace(scene.h, C.byref(fc), brdf_lut().ctypes.data, output.ctypes.data, w, h, first_bounce_mode)
 
 
 class OracleScene:
