@@ -278,9 +278,15 @@ int okj_taa_surface(void* p, const char* name, void** out_ptr, uint64_t* out_byt
     return 0;
 }
 
+void okj_rtdgi_debug(void* p, int enable, uint64_t* out8) {
+    Rtdgi* o = &((OkjRtdgi*)p)->r;
+    o->dbg_enabled = enable != 0;
+    if (out8) for (int i = 0; i < 8; ++i) out8[i] = o->dbg[i].load();
+}
 // reference_path_trace (reference.rs:8-26): accumulates one sample per pixel into `output` (RGBA32F). Returns the ray count.
 uint64_t okj_reference_path_trace(const void* scene, const KjFrameConstants* fc, const void* brdf_fg_lut, void* output, uint32_t w, uint32_t h, int first_bounce_mode) {
     static std::vector<h4> lut;
+    const char* mpl = getenv("OKJ_PT_MAX_PATH_LENGTH");   // test knob
     ReferencePtInputs in;
     in.scene = (const Scene*)scene;
     if (brdf_fg_lut) in.brdf_fg_lut = (const h4*)brdf_fg_lut;
@@ -289,6 +295,7 @@ uint64_t okj_reference_path_trace(const void* scene, const KjFrameConstants* fc,
         in.brdf_fg_lut = lut.data();
     }
     in.first_bounce_mode = first_bounce_mode;
+    if (mpl) in.max_path_length = uint32_t(atoi(mpl));
     return reference_path_trace(*(const FrameConstants*)fc, in, (f4*)output, w, h);
 }
 

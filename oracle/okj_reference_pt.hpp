@@ -29,6 +29,7 @@ struct ReferencePtInputs {
     const Scene* scene = nullptr;
     const h4* brdf_fg_lut = nullptr;
     int first_bounce_mode = 0;
+    uint32_t max_path_length = PT_MAX_EYE_PATH_LENGTH;   // test knob (truncated transport for stage-by-stage checks)
 };
 
 // One pixel, one sample: returns false when the sample is rejected (:364, any negative channel).
@@ -48,7 +49,7 @@ static inline bool reference_pt_sample(const FrameConstants& fc, const Reference
     const f3 sun_color = sun_color_in_direction(fc, sun_direction(fc));
     const bool indirect_only = in.first_bounce_mode != 0;
 
-    for (uint32_t path_length = 0; path_length < PT_MAX_EYE_PATH_LENGTH; ++path_length) {
+    for (uint32_t path_length = 0; path_length < in.max_path_length; ++path_length) {
         if (path_length == 1) outgoing_ray.tmax = FLT_MAX;
         ++*ray_count;
         const GbufferPathVertex primary_hit = gbuffer_raytrace(*in.scene, fc, outgoing_ray, path_length, false);

@@ -165,6 +165,8 @@ struct Rtdgi {
     struct TraceResult { f3 out_value; f3 hit_normal_ws; float hit_t; float pdf; bool is_hit; };
     f3 sun_color; // SUN_COLOR hoisted: depends only on frame constants (inc/sun.hlsl:21-33)
 
+    bool dbg_enabled = false;
+    std::atomic<uint64_t> dbg[8] = {};
     TraceResult do_the_thing(const FrameConstants& fc, const RtdgiInputs& in, uint32_t px, uint32_t py, f3 normal_ws, uint32_t& rng, Ray outgoing_ray) {
         const f4 gbuffer_tex_size = tex_size4(W, H);
         f3 total_radiance = mk3(0.0f);
@@ -184,9 +186,25 @@ struct Rtdgi {
             bool is_on_screen = fabsf(primary_hit_cs.x) < 1.0f && fabsf(primary_hit_cs.y) < 1.0f &&
                                 inverse_depth_relative_diff(primary_hit_cs.z, primary_hit_screen_depth) < 5e-3f;
             f4 reprojected_radiance = mk4(0.0f);
+            if (dbg_enabled) {
+                dbg[0].fetch_add(1);
+                const bool in_cs = fabsf(primary_hit_cs.x) < 1.0f && fabsf(primary_hit_cs.y) < 1.0f;
+                if (in_cs) dbg[1].fetch_add(1);
+                if (is_on_screen) dbg[2].fetch_add(1);
+                if (in_cs && !is_on_screen && primary_hit_cs.z > primary_hit_screen_depth) dbg[4].fetch_add(1);  // hit is in front of the visible surface
+            }
             if (is_on_screen) {
                 reprojected_radiance = unpack_rgba16f(sample_nearest_clamp(reprojected_history_tex, primary_hit_uv)) * fc.pre_exposure_delta;
                 is_on_screen = reprojected_radiance.w > 0;
+                if (dbg_enabled && is_on_screen) {
+                    dbg[3].fetch_add(1);
+                    if (in.ircache_lookup) {   // experiment only: compare the two sources of bounce light at the same hit
+                        uint32_t rng2 = rng;
+                        const f3 gi = in.ircache_lookup(outgoing_ray.o, primary_hit.position, gbuffer.normal, 1, rng2);
+                        dbg[5].fetch_add(uint64_t(1e4f * sRGB_to_luminance(xyz(reprojected_radiance))));
+                        dbg[6].fetch_add(uint64_t(1e4f * sRGB_to_luminance(gi)));
+                    }
+                }
             }
             gbuffer.roughness = lerp(gbuffer.roughness, 1.0f, ROUGHNESS_BIAS);
             const m33 tangent_to_world = build_orthonormal_basis(gbuffer.normal);
