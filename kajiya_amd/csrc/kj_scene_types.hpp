@@ -8,12 +8,15 @@ namespace kj {
 
 struct alignas(16) F4 { float x, y, z, w; };
 
-// 64 B: both children's AABBs + child references (see kj_bvh.hpp)
-struct BvhNode {
-    float lmin[3]; uint32_t left;
-    float lmax[3]; uint32_t right;
-    float rmin[3]; uint32_t pad0;
-    float rmax[3]; uint32_t pad1;
+// 64 B: 4-wide node, child boxes quantised to 8 bits per plane in the node's own frame (see kj_bvh.hpp).
+//   decoded plane = fma(q, 2^(exp8 - 127), origin); the builder rounds outwards and verifies with this exact expression.
+struct Bvh4Node {
+    float origin[3];
+    uint8_t exp8[4];        // per-axis IEEE exponent byte of the quantisation step; [3] = number of children
+    uint32_t child[4];      // inner: node index; leaf: KJ_BVH_LEAF | (count-1) << 28 | first triangle; 0xffffffff = empty
+    uint8_t qlo[3][4];      // [axis][child]
+    uint8_t qhi[3][4];
+    uint32_t pad[2];
 };
 // 48 B: world-space triangle in leaf order
 struct BvhTri {
@@ -21,17 +24,19 @@ struct BvhTri {
     float v1[3]; uint32_t inst;
     float v2[3]; uint32_t prim;
 };
-static_assert(sizeof(BvhNode) == 64, "node size");
+static_assert(sizeof(Bvh4Node) == 64, "node size");
 static_assert(sizeof(BvhTri) == 48, "tri size");
 
 #define KJ_BVH_LEAF 0x80000000u
 #define KJ_BVH_MAX_LEAF_TRIS 4u
+#define KJ_BVH_LDS_STACK 24u      // traversal stack entries kept in LDS per lane ...
+#define KJ_BVH_SPILL_STACK 104u   // ... deeper entries spill to private (scratch) memory; builds needing more are rejected
 
 struct BvhView {
-    const F4* nodes;         // 4 x 16 B per node
+    const F4* nodes;         // 4 x 16 B per node; node 0 is the root
     const F4* tris;          // 3 x 16 B per tri
-    uint32_t root;           // child reference of the root
-    uint32_t stack_entries;  // per-lane LDS stack depth a tracing kernel must provide
+    uint32_t root;           // always 0 (kept for the C-ABI debug query)
+    uint32_t stack_entries;  // per-lane LDS stack entries a tracing kernel must provide (KJ_BVH_LDS_STACK)
 };
 
 struct GpuMesh {  // inc/mesh.hlsl:10-18 (+ index_count)

@@ -1,11 +1,12 @@
 // KjScene: WorldRenderer's scene state for the GI path (world_renderer.rs:604-911):
 // mesh upload into one byte-addressed vertex buffer + GpuMesh table, instances,
-// triangle lights, and — replacing the driver's BLAS/TLAS — a host-built LBVH
-// (63-bit Morton codes, top-down split at the highest differing bit, <=4 tris
-// per leaf) uploaded as 64-byte two-box nodes and 48-byte leaf-ordered triangles.
+// triangle lights, and — replacing the driver's BLAS/TLAS — a host-built 4-wide
+// SAH BVH with quantised child boxes (bvh_build.cpp) uploaded as 64-byte nodes
+// and 48-byte leaf-ordered world-space triangles.
 // Plain C++ (no device code); compiled with -ffp-contract=off so the instance
 // transform of vertices rounds exactly like the oracle's.
 #include "kj_host.hpp"
+#include "kj_bvh_build.hpp"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -22,72 +23,6 @@ void set_last_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-struct Aabb {
-    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    void grow(const float* p) { for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], p[k]); mx[k] = std::max(mx[k], p[k]); } }
-    void grow(const Aabb& o) { for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], o.mn[k]); mx[k] = std::max(mx[k], o.mx[k]); } }
-};
-
-static inline uint64_t expand21(uint64_t v) {
-    v &= 0x1fffffull;
-    v = (v | v << 32) & 0x1f00000000ffffull;
-    v = (v | v << 16) & 0x1f0000ff0000ffull;
-    v = (v | v << 8) & 0x100f00f00f00f00full;
-    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
-    v = (v | v << 2) & 0x1249249249249249ull;
-    return v;
-}
-
-struct LbvhBuilder {
-    const std::vector<BvhTri>& tris;       // Morton-sorted
-    const std::vector<uint64_t>& codes;    // sorted
-    std::vector<BvhNode> nodes;
-    uint32_t max_depth = 0;
-
-    LbvhBuilder(const std::vector<BvhTri>& t, const std::vector<uint64_t>& c) : tris(t), codes(c) {}
-
-    static Aabb tri_bounds(const BvhTri& t) { Aabb b; b.grow(t.v0); b.grow(t.v1); b.grow(t.v2); return b; }
-
-    uint32_t find_split(uint32_t first, uint32_t last) const {
-        const uint64_t a = codes[first], b = codes[last];
-        if (a == b) return (first + last) >> 1;
-        const int common = __builtin_clzll(a ^ b);
-        // largest index in [first,last) sharing more than `common` leading bits with `a`
-        uint32_t split = first, step = last - first;
-        do {
-            step = (step + 1) >> 1;
-            const uint32_t ns = split + step;
-            if (ns < last) {
-                const uint64_t x = codes[ns] ^ a;
-                const int cp = x ? __builtin_clzll(x) : 64;
-                if (cp > common) split = ns;
-            }
-        } while (step > 1);
-        return split;
-    }
-
-    // returns child reference; fills `box`
-    uint32_t build(uint32_t first, uint32_t last, uint32_t depth, Aabb& box) {
-        max_depth = std::max(max_depth, depth);
-        const uint32_t count = last - first + 1;
-        if (count <= KJ_BVH_MAX_LEAF_TRIS) {
-            for (uint32_t i = first; i <= last; ++i) box.grow(tri_bounds(tris[i]));
-            return KJ_BVH_LEAF | ((count - 1) << 28) | first;
-        }
-        const uint32_t split = find_split(first, last);
-        const uint32_t idx = uint32_t(nodes.size());
-        nodes.push_back(BvhNode{});
-        Aabb lb, rb;
-        const uint32_t l = build(first, split, depth + 1, lb);
-        const uint32_t r = build(split + 1, last, depth + 1, rb);
-        BvhNode& n = nodes[idx];
-        for (int k = 0; k < 3; ++k) { n.lmin[k] = lb.mn[k]; n.lmax[k] = lb.mx[k]; n.rmin[k] = rb.mn[k]; n.rmax[k] = rb.mx[k]; }
-        n.left = l; n.right = r; n.pad0 = n.pad1 = 0;
-        box.grow(lb); box.grow(rb);
-        return idx;
-    }
-};
-
 SceneView scene_view(const KjScene& s) {
     SceneView v{};
     v.vertex_buffer = (const uint8_t*)s.d_vertex_buffer.p;
@@ -99,7 +34,7 @@ SceneView scene_view(const KjScene& s) {
     v.bvh.nodes = (const F4*)s.d_nodes.p;
     v.bvh.tris = (const F4*)s.d_tris.p;
     v.bvh.root = s.bvh_root;
-    v.bvh.stack_entries = s.bvh_max_depth + 2;
+    v.bvh.stack_entries = s.bvh_max_depth + 1;   // builder's bound on the traversal stack
     return v;
 }
 
@@ -254,42 +189,14 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     }
     KJ_REQUIRE(!wt.empty(), "scene has no triangles");
     KJ_REQUIRE(wt.size() < (1u << 28), "too many triangles for 28-bit leaf references");
-    // 2. Morton codes of centroids, sort
-    Aabb cb;
-    std::vector<float> cen(wt.size() * 3);
-    for (size_t i = 0; i < wt.size(); ++i) {
-        for (int k = 0; k < 3; ++k) cen[i * 3 + k] = (wt[i].v0[k] + wt[i].v1[k] + wt[i].v2[k]) * (1.0f / 3.0f);
-        cb.grow(&cen[i * 3]);
-    }
-    std::vector<std::pair<uint64_t, uint32_t>> keys(wt.size());
-    double inv[3];
-    for (int k = 0; k < 3; ++k) inv[k] = cb.mx[k] > cb.mn[k] ? 2097151.0 / double(cb.mx[k] - cb.mn[k]) : 0.0;
-    for (size_t i = 0; i < wt.size(); ++i) {
-        uint64_t q[3];
-        for (int k = 0; k < 3; ++k) q[k] = uint64_t(std::min(2097151.0, std::max(0.0, (double(cen[i * 3 + k]) - cb.mn[k]) * inv[k])));
-        keys[i] = {(expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]), uint32_t(i)};
-    }
-    std::sort(keys.begin(), keys.end());
-    std::vector<BvhTri> sorted(wt.size());
-    std::vector<uint64_t> codes(wt.size());
-    for (size_t i = 0; i < wt.size(); ++i) { sorted[i] = wt[keys[i].second]; codes[i] = keys[i].first; }
-    // 3. hierarchy
-    LbvhBuilder b(sorted, codes);
-    b.nodes.reserve(wt.size());
-    Aabb root_box;
-    uint32_t root = b.build(0, uint32_t(sorted.size() - 1), 0, root_box);
-    if (root & KJ_BVH_LEAF) {  // tiny scene: wrap the single leaf in a node whose right child is an empty box
-        BvhNode n{};
-        for (int k = 0; k < 3; ++k) { n.lmin[k] = root_box.mn[k]; n.lmax[k] = root_box.mx[k]; n.rmin[k] = FLT_MAX; n.rmax[k] = FLT_MAX; }  // unreachable box: both slab planes at +inf
-        n.left = root; n.right = root;
-        b.nodes.push_back(n);
-        root = uint32_t(b.nodes.size() - 1);
-        b.max_depth = 1;
-    }
-    s->tri_count = uint32_t(sorted.size());
+    // 2. hierarchy (bvh_build.cpp)
+    BuiltBvh b;
+    build_bvh4(wt, b);
+    KJ_REQUIRE(b.max_stack + 1 <= 256, "BVH too deep for the LDS traversal stack");
+    s->tri_count = uint32_t(b.tris.size());
     s->node_count = uint32_t(b.nodes.size());
-    s->bvh_root = root;
-    s->bvh_max_depth = b.max_depth;
+    s->bvh_root = 0;
+    s->bvh_max_depth = b.max_stack;
     s->light_count = uint32_t(lights.size());
     // 4. upload
     KJ_TRY_HIP(s->d_vertex_buffer.upload(s->vertex_buffer.data(), s->vertex_buffer.size(), stream));
@@ -298,8 +205,8 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     KJ_TRY_HIP(s->d_map_colors.upload(s->map_colors.data(), s->map_colors.size() * 4, stream));
     if (lights.empty()) lights.push_back(KjTriangleLight{});
     KJ_TRY_HIP(s->d_lights.upload(lights.data(), lights.size() * sizeof(KjTriangleLight), stream));
-    KJ_TRY_HIP(s->d_nodes.upload(b.nodes.data(), b.nodes.size() * sizeof(BvhNode), stream));
-    KJ_TRY_HIP(s->d_tris.upload(sorted.data(), sorted.size() * sizeof(BvhTri), stream));
+    KJ_TRY_HIP(s->d_nodes.upload(b.nodes.data(), b.nodes.size() * sizeof(Bvh4Node), stream));
+    KJ_TRY_HIP(s->d_tris.upload(b.tris.data(), b.tris.size() * sizeof(BvhTri), stream));
     KJ_TRY_HIP(hipStreamSynchronize(stream));  // host vectors go out of scope
     s->committed = true;
     return KJ_OK;
@@ -316,7 +223,7 @@ KjStatus kj_scene_stats(KjScene* s, uint32_t* out_tri_count, uint32_t* out_node_
     if (!s->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
     if (out_tri_count) *out_tri_count = s->tri_count;
     if (out_node_count) *out_node_count = s->node_count;
-    if (out_bvh_bytes) *out_bvh_bytes = uint64_t(s->node_count) * sizeof(BvhNode) + uint64_t(s->tri_count) * sizeof(BvhTri);
+    if (out_bvh_bytes) *out_bvh_bytes = uint64_t(s->node_count) * sizeof(Bvh4Node) + uint64_t(s->tri_count) * sizeof(BvhTri);
     return KJ_OK;
 }
 
