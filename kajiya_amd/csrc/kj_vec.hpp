@@ -313,7 +313,13 @@ KJ_HD V4 crunched_luma_chroma_to_linear_rgb(V4 v) { return v4(YCbCr_to_sRGB(xyz(
 template <typename T> struct Img {
     T* p; int w, h;
     KJ_HD bool inb(int x, int y) const { return uint32_t(x) < uint32_t(w) && uint32_t(y) < uint32_t(h); }
-    KJ_D T ld(int x, int y) const { T z = T(); return inb(x, y) ? p[size_t(y) * w + x] : z; }
+    // OOB load = 0. Branch-free: always load (texel 0 when out of bounds) and select the VALUE -- selecting between
+    // &p[i] and the address of a zero temporary makes the compiler spill the temporary to scratch and use flat loads.
+    KJ_D T ld(int x, int y) const {
+        const bool in = inb(x, y);
+        const T v = p[in ? size_t(y) * w + x : size_t(0)];
+        return in ? v : T();
+    }
     KJ_D T ldc(int x, int y) const {  // clamp-to-edge
         x = x < 0 ? 0 : (x >= w ? w - 1 : x); y = y < 0 ? 0 : (y >= h ? h - 1 : y);
         return p[size_t(y) * w + x];
