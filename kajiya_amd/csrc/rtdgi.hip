@@ -689,32 +689,44 @@ __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __
                                                          ImgU32 variance_history_output_tex, int row0, int row1) {
     const int W = output_tex.w, H = output_tex.h;
     TILE_XY(W, H)
-    if (!in_image) return;
     const FrameConstants& fc = *fcp;
+    const V4 history_mult{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
+    // LDS-staged 12x12 tile (8x8 outputs + the 5x5 stencil's halo): each texel's colour-space conversion is done once per
+    // tile instead of once per tap (25x per texture): .xyz = crunched luma-chroma of the input, .w = crunched history luma.
+    __shared__ float4 tile[12 * 12];
+    {
+        const int tx0 = int(blockIdx.x) * 8 - 2, ty0 = row0 + int(blockIdx.y) * 8 - 2;
+        for (int i = lane; i < 144; i += 64) {
+            const int tx = tx0 + i % 12, ty = ty0 + i / 12;
+            const V4 n = linear_rgb_to_crunched_luma_chroma(ld4(input_tex, tx, ty));
+            const V4 hn = linear_rgb_to_crunched_luma_chroma(ld4(history_tex, tx, ty) * history_mult);
+            tile[i] = make_float4(n.x, n.y, n.z, hn.x);
+        }
+    }
+    __syncthreads();
+    if (!in_image) return;
     const V2 uv = get_uv(float(x), float(y), tex_size4(W, H));
     const V4 center = linear_rgb_to_crunched_luma_chroma(ld4(input_tex, x, y));
     const V4 reproj = ld_reproj(reprojection_tex, x, y);
-    const V4 history_mult{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
     const V4 history = linear_rgb_to_crunched_luma_chroma(ld4(history_tex, x, y) * history_mult);
-    V4 vsum = v4(0.0f), vsum2 = v4(0.0f);
-    float wsum = 0, hist_diff = 0, hist_vsum = 0, hist_vsum2 = 0;
+    V3 vsum = v3(0.0f), vsum2 = v3(0.0f);
+    float wsum = 0, hist_vsum = 0;
+    const int lt = ((lane >> 3) + 2) * 12 + (lane & 7) + 2;
 #pragma unroll
     for (int dy = -2; dy <= 2; ++dy)
 #pragma unroll
         for (int dx = -2; dx <= 2; ++dx) {
-            const V4 neigh = linear_rgb_to_crunched_luma_chroma(ld4(input_tex, x + dx, y + dy));
-            const V4 hist_neigh = linear_rgb_to_crunched_luma_chroma(ld4(history_tex, x + dx, y + dy) * history_mult);
-            const float neigh_luma = neigh.x, hist_luma = hist_neigh.x;
+            const float4 t = tile[lt + dy * 12 + dx];
+            const V3 neigh{t.x, t.y, t.z};
+            const float hist_luma = t.w;
             const float w = expf(-3.0f * float(dx * dx + dy * dy) / float((2 + 1.) * (2 + 1.)));
             vsum += neigh * w;
             vsum2 += neigh * neigh * w;
             wsum += w;
-            hist_diff += fabsf(neigh_luma - hist_luma) / fmaxf(1e-5f, neigh_luma + hist_luma) * w;
             hist_vsum += hist_luma * w;
-            hist_vsum2 += hist_luma * hist_luma * w;
         }
-    const V4 ex = vsum / wsum, ex2 = vsum2 / wsum;
-    const V4 dev = vsqrt(vmax(v4(0.0f), ex2 - ex * ex));
+    const V3 ex = vsum / wsum, ex2 = vsum2 / wsum;
+    const V3 dev = vsqrt(vmax(v3(0.0f), ex2 - ex * ex));
     hist_vsum /= wsum;
     const V2 moments_history = sample_bilinear_clamp_rg16f(variance_history_tex.p, W, H, uv + V2{reproj.x, reproj.y}) *
                                V2{fc.pre_exposure_delta, fc.pre_exposure_delta * fc.pre_exposure_delta};
@@ -727,8 +739,8 @@ __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __
     const float current_sample_count = history.w;
     float clamp_box_size = 1 * lerp(0.25f, 2.0f, 1.0f - rt_invalid) * lerp(0.333f, 1.0f, saturate(reproj.w)) * 2;
     clamp_box_size = fmaxf(clamp_box_size, 0.5f);
-    const V4 nmin = center - dev * clamp_box_size, nmax = center + dev * clamp_box_size;
-    const V3 clamped_history = vclamp(xyz(history), xyz(nmin), xyz(nmax));
+    const V3 nmin = xyz(center) - dev * clamp_box_size, nmax = xyz(center) + dev * clamp_box_size;
+    const V3 clamped_history = vclamp(xyz(history), nmin, nmax);
     const float variance_adjusted_temporal_change = smoothstep(0.1f, 1.0f, 0.05f * temporal_change / center_temporal_dev);
     float max_sample_count = 32;
     max_sample_count = lerp(max_sample_count, 4.0f, variance_adjusted_temporal_change);

@@ -84,65 +84,117 @@ __global__ void __launch_bounds__(64) k_taa_reproject(const FrameConstants* __re
     st4(output_tex, x, y, v4(xyz(hp), fmaxf(0.0f, hp.w)));
 }
 
-// filter_input.hlsl:33-88
-struct FilteredInput { V3 clamped_ex, var; };
-KJ_D FilteredInput filter_input_inner(const ImgH4& input_tex, const ImgF32& depth_tex, int px, int py, float center_depth, float luma_cutoff, float depth_scale) {
-    V3 iex = v3(0.0f), iex2 = v3(0.0f), clamped_iex = v3(0.0f);
-    float iwsum = 0, clamped_iwsum = 0;
+// filter_input.hlsl:33-88. The shader calls filter_input_inner twice over the same 3x3 taps (first with an infinite
+// luma cutoff, then with 1.001x the first pass' luma); here the taps are decoded once and kept in registers, and
+// pow(x, 8) is three squarings.
+KJ_D float pow8(float x) { const float x2 = x * x, x4 = x2 * x2; return x4 * x4; }
+__global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32 depth_tex, ImgH4 output_tex, ImgH4 dev_output_tex, int row0, int row1) {
+    TILE_XY(output_tex.w, output_tex.h)
+    // LDS-staged 10x10 tile: .xyz = decoded YCbCr of the input texel, .w = depth (one decode per texel instead of nine)
+    __shared__ float4 tile[10 * 10];
+    {
+        const int tx0 = int(blockIdx.x) * 8 - 1, ty0 = row0 + int(blockIdx.y) * 8 - 1;
+        for (int i = lane; i < 100; i += 64) {
+            const int tx = tx0 + i % 10, ty = ty0 + i / 10;
+            const V3 c = sRGB_to_YCbCr(taa_decode_rgb(xyz(ld4(input_tex, tx, ty))));
+            tile[i] = make_float4(c.x, c.y, c.z, depth_tex.ld(tx, ty));
+        }
+    }
+    __syncthreads();
+    if (!in_image) return;
+    const int lt = ((lane >> 3) + 1) * 10 + (lane & 7) + 1;
+    const float center_depth = tile[lt].w;
+    const float depth_scale = 200.0f;
+    V3 s[9]; float wd[9];
 #pragma unroll
     for (int yy = -1; yy <= 1; ++yy)
 #pragma unroll
         for (int xx = -1; xx <= 1; ++xx) {
+            const int i = (yy + 1) * 3 + (xx + 1);
             const float distance_w = expf(-0.8f * float(xx * xx + yy * yy));
-            const V3 s = sRGB_to_YCbCr(taa_decode_rgb(xyz(ld4(input_tex, px + xx, py + yy))));
-            const float depth = depth_tex.ld(px + xx, py + yy);
+            const float4 t = tile[lt + yy * 10 + xx];
+            s[i] = V3{t.x, t.y, t.z};
             float w = 1;
-            w *= exp2f(-fminf(16.0f, depth_scale * inverse_depth_relative_diff(center_depth, depth)));
+            w *= exp2f(-fminf(16.0f, depth_scale * inverse_depth_relative_diff(center_depth, t.w)));
             w *= distance_w;
-            w *= powf(saturate(luma_cutoff / s.x), 8.0f);
-            clamped_iwsum += w;
-            clamped_iex += s * w;
-            iwsum += 1;
-            iex += s;
-            iex2 += s * s;
+            wd[i] = w;
         }
+    // pass 1: luma_cutoff = 1e10
+    V3 iex = v3(0.0f), iex2 = v3(0.0f), clamped_iex = v3(0.0f);
+    float clamped_iwsum = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float w = wd[i] * pow8(saturate(1e10f / s[i].x));
+        clamped_iwsum += w;
+        clamped_iex += s[i] * w;
+        iex += s[i];
+        iex2 += s[i] * s[i];
+    }
     clamped_iex = clamped_iex / clamped_iwsum;
-    iex = iex / iwsum;
-    iex2 = iex2 / iwsum;
-    return FilteredInput{clamped_iex, vmax(v3(0.0f), iex2 - iex * iex)};
-}
-__global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32 depth_tex, ImgH4 output_tex, ImgH4 dev_output_tex, int row0, int row1) {
-    TILE_XY(output_tex.w, output_tex.h)
-    if (!in_image) return;
-    const float center_depth = depth_tex.ld(x, y);
-    const FilteredInput a = filter_input_inner(input_tex, depth_tex, x, y, center_depth, 1e10f, 200.0f);
-    const FilteredInput b = filter_input_inner(input_tex, depth_tex, x, y, center_depth, a.clamped_ex.x * 1.001f, 200.0f);
-    st4(output_tex, x, y, v4(b.clamped_ex, 0.0f));
-    st4(dev_output_tex, x, y, v4(vsqrt(a.var), 0.0f));
+    iex = iex / 9.0f;
+    iex2 = iex2 / 9.0f;
+    const V3 var_a = vmax(v3(0.0f), iex2 - iex * iex);
+    // pass 2: luma_cutoff = first pass' luma * 1.001
+    const float cutoff = clamped_iex.x * 1.001f;
+    V3 cex = v3(0.0f); float cws = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float w = wd[i] * pow8(saturate(cutoff / s[i].x));
+        cws += w;
+        cex += s[i] * w;
+    }
+    cex = cex / cws;
+    st4(output_tex, x, y, v4(cex, 0.0f));
+    st4(dev_output_tex, x, y, v4(vsqrt(var_a), 0.0f));
 }
 
-// filter_history.hlsl:15-61
-KJ_D V3 fh_filter_input(const ImgH4& input_tex, V2 uv, float luma_cutoff, int k) {
+// filter_history.hlsl:15-61. Same two-pass structure as filter_input; K = 1 unless the history is > 1.75x the input extent.
+template <int K>
+KJ_D V3 fh_filter_input(const V3* taps, float luma_cutoff) {
     V3 iex = v3(0.0f);
     float iwsum = 0;
-    const int sx = int(floorf(uv.x * float(input_tex.w) + 1e-3f)), sy = int(floorf(uv.y * float(input_tex.h) + 1e-3f));
-    for (int yy = -k; yy <= k; ++yy)
-        for (int xx = -k; xx <= k; ++xx) {
-            const float distance_w = expf(-(0.8f / float(k * k)) * float(xx * xx + yy * yy));
-            const V3 s = sRGB_to_YCbCr(xyz(ld4(input_tex, sx + xx, sy + yy)));
-            const float w = distance_w * powf(saturate(luma_cutoff / s.x), 8.0f);
+#pragma unroll
+    for (int yy = -K; yy <= K; ++yy)
+#pragma unroll
+        for (int xx = -K; xx <= K; ++xx) {
+            const float distance_w = expf(-(0.8f / float(K * K)) * float(xx * xx + yy * yy));
+            const V3 s = taps[(yy + K) * (2 * K + 1) + (xx + K)];
+            const float w = distance_w * pow8(saturate(luma_cutoff / s.x));
             iwsum += w;
             iex += s * w;
         }
     return iex / iwsum;
 }
+template <int K, bool TILED>
 __global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_history, ImgH4 output_tex, int row0, int row1) {
     TILE_XY(output_tex.w, output_tex.h)
-    if (!in_image) return;
-    const int k = (float(reprojected_history.w) / float(output_tex.w) > 1.75f) ? 2 : 1;
-    const V2 uv = get_uv(float(x), float(y), tex_size4(output_tex.w, output_tex.h));
-    const float filtered_luma = fh_filter_input(reprojected_history, uv, 1e10f, k).x;
-    st4(output_tex, x, y, v4(fh_filter_input(reprojected_history, uv, filtered_luma * 1.001f, k), 0.0f));
+    constexpr int TW = 8 + 2 * K;
+    __shared__ float4 tile[TILED ? TW * TW : 1];
+    V3 taps[(2 * K + 1) * (2 * K + 1)];
+    if (TILED) {   // same extent: the stencil of pixel (x, y) is centred on texel (x, y); stage the converted tile once
+        const int tx0 = int(blockIdx.x) * 8 - K, ty0 = row0 + int(blockIdx.y) * 8 - K;
+        for (int i = lane; i < TW * TW; i += 64) {
+            const V3 c = sRGB_to_YCbCr(xyz(ld4(reprojected_history, tx0 + i % TW, ty0 + i / TW)));
+            tile[i] = make_float4(c.x, c.y, c.z, 0.0f);
+        }
+        __syncthreads();
+        if (!in_image) return;
+        const int lt = ((lane >> 3) + K) * TW + (lane & 7) + K;
+#pragma unroll
+        for (int yy = -K; yy <= K; ++yy)
+#pragma unroll
+            for (int xx = -K; xx <= K; ++xx) { const float4 t = tile[lt + yy * TW + xx]; taps[(yy + K) * (2 * K + 1) + (xx + K)] = V3{t.x, t.y, t.z}; }
+    } else {
+        if (!in_image) return;
+        const V2 uv = get_uv(float(x), float(y), tex_size4(output_tex.w, output_tex.h));
+        const int sx = int(floorf(uv.x * float(reprojected_history.w) + 1e-3f)), sy = int(floorf(uv.y * float(reprojected_history.h) + 1e-3f));
+#pragma unroll
+        for (int yy = -K; yy <= K; ++yy)
+#pragma unroll
+            for (int xx = -K; xx <= K; ++xx) taps[(yy + K) * (2 * K + 1) + (xx + K)] = sRGB_to_YCbCr(xyz(ld4(reprojected_history, sx + xx, sy + yy)));
+    }
+    const float filtered_luma = fh_filter_input<K>(taps, 1e10f).x;
+    st4(output_tex, x, y, v4(fh_filter_input<K>(taps, filtered_luma * 1.001f), 0.0f));
 }
 
 // input_prob.hlsl:50-108
@@ -200,33 +252,44 @@ __global__ void __launch_bounds__(64) k_taa_filter_prob2(ImgH1 input_tex, ImgH1 
     output_tex.st(x, y, f32_to_f16(fmaxf(0.0f, -1.0f / 10.0f * log2f(1e-30f + weighted.x / weighted.y))));
 }
 
-// inc/unjitter_taa.hlsl:58-125 (kernel half width 1)
+// inc/unjitter_taa.hlsl:58-125 (kernel half width 1). taa.hlsl calls it twice on the same taps (kernel_scale 1 and 0.333);
+// the taps are decoded once.
 struct Unjittered { V4 color; float coverage; V3 ex, ex2; };
-KJ_D Unjittered sample_image_unjitter_taa(const ImgH4& img, int opx, int opy, V2 out_size, V2 sample_offset_pixels, float kernel_scale) {
+template <bool TILED>
+KJ_D void sample_image_unjitter_taa2(const ImgH4& img, const float4* tile_cols /* 10x10, centred on this lane */, int opx, int opy, V2 out_size, V2 sample_offset_pixels, float ks_a, float ks_b, Unjittered& ra, Unjittered& rb) {
     const V2 scale = V2{float(img.w), float(img.h)} / out_size;
     const int bx = int((float(opx) + 0.5f) * scale.x), by = int((float(opy) + 0.5f) * scale.y);
     const V2 dst_sample_loc{float(opx) + 0.5f, float(opy) + 0.5f};
     const V2 base_src_sample_loc = V2{float(bx) + 0.5f + sample_offset_pixels.x, float(by) + 0.5f - sample_offset_pixels.y} / scale;
-    V4 res = v4(0.0f);
-    V3 ex = v3(0.0f), ex2 = v3(0.0f);
-    float dev_wt_sum = 0, wt_sum = 0;
+    V4 res_a = v4(0.0f), res_b = v4(0.0f);
+    V3 ex_a = v3(0.0f), ex2_a = v3(0.0f), ex_b = v3(0.0f), ex2_b = v3(0.0f);
+    float dev_wt_sum_a = 0, wt_sum_a = 0, dev_wt_sum_b = 0, wt_sum_b = 0;
 #pragma unroll
     for (int yy = -1; yy <= 1; ++yy)
 #pragma unroll
         for (int xx = -1; xx <= 1; ++xx) {
             const V2 src_sample_loc = base_src_sample_loc + V2{float(xx), float(yy)} / scale;
-            const V3 col = sRGB_to_YCbCr(taa_decode_rgb(xyz(ld4(img, bx + xx, by + yy))));
-            const V2 o = (src_sample_loc - dst_sample_loc) * kernel_scale;
-            const float dist2 = dot(o, o);
-            const float dev_wt = exp2f(-dist2 * scale.x);
-            const float wt = exp2f(-10.0f * dist2 * scale.x);
-            res += v4(col, 1.0f) * wt;
-            wt_sum += wt;
-            ex += col * dev_wt;
-            ex2 += col * col * dev_wt;
-            dev_wt_sum += dev_wt;
+            V3 col;
+            if (TILED) { const float4 t = tile_cols[yy * 10 + xx]; col = V3{t.x, t.y, t.z}; }
+            else col = sRGB_to_YCbCr(taa_decode_rgb(xyz(ld4(img, bx + xx, by + yy))));
+            const V2 off = src_sample_loc - dst_sample_loc;
+            {
+                const V2 o = off * ks_a;
+                const float dist2 = dot(o, o);
+                const float dev_wt = exp2f(-dist2 * scale.x), wt = exp2f(-10.0f * dist2 * scale.x);
+                res_a += v4(col, 1.0f) * wt; wt_sum_a += wt;
+                ex_a += col * dev_wt; ex2_a += col * col * dev_wt; dev_wt_sum_a += dev_wt;
+            }
+            {
+                const V2 o = off * ks_b;
+                const float dist2 = dot(o, o);
+                const float dev_wt = exp2f(-dist2 * scale.x), wt = exp2f(-10.0f * dist2 * scale.x);
+                res_b += v4(col, 1.0f) * wt; wt_sum_b += wt;
+                ex_b += col * dev_wt; ex2_b += col * col * dev_wt; dev_wt_sum_b += dev_wt;
+            }
         }
-    return Unjittered{res, wt_sum, ex / dev_wt_sum, ex2 / dev_wt_sum};
+    ra = Unjittered{res_a, wt_sum_a, ex_a / dev_wt_sum_a, ex2_a / dev_wt_sum_a};
+    rb = Unjittered{res_b, wt_sum_b, ex_b / dev_wt_sum_b, ex2_b / dev_wt_sum_b};
 }
 
 // taa.hlsl:94-338
@@ -236,10 +299,25 @@ struct TaaArgs {
     ImgH4 temporal_output_tex, output_tex, smooth_var_output_tex; ImgH2 velocity_output_tex;
     int row0, row1;
 };
+template <bool TILED>   // TILED: input extent == output extent, so both stencils are centred on texel (x, y) and can be staged through LDS
 __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
     const int row0 = a.row0, row1 = a.row1;
     const int OW = a.temporal_output_tex.w, OH = a.temporal_output_tex.h;
     TILE_XY(OW, OH)
+    __shared__ float4 hist_tile[TILED ? 12 * 12 : 1];   // raw reprojected history (5x5 blur)
+    __shared__ float4 col_tile[TILED ? 10 * 10 : 1];    // decoded YCbCr of the input (3x3 unjitter taps)
+    if (TILED) {
+        const int tx0 = int(blockIdx.x) * 8, ty0 = row0 + int(blockIdx.y) * 8;
+        for (int i = lane; i < 144; i += 64) {
+            const V4 h = ld4(a.history_tex, tx0 - 2 + i % 12, ty0 - 2 + i / 12);
+            hist_tile[i] = make_float4(h.x, h.y, h.z, h.w);
+        }
+        for (int i = lane; i < 100; i += 64) {
+            const V3 c = sRGB_to_YCbCr(taa_decode_rgb(xyz(ld4(a.input_tex, tx0 - 1 + i % 10, ty0 - 1 + i / 10))));
+            col_tile[i] = make_float4(c.x, c.y, c.z, 0.0f);
+        }
+        __syncthreads();
+    }
     if (!in_image) return;
     const FrameConstants& fc = *a.fc;
     const V4 ots = tex_size4(OW, OH);
@@ -247,7 +325,10 @@ __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
     const V2 sop{fc.view_constants.sample_offset_pixels[0], fc.view_constants.sample_offset_pixels[1]};
     const int rx = int(uint32_t((float(x) + 0.5f) * frac_.x)), ry = int(uint32_t((float(y) + 0.5f) * frac_.y));
     const V2 uv = get_uv(float(x), float(y), ots);
-    const V4 history_packed = ld4(a.history_tex, x, y);
+    const int lth = ((lane >> 3) + 2) * 12 + (lane & 7) + 2, ltc = ((lane >> 3) + 1) * 10 + (lane & 7) + 1;
+    V4 history_packed;
+    if (TILED) { const float4 t = hist_tile[lth]; history_packed = V4{t.x, t.y, t.z, t.w}; }
+    else history_packed = ld4(a.history_tex, x, y);
     V3 history = xyz(history_packed);
     float history_coverage = fmaxf(0.0f, history_packed.w);
     V4 csum = v4(0.0f); float wsum = 0;
@@ -256,7 +337,10 @@ __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
 #pragma unroll
         for (int ox = -2; ox <= 2; ++ox) {
             const float w = expf(-float(ox * ox + oy * oy));
-            csum += ld4(a.history_tex, x + ox, y + oy) * w;
+            V4 hv;
+            if (TILED) { const float4 t = hist_tile[lth + oy * 12 + ox]; hv = V4{t.x, t.y, t.z, t.w}; }
+            else hv = ld4(a.history_tex, x + ox, y + oy);
+            csum += hv * w;
             wsum += w;
         }
     const V4 bhistory_packed = csum / wsum;
@@ -266,8 +350,8 @@ __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
     bhistory = sRGB_to_YCbCr(bhistory);
     const V4 reproj = ld_reproj(a.reprojection_tex, rx, ry);
     const V2 reproj_xy = ld2h(a.closest_velocity_tex, x, y);
-    const Unjittered center_sample = sample_image_unjitter_taa(a.input_tex, x, y, V2{ots.x, ots.y}, sop, 1.0f);
-    const Unjittered bcenter_sample = sample_image_unjitter_taa(a.input_tex, x, y, V2{ots.x, ots.y}, sop, 0.333f);
+    Unjittered center_sample, bcenter_sample;
+    sample_image_unjitter_taa2<TILED>(a.input_tex, col_tile + (TILED ? ltc : 0), x, y, V2{ots.x, ots.y}, sop, 1.0f, 0.333f, center_sample, bcenter_sample);
     float coverage = center_sample.coverage;
     V3 center = xyz(center_sample.color);
     const V3 bcenter = xyz(bcenter_sample.color) / bcenter_sample.coverage;
@@ -405,7 +489,10 @@ static KjStatus taa_render_impl(KjTaa* t, const void* input_tex, uint32_t input_
         KJ_CHECK_LAUNCH();
     }
     if (mask & 4u) {
-        hipLaunchKernelGGL(k_taa_filter_history, gi, blk, 0, s, img<uint2>(reprojected_history, OW, OH), img<uint2>(filtered_history, IW, IH), ir0, ir1);
+        const ImgH4 rh = img<uint2>(reprojected_history, OW, OH), fh = img<uint2>(filtered_history, IW, IH);
+        if (float(OW) / float(IW) > 1.75f) hipLaunchKernelGGL((k_taa_filter_history<2, false>), gi, blk, 0, s, rh, fh, ir0, ir1);
+        else if (OW == IW && OH == IH) hipLaunchKernelGGL((k_taa_filter_history<1, true>), gi, blk, 0, s, rh, fh, ir0, ir1);
+        else hipLaunchKernelGGL((k_taa_filter_history<1, false>), gi, blk, 0, s, rh, fh, ir0, ir1);
         KJ_CHECK_LAUNCH();
     }
     if (mask & 8u) {
@@ -429,7 +516,8 @@ static KjStatus taa_render_impl(KjTaa* t, const void* input_tex, uint32_t input_
     a.smooth_var_output_tex = img<uint2>(sv_out, OW, OH); a.velocity_output_tex = img<uint32_t>(vel_out, OW, OH);
     a.row0 = or0; a.row1 = or1;
     if (mask & 64u) {
-        hipLaunchKernelGGL(k_taa, go, blk, 0, s, a);
+        if (IW == OW && IH == OH) hipLaunchKernelGGL(k_taa<true>, go, blk, 0, s, a);
+        else hipLaunchKernelGGL(k_taa<false>, go, blk, 0, s, a);
         KJ_CHECK_LAUNCH();
     }
     out->temporal_out = temporal_out;
