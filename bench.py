@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--scene", default="city", choices=["city", "ruins", "cornell"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=12)
+    ap.add_argument("--no-overlap", action="store_true", help="serial frames: do not overlap the next frame's ircache work with this frame's screen-space tail")
     ap.add_argument("--virtual-ranks", type=int, default=0, help="debug: run the N-way screen-tile split on ONE GPU (LocalComm)")
     ap.add_argument("--motion-halo", type=int, default=16, help="rows of history exchanged beyond the stencil (>= max |screen motion| per frame)")
     return ap.parse_args()
@@ -127,7 +128,7 @@ def main():
     single = split is None
 
     # ---- pre-generate the inputs of every frame (resident in HBM before the timed region; replicated on every rank)
-    n_frames = Wm + K + (args.profile_frames + 3 if single else 0)
+    n_frames = Wm + K + (args.profile_frames + 3 if single else 0) + 1
     fcs = frame_constants_list(W, H, n_frames, cam_args)
     inputs = []
     for fc in fcs:
@@ -157,8 +158,28 @@ def main():
     all_pipes = [gp] if single else list(split.pipes.values())
     gp_counters = [lib.tensor_from_ptr(*_counter_ptr(q, lib), torch.int64, (6,)) for q in all_pipes]
     irc_counters = [q.ircache_buffer("ray_counters", torch.int64) for q in all_pipes]
-    ray_log = torch.zeros((n_frames, 6), dtype=torch.int64, device=f"cuda:{local_rank}")
-    irc_log = torch.zeros((n_frames, 2), dtype=torch.int64, device=f"cuda:{local_rank}")
+    ray_log = torch.zeros((n_frames + 1, 6), dtype=torch.int64, device=f"cuda:{local_rank}")
+    irc_log = torch.zeros((n_frames + 1, 2), dtype=torch.int64, device=f"cuda:{local_rank}")
+    overlap = single and not args.no_overlap
+    serial_step = step
+    if overlap:
+        # frame pipelining (GpuPipeline.frame_pipelined): frame i+1's ircache maintenance + rays run on a second stream under
+        # frame i's screen-space tail. Same work per step, same dependencies; only the schedule differs.
+        irc_frame = [0]
+
+        def log_irc():
+            irc_log[irc_frame[0]].copy_(irc_counters[0], non_blocking=True)   # on the ircache stream, right after its rays
+        gp.on_ircache_traced = log_irc
+
+        def step(i):  # noqa: F811
+            gn, gb, d, rp = inputs[i]
+            gp.geometric_normal, gp.gbuffer, gp.depth = gn, gb, d
+            gp.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+            irc_frame[0] = i + 1
+            gp.frame_pipelined(fcs[i + 1])
+        torch.cuda.synchronize()
+        irc_frame[0] = 1
+        gp.pipeline_begin(fcs[1])
     for i in range(1, Wm):
         step(i)
 
@@ -172,7 +193,8 @@ def main():
     for i in range(Wm, Wm + K):
         step(i)
         ray_log[i].copy_(gp_counters[0], non_blocking=True)  # 48-byte device-to-device copy on the same stream
-        irc_log[i].copy_(irc_counters[0], non_blocking=True)
+        if not overlap:
+            irc_log[i].copy_(irc_counters[0], non_blocking=True)
         for c_, ic_ in zip(gp_counters[1:], irc_counters[1:]):   # virtual ranks only
             ray_log[i] += c_
             irc_log[i] += ic_
@@ -196,6 +218,10 @@ def main():
     total_rays = total_rays_all = rays_closest + rays_any + irc_rays
 
     seg, pass_ms, roofline = None, None, None
+    if overlap:
+        torch.cuda.synchronize()
+        gp.on_ircache_traced = None
+        step = serial_step
     if single:
         # ---- per-pass GPU timestamps (HIP events on the launch stream), after the timed region
         gp.set_profiling(True, False)
@@ -283,7 +309,7 @@ def main():
         "config": {"workload": f"{scene_label}, {W}x{H}, rtdgi: reproject+validate+trace+validity+temporal ReSTIR+2x spatial ReSTIR+"
                                "resolve+temporal+spatial denoise, irradiance cache (scroll/age/compact, accessibility+validate+trace rays, SH sum), TAA (7 passes) on the GI output",
                    "triangles": stats["triangles"], "bvh_nodes": stats["nodes"], "bvh_bytes": stats["bvh_bytes"],
-                   "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": "single GPU" if nsplit <= 1 else f"{nsplit}-way screen-tile split (16-row-aligned strips; halo exchange + temporal2 all-gather over "
+                   "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": ("single GPU, 2 HIP streams: next frame's ircache rays overlap this frame's screen-space tail" if overlap else "single GPU, serial frames") if nsplit <= 1 else f"{nsplit}-way screen-tile split (16-row-aligned strips; halo exchange + temporal2 all-gather over "
                                   + ("RCCL P2P" if world > 1 else "virtual ranks on one GPU") + f"; motion halo {args.motion_halo} rows; irradiance cache replicated per rank)"},
         "segment_ms": seg,
         "pass_ms": {n: round(v, 4) for n, v in zip(lib.GpuPipeline.PASS_NAMES, pass_ms)} if pass_ms else None,

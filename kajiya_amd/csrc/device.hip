@@ -18,9 +18,15 @@ __global__ void k_brdf_fg_lut(uint2* __restrict__ out) {
     const float roughness = fmaxf(1e-5f, float(y) / 63.0f);
     out[y * 64 + x] = pack_rgba16f(v4(integrate_brdf_fg(roughness, ndotv), 0.0f));
 }
-__global__ void k_sun_color(const FrameConstants* __restrict__ fc, float4* __restrict__ out) {
-    const V3 c = sun_color_in_direction(*fc, sun_direction(*fc));
-    *out = make_float4(c.x, c.y, c.z, 0.0f);
+// kj_frame_begin: store the frame constants (passed by value in the kernarg segment) into their ring slot and hoist SUN_COLOR.
+__global__ void __launch_bounds__(64) k_frame_begin(const KjFrameConstants fc, KjFrameConstants* __restrict__ dst, float4* __restrict__ sun_out) {
+    const uint32_t* src = (const uint32_t*)&fc;
+    uint32_t* d = (uint32_t*)dst;
+    for (uint32_t i = threadIdx.x; i < sizeof(KjFrameConstants) / 4; i += 64) d[i] = src[i];
+    if (threadIdx.x == 0) {
+        const V3 c = sun_color_in_direction(fc, sun_direction(fc));
+        *sun_out = make_float4(c.x, c.y, c.z, 0.0f);
+    }
 }
 __global__ void k_sky_cube(const FrameConstants* __restrict__ fc, uint2* __restrict__ out, int width) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, face = blockIdx.z;
@@ -194,9 +200,9 @@ KjStatus kj_frame_begin(KjDevice* dev, const KjFrameConstants* fc, void* stream_
     dev->fc_slot = (dev->fc_slot + 1) % KjDevice::FC_RING;
     dev->fc_host = *fc;
     KjFrameConstants* dst = (KjFrameConstants*)dev->frame_constants.p + dev->fc_slot;
-    KJ_TRY_HIP(hipMemcpyAsync(dst, fc, sizeof(KjFrameConstants), hipMemcpyHostToDevice, stream));
+    // The 1216-byte block travels as a kernel argument: no pageable-memory staging copy, fully asynchronous.
     dev->fc_dev = dst;
-    hipLaunchKernelGGL(k_sun_color, dim3(1), dim3(1), 0, stream, dst, (float4*)dev->sun_color.p + dev->fc_slot);
+    hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, stream, *fc, dst, (float4*)dev->sun_color.p + dev->fc_slot);
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }

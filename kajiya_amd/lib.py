@@ -229,6 +229,7 @@ class GpuPipeline:
         self.taa = C.c_void_p()
         check(L.kj_taa_create(dev.h, C.byref(self.taa)))
         self.taa_out = KjTaaOutput()
+        self.on_ircache_traced = None
         self.ircache = None
         if use_ircache:
             self.ircache = C.c_void_p()
@@ -288,6 +289,56 @@ class GpuPipeline:
             check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
         p = self.params(pass_mask)
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+
+    # ---- frame pipelining (async compute). The irradiance cache's maintenance + ray kernels of frame N+1 only depend on
+    # the cache state left by frame N's rtdgi validate/trace passes and on frame N+1's constants, and they are latency-bound
+    # (a few hundred waves walking the BVH). They are therefore issued on a second HIP stream as soon as frame N's trace pass
+    # is done and overlap frame N's screen-space tail (ReSTIR resampling, resolve, denoise, TAA). Same dependencies as the
+    # serial order of world_render_passes.rs:99-163, hence the same results (up to the cache's own atomics races).
+    def pipeline_begin(self, fc):
+        """Prime the pipeline: upload `fc` and issue the ircache work of the first frame on the side stream."""
+        torch = self.torch
+        assert self.ircache, "pipelining overlaps the irradiance cache; nothing to do without it"
+        self._s1 = torch.cuda.Stream()
+        self._ev_irc = [torch.cuda.Event(), torch.cuda.Event()]
+        self._ev_trace = [torch.cuda.Event(), torch.cuda.Event()]
+        self._pipe_i = 0
+        self._enqueue_ircache(fc, None)
+
+    def _enqueue_ircache(self, fc, wait_event):
+        torch = self.torch
+        s0 = torch.cuda.current_stream()
+        with torch.cuda.stream(self._s1):
+            self._s1.wait_stream(s0) if wait_event is None else self._s1.wait_event(wait_event)
+            self.dev.frame_begin(fc)
+            s = _stream_ptr()
+            check(self.L.kj_ircache_prepare(self.ircache, s))
+            check(self.L.kj_ircache_trace_irradiance(self.ircache, self.scene.h, self.sky16.data_ptr(), 16, s))
+            if self.on_ircache_traced is not None:
+                self.on_ircache_traced()          # e.g. the bench logs the cache's ray counters, stream-ordered
+            self._ev_irc[self._pipe_i & 1].record(self._s1)
+
+    def frame_pipelined(self, next_fc):
+        """One GI + TAA frame whose ircache work was issued earlier; then issue the next frame's (if any). The caller binds this
+        frame's G-buffer inputs before the call. `next_fc` = constants of the following frame or None for the last one."""
+        torch = self.torch
+        s0 = torch.cuda.current_stream()
+        i = self._pipe_i & 1
+        s0.wait_event(self._ev_irc[i])
+        s = _stream_ptr()
+        P = KJ_RTDGI_PASS
+        check(self.L.kj_rtdgi_reproject(self.rtdgi, self.reprojection_map_ptr, self.W, self.H, s))
+        check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
+        head = P["EXTRACT_HALF"] | P["VALIDATE"] | P["TRACE"]
+        p = self.params(head)
+        check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+        self._ev_trace[i].record(s0)
+        p = self.params((P["ALL"] & ~head) | (1 << 31))
+        check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+        self.taa_frame()
+        self._pipe_i += 1
+        if next_fc is not None:
+            self._enqueue_ircache(next_fc, self._ev_trace[i])
 
     def taa_frame(self, input_ptr=None, out_extent=None):
         """TaaRenderer::render on `input_ptr` (default: this frame's rtdgi screen_irradiance_tex)."""

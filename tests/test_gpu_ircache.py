@@ -138,3 +138,65 @@ def test_ircache_free_running_structure_and_statistics(gpu, oracle, device):
     r = P.compare(got, ref, "rgba16f")
     print("free-running GI with ircache:", r)
     assert r["rel_l2"] < 5e-2
+
+
+def test_pipelined_frames_match_serial_frames(gpu, device):
+    """GpuPipeline.frame_pipelined issues frame N+1's ircache work on a second stream under frame N's screen-space tail.
+    Dependencies are those of the serial order, so the result may differ only through the cache's own atomics races
+    (which also make two serial runs differ): compare the time-averaged GI and TAA outputs."""
+    import torch
+    from kajiya_amd import frame
+    W, H, N = 256, 160, 24
+    desc = T._scenes()["city20k"]
+    scene = gpu.Scene(device, desc)
+
+    def fcs():
+        fs = frame.FrameState((W, H))
+        fs.ircache_enabled = True
+        out = []
+        for i in range(N + 1):
+            out.append(fs.prepare_frame_constants(frame.orbit_camera(i, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.004)))
+            fs.retire_frame()
+        return out
+    F = fcs()
+    # inputs rendered once (they do not depend on the GI state)
+    src = gpu.GpuPipeline(device, scene, W, H)
+    inputs = []
+    for fc in F:
+        src.render_inputs(fc)
+        src.reprojection()
+        rp = gpu.tensor_from_ptr(src.reprojection_map_ptr.value, W * H * 8, torch.int16, (H, W, 4)).clone()
+        inputs.append((src.geometric_normal.clone(), src.gbuffer.clone(), src.depth.clone(), rp))
+    torch.cuda.synchronize()
+
+    def run(pipelined):
+        gp = gpu.GpuPipeline(device, scene, W, H, use_ircache=True)
+        gp.sky64, gp.sky16 = src.sky64, src.sky16
+        acc_gi = torch.zeros((H, W, 3), device="cuda")
+        acc_taa = torch.zeros((H, W, 3), device="cuda")
+        if pipelined:
+            gp.pipeline_begin(F[0])
+        for i in range(N):
+            gn, gb, d, rp = inputs[i]
+            gp.geometric_normal, gp.gbuffer, gp.depth = gn, gb, d
+            gp.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+            if pipelined:
+                gp.frame_pipelined(F[i + 1])
+            else:
+                device.frame_begin(F[i])
+                gp.gi_frame()
+                gp.taa_frame()
+            if i >= 8:
+                acc_gi += gp.surface("spatial_filtered_tex", torch.float16, (H, W, 4))[..., :3].float()
+                acc_taa += gp.taa_surface(f"taa:{i % 2}", torch.float16, (H, W, 4))[..., :3].float()
+        torch.cuda.synchronize()
+        return acc_gi.cpu().numpy(), acc_taa.cpu().numpy(), gp.ircache_ray_counts()
+    a_gi, a_taa, a_rays = run(False)
+    b_gi, b_taa, b_rays = run(True)
+    c_gi, c_taa, _ = run(False)          # serial vs serial: the noise floor of the comparison
+    rel = lambda x, y: float(np.sqrt(((x - y) ** 2).sum() / (y ** 2).sum()))
+    floor_gi, floor_taa = rel(c_gi, a_gi), rel(c_taa, a_taa)
+    print(f"pipelined vs serial: GI rel-L2 {rel(b_gi, a_gi):.5f} (serial-vs-serial floor {floor_gi:.5f}), TAA {rel(b_taa, a_taa):.5f} (floor {floor_taa:.5f}); ircache rays {a_rays} vs {b_rays}")
+    assert np.isfinite(b_gi).all() and np.isfinite(b_taa).all()
+    assert rel(b_gi, a_gi) < max(2e-2, 3 * floor_gi) and rel(b_taa, a_taa) < max(2e-2, 3 * floor_taa)
+    assert abs(sum(a_rays) - sum(b_rays)) / max(1, sum(a_rays)) < 0.05
