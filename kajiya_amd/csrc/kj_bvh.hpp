@@ -90,6 +90,12 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
     const float eps = 1e-20f;
     const V3 inv_d{1.0f / (fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x), 1.0f / (fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y),
                    1.0f / (fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z)};
+    // Traversal stack: the first KJ_BVH_LDS_STACK entries live in LDS ([level][lane]); the rare deeper ones spill to a
+    // private array (scratch). Near-first ordering keeps a typical ray's stack far below the builder's worst-case bound,
+    // so the LDS footprint (4 KB / wave) no longer caps occupancy the way a bound-sized LDS stack did (11 KB / wave).
+    uint32_t spill[KJ_BVH_SPILL_STACK];
+#define KJ_PUSH(v_) { const uint32_t pv_ = (v_); if (sp < KJ_BVH_LDS_STACK) stack[sp * stride] = pv_; else spill[sp - KJ_BVH_LDS_STACK] = pv_; sp++; }
+#define KJ_POP(dst_) { if (sp == 0) dst_ = NONE; else { --sp; dst_ = sp < KJ_BVH_LDS_STACK ? stack[sp * stride] : spill[sp - KJ_BVH_LDS_STACK]; } }
     uint32_t sp = 0;
     uint32_t cur = 0;   // root node
     const uint32_t NONE = 0xffffffffu;
@@ -123,11 +129,11 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
 #define KJ_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
             KJ_CSWAP(0, 1) KJ_CSWAP(2, 3) KJ_CSWAP(0, 2) KJ_CSWAP(1, 3) KJ_CSWAP(1, 2)
 #undef KJ_CSWAP
-            if (key[3] != NONE) { stack[sp * stride] = sel4(key[3] & 3u, ch.x, ch.y, ch.z, ch.w); sp++; }
-            if (key[2] != NONE) { stack[sp * stride] = sel4(key[2] & 3u, ch.x, ch.y, ch.z, ch.w); sp++; }
-            if (key[1] != NONE) { stack[sp * stride] = sel4(key[1] & 3u, ch.x, ch.y, ch.z, ch.w); sp++; }
+            if (key[3] != NONE) KJ_PUSH(sel4(key[3] & 3u, ch.x, ch.y, ch.z, ch.w))
+            if (key[2] != NONE) KJ_PUSH(sel4(key[2] & 3u, ch.x, ch.y, ch.z, ch.w))
+            if (key[1] != NONE) KJ_PUSH(sel4(key[1] & 3u, ch.x, ch.y, ch.z, ch.w))
             if (key[0] != NONE) cur = sel4(key[0] & 3u, ch.x, ch.y, ch.z, ch.w);
-            else cur = sp ? stack[(--sp) * stride] : NONE;
+            else KJ_POP(cur)
         } else {
             const uint32_t first = cur & 0x0fffffffu;
             const uint32_t count = ((cur >> 28) & 7u) + 1u;
@@ -139,9 +145,11 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
                     if (ANY_HIT) return h;
                 }
             }
-            cur = sp ? stack[(--sp) * stride] : NONE;
+            KJ_POP(cur)
         }
     }
+#undef KJ_PUSH
+#undef KJ_POP
     return h;
 }
 #endif // __HIPCC__

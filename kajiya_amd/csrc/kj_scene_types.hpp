@@ -29,8 +29,8 @@ static_assert(sizeof(BvhTri) == 48, "tri size");
 
 #define KJ_BVH_LEAF 0x80000000u
 #define KJ_BVH_MAX_LEAF_TRIS 4u
-#define KJ_BVH_LDS_STACK 24u      // traversal stack entries kept in LDS per lane ...
-#define KJ_BVH_SPILL_STACK 104u   // ... deeper entries spill to private (scratch) memory; builds needing more are rejected
+#define KJ_BVH_LDS_STACK 16u      // traversal stack entries kept in LDS per lane ...
+#define KJ_BVH_SPILL_STACK 112u   // ... deeper entries spill to private (scratch) memory; builds needing more are rejected
 
 struct BvhView {
     const F4* nodes;         // 4 x 16 B per node; node 0 is the root

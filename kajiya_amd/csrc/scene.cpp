@@ -34,7 +34,7 @@ SceneView scene_view(const KjScene& s) {
     v.bvh.nodes = (const F4*)s.d_nodes.p;
     v.bvh.tris = (const F4*)s.d_tris.p;
     v.bvh.root = s.bvh_root;
-    v.bvh.stack_entries = s.bvh_max_depth + 1;   // builder's bound on the traversal stack
+    v.bvh.stack_entries = KJ_BVH_LDS_STACK;      // LDS part of the traversal stack; deeper entries spill (kj_bvh.hpp)
     return v;
 }
 
@@ -192,7 +192,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     // 2. hierarchy (bvh_build.cpp)
     BuiltBvh b;
     build_bvh4(wt, b);
-    KJ_REQUIRE(b.max_stack + 1 <= 256, "BVH too deep for the LDS traversal stack");
+    KJ_REQUIRE(b.max_stack + 1 <= KJ_BVH_LDS_STACK + KJ_BVH_SPILL_STACK, "BVH too deep for the traversal stack");
     s->tri_count = uint32_t(b.tris.size());
     s->node_count = uint32_t(b.nodes.size());
     s->bvh_root = 0;
