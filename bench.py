@@ -294,8 +294,17 @@ def main():
         trace_bytes = hw * hh * 38 + trace_share * (closest_per_frame * bytes_per_closest + any_per_frame * bytes_per_any)
         trace_ms = pass_ms[3]
         achieved = trace_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        traffic = None   # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): committed measurement
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_trace_traffic.json")))
+            wl = pm["workload"]
+            if (wl["scene"], wl["tris"], wl["width"], wl["height"]) == (args.scene, args.tris, W, H):
+                traffic = int(1024 * (pm["fetch_kb_per_launch"] + pm["write_kb_per_launch"]))
+        except Exception:
+            traffic = None
         roofline = {"kernel": "k_rtdgi_trace", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": "profiles/pmc_trace_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
                     "avg_launch_ms": round(trace_ms, 4), "algorithmic_bytes_per_launch": int(trace_bytes),
                     "nodes_per_closest_ray": round(nodes_per_closest, 2), "tris_per_closest_ray": round(tris_per_closest, 2),
                     "nodes_per_any_ray": round(nodes_per_any, 2), "tris_per_any_ray": round(tris_per_any, 2),

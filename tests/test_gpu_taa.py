@@ -18,7 +18,7 @@ def _decode_r16f(raw):
     return raw.view(np.float16).astype(np.float32).reshape(-1, 1)
 
 
-@pytest.mark.parametrize("scene_name,W,H", [("cornell", 192, 160), ("city20k", 256, 144)])
+@pytest.mark.parametrize("scene_name,W,H", [("cornell", 192, 160), ("city20k", 256, 144), ("city20k", 123, 77)])
 def test_taa_per_frame_parity(gpu, oracle, device, scene_name, W, H):
     import torch
     desc = T._scenes()[scene_name]
