@@ -160,26 +160,29 @@ def main():
     irc_counters = [q.ircache_buffer("ray_counters", torch.int64) for q in all_pipes]
     ray_log = torch.zeros((n_frames + 1, 6), dtype=torch.int64, device=f"cuda:{local_rank}")
     irc_log = torch.zeros((n_frames + 1, 2), dtype=torch.int64, device=f"cuda:{local_rank}")
-    overlap = single and not args.no_overlap
+    overlap = not args.no_overlap
     serial_step = step
     if overlap:
-        # frame pipelining (GpuPipeline.frame_pipelined): frame i+1's ircache maintenance + rays run on a second stream under
-        # frame i's screen-space tail. Same work per step, same dependencies; only the schedule differs.
+        # frame pipelining (GpuPipeline.frame_pipelined / SplitRtdgi.frame_pipelined): frame i+1's ircache maintenance + rays run
+        # on a second stream under frame i's screen-space tail. Same work per step, same dependencies; only the schedule differs.
         irc_frame = [0]
 
-        def log_irc():
-            irc_log[irc_frame[0]].copy_(irc_counters[0], non_blocking=True)   # on the ircache stream, right after its rays
-        gp.on_ircache_traced = log_irc
+        def log_irc():   # on the ircache stream, right after its rays
+            irc_log[irc_frame[0]].copy_(irc_counters[0], non_blocking=True)
+            for ic_ in irc_counters[1:]:
+                irc_log[irc_frame[0]] += ic_
+        (gp if single else split).on_ircache_traced = log_irc
 
         def step(i):  # noqa: F811
             gn, gb, d, rp = inputs[i]
-            gp.geometric_normal, gp.gbuffer, gp.depth = gn, gb, d
-            gp.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+            for q in all_pipes:
+                q.geometric_normal, q.gbuffer, q.depth = gn, gb, d
+                q.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
             irc_frame[0] = i + 1
-            gp.frame_pipelined(fcs[i + 1])
+            (gp if single else split).frame_pipelined(fcs[i + 1])
         torch.cuda.synchronize()
         irc_frame[0] = 1
-        gp.pipeline_begin(fcs[1])
+        (gp if single else split).pipeline_begin(fcs[1])
     for i in range(1, Wm):
         step(i)
 
@@ -193,11 +196,12 @@ def main():
     for i in range(Wm, Wm + K):
         step(i)
         ray_log[i].copy_(gp_counters[0], non_blocking=True)  # 48-byte device-to-device copy on the same stream
+        for c_ in gp_counters[1:]:   # virtual ranks only
+            ray_log[i] += c_
         if not overlap:
             irc_log[i].copy_(irc_counters[0], non_blocking=True)
-        for c_, ic_ in zip(gp_counters[1:], irc_counters[1:]):   # virtual ranks only
-            ray_log[i] += c_
-            irc_log[i] += ic_
+            for ic_ in irc_counters[1:]:
+                irc_log[i] += ic_
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -220,7 +224,7 @@ def main():
     seg, pass_ms, roofline = None, None, None
     if overlap:
         torch.cuda.synchronize()
-        gp.on_ircache_traced = None
+        (gp if single else split).on_ircache_traced = None
         step = serial_step
     if single:
         # ---- per-pass GPU timestamps (HIP events on the launch stream), after the timed region
@@ -318,8 +322,9 @@ def main():
         "config": {"workload": f"{scene_label}, {W}x{H}, rtdgi: reproject+validate+trace+validity+temporal ReSTIR+2x spatial ReSTIR+"
                                "resolve+temporal+spatial denoise, irradiance cache (scroll/age/compact, accessibility+validate+trace rays, SH sum), TAA (7 passes) on the GI output",
                    "triangles": stats["triangles"], "bvh_nodes": stats["nodes"], "bvh_bytes": stats["bvh_bytes"],
-                   "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": ("single GPU, 2 HIP streams: next frame's ircache rays overlap this frame's screen-space tail" if overlap else "single GPU, serial frames") if nsplit <= 1 else f"{nsplit}-way screen-tile split (16-row-aligned strips; halo exchange + temporal2 all-gather over "
-                                  + ("RCCL P2P" if world > 1 else "virtual ranks on one GPU") + f"; motion halo {args.motion_halo} rows; irradiance cache replicated per rank)"},
+                   "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": ("single GPU, 2 HIP streams: next frame's ircache rays overlap this frame's screen-space tail" if overlap else "single GPU, serial frames") if nsplit <= 1 else f"{nsplit}-way screen-tile split (16-row-aligned strips; 6 batched halo exchanges per frame incl. the temporal2 all-gather, over "
+                                  + ("RCCL P2P" if world > 1 else "virtual ranks on one GPU") + f"; motion halo {args.motion_halo} rows; irradiance cache replicated per rank"
+                                  + ("; next frame's ircache work overlapped on a second stream)" if overlap else ")")},
         "segment_ms": seg,
         "pass_ms": {n: round(v, 4) for n, v in zip(lib.GpuPipeline.PASS_NAMES, pass_ms)} if pass_ms else None,
         "roofline": roofline,

@@ -113,8 +113,19 @@ class DistComm:
 
 
 class SplitRtdgi:
-    """Drives RtdgiRenderer::{reproject,render} strip by strip with halo exchanges.
-    `pipes`: {rank: GpuPipeline} for the ranks living in this process (one for DistComm, N for LocalComm)."""
+    """Drives RtdgiRenderer::{reproject,render} + TaaRenderer::render strip by strip with halo exchanges.
+    `pipes`: {rank: GpuPipeline} for the ranks living in this process (one for DistComm, N for LocalComm).
+
+    Six exchange points per frame (each ONE batched send/recv group):
+      A  frame start     all-gather of last frame's rtdgi.temporal2 (+variance); TAA's three histories (motion halo)
+      B  after validate  the five reservoir histories (validate rewrites them in place), invalidity, validity_pre
+      C  after trace     validity_in (2), candidate radiance / hit (11)
+      D  after temporal  reservoir, packed reservoir, radiance: 64 half-res rows (the "one-deep" exchange of SURVEY 8e-2)
+      H  after the temporal filter   16 full-res rows for the spatial filter's taps
+      I  before TAA      25 rows of the GI output
+    Between D and H nothing is exchanged: spatial pass 0 is over-computed on +-32 half-res rows, pass 1 on +-16, the resolve on
+    +-16 full-res rows, which covers every tap of the next pass (restir_spatial.hlsl:89-97,155-157; restir_resolve.hlsl:89-96;
+    temporal_filter.hlsl:69-89). TAA over-computes its intermediates the same way (taa_frame)."""
 
     def __init__(self, comm, pipes, width, height, motion_halo=8):
         self.comm, self.pipes = comm, pipes
@@ -123,27 +134,47 @@ class SplitRtdgi:
         self.motion_halo = motion_halo
         self.frame = 0
         self.taa_frames = 0
+        self._views = {}
+        self._plans = {}
+        self._side = None          # side stream state for pipelined ircache work
+        self.on_ircache_traced = None
 
     # -- helpers
+    def _surface(self, rank, name):
+        key = (rank, name)
+        t = self._views.get(key)
+        if t is None:
+            import torch
+            gp = self.pipes[rank]
+            if name.startswith("TAA/"):
+                t = gp.taa_surface(name[4:], torch.uint8, (self.H, self.W * TAA_SURF[name[4:].split(":")[0]]))
+            else:
+                bpt, res = SURF[name.split(":")[0]]
+                w = (self.W + 1) // 2 if res == "h" else self.W
+                h = (self.H + 1) // 2 if res == "h" else self.H
+                t = gp.surface(name, torch.uint8, (h, w * bpt))
+            self._views[key] = t      # renderer surfaces are allocated once per extent: the pointer is stable
+        return t
+
     def _rows_view(self, rank, name, a, b):
-        import torch
-        gp = self.pipes[rank]
-        if name.startswith("TAA/"):
-            return gp.taa_surface(name[4:], torch.uint8, (self.H, self.W * TAA_SURF[name[4:].split(":")[0]]))[a:b]
-        bpt, res = SURF[name.split(":")[0]]
-        w = (self.W + 1) // 2 if res == "h" else self.W
-        h = (self.H + 1) // 2 if res == "h" else self.H
-        t = gp.surface(name, torch.uint8, (h, w * bpt))
-        return t[a:b]
+        return self._surface(rank, name)[a:b]
 
     def _exchange(self, items):
         """items: [(surface name, halo rows or None)] -- ONE batched exchange for all of them (a single RCCL group:
         both ends enumerate (item, dst, src) in the same order, so per-pair send/recv order matches)."""
-        xfers = []
-        for name, halo in items:
-            res = "f" if name.startswith("TAA/") else SURF[name.split(":")[0]][1]
-            xfers += [(src, dst, (name, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H)]
+        key = tuple(items)
+        xfers = self._plans.get(key)
+        if xfers is None:
+            xfers = []
+            for name, halo in items:
+                res = "f" if name.startswith("TAA/") else SURF[name.split(":")[0]][1]
+                xfers += [(src, dst, (name, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H)]
+            self._plans[key] = xfers
         self.comm.run(xfers, lambda r, na, b: self._rows_view(r, na[0], na[1], b))
+
+    def _grow(self, rank, rows):
+        r0, r1 = self.strips[rank]
+        return max(0, r0 - rows), min(self.H, r1 + rows)
 
     def _render(self, rank, mask, rows=None, spatial_select=0):
         gp = self.pipes[rank]
@@ -153,70 +184,113 @@ class SplitRtdgi:
         p.spatial_pass_select = spatial_select
         klib.check(gp.L.kj_rtdgi_render(gp.rtdgi, C.byref(p), C.byref(gp.out), klib._stream_ptr()))
 
-    def gi_frame(self):
-        """One rtdgi frame (ircache per rank, if bound, runs through GpuPipeline's own calls before this)."""
+    def _ircache_head(self, gp, s):
+        klib.check(gp.L.kj_ircache_prepare(gp.ircache, s))
+        klib.check(gp.L.kj_ircache_trace_irradiance(gp.ircache, gp.scene.h, gp.sky16.data_ptr(), 16, s))
+
+    # -- frame pipelining (see GpuPipeline.frame_pipelined): each rank's replica of the ircache is updated on a side stream
+    def pipeline_begin(self, fc):
+        import torch
+        self._side = {"stream": torch.cuda.Stream(), "irc": [torch.cuda.Event(), torch.cuda.Event()], "trace": [torch.cuda.Event(), torch.cuda.Event()]}
+        self._enqueue_ircache(fc, None)
+
+    def _enqueue_ircache(self, fc, wait_event):
+        import torch
+        sd = self._side
+        s0 = torch.cuda.current_stream()
+        with torch.cuda.stream(sd["stream"]):
+            sd["stream"].wait_stream(s0) if wait_event is None else sd["stream"].wait_event(wait_event)
+            first = True
+            for r in self.comm.ranks:
+                gp = self.pipes[r]
+                if first:
+                    gp.dev.frame_begin(fc)     # one device (and one constants ring) per process
+                    first = False
+                if gp.ircache:
+                    self._ircache_head(gp, klib._stream_ptr())
+            if self.on_ircache_traced is not None:
+                self.on_ircache_traced()
+            sd["irc"][self.frame & 1].record(sd["stream"])
+
+    def frame_pipelined(self, next_fc):
+        """gi_frame + taa_frame with the ircache work issued ahead on the side stream; then issue the next frame's."""
+        import torch
+        i = self.frame & 1
+        torch.cuda.current_stream().wait_event(self._side["irc"][i])
+        self.gi_frame(ircache_done=True, trace_event=self._side["trace"][i])
+        self.taa_frame()
+        if next_fc is not None:
+            self._enqueue_ircache(next_fc, self._side["trace"][i])
+
+    def gi_frame(self, ircache_done=False, trace_event=None):
+        """One rtdgi frame. Unless `ircache_done`, each rank's ircache.prepare + trace_irradiance run here first (serial order)."""
         P = KJ_RTDGI_PASS
         out_sfx, hist_sfx = f":{self.frame % 2}", f":{1 - self.frame % 2}"
         M = self.motion_halo
         R = self.comm.ranks
+        # ---- A
+        items = []
         if self.frame > 0:
-            self._exchange([("rtdgi.temporal2" + hist_sfx, None), ("rtdgi.temporal2_var" + hist_sfx, None)])
+            items += [("rtdgi.temporal2" + hist_sfx, None), ("rtdgi.temporal2_var" + hist_sfx, None)]
+        if self.taa_frames > 0:
+            th = f":{1 - self.taa_frames % 2}"
+            items += [("TAA/taa" + th, M + 4 + 32), ("TAA/taa.velocity" + th, M + 2 + 16), ("TAA/taa.smooth_var" + th, M + 2 + 16)]
+        if items:
+            self._exchange(items)
         for r in R:
             gp = self.pipes[r]
             s = klib._stream_ptr()
-            if gp.ircache:
-                klib.check(gp.L.kj_ircache_prepare(gp.ircache, s))
-                klib.check(gp.L.kj_ircache_trace_irradiance(gp.ircache, gp.scene.h, gp.sky16.data_ptr(), 16, s))
+            if gp.ircache and not ircache_done:
+                self._ircache_head(gp, s)
             klib.check(gp.L.kj_rtdgi_reproject(gp.rtdgi, gp.reprojection_map_ptr, self.W, self.H, s))
             if gp.ircache:
                 klib.check(gp.L.kj_ircache_sum_up_irradiance_for_sampling(gp.ircache, s))
             self._render(r, P["EXTRACT_HALF"])                                   # replicated inputs: full frame, cheap
             self._render(r, P["VALIDATE"] | KEEP, self.strips[r])
+        # ---- B
+        items = [("rt_history_validity_pre_input_tex", M + 1)]
         if self.frame > 0:
-            self._exchange([(n + hist_sfx, M + 4) for n in ("rtdgi.reservoir", "rtdgi.ray_orig", "rtdgi.ray", "rtdgi.radiance", "rtdgi.hit_normal")]
-                           + [("rtdgi.invalidity" + hist_sfx, M + 8)])
-        self._exchange([("rt_history_validity_pre_input_tex", M + 1)])
+            items += [(n + hist_sfx, M + 4) for n in ("rtdgi.reservoir", "rtdgi.ray_orig", "rtdgi.ray", "rtdgi.radiance", "rtdgi.hit_normal")]
+            items += [("rtdgi.invalidity" + hist_sfx, M + 8)]
+        self._exchange(items)
         for r in R:
             self._render(r, P["TRACE"] | KEEP, self.strips[r])
-        self._exchange([("rt_history_validity_input_tex", 2), ("candidate_radiance_tex", 3), ("candidate_hit_tex", 3)])
+        if trace_event is not None:
+            import torch
+            trace_event.record(torch.cuda.current_stream())
+        # ---- C
+        self._exchange([("rt_history_validity_input_tex", 2), ("candidate_radiance_tex", 8 + 3), ("candidate_hit_tex", 8 + 3)])
         for r in R:
             self._render(r, P["VALIDITY_INTEGRATE"] | KEEP, self.strips[r])
             self._render(r, P["RESTIR_TEMPORAL"] | KEEP, self.strips[r])
-        self._exchange([("rtdgi.reservoir" + out_sfx, 32), ("temporal_reservoir_packed_tex", 51), ("rtdgi.radiance" + out_sfx, 51)])
+        # ---- D: the one-deep halo. Reach (half-res rows): pass 0 runs on own+-32 and taps +-32; pass 1 runs on own+-16, taps +-16
+        # and follows payloads another +-32; the resolve runs on own+-8, taps +-3 and follows payloads +-48.
+        self._exchange([("rtdgi.reservoir" + out_sfx, 64), ("temporal_reservoir_packed_tex", 64), ("rtdgi.radiance" + out_sfx, 64)])
         for r in R:
-            self._render(r, P["RESTIR_SPATIAL"] | KEEP, self.strips[r], spatial_select=1)
-        self._exchange([("reservoir_output_tex0", 16)])
-        for r in R:
-            self._render(r, P["RESTIR_SPATIAL"] | KEEP, self.strips[r], spatial_select=2)
-        self._exchange([("reservoir_output_tex1", 3)])
-        for r in R:
-            self._render(r, P["RESTIR_RESOLVE"] | KEEP, self.strips[r])
-        self._exchange([("irradiance_output_tex", 2)])
-        for r in R:
+            self._render(r, P["RESTIR_SPATIAL"] | KEEP, self._grow(r, 64), spatial_select=1)
+            self._render(r, P["RESTIR_SPATIAL"] | KEEP, self._grow(r, 32), spatial_select=2)
+            self._render(r, P["RESTIR_RESOLVE"] | KEEP, self._grow(r, 16))
             self._render(r, P["TEMPORAL_FILTER"] | KEEP, self.strips[r])
+        # ---- H
         self._exchange([("temporal_filtered_tex", 16)])
         for r in R:
             self._render(r, P["SPATIAL_FILTER"] | KEEP, self.strips[r])
         self.frame += 1
 
     def taa_frame(self):
-        """TaaRenderer::render on this frame's GI image, strip by strip. ONE exchange (the three histories and the
-        input's halo); the intermediate images are over-computed on up to 32 extra rows per side (8-row tile
+        """TaaRenderer::render on this frame's GI image, strip by strip. ONE exchange here (the input's halo; the three
+        histories travel with exchange A of gi_frame); the intermediate images are over-computed on up to 32 extra rows per side (8-row tile
         granularity) instead of being exchanged: prob_filter2 reaches +-4 rows of prob_filter, that +-1 of input_prob,
         that +-1 of the filtered history / input and +-2 of the input deviation, those +-1 of the reprojected history /
         input (taa/*.hlsl)."""
         import torch
-        M = self.motion_halo
         gi_out = "spatial_filtered_tex"
-        hist_sfx = f":{1 - self.taa_frames % 2}"
-        items = [(gi_out, 1 + 24)]                          # filter_input runs on +-24 rows
-        if self.taa_frames > 0:
-            items += [("TAA/taa" + hist_sfx, M + 4 + 32), ("TAA/taa.velocity" + hist_sfx, M + 2 + 16), ("TAA/taa.smooth_var" + hist_sfx, M + 2 + 16)]
-        self._exchange(items)
+        # ---- I
+        self._exchange([(gi_out, 1 + 24)])                   # filter_input runs on +-24 rows
         for r in self.comm.ranks:
             gp = self.pipes[r]
             r0, r1 = self.strips[r]
-            inp = gp.surface(gi_out, torch.uint8, (self.H, self.W * 8)).data_ptr()
+            inp = self._surface(r, gi_out).data_ptr()
 
             def run(mask, grow, keep=True):
                 a, b = max(0, r0 - grow), min(self.H, r1 + grow)

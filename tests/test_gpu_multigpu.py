@@ -33,6 +33,8 @@ def test_strip_split_is_bit_exact(gpu, device, n_ranks, W, H):
             b = pipes[r].surface("spatial_filtered_tex", torch.int16, (H, W, 4))
             neq = (a != b).any(dim=-1)
             assert not bool(neq.any()), f"frame {fi} rank {r}: {int(neq.sum())} texels differ (rows {torch.nonzero(neq.any(dim=1)).flatten()[:8].tolist()})"
+        rc = [pipes[r].ray_counts() for r in range(n_ranks)]
+        assert ref.ray_counts() == (sum(c[0] for c in rc), sum(c[1] for c in rc)), (fi, ref.ray_counts(), rc)
         ta = ref.taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4))
         for r in range(n_ranks):
             tb = pipes[r].taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4))
