@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--scene", default="city", choices=["city", "ruins", "cornell"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=12)
+    ap.add_argument("--no-ssgi", action="store_true", help="drive rtdgi with the constant SSAO guide instead of running SsgiRenderer each frame")
     ap.add_argument("--no-overlap", action="store_true", help="serial frames: do not overlap the next frame's ircache work with this frame's screen-space tail")
     ap.add_argument("--virtual-ranks", type=int, default=0, help="debug: run the N-way screen-tile split on ONE GPU (LocalComm)")
     ap.add_argument("--motion-halo", type=int, default=16, help="rows of history exchanged beyond the stencil (>= max |screen motion| per frame)")
@@ -138,6 +139,7 @@ def main():
         inputs.append((gp.geometric_normal.clone(), gp.gbuffer.clone(), gp.depth.clone(), rp))
     torch.cuda.synchronize()
     counters = gp_counters = None
+    use_ssgi = not args.no_ssgi    # in the screen-tile split every rank computes the (cheap) guide for the whole frame
 
     def step(i):
         gn, gb, d, rp = inputs[i]
@@ -145,12 +147,16 @@ def main():
         if single:
             gp.geometric_normal, gp.gbuffer, gp.depth = gn, gb, d
             gp.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+            if use_ssgi:
+                gp.ssgi_frame()   # SsgiRenderer::render -> the SSAO guide of this frame (world_render_passes.rs:90-96)
             gp.gi_frame()
             gp.taa_frame()   # TaaRenderer::render on the GI output (the reference feeds it the lit image; same kernels, same bytes)
         else:
             for q in split.pipes.values():
                 q.geometric_normal, q.gbuffer, q.depth = gn, gb, d
                 q.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+                if use_ssgi:
+                    q.ssgi_frame()
             split.gi_frame()
             split.taa_frame()
 
@@ -179,6 +185,9 @@ def main():
                 q.geometric_normal, q.gbuffer, q.depth = gn, gb, d
                 q.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
             irc_frame[0] = i + 1
+            if use_ssgi:
+                for q in all_pipes:
+                    q.ssgi_frame()
             (gp if single else split).frame_pipelined(fcs[i + 1])
         torch.cuda.synchronize()
         irc_frame[0] = 1
@@ -241,7 +250,7 @@ def main():
         pass_ms = [p / max(1, args.profile_frames) for p in pass_ms]
         gp.set_profiling(False, False)
         # ---- segment timers (torch events on the launch stream): ircache / rtdgi / taa
-        seg = {"ircache": 0.0, "rtdgi": 0.0, "taa": 0.0}
+        seg = {"ssgi": 0.0, "ircache": 0.0, "rtdgi": 0.0, "taa": 0.0}
         nseg = 6
         for i in range(base, base + nseg):   # replays inputs of already-used frames: timing only
             gn, gb, d, rp = inputs[i]
@@ -250,6 +259,9 @@ def main():
             dev.frame_begin(fcs[i])
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
             s_ = lib._stream_ptr()
+            evs = torch.cuda.Event(enable_timing=True); evs.record()
+            if use_ssgi:
+                gp.ssgi_frame()
             ev[0].record()
             lib.check(gp.L.kj_ircache_prepare(gp.ircache, s_))
             lib.check(gp.L.kj_ircache_trace_irradiance(gp.ircache, gp.scene.h, gp.sky16.data_ptr(), 16, s_))
@@ -264,6 +276,7 @@ def main():
             gp.taa_frame()
             ev5 = torch.cuda.Event(enable_timing=True); ev5.record()
             torch.cuda.synchronize()
+            seg["ssgi"] += evs.elapsed_time(ev[0])
             seg["ircache"] += ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])
             seg["rtdgi"] += ev[1].elapsed_time(ev[2]) + ev[3].elapsed_time(ev[4])
             seg["taa"] += ev[4].elapsed_time(ev5)
@@ -320,7 +333,8 @@ def main():
         "gi_frame_ms": round(ms_per_step, 4), "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{scene_label}, {W}x{H}, rtdgi: reproject+validate+trace+validity+temporal ReSTIR+2x spatial ReSTIR+"
-                               "resolve+temporal+spatial denoise, irradiance cache (scroll/age/compact, accessibility+validate+trace rays, SH sum), TAA (7 passes) on the GI output",
+                               "resolve+temporal+spatial denoise, irradiance cache (scroll/age/compact, accessibility+validate+trace rays, SH sum), TAA (7 passes) on the GI output"
+                               + (", SSAO guide (ssgi, 4 passes)" if use_ssgi else ", constant SSAO guide"),
                    "triangles": stats["triangles"], "bvh_nodes": stats["nodes"], "bvh_bytes": stats["bvh_bytes"],
                    "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": ("single GPU, 2 HIP streams: next frame's ircache rays overlap this frame's screen-space tail" if overlap else "single GPU, serial frames") if nsplit <= 1 else f"{nsplit}-way screen-tile split (16-row-aligned strips; 6 batched halo exchanges per frame incl. the temporal2 all-gather, over "
                                   + ("RCCL P2P" if world > 1 else "virtual ranks on one GPU") + f"; motion halo {args.motion_halo} rows; irradiance cache replicated per rank"

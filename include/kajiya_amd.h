@@ -331,6 +331,22 @@ KjStatus kj_taa_render_rows(KjTaa* t, const void* input_tex, uint32_t input_widt
 KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 
 /* ---------------------------------------------------------------------------
+ * SSAO / SSGI guide — feeds kernel radii and edge-stopping weights of the rtdgi spatial passes, resolve
+ * and spatial filter (KjRtdgiRenderParams.ssao_tex)
+ *   SsgiRenderer::render(rg, &GbufferDepth, reprojection_map, prev_radiance, bindless_set) -> ReadOnlyHandle<Image>
+ *   renderers/ssgi.rs:25-181; shaders/ssgi/{ssgi,spatial_filter,upsample,temporal_filter}.hlsl (USE_AO_ONLY 1)
+ * prev_radiance (RGBA16F lit image of the previous frame) is accepted for signature parity and ignored: with
+ * USE_AO_ONLY the colour accumulation never reaches the output. *out_ssao_r8 = R8_UNORM full-res image owned by the
+ * handle, valid until the next kj_ssgi_render.
+ * --------------------------------------------------------------------------- */
+typedef struct KjSsgi KjSsgi;
+KjStatus kj_ssgi_create(KjDevice* dev, KjSsgi** out);
+void kj_ssgi_destroy(KjSsgi* s);
+KjStatus kj_ssgi_render(KjSsgi* s, const KjGbufferDepth* gbuffer_depth, const void* reprojection_map, const void* prev_radiance,
+                        const void** out_ssao_r8, void* stream);
+KjStatus kj_ssgi_surface(KjSsgi* s, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
+
+/* ---------------------------------------------------------------------------
  * Reference path tracer — the convergence oracle of the GI path
  *   reference_path_trace(rg, &mut output_img, bindless_set, tlas)   renderers/reference.rs:8-26
  *   rt/reference_path_trace.rgen.hlsl:75-377 (16-segment eye paths, sun NEE with soft shadows, one triangle

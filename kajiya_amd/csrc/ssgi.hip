@@ -1,0 +1,326 @@
+// SsgiRenderer for gfx950 (renderers/ssgi.rs:25-181; assets/shaders/ssgi/{ssgi,spatial_filter,upsample,temporal_filter}.hlsl)
+// with the shipped switches: USE_AO_ONLY 1 (the colour accumulation never reaches the output, so prev_radiance is not
+// read), 6 half-samples per direction, 60 px kernel, no random jitter. Output: the R8_UNORM full-res "ssao" guide that
+// rtdgi's resolve / filters take as `ssao_tex` (world_render_passes.rs:90-96,156). 8x8 tile = one wave64.
+#include "kj_host.hpp"
+#include "kj_shading.hpp"
+
+using namespace kj;
+
+typedef Img<uint4> ImgU4;
+typedef Img<uint2> ImgU2;
+typedef Img<uint32_t> ImgU32;
+typedef Img<uint16_t> ImgH1;
+typedef Img<float> ImgF32;
+typedef Img<uint8_t> ImgR8;
+
+#define TILE_XY(W_, H_)                                                                    \
+    const int lane = threadIdx.x;                                                          \
+    const int x = int(blockIdx.x) * 8 + (lane & 7), y = int(blockIdx.y) * 8 + (lane >> 3); \
+    const bool in_image = x < (W_) && y < (H_);
+
+// GbufferDepth::half_view_normal / half_depth (renderers/mod.rs:31-71; extract_half_res_{gbuffer_view_normal_rgba8,depth}.hlsl)
+__global__ void __launch_bounds__(64) k_ssgi_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgU32 half_view_normal, ImgF32 half_depth) {
+    TILE_XY(half_depth.w, half_depth.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int sx = x * 2 + off.x, sy = y * 2 + off.y;
+    const V3 normal_ws = unpack_normal_11_10_11_no_normalize(gbuffer.ld(sx, sy).y);
+    const V3 normal_vs = normalize(xyz(mul44(fc.view_constants.world_to_view, v4(normal_ws, 0))));
+    half_view_normal.st(x, y, pack_rgba8_snorm(v4(normal_vs, 1.0f)));
+    half_depth.st(x, y, depth.ld(sx, sy));
+}
+
+// ssgi.hlsl:51-62
+KJ_D float ssgi_fast_sqrt(float v) { return __uint_as_float(0x1fbd1df5u + (__float_as_uint(v) >> 1u)); }
+KJ_D float ssgi_fast_acos(float in_x) {
+    const float ax = fabsf(in_x);
+    float res = -0.156583f * ax + 1.57079632679f;
+    res *= ssgi_fast_sqrt(1.0f - ax);
+    return in_x >= 0 ? res : 3.14159265359f - res;
+}
+KJ_D float ssgi_integrate_arc(float h1, float h2, float n) {
+    const float a = -cosf(2.0f * h1 - n) + cosf(n) + 2.0f * h1 * sinf(n);
+    const float b = -cosf(2.0f * h2 - n) + cosf(n) + 2.0f * h2 * sinf(n);
+    return 0.25f * (a + b);
+}
+KJ_D float ssgi_update_horizon(float prev, float cur, float blend) { return cur > prev ? lerp(prev, cur, blend) : prev; }
+// ssgi.hlsl:174-222 without the colour path
+KJ_D float ssgi_process_sample(const FrameConstants& fc, V4 sample_cs, V3 center_vs, V3 v_vs, float kernel_radius_ws, float theta_cos_max) {
+    if (sample_cs.z > 0) {
+        const V4 sample_vs4 = mul44(fc.view_constants.sample_to_view, sample_cs);
+        const V3 sample_vs = xyz(sample_vs4) / sample_vs4.w;
+        const V3 off = sample_vs - center_vs;
+        const float len = length(off);
+        const float sample_theta_cos = dot(off, v_vs) / len;
+        const float dn = len / kernel_radius_ws;
+        if (dn < 1.0f) theta_cos_max = ssgi_update_horizon(theta_cos_max, sample_theta_cos, smoothstep(1.0f, 0.0f, dn));
+    } else {
+        theta_cos_max = ssgi_update_horizon(theta_cos_max, -1.0f, 1.0f);
+    }
+    return theta_cos_max;
+}
+
+// "ssao" (ssgi.hlsl:230-341), half res, R16F
+__global__ void __launch_bounds__(64) k_ssgi(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 half_depth, ImgH1 output_tex, int W, int H) {
+    const int hw = output_tex.w, hh = output_tex.h;
+    TILE_XY(hw, hh)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const V4 input_tex_size = tex_size4(W, H), output_tex_size = tex_size4(hw, hh);
+    const V2 uv = get_uv(float(x), float(y), output_tex_size);
+    const float d = half_depth.ld(x, y);
+    if (d == 0.0f) { output_tex.st(x, y, f32_to_f16(0.0f)); return; }
+    const GbufferData g = gbuffer_unpack(gbuffer.ld(x * 2, y * 2));
+    const V3 normal_vs = normalize(xyz(mul44(fc.view_constants.world_to_view, v4(g.normal, 0))));
+    const ViewRay vrc = view_ray_from_uv_and_depth(fc, uv, d);
+    // ray_dir_vs: normalize(sample_to_view * (cs, 0, 1)).xyz
+    const V2 cs = uv_to_cs(uv);
+    const V3 ray_dir_vs = normalize(xyz(mul44(fc.view_constants.sample_to_view, V4{cs.x, cs.y, 0.0f, 1.0f})));
+    const V3 v_vs = -normalize(ray_dir_vs);
+    const V3 ray_hit_vs = vrc.hit_vs;
+    const uint32_t ux = uint32_t(x), uy = uint32_t(y);
+    const float temporal_rotations[6] = {60.0f, 300.0f, 180.0f, 240.0f, 120.0f, 0.0f};
+    const float temporal_offsets[4] = {0.0f, 0.5f, 0.25f, 0.75f};
+    const float spatial_direction_noise = 1.0f / 16.0f * float((((ux + uy) & 3u) << 2) + (ux & 3u));
+    const float temporal_direction_noise = temporal_rotations[fc.frame_index % 6] / 360.0f;
+    const float spatial_offset_noise = (1.0f / 4.0f) * float((uy - ux) & 3u);
+    const float temporal_offset_noise = temporal_offsets[fc.frame_index / 6 % 4];
+    const float ss_angle = frac(spatial_direction_noise + temporal_direction_noise) * 3.14159265359f;
+    const float rand_offset = frac(spatial_offset_noise + temporal_offset_noise);
+    V2 cs_slice_dir{cosf(ss_angle) * input_tex_size.y / input_tex_size.x, sinf(ss_angle)};
+    float kernel_radius_ws, kernel_radius_shrinkage;
+    {
+        const float ws_to_cs = 0.5f / -ray_hit_vs.z * fc.view_constants.view_to_clip[5];
+        const float cs_kernel_radius_scaled = 60.0f * output_tex_size.w;
+        kernel_radius_ws = cs_kernel_radius_scaled / ws_to_cs;
+        cs_slice_dir = cs_slice_dir * cs_kernel_radius_scaled;
+        kernel_radius_shrinkage = fminf(1.0f, 0.4f / cs_kernel_radius_scaled);
+    }
+    cs_slice_dir = cs_slice_dir * kernel_radius_shrinkage;
+    kernel_radius_ws *= kernel_radius_shrinkage;
+    const V3 center_vs = ray_hit_vs;
+    cs_slice_dir = cs_slice_dir * (1.0f / 6.0f);
+    const float* s2v = fc.view_constants.sample_to_view;   // column-major: M[r][c] = s2v[c * 4 + r]; row vector times matrix below
+    const V2 vs_slice_dir{cs_slice_dir.x * s2v[0] + cs_slice_dir.y * s2v[1], cs_slice_dir.x * s2v[4] + cs_slice_dir.y * s2v[5]};
+    const V3 slice_normal_vs = normalize(cross(v_vs, V3{vs_slice_dir.x, vs_slice_dir.y, 0}));
+    V3 proj_normal_vs = normal_vs - slice_normal_vs * dot(slice_normal_vs, normal_vs);
+    const float slice_contrib_weight = length(proj_normal_vs);
+    proj_normal_vs = proj_normal_vs / slice_contrib_weight;
+    const float sd = dot(vs_slice_dir, V2{proj_normal_vs.x - v_vs.x, proj_normal_vs.y - v_vs.y});
+    const float sgn = sd > 0 ? 1.0f : (sd < 0 ? -1.0f : 0.0f);
+    const float n_angle = ssgi_fast_acos(clampf(dot(proj_normal_vs, v_vs), -1.0f, 1.0f)) * sgn;
+    float theta_cos_max1 = cosf(n_angle - 1.57079632679f);
+    float theta_cos_max2 = cosf(n_angle + 1.57079632679f);
+    int pc0x = x, pc0y = y, pc1x = x, pc1y = y;
+    const V2 hit_cs{vrc.hit_cs.x, vrc.hit_cs.y};
+    for (uint32_t i = 0; i < 6; ++i) {
+        {
+            const float t = float(i) + rand_offset;
+            V4 sample_cs{hit_cs.x - cs_slice_dir.x * t, hit_cs.y - cs_slice_dir.y * t, 0, 1};
+            const V2 suv = cs_to_uv(V2{sample_cs.x, sample_cs.y});
+            const int spx = int(output_tex_size.x * suv.x), spy = int(output_tex_size.y * suv.y);
+            if (spx != pc0x || spy != pc0y) {
+                pc0x = spx; pc0y = spy;
+                sample_cs.z = half_depth.ld(spx, spy);
+                theta_cos_max1 = ssgi_process_sample(fc, sample_cs, center_vs, v_vs, kernel_radius_ws, theta_cos_max1);
+            }
+        }
+        {
+            const float t = float(i) + (1.0f - rand_offset);
+            V4 sample_cs{hit_cs.x + cs_slice_dir.x * t, hit_cs.y + cs_slice_dir.y * t, 0, 1};
+            const V2 suv = cs_to_uv(V2{sample_cs.x, sample_cs.y});
+            const int spx = int(output_tex_size.x * suv.x), spy = int(output_tex_size.y * suv.y);
+            if (spx != pc1x || spy != pc1y) {
+                pc1x = spx; pc1y = spy;
+                sample_cs.z = half_depth.ld(spx, spy);
+                theta_cos_max2 = ssgi_process_sample(fc, sample_cs, center_vs, v_vs, kernel_radius_ws, theta_cos_max2);
+            }
+        }
+    }
+    const float h1 = -ssgi_fast_acos(theta_cos_max1);
+    const float h2 = +ssgi_fast_acos(theta_cos_max2);
+    const float h1p = n_angle + fmaxf(h1 - n_angle, -1.57079632679f);
+    const float h2p = n_angle + fminf(h2 - n_angle, 1.57079632679f);
+    const float inv_ao = ssgi_integrate_arc(h1p, h2p, n_angle);
+    const float col = fmaxf(0.0f, inv_ao) * slice_contrib_weight;
+    output_tex.st(x, y, f32_to_f16(fmaxf(0.0f, col)));
+}
+
+// "ssao spatial" (spatial_filter.hlsl), half res
+__global__ void __launch_bounds__(64) k_ssgi_spatial(ImgH1 ssgi_tex, ImgF32 half_depth, ImgU32 half_view_normal, ImgH1 output_tex) {
+    TILE_XY(output_tex.w, output_tex.h)
+    if (!in_image) return;
+    float result = 0, w_sum = 0;
+    const float center_depth = half_depth.ld(x, y);
+    if (center_depth != 0.0f) {
+        const V3 center_normal = ld_nrm_snorm8(half_view_normal, x, y);
+        w_sum = 1.0f;
+        result = f16_to_f32(ssgi_tex.ld(x, y));
+#pragma unroll
+        for (int yy = -1; yy <= 1; ++yy)
+#pragma unroll
+            for (int xx = -1; xx <= 1; ++xx) {
+                if (xx == 0 && yy == 0) continue;
+                const float sdp = half_depth.ld(x + xx, y + yy);
+                if (sdp == 0.0f) continue;
+                const float s = f16_to_f32(ssgi_tex.ld(x + xx, y + yy));
+                const V3 n = ld_nrm_snorm8(half_view_normal, x + xx, y + yy);
+                const float depth_diff = 1.0f - (center_depth / sdp);
+                const float depth_factor = exp2f(-200.0f * fabsf(depth_diff));
+                float nf = fmaxf(0.0f, dot(n, center_normal));
+                nf *= nf; nf *= nf;
+                float w = 1;
+                w *= depth_factor;
+                w *= nf;
+                w_sum += w;
+                result += s * w;
+            }
+    }
+    output_tex.st(x, y, f32_to_f16(result / fmaxf(w_sum, 1e-5f)));
+}
+
+// "ssao upsample" (upsample.hlsl), full res, R16F
+__global__ void __launch_bounds__(64) k_ssgi_upsample(ImgH1 ssgi_tex, ImgF32 depth, ImgH1 output_tex) {
+    TILE_XY(output_tex.w, output_tex.h)
+    if (!in_image) return;
+    float result = 0, w_sum = 0;
+    const float center_depth = depth.ld(x, y);
+    if (center_depth != 0.0f) {
+#pragma unroll
+        for (int yy = -1; yy <= 1; ++yy)
+#pragma unroll
+            for (int xx = -1; xx <= 1; ++xx) {
+                const int sx = x / 2 + xx, sy = y / 2 + yy;
+                const float sdp = depth.ld(sx * 2, sy * 2);
+                if (sdp == 0.0f) continue;
+                const float s = f16_to_f32(ssgi_tex.ld(sx, sy));
+                const float depth_diff = 1.0f - (center_depth / sdp);
+                float w = 1;
+                w *= exp2f(-200.0f * fabsf(depth_diff));
+                w *= expf(-float(xx * xx + yy * yy));
+                w_sum += w;
+                result += s * w;
+            }
+    }
+    if (w_sum > 1e-6f) output_tex.st(x, y, f32_to_f16(result / w_sum));
+    else output_tex.st(x, y, ssgi_tex.ld(x / 2, y / 2));
+}
+
+// "ssao temporal" (temporal_filter.hlsl), full res; history R16F, final R8_UNORM
+KJ_D float sample_bilinear_clamp_r16f(const uint16_t* __restrict__ p, int w, int h, V2 uv) {
+    const float fx = uv.x * float(w) - 0.5f, fy = uv.y * float(h) - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float tx = fx - x0f, ty = fy - y0f;
+    const int x0 = int(x0f), y0 = int(y0f);
+    const int xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1), ya = min(max(y0, 0), h - 1), yb = min(max(y0 + 1, 0), h - 1);
+    const float s00 = f16_to_f32(p[size_t(ya) * w + xa]), s10 = f16_to_f32(p[size_t(ya) * w + xb]);
+    const float s01 = f16_to_f32(p[size_t(yb) * w + xa]), s11 = f16_to_f32(p[size_t(yb) * w + xb]);
+    const float a = s00 * (1.0f - tx) + s10 * tx, b = s01 * (1.0f - tx) + s11 * tx;
+    return a * (1.0f - ty) + b * ty;
+}
+__global__ void __launch_bounds__(64) k_ssgi_temporal(ImgH1 input_tex, ImgH1 history_tex, ImgU2 reprojection_tex, ImgR8 final_output_tex, ImgH1 history_output_tex) {
+    const int W = final_output_tex.w, H = final_output_tex.h;
+    TILE_XY(W, H)
+    if (!in_image) return;
+    const V2 uv = get_uv(float(x), float(y), tex_size4(W, H));
+    const float center = f16_to_f32(input_tex.ld(x, y));
+    const V4 reproj = ld_reproj(reprojection_tex, x, y);
+    const float history = sample_bilinear_clamp_r16f(history_tex.p, W, H, uv + V2{reproj.x, reproj.y});
+    float vsum = 0, vsum2 = 0, wsum = 0;
+#pragma unroll
+    for (int yy = -2; yy <= 2; ++yy)
+#pragma unroll
+        for (int xx = -2; xx <= 2; ++xx) {
+            const float neigh = f16_to_f32(input_tex.ld(x + xx * 2, y + yy * 2));
+            const float w = expf(-3.0f * float(xx * xx + yy * yy) / float((2 + 1.) * (2 + 1.)));
+            vsum += neigh * w;
+            vsum2 += neigh * neigh * w;
+            wsum += w;
+        }
+    const float ex = vsum / wsum, ex2 = vsum2 / wsum;
+    const float dev = sqrtf(fmaxf(0.0f, ex2 - ex * ex));
+    const float box_size = 0.5f, n_deviations = 5.0f;
+    const float nmin = lerp(center, ex, box_size * box_size) - dev * box_size * n_deviations;
+    const float nmax = lerp(center, ex, box_size * box_size) + dev * box_size * n_deviations;
+    const float clamped_history = clampf(history, nmin, nmax);
+    const float res = lerp(clamped_history, center, 1.0f / 8.0f);
+    history_output_tex.st(x, y, f32_to_f16(res));
+    final_output_tex.st(x, y, to_unorm8(res));
+}
+
+// ================================================================== host
+struct KjSsgi {
+    KjDevice* dev = nullptr;
+    int W = 0, H = 0;
+    std::map<std::string, kj::DevBuf> surf;
+    bool flip = false;
+    hipError_t err = hipSuccess;
+    void* get(const std::string& name, size_t bytes, hipStream_t s) {
+        kj::DevBuf& b = surf[name];
+        if (b.bytes != bytes) { hipError_t e = b.alloc(bytes, s); if (e != hipSuccess) err = e; }
+        return b.p;
+    }
+};
+
+#define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
+
+extern "C" {
+
+KjStatus kj_ssgi_create(KjDevice* dev, KjSsgi** out) {
+    KJ_REQUIRE(dev && out, "null argument");
+    KjSsgi* t = new KjSsgi();
+    t->dev = dev;
+    *out = t;
+    return KJ_OK;
+}
+void kj_ssgi_destroy(KjSsgi* t) { delete t; }
+
+// SsgiRenderer::render(rg, gbuffer_depth, reprojection_map, prev_radiance, bindless_descriptor_set) -> ssgi_tex (ssgi.rs:25-81)
+KjStatus kj_ssgi_render(KjSsgi* t, const KjGbufferDepth* gd, const void* reprojection_map, const void* prev_radiance, const void** out_ssao_r8, void* stream_) {
+    KJ_REQUIRE(t && gd && gd->gbuffer && gd->depth && reprojection_map && out_ssao_r8 && gd->width && gd->height, "null argument");
+    KJ_REQUIRE(t->dev->fc_dev, "kj_frame_begin not called");
+    (void)prev_radiance;   // only feeds the colour accumulation, which USE_AO_ONLY discards (ssgi.hlsl:318-324)
+    hipStream_t s = (hipStream_t)stream_;
+    const int W = int(gd->width), H = int(gd->height), hw = (W + 1) / 2, hh = (H + 1) / 2;
+    if (W != t->W || H != t->H) { t->surf.clear(); t->W = W; t->H = H; t->flip = false; }
+    const FrameConstants* fc = t->dev->fc_dev;
+    const size_t FB = size_t(W) * H, HB = size_t(hw) * hh;
+    void* half_view_normal = t->get("half_view_normal_tex", HB * 4, s);
+    void* half_depth = t->get("half_depth_tex", HB * 4, s);
+    void* ssgi_tex = t->get("ssgi_tex", HB * 2, s);
+    void* spatial = t->get("spatially_filtered_tex", HB * 2, s);
+    void* upsampled = t->get("upsampled_tex", FB * 2, s);
+    void* hist_out = t->get(t->flip ? "ssgi:1" : "ssgi:0", FB * 2, s);
+    void* hist = t->get(t->flip ? "ssgi:0" : "ssgi:1", FB * 2, s);
+    t->flip = !t->flip;
+    void* final_out = t->get("filtered_output_tex", FB, s);
+    KJ_TRY_HIP(t->err);
+    const dim3 gf((W + 7) / 8, (H + 7) / 8), gh((hw + 7) / 8, (hh + 7) / 8), blk(64);
+    const ImgU4 gbuffer = img<uint4>(gd->gbuffer, W, H);
+    const ImgF32 depth = img<float>(gd->depth, W, H);
+    hipLaunchKernelGGL(k_ssgi_extract_half, gh, blk, 0, s, fc, gbuffer, depth, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh));
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ssgi, gh, blk, 0, s, fc, gbuffer, img<float>(half_depth, hw, hh), img<uint16_t>(ssgi_tex, hw, hh), W, H);
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ssgi_spatial, gh, blk, 0, s, img<uint16_t>(ssgi_tex, hw, hh), img<float>(half_depth, hw, hh), img<uint32_t>(half_view_normal, hw, hh), img<uint16_t>(spatial, hw, hh));
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ssgi_upsample, gf, blk, 0, s, img<uint16_t>(spatial, hw, hh), depth, img<uint16_t>(upsampled, W, H));
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ssgi_temporal, gf, blk, 0, s, img<uint16_t>(upsampled, W, H), img<uint16_t>(hist, W, H), img<uint2>(reprojection_map, W, H), img<uint8_t>(final_out, W, H),
+                       img<uint16_t>(hist_out, W, H));
+    KJ_CHECK_LAUNCH();
+    *out_ssao_r8 = final_out;
+    return KJ_OK;
+}
+KjStatus kj_ssgi_surface(KjSsgi* t, const char* name, void** out_dev_ptr, uint64_t* out_bytes) {
+    KJ_REQUIRE(t && name && out_dev_ptr && out_bytes, "null argument");
+    auto it = t->surf.find(name);
+    if (it == t->surf.end()) { set_last_error("no ssgi surface named '%s'", name); return KJ_ERR_INVALID_ARGUMENT; }
+    *out_dev_ptr = it->second.p;
+    *out_bytes = it->second.bytes;
+    return KJ_OK;
+}
+
+}  // extern "C"

@@ -26,6 +26,7 @@ EXPORTS = [
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
     "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
+    "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_surface",
 ]
 
 _LIB = None
@@ -88,6 +89,9 @@ def load():
         "kj_taa_create": [vp, C.POINTER(vp)],
         "kj_taa_render": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp],
         "kj_taa_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
+        "kj_ssgi_create": [vp, C.POINTER(vp)],
+        "kj_ssgi_render": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.POINTER(vp), vp],
+        "kj_ssgi_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_reference_path_trace": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp],
         "kj_taa_render_rows": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp, u32, u32, u32],
     }
@@ -95,7 +99,7 @@ def load():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = i32
-    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy"):
+    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy"):
         f = getattr(L, name)
         f.argtypes = [vp]
         f.restype = None
@@ -230,6 +234,8 @@ class GpuPipeline:
         check(L.kj_taa_create(dev.h, C.byref(self.taa)))
         self.taa_out = KjTaaOutput()
         self.on_ircache_traced = None
+        self.ssgi = None
+        self.ssao_ptr = C.c_void_p()
         self.ircache = None
         if use_ircache:
             self.ircache = C.c_void_p()
@@ -266,7 +272,7 @@ class GpuPipeline:
         p.sky_cube_width = 16
         p.scene = self.scene.h
         p.ircache = self.ircache
-        p.ssao_tex = self.ssao.data_ptr()
+        p.ssao_tex = self.ssao_ptr.value if self.ssao_ptr.value else self.ssao.data_ptr()   # ssgi_frame() output, else the constant 1.0
         p.pass_mask = pass_mask
         return p
 
@@ -346,6 +352,19 @@ class GpuPipeline:
         inp = input_ptr if input_ptr is not None else self.out.screen_irradiance_tex
         check(self.L.kj_taa_render(self.taa, inp, self.W, self.H, self.reprojection_map_ptr, self.depth.data_ptr(), ow, oh, C.byref(self.taa_out), _stream_ptr()))
 
+    def ssgi_frame(self):
+        """SsgiRenderer::render (world_render_passes.rs:90-96): computes the SSAO guide; rtdgi's `ssao_tex` then points at it."""
+        if self.ssgi is None:
+            self.ssgi = C.c_void_p()
+            check(self.L.kj_ssgi_create(self.dev.h, C.byref(self.ssgi)))
+        g = self.gbuffer_depth()
+        check(self.L.kj_ssgi_render(self.ssgi, C.byref(g), self.reprojection_map_ptr, None, C.byref(self.ssao_ptr), _stream_ptr()))
+
+    def ssgi_surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        check(self.L.kj_ssgi_surface(self.ssgi, name.encode(), C.byref(ptr), C.byref(n)))
+        return tensor_from_ptr(ptr.value, n.value, dtype, shape)
+
     def reference_path_trace(self, accum, first_bounce_mode=0, interleave=(1, 0), ray_counter=None):
         """reference_path_trace (reference.rs:8-26): one more sample per pixel into `accum` (H, W, 4) float32 cuda tensor."""
         assert accum.dtype == self.torch.float32 and accum.is_contiguous() and tuple(accum.shape) == (self.H, self.W, 4)
@@ -407,6 +426,8 @@ class GpuPipeline:
             if self.ircache:
                 self.L.kj_ircache_destroy(self.ircache)
             self.L.kj_taa_destroy(self.taa)
+            if getattr(self, "ssgi", None):
+                self.L.kj_ssgi_destroy(self.ssgi)
         except Exception:
             pass
 

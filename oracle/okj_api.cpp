@@ -5,6 +5,7 @@
 #include "okj_ircache_trace.hpp"
 #include "okj_taa.hpp"
 #include "okj_reference_pt.hpp"
+#include "okj_ssgi.hpp"
 #include <cstdio>
 #include <chrono>
 #ifdef _OPENMP
@@ -271,6 +272,22 @@ const void* okj_taa_render(void* p, const KjFrameConstants* fc, const void* inpu
 }
 int okj_taa_surface(void* p, const char* name, void** out_ptr, uint64_t* out_bytes) {
     Taa* t = (Taa*)p;
+    auto it = t->surf.find(name);
+    if (it == t->surf.end()) return 1;
+    *out_ptr = it->second.data();
+    *out_bytes = it->second.size();
+    return 0;
+}
+
+// ---- ssgi (SsgiRenderer): returns the R8_UNORM full-res guide
+void* okj_ssgi_create() { return new Ssgi(); }
+void okj_ssgi_destroy(void* p) { delete (Ssgi*)p; }
+const void* okj_ssgi_render(void* p, const KjFrameConstants* fc, const void* gbuffer, const void* depth, const void* reprojection_map, uint32_t w, uint32_t h) {
+    Ssgi* s = (Ssgi*)p;
+    return s->render(*fc, ImgU4((void*)gbuffer, w, h), ImgR32F((void*)depth, w, h), ImgRGBA16S((void*)reprojection_map, w, h)).p;
+}
+int okj_ssgi_surface(void* p, const char* name, void** out_ptr, uint64_t* out_bytes) {
+    Ssgi* t = (Ssgi*)p;
     auto it = t->surf.find(name);
     if (it == t->surf.end()) return 1;
     *out_ptr = it->second.data();

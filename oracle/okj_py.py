@@ -82,6 +82,12 @@ def lib():
         L.okj_taa_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.okj_taa_surface.restype = C.c_int
         L.okj_taa_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.okj_ssgi_create.restype = C.c_void_p
+        L.okj_ssgi_destroy.argtypes = [C.c_void_p]
+        L.okj_ssgi_render.restype = C.c_void_p
+        L.okj_ssgi_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.okj_ssgi_surface.restype = C.c_int
+        L.okj_ssgi_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_reference_path_trace.restype = C.c_uint64
         L.okj_reference_path_trace.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
         L.okj_set_threads.argtypes = [C.c_int]
@@ -240,6 +246,22 @@ class OraclePipeline:
         tout = C.c_void_p()
         r = self.L.okj_taa_render(self.taa, C.byref(fc), inp, self.W, self.H, self.reprojection_map.ctypes.data, self.depth.ctypes.data, ow, oh, C.byref(tout))
         return r, tout.value
+
+    def ssgi_frame(self, fc):
+        """SsgiRenderer::render (world_render_passes.rs:90-96): computes the SSAO guide and binds it as rtdgi's ssao_tex."""
+        if not hasattr(self, "ssgi"):
+            self.ssgi = self.L.okj_ssgi_create()
+        ptr = self.L.okj_ssgi_render(self.ssgi, C.byref(fc), self.gbuffer.ctypes.data, self.depth.ctypes.data, self.reprojection_map.ctypes.data, self.W, self.H)
+        buf = (C.c_uint8 * (self.W * self.H)).from_address(ptr)
+        self.ssao = np.frombuffer(buf, dtype=np.uint8).reshape(self.H, self.W)
+        return self.ssao
+
+    def ssgi_surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        if self.L.okj_ssgi_surface(self.ssgi, name.encode(), C.byref(ptr), C.byref(n)) != 0:
+            raise KeyError(name)
+        buf = (C.c_uint8 * n.value).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def taa_surface(self, name, dtype, shape):
         ptr, n = C.c_void_p(), C.c_uint64()

@@ -251,3 +251,30 @@ def test_oracle_matches_golden_vectors(oracle):
     assert abs(int(got["ircache_entry_count"][0]) - int(ref["ircache_entry_count"][0])) <= 0.02 * int(ref["ircache_entry_count"][0]) + 2
     err = np.abs(got["reference_pt"][..., :3] - ref["reference_pt"][..., :3]).max(axis=-1) / (1e-3 + ref["reference_pt"][..., :3].max(axis=-1))
     assert (err > 1e-3).mean() < 0.02 and (got["reference_pt"][..., 3] == 4).all()
+
+
+def test_oracle_ssgi_guide_is_sane(oracle):
+    """SsgiRenderer restatement: an unoccluded plane is (nearly) unshadowed, the Cornell box darkens towards its corners, the
+    sky stays 0 and the temporal accumulation converges."""
+    from kajiya_amd import scenes, frame
+    W = H = 64
+    for name, desc in (("plane", _open_plane_scene()), ("cornell", scenes.cornell_box())):
+        op = oracle.OraclePipeline(oracle.OracleScene(desc), W, H)
+        fs = frame.FrameState((W, H))
+        aos = []
+        for i in range(24):
+            cam = frame.orbit_camera(0, (W, H), center=(0, 0.5, 0), radius=6.0, height=2.5, rate=0.0) if name == "plane" else \
+                frame.orbit_camera(0, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.01)
+            fc = fs.prepare_frame_constants(cam); fs.retire_frame()
+            op.render_inputs(fc); op.reprojection(fc)
+            aos.append(op.ssgi_frame(fc).astype(np.float32) / 255.0)
+        m = op.depth > 0
+        ao = aos[-1]
+        assert np.isfinite(ao).all() and ao.min() >= 0 and ao.max() <= 1
+        assert np.abs(aos[-1] - aos[-2])[m].mean() < 0.02
+        if name == "plane":
+            lower = m.copy(); lower[: H // 3] = False
+            assert ao[lower].mean() > 0.93, ao[lower].mean()
+        else:
+            centre = ao[H // 2 - 6:H // 2 + 6, W // 2 - 6:W // 2 + 6].mean()     # back wall, open
+            assert 0.4 < ao[m].mean() < 0.95 and ao[m].min() < 0.5 * centre
