@@ -330,6 +330,13 @@ KjStatus kj_taa_render_rows(KjTaa* t, const void* input_tex, uint32_t input_widt
                             uint32_t pass_mask, uint32_t row_begin, uint32_t row_end);
 KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 
+/* trace_sun_shadow_mask(rg, &GbufferDepth, tlas, bindless_set) -> Handle<Image>   renderers/shadows.rs:10-40,
+ * rt/trace_sun_shadow_mask.rgen.hlsl:19-60: one soft-shadow ray per full-res pixel towards a blue-noise sample of the sun
+ * disc; out_mask_r8 = R8_UNORM (255 lit / 0 shadowed, 255 for sky). The shadow denoiser (shadow_denoise.rs) is a later row.
+ * ray_counter_dev: optional device u64 that receives += rays traced. */
+KjStatus kj_trace_sun_shadow_mask(KjDevice* dev, KjScene* scene, const KjGbufferDepth* gbuffer_depth, void* out_mask_r8,
+                                  uint64_t* ray_counter_dev, void* stream);
+
 /* ---------------------------------------------------------------------------
  * SSAO / SSGI guide — feeds kernel radii and edge-stopping weights of the rtdgi spatial passes, resolve
  * and spatial filter (KjRtdgiRenderParams.ssao_tex)

@@ -160,9 +160,53 @@ __global__ void __launch_bounds__(64) k_trace_any(SceneView sc, const float4* __
     out[i] = bvh_trace<true>(sc.bvh, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, a.w, b.w, false, lds_stack + threadIdx.x, 64).slot != 0xffffffffu ? 1 : 0;
 }
 
+// rt/trace_sun_shadow_mask.rgen.hlsl:19-60 (USE_SOFT_SHADOWS 1): one shadow ray per full-res pixel, R8_UNORM mask
+__global__ void __launch_bounds__(64) k_sun_shadow_mask(const FrameConstants* __restrict__ fcp, SceneView sc, const uint32_t* __restrict__ blue_noise, Img<float> depth_tex,
+                                                         Img<uint32_t> geometric_normal_tex, Img<uint8_t> output_tex, unsigned long long* __restrict__ ray_counter) {
+    extern __shared__ uint32_t lds_stack[];
+    const int lane = threadIdx.x;
+    const int x = int(blockIdx.x) * 8 + (lane & 7), y = int(blockIdx.y) * 8 + (lane >> 3);
+    if (x >= output_tex.w || y >= output_tex.h) return;
+    const FrameConstants& fc = *fcp;
+    const V2 uv{(float(x) + 0.5f) / float(output_tex.w), (float(y) + 0.5f) / float(output_tex.h)};
+    const float z_over_w = depth_tex.ld(x, y);
+    if (0.0f == z_over_w) { output_tex.st(x, y, 255); return; }
+    const V2 cs = uv_to_cs(uv);
+    V4 pt_vs = mul44(fc.view_constants.sample_to_view, V4{cs.x, cs.y, z_over_w, 1.0f});
+    V4 pt_ws = mul44(fc.view_constants.view_to_world, pt_vs);
+    pt_ws = pt_ws / pt_ws.w;
+    pt_vs = pt_vs / pt_vs.w;
+    const V3 normal_vs = unpack_a2r10g10b10(geometric_normal_tex.ld(x, y)) * 2.0f - 1.0f;
+    const V3 normal_ws = xyz(mul44(fc.view_constants.view_to_world, v4(normal_vs, 0.0f)));
+    const float bias_amount = (-pt_vs.z + length(xyz(pt_ws))) * 1e-5f;
+    const V3 ray_origin = xyz(pt_ws) + normal_ws * bias_amount;
+    const V4 bn = blue_noise_for_pixel(blue_noise, uint32_t(x), uint32_t(y), fc.frame_index);
+    const V3 dir = sample_sun_direction(fc, V2{bn.x, bn.y}, true);
+    const bool is_shadowed = rt_is_shadowed<false>(sc, ray_origin, dir, 0.0f, FLT_MAX, lds_stack + lane, 64);
+    output_tex.st(x, y, is_shadowed ? 0 : 255);
+    if (ray_counter) {
+        const unsigned long long m = __ballot(true);
+        if ((__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(ray_counter, (unsigned long long)__popcll(m));
+    }
+}
+
 #define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
 
 extern "C" {
+
+// trace_sun_shadow_mask(rg, &GbufferDepth, tlas, bindless_set) -> Handle<Image> (renderers/shadows.rs:10-40)
+KjStatus kj_trace_sun_shadow_mask(KjDevice* dev, KjScene* scene, const KjGbufferDepth* gd, void* out_mask_r8, uint64_t* ray_counter_dev, void* stream) {
+    KJ_REQUIRE(dev && scene && gd && gd->depth && gd->geometric_normal && out_mask_r8 && gd->width && gd->height, "null argument");
+    KJ_REQUIRE(dev->fc_dev, "kj_frame_begin not called");
+    if (!scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
+    const SceneView sv = scene_view(*scene);
+    const int W = int(gd->width), H = int(gd->height);
+    hipLaunchKernelGGL(k_sun_shadow_mask, dim3((W + 7) / 8, (H + 7) / 8), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, dev->fc_dev, sv,
+                       (const uint32_t*)dev->blue_noise.p, img<float>(gd->depth, W, H), img<uint32_t>(gd->geometric_normal, W, H), img<uint8_t>(out_mask_r8, W, H),
+                       (unsigned long long*)ray_counter_dev);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
 
 KjStatus kj_device_create(int32_t ordinal, const uint8_t* blue_noise_rgba8_256, KjDevice** out) {
     KJ_REQUIRE(out && blue_noise_rgba8_256, "null argument");

@@ -26,7 +26,7 @@ EXPORTS = [
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
     "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
-    "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_surface",
+    "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_surface", "kj_trace_sun_shadow_mask",
 ]
 
 _LIB = None
@@ -89,6 +89,7 @@ def load():
         "kj_taa_create": [vp, C.POINTER(vp)],
         "kj_taa_render": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp],
         "kj_taa_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
+        "kj_trace_sun_shadow_mask": [vp, vp, C.POINTER(KjGbufferDepth), vp, vp, vp],
         "kj_ssgi_create": [vp, C.POINTER(vp)],
         "kj_ssgi_render": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.POINTER(vp), vp],
         "kj_ssgi_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
@@ -351,6 +352,14 @@ class GpuPipeline:
         ow, oh = out_extent or (self.W, self.H)
         inp = input_ptr if input_ptr is not None else self.out.screen_irradiance_tex
         check(self.L.kj_taa_render(self.taa, inp, self.W, self.H, self.reprojection_map_ptr, self.depth.data_ptr(), ow, oh, C.byref(self.taa_out), _stream_ptr()))
+
+    def sun_shadow_mask(self, out=None, ray_counter=None):
+        """trace_sun_shadow_mask (renderers/shadows.rs:10-40): R8 mask, one soft-shadow ray per pixel."""
+        if out is None:
+            out = self.torch.zeros((self.H, self.W), dtype=self.torch.uint8, device=self.depth.device)
+        g = self.gbuffer_depth()
+        check(self.L.kj_trace_sun_shadow_mask(self.dev.h, self.scene.h, C.byref(g), out.data_ptr(), ray_counter.data_ptr() if ray_counter is not None else None, _stream_ptr()))
+        return out
 
     def ssgi_frame(self):
         """SsgiRenderer::render (world_render_passes.rs:90-96): computes the SSAO guide; rtdgi's `ssao_tex` then points at it."""

@@ -279,6 +279,34 @@ int okj_taa_surface(void* p, const char* name, void** out_ptr, uint64_t* out_byt
     return 0;
 }
 
+// trace_sun_shadow_mask (renderers/shadows.rs:10-40; rt/trace_sun_shadow_mask.rgen.hlsl:19-60)
+void okj_trace_sun_shadow_mask(const void* scene, const KjFrameConstants* fcp, const uint8_t* blue_noise, const void* depth, const void* geometric_normal, void* out_r8, uint32_t w, uint32_t h) {
+    const Scene& sc = *(const Scene*)scene;
+    const FrameConstants& fc = *fcp;
+    ImgR32F depth_tex((void*)depth, w, h);
+    ImgU32 gn((void*)geometric_normal, w, h);
+    ImgR8 out(out_r8, w, h);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < int(h); ++y)
+        for (int x = 0; x < int(w); ++x) {
+            const f2 uv{(float(x) + 0.5f) / float(w), (float(y) + 0.5f) / float(h)};
+            const float z_over_w = depth_tex.ld(x, y);
+            if (0.0f == z_over_w) { out.st(x, y, 255); continue; }
+            const f2 cs = uv_to_cs(uv);
+            f4 pt_vs = mul44(fc.view_constants.sample_to_view, f4{cs.x, cs.y, z_over_w, 1.0f});
+            f4 pt_ws = mul44(fc.view_constants.view_to_world, pt_vs);
+            pt_ws = pt_ws / pt_ws.w;
+            pt_vs = pt_vs / pt_vs.w;
+            const f3 normal_vs = unpack_a2r10g10b10(gn.ld(x, y)) * 2.0f - 1.0f;
+            const f3 normal_ws = xyz(mul44(fc.view_constants.view_to_world, mk4(normal_vs, 0.0f)));
+            const float bias_amount = (-pt_vs.z + length(xyz(pt_ws))) * 1e-5f;
+            const f3 ray_origin = xyz(pt_ws) + normal_ws * bias_amount;
+            const f4 bn = blue_noise_for_pixel(blue_noise, uint32_t(x), uint32_t(y), fc.frame_index);
+            const f3 dir = sample_sun_direction(fc, f2{bn.x, bn.y}, true);
+            out.st(x, y, sc.trace_any(Ray{ray_origin, 0.0f, dir, FLT_MAX}) ? 0 : 255);
+        }
+}
+
 // ---- ssgi (SsgiRenderer): returns the R8_UNORM full-res guide
 void* okj_ssgi_create() { return new Ssgi(); }
 void okj_ssgi_destroy(void* p) { delete (Ssgi*)p; }

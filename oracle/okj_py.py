@@ -82,6 +82,7 @@ def lib():
         L.okj_taa_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.okj_taa_surface.restype = C.c_int
         L.okj_taa_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.okj_trace_sun_shadow_mask.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.okj_ssgi_create.restype = C.c_void_p
         L.okj_ssgi_destroy.argtypes = [C.c_void_p]
         L.okj_ssgi_render.restype = C.c_void_p
@@ -246,6 +247,12 @@ class OraclePipeline:
         tout = C.c_void_p()
         r = self.L.okj_taa_render(self.taa, C.byref(fc), inp, self.W, self.H, self.reprojection_map.ctypes.data, self.depth.ctypes.data, ow, oh, C.byref(tout))
         return r, tout.value
+
+    def sun_shadow_mask(self, fc):
+        """trace_sun_shadow_mask (renderers/shadows.rs:10-40)."""
+        out = np.zeros((self.H, self.W), np.uint8)
+        self.L.okj_trace_sun_shadow_mask(self.scene.h, C.byref(fc), self.bn.ctypes.data, self.depth.ctypes.data, self.geometric_normal.ctypes.data, out.ctypes.data, self.W, self.H)
+        return out
 
     def ssgi_frame(self, fc):
         """SsgiRenderer::render (world_render_passes.rs:90-96): computes the SSAO guide and binds it as rtdgi's ssao_tex."""

