@@ -206,16 +206,50 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
     return TraceResult{total_radiance, hit_normal_ws, hit_t, pdf, primary_hit.is_hit};
 }
 
+// ------------------------------------------------------------------ ray-pixel compaction (ours)
+// The two ray passes only do work on half-res pixels whose G-buffer sample is not sky. Mapping lanes 1:1 to pixels left
+// three quarters of the lane-slots idle in the benchmark view (rocprof VALUUtilization 26 %), so the passes run over a
+// compacted list instead: this kernel appends the live pixels of each 8x8 tile (one atomic per wave, tile order preserved
+// inside a wave) and writes the constant outputs the reference shaders give sky pixels (diffuse_validate.rgen.hlsl:56-59,
+// trace_diffuse.rgen.hlsl:56-61). Per-pixel results do not depend on the list order.
+__global__ void __launch_bounds__(64) k_rtdgi_list_pixels(const FrameConstants* __restrict__ fcp, ImgF32 depth, uint32_t* __restrict__ list, uint32_t* __restrict__ count,
+                                                           int hw, int hh, int fill_validate, int fill_trace, ImgR8 validity_pre_tex, ImgH4 candidate_irradiance_out_tex,
+                                                           ImgU32 candidate_normal_out_tex, ImgR8 validity_out_tex, int row0, int row1) {
+    TILE_XY(hw, hh)
+    const I2 off = halfres_subsample_offset(fcp->frame_index);
+    const bool live = in_image && depth.ld(x * 2 + off.x, y * 2 + off.y) != 0.0f;
+    const unsigned long long m = __ballot(live);
+    uint32_t base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (m != 0ull) {
+        if (lane == leader) base = atomicAdd(count, uint32_t(__popcll(m)));
+        base = __shfl(base, leader);
+    }
+    if (live) list[base + __popcll(m & ((1ull << lane) - 1ull))] = uint32_t(x) | (uint32_t(y) << 16);
+    else if (in_image) {
+        if (fill_validate) validity_pre_tex.st(x, y, to_unorm8(1.0f));
+        if (fill_trace) {
+            st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
+            candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
+            validity_out_tex.st(x, y, 0);
+        }
+    }
+}
+#define LIST_XY()                                                        \
+    const int lane = threadIdx.x;                                        \
+    const uint32_t li_ = blockIdx.x * 64u + uint32_t(lane);              \
+    if (li_ >= *pixel_count) return;                                     \
+    const uint32_t lp_ = pixel_list[li_];                                \
+    const int x = int(lp_ & 0xffffu), y = int(lp_ >> 16);
+
 // ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111
 template <bool STATS>
 __global__ void __launch_bounds__(64) k_rtdgi_validate(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
-                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, const uint32_t* __restrict__ pixel_list,
+                                                        const uint32_t* __restrict__ pixel_count) {
     extern __shared__ uint32_t lds_stack[];
-    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
-    if (!in_image) return;
+    LIST_XY()   // live (non-sky) pixels only; k_rtdgi_list_pixels wrote the sky value
     const FrameConstants& fc = *c.fc;
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    if (0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y)) { invalidity_out_tex.st(x, y, to_unorm8(1.0f)); return; }
     float invalidity = 0.0f;
     if (is_rtdgi_validation_frame(fc.frame_index)) {
         const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
@@ -245,20 +279,14 @@ __global__ void __launch_bounds__(64) k_rtdgi_validate(TraceCtx c, ImgU32 half_v
 // ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24
 template <bool STATS>
 __global__ void __launch_bounds__(64) k_rtdgi_trace(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
-                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, const uint32_t* __restrict__ pixel_list,
+                                                     const uint32_t* __restrict__ pixel_count) {
     extern __shared__ uint32_t lds_stack[];
-    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
-    if (!in_image) return;
+    LIST_XY()   // live (non-sky) pixels only; k_rtdgi_list_pixels wrote the sky outputs
     const FrameConstants& fc = *c.fc;
     const I2 off = halfres_subsample_offset(fc.frame_index);
     const int hx = x * 2 + off.x, hy = y * 2 + off.y;
     const float depth = c.depth.ld(hx, hy);
-    if (0.0f == depth) {
-        st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
-        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
-        invalidity_out_tex.st(x, y, 0);
-        return;
-    }
     const V4 gts = tex_size4(c.depth.w, c.depth.h);
     const V2 uv = get_uv(float(hx), float(hy), gts);
     const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
@@ -948,17 +976,27 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(1);
     }
+    uint32_t* pixel_list = (uint32_t*)r->get("ray_pixel_list", HB * 4 + 16, s);   // [0..HB) pixels, then the counter
+    uint32_t* pixel_count = pixel_list + HB;
+    const dim3 gl(uint32_t((size_t(hr1 - hr0) * hw + 63) / 64));
+    KJ_TRY_HIP(r->err);
+    if (mask & (KJ_RTDGI_PASS_VALIDATE | KJ_RTDGI_PASS_TRACE)) {
+        KJ_TRY_HIP(hipMemsetAsync(pixel_count, 0, 4, s));
+        hipLaunchKernelGGL(k_rtdgi_list_pixels, gh, blk, 0, s, fc, depth, pixel_list, pixel_count, hw, hh, (mask & KJ_RTDGI_PASS_VALIDATE) ? 1 : 0, (mask & KJ_RTDGI_PASS_TRACE) ? 1 : 0,
+                           img<uint8_t>(validity_pre, hw, hh), img<uint2>(candidate_radiance, hw, hh), img<uint32_t>(candidate_normal, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+    }
     if (mask & KJ_RTDGI_PASS_VALIDATE) {
         SCOPE_BEGIN(2);
-        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate<true> : k_rtdgi_validate<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
-                           img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate<true> : k_rtdgi_validate<false>, gl, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+                           img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), pixel_list, pixel_count);
         KJ_CHECK_LAUNCH();
         SCOPE_END(2);
     }
     if (mask & KJ_RTDGI_PASS_TRACE) {
         SCOPE_BEGIN(3);
-        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace<true> : k_rtdgi_trace<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
-                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace<true> : k_rtdgi_trace<false>, gl, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), pixel_list, pixel_count);
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
     }
