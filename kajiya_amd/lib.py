@@ -327,10 +327,19 @@ class GpuPipeline:
 
     def frame_pipelined(self, next_fc):
         """One GI + TAA frame whose ircache work was issued earlier; then issue the next frame's (if any). The caller binds this
-        frame's G-buffer inputs before the call. `next_fc` = constants of the following frame or None for the last one."""
+        frame's G-buffer inputs before the call. `next_fc` = constants of the following frame or None for the last one.
+
+        Three streams: the main one carries ssgi/rtdgi; the ircache stream runs the next frame's cache maintenance + rays from
+        the moment this frame's trace pass is recorded; the TAA stream runs this frame's TAA (VALU-bound) under the next
+        frame's ray passes (latency-bound: at 1080p they expose ~3 waves per SIMD). Hazards: the next spatial filter may
+        not overwrite `spatial_filtered_tex` before this TAA has read it (event below); everything else TAA touches is its own."""
         torch = self.torch
         s0 = torch.cuda.current_stream()
         i = self._pipe_i & 1
+        if not hasattr(self, "_s2"):
+            self._s2 = torch.cuda.Stream()
+            self._ev_gi = [torch.cuda.Event(), torch.cuda.Event()]
+            self._ev_taa = [torch.cuda.Event(), torch.cuda.Event()]
         s0.wait_event(self._ev_irc[i])
         s = _stream_ptr()
         P = KJ_RTDGI_PASS
@@ -340,12 +349,22 @@ class GpuPipeline:
         p = self.params(head)
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
         self._ev_trace[i].record(s0)
-        p = self.params((P["ALL"] & ~head) | (1 << 31))
+        p = self.params((P["ALL"] & ~head & ~P["SPATIAL_FILTER"]) | (1 << 31))
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
-        self.taa_frame()
+        if self._pipe_i > 0:
+            s0.wait_event(self._ev_taa[1 - i])           # last frame's TAA has consumed spatial_filtered_tex
+        p = self.params(P["SPATIAL_FILTER"] | (1 << 31))
+        check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+        self._ev_gi[i].record(s0)
+        with torch.cuda.stream(self._s2):
+            self._s2.wait_event(self._ev_gi[i])
+            self.taa_frame()
+            self._ev_taa[i].record(self._s2)
         self._pipe_i += 1
         if next_fc is not None:
             self._enqueue_ircache(next_fc, self._ev_trace[i])
+        else:
+            s0.wait_event(self._ev_taa[i])
 
     def taa_frame(self, input_ptr=None, out_extent=None):
         """TaaRenderer::render on `input_ptr` (default: this frame's rtdgi screen_irradiance_tex)."""
