@@ -295,7 +295,9 @@ KjStatus kj_ssgi_render(KjSsgi* t, const KjGbufferDepth* gd, const void* reproje
     void* hist_out = t->get(t->flip ? "ssgi:1" : "ssgi:0", FB * 2, s);
     void* hist = t->get(t->flip ? "ssgi:0" : "ssgi:1", FB * 2, s);
     t->flip = !t->flip;
-    void* final_out = t->get("filtered_output_tex", FB, s);
+    // the guide is double-buffered: a host that overlaps frames (GpuPipeline.frame_pipelined) lets frame N's spatial filter read
+    // guide N while frame N+1's ssgi pass is already writing guide N+1
+    void* final_out = t->get(t->flip ? "filtered_output_tex:0" : "filtered_output_tex:1", FB, s);
     KJ_TRY_HIP(t->err);
     const dim3 gf((W + 7) / 8, (H + 7) / 8), gh((hw + 7) / 8, (hh + 7) / 8), blk(64);
     const ImgU4 gbuffer = img<uint4>(gd->gbuffer, W, H);

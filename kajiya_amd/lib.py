@@ -329,10 +329,11 @@ class GpuPipeline:
         """One GI + TAA frame whose ircache work was issued earlier; then issue the next frame's (if any). The caller binds this
         frame's G-buffer inputs before the call. `next_fc` = constants of the following frame or None for the last one.
 
-        Three streams: the main one carries ssgi/rtdgi; the ircache stream runs the next frame's cache maintenance + rays from
-        the moment this frame's trace pass is recorded; the TAA stream runs this frame's TAA (VALU-bound) under the next
-        frame's ray passes (latency-bound: at 1080p they expose ~3 waves per SIMD). Hazards: the next spatial filter may
-        not overwrite `spatial_filtered_tex` before this TAA has read it (event below); everything else TAA touches is its own."""
+        Three streams: the main one carries ssgi/rtdgi up to the temporal filter; the ircache stream runs the next frame's cache
+        maintenance + rays from the moment this frame's trace pass is recorded; the third stream runs this frame's spatial
+        filter + TAA (VALU-bound) under the next frame's ray passes (latency-bound: at 1080p they expose ~3 waves per SIMD).
+        Hazards: the next frame's temporal filter may not overwrite `temporal_filtered_tex` before this spatial filter has read
+        it (event below); the SSAO guide is double-buffered inside KjSsgi; everything else on the third stream is its own."""
         torch = self.torch
         s0 = torch.cuda.current_stream()
         i = self._pipe_i & 1
@@ -349,15 +350,15 @@ class GpuPipeline:
         p = self.params(head)
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
         self._ev_trace[i].record(s0)
+        if self._pipe_i > 0:
+            s0.wait_event(self._ev_taa[1 - i])           # last frame's spatial filter has consumed temporal_filtered_tex
         p = self.params((P["ALL"] & ~head & ~P["SPATIAL_FILTER"]) | (1 << 31))
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
-        if self._pipe_i > 0:
-            s0.wait_event(self._ev_taa[1 - i])           # last frame's TAA has consumed spatial_filtered_tex
-        p = self.params(P["SPATIAL_FILTER"] | (1 << 31))
-        check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
         self._ev_gi[i].record(s0)
+        p = self.params(P["SPATIAL_FILTER"] | (1 << 31))      # captures this frame's inputs (guide N, depth N) now
         with torch.cuda.stream(self._s2):
             self._s2.wait_event(self._ev_gi[i])
+            check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), _stream_ptr()))
             self.taa_frame()
             self._ev_taa[i].record(self._s2)
         self._pipe_i += 1

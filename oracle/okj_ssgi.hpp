@@ -206,7 +206,7 @@ struct Ssgi {
         // ---- "ssao temporal" (temporal_filter.hlsl), full res; history R16F ping-pong "ssgi", output R8_UNORM
         ImgR16Fs hist_out = get<uint16_t>(flip ? "ssgi:1" : "ssgi:0", W, H), hist = get<uint16_t>(flip ? "ssgi:0" : "ssgi:1", W, H);
         flip = !flip;
-        ImgR8 final_out = get<uint8_t>("filtered_output_tex", W, H);
+        ImgR8 final_out = get<uint8_t>(flip ? "filtered_output_tex:0" : "filtered_output_tex:1", W, H);   // double-buffered like the HIP side
         const f4 ots = tex_size4(W, H);
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
