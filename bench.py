@@ -162,8 +162,9 @@ def main():
 
     step(0)  # allocates surfaces
     all_pipes = [gp] if single else list(split.pipes.values())
-    gp_counters = [lib.tensor_from_ptr(*_counter_ptr(q, lib), torch.int64, (6,)) for q in all_pipes]
-    irc_counters = [q.ircache_buffer("ray_counters", torch.int64) for q in all_pipes]
+    # device counters are striped over 64 cache lines of 16 u64 (kj_vec.hpp: KJ_COUNTER_SLOTS / KJ_COUNTER_STRIDE); sum the slots
+    gp_counters = [lib.tensor_from_ptr(*_counter_ptr(q, lib), torch.int64, (64, 16)) for q in all_pipes]
+    irc_counters = [q.ircache_buffer("ray_counters", torch.int64).view(64, 16) for q in all_pipes]
     ray_log = torch.zeros((n_frames + 1, 6), dtype=torch.int64, device=f"cuda:{local_rank}")
     irc_log = torch.zeros((n_frames + 1, 2), dtype=torch.int64, device=f"cuda:{local_rank}")
     overlap = not args.no_overlap
@@ -174,9 +175,9 @@ def main():
         irc_frame = [0]
 
         def log_irc():   # on the ircache stream, right after its rays
-            irc_log[irc_frame[0]].copy_(irc_counters[0], non_blocking=True)
+            irc_log[irc_frame[0]].copy_(irc_counters[0][:, :2].sum(dim=0))
             for ic_ in irc_counters[1:]:
-                irc_log[irc_frame[0]] += ic_
+                irc_log[irc_frame[0]] += ic_[:, :2].sum(dim=0)
         (gp if single else split).on_ircache_traced = log_irc
 
         def step(i):  # noqa: F811
@@ -204,13 +205,13 @@ def main():
     t0 = time.perf_counter()
     for i in range(Wm, Wm + K):
         step(i)
-        ray_log[i].copy_(gp_counters[0], non_blocking=True)  # 48-byte device-to-device copy on the same stream
+        ray_log[i].copy_(gp_counters[0][:, :6].sum(dim=0))  # tiny device-side reduction on the same stream
         for c_ in gp_counters[1:]:   # virtual ranks only
-            ray_log[i] += c_
+            ray_log[i] += c_[:, :6].sum(dim=0)
         if not overlap:
-            irc_log[i].copy_(irc_counters[0], non_blocking=True)
+            irc_log[i].copy_(irc_counters[0][:, :2].sum(dim=0))
             for ic_ in irc_counters[1:]:
-                irc_log[i] += ic_
+                irc_log[i] += ic_[:, :2].sum(dim=0)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

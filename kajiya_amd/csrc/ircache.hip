@@ -129,7 +129,7 @@ struct IrcTraceCtx {
 };
 KJ_D void irc_count_rays(unsigned long long* counters, int which) {
     const unsigned long long m = __ballot(true);
-    if ((__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counters[which], (unsigned long long)__popcll(m));
+    if ((__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
 }
 // trace_accessibility.rgen.hlsl:21-66
 __global__ void __launch_bounds__(64) k_irc_trace_accessibility(IrcTraceCtx c) {
@@ -365,7 +365,7 @@ KjStatus kj_ircache_create(KjDevice* dev, KjIrcache** out) {
     A(c->entry_cell, IRC_MAX_ENTRIES * 4); A(c->spatial, IRC_MAX_ENTRIES * 16); A(c->irradiance, size_t(IRC_MAX_ENTRIES) * 48);
     A(c->aux, size_t(IRC_MAX_ENTRIES) * 64 * 16); A(c->life, IRC_MAX_ENTRIES * 4); A(c->pool, IRC_MAX_ENTRIES * 4);
     A(c->entry_indirection, (IRC_MAX_ENTRIES + 64) * 4); A(c->reposition_proposal, IRC_MAX_ENTRIES * 16);
-    A(c->reposition_proposal_count, IRC_MAX_ENTRIES * 4); A(c->occupancy, IRC_MAX_ENTRIES * 4); A(c->ray_counters, 16);
+    A(c->reposition_proposal_count, IRC_MAX_ENTRIES * 4); A(c->occupancy, IRC_MAX_ENTRIES * 4); A(c->ray_counters, KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8);
     if (e != hipSuccess) { delete c; set_last_error("ircache allocation failed: %s", hipGetErrorString(e)); return KJ_ERR_OUT_OF_MEMORY; }
     *out = c;
     return KJ_OK;
@@ -445,7 +445,7 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     const size_t lds = size_t(tc.sc.bvh.stack_entries) * 64 * 4;
     KJ_REQUIRE(lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");
     const uint32_t grid = c->dev->num_cus * 8;
-    KJ_TRY_HIP(hipMemsetAsync(c->ray_counters.p, 0, 16, s));
+    KJ_TRY_HIP(hipMemsetAsync(c->ray_counters.p, 0, KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8, s));
     hipLaunchKernelGGL(k_irc_prepare_trace, dim3(1), dim3(1), 0, s, (uint32_t*)c->meta.p);
     KJ_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_irc_reset, dim3(grid), dim3(64), 0, s, tc.ic);
@@ -482,7 +482,10 @@ KjStatus kj_ircache_buffer(KjIrcache* c, const char* name, void** out_dev_ptr, u
 KjStatus kj_ircache_ray_counts(KjIrcache* c, uint64_t* out_closest, uint64_t* out_any) {
     KJ_REQUIRE(c && out_closest && out_any, "null argument");
     uint64_t v[2];
-    KJ_TRY_HIP(hipMemcpy(v, c->ray_counters.p, 16, hipMemcpyDeviceToHost));
+    unsigned long long all_[KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE];
+    KJ_TRY_HIP(hipMemcpy(all_, c->ray_counters.p, sizeof(all_), hipMemcpyDeviceToHost));
+    v[0] = v[1] = 0;
+    for (uint32_t sl = 0; sl < KJ_COUNTER_SLOTS; ++sl) { v[0] += all_[sl * KJ_COUNTER_STRIDE]; v[1] += all_[sl * KJ_COUNTER_STRIDE + 1]; }
     *out_closest = v[0]; *out_any = v[1];
     return KJ_OK;
 }

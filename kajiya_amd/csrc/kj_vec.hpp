@@ -309,6 +309,16 @@ KJ_HD V4 linear_rgb_to_crunched_luma_chroma(V4 v) {
 }
 KJ_HD V4 crunched_luma_chroma_to_linear_rgb(V4 v) { return v4(YCbCr_to_sRGB(xyz(v) * v.x), v.w); }
 
+// ---- device ray counters: one atomic per wave per ray query. All waves hammering ONE address serialise in L2 (measured: 10 %
+// of the trace kernel), so the counters are striped over KJ_COUNTER_SLOTS cache lines picked by workgroup id; readers sum them.
+#define KJ_COUNTER_SLOTS 64u
+#define KJ_COUNTER_STRIDE 16u   // u64 per slot = 128 B
+#ifdef __HIPCC__
+KJ_D unsigned long long* counter_slot(unsigned long long* base) {
+    return base + ((blockIdx.x + blockIdx.y * gridDim.x) & (KJ_COUNTER_SLOTS - 1u)) * KJ_COUNTER_STRIDE;
+}
+#endif
+
 // ---- flat-buffer "textures": OOB load = 0, OOB store dropped
 template <typename T> struct Img {
     T* p; int w, h;

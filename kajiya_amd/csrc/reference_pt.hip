@@ -150,7 +150,9 @@ __global__ void __launch_bounds__(64) k_reference_path_trace(PtArgs a) {
     const V3 c = V3{cur.x, cur.y, cur.z} / fmaxf(1.0f, cur.w);
     const V3 o = vmax(v3(0.0f), lerp(V3{prev.x, prev.y, prev.z}, c, lrp));
     a.output[size_t(y) * a.W + x] = make_float4(o.x, o.y, o.z, fmaxf(1.0f, tsc));
-    atomicAdd(a.ray_counter, (unsigned long long)rays);
+    if (a.ray_counter) {   // optional; one atomic per lane would serialise on a single address
+        atomicAdd(a.ray_counter, (unsigned long long)rays);
+    }
 }
 
 extern "C" {
@@ -175,9 +177,7 @@ KjStatus kj_reference_path_trace(KjDevice* dev, const KjScene* scene, void* outp
     a.W = int(width); a.H = int(height);
     a.first_bounce_mode = int(first_bounce_mode);
     a.interleave_count = interleave_count; a.interleave_index = interleave_index;
-    static unsigned long long* dummy = nullptr;
-    if (!ray_counter_dev && !dummy) KJ_TRY_HIP(hipMalloc(&dummy, 8));
-    a.ray_counter = ray_counter_dev ? (unsigned long long*)ray_counter_dev : dummy;
+    a.ray_counter = (unsigned long long*)ray_counter_dev;
     const uint32_t tiles = ((width + 7) / 8) * ((height + 7) / 8);
     const uint32_t my_tiles = (tiles - interleave_index + interleave_count - 1) / interleave_count;
     const size_t lds = size_t(a.sc.bvh.stack_entries) * 64 * 4;

@@ -124,7 +124,7 @@ struct TraceResult { V3 out_value; V3 hit_normal_ws; float hit_t; float pdf; boo
 
 KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
     const unsigned long long m = __ballot(active);
-    if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counters[which], (unsigned long long)__popcll(m));
+    if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
 }
 
 template <bool STATS>
@@ -198,58 +198,24 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
         total_radiance += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
     }
     if (STATS) {  // instrumentation build only: traversal work per ray type (SURVEY 8d "measured by the instrumented kernel")
-        atomicAdd(&c.ray_counters[2], (unsigned long long)st_closest.nodes);
-        atomicAdd(&c.ray_counters[3], (unsigned long long)st_closest.tris);
-        atomicAdd(&c.ray_counters[4], (unsigned long long)st_any.nodes);
-        atomicAdd(&c.ray_counters[5], (unsigned long long)st_any.tris);
+        atomicAdd(&counter_slot(c.ray_counters)[2], (unsigned long long)st_closest.nodes);
+        atomicAdd(&counter_slot(c.ray_counters)[3], (unsigned long long)st_closest.tris);
+        atomicAdd(&counter_slot(c.ray_counters)[4], (unsigned long long)st_any.nodes);
+        atomicAdd(&counter_slot(c.ray_counters)[5], (unsigned long long)st_any.tris);
     }
     return TraceResult{total_radiance, hit_normal_ws, hit_t, pdf, primary_hit.is_hit};
 }
 
-// ------------------------------------------------------------------ ray-pixel compaction (ours)
-// The two ray passes only do work on half-res pixels whose G-buffer sample is not sky. Mapping lanes 1:1 to pixels left
-// three quarters of the lane-slots idle in the benchmark view (rocprof VALUUtilization 26 %), so the passes run over a
-// compacted list instead: this kernel appends the live pixels of each 8x8 tile (one atomic per wave, tile order preserved
-// inside a wave) and writes the constant outputs the reference shaders give sky pixels (diffuse_validate.rgen.hlsl:56-59,
-// trace_diffuse.rgen.hlsl:56-61). Per-pixel results do not depend on the list order.
-__global__ void __launch_bounds__(64) k_rtdgi_list_pixels(const FrameConstants* __restrict__ fcp, ImgF32 depth, uint32_t* __restrict__ list, uint32_t* __restrict__ count,
-                                                           int hw, int hh, int fill_validate, int fill_trace, ImgR8 validity_pre_tex, ImgH4 candidate_irradiance_out_tex,
-                                                           ImgU32 candidate_normal_out_tex, ImgR8 validity_out_tex, int row0, int row1) {
-    TILE_XY(hw, hh)
-    const I2 off = halfres_subsample_offset(fcp->frame_index);
-    const bool live = in_image && depth.ld(x * 2 + off.x, y * 2 + off.y) != 0.0f;
-    const unsigned long long m = __ballot(live);
-    uint32_t base = 0;
-    const int leader = __ffsll((long long)m) - 1;
-    if (m != 0ull) {
-        if (lane == leader) base = atomicAdd(count, uint32_t(__popcll(m)));
-        base = __shfl(base, leader);
-    }
-    if (live) list[base + __popcll(m & ((1ull << lane) - 1ull))] = uint32_t(x) | (uint32_t(y) << 16);
-    else if (in_image) {
-        if (fill_validate) validity_pre_tex.st(x, y, to_unorm8(1.0f));
-        if (fill_trace) {
-            st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
-            candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
-            validity_out_tex.st(x, y, 0);
-        }
-    }
-}
-#define LIST_XY()                                                        \
-    const int lane = threadIdx.x;                                        \
-    const uint32_t li_ = blockIdx.x * 64u + uint32_t(lane);              \
-    if (li_ >= *pixel_count) return;                                     \
-    const uint32_t lp_ = pixel_list[li_];                                \
-    const int x = int(lp_ & 0xffffu), y = int(lp_ >> 16);
-
 // ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111
 template <bool STATS>
 __global__ void __launch_bounds__(64) k_rtdgi_validate(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
-                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, const uint32_t* __restrict__ pixel_list,
-                                                        const uint32_t* __restrict__ pixel_count) {
+                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
     extern __shared__ uint32_t lds_stack[];
-    LIST_XY()   // live (non-sky) pixels only; k_rtdgi_list_pixels wrote the sky value
+    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    if (!in_image) return;
     const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    if (0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y)) { invalidity_out_tex.st(x, y, to_unorm8(1.0f)); return; }
     float invalidity = 0.0f;
     if (is_rtdgi_validation_frame(fc.frame_index)) {
         const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
@@ -279,14 +245,20 @@ __global__ void __launch_bounds__(64) k_rtdgi_validate(TraceCtx c, ImgU32 half_v
 // ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24
 template <bool STATS>
 __global__ void __launch_bounds__(64) k_rtdgi_trace(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
-                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, const uint32_t* __restrict__ pixel_list,
-                                                     const uint32_t* __restrict__ pixel_count) {
+                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
     extern __shared__ uint32_t lds_stack[];
-    LIST_XY()   // live (non-sky) pixels only; k_rtdgi_list_pixels wrote the sky outputs
+    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    if (!in_image) return;
     const FrameConstants& fc = *c.fc;
     const I2 off = halfres_subsample_offset(fc.frame_index);
     const int hx = x * 2 + off.x, hy = y * 2 + off.y;
     const float depth = c.depth.ld(hx, hy);
+    if (0.0f == depth) {
+        st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
+        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
+        invalidity_out_tex.st(x, y, 0);
+        return;
+    }
     const V4 gts = tex_size4(c.depth.w, c.depth.h);
     const V2 uv = get_uv(float(hx), float(hy), gts);
     const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
@@ -831,7 +803,7 @@ struct KjRtdgi {
     bool temporal2_flip = false;
     void* temporal_output_tex = nullptr;        // ReprojectedRtdgi (rtdgi.rs:48-51)
     void* reprojected_history_tex = nullptr;
-    kj::DevBuf ray_counters;                    // 6 x u64
+    kj::DevBuf ray_counters;                    // KJ_COUNTER_SLOTS x (6 used of KJ_COUNTER_STRIDE) u64, see kj_vec.hpp
     bool profiling = false;                     // per-pass GPU timestamps (gpu-profiler scopes, kajiya-rg/src/graph.rs:941-944)
     bool count_traversal = false;               // instrumented trace kernels
     static const int NUM_SCOPES = 11;
@@ -870,7 +842,7 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     KJ_REQUIRE(dev && out, "null argument");
     KjRtdgi* r = new KjRtdgi();
     r->dev = dev;
-    if (r->ray_counters.alloc(48) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
+    if (r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
     *out = r;
     return KJ_OK;
 }
@@ -952,7 +924,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     void* temporal_filtered = r->get("temporal_filtered_tex", FB * 8, s);
     void* spatial_filtered = r->get("spatial_filtered_tex", FB * 8, s);
     KJ_TRY_HIP(r->err);
-    if (!(p->pass_mask & KJ_RTDGI_PASS_KEEP_TEMPORALS)) KJ_TRY_HIP(hipMemsetAsync(r->ray_counters.p, 0, 48, s));  // per frame; pass-by-pass calls accumulate
+    if (!(p->pass_mask & KJ_RTDGI_PASS_KEEP_TEMPORALS)) KJ_TRY_HIP(hipMemsetAsync(r->ray_counters.p, 0, KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8, s));  // per frame; pass-by-pass calls accumulate
 
     TraceCtx tc;
     tc.fc = fc;
@@ -976,27 +948,17 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(1);
     }
-    uint32_t* pixel_list = (uint32_t*)r->get("ray_pixel_list", HB * 4 + 16, s);   // [0..HB) pixels, then the counter
-    uint32_t* pixel_count = pixel_list + HB;
-    const dim3 gl(uint32_t((size_t(hr1 - hr0) * hw + 63) / 64));
-    KJ_TRY_HIP(r->err);
-    if (mask & (KJ_RTDGI_PASS_VALIDATE | KJ_RTDGI_PASS_TRACE)) {
-        KJ_TRY_HIP(hipMemsetAsync(pixel_count, 0, 4, s));
-        hipLaunchKernelGGL(k_rtdgi_list_pixels, gh, blk, 0, s, fc, depth, pixel_list, pixel_count, hw, hh, (mask & KJ_RTDGI_PASS_VALIDATE) ? 1 : 0, (mask & KJ_RTDGI_PASS_TRACE) ? 1 : 0,
-                           img<uint8_t>(validity_pre, hw, hh), img<uint2>(candidate_radiance, hw, hh), img<uint32_t>(candidate_normal, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
-        KJ_CHECK_LAUNCH();
-    }
     if (mask & KJ_RTDGI_PASS_VALIDATE) {
         SCOPE_BEGIN(2);
-        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate<true> : k_rtdgi_validate<false>, gl, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
-                           img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), pixel_list, pixel_count);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate<true> : k_rtdgi_validate<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+                           img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(2);
     }
     if (mask & KJ_RTDGI_PASS_TRACE) {
         SCOPE_BEGIN(3);
-        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace<true> : k_rtdgi_trace<false>, gl, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
-                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), pixel_list, pixel_count);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace<true> : k_rtdgi_trace<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
     }
@@ -1103,7 +1065,10 @@ KjStatus kj_rtdgi_surface(KjRtdgi* r, const char* name, void** out_dev_ptr, uint
 KjStatus kj_rtdgi_ray_counts(KjRtdgi* r, uint64_t* out_closest, uint64_t* out_any) {
     KJ_REQUIRE(r && out_closest && out_any, "null argument");
     uint64_t v[2];
-    KJ_TRY_HIP(hipMemcpy(v, r->ray_counters.p, 16, hipMemcpyDeviceToHost));
+    unsigned long long all_[KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE];
+    KJ_TRY_HIP(hipMemcpy(all_, r->ray_counters.p, sizeof(all_), hipMemcpyDeviceToHost));
+    v[0] = v[1] = 0;
+    for (uint32_t sl = 0; sl < KJ_COUNTER_SLOTS; ++sl) { v[0] += all_[sl * KJ_COUNTER_STRIDE]; v[1] += all_[sl * KJ_COUNTER_STRIDE + 1]; }
     *out_closest = v[0]; *out_any = v[1];
     return KJ_OK;
 }
@@ -1128,7 +1093,9 @@ KjStatus kj_rtdgi_pass_times_ms(KjRtdgi* r, float* out_ms, uint32_t count) {
 }
 KjStatus kj_rtdgi_traversal_counts(KjRtdgi* r, uint64_t out[6]) {
     KJ_REQUIRE(r && out, "null argument");
-    KJ_TRY_HIP(hipMemcpy(out, r->ray_counters.p, 48, hipMemcpyDeviceToHost));
+    unsigned long long all_[KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE];
+    KJ_TRY_HIP(hipMemcpy(all_, r->ray_counters.p, sizeof(all_), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 6; ++k) { out[k] = 0; for (uint32_t sl = 0; sl < KJ_COUNTER_SLOTS; ++sl) out[k] += all_[sl * KJ_COUNTER_STRIDE + k]; }
     return KJ_OK;
 }
 
