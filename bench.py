@@ -98,11 +98,16 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("KJ_BENCH_SHARE_GPU0"):   # debugging aid: several ranks on one GPU (only works if RCCL accepts duplicate devices)
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("KJ_BENCH_SHARE_GPU0"):
+            dist.init_process_group("gloo")      # RCCL rejects duplicate devices; exchanges are staged through host memory
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from kajiya_amd import lib
 
     W, H = args.width, args.height
@@ -119,7 +124,7 @@ def main():
         from kajiya_amd import multigpu
         if world > 1:
             split_pipes = {rank: gp}
-            comm = multigpu.DistComm(dist, rank, world)
+            comm = multigpu.DistComm(dist, rank, world, stage_through_host=bool(os.environ.get("KJ_BENCH_SHARE_GPU0")))
         else:
             split_pipes = {0: gp}
             for r in range(1, nsplit):
@@ -129,7 +134,7 @@ def main():
     single = split is None
 
     # ---- pre-generate the inputs of every frame (resident in HBM before the timed region; replicated on every rank)
-    n_frames = Wm + K + (args.profile_frames + 3 if single else 0) + 1
+    n_frames = Wm + K + args.profile_frames + 3 + 1
     fcs = frame_constants_list(W, H, n_frames, cam_args)
     inputs = []
     for fc in fcs:
@@ -221,6 +226,7 @@ def main():
     rays_closest = int(ray_log[Wm:Wm + K, 0].sum().item())
     rays_any = int(ray_log[Wm:Wm + K, 1].sum().item())
     irc_rays = int(irc_log[Wm:Wm + K].sum().item())
+    local_closest, local_any = rays_closest / max(1, nsplit if world == 1 else 1), rays_any / max(1, nsplit if world == 1 else 1)   # one rank's strip
     if world > 1:
         t = torch.tensor([rays_closest, rays_any, irc_rays], dtype=torch.int64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -236,8 +242,9 @@ def main():
         torch.cuda.synchronize()
         (gp if single else split).on_ircache_traced = None
         step = serial_step
-    if single:
-        # ---- per-pass GPU timestamps (HIP events on the launch stream), after the timed region
+    if True:
+        # ---- per-pass GPU timestamps (HIP events on the launch stream), after the timed region. In the screen-tile split these
+        # are the passes of THIS rank's strip (rank 0 reports).
         gp.set_profiling(True, False)
         pass_ms = [0.0] * 11
         trace_ms_list = []
@@ -252,7 +259,7 @@ def main():
         gp.set_profiling(False, False)
         # ---- segment timers (torch events on the launch stream): ircache / rtdgi / taa
         seg = {"ssgi": 0.0, "ircache": 0.0, "rtdgi": 0.0, "taa": 0.0}
-        nseg = 6
+        nseg = 6 if single else 0
         for i in range(base, base + nseg):   # replays inputs of already-used frames: timing only
             gn, gb, d, rp = inputs[i]
             gp.geometric_normal, gp.gbuffer, gp.depth = gn, gb, d
@@ -281,7 +288,7 @@ def main():
             seg["ircache"] += ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])
             seg["rtdgi"] += ev[1].elapsed_time(ev[2]) + ev[3].elapsed_time(ev[4])
             seg["taa"] += ev[4].elapsed_time(ev5)
-        seg = {k: round(v / nseg, 4) for k, v in seg.items()}
+        seg = {k: round(v / nseg, 4) for k, v in seg.items()} if nseg else None
         # ---- instrumented traversal counters (3 frames: one validation + two tracing frames)
         gp.set_profiling(False, True)
         trav = None
@@ -304,12 +311,13 @@ def main():
         tris_per_any = trav["any_tris"] / max(1, trav["any_rays"])
         # rays issued by the trace kernel per frame ~ measured split: trace issues (hw*hh non-sky) closest + shadow rays;
         # use the per-frame average of the timed region minus the validate kernel's share (1/3 of frames run validate).
-        closest_per_frame = rays_closest / K
-        any_per_frame = rays_any / K
+        closest_per_frame = local_closest / K
+        any_per_frame = local_any / K
         trace_share = 1.0 / (1.0 + 1.0 / 3.0)  # validate kernel traces the same count on every 3rd frame
         bytes_per_closest = nodes_per_closest * 64 + tris_per_closest * 48 + 232
         bytes_per_any = nodes_per_any * 64 + tris_per_any * 48
-        trace_bytes = hw * hh * 38 + trace_share * (closest_per_frame * bytes_per_closest + any_per_frame * bytes_per_any)
+        strip_frac = 1.0 / max(1, nsplit)
+        trace_bytes = hw * hh * 38 * strip_frac + trace_share * (closest_per_frame * bytes_per_closest + any_per_frame * bytes_per_any)
         trace_ms = pass_ms[3]
         achieved = trace_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         traffic = None   # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): committed measurement
@@ -338,7 +346,7 @@ def main():
                                + (", SSAO guide (ssgi, 4 passes)" if use_ssgi else ", constant SSAO guide"),
                    "triangles": stats["triangles"], "bvh_nodes": stats["nodes"], "bvh_bytes": stats["bvh_bytes"],
                    "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": ("single GPU, 2 HIP streams: next frame's ircache rays overlap this frame's screen-space tail" if overlap else "single GPU, serial frames") if nsplit <= 1 else f"{nsplit}-way screen-tile split (16-row-aligned strips; 6 batched halo exchanges per frame incl. the temporal2 all-gather, over "
-                                  + ("RCCL P2P" if world > 1 else "virtual ranks on one GPU") + f"; motion halo {args.motion_halo} rows; irradiance cache replicated per rank"
+                                  + (("gloo, host-staged (debug)" if os.environ.get("KJ_BENCH_SHARE_GPU0") else "RCCL P2P") if world > 1 else "virtual ranks on one GPU") + f"; motion halo {args.motion_halo} rows; irradiance cache replicated per rank"
                                   + ("; next frame's ircache work overlapped on a second stream)" if overlap else ")")},
         "segment_ms": seg,
         "pass_ms": {n: round(v, 4) for n, v in zip(lib.GpuPipeline.PASS_NAMES, pass_ms)} if pass_ms else None,

@@ -94,22 +94,34 @@ class LocalComm:
 
 
 class DistComm:
-    """torch.distributed point-to-point exchange (NCCL = RCCL on ROCm; gloo for CPU tests)."""
+    """torch.distributed point-to-point exchange (NCCL = RCCL on ROCm; gloo for CPU tests).
+    `stage_through_host`: debugging aid for the gloo backend with device tensors (several ranks sharing one GPU, where RCCL
+    refuses to start): sends are copied to host memory first, receives land in host memory and are copied back."""
 
-    def __init__(self, dist, rank, world):
+    def __init__(self, dist, rank, world, stage_through_host=False):
         self.dist, self.rank, self.n = dist, rank, world
         self.ranks = [rank]
+        self.stage = stage_through_host
 
     def run(self, xfers, get_rows):
-        ops = []
+        ops, landing = [], []
         for (src, dst, a, b) in xfers:
             if src == self.rank:
-                ops.append(self.dist.P2POp(self.dist.isend, get_rows(src, a, b), dst))
+                t = get_rows(src, a, b)
+                ops.append(self.dist.P2POp(self.dist.isend, t.cpu() if self.stage else t, dst))
             elif dst == self.rank:
-                ops.append(self.dist.P2POp(self.dist.irecv, get_rows(dst, a, b), src))
+                t = get_rows(dst, a, b)
+                if self.stage:
+                    import torch
+                    h = torch.empty(t.shape, dtype=t.dtype)
+                    landing.append((t, h))
+                    t = h
+                ops.append(self.dist.P2POp(self.dist.irecv, t, src))
         if ops:
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
+        for t, h in landing:
+            t.copy_(h)
 
 
 class SplitRtdgi:
