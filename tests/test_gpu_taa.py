@@ -54,3 +54,47 @@ def test_taa_per_frame_parity(gpu, oracle, device, scene_name, W, H):
             worst = max(worst, r["rel_l2"])
             assert r["rel_l2"] <= 1e-3 or r["mismatch_frac"] <= 2e-3, f"frame {fi} {name}: {r}"
     print(f"TAA worst per-surface rel-L2 over {len(fcs)} free-running frames ({scene_name}): {worst:.2e}")
+
+
+@pytest.mark.parametrize("scale_num,scale_den", [(2, 1), (3, 2)])
+def test_taa_upscaling_parity(gpu, oracle, device, scale_num, scale_den):
+    """TaaRenderer::render as a temporal upscaler (taa.rs:41-48 `output_extent`): 2x exercises the 5x5 history filter
+    (filter_history.hlsl:15-24, k = 2) and the coverage-driven accumulation, 1.5x the non-integer pixel mapping."""
+    import torch
+    W, H = 128, 96
+    OW, OH = W * scale_num // scale_den, H * scale_num // scale_den
+    desc = T._scenes()["city20k"]
+    op, gp = T._make_pipelines(gpu, oracle, device, desc, W, H)
+    repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    inp_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    worst = 0.0
+    for fi, fc in enumerate(T._frame_constants(W, H, 8, "city")):
+        op.frame(fc)
+        if fi > 0:   # identical temporal state on both sides: with non-integer scales a 1-ulp drift flips source-pixel choices
+            for n in ("taa:0", "taa:1", "taa.velocity:0", "taa.velocity:1", "taa.smooth_var:0", "taa.smooth_var:1"):
+                gp.taa_surface(n, torch.uint8, (-1,)).copy_(torch.from_numpy(op.taa_surface(n, np.uint8, (-1,)).copy()))
+        op.taa_frame(fc, out_extent=(OW, OH))
+        gp.dev.frame_begin(fc)
+        gp.depth.copy_(torch.from_numpy(op.depth))
+        repro_dev.copy_(torch.from_numpy(op.reprojection_map))
+        gp.reprojection_map_ptr = C.c_void_p(repro_dev.data_ptr())
+        inp_dev.copy_(torch.from_numpy(op.surface("spatial_filtered_tex", np.int16, (H, W, 4))))
+        gp.taa_frame(input_ptr=inp_dev.data_ptr(), out_extent=(OW, OH))
+        torch.cuda.synchronize()
+        for name, fmt in TAA_SURFACES.items():
+            if name == "filtered_history_img" and fi < 2:
+                continue
+            ref = op.taa_surface(name, np.uint8, (-1,))
+            got = gp.taa_surface(name, torch.uint8, (-1,)).cpu().numpy()
+            assert ref.size == got.size, (name, ref.size, got.size)
+            if fmt == "r16f":
+                a, b = _decode_r16f(got).astype(np.float64), _decode_r16f(ref).astype(np.float64)
+                rel = float(np.sqrt(((a - b) ** 2).sum()) / max(1e-12, np.sqrt((b ** 2).sum())))
+                r = {"rel_l2": rel, "mismatch_frac": float((np.abs(a - b) > 1e-3 + 1e-3 * np.abs(b)).mean())}
+            else:
+                r = P.compare(got, ref, fmt)
+            worst = max(worst, r["rel_l2"])
+            assert r["rel_l2"] <= 1e-3 or r["mismatch_frac"] <= 2e-3, f"frame {fi} {name}: {r}"
+    out = gp.taa_surface("this_frame_output_img", torch.float16, (OH, OW, 4)).float()
+    assert torch.isfinite(out).all() and float(out[..., :3].mean()) > 0
+    print(f"TAA {scale_num}/{scale_den}x upscaling worst per-surface rel-L2: {worst:.2e}")
