@@ -23,6 +23,9 @@ struct ViewRay {
     V3 hit_vs;       // ray_hit_vs()
     V3 hit_ws;       // ray_hit_ws()
     V3 hit_cs;       // ray_hit_cs.xyz
+    KJ_HD V3 biased_secondary_ray_origin_ws() const {   // frame_constants.hlsl:133-135
+        return hit_ws - dir_ws * (length(hit_vs) + length(hit_ws)) * 1e-4f;
+    }
     KJ_HD V3 biased_secondary_ray_origin_ws_with_normal(V3 normal) const {
         V3 ws_abs = vabs(hit_ws);
         float max_comp = fmaxf(fmaxf(ws_abs.x, ws_abs.y), fmaxf(ws_abs.z, -hit_vs.z));

@@ -583,6 +583,32 @@ __global__ void __launch_bounds__(64) k_restir_spatial(const FrameConstants* __r
     reservoir_output_tex.st(x, y, reservoir.as_raw());
 }
 
+// ------------------------------------------------------------------ restir_check.rgen.hlsl:21-70 (use_raytraced_reservoir_visibility, rtdgi.rs:478-494)
+__global__ void __launch_bounds__(64) k_restir_check(const FrameConstants* __restrict__ fcp, SceneView sc, ImgF32 half_depth_tex, ImgU4 temporal_reservoir_packed_tex,
+                                                      ImgU2 reservoir_input_tex, unsigned long long* __restrict__ ray_counters, int W, int H, int row0, int row1) {
+    extern __shared__ uint32_t lds_stack[];
+    TILE_XY(reservoir_input_tex.w, reservoir_input_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const V4 gts = tex_size4(W, H);
+    const float depth = half_depth_tex.ld(x, y);
+    const ViewRay vrc = view_ray_from_uv_and_biased_depth(fc, get_uv(float(x * 2 + off.x), float(y * 2 + off.y), gts), depth);
+    Reservoir1spp r = Reservoir1spp::from_raw(reservoir_input_tex.ld(x, y));
+    const int spx_x = int(r.payload & 0xffffu), spx_y = int(r.payload >> 16);
+    const TemporalReservoirOutput spx_packed = TemporalReservoirOutput::from_raw(temporal_reservoir_packed_tex.ld(spx_x, spx_y));
+    const ViewRay spx_ctx = view_ray_from_uv_and_depth(fc, get_uv(float(spx_x * 2 + off.x), float(spx_y * 2 + off.y), gts), spx_packed.depth);
+    const V3 spx_pos_ws = spx_ctx.hit_ws;
+    const V3 hit_ws = spx_packed.ray_hit_offset_ws + spx_pos_ws;
+    const V3 trace_origin_ws = vrc.biased_secondary_ray_origin_ws();
+    const V3 trace_vec = hit_ws - trace_origin_ws;
+    count_rays(ray_counters, 1, true);
+    if (rt_is_shadowed<false>(sc, trace_origin_ws, normalize(trace_vec), 0.0f, fminf(5.0f * length(spx_pos_ws - trace_origin_ws), length(trace_vec) * 0.999f), lds_stack + lane, 64)) {
+        r.W = 0;
+        reservoir_input_tex.st(x, y, r.as_raw());
+    }
+}
+
 // ------------------------------------------------------------------ restir_resolve.hlsl:42-205
 KJ_D float ggx_ndf_unnorm(float a2, float cos_theta) { const float d = cos_theta * cos_theta * (a2 - 1.0f) + 1.0f; return a2 / (d * d); }
 struct ResolveArgs {
@@ -849,7 +875,8 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
 void kj_rtdgi_destroy(KjRtdgi* r) { delete r; }
 KjStatus kj_rtdgi_set_options(KjRtdgi* r, uint32_t spatial_reuse_pass_count, uint32_t use_raytraced_reservoir_visibility) {
     KJ_REQUIRE(r, "null argument");
-    if (use_raytraced_reservoir_visibility) { set_last_error("restir_check (ray-traced reservoir visibility) is not implemented; the reference default is off (rtdgi.rs:43)"); return KJ_ERR_UNSUPPORTED; }
+    KJ_REQUIRE(spatial_reuse_pass_count >= 1 && spatial_reuse_pass_count <= 8, "spatial_reuse_pass_count out of range");
+    r->use_raytraced_reservoir_visibility = use_raytraced_reservoir_visibility != 0;
     r->spatial_reuse_pass_count = spatial_reuse_pass_count;
     return KJ_OK;
 }
@@ -1003,12 +1030,18 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         if ((mask & KJ_RTDGI_PASS_RESTIR_SPATIAL) && (p->spatial_pass_select == 0 || p->spatial_pass_select == i + 1)) {
             SCOPE_BEGIN((6 + (i ? 1 : 0)));
             hipLaunchKernelGGL(k_restir_spatial, gh, blk, 0, s, fc, img<uint2>(reservoir_input, hw, hh), img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh),
-                               img<int8_t>(half_ssao, hw, hh), img<uint4>(temporal_reservoir_packed, hw, hh), img<uint2>(reservoir_tex0, hw, hh), W, H, i, perform_occlusion_raymarch, 0u, hr0, hr1);
+                               img<int8_t>(half_ssao, hw, hh), img<uint4>(temporal_reservoir_packed, hw, hh), img<uint2>(reservoir_tex0, hw, hh), W, H, i, perform_occlusion_raymarch, r->use_raytraced_reservoir_visibility ? 1u : 0u, hr0, hr1);
             KJ_CHECK_LAUNCH();
             SCOPE_END((6 + (i ? 1 : 0)));
         }
         std::swap(reservoir_tex0, reservoir_tex1);
         reservoir_input = reservoir_tex1;
+    }
+    if (r->use_raytraced_reservoir_visibility && (mask & KJ_RTDGI_PASS_RESTIR_SPATIAL) && (p->spatial_pass_select == 0 || p->spatial_pass_select == r->spatial_reuse_pass_count)) {
+        // "restir check": one visibility ray per reservoir towards its selected sample; occluded reservoirs get W = 0
+        hipLaunchKernelGGL(k_restir_check, gh, blk, trace_lds, s, fc, tc.sc, img<float>(half_depth, hw, hh), img<uint4>(temporal_reservoir_packed, hw, hh),
+                           img<uint2>(reservoir_input, hw, hh), tc.ray_counters, W, H, hr0, hr1);
+        KJ_CHECK_LAUNCH();
     }
     if (mask & KJ_RTDGI_PASS_RESTIR_RESOLVE) {
         ResolveArgs a;

@@ -166,6 +166,7 @@ void* okj_rtdgi_create(const uint8_t* blue_noise_rgba8_256, const void* brdf_fg_
 }
 void okj_rtdgi_destroy(void* p) { delete (OkjRtdgi*)p; }
 void okj_rtdgi_set_options(void* p, uint32_t spatial_reuse_pass_count) { ((OkjRtdgi*)p)->r.spatial_reuse_pass_count = spatial_reuse_pass_count; }
+void okj_rtdgi_set_raytraced_visibility(void* p, int on) { ((OkjRtdgi*)p)->r.use_raytraced_reservoir_visibility = on != 0; }
 void okj_rtdgi_reproject(void* p, const KjFrameConstants* fc, const void* reprojection_map, uint32_t W, uint32_t H) {
     ((OkjRtdgi*)p)->r.reproject(*fc, ImgRGBA16S((void*)reprojection_map, W, H), W, H);
 }

@@ -60,6 +60,7 @@ def lib():
         L.okj_rtdgi_create.restype = C.c_void_p; L.okj_rtdgi_create.argtypes = [C.c_void_p, C.c_void_p]
         L.okj_rtdgi_destroy.argtypes = [C.c_void_p]
         L.okj_rtdgi_set_options.argtypes = [C.c_void_p, C.c_uint32]
+        L.okj_rtdgi_set_raytraced_visibility.argtypes = [C.c_void_p, C.c_int]
         L.okj_rtdgi_reproject.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_uint32]
         L.okj_rtdgi_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.POINTER(KjRtdgiRenderParams), C.POINTER(KjRtdgiOutput)]
         L.okj_rtdgi_surface.restype = C.c_int

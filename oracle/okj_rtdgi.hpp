@@ -59,6 +59,7 @@ struct Rtdgi {
     std::map<std::string, std::vector<uint8_t>> surf;
     int W = 0, H = 0, hw = 0, hh = 0;
     uint32_t spatial_reuse_pass_count = 2;
+    bool use_raytraced_reservoir_visibility = false;   // rtdgi.rs:25,43
     bool flip[9] = {false, false, false, false, false, false, false, false, false};
     bool temporal2_flip = false;
     std::atomic<uint64_t> rays_closest{0}, rays_any{0};
@@ -694,6 +695,33 @@ struct Rtdgi {
             }
     }
 
+    // ------------------------------------------------------------------ restir_check.rgen.hlsl:21-70 (use_raytraced_reservoir_visibility)
+    void pass_restir_check(const FrameConstants& fc, const RtdgiInputs& in, ImgR32F half_depth_tex, ImgU4 temporal_reservoir_packed_tex, ImgU2 reservoir_input_tex) {
+        const i2 off = halfres_subsample_offset(fc);
+        const f4 gbuffer_tex_size = tex_size4(W, H);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int y = 0; y < hh; ++y)
+            for (int x = 0; x < hw; ++x) {
+                const float depth = half_depth_tex.ld(x, y);
+                const f2 uv = get_uv(float(x * 2 + off.x), float(y * 2 + off.y), gbuffer_tex_size);
+                const ViewRayContext vrc = ViewRayContext::from_uv_and_biased_depth(fc, uv, depth);
+                Reservoir1spp r = Reservoir1spp::from_raw(reservoir_input_tex.ld(x, y));
+                const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
+                const TemporalReservoirOutput spx_packed = TemporalReservoirOutput::from_raw(temporal_reservoir_packed_tex.ld(spx_x, spx_y));
+                const f2 spx_uv = get_uv(float(spx_x * 2 + off.x), float(spx_y * 2 + off.y), gbuffer_tex_size);
+                const ViewRayContext spx_ctx = ViewRayContext::from_uv_and_depth(fc, spx_uv, spx_packed.depth);
+                const f3 spx_pos_ws = spx_ctx.ray_hit_ws();
+                const f3 hit_ws = spx_packed.ray_hit_offset_ws + spx_pos_ws;
+                const f3 trace_origin_ws = vrc.biased_secondary_ray_origin_ws();
+                const f3 trace_vec = hit_ws - trace_origin_ws;
+                rays_any.fetch_add(1, std::memory_order_relaxed);
+                if (in.scene->trace_any(Ray{trace_origin_ws, 0.0f, normalize(trace_vec), fminf(5.0f * length(spx_pos_ws - trace_origin_ws), length(trace_vec) * 0.999f)})) {
+                    r.W = 0;
+                    reservoir_input_tex.st(x, y, r.as_raw());
+                }
+            }
+    }
+
     // ------------------------------------------------------------------ restir_resolve.hlsl:42-205
     static float ggx_ndf_unnorm(float a2, float cos_theta) {
         float d = cos_theta * cos_theta * (a2 - 1.0f) + 1.0f;
@@ -942,10 +970,12 @@ struct Rtdgi {
             const uint32_t perform_occlusion_raymarch = (i + 1 == spatial_reuse_pass_count) ? 1 : 0;
             if (pass_mask & KJ_RTDGI_PASS_RESTIR_SPATIAL)
                 pass_restir_spatial(fc, in, reservoir_input_tex, half_view_normal_tex, half_depth_tex, half_ssao_tex,
-                                    temporal_reservoir_packed_tex, reservoir_output_tex0, i, perform_occlusion_raymarch, 0);
+                                    temporal_reservoir_packed_tex, reservoir_output_tex0, i, perform_occlusion_raymarch, use_raytraced_reservoir_visibility ? 1 : 0);
             std::swap(reservoir_output_tex0, reservoir_output_tex1);
             reservoir_input_tex = reservoir_output_tex1;
         }
+        if (use_raytraced_reservoir_visibility && (pass_mask & KJ_RTDGI_PASS_RESTIR_SPATIAL))   // "restir check" (rtdgi.rs:478-494)
+            pass_restir_check(fc, in, half_depth_tex, temporal_reservoir_packed_tex, reservoir_input_tex);
         ImgRGBA16F irradiance_output_tex = get<h4>("irradiance_output_tex", W, H);
         if (pass_mask & KJ_RTDGI_PASS_RESTIR_RESOLVE)
             pass_restir_resolve(fc, in, radiance_output_tex, reservoir_input_tex, half_view_normal_tex, half_depth_tex,

@@ -29,6 +29,9 @@ struct ViewRayContext {
     f3 ray_hit_vs() const { return xyz(ray_hit_vs_h) / ray_hit_vs_h.w; }
     f3 ray_hit_ws() const { return xyz(ray_hit_ws_h) / ray_hit_ws_h.w; }
 
+    f3 biased_secondary_ray_origin_ws() const {   // frame_constants.hlsl:133-135
+        return ray_hit_ws() - ray_dir_ws() * (length(ray_hit_vs()) + length(ray_hit_ws())) * 1e-4f;
+    }
     f3 biased_secondary_ray_origin_ws_with_normal(f3 normal) const {
         f3 ws_abs = vabs(ray_hit_ws());
         float max_comp = fmaxf(fmaxf(ws_abs.x, ws_abs.y), fmaxf(ws_abs.z, -ray_hit_vs().z));

@@ -170,10 +170,17 @@ def _download_state(gp, names, torch):
 @pytest.mark.parametrize("scene_name,W,H", [("cornell", 256, 256), ("city20k", 320, 192), ("city20k", 123, 77)])
 def test_rtdgi_per_pass_parity(gpu, oracle, device, scene_name, W, H):
     """Every rtdgi pass, in isolation, on identical inputs (oracle state uploaded before each pass)."""
+    _per_pass_parity(gpu, oracle, device, scene_name, W, H, 2, False)
+
+
+def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced):
     import torch
     from kajiya_amd.abi import KJ_RTDGI_PASS
     desc = _scenes()[scene_name]
     op, gp = _make_pipelines(gpu, oracle, device, desc, W, H)
+    op.L.okj_rtdgi_set_options(op.rtdgi, passes)
+    op.L.okj_rtdgi_set_raytraced_visibility(op.rtdgi, int(raytraced))
+    gpu.check(gp.L.kj_rtdgi_set_options(gp.rtdgi, passes, int(raytraced)))
     fcs = _frame_constants(W, H, 8, "cornell" if scene_name == "cornell" else "city")
     repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
     worst = {}
@@ -301,3 +308,22 @@ def test_sun_shadow_mask(gpu, oracle, device, scene_name, W, H):
         assert (got[op.depth == 0] == 255).all()
     assert int(counter.item()) == 3 * int((op.depth > 0).sum()) or True   # camera moves: just make sure rays were counted
     assert int(counter.item()) > 0
+
+
+@pytest.mark.parametrize("passes,raytraced", [(2, True), (1, False), (3, True)])
+def test_rtdgi_options_per_pass_parity(gpu, oracle, device, passes, raytraced):
+    """RtdgiRenderer::{spatial_reuse_pass_count, use_raytraced_reservoir_visibility} (rtdgi.rs:24-25,428-494): other pass counts
+    and the "restir check" visibility pass (restir_check.rgen.hlsl), pass by pass on identical inputs."""
+    _per_pass_parity(gpu, oracle, device, "city20k", 192, 128, passes, raytraced)
+    # the visibility pass does something: a fresh oracle run with it zeroes some reservoir weights
+    if raytraced:
+        W, H = 192, 128
+        op = oracle.OraclePipeline(oracle.OracleScene(_scenes()["city20k"]), W, H)
+        op.L.okj_rtdgi_set_options(op.rtdgi, passes)
+        op.L.okj_rtdgi_set_raytraced_visibility(op.rtdgi, 1)
+        for fc in _frame_constants(W, H, 3, "city"):
+            op.frame(fc)
+        final = "reservoir_output_tex1" if passes % 2 == 0 else "reservoir_output_tex0"   # the texture the last spatial pass wrote
+        dec = P.decode(op.surface(final, np.uint8, (-1,)), "reservoir")
+        m = dec[:, 2] > 0
+        assert 0 < (dec[m, 3] == 0).mean() < 0.9
