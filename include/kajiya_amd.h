@@ -337,6 +337,15 @@ KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t
 KjStatus kj_trace_sun_shadow_mask(KjDevice* dev, KjScene* scene, const KjGbufferDepth* gbuffer_depth, void* out_mask_r8,
                                   uint64_t* ray_counter_dev, void* stream);
 
+/* light_gbuffer(rg, gbuffer_depth, shadow_mask, rtr, rtdgi, ircache, wrc, temporal_output, output, sky_cube, convolved_sky_cube,
+ * bindless_set, debug_shading_mode, debug_show_wrc)   renderers/deferred.rs:6-60, shaders/light_gbuffer.hlsl:60-260 — the deferred
+ * combine: sun light through the shadow mask + emissive + diffuse GI * albedo * transmission (+ specular when rtr_tex is given) and
+ * the sky / sun disc where depth == 0. shadow_mask R8_UNORM; rtr_tex RGBA16F or NULL (black); rtdgi_tex RGBA16F; outputs RGBA16F
+ * (`out_temporal` is the image kajiya keeps as next frame's prev_radiance). debug_shading_mode 0-4 as in the shader (5 = ircache
+ * view and the wrc overlay: KJ_ERR_UNSUPPORTED). */
+KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gbuffer_depth, const void* shadow_mask_r8, const void* rtr_tex, const void* rtdgi_tex,
+                          const void* unconvolved_sky_cube, uint32_t sky_cube_width, void* out_temporal, void* out, uint32_t debug_shading_mode, void* stream);
+
 /* ---------------------------------------------------------------------------
  * SSAO / SSGI guide — feeds kernel radii and edge-stopping weights of the rtdgi spatial passes, resolve
  * and spatial filter (KjRtdgiRenderParams.ssao_tex)

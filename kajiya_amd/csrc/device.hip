@@ -160,6 +160,78 @@ __global__ void __launch_bounds__(64) k_trace_any(SceneView sc, const float4* __
     out[i] = bvh_trace<true>(sc.bvh, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, a.w, b.w, false, lds_stack + threadIdx.x, 64).slot != 0xffffffffu ? 1 : 0;
 }
 
+// light_gbuffer.hlsl:60-260 — the deferred combine: sun direct light through the shadow mask, emissive, diffuse
+// GI (rtdgi) times albedo and the specular layer's transmission, optional specular (rtr) term, sky + sun disc for depth == 0.
+// Debug shading modes 0-4 as in the shader; mode 5 (ircache view) and the wrc overlay are not built.
+struct LightGbufferArgs {
+    const FrameConstants* __restrict__ fc;
+    Img<uint4> gbuffer_tex; Img<float> depth_tex; Img<uint8_t> shadow_mask_tex; Img<uint2> rtr_tex; Img<uint2> rtdgi_tex;
+    Img<uint2> temporal_output_tex, output_tex;
+    const uint2* __restrict__ unconvolved_sky_cube; int sky_width;
+    const uint2* __restrict__ brdf_fg_lut;
+    const float4* __restrict__ sun_color;
+    uint32_t debug_shading_mode;
+};
+__global__ void __launch_bounds__(64) k_light_gbuffer(LightGbufferArgs a) {
+    const int lane = threadIdx.x;
+    const int x = int(blockIdx.x) * 8 + (lane & 7), y = int(blockIdx.y) * 8 + (lane >> 3);
+    const int W = a.output_tex.w, H = a.output_tex.h;
+    if (x >= W || y >= H) return;
+    const FrameConstants& fc = *a.fc;
+    const V4 ots = tex_size4(W, H);
+    const V2 uv = get_uv(float(x), float(y), ots);
+    const ViewRay vrc = view_ray_from_uv(fc, uv);
+    const V3 ray_d = vrc.dir_ws;
+    const float depth = a.depth_tex.ld(x, y);
+    const V3 sun_dir = sun_direction(fc);
+    if (depth == 0.0f) {
+        const float real_sun_angular_radius = 0.53f * 0.5f * KJ_PI / 180.0f;
+        const float sun_angular_radius_cos = fminf(cosf(real_sun_angular_radius), fc.sun_angular_radius_cos);
+        const float current_sun_angular_radius = acosf(sun_angular_radius_cos);
+        const float sun_radius_ratio = real_sun_angular_radius / current_sun_angular_radius;
+        V3 output = xyz(sample_cube_rgba16f(a.unconvolved_sky_cube, a.sky_width, ray_d));
+        if (dot(ray_d, sun_dir) > sun_angular_radius_cos) output += 800.0f * sun_color_in_direction(fc, ray_d) * sun_radius_ratio * sun_radius_ratio;
+        st4(a.temporal_output_tex, x, y, v4(output, 1.0f));
+        st4(a.output_tex, x, y, v4(output, 1.0f));
+        return;
+    }
+    float shadow_mask = from_unorm8(a.shadow_mask_tex.ld(x, y));
+    if (a.debug_shading_mode == 4u) shadow_mask = 1;
+    const GbufferData true_gbuffer = gbuffer_unpack(a.gbuffer_tex.ld(x, y));
+    GbufferData gbuffer = true_gbuffer;
+    if (a.debug_shading_mode == 1u) gbuffer.albedo = v3(0.5f);
+    const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
+    const V3 wi = to_local(tangent_to_world, sun_dir);
+    V3 wo = to_local(tangent_to_world, -ray_d);
+    if (wo.z < 0.0f) { wo.z *= -0.25f; wo = normalize(wo); }
+    const LayeredBrdf brdf = layered_brdf_from_gbuffer_ndotv(a.brdf_fg_lut, gbuffer, wo.z);
+    const V3 brdf_value = layered_brdf_evaluate_directional_light(brdf, wo, wi) * fmaxf(0.0f, wi.z);
+    const float4 sc4 = *a.sun_color;
+    const V3 light_radiance = shadow_mask * V3{sc4.x, sc4.y, sc4.z};
+    V3 total_radiance = brdf_value * light_radiance;
+    total_radiance += gbuffer.emissive;
+    V3 gi_irradiance = v3(0.0f);
+    if (a.debug_shading_mode != 4u) gi_irradiance = xyz(ld4(a.rtdgi_tex, x, y));
+    total_radiance += gi_irradiance * brdf.diff_albedo * brdf.preintegrated_transmission_fraction;
+    const V3 rtr = a.rtr_tex.p ? xyz(ld4(a.rtr_tex, x, y)) : v3(0.0f);
+    if (a.debug_shading_mode != 4u) {
+        V3 rtr_radiance = rtr * brdf.preintegrated_reflection;
+        if (a.debug_shading_mode == 1u) {
+            const LayeredBrdf true_brdf = layered_brdf_from_gbuffer_ndotv(a.brdf_fg_lut, true_gbuffer, wo.z);
+            rtr_radiance = rtr_radiance / true_brdf.preintegrated_reflection;
+        }
+        total_radiance += rtr_radiance;
+    }
+    st4(a.temporal_output_tex, x, y, v4(total_radiance, 1.0f));
+    V3 output = total_radiance;
+    if (a.debug_shading_mode == 3u) {
+        const LayeredBrdf true_brdf = layered_brdf_from_gbuffer_ndotv(a.brdf_fg_lut, true_gbuffer, wo.z);
+        output = rtr * brdf.preintegrated_reflection / true_brdf.preintegrated_reflection;
+    }
+    if (a.debug_shading_mode == 2u) output = gi_irradiance;
+    st4(a.output_tex, x, y, v4(output, 1.0f));
+}
+
 // rt/trace_sun_shadow_mask.rgen.hlsl:19-60 (USE_SOFT_SHADOWS 1): one shadow ray per full-res pixel, R8_UNORM mask
 __global__ void __launch_bounds__(64) k_sun_shadow_mask(const FrameConstants* __restrict__ fcp, SceneView sc, const uint32_t* __restrict__ blue_noise, Img<float> depth_tex,
                                                          Img<uint32_t> geometric_normal_tex, Img<uint8_t> output_tex, unsigned long long* __restrict__ ray_counter) {
@@ -193,6 +265,28 @@ __global__ void __launch_bounds__(64) k_sun_shadow_mask(const FrameConstants* __
 #define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
 
 extern "C" {
+
+// light_gbuffer (renderers/deferred.rs:6-60; shaders/light_gbuffer.hlsl): shadow_mask R8_UNORM, rtr_tex RGBA16F or NULL (= black),
+// rtdgi_tex RGBA16F, unconvolved_sky_cube 6 x w x w RGBA16F; outputs RGBA16F.
+KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gd, const void* shadow_mask_r8, const void* rtr_tex, const void* rtdgi_tex, const void* unconvolved_sky_cube,
+                          uint32_t sky_cube_width, void* out_temporal, void* out, uint32_t debug_shading_mode, void* stream) {
+    KJ_REQUIRE(dev && gd && gd->gbuffer && gd->depth && shadow_mask_r8 && rtdgi_tex && unconvolved_sky_cube && out_temporal && out && gd->width && gd->height, "null argument");
+    KJ_REQUIRE(dev->fc_dev, "kj_frame_begin not called");
+    if (debug_shading_mode > 4) { set_last_error("debug_shading_mode %u (ircache view) is not built", debug_shading_mode); return KJ_ERR_UNSUPPORTED; }
+    const int W = int(gd->width), H = int(gd->height);
+    LightGbufferArgs a;
+    a.fc = dev->fc_dev;
+    a.gbuffer_tex = img<uint4>(gd->gbuffer, W, H); a.depth_tex = img<float>(gd->depth, W, H); a.shadow_mask_tex = img<uint8_t>(shadow_mask_r8, W, H);
+    a.rtr_tex = img<uint2>(rtr_tex, W, H); a.rtdgi_tex = img<uint2>(rtdgi_tex, W, H);
+    a.temporal_output_tex = img<uint2>(out_temporal, W, H); a.output_tex = img<uint2>(out, W, H);
+    a.unconvolved_sky_cube = (const uint2*)unconvolved_sky_cube; a.sky_width = int(sky_cube_width);
+    a.brdf_fg_lut = (const uint2*)dev->brdf_fg_lut.p;
+    a.sun_color = (const float4*)dev->sun_color.p + dev->fc_slot;
+    a.debug_shading_mode = debug_shading_mode;
+    hipLaunchKernelGGL(k_light_gbuffer, dim3((W + 7) / 8, (H + 7) / 8), dim3(64), 0, (hipStream_t)stream, a);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
 
 // trace_sun_shadow_mask(rg, &GbufferDepth, tlas, bindless_set) -> Handle<Image> (renderers/shadows.rs:10-40)
 KjStatus kj_trace_sun_shadow_mask(KjDevice* dev, KjScene* scene, const KjGbufferDepth* gd, void* out_mask_r8, uint64_t* ray_counter_dev, void* stream) {

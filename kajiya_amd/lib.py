@@ -26,7 +26,7 @@ EXPORTS = [
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
     "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
-    "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_surface", "kj_trace_sun_shadow_mask",
+    "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_light_gbuffer",
 ]
 
 _LIB = None
@@ -89,6 +89,7 @@ def load():
         "kj_taa_create": [vp, C.POINTER(vp)],
         "kj_taa_render": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp],
         "kj_taa_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
+        "kj_light_gbuffer": [vp, C.POINTER(KjGbufferDepth), vp, vp, vp, vp, u32, vp, vp, u32, vp],
         "kj_trace_sun_shadow_mask": [vp, vp, C.POINTER(KjGbufferDepth), vp, vp, vp],
         "kj_ssgi_create": [vp, C.POINTER(vp)],
         "kj_ssgi_render": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.POINTER(vp), vp],
@@ -380,6 +381,17 @@ class GpuPipeline:
         g = self.gbuffer_depth()
         check(self.L.kj_trace_sun_shadow_mask(self.dev.h, self.scene.h, C.byref(g), out.data_ptr(), ray_counter.data_ptr() if ray_counter is not None else None, _stream_ptr()))
         return out
+
+    def light_gbuffer(self, shadow_mask, rtdgi_ptr=None, rtr_ptr=None, debug_shading_mode=0):
+        """light_gbuffer (renderers/deferred.rs:6-60): returns (temporal_output, output) RGBA16F images."""
+        t = self.torch
+        if not hasattr(self, "_lit"):
+            self._lit = (t.zeros((self.H, self.W, 4), dtype=t.float16, device=self.depth.device), t.zeros((self.H, self.W, 4), dtype=t.float16, device=self.depth.device))
+        g = self.gbuffer_depth()
+        gi = rtdgi_ptr if rtdgi_ptr is not None else self.out.screen_irradiance_tex
+        check(self.L.kj_light_gbuffer(self.dev.h, C.byref(g), shadow_mask.data_ptr(), rtr_ptr, gi, self.sky64.data_ptr(), 64, self._lit[0].data_ptr(), self._lit[1].data_ptr(),
+                                      debug_shading_mode, _stream_ptr()))
+        return self._lit
 
     def ssgi_frame(self):
         """SsgiRenderer::render (world_render_passes.rs:90-96): computes the SSAO guide; rtdgi's `ssao_tex` then points at it."""

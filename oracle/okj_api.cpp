@@ -308,6 +308,62 @@ void okj_trace_sun_shadow_mask(const void* scene, const KjFrameConstants* fcp, c
         }
 }
 
+// light_gbuffer (renderers/deferred.rs:6-60; shaders/light_gbuffer.hlsl:60-260), debug modes 0-4; rtr may be NULL (= black)
+void okj_light_gbuffer(const KjFrameConstants* fcp, const void* brdf_fg_lut, const void* gbuffer, const void* depth, const void* shadow_mask_r8, const void* rtr, const void* rtdgi,
+                       const void* sky_cube, int sky_w, void* out_temporal, void* out, uint32_t w, uint32_t h, uint32_t mode) {
+    const FrameConstants& fc = *fcp;
+    ImgU4 gbuffer_tex((void*)gbuffer, w, h); ImgR32F depth_tex((void*)depth, w, h); ImgR8 shadow_tex((void*)shadow_mask_r8, w, h);
+    ImgRGBA16F rtr_tex((void*)rtr, w, h), rtdgi_tex((void*)rtdgi, w, h), tout(out_temporal, w, h), oout(out, w, h);
+    const h4* lut = (const h4*)brdf_fg_lut;
+    const f3 sun_dir = sun_direction(fc);
+    const f3 sun_col = sun_color_in_direction(fc, sun_dir);
+    const f4 ots = tex_size4(w, h);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < int(h); ++y)
+        for (int x = 0; x < int(w); ++x) {
+            const f2 uv = get_uv(float(x), float(y), ots);
+            const ViewRayContext vrc = ViewRayContext::from_uv(fc, uv);
+            const f3 ray_d = vrc.ray_dir_ws();
+            const float d = depth_tex.ld(x, y);
+            if (d == 0.0f) {
+                const float real_r = 0.53f * 0.5f * M_PI_F / 180.0f;
+                const float sarc = fminf(cosf(real_r), fc.sun_angular_radius_cos);
+                const float ratio = real_r / acosf(sarc);
+                f3 o = xyz(sample_cube_rgba16f((const h4*)sky_cube, sky_w, ray_d));
+                if (dot(ray_d, sun_dir) > sarc) o += 800.0f * sun_color_in_direction(fc, ray_d) * ratio * ratio;
+                tout.st(x, y, pack_rgba16f(mk4(o, 1.0f))); oout.st(x, y, pack_rgba16f(mk4(o, 1.0f)));
+                continue;
+            }
+            float shadow_mask = from_unorm8(shadow_tex.ld(x, y));
+            if (mode == 4) shadow_mask = 1;
+            const GbufferData true_g = gbuffer_unpack(gbuffer_tex.ld(x, y));
+            GbufferData g = true_g;
+            if (mode == 1) g.albedo = mk3(0.5f);
+            const m33 t2w = build_orthonormal_basis(g.normal);
+            const f3 wi = mul(sun_dir, t2w);
+            f3 wo = mul(-ray_d, t2w);
+            if (wo.z < 0.0f) { wo.z *= -0.25f; wo = normalize(wo); }
+            const LayeredBrdf brdf = LayeredBrdf::from_gbuffer_ndotv(lut, g, wo.z);
+            const f3 brdf_value = brdf.evaluate_directional_light(wo, wi) * fmaxf(0.0f, wi.z);
+            f3 total = brdf_value * (shadow_mask * sun_col);
+            total += g.emissive;
+            f3 gi = mk3(0.0f);
+            if (mode != 4) gi = xyz(unpack_rgba16f(rtdgi_tex.ld(x, y)));
+            total += gi * brdf.diffuse_brdf.albedo * brdf.energy_preservation.preintegrated_transmission_fraction;
+            const f3 r = rtr ? xyz(unpack_rgba16f(rtr_tex.ld(x, y))) : mk3(0.0f);
+            if (mode != 4) {
+                f3 rr = r * brdf.energy_preservation.preintegrated_reflection;
+                if (mode == 1) rr = rr / LayeredBrdf::from_gbuffer_ndotv(lut, true_g, wo.z).energy_preservation.preintegrated_reflection;
+                total += rr;
+            }
+            tout.st(x, y, pack_rgba16f(mk4(total, 1.0f)));
+            f3 o = total;
+            if (mode == 3) o = r * brdf.energy_preservation.preintegrated_reflection / LayeredBrdf::from_gbuffer_ndotv(lut, true_g, wo.z).energy_preservation.preintegrated_reflection;
+            if (mode == 2) o = gi;
+            oout.st(x, y, pack_rgba16f(mk4(o, 1.0f)));
+        }
+}
+
 // ---- ssgi (SsgiRenderer): returns the R8_UNORM full-res guide
 void* okj_ssgi_create() { return new Ssgi(); }
 void okj_ssgi_destroy(void* p) { delete (Ssgi*)p; }

@@ -84,6 +84,7 @@ def lib():
         L.okj_taa_surface.restype = C.c_int
         L.okj_taa_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_trace_sun_shadow_mask.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.okj_light_gbuffer.argtypes = [C.POINTER(KjFrameConstants)] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.okj_ssgi_create.restype = C.c_void_p
         L.okj_ssgi_destroy.argtypes = [C.c_void_p]
         L.okj_ssgi_render.restype = C.c_void_p
@@ -254,6 +255,15 @@ class OraclePipeline:
         out = np.zeros((self.H, self.W), np.uint8)
         self.L.okj_trace_sun_shadow_mask(self.scene.h, C.byref(fc), self.bn.ctypes.data, self.depth.ctypes.data, self.geometric_normal.ctypes.data, out.ctypes.data, self.W, self.H)
         return out
+
+    def light_gbuffer(self, fc, shadow_mask, rtdgi=None, rtr=None, mode=0):
+        """light_gbuffer (renderers/deferred.rs:6-60): returns (temporal_output, output) as (H, W, 4) float16 arrays."""
+        t = np.zeros((self.H, self.W, 4), np.float16); o = np.zeros((self.H, self.W, 4), np.float16)
+        gi = rtdgi if rtdgi is not None else self.surface("spatial_filtered_tex", np.float16, (self.H, self.W, 4))
+        gi = np.ascontiguousarray(gi)
+        self.L.okj_light_gbuffer(C.byref(fc), brdf_lut().ctypes.data, self.gbuffer.ctypes.data, self.depth.ctypes.data, np.ascontiguousarray(shadow_mask).ctypes.data,
+                                 rtr.ctypes.data if rtr is not None else None, gi.ctypes.data, self.sky64.ctypes.data, 64, t.ctypes.data, o.ctypes.data, self.W, self.H, mode)
+        return t, o
 
     def ssgi_frame(self, fc):
         """SsgiRenderer::render (world_render_passes.rs:90-96): computes the SSAO guide and binds it as rtdgi's ssao_tex."""

@@ -327,3 +327,34 @@ def test_rtdgi_options_per_pass_parity(gpu, oracle, device, passes, raytraced):
         dec = P.decode(op.surface(final, np.uint8, (-1,)), "reservoir")
         m = dec[:, 2] > 0
         assert 0 < (dec[m, 3] == 0).mean() < 0.9
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_light_gbuffer(gpu, oracle, device, mode):
+    """The deferred combine (shaders/light_gbuffer.hlsl) on identical inputs: G-buffer, shadow mask, GI image, a
+    synthetic specular image and the sky cube, for every debug shading mode that is built."""
+    import torch
+    W, H = 224, 136
+    op, gp = _make_pipelines(gpu, oracle, device, _scenes()["city20k"], W, H)
+    fcs = _frame_constants(W, H, 3, "city")
+    for fc in fcs:
+        op.frame(fc)
+        gp.dev.frame_begin(fc)
+        _sync_inputs(op, gp, torch)
+    gp.sky64.copy_(torch.from_numpy(op.sky64.view(np.int16)))
+    fc = fcs[-1]
+    shadow = op.sun_shadow_mask(fc)
+    gi = op.surface("spatial_filtered_tex", np.float16, (H, W, 4)).copy()
+    rng = np.random.RandomState(5)
+    rtr = rng.uniform(0, 2, size=(H, W, 4)).astype(np.float16)
+    ref_t, ref_o = op.light_gbuffer(fc, shadow, gi, rtr, mode)
+    d_shadow, d_gi, d_rtr = torch.from_numpy(shadow).cuda(), torch.from_numpy(gi.view(np.int16)).cuda(), torch.from_numpy(rtr.view(np.int16)).cuda()
+    got_t, got_o = gp.light_gbuffer(d_shadow, rtdgi_ptr=d_gi.data_ptr(), rtr_ptr=d_rtr.data_ptr(), debug_shading_mode=mode)
+    torch.cuda.synchronize()
+    for name, a, b in (("temporal_output", got_t, ref_t), ("output", got_o, ref_o)):
+        r = P.compare(a.cpu().numpy().view(np.uint8).reshape(-1), b.view(np.uint8).reshape(-1), "rgba16f")
+        assert r["rel_l2"] <= REL_L2_TOL and r["bad_class"] == 0, (mode, name, r)
+    assert float(got_o.float()[..., :3].mean()) > 0
+    sky = op.depth == 0
+    if sky.any():
+        assert np.isfinite(ref_o[sky].astype(np.float32)).all()
