@@ -117,12 +117,16 @@ typedef struct KjMeshMaterial { /* 152 bytes, inc/mesh.hlsl:49-59; kajiya-asset 
 
 #define KJ_MESH_MATERIAL_FLAG_EMISSIVE_USED_AS_LIGHT 1u
 
-/* A material map. Round 1 supports the reference's `MeshMaterialMap::Placeholder`
- * (a 1x1 RGBA8 image, mesh.rs:60-66) and full RGBA8 images with a mip chain. */
+/* A material map: the reference's `MeshMaterialMap::Placeholder` (a 1x1 RGBA8 image, mesh.rs:60-66) or an RGBA8 image with
+ * its baked mip chain (`MeshMaterialMap::Image`, TexParams at mesh.rs:161-230: albedo / emissive are sRGB, spec is linear with
+ * x = perceptual roughness and y = metalness after the baker's channel swizzle). The asset baker (Lanczos mips, BC5/BC7
+ * compression, kajiya-asset/src/image.rs) is out of scope: the caller hands over decoded RGBA8 texels for every level. */
 typedef struct KjMaterialMap {
     uint8_t placeholder_rgba[4];
-    const uint8_t* image_rgba8; /* NULL => placeholder; else width*height*4 bytes (host) */
+    const uint8_t* image_rgba8; /* NULL => placeholder; else all mip levels back to back, level k = max(1,w>>k) x max(1,h>>k) x 4 bytes (host) */
     uint32_t width, height;
+    uint32_t mip_count;         /* >= 1 for images */
+    uint32_t srgb;              /* 1: R8G8B8A8_SRGB (rgb decoded per texel before filtering), 0: R8G8B8A8_UNORM */
 } KjMaterialMap;
 
 typedef struct KjMeshDesc {

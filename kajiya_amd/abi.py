@@ -51,7 +51,7 @@ assert C.sizeof(KjMeshMaterial) == 152
 
 
 class KjMaterialMap(C.Structure):
-    _fields_ = [("placeholder_rgba", C.c_uint8 * 4), ("image_rgba8", C.c_void_p), ("width", c_u32), ("height", c_u32)]
+    _fields_ = [("placeholder_rgba", C.c_uint8 * 4), ("image_rgba8", C.c_void_p), ("width", c_u32), ("height", c_u32), ("mip_count", c_u32), ("srgb", c_u32)]
 
 
 class KjMeshDesc(C.Structure):

@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(64) k_raster_gbuffer(const FrameConstants* __r
     const V3 pos = mad_nc(vr.origin_ws, vr.dir_ws, h.t);
     const V3 cs = position_world_to_sample(fc, pos);
     geometric_normal[idx] = pack_a2r10g10b10(gn_vs * 0.5f + 0.5f);
-    gbuffer[idx] = shade_gbuffer_hit(sc, fc, vr.dir_ws, h, 0);
+    // the raster pass samples with implicit derivatives; this stand-in uses the pixel's ray cone (width 0 at the eye)
+    gbuffer[idx] = shade_gbuffer_hit(sc, fc, vr.dir_ws, h, 0, pixel_ray_cone_from_image_height(fc, float(H)).width_at_t(h.t));
     depth[idx] = cs.z;
     velocity[idx] = make_uint2(0, 0);
 }

@@ -166,7 +166,7 @@ KJ_D IrcTraceResult ircache_trace(const IrcTraceCtx& c, const IrcVertex& entry, 
     result.hit_pos = v3(0.0f);
     V3 irradiance_sum = v3(0.0f);
     irc_count_rays(c.ray_counters, 0);
-    const GbufferPathVertex primary_hit = gbuffer_raytrace(c.sc, fc, ray_o, ray_d, 0.0f, FLT_MAX, 1, false, stack, 64);
+    const GbufferPathVertex primary_hit = gbuffer_raytrace(c.sc, fc, ray_o, ray_d, 0.0f, FLT_MAX, 1, false, stack, 64, nullptr, RayCone::from_spread_angle(0.1f));   // ircache_trace_common.inc.hlsl:83
     if (primary_hit.is_hit) {
         result.hit_pos = primary_hit.position;
         const V3 to_light_norm = sun_direction(fc);

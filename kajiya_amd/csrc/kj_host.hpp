@@ -78,10 +78,11 @@ struct KjScene {
     std::vector<std::vector<KjTriangleLight>> mesh_lights;
     struct Inst { uint32_t mesh; float xform[12]; float emissive_multiplier; bool alive; };
     std::vector<Inst> instances;
-    std::vector<float> map_colors; // 4 per map
+    std::vector<kj::MapDesc> maps;      // one per material map
+    std::vector<uint8_t> tex_data;      // RGBA8 mip chains of the image maps
     // committed device state
     bool committed = false;
-    kj::DevBuf d_vertex_buffer, d_meshes, d_instances, d_map_colors, d_lights, d_nodes, d_tris;
+    kj::DevBuf d_vertex_buffer, d_meshes, d_instances, d_maps, d_tex_data, d_lights, d_nodes, d_tris;
     uint32_t light_count = 0, tri_count = 0, node_count = 0, bvh_root = 0, bvh_max_depth = 0;
     kj::SceneView view() const;
 };

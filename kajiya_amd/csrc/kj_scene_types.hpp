@@ -39,6 +39,9 @@ struct BvhView {
     uint32_t stack_entries;  // per-lane LDS stack entries a tracing kernel must provide (KJ_BVH_LDS_STACK)
 };
 
+// 32 B per material map. flags: bits 0-7 = mip count (0 => 1x1 placeholder, `color`), bit 8 = sRGB texels.
+struct MapDesc { F4 color; uint32_t offset, width, height, flags; };
+
 struct GpuMesh {  // inc/mesh.hlsl:10-18 (+ index_count)
     uint32_t vertex_core_offset, vertex_uv_offset, vertex_mat_offset, vertex_aux_offset, vertex_tangent_offset, mat_data_offset, index_offset;
     uint32_t index_count;
@@ -53,7 +56,8 @@ struct SceneView {
     const uint8_t* vertex_buffer;
     const GpuMesh* meshes;
     const GpuInstance* instances;
-    const F4* map_colors;   // bindless "textures": 1x1 placeholders => constant colour
+    const MapDesc* maps;    // bindless "textures" (inc/bindless_textures.hlsl): placeholder colour or an RGBA8 mip chain in tex_data
+    const uint8_t* tex_data;
     const KjTriangleLight* lights;
     uint32_t light_count;
     BvhView bvh;

@@ -64,14 +64,17 @@ __global__ void __launch_bounds__(64) k_reference_path_trace(PtArgs a) {
     const V3 sun_color{sc4.x, sc4.y, sc4.z};
     const bool indirect_only = a.first_bounce_mode != 0;
     uint32_t rays = 0;
+    RayCone ray_cone = pixel_ray_cone_from_image_height(fc, float(a.H));   // :123-128
+    ray_cone.spread_angle *= 0.3f;                                       // "bias for texture sharpness"
 
     for (uint32_t path_length = 0; path_length < PT_MAX_EYE_PATH_LENGTH; ++path_length) {
         ++rays;
-        const GbufferPathVertex primary_hit = gbuffer_raytrace<false>(a.sc, fc, ray_o, ray_d, ray_tmin, FLT_MAX, path_length, false, stack, 64);
+        const GbufferPathVertex primary_hit = gbuffer_raytrace<false>(a.sc, fc, ray_o, ray_d, ray_tmin, FLT_MAX, path_length, false, stack, 64, nullptr, ray_cone);
         if (!primary_hit.is_hit) {
             total_radiance += throughput * atmosphere_default(fc, ray_d, sun_direction(fc));
             break;
         }
+        ray_cone = ray_cone.propagate(0.0f, primary_hit.ray_t);          // :151-152
         V2 su;
         su.x = uint_to_u01_float(hash1_mut(rng));
         su.y = uint_to_u01_float(hash1_mut(rng));

@@ -136,7 +136,9 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
     const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, ray_d) * 2 * KJ_PI));
     count_rays(c.ray_counters, 0, true);
     TraverseStats st_closest{0, 0}, st_any{0, 0};
-    const GbufferPathVertex primary_hit = gbuffer_raytrace<STATS>(c.sc, fc, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, 64, &st_closest);
+    // diffuse_trace_common.inc.hlsl:68-71: reflected cone = the half-res pixel cone propagated from the eye to the ray origin
+    const RayCone ray_cone = pixel_ray_cone_from_image_height(fc, float(c.depth.h) * 0.5f).propagate(0.03f, length(ray_o - get_eye_position(fc)));
+    const GbufferPathVertex primary_hit = gbuffer_raytrace<STATS>(c.sc, fc, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, 64, &st_closest, ray_cone);
     if (primary_hit.is_hit) {
         hit_t = primary_hit.ray_t;
         GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);

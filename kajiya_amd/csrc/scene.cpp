@@ -28,7 +28,8 @@ SceneView scene_view(const KjScene& s) {
     v.vertex_buffer = (const uint8_t*)s.d_vertex_buffer.p;
     v.meshes = (const GpuMesh*)s.d_meshes.p;
     v.instances = (const GpuInstance*)s.d_instances.p;
-    v.map_colors = (const F4*)s.d_map_colors.p;
+    v.maps = (const MapDesc*)s.d_maps.p;
+    v.tex_data = (const uint8_t*)s.d_tex_data.p;
     v.lights = (const KjTriangleLight*)s.d_lights.p;
     v.light_count = s.light_count;
     v.bvh.nodes = (const F4*)s.d_nodes.p;
@@ -71,12 +72,32 @@ KjStatus kj_scene_add_mesh(KjScene* s, const KjMeshDesc* d, uint32_t* out_mesh) 
     KJ_REQUIRE(d->verts && d->indices && d->materials && d->maps, "mesh streams missing");
     KJ_REQUIRE(d->index_count >= 3 && d->index_count % 3 == 0, "mesh must not be empty (world_renderer.rs:706-711)");
     for (uint32_t i = 0; i < d->map_count; ++i)
-        if (d->maps[i].image_rgba8) { set_last_error("image material maps are not supported yet (placeholders only)"); return KJ_ERR_UNSUPPORTED; }
+        if (d->maps[i].image_rgba8) {
+            const KjMaterialMap& mm = d->maps[i];
+            KJ_REQUIRE(mm.width >= 1 && mm.height >= 1 && mm.width <= 16384 && mm.height <= 16384, "image map extent out of range");
+            uint32_t full = 1;
+            while ((mm.width >> full) || (mm.height >> full)) ++full;
+            KJ_REQUIRE(mm.mip_count >= 1 && mm.mip_count <= full, "image map mip_count out of range");
+        }
     for (uint32_t i = 0; i < d->index_count; ++i) KJ_REQUIRE(d->indices[i] < d->vertex_count, "index out of range");
     std::vector<KjMeshMaterial> mats(d->materials, d->materials + d->material_count);
-    const uint32_t map_base = uint32_t(s->map_colors.size() / 4);
-    for (uint32_t i = 0; i < d->map_count; ++i)
-        for (int k = 0; k < 4; ++k) s->map_colors.push_back(float(d->maps[i].placeholder_rgba[k]) / 255.0f);
+    const uint32_t map_base = uint32_t(s->maps.size());
+    for (uint32_t i = 0; i < d->map_count; ++i) {
+        const KjMaterialMap& mm = d->maps[i];
+        MapDesc md{};
+        md.color = F4{float(mm.placeholder_rgba[0]) / 255.0f, float(mm.placeholder_rgba[1]) / 255.0f, float(mm.placeholder_rgba[2]) / 255.0f, float(mm.placeholder_rgba[3]) / 255.0f};
+        if (mm.image_rgba8) {
+            size_t bytes = 0;
+            for (uint32_t k = 0; k < mm.mip_count; ++k) bytes += size_t(std::max(1u, mm.width >> k)) * std::max(1u, mm.height >> k) * 4;
+            while (s->tex_data.size() % 16) s->tex_data.push_back(0);
+            KJ_REQUIRE(s->tex_data.size() + bytes < (size_t(1) << 32), "more than 4 GiB of material maps");
+            md.offset = uint32_t(s->tex_data.size());
+            md.width = mm.width; md.height = mm.height;
+            md.flags = mm.mip_count | (mm.srgb ? 0x100u : 0u);
+            s->tex_data.insert(s->tex_data.end(), mm.image_rgba8, mm.image_rgba8 + bytes);
+        }
+        s->maps.push_back(md);
+    }
     for (auto& m : mats) {
         for (int k = 0; k < 4; ++k) { KJ_REQUIRE(m.maps[k] < d->map_count, "material map index out of range"); m.maps[k] += map_base; }
         if (d->use_lights) m.flags |= KJ_MESH_MATERIAL_FLAG_EMISSIVE_USED_AS_LIGHT;
@@ -202,7 +223,9 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     KJ_TRY_HIP(s->d_vertex_buffer.upload(s->vertex_buffer.data(), s->vertex_buffer.size(), stream));
     KJ_TRY_HIP(s->d_meshes.upload(s->meshes.data(), s->meshes.size() * sizeof(GpuMesh), stream));
     KJ_TRY_HIP(s->d_instances.upload(ginst.data(), ginst.size() * sizeof(GpuInstance), stream));
-    KJ_TRY_HIP(s->d_map_colors.upload(s->map_colors.data(), s->map_colors.size() * 4, stream));
+    KJ_TRY_HIP(s->d_maps.upload(s->maps.data(), s->maps.size() * sizeof(MapDesc), stream));
+    if (s->tex_data.empty()) s->tex_data.resize(16, 0);
+    KJ_TRY_HIP(s->d_tex_data.upload(s->tex_data.data(), s->tex_data.size(), stream));
     if (lights.empty()) lights.push_back(KjTriangleLight{});
     KJ_TRY_HIP(s->d_lights.upload(lights.data(), lights.size() * sizeof(KjTriangleLight), stream));
     KJ_TRY_HIP(s->d_nodes.upload(b.nodes.data(), b.nodes.size() * sizeof(Bvh4Node), stream));

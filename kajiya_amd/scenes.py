@@ -22,6 +22,25 @@ def pack_unit_direction_11_10_11(n):
     return (z << np.uint32(21)) | (y << np.uint32(11)) | x
 
 
+def build_mip_chain(img):
+    """(h, w, 4) uint8 -> all mip levels back to back (2x2 box filter on the stored bytes, like the reference baker's
+    non-gamma-correct resize; kajiya-asset/src/image.rs:252-275 uses Lanczos3 — the baker is out of scope, this is test data)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    assert img.ndim == 3 and img.shape[2] == 4
+    levels = [img]
+    while levels[-1].shape[0] > 1 or levels[-1].shape[1] > 1:
+        a = levels[-1].astype(np.float32)
+        h, w = a.shape[:2]
+        nh, nw = max(1, h // 2), max(1, w // 2)
+        a = a[: nh * 2 if h > 1 else 1, : nw * 2 if w > 1 else 1]
+        if h > 1:
+            a = 0.5 * (a[0::2] + a[1::2])
+        if w > 1:
+            a = 0.5 * (a[:, 0::2] + a[:, 1::2])
+        levels.append(np.clip(np.rint(a), 0, 255).astype(np.uint8))
+    return np.concatenate([l.reshape(-1) for l in levels]), len(levels)
+
+
 class TriangleMesh:
     def __init__(self, positions, normals, indices, material_ids=None, materials=None, colors=None, uvs=None):
         self.positions = np.ascontiguousarray(positions, np.float32)
@@ -46,6 +65,7 @@ class TriangleMesh:
         verts["pos"] = self.positions
         verts["normal"] = pack_unit_direction_11_10_11(self.normals)
         mats = (KjMeshMaterial * len(self.materials))()
+        keep_images = []
         maps = (KjMaterialMap * (4 * len(self.materials)))()
         for i, m in enumerate(self.materials):
             mm = mats[i]
@@ -64,8 +84,20 @@ class TriangleMesh:
                 for j in range(4):
                     maps[4 * i + k].placeholder_rgba[j] = rgba[j]
                 maps[4 * i + k].image_rgba8 = None
+            # optional image maps (MeshMaterialMap::Image): "spec_image" / "albedo_image" / "emissive_image" = (h, w, 4) uint8 arrays;
+            # "map_transforms" = {slot: (a, b, c, d, tx, ty)} with slots 0 albedo, 2 spec, 3 emissive (mesh.rs:125-230)
+            for k, key, srgb in ((1, "spec_image", 0), (2, "albedo_image", 1), (3, "emissive_image", 1)):
+                if m.get(key) is not None:
+                    chain, nm = build_mip_chain(m[key])
+                    keep_images.append(chain)
+                    mp = maps[4 * i + k]
+                    mp.image_rgba8 = chain.ctypes.data
+                    mp.width, mp.height, mp.mip_count, mp.srgb = m[key].shape[1], m[key].shape[0], nm, srgb
+            for slot, t in (m.get("map_transforms") or {}).items():
+                for j, v in enumerate(t):
+                    mm.map_transforms[slot * 6 + j] = float(v)
         d = KjMeshDesc()
-        keep = [verts, self.indices, self.material_ids, mats, maps]
+        keep = [verts, self.indices, self.material_ids, mats, maps, keep_images]
         d.verts = verts.ctypes.data
         d.vertex_count = n
         d.uvs = self.uvs.ctypes.data if self.uvs is not None else None
@@ -199,6 +231,52 @@ def _mat(rng, emissive=None):
     alb = rng.uniform(0.2, 0.8, size=3)
     return dict(base_color=(alb[0], alb[1], alb[2], 1.0), roughness=float(rng.uniform(0.3, 1.0)), metalness=0.0,
                 emissive=(0, 0, 0) if emissive is None else emissive)
+
+
+def textured_test_scene(seed=11):
+    """A small scene whose materials use image maps with mip chains and uv transforms: a tiled floor, a wall, two boxes and a
+    sphere with checker / noise albedo, a roughness-metalness map and an emissive map. Used by the texture parity tests."""
+    rng = np.random.RandomState(seed)
+    sd = SceneDesc()
+
+    def checker(n, cells, c0, c1):
+        yy, xx = np.mgrid[0:n, 0:n]
+        m = (((xx * cells) // n + (yy * cells) // n) & 1).astype(bool)
+        img = np.zeros((n, n, 4), np.uint8)
+        img[...] = np.array(c0, np.uint8)
+        img[m] = np.array(c1, np.uint8)
+        return img
+    noise = rng.randint(0, 256, size=(64, 32, 4)).astype(np.uint8); noise[..., 3] = 255
+    spec = np.zeros((32, 32, 4), np.uint8); spec[..., 0] = rng.randint(60, 256, size=(32, 32)); spec[..., 1] = (rng.uniform(size=(32, 32)) < 0.3) * 255; spec[..., 2:] = 255
+    emis = checker(16, 4, (0, 0, 0, 255), (255, 160, 40, 255))
+    mats = [
+        dict(base_color=(1, 1, 1, 1), roughness=1.0, metalness=1.0, emissive=(0, 0, 0), albedo_image=checker(128, 8, (200, 60, 40, 255), (235, 235, 220, 255)),
+             spec_image=spec, map_transforms={0: (4.0, 0.0, 0.0, 4.0, 0.25, 0.0), 2: (1.0, 0.0, 0.0, 1.0, 0.0, 0.0)}),
+        dict(base_color=(0.9, 0.9, 1.0, 1), roughness=0.8, metalness=0.0, emissive=(0, 0, 0), albedo_image=noise,
+             map_transforms={0: (0.0, 1.0, -1.0, 0.0, 0.5, 0.5)}),
+        dict(base_color=(0.6, 0.6, 0.6, 1), roughness=0.7, metalness=0.0, emissive=(2.0, 2.0, 2.0), emissive_image=emis,
+             albedo_image=checker(64, 2, (90, 120, 200, 255), (30, 40, 60, 255)), map_transforms={3: (2.0, 0.0, 0.0, 2.0, 0.0, 0.0)}),
+    ]
+
+    def quad(p0, du, dv, n, mat, uvscale=1.0):
+        P = np.array([p0, p0 + du, p0 + du + dv, p0 + dv], np.float32)
+        N = np.tile(np.asarray(n, np.float32)[None], (4, 1))
+        UV = np.array([[0, 0], [uvscale, 0], [uvscale, uvscale], [0, uvscale]], np.float32)
+        return TriangleMesh(P, N, np.array([0, 1, 2, 0, 2, 3], np.uint32), materials=[mat], uvs=UV)
+    sd.add_instance(sd.add_mesh(quad(np.array([-8.0, 0, -8.0]), np.array([16.0, 0, 0]), np.array([0, 0, 16.0]), (0, 1, 0), mats[0], 2.0)), affine())
+    sd.add_instance(sd.add_mesh(quad(np.array([-8.0, 0, -6.0]), np.array([16.0, 0, 0]), np.array([0, 7.0, 0]), (0, 0, 1), mats[1], 3.0)), affine())
+    bp, bn, bidx = _box((1.5, 1.5, 1.5))
+    box_uv = np.tile(np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32), (len(bp) // 4 + 1, 1))[: len(bp)]
+    bm = TriangleMesh(bp, bn, bidx, materials=[mats[2]], uvs=box_uv)
+    bi = sd.add_mesh(bm)
+    sd.add_instance(bi, affine(t=(-2.5, 0.75, -1.0)))
+    sd.add_instance(bi, affine(scale=0.6, t=(2.0, 0.45, 1.5)))
+    sp, sn, sidx = _sphere(24, 16, 1.2)
+    th = np.arctan2(sp[:, 2], sp[:, 0]) / (2 * np.pi) + 0.5
+    ph = np.arccos(np.clip(sp[:, 1] / 1.2, -1, 1)) / np.pi
+    sm = TriangleMesh(sp, sn, sidx, materials=[mats[0]], uvs=np.stack([th, ph], -1).astype(np.float32))
+    sd.add_instance(sd.add_mesh(sm), affine(t=(0.5, 1.2, -2.5)))
+    return sd
 
 
 def procedural_city(target_tris=1_000_000, seed=1234, n_instances=64):

@@ -27,7 +27,7 @@ static inline IrcacheTraceResult ircache_trace(Ircache& ic, const FrameConstants
     const float roughness_bias = 0.5f;
     f3 irradiance_sum = mk3(0.0f);
     ic.rays_closest.fetch_add(1, std::memory_order_relaxed);
-    const GbufferPathVertex primary_hit = gbuffer_raytrace(*in.scene, fc, outgoing_ray, 1, false);
+    const GbufferPathVertex primary_hit = gbuffer_raytrace(*in.scene, fc, outgoing_ray, 1, false, RayCone{0.0f, 0.1f});   // ircache_trace_common.inc.hlsl:83
     if (primary_hit.is_hit) {
         result.hit_pos = primary_hit.position;
         const f3 to_light_norm = sun_direction(fc);

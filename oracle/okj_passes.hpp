@@ -72,7 +72,7 @@ static inline void raster_gbuffer(const Scene& sc, const FrameConstants& fc, int
             f2 uv = get_uv(float(x), float(y), ts);
             ViewRayContext vrc = ViewRayContext::from_uv(fc, uv);
             Ray ray{vrc.ray_origin_ws(), 0.0f, vrc.ray_dir_ws(), FLT_MAX};
-            GbufferPathVertex pv = gbuffer_raytrace(sc, fc, ray, 0, false);
+            GbufferPathVertex pv = gbuffer_raytrace(sc, fc, ray, 0, false, pixel_ray_cone_from_image_height(fc, float(H)));   // stand-in for the raster pass's implicit LOD
             if (!pv.is_hit) {
                 geometric_normal.st(x, y, 0);
                 gbuffer.st(x, y, u4{0, 0, 0, 0});

@@ -48,15 +48,18 @@ static inline bool reference_pt_sample(const FrameConstants& fc, const Reference
     float roughness_bias = 0.0f;
     const f3 sun_color = sun_color_in_direction(fc, sun_direction(fc));
     const bool indirect_only = in.first_bounce_mode != 0;
+    RayCone ray_cone = pixel_ray_cone_from_image_height(fc, float(H));   // :123-128
+    ray_cone.spread_angle *= 0.3f;
 
     for (uint32_t path_length = 0; path_length < in.max_path_length; ++path_length) {
         if (path_length == 1) outgoing_ray.tmax = FLT_MAX;
         ++*ray_count;
-        const GbufferPathVertex primary_hit = gbuffer_raytrace(*in.scene, fc, outgoing_ray, path_length, false);
+        const GbufferPathVertex primary_hit = gbuffer_raytrace(*in.scene, fc, outgoing_ray, path_length, false, ray_cone);
         if (!primary_hit.is_hit) {
             total_radiance += throughput * atmosphere_default(fc, outgoing_ray.d, sun_direction(fc));
             break;
         }
+        ray_cone = ray_cone.propagate(0.0f, primary_hit.ray_t);   // :151-152
         f2 su;
         su.x = uint_to_u01_float(hash1_mut(rng));
         su.y = uint_to_u01_float(hash1_mut(rng));

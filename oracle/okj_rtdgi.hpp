@@ -176,7 +176,8 @@ struct Rtdgi {
         float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, outgoing_ray.d) * 2 * M_PI_F));
         // ray cone only affects texture LOD (see okj_scene.hpp note)
         rays_closest.fetch_add(1, std::memory_order_relaxed);
-        const GbufferPathVertex primary_hit = gbuffer_raytrace(*in.scene, fc, outgoing_ray, 1, false);
+        const RayCone ray_cone = pixel_ray_cone_from_image_height(fc, gbuffer_tex_size.y * 0.5f).propagate(0.03f, length(outgoing_ray.o - get_eye_position(fc)));   // :68-71
+        const GbufferPathVertex primary_hit = gbuffer_raytrace(*in.scene, fc, outgoing_ray, 1, false, ray_cone);
         if (primary_hit.is_hit) {
             hit_t = primary_hit.ray_t;
             GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);

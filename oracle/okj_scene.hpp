@@ -83,7 +83,9 @@ struct Scene {
     std::vector<uint8_t> vertex_buffer; // byte-addressed, like the reference's 1 GiB buffer
     std::vector<GpuMesh> meshes;
     std::vector<Instance> instances;
-    std::vector<f4> map_colors;             // bindless "textures": placeholder 1x1 RGBA8 => constant
+    // bindless "textures" (inc/bindless_textures.hlsl): placeholder colour, or an RGBA8 mip chain (all levels back to back)
+    struct Map { f4 color; std::vector<uint8_t> texels; uint32_t width = 0, height = 0, mips = 0; bool srgb = false; };
+    std::vector<Map> maps;
     std::vector<std::vector<KjTriangleLight>> mesh_lights; // object-space, per mesh
     // committed
     std::vector<WorldTri> tris;
@@ -109,10 +111,19 @@ struct Scene {
         if (vertex_buffer.empty()) vertex_buffer.resize(64, 0);
         GpuMesh m{};
         std::vector<KjMeshMaterial> mats(d.materials, d.materials + d.material_count);
-        uint32_t map_base = uint32_t(map_colors.size());
+        uint32_t map_base = uint32_t(maps.size());
         for (uint32_t i = 0; i < d.map_count; ++i) {
-            const uint8_t* c = d.maps[i].placeholder_rgba;
-            map_colors.push_back(f4{c[0] / 255.0f, c[1] / 255.0f, c[2] / 255.0f, c[3] / 255.0f});
+            const KjMaterialMap& mm = d.maps[i];
+            const uint8_t* c = mm.placeholder_rgba;
+            Map m;
+            m.color = f4{c[0] / 255.0f, c[1] / 255.0f, c[2] / 255.0f, c[3] / 255.0f};
+            if (mm.image_rgba8) {
+                size_t bytes = 0;
+                for (uint32_t k = 0; k < mm.mip_count; ++k) bytes += size_t(std::max(1u, mm.width >> k)) * std::max(1u, mm.height >> k) * 4;
+                m.texels.assign(mm.image_rgba8, mm.image_rgba8 + bytes);
+                m.width = mm.width; m.height = mm.height; m.mips = mm.mip_count; m.srgb = mm.srgb != 0;
+            }
+            maps.push_back(std::move(m));
         }
         for (auto& mat : mats) {
             for (int k = 0; k < 4; ++k) mat.maps[k] += map_base;
@@ -304,6 +315,59 @@ struct Scene {
     }
 };
 
+// ---- material-map sampling: bindless_textures[idx].SampleLevel(sampler_llr, uv, lod) (rchit:96-99,106,172) — fixed-function in the
+// reference, defined as: RGBA8 texels -> float (sRGB maps decode rgb per texel first), bilinear with repeat addressing inside a
+// level, linear between floor(lod) and floor(lod)+1, lod clamped to [0, mips-1] (NaN -> 0).
+static inline float srgb8_to_linear(float c) { return c <= 0.04045f ? c * (1.0f / 12.92f) : powf((c + 0.055f) * (1.0f / 1.055f), 2.4f); }
+static inline f4 map_texel(const Scene::Map& m, size_t level_offset, int lw, int lh, int x, int y) {
+    x %= lw; if (x < 0) x += lw;
+    y %= lh; if (y < 0) y += lh;
+    const uint8_t* t = m.texels.data() + level_offset + (size_t(y) * lw + x) * 4;
+    f4 v{float(t[0]) * (1.0f / 255.0f), float(t[1]) * (1.0f / 255.0f), float(t[2]) * (1.0f / 255.0f), float(t[3]) * (1.0f / 255.0f)};
+    if (m.srgb) { v.x = srgb8_to_linear(v.x); v.y = srgb8_to_linear(v.y); v.z = srgb8_to_linear(v.z); }
+    return v;
+}
+static inline f4 map_bilinear(const Scene::Map& m, uint32_t level, f2 uv) {
+    size_t off = 0;
+    for (uint32_t k = 0; k < level; ++k) off += size_t(std::max(1u, m.width >> k)) * std::max(1u, m.height >> k) * 4;
+    const int lw = int(std::max(1u, m.width >> level)), lh = int(std::max(1u, m.height >> level));
+    const float fx = uv.x * float(lw) - 0.5f, fy = uv.y * float(lh) - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float tx = fx - x0f, ty = fy - y0f;
+    const int x0 = int(x0f), y0 = int(y0f);
+    const f4 s00 = map_texel(m, off, lw, lh, x0, y0), s10 = map_texel(m, off, lw, lh, x0 + 1, y0);
+    const f4 s01 = map_texel(m, off, lw, lh, x0, y0 + 1), s11 = map_texel(m, off, lw, lh, x0 + 1, y0 + 1);
+    const f4 a = s00 * (1.0f - tx) + s10 * tx, b = s01 * (1.0f - tx) + s11 * tx;
+    return a * (1.0f - ty) + b * ty;
+}
+static inline f4 sample_map(const Scene& sc, uint32_t idx, f2 uv, float lod) {
+    const Scene::Map& m = sc.maps[idx];
+    if (m.mips == 0) return m.color;
+    if (!(fabsf(uv.x) < 1e6f && fabsf(uv.y) < 1e6f)) uv = f2{0, 0};
+    lod = fminf(fmaxf(lod, 0.0f), float(m.mips - 1));
+    const float l0f = floorf(lod);
+    const uint32_t l0 = uint32_t(l0f);
+    const float f = lod - l0f;
+    const f4 c0 = map_bilinear(m, l0, uv);
+    if (f == 0.0f || l0 + 1 >= m.mips) return c0;
+    const f4 c1 = map_bilinear(m, l0 + 1, uv);
+    return c0 * (1.0f - f) + c1 * f;
+}
+// compute_texture_lod (rchit:29-44)
+static inline float texture_lod(const Scene& sc, uint32_t idx, float triangle_constant, f3 ray_direction, f3 surf_normal, float cone_width) {
+    const Scene::Map& m = sc.maps[idx];
+    const float w = m.mips ? float(m.width) : 1.0f, h = m.mips ? float(m.height) : 1.0f;
+    float lambda = triangle_constant;
+    lambda += log2f(fabsf(cone_width));
+    lambda += 0.5f * log2f(w * h);
+    lambda -= log2f(fabsf(dot(normalize(ray_direction), surf_normal)));
+    return lambda;
+}
+static inline f2 transform_material_uv(const KjMeshMaterial& mat, f2 uv, uint32_t map_idx) {   // inc/mesh.hlsl:63-68
+    const float* t = mat.map_transforms + map_idx * 6;
+    return f2{t[0] * uv.x + t[1] * uv.y + t[4], t[2] * uv.x + t[3] * uv.y + t[5]};
+}
+
 // inc/rt.hlsl:81-137 + rt/gbuffer.rchit.hlsl:46-202. Texture sampling of 1x1
 // placeholder maps returns their constant colour for every uv/LOD, so the
 // ray-cone LOD (rchit:29-44) does not influence the result for such maps.
@@ -315,7 +379,7 @@ struct GbufferPathVertex {
 };
 
 static inline GbufferPathVertex gbuffer_raytrace(const Scene& sc, const FrameConstants& fc, const Ray& ray,
-                                                 uint32_t path_length, bool cull_back_faces) {
+                                                 uint32_t path_length, bool cull_back_faces, RayCone ray_cone = RayCone{0.0f, 1.0f}) {
     GbufferPathVertex res;
     Hit h = sc.trace_closest(ray, cull_back_faces);
     if (!h.is_hit()) return res;
@@ -346,9 +410,23 @@ static inline GbufferPathVertex gbuffer_raytrace(const Scene& sc, const FrameCon
     KjMeshMaterial material;
     memcpy(&material, sc.vertex_buffer.data() + mesh.mat_data_offset + material_id * sizeof(KjMeshMaterial), sizeof(KjMeshMaterial));
 
-    const f4 albedo_texel = sc.map_colors[material.maps[2]];
+    // texture coordinates + ray-cone LOD (only evaluated when one of the three maps is an image: placeholders ignore both)
+    const bool any_image = (sc.maps[material.maps[1]].mips | sc.maps[material.maps[2]].mips | sc.maps[material.maps[3]].mips) != 0;
+    f2 uv{0, 0};
+    float lod_triangle_constant = 0;
+    f3 surf_normal_ws = mk3(0.0f);
+    const float cone_width = ray_cone.width_at_t(h.t * length(ray.d));
+    if (any_image) {
+        const f2 t0 = sc.load_f2(mesh.vertex_uv_offset + ind[0] * 8), t1 = sc.load_f2(mesh.vertex_uv_offset + ind[1] * 8), t2 = sc.load_f2(mesh.vertex_uv_offset + ind[2] * 8);
+        uv = t0 * bary.x + t1 * bary.y + t2 * bary.z;
+        const float twice_uv_area = fabsf((t1.x - t0.x) * (t2.y - t0.y) - (t2.x - t0.x) * (t1.y - t0.y));
+        const float twice_tri_area = length(cross(wt.v1 - wt.v0, wt.v2 - wt.v0));
+        lod_triangle_constant = 0.5f * log2f(twice_uv_area / twice_tri_area);
+        surf_normal_ws = normalize(xform_dir(inst.xform, surf_normal_os));
+    }
+    const f4 albedo_texel = sample_map(sc, material.maps[2], transform_material_uv(material, uv, 0), texture_lod(sc, material.maps[2], lod_triangle_constant, ray.d, surf_normal_ws, cone_width));
     f3 albedo = xyz(albedo_texel) * f3{material.base_color_mult[0], material.base_color_mult[1], material.base_color_mult[2]} * xyz(v_color);
-    const f4 metalness_roughness = sc.map_colors[material.maps[1]];
+    const f4 metalness_roughness = sample_map(sc, material.maps[1], transform_material_uv(material, uv, 2), texture_lod(sc, material.maps[1], lod_triangle_constant, ray.d, surf_normal_ws, cone_width));
     float perceptual_roughness = material.roughness_mult * metalness_roughness.x;
     float roughness = clampf(perceptual_roughness * perceptual_roughness, 1e-4f, 1.0f);
     float metalness = metalness_roughness.y * material.metalness_factor;
@@ -359,7 +437,8 @@ static inline GbufferPathVertex gbuffer_raytrace(const Scene& sc, const FrameCon
 
     f3 emissive = mk3(0.0f);
     if (0 == path_length || 0 == (material.flags & KJ_MESH_MATERIAL_FLAG_EMISSIVE_USED_AS_LIGHT)) {
-        emissive = mk3(1.0f) * xyz(sc.map_colors[material.maps[3]]) * f3{material.emissive[0], material.emissive[1], material.emissive[2]}
+        const f4 e = sample_map(sc, material.maps[3], transform_material_uv(material, uv, 3), texture_lod(sc, material.maps[3], lod_triangle_constant, ray.d, surf_normal_ws, cone_width));
+        emissive = mk3(1.0f) * xyz(e) * f3{material.emissive[0], material.emissive[1], material.emissive[2]}
             * inst.emissive_multiplier * fc.pre_exposure;
     }
     GbufferData g;

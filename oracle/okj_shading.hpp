@@ -107,6 +107,10 @@ struct RayCone {
     float width_at_t(float t) const { return width + spread_angle * t; }
 };
 
+static inline RayCone pixel_ray_cone_from_image_height(const FrameConstants& fc, float image_height) {   // frame_constants.hlsl:227-233
+    return RayCone{0.0f, pixel_cone_spread_angle_from_image_height(fc, image_height)};
+}
+
 // ------------------------------------------------------------------ brdf.hlsl
 static const float BRDF_SAMPLING_MIN_COS = 1e-5f;
 struct BrdfValue { f3 value_over_pdf{0, 0, 0}; f3 value{0, 0, 0}; float pdf = 0; f3 transmission_fraction{0, 0, 0}; };

@@ -22,6 +22,8 @@ def _frame_constants(W, H, n_frames, scene="cornell"):
     for i in range(n_frames):
         if scene == "cornell":
             cam = frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.01)
+        elif scene == "textured":
+            cam = frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=9.0, height=3.0, rate=0.01)
         else:
             cam = frame.orbit_camera(i, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.004)
         out.append(fs.prepare_frame_constants(cam))
@@ -41,7 +43,7 @@ def _random_rays(rng, n, lo, hi):
 
 def _scenes():
     from kajiya_amd import scenes
-    return {"cornell": scenes.cornell_box(), "city20k": scenes.procedural_city(target_tris=20000, seed=7, n_instances=24)}
+    return {"cornell": scenes.cornell_box(), "city20k": scenes.procedural_city(target_tris=20000, seed=7, n_instances=24), "textured": scenes.textured_test_scene()}
 
 
 @pytest.mark.parametrize("name", ["cornell", "city20k"])
@@ -181,7 +183,7 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced):
     op.L.okj_rtdgi_set_options(op.rtdgi, passes)
     op.L.okj_rtdgi_set_raytraced_visibility(op.rtdgi, int(raytraced))
     gpu.check(gp.L.kj_rtdgi_set_options(gp.rtdgi, passes, int(raytraced)))
-    fcs = _frame_constants(W, H, 8, "cornell" if scene_name == "cornell" else "city")
+    fcs = _frame_constants(W, H, 8, scene_name if scene_name in ("cornell", "textured") else "city")
     repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
     worst = {}
     for fi, fc in enumerate(fcs):
