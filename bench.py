@@ -86,10 +86,24 @@ def cpu_baseline(desc, cam_args, cores):
         a, b = op.ray_counts()
         c, d = op.ircache_ray_counts()
         rays += a + b + c + d
+    # one more frame on a single thread: the "CPU scalar reference" of SURVEY 8d (the multi-core figure above is the headline)
+    okj_py.lib().okj_set_threads(1)
+    fc = frame_constants_list(W, H, frames + 1, cam_args)[-1]
+    okj_py.lib().okj_set_threads(cores)
+    op.render_inputs(fc)
+    op.reprojection(fc)
+    okj_py.lib().okj_set_threads(1)
+    t0 = time.time()
+    op.gi_frame(fc)
+    t_1 = time.time() - t0
+    a, b = op.ray_counts()
+    c, d = op.ircache_ray_counts()
+    okj_py.lib().okj_set_threads(cores)
     return {"value": round(rays / t_gi / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"oracle ircache + rtdgi (all passes), same scene+camera, {frames} frames at {W}x{H} ({rays} rays in {t_gi:.2f} s; "
                       f"oracle BVH build {t_build:.1f} s not counted)",
-            "gi_frame_ms_at_sample_res": round(1e3 * t_gi / frames, 2)}
+            "gi_frame_ms_at_sample_res": round(1e3 * t_gi / frames, 2),
+            "scalar_1core": {"value": round((a + b + c + d) / t_1 / 1e6, 4), "unit": "Mrays/s", "gi_frame_ms": round(1e3 * t_1, 1), "sample": "1 more frame, 1 thread"}}
 
 
 def main():
