@@ -341,14 +341,29 @@ KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t
 KjStatus kj_trace_sun_shadow_mask(KjDevice* dev, KjScene* scene, const KjGbufferDepth* gbuffer_depth, void* out_mask_r8,
                                   uint64_t* ray_counter_dev, void* stream);
 
+/* ShadowDenoiseRenderer::render(rg, &GbufferDepth, shadow_mask, reprojection_map) -> ReadOnlyHandle<Image>
+ *   renderers/shadow_denoise.rs:19-148; shaders/shadow_denoise/{bitpack_shadow_mask,megakernel,spatial_filter}.hlsl over the
+ *   FidelityFX shadow denoiser (shadow_denoise/ffx/*.hlsl): bit-packed masks, temporal accumulation with moments and a
+ *   17x17 local neighbourhood clamp, three edge-stopping a-trous passes (steps 1, 2, 4).
+ * shadow_mask R8_UNORM (kj_trace_sun_shadow_mask); *out_rg16f = RG16F image owned by the handle (x = denoised shadow term,
+ * y = variance), valid until the next call. kajiya runs it only when sun_size_multiplier > 0 (world_render_passes.rs:131-136). */
+typedef struct KjShadowDenoise KjShadowDenoise;
+KjStatus kj_shadow_denoise_create(KjDevice* dev, KjShadowDenoise** out);
+void kj_shadow_denoise_destroy(KjShadowDenoise* s);
+KjStatus kj_shadow_denoise_render(KjShadowDenoise* s, const KjGbufferDepth* gbuffer_depth, const void* shadow_mask_r8, const void* reprojection_map,
+                                  const void** out_rg16f, void* stream);
+KjStatus kj_shadow_denoise_surface(KjShadowDenoise* s, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
+
 /* light_gbuffer(rg, gbuffer_depth, shadow_mask, rtr, rtdgi, ircache, wrc, temporal_output, output, sky_cube, convolved_sky_cube,
  * bindless_set, debug_shading_mode, debug_show_wrc)   renderers/deferred.rs:6-60, shaders/light_gbuffer.hlsl:60-260 — the deferred
  * combine: sun light through the shadow mask + emissive + diffuse GI * albedo * transmission (+ specular when rtr_tex is given) and
- * the sky / sun disc where depth == 0. shadow_mask R8_UNORM; rtr_tex RGBA16F or NULL (black); rtdgi_tex RGBA16F; outputs RGBA16F
+ * the sky / sun disc where depth == 0. shadow_mask = the raw R8_UNORM mask of kj_trace_sun_shadow_mask or (shadow_mask_is_rg16f) the RG16F
+ * image of kj_shadow_denoise_render; rtr_tex RGBA16F or NULL (black); rtdgi_tex RGBA16F; outputs RGBA16F
  * (`out_temporal` is the image kajiya keeps as next frame's prev_radiance). debug_shading_mode 0-4 as in the shader (5 = ircache
  * view and the wrc overlay: KJ_ERR_UNSUPPORTED). */
-KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gbuffer_depth, const void* shadow_mask_r8, const void* rtr_tex, const void* rtdgi_tex,
-                          const void* unconvolved_sky_cube, uint32_t sky_cube_width, void* out_temporal, void* out, uint32_t debug_shading_mode, void* stream);
+KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gbuffer_depth, const void* shadow_mask, uint32_t shadow_mask_is_rg16f, const void* rtr_tex,
+                          const void* rtdgi_tex, const void* unconvolved_sky_cube, uint32_t sky_cube_width, void* out_temporal, void* out,
+                          uint32_t debug_shading_mode, void* stream);
 
 /* ---------------------------------------------------------------------------
  * SSAO / SSGI guide — feeds kernel radii and edge-stopping weights of the rtdgi spatial passes, resolve

@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(64) k_trace_any(SceneView sc, const float4* __
 // Debug shading modes 0-4 as in the shader; mode 5 (ircache view) and the wrc overlay are not built.
 struct LightGbufferArgs {
     const FrameConstants* __restrict__ fc;
-    Img<uint4> gbuffer_tex; Img<float> depth_tex; Img<uint8_t> shadow_mask_tex; Img<uint2> rtr_tex; Img<uint2> rtdgi_tex;
+    Img<uint4> gbuffer_tex; Img<float> depth_tex; Img<uint8_t> shadow_mask_tex; Img<uint32_t> shadow_mask_rg16f; Img<uint2> rtr_tex; Img<uint2> rtdgi_tex;
     Img<uint2> temporal_output_tex, output_tex;
     const uint2* __restrict__ unconvolved_sky_cube; int sky_width;
     const uint2* __restrict__ brdf_fg_lut;
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(64) k_light_gbuffer(LightGbufferArgs a) {
         st4(a.output_tex, x, y, v4(output, 1.0f));
         return;
     }
-    float shadow_mask = from_unorm8(a.shadow_mask_tex.ld(x, y));
+    float shadow_mask = a.shadow_mask_rg16f.p ? ld2h(a.shadow_mask_rg16f, x, y).x : from_unorm8(a.shadow_mask_tex.ld(x, y));
     if (a.debug_shading_mode == 4u) shadow_mask = 1;
     const GbufferData true_gbuffer = gbuffer_unpack(a.gbuffer_tex.ld(x, y));
     GbufferData gbuffer = true_gbuffer;
@@ -267,17 +267,18 @@ __global__ void __launch_bounds__(64) k_sun_shadow_mask(const FrameConstants* __
 
 extern "C" {
 
-// light_gbuffer (renderers/deferred.rs:6-60; shaders/light_gbuffer.hlsl): shadow_mask R8_UNORM, rtr_tex RGBA16F or NULL (= black),
+// light_gbuffer (renderers/deferred.rs:6-60; shaders/light_gbuffer.hlsl): shadow_mask R8_UNORM (raw) or RG16F (.x, denoised), rtr_tex RGBA16F or NULL (= black),
 // rtdgi_tex RGBA16F, unconvolved_sky_cube 6 x w x w RGBA16F; outputs RGBA16F.
-KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gd, const void* shadow_mask_r8, const void* rtr_tex, const void* rtdgi_tex, const void* unconvolved_sky_cube,
-                          uint32_t sky_cube_width, void* out_temporal, void* out, uint32_t debug_shading_mode, void* stream) {
-    KJ_REQUIRE(dev && gd && gd->gbuffer && gd->depth && shadow_mask_r8 && rtdgi_tex && unconvolved_sky_cube && out_temporal && out && gd->width && gd->height, "null argument");
+KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gd, const void* shadow_mask, uint32_t shadow_mask_is_rg16f, const void* rtr_tex, const void* rtdgi_tex,
+                          const void* unconvolved_sky_cube, uint32_t sky_cube_width, void* out_temporal, void* out, uint32_t debug_shading_mode, void* stream) {
+    KJ_REQUIRE(dev && gd && gd->gbuffer && gd->depth && shadow_mask && rtdgi_tex && unconvolved_sky_cube && out_temporal && out && gd->width && gd->height, "null argument");
     KJ_REQUIRE(dev->fc_dev, "kj_frame_begin not called");
     if (debug_shading_mode > 4) { set_last_error("debug_shading_mode %u (ircache view) is not built", debug_shading_mode); return KJ_ERR_UNSUPPORTED; }
     const int W = int(gd->width), H = int(gd->height);
     LightGbufferArgs a;
     a.fc = dev->fc_dev;
-    a.gbuffer_tex = img<uint4>(gd->gbuffer, W, H); a.depth_tex = img<float>(gd->depth, W, H); a.shadow_mask_tex = img<uint8_t>(shadow_mask_r8, W, H);
+    a.gbuffer_tex = img<uint4>(gd->gbuffer, W, H); a.depth_tex = img<float>(gd->depth, W, H); a.shadow_mask_tex = img<uint8_t>(shadow_mask_is_rg16f ? nullptr : shadow_mask, W, H);
+    a.shadow_mask_rg16f = img<uint32_t>(shadow_mask_is_rg16f ? shadow_mask : nullptr, W, H);
     a.rtr_tex = img<uint2>(rtr_tex, W, H); a.rtdgi_tex = img<uint2>(rtdgi_tex, W, H);
     a.temporal_output_tex = img<uint2>(out_temporal, W, H); a.output_tex = img<uint2>(out, W, H);
     a.unconvolved_sky_cube = (const uint2*)unconvolved_sky_cube; a.sky_width = int(sky_cube_width);

@@ -27,6 +27,7 @@ EXPORTS = [
     "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
     "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_light_gbuffer",
+    "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_surface",
 ]
 
 _LIB = None
@@ -89,7 +90,10 @@ def load():
         "kj_taa_create": [vp, C.POINTER(vp)],
         "kj_taa_render": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp],
         "kj_taa_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
-        "kj_light_gbuffer": [vp, C.POINTER(KjGbufferDepth), vp, vp, vp, vp, u32, vp, vp, u32, vp],
+        "kj_light_gbuffer": [vp, C.POINTER(KjGbufferDepth), vp, u32, vp, vp, vp, u32, vp, vp, u32, vp],
+        "kj_shadow_denoise_create": [vp, C.POINTER(vp)],
+        "kj_shadow_denoise_render": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.POINTER(vp), vp],
+        "kj_shadow_denoise_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_trace_sun_shadow_mask": [vp, vp, C.POINTER(KjGbufferDepth), vp, vp, vp],
         "kj_ssgi_create": [vp, C.POINTER(vp)],
         "kj_ssgi_render": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.POINTER(vp), vp],
@@ -101,7 +105,7 @@ def load():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = i32
-    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy"):
+    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy", "kj_shadow_denoise_destroy"):
         f = getattr(L, name)
         f.argtypes = [vp]
         f.restype = None
@@ -382,15 +386,31 @@ class GpuPipeline:
         check(self.L.kj_trace_sun_shadow_mask(self.dev.h, self.scene.h, C.byref(g), out.data_ptr(), ray_counter.data_ptr() if ray_counter is not None else None, _stream_ptr()))
         return out
 
+    def shadow_denoise(self, shadow_mask):
+        """ShadowDenoiseRenderer::render (world_render_passes.rs:131-136): returns the RG16F image (H, W, 2) float16, x = shadow term."""
+        if getattr(self, "shadow_dn", None) is None:
+            self.shadow_dn = C.c_void_p()
+            check(self.L.kj_shadow_denoise_create(self.dev.h, C.byref(self.shadow_dn)))
+        g = self.gbuffer_depth()
+        out = C.c_void_p()
+        check(self.L.kj_shadow_denoise_render(self.shadow_dn, C.byref(g), shadow_mask.data_ptr(), self.reprojection_map_ptr, C.byref(out), _stream_ptr()))
+        return tensor_from_ptr(out.value, self.W * self.H * 4, self.torch.float16, (self.H, self.W, 2))
+
+    def shadow_denoise_surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        check(self.L.kj_shadow_denoise_surface(self.shadow_dn, name.encode(), C.byref(ptr), C.byref(n)))
+        return tensor_from_ptr(ptr.value, n.value, dtype, shape)
+
     def light_gbuffer(self, shadow_mask, rtdgi_ptr=None, rtr_ptr=None, debug_shading_mode=0):
-        """light_gbuffer (renderers/deferred.rs:6-60): returns (temporal_output, output) RGBA16F images."""
+        """light_gbuffer (renderers/deferred.rs:6-60): returns (temporal_output, output) RGBA16F images. `shadow_mask`: uint8 (H, W)
+        raw mask or float16 (H, W, 2) denoised image."""
         t = self.torch
         if not hasattr(self, "_lit"):
             self._lit = (t.zeros((self.H, self.W, 4), dtype=t.float16, device=self.depth.device), t.zeros((self.H, self.W, 4), dtype=t.float16, device=self.depth.device))
         g = self.gbuffer_depth()
         gi = rtdgi_ptr if rtdgi_ptr is not None else self.out.screen_irradiance_tex
-        check(self.L.kj_light_gbuffer(self.dev.h, C.byref(g), shadow_mask.data_ptr(), rtr_ptr, gi, self.sky64.data_ptr(), 64, self._lit[0].data_ptr(), self._lit[1].data_ptr(),
-                                      debug_shading_mode, _stream_ptr()))
+        check(self.L.kj_light_gbuffer(self.dev.h, C.byref(g), shadow_mask.data_ptr(), 1 if shadow_mask.dtype == t.float16 else 0, rtr_ptr, gi, self.sky64.data_ptr(), 64,
+                                      self._lit[0].data_ptr(), self._lit[1].data_ptr(), debug_shading_mode, _stream_ptr()))
         return self._lit
 
     def ssgi_frame(self):
@@ -469,6 +489,8 @@ class GpuPipeline:
             self.L.kj_taa_destroy(self.taa)
             if getattr(self, "ssgi", None):
                 self.L.kj_ssgi_destroy(self.ssgi)
+            if getattr(self, "shadow_dn", None):
+                self.L.kj_shadow_denoise_destroy(self.shadow_dn)
         except Exception:
             pass
 

@@ -6,6 +6,7 @@
 #include "okj_taa.hpp"
 #include "okj_reference_pt.hpp"
 #include "okj_ssgi.hpp"
+#include "okj_shadow_denoise.hpp"
 #include <cstdio>
 #include <chrono>
 #ifdef _OPENMP
@@ -362,6 +363,22 @@ void okj_light_gbuffer(const KjFrameConstants* fcp, const void* brdf_fg_lut, con
             if (mode == 2) o = gi;
             oout.st(x, y, pack_rgba16f(mk4(o, 1.0f)));
         }
+}
+
+// ---- shadow denoise (ShadowDenoiseRenderer): returns the RG16F image whose .x is the denoised shadow term
+void* okj_shadow_denoise_create() { ShadowDenoise::kernel_weight(0); return new ShadowDenoise(); }
+void okj_shadow_denoise_destroy(void* p) { delete (ShadowDenoise*)p; }
+const void* okj_shadow_denoise_render(void* p, const KjFrameConstants* fc, const void* shadow_mask_r8, const void* depth, const void* geometric_normal, const void* reprojection_map, uint32_t w, uint32_t h) {
+    ShadowDenoise* s = (ShadowDenoise*)p;
+    return s->render(*fc, ImgR8((void*)shadow_mask_r8, w, h), ImgR32F((void*)depth, w, h), ImgU32((void*)geometric_normal, w, h), ImgRGBA16S((void*)reprojection_map, w, h)).p;
+}
+int okj_shadow_denoise_surface(void* p, const char* name, void** out_ptr, uint64_t* out_bytes) {
+    ShadowDenoise* t = (ShadowDenoise*)p;
+    auto it = t->surf.find(name);
+    if (it == t->surf.end()) return 1;
+    *out_ptr = it->second.data();
+    *out_bytes = it->second.size();
+    return 0;
 }
 
 // ---- ssgi (SsgiRenderer): returns the R8_UNORM full-res guide

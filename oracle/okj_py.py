@@ -85,6 +85,12 @@ def lib():
         L.okj_taa_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_trace_sun_shadow_mask.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.okj_light_gbuffer.argtypes = [C.POINTER(KjFrameConstants)] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.okj_shadow_denoise_create.restype = C.c_void_p
+        L.okj_shadow_denoise_destroy.argtypes = [C.c_void_p]
+        L.okj_shadow_denoise_render.restype = C.c_void_p
+        L.okj_shadow_denoise_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.okj_shadow_denoise_surface.restype = C.c_int
+        L.okj_shadow_denoise_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_ssgi_create.restype = C.c_void_p
         L.okj_ssgi_destroy.argtypes = [C.c_void_p]
         L.okj_ssgi_render.restype = C.c_void_p
@@ -264,6 +270,22 @@ class OraclePipeline:
         self.L.okj_light_gbuffer(C.byref(fc), brdf_lut().ctypes.data, self.gbuffer.ctypes.data, self.depth.ctypes.data, np.ascontiguousarray(shadow_mask).ctypes.data,
                                  rtr.ctypes.data if rtr is not None else None, gi.ctypes.data, self.sky64.ctypes.data, 64, t.ctypes.data, o.ctypes.data, self.W, self.H, mode)
         return t, o
+
+    def shadow_denoise(self, fc, shadow_mask):
+        """ShadowDenoiseRenderer::render (world_render_passes.rs:131-136): returns the denoised shadow term as (H, W) float32."""
+        if not hasattr(self, "shadow_dn"):
+            self.shadow_dn = self.L.okj_shadow_denoise_create()
+        m = np.ascontiguousarray(shadow_mask, np.uint8)
+        ptr = self.L.okj_shadow_denoise_render(self.shadow_dn, C.byref(fc), m.ctypes.data, self.depth.ctypes.data, self.geometric_normal.ctypes.data, self.reprojection_map.ctypes.data, self.W, self.H)
+        buf = (C.c_uint16 * (self.W * self.H * 2)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.float16).reshape(self.H, self.W, 2)[..., 0].astype(np.float32)
+
+    def shadow_denoise_surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        if self.L.okj_shadow_denoise_surface(self.shadow_dn, name.encode(), C.byref(ptr), C.byref(n)) != 0:
+            raise KeyError(name)
+        buf = (C.c_uint8 * n.value).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def ssgi_frame(self, fc):
         """SsgiRenderer::render (world_render_passes.rs:90-96): computes the SSAO guide and binds it as rtdgi's ssao_tex."""

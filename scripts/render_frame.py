@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Renders N frames of the whole path in world_render_passes.rs order — G-buffer stand-in, reprojection map, ssgi, sun shadow mask,
+"""Renders N frames of the whole path in world_render_passes.rs order — G-buffer stand-in, reprojection map, ssgi, sun shadow mask + denoise,
 ircache, rtdgi, light_gbuffer, TAA on the lit image — and writes the last TAA output as a tone-mapped PNG (visual evidence)."""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -16,12 +16,12 @@ if scene_name == "cornell":
 else:
     desc, cam = scenes.procedural_city(target_tris=300_000, seed=1234), dict(center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.002)
 gp = lib.GpuPipeline(dev, lib.Scene(dev, desc), W, H, use_ircache=True)
-fs = frame.FrameState((W, H)); fs.ircache_enabled = True
+fs = frame.FrameState((W, H), sun_size_multiplier=4.0); fs.ircache_enabled = True
 for i in range(N):
     fc = fs.prepare_frame_constants(frame.orbit_camera(i, (W, H), **cam)); fs.retire_frame()
     gp.render_inputs(fc); gp.reprojection()
     gp.ssgi_frame()
-    shadow = gp.sun_shadow_mask()
+    shadow = gp.shadow_denoise(gp.sun_shadow_mask())      # world_render_passes.rs:123-136
     gp.gi_frame()
     lit_t, lit = gp.light_gbuffer(shadow)
     gp.taa_frame(input_ptr=lit.data_ptr())
