@@ -186,6 +186,35 @@ KjStatus kj_scene_commit(KjScene* scene, void* stream);
 KjStatus kj_scene_triangle_light_count(KjScene* scene, uint32_t* out);
 KjStatus kj_scene_stats(KjScene* scene, uint32_t* out_tri_count, uint32_t* out_node_count, uint64_t* out_bvh_bytes);
 
+/* Baked assets (`bin/bake` output, kajiya-asset-pipe/src/lib.rs:38-60): zero-copy, bounds-checked views of
+ * `cache/<name>.mesh` (PackedTriMesh::Flat, kajiya-asset/src/mesh.rs:796-807) and `cache/<identity:08x>.image`
+ * (GpuImage::Flat, mesh.rs:787-793) — the FlatVec layout of mesh.rs:460-632 — as WorldRenderer::add_mesh and
+ * load_gpu_image_asset read them (world_renderer.rs:297-322,604-700). Pointers alias the caller's bytes (host). The stream
+ * pointers drop straight into KjMeshDesc; `map_identities[k]` names the image file of the mesh's k-th material map. */
+typedef struct KjBakedMeshView {
+    const KjPackedVertex* verts;
+    const float* uvs;            /* NULL when the vector is empty */
+    const float* tangents;
+    const float* colors;
+    const uint32_t* indices;
+    const uint32_t* material_ids;
+    const KjMeshMaterial* materials;
+    const uint64_t* map_identities;
+    uint32_t vertex_count, index_count, material_count, map_count;
+} KjBakedMeshView;
+typedef struct KjBakedImageView {
+    uint32_t vk_format;          /* ash::vk::Format: 37/43 RGBA8 unorm/srgb, 131-134 BC1, 137/138 BC3, 139 BC4, 141 BC5, 145/146 BC7 */
+    uint32_t extent[3];
+    uint32_t mip_count;
+} KjBakedImageView;
+KjStatus kj_baked_mesh_view(const void* bytes, uint64_t size, KjBakedMeshView* out);
+KjStatus kj_baked_image_view(const void* bytes, uint64_t size, KjBakedImageView* out);
+KjStatus kj_baked_image_mip(const void* bytes, uint64_t size, uint32_t level, const uint8_t** out_data, uint64_t* out_len);
+/* Texel decode of one mip level to RGBA8 for KjMaterialMap (the reference leaves this to the texture unit): RGBA8, BC1, BC3,
+ * BC4 (r,0,0,1), BC5 (r,g,0,1). Other formats (BC7: the baker's default for albedo / emissive) return KJ_ERR_UNSUPPORTED;
+ * the Python host mirror decodes those (kajiya_amd/assets.py). */
+KjStatus kj_baked_image_decode_rgba8(uint32_t vk_format, const uint8_t* mip_data, uint64_t mip_len, uint32_t width, uint32_t height, uint8_t* out_rgba8);
+
 /* prepare_frame_constants (world_renderer.rs:1001-1108): upload this frame's UBO. */
 KjStatus kj_frame_begin(KjDevice* dev, const KjFrameConstants* fc, void* stream);
 
@@ -343,7 +372,7 @@ KjStatus kj_trace_sun_shadow_mask(KjDevice* dev, KjScene* scene, const KjGbuffer
 
 /* ShadowDenoiseRenderer::render(rg, &GbufferDepth, shadow_mask, reprojection_map) -> ReadOnlyHandle<Image>
  *   renderers/shadow_denoise.rs:19-148; shaders/shadow_denoise/{bitpack_shadow_mask,megakernel,spatial_filter}.hlsl over the
- *   FidelityFX shadow denoiser (shadow_denoise/ffx/*.hlsl): bit-packed masks, temporal accumulation with moments and a
+ *   FidelityFX shadow denoiser (the shadow_denoise/ffx shaders): bit-packed masks, temporal accumulation with moments and a
  *   17x17 local neighbourhood clamp, three edge-stopping a-trous passes (steps 1, 2, 4).
  * shadow_mask R8_UNORM (kj_trace_sun_shadow_mask); *out_rg16f = RG16F image owned by the handle (x = denoised shadow term,
  * y = variance), valid until the next call. kajiya runs it only when sun_size_multiplier > 0 (world_render_passes.rs:131-136). */

@@ -28,6 +28,7 @@ EXPORTS = [
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
     "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_light_gbuffer",
     "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_surface",
+    "kj_baked_mesh_view", "kj_baked_image_view", "kj_baked_image_mip", "kj_baked_image_decode_rgba8",
 ]
 
 _LIB = None

@@ -1,0 +1,172 @@
+"""Baked-asset reader: the FlatVec layout of kajiya-asset/src/mesh.rs:460-632 for PackedTriMesh / GpuImage,
+hand-derived offsets, truncation handling, BCn texel decode, and a baked scene that must trace exactly like the same scene
+handed over directly."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+import baked_writer as BW
+from kajiya_amd import assets as A
+from kajiya_amd import lib as klib
+from kajiya_amd import scenes as S
+
+
+def _tiny_mesh_bytes():
+    verts = np.zeros(3, dtype=[("pos", np.float32, 3), ("n", np.uint32)])
+    verts["pos"] = [[0, 0, 0], [1, 0, 0], [0, 1, 0]]
+    verts["n"] = 0x7ff003ff
+    uvs = np.array([[0, 0], [1, 0], [0, 1]], np.float32)
+    mats = np.zeros(38, np.uint32)
+    mats[4:8] = [0, 1, 2, 3]
+    return BW.write_packed_tri_mesh(verts, uvs, b"", b"", np.array([0, 1, 2], np.uint32), np.zeros(3, np.uint32), mats, np.arange(4, dtype=np.uint64) + 0xabcdef0123)
+
+
+def test_flat_layout_matches_hand_derived_offsets():
+    """Header = 8 FlatVecs (128 bytes); sections follow in field order; `offset` is relative to its own address
+    (mesh.rs:498-501,610-617). 3 verts (48 B) at 128, 3 uvs (24 B) at 176, empty tangents/colours at 200, indices at 200 ..."""
+    b = _tiny_mesh_bytes()
+    hdr = struct.unpack("<16Q", b[:128])
+    lens, offs = hdr[0::2], hdr[1::2]
+    assert lens == (3, 3, 0, 0, 3, 3, 1, 4)
+    starts = [8 + 16 * i + offs[i] for i in range(8)]
+    assert starts == [128, 176, 200, 200, 200, 212, 224, 376]
+    assert len(b) == 376 + 32
+    m = A.BakedMesh(b, lambda ident: None)
+    assert (m.vertex_count, m.triangle_count) == (3, 1)
+    assert m.map_identities == [0xabcdef0123 + i for i in range(4)]
+    np.testing.assert_array_equal(m.stream("indices"), [0, 1, 2])
+    np.testing.assert_array_equal(m.stream("uvs").reshape(3, 2), [[0, 0], [1, 0], [0, 1]])
+    assert m.stream("tangents").size == 0 and m.view.tangents is None and m.view.colors is None
+    assert m.stream("verts").reshape(3, 4)[1, 0] == np.float32(1.0).view(np.uint32)
+    assert list(m.stream("materials")[4:8]) == [0, 1, 2, 3]
+
+
+def test_truncated_and_foreign_files_are_rejected():
+    b = _tiny_mesh_bytes()
+    for cut in (0, 17, 127, 150, 300, len(b) - 1):
+        with pytest.raises(klib.KjError):
+            A.BakedMesh(b[:cut] if cut else b"\0", lambda ident: None)
+    bad = bytearray(b)
+    bad[8:16] = struct.pack("<Q", 1 << 40)          # verts offset far outside the file
+    with pytest.raises(klib.KjError):
+        A.BakedMesh(bytes(bad), lambda ident: None)
+    bad = bytearray(b)
+    bad[0:8] = struct.pack("<Q", (1 << 62))         # length overflow
+    with pytest.raises(klib.KjError):
+        A.BakedMesh(bytes(bad), lambda ident: None)
+    bad = bytearray(b)
+    bad[16:24] = struct.pack("<Q", 2)               # uv count != vertex count
+    with pytest.raises(klib.KjError):
+        A.BakedMesh(bytes(bad), lambda ident: None)
+    with pytest.raises(klib.KjError):
+        A.decode_baked_image(b"\0" * 16)
+
+
+def test_gpu_image_rgba8_mips_round_trip():
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 256, size=(8, 16, 4)).astype(np.uint8)
+    chain, n = S.build_mip_chain(img)
+    levels, off = [], 0
+    for k in range(n):
+        w, h = max(1, 16 >> k), max(1, 8 >> k)
+        levels.append(chain[off:off + w * h * 4].tobytes()); off += w * h * 4
+    blob = BW.write_gpu_image(43, (16, 8, 1), levels)
+    # hand-derived: header 32 B (format, extent, FlatVec), mip table at 32 (5 x 16 B), level 0 at 112
+    assert struct.unpack("<i3I2Q", blob[:32]) == (43, 16, 8, 1, 5, 8)
+    assert struct.unpack("<2Q", blob[32:48]) == (512, 112 - 40)
+    d = A.decode_baked_image(blob)
+    assert d["srgb"] and d["extent"] == (16, 8, 1) and len(d["levels"]) == 5
+    np.testing.assert_array_equal(d["levels"][0], img)
+    assert d["levels"][4].shape == (1, 1, 4)
+    np.testing.assert_array_equal(np.concatenate([l.reshape(-1) for l in d["levels"]]), chain)
+
+
+def _bc1_block(c0, c1, idx):
+    return struct.pack("<HHI", c0, c1, idx)
+
+
+def _bc4_block(a0, a1, idx3):
+    bits = 0
+    for i, v in enumerate(idx3):
+        bits |= v << (3 * i)
+    return bytes([a0, a1]) + bits.to_bytes(6, "little")
+
+
+def test_block_compressed_decode_known_answers():
+    # BC1, c0 > c1: palette {c0, c1, (2c0+c1)/3, (c0+2c1)/3}; 0xF800 = red, 0x001F = blue
+    idx = sum((i % 4) << (2 * i) for i in range(16))
+    blob = BW.write_gpu_image(131, (4, 4, 1), [_bc1_block(0xF800, 0x001F, idx)])
+    lv = A.decode_baked_image(blob)["levels"][0]
+    np.testing.assert_array_equal(lv[0], [[255, 0, 0, 255], [0, 0, 255, 255], [170, 0, 85, 255], [85, 0, 170, 255]])
+    # BC1 punch-through (c0 <= c1) in an RGBA format: index 3 = transparent black, index 2 = midpoint
+    blob = BW.write_gpu_image(133, (4, 4, 1), [_bc1_block(0x001F, 0xF800, idx)])
+    lv = A.decode_baked_image(blob)["levels"][0]
+    np.testing.assert_array_equal(lv[0], [[0, 0, 255, 255], [255, 0, 0, 255], [127, 0, 127, 255], [0, 0, 0, 0]])
+    # BC5: two BC4 channels; 8-value mode (a0 > a1) and 6-value mode with explicit 0 / 255
+    r = _bc4_block(255, 0, [0, 1, 2, 3, 4, 5, 6, 7] * 2)
+    g = _bc4_block(10, 110, [0, 1, 2, 3, 4, 5, 6, 7] * 2)
+    blob = BW.write_gpu_image(141, (4, 4, 1), [r + g])
+    lv = A.decode_baked_image(blob)["levels"][0]
+    np.testing.assert_array_equal(lv[0, :, 0], [255, 0, 218, 182])
+    np.testing.assert_array_equal(lv[1, :, 0], [145, 109, 72, 36])
+    np.testing.assert_array_equal(lv[0, :, 1], [10, 110, 30, 50])
+    np.testing.assert_array_equal(lv[1, :, 1], [70, 90, 0, 255])
+    assert (lv[..., 2] == 0).all() and (lv[..., 3] == 255).all()
+    # BC3 = BC4 alpha + BC1 colour (always 4-colour mode)
+    blob = BW.write_gpu_image(137, (4, 4, 1), [_bc4_block(200, 100, [0] * 8 + [1] * 8) + _bc1_block(0x001F, 0xF800, idx)])
+    lv = A.decode_baked_image(blob)["levels"][0]
+    np.testing.assert_array_equal(lv[0, 2], [85, 0, 170, 200])
+    np.testing.assert_array_equal(lv[3, 3], [170, 0, 85, 100])
+    # a 2x2 tail level stored as one padded block is cropped to the logical extent (image.rs:226-246)
+    blob = BW.write_gpu_image(131, (8, 8, 1), [_bc1_block(0xF800, 0x001F, 0) * 4, _bc1_block(0xF800, 0x001F, idx), _bc1_block(0x001F, 0xF800, 0), _bc1_block(0xF800, 0, 0)])
+    d = A.decode_baked_image(blob)
+    assert [l.shape for l in d["levels"]] == [(8, 8, 4), (4, 4, 4), (2, 2, 4), (1, 1, 4)]
+    np.testing.assert_array_equal(d["levels"][2][1, 1], [0, 0, 255, 255])
+
+
+def test_bc7_mode6_known_answer():
+    """BC7 mode 6 (one subset, 7-bit RGBA endpoints + p-bit, 4-bit indices): all indices 0 -> endpoint 0 = (e << 1 | p)."""
+    pytest.importorskip("PIL")
+    bits, pos = 0, 0
+
+    def put(v, n):
+        nonlocal bits, pos
+        bits |= (v & ((1 << n) - 1)) << pos
+        pos += n
+    put(1 << 6, 7)                                  # mode 6
+    for e0, e1 in ((0x7f, 0), (0x20, 0), (0x00, 0), (0x7f, 0)):   # R, G, B, A endpoint pairs
+        put(e0, 7); put(e1, 7)
+    put(1, 1); put(0, 1)                            # p-bits
+    block = bits.to_bytes(16, "little")             # indices: zero
+    blob = BW.write_gpu_image(146, (4, 4, 1), [block])
+    d = A.decode_baked_image(blob)
+    assert d["srgb"]
+    np.testing.assert_array_equal(d["levels"][0][2, 3], [255, 0x41, 0x01, 255])
+
+
+def test_baked_scene_traces_like_the_direct_scene(oracle, tmp_path):
+    """bake -> files -> load_baked_mesh -> add_mesh gives the same G-buffer hits (material maps, mips, uv transforms,
+    placeholders) as handing the TriangleMesh over directly; checked on the CPU oracle (the GPU twin is in test_gpu_textures)."""
+    okj_py = oracle
+    sd = S.textured_test_scene()
+    baked = S.SceneDesc()
+    for mi, m in enumerate(sd.meshes):
+        mesh_bytes, images = BW.bake_triangle_mesh(m)
+        (tmp_path / f"m{mi}.mesh").write_bytes(mesh_bytes)
+        for ident, blob in images.items():
+            (tmp_path / f"{ident:8x}.image").write_bytes(blob)
+        bm = A.load_baked_mesh(str(tmp_path / f"m{mi}.mesh"))
+        assert bm.triangle_count == m.triangle_count
+        baked.add_mesh(bm)
+    for mi, xf in sd.instances:
+        baked.add_instance(mi, xf)
+    import test_gpu_parity as T
+    W, H = 160, 96
+    fc = T._frame_constants(W, H, 1, "textured")[0]
+    pa, pb = (okj_py.OraclePipeline(okj_py.OracleScene(d), W, H) for d in (sd, baked))
+    pa.render_inputs(fc); pb.render_inputs(fc)
+    assert (pa.depth > 0).mean() > 0.5
+    for name in ("gbuffer", "geometric_normal", "depth", "velocity"):
+        np.testing.assert_array_equal(getattr(pa, name), getattr(pb, name), err_msg=name)

@@ -75,3 +75,32 @@ def test_image_map_validation(gpu, device):
     out = C.c_uint32()
     assert gpu.load().kj_scene_add_mesh(sc.h, C.byref(d), C.byref(out)) != 0
     assert b"mip_count" in gpu.load().kj_last_error()
+
+
+def test_baked_scene_matches_direct_scene_on_gpu(gpu, device, tmp_path):
+    """Baked-asset reader (tests/test_baked_assets.py holds the format tests): the textured scene written as
+    `.mesh` / `.image` files, loaded with load_baked_mesh and added through kj_scene_add_mesh, gives a bit-identical G-buffer."""
+    import torch
+    import baked_writer as BW
+    from kajiya_amd import assets as A, scenes as S
+    sd = S.textured_test_scene()
+    baked = S.SceneDesc()
+    for mi, m in enumerate(sd.meshes):
+        mesh_bytes, images = BW.bake_triangle_mesh(m)
+        (tmp_path / f"m{mi}.mesh").write_bytes(mesh_bytes)
+        for ident, blob in images.items():
+            (tmp_path / f"{ident:8x}.image").write_bytes(blob)
+        baked.add_mesh(A.load_baked_mesh(str(tmp_path / f"m{mi}.mesh")))
+    for mi, xf in sd.instances:
+        baked.add_instance(mi, xf)
+    W, H = 320, 200
+    fc = T._frame_constants(W, H, 1, "textured")[0]
+    outs = []
+    for d in (sd, baked):
+        gp = gpu.GpuPipeline(device, gpu.Scene(device, d), W, H)
+        gp.render_inputs(fc)
+        torch.cuda.synchronize()
+        outs.append((gp.gbuffer.cpu().numpy().copy(), gp.depth.cpu().numpy().copy(), gp.geometric_normal.cpu().numpy().copy()))
+    assert (outs[0][1] > 0).mean() > 0.5
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
