@@ -427,6 +427,58 @@ KjStatus kj_reference_path_trace(KjDevice* dev, const KjScene* scene, void* outp
                                  uint32_t first_bounce_mode, uint32_t interleave_count, uint32_t interleave_index,
                                  uint64_t* ray_counter_dev, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Ray-traced specular reflections
+ *   RtrRenderer::trace(rg, &GbufferDepth, reprojection_map, sky_cube, bindless_set, tlas, rtdgi_irradiance, RtdgiCandidates,
+ *                      &mut IrcacheRenderState, &WrcRenderState) -> TracedRtr                 renderers/rtr.rs:97-400
+ *   TracedRtr::filter_temporal(rg, &GbufferDepth, reprojection_map) -> Handle<Image>          renderers/rtr.rs:440-480
+ *   shaders/rtr/{reflection.rgen, reflection_trace_common.inc, reflection_validate.rgen, rtr_restir_temporal, resolve,
+ *   temporal_filter, spatial_cleanup}.hlsl with rtr_settings.hlsl as checked in.
+ * The caller owns the data tables the reference uploads in RtrRenderer::new: the three `blue-noise-sampler` (crate 0.1.0,
+ * spp64) tables RANKING_TILE / SCRAMBLING_TILE (128*128*8 u32 each) and SOBOL (256*256 u32), and rtr.rs's
+ * SPATIAL_RESOLVE_OFFSETS (16*4*8 int4). Host pointers, copied at create.
+ * kj_rtr_trace OVERWRITES the rtdgi candidate images where the surface is smooth (roughness <= 0.6, `reuse_rtdgi_rays`),
+ * exactly as the reference aliases them (rtr.rs:112-116). Temporal state ("rtr.temporal", "rtr.ray_len", "rtr.irradiance",
+ * "rtr.ray_orig", "rtr.ray", "rtr.reservoir", "rtr.rng", "rtr.hit_normal", each ":0"/":1") lives in the handle.
+ * The world radiance cache (USE_WORLD_RADIANCE_CACHE 0 in the shader) and LightingRenderer::render_specular are not included.
+ * Output of kj_rtr_filter_temporal: the B10G11R11_UFLOAT full-res image light_gbuffer consumes.
+ * --------------------------------------------------------------------------- */
+typedef struct KjRtr KjRtr;
+typedef struct KjRtrTables {
+    const uint32_t* ranking_tile;
+    const uint32_t* scrambling_tile;
+    const uint32_t* sobol;
+    const int32_t* spatial_resolve_offsets;
+} KjRtrTables;
+typedef struct KjRtrParams {
+    KjGbufferDepth gbuffer_depth;
+    const void* reprojection_map;     /* RGBA16_SNORM full res */
+    const void* sky_cube;             /* UNconvolved 6 x w x w RGBA16F (world_render_passes.rs:178) */
+    uint32_t sky_cube_width;
+    KjScene* scene;
+    KjIrcache* ircache;               /* NULL => lookups return 0 */
+    const void* rtdgi_irradiance;     /* RtdgiOutput::screen_irradiance_tex, RGBA16F full res */
+    void* candidate_radiance_tex;     /* RtdgiCandidates (KjRtdgiOutput): RGBA16F, RGBA16F, RGBA8_SNORM half res; read + written */
+    void* candidate_hit_tex;
+    void* candidate_normal_tex;
+    uint32_t pass_mask;               /* KJ_RTR_PASS_ALL for the product path */
+} KjRtrParams;
+#define KJ_RTR_PASS_TRACE 1u
+#define KJ_RTR_PASS_VALIDATE 2u
+#define KJ_RTR_PASS_RESTIR_TEMPORAL 4u
+#define KJ_RTR_PASS_RESOLVE 8u
+#define KJ_RTR_PASS_TEMPORAL_FILTER 16u
+#define KJ_RTR_PASS_CLEANUP 32u
+#define KJ_RTR_PASS_ALL 63u
+#define KJ_RTR_PASS_KEEP 0x80000000u  /* tests: do not advance the ping-pong state (run one pass of an already started frame) */
+KjStatus kj_rtr_create(KjDevice* dev, const KjRtrTables* tables, KjRtr** out);
+void kj_rtr_destroy(KjRtr* r);
+KjStatus kj_rtr_set_options(KjRtr* r, uint32_t reuse_rtdgi_rays);
+KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* params, void* stream);
+KjStatus kj_rtr_filter_temporal(KjRtr* r, const KjRtrParams* params, const void** out_resolved_r11g11b10f, void* stream);
+KjStatus kj_rtr_surface(KjRtr* r, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
+KjStatus kj_rtr_ray_counts(KjRtr* r, uint64_t* out_closest, uint64_t* out_any);
+
 #ifdef __cplusplus
 }
 #endif

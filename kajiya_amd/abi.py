@@ -94,3 +94,24 @@ KJ_RTDGI_PASS = dict(
 
 class KjTaaOutput(C.Structure):
     _fields_ = [("temporal_out", C.c_void_p), ("this_frame_out", C.c_void_p)]
+
+
+class KjRtrTables(C.Structure):
+    _fields_ = [("ranking_tile", C.c_void_p), ("scrambling_tile", C.c_void_p), ("sobol", C.c_void_p), ("spatial_resolve_offsets", C.c_void_p)]
+
+
+class KjRtrParams(C.Structure):
+    _fields_ = [
+        ("gbuffer_depth", KjGbufferDepth),
+        ("reprojection_map", C.c_void_p),
+        ("sky_cube", C.c_void_p), ("sky_cube_width", c_u32),
+        ("scene", C.c_void_p),
+        ("ircache", C.c_void_p),
+        ("rtdgi_irradiance", C.c_void_p),
+        ("candidate_radiance_tex", C.c_void_p), ("candidate_hit_tex", C.c_void_p), ("candidate_normal_tex", C.c_void_p),
+        ("pass_mask", c_u32),
+    ]
+
+
+KJ_RTR_PASS = {"TRACE": 1, "VALIDATE": 2, "RESTIR_TEMPORAL": 4, "RESOLVE": 8, "TEMPORAL_FILTER": 16, "CLEANUP": 32, "ALL": 63, "KEEP": 0x80000000}
+

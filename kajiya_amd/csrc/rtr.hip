@@ -1,0 +1,994 @@
+// RtrRenderer for gfx950: ray-traced specular reflections. One HIP kernel per reference pass
+// (renderers/rtr.rs:97-480; shaders/rtr/{reflection.rgen, reflection_trace_common.inc, reflection_validate.rgen,
+// rtr_restir_temporal, resolve, temporal_filter, spatial_cleanup}.hlsl with rtr_settings.hlsl as checked in), 8x8 pixel tile =
+// one wave64, the software BVH of kj_bvh.hpp instead of TraceRay. Host orchestration mirrors RtrRenderer::trace and
+// TracedRtr::filter_temporal including the eight ping-pong temporal resources.
+//
+// Where the reference leaves a result undefined this file picks the same value as the oracle (oracle/okj_rtr.hpp header):
+// the validate pass' partially written invalidity image is cleared first, a zero-length history ray is traced along +Z,
+// B10G11R11_UFLOAT stores round to nearest through fp16.
+#include "kj_host.hpp"
+#include "kj_scene.hpp"
+#include "kj_reservoir.hpp"
+#include "kj_ircache.hpp"
+#include "kj_ircache_host.hpp"
+
+using namespace kj;
+namespace kj { SceneView scene_view(const KjScene& s); }
+
+#define SKY_DIST 1e4f
+#define RTR_ROUGHNESS_CLAMP 6e-4f
+#define RTR_RESTIR_MAX_PDF_CLAMP 200.0f
+#define RTR_RESTIR_TEMPORAL_M_CLAMP 8.0f
+#define RTR_NEIGHBOR_RAY_ORIGIN_CENTER_BIAS 0.5f
+#define RTR_SAMPLING_BIAS 0.15f
+
+typedef Img<uint2> ImgH4;     // RGBA16F
+typedef Img<uint32_t> ImgU32; // RGBA8_SNORM / RG16F / A2R10G10B10 / B10G11R11_UFLOAT / R32_UINT
+typedef Img<float> ImgF32;
+typedef Img<uint4> ImgU4;
+typedef Img<uint2> ImgU2;     // RG32UI (reservoirs) and RGBA16_SNORM share the 8-byte texel
+typedef Img<uint8_t> ImgR8;
+typedef Img<float4> ImgF4;
+
+#define TILE_XY(W_, H_)                                                   \
+    const int lane = threadIdx.x;                                         \
+    const int x = int(blockIdx.x) * 8 + (lane & 7), y = int(blockIdx.y) * 8 + (lane >> 3); \
+    const bool in_image = x < (W_) && y < (H_);
+
+// ------------------------------------------------------------------ small device helpers
+KJ_D uint32_t f32_to_ufloat(float v, int mant_bits) {              // see okj::f32_to_ufloat
+    if (!(v > 0.0f)) return 0u;
+    const uint32_t h = uint32_t(f32_to_f16(v)) & 0x7fffu;
+    const int drop = 10 - mant_bits;
+    const uint32_t r = (h + (1u << (drop - 1))) >> drop;
+    const uint32_t max_finite = (30u << mant_bits) | ((1u << mant_bits) - 1u);
+    if (h >= 0x7c00u) return 31u << mant_bits;
+    return r > max_finite ? max_finite : r;
+}
+KJ_D float ufloat_to_f32(uint32_t v, int mant_bits) { return f16_to_f32(uint16_t(v << (10 - mant_bits))); }
+KJ_D uint32_t pack_r11g11b10f(V3 c) { return f32_to_ufloat(c.x, 6) | (f32_to_ufloat(c.y, 6) << 11) | (f32_to_ufloat(c.z, 5) << 22); }
+KJ_D V3 unpack_r11g11b10f(uint32_t p) { return V3{ufloat_to_f32(p & 0x7ffu, 6), ufloat_to_f32((p >> 11) & 0x7ffu, 6), ufloat_to_f32(p >> 22, 5)}; }
+
+KJ_D V3 get_prev_eye_position(const FrameConstants& fc) { const V4 e = mul44(fc.view_constants.prev_view_to_prev_world, V4{0, 0, 0, 1}); return xyz(e) / e.w; }
+KJ_D V3 position_world_to_view(const FrameConstants& fc, V3 v) { return xyz(mul44(fc.view_constants.world_to_view, v4(v, 1))); }
+KJ_D float depth_to_view_z(const FrameConstants& fc, float depth) { return 1.0f / (depth * -fc.view_constants.clip_to_view[11]); }
+KJ_D I2 hi_px_subpixel(uint32_t k) { return halfres_subsample_offset(k); }   // hi_px_subpixels[k & 3]
+KJ_D float ggx_ndf_0_1(float a2, float cos_theta) { const float d = cos_theta * cos_theta * (a2 - 1.0f) + 1.0f; return a2 * a2 / (d * d); }
+KJ_D float exponential_squish(float len, float s) { return exp2f(-clampf(s * len, 0.0f, 100.0f)); }
+KJ_D float exponential_unsquish(float len, float s) { return fmaxf(0.0f, -1.0f / s * log2f(1e-30f + len)); }
+KJ_D V3 soft_color_clamp(V3 center, V3 history, V3 ex, V3 dev) {
+    const V3 history_dist = vabs(history - ex) / vmax(vabs(history * 0.1f), dev);
+    const V3 closest_pt = vclamp(history, center - dev, center + dev);
+    return V3{lerp(history.x, closest_pt.x, smoothstep(1.0f, 3.0f, history_dist.x)), lerp(history.y, closest_pt.y, smoothstep(1.0f, 3.0f, history_dist.y)),
+              lerp(history.z, closest_pt.z, smoothstep(1.0f, 3.0f, history_dist.z))};
+}
+// rtr_restir_pack_unpack.inc.hlsl
+struct RtrRestirRayOrigin { V3 ray_origin_eye_offset_ws; float roughness; uint32_t frame_index_mod4; };
+KJ_D RtrRestirRayOrigin ray_origin_from_raw(float4 raw) {
+    const V2 misc = unpack_2x16f_uint(asuint(raw.w));
+    return RtrRestirRayOrigin{V3{raw.x, raw.y, raw.z}, misc.x, uint32_t(misc.y) & 3u};
+}
+KJ_D float4 ray_origin_to_raw(V3 o, float roughness, uint32_t frame_index_mod4) { return make_float4(o.x, o.y, o.z, asfloat(pack_2x16f_uint(roughness, float(frame_index_mod4)))); }
+
+struct FgLut { V3 preintegrated_reflection, preintegrated_reflection_mult; float valid_sample_fraction; };
+KJ_D FgLut specular_energy_preservation(const uint2* __restrict__ fg_lut, float roughness, V3 specular_albedo, float ndotv) {   // brdf_lut.hlsl:15-93
+    const float s = 63.0f / 64.0f, b = 0.5f / 64.0f;
+    const V4 fg = sample_bilinear_clamp_rgba16f(fg_lut, 64, 64, V2{ndotv * s + b, roughness * s + b});
+    const V3 single_scatter = specular_albedo * fg.x + fg.y;
+    const float e_ss = fg.x + fg.y;
+    const V3 f_ss = single_scatter / e_ss;
+    const V3 f_ss_tail = lerp(f_ss, v3(1.0f), 0.4f);
+    const V3 bounce_radiance = (1.0f - e_ss) * f_ss_tail;
+    const V3 mult = 1.0f + bounce_radiance / (1.0f - bounce_radiance);
+    return FgLut{single_scatter * mult, mult, fg.z};
+}
+
+struct RtrCtx {
+    const FrameConstants* __restrict__ fc;
+    SceneView sc;
+    ImgF32 depth; ImgU4 gbuffer;   // full res
+    ImgH4 rtdgi_tex;               // full res
+    const uint2* __restrict__ sky_cube; int sky_cube_width;
+    const uint2* __restrict__ brdf_fg_lut;
+    const float4* __restrict__ sun_color;
+    IrcacheView irc; bool has_ircache;
+    unsigned long long* __restrict__ ray_counters;
+    const uint32_t* __restrict__ ranking_tile; const uint32_t* __restrict__ scrambling_tile; const uint32_t* __restrict__ sobol;
+    uint32_t reuse_rtdgi_rays;
+};
+
+KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
+    const unsigned long long m = __ballot(active);
+    if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
+}
+KJ_D float blue_noise_sampler(const RtrCtx& c, int pixel_i, int pixel_j, int sample_index, int sample_dimension) {   // inc/blue_noise.hlsl:31-60
+    pixel_i &= 127; pixel_j &= 127; sample_index &= 255; sample_dimension &= 255;
+    const int ranked = sample_index ^ int(c.ranking_tile[sample_dimension + (pixel_i + pixel_j * 128) * 8]);
+    int value = int(c.sobol[sample_dimension + ranked * 256]);
+    value ^= int(c.scrambling_tile[(sample_dimension % 8) + (pixel_i + pixel_j * 128) * 8]);
+    return (0.5f + float(value)) / 256.0f;
+}
+
+// ------------------------------------------------------------------ GbufferDepth::half_view_normal / half_depth (renderers/mod.rs:44-71)
+__global__ void __launch_bounds__(64) k_rtr_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgU32 half_view_normal, ImgF32 half_depth) {
+    TILE_XY(half_depth.w, half_depth.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int sx = x * 2 + off.x, sy = y * 2 + off.y;
+    const V3 normal_ws = unpack_normal_11_10_11_no_normalize(gbuffer.ld(sx, sy).y);
+    const V3 normal_vs = normalize(xyz(mul44(fc.view_constants.world_to_view, v4(normal_ws, 0))));
+    half_view_normal.st(x, y, pack_rgba8_snorm(v4(normal_vs, 1.0f)));
+    half_depth.st(x, y, depth.ld(sx, sy));
+}
+
+// ------------------------------------------------------------------ reflection_trace_common.inc.hlsl:56-257
+struct RtrTraceResult { V3 total_radiance; float hit_t; V3 hit_normal_vs; };
+KJ_D RtrTraceResult rtr_trace_ray(const RtrCtx& c, float roughness, uint32_t& rng, V3 ray_o, V3 ray_d, uint32_t* stack) {
+    const FrameConstants& fc = *c.fc;
+    const float roughness_bias = roughness;
+    const float reflected_cone_spread_angle = sqrtf(roughness) * 0.05f;
+    const RayCone ray_cone = pixel_ray_cone_from_image_height(fc, float(c.depth.h)).propagate(reflected_cone_spread_angle, length(ray_o - get_eye_position(fc)));
+    count_rays(c.ray_counters, 0, true);
+    const GbufferPathVertex primary_hit = gbuffer_raytrace<false>(c.sc, fc, ray_o, ray_d, 0.0f, SKY_DIST, 1, false, stack, 64, nullptr, ray_cone);
+    if (primary_hit.is_hit) {
+        GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);
+        gbuffer.roughness = lerp(gbuffer.roughness, 1.0f, roughness_bias);
+        const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
+        const V3 wo = to_local(tangent_to_world, -ray_d);
+        const LayeredBrdf brdf = layered_brdf_from_gbuffer_ndotv(c.brdf_fg_lut, gbuffer, wo.z);
+        const V4 gts = tex_size4(c.depth.w, c.depth.h);
+        const V3 hit_cs = position_world_to_sample(fc, primary_hit.position);
+        const V2 hit_uv = cs_to_uv(V2{hit_cs.x, hit_cs.y});
+        const float screen_depth = sample_nearest_clamp(c.depth, hit_uv);
+        const uint4 screen_gbuffer = c.gbuffer.ld(int(hit_uv.x * gts.x), int(hit_uv.y * gts.y));
+        const V3 screen_normal_ws = unpack_normal_11_10_11(screen_gbuffer.y);
+        const bool is_on_screen = fabsf(hit_cs.x) < 1.0f && fabsf(hit_cs.y) < 1.0f && inverse_depth_relative_diff(hit_cs.z, screen_depth) < 5e-3f &&
+                                  dot(screen_normal_ws, -ray_d) > 0.0f && dot(screen_normal_ws, gbuffer.normal) > 0.7f;
+        V3 total_radiance = v3(0.0f);
+        {
+            V2 urand;
+            urand.x = uint_to_u01_float(hash1_mut(rng));
+            urand.y = uint_to_u01_float(hash1_mut(rng));
+            const float4 sc4 = *c.sun_color;
+            const V3 sun_radiance{sc4.x, sc4.y, sc4.z};
+            if (sun_radiance.x != 0 || sun_radiance.y != 0 || sun_radiance.z != 0) {
+                const V3 to_light_norm = sample_sun_direction(fc, urand, true);
+                count_rays(c.ray_counters, 1, true);
+                const bool is_shadowed = rt_is_shadowed<false>(c.sc, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, 64, nullptr);
+                const V3 wi = to_local(tangent_to_world, to_light_norm);
+                const V3 brdf_value = layered_brdf_evaluate(brdf, wo, wi) * fmaxf(0.0f, wi.z);
+                total_radiance += brdf_value * (is_shadowed ? v3(0.0f) : sun_radiance);
+            }
+        }
+        const V3 reflected_normal_vs = direction_world_to_view(fc, gbuffer.normal);
+        total_radiance += gbuffer.emissive;
+        if (is_on_screen) {
+            const V3 reprojected_radiance = xyz(unpack_rgba16f(sample_nearest_clamp(c.rtdgi_tex, hit_uv))) * fc.pre_exposure_delta;
+            total_radiance += reprojected_radiance * gbuffer.albedo;
+        } else {
+            V2 urand;
+            urand.x = uint_to_u01_float(hash1_mut(rng));
+            urand.y = uint_to_u01_float(hash1_mut(rng));
+            const uint32_t nl = min(fc.triangle_light_count, c.sc.light_count);
+            for (uint32_t li = 0; li < nl; ++li) {
+                const KjTriangleLight tl = c.sc.lights[li];
+                const V3 v0{tl.verts[0], tl.verts[1], tl.verts[2]}, v1{tl.verts[3], tl.verts[4], tl.verts[5]}, v2{tl.verts[6], tl.verts[7], tl.verts[8]};
+                const LightSampleArea ls = sample_triangle_light(v0, v1 - v0, v2 - v0, urand);
+                const V3 to_light_ws = ls.pos - primary_hit.position;
+                const float dist2 = dot(to_light_ws, to_light_ws);
+                const V3 to_light_norm_ws = to_light_ws * (1.0f / sqrtf(dist2));
+                const float to_psa_metric = fmaxf(0.0f, dot(to_light_norm_ws, gbuffer.normal)) * fmaxf(0.0f, dot(to_light_norm_ws, -ls.normal)) / dist2;
+                if (to_psa_metric > 0.0f) {
+                    count_rays(c.ray_counters, 1, true);
+                    const bool is_shadowed = rt_is_shadowed<false>(c.sc, primary_hit.position, to_light_norm_ws, 1e-4f, sqrtf(dist2) - 2e-4f, stack, 64, nullptr);
+                    const V3 bounce_albedo = lerp(gbuffer.albedo, v3(1.0f), 0.04f);
+                    const V3 brdf_value = bounce_albedo * to_psa_metric / KJ_PI;
+                    if (!is_shadowed) total_radiance += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * brdf_value / ls.pdf;
+                }
+            }
+            if (c.has_ircache) {
+                const float cone_width = ray_cone.propagate(0.0f, primary_hit.ray_t).width;
+                const V3 gi = ircache_lookup<false>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng, cone_width < 0.1f);
+                total_radiance += gi * gbuffer.albedo;
+            }
+        }
+        return RtrTraceResult{total_radiance, primary_hit.ray_t, reflected_normal_vs};
+    }
+    const V3 far_gi = xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
+    return RtrTraceResult{far_gi, SKY_DIST, -direction_world_to_view(fc, ray_d)};
+}
+
+// ------------------------------------------------------------------ reflection.rgen.hlsl:45-169
+__global__ void __launch_bounds__(64) k_rtr_trace(RtrCtx c, ImgH4 out0_tex, ImgH4 out1_tex, ImgU32 out2_tex, ImgU32 rng_out_tex) {
+    extern __shared__ uint32_t lds_stack[];
+    TILE_XY(out0_tex.w, out0_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+    const float depth = c.depth.ld(hx, hy);
+    if (0.0f == depth) { st4(out0_tex, x, y, V4{0.0f, 0.0f, 0.0f, -SKY_DIST}); return; }
+    const V4 gts = tex_size4(c.depth.w, c.depth.h);
+    const V2 uv = get_uv(float(hx), float(hy), gts);
+    GbufferData gbuffer = gbuffer_unpack(c.gbuffer.ld(hx, hy));
+    gbuffer.roughness = fmaxf(gbuffer.roughness, RTR_ROUGHNESS_CLAMP);
+    if (c.reuse_rtdgi_rays && gbuffer.roughness > 0.6f) return;
+    const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
+    const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
+    const V3 refl_ray_origin_ws = vr.biased_secondary_ray_origin_ws_with_normal(gbuffer.normal);
+    V3 wo = to_local(tangent_to_world, -vr.dir_ws);
+    if (wo.z < 0.0f) { wo.z *= -0.25f; wo = normalize(wo); }
+    const V3 spec_albedo = lerp(v3(0.04f), gbuffer.albedo, gbuffer.metalness);
+    const uint32_t noise_offset = fc.frame_index;
+    uint32_t rng = hash3(uint32_t(x), uint32_t(y), noise_offset);
+    V2 urand{blue_noise_sampler(c, x, y, int(noise_offset), 0), blue_noise_sampler(c, x, y, int(noise_offset), 1)};
+    urand.x = lerp(urand.x, 0.0f, RTR_SAMPLING_BIAS);
+    BrdfSample brdf_sample = specular_sample(gbuffer.roughness, spec_albedo, wo, urand);
+    for (uint32_t retry_i = 0; retry_i < 4u && !(brdf_sample.wi.z > 1e-6f); ++retry_i) {
+        urand.x = uint_to_u01_float(hash1_mut(rng));
+        urand.y = uint_to_u01_float(hash1_mut(rng));
+        urand.x = lerp(urand.x, 0.0f, RTR_SAMPLING_BIAS);
+        brdf_sample = specular_sample(gbuffer.roughness, spec_albedo, wo, urand);
+    }
+    if (brdf_sample.wi.z > 1e-6f) {
+        const float cos_theta = normalize(wo + brdf_sample.wi).z;
+        const V3 ray_d = to_world(tangent_to_world, brdf_sample.wi);
+        rng_out_tex.st(x, y, rng);
+        const RtrTraceResult result = rtr_trace_ray(c, gbuffer.roughness, rng, refl_ray_origin_ws, ray_d, lds_stack + lane);
+        const V3 hit_offset_ws = ray_d * result.hit_t;
+        const FgLut brdf_lut = specular_energy_preservation(c.brdf_fg_lut, gbuffer.roughness, spec_albedo, wo.z);
+        const float pdf = brdf_sample.pdf / brdf_lut.valid_sample_fraction;
+        st4(out0_tex, x, y, v4(result.total_radiance, 1.0f - cos_theta));
+        st4(out1_tex, x, y, v4(hit_offset_ws, pdf));
+        out2_tex.st(x, y, pack_rgba8_snorm(v4(result.hit_normal_vs, 0.0f)));
+    } else {
+        st4(out0_tex, x, y, V4{1.0f, 0.0f, 1.0f, 0.0f});
+        st4(out1_tex, x, y, v4(0.0f));
+    }
+}
+
+// ------------------------------------------------------------------ reflection_validate.rgen.hlsl:42-146 (one thread per 2x2 half-res quad)
+__global__ void __launch_bounds__(64) k_rtr_validate(RtrCtx c, ImgF4 ray_orig_history_tex, ImgH4 ray_history_tex, ImgU32 rng_history_tex, ImgH4 irradiance_history_tex,
+                                                      ImgU2 reservoir_history_tex, ImgR8 refl_restir_invalidity_tex, int qw, int qh) {
+    extern __shared__ uint32_t lds_stack[];
+    const int lane = threadIdx.x;
+    const int qx = int(blockIdx.x) * 8 + (lane & 7), qy = int(blockIdx.y) * 8 + (lane >> 3);
+    if (qx >= qw || qy >= qh) return;
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int x = qx * 2 + off.x, y = qy * 2 + off.y;
+    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+    const float depth = c.depth.ld(hx, hy);
+    if (0.0f == depth) { refl_restir_invalidity_tex.st(x, y, to_unorm8(1.0f)); return; }
+    GbufferData gbuffer = gbuffer_unpack(c.gbuffer.ld(hx, hy));
+    gbuffer.roughness = fmaxf(gbuffer.roughness, RTR_ROUGHNESS_CLAMP);
+    const float4 ro = ray_orig_history_tex.ld(x, y);
+    const V3 ray_orig_ws = V3{ro.x, ro.y, ro.z} + get_prev_eye_position(fc);
+    const V3 ray_hit_ws = xyz(ld4(ray_history_tex, x, y)) + ray_orig_ws;
+    const V3 d = ray_hit_ws - ray_orig_ws;
+    const float dl = length(d);
+    const V3 ray_d = dl > 0.0f ? d / dl : V3{0, 0, 1};
+    uint32_t rng = rng_history_tex.ld(x, y);
+    const RtrTraceResult result = rtr_trace_ray(c, gbuffer.roughness, rng, ray_orig_ws, ray_d, lds_stack + lane);
+    Reservoir1spp r = Reservoir1spp::from_raw(reservoir_history_tex.ld(x, y));
+    const V4 prev_irradiance_packed = ld4(irradiance_history_tex, x, y);
+    const V3 prev_irradiance = vmax(v3(0.0f), xyz(prev_irradiance_packed) * fc.pre_exposure_delta);
+    const V3 check_radiance = vmax(v3(0.0f), result.total_radiance);
+    const float rad_diff = length(vabs(prev_irradiance - check_radiance) / vmax(v3(1e-3f), prev_irradiance + check_radiance));
+    const float invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
+    r.M *= 1.0f - invalidity;
+    st4(irradiance_history_tex, x, y, v4(check_radiance, prev_irradiance_packed.w));
+    refl_restir_invalidity_tex.st(x, y, to_unorm8(invalidity));
+    reservoir_history_tex.st(x, y, r.as_raw());
+    for (uint32_t i = 1; i <= 3u; ++i) {
+        const I2 o = hi_px_subpixel(fc.frame_index + i);
+        const int nx = qx * 2 + o.x, ny = qy * 2 + o.y;
+        const V4 neighbor_prev_irradiance_packed = ld4(irradiance_history_tex, nx, ny);
+        const V3 a = vmax(v3(0.0f), xyz(neighbor_prev_irradiance_packed) * fc.pre_exposure_delta);
+        const V3 b = prev_irradiance;
+        const float neigh_rad_diff = length(vabs(a - b) / vmax(v3(1e-8f), a + b));
+        if (neigh_rad_diff < 0.2f) st4(irradiance_history_tex, nx, ny, v4(check_radiance, neighbor_prev_irradiance_packed.w));
+        refl_restir_invalidity_tex.st(nx, ny, to_unorm8(invalidity));
+        if (invalidity > 0.0f) {
+            Reservoir1spp rn = Reservoir1spp::from_raw(reservoir_history_tex.ld(nx, ny));
+            rn.M *= 1.0f - invalidity;
+            reservoir_history_tex.st(nx, ny, rn.as_raw());
+        }
+    }
+}
+
+// ------------------------------------------------------------------ rtr_restir_temporal.hlsl:105-153
+KJ_D void find_best_reprojection_in_neighborhood(const FrameConstants& fc, const ImgF4& ray_orig_history_tex, V4 gts, V2 base_px, I2& best_px, V3 refl_ray_origin_ws, bool wide) {
+    float best_dist = 1e10f;
+    const V2 clip_scale{fc.view_constants.clip_to_view[0], fc.view_constants.clip_to_view[5]};
+    const V2 offset_scale{1.0f * -2.0f * clip_scale.x * gts.z, -1.0f * -2.0f * clip_scale.y * gts.w};
+    const V3 look_direction = direction_view_to_world(fc, V3{0, 0, -1});
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    {
+        const float z_offset = dot(look_direction, refl_ray_origin_ws - get_eye_position(fc));
+        refl_ray_origin_ws += direction_view_to_world(fc, V3{float(off.x) * offset_scale.x * z_offset, float(off.y) * offset_scale.y * z_offset, 0.0f});
+    }
+    const int start_coord = wide ? -1 : 0;
+    for (int yy = start_coord; yy <= 1; ++yy)
+        for (int xx = start_coord; xx <= 1; ++xx) {
+            const I2 spx{int(floorf(base_px.x + float(xx))), int(floorf(base_px.y + float(yy)))};
+            const RtrRestirRayOrigin ray_orig = ray_origin_from_raw(ray_orig_history_tex.ld(spx.x, spx.y));
+            V3 orig = ray_orig.ray_origin_eye_offset_ws + get_prev_eye_position(fc);
+            const I2 orig_jitter = hi_px_subpixel(ray_orig.frame_index_mod4);
+            {
+                const float z_offset = dot(look_direction, orig);
+                orig += direction_view_to_world(fc, V3{float(orig_jitter.x) * offset_scale.x * z_offset, float(orig_jitter.y) * offset_scale.y * z_offset, 0.0f});
+            }
+            const float d = length(orig - refl_ray_origin_ws);
+            if (d < best_dist) { best_dist = d; best_px = spx; }
+        }
+}
+
+struct RtrTemporalArgs {
+    const FrameConstants* fc;
+    ImgU4 gbuffer_tex; ImgU32 half_view_normal_tex; ImgF32 depth_tex;
+    ImgH4 candidate0_tex, candidate1_tex; ImgU32 candidate2_tex;
+    ImgH4 irradiance_history_tex; ImgF4 ray_orig_history_tex; ImgH4 ray_history_tex; ImgU32 rng_history_tex; ImgU2 reservoir_history_tex;
+    ImgU2 reprojection_tex; ImgH4 hit_normal_history_tex;
+    ImgH4 irradiance_out_tex; ImgF4 ray_orig_output_tex; ImgH4 ray_output_tex; ImgU32 rng_output_tex; ImgH4 hit_normal_output_tex; ImgU2 reservoir_out_tex;
+};
+// ------------------------------------------------------------------ rtr_restir_temporal.hlsl:155-533
+__global__ void __launch_bounds__(64) k_rtr_restir_temporal(RtrTemporalArgs a) {
+    TILE_XY(a.irradiance_out_tex.w, a.irradiance_out_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *a.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+    const float depth = a.depth_tex.ld(hx, hy);
+    if (0.0f == depth) {
+        st4(a.irradiance_out_tex, x, y, V4{0.0f, 0.0f, 0.0f, -SKY_DIST});
+        st4(a.hit_normal_output_tex, x, y, v4(0.0f));
+        a.reservoir_out_tex.st(x, y, make_uint2(0, 0));
+        return;
+    }
+    const V4 gts = tex_size4(a.depth_tex.w, a.depth_tex.h);
+    const V2 uv = get_uv(float(hx), float(hy), gts);
+    const V3 normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, x, y);
+    const V3 normal_ws = direction_view_to_world(fc, normal_vs);
+    float local_normal_flatness = 1.0f;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) local_normal_flatness *= saturate(dot(normal_vs, ld_nrm_snorm8(a.half_view_normal_tex, x + dx, y + dy)));
+    float reprojection_neighborhood_stability = 1.0f;
+    for (int dy = 0; dy <= 1; ++dy)
+        for (int dx = 0; dx <= 1; ++dx) reprojection_neighborhood_stability *= ld_reproj(a.reprojection_tex, x * 2 + dx, y * 2 + dy).z;
+    const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
+    const V3 refl_ray_origin_ws = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
+    const V3 refl_ray_origin_vs = position_world_to_view(fc, refl_ray_origin_ws);
+    V3 outgoing_dir{0, 0, 1};
+    uint32_t rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index);
+    const GbufferData gbuffer = gbuffer_unpack(a.gbuffer_tex.ld(hx, hy));
+    const float a2 = fmaxf(RTR_ROUGHNESS_CLAMP, gbuffer.roughness) * fmaxf(RTR_ROUGHNESS_CLAMP, gbuffer.roughness);
+    float pdf_sel = 0.0f, cos_theta = 0.0f;
+    V3 irradiance_sel = v3(0.0f);
+    float4 ray_orig_sel = make_float4(0, 0, 0, 0);
+    V3 ray_hit_sel_ws = v3(1.0f), hit_normal_sel = v3(1.0f);
+    uint32_t rng_sel = a.rng_output_tex.ld(x, y);
+    StreamState stream_state{0.0f, 0.0f};
+    Reservoir1spp reservoir = Reservoir1spp::create();
+    const uint32_t reservoir_payload = uint32_t(x) | (uint32_t(y) << 16);
+    reservoir.payload = reservoir_payload;
+    {
+        const V4 hit0 = ld4(a.candidate0_tex, x, y), hit1 = ld4(a.candidate1_tex, x, y);
+        const V3 hit2 = xyz(unpack_rgba8_snorm(a.candidate2_tex.ld(x, y)));
+        const V3 out_value = xyz(hit0);
+        const float pdf = fminf(hit1.w, RTR_RESTIR_MAX_PDF_CLAMP);
+        const V3 hit_vs = xyz(hit1);
+        if (pdf > 0.0f) {
+            outgoing_dir = normalize(hit_vs);
+            const float p_q = fmaxf(1e-3f, sRGB_to_luminance(out_value)) * pdf;
+            const float inv_pdf_q = 1.0f / pdf;
+            pdf_sel = pdf;
+            cos_theta = 1.0f - hit0.w;
+            irradiance_sel = out_value;
+            ray_orig_sel = ray_origin_to_raw(refl_ray_origin_ws, gbuffer.roughness, fc.frame_index & 3u);
+            ray_hit_sel_ws = hit_vs + refl_ray_origin_ws;
+            hit_normal_sel = direction_view_to_world(fc, hit2);
+            if (p_q * inv_pdf_q > 0.0f) reservoir.init_with_stream(p_q, inv_pdf_q, stream_state, reservoir_payload);
+        }
+    }
+    const V4 center_reproj = ld_reproj(a.reprojection_tex, hx, hy);
+    {
+        const float ang_offset = float(((fc.frame_index + 7u) * 11u) % 32u) * KJ_TAU;
+        const uint32_t sample_count = center_reproj.z < 1.0f ? 5u : 1u;
+        const V3 prev_eye = get_prev_eye_position(fc);
+        for (uint32_t sample_i = 0; sample_i < sample_count && stream_state.M_sum < RTR_RESTIR_TEMPORAL_M_CLAMP; ++sample_i) {
+            const float ang = (float(sample_i) + ang_offset) * KJ_GOLDEN_ANGLE;
+            const float rpx_offset_radius = sqrtf(float(((sample_i - 1u) + fc.frame_index) & 3u) + 1.0f) * clampf(8.0f - stream_state.M_sum, 1.0f, 7.0f);
+            const V2 reservoir_px_offset_base{cosf(ang) * rpx_offset_radius, sinf(ang) * rpx_offset_radius};
+            const I2 rpx_offset = sample_i == 0 ? I2{0, 0} : I2{int(reservoir_px_offset_base.x), int(reservoir_px_offset_base.y)};
+            const V4 reproj = ld_reproj(a.reprojection_tex, hx + rpx_offset.x * 2, hy + rpx_offset.y * 2);
+            const V2 base_px{float(x) + gts.x * reproj.x / 2.0f, float(y) + gts.y * reproj.y / 2.0f};
+            I2 best_px{int(floorf(base_px.x + 0.5f)), int(floorf(base_px.y + 0.5f))};
+            if (reprojection_neighborhood_stability >= 1.0f) {
+                if (fabsf(gts.x * reproj.x) > 0.1f || fabsf(gts.y * reproj.y) > 0.1f)
+                    find_best_reprojection_in_neighborhood(fc, a.ray_orig_history_tex, gts, base_px, best_px, refl_ray_origin_ws, false);
+            } else {
+                find_best_reprojection_in_neighborhood(fc, a.ray_orig_history_tex, gts, base_px, best_px, refl_ray_origin_ws, true);
+            }
+            const I2 rpx{best_px.x + rpx_offset.x, best_px.y + rpx_offset.y};
+            Reservoir1spp r = Reservoir1spp::from_raw(a.reservoir_history_tex.ld(rpx.x, rpx.y));
+            const int spx = int(r.payload & 0xffffu), spy = int(r.payload >> 16);
+            float4 prev_ray_orig_and_roughness = a.ray_orig_history_tex.ld(spx, spy);
+            prev_ray_orig_and_roughness.x += prev_eye.x; prev_ray_orig_and_roughness.y += prev_eye.y; prev_ray_orig_and_roughness.z += prev_eye.z;   // .w: packed bits, untouched
+            const V3 prev_orig{prev_ray_orig_and_roughness.x, prev_ray_orig_and_roughness.y, prev_ray_orig_and_roughness.z};
+            const V3 od = refl_ray_origin_ws - prev_orig;
+            if (dot(od, od) > 0.05f * refl_ray_origin_vs.z * refl_ray_origin_vs.z) continue;
+            const V4 prev_irrad_raw = ld4(a.irradiance_history_tex, spx, spy);
+            const V3 prev_irrad = xyz(prev_irrad_raw) * fc.pre_exposure_delta;
+            const float prev_cos_theta = 1.0f - prev_irrad_raw.w;
+            const V4 sample_hit_ws_and_pdf_packed = ld4(a.ray_history_tex, spx, spy);
+            const float prev_pdf = sample_hit_ws_and_pdf_packed.w;
+            const V3 sample_hit_ws = xyz(sample_hit_ws_and_pdf_packed) + prev_orig;
+            const float prev_dist = length(xyz(sample_hit_ws_and_pdf_packed));
+            const V4 hn_raw = ld4(a.hit_normal_history_tex, spx, spy);
+            const V4 sample_hit_normal_ws_dot{hn_raw.x * 2.0f - 1.0f, hn_raw.y * 2.0f - 1.0f, hn_raw.z * 2.0f - 1.0f, hn_raw.w};
+            const V3 dir_to_sample_hit_unnorm = sample_hit_ws - refl_ray_origin_ws;
+            const float dist_to_sample_hit = length(dir_to_sample_hit_unnorm);
+            const V3 dir_to_sample_hit = normalize(dir_to_sample_hit_unnorm);
+            r.M = fminf(r.M, RTR_RESTIR_TEMPORAL_M_CLAMP);
+            {
+                const V3 current_wo = normalize(vr.hit_ws - get_eye_position(fc));
+                const V3 prev_wo = normalize(vr.hit_ws - prev_eye);
+                const float wo_dot = saturate(dot(current_wo, prev_wo));
+                const float wo_similarity = powf(saturate(ggx_ndf_0_1(fmaxf(3e-5f, a2), wo_dot)), 64.0f);
+                float mult = lerp(wo_similarity, 1.0f, smoothstep(0.05f, 0.5f, sqrtf(gbuffer.roughness)));
+                mult = lerp(1.0f, mult, local_normal_flatness);
+                r.M *= mult;
+            }
+            float p_q = 1.0f;
+            p_q *= fmaxf(1e-3f, sRGB_to_luminance(prev_irrad));
+            p_q *= stepf(0.0f, dot(dir_to_sample_hit, normal_ws));
+            p_q *= prev_pdf;
+            float jacobian = 1.0f;
+            jacobian *= clampf(prev_dist / dist_to_sample_hit, 1e-4f, 1e4f);
+            jacobian *= jacobian;
+            jacobian *= fmaxf(0.0f, -dot(xyz(sample_hit_normal_ws_dot), dir_to_sample_hit)) / fmaxf(1e-5f, sample_hit_normal_ws_dot.w);
+            {
+                const float threshold = lerp(1.1f, 4.0f, gbuffer.roughness * gbuffer.roughness);
+                if (!(jacobian < threshold && jacobian > 1.0f / threshold)) continue;
+            }
+            p_q *= jacobian;
+            if (reservoir.update_with_stream(r, p_q, 1.0f, stream_state, reservoir_payload, rng)) {
+                outgoing_dir = dir_to_sample_hit;
+                pdf_sel = prev_pdf;
+                cos_theta = prev_cos_theta;
+                irradiance_sel = prev_irrad;
+                ray_orig_sel = prev_ray_orig_and_roughness;
+                ray_hit_sel_ws = sample_hit_ws;
+                hit_normal_sel = xyz(sample_hit_normal_ws_dot);
+                rng_sel = a.rng_history_tex.ld(spx, spy);
+            }
+        }
+        reservoir.finish_stream(stream_state);
+        reservoir.W = fminf(reservoir.W, 1e20f);
+    }
+    const V4 hit_normal_ws_dot = v4(hit_normal_sel, -dot(hit_normal_sel, outgoing_dir));
+    st4(a.irradiance_out_tex, x, y, v4(irradiance_sel, 1.0f - cos_theta));
+    const V3 eye = get_eye_position(fc);
+    a.ray_orig_output_tex.st(x, y, make_float4(ray_orig_sel.x - eye.x, ray_orig_sel.y - eye.y, ray_orig_sel.z - eye.z, ray_orig_sel.w));
+    st4(a.hit_normal_output_tex, x, y, V4{hit_normal_ws_dot.x * 0.5f + 0.5f, hit_normal_ws_dot.y * 0.5f + 0.5f, hit_normal_ws_dot.z * 0.5f + 0.5f, hit_normal_ws_dot.w});
+    st4(a.ray_output_tex, x, y, v4(ray_hit_sel_ws - V3{ray_orig_sel.x, ray_orig_sel.y, ray_orig_sel.z}, pdf_sel));
+    a.rng_output_tex.st(x, y, rng_sel);
+    a.reservoir_out_tex.st(x, y, reservoir.as_raw());
+}
+
+// ------------------------------------------------------------------ resolve.hlsl:66-663 (USE_RESTIR, CUT_CORNERS_IN_MATH, BORROW_SAMPLES)
+struct RtrResolveArgs {
+    const FrameConstants* fc;
+    ImgU4 gbuffer_tex; ImgF32 depth_tex; ImgH4 hit1_tex; ImgU2 reprojection_tex; ImgU32 half_view_normal_tex; ImgU32 ray_len_history_tex;
+    ImgH4 restir_irradiance_tex, restir_ray_tex; ImgU2 restir_reservoir_tex; ImgF4 restir_ray_orig_tex;
+    ImgU32 output_tex; ImgU32 ray_len_output_tex;
+    const uint32_t* blue_noise; const uint2* brdf_fg_lut;
+};
+__global__ void __launch_bounds__(64) k_rtr_resolve(RtrResolveArgs a) {
+    TILE_XY(a.output_tex.w, a.output_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *a.fc;
+    const int hpx = x / 2, hpy = y / 2;
+    const V4 ots = tex_size4(a.output_tex.w, a.output_tex.h);
+    const V2 uv = get_uv(float(x), float(y), ots);
+    const float depth = a.depth_tex.ld(x, y);
+    if (0.0f == depth) { a.output_tex.st(x, y, 0u); return; }
+    GbufferData gbuffer = gbuffer_unpack(a.gbuffer_tex.ld(x, y));
+    const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
+    const V3 refl_ray_origin_ws = vr.biased_secondary_ray_origin_ws_with_normal(gbuffer.normal);
+    const V3 refl_ray_origin_vs = position_world_to_view(fc, refl_ray_origin_ws);
+    gbuffer.roughness = fmaxf(gbuffer.roughness, RTR_ROUGHNESS_CLAMP);
+    const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
+    V3 wo = to_local(tangent_to_world, -vr.dir_ws);
+    if (wo.z < 0.0f) { wo.z *= -0.25f; wo = normalize(wo); }
+    const LayeredBrdf lb = layered_brdf_from_gbuffer_ndotv(a.brdf_fg_lut, gbuffer, wo.z);
+    const uint32_t px_idx_in_quad = ((uint32_t(x & 1) | uint32_t(y & 1) * 2u) + fc.frame_index) & 3u;
+    const float a2 = fmaxf(RTR_ROUGHNESS_CLAMP, gbuffer.roughness) * fmaxf(RTR_ROUGHNESS_CLAMP, gbuffer.roughness);
+    const float surf_to_hit_dist = length(xyz(ld4(a.hit1_tex, hpx, hpy)));
+    const float eye_to_surf_dist = length(refl_ray_origin_vs);
+    V3 ray_dir_vs;
+    {
+        const V2 cs = uv_to_cs(uv);
+        ray_dir_vs = normalize(xyz(mul44(fc.view_constants.sample_to_view, V4{cs.x, cs.y, 0.0f, 1.0f})));
+    }
+    const float eye_ray_z_scale = -ray_dir_vs.z;
+    const V4 reprojection_params = ld_reproj(a.reprojection_tex, x, y);
+    const float ray_squish_scale = 16.0f / fmaxf(1e-5f, eye_to_surf_dist);
+    const float ray_len_avg = exponential_unsquish(lerp(
+        exponential_squish(sample_bilinear_clamp_rg16f(a.ray_len_history_tex.p, a.ray_len_history_tex.w, a.ray_len_history_tex.h, V2{uv.x + reprojection_params.x, uv.y + reprojection_params.y}).y, ray_squish_scale),
+        exponential_squish(surf_to_hit_dist, ray_squish_scale), 0.1f), ray_squish_scale);
+    V4 contrib_accum = v4(0.0f);
+    float ray_len_accum = 0.0f;
+    const V3 normal_vs = direction_world_to_view(fc, gbuffer.normal);
+    const float tan_theta = sqrtf(gbuffer.roughness) * 0.25f;
+    const float clip_to_view_11 = fc.view_constants.clip_to_view[5];
+    float kernel_size_ws;
+    {
+        const float clamped_ray_len_avg = fmaxf(ray_len_avg, eye_to_surf_dist / eye_ray_z_scale * clip_to_view_11 * 0.2f * smoothstep(0.0f, 0.05f * eye_to_surf_dist, ray_len_avg));
+        const float kernel_size_vs = clamped_ray_len_avg / (clamped_ray_len_avg + eye_to_surf_dist);
+        kernel_size_ws = kernel_size_vs * eye_to_surf_dist * eye_ray_z_scale;
+        kernel_size_ws *= tan_theta;
+    }
+    {
+        const float scale_factor = eye_to_surf_dist * eye_ray_z_scale * clip_to_view_11;
+        kernel_size_ws = fminf(kernel_size_ws, 0.1f * scale_factor);
+        kernel_size_ws = fmaxf(kernel_size_ws, ots.w * 4.0f * scale_factor);
+    }
+    V3 kernel_t1, kernel_t2;
+    {   // get_specular_filter_kernel_basis (resolve.hlsl:72-79) with specular_dominant_direction (brdf.hlsl:313-317)
+        const V3 v = -vr.dir_ws, n = gbuffer.normal;
+        const V3 r = reflect(-v, n);
+        const float f = (1.0f - gbuffer.roughness) * (sqrtf(1.0f - gbuffer.roughness) + gbuffer.roughness);
+        const V3 dominant = normalize(lerp(n, r, f));
+        const V3 reflected = reflect(-dominant, n);
+        kernel_t1 = normalize(cross(n, reflected)) * kernel_size_ws;
+        kernel_t2 = cross(reflected, kernel_t1);
+    }
+    const V4 blue = blue_noise_for_pixel(a.blue_noise, uint32_t(hpx + 16), uint32_t(hpy + 16), fc.frame_index);
+    const float KERNEL_SHARPNESS = 0.666f;
+    const float RADIUS_SAMPLE_MULT = 1.0f / powf(8.0f, KERNEL_SHARPNESS);
+    const float ang_offset = float(fc.frame_index * 59u % 128u) * KJ_PLASTIC;
+    const float RADIUS_INC_ON_FAIL = 0.25f;
+    const V3 eye = get_eye_position(fc);
+    float sample_radius_accum = 1.0f;
+    for (uint32_t sample_i = 1; sample_i <= 8u; ++sample_i, sample_radius_accum += RADIUS_INC_ON_FAIL) {
+        const bool is_center_sample = sample_i == 8u;
+        int sample_px_x, sample_px_y;
+        {
+            const float ang = (float(sample_i) + ang_offset) * KJ_GOLDEN_ANGLE + (float(px_idx_in_quad) / 4.0f) * KJ_TAU;
+            float sample_i_with_jitter = sample_radius_accum;
+            if (is_center_sample) sample_i_with_jitter = contrib_accum.w > 1e-8f ? blue.y : 0.0f;
+            else sample_i_with_jitter += blue.y;
+            const float radius = powf(sample_i_with_jitter, KERNEL_SHARPNESS) * RADIUS_SAMPLE_MULT;
+            const V3 offset_ws = (cosf(ang) * kernel_t1 + sinf(ang) * kernel_t2) * radius;
+            const V3 sample_ws = refl_ray_origin_ws + offset_ws;
+            const V3 sample_cs = position_world_to_sample(fc, sample_ws);
+            const V2 sample_uv = cs_to_uv(V2{sample_cs.x, sample_cs.y});
+            sample_px_x = int(floorf(sample_uv.x * ots.x / 2.0f));
+            sample_px_y = int(floorf(sample_uv.y * ots.y / 2.0f));
+        }
+        float rejection_bias = 1.0f;
+        const V3 sample_normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, sample_px_x, sample_px_y);
+        float pdf0_mult = 1.0f, pdf1_mult = 1.0f;
+        const uint2 reservoir_raw = a.restir_reservoir_tex.ld(sample_px_x, sample_px_y);
+        const Reservoir1spp r = Reservoir1spp::from_raw(reservoir_raw);
+        const int spx = int(r.payload & 0xffffu), spy = int(r.payload >> 16);
+        const RtrRestirRayOrigin sample_origin = ray_origin_from_raw(a.restir_ray_orig_tex.ld(spx, spy));
+        const V3 sample_origin_ws = sample_origin.ray_origin_eye_offset_ws + eye;
+        if (reservoir_raw.x == 0u || sample_origin.roughness > gbuffer.roughness * 2.0f) continue;
+        const V4 restir_ray = ld4(a.restir_ray_tex, spx, spy);
+        const V3 sample_hit_ws = xyz(restir_ray) + sample_origin_ws;
+        const V3 sample_origin_vs = position_world_to_view(fc, sample_origin_ws);
+        const V4 restir_irr = ld4(a.restir_irradiance_tex, spx, spy);
+        const V3 sample_radiance = xyz(restir_irr);
+        const float sample_ray_pdf = restir_ray.w;
+        const float neighbor_sampling_pdf = 1.0f / r.W;
+        const V3 sample_hit_vs_abs = position_world_to_view(fc, sample_hit_ws);
+        const V3 center_to_hit_vs = sample_hit_vs_abs - lerp(refl_ray_origin_vs, sample_origin_vs, RTR_NEIGHBOR_RAY_ORIGIN_CENTER_BIAS);
+        const float sample_cos_theta = 1.0f - restir_irr.w;
+        const float center_to_hit_dist = length(center_to_hit_vs);
+        const float sample_to_hit_dist = length(sample_hit_ws - sample_origin_ws);
+        {
+            const float d = length(sample_hit_vs_abs - lerp(refl_ray_origin_vs, sample_origin_vs, lerp(1.0f, RTR_NEIGHBOR_RAY_ORIGIN_CENTER_BIAS, 0.4f * fminf(1.0f, 3.0f * sqrtf(gbuffer.roughness)))));
+            pdf0_mult *= fmaxf(1e-5f, powf(d / sample_to_hit_dist, 2.0f));
+            pdf1_mult *= fmaxf(1.0f, powf(center_to_hit_dist / sample_to_hit_dist, 2.0f));
+        }
+        const V3 wi = normalize(to_local(tangent_to_world, direction_view_to_world(fc, center_to_hit_vs)));
+        if (wi.z < 1e-5f) continue;
+        rejection_bias *= dot(normal_vs, sample_normal_vs) > 0.7f ? 1.0f : 0.0f;
+        {
+            const float depth_diff = fabsf(refl_ray_origin_vs.z - sample_origin_vs.z) / fmaxf(1e-10f, kernel_size_ws);
+            rejection_bias *= exp2f(-fmaxf(0.3f, normal_vs.z) * depth_diff * depth_diff);
+        }
+        const V3 surface_offset = sample_origin_vs - refl_ray_origin_vs;
+        if (dot(center_to_hit_vs, normal_vs) * 0.2f / length(center_to_hit_vs) < dot(surface_offset, normal_vs) / length(surface_offset)) rejection_bias *= is_center_sample ? 1.0f : 0.0f;
+        const BrdfValue spec = specular_evaluate(lb.roughness, lb.spec_albedo, wo, wi);
+        const float spec_weight = spec.pdf * stepf(0.0f, wi.z);
+        float contrib_wt = 0.0f;
+        {
+            const float cos_theta = normalize(wo + wi).z;
+            const float bent_cos_theta = fminf(sample_cos_theta, cos_theta * 1.25f);
+            const float sample_ray_ndf = ggx_ndf(a2, bent_cos_theta);
+            const float center_ndf = ggx_ndf(a2, cos_theta);
+            const float bent_sample_pdf0 = spec.pdf * sample_ray_ndf / center_ndf;
+            const float pdf_lerp_t = smoothstep(0.4f, 0.7f, sqrtf(gbuffer.roughness)) * smoothstep(0.0f, 0.1f, ray_len_avg / eye_to_surf_dist);
+            const float pdf_x[2] = {fminf(bent_sample_pdf0, RTR_RESTIR_MAX_PDF_CLAMP), fminf(spec.pdf, RTR_RESTIR_MAX_PDF_CLAMP)};
+            const float pdf_y[2] = {neighbor_sampling_pdf * pdf0_mult, neighbor_sampling_pdf * pdf1_mult};
+            const float pdf_z[2] = {1.0f - pdf_lerp_t, pdf_lerp_t};
+#pragma unroll
+            for (int pdf_i = 0; pdf_i < 2; ++pdf_i) {
+                const float bent_sample_pdf = pdf_x[pdf_i], nsp = pdf_y[pdf_i], pdf_influence = pdf_z[pdf_i];
+                const float mis_weight = fmaxf(1e-4f, spec.pdf / (sample_ray_pdf + spec.pdf));
+                contrib_wt = rejection_bias * mis_weight * fmaxf(1e-10f, spec_weight / bent_sample_pdf);
+                contrib_accum = contrib_accum + v4(sample_radiance * bent_sample_pdf / nsp * spec.value_over_pdf, 1.0f) * contrib_wt * pdf_influence;
+            }
+        }
+        ray_len_accum += exponential_squish(surf_to_hit_dist, ray_squish_scale) * contrib_wt;
+        sample_radius_accum += 1.0f - RADIUS_INC_ON_FAIL;
+    }
+    const float contrib_norm_factor = fmaxf(1e-14f, contrib_accum.w);
+    V3 rgb = xyz(contrib_accum) / contrib_norm_factor;
+    ray_len_accum /= contrib_norm_factor;
+    rgb = rgb / lb.preintegrated_reflection;
+    rgb = rgb * lb.preintegrated_reflection_mult;
+    ray_len_accum = exponential_unsquish(ray_len_accum, ray_squish_scale);
+    a.output_tex.st(x, y, pack_r11g11b10f(rgb));
+    st2h(a.ray_len_output_tex, x, y, V2{ray_len_accum, ray_len_avg});
+}
+
+// image_sample_catmull_rom_5tap (inc/image.hlsl:88-172) with the identity remap
+KJ_D V4 catmull_rom_5tap(const ImgH4& tex, V2 uv, V2 tex_size) {
+    const V2 sample_pos = uv * tex_size;
+    const V2 tex_pos1{floorf(sample_pos.x - 0.5f) + 0.5f, floorf(sample_pos.y - 0.5f) + 0.5f};
+    const V2 f = sample_pos - tex_pos1;
+    const V2 w0 = f * (-0.5f + f * (1.0f - 0.5f * f));
+    const V2 w1 = 1.0f + f * f * (-2.5f + 1.5f * f);
+    const V2 w2 = f * (0.5f + f * (2.0f - 1.5f * f));
+    const V2 w3 = f * f * (-0.5f + 0.5f * f);
+    const V2 w12 = w1 + w2;
+    const V2 offset12 = w2 / (w1 + w2);
+    const V2 p0 = (tex_pos1 - 1.0f) / tex_size, p3 = (tex_pos1 + 2.0f) / tex_size, p12 = (tex_pos1 + offset12) / tex_size;
+    V4 result = v4(0.0f);
+    result += sample_bilinear_clamp_rgba16f(tex.p, tex.w, tex.h, V2{p12.x, p0.y}) * (w12.x * w0.y);
+    result += sample_bilinear_clamp_rgba16f(tex.p, tex.w, tex.h, V2{p0.x, p12.y}) * (w0.x * w12.y);
+    result += sample_bilinear_clamp_rgba16f(tex.p, tex.w, tex.h, V2{p12.x, p12.y}) * (w12.x * w12.y);
+    result += sample_bilinear_clamp_rgba16f(tex.p, tex.w, tex.h, V2{p3.x, p12.y}) * (w3.x * w12.y);
+    result += sample_bilinear_clamp_rgba16f(tex.p, tex.w, tex.h, V2{p12.x, p3.y}) * (w12.x * w3.y);
+    return result / (w12.x * w0.y + w0.x * w12.y + w12.x * w12.y + w3.x * w12.y + w12.x * w3.y);
+}
+
+// ------------------------------------------------------------------ temporal_filter.hlsl:37-259
+__global__ void __launch_bounds__(64) k_rtr_temporal_filter(const FrameConstants* __restrict__ fcp, ImgU32 input_tex, ImgH4 history_tex, ImgF32 depth_tex, ImgU32 ray_len_tex,
+                                                             ImgU2 reprojection_tex, ImgR8 refl_restir_invalidity_tex, ImgU4 gbuffer_tex, ImgH4 output_tex) {
+    TILE_XY(output_tex.w, output_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const V4 ots = tex_size4(output_tex.w, output_tex.h);
+    auto ld_in = [&](int sx, int sy) { return input_tex.inb(sx, sy) ? v4(unpack_r11g11b10f(input_tex.ld(sx, sy)), 1.0f) : v4(0.0f); };
+    const V4 center = linear_rgb_to_crunched_luma_chroma(ld_in(x, y));
+    const float refl_ray_length = clampf(ld2h(ray_len_tex, x, y).x, 0.0f, 1e3f);
+    const V2 uv = get_uv(float(x), float(y), ots);
+    const float center_depth = depth_tex.ld(x, y);
+    const ViewRay vr = view_ray_from_uv_and_depth(fc, uv, center_depth);
+    V3 ray_dir_vs;
+    {
+        const V2 cs = uv_to_cs(uv);
+        ray_dir_vs = normalize(xyz(mul44(fc.view_constants.sample_to_view, V4{cs.x, cs.y, 0.0f, 1.0f})));
+    }
+    const V3 reflection_hit_vs = vr.hit_vs + ray_dir_vs * refl_ray_length;
+    const V4 reflection_hit_cs = mul44(fc.view_constants.view_to_sample, v4(reflection_hit_vs, 1.0f));
+    const V4 prev_hit_cs = mul44(fc.view_constants.clip_to_prev_clip, reflection_hit_cs);
+    V2 hit_prev_uv = cs_to_uv(V2{prev_hit_cs.x / prev_hit_cs.w, prev_hit_cs.y / prev_hit_cs.w});
+    const V4 prev_reflector_cs = mul44(fc.view_constants.clip_to_prev_clip, v4(vr.hit_cs, 1.0f));
+    const V2 reflector_prev_uv = cs_to_uv(V2{prev_reflector_cs.x / prev_reflector_cs.w, prev_reflector_cs.y / prev_reflector_cs.w});
+    const V4 reproj = ld_reproj(reprojection_tex, x, y);
+    const float reflector_move_rate = fminf(1.0f, length(V2{reproj.x, reproj.y}) / length(reflector_prev_uv - uv));
+    hit_prev_uv = lerp(uv, hit_prev_uv, reflector_move_rate);
+    const uint32_t quad_reproj_valid_packed = uint32_t(reproj.z * 15.0f + 0.5f);
+    const V4 history_mult{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1.0f};
+    V4 history0 = v4(0.0f);
+    float history0_valid = 1.0f;
+    const V2 reproj_uv{uv.x + reproj.x, uv.y + reproj.y};
+    if (0u == quad_reproj_valid_packed) {
+        history0_valid = 0.0f;
+    } else if (15u == quad_reproj_valid_packed) {
+        history0 = vmax(v4(0.0f), catmull_rom_5tap(history_tex, reproj_uv, V2{ots.x, ots.y})) * history_mult;
+    } else {
+        const V4 qv{(quad_reproj_valid_packed & 1u) ? 1.0f : 0.0f, (quad_reproj_valid_packed & 2u) ? 1.0f : 0.0f, (quad_reproj_valid_packed & 4u) ? 1.0f : 0.0f,
+                    (quad_reproj_valid_packed & 8u) ? 1.0f : 0.0f};
+        // get_bilinear_filter (inc/bilinear.hlsl)
+        const V2 pxf{reproj_uv.x * ots.x - 0.5f, reproj_uv.y * ots.y - 0.5f};
+        const V2 origin{floorf(pxf.x), floorf(pxf.y)};
+        const V2 wts{pxf.x - origin.x, pxf.y - origin.y};
+        const int ox = int(origin.x), oy = int(origin.y);
+        const V4 s00 = ld4(history_tex, ox, oy) * history_mult, s10 = ld4(history_tex, ox + 1, oy) * history_mult;
+        const V4 s01 = ld4(history_tex, ox, oy + 1) * history_mult, s11 = ld4(history_tex, ox + 1, oy + 1) * history_mult;
+        V4 w{(1.0f - wts.x) * (1.0f - wts.y), wts.x * (1.0f - wts.y), (1.0f - wts.x) * wts.y, wts.x * wts.y};
+        w = w * qv;
+        const float wsum = dot(w, v4(1.0f));
+        if (wsum > 1e-5f) history0 = (s00 * w.x + s10 * w.y + s01 * w.z + s11 * w.w) * (1.0f / wsum);
+        else history0 = (s00 + s10 + s01 + s11) / 4.0f;
+    }
+    history0 = linear_rgb_to_crunched_luma_chroma(history0);
+    const V4 history1 = linear_rgb_to_crunched_luma_chroma(sample_bilinear_clamp_rgba16f(history_tex.p, history_tex.w, history_tex.h, hit_prev_uv) * history_mult);
+    const float history1_valid = quad_reproj_valid_packed == 15u ? 1.0f : 0.0f;
+    V4 vsum = v4(0.0f), vsum2 = v4(0.0f);
+    float wsum = 0.0f;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const float sample_depth = depth_tex.ld(x + dx, y + dy);
+            const V4 neigh = linear_rgb_to_crunched_luma_chroma(ld_in(x + dx, y + dy));
+            const float w = exp2f(-200.0f * fabsf(center_depth / sample_depth - 1.0f));
+            vsum = vsum + neigh * w;
+            vsum2 = vsum2 + neigh * neigh * w;
+            wsum += w;
+        }
+    const V4 ex = vsum / wsum, ex2 = vsum2 / wsum;
+    const V4 dev = vsqrt(vmax(v4(0.0f), ex2 - ex * ex));
+    const GbufferData gbuffer = gbuffer_unpack(gbuffer_tex.ld(x, y));
+    const float restir_invalidity = from_unorm8(refl_restir_invalidity_tex.ld(x / 2, y / 2));
+    const float n_deviations = lerp(reproj.z > 0.0f ? 2.0f : 1.25f, 0.625f, restir_invalidity);
+    float wo_similarity;
+    {
+        const V3 current_wo = normalize(vr.hit_ws - get_eye_position(fc));
+        const V3 prev_wo = normalize(vr.hit_ws - get_prev_eye_position(fc));
+        const float clamped_roughness = fmaxf(0.1f, gbuffer.roughness);
+        wo_similarity = powf(saturate(ggx_ndf_0_1(clamped_roughness * clamped_roughness, dot(current_wo, prev_wo))), 32.0f);
+    }
+    const float h0diff = length((xyz(history0) - xyz(ex)) / xyz(dev));
+    const float h1diff = length((xyz(history1) - xyz(ex)) / xyz(dev));
+    float h0_score = 1.0f * smoothstep(0.0f, 0.5f, sqrtf(gbuffer.roughness)) * lerp(wo_similarity, 1.0f, sqrtf(gbuffer.roughness));
+    float h1_score = (1.0f - h0_score) * lerp(1.0f, smoothstep(0.0f, 1.0f, h0diff - h1diff), smoothstep(0.0f, 0.15f, sqrtf(gbuffer.roughness)));
+    h0_score *= history0_valid;
+    h1_score *= history1_valid;
+    const float score_sum = h0_score + h1_score;
+    h0_score /= score_sum;
+    h1_score = 1.0f - h0_score;
+    if (!(h0_score < 1.001f)) { h0_score = 1.0f; h1_score = 0.0f; }
+    const V4 clamped_history0 = v4(soft_color_clamp(xyz(center), xyz(history0), xyz(ex), xyz(dev) * n_deviations), history0.w);
+    const V4 clamped_history1 = v4(soft_color_clamp(xyz(center), xyz(history1), xyz(ex), xyz(dev) * n_deviations), history1.w);
+    const V4 clamped_history = clamped_history0 * h0_score + clamped_history1 * h1_score;
+    const float max_sample_count = 16.0f;
+    const float current_sample_count = clamped_history.w * saturate(h0_score * history0_valid + h1_score * history1_valid);
+    V4 res = lerp(clamped_history, center, 1.0f / (1.0f + fminf(max_sample_count, current_sample_count * lerp(wo_similarity, 1.0f, 0.5f))));
+    res.w = fminf(current_sample_count, max_sample_count) + 1.0f;
+    res = crunched_luma_chroma_to_linear_rgb(res);
+    st4(output_tex, x, y, vmax(v4(0.0f), res));
+}
+
+// ------------------------------------------------------------------ spatial_cleanup.hlsl:20-65
+__global__ void __launch_bounds__(64) k_rtr_cleanup(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgF32 depth_tex, ImgU32 geometric_normal_tex, ImgU32 output_tex,
+                                                     const int4* __restrict__ spatial_resolve_offsets) {
+    TILE_XY(output_tex.w, output_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const V4 center = ld4(input_tex, x, y);
+    const float center_depth = depth_tex.ld(x, y);
+    const float center_sample_count = center.w;
+    if (center_sample_count >= 8.0f || center_depth == 0.0f) { output_tex.st(x, y, pack_r11g11b10f(xyz(center))); return; }
+    const V3 center_normal_vs = unpack_a2r10g10b10(geometric_normal_tex.ld(x, y)) * 2.0f - 1.0f;
+    const float filter_radius_ss = 0.5f * fc.view_constants.view_to_clip[5] / -depth_to_view_z(fc, center_depth);
+    const uint32_t filter_idx = uint32_t(clampf(filter_radius_ss * 7.0f, 0.0f, 7.0f));
+    V3 vsum = v3(0.0f);
+    float wsum = 0.0f;
+    const int sc = int(8.0f - center_sample_count / 2.0f);
+    const uint32_t sample_count = uint32_t(min(max(sc, 2), 8));
+    const int kernel_scale = center_sample_count < 4.0f ? 2 : 1;
+    const uint32_t px_idx_in_quad = ((uint32_t(x & 1) | uint32_t(y & 1) * 2u) + fc.frame_index) & 3u;
+    for (uint32_t sample_i = 0; sample_i < sample_count; ++sample_i) {
+        const int4 o = spatial_resolve_offsets[(px_idx_in_quad * 16u + sample_i) + 64u * filter_idx];
+        const int sx = x + kernel_scale * o.x, sy = y + kernel_scale * o.y;
+        const V3 neigh = vsqrt(xyz(ld4(input_tex, sx, sy)));
+        const float sample_depth = depth_tex.ld(sx, sy);
+        const V3 sample_normal_vs = geometric_normal_tex.inb(sx, sy) ? unpack_a2r10g10b10(geometric_normal_tex.ld(sx, sy)) * 2.0f - 1.0f : v3(-1.0f);
+        float w = 1.0f;
+        w *= exp2f(-50.0f * fabsf(center_normal_vs.z * (center_depth / sample_depth - 1.0f)));
+        const float dp = saturate(dot(center_normal_vs, sample_normal_vs));
+        w *= dp * dp * dp;
+        vsum += neigh * w;
+        wsum += w;
+    }
+    const V3 v = vsum / wsum;
+    output_tex.st(x, y, pack_r11g11b10f(v * v));
+}
+
+// ------------------------------------------------------------------ host
+struct KjRtr {
+    KjDevice* dev = nullptr;
+    bool reuse_rtdgi_rays = true;                       // rtr.rs:32,70
+    int W = 0, H = 0, hw = 0, hh = 0;
+    std::map<std::string, kj::DevBuf> surf;
+    bool flip[8] = {false, false, false, false, false, false, false, false};
+    kj::DevBuf ranking, scrambling, sobol, offsets, ray_counters;
+    // TracedRtr (rtr.rs:74-80)
+    void *resolved_tex = nullptr, *temporal_output_tex = nullptr, *history_tex = nullptr, *ray_len_tex = nullptr, *refl_restir_invalidity_tex = nullptr;
+    hipError_t err = hipSuccess;
+
+    void* get(const std::string& name, size_t bytes, hipStream_t s) {
+        kj::DevBuf& b = surf[name];
+        if (b.bytes != bytes) { hipError_t e = b.alloc(bytes, s); if (e != hipSuccess) err = e; }
+        return b.p;
+    }
+    void pingpong(const char* key, int idx, size_t bytes, hipStream_t s, void*& output, void*& history) {
+        std::string a = std::string(key) + ":0", b = std::string(key) + ":1";
+        if (flip[idx]) std::swap(a, b);
+        output = get(a, bytes, s);
+        history = get(b, bytes, s);
+        flip[idx] = !flip[idx];
+    }
+    void resize(int W_, int H_) {
+        if (W == W_ && H == H_) return;
+        W = W_; H = H_; hw = (W + 1) / 2; hh = (H + 1) / 2;
+        surf.clear();
+    }
+};
+
+#define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
+
+extern "C" {
+
+KjStatus kj_rtr_create(KjDevice* dev, const KjRtrTables* t, KjRtr** out) {
+    KJ_REQUIRE(dev && t && out, "null argument");
+    KJ_REQUIRE(t->ranking_tile && t->scrambling_tile && t->sobol && t->spatial_resolve_offsets, "all four tables are required");
+    KjRtr* r = new KjRtr();
+    r->dev = dev;
+    hipError_t e = r->ranking.upload(t->ranking_tile, 128 * 128 * 8 * 4);
+    if (e == hipSuccess) e = r->scrambling.upload(t->scrambling_tile, 128 * 128 * 8 * 4);
+    if (e == hipSuccess) e = r->sobol.upload(t->sobol, 256 * 256 * 4);
+    if (e == hipSuccess) e = r->offsets.upload(t->spatial_resolve_offsets, 16 * 4 * 8 * 16);
+    if (e == hipSuccess) e = r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);   // the tables are host memory owned by the caller
+    if (e != hipSuccess) { delete r; set_last_error("kj_rtr_create: %s", hipGetErrorString(e)); return KJ_ERR_HIP; }
+    *out = r;
+    return KJ_OK;
+}
+void kj_rtr_destroy(KjRtr* r) { delete r; }
+KjStatus kj_rtr_set_options(KjRtr* r, uint32_t reuse_rtdgi_rays) {
+    KJ_REQUIRE(r, "null argument");
+    r->reuse_rtdgi_rays = reuse_rtdgi_rays != 0;
+    return KJ_OK;
+}
+
+static KjStatus rtr_check_params(KjRtr* r, const KjRtrParams* p) {
+    KJ_REQUIRE(r && p, "null argument");
+    KJ_REQUIRE(p->scene && p->reprojection_map && p->sky_cube && p->rtdgi_irradiance && p->candidate_radiance_tex && p->candidate_hit_tex && p->candidate_normal_tex &&
+               p->gbuffer_depth.depth && p->gbuffer_depth.gbuffer && p->gbuffer_depth.geometric_normal, "missing input");
+    KJ_REQUIRE(p->gbuffer_depth.width > 0 && p->gbuffer_depth.height > 0 && p->gbuffer_depth.width < 65536 && p->gbuffer_depth.height < 65536, "bad extent");
+    KJ_REQUIRE(r->dev->fc_dev, "kj_frame_begin not called");
+    if (!p->scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
+    return KJ_OK;
+}
+
+KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* p, void* stream_) {
+    if (KjStatus st = rtr_check_params(r, p)) return st;
+    hipStream_t s = (hipStream_t)stream_;
+    r->resize(int(p->gbuffer_depth.width), int(p->gbuffer_depth.height));
+    const int W = r->W, H = r->H, hw = r->hw, hh = r->hh;
+    const FrameConstants* fc = r->dev->fc_dev;
+    const uint32_t mask = p->pass_mask;
+    if (mask & KJ_RTR_PASS_KEEP) for (bool& f : r->flip) f = !f;
+    const dim3 gh((hw + 7) / 8, (hh + 7) / 8), gf((W + 7) / 8, (H + 7) / 8), blk(64);
+    const size_t HB = size_t(hw) * hh, FB = size_t(W) * H;
+    const ImgU4 gbuffer = img<uint4>(p->gbuffer_depth.gbuffer, W, H);
+    const ImgF32 depth = img<float>(p->gbuffer_depth.depth, W, H);
+    const ImgU2 reprojection = img<uint2>(p->reprojection_map, W, H);
+    const ImgH4 refl0 = img<uint2>(p->candidate_radiance_tex, hw, hh), refl1 = img<uint2>(p->candidate_hit_tex, hw, hh);
+    const ImgU32 refl2 = img<uint32_t>(p->candidate_normal_tex, hw, hh);
+
+    void *rng_out, *rng_hist;               r->pingpong("rtr.rng", 6, HB * 4, s, rng_out, rng_hist);
+    void *ray_orig_out, *ray_orig_hist;     r->pingpong("rtr.ray_orig", 3, HB * 16, s, ray_orig_out, ray_orig_hist);
+    void* invalidity = r->get("refl_restir_invalidity_tex", HB, s);
+    void *hit_normal_out, *hit_normal_hist; r->pingpong("rtr.hit_normal", 7, HB * 8, s, hit_normal_out, hit_normal_hist);
+    void *irradiance_out, *irradiance_hist; r->pingpong("rtr.irradiance", 2, HB * 8, s, irradiance_out, irradiance_hist);
+    void *reservoir_out, *reservoir_hist;   r->pingpong("rtr.reservoir", 5, HB * 8, s, reservoir_out, reservoir_hist);
+    void *ray_out, *ray_hist;               r->pingpong("rtr.ray", 4, HB * 8, s, ray_out, ray_hist);
+    void* resolved = r->get("resolved_tex", FB * 4, s);
+    void *temporal_out, *temporal_hist;     r->pingpong("rtr.temporal", 0, FB * 8, s, temporal_out, temporal_hist);
+    void *ray_len_out, *ray_len_hist;       r->pingpong("rtr.ray_len", 1, FB * 4, s, ray_len_out, ray_len_hist);
+    void* half_view_normal = r->get("half_view_normal_tex", HB * 4, s);
+    void* half_depth = r->get("half_depth_tex", HB * 4, s);
+    KJ_TRY_HIP(r->err);
+    if (!(mask & KJ_RTR_PASS_KEEP)) KJ_TRY_HIP(hipMemsetAsync(r->ray_counters.p, 0, KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8, s));
+
+    RtrCtx c;
+    c.fc = fc;
+    c.sc = scene_view(*p->scene);
+    c.depth = depth; c.gbuffer = gbuffer;
+    c.rtdgi_tex = img<uint2>(p->rtdgi_irradiance, W, H);
+    c.sky_cube = (const uint2*)p->sky_cube; c.sky_cube_width = int(p->sky_cube_width);
+    c.brdf_fg_lut = (const uint2*)r->dev->brdf_fg_lut.p;
+    c.sun_color = (const float4*)r->dev->sun_color.p + r->dev->fc_slot;
+    c.has_ircache = p->ircache != nullptr;
+    if (p->ircache) { KJ_REQUIRE(!p->ircache->pending_irradiance_sum, "ircache sum-up pending (ircache.rs:67 assert)"); c.irc = p->ircache->view(); } else { memset(&c.irc, 0, sizeof(c.irc)); }
+    c.ray_counters = (unsigned long long*)r->ray_counters.p;
+    c.ranking_tile = (const uint32_t*)r->ranking.p; c.scrambling_tile = (const uint32_t*)r->scrambling.p; c.sobol = (const uint32_t*)r->sobol.p;
+    c.reuse_rtdgi_rays = r->reuse_rtdgi_rays ? 1u : 0u;
+    const size_t trace_lds = size_t(c.sc.bvh.stack_entries) * 64 * 4;
+    KJ_REQUIRE(trace_lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");
+
+    hipLaunchKernelGGL(k_rtr_extract_half, gh, blk, 0, s, fc, gbuffer, depth, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh));
+    KJ_CHECK_LAUNCH();
+    if (mask & KJ_RTR_PASS_TRACE) {
+        hipLaunchKernelGGL(k_rtr_trace, gh, blk, trace_lds, s, c, refl0, refl1, refl2, img<uint32_t>(rng_out, hw, hh));
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & KJ_RTR_PASS_VALIDATE) {
+        KJ_TRY_HIP(hipMemsetAsync(invalidity, 0, HB, s));
+        const int qw = (hw + 1) / 2, qh = (hh + 1) / 2;
+        hipLaunchKernelGGL(k_rtr_validate, dim3((qw + 7) / 8, (qh + 7) / 8), blk, trace_lds, s, c, img<float4>(ray_orig_hist, hw, hh), img<uint2>(ray_hist, hw, hh), img<uint32_t>(rng_hist, hw, hh),
+                           img<uint2>(irradiance_hist, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint8_t>(invalidity, hw, hh), qw, qh);
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & KJ_RTR_PASS_RESTIR_TEMPORAL) {
+        RtrTemporalArgs a;
+        a.fc = fc; a.gbuffer_tex = gbuffer; a.half_view_normal_tex = img<uint32_t>(half_view_normal, hw, hh); a.depth_tex = depth;
+        a.candidate0_tex = refl0; a.candidate1_tex = refl1; a.candidate2_tex = refl2;
+        a.irradiance_history_tex = img<uint2>(irradiance_hist, hw, hh); a.ray_orig_history_tex = img<float4>(ray_orig_hist, hw, hh); a.ray_history_tex = img<uint2>(ray_hist, hw, hh);
+        a.rng_history_tex = img<uint32_t>(rng_hist, hw, hh); a.reservoir_history_tex = img<uint2>(reservoir_hist, hw, hh);
+        a.reprojection_tex = reprojection; a.hit_normal_history_tex = img<uint2>(hit_normal_hist, hw, hh);
+        a.irradiance_out_tex = img<uint2>(irradiance_out, hw, hh); a.ray_orig_output_tex = img<float4>(ray_orig_out, hw, hh); a.ray_output_tex = img<uint2>(ray_out, hw, hh);
+        a.rng_output_tex = img<uint32_t>(rng_out, hw, hh); a.hit_normal_output_tex = img<uint2>(hit_normal_out, hw, hh); a.reservoir_out_tex = img<uint2>(reservoir_out, hw, hh);
+        hipLaunchKernelGGL(k_rtr_restir_temporal, gh, blk, 0, s, a);
+        KJ_CHECK_LAUNCH();
+    }
+    if (mask & KJ_RTR_PASS_RESOLVE) {
+        RtrResolveArgs a;
+        a.fc = fc; a.gbuffer_tex = gbuffer; a.depth_tex = depth; a.hit1_tex = refl1; a.reprojection_tex = reprojection;
+        a.half_view_normal_tex = img<uint32_t>(half_view_normal, hw, hh); a.ray_len_history_tex = img<uint32_t>(ray_len_hist, W, H);
+        a.restir_irradiance_tex = img<uint2>(irradiance_out, hw, hh); a.restir_ray_tex = img<uint2>(ray_out, hw, hh); a.restir_reservoir_tex = img<uint2>(reservoir_out, hw, hh);
+        a.restir_ray_orig_tex = img<float4>(ray_orig_out, hw, hh);
+        a.output_tex = img<uint32_t>(resolved, W, H); a.ray_len_output_tex = img<uint32_t>(ray_len_out, W, H);
+        a.blue_noise = (const uint32_t*)r->dev->blue_noise.p; a.brdf_fg_lut = (const uint2*)r->dev->brdf_fg_lut.p;
+        hipLaunchKernelGGL(k_rtr_resolve, gf, blk, 0, s, a);
+        KJ_CHECK_LAUNCH();
+    }
+    r->resolved_tex = resolved; r->temporal_output_tex = temporal_out; r->history_tex = temporal_hist; r->ray_len_tex = ray_len_out; r->refl_restir_invalidity_tex = invalidity;
+    return KJ_OK;
+}
+
+KjStatus kj_rtr_filter_temporal(KjRtr* r, const KjRtrParams* p, const void** out_resolved, void* stream_) {
+    if (KjStatus st = rtr_check_params(r, p)) return st;
+    KJ_REQUIRE(r->resolved_tex && int(p->gbuffer_depth.width) == r->W && int(p->gbuffer_depth.height) == r->H, "kj_rtr_trace must run first with the same extent");
+    hipStream_t s = (hipStream_t)stream_;
+    const int W = r->W, H = r->H, hw = r->hw, hh = r->hh;
+    const FrameConstants* fc = r->dev->fc_dev;
+    const dim3 gf((W + 7) / 8, (H + 7) / 8), blk(64);
+    const ImgF32 depth = img<float>(p->gbuffer_depth.depth, W, H);
+    if (p->pass_mask & KJ_RTR_PASS_TEMPORAL_FILTER) {
+        hipLaunchKernelGGL(k_rtr_temporal_filter, gf, blk, 0, s, fc, img<uint32_t>(r->resolved_tex, W, H), img<uint2>(r->history_tex, W, H), depth, img<uint32_t>(r->ray_len_tex, W, H),
+                           img<uint2>(p->reprojection_map, W, H), img<uint8_t>(r->refl_restir_invalidity_tex, hw, hh), img<uint4>(p->gbuffer_depth.gbuffer, W, H),
+                           img<uint2>(r->temporal_output_tex, W, H));
+        KJ_CHECK_LAUNCH();
+    }
+    if (p->pass_mask & KJ_RTR_PASS_CLEANUP) {
+        hipLaunchKernelGGL(k_rtr_cleanup, gf, blk, 0, s, fc, img<uint2>(r->temporal_output_tex, W, H), depth, img<uint32_t>(p->gbuffer_depth.geometric_normal, W, H),
+                           img<uint32_t>(r->resolved_tex, W, H), (const int4*)r->offsets.p);
+        KJ_CHECK_LAUNCH();
+    }
+    if (out_resolved) *out_resolved = r->resolved_tex;
+    return KJ_OK;
+}
+
+KjStatus kj_rtr_surface(KjRtr* r, const char* name, void** out_dev_ptr, uint64_t* out_bytes) {
+    KJ_REQUIRE(r && name && out_dev_ptr && out_bytes, "null argument");
+    auto it = r->surf.find(name);
+    KJ_REQUIRE(it != r->surf.end(), "unknown surface");
+    *out_dev_ptr = it->second.p;
+    *out_bytes = it->second.bytes;
+    return KJ_OK;
+}
+
+KjStatus kj_rtr_ray_counts(KjRtr* r, uint64_t* out_closest, uint64_t* out_any) {
+    KJ_REQUIRE(r && out_closest && out_any, "null argument");
+    std::vector<uint64_t> h(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE);
+    KJ_TRY_HIP(hipMemcpy(h.data(), r->ray_counters.p, h.size() * 8, hipMemcpyDeviceToHost));
+    uint64_t a = 0, b = 0;
+    for (uint32_t i = 0; i < KJ_COUNTER_SLOTS; ++i) { a += h[i * KJ_COUNTER_STRIDE]; b += h[i * KJ_COUNTER_STRIDE + 1]; }
+    *out_closest = a; *out_any = b;
+    return KJ_OK;
+}
+
+} // extern "C"

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import numpy as np
 
-from .abi import (KjFrameConstants, KjMeshDesc, KjGbufferDepth, KjRtdgiRenderParams, KjRtdgiOutput, KjTaaOutput, KJ_RTDGI_PASS)
+from .abi import (KjFrameConstants, KjMeshDesc, KjGbufferDepth, KjRtdgiRenderParams, KjRtdgiOutput, KjTaaOutput, KJ_RTDGI_PASS, KjRtrTables, KjRtrParams)
 from . import scenes as kscenes
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -29,6 +29,7 @@ EXPORTS = [
     "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_light_gbuffer",
     "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_surface",
     "kj_baked_mesh_view", "kj_baked_image_view", "kj_baked_image_mip", "kj_baked_image_decode_rgba8",
+    "kj_rtr_create", "kj_rtr_destroy", "kj_rtr_set_options", "kj_rtr_trace", "kj_rtr_filter_temporal", "kj_rtr_surface", "kj_rtr_ray_counts",
 ]
 
 _LIB = None
@@ -95,6 +96,12 @@ def load():
         "kj_shadow_denoise_create": [vp, C.POINTER(vp)],
         "kj_shadow_denoise_render": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.POINTER(vp), vp],
         "kj_shadow_denoise_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
+        "kj_rtr_create": [vp, C.POINTER(KjRtrTables), C.POINTER(vp)],
+        "kj_rtr_set_options": [vp, u32],
+        "kj_rtr_trace": [vp, C.POINTER(KjRtrParams), vp],
+        "kj_rtr_filter_temporal": [vp, C.POINTER(KjRtrParams), C.POINTER(vp), vp],
+        "kj_rtr_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
+        "kj_rtr_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "kj_trace_sun_shadow_mask": [vp, vp, C.POINTER(KjGbufferDepth), vp, vp, vp],
         "kj_ssgi_create": [vp, C.POINTER(vp)],
         "kj_ssgi_render": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.POINTER(vp), vp],
@@ -106,7 +113,7 @@ def load():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = i32
-    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy", "kj_shadow_denoise_destroy"):
+    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy", "kj_shadow_denoise_destroy", "kj_rtr_destroy"):
         f = getattr(L, name)
         f.argtypes = [vp]
         f.restype = None
@@ -397,6 +404,51 @@ class GpuPipeline:
         check(self.L.kj_shadow_denoise_render(self.shadow_dn, C.byref(g), shadow_mask.data_ptr(), self.reprojection_map_ptr, C.byref(out), _stream_ptr()))
         return tensor_from_ptr(out.value, self.W * self.H * 4, self.torch.float16, (self.H, self.W, 2))
 
+    def rtr_params(self, pass_mask=63):
+        """KjRtrParams for RtrRenderer::trace / filter_temporal (world_render_passes.rs:172-210): the unconvolved sky cube, this
+        frame's rtdgi output and candidates (which the trace pass overwrites where the surface is smooth)."""
+        p = KjRtrParams()
+        p.gbuffer_depth = self.gbuffer_depth()
+        p.reprojection_map = self.reprojection_map_ptr
+        p.sky_cube = self.sky64.data_ptr()
+        p.sky_cube_width = 64
+        p.scene = self.scene.h
+        p.ircache = self.ircache
+        p.rtdgi_irradiance = self.out.screen_irradiance_tex
+        p.candidate_radiance_tex = self.out.candidate_radiance_tex
+        p.candidate_hit_tex = self.out.candidate_hit_tex
+        p.candidate_normal_tex = self.out.candidate_normal_tex
+        p.pass_mask = pass_mask
+        return p
+
+    def rtr_frame(self, pass_mask=63, tables=None):
+        """RtrRenderer::trace + TracedRtr::filter_temporal after rtdgi.render (same stream). Returns the resolved
+        B10G11R11_UFLOAT image as an int32 (H, W) tensor view. `tables`: KjRtrTables (default: rtr_tables.standin_tables())."""
+        if getattr(self, "rtr", None) is None:
+            if tables is None:
+                from . import rtr_tables
+                tables, self._rtr_keep = rtr_tables.standin_tables()
+            self.rtr = C.c_void_p()
+            check(self.L.kj_rtr_create(self.dev.h, C.byref(tables), C.byref(self.rtr)))
+        p = self.rtr_params(pass_mask)
+        s = _stream_ptr()
+        out = C.c_void_p()
+        if pass_mask & 15:
+            check(self.L.kj_rtr_trace(self.rtr, C.byref(p), s))
+        if pass_mask & 48:
+            check(self.L.kj_rtr_filter_temporal(self.rtr, C.byref(p), C.byref(out), s))
+        return self.rtr_surface("resolved_tex", self.torch.int32, (self.H, self.W))
+
+    def rtr_surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        check(self.L.kj_rtr_surface(self.rtr, name.encode(), C.byref(ptr), C.byref(n)))
+        return tensor_from_ptr(ptr.value, n.value, dtype, shape)
+
+    def rtr_ray_counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self.L.kj_rtr_ray_counts(self.rtr, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def shadow_denoise_surface(self, name, dtype, shape):
         ptr, n = C.c_void_p(), C.c_uint64()
         check(self.L.kj_shadow_denoise_surface(self.shadow_dn, name.encode(), C.byref(ptr), C.byref(n)))
@@ -492,6 +544,8 @@ class GpuPipeline:
                 self.L.kj_ssgi_destroy(self.ssgi)
             if getattr(self, "shadow_dn", None):
                 self.L.kj_shadow_denoise_destroy(self.shadow_dn)
+            if getattr(self, "rtr", None):
+                self.L.kj_rtr_destroy(self.rtr)
         except Exception:
             pass
 

@@ -279,6 +279,34 @@ def textured_test_scene(seed=11):
     return sd
 
 
+def glossy_test_scene():
+    """Reflection test scene: a mirror-like metal floor (roughness 0.08), a glossy dielectric wall (0.3), a rough wall (0.8, its
+    reflection rays come from rtdgi's candidates), an emissive box, two diffuse boxes and a smooth metal sphere."""
+    sd = SceneDesc()
+
+    def quad(p0, du, dv, n, mat):
+        P = np.array([p0, p0 + du, p0 + du + dv, p0 + dv], np.float32)
+        N = np.tile(np.asarray(n, np.float32)[None], (4, 1))
+        return TriangleMesh(P, N, np.array([0, 1, 2, 0, 2, 3], np.uint32), materials=[mat])
+    floor = dict(base_color=(0.95, 0.93, 0.88, 1), roughness=0.08, metalness=1.0, emissive=(0, 0, 0))
+    gloss = dict(base_color=(0.2, 0.35, 0.7, 1), roughness=0.3, metalness=0.0, emissive=(0, 0, 0))
+    rough = dict(base_color=(0.7, 0.7, 0.7, 1), roughness=0.8, metalness=0.0, emissive=(0, 0, 0))
+    sd.add_instance(sd.add_mesh(quad(np.array([-8.0, 0, -8.0]), np.array([0, 0, 16.0]), np.array([16.0, 0, 0]), (0, 1, 0), floor)), affine())
+    sd.add_instance(sd.add_mesh(quad(np.array([-8.0, 0, -6.0]), np.array([16.0, 0, 0]), np.array([0, 7.0, 0]), (0, 0, 1), gloss)), affine())
+    sd.add_instance(sd.add_mesh(quad(np.array([-6.0, 0, 8.0]), np.array([0, 0, -16.0]), np.array([0, 7.0, 0]), (1, 0, 0), rough)), affine())
+    bp, bn, bidx = _box((1.5, 1.5, 1.5))
+    lamp = TriangleMesh(bp, bn, bidx, materials=[dict(base_color=(0.8, 0.8, 0.8, 1), roughness=0.6, metalness=0.0, emissive=(6.0, 3.0, 1.0))])
+    red = TriangleMesh(bp, bn, bidx, materials=[dict(base_color=(0.8, 0.15, 0.1, 1), roughness=0.9, metalness=0.0, emissive=(0, 0, 0))])
+    sd.add_instance(sd.add_mesh(lamp), affine(scale=0.6, t=(2.0, 0.45, 1.5)))
+    ri = sd.add_mesh(red)
+    sd.add_instance(ri, affine(t=(-2.5, 0.75, -1.0)))
+    sd.add_instance(ri, affine(scale=0.5, t=(0.0, 0.375, 2.5)))
+    sp, sn, sidx = _sphere(32, 20, 1.2)
+    ball = TriangleMesh(sp, sn, sidx, materials=[dict(base_color=(1.0, 0.85, 0.55, 1), roughness=0.15, metalness=1.0, emissive=(0, 0, 0))])
+    sd.add_instance(sd.add_mesh(ball), affine(t=(0.5, 1.2, -2.5)))
+    return sd
+
+
 def procedural_city(target_tris=1_000_000, seed=1234, n_instances=64):
     """Stand-in for `battle.ron` (asset missing): 8 meshes (boxes + tessellated
     spheres) x 64 instances over a rolling ground, ~target_tris triangles, 32 emissive triangles."""

@@ -7,6 +7,7 @@
 #include "okj_reference_pt.hpp"
 #include "okj_ssgi.hpp"
 #include "okj_shadow_denoise.hpp"
+#include "okj_rtr.hpp"
 #include <cstdio>
 #include <chrono>
 #ifdef _OPENMP
@@ -417,5 +418,70 @@ uint64_t okj_reference_path_trace(const void* scene, const KjFrameConstants* fc,
     if (mpl) in.max_path_length = uint32_t(atoi(mpl));
     return reference_path_trace(*(const FrameConstants*)fc, in, (f4*)output, w, h);
 }
+
+// ---- rtr (RtrRenderer, renderers/rtr.rs). params hold HOST pointers; params->scene / ircache are okj handles.
+struct OkjRtr {
+    Rtr r;
+    std::vector<uint8_t> blue_noise;
+    std::vector<h4> brdf_lut;
+    std::vector<uint32_t> ranking, scrambling, sobol;
+    std::vector<int32_t> offsets;
+};
+void* okj_rtr_create(const uint8_t* blue_noise_rgba8_256, const void* brdf_fg_lut, const KjRtrTables* t) {
+    OkjRtr* o = new OkjRtr();
+    o->blue_noise.assign(blue_noise_rgba8_256, blue_noise_rgba8_256 + 256 * 256 * 4);
+    o->brdf_lut.resize(64 * 64);
+    if (brdf_fg_lut) memcpy(o->brdf_lut.data(), brdf_fg_lut, 64 * 64 * 8);
+    else build_brdf_fg_lut(o->brdf_lut.data());
+    o->ranking.assign(t->ranking_tile, t->ranking_tile + 128 * 128 * 8);
+    o->scrambling.assign(t->scrambling_tile, t->scrambling_tile + 128 * 128 * 8);
+    o->sobol.assign(t->sobol, t->sobol + 256 * 256);
+    o->offsets.assign(t->spatial_resolve_offsets, t->spatial_resolve_offsets + 16 * 4 * 8 * 4);
+    return o;
+}
+void okj_rtr_destroy(void* p) { delete (OkjRtr*)p; }
+void okj_rtr_set_options(void* p, uint32_t reuse_rtdgi_rays) { ((OkjRtr*)p)->r.reuse_rtdgi_rays = reuse_rtdgi_rays != 0; }
+static RtrInputs okj_rtr_inputs(OkjRtr* o, const KjFrameConstants* fc, const KjRtrParams* params) {
+    RtrInputs in;
+    const int W = params->gbuffer_depth.width, H = params->gbuffer_depth.height, hw = (W + 1) / 2, hh = (H + 1) / 2;
+    in.W = W; in.H = H;
+    in.geometric_normal = ImgU32((void*)params->gbuffer_depth.geometric_normal, W, H);
+    in.gbuffer = ImgU4((void*)params->gbuffer_depth.gbuffer, W, H);
+    in.depth = ImgR32F((void*)params->gbuffer_depth.depth, W, H);
+    in.reprojection_map = ImgRGBA16S((void*)params->reprojection_map, W, H);
+    in.sky_cube = (const h4*)params->sky_cube;
+    in.sky_cube_width = params->sky_cube_width;
+    in.scene = (const Scene*)params->scene;
+    in.blue_noise = o->blue_noise.data();
+    in.brdf_fg_lut = o->brdf_lut.data();
+    in.rtdgi_irradiance = ImgRGBA16F((void*)params->rtdgi_irradiance, W, H);
+    in.refl0_tex = ImgRGBA16F(params->candidate_radiance_tex, hw, hh);
+    in.refl1_tex = ImgRGBA16F(params->candidate_hit_tex, hw, hh);
+    in.refl2_tex = ImgU32(params->candidate_normal_tex, hw, hh);
+    in.ranking_tile = o->ranking.data(); in.scrambling_tile = o->scrambling.data(); in.sobol = o->sobol.data();
+    in.spatial_resolve_offsets = o->offsets.data();
+    if (params->ircache) {
+        Ircache* ic = (Ircache*)params->ircache;
+        in.ircache_lookup = [ic, fc](f3 from, f3 pt, f3 n, uint32_t rank, bool stochastic, uint32_t& rng) { return ic->lookup(*fc, from, pt, n, rank, rng, false, stochastic); };
+    }
+    return in;
+}
+void okj_rtr_trace(void* p, const KjFrameConstants* fc, const KjRtrParams* params) {
+    OkjRtr* o = (OkjRtr*)p;
+    o->r.trace(*fc, okj_rtr_inputs(o, fc, params), params->pass_mask);
+}
+const void* okj_rtr_filter_temporal(void* p, const KjFrameConstants* fc, const KjRtrParams* params) {
+    OkjRtr* o = (OkjRtr*)p;
+    return o->r.filter_temporal(*fc, okj_rtr_inputs(o, fc, params), params->pass_mask).p;
+}
+int okj_rtr_surface(void* p, const char* name, void** out_ptr, uint64_t* out_bytes) {
+    OkjRtr* o = (OkjRtr*)p;
+    auto it = o->r.surf.find(name);
+    if (it == o->r.surf.end()) return 1;
+    *out_ptr = it->second.data();
+    *out_bytes = it->second.size();
+    return 0;
+}
+void okj_rtr_ray_counts(void* p, uint64_t* closest, uint64_t* any) { *closest = ((OkjRtr*)p)->r.rays_closest.load(); *any = ((OkjRtr*)p)->r.rays_any.load(); }
 
 } // extern "C"

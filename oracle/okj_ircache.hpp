@@ -162,13 +162,15 @@ struct Ircache {
         return R0 * (a + (1.0f - a) * (p + 1.0f) * powf(q, p));
     }
     struct LookupMaybeAllocate { bool found; uint32_t entry_idx; IrcacheVertex proposal; bool just_allocated; };
-    LookupMaybeAllocate lookup_maybe_allocate(const FrameConstants& fc, f3 query_from_ws, f3 pt_ws, f3 normal_ws, uint32_t query_rank, uint32_t& rng) {
+    LookupMaybeAllocate lookup_maybe_allocate(const FrameConstants& fc, f3 query_from_ws, f3 pt_ws, f3 normal_ws, uint32_t query_rank, uint32_t& rng, bool stochastic_interpolation = false) {
         bool allocated_by_us = false, just_allocated = false;
         // `select(stochastic_interpolation, float3(hash1_mut(rng)...) - 0.5, 0)` (lookup.hlsl:87-93): select() is a
         // function, so its arguments are evaluated and the rng advances three times even though
         // stochastic interpolation is never enabled on this path; the jitter itself is zero.
-        hash1_mut(rng); hash1_mut(rng); hash1_mut(rng);
-        const f3 jitter = mk3(0.0f);
+        // stochastic interpolation is never enabled on the rtdgi path; rtr enables it for wide ray cones (reflection_trace_common.inc.hlsl:212-220).
+        f3 jitter;
+        jitter.x = uint_to_u01_float(hash1_mut(rng)) - 0.5f; jitter.y = uint_to_u01_float(hash1_mut(rng)) - 0.5f; jitter.z = uint_to_u01_float(hash1_mut(rng)) - 0.5f;
+        if (!stochastic_interpolation) jitter = mk3(0.0f);
         {
             const Coord rc = ws_pos_to_ircache_coord(fc, pt_ws, normal_ws, jitter);
             const int32_t* so = fc.ircache_cascades[rc.cascade].voxels_scrolled_this_frame;
@@ -213,8 +215,8 @@ struct Ircache {
         return res;
     }
     // `precise` = IRCACHE_LOOKUP_PRECISE (defined by the ircache's own trace/validate shaders)
-    f3 lookup(const FrameConstants& fc, f3 query_from_ws, f3 pt_ws, f3 normal_ws, uint32_t query_rank, uint32_t& rng, bool precise) {
-        const LookupMaybeAllocate lk = lookup_maybe_allocate(fc, query_from_ws, pt_ws, normal_ws, query_rank, rng);
+    f3 lookup(const FrameConstants& fc, f3 query_from_ws, f3 pt_ws, f3 normal_ws, uint32_t query_rank, uint32_t& rng, bool precise, bool stochastic_interpolation = false) {
+        const LookupMaybeAllocate lk = lookup_maybe_allocate(fc, query_from_ws, pt_ws, normal_ws, query_rank, rng, stochastic_interpolation);
         if (lk.just_allocated) return mk3(0.0f);
         f3 irradiance_sum = mk3(0.0f);
         if (lk.found) {

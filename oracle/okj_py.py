@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from kajiya_amd.abi import (KjFrameConstants, KjMeshDesc, KjRtdgiRenderParams, KjRtdgiOutput, KJ_RTDGI_PASS)  # noqa: E402
+from kajiya_amd.abi import (KjFrameConstants, KjMeshDesc, KjRtdgiRenderParams, KjRtdgiOutput, KJ_RTDGI_PASS, KjRtrTables, KjRtrParams)  # noqa: E402
 from kajiya_amd import scenes as kscenes  # noqa: E402
 
 _LIB = None
@@ -84,6 +84,13 @@ def lib():
         L.okj_taa_surface.restype = C.c_int
         L.okj_taa_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_trace_sun_shadow_mask.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.okj_rtr_create.restype = C.c_void_p; L.okj_rtr_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(KjRtrTables)]
+        L.okj_rtr_destroy.argtypes = [C.c_void_p]
+        L.okj_rtr_set_options.argtypes = [C.c_void_p, C.c_uint32]
+        L.okj_rtr_trace.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.POINTER(KjRtrParams)]
+        L.okj_rtr_filter_temporal.restype = C.c_void_p; L.okj_rtr_filter_temporal.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.POINTER(KjRtrParams)]
+        L.okj_rtr_surface.restype = C.c_int; L.okj_rtr_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.okj_rtr_ray_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.okj_light_gbuffer.argtypes = [C.POINTER(KjFrameConstants)] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.okj_shadow_denoise_create.restype = C.c_void_p
         L.okj_shadow_denoise_destroy.argtypes = [C.c_void_p]
@@ -302,6 +309,52 @@ class OraclePipeline:
             raise KeyError(name)
         buf = (C.c_uint8 * n.value).from_address(ptr.value)
         return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def rtr_params(self, pass_mask=63):
+        """KjRtrParams for RtrRenderer::trace / filter_temporal (world_render_passes.rs:172-210): the unconvolved sky cube, this
+        frame's rtdgi output and candidates."""
+        p = KjRtrParams()
+        p.gbuffer_depth.geometric_normal = self.geometric_normal.ctypes.data
+        p.gbuffer_depth.gbuffer = self.gbuffer.ctypes.data
+        p.gbuffer_depth.depth = self.depth.ctypes.data
+        p.gbuffer_depth.width, p.gbuffer_depth.height = self.W, self.H
+        p.reprojection_map = self.reprojection_map.ctypes.data
+        p.sky_cube = self.sky64.ctypes.data
+        p.sky_cube_width = 64
+        p.scene = self.scene.h
+        p.ircache = self.L.okj_ircache_core(self.ircache) if self.ircache else None
+        p.rtdgi_irradiance = self.out.screen_irradiance_tex
+        p.candidate_radiance_tex = self.out.candidate_radiance_tex
+        p.candidate_hit_tex = self.out.candidate_hit_tex
+        p.candidate_normal_tex = self.out.candidate_normal_tex
+        p.pass_mask = pass_mask
+        return p
+
+    def rtr_frame(self, fc, pass_mask=63):
+        """RtrRenderer::trace + TracedRtr::filter_temporal after rtdgi.render; returns the resolved image as (H, W) uint32
+        (B10G11R11_UFLOAT)."""
+        if not hasattr(self, "rtr"):
+            from kajiya_amd import rtr_tables
+            t, self._rtr_keep = rtr_tables.standin_tables()
+            self.rtr = self.L.okj_rtr_create(self.bn.ctypes.data, brdf_lut().ctypes.data, C.byref(t))
+        p = self.rtr_params(pass_mask)
+        if pass_mask & 15:
+            self.L.okj_rtr_trace(self.rtr, C.byref(fc), C.byref(p))
+        if pass_mask & 48:
+            self.L.okj_rtr_filter_temporal(self.rtr, C.byref(fc), C.byref(p))
+        return self.rtr_surface("resolved_tex", np.uint32, (self.H, self.W))
+
+    def rtr_surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        if self.L.okj_rtr_surface(self.rtr, name.encode(), C.byref(ptr), C.byref(n)) != 0:
+            raise KeyError(name)
+        buf = (C.c_uint8 * n.value).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def rtr_ray_counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.L.okj_rtr_ray_counts(self.rtr, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def taa_surface(self, name, dtype, shape):
         ptr, n = C.c_void_p(), C.c_uint64()

@@ -11,9 +11,12 @@ FORMATS = {
     "half_ssao_tex": "r8s", "half_view_normal_tex": "rgba8s", "half_depth_tex": "r32f",
     "reprojected_history_tex": "rgba16f", "irradiance_output_tex": "rgba16f", "temporal_filtered_tex": "rgba16f",
     "spatial_filtered_tex": "rgba16f",
+    # rtr (renderers/rtr.rs:19-27,223-300)
+    "rtr.temporal": "rgba16f", "rtr.ray_len": "rg16f", "rtr.irradiance": "rgba16f", "rtr.ray_orig": "rtr_ray_orig", "rtr.ray": "rgba16f",
+    "rtr.reservoir": "reservoir", "rtr.rng": "u32", "rtr.hit_normal": "rgba16f", "refl_restir_invalidity_tex": "r8", "resolved_tex": "r11g11b10f",
 }
 FULL_RES = {"rtdgi.temporal2_var", "rtdgi.temporal2", "reprojected_history_tex", "irradiance_output_tex", "temporal_filtered_tex", "spatial_filtered_tex"}
-BYTES_PER_TEXEL = {"rgba16f": 8, "rgba32f": 16, "rg16f": 4, "reservoir": 8, "rgba8s": 4, "trp": 16, "r8": 1, "r8s": 1, "r32f": 4}
+BYTES_PER_TEXEL = {"r11g11b10f": 4, "u32": 4, "rtr_ray_orig": 16, "rgba16f": 8, "rgba32f": 16, "rg16f": 4, "reservoir": 8, "rgba8s": 4, "trp": 16, "r8": 1, "r8s": 1, "r32f": 4}
 
 
 def base_name(name):
@@ -54,6 +57,18 @@ def decode(raw_u8, fmt):
         px = (u[:, 0] & 0xffff).astype(np.float32)
         py = (u[:, 0] >> 16).astype(np.float32)
         return np.stack([px, py, mw[:, 0], mw[:, 1]], -1)
+    if fmt == "u32":       # exact-match data (rng seeds): compared as two 16-bit halves so float64 holds them exactly
+        u = raw.view(np.uint32).reshape(-1, 1)
+        return np.concatenate([(u & 0xffff).astype(np.float32), (u >> 16).astype(np.float32)], -1)
+    if fmt == "r11g11b10f":
+        u = raw.view(np.uint32).reshape(-1)
+        def uf(v, m):
+            return (v.astype(np.uint16) << (10 - m)).view(np.float16).astype(np.float32)
+        return np.stack([uf(u & 0x7ff, 6), uf((u >> 11) & 0x7ff, 6), uf(u >> 22, 5)], -1)
+    if fmt == "rtr_ray_orig":   # RtrRestirRayOrigin: xyz f32 + (roughness f16, frame_index_mod4 f16) packed in w
+        f = raw.view(np.float32).reshape(-1, 4)
+        w = raw.view(np.uint32).reshape(-1, 4)[:, 3:4].copy().view(np.float16).astype(np.float32).reshape(-1, 2)
+        return np.concatenate([f[:, :3], w], -1)
     if fmt == "trp":
         u = raw.view(np.uint32).reshape(-1, 4)
         depth = u[:, 0:1].copy().view(np.float32)

@@ -1,0 +1,102 @@
+"""GPU parity for the ray-traced reflections (RtrRenderer::trace + TracedRtr::filter_temporal): every pass in isolation on
+identical inputs against oracle/okj_rtr.hpp, and the free-running GPU path against the mirror-reflects-the-sky invariant."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity as P
+import test_gpu_parity as T
+import test_rtr_oracle as RO
+from kajiya_amd import scenes as S
+from kajiya_amd.abi import KJ_RTR_PASS
+
+pytestmark = pytest.mark.gpu
+
+RTR_PINGPONG = ["rtr.temporal", "rtr.ray_len", "rtr.irradiance", "rtr.ray_orig", "rtr.ray", "rtr.reservoir", "rtr.rng", "rtr.hit_normal"]
+RTR_NAMES = [n + s for n in RTR_PINGPONG for s in (":0", ":1")] + ["refl_restir_invalidity_tex", "resolved_tex"]
+CANDIDATES = ["candidate_radiance_tex", "candidate_hit_tex", "candidate_normal_tex"]
+RTR_PASS_ORDER = ["TRACE", "VALIDATE", "RESTIR_TEMPORAL", "RESOLVE", "TEMPORAL_FILTER", "CLEANUP"]
+
+
+def _oracle_rtr_state(op):
+    st = {n: op.rtr_surface(n, np.uint8, (-1,)).copy() for n in RTR_NAMES}
+    st.update({n: op.surface(n, np.uint8, (-1,)).copy() for n in CANDIDATES})
+    return st
+
+
+def _upload_rtr_state(gp, st, torch):
+    for n, raw in st.items():
+        t = gp.surface(n, torch.uint8, (-1,)) if n in CANDIDATES else gp.rtr_surface(n, torch.uint8, (-1,))
+        assert t.numel() == raw.size, (n, t.numel(), raw.size)
+        t.copy_(torch.from_numpy(raw))
+
+
+def _download_rtr_state(gp, torch):
+    return {n: (gp.surface(n, torch.uint8, (-1,)) if n in CANDIDATES else gp.rtr_surface(n, torch.uint8, (-1,))).cpu().numpy() for n in RTR_NAMES + CANDIDATES}
+
+
+@pytest.mark.parametrize("W,H", [(256, 160), (123, 77)])
+def test_rtr_per_pass_parity(gpu, oracle, device, W, H):
+    """Each of the six rtr passes on identical inputs: oracle rtdgi output / candidates and the oracle's rtr state are uploaded
+    before every pass. Second extent: odd sizes (ragged half- and quarter-res images, partial tiles)."""
+    import torch
+    desc = S.glossy_test_scene()
+    op, gp = T._make_pipelines(gpu, oracle, device, desc, W, H)
+    fcs = T._frame_constants(W, H, 7, "textured")
+    repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    worst = {}
+    for fi, fc in enumerate(fcs):
+        op.render_inputs(fc); op.reprojection(fc)
+        gp.dev.frame_begin(fc)
+        T._sync_inputs(op, gp, torch)
+        gp.sky64.copy_(torch.from_numpy(op.sky64.view(np.int16)))
+        repro_dev.copy_(torch.from_numpy(op.reprojection_map))
+        gp.reprojection_map_ptr = C.c_void_p(repro_dev.data_ptr())
+        op.rtdgi_frame(fc); gp.rtdgi_frame()
+        torch.cuda.synchronize()
+        T._upload_state(gp, T._oracle_surfaces(op), torch)          # identical rtdgi output + candidates
+        if fi < 4:
+            op.rtr_frame(fc); gp.rtr_frame()
+            torch.cuda.synchronize()
+            _upload_rtr_state(gp, _oracle_rtr_state(op), torch)
+            continue
+        for k, pname in enumerate(RTR_PASS_ORDER):
+            mask = KJ_RTR_PASS[pname] | (0 if k == 0 else KJ_RTR_PASS["KEEP"])
+            if k > 0:
+                _upload_rtr_state(gp, _oracle_rtr_state(op), torch)
+            op.rtr_frame(fc, mask); gp.rtr_frame(mask)
+            torch.cuda.synchronize()
+            ref, got = _oracle_rtr_state(op), _download_rtr_state(gp, torch)
+            for n in ref:
+                r = P.compare(got[n], ref[n], P.fmt_of(n))
+                key = (pname, P.base_name(n))
+                if key not in worst or r["rel_l2"] > worst[key]["rel_l2"]:
+                    worst[key] = r
+                assert r["rel_l2"] <= T.REL_L2_TOL or r["mismatch_frac"] <= T.MISMATCH_TOL, f"frame {fi} pass {pname} surface {n}: {r}"
+    for k, v in sorted(worst.items()):
+        if v["rel_l2"] > 0:
+            print(f"  {k[0]:>16s} {k[1]:<28s} rel_l2={v['rel_l2']:.2e} mismatch={v['mismatch_frac']:.2e}")
+
+
+def test_rtr_free_running_mirror_reflects_the_sky(gpu, oracle, device):
+    """The whole GPU frame (G-buffer, ircache, rtdgi, rtr) free-running for 12 frames: the mirror floor must resolve to the sky
+    radiance along the mirrored view direction, the image must be finite, and the ray budget must hold."""
+    import torch
+    W, H = 384, 240
+    desc = S.glossy_test_scene()
+    gp = gpu.GpuPipeline(device, gpu.Scene(device, desc), W, H, use_ircache=True)
+    fcs = T._frame_constants(W, H, 12, "textured")
+    for fc in fcs:
+        gp.frame(fc)
+        res = gp.rtr_frame()
+    torch.cuda.synchronize()
+    img = P.decode(res.cpu().numpy().view(np.uint8), "r11g11b10f").reshape(H, W, 3)
+    assert np.isfinite(img).all() and img.mean() > 0.05
+    osc = oracle.OracleScene(desc)
+    ratio = RO.mirror_vs_sky_ratio(osc, fcs[-1], gp.depth.cpu().numpy(), gp.sky64.cpu().numpy().view(np.uint16), img)
+    print("GPU rtr / sky on sky-reflecting mirror pixels: median %.3f p10 %.3f p90 %.3f (n=%d)" % (np.median(ratio), np.percentile(ratio, 10), np.percentile(ratio, 90), ratio.size))
+    assert 0.95 < np.median(ratio) < 1.06 and np.percentile(ratio, 10) > 0.85 and np.percentile(ratio, 90) < 1.3
+    closest, anyhit = gp.rtr_ray_counts()
+    hw, hh = (W + 1) // 2, (H + 1) // 2
+    assert 0 < closest <= hw * hh + ((hw + 1) // 2) * ((hh + 1) // 2) and anyhit <= 3 * closest, (closest, anyhit)
