@@ -6,7 +6,7 @@
 //
 // Where the reference leaves a result undefined this file picks the same value as the oracle (oracle/okj_rtr.hpp header):
 // the validate pass' partially written invalidity image is cleared first, a zero-length history ray is traced along +Z,
-// B10G11R11_UFLOAT stores round to nearest through fp16.
+// B10G11R11_UFLOAT stores round to nearest through fp16, resolve's sample-shadowing test ignores rounding-residue offsets.
 #include "kj_host.hpp"
 #include "kj_scene.hpp"
 #include "kj_reservoir.hpp"
@@ -558,7 +558,9 @@ __global__ void __launch_bounds__(64) k_rtr_resolve(RtrResolveArgs a) {
         const bool is_center_sample = sample_i == 8u;
         int sample_px_x, sample_px_y;
         {
-            const float ang = (float(sample_i) + ang_offset) * KJ_GOLDEN_ANGLE + (float(px_idx_in_quad) / 4.0f) * KJ_TAU;
+            // ang reaches several hundred radians (ulp 3e-5): a fused multiply-add here moves the tap by ~1e-4 px and flips which
+            // half-res pixel it lands in for ~0.5 % of the pixels, so the two roundings of the shader's expression are kept
+            const float ang = __fadd_rn(__fmul_rn(float(sample_i) + ang_offset, KJ_GOLDEN_ANGLE), (float(px_idx_in_quad) / 4.0f) * KJ_TAU);
             float sample_i_with_jitter = sample_radius_accum;
             if (is_center_sample) sample_i_with_jitter = contrib_accum.w > 1e-8f ? blue.y : 0.0f;
             else sample_i_with_jitter += blue.y;
@@ -604,7 +606,10 @@ __global__ void __launch_bounds__(64) k_rtr_resolve(RtrResolveArgs a) {
             rejection_bias *= exp2f(-fmaxf(0.3f, normal_vs.z) * depth_diff * depth_diff);
         }
         const V3 surface_offset = sample_origin_vs - refl_ray_origin_vs;
-        if (dot(center_to_hit_vs, normal_vs) * 0.2f / length(center_to_hit_vs) < dot(surface_offset, normal_vs) / length(surface_offset)) rejection_bias *= is_center_sample ? 1.0f : 0.0f;
+        // own half-res sample: the offset is a rounding residue (0/0 or a random direction in the shader) -> no rejection, as in the oracle
+        const float surface_offset_len = length(surface_offset);
+        if (surface_offset_len > 1e-5f * eye_to_surf_dist &&
+            dot(center_to_hit_vs, normal_vs) * 0.2f / length(center_to_hit_vs) < dot(surface_offset, normal_vs) / surface_offset_len) rejection_bias *= is_center_sample ? 1.0f : 0.0f;
         const BrdfValue spec = specular_evaluate(lb.roughness, lb.spec_albedo, wo, wi);
         const float spec_weight = spec.pdf * stepf(0.0f, wi.z);
         float contrib_wt = 0.0f;

@@ -13,6 +13,8 @@
 //    whatever the pooled image held): cleared to 0 at the start of each frame here.
 //  * reflection_validate normalises a zero vector where no history exists yet (first frames): the ray is traced along +Z.
 //  * B10G11R11_UFLOAT stores: round to nearest (ties up) through fp16, negative -> 0 (okj::pack_r11g11b10f).
+//  * resolve's approximate sample shadowing divides by the length of (sample origin - pixel origin), which for the pixel's own
+//    half-res sample is 0 or a 1-ulp rounding residue (NaN / random direction in the shader): residues count as zero = no rejection.
 #pragma once
 #include "okj_rtdgi.hpp"
 #include "okj_taa.hpp"
@@ -596,7 +598,12 @@ struct Rtr {
                         rejection_bias *= exp2f(-fmaxf(0.3f, normal_vs.z) * depth_diff * depth_diff);
                     }
                     const f3 surface_offset = sample_origin_vs - refl_ray_origin_vs;
-                    if (dot(center_to_hit_vs, normal_vs) * 0.2f / length(center_to_hit_vs) < dot(surface_offset, normal_vs) / length(surface_offset))
+                    // For the pixel that IS the half-res sample, surface_offset is the rounding residue of (origin - eye) + eye: exactly zero
+                    // gives the shader 0/0 = NaN (comparison false, no rejection), a 1-ulp residue gives it a random direction. Residues are
+                    // treated as zero (see the header): real neighbours are >= a pixel footprint (~4e-3 x distance) apart.
+                    const float surface_offset_len = length(surface_offset);
+                    if (surface_offset_len > 1e-5f * eye_to_surf_dist &&
+                        dot(center_to_hit_vs, normal_vs) * 0.2f / length(center_to_hit_vs) < dot(surface_offset, normal_vs) / surface_offset_len)
                         rejection_bias *= is_center_sample ? 1.0f : 0.0f;
                     const BrdfValue spec = specular_brdf.evaluate(wo, wi);
                     const float spec_weight = spec.pdf * step(0.0f, wi.z);

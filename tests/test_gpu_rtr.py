@@ -1,6 +1,7 @@
 """GPU parity for the ray-traced reflections (RtrRenderer::trace + TracedRtr::filter_temporal): every pass in isolation on
 identical inputs against oracle/okj_rtr.hpp, and the free-running GPU path against the mirror-reflects-the-sky invariant."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -45,7 +46,7 @@ def test_rtr_per_pass_parity(gpu, oracle, device, W, H):
     op, gp = T._make_pipelines(gpu, oracle, device, desc, W, H)
     fcs = T._frame_constants(W, H, 7, "textured")
     repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
-    worst = {}
+    worst, failures = {}, []
     for fi, fc in enumerate(fcs):
         op.render_inputs(fc); op.reprojection(fc)
         gp.dev.frame_begin(fc)
@@ -73,10 +74,18 @@ def test_rtr_per_pass_parity(gpu, oracle, device, W, H):
                 key = (pname, P.base_name(n))
                 if key not in worst or r["rel_l2"] > worst[key]["rel_l2"]:
                     worst[key] = r
-                assert r["rel_l2"] <= T.REL_L2_TOL or r["mismatch_frac"] <= T.MISMATCH_TOL, f"frame {fi} pass {pname} surface {n}: {r}"
+                ok = r["rel_l2"] <= T.REL_L2_TOL or r["mismatch_frac"] <= T.MISMATCH_TOL
+                if P.fmt_of(n) == "r11g11b10f":   # one-step rounding flips are expected (see parity.RTOL); they must stay rare and unbiased
+                    ok = r["mismatch_frac"] <= T.MISMATCH_TOL and r["differ_frac"] <= 0.03
+                if not ok:
+                    failures.append(f"frame {fi} pass {pname} surface {n}: {r}")
+                    if os.environ.get("KJ_TEST_DUMP"):   # debugging aid: arrays of the first failing surface, written next to the gpurun logs
+                        os.makedirs("gpurun_out", exist_ok=True)
+                        np.savez(f"gpurun_out/rtr_dbg_{W}_{fi}_{pname}.npz", got=got[n], ref=ref[n], gbuffer=op.gbuffer, depth=op.depth, name=n)
     for k, v in sorted(worst.items()):
         if v["rel_l2"] > 0:
-            print(f"  {k[0]:>16s} {k[1]:<28s} rel_l2={v['rel_l2']:.2e} mismatch={v['mismatch_frac']:.2e}")
+            print(f"  {k[0]:>16s} {k[1]:<28s} rel_l2={v['rel_l2']:.2e} mismatch={v['mismatch_frac']:.2e} differ={v['differ_frac']:.2e}")
+    assert not failures, "\n".join(failures[:12])
 
 
 def test_rtr_free_running_mirror_reflects_the_sky(gpu, oracle, device):
