@@ -387,7 +387,7 @@ KjStatus kj_shadow_denoise_surface(KjShadowDenoise* s, const char* name, void** 
  * bindless_set, debug_shading_mode, debug_show_wrc)   renderers/deferred.rs:6-60, shaders/light_gbuffer.hlsl:60-260 — the deferred
  * combine: sun light through the shadow mask + emissive + diffuse GI * albedo * transmission (+ specular when rtr_tex is given) and
  * the sky / sun disc where depth == 0. shadow_mask = the raw R8_UNORM mask of kj_trace_sun_shadow_mask or (shadow_mask_is_rg16f) the RG16F
- * image of kj_shadow_denoise_render; rtr_tex RGBA16F or NULL (black); rtdgi_tex RGBA16F; outputs RGBA16F
+ * image of kj_shadow_denoise_render; rtr_tex B10G11R11_UFLOAT (the image kj_rtr_filter_temporal returns) or NULL (black); rtdgi_tex RGBA16F; outputs RGBA16F
  * (`out_temporal` is the image kajiya keeps as next frame's prev_radiance). debug_shading_mode 0-4 as in the shader (5 = ircache
  * view and the wrc overlay: KJ_ERR_UNSUPPORTED). */
 KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gbuffer_depth, const void* shadow_mask, uint32_t shadow_mask_is_rg16f, const void* rtr_tex,

@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(64) k_trace_any(SceneView sc, const float4* __
 // Debug shading modes 0-4 as in the shader; mode 5 (ircache view) and the wrc overlay are not built.
 struct LightGbufferArgs {
     const FrameConstants* __restrict__ fc;
-    Img<uint4> gbuffer_tex; Img<float> depth_tex; Img<uint8_t> shadow_mask_tex; Img<uint32_t> shadow_mask_rg16f; Img<uint2> rtr_tex; Img<uint2> rtdgi_tex;
+    Img<uint4> gbuffer_tex; Img<float> depth_tex; Img<uint8_t> shadow_mask_tex; Img<uint32_t> shadow_mask_rg16f; Img<uint32_t> rtr_tex; Img<uint2> rtdgi_tex;
     Img<uint2> temporal_output_tex, output_tex;
     const uint2* __restrict__ unconvolved_sky_cube; int sky_width;
     const uint2* __restrict__ brdf_fg_lut;
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(64) k_light_gbuffer(LightGbufferArgs a) {
     V3 gi_irradiance = v3(0.0f);
     if (a.debug_shading_mode != 4u) gi_irradiance = xyz(ld4(a.rtdgi_tex, x, y));
     total_radiance += gi_irradiance * brdf.diff_albedo * brdf.preintegrated_transmission_fraction;
-    const V3 rtr = a.rtr_tex.p ? xyz(ld4(a.rtr_tex, x, y)) : v3(0.0f);
+    const V3 rtr = a.rtr_tex.p ? unpack_r11g11b10f(a.rtr_tex.ld(x, y)) : v3(0.0f);
     if (a.debug_shading_mode != 4u) {
         V3 rtr_radiance = rtr * brdf.preintegrated_reflection;
         if (a.debug_shading_mode == 1u) {
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(64) k_sun_shadow_mask(const FrameConstants* __
 
 extern "C" {
 
-// light_gbuffer (renderers/deferred.rs:6-60; shaders/light_gbuffer.hlsl): shadow_mask R8_UNORM (raw) or RG16F (.x, denoised), rtr_tex RGBA16F or NULL (= black),
+// light_gbuffer (renderers/deferred.rs:6-60; shaders/light_gbuffer.hlsl): shadow_mask R8_UNORM (raw) or RG16F (.x, denoised), rtr_tex B10G11R11_UFLOAT (kj_rtr_filter_temporal's output) or NULL (= black),
 // rtdgi_tex RGBA16F, unconvolved_sky_cube 6 x w x w RGBA16F; outputs RGBA16F.
 KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gd, const void* shadow_mask, uint32_t shadow_mask_is_rg16f, const void* rtr_tex, const void* rtdgi_tex,
                           const void* unconvolved_sky_cube, uint32_t sky_cube_width, void* out_temporal, void* out, uint32_t debug_shading_mode, void* stream) {
@@ -279,7 +279,7 @@ KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gd, const void* s
     a.fc = dev->fc_dev;
     a.gbuffer_tex = img<uint4>(gd->gbuffer, W, H); a.depth_tex = img<float>(gd->depth, W, H); a.shadow_mask_tex = img<uint8_t>(shadow_mask_is_rg16f ? nullptr : shadow_mask, W, H);
     a.shadow_mask_rg16f = img<uint32_t>(shadow_mask_is_rg16f ? shadow_mask : nullptr, W, H);
-    a.rtr_tex = img<uint2>(rtr_tex, W, H); a.rtdgi_tex = img<uint2>(rtdgi_tex, W, H);
+    a.rtr_tex = img<uint32_t>(rtr_tex, W, H); a.rtdgi_tex = img<uint2>(rtdgi_tex, W, H);
     a.temporal_output_tex = img<uint2>(out_temporal, W, H); a.output_tex = img<uint2>(out, W, H);
     a.unconvolved_sky_cube = (const uint2*)unconvolved_sky_cube; a.sky_width = int(sky_cube_width);
     a.brdf_fg_lut = (const uint2*)dev->brdf_fg_lut.p;

@@ -309,6 +309,22 @@ KJ_HD V4 linear_rgb_to_crunched_luma_chroma(V4 v) {
 }
 KJ_HD V4 crunched_luma_chroma_to_linear_rgb(V4 v) { return v4(YCbCr_to_sRGB(xyz(v) * v.x), v.w); }
 
+// B10G11R11_UFLOAT_PACK32 (rtr's resolved image): r bits 0..10 (5e6m), g 11..21, b 22..31 (5e5m); stores round to nearest through fp16
+#ifdef __HIPCC__
+KJ_D uint32_t f32_to_ufloat(float v, int mant_bits) {              // see okj::f32_to_ufloat
+    if (!(v > 0.0f)) return 0u;
+    const uint32_t h = uint32_t(f32_to_f16(v)) & 0x7fffu;
+    const int drop = 10 - mant_bits;
+    const uint32_t r = (h + (1u << (drop - 1))) >> drop;
+    const uint32_t max_finite = (30u << mant_bits) | ((1u << mant_bits) - 1u);
+    if (h >= 0x7c00u) return 31u << mant_bits;
+    return r > max_finite ? max_finite : r;
+}
+KJ_D float ufloat_to_f32(uint32_t v, int mant_bits) { return f16_to_f32(uint16_t(v << (10 - mant_bits))); }
+KJ_D uint32_t pack_r11g11b10f(V3 c) { return f32_to_ufloat(c.x, 6) | (f32_to_ufloat(c.y, 6) << 11) | (f32_to_ufloat(c.z, 5) << 22); }
+KJ_D V3 unpack_r11g11b10f(uint32_t p) { return V3{ufloat_to_f32(p & 0x7ffu, 6), ufloat_to_f32((p >> 11) & 0x7ffu, 6), ufloat_to_f32(p >> 22, 5)}; }
+#endif
+
 // ---- device ray counters: one atomic per wave per ray query. All waves hammering ONE address serialise in L2 (measured: 10 %
 // of the trace kernel), so the counters are striped over KJ_COUNTER_SLOTS cache lines picked by workgroup id; readers sum them.
 #define KJ_COUNTER_SLOTS 64u

@@ -37,19 +37,6 @@ typedef Img<float4> ImgF4;
     const bool in_image = x < (W_) && y < (H_);
 
 // ------------------------------------------------------------------ small device helpers
-KJ_D uint32_t f32_to_ufloat(float v, int mant_bits) {              // see okj::f32_to_ufloat
-    if (!(v > 0.0f)) return 0u;
-    const uint32_t h = uint32_t(f32_to_f16(v)) & 0x7fffu;
-    const int drop = 10 - mant_bits;
-    const uint32_t r = (h + (1u << (drop - 1))) >> drop;
-    const uint32_t max_finite = (30u << mant_bits) | ((1u << mant_bits) - 1u);
-    if (h >= 0x7c00u) return 31u << mant_bits;
-    return r > max_finite ? max_finite : r;
-}
-KJ_D float ufloat_to_f32(uint32_t v, int mant_bits) { return f16_to_f32(uint16_t(v << (10 - mant_bits))); }
-KJ_D uint32_t pack_r11g11b10f(V3 c) { return f32_to_ufloat(c.x, 6) | (f32_to_ufloat(c.y, 6) << 11) | (f32_to_ufloat(c.z, 5) << 22); }
-KJ_D V3 unpack_r11g11b10f(uint32_t p) { return V3{ufloat_to_f32(p & 0x7ffu, 6), ufloat_to_f32((p >> 11) & 0x7ffu, 6), ufloat_to_f32(p >> 22, 5)}; }
-
 KJ_D V3 get_prev_eye_position(const FrameConstants& fc) { const V4 e = mul44(fc.view_constants.prev_view_to_prev_world, V4{0, 0, 0, 1}); return xyz(e) / e.w; }
 KJ_D V3 position_world_to_view(const FrameConstants& fc, V3 v) { return xyz(mul44(fc.view_constants.world_to_view, v4(v, 1))); }
 KJ_D float depth_to_view_z(const FrameConstants& fc, float depth) { return 1.0f / (depth * -fc.view_constants.clip_to_view[11]); }

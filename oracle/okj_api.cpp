@@ -315,7 +315,7 @@ void okj_light_gbuffer(const KjFrameConstants* fcp, const void* brdf_fg_lut, con
                        const void* sky_cube, int sky_w, void* out_temporal, void* out, uint32_t w, uint32_t h, uint32_t mode) {
     const FrameConstants& fc = *fcp;
     ImgU4 gbuffer_tex((void*)gbuffer, w, h); ImgR32F depth_tex((void*)depth, w, h); ImgR8 shadow_tex((void*)shadow_mask_r8, w, h);
-    ImgRGBA16F rtr_tex((void*)rtr, w, h), rtdgi_tex((void*)rtdgi, w, h), tout(out_temporal, w, h), oout(out, w, h);
+    ImgU32 rtr_tex((void*)rtr, w, h); ImgRGBA16F rtdgi_tex((void*)rtdgi, w, h), tout(out_temporal, w, h), oout(out, w, h);
     const h4* lut = (const h4*)brdf_fg_lut;
     const f3 sun_dir = sun_direction(fc);
     const f3 sun_col = sun_color_in_direction(fc, sun_dir);
@@ -352,7 +352,7 @@ void okj_light_gbuffer(const KjFrameConstants* fcp, const void* brdf_fg_lut, con
             f3 gi = mk3(0.0f);
             if (mode != 4) gi = xyz(unpack_rgba16f(rtdgi_tex.ld(x, y)));
             total += gi * brdf.diffuse_brdf.albedo * brdf.energy_preservation.preintegrated_transmission_fraction;
-            const f3 r = rtr ? xyz(unpack_rgba16f(rtr_tex.ld(x, y))) : mk3(0.0f);
+            const f3 r = rtr ? unpack_r11g11b10f(rtr_tex.ld(x, y)) : mk3(0.0f);
             if (mode != 4) {
                 f3 rr = r * brdf.energy_preservation.preintegrated_reflection;
                 if (mode == 1) rr = rr / LayeredBrdf::from_gbuffer_ndotv(lut, true_g, wo.z).energy_preservation.preintegrated_reflection;

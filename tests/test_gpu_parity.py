@@ -348,9 +348,10 @@ def test_light_gbuffer(gpu, oracle, device, mode):
     shadow = op.sun_shadow_mask(fc)
     gi = op.surface("spatial_filtered_tex", np.float16, (H, W, 4)).copy()
     rng = np.random.RandomState(5)
-    rtr = rng.uniform(0, 2, size=(H, W, 4)).astype(np.float16)
+    # rtr input: B10G11R11_UFLOAT texels with random mantissas and exponents 8..16 (values ~ 0.008 .. 4)
+    rtr = ((rng.randint(8 << 6, 17 << 6, size=(H, W)) | (rng.randint(8 << 6, 17 << 6, size=(H, W)) << 11) | (rng.randint(8 << 5, 17 << 5, size=(H, W)) << 22)).astype(np.uint32))
     ref_t, ref_o = op.light_gbuffer(fc, shadow, gi, rtr, mode)
-    d_shadow, d_gi, d_rtr = torch.from_numpy(shadow).cuda(), torch.from_numpy(gi.view(np.int16)).cuda(), torch.from_numpy(rtr.view(np.int16)).cuda()
+    d_shadow, d_gi, d_rtr = torch.from_numpy(shadow).cuda(), torch.from_numpy(gi.view(np.int16)).cuda(), torch.from_numpy(rtr.view(np.int32)).cuda()
     got_t, got_o = gp.light_gbuffer(d_shadow, rtdgi_ptr=d_gi.data_ptr(), rtr_ptr=d_rtr.data_ptr(), debug_shading_mode=mode)
     torch.cuda.synchronize()
     for name, a, b in (("temporal_output", got_t, ref_t), ("output", got_o, ref_o)):
