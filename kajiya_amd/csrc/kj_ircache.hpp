@@ -85,9 +85,10 @@ KJ_HD uint32_t irc_cascade_idx(V3 local_pos, uint32_t reserved_cells) {
     return uint32_t(clampf(ceilf(fmaxf(0.0f, cascade_float)), 0.0f, float(IRC_CASCADE_COUNT - 1u)));
 }
 struct IrcCoord { uint32_t x, y, z, cascade; };
+template <bool JITTER = false>
 KJ_HD IrcCoord irc_ws_pos_to_coord(const FrameConstants& fc, V3 pos, V3 normal, V3 jitter = V3{0.0f, 0.0f, 0.0f}) {
     const V3 center{fc.ircache_grid_center[0], fc.ircache_grid_center[1], fc.ircache_grid_center[2]};
-    {   // stochastic interpolation (ircache_grid.hlsl:51-56); a no-op for zero jitter (every caller but rtr's wide-cone lookups)
+    if (JITTER) {   // stochastic interpolation (ircache_grid.hlsl:51-56); compiled out for every caller but rtr's lookups
         const uint32_t c0 = irc_cascade_idx(pos - center, 1u);
         pos = pos + (IRC_GRID_CELL_DIAMETER * float(1u << c0)) * jitter;
     }
@@ -112,15 +113,20 @@ KJ_D float irc_eval_sh_geometrics(float4 sh, V3 normal) {
 }
 
 // IrcacheLookupParams::lookup (lookup.hlsl:76-311). PRECISE = IRCACHE_LOOKUP_PRECISE.
-template <bool PRECISE>
+// STOCHASTIC: the caller may ask for stochastic interpolation (rtr only); otherwise the jitter code is compiled out.
+template <bool PRECISE, bool STOCHASTIC = false>
 KJ_D V3 ircache_lookup(const IrcacheView& ic, const FrameConstants& fc, V3 query_from_ws, V3 pt_ws, V3 normal_ws, uint32_t query_rank, uint32_t& rng,
                        bool stochastic_interpolation = false) {
     bool allocated_by_us = false, just_allocated = false;
     // select(stochastic_interpolation, float3(hash1_mut x3) - 0.5, 0): both arms are evaluated => rng advances 3x
-    V3 jitter;
-    jitter.x = uint_to_u01_float(hash1_mut(rng)) - 0.5f; jitter.y = uint_to_u01_float(hash1_mut(rng)) - 0.5f; jitter.z = uint_to_u01_float(hash1_mut(rng)) - 0.5f;
-    if (!stochastic_interpolation) jitter = v3(0.0f);
-    const IrcCoord rc = irc_ws_pos_to_coord(fc, pt_ws, normal_ws, jitter);
+    V3 jitter = v3(0.0f);
+    if (STOCHASTIC) {
+        jitter.x = uint_to_u01_float(hash1_mut(rng)) - 0.5f; jitter.y = uint_to_u01_float(hash1_mut(rng)) - 0.5f; jitter.z = uint_to_u01_float(hash1_mut(rng)) - 0.5f;
+        if (!stochastic_interpolation) jitter = v3(0.0f);
+    } else {
+        hash1_mut(rng); hash1_mut(rng); hash1_mut(rng);
+    }
+    const IrcCoord rc = irc_ws_pos_to_coord<STOCHASTIC>(fc, pt_ws, normal_ws, jitter);
     const uint32_t cell = irc_cell_idx(rc.x, rc.y, rc.z, rc.cascade);
     {
         const int32_t* so = fc.ircache_cascades[rc.cascade].voxels_scrolled_this_frame;

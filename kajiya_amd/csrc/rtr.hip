@@ -177,7 +177,7 @@ KJ_D RtrTraceResult rtr_trace_ray(const RtrCtx& c, float roughness, uint32_t& rn
             }
             if (c.has_ircache) {
                 const float cone_width = ray_cone.propagate(0.0f, primary_hit.ray_t).width;
-                const V3 gi = ircache_lookup<false>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng, cone_width < 0.1f);
+                const V3 gi = ircache_lookup<false, true>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng, cone_width < 0.1f);
                 total_radiance += gi * gbuffer.albedo;
             }
         }
@@ -798,6 +798,15 @@ struct KjRtr {
     // TracedRtr (rtr.rs:74-80)
     void *resolved_tex = nullptr, *temporal_output_tex = nullptr, *history_tex = nullptr, *ray_len_tex = nullptr, *refl_restir_invalidity_tex = nullptr;
     hipError_t err = hipSuccess;
+    // reflection trace and reflection validate are independent (new candidates vs. last frame's reservoirs) and both latency-bound:
+    // validate runs on a side stream, forked after the frame's inputs are ready and joined before the temporal pass.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~KjRtr() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
+    }
 
     void* get(const std::string& name, size_t bytes, hipStream_t s) {
         kj::DevBuf& b = surf[name];
@@ -833,6 +842,9 @@ KjStatus kj_rtr_create(KjDevice* dev, const KjRtrTables* t, KjRtr** out) {
     if (e == hipSuccess) e = r->offsets.upload(t->spatial_resolve_offsets, 16 * 4 * 8 * 16);
     if (e == hipSuccess) e = r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8);
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);   // the tables are host memory owned by the caller
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) { delete r; set_last_error("kj_rtr_create: %s", hipGetErrorString(e)); return KJ_ERR_HIP; }
     *out = r;
     return KJ_OK;
@@ -901,19 +913,24 @@ KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* p, void* stream_) {
     const size_t trace_lds = size_t(c.sc.bvh.stack_entries) * 64 * 4;
     KJ_REQUIRE(trace_lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");
 
+    const bool fork = (mask & KJ_RTR_PASS_TRACE) && (mask & KJ_RTR_PASS_VALIDATE);
+    hipStream_t sv = fork ? r->side : s;
+    if (fork) { KJ_TRY_HIP(hipEventRecord(r->ev_fork, s)); KJ_TRY_HIP(hipStreamWaitEvent(r->side, r->ev_fork, 0)); }
+    if (mask & KJ_RTR_PASS_VALIDATE) {
+        KJ_TRY_HIP(hipMemsetAsync(invalidity, 0, HB, sv));
+        const int qw = (hw + 1) / 2, qh = (hh + 1) / 2;
+        hipLaunchKernelGGL(k_rtr_validate, dim3((qw + 7) / 8, (qh + 7) / 8), blk, trace_lds, sv, c, img<float4>(ray_orig_hist, hw, hh), img<uint2>(ray_hist, hw, hh), img<uint32_t>(rng_hist, hw, hh),
+                           img<uint2>(irradiance_hist, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint8_t>(invalidity, hw, hh), qw, qh);
+        KJ_CHECK_LAUNCH();
+    }
+    if (fork) KJ_TRY_HIP(hipEventRecord(r->ev_join, r->side));
     hipLaunchKernelGGL(k_rtr_extract_half, gh, blk, 0, s, fc, gbuffer, depth, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh));
     KJ_CHECK_LAUNCH();
     if (mask & KJ_RTR_PASS_TRACE) {
         hipLaunchKernelGGL(k_rtr_trace, gh, blk, trace_lds, s, c, refl0, refl1, refl2, img<uint32_t>(rng_out, hw, hh));
         KJ_CHECK_LAUNCH();
     }
-    if (mask & KJ_RTR_PASS_VALIDATE) {
-        KJ_TRY_HIP(hipMemsetAsync(invalidity, 0, HB, s));
-        const int qw = (hw + 1) / 2, qh = (hh + 1) / 2;
-        hipLaunchKernelGGL(k_rtr_validate, dim3((qw + 7) / 8, (qh + 7) / 8), blk, trace_lds, s, c, img<float4>(ray_orig_hist, hw, hh), img<uint2>(ray_hist, hw, hh), img<uint32_t>(rng_hist, hw, hh),
-                           img<uint2>(irradiance_hist, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint8_t>(invalidity, hw, hh), qw, qh);
-        KJ_CHECK_LAUNCH();
-    }
+    if (fork) KJ_TRY_HIP(hipStreamWaitEvent(s, r->ev_join, 0));
     if (mask & KJ_RTR_PASS_RESTIR_TEMPORAL) {
         RtrTemporalArgs a;
         a.fc = fc; a.gbuffer_tex = gbuffer; a.half_view_normal_tex = img<uint32_t>(half_view_normal, hw, hh); a.depth_tex = depth;
