@@ -37,13 +37,15 @@ def _download_rtr_state(gp, torch):
     return {n: (gp.surface(n, torch.uint8, (-1,)) if n in CANDIDATES else gp.rtr_surface(n, torch.uint8, (-1,))).cpu().numpy() for n in RTR_NAMES + CANDIDATES}
 
 
-@pytest.mark.parametrize("W,H", [(256, 160), (123, 77)])
-def test_rtr_per_pass_parity(gpu, oracle, device, W, H):
+@pytest.mark.parametrize("W,H,reuse", [(256, 160, 1), (123, 77, 1), (160, 96, 0)])
+def test_rtr_per_pass_parity(gpu, oracle, device, W, H, reuse):
     """Each of the six rtr passes on identical inputs: oracle rtdgi output / candidates and the oracle's rtr state are uploaded
-    before every pass. Second extent: odd sizes (ragged half- and quarter-res images, partial tiles)."""
+    before every pass. Second extent: odd sizes (ragged half- and quarter-res images, partial tiles). Third: `reuse_rtdgi_rays`
+    off (rtr.rs:32: every pixel traces its own reflection ray, rough ones included)."""
     import torch
     desc = S.glossy_test_scene()
     op, gp = T._make_pipelines(gpu, oracle, device, desc, W, H)
+    set_reuse = None if reuse else (lambda: (op.L.okj_rtr_set_options(op.rtr, 0), gpu.check(gp.L.kj_rtr_set_options(gp.rtr, 0))))
     fcs = T._frame_constants(W, H, 7, "textured")
     repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
     worst, failures = {}, []
@@ -60,6 +62,8 @@ def test_rtr_per_pass_parity(gpu, oracle, device, W, H):
         if fi < 4:
             op.rtr_frame(fc); gp.rtr_frame()
             torch.cuda.synchronize()
+            if fi == 0 and set_reuse:
+                set_reuse()
             _upload_rtr_state(gp, _oracle_rtr_state(op), torch)
             continue
         for k, pname in enumerate(RTR_PASS_ORDER):
