@@ -3,7 +3,7 @@
 // quantised child boxes out (layout in kj_scene_types.hpp, traversal in kj_bvh.hpp).
 //
 //   1. binary BVH by binned SAH (16 bins x 3 axes, leaves of <= 4 triangles, median fallback);
-//   2. collapse to 4-wide: repeatedly open the child with the largest surface area;
+//   2. collapse to KJ_BVH_WIDTH-wide (4 or 8): repeatedly open the child with the largest surface area;
 //   3. quantise each child box to 8 bits per plane inside its parent's frame, rounding outwards and
 //      verifying with the exact decode the kernel uses (fma(q, scale, origin)), so a decoded box always
 //      contains the true one: traversal never loses a hit, and the triangles themselves stay fp32.
@@ -137,13 +137,14 @@ void build_bvh4(const std::vector<BvhTri>& world_tris, BuiltBvh& out) {
     };
     out.nodes.emplace_back();
     work.push_back({root, 0, 0});
+    constexpr int W = KJ_BVH_WIDTH;
     while (!work.empty()) {
         const Item it = work.back(); work.pop_back();
-        // gather up to 4 children by opening the largest inner child
-        uint32_t ch[4]; int nch = 0;
+        // gather up to W children by opening the inner child with the largest surface area
+        uint32_t ch[W]; int nch = 0;
         if (bn[it.bin].count > 0) ch[nch++] = it.bin;   // root is a leaf (tiny scene)
         else { ch[nch++] = bn[it.bin].left; ch[nch++] = bn[it.bin].right; }
-        while (nch < 4) {
+        while (nch < W) {
             int best = -1; float ba = -1.0f;
             for (int i = 0; i < nch; ++i)
                 if (bn[ch[i]].count == 0) { const float a = bn[ch[i]].box.half_area(); if (a > ba) { ba = a; best = i; } }
@@ -153,7 +154,7 @@ void build_bvh4(const std::vector<BvhTri>& world_tris, BuiltBvh& out) {
         }
         Box frame;
         for (int i = 0; i < nch; ++i) frame.grow(bn[ch[i]].box);
-        Bvh4Node node;
+        BvhNode node;
         memset(&node, 0, sizeof(node));
         float scale[3];
         for (int k = 0; k < 3; ++k) {
@@ -167,10 +168,20 @@ void build_bvh4(const std::vector<BvhTri>& world_tris, BuiltBvh& out) {
             node.exp8[k] = uint8_t(e + 127);
         }
         node.exp8[3] = uint8_t(nch);
-        uint32_t inner_children = 0;
-        for (int i = 0; i < 4; ++i) {
+        uint32_t child_ref[W];
+#if KJ_BVH_WIDTH == 8
+        node.child_base = uint32_t(out.nodes.size());
+        node.tri_base = uint32_t(out.tris.size());
+        uint32_t inner_rank = 0;
+#endif
+        for (int i = 0; i < W; ++i) {
             if (i >= nch) {  // empty slot: inverted box, never hit
+#if KJ_BVH_WIDTH == 8
+                node.meta[i] = 0xffu;
+#else
                 node.child[i] = 0xffffffffu;
+#endif
+                child_ref[i] = 0xffffffffu;
                 for (int k = 0; k < 3; ++k) { node.qlo[k][i] = 255; node.qhi[k][i] = 0; }
                 continue;
             }
@@ -184,20 +195,28 @@ void build_bvh4(const std::vector<BvhTri>& world_tris, BuiltBvh& out) {
                 while (hi < 255 && dec(uint32_t(hi), scale[k], node.origin[k]) < c.box.mx[k]) ++hi;
                 node.qlo[k][i] = uint8_t(lo); node.qhi[k][i] = uint8_t(hi);
             }
-            if (c.count > 0) node.child[i] = emit_leaf(c);
-            else {
-                node.child[i] = uint32_t(out.nodes.size());
+            if (c.count > 0) {
+                child_ref[i] = emit_leaf(c);
+#if KJ_BVH_WIDTH == 8
+                node.meta[i] = uint8_t(0x80u | ((c.count - 1) << 5) | ((child_ref[i] & 0x0fffffffu) - node.tri_base));
+#endif
+            } else {
+                child_ref[i] = uint32_t(out.nodes.size());
                 out.nodes.emplace_back();
-                ++inner_children;
+#if KJ_BVH_WIDTH == 8
+                node.meta[i] = uint8_t(inner_rank++);
+#endif
             }
+#if KJ_BVH_WIDTH != 8
+            node.child[i] = child_ref[i];
+#endif
         }
         // traversal pushes at most (children hit - 1) entries per visited node
         const uint32_t stack_here = it.stack_before + uint32_t(nch > 0 ? nch - 1 : 0);
         out.max_stack = std::max(out.max_stack, stack_here + 1);
         for (int i = 0; i < nch; ++i)
-            if (bn[ch[i]].count == 0) work.push_back({ch[i], node.child[i], stack_here});
+            if (bn[ch[i]].count == 0) work.push_back({ch[i], child_ref[i], stack_here});
         out.nodes[it.wide] = node;
-        (void)inner_children;
     }
 }
 

@@ -6,7 +6,7 @@
 namespace kj {
 
 struct BuiltBvh {
-    std::vector<Bvh4Node> nodes;   // node 0 is the root
+    std::vector<BvhNode> nodes;    // node 0 is the root (Bvh4Node or Bvh8Node, KJ_BVH_WIDTH)
     std::vector<BvhTri> tris;      // leaf order
     uint32_t max_stack = 1;        // upper bound of the traversal stack depth
 };

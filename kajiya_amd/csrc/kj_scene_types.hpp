@@ -18,6 +18,28 @@ struct Bvh4Node {
     uint8_t qhi[3][4];
     uint32_t pad[2];
 };
+// 80 B: 8-wide node (KJ_BVH_WIDTH 8). Same quantised child boxes; the children are stored contiguously so that one base index per kind
+// replaces the eight references: inner child i lives at node `child_base + rank`, leaf child i owns triangles from `tri_base + offset`.
+//   meta[i]: 0xff = empty; inner: rank among the inner children (0..7); leaf: 0x80 | (count - 1) << 5 | offset (<= 28: 8 leaves x 4 triangles)
+struct Bvh8Node {
+    float origin[3];
+    uint8_t exp8[4];        // [3] = number of children (they occupy slots 0..n-1)
+    uint32_t child_base, tri_base;
+    uint8_t meta[8];
+    uint8_t qlo[3][8];      // [axis][child]
+    uint8_t qhi[3][8];
+};
+static_assert(sizeof(Bvh8Node) == 80, "node size");
+#ifndef KJ_BVH_WIDTH
+#define KJ_BVH_WIDTH 4
+#endif
+#if KJ_BVH_WIDTH == 8
+typedef Bvh8Node BvhNode;
+#define KJ_BVH_NODE_F4 5
+#else
+typedef Bvh4Node BvhNode;
+#define KJ_BVH_NODE_F4 4
+#endif
 // 48 B: world-space triangle in leaf order
 struct BvhTri {
     float v0[3]; uint32_t world_id;
@@ -33,7 +55,7 @@ static_assert(sizeof(BvhTri) == 48, "tri size");
 #define KJ_BVH_SPILL_STACK 112u   // ... deeper entries spill to private (scratch) memory; builds needing more are rejected
 
 struct BvhView {
-    const F4* nodes;         // 4 x 16 B per node; node 0 is the root
+    const F4* nodes;         // KJ_BVH_NODE_F4 x 16 B per node; node 0 is the root
     const F4* tris;          // 3 x 16 B per tri
     uint32_t root;           // always 0 (kept for the C-ABI debug query)
     uint32_t stack_entries;  // per-lane LDS stack entries a tracing kernel must provide (KJ_BVH_LDS_STACK)

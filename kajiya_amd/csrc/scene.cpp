@@ -228,7 +228,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     KJ_TRY_HIP(s->d_tex_data.upload(s->tex_data.data(), s->tex_data.size(), stream));
     if (lights.empty()) lights.push_back(KjTriangleLight{});
     KJ_TRY_HIP(s->d_lights.upload(lights.data(), lights.size() * sizeof(KjTriangleLight), stream));
-    KJ_TRY_HIP(s->d_nodes.upload(b.nodes.data(), b.nodes.size() * sizeof(Bvh4Node), stream));
+    KJ_TRY_HIP(s->d_nodes.upload(b.nodes.data(), b.nodes.size() * sizeof(BvhNode), stream));
     KJ_TRY_HIP(s->d_tris.upload(b.tris.data(), b.tris.size() * sizeof(BvhTri), stream));
     KJ_TRY_HIP(hipStreamSynchronize(stream));  // host vectors go out of scope
     s->committed = true;
@@ -246,7 +246,7 @@ KjStatus kj_scene_stats(KjScene* s, uint32_t* out_tri_count, uint32_t* out_node_
     if (!s->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
     if (out_tri_count) *out_tri_count = s->tri_count;
     if (out_node_count) *out_node_count = s->node_count;
-    if (out_bvh_bytes) *out_bvh_bytes = uint64_t(s->node_count) * sizeof(Bvh4Node) + uint64_t(s->tri_count) * sizeof(BvhTri);
+    if (out_bvh_bytes) *out_bvh_bytes = uint64_t(s->node_count) * sizeof(BvhNode) + uint64_t(s->tri_count) * sizeof(BvhTri);
     return KJ_OK;
 }
 

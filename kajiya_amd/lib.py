@@ -13,7 +13,7 @@ from .abi import (KjFrameConstants, KjMeshDesc, KjGbufferDepth, KjRtdgiRenderPar
 from . import scenes as kscenes
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkajiya_amd.so")
+LIB_PATH = os.environ.get("KJ_AMD_LIB") or os.path.join(HERE, "libkajiya_amd.so")   # KJ_AMD_LIB: A/B a differently built library
 
 EXPORTS = [
     "kj_last_error", "kj_abi_version", "kj_device_create", "kj_device_destroy", "kj_device_brdf_lut",
