@@ -87,10 +87,17 @@ class LocalComm:
         self.ranks = list(range(n))
 
     def run(self, xfers, get_rows):
+        self.run_prepared(self.prepare(xfers, get_rows))
+
+    def prepare(self, xfers, get_rows):
+        """Resolve a transfer plan to (source rows, destination rows) tensor views once; the views stay valid as long as the surfaces do."""
+        return [(get_rows(src, a, b), get_rows(dst, a, b)) for (src, dst, a, b) in xfers]
+
+    def run_prepared(self, pairs):
         # snapshot sources first so that in-place updates of one rank cannot leak into another's copy
-        staged = [(dst, a, b, get_rows(src, a, b).clone()) for (src, dst, a, b) in xfers]
-        for dst, a, b, data in staged:
-            get_rows(dst, a, b).copy_(data)
+        staged = [src.clone() for src, _ in pairs]
+        for (_, dst), data in zip(pairs, staged):
+            dst.copy_(data)
 
 
 class DistComm:
@@ -102,6 +109,29 @@ class DistComm:
         self.dist, self.rank, self.n = dist, rank, world
         self.ranks = [rank]
         self.stage = stage_through_host
+
+    def prepare(self, xfers, get_rows):
+        """This rank's share of a transfer plan as [(is_send, rows view, peer)], in plan order (both ends of a pair enumerate the plan
+        identically, so sends and receives match up). Cached by the caller: per frame only the P2POp objects are rebuilt."""
+        if self.stage:
+            return ("staged", xfers, get_rows)
+        spec = []
+        for (src, dst, a, b) in xfers:
+            if src == self.rank:
+                spec.append((True, get_rows(src, a, b), dst))
+            elif dst == self.rank:
+                spec.append((False, get_rows(dst, a, b), src))
+        return spec
+
+    def run_prepared(self, spec):
+        if isinstance(spec, tuple) and spec and spec[0] == "staged":
+            return self.run(spec[1], spec[2])
+        if not spec:
+            return
+        d = self.dist
+        ops = [d.P2POp(d.isend if is_send else d.irecv, t, peer) for (is_send, t, peer) in spec]
+        for w in d.batch_isend_irecv(ops):
+            w.wait()
 
     def run(self, xfers, get_rows):
         ops, landing = [], []
@@ -148,6 +178,8 @@ class SplitRtdgi:
         self.taa_frames = 0
         self._views = {}
         self._plans = {}
+        self._params = {}
+        self._s = None
         self._side = None          # side stream state for pipelined ircache work
         self.on_ircache_traced = None
 
@@ -175,26 +207,34 @@ class SplitRtdgi:
         """items: [(surface name, halo rows or None)] -- ONE batched exchange for all of them (a single RCCL group:
         both ends enumerate (item, dst, src) in the same order, so per-pair send/recv order matches)."""
         key = tuple(items)
-        xfers = self._plans.get(key)
-        if xfers is None:
+        prepared = self._plans.get(key)
+        if prepared is None:
             xfers = []
             for name, halo in items:
                 res = "f" if name.startswith("TAA/") else SURF[name.split(":")[0]][1]
                 xfers += [(src, dst, (name, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H)]
-            self._plans[key] = xfers
-        self.comm.run(xfers, lambda r, na, b: self._rows_view(r, na[0], na[1], b))
+            # renderer surfaces keep their address for a given extent, so the row views can be resolved once per distinct item list
+            # (two per exchange point: the ping-pong suffixes alternate)
+            prepared = self.comm.prepare(xfers, lambda r, na, b: self._rows_view(r, na[0], na[1], b))
+            self._plans[key] = prepared
+        self.comm.run_prepared(prepared)
 
     def _grow(self, rank, rows):
         r0, r1 = self.strips[rank]
         return max(0, r0 - rows), min(self.H, r1 + rows)
 
     def _render(self, rank, mask, rows=None, spatial_select=0):
+        """One kj_rtdgi_render call. The parameter struct is built once per rank per frame (gi_frame) and only the pass mask, row range
+        and spatial-pass selector change between calls; the stream handle is looked up once per frame as well (host time per rank per
+        frame matters once the strips are small: scripts/split_host_overhead.py)."""
         gp = self.pipes[rank]
-        p = gp.params(mask)
-        if rows is not None:
-            p.row_begin, p.row_end = rows
+        p = self._params[rank]
+        p.pass_mask = mask
+        p.row_begin, p.row_end = rows if rows is not None else (0, 0)
         p.spatial_pass_select = spatial_select
-        klib.check(gp.L.kj_rtdgi_render(gp.rtdgi, C.byref(p), C.byref(gp.out), klib._stream_ptr()))
+        st = gp.L.kj_rtdgi_render(gp.rtdgi, C.byref(p), C.byref(gp.out), self._s)
+        if st != 0:
+            klib.check(st)
 
     def _ircache_head(self, gp, s):
         klib.check(gp.L.kj_ircache_prepare(gp.ircache, s))
@@ -240,6 +280,8 @@ class SplitRtdgi:
         out_sfx, hist_sfx = f":{self.frame % 2}", f":{1 - self.frame % 2}"
         M = self.motion_halo
         R = self.comm.ranks
+        self._s = klib._stream_ptr()
+        self._params = {r: self.pipes[r].params(0) for r in R}
         # ---- A
         items = []
         if self.frame > 0:
@@ -251,7 +293,7 @@ class SplitRtdgi:
             self._exchange(items)
         for r in R:
             gp = self.pipes[r]
-            s = klib._stream_ptr()
+            s = self._s
             if gp.ircache and not ircache_done:
                 self._ircache_head(gp, s)
             klib.check(gp.L.kj_rtdgi_reproject(gp.rtdgi, gp.reprojection_map_ptr, self.W, self.H, s))
@@ -297,17 +339,19 @@ class SplitRtdgi:
         input (taa/*.hlsl)."""
         import torch
         gi_out = "spatial_filtered_tex"
+        stream = klib._stream_ptr()
         # ---- I
         self._exchange([(gi_out, 1 + 24)])                   # filter_input runs on +-24 rows
         for r in self.comm.ranks:
             gp = self.pipes[r]
             r0, r1 = self.strips[r]
             inp = self._surface(r, gi_out).data_ptr()
+            depth_ptr = gp.depth.data_ptr()
 
             def run(mask, grow, keep=True):
                 a, b = max(0, r0 - grow), min(self.H, r1 + grow)
-                klib.check(gp.L.kj_taa_render_rows(gp.taa, inp, self.W, self.H, gp.reprojection_map_ptr, gp.depth.data_ptr(), self.W, self.H,
-                                                   C.byref(gp.taa_out), klib._stream_ptr(), mask | (KEEP if keep else 0), a, b))
+                klib.check(gp.L.kj_taa_render_rows(gp.taa, inp, self.W, self.H, gp.reprojection_map_ptr, depth_ptr, self.W, self.H,
+                                                   C.byref(gp.taa_out), stream, mask | (KEEP if keep else 0), a, b))
             run(1, 32, keep=False)         # reproject history (5-tap Catmull-Rom around uv + motion)
             run(2 | 4, 24)                 # filter input (+-1 input), filter history (+-1 reprojected history)
             run(8, 16)                     # input prob (+-2 deviation, +-1 filtered input / history)

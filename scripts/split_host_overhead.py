@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Host-side (Python + ctypes) cost per frame of the screen-tile split orchestrator, measured with N virtual ranks on one GPU:
-enqueue time without synchronisation vs GPU time. Per-rank cost in a real run ~= enqueue time / N."""
+enqueue time without synchronisation vs GPU time. Per-rank cost in a real run ~= enqueue time / N.
+usage: split_host_overhead.py N [WxH]  (at 1080p with many virtual ranks the one GPU is the bottleneck and back-pressures the enqueue;
+pass a small extent, e.g. 512x288, to read the host cost alone)"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import ctypes as C
@@ -8,6 +10,8 @@ import torch
 from kajiya_amd import lib, scenes, frame, multigpu
 
 W, H, N = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 2
+if len(sys.argv) > 2:   # a tiny extent makes the GPU side negligible, so the enqueue time is pure host (Python + ctypes + launch) cost
+    W, H = map(int, sys.argv[2].split("x"))
 dev = lib.Device(0)
 scene = lib.Scene(dev, scenes.procedural_city(target_tris=200_000, seed=1234))
 pipes = {r: lib.GpuPipeline(dev, scene, W, H, use_ircache=True) for r in range(N)}
