@@ -45,7 +45,30 @@ def generate():
     return out
 
 
+def generate_rtr():
+    """Reflections (oracle/okj_rtr.hpp) on the glossy test scene, 48x32, 5 frames, stand-in sampler tables (kajiya_amd/rtr_tables.py)."""
+    desc = scenes.glossy_test_scene()
+    W, H = 48, 32
+    op = okj_py.OraclePipeline(okj_py.OracleScene(desc), W, H)
+    fs = frame.FrameState((W, H))
+    for i in range(5):
+        fc = fs.prepare_frame_constants(frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=9.0, height=3.0, rate=0.01))
+        fs.retire_frame()
+        op.frame(fc)
+        res = op.rtr_frame(fc)
+    return {"resolved": res.copy(), "temporal": op.rtr_surface("rtr.temporal:0", np.uint16, (H, W, 4)).copy(),
+            "irradiance": op.rtr_surface("rtr.irradiance:0", np.uint16, (H // 2, W // 2, 4)).copy(),
+            "reservoir": op.rtr_surface("rtr.reservoir:0", np.uint32, (H // 2, W // 2, 2)).copy(),
+            "rng": op.rtr_surface("rtr.rng:0", np.uint32, (H // 2, W // 2)).copy(),
+            "ray_counts": np.array(op.rtr_ray_counts(), np.uint64)}
+
+
 if __name__ == "__main__":
+    r = generate_rtr()
+    path = os.path.join(ROOT, "tests", "golden", "oracle_rtr_glossy_48x32.npz")
+    np.savez_compressed(path, **r)
+    print("wrote", path, os.path.getsize(path), "bytes")
+    okj_py.lib().okj_set_threads(1)   # the ircache passes are order-dependent: one thread = deterministic (the test does the same)
     g = generate()
     path = os.path.join(ROOT, "tests", "golden", "oracle_cornell_32.npz")
     np.savez_compressed(path, **g)

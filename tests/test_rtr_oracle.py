@@ -126,3 +126,22 @@ def test_rtr_pass_by_pass_equals_whole_frame(oracle):
             np.testing.assert_array_equal(a.rtr_surface(n, np.uint8, (-1,)), b.rtr_surface(n, np.uint8, (-1,)), err_msg=n)
         for n in ("candidate_radiance_tex", "candidate_hit_tex", "candidate_normal_tex"):
             np.testing.assert_array_equal(a.surface(n, np.uint8, (-1,)), b.surface(n, np.uint8, (-1,)), err_msg=n)
+
+
+def test_rtr_oracle_matches_golden_vectors(oracle):
+    """tests/golden/oracle_rtr_glossy_48x32.npz (scripts/make_golden_vectors.py) pins the rtr restatement against silent changes
+    (it is the oracle's own output: the reference holds no vectors for this path)."""
+    import importlib.util, os
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    spec = importlib.util.spec_from_file_location("make_golden_vectors", os.path.join(root, "scripts", "make_golden_vectors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    got = mod.generate_rtr()
+    ref = np.load(os.path.join(root, "tests", "golden", "oracle_rtr_glossy_48x32.npz"))
+    assert np.array_equal(got["ray_counts"], ref["ray_counts"])
+    assert (got["rng"] != ref["rng"]).mean() < 0.01 and (got["reservoir"] != ref["reservoir"]).any(axis=-1).mean() < 0.01
+    for k in ("temporal", "irradiance"):
+        a, b = got[k].view(np.float16).astype(np.float32), ref[k].view(np.float16).astype(np.float32)
+        assert np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()) < 1e-3, k
+    r = P.compare(got["resolved"].view(np.uint8).reshape(-1), ref["resolved"].view(np.uint8).reshape(-1), "r11g11b10f")
+    assert r["mismatch_frac"] < 0.01, r
