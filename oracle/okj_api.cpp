@@ -484,4 +484,10 @@ int okj_rtr_surface(void* p, const char* name, void** out_ptr, uint64_t* out_byt
 }
 void okj_rtr_ray_counts(void* p, uint64_t* closest, uint64_t* any) { *closest = ((OkjRtr*)p)->r.rays_closest.load(); *any = ((OkjRtr*)p)->r.rays_any.load(); }
 
+// ws_pos_to_ircache_coord (ircache_grid.hlsl:40-80) for the property tests: out = {x, y, z, cascade}
+void okj_ircache_ws_pos_to_coord(const KjFrameConstants* fc, const float pos[3], const float normal[3], const float jitter[3], uint32_t out[4]) {
+    const Ircache::Coord c = Ircache::ws_pos_to_ircache_coord(*fc, f3{pos[0], pos[1], pos[2]}, f3{normal[0], normal[1], normal[2]}, f3{jitter[0], jitter[1], jitter[2]});
+    out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.cascade;
+}
+
 } // extern "C"

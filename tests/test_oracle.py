@@ -123,7 +123,7 @@ def test_ris_reservoir_is_unbiased(oracle):
 
 def test_bvh_matches_brute_force(oracle):
     from kajiya_amd import scenes
-    for desc, n in ((scenes.cornell_box(), 200000), (scenes.procedural_city(target_tris=6000, seed=3, n_instances=12), 30000)):
+    for desc, n in ((scenes.cornell_box(), 1000000), (scenes.procedural_city(target_tris=6000, seed=3, n_instances=12), 60000)):
         sc = oracle.OracleScene(desc)
         lo, hi = desc.bounds()
         rng = np.random.RandomState(5)
@@ -278,3 +278,65 @@ def test_oracle_ssgi_guide_is_sane(oracle):
         else:
             centre = ao[H // 2 - 6:H // 2 + 6, W // 2 - 6:W // 2 + 6].mean()     # back wall, open
             assert 0.4 < ao[m].mean() < 0.95 and ao[m].min() < 0.5 * centre
+
+
+def test_ircache_coord_round_trip_and_cascade_boundaries(oracle):
+    """ws_pos_to_ircache_coord (ircache/ircache_grid.hlsl:34-80) with the cascade constants of IrcacheRenderer::update_eye_position
+    (ircache.rs:126-158): the cascade is the smallest whose half extent minus the reserved cell holds the point; a cell's centre
+    maps back to the same coordinate; crossing a cascade boundary moves to the next cascade; moving the eye by whole cells keeps
+    world cells stable (coordinate shifts by the scroll); stochastic-interpolation jitter of +-0.5 cell stays within one cell."""
+    import ctypes as C
+    from kajiya_amd import frame
+    L = oracle.lib()
+    L.okj_ircache_ws_pos_to_coord.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 3 + [C.POINTER(C.c_uint32)]
+    CELL, SIZE, COUNT = 0.16 * 0.125, 32, 12
+
+    def consts(eye):
+        fs = frame.FrameState((64, 64)); fs.ircache_enabled = True
+        cam = frame.orbit_camera(0, (64, 64), center=(eye[0], eye[1], eye[2] - 6.0), radius=6.0, height=0.0, rate=0.0)   # eye = centre + (0, 0, radius)
+        fc = fs.prepare_frame_constants(cam)
+        np.testing.assert_allclose(list(fc.ircache_grid_center)[:3], eye, atol=1e-5)
+        return fc
+
+    def coord(fc, p, n=(0, 0, 0), j=(0, 0, 0)):
+        out = (C.c_uint32 * 4)()
+        L.okj_ircache_ws_pos_to_coord(C.byref(fc), (C.c_float * 3)(*p), (C.c_float * 3)(*n), (C.c_float * 3)(*j), out)
+        return tuple(out)
+    eye = np.array([1.3, -0.7, 2.9], np.float32)
+    fc = consts(eye)
+    rng = np.random.RandomState(4)
+    for _ in range(3000):
+        casc_true = rng.randint(0, COUNT)
+        d = CELL * (1 << casc_true)
+        # a point strictly inside cascade `casc_true`'s usable box and (for casc > 0) outside the previous one
+        half = (SIZE / 2 - 1) * CELL * (1 << casc_true) / d      # in cells of this cascade: 15
+        p_cells = rng.uniform(-half + 0.01, half - 0.01, size=3)
+        if casc_true > 0 and np.abs(p_cells).max() <= 7.5 + 0.01:   # inside the finer cascade's box (15 of its cells = 7.5 of ours)
+            p_cells[rng.randint(3)] = np.sign(rng.uniform(-1, 1)) * rng.uniform(7.6, half - 0.01)
+        p = eye + (p_cells * d).astype(np.float32)
+        x, y, z, c = coord(fc, p)
+        assert c == casc_true, (p_cells, c, casc_true)
+        org = np.array(list(fc.ircache_cascades[c].origin)[:3])
+        assert (org == np.floor(eye / d).astype(int) - SIZE // 2).all()
+        cell = np.floor(p / np.float32(d)).astype(int) - org
+        assert (np.array([x, y, z]) == np.clip(cell, 0, SIZE - 1)).all()
+        centre = ((np.array([x, y, z]) + org) + 0.5) * d
+        cm = np.abs((centre - eye) / d).max()
+        if not ((c == 0 or cm > 7.55) and cm < 14.95):
+            continue   # the boundary between two cascades' usable boxes cuts through this cell: its centre belongs to the other cascade
+        assert coord(fc, centre.astype(np.float32)) == (x, y, z, c)
+        # jitter up to half a cell moves at most one cell along each axis and never changes the cascade by more than one
+        xj, yj, zj, cj = coord(fc, centre.astype(np.float32), j=tuple(rng.uniform(-0.5, 0.5, size=3)))
+        assert abs(int(cj) - int(c)) <= 1
+        if cj == c:
+            assert max(abs(int(xj) - int(x)), abs(int(yj) - int(y)), abs(int(zj) - int(z))) <= 1
+    # the normal offsets the lookup by half a cell along the normal (IRCACHE_USE_NORMAL_BASED_CELL_OFFSET)
+    p = eye + np.array([3.25 * CELL, 0.25 * CELL, 0.25 * CELL], np.float32)
+    a, b = coord(fc, p), coord(fc, p, n=(1, 0, 0))
+    assert b[0] == a[0] + 1 or (p[0] / CELL) % 1 < 0.5
+    # scrolling: moving the eye by exactly 3 cells of cascade 2 shifts that cascade's coordinates by 3 and leaves the world cell the same
+    d2 = CELL * 4
+    fc2 = consts(eye + np.array([3 * d2, 0, 0], np.float32))
+    q = eye + np.array([2.3 * d2, -1.2 * d2, 0.4 * d2], np.float32) + np.array([8.5 * d2, 0, 0], np.float32)   # in cascade 2 for both eyes
+    c1, c2 = coord(fc, q), coord(fc2, q)
+    assert c1[3] == c2[3] == 2 and c1[0] - c2[0] == 3 and c1[1:3] == c2[1:3]
