@@ -1,0 +1,98 @@
+"""The C++ host mirror (include/kajiya_amd.hpp, examples/): frame constants must equal the Python mirror's (kajiya_amd/frame.py — both
+restate world_renderer.rs:1001-1129, camera.rs:66-125, view_constants.rs:25-121), and the compiled `world_render_passes` host must
+produce the same frame as the Python driver from the same baked scene files (GPU)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from kajiya_amd import frame
+from kajiya_amd.abi import KjFrameConstants
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EX = os.path.join(ROOT, "examples")
+
+
+def _build_examples():
+    if not os.path.exists(os.path.join(ROOT, "kajiya_amd", "libkajiya_amd.so")):
+        pytest.skip("libkajiya_amd.so not built")
+    subprocess.check_call(["make", "-s", "-C", EX])
+
+
+def test_cpp_frame_constants_match_python_mirror():
+    _build_examples()
+    W, H, N = 96, 64, 6
+    cam = dict(center=(0.0, 1.0, 0.0), radius=9.0, height=3.0, rate=0.01)
+    raw = subprocess.check_output([os.path.join(EX, "dump_frame_constants"), str(W), str(H), str(N), "0", "1", "0", "9", "3", "0.01"])
+    assert len(raw) == N * C.sizeof(KjFrameConstants) == N * 1216
+    fs = frame.FrameState((W, H))
+    mats = 11 * 64          # the eleven matrices of ViewConstants: double-precision camera maths rounded to f32 (numpy's BLAS and the plain
+    for i in range(N):      # C++ loops may differ in the last bit of a translation or of the four-matrix product clip_to_prev_clip)
+        ref = bytes(fs.prepare_frame_constants(frame.orbit_camera(i, (W, H), **cam)))
+        fs.retire_frame()
+        got = raw[i * 1216:(i + 1) * 1216]
+        assert got[mats:] == ref[mats:], i          # jitter, sun, frame index, exposure, overrides, ircache constants: bit-exact
+        ga, gb = np.frombuffer(got[:mats], np.float32), np.frombuffer(ref[:mats], np.float32)
+        c2pc = slice(6 * 16, 7 * 16)                  # clip_to_prev_clip = (P' V') (V^-1 P^-1): cancellation leaves ~1e-5 of noise in both mirrors
+        np.testing.assert_allclose(ga[c2pc], gb[c2pc], rtol=1e-5, atol=1e-4)
+        ga2, gb2 = np.delete(ga, np.r_[c2pc]), np.delete(gb, np.r_[c2pc])
+        np.testing.assert_allclose(ga2, gb2, rtol=2e-7, atol=2e-6)
+        assert (ga2 != gb2).mean() < 0.05
+
+
+@pytest.mark.gpu
+def test_cpp_world_render_passes_matches_python_driver(gpu, device, tmp_path):
+    """Bake the glossy test scene to kajiya's `.mesh` / `.image` format, render 8 frames with the compiled host
+    (examples/world_render_passes: mmap -> add_baked_mesh -> prepare_render_graph_standard) and with the Python driver: the GI image,
+    the reflections and the anti-aliased frame must agree (same kernels, same inputs; the only difference is clip_to_prev_clip's rounding
+    and the racy irradiance cache)."""
+    import torch
+    import baked_writer as BW
+    import parity as P
+    from kajiya_amd import rtr_tables, scenes as S
+    _build_examples()
+    W, H, N = 256, 160, 8
+    sd = S.glossy_test_scene()
+    lines = []
+    for mi, m in enumerate(sd.meshes):
+        mesh_bytes, images = BW.bake_triangle_mesh(m)
+        (tmp_path / f"m{mi}.mesh").write_bytes(mesh_bytes)
+        for ident, blob in images.items():
+            (tmp_path / f"{ident:8x}.image").write_bytes(blob)
+        lines.append(f"mesh m{mi}.mesh")
+    for mi, xf in sd.instances:
+        lines.append("instance %d %s" % (mi, " ".join(repr(float(v)) for v in np.asarray(xf, np.float32).reshape(-1))))
+    lines.append("camera 0 1 0 9 3 0.01")
+    (tmp_path / "scene.txt").write_text("\n".join(lines) + "\n")
+    t, (ranking, scrambling, sobol, offsets) = rtr_tables.standin_tables()
+    (tmp_path / "rtr_tables.bin").write_bytes(ranking.tobytes() + scrambling.tobytes() + sobol.tobytes() + offsets.tobytes())
+    bn = os.path.join(ROOT, "tests", "golden", "bluenoise_256_rgba8.bin")
+    out = subprocess.check_output([os.path.join(EX, "world_render_passes"), bn, str(tmp_path), str(W), str(H), str(N), str(tmp_path / "cpp")], timeout=300)
+    print(out.decode().strip())
+    # the Python driver, same pass order (scripts/render_frame.py)
+    gp = gpu.GpuPipeline(device, gpu.Scene(device, sd), W, H, use_ircache=True)
+    fs = frame.FrameState((W, H)); fs.ircache_enabled = True
+    for i in range(N):
+        fc = fs.prepare_frame_constants(frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=9.0, height=3.0, rate=0.01)); fs.retire_frame()
+        gp.render_inputs(fc); gp.reprojection()
+        gp.ssgi_frame()
+        shadow = gp.shadow_denoise(gp.sun_shadow_mask())
+        gp.gi_frame()
+        rtr = gp.rtr_frame()
+        lit_t, lit = gp.light_gbuffer(shadow, rtr_ptr=rtr.data_ptr())
+        gp.taa_frame(input_ptr=lit.data_ptr())
+    torch.cuda.synchronize()
+    ref = {"gi": gp.surface("spatial_filtered_tex", torch.uint8, (-1,)).cpu().numpy(), "rtr": rtr.cpu().numpy().view(np.uint8).reshape(-1),
+           "taa": gp.taa_surface("this_frame_output_img", torch.uint8, (-1,)).cpu().numpy(), "depth": gp.depth.cpu().numpy().view(np.uint8).reshape(-1)}
+    fmt = {"gi": "rgba16f", "rtr": "r11g11b10f", "taa": "rgba16f", "depth": "r32f"}
+    for k in ("depth", "gi", "rtr", "taa"):
+        got = np.fromfile(str(tmp_path / f"cpp_{k}.bin"), np.uint8)
+        r = P.compare(got, ref[k], fmt[k])
+        print(k, r)
+        if k == "depth":
+            assert r["mismatch_frac"] < 1e-3, r            # same G-buffer
+        else:
+            a, b = P.decode(got, fmt[k]).astype(np.float64), P.decode(ref[k], fmt[k]).astype(np.float64)
+            assert np.isfinite(a).all() and abs(a[..., :3].mean() / b[..., :3].mean() - 1.0) < 0.03 and r["rel_l2"] < 0.15, (k, r)
