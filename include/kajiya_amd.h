@@ -440,7 +440,7 @@ KjStatus kj_reference_path_trace(KjDevice* dev, const KjScene* scene, void* outp
  * kj_rtr_trace OVERWRITES the rtdgi candidate images where the surface is smooth (roughness <= 0.6, `reuse_rtdgi_rays`),
  * exactly as the reference aliases them (rtr.rs:112-116). Temporal state ("rtr.temporal", "rtr.ray_len", "rtr.irradiance",
  * "rtr.ray_orig", "rtr.ray", "rtr.reservoir", "rtr.rng", "rtr.hit_normal", each ":0"/":1") lives in the handle.
- * The world radiance cache (USE_WORLD_RADIANCE_CACHE 0 in the shader) and LightingRenderer::render_specular are not included.
+ * The world radiance cache (USE_WORLD_RADIANCE_CACHE 0 in the shader) is not included; LightingRenderer::render_specular is kj_rtr_render_specular_lights.
  * Output of kj_rtr_filter_temporal: the B10G11R11_UFLOAT full-res image light_gbuffer consumes.
  * --------------------------------------------------------------------------- */
 typedef struct KjRtr KjRtr;
@@ -475,6 +475,11 @@ KjStatus kj_rtr_create(KjDevice* dev, const KjRtrTables* tables, KjRtr** out);
 void kj_rtr_destroy(KjRtr* r);
 KjStatus kj_rtr_set_options(KjRtr* r, uint32_t reuse_rtdgi_rays);
 KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* params, void* stream);
+/* LightingRenderer::render_specular(&mut rtr.resolved_tex, rg, &GbufferDepth, bindless_set, tlas)   renderers/lighting.rs:23-88,
+ * shaders/lighting/{sample_lights.rgen, spatial_reuse_lights}.hlsl — specular from the triangle lights (one light sample + shadow ray per
+ * half-res pixel, 8-tap reuse), ADDED into the resolved image between kj_rtr_trace and kj_rtr_filter_temporal so both are filtered together
+ * (world_render_passes.rs:190-203). A no-op when the scene has no triangle lights, as in the reference. */
+KjStatus kj_rtr_render_specular_lights(KjRtr* r, const KjRtrParams* params, void* stream);
 KjStatus kj_rtr_filter_temporal(KjRtr* r, const KjRtrParams* params, const void** out_resolved_r11g11b10f, void* stream);
 KjStatus kj_rtr_surface(KjRtr* r, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 KjStatus kj_rtr_ray_counts(KjRtr* r, uint64_t* out_closest, uint64_t* out_any);

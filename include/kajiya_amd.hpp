@@ -323,6 +323,11 @@ inline TracedRtr RtrRenderer::trace(const GbufferDepth& g, const void* reproject
     return TracedRtr{h, p};
 }
 
+// LightingRenderer (renderers/lighting.rs): specular from the triangle lights, rendered into rtr's resolved image so both are filtered jointly
+struct LightingRenderer {
+    void render_specular(TracedRtr& rtr, hipStream_t s) { check(kj_rtr_render_specular_lights(rtr.h, &rtr.params, s), "kj_rtr_render_specular_lights"); }
+};
+
 struct TaaRenderer {
     KjTaa* h = nullptr;
     explicit TaaRenderer(Device& d) { check(kj_taa_create(d.h, &h), "kj_taa_create"); }
@@ -344,7 +349,7 @@ struct WorldRenderer {
     GbufferDepth gbuffer_depth;
     DeviceImage sky_cube, convolved_sky_cube, sun_shadow_mask, accum_img, debug_out_tex;
     ReprojectionRenderer reprojection; SsgiRenderer ssgi; ShadowDenoiseRenderer shadow_denoise; IrcacheRenderer ircache; RtdgiRenderer rtdgi;
-    RtrRenderer rtr; TaaRenderer taa;
+    RtrRenderer rtr; LightingRenderer lighting; TaaRenderer taa;
     FrameState frame_state;
     uint32_t debug_shading_mode = 0;
     float sky_key[8] = {-1, 0, 0, 0, 0, 0, 0, 0};
@@ -380,6 +385,7 @@ struct WorldRenderer {
         ircache_state.sum_up_irradiance_for_sampling(s);                                                        // :138-140
         o.rtdgi = rtdgi.render(gbuffer_depth, o.reprojection_map, convolved_sky_cube.p, 16, scene, &ircache_state, o.ssgi_tex, s);   // :145-163
         TracedRtr traced = rtr.trace(gbuffer_depth, o.reprojection_map, sky_cube.p, 64, scene, o.rtdgi, &ircache_state, s);        // :172-188
+        if (frame_state.triangle_light_count > 0) lighting.render_specular(traced, s);                          // :164-203 (any_triangle_lights)
         o.rtr = traced.filter_temporal(s);                                                                      // :205
         check(kj_light_gbuffer(device.h, &gd, o.denoised_shadow_mask, 1, o.rtr, o.rtdgi.screen_irradiance_tex, sky_cube.p, 64, accum_img.p, debug_out_tex.p,
                                debug_shading_mode, s), "kj_light_gbuffer");                                      // :219-234

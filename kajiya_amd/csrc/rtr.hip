@@ -787,6 +787,92 @@ __global__ void __launch_bounds__(64) k_rtr_cleanup(const FrameConstants* __rest
     output_tex.st(x, y, pack_r11g11b10f(v * v));
 }
 
+// ------------------------------------------------------------------ LightingRenderer::render_specular (renderers/lighting.rs:23-88)
+// sample_lights.rgen.hlsl:18-63: one triangle-light sample + shadow ray per half-res pixel
+__global__ void __launch_bounds__(64) k_lighting_sample_lights(const FrameConstants* __restrict__ fcp, SceneView sc, ImgF32 depth_tex, const uint32_t* __restrict__ blue_noise,
+                                                                ImgH4 out0_tex, ImgF4 out1_tex, ImgU32 out2_tex, unsigned long long* ray_counters) {
+    extern __shared__ uint32_t lds_stack[];
+    TILE_XY(out0_tex.w, out0_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+    const float depth = depth_tex.ld(hx, hy);
+    if (0.0f == depth) { st4(out0_tex, x, y, v4(0.0f)); return; }
+    const V2 uv = get_uv(float(hx), float(hy), tex_size4(depth_tex.w, depth_tex.h));
+    const ViewRay vr = view_ray_from_uv_and_depth(fc, uv, depth);
+    const V3 shadow_ray_origin = vr.biased_secondary_ray_origin_ws();
+    const V4 urand3 = blue_noise_for_pixel(blue_noise, uint32_t(x), uint32_t(y), fc.frame_index);
+    const uint32_t light_count = min(fc.triangle_light_count, sc.light_count);
+    const uint32_t light_idx = uint32_t(urand3.z * float(light_count)) % light_count;
+    const float light_choice_pmf = 1.0f / float(light_count);
+    const KjTriangleLight tl = sc.lights[light_idx];
+    const V3 v0{tl.verts[0], tl.verts[1], tl.verts[2]}, v1{tl.verts[3], tl.verts[4], tl.verts[5]}, v2{tl.verts[6], tl.verts[7], tl.verts[8]};
+    const LightSampleArea ls = sample_triangle_light(v0, v1 - v0, v2 - v0, V2{urand3.x, urand3.y});
+    const V3 to_light_ws = ls.pos - shadow_ray_origin;
+    const float dist_to_light = length(to_light_ws);
+    count_rays(ray_counters, 1, true);
+    const bool is_shadowed = rt_is_shadowed<false>(sc, shadow_ray_origin, to_light_ws / fmaxf(1e-8f, dist_to_light), 0.0f, dist_to_light - 1e-4f, lds_stack + lane, 64, nullptr);
+    st4(out0_tex, x, y, is_shadowed ? V4{0.0f, 0.0f, 0.0f, 1.0f} : V4{tl.radiance[0], tl.radiance[1], tl.radiance[2], 1.0f});
+    const V3 hit_vs = vr.hit_vs + direction_world_to_view(fc, to_light_ws);
+    out1_tex.st(x, y, make_float4(hit_vs.x, hit_vs.y, hit_vs.z, ls.pdf * light_choice_pmf));
+    out2_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, ls.normal), 0.0f)));
+}
+// spatial_reuse_lights.hlsl:33-168 (RENDER_INTO_RTR: the result is added to rtr's resolved image)
+__global__ void __launch_bounds__(64) k_lighting_spatial_reuse(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer_tex, ImgF32 depth_tex, ImgH4 hit0_tex, ImgF4 hit1_tex, ImgU32 hit2_tex,
+                                                                ImgU32 half_view_normal_tex, ImgF32 half_depth_tex, ImgU32 output_tex, const int4* __restrict__ spatial_resolve_offsets,
+                                                                const uint2* __restrict__ brdf_fg_lut) {
+    TILE_XY(output_tex.w, output_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const V4 ts = tex_size4(output_tex.w, output_tex.h);
+    const float depth = depth_tex.ld(x, y);
+    if (0.0f == depth) return;
+    const ViewRay vr = view_ray_from_uv_and_depth(fc, get_uv(float(x), float(y), ts), depth);
+    GbufferData g = gbuffer_unpack(gbuffer_tex.ld(x, y));
+    g.roughness = fmaxf(g.roughness, 3e-4f);
+    const Basis tangent_to_world = build_orthonormal_basis(g.normal);
+    V3 wo = to_local(tangent_to_world, -vr.dir_ws);
+    if (wo.z < 0.0f) { wo.z *= -0.25f; wo = normalize(wo); }
+    const LayeredBrdf lb = layered_brdf_from_gbuffer_ndotv(brdf_fg_lut, g, wo.z);
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const uint32_t px_idx_in_quad = ((uint32_t(x & 1) | uint32_t(y & 1) * 2u) + fc.frame_index) & 3u;
+    V4 contrib_accum = v4(0.0f);
+    const V3 normal_vs = direction_world_to_view(fc, g.normal);
+    for (uint32_t sample_i = 0; sample_i < 8u; ++sample_i) {
+        const int4 o = spatial_resolve_offsets[(px_idx_in_quad * 16u + sample_i) + 64u * 3u];
+        const int sx = x / 2 + o.x, sy = y / 2 + o.y;
+        const float sample_depth = half_depth_tex.ld(sx, sy);
+        const V4 packed0 = ld4(hit0_tex, sx, sy);
+        if (packed0.w != 0.0f && sample_depth != 0.0f) {
+            const ViewRay sr = view_ray_from_uv_and_depth(fc, get_uv(float(sx * 2 + off.x), float(sy * 2 + off.y), ts), sample_depth);
+            const V3 sample_origin_vs = sr.hit_vs;
+            const float4 packed1 = hit1_tex.ld(sx, sy);
+            float neighbor_sampling_pdf = packed1.w;
+            const V3 sample_hit_normal_vs = xyz(unpack_rgba8_snorm(hit2_tex.ld(sx, sy)));
+            const V3 center_to_hit_vs = V3{packed1.x, packed1.y, packed1.z} - lerp(vr.hit_vs, sample_origin_vs, 0.5f);
+            const V3 wi = normalize(to_local(tangent_to_world, direction_view_to_world(fc, center_to_hit_vs)));
+            const V3 sample_normal_vs = ld_nrm_snorm8(half_view_normal_tex, sx, sy);
+            float rejection_bias = 1.0f;
+            rejection_bias *= saturate((dot(normal_vs, sample_normal_vs) - 0.9f) / (0.999f - 0.9f));
+            rejection_bias *= exp2f(-10.0f * fabsf(depth / sample_depth - 1.0f));
+            {
+                const V3 surface_offset = sample_origin_vs - vr.hit_vs;
+                const float fraction_of_normal_direction_as_offset = dot(surface_offset, normal_vs) / length(surface_offset);   // 0/0 = NaN for the pixel's own sample: no rejection
+                if (wi.z > 0.0f && wi.z * 0.2f < fraction_of_normal_direction_as_offset) rejection_bias *= sample_i == 0u ? 1.0f : 0.0f;
+            }
+            const BrdfValue spec = specular_evaluate(lb.roughness, lb.spec_albedo, wo, wi);
+            const float center_to_hit_dist2 = dot(center_to_hit_vs, center_to_hit_vs);
+            const float to_psa_metric = fmaxf(0.0f, wi.z) * fmaxf(0.0f, dot(sample_hit_normal_vs, -normalize(center_to_hit_vs))) / center_to_hit_dist2;
+            neighbor_sampling_pdf /= to_psa_metric;
+            const V3 contrib_rgb = xyz(packed0) * spec.value * lb.preintegrated_reflection_mult * stepf(0.0f, wi.z) * (neighbor_sampling_pdf > 0.0f ? 1.0f / neighbor_sampling_pdf : 0.0f);
+            contrib_accum = contrib_accum + v4(contrib_rgb, 1.0f) * rejection_bias;
+        }
+    }
+    const V3 out_color = xyz(contrib_accum) / fmaxf(1e-8f, contrib_accum.w);
+    output_tex.st(x, y, pack_r11g11b10f(unpack_r11g11b10f(output_tex.ld(x, y)) + out_color));
+}
+
 // ------------------------------------------------------------------ host
 struct KjRtr {
     KjDevice* dev = nullptr;
@@ -955,6 +1041,34 @@ KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* p, void* stream_) {
         KJ_CHECK_LAUNCH();
     }
     r->resolved_tex = resolved; r->temporal_output_tex = temporal_out; r->history_tex = temporal_hist; r->ray_len_tex = ray_len_out; r->refl_restir_invalidity_tex = invalidity;
+    return KJ_OK;
+}
+
+KjStatus kj_rtr_render_specular_lights(KjRtr* r, const KjRtrParams* p, void* stream_) {
+    if (KjStatus st = rtr_check_params(r, p)) return st;
+    KJ_REQUIRE(r->resolved_tex && int(p->gbuffer_depth.width) == r->W && int(p->gbuffer_depth.height) == r->H, "kj_rtr_trace must run first with the same extent");
+    if (p->scene->light_count == 0 || r->dev->fc_host.triangle_light_count == 0) return KJ_OK;   // world_render_passes.rs:166-170,190: only with triangle lights
+    hipStream_t s = (hipStream_t)stream_;
+    const int W = r->W, H = r->H, hw = r->hw, hh = r->hh;
+    const FrameConstants* fc = r->dev->fc_dev;
+    const size_t HB = size_t(hw) * hh;
+    void* l0 = r->get("lighting.refl0_tex", HB * 8, s);
+    void* l1 = r->get("lighting.refl1_tex", HB * 16, s);
+    void* l2 = r->get("lighting.refl2_tex", HB * 4, s);
+    void* half_view_normal = r->get("half_view_normal_tex", HB * 4, s);
+    void* half_depth = r->get("half_depth_tex", HB * 4, s);
+    KJ_TRY_HIP(r->err);
+    const SceneView sc = scene_view(*p->scene);
+    const size_t trace_lds = size_t(sc.bvh.stack_entries) * 64 * 4;
+    const ImgF32 depth = img<float>(p->gbuffer_depth.depth, W, H);
+    const dim3 gh((hw + 7) / 8, (hh + 7) / 8), gf((W + 7) / 8, (H + 7) / 8), blk(64);
+    hipLaunchKernelGGL(k_lighting_sample_lights, gh, blk, trace_lds, s, fc, sc, depth, (const uint32_t*)r->dev->blue_noise.p, img<uint2>(l0, hw, hh), img<float4>(l1, hw, hh),
+                       img<uint32_t>(l2, hw, hh), (unsigned long long*)r->ray_counters.p);
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_lighting_spatial_reuse, gf, blk, 0, s, fc, img<uint4>(p->gbuffer_depth.gbuffer, W, H), depth, img<uint2>(l0, hw, hh), img<float4>(l1, hw, hh), img<uint32_t>(l2, hw, hh),
+                       img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), img<uint32_t>(r->resolved_tex, W, H), (const int4*)r->offsets.p,
+                       (const uint2*)r->dev->brdf_fg_lut.p);
+    KJ_CHECK_LAUNCH();
     return KJ_OK;
 }
 

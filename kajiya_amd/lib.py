@@ -29,7 +29,7 @@ EXPORTS = [
     "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_light_gbuffer",
     "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_surface",
     "kj_baked_mesh_view", "kj_baked_image_view", "kj_baked_image_mip", "kj_baked_image_decode_rgba8",
-    "kj_rtr_create", "kj_rtr_destroy", "kj_rtr_set_options", "kj_rtr_trace", "kj_rtr_filter_temporal", "kj_rtr_surface", "kj_rtr_ray_counts",
+    "kj_rtr_create", "kj_rtr_destroy", "kj_rtr_set_options", "kj_rtr_trace", "kj_rtr_render_specular_lights", "kj_rtr_filter_temporal", "kj_rtr_surface", "kj_rtr_ray_counts",
 ]
 
 _LIB = None
@@ -99,6 +99,7 @@ def load():
         "kj_rtr_create": [vp, C.POINTER(KjRtrTables), C.POINTER(vp)],
         "kj_rtr_set_options": [vp, u32],
         "kj_rtr_trace": [vp, C.POINTER(KjRtrParams), vp],
+        "kj_rtr_render_specular_lights": [vp, C.POINTER(KjRtrParams), vp],
         "kj_rtr_filter_temporal": [vp, C.POINTER(KjRtrParams), C.POINTER(vp), vp],
         "kj_rtr_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_rtr_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
@@ -421,7 +422,7 @@ class GpuPipeline:
         p.pass_mask = pass_mask
         return p
 
-    def rtr_frame(self, pass_mask=63, tables=None):
+    def rtr_frame(self, pass_mask=63, tables=None, specular_lights=False):
         """RtrRenderer::trace + TracedRtr::filter_temporal after rtdgi.render (same stream). Returns the resolved
         B10G11R11_UFLOAT image as an int32 (H, W) tensor view. `tables`: KjRtrTables (default: rtr_tables.standin_tables())."""
         if getattr(self, "rtr", None) is None:
@@ -435,6 +436,8 @@ class GpuPipeline:
         out = C.c_void_p()
         if pass_mask & 15:
             check(self.L.kj_rtr_trace(self.rtr, C.byref(p), s))
+        if specular_lights:
+            check(self.L.kj_rtr_render_specular_lights(self.rtr, C.byref(p), s))     # LightingRenderer::render_specular (no-op without triangle lights)
         if pass_mask & 48:
             check(self.L.kj_rtr_filter_temporal(self.rtr, C.byref(p), C.byref(out), s))
         return self.rtr_surface("resolved_tex", self.torch.int32, (self.H, self.W))

@@ -8,6 +8,7 @@
 #include "okj_ssgi.hpp"
 #include "okj_shadow_denoise.hpp"
 #include "okj_rtr.hpp"
+#include "okj_lighting.hpp"
 #include <cstdio>
 #include <chrono>
 #ifdef _OPENMP
@@ -488,6 +489,16 @@ void okj_rtr_ray_counts(void* p, uint64_t* closest, uint64_t* any) { *closest = 
 void okj_ircache_ws_pos_to_coord(const KjFrameConstants* fc, const float pos[3], const float normal[3], const float jitter[3], uint32_t out[4]) {
     const Ircache::Coord c = Ircache::ws_pos_to_ircache_coord(*fc, f3{pos[0], pos[1], pos[2]}, f3{normal[0], normal[1], normal[2]}, f3{jitter[0], jitter[1], jitter[2]});
     out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.cascade;
+}
+
+// LightingRenderer::render_specular (renderers/lighting.rs:23-88): adds the triangle lights' specular into `output_r11g11b10f` (rtr's resolved image)
+uint64_t okj_lighting_render_specular(const KjFrameConstants* fc, const void* scene, const uint8_t* blue_noise, const void* brdf_fg_lut, const void* gbuffer, const void* depth,
+                                      const int32_t* spatial_resolve_offsets, void* output_r11g11b10f, uint32_t w, uint32_t h) {
+    static Lighting l;
+    l.rays_any = 0;
+    l.render_specular(*fc, *(const Scene*)scene, ImgU4((void*)gbuffer, w, h), ImgR32F((void*)depth, w, h), blue_noise, (const h4*)brdf_fg_lut, spatial_resolve_offsets,
+                      Img<uint32_t>(output_r11g11b10f, w, h));
+    return l.rays_any.load();
 }
 
 } // extern "C"

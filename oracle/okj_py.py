@@ -91,6 +91,8 @@ def lib():
         L.okj_rtr_filter_temporal.restype = C.c_void_p; L.okj_rtr_filter_temporal.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.POINTER(KjRtrParams)]
         L.okj_rtr_surface.restype = C.c_int; L.okj_rtr_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_rtr_ray_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.okj_lighting_render_specular.restype = C.c_uint64
+        L.okj_lighting_render_specular.argtypes = [C.POINTER(KjFrameConstants)] + [C.c_void_p] * 7 + [C.c_uint32, C.c_uint32]
         L.okj_light_gbuffer.argtypes = [C.POINTER(KjFrameConstants)] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.okj_shadow_denoise_create.restype = C.c_void_p
         L.okj_shadow_denoise_destroy.argtypes = [C.c_void_p]
@@ -343,6 +345,15 @@ class OraclePipeline:
         if pass_mask & 48:
             self.L.okj_rtr_filter_temporal(self.rtr, C.byref(fc), C.byref(p))
         return self.rtr_surface("resolved_tex", np.uint32, (self.H, self.W))
+
+    def lighting_render_specular(self, fc, resolved_r11g11b10f):
+        """LightingRenderer::render_specular (renderers/lighting.rs:23-88): adds the triangle lights' specular into `resolved_r11g11b10f`
+        ((H, W) uint32, modified in place). Returns the number of shadow rays."""
+        from kajiya_amd import rtr_tables
+        t, keep = rtr_tables.standin_tables()
+        assert resolved_r11g11b10f.dtype == np.uint32 and resolved_r11g11b10f.flags["C_CONTIGUOUS"]
+        return self.L.okj_lighting_render_specular(C.byref(fc), self.scene.h, self.bn.ctypes.data, brdf_lut().ctypes.data, self.gbuffer.ctypes.data, self.depth.ctypes.data,
+                                                   keep[3].ctypes.data, resolved_r11g11b10f.ctypes.data, self.W, self.H)
 
     def rtr_surface(self, name, dtype, shape):
         ptr, n = C.c_void_p(), C.c_uint64()

@@ -113,3 +113,40 @@ def test_rtr_free_running_mirror_reflects_the_sky(gpu, oracle, device):
     closest, anyhit = gp.rtr_ray_counts()
     hw, hh = (W + 1) // 2, (H + 1) // 2
     assert 0 < closest <= hw * hh + ((hw + 1) // 2) * ((hh + 1) // 2) and anyhit <= 3 * closest, (closest, anyhit)
+
+
+def test_lighting_render_specular_parity(gpu, oracle, device):
+    """LightingRenderer::render_specular (specular from the triangle lights, added into rtr's resolved image before the temporal filter):
+    both sides start from the same random B10G11R11 image, G-buffer and frame constants; emissive meshes registered as lights."""
+    import torch
+    W, H = 256, 160
+    desc = S.glossy_test_scene()
+    osc, gsc = oracle.OracleScene(desc, use_lights=True), gpu.Scene(device, desc, use_lights=True)
+    n_lights = gsc.triangle_light_count
+    assert n_lights == osc.triangle_light_count and n_lights >= 12          # the emissive box
+    op, gp = oracle.OraclePipeline(osc, W, H), gpu.GpuPipeline(device, gsc, W, H)
+    repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    rng = np.random.RandomState(9)
+    for fi, fc in enumerate(T._frame_constants(W, H, 3, "textured")):
+        fc.triangle_light_count = n_lights
+        op.render_inputs(fc); op.reprojection(fc)
+        gp.dev.frame_begin(fc)
+        T._sync_inputs(op, gp, torch)
+        gp.sky64.copy_(torch.from_numpy(op.sky64.view(np.int16)))
+        repro_dev.copy_(torch.from_numpy(op.reprojection_map))
+        gp.reprojection_map_ptr = C.c_void_p(repro_dev.data_ptr())
+        op.rtdgi_frame(fc); gp.rtdgi_frame()
+        gp.rtr_frame(15)                                               # allocates resolved_tex and derives the half-res normal / depth from the synced G-buffer
+        base = (rng.randint(8 << 6, 15 << 6, size=(H, W)) | (rng.randint(8 << 6, 15 << 6, size=(H, W)) << 11) | (rng.randint(8 << 5, 15 << 5, size=(H, W)) << 22)).astype(np.uint32)
+        ref = base.copy()
+        rays = op.lighting_render_specular(fc, ref)
+        gp.rtr_surface("resolved_tex", torch.int32, (H, W)).copy_(torch.from_numpy(base.view(np.int32)))
+        p = gp.rtr_params(0)
+        gpu.check(gp.L.kj_rtr_render_specular_lights(gp.rtr, C.byref(p), None))
+        torch.cuda.synchronize()
+        got = gp.rtr_surface("resolved_tex", torch.uint8, (-1,)).cpu().numpy()
+        r = P.compare(got, ref.view(np.uint8).reshape(-1), "r11g11b10f")
+        added = P.decode(ref.view(np.uint8).reshape(-1), "r11g11b10f") - P.decode(base.view(np.uint8).reshape(-1), "r11g11b10f")
+        print(f"frame {fi}: {r}, shadow rays {rays}, pixels that received light specular {(added.max(-1) > 0).mean():.3f}")
+        assert rays > 0.3 * (W // 2) * (H // 2) and (added.max(-1) > 0).mean() > 0.02
+        assert r["mismatch_frac"] <= T.MISMATCH_TOL and r["differ_frac"] <= 0.03, r
