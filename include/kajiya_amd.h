@@ -211,8 +211,8 @@ KjStatus kj_baked_mesh_view(const void* bytes, uint64_t size, KjBakedMeshView* o
 KjStatus kj_baked_image_view(const void* bytes, uint64_t size, KjBakedImageView* out);
 KjStatus kj_baked_image_mip(const void* bytes, uint64_t size, uint32_t level, const uint8_t** out_data, uint64_t* out_len);
 /* Texel decode of one mip level to RGBA8 for KjMaterialMap (the reference leaves this to the texture unit): RGBA8, BC1, BC3,
- * BC4 (r,0,0,1), BC5 (r,g,0,1). Other formats (BC7: the baker's default for albedo / emissive) return KJ_ERR_UNSUPPORTED;
- * the Python host mirror decodes those (kajiya_amd/assets.py). */
+ * BC4 (r,0,0,1), BC5 (r,g,0,1), BC7 — every format kajiya's baker emits (kajiya-asset/src/image.rs:131-336). Other formats return
+ * KJ_ERR_UNSUPPORTED. */
 KjStatus kj_baked_image_decode_rgba8(uint32_t vk_format, const uint8_t* mip_data, uint64_t mip_len, uint32_t width, uint32_t height, uint8_t* out_rgba8);
 
 /* prepare_frame_constants (world_renderer.rs:1001-1108): upload this frame's UBO. */

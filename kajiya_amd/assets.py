@@ -4,8 +4,8 @@ load_gpu_image_asset (world_renderer.rs:297-322,604-700).
 
 The flat-format parsing is the C-ABI's (`kj_baked_mesh_view`, `kj_baked_image_view`, `kj_baked_image_mip`,
 csrc/baked_asset.cpp); this module maps files, resolves the mesh's map identities to image files, decodes every mip level
-to RGBA8 texels (natively for RGBA8 / BC1 / BC3 / BC4 / BC5, through Pillow's BCn decoder for BC7 — the texture unit's job
-in the reference) and hands `KjMeshDesc` to `kj_scene_add_mesh`, which is where the reference's own add_mesh starts.
+to RGBA8 texels (natively: RGBA8, BC1, BC3, BC4, BC5, BC7 — the texture unit's job in the reference; Pillow is only consulted for
+BC2 / BC6H, which kajiya's baker never emits) and hands `KjMeshDesc` to `kj_scene_add_mesh`, which is where the reference's own add_mesh starts.
 """
 import ctypes as C
 import mmap
@@ -76,14 +76,14 @@ def decode_baked_image(data):
         klib.check(L.kj_baked_image_mip(addr, size, k, C.byref(p), C.byref(n)))
         out = np.empty((h, w, 4), np.uint8)
         st = L.kj_baked_image_decode_rgba8(fmt, p, n.value, w, h, out.ctypes.data)
-        if st == 5 and (fmt in VK_BC7 or fmt in VK_BC2 or fmt in VK_BC6H):   # KJ_ERR_UNSUPPORTED: table-driven formats
+        if st == 5 and (fmt in VK_BC2 or fmt in VK_BC6H):   # KJ_ERR_UNSUPPORTED: formats the baker never emits (DDS pass-through only)
             from PIL import Image
             pw, ph = (w + 3) // 4 * 4, (h + 3) // 4 * 4
             need = pw * ph   # 16 bytes per 4x4 block
             if n.value < need:
                 raise klib.KjError("baked image: mip shorter than its block count")
             raw = C.string_at(p, need)
-            bcn = 7 if fmt in VK_BC7 else 2 if fmt in VK_BC2 else 6
+            bcn = 2 if fmt in VK_BC2 else 6
             out = np.asarray(Image.frombytes("RGBA", (pw, ph), raw, "bcn", bcn).convert("RGBA"))[:h, :w].copy()
         else:
             klib.check(st)

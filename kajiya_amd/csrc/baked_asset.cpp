@@ -7,11 +7,11 @@
 // (no padding), native endian. The views below are zero-copy: pointers into the caller's bytes, every range bounds-checked
 // (the reference trusts the file; a truncated file here is KJ_ERR_INVALID_ARGUMENT, not a fault).
 //
-// Texel decode to RGBA8 for the formats the baker emits without needing large tables: R8G8B8A8 (copy), BC1, BC3, BC4, BC5
-// (image.rs:131-213,289-336). BC7 (the baker's default for albedo / emissive) is decoded by the host mirror
-// (kajiya_amd/assets.py) — in the reference that is the GPU's fixed-function texture unit.
+// Texel decode to RGBA8 for every format the baker emits: R8G8B8A8 (copy), BC1, BC3, BC4, BC5 and BC7 (image.rs:131-213,289-336) — the
+// job of the GPU's fixed-function texture unit in the reference.
 #include "kj_host.hpp"
 #include <cstring>
+#include <utility>
 
 using namespace kj;
 
@@ -99,6 +99,76 @@ void decode_block(uint32_t fmt, const uint8_t* b, uint8_t out[16][4]) {
     }
 }
 
+#include "bc7_tables.inc"
+
+// BC7 (BPTC) block -> 16 RGBA8 texels. Mode table, bit order, endpoint expansion and interpolation weights per the format specification;
+// partition / anchor tables in bc7_tables.inc (scripts/derive_bc7_tables.py). Checked against Pillow's decoder on random blocks of every
+// mode (tests/test_baked_assets.py).
+struct Bc7Mode { uint8_t ns, pb, rb, isb, cb, ab, epb, spb, ib, ib2; };
+static const Bc7Mode BC7_MODES[8] = {{3, 4, 0, 0, 4, 0, 1, 0, 3, 0}, {2, 6, 0, 0, 6, 0, 0, 1, 3, 0}, {3, 6, 0, 0, 5, 0, 0, 0, 2, 0}, {2, 6, 0, 0, 7, 0, 1, 0, 2, 0},
+                                     {1, 0, 2, 1, 5, 6, 0, 0, 2, 3}, {1, 0, 2, 0, 7, 8, 0, 0, 2, 2}, {1, 0, 0, 0, 7, 7, 1, 0, 4, 0}, {2, 6, 0, 0, 5, 5, 1, 0, 2, 0}};
+static const uint8_t BC7_W2[4] = {0, 21, 43, 64}, BC7_W3[8] = {0, 9, 18, 27, 37, 46, 55, 64}, BC7_W4[16] = {0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64};
+
+void decode_bc7_block(const uint8_t* b, uint8_t out[16][4]) {
+    uint32_t pos = 0;
+    auto get = [&](uint32_t n) -> uint32_t {
+        uint32_t v = 0;
+        for (uint32_t i = 0; i < n; ++i, ++pos) v |= uint32_t((b[pos >> 3] >> (pos & 7)) & 1u) << i;
+        return v;
+    };
+    uint32_t mode = 0;
+    while (mode < 8 && get(1) == 0) ++mode;
+    if (mode >= 8) { memset(out, 0, 64); return; }                 // reserved: decodes to transparent black
+    const Bc7Mode m = BC7_MODES[mode];
+    const uint32_t partition = get(m.pb), rotation = get(m.rb), idx_mode = get(m.isb);
+    const uint32_t ne = 2u * m.ns;
+    uint32_t ep[6][4];
+    for (int ch = 0; ch < 3; ++ch) for (uint32_t e = 0; e < ne; ++e) ep[e][ch] = get(m.cb);
+    for (uint32_t e = 0; e < ne; ++e) ep[e][3] = m.ab ? get(m.ab) : 255u;
+    uint32_t cbits = m.cb, abits = m.ab;
+    if (m.epb) {
+        for (uint32_t e = 0; e < ne; ++e) {
+            const uint32_t pbit = get(1);
+            for (int ch = 0; ch < 3; ++ch) ep[e][ch] = (ep[e][ch] << 1) | pbit;
+            if (m.ab) ep[e][3] = (ep[e][3] << 1) | pbit;
+        }
+        ++cbits; if (m.ab) ++abits;
+    } else if (m.spb) {
+        for (uint32_t sub = 0; sub < m.ns; ++sub) {
+            const uint32_t pbit = get(1);
+            for (uint32_t e = 2 * sub; e < 2 * sub + 2; ++e) for (int ch = 0; ch < 3; ++ch) ep[e][ch] = (ep[e][ch] << 1) | pbit;
+        }
+        ++cbits;
+    }
+    for (uint32_t e = 0; e < ne; ++e) {
+        for (int ch = 0; ch < 3; ++ch) { uint32_t v = ep[e][ch] << (8 - cbits); ep[e][ch] = v | (v >> cbits); }
+        if (m.ab) { uint32_t v = ep[e][3] << (8 - abits); ep[e][3] = v | (v >> abits); }
+    }
+    const uint8_t* part = m.ns == 1 ? nullptr : (m.ns == 2 ? BC7_PARTITION2[partition] : BC7_PARTITION3[partition]);
+    const uint32_t anchor1 = m.ns == 2 ? BC7_ANCHOR2[partition] : (m.ns == 3 ? BC7_ANCHOR3A[partition] : 0xffu);
+    const uint32_t anchor2 = m.ns == 3 ? BC7_ANCHOR3B[partition] : 0xffu;
+    uint32_t idx0[16], idx1[16];
+    for (uint32_t i = 0; i < 16; ++i) idx0[i] = get((i == 0 || i == anchor1 || i == anchor2) ? m.ib - 1u : m.ib);
+    for (uint32_t i = 0; i < 16; ++i) idx1[i] = m.ib2 ? get(i == 0 ? m.ib2 - 1u : m.ib2) : 0u;
+    auto weight = [](uint32_t bits, uint32_t i) -> uint32_t { return bits == 2 ? BC7_W2[i] : (bits == 3 ? BC7_W3[i] : BC7_W4[i]); };
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t sub = part ? part[i] : 0u;
+        const uint32_t* e0 = ep[2 * sub];
+        const uint32_t* e1 = ep[2 * sub + 1];
+        uint32_t cw, aw;
+        if (!m.ib2) { cw = aw = weight(m.ib, idx0[i]); }
+        else if (!idx_mode) { cw = weight(m.ib, idx0[i]); aw = weight(m.ib2, idx1[i]); }
+        else { cw = weight(m.ib2, idx1[i]); aw = weight(m.ib, idx0[i]); }
+        uint8_t px[4];
+        for (int ch = 0; ch < 3; ++ch) px[ch] = uint8_t(((64 - cw) * e0[ch] + cw * e1[ch] + 32) >> 6);
+        px[3] = uint8_t(((64 - aw) * e0[3] + aw * e1[3] + 32) >> 6);
+        if (rotation == 1) std::swap(px[3], px[0]);
+        else if (rotation == 2) std::swap(px[3], px[1]);
+        else if (rotation == 3) std::swap(px[3], px[2]);
+        memcpy(out[i], px, 4);
+    }
+}
+
 uint32_t block_bytes(uint32_t fmt) {
     switch (fmt) {
         case VK_BC1_RGB_UNORM: case VK_BC1_RGB_SRGB: case VK_BC1_RGBA_UNORM: case VK_BC1_RGBA_SRGB: case VK_BC4_UNORM: return 8;
@@ -169,7 +239,7 @@ KjStatus kj_baked_image_decode_rgba8(uint32_t vk_format, const uint8_t* mip_data
         return KJ_OK;
     }
     const uint32_t bb = block_bytes(vk_format);
-    if (!bb || vk_format == VK_BC7_UNORM || vk_format == VK_BC7_SRGB) {
+    if (!bb) {
         set_last_error("baked image: vk::Format %u is not decoded natively", vk_format);
         return KJ_ERR_UNSUPPORTED;
     }
@@ -178,7 +248,8 @@ KjStatus kj_baked_image_decode_rgba8(uint32_t vk_format, const uint8_t* mip_data
     for (uint32_t by = 0; by < bh; ++by)
         for (uint32_t bx = 0; bx < bw; ++bx) {
             uint8_t texels[16][4];
-            decode_block(vk_format, mip_data + (uint64_t(by) * bw + bx) * bb, texels);
+            if (vk_format == VK_BC7_UNORM || vk_format == VK_BC7_SRGB) decode_bc7_block(mip_data + (uint64_t(by) * bw + bx) * bb, texels);
+            else decode_block(vk_format, mip_data + (uint64_t(by) * bw + bx) * bb, texels);
             for (uint32_t y = 0; y < 4 && by * 4 + y < height; ++y)
                 for (uint32_t x = 0; x < 4 && bx * 4 + x < width; ++x)
                     memcpy(out_rgba8 + (uint64_t(by * 4 + y) * width + bx * 4 + x) * 4, texels[y * 4 + x], 4);

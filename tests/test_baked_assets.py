@@ -128,7 +128,6 @@ def test_block_compressed_decode_known_answers():
 
 def test_bc7_mode6_known_answer():
     """BC7 mode 6 (one subset, 7-bit RGBA endpoints + p-bit, 4-bit indices): all indices 0 -> endpoint 0 = (e << 1 | p)."""
-    pytest.importorskip("PIL")
     bits, pos = 0, 0
 
     def put(v, n):
@@ -144,6 +143,34 @@ def test_bc7_mode6_known_answer():
     d = A.decode_baked_image(blob)
     assert d["srgb"]
     np.testing.assert_array_equal(d["levels"][0][2, 3], [255, 0x41, 0x01, 255])
+
+
+def test_bc7_native_decoder_matches_pillow_on_random_blocks():
+    """The native BC7 decoder (csrc/baked_asset.cpp, tables from scripts/derive_bc7_tables.py) against Pillow's on random blocks of all
+    eight modes: partitions, anchors, rotations, index selection, p-bits. (A reserved-mode block — first byte 0 — decodes to transparent black
+    per the format specification; Pillow makes it opaque black.)"""
+    Image = pytest.importorskip("PIL.Image")
+    L = A._bind()
+    rng = np.random.RandomState(12)
+    n = 16000
+    blocks = rng.randint(0, 256, size=(n, 16)).astype(np.uint8)
+    out = np.zeros((4, 4, 4), np.uint8)
+    for i in range(n):
+        m = i % 8
+        blocks[i, 0] = ((int(blocks[i, 0]) & (0xff ^ ((1 << (m + 1)) - 1))) | (1 << m)) & 0xff
+        raw = blocks[i].tobytes()
+        assert L.kj_baked_image_decode_rgba8(145, raw, 16, 4, 4, out.ctypes.data) == 0
+        ref = np.asarray(Image.frombytes("RGBA", (4, 4), raw, "bcn", 7))
+        assert np.array_equal(out, ref), (m, raw.hex())
+    assert L.kj_baked_image_decode_rgba8(145, bytes(16), 16, 4, 4, out.ctypes.data) == 0 and not out.any()
+    # a whole image: 8x8 = four blocks, cropped 6x5 logical extent
+    img_blocks = blocks[:4].tobytes()
+    full = np.zeros((8, 8, 4), np.uint8)
+    assert L.kj_baked_image_decode_rgba8(146, img_blocks, 64, 8, 8, full.ctypes.data) == 0
+    crop = np.zeros((5, 6, 4), np.uint8)
+    assert L.kj_baked_image_decode_rgba8(146, img_blocks, 64, 6, 5, crop.ctypes.data) == 0
+    np.testing.assert_array_equal(crop, full[:5, :6])
+    np.testing.assert_array_equal(full[:4, 4:], np.asarray(Image.frombytes("RGBA", (4, 4), blocks[1].tobytes(), "bcn", 7)))
 
 
 def test_baked_scene_traces_like_the_direct_scene(oracle, tmp_path):
