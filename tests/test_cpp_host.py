@@ -96,3 +96,14 @@ def test_cpp_world_render_passes_matches_python_driver(gpu, device, tmp_path):
         else:
             a, b = P.decode(got, fmt[k]).astype(np.float64), P.decode(ref[k], fmt[k]).astype(np.float64)
             assert np.isfinite(a).all() and abs(a[..., :3].mean() / b[..., :3].mean() - 1.0) < 0.03 and r["rel_l2"] < 0.15, (k, r)
+
+
+def test_cpp_host_reports_errors_instead_of_crashing(tmp_path):
+    """Error behaviour of the compiled host: every failing C-ABI / HIP call surfaces as kajiya_amd::Error -> message + exit code 1
+    (no GPU here: device creation fails; on a GPU box the missing scene file does)."""
+    _build_examples()
+    bn = os.path.join(ROOT, "tests", "golden", "bluenoise_256_rgba8.bin")
+    r = subprocess.run([os.path.join(EX, "world_render_passes"), bn, str(tmp_path), "64", "64", "1", str(tmp_path / "o")], capture_output=True, timeout=120)
+    assert r.returncode == 1 and r.stderr.decode().startswith("error: "), (r.returncode, r.stderr)
+    r = subprocess.run([os.path.join(EX, "world_render_passes")], capture_output=True, timeout=30)
+    assert r.returncode == 2 and b"usage:" in r.stderr
