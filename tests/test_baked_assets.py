@@ -197,3 +197,19 @@ def test_baked_scene_traces_like_the_direct_scene(oracle, tmp_path):
     assert (pa.depth > 0).mean() > 0.5
     for name in ("gbuffer", "geometric_normal", "depth", "velocity"):
         np.testing.assert_array_equal(getattr(pa, name), getattr(pb, name), err_msg=name)
+
+
+def test_bc1_bc3_bc4_bc5_native_decoders_match_pillow_on_random_blocks():
+    """Random blocks (both endpoint orders, i.e. 4-/3-colour BC1 and 8-/6-value BC4 modes) through the native decoders and Pillow's."""
+    Image = pytest.importorskip("PIL.Image")
+    L = A._bind()
+    rng = np.random.RandomState(21)
+    for bcn, vk, block_bytes, mode, channels in ((1, 133, 8, "RGBA", 4), (3, 137, 16, "RGBA", 4), (4, 139, 8, "L", 1), (5, 141, 16, "RGB", 2)):
+        out = np.zeros((4, 4, 4), np.uint8)
+        for _ in range(3000):
+            raw = rng.randint(0, 256, size=block_bytes).astype(np.uint8).tobytes()
+            assert L.kj_baked_image_decode_rgba8(vk, raw, block_bytes, 4, 4, out.ctypes.data) == 0
+            ref = np.asarray(Image.frombytes(mode, (4, 4), raw, "bcn", bcn)).reshape(4, 4, -1)
+            assert np.array_equal(out[..., :channels], ref[..., :channels]), (bcn, raw.hex())
+            if channels < 3:
+                assert (out[..., channels:3] == 0).all() and (out[..., 3] == 255).all()
