@@ -352,6 +352,8 @@ struct WorldRenderer {
     RtrRenderer rtr; LightingRenderer lighting; TaaRenderer taa;
     FrameState frame_state;
     uint32_t debug_shading_mode = 0;
+    bool reset_reference_accumulation = false;      // world_renderer.rs:183
+    DeviceImage refpt_accum;                         // "refpt.accum" temporal (RGBA32F: running mean + sample count)
     float sky_key[8] = {-1, 0, 0, 0, 0, 0, 0, 0};
 
     WorldRenderer(Device& dev, Scene& sc, uint32_t w, uint32_t h, const KjRtrTables& rtr_tables)
@@ -393,6 +395,23 @@ struct WorldRenderer {
         o.anti_aliased = taa.render(debug_out_tex.p, W, H, o.reprojection_map, gbuffer_depth.depth.p, temporal_upscale_extent, s);   // :254-263
         frame_state.retire_frame();
         return o;
+    }
+    // WorldRenderer::prepare_render_graph_reference (world_render_passes.rs:294-330): one more path-traced sample per pixel into the persistent
+    // "refpt.accum" image (cleared when reset_reference_accumulation is set, e.g. after the camera moved). Returns the RGBA32F accumulator;
+    // the reference then tone-maps it (post.render: out of scope).
+    const void* prepare_render_graph_reference(const CameraMatrices& camera, hipStream_t s) {
+        const size_t bytes = size_t(render_extent[0]) * render_extent[1] * 16;
+        if (refpt_accum.bytes != bytes) { refpt_accum.alloc(bytes); reset_reference_accumulation = false; }
+        frame_state.triangle_light_count = scene.triangle_light_count();
+        const KjFrameConstants fc = frame_state.prepare_frame_constants(camera, nullptr);
+        check(kj_frame_begin(device.h, &fc, s), "kj_frame_begin");
+        if (reset_reference_accumulation) {
+            reset_reference_accumulation = false;
+            check_hip(hipMemsetAsync(refpt_accum.p, 0, bytes, s), "hipMemsetAsync");
+        }
+        check(kj_reference_path_trace(device.h, scene.h, refpt_accum.p, render_extent[0], render_extent[1], 0, 1, 0, nullptr, s), "kj_reference_path_trace");
+        frame_state.retire_frame();
+        return refpt_accum.p;
     }
 };
 
