@@ -15,7 +15,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, H, W, q):
+def _worker(rank, world, port, H, W, q, prepared=False):
     import torch
     import torch.distributed as dist
     from kajiya_amd import multigpu
@@ -33,7 +33,13 @@ def _worker(rank, world, port, H, W, q):
             own = multigpu.half_rows(*strips[rank], H) if res == "h" else strips[rank]
             mine = torch.full_like(truth, 0xEE if rank == 0 else 0x77)
             mine[own[0]:own[1]] = truth[own[0]:own[1]]
-            comm.run(multigpu.transfers(strips, halo, res, H), lambda r, a, b: mine[a:b])
+            xf = multigpu.transfers(strips, halo, res, H)
+            if prepared:      # the path SplitRtdgi._exchange takes: resolve the plan once, replay it (twice here: the views must stay valid)
+                spec = comm.prepare(xf, lambda r, a, b: mine[a:b])
+                comm.run_prepared(spec)
+                comm.run_prepared(spec)
+            else:
+                comm.run(xf, lambda r, a, b: mine[a:b])
             lo = 0 if halo is None else max(0, own[0] - halo)
             hi = hh if halo is None else min(hh, own[1] + halo)
             ok = bool((mine[lo:hi] == truth[lo:hi]).all())
@@ -41,6 +47,26 @@ def _worker(rank, world, port, H, W, q):
             outside = torch.cat([mine[:lo], mine[hi:]])
             ok_out = bool((outside == (0xEE if rank == 0 else 0x77)).all()) if outside.numel() else True
             results[(res, bpt, halo)] = (ok, ok_out)
+        if prepared:
+            # several surfaces in ONE batched group, as one exchange point of the frame does (names tag the rows)
+            imgs = {}
+            truth = {}
+            xfers = []
+            for name, (res, bpt, halo) in {"a": ("h", 8, 12), "b": ("f", 4, None), "c": ("f", 8, 3)}.items():
+                hh = (H + 1) // 2 if res == "h" else H
+                ww = ((W + 1) // 2 if res == "h" else W) * bpt
+                truth[name] = torch.randint(0, 256, (hh, ww), dtype=torch.uint8, generator=g)
+                own = multigpu.half_rows(*strips[rank], H) if res == "h" else strips[rank]
+                imgs[name] = torch.full_like(truth[name], 0x10 + rank)
+                imgs[name][own[0]:own[1]] = truth[name][own[0]:own[1]]
+                xfers += [(src, dst, (name, a), b) for (src, dst, a, b) in multigpu.transfers(strips, halo, res, H)]
+            comm.run_prepared(comm.prepare(xfers, lambda r, na, b: imgs[na[0]][na[1]:b]))
+            for name, (res, bpt, halo) in {"a": ("h", 8, 12), "b": ("f", 4, None), "c": ("f", 8, 3)}.items():
+                hh = truth[name].shape[0]
+                own = multigpu.half_rows(*strips[rank], H) if res == "h" else strips[rank]
+                lo = 0 if halo is None else max(0, own[0] - halo)
+                hi = hh if halo is None else min(hh, own[1] + halo)
+                results[("batched", name)] = (bool((imgs[name][lo:hi] == truth[name][lo:hi]).all()), True)
         dist.barrier()
         q.put((rank, results))
     finally:
@@ -66,6 +92,30 @@ def test_distcomm_halo_exchange_gloo_world2():
         for key, (ok, ok_out) in results.items():
             assert ok, f"rank {rank}: halo rows wrong for {key}"
             assert ok_out, f"rank {rank}: rows outside the halo were written for {key}"
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world", [2, 4])
+def test_distcomm_prepared_plans_gloo(world):
+    """The cached-plan path of the frame loop (DistComm.prepare + run_prepared, several surfaces per batched group, replayed) with 2 and 4
+    processes: halo exchanges reach beyond the direct neighbour when strips are thin, all-gathers talk to every peer."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    H, W = 208, 64
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=200) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in got) == list(range(world))
+    for rank, results in got:
+        assert any(k[0] == "batched" for k in results)
+        for key, (ok, ok_out) in results.items():
+            assert ok and ok_out, f"rank {rank}: {key}"
 
 
 def test_transfer_plan_is_symmetric_and_minimal():
