@@ -42,6 +42,17 @@ def test_error_reporting_without_gpu():
     assert st != 0 and b"null" in L.kj_last_error()
     st = L.kj_rtdgi_render(None, None, None, None)
     assert st != 0
+    # every handle-taking entry point rejects NULL with KJ_ERR_INVALID_ARGUMENT (1) and a message, without touching a device
+    for name, args in (("kj_rtr_create", (None, None, None)), ("kj_rtr_trace", (None, None, None)), ("kj_rtr_filter_temporal", (None, None, None, None)),
+                       ("kj_rtr_render_specular_lights", (None, None, None)), ("kj_rtr_surface", (None, None, None, None)), ("kj_rtr_ray_counts", (None, None, None)),
+                       ("kj_ircache_prepare", (None, None)), ("kj_taa_render", (None, None, 0, 0, None, None, 0, 0, None, None)),
+                       ("kj_ssgi_render", (None, None, None, None, None, None)), ("kj_shadow_denoise_render", (None, None, None, None, None, None)),
+                       ("kj_baked_mesh_view", (None, 0, None)), ("kj_baked_image_view", (None, 0, None)), ("kj_baked_image_decode_rgba8", (37, None, 0, 4, 4, None))):
+        assert getattr(L, name)(*args) == 1, name
+        assert L.kj_last_error(), name
+    # destroy(NULL) is a no-op, like dropping a None
+    for name in ("kj_rtr_destroy", "kj_rtdgi_destroy", "kj_scene_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy", "kj_shadow_denoise_destroy", "kj_reprojection_destroy"):
+        getattr(L, name)(None)
 
 
 def test_frame_constants_builder():
