@@ -359,7 +359,7 @@ def main():
                                "resolve+temporal+spatial denoise, irradiance cache (scroll/age/compact, accessibility+validate+trace rays, SH sum), TAA (7 passes) on the GI output"
                                + (", SSAO guide (ssgi, 4 passes)" if use_ssgi else ", constant SSAO guide"),
                    "triangles": stats["triangles"], "bvh_nodes": stats["nodes"], "bvh_bytes": stats["bvh_bytes"],
-                   "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": ("single GPU, 2 HIP streams: next frame's ircache rays overlap this frame's screen-space tail" if overlap else "single GPU, serial frames") if nsplit <= 1 else f"{nsplit}-way screen-tile split (16-row-aligned strips; 6 batched halo exchanges per frame incl. the temporal2 all-gather, over "
+                   "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": ("single GPU, 3 HIP streams: next frame's ircache rays (side stream) and this frame's spatial filter + TAA (third stream) overlap the main stream's ray passes" if overlap else "single GPU, serial frames") if nsplit <= 1 else f"{nsplit}-way screen-tile split (16-row-aligned strips; 6 batched halo exchanges per frame incl. the temporal2 all-gather, over "
                                   + (("gloo, host-staged (debug)" if os.environ.get("KJ_BENCH_SHARE_GPU0") else "RCCL P2P") if world > 1 else "virtual ranks on one GPU") + f"; motion halo {args.motion_halo} rows; irradiance cache replicated per rank"
                                   + ("; next frame's ircache work overlapped on a second stream)" if overlap else ")")},
         "segment_ms": seg,
