@@ -365,7 +365,7 @@ KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t
 
 /* trace_sun_shadow_mask(rg, &GbufferDepth, tlas, bindless_set) -> Handle<Image>   renderers/shadows.rs:10-40,
  * rt/trace_sun_shadow_mask.rgen.hlsl:19-60: one soft-shadow ray per full-res pixel towards a blue-noise sample of the sun
- * disc; out_mask_r8 = R8_UNORM (255 lit / 0 shadowed, 255 for sky). The shadow denoiser (shadow_denoise.rs) is a later row.
+ * disc; out_mask_r8 = R8_UNORM (255 lit / 0 shadowed, 255 for sky). The shadow denoiser is kj_shadow_denoise_* below.
  * ray_counter_dev: optional device u64 that receives += rays traced. */
 KjStatus kj_trace_sun_shadow_mask(KjDevice* dev, KjScene* scene, const KjGbufferDepth* gbuffer_depth, void* out_mask_r8,
                                   uint64_t* ray_counter_dev, void* stream);
