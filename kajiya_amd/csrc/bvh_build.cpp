@@ -14,6 +14,11 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 
 namespace kj {
 
@@ -49,17 +54,29 @@ struct SahBuilder {
         const size_t n = t.size();
         pbox.resize(n); cen.resize(n * 3); idx.resize(n);
         std::iota(idx.begin(), idx.end(), 0u);
-        for (size_t i = 0; i < n; ++i) {
-            Box b; b.grow(t[i].v0); b.grow(t[i].v1); b.grow(t[i].v2);
-            pbox[i] = b;
-            for (int k = 0; k < 3; ++k) cen[i * 3 + k] = 0.5f * (b.mn[k] + b.mx[k]);
-        }
+        const uint32_t nt = n >= 65536 ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        auto fill = [&](size_t a, size_t e) {
+            for (size_t i = a; i < e; ++i) {
+                Box b; b.grow(t[i].v0); b.grow(t[i].v1); b.grow(t[i].v2);
+                pbox[i] = b;
+                for (int k = 0; k < 3; ++k) cen[i * 3 + k] = 0.5f * (b.mn[k] + b.mx[k]);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (uint32_t k = 1; k < nt; ++k) pool.emplace_back(fill, n * k / nt, n * (k + 1) / nt);
+        fill(0, n / nt);
+        for (auto& th : pool) th.join();
         nodes.reserve(n);
     }
 
-    uint32_t build(uint32_t first, uint32_t count, uint32_t depth) {
+    // Subtrees of at most `grain` primitives are not built here when `deferred` is given: a placeholder node is emitted and the range is
+    // recorded, to be built by a worker thread into its own vector and spliced in afterwards (build_parallel). A subtree only reads and
+    // permutes its own slice of `idx`, so the result is the same tree whichever thread builds it, and whatever the node numbering.
+    struct Deferred { uint32_t placeholder, first, count, depth; };
+    uint32_t build(std::vector<BinNode>& nodes, uint32_t first, uint32_t count, uint32_t depth, uint32_t grain = 0, std::vector<Deferred>* deferred = nullptr) {
         const uint32_t me = uint32_t(nodes.size());
         nodes.emplace_back();
+        if (deferred && count <= grain && depth > 0) { deferred->push_back({me, first, count, depth}); return me; }
         Box box, cbox;
         for (uint32_t i = first; i < first + count; ++i) { box.grow(pbox[idx[i]]); cbox.grow(&cen[size_t(idx[i]) * 3]); }
         nodes[me].box = box;
@@ -107,10 +124,38 @@ struct SahBuilder {
                              [&](uint32_t a, uint32_t b) { return cen[size_t(a) * 3 + ax] < cen[size_t(b) * 3 + ax]; });
         }
         if (mid == first || mid == first + count) mid = first + count / 2;
-        const uint32_t l = build(first, mid - first, depth + 1);
-        const uint32_t r = build(mid, first + count - mid, depth + 1);
+        const uint32_t l = build(nodes, first, mid - first, depth + 1, grain, deferred);
+        const uint32_t r = build(nodes, mid, first + count - mid, depth + 1, grain, deferred);
         nodes[me].left = l; nodes[me].right = r;
         return me;
+    }
+
+    // The whole tree into `nodes`, root at the returned index: the top levels on this thread, the deferred subtrees on `n_threads` workers.
+    uint32_t build_parallel(uint32_t n_threads) {
+        const uint32_t n = uint32_t(tris.size());
+        if (n_threads <= 1 || n < 65536) return build(nodes, 0, n, 0);
+        std::vector<Deferred> deferred;
+        const uint32_t root = build(nodes, 0, n, 0, std::max(4096u, n / (n_threads * 8u)), &deferred);
+        if (getenv("KJ_BVH_TIMING")) fprintf(stderr, "[bvh build] top levels done: %zu nodes, %zu deferred subtrees, %u threads\n", nodes.size(), deferred.size(), n_threads);
+        std::vector<std::vector<BinNode>> local(deferred.size());
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < deferred.size();) {
+                local[i].reserve(size_t(deferred[i].count) * 2);
+                build(local[i], deferred[i].first, deferred[i].count, deferred[i].depth);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
+        for (size_t i = 0; i < deferred.size(); ++i) {       // splice: local root replaces the placeholder, the rest is appended
+            const uint32_t base = uint32_t(nodes.size());
+            auto remap = [&](BinNode b) { if (b.count == 0) { b.left += base - 1; b.right += base - 1; } return b; };
+            nodes[deferred[i].placeholder] = remap(local[i][0]);
+            for (size_t j = 1; j < local[i].size(); ++j) nodes.push_back(remap(local[i][j]));
+        }
+        return root;
     }
 };
 
@@ -119,8 +164,15 @@ inline float dec(uint32_t q, float scale, float origin) { return origin + float(
 }  // namespace
 
 void build_bvh4(const std::vector<BvhTri>& world_tris, BuiltBvh& out) {
+    const bool timing = getenv("KJ_BVH_TIMING") != nullptr;     // prints the phase times of the host build to stderr
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[bvh build] %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
     SahBuilder sb(world_tris);
-    const uint32_t root = sb.build(0, uint32_t(world_tris.size()), 0);
+    lap("primitive boxes");
+    uint32_t n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("KJ_BVH_THREADS")) n_threads = uint32_t(std::max(1, atoi(e)));   // 1 = the sequential build (tests compare the two)
+    const uint32_t root = sb.build_parallel(n_threads);
+    lap("binary SAH tree");
     const std::vector<BinNode>& bn = sb.nodes;
     out.nodes.clear(); out.tris.clear();
     out.nodes.reserve(bn.size() / 2 + 1);
@@ -218,6 +270,7 @@ void build_bvh4(const std::vector<BvhTri>& world_tris, BuiltBvh& out) {
             if (bn[ch[i]].count == 0) work.push_back({ch[i], child_ref[i], stack_here});
         out.nodes[it.wide] = node;
     }
+    lap("collapse + quantise + emit");
 }
 
 }  // namespace kj
