@@ -22,6 +22,7 @@ Communication backends: `DistComm` = torch.distributed point-to-point (backend "
 the exactness test).
 """
 import ctypes as C
+import os
 import numpy as np
 
 from .abi import KJ_RTDGI_PASS
@@ -105,10 +106,14 @@ class DistComm:
     `stage_through_host`: debugging aid for the gloo backend with device tensors (several ranks sharing one GPU, where RCCL
     refuses to start): sends are copied to host memory first, receives land in host memory and are copied back."""
 
-    def __init__(self, dist, rank, world, stage_through_host=False):
+    def __init__(self, dist, rank, world, stage_through_host=False, packed=None):
         self.dist, self.rank, self.n = dist, rank, world
         self.ranks = [rank]
         self.stage = stage_through_host
+        # packed (opt-in, KJ_SPLIT_PACKED=1): one message per peer and exchange point instead of one per surface — the rows bound for a peer
+        # are concatenated into a staging buffer (one torch.cat), sent as one P2P op and scattered back on arrival. Fewer, larger RCCL
+        # operations; not measurable in the build environment (no multi-GPU node), hence off by default.
+        self.packed = bool(int(os.environ.get("KJ_SPLIT_PACKED", "0"))) if packed is None else packed
 
     def prepare(self, xfers, get_rows):
         """This rank's share of a transfer plan as [(is_send, rows view, peer)], in plan order (both ends of a pair enumerate the plan
@@ -121,11 +126,40 @@ class DistComm:
                 spec.append((True, get_rows(src, a, b), dst))
             elif dst == self.rank:
                 spec.append((False, get_rows(dst, a, b), src))
+        if self.packed and spec:
+            import torch
+            groups = {}          # (is_send, peer) -> [views] in plan order: the sender's order to a peer is the receiver's order from it
+            for is_send, t, peer in spec:
+                groups.setdefault((is_send, peer), []).append(t)
+            packed = []
+            for (is_send, peer), views in sorted(groups.items(), key=lambda kv: (kv[0][1], not kv[0][0])):
+                flat = [v.reshape(-1) for v in views]
+                buf = torch.empty(sum(f.numel() for f in flat), dtype=views[0].dtype, device=views[0].device)
+                packed.append((is_send, peer, buf, views, flat))
+            return ("packed", packed)
         return spec
 
     def run_prepared(self, spec):
         if isinstance(spec, tuple) and spec and spec[0] == "staged":
             return self.run(spec[1], spec[2])
+        if isinstance(spec, tuple) and spec and spec[0] == "packed":
+            import torch
+            d = self.dist
+            ops = []
+            for is_send, peer, buf, views, flat in spec[1]:
+                if is_send:
+                    torch.cat(flat, out=buf)
+                ops.append(d.P2POp(d.isend if is_send else d.irecv, buf, peer))
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+            for is_send, peer, buf, views, flat in spec[1]:
+                if not is_send:
+                    off = 0
+                    for v in views:
+                        n = v.numel()
+                        v.copy_(buf[off:off + n].view(v.shape))
+                        off += n
+            return
         if not spec:
             return
         d = self.dist

@@ -15,14 +15,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, H, W, q, prepared=False):
+def _worker(rank, world, port, H, W, q, prepared=False, packed=False):
     import torch
     import torch.distributed as dist
     from kajiya_amd import multigpu
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        comm = multigpu.DistComm(dist, rank, world)
+        comm = multigpu.DistComm(dist, rank, world, packed=packed)
         strips = multigpu.plan_strips(H, world)
         g = torch.Generator().manual_seed(1234)
         results = {}
@@ -95,16 +95,17 @@ def test_distcomm_halo_exchange_gloo_world2():
 
 
 @pytest.mark.timeout(240)
-@pytest.mark.parametrize("world", [2, 4])
-def test_distcomm_prepared_plans_gloo(world):
-    """The cached-plan path of the frame loop (DistComm.prepare + run_prepared, several surfaces per batched group, replayed) with 2 and 4
-    processes: halo exchanges reach beyond the direct neighbour when strips are thin, all-gathers talk to every peer."""
+@pytest.mark.parametrize("world,packed", [(2, False), (4, False), (3, True), (4, True)])
+def test_distcomm_prepared_plans_gloo(world, packed):
+    """The cached-plan path of the frame loop (DistComm.prepare + run_prepared, several surfaces per batched group, replayed) with 2 to 4
+    processes: halo exchanges reach beyond the direct neighbour when strips are thin, all-gathers talk to every peer. `packed`: the opt-in
+    one-message-per-peer variant (KJ_SPLIT_PACKED=1)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     H, W = 208, 64
-    procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, q, True)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, q, True, packed)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=200) for _ in procs]
