@@ -145,3 +145,23 @@ def test_rtr_oracle_matches_golden_vectors(oracle):
         assert np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()) < 1e-3, k
     r = P.compare(got["resolved"].view(np.uint8).reshape(-1), ref["resolved"].view(np.uint8).reshape(-1), "r11g11b10f")
     assert r["mismatch_frac"] < 0.01, r
+
+
+@pytest.mark.parametrize("W,H", [(2, 2), (7, 5), (33, 17)])
+def test_rtr_oracle_tiny_and_ragged_extents(oracle, W, H):
+    """Extents that are odd, smaller than a tile or than the quarter-res validation grid: every pass must run, stay finite and touch only its
+    own images (the reference's dispatches are rounded up to 8x8 groups with out-of-range stores dropped)."""
+    sd = S.glossy_test_scene()
+    op = oracle.OraclePipeline(oracle.OracleScene(sd), W, H)
+    for i, fc in enumerate(T._frame_constants(W, H, 4, "textured")):
+        op.frame(fc)
+        if i == 2:
+            op.L.okj_rtr_set_options(op.rtr, 0)        # every pixel traces its own reflection ray from here on
+        res = op.rtr_frame(fc)
+        img = P.decode(res.copy().view(np.uint8), "r11g11b10f")
+        assert res.shape == (H, W) and np.isfinite(img).all()
+        hw, hh = (W + 1) // 2, (H + 1) // 2
+        for name, bpt in (("rtr.irradiance:0", 8), ("rtr.ray_orig:0", 16), ("rtr.reservoir:1", 8), ("rtr.rng:0", 4), ("refl_restir_invalidity_tex", 1)):
+            assert op.rtr_surface(name, np.uint8, (-1,)).size == hw * hh * bpt, name
+        t = op.rtr_surface("rtr.temporal:0", np.float16, (H, W, 4)).astype(np.float32)
+        assert np.isfinite(t).all()
