@@ -6,7 +6,6 @@
   WorldRenderer::prepare_frame_constants    crates/lib/kajiya/src/world_renderer.rs:1001-1108
   supersample offsets (Halton 2,3)          world_renderer.rs:425-428,1116-1129
 """
-import ctypes as C
 import math
 import numpy as np
 from .abi import KjFrameConstants

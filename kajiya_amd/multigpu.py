@@ -23,7 +23,6 @@ the exactness test).
 """
 import ctypes as C
 import os
-import numpy as np
 
 from .abi import KJ_RTDGI_PASS
 from . import lib as klib

@@ -6,7 +6,6 @@ SPATIAL_RESOLVE_OFFSETS from its own source. Neither is shipped here: a kajiya i
 tests, the bench and the scripts this module generates STAND-INS with the same shapes and value ranges — a real (unscrambled)
 Sobol sequence, seeded white-noise ranking / scrambling tiles (no blue-noise optimisation) and distance-sorted, quad-disjoint
 offset rings — so parity against the oracle is exact on identical tables while image quality is only representative."""
-import ctypes as C
 
 import numpy as np
 
