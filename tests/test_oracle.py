@@ -340,3 +340,80 @@ def test_ircache_coord_round_trip_and_cascade_boundaries(oracle):
     q = eye + np.array([2.3 * d2, -1.2 * d2, 0.4 * d2], np.float32) + np.array([8.5 * d2, 0, 0], np.float32)   # in cascade 2 for both eyes
     c1, c2 = coord(fc, q), coord(fc2, q)
     assert c1[3] == c2[3] == 2 and c1[0] - c2[0] == 3 and c1[1:3] == c2[1:3]
+
+
+def test_sky_matches_the_reference_s_second_statement_of_the_atmosphere(oracle):
+    """The reference states its atmosphere twice: `inc/atmosphere_felix.hlsl` (what the sky-cube shader runs and what the oracle / kernels follow)
+    and a Rust port, `crates/lib/rust-shaders/src/atmosphere.rs` ("Derived from atmosphere_felix.hlsl"). This is an independent float64
+    restatement of the RUST text; the oracle's sky cube must agree with it along sampled directions — a cross-source pin of the sky term."""
+    from kajiya_amd import frame
+    L = oracle.lib()
+    PLANET_RADIUS, ATM_H = 6371000.0, 100000.0
+    centre = np.array([0.0, -PLANET_RADIUS, 0.0])
+    C_R, C_M, C_O = np.array([5.802, 13.558, 33.100]) * 1e-6, np.array([3.996] * 3) * 1e-6, np.array([0.650, 1.881, 0.085]) * 1e-6
+
+    def density(p):
+        h = np.linalg.norm(p - centre) - PLANET_RADIUS
+        return np.array([np.exp(-max(0.0, h / (ATM_H * 0.08))), np.exp(-max(0.0, h / (ATM_H * 0.012))), max(0.0, 1.0 - abs(h - 25000.0) / 15000.0)])
+
+    def isect(o, d):
+        o = o - centre
+        a, b, c = d @ d, 2.0 * (o @ d), o @ o - (PLANET_RADIUS + ATM_H) ** 2
+        disc = b * b - 4 * a * c
+        return (-1.0, -1.0) if disc < 0 else ((-b - np.sqrt(disc)) / (2 * a), (-b + np.sqrt(disc)) / (2 * a))
+
+    def optical_depth(o, d):
+        step = isect(o, d)[1] / 8
+        return sum(density(o + d * (i + 0.5) * step) * step for i in range(8))
+
+    def absorb(od):
+        return np.exp(-(od[0] * C_R + od[1] * C_M * 1.1 + od[2] * C_O))
+
+    def scattering(rd, ld):
+        o = np.zeros(3)
+        x0, x1 = isect(o, rd)
+        length = x1
+        if x0 > 0:
+            o = o + rd * x0; length -= x0
+        costh = rd @ ld
+        phase_r = 3.0 * (1.0 + costh * costh) / (16.0 * np.pi)
+        g = min(0.85, 0.9381); k = 1.55 * g - 0.55 * g ** 3
+        phase_m = (1.0 - k * k) / ((4.0 * np.pi) * (1.0 - k * costh) ** 2)
+        od, ray, mie, prev = np.zeros(3), np.zeros(3), np.zeros(3), 0.0
+        for i in range(1, 17):
+            t = (i / 16.0) ** 5.0 * length
+            step = t - prev
+            p = o + rd * (0.5 * (prev + t))
+            dens = density(p)
+            od = od + dens * step
+            vt, lt = absorb(od), absorb(optical_depth(p, ld))
+            ray = ray + vt * lt * phase_r * dens[0] * step
+            mie = mie + vt * lt * phase_m * dens[1] * step
+            prev = t
+        return (ray * C_R + mie * C_M) * 20.0
+
+    fs = frame.FrameState((64, 64))
+    fc = fs.prepare_frame_constants(frame.CameraMatrices((0, 0, 0), np.eye(3), 60.0, 1.0))
+    sun = np.array(list(fc.sun_direction)[:3], np.float64)
+    cube = np.zeros((6, 64, 64, 4), np.uint16)
+    L.okj_sky_cube_render(C.byref(fc), cube.ctypes.data)
+    rng = np.random.RandomState(2)
+    out = (C.c_float * 4)()
+    worst = 0.0
+    for _ in range(60):
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        if abs(d[1]) < 0.02:
+            continue                                    # the horizon line: a texel mixes sky and ground there
+        # texel-centre direction nearest to d (the cube stores one value per texel): sample the cube, then restate at the same direction by
+        # snapping d to that texel centre through the cube's own face mapping (dominant axis, 64 texels per face)
+        m = np.argmax(np.abs(d)); s = np.sign(d[m])
+        uv = np.delete(d, m) / abs(d[m])
+        uv = (np.floor((uv * 0.5 + 0.5) * 64) + 0.5) / 64 * 2 - 1
+        snapped = np.insert(uv, m, s); snapped /= np.linalg.norm(snapped)
+        L.okj_sample_cube(cube.ctypes.data, 64, (C.c_float * 3)(*snapped), out)
+        ref = scattering(snapped, sun) * float(fc.pre_exposure)
+        got = np.array(out[:3], np.float64)
+        err = np.abs(got - ref).max() / max(ref.max(), 1e-6)
+        worst = max(worst, err)
+    print(f"sky cube vs the Rust statement of the atmosphere: worst relative error {worst:.2e}")
+    assert worst < 2e-3     # fp16 storage of the cube (2^-11) + fp32 integration
