@@ -417,3 +417,92 @@ def test_sky_matches_the_reference_s_second_statement_of_the_atmosphere(oracle):
         worst = max(worst, err)
     print(f"sky cube vs the Rust statement of the atmosphere: worst relative error {worst:.2e}")
     assert worst < 2e-3     # fp16 storage of the cube (2^-11) + fp32 integration
+
+
+def _orbit_frame_constants(W, H, n, rate=0.01):
+    from kajiya_amd import frame
+    fs = frame.FrameState((W, H))
+    out = []
+    for i in range(n):
+        out.append(fs.prepare_frame_constants(frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=rate)))
+        fs.retire_frame()
+    return out
+
+
+def test_reprojection_map_matches_the_reference_s_rust_statement(oracle):
+    """`calculate_reprojection_map` exists twice in the reference: the HLSL the oracle / kernels follow and
+    `crates/lib/rust-shaders/src/calculate_reprojection_map.rs`. This float64 numpy restatement of the RUST text (Bilinear::new, the gather
+    order `.wzxy()`, the plane-distance test and its grazing-angle threshold, validity bits) must agree with the oracle on a moving-camera
+    frame: the motion vectors and the per-pixel 4-bit validity mask."""
+    from kajiya_amd import scenes
+    W, H = 160, 96
+    op = oracle.OraclePipeline(oracle.OracleScene(scenes.cornell_box()), W, H)
+    fcs = _orbit_frame_constants(W, H, 3, rate=0.03)
+    for fc in fcs[:2]:
+        op.render_inputs(fc); op.reprojection(fc)
+    prev_depth = op.depth.astype(np.float64).copy()
+    fc = fcs[2]
+    op.render_inputs(fc); op.reprojection(fc)
+    got = op.reprojection_map.astype(np.float64) / 32767.0
+    vc = fc.view_constants
+
+    def m44(a):
+        return np.array(list(a), np.float64).reshape(4, 4).T
+    c2v, v2c, c2pc, pc2pv = m44(vc.clip_to_view), m44(vc.view_to_clip), m44(vc.clip_to_prev_clip), m44(vc.prev_clip_to_prev_view)
+    ys, xs = np.mgrid[0:H, 0:W]
+    uv = np.stack([(xs + 0.5) / W, (ys + 0.5) / H], -1)
+    cs = (uv - 0.5) * np.array([2.0, -2.0])
+    depth = op.depth.astype(np.float64)
+    gn = op.geometric_normal
+    normal_vs = np.stack([((gn >> 20) & 1023), ((gn >> 10) & 1023), (gn & 1023)], -1).astype(np.float64) / 1023.0 * 2.0 - 1.0
+    vel = op.velocity.view(np.float16).astype(np.float64).reshape(H, W, 4)[..., :3]
+    pos_cs = np.concatenate([cs, depth[..., None], np.ones((H, W, 1))], -1)
+    pos_vs = pos_cs @ c2v.T
+    sky = depth == 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dist_to_point = -(pos_vs[..., 2] / pos_vs[..., 3])
+        prev_vs = pos_vs / pos_vs[..., 3:4] + np.concatenate([vel, np.zeros((H, W, 1))], -1)
+        prev_vs = np.where(sky[..., None], pos_vs, prev_vs)
+        prev_pcs = (prev_vs @ v2c.T) @ c2pc.T
+        prev_xy = np.where(sky[..., None], prev_pcs[..., :2], prev_pcs[..., :2] / prev_pcs[..., 3:4])
+    prev_uv = prev_xy * np.array([0.5, -0.5]) + 0.5
+    uv_diff = prev_uv - uv
+    # the one place the two statements differ: the (unused) Rust port truncates, the HLSL floors — one quantum apart for negative motion; HLSL wins
+    uv_diff_q = np.floor(uv_diff * 32767.0 + 0.5) / 32767.0
+    prev_uv_q = uv + uv_diff_q
+    with np.errstate(divide="ignore", invalid="ignore"):
+        prev_pvs = prev_pcs @ pc2pv.T
+        prev_pvs = prev_pvs / prev_pvs[..., 3:4]
+    plane_dist_prev_dz = np.minimum(normal_vs[..., 2], -0.2)
+    t = prev_uv_q * np.array([W, H]) - 0.5
+    origin = np.trunc(t).astype(int)
+    offs = [(0, 0), (1, 0), (0, 1), (1, 1)]
+    quad_validity = []
+    thr = 0.001 * (1080.0 / H)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pos3 = pos_vs[..., :3] / pos_vs[..., 3:4]
+        ndotv = (normal_vs * (pos3 / np.linalg.norm(pos3, axis=-1, keepdims=True))).sum(-1)
+        limit = thr * dist_to_point / -ndotv
+        for ox, oy in offs:
+            px_, py_ = origin[..., 0] + ox, origin[..., 1] + oy
+            d = prev_depth[np.clip(py_, 0, H - 1), np.clip(px_, 0, W - 1)]            # gather with clamp addressing, reordered .wzxy() = px0..px3
+            view_z = 1.0 / (d * -c2v[3, 2])                                            # depth_to_view_z: clip_to_view.to_cols_array_2d()[2][3] = row 3, col 2
+            dist = np.abs(plane_dist_prev_dz * (view_z - prev_pvs[..., 2]))
+            inb = (px_ >= 0) & (py_ >= 0) & (px_ < W) & (py_ < H)
+            quad_validity.append(((limit >= dist) & inb).astype(np.float64))              # Vec4::step(edge = quad_dists, x = limit)
+    validity = (quad_validity[0] + 2 * quad_validity[1] + 4 * quad_validity[2] + 8 * quad_validity[3]) / 15.0
+    frac = np.abs(0.5 - (prev_uv_q * np.array([W, H]) - np.trunc(prev_uv_q * np.array([W, H]))))
+    accuracy = 1.0 - frac[..., 0] - frac[..., 1]
+    geo = ~sky
+    dq = np.abs(got[..., :2] - uv_diff_q).max(-1) * 32767.0
+    print("motion quantum differences: ", {k: int((np.rint(dq) == k).sum()) for k in range(4)}, "sky", int(sky.sum()))
+    assert dq.max() <= 1.01 and (dq > 0.01).mean() < 0.02          # fp32 vs fp64 matrix products flip a rounding now and then
+    assert (got[..., 2:][sky] == 0).all()
+    nonneg = geo & (t[..., 0] >= 0) & (t[..., 1] >= 0)                                   # Rust truncates, HLSL floors: identical for non-negative coordinates
+    bits_got = np.rint(got[..., 2] * 15.0).astype(int)
+    bits_ref = np.rint(validity * 15.0).astype(int)
+    agree = (bits_got == bits_ref)[nonneg].mean()
+    print(f"reprojection validity bits agree on {agree:.4f} of {nonneg.sum()} pixels; moving pixels {np.abs(uv_diff_q[geo]).max() * W:.1f} px max")
+    assert agree > 0.995 and (bits_ref[nonneg] != 15).mean() > 0.01                       # and the frame has real disocclusions
+    # (.w: the HLSL's accuracy term is a newer formula — grazing-angle smoothstep, -1 off screen — than the Rust port's texel-centre distance; not compared)
+    assert np.isfinite(accuracy[nonneg]).all()
