@@ -506,3 +506,43 @@ def test_reprojection_map_matches_the_reference_s_rust_statement(oracle):
     assert agree > 0.995 and (bits_ref[nonneg] != 15).mean() > 0.01                       # and the frame has real disocclusions
     # (.w: the HLSL's accuracy term is a newer formula — grazing-angle smoothstep, -1 off screen — than the Rust port's texel-centre distance; not compared)
     assert np.isfinite(accuracy[nonneg]).all()
+
+
+def test_ssgi_spatial_filter_matches_the_reference_s_rust_statement(oracle):
+    """SSGI's edge-aware 3x3 filter exists as HLSL (`ssgi/spatial_filter.hlsl`, what runs: USE_RUST_SHADERS = false in renderers/ssgi.rs:7) and
+    as Rust (`rust-shaders/src/ssgi.rs: spatial_filter_cs`). numpy restatement of the Rust text on the oracle's own `ssgi_tex`, half-res depth
+    and view normals vs the oracle's `spatially_filtered_tex`. (The Rust upsample / temporal passes have drifted from the HLSL — a normal
+    weight the HLSL comments out, a reprojection-dependent blend factor — so they are not a second statement of what runs.)"""
+    from kajiya_amd import scenes
+    W, H = 128, 96
+    hw, hh = W // 2, H // 2
+    op = oracle.OraclePipeline(oracle.OracleScene(scenes.cornell_box()), W, H)
+    for fc in _orbit_frame_constants(W, H, 3):
+        op.render_inputs(fc); op.reprojection(fc); op.ssgi_frame(fc)
+    ssgi = op.ssgi_surface("ssgi_tex", np.float16, (hh, hw)).astype(np.float64)
+    depth = op.ssgi_surface("half_depth_tex", np.float32, (hh, hw)).astype(np.float64)
+    nrm = np.maximum(op.ssgi_surface("half_view_normal_tex", np.int8, (hh, hw, 4)).astype(np.float64) / 127.0, -1.0)[..., :3]
+    got = op.ssgi_surface("spatially_filtered_tex", np.float16, (hh, hw)).astype(np.float64)
+
+    def shifted(a, dx, dy, fill=0.0):     # a[y + dy, x + dx] with out-of-range fetches returning 0
+        out = np.full_like(a, fill)
+        ys, ye = max(0, -dy), min(a.shape[0], a.shape[0] - dy)
+        xs, xe = max(0, -dx), min(a.shape[1], a.shape[1] - dx)
+        out[ys:ye, xs:xe] = a[ys + dy:ye + dy, xs + dx:xe + dx]
+        return out
+    result, w_sum = ssgi.copy(), np.ones_like(ssgi)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            if dx == 0 and dy == 0:
+                continue
+            d, s, n = shifted(depth, dx, dy), shifted(ssgi, dx, dy), shifted(nrm, dx, dy)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                depth_factor = np.exp2(-200.0 * np.abs(1.0 - depth / d))
+            nf = np.maximum(0.0, (n * nrm).sum(-1)) ** 4
+            w = np.where(d != 0.0, depth_factor * nf, 0.0)
+            w_sum += w
+            result += s * w
+    ref = np.where(depth != 0.0, result / np.maximum(w_sum, 1e-5), 0.0)
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
+    print(f"ssgi spatial filter vs the Rust statement: max rel err {err.max():.2e}, occluded fraction {(ref[depth != 0] < 0.9).mean():.3f}")
+    assert err.max() < 2e-3 and (depth != 0).mean() > 0.5 and (ref[depth != 0] < 0.95).mean() > 0.02      # fp16 storage; the image has contrast
