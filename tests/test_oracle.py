@@ -546,3 +546,69 @@ def test_ssgi_spatial_filter_matches_the_reference_s_rust_statement(oracle):
     err = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
     print(f"ssgi spatial filter vs the Rust statement: max rel err {err.max():.2e}, occluded fraction {(ref[depth != 0] < 0.9).mean():.3f}")
     assert err.max() < 2e-3 and (depth != 0).mean() > 0.5 and (ref[depth != 0] < 0.95).mean() > 0.02      # fp16 storage; the image has contrast
+
+
+def test_packing_matches_the_reference_s_rust_statement(oracle):
+    """SURVEY 8c names `rust-shaders-shared/src/util.rs:158-210,307-383` as the independent statement of the packing helpers. numpy
+    restatement of that Rust text, bit-exact on random inputs: `float3_to_rgb9e5` / `rgb9e5_to_float3`, `unpack_normal_11_10_11`,
+    `unpack_color_888`, `hash1` / `hash_combine2` / `hash3`. The Rust `pack_unorm` truncates and its `pack_color_888` uses a bit-trick
+    sqrt where the HLSL that runs rounds (`+ 0.5`) and calls sqrt (inc/pack_unpack.hlsl:9-12,49-56): for those two the test only checks
+    the drift is what that difference predicts (packed fields differ by at most one step, never below the truncated value)."""
+    L = oracle.lib()
+    rng = np.random.RandomState(11)
+    f32, u32 = np.float32, np.uint32
+    out = (C.c_float * 3)()
+
+    def rust_float3_to_rgb9e5(rgb):
+        max_valid = f32(511.0 / 512.0 * 65536.0)
+        c = np.clip(np.asarray(rgb, f32), f32(0), max_valid)
+        maxrgb = c.max()
+        floor_log2 = int(maxrgb.view(u32) >> 23) - 127
+        exp_shared = max(-15 - 1, floor_log2) + 1 + 15
+        denom = f32(2.0) ** f32(exp_shared - 15 - 9)
+        if int(np.floor(maxrgb / denom + f32(0.5))) == 512:
+            denom = f32(denom * 2); exp_shared += 1
+        m = np.floor(c / denom + f32(0.5)).astype(np.uint64)
+        return int((m[0] << 23) | (m[1] << 14) | (m[2] << 5) | exp_shared) & 0xffffffff
+
+    def rust_rgb9e5_to_float3(v):
+        scale = f32(2.0) ** f32((v & 31) - 15 - 9)
+        return [f32((v >> 23) & 511) * scale, f32((v >> 14) & 511) * scale, f32((v >> 5) & 511) * scale]
+
+    cases = [rng.uniform(0, 1, 3) * 10.0 ** rng.uniform(-7, 5) for _ in range(4000)]
+    cases += [(0, 0, 0), (65408, 65408, 65408), (1e9, 1, 1), (-1, 0.5, 2), (0.99951171875, 0, 0), (0.999, 0.999, 0.999), (2 ** -16, 2 ** -17, 0)]
+    for rgb in cases:
+        rgb = [float(f32(x)) for x in rgb]
+        v = L.okj_float3_to_rgb9e5(*rgb)
+        assert v == rust_float3_to_rgb9e5(rgb), (rgb, hex(v))
+        L.okj_rgb9e5_to_float3(v, out)
+        assert [f32(x) for x in out] == rust_rgb9e5_to_float3(v)
+    for v in rng.randint(0, 2 ** 32, 2000, dtype=np.uint64):
+        v = int(v)
+        L.okj_rgb9e5_to_float3(v, out)
+        assert [f32(x) for x in out] == rust_rgb9e5_to_float3(v)
+        # unpack_normal_11_10_11: per-field unorm / max, * 2 - 1, normalised (util.rs:158-167)
+        raw = np.array([f32(v & 2047) / f32(2047), f32((v >> 11) & 1023) / f32(1023), f32(v >> 21) / f32(2047)], f32) * f32(2) - f32(1)
+        L.okj_unpack_normal_11_10_11(v, out)
+        n = raw / np.sqrt((raw.astype(np.float64) ** 2).sum())
+        assert np.abs(np.array(out[:]) - n).max() < 3e-7
+        # unpack_color_888 (util.rs:186-193)
+        c = np.array([f32(v & 255), f32((v >> 8) & 255), f32((v >> 16) & 255)], f32) / f32(255)
+        L.okj_unpack_color_888(v, out)
+        assert [f32(x) for x in out] == list(c * c)
+        # pack: HLSL rounds, Rust truncates
+        x = rng.uniform(-1, 1, 3); x /= np.linalg.norm(x)
+        p = L.okj_pack_normal_11_10_11(*[float(t) for t in x])
+        for shift, bits, val in ((0, 11, x[0]), (11, 10, x[1]), (21, 11, x[2])):
+            mx = (1 << bits) - 1
+            trunc = int(f32(np.clip(f32(val) * f32(0.5) + f32(0.5), 0, 1)) * f32(mx))
+            assert ((p >> shift) & mx) - trunc in (0, 1)
+    # hashes (util.rs:350-377) on random words: wrapping u32 arithmetic
+    def rust_hash1(x):
+        x = (x + (x << 10)) & 0xffffffff; x ^= x >> 6
+        x = (x + (x << 3)) & 0xffffffff; x ^= x >> 11
+        return (x + (x << 15)) & 0xffffffff
+    for a, b, c in rng.randint(0, 2 ** 32, (2000, 3), dtype=np.uint64):
+        a, b, c = int(a), int(b), int(c)
+        assert L.okj_hash1(a) == rust_hash1(a) == _hash1(a)
+        assert L.okj_hash3(a, b, c) == _hash_combine2(a, _hash_combine2(b, rust_hash1(c)))
