@@ -612,3 +612,30 @@ def test_packing_matches_the_reference_s_rust_statement(oracle):
         a, b, c = int(a), int(b), int(c)
         assert L.okj_hash1(a) == rust_hash1(a) == _hash1(a)
         assert L.okj_hash3(a, b, c) == _hash_combine2(a, _hash_combine2(b, rust_hash1(c)))
+
+
+def test_half_res_extracts_match_the_reference_s_rust_statement(oracle):
+    """`GbufferDepth::{half_depth, half_view_normal}` (renderers/mod.rs:31-71) exist as HLSL (`extract_half_res_depth.hlsl`,
+    `extract_half_res_gbuffer_view_normal_rgba8.hlsl`) and as Rust (`rust-shaders/src/extract_half_res_*.rs`): the sub-pixel picked from
+    each 2x2 quad cycles with `frame_index & 3` — (1,1) (1,0) (0,0) (0,1) in `inc/frame_constants.hlsl:235-240`, which is what runs and what
+    this test expects; the Rust files ("// not used") carry an older table (0,0) (1,1) (1,0) (0,1) — and the normal is the gbuffer's 11-10-11 field, not renormalised
+    before the world-to-view rotation, normalised after, stored RGBA8_SNORM."""
+    from kajiya_amd import scenes
+    W, H = 96, 64
+    hw, hh = W // 2, H // 2
+    op = oracle.OraclePipeline(oracle.OracleScene(scenes.cornell_box()), W, H)
+    offsets = [(1, 1), (1, 0), (0, 0), (0, 1)]
+    for fc in _orbit_frame_constants(W, H, 5):
+        op.render_inputs(fc); op.reprojection(fc); op.ssgi_frame(fc)
+        ox, oy = offsets[fc.frame_index & 3]
+        depth = op.ssgi_surface("half_depth_tex", np.float32, (hh, hw))
+        assert np.array_equal(depth, op.depth[oy::2, ox::2])
+        p = op.gbuffer[oy::2, ox::2, 1]
+        n = np.stack([(p & 2047) / 2047.0, ((p >> 11) & 1023) / 1023.0, (p >> 21) / 2047.0], -1) * 2.0 - 1.0
+        w2v = np.array(fc.view_constants.world_to_view[:], np.float64).reshape(4, 4).T[:3, :3]
+        nv = n @ w2v.T
+        nv /= np.linalg.norm(nv, axis=-1, keepdims=True)
+        got = op.ssgi_surface("half_view_normal_tex", np.int8, (hh, hw, 4)).astype(np.int32)
+        want = np.round(nv * 127.0)
+        hit = depth != 0
+        assert hit.mean() > 0.5 and np.abs(got[..., :3] - want)[hit].max() <= 1 and (np.abs(got[..., :3] - want)[hit] != 0).mean() < 0.01
