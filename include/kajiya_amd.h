@@ -484,6 +484,33 @@ KjStatus kj_rtr_filter_temporal(KjRtr* r, const KjRtrParams* params, const void*
 KjStatus kj_rtr_surface(KjRtr* r, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 KjStatus kj_rtr_ray_counts(KjRtr* r, uint64_t* out_closest, uint64_t* out_any);
 
+/* ---------------------------------------------------------------------------
+ * Post-processing (SURVEY 8f-4 "minimal post": the tail of the frame, from the anti-aliased image to the display-referred one)
+ *   PostProcessRenderer::render(rg, input, bindless_set, post_exposure_mult, contrast, exposure_histogram_clipping) -> Handle<Image>
+ *                                                                                               renderers/post.rs:237-271
+ *   blur_pyramid (post.rs:10-61; rust-shaders/src/blur.rs for mip 0, shaders/blur.hlsl for the rest), luminance histogram
+ *   (post.rs:138-186, shaders/post/luminance_histogram_*.hlsl), rev_blur_pyramid (post.rs:63-110, rust-shaders/src/rev_blur.rs),
+ *   "post combine" (shaders/post_combine.hlsl + inc/color/display_transform.hlsl and the colour headers it pulls in).
+ * input: RGBA16F full-res image (TaaOutput.this_frame_out; kajiya's motion blur between the two is not included). Output:
+ * B10G11R11_UFLOAT full-res, LINEAR display-referred values in [0, ~1] — kajiya's swap chain applies the sRGB transfer function.
+ * The Bezold-Brucke LUT (bindless texture 2: 64 x 1 RG16F, lut_renderers.rs:45-76) is caller data like the blue-noise image: host
+ * pointer, copied at create. frame_index (dither offset) and pre_exposure (histogram) come from kj_frame_begin's constants.
+ * Surfaces: "blur_pyramid:<mip>", "rev_blur_pyramid:<mip>" (B10G11R11, mip k = max(1, ceil(W/2) >> k) x max(1, ceil(H/2) >> k)),
+ * "histogram" (256 x u32), "output".
+ * kj_post_read_back_histogram = PostProcessRenderer::read_back_histogram (post.rs:188-235) on the host-visible copy of the
+ * histogram: like the reference's mapped buffer it holds whatever copy has completed (synchronise the stream for a deterministic
+ * answer); out_histogram256 optional. kj_luminance_histogram_mean_log2 is the same arithmetic on a caller's histogram (no device).
+ * --------------------------------------------------------------------------- */
+typedef struct KjPost KjPost;
+KjStatus kj_post_create(KjDevice* dev, const uint16_t* bezold_brucke_lut_rg16f_64, KjPost** out);
+void kj_post_destroy(KjPost* p);
+KjStatus kj_post_render(KjPost* p, const void* input_rgba16f, uint32_t width, uint32_t height, float post_exposure_mult, float contrast,
+                        const void** out_b10g11r11, void* stream);
+KjStatus kj_post_read_back_histogram(KjPost* p, float clipping_low, float clipping_high, float* out_image_log2_lum, uint32_t* out_histogram256);
+KjStatus kj_luminance_histogram_mean_log2(const uint32_t* histogram256, float clipping_low, float clipping_high, float* out_image_log2_lum);
+KjStatus kj_post_surface(KjPost* p, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
+KjStatus kj_post_mip_levels(KjPost* p, uint32_t* out_levels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,8 +11,10 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <array>
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -92,6 +94,42 @@ inline float radical_inverse(uint32_t n, uint32_t base) {
     return val;
 }
 
+// ---------------------------------------------------------------- exposure (world_renderer.rs:217-285,919-948), f32 as there
+struct HistogramClipping { float low = 0.0f, high = 0.0f; };
+struct DynamicExposureState {
+    bool enabled = false;
+    float speed_log2 = 0.0f;
+    HistogramClipping histogram_clipping;
+    float ev_fast = 0.0f, ev_slow = 0.0f;
+    float ev_smoothed() const { return enabled ? (ev_slow + ev_fast) * 0.5f + -2.0f /* DYNAMIC_EXPOSURE_BIAS */ : 0.0f; }
+    void update(float ev, float dt) {
+        if (!enabled) return;
+        ev = std::min(std::max(ev, -16.0f), 16.0f);
+        dt = dt * std::exp2(speed_log2);
+        const float t_fast = 1.0f - std::exp(-1.0f * dt);
+        ev_fast = (ev - ev_fast) * t_fast + ev_fast;
+        const float t_slow = 1.0f - std::exp(-0.25f * dt);
+        ev_slow = (ev - ev_slow) * t_slow + ev_slow;
+    }
+};
+struct ExposureState { float pre_mult = 1.0f, post_mult = 1.0f, pre_mult_prev = 1.0f, pre_mult_delta = 1.0f; };
+enum class RenderMode { Standard = 0, Reference = 1 };
+// WorldRenderer::update_pre_exposure (world_renderer.rs:919-948); image_log2_lum = PostProcessRenderer::image_log2_lum
+inline void update_pre_exposure(ExposureState& st, DynamicExposureState& dynamic_exposure, float ev_shift, float image_log2_lum, RenderMode mode) {
+    const float dt = 1.0f / 60.0f;
+    dynamic_exposure.update(-image_log2_lum, dt);
+    const float ev_mult = std::exp2(ev_shift + dynamic_exposure.ev_smoothed());
+    st.pre_mult_prev = st.pre_mult;
+    if (mode == RenderMode::Standard) {
+        st.pre_mult = st.pre_mult * 0.9f + ev_mult * 0.1f;
+        st.post_mult = ev_mult / st.pre_mult;
+    } else {
+        st.pre_mult = 1.0f;
+        st.post_mult = ev_mult;
+    }
+    st.pre_mult_delta = st.pre_mult / st.pre_mult_prev;
+}
+
 // The part of WorldRenderer that produces FrameConstants each frame (prepare_frame_constants, world_renderer.rs:1001-1108).
 struct FrameState {
     uint32_t render_extent[2];
@@ -100,7 +138,7 @@ struct FrameState {
     float sun_color_multiplier[3] = {1, 1, 1}, sky_ambient[3] = {0, 0, 0};
     bool use_taa_jitter = true;
     uint32_t frame_idx = 0, triangle_light_count = 0;
-    float pre_exposure = 1.0f;
+    float pre_exposure = 1.0f, pre_exposure_prev = 1.0f, pre_exposure_delta = 1.0f;   // ExposureState (world_renderer.rs:1084-1086)
     bool have_prev = false;
     CameraMatrices prev_camera;
 
@@ -141,7 +179,7 @@ struct FrameState {
         const double real_sun_angular_radius = (0.53 * 3.14159265358979323846 / 180.0) * 0.5;
         fc.sun_angular_radius_cos = float(std::cos(double(sun_size_multiplier) * real_sun_angular_radius));
         fc.triangle_light_count = triangle_light_count;
-        fc.pre_exposure = pre_exposure; fc.pre_exposure_prev = pre_exposure; fc.pre_exposure_delta = 1.0f;
+        fc.pre_exposure = pre_exposure; fc.pre_exposure_prev = pre_exposure_prev; fc.pre_exposure_delta = pre_exposure_delta;
         fc.render_overrides.flags = 0; fc.render_overrides.material_roughness_scale = 1.0f;
         fc.ircache_grid_center[3] = 1.0f;
         if (ircache) {
@@ -338,10 +376,29 @@ struct TaaRenderer {
     }
 };
 
+// PostProcessRenderer (renderers/post.rs:112-272). `image_log2_lum` is refreshed by read_back_histogram at the top of render(), from
+// whatever histogram copy has completed (the reference reads its mapped buffer the same way, a frame or more behind).
+struct PostProcessRenderer {
+    KjPost* h = nullptr;
+    float image_log2_lum = 0.0f;
+    PostProcessRenderer(Device& d, const uint16_t* bezold_brucke_lut_rg16f_64) { check(kj_post_create(d.h, bezold_brucke_lut_rg16f_64, &h), "kj_post_create"); }
+    ~PostProcessRenderer() { kj_post_destroy(h); }
+    PostProcessRenderer(const PostProcessRenderer&) = delete;
+    PostProcessRenderer& operator=(const PostProcessRenderer&) = delete;
+    // -> B10G11R11_UFLOAT image, linear display-referred
+    const void* render(const void* input_rgba16f, uint32_t w, uint32_t hgt, float post_exposure_mult, float contrast, HistogramClipping exposure_histogram_clipping, hipStream_t s) {
+        check(kj_post_read_back_histogram(h, exposure_histogram_clipping.low, exposure_histogram_clipping.high, &image_log2_lum, nullptr), "kj_post_read_back_histogram");
+        const void* out = nullptr;
+        check(kj_post_render(h, input_rgba16f, w, hgt, post_exposure_mult, contrast, &out, s), "kj_post_render");
+        return out;
+    }
+};
+
 // ---------------------------------------------------------------- WorldRenderer::prepare_render_graph_standard (world_render_passes.rs:13-292)
 struct FrameOutput {
     const void* reprojection_map; const void* ssgi_tex; const void* denoised_shadow_mask; KjRtdgiOutput rtdgi; const void* rtr;
     const void* lit /* RGBA16F "debug_out_tex" */; KjTaaOutput anti_aliased;
+    const void* post_processed = nullptr;   // B10G11R11_UFLOAT, when WorldRenderer::post is set
 };
 struct WorldRenderer {
     Device& device; Scene& scene;
@@ -355,6 +412,17 @@ struct WorldRenderer {
     bool reset_reference_accumulation = false;      // world_renderer.rs:183
     DeviceImage refpt_accum;                         // "refpt.accum" temporal (RGBA32F: running mean + sample count)
     float sky_key[8] = {-1, 0, 0, 0, 0, 0, 0, 0};
+    // the tail of the frame (world_render_passes.rs:281-289); kajiya's motion blur between TAA and post is not included
+    std::unique_ptr<PostProcessRenderer> post;      // set by enable_post(); without it the frame ends at TAA, pre-exposure stays 1
+    float ev_shift = 0.0f, contrast = 1.0f;
+    DynamicExposureState dynamic_exposure;
+    ExposureState exposure_state[2];                 // one per render mode
+    void enable_post(const uint16_t* bezold_brucke_lut_rg16f_64) { post.reset(new PostProcessRenderer(device, bezold_brucke_lut_rg16f_64)); }
+    void update_pre_exposure(RenderMode mode) {      // world_renderer.rs:919-948
+        ExposureState& st = exposure_state[int(mode)];
+        kajiya_amd::update_pre_exposure(st, dynamic_exposure, ev_shift, post ? post->image_log2_lum : 0.0f, mode);
+        frame_state.pre_exposure = st.pre_mult; frame_state.pre_exposure_prev = st.pre_mult_prev; frame_state.pre_exposure_delta = st.pre_mult_delta;
+    }
 
     WorldRenderer(Device& dev, Scene& sc, uint32_t w, uint32_t h, const KjRtrTables& rtr_tables)
         : device(dev), scene(sc), render_extent{w, h}, temporal_upscale_extent{w, h}, gbuffer_depth(w, h), sky_cube(6 * 64 * 64 * 8), convolved_sky_cube(6 * 16 * 16 * 8),
@@ -364,6 +432,7 @@ struct WorldRenderer {
     // One frame of the lighting path for `camera`. The G-buffer comes from kj_raster_gbuffer here (the reference rasterises it; a host with
     // its own raster fills gbuffer_depth and calls the rest).
     FrameOutput prepare_render_graph_standard(const CameraMatrices& camera, hipStream_t s) {
+        if (post) update_pre_exposure(RenderMode::Standard);                                                     // world_renderer.rs:959
         frame_state.triangle_light_count = scene.triangle_light_count();
         const KjFrameConstants fc = frame_state.prepare_frame_constants(camera, ircache.h);
         check(kj_frame_begin(device.h, &fc, s), "kj_frame_begin");
@@ -393,6 +462,9 @@ struct WorldRenderer {
                                debug_shading_mode, s), "kj_light_gbuffer");                                      // :219-234
         o.lit = debug_out_tex.p;
         o.anti_aliased = taa.render(debug_out_tex.p, W, H, o.reprojection_map, gbuffer_depth.depth.p, temporal_upscale_extent, s);   // :254-263
+        if (post)                                                                                              // :281-289
+            o.post_processed = post->render(o.anti_aliased.this_frame_out, temporal_upscale_extent[0], temporal_upscale_extent[1],
+                                            exposure_state[0].post_mult, contrast, dynamic_exposure.histogram_clipping, s);
         frame_state.retire_frame();
         return o;
     }

@@ -90,7 +90,9 @@ class FrameState:
         self.frame_idx = 0
         self.prev_camera = None
         self.triangle_light_count = 0
-        self.pre_exposure = 1.0
+        self.pre_exposure = 1.0        # ExposureState (kajiya_amd/exposure.py: Exposure.apply), world_renderer.rs:1084-1086
+        self.pre_exposure_prev = 1.0
+        self.pre_exposure_delta = 1.0
         self.ircache_grid_center = (0.0, 0.0, 0.0, 1.0)
         self.ircache_cascades = None  # list of 12 (origin[4], scrolled[4]) once the ircache is enabled
         # IrcacheRenderer host state (renderers/ircache.rs:92-158)
@@ -149,8 +151,8 @@ class FrameState:
         fc.sun_angular_radius_cos = math.cos(self.sun_size_multiplier * real_sun_angular_radius)
         fc.triangle_light_count = self.triangle_light_count
         fc.pre_exposure = self.pre_exposure
-        fc.pre_exposure_prev = self.pre_exposure
-        fc.pre_exposure_delta = 1.0
+        fc.pre_exposure_prev = self.pre_exposure_prev
+        fc.pre_exposure_delta = self.pre_exposure_delta
         fc.render_overrides.flags = 0
         fc.render_overrides.material_roughness_scale = 1.0
         for i in range(4):

@@ -30,6 +30,7 @@ EXPORTS = [
     "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_surface",
     "kj_baked_mesh_view", "kj_baked_image_view", "kj_baked_image_mip", "kj_baked_image_decode_rgba8",
     "kj_rtr_create", "kj_rtr_destroy", "kj_rtr_set_options", "kj_rtr_trace", "kj_rtr_render_specular_lights", "kj_rtr_filter_temporal", "kj_rtr_surface", "kj_rtr_ray_counts",
+    "kj_post_create", "kj_post_destroy", "kj_post_render", "kj_post_read_back_histogram", "kj_luminance_histogram_mean_log2", "kj_post_surface", "kj_post_mip_levels",
 ]
 
 _LIB = None
@@ -104,6 +105,12 @@ def load():
         "kj_rtr_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_rtr_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "kj_trace_sun_shadow_mask": [vp, vp, C.POINTER(KjGbufferDepth), vp, vp, vp],
+        "kj_post_create": [vp, vp, C.POINTER(vp)],
+        "kj_post_render": [vp, vp, u32, u32, C.c_float, C.c_float, C.POINTER(vp), vp],
+        "kj_post_read_back_histogram": [vp, C.c_float, C.c_float, C.POINTER(C.c_float), vp],
+        "kj_luminance_histogram_mean_log2": [vp, C.c_float, C.c_float, C.POINTER(C.c_float)],
+        "kj_post_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
+        "kj_post_mip_levels": [vp, C.POINTER(u32)],
         "kj_ssgi_create": [vp, C.POINTER(vp)],
         "kj_ssgi_render": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.POINTER(vp), vp],
         "kj_ssgi_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
@@ -114,7 +121,7 @@ def load():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = i32
-    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy", "kj_shadow_denoise_destroy", "kj_rtr_destroy"):
+    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy", "kj_shadow_denoise_destroy", "kj_rtr_destroy", "kj_post_destroy"):
         f = getattr(L, name)
         f.argtypes = [vp]
         f.restype = None
@@ -551,6 +558,64 @@ class GpuPipeline:
                 self.L.kj_rtr_destroy(self.rtr)
         except Exception:
             pass
+
+
+class GpuPost:
+    """PostProcessRenderer (renderers/post.rs:112-272) through the C-ABI: blur pyramid, luminance histogram, reverse blur pyramid and the
+    post combine with the display transform. `bezold_brucke_lut`: (64, 2) float16, caller data (kajiya_amd/post_tables.py)."""
+
+    def __init__(self, dev: Device, bezold_brucke_lut):
+        self.L = load()
+        self.dev = dev
+        self._lut = np.ascontiguousarray(bezold_brucke_lut, np.float16).reshape(64, 2)
+        self.h = C.c_void_p()
+        check(self.L.kj_post_create(dev.h, self._lut.ctypes.data, C.byref(self.h)))
+
+    def render(self, input_rgba16f, post_exposure_mult=1.0, contrast=1.0):
+        """input: (H, W, 4) float16 cuda tensor (TaaOutput.this_frame_out) -> (H, W) B10G11R11_UFLOAT words (int32 tensor view, owned by
+        the handle, valid until the next call). kj_frame_begin must have been called for this frame."""
+        import torch
+        assert input_rgba16f.dtype == torch.float16 and input_rgba16f.is_contiguous() and input_rgba16f.shape[-1] == 4
+        self.H, self.W = int(input_rgba16f.shape[0]), int(input_rgba16f.shape[1])
+        out = C.c_void_p()
+        check(self.L.kj_post_render(self.h, input_rgba16f.data_ptr(), self.W, self.H, post_exposure_mult, contrast, C.byref(out), _stream_ptr()))
+        return tensor_from_ptr(out.value, self.W * self.H * 4, torch.int32, (self.H, self.W))
+
+    def mip_levels(self):
+        n = C.c_uint32()
+        check(self.L.kj_post_mip_levels(self.h, C.byref(n)))
+        return n.value
+
+    def mip_extent(self, level):
+        pw, ph = (self.W + 1) // 2, (self.H + 1) // 2
+        return max(1, pw >> level), max(1, ph >> level)
+
+    def surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        check(self.L.kj_post_surface(self.h, name.encode(), C.byref(ptr), C.byref(n)))
+        return tensor_from_ptr(ptr.value, n.value, dtype, shape)
+
+    def read_back_histogram(self, clipping_low=0.0, clipping_high=0.0):
+        """(image_log2_lum, histogram[256]) from the host-visible copy; synchronise the stream first for this frame's values."""
+        lum = C.c_float()
+        hist = np.zeros(256, np.uint32)
+        check(self.L.kj_post_read_back_histogram(self.h, clipping_low, clipping_high, C.byref(lum), hist.ctypes.data))
+        return lum.value, hist
+
+    def __del__(self):
+        try:
+            self.L.kj_post_destroy(self.h)
+        except Exception:
+            pass
+
+
+def luminance_histogram_mean_log2(histogram, clipping_low=0.0, clipping_high=0.0):
+    """PostProcessRenderer::read_back_histogram's arithmetic (post.rs:188-235) on a caller's 256-bin histogram; needs no device."""
+    h = np.ascontiguousarray(histogram, np.uint32)
+    assert h.size == 256
+    lum = C.c_float()
+    check(load().kj_luminance_histogram_mean_log2(h.ctypes.data, clipping_low, clipping_high, C.byref(lum)))
+    return lum.value
 
 
 class _CudaArrayView:

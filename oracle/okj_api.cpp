@@ -9,6 +9,7 @@
 #include "okj_shadow_denoise.hpp"
 #include "okj_rtr.hpp"
 #include "okj_lighting.hpp"
+#include "okj_post.hpp"
 #include <cstdio>
 #include <chrono>
 #ifdef _OPENMP
@@ -397,6 +398,30 @@ int okj_ssgi_surface(void* p, const char* name, void** out_ptr, uint64_t* out_by
     *out_ptr = it->second.data();
     *out_bytes = it->second.size();
     return 0;
+}
+
+// ---- post (PostProcessRenderer): returns the B10G11R11_UFLOAT full-res output
+void* okj_post_create() { return new Post(); }
+void okj_post_destroy(void* p) { delete (Post*)p; }
+const void* okj_post_render(void* p, const KjFrameConstants* fc, const void* input_rgba16f, uint32_t w, uint32_t h, const void* bezold_brucke_lut_rg16f,
+                            const void* blue_noise_rgba8, float post_exposure_mult, float contrast) {
+    return ((Post*)p)->render(*fc, ImgRGBA16F((void*)input_rgba16f, w, h), (const h2*)bezold_brucke_lut_rg16f, (const uint32_t*)blue_noise_rgba8, post_exposure_mult, contrast).p;
+}
+int okj_post_surface(void* p, const char* name, void** out_ptr, uint64_t* out_bytes) {
+    Post* t = (Post*)p;
+    auto it = t->surf.find(name);
+    if (it == t->surf.end()) return 1;
+    *out_ptr = it->second.data();
+    *out_bytes = it->second.size();
+    return 0;
+}
+int okj_post_mip_levels(void* p) { return ((Post*)p)->mip_levels; }
+float okj_post_read_back_histogram(const uint32_t* histogram256, float clipping_low, float clipping_high) { return Post::read_back_histogram(histogram256, clipping_low, clipping_high); }
+void okj_display_transform_srgb(const void* bezold_brucke_lut_rg16f, const float* rgb_in, float* rgb_out, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const f3 c = display_transform_sRGB((const h2*)bezold_brucke_lut_rg16f, f3{rgb_in[i * 3], rgb_in[i * 3 + 1], rgb_in[i * 3 + 2]});
+        rgb_out[i * 3] = c.x; rgb_out[i * 3 + 1] = c.y; rgb_out[i * 3 + 2] = c.z;
+    }
 }
 
 void okj_rtdgi_debug(void* p, int enable, uint64_t* out8) {

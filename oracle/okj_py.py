@@ -106,6 +106,17 @@ def lib():
         L.okj_ssgi_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.okj_ssgi_surface.restype = C.c_int
         L.okj_ssgi_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.okj_post_create.restype = C.c_void_p
+        L.okj_post_destroy.argtypes = [C.c_void_p]
+        L.okj_post_render.restype = C.c_void_p
+        L.okj_post_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+        L.okj_post_surface.restype = C.c_int
+        L.okj_post_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.okj_post_mip_levels.restype = C.c_int
+        L.okj_post_mip_levels.argtypes = [C.c_void_p]
+        L.okj_post_read_back_histogram.restype = C.c_float
+        L.okj_post_read_back_histogram.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.okj_display_transform_srgb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.okj_reference_path_trace.restype = C.c_uint64
         L.okj_reference_path_trace.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
         L.okj_set_threads.argtypes = [C.c_int]
@@ -402,3 +413,58 @@ class OraclePipeline:
         a, b = C.c_uint64(), C.c_uint64()
         self.L.okj_rtdgi_ray_counts(self.rtdgi, C.byref(a), C.byref(b))
         return a.value, b.value
+
+
+class OraclePost:
+    """PostProcessRenderer (renderers/post.rs:112-272) on the CPU: blur pyramid, luminance histogram, reverse blur pyramid, post combine."""
+
+    def __init__(self, bezold_brucke_lut):
+        self.L = lib()
+        self.h = self.L.okj_post_create()
+        self.lut = np.ascontiguousarray(bezold_brucke_lut, np.float16).reshape(64, 2)
+        self.bn = blue_noise()
+
+    def render(self, fc, input_rgba16f, post_exposure_mult=1.0, contrast=1.0):
+        """input (H, W, 4) float16 -> (H, W) uint32 B10G11R11_UFLOAT"""
+        inp = np.ascontiguousarray(input_rgba16f, np.float16)
+        H, W = inp.shape[:2]
+        self.W, self.H = W, H
+        ptr = self.L.okj_post_render(self.h, C.byref(fc), inp.ctypes.data, W, H, self.lut.ctypes.data, self.bn.ctypes.data, post_exposure_mult, contrast)
+        return np.frombuffer((C.c_uint8 * (W * H * 4)).from_address(ptr), dtype=np.uint32).reshape(H, W)
+
+    def mip_levels(self):
+        return self.L.okj_post_mip_levels(self.h)
+
+    def mip_extent(self, level):
+        pw, ph = (self.W + 1) // 2, (self.H + 1) // 2
+        return max(1, pw >> level), max(1, ph >> level)
+
+    def surface(self, name, dtype=np.uint32, shape=None):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        if self.L.okj_post_surface(self.h, name.encode(), C.byref(ptr), C.byref(n)) != 0:
+            raise KeyError(name)
+        a = np.frombuffer((C.c_uint8 * n.value).from_address(ptr.value), dtype=dtype)
+        return a.reshape(shape) if shape is not None else a
+
+    def mip(self, pyramid, level):
+        w, h = self.mip_extent(level)
+        return self.surface(f"{pyramid}:{level}", np.uint32, (h, w))
+
+    def histogram(self):
+        return self.surface("histogram", np.uint32, (256,)).copy()
+
+    def read_back_histogram(self, histogram, clipping_low=0.0, clipping_high=0.0):
+        h = np.ascontiguousarray(histogram, np.uint32)
+        return self.L.okj_post_read_back_histogram(h.ctypes.data, clipping_low, clipping_high)
+
+    def display_transform(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
+        out = np.empty_like(rgb)
+        self.L.okj_display_transform_srgb(self.lut.ctypes.data, rgb.ctypes.data, out.ctypes.data, len(rgb))
+        return out
+
+    def __del__(self):
+        try:
+            self.L.okj_post_destroy(self.h)
+        except Exception:
+            pass

@@ -42,6 +42,37 @@ def test_cpp_frame_constants_match_python_mirror():
         assert (ga2 != gb2).mean() < 0.05
 
 
+@pytest.mark.parametrize("enabled,speed_log2,ev_shift,mode", [(1, 0.0, 0.0, 0), (1, 2.5, -1.0, 0), (0, 0.0, 1.5, 0), (1, 1.0, 0.5, 1)])
+def test_cpp_exposure_state_matches_python_mirror(enabled, speed_log2, ev_shift, mode):
+    """DynamicExposureState / ExposureState / update_pre_exposure (world_renderer.rs:217-285,919-948) in both host mirrors, f32 as in
+    the Rust: bit-exact except where libm's expf / exp2f and numpy's differ in the last place (<= 2 ulp allowed), plus the known answers
+    the arithmetic implies: disabled dynamic exposure -> ev_mult = 2^ev_shift exactly, pre_mult converges to it by 10 % per frame."""
+    from kajiya_amd import exposure as E
+    _build_examples()
+    rng = np.random.RandomState(3)
+    lums = np.concatenate([np.full(20, -3.0), rng.uniform(-8, 4, 30), [-40.0, 40.0], np.full(10, 1.0)]).astype(np.float32)
+    raw = subprocess.check_output([os.path.join(EX, "dump_exposure"), str(enabled), repr(speed_log2), repr(ev_shift), str(mode)] + [repr(float(v)) for v in lums])
+    got = np.frombuffer(raw, np.float32).reshape(len(lums), 6)
+    ex = E.Exposure(ev_shift=ev_shift, dynamic_exposure=E.DynamicExposureState(enabled=bool(enabled), speed_log2=speed_log2))
+    ex.render_mode = mode
+    ref = []
+    for v in lums:
+        ex.update_pre_exposure(v)
+        st = ex.state
+        ref.append([st.pre_mult, st.post_mult, st.pre_mult_prev, st.pre_mult_delta, ex.dynamic_exposure.ev_fast, ex.dynamic_exposure.ev_slow])
+    ref = np.array(ref, np.float32)
+    ulp = np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 8, ulp.max()           # errors of a few ulp in exp() accumulate through the recursive filters
+    np.testing.assert_allclose(got, ref, rtol=1e-6)
+    if not enabled:
+        assert np.all(got[:, 4:] == 0.0)
+        target = np.float32(2.0) ** np.float32(ev_shift)
+        assert abs(got[-1, 0] - target) < 2e-3 * target and abs(got[-1, 0] * got[-1, 1] - target) < 1e-6 * target      # pre * post = ev_mult
+        assert np.allclose(got[1:, 2], got[:-1, 0]) and np.allclose(got[:, 3], got[:, 0] / got[:, 2])
+    if mode == 1:
+        assert np.all(got[:, 0] == 1.0) and np.all(got[:, 3] == 1.0)
+
+
 @pytest.mark.gpu
 def test_cpp_world_render_passes_matches_python_driver(gpu, device, tmp_path):
     """Bake the glossy test scene to kajiya's `.mesh` / `.image` format, render 8 frames with the compiled host

@@ -1,0 +1,94 @@
+"""PostProcessRenderer (SURVEY 8f-4 "minimal post"): the HIP kernels through the C-ABI vs the oracle, on identical inputs.
+
+STATUS: written after round 1's GPU budget was spent — these tests have not run on hardware yet. Until they have, a failure is reported as
+XFAIL and a pass as XPASS (non-strict), so that an unverified addition cannot hide the state of the verified suite; the marker goes away
+with the first real run. What IS verified: the same kernel source executed on the CPU reproduces the oracle bit for bit
+(tests/test_post_emulation.py), and the oracle is pinned against the Rust text of the kernels that run in the reference
+(tests/test_post_oracle.py). The file sorts last on purpose.
+
+Tolerances: every image here is B10G11R11_UFLOAT. GPU and CPU differ by rounding noise (FMA contraction, ocml's exp / pow / log2), which a
+6- or 5-bit mantissa turns into whole-step flips at rounding boundaries; a later mip reads those flips, so "no texel further than TWO
+storage steps, nearly all identical" is the statement of parity for a free-running pyramid; the final image gets the same bound."""
+import numpy as np
+import pytest
+
+import parity as P
+from kajiya_amd import frame, post_tables
+
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="not yet run on hardware (round-1 GPU budget spent before this path was written)")]
+
+STEP = np.array([1 / 64, 1 / 64, 1 / 32])
+
+
+def _fc(W, H, frame_index, pre_exposure):
+    fs = frame.FrameState((W, H))
+    fs.frame_idx = frame_index
+    fs.pre_exposure = pre_exposure
+    return fs.prepare_frame_constants(frame.orbit_camera(0, (W, H)))
+
+
+def _compare(got_words, ref_words, what, max_differ):
+    a = P.decode(np.ascontiguousarray(got_words).view(np.uint8), "r11g11b10f").astype(np.float64)
+    b = P.decode(np.ascontiguousarray(ref_words).view(np.uint8), "r11g11b10f").astype(np.float64)
+    assert np.isfinite(a).all() and np.isfinite(b).all(), what
+    err = np.abs(a - b)
+    tol = np.maximum(np.abs(b), 2.0 ** -14) * STEP
+    differ = float((err > 0).any(-1).mean())
+    assert (err <= 2.05 * tol + 1e-9).all(), (what, float((err / tol).max()))
+    assert differ <= max_differ, (what, differ)
+    return differ
+
+
+@pytest.mark.parametrize("W,H,frame_index,mult,contrast,lut_seed", [(160, 90, 3, 1.3, 1.1, 0), (333, 187, 0, 1.0, 1.0, None), (1920, 1080, 5, 0.8, 1.0, 1)])
+def test_post_matches_oracle(gpu, oracle, device, W, H, frame_index, mult, contrast, lut_seed):
+    import torch
+    lut = post_tables.zero_bezold_brucke_lut() if lut_seed is None else post_tables.synthetic_bezold_brucke_lut(lut_seed)
+    rng = np.random.RandomState(W + H)
+    ys, xs = np.mgrid[0:H, 0:W]
+    img = np.stack([0.5 + 0.5 * np.sin(xs * 0.05), 0.5 + 0.5 * np.cos(ys * 0.07), 0.5 + 0.5 * np.sin((xs + ys) * 0.03)], -1) * rng.uniform(0.2, 3.0, (H, W, 1))
+    for _ in range(W * H // 2000):
+        img[rng.randint(H), rng.randint(W)] = rng.uniform(20, 900, 3)
+    img[: H // 6, : W // 5] = 0.0                                    # black: the NaN-chromaticity path
+    inp = np.concatenate([img, np.ones((H, W, 1))], -1).astype(np.float16)
+    fc = _fc(W, H, frame_index, 0.7)
+    op = oracle.OraclePost(lut)
+    ref = op.render(fc, inp, mult, contrast).copy()
+
+    gp = gpu.GpuPost(device, lut)
+    device.frame_begin(fc)
+    got = gp.render(torch.from_numpy(inp).cuda().contiguous(), mult, contrast)
+    torch.cuda.synchronize()
+    assert gp.mip_levels() == op.mip_levels()
+    worst = {}
+    for l in range(op.mip_levels()):
+        w, h = op.mip_extent(l)
+        assert gp.mip_extent(l) == (w, h)
+        for pyr in ("blur_pyramid", "rev_blur_pyramid"):
+            g = gp.surface(f"{pyr}:{l}", torch.int32, (h, w)).cpu().numpy().view(np.uint32)
+            worst[pyr] = max(worst.get(pyr, 0.0), _compare(g, op.mip(pyr, l), f"{pyr}:{l}", 0.03 if w * h > 500 else 0.2))
+    worst["output"] = _compare(got.cpu().numpy().view(np.uint32), ref, "output", 0.05)
+    hist_g = gp.surface("histogram", torch.int32, (256,)).cpu().numpy().view(np.uint32).astype(np.int64)
+    hist_o = op.histogram().astype(np.int64)
+    assert abs(int(hist_g.sum()) - int(hist_o.sum())) <= 0.002 * hist_o.sum()
+    assert np.abs(np.cumsum(hist_g) - np.cumsum(hist_o)).max() <= 0.004 * hist_o.sum()
+    lum, hist_rb = gp.read_back_histogram(0.1, 0.2)                  # the stream is synchronised: this frame's copy
+    assert np.array_equal(hist_rb.astype(np.int64), hist_g)
+    assert abs(lum - op.read_back_histogram(hist_o, 0.1, 0.2)) < 0.05
+    print(f"{W}x{H}: texels differing (by <= 2 storage steps): " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+
+
+def test_post_is_deterministic_and_reusable_across_extents(gpu, device):
+    """Same input twice -> identical words (the only atomics are integer adds); a different extent on the same handle reallocates."""
+    import torch
+    lut = post_tables.synthetic_bezold_brucke_lut(2)
+    gp = gpu.GpuPost(device, lut)
+    outs = []
+    for (W, H) in ((256, 144), (256, 144), (100, 60), (256, 144)):
+        inp = (np.random.RandomState(1).uniform(0, 2, (H, W, 4))).astype(np.float16)
+        device.frame_begin(_fc(W, H, 1, 1.0))
+        o = gp.render(torch.from_numpy(inp).cuda().contiguous())
+        torch.cuda.synchronize()
+        outs.append(o.cpu().numpy().copy())
+        h = gp.surface("histogram", torch.int32, (256,)).cpu().numpy().copy()
+        assert h.sum() > 0
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[3]) and outs[2].shape == (60, 100)
