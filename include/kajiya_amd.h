@@ -491,7 +491,7 @@ KjStatus kj_rtr_ray_counts(KjRtr* r, uint64_t* out_closest, uint64_t* out_any);
  *   blur_pyramid (post.rs:10-61; rust-shaders/src/blur.rs for mip 0, shaders/blur.hlsl for the rest), luminance histogram
  *   (post.rs:138-186, shaders/post/luminance_histogram_*.hlsl), rev_blur_pyramid (post.rs:63-110, rust-shaders/src/rev_blur.rs),
  *   "post combine" (shaders/post_combine.hlsl + inc/color/display_transform.hlsl and the colour headers it pulls in).
- * input: RGBA16F full-res image (TaaOutput.this_frame_out; kajiya's motion blur between the two is not included). Output:
+ * input: RGBA16F full-res image (TaaOutput.this_frame_out, or kj_motion_blur_render's output as in the reference). Output:
  * B10G11R11_UFLOAT full-res, LINEAR display-referred values in [0, ~1] — kajiya's swap chain applies the sRGB transfer function.
  * The Bezold-Brucke LUT (bindless texture 2: 64 x 1 RG16F, lut_renderers.rs:45-76) is caller data like the blue-noise image: host
  * pointer, copied at create. frame_index (dither offset) and pre_exposure (histogram) come from kj_frame_begin's constants.
@@ -510,6 +510,19 @@ KjStatus kj_post_read_back_histogram(KjPost* p, float clipping_low, float clippi
 KjStatus kj_luminance_histogram_mean_log2(const uint32_t* histogram256, float clipping_low, float clipping_high, float* out_image_log2_lum);
 KjStatus kj_post_surface(KjPost* p, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 KjStatus kj_post_mip_levels(KjPost* p, uint32_t* out_levels);
+
+/* motion_blur(rg, input, depth, reprojection_map) -> Handle<Image>     renderers/motion_blur.rs:5-72; rust-shaders/src/motion_blur.rs
+ * (velocity_reduce_x, velocity_reduce_y, velocity_dilate, motion_blur — all four are the Rust kernels the reference runs). Sits between
+ * TaaRenderer::render and PostProcessRenderer::render (world_render_passes.rs:265-266). input / output RGBA16F at (width, height) — the
+ * TAA output extent; depth R32F and reprojection_map RGBA16_SNORM at (depth_width, depth_height) — the render extent. *out_rgba16f is
+ * owned by the handle, valid until the next call. Surfaces: "velocity_reduced_x", "velocity_reduced_y", "velocity_dilated" (RG16F),
+ * "output". motion_blur_scale is the reference's constant 1.0. */
+typedef struct KjMotionBlur KjMotionBlur;
+KjStatus kj_motion_blur_create(KjDevice* dev, KjMotionBlur** out);
+void kj_motion_blur_destroy(KjMotionBlur* m);
+KjStatus kj_motion_blur_render(KjMotionBlur* m, const void* input_rgba16f, uint32_t width, uint32_t height, const void* depth_r32f, const void* reprojection_map,
+                               uint32_t depth_width, uint32_t depth_height, const void** out_rgba16f, void* stream);
+KjStatus kj_motion_blur_surface(KjMotionBlur* m, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 
 #ifdef __cplusplus
 }

@@ -376,6 +376,20 @@ struct TaaRenderer {
     }
 };
 
+// motion_blur(rg, input, depth, reprojection_map) -> Handle<Image>   (renderers/motion_blur.rs:5-72)
+struct MotionBlurRenderer {
+    KjMotionBlur* h = nullptr;
+    explicit MotionBlurRenderer(Device& d) { check(kj_motion_blur_create(d.h, &h), "kj_motion_blur_create"); }
+    ~MotionBlurRenderer() { kj_motion_blur_destroy(h); }
+    MotionBlurRenderer(const MotionBlurRenderer&) = delete;
+    MotionBlurRenderer& operator=(const MotionBlurRenderer&) = delete;
+    const void* render(const void* input_rgba16f, const uint32_t extent[2], const void* depth, const void* reprojection_map, const uint32_t depth_extent[2], hipStream_t s) {
+        const void* out = nullptr;
+        check(kj_motion_blur_render(h, input_rgba16f, extent[0], extent[1], depth, reprojection_map, depth_extent[0], depth_extent[1], &out, s), "kj_motion_blur_render");
+        return out;
+    }
+};
+
 // PostProcessRenderer (renderers/post.rs:112-272). `image_log2_lum` is refreshed by read_back_histogram at the top of render(), from
 // whatever histogram copy has completed (the reference reads its mapped buffer the same way, a frame or more behind).
 struct PostProcessRenderer {
@@ -398,6 +412,7 @@ struct PostProcessRenderer {
 struct FrameOutput {
     const void* reprojection_map; const void* ssgi_tex; const void* denoised_shadow_mask; KjRtdgiOutput rtdgi; const void* rtr;
     const void* lit /* RGBA16F "debug_out_tex" */; KjTaaOutput anti_aliased;
+    const void* final_post_input = nullptr; // RGBA16F after motion blur, when WorldRenderer::post is set
     const void* post_processed = nullptr;   // B10G11R11_UFLOAT, when WorldRenderer::post is set
 };
 struct WorldRenderer {
@@ -412,12 +427,16 @@ struct WorldRenderer {
     bool reset_reference_accumulation = false;      // world_renderer.rs:183
     DeviceImage refpt_accum;                         // "refpt.accum" temporal (RGBA32F: running mean + sample count)
     float sky_key[8] = {-1, 0, 0, 0, 0, 0, 0, 0};
-    // the tail of the frame (world_render_passes.rs:281-289); kajiya's motion blur between TAA and post is not included
+    // the tail of the frame (world_render_passes.rs:265-289): motion blur, then post
     std::unique_ptr<PostProcessRenderer> post;      // set by enable_post(); without it the frame ends at TAA, pre-exposure stays 1
+    std::unique_ptr<MotionBlurRenderer> motion_blur;
     float ev_shift = 0.0f, contrast = 1.0f;
     DynamicExposureState dynamic_exposure;
     ExposureState exposure_state[2];                 // one per render mode
-    void enable_post(const uint16_t* bezold_brucke_lut_rg16f_64) { post.reset(new PostProcessRenderer(device, bezold_brucke_lut_rg16f_64)); }
+    void enable_post(const uint16_t* bezold_brucke_lut_rg16f_64) {
+        post.reset(new PostProcessRenderer(device, bezold_brucke_lut_rg16f_64));
+        motion_blur.reset(new MotionBlurRenderer(device));
+    }
     void update_pre_exposure(RenderMode mode) {      // world_renderer.rs:919-948
         ExposureState& st = exposure_state[int(mode)];
         kajiya_amd::update_pre_exposure(st, dynamic_exposure, ev_shift, post ? post->image_log2_lum : 0.0f, mode);
@@ -462,9 +481,11 @@ struct WorldRenderer {
                                debug_shading_mode, s), "kj_light_gbuffer");                                      // :219-234
         o.lit = debug_out_tex.p;
         o.anti_aliased = taa.render(debug_out_tex.p, W, H, o.reprojection_map, gbuffer_depth.depth.p, temporal_upscale_extent, s);   // :254-263
-        if (post)                                                                                              // :281-289
-            o.post_processed = post->render(o.anti_aliased.this_frame_out, temporal_upscale_extent[0], temporal_upscale_extent[1],
-                                            exposure_state[0].post_mult, contrast, dynamic_exposure.histogram_clipping, s);
+        if (post) {
+            o.final_post_input = motion_blur->render(o.anti_aliased.this_frame_out, temporal_upscale_extent, gbuffer_depth.depth.p, o.reprojection_map, render_extent, s);   // :265-266
+            o.post_processed = post->render(o.final_post_input, temporal_upscale_extent[0], temporal_upscale_extent[1],
+                                            exposure_state[0].post_mult, contrast, dynamic_exposure.histogram_clipping, s);                                          // :281-289
+        }
         frame_state.retire_frame();
         return o;
     }

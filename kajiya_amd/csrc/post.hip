@@ -3,6 +3,7 @@
 //   luminance histogram post.rs:138-186, shaders/post/luminance_histogram_{clear,calculate,copy}.hlsl; read_back_histogram :188-235
 //   rev_blur_pyramid   post.rs:63-110, rust-shaders/src/rev_blur.rs
 //   post combine       shaders/post_combine.hlsl (glare 0.05, vignette, display transform, contrast, blue-noise dither)
+// and, ahead of it in the frame, motion_blur (renderers/motion_blur.rs + rust-shaders/src/motion_blur.rs), further down in this file.
 // Pyramids are B10G11R11_UFLOAT, half-res base, all mip levels minus one; each mip is its own flat surface ("blur_pyramid:<k>").
 // Choices where the reference leaves the result undefined are listed in oracle/okj_post.hpp's header and made identically here:
 // coarsest rev-blur mip = zeros, out-of-bounds blur fetches = 0 (and counted in the weight), NaN coordinate / NaN->uint = 0.
@@ -130,7 +131,130 @@ __global__ void __launch_bounds__(64) k_post_combine(const FrameConstants* __res
     output.st(x, y, pack_r11g11b10f(col));
 }
 
+// ================================================================== motion_blur (renderers/motion_blur.rs:5-72; rust-shaders/src/motion_blur.rs)
+// Four kernels, all Rust in the reference. reprojection_map RGBA16_SNORM + depth R32F at (DW, DH), input / output RGBA16F at (W, H).
+// Float -> uint casts saturate (negative / NaN -> 0), out-of-range fetches read 0, the lod-1 taps of the single-mip input read mip 0,
+// output alpha = 1 (oracle/okj_post.hpp lists the same choices).
+KJ_D void keep_largest(V3& largest, V2 v) { const float m2 = dot(v, v); if (m2 > largest.z) largest = V3{v.x, v.y, m2}; }
+__global__ void __launch_bounds__(64) k_velocity_reduce_x(ImgU2 reprojection_map, ImgU32 out) {           // :189-211
+    TILE_XY(out.w, out.h)
+    if (!in_image) return;
+    V3 largest = v3(0.0f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const V4 v = ld_reproj(reprojection_map, x * 16 + i, y); keep_largest(largest, V2{v.x, v.y}); }
+    st2h(out, x, y, V2{largest.x, largest.y});
+}
+__global__ void __launch_bounds__(64) k_velocity_reduce_y(ImgU32 in, ImgU32 out) {                        // :213-235
+    TILE_XY(out.w, out.h)
+    if (!in_image) return;
+    V3 largest = v3(0.0f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) keep_largest(largest, ld2h(in, x, y * 16 + i));
+    st2h(out, x, y, V2{largest.x, largest.y});
+}
+__global__ void __launch_bounds__(64) k_velocity_dilate(ImgU32 in, ImgU32 out) {                          // :237-264 (x outer, y inner)
+    TILE_XY(out.w, out.h)
+    if (!in_image) return;
+    V3 largest = v3(0.0f);
+    for (int xx = -2; xx <= 2; ++xx)
+        for (int yy = -2; yy <= 2; ++yy) keep_largest(largest, ld2h(in, x + xx, y + yy));
+    st2h(out, x, y, V2{largest.x, largest.y});
+}
+KJ_D float mb_depth_to_view_z(float depth, const FrameConstants& fc) { return 1.0f / (depth * -fc.view_constants.clip_to_view[11]); }     // util.rs:69-76
+KJ_D float mb_sample_weight(float center_depth, float sample_depth, float offset_len, float center_spread_len, float sample_spread_len, float depth_scale) {   // :18-42
+    const float d = sample_depth - center_depth;
+    const V2 dc = V2{saturate(0.5f + depth_scale * d), saturate(0.5f + -depth_scale * d)};
+    const V2 sc = V2{saturate(center_spread_len - (offset_len + 1.0f)), saturate(sample_spread_len - (offset_len + 1.0f))};
+    return dot(dc, sc);
+}
+KJ_D V4 sample_bilinear_clamp_snorm16(const ImgU2& i, V2 uv) {
+    const float fx = uv.x * float(i.w) - 0.5f, fy = uv.y * float(i.h) - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float tx = fx - x0f, ty = fy - y0f;
+    const int x0 = f2i_sat(x0f), y0 = f2i_sat(y0f);
+    const int xa = min(max(x0, 0), i.w - 1), xb = min(max(x0 + 1, 0), i.w - 1), ya = min(max(y0, 0), i.h - 1), yb = min(max(y0 + 1, 0), i.h - 1);
+    const V4 a = ld_reproj(i, xa, ya) * (1.0f - tx) + ld_reproj(i, xb, ya) * tx;
+    const V4 b = ld_reproj(i, xa, yb) * (1.0f - tx) + ld_reproj(i, xb, yb) * tx;
+    return a * (1.0f - ty) + b * ty;
+}
+__global__ void __launch_bounds__(64) k_motion_blur(const FrameConstants* __restrict__ fcp, ImgU2 input, ImgU2 reprojection_map, ImgU32 tile_velocity_tex, Img<float> depth,
+                                                    ImgU2 output) {                                      // :47-187
+    TILE_XY(output.w, output.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const int W = output.w, H = output.h, DW = depth.w, DH = depth.h;
+    const V2 depth_tex_size = V2{float(DW), float(DH)}, output_tex_size = V2{float(W), float(H)};
+    const float blur_scale = 0.5f * 1.0f;                  // motion_blur_scale = 1.0 (motion_blur.rs:53)
+    const V2 uv = V2{float(x) + 0.5f, float(y) + 0.5f} * V2{1.0f / float(W), 1.0f / float(H)};
+    int tox, toy, noise1;
+    {   // scrambled tile coordinates (:68-84), wrapping i32 arithmetic
+        uint32_t ux = uint32_t(x), uy = uint32_t(y);
+        ux += ux << 4; ux ^= uint32_t(int32_t(ux) >> 6);
+        uy += ux << 1; uy += uy << 6; uy ^= uint32_t(int32_t(uy) >> 2);
+        ux ^= uy;
+        noise1 = int32_t(ux ^ (uy << 1));
+        tox = int32_t(ux & 31u) - 15; toy = int32_t(uy & 31u) - 15;
+        noise1 = (noise1 & 31) - 15;
+    }
+    const V2 tile_coord_f = uv * depth_tex_size + V2{float(tox), float(toy)};
+    const uint32_t tcx = min(f2u_sat(tile_coord_f.x), uint32_t(DW - 1)) / 16u, tcy = min(f2u_sat(tile_coord_f.y), uint32_t(DH - 1)) / 16u;
+    const V2 tile_velocity = ld2h(tile_velocity_tex, int(tcx), int(tcy)) * blur_scale;
+    const int kernel_width = 4;
+    const float noise = 0.5f * float(noise1) / 15.0f;
+    const float center_offset_len = noise / float(kernel_width) * 0.5f;
+    const V2 center_uv = uv + tile_velocity * center_offset_len;
+    const V2 cpx = center_uv * output_tex_size;
+    const V3 center_color = xyz(ld4(input, int(min(f2u_sat(cpx.x), uint32_t(W - 1))), int(min(f2u_sat(cpx.y), uint32_t(H - 1)))));
+    const float center_depth = -mb_depth_to_view_z(sample_nearest_clamp(depth, center_uv), fc);
+    const V4 cv = sample_bilinear_clamp_snorm16(reprojection_map, center_uv);
+    const V2 center_velocity_px = (V2{cv.x, cv.y} * blur_scale) * depth_tex_size;
+    const float soft_z = 16.0f;
+    V4 sum = v4(0.0f);
+    float sample_count = 1.0f;
+    if (length(tile_velocity) > 0.0f) {
+        for (int i = 1; i < kernel_width; ++i) {
+            const float offset_len0 = (float(i) + noise) / float(kernel_width) * 0.5f;
+            const float offset_len1 = (float(-i) + noise) / float(kernel_width) * 0.5f;
+            const V2 uv0 = uv + tile_velocity * offset_len0, uv1 = uv + tile_velocity * offset_len1;
+            const V2 p0 = uv0 * depth_tex_size, p1 = uv1 * depth_tex_size;
+            const int px0 = int(min(f2u_sat(p0.x), 0x7fffffffu)), py0 = int(min(f2u_sat(p0.y), 0x7fffffffu));
+            const int px1 = int(min(f2u_sat(p1.x), 0x7fffffffu)), py1 = int(min(f2u_sat(p1.y), 0x7fffffffu));
+            const float d0 = -mb_depth_to_view_z(depth.ld(px0, py0), fc), d1 = -mb_depth_to_view_z(depth.ld(px1, py1), fc);
+            const V4 r0 = ld_reproj(reprojection_map, px0, py0), r1 = ld_reproj(reprojection_map, px1, py1);
+            const float v0 = length((V2{r0.x, r0.y} * blur_scale) * depth_tex_size), v1 = length((V2{r1.x, r1.y} * blur_scale) * depth_tex_size);
+            float weight0 = mb_sample_weight(center_depth, d0, length((uv0 - uv) * depth_tex_size), length(center_velocity_px), v0, soft_z);
+            float weight1 = mb_sample_weight(center_depth, d1, length((uv1 - uv) * depth_tex_size), length(center_velocity_px), v1, soft_z);
+            const bool m0 = d0 > d1, m1 = v1 > v0;
+            weight0 = (m0 && m1) ? weight1 : weight0;
+            weight1 = (m0 || m1) ? weight1 : weight0;
+            const float valid0 = (uv0.x == saturate(uv0.x) && uv0.y == saturate(uv0.y)) ? 1.0f : 0.0f;
+            const float valid1 = (uv1.x == saturate(uv1.x) && uv1.y == saturate(uv1.y)) ? 1.0f : 0.0f;
+            weight0 *= valid0; weight1 *= valid1;
+            sample_count += valid0 + valid1;
+            V4 c0 = sample_bilinear_clamp_rgba16f(input.p, W, H, uv0); c0.w = 1.0f;
+            sum += c0 * weight0;
+            V4 c1 = sample_bilinear_clamp_rgba16f(input.p, W, H, uv1); c1.w = 1.0f;
+            sum += c1 * weight1;
+        }
+        sum = sum * (1.0f / sample_count);
+    }
+    const V3 result = xyz(sum) + center_color * (1.0f - sum.w);
+    st4(output, x, y, v4(result, 1.0f));
+}
+
 // ================================================================== host
+struct KjMotionBlur {
+    KjDevice* dev = nullptr;
+    int W = 0, H = 0, DW = 0, DH = 0;
+    std::map<std::string, kj::DevBuf> surf;
+    hipError_t err = hipSuccess;
+    void* get(const std::string& name, size_t bytes, hipStream_t s) {
+        kj::DevBuf& b = surf[name];
+        if (b.bytes != bytes) { hipError_t e = b.alloc(bytes, s); if (e != hipSuccess) err = e; }
+        return b.p;
+    }
+};
+
 struct KjPost {
     KjDevice* dev = nullptr;
     int W = 0, H = 0, mip_levels = 0;
@@ -263,6 +387,52 @@ KjStatus kj_post_surface(KjPost* t, const char* name, void** out_dev_ptr, uint64
 KjStatus kj_post_mip_levels(KjPost* t, uint32_t* out_levels) {
     KJ_REQUIRE(t && out_levels, "null argument");
     *out_levels = uint32_t(t->mip_levels);
+    return KJ_OK;
+}
+
+KjStatus kj_motion_blur_create(KjDevice* dev, KjMotionBlur** out) {
+    KJ_REQUIRE(dev && out, "null argument");
+    KjMotionBlur* t = new KjMotionBlur();
+    t->dev = dev;
+    *out = t;
+    return KJ_OK;
+}
+void kj_motion_blur_destroy(KjMotionBlur* t) { delete t; }
+
+// motion_blur(rg, input, depth, reprojection_map) -> Handle<Image>   (renderers/motion_blur.rs:5-72)
+KjStatus kj_motion_blur_render(KjMotionBlur* t, const void* input_rgba16f, uint32_t width, uint32_t height, const void* depth_r32f, const void* reprojection_map,
+                               uint32_t depth_width, uint32_t depth_height, const void** out_rgba16f, void* stream_) {
+    KJ_REQUIRE(t && input_rgba16f && depth_r32f && reprojection_map && out_rgba16f && width && height && depth_width && depth_height, "null argument");
+    KJ_REQUIRE(t->dev->fc_dev, "kj_frame_begin not called");
+    hipStream_t s = (hipStream_t)stream_;
+    const int W = int(width), H = int(height), DW = int(depth_width), DH = int(depth_height);
+    if (W != t->W || H != t->H || DW != t->DW || DH != t->DH) { t->surf.clear(); t->W = W; t->H = H; t->DW = DW; t->DH = DH; }
+    const int tw = (DW + 15) / 16, th = (DH + 15) / 16;                   // VELOCITY_TILE_SIZE = 16
+    void* reduced_x = t->get("velocity_reduced_x", size_t(tw) * DH * 4, s);
+    void* reduced_y = t->get("velocity_reduced_y", size_t(tw) * th * 4, s);
+    void* dilated = t->get("velocity_dilated", size_t(tw) * th * 4, s);
+    void* output = t->get("output", size_t(W) * H * 8, s);
+    KJ_TRY_HIP(t->err);
+    const dim3 blk(64);
+    const ImgU2 reproj = img<uint2>(reprojection_map, DW, DH);
+    hipLaunchKernelGGL(k_velocity_reduce_x, dim3((tw + 7) / 8, (DH + 7) / 8), blk, 0, s, reproj, img<uint32_t>(reduced_x, tw, DH));
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_velocity_reduce_y, dim3((tw + 7) / 8, (th + 7) / 8), blk, 0, s, img<uint32_t>(reduced_x, tw, DH), img<uint32_t>(reduced_y, tw, th));
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_velocity_dilate, dim3((tw + 7) / 8, (th + 7) / 8), blk, 0, s, img<uint32_t>(reduced_y, tw, th), img<uint32_t>(dilated, tw, th));
+    KJ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_motion_blur, dim3((W + 7) / 8, (H + 7) / 8), blk, 0, s, t->dev->fc_dev, img<uint2>(input_rgba16f, W, H), reproj, img<uint32_t>(dilated, tw, th),
+                       img<float>(depth_r32f, DW, DH), img<uint2>(output, W, H));
+    KJ_CHECK_LAUNCH();
+    *out_rgba16f = output;
+    return KJ_OK;
+}
+KjStatus kj_motion_blur_surface(KjMotionBlur* t, const char* name, void** out_dev_ptr, uint64_t* out_bytes) {
+    KJ_REQUIRE(t && name && out_dev_ptr && out_bytes, "null argument");
+    auto it = t->surf.find(name);
+    if (it == t->surf.end()) { set_last_error("no motion-blur surface named '%s'", name); return KJ_ERR_INVALID_ARGUMENT; }
+    *out_dev_ptr = it->second.p;
+    *out_bytes = it->second.bytes;
     return KJ_OK;
 }
 

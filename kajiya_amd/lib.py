@@ -31,6 +31,7 @@ EXPORTS = [
     "kj_baked_mesh_view", "kj_baked_image_view", "kj_baked_image_mip", "kj_baked_image_decode_rgba8",
     "kj_rtr_create", "kj_rtr_destroy", "kj_rtr_set_options", "kj_rtr_trace", "kj_rtr_render_specular_lights", "kj_rtr_filter_temporal", "kj_rtr_surface", "kj_rtr_ray_counts",
     "kj_post_create", "kj_post_destroy", "kj_post_render", "kj_post_read_back_histogram", "kj_luminance_histogram_mean_log2", "kj_post_surface", "kj_post_mip_levels",
+    "kj_motion_blur_create", "kj_motion_blur_destroy", "kj_motion_blur_render", "kj_motion_blur_surface",
 ]
 
 _LIB = None
@@ -111,6 +112,9 @@ def load():
         "kj_luminance_histogram_mean_log2": [vp, C.c_float, C.c_float, C.POINTER(C.c_float)],
         "kj_post_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_post_mip_levels": [vp, C.POINTER(u32)],
+        "kj_motion_blur_create": [vp, C.POINTER(vp)],
+        "kj_motion_blur_render": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(vp), vp],
+        "kj_motion_blur_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_ssgi_create": [vp, C.POINTER(vp)],
         "kj_ssgi_render": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.POINTER(vp), vp],
         "kj_ssgi_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
@@ -121,7 +125,7 @@ def load():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = i32
-    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy", "kj_shadow_denoise_destroy", "kj_rtr_destroy", "kj_post_destroy"):
+    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy", "kj_shadow_denoise_destroy", "kj_rtr_destroy", "kj_post_destroy", "kj_motion_blur_destroy"):
         f = getattr(L, name)
         f.argtypes = [vp]
         f.restype = None
@@ -605,6 +609,39 @@ class GpuPost:
     def __del__(self):
         try:
             self.L.kj_post_destroy(self.h)
+        except Exception:
+            pass
+
+
+class GpuMotionBlur:
+    """motion_blur (renderers/motion_blur.rs:5-72) through the C-ABI."""
+
+    def __init__(self, dev: Device):
+        self.L = load()
+        self.dev = dev
+        self.h = C.c_void_p()
+        check(self.L.kj_motion_blur_create(dev.h, C.byref(self.h)))
+
+    def render(self, input_rgba16f, depth, reprojection_map):
+        """input (H, W, 4) float16, depth (DH, DW) float32, reprojection_map (DH, DW, 4) int16 cuda tensors -> (H, W, 4) float16 view owned by
+        the handle. kj_frame_begin must have been called for this frame."""
+        import torch
+        assert input_rgba16f.dtype == torch.float16 and depth.dtype == torch.float32 and reprojection_map.dtype == torch.int16
+        assert input_rgba16f.is_contiguous() and depth.is_contiguous() and reprojection_map.is_contiguous()
+        H, W = int(input_rgba16f.shape[0]), int(input_rgba16f.shape[1])
+        DH, DW = int(depth.shape[0]), int(depth.shape[1])
+        out = C.c_void_p()
+        check(self.L.kj_motion_blur_render(self.h, input_rgba16f.data_ptr(), W, H, depth.data_ptr(), reprojection_map.data_ptr(), DW, DH, C.byref(out), _stream_ptr()))
+        return tensor_from_ptr(out.value, W * H * 8, torch.float16, (H, W, 4))
+
+    def surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        check(self.L.kj_motion_blur_surface(self.h, name.encode(), C.byref(ptr), C.byref(n)))
+        return tensor_from_ptr(ptr.value, n.value, dtype, shape)
+
+    def __del__(self):
+        try:
+            self.L.kj_motion_blur_destroy(self.h)
         except Exception:
             pass
 

@@ -424,6 +424,22 @@ void okj_display_transform_srgb(const void* bezold_brucke_lut_rg16f, const float
     }
 }
 
+// ---- motion_blur (renderers/motion_blur.rs): returns the RGBA16F output
+void* okj_motion_blur_create() { return new MotionBlur(); }
+void okj_motion_blur_destroy(void* p) { delete (MotionBlur*)p; }
+const void* okj_motion_blur_render(void* p, const KjFrameConstants* fc, const void* input_rgba16f, uint32_t w, uint32_t h, const void* depth, const void* reprojection_map,
+                                   uint32_t dw, uint32_t dh) {
+    return ((MotionBlur*)p)->render(*fc, ImgRGBA16F((void*)input_rgba16f, w, h), ImgR32F((void*)depth, dw, dh), ImgRGBA16S((void*)reprojection_map, dw, dh)).p;
+}
+int okj_motion_blur_surface(void* p, const char* name, void** out_ptr, uint64_t* out_bytes) {
+    MotionBlur* t = (MotionBlur*)p;
+    auto it = t->surf.find(name);
+    if (it == t->surf.end()) return 1;
+    *out_ptr = it->second.data();
+    *out_bytes = it->second.size();
+    return 0;
+}
+
 void okj_rtdgi_debug(void* p, int enable, uint64_t* out8) {
     Rtdgi* o = &((OkjRtdgi*)p)->r;
     o->dbg_enabled = enable != 0;

@@ -343,4 +343,128 @@ struct Post {
     }
 };
 
+
+// ---------------------------------------------------------------- motion_blur (renderers/motion_blur.rs:5-72; rust-shaders/src/motion_blur.rs —
+// all four kernels are the Rust that runs). reprojection_map RGBA16_SNORM (xy = uv-space motion to the previous frame), depth R32F at
+// (dw, dh); input / output RGBA16F at (w, h). Chosen where the Rust leaves it to the GPU: float -> uint casts saturate (negative / NaN ->
+// 0), out-of-range fetches read 0, `sample_by_lod(.., 1.0)` of the single-mip input reads mip 0, output alpha = 1.
+struct MotionBlur {
+    std::map<std::string, std::vector<uint8_t>> surf;
+    template <typename T> Img<T> get(const std::string& name, int w, int h) {
+        auto& v = surf[name];
+        if (v.size() != size_t(w) * h * sizeof(T)) v.assign(size_t(w) * h * sizeof(T), 0);
+        return Img<T>(v.data(), w, h);
+    }
+    static float depth_to_view_z(float depth, const FrameConstants& fc) { return 1.0f / (depth * -fc.view_constants.clip_to_view[11]); }   // util.rs:69-76
+    static f2 depth_cmp(float center_depth, float sample_depth, float depth_scale) {                                                       // motion_blur.rs:18-22
+        const float d = sample_depth - center_depth;
+        return f2{saturate(0.5f + depth_scale * d), saturate(0.5f + -depth_scale * d)};
+    }
+    static f2 spread_cmp(float offset_len, f2 spread_len) { return f2{saturate(spread_len.x - (offset_len + 1.0f)), saturate(spread_len.y - (offset_len + 1.0f))}; }
+    static float sample_weight(float center_depth, float sample_depth, float offset_len, float center_spread_len, float sample_spread_len, float depth_scale) {
+        return dot(depth_cmp(center_depth, sample_depth, depth_scale), spread_cmp(offset_len, f2{center_spread_len, sample_spread_len}));
+    }
+    // one step of the three "largest velocity" reductions: keep v when its squared length beats the running maximum
+    static void keep_largest(f3& largest, f2 v) { const float m2 = dot(v, v); if (m2 > largest.z) largest = f3{v.x, v.y, m2}; }
+    static f4 sample_bilinear_clamp_snorm16(const ImgRGBA16S& i, f2 uv) {
+        const float fx = uv.x * float(i.w) - 0.5f, fy = uv.y * float(i.h) - 0.5f;
+        const float x0f = floorf(fx), y0f = floorf(fy);
+        const float tx = fx - x0f, ty = fy - y0f;
+        const int x0 = f2i_sat(x0f), y0 = f2i_sat(y0f);
+        auto cl = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
+        const int xa = cl(x0, i.w), xb = cl(x0 + 1, i.w), ya = cl(y0, i.h), yb = cl(y0 + 1, i.h);
+        const f4 a = ld_reproj(i, xa, ya) * (1.0f - tx) + ld_reproj(i, xb, ya) * tx;
+        const f4 b = ld_reproj(i, xa, yb) * (1.0f - tx) + ld_reproj(i, xb, yb) * tx;
+        return a * (1.0f - ty) + b * ty;
+    }
+
+    ImgRGBA16F render(const FrameConstants& fc, ImgRGBA16F input, ImgR32F depth, ImgRGBA16S reprojection_map) {
+        const int W = input.w, H = input.h, DW = depth.w, DH = depth.h;
+        const int tw = (DW + 15) / 16, th = (DH + 15) / 16;
+        ImgRG16F reduced_x = get<h2>("velocity_reduced_x", tw, DH), reduced_y = get<h2>("velocity_reduced_y", tw, th), dilated = get<h2>("velocity_dilated", tw, th);
+        for (int y = 0; y < DH; ++y)                                  // velocity_reduce_x (:189-211)
+            for (int x = 0; x < tw; ++x) {
+                f3 largest = mk3(0.0f);
+                for (int i = 0; i < 16; ++i) { const f4 v = ld_reproj(reprojection_map, x * 16 + i, y); keep_largest(largest, f2{v.x, v.y}); }
+                st2(reduced_x, x, y, f2{largest.x, largest.y});
+            }
+        for (int y = 0; y < th; ++y)                                  // velocity_reduce_y (:213-235)
+            for (int x = 0; x < tw; ++x) {
+                f3 largest = mk3(0.0f);
+                for (int i = 0; i < 16; ++i) keep_largest(largest, ld2(reduced_x, x, y * 16 + i));
+                st2(reduced_y, x, y, f2{largest.x, largest.y});
+            }
+        for (int y = 0; y < th; ++y)                                  // velocity_dilate (:237-264): x outer, y inner
+            for (int x = 0; x < tw; ++x) {
+                f3 largest = mk3(0.0f);
+                for (int xx = -2; xx <= 2; ++xx)
+                    for (int yy = -2; yy <= 2; ++yy) keep_largest(largest, ld2(reduced_y, x + xx, y + yy));
+                st2(dilated, x, y, f2{largest.x, largest.y});
+            }
+        ImgRGBA16F out = get<h4>("output", W, H);
+        const f2 depth_tex_size = f2{float(DW), float(DH)}, output_tex_size = f2{float(W), float(H)};
+        const float blur_scale = 0.5f * 1.0f;                         // motion_blur_scale = 1.0 (motion_blur.rs:53)
+        auto clampu = [](uint32_t v, uint32_t hi) { return v > hi ? hi : v; };
+        for (int y = 0; y < H; ++y)                                   // motion_blur (:47-187)
+            for (int x = 0; x < W; ++x) {
+                const f2 uv = f2{float(x) + 0.5f, float(y) + 0.5f} * f2{1.0f / float(W), 1.0f / float(H)};
+                int32_t tox = x, toy = y, noise1;
+                {   // wrapping i32 arithmetic, arithmetic right shifts (the operands stay non-negative for any real extent)
+                    uint32_t ux = uint32_t(tox), uy = uint32_t(toy);
+                    ux += ux << 4; ux ^= uint32_t(int32_t(ux) >> 6);
+                    uy += ux << 1; uy += uy << 6; uy ^= uint32_t(int32_t(uy) >> 2);
+                    ux ^= uy;
+                    noise1 = int32_t(ux ^ (uy << 1));
+                    tox = int32_t(ux & 31u) - 15; toy = int32_t(uy & 31u) - 15;
+                    noise1 = (noise1 & 31) - 15;
+                }
+                const f2 tile_coord_f = uv * depth_tex_size + f2{float(tox), float(toy)};
+                const uint32_t tcx = clampu(f2u_sat(tile_coord_f.x), uint32_t(DW - 1)) / 16u, tcy = clampu(f2u_sat(tile_coord_f.y), uint32_t(DH - 1)) / 16u;
+                const f2 tile_velocity = blur_scale * ld2(dilated, int(tcx), int(tcy));
+                const int kernel_width = 4;
+                const float noise = 0.5f * float(noise1) / 15.0f;
+                const float center_offset_len = noise / float(kernel_width) * 0.5f;
+                const f2 center_uv = uv + tile_velocity * center_offset_len;
+                const f2 cpx = center_uv * output_tex_size;
+                const f3 center_color = xyz(ld4(input, int(clampu(f2u_sat(cpx.x), uint32_t(W - 1))), int(clampu(f2u_sat(cpx.y), uint32_t(H - 1)))));
+                const float center_depth = -depth_to_view_z(sample_nearest_clamp(depth, center_uv), fc);
+                const f4 cv = sample_bilinear_clamp_snorm16(reprojection_map, center_uv);
+                const f2 center_velocity_px = (blur_scale * f2{cv.x, cv.y}) * depth_tex_size;
+                const float soft_z = 16.0f;
+                f4 sum = mk4(0.0f);
+                float sample_count = 1.0f;
+                if (length(tile_velocity) > 0.0f) {
+                    for (int i = 1; i < kernel_width; ++i) {
+                        const float offset_len0 = (float(i) + noise) / float(kernel_width) * 0.5f;
+                        const float offset_len1 = (float(-i) + noise) / float(kernel_width) * 0.5f;
+                        const f2 uv0 = uv + tile_velocity * offset_len0, uv1 = uv + tile_velocity * offset_len1;
+                        const f2 p0 = uv0 * depth_tex_size, p1 = uv1 * depth_tex_size;
+                        const int px0 = int(std::min(f2u_sat(p0.x), 0x7fffffffu)), py0 = int(std::min(f2u_sat(p0.y), 0x7fffffffu));
+                        const int px1 = int(std::min(f2u_sat(p1.x), 0x7fffffffu)), py1 = int(std::min(f2u_sat(p1.y), 0x7fffffffu));
+                        const float d0 = -depth_to_view_z(depth.ld(px0, py0), fc), d1 = -depth_to_view_z(depth.ld(px1, py1), fc);
+                        const f4 r0 = ld_reproj(reprojection_map, px0, py0), r1 = ld_reproj(reprojection_map, px1, py1);
+                        const float v0 = length(blur_scale * f2{r0.x, r0.y} * depth_tex_size), v1 = length(blur_scale * f2{r1.x, r1.y} * depth_tex_size);
+                        float weight0 = sample_weight(center_depth, d0, length((uv0 - uv) * depth_tex_size), length(center_velocity_px), v0, soft_z);
+                        float weight1 = sample_weight(center_depth, d1, length((uv1 - uv) * depth_tex_size), length(center_velocity_px), v1, soft_z);
+                        const bool m0 = d0 > d1, m1 = v1 > v0;
+                        weight0 = (m0 && m1) ? weight1 : weight0;
+                        weight1 = (m0 || m1) ? weight1 : weight0;
+                        const float valid0 = (uv0.x == saturate(uv0.x) && uv0.y == saturate(uv0.y)) ? 1.0f : 0.0f;
+                        const float valid1 = (uv1.x == saturate(uv1.x) && uv1.y == saturate(uv1.y)) ? 1.0f : 0.0f;
+                        weight0 *= valid0; weight1 *= valid1;
+                        sample_count += valid0 + valid1;
+                        f4 c0 = sample_bilinear_clamp(input, uv0); c0.w = 1.0f;
+                        sum += c0 * weight0;
+                        f4 c1 = sample_bilinear_clamp(input, uv1); c1.w = 1.0f;
+                        sum += c1 * weight1;
+                    }
+                    sum = sum * (1.0f / sample_count);
+                }
+                const f3 result = xyz(sum) + (1.0f - sum.w) * center_color;
+                st4(out, x, y, mk4(result, 1.0f));
+            }
+        return out;
+    }
+};
+
 }  // namespace okj

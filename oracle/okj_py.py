@@ -117,6 +117,12 @@ def lib():
         L.okj_post_read_back_histogram.restype = C.c_float
         L.okj_post_read_back_histogram.argtypes = [C.c_void_p, C.c_float, C.c_float]
         L.okj_display_transform_srgb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.okj_motion_blur_create.restype = C.c_void_p
+        L.okj_motion_blur_destroy.argtypes = [C.c_void_p]
+        L.okj_motion_blur_render.restype = C.c_void_p
+        L.okj_motion_blur_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.okj_motion_blur_surface.restype = C.c_int
+        L.okj_motion_blur_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_reference_path_trace.restype = C.c_uint64
         L.okj_reference_path_trace.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
         L.okj_set_threads.argtypes = [C.c_int]
@@ -466,5 +472,36 @@ class OraclePost:
     def __del__(self):
         try:
             self.L.okj_post_destroy(self.h)
+        except Exception:
+            pass
+
+
+class OracleMotionBlur:
+    """motion_blur (renderers/motion_blur.rs:5-72) on the CPU."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = self.L.okj_motion_blur_create()
+
+    def render(self, fc, input_rgba16f, depth, reprojection_map):
+        """input (H, W, 4) float16, depth (DH, DW) float32, reprojection_map (DH, DW, 4) int16 -> (H, W, 4) float16"""
+        inp = np.ascontiguousarray(input_rgba16f, np.float16)
+        d = np.ascontiguousarray(depth, np.float32)
+        r = np.ascontiguousarray(reprojection_map, np.int16)
+        H, W = inp.shape[:2]
+        DH, DW = d.shape
+        assert r.shape == (DH, DW, 4)
+        ptr = self.L.okj_motion_blur_render(self.h, C.byref(fc), inp.ctypes.data, W, H, d.ctypes.data, r.ctypes.data, DW, DH)
+        return np.frombuffer((C.c_uint8 * (W * H * 8)).from_address(ptr), dtype=np.float16).reshape(H, W, 4)
+
+    def surface(self, name, dtype, shape):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        if self.L.okj_motion_blur_surface(self.h, name.encode(), C.byref(ptr), C.byref(n)) != 0:
+            raise KeyError(name)
+        return np.frombuffer((C.c_uint8 * n.value).from_address(ptr.value), dtype=dtype).reshape(shape)
+
+    def __del__(self):
+        try:
+            self.L.okj_motion_blur_destroy(self.h)
         except Exception:
             pass

@@ -44,6 +44,10 @@ def emu():
     L.kj_post_surface.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.kj_post_mip_levels.argtypes = [vp, C.POINTER(u32)]
     L.kj_post_read_back_histogram.argtypes = [vp, f, f, C.POINTER(f), vp]
+    L.kj_motion_blur_create.argtypes = [vp, C.POINTER(vp)]
+    L.kj_motion_blur_destroy.argtypes = [vp]; L.kj_motion_blur_destroy.restype = None
+    L.kj_motion_blur_render.argtypes = [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(vp), vp]
+    L.kj_motion_blur_surface.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)]
     return L
 
 
@@ -186,3 +190,52 @@ def test_dynamic_exposure_loop_converges(emu, oracle):
         assert abs(a - b) <= 2 * 16                                                      # the displayed value has settled (dither aside)
     finally:
         ep.close()
+
+
+def _motion_inputs(W, H, DW, DH, seed):
+    """A moving foreground band over a slower background, a sky region (depth 0) and a fast strip at the border: every branch of
+    motion_blur.rs (mirrored weights, invalid taps outside [0, 1], NaN depth differences) gets exercised."""
+    rng = np.random.RandomState(seed)
+    inp = (rng.uniform(0, 1, (H, W, 4)) ** 2 * 3).astype(np.float16)
+    depth = np.full((DH, DW), 0.0012, np.float32) * rng.uniform(0.9, 1.1, (DH, DW)).astype(np.float32)
+    depth[DH // 3: DH // 2] = 0.004
+    depth[: DH // 8] = 0.0
+    vel = np.zeros((DH, DW, 2))
+    vel[..., 0] = 0.01 + 0.004 * np.sin(np.arange(DW) * 0.1)[None, :]
+    vel[DH // 3: DH // 2, :, 0] = -0.06
+    vel[DH // 3: DH // 2, :, 1] = 0.03
+    vel[:, : DW // 10, 0] = 0.2
+    vel[-DH // 6:, :, :] = 0.0
+    rm = np.zeros((DH, DW, 4), np.int16)
+    rm[..., :2] = np.round(np.clip(vel, -1, 1) * 32767)
+    rm[..., 2:] = rng.randint(-32767, 32767, (DH, DW, 2))
+    return inp, depth, rm
+
+
+@pytest.mark.parametrize("W,H,DW,DH", [(96, 64, 96, 64), (131, 77, 131, 77), (128, 96, 64, 48), (5, 3, 5, 3)])
+def test_motion_blur_kernels_on_cpu_equal_the_oracle(emu, oracle, W, H, DW, DH):
+    inp, depth, rm = _motion_inputs(W, H, DW, DH, W + DH)
+    fc = _fc(DW, DH, 2)
+    om = oracle.OracleMotionBlur()
+    ref = om.render(fc, inp, depth, rm).copy()
+    bn = oracle.blue_noise()
+    dev = emu.emu_device_create(bn.ctypes.data)
+    emu.emu_frame_begin(dev, C.byref(fc))
+    h = C.c_void_p()
+    assert emu.kj_motion_blur_create(dev, C.byref(h)) == 0
+    try:
+        out = C.c_void_p()
+        assert emu.kj_motion_blur_render(h, inp.ctypes.data, W, H, depth.ctypes.data, rm.ctypes.data, DW, DH, C.byref(out), None) == 0, emu.emu_last_error()
+        got = np.frombuffer((C.c_uint8 * (W * H * 8)).from_address(out.value), np.uint16).reshape(H, W, 4)
+        assert np.array_equal(got, ref.view(np.uint16))
+        tw, th = (DW + 15) // 16, (DH + 15) // 16
+        for name, shape in (("velocity_reduced_x", (DH, tw, 2)), ("velocity_reduced_y", (th, tw, 2)), ("velocity_dilated", (th, tw, 2))):
+            p, n = C.c_void_p(), C.c_uint64()
+            assert emu.kj_motion_blur_surface(h, name.encode(), C.byref(p), C.byref(n)) == 0
+            assert np.array_equal(np.frombuffer((C.c_uint8 * n.value).from_address(p.value), np.uint16).reshape(shape), om.surface(name, np.uint16, shape)), name
+        if W > 16:
+            assert (got[..., :3] != inp.view(np.uint16)[..., :3]).any(-1).mean() > 0.2            # it does blur
+        assert emu.kj_motion_blur_render(h, None, W, H, depth.ctypes.data, rm.ctypes.data, DW, DH, C.byref(out), None) != 0
+    finally:
+        emu.kj_motion_blur_destroy(h)
+        emu.emu_device_destroy(dev)

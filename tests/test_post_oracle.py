@@ -267,3 +267,138 @@ def test_post_combine_wiring(oracle):
     with_spot = _unpack(op.render(_fc(W, H, 0), spot).copy())
     base = _unpack(op.render(_fc(W, H, 0), np.where(spot > 1, 0.01, spot).astype(np.float16)).copy())
     assert with_spot[H // 2 + 6, W // 2 + 6, 1] > 2 * base[H // 2 + 6, W // 2 + 6, 1]
+
+
+# ---------------------------------------------------------------- motion_blur (renderers/motion_blur.rs, rust-shaders/src/motion_blur.rs)
+def _snorm(rm):
+    return np.maximum(rm.astype(np.float64) / 32767.0, -1.0)
+
+
+def _rust_motion_blur(fc, inp, depth, rm):
+    """`motion_blur` (rust-shaders/src/motion_blur.rs:47-187) and the three velocity kernels (:189-264), restated line by line in Python
+    floats (float64; the fp16 stores of the intermediate images are applied). Casts `as_uvec2()` saturate as Rust's `as` does."""
+    H, W = inp.shape[:2]
+    DH, DW = depth.shape
+    vel = _snorm(rm)[..., :2]
+    tw, th = -(-DW // 16), -(-DH // 16)
+    f16 = lambda a: np.asarray(a, np.float64).astype(np.float16).astype(np.float64)
+
+    def largest(vs):
+        best, m = np.zeros(2), 0.0
+        for v in vs:
+            m2 = float(v @ v)
+            if m2 > m:
+                best, m = v, m2
+        return best
+    fetch = lambda img, x, y: img[y, x] if 0 <= x < img.shape[1] and 0 <= y < img.shape[0] else np.zeros(img.shape[2:])
+    rx = np.array([[f16(largest([fetch(vel, x * 16 + i, y) for i in range(16)])) for x in range(tw)] for y in range(DH)])
+    ry = np.array([[f16(largest([fetch(rx, x, y * 16 + i) for i in range(16)])) for x in range(tw)] for y in range(th)])
+    dil = np.array([[f16(largest([fetch(ry, x + xx, y + yy) for xx in range(-2, 3) for yy in range(-2, 3)])) for x in range(tw)] for y in range(th)])
+    c2v = fc.view_constants.clip_to_view[11]
+    view_z = lambda d: np.float64(1.0) / (np.float64(d) * -c2v) if d != 0 else -np.inf
+    sat = lambda v: min(max(v, 0.0), 1.0) if v == v else 0.0
+    as_u = lambda v: int(v) if v > 0 else 0
+    col = inp.astype(np.float64)
+
+    def bilinear(img, u, v):
+        h, w = img.shape[:2]
+        fx, fy = u * w - 0.5, v * h - 0.5
+        x0, y0 = math.floor(fx), math.floor(fy)
+        tx, ty = fx - x0, fy - y0
+        cl = lambda a, n: min(max(a, 0), n - 1)
+        return ((img[cl(y0, h), cl(x0, w)] * (1 - tx) + img[cl(y0, h), cl(x0 + 1, w)] * tx) * (1 - ty)
+                + (img[cl(y0 + 1, h), cl(x0, w)] * (1 - tx) + img[cl(y0 + 1, h), cl(x0 + 1, w)] * tx) * ty)
+
+    def weight(cd, sd, offset_len, cs, ss):
+        with np.errstate(invalid="ignore"):
+            d = sd - cd
+        dc = (sat(0.5 + 16.0 * d), sat(0.5 - 16.0 * d))
+        sc = (sat(cs - (offset_len + 1.0)), sat(ss - (offset_len + 1.0)))
+        return dc[0] * sc[0] + dc[1] * sc[1]
+    out = np.zeros((H, W, 3))
+    M = 0xffffffff
+    for y in range(H):
+        for x in range(W):
+            uv = np.array([(x + 0.5) / W, (y + 0.5) / H])
+            tx_, ty_ = x, y
+            tx_ = (tx_ + (tx_ << 4)) & M; tx_ ^= tx_ >> 6
+            ty_ = (ty_ + (tx_ << 1)) & M; ty_ = (ty_ + (ty_ << 6)) & M; ty_ ^= ty_ >> 2
+            tx_ ^= ty_
+            noise1 = ((tx_ ^ (ty_ << 1)) & 31) - 15
+            off = np.array([(tx_ & 31) - 15, (ty_ & 31) - 15], np.float64)
+            tc = uv * [DW, DH] + off
+            tile = 0.5 * dil[min(as_u(tc[1]), DH - 1) // 16, min(as_u(tc[0]), DW - 1) // 16]
+            noise = 0.5 * noise1 / 15.0
+            center_uv = uv + tile * (noise / 4 * 0.5)
+            cp = center_uv * [W, H]
+            center_color = col[min(as_u(cp[1]), H - 1), min(as_u(cp[0]), W - 1), :3]
+            nx, ny = min(max(math.floor(center_uv[0] * DW), 0), DW - 1), min(max(math.floor(center_uv[1] * DH), 0), DH - 1)
+            center_depth = -view_z(depth[ny, nx])
+            cvel_px = 0.5 * bilinear(vel, center_uv[0], center_uv[1]) * [DW, DH]
+            s, sw, count = np.zeros(3), 0.0, 1.0
+            if np.hypot(*tile) > 0:
+                for i in range(1, 4):
+                    ol0, ol1 = (i + noise) / 4 * 0.5, (-i + noise) / 4 * 0.5
+                    uv0, uv1 = uv + tile * ol0, uv + tile * ol1
+                    p0, p1 = uv0 * [DW, DH], uv1 * [DW, DH]
+                    q0, q1 = (as_u(p0[0]), as_u(p0[1])), (as_u(p1[0]), as_u(p1[1]))
+                    dz = lambda q: -view_z(depth[q[1], q[0]] if q[0] < DW and q[1] < DH else 0.0)
+                    vz = lambda q: np.hypot(*(0.5 * (vel[q[1], q[0]] if q[0] < DW and q[1] < DH else np.zeros(2)) * [DW, DH]))
+                    d0, d1, v0, v1 = dz(q0), dz(q1), vz(q0), vz(q1)
+                    w0 = weight(center_depth, d0, np.hypot(*((uv0 - uv) * [DW, DH])), np.hypot(*cvel_px), v0)
+                    w1 = weight(center_depth, d1, np.hypot(*((uv1 - uv) * [DW, DH])), np.hypot(*cvel_px), v1)
+                    m0, m1 = d0 > d1, v1 > v0
+                    w0 = w1 if (m0 and m1) else w0
+                    w1 = w1 if (m0 or m1) else w0
+                    val0 = 1.0 if (0 <= uv0[0] <= 1 and 0 <= uv0[1] <= 1) else 0.0
+                    val1 = 1.0 if (0 <= uv1[0] <= 1 and 0 <= uv1[1] <= 1) else 0.0
+                    w0 *= val0; w1 *= val1
+                    count += val0 + val1
+                    s += bilinear(col, uv0[0], uv0[1])[:3] * w0 + bilinear(col, uv1[0], uv1[1])[:3] * w1
+                    sw += w0 + w1
+                s, sw = s / count, sw / count
+            out[y, x] = s + (1.0 - sw) * center_color
+    return out, rx, ry, dil
+
+
+def test_motion_blur_matches_the_rust_statement(oracle):
+    from test_post_emulation import _motion_inputs
+    W, H = 72, 48
+    inp, depth, rm = _motion_inputs(W, H, W, H, 9)
+    fc = _fc(W, H, 1)
+    om = oracle.OracleMotionBlur()
+    got = om.render(fc, inp, depth, rm).astype(np.float64)
+    ref, rx, ry, dil = _rust_motion_blur(fc, inp, depth, rm)
+    tw, th = -(-W // 16), -(-H // 16)
+    assert np.array_equal(om.surface("velocity_reduced_x", np.float16, (H, tw, 2)).astype(np.float64), rx)      # selections: exact
+    assert np.array_equal(om.surface("velocity_reduced_y", np.float16, (th, tw, 2)).astype(np.float64), ry)
+    assert np.array_equal(om.surface("velocity_dilated", np.float16, (th, tw, 2)).astype(np.float64), dil)
+    err = np.abs(got[..., :3] - ref)
+    # float32 vs float64 can move a tap across a texel edge (as_uvec2) on a handful of pixels; everything else is fp16 rounding
+    close = err <= np.abs(ref) * 2.0 ** -10 + 1e-4
+    assert close.all(-1).mean() > 0.995, close.all(-1).mean()
+    assert (got[..., 3] == 1.0).all()
+    assert (np.abs(got[..., :3] - inp[..., :3].astype(np.float64)) > 1e-3).any(-1).mean() > 0.15                 # and it is not the identity
+
+
+def test_motion_blur_properties(oracle):
+    W, H = 80, 48
+    fc = _fc(W, H, 0)
+    om = oracle.OracleMotionBlur()
+    rng = np.random.RandomState(4)
+    inp = rng.uniform(0, 2, (H, W, 4)).astype(np.float16)
+    depth = np.full((H, W), 0.002, np.float32)
+    still = np.zeros((H, W, 4), np.int16)
+    out = om.render(fc, inp, depth, still)
+    assert np.array_equal(out[..., :3], inp[..., :3])                      # no motion anywhere: the centre tap with weight 1
+    # uniform horizontal motion over a flat depth: columns mix, rows do not; an image constant along x is a fixed point
+    move = still.copy(); move[..., 0] = int(0.08 * 32767)
+    stripes = np.repeat(rng.uniform(0, 2, (H, 1, 4)), W, 1).astype(np.float16)
+    out = om.render(fc, stripes, depth, move).astype(np.float32)
+    assert np.abs(out[..., :3] - stripes[..., :3].astype(np.float32)).max() < 2e-3
+    out = om.render(fc, inp, depth, move).astype(np.float32)
+    assert out[..., :3].var() < 0.6 * inp[..., :3].astype(np.float32).var()
+    # sky (depth 0 -> infinite distance): inf - inf = NaN depth differences clamp to weight 0 (the Rust's comment), pixels stay as they are
+    sky = np.zeros((H, W), np.float32)
+    out = om.render(fc, inp, sky, move)
+    assert np.array_equal(out[..., :3], inp[..., :3])

@@ -92,3 +92,30 @@ def test_post_is_deterministic_and_reusable_across_extents(gpu, device):
         h = gp.surface("histogram", torch.int32, (256,)).cpu().numpy().copy()
         assert h.sum() > 0
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[3]) and outs[2].shape == (60, 100)
+
+
+@pytest.mark.parametrize("W,H,DW,DH", [(320, 180, 320, 180), (333, 187, 333, 187), (640, 360, 320, 180)])
+def test_motion_blur_matches_oracle(gpu, oracle, device, W, H, DW, DH):
+    """motion_blur (renderers/motion_blur.rs): the three velocity selections are exact (they only compare and copy fp16 values); the blurred
+    image is RGBA16F: fp16 rounding noise, except where rounding moves a tap across a texel edge (`as_uvec2`) — a handful of pixels."""
+    import torch
+    from test_post_emulation import _motion_inputs
+    inp, depth, rm = _motion_inputs(W, H, DW, DH, W + DH)
+    fc = _fc(DW, DH, 2, 1.0)
+    om = oracle.OracleMotionBlur()
+    ref = om.render(fc, inp, depth, rm).astype(np.float32)
+    gm = gpu.GpuMotionBlur(device)
+    device.frame_begin(fc)
+    got = gm.render(torch.from_numpy(inp).cuda(), torch.from_numpy(depth).cuda(), torch.from_numpy(rm).cuda())
+    torch.cuda.synchronize()
+    tw, th = (DW + 15) // 16, (DH + 15) // 16
+    for name, shape in (("velocity_reduced_x", (DH, tw, 2)), ("velocity_reduced_y", (th, tw, 2)), ("velocity_dilated", (th, tw, 2))):
+        g = gm.surface(name, torch.int16, shape).cpu().numpy().view(np.uint16)
+        assert np.array_equal(g, om.surface(name, np.uint16, shape)), name
+    g = got.float().cpu().numpy()
+    assert np.isfinite(g).all() and (g[..., 3] == 1.0).all()
+    err = np.abs(g[..., :3] - ref[..., :3])
+    close = (err <= np.abs(ref[..., :3]) * 2.0 ** -9 + 2e-4).all(-1)
+    rel = float(np.sqrt((err ** 2).sum() / (ref[..., :3] ** 2).sum()))
+    print(f"{W}x{H}: rel-L2 {rel:.2e}, pixels beyond fp16 rounding {1 - close.mean():.2e}")
+    assert close.mean() > 0.998 and rel < 1e-3
