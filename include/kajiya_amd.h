@@ -491,7 +491,8 @@ KjStatus kj_rtr_ray_counts(KjRtr* r, uint64_t* out_closest, uint64_t* out_any);
  *   blur_pyramid (post.rs:10-61; rust-shaders/src/blur.rs for mip 0, shaders/blur.hlsl for the rest), luminance histogram
  *   (post.rs:138-186, shaders/post/luminance_histogram_*.hlsl), rev_blur_pyramid (post.rs:63-110, rust-shaders/src/rev_blur.rs),
  *   "post combine" (shaders/post_combine.hlsl + inc/color/display_transform.hlsl and the colour headers it pulls in).
- * input: RGBA16F full-res image (TaaOutput.this_frame_out, or kj_motion_blur_render's output as in the reference). Output:
+ * input: full-res image, RGBA16F (TaaOutput.this_frame_out / kj_motion_blur_render's output: the standard frame) or RGBA32F (the path
+ * tracer's accumulation image: prepare_render_graph_reference hands it to post as is, world_render_passes.rs:294-330). Output:
  * B10G11R11_UFLOAT full-res, LINEAR display-referred values in [0, ~1] — kajiya's swap chain applies the sRGB transfer function.
  * The Bezold-Brucke LUT (bindless texture 2: 64 x 1 RG16F, lut_renderers.rs:45-76) is caller data like the blue-noise image: host
  * pointer, copied at create. frame_index (dither offset) and pre_exposure (histogram) come from kj_frame_begin's constants.
@@ -504,7 +505,8 @@ KjStatus kj_rtr_ray_counts(KjRtr* r, uint64_t* out_closest, uint64_t* out_any);
 typedef struct KjPost KjPost;
 KjStatus kj_post_create(KjDevice* dev, const uint16_t* bezold_brucke_lut_rg16f_64, KjPost** out);
 void kj_post_destroy(KjPost* p);
-KjStatus kj_post_render(KjPost* p, const void* input_rgba16f, uint32_t width, uint32_t height, float post_exposure_mult, float contrast,
+enum { KJ_POST_INPUT_RGBA16F = 0, KJ_POST_INPUT_RGBA32F = 1 };
+KjStatus kj_post_render(KjPost* p, const void* input, uint32_t input_format, uint32_t width, uint32_t height, float post_exposure_mult, float contrast,
                         const void** out_b10g11r11, void* stream);
 KjStatus kj_post_read_back_histogram(KjPost* p, float clipping_low, float clipping_high, float* out_image_log2_lum, uint32_t* out_histogram256);
 KjStatus kj_luminance_histogram_mean_log2(const uint32_t* histogram256, float clipping_low, float clipping_high, float* out_image_log2_lum);

@@ -400,10 +400,11 @@ struct PostProcessRenderer {
     PostProcessRenderer(const PostProcessRenderer&) = delete;
     PostProcessRenderer& operator=(const PostProcessRenderer&) = delete;
     // -> B10G11R11_UFLOAT image, linear display-referred
-    const void* render(const void* input_rgba16f, uint32_t w, uint32_t hgt, float post_exposure_mult, float contrast, HistogramClipping exposure_histogram_clipping, hipStream_t s) {
+    const void* render(const void* input, uint32_t w, uint32_t hgt, float post_exposure_mult, float contrast, HistogramClipping exposure_histogram_clipping, hipStream_t s,
+                       uint32_t input_format = KJ_POST_INPUT_RGBA16F) {
         check(kj_post_read_back_histogram(h, exposure_histogram_clipping.low, exposure_histogram_clipping.high, &image_log2_lum, nullptr), "kj_post_read_back_histogram");
         const void* out = nullptr;
-        check(kj_post_render(h, input_rgba16f, w, hgt, post_exposure_mult, contrast, &out, s), "kj_post_render");
+        check(kj_post_render(h, input, input_format, w, hgt, post_exposure_mult, contrast, &out, s), "kj_post_render");
         return out;
     }
 };
@@ -490,9 +491,10 @@ struct WorldRenderer {
         return o;
     }
     // WorldRenderer::prepare_render_graph_reference (world_render_passes.rs:294-330): one more path-traced sample per pixel into the persistent
-    // "refpt.accum" image (cleared when reset_reference_accumulation is set, e.g. after the camera moved). Returns the RGBA32F accumulator;
-    // the reference then tone-maps it (post.render: out of scope).
+    // "refpt.accum" image (cleared when reset_reference_accumulation is set, e.g. after the camera moved). Returns the RGBA32F accumulator,
+    // or — once enable_post() has been called — what the reference returns: post.render on the accumulator (:320-329), B10G11R11_UFLOAT.
     const void* prepare_render_graph_reference(const CameraMatrices& camera, hipStream_t s) {
+        if (post) update_pre_exposure(RenderMode::Reference);
         const size_t bytes = size_t(render_extent[0]) * render_extent[1] * 16;
         if (refpt_accum.bytes != bytes) { refpt_accum.alloc(bytes); reset_reference_accumulation = false; }
         frame_state.triangle_light_count = scene.triangle_light_count();
@@ -503,8 +505,11 @@ struct WorldRenderer {
             check_hip(hipMemsetAsync(refpt_accum.p, 0, bytes, s), "hipMemsetAsync");
         }
         check(kj_reference_path_trace(device.h, scene.h, refpt_accum.p, render_extent[0], render_extent[1], 0, 1, 0, nullptr, s), "kj_reference_path_trace");
+        const void* out = refpt_accum.p;
+        if (post)
+            out = post->render(refpt_accum.p, render_extent[0], render_extent[1], exposure_state[1].post_mult, contrast, dynamic_exposure.histogram_clipping, s, KJ_POST_INPUT_RGBA32F);
         frame_state.retire_frame();
-        return refpt_accum.p;
+        return out;
     }
 };
 

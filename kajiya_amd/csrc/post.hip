@@ -31,6 +31,8 @@ KJ_D float gaussian_wt(float dst_px, float src_px) {     // blur.rs:18-22 == blu
 }
 KJ_D V3 blur_fetch(const ImgU2& i, int x, int y) { return xyz(unpack_rgba16f(i.ld(x, y))); }
 KJ_D V3 blur_fetch(const ImgU32& i, int x, int y) { return unpack_r11g11b10f(i.ld(x, y)); }
+typedef Img<float4> ImgF4;     // RGBA32F: the reference path tracer's accumulation image (world_render_passes.rs:294-330 feeds it to post as is)
+KJ_D V3 blur_fetch(const ImgF4& i, int x, int y) { const float4 v = i.ld(x, y); return V3{v.x, v.y, v.z}; }
 
 // one blur + 2x downsample pass; VTAPS = 10 for the Rust kernel of mip 0 (`while y < KERNEL_RADIUS * 2`), 11 for blur.hlsl
 template <typename SRC, int VTAPS>
@@ -110,13 +112,14 @@ __global__ void __launch_bounds__(64) k_post_rev_blur(ImgU32 tail, ImgU32 src, I
 }
 
 // post_combine.hlsl:112-191
-__global__ void __launch_bounds__(64) k_post_combine(const FrameConstants* __restrict__ fcp, ImgU2 input, ImgU32 glare_tex, const uint32_t* __restrict__ bb_lut,
+template <typename SRC>
+__global__ void __launch_bounds__(64) k_post_combine(const FrameConstants* __restrict__ fcp, SRC input, ImgU32 glare_tex, const uint32_t* __restrict__ bb_lut,
                                                      const uint32_t* __restrict__ blue_noise, float input_multiplier, float contrast, ImgU32 output) {
     TILE_XY(output.w, output.h)
     if (!in_image) return;
     const V2 uv = V2{float(x) + 0.5f, float(y) + 0.5f} * V2{1.0f / float(output.w), 1.0f / float(output.h)};
     const V3 glare = sample_r11g11b10f_bilinear_clamp(glare_tex, uv);
-    V3 col = xyz(unpack_rgba16f(input.ld(x, y)));
+    V3 col = blur_fetch(input, x, y);
     col = lerp(col, glare, 0.05f);
     col = vmax(v3(0.0f), col);
     col = col * input_multiplier;
@@ -290,9 +293,10 @@ KjStatus kj_post_create(KjDevice* dev, const uint16_t* bezold_brucke_lut_rg16f_6
 }
 void kj_post_destroy(KjPost* t) { delete t; }
 
-KjStatus kj_post_render(KjPost* t, const void* input_rgba16f, uint32_t width, uint32_t height, float post_exposure_mult, float contrast,
+KjStatus kj_post_render(KjPost* t, const void* input, uint32_t input_format, uint32_t width, uint32_t height, float post_exposure_mult, float contrast,
                         const void** out_b10g11r11, void* stream_) {
-    KJ_REQUIRE(t && input_rgba16f && out_b10g11r11 && width && height, "null argument");
+    KJ_REQUIRE(t && input && out_b10g11r11 && width && height, "null argument");
+    KJ_REQUIRE(input_format == KJ_POST_INPUT_RGBA16F || input_format == KJ_POST_INPUT_RGBA32F, "input_format must be KJ_POST_INPUT_RGBA16F or KJ_POST_INPUT_RGBA32F");
     KJ_REQUIRE(t->dev->fc_dev, "kj_frame_begin not called");
     hipStream_t s = (hipStream_t)stream_;
     const int W = int(width), H = int(height), pw = (W + 1) / 2, ph = (H + 1) / 2;
@@ -312,7 +316,10 @@ KjStatus kj_post_render(KjPost* t, const void* input_rgba16f, uint32_t width, ui
     KJ_TRY_HIP(t->err);
     const dim3 blk(64);
     // ---- blur_pyramid
-    hipLaunchKernelGGL((k_post_blur<ImgU2, 10>), dim3((mw(0) + 63) / 64, mh(0)), blk, 0, s, img<uint2>(input_rgba16f, W, H), img<uint32_t>(blur[0], mw(0), mh(0)));
+    if (input_format == KJ_POST_INPUT_RGBA32F)
+        hipLaunchKernelGGL((k_post_blur<ImgF4, 10>), dim3((mw(0) + 63) / 64, mh(0)), blk, 0, s, img<float4>(input, W, H), img<uint32_t>(blur[0], mw(0), mh(0)));
+    else
+        hipLaunchKernelGGL((k_post_blur<ImgU2, 10>), dim3((mw(0) + 63) / 64, mh(0)), blk, 0, s, img<uint2>(input, W, H), img<uint32_t>(blur[0], mw(0), mh(0)));
     KJ_CHECK_LAUNCH();
     for (int l = 1; l < levels; ++l) {
         hipLaunchKernelGGL((k_post_blur<ImgU32, 11>), dim3((mw(l) + 63) / 64, mh(l)), blk, 0, s, img<uint32_t>(blur[l - 1], mw(l - 1), mh(l - 1)),
@@ -336,8 +343,12 @@ KjStatus kj_post_render(KjPost* t, const void* input_rgba16f, uint32_t width, ui
         KJ_CHECK_LAUNCH();
     }
     // ---- post combine
-    hipLaunchKernelGGL(k_post_combine, dim3((W + 7) / 8, (H + 7) / 8), blk, 0, s, fc, img<uint2>(input_rgba16f, W, H), img<uint32_t>(rev[0], mw(0), mh(0)),
-                       (const uint32_t*)t->bb_lut.p, (const uint32_t*)t->dev->blue_noise.p, post_exposure_mult, contrast, img<uint32_t>(output, W, H));
+    if (input_format == KJ_POST_INPUT_RGBA32F)
+        hipLaunchKernelGGL((k_post_combine<ImgF4>), dim3((W + 7) / 8, (H + 7) / 8), blk, 0, s, fc, img<float4>(input, W, H), img<uint32_t>(rev[0], mw(0), mh(0)),
+                           (const uint32_t*)t->bb_lut.p, (const uint32_t*)t->dev->blue_noise.p, post_exposure_mult, contrast, img<uint32_t>(output, W, H));
+    else
+        hipLaunchKernelGGL((k_post_combine<ImgU2>), dim3((W + 7) / 8, (H + 7) / 8), blk, 0, s, fc, img<uint2>(input, W, H), img<uint32_t>(rev[0], mw(0), mh(0)),
+                           (const uint32_t*)t->bb_lut.p, (const uint32_t*)t->dev->blue_noise.p, post_exposure_mult, contrast, img<uint32_t>(output, W, H));
     KJ_CHECK_LAUNCH();
     *out_b10g11r11 = output;
     return KJ_OK;

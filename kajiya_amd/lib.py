@@ -107,7 +107,7 @@ def load():
         "kj_rtr_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "kj_trace_sun_shadow_mask": [vp, vp, C.POINTER(KjGbufferDepth), vp, vp, vp],
         "kj_post_create": [vp, vp, C.POINTER(vp)],
-        "kj_post_render": [vp, vp, u32, u32, C.c_float, C.c_float, C.POINTER(vp), vp],
+        "kj_post_render": [vp, vp, u32, u32, u32, C.c_float, C.c_float, C.POINTER(vp), vp],
         "kj_post_read_back_histogram": [vp, C.c_float, C.c_float, C.POINTER(C.c_float), vp],
         "kj_luminance_histogram_mean_log2": [vp, C.c_float, C.c_float, C.POINTER(C.c_float)],
         "kj_post_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
@@ -576,13 +576,15 @@ class GpuPost:
         check(self.L.kj_post_create(dev.h, self._lut.ctypes.data, C.byref(self.h)))
 
     def render(self, input_rgba16f, post_exposure_mult=1.0, contrast=1.0):
-        """input: (H, W, 4) float16 cuda tensor (TaaOutput.this_frame_out) -> (H, W) B10G11R11_UFLOAT words (int32 tensor view, owned by
-        the handle, valid until the next call). kj_frame_begin must have been called for this frame."""
+        """input: (H, W, 4) float16 cuda tensor (TaaOutput.this_frame_out / the motion-blurred frame) or float32 (the path tracer's
+        accumulation image) -> (H, W) B10G11R11_UFLOAT words (int32 tensor view, owned by the handle, valid until the next call).
+        kj_frame_begin must have been called for this frame."""
         import torch
-        assert input_rgba16f.dtype == torch.float16 and input_rgba16f.is_contiguous() and input_rgba16f.shape[-1] == 4
+        assert input_rgba16f.dtype in (torch.float16, torch.float32) and input_rgba16f.is_contiguous() and input_rgba16f.shape[-1] == 4
         self.H, self.W = int(input_rgba16f.shape[0]), int(input_rgba16f.shape[1])
         out = C.c_void_p()
-        check(self.L.kj_post_render(self.h, input_rgba16f.data_ptr(), self.W, self.H, post_exposure_mult, contrast, C.byref(out), _stream_ptr()))
+        fmt = 1 if input_rgba16f.dtype == torch.float32 else 0      # KJ_POST_INPUT_RGBA32F / KJ_POST_INPUT_RGBA16F
+        check(self.L.kj_post_render(self.h, input_rgba16f.data_ptr(), fmt, self.W, self.H, post_exposure_mult, contrast, C.byref(out), _stream_ptr()))
         return tensor_from_ptr(out.value, self.W * self.H * 4, torch.int32, (self.H, self.W))
 
     def mip_levels(self):

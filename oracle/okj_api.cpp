@@ -403,9 +403,10 @@ int okj_ssgi_surface(void* p, const char* name, void** out_ptr, uint64_t* out_by
 // ---- post (PostProcessRenderer): returns the B10G11R11_UFLOAT full-res output
 void* okj_post_create() { return new Post(); }
 void okj_post_destroy(void* p) { delete (Post*)p; }
-const void* okj_post_render(void* p, const KjFrameConstants* fc, const void* input_rgba16f, uint32_t w, uint32_t h, const void* bezold_brucke_lut_rg16f,
+const void* okj_post_render(void* p, const KjFrameConstants* fc, const void* input, uint32_t input_is_rgba32f, uint32_t w, uint32_t h, const void* bezold_brucke_lut_rg16f,
                             const void* blue_noise_rgba8, float post_exposure_mult, float contrast) {
-    return ((Post*)p)->render(*fc, ImgRGBA16F((void*)input_rgba16f, w, h), (const h2*)bezold_brucke_lut_rg16f, (const uint32_t*)blue_noise_rgba8, post_exposure_mult, contrast).p;
+    return ((Post*)p)->render(*fc, ImgRGBA16F((void*)input, w, h), (const h2*)bezold_brucke_lut_rg16f, (const uint32_t*)blue_noise_rgba8, post_exposure_mult, contrast,
+                              input_is_rgba32f ? (const f4*)input : nullptr).p;
 }
 int okj_post_surface(void* p, const char* name, void** out_ptr, uint64_t* out_bytes) {
     Post* t = (Post*)p;

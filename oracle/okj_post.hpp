@@ -229,11 +229,16 @@ struct Post {
 
     // PostProcessRenderer::render (post.rs:237-271) without its leading read_back_histogram (a separate call here).
     // input RGBA16F W x H; returns the B10G11R11_UFLOAT W x H output.
-    ImgU32 render(const FrameConstants& fc, ImgRGBA16F input, const h2* bb_lut, const uint32_t* blue_noise_rgba8, float post_exposure_mult, float contrast) {
+    // `input`: RGBA16F (standard frame) or, with input32 != nullptr, RGBA32F (the path tracer's accumulation image, world_render_passes.rs:294-330)
+    ImgU32 render(const FrameConstants& fc, ImgRGBA16F input, const h2* bb_lut, const uint32_t* blue_noise_rgba8, float post_exposure_mult, float contrast, const f4* input32 = nullptr) {
         const int W = input.w, H = input.h, pw = (W + 1) / 2, ph = (H + 1) / 2;
+        auto in_rgb = [&](int x, int y) -> f3 {
+            if (!input32) return xyz(ld4(input, x, y));
+            return (x >= 0 && y >= 0 && x < W && y < H) ? xyz(input32[size_t(y) * W + x]) : mk3(0.0f);
+        };
         mip_levels = pyramid_mip_levels(pw, ph);
         // ---- blur_pyramid
-        blur_pass(mip("blur_pyramid", 0, pw, ph), 10, [&](int x, int y) { return xyz(ld4(input, x, y)); });
+        blur_pass(mip("blur_pyramid", 0, pw, ph), 10, in_rgb);
         for (int m = 1; m < mip_levels; ++m) {
             const ImgU32 src = mip("blur_pyramid", m - 1, pw, ph);
             blur_pass(mip("blur_pyramid", m, pw, ph), 11, [&](int x, int y) { return unpack_r11g11b10f(src.ld(x, y)); });
@@ -289,7 +294,7 @@ struct Post {
             for (int x = 0; x < W; ++x) {
                 const f2 uv = f2{float(x) + 0.5f, float(y) + 0.5f} * inv_extent;
                 const f3 glare = sample_r11g11b10f_bilinear_clamp(glare_tex, uv);
-                f3 col = xyz(ld4(input, x, y));
+                f3 col = in_rgb(x, y);
                 col = lerp(col, glare, 0.05f);
                 col = vmax(mk3(0.0f), col);
                 col = col * post_exposure_mult;

@@ -109,7 +109,7 @@ def lib():
         L.okj_post_create.restype = C.c_void_p
         L.okj_post_destroy.argtypes = [C.c_void_p]
         L.okj_post_render.restype = C.c_void_p
-        L.okj_post_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+        L.okj_post_render.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_float]
         L.okj_post_surface.restype = C.c_int
         L.okj_post_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_post_mip_levels.restype = C.c_int
@@ -431,11 +431,12 @@ class OraclePost:
         self.bn = blue_noise()
 
     def render(self, fc, input_rgba16f, post_exposure_mult=1.0, contrast=1.0):
-        """input (H, W, 4) float16 -> (H, W) uint32 B10G11R11_UFLOAT"""
-        inp = np.ascontiguousarray(input_rgba16f, np.float16)
+        """input (H, W, 4) float16 — or float32: the path tracer's accumulation image — -> (H, W) uint32 B10G11R11_UFLOAT"""
+        is32 = np.asarray(input_rgba16f).dtype == np.float32
+        inp = np.ascontiguousarray(input_rgba16f, np.float32 if is32 else np.float16)
         H, W = inp.shape[:2]
         self.W, self.H = W, H
-        ptr = self.L.okj_post_render(self.h, C.byref(fc), inp.ctypes.data, W, H, self.lut.ctypes.data, self.bn.ctypes.data, post_exposure_mult, contrast)
+        ptr = self.L.okj_post_render(self.h, C.byref(fc), inp.ctypes.data, 1 if is32 else 0, W, H, self.lut.ctypes.data, self.bn.ctypes.data, post_exposure_mult, contrast)
         return np.frombuffer((C.c_uint8 * (W * H * 4)).from_address(ptr), dtype=np.uint32).reshape(H, W)
 
     def mip_levels(self):

@@ -26,6 +26,7 @@
 
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
+struct float4 { float x, y, z, w; };
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 struct dim3 {

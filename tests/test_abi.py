@@ -48,7 +48,7 @@ def test_error_reporting_without_gpu():
                        ("kj_ircache_prepare", (None, None)), ("kj_taa_render", (None, None, 0, 0, None, None, 0, 0, None, None)),
                        ("kj_ssgi_render", (None, None, None, None, None, None)), ("kj_shadow_denoise_render", (None, None, None, None, None, None)),
                        ("kj_baked_mesh_view", (None, 0, None)), ("kj_baked_image_view", (None, 0, None)), ("kj_baked_image_decode_rgba8", (37, None, 0, 4, 4, None)),
-                       ("kj_post_create", (None, None, None)), ("kj_post_render", (None, None, 0, 0, 1.0, 1.0, None, None)), ("kj_post_surface", (None, None, None, None)),
+                       ("kj_post_create", (None, None, None)), ("kj_post_render", (None, None, 0, 0, 0, 1.0, 1.0, None, None)), ("kj_post_surface", (None, None, None, None)),
                        ("kj_post_read_back_histogram", (None, 0.0, 0.0, None, None)), ("kj_luminance_histogram_mean_log2", (None, 0.0, 0.0, None)), ("kj_post_mip_levels", (None, None)),
                        ("kj_motion_blur_create", (None, None)), ("kj_motion_blur_render", (None, None, 0, 0, None, None, 0, 0, None, None)), ("kj_motion_blur_surface", (None, None, None, None))):
         assert getattr(L, name)(*args) == 1, name

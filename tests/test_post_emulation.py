@@ -40,7 +40,7 @@ def emu():
     L.emu_f16_to_f32.restype = f; L.emu_f16_to_f32.argtypes = [C.c_uint16]
     L.kj_post_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.kj_post_destroy.argtypes = [vp]; L.kj_post_destroy.restype = None
-    L.kj_post_render.argtypes = [vp, vp, u32, u32, f, f, C.POINTER(vp), vp]
+    L.kj_post_render.argtypes = [vp, vp, u32, u32, u32, f, f, C.POINTER(vp), vp]
     L.kj_post_surface.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.kj_post_mip_levels.argtypes = [vp, C.POINTER(u32)]
     L.kj_post_read_back_histogram.argtypes = [vp, f, f, C.POINTER(f), vp]
@@ -59,11 +59,12 @@ class EmuPost:
         assert L.kj_post_create(self.dev, self._lut.ctypes.data, C.byref(self.h)) == 0, L.emu_last_error()
 
     def render(self, fc, inp, mult=1.0, contrast=1.0):
-        inp = np.ascontiguousarray(inp, np.float16)
+        is32 = np.asarray(inp).dtype == np.float32                    # KJ_POST_INPUT_RGBA32F: the path tracer's accumulation image
+        inp = np.ascontiguousarray(inp, np.float32 if is32 else np.float16)
         H, W = inp.shape[:2]
         self.L.emu_frame_begin(self.dev, C.byref(fc))
         out = C.c_void_p()
-        assert self.L.kj_post_render(self.h, inp.ctypes.data, W, H, mult, contrast, C.byref(out), None) == 0, self.L.emu_last_error()
+        assert self.L.kj_post_render(self.h, inp.ctypes.data, 1 if is32 else 0, W, H, mult, contrast, C.byref(out), None) == 0, self.L.emu_last_error()
         return np.frombuffer((C.c_uint8 * (W * H * 4)).from_address(out.value), np.uint32).reshape(H, W).copy()
 
     def surface(self, name):
@@ -127,6 +128,26 @@ def test_product_kernels_on_cpu_equal_the_oracle(emu, oracle, W, H, frame_index,
         ep.close()
 
 
+def test_rgba32f_input_of_the_reference_mode(emu, oracle):
+    """prepare_render_graph_reference (world_render_passes.rs:294-330) hands the RGBA32F accumulation image to post: same passes, wider
+    input. Values beyond fp16's range exercise the difference."""
+    W, H = 90, 60
+    lut = post_tables.synthetic_bezold_brucke_lut(5)
+    rng = np.random.RandomState(3)
+    acc = (rng.uniform(0, 1, (H, W, 4)) ** 4 * 50).astype(np.float32)
+    acc[3, 4, :3] = 3.0e5                                             # > 65504
+    acc[..., 3] = 17.0                                                # the accumulator's sample count: ignored
+    fc = _fc(W, H, 4)
+    op = oracle.OraclePost(lut)
+    ref = op.render(fc, acc, 0.25, 1.0).copy()
+    ep = EmuPost(emu, oracle.blue_noise(), lut)
+    try:
+        assert np.array_equal(ep.render(fc, acc, 0.25, 1.0), ref)
+        assert not np.array_equal(ref, op.render(fc, acc.astype(np.float16), 0.25, 1.0))      # fp16 would have clipped the highlight to inf
+    finally:
+        ep.close()
+
+
 def test_extent_change_and_error_paths(emu, oracle):
     """A second extent on the same handle reallocates every surface (post.hip: `surf.clear()`); NULL arguments and a missing
     kj_frame_begin are reported through the status code + last-error string, as everywhere in the C-ABI."""
@@ -139,8 +160,9 @@ def test_extent_change_and_error_paths(emu, oracle):
             op = oracle.OraclePost(lut)
             assert np.array_equal(ep.render(fc, inp), op.render(fc, inp))
         out = C.c_void_p()
-        assert emu.kj_post_render(ep.h, None, 8, 8, 1.0, 1.0, C.byref(out), None) != 0 and b"null argument" in emu.emu_last_error()
-        assert emu.kj_post_render(ep.h, C.c_void_p(1), 0, 8, 1.0, 1.0, C.byref(out), None) != 0
+        assert emu.kj_post_render(ep.h, None, 0, 8, 8, 1.0, 1.0, C.byref(out), None) != 0 and b"null argument" in emu.emu_last_error()
+        assert emu.kj_post_render(ep.h, C.c_void_p(1), 0, 0, 8, 1.0, 1.0, C.byref(out), None) != 0
+        assert emu.kj_post_render(ep.h, C.c_void_p(1), 7, 8, 8, 1.0, 1.0, C.byref(out), None) != 0 and b"input_format" in emu.emu_last_error()
         p, n = C.c_void_p(), C.c_uint64()
         assert emu.kj_post_surface(ep.h, b"no_such_surface", C.byref(p), C.byref(n)) != 0 and b"no post surface" in emu.emu_last_error()
         h = C.c_void_p()
@@ -153,7 +175,7 @@ def test_extent_change_and_error_paths(emu, oracle):
     assert emu.kj_post_create(dev, np.ascontiguousarray(lut).ctypes.data, C.byref(h)) == 0
     out = C.c_void_p()
     buf = np.zeros((4, 4, 4), np.float16)
-    assert emu.kj_post_render(h, buf.ctypes.data, 4, 4, 1.0, 1.0, C.byref(out), None) != 0 and b"kj_frame_begin" in emu.emu_last_error()
+    assert emu.kj_post_render(h, buf.ctypes.data, 0, 4, 4, 1.0, 1.0, C.byref(out), None) != 0 and b"kj_frame_begin" in emu.emu_last_error()
     emu.kj_post_destroy(h)
     emu.emu_device_destroy(dev)
 

@@ -77,6 +77,23 @@ def test_post_matches_oracle(gpu, oracle, device, W, H, frame_index, mult, contr
     print(f"{W}x{H}: texels differing (by <= 2 storage steps): " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
 
 
+def test_post_rgba32f_input_matches_oracle(gpu, oracle, device):
+    """The reference mode's input: the path tracer's RGBA32F accumulation image (world_render_passes.rs:294-330)."""
+    import torch
+    W, H = 320, 200
+    lut = post_tables.synthetic_bezold_brucke_lut(5)
+    rng = np.random.RandomState(3)
+    acc = (rng.uniform(0, 1, (H, W, 4)) ** 4 * 50).astype(np.float32)
+    acc[30, 40, :3] = 3.0e5
+    fc = _fc(W, H, 4, 1.0)
+    ref = oracle.OraclePost(lut).render(fc, acc, 0.25, 1.0).copy()
+    gp = gpu.GpuPost(device, lut)
+    device.frame_begin(fc)
+    got = gp.render(torch.from_numpy(acc).cuda().contiguous(), 0.25, 1.0)
+    torch.cuda.synchronize()
+    _compare(got.cpu().numpy().view(np.uint32), ref, "output (rgba32f input)", 0.05)
+
+
 def test_post_is_deterministic_and_reusable_across_extents(gpu, device):
     """Same input twice -> identical words (the only atomics are integer adds); a different extent on the same handle reallocates."""
     import torch
