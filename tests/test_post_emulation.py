@@ -261,3 +261,18 @@ def test_motion_blur_kernels_on_cpu_equal_the_oracle(emu, oracle, W, H, DW, DH):
     finally:
         emu.kj_motion_blur_destroy(h)
         emu.emu_device_destroy(dev)
+
+
+def test_kernels_are_clean_under_address_and_ub_sanitizers():
+    """tests/post_emu_sanitize.cpp: every kernel of post.hip over exact-size heap buffers (1x1 ... 31x257, an upscaled motion-blur case,
+    both input formats, black texels for the NaN path) with ASan + UBSan + float-cast-overflow. On the CPU stand-in device memory is heap
+    memory, so an index a GPU would fault on (or quietly read garbage from) aborts here."""
+    exe = os.path.join(BUILD, "post_emu_sanitize")
+    os.makedirs(BUILD, exist_ok=True)
+    src = os.path.join(ROOT, "tests", "post_emu_sanitize.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(s) for s in SOURCES + [src]):
+        subprocess.check_call(["g++", "-g", "-O1", "-std=c++20", "-pthread", "-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=all",
+                               "-I", os.path.join(ROOT, "tests", "hip_emu"), "-x", "c++", src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count(" ok ") == 8
