@@ -1,0 +1,56 @@
+"""TEST INFRASTRUCTURE: builds the WHOLE product (every .hip and .cpp under kajiya_amd/csrc) against the CPU stand-in for HIP in this
+directory -> tests/_build/emu_all/libkajiya_amd_emu.so, with AddressSanitizer + UBSan. The only edit made to the product source is the
+rewrite of the dynamic-LDS declaration form (`extern __shared__ T name[];`, which has no host-C++ spelling) in a scratch copy; everything
+else is compiled as it lies. Host compiler: ROCm's clang++ (the traversal code uses clang vector extensions). The result is never shipped
+and never loaded by the product: tests load it explicitly (KJ_AMD_LIB / tests/hip_emu/cpu_as_cuda.py)."""
+import glob
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "kajiya_amd", "csrc")
+OUT = os.path.join(ROOT, "tests", "_build", "emu_all")
+SO = os.path.join(OUT, "libkajiya_amd_emu.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+FLAGS = ["-g", "-O1", "-std=c++20", "-fPIC", "-pthread", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+         # float -> int casts of NaN / out-of-range values are DEFINED on the GPU (v_cvt_i32_f32 saturates, NaN -> 0) and the kernels rely on that
+         # where the reference's shaders do (e.g. a NaN direction reaching a cube lookup from an empty reservoir, clamped right after): not an error
+         "-fno-sanitize=float-cast-overflow",
+         "-I", os.path.join(ROOT, "tests", "hip_emu"), "-I", CSRC, "-D__HIP_PLATFORM_AMD__"]
+DYNAMIC_LDS = re.compile(r"extern __shared__ ([A-Za-z0-9_]+) ([A-Za-z0-9_]+)\[\];")
+
+
+def sanitizer_preload():
+    """LD_PRELOAD value for a python process that loads the instrumented library."""
+    rt = subprocess.check_output([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    return rt
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    deps = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
+        glob.glob(os.path.join(ROOT, "tests", "hip_emu", "hip", "*.h")) + [os.path.join(ROOT, "include", "kajiya_amd.h"), os.path.abspath(__file__)]
+    if os.path.exists(SO) and os.path.getmtime(SO) >= max(os.path.getmtime(d) for d in deps):
+        return SO
+
+    def compile_one(src):
+        name = os.path.splitext(os.path.basename(src))[0]
+        obj = os.path.join(OUT, name + ".o")
+        if src.endswith(".hip"):
+            text = DYNAMIC_LDS.sub(r"\1* \2 = (\1*)hip_emu::dynamic_lds();", open(src).read())
+            src = os.path.join(OUT, name + ".emu.cpp")
+            open(src, "w").write(text)
+        subprocess.check_call([CLANG] + FLAGS + ["-x", "c++", "-c", src, "-o", obj])
+        return obj
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+    srcs = [s for s in srcs if not os.path.basename(s).startswith("_")]
+    with ThreadPoolExecutor(8) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    subprocess.check_call([CLANG, "-shared", "-shared-libsan", "-fsanitize=address,undefined", "-Wl,-Bsymbolic", "-pthread", "-o", SO] + objs)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build())

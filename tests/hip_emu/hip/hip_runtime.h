@@ -4,15 +4,19 @@
 // blockDim host threads with a real barrier behind __syncthreads(), `__shared__` becomes one static array (workgroups run one after the
 // other), device memory is host memory. It checks the kernels' arithmetic, indexing and host sequencing against the oracle where no GPU
 // is available; it says nothing about code generation, and the -m gpu parity tests remain the statement about the real thing.
-// Not emulated (post.hip does not use them): wave intrinsics, textures, dynamic shared memory, streams that overlap.
+// Wave intrinsics exist for workgroups of ONE wave (<= 64 threads) whose lanes all reach the call, which is how the kernels here use them:
+// __shfl_xor, __ballot, __lane_id (an exchange array + the same barrier). Not emulated: divergent wave operations, textures, dynamic
+// shared memory, streams that overlap.
 #pragma once
 #include <algorithm>
 #include <barrier>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -27,6 +31,13 @@
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+inline int2 make_int2(int x, int y) { return int2{x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 struct dim3 {
@@ -42,13 +53,21 @@ inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 
 namespace hip_emu {
+// g_barrier: the barrier behind __syncthreads() and the wave intrinsics of the workgroup that is running. A lane that has returned from
+// the kernel drops out of it (as an exited lane drops out of the exec mask), so the remaining lanes can still vote / exchange.
 inline std::barrier<>* g_barrier = nullptr;
+inline bool g_lane_active[1024];
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     const unsigned n = block.x * block.y * block.z;
-    std::barrier<> bar(n);
-    g_barrier = &bar;
+    const size_t blocks = size_t(grid.x) * grid.y * grid.z;
+    if (blocks == 0 || n == 0) return;
+    std::barrier<> block_end(n);
+    std::unique_ptr<std::barrier<>> current;
     gridDim = grid;
     blockDim = block;
+    for (unsigned t = 0; t < n; ++t) g_lane_active[t] = true;
+    current.reset(new std::barrier<>(n));
+    g_barrier = current.get();
     std::vector<std::thread> threads;
     for (unsigned t = 0; t < n; ++t)
         threads.emplace_back([&, t]() {
@@ -58,17 +77,73 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                     for (unsigned bx = 0; bx < grid.x; ++bx) {
                         blockIdx = dim3(bx, by, bz);
                         body();
-                        bar.arrive_and_wait();      // the next workgroup reuses the static "LDS"
+                        g_lane_active[t] = false;
+                        g_barrier->arrive_and_drop();
+                        block_end.arrive_and_wait();          // everyone is out of the kernel: the static "LDS" may be reused
+                        if (t == 0) {                          // one lane re-arms the workgroup barrier for the next workgroup
+                            for (unsigned i = 0; i < n; ++i) g_lane_active[i] = true;
+                            current.reset(new std::barrier<>(n));
+                            g_barrier = current.get();
+                        }
+                        block_end.arrive_and_wait();
                     }
         });
     for (auto& th : threads) th.join();
     g_barrier = nullptr;
 }
 }  // namespace hip_emu
+// dynamic LDS (`extern __shared__ T name[];`): tests/test_kernel_sanitizers.py rewrites that one declaration form to
+// `T* name = (T*)hip_emu::dynamic_lds();` in a copy of the source; everything else is compiled as it lies.
+namespace hip_emu { inline unsigned long long g_dynamic_lds[64 * 1024 / 8]; inline void* dynamic_lds() { return g_dynamic_lds; } }
 inline void __syncthreads() { hip_emu::g_barrier->arrive_and_wait(); }
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hip_emu::launch(grid, block, [=]() { kernel(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hip_emu::launch(grid, block, [=]() { (kernel)(__VA_ARGS__); })
+
+// ---- wave intrinsics for one-wave workgroups with all lanes converged at the call
+namespace hip_emu {
+inline unsigned long long g_exchange[64];
+inline unsigned lane() { return threadIdx.x + threadIdx.y * blockDim.x + threadIdx.z * blockDim.x * blockDim.y; }
+inline void require_one_wave() { if (blockDim.x * blockDim.y * blockDim.z > 64) { fprintf(stderr, "hip_emu: wave intrinsic in a workgroup of more than 64 threads\n"); abort(); } }
+}  // namespace hip_emu
+inline unsigned __lane_id() { return hip_emu::lane(); }
+template <typename T> inline T __shfl_xor(T v, int lane_mask) {
+    static_assert(sizeof(T) <= 8, "hip_emu: __shfl_xor of a type wider than 8 bytes");
+    hip_emu::require_one_wave();
+    const unsigned l = hip_emu::lane(), n = blockDim.x * blockDim.y * blockDim.z;
+    memcpy(&hip_emu::g_exchange[l], &v, sizeof(T));
+    hip_emu::g_barrier->arrive_and_wait();
+    unsigned src = (l ^ unsigned(lane_mask)) < n ? (l ^ unsigned(lane_mask)) : l;
+    if (!hip_emu::g_lane_active[src]) src = l;         // reading an exited lane is undefined on hardware; keep it harmless here
+    T r;
+    memcpy(&r, &hip_emu::g_exchange[src], sizeof(T));
+    hip_emu::g_barrier->arrive_and_wait();
+    return r;
+}
+inline unsigned long long __ballot(int predicate) {
+    hip_emu::require_one_wave();
+    const unsigned l = hip_emu::lane(), n = blockDim.x * blockDim.y * blockDim.z;
+    hip_emu::g_exchange[l] = predicate ? 1ull : 0ull;
+    hip_emu::g_barrier->arrive_and_wait();
+    unsigned long long m = 0;
+    for (unsigned i = 0; i < n; ++i) if (hip_emu::g_lane_active[i]) m |= hip_emu::g_exchange[i] << i;
+    hip_emu::g_barrier->arrive_and_wait();
+    return m;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline float atomicAdd(float* p, float v) { float o, n; do { o = *p; n = o + v; } while (!__atomic_compare_exchange(p, &o, &n, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)); return o; }
+inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicAnd(unsigned* p, unsigned v) { return __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; while (o < v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
+inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; while (o > v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
+inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicCAS(unsigned* p, unsigned cmp, unsigned v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); return cmp; }
+inline float __fmul_rn(float a, float b) { return a * b; }     // the emulation builds with -ffp-contract=off: every product rounds once anyway
+inline float __fadd_rn(float a, float b) { return a + b; }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 
@@ -85,6 +160,26 @@ static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hi
 static inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t = nullptr) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipEventDefault = 0 };
+typedef struct hip_emu_event* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount = 256; char name[64] = "hip_emu"; };
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "hip_emu"; }
