@@ -1,0 +1,38 @@
+"""The `-m gpu` parity tests, unchanged, against the product source compiled for the CPU (tests/hip_emu) under AddressSanitizer + UBSan.
+No GPU.
+
+`KJ_HIP_EMU=1` makes tests/conftest.py's `gpu` fixture build tests/_build/emu_all/libkajiya_amd_emu.so (every .hip / .cpp of the product
+against the stand-in headers) and map torch's CUDA tensors to host memory; the tests then call the very same kj_* entry points. What a
+pass means: the kernel SOURCE and the host sequencing reproduce the oracle within the GPU tests' own tolerances, and no kernel reads or
+writes a byte outside its buffers, overflows a signed integer or shifts out of range — on the inputs of those tests. What it does not
+mean: anything about hipcc's code generation or the hardware (that is what the same tests do on an MI355X).
+
+This file runs a SMALL slice in a subprocess (about a minute); `scripts/run_gpu_suite_on_cpu.sh` runs everything that is affordable.
+Reading an exited lane in a wave exchange, divergent wave operations and float->int casts of NaN (defined on the GPU, relied upon where
+the reference's shaders do) are outside what the stand-in checks."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def run_emulated(pytest_args, timeout):
+    rt = subprocess.check_output([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    env = dict(os.environ, KJ_HIP_EMU="1", LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("KJ_AMD_LIB", None)
+    # -s: a sanitizer report goes to stderr and the process dies; with pytest's capture on it would vanish
+    return subprocess.run([sys.executable, "-m", "pytest", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider"] + pytest_args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs ROCm's clang++ as the host compiler")
+def test_a_slice_of_the_gpu_suite_passes_on_the_cpu_stand_in_under_sanitizers():
+    r = run_emulated(["tests/test_gpu_parity.py", "tests/test_gpu_ssgi.py", "tests/test_gpu_shadow_denoise.py", "tests/test_zz_gpu_post.py",
+                      "-k", "city20k-123-77 or light_gbuffer or (ray_queries and cornell) or (per_frame and cornell) or 160-90 or 320-180-320-180"], timeout=1500)
+    tail = r.stdout[-3000:] + r.stderr[-6000:]
+    assert r.returncode == 0, tail
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail

@@ -86,7 +86,8 @@ def test_post_rgba32f_input_matches_oracle(gpu, oracle, device):
     acc = (rng.uniform(0, 1, (H, W, 4)) ** 4 * 50).astype(np.float32)
     acc[30, 40, :3] = 3.0e5
     fc = _fc(W, H, 4, 1.0)
-    ref = oracle.OraclePost(lut).render(fc, acc, 0.25, 1.0).copy()
+    op = oracle.OraclePost(lut)                                     # keep it alive: render() returns a view of its memory
+    ref = op.render(fc, acc, 0.25, 1.0).copy()
     gp = gpu.GpuPost(device, lut)
     device.frame_begin(fc)
     got = gp.render(torch.from_numpy(acc).cuda().contiguous(), 0.25, 1.0)
