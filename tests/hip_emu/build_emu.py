@@ -11,14 +11,16 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "kajiya_amd", "csrc")
-OUT = os.path.join(ROOT, "tests", "_build", "emu_all")
+# KJ_EMU_DEFINES="-DKJ_BVH_FOLD_INVD ...": build an experiment variant of the product (same switches as scripts/build_variant.sh) into its own directory
+EXTRA = os.environ.get("KJ_EMU_DEFINES", "").split()
+OUT = os.path.join(ROOT, "tests", "_build", "emu_all" + ("_" + re.sub(r"[^A-Za-z0-9]+", "_", "".join(EXTRA)) if EXTRA else ""))
 SO = os.path.join(OUT, "libkajiya_amd_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 FLAGS = ["-g", "-O1", "-std=c++20", "-fPIC", "-pthread", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
          # float -> int casts of NaN / out-of-range values are DEFINED on the GPU (v_cvt_i32_f32 saturates, NaN -> 0) and the kernels rely on that
          # where the reference's shaders do (e.g. a NaN direction reaching a cube lookup from an empty reservoir, clamped right after): not an error
          "-fno-sanitize=float-cast-overflow",
-         "-I", os.path.join(ROOT, "tests", "hip_emu"), "-I", CSRC, "-D__HIP_PLATFORM_AMD__"]
+         "-I", os.path.join(ROOT, "tests", "hip_emu"), "-I", CSRC, "-D__HIP_PLATFORM_AMD__"] + EXTRA
 DYNAMIC_LDS = re.compile(r"extern __shared__ ([A-Za-z0-9_]+) ([A-Za-z0-9_]+)\[\];")
 
 
