@@ -25,7 +25,7 @@ def oracle():
 def gpu():
     """The product library on cuda:0. Fails (does not skip) if the HIP extension is missing."""
     import torch
-    if os.environ.get("KJ_HIP_EMU") == "1":
+    if os.environ.get("KJ_HIP_EMU") in ("1", "fast"):      # "1": threads + sanitizers; "fast": fibers, no sanitizers
         # explicit opt-in (tests/test_emulated_gpu_suite.py): the same tests drive the product source compiled against the CPU stand-in
         # for HIP, under sanitizers — see tests/hip_emu/. Never the default; a GPU box runs the branch below.
         sys.path.insert(0, os.path.join(TESTS, "hip_emu"))

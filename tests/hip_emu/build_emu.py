@@ -13,7 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CSRC = os.path.join(ROOT, "kajiya_amd", "csrc")
 # KJ_EMU_DEFINES="-DKJ_BVH_FOLD_INVD ...": build an experiment variant of the product (same switches as scripts/build_variant.sh) into its own directory
 EXTRA = os.environ.get("KJ_EMU_DEFINES", "").split()
-OUT = os.path.join(ROOT, "tests", "_build", "emu_all" + ("_" + re.sub(r"[^A-Za-z0-9]+", "_", "".join(EXTRA)) if EXTRA else ""))
+# KJ_HIP_EMU=fast: lanes as fibers, workgroups spread over the host cores, -O2, NO sanitizers (tests/hip_emu/hip/hip_runtime.h, fiber mode)
+FAST = os.environ.get("KJ_HIP_EMU") == "fast"
+OUT = os.path.join(ROOT, "tests", "_build", ("emu_fast" if FAST else "emu_all") + ("_" + re.sub(r"[^A-Za-z0-9]+", "_", "".join(EXTRA)) if EXTRA else ""))
 SO = os.path.join(OUT, "libkajiya_amd_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 FLAGS = ["-g", "-O1", "-std=c++20", "-fPIC", "-pthread", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
@@ -21,6 +23,8 @@ FLAGS = ["-g", "-O1", "-std=c++20", "-fPIC", "-pthread", "-ffp-contract=off", "-
          # where the reference's shaders do (e.g. a NaN direction reaching a cube lookup from an empty reservoir, clamped right after): not an error
          "-fno-sanitize=float-cast-overflow",
          "-I", os.path.join(ROOT, "tests", "hip_emu"), "-I", CSRC, "-D__HIP_PLATFORM_AMD__"] + EXTRA
+if FAST:
+    FLAGS = ["-g", "-O2", "-std=c++20", "-fPIC", "-pthread", "-ffp-contract=off", "-DHIP_EMU_FIBERS", "-I", os.path.join(ROOT, "tests", "hip_emu"), "-I", CSRC, "-D__HIP_PLATFORM_AMD__"] + EXTRA
 DYNAMIC_LDS = re.compile(r"extern __shared__ ([A-Za-z0-9_]+) ([A-Za-z0-9_]+)\[\];")
 
 
@@ -50,7 +54,8 @@ def build():
     srcs = [s for s in srcs if not os.path.basename(s).startswith("_")]
     with ThreadPoolExecutor(8) as ex:
         objs = list(ex.map(compile_one, srcs))
-    subprocess.check_call([CLANG, "-shared", "-shared-libsan", "-fsanitize=address,undefined", "-Wl,-Bsymbolic", "-pthread", "-o", SO] + objs)
+    link = ["-shared"] if FAST else ["-shared", "-shared-libsan", "-fsanitize=address,undefined"]
+    subprocess.check_call([CLANG] + link + ["-Wl,-Bsymbolic", "-pthread", "-o", SO] + objs)
     return SO
 
 

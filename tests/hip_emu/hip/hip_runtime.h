@@ -26,8 +26,6 @@
 #define __global__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static
-
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 struct float4 { float x, y, z, w; };
@@ -52,11 +50,16 @@ inline int max(int a, int b) { return a > b ? a : b; }
 inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 
+#ifndef HIP_EMU_FIBERS
+#define __shared__ static
 namespace hip_emu {
+// ---- threaded mode (default; what the sanitizer builds use): one host thread per lane.
 // g_barrier: the barrier behind __syncthreads() and the wave intrinsics of the workgroup that is running. A lane that has returned from
 // the kernel drops out of it (as an exited lane drops out of the exec mask), so the remaining lanes can still vote / exchange.
 inline std::barrier<>* g_barrier = nullptr;
 inline bool g_lane_active[1024];
+inline unsigned long long g_exchange[64];
+inline void barrier_wait() { g_barrier->arrive_and_wait(); }
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     const unsigned n = block.x * block.y * block.z;
     const size_t blocks = size_t(grid.x) * grid.y * grid.z;
@@ -92,15 +95,105 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     g_barrier = nullptr;
 }
 }  // namespace hip_emu
+#else
+#define __shared__ static thread_local
+#include <ucontext.h>
+#include <atomic>
+namespace hip_emu {
+// ---- fiber mode (-DHIP_EMU_FIBERS; fast, not for sanitizer builds): HIP_EMU_WORKERS host threads take workgroups off a shared counter; each
+// runs the lanes of its workgroup as ucontext fibers on that one thread. A lane runs until it finishes or reaches a barrier (__syncthreads or a
+// wave exchange); when every unfinished lane of the workgroup waits, all are released. `__shared__` is per host thread, so workgroups really
+// do run concurrently, and the atomics between them are real.
+enum { READY = 0, WAITING = 1, DONE = 2 };
+struct Fiber { ucontext_t ctx; char* stack = nullptr; int state = DONE; dim3 tid; };
+struct Worker {
+    ucontext_t scheduler;
+    std::vector<Fiber> fibers;
+    Fiber* running = nullptr;
+    const std::function<void()>* body = nullptr;
+    ~Worker() { for (auto& f : fibers) free(f.stack); }
+};
+inline thread_local Worker* g_worker = nullptr;
+inline thread_local bool g_lane_active[1024];
+inline thread_local unsigned long long g_exchange[64];
+inline void barrier_wait() {
+    Fiber* f = g_worker->running;
+    f->state = WAITING;
+    swapcontext(&f->ctx, &g_worker->scheduler);
+}
+inline void fiber_entry() {
+    Worker* w = g_worker;
+    (*w->body)();
+    w->running->state = DONE;
+    swapcontext(&w->running->ctx, &w->scheduler);
+}
+inline void run_block(Worker& w, unsigned n, dim3 block) {
+    static const size_t STACK = 512 * 1024;
+    if (w.fibers.size() < n) { w.fibers.resize(n); for (auto& f : w.fibers) if (!f.stack) f.stack = (char*)malloc(STACK); }
+    for (unsigned t = 0; t < n; ++t) {
+        Fiber& f = w.fibers[t];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = STACK;
+        f.ctx.uc_link = &w.scheduler;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        f.state = READY;
+        f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+        g_lane_active[t] = true;
+    }
+    unsigned alive = n;
+    while (alive) {
+        for (unsigned t = 0; t < n; ++t) {
+            Fiber& f = w.fibers[t];
+            if (f.state != READY) continue;
+            w.running = &f;
+            threadIdx = f.tid;
+            swapcontext(&w.scheduler, &f.ctx);
+            if (f.state == DONE) { --alive; g_lane_active[t] = false; }
+        }
+        for (unsigned t = 0; t < n; ++t) if (w.fibers[t].state == WAITING) w.fibers[t].state = READY;   // every unfinished lane has arrived
+    }
+}
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    const unsigned n = block.x * block.y * block.z;
+    const size_t blocks = size_t(grid.x) * grid.y * grid.z;
+    if (blocks == 0 || n == 0) return;
+    gridDim = grid;
+    blockDim = block;
+    static const unsigned workers = [] { const char* e = getenv("HIP_EMU_WORKERS"); unsigned v = e ? unsigned(atoi(e)) : std::thread::hardware_concurrency(); return v ? v : 1u; }();
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        static thread_local Worker w;
+        g_worker = &w;
+        w.body = &body;
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= blocks) break;
+            blockIdx = dim3(unsigned(b % grid.x), unsigned((b / grid.x) % grid.y), unsigned(b / (size_t(grid.x) * grid.y)));
+            run_block(w, n, block);
+        }
+    };
+    const unsigned nt = unsigned(std::min<size_t>(workers, blocks));
+    std::vector<std::thread> threads;
+    for (unsigned i = 1; i < nt; ++i) threads.emplace_back(work);
+    work();
+    for (auto& th : threads) th.join();
+}
+}  // namespace hip_emu
+#endif
+
 // dynamic LDS (`extern __shared__ T name[];`): tests/test_kernel_sanitizers.py rewrites that one declaration form to
 // `T* name = (T*)hip_emu::dynamic_lds();` in a copy of the source; everything else is compiled as it lies.
+#ifndef HIP_EMU_FIBERS
 namespace hip_emu { inline unsigned long long g_dynamic_lds[64 * 1024 / 8]; inline void* dynamic_lds() { return g_dynamic_lds; } }
-inline void __syncthreads() { hip_emu::g_barrier->arrive_and_wait(); }
+#else
+namespace hip_emu { inline thread_local unsigned long long g_dynamic_lds[64 * 1024 / 8]; inline void* dynamic_lds() { return g_dynamic_lds; } }
+#endif
+inline void __syncthreads() { hip_emu::barrier_wait(); }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hip_emu::launch(grid, block, [=]() { (kernel)(__VA_ARGS__); })
 
 // ---- wave intrinsics for one-wave workgroups with all lanes converged at the call
 namespace hip_emu {
-inline unsigned long long g_exchange[64];
 inline unsigned lane() { return threadIdx.x + threadIdx.y * blockDim.x + threadIdx.z * blockDim.x * blockDim.y; }
 inline void require_one_wave() { if (blockDim.x * blockDim.y * blockDim.z > 64) { fprintf(stderr, "hip_emu: wave intrinsic in a workgroup of more than 64 threads\n"); abort(); } }
 }  // namespace hip_emu
@@ -110,22 +203,22 @@ template <typename T> inline T __shfl_xor(T v, int lane_mask) {
     hip_emu::require_one_wave();
     const unsigned l = hip_emu::lane(), n = blockDim.x * blockDim.y * blockDim.z;
     memcpy(&hip_emu::g_exchange[l], &v, sizeof(T));
-    hip_emu::g_barrier->arrive_and_wait();
+    hip_emu::barrier_wait();
     unsigned src = (l ^ unsigned(lane_mask)) < n ? (l ^ unsigned(lane_mask)) : l;
     if (!hip_emu::g_lane_active[src]) src = l;         // reading an exited lane is undefined on hardware; keep it harmless here
     T r;
     memcpy(&r, &hip_emu::g_exchange[src], sizeof(T));
-    hip_emu::g_barrier->arrive_and_wait();
+    hip_emu::barrier_wait();
     return r;
 }
 inline unsigned long long __ballot(int predicate) {
     hip_emu::require_one_wave();
     const unsigned l = hip_emu::lane(), n = blockDim.x * blockDim.y * blockDim.z;
     hip_emu::g_exchange[l] = predicate ? 1ull : 0ull;
-    hip_emu::g_barrier->arrive_and_wait();
+    hip_emu::barrier_wait();
     unsigned long long m = 0;
     for (unsigned i = 0; i < n; ++i) if (hip_emu::g_lane_active[i]) m |= hip_emu::g_exchange[i] << i;
-    hip_emu::g_barrier->arrive_and_wait();
+    hip_emu::barrier_wait();
     return m;
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
