@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The whole frame of world_render_passes.rs incl. its tail: ... light_gbuffer -> TAA -> motion_blur -> PostProcessRenderer, with the
 exposure loop of world_renderer.rs:919-960 (dynamic exposure on). Writes the library's own display-referred output as an sRGB PNG and
-prints the per-frame time of the tail. NOT YET RUN ON HARDWARE (written after round 1's GPU budget was spent): first thing to run next.
+prints the per-frame time of the tail. NOT YET RUN ON HARDWARE (written after round 1's GPU budget was spent): first thing to run next. It has run end to end against the product
+source on the CPU stand-in for HIP (tests/hip_emu; profiles/r01_frame_cornell_post_480x270_cpu_stand_in.png).
 usage: render_frame_post.py [city|cornell|glossy] [out.png] [W H]"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
