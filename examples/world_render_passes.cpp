@@ -25,7 +25,7 @@ static void write_device(const std::string& path, const void* dev, size_t bytes)
 }
 
 int main(int argc, char** argv) {
-    if (argc < 7) { fprintf(stderr, "usage: %s <blue_noise.bin> <scene_dir> <W> <H> <frames> <out_prefix>\n", argv[0]); return 2; }
+    if (argc < 7) { fprintf(stderr, "usage: %s <blue_noise.bin> <scene_dir> <W> <H> <frames> <out_prefix> [post]\n", argv[0]); return 2; }
     try {
         const std::string dir = argv[2], out = argv[6];
         const uint32_t W = uint32_t(atoi(argv[3])), H = uint32_t(atoi(argv[4]));
@@ -76,6 +76,9 @@ int main(int argc, char** argv) {
         const uint32_t* t32 = (const uint32_t*)tb.data();
         KjRtrTables tables{t32, t32 + n_tile, t32 + 2 * n_tile, (const int32_t*)(t32 + 2 * n_tile + n_sobol)};
         WorldRenderer world(device, scene, W, H, tables);
+        const bool with_post = argc > 7 && std::string(argv[7]) == "post";     // the frame's tail: motion blur + PostProcessRenderer + the exposure loop
+        const std::vector<uint16_t> no_hue_shift(128, 0);                        // Bezold-Brucke LUT: caller data; zeros = no shift (kajiya_amd/post_tables.py)
+        if (with_post) world.enable_post(no_hue_shift.data());
 
         hipEvent_t e0, e1;
         check_hip(hipEventCreate(&e0), "hipEventCreate"); check_hip(hipEventCreate(&e1), "hipEventCreate");
@@ -103,6 +106,10 @@ int main(int argc, char** argv) {
         write_device(out + "_rtr.bin", last.rtr, size_t(W) * H * 4);
         write_device(out + "_taa.bin", last.anti_aliased.this_frame_out, size_t(W) * H * 8);
         write_device(out + "_depth.bin", world.gbuffer_depth.depth.p, size_t(W) * H * 4);
+        if (with_post) {
+            write_device(out + "_final_post_input.bin", last.final_post_input, size_t(W) * H * 8);
+            write_device(out + "_post.bin", last.post_processed, size_t(W) * H * 4);
+        }
         printf("{\"host\": \"c++ (include/kajiya_amd.hpp)\", \"extent\": [%u, %u], \"frames\": %d, \"gpu_ms_per_frame\": %.4f, \"wall_ms_per_frame_incl_sync\": %.4f, \"triangle_lights\": %u}\n",
                W, H, frames, timed ? gpu_ms / float(timed) : 0.0f, wall_ms / double(frames), scene.triangle_light_count());
         return 0;

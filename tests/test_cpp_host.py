@@ -73,6 +73,63 @@ def test_cpp_exposure_state_matches_python_mirror(enabled, speed_log2, ev_shift,
         assert np.all(got[:, 0] == 1.0) and np.all(got[:, 3] == 1.0)
 
 
+def _write_baked_scene(tmp_path, sd, camera="camera 0 1 0 9 3 0.01"):
+    """The scene directory examples/world_render_passes reads: baked `.mesh` / `.image` files + scene.txt."""
+    import baked_writer as BW
+    lines = []
+    for mi, m in enumerate(sd.meshes):
+        mesh_bytes, images = BW.bake_triangle_mesh(m)
+        (tmp_path / f"m{mi}.mesh").write_bytes(mesh_bytes)
+        for ident, blob in images.items():
+            (tmp_path / f"{ident:8x}.image").write_bytes(blob)
+        lines.append(f"mesh m{mi}.mesh")
+    for mi, xf in sd.instances:
+        lines.append("instance %d %s" % (mi, " ".join(repr(float(v)) for v in np.asarray(xf, np.float32).reshape(-1))))
+    lines.append(camera)
+    (tmp_path / "scene.txt").write_text("\n".join(lines) + "\n")
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs ROCm's clang++ as the host compiler")
+def test_cpp_host_whole_frame_with_post_on_the_cpu_stand_in(oracle, tmp_path):
+    """The compiled C++ host (examples/world_render_passes.cpp over include/kajiya_amd.hpp) built against the CPU stand-in for HIP and the
+    product source compiled for it (tests/hip_emu, fiber mode): WorldRenderer::prepare_render_graph_standard with enable_post() — G-buffer
+    ... TAA -> MotionBlurRenderer -> PostProcessRenderer, update_pre_exposure each frame — runs end to end without a GPU. The display
+    image it dumps must equal the oracle's post of the motion-blurred frame it dumps (same frame index for the dither, exposure 1)."""
+    import subprocess as sp
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hip_emu"))
+    from kajiya_amd import rtr_tables, scenes as S, post_tables
+    env = dict(os.environ, KJ_HIP_EMU="fast")
+    so = sp.check_output([sys.executable, os.path.join(ROOT, "tests", "hip_emu", "build_emu.py")], env=env, text=True).strip().splitlines()[-1]
+    exe = os.path.join(os.path.dirname(so), "world_render_passes_emu")
+    src = os.path.join(EX, "world_render_passes.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(p) for p in (src, so, os.path.join(ROOT, "include", "kajiya_amd.hpp"))):
+        sp.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-O1", "-std=c++20", "-pthread", "-DHIP_EMU_FIBERS", "-I", os.path.join(ROOT, "tests", "hip_emu"), "-x", "c++", src, "-o", exe,
+                       "-L", os.path.dirname(so), "-lkajiya_amd_emu", "-Wl,-rpath," + os.path.dirname(so)])
+    W, H, N = 96, 64, 6
+    _write_baked_scene(tmp_path, S.cornell_box(), camera="camera 0 1 0 6.5 0 0.02")
+    t, (ranking, scrambling, sobol, offsets) = rtr_tables.standin_tables()
+    with open(tmp_path / "rtr_tables.bin", "wb") as f:
+        for a in (ranking, scrambling, sobol, offsets):
+            f.write(np.ascontiguousarray(a).tobytes())
+    bn = os.path.join(ROOT, "tests", "golden", "bluenoise_256_rgba8.bin")
+    out = sp.check_output([exe, bn, str(tmp_path), str(W), str(H), str(N), str(tmp_path / "cpp"), "post"], timeout=600, text=True)
+    assert '"frames": %d' % N in out
+    taa = np.fromfile(tmp_path / "cpp_taa.bin", np.float16).reshape(H, W, 4)
+    blurred = np.fromfile(tmp_path / "cpp_final_post_input.bin", np.float16).reshape(H, W, 4)
+    post = np.fromfile(tmp_path / "cpp_post.bin", np.uint32).reshape(H, W)
+    assert np.isfinite(blurred.astype(np.float32)).all() and float(taa[..., :3].astype(np.float32).mean()) > 0.01
+    # slow orbit: motion blur leaves the box alone (tiles take the sky's velocity, the walls' own spread is below a pixel) or changes it a little
+    d = np.abs(blurred[..., :3].astype(np.float32) - taa[..., :3].astype(np.float32))
+    assert d.mean() < 0.2 * taa[..., :3].astype(np.float32).mean()
+    fs = frame.FrameState((W, H))
+    fs.frame_idx = N - 1
+    fc = fs.prepare_frame_constants(frame.orbit_camera(N - 1, (W, H)))
+    op = oracle.OraclePost(post_tables.zero_bezold_brucke_lut())
+    ref = op.render(fc, blurred, 1.0, 1.0)
+    assert np.array_equal(post, ref)
+
+
 @pytest.mark.gpu
 def test_cpp_world_render_passes_matches_python_driver(gpu, device, tmp_path):
     """Bake the glossy test scene to kajiya's `.mesh` / `.image` format, render 8 frames with the compiled host
@@ -86,17 +143,7 @@ def test_cpp_world_render_passes_matches_python_driver(gpu, device, tmp_path):
     _build_examples()
     W, H, N = 256, 160, 8
     sd = S.glossy_test_scene()
-    lines = []
-    for mi, m in enumerate(sd.meshes):
-        mesh_bytes, images = BW.bake_triangle_mesh(m)
-        (tmp_path / f"m{mi}.mesh").write_bytes(mesh_bytes)
-        for ident, blob in images.items():
-            (tmp_path / f"{ident:8x}.image").write_bytes(blob)
-        lines.append(f"mesh m{mi}.mesh")
-    for mi, xf in sd.instances:
-        lines.append("instance %d %s" % (mi, " ".join(repr(float(v)) for v in np.asarray(xf, np.float32).reshape(-1))))
-    lines.append("camera 0 1 0 9 3 0.01")
-    (tmp_path / "scene.txt").write_text("\n".join(lines) + "\n")
+    _write_baked_scene(tmp_path, sd)
     t, (ranking, scrambling, sobol, offsets) = rtr_tables.standin_tables()
     (tmp_path / "rtr_tables.bin").write_bytes(ranking.tobytes() + scrambling.tobytes() + sobol.tobytes() + offsets.tobytes())
     bn = os.path.join(ROOT, "tests", "golden", "bluenoise_256_rgba8.bin")
