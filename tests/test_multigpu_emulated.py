@@ -1,0 +1,97 @@
+"""The N>1 path end to end without a GPU: `world` PROCESSES, one rank each, torch.distributed over gloo on 127.0.0.1, every rank running the
+product's kernels on the CPU stand-in for HIP (tests/hip_emu, fiber mode) for its strip of the screen and exchanging halos through
+kajiya_amd.multigpu.DistComm — the same orchestrator code `bench.py --gpus N` runs over RCCL. After every frame each rank's gathered GI
+and TAA images must equal the unsplit frame bit for bit (the irradiance cache unbound, as in tests/test_gpu_multigpu.py).
+
+What the other multi-GPU tests leave open and this one closes: tests/test_multigpu_gloo.py moves synthetic bytes through DistComm,
+tests/test_gpu_multigpu.py runs the real kernels but with all ranks in one process (LocalComm). No 8-GPU node is available to the
+build, so this is the only place where separate processes, a real process group and the real kernels meet."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, W, H, frames, packed, q):
+    try:
+        os.environ["KJ_HIP_EMU"] = "fast"
+        os.environ.setdefault("HIP_EMU_WORKERS", "4")
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "hip_emu"))
+        import build_emu, cpu_as_cuda
+        cpu_as_cuda.install(build_emu.build())
+        import torch
+        import torch.distributed as dist
+        from kajiya_amd import lib, multigpu
+        import test_gpu_parity as T
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = lib.Device(0)
+        scene = lib.Scene(dev, T._scenes()["city20k"])
+        ref = lib.GpuPipeline(dev, scene, W, H)
+        pipe = lib.GpuPipeline(dev, scene, W, H)
+        split = multigpu.SplitRtdgi(multigpu.DistComm(dist, rank, world, packed=packed), {rank: pipe}, W, H, motion_halo=8)
+        worst = 0
+        for fi, fc in enumerate(T._frame_constants(W, H, frames, "city")):
+            ref.frame(fc)
+            pipe.render_inputs(fc)
+            pipe.reprojection()
+            split.gi_frame()
+            split.taa_frame()
+            ref.taa_frame()
+            split.gather_output("spatial_filtered_tex")
+            split.gather_output(f"TAA/taa:{fi % 2}")
+            a, b = ref.surface("spatial_filtered_tex", torch.int16, (H, W, 4)), pipe.surface("spatial_filtered_tex", torch.int16, (H, W, 4))
+            ta, tb = ref.taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4)), pipe.taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4))
+            worst = max(worst, int((a != b).any(dim=-1).sum()), int((ta != tb).any(dim=-1).sum()))
+        own = split.strips[rank]
+        q.put((rank, worst, pipe.ray_counts(), ref.ray_counts(), own))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:      # surface the failure in the parent instead of a hang
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None, None))
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs ROCm's clang++ as the host compiler")
+@pytest.mark.parametrize("world,packed", [(2, False), (3, True)])
+def test_strip_split_over_gloo_processes_with_the_real_kernels(world, packed):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hip_emu"))
+    env_before = os.environ.get("KJ_HIP_EMU")
+    os.environ["KJ_HIP_EMU"] = "fast"
+    try:
+        import build_emu
+        build_emu.build()                      # once, before the ranks race for it
+    finally:
+        if env_before is None:
+            os.environ.pop("KJ_HIP_EMU", None)
+        else:
+            os.environ["KJ_HIP_EMU"] = env_before
+    W, H, frames = 128, 96 if world == 2 else 144, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, frames, packed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert not [r for r in results if r[1] == "error"], "\n".join(str(r[2]) for r in results if r[1] == "error")
+    results.sort()
+    assert [r[1] for r in results] == [0] * world, results                     # every rank holds the unsplit frame, bit for bit
+    total = results[0][3]
+    assert (sum(r[2][0] for r in results), sum(r[2][1] for r in results)) == tuple(total), results    # the strips' rays add up to the unsplit frame's
+    assert results[0][4][0] == 0 and results[-1][4][1] == H
