@@ -62,5 +62,10 @@ def install(lib_path):
     torch.cuda.Stream = lambda *a, **k: _Stream()
     torch.cuda.Event = _Event
     torch.cuda.stream = lambda s: contextlib.nullcontext()
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.device_count = lambda: 8
+    torch.cuda.current_device = lambda: 0
+    torch.cuda.get_device_name = lambda *a, **k: "hip_emu (CPU stand-in)"
+    torch.cuda.empty_cache = lambda: None
     _mode = _CpuAsCuda()
     _mode.__enter__()
