@@ -182,8 +182,8 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 }  // namespace hip_emu
 #endif
 
-// dynamic LDS (`extern __shared__ T name[];`): tests/test_kernel_sanitizers.py rewrites that one declaration form to
-// `T* name = (T*)hip_emu::dynamic_lds();` in a copy of the source; everything else is compiled as it lies.
+// dynamic LDS (`extern __shared__ T name[];`): tests/hip_emu/build_emu.py rewrites that one declaration form to
+// `T* name = (T*)hip_emu::dynamic_lds();` in a scratch copy of the source; everything else is compiled as it lies.
 #ifndef HIP_EMU_FIBERS
 namespace hip_emu { inline unsigned long long g_dynamic_lds[64 * 1024 / 8]; inline void* dynamic_lds() { return g_dynamic_lds; } }
 #else
