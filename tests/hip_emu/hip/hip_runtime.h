@@ -1,12 +1,16 @@
-// TEST INFRASTRUCTURE (never shipped, never linked into libkajiya_amd.so): a CPU stand-in for the small slice of the HIP language and
-// runtime that kajiya_amd/csrc/post.hip uses. tests/post_emu.cpp includes the product's kernel SOURCE with this directory first on the
-// include path, so `#include <hip/hip_runtime.h>` lands here and the kernels run on the build machine: every workgroup is executed by
-// blockDim host threads with a real barrier behind __syncthreads(), `__shared__` becomes one static array (workgroups run one after the
-// other), device memory is host memory. It checks the kernels' arithmetic, indexing and host sequencing against the oracle where no GPU
-// is available; it says nothing about code generation, and the -m gpu parity tests remain the statement about the real thing.
-// Wave intrinsics exist for workgroups of ONE wave (<= 64 threads) whose lanes all reach the call, which is how the kernels here use them:
-// __shfl_xor, __ballot, __lane_id (an exchange array + the same barrier). Not emulated: divergent wave operations, textures, dynamic
-// shared memory, streams that overlap.
+// TEST INFRASTRUCTURE (never shipped, never linked into libkajiya_amd.so): a CPU stand-in for the part of the HIP language and runtime that
+// kajiya_amd/csrc uses. With this directory first on the include path `#include <hip/hip_runtime.h>` lands here and the product's kernel
+// SOURCE compiles as host C++ (tests/hip_emu/build_emu.py: the whole library; tests/post_emu.cpp: post.hip alone, with g++):
+//   * threaded mode (default): every workgroup is executed by blockDim host threads with a real barrier behind __syncthreads(),
+//     `__shared__` is one static array (workgroups run one after the other) — slow, but AddressSanitizer / UBSan understand it;
+//   * fiber mode (-DHIP_EMU_FIBERS): the lanes of a workgroup are ucontext fibers on one host thread, workgroups are spread over the cores,
+//     `__shared__` is per host thread — ~30x faster, no sanitizers.
+// Device memory is host memory, streams and events are no-ops, atomics are the host's. Wave intrinsics (__shfl_xor, __ballot, __lane_id)
+// work for workgroups of ONE wave (<= 64 threads) whose unfinished lanes all reach the call, which is how the kernels here use them; a lane
+// that has returned drops out of the exchange as it drops out of the exec mask. Dynamic LDS is handled by a source rewrite (see below).
+// It checks the kernels' arithmetic, indexing, LDS staging, wave votes and host sequencing against the oracle where no GPU is available; it
+// says nothing about hipcc's code generation or the hardware, and the -m gpu parity tests on an MI355X remain the statement about those.
+// Not emulated: divergent wave operations, textures, streams that actually overlap.
 #pragma once
 #include <algorithm>
 #include <barrier>
