@@ -205,10 +205,8 @@ def main():
                 q.geometric_normal, q.gbuffer, q.depth = gn, gb, d
                 q.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
             irc_frame[0] = i + 1
-            if use_ssgi:
-                for q in all_pipes:
-                    q.ssgi_frame()
-            (gp if single else split).frame_pipelined(fcs[i + 1])
+            # the SSAO guide reads frame i's constants, which the SIDE stream wrote: frame_pipelined orders it behind that write
+            (gp if single else split).frame_pipelined(fcs[i + 1], run_ssgi=use_ssgi)
         torch.cuda.synchronize()
         irc_frame[0] = 1
         (gp if single else split).pipeline_begin(fcs[1])
@@ -354,7 +352,7 @@ def main():
     out = {
         "metric": "gi_mrays_per_s", "value": round(total_rays_all / elapsed / 1e6, 3), "unit": "Mrays/s",
         "gi_frame_ms": round(ms_per_step, 4), "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{scene_label}, {W}x{H}, rtdgi: reproject+validate+trace+validity+temporal ReSTIR+2x spatial ReSTIR+"
                                "resolve+temporal+spatial denoise, irradiance cache (scroll/age/compact, accessibility+validate+trace rays, SH sum), TAA (7 passes) on the GI output"
                                + (", SSAO guide (ssgi, 4 passes)" if use_ssgi else ", constant SSAO guide"),

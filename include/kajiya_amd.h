@@ -199,7 +199,7 @@ typedef struct KjBakedMeshView {
     const uint32_t* indices;
     const uint32_t* material_ids;
     const KjMeshMaterial* materials;
-    const uint64_t* map_identities;
+    const uint64_t* map_identities; /* ONLY 4-BYTE ALIGNED inside the packed file (FlatVec has no padding): read entries with memcpy, never dereference */
     uint32_t vertex_count, index_count, material_count, map_count;
 } KjBakedMeshView;
 typedef struct KjBakedImageView {

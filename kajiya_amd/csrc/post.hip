@@ -357,8 +357,10 @@ KjStatus kj_post_render(KjPost* t, const void* input, uint32_t input_format, uin
 // PostProcessRenderer::read_back_histogram (post.rs:188-235), f64 as there
 KjStatus kj_luminance_histogram_mean_log2(const uint32_t* histogram, float clipping_low, float clipping_high, float* out_image_log2_lum) {
     KJ_REQUIRE(histogram && out_image_log2_lum, "null argument");
-    const double outlier_frac_lo = std::min(double(clipping_low), 1.0);
-    const double outlier_frac_hi = std::min(double(clipping_high), 1.0 - outlier_frac_lo);
+    // Rust's `as u32` saturates and maps NaN to 0; a C++ cast of a negative or NaN double is undefined: clamp first
+    auto frac01 = [](double v) { return v >= 0.0 ? std::min(v, 1.0) : 0.0; };   // NaN -> 0
+    const double outlier_frac_lo = frac01(double(clipping_low));
+    const double outlier_frac_hi = std::min(frac01(double(clipping_high)), 1.0 - outlier_frac_lo);
     uint32_t total = 0;
     for (int i = 0; i < 256; ++i) total += histogram[i];
     const uint32_t reject_lo = uint32_t(double(total) * outlier_frac_lo);

@@ -913,13 +913,17 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     const int W = r->W, H = r->H, hw = r->hw, hh = r->hh;
     const FrameConstants* fc = r->dev->fc_dev;
     const uint32_t mask = p->pass_mask;
-    if (mask & KJ_RTDGI_PASS_KEEP_TEMPORALS) for (bool& f : r->flip) f = !f;
     // rows of this call (screen-tile split): full-res [fr0, fr1), half-res [hr0, hr1); 0,0 = whole image
     int fr0 = 0, fr1 = H;
     if (p->row_end > p->row_begin) {
         KJ_REQUIRE(p->row_begin % 16 == 0 && (p->row_end % 16 == 0 || int(p->row_end) == H) && int(p->row_end) <= H, "row range must be 16-aligned (8x8 half-res tiles)");
         fr0 = int(p->row_begin); fr1 = int(p->row_end);
     }
+    if (p->ircache) KJ_REQUIRE(!p->ircache->pending_irradiance_sum, "ircache sum-up pending (ircache.rs:67 assert)");
+    KJ_REQUIRE(size_t(scene_view(*p->scene).bvh.stack_entries) * 64 * 4 <= 64 * 1024, "BVH too deep for the LDS traversal stack");
+    // every argument check is above: from here on the ping-pong state may change (an early return after this point would leave
+    // output and history swapped for the next call)
+    if (mask & KJ_RTDGI_PASS_KEEP_TEMPORALS) for (bool& f : r->flip) f = !f;
     const int hr0 = fr0 / 2, hr1 = fr1 == H ? hh : fr1 / 2;
     const dim3 gh((hw + 7) / 8, (hr1 - hr0 + 7) / 8), gf((W + 7) / 8, (fr1 - fr0 + 7) / 8), blk(64);
     const size_t HB = size_t(hw) * hh, FB = size_t(W) * H;
@@ -966,10 +970,9 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     tc.brdf_fg_lut = (const uint2*)r->dev->brdf_fg_lut.p;
     tc.sun_color = (const float4*)r->dev->sun_color.p + r->dev->fc_slot;
     tc.has_ircache = p->ircache != nullptr;
-    if (p->ircache) { KJ_REQUIRE(!p->ircache->pending_irradiance_sum, "ircache sum-up pending (ircache.rs:67 assert)"); tc.irc = p->ircache->view(); } else { memset(&tc.irc, 0, sizeof(tc.irc)); }
+    if (p->ircache) tc.irc = p->ircache->view(); else memset(&tc.irc, 0, sizeof(tc.irc));
     tc.ray_counters = (unsigned long long*)r->ray_counters.p;
     const size_t trace_lds = size_t(tc.sc.bvh.stack_entries) * 64 * 4;
-    KJ_REQUIRE(trace_lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");
 
     if (mask & KJ_RTDGI_PASS_EXTRACT_HALF) {
         SCOPE_BEGIN(1);

@@ -456,13 +456,13 @@ static KjStatus taa_render_impl(KjTaa* t, const void* input_tex, uint32_t input_
     if (IW != t->IW || IH != t->IH || OW != t->OW || OH != t->OH) { t->surf.clear(); t->IW = IW; t->IH = IH; t->OW = OW; t->OH = OH; }
     const FrameConstants* fc = t->dev->fc_dev;
     const size_t OB = size_t(OW) * OH, IB = size_t(IW) * IH;
-    if (mask & 0x80000000u) for (bool& f : t->flip) f = !f;  // KEEP_TEMPORALS: same ping-pong assignment as the previous call
     int or0 = 0, or1 = OH;
     if (row_end > row_begin) {
         KJ_REQUIRE(IW == OW && IH == OH, "row ranges need input extent == output extent");
         KJ_REQUIRE(row_begin % 8 == 0 && (row_end % 8 == 0 || int(row_end) == OH) && int(row_end) <= OH, "row range must be 8-aligned");
         or0 = int(row_begin); or1 = int(row_end);
     }
+    if (mask & 0x80000000u) for (bool& f : t->flip) f = !f;  // KEEP_TEMPORALS: same ping-pong assignment as the previous call (after every argument check)
     const int ir0 = or0, ir1 = or1;
     void *temporal_out, *history; t->pingpong("taa", 0, OB * 8, s, temporal_out, history);
     void *vel_out, *vel_hist;     t->pingpong("taa.velocity", 1, OB * 4, s, vel_out, vel_hist);

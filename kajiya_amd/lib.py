@@ -333,6 +333,7 @@ class GpuPipeline:
         assert self.ircache, "pipelining overlaps the irradiance cache; nothing to do without it"
         self._s1 = torch.cuda.Stream()
         self._ev_irc = [torch.cuda.Event(), torch.cuda.Event()]
+        self._ev_fc = [torch.cuda.Event(), torch.cuda.Event()]      # frame constants of frame i are in place (k_frame_begin ran on the side stream)
         self._ev_trace = [torch.cuda.Event(), torch.cuda.Event()]
         self._pipe_i = 0
         self._enqueue_ircache(fc, None)
@@ -343,6 +344,7 @@ class GpuPipeline:
         with torch.cuda.stream(self._s1):
             self._s1.wait_stream(s0) if wait_event is None else self._s1.wait_event(wait_event)
             self.dev.frame_begin(fc)
+            self._ev_fc[self._pipe_i & 1].record(self._s1)
             s = _stream_ptr()
             check(self.L.kj_ircache_prepare(self.ircache, s))
             check(self.L.kj_ircache_trace_irradiance(self.ircache, self.scene.h, self.sky16.data_ptr(), 16, s))
@@ -350,9 +352,11 @@ class GpuPipeline:
                 self.on_ircache_traced()          # e.g. the bench logs the cache's ray counters, stream-ordered
             self._ev_irc[self._pipe_i & 1].record(self._s1)
 
-    def frame_pipelined(self, next_fc):
+    def frame_pipelined(self, next_fc, run_ssgi=False):
         """One GI + TAA frame whose ircache work was issued earlier; then issue the next frame's (if any). The caller binds this
         frame's G-buffer inputs before the call. `next_fc` = constants of the following frame or None for the last one.
+        `run_ssgi`: compute the SSAO guide first (SsgiRenderer::render) -- it reads this frame's constants, which the SIDE stream
+        wrote, so it is ordered behind that write here rather than issued by the caller.
 
         Three streams: the main one carries ssgi/rtdgi up to the temporal filter; the ircache stream runs the next frame's cache
         maintenance + rays from the moment this frame's trace pass is recorded; the third stream runs this frame's spatial
@@ -366,6 +370,9 @@ class GpuPipeline:
             self._s2 = torch.cuda.Stream()
             self._ev_gi = [torch.cuda.Event(), torch.cuda.Event()]
             self._ev_taa = [torch.cuda.Event(), torch.cuda.Event()]
+        if run_ssgi:
+            s0.wait_event(self._ev_fc[i])
+            self.ssgi_frame()
         s0.wait_event(self._ev_irc[i])
         s = _stream_ptr()
         P = KJ_RTDGI_PASS

@@ -276,7 +276,8 @@ class SplitRtdgi:
     # -- frame pipelining (see GpuPipeline.frame_pipelined): each rank's replica of the ircache is updated on a side stream
     def pipeline_begin(self, fc):
         import torch
-        self._side = {"stream": torch.cuda.Stream(), "irc": [torch.cuda.Event(), torch.cuda.Event()], "trace": [torch.cuda.Event(), torch.cuda.Event()]}
+        self._side = {"stream": torch.cuda.Stream(), "irc": [torch.cuda.Event(), torch.cuda.Event()], "trace": [torch.cuda.Event(), torch.cuda.Event()],
+                      "fc": [torch.cuda.Event(), torch.cuda.Event()]}
         self._enqueue_ircache(fc, None)
 
     def _enqueue_ircache(self, fc, wait_event):
@@ -290,6 +291,7 @@ class SplitRtdgi:
                 gp = self.pipes[r]
                 if first:
                     gp.dev.frame_begin(fc)     # one device (and one constants ring) per process
+                    sd["fc"][self.frame & 1].record(sd["stream"])
                     first = False
                 if gp.ircache:
                     self._ircache_head(gp, klib._stream_ptr())
@@ -297,10 +299,15 @@ class SplitRtdgi:
                 self.on_ircache_traced()
             sd["irc"][self.frame & 1].record(sd["stream"])
 
-    def frame_pipelined(self, next_fc):
-        """gi_frame + taa_frame with the ircache work issued ahead on the side stream; then issue the next frame's."""
+    def frame_pipelined(self, next_fc, run_ssgi=False):
+        """gi_frame + taa_frame with the ircache work issued ahead on the side stream; then issue the next frame's.
+        `run_ssgi`: every rank's SSAO guide first, ordered behind the side stream's write of this frame's constants."""
         import torch
         i = self.frame & 1
+        if run_ssgi:
+            torch.cuda.current_stream().wait_event(self._side["fc"][i])
+            for q in self.pipes.values():
+                q.ssgi_frame()
         torch.cuda.current_stream().wait_event(self._side["irc"][i])
         self.gi_frame(ircache_done=True, trace_event=self._side["trace"][i])
         self.taa_frame()

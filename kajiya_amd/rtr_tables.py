@@ -2,10 +2,15 @@
 
 The reference gets RANKING_TILE / SCRAMBLING_TILE / SOBOL from the third-party crate `blue-noise-sampler 0.1.0` (spp64; the
 tables of Heitz et al., "A Low-Discrepancy Sampler that Distributes Monte Carlo Errors as a Blue Noise in Screen Space") and
-SPATIAL_RESOLVE_OFFSETS from its own source. Neither is shipped here: a kajiya integration passes its own statics. For the
-tests, the bench and the scripts this module generates STAND-INS with the same shapes and value ranges — a real (unscrambled)
-Sobol sequence, seeded white-noise ranking / scrambling tiles (no blue-noise optimisation) and distance-sorted, quad-disjoint
-offset rings — so parity against the oracle is exact on identical tables while image quality is only representative."""
+SPATIAL_RESOLVE_OFFSETS from its own source (rtr.rs:402-915). A kajiya integration passes its own statics. Here:
+
+* SPATIAL_RESOLVE_OFFSETS is the reference's table, read out of rtr.rs by scripts/extract_rtr_offsets.py into
+  kajiya_amd/data/spatial_resolve_offsets_i32x4.bin and handed to kj_rtr_create as caller data (`spatial_resolve_offsets()`);
+* the sampler crate is absent from the checkout (a Cargo.lock dependency), so RANKING_TILE / SCRAMBLING_TILE / SOBOL are
+  STAND-INS with the same shapes and value ranges — a real (unscrambled) Sobol sequence and seeded white-noise ranking /
+  scrambling tiles (no blue-noise optimisation): parity against the oracle is exact on identical tables, image noise is only
+  representative."""
+import os
 
 import numpy as np
 
@@ -26,9 +31,17 @@ def ranking_and_scrambling(seed=2024):
     return ranking, scrambling
 
 
-def spatial_resolve_offsets(seed=7):
-    """(16 * 4 * 8, 4) int32: for each of 8 filter sizes, 4 quad-pixel variants x 16 taps; tap 0 = (0, 0), the others unique
-    integer offsets inside a disc that grows with the filter index, disjoint between the 4 variants, sorted by distance."""
+def spatial_resolve_offsets():
+    """(16 * 4 * 8, 4) int32, the reference's SPATIAL_RESOLVE_OFFSETS: for each of 8 filter sizes, 4 quad-pixel variants x 16 taps."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "spatial_resolve_offsets_i32x4.bin")
+    t = np.fromfile(path, dtype=np.int32).reshape(-1, 4)
+    assert t.shape == (16 * 4 * 8, 4)
+    return np.ascontiguousarray(t)
+
+
+def synthetic_spatial_resolve_offsets(seed=7):
+    """A table of the same shape made up from scratch (distance-sorted, quad-disjoint rings): only used by tests that want a
+    second, different table to show the kernels take it as data."""
     rng = np.random.RandomState(seed)
     out = np.zeros((8, 4, 16, 4), np.int32)
     for f in range(8):

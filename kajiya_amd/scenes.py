@@ -10,7 +10,8 @@ import os
 import numpy as np
 from .abi import KjMeshDesc, KjMeshMaterial, KjMaterialMap
 
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")   # reference-held DATA assets converted by scripts/make_golden_assets.py
+GOLDEN_DIR = DATA_DIR
 
 
 def pack_unit_direction_11_10_11(n):
@@ -157,13 +158,25 @@ class SceneDesc:
 
 def cornell_box():
     """assets/scenes/cornell_box.ron: cornell_box/scene.gltf scaled x2 at (0,-1,0).
-    Geometry from tests/golden/cornell_box.npz (scripts/make_golden_assets.py)."""
-    z = np.load(os.path.join(GOLDEN_DIR, "cornell_box.npz"))
+    Geometry from kajiya_amd/data/cornell_box.npz (scripts/make_golden_assets.py)."""
+    s = SceneDesc()
+    s.add_instance(s.add_mesh(_baked_gltf("cornell_box.npz")), translation((0.0, -1.0, 0.0)))
+    return s
+
+
+def _baked_gltf(name):
+    z = np.load(os.path.join(DATA_DIR, name))
     mats = [dict(base_color=z["mat_base_color"][i], roughness=float(z["mat_roughness"][i]),
                  metalness=float(z["mat_metalness"][i]), emissive=z["mat_emissive"][i]) for i in range(len(z["mat_roughness"]))]
-    mesh = TriangleMesh(z["positions"], z["normals"], z["indices"], z["material_ids"], mats)
+    return TriangleMesh(z["positions"], z["normals"], z["indices"], z["material_ids"], mats)
+
+
+def pica_diorama():
+    """assets/scenes/pica.ron: pica_pica_-_mini_diorama_01/scene.gltf scaled x0.1 at the origin -- the one real production
+    asset in the reference checkout (76 k triangles, 170 primitives, node transforms baked by the importer). Geometry +
+    material factors from kajiya_amd/data/pica_diorama.npz (scripts/make_golden_assets.py); image maps are not carried."""
     s = SceneDesc()
-    s.add_instance(s.add_mesh(mesh), translation((0.0, -1.0, 0.0)))
+    s.add_instance(s.add_mesh(_baked_gltf("pica_diorama.npz")), affine())
     return s
 
 

@@ -28,6 +28,6 @@ open(os.path.join(d, "scene.txt"), "w").write("\n".join(lines) + "\n")
 t, (ranking, scrambling, sobol, offsets) = rtr_tables.standin_tables()
 open(os.path.join(d, "rtr_tables.bin"), "wb").write(ranking.tobytes() + scrambling.tobytes() + sobol.tobytes() + offsets.tobytes())
 subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
-out = subprocess.check_output([os.path.join(ROOT, "examples", "world_render_passes"), os.path.join(ROOT, "tests", "golden", "bluenoise_256_rgba8.bin"), d, str(W), str(H), str(frames),
+out = subprocess.check_output([os.path.join(ROOT, "examples", "world_render_passes"), os.path.join(ROOT, "kajiya_amd", "data", "bluenoise_256_rgba8.bin"), d, str(W), str(H), str(frames),
                                os.path.join(d, "out")])
 print(out.decode().strip()[:-1] + f', "scene": "{name}", "triangles": {sum(m.triangle_count for m in sd.meshes)}}}')

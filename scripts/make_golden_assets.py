@@ -2,18 +2,21 @@
 """Generate committed fixtures from the reference's DATA assets (run in the build
 container only; /root/reference does not exist on the GPU box).
 
-  tests/golden/bluenoise_256_rgba8.bin  <- assets/images/bluenoise/256_256/LDR_RGBA_0.png
+  kajiya_amd/data/bluenoise_256_rgba8.bin  <- assets/images/bluenoise/256_256/LDR_RGBA_0.png
         (bindless texture #1, default_world_renderer.rs:27; raw RGBA8, 262144 bytes)
-  tests/golden/cornell_box.npz          <- assets/meshes/cornell_box/scene.{gltf,bin}
+  kajiya_amd/data/cornell_box.npz          <- assets/meshes/cornell_box/scene.{gltf,bin}
         imported the way kajiya-asset does (mesh.rs:279-437: node transforms baked,
         per-primitive material, winding flip on negative determinant), scale 2
         (assets/scenes/cornell_box.ron).
+  kajiya_amd/data/pica_diorama.npz         <- assets/meshes/pica_pica_-_mini_diorama_01/scene.{gltf,bin}
+        same import, scale 0.1 (assets/scenes/pica.ron). Geometry + per-material factors only: the six image maps
+        (decals, one metallic-roughness map) are not carried, their materials keep the constant factors.
 """
 import json, os, struct, sys
 import numpy as np
 
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "kajiya_amd", "data")
 
 
 def quat_to_mat(q):
@@ -111,6 +114,11 @@ def main():
     m = load_gltf(os.path.join(REF, "assets/meshes/cornell_box/scene.gltf"), 2.0)
     np.savez_compressed(os.path.join(OUT, "cornell_box.npz"), **m)
     print("cornell:", m["positions"].shape, m["indices"].shape, "materials", len(m["mat_roughness"]))
+    print("bounds", m["positions"].min(0), m["positions"].max(0))
+    m = load_gltf(os.path.join(REF, "assets/meshes/pica_pica_-_mini_diorama_01/scene.gltf"), 0.1)
+    # indexed vertices repeat per node instance after baking; store what the importer produces, losslessly
+    np.savez_compressed(os.path.join(OUT, "pica_diorama.npz"), **m)
+    print("pica:", m["positions"].shape, m["indices"].shape, "materials", len(m["mat_roughness"]))
     print("bounds", m["positions"].min(0), m["positions"].max(0))
 
 

@@ -112,7 +112,7 @@ def test_cpp_host_whole_frame_with_post_on_the_cpu_stand_in(oracle, tmp_path):
     with open(tmp_path / "rtr_tables.bin", "wb") as f:
         for a in (ranking, scrambling, sobol, offsets):
             f.write(np.ascontiguousarray(a).tobytes())
-    bn = os.path.join(ROOT, "tests", "golden", "bluenoise_256_rgba8.bin")
+    bn = os.path.join(ROOT, "kajiya_amd", "data", "bluenoise_256_rgba8.bin")
     out = sp.check_output([exe, bn, str(tmp_path), str(W), str(H), str(N), str(tmp_path / "cpp"), "post"], timeout=600, text=True)
     assert '"frames": %d' % N in out
     taa = np.fromfile(tmp_path / "cpp_taa.bin", np.float16).reshape(H, W, 4)
@@ -146,7 +146,7 @@ def test_cpp_world_render_passes_matches_python_driver(gpu, device, tmp_path):
     _write_baked_scene(tmp_path, sd)
     t, (ranking, scrambling, sobol, offsets) = rtr_tables.standin_tables()
     (tmp_path / "rtr_tables.bin").write_bytes(ranking.tobytes() + scrambling.tobytes() + sobol.tobytes() + offsets.tobytes())
-    bn = os.path.join(ROOT, "tests", "golden", "bluenoise_256_rgba8.bin")
+    bn = os.path.join(ROOT, "kajiya_amd", "data", "bluenoise_256_rgba8.bin")
     out = subprocess.check_output([os.path.join(EX, "world_render_passes"), bn, str(tmp_path), str(W), str(H), str(N), str(tmp_path / "cpp")], timeout=300)
     print(out.decode().strip())
     # the Python driver, same pass order (scripts/render_frame.py)
@@ -181,7 +181,7 @@ def test_cpp_host_reports_errors_instead_of_crashing(tmp_path):
     """Error behaviour of the compiled host: every failing C-ABI / HIP call surfaces as kajiya_amd::Error -> message + exit code 1
     (no GPU here: device creation fails; on a GPU box the missing scene file does)."""
     _build_examples()
-    bn = os.path.join(ROOT, "tests", "golden", "bluenoise_256_rgba8.bin")
+    bn = os.path.join(ROOT, "kajiya_amd", "data", "bluenoise_256_rgba8.bin")
     r = subprocess.run([os.path.join(EX, "world_render_passes"), bn, str(tmp_path), "64", "64", "1", str(tmp_path / "o")], capture_output=True, timeout=120)
     assert r.returncode == 1 and r.stderr.decode().startswith("error: "), (r.returncode, r.stderr)
     r = subprocess.run([os.path.join(EX, "world_render_passes")], capture_output=True, timeout=30)

@@ -48,7 +48,7 @@ def test_the_gpu_suite_passes_on_the_cpu_stand_in():
     """Every `-m gpu` parity test except the ones sized for hardware (full-size frames, the 1080p post case, the 512^2 convergence run, the
     48-frame pipelining test, two 10-frame free-running runs, the two larger per-pass rtdgi cases (the 123x77 one stays), the compiled C++ host which links the real library), in the stand-in's fiber mode: about two and a half
     minutes on 8 cores. The tests' own tolerances apply unchanged."""
-    r = run_emulated(["tests", "--deselect", "tests/test_gpu_fullsize.py", "-k", "not 1920 and not cpp_world_render_passes and not converges_to_reference_pt and not pipelined_frames and not free_running_structure and not with_ssgi_guide and not cornell-256-256 and not city20k-320-192"],
+    r = run_emulated(["tests", "--deselect", "tests/test_gpu_fullsize.py", "--deselect", "tests/test_gpu_baseline_sizes.py", "-k", "not 1920 and not cpp_world_render_passes and not converges_to_reference_pt and not pipelined_frames and not free_running_structure and not with_ssgi_guide and not cornell-256-256 and not city20k-320-192"],
                      timeout=2400, fast=True)
     tail = r.stdout[-3000:] + r.stderr[-3000:]
     assert r.returncode == 0, tail

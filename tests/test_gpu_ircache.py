@@ -14,13 +14,17 @@ BUFS = {"meta": np.uint32, "grid_meta": np.uint32, "entry_cell": np.uint32, "spa
         "life": np.uint32, "pool": np.uint32, "entry_indirection": np.uint32, "reposition_proposal": np.float32, "reposition_proposal_count": np.uint32}
 
 
-def _frames(W, H, n, use_ircache=True):
+def _frames(W, H, n, use_ircache=True, scene="cornell"):
     from kajiya_amd import frame
     fs = frame.FrameState((W, H))
     fs.ircache_enabled = use_ircache
     out = []
     for i in range(n):
-        out.append(fs.prepare_frame_constants(frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.02)))
+        if scene == "cornell":
+            cam = frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.02)
+        else:
+            cam = frame.orbit_camera(i, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.004)
+        out.append(fs.prepare_frame_constants(cam))
         fs.retire_frame()
     return out
 
@@ -37,15 +41,17 @@ def test_ircache_maintenance_and_sum_are_exact_on_identical_state(gpu, oracle, d
     """scroll/age/scan/compact and the SH sum-up are deterministic given the same state (single-threaded oracle
     order == any GPU order up to the free-list permutation): run the oracle for several frames, upload its
     state, run one prepare() on both, compare."""
+    one_frame_on_identical_state(gpu, oracle, device, "cornell", 128, 128)
+
+
+def one_frame_on_identical_state(gpu, oracle, device, scene_name, W, H):
     import torch
-    from kajiya_amd import scenes
-    W = H = 128
-    desc = scenes.cornell_box()
+    desc = T._scenes()[scene_name]
     oracle.lib().okj_set_threads(1)
     try:
         op = oracle.OraclePipeline(oracle.OracleScene(desc), W, H, use_ircache=True)
         gp = gpu.GpuPipeline(device, gpu.Scene(device, desc), W, H, use_ircache=True)
-        fcs = _frames(W, H, 8)
+        fcs = _frames(W, H, 8, scene="cornell" if scene_name == "cornell" else "city")
         for fc in fcs[:6]:
             op.frame(fc)
         # GPU: run one frame to initialise, then overwrite its state with the oracle's
@@ -140,8 +146,10 @@ def test_ircache_free_running_structure_and_statistics(gpu, oracle, device):
     assert r["rel_l2"] < 5e-2
 
 
-def test_pipelined_frames_match_serial_frames(gpu, device):
-    """GpuPipeline.frame_pipelined issues frame N+1's ircache work on a second stream under frame N's screen-space tail.
+@pytest.mark.parametrize("with_ssgi", [False, True])
+def test_pipelined_frames_match_serial_frames(gpu, device, with_ssgi):
+    """(with_ssgi: the SSAO guide is computed every frame as the bench does; it reads the frame constants the SIDE stream writes.)
+    GpuPipeline.frame_pipelined issues frame N+1's ircache work on a second stream under frame N's screen-space tail.
     Dependencies are those of the serial order, so the result may differ only through the cache's own atomics races
     (which also make two serial runs differ): compare the time-averaged GI and TAA outputs."""
     import torch
@@ -181,9 +189,12 @@ def test_pipelined_frames_match_serial_frames(gpu, device):
             gp.geometric_normal, gp.gbuffer, gp.depth = gn, gb, d
             gp.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
             if pipelined:
-                gp.frame_pipelined(F[i + 1])
+                gp.frame_pipelined(F[i + 1], run_ssgi=with_ssgi)
+                torch.cuda.current_stream().wait_event(gp._ev_taa[i & 1])    # spatial filter + TAA of this frame run on the third stream
             else:
                 device.frame_begin(F[i])
+                if with_ssgi:
+                    gp.ssgi_frame()
                 gp.gi_frame()
                 gp.taa_frame()
             if i >= 8:

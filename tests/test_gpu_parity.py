@@ -24,6 +24,8 @@ def _frame_constants(W, H, n_frames, scene="cornell"):
             cam = frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.01)
         elif scene == "textured":
             cam = frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=9.0, height=3.0, rate=0.01)
+        elif scene == "pica":
+            cam = frame.orbit_camera(i, (W, H), center=(-0.4, 0.5, -0.6), radius=5.0, height=1.6, rate=0.01)
         else:
             cam = frame.orbit_camera(i, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.004)
         out.append(fs.prepare_frame_constants(cam))
@@ -41,12 +43,25 @@ def _random_rays(rng, n, lo, hi):
     return rays
 
 
+class _Scenes:
+    """name -> SceneDesc, built on first use (the BASELINE-size scenes are expensive)."""
+    _cache = {}
+
+    def __getitem__(self, name):
+        from kajiya_amd import scenes
+        make = {"cornell": scenes.cornell_box, "city20k": lambda: scenes.procedural_city(target_tris=20000, seed=7, n_instances=24),
+                "textured": scenes.textured_test_scene, "pica": scenes.pica_diorama,
+                "city1m": lambda: scenes.procedural_city(target_tris=1_000_000, seed=1234)}   # the bench's configs[1] stand-in
+        if name not in self._cache:
+            self._cache[name] = make[name]()
+        return self._cache[name]
+
+
 def _scenes():
-    from kajiya_amd import scenes
-    return {"cornell": scenes.cornell_box(), "city20k": scenes.procedural_city(target_tris=20000, seed=7, n_instances=24), "textured": scenes.textured_test_scene()}
+    return _Scenes()
 
 
-@pytest.mark.parametrize("name", ["cornell", "city20k"])
+@pytest.mark.parametrize("name", ["cornell", "city20k", "pica"])
 def test_ray_queries_bit_exact(gpu, oracle, device, name):
     import torch
     desc = _scenes()[name]
@@ -183,7 +198,7 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced):
     op.L.okj_rtdgi_set_options(op.rtdgi, passes)
     op.L.okj_rtdgi_set_raytraced_visibility(op.rtdgi, int(raytraced))
     gpu.check(gp.L.kj_rtdgi_set_options(gp.rtdgi, passes, int(raytraced)))
-    fcs = _frame_constants(W, H, 8, scene_name if scene_name in ("cornell", "textured") else "city")
+    fcs = _frame_constants(W, H, 8, scene_name if scene_name in ("cornell", "textured", "pica") else "city")
     repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
     worst = {}
     for fi, fc in enumerate(fcs):
@@ -220,7 +235,7 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced):
                 key = (pname, P.base_name(n))
                 if key not in worst or r["rel_l2"] > worst[key]["rel_l2"]:
                     worst[key] = r
-                assert r["rel_l2"] <= REL_L2_TOL or r["mismatch_frac"] <= MISMATCH_TOL, f"frame {fi} pass {pname} surface {n}: {r}"
+                assert P.within_bars(r), f"frame {fi} pass {pname} surface {n}: {r}"
     for k, v in sorted(worst.items()):
         if v["rel_l2"] > 0:
             print(f"  {k[0]:>20s} {k[1]:<36s} rel_l2={v['rel_l2']:.2e} mismatch={v['mismatch_frac']:.2e}")

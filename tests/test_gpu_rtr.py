@@ -78,7 +78,7 @@ def test_rtr_per_pass_parity(gpu, oracle, device, W, H, reuse):
                 key = (pname, P.base_name(n))
                 if key not in worst or r["rel_l2"] > worst[key]["rel_l2"]:
                     worst[key] = r
-                ok = r["rel_l2"] <= T.REL_L2_TOL or r["mismatch_frac"] <= T.MISMATCH_TOL
+                ok = P.within_bars_with_flips(r)
                 if P.fmt_of(n) == "r11g11b10f":   # one-step rounding flips are expected (see parity.RTOL); they must stay rare and unbiased
                     ok = r["mismatch_frac"] <= T.MISMATCH_TOL and r["differ_frac"] <= 0.03
                 if not ok:
