@@ -5,6 +5,7 @@
 //   raw ray-query entry points (inc/rt.hlsl:58-137).
 #include "kj_host.hpp"
 #include "kj_scene.hpp"
+#include "kj_screen.hpp"
 
 using namespace kj;
 
@@ -18,14 +19,26 @@ __global__ void k_brdf_fg_lut(uint2* __restrict__ out) {
     const float roughness = fmaxf(1e-5f, float(y) / 63.0f);
     out[y * 64 + x] = pack_rgba16f(v4(integrate_brdf_fg(roughness, ndotv), 0.0f));
 }
-// kj_frame_begin: store the frame constants (passed by value in the kernarg segment) into their ring slot and hoist SUN_COLOR.
-__global__ void __launch_bounds__(64) k_frame_begin(const KjFrameConstants fc, KjFrameConstants* __restrict__ dst, float4* __restrict__ sun_out) {
+// kj_frame_begin: store the frame constants (passed by value in the kernarg segment) into their ring slot, hoist SUN_COLOR and
+// derive the matrix products the screen-space passes use per tap (kj_screen.hpp: FrameDerived), in double, rounded once.
+__global__ void __launch_bounds__(64) k_frame_begin(const KjFrameConstants fc, FrameBlock* __restrict__ dst, float4* __restrict__ sun_out) {
     const uint32_t* src = (const uint32_t*)&fc;
-    uint32_t* d = (uint32_t*)dst;
+    uint32_t* d = (uint32_t*)&dst->fc;
     for (uint32_t i = threadIdx.x; i < sizeof(KjFrameConstants) / 4; i += 64) d[i] = src[i];
+    const KjViewConstants& vc = fc.view_constants;
+    if (threadIdx.x < 48) {
+        const uint32_t which = threadIdx.x >> 4, e = threadIdx.x & 15u, c = e >> 2, r = e & 3u;
+        const float* A = which == 0 ? vc.view_to_world : (which == 1 ? vc.view_to_clip : vc.view_to_sample);
+        const float* B = which == 0 ? vc.sample_to_view : vc.world_to_view;
+        double acc = 0.0;
+        for (uint32_t k = 0; k < 4; ++k) acc += double(A[k * 4 + r]) * double(B[c * 4 + k]);
+        (which == 0 ? dst->fd.sample_to_world : (which == 1 ? dst->fd.world_to_clip : dst->fd.world_to_sample))[e] = float(acc);
+    }
     if (threadIdx.x == 0) {
         const V3 c = sun_color_in_direction(fc, sun_direction(fc));
         *sun_out = make_float4(c.x, c.y, c.z, 0.0f);
+        const V3 eye = get_eye_position(fc);
+        dst->fd.eye_ws[0] = eye.x; dst->fd.eye_ws[1] = eye.y; dst->fd.eye_ws[2] = eye.z; dst->fd.eye_ws[3] = 1.0f;
     }
 }
 __global__ void k_sky_cube(const FrameConstants* __restrict__ fc, uint2* __restrict__ out, int width) {
@@ -318,7 +331,7 @@ KjStatus kj_device_create(int32_t ordinal, const uint8_t* blue_noise_rgba8_256, 
     do {
         if (d->blue_noise.upload(blue_noise_rgba8_256, 256 * 256 * 4) != hipSuccess) { st = KJ_ERR_OUT_OF_MEMORY; break; }
         if (d->brdf_fg_lut.alloc(64 * 64 * 8) != hipSuccess) { st = KJ_ERR_OUT_OF_MEMORY; break; }
-        if (d->frame_constants.alloc(sizeof(KjFrameConstants) * KjDevice::FC_RING) != hipSuccess) { st = KJ_ERR_OUT_OF_MEMORY; break; }
+        if (d->frame_constants.alloc(sizeof(FrameBlock) * KjDevice::FC_RING) != hipSuccess) { st = KJ_ERR_OUT_OF_MEMORY; break; }
         if (d->sun_color.alloc(16 * KjDevice::FC_RING) != hipSuccess) { st = KJ_ERR_OUT_OF_MEMORY; break; }
         hipLaunchKernelGGL(k_brdf_fg_lut, dim3(8, 8), dim3(8, 8), 0, 0, (uint2*)d->brdf_fg_lut.p);
         if (hipDeviceSynchronize() != hipSuccess) { st = KJ_ERR_HIP; break; }
@@ -339,9 +352,9 @@ KjStatus kj_frame_begin(KjDevice* dev, const KjFrameConstants* fc, void* stream_
     hipStream_t stream = (hipStream_t)stream_;
     dev->fc_slot = (dev->fc_slot + 1) % KjDevice::FC_RING;
     dev->fc_host = *fc;
-    KjFrameConstants* dst = (KjFrameConstants*)dev->frame_constants.p + dev->fc_slot;
+    FrameBlock* dst = (FrameBlock*)dev->frame_constants.p + dev->fc_slot;
     // The 1216-byte block travels as a kernel argument: no pageable-memory staging copy, fully asynchronous.
-    dev->fc_dev = dst;
+    dev->fc_dev = &dst->fc;
     hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, stream, *fc, dst, (float4*)dev->sun_color.p + dev->fc_slot);
     KJ_CHECK_LAUNCH();
     return KJ_OK;

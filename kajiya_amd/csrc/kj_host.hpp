@@ -61,7 +61,7 @@ struct KjDevice {
     int ordinal = 0;
     kj::DevBuf blue_noise;      // 256x256 RGBA8
     kj::DevBuf brdf_fg_lut;     // 64x64 RGBA16F
-    kj::DevBuf frame_constants; // ring of KjFrameConstants
+    kj::DevBuf frame_constants; // ring of kj::FrameBlock (the caller's KjFrameConstants + the per-frame products derived from it, kj_screen.hpp)
     uint32_t fc_slot = 0;
     static const uint32_t FC_RING = 16;
     KjFrameConstants fc_host{};           // last uploaded

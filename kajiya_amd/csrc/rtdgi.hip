@@ -7,6 +7,9 @@
 #include "kj_reservoir.hpp"
 #include "kj_ircache.hpp"
 #include "kj_ircache_host.hpp"
+#include "kj_screen.hpp"
+#include "rtdgi_resample.hpp"
+#include <cstdlib>
 
 using namespace kj;
 namespace kj { SceneView scene_view(const KjScene& s); }
@@ -34,8 +37,10 @@ typedef Img<float4> ImgF4;
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
 // ------------------------------------------------------------------ extract_half_res_{gbuffer_view_normal_rgba8,depth,ssao}.hlsl (fused)
+// Besides the reference's three half-res images this writes them once more as ONE 8-byte record per pixel
+// {depth bits, view normal snorm8 x3 | ssao snorm8 << 24}: what the resampling passes stage in LDS / fetch per tap (rtdgi_resample.hip).
 __global__ void __launch_bounds__(64) k_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgR8 ssao, ImgU32 half_view_normal,
-                                                      ImgF32 half_depth, ImgR8S half_ssao, int row0, int row1) {
+                                                      ImgF32 half_depth, ImgR8S half_ssao, ImgU2 half_gbuf, int row0, int row1) {
     TILE_XY(half_depth.w, half_depth.h)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
@@ -43,9 +48,13 @@ __global__ void __launch_bounds__(64) k_extract_half(const FrameConstants* __res
     const int sx = x * 2 + off.x, sy = y * 2 + off.y;
     const V3 normal_ws = unpack_normal_11_10_11_no_normalize(gbuffer.ld(sx, sy).y);
     const V3 normal_vs = normalize(xyz(mul44(fc.view_constants.world_to_view, v4(normal_ws, 0))));
-    half_view_normal.st(x, y, pack_rgba8_snorm(v4(normal_vs, 1.0f)));
-    half_depth.st(x, y, depth.ld(sx, sy));
-    half_ssao.st(x, y, to_snorm8(from_unorm8(ssao.ld(sx, sy))));
+    const uint32_t packed_normal = pack_rgba8_snorm(v4(normal_vs, 1.0f));
+    const float d = depth.ld(sx, sy);
+    const int8_t ao = to_snorm8(from_unorm8(ssao.ld(sx, sy)));
+    half_view_normal.st(x, y, packed_normal);
+    half_depth.st(x, y, d);
+    half_ssao.st(x, y, ao);
+    half_gbuf.st(x, y, make_uint2(asuint(d), (packed_normal & 0x00ffffffu) | (uint32_t(uint8_t(ao)) << 24)));
 }
 
 // ------------------------------------------------------------------ fullres_reproject.hlsl:29-76
@@ -460,130 +469,7 @@ __global__ void __launch_bounds__(64) k_restir_temporal(RestirTemporalArgs a) {
     a.temporal_reservoir_packed_tex.st(x, y, rp.as_raw());
 }
 
-// ------------------------------------------------------------------ occlusion_raymarch.hlsl:75-146 (half-res depth, no colour bounce)
-KJ_D void occlusion_raymarch(const FrameConstants& fc, V2 start_uv, V3 start_cs, V3 end_ws, int max_sample_count, const ImgF32& half_depth, int W, int H, float& visibility) {
-    const V2 fullres{float(W), float(H)}, halfres{float(half_depth.w), float(half_depth.h)};
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    const V3 end_cs = position_world_to_clip(fc, end_ws);
-    const V2 len_px = (cs_to_uv(V2{end_cs.x, end_cs.y}) - start_uv) * halfres;
-    const int k_count = min(max_sample_count, int(floorf(length(len_px) / 2.0f)));
-    const float Z_LAYER_THICKNESS = 0.05f;
-    const float depth_step_per_z = (end_cs.z - start_cs.z) / length(V2{end_cs.x, end_cs.y} - V2{start_cs.x, start_cs.y});
-    const float t_step = 1.0f / float(k_count);
-    float t = 0.5f * t_step;
-    for (int k = 0; k < k_count; ++k) {
-        const V3 interp_cs = lerp(start_cs, end_cs, t);
-        const V2 uv_at = cs_to_uv(V2{interp_cs.x, interp_cs.y});
-        const V2 fp{floorf(uv_at.x * fullres.x - float(off.x)), floorf(uv_at.y * fullres.y - float(off.y))};
-        const uint32_t ux = fp.x > 0 ? uint32_t(fp.x) : 0u, uy = fp.y > 0 ? uint32_t(fp.y) : 0u;
-        const uint32_t pxi = (ux & ~1u) + uint32_t(off.x), pyi = (uy & ~1u) + uint32_t(off.y);
-        const float depth_at = half_depth.ld(int(pxi >> 1u), int(pyi >> 1u));
-        const V2 qcs = uv_to_cs(V2{(float(pxi) + 0.5f) / fullres.x, (float(pyi) + 0.5f) / fullres.y});
-        const float biased_z = start_cs.z + depth_step_per_z * length(qcs - V2{start_cs.x, start_cs.y});
-        if (depth_at > biased_z) {
-            const float depth_diff = inverse_depth_relative_diff(interp_cs.z, depth_at);
-            visibility *= 1 - smoothstep(Z_LAYER_THICKNESS, Z_LAYER_THICKNESS * 0.5f, depth_diff);
-        }
-        t += t_step;
-    }
-}
-
-// ------------------------------------------------------------------ restir_spatial.hlsl:48-372
-KJ_D float normal_inluence_nonlinearity(float x, float b) { return x < -b ? 0.0f : (x + b) * (x + b) / (4 * b); }
-__global__ void __launch_bounds__(64) k_restir_spatial(const FrameConstants* __restrict__ fcp, ImgU2 reservoir_input_tex, ImgU32 half_view_normal_tex, ImgF32 half_depth_tex,
-                                                        ImgR8S half_ssao_tex, ImgU4 temporal_reservoir_packed_tex, ImgU2 reservoir_output_tex, int W, int H,
-                                                        uint32_t spatial_reuse_pass_idx, uint32_t perform_occlusion_raymarch, uint32_t occlusion_raymarch_importance_only, int row0, int row1) {
-    const int hw = reservoir_output_tex.w, hh = reservoir_output_tex.h;
-    TILE_XY(hw, hh)
-    if (!in_image) return;
-    const FrameConstants& fc = *fcp;
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    const V4 gts = tex_size4(W, H);
-    const float depth = half_depth_tex.ld(x, y);
-    uint32_t rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index + spatial_reuse_pass_idx * 123u);
-    const V2 uv = get_uv(float(x * 2 + off.x), float(y * 2 + off.y), gts);
-    const ViewRay vr = view_ray_from_uv_and_depth(fc, uv, depth);
-    const V3 center_normal_vs = ld_nrm_snorm8(half_view_normal_tex, x, y);
-    const V3 center_normal_ws = direction_view_to_world(fc, center_normal_vs);
-    const float center_depth = depth;
-    const float center_ssao = from_snorm8(half_ssao_tex.ld(x, y));
-    StreamState stream_state{0, 0};
-    Reservoir1spp reservoir = Reservoir1spp::create();
-    const float sample_radius_offset = uint_to_u01_float(hash1_mut(rng));
-    const Reservoir1spp center_r = Reservoir1spp::from_raw(reservoir_input_tex.ld(x, y));
-    float kernel_tightness = 1.0f - center_ssao;
-    const float MAX_INPUT_M_IN_PASS = spatial_reuse_pass_idx == 0 ? RESTIR_TEMPORAL_M_CLAMP : RESTIR_TEMPORAL_M_CLAMP * 8.0f;
-    kernel_tightness = lerp(kernel_tightness, 1.0f, 0.5f * smoothstep(MAX_INPUT_M_IN_PASS * 0.5f, MAX_INPUT_M_IN_PASS, center_r.M));
-    float max_kernel_radius = spatial_reuse_pass_idx == 0 ? lerp(32.0f, 12.0f, kernel_tightness) : lerp(16.0f, 6.0f, kernel_tightness);
-    if (spatial_reuse_pass_idx >= 2) max_kernel_radius = 8;
-    const V2 dist_to_edge_xy = vmin(V2{float(x), float(y)}, V2{float(hw) - float(x), float(hh) - float(y)});
-    const float allow_edge_overstep = center_r.M < 10 ? 100.0f : 1.25f;
-    const V2 kernel_radius = vmin(V2{max_kernel_radius, max_kernel_radius}, dist_to_edge_xy * allow_edge_overstep);
-    const uint32_t sample_count = spatial_reuse_pass_idx == 0 ? 8u : 5u;
-    const uint32_t shift = spatial_reuse_pass_idx == 0 ? 3u : 2u;
-    const float ang_offset = uint_to_u01_float(hash3(uint32_t(x) >> shift, uint32_t(y) >> shift, fc.frame_index * 2u + spatial_reuse_pass_idx)) * KJ_PI * 2;
-    for (uint32_t sample_i = 0; sample_i < sample_count; ++sample_i) {
-        const float ang = (float(sample_i) + ang_offset) * KJ_GOLDEN_ANGLE;
-        const V2 radius = 0 == sample_i ? V2{0, 0} : (powf((float(sample_i) + sample_radius_offset) / float(sample_count), 0.5f) * kernel_radius);
-        const V2 cs_ang = cos_sin_turns(ang);
-        const I2 rpx_offset{int(cs_ang.x * radius.x), int(cs_ang.y * radius.y)};
-        const bool is_center_sample = sample_i == 0;
-        const I2 rpx{x + rpx_offset.x, y + rpx_offset.y};
-        const uint2 reservoir_raw = reservoir_input_tex.ld(rpx.x, rpx.y);
-        if (0 == reservoir_raw.x) continue;
-        Reservoir1spp r = Reservoir1spp::from_raw(reservoir_raw);
-        r.M = fminf(r.M, 500.0f);
-        const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
-        const TemporalReservoirOutput spx_packed = TemporalReservoirOutput::from_raw(temporal_reservoir_packed_tex.ld(spx_x, spx_y));
-        float visibility = 1, relevance = 1;
-        const V3 sample_normal_vs = ld_nrm_snorm8(half_view_normal_tex, rpx.x, rpx.y);
-        const float normal_similarity_dot = dot(sample_normal_vs, center_normal_vs);
-        relevance *= normal_inluence_nonlinearity(normal_similarity_dot, 0.5f) / normal_inluence_nonlinearity(1.0f, 0.5f);
-        const float sample_ssao = from_snorm8(half_ssao_tex.ld(rpx.x, rpx.y));
-        relevance *= 1 - fabsf(sample_ssao - center_ssao);
-        const V2 rpx_uv = get_uv(float(rpx.x * 2 + off.x), float(rpx.y * 2 + off.y), gts);
-        const float rpx_depth = half_depth_tex.ld(rpx.x, rpx.y);
-        if (rpx_depth == 0.0f) continue;
-        const ViewRay rpx_ray = view_ray_from_uv_and_depth(fc, rpx_uv, rpx_depth);
-        const V2 spx_uv = get_uv(float(spx_x * 2 + off.x), float(spx_y * 2 + off.y), gts);
-        const ViewRay spx_ray = view_ray_from_uv_and_depth(fc, spx_uv, spx_packed.depth);
-        const V3 sample_hit_ws = spx_packed.ray_hit_offset_ws + spx_ray.hit_ws;
-        const V3 reused_unnorm = sample_hit_ws - rpx_ray.hit_ws;
-        const float reused_dist = length(reused_unnorm);
-        const V3 reused_dir = reused_unnorm / reused_dist;
-        const V3 dir_unnorm = sample_hit_ws - vr.hit_ws;
-        const float dist_to_sample_hit = length(dir_unnorm);
-        const V3 dir_to_sample_hit = normalize(dir_unnorm);
-        if (!is_center_sample) {
-            const float depth_diff = fabsf(fmaxf(0.3f, center_normal_vs.z) * (center_depth / rpx_depth - 1.0f));
-            relevance *= 1 - smoothstep(0.0f, spatial_reuse_pass_idx == 0 ? 0.15f : 0.1f, depth_diff);
-        }
-        if (perform_occlusion_raymarch) {
-            const float surface_offset_len = length(view_ray_from_uv_and_depth(fc, spx_uv, depth).hit_vs - vr.hit_vs);
-            const V3 march_dir = sample_hit_ws - vr.hit_ws;
-            const V3 end_ws = vr.hit_ws + march_dir * fminf(1.0f, 3.0f * surface_offset_len / length(march_dir));
-            occlusion_raymarch(fc, uv, vr.hit_cs, end_ws, 6, half_depth_tex, W, H, visibility);
-        }
-        const float center_to_hit_vis = -dot(spx_packed.hit_normal_ws, dir_to_sample_hit);
-        const float reused_to_hit_vis = -dot(spx_packed.hit_normal_ws, reused_dir);
-        float p_q = 1;
-        p_q *= spx_packed.luminance;
-        p_q *= fmaxf(0.0f, dot(dir_to_sample_hit, center_normal_ws));
-        float jacobian = 1;
-        jacobian *= reused_dist / dist_to_sample_hit;
-        jacobian *= jacobian;
-        jacobian *= clampf(center_to_hit_vis / reused_to_hit_vis, 0.0f, 1e4f);
-        jacobian = sqrtf(jacobian);
-        if (is_center_sample) jacobian = 1;
-        if (!(p_q >= 0)) continue;
-        r.M *= relevance;
-        if (occlusion_raymarch_importance_only) { p_q *= lerp(0.25f, 1.0f, visibility); visibility = 1; }
-        reservoir.update_with_stream(r, p_q, visibility * jacobian, stream_state, r.payload, rng);
-    }
-    reservoir.finish_stream(stream_state);
-    reservoir.W = fminf(reservoir.W, RESTIR_RESERVOIR_W_CLAMP);
-    reservoir_output_tex.st(x, y, reservoir.as_raw());
-}
+// restir_spatial.hlsl + occlusion_raymarch.hlsl: rtdgi_resample.hip (k_restir_spatial<>)
 
 // ------------------------------------------------------------------ restir_check.rgen.hlsl:21-70 (use_raytraced_reservoir_visibility, rtdgi.rs:478-494)
 __global__ void __launch_bounds__(64) k_restir_check(const FrameConstants* __restrict__ fcp, SceneView sc, ImgF32 half_depth_tex, ImgU4 temporal_reservoir_packed_tex,
@@ -611,105 +497,7 @@ __global__ void __launch_bounds__(64) k_restir_check(const FrameConstants* __res
     }
 }
 
-// ------------------------------------------------------------------ restir_resolve.hlsl:42-205
-KJ_D float ggx_ndf_unnorm(float a2, float cos_theta) { const float d = cos_theta * cos_theta * (a2 - 1.0f) + 1.0f; return a2 / (d * d); }
-struct ResolveArgs {
-    const FrameConstants* __restrict__ fc;
-    ImgH4 radiance_tex; ImgU2 reservoir_input_tex; ImgU4 gbuffer_tex; ImgF32 depth_tex; ImgU32 half_view_normal_tex; ImgF32 half_depth_tex; ImgR8 ssao_tex;
-    ImgH4 candidate_radiance_tex; ImgH4 candidate_hit_tex; ImgU4 temporal_reservoir_packed_tex; ImgH4 irradiance_output_tex;
-    const uint32_t* __restrict__ blue_noise;
-    int row0, row1;
-};
-__global__ void __launch_bounds__(64) k_restir_resolve(ResolveArgs a) {
-    const int row0 = a.row0, row1 = a.row1;
-    const int W = a.irradiance_output_tex.w, H = a.irradiance_output_tex.h;
-    TILE_XY(W, H)
-    if (!in_image) return;
-    const FrameConstants& fc = *a.fc;
-    const float depth = a.depth_tex.ld(x, y);
-    if (0 == depth) { st4(a.irradiance_output_tex, x, y, v4(0.0f)); return; }
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    const V4 gts = tex_size4(W, H);
-    const V2 uv = get_uv(float(x), float(y), gts);
-    const ViewRay vr = view_ray_from_uv_and_depth(fc, uv, depth);
-    const GbufferData gbuffer = gbuffer_unpack(a.gbuffer_tex.ld(x, y));
-    const V3 center_normal_ws = gbuffer.normal;
-    const V3 center_normal_vs = direction_world_to_view(fc, center_normal_ws);
-    const float center_depth = depth;
-    const float center_ssao = from_unorm8(a.ssao_tex.ld(x, y));
-    const uint32_t frame_hash = hash1(fc.frame_index);
-    const uint32_t px_idx_in_quad = (((uint32_t(x) & 1u) | (uint32_t(y) & 1u) * 2u) + frame_hash) & 3u;
-    const float blue_x = blue_noise_for_pixel(a.blue_noise, x, y, fc.frame_index).x * KJ_TAU;
-    const float near_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
-    const float near_start = near_end * 0.5f;
-    const float near_field_influence = center_ssao;
-    V3 total_irradiance = v3(0.0f);
-    bool sharpen_gi_kernel = false;
-    {
-        float w_sum = 0;
-        V3 weighted = v3(0.0f);
-        for (uint32_t si = 0; si < 4u; ++si) {
-            const float ang = (float(si) + blue_x) * KJ_GOLDEN_ANGLE + (float(px_idx_in_quad) / 4.0f) * KJ_TAU;
-            const float radius = powf(float(si), 0.666f) * 1.0f + 0.4f;
-            const V2 rpo = cos_sin_turns(ang) * radius;
-            const int rx = int(floorf(float(x) * 0.5f + rpo.x)), ry = int(floorf(float(y) * 0.5f + rpo.y));
-            const V2 rpx_uv = get_uv(float(rx * 2 + off.x), float(ry * 2 + off.y), gts);
-            const float rpx_depth = a.half_depth_tex.ld(rx, ry);
-            const ViewRay rpx_ray = view_ray_from_uv_and_depth(fc, rpx_uv, rpx_depth);
-            const V3 hit_ws = xyz(ld4(a.candidate_hit_tex, rx, ry)) + rpx_ray.hit_ws;
-            const V3 sample_offset = hit_ws - vr.hit_ws;
-            const float sample_dist = length(sample_offset);
-            const V3 sample_dir = sample_offset / sample_dist;
-            const float geometric_term = 2 * fmaxf(0.0f, dot(center_normal_ws, sample_dir));
-            const float atten = smoothstep(near_end, near_start, sample_dist);
-            sharpen_gi_kernel |= atten > 0.9f;
-            V3 contribution = xyz(ld4(a.candidate_radiance_tex, rx, ry)) * geometric_term;
-            contribution *= lerp(0.0f, atten, near_field_influence);
-            const V3 sample_normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, rx, ry);
-            float w = 1;
-            w *= ggx_ndf_unnorm(0.01f, saturate(dot(center_normal_vs, sample_normal_vs)));
-            w *= exp2f(-200.0f * fabsf(center_normal_vs.z * (center_depth / rpx_depth - 1.0f)));
-            weighted += contribution * w;
-            w_sum += w;
-        }
-        total_irradiance += weighted / fmaxf(1e-20f, w_sum);
-    }
-    {
-        float w_sum = 0;
-        V3 weighted = v3(0.0f);
-        const float kernel_scale = sharpen_gi_kernel ? 0.5f : 1.0f;
-        for (uint32_t si = 0; si < 4u; ++si) {
-            const float ang = (float(si) + blue_x) * KJ_GOLDEN_ANGLE + (float(px_idx_in_quad) / 4.0f) * KJ_TAU;
-            const float radius = powf(float(si), 0.666f) * 1.0f * kernel_scale + 0.4f * kernel_scale;
-            const V2 rpo = cos_sin_turns(ang) * radius;
-            const int rx = int(floorf(float(x) * 0.5f + rpo.x)), ry = int(floorf(float(y) * 0.5f + rpo.y));
-            const Reservoir1spp r = Reservoir1spp::from_raw(a.reservoir_input_tex.ld(rx, ry));
-            const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
-            const TemporalReservoirOutput spx_packed = TemporalReservoirOutput::from_raw(a.temporal_reservoir_packed_tex.ld(spx_x, spx_y));
-            const V2 spx_uv = get_uv(float(spx_x * 2 + off.x), float(spx_y * 2 + off.y), gts);
-            const ViewRay spx_ray = view_ray_from_uv_and_depth(fc, spx_uv, spx_packed.depth);
-            const float rpx_depth = a.half_depth_tex.ld(rx, ry);
-            const V3 hit_ws = spx_packed.ray_hit_offset_ws + spx_ray.hit_ws;
-            const V3 sample_offset = hit_ws - vr.hit_ws;
-            const float sample_dist = length(sample_offset);
-            const V3 sample_dir = sample_offset / sample_dist;
-            const float geometric_term = 2 * fmaxf(0.0f, dot(center_normal_ws, sample_dir));
-            V3 radiance = xyz(ld4(a.radiance_tex, spx_x, spx_y));
-            radiance *= lerp(1.0f, smoothstep(near_start, near_end, sample_dist), near_field_influence);
-            const V3 contribution = radiance * geometric_term * r.W;
-            const V3 sample_normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, spx_x, spx_y);
-            const float sample_ssao = from_unorm8(a.ssao_tex.ld(rx * 2 + off.x, ry * 2 + off.y));
-            float w = 1;
-            w *= ggx_ndf_unnorm(0.01f, saturate(dot(center_normal_vs, sample_normal_vs)));
-            w *= exp2f(-200.0f * fabsf(center_normal_vs.z * (center_depth / rpx_depth - 1.0f)));
-            w *= exp2f(-20.0f * fabsf(center_ssao - sample_ssao));
-            weighted += contribution * w;
-            w_sum += w;
-        }
-        total_irradiance += weighted / fmaxf(1e-20f, w_sum);
-    }
-    st4(a.irradiance_output_tex, x, y, v4(total_irradiance, 1));
-}
+// restir_resolve.hlsl: rtdgi_resample.hip (k_restir_resolve)
 
 // ------------------------------------------------------------------ temporal_filter.hlsl:39-252
 __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgH4 history_tex, ImgU32 variance_history_tex /*RG16F*/,
@@ -780,45 +568,7 @@ __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __
     st4(output_tex, x, y, v4(xyz(output), saturate(output_sample_count * lerp(1.0f, 0.5f, rt_invalid) * smoothstep(0.3f, 0.0f, temporal_change) / 32.0f)));
 }
 
-// ------------------------------------------------------------------ spatial_filter.hlsl:34-101
-KJ_D V3 crunch(V3 v) { return v * (1.0f / (max3(v.x, v.y, v.z) + 1.0f)); }
-KJ_D V3 uncrunch(V3 v) { return v * (1.0f / (1.0f - max3(v.x, v.y, v.z))); }
-__global__ void __launch_bounds__(64) k_spatial_filter(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgF32 depth_tex, ImgR8 ssao_tex, ImgU32 geometric_normal_tex, ImgH4 output_tex, int row0, int row1) {
-    TILE_XY(output_tex.w, output_tex.h)
-    if (!in_image) return;
-    const FrameConstants& fc = *fcp;
-    const V4 c = ld4(input_tex, x, y);
-    const float center_validity = c.w;
-    const V3 center_value = xyz(c);
-    if (center_validity == 1) { st4(output_tex, x, y, v4(center_value, 1.0f)); return; }
-    const float center_depth = depth_tex.ld(x, y);
-    const float center_ssao = from_unorm8(ssao_tex.ld(x, y));
-    const V3 center_normal_vs = unpack_a2r10g10b10(geometric_normal_tex.ld(x, y)) * 2.0f - 1.0f;
-    const float ang_off = float((fc.frame_index * 23u) % 32u) * KJ_TAU + interleaved_gradient_noise(x, y) * KJ_PI;
-    const uint32_t MAX_SAMPLE_COUNT = 8;
-    const float MAX_RADIUS_PX = sqrtf(lerp(16.0f * 16.0f, 2.0f * 2.0f, center_validity));
-    const float KERNEL_SHARPNESS = 0.666f;
-    const uint32_t sample_count = min(max(uint32_t(exp2f(4.0f * square(1.0f - center_validity))), 2u), MAX_SAMPLE_COUNT);
-    V4 sum = v4(crunch(center_value), 1);
-    const float RADIUS_SAMPLE_MULT = MAX_RADIUS_PX / powf(float(MAX_SAMPLE_COUNT - 1), KERNEL_SHARPNESS);
-    for (uint32_t si = 1; si < MAX_SAMPLE_COUNT; ++si) {
-        const float ang = (float(si) + ang_off) * KJ_GOLDEN_ANGLE;
-        const float radius = powf(float(si), KERNEL_SHARPNESS) * RADIUS_SAMPLE_MULT;
-        const V2 so = cos_sin_turns(ang) * radius;
-        const int sx = int(float(x) + so.x), sy = int(float(y) + so.y);
-        const float sample_depth = depth_tex.ld(sx, sy);
-        if (sample_depth != 0 && si < sample_count) {
-            const V3 sample_val = xyz(ld4(input_tex, sx, sy));
-            const float sample_ssao = from_unorm8(ssao_tex.ld(sx, sy));
-            float wt = 1;
-            wt *= exp2f(-100.0f * fabsf(center_normal_vs.z * (center_depth / sample_depth - 1.0f)));
-            wt *= exp2f(-20.0f * fabsf(sample_ssao - center_ssao));
-            sum += v4(crunch(sample_val), 1.0f) * wt;
-        }
-    }
-    const float norm_factor = 1.0f / fmaxf(1e-5f, sum.w);
-    st4(output_tex, x, y, v4(uncrunch(xyz(sum) * norm_factor), 1.0f));
-}
+// spatial_filter.hlsl: rtdgi_resample.hip (k_spatial_filter)
 
 // ================================================================== host side
 struct KjRtdgi {
@@ -834,6 +584,7 @@ struct KjRtdgi {
     kj::DevBuf ray_counters;                    // KJ_COUNTER_SLOTS x (6 used of KJ_COUNTER_STRIDE) u64, see kj_vec.hpp
     bool profiling = false;                     // per-pass GPU timestamps (gpu-profiler scopes, kajiya-rg/src/graph.rs:941-944)
     bool count_traversal = false;               // instrumented trace kernels
+    int resample_variant = 0;                   // A/B switch of the resampling kernels' LDS staging (KJ_RTDGI_RESAMPLE_VARIANT; rtdgi_resample.hpp)
     static const int NUM_SCOPES = 11;
     hipEvent_t ev[NUM_SCOPES][2] = {};
     bool ev_valid[NUM_SCOPES] = {};
@@ -870,6 +621,7 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     KJ_REQUIRE(dev && out, "null argument");
     KjRtdgi* r = new KjRtdgi();
     r->dev = dev;
+    if (const char* v = getenv("KJ_RTDGI_RESAMPLE_VARIANT")) r->resample_variant = atoi(v);
     if (r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
     *out = r;
     return KJ_OK;
@@ -937,6 +689,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     void* half_ssao = r->get("half_ssao_tex", HB, s);
     void* half_view_normal = r->get("half_view_normal_tex", HB * 4, s);
     void* half_depth = r->get("half_depth_tex", HB * 4, s);
+    void* half_gbuf = r->get("half_gbuf", HB * 8, s);
     void *hit_normal_out, *hit_normal_hist; r->pingpong("rtdgi.hit_normal", 0, HB * 8, s, hit_normal_out, hit_normal_hist);
     void *candidate_out, *candidate_hist;   r->pingpong("rtdgi.candidate", 1, HB * 8, s, candidate_out, candidate_hist);
     void* candidate_radiance = r->get("candidate_radiance_tex", HB * 8, s);
@@ -976,7 +729,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
 
     if (mask & KJ_RTDGI_PASS_EXTRACT_HALF) {
         SCOPE_BEGIN(1);
-        hipLaunchKernelGGL(k_extract_half, gh, blk, 0, s, fc, gbuffer, depth, ssao, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), img<int8_t>(half_ssao, hw, hh), hr0, hr1);
+        hipLaunchKernelGGL(k_extract_half, gh, blk, 0, s, fc, gbuffer, depth, ssao, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), img<int8_t>(half_ssao, hw, hh), img<uint2>(half_gbuf, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(1);
     }
@@ -1034,9 +787,12 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         const uint32_t perform_occlusion_raymarch = (i + 1 == r->spatial_reuse_pass_count) ? 1u : 0u;
         if ((mask & KJ_RTDGI_PASS_RESTIR_SPATIAL) && (p->spatial_pass_select == 0 || p->spatial_pass_select == i + 1)) {
             SCOPE_BEGIN((6 + (i ? 1 : 0)));
-            hipLaunchKernelGGL(k_restir_spatial, gh, blk, 0, s, fc, img<uint2>(reservoir_input, hw, hh), img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh),
-                               img<int8_t>(half_ssao, hw, hh), img<uint4>(temporal_reservoir_packed, hw, hh), img<uint2>(reservoir_tex0, hw, hh), W, H, i, perform_occlusion_raymarch, r->use_raytraced_reservoir_visibility ? 1u : 0u, hr0, hr1);
-            KJ_CHECK_LAUNCH();
+            SpatialLaunch L;
+            L.fc = fc; L.reservoir_input = reservoir_input; L.half_gbuf = half_gbuf; L.half_depth = half_depth; L.temporal_reservoir_packed = temporal_reservoir_packed;
+            L.reservoir_output = reservoir_tex0; L.W = W; L.H = H; L.hw = hw; L.hh = hh;
+            L.pass_idx = i; L.perform_occlusion_raymarch = perform_occlusion_raymarch; L.occlusion_raymarch_importance_only = r->use_raytraced_reservoir_visibility ? 1u : 0u;
+            L.row0 = hr0; L.row1 = hr1; L.variant = r->resample_variant;
+            KJ_TRY_HIP(launch_restir_spatial(L, s));
             SCOPE_END((6 + (i ? 1 : 0)));
         }
         std::swap(reservoir_tex0, reservoir_tex1);
@@ -1049,23 +805,13 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
     }
     if (mask & KJ_RTDGI_PASS_RESTIR_RESOLVE) {
-        ResolveArgs a;
-        a.fc = fc;
-        a.radiance_tex = img<uint2>(radiance_out, hw, hh);
-        a.reservoir_input_tex = img<uint2>(reservoir_input, hw, hh);
-        a.gbuffer_tex = gbuffer; a.depth_tex = depth;
-        a.half_view_normal_tex = img<uint32_t>(half_view_normal, hw, hh);
-        a.half_depth_tex = img<float>(half_depth, hw, hh);
-        a.ssao_tex = ssao;
-        a.candidate_radiance_tex = img<uint2>(candidate_radiance, hw, hh);
-        a.candidate_hit_tex = img<uint2>(candidate_hit, hw, hh);
-        a.temporal_reservoir_packed_tex = img<uint4>(temporal_reservoir_packed, hw, hh);
-        a.irradiance_output_tex = img<uint2>(irradiance, W, H);
-        a.blue_noise = (const uint32_t*)r->dev->blue_noise.p;
+        ResolveLaunch L;
+        L.fc = fc; L.radiance = radiance_out; L.reservoir_input = reservoir_input; L.gbuffer = p->gbuffer_depth.gbuffer; L.depth = p->gbuffer_depth.depth;
+        L.half_gbuf = half_gbuf; L.ssao = p->ssao_tex; L.candidate_radiance = candidate_radiance; L.candidate_hit = candidate_hit;
+        L.temporal_reservoir_packed = temporal_reservoir_packed; L.blue_noise = r->dev->blue_noise.p; L.irradiance_output = irradiance;
+        L.W = W; L.H = H; L.hw = hw; L.hh = hh; L.row0 = fr0; L.row1 = fr1;
         SCOPE_BEGIN(8);
-        a.row0 = fr0; a.row1 = fr1;
-        hipLaunchKernelGGL(k_restir_resolve, gf, blk, 0, s, a);
-        KJ_CHECK_LAUNCH();
+        KJ_TRY_HIP(launch_restir_resolve(L, s));
         SCOPE_END(8);
     }
     if (mask & KJ_RTDGI_PASS_TEMPORAL_FILTER) {
@@ -1078,8 +824,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     }
     if (mask & KJ_RTDGI_PASS_SPATIAL_FILTER) {
         SCOPE_BEGIN(10);
-        hipLaunchKernelGGL(k_spatial_filter, gf, blk, 0, s, fc, img<uint2>(temporal_filtered, W, H), depth, ssao, geometric_normal, img<uint2>(spatial_filtered, W, H), fr0, fr1);
-        KJ_CHECK_LAUNCH();
+        KJ_TRY_HIP(launch_spatial_filter(fc, temporal_filtered, p->gbuffer_depth.depth, p->ssao_tex, p->gbuffer_depth.geometric_normal, spatial_filtered, W, H, fr0, fr1, s));
         SCOPE_END(10);
     }
     if (out) {

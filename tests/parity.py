@@ -82,11 +82,29 @@ def decode(raw_u8, fmt):
 # B10G11R11_UFLOAT keeps 6 / 6 / 5 mantissa bits: two values 1e-6 apart can land on either side of a rounding boundary, which moves the
 # stored value by a whole step (1.6 % / 3.1 %). A texel counts as mismatching only when it is off by MORE than one step.
 VECTOR_FORMATS = {"rgba32f"}     # rtdgi.ray_orig: xyz = ray origin in world space
+EXACT_FORMATS = {"u32", "reservoir"}   # integer-coded channels (rng state, reservoir payload coordinates): no absolute slack
 RTOL = {"r11g11b10f": np.array([1.0 / 64, 1.0 / 64, 1.0 / 32]) * 1.02}
 
 
-def compare(a_raw, b_raw, fmt, atol=0.0):
-    """Returns dict(rel_l2, mismatch_frac, max_abs, n). NaN==NaN and inf==inf count as equal."""
+ATOL_RMS = 1e-4   # see compare()
+
+
+def is_vector(name):
+    """Surfaces whose texel is a world-space vector (a ray, a hit offset, a ray origin): judged against the vector's magnitude."""
+    return base_name(name) in VECTOR_SURFACES
+
+
+VECTOR_SURFACES = {"rtdgi.ray_orig", "rtdgi.ray", "candidate_hit_tex", "rtr.ray", "rtr.ray_orig"}
+
+
+def compare(a_raw, b_raw, fmt, atol=0.0, vector=False):
+    """Returns dict(rel_l2, mismatch_frac, max_abs, n, ...). NaN==NaN and inf==inf count as equal.
+
+    A texel is an OUTLIER (counted in mismatch_frac) when a channel is off by more than 0.1 % of its own value + 0.01 % of the
+    image's RMS level. The second term is what makes the count meaningful for ill-conditioned channels -- a variance formed as
+    E[x^2] - E[x]^2, a near-black texel of a bright image -- whose relative error is unbounded however exact the arithmetic;
+    it is 1/10 of the rel-L2 bar, so it cannot hide an error that matters to the image. For `vector` surfaces the 0.1 % is
+    taken of the texel's largest component (a hit offset of 1e4 units along x has no meaningful relative error in its y)."""
     a, b = decode(a_raw, fmt).astype(np.float64), decode(b_raw, fmt).astype(np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
     both_nan = np.isnan(a) & np.isnan(b)
@@ -97,9 +115,12 @@ def compare(a_raw, b_raw, fmt, atol=0.0):
     d = np.where(fin, a - b, 0.0)
     ref = np.where(fin, b, 0.0)
     num, den = np.sqrt((d * d).sum()), np.sqrt((ref * ref).sum())
-    tol = atol + RTOL.get(fmt, 1e-3) * np.abs(ref)
-    if fmt in VECTOR_FORMATS:   # a world-space position: 1e-3 of the vector's magnitude (a component that happens to be ~0 has no scale of its own)
-        tol = atol + 1e-3 * np.abs(ref[..., :3]).max(axis=-1, keepdims=True) * np.ones_like(ref)
+    rms = den / np.sqrt(max(1, ref.size))
+    mag = np.abs(ref)
+    if vector or fmt in VECTOR_FORMATS:
+        mag = np.abs(ref[..., :3]).max(axis=-1, keepdims=True) * np.ones_like(ref)
+        mag[..., 3:] = np.abs(ref[..., 3:])
+    tol = atol + RTOL.get(fmt, 1e-3) * mag + (0.0 if fmt in EXACT_FORMATS else ATOL_RMS * rms)
     mism = ((np.abs(d) > tol) & fin) | bad_class
     texel_mism = mism.any(axis=-1)
     din = np.where(texel_mism[..., None], 0.0, d)     # the image without its outlier texels (a flipped reservoir pick replaces the whole texel)
@@ -118,7 +139,17 @@ def within_bars(r, rel_l2_tol=REL_L2_TOL, mismatch_tol=MISMATCH_TOL):
 
 
 def within_bars_with_flips(r, flip_tol=MISMATCH_TOL, outlier_cap=1e-2):
-    """For surfaces downstream of a stochastic pick (rtr's reservoirs carry radiance spanning decades, so ONE flipped pick in 40 k texels
-    moves the whole-image L2 past 1e-3): the outlier texels are counted and capped, everything else meets the 1e-3 bar, and the
-    outliers may not dominate the image either."""
+    """For the outputs of passes that take DISCRETE decisions on float comparisons -- a shadow ray grazing an edge, the 5e-3 depth
+    gate that picks last frame's radiance or the irradiance cache for a hit (diffuse_trace_common.inc.hlsl:85-107), a reservoir's
+    `w / w_sum >= dart` -- a last-bit difference replaces a texel's whole value, and with radiance spanning decades ONE such texel
+    in 10^5 moves the whole-image L2 past 1e-3. There the outlier texels are counted and capped (<= 0.2 %, or 8 texels on a tiny
+    image), every other texel meets the 1e-3 bar as an image, and the outliers may not dominate the image either (<= 1e-2)."""
+    flip_tol = max(flip_tol, 8.0 / max(1, r["n"]))
     return r["rel_l2_inliers"] <= REL_L2_TOL and r["mismatch_frac"] <= flip_tol and r["rel_l2"] <= outlier_cap and r.get("bad_class", 0) == 0
+
+
+RAY_PASSES = {"VALIDATE", "TRACE"}   # rtdgi / rtr passes whose outputs carry such decisions
+
+
+def pass_within_bars(pass_name, r):
+    return within_bars_with_flips(r) if pass_name in RAY_PASSES else within_bars(r)

@@ -74,7 +74,7 @@ def test_rtr_per_pass_parity(gpu, oracle, device, W, H, reuse):
             torch.cuda.synchronize()
             ref, got = _oracle_rtr_state(op), _download_rtr_state(gp, torch)
             for n in ref:
-                r = P.compare(got[n], ref[n], P.fmt_of(n))
+                r = P.compare(got[n], ref[n], P.fmt_of(n), vector=P.is_vector(n))
                 key = (pname, P.base_name(n))
                 if key not in worst or r["rel_l2"] > worst[key]["rel_l2"]:
                     worst[key] = r
