@@ -6,6 +6,8 @@
 #include "kj_host.hpp"
 #include "kj_scene.hpp"
 #include "kj_screen.hpp"
+#include <cstdlib>
+#include <algorithm>
 
 using namespace kj;
 
@@ -158,6 +160,8 @@ __global__ void __launch_bounds__(64) k_reprojection_map(const FrameConstants* _
 }
 
 // ------------------------------------------------------------------ raw ray queries
+// Ray streams (kj_bvh.hpp: bvh_trace_stream): persistent waves, lanes refill as rays finish. KJ_TRACE_PER_RAY=1 selects the
+// one-ray-per-lane kernels (A/B measurements, scripts/traversal_microbench.py).
 __global__ void __launch_bounds__(64) k_trace_closest(SceneView sc, const float4* __restrict__ rays, float4* __restrict__ hits, uint32_t count, int cull_back) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
@@ -172,6 +176,16 @@ __global__ void __launch_bounds__(64) k_trace_any(SceneView sc, const float4* __
     if (i >= count) return;
     const float4 a = rays[i * 2], b = rays[i * 2 + 1];
     out[i] = bvh_trace<true>(sc.bvh, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, a.w, b.w, false, lds_stack + threadIdx.x, 64).slot != 0xffffffffu ? 1 : 0;
+}
+__global__ void __launch_bounds__(64) k_trace_closest_stream(SceneView sc, const float4* __restrict__ rays, float4* __restrict__ hits, uint32_t count, int cull_back, StreamTune tune) {
+    extern __shared__ uint32_t lds_stack[];
+    bvh_trace_stream<false>(sc.bvh, rays, count, cull_back != 0, blockIdx.x, gridDim.x, lds_stack + threadIdx.x, 64,
+                            [&](uint32_t i, const RayHit& h) { hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.world_id)); }, tune);
+}
+__global__ void __launch_bounds__(64) k_trace_any_stream(SceneView sc, const float4* __restrict__ rays, uint8_t* __restrict__ out, uint32_t count, StreamTune tune) {
+    extern __shared__ uint32_t lds_stack[];
+    bvh_trace_stream<true>(sc.bvh, rays, count, false, blockIdx.x, gridDim.x, lds_stack + threadIdx.x, 64,
+                           [&](uint32_t i, const RayHit& h) { out[i] = h.slot != 0xffffffffu ? 1 : 0; }, tune);
 }
 
 // light_gbuffer.hlsl:60-260 — the deferred combine: sun direct light through the shadow mask, emissive, diffuse
@@ -383,12 +397,28 @@ KjStatus kj_raster_gbuffer(KjDevice* dev, KjScene* scene, uint32_t W, uint32_t H
     return KJ_OK;
 }
 
+// persistent waves of a ray-stream launch: enough to fill the chip (KJ_STREAM_WAVES_PER_CU per CU, default 24), never more than chunks
+static uint32_t stream_waves(const KjDevice* dev, uint32_t count) {
+    const uint32_t per_cu = getenv("KJ_STREAM_WAVES_PER_CU") ? uint32_t(atoi(getenv("KJ_STREAM_WAVES_PER_CU"))) : 24u;
+    const uint32_t chunks = (count + KJ_STREAM_CHUNK - 1u) / KJ_STREAM_CHUNK;
+    return std::max(1u, std::min(chunks, dev->num_cus * per_cu));
+}
+static StreamTune stream_tune() {   // scheduling knobs, overridable for measurements
+    StreamTune t{16u, 1u, 1u};
+    if (const char* v = getenv("KJ_STREAM_REFILL")) t.refill_threshold = uint32_t(atoi(v));
+    if (const char* v = getenv("KJ_STREAM_NODE_WEIGHT")) t.node_weight = uint32_t(atoi(v));
+    if (const char* v = getenv("KJ_STREAM_TRI_WEIGHT")) t.tri_weight = uint32_t(atoi(v));
+    return t;
+}
 KjStatus kj_trace_closest(KjScene* scene, const void* rays, void* hits, uint32_t count, uint32_t cull_back_faces, void* stream) {
     KJ_REQUIRE(scene && rays && hits, "null argument");
     if (!scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
     if (count == 0) return KJ_OK;
     const SceneView sv = scene_view(*scene);
-    hipLaunchKernelGGL(k_trace_closest, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (float4*)hits, count, int(cull_back_faces));
+    if (getenv("KJ_TRACE_PER_RAY"))
+        hipLaunchKernelGGL(k_trace_closest, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (float4*)hits, count, int(cull_back_faces));
+    else
+        hipLaunchKernelGGL(k_trace_closest_stream, dim3(stream_waves(scene->dev, count)), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (float4*)hits, count, int(cull_back_faces), stream_tune());
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }
@@ -397,7 +427,10 @@ KjStatus kj_trace_any(KjScene* scene, const void* rays, void* out_u8, uint32_t c
     if (!scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
     if (count == 0) return KJ_OK;
     const SceneView sv = scene_view(*scene);
-    hipLaunchKernelGGL(k_trace_any, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count);
+    if (getenv("KJ_TRACE_PER_RAY"))
+        hipLaunchKernelGGL(k_trace_any, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count);
+    else
+        hipLaunchKernelGGL(k_trace_any_stream, dim3(stream_waves(scene->dev, count)), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count, stream_tune());
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }

@@ -2,15 +2,16 @@
 // (inc/rt.hlsl:58-70,112-137; BLAS/TLAS in kajiya-backend/src/vulkan/ray_tracing.rs).
 //
 // Layout (built by bvh_build.cpp, resident in HBM / Infinity Cache):
-//   (KJ_BVH_WIDTH 8 selects the 80-B Bvh8Node variant, see kj_scene_types.hpp and the #if in bvh_trace)
 //   Bvh4Node 64 B : up to four children; each child's AABB is 6 bytes (8 bits per plane) inside the node's own
 //                   frame (origin + power-of-two step per axis). One visit = 3.5 x 16-B loads per lane and tests
 //                   four boxes, so a ray takes about half the dependent steps and a quarter of the node bytes
 //                   of a two-box fp32 node. Decoded planes are fma(q, step, origin): never inside the true box.
 //   BvhTri   48 B : world-space fp32 vertices + ids, stored in leaf order (3 x 16-B loads).
 // Child reference: bit31 = leaf; leaf => bits[30:28] = count-1, bits[27:0] = first tri slot; 0xffffffff = empty.
-// Traversal: one loop, nearest child first (4-key sorting network on the entry distances), per-lane stack in
-// LDS laid out [level][lane] (bank-conflict free: consecutive lanes hit consecutive banks).
+// Traversal: nearest child first (4-key sorting network on the entry distances), per-lane stack in LDS laid out
+// [level][lane] (bank-conflict free: consecutive lanes hit consecutive banks). Two drivers share the step functions:
+// bvh_trace() (one ray per lane, inside a caller's kernel) and bvh_trace_stream() (a persistent wave over a ray array:
+// lanes refill as their rays finish, and each wave step issues the block -- node or triangle -- most lanes wait for).
 // Ray/triangle: Moller-Trumbore, FP contraction OFF so (t,u,v) are bit-identical to
 // the oracle; equal-t ties go to the lowest world triangle id.
 #pragma once
@@ -79,192 +80,200 @@ struct TraverseStats { uint32_t nodes, tris; };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 KJ_D float q8(uint32_t packed, int i) { return float((packed >> (8 * i)) & 0xffu); }   // v_cvt_f32_ubyte<i>
-KJ_D uint32_t sel4(uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d)); }
 
-template <bool ANY_HIT, bool STATS = false>
-KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bool cull_back, uint32_t* stack, uint32_t stride, TraverseStats* stats = nullptr) {
+#define KJ_BVH_NONE 0xffffffffu
+#if KJ_BVH_WIDTH != 4
+#error "the traversal is written for the 4-wide node (an 8-wide variant measured 24 % slower in round 1 and was dropped)"
+#endif
+
+// One ray in flight. `cur` is the reference about to be visited (a node, a leaf's next triangle, or KJ_BVH_NONE = finished).
+struct RayState {
+    V3 o, d, inv_d;
+    float tmin, tmax;
     RayHit h;
-    h.t = FLT_MAX; h.u = 0; h.v = 0; h.slot = 0xffffffffu; h.world_id = 0xffffffffu;
+    uint32_t sp, cur;
+    bool cull_back;
+};
+
+template <bool ANY_HIT>
+KJ_D void ray_begin(RayState& S, V3 o, V3 d, float tmin, float tmax, bool cull_back) {
+    S.o = o; S.d = d; S.tmin = tmin; S.tmax = tmax; S.cull_back = cull_back;
+    S.h.t = FLT_MAX; S.h.u = 0; S.h.v = 0; S.h.slot = 0xffffffffu; S.h.world_id = 0xffffffffu;
+    S.sp = 0;
     // Rays with a non-finite origin or direction are misses (the reference's validation pass issues such
     // rays for pixels without history; a hardware traversal unit rejects every box for them). Without
     // this, NaN slabs pass the fmin/fmax test and the whole tree is walked.
-    if (!(fabsf(o.x) <= FLT_MAX && fabsf(o.y) <= FLT_MAX && fabsf(o.z) <= FLT_MAX && fabsf(d.x) <= FLT_MAX && fabsf(d.y) <= FLT_MAX && fabsf(d.z) <= FLT_MAX)) return h;
+    const bool finite = fabsf(o.x) <= FLT_MAX && fabsf(o.y) <= FLT_MAX && fabsf(o.z) <= FLT_MAX && fabsf(d.x) <= FLT_MAX && fabsf(d.y) <= FLT_MAX && fabsf(d.z) <= FLT_MAX;
+    S.cur = finite ? 0u : KJ_BVH_NONE;   // node 0 is the root
     const float eps = 1e-20f;
-    const V3 inv_d{1.0f / (fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x), 1.0f / (fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y),
-                   1.0f / (fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z)};
-    // Traversal stack: the first KJ_BVH_LDS_STACK entries live in LDS ([level][lane]); the rare deeper ones spill to a
-    // private array (scratch). Near-first ordering keeps a typical ray's stack far below the builder's worst-case bound,
-    // so the LDS footprint (4 KB / wave) no longer caps occupancy the way a bound-sized LDS stack did (11 KB / wave).
-    uint32_t spill[KJ_BVH_SPILL_STACK];
-#define KJ_PUSH(v_) { const uint32_t pv_ = (v_); if (sp < KJ_BVH_LDS_STACK) stack[sp * stride] = pv_; else spill[sp - KJ_BVH_LDS_STACK] = pv_; sp++; }
-#define KJ_POP(dst_) { if (sp == 0) dst_ = NONE; else { --sp; dst_ = sp < KJ_BVH_LDS_STACK ? stack[sp * stride] : spill[sp - KJ_BVH_LDS_STACK]; } }
+    S.inv_d = V3{1.0f / (fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x), 1.0f / (fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y),
+                 1.0f / (fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z)};
+}
+
+// Traversal stack: the first KJ_BVH_LDS_STACK entries live in LDS ([level][lane]); the rare deeper ones spill to a
+// private array (scratch). Near-first ordering keeps a typical ray's stack far below the builder's worst-case bound,
+// so the LDS footprint (4 KB / wave) does not cap occupancy the way a bound-sized LDS stack did (11 KB / wave).
+#define KJ_PUSH(v_) { const uint32_t pv_ = (v_); if (S.sp < KJ_BVH_LDS_STACK) stack[S.sp * stride] = pv_; else spill[S.sp - KJ_BVH_LDS_STACK] = pv_; S.sp++; }
+#define KJ_POP(dst_) { if (S.sp == 0) dst_ = KJ_BVH_NONE; else { --S.sp; dst_ = S.sp < KJ_BVH_LDS_STACK ? stack[S.sp * stride] : spill[S.sp - KJ_BVH_LDS_STACK]; } }
+
+// Visit the 4-wide node S.cur: test its four quantised child boxes, continue with the nearest hit child, push the others.
+template <bool ANY_HIT, bool STATS>
+KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
+    const uint32_t NONE = KJ_BVH_NONE;
+    const float4* __restrict__ n = (const float4*)bvh.nodes + size_t(S.cur) * 4;
+    const float4 n0 = n[0];
+    const uint4 ch = *(const uint4*)(n + 1);
+    const uint4 qa = *(const uint4*)(n + 2);     // qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4]
+    const uint2 qb = *(const uint2*)(n + 3);     // qhi.y[4], qhi.z[4]
+    if (STATS) stats->nodes++;
+    const V3 o = S.o, inv_d = S.inv_d;
+    const float tmin = S.tmin;
     const bool neg_x = inv_d.x < 0.0f, neg_y = inv_d.y < 0.0f, neg_z = inv_d.z < 0.0f;
-    uint32_t sp = 0;
-    uint32_t cur = 0;   // root node
-    const uint32_t NONE = 0xffffffffu;
-    // One loop, one step per iteration: a node visit or ONE triangle test. (A while-while variant that parks lanes until the
-    // whole wave has a leaf measured 25 % slower with these short 4-wide descents; testing a whole leaf per iteration makes
-    // every iteration of a mixed wave pay for up to four triangle tests.)
-    while (cur != NONE) {
-#if KJ_BVH_WIDTH == 8
-        if (!(cur & KJ_BVH_LEAF)) {
-            // 8-wide node, 80 B = 5 x 16-B loads: fewer dependent steps per ray than the 4-wide tree at ~2x the ALU per step.
-            const float4* __restrict__ n = (const float4*)bvh.nodes + size_t(cur) * 5;
-            const float4 n0 = n[0];
-            const uint4 m = *(const uint4*)(n + 1);      // child_base, tri_base, meta[0..3], meta[4..7]
-            const uint4 qa = *(const uint4*)(n + 2);     // qlo.x[0..3], qlo.x[4..7], qlo.y[0..3], qlo.y[4..7]
-            const uint4 qb = *(const uint4*)(n + 3);     // qlo.z[0..3], qlo.z[4..7], qhi.x[0..3], qhi.x[4..7]
-            const uint4 qc = *(const uint4*)(n + 4);     // qhi.y[0..3], qhi.y[4..7], qhi.z[0..3], qhi.z[4..7]
-            if (STATS) stats->nodes++;
-            const float tlimit = ANY_HIT ? tmax : fminf(h.t, tmax);
-            const uint32_t e = __float_as_uint(n0.w);
-            const uint32_t nch = e >> 24;
-            const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23), sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
-            // near / far plane bytes picked once per node from the ray's direction signs; [0] = children 0..3, [1] = children 4..7
-            const uint32_t nqx[2] = {neg_x ? qb.z : qa.x, neg_x ? qb.w : qa.y}, fqx[2] = {neg_x ? qa.x : qb.z, neg_x ? qa.y : qb.w};
-            const uint32_t nqy[2] = {neg_y ? qc.x : qa.z, neg_y ? qc.y : qa.w}, fqy[2] = {neg_y ? qa.z : qc.x, neg_y ? qa.w : qc.y};
-            const uint32_t nqz[2] = {neg_z ? qc.z : qb.x, neg_z ? qc.w : qb.y}, fqz[2] = {neg_z ? qb.x : qc.z, neg_z ? qb.y : qc.w};
-            const float bx = n0.x - o.x, by = n0.y - o.y, bz = n0.z - o.z;
-            uint32_t key[8];
+    const float tlimit = ANY_HIT ? S.tmax : fminf(S.h.t, S.tmax);
+    const uint32_t e = __float_as_uint(n0.w);
+    const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23), sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
+    // The kernels that call this are VALU-bound, so the four slab tests are written for few instructions:
+    //  * the ray's direction signs pick the near / far plane bytes once per node (6 selects) instead of a min/max per plane;
+    //  * `origin - o` is folded into the decode: plane - o = fma(q, step, origin - o) (one more rounding than the builder's
+    //    check, i.e. <= 1 ulp of the plane distance -- covered many times over by the slack on the far side below);
+    //  * children are processed in pairs so the compiler can use packed-fp32 fma / mul (v_pk_fma_f32, v_pk_mul_f32).
+    const uint32_t nqx = neg_x ? qa.w : qa.x, fqx = neg_x ? qa.x : qa.w;
+    const uint32_t nqy = neg_y ? qb.x : qa.y, fqy = neg_y ? qa.y : qb.x;
+    const uint32_t nqz = neg_z ? qb.y : qa.z, fqz = neg_z ? qa.z : qb.y;
+    const float bx = n0.x - o.x, by = n0.y - o.y, bz = n0.z - o.z;
+    uint32_t key[4];
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
-                const int w = pr >> 1, i0 = (pr & 1) * 2, i1 = i0 + 1;
-                const f32x2 tnx = __builtin_elementwise_fma(f32x2{q8(nqx[w], i0), q8(nqx[w], i1)}, f32x2{sx, sx}, f32x2{bx, bx}) * f32x2{inv_d.x, inv_d.x};
-                const f32x2 tny = __builtin_elementwise_fma(f32x2{q8(nqy[w], i0), q8(nqy[w], i1)}, f32x2{sy, sy}, f32x2{by, by}) * f32x2{inv_d.y, inv_d.y};
-                const f32x2 tnz = __builtin_elementwise_fma(f32x2{q8(nqz[w], i0), q8(nqz[w], i1)}, f32x2{sz, sz}, f32x2{bz, bz}) * f32x2{inv_d.z, inv_d.z};
-                const f32x2 tfx = __builtin_elementwise_fma(f32x2{q8(fqx[w], i0), q8(fqx[w], i1)}, f32x2{sx, sx}, f32x2{bx, bx}) * f32x2{inv_d.x, inv_d.x};
-                const f32x2 tfy = __builtin_elementwise_fma(f32x2{q8(fqy[w], i0), q8(fqy[w], i1)}, f32x2{sy, sy}, f32x2{by, by}) * f32x2{inv_d.y, inv_d.y};
-                const f32x2 tfz = __builtin_elementwise_fma(f32x2{q8(fqz[w], i0), q8(fqz[w], i1)}, f32x2{sz, sz}, f32x2{bz, bz}) * f32x2{inv_d.z, inv_d.z};
+    for (int pr = 0; pr < 2; ++pr) {
+        const int i0 = pr * 2, i1 = pr * 2 + 1;
+        const f32x2 tnx = __builtin_elementwise_fma(f32x2{q8(nqx, i0), q8(nqx, i1)}, f32x2{sx, sx}, f32x2{bx, bx}) * f32x2{inv_d.x, inv_d.x};
+        const f32x2 tny = __builtin_elementwise_fma(f32x2{q8(nqy, i0), q8(nqy, i1)}, f32x2{sy, sy}, f32x2{by, by}) * f32x2{inv_d.y, inv_d.y};
+        const f32x2 tnz = __builtin_elementwise_fma(f32x2{q8(nqz, i0), q8(nqz, i1)}, f32x2{sz, sz}, f32x2{bz, bz}) * f32x2{inv_d.z, inv_d.z};
+        const f32x2 tfx = __builtin_elementwise_fma(f32x2{q8(fqx, i0), q8(fqx, i1)}, f32x2{sx, sx}, f32x2{bx, bx}) * f32x2{inv_d.x, inv_d.x};
+        const f32x2 tfy = __builtin_elementwise_fma(f32x2{q8(fqy, i0), q8(fqy, i1)}, f32x2{sy, sy}, f32x2{by, by}) * f32x2{inv_d.y, inv_d.y};
+        const f32x2 tfz = __builtin_elementwise_fma(f32x2{q8(fqz, i0), q8(fqz, i1)}, f32x2{sz, sz}, f32x2{bz, bz}) * f32x2{inv_d.z, inv_d.z};
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int i = pr * 2 + k;
-                    const float tn = fmaxf(fmaxf(fmaxf(tnx[k], tny[k]), tnz[k]), tmin);
-                    const float tf = fminf(fminf(fminf(tfx[k], tfy[k]), tfz[k]), tlimit);
-                    const bool hit = (tn <= tf * 1.000001f + 1e-30f) && uint32_t(i) < nch;    // children occupy slots 0..nch-1
-                    key[i] = hit ? ((__float_as_uint(tn) & 0x7ffffff8u) | uint32_t(i)) : NONE;  // tn >= tmin >= 0: float order == integer order
-                }
-            }
-            // sort ascending by entry distance (19-comparator network for 8 keys); misses (NONE) sink to the end
-#define KJ_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
-            KJ_CSWAP(0, 1) KJ_CSWAP(2, 3) KJ_CSWAP(4, 5) KJ_CSWAP(6, 7) KJ_CSWAP(0, 2) KJ_CSWAP(1, 3) KJ_CSWAP(4, 6) KJ_CSWAP(5, 7)
-            KJ_CSWAP(1, 2) KJ_CSWAP(5, 6) KJ_CSWAP(0, 4) KJ_CSWAP(3, 7) KJ_CSWAP(1, 5) KJ_CSWAP(2, 6) KJ_CSWAP(1, 4) KJ_CSWAP(3, 6)
-            KJ_CSWAP(2, 4) KJ_CSWAP(3, 5) KJ_CSWAP(3, 4)
-#undef KJ_CSWAP
-            // child reference from the slot index: meta byte -> node index (child_base + rank) or leaf reference
-#define KJ_REF8(k_, dst_) { const uint32_t i_ = (k_) & 7u; const uint32_t mb_ = (((i_ & 4u) ? m.w : m.z) >> ((i_ & 3u) * 8u)) & 0xffu; \
-                            dst_ = (mb_ & 0x80u) ? (KJ_BVH_LEAF | (((mb_ >> 5) & 3u) << 28) | (m.y + (mb_ & 31u))) : (m.x + mb_); }
-#pragma unroll
-            for (int j = 7; j >= 1; --j)
-                if (key[j] != NONE) { uint32_t r_; KJ_REF8(key[j], r_) KJ_PUSH(r_) }
-            if (key[0] != NONE) { KJ_REF8(key[0], cur) }
-            else KJ_POP(cur)
-#undef KJ_REF8
-#else
-        if (!(cur & KJ_BVH_LEAF)) {
-            const float4* __restrict__ n = (const float4*)bvh.nodes + size_t(cur) * 4;
-            const float4 n0 = n[0];
-            const uint4 ch = *(const uint4*)(n + 1);
-            const uint4 qa = *(const uint4*)(n + 2);     // qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4]
-            const uint2 qb = *(const uint2*)(n + 3);     // qhi.y[4], qhi.z[4]
-            if (STATS) stats->nodes++;
-            const float tlimit = ANY_HIT ? tmax : fminf(h.t, tmax);
-            const uint32_t e = __float_as_uint(n0.w);
-            const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23), sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
-            // The kernels that call this are VALU-bound, so the four slab tests are written for few instructions:
-            //  * the ray's direction signs pick the near / far plane bytes once per node (6 selects) instead of a min/max per plane;
-            //  * `origin - o` is folded into the decode: plane - o = fma(q, step, origin - o) (one more rounding than the builder's
-            //    check, i.e. <= 1 ulp of the plane distance -- covered many times over by the slack on the far side below);
-            //  * children are processed in pairs so the compiler can use packed-fp32 fma / mul (v_pk_fma_f32, v_pk_mul_f32).
-            const uint32_t nqx = neg_x ? qa.w : qa.x, fqx = neg_x ? qa.x : qa.w;
-            const uint32_t nqy = neg_y ? qb.x : qa.y, fqy = neg_y ? qa.y : qb.x;
-            const uint32_t nqz = neg_z ? qb.y : qa.z, fqz = neg_z ? qa.z : qb.y;
-            const float bx = n0.x - o.x, by = n0.y - o.y, bz = n0.z - o.z;
-            uint32_t key[4];
-#ifdef KJ_BVH_FOLD_INVD
-            // experiment (scripts/build_variant.sh): t = fma(q, step * inv_d, (origin - o) * inv_d) — six multiplies per node instead of one per plane.
-            // Rounds differently from the builder's check by ~1 ulp of the larger term; hits stay exact (triangles decide), only box culling moves.
-            const float sxi = sx * inv_d.x, syi = sy * inv_d.y, szi = sz * inv_d.z, bxi = bx * inv_d.x, byi = by * inv_d.y, bzi = bz * inv_d.z;
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int i0 = pr * 2, i1 = pr * 2 + 1;
-                const f32x2 tnx = __builtin_elementwise_fma(f32x2{q8(nqx, i0), q8(nqx, i1)}, f32x2{sxi, sxi}, f32x2{bxi, bxi});
-                const f32x2 tny = __builtin_elementwise_fma(f32x2{q8(nqy, i0), q8(nqy, i1)}, f32x2{syi, syi}, f32x2{byi, byi});
-                const f32x2 tnz = __builtin_elementwise_fma(f32x2{q8(nqz, i0), q8(nqz, i1)}, f32x2{szi, szi}, f32x2{bzi, bzi});
-                const f32x2 tfx = __builtin_elementwise_fma(f32x2{q8(fqx, i0), q8(fqx, i1)}, f32x2{sxi, sxi}, f32x2{bxi, bxi});
-                const f32x2 tfy = __builtin_elementwise_fma(f32x2{q8(fqy, i0), q8(fqy, i1)}, f32x2{syi, syi}, f32x2{byi, byi});
-                const f32x2 tfz = __builtin_elementwise_fma(f32x2{q8(fqz, i0), q8(fqz, i1)}, f32x2{szi, szi}, f32x2{bzi, bzi});
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int i = pr * 2 + k;
-                    const float tn = fmaxf(fmaxf(fmaxf(tnx[k], tny[k]), tnz[k]), tmin);
-                    const float tf = fminf(fminf(fminf(tfx[k], tfy[k]), tfz[k]), tlimit);
-                    const uint32_t c = i == 0 ? ch.x : (i == 1 ? ch.y : (i == 2 ? ch.z : ch.w));
-                    const bool hit = (tn <= tf * 1.00001f + 1e-30f) && c != NONE;      // wider far-side slack for the extra rounding
-                    key[i] = hit ? __float_as_uint(tn) : NONE;
-                }
-            }
-#else
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int i0 = pr * 2, i1 = pr * 2 + 1;
-                const f32x2 tnx = __builtin_elementwise_fma(f32x2{q8(nqx, i0), q8(nqx, i1)}, f32x2{sx, sx}, f32x2{bx, bx}) * f32x2{inv_d.x, inv_d.x};
-                const f32x2 tny = __builtin_elementwise_fma(f32x2{q8(nqy, i0), q8(nqy, i1)}, f32x2{sy, sy}, f32x2{by, by}) * f32x2{inv_d.y, inv_d.y};
-                const f32x2 tnz = __builtin_elementwise_fma(f32x2{q8(nqz, i0), q8(nqz, i1)}, f32x2{sz, sz}, f32x2{bz, bz}) * f32x2{inv_d.z, inv_d.z};
-                const f32x2 tfx = __builtin_elementwise_fma(f32x2{q8(fqx, i0), q8(fqx, i1)}, f32x2{sx, sx}, f32x2{bx, bx}) * f32x2{inv_d.x, inv_d.x};
-                const f32x2 tfy = __builtin_elementwise_fma(f32x2{q8(fqy, i0), q8(fqy, i1)}, f32x2{sy, sy}, f32x2{by, by}) * f32x2{inv_d.y, inv_d.y};
-                const f32x2 tfz = __builtin_elementwise_fma(f32x2{q8(fqz, i0), q8(fqz, i1)}, f32x2{sz, sz}, f32x2{bz, bz}) * f32x2{inv_d.z, inv_d.z};
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int i = pr * 2 + k;
-                    const float tn = fmaxf(fmaxf(fmaxf(tnx[k], tny[k]), tnz[k]), tmin);
-                    const float tf = fminf(fminf(fminf(tfx[k], tfy[k]), tfz[k]), tlimit);
-                    // conservative acceptance (a few ulps of slack on the far side); empty slots hold an inverted box and a NONE reference
-                    const uint32_t c = i == 0 ? ch.x : (i == 1 ? ch.y : (i == 2 ? ch.z : ch.w));
-                    const bool hit = (tn <= tf * 1.000001f + 1e-30f) && c != NONE;
-                    key[i] = hit ? __float_as_uint(tn) : NONE;   // tn >= tmin >= 0: float order == integer order
-                }
-            }
-#endif
-            // The traversal is instruction-issue bound (an 8-wide tree with 30 % fewer node visits ran 24 % slower), so this tail is
-            // branch-free: (key, reference) pairs go through a 5-comparator network as selects — no index bits, no select chain — and
-            // the three farther children are stored to the LDS stack unconditionally, the stack pointer advancing only for hits
-            // (sorted order puts the hits first; a non-hit's store is overwritten by the next push or ignored).
-            uint32_t ref[4] = {ch.x, ch.y, ch.z, ch.w};
-#define KJ_CSWAP(a, b) { const bool sw_ = key[b] < key[a]; const uint32_t ka_ = key[a], kb_ = key[b], ra_ = ref[a], rb_ = ref[b]; \
-                         key[a] = sw_ ? kb_ : ka_; key[b] = sw_ ? ka_ : kb_; ref[a] = sw_ ? rb_ : ra_; ref[b] = sw_ ? ra_ : rb_; }
-            // closest-hit rays visit children nearest first; occlusion rays take them in slot order: any hit ends the ray, the push logic below
-            // is order-agnostic, and skipping the network measured +8 % any-hit rays/s (3.16 -> 3.42 G/s) for a few more node visits
-            if (!ANY_HIT) { KJ_CSWAP(0, 1) KJ_CSWAP(2, 3) KJ_CSWAP(0, 2) KJ_CSWAP(1, 3) KJ_CSWAP(1, 2) }
-#undef KJ_CSWAP
-            if (sp + 3u <= KJ_BVH_LDS_STACK) {
-                stack[sp * stride] = ref[3]; sp += key[3] != NONE ? 1u : 0u;
-                stack[sp * stride] = ref[2]; sp += key[2] != NONE ? 1u : 0u;
-                stack[sp * stride] = ref[1]; sp += key[1] != NONE ? 1u : 0u;
-            } else {   // deep lanes: entries beyond the LDS part spill to private memory
-                if (key[3] != NONE) KJ_PUSH(ref[3])
-                if (key[2] != NONE) KJ_PUSH(ref[2])
-                if (key[1] != NONE) KJ_PUSH(ref[1])
-            }
-            if (key[0] != NONE) cur = ref[0];
-            else KJ_POP(cur)
-#endif
-        } else {
-            const uint32_t first = cur & 0x0fffffffu;
-            const uint32_t rest = (cur >> 28) & 7u;      // triangles left after this one
-            const float4* __restrict__ tp = (const float4*)bvh.tris + size_t(first) * 3;
-            const float4 a = tp[0], b = tp[1], c = tp[2];
-            if (STATS) stats->tris++;
-            if (intersect_tri(o, d, tmin, tmax, a, b, c, first, cull_back, h)) {
-                if (ANY_HIT) return h;
-            }
-            if (rest) cur = KJ_BVH_LEAF | ((rest - 1u) << 28) | (first + 1u);
-            else KJ_POP(cur)
+        for (int k = 0; k < 2; ++k) {
+            const int i = pr * 2 + k;
+            const float tn = fmaxf(fmaxf(fmaxf(tnx[k], tny[k]), tnz[k]), tmin);
+            const float tf = fminf(fminf(fminf(tfx[k], tfy[k]), tfz[k]), tlimit);
+            // conservative acceptance (a few ulps of slack on the far side); empty slots hold an inverted box and a NONE reference
+            const uint32_t c = i == 0 ? ch.x : (i == 1 ? ch.y : (i == 2 ? ch.z : ch.w));
+            const bool hit = (tn <= tf * 1.000001f + 1e-30f) && c != NONE;
+            key[i] = hit ? __float_as_uint(tn) : NONE;   // tn >= tmin >= 0: float order == integer order
         }
     }
+    // Branch-free tail: (key, reference) pairs go through a 5-comparator network as selects and the three farther children are
+    // stored to the LDS stack unconditionally, the stack pointer advancing only for hits (sorted order puts the hits first; a
+    // non-hit's store is overwritten by the next push or ignored).
+    uint32_t ref[4] = {ch.x, ch.y, ch.z, ch.w};
+#define KJ_CSWAP(a, b) { const bool sw_ = key[b] < key[a]; const uint32_t ka_ = key[a], kb_ = key[b], ra_ = ref[a], rb_ = ref[b]; \
+                         key[a] = sw_ ? kb_ : ka_; key[b] = sw_ ? ka_ : kb_; ref[a] = sw_ ? rb_ : ra_; ref[b] = sw_ ? ra_ : rb_; }
+    // closest-hit rays visit children nearest first; occlusion rays take them in slot order: any hit ends the ray, the push logic below
+    // is order-agnostic, and skipping the network measured +8 % any-hit rays/s for a few more node visits
+    if (!ANY_HIT) { KJ_CSWAP(0, 1) KJ_CSWAP(2, 3) KJ_CSWAP(0, 2) KJ_CSWAP(1, 3) KJ_CSWAP(1, 2) }
+#undef KJ_CSWAP
+    if (S.sp + 3u <= KJ_BVH_LDS_STACK) {
+        stack[S.sp * stride] = ref[3]; S.sp += key[3] != NONE ? 1u : 0u;
+        stack[S.sp * stride] = ref[2]; S.sp += key[2] != NONE ? 1u : 0u;
+        stack[S.sp * stride] = ref[1]; S.sp += key[1] != NONE ? 1u : 0u;
+    } else {   // deep lanes: entries beyond the LDS part spill to private memory
+        if (key[3] != NONE) KJ_PUSH(ref[3])
+        if (key[2] != NONE) KJ_PUSH(ref[2])
+        if (key[1] != NONE) KJ_PUSH(ref[1])
+    }
+    if (key[0] != NONE) S.cur = ref[0];
+    else KJ_POP(S.cur)
+}
+
+// Test ONE triangle of the leaf S.cur; an occlusion ray that hits is finished.
+template <bool ANY_HIT, bool STATS>
+KJ_D void tri_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
+    const uint32_t first = S.cur & 0x0fffffffu;
+    const uint32_t rest = (S.cur >> 28) & 7u;      // triangles left after this one
+    const float4* __restrict__ tp = (const float4*)bvh.tris + size_t(first) * 3;
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    if (STATS) stats->tris++;
+    if (intersect_tri(S.o, S.d, S.tmin, S.tmax, a, b, c, first, S.cull_back, S.h)) {
+        if (ANY_HIT) { S.cur = KJ_BVH_NONE; return; }
+    }
+    if (rest) S.cur = KJ_BVH_LEAF | ((rest - 1u) << 28) | (first + 1u);
+    else KJ_POP(S.cur)
+}
+
+// One ray, start to finish, inside a caller's kernel: one step per iteration, a node visit or ONE triangle test.
+template <bool ANY_HIT, bool STATS = false>
+KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bool cull_back, uint32_t* stack, uint32_t stride, TraverseStats* stats = nullptr) {
+    RayState S;
+    ray_begin<ANY_HIT>(S, o, d, tmin, tmax, cull_back);
+    uint32_t spill[KJ_BVH_SPILL_STACK];
+    while (S.cur != KJ_BVH_NONE) {
+        if (!(S.cur & KJ_BVH_LEAF)) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);
+        else tri_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);
+    }
+    return S.h;
+}
+
+// ---- ray streams: a persistent wave works through a dense array of rays, keeping all 64 lanes busy.
+//  * rays[i] = {origin.xyz, tmin}, {direction.xyz, tmax}; tmax < 0 marks "no ray here" (a sky pixel's slot): result = miss.
+//  * A wave owns chunks of KJ_STREAM_CHUNK consecutive rays, interleaved with the other waves of the launch (no atomics). A lane
+//    whose ray has finished parks; once a quarter of the wave is parked, all parked lanes store their results and take the next
+//    rays of the chunk in one go (wave vote + prefix count) -- so one long ray no longer holds 63 finished lanes hostage.
+//  * A wave step runs EITHER the node block or the triangle block, whichever the larger share of its lanes is waiting for; lanes
+//    waiting for the other block sit the step out. In a single-ray-per-lane loop a mixed wave pays for both blocks every
+//    iteration; here every issued block works for the majority of the lanes.
+//  Per-ray results are identical to bvh_trace() (same steps in the same order for each ray; only the interleaving differs).
+#define KJ_STREAM_CHUNK 256u
+// scheduling knobs of a stream launch (uniform): lanes parked before a refill; a step runs the node block when nodes * node_weight >= tris * tri_weight
+struct StreamTune { uint32_t refill_threshold, node_weight, tri_weight; };
+struct StreamHit { float t, u, v; uint32_t slot; };   // closest hit: slot = leaf-order triangle index, 0xffffffff = miss; occlusion: slot != 0xffffffff = blocked
+
+// `emit(ray_index, hit)` stores one finished ray's result.
+template <bool ANY_HIT, bool STATS = false, typename Emit>
+KJ_D void bvh_trace_stream(const BvhView& bvh, const float4* __restrict__ rays, uint32_t count, bool cull_back,
+                           uint32_t wave_index, uint32_t wave_count, uint32_t* stack, uint32_t stride, Emit emit, StreamTune tune = StreamTune{16u, 1u, 1u},
+                           TraverseStats* stats = nullptr) {
+    const uint32_t lane = __lane_id() & 63u;
+    const unsigned long long lane_bit = 1ull << lane;
+    RayState S;
+    S.cur = KJ_BVH_NONE; S.sp = 0;
+    S.h.t = FLT_MAX; S.h.u = S.h.v = 0; S.h.slot = S.h.world_id = 0xffffffffu;
+    uint32_t spill[KJ_BVH_SPILL_STACK];
+    bool live = false;
+    uint32_t ray_index = 0;
+    uint32_t chunk = wave_index, cursor = wave_index * KJ_STREAM_CHUNK;
+    uint32_t chunk_end = min(count, cursor + KJ_STREAM_CHUNK);
+    bool exhausted = cursor >= count;
+    for (;;) {
+        const bool parked = S.cur == KJ_BVH_NONE;
+        const unsigned long long pm = __ballot(parked);
+        const uint32_t n_parked = uint32_t(__popcll(pm));
+        if (!exhausted && (n_parked >= tune.refill_threshold || pm == ~0ull)) {
+            if (parked && live) { emit(ray_index, S.h); live = false; }
+            if (cursor == chunk_end) {
+                chunk += wave_count; cursor = chunk * KJ_STREAM_CHUNK; chunk_end = min(count, cursor + KJ_STREAM_CHUNK);
+                if (cursor >= count) { exhausted = true; chunk_end = cursor; }
+            }
+            const uint32_t take = min(n_parked, chunk_end - cursor);
+            const uint32_t rank = uint32_t(__popcll(pm & (lane_bit - 1ull)));
+            if (parked && rank < take) {
+                ray_index = cursor + rank;
+                const float4 a = rays[size_t(ray_index) * 2], b = rays[size_t(ray_index) * 2 + 1];
+                ray_begin<ANY_HIT>(S, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, a.w, b.w, cull_back);
+                if (!(b.w >= 0.0f)) S.cur = KJ_BVH_NONE;     // "no ray here"
+                live = true;
+            }
+            cursor += take;
+        }
+        const bool want_node = S.cur != KJ_BVH_NONE && !(S.cur & KJ_BVH_LEAF), want_tri = S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF);
+        const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
+        if (nn + nt == 0u) { if (exhausted) break; else continue; }
+        if (nt == 0u || (nn != 0u && nn * tune.node_weight >= nt * tune.tri_weight)) { if (want_node) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
+        else { if (want_tri) tri_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
+    }
+    if (live) emit(ray_index, S.h);
+}
 #undef KJ_PUSH
 #undef KJ_POP
-    return h;
-}
 #endif // __HIPCC__
 
 } // namespace kj

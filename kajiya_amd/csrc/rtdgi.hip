@@ -584,7 +584,7 @@ struct KjRtdgi {
     kj::DevBuf ray_counters;                    // KJ_COUNTER_SLOTS x (6 used of KJ_COUNTER_STRIDE) u64, see kj_vec.hpp
     bool profiling = false;                     // per-pass GPU timestamps (gpu-profiler scopes, kajiya-rg/src/graph.rs:941-944)
     bool count_traversal = false;               // instrumented trace kernels
-    int resample_variant = 0;                   // A/B switch of the resampling kernels' LDS staging (KJ_RTDGI_RESAMPLE_VARIANT; rtdgi_resample.hpp)
+    int resample_variant = 2;                   // spatial reuse: 2 = per-tap gathers (fastest measured), 0 / 1 = LDS-staged tiles (KJ_RTDGI_RESAMPLE_VARIANT; rtdgi_resample.hpp)
     static const int NUM_SCOPES = 11;
     hipEvent_t ev[NUM_SCOPES][2] = {};
     bool ev_valid[NUM_SCOPES] = {};

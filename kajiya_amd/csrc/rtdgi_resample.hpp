@@ -13,7 +13,10 @@ struct SpatialLaunch {
     int W, H, hw, hh;
     uint32_t pass_idx, perform_occlusion_raymarch, occlusion_raymarch_importance_only;
     int row0, row1;
-    int variant;      // 0: LDS tiles, largest workgroups (default); 1: LDS tiles, 16x16 workgroups; 2: no LDS staging (A/B measurements)
+    // 2 (default): G-buffer records gathered per tap; 0: staged in LDS by 32x32 (first pass) / 16x16 workgroups; 1: LDS, 16x16 workgroups.
+    // Measured at 1080p (profiles/r02_spatial_variants.md): first pass 37.6 us (2) / 49.7 (0) / 58.0 (1), second pass 44.7 / 48.0 / 47.9:
+    // a tap window of 72x72 texels per 8x8 block is ten times the bytes the taps read, and the fill serialises the workgroup.
+    int variant;
 };
 hipError_t launch_restir_spatial(const SpatialLaunch& L, hipStream_t s);
 

@@ -25,11 +25,29 @@ d2 = torch.from_numpy(rng.normal(size=(N, 3)).astype(np.float32)).cuda(); d2 = d
 d2[:, 1] = d2[:, 1].abs()          # roofs / ground mostly face up: upper hemisphere
 r1 = torch.zeros((N, 8), device="cuda"); r1[:, :3] = p + 1e-3 * d2; r1[:, 4:7] = d2; r1[:, 7] = 1e4
 r1 = r1[ok].contiguous(); M = r1.shape[0]
-for name, fn in (("closest", lambda: scene.trace_closest(r1, M)), ("any", lambda: scene.trace_any(r1, M))):
-    fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10): fn()
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    print(f"{name}: {M} rays in {ms:.3f} ms = {M / ms / 1e3:.1f} Mrays/s")
+def measure(label):
+    out = []
+    for name, fn in (("closest", lambda: scene.trace_closest(r1, M)), ("any", lambda: scene.trace_any(r1, M))):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        out.append(f"{name}: {ms:.3f} ms = {M / ms / 1e3:.0f} Mrays/s")
+    print(f"{label:<44s} {M} rays  " + "   ".join(out), flush=True)
+
+
+# the C-ABI reads these switches at every call (device.hip: stream_waves / stream_tune / KJ_TRACE_PER_RAY)
+KNOBS = ("KJ_TRACE_PER_RAY", "KJ_STREAM_WAVES_PER_CU", "KJ_STREAM_REFILL", "KJ_STREAM_NODE_WEIGHT", "KJ_STREAM_TRI_WEIGHT")
+configs = [dict(KJ_TRACE_PER_RAY="1"), dict()]
+if "--sweep" in sys.argv:
+    configs += [dict(KJ_STREAM_WAVES_PER_CU=str(w)) for w in (8, 16, 32)]
+    configs += [dict(KJ_STREAM_REFILL=str(t)) for t in (1, 8, 32, 48)]
+    configs += [dict(KJ_STREAM_NODE_WEIGHT="2", KJ_STREAM_TRI_WEIGHT="1"), dict(KJ_STREAM_NODE_WEIGHT="1", KJ_STREAM_TRI_WEIGHT="2"),
+                dict(KJ_STREAM_NODE_WEIGHT="1", KJ_STREAM_TRI_WEIGHT="0"), dict(KJ_STREAM_NODE_WEIGHT="1", KJ_STREAM_TRI_WEIGHT="3")]
+for cfg in configs:
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(cfg)
+    measure("one ray per lane (bvh_trace)" if cfg.get("KJ_TRACE_PER_RAY") else "stream " + (" ".join(f"{k[10:].lower()}={v}" for k, v in cfg.items()) or "(defaults)"))

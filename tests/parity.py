@@ -143,9 +143,11 @@ def within_bars_with_flips(r, flip_tol=MISMATCH_TOL, outlier_cap=1e-2):
     gate that picks last frame's radiance or the irradiance cache for a hit (diffuse_trace_common.inc.hlsl:85-107), a reservoir's
     `w / w_sum >= dart` -- a last-bit difference replaces a texel's whole value, and with radiance spanning decades ONE such texel
     in 10^5 moves the whole-image L2 past 1e-3. There the outlier texels are counted and capped (<= 0.2 %, or 8 texels on a tiny
-    image), every other texel meets the 1e-3 bar as an image, and the outliers may not dominate the image either (<= 1e-2)."""
+    image), every other texel meets the 1e-3 bar as an image, and beyond a handful (8) the outliers may not dominate the image
+    either (<= 1e-2)."""
+    few = r["mismatch_frac"] * r["n"] <= 8.5          # a handful of texels: on a small image ONE bright flipped texel is > 1e-2 of the image's L2
     flip_tol = max(flip_tol, 8.0 / max(1, r["n"]))
-    return r["rel_l2_inliers"] <= REL_L2_TOL and r["mismatch_frac"] <= flip_tol and r["rel_l2"] <= outlier_cap and r.get("bad_class", 0) == 0
+    return r["rel_l2_inliers"] <= REL_L2_TOL and r["mismatch_frac"] <= flip_tol and (few or r["rel_l2"] <= outlier_cap) and r.get("bad_class", 0) == 0
 
 
 RAY_PASSES = {"VALIDATE", "TRACE"}   # rtdgi / rtr passes whose outputs carry such decisions
