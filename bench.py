@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-ssgi", action="store_true", help="drive rtdgi with the constant SSAO guide instead of running SsgiRenderer each frame")
     ap.add_argument("--no-overlap", action="store_true", help="serial frames: do not overlap the next frame's ircache work with this frame's screen-space tail")
     ap.add_argument("--virtual-ranks", type=int, default=0, help="debug: run the N-way screen-tile split on ONE GPU (LocalComm)")
+    ap.add_argument("--pmc-calibration-copy", action="store_true", help="after the timed region, copy 512 MiB with the library's `pmc_calibration_copy` kernel: a known byte count for scripts/pmc_collect.sh")
     ap.add_argument("--motion-halo", type=int, default=16, help="rows of history exchanged beyond the stencil (>= max |screen motion| per frame)")
     return ap.parse_args()
 
@@ -249,7 +250,7 @@ def main():
         irc_rays //= nsplit
     total_rays = total_rays_all = rays_closest + rays_any + irc_rays
 
-    seg, pass_ms, roofline = None, None, None
+    seg, pass_ms, roofline, roofline_all = None, None, None, None
     if overlap:
         torch.cuda.synchronize()
         (gp if single else split).on_ircache_traced = None
@@ -332,21 +333,56 @@ def main():
         trace_bytes = hw * hh * 38 * strip_frac + trace_share * (closest_per_frame * bytes_per_closest + any_per_frame * bytes_per_any)
         trace_ms = pass_ms[3]
         achieved = trace_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-        traffic = None   # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): committed measurement
+        # ---- per-kernel rooflines. `achieved` = ALGORITHMIC bytes (every input texel read once + every output written
+        # once, x the units of one launch) / the kernel's average launch time measured above with HIP events on the launch stream.
+        # `traffic` = HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_kernels.json, produced by
+        # scripts/pmc_collect.sh on this workload; rocprofv3 cannot run inside this process), FETCH_SIZE doubled per the microarch
+        # guide's gfx950 correction, and `hbm_frac` = traffic / launch time / peak: what the memory system actually moved. For the ray
+        # kernel the two differ by design: its algorithmic bytes are BVH nodes and triangles that live in L2 / Infinity Cache.
+        pmc = {}
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_trace_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_kernels.json")))
             wl = pm["workload"]
             if (wl["scene"], wl["tris"], wl["width"], wl["height"]) == (args.scene, args.tris, W, H):
-                traffic = int(1024 * (pm["fetch_kb_per_launch"] + pm["write_kb_per_launch"]))
+                pmc = pm["kernels"]
         except Exception:
-            traffic = None
-        roofline = {"kernel": "k_rtdgi_trace", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": "profiles/pmc_trace_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
-                    "avg_launch_ms": round(trace_ms, 4), "algorithmic_bytes_per_launch": int(trace_bytes),
-                    "nodes_per_closest_ray": round(nodes_per_closest, 2), "tris_per_closest_ray": round(tris_per_closest, 2),
-                    "nodes_per_any_ray": round(nodes_per_any, 2), "tris_per_any_ray": round(tris_per_any, 2),
-                    "dominant_by_time": dom_name}
+            pmc = {}
+        n_h2, n_f = hw * hh * strip_frac, W * H * strip_frac
+        # pass -> (kernel name as rocprofv3 prints it, units per launch, algorithmic bytes per unit [SURVEY 8d table])
+        table = [("rtdgi reproject", "k_fullres_reproject", n_f, 24), ("extract half", "k_extract_half", n_h2, 30), ("validity integrate", "k_validity_integrate", n_h2, 25),
+                 ("restir temporal", "k_restir_temporal", n_h2, 168), ("restir spatial 0", "k_restir_spatial<32, 8, 16, 16, false>", n_h2, 41),
+                 ("restir spatial 1", "k_restir_spatial<16, 5, 16, 16, false>", n_h2, 41), ("restir resolve", "k_restir_resolve", n_f, 43),
+                 ("rtdgi temporal", "k_temporal_filter", n_f, 49), ("rtdgi spatial", "k_spatial_filter", n_f, 25)]
+
+        def entry(kernel, ms, algo_bytes, note=None):
+            e = {"kernel": kernel, "bound": "hbm", "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
+                 "achieved": round(algo_bytes / (ms * 1e-3) / 1e9, 2) if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            e["frac"] = round(e["achieved"] / HBM_PEAK_GBS, 5)
+            k = pmc.get(kernel) or pmc.get(kernel.split("<")[0])
+            if k and "fetch_bytes_corrected" in k and "write_bytes" in k:
+                e["traffic"] = int(k["fetch_bytes_corrected"] + k["write_bytes"])
+                e["hbm_frac"] = round(e["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None
+            else:
+                e["traffic"], e["hbm_frac"] = None, None
+            for src, dst in (("VALUBusy", "valu_busy_pct"), ("VALUUtilization", "valu_lane_utilization_pct"), ("MemUnitStalled", "mem_unit_stalled_pct")):
+                if k and src in k:
+                    e[dst] = round(k[src], 1)
+            if note:
+                e["note"] = note
+            return e
+        ray_kernel = "k_rtdgi_trace"
+        roofline = entry(ray_kernel, trace_ms, trace_bytes)
+        roofline.update({"traffic_source": "profiles/pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md)" if roofline["traffic"] else None,
+                         "nodes_per_closest_ray": round(nodes_per_closest, 2), "tris_per_closest_ray": round(tris_per_closest, 2),
+                         "nodes_per_any_ray": round(nodes_per_any, 2), "tris_per_any_ray": round(tris_per_any, 2), "dominant_by_time": dom_name})
+        roofline_all = [roofline] + [entry(kern, pass_ms[lib.GpuPipeline.PASS_NAMES.index(pname)], units * bpu) for pname, kern, units, bpu in table]
+        if seg:
+            roofline_all.append(entry("taa (7 kernels)", seg["taa"], W * H * 224, "segment: sum of the seven TAA launches"))
+        if args.pmc_calibration_copy and single:
+            nbytes = 512 << 20
+            a_ = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}"); b_ = torch.empty_like(a_)
+            lib.check(gp.L.kj_debug_calibration_copy(b_.data_ptr(), a_.data_ptr(), nbytes, lib._stream_ptr()))
+            torch.cuda.synchronize()
 
     ms_per_step = 1e3 * elapsed / K
     out = {
@@ -363,6 +399,7 @@ def main():
         "segment_ms": seg,
         "pass_ms": {n: round(v, 4) for n, v in zip(lib.GpuPipeline.PASS_NAMES, pass_ms)} if pass_ms else None,
         "roofline": roofline,
+        "roofline_all": roofline_all,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

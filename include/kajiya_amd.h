@@ -223,6 +223,9 @@ KjStatus kj_frame_begin(KjDevice* dev, const KjFrameConstants* fc, void* stream)
  * with t = FLT_MAX on miss; any-hit variant writes 1 byte per ray. */
 KjStatus kj_trace_closest(KjScene* scene, const void* rays, void* hits, uint32_t count, uint32_t cull_back_faces, void* stream);
 KjStatus kj_trace_any(KjScene* scene, const void* rays, void* out_u8, uint32_t count, void* stream);
+/* Measurement aid, no reference counterpart: copies `bytes` (multiple of 16) device-to-device with a plain 16-B-per-lane kernel named
+ * `pmc_calibration_copy`, a known byte count against which rocprofv3's FETCH_SIZE / WRITE_SIZE are calibrated (scripts/pmc_collect.sh). */
+KjStatus kj_debug_calibration_copy(void* dst, const void* src, uint64_t bytes, void* stream);
 
 /* G-buffer stand-in for raster_meshes (renderers/raster_meshes.rs; packing as in
  * raster_simple_ps.hlsl:126-137): primary rays through the jittered camera.

@@ -188,6 +188,10 @@ __global__ void __launch_bounds__(64) k_trace_any_stream(SceneView sc, const flo
                            [&](uint32_t i, const RayHit& h) { out[i] = h.slot != 0xffffffffu ? 1 : 0; }, tune);
 }
 
+__global__ void __launch_bounds__(256) pmc_calibration_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) dst[i] = src[i];
+}
+
 // light_gbuffer.hlsl:60-260 — the deferred combine: sun direct light through the shadow mask, emissive, diffuse
 // GI (rtdgi) times albedo and the specular layer's transmission, optional specular (rtr) term, sky + sun disc for depth == 0.
 // Debug shading modes 0-4 as in the shader; mode 5 (ircache view) and the wrc overlay are not built.
@@ -404,7 +408,7 @@ static uint32_t stream_waves(const KjDevice* dev, uint32_t count) {
     return std::max(1u, std::min(chunks, dev->num_cus * per_cu));
 }
 static StreamTune stream_tune() {   // scheduling knobs, overridable for measurements
-    StreamTune t{16u, 1u, 1u};
+    StreamTune t{16u, 1u, 2u};
     if (const char* v = getenv("KJ_STREAM_REFILL")) t.refill_threshold = uint32_t(atoi(v));
     if (const char* v = getenv("KJ_STREAM_NODE_WEIGHT")) t.node_weight = uint32_t(atoi(v));
     if (const char* v = getenv("KJ_STREAM_TRI_WEIGHT")) t.tri_weight = uint32_t(atoi(v));
@@ -431,6 +435,13 @@ KjStatus kj_trace_any(KjScene* scene, const void* rays, void* out_u8, uint32_t c
         hipLaunchKernelGGL(k_trace_any, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count);
     else
         hipLaunchKernelGGL(k_trace_any_stream, dim3(stream_waves(scene->dev, count)), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count, stream_tune());
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+
+KjStatus kj_debug_calibration_copy(void* dst, const void* src, uint64_t bytes, void* stream) {
+    KJ_REQUIRE(dst && src && bytes % 16 == 0, "null argument / size not a multiple of 16");
+    hipLaunchKernelGGL(pmc_calibration_copy, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, size_t(bytes / 16));
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }

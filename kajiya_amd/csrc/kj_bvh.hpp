@@ -230,7 +230,7 @@ struct StreamHit { float t, u, v; uint32_t slot; };   // closest hit: slot = lea
 // `emit(ray_index, hit)` stores one finished ray's result.
 template <bool ANY_HIT, bool STATS = false, typename Emit>
 KJ_D void bvh_trace_stream(const BvhView& bvh, const float4* __restrict__ rays, uint32_t count, bool cull_back,
-                           uint32_t wave_index, uint32_t wave_count, uint32_t* stack, uint32_t stride, Emit emit, StreamTune tune = StreamTune{16u, 1u, 1u},
+                           uint32_t wave_index, uint32_t wave_count, uint32_t* stack, uint32_t stride, Emit emit, StreamTune tune = StreamTune{16u, 1u, 2u},
                            TraverseStats* stats = nullptr) {
     const uint32_t lane = __lane_id() & 63u;
     const unsigned long long lane_bit = 1ull << lane;

@@ -10,6 +10,7 @@
 #include "kj_screen.hpp"
 #include "rtdgi_resample.hpp"
 #include <cstdlib>
+#include <algorithm>
 
 using namespace kj;
 namespace kj { SceneView scene_view(const KjScene& s); }
@@ -129,30 +130,144 @@ struct TraceCtx {
     IrcacheView irc; bool has_ircache;              // IrcacheRenderState bound via bind_mut (rtdgi.rs:321,350)
     unsigned long long* __restrict__ ray_counters;  // [0]=closest rays, [1]=any-hit rays, [2..5]=nodes/tris visited (closest, any) in STATS builds
 };
-struct TraceResult { V3 out_value; V3 hit_normal_ws; float hit_t; float pdf; bool is_hit; };
 
 KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
     const unsigned long long m = __ballot(active);
     if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
 }
 
-template <bool STATS>
-KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3 normal_ws, uint32_t& rng, V3 ray_o, V3 ray_d, float ray_tmax, uint32_t* stack) {
+// The reference's ray-generation shaders (trace_diffuse.rgen.hlsl, diffuse_validate.rgen.hlsl) run ray generation, traversal,
+// hit shading, the sun's shadow ray and the result's bookkeeping in one invocation per pixel. On gfx950 that is a megakernel
+// whose waves idle three lanes out of four (sky pixels, rays of unequal length, node / triangle steps interleaved, hit vs miss
+// shading). Here a ray pass is five launches over dense per-pixel arrays (ray i = lane i % 64 of 8x8 tile i / 64 of the launch):
+//   1. ray generation          -> rays_a[i]            (k_rtdgi_trace_raygen / k_rtdgi_validate_raygen; "no ray" for sky pixels)
+//   2. closest-hit ray stream  -> hits_a[i]            (kj_bvh.hpp: bvh_trace_stream -- persistent waves, lane refill, block voting)
+//   3. hit shading             -> rays_b[i], state[i]  (k_rtdgi_shade: G-buffer of the hit, sun shadow ray, lights, irradiance cache)
+//   4. occlusion ray stream    -> occl_b[i]
+//   5. finish                  -> the pass's images    (k_rtdgi_trace_finish / k_rtdgi_validate_finish)
+// The arithmetic of diffuse_trace_common.inc.hlsl:38-221 is unchanged, including the order in which the radiance terms are summed
+// (the shade step carries the sum twice, with and without the sun's term, and the finish step picks one).
+struct RayStage {
+    float4* __restrict__ rays_a; float4* __restrict__ hits_a;     // 2 x float4 per ray; (t, u, v, slot bits) per hit
+    float4* __restrict__ rays_b; uint32_t* __restrict__ occl_b;   // sun shadow rays; 1 = blocked
+    float4* __restrict__ state;                                   // 2 x float4 per pixel: (radiance if sun visible, hit_t), (radiance if sun blocked, is_hit)
+};
+#define KJ_NO_RAY -1.0f
+KJ_D uint32_t stage_index(int lane) { return (blockIdx.y * gridDim.x + blockIdx.x) * 64u + uint32_t(lane); }
+KJ_D void put_ray(float4* rays, uint32_t i, V3 o, float tmin, V3 d, float tmax) {
+    rays[size_t(i) * 2] = make_float4(o.x, o.y, o.z, tmin);
+    rays[size_t(i) * 2 + 1] = make_float4(d.x, d.y, d.z, tmax);
+}
+KJ_D void put_no_ray(float4* rays, uint32_t i) { put_ray(rays, i, v3(0.0f), 0.0f, v3(0.0f), KJ_NO_RAY); }
+
+// ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24: ray generation
+__global__ void __launch_bounds__(64) k_rtdgi_trace_raygen(TraceCtx c, RayStage st, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
+                                                            ImgU32 candidate_normal_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    const uint32_t idx = stage_index(lane);
     const FrameConstants& fc = *c.fc;
-    V3 total_radiance = v3(0.0f);
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+    const float depth = in_image ? c.depth.ld(hx, hy) : 0.0f;
+    const bool has_ray = in_image && depth != 0.0f;
+    count_rays(c.ray_counters, 0, has_ray);
+    if (!has_ray) {
+        put_no_ray(st.rays_a, idx);
+        if (in_image) {
+            st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
+            candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
+            invalidity_out_tex.st(x, y, 0);
+        }
+        return;
+    }
+    const V4 gts = tex_size4(c.depth.w, c.depth.h);
+    const V2 uv = get_uv(float(hx), float(hy), gts);
+    const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
+    const float near_field_fade_out_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
+    const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
+    const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
+    const Basis tangent_to_world = build_orthonormal_basis(normal_ws);
+    const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, fc.frame_index);
+    const V3 outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
+    const V3 origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
+    put_ray(st.rays_a, idx, origin, 0.0f, outgoing_dir, tracing_frame ? SKY_DIST : near_field_fade_out_end);
+    const float cos_theta = dot(normalize(outgoing_dir - vr.dir_ws), normal_ws);
+    st4(candidate_irradiance_out_tex, x, y, V4{0, 0, 0, 1.0f - cos_theta});   // rgb: the finish step
+    const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
+    const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
+    invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
+}
+// ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111: ray generation (the kept sample's ray again)
+__global__ void __launch_bounds__(64) k_rtdgi_validate_raygen(TraceCtx c, RayStage st, ImgH4 reservoir_ray_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    const uint32_t idx = stage_index(lane);
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const bool sky = in_image && 0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y);
+    const bool has_ray = in_image && !sky && is_rtdgi_validation_frame(fc.frame_index);
+    count_rays(c.ray_counters, 0, has_ray);
+    if (!has_ray) {
+        put_no_ray(st.rays_a, idx);
+        if (in_image) invalidity_out_tex.st(x, y, to_unorm8(sky ? 1.0f : 0.0f));
+        return;
+    }
+    const float4 ro = ray_orig_history_tex.ld(x, y);
+    const V3 prev_ray_orig{ro.x, ro.y, ro.z};
+    const V3 prev_hit_pos = xyz(ld4(reservoir_ray_history_tex, x, y)) + prev_ray_orig;
+    put_ray(st.rays_a, idx, prev_ray_orig, 0.0f, normalize(prev_hit_pos - prev_ray_orig), SKY_DIST);
+}
+
+// ------------------------------------------------------------------ closest-hit / occlusion streams over a stage's rays
+template <bool ANY_HIT, bool STATS>
+__global__ void __launch_bounds__(64) k_rtdgi_ray_stream(BvhView bvh, const float4* __restrict__ rays, float4* __restrict__ hits, uint32_t* __restrict__ occl, uint32_t count,
+                                                          unsigned long long* __restrict__ ray_counters) {
+    extern __shared__ uint32_t lds_stack[];
+    TraverseStats stats{0, 0};
+    bvh_trace_stream<ANY_HIT, STATS>(bvh, rays, count, false, blockIdx.x, gridDim.x, lds_stack + threadIdx.x, 64,
+                                     [&](uint32_t i, const RayHit& h) {
+                                         if (ANY_HIT) occl[i] = h.slot != 0xffffffffu ? 1u : 0u;
+                                         else hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+                                     }, StreamTune{16u, 1u, 2u}, &stats);
+    if (STATS) {  // instrumentation build only: traversal work per ray type (SURVEY 8d "measured by the instrumented kernel")
+        atomicAdd(&counter_slot(ray_counters)[ANY_HIT ? 4 : 2], (unsigned long long)stats.nodes);
+        atomicAdd(&counter_slot(ray_counters)[ANY_HIT ? 5 : 3], (unsigned long long)stats.tris);
+    }
+}
+
+// ------------------------------------------------------------------ diffuse_trace_common.inc.hlsl:38-221: everything after the closest-hit query
+template <bool VALIDATE>
+__global__ void __launch_bounds__(64) k_rtdgi_shade(TraceCtx c, RayStage st, ImgU32 half_view_normal_tex, ImgU32 candidate_normal_out_tex,
+                                                     ImgH4 candidate_hit_out_tex, int hw, int hh, int row0, int row1) {
+    extern __shared__ uint32_t lds_stack[];
+    TILE_XY(hw, hh)
+    const uint32_t idx = stage_index(lane);
+    const float4 ra = st.rays_a[size_t(idx) * 2], rb = st.rays_a[size_t(idx) * 2 + 1];
+    if (!(rb.w >= 0.0f)) { put_no_ray(st.rays_b, idx); return; }
+    const FrameConstants& fc = *c.fc;
+    const V3 ray_o{ra.x, ra.y, ra.z}, ray_d{rb.x, rb.y, rb.z};
+    const float ray_tmax = rb.w;
+    const float4 hrec = st.hits_a[idx];
+    RayHit h;
+    h.t = hrec.x; h.u = hrec.y; h.v = hrec.z; h.slot = __float_as_uint(hrec.w); h.world_id = 0;
+    const bool is_hit = h.slot != 0xffffffffu;
+    const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
+    uint32_t rng = VALIDATE ? hash3(uint32_t(x), uint32_t(y), 0) : hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u);
+    uint32_t* stack = lds_stack + lane;
+    // the radiance sum, carried twice: `lit` if the sun's shadow ray turns out free, `shadowed` if blocked
+    V3 lit = v3(0.0f), shadowed = v3(0.0f);
     V3 hit_normal_ws = -ray_d;
     float hit_t = ray_tmax;
-    const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, ray_d) * 2 * KJ_PI));
-    count_rays(c.ray_counters, 0, true);
-    TraverseStats st_closest{0, 0}, st_any{0, 0};
-    // diffuse_trace_common.inc.hlsl:68-71: reflected cone = the half-res pixel cone propagated from the eye to the ray origin
-    const RayCone ray_cone = pixel_ray_cone_from_image_height(fc, float(c.depth.h) * 0.5f).propagate(0.03f, length(ray_o - get_eye_position(fc)));
-    const GbufferPathVertex primary_hit = gbuffer_raytrace<STATS>(c.sc, fc, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, 64, &st_closest, ray_cone);
-    if (primary_hit.is_hit) {
-        hit_t = primary_hit.ray_t;
-        GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);
+    bool shadow_ray = false;
+    if (is_hit) {
+        // GbufferRaytrace::trace after the traversal (inc/rt.hlsl:112-137): shade the hit; the reflected cone is the half-res pixel
+        // cone propagated from the eye to the ray origin (diffuse_trace_common.inc.hlsl:68-71)
+        const RayCone ray_cone = pixel_ray_cone_from_image_height(fc, float(c.depth.h) * 0.5f).propagate(0.03f, length(ray_o - get_eye_position(fc)));
+        const uint4 gbuffer_packed = shade_gbuffer_hit(c.sc, fc, ray_d, h, 1, ray_cone.width_at_t(h.t * length(ray_d)));
+        const V3 hit_position = mad_nc(ray_o, ray_d, h.t);
+        hit_t = h.t;
+        GbufferData gbuffer = gbuffer_unpack(gbuffer_packed);
         hit_normal_ws = gbuffer.normal;
-        const V3 hit_cs = position_world_to_sample(fc, primary_hit.position);
+        const V3 hit_cs = position_world_to_sample(fc, hit_position);
         const V2 hit_uv = cs_to_uv(V2{hit_cs.x, hit_cs.y});
         const float screen_depth = sample_nearest_clamp(c.depth, hit_uv);
         bool is_on_screen = fabsf(hit_cs.x) < 1.0f && fabsf(hit_cs.y) < 1.0f && inverse_depth_relative_diff(hit_cs.z, screen_depth) < 5e-3f;
@@ -168,17 +283,19 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
         const float4 sc4 = *c.sun_color;
         const V3 sun_radiance{sc4.x, sc4.y, sc4.z};
         if (sun_radiance.x != 0 || sun_radiance.y != 0 || sun_radiance.z != 0) {
-            const V4 bn = blue_noise_for_pixel(c.blue_noise, px, py, rng);
+            const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, rng);
             const V3 to_light_norm = sample_sun_direction(fc, V2{bn.x, bn.y}, false);
-            count_rays(c.ray_counters, 1, true);
-            const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, 64, &st_any);
+            put_ray(st.rays_b, idx, hit_position, 1e-4f, to_light_norm, SKY_DIST);
+            shadow_ray = true;
             const V3 wi = to_local(tangent_to_world, to_light_norm);
             const V3 brdf_value = layered_brdf_evaluate(brdf, wo, wi) * fmaxf(0.0f, wi.z);
-            total_radiance += brdf_value * (is_shadowed ? v3(0.0f) : sun_radiance);
+            lit += brdf_value * sun_radiance;
+            shadowed += brdf_value * v3(0.0f);
         }
-        total_radiance += gbuffer.emissive;
+        lit += gbuffer.emissive; shadowed += gbuffer.emissive;
         if (is_on_screen) {
-            total_radiance += xyz(reprojected_radiance) * gbuffer.albedo;
+            const V3 t = xyz(reprojected_radiance) * gbuffer.albedo;
+            lit += t; shadowed += t;
         } else {
             V2 urand;
             urand.x = uint_to_u01_float(hash1_mut(rng));
@@ -188,111 +305,80 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
                 const KjTriangleLight tl = c.sc.lights[li];
                 const V3 v0{tl.verts[0], tl.verts[1], tl.verts[2]}, v1{tl.verts[3], tl.verts[4], tl.verts[5]}, v2{tl.verts[6], tl.verts[7], tl.verts[8]};
                 const LightSampleArea ls = sample_triangle_light(v0, v1 - v0, v2 - v0, urand);
-                const V3 to_light_ws = ls.pos - primary_hit.position;
+                const V3 to_light_ws = ls.pos - hit_position;
                 const float dist2 = dot(to_light_ws, to_light_ws);
                 const V3 to_light_norm_ws = to_light_ws * (1.0f / sqrtf(dist2));
                 const float to_psa_metric = fmaxf(0.0f, dot(to_light_norm_ws, gbuffer.normal)) * fmaxf(0.0f, dot(to_light_norm_ws, -ls.normal)) / dist2;
-                if (to_psa_metric > 0.0f) {
+                if (to_psa_metric > 0.0f) {   // few, short rays of the off-screen minority: traced in place
                     count_rays(c.ray_counters, 1, true);
-                    const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, 64, &st_any);
+                    const bool is_shadowed = rt_is_shadowed<false>(c.sc, hit_position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, 64);
                     const V3 bounce_albedo = lerp(gbuffer.albedo, v3(1.0f), 0.04f);
                     const V3 brdf_value = bounce_albedo * to_psa_metric / KJ_PI;
-                    if (!is_shadowed) total_radiance += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * brdf_value / ls.pdf;
+                    if (!is_shadowed) { const V3 t = V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * brdf_value / ls.pdf; lit += t; shadowed += t; }
                 }
             }
             if (c.has_ircache) {  // USE_IRCACHE (diffuse_trace_common.inc.hlsl:189-198); unbound => contributes 0 (BASELINE config 1)
-                const V3 gi = ircache_lookup<false>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng);
-                total_radiance += gi * gbuffer.albedo;
+                const V3 t = ircache_lookup<false>(c.irc, fc, ray_o, hit_position, gbuffer.normal, 1u, rng) * gbuffer.albedo;
+                lit += t; shadowed += t;
             }
         }
     } else {
-        total_radiance += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
+        const V3 t = xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
+        lit += t; shadowed += t;
     }
-    if (STATS) {  // instrumentation build only: traversal work per ray type (SURVEY 8d "measured by the instrumented kernel")
-        atomicAdd(&counter_slot(c.ray_counters)[2], (unsigned long long)st_closest.nodes);
-        atomicAdd(&counter_slot(c.ray_counters)[3], (unsigned long long)st_closest.tris);
-        atomicAdd(&counter_slot(c.ray_counters)[4], (unsigned long long)st_any.nodes);
-        atomicAdd(&counter_slot(c.ray_counters)[5], (unsigned long long)st_any.tris);
+    count_rays(c.ray_counters, 1, shadow_ray);
+    if (!shadow_ray) put_no_ray(st.rays_b, idx);
+    st.state[size_t(idx) * 2] = make_float4(lit.x, lit.y, lit.z, hit_t);
+    st.state[size_t(idx) * 2 + 1] = make_float4(shadowed.x, shadowed.y, shadowed.z, is_hit ? 1.0f : 0.0f);
+    if (!VALIDATE) {
+        const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
+        const float out_hit_t = (!tracing_frame && !is_hit) ? SKY_DIST : hit_t;
+        const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, ray_d) * 2 * KJ_PI));
+        st4(candidate_hit_out_tex, x, y, v4(ray_d * out_hit_t, pdf * (tracing_frame ? 1.0f : -1.0f)));
+        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, hit_normal_ws), 0)));
     }
-    return TraceResult{total_radiance, hit_normal_ws, hit_t, pdf, primary_hit.is_hit};
 }
 
-// ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111
-template <bool STATS>
-__global__ void __launch_bounds__(64) k_rtdgi_validate(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
-                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
-    extern __shared__ uint32_t lds_stack[];
+// ------------------------------------------------------------------ finish: trace_diffuse.rgen.hlsl:103-113
+__global__ void __launch_bounds__(64) k_rtdgi_trace_finish(const FrameConstants* __restrict__ fcp, RayStage st, ImgH4 candidate_irradiance_out_tex, int row0, int row1) {
+    TILE_XY(candidate_irradiance_out_tex.w, candidate_irradiance_out_tex.h)
+    const uint32_t idx = stage_index(lane);
+    if (!in_image || !(st.rays_a[size_t(idx) * 2 + 1].w >= 0.0f)) return;
+    const float4 s0 = st.state[size_t(idx) * 2], s1 = st.state[size_t(idx) * 2 + 1];
+    const bool blocked = st.rays_b[size_t(idx) * 2 + 1].w >= 0.0f && st.occl_b[idx] != 0u;
+    V3 out_value = blocked ? V3{s1.x, s1.y, s1.z} : V3{s0.x, s0.y, s0.z};
+    if (is_rtdgi_validation_frame(fcp->frame_index) && s1.w == 0.0f) out_value = v3(0.0f);
+    const float w = unpack_rgba16f(candidate_irradiance_out_tex.ld(x, y)).w;
+    st4(candidate_irradiance_out_tex, x, y, v4(out_value, w));
+}
+// ------------------------------------------------------------------ finish: diffuse_validate.rgen.hlsl:84-110
+__global__ void __launch_bounds__(64) k_rtdgi_validate_finish(RayStage st, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex, ImgH4 irradiance_history_tex,
+                                                               ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
     TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
-    if (!in_image) return;
-    const FrameConstants& fc = *c.fc;
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    if (0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y)) { invalidity_out_tex.st(x, y, to_unorm8(1.0f)); return; }
-    float invalidity = 0.0f;
-    if (is_rtdgi_validation_frame(fc.frame_index)) {
-        const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
-        const float4 ro = ray_orig_history_tex.ld(x, y);
-        const V3 prev_ray_orig{ro.x, ro.y, ro.z};
-        const V3 prev_hit_pos = xyz(ld4(reservoir_ray_history_tex, x, y)) + prev_ray_orig;
-        const V4 prev_radiance_packed = ld4(irradiance_history_tex, x, y);
-        const V3 prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
-        uint32_t rng = hash3(uint32_t(x), uint32_t(y), 0);
-        const TraceResult result = trace_candidate<STATS>(c, x, y, normal_ws, rng, prev_ray_orig, normalize(prev_hit_pos - prev_ray_orig), SKY_DIST, lds_stack + lane);
-        const V3 new_radiance = vmax(v3(0.0f), result.out_value);
-        const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
-        invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
-        const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
-        if (fabsf(result.hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
-            st4(irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
-            Reservoir1spp r = Reservoir1spp::from_raw(reservoir_tex.ld(x, y));
-            const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
-            r.M *= clampf(lum_old / fmaxf(1e-8f, lum_new), 0.03f, 1.0f);
-            r.W *= clampf(lum_old / fmaxf(1e-8f, lum_new) * 10.0f, 0.01f, 1.0f);
-            reservoir_tex.st(x, y, r.as_raw());
-        }
+    const uint32_t idx = stage_index(lane);
+    if (!in_image || !(st.rays_a[size_t(idx) * 2 + 1].w >= 0.0f)) return;
+    const float4 s0 = st.state[size_t(idx) * 2], s1 = st.state[size_t(idx) * 2 + 1];
+    const bool blocked = st.rays_b[size_t(idx) * 2 + 1].w >= 0.0f && st.occl_b[idx] != 0u;
+    const V3 out_value = blocked ? V3{s1.x, s1.y, s1.z} : V3{s0.x, s0.y, s0.z};
+    const float result_hit_t = s0.w;
+    const float4 ro = ray_orig_history_tex.ld(x, y);
+    const V3 prev_ray_orig{ro.x, ro.y, ro.z};
+    const V3 prev_hit_pos = xyz(ld4(reservoir_ray_history_tex, x, y)) + prev_ray_orig;
+    const V4 prev_radiance_packed = ld4(irradiance_history_tex, x, y);
+    const V3 prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
+    const V3 new_radiance = vmax(v3(0.0f), out_value);
+    const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
+    const float invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
+    const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
+    if (fabsf(result_hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
+        st4(irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
+        Reservoir1spp r = Reservoir1spp::from_raw(reservoir_tex.ld(x, y));
+        const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
+        r.M *= clampf(lum_old / fmaxf(1e-8f, lum_new), 0.03f, 1.0f);
+        r.W *= clampf(lum_old / fmaxf(1e-8f, lum_new) * 10.0f, 0.01f, 1.0f);
+        reservoir_tex.st(x, y, r.as_raw());
     }
     invalidity_out_tex.st(x, y, to_unorm8(invalidity));
-}
-
-// ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24
-template <bool STATS>
-__global__ void __launch_bounds__(64) k_rtdgi_trace(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
-                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
-    extern __shared__ uint32_t lds_stack[];
-    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
-    if (!in_image) return;
-    const FrameConstants& fc = *c.fc;
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
-    const float depth = c.depth.ld(hx, hy);
-    if (0.0f == depth) {
-        st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
-        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
-        invalidity_out_tex.st(x, y, 0);
-        return;
-    }
-    const V4 gts = tex_size4(c.depth.w, c.depth.h);
-    const V2 uv = get_uv(float(hx), float(hy), gts);
-    const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
-    const float near_field_fade_out_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
-    const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
-    {
-        const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
-        const Basis tangent_to_world = build_orthonormal_basis(normal_ws);
-        const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, fc.frame_index);
-        const V3 outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
-        const V3 origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
-        uint32_t rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u);
-        TraceResult result = trace_candidate<STATS>(c, x, y, normal_ws, rng, origin, outgoing_dir, tracing_frame ? SKY_DIST : near_field_fade_out_end, lds_stack + lane);
-        if (!tracing_frame && !result.is_hit) { result.out_value = v3(0.0f); result.hit_t = SKY_DIST; }
-        const V3 hit_offset_ws = outgoing_dir * result.hit_t;
-        const float cos_theta = dot(normalize(outgoing_dir - vr.dir_ws), normal_ws);
-        st4(candidate_irradiance_out_tex, x, y, v4(result.out_value, 1.0f - cos_theta));
-        st4(candidate_hit_out_tex, x, y, v4(hit_offset_ws, result.pdf * (tracing_frame ? 1.0f : -1.0f)));
-        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, result.hit_normal_ws), 0)));
-    }
-    const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
-    const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
-    invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
 }
 
 // ------------------------------------------------------------------ temporal_validity_integrate.hlsl:21-119
@@ -584,6 +670,7 @@ struct KjRtdgi {
     kj::DevBuf ray_counters;                    // KJ_COUNTER_SLOTS x (6 used of KJ_COUNTER_STRIDE) u64, see kj_vec.hpp
     bool profiling = false;                     // per-pass GPU timestamps (gpu-profiler scopes, kajiya-rg/src/graph.rs:941-944)
     bool count_traversal = false;               // instrumented trace kernels
+    uint32_t stream_waves_per_cu = 24;          // persistent waves per CU of a ray-stream launch (measured best of 8 / 16 / 24 / 32: scripts/traversal_microbench.py)
     int resample_variant = 2;                   // spatial reuse: 2 = per-tap gathers (fastest measured), 0 / 1 = LDS-staged tiles (KJ_RTDGI_RESAMPLE_VARIANT; rtdgi_resample.hpp)
     static const int NUM_SCOPES = 11;
     hipEvent_t ev[NUM_SCOPES][2] = {};
@@ -733,17 +820,45 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(1);
     }
+    // the ray passes' stage buffers (dense, one slot per lane of every 8x8 tile of the launch)
+    const uint32_t stage_rays = gh.x * gh.y * 64u;
+    const size_t stage_full = size_t((hw + 7) / 8) * ((hh + 7) / 8) * 64;
+    RayStage st;
+    st.rays_a = (float4*)r->get("stage.rays_a", stage_full * 32, s);
+    st.hits_a = (float4*)r->get("stage.hits_a", stage_full * 16, s);
+    st.rays_b = (float4*)r->get("stage.rays_b", stage_full * 32, s);
+    st.occl_b = (uint32_t*)r->get("stage.occl_b", stage_full * 4, s);
+    st.state = (float4*)r->get("stage.state", stage_full * 32, s);
+    KJ_TRY_HIP(r->err);
+    const uint32_t stream_grid = std::max(1u, std::min((stage_rays + KJ_STREAM_CHUNK - 1u) / KJ_STREAM_CHUNK, r->dev->num_cus * r->stream_waves_per_cu));
+    auto trace_streams = [&](bool closest) {
+        if (closest) hipLaunchKernelGGL((r->count_traversal ? k_rtdgi_ray_stream<false, true> : k_rtdgi_ray_stream<false, false>), dim3(stream_grid), blk, trace_lds, s, tc.sc.bvh,
+                                        (const float4*)st.rays_a, st.hits_a, (uint32_t*)nullptr, stage_rays, tc.ray_counters);
+        else hipLaunchKernelGGL((r->count_traversal ? k_rtdgi_ray_stream<true, true> : k_rtdgi_ray_stream<true, false>), dim3(stream_grid), blk, trace_lds, s, tc.sc.bvh,
+                                (const float4*)st.rays_b, (float4*)nullptr, st.occl_b, stage_rays, tc.ray_counters);
+    };
     if (mask & KJ_RTDGI_PASS_VALIDATE) {
         SCOPE_BEGIN(2);
-        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate<true> : k_rtdgi_validate<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
-                           img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
+        hipLaunchKernelGGL(k_rtdgi_validate_raygen, gh, blk, 0, s, tc, st, img<uint2>(ray_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
+        if (is_rtdgi_validation_frame(r->dev->fc_host.frame_index)) {   // on the two tracing frames of three the pass has no rays: only the invalidity image is written
+            trace_streams(true);
+            hipLaunchKernelGGL(k_rtdgi_shade<true>, gh, blk, trace_lds, s, tc, st, img<uint32_t>(half_view_normal, hw, hh), img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), hw, hh, hr0, hr1);
+            trace_streams(false);
+            hipLaunchKernelGGL(k_rtdgi_validate_finish, gh, blk, 0, s, st, img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh), img<uint2>(radiance_hist, hw, hh),
+                               img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
+            KJ_CHECK_LAUNCH();
+        }
         SCOPE_END(2);
     }
     if (mask & KJ_RTDGI_PASS_TRACE) {
         SCOPE_BEGIN(3);
-        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace<true> : k_rtdgi_trace<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
-                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+        hipLaunchKernelGGL(k_rtdgi_trace_raygen, gh, blk, 0, s, tc, st, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+                           img<uint32_t>(candidate_normal, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+        trace_streams(true);
+        hipLaunchKernelGGL(k_rtdgi_shade<false>, gh, blk, trace_lds, s, tc, st, img<uint32_t>(half_view_normal, hw, hh), img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), hw, hh, hr0, hr1);
+        trace_streams(false);
+        hipLaunchKernelGGL(k_rtdgi_trace_finish, gh, blk, 0, s, fc, st, img<uint2>(candidate_radiance, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
     }
