@@ -401,14 +401,10 @@ KjStatus kj_raster_gbuffer(KjDevice* dev, KjScene* scene, uint32_t W, uint32_t H
     return KJ_OK;
 }
 
-// persistent waves of a ray-stream launch: enough to fill the chip (KJ_STREAM_WAVES_PER_CU per CU, default 24), never more than chunks
-static uint32_t stream_waves(const KjDevice* dev, uint32_t count) {
+// waves + scheduling knobs of a ray-stream launch: enough waves to fill the chip (KJ_STREAM_WAVES_PER_CU per CU, default 24); knobs overridable for measurements
+static StreamTune stream_launch(const KjDevice* dev, uint32_t count, uint32_t* waves) {
     const uint32_t per_cu = getenv("KJ_STREAM_WAVES_PER_CU") ? uint32_t(atoi(getenv("KJ_STREAM_WAVES_PER_CU"))) : 24u;
-    const uint32_t chunks = (count + KJ_STREAM_CHUNK - 1u) / KJ_STREAM_CHUNK;
-    return std::max(1u, std::min(chunks, dev->num_cus * per_cu));
-}
-static StreamTune stream_tune() {   // scheduling knobs, overridable for measurements
-    StreamTune t{16u, 1u, 2u};
+    StreamTune t = stream_tune_for(count, dev->num_cus * per_cu, waves);
     if (const char* v = getenv("KJ_STREAM_REFILL")) t.refill_threshold = uint32_t(atoi(v));
     if (const char* v = getenv("KJ_STREAM_NODE_WEIGHT")) t.node_weight = uint32_t(atoi(v));
     if (const char* v = getenv("KJ_STREAM_TRI_WEIGHT")) t.tri_weight = uint32_t(atoi(v));
@@ -421,8 +417,10 @@ KjStatus kj_trace_closest(KjScene* scene, const void* rays, void* hits, uint32_t
     const SceneView sv = scene_view(*scene);
     if (getenv("KJ_TRACE_PER_RAY"))
         hipLaunchKernelGGL(k_trace_closest, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (float4*)hits, count, int(cull_back_faces));
-    else
-        hipLaunchKernelGGL(k_trace_closest_stream, dim3(stream_waves(scene->dev, count)), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (float4*)hits, count, int(cull_back_faces), stream_tune());
+    else {
+        uint32_t waves; const StreamTune tune = stream_launch(scene->dev, count, &waves);
+        hipLaunchKernelGGL(k_trace_closest_stream, dim3(waves), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (float4*)hits, count, int(cull_back_faces), tune);
+    }
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }
@@ -433,8 +431,10 @@ KjStatus kj_trace_any(KjScene* scene, const void* rays, void* out_u8, uint32_t c
     const SceneView sv = scene_view(*scene);
     if (getenv("KJ_TRACE_PER_RAY"))
         hipLaunchKernelGGL(k_trace_any, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count);
-    else
-        hipLaunchKernelGGL(k_trace_any_stream, dim3(stream_waves(scene->dev, count)), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count, stream_tune());
+    else {
+        uint32_t waves; const StreamTune tune = stream_launch(scene->dev, count, &waves);
+        hipLaunchKernelGGL(k_trace_any_stream, dim3(waves), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count, tune);
+    }
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }

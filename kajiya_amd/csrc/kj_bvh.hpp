@@ -200,16 +200,29 @@ KJ_D void tri_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t st
     else KJ_POP(S.cur)
 }
 
-// One ray, start to finish, inside a caller's kernel: one step per iteration, a node visit or ONE triangle test.
+// One ray per lane, start to finish, inside a caller's kernel. The lanes of the wave that are in the call step together: each
+// wave step issues EITHER the node block or the triangle block, whichever more lanes are waiting for (triangle lanes count
+// double: their block is the cheaper one), instead of a mixed wave paying for both blocks in every iteration. Per-ray results do
+// not depend on the interleaving. (On the tests' CPU stand-in for HIP lanes run one at a time and each simply loops by itself.)
 template <bool ANY_HIT, bool STATS = false>
 KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bool cull_back, uint32_t* stack, uint32_t stride, TraverseStats* stats = nullptr) {
     RayState S;
     ray_begin<ANY_HIT>(S, o, d, tmin, tmax, cull_back);
     uint32_t spill[KJ_BVH_SPILL_STACK];
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (;;) {
+        const bool want_node = S.cur != KJ_BVH_NONE && !(S.cur & KJ_BVH_LEAF), want_tri = S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF);
+        const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
+        if (nn + nt == 0u) break;
+        if (nt == 0u || (nn != 0u && nn >= nt * 2u)) { if (want_node) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
+        else { if (want_tri) tri_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
+    }
+#else
     while (S.cur != KJ_BVH_NONE) {
         if (!(S.cur & KJ_BVH_LEAF)) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);
         else tri_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);
     }
+#endif
     return S.h;
 }
 
@@ -222,15 +235,23 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
 //    waiting for the other block sit the step out. In a single-ray-per-lane loop a mixed wave pays for both blocks every
 //    iteration; here every issued block works for the majority of the lanes.
 //  Per-ray results are identical to bvh_trace() (same steps in the same order for each ray; only the interleaving differs).
-#define KJ_STREAM_CHUNK 256u
+#define KJ_STREAM_CHUNK 256u     // rays a wave takes at a time; a launch shrinks it (down to 64) when that is needed to give every wave slot a chunk
 // scheduling knobs of a stream launch (uniform): lanes parked before a refill; a step runs the node block when nodes * node_weight >= tris * tri_weight
-struct StreamTune { uint32_t refill_threshold, node_weight, tri_weight; };
+struct StreamTune { uint32_t refill_threshold, node_weight, tri_weight, chunk; };
+// waves and chunk size of a stream launch over `count` rays on a chip with `wave_slots` persistent waves to fill
+KJ_HD StreamTune stream_tune_for(uint32_t count, uint32_t wave_slots, uint32_t* out_waves) {
+    uint32_t chunk = ((count / (wave_slots ? wave_slots : 1u) + 63u) / 64u) * 64u;
+    chunk = chunk < 64u ? 64u : (chunk > KJ_STREAM_CHUNK ? KJ_STREAM_CHUNK : chunk);
+    const uint32_t chunks = (count + chunk - 1u) / chunk;
+    *out_waves = chunks < 1u ? 1u : (chunks < wave_slots ? chunks : wave_slots);
+    return StreamTune{16u, 1u, 2u, chunk};
+}
 struct StreamHit { float t, u, v; uint32_t slot; };   // closest hit: slot = leaf-order triangle index, 0xffffffff = miss; occlusion: slot != 0xffffffff = blocked
 
 // `emit(ray_index, hit)` stores one finished ray's result.
 template <bool ANY_HIT, bool STATS = false, typename Emit>
 KJ_D void bvh_trace_stream(const BvhView& bvh, const float4* __restrict__ rays, uint32_t count, bool cull_back,
-                           uint32_t wave_index, uint32_t wave_count, uint32_t* stack, uint32_t stride, Emit emit, StreamTune tune = StreamTune{16u, 1u, 2u},
+                           uint32_t wave_index, uint32_t wave_count, uint32_t* stack, uint32_t stride, Emit emit, StreamTune tune = StreamTune{16u, 1u, 2u, KJ_STREAM_CHUNK},
                            TraverseStats* stats = nullptr) {
     const uint32_t lane = __lane_id() & 63u;
     const unsigned long long lane_bit = 1ull << lane;
@@ -240,8 +261,8 @@ KJ_D void bvh_trace_stream(const BvhView& bvh, const float4* __restrict__ rays, 
     uint32_t spill[KJ_BVH_SPILL_STACK];
     bool live = false;
     uint32_t ray_index = 0;
-    uint32_t chunk = wave_index, cursor = wave_index * KJ_STREAM_CHUNK;
-    uint32_t chunk_end = min(count, cursor + KJ_STREAM_CHUNK);
+    uint32_t chunk = wave_index, cursor = wave_index * tune.chunk;
+    uint32_t chunk_end = min(count, cursor + tune.chunk);
     bool exhausted = cursor >= count;
     for (;;) {
         const bool parked = S.cur == KJ_BVH_NONE;
@@ -250,7 +271,7 @@ KJ_D void bvh_trace_stream(const BvhView& bvh, const float4* __restrict__ rays, 
         if (!exhausted && (n_parked >= tune.refill_threshold || pm == ~0ull)) {
             if (parked && live) { emit(ray_index, S.h); live = false; }
             if (cursor == chunk_end) {
-                chunk += wave_count; cursor = chunk * KJ_STREAM_CHUNK; chunk_end = min(count, cursor + KJ_STREAM_CHUNK);
+                chunk += wave_count; cursor = chunk * tune.chunk; chunk_end = min(count, cursor + tune.chunk);
                 if (cursor >= count) { exhausted = true; chunk_end = cursor; }
             }
             const uint32_t take = min(n_parked, chunk_end - cursor);

@@ -136,6 +136,171 @@ KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
     if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
 }
 
+// ---- fused form of the two ray passes: one invocation per pixel does ray generation, both traversals, hit shading and the
+// bookkeeping, as the reference's ray-generation shaders do. Used for launches too small to fill the chip more than once (at
+// 1080p a pass is 8100 waves for 8192 wave slots: nothing to refill from, and the dependent launches of the staged form below only
+// add latency -- measured 0.52 ms against 0.26 ms); the traversal inside still votes per wave on node vs triangle steps.
+struct TraceResult { V3 out_value; V3 hit_normal_ws; float hit_t; float pdf; bool is_hit; };
+template <bool STATS>
+KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3 normal_ws, uint32_t& rng, V3 ray_o, V3 ray_d, float ray_tmax, uint32_t* stack) {
+    const FrameConstants& fc = *c.fc;
+    V3 total_radiance = v3(0.0f);
+    V3 hit_normal_ws = -ray_d;
+    float hit_t = ray_tmax;
+    const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, ray_d) * 2 * KJ_PI));
+    count_rays(c.ray_counters, 0, true);
+    TraverseStats st_closest{0, 0}, st_any{0, 0};
+    // diffuse_trace_common.inc.hlsl:68-71: reflected cone = the half-res pixel cone propagated from the eye to the ray origin
+    const RayCone ray_cone = pixel_ray_cone_from_image_height(fc, float(c.depth.h) * 0.5f).propagate(0.03f, length(ray_o - get_eye_position(fc)));
+    const GbufferPathVertex primary_hit = gbuffer_raytrace<STATS>(c.sc, fc, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, 64, &st_closest, ray_cone);
+    if (primary_hit.is_hit) {
+        hit_t = primary_hit.ray_t;
+        GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);
+        hit_normal_ws = gbuffer.normal;
+        const V3 hit_cs = position_world_to_sample(fc, primary_hit.position);
+        const V2 hit_uv = cs_to_uv(V2{hit_cs.x, hit_cs.y});
+        const float screen_depth = sample_nearest_clamp(c.depth, hit_uv);
+        bool is_on_screen = fabsf(hit_cs.x) < 1.0f && fabsf(hit_cs.y) < 1.0f && inverse_depth_relative_diff(hit_cs.z, screen_depth) < 5e-3f;
+        V4 reprojected_radiance = v4(0.0f);
+        if (is_on_screen) {
+            reprojected_radiance = unpack_rgba16f(sample_nearest_clamp(c.reprojected_gi, hit_uv)) * fc.pre_exposure_delta;
+            is_on_screen = reprojected_radiance.w > 0;
+        }
+        gbuffer.roughness = lerp(gbuffer.roughness, 1.0f, ROUGHNESS_BIAS);
+        const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
+        const V3 wo = to_local(tangent_to_world, -ray_d);
+        const LayeredBrdf brdf = layered_brdf_from_gbuffer_ndotv(c.brdf_fg_lut, gbuffer, wo.z);
+        const float4 sc4 = *c.sun_color;
+        const V3 sun_radiance{sc4.x, sc4.y, sc4.z};
+        if (sun_radiance.x != 0 || sun_radiance.y != 0 || sun_radiance.z != 0) {
+            const V4 bn = blue_noise_for_pixel(c.blue_noise, px, py, rng);
+            const V3 to_light_norm = sample_sun_direction(fc, V2{bn.x, bn.y}, false);
+            count_rays(c.ray_counters, 1, true);
+            const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, 64, &st_any);
+            const V3 wi = to_local(tangent_to_world, to_light_norm);
+            const V3 brdf_value = layered_brdf_evaluate(brdf, wo, wi) * fmaxf(0.0f, wi.z);
+            total_radiance += brdf_value * (is_shadowed ? v3(0.0f) : sun_radiance);
+        }
+        total_radiance += gbuffer.emissive;
+        if (is_on_screen) {
+            total_radiance += xyz(reprojected_radiance) * gbuffer.albedo;
+        } else {
+            V2 urand;
+            urand.x = uint_to_u01_float(hash1_mut(rng));
+            urand.y = uint_to_u01_float(hash1_mut(rng));
+            const uint32_t nl = min(fc.triangle_light_count, c.sc.light_count);
+            for (uint32_t li = 0; li < nl; ++li) {
+                const KjTriangleLight tl = c.sc.lights[li];
+                const V3 v0{tl.verts[0], tl.verts[1], tl.verts[2]}, v1{tl.verts[3], tl.verts[4], tl.verts[5]}, v2{tl.verts[6], tl.verts[7], tl.verts[8]};
+                const LightSampleArea ls = sample_triangle_light(v0, v1 - v0, v2 - v0, urand);
+                const V3 to_light_ws = ls.pos - primary_hit.position;
+                const float dist2 = dot(to_light_ws, to_light_ws);
+                const V3 to_light_norm_ws = to_light_ws * (1.0f / sqrtf(dist2));
+                const float to_psa_metric = fmaxf(0.0f, dot(to_light_norm_ws, gbuffer.normal)) * fmaxf(0.0f, dot(to_light_norm_ws, -ls.normal)) / dist2;
+                if (to_psa_metric > 0.0f) {
+                    count_rays(c.ray_counters, 1, true);
+                    const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, 64, &st_any);
+                    const V3 bounce_albedo = lerp(gbuffer.albedo, v3(1.0f), 0.04f);
+                    const V3 brdf_value = bounce_albedo * to_psa_metric / KJ_PI;
+                    if (!is_shadowed) total_radiance += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * brdf_value / ls.pdf;
+                }
+            }
+            if (c.has_ircache) {  // USE_IRCACHE (diffuse_trace_common.inc.hlsl:189-198); unbound => contributes 0 (BASELINE config 1)
+                const V3 gi = ircache_lookup<false>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng);
+                total_radiance += gi * gbuffer.albedo;
+            }
+        }
+    } else {
+        total_radiance += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
+    }
+    if (STATS) {  // instrumentation build only: traversal work per ray type (SURVEY 8d "measured by the instrumented kernel")
+        atomicAdd(&counter_slot(c.ray_counters)[2], (unsigned long long)st_closest.nodes);
+        atomicAdd(&counter_slot(c.ray_counters)[3], (unsigned long long)st_closest.tris);
+        atomicAdd(&counter_slot(c.ray_counters)[4], (unsigned long long)st_any.nodes);
+        atomicAdd(&counter_slot(c.ray_counters)[5], (unsigned long long)st_any.tris);
+    }
+    return TraceResult{total_radiance, hit_normal_ws, hit_t, pdf, primary_hit.is_hit};
+}
+
+// ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111
+template <bool STATS>
+__global__ void __launch_bounds__(64) k_rtdgi_validate_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
+                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+    extern __shared__ uint32_t lds_stack[];
+    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    if (0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y)) { invalidity_out_tex.st(x, y, to_unorm8(1.0f)); return; }
+    float invalidity = 0.0f;
+    if (is_rtdgi_validation_frame(fc.frame_index)) {
+        const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
+        const float4 ro = ray_orig_history_tex.ld(x, y);
+        const V3 prev_ray_orig{ro.x, ro.y, ro.z};
+        const V3 prev_hit_pos = xyz(ld4(reservoir_ray_history_tex, x, y)) + prev_ray_orig;
+        const V4 prev_radiance_packed = ld4(irradiance_history_tex, x, y);
+        const V3 prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
+        uint32_t rng = hash3(uint32_t(x), uint32_t(y), 0);
+        const TraceResult result = trace_candidate<STATS>(c, x, y, normal_ws, rng, prev_ray_orig, normalize(prev_hit_pos - prev_ray_orig), SKY_DIST, lds_stack + lane);
+        const V3 new_radiance = vmax(v3(0.0f), result.out_value);
+        const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
+        invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
+        const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
+        if (fabsf(result.hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
+            st4(irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
+            Reservoir1spp r = Reservoir1spp::from_raw(reservoir_tex.ld(x, y));
+            const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
+            r.M *= clampf(lum_old / fmaxf(1e-8f, lum_new), 0.03f, 1.0f);
+            r.W *= clampf(lum_old / fmaxf(1e-8f, lum_new) * 10.0f, 0.01f, 1.0f);
+            reservoir_tex.st(x, y, r.as_raw());
+        }
+    }
+    invalidity_out_tex.st(x, y, to_unorm8(invalidity));
+}
+
+// ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24
+template <bool STATS>
+__global__ void __launch_bounds__(64) k_rtdgi_trace_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
+                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+    extern __shared__ uint32_t lds_stack[];
+    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    if (!in_image) return;
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+    const float depth = c.depth.ld(hx, hy);
+    if (0.0f == depth) {
+        st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
+        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
+        invalidity_out_tex.st(x, y, 0);
+        return;
+    }
+    const V4 gts = tex_size4(c.depth.w, c.depth.h);
+    const V2 uv = get_uv(float(hx), float(hy), gts);
+    const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
+    const float near_field_fade_out_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
+    const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
+    {
+        const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
+        const Basis tangent_to_world = build_orthonormal_basis(normal_ws);
+        const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, fc.frame_index);
+        const V3 outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
+        const V3 origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
+        uint32_t rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u);
+        TraceResult result = trace_candidate<STATS>(c, x, y, normal_ws, rng, origin, outgoing_dir, tracing_frame ? SKY_DIST : near_field_fade_out_end, lds_stack + lane);
+        if (!tracing_frame && !result.is_hit) { result.out_value = v3(0.0f); result.hit_t = SKY_DIST; }
+        const V3 hit_offset_ws = outgoing_dir * result.hit_t;
+        const float cos_theta = dot(normalize(outgoing_dir - vr.dir_ws), normal_ws);
+        st4(candidate_irradiance_out_tex, x, y, v4(result.out_value, 1.0f - cos_theta));
+        st4(candidate_hit_out_tex, x, y, v4(hit_offset_ws, result.pdf * (tracing_frame ? 1.0f : -1.0f)));
+        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, result.hit_normal_ws), 0)));
+    }
+    const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
+    const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
+    invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
+}
+
+// ---- staged form, for launches that hold several wave-fulls of rays per wave slot (1440p and up: KjRtdgi::staged_min_rays).
 // The reference's ray-generation shaders (trace_diffuse.rgen.hlsl, diffuse_validate.rgen.hlsl) run ray generation, traversal,
 // hit shading, the sun's shadow ray and the result's bookkeeping in one invocation per pixel. On gfx950 that is a megakernel
 // whose waves idle three lanes out of four (sky pixels, rays of unequal length, node / triangle steps interleaved, hit vs miss
@@ -220,14 +385,14 @@ __global__ void __launch_bounds__(64) k_rtdgi_validate_raygen(TraceCtx c, RaySta
 // ------------------------------------------------------------------ closest-hit / occlusion streams over a stage's rays
 template <bool ANY_HIT, bool STATS>
 __global__ void __launch_bounds__(64) k_rtdgi_ray_stream(BvhView bvh, const float4* __restrict__ rays, float4* __restrict__ hits, uint32_t* __restrict__ occl, uint32_t count,
-                                                          unsigned long long* __restrict__ ray_counters) {
+                                                          unsigned long long* __restrict__ ray_counters, StreamTune tune) {
     extern __shared__ uint32_t lds_stack[];
     TraverseStats stats{0, 0};
     bvh_trace_stream<ANY_HIT, STATS>(bvh, rays, count, false, blockIdx.x, gridDim.x, lds_stack + threadIdx.x, 64,
                                      [&](uint32_t i, const RayHit& h) {
                                          if (ANY_HIT) occl[i] = h.slot != 0xffffffffu ? 1u : 0u;
                                          else hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
-                                     }, StreamTune{16u, 1u, 2u}, &stats);
+                                     }, tune, &stats);
     if (STATS) {  // instrumentation build only: traversal work per ray type (SURVEY 8d "measured by the instrumented kernel")
         atomicAdd(&counter_slot(ray_counters)[ANY_HIT ? 4 : 2], (unsigned long long)stats.nodes);
         atomicAdd(&counter_slot(ray_counters)[ANY_HIT ? 5 : 3], (unsigned long long)stats.tris);
@@ -670,6 +835,7 @@ struct KjRtdgi {
     kj::DevBuf ray_counters;                    // KJ_COUNTER_SLOTS x (6 used of KJ_COUNTER_STRIDE) u64, see kj_vec.hpp
     bool profiling = false;                     // per-pass GPU timestamps (gpu-profiler scopes, kajiya-rg/src/graph.rs:941-944)
     bool count_traversal = false;               // instrumented trace kernels
+    uint32_t staged_min_rays = 1200000;         // ray passes run staged (ray streams) from this many ray slots per launch, fused below (KJ_RTDGI_STAGED_MIN_RAYS)
     uint32_t stream_waves_per_cu = 24;          // persistent waves per CU of a ray-stream launch (measured best of 8 / 16 / 24 / 32: scripts/traversal_microbench.py)
     int resample_variant = 2;                   // spatial reuse: 2 = per-tap gathers (fastest measured), 0 / 1 = LDS-staged tiles (KJ_RTDGI_RESAMPLE_VARIANT; rtdgi_resample.hpp)
     static const int NUM_SCOPES = 11;
@@ -709,6 +875,7 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     KjRtdgi* r = new KjRtdgi();
     r->dev = dev;
     if (const char* v = getenv("KJ_RTDGI_RESAMPLE_VARIANT")) r->resample_variant = atoi(v);
+    if (const char* v = getenv("KJ_RTDGI_STAGED_MIN_RAYS")) r->staged_min_rays = uint32_t(atoll(v));
     if (r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
     *out = r;
     return KJ_OK;
@@ -823,21 +990,39 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     // the ray passes' stage buffers (dense, one slot per lane of every 8x8 tile of the launch)
     const uint32_t stage_rays = gh.x * gh.y * 64u;
     const size_t stage_full = size_t((hw + 7) / 8) * ((hh + 7) / 8) * 64;
-    RayStage st;
+    RayStage st{};
+    if (stage_rays >= r->staged_min_rays) {
     st.rays_a = (float4*)r->get("stage.rays_a", stage_full * 32, s);
     st.hits_a = (float4*)r->get("stage.hits_a", stage_full * 16, s);
     st.rays_b = (float4*)r->get("stage.rays_b", stage_full * 32, s);
     st.occl_b = (uint32_t*)r->get("stage.occl_b", stage_full * 4, s);
     st.state = (float4*)r->get("stage.state", stage_full * 32, s);
+    }
     KJ_TRY_HIP(r->err);
-    const uint32_t stream_grid = std::max(1u, std::min((stage_rays + KJ_STREAM_CHUNK - 1u) / KJ_STREAM_CHUNK, r->dev->num_cus * r->stream_waves_per_cu));
+    uint32_t stream_grid;
+    const StreamTune stream_tune = stream_tune_for(stage_rays, r->dev->num_cus * r->stream_waves_per_cu, &stream_grid);
     auto trace_streams = [&](bool closest) {
         if (closest) hipLaunchKernelGGL((r->count_traversal ? k_rtdgi_ray_stream<false, true> : k_rtdgi_ray_stream<false, false>), dim3(stream_grid), blk, trace_lds, s, tc.sc.bvh,
-                                        (const float4*)st.rays_a, st.hits_a, (uint32_t*)nullptr, stage_rays, tc.ray_counters);
+                                        (const float4*)st.rays_a, st.hits_a, (uint32_t*)nullptr, stage_rays, tc.ray_counters, stream_tune);
         else hipLaunchKernelGGL((r->count_traversal ? k_rtdgi_ray_stream<true, true> : k_rtdgi_ray_stream<true, false>), dim3(stream_grid), blk, trace_lds, s, tc.sc.bvh,
-                                (const float4*)st.rays_b, (float4*)nullptr, st.occl_b, stage_rays, tc.ray_counters);
+                                (const float4*)st.rays_b, (float4*)nullptr, st.occl_b, stage_rays, tc.ray_counters, stream_tune);
     };
-    if (mask & KJ_RTDGI_PASS_VALIDATE) {
+    const bool staged = stage_rays >= r->staged_min_rays;
+    if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged) {
+        SCOPE_BEGIN(2);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+                           img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(2);
+    }
+    if ((mask & KJ_RTDGI_PASS_TRACE) && !staged) {
+        SCOPE_BEGIN(3);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(3);
+    }
+    if ((mask & KJ_RTDGI_PASS_VALIDATE) && staged) {
         SCOPE_BEGIN(2);
         hipLaunchKernelGGL(k_rtdgi_validate_raygen, gh, blk, 0, s, tc, st, img<uint2>(ray_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
@@ -851,7 +1036,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         }
         SCOPE_END(2);
     }
-    if (mask & KJ_RTDGI_PASS_TRACE) {
+    if ((mask & KJ_RTDGI_PASS_TRACE) && staged) {
         SCOPE_BEGIN(3);
         hipLaunchKernelGGL(k_rtdgi_trace_raygen, gh, blk, 0, s, tc, st, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
                            img<uint32_t>(candidate_normal, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
