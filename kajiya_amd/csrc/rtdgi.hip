@@ -136,10 +136,13 @@ KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
     if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
 }
 
-// ---- fused form of the two ray passes: one invocation per pixel does ray generation, both traversals, hit shading and the
-// bookkeeping, as the reference's ray-generation shaders do. Used for launches too small to fill the chip more than once (at
-// 1080p a pass is 8100 waves for 8192 wave slots: nothing to refill from, and the dependent launches of the staged form below only
-// add latency -- measured 0.52 ms against 0.26 ms); the traversal inside still votes per wave on node vs triangle steps.
+// ---- fused form of the two ray passes (the default): one invocation per pixel does ray generation, both traversals, hit shading
+// and the bookkeeping, as the reference's ray-generation shaders do; the traversal inside votes per wave on node vs triangle steps.
+// Measured against the staged form below (profiles/r02_ray_pipeline_variants.md): trace pass 0.259 ms fused / 0.437 staged at
+// 1080p (518 k rays: 8100 waves for 8192 wave slots, nothing to refill from, and five dependent launches instead of one) and
+// 0.777 / 0.918 ms at 4K (2.07 M rays). The fused kernel already runs at the speed of its two traversals alone (0.24 ms at the
+// stream rates of scripts/traversal_microbench.py): hit shading hides completely behind other waves' memory latency, so taking
+// it out of the kernel buys nothing and the extra round trips through memory (96 B per ray) cost.
 struct TraceResult { V3 out_value; V3 hit_normal_ws; float hit_t; float pdf; bool is_hit; };
 template <bool STATS>
 KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3 normal_ws, uint32_t& rng, V3 ray_o, V3 ray_d, float ray_tmax, uint32_t* stack) {
@@ -300,7 +303,8 @@ __global__ void __launch_bounds__(64) k_rtdgi_trace_fused(TraceCtx c, ImgU32 hal
     invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
 }
 
-// ---- staged form, for launches that hold several wave-fulls of rays per wave slot (1440p and up: KjRtdgi::staged_min_rays).
+// ---- staged form (KJ_RTDGI_STAGED_MIN_RAYS=0 selects it; kept for measurements and for callers that batch rays: its stream
+// kernels are what kj_trace_closest / kj_trace_any run, +28 % rays/s over one ray per lane on 1.6 M incoherent rays).
 // The reference's ray-generation shaders (trace_diffuse.rgen.hlsl, diffuse_validate.rgen.hlsl) run ray generation, traversal,
 // hit shading, the sun's shadow ray and the result's bookkeeping in one invocation per pixel. On gfx950 that is a megakernel
 // whose waves idle three lanes out of four (sky pixels, rays of unequal length, node / triangle steps interleaved, hit vs miss
@@ -835,7 +839,7 @@ struct KjRtdgi {
     kj::DevBuf ray_counters;                    // KJ_COUNTER_SLOTS x (6 used of KJ_COUNTER_STRIDE) u64, see kj_vec.hpp
     bool profiling = false;                     // per-pass GPU timestamps (gpu-profiler scopes, kajiya-rg/src/graph.rs:941-944)
     bool count_traversal = false;               // instrumented trace kernels
-    uint32_t staged_min_rays = 1200000;         // ray passes run staged (ray streams) from this many ray slots per launch, fused below (KJ_RTDGI_STAGED_MIN_RAYS)
+    uint32_t staged_min_rays = 0xffffffffu;     // ray passes run staged (ray streams) from this many ray slots per launch (KJ_RTDGI_STAGED_MIN_RAYS); default: never, see below
     uint32_t stream_waves_per_cu = 24;          // persistent waves per CU of a ray-stream launch (measured best of 8 / 16 / 24 / 32: scripts/traversal_microbench.py)
     int resample_variant = 2;                   // spatial reuse: 2 = per-tap gathers (fastest measured), 0 / 1 = LDS-staged tiles (KJ_RTDGI_RESAMPLE_VARIANT; rtdgi_resample.hpp)
     static const int NUM_SCOPES = 11;
