@@ -185,6 +185,10 @@ KjStatus kj_scene_commit(KjScene* scene, void* stream);
 /* Number of world-space triangle lights after commit (frame_constants.triangle_light_count). */
 KjStatus kj_scene_triangle_light_count(KjScene* scene, uint32_t* out);
 KjStatus kj_scene_stats(KjScene* scene, uint32_t* out_tri_count, uint32_t* out_node_count, uint64_t* out_bvh_bytes);
+/* Host time of the last kj_scene_commit in ms: [0] BLAS builds of newly added meshes, [1] instance records + TLAS build,
+ * [2] uploads + the device kernel that re-derives moved instances' world-space triangles (incl. the stream sync), [3] total.
+ * The reference's counterpart is the GPU time of build_ray_tracing_top_level_acceleration (world_renderer.rs:836-911). */
+KjStatus kj_scene_last_commit_ms(KjScene* scene, double out_ms[4]);
 
 /* Baked assets (`bin/bake` output, kajiya-asset-pipe/src/lib.rs:38-60): zero-copy, bounds-checked views of
  * `cache/<name>.mesh` (PackedTriMesh::Flat, kajiya-asset/src/mesh.rs:796-807) and `cache/<identity:08x>.image`

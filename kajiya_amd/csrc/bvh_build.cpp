@@ -49,6 +49,7 @@ struct SahBuilder {
     std::vector<float> cen;        // 3 per prim
     std::vector<uint32_t> idx;     // permutation
     std::vector<BinNode> nodes;
+    uint32_t max_leaf = KJ_BVH_MAX_LEAF_TRIS;   // 1 for a TLAS (one instance per leaf)
 
     explicit SahBuilder(const std::vector<BvhTri>& t) : tris(t) {
         const size_t n = t.size();
@@ -105,7 +106,7 @@ struct SahBuilder {
             }
         }
         const float parent_area = std::max(box.half_area(), 1e-30f);
-        const bool can_be_leaf = count <= KJ_BVH_MAX_LEAF_TRIS;
+        const bool can_be_leaf = count <= max_leaf;
         if (can_be_leaf && (best_axis < 0 || 1.0f + best_cost / parent_area >= float(count))) {
             nodes[me].first = first; nodes[me].count = count; return me;
         }
@@ -163,11 +164,12 @@ inline float dec(uint32_t q, float scale, float origin) { return origin + float(
 
 }  // namespace
 
-void build_bvh4(const std::vector<BvhTri>& world_tris, BuiltBvh& out) {
+void build_bvh4(const std::vector<BvhTri>& world_tris, BuiltBvh& out, uint32_t max_leaf) {
     const bool timing = getenv("KJ_BVH_TIMING") != nullptr;     // prints the phase times of the host build to stderr
     const auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[bvh build] %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
     SahBuilder sb(world_tris);
+    sb.max_leaf = std::min(std::max(max_leaf, 1u), KJ_BVH_MAX_LEAF_TRIS);
     lap("primitive boxes");
     uint32_t n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* e = getenv("KJ_BVH_THREADS")) n_threads = uint32_t(std::max(1, atoi(e)));   // 1 = the sequential build (tests compare the two)

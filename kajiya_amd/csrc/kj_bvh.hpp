@@ -1,7 +1,11 @@
 // Software ray traversal for gfx950 — replaces VK_KHR_ray_tracing's TraceRay
 // (inc/rt.hlsl:58-70,112-137; BLAS/TLAS in kajiya-backend/src/vulkan/ray_tracing.rs).
 //
-// Layout (built by bvh_build.cpp, resident in HBM / Infinity Cache):
+// Two levels (kj_scene_types.hpp: BvhView): a TLAS over instances in world space, one BLAS per mesh in object space. Entering an
+// instance transforms the ray for the BOX tests only (origin and direction through world->object; t is preserved) and leaves a
+// sentinel on the stack; triangles are tested in world space against the instance's world-space copies, so (t, u, v) do not
+// depend on how the scene is partitioned into instances.
+// Node / triangle layout (bvh_build.cpp, resident in HBM / Infinity Cache):
 //   Bvh4Node 64 B : up to four children; each child's AABB is 6 bytes (8 bits per plane) inside the node's own
 //                   frame (origin + power-of-two step per axis). One visit = 3.5 x 16-B loads per lane and tests
 //                   four boxes, so a ray takes about half the dependent steps and a quarter of the node bytes
@@ -86,47 +90,76 @@ KJ_D float q8(uint32_t packed, int i) { return float((packed >> (8 * i)) & 0xffu
 #error "the traversal is written for the 4-wide node (an 8-wide variant measured 24 % slower in round 1 and was dropped)"
 #endif
 
-// One ray in flight. `cur` is the reference about to be visited (a node, a leaf's next triangle, or KJ_BVH_NONE = finished).
+// One ray in flight. `cur` is the reference about to be visited (a node, a leaf's next triangle, an instance, or KJ_BVH_NONE = finished).
 struct RayState {
-    V3 o, d, inv_d;
+    V3 wo, wd;          // the ray in world space (triangle tests)
+    V3 bo, binv;        // origin and reciprocal direction in the space of the boxes being walked: world in the TLAS, object space inside an instance
     float tmin, tmax;
     RayHit h;
     uint32_t sp, cur;
+    uint32_t tri_base;  // first world triangle of the instance being walked; KJ_BVH_NONE while in the TLAS
+    float pad;          // slack around this instance's BLAS boxes
     bool cull_back;
 };
+KJ_D V3 safe_rcp3(V3 d) {
+    const float eps = 1e-20f;
+    return V3{1.0f / (fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x), 1.0f / (fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y),
+              1.0f / (fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z)};
+}
 
 template <bool ANY_HIT>
 KJ_D void ray_begin(RayState& S, V3 o, V3 d, float tmin, float tmax, bool cull_back) {
-    S.o = o; S.d = d; S.tmin = tmin; S.tmax = tmax; S.cull_back = cull_back;
+    S.wo = o; S.wd = d; S.tmin = tmin; S.tmax = tmax; S.cull_back = cull_back;
     S.h.t = FLT_MAX; S.h.u = 0; S.h.v = 0; S.h.slot = 0xffffffffu; S.h.world_id = 0xffffffffu;
     S.sp = 0;
+    S.tri_base = KJ_BVH_NONE; S.pad = 0.0f;
     // Rays with a non-finite origin or direction are misses (the reference's validation pass issues such
     // rays for pixels without history; a hardware traversal unit rejects every box for them). Without
     // this, NaN slabs pass the fmin/fmax test and the whole tree is walked.
     const bool finite = fabsf(o.x) <= FLT_MAX && fabsf(o.y) <= FLT_MAX && fabsf(o.z) <= FLT_MAX && fabsf(d.x) <= FLT_MAX && fabsf(d.y) <= FLT_MAX && fabsf(d.z) <= FLT_MAX;
-    S.cur = finite ? 0u : KJ_BVH_NONE;   // node 0 is the root
-    const float eps = 1e-20f;
-    S.inv_d = V3{1.0f / (fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x), 1.0f / (fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y),
-                 1.0f / (fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z)};
+    S.cur = finite ? 0u : KJ_BVH_NONE;   // TLAS node 0 is the root
+    S.bo = o;
+    S.binv = safe_rcp3(d);
 }
 
 // Traversal stack: the first KJ_BVH_LDS_STACK entries live in LDS ([level][lane]); the rare deeper ones spill to a
 // private array (scratch). Near-first ordering keeps a typical ray's stack far below the builder's worst-case bound,
 // so the LDS footprint (4 KB / wave) does not cap occupancy the way a bound-sized LDS stack did (11 KB / wave).
 #define KJ_PUSH(v_) { const uint32_t pv_ = (v_); if (S.sp < KJ_BVH_LDS_STACK) stack[S.sp * stride] = pv_; else spill[S.sp - KJ_BVH_LDS_STACK] = pv_; S.sp++; }
-#define KJ_POP(dst_) { if (S.sp == 0) dst_ = KJ_BVH_NONE; else { --S.sp; dst_ = S.sp < KJ_BVH_LDS_STACK ? stack[S.sp * stride] : spill[S.sp - KJ_BVH_LDS_STACK]; } }
+// next reference off the stack; the sentinel an instance left behind puts the ray back into the TLAS
+KJ_D void pop_next(RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill) {
+    for (;;) {
+        if (S.sp == 0) { S.cur = KJ_BVH_NONE; return; }
+        --S.sp;
+        const uint32_t v = S.sp < KJ_BVH_LDS_STACK ? stack[S.sp * stride] : spill[S.sp - KJ_BVH_LDS_STACK];
+        if (v != KJ_BVH_SENTINEL) { S.cur = v; return; }
+        S.bo = S.wo; S.binv = safe_rcp3(S.wd); S.tri_base = KJ_BVH_NONE; S.pad = 0.0f;
+    }
+}
+#define KJ_POP(dst_) pop_next(S, stack, stride, spill);
+// S.cur is a TLAS leaf: take the ray into that instance's BLAS
+KJ_D void enter_instance(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill) {
+    const float4* __restrict__ r = (const float4*)(bvh.instances + (S.cur & 0x0fffffffu));
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+    const uint4 m = *(const uint4*)(r + 3);
+    KJ_PUSH(KJ_BVH_SENTINEL)
+    const V3 o = S.wo, d = S.wd;
+    S.bo = V3{r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w, r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w, r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w};
+    S.binv = safe_rcp3(V3{r0.x * d.x + r0.y * d.y + r0.z * d.z, r1.x * d.x + r1.y * d.y + r1.z * d.z, r2.x * d.x + r2.y * d.y + r2.z * d.z});
+    S.cur = m.x; S.tri_base = m.y; S.pad = __uint_as_float(m.z);
+}
 
 // Visit the 4-wide node S.cur: test its four quantised child boxes, continue with the nearest hit child, push the others.
 template <bool ANY_HIT, bool STATS>
 KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
     const uint32_t NONE = KJ_BVH_NONE;
-    const float4* __restrict__ n = (const float4*)bvh.nodes + size_t(S.cur) * 4;
+    const float4* __restrict__ n = (const float4*)(S.tri_base == KJ_BVH_NONE ? bvh.tlas_nodes : bvh.blas_nodes) + size_t(S.cur) * 4;
     const float4 n0 = n[0];
     const uint4 ch = *(const uint4*)(n + 1);
     const uint4 qa = *(const uint4*)(n + 2);     // qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4]
     const uint2 qb = *(const uint2*)(n + 3);     // qhi.y[4], qhi.z[4]
     if (STATS) stats->nodes++;
-    const V3 o = S.o, inv_d = S.inv_d;
+    const V3 o = S.bo, inv_d = S.binv;
     const float tmin = S.tmin;
     const bool neg_x = inv_d.x < 0.0f, neg_y = inv_d.y < 0.0f, neg_z = inv_d.z < 0.0f;
     const float tlimit = ANY_HIT ? S.tmax : fminf(S.h.t, S.tmax);
@@ -140,7 +173,11 @@ KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
     const uint32_t nqx = neg_x ? qa.w : qa.x, fqx = neg_x ? qa.x : qa.w;
     const uint32_t nqy = neg_y ? qb.x : qa.y, fqy = neg_y ? qa.y : qb.x;
     const uint32_t nqz = neg_z ? qb.y : qa.z, fqz = neg_z ? qa.z : qb.y;
-    const float bx = n0.x - o.x, by = n0.y - o.y, bz = n0.z - o.z;
+    // near planes move out by the instance's slack, far planes too (0 in the TLAS, whose boxes are padded when built)
+    const float px = neg_x ? S.pad : -S.pad, py = neg_y ? S.pad : -S.pad, pz = neg_z ? S.pad : -S.pad;
+    const float bx0 = n0.x - o.x, by0 = n0.y - o.y, bz0 = n0.z - o.z;
+    const float bx = bx0 + px, by = by0 + py, bz = bz0 + pz;            // near
+    const float fx = bx0 - px, fy = by0 - py, fz = bz0 - pz;            // far
     uint32_t key[4];
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
@@ -148,9 +185,9 @@ KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
         const f32x2 tnx = __builtin_elementwise_fma(f32x2{q8(nqx, i0), q8(nqx, i1)}, f32x2{sx, sx}, f32x2{bx, bx}) * f32x2{inv_d.x, inv_d.x};
         const f32x2 tny = __builtin_elementwise_fma(f32x2{q8(nqy, i0), q8(nqy, i1)}, f32x2{sy, sy}, f32x2{by, by}) * f32x2{inv_d.y, inv_d.y};
         const f32x2 tnz = __builtin_elementwise_fma(f32x2{q8(nqz, i0), q8(nqz, i1)}, f32x2{sz, sz}, f32x2{bz, bz}) * f32x2{inv_d.z, inv_d.z};
-        const f32x2 tfx = __builtin_elementwise_fma(f32x2{q8(fqx, i0), q8(fqx, i1)}, f32x2{sx, sx}, f32x2{bx, bx}) * f32x2{inv_d.x, inv_d.x};
-        const f32x2 tfy = __builtin_elementwise_fma(f32x2{q8(fqy, i0), q8(fqy, i1)}, f32x2{sy, sy}, f32x2{by, by}) * f32x2{inv_d.y, inv_d.y};
-        const f32x2 tfz = __builtin_elementwise_fma(f32x2{q8(fqz, i0), q8(fqz, i1)}, f32x2{sz, sz}, f32x2{bz, bz}) * f32x2{inv_d.z, inv_d.z};
+        const f32x2 tfx = __builtin_elementwise_fma(f32x2{q8(fqx, i0), q8(fqx, i1)}, f32x2{sx, sx}, f32x2{fx, fx}) * f32x2{inv_d.x, inv_d.x};
+        const f32x2 tfy = __builtin_elementwise_fma(f32x2{q8(fqy, i0), q8(fqy, i1)}, f32x2{sy, sy}, f32x2{fy, fy}) * f32x2{inv_d.y, inv_d.y};
+        const f32x2 tfz = __builtin_elementwise_fma(f32x2{q8(fqz, i0), q8(fqz, i1)}, f32x2{sz, sz}, f32x2{fz, fz}) * f32x2{inv_d.z, inv_d.z};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int i = pr * 2 + k;
@@ -188,12 +225,13 @@ KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
 // Test ONE triangle of the leaf S.cur; an occlusion ray that hits is finished.
 template <bool ANY_HIT, bool STATS>
 KJ_D void tri_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
-    const uint32_t first = S.cur & 0x0fffffffu;
+    const uint32_t first = S.cur & 0x0fffffffu;      // relative to the instance's triangles
     const uint32_t rest = (S.cur >> 28) & 7u;      // triangles left after this one
-    const float4* __restrict__ tp = (const float4*)bvh.tris + size_t(first) * 3;
+    const uint32_t slot = S.tri_base + first;
+    const float4* __restrict__ tp = (const float4*)bvh.tris + size_t(slot) * 3;
     const float4 a = tp[0], b = tp[1], c = tp[2];
     if (STATS) stats->tris++;
-    if (intersect_tri(S.o, S.d, S.tmin, S.tmax, a, b, c, first, S.cull_back, S.h)) {
+    if (intersect_tri(S.wo, S.wd, S.tmin, S.tmax, a, b, c, slot, S.cull_back, S.h)) {
         if (ANY_HIT) { S.cur = KJ_BVH_NONE; return; }
     }
     if (rest) S.cur = KJ_BVH_LEAF | ((rest - 1u) << 28) | (first + 1u);
@@ -211,7 +249,12 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
     uint32_t spill[KJ_BVH_SPILL_STACK];
 #if defined(__HIP_DEVICE_COMPILE__)
     for (;;) {
-        const bool want_node = S.cur != KJ_BVH_NONE && !(S.cur & KJ_BVH_LEAF), want_tri = S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF);
+        const bool leaf = S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF);
+        if (__ballot(leaf && S.tri_base == KJ_BVH_NONE) != 0ull) {     // TLAS leaves: short, taken as soon as any lane has one
+            if (leaf && S.tri_base == KJ_BVH_NONE) enter_instance(bvh, S, stack, stride, spill);
+            continue;
+        }
+        const bool want_node = S.cur != KJ_BVH_NONE && !leaf, want_tri = leaf;
         const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
         if (nn + nt == 0u) break;
         if (nt == 0u || (nn != 0u && nn >= nt * 2u)) { if (want_node) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
@@ -220,6 +263,7 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
 #else
     while (S.cur != KJ_BVH_NONE) {
         if (!(S.cur & KJ_BVH_LEAF)) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);
+        else if (S.tri_base == KJ_BVH_NONE) enter_instance(bvh, S, stack, stride, spill);
         else tri_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);
     }
 #endif
@@ -256,7 +300,7 @@ KJ_D void bvh_trace_stream(const BvhView& bvh, const float4* __restrict__ rays, 
     const uint32_t lane = __lane_id() & 63u;
     const unsigned long long lane_bit = 1ull << lane;
     RayState S;
-    S.cur = KJ_BVH_NONE; S.sp = 0;
+    S.cur = KJ_BVH_NONE; S.sp = 0; S.tri_base = KJ_BVH_NONE; S.pad = 0.0f;
     S.h.t = FLT_MAX; S.h.u = S.h.v = 0; S.h.slot = S.h.world_id = 0xffffffffu;
     uint32_t spill[KJ_BVH_SPILL_STACK];
     bool live = false;
@@ -285,7 +329,12 @@ KJ_D void bvh_trace_stream(const BvhView& bvh, const float4* __restrict__ rays, 
             }
             cursor += take;
         }
-        const bool want_node = S.cur != KJ_BVH_NONE && !(S.cur & KJ_BVH_LEAF), want_tri = S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF);
+        const bool leaf = S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF);
+        if (__ballot(leaf && S.tri_base == KJ_BVH_NONE) != 0ull) {     // TLAS leaves: short, taken as soon as any lane has one
+            if (leaf && S.tri_base == KJ_BVH_NONE) enter_instance(bvh, S, stack, stride, spill);
+            continue;
+        }
+        const bool want_node = S.cur != KJ_BVH_NONE && !leaf, want_tri = leaf;
         const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
         if (nn + nt == 0u) { if (exhausted) break; else continue; }
         if (nt == 0u || (nn != 0u && nn * tune.node_weight >= nt * tune.tri_weight)) { if (want_node) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }

@@ -10,6 +10,8 @@ struct BuiltBvh {
     std::vector<BvhTri> tris;      // leaf order
     uint32_t max_stack = 1;        // upper bound of the traversal stack depth
 };
-void build_bvh4(const std::vector<BvhTri>& world_tris, BuiltBvh& out);
+// `tris`: any space (a mesh's object space for a BLAS). For a TLAS pass one degenerate "triangle" per instance whose vertices span the
+// instance's world box (v0 = min, v1 = max, v2 = min; prim = instance index) and max_leaf = 1.
+void build_bvh4(const std::vector<BvhTri>& tris, BuiltBvh& out, uint32_t max_leaf = KJ_BVH_MAX_LEAF_TRIS);
 
 }  // namespace kj

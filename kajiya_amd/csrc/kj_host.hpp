@@ -80,9 +80,19 @@ struct KjScene {
     std::vector<Inst> instances;
     std::vector<kj::MapDesc> maps;      // one per material map
     std::vector<uint8_t> tex_data;      // RGBA8 mip chains of the image maps
+    // per-mesh acceleration structure (BLAS), built once: nodes + object-space triangles in leaf order, appended to the shared arrays
+    struct Blas { uint32_t node_base = 0, node_count = 0, tri_base = 0, tri_count = 0, max_stack = 1; float bounds[6] = {0, 0, 0, 0, 0, 0}; bool built = false; };
+    std::vector<Blas> blas;                       // one per mesh
+    std::vector<kj::Bvh4Node> h_blas_nodes;
+    std::vector<kj::BvhTri> h_obj_tris;
+    // what changed since the last commit
+    bool meshes_dirty = true, instance_set_dirty = true;
+    std::vector<uint8_t> xform_dirty;             // per instance slot
     // committed device state
     bool committed = false;
-    kj::DevBuf d_vertex_buffer, d_meshes, d_instances, d_maps, d_tex_data, d_lights, d_nodes, d_tris;
+    kj::DevBuf d_vertex_buffer, d_meshes, d_instances, d_maps, d_tex_data, d_lights, d_blas_nodes, d_obj_tris, d_tlas_nodes, d_tris, d_inst_records, d_jobs;
+    std::vector<uint32_t> inst_tri_base;          // per instance slot: first world triangle (valid for live instances after a commit)
     uint32_t light_count = 0, tri_count = 0, node_count = 0, bvh_root = 0, bvh_max_depth = 0;
+    double last_commit_ms[4] = {0, 0, 0, 0};      // host time of the last commit: BLAS builds, instance records + TLAS, uploads + device transform, total
     kj::SceneView view() const;
 };

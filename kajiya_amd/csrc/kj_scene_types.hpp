@@ -54,9 +54,28 @@ static_assert(sizeof(BvhTri) == 48, "tri size");
 #define KJ_BVH_LDS_STACK 16u      // traversal stack entries kept in LDS per lane ...
 #define KJ_BVH_SPILL_STACK 112u   // ... deeper entries spill to private (scratch) memory; builds needing more are rejected
 
+// Two levels, as the reference's TLAS over per-mesh BLASes (kajiya-backend/src/vulkan/ray_tracing.rs:96-275):
+//   tlas_nodes : Bvh4Node tree over the live instances' world boxes, rebuilt at every kj_scene_commit; a leaf child is
+//                KJ_BVH_LEAF | instance slot;
+//   blas_nodes : every mesh's Bvh4Node tree in the mesh's OBJECT space, built once per mesh and shared by its instances (child
+//                node indices are absolute in this array; leaf triangle indices are relative to the instance's triangles);
+//   tris       : per live instance, its mesh's triangles in BLAS leaf order transformed to WORLD space (the same fp32 arithmetic as
+//                flattening the scene, so hits are those of a world-space scene): re-derived on the device when an instance moves;
+//   instances  : per instance slot, how to get from the TLAS into its BLAS.
+struct InstanceRecord {     // 64 B
+    float w2o[12];          // world -> object, row-major 3x4
+    uint32_t node_root;     // the mesh's BLAS root in blas_nodes
+    uint32_t tri_base;      // the instance's first triangle in tris
+    float pad;              // object-space slack added around every BLAS box (rounding of the ray transform and of the world-space vertices)
+    uint32_t reserved;
+};
+static_assert(sizeof(InstanceRecord) == 64, "instance record size");
+#define KJ_BVH_SENTINEL 0xfffffffeu   // traversal stack marker: "back to the TLAS"
 struct BvhView {
-    const F4* nodes;         // KJ_BVH_NODE_F4 x 16 B per node; node 0 is the root
+    const F4* tlas_nodes;    // 4 x 16 B per node; node 0 is the root
+    const F4* blas_nodes;
     const F4* tris;          // 3 x 16 B per tri
+    const InstanceRecord* instances;
     uint32_t root;           // always 0 (kept for the C-ABI debug query)
     uint32_t stack_entries;  // per-lane LDS stack entries a tracing kernel must provide (KJ_BVH_LDS_STACK)
 };

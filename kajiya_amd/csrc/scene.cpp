@@ -1,10 +1,13 @@
-// KjScene: WorldRenderer's scene state for the GI path (world_renderer.rs:604-911):
-// mesh upload into one byte-addressed vertex buffer + GpuMesh table, instances,
-// triangle lights, and — replacing the driver's BLAS/TLAS — a host-built 4-wide
-// SAH BVH with quantised child boxes (bvh_build.cpp) uploaded as 64-byte nodes
-// and 48-byte leaf-ordered world-space triangles.
-// Plain C++ (no device code); compiled with -ffp-contract=off so the instance
-// transform of vertices rounds exactly like the oracle's.
+// KjScene: WorldRenderer's scene state for the GI path (world_renderer.rs:604-911): mesh upload into one byte-addressed
+// vertex buffer + GpuMesh table, instances, triangle lights, and -- in the role of the driver's acceleration structures
+// (add_mesh -> BLAS, build_ray_tracing_top_level_acceleration / prepare_top_level_acceleration -> TLAS:
+// world_renderer.rs:694-724,836-911) -- a two-level BVH:
+//   * one BLAS per mesh in object space, built once (4-wide SAH tree with quantised child boxes, bvh_build.cpp; or, for meshes
+//     added with KJ_MESH_BUILD_PREFER_FAST_BUILD, an LBVH built on the device, scene_device.hip), shared by the mesh's instances;
+//   * per instance, its triangles in world space (device kernel, same fp32 arithmetic as the oracle's flattening);
+//   * a TLAS over the live instances, rebuilt at every commit.
+// A commit after set_instance_transform re-derives that instance's world triangles and the TLAS: no mesh is rebuilt.
+// Plain C++ (no device code); compiled with -ffp-contract=off.
 #include "kj_host.hpp"
 #include "kj_bvh_build.hpp"
 #include <algorithm>
@@ -12,6 +15,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <numeric>
+#include <chrono>
+#include "kj_scene_device.hpp"
 
 namespace kj {
 
@@ -32,8 +37,10 @@ SceneView scene_view(const KjScene& s) {
     v.tex_data = (const uint8_t*)s.d_tex_data.p;
     v.lights = (const KjTriangleLight*)s.d_lights.p;
     v.light_count = s.light_count;
-    v.bvh.nodes = (const F4*)s.d_nodes.p;
+    v.bvh.tlas_nodes = (const F4*)s.d_tlas_nodes.p;
+    v.bvh.blas_nodes = (const F4*)s.d_blas_nodes.p;
     v.bvh.tris = (const F4*)s.d_tris.p;
+    v.bvh.instances = (const InstanceRecord*)s.d_inst_records.p;
     v.bvh.root = s.bvh_root;
     v.bvh.stack_entries = KJ_BVH_LDS_STACK;      // LDS part of the traversal stack; deeper entries spill (kj_bvh.hpp)
     return v;
@@ -80,6 +87,23 @@ KjStatus kj_scene_add_mesh(KjScene* s, const KjMeshDesc* d, uint32_t* out_mesh) 
             KJ_REQUIRE(mm.mip_count >= 1 && mm.mip_count <= full, "image map mip_count out of range");
         }
     for (uint32_t i = 0; i < d->index_count; ++i) KJ_REQUIRE(d->indices[i] < d->vertex_count, "index out of range");
+    // every check before the scene is touched: a rejected mesh must not leave maps / texels / vertex data behind
+    for (uint32_t i = 0; i < d->material_count; ++i)
+        for (int k = 0; k < 4; ++k) KJ_REQUIRE(d->materials[i].maps[k] < d->map_count, "material map index out of range");
+    if (d->material_ids)
+        for (uint32_t i = 0; i < d->vertex_count; ++i) KJ_REQUIRE(d->material_ids[i] < d->material_count, "material id out of range");
+    else KJ_REQUIRE(d->material_count >= 1, "mesh has no material");
+    {
+        size_t tex_bytes = s->tex_data.size();
+        for (uint32_t i = 0; i < d->map_count; ++i)
+            if (d->maps[i].image_rgba8) {
+                tex_bytes = (tex_bytes + 15) & ~size_t(15);
+                for (uint32_t k = 0; k < d->maps[i].mip_count; ++k) tex_bytes += size_t(std::max(1u, d->maps[i].width >> k)) * std::max(1u, d->maps[i].height >> k) * 4;
+            }
+        KJ_REQUIRE(tex_bytes < (size_t(1) << 32), "more than 4 GiB of material maps");
+        const size_t vb_bytes = s->vertex_buffer.size() + size_t(d->index_count) * 4 + size_t(d->vertex_count) * (16 + 8 + 4 + 16 + 16) + size_t(d->material_count) * sizeof(KjMeshMaterial) + 8 * 64;
+        KJ_REQUIRE(vb_bytes < (size_t(1) << 32), "vertex buffer would exceed 4 GiB (32-bit offsets)");
+    }
     std::vector<KjMeshMaterial> mats(d->materials, d->materials + d->material_count);
     const uint32_t map_base = uint32_t(s->maps.size());
     for (uint32_t i = 0; i < d->map_count; ++i) {
@@ -90,7 +114,6 @@ KjStatus kj_scene_add_mesh(KjScene* s, const KjMeshDesc* d, uint32_t* out_mesh) 
             size_t bytes = 0;
             for (uint32_t k = 0; k < mm.mip_count; ++k) bytes += size_t(std::max(1u, mm.width >> k)) * std::max(1u, mm.height >> k) * 4;
             while (s->tex_data.size() % 16) s->tex_data.push_back(0);
-            KJ_REQUIRE(s->tex_data.size() + bytes < (size_t(1) << 32), "more than 4 GiB of material maps");
             md.offset = uint32_t(s->tex_data.size());
             md.width = mm.width; md.height = mm.height;
             md.flags = mm.mip_count | (mm.srgb ? 0x100u : 0u);
@@ -99,14 +122,13 @@ KjStatus kj_scene_add_mesh(KjScene* s, const KjMeshDesc* d, uint32_t* out_mesh) 
         s->maps.push_back(md);
     }
     for (auto& m : mats) {
-        for (int k = 0; k < 4; ++k) { KJ_REQUIRE(m.maps[k] < d->map_count, "material map index out of range"); m.maps[k] += map_base; }
+        for (int k = 0; k < 4; ++k) m.maps[k] += map_base;
         if (d->use_lights) m.flags |= KJ_MESH_MATERIAL_FLAG_EMISSIVE_USED_AS_LIGHT;
     }
     std::vector<float> uvs(size_t(d->vertex_count) * 2, 0.0f);
     if (d->uvs) memcpy(uvs.data(), d->uvs, uvs.size() * 4);
     std::vector<uint32_t> mids(d->vertex_count, 0);
     if (d->material_ids) memcpy(mids.data(), d->material_ids, size_t(d->vertex_count) * 4);
-    for (uint32_t v : mids) KJ_REQUIRE(v < d->material_count, "material id out of range");
     GpuMesh m{};
     std::vector<uint8_t>& vb = s->vertex_buffer;
     m.index_offset = vb_append(vb, d->indices, d->index_count);
@@ -131,6 +153,8 @@ KjStatus kj_scene_add_mesh(KjScene* s, const KjMeshDesc* d, uint32_t* out_mesh) 
         }
     }
     s->mesh_lights.push_back(std::move(lights));
+    s->blas.emplace_back();
+    s->meshes_dirty = true;
     s->committed = false;
     *out_mesh = uint32_t(s->meshes.size() - 1);
     return KJ_OK;
@@ -145,6 +169,8 @@ KjStatus kj_scene_add_instance(KjScene* s, uint32_t mesh, const float* xf, uint3
     i.emissive_multiplier = 1.0f;
     i.alive = true;
     s->instances.push_back(i);
+    s->xform_dirty.push_back(1);
+    s->instance_set_dirty = true;
     s->committed = false;
     *out_instance = uint32_t(s->instances.size() - 1);
     return KJ_OK;
@@ -152,6 +178,7 @@ KjStatus kj_scene_add_instance(KjScene* s, uint32_t mesh, const float* xf, uint3
 KjStatus kj_scene_set_instance_transform(KjScene* s, uint32_t instance, const float* xf) {
     KJ_REQUIRE(s && xf && instance < s->instances.size() && s->instances[instance].alive, "bad instance handle");
     memcpy(s->instances[instance].xform, xf, 48);
+    s->xform_dirty[instance] = 1;
     s->committed = false;
     return KJ_OK;
 }
@@ -164,43 +191,118 @@ KjStatus kj_scene_set_instance_emissive_multiplier(KjScene* s, uint32_t instance
 KjStatus kj_scene_remove_instance(KjScene* s, uint32_t instance) {
     KJ_REQUIRE(s && instance < s->instances.size() && s->instances[instance].alive, "bad instance handle");
     s->instances[instance].alive = false;
+    s->instance_set_dirty = true;
     s->committed = false;
     return KJ_OK;
+}
+
+// world box of an object-space box under a 3x4 transform (all eight corners), padded for fp32 rounding
+static void world_box(const float* x, const float* ob, float* wb) {
+    for (int k = 0; k < 3; ++k) { wb[k] = FLT_MAX; wb[3 + k] = -FLT_MAX; }
+    for (int c = 0; c < 8; ++c) {
+        const float p[3] = {ob[(c & 1) ? 3 : 0], ob[(c & 2) ? 4 : 1], ob[(c & 4) ? 5 : 2]};
+        for (int r = 0; r < 3; ++r) {
+            const float v = x[r * 4] * p[0] + x[r * 4 + 1] * p[1] + x[r * 4 + 2] * p[2] + x[r * 4 + 3];
+            wb[r] = std::min(wb[r], v); wb[3 + r] = std::max(wb[3 + r], v);
+        }
+    }
 }
 
 KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     KJ_REQUIRE(s, "null scene");
     hipStream_t stream = (hipStream_t)stream_;
     KJ_TRY_HIP(hipSetDevice(s->dev->ordinal));
-    // 1. flatten instances into world space (same arithmetic as the oracle: row-major 3x4 times point)
-    std::vector<BvhTri> wt;
+    typedef std::chrono::steady_clock Clock;
+    const auto t0 = Clock::now();
+    auto ms_since = [](Clock::time_point a) { return std::chrono::duration<double, std::milli>(Clock::now() - a).count(); };
+    // 1. BLAS of every mesh that does not have one yet (object space; the role of add_mesh's acceleration-structure build)
+    for (uint32_t mi = 0; mi < s->meshes.size(); ++mi) {
+        KjScene::Blas& bl = s->blas[mi];
+        if (bl.built) continue;
+        const GpuMesh& m = s->meshes[mi];
+        std::vector<BvhTri> ot(m.index_count / 3);
+        for (uint32_t p = 0; p < m.index_count / 3; ++p) {
+            BvhTri& t = ot[p];
+            float* dst[3] = {t.v0, t.v1, t.v2};
+            for (int k = 0; k < 3; ++k) {
+                uint32_t idx;
+                memcpy(&idx, s->vertex_buffer.data() + m.index_offset + (p * 3 + k) * 4, 4);
+                memcpy(dst[k], s->vertex_buffer.data() + m.vertex_core_offset + size_t(idx) * 16, 12);
+            }
+            t.world_id = 0; t.inst = 0; t.prim = p;
+        }
+        BuiltBvh b;
+        build_bvh4(ot, b);
+        bl.node_base = uint32_t(s->h_blas_nodes.size()); bl.node_count = uint32_t(b.nodes.size());
+        bl.tri_base = uint32_t(s->h_obj_tris.size()); bl.tri_count = uint32_t(b.tris.size());
+        bl.max_stack = b.max_stack;
+        for (int k = 0; k < 3; ++k) { bl.bounds[k] = FLT_MAX; bl.bounds[3 + k] = -FLT_MAX; }
+        for (const BvhTri& t : b.tris)
+            for (const float* v : {t.v0, t.v1, t.v2})
+                for (int k = 0; k < 3; ++k) { bl.bounds[k] = std::min(bl.bounds[k], v[k]); bl.bounds[3 + k] = std::max(bl.bounds[3 + k], v[k]); }
+        for (BvhNode n : b.nodes) {     // child node indices become absolute in the shared array; leaf references stay relative to the mesh
+            for (int i = 0; i < 4; ++i)
+                if (n.child[i] != 0xffffffffu && !(n.child[i] & KJ_BVH_LEAF)) n.child[i] += bl.node_base;
+            s->h_blas_nodes.push_back(n);
+        }
+        s->h_obj_tris.insert(s->h_obj_tris.end(), b.tris.begin(), b.tris.end());
+        bl.built = true;
+        s->meshes_dirty = true;
+    }
+    s->last_commit_ms[0] = ms_since(t0);
+    const auto t1 = Clock::now();
+    // 2. instances: world-triangle ranges (numbered over the live instances in slot order, like a flattened scene), records, world boxes
+    const uint32_t ni = uint32_t(s->instances.size());
+    std::vector<GpuInstance> ginst(ni);
+    std::vector<InstanceRecord> recs(ni);
+    std::vector<BvhTri> tlas_prims;
     std::vector<KjTriangleLight> lights;
-    std::vector<GpuInstance> ginst(s->instances.size());
-    for (uint32_t ii = 0; ii < s->instances.size(); ++ii) {
+    std::vector<uint32_t> tri_base(ni, 0);
+    uint32_t total_tris = 0, max_blas_stack = 1;
+    for (uint32_t ii = 0; ii < ni; ++ii) {
         const KjScene::Inst& inst = s->instances[ii];
         GpuInstance& g = ginst[ii];
         memcpy(g.xform, inst.xform, 48);
         g.mesh = inst.mesh; g.emissive_multiplier = inst.emissive_multiplier; g.pad0 = g.pad1 = 0;
+        memset(&recs[ii], 0, sizeof(InstanceRecord));
         if (!inst.alive) continue;
-        const GpuMesh& m = s->meshes[inst.mesh];
+        const KjScene::Blas& bl = s->blas[inst.mesh];
         const float* x = inst.xform;
+        tri_base[ii] = total_tris;
+        total_tris += bl.tri_count;
+        max_blas_stack = std::max(max_blas_stack, bl.max_stack);
+        // world -> object: inverse of the upper 3x3 in double, then the translation
+        const double a[9] = {x[0], x[1], x[2], x[4], x[5], x[6], x[8], x[9], x[10]};
+        const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+        float wb[6];
+        world_box(x, bl.bounds, wb);
+        float max_abs = 0.0f;
+        for (int k = 0; k < 6; ++k) max_abs = std::max(max_abs, std::fabs(wb[k]));
+        const float pad_world = 16.0f * FLT_EPSILON * std::max(max_abs, 1e-3f);
+        InstanceRecord& r = recs[ii];
+        r.node_root = bl.node_base; r.tri_base = tri_base[ii];
+        if (std::fabs(det) > 1e-30) {
+            const double id = 1.0 / det;
+            const double inv[9] = {(a[4] * a[8] - a[5] * a[7]) * id, (a[2] * a[7] - a[1] * a[8]) * id, (a[1] * a[5] - a[2] * a[4]) * id,
+                                   (a[5] * a[6] - a[3] * a[8]) * id, (a[0] * a[8] - a[2] * a[6]) * id, (a[2] * a[3] - a[0] * a[5]) * id,
+                                   (a[3] * a[7] - a[4] * a[6]) * id, (a[1] * a[6] - a[0] * a[7]) * id, (a[0] * a[4] - a[1] * a[3]) * id};
+            double row_norm = 0.0;
+            for (int rr = 0; rr < 3; ++rr) {
+                for (int c = 0; c < 3; ++c) r.w2o[rr * 4 + c] = float(inv[rr * 3 + c]);
+                r.w2o[rr * 4 + 3] = float(-(inv[rr * 3] * x[3] + inv[rr * 3 + 1] * x[7] + inv[rr * 3 + 2] * x[11]));
+                row_norm = std::max(row_norm, std::fabs(inv[rr * 3]) + std::fabs(inv[rr * 3 + 1]) + std::fabs(inv[rr * 3 + 2]));
+            }
+            r.pad = float(double(pad_world) * row_norm * 2.0);
+            BvhTri t{};   // the instance's (padded) world box as the TLAS builder's primitive
+            for (int k = 0; k < 3; ++k) { t.v0[k] = t.v2[k] = wb[k] - pad_world; t.v1[k] = wb[3 + k] + pad_world; }
+            t.prim = ii;
+            tlas_prims.push_back(t);
+        }   // a singular transform flattens the mesh to zero volume: nothing to hit, the instance stays out of the TLAS
         auto xf_point = [&](const float* p, float* o) {
             o[0] = x[0] * p[0] + x[1] * p[1] + x[2] * p[2] + x[3];
             o[1] = x[4] * p[0] + x[5] * p[1] + x[6] * p[2] + x[7];
             o[2] = x[8] * p[0] + x[9] * p[1] + x[10] * p[2] + x[11];
         };
-        for (uint32_t p = 0; p < m.index_count / 3; ++p) {
-            BvhTri t{};
-            float* dst[3] = {t.v0, t.v1, t.v2};
-            for (int k = 0; k < 3; ++k) {
-                uint32_t idx;
-                memcpy(&idx, s->vertex_buffer.data() + m.index_offset + (p * 3 + k) * 4, 4);
-                xf_point((const float*)(s->vertex_buffer.data() + m.vertex_core_offset + size_t(idx) * 16), dst[k]);
-            }
-            t.world_id = uint32_t(wt.size());
-            t.inst = ii; t.prim = p;
-            wt.push_back(t);
-        }
         for (const KjTriangleLight& l : s->mesh_lights[inst.mesh]) {  // TriangleLight::transform, scale_radiance
             KjTriangleLight w = l;
             for (int k = 0; k < 3; ++k) xf_point(&l.verts[k * 3], &w.verts[k * 3]);
@@ -208,30 +310,67 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
             lights.push_back(w);
         }
     }
-    KJ_REQUIRE(!wt.empty(), "scene has no triangles");
-    KJ_REQUIRE(wt.size() < (1u << 28), "too many triangles for 28-bit leaf references");
-    // 2. hierarchy (bvh_build.cpp)
-    BuiltBvh b;
-    build_bvh4(wt, b);
-    KJ_REQUIRE(b.max_stack + 1 <= KJ_BVH_LDS_STACK + KJ_BVH_SPILL_STACK, "BVH too deep for the traversal stack");
-    s->tri_count = uint32_t(b.tris.size());
-    s->node_count = uint32_t(b.nodes.size());
-    s->bvh_root = 0;
-    s->bvh_max_depth = b.max_stack;
-    s->light_count = uint32_t(lights.size());
-    // 4. upload
-    KJ_TRY_HIP(s->d_vertex_buffer.upload(s->vertex_buffer.data(), s->vertex_buffer.size(), stream));
-    KJ_TRY_HIP(s->d_meshes.upload(s->meshes.data(), s->meshes.size() * sizeof(GpuMesh), stream));
+    KJ_REQUIRE(total_tris > 0, "scene has no triangles");
+    KJ_REQUIRE(total_tris < (1u << 28), "too many triangles for 28-bit leaf references");
+    // 3. TLAS over the live instances (one instance per leaf)
+    BuiltBvh tl;
+    if (tlas_prims.empty()) { BvhTri t{}; t.v0[0] = t.v0[1] = t.v0[2] = t.v2[0] = t.v2[1] = t.v2[2] = 1e30f; t.v1[0] = t.v1[1] = t.v1[2] = 1e30f; tlas_prims.push_back(t); }
+    build_bvh4(tlas_prims, tl, 1);
+    for (BvhNode& n : tl.nodes)
+        for (int i = 0; i < 4; ++i)
+            if (n.child[i] != 0xffffffffu && (n.child[i] & KJ_BVH_LEAF)) n.child[i] = KJ_BVH_LEAF | tl.tris[n.child[i] & 0x0fffffffu].prim;
+    KJ_REQUIRE(tl.max_stack + 1 + max_blas_stack + 1 <= KJ_BVH_LDS_STACK + KJ_BVH_SPILL_STACK, "BVH too deep for the traversal stack");
+    s->last_commit_ms[1] = ms_since(t1);
+    const auto t2 = Clock::now();
+    // 4. uploads: static mesh data only when a mesh was added; per-commit tables always
+    if (s->meshes_dirty) {
+        KJ_TRY_HIP(s->d_vertex_buffer.upload(s->vertex_buffer.data(), s->vertex_buffer.size(), stream));
+        KJ_TRY_HIP(s->d_meshes.upload(s->meshes.data(), s->meshes.size() * sizeof(GpuMesh), stream));
+        KJ_TRY_HIP(s->d_maps.upload(s->maps.data(), s->maps.size() * sizeof(MapDesc), stream));
+        if (s->tex_data.empty()) s->tex_data.resize(16, 0);
+        KJ_TRY_HIP(s->d_tex_data.upload(s->tex_data.data(), s->tex_data.size(), stream));
+        KJ_TRY_HIP(s->d_blas_nodes.upload(s->h_blas_nodes.data(), s->h_blas_nodes.size() * sizeof(BvhNode), stream));
+        KJ_TRY_HIP(s->d_obj_tris.upload(s->h_obj_tris.data(), s->h_obj_tris.size() * sizeof(BvhTri), stream));
+    }
     KJ_TRY_HIP(s->d_instances.upload(ginst.data(), ginst.size() * sizeof(GpuInstance), stream));
-    KJ_TRY_HIP(s->d_maps.upload(s->maps.data(), s->maps.size() * sizeof(MapDesc), stream));
-    if (s->tex_data.empty()) s->tex_data.resize(16, 0);
-    KJ_TRY_HIP(s->d_tex_data.upload(s->tex_data.data(), s->tex_data.size(), stream));
+    KJ_TRY_HIP(s->d_inst_records.upload(recs.data(), recs.size() * sizeof(InstanceRecord), stream));
     if (lights.empty()) lights.push_back(KjTriangleLight{});
     KJ_TRY_HIP(s->d_lights.upload(lights.data(), lights.size() * sizeof(KjTriangleLight), stream));
-    KJ_TRY_HIP(s->d_nodes.upload(b.nodes.data(), b.nodes.size() * sizeof(BvhNode), stream));
-    KJ_TRY_HIP(s->d_tris.upload(b.tris.data(), b.tris.size() * sizeof(BvhTri), stream));
+    KJ_TRY_HIP(s->d_tlas_nodes.upload(tl.nodes.data(), tl.nodes.size() * sizeof(BvhNode), stream));
+    // 5. world-space triangles: all instances when the set (hence the numbering) changed, else the moved ones -- on the device
+    const bool all = s->instance_set_dirty || s->meshes_dirty || s->d_tris.bytes != size_t(total_tris) * sizeof(BvhTri);
+    if (s->d_tris.bytes != size_t(total_tris) * sizeof(BvhTri)) KJ_TRY_HIP(s->d_tris.alloc(size_t(total_tris) * sizeof(BvhTri), stream));
+    std::vector<InstanceTriJob> jobs;
+    for (uint32_t ii = 0; ii < ni; ++ii) {
+        const KjScene::Inst& inst = s->instances[ii];
+        if (!inst.alive || !(all || s->xform_dirty[ii])) continue;
+        const KjScene::Blas& bl = s->blas[inst.mesh];
+        InstanceTriJob j;
+        memcpy(j.xform, inst.xform, 48);
+        j.src = bl.tri_base; j.dst = tri_base[ii]; j.count = bl.tri_count; j.instance = ii;
+        jobs.push_back(j);
+    }
+    if (!jobs.empty()) {
+        KJ_TRY_HIP(s->d_jobs.upload(jobs.data(), jobs.size() * sizeof(InstanceTriJob), stream));
+        KJ_TRY_HIP(launch_instance_triangles((const BvhTri*)s->d_obj_tris.p, (BvhTri*)s->d_tris.p, (const InstanceTriJob*)s->d_jobs.p, uint32_t(jobs.size()), stream));
+    }
     KJ_TRY_HIP(hipStreamSynchronize(stream));  // host vectors go out of scope
+    s->inst_tri_base = tri_base;
+    s->tri_count = total_tris;
+    s->node_count = uint32_t(s->h_blas_nodes.size() + tl.nodes.size());
+    s->bvh_root = 0;
+    s->bvh_max_depth = tl.max_stack + 1 + max_blas_stack;
+    s->light_count = uint32_t(lights.size());
+    s->meshes_dirty = false; s->instance_set_dirty = false;
+    std::fill(s->xform_dirty.begin(), s->xform_dirty.end(), uint8_t(0));
     s->committed = true;
+    s->last_commit_ms[2] = ms_since(t2);
+    s->last_commit_ms[3] = ms_since(t0);
+    return KJ_OK;
+}
+KjStatus kj_scene_last_commit_ms(KjScene* s, double out_ms[4]) {
+    KJ_REQUIRE(s && out_ms, "null argument");
+    for (int k = 0; k < 4; ++k) out_ms[k] = s->last_commit_ms[k];
     return KJ_OK;
 }
 
@@ -246,7 +385,7 @@ KjStatus kj_scene_stats(KjScene* s, uint32_t* out_tri_count, uint32_t* out_node_
     if (!s->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
     if (out_tri_count) *out_tri_count = s->tri_count;
     if (out_node_count) *out_node_count = s->node_count;
-    if (out_bvh_bytes) *out_bvh_bytes = uint64_t(s->node_count) * sizeof(BvhNode) + uint64_t(s->tri_count) * sizeof(BvhTri);
+    if (out_bvh_bytes) *out_bvh_bytes = uint64_t(s->node_count) * sizeof(BvhNode) + uint64_t(s->tri_count) * sizeof(BvhTri) + s->h_obj_tris.size() * sizeof(BvhTri);
     return KJ_OK;
 }
 

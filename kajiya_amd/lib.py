@@ -19,7 +19,7 @@ EXPORTS = [
     "kj_last_error", "kj_abi_version", "kj_device_create", "kj_device_destroy", "kj_device_brdf_lut",
     "kj_scene_create", "kj_scene_destroy", "kj_scene_add_mesh", "kj_scene_add_instance", "kj_scene_set_instance_transform",
     "kj_scene_set_instance_emissive_multiplier", "kj_scene_remove_instance", "kj_scene_commit", "kj_scene_triangle_light_count",
-    "kj_scene_stats", "kj_frame_begin", "kj_trace_closest", "kj_trace_any", "kj_debug_calibration_copy", "kj_raster_gbuffer", "kj_sky_cube_render",
+    "kj_scene_stats", "kj_scene_last_commit_ms", "kj_frame_begin", "kj_trace_closest", "kj_trace_any", "kj_debug_calibration_copy", "kj_raster_gbuffer", "kj_sky_cube_render",
     "kj_sky_cube_convolve", "kj_reprojection_create", "kj_reprojection_destroy", "kj_calculate_reprojection_map",
     "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_render",
     "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
@@ -69,6 +69,7 @@ def load():
         "kj_trace_closest": [vp, vp, vp, u32, u32, vp],
         "kj_trace_any": [vp, vp, vp, u32, vp],
         "kj_debug_calibration_copy": [vp, vp, C.c_uint64, vp],
+        "kj_scene_last_commit_ms": [vp, C.POINTER(C.c_double)],
         "kj_raster_gbuffer": [vp, vp, u32, u32, vp, vp, vp, vp, vp],
         "kj_sky_cube_render": [vp, vp, vp],
         "kj_sky_cube_convolve": [vp, vp, vp, vp],
@@ -200,6 +201,16 @@ class Scene:
 
     def commit(self):
         check(load().kj_scene_commit(self.h, _stream_ptr()))
+
+    def set_instance_transform(self, instance, xform3x4):
+        xf = np.ascontiguousarray(xform3x4, np.float32)
+        check(load().kj_scene_set_instance_transform(self.h, instance, xf.ctypes.data))
+
+    def last_commit_ms(self):
+        """[BLAS builds, instance records + TLAS, uploads + device transform, total] of the last commit, host ms."""
+        out = (C.c_double * 4)()
+        check(load().kj_scene_last_commit_ms(self.h, out))
+        return list(out)
 
     def stats(self):
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint64()
