@@ -189,6 +189,12 @@ KjStatus kj_scene_stats(KjScene* scene, uint32_t* out_tri_count, uint32_t* out_n
  * [2] uploads + the device kernel that re-derives moved instances' world-space triangles (incl. the stream sync), [3] total.
  * The reference's counterpart is the GPU time of build_ray_tracing_top_level_acceleration (world_renderer.rs:836-911). */
 KjStatus kj_scene_last_commit_ms(KjScene* scene, double out_ms[4]);
+/* How the BLAS of meshes added FROM NOW ON is built at the next commit (vk::BuildAccelerationStructureFlagsKHR, ray_tracing.rs:438):
+ * KJ_BLAS_BUILD_FAST_TRACE = binned-SAH tree built on the host (kajiya's PREFER_FAST_TRACE; the default),
+ * KJ_BLAS_BUILD_FAST_BUILD = linear BVH built on the device (Morton sort + Karras hierarchy + bottom-up boxes + 4-wide collapse). */
+#define KJ_BLAS_BUILD_FAST_TRACE 0u
+#define KJ_BLAS_BUILD_FAST_BUILD 1u
+KjStatus kj_scene_set_blas_build_mode(KjScene* scene, uint32_t mode);
 
 /* Baked assets (`bin/bake` output, kajiya-asset-pipe/src/lib.rs:38-60): zero-copy, bounds-checked views of
  * `cache/<name>.mesh` (PackedTriMesh::Flat, kajiya-asset/src/mesh.rs:796-807) and `cache/<identity:08x>.image`

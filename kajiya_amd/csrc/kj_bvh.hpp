@@ -101,10 +101,18 @@ struct RayState {
     float pad;          // slack around this instance's BLAS boxes
     bool cull_back;
 };
+// reciprocal direction for the slab tests (v_rcp_f32: the boxes are conservative by several ulps, the triangles never see this)
+KJ_D float rcp_box(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
 KJ_D V3 safe_rcp3(V3 d) {
     const float eps = 1e-20f;
-    return V3{1.0f / (fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x), 1.0f / (fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y),
-              1.0f / (fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z)};
+    return V3{rcp_box(fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x), rcp_box(fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y),
+              rcp_box(fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z)};
 }
 
 template <bool ANY_HIT>
@@ -149,10 +157,16 @@ KJ_D void enter_instance(const BvhView& bvh, RayState& S, uint32_t* stack, uint3
     S.cur = m.x; S.tri_base = m.y; S.pad = __uint_as_float(m.z);
 }
 
-// Visit the 4-wide node S.cur: test its four quantised child boxes, continue with the nearest hit child, push the others.
+// Visit the 4-wide node S.cur (or, from the TLAS, the root of the instance S.cur names): test its four quantised child boxes,
+// continue with the nearest hit child, push the others. A reference is a NODE-step reference when it is an inner node or a TLAS leaf.
+KJ_D bool wants_node_step(const RayState& S) { return S.cur != KJ_BVH_NONE && (!(S.cur & KJ_BVH_LEAF) || S.tri_base == KJ_BVH_NONE); }
+KJ_D bool wants_tri_step(const RayState& S) { return S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF) && S.tri_base != KJ_BVH_NONE; }
 template <bool ANY_HIT, bool STATS>
 KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
     const uint32_t NONE = KJ_BVH_NONE;
+    // a TLAS leaf is an instance: step into it and visit its BLAS root in this same step (a separate "enter" step would run for a
+    // handful of lanes in nearly every wave iteration: 64 lanes x a few instances per ray)
+    if (S.cur & KJ_BVH_LEAF) enter_instance(bvh, S, stack, stride, spill);
     const float4* __restrict__ n = (const float4*)(S.tri_base == KJ_BVH_NONE ? bvh.tlas_nodes : bvh.blas_nodes) + size_t(S.cur) * 4;
     const float4 n0 = n[0];
     const uint4 ch = *(const uint4*)(n + 1);
@@ -249,12 +263,7 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
     uint32_t spill[KJ_BVH_SPILL_STACK];
 #if defined(__HIP_DEVICE_COMPILE__)
     for (;;) {
-        const bool leaf = S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF);
-        if (__ballot(leaf && S.tri_base == KJ_BVH_NONE) != 0ull) {     // TLAS leaves: short, taken as soon as any lane has one
-            if (leaf && S.tri_base == KJ_BVH_NONE) enter_instance(bvh, S, stack, stride, spill);
-            continue;
-        }
-        const bool want_node = S.cur != KJ_BVH_NONE && !leaf, want_tri = leaf;
+        const bool want_node = wants_node_step(S), want_tri = wants_tri_step(S);
         const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
         if (nn + nt == 0u) break;
         if (nt == 0u || (nn != 0u && nn >= nt * 2u)) { if (want_node) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
@@ -262,8 +271,7 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
     }
 #else
     while (S.cur != KJ_BVH_NONE) {
-        if (!(S.cur & KJ_BVH_LEAF)) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);
-        else if (S.tri_base == KJ_BVH_NONE) enter_instance(bvh, S, stack, stride, spill);
+        if (wants_node_step(S)) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);
         else tri_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);
     }
 #endif
@@ -329,12 +337,7 @@ KJ_D void bvh_trace_stream(const BvhView& bvh, const float4* __restrict__ rays, 
             }
             cursor += take;
         }
-        const bool leaf = S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF);
-        if (__ballot(leaf && S.tri_base == KJ_BVH_NONE) != 0ull) {     // TLAS leaves: short, taken as soon as any lane has one
-            if (leaf && S.tri_base == KJ_BVH_NONE) enter_instance(bvh, S, stack, stride, spill);
-            continue;
-        }
-        const bool want_node = S.cur != KJ_BVH_NONE && !leaf, want_tri = leaf;
+        const bool want_node = wants_node_step(S), want_tri = wants_tri_step(S);
         const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
         if (nn + nt == 0u) { if (exhausted) break; else continue; }
         if (nt == 0u || (nn != 0u && nn * tune.node_weight >= nt * tune.tri_weight)) { if (want_node) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }

@@ -83,8 +83,9 @@ struct KjScene {
     // per-mesh acceleration structure (BLAS), built once: nodes + object-space triangles in leaf order, appended to the shared arrays
     struct Blas { uint32_t node_base = 0, node_count = 0, tri_base = 0, tri_count = 0, max_stack = 1; float bounds[6] = {0, 0, 0, 0, 0, 0}; bool built = false; };
     std::vector<Blas> blas;                       // one per mesh
-    std::vector<kj::Bvh4Node> h_blas_nodes;
-    std::vector<kj::BvhTri> h_obj_tris;
+    uint32_t blas_nodes_used = 0, obj_tris_used = 0;   // fill of the two device pools every BLAS lives in (d_blas_nodes, d_obj_tris)
+    uint32_t blas_build_mode = 0;                 // for meshes added from now on: 0 = SAH on the host (fast trace), 1 = LBVH on the device (fast build)
+    std::vector<uint8_t> mesh_build_mode;         // per mesh
     // what changed since the last commit
     bool meshes_dirty = true, instance_set_dirty = true;
     std::vector<uint8_t> xform_dirty;             // per instance slot

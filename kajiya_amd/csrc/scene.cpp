@@ -154,6 +154,7 @@ KjStatus kj_scene_add_mesh(KjScene* s, const KjMeshDesc* d, uint32_t* out_mesh) 
     }
     s->mesh_lights.push_back(std::move(lights));
     s->blas.emplace_back();
+    s->mesh_build_mode.push_back(uint8_t(s->blas_build_mode));
     s->meshes_dirty = true;
     s->committed = false;
     *out_mesh = uint32_t(s->meshes.size() - 1);
@@ -215,39 +216,70 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     typedef std::chrono::steady_clock Clock;
     const auto t0 = Clock::now();
     auto ms_since = [](Clock::time_point a) { return std::chrono::duration<double, std::milli>(Clock::now() - a).count(); };
-    // 1. BLAS of every mesh that does not have one yet (object space; the role of add_mesh's acceleration-structure build)
+    // 1. static mesh data, then the BLAS of every mesh that does not have one yet (object space; the role of add_mesh's
+    //    acceleration-structure build). Both BLAS pools only ever grow: existing meshes keep their place.
+    if (s->meshes_dirty) {
+        KJ_TRY_HIP(s->d_vertex_buffer.upload(s->vertex_buffer.data(), s->vertex_buffer.size(), stream));
+        KJ_TRY_HIP(s->d_meshes.upload(s->meshes.data(), s->meshes.size() * sizeof(GpuMesh), stream));
+        KJ_TRY_HIP(s->d_maps.upload(s->maps.data(), s->maps.size() * sizeof(MapDesc), stream));
+        if (s->tex_data.empty()) s->tex_data.resize(16, 0);
+        KJ_TRY_HIP(s->d_tex_data.upload(s->tex_data.data(), s->tex_data.size(), stream));
+    }
+    auto grow_pool = [&](kj::DevBuf& pool, size_t used_bytes, size_t need_bytes) -> hipError_t {
+        if (need_bytes <= pool.bytes) return hipSuccess;
+        kj::DevBuf bigger;
+        hipError_t e = bigger.alloc(std::max(need_bytes, pool.bytes + pool.bytes / 2), stream);
+        if (e != hipSuccess) return e;
+        if (used_bytes) { e = hipMemcpyAsync(bigger.p, pool.p, used_bytes, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) return e; }
+        e = hipStreamSynchronize(stream);
+        std::swap(pool.p, bigger.p); std::swap(pool.bytes, bigger.bytes);
+        return e;
+    };
     for (uint32_t mi = 0; mi < s->meshes.size(); ++mi) {
         KjScene::Blas& bl = s->blas[mi];
         if (bl.built) continue;
         const GpuMesh& m = s->meshes[mi];
-        std::vector<BvhTri> ot(m.index_count / 3);
-        for (uint32_t p = 0; p < m.index_count / 3; ++p) {
-            BvhTri& t = ot[p];
-            float* dst[3] = {t.v0, t.v1, t.v2};
-            for (int k = 0; k < 3; ++k) {
-                uint32_t idx;
-                memcpy(&idx, s->vertex_buffer.data() + m.index_offset + (p * 3 + k) * 4, 4);
-                memcpy(dst[k], s->vertex_buffer.data() + m.vertex_core_offset + size_t(idx) * 16, 12);
+        const uint32_t ntri = m.index_count / 3;
+        bl.node_base = s->blas_nodes_used; bl.tri_base = s->obj_tris_used; bl.tri_count = ntri;
+        if (s->mesh_build_mode[mi] == 1) {   // LBVH on the device, straight into the pools (at most one node per triangle)
+            KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), size_t(s->blas_nodes_used + ntri + 1) * sizeof(BvhNode)));
+            KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), size_t(s->obj_tris_used + ntri) * sizeof(BvhTri)));
+            LbvhResult lr;
+            KJ_TRY_HIP(build_blas_lbvh_device((const uint8_t*)s->d_vertex_buffer.p, m, bl.node_base, (Bvh4Node*)s->d_blas_nodes.p + bl.node_base, (BvhTri*)s->d_obj_tris.p + bl.tri_base, &lr, stream));
+            bl.node_count = lr.node_count; bl.max_stack = lr.max_stack;
+            memcpy(bl.bounds, lr.bounds, 24);
+        } else {                              // binned SAH on the host
+            std::vector<BvhTri> ot(ntri);
+            for (uint32_t p = 0; p < ntri; ++p) {
+                BvhTri& t = ot[p];
+                float* dst[3] = {t.v0, t.v1, t.v2};
+                for (int k = 0; k < 3; ++k) {
+                    uint32_t idx;
+                    memcpy(&idx, s->vertex_buffer.data() + m.index_offset + (p * 3 + k) * 4, 4);
+                    memcpy(dst[k], s->vertex_buffer.data() + m.vertex_core_offset + size_t(idx) * 16, 12);
+                }
+                t.world_id = 0; t.inst = 0; t.prim = p;
             }
-            t.world_id = 0; t.inst = 0; t.prim = p;
+            BuiltBvh b;
+            build_bvh4(ot, b);
+            bl.node_count = uint32_t(b.nodes.size());
+            bl.max_stack = b.max_stack;
+            for (int k = 0; k < 3; ++k) { bl.bounds[k] = FLT_MAX; bl.bounds[3 + k] = -FLT_MAX; }
+            for (const BvhTri& t : b.tris)
+                for (const float* v : {t.v0, t.v1, t.v2})
+                    for (int k = 0; k < 3; ++k) { bl.bounds[k] = std::min(bl.bounds[k], v[k]); bl.bounds[3 + k] = std::max(bl.bounds[3 + k], v[k]); }
+            for (BvhNode& n : b.nodes)      // child node indices become absolute in the pool; leaf references stay relative to the mesh
+                for (int i = 0; i < 4; ++i)
+                    if (n.child[i] != 0xffffffffu && !(n.child[i] & KJ_BVH_LEAF)) n.child[i] += bl.node_base;
+            KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), size_t(s->blas_nodes_used + bl.node_count) * sizeof(BvhNode)));
+            KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), size_t(s->obj_tris_used + ntri) * sizeof(BvhTri)));
+            KJ_TRY_HIP(hipMemcpyAsync((BvhNode*)s->d_blas_nodes.p + bl.node_base, b.nodes.data(), b.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, stream));
+            KJ_TRY_HIP(hipMemcpyAsync((BvhTri*)s->d_obj_tris.p + bl.tri_base, b.tris.data(), b.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice, stream));
+            KJ_TRY_HIP(hipStreamSynchronize(stream));    // b goes out of scope
         }
-        BuiltBvh b;
-        build_bvh4(ot, b);
-        bl.node_base = uint32_t(s->h_blas_nodes.size()); bl.node_count = uint32_t(b.nodes.size());
-        bl.tri_base = uint32_t(s->h_obj_tris.size()); bl.tri_count = uint32_t(b.tris.size());
-        bl.max_stack = b.max_stack;
-        for (int k = 0; k < 3; ++k) { bl.bounds[k] = FLT_MAX; bl.bounds[3 + k] = -FLT_MAX; }
-        for (const BvhTri& t : b.tris)
-            for (const float* v : {t.v0, t.v1, t.v2})
-                for (int k = 0; k < 3; ++k) { bl.bounds[k] = std::min(bl.bounds[k], v[k]); bl.bounds[3 + k] = std::max(bl.bounds[3 + k], v[k]); }
-        for (BvhNode n : b.nodes) {     // child node indices become absolute in the shared array; leaf references stay relative to the mesh
-            for (int i = 0; i < 4; ++i)
-                if (n.child[i] != 0xffffffffu && !(n.child[i] & KJ_BVH_LEAF)) n.child[i] += bl.node_base;
-            s->h_blas_nodes.push_back(n);
-        }
-        s->h_obj_tris.insert(s->h_obj_tris.end(), b.tris.begin(), b.tris.end());
+        s->blas_nodes_used += bl.node_count;
+        s->obj_tris_used += ntri;
         bl.built = true;
-        s->meshes_dirty = true;
     }
     s->last_commit_ms[0] = ms_since(t0);
     const auto t1 = Clock::now();
@@ -322,16 +354,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     KJ_REQUIRE(tl.max_stack + 1 + max_blas_stack + 1 <= KJ_BVH_LDS_STACK + KJ_BVH_SPILL_STACK, "BVH too deep for the traversal stack");
     s->last_commit_ms[1] = ms_since(t1);
     const auto t2 = Clock::now();
-    // 4. uploads: static mesh data only when a mesh was added; per-commit tables always
-    if (s->meshes_dirty) {
-        KJ_TRY_HIP(s->d_vertex_buffer.upload(s->vertex_buffer.data(), s->vertex_buffer.size(), stream));
-        KJ_TRY_HIP(s->d_meshes.upload(s->meshes.data(), s->meshes.size() * sizeof(GpuMesh), stream));
-        KJ_TRY_HIP(s->d_maps.upload(s->maps.data(), s->maps.size() * sizeof(MapDesc), stream));
-        if (s->tex_data.empty()) s->tex_data.resize(16, 0);
-        KJ_TRY_HIP(s->d_tex_data.upload(s->tex_data.data(), s->tex_data.size(), stream));
-        KJ_TRY_HIP(s->d_blas_nodes.upload(s->h_blas_nodes.data(), s->h_blas_nodes.size() * sizeof(BvhNode), stream));
-        KJ_TRY_HIP(s->d_obj_tris.upload(s->h_obj_tris.data(), s->h_obj_tris.size() * sizeof(BvhTri), stream));
-    }
+    // 4. per-commit tables
     KJ_TRY_HIP(s->d_instances.upload(ginst.data(), ginst.size() * sizeof(GpuInstance), stream));
     KJ_TRY_HIP(s->d_inst_records.upload(recs.data(), recs.size() * sizeof(InstanceRecord), stream));
     if (lights.empty()) lights.push_back(KjTriangleLight{});
@@ -357,7 +380,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     KJ_TRY_HIP(hipStreamSynchronize(stream));  // host vectors go out of scope
     s->inst_tri_base = tri_base;
     s->tri_count = total_tris;
-    s->node_count = uint32_t(s->h_blas_nodes.size() + tl.nodes.size());
+    s->node_count = uint32_t(s->blas_nodes_used + tl.nodes.size());
     s->bvh_root = 0;
     s->bvh_max_depth = tl.max_stack + 1 + max_blas_stack;
     s->light_count = uint32_t(lights.size());
@@ -366,6 +389,11 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     s->committed = true;
     s->last_commit_ms[2] = ms_since(t2);
     s->last_commit_ms[3] = ms_since(t0);
+    return KJ_OK;
+}
+KjStatus kj_scene_set_blas_build_mode(KjScene* s, uint32_t mode) {
+    KJ_REQUIRE(s && mode <= 1, "mode must be KJ_BLAS_BUILD_FAST_TRACE (0) or KJ_BLAS_BUILD_FAST_BUILD (1)");
+    s->blas_build_mode = mode;
     return KJ_OK;
 }
 KjStatus kj_scene_last_commit_ms(KjScene* s, double out_ms[4]) {
@@ -385,7 +413,7 @@ KjStatus kj_scene_stats(KjScene* s, uint32_t* out_tri_count, uint32_t* out_node_
     if (!s->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
     if (out_tri_count) *out_tri_count = s->tri_count;
     if (out_node_count) *out_node_count = s->node_count;
-    if (out_bvh_bytes) *out_bvh_bytes = uint64_t(s->node_count) * sizeof(BvhNode) + uint64_t(s->tri_count) * sizeof(BvhTri) + s->h_obj_tris.size() * sizeof(BvhTri);
+    if (out_bvh_bytes) *out_bvh_bytes = uint64_t(s->node_count) * sizeof(BvhNode) + uint64_t(s->tri_count) * sizeof(BvhTri) + uint64_t(s->obj_tris_used) * sizeof(BvhTri);
     return KJ_OK;
 }
 

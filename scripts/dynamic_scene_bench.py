@@ -41,8 +41,19 @@ for it in range(5):
     allm.append(timed_commit())
 lib.check(lib.load().kj_scene_remove_instance(scene.h, 5))
 rem = timed_commit()
+# the same scene with every BLAS built on the device (KJ_BLAS_BUILD_FAST_BUILD): first commit = full build of all meshes
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+scene_fast = lib.Scene(dev, desc, fast_build=True)
+torch.cuda.synchronize()
+fast_first = dict(wall_ms=1e3 * (time.perf_counter() - t0), phases_ms=scene_fast.last_commit_ms(), **scene_fast.stats())
+t0 = time.perf_counter()
+scene_fast2 = lib.Scene(dev, desc, fast_build=True)     # second time: allocator and code objects warm
+torch.cuda.synchronize()
+fast_second = dict(wall_ms=1e3 * (time.perf_counter() - t0), phases_ms=scene_fast2.last_commit_ms())
 med = lambda xs: float(np.median(xs))
 print(json.dumps({"scene": f"procedural_city {tris} tris, {n_inst} instances of {len(desc.meshes)} meshes", "first_commit": first,
                   "move_one_instance_commit_ms": {"wall_median": med([w for w, _ in one]), "wall_min": min(w for w, _ in one), "phases_median": [med([p[k] for _, p in one]) for k in range(4)]},
                   "move_all_instances_commit_ms": {"wall_median": med([w for w, _ in allm]), "phases_median": [med([p[k] for _, p in allm]) for k in range(4)]},
-                  "remove_one_instance_commit_ms": {"wall": rem[0], "phases": rem[1]}}))
+                  "remove_one_instance_commit_ms": {"wall": rem[0], "phases": rem[1]},
+                  "device_lbvh_first_commit": fast_first, "device_lbvh_first_commit_warm": fast_second}))

@@ -9,7 +9,7 @@ from kajiya_amd import lib, scenes
 
 dev = lib.Device(0)
 desc = scenes.procedural_city(target_tris=1_000_000, seed=1234)
-scene = lib.Scene(dev, desc)
+scene = lib.Scene(dev, desc, fast_build="--fast-build" in sys.argv)   # --fast-build: BLASes as device-built LBVHs
 lo, hi = desc.bounds()
 rng = np.random.RandomState(1)
 N = 1 << 21

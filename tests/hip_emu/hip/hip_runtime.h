@@ -25,6 +25,7 @@
 #include <vector>
 
 #define __HIPCC__ 1
+#define KJ_HIP_EMU_HOST 1   // lets a translation unit leave out what only exists on the device side (rocPRIM sorts)
 #define __host__
 #define __device__
 #define __global__
@@ -248,7 +249,7 @@ inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return
 // when the real library happens to be loaded in the same process.
 typedef int hipError_t;
 typedef void* hipStream_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 enum { hipHostMallocDefault = 0 };
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
