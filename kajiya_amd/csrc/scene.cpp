@@ -357,7 +357,8 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     // 4. per-commit tables
     KJ_TRY_HIP(s->d_instances.upload(ginst.data(), ginst.size() * sizeof(GpuInstance), stream));
     KJ_TRY_HIP(s->d_inst_records.upload(recs.data(), recs.size() * sizeof(InstanceRecord), stream));
-    if (lights.empty()) lights.push_back(KjTriangleLight{});
+    const uint32_t light_count = uint32_t(lights.size());
+    if (lights.empty()) lights.push_back(KjTriangleLight{});     // keep the buffer non-empty
     KJ_TRY_HIP(s->d_lights.upload(lights.data(), lights.size() * sizeof(KjTriangleLight), stream));
     KJ_TRY_HIP(s->d_tlas_nodes.upload(tl.nodes.data(), tl.nodes.size() * sizeof(BvhNode), stream));
     // 5. world-space triangles: all instances when the set (hence the numbering) changed, else the moved ones -- on the device
@@ -383,7 +384,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     s->node_count = uint32_t(s->blas_nodes_used + tl.nodes.size());
     s->bvh_root = 0;
     s->bvh_max_depth = tl.max_stack + 1 + max_blas_stack;
-    s->light_count = uint32_t(lights.size());
+    s->light_count = light_count;
     s->meshes_dirty = false; s->instance_set_dirty = false;
     std::fill(s->xform_dirty.begin(), s->xform_dirty.end(), uint8_t(0));
     s->committed = true;
