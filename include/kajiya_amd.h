@@ -352,6 +352,20 @@ KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream);
 /* Debug access to the persistent buffers by the reference's names without the "ircache." prefix
  * ("meta", "grid_meta", "entry_cell", "spatial", "irradiance", "aux", "life", "pool",
  *  "entry_indirection", "reposition_proposal", "reposition_proposal_count"). */
+/* Deferred updates -- the irradiance cache under a screen-tile split. The reference's lookups allocate cells, refresh
+ * entry lives and vote for entry positions with atomics as they go (lookup.hlsl:118-150,287-301): replicas of the cache fed by
+ * different strips drift apart. With deferred updates on, a lookup returns the same value but only RECORDS those effects (one 32-byte
+ * KjIrcacheRequest per lookup, in a slot of its own); the host gathers the records of all ranks and every rank replays the union in
+ * one canonical order (by cell, then by the lookup's position in the frame), which leaves all replicas bit-identical -- and identical
+ * to one GPU running the same frame in this mode. Per frame: begin_requests, the frame's passes, collect_requests per slot range
+ * (kj_ircache_request_ranges: rtdgi validate, rtdgi trace -- rows of a strip are contiguous slots --, the cache's validate and trace
+ * rays), exchange, apply_requests on the merged list. */
+KjStatus kj_ircache_set_deferred_updates(KjIrcache* ircache, uint32_t enable);
+KjStatus kj_ircache_begin_requests(KjIrcache* ircache, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, void* stream);
+KjStatus kj_ircache_request_ranges(KjIrcache* ircache, uint32_t out_first_slot[4], uint32_t out_slot_count[4]);
+KjStatus kj_ircache_collect_requests(KjIrcache* ircache, uint32_t first_slot, uint32_t slot_count, void* out_list /* device, 32 B each */, uint32_t out_capacity,
+                                     void* out_count_dev /* device u32, incremented */, void* stream);
+KjStatus kj_ircache_apply_requests(KjIrcache* ircache, const void* list /* device */, uint32_t count, void* stream);
 KjStatus kj_ircache_buffer(KjIrcache* c, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 KjStatus kj_ircache_ray_counts(KjIrcache* c, uint64_t* out_closest, uint64_t* out_any);
 

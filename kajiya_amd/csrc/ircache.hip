@@ -7,6 +7,11 @@
 #include "kj_scene.hpp"
 #include "kj_ircache.hpp"
 #include "kj_reservoir.hpp"
+#include "kj_ircache_host.hpp"
+#include <algorithm>
+#ifndef KJ_HIP_EMU_HOST
+#include <hipcub/hipcub.hpp>
+#endif
 
 using namespace kj;
 namespace kj { SceneView scene_view(const KjScene& s); }
@@ -19,7 +24,7 @@ __global__ void k_irc_clear_pool(uint32_t* __restrict__ pool, uint32_t* __restri
 // scroll_cascades.hlsl:13-69 — one thread per destination cell
 __global__ void __launch_bounds__(256) k_irc_scroll_cascades(const FrameConstants* __restrict__ fc, const uint2* __restrict__ src, uint2* __restrict__ dst,
                                                               uint32_t* __restrict__ entry_cell, float4* __restrict__ irradiance, uint32_t* __restrict__ life,
-                                                              uint32_t* __restrict__ pool, uint32_t* __restrict__ meta) {
+                                                              uint32_t* __restrict__ pool, uint32_t* __restrict__ meta, uint32_t* __restrict__ freed) {
     const uint32_t dst_cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (dst_cell >= IRC_MAX_GRID_CELLS) return;
     const uint32_t x = dst_cell & 31u, y = (dst_cell >> 5) & 31u, z = (dst_cell >> 10) & 31u, cascade = dst_cell >> 15;
@@ -31,8 +36,8 @@ __global__ void __launch_bounds__(256) k_irc_scroll_cascades(const FrameConstant
             const uint32_t entry_idx = m.x;
             life[entry_idx] = IRC_LIFE_RECYCLED;
             for (int i = 0; i < 3; ++i) irradiance[entry_idx * 3 + i] = make_float4(0, 0, 0, 0);
-            const uint32_t c = atomicAdd(&meta[IRC_META_ALLOC_COUNT], 0xffffffffu);
-            pool[c - 1u] = entry_idx;
+            if (freed) freed[entry_idx] = 1u;      // deterministic mode: returned to the pool in entry order by k_irc_push_freed
+            else { const uint32_t c = atomicAdd(&meta[IRC_META_ALLOC_COUNT], 0xffffffffu); pool[c - 1u] = entry_idx; }
         }
     }
     const uint32_t sx = uint32_t(int(x) + sb[0]), sy = uint32_t(int(y) + sb[1]), sz = uint32_t(int(z) + sb[2]);
@@ -45,7 +50,7 @@ __global__ void __launch_bounds__(256) k_irc_scroll_cascades(const FrameConstant
     }
 }
 // age_ircache_entries.hlsl:22-94 (+ prepare_age_dispatch_args.hlsl: the reference dispatches ceil(entry_count/64) groups)
-__global__ void __launch_bounds__(256) k_irc_age(IrcacheView ic, uint32_t* __restrict__ occupancy) {
+__global__ void __launch_bounds__(256) k_irc_age(IrcacheView ic, uint32_t* __restrict__ occupancy, uint32_t* __restrict__ freed) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= IRC_MAX_ENTRIES) return;
     const uint32_t total_entry_count = ic.meta[IRC_META_ENTRY_COUNT];
@@ -61,8 +66,8 @@ __global__ void __launch_bounds__(256) k_irc_age(IrcacheView ic, uint32_t* __res
             } else {
                 ic.life[e] = IRC_LIFE_RECYCLED;
                 for (int i = 0; i < 3; ++i) ic.irradiance[e * 3 + i] = make_float4(0, 0, 0, 0);
-                const uint32_t c = atomicAdd(&ic.meta[IRC_META_ALLOC_COUNT], 0xffffffffu);
-                ic.pool[c - 1u] = e;
+                if (freed) freed[e] = 1u;
+                else { const uint32_t c = atomicAdd(&ic.meta[IRC_META_ALLOC_COUNT], 0xffffffffu); ic.pool[c - 1u] = e; }
                 atomicAnd(&ic.grid_meta[ic.entry_cell[e]].y, ~(IRC_META_OCCUPIED | IRC_META_JUST_ALLOCATED));
             }
         }
@@ -98,6 +103,16 @@ __global__ void __launch_bounds__(1024) k_irc_scan(uint32_t* __restrict__ data) 
 #pragma unroll
     for (int i = 0; i < 16; ++i) { uint4 a = v[i]; a.x += base; a.y += base; a.z += base; a.w += base; p[i] = a; }
 }
+// deterministic mode (deferred updates): entries freed by the scroll and age passes go back to the pool in ascending entry order
+// (`freed_scan` = inclusive scan of the flags) instead of in the order their threads happened to run
+__global__ void __launch_bounds__(256) k_irc_push_freed(const uint32_t* __restrict__ freed_scan, uint32_t* __restrict__ pool, uint32_t* __restrict__ meta_alloc_count_after) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= IRC_MAX_ENTRIES) return;
+    const uint32_t total = freed_scan[IRC_MAX_ENTRIES - 1u], incl = freed_scan[e], before = e ? freed_scan[e - 1u] : 0u;
+    const uint32_t new_count = meta_alloc_count_after[IRC_META_ALLOC_COUNT] - total;
+    if (incl != before) pool[new_count + before] = e;
+}
+__global__ void k_irc_pop_freed_count(const uint32_t* __restrict__ freed_scan, uint32_t* __restrict__ meta) { meta[IRC_META_ALLOC_COUNT] -= freed_scan[IRC_MAX_ENTRIES - 1u]; }
 // ircache_compact_entries.hlsl
 __global__ void __launch_bounds__(256) k_irc_compact(const uint32_t* __restrict__ meta, const uint32_t* __restrict__ life, const uint32_t* __restrict__ occupancy,
                                                       uint32_t* __restrict__ indirection) {
@@ -117,6 +132,15 @@ __global__ void __launch_bounds__(64) k_irc_reset(IrcacheView ic) {
     }
 }
 
+// deterministic mode: the half of every live entry's aux block that lookups read (reservoirs + contributions), as it is before a pass
+__global__ void __launch_bounds__(256) k_irc_snapshot_aux(const uint32_t* __restrict__ meta, const float4* __restrict__ aux, float4* __restrict__ snap) {
+    const uint32_t n = meta[IRC_META_ENTRY_COUNT] * 32u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const size_t o = size_t(i >> 5) * IRC_AUX_STRIDE + (i & 31u);
+        snap[o] = aux[o];
+    }
+}
+
 // ------------------------------------------------------------------ ray passes
 struct IrcTraceCtx {
     const FrameConstants* __restrict__ fc;
@@ -126,6 +150,7 @@ struct IrcTraceCtx {
     const uint2* __restrict__ brdf_fg_lut;
     const float4* __restrict__ sun_color;
     unsigned long long* __restrict__ ray_counters;
+    uint32_t request_slot_base;      // first slot of the cache's own passes in IrcacheView::requests (deferred updates)
 };
 KJ_D void irc_count_rays(unsigned long long* counters, int which) {
     const unsigned long long m = __ballot(true);
@@ -157,7 +182,7 @@ __global__ void __launch_bounds__(64) k_irc_trace_accessibility(IrcTraceCtx c) {
 
 struct IrcTraceResult { V3 incident_radiance, direction, hit_pos; };
 // ircache_trace_common.inc.hlsl:37-227 (MAX_PATH_LENGTH = 1)
-KJ_D IrcTraceResult ircache_trace(const IrcTraceCtx& c, const IrcVertex& entry, uint32_t sample_params, uint32_t life, uint32_t* stack) {
+KJ_D IrcTraceResult ircache_trace(const IrcTraceCtx& c, const IrcVertex& entry, uint32_t sample_params, uint32_t life, uint32_t* stack, uint32_t request_slot, uint32_t request_key) {
     const FrameConstants& fc = *c.fc;
     uint32_t rng = hash1(sample_params >> 4u);
     const V3 ray_o = entry.position, ray_d = irc_sample_direction(sample_params);
@@ -204,7 +229,7 @@ KJ_D IrcTraceResult ircache_trace(const IrcTraceCtx& c, const IrcVertex& entry, 
                 if (!sh) irradiance_sum += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * layered_brdf_evaluate(brdf, wo, wi2) / ls.pdf * to_psa_metric / light_selection_pmf;
             }
         }
-        irradiance_sum += ircache_lookup<true>(c.ic, fc, entry.position, primary_hit.position, gbuffer.normal, 1u + life / IRC_LIFE_PER_RANK, rng) * gbuffer.albedo;
+        irradiance_sum += ircache_lookup<true>(c.ic, fc, entry.position, primary_hit.position, gbuffer.normal, 1u + life / IRC_LIFE_PER_RANK, rng, false, request_slot, request_key) * gbuffer.albedo;
     } else {
         result.hit_pos = ray_o + ray_d * 1000.0f;
         irradiance_sum += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
@@ -230,7 +255,7 @@ __global__ void __launch_bounds__(64) k_irc_validate(IrcTraceCtx c) {
             float4 pv = ic.aux[output_idx + IRC_OCTA_DIMS2];
             pv.x *= fc.pre_exposure_delta; pv.y *= fc.pre_exposure_delta; pv.z *= fc.pre_exposure_delta;
             const IrcVertex prev_entry = irc_unpack_vertex(ic.aux[output_idx + IRC_OCTA_DIMS2 * 2]);
-            const IrcTraceResult prev_traced = ircache_trace(c, prev_entry, r.payload, life, lds_stack + threadIdx.x);
+            const IrcTraceResult prev_traced = ircache_trace(c, prev_entry, r.payload, life, lds_stack + threadIdx.x, c.request_slot_base + d, (3u << 28) | d);
             const float limiter = lerp(0.5f, 1.0f, smoothstep(-0.1f, 0.0f, dot(prev_traced.direction, prev_entry.normal)));
             const V3 a = prev_traced.incident_radiance * limiter;
             const V3 b{pv.x, pv.y, pv.z};
@@ -259,7 +284,7 @@ __global__ void __launch_bounds__(64) k_irc_trace_irradiance(IrcTraceCtx c) {
         const IrcVertex entry = irc_unpack_vertex(packed_entry);
         uint32_t rng = hash1(hash1(entry_idx) + fc.frame_index);
         const uint32_t sp = irc_sample_params(IRC_SAMPLES_PER_FRAME, entry_idx, sample_idx, fc.frame_index);
-        const IrcTraceResult traced = ircache_trace(c, entry, sp, life, lds_stack + threadIdx.x);
+        const IrcTraceResult traced = ircache_trace(c, entry, sp, life, lds_stack + threadIdx.x, c.request_slot_base + KjIrcache::REQ_E + d, (4u << 28) | d);
         const float limiter = lerp(0.5f, 1.0f, smoothstep(-0.1f, 0.0f, dot(traced.direction, entry.normal)));
         const V3 new_value = traced.incident_radiance * limiter;
         StreamState stream_state{0, 0};
@@ -332,6 +357,119 @@ __global__ void __launch_bounds__(64) k_irc_sum_up(const FrameConstants* __restr
     }
 }
 
+
+// ------------------------------------------------------------------ deferred updates: replay of recorded lookups
+// Canonical order = (cell, key): what a cell receives does not depend on which GPU's strip a lookup came from, so every replica of
+// the cache ends up bit-identical, and identical to a single GPU replaying the same frame.
+//   * a cell nobody occupies is allocated by its first lookup that may allocate; new cells take pool entries in cell order;
+//   * an occupied cell's lookups run through lookup.hlsl:287-301 one after the other: life refresh (min), then the position vote --
+//     accepted with probability 1 / (votes so far + 1), using the random number the lookup drew when it ran.
+__global__ void __launch_bounds__(256) k_irc_collect_requests(const IrcRequest* __restrict__ slots, uint32_t n, IrcRequest* __restrict__ out, uint32_t capacity, uint32_t* __restrict__ count) {
+    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < n && slots[i].cell != 0xffffffffu;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned long long m = __ballot(valid);        // one atomic per wave (a counter hit by every lane serialises in L2)
+        const uint32_t lane = threadIdx.x & 63u;
+        const int leader = m ? __ffsll((long long)m) - 1 : 0;
+        uint32_t wave_base = 0;
+        if (m != 0ull && int(lane) == leader) wave_base = atomicAdd(count, uint32_t(__popcll(m)));
+        wave_base = __shfl(wave_base, leader);
+        const uint32_t o = wave_base + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+#else
+        const uint32_t o = valid ? atomicAdd(count, 1u) : 0u;
+#endif
+        if (valid && o < capacity) out[o] = slots[i];
+    }
+}
+__global__ void __launch_bounds__(256) k_irc_request_keys(const IrcRequest* __restrict__ rq, uint32_t n, unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = ((unsigned long long)rq[i].cell << 32) | rq[i].key;
+    idx[i] = i;
+}
+// per segment head: does this cell get allocated now? (flag -> exclusive scan gives its place in the pool)
+__global__ void __launch_bounds__(256) k_irc_request_heads(IrcacheView ic, const IrcRequest* __restrict__ rq, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ idx, uint32_t n,
+                                                            uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t cell = uint32_t(keys[i] >> 32);
+    uint32_t f = 0;
+    if (cell != 0xffffffffu && (i == 0 || uint32_t(keys[i - 1] >> 32) != cell) && (ic.grid_meta[cell].y & IRC_META_OCCUPIED) == 0)
+        for (uint32_t j = i; j < n && uint32_t(keys[j] >> 32) == cell; ++j)
+            if (!(rq[idx[j]].bits & 0x100u)) { f = 1; break; }
+    flags[i] = f;
+}
+__global__ void __launch_bounds__(256) k_irc_request_apply(IrcacheView ic, const IrcRequest* __restrict__ rq, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ idx, uint32_t n,
+                                                            const uint32_t* __restrict__ flags, const uint32_t* __restrict__ ranks, uint32_t* __restrict__ scratch) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t cell = uint32_t(keys[i] >> 32);
+    if (cell == 0xffffffffu || (i != 0 && uint32_t(keys[i - 1] >> 32) == cell)) return;     // segment heads only
+    const uint2 gm = ic.grid_meta[cell];
+    if ((gm.y & IRC_META_OCCUPIED) == 0) {
+        if (!flags[i]) return;
+        const uint32_t alloc_idx = ic.meta[IRC_META_ALLOC_COUNT] + ranks[i];
+        if (alloc_idx >= IRC_MAX_ENTRIES) return;                                           // pool exhausted: the cell stays empty
+        uint32_t j = i;
+        while (rq[idx[j]].bits & 0x100u) ++j;                                               // the first lookup allowed to allocate
+        const IrcRequest a = rq[idx[j]];
+        const uint32_t entry_idx = ic.pool[alloc_idx];
+        atomicMax(&ic.meta[IRC_META_ENTRY_COUNT], entry_idx + 1u);
+        ic.life[entry_idx] = (a.bits & 0xffu) * IRC_LIFE_PER_RANK;
+        ic.entry_cell[entry_idx] = cell;
+        ic.grid_meta[cell] = make_uint2(entry_idx, gm.y | IRC_META_OCCUPIED | IRC_META_JUST_ALLOCATED);
+        ic.reposition_proposal[entry_idx] = a.proposal;
+        return;
+    }
+    if (gm.y & IRC_META_JUST_ALLOCATED) return;
+    const uint32_t entry_idx = gm.x;
+    uint32_t life = ic.life[entry_idx], votes = ic.reposition_proposal_count[entry_idx];
+    float4 proposal = ic.reposition_proposal[entry_idx];
+    bool voted = false;
+    for (uint32_t j = i; j < n && uint32_t(keys[j] >> 32) == cell; ++j) {
+        const IrcRequest r = rq[idx[j]];
+        const uint32_t query_rank = r.bits & 0xffu;
+        if (life < IRC_LIFE_RECYCLE) {
+            const uint32_t prev_life = life;
+            const uint32_t new_life = query_rank * IRC_LIFE_PER_RANK;
+            if (new_life < prev_life) life = new_life;
+            if (query_rank <= prev_life / IRC_LIFE_PER_RANK) {
+                if (r.dart <= 1.0f / (float(votes) + 1.0f)) { proposal = r.proposal; voted = true; }
+                ++votes;
+            }
+        }
+    }
+    ic.life[entry_idx] = life;
+    ic.reposition_proposal_count[entry_idx] = votes;
+    if (voted) ic.reposition_proposal[entry_idx] = proposal;
+}
+__global__ void k_irc_request_finish(IrcacheView ic, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ ranks, uint32_t n) {
+    const uint32_t allocated = ranks[n - 1] + flags[n - 1];
+    const uint32_t before = ic.meta[IRC_META_ALLOC_COUNT];
+    ic.meta[IRC_META_ALLOC_COUNT] = min(before + allocated, uint32_t(IRC_MAX_ENTRIES));
+}
+#ifdef KJ_HIP_EMU_HOST
+#include <algorithm>
+#include <vector>
+static void irc_apply_requests_host(IrcacheView ic, const IrcRequest* rq, uint32_t n) {
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rq[a].cell != rq[b].cell ? rq[a].cell < rq[b].cell : rq[a].key < rq[b].key; });
+    std::vector<unsigned long long> keys(n);
+    for (uint32_t i = 0; i < n; ++i) keys[i] = ((unsigned long long)rq[order[i]].cell << 32) | rq[order[i]].key;
+    std::vector<uint32_t> flags(n), ranks(n), scratch(4);
+    blockDim = dim3(256); gridDim = dim3((n + 255) / 256);
+    for (uint32_t b = 0; b < gridDim.x; ++b)
+        for (uint32_t t = 0; t < 256; ++t) { blockIdx = dim3(b); threadIdx = dim3(t); k_irc_request_heads(ic, rq, keys.data(), order.data(), n, flags.data()); }
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < n; ++i) { ranks[i] = acc; acc += flags[i]; }
+    for (uint32_t b = 0; b < gridDim.x; ++b)
+        for (uint32_t t = 0; t < 256; ++t) { blockIdx = dim3(b); threadIdx = dim3(t); k_irc_request_apply(ic, rq, keys.data(), order.data(), n, flags.data(), ranks.data(), scratch.data()); }
+    k_irc_request_finish(ic, flags.data(), ranks.data(), n);
+}
+#endif
+
 // ================================================================== host
 #include "kj_ircache_host.hpp"
 
@@ -343,11 +481,13 @@ IrcacheView KjIrcache::view() const {
     v.spatial = (float4*)spatial.p;
     v.irradiance = (float4*)irradiance.p;
     v.aux = (float4*)aux.p;
+    v.aux_read = (const float4*)aux.p;
     v.life = (uint32_t*)life.p;
     v.pool = (uint32_t*)pool.p;
     v.reposition_proposal = (float4*)reposition_proposal.p;
     v.reposition_proposal_count = (uint32_t*)reposition_proposal_count.p;
     v.entry_indirection = (const uint32_t*)entry_indirection.p;
+    v.requests = deferred ? (IrcRequest*)requests.p : nullptr;
     return v;
 }
 
@@ -406,21 +546,33 @@ KjStatus kj_ircache_prepare(KjIrcache* c, void* stream_) {
     hipStream_t s = (hipStream_t)stream_;
     int a = 0, b = 1;
     if (c->parity == 1) std::swap(a, b);
+    uint32_t* freed = nullptr;
+    if (c->deferred) {
+        if (c->freed.bytes != IRC_MAX_ENTRIES * 4) KJ_TRY_HIP(c->freed.alloc(IRC_MAX_ENTRIES * 4, s));
+        KJ_TRY_HIP(hipMemsetAsync(c->freed.p, 0, IRC_MAX_ENTRIES * 4, s));
+        freed = (uint32_t*)c->freed.p;
+    }
     if (!c->initialized) {
         hipLaunchKernelGGL(k_irc_clear_pool, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, (uint32_t*)c->pool.p, (uint32_t*)c->life.p);
         KJ_CHECK_LAUNCH();
         c->initialized = true;
     } else {
         hipLaunchKernelGGL(k_irc_scroll_cascades, dim3(IRC_MAX_GRID_CELLS / 256), dim3(256), 0, s, c->dev->fc_dev, (const uint2*)c->grid_meta[a].p, (uint2*)c->grid_meta[b].p,
-                           (uint32_t*)c->entry_cell.p, (float4*)c->irradiance.p, (uint32_t*)c->life.p, (uint32_t*)c->pool.p, (uint32_t*)c->meta.p);
+                           (uint32_t*)c->entry_cell.p, (float4*)c->irradiance.p, (uint32_t*)c->life.p, (uint32_t*)c->pool.p, (uint32_t*)c->meta.p, freed);
         KJ_CHECK_LAUNCH();
         std::swap(a, b);
         c->parity = (c->parity + 1) % 2;
     }
     c->cur = a;
     const IrcacheView v = c->view();
-    hipLaunchKernelGGL(k_irc_age, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, v, (uint32_t*)c->occupancy.p);
+    hipLaunchKernelGGL(k_irc_age, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, v, (uint32_t*)c->occupancy.p, freed);
     KJ_CHECK_LAUNCH();
+    if (freed) {
+        hipLaunchKernelGGL(k_irc_scan, dim3(1), dim3(1024), 0, s, freed);
+        hipLaunchKernelGGL(k_irc_push_freed, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, (const uint32_t*)freed, (uint32_t*)c->pool.p, (uint32_t*)c->meta.p);
+        hipLaunchKernelGGL(k_irc_pop_freed_count, dim3(1), dim3(1), 0, s, (const uint32_t*)freed, (uint32_t*)c->meta.p);
+        KJ_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(k_irc_scan, dim3(1), dim3(1024), 0, s, (uint32_t*)c->occupancy.p);
     KJ_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_irc_compact, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, (const uint32_t*)c->meta.p, (const uint32_t*)c->life.p, (const uint32_t*)c->occupancy.p,
@@ -442,6 +594,7 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     tc.brdf_fg_lut = (const uint2*)c->dev->brdf_fg_lut.p;
     tc.sun_color = (const float4*)c->dev->sun_color.p + c->dev->fc_slot;
     tc.ray_counters = (unsigned long long*)c->ray_counters.p;
+    tc.request_slot_base = 2u * c->req_half_pixels;
     const size_t lds = size_t(tc.sc.bvh.stack_entries) * 64 * 4;
     KJ_REQUIRE(lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");
     const uint32_t grid = c->dev->num_cus * 8;
@@ -452,8 +605,14 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     KJ_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_irc_trace_accessibility, dim3(grid), dim3(64), lds, s, tc);
     KJ_CHECK_LAUNCH();
+    if (c->deferred) {   // lookups inside the next two passes read other entries' aux while those are rewritten: give them a snapshot
+        if (c->aux_snapshot.bytes != c->aux.bytes) KJ_TRY_HIP(c->aux_snapshot.alloc(c->aux.bytes, s));
+        tc.ic.aux_read = (const float4*)c->aux_snapshot.p;
+        hipLaunchKernelGGL(k_irc_snapshot_aux, dim3(c->dev->num_cus * 4), dim3(256), 0, s, (const uint32_t*)c->meta.p, (const float4*)c->aux.p, (float4*)c->aux_snapshot.p);
+    }
     hipLaunchKernelGGL(k_irc_validate, dim3(grid), dim3(64), lds, s, tc);
     KJ_CHECK_LAUNCH();
+    if (c->deferred) hipLaunchKernelGGL(k_irc_snapshot_aux, dim3(c->dev->num_cus * 4), dim3(256), 0, s, (const uint32_t*)c->meta.p, (const float4*)c->aux.p, (float4*)c->aux_snapshot.p);
     hipLaunchKernelGGL(k_irc_trace_irradiance, dim3(grid), dim3(64), lds, s, tc);
     KJ_CHECK_LAUNCH();
     c->pending_irradiance_sum = true;
@@ -466,6 +625,67 @@ KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream_) 
     hipLaunchKernelGGL(k_irc_sum_up, dim3(c->dev->num_cus * 4), dim3(64), 0, (hipStream_t)stream_, c->dev->fc_dev, c->view());
     KJ_CHECK_LAUNCH();
     c->pending_irradiance_sum = false;
+    return KJ_OK;
+}
+// ---- deferred updates: begin (clear the frame's slots), collect (compact a slot range into a list), apply (replay a merged list)
+KjStatus kj_ircache_set_deferred_updates(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->deferred = enable != 0; return KJ_OK; }
+KjStatus kj_ircache_begin_requests(KjIrcache* c, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, void* stream_) {
+    KJ_REQUIRE(c && c->deferred, "deferred updates are off (kj_ircache_set_deferred_updates)");
+    hipStream_t s = (hipStream_t)stream_;
+    c->req_half_pixels = rtdgi_half_width * rtdgi_half_height;
+    const size_t bytes = size_t(c->request_slots()) * sizeof(IrcRequest);
+    if (c->requests.bytes != bytes) KJ_TRY_HIP(c->requests.alloc(bytes, s));
+    KJ_TRY_HIP(hipMemsetAsync(c->requests.p, 0xff, bytes, s));      // cell = 0xffffffff: unused
+    return KJ_OK;
+}
+KjStatus kj_ircache_request_ranges(KjIrcache* c, uint32_t out_first_slot[4], uint32_t out_slot_count[4]) {
+    KJ_REQUIRE(c && out_first_slot && out_slot_count, "null argument");
+    const uint32_t hb = c->req_half_pixels, e = KjIrcache::REQ_E;
+    const uint32_t first[4] = {0u, hb, 2u * hb, 2u * hb + e}, count[4] = {hb, hb, e, e};
+    for (int k = 0; k < 4; ++k) { out_first_slot[k] = first[k]; out_slot_count[k] = count[k]; }
+    return KJ_OK;
+}
+KjStatus kj_ircache_collect_requests(KjIrcache* c, uint32_t first_slot, uint32_t slot_count, void* out_list, uint32_t out_capacity, void* out_count_dev, void* stream_) {
+    KJ_REQUIRE(c && c->deferred && out_list && out_count_dev && c->requests.p, "null argument / no requests recorded");
+    KJ_REQUIRE(uint64_t(first_slot) + slot_count <= c->request_slots(), "slot range out of bounds");
+    if (slot_count == 0) return KJ_OK;
+    hipLaunchKernelGGL(k_irc_collect_requests, dim3(std::min(4096u, (slot_count + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream_, (const IrcRequest*)c->requests.p + first_slot, slot_count,
+                       (IrcRequest*)out_list, out_capacity, (uint32_t*)out_count_dev);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+KjStatus kj_ircache_apply_requests(KjIrcache* c, const void* list, uint32_t count, void* stream_) {
+    KJ_REQUIRE(c && (list || count == 0), "null argument");
+    if (count == 0) return KJ_OK;
+    hipStream_t s = (hipStream_t)stream_;
+    IrcacheView v = c->view();
+    v.requests = nullptr;
+    const IrcRequest* rq = (const IrcRequest*)list;
+#ifdef KJ_HIP_EMU_HOST
+    irc_apply_requests_host(v, rq, count);      // the CPU stand-in for HIP has no device sort: same replay, plain loops
+#else
+    auto A = [&](kj::DevBuf& b, size_t n) { if (b.bytes < n) { hipError_t e = b.alloc(n, s); if (e != hipSuccess) c->err = e; } };
+    A(c->req_sort_keys, size_t(count) * 8); A(c->req_sort_keys2, size_t(count) * 8); A(c->req_sort_idx, size_t(count) * 4); A(c->req_sort_idx2, size_t(count) * 4);
+    A(c->req_flags, size_t(count) * 4); A(c->req_ranks, size_t(count) * 4); A(c->req_count, 16);
+    KJ_TRY_HIP(c->err);
+    const dim3 g((count + 255) / 256), b(256);
+    hipLaunchKernelGGL(k_irc_request_keys, g, b, 0, s, rq, count, (unsigned long long*)c->req_sort_keys.p, (uint32_t*)c->req_sort_idx.p);
+    size_t tmp_bytes = 0;
+    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned long long*)c->req_sort_keys.p, (unsigned long long*)c->req_sort_keys2.p, (const uint32_t*)c->req_sort_idx.p,
+                                                  (uint32_t*)c->req_sort_idx2.p, int(count), 0, 64, s));
+    size_t scan_bytes = 0;
+    KJ_TRY_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)c->req_flags.p, (uint32_t*)c->req_ranks.p, int(count), s));
+    A(c->req_tmp, std::max(tmp_bytes, scan_bytes) + 16);
+    KJ_TRY_HIP(c->err);
+    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(c->req_tmp.p, tmp_bytes, (const unsigned long long*)c->req_sort_keys.p, (unsigned long long*)c->req_sort_keys2.p, (const uint32_t*)c->req_sort_idx.p,
+                                                  (uint32_t*)c->req_sort_idx2.p, int(count), 0, 64, s));
+    hipLaunchKernelGGL(k_irc_request_heads, g, b, 0, s, v, rq, (const unsigned long long*)c->req_sort_keys2.p, (const uint32_t*)c->req_sort_idx2.p, count, (uint32_t*)c->req_flags.p);
+    KJ_TRY_HIP(hipcub::DeviceScan::ExclusiveSum(c->req_tmp.p, scan_bytes, (const uint32_t*)c->req_flags.p, (uint32_t*)c->req_ranks.p, int(count), s));
+    hipLaunchKernelGGL(k_irc_request_apply, g, b, 0, s, v, rq, (const unsigned long long*)c->req_sort_keys2.p, (const uint32_t*)c->req_sort_idx2.p, count, (const uint32_t*)c->req_flags.p,
+                       (const uint32_t*)c->req_ranks.p, (uint32_t*)c->req_count.p);
+    hipLaunchKernelGGL(k_irc_request_finish, dim3(1), dim3(1), 0, s, v, (const uint32_t*)c->req_flags.p, (const uint32_t*)c->req_ranks.p, count);
+    KJ_CHECK_LAUNCH();
+#endif
     return KJ_OK;
 }
 KjStatus kj_ircache_buffer(KjIrcache* c, const char* name, void** out_dev_ptr, uint64_t* out_bytes) {

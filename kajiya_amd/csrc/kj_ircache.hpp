@@ -36,11 +36,25 @@ struct IrcacheView {
     float4* spatial;                    // pos + 11:10:11 normal
     float4* irradiance;                 // 3 per entry (L1 SH per colour channel)
     float4* aux;                        // 64 per entry: 16 reservoirs, 16 (radiance, W), 16 origin vertices, 16 unused
+    const float4* aux_read;             // what PRECISE lookups read: `aux` itself (the reference's racy read-while-written), or a snapshot taken
+                                        // before the pass (deterministic mode: one of the racy program's legal outcomes, the same on every replica)
     uint32_t* life;
     uint32_t* pool;
     float4* reposition_proposal;
     uint32_t* reposition_proposal_count;
     const uint32_t* entry_indirection;
+    // Deferred updates (screen-tile split across GPUs): when `requests` is set, a lookup changes nothing in the cache;
+    // it records what it WOULD have done (allocate the cell, refresh the entry's life, vote for its position) in its own slot
+    // requests[request_slot], and kj_ircache_apply_requests replays the merged records of all ranks in one canonical order.
+    struct IrcRequest* requests;
+};
+// One lookup's side effects. `cell` = 0xffffffff marks an unused slot. 32 bytes.
+struct IrcRequest {
+    uint32_t cell;          // grid cell the lookup resolved to
+    uint32_t key;           // canonical position of the lookup in the frame: pass << 28 | pixel (or sample) index
+    uint32_t bits;          // query_rank | skip_allocation << 8
+    float dart;             // the lookup's random number for the position vote (lookup.hlsl:299-301)
+    float4 proposal;        // packed IrcVertex it proposes for the entry
 };
 
 KJ_HD bool irc_life_valid(uint32_t life) { return life < IRC_LIFE_PER_RANK * IRC_RANK_COUNT; }
@@ -116,7 +130,7 @@ KJ_D float irc_eval_sh_geometrics(float4 sh, V3 normal) {
 // STOCHASTIC: the caller may ask for stochastic interpolation (rtr only); otherwise the jitter code is compiled out.
 template <bool PRECISE, bool STOCHASTIC = false>
 KJ_D V3 ircache_lookup(const IrcacheView& ic, const FrameConstants& fc, V3 query_from_ws, V3 pt_ws, V3 normal_ws, uint32_t query_rank, uint32_t& rng,
-                       bool stochastic_interpolation = false) {
+                       bool stochastic_interpolation = false, uint32_t request_slot = 0, uint32_t request_key = 0) {
     bool allocated_by_us = false, just_allocated = false;
     // select(stochastic_interpolation, float3(hash1_mut x3) - 0.5, 0): both arms are evaluated => rng advances 3x
     V3 jitter = v3(0.0f);
@@ -137,6 +151,19 @@ KJ_D V3 ircache_lookup(const IrcacheView& ic, const FrameConstants& fc, V3 query
         const bool skip_allocation = query_rank >= IRC_RANK_COUNT || (was_just_scrolled_in && query_rank > 0);
         const uint32_t entry_flags = ic.grid_meta[cell].y;
         just_allocated = (entry_flags & IRC_META_JUST_ALLOCATED) != 0;
+        if (ic.requests) {
+            // deferred: the value returned below does not depend on this frame's updates (an unoccupied cell yields 0 whether or not
+            // someone allocates it now; an occupied one reads irradiance no lookup writes), so the updates can be replayed later
+            IrcRequest rq;
+            rq.cell = cell; rq.key = request_key; rq.bits = query_rank | (skip_allocation ? 0x100u : 0u);
+            rq.dart = uint_to_u01_float(hash1_mut(rng));
+            V3 otq = query_from_ws - pt_ws;
+            const float cd = IRC_GRID_CELL_DIAMETER * float(1u << rc.cascade);
+            otq = otq * (cd / fmaxf(cd / 0.5f, length(otq)));
+            rq.proposal = irc_pack_vertex(IrcVertex{pt_ws + otq, normal_ws});
+            ic.requests[request_slot] = rq;
+            if ((entry_flags & IRC_META_OCCUPIED) == 0 || just_allocated) return v3(0.0f);
+        } else
         if (!skip_allocation && (entry_flags & IRC_META_OCCUPIED) == 0) {
             const uint32_t prev = atomicOr(&ic.grid_meta[cell].y, IRC_META_OCCUPIED | IRC_META_JUST_ALLOCATED);
             if ((prev & IRC_META_OCCUPIED) == 0) {
@@ -171,10 +198,10 @@ KJ_D V3 ircache_lookup(const IrcacheView& ic, const FrameConstants& fc, V3 query
         if (PRECISE) {
             float weight_sum = 0;
             for (uint32_t octa_idx = 0; octa_idx < IRC_OCTA_DIMS2; ++octa_idx) {
-                const uint32_t payload = asuint(ic.aux[size_t(entry_idx) * IRC_AUX_STRIDE + octa_idx].x);
+                const uint32_t payload = asuint(ic.aux_read[size_t(entry_idx) * IRC_AUX_STRIDE + octa_idx].x);
                 const float wt = dot(irc_sample_direction(payload), normal_ws);
                 if (wt > 0.0f) {
-                    const float4 contrib = ic.aux[size_t(entry_idx) * IRC_AUX_STRIDE + IRC_OCTA_DIMS2 + octa_idx];
+                    const float4 contrib = ic.aux_read[size_t(entry_idx) * IRC_AUX_STRIDE + IRC_OCTA_DIMS2 + octa_idx];
                     irr += V3{contrib.x, contrib.y, contrib.z} * (wt * contrib.w);
                     weight_sum += wt;
                 }
@@ -187,7 +214,7 @@ KJ_D V3 ircache_lookup(const IrcacheView& ic, const FrameConstants& fc, V3 query
         }
         irradiance_sum = vmax(v3(0.0f), irr);
         const uint32_t prev_life = ic.life[entry_idx];
-        if (prev_life < IRC_LIFE_RECYCLE) {
+        if (!ic.requests && prev_life < IRC_LIFE_RECYCLE) {
             const uint32_t new_life = query_rank * IRC_LIFE_PER_RANK;
             if (new_life < prev_life) atomicMin(&ic.life[entry_idx], new_life);
             if (query_rank <= prev_life / IRC_LIFE_PER_RANK) {

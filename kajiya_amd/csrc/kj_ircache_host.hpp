@@ -14,5 +14,13 @@ struct KjIrcache {
     int cur_scroll[12][3] = {}, prev_scroll[12][3] = {};
     int parity = 0;
     int cur = 0;  // which grid_meta buffer is live after prepare()
+    // deferred updates (kj_ircache.hpp: IrcRequest): one slot per possible lookup of the frame, in four ranges
+    //   [0, HB) rtdgi validate | [HB, 2 HB) rtdgi trace | [2 HB, 2 HB + E) the cache's validate rays | [2 HB + E, 2 HB + 2 E) its trace rays
+    bool deferred = false;
+    uint32_t req_half_pixels = 0;       // HB of the current frame
+    kj::DevBuf freed, aux_snapshot, requests, req_sort_keys, req_sort_keys2, req_sort_idx, req_sort_idx2, req_flags, req_ranks, req_tmp, req_count;
+    hipError_t err = hipSuccess;
+    static constexpr uint32_t REQ_E = IRC_MAX_ENTRIES * IRC_SAMPLES_PER_FRAME;
+    uint32_t request_slots() const { return 2u * req_half_pixels + 2u * REQ_E; }
     kj::IrcacheView view() const;
 };

@@ -128,6 +128,7 @@ struct TraceCtx {
     const uint2* __restrict__ brdf_fg_lut;
     const float4* __restrict__ sun_color;
     IrcacheView irc; bool has_ircache;              // IrcacheRenderState bound via bind_mut (rtdgi.rs:321,350)
+    uint32_t request_slot_base, request_key_base, request_stride;   // deferred ircache updates: slot / key of pixel (x, y) = base + y * stride + x
     unsigned long long* __restrict__ ray_counters;  // [0]=closest rays, [1]=any-hit rays, [2..5]=nodes/tris visited (closest, any) in STATS builds
 };
 
@@ -209,7 +210,8 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
                 }
             }
             if (c.has_ircache) {  // USE_IRCACHE (diffuse_trace_common.inc.hlsl:189-198); unbound => contributes 0 (BASELINE config 1)
-                const V3 gi = ircache_lookup<false>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng);
+                const uint32_t rq = py * c.request_stride + px;
+                const V3 gi = ircache_lookup<false>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng, false, c.request_slot_base + rq, c.request_key_base | rq);
                 total_radiance += gi * gbuffer.albedo;
             }
         }
@@ -487,7 +489,8 @@ __global__ void __launch_bounds__(64) k_rtdgi_shade(TraceCtx c, RayStage st, Img
                 }
             }
             if (c.has_ircache) {  // USE_IRCACHE (diffuse_trace_common.inc.hlsl:189-198); unbound => contributes 0 (BASELINE config 1)
-                const V3 t = ircache_lookup<false>(c.irc, fc, ray_o, hit_position, gbuffer.normal, 1u, rng) * gbuffer.albedo;
+                const uint32_t rq = uint32_t(y) * c.request_stride + uint32_t(x);
+                const V3 t = ircache_lookup<false>(c.irc, fc, ray_o, hit_position, gbuffer.normal, 1u, rng, false, c.request_slot_base + rq, c.request_key_base | rq) * gbuffer.albedo;
                 lit += t; shadowed += t;
             }
         }
@@ -983,6 +986,8 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     tc.has_ircache = p->ircache != nullptr;
     if (p->ircache) tc.irc = p->ircache->view(); else memset(&tc.irc, 0, sizeof(tc.irc));
     tc.ray_counters = (unsigned long long*)r->ray_counters.p;
+    tc.request_stride = uint32_t(hw); tc.request_slot_base = 0; tc.request_key_base = 1u << 28;     // validate pass; the trace pass re-bases below
+    if (p->ircache && p->ircache->deferred) KJ_REQUIRE(p->ircache->req_half_pixels == uint32_t(hw) * uint32_t(hh), "kj_ircache_begin_requests must be called with this frame's half-res extent");
     const size_t trace_lds = size_t(tc.sc.bvh.stack_entries) * 64 * 4;
 
     if (mask & KJ_RTDGI_PASS_EXTRACT_HALF) {
@@ -1019,6 +1024,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(2);
     }
+    tc.request_slot_base = uint32_t(hw) * uint32_t(hh); tc.request_key_base = 2u << 28;
     if ((mask & KJ_RTDGI_PASS_TRACE) && !staged) {
         SCOPE_BEGIN(3);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),

@@ -24,7 +24,7 @@ EXPORTS = [
     "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_render",
     "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
-    "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts",
+    "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts", "kj_ircache_set_deferred_updates", "kj_ircache_begin_requests", "kj_ircache_request_ranges", "kj_ircache_collect_requests", "kj_ircache_apply_requests",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
     "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_light_gbuffer",
     "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_surface",
@@ -70,6 +70,11 @@ def load():
         "kj_trace_any": [vp, vp, vp, u32, vp],
         "kj_debug_calibration_copy": [vp, vp, C.c_uint64, vp],
         "kj_scene_last_commit_ms": [vp, C.POINTER(C.c_double)],
+        "kj_ircache_set_deferred_updates": [vp, u32],
+        "kj_ircache_begin_requests": [vp, u32, u32, vp],
+        "kj_ircache_request_ranges": [vp, C.POINTER(u32), C.POINTER(u32)],
+        "kj_ircache_collect_requests": [vp, u32, u32, vp, u32, vp, vp],
+        "kj_ircache_apply_requests": [vp, vp, u32, vp],
         "kj_scene_set_blas_build_mode": [vp, u32],
         "kj_raster_gbuffer": [vp, vp, u32, u32, vp, vp, vp, vp, vp],
         "kj_sky_cube_render": [vp, vp, vp],
@@ -328,7 +333,10 @@ class GpuPipeline:
         """The GI frame in world_render_passes.rs order: ircache.prepare, trace_irradiance (:99,113-121),
         rtdgi.reproject (:129), ircache sum-up (:138-140), rtdgi.render (:145-163)."""
         s = _stream_ptr()
+        deferred = self.ircache and getattr(self, "ircache_deferred", False)
         if self.ircache:
+            if deferred:
+                self.ircache_begin_requests()
             check(self.L.kj_ircache_prepare(self.ircache, s))
             check(self.L.kj_ircache_trace_irradiance(self.ircache, self.scene.h, self.sky16.data_ptr(), 16, s))
         check(self.L.kj_rtdgi_reproject(self.rtdgi, self.reprojection_map_ptr, self.W, self.H, s))
@@ -336,6 +344,8 @@ class GpuPipeline:
             check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
         p = self.params(pass_mask)
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+        if deferred:
+            self.ircache_replay_own_requests()
 
     # ---- frame pipelining (async compute). The irradiance cache's maintenance + ray kernels of frame N+1 only depend on
     # the cache state left by frame N's rtdgi validate/trace passes and on frame N+1's constants, and they are latency-bound
@@ -413,6 +423,47 @@ class GpuPipeline:
             self._enqueue_ircache(next_fc, self._ev_trace[i])
         else:
             s0.wait_event(self._ev_taa[i])
+
+    # ---- deferred irradiance-cache updates (include/kajiya_amd.h: kj_ircache_set_deferred_updates): lookups record, the host replays
+    def ircache_set_deferred(self, enable=True):
+        check(self.L.kj_ircache_set_deferred_updates(self.ircache, int(enable)))
+        self.ircache_deferred = bool(enable)
+
+    def ircache_begin_requests(self):
+        check(self.L.kj_ircache_begin_requests(self.ircache, (self.W + 1) // 2, (self.H + 1) // 2, _stream_ptr()))
+
+    def ircache_request_ranges(self):
+        first, count = (C.c_uint32 * 4)(), (C.c_uint32 * 4)()
+        check(self.L.kj_ircache_request_ranges(self.ircache, first, count))
+        return list(first), list(count)
+
+    def ircache_collect(self, ranges, capacity=None):
+        """Compacts the recorded requests of the slot ranges [(first, count), ...] into one device list; returns (int32 tensor
+        [capacity, 8], device int32 counter). 32 bytes per request."""
+        torch = self.torch
+        capacity = capacity or sum(c for _, c in ranges)
+        key = ("_req_list", capacity)
+        buf = getattr(self, "_req_bufs", {}).get(key)
+        if buf is None:
+            buf = torch.empty((max(1, capacity), 8), dtype=torch.int32, device=self.depth.device)
+            self._req_bufs = getattr(self, "_req_bufs", {})
+            self._req_bufs[key] = buf
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.depth.device)
+        s = _stream_ptr()
+        for first, count in ranges:
+            if count:
+                check(self.L.kj_ircache_collect_requests(self.ircache, first, count, buf.data_ptr(), capacity, cnt.data_ptr(), s))
+        return buf, cnt
+
+    def ircache_apply(self, requests, count):
+        if count:
+            check(self.L.kj_ircache_apply_requests(self.ircache, requests.data_ptr(), int(count), _stream_ptr()))
+
+    def ircache_replay_own_requests(self):
+        """Single GPU in deferred mode: everything this frame's lookups recorded, replayed in the canonical order."""
+        first, count = self.ircache_request_ranges()
+        buf, cnt = self.ircache_collect(list(zip(first, count)))
+        self.ircache_apply(buf, int(cnt.item()))
 
     def taa_frame(self, input_ptr=None, out_extent=None):
         """TaaRenderer::render on `input_ptr` (default: this frame's rtdgi screen_irradiance_tex)."""

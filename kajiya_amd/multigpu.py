@@ -99,6 +99,16 @@ class LocalComm:
         for (_, dst), data in zip(pairs, staged):
             dst.copy_(data)
 
+    def all_gather_rows(self, parts):
+        """parts: {rank: (tensor [capacity, k], valid row count)} -> {rank: every rank's valid rows, concatenated in rank order}."""
+        return _local_all_gather_rows(parts, self.ranks)
+
+
+def _local_all_gather_rows(parts, ranks):
+    import torch
+    cat = torch.cat([parts[r][0][:parts[r][1]] for r in sorted(parts)], dim=0)
+    return {r: cat for r in ranks}
+
 
 class DistComm:
     """torch.distributed point-to-point exchange (NCCL = RCCL on ROCm; gloo for CPU tests).
@@ -166,6 +176,27 @@ class DistComm:
         for w in d.batch_isend_irecv(ops):
             w.wait()
 
+    def all_gather_rows(self, parts):
+        """Variable-length all-gather: the row counts first (one small all_gather), then the rows padded to the largest count."""
+        import torch
+        d = self.dist
+        buf, n = parts[self.rank]
+        dev = buf.device
+        stage = self.stage or d.get_backend() == "gloo" and dev.type != "cpu"
+        counts = torch.zeros(self.n, dtype=torch.int64, device="cpu" if stage else dev)
+        mine = torch.tensor([n], dtype=torch.int64, device=counts.device)
+        d.all_gather_into_tensor(counts, mine)
+        counts = [int(c) for c in counts.tolist()]
+        m = max(counts)
+        if m == 0:
+            return {self.rank: buf[:0]}
+        send = torch.zeros((m, buf.shape[1]), dtype=buf.dtype, device="cpu" if stage else dev)
+        send[:n].copy_(buf[:n])
+        recv = torch.empty((self.n * m, buf.shape[1]), dtype=buf.dtype, device=send.device)
+        d.all_gather_into_tensor(recv, send)
+        rows = torch.cat([recv[i * m:i * m + counts[i]] for i in range(self.n)], dim=0).to(dev)
+        return {self.rank: rows}
+
     def run(self, xfers, get_rows):
         ops, landing = [], []
         for (src, dst, a, b) in xfers:
@@ -215,6 +246,13 @@ class SplitRtdgi:
         self._s = None
         self._side = None          # side stream state for pipelined ircache work
         self.on_ircache_traced = None
+        # every rank keeps a replica of the irradiance cache. With `consistent_ircache` the replicas record their lookups'
+        # side effects instead of applying them (kj_ircache_set_deferred_updates), the records of all strips are all-gathered after the
+        # trace pass and every rank replays the same merged list: the replicas stay bit-identical (no seams between strips).
+        self.consistent_ircache = all(gp.ircache for gp in pipes.values())
+        for gp in pipes.values():
+            if gp.ircache:
+                gp.ircache_set_deferred(self.consistent_ircache)
 
     # -- helpers
     def _surface(self, rank, name):
@@ -270,6 +308,8 @@ class SplitRtdgi:
             klib.check(st)
 
     def _ircache_head(self, gp, s):
+        if self.consistent_ircache:
+            gp.ircache_begin_requests()
         klib.check(gp.L.kj_ircache_prepare(gp.ircache, s))
         klib.check(gp.L.kj_ircache_trace_irradiance(gp.ircache, gp.scene.h, gp.sky16.data_ptr(), 16, s))
 
@@ -349,6 +389,8 @@ class SplitRtdgi:
         self._exchange(items)
         for r in R:
             self._render(r, P["TRACE"] | KEEP, self.strips[r])
+        if self.consistent_ircache:
+            self._merge_ircache_requests()
         if trace_event is not None:
             import torch
             trace_event.record(torch.cuda.current_stream())
@@ -370,6 +412,28 @@ class SplitRtdgi:
         for r in R:
             self._render(r, P["SPATIAL_FILTER"] | KEEP, self.strips[r])
         self.frame += 1
+
+    def _merge_ircache_requests(self):
+        """All-gather of this frame's recorded cache updates, then the same replay on every rank. A strip's rtdgi lookups (validate and
+        trace pass) occupy contiguous slots (rows of the half-res image); the cache's own ray passes are replicated, so their records
+        are identical on every rank and stay local."""
+        import torch
+        hw = (self.W + 1) // 2
+        strip_lists, irc_lists = {}, {}
+        for r in self.comm.ranks:
+            gp = self.pipes[r]
+            first, count = gp.ircache_request_ranges()
+            h0, h1 = half_rows(*self.strips[r], self.H)
+            strip_lists[r] = gp.ircache_collect([(first[0] + h0 * hw, (h1 - h0) * hw), (first[1] + h0 * hw, (h1 - h0) * hw)], capacity=2 * (h1 - h0) * hw)
+            irc_lists[r] = gp.ircache_collect([(first[2], count[2]), (first[3], count[3])], capacity=count[2] + count[3])
+        gathered = self.comm.all_gather_rows({r: (buf, int(cnt.item())) for r, (buf, cnt) in strip_lists.items()})
+        for r in self.comm.ranks:
+            gp = self.pipes[r]
+            buf, cnt = irc_lists[r]
+            n = int(cnt.item())
+            merged = torch.cat([gathered[r], buf[:n]], dim=0).contiguous()
+            gp.ircache_apply(merged, merged.shape[0])
+            self._keepalive = merged
 
     def taa_frame(self):
         """TaaRenderer::render on this frame's GI image, strip by strip. ONE exchange here (the input's halo; the three

@@ -42,6 +42,56 @@ def test_strip_split_is_bit_exact(gpu, device, n_ranks, W, H):
             assert not bool(neq.any()), f"TAA frame {fi} rank {r}: {int(neq.sum())} texels differ (rows {torch.nonzero(neq.any(dim=1)).flatten()[:8].tolist()})"
 
 
+IRC_BUFS = ("meta", "grid_meta", "entry_cell", "spatial", "irradiance", "aux", "life", "pool", "reposition_proposal", "reposition_proposal_count")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,W,H", [(2, 256, 160), (3, 320, 208)])
+def test_strip_split_with_the_irradiance_cache_is_bit_exact(gpu, device, n_ranks, W, H):
+    """with the cache bound every rank keeps a replica; the strips' lookups are recorded, all-gathered and replayed in
+    one canonical order on every replica (kj_ircache_apply_requests). The replicas must stay bit-identical to each other AND to a
+    single GPU running the same frames in the same (deferred, deterministic) mode: GI image, TAA image and every cache buffer."""
+    import torch
+    from kajiya_amd import multigpu
+    desc = T._scenes()["city20k"]
+    scene = gpu.Scene(device, desc)
+    ref = gpu.GpuPipeline(device, scene, W, H, use_ircache=True)
+    ref.ircache_set_deferred(True)
+    pipes = {r: gpu.GpuPipeline(device, scene, W, H, use_ircache=True) for r in range(n_ranks)}
+    split = multigpu.SplitRtdgi(multigpu.LocalComm(n_ranks), pipes, W, H, motion_halo=8)
+    assert split.consistent_ircache
+    from kajiya_amd import frame
+    fs = frame.FrameState((W, H))
+    fs.ircache_enabled = True
+    for fi in range(8):
+        fc = fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.02))
+        fs.retire_frame()
+        ref.frame(fc)
+        for r in range(n_ranks):
+            pipes[r].render_inputs(fc)
+            pipes[r].reprojection()
+        split.gi_frame()
+        split.taa_frame()
+        ref.taa_frame()
+        split.gather_output("spatial_filtered_tex")
+        split.gather_output(f"TAA/taa:{fi % 2}")
+        torch.cuda.synchronize()
+        for name in IRC_BUFS:
+            a = ref.ircache_buffer(name, torch.uint8)
+            for r in range(n_ranks):
+                b = pipes[r].ircache_buffer(name, torch.uint8)
+                assert torch.equal(a, b), f"frame {fi} rank {r}: ircache buffer {name} differs in {int((a != b).sum())} bytes"
+        a = ref.surface("spatial_filtered_tex", torch.int16, (H, W, 4))
+        ta = ref.taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4))
+        for r in range(n_ranks):
+            neq = (a != pipes[r].surface("spatial_filtered_tex", torch.int16, (H, W, 4))).any(dim=-1)
+            assert not bool(neq.any()), f"frame {fi} rank {r}: {int(neq.sum())} GI texels differ (rows {torch.nonzero(neq.any(dim=1)).flatten()[:8].tolist()})"
+            neq = (ta != pipes[r].taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4))).any(dim=-1)
+            assert not bool(neq.any()), f"TAA frame {fi} rank {r}: {int(neq.sum())} texels differ"
+    meta = ref.ircache_buffer("meta", torch.int32).cpu().numpy()
+    assert meta[3] > 50, meta     # the cache did allocate entries
+
+
 def test_strip_plan_and_transfers():
     from kajiya_amd import multigpu
     for H, n in ((1080, 8), (2160, 8), (1080, 3), (160, 2)):
