@@ -2,6 +2,7 @@
 // crates/lib/kajiya/src/renderers/rtdgi.rs:143-554 and every shader it records
 // (assets/shaders/rtdgi/*.hlsl). One function per reference pass.
 #pragma once
+#include <cstdlib>
 #include "okj_passes.hpp"
 #include "okj_reservoir.hpp"
 #include "okj_ircache.hpp"
@@ -185,8 +186,10 @@ struct Rtdgi {
             const f3 primary_hit_cs = position_world_to_sample(fc, primary_hit.position);
             const f2 primary_hit_uv = cs_to_uv(f2{primary_hit_cs.x, primary_hit_cs.y});
             const float primary_hit_screen_depth = sample_nearest_clamp(in.depth, primary_hit_uv);
+            // OKJ_RTDGI_DEPTH_GATE: experiment knob of scripts/pt_deficit_attribution.py (default = the shader's 5e-3)
+            static const float depth_gate = getenv("OKJ_RTDGI_DEPTH_GATE") ? float(atof(getenv("OKJ_RTDGI_DEPTH_GATE"))) : 5e-3f;
             bool is_on_screen = fabsf(primary_hit_cs.x) < 1.0f && fabsf(primary_hit_cs.y) < 1.0f &&
-                                inverse_depth_relative_diff(primary_hit_cs.z, primary_hit_screen_depth) < 5e-3f;
+                                inverse_depth_relative_diff(primary_hit_cs.z, primary_hit_screen_depth) < depth_gate;
             f4 reprojected_radiance = mk4(0.0f);
             if (dbg_enabled) {
                 dbg[0].fetch_add(1);
