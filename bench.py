@@ -370,7 +370,7 @@ def main():
             if note:
                 e["note"] = note
             return e
-        ray_kernel = "k_rtdgi_trace"
+        ray_kernel = "k_rtdgi_trace_fused<false>"
         roofline = entry(ray_kernel, trace_ms, trace_bytes)
         roofline.update({"traffic_source": "profiles/pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md)" if roofline["traffic"] else None,
                          "nodes_per_closest_ray": round(nodes_per_closest, 2), "tris_per_closest_ray": round(tris_per_closest, 2),

@@ -93,7 +93,7 @@ struct KjScene {
     bool committed = false;
     kj::DevBuf d_vertex_buffer, d_meshes, d_instances, d_maps, d_tex_data, d_lights, d_blas_nodes, d_obj_tris, d_tlas_nodes, d_tris, d_inst_records, d_jobs;
     std::vector<uint32_t> inst_tri_base;          // per instance slot: first world triangle (valid for live instances after a commit)
-    uint32_t light_count = 0, tri_count = 0, node_count = 0, bvh_root = 0, bvh_max_depth = 0;
+    uint32_t light_count = 0, tri_count = 0, node_count = 0, tlas_node_count = 0, bvh_root = 0, bvh_max_depth = 0;
     double last_commit_ms[4] = {0, 0, 0, 0};      // host time of the last commit: BLAS builds, instance records + TLAS, uploads + device transform, total
     kj::SceneView view() const;
 };

@@ -77,8 +77,12 @@ struct BvhView {
     const F4* tris;          // 3 x 16 B per tri
     const InstanceRecord* instances;
     uint32_t root;           // always 0 (kept for the C-ABI debug query)
-    uint32_t stack_entries;  // per-lane LDS stack entries a tracing kernel must provide (KJ_BVH_LDS_STACK)
+    uint32_t stack_entries;  // dynamic LDS a tracing kernel must provide, in units of 64 dwords: the KJ_BVH_LDS_STACK levels of the per-lane
+                             // stacks + (when lds_table_dwords != 0) room for a copy of the TLAS nodes and the instance records
+    uint32_t tlas_node_count, instance_count;
+    uint32_t lds_table_dwords;   // (tlas_node_count + instance_count) * 16 when that fits KJ_BVH_LDS_TABLE_MAX_BYTES, else 0: no copy, global reads
 };
+#define KJ_BVH_LDS_TABLE_MAX_BYTES 12288u
 
 // 32 B per material map. flags: bits 0-7 = mip count (0 => 1x1 placeholder, `color`), bit 8 = sRGB texels.
 struct MapDesc { F4 color; uint32_t offset, width, height, flags; };

@@ -16,6 +16,7 @@
 #include <cstdarg>
 #include <numeric>
 #include <chrono>
+#include <cstdlib>
 #include "kj_scene_device.hpp"
 
 namespace kj {
@@ -42,7 +43,12 @@ SceneView scene_view(const KjScene& s) {
     v.bvh.tris = (const F4*)s.d_tris.p;
     v.bvh.instances = (const InstanceRecord*)s.d_inst_records.p;
     v.bvh.root = s.bvh_root;
-    v.bvh.stack_entries = KJ_BVH_LDS_STACK;      // LDS part of the traversal stack; deeper entries spill (kj_bvh.hpp)
+    v.bvh.tlas_node_count = s.tlas_node_count;
+    v.bvh.instance_count = uint32_t(s.instances.size());
+    const uint32_t table_bytes = (v.bvh.tlas_node_count + v.bvh.instance_count) * 64u;
+    v.bvh.lds_table_dwords = (table_bytes <= KJ_BVH_LDS_TABLE_MAX_BYTES && !getenv("KJ_BVH_NO_LDS_TABLES")) ? table_bytes / 4u : 0u;
+    // LDS part of the traversal stack (deeper entries spill, kj_bvh.hpp) + the small scenes' TLAS / instance table copy
+    v.bvh.stack_entries = KJ_BVH_LDS_STACK + (v.bvh.lds_table_dwords + 63u) / 64u;
     return v;
 }
 
@@ -382,6 +388,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     s->inst_tri_base = tri_base;
     s->tri_count = total_tris;
     s->node_count = uint32_t(s->blas_nodes_used + tl.nodes.size());
+    s->tlas_node_count = uint32_t(tl.nodes.size());
     s->bvh_root = 0;
     s->bvh_max_depth = tl.max_stack + 1 + max_blas_stack;
     s->light_count = light_count;

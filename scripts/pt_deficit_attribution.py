@@ -27,7 +27,7 @@ if mode == "pt":
     for i in range(n):
         fc = fs.prepare_frame_constants(cam()); fs.retire_frame()
         okj_py.reference_path_trace(osc, fc, acc, first_bounce_mode=2)
-    img = acc[..., :3] / acc[..., 3:4]
+    img = acc[..., :3]          # the accumulator keeps the running mean in rgb and the sample count in w (reference.rs / okj_reference_pt.hpp)
 else:
     irc = mode == "gi_irc"
     op = okj_py.OraclePipeline(osc, W, H, use_ircache=irc)

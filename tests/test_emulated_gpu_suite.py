@@ -36,7 +36,7 @@ def run_emulated(pytest_args, timeout, fast=False):
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs ROCm's clang++ as the host compiler")
 def test_a_slice_of_the_gpu_suite_passes_on_the_cpu_stand_in_under_sanitizers():
     r = run_emulated(["tests/test_gpu_parity.py", "tests/test_gpu_ssgi.py", "tests/test_gpu_shadow_denoise.py", "tests/test_zz_gpu_post.py",
-                      "-k", "city20k-123-77 or light_gbuffer[0] or (ray_queries and cornell) or (per_frame and cornell) or 160-90 or 320-180-320-180"], timeout=1500)
+                      "-k", "(test_rtdgi_per_pass_parity and city20k-123-77) or light_gbuffer[0] or 160-90 or 320-180-320-180"], timeout=1500)
     tail = r.stdout[-3000:] + r.stderr[-6000:]
     assert r.returncode == 0, tail
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, tail

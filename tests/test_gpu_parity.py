@@ -91,8 +91,11 @@ def test_device_built_lbvh_ray_queries_bit_exact(gpu, oracle, device, name):
     """KJ_BLAS_BUILD_FAST_BUILD: every mesh's BLAS is a linear BVH built on the device (lbvh_build.hip). Another tree, the same hits:
     (t, u, v, triangle) must equal the oracle's (whose BVH is a median split built on the host) bit for bit, for closest-hit,
     any-hit and back-face-culled queries, and after moving an instance."""
+    import os
     import torch
     from kajiya_amd import scenes
+    if os.environ.get("KJ_HIP_EMU"):
+        pytest.skip("the device builder sorts with rocPRIM: not part of the CPU stand-in for HIP")
     desc = _scenes()[name]
     osc = oracle.OracleScene(desc)
     gsc = gpu.Scene(device, desc, fast_build=True)
