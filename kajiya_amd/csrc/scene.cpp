@@ -46,7 +46,9 @@ SceneView scene_view(const KjScene& s) {
     v.bvh.tlas_node_count = s.tlas_node_count;
     v.bvh.instance_count = uint32_t(s.instances.size());
     const uint32_t table_bytes = (v.bvh.tlas_node_count + v.bvh.instance_count) * 64u;
-    v.bvh.lds_table_dwords = (table_bytes <= KJ_BVH_LDS_TABLE_MAX_BYTES && !getenv("KJ_BVH_NO_LDS_TABLES")) ? table_bytes / 4u : 0u;
+    // opt-in (KJ_BVH_LDS_TABLES=1): measured SLOWER as staged today -- one cooperative copy per trace call, 9.6 KB of LDS per wave:
+    // 1889 / 2241 Mrays/s (one ray per lane / stream) against 2177 / 2669 without, no difference inside the frame
+    v.bvh.lds_table_dwords = (table_bytes <= KJ_BVH_LDS_TABLE_MAX_BYTES && getenv("KJ_BVH_LDS_TABLES")) ? table_bytes / 4u : 0u;
     // LDS part of the traversal stack (deeper entries spill, kj_bvh.hpp) + the small scenes' TLAS / instance table copy
     v.bvh.stack_entries = KJ_BVH_LDS_STACK + (v.bvh.lds_table_dwords + 63u) / 64u;
     return v;

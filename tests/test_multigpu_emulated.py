@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, H, frames, packed, q):
+def _worker(rank, world, port, W, H, frames, packed, q, with_ircache=False):
     try:
         os.environ["KJ_HIP_EMU"] = "fast"
         os.environ.setdefault("HIP_EMU_WORKERS", "4")
@@ -40,11 +40,21 @@ def _worker(rank, world, port, W, H, frames, packed, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dev = lib.Device(0)
         scene = lib.Scene(dev, T._scenes()["city20k"])
-        ref = lib.GpuPipeline(dev, scene, W, H)
-        pipe = lib.GpuPipeline(dev, scene, W, H)
+        ref = lib.GpuPipeline(dev, scene, W, H, use_ircache=with_ircache)
+        pipe = lib.GpuPipeline(dev, scene, W, H, use_ircache=with_ircache)
+        if with_ircache:
+            ref.ircache_set_deferred(True)      # the single-GPU frame in the same deterministic mode the split puts the replicas in
         split = multigpu.SplitRtdgi(multigpu.DistComm(dist, rank, world, packed=packed), {rank: pipe}, W, H, motion_halo=8)
+        assert split.consistent_ircache == with_ircache
         worst = 0
-        for fi, fc in enumerate(T._frame_constants(W, H, frames, "city")):
+        from kajiya_amd import frame as kframe
+        fs = kframe.FrameState((W, H))
+        fs.ircache_enabled = with_ircache
+        fcs = []
+        for i in range(frames):
+            fcs.append(fs.prepare_frame_constants(kframe.orbit_camera(i, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.004)))
+            fs.retire_frame()
+        for fi, fc in enumerate(fcs):
             ref.frame(fc)
             pipe.render_inputs(fc)
             pipe.reprojection()
@@ -56,6 +66,9 @@ def _worker(rank, world, port, W, H, frames, packed, q):
             a, b = ref.surface("spatial_filtered_tex", torch.int16, (H, W, 4)), pipe.surface("spatial_filtered_tex", torch.int16, (H, W, 4))
             ta, tb = ref.taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4)), pipe.taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4))
             worst = max(worst, int((a != b).any(dim=-1).sum()), int((ta != tb).any(dim=-1).sum()))
+            if with_ircache:      # every replica of the cache equals the single-GPU cache, buffer by buffer
+                for name in ("meta", "grid_meta", "entry_cell", "irradiance", "life", "pool", "reposition_proposal", "reposition_proposal_count"):
+                    worst = max(worst, int((ref.ircache_buffer(name, torch.uint8) != pipe.ircache_buffer(name, torch.uint8)).sum()))
         own = split.strips[rank]
         q.put((rank, worst, pipe.ray_counts(), ref.ray_counts(), own))
         dist.barrier()
@@ -66,8 +79,10 @@ def _worker(rank, world, port, W, H, frames, packed, q):
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs ROCm's clang++ as the host compiler")
-@pytest.mark.parametrize("world,packed", [(2, False), (3, True)])
-def test_strip_split_over_gloo_processes_with_the_real_kernels(world, packed):
+@pytest.mark.parametrize("world,packed,with_ircache", [(2, False, False), (3, True, False), (2, False, True)])
+def test_strip_split_over_gloo_processes_with_the_real_kernels(world, packed, with_ircache):
+    """with_ircache: the irradiance cache bound on every rank; the strips' recorded cache updates travel through DistComm.all_gather_rows
+    and every replica must stay bit-identical to the single-GPU cache."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "hip_emu"))
     env_before = os.environ.get("KJ_HIP_EMU")
     os.environ["KJ_HIP_EMU"] = "fast"
@@ -83,7 +98,7 @@ def test_strip_split_over_gloo_processes_with_the_real_kernels(world, packed):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, frames, packed, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, frames, packed, q, with_ircache)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=900) for _ in range(world)]
