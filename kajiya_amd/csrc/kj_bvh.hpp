@@ -86,12 +86,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 KJ_D float q8(uint32_t packed, int i) { return float((packed >> (8 * i)) & 0xffu); }   // v_cvt_f32_ubyte<i>
 
 #define KJ_BVH_NONE 0xffffffffu
-// pointer to the LDS copy of the small tables (bvh_stage_tables). Kept generic: the traversal stack already mixes LDS and private
-// memory behind one pointer type, so these are flat accesses that resolve to LDS (typed LDS pointers measured more instructions, not fewer)
-typedef const uint32_t* LdsTablePtr;
-typedef const float4* LdsF4Ptr;
-typedef const uint4* LdsU4Ptr;
-typedef const uint2* LdsU2Ptr;
 #if KJ_BVH_WIDTH != 4
 #error "the traversal is written for the 4-wide node (an 8-wide variant measured 24 % slower in round 1 and was dropped)"
 #endif
@@ -106,7 +100,6 @@ struct RayState {
     uint32_t tri_base;  // first world triangle of the instance being walked; KJ_BVH_NONE while in the TLAS
     float pad;          // slack around this instance's BLAS boxes
     bool cull_back;
-    LdsTablePtr tables;       // LDS copy of {TLAS nodes, instance records} (bvh_stage_tables), or null: read them from memory
 };
 // reciprocal direction for the slab tests (v_rcp_f32: the boxes are conservative by several ulps, the triangles never see this)
 KJ_D float rcp_box(float x) {
@@ -127,7 +120,7 @@ KJ_D void ray_begin(RayState& S, V3 o, V3 d, float tmin, float tmax, bool cull_b
     S.wo = o; S.wd = d; S.tmin = tmin; S.tmax = tmax; S.cull_back = cull_back;
     S.h.t = FLT_MAX; S.h.u = 0; S.h.v = 0; S.h.slot = 0xffffffffu; S.h.world_id = 0xffffffffu;
     S.sp = 0;
-    S.tri_base = KJ_BVH_NONE; S.pad = 0.0f; S.tables = nullptr;
+    S.tri_base = KJ_BVH_NONE; S.pad = 0.0f;
     // Rays with a non-finite origin or direction are misses (the reference's validation pass issues such
     // rays for pixels without history; a hardware traversal unit rejects every box for them). Without
     // this, NaN slabs pass the fmin/fmax test and the whole tree is walked.
@@ -152,24 +145,6 @@ KJ_D void pop_next(RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spil
     }
 }
 #define KJ_POP(dst_) pop_next(S, stack, stride, spill);
-// S.cur is a TLAS leaf: take the ray into that instance's BLAS
-KJ_D void enter_instance(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill) {
-    const uint32_t slot = S.cur & 0x0fffffffu;
-    float4 r0, r1, r2; uint4 m;
-    if (S.tables) {     // the instance table is staged in LDS: no round trip to L2 before the BLAS root can be fetched
-        LdsF4Ptr r = (LdsF4Ptr)S.tables + (bvh.tlas_node_count + slot) * 4u;
-        r0 = r[0]; r1 = r[1]; r2 = r[2]; m = *(LdsU4Ptr)(r + 3);
-    } else {
-        const float4* __restrict__ r = (const float4*)(bvh.instances + slot);
-        r0 = r[0]; r1 = r[1]; r2 = r[2]; m = *(const uint4*)(r + 3);
-    }
-    KJ_PUSH(KJ_BVH_SENTINEL)
-    const V3 o = S.wo, d = S.wd;
-    S.bo = V3{r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w, r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w, r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w};
-    S.binv = safe_rcp3(V3{r0.x * d.x + r0.y * d.y + r0.z * d.z, r1.x * d.x + r1.y * d.y + r1.z * d.z, r2.x * d.x + r2.y * d.y + r2.z * d.z});
-    S.cur = m.x; S.tri_base = m.y; S.pad = __uint_as_float(m.z);
-}
-
 // Visit the 4-wide node S.cur (or, from the TLAS, the root of the instance S.cur names): test its four quantised child boxes,
 // continue with the nearest hit child, push the others. A reference is a NODE-step reference when it is an inner node or a TLAS leaf.
 KJ_D bool wants_node_step(const RayState& S) { return S.cur != KJ_BVH_NONE && (!(S.cur & KJ_BVH_LEAF) || S.tri_base == KJ_BVH_NONE); }
@@ -177,16 +152,21 @@ KJ_D bool wants_tri_step(const RayState& S) { return S.cur != KJ_BVH_NONE && (S.
 template <bool ANY_HIT, bool STATS>
 KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
     const uint32_t NONE = KJ_BVH_NONE;
-    // a TLAS leaf is an instance: step into it and visit its BLAS root in this same step (a separate "enter" step would run for a
-    // handful of lanes in nearly every wave iteration: 64 lanes x a few instances per ray)
-    if (S.cur & KJ_BVH_LEAF) enter_instance(bvh, S, stack, stride, spill);
-    float4 n0; uint4 ch, qa; uint2 qb;           // qa = qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4]; qb = qhi.y[4], qhi.z[4]
-    if (S.tables && S.tri_base == KJ_BVH_NONE) { // TLAS node, staged in LDS
-        LdsF4Ptr n = (LdsF4Ptr)S.tables + S.cur * 4u;
-        n0 = n[0]; ch = *(LdsU4Ptr)(n + 1); qa = *(LdsU4Ptr)(n + 2); qb = *(LdsU2Ptr)(n + 3);
-    } else {
-        const float4* __restrict__ n = (const float4*)(S.tri_base == KJ_BVH_NONE ? bvh.tlas_nodes : bvh.blas_nodes) + size_t(S.cur) * 4;
-        n0 = n[0]; ch = *(const uint4*)(n + 1); qa = *(const uint4*)(n + 2); qb = *(const uint2*)(n + 3);
+    // A TLAS leaf is an instance: step into it and visit its BLAS root in this same step (a separate "enter" step would run for a
+    // handful of lanes in nearly every wave iteration: 64 lanes x a few instances per ray). The instance record carries a copy of that
+    // root node, so the lane's node fetch and its transform fetch go out together -- ONE memory round trip for the step, as for the
+    // lanes that stay inside a tree (fetching blas_nodes[record.node_root] after the record doubled the latency of nearly every step).
+    const bool entering = (S.cur & KJ_BVH_LEAF) != 0u;
+    const float4* __restrict__ rec = (const float4*)(bvh.instances + (S.cur & 0x0fffffffu));
+    const float4* __restrict__ n = entering ? rec + 4 : (const float4*)(S.tri_base == KJ_BVH_NONE ? bvh.tlas_nodes : bvh.blas_nodes) + size_t(S.cur) * 4;
+    const float4 n0 = n[0]; const uint4 ch = *(const uint4*)(n + 1), qa = *(const uint4*)(n + 2); const uint2 qb = *(const uint2*)(n + 3);
+    if (entering) {
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; const uint4 m = *(const uint4*)(rec + 3);
+        KJ_PUSH(KJ_BVH_SENTINEL)
+        const V3 o = S.wo, d = S.wd;
+        S.bo = V3{r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w, r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w, r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w};
+        S.binv = safe_rcp3(V3{r0.x * d.x + r0.y * d.y + r0.z * d.z, r1.x * d.x + r1.y * d.y + r1.z * d.z, r2.x * d.x + r2.y * d.y + r2.z * d.z});
+        S.tri_base = m.y; S.pad = __uint_as_float(m.z);
     }
     if (STATS) stats->nodes++;
     const V3 o = S.bo, inv_d = S.binv;
@@ -268,30 +248,6 @@ KJ_D void tri_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t st
     else KJ_POP(S.cur)
 }
 
-// Small scenes' TLAS nodes and instance records, copied into the workgroup's LDS behind the traversal stacks by the lanes that are in
-// the call (ballot + prefix count: the call may sit in divergent code). Every TLAS step and every instance entry of the trace that
-// follows is then an LDS read instead of a dependent L2 round trip -- the round trips the two-level structure added over a flattened
-// scene. Returns the copy (or nullptr: tables too large / the tests' CPU stand-in, where lanes run one at a time).
-KJ_D LdsTablePtr bvh_stage_tables(const BvhView& bvh, uint32_t* stack, uint32_t stride) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (bvh.lds_table_dwords == 0u) return nullptr;
-    const uint32_t lane = __lane_id() & 63u;
-    uint4* dst = (uint4*)((stack - lane) + KJ_BVH_LDS_STACK * stride);
-    const unsigned long long m = __ballot(true);
-    const uint32_t rank = uint32_t(__popcll(m & ((1ull << lane) - 1ull))), n_lanes = uint32_t(__popcll(m));
-    const uint32_t n_tlas = bvh.tlas_node_count * 4u, n_all = bvh.lds_table_dwords / 4u;
-    const uint4* __restrict__ a = (const uint4*)bvh.tlas_nodes;
-    const uint4* __restrict__ b = (const uint4*)bvh.instances;
-    for (uint32_t i = rank; i < n_all; i += n_lanes) dst[i] = i < n_tlas ? a[i] : b[i - n_tlas];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    return (LdsTablePtr)(uint32_t*)dst;
-#else
-    return nullptr;
-#endif
-}
-
 // One ray per lane, start to finish, inside a caller's kernel. The lanes of the wave that are in the call step together: each
 // wave step issues EITHER the node block or the triangle block, whichever more lanes are waiting for (triangle lanes count
 // double: their block is the cheaper one), instead of a mixed wave paying for both blocks in every iteration. Per-ray results do
@@ -300,7 +256,6 @@ template <bool ANY_HIT, bool STATS = false>
 KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bool cull_back, uint32_t* stack, uint32_t stride, TraverseStats* stats = nullptr) {
     RayState S;
     ray_begin<ANY_HIT>(S, o, d, tmin, tmax, cull_back);
-    S.tables = bvh_stage_tables(bvh, stack, stride);
     uint32_t spill[KJ_BVH_SPILL_STACK];
 #if defined(__HIP_DEVICE_COMPILE__)
     for (;;) {
@@ -350,8 +305,6 @@ KJ_D void bvh_trace_stream(const BvhView& bvh, const float4* __restrict__ rays, 
     const unsigned long long lane_bit = 1ull << lane;
     RayState S;
     S.cur = KJ_BVH_NONE; S.sp = 0; S.tri_base = KJ_BVH_NONE; S.pad = 0.0f;
-    LdsTablePtr tables = bvh_stage_tables(bvh, stack, stride);     // once per persistent wave
-    S.tables = tables;
     S.h.t = FLT_MAX; S.h.u = S.h.v = 0; S.h.slot = S.h.world_id = 0xffffffffu;
     uint32_t spill[KJ_BVH_SPILL_STACK];
     bool live = false;
@@ -375,7 +328,6 @@ KJ_D void bvh_trace_stream(const BvhView& bvh, const float4* __restrict__ rays, 
                 ray_index = cursor + rank;
                 const float4 a = rays[size_t(ray_index) * 2], b = rays[size_t(ray_index) * 2 + 1];
                 ray_begin<ANY_HIT>(S, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, a.w, b.w, cull_back);
-                S.tables = tables;
                 if (!(b.w >= 0.0f)) S.cur = KJ_BVH_NONE;     // "no ray here"
                 live = true;
             }

@@ -10,6 +10,9 @@ struct InstanceTriJob { float xform[12]; uint32_t src, dst, count, instance; };
 static_assert(sizeof(InstanceTriJob) == 64, "job size");
 hipError_t launch_instance_triangles(const BvhTri* obj_tris, BvhTri* world_tris, const InstanceTriJob* jobs, uint32_t job_count, hipStream_t s);
 
+// recs[i].root = blas_nodes[recs[i].node_root] for every instance record.
+hipError_t launch_instance_roots(InstanceRecord* recs, const Bvh4Node* blas_nodes, uint32_t count, hipStream_t s);
+
 // A mesh's BLAS built on the device as a linear BVH (lbvh_build.hip): nodes into d_nodes_out[0 .. node_count) with child node
 // indices offset by node_base, object-space triangles in leaf order into d_tris_out[0 .. index_count / 3). Synchronises the stream.
 struct LbvhResult { float bounds[6]; uint32_t node_count, max_stack; };

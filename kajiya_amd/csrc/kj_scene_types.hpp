@@ -62,14 +62,16 @@ static_assert(sizeof(BvhTri) == 48, "tri size");
 //   tris       : per live instance, its mesh's triangles in BLAS leaf order transformed to WORLD space (the same fp32 arithmetic as
 //                flattening the scene, so hits are those of a world-space scene): re-derived on the device when an instance moves;
 //   instances  : per instance slot, how to get from the TLAS into its BLAS.
-struct InstanceRecord {     // 64 B
+struct InstanceRecord {     // 128 B
     float w2o[12];          // world -> object, row-major 3x4
     uint32_t node_root;     // the mesh's BLAS root in blas_nodes
     uint32_t tri_base;      // the instance's first triangle in tris
     float pad;              // object-space slack added around every BLAS box (rounding of the ray transform and of the world-space vertices)
     uint32_t reserved;
+    Bvh4Node root;          // copy of blas_nodes[node_root] (filled on the device at commit): a ray entering the instance gets the transform
+                            // AND the first node to test from one address, i.e. in one memory round trip instead of two dependent ones
 };
-static_assert(sizeof(InstanceRecord) == 64, "instance record size");
+static_assert(sizeof(InstanceRecord) == 128, "instance record size");
 #define KJ_BVH_SENTINEL 0xfffffffeu   // traversal stack marker: "back to the TLAS"
 struct BvhView {
     const F4* tlas_nodes;    // 4 x 16 B per node; node 0 is the root
@@ -77,12 +79,9 @@ struct BvhView {
     const F4* tris;          // 3 x 16 B per tri
     const InstanceRecord* instances;
     uint32_t root;           // always 0 (kept for the C-ABI debug query)
-    uint32_t stack_entries;  // dynamic LDS a tracing kernel must provide, in units of 64 dwords: the KJ_BVH_LDS_STACK levels of the per-lane
-                             // stacks + (when lds_table_dwords != 0) room for a copy of the TLAS nodes and the instance records
+    uint32_t stack_entries;  // dynamic LDS a tracing kernel must provide, in units of 64 dwords: the KJ_BVH_LDS_STACK levels of the per-lane stacks
     uint32_t tlas_node_count, instance_count;
-    uint32_t lds_table_dwords;   // (tlas_node_count + instance_count) * 16 when that fits KJ_BVH_LDS_TABLE_MAX_BYTES, else 0: no copy, global reads
 };
-#define KJ_BVH_LDS_TABLE_MAX_BYTES 12288u
 
 // 32 B per material map. flags: bits 0-7 = mip count (0 => 1x1 placeholder, `color`), bit 8 = sRGB texels.
 struct MapDesc { F4 color; uint32_t offset, width, height, flags; };

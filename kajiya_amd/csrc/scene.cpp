@@ -45,12 +45,7 @@ SceneView scene_view(const KjScene& s) {
     v.bvh.root = s.bvh_root;
     v.bvh.tlas_node_count = s.tlas_node_count;
     v.bvh.instance_count = uint32_t(s.instances.size());
-    const uint32_t table_bytes = (v.bvh.tlas_node_count + v.bvh.instance_count) * 64u;
-    // opt-in (KJ_BVH_LDS_TABLES=1): measured SLOWER as staged today -- one cooperative copy per trace call, 9.6 KB of LDS per wave:
-    // 1889 / 2241 Mrays/s (one ray per lane / stream) against 2177 / 2669 without, no difference inside the frame
-    v.bvh.lds_table_dwords = (table_bytes <= KJ_BVH_LDS_TABLE_MAX_BYTES && getenv("KJ_BVH_LDS_TABLES")) ? table_bytes / 4u : 0u;
-    // LDS part of the traversal stack (deeper entries spill, kj_bvh.hpp) + the small scenes' TLAS / instance table copy
-    v.bvh.stack_entries = KJ_BVH_LDS_STACK + (v.bvh.lds_table_dwords + 63u) / 64u;
+    v.bvh.stack_entries = KJ_BVH_LDS_STACK;   // LDS part of the traversal stack (deeper entries spill, kj_bvh.hpp)
     return v;
 }
 
@@ -365,6 +360,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     // 4. per-commit tables
     KJ_TRY_HIP(s->d_instances.upload(ginst.data(), ginst.size() * sizeof(GpuInstance), stream));
     KJ_TRY_HIP(s->d_inst_records.upload(recs.data(), recs.size() * sizeof(InstanceRecord), stream));
+    KJ_TRY_HIP(launch_instance_roots((InstanceRecord*)s->d_inst_records.p, (const Bvh4Node*)s->d_blas_nodes.p, ni, stream));
     const uint32_t light_count = uint32_t(lights.size());
     if (lights.empty()) lights.push_back(KjTriangleLight{});     // keep the buffer non-empty
     KJ_TRY_HIP(s->d_lights.upload(lights.data(), lights.size() * sizeof(KjTriangleLight), stream));

@@ -31,7 +31,21 @@ __global__ void __launch_bounds__(256) k_instance_triangles(const BvhTri* __rest
     }
 }
 
+// Each instance record carries a copy of its mesh's BLAS root node (kj_scene_types.hpp): 4 lanes x 16 B per record.
+__global__ void __launch_bounds__(256) k_instance_roots(InstanceRecord* __restrict__ recs, const Bvh4Node* __restrict__ blas_nodes, uint32_t count) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, r = i >> 2, q = i & 3u;
+    if (r >= count) return;
+    const uint4* src = (const uint4*)(blas_nodes + recs[r].node_root);
+    ((uint4*)&recs[r].root)[q] = src[q];
+}
+
 namespace kj {
+
+hipError_t launch_instance_roots(InstanceRecord* recs, const Bvh4Node* blas_nodes, uint32_t count, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_instance_roots, dim3((count * 4 + 255) / 256), dim3(256), 0, s, recs, blas_nodes, count);
+    return hipGetLastError();
+}
 
 hipError_t launch_instance_triangles(const BvhTri* obj_tris, BvhTri* world_tris, const InstanceTriJob* jobs, uint32_t job_count, hipStream_t s) {
     if (job_count == 0) return hipSuccess;
