@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tris", type=int, default=1_000_000)
-    ap.add_argument("--scene", default="city", choices=["city", "ruins", "cornell"])
+    ap.add_argument("--scene", default="city", choices=["city", "ruins", "cornell", "pica"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=12)
     ap.add_argument("--no-ssgi", action="store_true", help="drive rtdgi with the constant SSAO guide instead of running SsgiRenderer each frame")
@@ -53,6 +53,8 @@ def make_scene(name, tris):
     if name == "ruins":
         return scenes.procedural_ruins(target_tris=tris, seed=5678), dict(center=(0.0, 3.0, 0.0), radius=34.0, height=5.0, rate=0.004), \
             f"procedural_ruins seed 5678 (~{tris} tris, Ruins stand-in)"
+    if name == "pica":     # the reference's own production asset (assets/scenes/pica.ron): 76 k triangles, one instance
+        return scenes.pica_diorama(), dict(center=(-0.4, 0.5, -0.6), radius=5.0, height=1.6, rate=0.01), "pica_pica mini diorama (assets/scenes/pica.ron geometry, material factors; no image maps)"
     return scenes.cornell_box(), dict(center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.01), "cornell_box"
 
 

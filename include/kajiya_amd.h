@@ -178,15 +178,16 @@ KjStatus kj_scene_add_instance(KjScene* scene, uint32_t mesh, const float transf
 KjStatus kj_scene_set_instance_transform(KjScene* scene, uint32_t instance, const float transform3x4[12]);
 KjStatus kj_scene_set_instance_emissive_multiplier(KjScene* scene, uint32_t instance, float v);
 KjStatus kj_scene_remove_instance(KjScene* scene, uint32_t instance);
-/* build_ray_tracing_top_level_acceleration + prepare_top_level_acceleration
- * (world_renderer.rs:836,865): builds the software LBVH over all instances
- * (replaces BLAS/TLAS) and uploads the scene tables. */
+/* build_ray_tracing_top_level_acceleration + prepare_top_level_acceleration (world_renderer.rs:836,865) and the BLAS builds of
+ * add_mesh (:694-724): builds the BLAS of every mesh added since the last commit, re-derives the world-space triangles and nodes of
+ * the instances that moved (on the device), rebuilds the tree over the instances and uploads the scene tables. Stream-ordered, but
+ * returns after the stream has drained. */
 KjStatus kj_scene_commit(KjScene* scene, void* stream);
 /* Number of world-space triangle lights after commit (frame_constants.triangle_light_count). */
 KjStatus kj_scene_triangle_light_count(KjScene* scene, uint32_t* out);
 KjStatus kj_scene_stats(KjScene* scene, uint32_t* out_tri_count, uint32_t* out_node_count, uint64_t* out_bvh_bytes);
-/* Host time of the last kj_scene_commit in ms: [0] BLAS builds of newly added meshes, [1] instance records + TLAS build,
- * [2] uploads + the device kernel that re-derives moved instances' world-space triangles (incl. the stream sync), [3] total.
+/* Host time of the last kj_scene_commit in ms: [0] BLAS builds of newly added meshes, [1] instance tables + top-tree build,
+ * [2] uploads + the device kernels that re-derive moved instances' world-space triangles and nodes (incl. the stream sync), [3] total.
  * The reference's counterpart is the GPU time of build_ray_tracing_top_level_acceleration (world_renderer.rs:836-911). */
 KjStatus kj_scene_last_commit_ms(KjScene* scene, double out_ms[4]);
 /* How the BLAS of meshes added FROM NOW ON is built at the next commit (vk::BuildAccelerationStructureFlagsKHR, ray_tracing.rs:438):

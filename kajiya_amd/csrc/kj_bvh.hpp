@@ -1,10 +1,11 @@
 // Software ray traversal for gfx950 — replaces VK_KHR_ray_tracing's TraceRay
 // (inc/rt.hlsl:58-70,112-137; BLAS/TLAS in kajiya-backend/src/vulkan/ray_tracing.rs).
 //
-// Two levels (kj_scene_types.hpp: BvhView): a TLAS over instances in world space, one BLAS per mesh in object space. Entering an
-// instance transforms the ray for the BOX tests only (origin and direction through world->object; t is preserved) and leaves a
-// sentinel on the stack; triangles are tested in world space against the instance's world-space copies, so (t, u, v) do not
-// depend on how the scene is partitioned into instances.
+// One tree in world space (kj_scene_types.hpp: BvhView): a top tree over the instances whose leaf children are the root nodes of the
+// instances' own trees -- each a copy of its mesh's BLAS refit around the instance's world-space triangles when the instance moves
+// (scene_device.hip). The walk therefore never transforms a ray or keeps per-instance state; (t, u, v) come from world-space
+// triangles and do not depend on how the scene is partitioned into instances. (A walk that descended into object-space BLASes
+// through per-instance ray transforms was built first and measured 22-28 % fewer rays/s: DESIGN 3.1.)
 // Node / triangle layout (bvh_build.cpp, resident in HBM / Infinity Cache):
 //   Bvh4Node 64 B : up to four children; each child's AABB is 6 bytes (8 bits per plane) inside the node's own
 //                   frame (origin + power-of-two step per axis). One visit = 3.5 x 16-B loads per lane and tests
@@ -90,15 +91,13 @@ KJ_D float q8(uint32_t packed, int i) { return float((packed >> (8 * i)) & 0xffu
 #error "the traversal is written for the 4-wide node (an 8-wide variant measured 24 % slower in round 1 and was dropped)"
 #endif
 
-// One ray in flight. `cur` is the reference about to be visited (a node, a leaf's next triangle, an instance, or KJ_BVH_NONE = finished).
+// One ray in flight. `cur` is the reference about to be visited (a node, a leaf's next triangle, or KJ_BVH_NONE = finished).
 struct RayState {
-    V3 wo, wd;          // the ray in world space (triangle tests)
-    V3 bo, binv;        // origin and reciprocal direction in the space of the boxes being walked: world in the TLAS, object space inside an instance
+    V3 wo, wd;          // the ray (world space, like every box and triangle of the tree)
+    V3 binv;            // reciprocal direction for the slab tests
     float tmin, tmax;
     RayHit h;
     uint32_t sp, cur;
-    uint32_t tri_base;  // first world triangle of the instance being walked; KJ_BVH_NONE while in the TLAS
-    float pad;          // slack around this instance's BLAS boxes
     bool cull_back;
 };
 // reciprocal direction for the slab tests (v_rcp_f32: the boxes are conservative by several ulps, the triangles never see this)
@@ -120,13 +119,11 @@ KJ_D void ray_begin(RayState& S, V3 o, V3 d, float tmin, float tmax, bool cull_b
     S.wo = o; S.wd = d; S.tmin = tmin; S.tmax = tmax; S.cull_back = cull_back;
     S.h.t = FLT_MAX; S.h.u = 0; S.h.v = 0; S.h.slot = 0xffffffffu; S.h.world_id = 0xffffffffu;
     S.sp = 0;
-    S.tri_base = KJ_BVH_NONE; S.pad = 0.0f;
     // Rays with a non-finite origin or direction are misses (the reference's validation pass issues such
     // rays for pixels without history; a hardware traversal unit rejects every box for them). Without
     // this, NaN slabs pass the fmin/fmax test and the whole tree is walked.
     const bool finite = fabsf(o.x) <= FLT_MAX && fabsf(o.y) <= FLT_MAX && fabsf(o.z) <= FLT_MAX && fabsf(d.x) <= FLT_MAX && fabsf(d.y) <= FLT_MAX && fabsf(d.z) <= FLT_MAX;
-    S.cur = finite ? 0u : KJ_BVH_NONE;   // TLAS node 0 is the root
-    S.bo = o;
+    S.cur = finite ? 0u : KJ_BVH_NONE;   // node 0 is the root
     S.binv = safe_rcp3(d);
 }
 
@@ -134,42 +131,23 @@ KJ_D void ray_begin(RayState& S, V3 o, V3 d, float tmin, float tmax, bool cull_b
 // private array (scratch). Near-first ordering keeps a typical ray's stack far below the builder's worst-case bound,
 // so the LDS footprint (4 KB / wave) does not cap occupancy the way a bound-sized LDS stack did (11 KB / wave).
 #define KJ_PUSH(v_) { const uint32_t pv_ = (v_); if (S.sp < KJ_BVH_LDS_STACK) stack[S.sp * stride] = pv_; else spill[S.sp - KJ_BVH_LDS_STACK] = pv_; S.sp++; }
-// next reference off the stack; the sentinel an instance left behind puts the ray back into the TLAS
+// next reference off the stack
 KJ_D void pop_next(RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill) {
-    for (;;) {
-        if (S.sp == 0) { S.cur = KJ_BVH_NONE; return; }
-        --S.sp;
-        const uint32_t v = S.sp < KJ_BVH_LDS_STACK ? stack[S.sp * stride] : spill[S.sp - KJ_BVH_LDS_STACK];
-        if (v != KJ_BVH_SENTINEL) { S.cur = v; return; }
-        S.bo = S.wo; S.binv = safe_rcp3(S.wd); S.tri_base = KJ_BVH_NONE; S.pad = 0.0f;
-    }
+    if (S.sp == 0) { S.cur = KJ_BVH_NONE; return; }
+    --S.sp;
+    S.cur = S.sp < KJ_BVH_LDS_STACK ? stack[S.sp * stride] : spill[S.sp - KJ_BVH_LDS_STACK];
 }
 #define KJ_POP(dst_) pop_next(S, stack, stride, spill);
-// Visit the 4-wide node S.cur (or, from the TLAS, the root of the instance S.cur names): test its four quantised child boxes,
-// continue with the nearest hit child, push the others. A reference is a NODE-step reference when it is an inner node or a TLAS leaf.
-KJ_D bool wants_node_step(const RayState& S) { return S.cur != KJ_BVH_NONE && (!(S.cur & KJ_BVH_LEAF) || S.tri_base == KJ_BVH_NONE); }
-KJ_D bool wants_tri_step(const RayState& S) { return S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF) && S.tri_base != KJ_BVH_NONE; }
+// Visit the 4-wide node S.cur: test its four quantised child boxes, continue with the nearest hit child, push the others.
+KJ_D bool wants_node_step(const RayState& S) { return S.cur != KJ_BVH_NONE && !(S.cur & KJ_BVH_LEAF); }
+KJ_D bool wants_tri_step(const RayState& S) { return S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF); }
 template <bool ANY_HIT, bool STATS>
 KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
     const uint32_t NONE = KJ_BVH_NONE;
-    // A TLAS leaf is an instance: step into it and visit its BLAS root in this same step (a separate "enter" step would run for a
-    // handful of lanes in nearly every wave iteration: 64 lanes x a few instances per ray). The instance record carries a copy of that
-    // root node, so the lane's node fetch and its transform fetch go out together -- ONE memory round trip for the step, as for the
-    // lanes that stay inside a tree (fetching blas_nodes[record.node_root] after the record doubled the latency of nearly every step).
-    const bool entering = (S.cur & KJ_BVH_LEAF) != 0u;
-    const float4* __restrict__ rec = (const float4*)(bvh.instances + (S.cur & 0x0fffffffu));
-    const float4* __restrict__ n = entering ? rec + 4 : (const float4*)(S.tri_base == KJ_BVH_NONE ? bvh.tlas_nodes : bvh.blas_nodes) + size_t(S.cur) * 4;
+    const float4* __restrict__ n = (const float4*)bvh.nodes + size_t(S.cur) * 4;
     const float4 n0 = n[0]; const uint4 ch = *(const uint4*)(n + 1), qa = *(const uint4*)(n + 2); const uint2 qb = *(const uint2*)(n + 3);
-    if (entering) {
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; const uint4 m = *(const uint4*)(rec + 3);
-        KJ_PUSH(KJ_BVH_SENTINEL)
-        const V3 o = S.wo, d = S.wd;
-        S.bo = V3{r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w, r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w, r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w};
-        S.binv = safe_rcp3(V3{r0.x * d.x + r0.y * d.y + r0.z * d.z, r1.x * d.x + r1.y * d.y + r1.z * d.z, r2.x * d.x + r2.y * d.y + r2.z * d.z});
-        S.tri_base = m.y; S.pad = __uint_as_float(m.z);
-    }
     if (STATS) stats->nodes++;
-    const V3 o = S.bo, inv_d = S.binv;
+    const V3 o = S.wo, inv_d = S.binv;
     const float tmin = S.tmin;
     const bool neg_x = inv_d.x < 0.0f, neg_y = inv_d.y < 0.0f, neg_z = inv_d.z < 0.0f;
     const float tlimit = ANY_HIT ? S.tmax : fminf(S.h.t, S.tmax);
@@ -183,11 +161,8 @@ KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
     const uint32_t nqx = neg_x ? qa.w : qa.x, fqx = neg_x ? qa.x : qa.w;
     const uint32_t nqy = neg_y ? qb.x : qa.y, fqy = neg_y ? qa.y : qb.x;
     const uint32_t nqz = neg_z ? qb.y : qa.z, fqz = neg_z ? qa.z : qb.y;
-    // near planes move out by the instance's slack, far planes too (0 in the TLAS, whose boxes are padded when built)
-    const float px = neg_x ? S.pad : -S.pad, py = neg_y ? S.pad : -S.pad, pz = neg_z ? S.pad : -S.pad;
-    const float bx0 = n0.x - o.x, by0 = n0.y - o.y, bz0 = n0.z - o.z;
-    const float bx = bx0 + px, by = by0 + py, bz = bz0 + pz;            // near
-    const float fx = bx0 - px, fy = by0 - py, fz = bz0 - pz;            // far
+    const float bx = n0.x - o.x, by = n0.y - o.y, bz = n0.z - o.z;
+    const float fx = bx, fy = by, fz = bz;
     uint32_t key[4];
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
@@ -235,9 +210,9 @@ KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
 // Test ONE triangle of the leaf S.cur; an occlusion ray that hits is finished.
 template <bool ANY_HIT, bool STATS>
 KJ_D void tri_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
-    const uint32_t first = S.cur & 0x0fffffffu;      // relative to the instance's triangles
+    const uint32_t first = S.cur & 0x0fffffffu;
     const uint32_t rest = (S.cur >> 28) & 7u;      // triangles left after this one
-    const uint32_t slot = S.tri_base + first;
+    const uint32_t slot = first;
     const float4* __restrict__ tp = (const float4*)bvh.tris + size_t(slot) * 3;
     const float4 a = tp[0], b = tp[1], c = tp[2];
     if (STATS) stats->tris++;
@@ -304,7 +279,7 @@ KJ_D void bvh_trace_stream(const BvhView& bvh, const float4* __restrict__ rays, 
     const uint32_t lane = __lane_id() & 63u;
     const unsigned long long lane_bit = 1ull << lane;
     RayState S;
-    S.cur = KJ_BVH_NONE; S.sp = 0; S.tri_base = KJ_BVH_NONE; S.pad = 0.0f;
+    S.cur = KJ_BVH_NONE; S.sp = 0;
     S.h.t = FLT_MAX; S.h.u = S.h.v = 0; S.h.slot = S.h.world_id = 0xffffffffu;
     uint32_t spill[KJ_BVH_SPILL_STACK];
     bool live = false;

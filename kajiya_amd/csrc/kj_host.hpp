@@ -80,8 +80,9 @@ struct KjScene {
     std::vector<Inst> instances;
     std::vector<kj::MapDesc> maps;      // one per material map
     std::vector<uint8_t> tex_data;      // RGBA8 mip chains of the image maps
-    // per-mesh acceleration structure (BLAS), built once: nodes + object-space triangles in leaf order, appended to the shared arrays
-    struct Blas { uint32_t node_base = 0, node_count = 0, tri_base = 0, tri_count = 0, max_stack = 1; float bounds[6] = {0, 0, 0, 0, 0, 0}; bool built = false; };
+    // per-mesh acceleration structure (BLAS), built once: node topology (+ parent links) and object-space triangles in leaf order, appended to the shared arrays
+    struct Blas { uint32_t node_base = 0, node_count = 0, tri_base = 0, tri_count = 0, max_stack = 1; float bounds[6] = {0, 0, 0, 0, 0, 0}; bool built = false;
+                  uint32_t root = 0, heights_base = 0, height_count = 0, wide_heights = 0; };   // root node (relative); the refit's bottom-up steps (kj_scene_device.hpp: InstanceRefitJob)
     std::vector<Blas> blas;                       // one per mesh
     uint32_t blas_nodes_used = 0, obj_tris_used = 0;   // fill of the two device pools every BLAS lives in (d_blas_nodes, d_obj_tris)
     uint32_t blas_build_mode = 0;                 // for meshes added from now on: 0 = SAH on the host (fast trace), 1 = LBVH on the device (fast build)
@@ -91,9 +92,14 @@ struct KjScene {
     std::vector<uint8_t> xform_dirty;             // per instance slot
     // committed device state
     bool committed = false;
-    kj::DevBuf d_vertex_buffer, d_meshes, d_instances, d_maps, d_tex_data, d_lights, d_blas_nodes, d_obj_tris, d_tlas_nodes, d_tris, d_inst_records, d_jobs;
+    kj::DevBuf d_vertex_buffer, d_meshes, d_instances, d_maps, d_tex_data, d_lights, d_blas_nodes, d_obj_tris, d_tris, d_jobs, d_refit_jobs;
+    kj::DevBuf d_nodes, d_node_boxes;               // the world-space tree (top tree + one region per instance), the refit's per-node scratch box
+    kj::DevBuf d_blas_steps;                        // per mesh: {first, end} node of every step of its instances' bottom-up refit
+    std::vector<uint32_t> blas_steps;               // host copy of d_blas_steps
+    std::vector<uint32_t> inst_node_base;         // per instance slot: first node of its region in d_nodes
+    uint32_t tlas_capacity = 0, world_nodes = 0;   // nodes reserved for the top tree at the front of d_nodes; nodes in use overall
     std::vector<uint32_t> inst_tri_base;          // per instance slot: first world triangle (valid for live instances after a commit)
     uint32_t light_count = 0, tri_count = 0, node_count = 0, tlas_node_count = 0, bvh_root = 0, bvh_max_depth = 0;
-    double last_commit_ms[4] = {0, 0, 0, 0};      // host time of the last commit: BLAS builds, instance records + TLAS, uploads + device transform, total
+    double last_commit_ms[4] = {0, 0, 0, 0};      // host time of the last commit: BLAS builds, instance tables + top tree, uploads + device transform / refit, total
     kj::SceneView view() const;
 };

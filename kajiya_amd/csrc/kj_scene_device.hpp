@@ -1,6 +1,7 @@
 // Device-side parts of the scene's acceleration structures (scene_device.hip), called from scene.cpp's commit.
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <vector>
 #include "kj_scene_types.hpp"
 
 namespace kj {
@@ -10,12 +11,21 @@ struct InstanceTriJob { float xform[12]; uint32_t src, dst, count, instance; };
 static_assert(sizeof(InstanceTriJob) == 64, "job size");
 hipError_t launch_instance_triangles(const BvhTri* obj_tris, BvhTri* world_tris, const InstanceTriJob* jobs, uint32_t job_count, hipStream_t s);
 
-// recs[i].root = blas_nodes[recs[i].node_root] for every instance record.
-hipError_t launch_instance_roots(InstanceRecord* recs, const Bvh4Node* blas_nodes, uint32_t count, hipStream_t s);
+// One instance's world-space tree: nodes[dst + i] = BLAS node blas_nodes[src + i] refit around world_tris[tri_base ..] (which must have
+// been derived already on the same stream), child references rebased to `dst` / `tri_base`.
+//   steps[heights + h]    : {first, end} node (relative) of the h-th step of the bottom-up order, h in [0, height_count): a step only reads
+//                           boxes that earlier steps wrote. Host-built BLASes are sorted by node height (0 = all children are leaves, the
+//                           root last); device-built ones are laid out by depth and walked deepest level first.
+//   wide_heights          : steps [0, wide_heights) get a launch of their own, the rest (each <= KJ_REFIT_TOP_NODES nodes) one workgroup
+//   boxes                 : 24 B per world node (scratch)
+#define KJ_REFIT_TOP_NODES 1024
+struct InstanceRefitJob { uint32_t src, dst, node_count, tri_base, heights, height_count, wide_heights, pad; };
+hipError_t launch_instance_refit(const Bvh4Node* blas_nodes, const uint2* steps, const BvhTri* world_tris, const InstanceRefitJob* jobs, uint32_t job_count,
+                                 uint32_t max_wide_heights, Bvh4Node* nodes, void* boxes, hipStream_t s);
 
 // A mesh's BLAS built on the device as a linear BVH (lbvh_build.hip): nodes into d_nodes_out[0 .. node_count) with child node
 // indices offset by node_base, object-space triangles in leaf order into d_tris_out[0 .. index_count / 3). Synchronises the stream.
-struct LbvhResult { float bounds[6]; uint32_t node_count, max_stack; };
+struct LbvhResult { float bounds[6]; uint32_t node_count, max_stack; std::vector<uint32_t> level_starts; };   // level d (0 = the root) = nodes [level_starts[d], level_starts[d + 1])
 hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, hipStream_t s);
 
 }  // namespace kj

@@ -54,33 +54,20 @@ static_assert(sizeof(BvhTri) == 48, "tri size");
 #define KJ_BVH_LDS_STACK 16u      // traversal stack entries kept in LDS per lane ...
 #define KJ_BVH_SPILL_STACK 112u   // ... deeper entries spill to private (scratch) memory; builds needing more are rejected
 
-// Two levels, as the reference's TLAS over per-mesh BLASes (kajiya-backend/src/vulkan/ray_tracing.rs:96-275):
-//   tlas_nodes : Bvh4Node tree over the live instances' world boxes, rebuilt at every kj_scene_commit; a leaf child is
-//                KJ_BVH_LEAF | instance slot;
-//   blas_nodes : every mesh's Bvh4Node tree in the mesh's OBJECT space, built once per mesh and shared by its instances (child
-//                node indices are absolute in this array; leaf triangle indices are relative to the instance's triangles);
-//   tris       : per live instance, its mesh's triangles in BLAS leaf order transformed to WORLD space (the same fp32 arithmetic as
-//                flattening the scene, so hits are those of a world-space scene): re-derived on the device when an instance moves;
-//   instances  : per instance slot, how to get from the TLAS into its BLAS.
-struct InstanceRecord {     // 128 B
-    float w2o[12];          // world -> object, row-major 3x4
-    uint32_t node_root;     // the mesh's BLAS root in blas_nodes
-    uint32_t tri_base;      // the instance's first triangle in tris
-    float pad;              // object-space slack added around every BLAS box (rounding of the ray transform and of the world-space vertices)
-    uint32_t reserved;
-    Bvh4Node root;          // copy of blas_nodes[node_root] (filled on the device at commit): a ray entering the instance gets the transform
-                            // AND the first node to test from one address, i.e. in one memory round trip instead of two dependent ones
-};
-static_assert(sizeof(InstanceRecord) == 128, "instance record size");
-#define KJ_BVH_SENTINEL 0xfffffffeu   // traversal stack marker: "back to the TLAS"
+// The reference's TLAS over per-mesh BLASes (kajiya-backend/src/vulkan/ray_tracing.rs:96-275), laid out so that a ray walks ONE tree in
+// world space -- no ray transform, no per-instance state in the traversal loop:
+//   * per MESH, built once: the BLAS topology (Bvh4Node tree over the mesh's object-space triangles, host SAH or device LBVH) and the
+//     triangles in leaf order, plus the nodes listed by height for the refit below.
+//   * per INSTANCE, re-derived on the device when the instance moves (scene_device.hip): its triangles in WORLD space (the same fp32
+//     arithmetic as flattening the scene, so hits are those of a world-space scene) and a copy of the mesh's tree whose boxes are refit
+//     bottom-up around those world-space triangles and re-quantised -- tight under rotation, unlike transformed object-space boxes.
+//   * per COMMIT: a small tree over the instances' world boxes (host), whose leaf children point straight at the instances' root nodes.
+// All of it lives in one node array: [0, tlas_capacity) the top tree (node 0 = root), then one region per instance.
 struct BvhView {
-    const F4* tlas_nodes;    // 4 x 16 B per node; node 0 is the root
-    const F4* blas_nodes;
+    const F4* nodes;         // 4 x 16 B per node; node 0 is the root
     const F4* tris;          // 3 x 16 B per tri
-    const InstanceRecord* instances;
     uint32_t root;           // always 0 (kept for the C-ABI debug query)
     uint32_t stack_entries;  // dynamic LDS a tracing kernel must provide, in units of 64 dwords: the KJ_BVH_LDS_STACK levels of the per-lane stacks
-    uint32_t tlas_node_count, instance_count;
 };
 
 // 32 B per material map. flags: bits 0-7 = mip count (0 => 1x1 placeholder, `color`), bit 8 = sRGB texels.

@@ -240,12 +240,14 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
     uint32_t in_count = 1;
     DevBuf* qin = &q0; DevBuf* qout = &q1;
     uint32_t host_counters[4] = {0, 1, 0, 0};
+    result->level_starts.assign({0u, 1u});       // a level's nodes are allocated while the level above is collapsed: each level is one contiguous run
     while (in_count) {
         hipLaunchKernelGGL(k_lbvh_collapse, dim3((in_count + 63) / 64), dim3(64), 0, s, int(n), (const uint2*)children.p, (const uint2*)range.p, (const Box6*)nbox.p, (const CollapseItem*)qin->p, in_count,
                            (CollapseItem*)qout->p, (uint32_t*)counters.p, d_nodes_out, node_base);
         KJ_LB(hipMemcpyAsync(host_counters, counters.p, 16, hipMemcpyDeviceToHost, s));
         KJ_LB(hipStreamSynchronize(s));
         in_count = host_counters[0];
+        if (host_counters[1] > result->level_starts.back()) result->level_starts.push_back(host_counters[1]);
         const uint32_t zero = 0;
         KJ_LB(hipMemcpyAsync(counters.p, &zero, 4, hipMemcpyHostToDevice, s));
         std::swap(qin, qout);

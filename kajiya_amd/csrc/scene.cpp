@@ -38,13 +38,9 @@ SceneView scene_view(const KjScene& s) {
     v.tex_data = (const uint8_t*)s.d_tex_data.p;
     v.lights = (const KjTriangleLight*)s.d_lights.p;
     v.light_count = s.light_count;
-    v.bvh.tlas_nodes = (const F4*)s.d_tlas_nodes.p;
-    v.bvh.blas_nodes = (const F4*)s.d_blas_nodes.p;
+    v.bvh.nodes = (const F4*)s.d_nodes.p;
     v.bvh.tris = (const F4*)s.d_tris.p;
-    v.bvh.instances = (const InstanceRecord*)s.d_inst_records.p;
     v.bvh.root = s.bvh_root;
-    v.bvh.tlas_node_count = s.tlas_node_count;
-    v.bvh.instance_count = uint32_t(s.instances.size());
     v.bvh.stack_entries = KJ_BVH_LDS_STACK;   // LDS part of the traversal stack (deeper entries spill, kj_bvh.hpp)
     return v;
 }
@@ -212,6 +208,45 @@ static void world_box(const float* x, const float* ob, float* wb) {
     }
 }
 
+// Reorders a BLAS (child indices absolute, root = nodes[0]) by node HEIGHT: 0 = all children are leaves, else 1 + the tallest inner
+// child -- the order the per-instance refit works in (scene_device.hip): a height only reads boxes of lower heights, i.e. of lower
+// indices. The root ends up LAST. starts[h] = first node of height h (starts.back() = count).
+static void blas_sort_by_height(std::vector<BvhNode>& nodes, uint32_t node_base, std::vector<uint32_t>& starts) {
+    const uint32_t count = uint32_t(nodes.size());
+    std::vector<uint32_t> bfs;
+    bfs.reserve(count);
+    bfs.push_back(0);
+    for (size_t q = 0; q < bfs.size(); ++q)
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t c = nodes[bfs[q]].child[i];
+            if (c != 0xffffffffu && !(c & KJ_BVH_LEAF)) bfs.push_back(c - node_base);
+        }
+    std::vector<uint32_t> height(count, 0);
+    uint32_t tallest = 0;
+    for (size_t q = bfs.size(); q-- > 0;) {     // children come after their parent in breadth-first order
+        uint32_t h = 0;
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t c = nodes[bfs[q]].child[i];
+            if (c != 0xffffffffu && !(c & KJ_BVH_LEAF)) h = std::max(h, height[c - node_base] + 1u);
+        }
+        height[bfs[q]] = h;
+        tallest = std::max(tallest, h);
+    }
+    starts.assign(tallest + 2, 0);
+    for (uint32_t n : bfs) starts[height[n] + 1]++;
+    for (uint32_t h = 0; h <= tallest; ++h) starts[h + 1] += starts[h];
+    std::vector<uint32_t> fill(starts.begin(), starts.end() - 1), new_index(count, 0);
+    for (uint32_t n : bfs) new_index[n] = fill[height[n]]++;
+    std::vector<BvhNode> sorted(bfs.size());     // (nodes unreachable from the root, if a builder left any, are dropped)
+    for (uint32_t n : bfs) {
+        BvhNode v = nodes[n];
+        for (int i = 0; i < 4; ++i)
+            if (v.child[i] != 0xffffffffu && !(v.child[i] & KJ_BVH_LEAF)) v.child[i] = node_base + new_index[v.child[i] - node_base];
+        sorted[new_index[n]] = v;
+    }
+    nodes.swap(sorted);
+}
+
 KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     KJ_REQUIRE(s, "null scene");
     hipStream_t stream = (hipStream_t)stream_;
@@ -244,6 +279,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         const GpuMesh& m = s->meshes[mi];
         const uint32_t ntri = m.index_count / 3;
         bl.node_base = s->blas_nodes_used; bl.tri_base = s->obj_tris_used; bl.tri_count = ntri;
+        std::vector<uint32_t> steps;          // {first, end} node of every step of the refit's bottom-up order
         if (s->mesh_build_mode[mi] == 1) {   // LBVH on the device, straight into the pools (at most one node per triangle)
             KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), size_t(s->blas_nodes_used + ntri + 1) * sizeof(BvhNode)));
             KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), size_t(s->obj_tris_used + ntri) * sizeof(BvhTri)));
@@ -251,6 +287,9 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
             KJ_TRY_HIP(build_blas_lbvh_device((const uint8_t*)s->d_vertex_buffer.p, m, bl.node_base, (Bvh4Node*)s->d_blas_nodes.p + bl.node_base, (BvhTri*)s->d_obj_tris.p + bl.tri_base, &lr, stream));
             bl.node_count = lr.node_count; bl.max_stack = lr.max_stack;
             memcpy(bl.bounds, lr.bounds, 24);
+            // laid out by depth on the device: the refit walks the levels deepest first, the root is node 0
+            for (size_t d = lr.level_starts.size() - 1; d-- > 0;) { steps.push_back(lr.level_starts[d]); steps.push_back(lr.level_starts[d + 1]); }
+            bl.root = 0;
         } else {                              // binned SAH on the host
             std::vector<BvhTri> ot(ntri);
             for (uint32_t p = 0; p < ntri; ++p) {
@@ -276,35 +315,51 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
                     if (n.child[i] != 0xffffffffu && !(n.child[i] & KJ_BVH_LEAF)) n.child[i] += bl.node_base;
             KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), size_t(s->blas_nodes_used + bl.node_count) * sizeof(BvhNode)));
             KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), size_t(s->obj_tris_used + ntri) * sizeof(BvhTri)));
-            KJ_TRY_HIP(hipMemcpyAsync((BvhNode*)s->d_blas_nodes.p + bl.node_base, b.nodes.data(), b.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, stream));
             KJ_TRY_HIP(hipMemcpyAsync((BvhTri*)s->d_obj_tris.p + bl.tri_base, b.tris.data(), b.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice, stream));
+            // nodes sorted by height (what the refit of this mesh's instances walks), then into the pool
+            std::vector<uint32_t> starts;
+            blas_sort_by_height(b.nodes, bl.node_base, starts);
+            bl.node_count = uint32_t(b.nodes.size());
+            bl.root = bl.node_count - 1u;
+            for (size_t h = 0; h + 1 < starts.size(); ++h) { steps.push_back(starts[h]); steps.push_back(starts[h + 1]); }
+            KJ_TRY_HIP(hipMemcpyAsync((BvhNode*)s->d_blas_nodes.p + bl.node_base, b.nodes.data(), b.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, stream));
             KJ_TRY_HIP(hipStreamSynchronize(stream));    // b goes out of scope
+        }
+        bl.heights_base = uint32_t(s->blas_steps.size() / 2);
+        bl.height_count = uint32_t(steps.size() / 2);
+        bl.wide_heights = bl.height_count;     // steps [0, wide) get a launch of their own: up to the last one too populous for one workgroup
+        while (bl.wide_heights > 0 && steps[2 * bl.wide_heights - 1] - steps[2 * bl.wide_heights - 2] <= KJ_REFIT_TOP_NODES) --bl.wide_heights;
+        s->blas_steps.insert(s->blas_steps.end(), steps.begin(), steps.end());
+        if (getenv("KJ_SCENE_DEBUG")) {
+            fprintf(stderr, "[kj] mesh %u: %u tris, %u nodes, %u refit steps (%u wide):", mi, ntri, bl.node_count, bl.height_count, bl.wide_heights);
+            for (size_t h = 0; h < steps.size(); h += 2) fprintf(stderr, " %u", steps[h + 1] - steps[h]);
+            fprintf(stderr, "\n");
         }
         s->blas_nodes_used += bl.node_count;
         s->obj_tris_used += ntri;
         bl.built = true;
     }
+    if (s->meshes_dirty) KJ_TRY_HIP(s->d_blas_steps.upload(s->blas_steps.data(), s->blas_steps.size() * 4, stream));
     s->last_commit_ms[0] = ms_since(t0);
     const auto t1 = Clock::now();
-    // 2. instances: world-triangle ranges (numbered over the live instances in slot order, like a flattened scene), records, world boxes
+    // 2. instances: world-triangle and world-node ranges (numbered over the live instances in slot order, like a flattened scene), world boxes
     const uint32_t ni = uint32_t(s->instances.size());
     std::vector<GpuInstance> ginst(ni);
-    std::vector<InstanceRecord> recs(ni);
     std::vector<BvhTri> tlas_prims;
     std::vector<KjTriangleLight> lights;
-    std::vector<uint32_t> tri_base(ni, 0);
-    uint32_t total_tris = 0, max_blas_stack = 1;
+    std::vector<uint32_t> tri_base(ni, 0), node_base(ni, 0);
+    const uint32_t tlas_capacity = std::max(1u, ni);     // a 4-wide tree over n single-instance leaves has fewer than n nodes
+    uint32_t total_tris = 0, total_nodes = tlas_capacity, max_blas_stack = 1;
     for (uint32_t ii = 0; ii < ni; ++ii) {
         const KjScene::Inst& inst = s->instances[ii];
         GpuInstance& g = ginst[ii];
         memcpy(g.xform, inst.xform, 48);
         g.mesh = inst.mesh; g.emissive_multiplier = inst.emissive_multiplier; g.pad0 = g.pad1 = 0;
-        memset(&recs[ii], 0, sizeof(InstanceRecord));
         if (!inst.alive) continue;
         const KjScene::Blas& bl = s->blas[inst.mesh];
         const float* x = inst.xform;
-        tri_base[ii] = total_tris;
-        total_tris += bl.tri_count;
+        tri_base[ii] = total_tris; node_base[ii] = total_nodes;
+        total_tris += bl.tri_count; total_nodes += bl.node_count;
         max_blas_stack = std::max(max_blas_stack, bl.max_stack);
         // world -> object: inverse of the upper 3x3 in double, then the translation
         const double a[9] = {x[0], x[1], x[2], x[4], x[5], x[6], x[8], x[9], x[10]};
@@ -314,25 +369,13 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         float max_abs = 0.0f;
         for (int k = 0; k < 6; ++k) max_abs = std::max(max_abs, std::fabs(wb[k]));
         const float pad_world = 16.0f * FLT_EPSILON * std::max(max_abs, 1e-3f);
-        InstanceRecord& r = recs[ii];
-        r.node_root = bl.node_base; r.tri_base = tri_base[ii];
         if (std::fabs(det) > 1e-30) {
-            const double id = 1.0 / det;
-            const double inv[9] = {(a[4] * a[8] - a[5] * a[7]) * id, (a[2] * a[7] - a[1] * a[8]) * id, (a[1] * a[5] - a[2] * a[4]) * id,
-                                   (a[5] * a[6] - a[3] * a[8]) * id, (a[0] * a[8] - a[2] * a[6]) * id, (a[2] * a[3] - a[0] * a[5]) * id,
-                                   (a[3] * a[7] - a[4] * a[6]) * id, (a[1] * a[6] - a[0] * a[7]) * id, (a[0] * a[4] - a[1] * a[3]) * id};
-            double row_norm = 0.0;
-            for (int rr = 0; rr < 3; ++rr) {
-                for (int c = 0; c < 3; ++c) r.w2o[rr * 4 + c] = float(inv[rr * 3 + c]);
-                r.w2o[rr * 4 + 3] = float(-(inv[rr * 3] * x[3] + inv[rr * 3 + 1] * x[7] + inv[rr * 3 + 2] * x[11]));
-                row_norm = std::max(row_norm, std::fabs(inv[rr * 3]) + std::fabs(inv[rr * 3 + 1]) + std::fabs(inv[rr * 3 + 2]));
-            }
-            r.pad = float(double(pad_world) * row_norm * 2.0);
-            BvhTri t{};   // the instance's (padded) world box as the TLAS builder's primitive
+            BvhTri t{};   // the instance's (padded) world box as the top tree's primitive: it encloses the refit root, whose triangles are
+                          // the transformed vertices -- all inside the transformed corners' box up to rounding, which the pad covers
             for (int k = 0; k < 3; ++k) { t.v0[k] = t.v2[k] = wb[k] - pad_world; t.v1[k] = wb[3 + k] + pad_world; }
             t.prim = ii;
             tlas_prims.push_back(t);
-        }   // a singular transform flattens the mesh to zero volume: nothing to hit, the instance stays out of the TLAS
+        }   // a singular transform flattens the mesh to zero volume: nothing to hit, the instance stays out of the top tree
         auto xf_point = [&](const float* p, float* o) {
             o[0] = x[0] * p[0] + x[1] * p[1] + x[2] * p[2] + x[3];
             o[1] = x[4] * p[0] + x[5] * p[1] + x[6] * p[2] + x[7];
@@ -347,28 +390,42 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     }
     KJ_REQUIRE(total_tris > 0, "scene has no triangles");
     KJ_REQUIRE(total_tris < (1u << 28), "too many triangles for 28-bit leaf references");
-    // 3. TLAS over the live instances (one instance per leaf)
+    // 3. top tree over the live instances (one instance per leaf): a leaf child becomes a reference to that instance's root NODE
     BuiltBvh tl;
-    if (tlas_prims.empty()) { BvhTri t{}; t.v0[0] = t.v0[1] = t.v0[2] = t.v2[0] = t.v2[1] = t.v2[2] = 1e30f; t.v1[0] = t.v1[1] = t.v1[2] = 1e30f; tlas_prims.push_back(t); }
-    build_bvh4(tlas_prims, tl, 1);
-    for (BvhNode& n : tl.nodes)
-        for (int i = 0; i < 4; ++i)
-            if (n.child[i] != 0xffffffffu && (n.child[i] & KJ_BVH_LEAF)) n.child[i] = KJ_BVH_LEAF | tl.tris[n.child[i] & 0x0fffffffu].prim;
-    KJ_REQUIRE(tl.max_stack + 1 + max_blas_stack + 1 <= KJ_BVH_LDS_STACK + KJ_BVH_SPILL_STACK, "BVH too deep for the traversal stack");
+    if (tlas_prims.empty()) {     // nothing to hit: a root with four empty children
+        BvhNode n;
+        memset(&n, 0, sizeof(n));
+        for (int i = 0; i < 4; ++i) { n.child[i] = 0xffffffffu; for (int k = 0; k < 3; ++k) { n.qlo[k][i] = 255; n.qhi[k][i] = 0; } }
+        for (int k = 0; k < 3; ++k) n.exp8[k] = 127;
+        tl.nodes.push_back(n);
+        tl.max_stack = 1;
+    } else {
+        build_bvh4(tlas_prims, tl, 1);
+        for (BvhNode& n : tl.nodes)
+            for (int i = 0; i < 4; ++i)
+                if (n.child[i] != 0xffffffffu && (n.child[i] & KJ_BVH_LEAF)) { const uint32_t ii = tl.tris[n.child[i] & 0x0fffffffu].prim; n.child[i] = node_base[ii] + s->blas[s->instances[ii].mesh].root; }
+    }
+    KJ_REQUIRE(tl.nodes.size() <= tlas_capacity, "top tree larger than its reservation");
+    KJ_REQUIRE(tl.max_stack + 1 + max_blas_stack <= KJ_BVH_LDS_STACK + KJ_BVH_SPILL_STACK, "BVH too deep for the traversal stack");
     s->last_commit_ms[1] = ms_since(t1);
     const auto t2 = Clock::now();
     // 4. per-commit tables
     KJ_TRY_HIP(s->d_instances.upload(ginst.data(), ginst.size() * sizeof(GpuInstance), stream));
-    KJ_TRY_HIP(s->d_inst_records.upload(recs.data(), recs.size() * sizeof(InstanceRecord), stream));
-    KJ_TRY_HIP(launch_instance_roots((InstanceRecord*)s->d_inst_records.p, (const Bvh4Node*)s->d_blas_nodes.p, ni, stream));
     const uint32_t light_count = uint32_t(lights.size());
     if (lights.empty()) lights.push_back(KjTriangleLight{});     // keep the buffer non-empty
     KJ_TRY_HIP(s->d_lights.upload(lights.data(), lights.size() * sizeof(KjTriangleLight), stream));
-    KJ_TRY_HIP(s->d_tlas_nodes.upload(tl.nodes.data(), tl.nodes.size() * sizeof(BvhNode), stream));
-    // 5. world-space triangles: all instances when the set (hence the numbering) changed, else the moved ones -- on the device
-    const bool all = s->instance_set_dirty || s->meshes_dirty || s->d_tris.bytes != size_t(total_tris) * sizeof(BvhTri);
+    // 5. world-space triangles and nodes: all instances when the set (hence the numbering) changed, else the moved ones -- on the device
+    const bool relayout = s->d_tris.bytes != size_t(total_tris) * sizeof(BvhTri) || s->world_nodes != total_nodes || s->tlas_capacity != tlas_capacity;
+    const bool all = s->instance_set_dirty || s->meshes_dirty || relayout;
     if (s->d_tris.bytes != size_t(total_tris) * sizeof(BvhTri)) KJ_TRY_HIP(s->d_tris.alloc(size_t(total_tris) * sizeof(BvhTri), stream));
+    if (s->d_nodes.bytes != size_t(total_nodes) * sizeof(BvhNode)) {
+        KJ_TRY_HIP(s->d_nodes.alloc(size_t(total_nodes) * sizeof(BvhNode), stream));
+        KJ_TRY_HIP(s->d_node_boxes.alloc(size_t(total_nodes) * 24, stream));
+    }
+    KJ_TRY_HIP(hipMemcpyAsync(s->d_nodes.p, tl.nodes.data(), tl.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, stream));
     std::vector<InstanceTriJob> jobs;
+    std::vector<InstanceRefitJob> refits;
+    uint32_t max_wide = 0;
     for (uint32_t ii = 0; ii < ni; ++ii) {
         const KjScene::Inst& inst = s->instances[ii];
         if (!inst.alive || !(all || s->xform_dirty[ii])) continue;
@@ -377,15 +434,22 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         memcpy(j.xform, inst.xform, 48);
         j.src = bl.tri_base; j.dst = tri_base[ii]; j.count = bl.tri_count; j.instance = ii;
         jobs.push_back(j);
+        refits.push_back(InstanceRefitJob{bl.node_base, node_base[ii], bl.node_count, tri_base[ii], bl.heights_base, bl.height_count, bl.wide_heights, 0});
+        max_wide = std::max(max_wide, bl.wide_heights);
     }
     if (!jobs.empty()) {
         KJ_TRY_HIP(s->d_jobs.upload(jobs.data(), jobs.size() * sizeof(InstanceTriJob), stream));
+        KJ_TRY_HIP(s->d_refit_jobs.upload(refits.data(), refits.size() * sizeof(InstanceRefitJob), stream));
         KJ_TRY_HIP(launch_instance_triangles((const BvhTri*)s->d_obj_tris.p, (BvhTri*)s->d_tris.p, (const InstanceTriJob*)s->d_jobs.p, uint32_t(jobs.size()), stream));
+        KJ_TRY_HIP(launch_instance_refit((const Bvh4Node*)s->d_blas_nodes.p, (const uint2*)s->d_blas_steps.p, (const BvhTri*)s->d_tris.p,
+                                         (const InstanceRefitJob*)s->d_refit_jobs.p, uint32_t(refits.size()), max_wide, (Bvh4Node*)s->d_nodes.p, s->d_node_boxes.p, stream));
     }
     KJ_TRY_HIP(hipStreamSynchronize(stream));  // host vectors go out of scope
     s->inst_tri_base = tri_base;
+    s->inst_node_base = node_base;
     s->tri_count = total_tris;
-    s->node_count = uint32_t(s->blas_nodes_used + tl.nodes.size());
+    s->node_count = total_nodes;
+    s->world_nodes = total_nodes; s->tlas_capacity = tlas_capacity;
     s->tlas_node_count = uint32_t(tl.nodes.size());
     s->bvh_root = 0;
     s->bvh_max_depth = tl.max_stack + 1 + max_blas_stack;
