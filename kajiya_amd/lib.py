@@ -49,6 +49,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise KjError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(kajiya_amd has no CPU fallback)")
+    try:      # torch brings its own HIP runtime: it has to be in the process first so that this library binds to the same one (loaded the
+        import torch  # noqa: F401  # other way round, the second runtime finds no device: `hipGetDeviceCount -> no ROCm-capable device`)
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
     L.kj_last_error.restype = C.c_char_p
