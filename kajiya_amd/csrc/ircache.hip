@@ -151,6 +151,7 @@ struct IrcTraceCtx {
     const float4* __restrict__ sun_color;
     unsigned long long* __restrict__ ray_counters;
     uint32_t request_slot_base;      // first slot of the cache's own passes in IrcacheView::requests (deferred updates)
+    uint32_t lanes;                  // work items per wave (<= 64): see kj_ircache_trace_irradiance
 };
 KJ_D void irc_count_rays(unsigned long long* counters, int which) {
     const unsigned long long m = __ballot(true);
@@ -161,7 +162,8 @@ __global__ void __launch_bounds__(64) k_irc_trace_accessibility(IrcTraceCtx c) {
     extern __shared__ uint32_t lds_stack[];
     const IrcacheView& ic = c.ic;
     const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_OCTA_DIMS2;
-    for (uint32_t d = blockIdx.x * 64u + threadIdx.x; d < total; d += gridDim.x * 64u) {
+    if (threadIdx.x >= c.lanes) return;
+    for (uint32_t d = blockIdx.x * c.lanes + threadIdx.x; d < total; d += gridDim.x * c.lanes) {
         const uint32_t entry_idx = ic.entry_indirection[d / IRC_OCTA_DIMS2];
         const uint32_t octa_idx = d % IRC_OCTA_DIMS2;
         if (!irc_life_valid(ic.life[entry_idx])) continue;
@@ -243,7 +245,8 @@ __global__ void __launch_bounds__(64) k_irc_validate(IrcTraceCtx c) {
     const IrcacheView& ic = c.ic;
     const FrameConstants& fc = *c.fc;
     const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_VALIDATION_SAMPLES_PER_FRAME;
-    for (uint32_t d = blockIdx.x * 64u + threadIdx.x; d < total; d += gridDim.x * 64u) {
+    if (threadIdx.x >= c.lanes) return;
+    for (uint32_t d = blockIdx.x * c.lanes + threadIdx.x; d < total; d += gridDim.x * c.lanes) {
         const uint32_t entry_idx = ic.entry_indirection[d / IRC_VALIDATION_SAMPLES_PER_FRAME];
         const uint32_t sample_idx = d % IRC_VALIDATION_SAMPLES_PER_FRAME;
         const uint32_t life = ic.life[entry_idx];
@@ -276,7 +279,8 @@ __global__ void __launch_bounds__(64) k_irc_trace_irradiance(IrcTraceCtx c) {
     const IrcacheView& ic = c.ic;
     const FrameConstants& fc = *c.fc;
     const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME;
-    for (uint32_t d = blockIdx.x * 64u + threadIdx.x; d < total; d += gridDim.x * 64u) {
+    if (threadIdx.x >= c.lanes) return;
+    for (uint32_t d = blockIdx.x * c.lanes + threadIdx.x; d < total; d += gridDim.x * c.lanes) {
         const uint32_t entry_idx = ic.entry_indirection[d / IRC_SAMPLES_PER_FRAME];
         const uint32_t sample_idx = d % IRC_SAMPLES_PER_FRAME;
         const uint32_t life = ic.life[entry_idx];
@@ -597,7 +601,13 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     tc.request_slot_base = 2u * c->req_half_pixels;
     const size_t lds = size_t(tc.sc.bvh.stack_entries) * 64 * 4;
     KJ_REQUIRE(lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");
-    const uint32_t grid = c->dev->num_cus * 8;
+    // The cache's ray passes are small (a few thousand entries x 4 paths: ~125 full waves on 1024 SIMDs) and each path is a chain of
+    // ~150 dependent fetches, so a pass takes as long as its slowest WAVE: the union of 64 divergent paths' steps, each step waiting for
+    // the slowest of 64 scattered loads. Spread thin instead -- `lanes` paths per wave, the other lanes idle: more waves than the
+    // machine has SIMDs either way, but each wave's step count is the maximum over fewer paths and its loads return sooner.
+    static const uint32_t lanes_env = getenv("KJ_IRC_LANES") ? uint32_t(atoi(getenv("KJ_IRC_LANES"))) : 0u;
+    tc.lanes = lanes_env >= 1u && lanes_env <= 64u ? lanes_env : 8u;
+    const uint32_t grid = c->dev->num_cus * 32;
     KJ_TRY_HIP(hipMemsetAsync(c->ray_counters.p, 0, KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8, s));
     hipLaunchKernelGGL(k_irc_prepare_trace, dim3(1), dim3(1), 0, s, (uint32_t*)c->meta.p);
     KJ_CHECK_LAUNCH();

@@ -932,7 +932,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_REQUIRE(p->row_begin % 16 == 0 && (p->row_end % 16 == 0 || int(p->row_end) == H) && int(p->row_end) <= H, "row range must be 16-aligned (8x8 half-res tiles)");
         fr0 = int(p->row_begin); fr1 = int(p->row_end);
     }
-    if (p->ircache) KJ_REQUIRE(!p->ircache->pending_irradiance_sum, "ircache sum-up pending (ircache.rs:67 assert)");
+    if (p->ircache && (mask & (KJ_RTDGI_PASS_VALIDATE | KJ_RTDGI_PASS_TRACE))) KJ_REQUIRE(!p->ircache->pending_irradiance_sum, "ircache sum-up pending (ircache.rs:67 assert)");   // the passes that look the cache up
     KJ_REQUIRE(size_t(scene_view(*p->scene).bvh.stack_entries) * 64 * 4 <= 64 * 1024, "BVH too deep for the LDS traversal stack");
     // every argument check is above: from here on the ping-pong state may change (an early return after this point would leave
     // output and history swapped for the next call)

@@ -399,16 +399,20 @@ class GpuPipeline:
             self._s2 = torch.cuda.Stream()
             self._ev_gi = [torch.cuda.Event(), torch.cuda.Event()]
             self._ev_taa = [torch.cuda.Event(), torch.cuda.Event()]
+        # everything that does not read the cache goes first: the wait for the cache stream sits in the frame-to-frame critical
+        # cycle (this frame's ray passes -> next frame's cache rays -> next frame's ray passes); measured -1.6 % per frame
+        s0.wait_event(self._ev_fc[i])
         if run_ssgi:
-            s0.wait_event(self._ev_fc[i])
             self.ssgi_frame()
-        s0.wait_event(self._ev_irc[i])
         s = _stream_ptr()
         P = KJ_RTDGI_PASS
         check(self.L.kj_rtdgi_reproject(self.rtdgi, self.reprojection_map_ptr, self.W, self.H, s))
+        p = self.params(P["EXTRACT_HALF"])
+        check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+        s0.wait_event(self._ev_irc[i])
         check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
         head = P["EXTRACT_HALF"] | P["VALIDATE"] | P["TRACE"]
-        p = self.params(head)
+        p = self.params(P["VALIDATE"] | P["TRACE"] | (1 << 31))
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
         self._ev_trace[i].record(s0)
         if self._pipe_i > 0:

@@ -63,8 +63,10 @@ def taa_per_frame_parity(gpu, oracle, device, scene_name, W, H, n_frames=8):
             # texels) the quotient is ill-conditioned in the reference itself, so for this image up to 1 % of the texels may be outliers
             # (at most 5e-4 off in absolute terms at 1080p); the image as a whole still has to meet 1e-3. input_prob.hlsl:77-100 divides the
             # squared colour difference by a variance formed as E[x^2] - E[x]^2 of fp16 inputs (1e-6 floor) inside exp2(): the same
-            # allowance there (measured 0.23 % at 1080p on the city, whole-image rel-L2 6e-4).
-            ok = P.within_bars(r, mismatch_tol=1e-2) if name in ("filtered_history_img", "input_prob_img") else P.within_bars(r)
+            # allowance there and for its two dilations (filter_prob.hlsl, filter_prob2.hlsl), which carry the same texels forward (measured
+            # 0.23 % at 1080p on the city, whole-image rel-L2 5e-4 .. 6e-4).
+            ill_conditioned = ("filtered_history_img", "input_prob_img", "prob_filtered1_img", "prob_filtered2_img")
+            ok = P.within_bars(r, mismatch_tol=1e-2) if name in ill_conditioned else P.within_bars(r)
             assert ok, f"frame {fi} {name}: {r}"
     print(f"TAA worst per-surface rel-L2 over {len(fcs)} frames on identical inputs and history ({scene_name}): {worst:.2e}")
 
