@@ -29,11 +29,13 @@ KJ_D float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 KJ_D float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
 KJ_D float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
 KJ_D float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+KJ_D float log2_fast(float x) { return __builtin_amdgcn_logf(x); }
 #else
 KJ_HD float rcp_fast(float x) { return 1.0f / x; }
 KJ_HD float rsq_fast(float x) { return 1.0f / sqrtf(x); }
 KJ_HD float sqrt_fast(float x) { return sqrtf(x); }
 KJ_HD float exp2_fast(float x) { return exp2f(x); }
+KJ_HD float log2_fast(float x) { return log2f(x); }
 #endif
 KJ_HD float length_fast(V3 a) { return sqrt_fast(dot(a, a)); }
 KJ_HD float length_fast(V2 a) { return sqrt_fast(dot(a, a)); }

@@ -3,6 +3,7 @@
 // uses __shfl_xor like WaveReadLaneAt in reproject_history.hlsl:80-82).
 #include "kj_host.hpp"
 #include "kj_shading.hpp"
+#include "kj_screen.hpp"
 
 using namespace kj;
 
@@ -11,6 +12,17 @@ typedef Img<uint32_t> ImgH2;   // RG16F
 typedef Img<uint16_t> ImgH1;   // R16F
 typedef Img<float> ImgF32;
 
+// These kernels are VALU-bound (PMC: VALUBusy 82-97 % at full lane utilisation), so they are written for few instructions: an IEEE
+// division is ~12 VALU instructions on gfx950, sqrtf 18, libm exp2f / log2f ~10 (v_exp_f32 / v_log_f32 wrapped for denormals).
+// One stage is hypersensitive, and that decides what may change where: input_prob divides the squared difference of the filtered
+// input and the filtered history by a variance floored at 1e-6, so ONE fp16 ulp in either image moves a texel's probability by O(1)
+// in flat regions. Everything upstream of it (history reprojection, the input / history filters, their colour decode) therefore
+// keeps the reference's operations bit for bit and only takes transformations that cannot change a result:
+//  * exp2 / log2 of arguments whose results stay in the normal range go straight to v_exp_f32 / v_log_f32 (same bits as libm there);
+//  * `pow8(saturate(1e10 / luma))` -- the first of the two passes of the input / history filters -- is 1 for every luma in
+//    [+0, 1e10], decided by one integer compare on the bits; the division runs only for the others.
+// Inside input_prob and in the final pass (k_taa: blends, clamps, the fp16 stores of the frame's outputs), quotients use v_rcp_f32 +
+// multiply and square roots v_sqrt_f32 (1 ulp each); what stays IEEE there: the moments E[x], E[x^2] a variance is formed from.
 // Row-range aware tile mapping (see rtdgi.hip): rows [row0, row1) of the kernel's own resolution.
 #define TILE_XY(W_, H_)                                                                          \
     const int lane = threadIdx.x;                                                                \
@@ -18,8 +30,12 @@ typedef Img<float> ImgF32;
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
 // taa_common.hlsl (TAA_NONLINEARITY_TYPE 1, TAA_COLOR_MAPPING_MODE 1)
-KJ_D V3 taa_decode_rgb(V3 v) { const float m = max3(v.x, v.y, v.z); return v * sqrtf(fmaxf(0.0f, m)) / fmaxf(1e-20f, m); }
-KJ_D V3 taa_encode_rgb(V3 v) { const float m = max3(v.x, v.y, v.z); return v * (m * m) / fmaxf(1e-20f, m); }
+KJ_D V3 taa_decode_rgb(V3 v) { const float m = max3(v.x, v.y, v.z); return v * sqrtf(fmaxf(0.0f, m)) / fmaxf(1e-20f, m); }     // (upstream of input_prob: exact)
+KJ_D V3 taa_encode_rgb(V3 v) { const float m = max3(v.x, v.y, v.z); return v * ((m * m) * rcp_fast(fmaxf(1e-20f, m))); }
+// pow8(saturate(cutoff / luma)) of the input / history filters. cutoff = 1e10 ("no cutoff"): 1 for every luma in [+0, 1e10]
+KJ_D float pow8_(float x) { const float x2 = x * x, x4 = x2 * x2; return x4 * x4; }
+KJ_D float luma_weight_uncut(float luma) { return __float_as_uint(luma) <= __float_as_uint(1e10f) ? 1.0f : pow8_(saturate(1e10f / luma)); }
+KJ_D float luma_weight(float cutoff, float luma) { return pow8_(saturate(cutoff / luma)); }
 KJ_D float ld1h(const ImgH1& i, int x, int y) { return f16_to_f32(i.ld(x, y)); }
 
 // image_sample_catmull_rom_5tap (inc/image.hlsl:88-172); the history remap (decode_rgb * pre_exposure_delta) is applied per tap
@@ -87,7 +103,6 @@ __global__ void __launch_bounds__(64) k_taa_reproject(const FrameConstants* __re
 // filter_input.hlsl:33-88. The shader calls filter_input_inner twice over the same 3x3 taps (first with an infinite
 // luma cutoff, then with 1.001x the first pass' luma); here the taps are decoded once and kept in registers, and
 // pow(x, 8) is three squarings.
-KJ_D float pow8(float x) { const float x2 = x * x, x4 = x2 * x2; return x4 * x4; }
 __global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32 depth_tex, ImgH4 output_tex, ImgH4 dev_output_tex, int row0, int row1) {
     TILE_XY(output_tex.w, output_tex.h)
     // LDS-staged 10x10 tile: .xyz = decoded YCbCr of the input texel, .w = depth (one decode per texel instead of nine)
@@ -115,7 +130,7 @@ __global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32
             const float4 t = tile[lt + yy * 10 + xx];
             s[i] = V3{t.x, t.y, t.z};
             float w = 1;
-            w *= exp2f(-fminf(16.0f, depth_scale * inverse_depth_relative_diff(center_depth, t.w)));
+            w *= exp2_fast(-fminf(16.0f, depth_scale * inverse_depth_relative_diff(center_depth, t.w)));     // >= 2^-16: same bits as exp2f
             w *= distance_w;
             wd[i] = w;
         }
@@ -124,7 +139,7 @@ __global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32
     float clamped_iwsum = 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const float w = wd[i] * pow8(saturate(1e10f / s[i].x));
+        const float w = wd[i] * luma_weight_uncut(s[i].x);
         clamped_iwsum += w;
         clamped_iex += s[i] * w;
         iex += s[i];
@@ -139,7 +154,7 @@ __global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32
     V3 cex = v3(0.0f); float cws = 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const float w = wd[i] * pow8(saturate(cutoff / s[i].x));
+        const float w = wd[i] * luma_weight(cutoff, s[i].x);
         cws += w;
         cex += s[i] * w;
     }
@@ -149,7 +164,7 @@ __global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32
 }
 
 // filter_history.hlsl:15-61. Same two-pass structure as filter_input; K = 1 unless the history is > 1.75x the input extent.
-template <int K>
+template <int K, bool UNCUT>
 KJ_D V3 fh_filter_input(const V3* taps, float luma_cutoff) {
     V3 iex = v3(0.0f);
     float iwsum = 0;
@@ -159,7 +174,7 @@ KJ_D V3 fh_filter_input(const V3* taps, float luma_cutoff) {
         for (int xx = -K; xx <= K; ++xx) {
             const float distance_w = expf(-(0.8f / float(K * K)) * float(xx * xx + yy * yy));
             const V3 s = taps[(yy + K) * (2 * K + 1) + (xx + K)];
-            const float w = distance_w * pow8(saturate(luma_cutoff / s.x));
+            const float w = distance_w * (UNCUT ? luma_weight_uncut(s.x) : luma_weight(luma_cutoff, s.x));
             iwsum += w;
             iex += s * w;
         }
@@ -193,8 +208,8 @@ __global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_his
 #pragma unroll
             for (int xx = -K; xx <= K; ++xx) taps[(yy + K) * (2 * K + 1) + (xx + K)] = sRGB_to_YCbCr(xyz(ld4(reprojected_history, sx + xx, sy + yy)));
     }
-    const float filtered_luma = fh_filter_input<K>(taps, 1e10f).x;
-    st4(output_tex, x, y, v4(fh_filter_input<K>(taps, filtered_luma * 1.001f), 0.0f));
+    const float filtered_luma = fh_filter_input<K, true>(taps, 1e10f).x;
+    st4(output_tex, x, y, v4(fh_filter_input<K, false>(taps, filtered_luma * 1.001f), 0.0f));
 }
 
 // input_prob.hlsl:50-108
@@ -217,6 +232,7 @@ __global__ void __launch_bounds__(64) k_taa_input_prob(const FrameConstants* __r
     const V3 closest_smooth_var = xyz(sample_bilinear_clamp_rgba16f(smooth_var_history_tex.p, smooth_var_history_tex.w, smooth_var_history_tex.h, huv));
     const V2 closest_vel = sample_bilinear_clamp_rg16f(velocity_history_tex.p, velocity_history_tex.w, velocity_history_tex.h, huv) * fc->delta_time_seconds;
     const V3 combined_var = vmin(closest_smooth_var, ivar * 10.0f);
+    const V3 inv_var{rcp_fast(fmaxf(1e-6f, combined_var.x)), rcp_fast(fmaxf(1e-6f, combined_var.y)), rcp_fast(fmaxf(1e-6f, combined_var.z))};
     float input_prob = 0;
 #pragma unroll
     for (int oy = -1; oy <= 1; ++oy)
@@ -224,8 +240,9 @@ __global__ void __launch_bounds__(64) k_taa_input_prob(const FrameConstants* __r
         for (int ox = -1; ox <= 1; ++ox) {
             const V3 idiff = xyz(ld4(filtered_input_tex, x + ox, y + oy)) - xyz(closest_history);
             const V4 rv = ld_reproj(reprojection_tex, x + ox, y + oy);
-            const V2 q{(rv.x - closest_vel.x) / fmaxf(1.0f, fabsf(rv.x + closest_vel.x)), (rv.y - closest_vel.y) / fmaxf(1.0f, fabsf(rv.y + closest_vel.y))};
-            const float prob = exp2f(-1.0f * length(idiff * idiff / vmax(v3(1e-6f), combined_var)) - 1000.0f * length(q));
+            const V2 q{(rv.x - closest_vel.x) * rcp_fast(fmaxf(1.0f, fabsf(rv.x + closest_vel.x))), (rv.y - closest_vel.y) * rcp_fast(fmaxf(1.0f, fabsf(rv.y + closest_vel.y)))};
+            // (results below 2^-126 come out as 0: the image is fp16)
+            const float prob = exp2_fast(-1.0f * length_fast(idiff * idiff * inv_var) - 1000.0f * length_fast(q));
             input_prob = fmaxf(input_prob, prob);
         }
     output_tex.st(x, y, f32_to_f16(input_prob));
@@ -248,8 +265,8 @@ __global__ void __launch_bounds__(64) k_taa_filter_prob2(ImgH1 input_tex, ImgH1 
 #pragma unroll
     for (int oy = -2; oy <= 2; ++oy)
 #pragma unroll
-        for (int ox = -2; ox <= 2; ++ox) weighted += V2{exp2f(-clampf(10.0f * ld1h(input_tex, x + ox * 2, y + oy * 2), 0.0f, 100.0f)), 1.0f};
-    output_tex.st(x, y, f32_to_f16(fmaxf(0.0f, -1.0f / 10.0f * log2f(1e-30f + weighted.x / weighted.y))));
+        for (int ox = -2; ox <= 2; ++ox) weighted += V2{exp2_fast(-clampf(10.0f * ld1h(input_tex, x + ox * 2, y + oy * 2), 0.0f, 100.0f)), 1.0f};     // >= 2^-100: normal range
+    output_tex.st(x, y, f32_to_f16(fmaxf(0.0f, -1.0f / 10.0f * log2_fast(1e-30f + weighted.x / weighted.y))));
 }
 
 // inc/unjitter_taa.hlsl:58-125 (kernel half width 1). taa.hlsl calls it twice on the same taps (kernel_scale 1 and 0.333);
@@ -276,19 +293,19 @@ KJ_D void sample_image_unjitter_taa2(const ImgH4& img, const float4* tile_cols /
             {
                 const V2 o = off * ks_a;
                 const float dist2 = dot(o, o);
-                const float dev_wt = exp2f(-dist2 * scale.x), wt = exp2f(-10.0f * dist2 * scale.x);
+                const float dev_wt = exp2_fast(-dist2 * scale.x), wt = exp2_fast(-10.0f * dist2 * scale.x);     // |arg| < 100: normal range
                 res_a += v4(col, 1.0f) * wt; wt_sum_a += wt;
                 ex_a += col * dev_wt; ex2_a += col * col * dev_wt; dev_wt_sum_a += dev_wt;
             }
             {
                 const V2 o = off * ks_b;
                 const float dist2 = dot(o, o);
-                const float dev_wt = exp2f(-dist2 * scale.x), wt = exp2f(-10.0f * dist2 * scale.x);
+                const float dev_wt = exp2_fast(-dist2 * scale.x), wt = exp2_fast(-10.0f * dist2 * scale.x);
                 res_b += v4(col, 1.0f) * wt; wt_sum_b += wt;
                 ex_b += col * dev_wt; ex2_b += col * col * dev_wt; dev_wt_sum_b += dev_wt;
             }
         }
-    ra = Unjittered{res_a, wt_sum_a, ex_a / dev_wt_sum_a, ex2_a / dev_wt_sum_a};
+    ra = Unjittered{res_a, wt_sum_a, ex_a / dev_wt_sum_a, ex2_a / dev_wt_sum_a};     // IEEE: a variance is formed from these moments
     rb = Unjittered{res_b, wt_sum_b, ex_b / dev_wt_sum_b, ex2_b / dev_wt_sum_b};
 }
 
@@ -343,7 +360,7 @@ __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
             csum += hv * w;
             wsum += w;
         }
-    const V4 bhistory_packed = csum / wsum;
+    const V4 bhistory_packed = csum * (1.0f / wsum);     // (wsum is a compile-time constant)
     V3 bhistory = xyz(bhistory_packed);
     const float bhistory_coverage = bhistory_packed.w;
     history = sRGB_to_YCbCr(history);
@@ -354,7 +371,7 @@ __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
     sample_image_unjitter_taa2<TILED>(a.input_tex, col_tile + (TILED ? ltc : 0), x, y, V2{ots.x, ots.y}, sop, 1.0f, 0.333f, center_sample, bcenter_sample);
     float coverage = center_sample.coverage;
     V3 center = xyz(center_sample.color);
-    const V3 bcenter = xyz(bcenter_sample.color) / bcenter_sample.coverage;
+    const V3 bcenter = xyz(bcenter_sample.color) * rcp_fast(bcenter_sample.coverage);
     history = lerp(history, bcenter, saturate(1.0f - history_coverage));
     bhistory = lerp(bhistory, bcenter, saturate(1.0f - bhistory_coverage));
     const float input_prob = ld1h(a.input_prob_tex, rx, ry);
@@ -363,19 +380,20 @@ __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
     const V3 prev_var = v3(sample_bilinear_clamp_rgba16f(a.smooth_var_history_tex.p, OW, OH, uv + reproj_xy).x);
     const V2 vel_now = reproj_xy / fc.delta_time_seconds;
     const V2 vel_prev = sample_bilinear_clamp_rg16f(a.velocity_history_tex.p, OW, OH, uv + reproj_xy);
-    const V2 vq{(vel_now.x - vel_prev.x) / fmaxf(1.0f, fabsf(vel_now.x + vel_prev.x)), (vel_now.y - vel_prev.y) / fmaxf(1.0f, fabsf(vel_now.y + vel_prev.y))};
-    const float var_blend = saturate(0.3f + 0.7f * (1 - reproj.z) + length(vq));
+    const V2 vq{(vel_now.x - vel_prev.x) * rcp_fast(fmaxf(1.0f, fabsf(vel_now.x + vel_prev.x))), (vel_now.y - vel_prev.y) * rcp_fast(fmaxf(1.0f, fabsf(vel_now.y + vel_prev.y)))};
+    const float var_blend = saturate(0.3f + 0.7f * (1 - reproj.z) + length_fast(vq));
     V3 smooth_var = vmax(var, lerp(prev_var, var, var_blend));
     smooth_var = lerp(var, smooth_var, saturate(input_prob));
-    const V3 input_dev = vsqrt(var);
+    const V3 input_dev{sqrt_fast(var.x), sqrt_fast(var.y), sqrt_fast(var.z)};
     V3 clamped_history;
     {
         const float box_n_deviations = lerp(0.8f, 3.0f, input_prob);
         const V3 nmin = ex - input_dev * box_n_deviations, nmax = ex + input_dev * box_n_deviations;
         const V3 clamped_bhistory = vclamp(bhistory, nmin, nmax);
-        const float clamping_event = length(vmax(v3(0.0f), vmax(bhistory - nmax, nmin - bhistory)) / vmax(v3(0.01f), ex));
-        const V3 outlier3 = vmax(v3(0.0f), vmax(nmin - history, history - nmax) / (0.1f + vmax(vmax(vabs(history), vabs(ex)), v3(1e-5f))));
-        const V3 boutlier3 = vmax(v3(0.0f), vmax(nmin - bhistory, bhistory - nmax) / (0.1f + vmax(vmax(vabs(bhistory), vabs(ex)), v3(1e-5f))));
+        auto rcp3 = [](V3 a) { return V3{rcp_fast(a.x), rcp_fast(a.y), rcp_fast(a.z)}; };
+        const float clamping_event = length_fast(vmax(v3(0.0f), vmax(bhistory - nmax, nmin - bhistory)) * rcp3(vmax(v3(0.01f), ex)));
+        const V3 outlier3 = vmax(v3(0.0f), vmax(nmin - history, history - nmax) * rcp3(0.1f + vmax(vmax(vabs(history), vabs(ex)), v3(1e-5f))));
+        const V3 boutlier3 = vmax(v3(0.0f), vmax(nmin - bhistory, bhistory - nmax) * rcp3(0.1f + vmax(vmax(vabs(bhistory), vabs(ex)), v3(1e-5f))));
         const float outlier = fmaxf(outlier3.x, fmaxf(outlier3.y, outlier3.z));
         const float boutlier = fmaxf(boutlier3.x, fmaxf(boutlier3.y, boutlier3.z));
         const V2 huv = uv + reproj_xy;
@@ -383,13 +401,13 @@ __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
         if (history_valid) {
             const float non_disoccluding_outliers = fmaxf(0.0f, outlier - boutlier) * 10;
             const V3 unclamped_history_detail = history - clamped_bhistory;
-            const float temporal_clamping_detail = fabsf(unclamped_history_detail.x / fmaxf(1e-3f, input_dev.x)) * 0.05f;
+            const float temporal_clamping_detail = fabsf(unclamped_history_detail.x * rcp_fast(fmaxf(1e-3f, input_dev.x))) * 0.05f;
             const float temporal_stability = saturate(1 - temporal_clamping_detail);
             const float allow_unclamped_detail = saturate(non_disoccluding_outliers) * temporal_stability;
             V3 history_detail = history - bhistory;
             history_detail = lerp(history_detail, unclamped_history_detail, allow_unclamped_detail);
-            const float initial_bclamp_amount = saturate(dot(clamped_bhistory - bhistory, bcenter - bhistory) /
-                                                         fmaxf(1e-5f, length(clamped_bhistory - bhistory) * length(bcenter - bhistory)));
+            const float initial_bclamp_amount = saturate(dot(clamped_bhistory - bhistory, bcenter - bhistory) *
+                                                         rcp_fast(fmaxf(1e-5f, length_fast(clamped_bhistory - bhistory) * length_fast(bcenter - bhistory))));
             const float keep_detail = 1 - saturate(initial_bclamp_amount) * (1 - allow_unclamped_detail);
             history_detail *= keep_detail;
             clamped_history = clamped_bhistory + history_detail;
@@ -403,13 +421,13 @@ __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
         clamped_history = lerp(clamped_history, history, smoothstep(0.5f, 1.0f, input_prob));
     }
     float total_coverage = fmaxf(1e-5f, history_coverage + coverage);
-    V3 temporal_result = (clamped_history * history_coverage + center) / total_coverage;
+    V3 temporal_result = (clamped_history * history_coverage + center) * rcp_fast(total_coverage);
     total_coverage = fminf(fmaxf(2.0f, 8.0f / (frac_.x * frac_.y)), total_coverage);
     st4(a.smooth_var_output_tex, x, y, v4(smooth_var, 0.0f));
     temporal_result = vmax(v3(0.0f), taa_encode_rgb(YCbCr_to_sRGB(temporal_result)));
     st4(a.temporal_output_tex, x, y, v4(temporal_result, total_coverage));
     st4(a.output_tex, x, y, v4(temporal_result, 0.0f));
-    st2h(a.velocity_output_tex, x, y, reproj_xy / fc.delta_time_seconds);
+    st2h(a.velocity_output_tex, x, y, vel_now);
 }
 
 // ================================================================== host

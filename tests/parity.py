@@ -133,9 +133,10 @@ REL_L2_TOL = 1e-3      # north-star tolerance (BASELINE.json) for deterministic 
 MISMATCH_TOL = 2e-3    # fraction of texels allowed to be off by more than 1e-3 relative (discrete flips: a reservoir pick, an int() tap)
 
 
-def within_bars(r, rel_l2_tol=REL_L2_TOL, mismatch_tol=MISMATCH_TOL):
-    """All three at once: the image as a whole (relative L2), the count of outlier texels, and no finite-vs-non-finite disagreement."""
-    return r["rel_l2"] <= rel_l2_tol and r["mismatch_frac"] <= mismatch_tol and r.get("bad_class", 0) == 0
+def within_bars(r, rel_l2_tol=REL_L2_TOL, mismatch_tol=MISMATCH_TOL, bad_class_texels=0):
+    """All three at once: the image as a whole (relative L2), the count of outlier texels, and no finite-vs-non-finite disagreement
+    (`bad_class_texels`: how many such texels a caller tolerates, for a surface whose formula is 0 / 0 at isolated texels)."""
+    return r["rel_l2"] <= rel_l2_tol and r["mismatch_frac"] <= mismatch_tol and r.get("bad_class", 0) <= bad_class_texels
 
 
 def within_bars_with_flips(r, flip_tol=MISMATCH_TOL, outlier_cap=1e-2):
