@@ -229,7 +229,12 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
 
 // ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111
 template <bool STATS>
-__global__ void __launch_bounds__(64, 4) k_rtdgi_validate_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
+// waves per SIMD the fused ray kernels are compiled for: 4 = 123 VGPRs, no spills; 5 = 96 VGPRs + 20 spilled dwords outside the traversal
+// loop: trace pass -2 %; 6 = 80 VGPRs + 48 dwords: +30 % (measured, same box)
+#ifndef KJ_FUSED_WAVES
+#define KJ_FUSED_WAVES 5
+#endif
+__global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_validate_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
                                                         ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
     extern __shared__ uint32_t lds_stack[];
     TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
@@ -265,7 +270,7 @@ __global__ void __launch_bounds__(64, 4) k_rtdgi_validate_fused(TraceCtx c, ImgU
 
 // ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24
 template <bool STATS>
-__global__ void __launch_bounds__(64, 4) k_rtdgi_trace_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
+__global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
                                                      ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
     extern __shared__ uint32_t lds_stack[];
     TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
