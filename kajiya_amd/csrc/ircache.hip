@@ -601,13 +601,14 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     tc.request_slot_base = 2u * c->req_half_pixels;
     const size_t lds = size_t(tc.sc.bvh.stack_entries) * 64 * 4;
     KJ_REQUIRE(lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");
-    // The cache's ray passes are small (a few thousand entries x 4 paths: ~125 full waves on 1024 SIMDs) and each path is a chain of
-    // ~150 dependent fetches, so a pass takes as long as its slowest WAVE: the union of 64 divergent paths' steps, each step waiting for
-    // the slowest of 64 scattered loads. Spread thin instead -- `lanes` paths per wave, the other lanes idle: more waves than the
-    // machine has SIMDs either way, but each wave's step count is the maximum over fewer paths and its loads return sooner.
+    // The cache's ray passes are small (a few thousand entries x 4 paths: ~107 full waves on 1024 SIMDs) and each path is a chain of
+    // ~150 dependent traversal steps, so a pass takes as long as its slowest WAVE. KJ_IRC_LANES=n spreads them thin -- n paths per
+    // wave, the other lanes idle -- which measured -2.5 % per frame at n = 8 (each wave's step count is the maximum over fewer
+    // divergent paths). Not the default: with 8x as many waves in flight a lookup sees fewer of the same pass' updates, which moves the
+    // racy passes further from the sequential oracle (SH rel-L2 on identical state, 1080p city: 1.1e-2 at 64, 2.3e-2 at 8; bar 2e-2).
     static const uint32_t lanes_env = getenv("KJ_IRC_LANES") ? uint32_t(atoi(getenv("KJ_IRC_LANES"))) : 0u;
-    tc.lanes = lanes_env >= 1u && lanes_env <= 64u ? lanes_env : 8u;
-    const uint32_t grid = c->dev->num_cus * 32;
+    tc.lanes = lanes_env >= 1u && lanes_env <= 64u ? lanes_env : 64u;
+    const uint32_t grid = c->dev->num_cus * (tc.lanes < 64u ? 32u : 8u);
     KJ_TRY_HIP(hipMemsetAsync(c->ray_counters.p, 0, KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8, s));
     hipLaunchKernelGGL(k_irc_prepare_trace, dim3(1), dim3(1), 0, s, (uint32_t*)c->meta.p);
     KJ_CHECK_LAUNCH();
