@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 measurements on the GPU box (gpurun -- bash scripts/r02_final_runs.sh): everything lands in gpurun_out/ and is copied to profiles/ by hand.
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
-python -m pytest tests -m gpu -q -x > gpurun_out/r02_gpu_tests.log 2>&1; tail -3 gpurun_out/r02_gpu_tests.log
+python -m pytest tests -m gpu -q > gpurun_out/r02_gpu_tests.log 2>&1; tail -3 gpurun_out/r02_gpu_tests.log
 python __graft_entry__.py smoke > gpurun_out/r02_smoke.log 2>&1; tail -2 gpurun_out/r02_smoke.log
 python bench.py > gpurun_out/r02_bench_1080p.json 2> gpurun_out/r02_bench_1080p.err
 python bench.py --no-overlap --no-cpu-baseline > gpurun_out/r02_bench_1080p_serial.json 2> /dev/null
