@@ -361,21 +361,19 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         tri_base[ii] = total_tris; node_base[ii] = total_nodes;
         total_tris += bl.tri_count; total_nodes += bl.node_count;
         max_blas_stack = std::max(max_blas_stack, bl.max_stack);
-        // world -> object: inverse of the upper 3x3 in double, then the translation
-        const double a[9] = {x[0], x[1], x[2], x[4], x[5], x[6], x[8], x[9], x[10]};
-        const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
         float wb[6];
         world_box(x, bl.bounds, wb);
         float max_abs = 0.0f;
         for (int k = 0; k < 6; ++k) max_abs = std::max(max_abs, std::fabs(wb[k]));
         const float pad_world = 16.0f * FLT_EPSILON * std::max(max_abs, 1e-3f);
-        if (std::fabs(det) > 1e-30) {
-            BvhTri t{};   // the instance's (padded) world box as the top tree's primitive: it encloses the refit root, whose triangles are
-                          // the transformed vertices -- all inside the transformed corners' box up to rounding, which the pad covers
+        {   // the instance's (padded) world box as the top tree's primitive: it encloses the refit root, whose triangles are the
+            // transformed vertices -- all inside the transformed corners' box up to rounding, which the pad covers. Any transform will
+            // do, singular ones included (a mesh flattened into a plane still has triangles to hit): nothing here needs its inverse.
+            BvhTri t{};
             for (int k = 0; k < 3; ++k) { t.v0[k] = t.v2[k] = wb[k] - pad_world; t.v1[k] = wb[3 + k] + pad_world; }
             t.prim = ii;
             tlas_prims.push_back(t);
-        }   // a singular transform flattens the mesh to zero volume: nothing to hit, the instance stays out of the top tree
+        }
         auto xf_point = [&](const float* p, float* o) {
             o[0] = x[0] * p[0] + x[1] * p[1] + x[2] * p[2] + x[3];
             o[1] = x[4] * p[0] + x[5] * p[1] + x[6] * p[2] + x[7];

@@ -357,6 +357,100 @@ def test_scene_edits_and_ragged_queries(gpu, oracle, device):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and (a[:, 0] < 3e38).any()
 
 
+def _rotation(axis, angle):
+    axis = np.asarray(axis, np.float64); axis /= np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+
+
+def _blob(rng, n_tris, size=1.0):
+    """n_tris random small triangles scattered in a cube: a mesh whose BLAS shape is decided by the triangle count alone."""
+    from kajiya_amd import scenes
+    c = rng.uniform(-size, size, (n_tris, 1, 3))
+    p = (c + rng.uniform(-0.15, 0.15, (n_tris, 3, 3)) * size).reshape(-1, 3).astype(np.float32)
+    n = np.tile(np.array([[0, 0, 1]], np.float32), (len(p), 1))
+    return scenes.TriangleMesh(p, n, np.arange(len(p), dtype=np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast_build", [False, True])
+def test_instance_trees_under_rotation_mirroring_and_repeated_edits(gpu, oracle, device, fast_build):
+    """The per-instance world-space trees (scene_device.hip: refit by node height, four lanes per node) at their corners: meshes of
+    1, 4, 5, 17 and 1300 triangles (one-node trees, one refit step, several steps, a step wider than one workgroup pass), instances
+    rotated about arbitrary axes, scaled by 1e-2 .. 30, mirrored (negative determinant), flattened to zero volume (out of the top
+    tree), 300 instances of the smallest meshes (a deeper top tree), then three rounds of edits -- move everything, remove some,
+    ADD new instances of old meshes and a new mesh -- each followed by a commit. Ray queries stay bit-exact against an oracle scene
+    built from scratch in the edited state every time. `fast_build`: every BLAS built on the device as an LBVH (its refit walks
+    depth levels instead of node heights)."""
+    import os
+    import torch
+    from kajiya_amd import scenes
+    if fast_build and os.environ.get("KJ_HIP_EMU"):
+        pytest.skip("the device LBVH build needs the device sort (not in the CPU stand-in)")
+    rng = np.random.RandomState(42)
+    L = gpu.load()
+    meshes = [_blob(rng, n) for n in (1, 4, 5, 17, 1300)]
+    desc = scenes.SceneDesc()
+    for m in meshes:
+        desc.add_mesh(m)
+
+    def random_xform(k):
+        r = _rotation(rng.normal(size=3), rng.uniform(0, 2 * np.pi))
+        s = 10.0 ** rng.uniform(-2, 1.5) if k % 7 == 0 else rng.uniform(0.5, 2.0)
+        if k % 5 == 0:
+            r = r @ np.diag([1.0, -1.0, 1.0])                      # mirrored
+        if k % 31 == 30:
+            r = r @ np.diag([1.0, 1.0, 0.0])                       # singular: zero volume
+        return scenes.affine(r, s, rng.uniform(-20, 20, 3))
+    live = []                                                      # (mesh, xform) per instance SLOT; None = removed
+    for k in range(300):
+        live.append((int(rng.randint(0, 4)) if k % 50 else 4, random_xform(k)))
+        desc.add_instance(*live[-1])
+    gsc = gpu.Scene(device, desc, fast_build=fast_build)
+
+    def check(tag):
+        cur = scenes.SceneDesc()
+        for m in meshes:
+            cur.add_mesh(m)
+        for e in live:
+            if e is not None:
+                cur.add_instance(*e)
+        osc = oracle.OracleScene(cur)
+        assert gsc.stats()["triangles"] == osc.triangle_count, tag
+        lo, hi = cur.bounds()
+        rays = _random_rays(rng, 40_000, lo.astype(np.float32), hi.astype(np.float32))
+        # half of them aimed at an instance (the scene is sparse: uniformly random rays mostly miss)
+        at = np.array([e[1][:, 3] for e in live if e is not None], np.float32)[rng.randint(0, sum(e is not None for e in live), 20_000)]
+        d = at + rng.normal(scale=0.3, size=at.shape).astype(np.float32) - rays[:20_000, 0:3]
+        rays[:20_000, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True); rays[:20_000, 7] = 1e4
+        ref = osc.trace_closest(rays)
+        got = gsc.trace_closest(torch.from_numpy(rays).cuda(), len(rays)).cpu().numpy()
+        bad = (ref.view(np.uint32) != got.view(np.uint32)).any(axis=1)
+        assert not bad.any(), f"{tag}: {int(bad.sum())} of {len(rays)} rays differ"
+        assert (ref[:, 0] < 3e38).mean() > 0.03, tag            # the batch does hit things (a few thousand hits per check)
+        assert np.array_equal(osc.trace_any(rays), gsc.trace_any(torch.from_numpy(rays).cuda(), len(rays)).cpu().numpy()), tag
+    check("initial")
+    for rnd in range(3):
+        for slot, e in enumerate(live):
+            if e is None:
+                continue
+            if rng.uniform() < 0.5:                                # move half of what is alive
+                live[slot] = (e[0], random_xform(slot + 1000 * (rnd + 1)))
+                gpu.check(L.kj_scene_set_instance_transform(gsc.h, slot, live[slot][1].ctypes.data))
+            elif rng.uniform() < 0.1:
+                live[slot] = None
+                gpu.check(L.kj_scene_remove_instance(gsc.h, slot))
+        if rnd == 1:                                               # a mesh added after the first commit
+            meshes.append(_blob(rng, 333))
+            assert gsc.add_mesh(meshes[-1]) == len(meshes) - 1
+        for k in range(20):                                        # new instances, of the newest mesh too
+            e = (int(rng.randint(0, len(meshes))), random_xform(5000 + 100 * rnd + k))
+            assert gsc.add_instance(*e) == len(live)
+            live.append(e)
+        gsc.commit()
+        check(f"after edit round {rnd}")
+
+
 @pytest.mark.parametrize("scene_name,W,H", [("cornell", 200, 136), ("city20k", 256, 144)])
 def test_sun_shadow_mask(gpu, oracle, device, scene_name, W, H):
     """trace_sun_shadow_mask (renderers/shadows.rs:10-40): one soft-shadow ray per pixel on identical G-buffer inputs. The mask
