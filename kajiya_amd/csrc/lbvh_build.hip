@@ -123,11 +123,13 @@ __global__ void __launch_bounds__(256) k_lbvh_refit(const Box6* __restrict__ pbo
 }
 // One level of the 4-wide tree. item = (binary internal node, output node index, depth).
 struct CollapseItem { uint32_t bin, out, depth; };
+// The level's queue length lives on the device (queue_len[level]; the kernel appends to queue_len[level + 1]): the host launches every
+// level with a grid that is large enough by construction (<= 4^level items, <= one per triangle) and reads nothing back in between.
 __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __restrict__ children, const uint2* __restrict__ range, const Box6* __restrict__ nbox, const CollapseItem* __restrict__ in,
-                                                       uint32_t in_count, CollapseItem* __restrict__ out, uint32_t* __restrict__ counters /*[0]=next queue size, [1]=nodes, [2]=max depth*/,
+                                                       uint32_t* __restrict__ queue_len, uint32_t level, CollapseItem* __restrict__ out, uint32_t* __restrict__ counters /*[1]=nodes, [2]=max depth*/,
                                                        Bvh4Node* __restrict__ nodes, uint32_t node_base) {
-    const uint32_t w = blockIdx.x * 64 + threadIdx.x;
-    if (w >= in_count) return;
+    const uint32_t in_count = queue_len[level];
+    for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < in_count; w += gridDim.x * 64) {
     const CollapseItem it = in[w];
     auto is_leaf = [&](uint32_t id) { return id >= uint32_t(n - 1) || range[id].y - range[id].x + 1u <= KJ_BVH_MAX_LEAF_TRIS; };
     uint32_t ch[4]; int nch = 0;
@@ -182,11 +184,14 @@ __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __rest
         } else {
             const uint32_t o = atomicAdd(&counters[1], 1u);
             node.child[i] = node_base + o;
-            out[atomicAdd(&counters[0], 1u)] = CollapseItem{ch[i], o, it.depth + uint32_t(nch - 1)};
+            out[atomicAdd(&queue_len[level + 1], 1u)] = CollapseItem{ch[i], o, it.depth + uint32_t(nch - 1)};
         }
     }
     nodes[it.out] = node;
+    }
 }
+// after a level: how many nodes exist now (= where the next level's nodes start)
+__global__ void k_lbvh_level_end(const uint32_t* __restrict__ counters, uint32_t* __restrict__ level_nodes, uint32_t level) { level_nodes[level + 1] = counters[1]; }
 __global__ void __launch_bounds__(256) k_lbvh_emit_tris(const uint8_t* __restrict__ vb, GpuMesh m, const uint32_t* __restrict__ ids, uint32_t n, BvhTri* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -208,48 +213,79 @@ __global__ void __launch_bounds__(256) k_lbvh_emit_tris(const uint8_t* __restric
 namespace kj {
 
 #ifdef KJ_HIP_EMU_HOST
-hipError_t build_blas_lbvh_device(const uint8_t*, const GpuMesh&, uint32_t, Bvh4Node*, BvhTri*, LbvhResult*, hipStream_t) { return hipErrorInvalidValue; }   // the CPU stand-in has no device sort: fast-build meshes need the real device
+hipError_t build_blas_lbvh_device(const uint8_t*, const GpuMesh&, uint32_t, Bvh4Node*, BvhTri*, LbvhResult*, LbvhScratch*, hipStream_t) { return hipErrorInvalidValue; }   // the CPU stand-in has no device sort: fast-build meshes need the real device
 #else
 #define KJ_LB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
-hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, hipStream_t s) {
+hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s) {
     const uint32_t n = mesh.index_count / 3;
-    if (n == 0) return hipErrorInvalidValue;
-    DevBuf pbox, ob, codes, ids, codes2, ids2, children, range, parent, visits, nbox, q0, q1, counters, tmp;
-    KJ_LB(pbox.alloc(size_t(n) * sizeof(Box6), s)); KJ_LB(ob.alloc(32, s));
-    KJ_LB(codes.alloc(size_t(n) * 4, s)); KJ_LB(ids.alloc(size_t(n) * 4, s)); KJ_LB(codes2.alloc(size_t(n) * 4, s)); KJ_LB(ids2.alloc(size_t(n) * 4, s));
-    KJ_LB(children.alloc(size_t(n) * 8, s)); KJ_LB(range.alloc(size_t(n) * 8, s)); KJ_LB(parent.alloc(size_t(2 * n) * 4, s)); KJ_LB(visits.alloc(size_t(n) * 4, s));
-    KJ_LB(nbox.alloc(size_t(2 * n) * sizeof(Box6), s)); KJ_LB(q0.alloc(size_t(n + 1) * sizeof(CollapseItem), s)); KJ_LB(q1.alloc(size_t(n + 1) * sizeof(CollapseItem), s));
-    KJ_LB(counters.alloc(16, s));
+    if (n == 0 || !scratch) return hipErrorInvalidValue;
+    // working set: 15 device buffers, kept by the caller across the meshes of a commit (allocating and freeing them per mesh cost a
+    // third of a nine-mesh build: hipFree synchronises the device) and grown when a larger mesh comes along
+    if (scratch->capacity < n) {
+        const size_t c = size_t(n) + n / 4;
+        const size_t sizes[LbvhScratch::BUFFERS] = {c * sizeof(Box6), 32, c * 4, c * 4, c * 4, c * 4, c * 8, c * 8, 2 * c * 4, c * 4, 2 * c * sizeof(Box6),
+                                                    (c + 1) * sizeof(CollapseItem), (c + 1) * sizeof(CollapseItem), 16};
+        for (int k = 0; k < LbvhScratch::BUFFERS; ++k) KJ_LB(scratch->buf[k].alloc(sizes[k], s));
+        scratch->capacity = uint32_t(c);
+    }
+    DevBuf &pbox = scratch->buf[0], &ob = scratch->buf[1], &codes = scratch->buf[2], &ids = scratch->buf[3], &codes2 = scratch->buf[4], &ids2 = scratch->buf[5],
+           &children = scratch->buf[6], &range = scratch->buf[7], &parent = scratch->buf[8], &visits = scratch->buf[9], &nbox = scratch->buf[10], &q0 = scratch->buf[11],
+           &q1 = scratch->buf[12], &counters = scratch->buf[13], &tmp = scratch->tmp;
+    KJ_LB(hipMemsetAsync(visits.p, 0, size_t(n) * 4, s));      // the refit's arrival counters
     const dim3 g((n + 255) / 256), b(256);
     hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, (uint32_t*)ob.p);
     hipLaunchKernelGGL(k_lbvh_prims, g, b, 0, s, d_vertex_buffer, mesh, n, (Box6*)pbox.p, (uint32_t*)ob.p);
     hipLaunchKernelGGL(k_lbvh_morton, g, b, 0, s, (const Box6*)pbox.p, (const uint32_t*)ob.p, n, (uint32_t*)codes.p, (uint32_t*)ids.p);
     size_t tmp_bytes = 0;
     KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t*)codes.p, (uint32_t*)codes2.p, (const uint32_t*)ids.p, (uint32_t*)ids2.p, int(n), 0, 30, s));
-    KJ_LB(tmp.alloc(tmp_bytes ? tmp_bytes : 16, s));
+    if (tmp.bytes < (tmp_bytes ? tmp_bytes : 16)) KJ_LB(tmp.alloc(tmp_bytes ? tmp_bytes : 16, s));
     KJ_LB(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const uint32_t*)codes.p, (uint32_t*)codes2.p, (const uint32_t*)ids.p, (uint32_t*)ids2.p, int(n), 0, 30, s));
     if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, g, b, 0, s, (const uint32_t*)codes2.p, int(n), (uint2*)children.p, (uint2*)range.p, (uint32_t*)parent.p);
     else KJ_LB(hipMemsetAsync(parent.p, 0xff, 8, s));
     hipLaunchKernelGGL(k_lbvh_refit, g, b, 0, s, (const Box6*)pbox.p, (const uint32_t*)ids2.p, int(n), (const uint2*)children.p, (const uint32_t*)parent.p, (uint32_t*)visits.p, (Box6*)nbox.p);
-    // collapse, level by level; counters = {next queue size, nodes allocated, max stack}
-    const uint32_t init_counters[4] = {0u, 1u, 0u, 0u};
+    // collapse, level by level, without a read-back per level: counters = {-, nodes allocated, max stack}; queue_len[l] = items of level l;
+    // level_nodes[l] = nodes allocated before level l's children (a level's nodes are one contiguous run). KJ_LBVH_LEVELS levels are
+    // issued blind -- far more than a tree over distinct Morton codes needs (13 for 250 k triangles) --, then ONE read-back; a deeper
+    // tree (many coincident centroids) continues level by level with a read-back each.
+    constexpr uint32_t KJ_LBVH_LEVELS = 40;
+    DevBuf &queue_len = scratch->queue_len, &level_nodes = scratch->level_nodes;
+    KJ_LB(queue_len.alloc((KJ_LBVH_LEVELS + 2) * 4, s)); KJ_LB(level_nodes.alloc((KJ_LBVH_LEVELS + 2) * 4, s));      // (no-ops after the first mesh)
+    KJ_LB(hipMemsetAsync(queue_len.p, 0, (KJ_LBVH_LEVELS + 2) * 4, s)); KJ_LB(hipMemsetAsync(level_nodes.p, 0, (KJ_LBVH_LEVELS + 2) * 4, s));
+    const uint32_t init_counters[4] = {0u, 1u, 0u, 0u}, one = 1u;
     const CollapseItem root{0u, 0u, 0u};
     KJ_LB(hipMemcpyAsync(counters.p, init_counters, 16, hipMemcpyHostToDevice, s));
+    KJ_LB(hipMemcpyAsync(queue_len.p, &one, 4, hipMemcpyHostToDevice, s));
+    KJ_LB(hipMemcpyAsync((uint32_t*)level_nodes.p + 1, &one, 4, hipMemcpyHostToDevice, s));      // level 0 = the root = node 0
     KJ_LB(hipMemcpyAsync(q0.p, &root, sizeof(root), hipMemcpyHostToDevice, s));
-    KJ_LB(hipStreamSynchronize(s));
-    uint32_t in_count = 1;
     DevBuf* qin = &q0; DevBuf* qout = &q1;
-    uint32_t host_counters[4] = {0, 1, 0, 0};
-    result->level_starts.assign({0u, 1u});       // a level's nodes are allocated while the level above is collapsed: each level is one contiguous run
-    while (in_count) {
-        hipLaunchKernelGGL(k_lbvh_collapse, dim3((in_count + 63) / 64), dim3(64), 0, s, int(n), (const uint2*)children.p, (const uint2*)range.p, (const Box6*)nbox.p, (const CollapseItem*)qin->p, in_count,
-                           (CollapseItem*)qout->p, (uint32_t*)counters.p, d_nodes_out, node_base);
+    uint64_t bound = 1;
+    for (uint32_t level = 0; level < KJ_LBVH_LEVELS; ++level) {
+        const uint32_t items = uint32_t(std::min<uint64_t>(bound, n));
+        hipLaunchKernelGGL(k_lbvh_collapse, dim3(std::min(4096u, (items + 63) / 64)), dim3(64), 0, s, int(n), (const uint2*)children.p, (const uint2*)range.p, (const Box6*)nbox.p,
+                           (const CollapseItem*)qin->p, (uint32_t*)queue_len.p, level, (CollapseItem*)qout->p, (uint32_t*)counters.p, d_nodes_out, node_base);
+        hipLaunchKernelGGL(k_lbvh_level_end, dim3(1), dim3(1), 0, s, (const uint32_t*)counters.p, (uint32_t*)level_nodes.p, level + 1);
+        bound = std::min<uint64_t>(bound * 4, uint64_t(n));
+        std::swap(qin, qout);
+    }
+    uint32_t host_counters[4] = {0, 1, 0, 0}, host_levels[KJ_LBVH_LEVELS + 2], host_queue[KJ_LBVH_LEVELS + 2];
+    KJ_LB(hipMemcpyAsync(host_levels, level_nodes.p, sizeof(host_levels), hipMemcpyDeviceToHost, s));
+    KJ_LB(hipMemcpyAsync(host_queue, queue_len.p, sizeof(host_queue), hipMemcpyDeviceToHost, s));
+    KJ_LB(hipMemcpyAsync(host_counters, counters.p, 16, hipMemcpyDeviceToHost, s));
+    KJ_LB(hipStreamSynchronize(s));
+    result->level_starts.assign({0u});
+    for (uint32_t l = 1; l <= KJ_LBVH_LEVELS + 1; ++l)
+        if (host_levels[l] > result->level_starts.back()) result->level_starts.push_back(host_levels[l]);
+    uint32_t in_count = host_queue[KJ_LBVH_LEVELS];
+    while (in_count) {      // deeper than the blind part: one level at a time
+        const uint32_t lens[2] = {in_count, 0u};
+        KJ_LB(hipMemcpyAsync(queue_len.p, lens, 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_lbvh_collapse, dim3(std::min(4096u, (in_count + 63) / 64)), dim3(64), 0, s, int(n), (const uint2*)children.p, (const uint2*)range.p, (const Box6*)nbox.p,
+                           (const CollapseItem*)qin->p, (uint32_t*)queue_len.p, 0u, (CollapseItem*)qout->p, (uint32_t*)counters.p, d_nodes_out, node_base);
+        KJ_LB(hipMemcpyAsync(host_queue, queue_len.p, 8, hipMemcpyDeviceToHost, s));
         KJ_LB(hipMemcpyAsync(host_counters, counters.p, 16, hipMemcpyDeviceToHost, s));
         KJ_LB(hipStreamSynchronize(s));
-        in_count = host_counters[0];
+        in_count = host_queue[1];
         if (host_counters[1] > result->level_starts.back()) result->level_starts.push_back(host_counters[1]);
-        const uint32_t zero = 0;
-        KJ_LB(hipMemcpyAsync(counters.p, &zero, 4, hipMemcpyHostToDevice, s));
         std::swap(qin, qout);
     }
     hipLaunchKernelGGL(k_lbvh_emit_tris, g, b, 0, s, d_vertex_buffer, mesh, (const uint32_t*)ids2.p, n, d_tris_out);

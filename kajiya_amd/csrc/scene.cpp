@@ -273,6 +273,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         std::swap(pool.p, bigger.p); std::swap(pool.bytes, bigger.bytes);
         return e;
     };
+    LbvhScratch lbvh_scratch;     // device-side builds of this commit share their working buffers
     for (uint32_t mi = 0; mi < s->meshes.size(); ++mi) {
         KjScene::Blas& bl = s->blas[mi];
         if (bl.built) continue;
@@ -284,7 +285,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
             KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), size_t(s->blas_nodes_used + ntri + 1) * sizeof(BvhNode)));
             KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), size_t(s->obj_tris_used + ntri) * sizeof(BvhTri)));
             LbvhResult lr;
-            KJ_TRY_HIP(build_blas_lbvh_device((const uint8_t*)s->d_vertex_buffer.p, m, bl.node_base, (Bvh4Node*)s->d_blas_nodes.p + bl.node_base, (BvhTri*)s->d_obj_tris.p + bl.tri_base, &lr, stream));
+            KJ_TRY_HIP(build_blas_lbvh_device((const uint8_t*)s->d_vertex_buffer.p, m, bl.node_base, (Bvh4Node*)s->d_blas_nodes.p + bl.node_base, (BvhTri*)s->d_obj_tris.p + bl.tri_base, &lr, &lbvh_scratch, stream));
             bl.node_count = lr.node_count; bl.max_stack = lr.max_stack;
             memcpy(bl.bounds, lr.bounds, 24);
             // laid out by depth on the device: the refit walks the levels deepest first, the root is node 0
