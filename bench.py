@@ -147,7 +147,14 @@ def main():
             for r in range(1, nsplit):
                 split_pipes[r] = lib.GpuPipeline(dev, scene, W, H, device=f"cuda:{local_rank}", use_ircache=True)
             comm = multigpu.LocalComm(nsplit)
-        split = multigpu.SplitRtdgi(comm, split_pipes, W, H, motion_halo=args.motion_halo)
+        if os.environ.get("KJ_SPLIT_NATIVE") == "1":
+            # opt-in: the compiled orchestrator (csrc/split.cpp) with its own RCCL communicator -- one packed ncclSend / ncclRecv per peer
+            # and exchange point. Bit-exact against the Python orchestrator on virtual ranks; its RCCL transport has never run (no
+            # multi-GPU node in the build environment), hence not the default.
+            nccl = multigpu.NativeSplit.rccl_comm_from_torch(dist, rank, world, f"cuda:{local_rank}") if world > 1 else None
+            split = multigpu.NativeSplit(nsplit, split_pipes, W, H, motion_halo=args.motion_halo, nccl_comm=nccl)
+        else:
+            split = multigpu.SplitRtdgi(comm, split_pipes, W, H, motion_halo=args.motion_halo)
     single = split is None
 
     # ---- pre-generate the inputs of every frame (resident in HBM before the timed region; replicated on every rank)
@@ -305,12 +312,34 @@ def main():
             seg["taa"] += ev[4].elapsed_time(ev5)
         seg = {k: round(v / nseg, 4) for k, v in seg.items()} if nseg else None
         # ---- instrumented traversal counters (3 frames: one validation + two tracing frames)
+        # The frame is issued in two parts so that the TRACE kernel's own rays can be told from the validate kernel's (the per-frame ray
+        # counters cover both): everything up to the validate pass, read the counters, the rest, read them again.
         gp.set_profiling(False, True)
-        trav = None
+        trav, trace_only = None, None
+        Pm = lib.KJ_RTDGI_PASS
+        head_mask = Pm["EXTRACT_HALF"] | Pm["VALIDATE"]
         for i in range(base + args.profile_frames, base + args.profile_frames + 3):
-            step(i)
-            torch.cuda.synchronize()
-            c = gp.traversal_counts()
+            if single:
+                gn, gb, d, rp = inputs[i]
+                dev.frame_begin(fcs[i])
+                gp.geometric_normal, gp.gbuffer, gp.depth = gn, gb, d
+                gp.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+                if use_ssgi:
+                    gp.ssgi_frame()
+                gp.gi_frame(head_mask)
+                torch.cuda.synchronize()
+                a = gp.traversal_counts()
+                prm = gp.params((Pm["ALL"] & ~head_mask) | (1 << 31))
+                lib.check(gp.L.kj_rtdgi_render(gp.rtdgi, C.byref(prm), C.byref(gp.out), None))
+                gp.taa_frame()
+                torch.cuda.synchronize()
+                c = gp.traversal_counts()
+                t_only = {k: c[k] - a[k] for k in c}
+                trace_only = t_only if trace_only is None else {k: trace_only[k] + t_only[k] for k in c}
+            else:
+                step(i)
+                torch.cuda.synchronize()
+                c = gp.traversal_counts()
             trav = c if trav is None else {k: trav[k] + c[k] for k in c}
         gp.set_profiling(False, False)
 
@@ -328,11 +357,17 @@ def main():
         # use the per-frame average of the timed region minus the validate kernel's share (1/3 of frames run validate).
         closest_per_frame = local_closest / K
         any_per_frame = local_any / K
-        trace_share = 1.0 / (1.0 + 1.0 / 3.0)  # validate kernel traces the same count on every 3rd frame
-        bytes_per_closest = nodes_per_closest * 64 + tris_per_closest * 48 + 232
-        bytes_per_any = nodes_per_any * 64 + tris_per_any * 48
         strip_frac = 1.0 / max(1, nsplit)
-        trace_bytes = hw * hh * 38 * strip_frac + trace_share * (closest_per_frame * bytes_per_closest + any_per_frame * bytes_per_any)
+        if trace_only is not None:      # the trace kernel's own rays and its own nodes / triangles, counted (3 instrumented frames)
+            ray_bytes = (trace_only["closest_nodes"] + trace_only["any_nodes"]) * 64 + (trace_only["closest_tris"] + trace_only["any_tris"]) * 48 + trace_only["closest_rays"] * 232
+            trace_bytes = hw * hh * 38 * strip_frac + ray_bytes / 3.0
+            trace_rays_note = {"trace_kernel_closest_rays_per_launch": round(trace_only["closest_rays"] / 3.0, 1), "trace_kernel_any_rays_per_launch": round(trace_only["any_rays"] / 3.0, 1)}
+        else:                           # split runs: the validate kernel traces about a third as many rays per frame as the trace kernel
+            trace_share = 1.0 / (1.0 + 1.0 / 3.0)
+            bytes_per_closest = nodes_per_closest * 64 + tris_per_closest * 48 + 232
+            bytes_per_any = nodes_per_any * 64 + tris_per_any * 48
+            trace_bytes = hw * hh * 38 * strip_frac + trace_share * (closest_per_frame * bytes_per_closest + any_per_frame * bytes_per_any)
+            trace_rays_note = {"trace_kernel_ray_share": "estimated 0.75 of the frame's rays (split run)"}
         trace_ms = pass_ms[3]
         achieved = trace_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         # ---- per-kernel rooflines. `achieved` = ALGORITHMIC bytes (every input texel read once + every output written
@@ -377,6 +412,7 @@ def main():
         roofline.update({"traffic_source": "profiles/pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md)" if roofline["traffic"] else None,
                          "nodes_per_closest_ray": round(nodes_per_closest, 2), "tris_per_closest_ray": round(tris_per_closest, 2),
                          "nodes_per_any_ray": round(nodes_per_any, 2), "tris_per_any_ray": round(tris_per_any, 2), "dominant_by_time": dom_name})
+        roofline.update(trace_rays_note)
         roofline_all = [roofline] + [entry(kern, pass_ms[lib.GpuPipeline.PASS_NAMES.index(pname)], units * bpu) for pname, kern, units, bpu in table]
         if seg:
             roofline_all.append(entry("taa (7 kernels)", seg["taa"], W * H * 224, "segment: sum of the seven TAA launches"))

@@ -554,6 +554,42 @@ KjStatus kj_motion_blur_render(KjMotionBlur* m, const void* input_rgba16f, uint3
                                uint32_t depth_width, uint32_t depth_height, const void** out_rgba16f, void* stream);
 KjStatus kj_motion_blur_surface(KjMotionBlur* m, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 
+/* ---------------------------------------------------------------------------
+ * Screen-tile split across the GPUs of a node (north star: "partition across the GPUs of one node by screen-space tile with
+ * a halo exchange of reservoirs / history over RCCL / xGMI"). The reference has no counterpart: kajiya renders on one GPU; what is split
+ * is RtdgiRenderer::render (rtdgi.rs:173-554) + TaaRenderer::render (taa.rs:41-191) of ONE frame, pass by pass, with the irradiance
+ * cache replicated and kept bit-identical across ranks (kj_ircache_set_deferred_updates). KjSplit is the compiled orchestrator:
+ * one per process, created over the renderers of the ranks living in that process -- exactly one with an RCCL communicator
+ * (`nccl_comm`, an ncclComm_t), or all `world` of them without (virtual ranks on one device: the exchange is device-to-device copies).
+ * It calls the entry points above with row ranges and exchanges halos in between: one packed message per peer and exchange point,
+ * ncclSend / ncclRecv inside one group. kajiya_amd/multigpu.py is the reference implementation of the same schedule.
+ * Strips are 16-row aligned; surfaces are looked up by name through kj_rtdgi_surface / kj_taa_surface. RCCL is loaded with dlopen on
+ * first use: kj_split_rccl_* bootstrap a communicator from a 128-byte id the caller broadcasts by its own means.
+ * --------------------------------------------------------------------------- */
+typedef struct KjSplit KjSplit;
+typedef struct KjSplitRank { KjRtdgi* rtdgi; KjTaa* taa; KjIrcache* ircache /* NULL: cache unbound */; KjScene* scene; } KjSplitRank;
+typedef struct KjSplitFrame {            /* one rank's inputs of a frame */
+    KjRtdgiRenderParams rtdgi;           /* as for kj_rtdgi_render; pass_mask, row_begin / row_end and spatial_pass_select are overwritten */
+    KjRtdgiOutput* rtdgi_out;
+    KjTaaOutput* taa_out;
+    const void* sky_cube16;              /* convolved cube for kj_ircache_trace_irradiance (unused when the cache's passes ran already) */
+} KjSplitFrame;
+KjStatus kj_split_create(uint32_t world, uint32_t first_rank, uint32_t local_ranks, const KjSplitRank* ranks, uint32_t width, uint32_t height,
+                         uint32_t motion_halo /* rows of history exchanged beyond the stencils: >= max |screen motion| per frame */, void* nccl_comm, KjSplit** out);
+void kj_split_destroy(KjSplit* split);
+KjStatus kj_split_strip(KjSplit* split, uint32_t rank, uint32_t* out_row_begin, uint32_t* out_row_end);
+/* One GI frame: [cache prepare + rays unless ircache_done], reproject, the rtdgi passes with exchanges A-D and H, the merged replay of the
+ * cache's recorded updates. `frames`: one entry per LOCAL rank. `trace_done_event`: optional hipEvent_t recorded once the ray passes (and
+ * the cache replay) are enqueued -- where a caller may start the next frame's cache work on another stream. */
+KjStatus kj_split_gi_frame(KjSplit* split, const KjSplitFrame* frames, uint32_t ircache_done, void* trace_done_event, void* stream);
+/* TAA on the GI output of the frame just rendered (exchange I + strip-wise TaaRenderer::render). */
+KjStatus kj_split_taa_frame(KjSplit* split, const KjSplitFrame* frames, void* stream);
+/* Every rank receives the owners' rows of a surface ("spatial_filtered_tex", "TAA/taa:0", ...): result collection. */
+KjStatus kj_split_gather(KjSplit* split, const char* surface_name, void* stream);
+KjStatus kj_split_rccl_unique_id(uint8_t out_id[128]);
+KjStatus kj_split_rccl_comm_create(const uint8_t id[128], uint32_t world, uint32_t rank, void** out_comm);
+void kj_split_rccl_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,14 @@ class KjTaaOutput(C.Structure):
     _fields_ = [("temporal_out", C.c_void_p), ("this_frame_out", C.c_void_p)]
 
 
+class KjSplitRank(C.Structure):
+    _fields_ = [("rtdgi", C.c_void_p), ("taa", C.c_void_p), ("ircache", C.c_void_p), ("scene", C.c_void_p)]
+
+
+class KjSplitFrame(C.Structure):
+    _fields_ = [("rtdgi", KjRtdgiRenderParams), ("rtdgi_out", C.POINTER(KjRtdgiOutput)), ("taa_out", C.POINTER(KjTaaOutput)), ("sky_cube16", C.c_void_p)]
+
+
 class KjRtrTables(C.Structure):
     _fields_ = [("ranking_tile", C.c_void_p), ("scrambling_tile", C.c_void_p), ("sobol", C.c_void_p), ("spatial_resolve_offsets", C.c_void_p)]
 

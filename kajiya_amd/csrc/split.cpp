@@ -1,0 +1,429 @@
+// Native orchestrator of the screen-tile split (the compiled counterpart of kajiya_amd/multigpu.py, which stays the
+// reference implementation it is tested against: tests/test_gpu_multigpu.py::test_native_split_*).
+//
+// One KjSplit per process. It owns no renderer state: it is handed the renderers of the ranks that live in this process
+// (one for a real run, all of them for the virtual-rank tests) and drives RtdgiRenderer::render / TaaRenderer::render strip by strip
+// through the same C-ABI a single-GPU caller uses, exchanging halos between passes:
+//   * every rank keeps full-size surfaces; a pass runs on the rank's own full-res rows (16-aligned cuts, so 8x8 half-res tiles never
+//     straddle one), reads reach into the neighbours' rows, and the rows a consumer can reach are fetched from their owners first;
+//   * ONE message per peer and exchange point: the row blocks bound for a peer are packed into a staging buffer (device-to-device
+//     copies on the frame's stream), sent with ncclSend inside one ncclGroup with the matching ncclRecv, and scattered on arrival.
+//     Both ends enumerate (item, destination, source) in the same order, so the packed layouts agree without a header;
+//   * RCCL is resolved with dlopen at the first use (the library has no link-time dependency on it; a single-GPU process never loads
+//     it). With every rank in the process the same packed buffers travel by a device-to-device copy instead.
+// The schedule (which surfaces, how many halo rows, which passes over-compute instead of exchanging) is the one documented in
+// kajiya_amd/multigpu.py and DESIGN 7; the reach of every pass is cited there.
+#include "kj_host.hpp"
+#include "kj_ircache_host.hpp"
+#include <dlfcn.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace kj;
+
+namespace {
+
+struct SurfInfo { uint32_t bytes_per_texel; bool half; };
+// surface name (without the ping-pong suffix) -> texel size and resolution; the split's working set (multigpu.py: SURF / TAA_SURF)
+const std::map<std::string, SurfInfo>& surf_table() {
+    static const std::map<std::string, SurfInfo> t = {
+        {"rtdgi.reservoir", {8, true}}, {"rtdgi.ray_orig", {16, true}}, {"rtdgi.ray", {8, true}}, {"rtdgi.radiance", {8, true}}, {"rtdgi.hit_normal", {8, true}},
+        {"rtdgi.invalidity", {4, true}}, {"rtdgi.candidate", {8, true}}, {"rtdgi.temporal2", {8, false}}, {"rtdgi.temporal2_var", {4, false}},
+        {"rt_history_validity_pre_input_tex", {1, true}}, {"rt_history_validity_input_tex", {1, true}}, {"candidate_radiance_tex", {8, true}},
+        {"candidate_hit_tex", {8, true}}, {"temporal_reservoir_packed_tex", {16, true}}, {"reservoir_output_tex0", {8, true}}, {"reservoir_output_tex1", {8, true}},
+        {"irradiance_output_tex", {8, false}}, {"temporal_filtered_tex", {8, false}}, {"spatial_filtered_tex", {8, false}},
+        {"TAA/taa", {8, false}}, {"TAA/taa.velocity", {4, false}}, {"TAA/taa.smooth_var", {8, false}}, {"TAA/this_frame_output_img", {8, false}},
+    };
+    return t;
+}
+
+// the handful of RCCL entry points the exchange needs, resolved at run time
+struct Rccl {
+    struct Id128 { char b[128]; };      // ncclUniqueId, passed by value
+    void* lib = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        auto sym = [&](const char* n) { return dlsym(lib, n); };
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Send = (decltype(Send))sym("ncclSend"); Recv = (decltype(Recv))sym("ncclRecv"); AllGather = (decltype(AllGather))sym("ncclAllGather");
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId"); CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy"); GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        return GroupStart && GroupEnd && Send && Recv && AllGather && GetUniqueId && CommInitRank && CommDestroy;
+    }
+};
+Rccl g_rccl;
+constexpr int NCCL_UINT8 = 1, NCCL_UINT32 = 3;     // ncclDataType_t (nccl.h): ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3
+
+struct Item { std::string name; int halo; };        // halo < 0: every row (all-gather)
+struct Block { uint32_t src, dst; std::string name; uint32_t row0, row1; };
+
+}  // namespace
+
+struct KjSplit {
+    uint32_t world = 0, first = 0, local = 0, W = 0, H = 0, hw = 0, hh = 0, motion_halo = 8;
+    std::vector<KjSplitRank> ranks;                        // the local ones, rank = first + index
+    std::vector<std::pair<uint32_t, uint32_t>> strips;     // full-res rows [r0, r1) of every rank of the job
+    uint32_t frame = 0, taa_frames = 0;
+    bool consistent_ircache = false;
+    void* nccl = nullptr;                                  // ncclComm_t; null: every rank is local
+    std::map<std::pair<uint32_t, std::string>, std::pair<uint8_t*, uint64_t>> surfaces;     // (local index, name) -> base pointer, bytes
+    std::vector<DevBuf> send_stage, recv_stage;            // [local rank * world + peer]: the packed rows of one exchange
+    // the cache's recorded updates of a frame
+    std::vector<DevBuf> strip_list, irc_list, merged, counts;   // per local rank; counts = two device dwords {strip, cache passes}
+    DevBuf all_counts;                                     // RCCL: every rank's strip count
+    std::vector<DevBuf> peer_lists;                        // RCCL: the other ranks' strip lists
+};
+
+namespace {
+
+std::pair<uint32_t, uint32_t> half_rows(const KjSplit& s, std::pair<uint32_t, uint32_t> f) { return {f.first / 2, f.second == s.H ? s.hh : f.second / 2}; }
+
+bool is_local(const KjSplit& s, uint32_t rank) { return rank >= s.first && rank < s.first + s.local; }
+
+const SurfInfo* info_of(const std::string& name) {
+    const std::string base = name.substr(0, name.find(':'));
+    auto it = surf_table().find(base);
+    return it == surf_table().end() ? nullptr : &it->second;
+}
+
+KjStatus surface_of(KjSplit& s, uint32_t rank, const std::string& name, uint8_t** out, uint32_t* row_bytes) {
+    const SurfInfo* si = info_of(name);
+    KJ_REQUIRE(si && is_local(s, rank), "unknown surface / rank not in this process");
+    const uint32_t li = rank - s.first;
+    auto key = std::make_pair(li, name);
+    auto it = s.surfaces.find(key);
+    if (it == s.surfaces.end()) {     // renderer surfaces are allocated once per extent: the pointer is stable
+        void* p = nullptr; uint64_t bytes = 0;
+        const KjStatus st = name.rfind("TAA/", 0) == 0 ? kj_taa_surface(s.ranks[li].taa, name.c_str() + 4, &p, &bytes) : kj_rtdgi_surface(s.ranks[li].rtdgi, name.c_str(), &p, &bytes);
+        if (st != KJ_OK) return st;
+        it = s.surfaces.emplace(key, std::make_pair((uint8_t*)p, bytes)).first;
+    }
+    *row_bytes = (si->half ? s.hw : s.W) * si->bytes_per_texel;
+    KJ_REQUIRE(it->second.second == uint64_t(*row_bytes) * (si->half ? s.hh : s.H), "surface extent does not match the split's");
+    *out = it->second.first;
+    return KJ_OK;
+}
+
+// every (source rank, destination rank, rows) so that each rank holds [own0 - halo, own1 + halo) of the surface afterwards
+void plan(const KjSplit& s, const std::vector<Item>& items, std::vector<Block>& out) {
+    for (const Item& it : items) {
+        const SurfInfo* si = info_of(it.name);
+        const uint32_t total = si->half ? s.hh : s.H;
+        for (uint32_t dst = 0; dst < s.world; ++dst) {
+            const auto od = si->half ? half_rows(s, s.strips[dst]) : s.strips[dst];
+            const uint32_t lo = it.halo < 0 ? 0u : uint32_t(std::max<int64_t>(0, int64_t(od.first) - it.halo));
+            const uint32_t hi = it.halo < 0 ? total : std::min<uint32_t>(total, od.second + uint32_t(it.halo));
+            for (uint32_t src = 0; src < s.world; ++src) {
+                if (src == dst) continue;
+                const auto os = si->half ? half_rows(s, s.strips[src]) : s.strips[src];
+                const uint32_t a = std::max(lo, os.first), b = std::min(hi, os.second);
+                if (b > a) out.push_back(Block{src, dst, it.name, a, b});
+            }
+        }
+    }
+}
+
+// ONE batched exchange for all items: pack per (local rank, peer), transport, scatter. Virtual ranks take the same path with a
+// device-to-device copy as the transport, so the packing order and offsets RCCL relies on are what the virtual-rank tests exercise.
+KjStatus exchange(KjSplit& s, const std::vector<Item>& items, hipStream_t st) {
+    if (items.empty() || s.world == 1) return KJ_OK;
+    for (const Item& it : items) KJ_REQUIRE(info_of(it.name), "unknown surface name in an exchange");
+    std::vector<Block> blocks;
+    plan(s, items, blocks);
+    auto row_bytes = [&](const Block& b) { return size_t((info_of(b.name)->half ? s.hw : s.W)) * info_of(b.name)->bytes_per_texel; };
+    // bytes per (local rank, peer), both directions
+    std::vector<std::vector<size_t>> send_bytes(s.local, std::vector<size_t>(s.world, 0)), recv_bytes(s.local, std::vector<size_t>(s.world, 0));
+    for (const Block& b : blocks) {
+        if (is_local(s, b.src)) send_bytes[b.src - s.first][b.dst] += size_t(b.row1 - b.row0) * row_bytes(b);
+        if (is_local(s, b.dst)) recv_bytes[b.dst - s.first][b.src] += size_t(b.row1 - b.row0) * row_bytes(b);
+    }
+    for (uint32_t li = 0; li < s.local; ++li)
+        for (uint32_t p = 0; p < s.world; ++p) {
+            DevBuf &sb = s.send_stage[li * s.world + p], &rbuf = s.recv_stage[li * s.world + p];
+            if (sb.bytes < send_bytes[li][p]) KJ_TRY_HIP(sb.alloc(send_bytes[li][p] + send_bytes[li][p] / 4, st));
+            if (rbuf.bytes < recv_bytes[li][p]) KJ_TRY_HIP(rbuf.alloc(recv_bytes[li][p] + recv_bytes[li][p] / 4, st));
+        }
+    std::vector<std::vector<size_t>> off(s.local, std::vector<size_t>(s.world, 0));
+    for (const Block& b : blocks) {      // pack: the blocks bound for a peer, in plan order
+        if (!is_local(s, b.src)) continue;
+        const uint32_t li = b.src - s.first;
+        uint8_t* ps; uint32_t rb;
+        const KjStatus e = surface_of(s, b.src, b.name, &ps, &rb); if (e != KJ_OK) return e;
+        const size_t n = size_t(b.row1 - b.row0) * rb;
+        KJ_TRY_HIP(hipMemcpyAsync((uint8_t*)s.send_stage[li * s.world + b.dst].p + off[li][b.dst], ps + size_t(b.row0) * rb, n, hipMemcpyDeviceToDevice, st));
+        off[li][b.dst] += n;
+    }
+    if (s.nccl) {       // one message per peer, all of them in one group
+        KJ_REQUIRE(g_rccl.GroupStart() == 0, "ncclGroupStart failed");
+        for (uint32_t p = 0; p < s.world; ++p) {
+            if (send_bytes[0][p]) KJ_REQUIRE(g_rccl.Send(s.send_stage[p].p, send_bytes[0][p], NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclSend failed");
+            if (recv_bytes[0][p]) KJ_REQUIRE(g_rccl.Recv(s.recv_stage[p].p, recv_bytes[0][p], NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclRecv failed");
+        }
+        KJ_REQUIRE(g_rccl.GroupEnd() == 0, "ncclGroupEnd failed");
+    } else {            // every rank lives here: the "wire" is a copy from the sender's staging buffer to the receiver's
+        for (uint32_t src = 0; src < s.world; ++src)
+            for (uint32_t dst = 0; dst < s.world; ++dst)
+                if (send_bytes[src][dst]) {
+                    KJ_REQUIRE(send_bytes[src][dst] == recv_bytes[dst][src], "packed sizes disagree between the two ends of an exchange");
+                    KJ_TRY_HIP(hipMemcpyAsync(s.recv_stage[dst * s.world + src].p, s.send_stage[src * s.world + dst].p, send_bytes[src][dst], hipMemcpyDeviceToDevice, st));
+                }
+    }
+    for (auto& o : off) std::fill(o.begin(), o.end(), 0);
+    for (const Block& b : blocks) {      // scatter, in the same order
+        if (!is_local(s, b.dst)) continue;
+        const uint32_t li = b.dst - s.first;
+        uint8_t* pd; uint32_t rb;
+        const KjStatus e = surface_of(s, b.dst, b.name, &pd, &rb); if (e != KJ_OK) return e;
+        const size_t n = size_t(b.row1 - b.row0) * rb;
+        KJ_TRY_HIP(hipMemcpyAsync(pd + size_t(b.row0) * rb, (const uint8_t*)s.recv_stage[li * s.world + b.src].p + off[li][b.src], n, hipMemcpyDeviceToDevice, st));
+        off[li][b.src] += n;
+    }
+    return KJ_OK;
+}
+
+std::pair<uint32_t, uint32_t> grow(const KjSplit& s, uint32_t rank, uint32_t rows) {
+    const auto f = s.strips[rank];
+    return {f.first > rows ? f.first - rows : 0u, std::min(s.H, f.second + rows)};
+}
+
+KjStatus render(KjSplit& s, uint32_t li, const KjSplitFrame& fr, uint32_t mask, std::pair<uint32_t, uint32_t> rows, uint32_t spatial_select, hipStream_t st) {
+    KjRtdgiRenderParams p = fr.rtdgi;
+    p.pass_mask = mask;
+    p.row_begin = rows.first; p.row_end = rows.second;
+    p.spatial_pass_select = spatial_select;
+    return kj_rtdgi_render(s.ranks[li].rtdgi, &p, fr.rtdgi_out, st);
+}
+
+KjStatus ircache_head(KjSplit& s, uint32_t li, const KjSplitFrame& fr, hipStream_t st) {
+    KjIrcache* c = s.ranks[li].ircache;
+    KjStatus e;
+    if (s.consistent_ircache && (e = kj_ircache_begin_requests(c, s.hw, s.hh, st)) != KJ_OK) return e;
+    if ((e = kj_ircache_prepare(c, st)) != KJ_OK) return e;
+    return kj_ircache_trace_irradiance(c, s.ranks[li].scene, fr.sky_cube16, 16, st);
+}
+
+// All-gather of this frame's recorded cache updates, then the same replay on every rank. A strip's rtdgi lookups (validate and trace
+// pass) occupy contiguous slots (rows of the half-res image); the cache's own ray passes are replicated, so their records are identical
+// on every rank and stay local. Merged order = every rank's strip records in rank order, then the cache's own (multigpu.py).
+KjStatus merge_ircache_requests(KjSplit& s, hipStream_t st) {
+    const size_t RQ = 32;
+    std::vector<uint32_t> n_strip(s.local), n_irc(s.local), cap_strip(s.local), cap_irc(s.local);
+    for (uint32_t li = 0; li < s.local; ++li) {
+        KjIrcache* c = s.ranks[li].ircache;
+        uint32_t first[4], count[4];
+        KjStatus e = kj_ircache_request_ranges(c, first, count); if (e != KJ_OK) return e;
+        const auto h = half_rows(s, s.strips[s.first + li]);
+        const uint32_t px = (h.second - h.first) * s.hw;
+        cap_strip[li] = 2 * px; cap_irc[li] = count[2] + count[3];
+        if (s.strip_list[li].bytes < size_t(cap_strip[li]) * RQ) KJ_TRY_HIP(s.strip_list[li].alloc(size_t(cap_strip[li]) * RQ, st));
+        if (s.irc_list[li].bytes < size_t(cap_irc[li]) * RQ) KJ_TRY_HIP(s.irc_list[li].alloc(size_t(cap_irc[li]) * RQ, st));
+        if (!s.counts[li].p) KJ_TRY_HIP(s.counts[li].alloc(8, st));
+        KJ_TRY_HIP(hipMemsetAsync(s.counts[li].p, 0, 8, st));
+        uint32_t* cnt = (uint32_t*)s.counts[li].p;
+        if ((e = kj_ircache_collect_requests(c, first[0] + h.first * s.hw, px, s.strip_list[li].p, cap_strip[li], cnt, st)) != KJ_OK) return e;
+        if ((e = kj_ircache_collect_requests(c, first[1] + h.first * s.hw, px, s.strip_list[li].p, cap_strip[li], cnt, st)) != KJ_OK) return e;
+        if ((e = kj_ircache_collect_requests(c, first[2], count[2], s.irc_list[li].p, cap_irc[li], cnt + 1, st)) != KJ_OK) return e;
+        if ((e = kj_ircache_collect_requests(c, first[3], count[3], s.irc_list[li].p, cap_irc[li], cnt + 1, st)) != KJ_OK) return e;
+    }
+    for (uint32_t li = 0; li < s.local; ++li) {
+        uint32_t host[2];
+        KJ_TRY_HIP(hipMemcpyAsync(host, s.counts[li].p, 8, hipMemcpyDeviceToHost, st));
+        KJ_TRY_HIP(hipStreamSynchronize(st));      // the list lengths are needed on the host (as in the reference orchestrator)
+        n_strip[li] = host[0]; n_irc[li] = host[1];
+    }
+    std::vector<uint32_t> all_strip(s.world, 0);
+    if (!s.nccl) for (uint32_t li = 0; li < s.local; ++li) all_strip[li] = n_strip[li];
+    else {
+        if (!s.all_counts.p) KJ_TRY_HIP(s.all_counts.alloc(size_t(s.world) * 4, st));
+        KJ_REQUIRE(g_rccl.AllGather(s.counts[0].p, s.all_counts.p, 1, NCCL_UINT32, s.nccl, st) == 0, "ncclAllGather failed");
+        KJ_TRY_HIP(hipMemcpyAsync(all_strip.data(), s.all_counts.p, size_t(s.world) * 4, hipMemcpyDeviceToHost, st));
+        KJ_TRY_HIP(hipStreamSynchronize(st));
+        const uint32_t me = s.first;
+        for (uint32_t p = 0; p < s.world; ++p)
+            if (p != me && s.peer_lists[p].bytes < size_t(all_strip[p]) * RQ) KJ_TRY_HIP(s.peer_lists[p].alloc(size_t(all_strip[p]) * RQ + 4096, st));
+        KJ_REQUIRE(g_rccl.GroupStart() == 0, "ncclGroupStart failed");
+        for (uint32_t p = 0; p < s.world; ++p) {
+            if (p == me) continue;
+            if (all_strip[me]) KJ_REQUIRE(g_rccl.Send(s.strip_list[0].p, size_t(all_strip[me]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclSend failed");
+            if (all_strip[p]) KJ_REQUIRE(g_rccl.Recv(s.peer_lists[p].p, size_t(all_strip[p]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclRecv failed");
+        }
+        KJ_REQUIRE(g_rccl.GroupEnd() == 0, "ncclGroupEnd failed");
+    }
+    size_t total_strip = 0;
+    for (uint32_t p = 0; p < s.world; ++p) total_strip += all_strip[p];
+    for (uint32_t li = 0; li < s.local; ++li) {
+        const size_t total = total_strip + n_irc[li];
+        if (s.merged[li].bytes < std::max<size_t>(total, 1) * RQ) KJ_TRY_HIP(s.merged[li].alloc(std::max<size_t>(total, 1) * RQ + total * RQ / 4, st));
+        size_t off = 0;
+        for (uint32_t p = 0; p < s.world; ++p) {
+            const void* src = is_local(s, p) ? s.strip_list[p - s.first].p : s.peer_lists[p].p;
+            if (all_strip[p]) KJ_TRY_HIP(hipMemcpyAsync((uint8_t*)s.merged[li].p + off, src, size_t(all_strip[p]) * RQ, hipMemcpyDeviceToDevice, st));
+            off += size_t(all_strip[p]) * RQ;
+        }
+        if (n_irc[li]) KJ_TRY_HIP(hipMemcpyAsync((uint8_t*)s.merged[li].p + off, s.irc_list[li].p, size_t(n_irc[li]) * RQ, hipMemcpyDeviceToDevice, st));
+        const KjStatus e = kj_ircache_apply_requests(s.ranks[li].ircache, s.merged[li].p, uint32_t(total), st);
+        if (e != KJ_OK) return e;
+    }
+    return KJ_OK;
+}
+
+std::string sfx(const char* name, uint32_t k) { return std::string(name) + ":" + std::to_string(k); }
+
+}  // namespace
+
+extern "C" {
+
+KjStatus kj_split_create(uint32_t world, uint32_t first_rank, uint32_t local_ranks, const KjSplitRank* ranks, uint32_t width, uint32_t height, uint32_t motion_halo,
+                         void* nccl_comm, KjSplit** out) {
+    KJ_REQUIRE(out && ranks && world >= 1 && local_ranks >= 1 && first_rank + local_ranks <= world, "bad rank layout");
+    KJ_REQUIRE(nccl_comm ? local_ranks == 1 : local_ranks == world, "without a communicator every rank must live in this process; with one, exactly one does");
+    KJ_REQUIRE(width >= 16 && height >= 16 * world, "image too small for this many strips");
+    if (nccl_comm) KJ_REQUIRE(g_rccl.load(), "librccl.so could not be loaded");
+    KjSplit* s = new KjSplit();
+    s->world = world; s->first = first_rank; s->local = local_ranks; s->W = width; s->H = height; s->hw = (width + 1) / 2; s->hh = (height + 1) / 2;
+    s->motion_halo = motion_halo; s->nccl = nccl_comm;
+    s->ranks.assign(ranks, ranks + local_ranks);
+    // 16-aligned cuts, as even as possible (multigpu.py: plan_strips)
+    const uint32_t units = (height + 15) / 16, base = units / world, extra = units % world;
+    uint32_t u = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        const uint32_t cnt = base + (r < extra ? 1u : 0u);
+        s->strips.push_back({std::min(u * 16, height), std::min((u + cnt) * 16, height)});
+        u += cnt;
+    }
+    bool all_cached = true;
+    for (const KjSplitRank& r : s->ranks) { if (!r.rtdgi || !r.taa || !r.scene) { delete s; KJ_REQUIRE(false, "a rank needs rtdgi, taa and scene handles"); } all_cached &= r.ircache != nullptr; }
+    s->consistent_ircache = all_cached;
+    for (const KjSplitRank& r : s->ranks)
+        if (r.ircache) { const KjStatus e = kj_ircache_set_deferred_updates(r.ircache, all_cached ? 1u : 0u); if (e != KJ_OK) { delete s; return e; } }
+    s->send_stage = std::vector<DevBuf>(size_t(local_ranks) * world); s->recv_stage = std::vector<DevBuf>(size_t(local_ranks) * world); s->peer_lists = std::vector<DevBuf>(world);
+    s->strip_list = std::vector<DevBuf>(local_ranks); s->irc_list = std::vector<DevBuf>(local_ranks); s->merged = std::vector<DevBuf>(local_ranks); s->counts = std::vector<DevBuf>(local_ranks);
+    *out = s;
+    return KJ_OK;
+}
+void kj_split_destroy(KjSplit* s) { delete s; }
+
+KjStatus kj_split_strip(KjSplit* s, uint32_t rank, uint32_t* out_row_begin, uint32_t* out_row_end) {
+    KJ_REQUIRE(s && rank < s->world && out_row_begin && out_row_end, "bad argument");
+    *out_row_begin = s->strips[rank].first; *out_row_end = s->strips[rank].second;
+    return KJ_OK;
+}
+
+#define KJ_SPLIT_TRY(expr) do { const KjStatus e_ = (expr); if (e_ != KJ_OK) return e_; } while (0)
+
+// One rtdgi frame (multigpu.py: SplitRtdgi.gi_frame). `frames`: one entry per local rank.
+KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t ircache_done, void* trace_done_event, void* stream) {
+    KJ_REQUIRE(s && frames, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t KEEP = KJ_RTDGI_PASS_KEEP_TEMPORALS, M = s->motion_halo;
+    const uint32_t out_i = s->frame % 2, hist_i = 1 - s->frame % 2;
+    std::vector<Item> items;
+    // ---- A: last frame's denoised GI everywhere (the trace pass reads it at the hit's screen position); TAA's histories (motion halo)
+    if (s->frame > 0) { items.push_back({sfx("rtdgi.temporal2", hist_i), -1}); items.push_back({sfx("rtdgi.temporal2_var", hist_i), -1}); }
+    if (s->taa_frames > 0) {
+        const uint32_t th = 1 - s->taa_frames % 2;
+        items.push_back({sfx("TAA/taa", th), int(M + 4 + 32)}); items.push_back({sfx("TAA/taa.velocity", th), int(M + 2 + 16)}); items.push_back({sfx("TAA/taa.smooth_var", th), int(M + 2 + 16)});
+    }
+    KJ_SPLIT_TRY(exchange(*s, items, st));
+    for (uint32_t li = 0; li < s->local; ++li) {
+        const KjSplitRank& r = s->ranks[li];
+        if (r.ircache && !ircache_done) KJ_SPLIT_TRY(ircache_head(*s, li, frames[li], st));
+        KJ_SPLIT_TRY(kj_rtdgi_reproject(r.rtdgi, frames[li].rtdgi.reprojection_map, s->W, s->H, st));
+        if (r.ircache) KJ_SPLIT_TRY(kj_ircache_sum_up_irradiance_for_sampling(r.ircache, st));
+        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_EXTRACT_HALF, {0, 0}, 0, st));      // replicated inputs: full frame, cheap
+        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_VALIDATE | KEEP, s->strips[s->first + li], 0, st));
+    }
+    // ---- B: validate rewrites the reservoir histories in place
+    items.clear();
+    items.push_back({"rt_history_validity_pre_input_tex", int(M + 1)});
+    if (s->frame > 0) {
+        for (const char* n : {"rtdgi.reservoir", "rtdgi.ray_orig", "rtdgi.ray", "rtdgi.radiance", "rtdgi.hit_normal"}) items.push_back({sfx(n, hist_i), int(M + 4)});
+        items.push_back({sfx("rtdgi.invalidity", hist_i), int(M + 8)});
+    }
+    KJ_SPLIT_TRY(exchange(*s, items, st));
+    for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_TRACE | KEEP, s->strips[s->first + li], 0, st));
+    if (s->consistent_ircache) KJ_SPLIT_TRY(merge_ircache_requests(*s, st));
+    if (trace_done_event) KJ_TRY_HIP(hipEventRecord((hipEvent_t)trace_done_event, st));
+    // ---- C
+    KJ_SPLIT_TRY(exchange(*s, {{"rt_history_validity_input_tex", 2}, {"candidate_radiance_tex", 8 + 3}, {"candidate_hit_tex", 8 + 3}}, st));
+    for (uint32_t li = 0; li < s->local; ++li) {
+        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_VALIDITY_INTEGRATE | KEEP, s->strips[s->first + li], 0, st));
+        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_RESTIR_TEMPORAL | KEEP, s->strips[s->first + li], 0, st));
+    }
+    // ---- D: the one-deep halo; the spatial passes and the resolve over-compute inside it instead of exchanging again
+    KJ_SPLIT_TRY(exchange(*s, {{sfx("rtdgi.reservoir", out_i), 64}, {"temporal_reservoir_packed_tex", 64}, {sfx("rtdgi.radiance", out_i), 64}}, st));
+    for (uint32_t li = 0; li < s->local; ++li) {
+        const uint32_t rank = s->first + li;
+        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_RESTIR_SPATIAL | KEEP, grow(*s, rank, 64), 1, st));
+        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_RESTIR_SPATIAL | KEEP, grow(*s, rank, 32), 2, st));
+        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_RESTIR_RESOLVE | KEEP, grow(*s, rank, 16), 0, st));
+        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_TEMPORAL_FILTER | KEEP, s->strips[rank], 0, st));
+    }
+    // ---- H
+    KJ_SPLIT_TRY(exchange(*s, {{"temporal_filtered_tex", 16}}, st));
+    for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_SPATIAL_FILTER | KEEP, s->strips[s->first + li], 0, st));
+    s->frame++;
+    return KJ_OK;
+}
+
+// TaaRenderer::render on this frame's GI image, strip by strip (multigpu.py: SplitRtdgi.taa_frame): one exchange (the input's halo;
+// the three histories travelled with exchange A of gi_frame), the intermediates over-computed on up to 32 extra rows per side.
+KjStatus kj_split_taa_frame(KjSplit* s, const KjSplitFrame* frames, void* stream) {
+    KJ_REQUIRE(s && frames, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    KJ_SPLIT_TRY(exchange(*s, {{"spatial_filtered_tex", 1 + 24}}, st));
+    for (uint32_t li = 0; li < s->local; ++li) {
+        const uint32_t rank = s->first + li;
+        uint8_t* inp; uint32_t rb;
+        KJ_SPLIT_TRY(surface_of(*s, rank, "spatial_filtered_tex", &inp, &rb));
+        const struct { uint32_t mask, grow; bool keep; } steps[5] = {{1, 32, false}, {2 | 4, 24, true}, {8, 16, true}, {16, 8, true}, {32 | 64, 0, true}};
+        for (const auto& stp : steps) {
+            const auto rows = grow(*s, rank, stp.grow);
+            KJ_SPLIT_TRY(kj_taa_render_rows(s->ranks[li].taa, inp, s->W, s->H, frames[li].rtdgi.reprojection_map, frames[li].rtdgi.gbuffer_depth.depth, s->W, s->H, frames[li].taa_out, st,
+                                            stp.mask | (stp.keep ? KJ_RTDGI_PASS_KEEP_TEMPORALS : 0u), rows.first, rows.second));
+        }
+    }
+    s->taa_frames++;
+    return KJ_OK;
+}
+
+// Assemble a full image on every rank from the owners' rows (result collection; not part of a timed frame).
+KjStatus kj_split_gather(KjSplit* s, const char* surface_name, void* stream) {
+    KJ_REQUIRE(s && surface_name, "null argument");
+    return exchange(*s, {{surface_name, -1}}, (hipStream_t)stream);
+}
+
+// RCCL bootstrap without a link-time dependency: rank 0 makes the id, the caller broadcasts its 128 bytes by whatever means it has
+// (torch.distributed, MPI, a file), every rank turns it into a communicator.
+KjStatus kj_split_rccl_unique_id(uint8_t out_id[128]) {
+    KJ_REQUIRE(out_id, "null argument");
+    KJ_REQUIRE(g_rccl.load(), "librccl.so could not be loaded");
+    KJ_REQUIRE(g_rccl.GetUniqueId(out_id) == 0, "ncclGetUniqueId failed");
+    return KJ_OK;
+}
+KjStatus kj_split_rccl_comm_create(const uint8_t id[128], uint32_t world, uint32_t rank, void** out_comm) {
+    KJ_REQUIRE(id && out_comm && rank < world, "bad argument");
+    KJ_REQUIRE(g_rccl.load(), "librccl.so could not be loaded");
+    Rccl::Id128 v; memcpy(v.b, id, 128);
+    KJ_REQUIRE(g_rccl.CommInitRank(out_comm, int(world), v, int(rank)) == 0, "ncclCommInitRank failed");
+    return KJ_OK;
+}
+void kj_split_rccl_comm_destroy(void* comm) { if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm); }
+
+}  // extern "C"

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import numpy as np
 
-from .abi import (KjFrameConstants, KjMeshDesc, KjGbufferDepth, KjRtdgiRenderParams, KjRtdgiOutput, KjTaaOutput, KJ_RTDGI_PASS, KjRtrTables, KjRtrParams)
+from .abi import (KjFrameConstants, KjMeshDesc, KjGbufferDepth, KjRtdgiRenderParams, KjRtdgiOutput, KjTaaOutput, KJ_RTDGI_PASS, KjRtrTables, KjRtrParams, KjSplitRank, KjSplitFrame)
 from . import scenes as kscenes
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -32,6 +32,8 @@ EXPORTS = [
     "kj_rtr_create", "kj_rtr_destroy", "kj_rtr_set_options", "kj_rtr_trace", "kj_rtr_render_specular_lights", "kj_rtr_filter_temporal", "kj_rtr_surface", "kj_rtr_ray_counts",
     "kj_post_create", "kj_post_destroy", "kj_post_render", "kj_post_read_back_histogram", "kj_luminance_histogram_mean_log2", "kj_post_surface", "kj_post_mip_levels",
     "kj_motion_blur_create", "kj_motion_blur_destroy", "kj_motion_blur_render", "kj_motion_blur_surface",
+    "kj_split_create", "kj_split_destroy", "kj_split_strip", "kj_split_gi_frame", "kj_split_taa_frame", "kj_split_gather",
+    "kj_split_rccl_unique_id", "kj_split_rccl_comm_create", "kj_split_rccl_comm_destroy",
 ]
 
 _LIB = None
@@ -132,12 +134,19 @@ def load():
         "kj_ssgi_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_reference_path_trace": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp],
         "kj_taa_render_rows": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp, u32, u32, u32],
+        "kj_split_create": [u32, u32, u32, C.POINTER(KjSplitRank), u32, u32, u32, vp, C.POINTER(vp)],
+        "kj_split_strip": [vp, u32, C.POINTER(u32), C.POINTER(u32)],
+        "kj_split_gi_frame": [vp, C.POINTER(KjSplitFrame), u32, vp, vp],
+        "kj_split_taa_frame": [vp, C.POINTER(KjSplitFrame), vp],
+        "kj_split_gather": [vp, C.c_char_p, vp],
+        "kj_split_rccl_unique_id": [vp],
+        "kj_split_rccl_comm_create": [vp, u32, u32, C.POINTER(vp)],
     }
     for name, args in sig.items():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = i32
-    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy", "kj_shadow_denoise_destroy", "kj_rtr_destroy", "kj_post_destroy", "kj_motion_blur_destroy"):
+    for name in ("kj_device_destroy", "kj_scene_destroy", "kj_reprojection_destroy", "kj_rtdgi_destroy", "kj_ircache_destroy", "kj_taa_destroy", "kj_ssgi_destroy", "kj_shadow_denoise_destroy", "kj_rtr_destroy", "kj_post_destroy", "kj_motion_blur_destroy", "kj_split_destroy", "kj_split_rccl_comm_destroy"):
         f = getattr(L, name)
         f.argtypes = [vp]
         f.restype = None

@@ -466,3 +466,133 @@ class SplitRtdgi:
     def gather_output(self, name="spatial_filtered_tex"):
         """Assemble the full image from every rank's own rows (result collection; not part of the timed frame)."""
         self._exchange([(name, None)])
+
+
+class NativeSplit:
+    """The same frame schedule driven by the compiled orchestrator (csrc/split.cpp: KjSplit) instead of SplitRtdgi: one C-ABI call per
+    GI frame and one per TAA frame; the strip planning, the pass-by-pass kj_rtdgi_render / kj_taa_render_rows calls, the exchanges
+    (one packed message per peer and exchange point over RCCL, or device-to-device copies between virtual ranks) and the merged replay
+    of the irradiance cache's recorded updates all happen on the other side of the boundary. SplitRtdgi stays the reference it is
+    tested against (tests/test_gpu_multigpu.py::test_native_split_matches_the_python_orchestrator).
+
+    `pipes`: {rank: GpuPipeline} for the ranks living in this process -- all `world` of them (virtual ranks on one device), or one
+    together with `nccl_comm` (an ncclComm_t as an integer: NativeSplit.rccl_comm_from_torch makes one)."""
+
+    def __init__(self, world, pipes, width, height, motion_halo=8, nccl_comm=None):
+        from .abi import KjSplitRank, KjSplitFrame
+        self.L = klib.load()
+        self.pipes = pipes
+        self.ranks = sorted(pipes)
+        self.W, self.H = width, height
+        arr = (KjSplitRank * len(self.ranks))()
+        for i, r in enumerate(self.ranks):
+            gp = pipes[r]
+            arr[i].rtdgi, arr[i].taa, arr[i].ircache, arr[i].scene = gp.rtdgi, gp.taa, gp.ircache, gp.scene.h
+        self.h = C.c_void_p()
+        klib.check(self.L.kj_split_create(world, self.ranks[0], len(self.ranks), arr, width, height, motion_halo, nccl_comm, C.byref(self.h)))
+        self._frames = (KjSplitFrame * len(self.ranks))()
+        self.frame = 0
+        self.on_ircache_traced = None
+        self.consistent_ircache = all(gp.ircache for gp in pipes.values())
+        for gp in pipes.values():
+            gp.ircache_deferred = bool(gp.ircache) and self.consistent_ircache
+
+    def __del__(self):
+        try:
+            self.L.kj_split_destroy(self.h)
+        except Exception:
+            pass
+
+    def strip(self, rank):
+        a, b = C.c_uint32(), C.c_uint32()
+        klib.check(self.L.kj_split_strip(self.h, rank, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def _fill(self):
+        for i, r in enumerate(self.ranks):
+            gp = self.pipes[r]
+            f = self._frames[i]
+            f.rtdgi = gp.params(0)
+            f.rtdgi_out = C.pointer(gp.out)
+            f.taa_out = C.pointer(gp.taa_out)
+            f.sky_cube16 = gp.sky16.data_ptr()
+
+    def gi_frame(self, ircache_done=False, trace_event=None):
+        self._fill()
+        handle = None
+        if trace_event is not None:
+            try:                           # a torch.cuda.Event's hipEvent_t exists once it has been recorded
+                trace_event.record()
+                handle = int(trace_event.cuda_event)
+            except Exception:
+                handle = None
+        klib.check(self.L.kj_split_gi_frame(self.h, self._frames, int(ircache_done), handle, klib._stream_ptr()))
+        if trace_event is not None and handle is None:
+            trace_event.record()           # no native handle (the tests' CPU stand-in): recorded after the frame instead of mid-frame
+        self.frame += 1
+
+    # -- frame pipelining, as SplitRtdgi: every rank's cache replica is updated on a side stream under the previous frame's tail
+    def pipeline_begin(self, fc):
+        import torch
+        self._side = {"stream": torch.cuda.Stream(), "irc": [torch.cuda.Event(), torch.cuda.Event()], "trace": [torch.cuda.Event(), torch.cuda.Event()],
+                      "fc": [torch.cuda.Event(), torch.cuda.Event()]}
+        self._enqueue_ircache(fc, None)
+
+    def _enqueue_ircache(self, fc, wait_event):
+        import torch
+        sd = self._side
+        s0 = torch.cuda.current_stream()
+        with torch.cuda.stream(sd["stream"]):
+            sd["stream"].wait_stream(s0) if wait_event is None else sd["stream"].wait_event(wait_event)
+            first = True
+            for r in self.ranks:
+                gp = self.pipes[r]
+                if first:
+                    gp.dev.frame_begin(fc)
+                    sd["fc"][self.frame & 1].record(sd["stream"])
+                    first = False
+                if gp.ircache:
+                    s = klib._stream_ptr()
+                    if self.consistent_ircache:
+                        gp.ircache_begin_requests()
+                    klib.check(gp.L.kj_ircache_prepare(gp.ircache, s))
+                    klib.check(gp.L.kj_ircache_trace_irradiance(gp.ircache, gp.scene.h, gp.sky16.data_ptr(), 16, s))
+            if self.on_ircache_traced is not None:
+                self.on_ircache_traced()
+            sd["irc"][self.frame & 1].record(sd["stream"])
+
+    def frame_pipelined(self, next_fc, run_ssgi=False):
+        import torch
+        i = self.frame & 1
+        if run_ssgi:
+            torch.cuda.current_stream().wait_event(self._side["fc"][i])
+            for q in self.pipes.values():
+                q.ssgi_frame()
+        torch.cuda.current_stream().wait_event(self._side["irc"][i])
+        self.gi_frame(ircache_done=True, trace_event=self._side["trace"][i])     # (advances self.frame)
+        self.taa_frame()
+        if next_fc is not None:
+            self._enqueue_ircache(next_fc, self._side["trace"][i])
+
+    def taa_frame(self):
+        self._fill()
+        klib.check(self.L.kj_split_taa_frame(self.h, self._frames, klib._stream_ptr()))
+
+    def gather_output(self, name="spatial_filtered_tex"):
+        klib.check(self.L.kj_split_gather(self.h, name.encode(), klib._stream_ptr()))
+
+    @staticmethod
+    def rccl_comm_from_torch(dist, rank, world, device):
+        """An RCCL communicator of the library's own (torch does not hand out its ncclComm_t): rank 0 draws the id, torch.distributed
+        broadcasts its 128 bytes, every rank initialises. Returns the ncclComm_t as an integer."""
+        import torch
+        L = klib.load()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            klib.check(L.kj_split_rccl_unique_id(ident))
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=device)
+        dist.broadcast(t, src=0)
+        ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        comm = C.c_void_p()
+        klib.check(L.kj_split_rccl_comm_create(ident, world, rank, C.byref(comm)))
+        return comm.value

@@ -92,6 +92,52 @@ def test_strip_split_with_the_irradiance_cache_is_bit_exact(gpu, device, n_ranks
     assert meta[3] > 50, meta     # the cache did allocate entries
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,W,H,with_cache", [(2, 256, 160, False), (3, 320, 208, True)])
+def test_native_split_matches_the_python_orchestrator(gpu, device, n_ranks, W, H, with_cache):
+    """The compiled orchestrator (csrc/split.cpp: KjSplit, virtual ranks = device-to-device exchanges) against the reference
+    implementation of the same schedule (multigpu.SplitRtdgi / LocalComm) and against ONE unsplit pipeline: GI image, TAA image and --
+    with the cache bound -- every cache buffer bit for bit, over frames with a moving camera."""
+    import torch
+    from kajiya_amd import multigpu, frame
+    desc = T._scenes()["city20k"]
+    scene = gpu.Scene(device, desc)
+    ref = gpu.GpuPipeline(device, scene, W, H, use_ircache=with_cache)
+    if with_cache:
+        ref.ircache_set_deferred(True)
+    py_pipes = {r: gpu.GpuPipeline(device, scene, W, H, use_ircache=with_cache) for r in range(n_ranks)}
+    nat_pipes = {r: gpu.GpuPipeline(device, scene, W, H, use_ircache=with_cache) for r in range(n_ranks)}
+    py = multigpu.SplitRtdgi(multigpu.LocalComm(n_ranks), py_pipes, W, H, motion_halo=8)
+    nat = multigpu.NativeSplit(n_ranks, nat_pipes, W, H, motion_halo=8)
+    assert [nat.strip(r) for r in range(n_ranks)] == py.strips
+    fs = frame.FrameState((W, H))
+    fs.ircache_enabled = with_cache
+    for fi in range(6):
+        fc = fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.02))
+        fs.retire_frame()
+        ref.frame(fc)
+        ref.taa_frame()
+        for pipes in (py_pipes, nat_pipes):
+            for r in range(n_ranks):
+                pipes[r].render_inputs(fc)
+                pipes[r].reprojection()
+        py.gi_frame(); py.taa_frame()
+        nat.gi_frame(); nat.taa_frame()
+        for sp in (py, nat):
+            sp.gather_output("spatial_filtered_tex")
+            sp.gather_output(f"TAA/taa:{fi % 2}")
+        torch.cuda.synchronize()
+        a = ref.surface("spatial_filtered_tex", torch.int16, (H, W, 4))
+        ta = ref.taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4))
+        for r in range(n_ranks):
+            for tag, pipes in (("python", py_pipes), ("native", nat_pipes)):
+                assert torch.equal(a, pipes[r].surface("spatial_filtered_tex", torch.int16, (H, W, 4))), f"frame {fi} rank {r} ({tag}): GI image differs"
+                assert torch.equal(ta, pipes[r].taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4))), f"frame {fi} rank {r} ({tag}): TAA image differs"
+            if with_cache:
+                for name in IRC_BUFS:
+                    assert torch.equal(ref.ircache_buffer(name, torch.uint8), nat_pipes[r].ircache_buffer(name, torch.uint8)), f"frame {fi} rank {r}: ircache buffer {name} differs"
+
+
 def test_strip_plan_and_transfers():
     from kajiya_amd import multigpu
     for H, n in ((1080, 8), (2160, 8), (1080, 3), (160, 2)):
