@@ -578,10 +578,13 @@ KjStatus kj_split_create(uint32_t world, uint32_t first_rank, uint32_t local_ran
                          uint32_t motion_halo /* rows of history exchanged beyond the stencils: >= max |screen motion| per frame */, void* nccl_comm, KjSplit** out);
 void kj_split_destroy(KjSplit* split);
 KjStatus kj_split_strip(KjSplit* split, uint32_t rank, uint32_t* out_row_begin, uint32_t* out_row_end);
-/* One GI frame: [cache prepare + rays unless ircache_done], reproject, the rtdgi passes with exchanges A-D and H, the merged replay of the
- * cache's recorded updates. `frames`: one entry per LOCAL rank. `trace_done_event`: optional hipEvent_t recorded once the ray passes (and
- * the cache replay) are enqueued -- where a caller may start the next frame's cache work on another stream. */
-KjStatus kj_split_gi_frame(KjSplit* split, const KjSplitFrame* frames, uint32_t ircache_done, void* trace_done_event, void* stream);
+/* One GI frame: [cache prepare + rays unless KJ_SPLIT_IRCACHE_DONE], reproject, the rtdgi passes with exchanges A-D and H, and -- unless
+ * KJ_SPLIT_DEFER_IRCACHE_MERGE -- the merged replay of the cache's recorded updates (it reads list lengths back: two host syncs; a
+ * pipelining caller defers it and calls kj_split_merge_ircache on its cache stream once the frame is enqueued, before the next frame's
+ * cache work). `frames`: one entry per LOCAL rank. `trace_done_event`: optional hipEvent_t recorded once the ray passes are enqueued. */
+enum { KJ_SPLIT_IRCACHE_DONE = 1u, KJ_SPLIT_DEFER_IRCACHE_MERGE = 2u };
+KjStatus kj_split_gi_frame(KjSplit* split, const KjSplitFrame* frames, uint32_t flags, void* trace_done_event, void* stream);
+KjStatus kj_split_merge_ircache(KjSplit* split, void* stream);
 /* TAA on the GI output of the frame just rendered (exchange I + strip-wise TaaRenderer::render). */
 KjStatus kj_split_taa_frame(KjSplit* split, const KjSplitFrame* frames, void* stream);
 /* Every rank receives the owners' rows of a surface ("spatial_filtered_tex", "TAA/taa:0", ...): result collection. */

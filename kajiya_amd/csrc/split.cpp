@@ -328,8 +328,9 @@ KjStatus kj_split_strip(KjSplit* s, uint32_t rank, uint32_t* out_row_begin, uint
 #define KJ_SPLIT_TRY(expr) do { const KjStatus e_ = (expr); if (e_ != KJ_OK) return e_; } while (0)
 
 // One rtdgi frame (multigpu.py: SplitRtdgi.gi_frame). `frames`: one entry per local rank.
-KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t ircache_done, void* trace_done_event, void* stream) {
+KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flags, void* trace_done_event, void* stream) {
     KJ_REQUIRE(s && frames, "null argument");
+    const bool ircache_done = (flags & KJ_SPLIT_IRCACHE_DONE) != 0, defer_merge = (flags & KJ_SPLIT_DEFER_IRCACHE_MERGE) != 0;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t KEEP = KJ_RTDGI_PASS_KEEP_TEMPORALS, M = s->motion_halo;
     const uint32_t out_i = s->frame % 2, hist_i = 1 - s->frame % 2;
@@ -358,7 +359,7 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t irca
     }
     KJ_SPLIT_TRY(exchange(*s, items, st));
     for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_TRACE | KEEP, s->strips[s->first + li], 0, st));
-    if (s->consistent_ircache) KJ_SPLIT_TRY(merge_ircache_requests(*s, st));
+    if (s->consistent_ircache && !defer_merge) KJ_SPLIT_TRY(merge_ircache_requests(*s, st));
     if (trace_done_event) KJ_TRY_HIP(hipEventRecord((hipEvent_t)trace_done_event, st));
     // ---- C
     KJ_SPLIT_TRY(exchange(*s, {{"rt_history_validity_input_tex", 2}, {"candidate_radiance_tex", 8 + 3}, {"candidate_hit_tex", 8 + 3}}, st));
@@ -380,6 +381,14 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t irca
     for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_SPATIAL_FILTER | KEEP, s->strips[s->first + li], 0, st));
     s->frame++;
     return KJ_OK;
+}
+
+// The replay a frame issued with KJ_SPLIT_DEFER_IRCACHE_MERGE left out: all-gather of the frame's recorded cache updates + the same
+// replay on every rank. It reads the list lengths back (two host syncs on `stream`), which is why a pipelining caller runs it on its cache
+// stream after the whole frame is enqueued -- before the next frame's kj_ircache_prepare.
+KjStatus kj_split_merge_ircache(KjSplit* s, void* stream) {
+    KJ_REQUIRE(s, "null argument");
+    return s->consistent_ircache ? merge_ircache_requests(*s, (hipStream_t)stream) : KJ_OK;
 }
 
 // TaaRenderer::render on this frame's GI image, strip by strip (multigpu.py: SplitRtdgi.taa_frame): one exchange (the input's halo;

@@ -326,6 +326,8 @@ class SplitRtdgi:
         s0 = torch.cuda.current_stream()
         with torch.cuda.stream(sd["stream"]):
             sd["stream"].wait_stream(s0) if wait_event is None else sd["stream"].wait_event(wait_event)
+            if self.consistent_ircache and wait_event is not None:
+                self._merge_ircache_requests()   # last frame's recorded cache updates (its ray passes are behind wait_event)
             first = True
             for r in self.comm.ranks:
                 gp = self.pipes[r]
@@ -349,13 +351,21 @@ class SplitRtdgi:
             for q in self.pipes.values():
                 q.ssgi_frame()
         torch.cuda.current_stream().wait_event(self._side["irc"][i])
-        self.gi_frame(ircache_done=True, trace_event=self._side["trace"][i])
+        self.gi_frame(ircache_done=True, trace_event=self._side["trace"][i], defer_merge=True)
         self.taa_frame()
         if next_fc is not None:
             self._enqueue_ircache(next_fc, self._side["trace"][i])
+        elif self.consistent_ircache:             # last frame: nothing follows on the side stream, replay there all the same
+            sd = self._side
+            with torch.cuda.stream(sd["stream"]):
+                sd["stream"].wait_event(sd["trace"][i])
+                self._merge_ircache_requests()
+            torch.cuda.current_stream().wait_stream(sd["stream"])
 
-    def gi_frame(self, ircache_done=False, trace_event=None):
-        """One rtdgi frame. Unless `ircache_done`, each rank's ircache.prepare + trace_irradiance run here first (serial order)."""
+    def gi_frame(self, ircache_done=False, trace_event=None, defer_merge=False):
+        """One rtdgi frame. Unless `ircache_done`, each rank's ircache.prepare + trace_irradiance run here first (serial order).
+        `defer_merge`: leave the replay of the cache's recorded updates to the caller (frame_pipelined runs it on the side stream
+        once the whole frame is enqueued: its host syncs then wait for the ray passes while the main stream still has work queued)."""
         P = KJ_RTDGI_PASS
         out_sfx, hist_sfx = f":{self.frame % 2}", f":{1 - self.frame % 2}"
         M = self.motion_halo
@@ -389,7 +399,7 @@ class SplitRtdgi:
         self._exchange(items)
         for r in R:
             self._render(r, P["TRACE"] | KEEP, self.strips[r])
-        if self.consistent_ircache:
+        if self.consistent_ircache and not defer_merge:
             self._merge_ircache_requests()
         if trace_event is not None:
             import torch
@@ -517,7 +527,7 @@ class NativeSplit:
             f.taa_out = C.pointer(gp.taa_out)
             f.sky_cube16 = gp.sky16.data_ptr()
 
-    def gi_frame(self, ircache_done=False, trace_event=None):
+    def gi_frame(self, ircache_done=False, trace_event=None, defer_merge=False):
         self._fill()
         handle = None
         if trace_event is not None:
@@ -526,7 +536,7 @@ class NativeSplit:
                 handle = int(trace_event.cuda_event)
             except Exception:
                 handle = None
-        klib.check(self.L.kj_split_gi_frame(self.h, self._frames, int(ircache_done), handle, klib._stream_ptr()))
+        klib.check(self.L.kj_split_gi_frame(self.h, self._frames, int(ircache_done) | (2 if defer_merge else 0), handle, klib._stream_ptr()))
         if trace_event is not None and handle is None:
             trace_event.record()           # no native handle (the tests' CPU stand-in): recorded after the frame instead of mid-frame
         self.frame += 1
@@ -544,6 +554,8 @@ class NativeSplit:
         s0 = torch.cuda.current_stream()
         with torch.cuda.stream(sd["stream"]):
             sd["stream"].wait_stream(s0) if wait_event is None else sd["stream"].wait_event(wait_event)
+            if self.consistent_ircache and wait_event is not None:
+                klib.check(self.L.kj_split_merge_ircache(self.h, klib._stream_ptr()))
             first = True
             for r in self.ranks:
                 gp = self.pipes[r]
@@ -569,10 +581,16 @@ class NativeSplit:
             for q in self.pipes.values():
                 q.ssgi_frame()
         torch.cuda.current_stream().wait_event(self._side["irc"][i])
-        self.gi_frame(ircache_done=True, trace_event=self._side["trace"][i])     # (advances self.frame)
+        self.gi_frame(ircache_done=True, trace_event=self._side["trace"][i], defer_merge=True)     # (advances self.frame)
         self.taa_frame()
         if next_fc is not None:
             self._enqueue_ircache(next_fc, self._side["trace"][i])
+        elif self.consistent_ircache:
+            sd = self._side
+            with torch.cuda.stream(sd["stream"]):
+                sd["stream"].wait_event(sd["trace"][i])
+                klib.check(self.L.kj_split_merge_ircache(self.h, klib._stream_ptr()))
+            torch.cuda.current_stream().wait_stream(sd["stream"])
 
     def taa_frame(self):
         self._fill()

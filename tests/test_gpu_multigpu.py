@@ -138,6 +138,68 @@ def test_native_split_matches_the_python_orchestrator(gpu, device, n_ranks, W, H
                     assert torch.equal(ref.ircache_buffer(name, torch.uint8), nat_pipes[r].ircache_buffer(name, torch.uint8)), f"frame {fi} rank {r}: ircache buffer {name} differs"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("native", [False, True])
+def test_pipelined_split_frames_match_serial_split_frames(gpu, device, native):
+    """frame_pipelined of the split (the cache's work of frame N+1 on a side stream; the replay of frame N's recorded cache updates
+    deferred to that stream, after the whole frame is enqueued) against the same frames issued serially: GI image, TAA image and every
+    cache buffer of every rank bit for bit. Both orchestrators."""
+    import ctypes as C
+    import torch
+    from kajiya_amd import multigpu, frame
+    W, H, n_ranks, K = 256, 160, 2, 6
+    desc = T._scenes()["city20k"]
+    scene = gpu.Scene(device, desc)
+
+    def make():
+        pipes = {r: gpu.GpuPipeline(device, scene, W, H, use_ircache=True) for r in range(n_ranks)}
+        sp = multigpu.NativeSplit(n_ranks, pipes, W, H, motion_halo=8) if native else multigpu.SplitRtdgi(multigpu.LocalComm(n_ranks), pipes, W, H, motion_halo=8)
+        return pipes, sp
+    fs = frame.FrameState((W, H))
+    fs.ircache_enabled = True
+    fcs = []
+    for fi in range(K + 1):
+        fcs.append(fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.02)))
+        fs.retire_frame()
+    gen = gpu.GpuPipeline(device, scene, W, H)
+    inputs = []
+    for fc in fcs:
+        gen.render_inputs(fc)
+        gen.reprojection()
+        rp = gpu.tensor_from_ptr(gen.reprojection_map_ptr.value, W * H * 8, torch.int16, (H, W, 4)).clone()
+        inputs.append((gen.geometric_normal.clone(), gen.gbuffer.clone(), gen.depth.clone(), rp, gen.sky16.clone()))
+    torch.cuda.synchronize()
+
+    def bind(pipes, i):
+        gn, gb, d, rp, sky = inputs[i]
+        for q in pipes.values():
+            q.geometric_normal, q.gbuffer, q.depth, q.sky16 = gn, gb, d, sky
+            q.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+    ser_pipes, ser = make()
+    for i in range(K):
+        bind(ser_pipes, i)
+        device.frame_begin(fcs[i])
+        ser.gi_frame()
+        ser.taa_frame()
+    torch.cuda.synchronize()
+    pip_pipes, pip = make()
+    bind(pip_pipes, 0)
+    pip.pipeline_begin(fcs[0])
+    for i in range(K):
+        bind(pip_pipes, i)
+        pip.frame_pipelined(fcs[i + 1] if i + 1 < K else None)
+    torch.cuda.synchronize()
+    for sp in (ser, pip):
+        sp.gather_output("spatial_filtered_tex")
+        sp.gather_output(f"TAA/taa:{(K - 1) % 2}")
+    torch.cuda.synchronize()
+    for r in range(n_ranks):
+        assert torch.equal(ser_pipes[r].surface("spatial_filtered_tex", torch.int16, (H, W, 4)), pip_pipes[r].surface("spatial_filtered_tex", torch.int16, (H, W, 4))), f"rank {r}: GI image"
+        assert torch.equal(ser_pipes[r].taa_surface(f"taa:{(K - 1) % 2}", torch.int16, (H, W, 4)), pip_pipes[r].taa_surface(f"taa:{(K - 1) % 2}", torch.int16, (H, W, 4))), f"rank {r}: TAA image"
+        for name in IRC_BUFS:
+            assert torch.equal(ser_pipes[r].ircache_buffer(name, torch.uint8), pip_pipes[r].ircache_buffer(name, torch.uint8)), f"rank {r}: ircache buffer {name}"
+
+
 def test_strip_plan_and_transfers():
     from kajiya_amd import multigpu
     for H, n in ((1080, 8), (2160, 8), (1080, 3), (160, 2)):
