@@ -264,6 +264,11 @@ struct Scene {
     InstanceHandle add_instance(MeshHandle mesh, const float transform3x4[12]) { uint32_t i = 0; check(kj_scene_add_instance(h, mesh.idx, transform3x4, &i), "kj_scene_add_instance"); return InstanceHandle{i}; }
     void set_instance_transform(InstanceHandle inst, const float transform3x4[12]) { check(kj_scene_set_instance_transform(h, inst.idx, transform3x4), "kj_scene_set_instance_transform"); }
     void remove_instance(InstanceHandle inst) { check(kj_scene_remove_instance(h, inst.idx), "kj_scene_remove_instance"); }
+    // how the BLAS of meshes added from now on is built (ray_tracing.rs:438 build flags): PREFER_FAST_TRACE = binned SAH on the host,
+    // PREFER_FAST_BUILD = linear BVH on the device
+    void set_blas_build_mode(bool prefer_fast_build) { check(kj_scene_set_blas_build_mode(h, prefer_fast_build ? KJ_BLAS_BUILD_FAST_BUILD : KJ_BLAS_BUILD_FAST_TRACE), "kj_scene_set_blas_build_mode"); }
+    // host ms of the last build_ray_tracing_top_level_acceleration: {BLAS builds, instance tables + top tree, uploads + device refit, total}
+    std::array<double, 4> last_commit_ms() const { std::array<double, 4> t{}; check(kj_scene_last_commit_ms(h, t.data()), "kj_scene_last_commit_ms"); return t; }
     // build_ray_tracing_top_level_acceleration + prepare_top_level_acceleration
     void build_ray_tracing_top_level_acceleration(hipStream_t s) { check(kj_scene_commit(h, s), "kj_scene_commit"); }
     uint32_t triangle_light_count() const { uint32_t n = 0; check(kj_scene_triangle_light_count(h, &n), "kj_scene_triangle_light_count"); return n; }
