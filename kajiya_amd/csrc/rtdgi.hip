@@ -140,10 +140,10 @@ KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
 // ---- fused form of the two ray passes (the default): one invocation per pixel does ray generation, both traversals, hit shading
 // and the bookkeeping, as the reference's ray-generation shaders do; the traversal inside votes per wave on node vs triangle steps.
 // Measured against the staged form below (profiles/r02_ray_pipeline_variants.md): trace pass 0.259 ms fused / 0.437 staged at
-// 1080p (518 k rays: 8100 waves for 8192 wave slots, nothing to refill from, and five dependent launches instead of one) and
-// 0.777 / 0.918 ms at 4K (2.07 M rays). The fused kernel already runs at the speed of its two traversals alone (0.24 ms at the
-// stream rates of scripts/traversal_microbench.py): hit shading hides completely behind other waves' memory latency, so taking
-// it out of the kernel buys nothing and the extra round trips through memory (96 B per ray) cost.
+// 1080p (292 k closest + 91 k occlusion rays per launch: 47 rays per persistent wave, nothing to refill from, and five dependent
+// launches instead of one) and 0.777 / 0.918 ms at 4K. The kernel is bound by the wave-instructions it issues at 34 % lane
+// utilisation (two thirds of the rays leave the scene, and their lanes idle through hit shading and the shadow ray): its rays alone
+// would take 0.13 of its 0.28 ms at the microbench's rates.
 struct TraceResult { V3 out_value; V3 hit_normal_ws; float hit_t; float pdf; bool is_hit; };
 template <bool STATS>
 KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3 normal_ws, uint32_t& rng, V3 ray_o, V3 ray_d, float ray_tmax, uint32_t* stack) {
