@@ -15,6 +15,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <numeric>
+#include <future>
+#include <map>
+#include <memory>
 #include <chrono>
 #include <cstdlib>
 #include "kj_scene_device.hpp"
@@ -274,6 +277,29 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         return e;
     };
     LbvhScratch lbvh_scratch;     // device-side builds of this commit share their working buffers
+    // host SAH builds of all new meshes run concurrently (a small mesh builds on one thread: nine of them one after the other were
+    // half of a first commit); each result is the same tree whatever runs beside it
+    auto host_build = [s](uint32_t mi) {
+        const GpuMesh& m = s->meshes[mi];
+        const uint32_t ntri = m.index_count / 3;
+        std::vector<BvhTri> ot(ntri);
+        for (uint32_t p = 0; p < ntri; ++p) {
+            BvhTri& t = ot[p];
+            float* dst[3] = {t.v0, t.v1, t.v2};
+            for (int k = 0; k < 3; ++k) {
+                uint32_t idx;
+                memcpy(&idx, s->vertex_buffer.data() + m.index_offset + (p * 3 + k) * 4, 4);
+                memcpy(dst[k], s->vertex_buffer.data() + m.vertex_core_offset + size_t(idx) * 16, 12);
+            }
+            t.world_id = 0; t.inst = 0; t.prim = p;
+        }
+        std::unique_ptr<BuiltBvh> b(new BuiltBvh());
+        build_bvh4(ot, *b);
+        return b;
+    };
+    std::map<uint32_t, std::future<std::unique_ptr<BuiltBvh>>> host_builds;
+    for (uint32_t mi = 0; mi < s->meshes.size(); ++mi)
+        if (!s->blas[mi].built && s->mesh_build_mode[mi] != 1) host_builds[mi] = std::async(std::launch::async, host_build, mi);
     for (uint32_t mi = 0; mi < s->meshes.size(); ++mi) {
         KjScene::Blas& bl = s->blas[mi];
         if (bl.built) continue;
@@ -292,19 +318,8 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
             for (size_t d = lr.level_starts.size() - 1; d-- > 0;) { steps.push_back(lr.level_starts[d]); steps.push_back(lr.level_starts[d + 1]); }
             bl.root = 0;
         } else {                              // binned SAH on the host
-            std::vector<BvhTri> ot(ntri);
-            for (uint32_t p = 0; p < ntri; ++p) {
-                BvhTri& t = ot[p];
-                float* dst[3] = {t.v0, t.v1, t.v2};
-                for (int k = 0; k < 3; ++k) {
-                    uint32_t idx;
-                    memcpy(&idx, s->vertex_buffer.data() + m.index_offset + (p * 3 + k) * 4, 4);
-                    memcpy(dst[k], s->vertex_buffer.data() + m.vertex_core_offset + size_t(idx) * 16, 12);
-                }
-                t.world_id = 0; t.inst = 0; t.prim = p;
-            }
-            BuiltBvh b;
-            build_bvh4(ot, b);
+            std::unique_ptr<BuiltBvh> built = host_builds[mi].get();
+            BuiltBvh& b = *built;
             bl.node_count = uint32_t(b.nodes.size());
             bl.max_stack = b.max_stack;
             for (int k = 0; k < 3; ++k) { bl.bounds[k] = FLT_MAX; bl.bounds[3 + k] = -FLT_MAX; }
