@@ -93,7 +93,7 @@ def test_strip_split_with_the_irradiance_cache_is_bit_exact(gpu, device, n_ranks
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_ranks,W,H,with_cache", [(2, 256, 160, False), (3, 320, 208, True)])
+@pytest.mark.parametrize("n_ranks,W,H,with_cache", [(2, 256, 160, False), (3, 320, 208, True), (8, 192, 256, True)])
 def test_native_split_matches_the_python_orchestrator(gpu, device, n_ranks, W, H, with_cache):
     """The compiled orchestrator (csrc/split.cpp: KjSplit, virtual ranks = device-to-device exchanges) against the reference
     implementation of the same schedule (multigpu.SplitRtdgi / LocalComm) and against ONE unsplit pipeline: GI image, TAA image and --
