@@ -3,6 +3,7 @@
 #include "kj_scene_device.hpp"
 #include "kj_vec.hpp"
 #include <cfloat>
+#include <algorithm>
 
 using namespace kj;
 
@@ -150,16 +151,18 @@ namespace kj {
 
 hipError_t launch_instance_refit(const Bvh4Node* blas_nodes, const uint2* steps, const BvhTri* world_tris, const InstanceRefitJob* jobs, uint32_t job_count,
                                  uint32_t max_wide_heights, Bvh4Node* nodes, void* boxes, hipStream_t s) {
-    if (job_count == 0) return hipSuccess;
-    for (uint32_t h = 0; h < max_wide_heights; ++h)
-        hipLaunchKernelGGL(k_instance_refit_height, dim3(256, job_count), dim3(256), 0, s, blas_nodes, steps, world_tris, jobs, nodes, (Box6*)boxes, h);
-    hipLaunchKernelGGL(k_instance_refit_top, dim3(job_count), dim3(KJ_REFIT_TOP_NODES), 0, s, blas_nodes, steps, world_tris, jobs, nodes, (Box6*)boxes);
+    for (uint32_t j0 = 0; j0 < job_count; j0 += 32768u) {      // (grid.y is limited to 65535)
+        const uint32_t n = std::min(32768u, job_count - j0);
+        for (uint32_t h = 0; h < max_wide_heights; ++h)
+            hipLaunchKernelGGL(k_instance_refit_height, dim3(256, n), dim3(256), 0, s, blas_nodes, steps, world_tris, jobs + j0, nodes, (Box6*)boxes, h);
+        hipLaunchKernelGGL(k_instance_refit_top, dim3(n), dim3(KJ_REFIT_TOP_NODES), 0, s, blas_nodes, steps, world_tris, jobs + j0, nodes, (Box6*)boxes);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_instance_triangles(const BvhTri* obj_tris, BvhTri* world_tris, const InstanceTriJob* jobs, uint32_t job_count, hipStream_t s) {
-    if (job_count == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_instance_triangles, dim3(64, job_count), dim3(256), 0, s, obj_tris, world_tris, jobs);
+    for (uint32_t j0 = 0; j0 < job_count; j0 += 32768u)        // (grid.y is limited to 65535)
+        hipLaunchKernelGGL(k_instance_triangles, dim3(64, std::min(32768u, job_count - j0)), dim3(256), 0, s, obj_tris, world_tris, jobs + j0);
     return hipGetLastError();
 }
 
