@@ -193,7 +193,7 @@ void okj_rtdgi_render(void* p, const KjFrameConstants* fc, const KjRtdgiRenderPa
     if (params->ircache) {
         Ircache* ic = (Ircache*)params->ircache;
         const KjFrameConstants* fcp = fc;
-        in.ircache_lookup = [ic, fcp](f3 from, f3 pt, f3 n, uint32_t rank, uint32_t& rng) { return ic->lookup(*fcp, from, pt, n, rank, rng, false); };
+        in.ircache_lookup = [ic, fcp](f3 from, f3 pt, f3 n, uint32_t rank, uint32_t& rng, uint32_t key) { Ircache::request_key() = key; return ic->lookup(*fcp, from, pt, n, rank, rng, false); };
     }
     Rtdgi::Output r = o->r.render(*fc, in, params->pass_mask);
     if (out) {
@@ -243,9 +243,19 @@ void okj_ircache_trace_irradiance(void* p, const KjFrameConstants* fc, void* sce
     o->ic.rays_closest = 0; o->ic.rays_any = 0;
     IrcacheTracer::prepare_and_reset(o->ic);
     IrcacheTracer::trace_accessibility(o->ic, in);
+    // deterministic mode: lookups inside the next two passes read other entries' aux while those are rewritten: give them a snapshot
+    o->ic.read_aux_snapshot = o->ic.deferred;
+    if (o->ic.deferred) o->ic.snapshot_aux();
     IrcacheTracer::validate(o->ic, *fc, in, sun_color);
+    if (o->ic.deferred) o->ic.snapshot_aux();
     IrcacheTracer::trace_irradiance(o->ic, *fc, in, sun_color);
+    o->ic.read_aux_snapshot = false;
 }
+// deterministic mode (okj_ircache.hpp header): record-then-replay of the lookups' side effects
+void okj_ircache_set_deferred_updates(void* p, int enable) { ((OkjIrcache*)p)->ic.deferred = enable != 0; }
+void okj_ircache_begin_requests(void* p) { ((OkjIrcache*)p)->ic.begin_requests(); }
+uint64_t okj_ircache_request_count(void* p) { return ((OkjIrcache*)p)->ic.requests.size(); }
+void okj_ircache_apply_requests(void* p) { ((OkjIrcache*)p)->ic.apply_requests(); }
 void okj_ircache_sum_up(void* p, const KjFrameConstants* fc) { IrcacheTracer::sum_up(((OkjIrcache*)p)->ic, *fc); }
 int okj_ircache_buffer(void* p, const char* name, void** out_ptr, uint64_t* out_bytes) {
     Ircache& ic = ((OkjIrcache*)p)->ic;

@@ -3,11 +3,19 @@
 // prefix_scan/* (semantics: inclusive scan). Atomics use __atomic builtins so the passes can
 // run under OpenMP like the GPU (order-dependent, as in the reference: docs/gi-overview.md:296);
 // run single-threaded for a deterministic order.
+// `deferred` = the deterministic mode: the statement of the SAME order-free semantics the product defines for its multi-GPU split
+// (include/kajiya_amd.h: kj_ircache_set_deferred_updates) -- lookups return their value and only RECORD their side effects
+// (lookup.hlsl:118-150,287-301), which are replayed after the frame's ray passes in (cell, position of the lookup in the frame)
+// order; entries freed by scroll / age return to the pool in entry order; precise lookups inside the cache's own ray passes read a
+// snapshot of `aux` taken before the pass. Every outcome is one the racy reference program can produce; none depends on thread
+// interleaving, so GPU-vs-oracle comparisons of the cache can be held to the same bars as the deterministic passes.
 #pragma once
 #include "okj_scene.hpp"
 #include "okj_reservoir.hpp"
 #include <atomic>
 #include <functional>
+#include <algorithm>
+#include <mutex>
 
 namespace okj {
 
@@ -79,6 +87,15 @@ struct Ircache {
     bool enable_scroll = true;
     int cur = 0;  // index of the live grid_meta buffer after prepare()
     std::atomic<uint64_t> rays_closest{0}, rays_any{0};
+    // ---- deterministic mode (see the header comment)
+    struct Request { uint32_t cell, key, bits; float dart; f4 proposal; };   // bits = query_rank | skip_allocation << 8
+    bool deferred = false;
+    std::vector<Request> requests;
+    std::mutex requests_mutex;
+    std::vector<f4> aux_snapshot;
+    std::vector<uint32_t> freed;
+    bool read_aux_snapshot = false;                                            // precise lookups read aux_snapshot instead of aux
+    static uint32_t& request_key() { static thread_local uint32_t k = 0; return k; }   // set by the caller right before lookup()
 
     Ircache() {
         meta.assign(8, 0);
@@ -216,31 +233,13 @@ struct Ircache {
     }
     // `precise` = IRCACHE_LOOKUP_PRECISE (defined by the ircache's own trace/validate shaders)
     f3 lookup(const FrameConstants& fc, f3 query_from_ws, f3 pt_ws, f3 normal_ws, uint32_t query_rank, uint32_t& rng, bool precise, bool stochastic_interpolation = false) {
+        if (deferred) return lookup_deferred(fc, query_from_ws, pt_ws, normal_ws, query_rank, rng, precise, stochastic_interpolation);
         const LookupMaybeAllocate lk = lookup_maybe_allocate(fc, query_from_ws, pt_ws, normal_ws, query_rank, rng, stochastic_interpolation);
         if (lk.just_allocated) return mk3(0.0f);
         f3 irradiance_sum = mk3(0.0f);
         if (lk.found) {
             const uint32_t entry_idx = lk.entry_idx;
-            f3 irr = mk3(0.0f);
-            if (precise) {
-                float weight_sum = 0;
-                for (uint32_t octa_idx = 0; octa_idx < IRCACHE_OCTA_DIMS2; ++octa_idx) {
-                    const f4 r0 = aux[size_t(entry_idx) * IRCACHE_AUX_STRIDE + octa_idx];
-                    const f3 dir = SampleParams{asuint(r0.x)}.direction();
-                    const float wt = dot(dir, normal_ws);
-                    if (wt > 0.0f) {
-                        const f4 contrib = aux[size_t(entry_idx) * IRCACHE_AUX_STRIDE + IRCACHE_OCTA_DIMS2 + octa_idx];
-                        irr += xyz(contrib) * (wt * contrib.w);
-                        weight_sum += wt;
-                    }
-                }
-                irr = irr / fmaxf(1.0f, weight_sum);
-            } else {
-                irr.x = eval_sh_geometrics(irradiance[entry_idx * 3 + 0], normal_ws);
-                irr.y = eval_sh_geometrics(irradiance[entry_idx * 3 + 1], normal_ws);
-                irr.z = eval_sh_geometrics(irradiance[entry_idx * 3 + 2], normal_ws);
-            }
-            irr = vmax(mk3(0.0f), irr);
+            const f3 irr = entry_irradiance(entry_idx, normal_ws, precise);
             irradiance_sum += irr;
             const uint32_t prev_life = __atomic_load_n(&life[entry_idx], __ATOMIC_RELAXED);
             if (prev_life < IRCACHE_ENTRY_LIFE_RECYCLE) {
@@ -258,10 +257,119 @@ struct Ircache {
         return irradiance_sum;
     }
 
+    // the value half of lookup() (lookup.hlsl:239-285), no side effects
+    f3 entry_irradiance(uint32_t entry_idx, f3 normal_ws, bool precise) const {
+        f3 irr = mk3(0.0f);
+        if (precise) {
+            const f4* a = read_aux_snapshot ? aux_snapshot.data() : aux.data();
+            float weight_sum = 0;
+            for (uint32_t octa_idx = 0; octa_idx < IRCACHE_OCTA_DIMS2; ++octa_idx) {
+                const f4 r0 = a[size_t(entry_idx) * IRCACHE_AUX_STRIDE + octa_idx];
+                const f3 dir = SampleParams{asuint(r0.x)}.direction();
+                const float wt = dot(dir, normal_ws);
+                if (wt > 0.0f) {
+                    const f4 contrib = a[size_t(entry_idx) * IRCACHE_AUX_STRIDE + IRCACHE_OCTA_DIMS2 + octa_idx];
+                    irr += xyz(contrib) * (wt * contrib.w);
+                    weight_sum += wt;
+                }
+            }
+            irr = irr / fmaxf(1.0f, weight_sum);
+        } else {
+            irr.x = eval_sh_geometrics(irradiance[entry_idx * 3 + 0], normal_ws);
+            irr.y = eval_sh_geometrics(irradiance[entry_idx * 3 + 1], normal_ws);
+            irr.z = eval_sh_geometrics(irradiance[entry_idx * 3 + 2], normal_ws);
+        }
+        return vmax(mk3(0.0f), irr);
+    }
+    // Deterministic mode: the lookup's value does not depend on this frame's updates (an unoccupied cell yields 0 whether or not someone
+    // allocates it now; an occupied one reads irradiance no lookup writes), so the updates are recorded and replayed by apply_requests().
+    f3 lookup_deferred(const FrameConstants& fc, f3 query_from_ws, f3 pt_ws, f3 normal_ws, uint32_t query_rank, uint32_t& rng, bool precise, bool stochastic_interpolation) {
+        f3 jitter;
+        jitter.x = uint_to_u01_float(hash1_mut(rng)) - 0.5f; jitter.y = uint_to_u01_float(hash1_mut(rng)) - 0.5f; jitter.z = uint_to_u01_float(hash1_mut(rng)) - 0.5f;
+        if (!stochastic_interpolation) jitter = mk3(0.0f);
+        const Coord rc = ws_pos_to_ircache_coord(fc, pt_ws, normal_ws, jitter);
+        const int32_t* so = fc.ircache_cascades[rc.cascade].voxels_scrolled_this_frame;
+        const int c[3] = {int(rc.x), int(rc.y), int(rc.z)};
+        bool was_just_scrolled_in = false;
+        for (int k = 0; k < 3; ++k) was_just_scrolled_in |= so[k] > 0 ? (c[k] + so[k] >= int(IRCACHE_CASCADE_SIZE)) : (c[k] < -so[k]);
+        const bool skip_allocation = query_rank >= IRCACHE_ENTRY_RANK_COUNT || (was_just_scrolled_in && query_rank > 0);
+        const uint32_t cell = rc.cell();
+        const u2 cell_meta = gm()[cell];
+        Request rq;
+        rq.cell = cell; rq.key = request_key(); rq.bits = query_rank | (skip_allocation ? 0x100u : 0u);
+        rq.dart = uint_to_u01_float(hash1_mut(rng));
+        const float cell_diameter = IRCACHE_GRID_CELL_DIAMETER * float(1u << rc.cascade);
+        f3 offset_towards_query = query_from_ws - pt_ws;
+        offset_towards_query = offset_towards_query * (cell_diameter / fmaxf(cell_diameter / 0.5f, length(offset_towards_query)));
+        rq.proposal = pack_vertex(IrcacheVertex{pt_ws + offset_towards_query, normal_ws});
+        { std::lock_guard<std::mutex> g(requests_mutex); requests.push_back(rq); }
+        if ((cell_meta.y & IRCACHE_ENTRY_META_OCCUPIED) == 0 || (cell_meta.y & IRCACHE_ENTRY_META_JUST_ALLOCATED) != 0) return mk3(0.0f);
+        return entry_irradiance(cell_meta.x, normal_ws, precise);
+    }
+    void begin_requests() { requests.clear(); }
+    void snapshot_aux() {   // the half of every entry's block that lookups read, as it is before a pass
+        if (aux_snapshot.size() != aux.size()) aux_snapshot.assign(aux.size(), f4{0, 0, 0, 0});
+        const size_t n = size_t(meta[META_ENTRY_COUNT]) * 32;
+        for (size_t i = 0; i < n; ++i) { const size_t o = (i >> 5) * IRCACHE_AUX_STRIDE + (i & 31u); aux_snapshot[o] = aux[o]; }
+    }
+    // Replay of the frame's recorded lookups in the canonical order (cell, key):
+    //   * a cell nobody occupies is allocated by its first lookup that may allocate; new cells take pool entries in cell order;
+    //   * an occupied cell's lookups run through lookup.hlsl:287-301 one after the other: life refresh (min), then the position vote --
+    //     accepted with probability 1 / (votes so far + 1), using the random number the lookup drew when it ran.
+    void apply_requests() {
+        std::vector<Request>& rq = requests;
+        std::sort(rq.begin(), rq.end(), [](const Request& a, const Request& b) { return a.cell != b.cell ? a.cell < b.cell : a.key < b.key; });
+        const size_t n = rq.size();
+        const uint32_t alloc_before = meta[META_ALLOC_COUNT];
+        uint32_t allocated = 0;
+        for (size_t i = 0; i < n;) {
+            size_t e = i;
+            while (e < n && rq[e].cell == rq[i].cell) ++e;
+            const uint32_t cell = rq[i].cell;
+            const u2 m = gm()[cell];
+            if ((m.y & IRCACHE_ENTRY_META_OCCUPIED) == 0) {
+                size_t j = i;
+                while (j < e && (rq[j].bits & 0x100u)) ++j;                 // the first lookup allowed to allocate
+                if (j < e) {
+                    const uint32_t alloc_idx = alloc_before + allocated++;
+                    if (alloc_idx < IRCACHE_MAX_ENTRIES) {                    // else: pool exhausted, the cell stays empty
+                        const uint32_t entry_idx = pool[alloc_idx];
+                        meta[META_ENTRY_COUNT] = std::max(meta[META_ENTRY_COUNT], entry_idx + 1);
+                        life[entry_idx] = ircache_entry_life_for_rank(rq[j].bits & 0xffu);
+                        entry_cell[entry_idx] = cell;
+                        gm()[cell] = u2{entry_idx, m.y | IRCACHE_ENTRY_META_OCCUPIED | IRCACHE_ENTRY_META_JUST_ALLOCATED};
+                        reposition_proposal[entry_idx] = rq[j].proposal;
+                    }
+                }
+            } else if ((m.y & IRCACHE_ENTRY_META_JUST_ALLOCATED) == 0) {
+                const uint32_t entry_idx = m.x;
+                uint32_t lf = life[entry_idx], votes = reposition_proposal_count[entry_idx];
+                for (size_t j = i; j < e; ++j) {
+                    const uint32_t query_rank = rq[j].bits & 0xffu;
+                    if (lf < IRCACHE_ENTRY_LIFE_RECYCLE) {
+                        const uint32_t prev_life = lf;
+                        const uint32_t new_life = ircache_entry_life_for_rank(query_rank);
+                        if (new_life < prev_life) lf = new_life;
+                        if (query_rank <= ircache_entry_life_to_rank(prev_life)) {
+                            if (rq[j].dart <= 1.0f / (float(votes) + 1.0f)) reposition_proposal[entry_idx] = rq[j].proposal;
+                            ++votes;
+                        }
+                    }
+                }
+                life[entry_idx] = lf;
+                reposition_proposal_count[entry_idx] = votes;
+            }
+            i = e;
+        }
+        meta[META_ALLOC_COUNT] = std::min(alloc_before + allocated, IRCACHE_MAX_ENTRIES);
+        requests.clear();
+    }
+
     // ---- prepare (ircache.rs:168-350)
     void prepare(const FrameConstants& fc) {
         int a = 0, b = 1;                      // grid_meta_buf, grid_meta_buf2
         if (parity == 1) std::swap(a, b);
+        if (deferred) freed.assign(IRCACHE_MAX_ENTRIES, 0);
         if (!initialized) {
             for (uint32_t i = 0; i < IRCACHE_MAX_ENTRIES; ++i) { pool[i] = i; life[i] = IRCACHE_ENTRY_LIFE_RECYCLED; }  // clear_ircache_pool.hlsl
             initialized = true;
@@ -274,6 +382,14 @@ struct Ircache {
         const uint32_t entry_count = meta[META_ENTRY_COUNT];
         const uint32_t groups = (entry_count + 63) / 64;                     // prepare_age_dispatch_args.hlsl
         age_entries(groups * 64);
+        if (deferred) {   // entries freed by the two passes above go back to the pool in ascending entry order
+            uint32_t total = 0;
+            for (uint32_t e = 0; e < IRCACHE_MAX_ENTRIES; ++e) total += freed[e];
+            const uint32_t new_count = meta[META_ALLOC_COUNT] - total;
+            uint32_t before = 0;
+            for (uint32_t e = 0; e < IRCACHE_MAX_ENTRIES; ++e) if (freed[e]) pool[new_count + before++] = e;
+            meta[META_ALLOC_COUNT] = new_count;
+        }
         // inclusive prefix scan of the occupancy flags (prefix_scan/*.hlsl)
         uint32_t run = 0;
         for (uint32_t i = 0; i < IRCACHE_MAX_ENTRIES; ++i) { run += entry_occupancy[i]; entry_occupancy[i] = run; }
@@ -297,8 +413,8 @@ struct Ircache {
                                 const uint32_t entry_idx = m.x;
                                 life[entry_idx] = IRCACHE_ENTRY_LIFE_RECYCLED;
                                 for (int i = 0; i < 3; ++i) irradiance[entry_idx * 3 + i] = f4{0, 0, 0, 0};
-                                const uint32_t c = atomic_add(&meta[META_ALLOC_COUNT], uint32_t(-1));
-                                pool[c - 1] = entry_idx;
+                                if (deferred) freed[entry_idx] = 1;
+                                else { const uint32_t c = atomic_add(&meta[META_ALLOC_COUNT], uint32_t(-1)); pool[c - 1] = entry_idx; }
                             }
                         }
                         const uint32_t sx = uint32_t(int(x) + sb[0]), sy = uint32_t(int(y) + sb[1]), sz = uint32_t(int(z) + sb[2]);
@@ -326,8 +442,8 @@ struct Ircache {
                     } else {
                         life[e] = IRCACHE_ENTRY_LIFE_RECYCLED;
                         for (int i = 0; i < 3; ++i) irradiance[e * 3 + i] = f4{0, 0, 0, 0};
-                        const uint32_t c = atomic_add(&meta[META_ALLOC_COUNT], uint32_t(-1));
-                        pool[c - 1] = e;
+                        if (deferred) freed[e] = 1;
+                        else { const uint32_t c = atomic_add(&meta[META_ALLOC_COUNT], uint32_t(-1)); pool[c - 1] = e; }
                         atomic_and(&gm()[entry_cell[e]].y, ~(IRCACHE_ENTRY_META_OCCUPIED | IRCACHE_ENTRY_META_JUST_ALLOCATED));
                     }
                 }

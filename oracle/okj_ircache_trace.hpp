@@ -122,6 +122,7 @@ struct IrcacheTracer {
             if (r.M > 0) {
                 f4 prev_value_and_count = ic.aux[output_idx + IRCACHE_OCTA_DIMS2] * f4{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
                 const IrcacheVertex prev_entry = unpack_vertex(ic.aux[output_idx + IRCACHE_OCTA_DIMS2 * 2]);
+                Ircache::request_key() = (3u << 28) | uint32_t(d);      // deterministic mode: this lookup's place in the frame
                 const IrcacheTraceResult prev_traced = ircache_trace(ic, fc, in, sun_color, prev_entry, SampleParams{r.payload}, life);
                 const float limiter = lerp(0.5f, 1.0f, smoothstep(-0.1f, 0.0f, dot(prev_traced.direction, prev_entry.normal)));
                 const f3 a = prev_traced.incident_radiance * limiter;
@@ -149,6 +150,7 @@ struct IrcacheTracer {
             const IrcacheVertex entry = unpack_vertex(packed_entry);
             uint32_t rng = hash1(hash1(entry_idx) + fc.frame_index);
             const SampleParams sp = SampleParams::from_spf_entry_sample_frame(IRCACHE_SAMPLES_PER_FRAME, entry_idx, sample_idx, fc.frame_index);
+            Ircache::request_key() = (4u << 28) | uint32_t(d);
             const IrcacheTraceResult traced = ircache_trace(ic, fc, in, sun_color, entry, sp, life);
             const float limiter = lerp(0.5f, 1.0f, smoothstep(-0.1f, 0.0f, dot(traced.direction, entry.normal)));
             const f3 new_value = traced.incident_radiance * limiter;

@@ -77,6 +77,10 @@ def lib():
         L.okj_ircache_buffer.restype = C.c_int
         L.okj_ircache_buffer.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_ircache_ray_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.okj_ircache_set_deferred_updates.argtypes = [C.c_void_p, C.c_int]
+        L.okj_ircache_begin_requests.argtypes = [C.c_void_p]
+        L.okj_ircache_apply_requests.argtypes = [C.c_void_p]
+        L.okj_ircache_request_count.argtypes = [C.c_void_p]; L.okj_ircache_request_count.restype = C.c_uint64
         L.okj_taa_create.restype = C.c_void_p
         L.okj_taa_destroy.argtypes = [C.c_void_p]
         L.okj_taa_render.restype = C.c_void_p
@@ -264,13 +268,24 @@ class OraclePipeline:
     def gi_frame(self, fc, pass_mask=KJ_RTDGI_PASS["ALL"]):
         """The GI frame in world_render_passes.rs order: ircache prepare/trace, rtdgi.reproject,
         ircache sum-up (deliberately delayed, :138-140), rtdgi.render."""
+        deferred = self.ircache and getattr(self, "ircache_deferred", False)
         if self.ircache:
+            if deferred:
+                self.L.okj_ircache_begin_requests(self.ircache)
             self.ircache_prepare_and_trace(fc)
         self.L.okj_rtdgi_reproject(self.rtdgi, C.byref(fc), self.reprojection_map.ctypes.data, self.W, self.H)
         if self.ircache:
             self.ircache_sum_up(fc)
         p = self.params(pass_mask)
         self.L.okj_rtdgi_render(self.rtdgi, C.byref(fc), C.byref(p), C.byref(self.out))
+        if deferred:
+            self.L.okj_ircache_apply_requests(self.ircache)
+
+    def ircache_set_deferred(self, enable=True):
+        """The cache's deterministic mode (oracle/okj_ircache.hpp header): the same order-free semantics as the product's
+        kj_ircache_set_deferred_updates, so that cache state can be compared under the deterministic passes' bars."""
+        self.L.okj_ircache_set_deferred_updates(self.ircache, int(enable))
+        self.ircache_deferred = bool(enable)
 
     def taa_frame(self, fc, input_ptr=None, out_extent=None):
         """TaaRenderer::render on `input_ptr` (default: this frame's rtdgi screen_irradiance_tex)."""

@@ -106,6 +106,12 @@ def compare(a_raw, b_raw, fmt, atol=0.0, vector=False):
     it is 1/10 of the rel-L2 bar, so it cannot hide an error that matters to the image. For `vector` surfaces the 0.1 % is
     taken of the texel's largest component (a hit offset of 1e4 units along x has no meaningful relative error in its y)."""
     a, b = decode(a_raw, fmt).astype(np.float64), decode(b_raw, fmt).astype(np.float64)
+    return compare_decoded(a, b, atol=atol, vector=vector or fmt in VECTOR_FORMATS, exact=fmt in EXACT_FORMATS, rtol=RTOL.get(fmt, 1e-3))
+
+
+def compare_decoded(a, b, atol=0.0, vector=False, exact=False, rtol=1e-3):
+    """compare() on arrays that are already decoded to floats, shape (records, channels)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
     both_nan = np.isnan(a) & np.isnan(b)
     same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
@@ -117,14 +123,14 @@ def compare(a_raw, b_raw, fmt, atol=0.0, vector=False):
     num, den = np.sqrt((d * d).sum()), np.sqrt((ref * ref).sum())
     rms = den / np.sqrt(max(1, ref.size))
     mag = np.abs(ref)
-    if vector or fmt in VECTOR_FORMATS:
+    if vector:
         mag = np.abs(ref[..., :3]).max(axis=-1, keepdims=True) * np.ones_like(ref)
         mag[..., 3:] = np.abs(ref[..., 3:])
-    tol = atol + RTOL.get(fmt, 1e-3) * mag + (0.0 if fmt in EXACT_FORMATS else ATOL_RMS * rms)
+    tol = atol + rtol * mag + (0.0 if exact else ATOL_RMS * rms)
     mism = ((np.abs(d) > tol) & fin) | bad_class
     texel_mism = mism.any(axis=-1)
     din = np.where(texel_mism[..., None], 0.0, d)     # the image without its outlier texels (a flipped reservoir pick replaces the whole texel)
-    return dict(rel_l2=float(num / den) if den > 0 else float(num), mismatch_frac=float(texel_mism.mean()), differ_frac=float(((d != 0) | bad_class).any(axis=-1).mean()),
+    return dict(rel_l2=float(num / den) if den > 0 else float(num), mismatch_frac=float(texel_mism.mean()) if texel_mism.size else 0.0, differ_frac=float(((d != 0) | bad_class).any(axis=-1).mean()) if texel_mism.size else 0.0,
                 max_abs=float(np.abs(d).max()) if d.size else 0.0, n=int(a.shape[0]), bad_class=int(bad_class.sum()),
                 rel_l2_inliers=float(np.sqrt((din * din).sum()) / den) if den > 0 else float(np.sqrt((din * din).sum())))
 

@@ -34,3 +34,11 @@ def test_ircache_maintenance_and_lookup_at_1080p(gpu, oracle, device):
     import torch
     import test_gpu_ircache as TI
     TI.one_frame_on_identical_state(gpu, oracle, device, "city1m", 1920, 1080)
+
+
+def test_ircache_deterministic_mode_parity_at_1080p(gpu, oracle, device):
+    """Whole GI frames at 1080p on the 1 M-triangle city with the cache in its deterministic mode on both sides, each frame from
+    identical state: the cache per cell (occupancy, lives, votes exact up to a handful of cells; SH, reservoirs, origins within the
+    1e-3 bars) and the GI output (test_gpu_ircache.py: deterministic_frames_on_identical_state)."""
+    import test_gpu_ircache as TI
+    TI.deterministic_frames_on_identical_state(gpu, oracle, device, "city1m", 1920, 1080, warmup=4, frames=2)
