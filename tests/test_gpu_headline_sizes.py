@@ -1,0 +1,169 @@
+"""GPU-vs-oracle parity at the sizes of BASELINE.json's HEADLINE configs (until round 3 nothing above 1080p had a
+parity test, and rtr / shadows / the deferred combine were only compared at <= 256^2):
+
+  configs[3] / north-star target   3840x2160 on the ~4 M-triangle procedural ruins (the Ruins asset is not in the reference checkout):
+                                   every rtdgi pass in isolation + TAA, on identical inputs
+  configs[2]                       2560x1440 on the same scene, the full lighting frame of world_render_passes.rs:124-291: SSAO guide,
+                                   sun shadow mask + denoiser, rtdgi, rtr (six passes), light_gbuffer, TAA on the lit image
+
+Same bars as everywhere else (tests/parity.py): rel-L2 <= 1e-3 AND <= 0.2 % outlier texels AND no finite / non-finite disagreement,
+the flips form for ray passes. Sized for the GPU box: the oracle needs 2-5 s per pass-frame at these extents, so fewer frames than
+the small-extent tests (which cover the ragged / edge cases); each compared set still holds a validation and a tracing frame."""
+import ctypes as C
+import numpy as np
+import pytest
+
+import parity as P
+import test_gpu_parity as T
+import test_gpu_taa as TT
+import test_gpu_rtr as TR
+import test_gpu_shadow_denoise as TS
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rtdgi_per_pass_and_taa_parity_at_4k_ruins(gpu, oracle, device):
+    """Frames 0-2 warm up (whole frames, state forced to the oracle's); frame 3 is a validation frame (3 % 3 == 0), frame 4 a tracing
+    frame: every rtdgi pass in isolation, then TAA (all 15 surfaces) on the frame the oracle has just finished -- a 4K oracle frame
+    costs 10-30 s of host time, so the two share it."""
+    taa = TT.TaaStep(gpu, 3840, 2160)
+    T._per_pass_parity(gpu, oracle, device, "ruins4m", 3840, 2160, 2, False, n_frames=5, warmup=3,
+                       after_frame=lambda op, gp, fi, fc: taa(op, gp, fi, fc, compare=fi >= 2))
+    print(f"TAA at 4K on identical inputs and history: worst per-surface rel-L2 {taa.worst:.2e}")
+
+
+def test_config3_lighting_frame_parity_at_1440p_ruins(gpu, oracle, device):
+    config3_lighting_frame_parity(gpu, oracle, device, "ruins4m", 2560, 1440)
+
+
+def test_config3_lighting_frame_parity_small(gpu, oracle, device):
+    """The same composite on a small extent (odd sizes: ragged half- / quarter-res images), cheap enough for the CPU stand-in."""
+    config3_lighting_frame_parity(gpu, oracle, device, "city20k", 171, 99)
+
+
+def config3_lighting_frame_parity(gpu, oracle, device, scene_name, W, H):
+    """One frame = ssgi -> sun shadow mask -> shadow denoise -> rtdgi -> rtr -> light_gbuffer -> TAA (config3_bench.py's order). Every
+    stage runs on both sides from identical inputs and identical temporal state (the oracle's, uploaded); 2 warm-up frames, then 2
+    compared frames."""
+    import torch
+    from kajiya_amd import frame
+    desc = T._scenes()[scene_name]
+    op, gp = T._make_pipelines(gpu, oracle, device, desc, W, H)
+    fs = frame.FrameState((W, H), sun_size_multiplier=4.0)
+    fcs = []
+    for i in range(4):
+        cam = frame.orbit_camera(i, (W, H), center=(0.0, 3.0, 0.0), radius=34.0, height=5.0, rate=0.004) if scene_name.startswith("ruins") else \
+            frame.orbit_camera(i, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.004)
+        fcs.append(fs.prepare_frame_constants(cam))
+        fs.retire_frame()
+    repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    ssao_dev = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    lit_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    report = {}
+
+    def note(key, r):
+        if key not in report or r["rel_l2"] > report[key]["rel_l2"]:
+            report[key] = r
+
+    for fi, fc in enumerate(fcs):
+        compared = fi >= 2
+        op.render_inputs(fc); op.reprojection(fc)
+        gp.dev.frame_begin(fc)
+        T._sync_inputs(op, gp, torch)
+        gp.sky64.copy_(torch.from_numpy(op.sky64.view(np.int16)))
+        repro_dev.copy_(torch.from_numpy(op.reprojection_map))
+        gp.reprojection_map_ptr = C.c_void_p(repro_dev.data_ptr())
+        # ---- SSAO guide (SsgiRenderer::render), identical history
+        if fi > 0:
+            for n in ("ssgi:0", "ssgi:1"):
+                gp.ssgi_surface(n, torch.uint8, (-1,)).copy_(torch.from_numpy(op.ssgi_surface(n, np.uint8, (-1,)).copy()))
+        ref_ao = op.ssgi_frame(fc).copy()
+        gp.ssgi_frame()
+        torch.cuda.synchronize()
+        got_ao = gpu.tensor_from_ptr(gp.ssao_ptr.value, W * H, torch.uint8, (H, W)).cpu().numpy()
+        if compared:
+            d = np.abs(got_ao.astype(np.int32) - ref_ao.astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 5e-3, ("ssao", fi, d.max(), (d > 0).mean())     # R8 rounding flips only
+        ssao_dev.copy_(torch.from_numpy(ref_ao)); gp.ssao_ptr = C.c_void_p(ssao_dev.data_ptr())     # identical guide downstream
+        # ---- sun shadow mask (one soft-shadow ray per pixel) + denoiser
+        ref_mask = op.sun_shadow_mask(fc)
+        got_mask = gp.sun_shadow_mask().cpu().numpy()
+        if compared:
+            flips = float((got_mask != ref_mask).mean())
+            report[("shadow mask", "flipped pixels")] = dict(rel_l2=flips, mismatch_frac=flips)
+            assert flips <= P.MISMATCH_TOL, ("sun shadow mask", fi, flips)
+        if fi > 0:
+            for n in ("shadow_denoise_accum:0", "shadow_denoise_accum:1", "shadow_denoise_moments:0", "shadow_denoise_moments:1"):
+                gp.shadow_denoise_surface(n, torch.uint8, (-1,)).copy_(torch.from_numpy(op.shadow_denoise_surface(n, np.uint8, (-1,)).copy()))
+        ref_shadow = op.shadow_denoise(fc, ref_mask)
+        got_shadow = gp.shadow_denoise(torch.from_numpy(ref_mask).cuda())
+        torch.cuda.synchronize()
+        if compared:
+            for name, fmt in TS.SURF.items():
+                a = gp.shadow_denoise_surface(name, torch.uint8, (-1,)).cpu().numpy()
+                b = op.shadow_denoise_surface(name, np.uint8, (-1,))
+                if fmt == "u32":
+                    assert np.array_equal(a, b), (fi, name)
+                    continue
+                r = P.compare(a, b, fmt)
+                note(("shadow denoise", name.split(":")[0]), r)
+                assert P.within_bars(r), (fi, name, r)
+        # ---- rtdgi (per-pass parity at this scene: the 4K test above) + rtr, six passes in isolation on identical state
+        if not compared:
+            op.rtdgi_frame(fc); gp.rtdgi_frame()
+            torch.cuda.synchronize()
+            T._upload_state(gp, T._oracle_surfaces(op), torch)
+            op.rtr_frame(fc); gp.rtr_frame()
+            torch.cuda.synchronize()
+            TR._upload_rtr_state(gp, TR._oracle_rtr_state(op), torch)
+        else:
+            pre = T._oracle_surfaces(op)
+            T._upload_state(gp, pre, torch)
+            op.rtdgi_frame(fc); gp.rtdgi_frame()
+            torch.cuda.synchronize()
+            r = P.compare(gp.surface("spatial_filtered_tex", torch.uint8, (-1,)).cpu().numpy(), op.surface("spatial_filtered_tex", np.uint8, (-1,)), "rgba16f")
+            note(("rtdgi whole frame", "spatial_filtered_tex"), r)
+            assert P.within_bars_with_flips(r), ("rtdgi", fi, r)
+            T._upload_state(gp, T._oracle_surfaces(op), torch)
+            for k, pname in enumerate(TR.RTR_PASS_ORDER):
+                mask = TR.KJ_RTR_PASS[pname] | (0 if k == 0 else TR.KJ_RTR_PASS["KEEP"])
+                if k > 0:
+                    TR._upload_rtr_state(gp, TR._oracle_rtr_state(op), torch)
+                op.rtr_frame(fc, mask); gp.rtr_frame(mask)
+                torch.cuda.synchronize()
+                ref, got = TR._oracle_rtr_state(op), TR._download_rtr_state(gp, torch)
+                for n in ref:
+                    r = P.compare(got[n], ref[n], P.fmt_of(n), vector=P.is_vector(n))
+                    note(("rtr " + pname, P.base_name(n)), r)
+                    ok = P.pass_within_bars(pname, r)
+                    if P.fmt_of(n) == "r11g11b10f":
+                        ok = r["mismatch_frac"] <= T.MISMATCH_TOL and r["differ_frac"] <= 0.03
+                    assert ok, f"frame {fi} rtr pass {pname} surface {n}: {r}"
+            TR._upload_rtr_state(gp, TR._oracle_rtr_state(op), torch)
+        # ---- deferred combine on the oracle's shadow mask, GI and reflections (the oracle's combine reads the R8 mask)
+        rtr_ref = op.rtr_surface("resolved_tex", np.uint32, (H, W)).copy()
+        gi_ref = op.surface("spatial_filtered_tex", np.float16, (H, W, 4)).copy()
+        ref_t, ref_o = op.light_gbuffer(fc, ref_mask, gi_ref, rtr_ref, 0)
+        d_mask, d_gi, d_rtr = torch.from_numpy(ref_mask).cuda(), torch.from_numpy(gi_ref.view(np.int16)).cuda(), torch.from_numpy(rtr_ref.view(np.int32)).cuda()
+        got_t, got_o = gp.light_gbuffer(d_mask, rtdgi_ptr=d_gi.data_ptr(), rtr_ptr=d_rtr.data_ptr())
+        torch.cuda.synchronize()
+        if compared:
+            for name, a, b in (("temporal_output", got_t, ref_t), ("output", got_o, ref_o)):
+                r = P.compare(a.cpu().numpy().view(np.uint8).reshape(-1), b.view(np.uint8).reshape(-1), "rgba16f")
+                note(("light_gbuffer", name), r)
+                assert P.within_bars(r), (fi, name, r)
+        # ---- TAA on the lit image, identical history
+        if fi > 0:
+            for n in ("taa:0", "taa:1", "taa.velocity:0", "taa.velocity:1", "taa.smooth_var:0", "taa.smooth_var:1"):
+                gp.taa_surface(n, torch.uint8, (-1,)).copy_(torch.from_numpy(op.taa_surface(n, np.uint8, (-1,)).copy()))
+        lit = np.ascontiguousarray(ref_o)
+        op.taa_frame(fc, input_ptr=lit.ctypes.data)
+        lit_dev.copy_(torch.from_numpy(lit.view(np.int16)))
+        gp.taa_frame(input_ptr=lit_dev.data_ptr())
+        torch.cuda.synchronize()
+        if compared:
+            r = P.compare(gp.taa_surface("this_frame_output_img", torch.uint8, (-1,)).cpu().numpy(), op.taa_surface("this_frame_output_img", np.uint8, (-1,)), "rgba16f")
+            note(("taa", "this_frame_output_img"), r)
+            assert P.within_bars(r), ("taa", fi, r)
+    for k, v in sorted(report.items()):
+        print(f"  {k[0]:>22s} {k[1]:<30s} rel_l2={v['rel_l2']:.2e} mismatch={v['mismatch_frac']:.2e}")

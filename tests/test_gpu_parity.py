@@ -26,6 +26,8 @@ def _frame_constants(W, H, n_frames, scene="cornell"):
             cam = frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=9.0, height=3.0, rate=0.01)
         elif scene == "pica":
             cam = frame.orbit_camera(i, (W, H), center=(-0.4, 0.5, -0.6), radius=5.0, height=1.6, rate=0.01)
+        elif scene == "ruins":     # the bench's 4K / 1440p camera (scripts/config3_bench.py)
+            cam = frame.orbit_camera(i, (W, H), center=(0.0, 3.0, 0.0), radius=34.0, height=5.0, rate=0.004)
         else:
             cam = frame.orbit_camera(i, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.004)
         out.append(fs.prepare_frame_constants(cam))
@@ -51,7 +53,8 @@ class _Scenes:
         from kajiya_amd import scenes
         make = {"cornell": scenes.cornell_box, "city20k": lambda: scenes.procedural_city(target_tris=20000, seed=7, n_instances=24),
                 "textured": scenes.textured_test_scene, "pica": scenes.pica_diorama,
-                "city1m": lambda: scenes.procedural_city(target_tris=1_000_000, seed=1234)}   # the bench's configs[1] stand-in
+                "city1m": lambda: scenes.procedural_city(target_tris=1_000_000, seed=1234),   # the bench's configs[1] stand-in
+                "ruins4m": lambda: scenes.procedural_ruins(target_tris=4_000_000, seed=5678)}  # configs[2..4] stand-in (Ruins is not in the checkout)
         if name not in self._cache:
             self._cache[name] = make[name]()
         return self._cache[name]
@@ -242,7 +245,11 @@ def test_rtdgi_per_pass_parity(gpu, oracle, device, scene_name, W, H):
     _per_pass_parity(gpu, oracle, device, scene_name, W, H, 2, False)
 
 
-def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced):
+def camera_of(scene_name):
+    return scene_name if scene_name in ("cornell", "textured", "pica") else ("ruins" if scene_name.startswith("ruins") else "city")
+
+
+def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced, n_frames=8, warmup=5, after_frame=None):
     import torch
     from kajiya_amd.abi import KJ_RTDGI_PASS
     desc = _scenes()[scene_name]
@@ -250,7 +257,7 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced):
     op.L.okj_rtdgi_set_options(op.rtdgi, passes)
     op.L.okj_rtdgi_set_raytraced_visibility(op.rtdgi, int(raytraced))
     gpu.check(gp.L.kj_rtdgi_set_options(gp.rtdgi, passes, int(raytraced)))
-    fcs = _frame_constants(W, H, 8, scene_name if scene_name in ("cornell", "textured", "pica") else "city")
+    fcs = _frame_constants(W, H, n_frames, camera_of(scene_name))
     repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
     worst = {}
     for fi, fc in enumerate(fcs):
@@ -259,11 +266,13 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced):
         _sync_inputs(op, gp, torch)
         repro_dev.copy_(torch.from_numpy(op.reprojection_map))
         gp.reprojection_map_ptr = C.c_void_p(repro_dev.data_ptr())
-        if fi < 5:
+        if fi < warmup:
             # warm-up frames: run whole frames on both, then force the GPU state to the oracle's
             op.rtdgi_frame(fc); gp.rtdgi_frame()
             torch.cuda.synchronize()
             _upload_state(gp, _oracle_surfaces(op), torch)
+            if after_frame:
+                after_frame(op, gp, fi, fc)
             continue
         # --- pass-by-pass frames (covers a validation frame (fi%3==0) and tracing frames)
         pre = _oracle_surfaces(op)
@@ -288,6 +297,8 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced):
                 if key not in worst or r["rel_l2"] > worst[key]["rel_l2"]:
                     worst[key] = r
                 assert P.pass_within_bars(pname, r), f"frame {fi} pass {pname} surface {n}: {r}"
+        if after_frame:       # e.g. TAA on the frame the oracle has just finished (tests/test_gpu_headline_sizes.py)
+            after_frame(op, gp, fi, fc)
     for k, v in sorted(worst.items()):
         if v["rel_l2"] > 0:
             print(f"  {k[0]:>20s} {k[1]:<36s} rel_l2={v['rel_l2']:.2e} mismatch={v['mismatch_frac']:.2e}")

@@ -27,23 +27,41 @@ def taa_per_frame_parity(gpu, oracle, device, scene_name, W, H, n_frames=8):
     import torch
     desc = T._scenes()[scene_name]
     op, gp = T._make_pipelines(gpu, oracle, device, desc, W, H)
-    fcs = T._frame_constants(W, H, n_frames, "cornell" if scene_name == "cornell" else "city")
-    repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
-    inp_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
-    worst = 0.0
+    fcs = T._frame_constants(W, H, n_frames, T.camera_of(scene_name))
+    step = TaaStep(gpu, W, H)
     for fi, fc in enumerate(fcs):
         op.frame(fc)                       # oracle: inputs + reprojection + rtdgi
+        step(op, gp, fi, fc)
+    print(f"TAA worst per-surface rel-L2 over {len(fcs)} frames on identical inputs and history ({scene_name}): {step.worst:.2e}")
+
+
+class TaaStep:
+    """One TAA frame on both sides from identical input (the oracle's rtdgi output of this frame), reprojection map, depth and
+    temporal state, all 15 surfaces compared. Callable per frame so that other per-frame tests can run TAA on the frames they
+    already paid the oracle for (tests/test_gpu_headline_sizes.py)."""
+
+    def __init__(self, gpu, W, H):
+        import torch
+        self.torch, self.W, self.H = torch, W, H
+        self.repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+        self.inp_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+        self.worst = 0.0
+
+    def __call__(self, op, gp, fi, fc, compare=True):
+        torch, W, H = self.torch, self.W, self.H
         if fi > 0:   # identical temporal state on both sides, like every other per-pass test (a free-running GPU history compounds 1-ulp differences)
             for n in ("taa:0", "taa:1", "taa.velocity:0", "taa.velocity:1", "taa.smooth_var:0", "taa.smooth_var:1"):
                 gp.taa_surface(n, torch.uint8, (-1,)).copy_(torch.from_numpy(op.taa_surface(n, np.uint8, (-1,)).copy()))
         op.taa_frame(fc)
         gp.dev.frame_begin(fc)
         gp.depth.copy_(torch.from_numpy(op.depth))
-        repro_dev.copy_(torch.from_numpy(op.reprojection_map))
-        gp.reprojection_map_ptr = C.c_void_p(repro_dev.data_ptr())
-        inp_dev.copy_(torch.from_numpy(op.surface("spatial_filtered_tex", np.int16, (H, W, 4))))
-        gp.taa_frame(input_ptr=inp_dev.data_ptr())
+        self.repro_dev.copy_(torch.from_numpy(op.reprojection_map))
+        gp.reprojection_map_ptr = C.c_void_p(self.repro_dev.data_ptr())
+        self.inp_dev.copy_(torch.from_numpy(op.surface("spatial_filtered_tex", np.int16, (H, W, 4))))
+        gp.taa_frame(input_ptr=self.inp_dev.data_ptr())
         torch.cuda.synchronize()
+        if not compare:
+            return
         for name, fmt in TAA_SURFACES.items():
             if name == "filtered_history_img" and fi < 2:
                 # filter_history.hlsl:37 divides by the history luma; on the first frames the history is sparse and the
@@ -58,7 +76,7 @@ def taa_per_frame_parity(gpu, oracle, device, scene_name, W, H, n_frames=8):
                 r = {"rel_l2": rel, "mismatch_frac": float((np.abs(a - b) > 1e-3 + 1e-3 * np.abs(b)).mean())}
             else:
                 r = P.compare(got, ref, fmt)
-            worst = max(worst, r["rel_l2"])
+            self.worst = max(self.worst, r["rel_l2"])
             # filter_history.hlsl:37 weights taps by pow8(saturate(cutoff / luma)): where the history is dark (luma ~ 0, freshly disoccluded
             # texels) the quotient is ill-conditioned in the reference itself, so for this image up to 1 % of the texels may be outliers
             # (at most 5e-4 off in absolute terms at 1080p); the image as a whole still has to meet 1e-3. input_prob.hlsl:77-100 divides the
@@ -71,7 +89,6 @@ def taa_per_frame_parity(gpu, oracle, device, scene_name, W, H, n_frames=8):
             # the other; up to 1e-5 of the texels may, for this image only)
             ok = P.within_bars(r, mismatch_tol=1e-2, bad_class_texels=int(1e-5 * r.get("n", 0)) if name == "filtered_history_img" else 0) if name in ill_conditioned else P.within_bars(r)
             assert ok, f"frame {fi} {name}: {r}"
-    print(f"TAA worst per-surface rel-L2 over {len(fcs)} frames on identical inputs and history ({scene_name}): {worst:.2e}")
 
 
 @pytest.mark.parametrize("scale_num,scale_den", [(2, 1), (3, 2)])

@@ -1,10 +1,8 @@
 """PostProcessRenderer (SURVEY 8f-4 "minimal post"): the HIP kernels through the C-ABI vs the oracle, on identical inputs.
 
-STATUS: written after round 1's GPU budget was spent — these tests have not run on hardware yet. Until they have, a failure is reported as
-XFAIL and a pass as XPASS (non-strict), so that an unverified addition cannot hide the state of the verified suite; the marker goes away
-with the first real run. What IS verified: the same kernel source executed on the CPU reproduces the oracle bit for bit
-(tests/test_post_emulation.py), and the oracle is pinned against the Rust text of the kernels that run in the reference
-(tests/test_post_oracle.py). The file sorts last on purpose.
+Verified on hardware since round 2 (the kernel source executed on the CPU also reproduces the oracle bit for bit,
+tests/test_post_emulation.py, and the oracle is pinned against the Rust text of the kernels that run in the reference,
+tests/test_post_oracle.py). The file sorts last for historical reasons.
 
 Tolerances: every image here is B10G11R11_UFLOAT. GPU and CPU differ by rounding noise (FMA contraction, ocml's exp / pow / log2), which a
 6- or 5-bit mantissa turns into whole-step flips at rounding boundaries; a later mip reads those flips, so "no texel further than TWO
@@ -15,7 +13,7 @@ import pytest
 import parity as P
 from kajiya_amd import frame, post_tables
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="not yet run on hardware (round-1 GPU budget spent before this path was written)")]
+pytestmark = pytest.mark.gpu
 
 STEP = np.array([1 / 64, 1 / 64, 1 / 32])
 
