@@ -330,6 +330,14 @@ KjStatus kj_rtdgi_set_profiling(KjRtdgi* r, uint32_t enable_pass_timers, uint32_
 KjStatus kj_rtdgi_pass_times_ms(KjRtdgi* r, float* out_ms, uint32_t count);
 /* out[6] = closest rays, any-hit rays, nodes (closest), tris (closest), nodes (any), tris (any) */
 KjStatus kj_rtdgi_traversal_counts(KjRtdgi* r, uint64_t out[6]);
+/* How the two ray-tracing passes (`rtdgi validate`, `rtdgi trace`: rtdgi.rs:283-365) are scheduled on the device. The outputs are
+ * bit-identical for every form; the knob exists for A/B measurements in one process (kj_rtdgi_create takes its default from
+ * KJ_RTDGI_GROUPED / KJ_RTDGI_STAGED_MIN_RAYS).
+ *   KJ_RTDGI_RAYS_GROUPED (default): 256-thread workgroups, hit shading regrouped onto full waves through LDS
+ *   KJ_RTDGI_RAYS_FUSED: one wave per 8x8 tile runs ray generation, both traversals and hit shading (the ray-generation shader's shape)
+ *   KJ_RTDGI_RAYS_STAGED: five launches over dense ray arrays (ray streams) */
+enum { KJ_RTDGI_RAYS_GROUPED = 0, KJ_RTDGI_RAYS_FUSED = 1, KJ_RTDGI_RAYS_STAGED = 2 };
+KjStatus kj_rtdgi_set_ray_pass_form(KjRtdgi* r, uint32_t form);
 /* Ray counters of the last kj_rtdgi_render (closest-hit rays, any-hit rays). */
 KjStatus kj_rtdgi_ray_counts(KjRtdgi* r, uint64_t* out_closest, uint64_t* out_any);
 

@@ -133,6 +133,10 @@ struct TraceCtx {
 };
 
 KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
+#if !defined(__HIP_DEVICE_COMPILE__)      // the tests' CPU stand-in for HIP has no wave votes in multi-wave workgroups: one atomic per lane
+    if (active) atomicAdd(&counter_slot(counters)[which], 1ull);
+    return;
+#endif
     const unsigned long long m = __ballot(active);
     if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
 }
@@ -145,6 +149,85 @@ KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
 // utilisation (two thirds of the rays leave the scene, and their lanes idle through hit shading and the shadow ray): its rays alone
 // would take 0.13 of its 0.28 ms at the microbench's rates.
 struct TraceResult { V3 out_value; V3 hit_normal_ws; float hit_t; float pdf; bool is_hit; };
+// Everything diffuse_trace_common.inc.hlsl:80-200 does for a ray that HIT (the divergent part: G-buffer of the hit, the sun's shadow ray,
+// the triangle lights, last frame's GI or the irradiance cache). Shared by the fused and the grouped form of the ray passes so that both
+// sum the radiance terms with the same arithmetic in the same order. Returns the radiance; `hit_normal_ws` = the hit's shading normal.
+template <bool STATS>
+KJ_D V3 shade_candidate_hit(const TraceCtx& c, uint32_t px, uint32_t py, uint32_t& rng, V3 ray_o, V3 ray_d, const GbufferPathVertex& primary_hit, uint32_t* stack, uint32_t stride,
+                            TraverseStats* st_any, V3& hit_normal_ws) {
+    const FrameConstants& fc = *c.fc;
+    V3 total_radiance = v3(0.0f);
+    GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);
+    hit_normal_ws = gbuffer.normal;
+    const V3 hit_cs = position_world_to_sample(fc, primary_hit.position);
+    const V2 hit_uv = cs_to_uv(V2{hit_cs.x, hit_cs.y});
+    const float screen_depth = sample_nearest_clamp(c.depth, hit_uv);
+    bool is_on_screen = fabsf(hit_cs.x) < 1.0f && fabsf(hit_cs.y) < 1.0f && inverse_depth_relative_diff(hit_cs.z, screen_depth) < 5e-3f;
+    V4 reprojected_radiance = v4(0.0f);
+    if (is_on_screen) {
+        reprojected_radiance = unpack_rgba16f(sample_nearest_clamp(c.reprojected_gi, hit_uv)) * fc.pre_exposure_delta;
+        is_on_screen = reprojected_radiance.w > 0;
+    }
+    gbuffer.roughness = lerp(gbuffer.roughness, 1.0f, ROUGHNESS_BIAS);
+    const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
+    const V3 wo = to_local(tangent_to_world, -ray_d);
+    const LayeredBrdf brdf = layered_brdf_from_gbuffer_ndotv(c.brdf_fg_lut, gbuffer, wo.z);
+    const float4 sc4 = *c.sun_color;
+    const V3 sun_radiance{sc4.x, sc4.y, sc4.z};
+    if (sun_radiance.x != 0 || sun_radiance.y != 0 || sun_radiance.z != 0) {
+        const V4 bn = blue_noise_for_pixel(c.blue_noise, px, py, rng);
+        const V3 to_light_norm = sample_sun_direction(fc, V2{bn.x, bn.y}, false);
+        count_rays(c.ray_counters, 1, true);
+        const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, stride, st_any);
+        const V3 wi = to_local(tangent_to_world, to_light_norm);
+        const V3 brdf_value = layered_brdf_evaluate(brdf, wo, wi) * fmaxf(0.0f, wi.z);
+        total_radiance += brdf_value * (is_shadowed ? v3(0.0f) : sun_radiance);
+    }
+    total_radiance += gbuffer.emissive;
+    if (is_on_screen) {
+        total_radiance += xyz(reprojected_radiance) * gbuffer.albedo;
+    } else {
+        V2 urand;
+        urand.x = uint_to_u01_float(hash1_mut(rng));
+        urand.y = uint_to_u01_float(hash1_mut(rng));
+        const uint32_t nl = min(fc.triangle_light_count, c.sc.light_count);
+        for (uint32_t li = 0; li < nl; ++li) {
+            const KjTriangleLight tl = c.sc.lights[li];
+            const V3 v0{tl.verts[0], tl.verts[1], tl.verts[2]}, v1{tl.verts[3], tl.verts[4], tl.verts[5]}, v2{tl.verts[6], tl.verts[7], tl.verts[8]};
+            const LightSampleArea ls = sample_triangle_light(v0, v1 - v0, v2 - v0, urand);
+            const V3 to_light_ws = ls.pos - primary_hit.position;
+            const float dist2 = dot(to_light_ws, to_light_ws);
+            const V3 to_light_norm_ws = to_light_ws * (1.0f / sqrtf(dist2));
+            const float to_psa_metric = fmaxf(0.0f, dot(to_light_norm_ws, gbuffer.normal)) * fmaxf(0.0f, dot(to_light_norm_ws, -ls.normal)) / dist2;
+            if (to_psa_metric > 0.0f) {
+                count_rays(c.ray_counters, 1, true);
+                const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, stride, st_any);
+                const V3 bounce_albedo = lerp(gbuffer.albedo, v3(1.0f), 0.04f);
+                const V3 brdf_value = bounce_albedo * to_psa_metric / KJ_PI;
+                if (!is_shadowed) total_radiance += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * brdf_value / ls.pdf;
+            }
+        }
+        if (c.has_ircache) {  // USE_IRCACHE (diffuse_trace_common.inc.hlsl:189-198); unbound => contributes 0 (BASELINE config 1)
+            const uint32_t rq = py * c.request_stride + px;
+            const V3 gi = ircache_lookup<false>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng, false, c.request_slot_base + rq, c.request_key_base | rq);
+            total_radiance += gi * gbuffer.albedo;
+        }
+    }
+    return total_radiance;
+}
+// diffuse_trace_common.inc.hlsl:68-71: reflected cone = the half-res pixel cone propagated from the eye to the ray origin
+KJ_D RayCone candidate_ray_cone(const TraceCtx& c, V3 ray_o) {
+    return pixel_ray_cone_from_image_height(*c.fc, float(c.depth.h) * 0.5f).propagate(0.03f, length(ray_o - get_eye_position(*c.fc)));
+}
+template <bool STATS>
+KJ_D void add_traversal_stats(const TraceCtx& c, const TraverseStats& st_closest, const TraverseStats& st_any) {
+    if (STATS) {  // instrumentation build only: traversal work per ray type (SURVEY 8d "measured by the instrumented kernel")
+        atomicAdd(&counter_slot(c.ray_counters)[2], (unsigned long long)st_closest.nodes);
+        atomicAdd(&counter_slot(c.ray_counters)[3], (unsigned long long)st_closest.tris);
+        atomicAdd(&counter_slot(c.ray_counters)[4], (unsigned long long)st_any.nodes);
+        atomicAdd(&counter_slot(c.ray_counters)[5], (unsigned long long)st_any.tris);
+    }
+}
 template <bool STATS>
 KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3 normal_ws, uint32_t& rng, V3 ray_o, V3 ray_d, float ray_tmax, uint32_t* stack) {
     const FrameConstants& fc = *c.fc;
@@ -154,77 +237,113 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
     const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, ray_d) * 2 * KJ_PI));
     count_rays(c.ray_counters, 0, true);
     TraverseStats st_closest{0, 0}, st_any{0, 0};
-    // diffuse_trace_common.inc.hlsl:68-71: reflected cone = the half-res pixel cone propagated from the eye to the ray origin
-    const RayCone ray_cone = pixel_ray_cone_from_image_height(fc, float(c.depth.h) * 0.5f).propagate(0.03f, length(ray_o - get_eye_position(fc)));
-    const GbufferPathVertex primary_hit = gbuffer_raytrace<STATS>(c.sc, fc, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, 64, &st_closest, ray_cone);
+    const GbufferPathVertex primary_hit = gbuffer_raytrace<STATS>(c.sc, fc, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, 64, &st_closest, candidate_ray_cone(c, ray_o));
     if (primary_hit.is_hit) {
         hit_t = primary_hit.ray_t;
-        GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);
-        hit_normal_ws = gbuffer.normal;
-        const V3 hit_cs = position_world_to_sample(fc, primary_hit.position);
-        const V2 hit_uv = cs_to_uv(V2{hit_cs.x, hit_cs.y});
-        const float screen_depth = sample_nearest_clamp(c.depth, hit_uv);
-        bool is_on_screen = fabsf(hit_cs.x) < 1.0f && fabsf(hit_cs.y) < 1.0f && inverse_depth_relative_diff(hit_cs.z, screen_depth) < 5e-3f;
-        V4 reprojected_radiance = v4(0.0f);
-        if (is_on_screen) {
-            reprojected_radiance = unpack_rgba16f(sample_nearest_clamp(c.reprojected_gi, hit_uv)) * fc.pre_exposure_delta;
-            is_on_screen = reprojected_radiance.w > 0;
-        }
-        gbuffer.roughness = lerp(gbuffer.roughness, 1.0f, ROUGHNESS_BIAS);
-        const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
-        const V3 wo = to_local(tangent_to_world, -ray_d);
-        const LayeredBrdf brdf = layered_brdf_from_gbuffer_ndotv(c.brdf_fg_lut, gbuffer, wo.z);
-        const float4 sc4 = *c.sun_color;
-        const V3 sun_radiance{sc4.x, sc4.y, sc4.z};
-        if (sun_radiance.x != 0 || sun_radiance.y != 0 || sun_radiance.z != 0) {
-            const V4 bn = blue_noise_for_pixel(c.blue_noise, px, py, rng);
-            const V3 to_light_norm = sample_sun_direction(fc, V2{bn.x, bn.y}, false);
-            count_rays(c.ray_counters, 1, true);
-            const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, 64, &st_any);
-            const V3 wi = to_local(tangent_to_world, to_light_norm);
-            const V3 brdf_value = layered_brdf_evaluate(brdf, wo, wi) * fmaxf(0.0f, wi.z);
-            total_radiance += brdf_value * (is_shadowed ? v3(0.0f) : sun_radiance);
-        }
-        total_radiance += gbuffer.emissive;
-        if (is_on_screen) {
-            total_radiance += xyz(reprojected_radiance) * gbuffer.albedo;
-        } else {
-            V2 urand;
-            urand.x = uint_to_u01_float(hash1_mut(rng));
-            urand.y = uint_to_u01_float(hash1_mut(rng));
-            const uint32_t nl = min(fc.triangle_light_count, c.sc.light_count);
-            for (uint32_t li = 0; li < nl; ++li) {
-                const KjTriangleLight tl = c.sc.lights[li];
-                const V3 v0{tl.verts[0], tl.verts[1], tl.verts[2]}, v1{tl.verts[3], tl.verts[4], tl.verts[5]}, v2{tl.verts[6], tl.verts[7], tl.verts[8]};
-                const LightSampleArea ls = sample_triangle_light(v0, v1 - v0, v2 - v0, urand);
-                const V3 to_light_ws = ls.pos - primary_hit.position;
-                const float dist2 = dot(to_light_ws, to_light_ws);
-                const V3 to_light_norm_ws = to_light_ws * (1.0f / sqrtf(dist2));
-                const float to_psa_metric = fmaxf(0.0f, dot(to_light_norm_ws, gbuffer.normal)) * fmaxf(0.0f, dot(to_light_norm_ws, -ls.normal)) / dist2;
-                if (to_psa_metric > 0.0f) {
-                    count_rays(c.ray_counters, 1, true);
-                    const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, 64, &st_any);
-                    const V3 bounce_albedo = lerp(gbuffer.albedo, v3(1.0f), 0.04f);
-                    const V3 brdf_value = bounce_albedo * to_psa_metric / KJ_PI;
-                    if (!is_shadowed) total_radiance += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * brdf_value / ls.pdf;
-                }
-            }
-            if (c.has_ircache) {  // USE_IRCACHE (diffuse_trace_common.inc.hlsl:189-198); unbound => contributes 0 (BASELINE config 1)
-                const uint32_t rq = py * c.request_stride + px;
-                const V3 gi = ircache_lookup<false>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng, false, c.request_slot_base + rq, c.request_key_base | rq);
-                total_radiance += gi * gbuffer.albedo;
-            }
-        }
+        total_radiance = shade_candidate_hit<STATS>(c, px, py, rng, ray_o, ray_d, primary_hit, stack, 64, &st_any, hit_normal_ws);
     } else {
         total_radiance += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
     }
-    if (STATS) {  // instrumentation build only: traversal work per ray type (SURVEY 8d "measured by the instrumented kernel")
-        atomicAdd(&counter_slot(c.ray_counters)[2], (unsigned long long)st_closest.nodes);
-        atomicAdd(&counter_slot(c.ray_counters)[3], (unsigned long long)st_closest.tris);
-        atomicAdd(&counter_slot(c.ray_counters)[4], (unsigned long long)st_any.nodes);
-        atomicAdd(&counter_slot(c.ray_counters)[5], (unsigned long long)st_any.tris);
-    }
+    add_traversal_stats<STATS>(c, st_closest, st_any);
     return TraceResult{total_radiance, hit_normal_ws, hit_t, pdf, primary_hit.is_hit};
+}
+
+// ---- grouped form of the two ray passes (the default): a 256-thread workgroup = four 8x8 tiles (2 x 2). Two thirds of the candidate
+// rays leave the scene, so in the fused form above a wave runs everything after the closest-hit query -- G-buffer of the hit, the sun's
+// shadow-ray traversal, lights, cache lookup -- with a sixth of its lanes (lane utilisation 34 % over the kernel, PMC). Here
+//   1. every pixel traces its closest-hit ray (as before);
+//   2. lanes that hit park a 48-byte record {ray, (t, u, v, triangle), pixel, rng} in LDS, compacted per wave by ballot + prefix count;
+//   3. the workgroup's records are dealt to ceil(n / 64) of its waves, evenly, and THOSE waves run shade_candidate_hit on full(er)
+//      waves -- one shadow-ray traversal for four tiles' hits instead of four mostly empty ones; the other waves sleep at the barrier;
+//   4. results return through LDS to the pixels that own them.
+// The arithmetic per ray, the order of the radiance sums and the rng streams are those of the fused form (same functions), so the
+// outputs are bit-identical to it. LDS per workgroup: the traversal stacks (16 x 256 dwords) + 256 records (12 KB, reused for the
+// results) = 28 KB -> five workgroups = 20 waves per CU, the fused form's occupancy.
+struct HitRecord { float ox, oy, oz, dx, dy, dz, t, u, v; uint32_t slot, pixel_and_owner, rng; };     // pixel_and_owner = px | py << 12 | owner thread << 24
+#define KJ_GROUP_THREADS 256u
+KJ_HD size_t grouped_lds_bytes(uint32_t stack_entries) { return size_t(stack_entries) * KJ_GROUP_THREADS * 4 + KJ_GROUP_THREADS * sizeof(HitRecord) + 16; }
+// 2 x 2 tiles: wave w covers tile (w & 1, w >> 1) of the 16 x 16 block
+#define GROUP_TILE_XY(W_, H_)                                                                                              \
+    const int lane = int(threadIdx.x & 63u), wave = int(threadIdx.x >> 6);                                                  \
+    const int x = int(blockIdx.x) * 16 + (wave & 1) * 8 + (lane & 7), y = row0 + int(blockIdx.y) * 16 + (wave >> 1) * 8 + (lane >> 3); \
+    const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
+// Called by ALL threads of the workgroup (barriers inside); `has_ray` false = this pixel traces nothing (sky, outside the image).
+template <bool STATS>
+KJ_D TraceResult trace_candidate_grouped(const TraceCtx& c, bool has_ray, uint32_t px, uint32_t py, V3 normal_ws, uint32_t rng, V3 ray_o, V3 ray_d, float ray_tmax, uint32_t* lds) {
+    const FrameConstants& fc = *c.fc;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t* stack = lds + tid;
+    HitRecord* rec = (HitRecord*)(lds + size_t(c.sc.bvh.stack_entries) * KJ_GROUP_THREADS);
+    uint32_t* counts = (uint32_t*)(rec + KJ_GROUP_THREADS);
+    V3 total_radiance = v3(0.0f);
+    V3 hit_normal_ws = -ray_d;
+    float hit_t = ray_tmax;
+    const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, ray_d) * 2 * KJ_PI));
+    TraverseStats st_closest{0, 0}, st_any{0, 0};
+    RayHit h;
+    h.slot = 0xffffffffu; h.t = 0; h.u = 0; h.v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    count_rays(c.ray_counters, 0, has_ray);
+#else
+    if (has_ray) atomicAdd(&counter_slot(c.ray_counters)[0], 1ull);
+    if (lane == 0) counts[wave] = 0;
+    __syncthreads();
+#endif
+    if (has_ray) h = bvh_trace<false, STATS>(c.sc.bvh, ray_o, ray_d, 0.0f, ray_tmax, false, stack, KJ_GROUP_THREADS, &st_closest);
+    const bool hit = has_ray && h.slot != 0xffffffffu;
+    if (has_ray && !hit) total_radiance += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
+    // 2. park the hits, compacted per wave
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long hm = __ballot(hit);
+    const uint32_t rank = uint32_t(__popcll(hm & ((1ull << lane) - 1ull)));
+    if (lane == 0) counts[wave] = uint32_t(__popcll(hm));
+#else
+    const uint32_t rank = hit ? atomicAdd(&counts[wave], 1u) : 0u;    // the CPU stand-in has no wave votes in multi-wave workgroups
+#endif
+    if (hit) {
+        HitRecord r;
+        r.ox = ray_o.x; r.oy = ray_o.y; r.oz = ray_o.z; r.dx = ray_d.x; r.dy = ray_d.y; r.dz = ray_d.z;
+        r.t = h.t; r.u = h.u; r.v = h.v; r.slot = h.slot; r.pixel_and_owner = px | (py << 12) | (tid << 24); r.rng = rng;
+        rec[wave * 64u + rank] = r;
+    }
+    __syncthreads();
+    // 3. deal the workgroup's records to as few waves as hold them, evenly
+    const uint32_t n0 = counts[0], n1 = counts[1], n2 = counts[2], n3 = counts[3], total = n0 + n1 + n2 + n3;
+    const uint32_t waves_used = (total + 63u) / 64u;
+    const uint32_t per_wave = waves_used ? (total + waves_used - 1u) / waves_used : 0u;
+    const uint32_t first = wave * per_wave;
+    const bool work = wave < waves_used && first + lane < min(total, first + per_wave);
+    HitRecord r;
+    if (work) {
+        uint32_t j = first + lane, sw = 0;
+        if (j >= n0) { j -= n0; sw = 1; if (j >= n1) { j -= n1; sw = 2; if (j >= n2) { j -= n2; sw = 3; } } }
+        r = rec[sw * 64u + j];
+    }
+    __syncthreads();                       // every record is in registers: the area now takes the results
+    float* results = (float*)rec;          // [owner thread][radiance.xyz, hit normal.xyz]
+    if (work) {
+        const V3 o{r.ox, r.oy, r.oz}, d{r.dx, r.dy, r.dz};
+        RayHit rh;
+        rh.t = r.t; rh.u = r.u; rh.v = r.v; rh.slot = r.slot; rh.world_id = 0;
+        GbufferPathVertex pv;
+        pv.is_hit = true; pv.ray_t = r.t;
+        pv.gbuffer_packed = shade_gbuffer_hit(c.sc, fc, d, rh, 1, candidate_ray_cone(c, o).width_at_t(r.t * length(d)));      // GbufferRaytrace::trace, inc/rt.hlsl:112-137
+        pv.position = mad_nc(o, d, r.t);
+        uint32_t rrng = r.rng;
+        V3 n;
+        const V3 rad = shade_candidate_hit<STATS>(c, r.pixel_and_owner & 0xfffu, (r.pixel_and_owner >> 12) & 0xfffu, rrng, o, d, pv, stack, KJ_GROUP_THREADS, &st_any, n);
+        float* dst = results + (r.pixel_and_owner >> 24) * 6u;
+        dst[0] = rad.x; dst[1] = rad.y; dst[2] = rad.z; dst[3] = n.x; dst[4] = n.y; dst[5] = n.z;
+    }
+    __syncthreads();
+    if (hit) {
+        const float* src = results + tid * 6u;
+        total_radiance = V3{src[0], src[1], src[2]};
+        hit_normal_ws = V3{src[3], src[4], src[5]};
+        hit_t = h.t;
+    }
+    add_traversal_stats<STATS>(c, st_closest, st_any);
+    return TraceResult{total_radiance, hit_normal_ws, hit_t, pdf, hit};
 }
 
 // ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111
@@ -305,6 +424,96 @@ __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_fused(TraceC
         st4(candidate_hit_out_tex, x, y, v4(hit_offset_ws, result.pdf * (tracing_frame ? 1.0f : -1.0f)));
         candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, result.hit_normal_ws), 0)));
     }
+    const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
+    const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
+    invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
+}
+
+// ---- the two ray passes in the grouped form (trace_candidate_grouped above)
+#ifndef KJ_GROUPED_WAVES
+#define KJ_GROUPED_WAVES 5
+#endif
+template <bool STATS>
+__global__ void __launch_bounds__(KJ_GROUP_THREADS, KJ_GROUPED_WAVES) k_rtdgi_validate_grouped(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
+                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+    extern __shared__ uint32_t lds_group[];
+    GROUP_TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const bool sky = in_image && 0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y);
+    if (!is_rtdgi_validation_frame(fc.frame_index)) {      // uniform: two frames of three the pass only writes the invalidity image
+        if (in_image) invalidity_out_tex.st(x, y, to_unorm8(sky ? 1.0f : 0.0f));
+        return;
+    }
+    const bool has_ray = in_image && !sky;
+    V3 normal_ws = v3(0.0f), prev_ray_orig = v3(0.0f), prev_hit_pos = v3(0.0f), prev_radiance = v3(0.0f), dir = V3{0.0f, 0.0f, 1.0f};
+    V4 prev_radiance_packed = v4(0.0f);
+    if (has_ray) {
+        normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
+        const float4 ro = ray_orig_history_tex.ld(x, y);
+        prev_ray_orig = V3{ro.x, ro.y, ro.z};
+        prev_hit_pos = xyz(ld4(reservoir_ray_history_tex, x, y)) + prev_ray_orig;
+        prev_radiance_packed = ld4(irradiance_history_tex, x, y);
+        prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
+        dir = normalize(prev_hit_pos - prev_ray_orig);
+    }
+    const TraceResult result = trace_candidate_grouped<STATS>(c, has_ray, uint32_t(x), uint32_t(y), normal_ws, hash3(uint32_t(x), uint32_t(y), 0), prev_ray_orig, dir, SKY_DIST, lds_group);
+    if (!in_image) return;
+    if (sky) { invalidity_out_tex.st(x, y, to_unorm8(1.0f)); return; }
+    const V3 new_radiance = vmax(v3(0.0f), result.out_value);
+    const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
+    const float invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
+    const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
+    if (fabsf(result.hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
+        st4(irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
+        Reservoir1spp r = Reservoir1spp::from_raw(reservoir_tex.ld(x, y));
+        const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
+        r.M *= clampf(lum_old / fmaxf(1e-8f, lum_new), 0.03f, 1.0f);
+        r.W *= clampf(lum_old / fmaxf(1e-8f, lum_new) * 10.0f, 0.01f, 1.0f);
+        reservoir_tex.st(x, y, r.as_raw());
+    }
+    invalidity_out_tex.st(x, y, to_unorm8(invalidity));
+}
+template <bool STATS>
+__global__ void __launch_bounds__(KJ_GROUP_THREADS, KJ_GROUPED_WAVES) k_rtdgi_trace_grouped(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
+                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+    extern __shared__ uint32_t lds_group[];
+    GROUP_TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+    const float depth = in_image ? c.depth.ld(hx, hy) : 0.0f;
+    const bool has_ray = in_image && depth != 0.0f;
+    const V4 gts = tex_size4(c.depth.w, c.depth.h);
+    const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
+    V3 normal_ws = v3(0.0f), outgoing_dir = V3{0.0f, 0.0f, 1.0f}, origin = v3(0.0f), view_dir = v3(0.0f);
+    float tmax = SKY_DIST;
+    if (has_ray) {
+        const V2 uv = get_uv(float(hx), float(hy), gts);
+        const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
+        const float near_field_fade_out_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
+        normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
+        const Basis tangent_to_world = build_orthonormal_basis(normal_ws);
+        const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, fc.frame_index);
+        outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
+        origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
+        view_dir = vr.dir_ws;
+        tmax = tracing_frame ? SKY_DIST : near_field_fade_out_end;
+    }
+    TraceResult result = trace_candidate_grouped<STATS>(c, has_ray, uint32_t(x), uint32_t(y), normal_ws, hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u), origin, outgoing_dir, tmax, lds_group);
+    if (!in_image) return;
+    if (!has_ray) {
+        st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
+        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
+        invalidity_out_tex.st(x, y, 0);
+        return;
+    }
+    if (!tracing_frame && !result.is_hit) { result.out_value = v3(0.0f); result.hit_t = SKY_DIST; }
+    const V3 hit_offset_ws = outgoing_dir * result.hit_t;
+    const float cos_theta = dot(normalize(outgoing_dir - view_dir), normal_ws);
+    st4(candidate_irradiance_out_tex, x, y, v4(result.out_value, 1.0f - cos_theta));
+    st4(candidate_hit_out_tex, x, y, v4(hit_offset_ws, result.pdf * (tracing_frame ? 1.0f : -1.0f)));
+    candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, result.hit_normal_ws), 0)));
     const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
     const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
     invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
@@ -857,6 +1066,7 @@ struct KjRtdgi {
     bool count_traversal = false;               // instrumented trace kernels
     uint32_t staged_min_rays = 0xffffffffu;     // ray passes run staged (ray streams) from this many ray slots per launch (KJ_RTDGI_STAGED_MIN_RAYS); default: never, see below
     uint32_t stream_waves_per_cu = 24;          // persistent waves per CU of a ray-stream launch (measured best of 8 / 16 / 24 / 32: scripts/traversal_microbench.py)
+    bool grouped_rays = true;                   // the ray passes' form when not staged: grouped (hit shading regrouped inside a 256-thread workgroup) or fused (KJ_RTDGI_GROUPED=0)
     int resample_variant = 2;                   // spatial reuse: 2 = per-tap gathers (fastest measured), 0 / 1 = LDS-staged tiles (KJ_RTDGI_RESAMPLE_VARIANT; rtdgi_resample.hpp)
     static const int NUM_SCOPES = 11;
     hipEvent_t ev[NUM_SCOPES][2] = {};
@@ -896,6 +1106,7 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     r->dev = dev;
     if (const char* v = getenv("KJ_RTDGI_RESAMPLE_VARIANT")) r->resample_variant = atoi(v);
     if (const char* v = getenv("KJ_RTDGI_STAGED_MIN_RAYS")) r->staged_min_rays = uint32_t(atoll(v));
+    if (const char* v = getenv("KJ_RTDGI_GROUPED")) r->grouped_rays = atoi(v) != 0;
     if (r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
     *out = r;
     return KJ_OK;
@@ -1030,7 +1241,19 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
                                 (const float4*)st.rays_b, (float4*)nullptr, st.occl_b, stage_rays, tc.ray_counters, stream_tune);
     };
     const bool staged = stage_rays >= r->staged_min_rays;
-    if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged) {
+    // the fused form (one wave per tile does everything) or the grouped one (hit shading regrouped inside a 256-thread workgroup); same
+    // outputs bit for bit (kj_rtdgi_set_ray_pass_form)
+    const bool grouped = r->grouped_rays;
+    const dim3 gg((hw + 15) / 16, (uint32_t(hr1 - hr0) + 15) / 16), gblk(KJ_GROUP_THREADS);
+    const size_t grouped_lds = grouped_lds_bytes(tc.sc.bvh.stack_entries);
+    if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged && grouped) {
+        SCOPE_BEGIN(2);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_grouped<true> : k_rtdgi_validate_grouped<false>, gg, gblk, grouped_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+                           img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(2);
+    }
+    if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged && !grouped) {
         SCOPE_BEGIN(2);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
                            img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
@@ -1038,7 +1261,14 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         SCOPE_END(2);
     }
     tc.request_slot_base = uint32_t(hw) * uint32_t(hh); tc.request_key_base = 2u << 28;
-    if ((mask & KJ_RTDGI_PASS_TRACE) && !staged) {
+    if ((mask & KJ_RTDGI_PASS_TRACE) && !staged && grouped) {
+        SCOPE_BEGIN(3);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_grouped<true> : k_rtdgi_trace_grouped<false>, gg, gblk, grouped_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(3);
+    }
+    if ((mask & KJ_RTDGI_PASS_TRACE) && !staged && !grouped) {
         SCOPE_BEGIN(3);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
                            img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
@@ -1051,7 +1281,9 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         if (is_rtdgi_validation_frame(r->dev->fc_host.frame_index)) {   // on the two tracing frames of three the pass has no rays: only the invalidity image is written
             trace_streams(true);
-            hipLaunchKernelGGL(k_rtdgi_shade<true>, gh, blk, trace_lds, s, tc, st, img<uint32_t>(half_view_normal, hw, hh), img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), hw, hh, hr0, hr1);
+            TraceCtx vc = tc;        // the validate pass' own request slots / keys (tc was re-based for the trace pass above)
+            vc.request_slot_base = 0; vc.request_key_base = 1u << 28;
+            hipLaunchKernelGGL(k_rtdgi_shade<true>, gh, blk, trace_lds, s, vc, st, img<uint32_t>(half_view_normal, hw, hh), img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), hw, hh, hr0, hr1);
             trace_streams(false);
             hipLaunchKernelGGL(k_rtdgi_validate_finish, gh, blk, 0, s, st, img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh), img<uint2>(radiance_hist, hw, hh),
                                img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
@@ -1187,6 +1419,12 @@ KjStatus kj_rtdgi_set_profiling(KjRtdgi* r, uint32_t enable_pass_timers, uint32_
     }
     r->profiling = enable_pass_timers != 0;
     r->count_traversal = count_traversal != 0;
+    return KJ_OK;
+}
+KjStatus kj_rtdgi_set_ray_pass_form(KjRtdgi* r, uint32_t form) {
+    KJ_REQUIRE(r && form <= KJ_RTDGI_RAYS_STAGED, "null argument / unknown form");
+    r->grouped_rays = form == KJ_RTDGI_RAYS_GROUPED;
+    r->staged_min_rays = form == KJ_RTDGI_RAYS_STAGED ? 0u : 0xffffffffu;
     return KJ_OK;
 }
 KjStatus kj_rtdgi_pass_times_ms(KjRtdgi* r, float* out_ms, uint32_t count) {

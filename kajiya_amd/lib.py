@@ -22,7 +22,7 @@ EXPORTS = [
     "kj_scene_stats", "kj_scene_last_commit_ms", "kj_scene_set_blas_build_mode", "kj_frame_begin", "kj_trace_closest", "kj_trace_any", "kj_debug_calibration_copy", "kj_raster_gbuffer", "kj_sky_cube_render",
     "kj_sky_cube_convolve", "kj_reprojection_create", "kj_reprojection_destroy", "kj_calculate_reprojection_map",
     "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_render",
-    "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
+    "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_set_ray_pass_form", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
     "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts", "kj_ircache_set_deferred_updates", "kj_ircache_begin_requests", "kj_ircache_request_ranges", "kj_ircache_collect_requests", "kj_ircache_apply_requests",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
@@ -94,6 +94,7 @@ def load():
         "kj_rtdgi_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_rtdgi_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "kj_rtdgi_set_profiling": [vp, u32, u32],
+        "kj_rtdgi_set_ray_pass_form": [vp, u32],
         "kj_rtdgi_pass_times_ms": [vp, C.POINTER(C.c_float), u32],
         "kj_rtdgi_traversal_counts": [vp, C.POINTER(C.c_uint64)],
         "kj_ircache_create": [vp, C.POINTER(vp)],
@@ -455,12 +456,14 @@ class GpuPipeline:
         check(self.L.kj_ircache_request_ranges(self.ircache, first, count))
         return list(first), list(count)
 
-    def ircache_collect(self, ranges, capacity=None):
+    def ircache_collect(self, ranges, capacity=None, tag="all"):
         """Compacts the recorded requests of the slot ranges [(first, count), ...] into one device list; returns (int32 tensor
-        [capacity, 8], device int32 counter). 32 bytes per request."""
+        [capacity, 8], device int32 counter). 32 bytes per request. The list buffer is cached per (`tag`, capacity): two lists that
+        are alive at the same time (a strip's and the cache passes' in the split) must carry different tags -- with equal
+        capacities (2 x 262144 half-res pixels == 2 x IRC_MAX_ENTRIES x 4) they would otherwise share one buffer."""
         torch = self.torch
         capacity = capacity or sum(c for _, c in ranges)
-        key = ("_req_list", capacity)
+        key = ("_req_list", tag, capacity)
         buf = getattr(self, "_req_bufs", {}).get(key)
         if buf is None:
             buf = torch.empty((max(1, capacity), 8), dtype=torch.int32, device=self.depth.device)
@@ -624,6 +627,12 @@ class GpuPipeline:
 
     PASS_NAMES = ["rtdgi reproject", "extract half", "rtdgi validate", "rtdgi trace", "validity integrate", "restir temporal",
                   "restir spatial 0", "restir spatial 1", "restir resolve", "rtdgi temporal", "rtdgi spatial"]
+
+    RAY_PASS_FORMS = {"grouped": 0, "fused": 1, "staged": 2}
+
+    def set_ray_pass_form(self, form):
+        """How `rtdgi validate` / `rtdgi trace` are scheduled (include/kajiya_amd.h: KJ_RTDGI_RAYS_*); outputs are identical for all."""
+        check(self.L.kj_rtdgi_set_ray_pass_form(self.rtdgi, self.RAY_PASS_FORMS[form]))
 
     def set_profiling(self, pass_timers=True, count_traversal=False):
         check(self.L.kj_rtdgi_set_profiling(self.rtdgi, int(pass_timers), int(count_traversal)))

@@ -434,8 +434,8 @@ class SplitRtdgi:
             gp = self.pipes[r]
             first, count = gp.ircache_request_ranges()
             h0, h1 = half_rows(*self.strips[r], self.H)
-            strip_lists[r] = gp.ircache_collect([(first[0] + h0 * hw, (h1 - h0) * hw), (first[1] + h0 * hw, (h1 - h0) * hw)], capacity=2 * (h1 - h0) * hw)
-            irc_lists[r] = gp.ircache_collect([(first[2], count[2]), (first[3], count[3])], capacity=count[2] + count[3])
+            strip_lists[r] = gp.ircache_collect([(first[0] + h0 * hw, (h1 - h0) * hw), (first[1] + h0 * hw, (h1 - h0) * hw)], capacity=2 * (h1 - h0) * hw, tag="strip")
+            irc_lists[r] = gp.ircache_collect([(first[2], count[2]), (first[3], count[3])], capacity=count[2] + count[3], tag="cache passes")
         gathered = self.comm.all_gather_rows({r: (buf, int(cnt.item())) for r, (buf, cnt) in strip_lists.items()})
         for r in self.comm.ranks:
             gp = self.pipes[r]

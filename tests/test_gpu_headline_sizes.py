@@ -28,7 +28,7 @@ def test_rtdgi_per_pass_and_taa_parity_at_4k_ruins(gpu, oracle, device):
     costs 10-30 s of host time, so the two share it."""
     taa = TT.TaaStep(gpu, 3840, 2160)
     T._per_pass_parity(gpu, oracle, device, "ruins4m", 3840, 2160, 2, False, n_frames=5, warmup=3,
-                       after_frame=lambda op, gp, fi, fc: taa(op, gp, fi, fc, compare=fi >= 2))
+                       after_frame=lambda op, gp, fi, fc: taa(op, gp, fi, fc, compare=fi >= 3))      # the two pass-by-pass frames; TAA's history is dense by then
     print(f"TAA at 4K on identical inputs and history: worst per-surface rel-L2 {taa.worst:.2e}")
 
 
@@ -123,7 +123,10 @@ def config3_lighting_frame_parity(gpu, oracle, device, scene_name, W, H):
             torch.cuda.synchronize()
             r = P.compare(gp.surface("spatial_filtered_tex", torch.uint8, (-1,)).cpu().numpy(), op.surface("spatial_filtered_tex", np.uint8, (-1,)), "rgba16f")
             note(("rtdgi whole frame", "spatial_filtered_tex"), r)
-            assert P.within_bars_with_flips(r), ("rtdgi", fi, r)
+            # the whole frame in one go (its passes in isolation: the 4K test above): a candidate whose shadow ray or depth gate flipped
+            # (1e-4 of the half-res texels) reaches ~50 full-res neighbours through the resampling chain and the denoiser, each by a
+            # little -- the image-level bar holds, the count of slightly-off texels is reported and bounded loosely
+            assert r["rel_l2"] <= P.REL_L2_TOL and r["bad_class"] == 0 and r["mismatch_frac"] <= 2e-2, f"rtdgi whole frame {fi}: {r}"
             T._upload_state(gp, T._oracle_surfaces(op), torch)
             for k, pname in enumerate(TR.RTR_PASS_ORDER):
                 mask = TR.KJ_RTR_PASS[pname] | (0 if k == 0 else TR.KJ_RTR_PASS["KEEP"])
@@ -133,11 +136,8 @@ def config3_lighting_frame_parity(gpu, oracle, device, scene_name, W, H):
                 torch.cuda.synchronize()
                 ref, got = TR._oracle_rtr_state(op), TR._download_rtr_state(gp, torch)
                 for n in ref:
-                    r = P.compare(got[n], ref[n], P.fmt_of(n), vector=P.is_vector(n))
+                    r, ok = TR.rtr_surface_within_bars(pname, n, got[n], ref[n])
                     note(("rtr " + pname, P.base_name(n)), r)
-                    ok = P.pass_within_bars(pname, r)
-                    if P.fmt_of(n) == "r11g11b10f":
-                        ok = r["mismatch_frac"] <= T.MISMATCH_TOL and r["differ_frac"] <= 0.03
                     assert ok, f"frame {fi} rtr pass {pname} surface {n}: {r}"
             TR._upload_rtr_state(gp, TR._oracle_rtr_state(op), torch)
         # ---- deferred combine on the oracle's shadow mask, GI and reflections (the oracle's combine reads the R8 mask)

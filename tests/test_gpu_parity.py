@@ -304,6 +304,44 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced, n
             print(f"  {k[0]:>20s} {k[1]:<36s} rel_l2={v['rel_l2']:.2e} mismatch={v['mismatch_frac']:.2e}")
 
 
+@pytest.mark.parametrize("scene_name,W,H,with_cache", [("city20k", 200, 120, True), ("cornell", 123, 77, False)])
+def test_ray_pass_forms_are_bit_identical(gpu, device, scene_name, W, H, with_cache):
+    """The grouped form of the two ray passes (256-thread workgroups: hit shading regrouped onto full waves through LDS; the default),
+    the fused form (one wave per tile) and the staged form (ray streams) produce the same images bit for bit over free-running
+    frames -- validation and tracing frames, ragged extents (partial 16x16 blocks), with the irradiance cache bound in its
+    deterministic mode (the racy mode differs from run to run by design) and its recorded requests compared as well."""
+    import torch
+    from kajiya_amd import frame
+    scene = gpu.Scene(device, _scenes()[scene_name])
+    pipes = {}
+    for form in ("grouped", "fused", "staged"):
+        gp = gpu.GpuPipeline(device, scene, W, H, use_ircache=with_cache)
+        gp.set_ray_pass_form(form)
+        if with_cache:
+            gp.ircache_set_deferred(True)
+        pipes[form] = gp
+    fs = frame.FrameState((W, H))
+    fs.ircache_enabled = with_cache
+    names = ["candidate_radiance_tex", "candidate_hit_tex", "candidate_normal_tex", "rt_history_validity_pre_input_tex", "rt_history_validity_input_tex", "spatial_filtered_tex"]
+    for fi in range(7):
+        cam = frame.orbit_camera(fi, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.02) if scene_name == "cornell" else \
+            frame.orbit_camera(fi, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.01)
+        fc = fs.prepare_frame_constants(cam); fs.retire_frame()
+        for gp in pipes.values():
+            gp.frame(fc)
+        torch.cuda.synchronize()
+        ref = pipes["fused"]
+        for form in ("grouped", "staged"):
+            for n in names + [k + s for k in ("rtdgi.radiance", "rtdgi.reservoir") for s in (":0", ":1")]:
+                a, b = ref.surface(n, torch.uint8, (-1,)), pipes[form].surface(n, torch.uint8, (-1,))
+                assert torch.equal(a, b), f"frame {fi}: {form} vs fused: {n} differs in {int((a != b).sum())} bytes"
+            assert ref.ray_counts() == pipes[form].ray_counts(), (fi, form, ref.ray_counts(), pipes[form].ray_counts())
+            if with_cache:
+                for n in ("meta", "grid_meta", "life", "irradiance", "reposition_proposal", "reposition_proposal_count"):
+                    assert torch.equal(ref.ircache_buffer(n, torch.uint8), pipes[form].ircache_buffer(n, torch.uint8)), (fi, form, n)
+    assert ref.ray_counts()[0] > 0.2 * ((W + 1) // 2) * ((H + 1) // 2)
+
+
 def test_rtdgi_free_running_parity(gpu, oracle, device):
     """Both implementations run 12 frames independently from the same scene/camera (GPU consumes
     its own G-buffer and history). Discrete reservoir flips accumulate, so the bar is looser."""

@@ -45,10 +45,40 @@ def test_rtr_per_pass_parity(gpu, oracle, device, W, H, reuse):
     rtr_per_pass_parity(gpu, oracle, device, S.glossy_test_scene(), W, H, reuse, T._frame_constants(W, H, 7, "textured"), warmup=4)
 
 
+def rtr_surface_within_bars(pname, name, got, ref):
+    """parity.pass_within_bars for one rtr surface after pass `pname`, with the two rtr-specific rules:
+
+    * a reservoir pick (`w / w_sum >= dart`, restir_temporal.hlsl) is a discrete decision like a ray pass' shadow ray: RESTIR_TEMPORAL
+      gets the flips form of the bars as well;
+    * `candidate_hit_tex.w` after TRACE is the GGX VNDF pdf of the sampled direction (inc/brdf.hlsl:44-47: D = a2 / (pi d^2), d = c^2 (a2 - 1)
+      + 1). For near-mirror lobes d cancels to ~1e-4 .. 1e-5 from terms of size 1, so ONE ulp of the microfacet cosine c -- which an fma
+      contraction or another libm's cos() upstream of it moves -- changes D by up to 1 %: on hardware 2 % of the texels (all with pdf >
+      100) differ by 1e-3 .. 9e-3 from the oracle, and the oracle differs from itself by as much when c is perturbed by one ulp
+      (measured: OKJ_ULP experiment). The hit VECTOR (xyz) keeps the standard bars; the pdf channel is an outlier beyond 1e-3
+      where the lobe is well-conditioned (|pdf| <= 32) and beyond 2e-2 where it is not; the image-level 1e-3 holds for both."""
+    fmt = P.fmt_of(name)
+    r = P.compare(got, ref, fmt, vector=P.is_vector(name))
+    if fmt == "r11g11b10f":   # one-step rounding flips are expected (see parity.RTOL); they must stay rare and unbiased
+        return r, (r["mismatch_frac"] <= T.MISMATCH_TOL and r["differ_frac"] <= 0.03)
+    flips = pname in ("TRACE", "VALIDATE", "RESTIR_TEMPORAL")
+    if pname == "TRACE" and P.base_name(name) == "candidate_hit_tex":
+        a, b = P.decode(got, fmt).astype(np.float64), P.decode(ref, fmt).astype(np.float64)
+        r = P.compare_decoded(a[:, :3], b[:, :3], vector=True)
+        pa, pb = a[:, 3:], b[:, 3:]
+        near_mirror = np.abs(pb) > 32.0
+        rp = P.compare_decoded(np.where(near_mirror, 0.0, pa), np.where(near_mirror, 0.0, pb))
+        rm = P.compare_decoded(np.where(near_mirror, pa, 0.0), np.where(near_mirror, pb, 0.0), rtol=2e-2)
+        whole = P.compare_decoded(pa, pb)
+        ok = P.within_bars_with_flips(r) and P.within_bars_with_flips(rp) and P.within_bars_with_flips(rm) and whole["rel_l2"] <= P.REL_L2_TOL and whole["bad_class"] == 0
+        r = dict(r, pdf_rel_l2=whole["rel_l2"], pdf_outliers_1e3=whole["mismatch_frac"], pdf_outliers_rough=rp["mismatch_frac"], pdf_outliers_near_mirror_2e2=rm["mismatch_frac"])
+        return r, ok
+    return r, (P.within_bars_with_flips(r) if flips else P.within_bars(r))
+
+
 def rtr_per_pass_parity(gpu, oracle, device, desc, W, H, reuse, fcs, warmup, pipelines=None):
-    """Bars: parity.pass_within_bars -- rel-L2 AND outlier count AND no finite / non-finite disagreement for the deterministic passes,
-    the flips form for the two ray passes (a texel whose shadow ray or depth gate falls the other way is replaced as a whole) -- the
-    same bars as rtdgi (until round 3 rtr passed on the image OR the count)."""
+    """Bars: rtr_surface_within_bars -- rel-L2 AND outlier count AND no finite / non-finite disagreement for the deterministic passes,
+    the flips form for the passes that take discrete decisions -- rtdgi's bars (until round 3 rtr passed on the
+    image OR the count), with one documented rule for the ill-conditioned pdf channel."""
     import torch
     op, gp = pipelines or T._make_pipelines(gpu, oracle, device, desc, W, H)
     set_reuse = None if reuse else (lambda: (op.L.okj_rtr_set_options(op.rtr, 0), gpu.check(gp.L.kj_rtr_set_options(gp.rtr, 0))))
@@ -79,13 +109,10 @@ def rtr_per_pass_parity(gpu, oracle, device, desc, W, H, reuse, fcs, warmup, pip
             torch.cuda.synchronize()
             ref, got = _oracle_rtr_state(op), _download_rtr_state(gp, torch)
             for n in ref:
-                r = P.compare(got[n], ref[n], P.fmt_of(n), vector=P.is_vector(n))
+                r, ok = rtr_surface_within_bars(pname, n, got[n], ref[n])
                 key = (pname, P.base_name(n))
                 if key not in worst or r["rel_l2"] > worst[key]["rel_l2"]:
                     worst[key] = r
-                ok = P.pass_within_bars(pname, r)
-                if P.fmt_of(n) == "r11g11b10f":   # one-step rounding flips are expected (see parity.RTOL); they must stay rare and unbiased
-                    ok = r["mismatch_frac"] <= T.MISMATCH_TOL and r["differ_frac"] <= 0.03
                 if not ok:
                     failures.append(f"frame {fi} pass {pname} surface {n}: {r}")
                     if os.environ.get("KJ_TEST_DUMP"):   # debugging aid: arrays of the first failing surface, written next to the gpurun logs
