@@ -170,6 +170,23 @@ __global__ void __launch_bounds__(64) k_trace_closest(SceneView sc, const float4
     const RayHit h = bvh_trace<false>(sc.bvh, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, a.w, b.w, cull_back != 0, lds_stack + threadIdx.x, 64);
     hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.world_id));
 }
+// four lanes per ray (kj_bvh.hpp: bvh_trace_quad): what small batches use -- 16 rays per wave, four times the waves, shorter steps
+__global__ void __launch_bounds__(64) k_trace_closest_quad(SceneView sc, const float4* __restrict__ rays, float4* __restrict__ hits, uint32_t count, int cull_back) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t i = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const bool active = i < count;
+    const float4 a = active ? rays[i * 2] : make_float4(0, 0, 0, 0), b = active ? rays[i * 2 + 1] : make_float4(0, 0, 1, 0);
+    const RayHit h = bvh_trace_quad<false>(sc.bvh, active, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, a.w, b.w, cull_back != 0, lds_stack + (threadIdx.x >> 2), 16);
+    if (active && (threadIdx.x & 3u) == 0u) hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.world_id));
+}
+__global__ void __launch_bounds__(64) k_trace_any_quad(SceneView sc, const float4* __restrict__ rays, uint8_t* __restrict__ out, uint32_t count) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t i = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const bool active = i < count;
+    const float4 a = active ? rays[i * 2] : make_float4(0, 0, 0, 0), b = active ? rays[i * 2 + 1] : make_float4(0, 0, 1, 0);
+    const RayHit h = bvh_trace_quad<true>(sc.bvh, active, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, a.w, b.w, false, lds_stack + (threadIdx.x >> 2), 16);
+    if (active && (threadIdx.x & 3u) == 0u) out[i] = h.slot != 0xffffffffu ? 1 : 0;
+}
 __global__ void __launch_bounds__(64) k_trace_any(SceneView sc, const float4* __restrict__ rays, uint8_t* __restrict__ out, uint32_t count) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
@@ -410,12 +427,20 @@ static StreamTune stream_launch(const KjDevice* dev, uint32_t count, uint32_t* w
     if (const char* v = getenv("KJ_STREAM_TRI_WEIGHT")) t.tri_weight = uint32_t(atoi(v));
     return t;
 }
+// Batches too small to fill the chip with one ray per lane (fewer rays than ~4 waves per SIMD would hold) walk with four lanes per ray
+// (kj_bvh.hpp: bvh_trace_quad). KJ_TRACE_QUAD_MAX_RAYS overrides the threshold (0 = never).
+static uint32_t quad_max_rays(const KjDevice* dev) {
+    static const long env = getenv("KJ_TRACE_QUAD_MAX_RAYS") ? atol(getenv("KJ_TRACE_QUAD_MAX_RAYS")) : -1;
+    return env >= 0 ? uint32_t(env) : dev->num_cus * 4u * 4u * 16u;      // 4 SIMDs x 4 waves x 16 rays per CU: 65536 on MI355X
+}
 KjStatus kj_trace_closest(KjScene* scene, const void* rays, void* hits, uint32_t count, uint32_t cull_back_faces, void* stream) {
     KJ_REQUIRE(scene && rays && hits, "null argument");
     if (!scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
     if (count == 0) return KJ_OK;
     const SceneView sv = scene_view(*scene);
-    if (getenv("KJ_TRACE_PER_RAY"))
+    if (count <= quad_max_rays(scene->dev))
+        hipLaunchKernelGGL(k_trace_closest_quad, dim3((count + 15) / 16), dim3(64), quad_stack_bytes(), (hipStream_t)stream, sv, (const float4*)rays, (float4*)hits, count, int(cull_back_faces));
+    else if (getenv("KJ_TRACE_PER_RAY"))
         hipLaunchKernelGGL(k_trace_closest, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (float4*)hits, count, int(cull_back_faces));
     else {
         uint32_t waves; const StreamTune tune = stream_launch(scene->dev, count, &waves);
@@ -429,7 +454,9 @@ KjStatus kj_trace_any(KjScene* scene, const void* rays, void* out_u8, uint32_t c
     if (!scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
     if (count == 0) return KJ_OK;
     const SceneView sv = scene_view(*scene);
-    if (getenv("KJ_TRACE_PER_RAY"))
+    if (count <= quad_max_rays(scene->dev))
+        hipLaunchKernelGGL(k_trace_any_quad, dim3((count + 15) / 16), dim3(64), quad_stack_bytes(), (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count);
+    else if (getenv("KJ_TRACE_PER_RAY"))
         hipLaunchKernelGGL(k_trace_any, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count);
     else {
         uint32_t waves; const StreamTune tune = stream_launch(scene->dev, count, &waves);

@@ -153,17 +153,27 @@ struct IrcTraceCtx {
     uint32_t request_slot_base;      // first slot of the cache's own passes in IrcacheView::requests (deferred updates)
     uint32_t lanes;                  // work items per wave (<= 64): see kj_ircache_trace_irradiance
 };
-KJ_D void irc_count_rays(unsigned long long* counters, int which) {
-    const unsigned long long m = __ballot(true);
-    if ((__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
+// one count per path: in the QUAD form the four lanes of a path run the same code, lane 0 counts
+template <bool QUAD> KJ_D void irc_count_path_rays(unsigned long long* counters, int which) {
+    const unsigned long long m = __ballot(true) & (QUAD ? 0x1111111111111111ull : ~0ull);
+    if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
 }
+// Work distribution of the three ray kernels. QUAD (the default): 16 paths per wave, four lanes each; else `lanes` paths per wave, one lane each.
+#define IRC_PATH_LOOP(total_)                                                                                                     \
+    const uint32_t per_wave_ = QUAD ? 16u : c.lanes;                                                                                \
+    const uint32_t slot_ = QUAD ? (threadIdx.x >> 2) : threadIdx.x;                                                                 \
+    const bool lead = !QUAD || (threadIdx.x & 3u) == 0u;                                                                            \
+    uint32_t* const stack = lds_stack + slot_;                                                                                      \
+    const uint32_t stride = QUAD ? 16u : 64u;                                                                                       \
+    if (slot_ >= per_wave_) return;                                                                                                 \
+    for (uint32_t d = blockIdx.x * per_wave_ + slot_; d < (total_); d += gridDim.x * per_wave_)
 // trace_accessibility.rgen.hlsl:21-66
+template <bool QUAD>
 __global__ void __launch_bounds__(64) k_irc_trace_accessibility(IrcTraceCtx c) {
     extern __shared__ uint32_t lds_stack[];
     const IrcacheView& ic = c.ic;
     const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_OCTA_DIMS2;
-    if (threadIdx.x >= c.lanes) return;
-    for (uint32_t d = blockIdx.x * c.lanes + threadIdx.x; d < total; d += gridDim.x * c.lanes) {
+    IRC_PATH_LOOP(total) {
         const uint32_t entry_idx = ic.entry_indirection[d / IRC_OCTA_DIMS2];
         const uint32_t octa_idx = d % IRC_OCTA_DIMS2;
         if (!irc_life_valid(ic.life[entry_idx])) continue;
@@ -172,8 +182,10 @@ __global__ void __launch_bounds__(64) k_irc_trace_accessibility(IrcTraceCtx c) {
         const float4 r0 = ic.aux[output_idx];
         Reservoir1spp r = Reservoir1spp::from_raw(make_uint2(asuint(r0.x), asuint(r0.y)));
         const IrcVertex prev_entry = irc_unpack_vertex(ic.aux[output_idx + IRC_OCTA_DIMS2 * 2]);
-        irc_count_rays(c.ray_counters, 1);
-        if (rt_is_shadowed(c.sc, entry.position, prev_entry.position - entry.position, 0.001f, 0.999f, lds_stack + threadIdx.x, 64)) {
+        irc_count_path_rays<QUAD>(c.ray_counters, 1);
+        const bool blocked = QUAD ? rt_is_shadowed_quad(c.sc, true, entry.position, prev_entry.position - entry.position, 0.001f, 0.999f, stack, stride)
+                                  : rt_is_shadowed(c.sc, entry.position, prev_entry.position - entry.position, 0.001f, 0.999f, stack, stride);
+        if (blocked && lead) {
             r.M *= 0.8f;
             const uint2 raw = r.as_raw();
             float2* dst = (float2*)&ic.aux[output_idx];
@@ -183,22 +195,28 @@ __global__ void __launch_bounds__(64) k_irc_trace_accessibility(IrcTraceCtx c) {
 }
 
 struct IrcTraceResult { V3 incident_radiance, direction, hit_pos; };
+// QUAD: four lanes per path (kj_bvh.hpp: bvh_trace_quad). All four run the shading code below on the same inputs; the ray counters and
+// the cache lookup (atomics, or the recorded request) are lane 0's, whose result is handed to the others.
 // ircache_trace_common.inc.hlsl:37-227 (MAX_PATH_LENGTH = 1)
-KJ_D IrcTraceResult ircache_trace(const IrcTraceCtx& c, const IrcVertex& entry, uint32_t sample_params, uint32_t life, uint32_t* stack, uint32_t request_slot, uint32_t request_key) {
+template <bool QUAD>
+KJ_D IrcTraceResult ircache_trace(const IrcTraceCtx& c, const IrcVertex& entry, uint32_t sample_params, uint32_t life, uint32_t* stack, uint32_t stride, uint32_t request_slot, uint32_t request_key) {
     const FrameConstants& fc = *c.fc;
+    const bool lead = !QUAD || (threadIdx.x & 3u) == 0u;
     uint32_t rng = hash1(sample_params >> 4u);
     const V3 ray_o = entry.position, ray_d = irc_sample_direction(sample_params);
     IrcTraceResult result;
     result.direction = ray_d;
     result.hit_pos = v3(0.0f);
     V3 irradiance_sum = v3(0.0f);
-    irc_count_rays(c.ray_counters, 0);
-    const GbufferPathVertex primary_hit = gbuffer_raytrace(c.sc, fc, ray_o, ray_d, 0.0f, FLT_MAX, 1, false, stack, 64, nullptr, RayCone::from_spread_angle(0.1f));   // ircache_trace_common.inc.hlsl:83
+    irc_count_path_rays<QUAD>(c.ray_counters, 0);
+    const GbufferPathVertex primary_hit = QUAD ? gbuffer_raytrace_quad(c.sc, fc, true, ray_o, ray_d, 0.0f, FLT_MAX, 1, false, stack, stride, RayCone::from_spread_angle(0.1f))
+                                               : gbuffer_raytrace(c.sc, fc, ray_o, ray_d, 0.0f, FLT_MAX, 1, false, stack, stride, nullptr, RayCone::from_spread_angle(0.1f));   // ircache_trace_common.inc.hlsl:83
     if (primary_hit.is_hit) {
         result.hit_pos = primary_hit.position;
         const V3 to_light_norm = sun_direction(fc);
-        irc_count_rays(c.ray_counters, 1);
-        const bool is_shadowed = rt_is_shadowed(c.sc, primary_hit.position, to_light_norm, 1e-4f, FLT_MAX, stack, 64);
+        irc_count_path_rays<QUAD>(c.ray_counters, 1);
+        const bool is_shadowed = QUAD ? rt_is_shadowed_quad(c.sc, true, primary_hit.position, to_light_norm, 1e-4f, FLT_MAX, stack, stride)
+                                      : rt_is_shadowed(c.sc, primary_hit.position, to_light_norm, 1e-4f, FLT_MAX, stack, stride);
         const GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);
         const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
         const V3 wi = to_local(tangent_to_world, to_light_norm);
@@ -226,12 +244,16 @@ KJ_D IrcTraceResult ircache_trace(const IrcTraceCtx& c, const IrcVertex& entry, 
             const float to_psa_metric = fmaxf(0.0f, dot(to_light_norm_ws, gbuffer.normal)) * fmaxf(0.0f, dot(to_light_norm_ws, -ls.normal)) / dist2;
             if (to_psa_metric > 0.0f) {
                 const V3 wi2 = to_local(tangent_to_world, to_light_norm_ws);
-                irc_count_rays(c.ray_counters, 1);
-                const bool sh = rt_is_shadowed(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, 64);
+                irc_count_path_rays<QUAD>(c.ray_counters, 1);
+                const bool sh = QUAD ? rt_is_shadowed_quad(c.sc, true, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, stride)
+                                     : rt_is_shadowed(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, stride);
                 if (!sh) irradiance_sum += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * layered_brdf_evaluate(brdf, wo, wi2) / ls.pdf * to_psa_metric / light_selection_pmf;
             }
         }
-        irradiance_sum += ircache_lookup<true>(c.ic, fc, entry.position, primary_hit.position, gbuffer.normal, 1u + life / IRC_LIFE_PER_RANK, rng, false, request_slot, request_key) * gbuffer.albedo;
+        V3 cached = v3(0.0f);
+        if (lead) cached = ircache_lookup<true>(c.ic, fc, entry.position, primary_hit.position, gbuffer.normal, 1u + life / IRC_LIFE_PER_RANK, rng, false, request_slot, request_key);
+        if (QUAD) cached = quad_broadcast0(cached);
+        irradiance_sum += cached * gbuffer.albedo;
     } else {
         result.hit_pos = ray_o + ray_d * 1000.0f;
         irradiance_sum += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
@@ -240,13 +262,13 @@ KJ_D IrcTraceResult ircache_trace(const IrcTraceCtx& c, const IrcVertex& entry, 
     return result;
 }
 // ircache_validate.rgen.hlsl:44-131
+template <bool QUAD>
 __global__ void __launch_bounds__(64) k_irc_validate(IrcTraceCtx c) {
     extern __shared__ uint32_t lds_stack[];
     const IrcacheView& ic = c.ic;
     const FrameConstants& fc = *c.fc;
     const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_VALIDATION_SAMPLES_PER_FRAME;
-    if (threadIdx.x >= c.lanes) return;
-    for (uint32_t d = blockIdx.x * c.lanes + threadIdx.x; d < total; d += gridDim.x * c.lanes) {
+    IRC_PATH_LOOP(total) {
         const uint32_t entry_idx = ic.entry_indirection[d / IRC_VALIDATION_SAMPLES_PER_FRAME];
         const uint32_t sample_idx = d % IRC_VALIDATION_SAMPLES_PER_FRAME;
         const uint32_t life = ic.life[entry_idx];
@@ -258,7 +280,7 @@ __global__ void __launch_bounds__(64) k_irc_validate(IrcTraceCtx c) {
             float4 pv = ic.aux[output_idx + IRC_OCTA_DIMS2];
             pv.x *= fc.pre_exposure_delta; pv.y *= fc.pre_exposure_delta; pv.z *= fc.pre_exposure_delta;
             const IrcVertex prev_entry = irc_unpack_vertex(ic.aux[output_idx + IRC_OCTA_DIMS2 * 2]);
-            const IrcTraceResult prev_traced = ircache_trace(c, prev_entry, r.payload, life, lds_stack + threadIdx.x, c.request_slot_base + d, (3u << 28) | d);
+            const IrcTraceResult prev_traced = ircache_trace<QUAD>(c, prev_entry, r.payload, life, stack, stride, c.request_slot_base + d, (3u << 28) | d);
             const float limiter = lerp(0.5f, 1.0f, smoothstep(-0.1f, 0.0f, dot(prev_traced.direction, prev_entry.normal)));
             const V3 a = prev_traced.incident_radiance * limiter;
             const V3 b{pv.x, pv.y, pv.z};
@@ -266,21 +288,23 @@ __global__ void __launch_bounds__(64) k_irc_validate(IrcTraceCtx c) {
             const float dist = fmaxf(dist3.x, fmaxf(dist3.y, dist3.z));
             const float invalidity = smoothstep(0.1f, 0.5f, dist);
             r.M = fmaxf(0.0f, fminf(r.M, exp2f(log2f(float(IRC_RESTIR_M_CLAMP)) * (1.0f - invalidity))));
-            const uint2 raw = r.as_raw();
-            float2* dst = (float2*)&ic.aux[output_idx];
-            *dst = make_float2(asfloat(raw.x), asfloat(raw.y));
-            ic.aux[output_idx + IRC_OCTA_DIMS2] = make_float4(a.x, a.y, a.z, pv.w);
+            if (lead) {
+                const uint2 raw = r.as_raw();
+                float2* dst = (float2*)&ic.aux[output_idx];
+                *dst = make_float2(asfloat(raw.x), asfloat(raw.y));
+                ic.aux[output_idx + IRC_OCTA_DIMS2] = make_float4(a.x, a.y, a.z, pv.w);
+            }
         }
     }
 }
 // trace_irradiance.rgen.hlsl:44-145
+template <bool QUAD>
 __global__ void __launch_bounds__(64) k_irc_trace_irradiance(IrcTraceCtx c) {
     extern __shared__ uint32_t lds_stack[];
     const IrcacheView& ic = c.ic;
     const FrameConstants& fc = *c.fc;
     const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME;
-    if (threadIdx.x >= c.lanes) return;
-    for (uint32_t d = blockIdx.x * c.lanes + threadIdx.x; d < total; d += gridDim.x * c.lanes) {
+    IRC_PATH_LOOP(total) {
         const uint32_t entry_idx = ic.entry_indirection[d / IRC_SAMPLES_PER_FRAME];
         const uint32_t sample_idx = d % IRC_SAMPLES_PER_FRAME;
         const uint32_t life = ic.life[entry_idx];
@@ -288,7 +312,7 @@ __global__ void __launch_bounds__(64) k_irc_trace_irradiance(IrcTraceCtx c) {
         const IrcVertex entry = irc_unpack_vertex(packed_entry);
         uint32_t rng = hash1(hash1(entry_idx) + fc.frame_index);
         const uint32_t sp = irc_sample_params(IRC_SAMPLES_PER_FRAME, entry_idx, sample_idx, fc.frame_index);
-        const IrcTraceResult traced = ircache_trace(c, entry, sp, life, lds_stack + threadIdx.x, c.request_slot_base + KjIrcache::REQ_E + d, (4u << 28) | d);
+        const IrcTraceResult traced = ircache_trace<QUAD>(c, entry, sp, life, stack, stride, c.request_slot_base + KjIrcache::REQ_E + d, (4u << 28) | d);
         const float limiter = lerp(0.5f, 1.0f, smoothstep(-0.1f, 0.0f, dot(traced.direction, entry.normal)));
         const V3 new_value = traced.incident_radiance * limiter;
         StreamState stream_state{0, 0};
@@ -311,11 +335,13 @@ __global__ void __launch_bounds__(64) k_irc_trace_irradiance(IrcTraceCtx c) {
             }
         }
         reservoir.finish_stream(stream_state);
-        const uint2 raw = reservoir.as_raw();
-        float2* dst = (float2*)&ic.aux[output_idx];
-        *dst = make_float2(asfloat(raw.x), asfloat(raw.y));
-        ic.aux[output_idx + IRC_OCTA_DIMS2] = make_float4(val_sel.x, val_sel.y, val_sel.z, reservoir.W);
-        if (selected_new) ic.aux[output_idx + IRC_OCTA_DIMS2 * 2] = packed_entry;
+        if (lead) {
+            const uint2 raw = reservoir.as_raw();
+            float2* dst = (float2*)&ic.aux[output_idx];
+            *dst = make_float2(asfloat(raw.x), asfloat(raw.y));
+            ic.aux[output_idx + IRC_OCTA_DIMS2] = make_float4(val_sel.x, val_sel.y, val_sel.z, reservoir.W);
+            if (selected_new) ic.aux[output_idx + IRC_OCTA_DIMS2 * 2] = packed_entry;
+        }
     }
 }
 // sum_up_irradiance.hlsl:34-89 — 16 lanes per entry (one per octahedral cell), shuffle-reduced
@@ -608,23 +634,27 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     // racy passes further from the sequential oracle (SH rel-L2 on identical state, 1080p city: 1.1e-2 at 64, 2.3e-2 at 8; bar 2e-2).
     static const uint32_t lanes_env = getenv("KJ_IRC_LANES") ? uint32_t(atoi(getenv("KJ_IRC_LANES"))) : 0u;
     tc.lanes = lanes_env >= 1u && lanes_env <= 64u ? lanes_env : 64u;
-    const uint32_t grid = c->dev->num_cus * (tc.lanes < 64u ? 32u : 8u);
+    // Default: four lanes per path (kj_bvh.hpp: bvh_trace_quad) -- 16 paths per wave, a ~75-instruction step instead of ~200, four
+    // times the waves. KJ_IRC_QUAD=0: one lane per path.
+    static const bool quad = !(getenv("KJ_IRC_QUAD") && atoi(getenv("KJ_IRC_QUAD")) == 0);
+    const uint32_t grid = c->dev->num_cus * (quad ? 32u : (tc.lanes < 64u ? 32u : 8u));
+    const size_t lds_rays = quad ? quad_stack_bytes() : lds;
     KJ_TRY_HIP(hipMemsetAsync(c->ray_counters.p, 0, KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8, s));
     hipLaunchKernelGGL(k_irc_prepare_trace, dim3(1), dim3(1), 0, s, (uint32_t*)c->meta.p);
     KJ_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_irc_reset, dim3(grid), dim3(64), 0, s, tc.ic);
     KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_irc_trace_accessibility, dim3(grid), dim3(64), lds, s, tc);
+    hipLaunchKernelGGL(quad ? k_irc_trace_accessibility<true> : k_irc_trace_accessibility<false>, dim3(grid), dim3(64), lds_rays, s, tc);
     KJ_CHECK_LAUNCH();
     if (c->deferred) {   // lookups inside the next two passes read other entries' aux while those are rewritten: give them a snapshot
         if (c->aux_snapshot.bytes != c->aux.bytes) KJ_TRY_HIP(c->aux_snapshot.alloc(c->aux.bytes, s));
         tc.ic.aux_read = (const float4*)c->aux_snapshot.p;
         hipLaunchKernelGGL(k_irc_snapshot_aux, dim3(c->dev->num_cus * 4), dim3(256), 0, s, (const uint32_t*)c->meta.p, (const float4*)c->aux.p, (float4*)c->aux_snapshot.p);
     }
-    hipLaunchKernelGGL(k_irc_validate, dim3(grid), dim3(64), lds, s, tc);
+    hipLaunchKernelGGL(quad ? k_irc_validate<true> : k_irc_validate<false>, dim3(grid), dim3(64), lds_rays, s, tc);
     KJ_CHECK_LAUNCH();
     if (c->deferred) hipLaunchKernelGGL(k_irc_snapshot_aux, dim3(c->dev->num_cus * 4), dim3(256), 0, s, (const uint32_t*)c->meta.p, (const float4*)c->aux.p, (float4*)c->aux_snapshot.p);
-    hipLaunchKernelGGL(k_irc_trace_irradiance, dim3(grid), dim3(64), lds, s, tc);
+    hipLaunchKernelGGL(quad ? k_irc_trace_irradiance<true> : k_irc_trace_irradiance<false>, dim3(grid), dim3(64), lds_rays, s, tc);
     KJ_CHECK_LAUNCH();
     c->pending_irradiance_sum = true;
     return KJ_OK;

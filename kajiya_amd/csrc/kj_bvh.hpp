@@ -249,6 +249,137 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
     return S.h;
 }
 
+// ---- four lanes per ray ("quad"): for launches too small to fill the chip with one ray per lane (the irradiance cache's ray passes:
+// ~30 k rays = 470 waves on 1024 SIMDs, each a chain of ~60 dependent ~200-instruction steps). The four lanes 4q .. 4q+3 of a wave carry
+// the SAME ray; at a node lane k tests child k's box, at a leaf it tests triangle k (and k + 4); the four results meet through DPP
+// quad permutes (one VALU instruction each, no LDS). A step is ~75 instructions instead of ~200, a wave waits for the slowest of 16
+// rays instead of 64, and the launch has four times the waves. The caller runs its shading code on all four lanes (same inputs, same
+// results) and lets lane 0 of each quad perform the side effects. Per-ray results are those of bvh_trace(): the closest hit with
+// equal-t ties going to the lowest world triangle id does not depend on the order boxes and triangles are visited in.
+#define KJ_QUAD_LDS_STACK 32u     // stack entries per quad kept in LDS ([level][quad]: 16 quads x 32 levels x 4 B = 2 KB per wave); deeper ones spill
+KJ_HD size_t quad_stack_bytes() { return size_t(KJ_QUAD_LDS_STACK) * 16u * 4u; }
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL> KJ_D uint32_t quad_perm(uint32_t v) { return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, 0xf, 0xf, false)); }
+template <int CTRL> KJ_D float quad_perm(float v) { return __uint_as_float(quad_perm<CTRL>(__float_as_uint(v))); }
+#define KJ_QP_ROT1 0x39   // quad_perm:[1,2,3,0]: lane k reads lane (k + 1) & 3
+#define KJ_QP_ROT2 0x4E   // [2,3,0,1]
+#define KJ_QP_ROT3 0x93   // [3,0,1,2]
+#define KJ_QP_XOR1 0xB1   // [1,0,3,2]
+#define KJ_QP_BCAST0 0x00 // [0,0,0,0]
+KJ_D float quad_broadcast0(float v) { return quad_perm<KJ_QP_BCAST0>(v); }
+KJ_D uint32_t quad_broadcast0(uint32_t v) { return quad_perm<KJ_QP_BCAST0>(v); }
+#else
+KJ_D float quad_broadcast0(float v) { return v; }       // the tests' CPU stand-in runs one lane at a time: every lane computes everything itself
+KJ_D uint32_t quad_broadcast0(uint32_t v) { return v; }
+#endif
+KJ_D V3 quad_broadcast0(V3 v) { return V3{quad_broadcast0(v.x), quad_broadcast0(v.y), quad_broadcast0(v.z)}; }
+
+// next reference off a quad's stack: the LDS part is read unconditionally (one ds_read, no generic pointer), the rare deep entries from the spill copy
+KJ_D void quad_pop(RayState& S, const uint32_t* stack, uint32_t stride, const uint32_t* spill) {
+    if (S.sp == 0) { S.cur = KJ_BVH_NONE; return; }
+    --S.sp;
+    uint32_t v = stack[(S.sp < KJ_QUAD_LDS_STACK ? S.sp : KJ_QUAD_LDS_STACK - 1u) * stride];
+    if (S.sp >= KJ_QUAD_LDS_STACK) v = spill[S.sp - KJ_QUAD_LDS_STACK];
+    S.cur = v;
+}
+// `stack`: LDS base of this QUAD's stack (entries at stack[level * stride]); all four lanes pass the same ray and the same `active`.
+template <bool ANY_HIT, bool STATS = false>
+KJ_D RayHit bvh_trace_quad(const BvhView& bvh, bool active, V3 o, V3 d, float tmin, float tmax, bool cull_back, uint32_t* stack, uint32_t stride, TraverseStats* stats = nullptr) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (!active) { RayHit h; h.t = FLT_MAX; h.u = h.v = 0; h.slot = h.world_id = 0xffffffffu; return h; }
+    uint32_t own[KJ_BVH_LDS_STACK];      // the stand-in's lanes run one after the other: each walks the ray alone, on a private stack
+    return bvh_trace<ANY_HIT, STATS>(bvh, o, d, tmin, tmax, cull_back, own, 1, stats);
+#else
+    const uint32_t NONE = KJ_BVH_NONE;
+    const uint32_t k = __lane_id() & 3u;
+    RayState S;
+    ray_begin<ANY_HIT>(S, o, d, tmin, tmax, cull_back);
+    if (!active) S.cur = NONE;
+    uint32_t spill[KJ_BVH_SPILL_STACK];   // identical in the four lanes (every lane pushes every entry)
+    const V3 inv_d = S.binv;
+    const bool neg_x = inv_d.x < 0.0f, neg_y = inv_d.y < 0.0f, neg_z = inv_d.z < 0.0f;
+    for (;;) {
+        const bool want_node = wants_node_step(S), want_tri = wants_tri_step(S);
+        const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
+        if (nn + nt == 0u) break;
+        if (nt == 0u || (nn != 0u && nn >= nt * 2u)) {
+            if (want_node) {
+                const float4* __restrict__ n = (const float4*)bvh.nodes + size_t(S.cur) * 4;
+                const float4 n0 = n[0]; const uint4 ch = *(const uint4*)(n + 1), qa = *(const uint4*)(n + 2); const uint2 qb = *(const uint2*)(n + 3);
+                if (STATS && k == 0u) stats->nodes++;
+                const float tlimit = ANY_HIT ? S.tmax : fminf(S.h.t, S.tmax);
+                const uint32_t e = __float_as_uint(n0.w);
+                const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23), sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
+                const uint32_t sh = k * 8u;
+                const float nqx = float(((neg_x ? qa.w : qa.x) >> sh) & 0xffu), fqx = float(((neg_x ? qa.x : qa.w) >> sh) & 0xffu);
+                const float nqy = float(((neg_y ? qb.x : qa.y) >> sh) & 0xffu), fqy = float(((neg_y ? qa.y : qb.x) >> sh) & 0xffu);
+                const float nqz = float(((neg_z ? qb.y : qa.z) >> sh) & 0xffu), fqz = float(((neg_z ? qa.z : qb.y) >> sh) & 0xffu);
+                const float bx = n0.x - S.wo.x, by = n0.y - S.wo.y, bz = n0.z - S.wo.z;
+                const float tnx = fmaf(nqx, sx, bx) * inv_d.x, tny = fmaf(nqy, sy, by) * inv_d.y, tnz = fmaf(nqz, sz, bz) * inv_d.z;
+                const float tfx = fmaf(fqx, sx, bx) * inv_d.x, tfy = fmaf(fqy, sy, by) * inv_d.y, tfz = fmaf(fqz, sz, bz) * inv_d.z;
+                const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), S.tmin);
+                const float tf = fminf(fminf(fminf(tfx, tfy), tfz), tlimit);
+                uint32_t c = ch.x;
+                c = k == 1u ? ch.y : c; c = k == 2u ? ch.z : c; c = k == 3u ? ch.w : c;
+                const bool hit = (tn <= tf * 1.000001f + 1e-30f) & (c != NONE);
+                // key = entry distance with the child index in its two low bits (all four keys distinct; tn >= tmin >= 0: float order ==
+                // integer order); occlusion rays take the children in slot order. (key, reference) pairs of the four lanes travel
+                // through quad rotations and a 5-comparator network of selects: every lane ends up with the same sorted list.
+                const uint32_t key = hit ? ((ANY_HIT ? 0u : (__float_as_uint(tn) & ~3u)) | k) : NONE;
+                uint32_t s0 = key, s1 = quad_perm<KJ_QP_ROT1>(key), s2 = quad_perm<KJ_QP_ROT2>(key), s3 = quad_perm<KJ_QP_ROT3>(key);
+                uint32_t r0 = c, r1 = quad_perm<KJ_QP_ROT1>(c), r2 = quad_perm<KJ_QP_ROT2>(c), r3 = quad_perm<KJ_QP_ROT3>(c);
+#define KJ_QSWAP(a, b, ra, rb) { const bool sw_ = b < a; const uint32_t ka_ = a, kb_ = b, pa_ = ra, pb_ = rb; a = sw_ ? kb_ : ka_; b = sw_ ? ka_ : kb_; ra = sw_ ? pb_ : pa_; rb = sw_ ? pa_ : pb_; }
+                KJ_QSWAP(s0, s1, r0, r1) KJ_QSWAP(s2, s3, r2, r3) KJ_QSWAP(s0, s2, r0, r2) KJ_QSWAP(s1, s3, r1, r3) KJ_QSWAP(s1, s2, r1, r2)
+#undef KJ_QSWAP
+                const uint32_t pushes = (s1 != NONE ? 1u : 0u) + (s2 != NONE ? 1u : 0u) + (s3 != NONE ? 1u : 0u);      // hits sort first: s0 is a hit when any is
+                if (S.sp + 3u <= KJ_QUAD_LDS_STACK) {
+                    // lane j (1..3) stores the j-th nearest child, the farthest deepest; a non-hit's slot lies beyond the new stack pointer
+                    const uint32_t mine = k == 1u ? r1 : (k == 2u ? r2 : r3);
+                    if ((k != 0u) & (k <= pushes)) stack[(S.sp + pushes - k) * stride] = mine;
+                    __builtin_amdgcn_wave_barrier();      // the pops read what OTHER lanes of the quad stored (LDS is in order per wave; this pins the compiler)
+                    S.sp += pushes;
+                } else {
+                    const uint32_t okey[3] = {s3, s2, s1}, oref[3] = {r3, r2, r1};
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (okey[j] != NONE) {
+                            if (S.sp < KJ_QUAD_LDS_STACK) { if (k == 0u) stack[S.sp * stride] = oref[j]; } else spill[S.sp - KJ_QUAD_LDS_STACK] = oref[j];
+                            S.sp++;
+                        }
+                }
+                if (s0 != NONE) S.cur = r0;
+                else quad_pop(S, stack, stride, spill);
+            }
+        } else if (want_tri) {
+            const uint32_t first = S.cur & 0x0fffffffu;
+            const uint32_t count = ((S.cur >> 28) & 7u) + 1u;
+            bool any = false;
+            for (uint32_t base = 0; base < count; base += 4u) {
+                const uint32_t i = base + k;
+                if (i < count) {
+                    const uint32_t slot = first + i;
+                    const float4* __restrict__ tp = (const float4*)bvh.tris + size_t(slot) * 3;
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    if (STATS) stats->tris++;
+                    any |= intersect_tri(S.wo, S.wd, S.tmin, S.tmax, a, b, c, slot, S.cull_back, S.h);
+                }
+            }
+            // the quad's best candidate: (t, world id) lexicographic minimum, two exchange rounds
+#define KJ_QMIN(CTRL) { const float t_ = quad_perm<CTRL>(S.h.t), u_ = quad_perm<CTRL>(S.h.u), v_ = quad_perm<CTRL>(S.h.v); \
+                        const uint32_t sl_ = quad_perm<CTRL>(S.h.slot), w_ = quad_perm<CTRL>(S.h.world_id);                    \
+                        const bool take_ = (t_ < S.h.t) | ((t_ == S.h.t) & (w_ < S.h.world_id));                                      \
+                        S.h.t = take_ ? t_ : S.h.t; S.h.u = take_ ? u_ : S.h.u; S.h.v = take_ ? v_ : S.h.v; S.h.slot = take_ ? sl_ : S.h.slot; S.h.world_id = take_ ? w_ : S.h.world_id; }
+            KJ_QMIN(KJ_QP_XOR1) KJ_QMIN(KJ_QP_ROT2)
+#undef KJ_QMIN
+            if (ANY_HIT && S.h.slot != 0xffffffffu) S.cur = NONE;
+            else quad_pop(S, stack, stride, spill);
+            (void)any;
+        }
+    }
+    return S.h;
+#endif
+}
+
 // ---- ray streams: a persistent wave works through a dense array of rays, keeping all 64 lanes busy.
 //  * rays[i] = {origin.xyz, tmin}, {direction.xyz, tmax}; tmax < 0 marks "no ray here" (a sky pixel's slot): result = miss.
 //  * A wave owns chunks of KJ_STREAM_CHUNK consecutive rays, interleaved with the other waves of the launch (no atomics). A lane

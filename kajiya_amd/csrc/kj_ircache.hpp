@@ -115,6 +115,17 @@ KJ_HD IrcCoord irc_ws_pos_to_coord(const FrameConstants& fc, V3 pos, V3 normal, 
 }
 
 #ifdef __HIPCC__
+// The position a lookup proposes for its entry (lookup.hlsl:262-272): the hit point pulled towards the query by at most one cell.
+// Every product and sum rounds separately: the same lookup is inlined into several kernels (the ray passes' fused / grouped / staged
+// forms, rtr, the cache's own passes) and an fma contraction that differs between them would make the proposals -- and through them next
+// frame's entry positions -- depend on which kernel ran.
+KJ_D IrcVertex irc_reposition_proposal(V3 query_from_ws, V3 pt_ws, V3 normal_ws, float cell_diameter) {
+#pragma clang fp contract(off)
+    const V3 otq{query_from_ws.x - pt_ws.x, query_from_ws.y - pt_ws.y, query_from_ws.z - pt_ws.z};
+    const float len = sqrtf(otq.x * otq.x + otq.y * otq.y + otq.z * otq.z);
+    const float scale = cell_diameter / fmaxf(cell_diameter / 0.5f, len);
+    return IrcVertex{V3{pt_ws.x + otq.x * scale, pt_ws.y + otq.y * scale, pt_ws.z + otq.z * scale}, normal_ws};
+}
 // lookup.hlsl:197-212
 KJ_D float irc_eval_sh_geometrics(float4 sh, V3 normal) {
     const float R0 = sh.x;
@@ -157,10 +168,7 @@ KJ_D V3 ircache_lookup(const IrcacheView& ic, const FrameConstants& fc, V3 query
             IrcRequest rq;
             rq.cell = cell; rq.key = request_key; rq.bits = query_rank | (skip_allocation ? 0x100u : 0u);
             rq.dart = uint_to_u01_float(hash1_mut(rng));
-            V3 otq = query_from_ws - pt_ws;
-            const float cd = IRC_GRID_CELL_DIAMETER * float(1u << rc.cascade);
-            otq = otq * (cd / fmaxf(cd / 0.5f, length(otq)));
-            rq.proposal = irc_pack_vertex(IrcVertex{pt_ws + otq, normal_ws});
+            rq.proposal = irc_pack_vertex(irc_reposition_proposal(query_from_ws, pt_ws, normal_ws, IRC_GRID_CELL_DIAMETER * float(1u << rc.cascade)));
             ic.requests[request_slot] = rq;
             if ((entry_flags & IRC_META_OCCUPIED) == 0 || just_allocated) return v3(0.0f);
         } else
@@ -187,9 +195,7 @@ KJ_D V3 ircache_lookup(const IrcacheView& ic, const FrameConstants& fc, V3 query
     const bool found = (cell_meta.y & IRC_META_OCCUPIED) != 0;
     const uint32_t entry_idx = cell_meta.x;
     const float cell_diameter = IRC_GRID_CELL_DIAMETER * float(1u << rc.cascade);
-    V3 offset_towards_query = query_from_ws - pt_ws;
-    offset_towards_query = offset_towards_query * (cell_diameter / fmaxf(cell_diameter / 0.5f, length(offset_towards_query)));
-    const IrcVertex proposal{pt_ws + offset_towards_query, normal_ws};
+    const IrcVertex proposal = irc_reposition_proposal(query_from_ws, pt_ws, normal_ws, cell_diameter);
     if (allocated_by_us && found) ic.reposition_proposal[entry_idx] = irc_pack_vertex(proposal);
     if (just_allocated) return v3(0.0f);
     V3 irradiance_sum = v3(0.0f);

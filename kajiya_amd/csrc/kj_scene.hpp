@@ -172,6 +172,25 @@ KJ_D GbufferPathVertex gbuffer_raytrace(const SceneView& sc, const FrameConstant
     }
     return res;
 }
+// the same two queries with four lanes per ray (kj_bvh.hpp: bvh_trace_quad); every lane of the quad gets the result
+KJ_D GbufferPathVertex gbuffer_raytrace_quad(const SceneView& sc, const FrameConstants& fc, bool active, V3 o, V3 d, float tmin, float tmax, uint32_t path_length,
+                                             bool cull_back_faces, uint32_t* stack, uint32_t stride, RayCone ray_cone) {
+    GbufferPathVertex res;
+    const RayHit h = bvh_trace_quad<false>(sc.bvh, active, o, d, tmin, tmax, cull_back_faces, stack, stride);
+    res.is_hit = active && h.slot != 0xffffffffu;
+    res.ray_t = h.t;
+    if (res.is_hit) {
+        res.gbuffer_packed = shade_gbuffer_hit(sc, fc, d, h, path_length, ray_cone.width_at_t(h.t * length(d)));
+        res.position = mad_nc(o, d, h.t);
+    } else {
+        res.gbuffer_packed = make_uint4(0, 0, 0, 0);
+        res.position = v3(0.0f);
+    }
+    return res;
+}
+KJ_D bool rt_is_shadowed_quad(const SceneView& sc, bool active, V3 o, V3 d, float tmin, float tmax, uint32_t* stack, uint32_t stride) {
+    return bvh_trace_quad<true>(sc.bvh, active, o, d, tmin, tmax, false, stack, stride).slot != 0xffffffffu;
+}
 // rt_is_shadowed (inc/rt.hlsl:58-70)
 template <bool STATS = false>
 KJ_D bool rt_is_shadowed(const SceneView& sc, V3 o, V3 d, float tmin, float tmax, uint32_t* stack, uint32_t stride, TraverseStats* stats = nullptr) {

@@ -162,7 +162,10 @@ def within_bars_with_flips(r, flip_tol=MISMATCH_TOL, outlier_cap=1e-2):
     return r["rel_l2_inliers"] <= REL_L2_TOL and r["mismatch_frac"] <= flip_tol and (few or r["rel_l2"] <= outlier_cap) and r.get("bad_class", 0) == 0
 
 
-RAY_PASSES = {"VALIDATE", "TRACE"}   # rtdgi / rtr passes whose outputs carry such decisions
+# rtdgi / rtr passes whose outputs carry such decisions: the two ray passes, and the resampling passes, which keep or replace a whole
+# reservoir on `w / w_sum >= dart` (at 4K two texels of 2 M pick the other sample on hardware -- a 1e4-long sky ray instead of a short
+# one -- which alone is 1.5e-3 of the image's L2)
+RAY_PASSES = {"VALIDATE", "TRACE", "RESTIR_TEMPORAL", "RESTIR_SPATIAL"}
 
 
 def pass_within_bars(pass_name, r):

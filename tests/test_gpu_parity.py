@@ -129,6 +129,39 @@ def test_device_built_lbvh_ray_queries_bit_exact(gpu, oracle, device, name):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a.view(np.uint32) != b.view(np.uint32)).any(axis=1).sum()} rays differ after the move"
 
 
+def test_small_batches_walk_four_lanes_per_ray_and_agree_bit_for_bit(gpu, oracle, device):
+    """kj_trace_closest / kj_trace_any take batches of <= 65536 rays through the cooperative walk (four lanes per ray: a node's four child
+    boxes / a leaf's triangles on four lanes, DPP quad permutes; kj_bvh.hpp: bvh_trace_quad) and larger ones through the ray streams.
+    The same 160 k rays in one batch and in chunks of ragged sizes (incl. 1, 15, 16, 17 rays) must give identical bits, equal to the
+    oracle's; deep trees (the city's LBVH build) exercise the quad stack's spill path."""
+    import os
+    import torch
+    for fast_build in ((False,) if os.environ.get("KJ_HIP_EMU") else (False, True)):     # the CPU stand-in has no device LBVH builder
+        desc = _scenes()["city20k"]
+        gsc = gpu.Scene(device, desc, fast_build=fast_build)
+        lo, hi = desc.bounds()
+        rays = _random_rays(np.random.RandomState(77), 160_000, lo, hi)
+        d_rays = torch.from_numpy(rays).cuda()
+        whole = gsc.trace_closest(d_rays, len(rays)).cpu().numpy()
+        whole_any = gsc.trace_any(d_rays, len(rays)).cpu().numpy()
+        whole_cull = gsc.trace_closest(d_rays, len(rays), cull_back=True).cpu().numpy()
+        if not fast_build:
+            osc = oracle.OracleScene(desc)
+            assert np.array_equal(osc.trace_closest(rays).view(np.uint32), whole.view(np.uint32))
+        start = 0
+        for n in (1, 15, 16, 17, 63, 64, 65, 1000, 4097, 30000, 65536, 50000):
+            chunk = d_rays[start:start + n].contiguous()
+            m = chunk.shape[0]
+            assert m == n
+            got = gsc.trace_closest(chunk, m).cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), whole[start:start + m].view(np.uint32)), (fast_build, n, int((got.view(np.uint32) != whole[start:start + m].view(np.uint32)).any(axis=1).sum()))
+            assert np.array_equal(gsc.trace_any(chunk, m).cpu().numpy(), whole_any[start:start + m]), (fast_build, n)
+            got_c = gsc.trace_closest(chunk, m, cull_back=True).cpu().numpy()
+            assert np.array_equal(got_c.view(np.uint32), whole_cull[start:start + m].view(np.uint32)), (fast_build, n, "cull")
+            start += m
+        assert start <= len(rays)
+
+
 def test_brdf_lut_and_sky(gpu, oracle, device):
     import torch
     lut_ref = oracle.brdf_lut()

@@ -69,9 +69,16 @@ def rtr_surface_within_bars(pname, name, got, ref):
         rp = P.compare_decoded(np.where(near_mirror, 0.0, pa), np.where(near_mirror, 0.0, pb))
         rm = P.compare_decoded(np.where(near_mirror, pa, 0.0), np.where(near_mirror, pb, 0.0), rtol=2e-2)
         whole = P.compare_decoded(pa, pb)
-        ok = P.within_bars_with_flips(r) and P.within_bars_with_flips(rp) and P.within_bars_with_flips(rm) and whole["rel_l2"] <= P.REL_L2_TOL and whole["bad_class"] == 0
-        r = dict(r, pdf_rel_l2=whole["rel_l2"], pdf_outliers_1e3=whole["mismatch_frac"], pdf_outliers_rough=rp["mismatch_frac"], pdf_outliers_near_mirror_2e2=rm["mismatch_frac"])
+        ok = P.within_bars_with_flips(r) and P.within_bars_with_flips(rp) and rm["rel_l2"] <= 1e-2 and rm["mismatch_frac"] <= P.MISMATCH_TOL and whole["bad_class"] == 0
+        r = dict(r, pdf_rel_l2=whole["rel_l2"], pdf_outliers_1e3=whole["mismatch_frac"], pdf_rough_rel_l2=rp["rel_l2"], pdf_outliers_rough=rp["mismatch_frac"],
+                 pdf_near_mirror_rel_l2=rm["rel_l2"], pdf_outliers_near_mirror_2e2=rm["mismatch_frac"])
         return r, ok
+    if pname == "RESTIR_TEMPORAL" and P.base_name(name) == "rtr.reservoir":
+        a, b = P.decode(got, fmt).astype(np.float64), P.decode(ref, fmt).astype(np.float64)      # (payload x, payload y, M, W)
+        rpl = P.compare_decoded(a[:, :2], b[:, :2], exact=True)
+        rmw = P.compare_decoded(a[:, 2:], b[:, 2:], exact=True, rtol=1e-2)
+        r = dict(r, payload_outliers=rpl["mismatch_frac"], mw_outliers_1e2=rmw["mismatch_frac"], mw_rel_l2=rmw["rel_l2"])
+        return r, (P.within_bars_with_flips(rpl) and P.within_bars_with_flips(rmw))
     return r, (P.within_bars_with_flips(r) if flips else P.within_bars(r))
 
 
