@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--scene", default="city", choices=["city", "ruins", "cornell", "pica"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the two headline-size measurements appended as `also` (4K ruins GI frame; 1440p config-3 lighting frame)")
     ap.add_argument("--profile-frames", type=int, default=12)
     ap.add_argument("--no-ssgi", action="store_true", help="drive rtdgi with the constant SSAO guide instead of running SsgiRenderer each frame")
     ap.add_argument("--no-overlap", action="store_true", help="serial frames: do not overlap the next frame's ircache work with this frame's screen-space tail")
@@ -107,6 +108,40 @@ def cpu_baseline(desc, cam_args, cores):
                       f"oracle BVH build {t_build:.1f} s not counted)",
             "gi_frame_ms_at_sample_res": round(1e3 * t_gi / frames, 2),
             "scalar_1core": {"value": round((a + b + c + d) / t_1 / 1e6, 4), "unit": "Mrays/s", "gi_frame_ms": round(1e3 * t_1, 1), "sample": "1 more frame, 1 thread"}}
+
+
+def also_measurements():
+    """The headline configs of BASELINE.json next to the primary 1080p line, each measured by a child process after
+    the primary timed region has finished (own scene, own inputs resident in HBM before its own timed region):
+      * 3840x2160 GI frame on the ~4 M-triangle ruins (north-star target: >= 30 fps = 33.3 ms) -- this script with other arguments;
+      * 2560x1440 full lighting frame of configs[2] (ssgi, sun shadows + denoise, ircache + rtdgi, rtr, light_gbuffer, TAA) -- scripts/config3_bench.py."""
+    import subprocess
+    out = []
+    env = dict(os.environ)
+    for label, cmd in (("4K GI frame, ruins ~4M tris (configs[3] on one GPU / north-star target)",
+                        [sys.executable, os.path.join(ROOT, "bench.py"), "--no-also", "--no-cpu-baseline", "--scene", "ruins", "--tris", "4000000", "--width", "3840", "--height", "2160",
+                         "--steps", "36", "--warmup", "12", "--profile-frames", "6"]),
+                       ("1440p full lighting frame, ruins ~4M tris (configs[2])",
+                        [sys.executable, os.path.join(ROOT, "scripts", "config3_bench.py"), "--frames", "36", "--warmup", "12"])):
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            j = json.loads(line)
+        except Exception as e:      # a failed side measurement must not take the primary line with it
+            out.append({"what": label, "error": repr(e)[:200]})
+            continue
+        e = {"what": label, "wall_s": round(time.time() - t0, 1)}
+        if "gi_frame_ms" in j:
+            rf = j.get("roofline") or {}
+            e.update({"gi_frame_ms": j["gi_frame_ms"], "fps": round(1000.0 / j["gi_frame_ms"], 1), "mrays_per_s": j["value"], "workload": j["config"]["workload"][:120],
+                      "rays_per_frame": j["config"]["rays_per_frame"], "segment_ms": j.get("segment_ms"), "pass_ms": j.get("pass_ms"),
+                      "roofline": {k: rf.get(k) for k in ("kernel", "bound", "avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac")}})
+        else:
+            e.update({"frame_ms": j["frame_ms"], "fps": j["fps"], "mrays_per_s": j["mrays_per_s"], "workload": j["workload"], "segment_ms": j["segment_ms"], "rays_per_frame": j["rays_per_frame"],
+                      "overlap": j.get("overlap")})
+        out.append(e)
+    return out
 
 
 def main():
@@ -439,6 +474,11 @@ def main():
         "roofline": roofline,
         "roofline_all": roofline_all,
     }
+    out["comm_ranks"] = (dist.get_world_size() if world > 1 else 1)     # what the communicator itself reports: an N > 1 run certifies its rank count
+    if rank == 0 and world == 1 and not args.no_also and nsplit <= 1:
+        inputs.clear()              # the primary workload's frames: free their HBM before the children build theirs
+        torch.cuda.empty_cache()
+        out["also"] = also_measurements()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         try:  # respect a cgroup CPU quota: oversubscribed OpenMP threads spin and distort the baseline

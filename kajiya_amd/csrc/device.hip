@@ -430,7 +430,7 @@ static StreamTune stream_launch(const KjDevice* dev, uint32_t count, uint32_t* w
 // Batches too small to fill the chip with one ray per lane (fewer rays than ~4 waves per SIMD would hold) walk with four lanes per ray
 // (kj_bvh.hpp: bvh_trace_quad). KJ_TRACE_QUAD_MAX_RAYS overrides the threshold (0 = never).
 static uint32_t quad_max_rays(const KjDevice* dev) {
-    static const long env = getenv("KJ_TRACE_QUAD_MAX_RAYS") ? atol(getenv("KJ_TRACE_QUAD_MAX_RAYS")) : -1;
+    const long env = getenv("KJ_TRACE_QUAD_MAX_RAYS") ? atol(getenv("KJ_TRACE_QUAD_MAX_RAYS")) : -1;
     return env >= 0 ? uint32_t(env) : dev->num_cus * 4u * 4u * 16u;      // 4 SIMDs x 4 waves x 16 rays per CU: 65536 on MI355X
 }
 KjStatus kj_trace_closest(KjScene* scene, const void* rays, void* hits, uint32_t count, uint32_t cull_back_faces, void* stream) {

@@ -519,6 +519,199 @@ __global__ void __launch_bounds__(KJ_GROUP_THREADS, KJ_GROUPED_WAVES) k_rtdgi_tr
     invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
 }
 
+// ---- split form of the two ray passes: TWO launches per pass.
+//   A. one wave per 8x8 tile: ray generation, the closest-hit traversal, everything a pixel whose ray MISSED needs (sky radiance, its
+//      outputs). Lanes that hit append a 64-byte record {ray, (t, u, v, triangle), pixel, rng, what the pixel's epilogue needs} to their
+//      tile's slots of a global array (ballot + prefix count, no atomics) and the wave ends -- its registers and its slot are free
+//      for the next tile while the hits wait.
+//   B. one wave per KJ_SPLIT_TILES tiles: gathers those tiles' records onto its lanes (a sixth of the pixels hit: four tiles fill
+//      a wave to ~70 %), runs shade_candidate_hit -- G-buffer of the hit, ONE shadow-ray traversal for four tiles' hits, lights, cache
+//      lookup -- and writes the hit pixels' outputs.
+// Unlike the grouped form nothing idles holding a wave slot, unlike the staged form there are two launches, not five, and no ray streams;
+// kernel A needs no shading registers, so it is compiled for more waves per SIMD. Same functions, same arithmetic and rng streams as
+// the fused form: bit-identical outputs.
+struct SplitRecord { float ox, oy, oz, t; float dx, dy, dz, u; float v, e0, e1, e2; uint32_t slot, pixel, rng, pad; };    // 64 B; e0..e2: the pass' epilogue inputs
+#define KJ_SPLIT_TILES 4u
+#ifndef KJ_SPLIT_A_WAVES
+#define KJ_SPLIT_A_WAVES 6
+#endif
+struct SplitStage { SplitRecord* __restrict__ records; uint32_t* __restrict__ counts; uint32_t tiles; };
+// A lane that hit parks its record; returns nothing. Called by every lane still in the kernel (wave vote inside).
+KJ_D void split_park(const SplitStage& st, bool hit, const SplitRecord& r) {
+    const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned long long hm = __ballot(hit);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rank = uint32_t(__popcll(hm & ((1ull << lane) - 1ull)));
+    if (hit) st.records[size_t(tile) * 64u + rank] = r;
+    if (hm == 0ull || (__ffsll((long long)hm) - 1) == int(lane)) { if (hit || hm == 0ull) st.counts[tile] = uint32_t(__popcll(hm)); }
+}
+template <bool STATS>
+__global__ void __launch_bounds__(64, KJ_SPLIT_A_WAVES) k_rtdgi_trace_closest(TraceCtx c, SplitStage st, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
+                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+    extern __shared__ uint32_t lds_stack[];
+    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+    const float depth = in_image ? c.depth.ld(hx, hy) : 0.0f;
+    const bool has_ray = in_image && depth != 0.0f;
+    count_rays(c.ray_counters, 0, has_ray);
+    if (in_image && !has_ray) {
+        st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
+        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
+        invalidity_out_tex.st(x, y, 0);
+    }
+    bool hit = false;
+    SplitRecord rec{};
+    if (has_ray) {
+        const V4 gts = tex_size4(c.depth.w, c.depth.h);
+        const V2 uv = get_uv(float(hx), float(hy), gts);
+        const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
+        const float near_field_fade_out_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
+        const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
+        const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
+        const Basis tangent_to_world = build_orthonormal_basis(normal_ws);
+        const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, fc.frame_index);
+        const V3 outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
+        const V3 origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
+        const float tmax = tracing_frame ? SKY_DIST : near_field_fade_out_end;
+        const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, outgoing_dir) * 2 * KJ_PI));
+        const float cos_theta = dot(normalize(outgoing_dir - vr.dir_ws), normal_ws);
+        TraverseStats st_closest{0, 0};
+        const RayHit h = bvh_trace<false, STATS>(c.sc.bvh, origin, outgoing_dir, 0.0f, tmax, false, lds_stack + lane, 64, &st_closest);
+        if (STATS) { atomicAdd(&counter_slot(c.ray_counters)[2], (unsigned long long)st_closest.nodes); atomicAdd(&counter_slot(c.ray_counters)[3], (unsigned long long)st_closest.tris); }
+        hit = h.slot != 0xffffffffu;
+        if (hit) {
+            rec.ox = origin.x; rec.oy = origin.y; rec.oz = origin.z; rec.t = h.t; rec.dx = outgoing_dir.x; rec.dy = outgoing_dir.y; rec.dz = outgoing_dir.z; rec.u = h.u; rec.v = h.v;
+            rec.e0 = cos_theta; rec.e1 = pdf; rec.e2 = 0.0f;
+            rec.slot = h.slot; rec.pixel = uint32_t(x) | (uint32_t(y) << 16); rec.rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u); rec.pad = 0;
+        } else {   // the ray left the scene: the sky, or nothing at all inside the near field of a validation frame
+            const V3 out_value = tracing_frame ? xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, outgoing_dir)) : v3(0.0f);
+            const float hit_t = tracing_frame ? tmax : SKY_DIST;
+            st4(candidate_irradiance_out_tex, x, y, v4(out_value, 1.0f - cos_theta));
+            st4(candidate_hit_out_tex, x, y, v4(outgoing_dir * hit_t, pdf * (tracing_frame ? 1.0f : -1.0f)));
+            candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, -outgoing_dir), 0)));
+        }
+        const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
+        const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
+        invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
+    }
+    split_park(st, hit, rec);
+}
+// lane -> record of this wave's KJ_SPLIT_TILES tiles, `batch` = which 64 of them; false = no record for this lane
+KJ_D bool split_fetch(const SplitStage& st, uint32_t batch, SplitRecord& r, uint32_t& total) {
+    const uint32_t t0 = blockIdx.x * KJ_SPLIT_TILES;
+    uint32_t cnt[KJ_SPLIT_TILES];
+    total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < KJ_SPLIT_TILES; ++k) { cnt[k] = t0 + k < st.tiles ? st.counts[t0 + k] : 0u; total += cnt[k]; }
+    uint32_t j = batch * 64u + (threadIdx.x & 63u);
+    if (j >= total) return false;
+    uint32_t tile = 0;
+#pragma unroll
+    for (uint32_t k = 0; k + 1 < KJ_SPLIT_TILES; ++k) if (tile == k && j >= cnt[k]) { j -= cnt[k]; tile = k + 1; }
+    r = st.records[size_t(t0 + tile) * 64u + j];
+    return true;
+}
+template <bool STATS>
+KJ_D V3 split_shade(const TraceCtx& c, const SplitRecord& r, uint32_t* stack, V3& hit_normal_ws) {
+    const FrameConstants& fc = *c.fc;
+    const V3 o{r.ox, r.oy, r.oz}, d{r.dx, r.dy, r.dz};
+    RayHit rh;
+    rh.t = r.t; rh.u = r.u; rh.v = r.v; rh.slot = r.slot; rh.world_id = 0;
+    GbufferPathVertex pv;
+    pv.is_hit = true; pv.ray_t = r.t;
+    pv.gbuffer_packed = shade_gbuffer_hit(c.sc, fc, d, rh, 1, candidate_ray_cone(c, o).width_at_t(r.t * length(d)));      // GbufferRaytrace::trace, inc/rt.hlsl:112-137
+    pv.position = mad_nc(o, d, r.t);
+    uint32_t rng = r.rng;
+    TraverseStats st_any{0, 0};
+    const V3 rad = shade_candidate_hit<STATS>(c, r.pixel & 0xffffu, r.pixel >> 16, rng, o, d, pv, stack, 64, &st_any, hit_normal_ws);
+    if (STATS) { atomicAdd(&counter_slot(c.ray_counters)[4], (unsigned long long)st_any.nodes); atomicAdd(&counter_slot(c.ray_counters)[5], (unsigned long long)st_any.tris); }
+    return rad;
+}
+template <bool STATS>
+__global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_shade(TraceCtx c, SplitStage st, ImgH4 candidate_irradiance_out_tex, ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex) {
+    extern __shared__ uint32_t lds_stack[];
+    const FrameConstants& fc = *c.fc;
+    const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
+    uint32_t total = 1;
+    for (uint32_t batch = 0; batch * 64u < total; ++batch) {
+        SplitRecord r;
+        if (!split_fetch(st, batch, r, total)) continue;
+        V3 hit_normal_ws;
+        const V3 rad = split_shade<STATS>(c, r, lds_stack + (threadIdx.x & 63u), hit_normal_ws);
+        const int x = int(r.pixel & 0xffffu), y = int(r.pixel >> 16);
+        const V3 d{r.dx, r.dy, r.dz};
+        st4(candidate_irradiance_out_tex, x, y, v4(rad, 1.0f - r.e0));
+        st4(candidate_hit_out_tex, x, y, v4(d * r.t, r.e1 * (tracing_frame ? 1.0f : -1.0f)));
+        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, hit_normal_ws), 0)));
+    }
+}
+// diffuse_validate.rgen.hlsl:46-111 after the re-traced sample's radiance and distance are known
+KJ_D void validate_finish_pixel(int x, int y, V3 out_value, float hit_t, V3 prev_ray_orig, V3 prev_hit_pos, V4 prev_radiance_packed, ImgU2 reservoir_tex, ImgH4 irradiance_history_tex,
+                                ImgR8 invalidity_out_tex) {
+    const V3 prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
+    const V3 new_radiance = vmax(v3(0.0f), out_value);
+    const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
+    const float invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
+    const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
+    if (fabsf(hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
+        st4(irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
+        Reservoir1spp r = Reservoir1spp::from_raw(reservoir_tex.ld(x, y));
+        const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
+        r.M *= clampf(lum_old / fmaxf(1e-8f, lum_new), 0.03f, 1.0f);
+        r.W *= clampf(lum_old / fmaxf(1e-8f, lum_new) * 10.0f, 0.01f, 1.0f);
+        reservoir_tex.st(x, y, r.as_raw());
+    }
+    invalidity_out_tex.st(x, y, to_unorm8(invalidity));
+}
+template <bool STATS>
+__global__ void __launch_bounds__(64, KJ_SPLIT_A_WAVES) k_rtdgi_validate_closest(TraceCtx c, SplitStage st, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
+                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+    extern __shared__ uint32_t lds_stack[];
+    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const bool sky = in_image && 0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y);
+    const bool has_ray = in_image && !sky;
+    count_rays(c.ray_counters, 0, has_ray);
+    if (sky) invalidity_out_tex.st(x, y, to_unorm8(1.0f));
+    bool hit = false;
+    SplitRecord rec{};
+    if (has_ray) {
+        const float4 ro = ray_orig_history_tex.ld(x, y);
+        const V3 prev_ray_orig{ro.x, ro.y, ro.z};
+        const V3 prev_hit_pos = xyz(ld4(reservoir_ray_history_tex, x, y)) + prev_ray_orig;
+        const V3 dir = normalize(prev_hit_pos - prev_ray_orig);
+        TraverseStats st_closest{0, 0};
+        const RayHit h = bvh_trace<false, STATS>(c.sc.bvh, prev_ray_orig, dir, 0.0f, SKY_DIST, false, lds_stack + lane, 64, &st_closest);
+        if (STATS) { atomicAdd(&counter_slot(c.ray_counters)[2], (unsigned long long)st_closest.nodes); atomicAdd(&counter_slot(c.ray_counters)[3], (unsigned long long)st_closest.tris); }
+        hit = h.slot != 0xffffffffu;
+        if (hit) {
+            rec.ox = prev_ray_orig.x; rec.oy = prev_ray_orig.y; rec.oz = prev_ray_orig.z; rec.t = h.t; rec.dx = dir.x; rec.dy = dir.y; rec.dz = dir.z; rec.u = h.u; rec.v = h.v;
+            rec.e0 = prev_hit_pos.x; rec.e1 = prev_hit_pos.y; rec.e2 = prev_hit_pos.z;
+            rec.slot = h.slot; rec.pixel = uint32_t(x) | (uint32_t(y) << 16); rec.rng = hash3(uint32_t(x), uint32_t(y), 0); rec.pad = 0;
+        } else {
+            validate_finish_pixel(x, y, xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, dir)), SKY_DIST, prev_ray_orig, prev_hit_pos, ld4(irradiance_history_tex, x, y), reservoir_tex,
+                                  irradiance_history_tex, invalidity_out_tex);
+        }
+    }
+    split_park(st, hit, rec);
+}
+template <bool STATS>
+__global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_validate_shade(TraceCtx c, SplitStage st, ImgU2 reservoir_tex, ImgH4 irradiance_history_tex, ImgR8 invalidity_out_tex) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t total = 1;
+    for (uint32_t batch = 0; batch * 64u < total; ++batch) {
+        SplitRecord r;
+        if (!split_fetch(st, batch, r, total)) continue;
+        V3 hit_normal_ws;
+        const V3 rad = split_shade<STATS>(c, r, lds_stack + (threadIdx.x & 63u), hit_normal_ws);
+        const int x = int(r.pixel & 0xffffu), y = int(r.pixel >> 16);
+        validate_finish_pixel(x, y, rad, r.t, V3{r.ox, r.oy, r.oz}, V3{r.e0, r.e1, r.e2}, ld4(irradiance_history_tex, x, y), reservoir_tex, irradiance_history_tex, invalidity_out_tex);
+    }
+}
+
 // ---- staged form (KJ_RTDGI_STAGED_MIN_RAYS=0 selects it; kept for measurements and for callers that batch rays: its stream
 // kernels are what kj_trace_closest / kj_trace_any run, +28 % rays/s over one ray per lane on 1.6 M incoherent rays).
 // The reference's ray-generation shaders (trace_diffuse.rgen.hlsl, diffuse_validate.rgen.hlsl) run ray generation, traversal,
@@ -1066,6 +1259,7 @@ struct KjRtdgi {
     bool count_traversal = false;               // instrumented trace kernels
     uint32_t staged_min_rays = 0xffffffffu;     // ray passes run staged (ray streams) from this many ray slots per launch (KJ_RTDGI_STAGED_MIN_RAYS); default: never, see below
     uint32_t stream_waves_per_cu = 24;          // persistent waves per CU of a ray-stream launch (measured best of 8 / 16 / 24 / 32: scripts/traversal_microbench.py)
+    bool split_rays = false;                    // the ray passes as two launches each: closest-hit + misses | hit shading on compacted records (kj_rtdgi_set_ray_pass_form)
     bool grouped_rays = true;                   // the ray passes' form when not staged: grouped (hit shading regrouped inside a 256-thread workgroup) or fused (KJ_RTDGI_GROUPED=0)
     int resample_variant = 2;                   // spatial reuse: 2 = per-tap gathers (fastest measured), 0 / 1 = LDS-staged tiles (KJ_RTDGI_RESAMPLE_VARIANT; rtdgi_resample.hpp)
     static const int NUM_SCOPES = 11;
@@ -1107,6 +1301,7 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     if (const char* v = getenv("KJ_RTDGI_RESAMPLE_VARIANT")) r->resample_variant = atoi(v);
     if (const char* v = getenv("KJ_RTDGI_STAGED_MIN_RAYS")) r->staged_min_rays = uint32_t(atoll(v));
     if (const char* v = getenv("KJ_RTDGI_GROUPED")) r->grouped_rays = atoi(v) != 0;
+    if (const char* v = getenv("KJ_RTDGI_SPLIT")) r->split_rays = atoi(v) != 0;
     if (r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
     *out = r;
     return KJ_OK;
@@ -1243,7 +1438,29 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     const bool staged = stage_rays >= r->staged_min_rays;
     // the fused form (one wave per tile does everything) or the grouped one (hit shading regrouped inside a 256-thread workgroup); same
     // outputs bit for bit (kj_rtdgi_set_ray_pass_form)
-    const bool grouped = r->grouped_rays;
+    const bool split = r->split_rays && !staged;
+    const bool grouped = r->grouped_rays && !split;
+    SplitStage sst{};
+    if (split) {
+        sst.tiles = gh.x * gh.y;
+        sst.records = (SplitRecord*)r->get("split.records", size_t(((hw + 7) / 8) * ((hh + 7) / 8)) * 64 * sizeof(SplitRecord), s);
+        sst.counts = (uint32_t*)r->get("split.counts", size_t(((hw + 7) / 8) * ((hh + 7) / 8)) * 4, s);
+        KJ_TRY_HIP(r->err);
+    }
+    const dim3 gshade((gh.x * gh.y + KJ_SPLIT_TILES - 1) / KJ_SPLIT_TILES);
+    if ((mask & KJ_RTDGI_PASS_VALIDATE) && split) {
+        SCOPE_BEGIN(2);
+        if (is_rtdgi_validation_frame(r->dev->fc_host.frame_index)) {
+            hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_closest<true> : k_rtdgi_validate_closest<false>, gh, blk, trace_lds, s, tc, sst, img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+                               img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
+            hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_shade<true> : k_rtdgi_validate_shade<false>, gshade, blk, trace_lds, s, tc, sst, img<uint2>(reservoir_hist, hw, hh), img<uint2>(radiance_hist, hw, hh),
+                               img<uint8_t>(validity_pre, hw, hh));
+        } else   // two frames of three the pass only writes the invalidity image: the fused kernel does just that
+            hipLaunchKernelGGL(k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+                               img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(2);
+    }
     const dim3 gg((hw + 15) / 16, (uint32_t(hr1 - hr0) + 15) / 16), gblk(KJ_GROUP_THREADS);
     const size_t grouped_lds = grouped_lds_bytes(tc.sc.bvh.stack_entries);
     if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged && grouped) {
@@ -1253,7 +1470,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(2);
     }
-    if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged && !grouped) {
+    if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged && !grouped && !split) {
         SCOPE_BEGIN(2);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
                            img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
@@ -1268,7 +1485,16 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
     }
-    if ((mask & KJ_RTDGI_PASS_TRACE) && !staged && !grouped) {
+    if ((mask & KJ_RTDGI_PASS_TRACE) && split) {
+        SCOPE_BEGIN(3);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_closest<true> : k_rtdgi_trace_closest<false>, gh, blk, trace_lds, s, tc, sst, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_shade<true> : k_rtdgi_trace_shade<false>, gshade, blk, trace_lds, s, tc, sst, img<uint2>(candidate_radiance, hw, hh), img<uint32_t>(candidate_normal, hw, hh),
+                           img<uint2>(candidate_hit, hw, hh));
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(3);
+    }
+    if ((mask & KJ_RTDGI_PASS_TRACE) && !staged && !grouped && !split) {
         SCOPE_BEGIN(3);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
                            img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
@@ -1422,8 +1648,9 @@ KjStatus kj_rtdgi_set_profiling(KjRtdgi* r, uint32_t enable_pass_timers, uint32_
     return KJ_OK;
 }
 KjStatus kj_rtdgi_set_ray_pass_form(KjRtdgi* r, uint32_t form) {
-    KJ_REQUIRE(r && form <= KJ_RTDGI_RAYS_STAGED, "null argument / unknown form");
+    KJ_REQUIRE(r && form <= KJ_RTDGI_RAYS_SPLIT, "null argument / unknown form");
     r->grouped_rays = form == KJ_RTDGI_RAYS_GROUPED;
+    r->split_rays = form == KJ_RTDGI_RAYS_SPLIT;
     r->staged_min_rays = form == KJ_RTDGI_RAYS_STAGED ? 0u : 0xffffffffu;
     return KJ_OK;
 }

@@ -39,8 +39,9 @@ def measure(label):
 
 
 # the C-ABI reads these switches at every call (device.hip: stream_waves / stream_tune / KJ_TRACE_PER_RAY)
-KNOBS = ("KJ_TRACE_PER_RAY", "KJ_STREAM_WAVES_PER_CU", "KJ_STREAM_REFILL", "KJ_STREAM_NODE_WEIGHT", "KJ_STREAM_TRI_WEIGHT")
-configs = [dict(KJ_TRACE_PER_RAY="1"), dict()]
+KNOBS = ("KJ_TRACE_QUAD_MAX_RAYS", "KJ_TRACE_PER_RAY", "KJ_STREAM_WAVES_PER_CU", "KJ_STREAM_REFILL", "KJ_STREAM_NODE_WEIGHT", "KJ_STREAM_TRI_WEIGHT")
+os.environ["KJ_TRACE_QUAD_MAX_RAYS"] = "0"
+configs = [dict(KJ_TRACE_PER_RAY="1", KJ_TRACE_QUAD_MAX_RAYS="0"), dict(KJ_TRACE_QUAD_MAX_RAYS="0")]
 if "--sweep" in sys.argv:
     configs += [dict(KJ_STREAM_WAVES_PER_CU=str(w)) for w in (8, 16, 32)]
     configs += [dict(KJ_STREAM_REFILL=str(t)) for t in (1, 8, 32, 48)]
@@ -51,3 +52,26 @@ for cfg in configs:
         os.environ.pop(k, None)
     os.environ.update(cfg)
     measure("one ray per lane (bvh_trace)" if cfg.get("KJ_TRACE_PER_RAY") else "stream " + (" ".join(f"{k[10:].lower()}={v}" for k, v in cfg.items()) or "(defaults)"))
+
+
+# ---- small batches (the irradiance cache's ray passes issue ~28 k paths per launch): one ray per lane vs ray stream vs four lanes per ray
+def measure_small(label, n):
+    sub = r1[:n].contiguous()
+    out = []
+    for name, fn in (("closest", lambda: scene.trace_closest(sub, n)), ("any", lambda: scene.trace_any(sub, n))):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        out.append(f"{name}: {ms * 1e3:.1f} us = {n / ms / 1e3:.0f} Mrays/s")
+    print(f"{label:<44s} {n} rays  " + "   ".join(out), flush=True)
+
+
+for n in (8192, 28672, 65536):
+    for label, cfg in (("one ray per lane", dict(KJ_TRACE_PER_RAY="1", KJ_TRACE_QUAD_MAX_RAYS="0")), ("stream", dict(KJ_TRACE_QUAD_MAX_RAYS="0")), ("four lanes per ray (quad)", dict(KJ_TRACE_QUAD_MAX_RAYS="1000000"))):
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update(cfg)
+        measure_small(label, n)

@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUN = os.path.join(ROOT, "tests", "hip_emu", "run_with_emu.py")
 CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"]
-TOY = ["--steps", "3", "--warmup", "2", "--width", "128", "--height", "96", "--tris", "20000", "--profile-frames", "2"]
+TOY = ["--steps", "3", "--warmup", "2", "--width", "128", "--height", "96", "--tris", "20000", "--profile-frames", "2", "--no-also"]   # --no-also: the 4K / 1440p side measurements are sized for the GPU
 
 
 def _json_line(out):
@@ -36,6 +36,7 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert j["metric"] == "gi_mrays_per_s" and j["vs_baseline"] is None and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
     assert j["value"] > 0 and j["ms_per_step"] > 0 and "2-way screen-tile split" in j["config"]["parallelism"]
     assert j["config"]["rays_per_frame"] > 1000                                   # both strips' rays were counted
+    assert j["comm_ranks"] == 2                                                    # what the communicator reports, not what --gpus asked for
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs ROCm's clang++ as the host compiler")
@@ -44,7 +45,7 @@ def test_bench_single_rank_line_has_roofline_and_cpu_baseline():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     j = _json_line(r.stdout)
     assert all(k in j for k in CONTRACT + ["cpu_baseline"]), sorted(j)
-    assert j["n_gpus"] == 1 and j["scaling"] in ("weak", "strong")
+    assert j["n_gpus"] == 1 and j["scaling"] in ("weak", "strong") and j["comm_ranks"] == 1
     assert set(["bound", "achieved", "peak", "unit", "frac", "traffic"]) <= set(j["roofline"])
     cb = j["cpu_baseline"]
     assert set(["value", "unit", "cores", "kind", "sample"]) <= set(cb) and cb["kind"] in ("port", "reference") and cb["value"] > 0

@@ -338,16 +338,21 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced, n
 
 
 @pytest.mark.parametrize("scene_name,W,H,with_cache", [("city20k", 200, 120, True), ("cornell", 123, 77, False)])
-def test_ray_pass_forms_are_bit_identical(gpu, device, scene_name, W, H, with_cache):
-    """The grouped form of the two ray passes (256-thread workgroups: hit shading regrouped onto full waves through LDS; the default),
-    the fused form (one wave per tile) and the staged form (ray streams) produce the same images bit for bit over free-running
-    frames -- validation and tracing frames, ragged extents (partial 16x16 blocks), with the irradiance cache bound in its
-    deterministic mode (the racy mode differs from run to run by design) and its recorded requests compared as well."""
+def test_ray_pass_forms_agree(gpu, device, scene_name, W, H, with_cache):
+    """The four schedules of the two ray passes -- fused (one wave per tile does everything), grouped (256-thread workgroups, hit shading
+    regrouped through LDS), split (two launches: closest hit + misses | hit shading on records compacted across tiles) and staged (ray
+    streams) -- run the same functions on the same rays. Over free-running frames (validation and tracing frames, ragged extents):
+
+      * without the cache every surface is bit-identical, frame after frame;
+      * with the cache bound (deterministic mode: the racy one differs from run to run by design) ray counts and the integer cache
+        state are identical and the images agree to fp16 rounding -- on hardware a ray origin may differ in its last fp32 bit between
+        two KERNELS (each inlines the view-ray arithmetic and contracts it its own way), which the fp16 images do not see but the
+        cache's fp32 position proposals do, and those feed next frame's cache rays."""
     import torch
     from kajiya_amd import frame
     scene = gpu.Scene(device, _scenes()[scene_name])
     pipes = {}
-    for form in ("grouped", "fused", "staged"):
+    for form in ("grouped", "fused", "staged", "split"):
         gp = gpu.GpuPipeline(device, scene, W, H, use_ircache=with_cache)
         gp.set_ray_pass_form(form)
         if with_cache:
@@ -356,6 +361,8 @@ def test_ray_pass_forms_are_bit_identical(gpu, device, scene_name, W, H, with_ca
     fs = frame.FrameState((W, H))
     fs.ircache_enabled = with_cache
     names = ["candidate_radiance_tex", "candidate_hit_tex", "candidate_normal_tex", "rt_history_validity_pre_input_tex", "rt_history_validity_input_tex", "spatial_filtered_tex"]
+    names += [k + s for k in ("rtdgi.radiance", "rtdgi.reservoir") for s in (":0", ":1")]
+    worst = 0.0
     for fi in range(7):
         cam = frame.orbit_camera(fi, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.02) if scene_name == "cornell" else \
             frame.orbit_camera(fi, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.01)
@@ -364,15 +371,29 @@ def test_ray_pass_forms_are_bit_identical(gpu, device, scene_name, W, H, with_ca
             gp.frame(fc)
         torch.cuda.synchronize()
         ref = pipes["fused"]
-        for form in ("grouped", "staged"):
-            for n in names + [k + s for k in ("rtdgi.radiance", "rtdgi.reservoir") for s in (":0", ":1")]:
-                a, b = ref.surface(n, torch.uint8, (-1,)), pipes[form].surface(n, torch.uint8, (-1,))
-                assert torch.equal(a, b), f"frame {fi}: {form} vs fused: {n} differs in {int((a != b).sum())} bytes"
-            assert ref.ray_counts() == pipes[form].ray_counts(), (fi, form, ref.ray_counts(), pipes[form].ray_counts())
+        for form in ("grouped", "staged", "split"):
+            q = pipes[form]
+            assert ref.ray_counts() == q.ray_counts(), (fi, form, ref.ray_counts(), q.ray_counts())
+            for n in names:
+                a, b = ref.surface(n, torch.uint8, (-1,)), q.surface(n, torch.uint8, (-1,))
+                if torch.equal(a, b):
+                    continue
+                assert with_cache, f"frame {fi}: {form} vs fused: {n} differs in {int((a != b).sum())} bytes"
+                r = P.compare(b.cpu().numpy(), a.cpu().numpy(), P.fmt_of(n), vector=P.is_vector(n))
+                worst = max(worst, r["rel_l2"])
+                assert P.within_bars_with_flips(r) and r["rel_l2"] <= 1e-3, f"frame {fi}: {form} vs fused: {n}: {r}"
             if with_cache:
-                for n in ("meta", "grid_meta", "life", "irradiance", "reposition_proposal", "reposition_proposal_count"):
-                    assert torch.equal(ref.ircache_buffer(n, torch.uint8), pipes[form].ircache_buffer(n, torch.uint8)), (fi, form, n)
+                for n in ("meta", "grid_meta", "life", "reposition_proposal_count"):
+                    assert torch.equal(ref.ircache_buffer(n, torch.uint8), q.ircache_buffer(n, torch.uint8)), (fi, form, n)
+                for n in ("irradiance", "reposition_proposal", "spatial"):
+                    a, b = ref.ircache_buffer(n, torch.float32).cpu().numpy().reshape(-1, 4), q.ircache_buffer(n, torch.float32).cpu().numpy().reshape(-1, 4)
+                    if n != "irradiance":      # packed vertices: xyz + 11:10:11 normal bits
+                        assert np.array_equal(a[:, 3].view(np.uint32), b[:, 3].view(np.uint32)), (fi, form, n, "normals")
+                        a, b = a[:, :3], b[:, :3]
+                    r = P.compare_decoded(b, a, vector=n != "irradiance")
+                    assert r["rel_l2"] <= 1e-5 and r["mismatch_frac"] <= 1e-3, f"frame {fi}: {form} vs fused: ircache {n}: {r}"
     assert ref.ray_counts()[0] > 0.2 * ((W + 1) // 2) * ((H + 1) // 2)
+    print(f"forms vs fused, {scene_name}: worst image rel-L2 {worst:.2e}")
 
 
 def test_rtdgi_free_running_parity(gpu, oracle, device):

@@ -48,8 +48,11 @@ def test_rtr_per_pass_parity(gpu, oracle, device, W, H, reuse):
 def rtr_surface_within_bars(pname, name, got, ref):
     """parity.pass_within_bars for one rtr surface after pass `pname`, with the two rtr-specific rules:
 
-    * a reservoir pick (`w / w_sum >= dart`, restir_temporal.hlsl) is a discrete decision like a ray pass' shadow ray: RESTIR_TEMPORAL
-      gets the flips form of the bars as well;
+    * every rtr pass takes discrete decisions on float comparisons (a reservoir pick `w / w_sum >= dart`, the resolve's choice of the
+      sample whose ray length it keeps, the filters' reprojection validity): all six get the flips form of the bars -- outlier texels
+      counted and capped at 0.2 %, everything else within 1e-3 as an image, the outliers not above 1e-2 of the image beyond a
+      handful. `rtr.ray_len` is exempt from that last cap: a texel holds either a surface distance or the sky's 1e4, so ONE flipped
+      choice in 10^4 texels is 4e-2 of its L2 (measured: 12 of 16929 texels at 171x99 on hardware);
     * `candidate_hit_tex.w` after TRACE is the GGX VNDF pdf of the sampled direction (inc/brdf.hlsl:44-47: D = a2 / (pi d^2), d = c^2 (a2 - 1)
       + 1). For near-mirror lobes d cancels to ~1e-4 .. 1e-5 from terms of size 1, so ONE ulp of the microfacet cosine c -- which an fma
       contraction or another libm's cos() upstream of it moves -- changes D by up to 1 %: on hardware 2 % of the texels (all with pdf >
@@ -60,7 +63,8 @@ def rtr_surface_within_bars(pname, name, got, ref):
     r = P.compare(got, ref, fmt, vector=P.is_vector(name))
     if fmt == "r11g11b10f":   # one-step rounding flips are expected (see parity.RTOL); they must stay rare and unbiased
         return r, (r["mismatch_frac"] <= T.MISMATCH_TOL and r["differ_frac"] <= 0.03)
-    flips = pname in ("TRACE", "VALIDATE", "RESTIR_TEMPORAL")
+    if P.base_name(name) == "rtr.ray_len":
+        return r, P.within_bars_with_flips(r, outlier_cap=float("inf"))
     if pname == "TRACE" and P.base_name(name) == "candidate_hit_tex":
         a, b = P.decode(got, fmt).astype(np.float64), P.decode(ref, fmt).astype(np.float64)
         r = P.compare_decoded(a[:, :3], b[:, :3], vector=True)
@@ -79,7 +83,7 @@ def rtr_surface_within_bars(pname, name, got, ref):
         rmw = P.compare_decoded(a[:, 2:], b[:, 2:], exact=True, rtol=1e-2)
         r = dict(r, payload_outliers=rpl["mismatch_frac"], mw_outliers_1e2=rmw["mismatch_frac"], mw_rel_l2=rmw["rel_l2"])
         return r, (P.within_bars_with_flips(rpl) and P.within_bars_with_flips(rmw))
-    return r, (P.within_bars_with_flips(r) if flips else P.within_bars(r))
+    return r, P.within_bars_with_flips(r)
 
 
 def rtr_per_pass_parity(gpu, oracle, device, desc, W, H, reuse, fcs, warmup, pipelines=None):
