@@ -333,8 +333,9 @@ KjStatus kj_rtdgi_traversal_counts(KjRtdgi* r, uint64_t out[6]);
 /* How the two ray-tracing passes (`rtdgi validate`, `rtdgi trace`: rtdgi.rs:283-365) are scheduled on the device. The outputs are
  * bit-identical for every form; the knob exists for A/B measurements in one process (kj_rtdgi_create takes its default from
  * KJ_RTDGI_GROUPED / KJ_RTDGI_STAGED_MIN_RAYS).
- *   KJ_RTDGI_RAYS_GROUPED (default): 256-thread workgroups, hit shading regrouped onto full waves through LDS
- *   KJ_RTDGI_RAYS_FUSED: one wave per 8x8 tile runs ray generation, both traversals and hit shading (the ray-generation shader's shape)
+ *   KJ_RTDGI_RAYS_FUSED (default, the fastest measured: profiles/r03_ray_pass_forms.md): one wave per 8x8 tile runs ray generation, both
+ *     traversals and hit shading (the ray-generation shader's shape)
+ *   KJ_RTDGI_RAYS_GROUPED: 256-thread workgroups, hit shading regrouped onto full waves through LDS
  *   KJ_RTDGI_RAYS_STAGED: five launches over dense ray arrays (ray streams)
  *   KJ_RTDGI_RAYS_SPLIT: two launches: closest-hit traversal + everything a miss needs | hit shading on records compacted across tiles */
 enum { KJ_RTDGI_RAYS_GROUPED = 0, KJ_RTDGI_RAYS_FUSED = 1, KJ_RTDGI_RAYS_STAGED = 2, KJ_RTDGI_RAYS_SPLIT = 3 };

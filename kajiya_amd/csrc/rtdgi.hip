@@ -248,7 +248,8 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
     return TraceResult{total_radiance, hit_normal_ws, hit_t, pdf, primary_hit.is_hit};
 }
 
-// ---- grouped form of the two ray passes (the default): a 256-thread workgroup = four 8x8 tiles (2 x 2). Two thirds of the candidate
+// ---- grouped form of the two ray passes (built for VERDICT r2 item 3, measured, NOT the default: trace pass 0.282 ms vs 0.273 fused at
+// 1080p, 0.814 vs 0.773 at 4K, same lease; profiles/r03_ray_pass_forms.md): a 256-thread workgroup = four 8x8 tiles (2 x 2). Two thirds of the candidate
 // rays leave the scene, so in the fused form above a wave runs everything after the closest-hit query -- G-buffer of the hit, the sun's
 // shadow-ray traversal, lights, cache lookup -- with a sixth of its lanes (lane utilisation 34 % over the kernel, PMC). Here
 //   1. every pixel traces its closest-hit ray (as before);
@@ -256,6 +257,9 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
 //   3. the workgroup's records are dealt to ceil(n / 64) of its waves, evenly, and THOSE waves run shade_candidate_hit on full(er)
 //      waves -- one shadow-ray traversal for four tiles' hits instead of four mostly empty ones; the other waves sleep at the barrier;
 //   4. results return through LDS to the pixels that own them.
+// Why it loses: the pass is bound by the dependent chain each wave walks (~100 traversal steps of ~1.5-2 us), not by issue slots; a wave
+// parked at the barrier still holds its slot, so four waves waiting for ONE fuller shadow-ray walk (whose chain is the maximum over 44
+// rays instead of 11) cost more slot-time than four short walks side by side.
 // The arithmetic per ray, the order of the radiance sums and the rng streams are those of the fused form (same functions), so the
 // outputs are bit-identical to it. LDS per workgroup: the traversal stacks (16 x 256 dwords) + 256 records (12 KB, reused for the
 // results) = 28 KB -> five workgroups = 20 waves per CU, the fused form's occupancy.
@@ -519,7 +523,9 @@ __global__ void __launch_bounds__(KJ_GROUP_THREADS, KJ_GROUPED_WAVES) k_rtdgi_tr
     invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
 }
 
-// ---- split form of the two ray passes: TWO launches per pass.
+// ---- split form of the two ray passes (measured, NOT the default: at 1080p the closest-hit launch alone takes 0.188 ms of the fused
+// kernel's 0.268 and the shading launch 0.260 -- 2025 waves on 1024 SIMDs, each a chain of ~130 dependent steps with nothing to hide
+// its latency behind; 0.796 vs 0.750 ms at 4K; profiles/r03_ray_pass_forms.md): TWO launches per pass.
 //   A. one wave per 8x8 tile: ray generation, the closest-hit traversal, everything a pixel whose ray MISSED needs (sky radiance, its
 //      outputs). Lanes that hit append a 64-byte record {ray, (t, u, v, triangle), pixel, rng, what the pixel's epilogue needs} to their
 //      tile's slots of a global array (ballot + prefix count, no atomics) and the wave ends -- its registers and its slot are free
@@ -1260,7 +1266,7 @@ struct KjRtdgi {
     uint32_t staged_min_rays = 0xffffffffu;     // ray passes run staged (ray streams) from this many ray slots per launch (KJ_RTDGI_STAGED_MIN_RAYS); default: never, see below
     uint32_t stream_waves_per_cu = 24;          // persistent waves per CU of a ray-stream launch (measured best of 8 / 16 / 24 / 32: scripts/traversal_microbench.py)
     bool split_rays = false;                    // the ray passes as two launches each: closest-hit + misses | hit shading on compacted records (kj_rtdgi_set_ray_pass_form)
-    bool grouped_rays = true;                   // the ray passes' form when not staged: grouped (hit shading regrouped inside a 256-thread workgroup) or fused (KJ_RTDGI_GROUPED=0)
+    bool grouped_rays = false;                  // the ray passes' form when not staged: grouped (hit shading regrouped inside a 256-thread workgroup) or fused (KJ_RTDGI_GROUPED=0)
     int resample_variant = 2;                   // spatial reuse: 2 = per-tap gathers (fastest measured), 0 / 1 = LDS-staged tiles (KJ_RTDGI_RESAMPLE_VARIANT; rtdgi_resample.hpp)
     static const int NUM_SCOPES = 11;
     hipEvent_t ev[NUM_SCOPES][2] = {};

@@ -1,14 +1,14 @@
 # round-3 A/B runs on one GPU lease (scratch outputs under gpurun_out/)
-mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline --steps 60 --warmup 24 --profile-frames 12"
-(time python -m pytest tests/test_gpu_parity.py tests/test_gpu_rtr.py -k "ray_pass_forms or per_pass_parity and not 256-256 and not 320-192" -q -s -m gpu -p no:cacheprovider) > gpurun_out/c4_tests_a.log 2>&1
+ROOT=$PWD; mkdir -p gpurun_out
+B="python $ROOT/bench.py --no-cpu-baseline --no-also --steps 30 --warmup 12 --profile-frames 9 --no-overlap"
+for v in sa4 sa5 sa8; do KJ_AMD_LIB=$ROOT/kajiya_amd/libkajiya_amd_$v.so KJ_RTDGI_SPLIT=1 $B > gpurun_out/c5_bench_split_$v.json 2>/dev/null; done
+KJ_RTDGI_SPLIT=1 $B > gpurun_out/c5_bench_split_sa6.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
 for f in split fused; do
   if [ $f = split ]; then export KJ_RTDGI_SPLIT=1; else export KJ_RTDGI_SPLIT=0; fi
-  KJ_RTDGI_GROUPED=0 $B --no-overlap > gpurun_out/c4_bench_1080_serial_$f.json 2> gpurun_out/c4_bench_1080_serial_$f.err
-  KJ_RTDGI_GROUPED=0 $B > gpurun_out/c4_bench_1080_$f.json 2> gpurun_out/c4_bench_1080_$f.err
-  KJ_RTDGI_GROUPED=0 $B --scene ruins --tris 4000000 --width 3840 --height 2160 > gpurun_out/c4_bench_4k_$f.json 2> gpurun_out/c4_bench_4k_$f.err
+  rm -rf $ROOT/gpurun_out/c5_prof_$f
+  KJ_RTDGI_GROUPED=0 timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/c5_prof_$f -o stats --output-format csv -- $B > $ROOT/gpurun_out/c5_prof_$f.log 2>&1
+  cp $(find $ROOT/gpurun_out/c5_prof_$f -name "*kernel_stats.csv" | head -1) $ROOT/gpurun_out/c5_kernel_stats_$f.csv
+  rm -rf $ROOT/gpurun_out/c5_prof_$f
 done
-unset KJ_RTDGI_SPLIT
-KJ_IRC_QUAD=0 KJ_RTDGI_GROUPED=0 $B --no-overlap > gpurun_out/c4_bench_1080_serial_fused_noquad.json 2>/dev/null
-(time python -m pytest tests/test_gpu_headline_sizes.py -q -s -m gpu -p no:cacheprovider --durations=10) > gpurun_out/c4_headline.log 2>&1
 echo done
