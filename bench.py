@@ -191,6 +191,13 @@ def main():
         else:
             split = multigpu.SplitRtdgi(comm, split_pipes, W, H, motion_halo=args.motion_halo)
     single = split is None
+    if split is not None and hasattr(split, "self_test"):
+        # before frame 0: every kind of exchange of the frame schedule once, on scratch images, checked on the device (multigpu.py)
+        passed = split.self_test()
+        if rank == 0:
+            print(f"[bench] {'RCCL' if world > 1 and not os.environ.get('KJ_BENCH_SHARE_GPU0') else ('gloo' if world > 1 else 'virtual')} {nsplit} ranks "
+                  f"{'OK' if passed else 'FAILED'}: exchange self-test ({'passed' if passed else 'wrong rows delivered'})", file=sys.stderr, flush=True)
+        assert passed, "split transport self-test failed"
 
     # ---- pre-generate the inputs of every frame (resident in HBM before the timed region; replicated on every rank)
     n_frames = Wm + K + args.profile_frames + 3 + 1

@@ -294,6 +294,67 @@ class SplitRtdgi:
         r0, r1 = self.strips[rank]
         return max(0, r0 - rows), min(self.H, r1 + rows)
 
+    def self_test(self, device=None):
+        """Start-up check of the transport, before frame 0: every kind of exchange the frame schedule uses -- the all-gather of a
+        full-res image, motion halos, the 64-row one-deep halo of half-res records, full-res stencil halos, the variable-length
+        all-gather of cache records -- runs once on scratch images whose rows carry their OWNER's rank, through the same
+        `comm.prepare` / `run_prepared` / `all_gather_rows` code (incl. the packed mode), and each rank then checks on the device that
+        every row it is entitled to holds the owner's pattern. Returns True when every rank passed (collective); the first N > 1 run on
+        real hardware certifies its own communicator this way (bench.py prints "RCCL <n> ranks OK")."""
+        import torch
+        n = self.comm.n
+        dev = device or next(iter(self.pipes.values())).depth.device
+        M = self.motion_halo
+        plans = [("all-gather, full res, 8 B", "f", 8, None), ("motion halo, half res, 16 B", "h", 16, M + 4), ("one-deep halo, half res, 16 B", "h", 16, 64),
+                 ("stencil halo, full res, 8 B", "f", 8, 16), ("TAA input halo, full res, 8 B", "f", 8, 25), ("validity halo, half res, 1 B", "h", 1, M + 1)]
+        ok = True
+        owner_of = {}
+        for res in ("h", "f"):
+            total = (self.H + 1) // 2 if res == "h" else self.H
+            o = torch.zeros(total, dtype=torch.uint8)
+            for r, (a, b) in enumerate(self.strips):
+                a2, b2 = half_rows(a, b, self.H) if res == "h" else (a, b)
+                o[a2:b2] = r + 1
+            owner_of[res] = o.to(dev)
+        for k, (what, res, bpt, halo) in enumerate(plans):
+            h = (self.H + 1) // 2 if res == "h" else self.H
+            w = ((self.W + 1) // 2 if res == "h" else self.W) * bpt
+            scratch = {}
+            for r in self.comm.ranks:
+                t = torch.zeros((h, w), dtype=torch.uint8, device=dev)
+                a, b = self.strips[r]
+                a2, b2 = half_rows(a, b, self.H) if res == "h" else (a, b)
+                t[a2:b2] = (r + 1) * 8 + k            # the owner's pattern; every other row stays 0 until the exchange fills it
+                scratch[r] = t
+            xfers = [(src, dst, (k, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H)]
+            self.comm.run_prepared(self.comm.prepare(xfers, lambda r, na, b: scratch[r][na[1]:b]))
+            for r in self.comm.ranks:
+                a, b = self.strips[r]
+                a2, b2 = half_rows(a, b, self.H) if res == "h" else (a, b)
+                lo, hi = (0, h) if halo is None else (max(0, a2 - halo), min(h, b2 + halo))
+                expect = (owner_of[res][lo:hi].to(torch.int32) * 8 + k).to(torch.uint8)
+                good = bool((scratch[r][lo:hi] == expect[:, None]).all().item())
+                outside = bool((scratch[r][:lo] == 0).all().item()) and bool((scratch[r][hi:] == 0).all().item())
+                if not (good and outside):
+                    ok = False
+                    import sys
+                    print(f"[kajiya_amd split self-test] rank {r}: exchange '{what}' delivered wrong rows", file=sys.stderr, flush=True)
+        # the variable-length all-gather of cache records: rank r contributes r + 1 rows of value r + 1
+        parts = {}
+        for r in self.comm.ranks:
+            buf = torch.full((n + 3, 8), r + 1, dtype=torch.int32, device=dev)
+            parts[r] = (buf, r + 1)
+        got = self.comm.all_gather_rows(parts)
+        want = torch.cat([torch.full((q + 1, 8), q + 1, dtype=torch.int32) for q in range(n)], dim=0).to(dev)
+        for r in self.comm.ranks:
+            if got[r].shape != want.shape or not bool((got[r] == want).all().item()):
+                ok = False
+        if isinstance(self.comm, DistComm):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if (self.comm.stage or self.comm.dist.get_backend() == "gloo") else dev)
+            self.comm.dist.all_reduce(flag, op=self.comm.dist.ReduceOp.MIN)
+            ok = bool(int(flag.item()))
+        return ok
+
     def _render(self, rank, mask, rows=None, spatial_select=0):
         """One kj_rtdgi_render call. The parameter struct is built once per rank per frame (gi_frame) and only the pass mask, row range
         and spatial-pass selector change between calls; the stream handle is looked up once per frame as well (host time per rank per
