@@ -166,7 +166,7 @@ def main():
     K, Wm = args.steps, args.warmup
     desc, cam_args, scene_label = make_scene(args.scene, args.tris)
     dev = lib.Device(local_rank)
-    scene = lib.Scene(dev, desc)
+    scene = lib.Scene(dev, desc, fast_build=bool(os.environ.get("KJ_BENCH_FAST_BUILD")))     # KJ_BENCH_FAST_BUILD=1: BLASes as device-built LBVHs (measurements)
     stats = scene.stats()
     gp = lib.GpuPipeline(dev, scene, W, H, device=f"cuda:{local_rank}", use_ircache=True)
     # ---- N > 1: screen-tile split of the SAME frame (strong scaling): one strip per rank, halo exchange over RCCL

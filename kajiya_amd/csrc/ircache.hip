@@ -573,6 +573,10 @@ KjStatus kj_ircache_set_enable_scroll(KjIrcache* c, uint32_t enable) { KJ_REQUIR
 // IrcacheRenderer::prepare (ircache.rs:168-350)
 KjStatus kj_ircache_prepare(KjIrcache* c, void* stream_) {
     KJ_REQUIRE(c && c->dev->fc_dev, "null argument / kj_frame_begin not called");
+    // deferred mode: this frame's lookups only RECORD; without a cleared slot array and a later replay the cache would silently stop
+    // allocating and refreshing entries
+    KJ_REQUIRE(!c->deferred || c->requests_begun, "deferred updates are on: call kj_ircache_begin_requests before kj_ircache_prepare every frame (or kj_ircache_set_deferred_updates(c, 0))");
+    c->requests_begun = false;
     hipStream_t s = (hipStream_t)stream_;
     int a = 0, b = 1;
     if (c->parity == 1) std::swap(a, b);
@@ -677,6 +681,7 @@ KjStatus kj_ircache_begin_requests(KjIrcache* c, uint32_t rtdgi_half_width, uint
     const size_t bytes = size_t(c->request_slots()) * sizeof(IrcRequest);
     if (c->requests.bytes != bytes) KJ_TRY_HIP(c->requests.alloc(bytes, s));
     KJ_TRY_HIP(hipMemsetAsync(c->requests.p, 0xff, bytes, s));      // cell = 0xffffffff: unused
+    c->requests_begun = true;
     return KJ_OK;
 }
 KjStatus kj_ircache_request_ranges(KjIrcache* c, uint32_t out_first_slot[4], uint32_t out_slot_count[4]) {

@@ -17,6 +17,7 @@ struct KjIrcache {
     // deferred updates (kj_ircache.hpp: IrcRequest): one slot per possible lookup of the frame, in four ranges
     //   [0, HB) rtdgi validate | [HB, 2 HB) rtdgi trace | [2 HB, 2 HB + E) the cache's validate rays | [2 HB + E, 2 HB + 2 E) its trace rays
     bool deferred = false;
+    bool requests_begun = false;        // kj_ircache_begin_requests ran for the frame kj_ircache_prepare is about to open (deferred mode)
     uint32_t req_half_pixels = 0;       // HB of the current frame
     kj::DevBuf freed, aux_snapshot, requests, req_sort_keys, req_sort_keys2, req_sort_idx, req_sort_idx2, req_flags, req_ranks, req_tmp, req_count;
     hipError_t err = hipSuccess;

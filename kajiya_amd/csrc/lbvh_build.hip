@@ -1,7 +1,7 @@
 // Acceleration-structure build ON THE DEVICE: a mesh's BLAS as a linear BVH -- the "prefer fast build" counterpart of the
 // host SAH builder (bvh_build.cpp), same node format, same traversal.
 //   1. per triangle: object-space box + centroid, mesh bounds by atomic min / max                        (k_lbvh_prims)
-//   2. 30-bit Morton code of the centroid inside the mesh bounds                                        (k_lbvh_morton)
+//   2. 63-bit Morton code (21 bits per axis) of the centroid inside the mesh bounds                                       (k_lbvh_morton)
 //   3. radix sort of (code, triangle) pairs                                                             (rocPRIM via hipCUB)
 //   4. binary radix tree over the sorted codes, one thread per internal node (Karras 2012; equal codes are told
 //      apart by their position), then boxes bottom-up: the second thread to reach a node carries on         (k_lbvh_hierarchy, k_lbvh_refit)
@@ -50,12 +50,21 @@ __global__ void __launch_bounds__(256) k_lbvh_prims(const uint8_t* __restrict__ 
     pbox[i] = b;
     for (int k = 0; k < 3; ++k) { atomicMin(&ob[k], f2o(b.mn[k])); atomicMax(&ob[3 + k], f2o(b.mx[k])); }
 }
-KJ_D uint32_t spread10(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u;
-    return v;
+// 21 bits per axis -> every third bit of a 63-bit code. (Round 2 used 10 bits per axis: in a 250 k-triangle mesh whole neighbourhoods
+// share one 30-bit code, and triangles with equal codes are split by their POSITION in the sorted array, i.e. arbitrarily in space.)
+typedef unsigned long long MortonCode;
+#ifdef KJ_LBVH_MORTON30
+#define KJ_MORTON_BITS 10
+#else
+#define KJ_MORTON_BITS 21
+#endif
+KJ_D MortonCode spread21(uint32_t v) {
+    MortonCode x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull; x = (x | x << 16) & 0x1f0000ff0000ffull; x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull; x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
 }
-__global__ void __launch_bounds__(256) k_lbvh_morton(const Box6* __restrict__ pbox, const uint32_t* __restrict__ ob, uint32_t n, uint32_t* __restrict__ codes, uint32_t* __restrict__ ids) {
+__global__ void __launch_bounds__(256) k_lbvh_morton(const Box6* __restrict__ pbox, const uint32_t* __restrict__ ob, uint32_t n, MortonCode* __restrict__ codes, uint32_t* __restrict__ ids) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     uint32_t q[3];
@@ -63,19 +72,20 @@ __global__ void __launch_bounds__(256) k_lbvh_morton(const Box6* __restrict__ pb
         const float lo = o2f(ob[k]), hi = o2f(ob[3 + k]);
         const float c = 0.5f * (pbox[i].mn[k] + pbox[i].mx[k]);
         const float t = hi > lo ? (c - lo) / (hi - lo) : 0.0f;
-        q[k] = uint32_t(fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f));
+        const float cells = float(1u << KJ_MORTON_BITS);
+        q[k] = uint32_t(fminf(fmaxf(t * cells, 0.0f), cells - 1.0f));
     }
-    codes[i] = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+    codes[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
     ids[i] = i;
 }
 // number of leading bits codes i and j share; equal codes are ordered by position
-KJ_D int lcp(const uint32_t* __restrict__ codes, int n, int i, int j) {
+KJ_D int lcp(const MortonCode* __restrict__ codes, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    const uint32_t a = codes[i], b = codes[j];
-    return a != b ? __clz(int(a ^ b)) : 32 + __clz(int(uint32_t(i) ^ uint32_t(j)));
+    const MortonCode a = codes[i], b = codes[j];
+    return a != b ? __clzll((long long)(a ^ b)) : 64 + __clz(int(uint32_t(i) ^ uint32_t(j)));
 }
 // Binary radix tree. Node ids: internal i in [0, n-1), leaf k as (n - 1 + k). parent[] over all 2n-1 ids.
-__global__ void __launch_bounds__(256) k_lbvh_hierarchy(const uint32_t* __restrict__ codes, int n, uint2* __restrict__ children, uint2* __restrict__ range, uint32_t* __restrict__ parent) {
+__global__ void __launch_bounds__(256) k_lbvh_hierarchy(const MortonCode* __restrict__ codes, int n, uint2* __restrict__ children, uint2* __restrict__ range, uint32_t* __restrict__ parent) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n - 1) return;
     const int d = lcp(codes, n, i, i + 1) - lcp(codes, n, i, i - 1) >= 0 ? 1 : -1;
@@ -223,7 +233,7 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
     // third of a nine-mesh build: hipFree synchronises the device) and grown when a larger mesh comes along
     if (scratch->capacity < n) {
         const size_t c = size_t(n) + n / 4;
-        const size_t sizes[LbvhScratch::BUFFERS] = {c * sizeof(Box6), 32, c * 4, c * 4, c * 4, c * 4, c * 8, c * 8, 2 * c * 4, c * 4, 2 * c * sizeof(Box6),
+        const size_t sizes[LbvhScratch::BUFFERS] = {c * sizeof(Box6), 32, c * 8, c * 4, c * 8, c * 4, c * 8, c * 8, 2 * c * 4, c * 4, 2 * c * sizeof(Box6),
                                                     (c + 1) * sizeof(CollapseItem), (c + 1) * sizeof(CollapseItem), 16};
         for (int k = 0; k < LbvhScratch::BUFFERS; ++k) KJ_LB(scratch->buf[k].alloc(sizes[k], s));
         scratch->capacity = uint32_t(c);
@@ -235,12 +245,12 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
     const dim3 g((n + 255) / 256), b(256);
     hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, (uint32_t*)ob.p);
     hipLaunchKernelGGL(k_lbvh_prims, g, b, 0, s, d_vertex_buffer, mesh, n, (Box6*)pbox.p, (uint32_t*)ob.p);
-    hipLaunchKernelGGL(k_lbvh_morton, g, b, 0, s, (const Box6*)pbox.p, (const uint32_t*)ob.p, n, (uint32_t*)codes.p, (uint32_t*)ids.p);
+    hipLaunchKernelGGL(k_lbvh_morton, g, b, 0, s, (const Box6*)pbox.p, (const uint32_t*)ob.p, n, (MortonCode*)codes.p, (uint32_t*)ids.p);
     size_t tmp_bytes = 0;
-    KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t*)codes.p, (uint32_t*)codes2.p, (const uint32_t*)ids.p, (uint32_t*)ids2.p, int(n), 0, 30, s));
+    KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const MortonCode*)codes.p, (MortonCode*)codes2.p, (const uint32_t*)ids.p, (uint32_t*)ids2.p, int(n), 0, 3 * KJ_MORTON_BITS, s));
     if (tmp.bytes < (tmp_bytes ? tmp_bytes : 16)) KJ_LB(tmp.alloc(tmp_bytes ? tmp_bytes : 16, s));
-    KJ_LB(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const uint32_t*)codes.p, (uint32_t*)codes2.p, (const uint32_t*)ids.p, (uint32_t*)ids2.p, int(n), 0, 30, s));
-    if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, g, b, 0, s, (const uint32_t*)codes2.p, int(n), (uint2*)children.p, (uint2*)range.p, (uint32_t*)parent.p);
+    KJ_LB(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const MortonCode*)codes.p, (MortonCode*)codes2.p, (const uint32_t*)ids.p, (uint32_t*)ids2.p, int(n), 0, 3 * KJ_MORTON_BITS, s));
+    if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, g, b, 0, s, (const MortonCode*)codes2.p, int(n), (uint2*)children.p, (uint2*)range.p, (uint32_t*)parent.p);
     else KJ_LB(hipMemsetAsync(parent.p, 0xff, 8, s));
     hipLaunchKernelGGL(k_lbvh_refit, g, b, 0, s, (const Box6*)pbox.p, (const uint32_t*)ids2.p, int(n), (const uint2*)children.p, (const uint32_t*)parent.p, (uint32_t*)visits.p, (Box6*)nbox.p);
     // collapse, level by level, without a read-back per level: counters = {-, nodes allocated, max stack}; queue_len[l] = items of level l;

@@ -16,6 +16,7 @@
 #include <cstdarg>
 #include <numeric>
 #include <future>
+#include <thread>
 #include <map>
 #include <memory>
 #include <chrono>
@@ -297,9 +298,26 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         build_bvh4(ot, *b);
         return b;
     };
+    // at most `hardware_concurrency` builds in flight (each may spawn workers of its own for a large mesh, and holds a copy of its
+    // triangles): a first commit with thousands of small meshes must not start thousands of threads. A build that
+    // cannot get its thread or its memory is reported as a status, not as an exception through the C boundary.
     std::map<uint32_t, std::future<std::unique_ptr<BuiltBvh>>> host_builds;
+    std::vector<uint32_t> to_build;
     for (uint32_t mi = 0; mi < s->meshes.size(); ++mi)
-        if (!s->blas[mi].built && s->mesh_build_mode[mi] != 1) host_builds[mi] = std::async(std::launch::async, host_build, mi);
+        if (!s->blas[mi].built && s->mesh_build_mode[mi] != 1) to_build.push_back(mi);
+    const size_t max_in_flight = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    size_t next_build = 0;
+    auto start_builds = [&]() -> bool {
+        try {
+            while (next_build < to_build.size() && host_builds.size() < max_in_flight) {
+                const uint32_t mi = to_build[next_build];
+                host_builds[mi] = std::async(std::launch::async, host_build, mi);
+                ++next_build;
+            }
+        } catch (const std::exception&) { return false; }
+        return true;
+    };
+    if (!start_builds() && host_builds.empty()) { set_last_error("could not start a BLAS build thread"); return KJ_ERR_OUT_OF_MEMORY; }
     for (uint32_t mi = 0; mi < s->meshes.size(); ++mi) {
         KjScene::Blas& bl = s->blas[mi];
         if (bl.built) continue;
@@ -318,7 +336,17 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
             for (size_t d = lr.level_starts.size() - 1; d-- > 0;) { steps.push_back(lr.level_starts[d]); steps.push_back(lr.level_starts[d + 1]); }
             bl.root = 0;
         } else {                              // binned SAH on the host
-            std::unique_ptr<BuiltBvh> built = host_builds[mi].get();
+            if (!host_builds.count(mi)) {      // not started yet (the in-flight limit): start it now, alone if need be
+                try { host_builds[mi] = std::async(std::launch::async, host_build, mi); }
+                catch (const std::exception&) { host_builds[mi] = std::async(std::launch::deferred, host_build, mi); }
+                next_build = std::max(next_build, size_t(std::find(to_build.begin(), to_build.end(), mi) - to_build.begin()) + 1);
+            }
+            std::unique_ptr<BuiltBvh> built;
+            try { built = host_builds[mi].get(); }
+            catch (const std::bad_alloc&) { set_last_error("out of host memory building the BLAS of mesh %u", mi); return KJ_ERR_OUT_OF_MEMORY; }
+            catch (const std::exception& e) { set_last_error("BLAS build of mesh %u failed: %s", mi, e.what()); return KJ_ERR_OUT_OF_MEMORY; }
+            host_builds.erase(mi);
+            start_builds();                    // a slot is free: keep the builders busy
             BuiltBvh& b = *built;
             bl.node_count = uint32_t(b.nodes.size());
             bl.max_stack = b.max_stack;
@@ -497,7 +525,11 @@ KjStatus kj_scene_stats(KjScene* s, uint32_t* out_tri_count, uint32_t* out_node_
     if (!s->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
     if (out_tri_count) *out_tri_count = s->tri_count;
     if (out_node_count) *out_node_count = s->node_count;
-    if (out_bvh_bytes) *out_bvh_bytes = uint64_t(s->node_count) * sizeof(BvhNode) + uint64_t(s->tri_count) * sizeof(BvhTri) + uint64_t(s->obj_tris_used) * sizeof(BvhTri);
+    // everything the acceleration structure keeps on the device: per-INSTANCE world nodes (64 B) and world triangles (48 B) -- unlike
+    // the reference's TLAS / BLAS, instancing saves no memory here: an instance costs its mesh's whole tree again -- plus the per-mesh
+    // BLAS pool (object-space nodes + triangles), the refit's box scratch (24 B per world node) and the refit step table
+    if (out_bvh_bytes) *out_bvh_bytes = uint64_t(s->node_count) * sizeof(BvhNode) + uint64_t(s->tri_count) * sizeof(BvhTri) + uint64_t(s->obj_tris_used) * sizeof(BvhTri) +
+                                        uint64_t(s->blas_nodes_used) * sizeof(BvhNode) + uint64_t(s->node_count) * 24u + uint64_t(s->blas_steps.size()) * 4u;
     return KJ_OK;
 }
 

@@ -151,19 +151,30 @@ namespace kj {
 
 hipError_t launch_instance_refit(const Bvh4Node* blas_nodes, const uint2* steps, const BvhTri* world_tris, const InstanceRefitJob* jobs, uint32_t job_count,
                                  uint32_t max_wide_heights, Bvh4Node* nodes, void* boxes, hipStream_t s) {
+    if (job_count == 0) return hipSuccess;      // (and leave a sticky error of some earlier, unrelated call where it is)
+    // blocks along x per job: enough for the populous heights of a large mesh, fewer when there are thousands of jobs (a grid of
+    // 256 x 32768 mostly idle workgroups per height is seconds of launch overhead)
+    const uint32_t gx = job_count <= 64u ? 256u : (job_count <= 1024u ? 64u : 16u);
     for (uint32_t j0 = 0; j0 < job_count; j0 += 32768u) {      // (grid.y is limited to 65535)
         const uint32_t n = std::min(32768u, job_count - j0);
         for (uint32_t h = 0; h < max_wide_heights; ++h)
-            hipLaunchKernelGGL(k_instance_refit_height, dim3(256, n), dim3(256), 0, s, blas_nodes, steps, world_tris, jobs + j0, nodes, (Box6*)boxes, h);
+            hipLaunchKernelGGL(k_instance_refit_height, dim3(gx, n), dim3(256), 0, s, blas_nodes, steps, world_tris, jobs + j0, nodes, (Box6*)boxes, h);
         hipLaunchKernelGGL(k_instance_refit_top, dim3(n), dim3(KJ_REFIT_TOP_NODES), 0, s, blas_nodes, steps, world_tris, jobs + j0, nodes, (Box6*)boxes);
+        const hipError_t e = hipGetLastError();      // per chunk: a failed launch is reported where it happened
+        if (e != hipSuccess) return e;
     }
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 hipError_t launch_instance_triangles(const BvhTri* obj_tris, BvhTri* world_tris, const InstanceTriJob* jobs, uint32_t job_count, hipStream_t s) {
-    for (uint32_t j0 = 0; j0 < job_count; j0 += 32768u)        // (grid.y is limited to 65535)
-        hipLaunchKernelGGL(k_instance_triangles, dim3(64, std::min(32768u, job_count - j0)), dim3(256), 0, s, obj_tris, world_tris, jobs + j0);
-    return hipGetLastError();
+    if (job_count == 0) return hipSuccess;
+    const uint32_t gx = job_count <= 64u ? 64u : (job_count <= 1024u ? 16u : 4u);
+    for (uint32_t j0 = 0; j0 < job_count; j0 += 32768u) {      // (grid.y is limited to 65535)
+        hipLaunchKernelGGL(k_instance_triangles, dim3(gx, std::min(32768u, job_count - j0)), dim3(256), 0, s, obj_tris, world_tris, jobs + j0);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace kj

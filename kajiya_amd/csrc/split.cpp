@@ -81,6 +81,7 @@ struct KjSplit {
     std::vector<std::pair<uint32_t, uint32_t>> strips;     // full-res rows [r0, r1) of every rank of the job
     uint32_t frame = 0, taa_frames = 0;
     bool consistent_ircache = false;
+    std::vector<uint8_t> ircache_was_deferred;             // each local cache's mode before kj_split_create changed it: restored by kj_split_destroy
     void* nccl = nullptr;                                  // ncclComm_t; null: every rank is local
     std::map<std::pair<uint32_t, std::string>, std::pair<uint8_t*, uint64_t>> surfaces;     // (local index, name) -> base pointer, bytes
     std::vector<DevBuf> send_stage, recv_stage;            // [local rank * world + peer]: the packed rows of one exchange
@@ -310,14 +311,22 @@ KjStatus kj_split_create(uint32_t world, uint32_t first_rank, uint32_t local_ran
     bool all_cached = true;
     for (const KjSplitRank& r : s->ranks) { if (!r.rtdgi || !r.taa || !r.scene) { delete s; KJ_REQUIRE(false, "a rank needs rtdgi, taa and scene handles"); } all_cached &= r.ircache != nullptr; }
     s->consistent_ircache = all_cached;
-    for (const KjSplitRank& r : s->ranks)
+    for (const KjSplitRank& r : s->ranks) {
+        s->ircache_was_deferred.push_back(r.ircache && r.ircache->deferred ? 1 : 0);
         if (r.ircache) { const KjStatus e = kj_ircache_set_deferred_updates(r.ircache, all_cached ? 1u : 0u); if (e != KJ_OK) { delete s; return e; } }
+    }
     s->send_stage = std::vector<DevBuf>(size_t(local_ranks) * world); s->recv_stage = std::vector<DevBuf>(size_t(local_ranks) * world); s->peer_lists = std::vector<DevBuf>(world);
     s->strip_list = std::vector<DevBuf>(local_ranks); s->irc_list = std::vector<DevBuf>(local_ranks); s->merged = std::vector<DevBuf>(local_ranks); s->counts = std::vector<DevBuf>(local_ranks);
     *out = s;
     return KJ_OK;
 }
-void kj_split_destroy(KjSplit* s) { delete s; }
+void kj_split_destroy(KjSplit* s) {
+    if (!s) return;
+    // hand the caches back in the mode they came in: a plain kj_rtdgi_render caller would otherwise keep RECORDING lookups that nobody replays
+    for (size_t i = 0; i < s->ranks.size() && i < s->ircache_was_deferred.size(); ++i)
+        if (s->ranks[i].ircache) kj_ircache_set_deferred_updates(s->ranks[i].ircache, s->ircache_was_deferred[i]);
+    delete s;
+}
 
 KjStatus kj_split_strip(KjSplit* s, uint32_t rank, uint32_t* out_row_begin, uint32_t* out_row_end) {
     KJ_REQUIRE(s && rank < s->world && out_row_begin && out_row_end, "bad argument");

@@ -1,14 +1,12 @@
 # round-3 A/B runs on one GPU lease (scratch outputs under gpurun_out/)
 ROOT=$PWD; mkdir -p gpurun_out
-B="python $ROOT/bench.py --no-cpu-baseline --no-also --steps 30 --warmup 12 --profile-frames 9 --no-overlap"
-for v in sa4 sa5 sa8; do KJ_AMD_LIB=$ROOT/kajiya_amd/libkajiya_amd_$v.so KJ_RTDGI_SPLIT=1 $B > gpurun_out/c5_bench_split_$v.json 2>/dev/null; done
-KJ_RTDGI_SPLIT=1 $B > gpurun_out/c5_bench_split_sa6.json 2>/dev/null
-cd /tmp && export TMPDIR=/tmp
-for f in split fused; do
-  if [ $f = split ]; then export KJ_RTDGI_SPLIT=1; else export KJ_RTDGI_SPLIT=0; fi
-  rm -rf $ROOT/gpurun_out/c5_prof_$f
-  KJ_RTDGI_GROUPED=0 timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/c5_prof_$f -o stats --output-format csv -- $B > $ROOT/gpurun_out/c5_prof_$f.log 2>&1
-  cp $(find $ROOT/gpurun_out/c5_prof_$f -name "*kernel_stats.csv" | head -1) $ROOT/gpurun_out/c5_kernel_stats_$f.csv
-  rm -rf $ROOT/gpurun_out/c5_prof_$f
-done
+(time python -m pytest tests/test_gpu_parity.py -k "lbvh or instance_trees or four_lanes" -q -s -m gpu -p no:cacheprovider) > gpurun_out/c6_tests.log 2>&1
+python scripts/traversal_microbench.py --fast-build > gpurun_out/c6_microbench_m63.log 2>&1
+KJ_AMD_LIB=$ROOT/kajiya_amd/libkajiya_amd_m30.so python scripts/traversal_microbench.py --fast-build > gpurun_out/c6_microbench_m30.log 2>&1
+python scripts/traversal_microbench.py > gpurun_out/c6_microbench_sah.log 2>&1
+B="python bench.py --no-cpu-baseline --no-also --steps 24 --warmup 12 --profile-frames 6 --no-overlap"
+KJ_BENCH_FAST_BUILD=1 $B > gpurun_out/c6_bench_fast_m63.json 2>/dev/null
+KJ_BENCH_FAST_BUILD=1 KJ_AMD_LIB=$ROOT/kajiya_amd/libkajiya_amd_m30.so $B > gpurun_out/c6_bench_fast_m30.json 2>/dev/null
+$B > gpurun_out/c6_bench_sah.json 2>/dev/null
+python scripts/dynamic_scene_bench.py > gpurun_out/c6_dynamic_scene.json 2>gpurun_out/c6_dynamic_scene.err
 echo done
