@@ -89,16 +89,20 @@ struct KjScene {
     std::vector<uint8_t> mesh_build_mode;         // per mesh
     // what changed since the last commit
     bool meshes_dirty = true, instance_set_dirty = true;
+    bool instances_added = true;                  // since the last commit: the world arrays must be laid out anew (a removal alone leaves a hole instead)
     std::vector<uint8_t> xform_dirty;             // per instance slot
     // committed device state
-    bool committed = false;
+    bool committed = false, committed_once = false;
     kj::DevBuf d_vertex_buffer, d_meshes, d_instances, d_maps, d_tex_data, d_lights, d_blas_nodes, d_obj_tris, d_tris, d_jobs, d_refit_jobs;
     kj::DevBuf d_nodes, d_node_boxes;               // the world-space tree (top tree + one region per instance), the refit's per-node scratch box
     kj::DevBuf d_blas_steps;                        // per mesh: {first, end} node of every step of its instances' bottom-up refit
     std::vector<uint32_t> blas_steps;               // host copy of d_blas_steps
     std::vector<uint32_t> inst_node_base;         // per instance slot: first node of its region in d_nodes
     uint32_t tlas_capacity = 0, world_nodes = 0;   // nodes reserved for the top tree at the front of d_nodes; nodes in use overall
+    std::vector<uint32_t> inst_id_base;           // per instance slot: first world triangle ID (dense over the live instances)
+    kj::DevBuf d_renumber_jobs;
     std::vector<uint32_t> inst_tri_base;          // per instance slot: first world triangle (valid for live instances after a commit)
+    uint32_t live_tri_count = 0;                  // triangles of the live instances (tri_count = size of the world array: holes of removed instances included)
     uint32_t light_count = 0, tri_count = 0, node_count = 0, tlas_node_count = 0, bvh_root = 0, bvh_max_depth = 0;
     double last_commit_ms[4] = {0, 0, 0, 0};      // host time of the last commit: BLAS builds, instance tables + top tree, uploads + device transform / refit, total
     kj::SceneView view() const;

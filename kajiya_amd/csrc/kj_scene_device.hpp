@@ -7,9 +7,14 @@
 namespace kj {
 
 // One instance's world-space triangles: dst[i] = xform * src[i] for `count` triangles of the mesh's leaf-ordered list.
-struct InstanceTriJob { float xform[12]; uint32_t src, dst, count, instance; };
-static_assert(sizeof(InstanceTriJob) == 64, "job size");
+// `id_base`: the instance's first WORLD TRIANGLE ID -- the dense numbering over the live instances in slot order that ray queries report
+// and equal-t ties are broken by; `dst`: where its triangles live in the world array (the same number until an instance is removed:
+// a removal leaves a hole in the array, the ids stay dense).
+struct InstanceTriJob { float xform[12]; uint32_t src, dst, count, instance, id_base, pad[3]; };
+static_assert(sizeof(InstanceTriJob) == 80, "job size");
 hipError_t launch_instance_triangles(const BvhTri* obj_tris, BvhTri* world_tris, const InstanceTriJob* jobs, uint32_t job_count, hipStream_t s);
+// only the ids again (after a removal shifted the numbering of the instances behind it): 4 bytes per triangle instead of the transform + refit
+hipError_t launch_instance_renumber(BvhTri* world_tris, const InstanceTriJob* jobs, uint32_t job_count, hipStream_t s);
 
 // One instance's world-space tree: nodes[dst + i] = BLAS node blas_nodes[src + i] refit around world_tris[tri_base ..] (which must have
 // been derived already on the same stream), child references rebased to `dst` / `tri_base`.

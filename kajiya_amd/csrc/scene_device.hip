@@ -26,11 +26,16 @@ __global__ void __launch_bounds__(256) k_instance_triangles(const BvhTri* __rest
             dst[k][1] = x[4] * p[0] + x[5] * p[1] + x[6] * p[2] + x[7];
             dst[k][2] = x[8] * p[0] + x[9] * p[1] + x[10] * p[2] + x[11];
         }
-        o.world_id = j.dst + t.prim;
+        o.world_id = j.id_base + t.prim;
         o.inst = j.instance;
         o.prim = t.prim;
         world_tris[j.dst + i] = o;
     }
+}
+
+__global__ void __launch_bounds__(256) k_instance_renumber(BvhTri* __restrict__ world_tris, const InstanceTriJob* __restrict__ jobs) {
+    const InstanceTriJob j = jobs[blockIdx.y];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < j.count; i += gridDim.x * 256) world_tris[j.dst + i].world_id = j.id_base + world_tris[j.dst + i].prim;
 }
 
 // One instance's world-space tree: the mesh's BLAS topology with every child box refit around the instance's WORLD-space triangles
@@ -171,6 +176,17 @@ hipError_t launch_instance_triangles(const BvhTri* obj_tris, BvhTri* world_tris,
     const uint32_t gx = job_count <= 64u ? 64u : (job_count <= 1024u ? 16u : 4u);
     for (uint32_t j0 = 0; j0 < job_count; j0 += 32768u) {      // (grid.y is limited to 65535)
         hipLaunchKernelGGL(k_instance_triangles, dim3(gx, std::min(32768u, job_count - j0)), dim3(256), 0, s, obj_tris, world_tris, jobs + j0);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_instance_renumber(BvhTri* world_tris, const InstanceTriJob* jobs, uint32_t job_count, hipStream_t s) {
+    if (job_count == 0) return hipSuccess;
+    const uint32_t gx = job_count <= 64u ? 64u : (job_count <= 1024u ? 16u : 4u);
+    for (uint32_t j0 = 0; j0 < job_count; j0 += 32768u) {
+        hipLaunchKernelGGL(k_instance_renumber, dim3(gx, std::min(32768u, job_count - j0)), dim3(256), 0, s, world_tris, jobs + j0);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
