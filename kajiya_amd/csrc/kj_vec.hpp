@@ -335,6 +335,30 @@ KJ_D unsigned long long* counter_slot(unsigned long long* base) {
 }
 #endif
 
+// ---- XCD-aware tile order. MI355X dispatches workgroup `b` (x fastest) to XCD `b % 8`, each XCD with its own 4 MiB L2. With the
+// plain blockIdx -> tile mapping horizontally adjacent tiles of a screen pass sit on eight different L2s (and, image widths being
+// multiples of 64, an XCD owns 8-pixel COLUMNS spaced 64 pixels apart): every halo texel, every gather of a neighbour's reservoir
+// and every BVH node under a region of the screen is fetched into up to eight L2s. xcd_tile() hands XCD k the k-th contiguous
+// eighth of the launch's tiles in row-major order -- a band of whole tile rows -- so a pass's reach (3..32 px) stays inside one L2
+// except at the seven band edges. Bijective for any grid size (the first n % 8 XCDs take one tile more). The dispatch order is not
+// a contract (MI355X_MICROARCH.md, "Workgroup dispatch"): a different placement costs speed, never correctness.
+#ifndef KJ_XCD_SWIZZLE
+#define KJ_XCD_SWIZZLE 1
+#endif
+#ifdef __HIPCC__
+KJ_D uint2 xcd_tile() {
+#if KJ_XCD_SWIZZLE
+    const uint32_t gx = gridDim.x, n = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
+    const uint32_t q = n >> 3, r = n & 7u, xcd = id & 7u;
+    const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (id >> 3);
+    const uint32_t ty = t / gx;
+    return make_uint2(t - ty * gx, ty);
+#else
+    return make_uint2(blockIdx.x, blockIdx.y);
+#endif
+}
+#endif
+
 // ---- flat-buffer "textures": OOB load = 0, OOB store dropped
 template <typename T> struct Img {
     T* p; int w, h;

@@ -34,7 +34,8 @@ typedef Img<float4> ImgF4;
 // (row0 a multiple of 8) so the same kernels serve the screen-tile split across GPUs.
 #define TILE_XY(W_, H_)                                                   \
     const int lane = threadIdx.x;                                         \
-    const int x = int(blockIdx.x) * 8 + (lane & 7), y = row0 + int(blockIdx.y) * 8 + (lane >> 3); \
+    const uint2 kj_tb = kj::xcd_tile();                                   \
+    const int x = int(kj_tb.x) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
 // ------------------------------------------------------------------ extract_half_res_{gbuffer_view_normal_rgba8,depth,ssao}.hlsl (fused)
@@ -269,7 +270,8 @@ KJ_HD size_t grouped_lds_bytes(uint32_t stack_entries) { return size_t(stack_ent
 // 2 x 2 tiles: wave w covers tile (w & 1, w >> 1) of the 16 x 16 block
 #define GROUP_TILE_XY(W_, H_)                                                                                              \
     const int lane = int(threadIdx.x & 63u), wave = int(threadIdx.x >> 6);                                                  \
-    const int x = int(blockIdx.x) * 16 + (wave & 1) * 8 + (lane & 7), y = row0 + int(blockIdx.y) * 16 + (wave >> 1) * 8 + (lane >> 3); \
+    const uint2 kj_tb = kj::xcd_tile();                                                                                    \
+    const int x = int(kj_tb.x) * 16 + (wave & 1) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * 16 + (wave >> 1) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 // Called by ALL threads of the workgroup (barriers inside); `has_ray` false = this pixel traces nothing (sky, outside the image).
 template <bool STATS>
@@ -986,14 +988,18 @@ __global__ void __launch_bounds__(64) k_validity_integrate(const FrameConstants*
     ib = lerp(ib, __shfl_xor(ib, 16), 0.5f);
     ib = smoothstep(0.0f, 1.0f, ib);
     const float center_depth = half_depth_tex.ld(x, y);
-    float edge = 1;
+    // the shader's loop leaves its inner loop at the first failed texel with edge = 0, and edge only ever takes the values 0 and 1:
+    // the result is 1 exactly when all six texels pass both tests, so all twelve loads are issued together and nothing branches
+    bool edge_ok = true;
+#pragma unroll
     for (int oy = 0; oy <= 2; ++oy)
+#pragma unroll
         for (int ox = 1; ox <= 2; ++ox) {
             const V4 reproj = ld_reproj(reprojection_tex, x * 2 + ox, y * 2 + oy);
             const float sample_depth = half_depth_tex.ld(x + ox / 2, y + oy / 2);
-            if (reproj.w < 0 || inverse_depth_relative_diff(center_depth, sample_depth) > 0.1f) { edge = 0; break; }
-            edge *= (reproj.z == 0 && sample_depth != 0) ? 1.0f : 0.0f;
+            edge_ok = edge_ok && !(reproj.w < 0 || inverse_depth_relative_diff(center_depth, sample_depth) > 0.1f) && (reproj.z == 0 && sample_depth != 0);
         }
+    float edge = edge_ok ? 1.0f : 0.0f;
     edge = fmaxf(edge, __shfl_xor(edge, 1));
     edge = fmaxf(edge, __shfl_xor(edge, 8));
     ib = saturate(ib + edge);
@@ -1004,7 +1010,7 @@ __global__ void __launch_bounds__(64) k_validity_integrate(const FrameConstants*
     for (uint32_t si = 0; si < 8u; ++si) {
         const float ang = (float(si) + ang_off) * KJ_GOLDEN_ANGLE;
         const float radius = float(si) * 1.0f;
-        const V2 so = cos_sin_turns(ang) * radius;
+        const V2 so = cos_sin_turns_fast(ang) * radius;      // same reduction in revolutions, < 1 ulp (kj_screen.hpp): libm's sinf + cosf are 235 instructions per tap
         history += ld2h(history_tex, int(reproj_px.x + so.x), int(reproj_px.y + so.y)).x;
     }
     history /= 8;
@@ -1067,52 +1073,79 @@ __global__ void __launch_bounds__(64) k_restir_temporal(RestirTemporalArgs a) {
     // xor_seq[frame&3] = {(3,3),(2,1),(1,2),(3,3)} ; offsets[4] = {(-1,-1),(1,1),(-1,1),(1,-1)}
     const uint32_t pxv_x = (fi & 3u) == 1u ? 2u : ((fi & 3u) == 2u ? 1u : 3u);
     const uint32_t pxv_y = (fi & 3u) == 1u ? 1u : ((fi & 3u) == 2u ? 2u : 3u);
-    for (uint32_t sample_i = 0; sample_i < 5u && stream_state.M_sum < 1.25f * RESTIR_TEMPORAL_M_CLAMP; ++sample_i) {
+    // The five history taps. The shader walks them one after the other and every tap is a chain of dependent fetches (reprojection ->
+    // reservoir -> the four images at the reservoir's sample pixel); a wave spends the pass waiting for ~20 round trips. Here the
+    // fetches of all taps are issued level by level -- nothing a tap loads depends on what an earlier tap decided -- and the loop that
+    // follows only does arithmetic, in the shader's order (the early-out on M_sum and every rejection test included). Weights use the
+    // single-instruction reciprocal / rsqrt (pow(x, 4) is two squarings: libm's powf is 163 instructions per tap); the rejection
+    // tests, which are comparisons, keep IEEE arithmetic.
+    struct Tap { bool skip; float reproj_z; uint2 res; float sample_depth; uint32_t normal_raw; float4 pro; uint2 rh, hn, prev_rad; };     // texels as loaded: 15 registers per tap
+    Tap taps[5];
+#pragma unroll
+    for (uint32_t sample_i = 0; sample_i < 5u; ++sample_i) {
+        Tap& t = taps[sample_i];
         I2 rpx_offset{0, 0};
+        t.skip = false;
         if (sample_i != 0) {
             const uint32_t ia = fi & 3u, ib = (sample_i + (fi ^ 1u)) & 3u;
             auto ofs = [](uint32_t i) { return I2{(i == 1u || i == 3u) ? 1 : -1, (i == 1u || i == 2u) ? 1 : -1}; };
             const I2 oa = ofs(ia), ob = ofs(ib);
             rpx_offset = I2{oa.x + ob.x, oa.y + ob.y};
-            if (rpx_offset.x == 0 && rpx_offset.y == 0) continue;
+            t.skip = rpx_offset.x == 0 && rpx_offset.y == 0;
         }
         const V4 reproj = ld_reproj(a.reprojection_tex, hx + rpx_offset.x * 2, hy + rpx_offset.y * 2);
+        t.reproj_z = reproj.z;
         const V2 base = sample_i == 0 ? V2{float(x), float(y)} : V2{float(uint32_t(x + rpx_offset.x) ^ pxv_x), float(uint32_t(y + rpx_offset.y) ^ pxv_y)};
         const int prx = f2i_sat(floorf(base.x + gts.x * reproj.x * 0.5f + 0.0f + 0.5f)), pry = f2i_sat(floorf(base.y + gts.y * reproj.y * 0.5f + 0.0f + 0.5f));
         const I2 rpx{wrap_add(prx, rpx_offset.x), wrap_add(pry, rpx_offset.y)};
         const int pnx = f2i_sat(floorf(base.x + 0.5f)), pny = f2i_sat(floorf(base.y + 0.5f));
         const I2 neighbor_px{wrap_add(pnx, rpx_offset.x), wrap_add(pny, rpx_offset.y)};
         const int nhx = wrap_mul2_add(neighbor_px.x, off.x), nhy = wrap_mul2_add(neighbor_px.y, off.y);
-        Reservoir1spp r = Reservoir1spp::from_raw(a.reservoir_history_tex.ld(rpx.x, rpx.y));
-        const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
+        t.res = a.reservoir_history_tex.ld(rpx.x, rpx.y);
+        t.sample_depth = a.depth_tex.ld(nhx, nhy);
+        t.normal_raw = a.half_view_normal_tex.ld(neighbor_px.x, neighbor_px.y);
+    }
+#pragma unroll
+    for (uint32_t sample_i = 0; sample_i < 5u; ++sample_i) {
+        Tap& t = taps[sample_i];
+        const int spx_x = int(t.res.x & 0xffff), spx_y = int(t.res.x >> 16);
+        t.pro = a.ray_orig_history_tex.ld(spx_x, spx_y);
+        t.rh = a.ray_history_tex.ld(spx_x, spx_y);
+        t.hn = a.hit_normal_history_tex.ld(spx_x, spx_y);
+        t.prev_rad = a.radiance_history_tex.ld(spx_x, spx_y);
+    }
+    const float M_clamp_now = exp2f(log2f(RESTIR_TEMPORAL_M_CLAMP) * (1.0f - rt_invalidity));
+#pragma unroll
+    for (uint32_t sample_i = 0; sample_i < 5u; ++sample_i) {
+        if (!(stream_state.M_sum < 1.25f * RESTIR_TEMPORAL_M_CLAMP)) break;
+        const Tap& t = taps[sample_i];
+        if (t.skip) continue;
+        Reservoir1spp r = Reservoir1spp::from_raw(t.res);
         float relevance = 1;
-        const float sample_depth = a.depth_tex.ld(nhx, nhy);
-        const float4 pro = a.ray_orig_history_tex.ld(spx_x, spx_y);
-        const V3 prev_ray_orig{pro.x, pro.y, pro.z};
+        const float sample_depth = t.sample_depth;
+        const V3 prev_ray_orig{t.pro.x, t.pro.y, t.pro.z};
         if (length(prev_ray_orig - refl_ray_origin_ws) > 0.1f * -vr.hit_vs.z) continue;
         if (0 == sample_depth) continue;
-        if (reproj.z == 0) continue;
-        relevance *= 1 - smoothstep(0.0f, 0.1f, inverse_depth_relative_diff(depth, sample_depth));
-        const V3 sample_normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, neighbor_px.x, neighbor_px.y);
-        const float normal_similarity_dot = fmaxf(0.0f, dot(sample_normal_vs, normal_vs));
+        if (t.reproj_z == 0) continue;
+        relevance *= 1 - smoothstep_fast(0.0f, 0.1f, fabsf(fmaxf(1e-20f, depth) * rcp_fast(fmaxf(1e-20f, sample_depth)) - 1.0f));
+        const float normal_similarity_dot = fmaxf(0.0f, dot(xyz(unpack_rgba8_snorm(t.normal_raw)), normal_vs));
         if (sample_i != 0 && normal_similarity_dot < 0.2f) continue;
-        relevance *= powf(normal_similarity_dot, 4.0f);
-        const V4 rh = ld4(a.ray_history_tex, spx_x, spx_y);
+        relevance *= square(square(normal_similarity_dot));
+        const V4 rh = unpack_rgba16f(t.rh), hn = unpack_rgba16f(t.hn);
         const V3 sample_hit_ws = xyz(rh) + prev_ray_orig;
         const float prev_dist = rh.w;
-        const V4 hn = ld4(a.hit_normal_history_tex, spx_x, spx_y);
         const V4 sample_hit_normal_ws_dot{hn.x * 2 - 1, hn.y * 2 - 1, hn.z * 2 - 1, hn.w};
         const V3 dir_to_sample_hit_unnorm = sample_hit_ws - refl_ray_origin_ws;
-        const float dist_to_sample_hit = length(dir_to_sample_hit_unnorm);
-        const V3 dir_to_sample_hit = normalize(dir_to_sample_hit_unnorm);
+        const float inv_dist_to_sample_hit = rsq_fast(dot(dir_to_sample_hit_unnorm, dir_to_sample_hit_unnorm));
+        const V3 dir_to_sample_hit = dir_to_sample_hit_unnorm * inv_dist_to_sample_hit;
         const float center_to_hit_vis = -dot(xyz(sample_hit_normal_ws_dot), dir_to_sample_hit);
-        const V4 prev_rad = ld4(a.radiance_history_tex, spx_x, spx_y) * V4{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
-        r.M = fmaxf(0.0f, fminf(r.M, exp2f(log2f(RESTIR_TEMPORAL_M_CLAMP) * (1.0f - rt_invalidity))));
+        const V4 prev_rad = unpack_rgba16f(t.prev_rad) * V4{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
+        r.M = fmaxf(0.0f, fminf(r.M, M_clamp_now));
         const float p_q = 1 * fmaxf(0.0f, sRGB_to_luminance(xyz(prev_rad))) * stepf(0.0f, dot(dir_to_sample_hit, normal_ws));
         float jacobian = 1;
-        jacobian *= clampf(prev_dist / dist_to_sample_hit, 1e-4f, 1e4f);
+        jacobian *= clampf(prev_dist * inv_dist_to_sample_hit, 1e-4f, 1e4f);
         jacobian *= jacobian;
-        jacobian *= clampf(center_to_hit_vis / sample_hit_normal_ws_dot.w, 0.0f, 1e4f);
+        jacobian *= clampf(center_to_hit_vis * rcp_fast(sample_hit_normal_ws_dot.w), 0.0f, 1e4f);
         r.M *= relevance;
         if (0 == sample_i) center_M = r.M;
         if (reservoir.update_with_stream(r, p_q, jacobian * 1.0f, stream_state, reservoir_payload, rng)) {
@@ -1188,7 +1221,7 @@ __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __
     // tile instead of once per tap (25x per texture): .xyz = crunched luma-chroma of the input, .w = crunched history luma.
     __shared__ float4 tile[12 * 12];
     {
-        const int tx0 = int(blockIdx.x) * 8 - 2, ty0 = row0 + int(blockIdx.y) * 8 - 2;
+        const int tx0 = int(kj_tb.x) * 8 - 2, ty0 = row0 + int(kj_tb.y) * 8 - 2;
         for (int i = lane; i < 144; i += 64) {
             const int tx = tx0 + i % 12, ty = ty0 + i / 12;
             const V4 n = crunch_fast(ld4(input_tex, tx, ty));

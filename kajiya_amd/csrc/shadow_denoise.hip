@@ -13,7 +13,8 @@ typedef Img<uint8_t> ImgR8;
 
 #define TILE_XY()                                                                          \
     const int lane = threadIdx.x;                                                          \
-    const int x = int(blockIdx.x) * 8 + (lane & 7), y = int(blockIdx.y) * 8 + (lane >> 3);
+    const uint2 kj_tb = kj::xcd_tile();                                                    \
+    const int x = int(kj_tb.x) * 8 + (lane & 7), y = int(kj_tb.y) * 8 + (lane >> 3);
 
 // "shadow bitpack" (bitpack_shadow_mask.hlsl + ffx prepare): bit (y%4)*8 + x%8 of tile (x/8, y/4) = ray reached the light
 __global__ void __launch_bounds__(64) k_shadow_bitpack(ImgR8 input_tex, ImgU32 output_tex) {
@@ -21,8 +22,8 @@ __global__ void __launch_bounds__(64) k_shadow_bitpack(ImgR8 input_tex, ImgU32 o
     const bool hit = from_unorm8(input_tex.ld(x, y)) > 0.5f;     // OOB = 0 = shadowed, like the shader's OOB load
     const unsigned long long m = __ballot(hit);
     if (lane == 0) {
-        output_tex.st(int(blockIdx.x), int(blockIdx.y) * 2, uint32_t(m & 0xffffffffull));
-        output_tex.st(int(blockIdx.x), int(blockIdx.y) * 2 + 1, uint32_t(m >> 32));
+        output_tex.st(int(kj_tb.x), int(kj_tb.y) * 2, uint32_t(m & 0xffffffffull));
+        output_tex.st(int(kj_tb.x), int(kj_tb.y) * 2 + 1, uint32_t(m >> 32));
     }
 }
 
@@ -88,7 +89,7 @@ KJ_D float shadow_horizontal_neighborhood(const ShadowTemporalArgs& a, int dx, i
 // "shadow temporal" (megakernel.hlsl + ffx tile classification)
 __global__ void __launch_bounds__(64) k_shadow_temporal(ShadowTemporalArgs a) {
     TILE_XY()
-    const int gx = int(blockIdx.x), gy = int(blockIdx.y);
+    const int gx = int(kj_tb.x), gy = int(kj_tb.y);
     // FFX_DNSR_Shadows_SearchSpatialRegion: 3 x 6 masks around the two 8x4 tiles of this block (wave-uniform)
     uint32_t or_mask = 0, and_mask = 0xFFFFFFFFu;
     for (int j = -2; j <= 3; ++j)
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(64) k_shadow_temporal(ShadowTemporalArgs a) {
 __global__ void __launch_bounds__(64) k_shadow_spatial(ImgU32 input_tex /*RG16F*/, ImgU32 meta_tex, ImgU32 geometric_normal_tex, ImgF32 depth_tex, ImgU32 output_tex, int stepsize) {
     TILE_XY()
     const int W = depth_tex.w, H = depth_tex.h;
-    const uint32_t meta = meta_tex.ld(int(blockIdx.x), int(blockIdx.y));
+    const uint32_t meta = meta_tex.ld(int(kj_tb.x), int(kj_tb.y));
     if (meta & 1u) {   // cleared tile, pass index 0: write the constant
         st2h(output_tex, x, y, V2{(meta & 2u) ? 1.0f : 0.0f, 0.0f});
         return;
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(64) k_shadow_spatial(ImgU32 input_tex /*RG16F*
     __shared__ float s_depth[16][16];
     for (int i = lane; i < 256; i += 64) {
         const int tx = i & 15, ty = i >> 4;
-        const int px = min(max(int(blockIdx.x) * 8 - 4 + tx, 0), W - 1), py = min(max(int(blockIdx.y) * 8 - 4 + ty, 0), H - 1);
+        const int px = min(max(int(kj_tb.x) * 8 - 4 + tx, 0), W - 1), py = min(max(int(kj_tb.y) * 8 - 4 + ty, 0), H - 1);
         const V3 n = unpack_a2r10g10b10(geometric_normal_tex.ld(px, py)) * 2.0f - 1.0f;
         s_in[ty][tx] = input_tex.ld(px, py);                       // already two packed halves
         s_depth[ty][tx] = depth_tex.ld(px, py);

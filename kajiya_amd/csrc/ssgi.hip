@@ -16,7 +16,8 @@ typedef Img<uint8_t> ImgR8;
 
 #define TILE_XY(W_, H_)                                                                    \
     const int lane = threadIdx.x;                                                          \
-    const int x = int(blockIdx.x) * 8 + (lane & 7), y = int(blockIdx.y) * 8 + (lane >> 3); \
+    const uint2 kj_tb = kj::xcd_tile();                                                    \
+    const int x = int(kj_tb.x) * 8 + (lane & 7), y = int(kj_tb.y) * 8 + (lane >> 3);       \
     const bool in_image = x < (W_) && y < (H_);
 
 // GbufferDepth::half_view_normal / half_depth (renderers/mod.rs:31-71; extract_half_res_{gbuffer_view_normal_rgba8,depth}.hlsl)

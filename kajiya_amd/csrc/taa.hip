@@ -4,6 +4,7 @@
 #include "kj_host.hpp"
 #include "kj_shading.hpp"
 #include "kj_screen.hpp"
+#include <cstdlib>
 
 using namespace kj;
 
@@ -26,7 +27,8 @@ typedef Img<float> ImgF32;
 // Row-range aware tile mapping (see rtdgi.hip): rows [row0, row1) of the kernel's own resolution.
 #define TILE_XY(W_, H_)                                                                          \
     const int lane = threadIdx.x;                                                                \
-    const int x = int(blockIdx.x) * 8 + (lane & 7), y = row0 + int(blockIdx.y) * 8 + (lane >> 3); \
+    const uint2 kj_tb = kj::xcd_tile();                                                          \
+    const int x = int(kj_tb.x) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
 // taa_common.hlsl (TAA_NONLINEARITY_TYPE 1, TAA_COLOR_MAPPING_MODE 1)
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32
     // LDS-staged 10x10 tile: .xyz = decoded YCbCr of the input texel, .w = depth (one decode per texel instead of nine)
     __shared__ float4 tile[10 * 10];
     {
-        const int tx0 = int(blockIdx.x) * 8 - 1, ty0 = row0 + int(blockIdx.y) * 8 - 1;
+        const int tx0 = int(kj_tb.x) * 8 - 1, ty0 = row0 + int(kj_tb.y) * 8 - 1;
         for (int i = lane; i < 100; i += 64) {
             const int tx = tx0 + i % 10, ty = ty0 + i / 10;
             const V3 c = sRGB_to_YCbCr(taa_decode_rgb(xyz(ld4(input_tex, tx, ty))));
@@ -187,7 +189,7 @@ __global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_his
     __shared__ float4 tile[TILED ? TW * TW : 1];
     V3 taps[(2 * K + 1) * (2 * K + 1)];
     if (TILED) {   // same extent: the stencil of pixel (x, y) is centred on texel (x, y); stage the converted tile once
-        const int tx0 = int(blockIdx.x) * 8 - K, ty0 = row0 + int(blockIdx.y) * 8 - K;
+        const int tx0 = int(kj_tb.x) * 8 - K, ty0 = row0 + int(kj_tb.y) * 8 - K;
         for (int i = lane; i < TW * TW; i += 64) {
             const V3 c = sRGB_to_YCbCr(xyz(ld4(reprojected_history, tx0 + i % TW, ty0 + i / TW)));
             tile[i] = make_float4(c.x, c.y, c.z, 0.0f);
@@ -269,6 +271,45 @@ __global__ void __launch_bounds__(64) k_taa_filter_prob2(ImgH1 input_tex, ImgH1 
     output_tex.st(x, y, f32_to_f16(fmaxf(0.0f, -1.0f / 10.0f * log2_fast(1e-30f + weighted.x / weighted.y))));
 }
 
+// filter_prob.hlsl + filter_prob2.hlsl in one launch (same extent, whole-image calls): a 16x16 pixel workgroup stages the 26x26
+// probabilities its outputs can reach (4 px of filter_prob2's stride-2 5x5 + 1 px of filter_prob's 3x3), takes the 3x3 maxima of the
+// inner 24x24 in LDS and runs the second filter from there. Both images are still written (prob_filtered1_img is a named surface);
+// same values bit for bit: the maxima of fp16 values are exact and the second filter sums in the same order.
+__global__ void __launch_bounds__(256) k_taa_filter_prob_both(ImgH1 input_tex, ImgH1 prob1_tex, ImgH1 output_tex) {
+    __shared__ float s_in[26 * 26];
+    __shared__ float s_p1[24 * 24];
+    const int W = output_tex.w, H = output_tex.h;
+    const int tid = int(threadIdx.x);
+    const uint2 tb = xcd_tile();
+    const int bx0 = int(tb.x) * 16, by0 = int(tb.y) * 16;
+    for (int i = tid; i < 26 * 26; i += 256) { const int ty = i / 26, tx = i - ty * 26; s_in[i] = ld1h(input_tex, bx0 - 5 + tx, by0 - 5 + ty); }
+    __syncthreads();
+    for (int i = tid; i < 24 * 24; i += 256) {
+        const int ty = i / 24, tx = i - ty * 24;
+        const int px = bx0 - 4 + tx, py = by0 - 4 + ty;
+        float prob = 0.0f;     // outside the image the second filter reads 0 (an out-of-bounds load of prob_filtered1_img)
+        if (uint32_t(px) < uint32_t(W) && uint32_t(py) < uint32_t(H)) {
+            prob = s_in[(ty + 1) * 26 + tx + 1];
+#pragma unroll
+            for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+                for (int ox = -1; ox <= 1; ++ox) prob = fmaxf(prob, s_in[(ty + 1 + oy) * 26 + tx + 1 + ox]);
+        }
+        s_p1[i] = prob;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    const int x = bx0 + lx, y = by0 + ly;
+    if (!(x < W && y < H)) return;
+    prob1_tex.st(x, y, f32_to_f16(s_p1[(ly + 4) * 24 + lx + 4]));
+    V2 weighted{0, 0};
+#pragma unroll
+    for (int oy = -2; oy <= 2; ++oy)
+#pragma unroll
+        for (int ox = -2; ox <= 2; ++ox) weighted += V2{exp2_fast(-clampf(10.0f * s_p1[(ly + 4 + oy * 2) * 24 + lx + 4 + ox * 2], 0.0f, 100.0f)), 1.0f};
+    output_tex.st(x, y, f32_to_f16(fmaxf(0.0f, -1.0f / 10.0f * log2_fast(1e-30f + weighted.x / weighted.y))));
+}
+
 // inc/unjitter_taa.hlsl:58-125 (kernel half width 1). taa.hlsl calls it twice on the same taps (kernel_scale 1 and 0.333);
 // the taps are decoded once.
 struct Unjittered { V4 color; float coverage; V3 ex, ex2; };
@@ -324,7 +365,7 @@ __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
     __shared__ float4 hist_tile[TILED ? 12 * 12 : 1];   // raw reprojected history (5x5 blur)
     __shared__ float4 col_tile[TILED ? 10 * 10 : 1];    // decoded YCbCr of the input (3x3 unjitter taps)
     if (TILED) {
-        const int tx0 = int(blockIdx.x) * 8, ty0 = row0 + int(blockIdx.y) * 8;
+        const int tx0 = int(kj_tb.x) * 8, ty0 = row0 + int(kj_tb.y) * 8;
         for (int i = lane; i < 144; i += 64) {
             const V4 h = ld4(a.history_tex, tx0 - 2 + i % 12, ty0 - 2 + i / 12);
             hist_tile[i] = make_float4(h.x, h.y, h.z, h.w);
@@ -436,6 +477,7 @@ struct KjTaa {
     int IW = 0, IH = 0, OW = 0, OH = 0;
     std::map<std::string, kj::DevBuf> surf;
     bool flip[3] = {false, false, false};
+    bool merge_prob_filters = true;             // filter_prob + filter_prob2 as one launch when both run over the whole image (KJ_TAA_MERGE_PROB=0: two launches)
     hipError_t err = hipSuccess;
     void* get(const std::string& name, size_t bytes, hipStream_t s) {
         kj::DevBuf& b = surf[name];
@@ -459,6 +501,7 @@ KjStatus kj_taa_create(KjDevice* dev, KjTaa** out) {
     KJ_REQUIRE(dev && out, "null argument");
     KjTaa* t = new KjTaa();
     t->dev = dev;
+    if (const char* v = getenv("KJ_TAA_MERGE_PROB")) t->merge_prob_filters = atoi(v) != 0;
     *out = t;
     return KJ_OK;
 }
@@ -518,11 +561,16 @@ static KjStatus taa_render_impl(KjTaa* t, const void* input_tex, uint32_t input_
                        img<uint2>(sv_hist, OW, OH), img<uint32_t>(vel_hist, OW, OH), img<uint16_t>(input_prob, IW, IH), ir0, ir1);
         KJ_CHECK_LAUNCH();
     }
-    if (mask & 16u) {
+    const bool both_prob_filters = t->merge_prob_filters && (mask & 48u) == 48u && ir0 == 0 && ir1 == IH;     // whole image, both passes: one launch through LDS
+    if (both_prob_filters) {
+        hipLaunchKernelGGL(k_taa_filter_prob_both, dim3((IW + 15) / 16, (IH + 15) / 16), dim3(256), 0, s, img<uint16_t>(input_prob, IW, IH), img<uint16_t>(prob1, IW, IH), img<uint16_t>(prob2, IW, IH));
+        KJ_CHECK_LAUNCH();
+    }
+    if ((mask & 16u) && !both_prob_filters) {
         hipLaunchKernelGGL(k_taa_filter_prob, gi, blk, 0, s, img<uint16_t>(input_prob, IW, IH), img<uint16_t>(prob1, IW, IH), ir0, ir1);
         KJ_CHECK_LAUNCH();
     }
-    if (mask & 32u) {
+    if ((mask & 32u) && !both_prob_filters) {
         hipLaunchKernelGGL(k_taa_filter_prob2, gi, blk, 0, s, img<uint16_t>(prob1, IW, IH), img<uint16_t>(prob2, IW, IH), ir0, ir1);
         KJ_CHECK_LAUNCH();
     }
