@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64) k_convolve_cube(const uint2* __restrict__ 
 __global__ void __launch_bounds__(64) k_raster_gbuffer(const FrameConstants* __restrict__ fcp, SceneView sc, int W, int H, uint32_t* __restrict__ geometric_normal,
                                                         uint4* __restrict__ gbuffer, float* __restrict__ depth, uint2* __restrict__ velocity) {
     extern __shared__ uint32_t lds_stack[];
-    const uint2 tb = xcd_tile();
+    const uint2 tb = tile_order<KJ_TILES_PLAIN>();
     const int x = int(tb.x) * 8 + int(threadIdx.x & 7), y = int(tb.y) * 8 + int(threadIdx.x >> 3);
     if (x >= W || y >= H) return;
     const FrameConstants& fc = *fcp;
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(64) k_raster_gbuffer(const FrameConstants* __r
 __global__ void __launch_bounds__(64) k_reprojection_map(const FrameConstants* __restrict__ fcp, int W, int H, const float* __restrict__ depth_p,
                                                           const uint32_t* __restrict__ gn_p, const float* __restrict__ prev_depth_p,
                                                           const uint2* __restrict__ velocity_p, uint2* __restrict__ out_p) {
-    const uint2 tb = xcd_tile();
+    const uint2 tb = tile_order<KJ_TILES_PLAIN>();
     const int x = int(tb.x) * 8 + int(threadIdx.x & 7), y = int(tb.y) * 8 + int(threadIdx.x >> 3);
     if (x >= W || y >= H) return;
     const FrameConstants& fc = *fcp;
@@ -225,7 +225,7 @@ struct LightGbufferArgs {
 };
 __global__ void __launch_bounds__(64) k_light_gbuffer(LightGbufferArgs a) {
     const int lane = threadIdx.x;
-    const uint2 tb = xcd_tile();
+    const uint2 tb = tile_order<KJ_TILES_PLAIN>();
     const int x = int(tb.x) * 8 + (lane & 7), y = int(tb.y) * 8 + (lane >> 3);
     const int W = a.output_tex.w, H = a.output_tex.h;
     if (x >= W || y >= H) return;
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(64) k_sun_shadow_mask(const FrameConstants* __
                                                          Img<uint32_t> geometric_normal_tex, Img<uint8_t> output_tex, unsigned long long* __restrict__ ray_counter) {
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x;
-    const uint2 tb = xcd_tile();
+    const uint2 tb = tile_order<KJ_TILES_PLAIN>();
     const int x = int(tb.x) * 8 + (lane & 7), y = int(tb.y) * 8 + (lane >> 3);
     if (x >= output_tex.w || y >= output_tex.h) return;
     const FrameConstants& fc = *fcp;

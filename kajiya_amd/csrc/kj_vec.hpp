@@ -337,25 +337,53 @@ KJ_D unsigned long long* counter_slot(unsigned long long* base) {
 
 // ---- XCD-aware tile order. MI355X dispatches workgroup `b` (x fastest) to XCD `b % 8`, each XCD with its own 4 MiB L2. With the
 // plain blockIdx -> tile mapping horizontally adjacent tiles of a screen pass sit on eight different L2s (and, image widths being
-// multiples of 64, an XCD owns 8-pixel COLUMNS spaced 64 pixels apart): every halo texel, every gather of a neighbour's reservoir
-// and every BVH node under a region of the screen is fetched into up to eight L2s. xcd_tile() hands XCD k the k-th contiguous
-// eighth of the launch's tiles in row-major order -- a band of whole tile rows -- so a pass's reach (3..32 px) stays inside one L2
-// except at the seven band edges. Bijective for any grid size (the first n % 8 XCDs take one tile more). The dispatch order is not
-// a contract (MI355X_MICROARCH.md, "Workgroup dispatch"): a different placement costs speed, never correctness.
-#ifndef KJ_XCD_SWIZZLE
-#define KJ_XCD_SWIZZLE 1
-#endif
+// multiples of 64, an XCD owns 8-pixel COLUMNS spaced 64 pixels apart): every halo texel and every gather of a neighbour's
+// reservoir is fetched into up to eight L2s. tile_order<MODE>() remaps the workgroup id to a tile so that neighbours share an XCD:
+//   KJ_TILES_ROWS   whole tile rows, dealt round-robin (XCD k takes rows k, k + 8, ...): horizontal neighbours share an L2 and the
+//                   eight rows in flight at any time are adjacent;
+//   KJ_TILES_BANDS  column bands ~8 tiles wide and as tall as the launch, dealt round-robin: neighbours in both directions share an
+//                   L2 except across band edges, and every XCD sees the image top to bottom (sky and ground alike);
+//   KJ_TILES_PLAIN  blockIdx as is.
+// Which one a kernel uses is a measured choice per kernel (profiles/r03_xcd_tile_order.md): passes whose work per tile is uniform
+// gain 3-17 % from sharing an L2 with their neighbours; passes that skip sky tiles (the ray passes, the resampling passes, the
+// resolve) need the load balance of the plain order more than the locality -- contiguous eighths of the image, the textbook remap
+// for GEMM tiles, made the trace pass 49 % slower (a launch lasts as long as its busiest XCD). Every mode is a bijection for any
+// grid size (what does not fill a whole group of eight keeps the plain order). The dispatch order is not a contract
+// (MI355X_MICROARCH.md, "Workgroup dispatch"): a different placement costs speed, never correctness.
+#define KJ_TILES_PLAIN 0
+#define KJ_TILES_ROWS 1
+#define KJ_TILES_BANDS 2
 #ifdef __HIPCC__
-KJ_D uint2 xcd_tile() {
-#if KJ_XCD_SWIZZLE
-    const uint32_t gx = gridDim.x, n = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
-    const uint32_t q = n >> 3, r = n & 7u, xcd = id & 7u;
-    const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (id >> 3);
-    const uint32_t ty = t / gx;
-    return make_uint2(t - ty * gx, ty);
+template <int MODE_>
+KJ_D uint2 tile_order() {
+#ifdef KJ_TILES_ALL
+    constexpr int MODE = KJ_TILES_ALL;          // experiment builds: one order for every kernel
 #else
-    return make_uint2(blockIdx.x, blockIdx.y);
+    constexpr int MODE = MODE_;
 #endif
+    const uint32_t gx = gridDim.x, gy = gridDim.y, id = blockIdx.y * gx + blockIdx.x;
+    if (MODE == KJ_TILES_ROWS) {
+        const uint32_t n_full = (gy & ~7u) * gx;                    // tiles in whole groups of eight rows
+        if (id >= n_full) return make_uint2(blockIdx.x, blockIdx.y);
+        const uint32_t xcd = id & 7u, k = id >> 3;                  // the k-th workgroup this XCD receives
+        const uint32_t c = k / gx;                                  // its c-th row = row c * 8 + xcd of the image
+        return make_uint2(k - c * gx, c * 8u + xcd);
+    }
+    if (MODE == KJ_TILES_BANDS) {
+        const uint32_t g = gx >= 96u ? (gx + 32u) / 64u : 1u;       // bands per XCD (about 8 tiles wide each)
+        const uint32_t bw = gx / (8u * g);                          // band width in tiles
+        const uint32_t n_full = 8u * g * bw * gy;                   // tiles inside the bands; the columns right of them keep the plain order
+        if (bw == 0u || id >= n_full) {
+            const uint32_t rest = id - (bw ? n_full : 0u), rw = gx - 8u * g * bw, ry = rest / rw;
+            return make_uint2(8u * g * bw + (rest - ry * rw), ry);
+        }
+        const uint32_t xcd = id & 7u, k = id >> 3;
+        const uint32_t per_band = bw * gy;
+        const uint32_t b = k / per_band, w = k - b * per_band;      // this XCD's b-th band = band b * 8 + xcd of the image
+        const uint32_t wy = w / bw;
+        return make_uint2((b * 8u + xcd) * bw + (w - wy * bw), wy);
+    }
+    return make_uint2(blockIdx.x, blockIdx.y);
 }
 #endif
 

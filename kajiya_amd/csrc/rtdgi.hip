@@ -32,9 +32,10 @@ typedef Img<float4> ImgF4;
 
 // Row-range aware tile mapping: a launch covers image rows [row0, row1) of the kernel's own resolution
 // (row0 a multiple of 8) so the same kernels serve the screen-tile split across GPUs.
-#define TILE_XY(W_, H_)                                                   \
+#define TILE_XY(W_, H_) TILE_XY_M(W_, H_, KJ_TILES_PLAIN)
+#define TILE_XY_M(W_, H_, MODE_)                                          \
     const int lane = threadIdx.x;                                         \
-    const uint2 kj_tb = kj::xcd_tile();                                   \
+    const uint2 kj_tb = kj::tile_order<MODE_>();                          \
     const int x = int(kj_tb.x) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
@@ -43,7 +44,7 @@ typedef Img<float4> ImgF4;
 // {depth bits, view normal snorm8 x3 | ssao snorm8 << 24}: what the resampling passes stage in LDS / fetch per tap (rtdgi_resample.hip).
 __global__ void __launch_bounds__(64) k_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgR8 ssao, ImgU32 half_view_normal,
                                                       ImgF32 half_depth, ImgR8S half_ssao, ImgU2 half_gbuf, int row0, int row1) {
-    TILE_XY(half_depth.w, half_depth.h)
+    TILE_XY_M(half_depth.w, half_depth.h, KJ_TILES_ROWS)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
     const I2 off = halfres_subsample_offset(fc.frame_index);
@@ -270,7 +271,7 @@ KJ_HD size_t grouped_lds_bytes(uint32_t stack_entries) { return size_t(stack_ent
 // 2 x 2 tiles: wave w covers tile (w & 1, w >> 1) of the 16 x 16 block
 #define GROUP_TILE_XY(W_, H_)                                                                                              \
     const int lane = int(threadIdx.x & 63u), wave = int(threadIdx.x >> 6);                                                  \
-    const uint2 kj_tb = kj::xcd_tile();                                                                                    \
+    const uint2 kj_tb = kj::tile_order<KJ_TILES_PLAIN>();                                                                  \
     const int x = int(kj_tb.x) * 16 + (wave & 1) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * 16 + (wave >> 1) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 // Called by ALL threads of the workgroup (barriers inside); `has_ray` false = this pixel traces nothing (sky, outside the image).
@@ -972,7 +973,7 @@ __global__ void __launch_bounds__(64) k_rtdgi_validate_finish(RayStage st, ImgU2
 // WaveReadLaneAt(v, lane^k) inside the 8x8 group == __shfl_xor(v, k) on wave64.
 __global__ void __launch_bounds__(64) k_validity_integrate(const FrameConstants* __restrict__ fcp, ImgR8 input_tex, ImgU32 history_tex /*RG16F*/, ImgU2 reprojection_tex,
                                                             ImgF32 half_depth_tex, ImgU32 output_tex /*RG16F*/, int W, int H, int row0, int row1) {
-    TILE_XY(output_tex.w, output_tex.h)
+    TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     const FrameConstants& fc = *fcp;
     V2 invalid_blurred{0, 0};
 #pragma unroll
@@ -1029,7 +1030,7 @@ struct RestirTemporalArgs {
 };
 __global__ void __launch_bounds__(64) k_restir_temporal(RestirTemporalArgs a) {
     const int row0 = a.row0, row1 = a.row1;
-    TILE_XY(a.reservoir_out_tex.w, a.reservoir_out_tex.h)
+    TILE_XY_M(a.reservoir_out_tex.w, a.reservoir_out_tex.h, KJ_TILES_ROWS)
     if (!in_image) return;
     const FrameConstants& fc = *a.fc;
     const I2 off = halfres_subsample_offset(fc.frame_index);
@@ -1073,73 +1074,52 @@ __global__ void __launch_bounds__(64) k_restir_temporal(RestirTemporalArgs a) {
     // xor_seq[frame&3] = {(3,3),(2,1),(1,2),(3,3)} ; offsets[4] = {(-1,-1),(1,1),(-1,1),(1,-1)}
     const uint32_t pxv_x = (fi & 3u) == 1u ? 2u : ((fi & 3u) == 2u ? 1u : 3u);
     const uint32_t pxv_y = (fi & 3u) == 1u ? 1u : ((fi & 3u) == 2u ? 2u : 3u);
-    // The five history taps. The shader walks them one after the other and every tap is a chain of dependent fetches (reprojection ->
-    // reservoir -> the four images at the reservoir's sample pixel); a wave spends the pass waiting for ~20 round trips. Here the
-    // fetches of all taps are issued level by level -- nothing a tap loads depends on what an earlier tap decided -- and the loop that
-    // follows only does arithmetic, in the shader's order (the early-out on M_sum and every rejection test included). Weights use the
-    // single-instruction reciprocal / rsqrt (pow(x, 4) is two squarings: libm's powf is 163 instructions per tap); the rejection
-    // tests, which are comparisons, keep IEEE arithmetic.
-    struct Tap { bool skip; float reproj_z; uint2 res; float sample_depth; uint32_t normal_raw; float4 pro; uint2 rh, hn, prev_rad; };     // texels as loaded: 15 registers per tap
-    Tap taps[5];
-#pragma unroll
-    for (uint32_t sample_i = 0; sample_i < 5u; ++sample_i) {
-        Tap& t = taps[sample_i];
+    // The history taps, walked one after the other as in the shader: the loop stops once the accumulated M passes 1.25 x the clamp, with
+    // converged history after the second tap. Measured alternatives (profiles/r03_screen_chain.md): fetching all five taps level by level
+    // up front (52 us against the loop's 37: three taps' worth of scattered loads nobody uses, 120 registers) and prefetching the first
+    // two (48 us). What did pay: pow(x, 4) as two squarings (libm's powf is 163 instructions per tap) and the single-instruction
+    // reciprocal / rsqrt in the weights; the rejection tests, which are comparisons, keep IEEE arithmetic.
+    const float M_clamp_now = exp2f(log2f(RESTIR_TEMPORAL_M_CLAMP) * (1.0f - rt_invalidity));
+    for (uint32_t sample_i = 0; sample_i < 5u && stream_state.M_sum < 1.25f * RESTIR_TEMPORAL_M_CLAMP; ++sample_i) {
         I2 rpx_offset{0, 0};
-        t.skip = false;
         if (sample_i != 0) {
             const uint32_t ia = fi & 3u, ib = (sample_i + (fi ^ 1u)) & 3u;
             auto ofs = [](uint32_t i) { return I2{(i == 1u || i == 3u) ? 1 : -1, (i == 1u || i == 2u) ? 1 : -1}; };
             const I2 oa = ofs(ia), ob = ofs(ib);
             rpx_offset = I2{oa.x + ob.x, oa.y + ob.y};
-            t.skip = rpx_offset.x == 0 && rpx_offset.y == 0;
+            if (rpx_offset.x == 0 && rpx_offset.y == 0) continue;
         }
         const V4 reproj = ld_reproj(a.reprojection_tex, hx + rpx_offset.x * 2, hy + rpx_offset.y * 2);
-        t.reproj_z = reproj.z;
         const V2 base = sample_i == 0 ? V2{float(x), float(y)} : V2{float(uint32_t(x + rpx_offset.x) ^ pxv_x), float(uint32_t(y + rpx_offset.y) ^ pxv_y)};
         const int prx = f2i_sat(floorf(base.x + gts.x * reproj.x * 0.5f + 0.0f + 0.5f)), pry = f2i_sat(floorf(base.y + gts.y * reproj.y * 0.5f + 0.0f + 0.5f));
         const I2 rpx{wrap_add(prx, rpx_offset.x), wrap_add(pry, rpx_offset.y)};
         const int pnx = f2i_sat(floorf(base.x + 0.5f)), pny = f2i_sat(floorf(base.y + 0.5f));
         const I2 neighbor_px{wrap_add(pnx, rpx_offset.x), wrap_add(pny, rpx_offset.y)};
         const int nhx = wrap_mul2_add(neighbor_px.x, off.x), nhy = wrap_mul2_add(neighbor_px.y, off.y);
-        t.res = a.reservoir_history_tex.ld(rpx.x, rpx.y);
-        t.sample_depth = a.depth_tex.ld(nhx, nhy);
-        t.normal_raw = a.half_view_normal_tex.ld(neighbor_px.x, neighbor_px.y);
-    }
-#pragma unroll
-    for (uint32_t sample_i = 0; sample_i < 5u; ++sample_i) {
-        Tap& t = taps[sample_i];
-        const int spx_x = int(t.res.x & 0xffff), spx_y = int(t.res.x >> 16);
-        t.pro = a.ray_orig_history_tex.ld(spx_x, spx_y);
-        t.rh = a.ray_history_tex.ld(spx_x, spx_y);
-        t.hn = a.hit_normal_history_tex.ld(spx_x, spx_y);
-        t.prev_rad = a.radiance_history_tex.ld(spx_x, spx_y);
-    }
-    const float M_clamp_now = exp2f(log2f(RESTIR_TEMPORAL_M_CLAMP) * (1.0f - rt_invalidity));
-#pragma unroll
-    for (uint32_t sample_i = 0; sample_i < 5u; ++sample_i) {
-        if (!(stream_state.M_sum < 1.25f * RESTIR_TEMPORAL_M_CLAMP)) break;
-        const Tap& t = taps[sample_i];
-        if (t.skip) continue;
-        Reservoir1spp r = Reservoir1spp::from_raw(t.res);
+        Reservoir1spp r = Reservoir1spp::from_raw(a.reservoir_history_tex.ld(rpx.x, rpx.y));
+        const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
         float relevance = 1;
-        const float sample_depth = t.sample_depth;
-        const V3 prev_ray_orig{t.pro.x, t.pro.y, t.pro.z};
+        const float sample_depth = a.depth_tex.ld(nhx, nhy);
+        const float4 pro = a.ray_orig_history_tex.ld(spx_x, spx_y);
+        const V3 prev_ray_orig{pro.x, pro.y, pro.z};
         if (length(prev_ray_orig - refl_ray_origin_ws) > 0.1f * -vr.hit_vs.z) continue;
         if (0 == sample_depth) continue;
-        if (t.reproj_z == 0) continue;
+        if (reproj.z == 0) continue;
         relevance *= 1 - smoothstep_fast(0.0f, 0.1f, fabsf(fmaxf(1e-20f, depth) * rcp_fast(fmaxf(1e-20f, sample_depth)) - 1.0f));
-        const float normal_similarity_dot = fmaxf(0.0f, dot(xyz(unpack_rgba8_snorm(t.normal_raw)), normal_vs));
+        const V3 sample_normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, neighbor_px.x, neighbor_px.y);
+        const float normal_similarity_dot = fmaxf(0.0f, dot(sample_normal_vs, normal_vs));
         if (sample_i != 0 && normal_similarity_dot < 0.2f) continue;
         relevance *= square(square(normal_similarity_dot));
-        const V4 rh = unpack_rgba16f(t.rh), hn = unpack_rgba16f(t.hn);
+        const V4 rh = ld4(a.ray_history_tex, spx_x, spx_y);
         const V3 sample_hit_ws = xyz(rh) + prev_ray_orig;
         const float prev_dist = rh.w;
+        const V4 hn = ld4(a.hit_normal_history_tex, spx_x, spx_y);
         const V4 sample_hit_normal_ws_dot{hn.x * 2 - 1, hn.y * 2 - 1, hn.z * 2 - 1, hn.w};
         const V3 dir_to_sample_hit_unnorm = sample_hit_ws - refl_ray_origin_ws;
         const float inv_dist_to_sample_hit = rsq_fast(dot(dir_to_sample_hit_unnorm, dir_to_sample_hit_unnorm));
         const V3 dir_to_sample_hit = dir_to_sample_hit_unnorm * inv_dist_to_sample_hit;
         const float center_to_hit_vis = -dot(xyz(sample_hit_normal_ws_dot), dir_to_sample_hit);
-        const V4 prev_rad = unpack_rgba16f(t.prev_rad) * V4{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
+        const V4 prev_rad = ld4(a.radiance_history_tex, spx_x, spx_y) * V4{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
         r.M = fmaxf(0.0f, fminf(r.M, M_clamp_now));
         const float p_q = 1 * fmaxf(0.0f, sRGB_to_luminance(xyz(prev_rad))) * stepf(0.0f, dot(dir_to_sample_hit, normal_ws));
         float jacobian = 1;
@@ -1214,7 +1194,7 @@ __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __
                                                          ImgU2 reprojection_tex, ImgU32 rt_history_invalidity_tex /*RG16F half*/, ImgH4 output_tex, ImgH4 history_output_tex,
                                                          ImgU32 variance_history_output_tex, int row0, int row1) {
     const int W = output_tex.w, H = output_tex.h;
-    TILE_XY(W, H)
+    TILE_XY_M(W, H, KJ_TILES_ROWS)
     const FrameConstants& fc = *fcp;
     const V4 history_mult{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
     // LDS-staged 12x12 tile (8x8 outputs + the 5x5 stencil's halo): each texel's colour-space conversion is done once per
@@ -1300,6 +1280,7 @@ struct KjRtdgi {
     uint32_t stream_waves_per_cu = 24;          // persistent waves per CU of a ray-stream launch (measured best of 8 / 16 / 24 / 32: scripts/traversal_microbench.py)
     bool split_rays = false;                    // the ray passes as two launches each: closest-hit + misses | hit shading on compacted records (kj_rtdgi_set_ray_pass_form)
     bool grouped_rays = false;                  // the ray passes' form when not staged: grouped (hit shading regrouped inside a 256-thread workgroup) or fused (KJ_RTDGI_GROUPED=0)
+    uint32_t ray_waves_per_simd = 0;            // 0 = whatever fits
     int resample_variant = 2;                   // spatial reuse: 2 = per-tap gathers (fastest measured), 0 / 1 = LDS-staged tiles (KJ_RTDGI_RESAMPLE_VARIANT; rtdgi_resample.hpp)
     static const int NUM_SCOPES = 11;
     hipEvent_t ev[NUM_SCOPES][2] = {};
@@ -1341,6 +1322,7 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     if (const char* v = getenv("KJ_RTDGI_STAGED_MIN_RAYS")) r->staged_min_rays = uint32_t(atoll(v));
     if (const char* v = getenv("KJ_RTDGI_GROUPED")) r->grouped_rays = atoi(v) != 0;
     if (const char* v = getenv("KJ_RTDGI_SPLIT")) r->split_rays = atoi(v) != 0;
+    if (const char* v = getenv("KJ_RTDGI_WAVES_PER_SIMD")) r->ray_waves_per_simd = uint32_t(std::max(0, atoi(v)));
     if (r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
     *out = r;
     return KJ_OK;
@@ -1446,7 +1428,10 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     tc.ray_counters = (unsigned long long*)r->ray_counters.p;
     tc.request_stride = uint32_t(hw); tc.request_slot_base = 0; tc.request_key_base = 1u << 28;     // validate pass; the trace pass re-bases below
     if (p->ircache && p->ircache->deferred) KJ_REQUIRE(p->ircache->req_half_pixels == uint32_t(hw) * uint32_t(hh), "kj_ircache_begin_requests must be called with this frame's half-res extent");
-    const size_t trace_lds = size_t(tc.sc.bvh.stack_entries) * 64 * 4;
+    size_t trace_lds = size_t(tc.sc.bvh.stack_entries) * 64 * 4;
+    // experiment knob (KJ_RTDGI_WAVES_PER_SIMD=n): cap the fused ray kernels' occupancy through their LDS request, so that tiles are handed
+    // out as waves retire instead of all at once (160 KB of LDS per CU, four SIMDs)
+    if (r->ray_waves_per_simd) trace_lds = std::max(trace_lds, (size_t(160 * 1024) / (4u * r->ray_waves_per_simd)) & ~size_t(255));
 
     if (mask & KJ_RTDGI_PASS_EXTRACT_HALF) {
         SCOPE_BEGIN(1);

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
     const FrameDerived& fd = frame_derived(a.fc);
     const int hw = a.reservoir_output_tex.w, hh = a.reservoir_output_tex.h;
     const int tid = int(threadIdx.x), wave = tid >> 6, lane = tid & 63;
-    const uint2 tb = xcd_tile();
+    const uint2 tb = tile_order<KJ_TILES_PLAIN>();
     const int bx0 = int(tb.x) * BW, by0 = a.row0 + int(tb.y) * BH;
     const int tx0 = bx0 - R, ty0 = by0 - R;
     if (TILE) {
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) k_restir_resolve(ResolveArgs2 a) {
     const FrameDerived& fd = frame_derived(a.fc);
     const int W = a.irradiance_output_tex.w, H = a.irradiance_output_tex.h;
     const int tid = int(threadIdx.x), wave = tid >> 6, lane = tid & 63;
-    const uint2 tb = xcd_tile();
+    const uint2 tb = tile_order<KJ_TILES_PLAIN>();
     const int bx0 = int(tb.x) * 16, by0 = a.row0 + int(tb.y) * 16;
     const int hx0 = (bx0 >> 1) - HALO, hy0 = (by0 >> 1) - HALO;
     const I2 off = halfres_subsample_offset(fc.frame_index);
@@ -368,7 +368,7 @@ KJ_D V3 uncrunch(V3 v) { return v * rcp_fast(1.0f - max3(v.x, v.y, v.z)); }
 __global__ void __launch_bounds__(64) k_spatial_filter(const FrameConstants* __restrict__ fcp, Img<uint2> input_tex, Img<float> depth_tex, Img<uint8_t> ssao_tex,
                                                         Img<uint32_t> geometric_normal_tex, Img<uint2> output_tex, int row0, int row1) {
     const int lane = threadIdx.x;
-    const uint2 tb = xcd_tile();
+    const uint2 tb = tile_order<KJ_TILES_BANDS>();
     const int x = int(tb.x) * 8 + (lane & 7), y = row0 + int(tb.y) * 8 + (lane >> 3);
     if (!(x < output_tex.w && y < (output_tex.h < row1 ? output_tex.h : row1))) return;
     const FrameConstants& fc = *fcp;

@@ -33,7 +33,7 @@ typedef Img<float4> ImgF4;
 
 #define TILE_XY(W_, H_)                                                   \
     const int lane = threadIdx.x;                                         \
-    const uint2 kj_tb = kj::xcd_tile();                                   \
+    const uint2 kj_tb = kj::tile_order<KJ_TILES_PLAIN>();                 \
     const int x = int(kj_tb.x) * 8 + (lane & 7), y = int(kj_tb.y) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < (H_);
 
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(64) k_rtr_validate(RtrCtx c, ImgF4 ray_orig_hi
                                                       ImgU2 reservoir_history_tex, ImgR8 refl_restir_invalidity_tex, int qw, int qh) {
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x;
-    const uint2 tb = xcd_tile();
+    const uint2 tb = tile_order<KJ_TILES_PLAIN>();
     const int qx = int(tb.x) * 8 + (lane & 7), qy = int(tb.y) * 8 + (lane >> 3);
     if (qx >= qw || qy >= qh) return;
     const FrameConstants& fc = *c.fc;

@@ -13,7 +13,7 @@ typedef Img<uint8_t> ImgR8;
 
 #define TILE_XY()                                                                          \
     const int lane = threadIdx.x;                                                          \
-    const uint2 kj_tb = kj::xcd_tile();                                                    \
+    const uint2 kj_tb = kj::tile_order<KJ_TILES_PLAIN>();                                  \
     const int x = int(kj_tb.x) * 8 + (lane & 7), y = int(kj_tb.y) * 8 + (lane >> 3);
 
 // "shadow bitpack" (bitpack_shadow_mask.hlsl + ffx prepare): bit (y%4)*8 + x%8 of tile (x/8, y/4) = ray reached the light

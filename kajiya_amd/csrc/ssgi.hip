@@ -14,15 +14,16 @@ typedef Img<uint16_t> ImgH1;
 typedef Img<float> ImgF32;
 typedef Img<uint8_t> ImgR8;
 
-#define TILE_XY(W_, H_)                                                                    \
+#define TILE_XY(W_, H_) TILE_XY_M(W_, H_, KJ_TILES_PLAIN)
+#define TILE_XY_M(W_, H_, MODE_)                                                           \
     const int lane = threadIdx.x;                                                          \
-    const uint2 kj_tb = kj::xcd_tile();                                                    \
+    const uint2 kj_tb = kj::tile_order<MODE_>();                                           \
     const int x = int(kj_tb.x) * 8 + (lane & 7), y = int(kj_tb.y) * 8 + (lane >> 3);       \
     const bool in_image = x < (W_) && y < (H_);
 
 // GbufferDepth::half_view_normal / half_depth (renderers/mod.rs:31-71; extract_half_res_{gbuffer_view_normal_rgba8,depth}.hlsl)
 __global__ void __launch_bounds__(64) k_ssgi_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgU32 half_view_normal, ImgF32 half_depth) {
-    TILE_XY(half_depth.w, half_depth.h)
+    TILE_XY_M(half_depth.w, half_depth.h, KJ_TILES_ROWS)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
     const I2 off = halfres_subsample_offset(fc.frame_index);
@@ -151,7 +152,7 @@ __global__ void __launch_bounds__(64) k_ssgi(const FrameConstants* __restrict__ 
 
 // "ssao spatial" (spatial_filter.hlsl), half res
 __global__ void __launch_bounds__(64) k_ssgi_spatial(ImgH1 ssgi_tex, ImgF32 half_depth, ImgU32 half_view_normal, ImgH1 output_tex) {
-    TILE_XY(output_tex.w, output_tex.h)
+    TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     if (!in_image) return;
     float result = 0, w_sum = 0;
     const float center_depth = half_depth.ld(x, y);
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(64) k_ssgi_spatial(ImgH1 ssgi_tex, ImgF32 half
 
 // "ssao upsample" (upsample.hlsl), full res, R16F
 __global__ void __launch_bounds__(64) k_ssgi_upsample(ImgH1 ssgi_tex, ImgF32 depth, ImgH1 output_tex) {
-    TILE_XY(output_tex.w, output_tex.h)
+    TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     if (!in_image) return;
     float result = 0, w_sum = 0;
     const float center_depth = depth.ld(x, y);
@@ -223,7 +224,7 @@ KJ_D float sample_bilinear_clamp_r16f(const uint16_t* __restrict__ p, int w, int
 }
 __global__ void __launch_bounds__(64) k_ssgi_temporal(ImgH1 input_tex, ImgH1 history_tex, ImgU2 reprojection_tex, ImgR8 final_output_tex, ImgH1 history_output_tex) {
     const int W = final_output_tex.w, H = final_output_tex.h;
-    TILE_XY(W, H)
+    TILE_XY_M(W, H, KJ_TILES_ROWS)
     if (!in_image) return;
     const V2 uv = get_uv(float(x), float(y), tex_size4(W, H));
     const float center = f16_to_f32(input_tex.ld(x, y));

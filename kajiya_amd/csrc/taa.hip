@@ -25,9 +25,10 @@ typedef Img<float> ImgF32;
 // Inside input_prob and in the final pass (k_taa: blends, clamps, the fp16 stores of the frame's outputs), quotients use v_rcp_f32 +
 // multiply and square roots v_sqrt_f32 (1 ulp each); what stays IEEE there: the moments E[x], E[x^2] a variance is formed from.
 // Row-range aware tile mapping (see rtdgi.hip): rows [row0, row1) of the kernel's own resolution.
-#define TILE_XY(W_, H_)                                                                          \
+#define TILE_XY(W_, H_) TILE_XY_M(W_, H_, KJ_TILES_PLAIN)
+#define TILE_XY_M(W_, H_, MODE_)                                                                 \
     const int lane = threadIdx.x;                                                                \
-    const uint2 kj_tb = kj::xcd_tile();                                                          \
+    const uint2 kj_tb = kj::tile_order<MODE_>();                                                 \
     const int x = int(kj_tb.x) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
@@ -69,7 +70,7 @@ KJ_D V4 catmull_rom_5tap_history(const ImgH4& tex, V2 uv, V2 tex_size, float ped
 __global__ void __launch_bounds__(64) k_taa_reproject(const FrameConstants* __restrict__ fc, ImgH4 history_tex, ImgH4 reprojection_tex, ImgF32 depth_tex, ImgH4 output_tex,
                                                        ImgH2 closest_velocity_output, int IW, int IH, int row0, int row1) {
     const int OW = output_tex.w, OH = output_tex.h;
-    TILE_XY(OW, OH)
+    TILE_XY_M(OW, OH, KJ_TILES_ROWS)
     const V4 its = tex_size4(IW, IH), ots = tex_size4(OW, OH);
     const V2 scale{its.x / ots.x, its.y / ots.y};
     const int rx = int(uint32_t((float(x) + 0.5f) * scale.x)), ry = int(uint32_t((float(y) + 0.5f) * scale.y));
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(64) k_taa_reproject(const FrameConstants* __re
 // luma cutoff, then with 1.001x the first pass' luma); here the taps are decoded once and kept in registers, and
 // pow(x, 8) is three squarings.
 __global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32 depth_tex, ImgH4 output_tex, ImgH4 dev_output_tex, int row0, int row1) {
-    TILE_XY(output_tex.w, output_tex.h)
+    TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     // LDS-staged 10x10 tile: .xyz = decoded YCbCr of the input texel, .w = depth (one decode per texel instead of nine)
     __shared__ float4 tile[10 * 10];
     {
@@ -184,7 +185,7 @@ KJ_D V3 fh_filter_input(const V3* taps, float luma_cutoff) {
 }
 template <int K, bool TILED>
 __global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_history, ImgH4 output_tex, int row0, int row1) {
-    TILE_XY(output_tex.w, output_tex.h)
+    TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     constexpr int TW = 8 + 2 * K;
     __shared__ float4 tile[TILED ? TW * TW : 1];
     V3 taps[(2 * K + 1) * (2 * K + 1)];
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_his
 __global__ void __launch_bounds__(64) k_taa_input_prob(const FrameConstants* __restrict__ fc, ImgH4 filtered_input_tex, ImgH4 filtered_input_dev_tex, ImgH4 filtered_history_tex,
                                                         ImgH4 reprojection_tex, ImgH4 smooth_var_history_tex, ImgH2 velocity_history_tex, ImgH1 output_tex, int row0, int row1) {
     const int IW = output_tex.w, IH = output_tex.h;
-    TILE_XY(IW, IH)
+    TILE_XY_M(IW, IH, KJ_TILES_ROWS)
     if (!in_image) return;
     const V4 its = tex_size4(IW, IH);
     V3 ivar = v3(0.0f);
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(256) k_taa_filter_prob_both(ImgH1 input_tex, I
     __shared__ float s_p1[24 * 24];
     const int W = output_tex.w, H = output_tex.h;
     const int tid = int(threadIdx.x);
-    const uint2 tb = xcd_tile();
+    const uint2 tb = tile_order<KJ_TILES_ROWS>();
     const int bx0 = int(tb.x) * 16, by0 = int(tb.y) * 16;
     for (int i = tid; i < 26 * 26; i += 256) { const int ty = i / 26, tx = i - ty * 26; s_in[i] = ld1h(input_tex, bx0 - 5 + tx, by0 - 5 + ty); }
     __syncthreads();
@@ -361,7 +362,7 @@ template <bool TILED>   // TILED: input extent == output extent, so both stencil
 __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
     const int row0 = a.row0, row1 = a.row1;
     const int OW = a.temporal_output_tex.w, OH = a.temporal_output_tex.h;
-    TILE_XY(OW, OH)
+    TILE_XY_M(OW, OH, KJ_TILES_ROWS)
     __shared__ float4 hist_tile[TILED ? 12 * 12 : 1];   // raw reprojected history (5x5 blur)
     __shared__ float4 col_tile[TILED ? 10 * 10 : 1];    // decoded YCbCr of the input (3x3 unjitter taps)
     if (TILED) {
