@@ -192,9 +192,13 @@ KjStatus kj_scene_stats(KjScene* scene, uint32_t* out_tri_count, uint32_t* out_n
 KjStatus kj_scene_last_commit_ms(KjScene* scene, double out_ms[4]);
 /* How the BLAS of meshes added FROM NOW ON is built at the next commit (vk::BuildAccelerationStructureFlagsKHR, ray_tracing.rs:438):
  * KJ_BLAS_BUILD_FAST_TRACE = binned-SAH tree built on the host (kajiya's PREFER_FAST_TRACE; the default),
- * KJ_BLAS_BUILD_FAST_BUILD = linear BVH built on the device (Morton sort + Karras hierarchy + bottom-up boxes + 4-wide collapse). */
+ * KJ_BLAS_BUILD_FAST_BUILD = linear BVH built on the device (Morton sort + Karras hierarchy + bottom-up boxes + 4-wide collapse),
+ * KJ_BLAS_BUILD_DEVICE_PLOC = built on the device as well, the hierarchy by bottom-up agglomerative clustering over the Morton order
+ *   (PLOC) with SAH leaf selection: trace rates close to the host SAH trees at a device build's cost (no Vulkan counterpart: the
+ *   driver's PREFER_FAST_TRACE build also runs on the GPU). */
 #define KJ_BLAS_BUILD_FAST_TRACE 0u
 #define KJ_BLAS_BUILD_FAST_BUILD 1u
+#define KJ_BLAS_BUILD_DEVICE_PLOC 2u
 KjStatus kj_scene_set_blas_build_mode(KjScene* scene, uint32_t mode);
 
 /* Baked assets (`bin/bake` output, kajiya-asset-pipe/src/lib.rs:38-60): zero-copy, bounds-checked views of

@@ -9,9 +9,7 @@
 #include "kj_reservoir.hpp"
 #include "kj_ircache_host.hpp"
 #include <algorithm>
-#ifndef KJ_HIP_EMU_HOST
 #include <hipcub/hipcub.hpp>
-#endif
 
 using namespace kj;
 namespace kj { SceneView scene_view(const KjScene& s); }
@@ -152,6 +150,7 @@ struct IrcTraceCtx {
     unsigned long long* __restrict__ ray_counters;
     uint32_t request_slot_base;      // first slot of the cache's own passes in IrcacheView::requests (deferred updates)
     uint32_t lanes;                  // work items per wave (<= 64): see kj_ircache_trace_irradiance
+    uint32_t part_index, part_count; // this launch takes the entries at positions part_index, part_index + part_count, ... of the tracing list
 };
 // one count per path: in the QUAD form the four lanes of a path run the same code, lane 0 counts
 template <bool QUAD> KJ_D void irc_count_path_rays(unsigned long long* counters, int which) {
@@ -159,21 +158,22 @@ template <bool QUAD> KJ_D void irc_count_path_rays(unsigned long long* counters,
     if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
 }
 // Work distribution of the three ray kernels. QUAD (the default): 16 paths per wave, four lanes each; else `lanes` paths per wave, one lane each.
-#define IRC_PATH_LOOP(total_)                                                                                                     \
+#define IRC_PATH_LOOP(entries_, per_entry_)                                                                                      \
     const uint32_t per_wave_ = QUAD ? 16u : c.lanes;                                                                                \
     const uint32_t slot_ = QUAD ? (threadIdx.x >> 2) : threadIdx.x;                                                                 \
     const bool lead = !QUAD || (threadIdx.x & 3u) == 0u;                                                                            \
     uint32_t* const stack = lds_stack + slot_;                                                                                      \
     const uint32_t stride = QUAD ? 16u : 64u;                                                                                       \
     if (slot_ >= per_wave_) return;                                                                                                 \
-    for (uint32_t d = blockIdx.x * per_wave_ + slot_; d < (total_); d += gridDim.x * per_wave_)
+    const uint32_t own_entries_ = ((entries_) + c.part_count - 1u - c.part_index) / c.part_count;                                   \
+    for (uint32_t local_ = blockIdx.x * per_wave_ + slot_, d = 0; local_ < own_entries_ * (per_entry_) &&                           \
+         ((d = ((local_ / (per_entry_)) * c.part_count + c.part_index) * (per_entry_) + local_ % (per_entry_)), true); local_ += gridDim.x * per_wave_)
 // trace_accessibility.rgen.hlsl:21-66
 template <bool QUAD>
 __global__ void __launch_bounds__(64) k_irc_trace_accessibility(IrcTraceCtx c) {
     extern __shared__ uint32_t lds_stack[];
     const IrcacheView& ic = c.ic;
-    const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_OCTA_DIMS2;
-    IRC_PATH_LOOP(total) {
+    IRC_PATH_LOOP(ic.meta[IRC_META_TRACING_ALLOC_COUNT], IRC_OCTA_DIMS2) {
         const uint32_t entry_idx = ic.entry_indirection[d / IRC_OCTA_DIMS2];
         const uint32_t octa_idx = d % IRC_OCTA_DIMS2;
         if (!irc_life_valid(ic.life[entry_idx])) continue;
@@ -267,8 +267,7 @@ __global__ void __launch_bounds__(64) k_irc_validate(IrcTraceCtx c) {
     extern __shared__ uint32_t lds_stack[];
     const IrcacheView& ic = c.ic;
     const FrameConstants& fc = *c.fc;
-    const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_VALIDATION_SAMPLES_PER_FRAME;
-    IRC_PATH_LOOP(total) {
+    IRC_PATH_LOOP(ic.meta[IRC_META_TRACING_ALLOC_COUNT], IRC_VALIDATION_SAMPLES_PER_FRAME) {
         const uint32_t entry_idx = ic.entry_indirection[d / IRC_VALIDATION_SAMPLES_PER_FRAME];
         const uint32_t sample_idx = d % IRC_VALIDATION_SAMPLES_PER_FRAME;
         const uint32_t life = ic.life[entry_idx];
@@ -303,8 +302,7 @@ __global__ void __launch_bounds__(64) k_irc_trace_irradiance(IrcTraceCtx c) {
     extern __shared__ uint32_t lds_stack[];
     const IrcacheView& ic = c.ic;
     const FrameConstants& fc = *c.fc;
-    const uint32_t total = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME;
-    IRC_PATH_LOOP(total) {
+    IRC_PATH_LOOP(ic.meta[IRC_META_TRACING_ALLOC_COUNT], IRC_SAMPLES_PER_FRAME) {
         const uint32_t entry_idx = ic.entry_indirection[d / IRC_SAMPLES_PER_FRAME];
         const uint32_t sample_idx = d % IRC_SAMPLES_PER_FRAME;
         const uint32_t life = ic.life[entry_idx];
@@ -479,26 +477,6 @@ __global__ void k_irc_request_finish(IrcacheView ic, const uint32_t* __restrict_
     const uint32_t before = ic.meta[IRC_META_ALLOC_COUNT];
     ic.meta[IRC_META_ALLOC_COUNT] = min(before + allocated, uint32_t(IRC_MAX_ENTRIES));
 }
-#ifdef KJ_HIP_EMU_HOST
-#include <algorithm>
-#include <vector>
-static void irc_apply_requests_host(IrcacheView ic, const IrcRequest* rq, uint32_t n) {
-    std::vector<uint32_t> order(n);
-    for (uint32_t i = 0; i < n; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rq[a].cell != rq[b].cell ? rq[a].cell < rq[b].cell : rq[a].key < rq[b].key; });
-    std::vector<unsigned long long> keys(n);
-    for (uint32_t i = 0; i < n; ++i) keys[i] = ((unsigned long long)rq[order[i]].cell << 32) | rq[order[i]].key;
-    std::vector<uint32_t> flags(n), ranks(n), scratch(4);
-    blockDim = dim3(256); gridDim = dim3((n + 255) / 256);
-    for (uint32_t b = 0; b < gridDim.x; ++b)
-        for (uint32_t t = 0; t < 256; ++t) { blockIdx = dim3(b); threadIdx = dim3(t); k_irc_request_heads(ic, rq, keys.data(), order.data(), n, flags.data()); }
-    uint32_t acc = 0;
-    for (uint32_t i = 0; i < n; ++i) { ranks[i] = acc; acc += flags[i]; }
-    for (uint32_t b = 0; b < gridDim.x; ++b)
-        for (uint32_t t = 0; t < 256; ++t) { blockIdx = dim3(b); threadIdx = dim3(t); k_irc_request_apply(ic, rq, keys.data(), order.data(), n, flags.data(), ranks.data(), scratch.data()); }
-    k_irc_request_finish(ic, flags.data(), ranks.data(), n);
-}
-#endif
 
 // ================================================================== host
 #include "kj_ircache_host.hpp"
@@ -638,6 +616,13 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     // racy passes further from the sequential oracle (SH rel-L2 on identical state, 1080p city: 1.1e-2 at 64, 2.3e-2 at 8; bar 2e-2).
     static const uint32_t lanes_env = getenv("KJ_IRC_LANES") ? uint32_t(atoi(getenv("KJ_IRC_LANES"))) : 0u;
     tc.lanes = lanes_env >= 1u && lanes_env <= 64u ? lanes_env : 64u;
+    // KJ_IRC_PART="i/n" (a measurement switch, scripts/ircache_partition_probe.sh): the three ray passes take every n-th entry only -- what
+    // one rank of n would trace if the cache's own rays were dealt out across ranks. Results are then incomplete by construction.
+    tc.part_index = 0u; tc.part_count = 1u;
+    if (const char* pe = getenv("KJ_IRC_PART")) {
+        unsigned pi = 0, pn = 1;
+        if (sscanf(pe, "%u/%u", &pi, &pn) == 2 && pn >= 1u && pi < pn) { tc.part_index = pi; tc.part_count = pn; }
+    }
     // Default: four lanes per path (kj_bvh.hpp: bvh_trace_quad) -- 16 paths per wave, a ~75-instruction step instead of ~200, four
     // times the waves. KJ_IRC_QUAD=0: one lane per path.
     static const bool quad = !(getenv("KJ_IRC_QUAD") && atoi(getenv("KJ_IRC_QUAD")) == 0);
@@ -707,9 +692,6 @@ KjStatus kj_ircache_apply_requests(KjIrcache* c, const void* list, uint32_t coun
     IrcacheView v = c->view();
     v.requests = nullptr;
     const IrcRequest* rq = (const IrcRequest*)list;
-#ifdef KJ_HIP_EMU_HOST
-    irc_apply_requests_host(v, rq, count);      // the CPU stand-in for HIP has no device sort: same replay, plain loops
-#else
     auto A = [&](kj::DevBuf& b, size_t n) { if (b.bytes < n) { hipError_t e = b.alloc(n, s); if (e != hipSuccess) c->err = e; } };
     A(c->req_sort_keys, size_t(count) * 8); A(c->req_sort_keys2, size_t(count) * 8); A(c->req_sort_idx, size_t(count) * 4); A(c->req_sort_idx2, size_t(count) * 4);
     A(c->req_flags, size_t(count) * 4); A(c->req_ranks, size_t(count) * 4); A(c->req_count, 16);
@@ -731,7 +713,6 @@ KjStatus kj_ircache_apply_requests(KjIrcache* c, const void* list, uint32_t coun
                        (const uint32_t*)c->req_ranks.p, (uint32_t*)c->req_count.p);
     hipLaunchKernelGGL(k_irc_request_finish, dim3(1), dim3(1), 0, s, v, (const uint32_t*)c->req_flags.p, (const uint32_t*)c->req_ranks.p, count);
     KJ_CHECK_LAUNCH();
-#endif
     return KJ_OK;
 }
 KjStatus kj_ircache_buffer(KjIrcache* c, const char* name, void** out_dev_ptr, uint64_t* out_bytes) {

@@ -85,7 +85,7 @@ struct KjScene {
                   uint32_t root = 0, heights_base = 0, height_count = 0, wide_heights = 0; };   // root node (relative); the refit's bottom-up steps (kj_scene_device.hpp: InstanceRefitJob)
     std::vector<Blas> blas;                       // one per mesh
     uint32_t blas_nodes_used = 0, obj_tris_used = 0;   // fill of the two device pools every BLAS lives in (d_blas_nodes, d_obj_tris)
-    uint32_t blas_build_mode = 0;                 // for meshes added from now on: 0 = SAH on the host (fast trace), 1 = LBVH on the device (fast build)
+    uint32_t blas_build_mode = 0;                 // for meshes added from now on: 0 = SAH on the host (fast trace), 1 = LBVH on the device (fast build), 2 = PLOC on the device
     std::vector<uint8_t> mesh_build_mode;         // per mesh
     // what changed since the last commit
     bool meshes_dirty = true, instance_set_dirty = true;

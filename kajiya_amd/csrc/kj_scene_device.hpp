@@ -32,6 +32,6 @@ hipError_t launch_instance_refit(const Bvh4Node* blas_nodes, const uint2* steps,
 // indices offset by node_base, object-space triangles in leaf order into d_tris_out[0 .. index_count / 3). Synchronises the stream.
 struct LbvhResult { float bounds[6]; uint32_t node_count, max_stack; std::vector<uint32_t> level_starts; };   // level d (0 = the root) = nodes [level_starts[d], level_starts[d + 1])
 struct LbvhScratch { static constexpr int BUFFERS = 14; DevBuf buf[BUFFERS], tmp, queue_len, level_nodes; uint32_t capacity = 0; };   // the build's working set, reused across meshes
-hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s);
+hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s, bool ploc);   // ploc: hierarchy by agglomerative clustering instead of Morton-code splits
 
 }  // namespace kj

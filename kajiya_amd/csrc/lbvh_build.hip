@@ -11,18 +11,28 @@
 //   6. triangles in sorted (= leaf) order                                                                 (k_lbvh_emit_tris)
 // Trees are shallower in quality than SAH ones (more node visits per ray); hits are identical: the triangles decide, and equal-t
 // ties go to the lowest world triangle id whatever the tree.
+//
+// KJ_BLAS_BUILD_DEVICE_PLOC replaces step 4 by bottom-up agglomerative clustering over the Morton order (PLOC, Meister & Bittner 2018):
+//   4'. every cluster (at first: every triangle) looks PLOC_RADIUS neighbours to either side of its place in the Morton order for the one
+//       whose union with it has the smallest surface area; mutual nearest neighbours merge into a new node; the cluster list is
+//       compacted in order (block scan + scan of the block totals); repeated until one cluster is left (~log n rounds, four launches
+//       each, no read-back except every fourth round for the launch size). Each node carries its subtree's triangle count and SAH
+//       cost; a subtree of <= KJ_BVH_MAX_LEAF_TRIS triangles becomes a leaf where that is the cheaper of the two (the host builder's rule). (k_ploc_*)
+//   5'. the same 4-wide collapse; a subtree's triangles are no longer contiguous in the Morton order, so the collapse hands out
+//       triangle slots top-down (first slot of a child = first slot of its parent + the counts of the children before it) and a leaf
+//       writes its triangles' ids there.                                                                  (k_ploc_collapse)
+// Trees built this way trace within a few percent of the host SAH trees (scripts/traversal_microbench.py) at a fraction of the build time.
 #include "kj_host.hpp"
 #include "kj_scene_device.hpp"
 #include "kj_vec.hpp"
 #include <cfloat>
+#include <cstdio>
+#include <cstdlib>
 
-#ifndef KJ_HIP_EMU_HOST
 #include <hipcub/hipcub.hpp>
-#endif
 
 using namespace kj;
 
-#ifndef KJ_HIP_EMU_HOST
 namespace {
 
 struct Box6 { float mn[3], mx[3]; };
@@ -67,11 +77,15 @@ KJ_D MortonCode spread21(uint32_t v) {
 __global__ void __launch_bounds__(256) k_lbvh_morton(const Box6* __restrict__ pbox, const uint32_t* __restrict__ ob, uint32_t n, MortonCode* __restrict__ codes, uint32_t* __restrict__ ids) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // one scale for the three axes (the cube around the mesh): with a scale per axis a flat mesh -- a terrain -- would spend a third of
+    // its code bits on height noise and neighbours in the code order would not be neighbours in space
+    float ext = 0.0f;
+    for (int k = 0; k < 3; ++k) ext = fmaxf(ext, o2f(ob[3 + k]) - o2f(ob[k]));
     uint32_t q[3];
     for (int k = 0; k < 3; ++k) {
-        const float lo = o2f(ob[k]), hi = o2f(ob[3 + k]);
+        const float lo = o2f(ob[k]);
         const float c = 0.5f * (pbox[i].mn[k] + pbox[i].mx[k]);
-        const float t = hi > lo ? (c - lo) / (hi - lo) : 0.0f;
+        const float t = ext > 0.0f ? (c - lo) / ext : 0.0f;
         const float cells = float(1u << KJ_MORTON_BITS);
         q[k] = uint32_t(fminf(fmaxf(t * cells, 0.0f), cells - 1.0f));
     }
@@ -131,6 +145,34 @@ __global__ void __launch_bounds__(256) k_lbvh_refit(const Box6* __restrict__ pbo
         cur = parent[cur];
     }
 }
+// The frame of a 4-wide node (origin + power-of-two step per axis around its children's boxes) ...
+KJ_D void node_frame(const Box6* cb, int nch, Bvh4Node& node, float scale[3]) {
+    Box6 frame;
+    for (int k = 0; k < 3; ++k) { frame.mn[k] = FLT_MAX; frame.mx[k] = -FLT_MAX; }
+    for (int i = 0; i < nch; ++i) for (int k = 0; k < 3; ++k) { frame.mn[k] = fminf(frame.mn[k], cb[i].mn[k]); frame.mx[k] = fmaxf(frame.mx[k], cb[i].mx[k]); }
+    memset(&node, 0, sizeof(node));
+    for (int k = 0; k < 3; ++k) {
+        node.origin[k] = frame.mn[k];
+        const float ext = frame.mx[k] - frame.mn[k];
+        int e = -120;
+        if (ext > 0.0f) { (void)frexpf(ext / 254.0f, &e); }     // smallest power of two with ext / 2^e <= 254
+        e = min(127, max(-120, e));
+        scale[k] = ldexpf(1.0f, e);
+        node.exp8[k] = uint8_t(e + 127);
+    }
+}
+// ... and child i's box in it: 8 bits per plane, rounded outwards against the traversal's own decode fma(q, step, origin)
+KJ_D void quantise_child(Bvh4Node& node, const float scale[3], int i, const Box6& b) {
+    for (int k = 0; k < 3; ++k) {
+#pragma clang fp contract(off)
+        const float inv = 1.0f / scale[k];
+        int lo = int(floorf((b.mn[k] - node.origin[k]) * inv)), hi = int(ceilf((b.mx[k] - node.origin[k]) * inv));
+        lo = min(255, max(0, lo)); hi = min(255, max(0, hi));
+        while (lo > 0 && node.origin[k] + float(lo) * scale[k] > b.mn[k]) --lo;
+        while (hi < 255 && node.origin[k] + float(hi) * scale[k] < b.mx[k]) ++hi;
+        node.qlo[k][i] = uint8_t(lo); node.qhi[k][i] = uint8_t(hi);
+    }
+}
 // One level of the 4-wide tree. item = (binary internal node, output node index, depth).
 struct CollapseItem { uint32_t bin, out, depth; };
 // The level's queue length lives on the device (queue_len[level]; the kernel appends to queue_len[level + 1]): the host launches every
@@ -153,21 +195,11 @@ __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __rest
         const uint2 c = children[ch[best]];
         ch[best] = c.x; ch[nch++] = c.y;
     }
-    Box6 frame;
-    for (int k = 0; k < 3; ++k) { frame.mn[k] = FLT_MAX; frame.mx[k] = -FLT_MAX; }
-    for (int i = 0; i < nch; ++i) { const Box6 b = nbox[n == 1 ? 0 : ch[i]]; for (int k = 0; k < 3; ++k) { frame.mn[k] = fminf(frame.mn[k], b.mn[k]); frame.mx[k] = fmaxf(frame.mx[k], b.mx[k]); } }
+    Box6 cb[4];
+    for (int i = 0; i < nch; ++i) cb[i] = nbox[n == 1 ? 0 : ch[i]];
     Bvh4Node node;
-    memset(&node, 0, sizeof(node));
     float scale[3];
-    for (int k = 0; k < 3; ++k) {
-        node.origin[k] = frame.mn[k];
-        const float ext = frame.mx[k] - frame.mn[k];
-        int e = -120;
-        if (ext > 0.0f) { (void)frexpf(ext / 254.0f, &e); }     // smallest power of two with ext / 2^e <= 254
-        e = min(127, max(-120, e));
-        scale[k] = ldexpf(1.0f, e);
-        node.exp8[k] = uint8_t(e + 127);
-    }
+    node_frame(cb, nch, node, scale);
     node.exp8[3] = uint8_t(nch);
     atomicMax(&counters[2], it.depth + uint32_t(nch));     // stack entries below this node + what its visit can push, + 1
     for (int i = 0; i < 4; ++i) {
@@ -176,16 +208,7 @@ __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __rest
             for (int k = 0; k < 3; ++k) { node.qlo[k][i] = 255; node.qhi[k][i] = 0; }
             continue;
         }
-        const Box6 b = nbox[n == 1 ? 0 : ch[i]];
-        for (int k = 0; k < 3; ++k) {
-#pragma clang fp contract(off)
-            const float inv = 1.0f / scale[k];
-            int lo = int(floorf((b.mn[k] - node.origin[k]) * inv)), hi = int(ceilf((b.mx[k] - node.origin[k]) * inv));
-            lo = min(255, max(0, lo)); hi = min(255, max(0, hi));
-            while (lo > 0 && node.origin[k] + float(lo) * scale[k] > b.mn[k]) --lo;
-            while (hi < 255 && node.origin[k] + float(hi) * scale[k] < b.mx[k]) ++hi;
-            node.qlo[k][i] = uint8_t(lo); node.qhi[k][i] = uint8_t(hi);
-        }
+        quantise_child(node, scale, i, cb[i]);
         if (n == 1) node.child[i] = KJ_BVH_LEAF;
         else if (is_leaf(ch[i])) {
             const uint32_t first = ch[i] >= uint32_t(n - 1) ? ch[i] - uint32_t(n - 1) : range[ch[i]].x;
@@ -217,16 +240,289 @@ __global__ void __launch_bounds__(256) k_lbvh_emit_tris(const uint8_t* __restric
     out[i] = t;
 }
 
-}  // namespace
+// ------------------------------------------------------------------ PLOC: bottom-up clustering over the Morton order (header, step 4')
+// Binary node ids here: leaf k (the k-th triangle in Morton order) = k, inner node j = n + j. Per node: box, `cnt` = triangles below it with
+// bit 31 set when the subtree is emitted as ONE leaf, `cost` = SAH cost of the subtree (traversal step = 1, triangle test = 1: bvh_build.cpp).
+#ifndef PLOC_RADIUS
+#define PLOC_RADIUS 16
 #endif
+#define PLOC_BLOCK 256
+#define PLOC_LEAF_FLAG 0x80000000u
+#define PLOC_NONE 0xffffffffu
+KJ_D Box6 box_union(const Box6& a, const Box6& b) {
+    Box6 u;
+    for (int q = 0; q < 3; ++q) { u.mn[q] = fminf(a.mn[q], b.mn[q]); u.mx[q] = fmaxf(a.mx[q], b.mx[q]); }
+    return u;
+}
+// exclusive scan of one value per thread of a PLOC_BLOCK-thread workgroup through LDS; returns the thread's prefix, *total = the block's sum
+KJ_D uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds /*[PLOC_BLOCK]*/, uint32_t* total) {
+    const uint32_t t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < PLOC_BLOCK; off <<= 1) {
+        const uint32_t add = t >= off ? lds[t - off] : 0u;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    const uint32_t incl = lds[t];
+    *total = lds[PLOC_BLOCK - 1];
+    __syncthreads();
+    return incl - v;
+}
+__global__ void __launch_bounds__(256) k_ploc_init(const Box6* __restrict__ pbox, const uint32_t* __restrict__ ids, uint32_t n, Box6* __restrict__ nbox, uint32_t* __restrict__ cnt, float* __restrict__ cost,
+                                                    uint32_t* __restrict__ clusters, uint32_t* __restrict__ mcount) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k == 0) { mcount[0] = n; mcount[1] = 0u; /* inner nodes made so far */ }
+    if (k >= n) return;
+    nbox[k] = pbox[ids[k]];
+    cnt[k] = 1u | PLOC_LEAF_FLAG;
+    cost[k] = 1.0f;
+    clusters[k] = k;
+}
+// nearest neighbour of every cluster inside the window. Pairs are compared by (area of the union, index distance, parity of the lower
+// index, lower index): a strict order on unordered pairs, the same from both ends, so the smallest pair of a neighbourhood is always mutual
+// -- and runs of identical boxes (coincident triangles) pair up (0,1)(2,3).. in one round instead of one merge per round.
+__global__ void __launch_bounds__(PLOC_BLOCK) k_ploc_nearest(const uint32_t* __restrict__ clusters, const Box6* __restrict__ nbox, const uint32_t* __restrict__ mcount, uint32_t* __restrict__ nearest) {
+    __shared__ Box6 lb[PLOC_BLOCK + 2 * PLOC_RADIUS];
+    const uint32_t m = mcount[0];
+    const uint32_t base = blockIdx.x * PLOC_BLOCK;
+    if (base >= m || m < 2u) return;
+    for (uint32_t t = threadIdx.x; t < PLOC_BLOCK + 2 * PLOC_RADIUS; t += PLOC_BLOCK) {
+        const long long g = (long long)base + t - PLOC_RADIUS;
+        if (g >= 0 && g < (long long)m) lb[t] = nbox[clusters[g]];
+    }
+    __syncthreads();
+    const uint32_t i = base + threadIdx.x;
+    if (i >= m) return;
+    const Box6 mine = lb[threadIdx.x + PLOC_RADIUS];
+    float best_d = FLT_MAX; uint32_t best_j = PLOC_NONE, best_dist = 0, best_par = 0, best_lo = 0;
+    for (int o = -PLOC_RADIUS; o <= PLOC_RADIUS; ++o) {
+        const long long g = (long long)i + o;
+        if (o == 0 || g < 0 || g >= (long long)m) continue;
+        const float d = half_area(box_union(mine, lb[int(threadIdx.x) + PLOC_RADIUS + o]));
+        const uint32_t j = uint32_t(g), dist = uint32_t(o < 0 ? -o : o), lo = min(i, j), par = lo & 1u;
+        const bool better = best_j == PLOC_NONE || d < best_d || (d == best_d && (dist < best_dist || (dist == best_dist && (par < best_par || (par == best_par && lo < best_lo)))));
+        if (better) { best_d = d; best_j = j; best_dist = dist; best_par = par; best_lo = lo; }
+    }
+    nearest[i] = best_j;
+}
+// mutual nearest neighbours merge: the lower one makes the node and keeps the place, the upper one leaves the list
+__global__ void __launch_bounds__(PLOC_BLOCK) k_ploc_merge(const uint32_t* __restrict__ clusters, const uint32_t* __restrict__ nearest, uint32_t n, uint32_t* __restrict__ mcount, Box6* __restrict__ nbox,
+                                                            uint2* __restrict__ children, uint32_t* __restrict__ cnt, float* __restrict__ cost, uint32_t* __restrict__ merged, uint32_t* __restrict__ block_valid) {
+    __shared__ uint32_t lds[PLOC_BLOCK];
+    __shared__ uint32_t node_base;
+    const uint32_t m = mcount[0];
+    const uint32_t base = blockIdx.x * PLOC_BLOCK;
+    if (base >= m || m < 2u) return;
+    const uint32_t i = base + threadIdx.x;
+    uint32_t j = PLOC_NONE;
+    bool makes = false, leaves = false;
+    if (i < m) {
+        j = nearest[i];
+        const bool mutual = j != PLOC_NONE && nearest[j] == i;
+        makes = mutual && i < j;
+        leaves = mutual && i > j;
+    }
+    uint32_t total;
+    const uint32_t my = block_exclusive_scan(makes ? 1u : 0u, lds, &total);
+    if (threadIdx.x == 0) node_base = total ? atomicAdd(&mcount[1], total) : 0u;
+    __syncthreads();
+    uint32_t valid_total;
+    (void)block_exclusive_scan((i < m && !leaves) ? 1u : 0u, lds, &valid_total);
+    if (threadIdx.x == 0) block_valid[blockIdx.x] = valid_total;
+    if (i >= m) return;
+    uint32_t keep = clusters[i];
+    if (makes) {
+        const uint32_t a = keep, b = clusters[j], inner = node_base + my, id = n + inner;
+        const Box6 ba = nbox[a], bb = nbox[b], u = box_union(ba, bb);
+        nbox[id] = u;
+        children[inner] = make_uint2(a, b);
+        const uint32_t count = (cnt[a] & ~PLOC_LEAF_FLAG) + (cnt[b] & ~PLOC_LEAF_FLAG);
+        const float as_inner = 1.0f + (half_area(ba) * cost[a] + half_area(bb) * cost[b]) / fmaxf(half_area(u), 1e-30f);
+        const bool leaf = count <= KJ_BVH_MAX_LEAF_TRIS && float(count) <= as_inner;
+        cnt[id] = count | (leaf ? PLOC_LEAF_FLAG : 0u);
+        cost[id] = leaf ? float(count) : as_inner;
+        keep = id;
+    }
+    merged[i] = leaves ? PLOC_NONE : keep;
+}
+// offsets of the blocks' survivors (one workgroup; `nb` block totals) and the new cluster count
+__global__ void __launch_bounds__(1024) k_ploc_block_offsets(uint32_t* __restrict__ block_valid, uint32_t* __restrict__ mcount) {
+    __shared__ uint32_t part[1024];
+    const uint32_t m = mcount[0];
+    if (m < 2u) return;
+    const uint32_t nb = (m + PLOC_BLOCK - 1) / PLOC_BLOCK, per = (nb + 1023u) / 1024u;
+    const uint32_t t = threadIdx.x, lo = min(nb, t * per), hi = min(nb, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; ++b) sum += block_valid[b];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t add = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t b = lo; b < hi; ++b) { const uint32_t v = block_valid[b]; block_valid[b] = run; run += v; }
+    if (t == 1023u) mcount[2] = part[1023];      // next round's count; k_ploc_compact moves it to mcount[0] when it is done with the old one
+}
+__global__ void __launch_bounds__(PLOC_BLOCK) k_ploc_compact(const uint32_t* __restrict__ merged, const uint32_t* __restrict__ block_valid, uint32_t* __restrict__ mcount, uint32_t* __restrict__ clusters_out,
+                                                              uint32_t* __restrict__ done_blocks) {
+    __shared__ uint32_t lds[PLOC_BLOCK];
+    const uint32_t m = mcount[0];
+    const uint32_t base = blockIdx.x * PLOC_BLOCK;
+    if (base >= m || m < 2u) return;
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < m ? merged[i] : PLOC_NONE;
+    uint32_t total;
+    const uint32_t my = block_exclusive_scan(v != PLOC_NONE ? 1u : 0u, lds, &total);
+    if (v != PLOC_NONE) clusters_out[block_valid[blockIdx.x] + my] = v;
+    // the last block to finish publishes the new count (every block of this launch has read the old one by then)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const uint32_t nb = (m + PLOC_BLOCK - 1) / PLOC_BLOCK;
+        if (atomicAdd(done_blocks, 1u) + 1u == nb) { *done_blocks = 0u; __threadfence(); mcount[0] = mcount[2]; }
+    }
+}
+
+// The last rounds in ONE launch: once PLOC_TAIL clusters or fewer are left a single workgroup carries on by itself -- cluster list,
+// boxes and nearest neighbours in LDS, a barrier where the multi-launch rounds have a kernel boundary. (The tail is where rounds are
+// many and small: a 2 k-triangle mesh takes 36 rounds, a 250 k-triangle one ~50, the last ~25 of them on fewer than a thousand clusters.)
+#define PLOC_TAIL 1024
+KJ_D uint32_t tail_exclusive_scan(uint32_t v, uint32_t* lds /*[PLOC_TAIL]*/, uint32_t* total) {
+    const uint32_t t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < PLOC_TAIL; off <<= 1) {
+        const uint32_t add = t >= off ? lds[t - off] : 0u;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    const uint32_t incl = lds[t];
+    *total = lds[PLOC_TAIL - 1];
+    __syncthreads();
+    return incl - v;
+}
+__global__ void __launch_bounds__(PLOC_TAIL) k_ploc_tail(uint32_t* __restrict__ clusters, uint32_t n, uint32_t* __restrict__ mcount, Box6* __restrict__ nbox, uint2* __restrict__ children,
+                                                          uint32_t* __restrict__ cnt, float* __restrict__ cost) {
+    __shared__ Box6 lb[PLOC_TAIL];
+    __shared__ uint32_t lc[PLOC_TAIL], ln[PLOC_TAIL], scan[PLOC_TAIL];
+    const uint32_t i = threadIdx.x;
+    uint32_t m = mcount[0], made = mcount[1];
+    if (m > PLOC_TAIL) return;
+    if (i < m) { lc[i] = clusters[i]; lb[i] = nbox[lc[i]]; }
+    __syncthreads();
+    while (m > 1u) {
+        uint32_t best_j = PLOC_NONE;
+        if (i < m) {
+            const Box6 mine = lb[i];
+            float best_d = FLT_MAX; uint32_t best_dist = 0, best_par = 0, best_lo = 0;
+            for (int o = -PLOC_RADIUS; o <= PLOC_RADIUS; ++o) {
+                const int g = int(i) + o;
+                if (o == 0 || g < 0 || g >= int(m)) continue;
+                const float d = half_area(box_union(mine, lb[g]));
+                const uint32_t j = uint32_t(g), dist = uint32_t(o < 0 ? -o : o), lo = min(i, j), par = lo & 1u;
+                const bool better = best_j == PLOC_NONE || d < best_d || (d == best_d && (dist < best_dist || (dist == best_dist && (par < best_par || (par == best_par && lo < best_lo)))));
+                if (better) { best_d = d; best_j = j; best_dist = dist; best_par = par; best_lo = lo; }
+            }
+            ln[i] = best_j;
+        }
+        __syncthreads();
+        const bool mutual = i < m && best_j != PLOC_NONE && ln[best_j] == i;
+        const bool makes = mutual && i < best_j, leaves = mutual && i > best_j;
+        uint32_t total_made, total_valid;
+        const uint32_t my_node = tail_exclusive_scan(makes ? 1u : 0u, scan, &total_made);
+        const uint32_t my_place = tail_exclusive_scan((i < m && !leaves) ? 1u : 0u, scan, &total_valid);
+        uint32_t keep = i < m ? lc[i] : PLOC_NONE;
+        Box6 kb = i < m ? lb[i] : Box6{};
+        if (makes) {
+            const uint32_t a = keep, b = lc[best_j], inner = made + my_node, id = n + inner;
+            const Box6 ba = kb, bb = lb[best_j], u = box_union(ba, bb);
+            nbox[id] = u;
+            children[inner] = make_uint2(a, b);
+            const uint32_t count = (cnt[a] & ~PLOC_LEAF_FLAG) + (cnt[b] & ~PLOC_LEAF_FLAG);
+            const float as_inner = 1.0f + (half_area(ba) * cost[a] + half_area(bb) * cost[b]) / fmaxf(half_area(u), 1e-30f);
+            const bool leaf = count <= KJ_BVH_MAX_LEAF_TRIS && float(count) <= as_inner;
+            cnt[id] = count | (leaf ? PLOC_LEAF_FLAG : 0u);
+            cost[id] = leaf ? float(count) : as_inner;
+            keep = id; kb = u;
+        }
+        __syncthreads();      // everyone has read its neighbours' lc / lb / cnt / cost of this round
+        if (i < m && !leaves) { lc[my_place] = keep; lb[my_place] = kb; }
+        made += total_made;
+        m = total_valid;
+        __threadfence();      // this workgroup's own cnt / cost writes are read back next round by other lanes
+        __syncthreads();
+    }
+    if (i == 0) { clusters[0] = lc[0]; mcount[0] = 1u; mcount[1] = made; }
+}
+struct PlocItem { uint32_t bin, out, depth, first; };
+__global__ void k_ploc_root(const uint32_t* __restrict__ clusters, PlocItem* __restrict__ q) { q[0] = PlocItem{clusters[0], 0u, 0u, 0u}; }
+// One level of the 4-wide tree over the PLOC hierarchy: as k_lbvh_collapse, plus the top-down hand-out of triangle slots.
+__global__ void __launch_bounds__(64) k_ploc_collapse(uint32_t n, const uint2* __restrict__ children, const uint32_t* __restrict__ cnt, const Box6* __restrict__ nbox, const uint32_t* __restrict__ sorted_ids,
+                                                       const PlocItem* __restrict__ in, uint32_t* __restrict__ queue_len, uint32_t level, PlocItem* __restrict__ out, uint32_t* __restrict__ counters,
+                                                       Bvh4Node* __restrict__ nodes, uint32_t node_base, uint32_t* __restrict__ tri_order) {
+    const uint32_t in_count = queue_len[level];
+    for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < in_count; w += gridDim.x * 64) {
+        const PlocItem it = in[w];
+        auto is_leaf = [&](uint32_t id) { return (cnt[id] & PLOC_LEAF_FLAG) != 0u; };
+        uint32_t ch[4]; int nch = 0;
+        if (is_leaf(it.bin)) ch[nch++] = it.bin;          // the whole mesh fits one leaf
+        else { const uint2 c = children[it.bin - n]; ch[nch++] = c.x; ch[nch++] = c.y; }
+        while (nch < 4) {
+            int best = -1; float ba = -1.0f;
+            for (int i = 0; i < nch; ++i)
+                if (!is_leaf(ch[i])) { const float a = half_area(nbox[ch[i]]); if (a > ba) { ba = a; best = i; } }
+            if (best < 0) break;
+            const uint2 c = children[ch[best] - n];
+            ch[best] = c.x; ch[nch++] = c.y;
+        }
+        Box6 cb[4];
+        for (int i = 0; i < nch; ++i) cb[i] = nbox[ch[i]];
+        Bvh4Node node;
+        float scale[3];
+        node_frame(cb, nch, node, scale);
+        node.exp8[3] = uint8_t(nch);
+        atomicMax(&counters[2], it.depth + uint32_t(nch));
+        uint32_t first = it.first;
+        for (int i = 0; i < 4; ++i) {
+            if (i >= nch) {
+                node.child[i] = 0xffffffffu;
+                for (int k = 0; k < 3; ++k) { node.qlo[k][i] = 255; node.qhi[k][i] = 0; }
+                continue;
+            }
+            quantise_child(node, scale, i, cb[i]);
+            const uint32_t count = cnt[ch[i]] & ~PLOC_LEAF_FLAG;
+            if (is_leaf(ch[i])) {
+                node.child[i] = KJ_BVH_LEAF | ((count - 1u) << 28) | first;
+                uint32_t stack[KJ_BVH_MAX_LEAF_TRIS + 1]; int sp = 0; uint32_t o = first;      // the leaf's triangles, left to right
+                stack[sp++] = ch[i];
+                while (sp) {
+                    const uint32_t id = stack[--sp];
+                    if (id < n) tri_order[o++] = sorted_ids[id];
+                    else { const uint2 c = children[id - n]; stack[sp++] = c.y; stack[sp++] = c.x; }
+                }
+            } else {
+                const uint32_t o = atomicAdd(&counters[1], 1u);
+                node.child[i] = node_base + o;
+                out[atomicAdd(&queue_len[level + 1], 1u)] = PlocItem{ch[i], o, it.depth + uint32_t(nch - 1), first};
+            }
+            first += count;
+        }
+        nodes[it.out] = node;
+    }
+}
+
+}  // namespace
 
 namespace kj {
 
-#ifdef KJ_HIP_EMU_HOST
-hipError_t build_blas_lbvh_device(const uint8_t*, const GpuMesh&, uint32_t, Bvh4Node*, BvhTri*, LbvhResult*, LbvhScratch*, hipStream_t) { return hipErrorInvalidValue; }   // the CPU stand-in has no device sort: fast-build meshes need the real device
-#else
 #define KJ_LB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
-hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s) {
+hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s, bool ploc) {
     const uint32_t n = mesh.index_count / 3;
     if (n == 0 || !scratch) return hipErrorInvalidValue;
     // working set: 15 device buffers, kept by the caller across the meshes of a commit (allocating and freeing them per mesh cost a
@@ -234,53 +530,102 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
     if (scratch->capacity < n) {
         const size_t c = size_t(n) + n / 4;
         const size_t sizes[LbvhScratch::BUFFERS] = {c * sizeof(Box6), 32, c * 8, c * 4, c * 8, c * 4, c * 8, c * 8, 2 * c * 4, c * 4, 2 * c * sizeof(Box6),
-                                                    (c + 1) * sizeof(CollapseItem), (c + 1) * sizeof(CollapseItem), 16};
+                                                    (c + 1) * sizeof(PlocItem), (c + 1) * sizeof(PlocItem), 64};
         for (int k = 0; k < LbvhScratch::BUFFERS; ++k) KJ_LB(scratch->buf[k].alloc(sizes[k], s));
         scratch->capacity = uint32_t(c);
     }
-    DevBuf &pbox = scratch->buf[0], &ob = scratch->buf[1], &codes = scratch->buf[2], &ids = scratch->buf[3], &codes2 = scratch->buf[4], &ids2 = scratch->buf[5],
-           &children = scratch->buf[6], &range = scratch->buf[7], &parent = scratch->buf[8], &visits = scratch->buf[9], &nbox = scratch->buf[10], &q0 = scratch->buf[11],
-           &q1 = scratch->buf[12], &counters = scratch->buf[13], &tmp = scratch->tmp;
-    KJ_LB(hipMemsetAsync(visits.p, 0, size_t(n) * 4, s));      // the refit's arrival counters
+    // typed views of the working set (a buffer serves several stages: what PLOC clusters in is what the sort is done with)
+    Box6* const pbox = (Box6*)scratch->buf[0].p;
+    uint32_t* const ob = (uint32_t*)scratch->buf[1].p;
+    MortonCode* const codes = (MortonCode*)scratch->buf[2].p;
+    uint32_t* const ids = (uint32_t*)scratch->buf[3].p;
+    MortonCode* const codes2 = (MortonCode*)scratch->buf[4].p;
+    uint32_t* const ids2 = (uint32_t*)scratch->buf[5].p;            // triangle ids in Morton order
+    uint2* const children = (uint2*)scratch->buf[6].p;
+    uint2* const range = (uint2*)scratch->buf[7].p;
+    uint32_t* const parent = (uint32_t*)scratch->buf[8].p;
+    uint32_t* const visits = (uint32_t*)scratch->buf[9].p;
+    Box6* const nbox = (Box6*)scratch->buf[10].p;
+    void* const q0 = scratch->buf[11].p; void* const q1 = scratch->buf[12].p;
+    uint32_t* const counters = (uint32_t*)scratch->buf[13].p;
+    DevBuf& tmp = scratch->tmp;
+    const uint32_t cap = scratch->capacity;
+    uint32_t* const clusters = (uint32_t*)codes;              // PLOC: the cluster list, ...
+    uint32_t* const merged = (uint32_t*)codes + cap;          // ... its next state before compaction,
+    uint32_t* const nearest = ids;                            // every cluster's nearest neighbour,
+    uint32_t* const cnt = parent;                             // per node: triangles below (bit 31: emitted as one leaf)
+    float* const cost = (float*)range;                        // per node: SAH cost of the subtree
+    uint32_t* const block_valid = visits;                     // survivors per block, then their offsets
+    uint32_t* const mcount = counters + 4;                    // {clusters, inner nodes made, next round's clusters, blocks done}
+    uint32_t* const tri_order = (uint32_t*)codes2;            // triangle ids in leaf order (the collapse writes it)
+    KJ_LB(hipMemsetAsync(visits, 0, size_t(n) * 4, s));      // the refit's arrival counters
     const dim3 g((n + 255) / 256), b(256);
-    hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, (uint32_t*)ob.p);
-    hipLaunchKernelGGL(k_lbvh_prims, g, b, 0, s, d_vertex_buffer, mesh, n, (Box6*)pbox.p, (uint32_t*)ob.p);
-    hipLaunchKernelGGL(k_lbvh_morton, g, b, 0, s, (const Box6*)pbox.p, (const uint32_t*)ob.p, n, (MortonCode*)codes.p, (uint32_t*)ids.p);
+    hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, ob);
+    hipLaunchKernelGGL(k_lbvh_prims, g, b, 0, s, d_vertex_buffer, mesh, n, pbox, ob);
+    hipLaunchKernelGGL(k_lbvh_morton, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ob, n, codes, ids);
     size_t tmp_bytes = 0;
-    KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const MortonCode*)codes.p, (MortonCode*)codes2.p, (const uint32_t*)ids.p, (uint32_t*)ids2.p, int(n), 0, 3 * KJ_MORTON_BITS, s));
+    KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const MortonCode*)codes, codes2, (const uint32_t*)ids, ids2, int(n), 0, 3 * KJ_MORTON_BITS, s));
     if (tmp.bytes < (tmp_bytes ? tmp_bytes : 16)) KJ_LB(tmp.alloc(tmp_bytes ? tmp_bytes : 16, s));
-    KJ_LB(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const MortonCode*)codes.p, (MortonCode*)codes2.p, (const uint32_t*)ids.p, (uint32_t*)ids2.p, int(n), 0, 3 * KJ_MORTON_BITS, s));
-    if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, g, b, 0, s, (const MortonCode*)codes2.p, int(n), (uint2*)children.p, (uint2*)range.p, (uint32_t*)parent.p);
-    else KJ_LB(hipMemsetAsync(parent.p, 0xff, 8, s));
-    hipLaunchKernelGGL(k_lbvh_refit, g, b, 0, s, (const Box6*)pbox.p, (const uint32_t*)ids2.p, int(n), (const uint2*)children.p, (const uint32_t*)parent.p, (uint32_t*)visits.p, (Box6*)nbox.p);
+    KJ_LB(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const MortonCode*)codes, codes2, (const uint32_t*)ids, ids2, int(n), 0, 3 * KJ_MORTON_BITS, s));
+    if (ploc) {
+        KJ_LB(hipMemsetAsync(counters, 0, 64, s));
+        hipLaunchKernelGGL(k_ploc_init, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ids2, n, nbox, cnt, cost, clusters, mcount);
+        uint32_t m = n, rounds = 0;
+        while (m > PLOC_TAIL) {
+            const dim3 gr((m + PLOC_BLOCK - 1) / PLOC_BLOCK);
+            for (int k = 0; k < 4; ++k) {      // four rounds on the last known count (it only shrinks; blocks past the end leave at once)
+                hipLaunchKernelGGL(k_ploc_nearest, gr, dim3(PLOC_BLOCK), 0, s, (const uint32_t*)clusters, (const Box6*)nbox, (const uint32_t*)mcount, nearest);
+                hipLaunchKernelGGL(k_ploc_merge, gr, dim3(PLOC_BLOCK), 0, s, (const uint32_t*)clusters, (const uint32_t*)nearest, n, mcount, nbox, children, cnt, cost, merged, block_valid);
+                hipLaunchKernelGGL(k_ploc_block_offsets, dim3(1), dim3(1024), 0, s, block_valid, mcount);
+                hipLaunchKernelGGL(k_ploc_compact, gr, dim3(PLOC_BLOCK), 0, s, (const uint32_t*)merged, (const uint32_t*)block_valid, mcount, clusters, mcount + 3);
+            }
+            KJ_LB(hipMemcpyAsync(&m, mcount, 4, hipMemcpyDeviceToHost, s));
+            KJ_LB(hipStreamSynchronize(s));
+            if (++rounds > n) return hipErrorUnknown;      // every round merges at least one pair
+            if (getenv("KJ_BVH_TIMING")) fprintf(stderr, "[ploc] after %u rounds: %u clusters\n", rounds * 4u, m);
+        }
+        if (m > 1u) hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(PLOC_TAIL), 0, s, clusters, n, mcount, nbox, children, cnt, cost);
+    } else {
+        if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, g, b, 0, s, (const MortonCode*)codes2, int(n), children, range, parent);
+        else KJ_LB(hipMemsetAsync(parent, 0xff, 8, s));
+        hipLaunchKernelGGL(k_lbvh_refit, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ids2, int(n), (const uint2*)children, (const uint32_t*)parent, visits, nbox);
+    }
     // collapse, level by level, without a read-back per level: counters = {-, nodes allocated, max stack}; queue_len[l] = items of level l;
     // level_nodes[l] = nodes allocated before level l's children (a level's nodes are one contiguous run). KJ_LBVH_LEVELS levels are
     // issued blind -- far more than a tree over distinct Morton codes needs (13 for 250 k triangles) --, then ONE read-back; a deeper
     // tree (many coincident centroids) continues level by level with a read-back each.
     constexpr uint32_t KJ_LBVH_LEVELS = 40;
-    DevBuf &queue_len = scratch->queue_len, &level_nodes = scratch->level_nodes;
-    KJ_LB(queue_len.alloc((KJ_LBVH_LEVELS + 2) * 4, s)); KJ_LB(level_nodes.alloc((KJ_LBVH_LEVELS + 2) * 4, s));      // (no-ops after the first mesh)
-    KJ_LB(hipMemsetAsync(queue_len.p, 0, (KJ_LBVH_LEVELS + 2) * 4, s)); KJ_LB(hipMemsetAsync(level_nodes.p, 0, (KJ_LBVH_LEVELS + 2) * 4, s));
+    KJ_LB(scratch->queue_len.alloc((KJ_LBVH_LEVELS + 2) * 4, s)); KJ_LB(scratch->level_nodes.alloc((KJ_LBVH_LEVELS + 2) * 4, s));      // (no-ops after the first mesh)
+    uint32_t* const queue_len = (uint32_t*)scratch->queue_len.p;
+    uint32_t* const level_nodes = (uint32_t*)scratch->level_nodes.p;
+    KJ_LB(hipMemsetAsync(queue_len, 0, (KJ_LBVH_LEVELS + 2) * 4, s)); KJ_LB(hipMemsetAsync(level_nodes, 0, (KJ_LBVH_LEVELS + 2) * 4, s));
     const uint32_t init_counters[4] = {0u, 1u, 0u, 0u}, one = 1u;
     const CollapseItem root{0u, 0u, 0u};
-    KJ_LB(hipMemcpyAsync(counters.p, init_counters, 16, hipMemcpyHostToDevice, s));
-    KJ_LB(hipMemcpyAsync(queue_len.p, &one, 4, hipMemcpyHostToDevice, s));
-    KJ_LB(hipMemcpyAsync((uint32_t*)level_nodes.p + 1, &one, 4, hipMemcpyHostToDevice, s));      // level 0 = the root = node 0
-    KJ_LB(hipMemcpyAsync(q0.p, &root, sizeof(root), hipMemcpyHostToDevice, s));
-    DevBuf* qin = &q0; DevBuf* qout = &q1;
+    void* qin = q0; void* qout = q1;
+    auto collapse = [&](uint32_t items, uint32_t level) {
+        const dim3 cg(std::min(4096u, (items + 63) / 64));
+        const void* in = qin; void* out = qout;
+        if (ploc) hipLaunchKernelGGL(k_ploc_collapse, cg, dim3(64), 0, s, n, (const uint2*)children, (const uint32_t*)cnt, (const Box6*)nbox, (const uint32_t*)ids2, (const PlocItem*)in, queue_len, level,
+                                     (PlocItem*)out, counters, d_nodes_out, node_base, tri_order);
+        else hipLaunchKernelGGL(k_lbvh_collapse, cg, dim3(64), 0, s, int(n), (const uint2*)children, (const uint2*)range, (const Box6*)nbox, (const CollapseItem*)in, queue_len, level, (CollapseItem*)out,
+                                counters, d_nodes_out, node_base);
+    };
+    KJ_LB(hipMemcpyAsync(counters, init_counters, 16, hipMemcpyHostToDevice, s));
+    KJ_LB(hipMemcpyAsync(queue_len, &one, 4, hipMemcpyHostToDevice, s));
+    KJ_LB(hipMemcpyAsync(level_nodes + 1, &one, 4, hipMemcpyHostToDevice, s));      // level 0 = the root = node 0
+    if (ploc) hipLaunchKernelGGL(k_ploc_root, dim3(1), dim3(1), 0, s, (const uint32_t*)clusters, (PlocItem*)q0);
+    else KJ_LB(hipMemcpyAsync(q0, &root, sizeof(root), hipMemcpyHostToDevice, s));
     uint64_t bound = 1;
     for (uint32_t level = 0; level < KJ_LBVH_LEVELS; ++level) {
-        const uint32_t items = uint32_t(std::min<uint64_t>(bound, n));
-        hipLaunchKernelGGL(k_lbvh_collapse, dim3(std::min(4096u, (items + 63) / 64)), dim3(64), 0, s, int(n), (const uint2*)children.p, (const uint2*)range.p, (const Box6*)nbox.p,
-                           (const CollapseItem*)qin->p, (uint32_t*)queue_len.p, level, (CollapseItem*)qout->p, (uint32_t*)counters.p, d_nodes_out, node_base);
-        hipLaunchKernelGGL(k_lbvh_level_end, dim3(1), dim3(1), 0, s, (const uint32_t*)counters.p, (uint32_t*)level_nodes.p, level + 1);
+        collapse(uint32_t(std::min<uint64_t>(bound, n)), level);
+        hipLaunchKernelGGL(k_lbvh_level_end, dim3(1), dim3(1), 0, s, (const uint32_t*)counters, level_nodes, level + 1);
         bound = std::min<uint64_t>(bound * 4, uint64_t(n));
         std::swap(qin, qout);
     }
     uint32_t host_counters[4] = {0, 1, 0, 0}, host_levels[KJ_LBVH_LEVELS + 2], host_queue[KJ_LBVH_LEVELS + 2];
-    KJ_LB(hipMemcpyAsync(host_levels, level_nodes.p, sizeof(host_levels), hipMemcpyDeviceToHost, s));
-    KJ_LB(hipMemcpyAsync(host_queue, queue_len.p, sizeof(host_queue), hipMemcpyDeviceToHost, s));
-    KJ_LB(hipMemcpyAsync(host_counters, counters.p, 16, hipMemcpyDeviceToHost, s));
+    KJ_LB(hipMemcpyAsync(host_levels, level_nodes, sizeof(host_levels), hipMemcpyDeviceToHost, s));
+    KJ_LB(hipMemcpyAsync(host_queue, queue_len, sizeof(host_queue), hipMemcpyDeviceToHost, s));
+    KJ_LB(hipMemcpyAsync(host_counters, counters, 16, hipMemcpyDeviceToHost, s));
     KJ_LB(hipStreamSynchronize(s));
     result->level_starts.assign({0u});
     for (uint32_t l = 1; l <= KJ_LBVH_LEVELS + 1; ++l)
@@ -288,19 +633,18 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
     uint32_t in_count = host_queue[KJ_LBVH_LEVELS];
     while (in_count) {      // deeper than the blind part: one level at a time
         const uint32_t lens[2] = {in_count, 0u};
-        KJ_LB(hipMemcpyAsync(queue_len.p, lens, 8, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_lbvh_collapse, dim3(std::min(4096u, (in_count + 63) / 64)), dim3(64), 0, s, int(n), (const uint2*)children.p, (const uint2*)range.p, (const Box6*)nbox.p,
-                           (const CollapseItem*)qin->p, (uint32_t*)queue_len.p, 0u, (CollapseItem*)qout->p, (uint32_t*)counters.p, d_nodes_out, node_base);
-        KJ_LB(hipMemcpyAsync(host_queue, queue_len.p, 8, hipMemcpyDeviceToHost, s));
-        KJ_LB(hipMemcpyAsync(host_counters, counters.p, 16, hipMemcpyDeviceToHost, s));
+        KJ_LB(hipMemcpyAsync(queue_len, lens, 8, hipMemcpyHostToDevice, s));
+        collapse(in_count, 0u);
+        KJ_LB(hipMemcpyAsync(host_queue, queue_len, 8, hipMemcpyDeviceToHost, s));
+        KJ_LB(hipMemcpyAsync(host_counters, counters, 16, hipMemcpyDeviceToHost, s));
         KJ_LB(hipStreamSynchronize(s));
         in_count = host_queue[1];
         if (host_counters[1] > result->level_starts.back()) result->level_starts.push_back(host_counters[1]);
         std::swap(qin, qout);
     }
-    hipLaunchKernelGGL(k_lbvh_emit_tris, g, b, 0, s, d_vertex_buffer, mesh, (const uint32_t*)ids2.p, n, d_tris_out);
+    hipLaunchKernelGGL(k_lbvh_emit_tris, g, b, 0, s, d_vertex_buffer, mesh, ploc ? (const uint32_t*)tri_order : (const uint32_t*)ids2, n, d_tris_out);
     uint32_t hob[8];
-    KJ_LB(hipMemcpyAsync(hob, ob.p, 24, hipMemcpyDeviceToHost, s));
+    KJ_LB(hipMemcpyAsync(hob, ob, 24, hipMemcpyDeviceToHost, s));
     KJ_LB(hipStreamSynchronize(s));
     KJ_LB(hipGetLastError());
     for (int k = 0; k < 6; ++k) {
@@ -312,6 +656,5 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
     result->max_stack = host_counters[2] > 0 ? host_counters[2] : 1;
     return hipSuccess;
 }
-#endif
 
 }  // namespace kj

@@ -305,7 +305,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     std::map<uint32_t, std::future<std::unique_ptr<BuiltBvh>>> host_builds;
     std::vector<uint32_t> to_build;
     for (uint32_t mi = 0; mi < s->meshes.size(); ++mi)
-        if (!s->blas[mi].built && s->mesh_build_mode[mi] != 1) to_build.push_back(mi);
+        if (!s->blas[mi].built && s->mesh_build_mode[mi] == 0) to_build.push_back(mi);
     const size_t max_in_flight = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     size_t next_build = 0;
     auto start_builds = [&]() -> bool {
@@ -326,11 +326,11 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         const uint32_t ntri = m.index_count / 3;
         bl.node_base = s->blas_nodes_used; bl.tri_base = s->obj_tris_used; bl.tri_count = ntri;
         std::vector<uint32_t> steps;          // {first, end} node of every step of the refit's bottom-up order
-        if (s->mesh_build_mode[mi] == 1) {   // LBVH on the device, straight into the pools (at most one node per triangle)
+        if (s->mesh_build_mode[mi] != 0) {   // on the device (LBVH or PLOC), straight into the pools (at most one node per triangle)
             KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), size_t(s->blas_nodes_used + ntri + 1) * sizeof(BvhNode)));
             KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), size_t(s->obj_tris_used + ntri) * sizeof(BvhTri)));
             LbvhResult lr;
-            KJ_TRY_HIP(build_blas_lbvh_device((const uint8_t*)s->d_vertex_buffer.p, m, bl.node_base, (Bvh4Node*)s->d_blas_nodes.p + bl.node_base, (BvhTri*)s->d_obj_tris.p + bl.tri_base, &lr, &lbvh_scratch, stream));
+            KJ_TRY_HIP(build_blas_lbvh_device((const uint8_t*)s->d_vertex_buffer.p, m, bl.node_base, (Bvh4Node*)s->d_blas_nodes.p + bl.node_base, (BvhTri*)s->d_obj_tris.p + bl.tri_base, &lr, &lbvh_scratch, stream, s->mesh_build_mode[mi] == 2));
             bl.node_count = lr.node_count; bl.max_stack = lr.max_stack;
             memcpy(bl.bounds, lr.bounds, 24);
             // laid out by depth on the device: the refit walks the levels deepest first, the root is node 0
@@ -524,7 +524,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     return KJ_OK;
 }
 KjStatus kj_scene_set_blas_build_mode(KjScene* s, uint32_t mode) {
-    KJ_REQUIRE(s && mode <= 1, "mode must be KJ_BLAS_BUILD_FAST_TRACE (0) or KJ_BLAS_BUILD_FAST_BUILD (1)");
+    KJ_REQUIRE(s && mode <= 2, "mode must be KJ_BLAS_BUILD_FAST_TRACE (0), KJ_BLAS_BUILD_FAST_BUILD (1) or KJ_BLAS_BUILD_DEVICE_PLOC (2)");
     s->blas_build_mode = mode;
     return KJ_OK;
 }

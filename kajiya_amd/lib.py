@@ -199,8 +199,8 @@ class Scene:
         self.dev = dev
         self.h = C.c_void_p()
         check(L.kj_scene_create(dev.h, C.byref(self.h)))
-        if fast_build:      # BLASes as LBVHs built on the device instead of SAH trees built on the host
-            check(L.kj_scene_set_blas_build_mode(self.h, 1))
+        if fast_build:      # BLASes built on the device instead of SAH trees built on the host: True / 1 = LBVH, "ploc" / 2 = PLOC
+            check(L.kj_scene_set_blas_build_mode(self.h, 2 if fast_build in ("ploc", 2) and fast_build is not True else 1))
         self._keep = []
         if desc is not None:
             for m in desc.meshes:

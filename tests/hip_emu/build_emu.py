@@ -37,7 +37,7 @@ def sanitizer_preload():
 def build():
     os.makedirs(OUT, exist_ok=True)
     deps = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
-        glob.glob(os.path.join(ROOT, "tests", "hip_emu", "hip", "*.h")) + [os.path.join(ROOT, "include", "kajiya_amd.h"), os.path.abspath(__file__)]
+        glob.glob(os.path.join(ROOT, "tests", "hip_emu", "hip", "*.h")) + glob.glob(os.path.join(ROOT, "tests", "hip_emu", "hipcub", "*.hpp")) + [os.path.join(ROOT, "include", "kajiya_amd.h"), os.path.abspath(__file__)]
     if os.path.exists(SO) and os.path.getmtime(SO) >= max(os.path.getmtime(d) for d in deps):
         return SO
 

@@ -25,7 +25,6 @@
 #include <vector>
 
 #define __HIPCC__ 1
-#define KJ_HIP_EMU_HOST 1   // lets a translation unit leave out what only exists on the device side (rocPRIM sorts)
 #define __host__
 #define __device__
 #define __global__
@@ -230,6 +229,8 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __clz(int v) { return v ? __builtin_clz(unsigned(v)) : 32; }
+inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
@@ -251,7 +252,7 @@ inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return
 // when the real library happens to be loaded in the same process.
 typedef int hipError_t;
 typedef void* hipStream_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 enum { hipHostMallocDefault = 0 };
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }

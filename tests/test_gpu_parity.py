@@ -89,19 +89,17 @@ def test_ray_queries_bit_exact(gpu, oracle, device, name):
     assert np.array_equal(ref_c.view(np.uint32), got_c.view(np.uint32))
 
 
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
 @pytest.mark.parametrize("name", ["cornell", "city20k", "pica"])
-def test_device_built_lbvh_ray_queries_bit_exact(gpu, oracle, device, name):
-    """KJ_BLAS_BUILD_FAST_BUILD: every mesh's BLAS is a linear BVH built on the device (lbvh_build.hip). Another tree, the same hits:
-    (t, u, v, triangle) must equal the oracle's (whose BVH is a median split built on the host) bit for bit, for closest-hit,
-    any-hit and back-face-culled queries, and after moving an instance."""
-    import os
+def test_device_built_lbvh_ray_queries_bit_exact(gpu, oracle, device, name, builder):
+    """KJ_BLAS_BUILD_FAST_BUILD / KJ_BLAS_BUILD_DEVICE_PLOC: every mesh's BLAS is built on the device (lbvh_build.hip: Morton-split
+    hierarchy / agglomerative clustering). Other trees, the same hits: (t, u, v, triangle) must equal the oracle's (whose BVH is a
+    median split built on the host) bit for bit, for closest-hit, any-hit and back-face-culled queries, and after moving an instance."""
     import torch
     from kajiya_amd import scenes
-    if os.environ.get("KJ_HIP_EMU"):
-        pytest.skip("the device builder sorts with rocPRIM: not part of the CPU stand-in for HIP")
     desc = _scenes()[name]
     osc = oracle.OracleScene(desc)
-    gsc = gpu.Scene(device, desc, fast_build=True)
+    gsc = gpu.Scene(device, desc, fast_build=True if builder == "lbvh" else "ploc")
     assert gsc.stats()["triangles"] == osc.triangle_count
     lo, hi = desc.bounds()
     rng = np.random.RandomState(321)
@@ -136,7 +134,7 @@ def test_small_batches_walk_four_lanes_per_ray_and_agree_bit_for_bit(gpu, oracle
     oracle's; deep trees (the city's LBVH build) exercise the quad stack's spill path."""
     import os
     import torch
-    for fast_build in ((False,) if os.environ.get("KJ_HIP_EMU") else (False, True)):     # the CPU stand-in has no device LBVH builder
+    for fast_build in (False, True, "ploc"):
         desc = _scenes()["city20k"]
         gsc = gpu.Scene(device, desc, fast_build=fast_build)
         lo, hi = desc.bounds()
@@ -476,20 +474,18 @@ def _blob(rng, n_tris, size=1.0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fast_build", [False, True])
+@pytest.mark.parametrize("fast_build", [False, True, "ploc"])
 def test_instance_trees_under_rotation_mirroring_and_repeated_edits(gpu, oracle, device, fast_build):
     """The per-instance world-space trees (scene_device.hip: refit by node height, four lanes per node) at their corners: meshes of
     1, 4, 5, 17 and 1300 triangles (one-node trees, one refit step, several steps, a step wider than one workgroup pass), instances
     rotated about arbitrary axes, scaled by 1e-2 .. 30, mirrored (negative determinant), flattened to zero volume (out of the top
     tree), 300 instances of the smallest meshes (a deeper top tree), then three rounds of edits -- move everything, remove some,
     ADD new instances of old meshes and a new mesh -- each followed by a commit. Ray queries stay bit-exact against an oracle scene
-    built from scratch in the edited state every time. `fast_build`: every BLAS built on the device as an LBVH (its refit walks
+    built from scratch in the edited state every time. `fast_build`: every BLAS built on the device (LBVH, or PLOC: the refit walks
     depth levels instead of node heights)."""
     import os
     import torch
     from kajiya_amd import scenes
-    if fast_build and os.environ.get("KJ_HIP_EMU"):
-        pytest.skip("the device LBVH build needs the device sort (not in the CPU stand-in)")
     rng = np.random.RandomState(42)
     L = gpu.load()
     meshes = [_blob(rng, n) for n in (1, 4, 5, 17, 1300)]
