@@ -136,7 +136,7 @@ def also_measurements():
             rf = j.get("roofline") or {}
             e.update({"gi_frame_ms": j["gi_frame_ms"], "fps": round(1000.0 / j["gi_frame_ms"], 1), "mrays_per_s": j["value"], "workload": j["config"]["workload"][:120],
                       "rays_per_frame": j["config"]["rays_per_frame"], "segment_ms": j.get("segment_ms"), "pass_ms": j.get("pass_ms"),
-                      "roofline": {k: rf.get(k) for k in ("kernel", "bound", "avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac")}})
+                      "roofline": {k: rf.get(k) for k in ("kernel", "bound", "limited_by", "avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac")}})
         else:
             e.update({"frame_ms": j["frame_ms"], "fps": j["fps"], "mrays_per_s": j["mrays_per_s"], "workload": j["workload"], "segment_ms": j["segment_ms"], "rays_per_frame": j["rays_per_frame"],
                       "overlap": j.get("overlap")})
@@ -418,14 +418,16 @@ def main():
         # scripts/pmc_collect.sh on this workload; rocprofv3 cannot run inside this process), FETCH_SIZE doubled per the microarch
         # guide's gfx950 correction, and `hbm_frac` = traffic / launch time / peak: what the memory system actually moved. For the ray
         # kernel the two differ by design: its algorithmic bytes are BVH nodes and triangles that live in L2 / Infinity Cache.
-        pmc = {}
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_kernels.json")))
-            wl = pm["workload"]
-            if (wl["scene"], wl["tris"], wl["width"], wl["height"]) == (args.scene, args.tris, W, H):
-                pmc = pm["kernels"]
-        except Exception:
-            pmc = {}
+        pmc, pmc_file = {}, None
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_kernels*.json"))):      # one file per profiled workload (scripts/pmc_collect.sh)
+            try:
+                pm = json.load(open(path))
+                wl = pm["workload"]
+                if (wl["scene"], wl["tris"], wl["width"], wl["height"]) == (args.scene, args.tris, W, H):
+                    pmc, pmc_file = pm["kernels"], os.path.relpath(path, ROOT)
+            except Exception:
+                continue
         n_h2, n_f = hw * hh * strip_frac, W * H * strip_frac
         # pass -> (kernel name as rocprofv3 prints it, units per launch, algorithmic bytes per unit [SURVEY 8d table])
         table = [("rtdgi reproject", "k_fullres_reproject", n_f, 24), ("extract half", "k_extract_half", n_h2, 30), ("validity integrate", "k_validity_integrate", n_h2, 25),
@@ -446,12 +448,25 @@ def main():
             for src, dst in (("VALUBusy", "valu_busy_pct"), ("VALUUtilization", "valu_lane_utilization_pct"), ("MemUnitStalled", "mem_unit_stalled_pct")):
                 if k and src in k:
                     e[dst] = round(k[src], 1)
+            # `bound` names the roofline `achieved` is priced against (the contract's "hbm" | "mfma"; this path has no dense contraction).
+            # `limited_by` is what the counters of the same kernel say actually limits it.
+            vb, hf, ms_ = e.get("valu_busy_pct"), e.get("hbm_frac"), e.get("mem_unit_stalled_pct")
+            if vb is None or hf is None:
+                e["limited_by"] = None
+            elif hf >= 0.6:
+                e["limited_by"] = f"hbm bandwidth (traffic at {hf:.2f} of peak)"
+            elif vb >= 75.0:
+                e["limited_by"] = f"valu issue (VALUBusy {vb:.0f} %)"
+            elif ms_ is not None and ms_ >= 20.0:
+                e["limited_by"] = f"memory unit (MemUnitStalled {ms_:.0f} %)"
+            else:
+                e["limited_by"] = f"latency: neither the VALUs ({vb:.0f} % busy) nor HBM ({hf:.2f} of peak) saturated -- dependent loads / occupancy"
             if note:
                 e["note"] = note
             return e
         ray_kernel = "k_rtdgi_trace_fused<false>"
         roofline = entry(ray_kernel, trace_ms, trace_bytes)
-        roofline.update({"traffic_source": "profiles/pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md)" if roofline["traffic"] else None,
+        roofline.update({"traffic_source": f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md)" if roofline["traffic"] else None,
                          "nodes_per_closest_ray": round(nodes_per_closest, 2), "tris_per_closest_ray": round(tris_per_closest, 2),
                          "nodes_per_any_ray": round(nodes_per_any, 2), "tris_per_any_ray": round(tris_per_any, 2), "dominant_by_time": dom_name})
         roofline.update(trace_rays_note)
