@@ -392,6 +392,9 @@ __global__ void __launch_bounds__(PLOC_BLOCK) k_ploc_compact(const uint32_t* __r
 // boxes and nearest neighbours in LDS, a barrier where the multi-launch rounds have a kernel boundary. (The tail is where rounds are
 // many and small: a 2 k-triangle mesh takes 36 rounds, a 250 k-triangle one ~50, the last ~25 of them on fewer than a thousand clusters.)
 #define PLOC_TAIL 1024
+#ifndef KJ_LBVH_BATCH
+#define KJ_LBVH_BATCH 14u      // collapse levels issued between two read-backs (tests build a variant with 3 to walk the continuation)
+#endif
 KJ_D uint32_t tail_exclusive_scan(uint32_t v, uint32_t* lds /*[PLOC_TAIL]*/, uint32_t* total) {
     const uint32_t t = threadIdx.x;
     lds[t] = v;
@@ -590,16 +593,14 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
         else KJ_LB(hipMemsetAsync(parent, 0xff, 8, s));
         hipLaunchKernelGGL(k_lbvh_refit, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ids2, int(n), (const uint2*)children, (const uint32_t*)parent, visits, nbox);
     }
-    // collapse, level by level, without a read-back per level: counters = {-, nodes allocated, max stack}; queue_len[l] = items of level l;
-    // level_nodes[l] = nodes allocated before level l's children (a level's nodes are one contiguous run). KJ_LBVH_LEVELS levels are
-    // issued blind -- far more than a tree over distinct Morton codes needs (13 for 250 k triangles) --, then ONE read-back; a deeper
-    // tree (many coincident centroids) continues level by level with a read-back each.
-    constexpr uint32_t KJ_LBVH_LEVELS = 40;
-    KJ_LB(scratch->queue_len.alloc((KJ_LBVH_LEVELS + 2) * 4, s)); KJ_LB(scratch->level_nodes.alloc((KJ_LBVH_LEVELS + 2) * 4, s));      // (no-ops after the first mesh)
+    // collapse, level by level: counters = {-, nodes allocated, max stack}; queue_len[l] = items of level l (the kernel of level l appends to
+    // queue_len[l + 1]); level_nodes[l] = nodes allocated before level l's children (a level's nodes are one contiguous run). Levels are
+    // issued KJ_LBVH_BATCH at a time without looking at the queues -- every launch is sized by the bound 4^level, <= one item per triangle --,
+    // then ONE read-back says whether the tree goes deeper (a 250 k-triangle mesh has ~13 levels; many coincident centroids make deep ones).
+    KJ_LB(scratch->queue_len.alloc((KJ_LBVH_BATCH + 2) * 4, s)); KJ_LB(scratch->level_nodes.alloc((KJ_LBVH_BATCH + 2) * 4, s));      // (no-ops after the first mesh)
     uint32_t* const queue_len = (uint32_t*)scratch->queue_len.p;
     uint32_t* const level_nodes = (uint32_t*)scratch->level_nodes.p;
-    KJ_LB(hipMemsetAsync(queue_len, 0, (KJ_LBVH_LEVELS + 2) * 4, s)); KJ_LB(hipMemsetAsync(level_nodes, 0, (KJ_LBVH_LEVELS + 2) * 4, s));
-    const uint32_t init_counters[4] = {0u, 1u, 0u, 0u}, one = 1u;
+    const uint32_t init_counters[4] = {0u, 1u, 0u, 0u};
     const CollapseItem root{0u, 0u, 0u};
     void* qin = q0; void* qout = q1;
     auto collapse = [&](uint32_t items, uint32_t level) {
@@ -611,36 +612,32 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
                                 counters, d_nodes_out, node_base);
     };
     KJ_LB(hipMemcpyAsync(counters, init_counters, 16, hipMemcpyHostToDevice, s));
-    KJ_LB(hipMemcpyAsync(queue_len, &one, 4, hipMemcpyHostToDevice, s));
-    KJ_LB(hipMemcpyAsync(level_nodes + 1, &one, 4, hipMemcpyHostToDevice, s));      // level 0 = the root = node 0
     if (ploc) hipLaunchKernelGGL(k_ploc_root, dim3(1), dim3(1), 0, s, (const uint32_t*)clusters, (PlocItem*)q0);
     else KJ_LB(hipMemcpyAsync(q0, &root, sizeof(root), hipMemcpyHostToDevice, s));
-    uint64_t bound = 1;
-    for (uint32_t level = 0; level < KJ_LBVH_LEVELS; ++level) {
-        collapse(uint32_t(std::min<uint64_t>(bound, n)), level);
-        hipLaunchKernelGGL(k_lbvh_level_end, dim3(1), dim3(1), 0, s, (const uint32_t*)counters, level_nodes, level + 1);
-        bound = std::min<uint64_t>(bound * 4, uint64_t(n));
-        std::swap(qin, qout);
-    }
-    uint32_t host_counters[4] = {0, 1, 0, 0}, host_levels[KJ_LBVH_LEVELS + 2], host_queue[KJ_LBVH_LEVELS + 2];
-    KJ_LB(hipMemcpyAsync(host_levels, level_nodes, sizeof(host_levels), hipMemcpyDeviceToHost, s));
-    KJ_LB(hipMemcpyAsync(host_queue, queue_len, sizeof(host_queue), hipMemcpyDeviceToHost, s));
-    KJ_LB(hipMemcpyAsync(host_counters, counters, 16, hipMemcpyDeviceToHost, s));
-    KJ_LB(hipStreamSynchronize(s));
+    uint32_t host_counters[4] = {0, 1, 0, 0}, host_levels[KJ_LBVH_BATCH + 2], host_queue[KJ_LBVH_BATCH + 2];
     result->level_starts.assign({0u});
-    for (uint32_t l = 1; l <= KJ_LBVH_LEVELS + 1; ++l)
-        if (host_levels[l] > result->level_starts.back()) result->level_starts.push_back(host_levels[l]);
-    uint32_t in_count = host_queue[KJ_LBVH_LEVELS];
-    while (in_count) {      // deeper than the blind part: one level at a time
-        const uint32_t lens[2] = {in_count, 0u};
-        KJ_LB(hipMemcpyAsync(queue_len, lens, 8, hipMemcpyHostToDevice, s));
-        collapse(in_count, 0u);
-        KJ_LB(hipMemcpyAsync(host_queue, queue_len, 8, hipMemcpyDeviceToHost, s));
+    uint64_t bound = 1;
+    uint32_t in_count = 1u, nodes_before = 1u;      // level 0 = the root = node 0
+    while (in_count) {
+        uint32_t queue_head[KJ_LBVH_BATCH + 2] = {}, level_head[KJ_LBVH_BATCH + 2] = {};
+        queue_head[0] = in_count; level_head[1] = nodes_before;
+        KJ_LB(hipMemcpyAsync(queue_len, queue_head, sizeof(queue_head), hipMemcpyHostToDevice, s));
+        KJ_LB(hipMemcpyAsync(level_nodes, level_head, sizeof(level_head), hipMemcpyHostToDevice, s));
+        for (uint32_t level = 0; level < KJ_LBVH_BATCH; ++level) {
+            collapse(uint32_t(std::min<uint64_t>(std::max<uint64_t>(bound, in_count), n)), level);
+            hipLaunchKernelGGL(k_lbvh_level_end, dim3(1), dim3(1), 0, s, (const uint32_t*)counters, level_nodes, level + 1);
+            bound = std::min<uint64_t>(std::max<uint64_t>(bound, in_count) * 4, uint64_t(n));
+            std::swap(qin, qout);
+        }
+        KJ_LB(hipMemcpyAsync(host_levels, level_nodes, sizeof(host_levels), hipMemcpyDeviceToHost, s));
+        KJ_LB(hipMemcpyAsync(host_queue, queue_len, sizeof(host_queue), hipMemcpyDeviceToHost, s));
         KJ_LB(hipMemcpyAsync(host_counters, counters, 16, hipMemcpyDeviceToHost, s));
         KJ_LB(hipStreamSynchronize(s));
-        in_count = host_queue[1];
-        if (host_counters[1] > result->level_starts.back()) result->level_starts.push_back(host_counters[1]);
-        std::swap(qin, qout);
+        for (uint32_t l = 1; l <= KJ_LBVH_BATCH + 1; ++l)
+            if (host_levels[l] > result->level_starts.back()) result->level_starts.push_back(host_levels[l]);
+        in_count = host_queue[KJ_LBVH_BATCH];
+        nodes_before = host_counters[1];
+        if (result->level_starts.size() > 4096) return hipErrorUnknown;
     }
     hipLaunchKernelGGL(k_lbvh_emit_tris, g, b, 0, s, d_vertex_buffer, mesh, ploc ? (const uint32_t*)tri_order : (const uint32_t*)ids2, n, d_tris_out);
     uint32_t hob[8];

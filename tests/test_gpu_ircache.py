@@ -102,7 +102,11 @@ def one_frame_on_identical_state(gpu, oracle, device, scene_name, W, H):
         live = ia
         num = np.sqrt(((irr_a[live] - irr_b[live]) ** 2).sum()); den = np.sqrt((irr_a[live] ** 2).sum())
         print("ircache SH rel-L2 on identical state:", num / den, "entries", len(live))
-        assert num / den < 2e-2
+        # A statistical bar, not the parity bar: in this (the reference's racy) mode a lookup sees however many of the same pass' updates
+        # happen to have landed -- the sequential oracle sees all earlier ones, the GPU with four lanes per path and four times the waves in
+        # flight sees fewer (measured 1.1e-2 with one lane per path, 2.3e-2 with four, 1080p city). Parity of the cache is held at 1e-3 by
+        # the deterministic mode on both sides (deterministic_frames_on_identical_state below).
+        assert num / den < 5e-2
     finally:
         oracle.lib().okj_set_threads(oracle.lib().okj_get_max_threads())
 
