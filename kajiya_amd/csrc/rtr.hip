@@ -7,58 +7,11 @@
 // Where the reference leaves a result undefined this file picks the same value as the oracle (oracle/okj_rtr.hpp header):
 // the validate pass' partially written invalidity image is cleared first, a zero-length history ray is traced along +Z,
 // B10G11R11_UFLOAT stores round to nearest through fp16, resolve's sample-shadowing test ignores rounding-residue offsets.
-#include "kj_host.hpp"
-#include "kj_scene.hpp"
-#include "kj_reservoir.hpp"
+#include "kj_rtr.hpp"
 #include "kj_ircache.hpp"
 #include "kj_ircache_host.hpp"
 
-using namespace kj;
 namespace kj { SceneView scene_view(const KjScene& s); }
-
-#define SKY_DIST 1e4f
-#define RTR_ROUGHNESS_CLAMP 6e-4f
-#define RTR_RESTIR_MAX_PDF_CLAMP 200.0f
-#define RTR_RESTIR_TEMPORAL_M_CLAMP 8.0f
-#define RTR_NEIGHBOR_RAY_ORIGIN_CENTER_BIAS 0.5f
-#define RTR_SAMPLING_BIAS 0.15f
-
-typedef Img<uint2> ImgH4;     // RGBA16F
-typedef Img<uint32_t> ImgU32; // RGBA8_SNORM / RG16F / A2R10G10B10 / B10G11R11_UFLOAT / R32_UINT
-typedef Img<float> ImgF32;
-typedef Img<uint4> ImgU4;
-typedef Img<uint2> ImgU2;     // RG32UI (reservoirs) and RGBA16_SNORM share the 8-byte texel
-typedef Img<uint8_t> ImgR8;
-typedef Img<float4> ImgF4;
-
-#define TILE_XY(W_, H_)                                                   \
-    const int lane = threadIdx.x;                                         \
-    const uint2 kj_tb = kj::tile_order<KJ_TILES_PLAIN>();                 \
-    const int x = int(kj_tb.x) * 8 + (lane & 7), y = int(kj_tb.y) * 8 + (lane >> 3); \
-    const bool in_image = x < (W_) && y < (H_);
-
-// ------------------------------------------------------------------ small device helpers
-KJ_D V3 get_prev_eye_position(const FrameConstants& fc) { const V4 e = mul44(fc.view_constants.prev_view_to_prev_world, V4{0, 0, 0, 1}); return xyz(e) / e.w; }
-KJ_D V3 position_world_to_view(const FrameConstants& fc, V3 v) { return xyz(mul44(fc.view_constants.world_to_view, v4(v, 1))); }
-KJ_D float depth_to_view_z(const FrameConstants& fc, float depth) { return 1.0f / (depth * -fc.view_constants.clip_to_view[11]); }
-KJ_D I2 hi_px_subpixel(uint32_t k) { return halfres_subsample_offset(k); }   // hi_px_subpixels[k & 3]
-KJ_D float ggx_ndf_0_1(float a2, float cos_theta) { const float d = cos_theta * cos_theta * (a2 - 1.0f) + 1.0f; return a2 * a2 / (d * d); }
-KJ_D float exponential_squish(float len, float s) { return exp2f(-clampf(s * len, 0.0f, 100.0f)); }
-KJ_D float exponential_unsquish(float len, float s) { return fmaxf(0.0f, -1.0f / s * log2f(1e-30f + len)); }
-KJ_D V3 soft_color_clamp(V3 center, V3 history, V3 ex, V3 dev) {
-    const V3 history_dist = vabs(history - ex) / vmax(vabs(history * 0.1f), dev);
-    const V3 closest_pt = vclamp(history, center - dev, center + dev);
-    return V3{lerp(history.x, closest_pt.x, smoothstep(1.0f, 3.0f, history_dist.x)), lerp(history.y, closest_pt.y, smoothstep(1.0f, 3.0f, history_dist.y)),
-              lerp(history.z, closest_pt.z, smoothstep(1.0f, 3.0f, history_dist.z))};
-}
-// rtr_restir_pack_unpack.inc.hlsl
-struct RtrRestirRayOrigin { V3 ray_origin_eye_offset_ws; float roughness; uint32_t frame_index_mod4; };
-KJ_D RtrRestirRayOrigin ray_origin_from_raw(float4 raw) {
-    const V2 misc = unpack_2x16f_uint(asuint(raw.w));
-    return RtrRestirRayOrigin{V3{raw.x, raw.y, raw.z}, misc.x, uint32_t(misc.y) & 3u};
-}
-KJ_D float4 ray_origin_to_raw(V3 o, float roughness, uint32_t frame_index_mod4) { return make_float4(o.x, o.y, o.z, asfloat(pack_2x16f_uint(roughness, float(frame_index_mod4)))); }
-
 struct FgLut { V3 preintegrated_reflection, preintegrated_reflection_mult; float valid_sample_fraction; };
 KJ_D FgLut specular_energy_preservation(const uint2* __restrict__ fg_lut, float roughness, V3 specular_albedo, float ndotv) {   // brdf_lut.hlsl:15-93
     const float s = 63.0f / 64.0f, b = 0.5f / 64.0f;
@@ -468,327 +421,6 @@ __global__ void __launch_bounds__(64) k_rtr_restir_temporal(RtrTemporalArgs a) {
     a.reservoir_out_tex.st(x, y, reservoir.as_raw());
 }
 
-// ------------------------------------------------------------------ resolve.hlsl:66-663 (USE_RESTIR, CUT_CORNERS_IN_MATH, BORROW_SAMPLES)
-struct RtrResolveArgs {
-    const FrameConstants* fc;
-    ImgU4 gbuffer_tex; ImgF32 depth_tex; ImgH4 hit1_tex; ImgU2 reprojection_tex; ImgU32 half_view_normal_tex; ImgU32 ray_len_history_tex;
-    ImgH4 restir_irradiance_tex, restir_ray_tex; ImgU2 restir_reservoir_tex; ImgF4 restir_ray_orig_tex;
-    ImgU32 output_tex; ImgU32 ray_len_output_tex;
-    const uint32_t* blue_noise; const uint2* brdf_fg_lut;
-};
-__global__ void __launch_bounds__(64) k_rtr_resolve(RtrResolveArgs a) {
-    TILE_XY(a.output_tex.w, a.output_tex.h)
-    if (!in_image) return;
-    const FrameConstants& fc = *a.fc;
-    const int hpx = x / 2, hpy = y / 2;
-    const V4 ots = tex_size4(a.output_tex.w, a.output_tex.h);
-    const V2 uv = get_uv(float(x), float(y), ots);
-    const float depth = a.depth_tex.ld(x, y);
-    if (0.0f == depth) { a.output_tex.st(x, y, 0u); return; }
-    GbufferData gbuffer = gbuffer_unpack(a.gbuffer_tex.ld(x, y));
-    const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
-    const V3 refl_ray_origin_ws = vr.biased_secondary_ray_origin_ws_with_normal(gbuffer.normal);
-    const V3 refl_ray_origin_vs = position_world_to_view(fc, refl_ray_origin_ws);
-    gbuffer.roughness = fmaxf(gbuffer.roughness, RTR_ROUGHNESS_CLAMP);
-    const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
-    V3 wo = to_local(tangent_to_world, -vr.dir_ws);
-    if (wo.z < 0.0f) { wo.z *= -0.25f; wo = normalize(wo); }
-    const LayeredBrdf lb = layered_brdf_from_gbuffer_ndotv(a.brdf_fg_lut, gbuffer, wo.z);
-    const uint32_t px_idx_in_quad = ((uint32_t(x & 1) | uint32_t(y & 1) * 2u) + fc.frame_index) & 3u;
-    const float a2 = fmaxf(RTR_ROUGHNESS_CLAMP, gbuffer.roughness) * fmaxf(RTR_ROUGHNESS_CLAMP, gbuffer.roughness);
-    const float surf_to_hit_dist = length(xyz(ld4(a.hit1_tex, hpx, hpy)));
-    const float eye_to_surf_dist = length(refl_ray_origin_vs);
-    V3 ray_dir_vs;
-    {
-        const V2 cs = uv_to_cs(uv);
-        ray_dir_vs = normalize(xyz(mul44(fc.view_constants.sample_to_view, V4{cs.x, cs.y, 0.0f, 1.0f})));
-    }
-    const float eye_ray_z_scale = -ray_dir_vs.z;
-    const V4 reprojection_params = ld_reproj(a.reprojection_tex, x, y);
-    const float ray_squish_scale = 16.0f / fmaxf(1e-5f, eye_to_surf_dist);
-    const float ray_len_avg = exponential_unsquish(lerp(
-        exponential_squish(sample_bilinear_clamp_rg16f(a.ray_len_history_tex.p, a.ray_len_history_tex.w, a.ray_len_history_tex.h, V2{uv.x + reprojection_params.x, uv.y + reprojection_params.y}).y, ray_squish_scale),
-        exponential_squish(surf_to_hit_dist, ray_squish_scale), 0.1f), ray_squish_scale);
-    V4 contrib_accum = v4(0.0f);
-    float ray_len_accum = 0.0f;
-    const V3 normal_vs = direction_world_to_view(fc, gbuffer.normal);
-    const float tan_theta = sqrtf(gbuffer.roughness) * 0.25f;
-    const float clip_to_view_11 = fc.view_constants.clip_to_view[5];
-    float kernel_size_ws;
-    {
-        const float clamped_ray_len_avg = fmaxf(ray_len_avg, eye_to_surf_dist / eye_ray_z_scale * clip_to_view_11 * 0.2f * smoothstep(0.0f, 0.05f * eye_to_surf_dist, ray_len_avg));
-        const float kernel_size_vs = clamped_ray_len_avg / (clamped_ray_len_avg + eye_to_surf_dist);
-        kernel_size_ws = kernel_size_vs * eye_to_surf_dist * eye_ray_z_scale;
-        kernel_size_ws *= tan_theta;
-    }
-    {
-        const float scale_factor = eye_to_surf_dist * eye_ray_z_scale * clip_to_view_11;
-        kernel_size_ws = fminf(kernel_size_ws, 0.1f * scale_factor);
-        kernel_size_ws = fmaxf(kernel_size_ws, ots.w * 4.0f * scale_factor);
-    }
-    V3 kernel_t1, kernel_t2;
-    {   // get_specular_filter_kernel_basis (resolve.hlsl:72-79) with specular_dominant_direction (brdf.hlsl:313-317)
-        const V3 v = -vr.dir_ws, n = gbuffer.normal;
-        const V3 r = reflect(-v, n);
-        const float f = (1.0f - gbuffer.roughness) * (sqrtf(1.0f - gbuffer.roughness) + gbuffer.roughness);
-        const V3 dominant = normalize(lerp(n, r, f));
-        const V3 reflected = reflect(-dominant, n);
-        kernel_t1 = normalize(cross(n, reflected)) * kernel_size_ws;
-        kernel_t2 = cross(reflected, kernel_t1);
-    }
-    const V4 blue = blue_noise_for_pixel(a.blue_noise, uint32_t(hpx + 16), uint32_t(hpy + 16), fc.frame_index);
-    const float KERNEL_SHARPNESS = 0.666f;
-    const float RADIUS_SAMPLE_MULT = 1.0f / powf(8.0f, KERNEL_SHARPNESS);
-    const float ang_offset = float(fc.frame_index * 59u % 128u) * KJ_PLASTIC;
-    const float RADIUS_INC_ON_FAIL = 0.25f;
-    const V3 eye = get_eye_position(fc);
-    float sample_radius_accum = 1.0f;
-    for (uint32_t sample_i = 1; sample_i <= 8u; ++sample_i, sample_radius_accum += RADIUS_INC_ON_FAIL) {
-        const bool is_center_sample = sample_i == 8u;
-        int sample_px_x, sample_px_y;
-        {
-            // ang reaches several hundred radians (ulp 3e-5): a fused multiply-add here moves the tap by ~1e-4 px and flips which
-            // half-res pixel it lands in for ~0.5 % of the pixels, so the two roundings of the shader's expression are kept
-            const float ang = __fadd_rn(__fmul_rn(float(sample_i) + ang_offset, KJ_GOLDEN_ANGLE), (float(px_idx_in_quad) / 4.0f) * KJ_TAU);
-            float sample_i_with_jitter = sample_radius_accum;
-            if (is_center_sample) sample_i_with_jitter = contrib_accum.w > 1e-8f ? blue.y : 0.0f;
-            else sample_i_with_jitter += blue.y;
-            const float radius = powf(sample_i_with_jitter, KERNEL_SHARPNESS) * RADIUS_SAMPLE_MULT;
-            const V3 offset_ws = (cosf(ang) * kernel_t1 + sinf(ang) * kernel_t2) * radius;
-            const V3 sample_ws = refl_ray_origin_ws + offset_ws;
-            const V3 sample_cs = position_world_to_sample(fc, sample_ws);
-            const V2 sample_uv = cs_to_uv(V2{sample_cs.x, sample_cs.y});
-            sample_px_x = int(floorf(sample_uv.x * ots.x / 2.0f));
-            sample_px_y = int(floorf(sample_uv.y * ots.y / 2.0f));
-        }
-        float rejection_bias = 1.0f;
-        const V3 sample_normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, sample_px_x, sample_px_y);
-        float pdf0_mult = 1.0f, pdf1_mult = 1.0f;
-        const uint2 reservoir_raw = a.restir_reservoir_tex.ld(sample_px_x, sample_px_y);
-        const Reservoir1spp r = Reservoir1spp::from_raw(reservoir_raw);
-        const int spx = int(r.payload & 0xffffu), spy = int(r.payload >> 16);
-        const RtrRestirRayOrigin sample_origin = ray_origin_from_raw(a.restir_ray_orig_tex.ld(spx, spy));
-        const V3 sample_origin_ws = sample_origin.ray_origin_eye_offset_ws + eye;
-        if (reservoir_raw.x == 0u || sample_origin.roughness > gbuffer.roughness * 2.0f) continue;
-        const V4 restir_ray = ld4(a.restir_ray_tex, spx, spy);
-        const V3 sample_hit_ws = xyz(restir_ray) + sample_origin_ws;
-        const V3 sample_origin_vs = position_world_to_view(fc, sample_origin_ws);
-        const V4 restir_irr = ld4(a.restir_irradiance_tex, spx, spy);
-        const V3 sample_radiance = xyz(restir_irr);
-        const float sample_ray_pdf = restir_ray.w;
-        const float neighbor_sampling_pdf = 1.0f / r.W;
-        const V3 sample_hit_vs_abs = position_world_to_view(fc, sample_hit_ws);
-        const V3 center_to_hit_vs = sample_hit_vs_abs - lerp(refl_ray_origin_vs, sample_origin_vs, RTR_NEIGHBOR_RAY_ORIGIN_CENTER_BIAS);
-        const float sample_cos_theta = 1.0f - restir_irr.w;
-        const float center_to_hit_dist = length(center_to_hit_vs);
-        const float sample_to_hit_dist = length(sample_hit_ws - sample_origin_ws);
-        {
-            const float d = length(sample_hit_vs_abs - lerp(refl_ray_origin_vs, sample_origin_vs, lerp(1.0f, RTR_NEIGHBOR_RAY_ORIGIN_CENTER_BIAS, 0.4f * fminf(1.0f, 3.0f * sqrtf(gbuffer.roughness)))));
-            pdf0_mult *= fmaxf(1e-5f, powf(d / sample_to_hit_dist, 2.0f));
-            pdf1_mult *= fmaxf(1.0f, powf(center_to_hit_dist / sample_to_hit_dist, 2.0f));
-        }
-        const V3 wi = normalize(to_local(tangent_to_world, direction_view_to_world(fc, center_to_hit_vs)));
-        if (wi.z < 1e-5f) continue;
-        rejection_bias *= dot(normal_vs, sample_normal_vs) > 0.7f ? 1.0f : 0.0f;
-        {
-            const float depth_diff = fabsf(refl_ray_origin_vs.z - sample_origin_vs.z) / fmaxf(1e-10f, kernel_size_ws);
-            rejection_bias *= exp2f(-fmaxf(0.3f, normal_vs.z) * depth_diff * depth_diff);
-        }
-        const V3 surface_offset = sample_origin_vs - refl_ray_origin_vs;
-        // own half-res sample: the offset is a rounding residue (0/0 or a random direction in the shader) -> no rejection, as in the oracle
-        const float surface_offset_len = length(surface_offset);
-        if (surface_offset_len > 1e-5f * eye_to_surf_dist &&
-            dot(center_to_hit_vs, normal_vs) * 0.2f / length(center_to_hit_vs) < dot(surface_offset, normal_vs) / surface_offset_len) rejection_bias *= is_center_sample ? 1.0f : 0.0f;
-        const BrdfValue spec = specular_evaluate(lb.roughness, lb.spec_albedo, wo, wi);
-        const float spec_weight = spec.pdf * stepf(0.0f, wi.z);
-        float contrib_wt = 0.0f;
-        {
-            const float cos_theta = normalize(wo + wi).z;
-            const float bent_cos_theta = fminf(sample_cos_theta, cos_theta * 1.25f);
-            const float sample_ray_ndf = ggx_ndf(a2, bent_cos_theta);
-            const float center_ndf = ggx_ndf(a2, cos_theta);
-            const float bent_sample_pdf0 = spec.pdf * sample_ray_ndf / center_ndf;
-            const float pdf_lerp_t = smoothstep(0.4f, 0.7f, sqrtf(gbuffer.roughness)) * smoothstep(0.0f, 0.1f, ray_len_avg / eye_to_surf_dist);
-            const float pdf_x[2] = {fminf(bent_sample_pdf0, RTR_RESTIR_MAX_PDF_CLAMP), fminf(spec.pdf, RTR_RESTIR_MAX_PDF_CLAMP)};
-            const float pdf_y[2] = {neighbor_sampling_pdf * pdf0_mult, neighbor_sampling_pdf * pdf1_mult};
-            const float pdf_z[2] = {1.0f - pdf_lerp_t, pdf_lerp_t};
-#pragma unroll
-            for (int pdf_i = 0; pdf_i < 2; ++pdf_i) {
-                const float bent_sample_pdf = pdf_x[pdf_i], nsp = pdf_y[pdf_i], pdf_influence = pdf_z[pdf_i];
-                const float mis_weight = fmaxf(1e-4f, spec.pdf / (sample_ray_pdf + spec.pdf));
-                contrib_wt = rejection_bias * mis_weight * fmaxf(1e-10f, spec_weight / bent_sample_pdf);
-                contrib_accum = contrib_accum + v4(sample_radiance * bent_sample_pdf / nsp * spec.value_over_pdf, 1.0f) * contrib_wt * pdf_influence;
-            }
-        }
-        ray_len_accum += exponential_squish(surf_to_hit_dist, ray_squish_scale) * contrib_wt;
-        sample_radius_accum += 1.0f - RADIUS_INC_ON_FAIL;
-    }
-    const float contrib_norm_factor = fmaxf(1e-14f, contrib_accum.w);
-    V3 rgb = xyz(contrib_accum) / contrib_norm_factor;
-    ray_len_accum /= contrib_norm_factor;
-    rgb = rgb / lb.preintegrated_reflection;
-    rgb = rgb * lb.preintegrated_reflection_mult;
-    ray_len_accum = exponential_unsquish(ray_len_accum, ray_squish_scale);
-    a.output_tex.st(x, y, pack_r11g11b10f(rgb));
-    st2h(a.ray_len_output_tex, x, y, V2{ray_len_accum, ray_len_avg});
-}
-
-// image_sample_catmull_rom_5tap (inc/image.hlsl:88-172) with the identity remap
-KJ_D V4 catmull_rom_5tap(const ImgH4& tex, V2 uv, V2 tex_size) {
-    const V2 sample_pos = uv * tex_size;
-    const V2 tex_pos1{floorf(sample_pos.x - 0.5f) + 0.5f, floorf(sample_pos.y - 0.5f) + 0.5f};
-    const V2 f = sample_pos - tex_pos1;
-    const V2 w0 = f * (-0.5f + f * (1.0f - 0.5f * f));
-    const V2 w1 = 1.0f + f * f * (-2.5f + 1.5f * f);
-    const V2 w2 = f * (0.5f + f * (2.0f - 1.5f * f));
-    const V2 w3 = f * f * (-0.5f + 0.5f * f);
-    const V2 w12 = w1 + w2;
-    const V2 offset12 = w2 / (w1 + w2);
-    const V2 p0 = (tex_pos1 - 1.0f) / tex_size, p3 = (tex_pos1 + 2.0f) / tex_size, p12 = (tex_pos1 + offset12) / tex_size;
-    V4 result = v4(0.0f);
-    result += sample_bilinear_clamp_rgba16f(tex.p, tex.w, tex.h, V2{p12.x, p0.y}) * (w12.x * w0.y);
-    result += sample_bilinear_clamp_rgba16f(tex.p, tex.w, tex.h, V2{p0.x, p12.y}) * (w0.x * w12.y);
-    result += sample_bilinear_clamp_rgba16f(tex.p, tex.w, tex.h, V2{p12.x, p12.y}) * (w12.x * w12.y);
-    result += sample_bilinear_clamp_rgba16f(tex.p, tex.w, tex.h, V2{p3.x, p12.y}) * (w3.x * w12.y);
-    result += sample_bilinear_clamp_rgba16f(tex.p, tex.w, tex.h, V2{p12.x, p3.y}) * (w12.x * w3.y);
-    return result / (w12.x * w0.y + w0.x * w12.y + w12.x * w12.y + w3.x * w12.y + w12.x * w3.y);
-}
-
-// ------------------------------------------------------------------ temporal_filter.hlsl:37-259
-__global__ void __launch_bounds__(64) k_rtr_temporal_filter(const FrameConstants* __restrict__ fcp, ImgU32 input_tex, ImgH4 history_tex, ImgF32 depth_tex, ImgU32 ray_len_tex,
-                                                             ImgU2 reprojection_tex, ImgR8 refl_restir_invalidity_tex, ImgU4 gbuffer_tex, ImgH4 output_tex) {
-    TILE_XY(output_tex.w, output_tex.h)
-    if (!in_image) return;
-    const FrameConstants& fc = *fcp;
-    const V4 ots = tex_size4(output_tex.w, output_tex.h);
-    auto ld_in = [&](int sx, int sy) { return input_tex.inb(sx, sy) ? v4(unpack_r11g11b10f(input_tex.ld(sx, sy)), 1.0f) : v4(0.0f); };
-    const V4 center = linear_rgb_to_crunched_luma_chroma(ld_in(x, y));
-    const float refl_ray_length = clampf(ld2h(ray_len_tex, x, y).x, 0.0f, 1e3f);
-    const V2 uv = get_uv(float(x), float(y), ots);
-    const float center_depth = depth_tex.ld(x, y);
-    const ViewRay vr = view_ray_from_uv_and_depth(fc, uv, center_depth);
-    V3 ray_dir_vs;
-    {
-        const V2 cs = uv_to_cs(uv);
-        ray_dir_vs = normalize(xyz(mul44(fc.view_constants.sample_to_view, V4{cs.x, cs.y, 0.0f, 1.0f})));
-    }
-    const V3 reflection_hit_vs = vr.hit_vs + ray_dir_vs * refl_ray_length;
-    const V4 reflection_hit_cs = mul44(fc.view_constants.view_to_sample, v4(reflection_hit_vs, 1.0f));
-    const V4 prev_hit_cs = mul44(fc.view_constants.clip_to_prev_clip, reflection_hit_cs);
-    V2 hit_prev_uv = cs_to_uv(V2{prev_hit_cs.x / prev_hit_cs.w, prev_hit_cs.y / prev_hit_cs.w});
-    const V4 prev_reflector_cs = mul44(fc.view_constants.clip_to_prev_clip, v4(vr.hit_cs, 1.0f));
-    const V2 reflector_prev_uv = cs_to_uv(V2{prev_reflector_cs.x / prev_reflector_cs.w, prev_reflector_cs.y / prev_reflector_cs.w});
-    const V4 reproj = ld_reproj(reprojection_tex, x, y);
-    const float reflector_move_rate = fminf(1.0f, length(V2{reproj.x, reproj.y}) / length(reflector_prev_uv - uv));
-    hit_prev_uv = lerp(uv, hit_prev_uv, reflector_move_rate);
-    const uint32_t quad_reproj_valid_packed = uint32_t(reproj.z * 15.0f + 0.5f);
-    const V4 history_mult{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1.0f};
-    V4 history0 = v4(0.0f);
-    float history0_valid = 1.0f;
-    const V2 reproj_uv{uv.x + reproj.x, uv.y + reproj.y};
-    if (0u == quad_reproj_valid_packed) {
-        history0_valid = 0.0f;
-    } else if (15u == quad_reproj_valid_packed) {
-        history0 = vmax(v4(0.0f), catmull_rom_5tap(history_tex, reproj_uv, V2{ots.x, ots.y})) * history_mult;
-    } else {
-        const V4 qv{(quad_reproj_valid_packed & 1u) ? 1.0f : 0.0f, (quad_reproj_valid_packed & 2u) ? 1.0f : 0.0f, (quad_reproj_valid_packed & 4u) ? 1.0f : 0.0f,
-                    (quad_reproj_valid_packed & 8u) ? 1.0f : 0.0f};
-        // get_bilinear_filter (inc/bilinear.hlsl)
-        const V2 pxf{reproj_uv.x * ots.x - 0.5f, reproj_uv.y * ots.y - 0.5f};
-        const V2 origin{floorf(pxf.x), floorf(pxf.y)};
-        const V2 wts{pxf.x - origin.x, pxf.y - origin.y};
-        const int ox = int(origin.x), oy = int(origin.y);
-        const V4 s00 = ld4(history_tex, ox, oy) * history_mult, s10 = ld4(history_tex, ox + 1, oy) * history_mult;
-        const V4 s01 = ld4(history_tex, ox, oy + 1) * history_mult, s11 = ld4(history_tex, ox + 1, oy + 1) * history_mult;
-        V4 w{(1.0f - wts.x) * (1.0f - wts.y), wts.x * (1.0f - wts.y), (1.0f - wts.x) * wts.y, wts.x * wts.y};
-        w = w * qv;
-        const float wsum = dot(w, v4(1.0f));
-        if (wsum > 1e-5f) history0 = (s00 * w.x + s10 * w.y + s01 * w.z + s11 * w.w) * (1.0f / wsum);
-        else history0 = (s00 + s10 + s01 + s11) / 4.0f;
-    }
-    history0 = linear_rgb_to_crunched_luma_chroma(history0);
-    const V4 history1 = linear_rgb_to_crunched_luma_chroma(sample_bilinear_clamp_rgba16f(history_tex.p, history_tex.w, history_tex.h, hit_prev_uv) * history_mult);
-    const float history1_valid = quad_reproj_valid_packed == 15u ? 1.0f : 0.0f;
-    V4 vsum = v4(0.0f), vsum2 = v4(0.0f);
-    float wsum = 0.0f;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const float sample_depth = depth_tex.ld(x + dx, y + dy);
-            const V4 neigh = linear_rgb_to_crunched_luma_chroma(ld_in(x + dx, y + dy));
-            const float w = exp2f(-200.0f * fabsf(center_depth / sample_depth - 1.0f));
-            vsum = vsum + neigh * w;
-            vsum2 = vsum2 + neigh * neigh * w;
-            wsum += w;
-        }
-    const V4 ex = vsum / wsum, ex2 = vsum2 / wsum;
-    const V4 dev = vsqrt(vmax(v4(0.0f), ex2 - ex * ex));
-    const GbufferData gbuffer = gbuffer_unpack(gbuffer_tex.ld(x, y));
-    const float restir_invalidity = from_unorm8(refl_restir_invalidity_tex.ld(x / 2, y / 2));
-    const float n_deviations = lerp(reproj.z > 0.0f ? 2.0f : 1.25f, 0.625f, restir_invalidity);
-    float wo_similarity;
-    {
-        const V3 current_wo = normalize(vr.hit_ws - get_eye_position(fc));
-        const V3 prev_wo = normalize(vr.hit_ws - get_prev_eye_position(fc));
-        const float clamped_roughness = fmaxf(0.1f, gbuffer.roughness);
-        wo_similarity = powf(saturate(ggx_ndf_0_1(clamped_roughness * clamped_roughness, dot(current_wo, prev_wo))), 32.0f);
-    }
-    const float h0diff = length((xyz(history0) - xyz(ex)) / xyz(dev));
-    const float h1diff = length((xyz(history1) - xyz(ex)) / xyz(dev));
-    float h0_score = 1.0f * smoothstep(0.0f, 0.5f, sqrtf(gbuffer.roughness)) * lerp(wo_similarity, 1.0f, sqrtf(gbuffer.roughness));
-    float h1_score = (1.0f - h0_score) * lerp(1.0f, smoothstep(0.0f, 1.0f, h0diff - h1diff), smoothstep(0.0f, 0.15f, sqrtf(gbuffer.roughness)));
-    h0_score *= history0_valid;
-    h1_score *= history1_valid;
-    const float score_sum = h0_score + h1_score;
-    h0_score /= score_sum;
-    h1_score = 1.0f - h0_score;
-    if (!(h0_score < 1.001f)) { h0_score = 1.0f; h1_score = 0.0f; }
-    const V4 clamped_history0 = v4(soft_color_clamp(xyz(center), xyz(history0), xyz(ex), xyz(dev) * n_deviations), history0.w);
-    const V4 clamped_history1 = v4(soft_color_clamp(xyz(center), xyz(history1), xyz(ex), xyz(dev) * n_deviations), history1.w);
-    const V4 clamped_history = clamped_history0 * h0_score + clamped_history1 * h1_score;
-    const float max_sample_count = 16.0f;
-    const float current_sample_count = clamped_history.w * saturate(h0_score * history0_valid + h1_score * history1_valid);
-    V4 res = lerp(clamped_history, center, 1.0f / (1.0f + fminf(max_sample_count, current_sample_count * lerp(wo_similarity, 1.0f, 0.5f))));
-    res.w = fminf(current_sample_count, max_sample_count) + 1.0f;
-    res = crunched_luma_chroma_to_linear_rgb(res);
-    st4(output_tex, x, y, vmax(v4(0.0f), res));
-}
-
-// ------------------------------------------------------------------ spatial_cleanup.hlsl:20-65
-__global__ void __launch_bounds__(64) k_rtr_cleanup(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgF32 depth_tex, ImgU32 geometric_normal_tex, ImgU32 output_tex,
-                                                     const int4* __restrict__ spatial_resolve_offsets) {
-    TILE_XY(output_tex.w, output_tex.h)
-    if (!in_image) return;
-    const FrameConstants& fc = *fcp;
-    const V4 center = ld4(input_tex, x, y);
-    const float center_depth = depth_tex.ld(x, y);
-    const float center_sample_count = center.w;
-    if (center_sample_count >= 8.0f || center_depth == 0.0f) { output_tex.st(x, y, pack_r11g11b10f(xyz(center))); return; }
-    const V3 center_normal_vs = unpack_a2r10g10b10(geometric_normal_tex.ld(x, y)) * 2.0f - 1.0f;
-    const float filter_radius_ss = 0.5f * fc.view_constants.view_to_clip[5] / -depth_to_view_z(fc, center_depth);
-    const uint32_t filter_idx = uint32_t(clampf(filter_radius_ss * 7.0f, 0.0f, 7.0f));
-    V3 vsum = v3(0.0f);
-    float wsum = 0.0f;
-    const int sc = int(8.0f - center_sample_count / 2.0f);
-    const uint32_t sample_count = uint32_t(min(max(sc, 2), 8));
-    const int kernel_scale = center_sample_count < 4.0f ? 2 : 1;
-    const uint32_t px_idx_in_quad = ((uint32_t(x & 1) | uint32_t(y & 1) * 2u) + fc.frame_index) & 3u;
-    for (uint32_t sample_i = 0; sample_i < sample_count; ++sample_i) {
-        const int4 o = spatial_resolve_offsets[(px_idx_in_quad * 16u + sample_i) + 64u * filter_idx];
-        const int sx = x + kernel_scale * o.x, sy = y + kernel_scale * o.y;
-        const V3 neigh = vsqrt(xyz(ld4(input_tex, sx, sy)));
-        const float sample_depth = depth_tex.ld(sx, sy);
-        const V3 sample_normal_vs = geometric_normal_tex.inb(sx, sy) ? unpack_a2r10g10b10(geometric_normal_tex.ld(sx, sy)) * 2.0f - 1.0f : v3(-1.0f);
-        float w = 1.0f;
-        w *= exp2f(-50.0f * fabsf(center_normal_vs.z * (center_depth / sample_depth - 1.0f)));
-        const float dp = saturate(dot(center_normal_vs, sample_normal_vs));
-        w *= dp * dp * dp;
-        vsum += neigh * w;
-        wsum += w;
-    }
-    const V3 v = vsum / wsum;
-    output_tex.st(x, y, pack_r11g11b10f(v * v));
-}
-
 // ------------------------------------------------------------------ LightingRenderer::render_specular (renderers/lighting.rs:23-88)
 // sample_lights.rgen.hlsl:18-63: one triangle-light sample + shadow ray per half-res pixel
 __global__ void __launch_bounds__(64) k_lighting_sample_lights(const FrameConstants* __restrict__ fcp, SceneView sc, ImgF32 depth_tex, const uint32_t* __restrict__ blue_noise,
@@ -1039,8 +671,7 @@ KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* p, void* stream_) {
         a.restir_ray_orig_tex = img<float4>(ray_orig_out, hw, hh);
         a.output_tex = img<uint32_t>(resolved, W, H); a.ray_len_output_tex = img<uint32_t>(ray_len_out, W, H);
         a.blue_noise = (const uint32_t*)r->dev->blue_noise.p; a.brdf_fg_lut = (const uint2*)r->dev->brdf_fg_lut.p;
-        hipLaunchKernelGGL(k_rtr_resolve, gf, blk, 0, s, a);
-        KJ_CHECK_LAUNCH();
+        KJ_TRY_HIP(launch_rtr_resolve(a, s));
     }
     r->resolved_tex = resolved; r->temporal_output_tex = temporal_out; r->history_tex = temporal_hist; r->ray_len_tex = ray_len_out; r->refl_restir_invalidity_tex = invalidity;
     return KJ_OK;
@@ -1083,15 +714,13 @@ KjStatus kj_rtr_filter_temporal(KjRtr* r, const KjRtrParams* p, const void** out
     const dim3 gf((W + 7) / 8, (H + 7) / 8), blk(64);
     const ImgF32 depth = img<float>(p->gbuffer_depth.depth, W, H);
     if (p->pass_mask & KJ_RTR_PASS_TEMPORAL_FILTER) {
-        hipLaunchKernelGGL(k_rtr_temporal_filter, gf, blk, 0, s, fc, img<uint32_t>(r->resolved_tex, W, H), img<uint2>(r->history_tex, W, H), depth, img<uint32_t>(r->ray_len_tex, W, H),
-                           img<uint2>(p->reprojection_map, W, H), img<uint8_t>(r->refl_restir_invalidity_tex, hw, hh), img<uint4>(p->gbuffer_depth.gbuffer, W, H),
-                           img<uint2>(r->temporal_output_tex, W, H));
-        KJ_CHECK_LAUNCH();
+        const RtrTemporalFilterArgs a{fc, img<uint32_t>(r->resolved_tex, W, H), img<uint2>(r->history_tex, W, H), depth, img<uint32_t>(r->ray_len_tex, W, H), img<uint2>(p->reprojection_map, W, H),
+                                      img<uint8_t>(r->refl_restir_invalidity_tex, hw, hh), img<uint4>(p->gbuffer_depth.gbuffer, W, H), img<uint2>(r->temporal_output_tex, W, H)};
+        KJ_TRY_HIP(launch_rtr_temporal_filter(a, s));
     }
     if (p->pass_mask & KJ_RTR_PASS_CLEANUP) {
-        hipLaunchKernelGGL(k_rtr_cleanup, gf, blk, 0, s, fc, img<uint2>(r->temporal_output_tex, W, H), depth, img<uint32_t>(p->gbuffer_depth.geometric_normal, W, H),
-                           img<uint32_t>(r->resolved_tex, W, H), (const int4*)r->offsets.p);
-        KJ_CHECK_LAUNCH();
+        const RtrCleanupArgs a{fc, img<uint2>(r->temporal_output_tex, W, H), depth, img<uint32_t>(p->gbuffer_depth.geometric_normal, W, H), img<uint32_t>(r->resolved_tex, W, H), (const int4*)r->offsets.p};
+        KJ_TRY_HIP(launch_rtr_cleanup(a, s));
     }
     if (out_resolved) *out_resolved = r->resolved_tex;
     return KJ_OK;
