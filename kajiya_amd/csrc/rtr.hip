@@ -142,7 +142,11 @@ KJ_D RtrTraceResult rtr_trace_ray(const RtrCtx& c, float roughness, uint32_t& rn
 }
 
 // ------------------------------------------------------------------ reflection.rgen.hlsl:45-169
-__global__ void __launch_bounds__(64) k_rtr_trace(RtrCtx c, ImgH4 out0_tex, ImgH4 out1_tex, ImgU32 out2_tex, ImgU32 rng_out_tex) {
+// waves per SIMD the two ray kernels are compiled for (rtdgi's fused ray kernels: 5, rtdgi.hip)
+#ifndef KJ_RTR_WAVES
+#define KJ_RTR_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, KJ_RTR_WAVES) k_rtr_trace(RtrCtx c, ImgH4 out0_tex, ImgH4 out1_tex, ImgU32 out2_tex, ImgU32 rng_out_tex) {
     extern __shared__ uint32_t lds_stack[];
     TILE_XY(out0_tex.w, out0_tex.h)
     if (!in_image) return;
@@ -191,7 +195,7 @@ __global__ void __launch_bounds__(64) k_rtr_trace(RtrCtx c, ImgH4 out0_tex, ImgH
 }
 
 // ------------------------------------------------------------------ reflection_validate.rgen.hlsl:42-146 (one thread per 2x2 half-res quad)
-__global__ void __launch_bounds__(64) k_rtr_validate(RtrCtx c, ImgF4 ray_orig_history_tex, ImgH4 ray_history_tex, ImgU32 rng_history_tex, ImgH4 irradiance_history_tex,
+__global__ void __launch_bounds__(64, KJ_RTR_WAVES) k_rtr_validate(RtrCtx c, ImgF4 ray_orig_history_tex, ImgH4 ray_history_tex, ImgU32 rng_history_tex, ImgH4 irradiance_history_tex,
                                                       ImgU2 reservoir_history_tex, ImgR8 refl_restir_invalidity_tex, int qw, int qh) {
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x;
