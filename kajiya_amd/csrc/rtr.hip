@@ -283,8 +283,16 @@ struct RtrTemporalArgs {
 // ------------------------------------------------------------------ rtr_restir_temporal.hlsl:155-533
 __global__ void __launch_bounds__(64) k_rtr_restir_temporal(RtrTemporalArgs a) {
     TILE_XY(a.irradiance_out_tex.w, a.irradiance_out_tex.h)
-    if (!in_image) return;
     const FrameConstants& fc = *a.fc;
+    // the five taps' spiral directions depend on the tap and the frame only: evaluated once per workgroup with the reference's cosf / sinf
+    __shared__ float tap_cos[5], tap_sin[5];
+    if (lane < 5) {
+        const float ang_offset_t = float(((fc.frame_index + 7u) * 11u) % 32u) * KJ_TAU;
+        const float ang_t = (float(lane) + ang_offset_t) * KJ_GOLDEN_ANGLE;
+        tap_cos[lane] = cosf(ang_t); tap_sin[lane] = sinf(ang_t);
+    }
+    __syncthreads();
+    if (!in_image) return;
     const I2 off = halfres_subsample_offset(fc.frame_index);
     const int hx = x * 2 + off.x, hy = y * 2 + off.y;
     const float depth = a.depth_tex.ld(hx, hy);
@@ -341,13 +349,11 @@ __global__ void __launch_bounds__(64) k_rtr_restir_temporal(RtrTemporalArgs a) {
     }
     const V4 center_reproj = ld_reproj(a.reprojection_tex, hx, hy);
     {
-        const float ang_offset = float(((fc.frame_index + 7u) * 11u) % 32u) * KJ_TAU;
         const uint32_t sample_count = center_reproj.z < 1.0f ? 5u : 1u;
         const V3 prev_eye = get_prev_eye_position(fc);
         for (uint32_t sample_i = 0; sample_i < sample_count && stream_state.M_sum < RTR_RESTIR_TEMPORAL_M_CLAMP; ++sample_i) {
-            const float ang = (float(sample_i) + ang_offset) * KJ_GOLDEN_ANGLE;
             const float rpx_offset_radius = sqrtf(float(((sample_i - 1u) + fc.frame_index) & 3u) + 1.0f) * clampf(8.0f - stream_state.M_sum, 1.0f, 7.0f);
-            const V2 reservoir_px_offset_base{cosf(ang) * rpx_offset_radius, sinf(ang) * rpx_offset_radius};
+            const V2 reservoir_px_offset_base{tap_cos[sample_i] * rpx_offset_radius, tap_sin[sample_i] * rpx_offset_radius};
             const I2 rpx_offset = sample_i == 0 ? I2{0, 0} : I2{int(reservoir_px_offset_base.x), int(reservoir_px_offset_base.y)};
             const V4 reproj = ld_reproj(a.reprojection_tex, hx + rpx_offset.x * 2, hy + rpx_offset.y * 2);
             const V2 base_px{float(x) + gts.x * reproj.x / 2.0f, float(y) + gts.y * reproj.y / 2.0f};
@@ -383,7 +389,9 @@ __global__ void __launch_bounds__(64) k_rtr_restir_temporal(RtrTemporalArgs a) {
                 const V3 current_wo = normalize(vr.hit_ws - get_eye_position(fc));
                 const V3 prev_wo = normalize(vr.hit_ws - prev_eye);
                 const float wo_dot = saturate(dot(current_wo, prev_wo));
-                const float wo_similarity = powf(saturate(ggx_ndf_0_1(fmaxf(3e-5f, a2), wo_dot)), 64.0f);
+                float wo_similarity = saturate(ggx_ndf_0_1(fmaxf(3e-5f, a2), wo_dot));      // ^64 by squaring (libm powf: 163 VALU instructions)
+                wo_similarity *= wo_similarity; wo_similarity *= wo_similarity; wo_similarity *= wo_similarity;
+                wo_similarity *= wo_similarity; wo_similarity *= wo_similarity; wo_similarity *= wo_similarity;
                 float mult = lerp(wo_similarity, 1.0f, smoothstep(0.05f, 0.5f, sqrtf(gbuffer.roughness)));
                 mult = lerp(1.0f, mult, local_normal_flatness);
                 r.M *= mult;

@@ -3,6 +3,7 @@
 // for the list). 8x8 tile = one wave64: the 8x4 bit masks of the "prepare" pass are the two halves of one 64-bit ballot.
 #include "kj_host.hpp"
 #include "kj_shading.hpp"
+#include "kj_screen.hpp"
 
 using namespace kj;
 
@@ -194,6 +195,7 @@ __global__ void __launch_bounds__(64) k_shadow_spatial(ImgU32 input_tex /*RG16F*
         const float t_ = fmaxf(0.0f, 1.0f - 2.0f * std_deviation);
         const float kernel_sharpening = fmaxf(1e-10f, 1.0f - t_ * t_);
         const float kernel[3] = {1.0f, exp2f(-0.5849625007211563f / kernel_sharpening), exp2f(-2.584962500721156f / kernel_sharpening)};
+        const float inv_std_log2e = 1.4426950408889634f / std_deviation;
 #pragma unroll
         for (int yy = -1; yy <= 1; ++yy)
 #pragma unroll
@@ -205,9 +207,13 @@ __global__ void __launch_bounds__(64) k_shadow_spatial(ImgU32 input_tex /*RG16F*
                 const V2 shadow_neigh = unpack_2x16f_uint(s_in[ty][tx]);
                 const float sky_mul = ((xx == 0 && yy == 0) || depth_neigh >= 1.0f || depth_neigh <= 0.0f) ? 0.0f : 1.0f;
                 float w = kernel[xx < 0 ? -xx : xx] * kernel[yy < 0 ? -yy : yy];
-                w *= expf(-fabsf(shadow_center.x - shadow_neigh.x) / std_deviation);
-                w *= exp2f(-fabsf(1.0f - (depth / depth_neigh)) / 0.01f);
-                w *= powf(saturate(dot(normal_center, normal_neigh)), 32.0f);
+                // weights: exp() as v_exp_f32 of the argument in base 2, pow(x, 32) as five squarings (libm's powf is 163 VALU instructions on
+                // gfx950 and ran nine times per pixel in each of the three passes)
+                w *= exp2_fast(-fabsf(shadow_center.x - shadow_neigh.x) * inv_std_log2e);
+                w *= exp2_fast(-fabsf(1.0f - depth * rcp_fast(depth_neigh)) * 100.0f);
+                float nd = saturate(dot(normal_center, normal_neigh));
+                nd *= nd; nd *= nd; nd *= nd; nd *= nd; nd *= nd;
+                w *= nd;
                 w *= sky_mul;
                 shadow_sum += V2{w, w * w} * shadow_neigh;
                 weight_sum += w;

@@ -4,6 +4,7 @@
 // rtdgi's resolve / filters take as `ssao_tex` (world_render_passes.rs:90-96,156). 8x8 tile = one wave64.
 #include "kj_host.hpp"
 #include "kj_shading.hpp"
+#include "kj_screen.hpp"
 
 using namespace kj;
 
@@ -42,9 +43,12 @@ KJ_D float ssgi_fast_acos(float in_x) {
     res *= ssgi_fast_sqrt(1.0f - ax);
     return in_x >= 0 ? res : 3.14159265359f - res;
 }
+// cos / sin through cos_sin_turns_fast (kj_screen.hpp: quadrant reduction + two short polynomials, < 1 ulp): libm's cosf / sinf are ~115
+// VALU instructions each on gfx950 and this kernel evaluated ten of them per pixel
 KJ_D float ssgi_integrate_arc(float h1, float h2, float n) {
-    const float a = -cosf(2.0f * h1 - n) + cosf(n) + 2.0f * h1 * sinf(n);
-    const float b = -cosf(2.0f * h2 - n) + cosf(n) + 2.0f * h2 * sinf(n);
+    const V2 csn = cos_sin_turns_fast(n);
+    const float a = -cos_sin_turns_fast(2.0f * h1 - n).x + csn.x + 2.0f * h1 * csn.y;
+    const float b = -cos_sin_turns_fast(2.0f * h2 - n).x + csn.x + 2.0f * h2 * csn.y;
     return 0.25f * (a + b);
 }
 KJ_D float ssgi_update_horizon(float prev, float cur, float blend) { return cur > prev ? lerp(prev, cur, blend) : prev; }
@@ -91,7 +95,8 @@ __global__ void __launch_bounds__(64) k_ssgi(const FrameConstants* __restrict__ 
     const float temporal_offset_noise = temporal_offsets[fc.frame_index / 6 % 4];
     const float ss_angle = frac(spatial_direction_noise + temporal_direction_noise) * 3.14159265359f;
     const float rand_offset = frac(spatial_offset_noise + temporal_offset_noise);
-    V2 cs_slice_dir{cosf(ss_angle) * input_tex_size.y / input_tex_size.x, sinf(ss_angle)};
+    const V2 cs_ss = cos_sin_turns_fast(ss_angle);
+    V2 cs_slice_dir{cs_ss.x * input_tex_size.y / input_tex_size.x, cs_ss.y};
     float kernel_radius_ws, kernel_radius_shrinkage;
     {
         const float ws_to_cs = 0.5f / -ray_hit_vs.z * fc.view_constants.view_to_clip[5];
@@ -113,8 +118,8 @@ __global__ void __launch_bounds__(64) k_ssgi(const FrameConstants* __restrict__ 
     const float sd = dot(vs_slice_dir, V2{proj_normal_vs.x - v_vs.x, proj_normal_vs.y - v_vs.y});
     const float sgn = sd > 0 ? 1.0f : (sd < 0 ? -1.0f : 0.0f);
     const float n_angle = ssgi_fast_acos(clampf(dot(proj_normal_vs, v_vs), -1.0f, 1.0f)) * sgn;
-    float theta_cos_max1 = cosf(n_angle - 1.57079632679f);
-    float theta_cos_max2 = cosf(n_angle + 1.57079632679f);
+    float theta_cos_max1 = cos_sin_turns_fast(n_angle - 1.57079632679f).x;
+    float theta_cos_max2 = cos_sin_turns_fast(n_angle + 1.57079632679f).x;
     int pc0x = x, pc0y = y, pc1x = x, pc1y = y;
     const V2 hit_cs{vrc.hit_cs.x, vrc.hit_cs.y};
     for (uint32_t i = 0; i < 6; ++i) {
