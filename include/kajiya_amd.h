@@ -200,6 +200,10 @@ KjStatus kj_scene_last_commit_ms(KjScene* scene, double out_ms[4]);
 #define KJ_BLAS_BUILD_FAST_BUILD 1u
 #define KJ_BLAS_BUILD_DEVICE_PLOC 2u
 KjStatus kj_scene_set_blas_build_mode(KjScene* scene, uint32_t mode);
+/* Top-tree granularity from the next commit on. 0 (default): one top-tree leaf per instance, as a driver's TLAS (ray_tracing.rs:277-407). 1: the
+ * largest nodes of the instances' top levels become the leaves (opened greedily by world-space surface area, 4 per instance slot on average):
+ * large instances that overlap many others -- a terrain -- stop being one box around everything. Same hits either way. */
+KjStatus kj_scene_set_open_instances(KjScene* scene, uint32_t enable);
 
 /* Baked assets (`bin/bake` output, kajiya-asset-pipe/src/lib.rs:38-60): zero-copy, bounds-checked views of
  * `cache/<name>.mesh` (PackedTriMesh::Flat, kajiya-asset/src/mesh.rs:796-807) and `cache/<identity:08x>.image`

@@ -84,6 +84,11 @@ struct KjScene {
     struct Blas { uint32_t node_base = 0, node_count = 0, tri_base = 0, tri_count = 0, max_stack = 1; float bounds[6] = {0, 0, 0, 0, 0, 0}; bool built = false;
                   uint32_t root = 0, heights_base = 0, height_count = 0, wide_heights = 0; };   // root node (relative); the refit's bottom-up steps (kj_scene_device.hpp: InstanceRefitJob)
     std::vector<Blas> blas;                       // one per mesh
+    // The top levels of every BLAS as the host sees them: node (relative to the mesh's first node), its object-space box (decoded from its parent's
+    // quantised child slot: conservative) and its inner children. What kj_scene_commit opens into the top tree instead of whole instances.
+    struct BlasTopNode { uint32_t node; float box[6]; uint32_t first_child, child_count; };      // child_count 0: has a leaf child (or lies below the kept levels): not opened
+    std::vector<std::vector<BlasTopNode>> blas_top;   // one list per mesh, [0] = the root
+    bool open_instances = false;                  // kj_scene_set_open_instances / KJ_SCENE_OPEN_INSTANCES=1: top-tree leaves are nodes of the instances' top levels instead of whole instances
     uint32_t blas_nodes_used = 0, obj_tris_used = 0;   // fill of the two device pools every BLAS lives in (d_blas_nodes, d_obj_tris)
     uint32_t blas_build_mode = 0;                 // for meshes added from now on: 0 = SAH on the host (fast trace), 1 = LBVH on the device (fast build), 2 = PLOC on the device
     std::vector<uint8_t> mesh_build_mode;         // per mesh

@@ -19,7 +19,7 @@ EXPORTS = [
     "kj_last_error", "kj_abi_version", "kj_device_create", "kj_device_destroy", "kj_device_brdf_lut",
     "kj_scene_create", "kj_scene_destroy", "kj_scene_add_mesh", "kj_scene_add_instance", "kj_scene_set_instance_transform",
     "kj_scene_set_instance_emissive_multiplier", "kj_scene_remove_instance", "kj_scene_commit", "kj_scene_triangle_light_count",
-    "kj_scene_stats", "kj_scene_last_commit_ms", "kj_scene_set_blas_build_mode", "kj_frame_begin", "kj_trace_closest", "kj_trace_any", "kj_debug_calibration_copy", "kj_raster_gbuffer", "kj_sky_cube_render",
+    "kj_scene_stats", "kj_scene_last_commit_ms", "kj_scene_set_blas_build_mode", "kj_scene_set_open_instances", "kj_frame_begin", "kj_trace_closest", "kj_trace_any", "kj_debug_calibration_copy", "kj_raster_gbuffer", "kj_sky_cube_render",
     "kj_sky_cube_convolve", "kj_reprojection_create", "kj_reprojection_destroy", "kj_calculate_reprojection_map",
     "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_render",
     "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_set_ray_pass_form", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
@@ -82,6 +82,7 @@ def load():
         "kj_ircache_collect_requests": [vp, u32, u32, vp, u32, vp, vp],
         "kj_ircache_apply_requests": [vp, vp, u32, vp],
         "kj_scene_set_blas_build_mode": [vp, u32],
+        "kj_scene_set_open_instances": [vp, u32],
         "kj_raster_gbuffer": [vp, vp, u32, u32, vp, vp, vp, vp, vp],
         "kj_sky_cube_render": [vp, vp, vp],
         "kj_sky_cube_convolve": [vp, vp, vp, vp],
@@ -194,11 +195,13 @@ class Device:
 class Scene:
     """WorldRenderer scene state: add_mesh / add_instance / commit (builds the software LBVH)."""
 
-    def __init__(self, dev: Device, desc: kscenes.SceneDesc = None, use_lights=False, fast_build=False):
+    def __init__(self, dev: Device, desc: kscenes.SceneDesc = None, use_lights=False, fast_build=False, open_instances=False):
         L = load()
         self.dev = dev
         self.h = C.c_void_p()
         check(L.kj_scene_create(dev.h, C.byref(self.h)))
+        if open_instances:  # top-tree leaves = nodes of the instances' top levels instead of whole instances
+            check(L.kj_scene_set_open_instances(self.h, 1))
         if fast_build:      # BLASes built on the device instead of SAH trees built on the host: True / 1 = LBVH, "ploc" / 2 = PLOC
             check(L.kj_scene_set_blas_build_mode(self.h, 2 if fast_build in ("ploc", 2) and fast_build is not True else 1))
         self._keep = []

@@ -1,6 +1,6 @@
 # experiment: the ray translation units compiled with approximate division / sqrt (NOT parity-safe as is): how much would their shading code gain?
 ROOT=$PWD; mkdir -p gpurun_out; cd /tmp; export TMPDIR=/tmp
-B="python $ROOT/bench.py --no-cpu-baseline --no-also --steps 24 --warmup 12 --profile-frames 6 --no-overlap"
+B="python $ROOT/bench.py --no-cpu-baseline --no-also --steps 24 --warmup 12 --profile-frames 6 --no-overlap ${BENCH_ARGS:-}"
 timeout 400 $B > /dev/null 2>&1
 for v in def fastray def fastray; do
   if [ $v = def ]; then unset KJ_AMD_LIB; else export KJ_AMD_LIB=$ROOT/kajiya_amd/libkajiya_amd_$v.so; fi

@@ -474,7 +474,7 @@ def _blob(rng, n_tris, size=1.0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fast_build", [False, True, "ploc"])
+@pytest.mark.parametrize("fast_build", [False, True, "ploc", "open"])
 def test_instance_trees_under_rotation_mirroring_and_repeated_edits(gpu, oracle, device, fast_build):
     """The per-instance world-space trees (scene_device.hip: refit by node height, four lanes per node) at their corners: meshes of
     1, 4, 5, 17 and 1300 triangles (one-node trees, one refit step, several steps, a step wider than one workgroup pass), instances
@@ -505,7 +505,8 @@ def test_instance_trees_under_rotation_mirroring_and_repeated_edits(gpu, oracle,
     for k in range(300):
         live.append((int(rng.randint(0, 4)) if k % 50 else 4, random_xform(k)))
         desc.add_instance(*live[-1])
-    gsc = gpu.Scene(device, desc, fast_build=fast_build)
+    open_instances = fast_build == "open"     # host-built BLASes; top-tree leaves = nodes of the instances' top levels (kj_scene_set_open_instances)
+    gsc = gpu.Scene(device, desc, fast_build=False if open_instances else fast_build, open_instances=open_instances)
 
     def check(tag):
         cur = scenes.SceneDesc()
