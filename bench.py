@@ -262,8 +262,18 @@ def main():
         torch.cuda.synchronize()
         irc_frame[0] = 1
         (gp if single else split).pipeline_begin(fcs[1])
+    def log_rays(i):      # tiny device-side reductions on the launch stream: this frame's ray counters into row i of the logs
+        ray_log[i].copy_(gp_counters[0][:, :6].sum(dim=0))
+        for c_ in gp_counters[1:]:   # virtual ranks only
+            ray_log[i] += c_[:, :6].sum(dim=0)
+        if not overlap:
+            irc_log[i].copy_(irc_counters[0][:, :2].sum(dim=0))
+            for ic_ in irc_counters[1:]:
+                irc_log[i] += ic_[:, :2].sum(dim=0)
+
     for i in range(1, Wm):
         step(i)
+        log_rays(i)       # warm-up runs EXACTLY what a timed step runs (torch loads a reduction kernel's code object at its first use: 40 ms)
 
     def barrier():
         if world > 1:
@@ -272,17 +282,15 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
+    step_host_s = []      # KJ_BENCH_STEP_TIMES=1: host time at which each step had been ISSUED (no syncs added), printed to stderr afterwards
     for i in range(Wm, Wm + K):
         step(i)
-        ray_log[i].copy_(gp_counters[0][:, :6].sum(dim=0))  # tiny device-side reduction on the same stream
-        for c_ in gp_counters[1:]:   # virtual ranks only
-            ray_log[i] += c_[:, :6].sum(dim=0)
-        if not overlap:
-            irc_log[i].copy_(irc_counters[0][:, :2].sum(dim=0))
-            for ic_ in irc_counters[1:]:
-                irc_log[i] += ic_[:, :2].sum(dim=0)
+        log_rays(i)
+        step_host_s.append(time.perf_counter() - t0)
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("KJ_BENCH_STEP_TIMES"):
+        print("[bench] issue times of the timed steps (ms since t0):", " ".join(f"{1e3 * v:.2f}" for v in step_host_s), f"| done {1e3 * elapsed:.2f}", file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
