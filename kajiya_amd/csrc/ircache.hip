@@ -416,32 +416,75 @@ __global__ void __launch_bounds__(256) k_irc_request_keys(const IrcRequest* __re
     keys[i] = ((unsigned long long)rq[i].cell << 32) | rq[i].key;
     idx[i] = i;
 }
-// per segment head: does this cell get allocated now? (flag -> exclusive scan gives its place in the pool)
-__global__ void __launch_bounds__(256) k_irc_request_heads(IrcacheView ic, const IrcRequest* __restrict__ rq, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ idx, uint32_t n,
-                                                            uint32_t* __restrict__ flags) {
+// The replay of a cell's lookups is a sequential recurrence in the reference's order (life refresh = running minimum, the position vote = reservoir
+// sampling with the vote count as its state), and a cell near the camera receives tens of thousands of lookups per frame: one thread per cell (round 2)
+// spent 1.0 ms at 1080p / 1.7 ms at 4K on its longest cells (rocprofv3, virtual ranks). It is evaluated here for all records at once through
+// segmented scans over the sorted list (hipCUB scan-by-key, key = cell):
+//   * lookup i refreshes the life to rank_i * IRC_LIFE_PER_RANK when that is lower: the cell's life ends as min(life0, min rank_i * L);
+//   * lookup i votes iff rank_i <= (life before it) / L = min(life0 / L, min_{j < i} rank_j): an exclusive running MINIMUM;
+//   * the k-th voter's proposal replaces the current one iff its dart <= 1 / (votes0 + k + 1), k = number of voters before it: an exclusive running
+//     SUM; the proposal that survives is the LAST accepted one (an atomicMax per accepted vote on the segment's head slot: ~ln(n) per cell);
+//   * an unoccupied cell is allocated by its first lookup that may allocate: a running minimum over positions, carried in the same scan.
+// The segment's TAIL record (last of its cell) then holds every total and writes the cell's state; new cells take pool entries in cell order as before.
+struct IrcSegMin { uint32_t rank, first_allowed, head, pad; };      // componentwise minima over a cell's records [segment start .. i]
+struct IrcSegMinOp { KJ_HD IrcSegMin operator()(const IrcSegMin& a, const IrcSegMin& b) const { return IrcSegMin{a.rank < b.rank ? a.rank : b.rank, a.first_allowed < b.first_allowed ? a.first_allowed : b.first_allowed, a.head < b.head ? a.head : b.head, 0u}; } };
+struct IrcSumOp { KJ_HD uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
+__global__ void __launch_bounds__(256) k_irc_request_prepare(const IrcRequest* __restrict__ rq, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ idx, uint32_t n,
+                                                              uint32_t* __restrict__ cells, IrcSegMin* __restrict__ seg_in, uint32_t* __restrict__ last_accepted) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t cell = uint32_t(keys[i] >> 32);
-    uint32_t f = 0;
-    if (cell != 0xffffffffu && (i == 0 || uint32_t(keys[i - 1] >> 32) != cell) && (ic.grid_meta[cell].y & IRC_META_OCCUPIED) == 0)
-        for (uint32_t j = i; j < n && uint32_t(keys[j] >> 32) == cell; ++j)
-            if (!(rq[idx[j]].bits & 0x100u)) { f = 1; break; }
-    flags[i] = f;
+    const uint32_t bits = rq[idx[i]].bits;
+    cells[i] = uint32_t(keys[i] >> 32);
+    seg_in[i] = IrcSegMin{bits & 0xffu, (bits & 0x100u) ? 0xffffffffu : i, i, 0u};
+    last_accepted[i] = 0u;
 }
-__global__ void __launch_bounds__(256) k_irc_request_apply(IrcacheView ic, const IrcRequest* __restrict__ rq, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ idx, uint32_t n,
-                                                            const uint32_t* __restrict__ flags, const uint32_t* __restrict__ ranks, uint32_t* __restrict__ scratch) {
+KJ_D bool irc_is_tail(const uint32_t* __restrict__ cells, uint32_t i, uint32_t n) { return i + 1u == n || cells[i + 1u] != cells[i]; }
+// is a live, not-just-allocated entry behind the cell whose lookups may refresh it? (the loop guard of lookup.hlsl:287: life < IRC_LIFE_RECYCLE)
+KJ_D bool irc_replay_entry(const IrcacheView& ic, uint32_t cell, uint32_t* entry, uint32_t* life0) {
+    if (cell == 0xffffffffu) return false;
+    const uint2 gm = ic.grid_meta[cell];
+    if ((gm.y & IRC_META_OCCUPIED) == 0 || (gm.y & IRC_META_JUST_ALLOCATED) != 0) return false;
+    *entry = gm.x; *life0 = ic.life[gm.x];
+    return *life0 < IRC_LIFE_RECYCLE;
+}
+// voters (for the running sum) and, at the tails of unoccupied cells, the allocation flag (for the pool order)
+__global__ void __launch_bounds__(256) k_irc_request_voters(IrcacheView ic, const uint32_t* __restrict__ cells, const IrcSegMin* __restrict__ seg_in, const IrcSegMin* __restrict__ seg, uint32_t n,
+                                                             uint32_t* __restrict__ voter, uint32_t* __restrict__ flags) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t cell = uint32_t(keys[i] >> 32);
-    if (cell == 0xffffffffu || (i != 0 && uint32_t(keys[i - 1] >> 32) == cell)) return;     // segment heads only
+    const uint32_t cell = cells[i];
+    uint32_t v = 0u, f = 0u, entry, life0;
+    if (cell != 0xffffffffu && (ic.grid_meta[cell].y & IRC_META_OCCUPIED) == 0) f = (irc_is_tail(cells, i, n) && seg[i].first_allowed != 0xffffffffu) ? 1u : 0u;
+    else if (irc_replay_entry(ic, cell, &entry, &life0)) {
+        const uint32_t rank_before = seg[i].head == i ? 0xffffffffu : seg[i - 1u].rank;      // minimum over the cell's earlier lookups
+        v = seg_in[i].rank <= min(rank_before, life0 / IRC_LIFE_PER_RANK) ? 1u : 0u;
+    }
+    voter[i] = v; flags[i] = f;
+}
+__global__ void __launch_bounds__(256) k_irc_request_accept(IrcacheView ic, const IrcRequest* __restrict__ rq, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ cells,
+                                                             const IrcSegMin* __restrict__ seg, const uint32_t* __restrict__ voter, const uint32_t* __restrict__ voters_incl, uint32_t n,
+                                                             uint32_t* __restrict__ last_accepted) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !voter[i]) return;
+    const uint32_t entry = ic.grid_meta[cells[i]].x;
+    const uint32_t votes_before = ic.reposition_proposal_count[entry] + (voters_incl[i] - 1u);
+    if (rq[idx[i]].dart <= 1.0f / (float(votes_before) + 1.0f)) atomicMax(&last_accepted[seg[i].head], i + 1u);
+}
+// the tail record of every cell writes the cell's new state
+__global__ void __launch_bounds__(256) k_irc_request_apply(IrcacheView ic, const IrcRequest* __restrict__ rq, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ cells,
+                                                            const IrcSegMin* __restrict__ seg, const uint32_t* __restrict__ voters_incl, const uint32_t* __restrict__ last_accepted, uint32_t n,
+                                                            const uint32_t* __restrict__ flags, const uint32_t* __restrict__ ranks) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t cell = cells[i];
+    if (cell == 0xffffffffu || !irc_is_tail(cells, i, n)) return;
+    const IrcSegMin m = seg[i];
     const uint2 gm = ic.grid_meta[cell];
     if ((gm.y & IRC_META_OCCUPIED) == 0) {
         if (!flags[i]) return;
         const uint32_t alloc_idx = ic.meta[IRC_META_ALLOC_COUNT] + ranks[i];
         if (alloc_idx >= IRC_MAX_ENTRIES) return;                                           // pool exhausted: the cell stays empty
-        uint32_t j = i;
-        while (rq[idx[j]].bits & 0x100u) ++j;                                               // the first lookup allowed to allocate
-        const IrcRequest a = rq[idx[j]];
+        const IrcRequest a = rq[idx[m.first_allowed]];                                      // the first lookup allowed to allocate
         const uint32_t entry_idx = ic.pool[alloc_idx];
         atomicMax(&ic.meta[IRC_META_ENTRY_COUNT], entry_idx + 1u);
         ic.life[entry_idx] = (a.bits & 0xffu) * IRC_LIFE_PER_RANK;
@@ -450,27 +493,12 @@ __global__ void __launch_bounds__(256) k_irc_request_apply(IrcacheView ic, const
         ic.reposition_proposal[entry_idx] = a.proposal;
         return;
     }
-    if (gm.y & IRC_META_JUST_ALLOCATED) return;
-    const uint32_t entry_idx = gm.x;
-    uint32_t life = ic.life[entry_idx], votes = ic.reposition_proposal_count[entry_idx];
-    float4 proposal = ic.reposition_proposal[entry_idx];
-    bool voted = false;
-    for (uint32_t j = i; j < n && uint32_t(keys[j] >> 32) == cell; ++j) {
-        const IrcRequest r = rq[idx[j]];
-        const uint32_t query_rank = r.bits & 0xffu;
-        if (life < IRC_LIFE_RECYCLE) {
-            const uint32_t prev_life = life;
-            const uint32_t new_life = query_rank * IRC_LIFE_PER_RANK;
-            if (new_life < prev_life) life = new_life;
-            if (query_rank <= prev_life / IRC_LIFE_PER_RANK) {
-                if (r.dart <= 1.0f / (float(votes) + 1.0f)) { proposal = r.proposal; voted = true; }
-                ++votes;
-            }
-        }
-    }
-    ic.life[entry_idx] = life;
-    ic.reposition_proposal_count[entry_idx] = votes;
-    if (voted) ic.reposition_proposal[entry_idx] = proposal;
+    uint32_t entry, life0;
+    if (!irc_replay_entry(ic, cell, &entry, &life0)) return;
+    ic.life[entry] = min(life0, m.rank * IRC_LIFE_PER_RANK);
+    ic.reposition_proposal_count[entry] += voters_incl[i];
+    const uint32_t la = last_accepted[m.head];
+    if (la) ic.reposition_proposal[entry] = rq[idx[la - 1u]].proposal;
 }
 __global__ void k_irc_request_finish(IrcacheView ic, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ ranks, uint32_t n) {
     const uint32_t allocated = ranks[n - 1] + flags[n - 1];
@@ -695,22 +723,34 @@ KjStatus kj_ircache_apply_requests(KjIrcache* c, const void* list, uint32_t coun
     auto A = [&](kj::DevBuf& b, size_t n) { if (b.bytes < n) { hipError_t e = b.alloc(n, s); if (e != hipSuccess) c->err = e; } };
     A(c->req_sort_keys, size_t(count) * 8); A(c->req_sort_keys2, size_t(count) * 8); A(c->req_sort_idx, size_t(count) * 4); A(c->req_sort_idx2, size_t(count) * 4);
     A(c->req_flags, size_t(count) * 4); A(c->req_ranks, size_t(count) * 4); A(c->req_count, 16);
+    A(c->req_cells, size_t(count) * 4); A(c->req_seg_in, size_t(count) * sizeof(IrcSegMin)); A(c->req_seg, size_t(count) * sizeof(IrcSegMin));
+    A(c->req_voter, size_t(count) * 4); A(c->req_voters_incl, size_t(count) * 4); A(c->req_last_accepted, size_t(count) * 4);
     KJ_TRY_HIP(c->err);
     const dim3 g((count + 255) / 256), b(256);
-    hipLaunchKernelGGL(k_irc_request_keys, g, b, 0, s, rq, count, (unsigned long long*)c->req_sort_keys.p, (uint32_t*)c->req_sort_idx.p);
-    size_t tmp_bytes = 0;
-    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned long long*)c->req_sort_keys.p, (unsigned long long*)c->req_sort_keys2.p, (const uint32_t*)c->req_sort_idx.p,
-                                                  (uint32_t*)c->req_sort_idx2.p, int(count), 0, 64, s));
-    size_t scan_bytes = 0;
-    KJ_TRY_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)c->req_flags.p, (uint32_t*)c->req_ranks.p, int(count), s));
-    A(c->req_tmp, std::max(tmp_bytes, scan_bytes) + 16);
+    unsigned long long* const keys = (unsigned long long*)c->req_sort_keys.p; unsigned long long* const keys_sorted = (unsigned long long*)c->req_sort_keys2.p;
+    uint32_t* const idx = (uint32_t*)c->req_sort_idx.p; uint32_t* const idx_sorted = (uint32_t*)c->req_sort_idx2.p;
+    uint32_t* const cells = (uint32_t*)c->req_cells.p;
+    IrcSegMin* const seg_in = (IrcSegMin*)c->req_seg_in.p; IrcSegMin* const seg = (IrcSegMin*)c->req_seg.p;
+    uint32_t* const voter = (uint32_t*)c->req_voter.p; uint32_t* const voters_incl = (uint32_t*)c->req_voters_incl.p; uint32_t* const last_accepted = (uint32_t*)c->req_last_accepted.p;
+    uint32_t* const flags = (uint32_t*)c->req_flags.p; uint32_t* const ranks = (uint32_t*)c->req_ranks.p;
+    hipLaunchKernelGGL(k_irc_request_keys, g, b, 0, s, rq, count, keys, idx);
+    size_t sort_bytes = 0, scan_bytes = 0, seg_bytes = 0, sum_bytes = 0;
+    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)keys, keys_sorted, (const uint32_t*)idx, idx_sorted, int(count), 0, 64, s));
+    KJ_TRY_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)flags, ranks, int(count), s));
+    KJ_TRY_HIP(hipcub::DeviceScan::InclusiveScanByKey(nullptr, seg_bytes, (const uint32_t*)cells, (const IrcSegMin*)seg_in, seg, IrcSegMinOp(), count, hipcub::Equality(), s));
+    KJ_TRY_HIP(hipcub::DeviceScan::InclusiveScanByKey(nullptr, sum_bytes, (const uint32_t*)cells, (const uint32_t*)voter, voters_incl, IrcSumOp(), count, hipcub::Equality(), s));
+    const size_t tmp_bytes = std::max(std::max(sort_bytes, scan_bytes), std::max(seg_bytes, sum_bytes));
+    A(c->req_tmp, tmp_bytes + 16);
     KJ_TRY_HIP(c->err);
-    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(c->req_tmp.p, tmp_bytes, (const unsigned long long*)c->req_sort_keys.p, (unsigned long long*)c->req_sort_keys2.p, (const uint32_t*)c->req_sort_idx.p,
-                                                  (uint32_t*)c->req_sort_idx2.p, int(count), 0, 64, s));
-    hipLaunchKernelGGL(k_irc_request_heads, g, b, 0, s, v, rq, (const unsigned long long*)c->req_sort_keys2.p, (const uint32_t*)c->req_sort_idx2.p, count, (uint32_t*)c->req_flags.p);
-    KJ_TRY_HIP(hipcub::DeviceScan::ExclusiveSum(c->req_tmp.p, scan_bytes, (const uint32_t*)c->req_flags.p, (uint32_t*)c->req_ranks.p, int(count), s));
-    hipLaunchKernelGGL(k_irc_request_apply, g, b, 0, s, v, rq, (const unsigned long long*)c->req_sort_keys2.p, (const uint32_t*)c->req_sort_idx2.p, count, (const uint32_t*)c->req_flags.p,
-                       (const uint32_t*)c->req_ranks.p, (uint32_t*)c->req_count.p);
+    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(c->req_tmp.p, sort_bytes, (const unsigned long long*)keys, keys_sorted, (const uint32_t*)idx, idx_sorted, int(count), 0, 64, s));
+    hipLaunchKernelGGL(k_irc_request_prepare, g, b, 0, s, rq, (const unsigned long long*)keys_sorted, (const uint32_t*)idx_sorted, count, cells, seg_in, last_accepted);
+    KJ_TRY_HIP(hipcub::DeviceScan::InclusiveScanByKey(c->req_tmp.p, seg_bytes, (const uint32_t*)cells, (const IrcSegMin*)seg_in, seg, IrcSegMinOp(), count, hipcub::Equality(), s));
+    hipLaunchKernelGGL(k_irc_request_voters, g, b, 0, s, v, (const uint32_t*)cells, (const IrcSegMin*)seg_in, (const IrcSegMin*)seg, count, voter, flags);
+    KJ_TRY_HIP(hipcub::DeviceScan::InclusiveScanByKey(c->req_tmp.p, sum_bytes, (const uint32_t*)cells, (const uint32_t*)voter, voters_incl, IrcSumOp(), count, hipcub::Equality(), s));
+    KJ_TRY_HIP(hipcub::DeviceScan::ExclusiveSum(c->req_tmp.p, scan_bytes, (const uint32_t*)flags, ranks, int(count), s));
+    hipLaunchKernelGGL(k_irc_request_accept, g, b, 0, s, v, rq, (const uint32_t*)idx_sorted, (const uint32_t*)cells, (const IrcSegMin*)seg, (const uint32_t*)voter, (const uint32_t*)voters_incl, count, last_accepted);
+    hipLaunchKernelGGL(k_irc_request_apply, g, b, 0, s, v, rq, (const uint32_t*)idx_sorted, (const uint32_t*)cells, (const IrcSegMin*)seg, (const uint32_t*)voters_incl, (const uint32_t*)last_accepted, count,
+                       (const uint32_t*)flags, (const uint32_t*)ranks);
     hipLaunchKernelGGL(k_irc_request_finish, dim3(1), dim3(1), 0, s, v, (const uint32_t*)c->req_flags.p, (const uint32_t*)c->req_ranks.p, count);
     KJ_CHECK_LAUNCH();
     return KJ_OK;

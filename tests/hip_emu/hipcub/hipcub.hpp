@@ -24,7 +24,18 @@ struct DeviceRadixSort {
         return hipSuccess;
     }
 };
+struct Equality { template <typename A, typename B> bool operator()(const A& a, const B& b) const { return a == b; } };
 struct DeviceScan {
+    // inclusive scan with `op` restarting wherever the key changes
+    template <typename K, typename In, typename Out, typename Op, typename N, typename Eq = Equality>
+    static hipError_t InclusiveScanByKey(void* d_temp_storage, size_t& temp_storage_bytes, const K* keys, const In* in, Out* out, Op op, N n, Eq eq = Eq(), hipStream_t = nullptr) {
+        if (!d_temp_storage) { temp_storage_bytes = 16; return hipSuccess; }
+        for (size_t i = 0; i < size_t(n); ++i) {
+            if (i == 0 || !eq(keys[i - 1], keys[i])) out[i] = Out(in[i]);
+            else { const Out prev = out[i - 1]; out[i] = op(prev, Out(in[i])); }
+        }
+        return hipSuccess;
+    }
     template <typename In, typename Out>
     static hipError_t ExclusiveSum(void* d_temp_storage, size_t& temp_storage_bytes, const In* in, Out* out, int n, hipStream_t = nullptr) {
         if (!d_temp_storage) { temp_storage_bytes = 16; return hipSuccess; }
