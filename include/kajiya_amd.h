@@ -279,6 +279,9 @@ KjStatus kj_rtdgi_set_options(KjRtdgi* r, uint32_t spatial_reuse_pass_count, uin
 
 /* RtdgiRenderer::reproject (rtdgi.rs:143-170). */
 KjStatus kj_rtdgi_reproject(KjRtdgi* r, const void* reprojection_map, uint32_t width, uint32_t height, void* stream);
+/* The same for full-res rows [row_begin, row_end) only (row_begin a multiple of 8): the screen-tile split reprojects strip by strip and all-gathers
+ * `reprojected_history_tex` (kj_rtdgi_surface), which the trace pass reads anywhere on screen. Reads the history within motion + 2 rows of the range. */
+KjStatus kj_rtdgi_reproject_rows(KjRtdgi* r, const void* reprojection_map, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end, void* stream);
 
 /* Pass bits for kj_rtdgi_render's pass_mask (data-flow order, rtdgi.rs:189-553). */
 enum {

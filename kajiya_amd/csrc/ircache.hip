@@ -426,6 +426,10 @@ __global__ void __launch_bounds__(256) k_irc_request_keys(const IrcRequest* __re
 //     SUM; the proposal that survives is the LAST accepted one (an atomicMax per accepted vote on the segment's head slot: ~ln(n) per cell);
 //   * an unoccupied cell is allocated by its first lookup that may allocate: a running minimum over positions, carried in the same scan.
 // The segment's TAIL record (last of its cell) then holds every total and writes the cell's state; new cells take pool entries in cell order as before.
+// sort key = cell << 32 | position of the lookup in the frame; cells are < IRC_MAX_GRID_CELLS < 2^19 (an unused slot's 0xffffffff keeps its low
+// 19 bits set and still sorts behind every real cell), so the radix sort runs over 51 bits instead of 64
+#define KJ_IRC_SORT_BITS (32 + 19)
+static_assert(IRC_MAX_GRID_CELLS <= (1u << 19), "sort key width");
 struct IrcSegMin { uint32_t rank, first_allowed, head, pad; };      // componentwise minima over a cell's records [segment start .. i]
 struct IrcSegMinOp { KJ_HD IrcSegMin operator()(const IrcSegMin& a, const IrcSegMin& b) const { return IrcSegMin{a.rank < b.rank ? a.rank : b.rank, a.first_allowed < b.first_allowed ? a.first_allowed : b.first_allowed, a.head < b.head ? a.head : b.head, 0u}; } };
 struct IrcSumOp { KJ_HD uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
@@ -735,14 +739,14 @@ KjStatus kj_ircache_apply_requests(KjIrcache* c, const void* list, uint32_t coun
     uint32_t* const flags = (uint32_t*)c->req_flags.p; uint32_t* const ranks = (uint32_t*)c->req_ranks.p;
     hipLaunchKernelGGL(k_irc_request_keys, g, b, 0, s, rq, count, keys, idx);
     size_t sort_bytes = 0, scan_bytes = 0, seg_bytes = 0, sum_bytes = 0;
-    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)keys, keys_sorted, (const uint32_t*)idx, idx_sorted, int(count), 0, 64, s));
+    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)keys, keys_sorted, (const uint32_t*)idx, idx_sorted, int(count), 0, KJ_IRC_SORT_BITS, s));
     KJ_TRY_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)flags, ranks, int(count), s));
     KJ_TRY_HIP(hipcub::DeviceScan::InclusiveScanByKey(nullptr, seg_bytes, (const uint32_t*)cells, (const IrcSegMin*)seg_in, seg, IrcSegMinOp(), count, hipcub::Equality(), s));
     KJ_TRY_HIP(hipcub::DeviceScan::InclusiveScanByKey(nullptr, sum_bytes, (const uint32_t*)cells, (const uint32_t*)voter, voters_incl, IrcSumOp(), count, hipcub::Equality(), s));
     const size_t tmp_bytes = std::max(std::max(sort_bytes, scan_bytes), std::max(seg_bytes, sum_bytes));
     A(c->req_tmp, tmp_bytes + 16);
     KJ_TRY_HIP(c->err);
-    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(c->req_tmp.p, sort_bytes, (const unsigned long long*)keys, keys_sorted, (const uint32_t*)idx, idx_sorted, int(count), 0, 64, s));
+    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(c->req_tmp.p, sort_bytes, (const unsigned long long*)keys, keys_sorted, (const uint32_t*)idx, idx_sorted, int(count), 0, KJ_IRC_SORT_BITS, s));
     hipLaunchKernelGGL(k_irc_request_prepare, g, b, 0, s, rq, (const unsigned long long*)keys_sorted, (const uint32_t*)idx_sorted, count, cells, seg_in, last_accepted);
     KJ_TRY_HIP(hipcub::DeviceScan::InclusiveScanByKey(c->req_tmp.p, seg_bytes, (const uint32_t*)cells, (const IrcSegMin*)seg_in, seg, IrcSegMinOp(), count, hipcub::Equality(), s));
     hipLaunchKernelGGL(k_irc_request_voters, g, b, 0, s, v, (const uint32_t*)cells, (const IrcSegMin*)seg_in, (const IrcSegMin*)seg, count, voter, flags);

@@ -1337,7 +1337,13 @@ KjStatus kj_rtdgi_set_options(KjRtdgi* r, uint32_t spatial_reuse_pass_count, uin
 }
 
 KjStatus kj_rtdgi_reproject(KjRtdgi* r, const void* reprojection_map, uint32_t width, uint32_t height, void* stream_) {
+    return kj_rtdgi_reproject_rows(r, reprojection_map, width, height, 0u, height, stream_);
+}
+// rows [row_begin, row_end) only (the screen-tile split: a rank reprojects its own strip; the trace pass reads the reprojected image anywhere on
+// screen, so the orchestrator all-gathers the strips afterwards)
+KjStatus kj_rtdgi_reproject_rows(KjRtdgi* r, const void* reprojection_map, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end, void* stream_) {
     KJ_REQUIRE(r && reprojection_map && width && height, "null argument");
+    KJ_REQUIRE(row_begin < row_end && row_end <= height && (row_begin % 8u) == 0u, "rows must be a non-empty range starting on a tile row");
     hipStream_t s = (hipStream_t)stream_;
     r->resize(int(width), int(height));
     const int W = r->W, H = r->H;
@@ -1349,8 +1355,8 @@ KjStatus kj_rtdgi_reproject(KjRtdgi* r, const void* reprojection_map, uint32_t w
     r->reprojected_history_tex = r->get("reprojected_history_tex", size_t(W) * H * 8, s);
     KJ_TRY_HIP(r->err);
     SCOPE_BEGIN(0);
-    hipLaunchKernelGGL(k_fullres_reproject, dim3((W + 7) / 8, (H + 7) / 8), dim3(64), 0, s, img<uint2>(history, W, H), img<uint2>(reprojection_map, W, H),
-                       img<uint2>(r->reprojected_history_tex, W, H), 0, H);
+    hipLaunchKernelGGL(k_fullres_reproject, dim3((W + 7) / 8, (int(row_end - row_begin) + 7) / 8), dim3(64), 0, s, img<uint2>(history, W, H), img<uint2>(reprojection_map, W, H),
+                       img<uint2>(r->reprojected_history_tex, W, H), int(row_begin), int(row_end));
     KJ_CHECK_LAUNCH();
     SCOPE_END(0);
     return KJ_OK;

@@ -33,7 +33,7 @@ const std::map<std::string, SurfInfo>& surf_table() {
         {"rtdgi.invalidity", {4, true}}, {"rtdgi.candidate", {8, true}}, {"rtdgi.temporal2", {8, false}}, {"rtdgi.temporal2_var", {4, false}},
         {"rt_history_validity_pre_input_tex", {1, true}}, {"rt_history_validity_input_tex", {1, true}}, {"candidate_radiance_tex", {8, true}},
         {"candidate_hit_tex", {8, true}}, {"temporal_reservoir_packed_tex", {16, true}}, {"reservoir_output_tex0", {8, true}}, {"reservoir_output_tex1", {8, true}},
-        {"irradiance_output_tex", {8, false}}, {"temporal_filtered_tex", {8, false}}, {"spatial_filtered_tex", {8, false}},
+        {"irradiance_output_tex", {8, false}}, {"temporal_filtered_tex", {8, false}}, {"spatial_filtered_tex", {8, false}}, {"reprojected_history_tex", {8, false}},
         {"TAA/taa", {8, false}}, {"TAA/taa.velocity", {4, false}}, {"TAA/taa.smooth_var", {8, false}}, {"TAA/this_frame_output_img", {8, false}},
     };
     return t;
@@ -344,8 +344,10 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
     const uint32_t KEEP = KJ_RTDGI_PASS_KEEP_TEMPORALS, M = s->motion_halo;
     const uint32_t out_i = s->frame % 2, hist_i = 1 - s->frame % 2;
     std::vector<Item> items;
-    // ---- A: last frame's denoised GI everywhere (the trace pass reads it at the hit's screen position); TAA's histories (motion halo)
-    if (s->frame > 0) { items.push_back({sfx("rtdgi.temporal2", hist_i), -1}); items.push_back({sfx("rtdgi.temporal2_var", hist_i), -1}); }
+    // ---- A: last frame's denoised GI and its variance are read through the motion vectors only (fullres_reproject: a 4x4 footprint around the
+    // reprojected pixel; temporal_filter: a bilinear tap): halos, like TAA's histories. What the trace pass reads ANYWHERE on screen is the
+    // reprojected image: every rank reprojects its own strip and the strips are all-gathered (A').
+    if (s->frame > 0) { items.push_back({sfx("rtdgi.temporal2", hist_i), int(M + 3)}); items.push_back({sfx("rtdgi.temporal2_var", hist_i), int(M + 2)}); }
     if (s->taa_frames > 0) {
         const uint32_t th = 1 - s->taa_frames % 2;
         items.push_back({sfx("TAA/taa", th), int(M + 4 + 32)}); items.push_back({sfx("TAA/taa.velocity", th), int(M + 2 + 16)}); items.push_back({sfx("TAA/taa.smooth_var", th), int(M + 2 + 16)});
@@ -354,7 +356,14 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
     for (uint32_t li = 0; li < s->local; ++li) {
         const KjSplitRank& r = s->ranks[li];
         if (r.ircache && !ircache_done) KJ_SPLIT_TRY(ircache_head(*s, li, frames[li], st));
-        KJ_SPLIT_TRY(kj_rtdgi_reproject(r.rtdgi, frames[li].rtdgi.reprojection_map, s->W, s->H, st));
+        const auto own = s->strips[s->first + li];
+        KJ_SPLIT_TRY(kj_rtdgi_reproject_rows(r.rtdgi, frames[li].rtdgi.reprojection_map, s->W, s->H, own.first, own.second, st));
+    }
+    items.clear();
+    items.push_back({"reprojected_history_tex", -1});
+    KJ_SPLIT_TRY(exchange(*s, items, st));
+    for (uint32_t li = 0; li < s->local; ++li) {
+        const KjSplitRank& r = s->ranks[li];
         if (r.ircache) KJ_SPLIT_TRY(kj_ircache_sum_up_irradiance_for_sampling(r.ircache, st));
         KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_EXTRACT_HALF, {0, 0}, 0, st));      // replicated inputs: full frame, cheap
         KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_VALIDATE | KEEP, s->strips[s->first + li], 0, st));
