@@ -210,7 +210,7 @@ def main():
         inputs.append((gp.geometric_normal.clone(), gp.gbuffer.clone(), gp.depth.clone(), rp))
     torch.cuda.synchronize()
     counters = gp_counters = None
-    use_ssgi = not args.no_ssgi    # in the screen-tile split every rank computes the (cheap) guide for the whole frame
+    use_ssgi = not args.no_ssgi
 
     def step(i):
         gn, gb, d, rp = inputs[i]
@@ -226,8 +226,8 @@ def main():
             for q in split.pipes.values():
                 q.geometric_normal, q.gbuffer, q.depth = gn, gb, d
                 q.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
-                if use_ssgi:
-                    q.ssgi_frame()
+            if use_ssgi:
+                split.ssgi_frame()      # the SSAO guide strip by strip (+ halo exchanges); the native orchestrator still computes the whole frame's on every rank
             split.gi_frame()
             split.taa_frame()
 

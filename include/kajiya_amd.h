@@ -457,6 +457,11 @@ KjStatus kj_ssgi_create(KjDevice* dev, KjSsgi** out);
 void kj_ssgi_destroy(KjSsgi* s);
 KjStatus kj_ssgi_render(KjSsgi* s, const KjGbufferDepth* gbuffer_depth, const void* reprojection_map, const void* prev_radiance,
                         const void** out_ssao_r8, void* stream);
+/* The same for full-res rows [row_begin, row_end) (row_begin a multiple of 16): the screen-tile split computes the guide strip by strip. The
+ * intermediate passes over-compute the rows the next pass reaches into; only the temporal pass' history (`ssgi:0|1`, kj_ssgi_surface) is read
+ * outside the strip, within motion + 1 rows: the orchestrator exchanges that halo, and the finished guide's halo its consumers reach into. */
+KjStatus kj_ssgi_render_rows(KjSsgi* ssgi, const KjGbufferDepth* gbuffer_depth, const void* reprojection_map, const void* prev_radiance, uint32_t row_begin, uint32_t row_end,
+                             const void** out_ssao_r8, void* stream);
 KjStatus kj_ssgi_surface(KjSsgi* s, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 
 /* ---------------------------------------------------------------------------

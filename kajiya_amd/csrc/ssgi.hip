@@ -19,11 +19,11 @@ typedef Img<uint8_t> ImgR8;
 #define TILE_XY_M(W_, H_, MODE_)                                                           \
     const int lane = threadIdx.x;                                                          \
     const uint2 kj_tb = kj::tile_order<MODE_>();                                           \
-    const int x = int(kj_tb.x) * 8 + (lane & 7), y = int(kj_tb.y) * 8 + (lane >> 3);       \
-    const bool in_image = x < (W_) && y < (H_);
+    const int x = int(kj_tb.x) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * 8 + (lane >> 3); \
+    const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);      /* rows [row0, row1) of the image: the launch covers just those tiles */
 
 // GbufferDepth::half_view_normal / half_depth (renderers/mod.rs:31-71; extract_half_res_{gbuffer_view_normal_rgba8,depth}.hlsl)
-__global__ void __launch_bounds__(64) k_ssgi_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgU32 half_view_normal, ImgF32 half_depth) {
+__global__ void __launch_bounds__(64) k_ssgi_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgU32 half_view_normal, ImgF32 half_depth, int row0, int row1) {
     TILE_XY_M(half_depth.w, half_depth.h, KJ_TILES_ROWS)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
@@ -69,7 +69,7 @@ KJ_D float ssgi_process_sample(const FrameConstants& fc, V4 sample_cs, V3 center
 }
 
 // "ssao" (ssgi.hlsl:230-341), half res, R16F
-__global__ void __launch_bounds__(64) k_ssgi(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 half_depth, ImgH1 output_tex, int W, int H) {
+__global__ void __launch_bounds__(64) k_ssgi(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 half_depth, ImgH1 output_tex, int W, int H, int row0, int row1) {
     const int hw = output_tex.w, hh = output_tex.h;
     TILE_XY(hw, hh)
     if (!in_image) return;
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(64) k_ssgi(const FrameConstants* __restrict__ 
 }
 
 // "ssao spatial" (spatial_filter.hlsl), half res
-__global__ void __launch_bounds__(64) k_ssgi_spatial(ImgH1 ssgi_tex, ImgF32 half_depth, ImgU32 half_view_normal, ImgH1 output_tex) {
+__global__ void __launch_bounds__(64) k_ssgi_spatial(ImgH1 ssgi_tex, ImgF32 half_depth, ImgU32 half_view_normal, ImgH1 output_tex, int row0, int row1) {
     TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     if (!in_image) return;
     float result = 0, w_sum = 0;
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(64) k_ssgi_spatial(ImgH1 ssgi_tex, ImgF32 half
 }
 
 // "ssao upsample" (upsample.hlsl), full res, R16F
-__global__ void __launch_bounds__(64) k_ssgi_upsample(ImgH1 ssgi_tex, ImgF32 depth, ImgH1 output_tex) {
+__global__ void __launch_bounds__(64) k_ssgi_upsample(ImgH1 ssgi_tex, ImgF32 depth, ImgH1 output_tex, int row0, int row1) {
     TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     if (!in_image) return;
     float result = 0, w_sum = 0;
@@ -227,7 +227,7 @@ KJ_D float sample_bilinear_clamp_r16f(const uint16_t* __restrict__ p, int w, int
     const float a = s00 * (1.0f - tx) + s10 * tx, b = s01 * (1.0f - tx) + s11 * tx;
     return a * (1.0f - ty) + b * ty;
 }
-__global__ void __launch_bounds__(64) k_ssgi_temporal(ImgH1 input_tex, ImgH1 history_tex, ImgU2 reprojection_tex, ImgR8 final_output_tex, ImgH1 history_output_tex) {
+__global__ void __launch_bounds__(64) k_ssgi_temporal(ImgH1 input_tex, ImgH1 history_tex, ImgU2 reprojection_tex, ImgR8 final_output_tex, ImgH1 history_output_tex, int row0, int row1) {
     const int W = final_output_tex.w, H = final_output_tex.h;
     TILE_XY_M(W, H, KJ_TILES_ROWS)
     if (!in_image) return;
@@ -286,8 +286,18 @@ void kj_ssgi_destroy(KjSsgi* t) { delete t; }
 
 // SsgiRenderer::render(rg, gbuffer_depth, reprojection_map, prev_radiance, bindless_descriptor_set) -> ssgi_tex (ssgi.rs:25-81)
 KjStatus kj_ssgi_render(KjSsgi* t, const KjGbufferDepth* gd, const void* reprojection_map, const void* prev_radiance, const void** out_ssao_r8, void* stream_) {
+    KJ_REQUIRE(gd, "null argument");
+    return kj_ssgi_render_rows(t, gd, reprojection_map, prev_radiance, 0u, gd->height, out_ssao_r8, stream_);
+}
+// The guide for full-res rows [row_begin, row_end) (row_begin a multiple of 16): the screen-tile split computes it strip by strip. Every pass runs on
+// the rows the next one reaches into, so nothing but the temporal pass' history (read through the motion vectors) comes from outside the strip:
+//   temporal [r0, r1) reads the upsampled image +-4 rows -> upsample [r0 - 8, r1 + 8) reads the filtered half-res image +-1 -> spatial
+//   [r0/2 - 8, r1/2 + 8) reads ssgi_tex +-1 -> k_ssgi [r0/2 - 16, r1/2 + 16) reads half_depth along its slices, <= 70 rows away -> extract +-88.
+KjStatus kj_ssgi_render_rows(KjSsgi* t, const KjGbufferDepth* gd, const void* reprojection_map, const void* prev_radiance, uint32_t row_begin, uint32_t row_end,
+                             const void** out_ssao_r8, void* stream_) {
     KJ_REQUIRE(t && gd && gd->gbuffer && gd->depth && reprojection_map && out_ssao_r8 && gd->width && gd->height, "null argument");
     KJ_REQUIRE(t->dev->fc_dev, "kj_frame_begin not called");
+    KJ_REQUIRE(row_begin < row_end && row_end <= gd->height && (row_begin % 16u) == 0u, "rows must be a non-empty range starting on a 16-row boundary");
     (void)prev_radiance;   // only feeds the colour accumulation, which USE_AO_ONLY discards (ssgi.hlsl:318-324)
     hipStream_t s = (hipStream_t)stream_;
     const int W = int(gd->width), H = int(gd->height), hw = (W + 1) / 2, hh = (H + 1) / 2;
@@ -306,19 +316,28 @@ KjStatus kj_ssgi_render(KjSsgi* t, const KjGbufferDepth* gd, const void* reproje
     // guide N while frame N+1's ssgi pass is already writing guide N+1
     void* final_out = t->get(t->flip ? "filtered_output_tex:0" : "filtered_output_tex:1", FB, s);
     KJ_TRY_HIP(t->err);
-    const dim3 gf((W + 7) / 8, (H + 7) / 8), gh((hw + 7) / 8, (hh + 7) / 8), blk(64);
+    const dim3 blk(64);
     const ImgU4 gbuffer = img<uint4>(gd->gbuffer, W, H);
     const ImgF32 depth = img<float>(gd->depth, W, H);
-    hipLaunchKernelGGL(k_ssgi_extract_half, gh, blk, 0, s, fc, gbuffer, depth, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh));
+    const bool whole = row_begin == 0u && int(row_end) == H;
+    const int r0 = int(row_begin), r1 = int(row_end), h0 = r0 / 2, h1 = r1 == H ? hh : r1 / 2;
+    auto rows = [&](int a, int b, int limit, int& o0, int& o1) { o0 = whole ? 0 : std::max(0, a); o1 = whole ? limit : std::min(limit, b); };
+    auto grid = [&](int width, int a, int b) { return dim3((width + 7) / 8, (b - a + 7) / 8); };
+    int a, b;
+    rows(h0 - 88, h1 + 88, hh, a, b);
+    hipLaunchKernelGGL(k_ssgi_extract_half, grid(hw, a, b), blk, 0, s, fc, gbuffer, depth, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), a, b);
     KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ssgi, gh, blk, 0, s, fc, gbuffer, img<float>(half_depth, hw, hh), img<uint16_t>(ssgi_tex, hw, hh), W, H);
+    rows(h0 - 16, h1 + 16, hh, a, b);
+    hipLaunchKernelGGL(k_ssgi, grid(hw, a, b), blk, 0, s, fc, gbuffer, img<float>(half_depth, hw, hh), img<uint16_t>(ssgi_tex, hw, hh), W, H, a, b);
     KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ssgi_spatial, gh, blk, 0, s, img<uint16_t>(ssgi_tex, hw, hh), img<float>(half_depth, hw, hh), img<uint32_t>(half_view_normal, hw, hh), img<uint16_t>(spatial, hw, hh));
+    rows(h0 - 8, h1 + 8, hh, a, b);
+    hipLaunchKernelGGL(k_ssgi_spatial, grid(hw, a, b), blk, 0, s, img<uint16_t>(ssgi_tex, hw, hh), img<float>(half_depth, hw, hh), img<uint32_t>(half_view_normal, hw, hh), img<uint16_t>(spatial, hw, hh), a, b);
     KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ssgi_upsample, gf, blk, 0, s, img<uint16_t>(spatial, hw, hh), depth, img<uint16_t>(upsampled, W, H));
+    rows(r0 - 8, r1 + 8, H, a, b);
+    hipLaunchKernelGGL(k_ssgi_upsample, grid(W, a, b), blk, 0, s, img<uint16_t>(spatial, hw, hh), depth, img<uint16_t>(upsampled, W, H), a, b);
     KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ssgi_temporal, gf, blk, 0, s, img<uint16_t>(upsampled, W, H), img<uint16_t>(hist, W, H), img<uint2>(reprojection_map, W, H), img<uint8_t>(final_out, W, H),
-                       img<uint16_t>(hist_out, W, H));
+    hipLaunchKernelGGL(k_ssgi_temporal, grid(W, r0, r1), blk, 0, s, img<uint16_t>(upsampled, W, H), img<uint16_t>(hist, W, H), img<uint2>(reprojection_map, W, H), img<uint8_t>(final_out, W, H),
+                       img<uint16_t>(hist_out, W, H), r0, r1);
     KJ_CHECK_LAUNCH();
     *out_ssao_r8 = final_out;
     return KJ_OK;

@@ -26,7 +26,7 @@ EXPORTS = [
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
     "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts", "kj_ircache_set_deferred_updates", "kj_ircache_begin_requests", "kj_ircache_request_ranges", "kj_ircache_collect_requests", "kj_ircache_apply_requests",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
-    "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_light_gbuffer",
+    "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_render_rows", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_light_gbuffer",
     "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_surface",
     "kj_baked_mesh_view", "kj_baked_image_view", "kj_baked_image_mip", "kj_baked_image_decode_rgba8",
     "kj_rtr_create", "kj_rtr_destroy", "kj_rtr_set_options", "kj_rtr_trace", "kj_rtr_render_specular_lights", "kj_rtr_filter_temporal", "kj_rtr_surface", "kj_rtr_ray_counts",
@@ -134,6 +134,7 @@ def load():
         "kj_motion_blur_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_ssgi_create": [vp, C.POINTER(vp)],
         "kj_ssgi_render": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.POINTER(vp), vp],
+        "kj_ssgi_render_rows": [vp, C.POINTER(KjGbufferDepth), vp, vp, u32, u32, C.POINTER(vp), vp],
         "kj_ssgi_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_reference_path_trace": [vp, vp, vp, u32, u32, u32, u32, u32, vp, vp],
         "kj_taa_render_rows": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp, u32, u32, u32],
@@ -578,13 +579,17 @@ class GpuPipeline:
                                       self._lit[0].data_ptr(), self._lit[1].data_ptr(), debug_shading_mode, _stream_ptr()))
         return self._lit
 
-    def ssgi_frame(self):
-        """SsgiRenderer::render (world_render_passes.rs:90-96): computes the SSAO guide; rtdgi's `ssao_tex` then points at it."""
+    def ssgi_frame(self, rows=None):
+        """SsgiRenderer::render (world_render_passes.rs:90-96): computes the SSAO guide; rtdgi's `ssao_tex` then points at it.
+        `rows` = (row_begin, row_end): only those full-res rows (the screen-tile split, kj_ssgi_render_rows)."""
         if self.ssgi is None:
             self.ssgi = C.c_void_p()
             check(self.L.kj_ssgi_create(self.dev.h, C.byref(self.ssgi)))
         g = self.gbuffer_depth()
-        check(self.L.kj_ssgi_render(self.ssgi, C.byref(g), self.reprojection_map_ptr, None, C.byref(self.ssao_ptr), _stream_ptr()))
+        if rows is None:
+            check(self.L.kj_ssgi_render(self.ssgi, C.byref(g), self.reprojection_map_ptr, None, C.byref(self.ssao_ptr), _stream_ptr()))
+        else:
+            check(self.L.kj_ssgi_render_rows(self.ssgi, C.byref(g), self.reprojection_map_ptr, None, rows[0], rows[1], C.byref(self.ssao_ptr), _stream_ptr()))
 
     def ssgi_surface(self, name, dtype, shape):
         ptr, n = C.c_void_p(), C.c_uint64()

@@ -39,6 +39,11 @@ SURF = {
 }
 # TaaRenderer surfaces (all full-res; input extent == output extent in the split path)
 TAA_SURF = {"taa": 8, "taa.velocity": 4, "taa.smooth_var": 8, "this_frame_output_img": 8}
+# SsgiRenderer surfaces the split exchanges (full-res): the temporal pass' history (R16F) and the finished guide (R8)
+SSGI_SURF = {"ssgi": 2, "filtered_output_tex": 1}
+# rows of the SSAO guide a rank's rtdgi passes reach beyond its strip: the first spatial pass runs on own +- 64 full-res rows and its taps reach another
+# 32 half-res rows (the guide travels inside the half-res G-buffer record extract_half writes), + the half-res subsample offset
+GUIDE_HALO = 144
 
 
 def plan_strips(height, n):
@@ -264,6 +269,8 @@ class SplitRtdgi:
             gp = self.pipes[rank]
             if name.startswith("TAA/"):
                 t = gp.taa_surface(name[4:], torch.uint8, (self.H, self.W * TAA_SURF[name[4:].split(":")[0]]))
+            elif name.startswith("SSGI/"):
+                t = gp.ssgi_surface(name[5:], torch.uint8, (self.H, self.W * SSGI_SURF[name[5:].split(":")[0]]))
             else:
                 bpt, res = SURF[name.split(":")[0]]
                 w = (self.W + 1) // 2 if res == "h" else self.W
@@ -283,7 +290,7 @@ class SplitRtdgi:
         if prepared is None:
             xfers = []
             for name, halo in items:
-                res = "f" if name.startswith("TAA/") else SURF[name.split(":")[0]][1]
+                res = "f" if name.startswith(("TAA/", "SSGI/")) else SURF[name.split(":")[0]][1]
                 xfers += [(src, dst, (name, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H)]
             # renderer surfaces keep their address for a given extent, so the row views can be resolved once per distinct item list
             # (two per exchange point: the ping-pong suffixes alternate)
@@ -410,8 +417,7 @@ class SplitRtdgi:
         i = self.frame & 1
         if run_ssgi:
             torch.cuda.current_stream().wait_event(self._side["fc"][i])
-            for q in self.pipes.values():
-                q.ssgi_frame()
+            self.ssgi_frame()
         torch.cuda.current_stream().wait_event(self._side["irc"][i])
         self.gi_frame(ircache_done=True, trace_event=self._side["trace"][i], defer_merge=True)
         self.taa_frame()
@@ -423,6 +429,20 @@ class SplitRtdgi:
                 sd["stream"].wait_event(sd["trace"][i])
                 self._merge_ircache_requests()
             torch.cuda.current_stream().wait_stream(sd["stream"])
+
+    def ssgi_frame(self):
+        """SsgiRenderer::render strip by strip (kj_ssgi_render_rows), before gi_frame: every rank computes the SSAO guide for its own rows -- the
+        intermediate passes over-compute what the next pass reaches into -- after the halo of the temporal pass' history has arrived, then the
+        finished guide's halo is exchanged: rtdgi's passes read it up to GUIDE_HALO rows beyond the strip (gi_frame runs extract_half on those
+        rows). Round 2 computed the whole frame's guide on every rank: 0.25 ms of replicated work per rank at 4K."""
+        self.ssgi_frames = getattr(self, "ssgi_frames", 0)
+        M = self.motion_halo
+        if self.ssgi_frames > 0:
+            self._exchange([(f"SSGI/ssgi:{1 - self.ssgi_frames % 2}", M + 2)])
+        for r in self.comm.ranks:
+            self.pipes[r].ssgi_frame(rows=self.strips[r])
+        self._exchange([(f"SSGI/filtered_output_tex:{self.ssgi_frames % 2}", GUIDE_HALO + 2)])
+        self.ssgi_frames += 1
 
     def gi_frame(self, ircache_done=False, trace_event=None, defer_merge=False):
         """One rtdgi frame. Unless `ircache_done`, each rank's ircache.prepare + trace_irradiance run here first (serial order).
@@ -459,7 +479,10 @@ class SplitRtdgi:
             s = self._s
             if gp.ircache:
                 klib.check(gp.L.kj_ircache_sum_up_irradiance_for_sampling(gp.ircache, s))
-            self._render(r, P["EXTRACT_HALF"])                                   # replicated inputs: full frame, cheap
+            # the half-res images and G-buffer records for the WHOLE frame (replicated inputs, cheap): the resolve reads the view normal at every
+            # reservoir's sample pixel, and an empty reservoir's payload is pixel (0, 0) -- rows far outside the strip. With the strip-wise guide
+            # (self.ssgi_frame) the records' ssao byte is only meaningful on own +- GUIDE_HALO rows, which is where it is read.
+            self._render(r, P["EXTRACT_HALF"])
             self._render(r, P["VALIDATE"] | KEEP, self.strips[r])
         # ---- B
         items = [("rt_history_validity_pre_input_tex", M + 1)]
@@ -642,6 +665,11 @@ class NativeSplit:
             if self.on_ircache_traced is not None:
                 self.on_ircache_traced()
             sd["irc"][self.frame & 1].record(sd["stream"])
+
+    def ssgi_frame(self):
+        """The SSAO guide before gi_frame. Here: the whole frame's on every rank (the strip-wise form with its two halo exchanges is SplitRtdgi's)."""
+        for q in self.pipes.values():
+            q.ssgi_frame()
 
     def frame_pipelined(self, next_fc, run_ssgi=False):
         import torch

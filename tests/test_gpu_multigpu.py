@@ -7,8 +7,10 @@ import test_gpu_parity as T
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_ranks,W,H", [(2, 256, 160), (3, 320, 208)])
-def test_strip_split_is_bit_exact(gpu, device, n_ranks, W, H):
+@pytest.mark.parametrize("n_ranks,W,H,with_ssgi", [(2, 256, 160, False), (3, 320, 208, False), (2, 256, 160, True), (3, 320, 208, True), (2, 384, 800, True)])
+def test_strip_split_is_bit_exact(gpu, device, n_ranks, W, H, with_ssgi):
+    """`with_ssgi`: the SSAO guide computed strip by strip as well (SplitRtdgi.ssgi_frame: kj_ssgi_render_rows + the halo exchanges of its history
+    and of the finished guide) instead of the constant guide; 384x800 on two ranks: strips of 400 rows, taller than every halo involved."""
     import torch
     from kajiya_amd import multigpu
     desc = T._scenes()["city20k"]
@@ -17,17 +19,28 @@ def test_strip_split_is_bit_exact(gpu, device, n_ranks, W, H):
     pipes = {r: gpu.GpuPipeline(device, scene, W, H) for r in range(n_ranks)}
     split = multigpu.SplitRtdgi(multigpu.LocalComm(n_ranks), pipes, W, H, motion_halo=8)
     assert split.strips[0][0] == 0 and split.strips[-1][1] == H
-    for fi, fc in enumerate(T._frame_constants(W, H, 7, "city")):
-        ref.frame(fc)
+    for fi, fc in enumerate(T._frame_constants(W, H, 5 if H > 400 else 7, "city")):
+        if with_ssgi:
+            ref.dev.frame_begin(fc); ref.render_inputs(fc); ref.reprojection(); ref.ssgi_frame(); ref.gi_frame()
+        else:
+            ref.frame(fc)
         for r in range(n_ranks):
             pipes[r].render_inputs(fc)
             pipes[r].reprojection()
+        if with_ssgi:
+            split.ssgi_frame()
         split.gi_frame()
         split.taa_frame()
         ref.taa_frame()
         split.gather_output("spatial_filtered_tex")
         split.gather_output(f"TAA/taa:{fi % 2}")
         torch.cuda.synchronize()
+        if with_ssgi:      # the guide itself, on every rank's own rows
+            ga = ref.ssgi_surface(f"filtered_output_tex:{fi % 2}", torch.uint8, (H, W))
+            for r in range(n_ranks):
+                r0, r1 = split.strips[r]
+                gb = pipes[r].ssgi_surface(f"filtered_output_tex:{fi % 2}", torch.uint8, (H, W))
+                assert torch.equal(ga[r0:r1], gb[r0:r1]), f"frame {fi} rank {r}: SSAO guide differs in {int((ga[r0:r1] != gb[r0:r1]).sum())} texels of its strip"
         a = ref.surface("spatial_filtered_tex", torch.int16, (H, W, 4))
         for r in range(n_ranks):
             b = pipes[r].surface("spatial_filtered_tex", torch.int16, (H, W, 4))
