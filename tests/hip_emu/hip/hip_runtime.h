@@ -21,6 +21,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -47,7 +48,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 inline thread_local dim3 threadIdx, blockIdx;
-inline dim3 gridDim, blockDim;
+inline thread_local dim3 gridDim, blockDim;     // per host thread: launches may come from several host threads at once (every worker of a launch sets its own copy)
 
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
@@ -70,6 +71,8 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     if (blocks == 0 || n == 0) return;
     std::barrier<> block_end(n);
     std::unique_ptr<std::barrier<>> current;
+    static std::mutex one_launch_at_a_time;      // this mode keeps the running workgroup's barrier and "LDS" in process-wide statics
+    std::lock_guard<std::mutex> lock(one_launch_at_a_time);
     gridDim = grid;
     blockDim = block;
     for (unsigned t = 0; t < n; ++t) g_lane_active[t] = true;
@@ -78,6 +81,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     std::vector<std::thread> threads;
     for (unsigned t = 0; t < n; ++t)
         threads.emplace_back([&, t]() {
+            gridDim = grid; blockDim = block;
             threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
             for (unsigned bz = 0; bz < grid.z; ++bz)
                 for (unsigned by = 0; by < grid.y; ++by)
@@ -168,6 +172,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     std::atomic<size_t> next{0};
     auto work = [&]() {
         static thread_local Worker w;
+        gridDim = grid; blockDim = block;
         g_worker = &w;
         w.body = &body;
         for (;;) {
