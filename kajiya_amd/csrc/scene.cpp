@@ -11,7 +11,6 @@
 #include "kj_host.hpp"
 #include "kj_bvh_build.hpp"
 #include <algorithm>
-#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -319,6 +318,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         std::swap(pool.p, bigger.p); std::swap(pool.bytes, bigger.bytes);
         return e;
     };
+    LbvhScratch lbvh_scratch;     // device-side builds of this commit share their working buffers
     // host SAH builds of all new meshes run concurrently (a small mesh builds on one thread: nine of them one after the other were
     // half of a first commit); each result is the same tree whatever runs beside it
     auto host_build = [s](uint32_t mi) {
@@ -358,61 +358,19 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         } catch (const std::exception&) { return false; }
         return true;
     };
-    if (!start_builds() && host_builds.empty() && !to_build.empty()) { set_last_error("could not start a BLAS build thread"); return KJ_ERR_OUT_OF_MEMORY; }
-    // Device-side builds (LBVH / PLOC) of this commit: straight into the pools, each mesh with a reservation of one node per triangle (the builders'
-    // bound; a 4-wide tree uses about a quarter of it) so that every mesh's place is known before any is built and the pools are grown ONCE. A build is a
-    // chain of small launches and a dozen read-backs -- launch-latency sized for all but the largest meshes --, so up to four run side by side, each
-    // on a stream and a working set of its own (nine meshes, 985 k triangles: 7.2 -> see profiles/r03_blas_builders.md).
-    std::vector<uint32_t> device_meshes;
-    std::map<uint32_t, LbvhResult> device_results;
-    for (uint32_t mi = 0; mi < s->meshes.size(); ++mi)
-        if (!s->blas[mi].built && s->mesh_build_mode[mi] != 0) device_meshes.push_back(mi);
-    if (!device_meshes.empty()) {
-        uint32_t nodes_end = s->blas_nodes_used, tris_end = s->obj_tris_used;
-        for (uint32_t mi : device_meshes) {
-            KjScene::Blas& bl = s->blas[mi];
-            const uint32_t ntri = s->meshes[mi].index_count / 3;
-            bl.node_base = nodes_end; bl.tri_base = tris_end; bl.tri_count = ntri;
-            nodes_end += ntri + 1u; tris_end += ntri;
-            device_results[mi] = LbvhResult();
-        }
-        KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), size_t(nodes_end) * sizeof(BvhNode)));
-        KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), size_t(tris_end) * sizeof(BvhTri)));
-        KJ_TRY_HIP(hipStreamSynchronize(stream));      // the vertex buffer upload and the pools' moves are done before other streams read / write them
-        const uint32_t n_workers = uint32_t(std::min<size_t>(4, device_meshes.size()));
-        std::atomic<size_t> next_mesh{0};
-        std::vector<hipError_t> worker_error(n_workers, hipSuccess);
-        auto worker = [&](uint32_t w) {
-            hipError_t e = hipSetDevice(s->dev->ordinal);
-            hipStream_t ws = nullptr;
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&ws, hipStreamNonBlocking);
-            LbvhScratch scratch;      // this worker's builds share their working buffers
-            for (size_t k; e == hipSuccess && (k = next_mesh.fetch_add(1)) < device_meshes.size();) {
-                const uint32_t mi = device_meshes[k];
-                const KjScene::Blas& bl = s->blas[mi];
-                e = build_blas_lbvh_device((const uint8_t*)s->d_vertex_buffer.p, s->meshes[mi], bl.node_base, (Bvh4Node*)s->d_blas_nodes.p + bl.node_base, (BvhTri*)s->d_obj_tris.p + bl.tri_base,
-                                           &device_results[mi], &scratch, ws, s->mesh_build_mode[mi] == 2);
-            }
-            if (ws) { if (e == hipSuccess) e = hipStreamSynchronize(ws); (void)hipStreamDestroy(ws); }
-            worker_error[w] = e;
-        };
-        std::vector<std::thread> pool;
-        try { for (uint32_t w = 1; w < n_workers; ++w) pool.emplace_back(worker, w); } catch (const std::exception&) {}      // fewer threads: the others' meshes fall to those that started
-        worker(0);
-        for (std::thread& t : pool) t.join();
-        for (hipError_t e : worker_error) KJ_TRY_HIP(e);
-        s->blas_nodes_used = nodes_end; s->obj_tris_used = tris_end;
-    }
+    if (!start_builds() && host_builds.empty()) { set_last_error("could not start a BLAS build thread"); return KJ_ERR_OUT_OF_MEMORY; }
     for (uint32_t mi = 0; mi < s->meshes.size(); ++mi) {
         KjScene::Blas& bl = s->blas[mi];
         if (bl.built) continue;
         const GpuMesh& m = s->meshes[mi];
         const uint32_t ntri = m.index_count / 3;
-        const bool on_device = s->mesh_build_mode[mi] != 0;
-        if (!on_device) { bl.node_base = s->blas_nodes_used; bl.tri_base = s->obj_tris_used; bl.tri_count = ntri; }
+        bl.node_base = s->blas_nodes_used; bl.tri_base = s->obj_tris_used; bl.tri_count = ntri;
         std::vector<uint32_t> steps;          // {first, end} node of every step of the refit's bottom-up order
-        if (on_device) {   // built above
-            const LbvhResult& lr = device_results[mi];
+        if (s->mesh_build_mode[mi] != 0) {   // on the device (LBVH or PLOC), straight into the pools (at most one node per triangle)
+            KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), size_t(s->blas_nodes_used + ntri + 1) * sizeof(BvhNode)));
+            KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), size_t(s->obj_tris_used + ntri) * sizeof(BvhTri)));
+            LbvhResult lr;
+            KJ_TRY_HIP(build_blas_lbvh_device((const uint8_t*)s->d_vertex_buffer.p, m, bl.node_base, (Bvh4Node*)s->d_blas_nodes.p + bl.node_base, (BvhTri*)s->d_obj_tris.p + bl.tri_base, &lr, &lbvh_scratch, stream, s->mesh_build_mode[mi] == 2));
             bl.node_count = lr.node_count; bl.max_stack = lr.max_stack;
             memcpy(bl.bounds, lr.bounds, 24);
             // laid out by depth on the device: the refit walks the levels deepest first, the root is node 0
@@ -469,7 +427,8 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
             for (size_t h = 0; h < steps.size(); h += 2) fprintf(stderr, " %u", steps[h + 1] - steps[h]);
             fprintf(stderr, "\n");
         }
-        if (!on_device) { s->blas_nodes_used += bl.node_count; s->obj_tris_used += ntri; }
+        s->blas_nodes_used += bl.node_count;
+        s->obj_tris_used += ntri;
         bl.built = true;
     }
     if (s->meshes_dirty) KJ_TRY_HIP(s->d_blas_steps.upload(s->blas_steps.data(), s->blas_steps.size() * 4, stream));
