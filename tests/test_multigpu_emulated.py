@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, H, frames, packed, q, with_ircache=False):
+def _worker(rank, world, port, W, H, frames, packed, q, with_ircache=False, with_ssgi=False):
     try:
         os.environ["KJ_HIP_EMU"] = "fast"
         os.environ.setdefault("HIP_EMU_WORKERS", "4")
@@ -55,9 +55,14 @@ def _worker(rank, world, port, W, H, frames, packed, q, with_ircache=False):
             fcs.append(fs.prepare_frame_constants(kframe.orbit_camera(i, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.004)))
             fs.retire_frame()
         for fi, fc in enumerate(fcs):
-            ref.frame(fc)
+            if with_ssgi:      # the SSAO guide: whole-frame on the reference, strip by strip (+ its two halo exchanges over gloo) in the split
+                ref.render_inputs(fc); ref.reprojection(); ref.ssgi_frame(); ref.gi_frame()
+            else:
+                ref.frame(fc)
             pipe.render_inputs(fc)
             pipe.reprojection()
+            if with_ssgi:
+                split.ssgi_frame()
             split.gi_frame()
             split.taa_frame()
             ref.taa_frame()
@@ -79,8 +84,8 @@ def _worker(rank, world, port, W, H, frames, packed, q, with_ircache=False):
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs ROCm's clang++ as the host compiler")
-@pytest.mark.parametrize("world,packed,with_ircache", [(2, False, False), (3, True, False), (2, False, True)])
-def test_strip_split_over_gloo_processes_with_the_real_kernels(world, packed, with_ircache):
+@pytest.mark.parametrize("world,packed,with_ircache,with_ssgi", [(2, False, False, False), (3, True, False, True), (2, False, True, False)])
+def test_strip_split_over_gloo_processes_with_the_real_kernels(world, packed, with_ircache, with_ssgi):
     """with_ircache: the irradiance cache bound on every rank; the strips' recorded cache updates travel through DistComm.all_gather_rows
     and every replica must stay bit-identical to the single-GPU cache."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "hip_emu"))
@@ -98,7 +103,7 @@ def test_strip_split_over_gloo_processes_with_the_real_kernels(world, packed, wi
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, frames, packed, q, with_ircache)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, frames, packed, q, with_ircache, with_ssgi)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=900) for _ in range(world)]
