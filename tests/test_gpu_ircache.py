@@ -339,3 +339,113 @@ def test_ircache_deterministic_free_running(gpu, oracle, device):
     r = P.compare(gp.surface("spatial_filtered_tex", torch.uint8, (-1,)).cpu().numpy(), op.surface("spatial_filtered_tex", np.uint8, (-1,)), "rgba16f")
     print("free-running GI with the deterministic cache:", r)
     assert r["rel_l2"] < 5e-3, r
+
+
+def _sequential_replay(state, req):
+    """The recurrence kj_ircache_apply_requests evaluates with segmented scans, stated the slow way (lookup.hlsl:118-150, 287-301 in the canonical
+    order: by cell, then by the lookup's position in the frame). `state`: dict of numpy arrays (modified in place); `req`: [n, 8] uint32 records
+    {cell, key, bits, dart, proposal x4}."""
+    LIFE_PER_RANK, LIFE_RECYCLE, MAX_ENTRIES, OCC, JUST = 4, 0x8000000, 65536, 1, 2
+    order = sorted(range(len(req)), key=lambda i: (int(req[i, 0]), int(req[i, 1])))
+    gm, life, votes, prop, pool, meta, ecell = state["grid_meta"], state["life"], state["reposition_proposal_count"], state["reposition_proposal"], state["pool"], state["meta"], state["entry_cell"]
+    alloc0 = int(meta[3])
+    new_cells = 0
+    i = 0
+    while i < len(order):
+        cell = int(req[order[i], 0])
+        j = i
+        while j < len(order) and int(req[order[j], 0]) == cell:
+            j += 1
+        seg = [order[k] for k in range(i, j)]
+        i = j
+        if cell == 0xffffffff:
+            continue
+        flags = int(gm[cell, 1])
+        if not (flags & OCC):
+            first = next((k for k in seg if not (int(req[k, 2]) & 0x100)), None)
+            if first is None:
+                continue
+            alloc_idx = alloc0 + new_cells
+            new_cells += 1
+            if alloc_idx >= MAX_ENTRIES:
+                continue
+            e = int(pool[alloc_idx])
+            meta[2] = max(int(meta[2]), e + 1)
+            life[e] = (int(req[first, 2]) & 0xff) * LIFE_PER_RANK
+            ecell[e] = cell
+            gm[cell] = (e, flags | OCC | JUST)
+            prop[e] = req[first, 4:8]
+            continue
+        if flags & JUST:
+            continue
+        e = int(gm[cell, 0])
+        cur_life, cur_votes = int(life[e]), int(votes[e])
+        for k in seg:
+            rank = int(req[k, 2]) & 0xff
+            if cur_life < LIFE_RECYCLE:
+                prev = cur_life
+                if rank * LIFE_PER_RANK < prev:
+                    cur_life = rank * LIFE_PER_RANK
+                if rank <= prev // LIFE_PER_RANK:
+                    dart = req[k, 3:4].view(np.float32)[0]
+                    if dart <= np.float32(1.0) / (np.float32(cur_votes) + np.float32(1.0)):
+                        prop[e] = req[k, 4:8]
+                    cur_votes += 1
+        life[e], votes[e] = cur_life, cur_votes
+    meta[3] = min(alloc0 + new_cells, MAX_ENTRIES)
+
+
+@pytest.mark.parametrize("case", ["random", "one hot cell", "nobody may allocate", "recycled and fresh"])
+def test_replay_of_recorded_lookups_equals_the_sequential_recurrence(gpu, device, case):
+    """kj_ircache_apply_requests on synthetic record lists against `_sequential_replay`, every touched buffer bit for bit: 60 k records over occupied
+    and empty cells; 40 k records on ONE cell (the case that took a thread a millisecond before the scans); lists whose lookups may not allocate;
+    entries past IRC_LIFE_RECYCLE and cells allocated this frame (both left alone)."""
+    import torch
+    W = H = 96
+    gp = gpu.GpuPipeline(device, gpu.Scene(device, T._scenes()["cornell"]), W, H, use_ircache=True)
+    gp.ircache_set_deferred(True)
+    for fc in _frames(W, H, 4, scene="cornell"):
+        gp.dev.frame_begin(fc); gp.render_inputs(fc); gp.reprojection(); gp.gi_frame()
+    torch.cuda.synchronize()
+    names = {"grid_meta": np.uint32, "life": np.uint32, "reposition_proposal_count": np.uint32, "reposition_proposal": np.uint32, "pool": np.uint32, "meta": np.uint32, "entry_cell": np.uint32}
+    state = {n: gp.ircache_buffer(n, torch.uint8).cpu().numpy().view(dt).copy() for n, dt in names.items()}
+    state["grid_meta"] = state["grid_meta"].reshape(-1, 2); state["reposition_proposal"] = state["reposition_proposal"].reshape(-1, 4)
+    gm = state["grid_meta"]
+    occupied = np.nonzero(gm[:, 1] & 1)[0]
+    empty = np.nonzero((gm[:, 1] & 1) == 0)[0]
+    assert len(occupied) > 50
+    rng = np.random.RandomState(11)
+    if case == "recycled and fresh":      # a third of the occupied cells' entries recycled, a third of the cells marked just allocated
+        sel = rng.permutation(len(occupied))
+        for c in occupied[sel[: len(sel) // 3]]:
+            state["life"][gm[c, 0]] = 0x8000000 + rng.randint(0, 2)
+        for c in occupied[sel[len(sel) // 3: 2 * len(sel) // 3]]:
+            gm[c, 1] |= 2
+        for n in ("life", "grid_meta"):
+            gp.ircache_buffer(n, torch.uint8).copy_(torch.from_numpy(state[n].reshape(-1).view(np.uint8)))
+    n = 40_000 if case == "one hot cell" else 60_000
+    req = np.zeros((n, 8), np.uint32)
+    if case == "one hot cell":
+        req[:, 0] = occupied[len(occupied) // 2]
+    else:
+        pick_empty = rng.uniform(size=n) < 0.15
+        req[:, 0] = np.where(pick_empty, empty[rng.randint(0, min(len(empty), 400), size=n)], occupied[rng.randint(0, len(occupied), size=n)])
+        req[rng.uniform(size=n) < 0.02, 0] = 0xffffffff      # unused slots inside the list
+    req[:, 1] = rng.permutation(n).astype(np.uint32) | (np.uint32(3) << 28)      # distinct positions in the frame
+    rank = rng.randint(0, 5, size=n).astype(np.uint32)
+    skip = (rank >= 3) | (rng.uniform(size=n) < (1.0 if case == "nobody may allocate" else 0.2))
+    req[:, 2] = rank | (skip.astype(np.uint32) << 8)
+    req[:, 3] = rng.uniform(size=n).astype(np.float32).view(np.uint32)
+    req[:, 4:8] = rng.randint(0, 2**31, size=(n, 4)).astype(np.uint32)
+    d_req = torch.from_numpy(req.view(np.int32)).cuda()
+    gp.ircache_apply(d_req, n)
+    torch.cuda.synchronize()
+    _sequential_replay(state, req)
+    for name, dt in names.items():
+        got = gp.ircache_buffer(name, torch.uint8).cpu().numpy().view(dt)
+        want = state[name].reshape(-1)
+        if name == "pool":      # new cells take entries pool[alloc0 ..]: the pool itself is not written
+            assert np.array_equal(got, want)
+            continue
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (case, name, len(bad), bad[:8].tolist(), got[bad[:4]].tolist(), want[bad[:4]].tolist())
