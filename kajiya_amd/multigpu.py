@@ -6,8 +6,9 @@ tiles never straddle a cut). Every rank keeps full-size surfaces but runs each p
 (`KjRtdgiRenderParams.row_begin/row_end`); between passes the rows a consumer pass can reach are fetched
 from their owners:
 
-  * last frame's denoised GI (`rtdgi.temporal2`, + its variance) is ALL-GATHERED: the trace pass reads it at the
-    hit point's screen position, anywhere on screen (diffuse_trace_common.inc.hlsl:85-107);
+  * the REPROJECTED GI history is ALL-GATHERED after every rank has reprojected its own strip: the trace pass reads it at the
+    hit point's screen position, anywhere on screen (diffuse_trace_common.inc.hlsl:85-107); last frame's denoised GI
+    (`rtdgi.temporal2`) and its variance themselves are only read through the motion vectors: halos;
   * everything else is a bounded HALO: motion+4 rows of the five reservoir histories before the temporal
     pass, 51 half-res rows of {reservoir, packed reservoir, radiance} after it (spatial 32 + 16, resolve 3;
     restir_spatial.hlsl:89-97, restir_resolve.hlsl:89-96), 16 / 3 rows between the spatial passes, 2 / 16
