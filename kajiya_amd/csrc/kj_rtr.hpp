@@ -23,11 +23,16 @@ typedef Img<uint2> ImgU2;     // RG32UI (reservoirs) and RGBA16_SNORM share the 
 typedef Img<uint8_t> ImgR8;
 typedef Img<float4> ImgF4;
 
-#define TILE_XY(W_, H_)                                                   \
+// workgroup -> tile order (kj_vec.hpp: tile_order; profiles/r03_xcd_tile_order.md): the passes whose every tile costs the same take whole tile rows per
+// XCD (TILE_XY_ROWS: temporal filter 180 -> 172 us, cleanup 51 -> 44, extract_half 14.6 -> 13.0 at 1440p); the ray passes, the reservoir pass and
+// the resolve keep the plain order (measured equal or 1-2 % slower with rows)
+#define TILE_XY_ORDER(W_, H_, MODE_)                                      \
     const int lane = threadIdx.x;                                         \
-    const uint2 kj_tb = kj::tile_order<KJ_TILES_PLAIN>();                 \
+    const uint2 kj_tb = kj::tile_order<MODE_>();                          \
     const int x = int(kj_tb.x) * 8 + (lane & 7), y = int(kj_tb.y) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < (H_);
+#define TILE_XY(W_, H_) TILE_XY_ORDER(W_, H_, KJ_TILES_PLAIN)
+#define TILE_XY_ROWS(W_, H_) TILE_XY_ORDER(W_, H_, KJ_TILES_ROWS)
 
 // ------------------------------------------------------------------ small device helpers
 KJ_D V3 get_prev_eye_position(const FrameConstants& fc) { const V4 e = mul44(fc.view_constants.prev_view_to_prev_world, V4{0, 0, 0, 1}); return xyz(e) / e.w; }

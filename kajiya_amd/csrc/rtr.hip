@@ -53,7 +53,7 @@ KJ_D float blue_noise_sampler(const RtrCtx& c, int pixel_i, int pixel_j, int sam
 
 // ------------------------------------------------------------------ GbufferDepth::half_view_normal / half_depth (renderers/mod.rs:44-71)
 __global__ void __launch_bounds__(64) k_rtr_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgU32 half_view_normal, ImgF32 half_depth) {
-    TILE_XY(half_depth.w, half_depth.h)
+    TILE_XY_ROWS(half_depth.w, half_depth.h)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
     const I2 off = halfres_subsample_offset(fc.frame_index);

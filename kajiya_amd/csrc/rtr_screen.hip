@@ -250,7 +250,7 @@ KJ_D V3 soft_color_clamp_fast(V3 center, V3 history, V3 ex, V3 dev) {
 // ------------------------------------------------------------------ temporal_filter.hlsl:37-259
 __global__ void __launch_bounds__(64) k_rtr_temporal_filter(const FrameConstants* __restrict__ fcp, ImgU32 input_tex, ImgH4 history_tex, ImgF32 depth_tex, ImgU32 ray_len_tex,
                                                              ImgU2 reprojection_tex, ImgR8 refl_restir_invalidity_tex, ImgU4 gbuffer_tex, ImgH4 output_tex) {
-    TILE_XY(output_tex.w, output_tex.h)
+    TILE_XY_ROWS(output_tex.w, output_tex.h)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
     const V4 ots = tex_size4(output_tex.w, output_tex.h);
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(64) k_rtr_temporal_filter(const FrameConstants
 // ------------------------------------------------------------------ spatial_cleanup.hlsl:20-65
 __global__ void __launch_bounds__(64) k_rtr_cleanup(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgF32 depth_tex, ImgU32 geometric_normal_tex, ImgU32 output_tex,
                                                      const int4* __restrict__ spatial_resolve_offsets) {
-    TILE_XY(output_tex.w, output_tex.h)
+    TILE_XY_ROWS(output_tex.w, output_tex.h)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
     const V4 center = ld4(input_tex, x, y);
