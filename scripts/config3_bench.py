@@ -57,8 +57,8 @@ for i in range(K0, K0 + K + 7):
     rp = lib.tensor_from_ptr(gp.reprojection_map_ptr.value, W * H * 8, torch.int16, (H, W, 4)).clone()
     fcs.append(fc); inputs.append((gp.geometric_normal.clone(), gp.gbuffer.clone(), gp.depth.clone(), rp))
 torch.cuda.synchronize()
-main, side = torch.cuda.current_stream(), torch.cuda.Stream()
-ev_fc, ev_irc, ev_rtr = ([torch.cuda.Event(), torch.cuda.Event()] for _ in range(3))
+main, side, tail = torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()
+ev_fc, ev_irc, ev_rtr, ev_lit, ev_taa = ([torch.cuda.Event(), torch.cuda.Event()] for _ in range(5))
 L = gp.L
 
 
@@ -86,8 +86,14 @@ def overlapped_frame(j):
     p = gp.params((P["ALL"] & ~P["EXTRACT_HALF"]) | (1 << 31)); lib.check(L.kj_rtdgi_render(gp.rtdgi, C.byref(p), C.byref(gp.out), s))
     rtr = gp.rtr_frame()
     ev_rtr[j & 1].record(main)
+    if j > 0:
+        main.wait_event(ev_taa[(j - 1) & 1])      # last frame's TAA has read the lit image this deferred combine overwrites
     lit_t, lit = gp.light_gbuffer(shadow, rtr_ptr=rtr.data_ptr())
-    gp.taa_frame(input_ptr=lit.data_ptr())
+    ev_lit[j & 1].record(main)
+    with torch.cuda.stream(tail):                # TAA (VALU-bound) on a third stream: under the next frame's SSAO guide and shadow rays
+        tail.wait_event(ev_lit[j & 1])
+        gp.taa_frame(input_ptr=lit.data_ptr())
+        ev_taa[j & 1].record(tail)
     enqueue_cache(j + 1, ev_rtr[j & 1])
 
 
@@ -105,5 +111,5 @@ all_rays = sum(v[0] + v[1] for v in rays.values()) / n + shadow_rays
 print(json.dumps({"config": "BASELINE configs[2]", "workload": f"procedural_ruins {a.tris} tris (Ruins stand-in) @ {W}x{H}", "frame_ms": round(total, 4), "fps": round(1000.0 / total, 1),
                   "serial_frame_ms": round(serial_total, 4), "segment_ms": seg, "rays_per_frame": {k: [v[0] / n, v[1] / n] for k, v in rays.items()} | {"sun shadow": [0, shadow_rays]},
                   "mrays_per_s": round(all_rays / total / 1e3, 1), "frames": K, "serial_frames": n,
-                  "overlap": "ircache of frame N+1 on a second stream under frame N's deferred combine + TAA and frame N+1's SSAO guide + shadows; segment_ms from a serial run of the same frames",
+                  "overlap": "ircache of frame N+1 on a second stream from the end of frame N's reflections; TAA of frame N on a third stream under frame N+1's SSAO guide + shadows; segment_ms from a serial run of the same frames",
                   "rtr_tables": "stand-in"}))
