@@ -611,6 +611,9 @@ KjStatus kj_split_strip(KjSplit* split, uint32_t rank, uint32_t* out_row_begin, 
 enum { KJ_SPLIT_IRCACHE_DONE = 1u, KJ_SPLIT_DEFER_IRCACHE_MERGE = 2u };
 KjStatus kj_split_gi_frame(KjSplit* split, const KjSplitFrame* frames, uint32_t flags, void* trace_done_event, void* stream);
 KjStatus kj_split_merge_ircache(KjSplit* split, void* stream);
+/* The SSAO guide of the frame, before kj_split_gi_frame: SsgiRenderer::render strip by strip (kj_ssgi_render_rows) with the halo exchanges of its temporal
+ * history and of the finished guide. `ssgi`, `out_ssao_r8`: one entry per LOCAL rank; out_ssao_r8[i] is what frames[i].rtdgi.ssao_tex must point at. */
+KjStatus kj_split_ssgi_frame(KjSplit* split, KjSsgi* const* ssgi, const KjSplitFrame* frames, const void** out_ssao_r8, void* stream);
 /* TAA on the GI output of the frame just rendered (exchange I + strip-wise TaaRenderer::render). */
 KjStatus kj_split_taa_frame(KjSplit* split, const KjSplitFrame* frames, void* stream);
 /* Every rank receives the owners' rows of a surface ("spatial_filtered_tex", "TAA/taa:0", ...): result collection. */

@@ -34,6 +34,7 @@ const std::map<std::string, SurfInfo>& surf_table() {
         {"rt_history_validity_pre_input_tex", {1, true}}, {"rt_history_validity_input_tex", {1, true}}, {"candidate_radiance_tex", {8, true}},
         {"candidate_hit_tex", {8, true}}, {"temporal_reservoir_packed_tex", {16, true}}, {"reservoir_output_tex0", {8, true}}, {"reservoir_output_tex1", {8, true}},
         {"irradiance_output_tex", {8, false}}, {"temporal_filtered_tex", {8, false}}, {"spatial_filtered_tex", {8, false}}, {"reprojected_history_tex", {8, false}},
+        {"SSGI/ssgi", {2, false}}, {"SSGI/filtered_output_tex", {1, false}},
         {"TAA/taa", {8, false}}, {"TAA/taa.velocity", {4, false}}, {"TAA/taa.smooth_var", {8, false}}, {"TAA/this_frame_output_img", {8, false}},
     };
     return t;
@@ -79,7 +80,8 @@ struct KjSplit {
     uint32_t world = 0, first = 0, local = 0, W = 0, H = 0, hw = 0, hh = 0, motion_halo = 8;
     std::vector<KjSplitRank> ranks;                        // the local ones, rank = first + index
     std::vector<std::pair<uint32_t, uint32_t>> strips;     // full-res rows [r0, r1) of every rank of the job
-    uint32_t frame = 0, taa_frames = 0;
+    uint32_t frame = 0, taa_frames = 0, ssgi_frames = 0;
+    std::vector<KjSsgi*> ssgi;                             // the local ranks' SsgiRenderers (kj_split_ssgi_frame)
     bool consistent_ircache = false;
     std::vector<uint8_t> ircache_was_deferred;             // each local cache's mode before kj_split_create changed it: restored by kj_split_destroy
     void* nccl = nullptr;                                  // ncclComm_t; null: every rank is local
@@ -111,7 +113,10 @@ KjStatus surface_of(KjSplit& s, uint32_t rank, const std::string& name, uint8_t*
     auto it = s.surfaces.find(key);
     if (it == s.surfaces.end()) {     // renderer surfaces are allocated once per extent: the pointer is stable
         void* p = nullptr; uint64_t bytes = 0;
-        const KjStatus st = name.rfind("TAA/", 0) == 0 ? kj_taa_surface(s.ranks[li].taa, name.c_str() + 4, &p, &bytes) : kj_rtdgi_surface(s.ranks[li].rtdgi, name.c_str(), &p, &bytes);
+        KJ_REQUIRE(name.rfind("SSGI/", 0) != 0 || (li < s.ssgi.size() && s.ssgi[li]), "no SsgiRenderer bound to this rank");
+        const KjStatus st = name.rfind("TAA/", 0) == 0    ? kj_taa_surface(s.ranks[li].taa, name.c_str() + 4, &p, &bytes)
+                            : name.rfind("SSGI/", 0) == 0 ? kj_ssgi_surface(s.ssgi[li], name.c_str() + 5, &p, &bytes)
+                                                          : kj_rtdgi_surface(s.ranks[li].rtdgi, name.c_str(), &p, &bytes);
         if (st != KJ_OK) return st;
         it = s.surfaces.emplace(key, std::make_pair((uint8_t*)p, bytes)).first;
     }
@@ -407,6 +412,24 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
 KjStatus kj_split_merge_ircache(KjSplit* s, void* stream) {
     KJ_REQUIRE(s, "null argument");
     return s->consistent_ircache ? merge_ircache_requests(*s, (hipStream_t)stream) : KJ_OK;
+}
+
+// SsgiRenderer::render strip by strip, before kj_split_gi_frame (multigpu.py: SplitRtdgi.ssgi_frame): the halo of the temporal pass' history, every local
+// rank's own rows (kj_ssgi_render_rows over-computes what its passes reach into), then the halo of the finished guide that the rtdgi passes read beyond
+// the strip (144 rows: the first spatial pass runs on own +- 64 rows and its taps reach 32 half-res rows further). out_ssao_r8[li] -> rtdgi.ssao_tex.
+KjStatus kj_split_ssgi_frame(KjSplit* s, KjSsgi* const* ssgi, const KjSplitFrame* frames, const void** out_ssao_r8, void* stream) {
+    KJ_REQUIRE(s && ssgi && frames && out_ssao_r8, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    s->ssgi.assign(ssgi, ssgi + s->local);
+    for (KjSsgi* g : s->ssgi) KJ_REQUIRE(g, "null SsgiRenderer");
+    if (s->ssgi_frames > 0) KJ_SPLIT_TRY(exchange(*s, {{sfx("SSGI/ssgi", 1 - s->ssgi_frames % 2), int(s->motion_halo + 2)}}, st));
+    for (uint32_t li = 0; li < s->local; ++li) {
+        const auto own = s->strips[s->first + li];
+        KJ_SPLIT_TRY(kj_ssgi_render_rows(ssgi[li], &frames[li].rtdgi.gbuffer_depth, frames[li].rtdgi.reprojection_map, nullptr, own.first, own.second, &out_ssao_r8[li], st));
+    }
+    KJ_SPLIT_TRY(exchange(*s, {{sfx("SSGI/filtered_output_tex", s->ssgi_frames % 2), 144 + 2}}, st));
+    ++s->ssgi_frames;
+    return KJ_OK;
 }
 
 // TaaRenderer::render on this frame's GI image, strip by strip (multigpu.py: SplitRtdgi.taa_frame): one exchange (the input's halo;

@@ -668,17 +668,26 @@ class NativeSplit:
             sd["irc"][self.frame & 1].record(sd["stream"])
 
     def ssgi_frame(self):
-        """The SSAO guide before gi_frame. Here: the whole frame's on every rank (the strip-wise form with its two halo exchanges is SplitRtdgi's)."""
-        for q in self.pipes.values():
-            q.ssgi_frame()
+        """The SSAO guide before gi_frame, strip by strip with its two halo exchanges (kj_split_ssgi_frame; SplitRtdgi.ssgi_frame is the reference)."""
+        n = len(self.ranks)
+        handles, outs = (C.c_void_p * n)(), (C.c_void_p * n)()
+        for i, r in enumerate(self.ranks):
+            gp = self.pipes[r]
+            if gp.ssgi is None:
+                gp.ssgi = C.c_void_p()
+                klib.check(self.L.kj_ssgi_create(gp.dev.h, C.byref(gp.ssgi)))
+            handles[i] = gp.ssgi.value
+        self._fill()
+        klib.check(self.L.kj_split_ssgi_frame(self.h, handles, self._frames, outs, klib._stream_ptr()))
+        for i, r in enumerate(self.ranks):
+            self.pipes[r].ssao_ptr = C.c_void_p(outs[i])
 
     def frame_pipelined(self, next_fc, run_ssgi=False):
         import torch
         i = self.frame & 1
         if run_ssgi:
             torch.cuda.current_stream().wait_event(self._side["fc"][i])
-            for q in self.pipes.values():
-                q.ssgi_frame()
+            self.ssgi_frame()
         torch.cuda.current_stream().wait_event(self._side["irc"][i])
         self.gi_frame(ircache_done=True, trace_event=self._side["trace"][i], defer_merge=True)     # (advances self.frame)
         self.taa_frame()

@@ -108,8 +108,8 @@ def test_strip_split_with_the_irradiance_cache_is_bit_exact(gpu, device, n_ranks
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_ranks,W,H,with_cache", [(2, 256, 160, False), (3, 320, 208, True), (8, 192, 256, True)])
-def test_native_split_matches_the_python_orchestrator(gpu, device, n_ranks, W, H, with_cache):
+@pytest.mark.parametrize("n_ranks,W,H,with_cache,with_ssgi", [(2, 256, 160, False, False), (3, 320, 208, True, False), (8, 192, 256, True, False), (2, 256, 160, False, True), (2, 384, 800, True, True)])
+def test_native_split_matches_the_python_orchestrator(gpu, device, n_ranks, W, H, with_cache, with_ssgi):
     """The compiled orchestrator (csrc/split.cpp: KjSplit, virtual ranks = device-to-device exchanges) against the reference
     implementation of the same schedule (multigpu.SplitRtdgi / LocalComm) and against ONE unsplit pipeline: GI image, TAA image and --
     with the cache bound -- every cache buffer bit for bit, over frames with a moving camera."""
@@ -127,15 +127,20 @@ def test_native_split_matches_the_python_orchestrator(gpu, device, n_ranks, W, H
     assert [nat.strip(r) for r in range(n_ranks)] == py.strips
     fs = frame.FrameState((W, H))
     fs.ircache_enabled = with_cache
-    for fi in range(6):
+    for fi in range(4 if H > 400 else 6):
         fc = fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.02))
         fs.retire_frame()
-        ref.frame(fc)
+        if with_ssgi:      # the SSAO guide: whole-frame on the reference, strip by strip in both orchestrators (kj_split_ssgi_frame / SplitRtdgi.ssgi_frame)
+            ref.render_inputs(fc); ref.reprojection(); ref.ssgi_frame(); ref.gi_frame()
+        else:
+            ref.frame(fc)
         ref.taa_frame()
         for pipes in (py_pipes, nat_pipes):
             for r in range(n_ranks):
                 pipes[r].render_inputs(fc)
                 pipes[r].reprojection()
+        if with_ssgi:
+            py.ssgi_frame(); nat.ssgi_frame()
         py.gi_frame(); py.taa_frame()
         nat.gi_frame(); nat.taa_frame()
         for sp in (py, nat):
