@@ -227,7 +227,7 @@ def main():
                 q.geometric_normal, q.gbuffer, q.depth = gn, gb, d
                 q.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
             if use_ssgi:
-                split.ssgi_frame()      # the SSAO guide strip by strip (+ halo exchanges); the native orchestrator still computes the whole frame's on every rank
+                split.ssgi_frame()      # the SSAO guide strip by strip (+ its two halo exchanges)
             split.gi_frame()
             split.taa_frame()
 
