@@ -247,6 +247,7 @@ class SplitRtdgi:
         self.motion_halo = motion_halo
         self.frame = 0
         self.taa_frames = 0
+        self.ssgi_frames = 0
         self._views = {}
         self._plans = {}
         self._params = {}
@@ -436,7 +437,6 @@ class SplitRtdgi:
         intermediate passes over-compute what the next pass reaches into -- after the halo of the temporal pass' history has arrived, then the
         finished guide's halo is exchanged: rtdgi's passes read it up to GUIDE_HALO rows beyond the strip (gi_frame runs extract_half on those
         rows). Round 2 computed the whole frame's guide on every rank: 0.25 ms of replicated work per rank at 4K."""
-        self.ssgi_frames = getattr(self, "ssgi_frames", 0)
         M = self.motion_halo
         if self.ssgi_frames > 0:
             self._exchange([(f"SSGI/ssgi:{1 - self.ssgi_frames % 2}", M + 2)])
