@@ -30,7 +30,7 @@ hipError_t launch_instance_refit(const Bvh4Node* blas_nodes, const uint2* steps,
 
 // A mesh's BLAS built on the device as a linear BVH (lbvh_build.hip): nodes into d_nodes_out[0 .. node_count) with child node
 // indices offset by node_base, object-space triangles in leaf order into d_tris_out[0 .. index_count / 3). Synchronises the stream.
-struct LbvhResult { float bounds[6]; uint32_t node_count, max_stack; std::vector<uint32_t> level_starts; };   // level d (0 = the root) = nodes [level_starts[d], level_starts[d + 1])
+struct LbvhResult { static constexpr size_t HEAD_NODES = 341; float bounds[6]; uint32_t node_count, max_stack; std::vector<uint32_t> level_starts; std::vector<Bvh4Node> head; /* the first nodes (the tree is laid out level by level) */ };   // level d (0 = the root) = nodes [level_starts[d], level_starts[d + 1])
 struct LbvhScratch { static constexpr int BUFFERS = 14; DevBuf buf[BUFFERS], tmp, queue_len, level_nodes; uint32_t capacity = 0; };   // the build's working set, reused across meshes
 hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s, bool ploc);   // ploc: hierarchy by agglomerative clustering instead of Morton-code splits
 

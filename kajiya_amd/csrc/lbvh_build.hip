@@ -179,7 +179,7 @@ struct CollapseItem { uint32_t bin, out, depth; };
 // level with a grid that is large enough by construction (<= 4^level items, <= one per triangle) and reads nothing back in between.
 __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __restrict__ children, const uint2* __restrict__ range, const Box6* __restrict__ nbox, const CollapseItem* __restrict__ in,
                                                        uint32_t* __restrict__ queue_len, uint32_t level, CollapseItem* __restrict__ out, uint32_t* __restrict__ counters /*[1]=nodes, [2]=max depth*/,
-                                                       Bvh4Node* __restrict__ nodes, uint32_t node_base) {
+                                                       Bvh4Node* __restrict__ nodes, uint32_t node_base, uint32_t* __restrict__ level_nodes, uint32_t* __restrict__ level_done) {
     const uint32_t in_count = queue_len[level];
     for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < in_count; w += gridDim.x * 64) {
     const CollapseItem it = in[w];
@@ -222,9 +222,14 @@ __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __rest
     }
     nodes[it.out] = node;
     }
+    // the last workgroup of the level to finish records how many nodes exist now: where the next level's nodes start (the levels of a tree are
+    // contiguous runs, which the per-instance refit walks deepest first). It was a launch of its own per level.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&level_done[level], 1u) + 1u == gridDim.x) level_nodes[level + 2] = atomicAdd(&counters[1], 0u);
+    }
 }
-// after a level: how many nodes exist now (= where the next level's nodes start)
-__global__ void k_lbvh_level_end(const uint32_t* __restrict__ counters, uint32_t* __restrict__ level_nodes, uint32_t level) { level_nodes[level + 1] = counters[1]; }
 __global__ void __launch_bounds__(256) k_lbvh_emit_tris(const uint8_t* __restrict__ vb, GpuMesh m, const uint32_t* __restrict__ ids, uint32_t n, BvhTri* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -468,7 +473,7 @@ __global__ void k_ploc_root(const uint32_t* __restrict__ clusters, PlocItem* __r
 // One level of the 4-wide tree over the PLOC hierarchy: as k_lbvh_collapse, plus the top-down hand-out of triangle slots.
 __global__ void __launch_bounds__(64) k_ploc_collapse(uint32_t n, const uint2* __restrict__ children, const uint32_t* __restrict__ cnt, const Box6* __restrict__ nbox, const uint32_t* __restrict__ sorted_ids,
                                                        const PlocItem* __restrict__ in, uint32_t* __restrict__ queue_len, uint32_t level, PlocItem* __restrict__ out, uint32_t* __restrict__ counters,
-                                                       Bvh4Node* __restrict__ nodes, uint32_t node_base, uint32_t* __restrict__ tri_order) {
+                                                       Bvh4Node* __restrict__ nodes, uint32_t node_base, uint32_t* __restrict__ tri_order, uint32_t* __restrict__ level_nodes, uint32_t* __restrict__ level_done) {
     const uint32_t in_count = queue_len[level];
     for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < in_count; w += gridDim.x * 64) {
         const PlocItem it = in[w];
@@ -517,6 +522,13 @@ __global__ void __launch_bounds__(64) k_ploc_collapse(uint32_t n, const uint2* _
             first += count;
         }
         nodes[it.out] = node;
+    }
+    // the last workgroup of the level to finish records how many nodes exist now: where the next level's nodes start (the levels of a tree are
+    // contiguous runs, which the per-instance refit walks deepest first). It was a launch of its own per level.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&level_done[level], 1u) + 1u == gridDim.x) level_nodes[level + 2] = atomicAdd(&counters[1], 0u);
     }
 }
 
@@ -597,9 +609,10 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
     // queue_len[l + 1]); level_nodes[l] = nodes allocated before level l's children (a level's nodes are one contiguous run). Levels are
     // issued KJ_LBVH_BATCH at a time without looking at the queues -- every launch is sized by the bound 4^level, <= one item per triangle --,
     // then ONE read-back says whether the tree goes deeper (a 250 k-triangle mesh has ~13 levels; many coincident centroids make deep ones).
-    KJ_LB(scratch->queue_len.alloc((KJ_LBVH_BATCH + 2) * 4, s)); KJ_LB(scratch->level_nodes.alloc((KJ_LBVH_BATCH + 2) * 4, s));      // (no-ops after the first mesh)
+    KJ_LB(scratch->queue_len.alloc((KJ_LBVH_BATCH + 2) * 4, s)); KJ_LB(scratch->level_nodes.alloc((2 * KJ_LBVH_BATCH + 4) * 4, s));      // (no-ops after the first mesh)
     uint32_t* const queue_len = (uint32_t*)scratch->queue_len.p;
-    uint32_t* const level_nodes = (uint32_t*)scratch->level_nodes.p;
+    uint32_t* const level_nodes = (uint32_t*)scratch->level_nodes.p;       // [0 .. BATCH + 2): nodes before each level; then one arrival counter per level
+    uint32_t* const level_done = level_nodes + KJ_LBVH_BATCH + 2;
     const uint32_t init_counters[4] = {0u, 1u, 0u, 0u};
     const CollapseItem root{0u, 0u, 0u};
     void* qin = q0; void* qout = q1;
@@ -607,31 +620,38 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
         const dim3 cg(std::min(4096u, (items + 63) / 64));
         const void* in = qin; void* out = qout;
         if (ploc) hipLaunchKernelGGL(k_ploc_collapse, cg, dim3(64), 0, s, n, (const uint2*)children, (const uint32_t*)cnt, (const Box6*)nbox, (const uint32_t*)ids2, (const PlocItem*)in, queue_len, level,
-                                     (PlocItem*)out, counters, d_nodes_out, node_base, tri_order);
+                                     (PlocItem*)out, counters, d_nodes_out, node_base, tri_order, level_nodes, level_done);
         else hipLaunchKernelGGL(k_lbvh_collapse, cg, dim3(64), 0, s, int(n), (const uint2*)children, (const uint2*)range, (const Box6*)nbox, (const CollapseItem*)in, queue_len, level, (CollapseItem*)out,
-                                counters, d_nodes_out, node_base);
+                                counters, d_nodes_out, node_base, level_nodes, level_done);
     };
     KJ_LB(hipMemcpyAsync(counters, init_counters, 16, hipMemcpyHostToDevice, s));
-    if (ploc) hipLaunchKernelGGL(k_ploc_root, dim3(1), dim3(1), 0, s, (const uint32_t*)clusters, (PlocItem*)q0);
-    else KJ_LB(hipMemcpyAsync(q0, &root, sizeof(root), hipMemcpyHostToDevice, s));
-    uint32_t host_counters[4] = {0, 1, 0, 0}, host_levels[KJ_LBVH_BATCH + 2], host_queue[KJ_LBVH_BATCH + 2];
+    if (ploc) {
+        hipLaunchKernelGGL(k_ploc_root, dim3(1), dim3(1), 0, s, (const uint32_t*)clusters, (PlocItem*)q0);
+        KJ_LB(hipMemsetAsync(tri_order, 0, size_t(n) * 4, s));      // slots a deep tree has not reached after the first batch must still name a triangle (emit below)
+    } else KJ_LB(hipMemcpyAsync(q0, &root, sizeof(root), hipMemcpyHostToDevice, s));
+    uint32_t host_counters[4] = {0, 1, 0, 0}, host_levels[KJ_LBVH_BATCH + 2], host_queue[KJ_LBVH_BATCH + 2], hob[8];
     result->level_starts.assign({0u});
+    result->head.resize(std::min<size_t>(size_t(n) + 1, LbvhResult::HEAD_NODES));
     uint64_t bound = 1;
     uint32_t in_count = 1u, nodes_before = 1u;      // level 0 = the root = node 0
     while (in_count) {
-        uint32_t queue_head[KJ_LBVH_BATCH + 2] = {}, level_head[KJ_LBVH_BATCH + 2] = {};
+        uint32_t queue_head[KJ_LBVH_BATCH + 2] = {}, level_head[2 * KJ_LBVH_BATCH + 4] = {};
         queue_head[0] = in_count; level_head[1] = nodes_before;
         KJ_LB(hipMemcpyAsync(queue_len, queue_head, sizeof(queue_head), hipMemcpyHostToDevice, s));
         KJ_LB(hipMemcpyAsync(level_nodes, level_head, sizeof(level_head), hipMemcpyHostToDevice, s));
         for (uint32_t level = 0; level < KJ_LBVH_BATCH; ++level) {
             collapse(uint32_t(std::min<uint64_t>(std::max<uint64_t>(bound, in_count), n)), level);
-            hipLaunchKernelGGL(k_lbvh_level_end, dim3(1), dim3(1), 0, s, (const uint32_t*)counters, level_nodes, level + 1);
             bound = std::min<uint64_t>(std::max<uint64_t>(bound, in_count) * 4, uint64_t(n));
             std::swap(qin, qout);
         }
+        // everything else the caller needs rides the same read-back: a tree that fits one batch (every mesh so far) costs ONE synchronisation.
+        // (The triangles in leaf order: PLOC's order is written by the collapse; if the tree turns out deeper, the last batch emits them again.)
+        hipLaunchKernelGGL(k_lbvh_emit_tris, g, b, 0, s, d_vertex_buffer, mesh, ploc ? (const uint32_t*)tri_order : (const uint32_t*)ids2, n, d_tris_out);
         KJ_LB(hipMemcpyAsync(host_levels, level_nodes, sizeof(host_levels), hipMemcpyDeviceToHost, s));
         KJ_LB(hipMemcpyAsync(host_queue, queue_len, sizeof(host_queue), hipMemcpyDeviceToHost, s));
         KJ_LB(hipMemcpyAsync(host_counters, counters, 16, hipMemcpyDeviceToHost, s));
+        KJ_LB(hipMemcpyAsync(hob, ob, 24, hipMemcpyDeviceToHost, s));
+        KJ_LB(hipMemcpyAsync(result->head.data(), d_nodes_out, result->head.size() * sizeof(Bvh4Node), hipMemcpyDeviceToHost, s));      // the top levels, for the caller's top-tree build
         KJ_LB(hipStreamSynchronize(s));
         for (uint32_t l = 1; l <= KJ_LBVH_BATCH + 1; ++l)
             if (host_levels[l] > result->level_starts.back()) result->level_starts.push_back(host_levels[l]);
@@ -639,16 +659,13 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
         nodes_before = host_counters[1];
         if (result->level_starts.size() > 4096) return hipErrorUnknown;
     }
-    hipLaunchKernelGGL(k_lbvh_emit_tris, g, b, 0, s, d_vertex_buffer, mesh, ploc ? (const uint32_t*)tri_order : (const uint32_t*)ids2, n, d_tris_out);
-    uint32_t hob[8];
-    KJ_LB(hipMemcpyAsync(hob, ob, 24, hipMemcpyDeviceToHost, s));
-    KJ_LB(hipStreamSynchronize(s));
     KJ_LB(hipGetLastError());
     for (int k = 0; k < 6; ++k) {
         const uint32_t o = hob[k];
         const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
         memcpy(&result->bounds[k], &u, 4);
     }
+    result->head.resize(std::min<size_t>(result->head.size(), host_counters[1]));
     result->node_count = host_counters[1];
     result->max_stack = host_counters[2] > 0 ? host_counters[2] : 1;
     return hipSuccess;

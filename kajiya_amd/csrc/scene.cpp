@@ -376,12 +376,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
             // laid out by depth on the device: the refit walks the levels deepest first, the root is node 0
             for (size_t d = lr.level_starts.size() - 1; d-- > 0;) { steps.push_back(lr.level_starts[d]); steps.push_back(lr.level_starts[d + 1]); }
             bl.root = 0;
-            {   // its top levels (the first nodes: the builder lays the tree out level by level) for the top-tree build
-                std::vector<BvhNode> head(std::min<uint32_t>(bl.node_count, KJ_BLAS_TOP_NODES));
-                KJ_TRY_HIP(hipMemcpyAsync(head.data(), (const BvhNode*)s->d_blas_nodes.p + bl.node_base, head.size() * sizeof(BvhNode), hipMemcpyDeviceToHost, stream));
-                KJ_TRY_HIP(hipStreamSynchronize(stream));
-                extract_blas_top(head.data(), uint32_t(head.size()), bl.node_base, 0u, bl.bounds, KJ_BLAS_TOP_NODES, s->blas_top[mi]);
-            }
+            extract_blas_top(lr.head.data(), uint32_t(lr.head.size()), bl.node_base, 0u, bl.bounds, KJ_BLAS_TOP_NODES, s->blas_top[mi]);      // its top levels, read back with the build's own results
         } else {                              // binned SAH on the host
             if (!host_builds.count(mi)) {      // not started yet (the in-flight limit): start it now, alone if need be
                 try { host_builds[mi] = std::async(std::launch::async, host_build, mi); }
