@@ -171,6 +171,7 @@ def main():
     gp = lib.GpuPipeline(dev, scene, W, H, device=f"cuda:{local_rank}", use_ircache=True)
     # ---- N > 1: screen-tile split of the SAME frame (strong scaling): one strip per rank, halo exchange over RCCL
     split = None
+    transport = "none"
     nsplit = world if world > 1 else args.virtual_ranks
     if nsplit > 1:
         from kajiya_amd import multigpu
@@ -182,22 +183,42 @@ def main():
             for r in range(1, nsplit):
                 split_pipes[r] = lib.GpuPipeline(dev, scene, W, H, device=f"cuda:{local_rank}", use_ircache=True)
             comm = multigpu.LocalComm(nsplit)
-        if os.environ.get("KJ_SPLIT_NATIVE") == "1":
-            # opt-in: the compiled orchestrator (csrc/split.cpp) with its own RCCL communicator -- one packed ncclSend / ncclRecv per peer
-            # and exchange point. Bit-exact against the Python orchestrator on virtual ranks; its RCCL transport has never run (no
-            # multi-GPU node in the build environment), hence not the default.
-            nccl = multigpu.NativeSplit.rccl_comm_from_torch(dist, rank, world, f"cuda:{local_rank}") if world > 1 else None
-            split = multigpu.NativeSplit(nsplit, split_pipes, W, H, motion_halo=args.motion_halo, nccl_comm=nccl)
-        else:
+        # Default for a real N-process job: the compiled orchestrator (csrc/split.cpp) with its own RCCL communicator -- one C-ABI call per frame, one
+        # packed ncclSend / ncclRecv per peer and exchange point. It certifies itself before frame 0 (kj_split_self_test, verdicts combined over the
+        # ranks); if the communicator cannot be made or the self-test fails on ANY rank, every rank falls back to the Python orchestrator over
+        # torch.distributed (KJ_SPLIT_NATIVE=0 selects that one outright; virtual ranks use it unless KJ_SPLIT_NATIVE=1).
+        want_native = os.environ.get("KJ_SPLIT_NATIVE", "1" if world > 1 and not os.environ.get("KJ_BENCH_SHARE_GPU0") else "0") == "1"
+        transport = "virtual"
+        if want_native:
+            try:
+                nccl = multigpu.NativeSplit.rccl_comm_from_torch(dist, rank, world, f"cuda:{local_rank}") if world > 1 else None
+                split = multigpu.NativeSplit(nsplit, split_pipes, W, H, motion_halo=args.motion_halo, nccl_comm=nccl)
+                created = True
+            except Exception as e:
+                print(f"[bench] rank {rank}: compiled split orchestrator unavailable ({e})", file=sys.stderr, flush=True)
+                split, created = None, False
+            if world > 1:      # creation is not collective-safe by itself: agree before anybody enters the self-test's exchanges
+                flag = torch.tensor([1 if created else 0], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else f"cuda:{local_rank}")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if not int(flag.item()):
+                    split = None
+            if split is not None:
+                passed = split.self_test(dist if world > 1 else None)
+                transport = "RCCL (compiled orchestrator)" if world > 1 else "virtual (compiled orchestrator)"
+                if rank == 0:
+                    print(f"[bench] {transport} {nsplit} ranks {'OK' if passed else 'FAILED'}: exchange self-test ({'passed' if passed else 'wrong rows delivered'})", file=sys.stderr, flush=True)
+                if not passed:
+                    split = None
+            if split is None and rank == 0:
+                print("[bench] falling back to the Python orchestrator over torch.distributed", file=sys.stderr, flush=True)
+        if split is None:
             split = multigpu.SplitRtdgi(comm, split_pipes, W, H, motion_halo=args.motion_halo)
+            passed = split.self_test()      # before frame 0: every kind of exchange of the frame schedule once, on scratch images, checked on the device (multigpu.py)
+            transport = ("RCCL" if not os.environ.get("KJ_BENCH_SHARE_GPU0") else "gloo") if world > 1 else "virtual"
+            if rank == 0:
+                print(f"[bench] {transport} {nsplit} ranks {'OK' if passed else 'FAILED'}: exchange self-test ({'passed' if passed else 'wrong rows delivered'})", file=sys.stderr, flush=True)
+            assert passed, "split transport self-test failed"
     single = split is None
-    if split is not None and hasattr(split, "self_test"):
-        # before frame 0: every kind of exchange of the frame schedule once, on scratch images, checked on the device (multigpu.py)
-        passed = split.self_test()
-        if rank == 0:
-            print(f"[bench] {'RCCL' if world > 1 and not os.environ.get('KJ_BENCH_SHARE_GPU0') else ('gloo' if world > 1 else 'virtual')} {nsplit} ranks "
-                  f"{'OK' if passed else 'FAILED'}: exchange self-test ({'passed' if passed else 'wrong rows delivered'})", file=sys.stderr, flush=True)
-        assert passed, "split transport self-test failed"
 
     # ---- pre-generate the inputs of every frame (resident in HBM before the timed region; replicated on every rank)
     n_frames = Wm + K + args.profile_frames + 3 + 1
@@ -497,7 +518,7 @@ def main():
                                + (", SSAO guide (ssgi, 4 passes)" if use_ssgi else ", constant SSAO guide"),
                    "triangles": stats["triangles"], "bvh_nodes": stats["nodes"], "bvh_bytes": stats["bvh_bytes"],
                    "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": ("single GPU, 3 HIP streams: next frame's ircache rays (side stream) and this frame's spatial filter + TAA (third stream) overlap the main stream's ray passes" if overlap else "single GPU, serial frames") if nsplit <= 1 else f"{nsplit}-way screen-tile split (16-row-aligned strips; 6 batched halo exchanges per frame incl. the temporal2 all-gather, over "
-                                  + (("gloo, host-staged (debug)" if os.environ.get("KJ_BENCH_SHARE_GPU0") else "RCCL P2P") if world > 1 else "virtual ranks on one GPU") + f"; motion halo {args.motion_halo} rows; irradiance cache replicated per rank"
+                                  + (("gloo, host-staged (debug)" if os.environ.get("KJ_BENCH_SHARE_GPU0") and "compiled" not in transport else "RCCL P2P") if world > 1 else "virtual ranks on one GPU") + f"; orchestrator: {'compiled (kj_split_*)' if 'compiled' in transport else 'python (multigpu.SplitRtdgi)'}" + f"; motion halo {args.motion_halo} rows; irradiance cache replicated per rank"
                                   + ("; next frame's ircache work overlapped on a second stream)" if overlap else ")")},
         "segment_ms": seg,
         "pass_ms": {n: round(v, 4) for n, v in zip(lib.GpuPipeline.PASS_NAMES, pass_ms)} if pass_ms else None,

@@ -618,6 +618,11 @@ KjStatus kj_split_ssgi_frame(KjSplit* split, KjSsgi* const* ssgi, const KjSplitF
 KjStatus kj_split_taa_frame(KjSplit* split, const KjSplitFrame* frames, void* stream);
 /* Every rank receives the owners' rows of a surface ("spatial_filtered_tex", "TAA/taa:0", ...): result collection. */
 KjStatus kj_split_gather(KjSplit* split, const char* surface_name, void* stream);
+/* Start-up check of the transport, before frame 0: every kind of exchange of the frame schedule (all-gather of an image, mixed surfaces packed into one message
+ * per peer, the 64-row one-deep halo, stencil halos, the variable-length all-gather of the cache's record lists) once on scratch images whose rows carry their
+ * owner's rank, read back and checked row by row. *out_passed: 1 when every rank of this process holds exactly the rows it is entitled to (combine the
+ * processes' verdicts with the caller's own collective). Synchronises `stream`. No counterpart in the reference (single-GPU). */
+KjStatus kj_split_self_test(KjSplit* split, uint32_t* out_passed, void* stream);
 KjStatus kj_split_rccl_unique_id(uint8_t out_id[128]);
 KjStatus kj_split_rccl_comm_create(const uint8_t id[128], uint32_t world, uint32_t rank, void** out_comm);
 void kj_split_rccl_comm_destroy(void* comm);

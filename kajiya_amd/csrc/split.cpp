@@ -36,6 +36,7 @@ const std::map<std::string, SurfInfo>& surf_table() {
         {"irradiance_output_tex", {8, false}}, {"temporal_filtered_tex", {8, false}}, {"spatial_filtered_tex", {8, false}}, {"reprojected_history_tex", {8, false}},
         {"SSGI/ssgi", {2, false}}, {"SSGI/filtered_output_tex", {1, false}},
         {"TAA/taa", {8, false}}, {"TAA/taa.velocity", {4, false}}, {"TAA/taa.smooth_var", {8, false}}, {"TAA/this_frame_output_img", {8, false}},
+        {"selftest.h16", {16, true}}, {"selftest.h1", {1, true}}, {"selftest.f8", {8, false}}, {"selftest.f4", {4, false}},      // kj_split_self_test's scratch images
     };
     return t;
 }
@@ -55,10 +56,13 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
     bool load() {
         if (lib) return true;
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (lib) break;
-        }
+        // KJ_RCCL_LIB: a specific RCCL build (or, in tests/test_multigpu_emulated.py, a socket-backed stand-in that lets this transport run between CPU processes)
+        if (const char* over = getenv("KJ_RCCL_LIB")) lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        else
+            for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+                lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (lib) break;
+            }
         if (!lib) return false;
         auto sym = [&](const char* n) { return dlsym(lib, n); };
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
@@ -224,6 +228,47 @@ KjStatus ircache_head(KjSplit& s, uint32_t li, const KjSplitFrame& fr, hipStream
     return kj_ircache_trace_irradiance(c, s.ranks[li].scene, fr.sky_cube16, 16, st);
 }
 
+// The transport of the merge: every rank's strip list (strip_list[li], n_strip[li] records of 32 bytes; counts[li]'s first dword holds the same
+// number on the device) reaches every rank. Virtual ranks: nothing moves. RCCL: all-gather of the counts, then one send / receive per peer.
+KjStatus gather_strip_lists(KjSplit& s, const std::vector<uint32_t>& n_strip, std::vector<uint32_t>& all_strip, hipStream_t st) {
+    const size_t RQ = 32;
+    all_strip.assign(s.world, 0);
+    if (!s.nccl) { for (uint32_t li = 0; li < s.local; ++li) all_strip[li] = n_strip[li]; return KJ_OK; }
+    if (!s.all_counts.p) KJ_TRY_HIP(s.all_counts.alloc(size_t(s.world) * 4, st));
+    KJ_REQUIRE(g_rccl.AllGather(s.counts[0].p, s.all_counts.p, 1, NCCL_UINT32, s.nccl, st) == 0, "ncclAllGather failed");
+    KJ_TRY_HIP(hipMemcpyAsync(all_strip.data(), s.all_counts.p, size_t(s.world) * 4, hipMemcpyDeviceToHost, st));
+    KJ_TRY_HIP(hipStreamSynchronize(st));
+    const uint32_t me = s.first;
+    KJ_REQUIRE(all_strip[me] == n_strip[0], "the all-gathered record count of this rank is not the one it contributed");
+    for (uint32_t p = 0; p < s.world; ++p)
+        if (p != me && s.peer_lists[p].bytes < size_t(all_strip[p]) * RQ) KJ_TRY_HIP(s.peer_lists[p].alloc(size_t(all_strip[p]) * RQ + 4096, st));
+    KJ_REQUIRE(g_rccl.GroupStart() == 0, "ncclGroupStart failed");
+    for (uint32_t p = 0; p < s.world; ++p) {
+        if (p == me) continue;
+        if (all_strip[me]) KJ_REQUIRE(g_rccl.Send(s.strip_list[0].p, size_t(all_strip[me]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclSend failed");
+        if (all_strip[p]) KJ_REQUIRE(g_rccl.Recv(s.peer_lists[p].p, size_t(all_strip[p]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclRecv failed");
+    }
+    KJ_REQUIRE(g_rccl.GroupEnd() == 0, "ncclGroupEnd failed");
+    return KJ_OK;
+}
+
+// merged[li] = every rank's strip records in rank order, then local rank li's own n_irc records (irc_list[li])
+KjStatus assemble_lists(KjSplit& s, uint32_t li, const std::vector<uint32_t>& all_strip, uint32_t n_irc, size_t* out_total, hipStream_t st) {
+    const size_t RQ = 32;
+    size_t total = n_irc;
+    for (uint32_t p = 0; p < s.world; ++p) total += all_strip[p];
+    if (s.merged[li].bytes < std::max<size_t>(total, 1) * RQ) KJ_TRY_HIP(s.merged[li].alloc(std::max<size_t>(total, 1) * RQ + total * RQ / 4, st));
+    size_t off = 0;
+    for (uint32_t p = 0; p < s.world; ++p) {
+        const void* src = is_local(s, p) ? s.strip_list[p - s.first].p : s.peer_lists[p].p;
+        if (all_strip[p]) KJ_TRY_HIP(hipMemcpyAsync((uint8_t*)s.merged[li].p + off, src, size_t(all_strip[p]) * RQ, hipMemcpyDeviceToDevice, st));
+        off += size_t(all_strip[p]) * RQ;
+    }
+    if (n_irc) KJ_TRY_HIP(hipMemcpyAsync((uint8_t*)s.merged[li].p + off, s.irc_list[li].p, size_t(n_irc) * RQ, hipMemcpyDeviceToDevice, st));
+    *out_total = total;
+    return KJ_OK;
+}
+
 // All-gather of this frame's recorded cache updates, then the same replay on every rank. A strip's rtdgi lookups (validate and trace
 // pass) occupy contiguous slots (rows of the half-res image); the cache's own ray passes are replicated, so their records are identical
 // on every rank and stay local. Merged order = every rank's strip records in rank order, then the cache's own (multigpu.py).
@@ -247,44 +292,16 @@ KjStatus merge_ircache_requests(KjSplit& s, hipStream_t st) {
         if ((e = kj_ircache_collect_requests(c, first[2], count[2], s.irc_list[li].p, cap_irc[li], cnt + 1, st)) != KJ_OK) return e;
         if ((e = kj_ircache_collect_requests(c, first[3], count[3], s.irc_list[li].p, cap_irc[li], cnt + 1, st)) != KJ_OK) return e;
     }
+    std::vector<uint32_t> host(size_t(s.local) * 2);
+    for (uint32_t li = 0; li < s.local; ++li) KJ_TRY_HIP(hipMemcpyAsync(&host[li * 2], s.counts[li].p, 8, hipMemcpyDeviceToHost, st));
+    KJ_TRY_HIP(hipStreamSynchronize(st));      // the list lengths are needed on the host (as in the reference orchestrator)
+    for (uint32_t li = 0; li < s.local; ++li) { n_strip[li] = host[li * 2]; n_irc[li] = host[li * 2 + 1]; }
+    std::vector<uint32_t> all_strip;
+    KjStatus e = gather_strip_lists(s, n_strip, all_strip, st); if (e != KJ_OK) return e;
     for (uint32_t li = 0; li < s.local; ++li) {
-        uint32_t host[2];
-        KJ_TRY_HIP(hipMemcpyAsync(host, s.counts[li].p, 8, hipMemcpyDeviceToHost, st));
-        KJ_TRY_HIP(hipStreamSynchronize(st));      // the list lengths are needed on the host (as in the reference orchestrator)
-        n_strip[li] = host[0]; n_irc[li] = host[1];
-    }
-    std::vector<uint32_t> all_strip(s.world, 0);
-    if (!s.nccl) for (uint32_t li = 0; li < s.local; ++li) all_strip[li] = n_strip[li];
-    else {
-        if (!s.all_counts.p) KJ_TRY_HIP(s.all_counts.alloc(size_t(s.world) * 4, st));
-        KJ_REQUIRE(g_rccl.AllGather(s.counts[0].p, s.all_counts.p, 1, NCCL_UINT32, s.nccl, st) == 0, "ncclAllGather failed");
-        KJ_TRY_HIP(hipMemcpyAsync(all_strip.data(), s.all_counts.p, size_t(s.world) * 4, hipMemcpyDeviceToHost, st));
-        KJ_TRY_HIP(hipStreamSynchronize(st));
-        const uint32_t me = s.first;
-        for (uint32_t p = 0; p < s.world; ++p)
-            if (p != me && s.peer_lists[p].bytes < size_t(all_strip[p]) * RQ) KJ_TRY_HIP(s.peer_lists[p].alloc(size_t(all_strip[p]) * RQ + 4096, st));
-        KJ_REQUIRE(g_rccl.GroupStart() == 0, "ncclGroupStart failed");
-        for (uint32_t p = 0; p < s.world; ++p) {
-            if (p == me) continue;
-            if (all_strip[me]) KJ_REQUIRE(g_rccl.Send(s.strip_list[0].p, size_t(all_strip[me]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclSend failed");
-            if (all_strip[p]) KJ_REQUIRE(g_rccl.Recv(s.peer_lists[p].p, size_t(all_strip[p]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclRecv failed");
-        }
-        KJ_REQUIRE(g_rccl.GroupEnd() == 0, "ncclGroupEnd failed");
-    }
-    size_t total_strip = 0;
-    for (uint32_t p = 0; p < s.world; ++p) total_strip += all_strip[p];
-    for (uint32_t li = 0; li < s.local; ++li) {
-        const size_t total = total_strip + n_irc[li];
-        if (s.merged[li].bytes < std::max<size_t>(total, 1) * RQ) KJ_TRY_HIP(s.merged[li].alloc(std::max<size_t>(total, 1) * RQ + total * RQ / 4, st));
-        size_t off = 0;
-        for (uint32_t p = 0; p < s.world; ++p) {
-            const void* src = is_local(s, p) ? s.strip_list[p - s.first].p : s.peer_lists[p].p;
-            if (all_strip[p]) KJ_TRY_HIP(hipMemcpyAsync((uint8_t*)s.merged[li].p + off, src, size_t(all_strip[p]) * RQ, hipMemcpyDeviceToDevice, st));
-            off += size_t(all_strip[p]) * RQ;
-        }
-        if (n_irc[li]) KJ_TRY_HIP(hipMemcpyAsync((uint8_t*)s.merged[li].p + off, s.irc_list[li].p, size_t(n_irc[li]) * RQ, hipMemcpyDeviceToDevice, st));
-        const KjStatus e = kj_ircache_apply_requests(s.ranks[li].ircache, s.merged[li].p, uint32_t(total), st);
-        if (e != KJ_OK) return e;
+        size_t total = 0;
+        if ((e = assemble_lists(s, li, all_strip, n_irc[li], &total, st)) != KJ_OK) return e;
+        if ((e = kj_ircache_apply_requests(s.ranks[li].ircache, s.merged[li].p, uint32_t(total), st)) != KJ_OK) return e;
     }
     return KJ_OK;
 }
@@ -457,6 +474,102 @@ KjStatus kj_split_taa_frame(KjSplit* s, const KjSplitFrame* frames, void* stream
 KjStatus kj_split_gather(KjSplit* s, const char* surface_name, void* stream) {
     KJ_REQUIRE(s && surface_name, "null argument");
     return exchange(*s, {{surface_name, -1}}, (hipStream_t)stream);
+}
+
+// Start-up check of the transport, before frame 0 (multigpu.py: SplitRtdgi.self_test is the same check of the Python orchestrator's): every kind of exchange the
+// frame schedule uses -- the all-gather of a full-res image, several surfaces of different texel sizes and halos packed into one message per peer, the 64-row
+// one-deep halo, stencil halos, and the variable-length all-gather of the cache's record lists -- runs once on scratch images whose rows carry their OWNER's
+// rank, through exchange() / gather_strip_lists() themselves; each local rank's images are then read back and every row it is entitled to must hold the
+// owner's pattern, every other row must be untouched. *out_passed = 1 when all local ranks passed; the caller combines the ranks' verdicts (bench.py:
+// all-reduce MIN) -- a transport error is returned as an error. Synchronises `stream`; not for use inside a frame.
+KjStatus kj_split_self_test(KjSplit* s, uint32_t* out_passed, void* stream) {
+    KJ_REQUIRE(s && out_passed, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    *out_passed = 1;
+    if (s->world == 1) return KJ_OK;
+    const int M = int(s->motion_halo);
+    const std::vector<std::vector<Item>> rounds = {
+        {{"selftest.f8", -1}},
+        {{"selftest.h16", M + 4}, {"selftest.h1", M + 1}, {"selftest.f8", M + 3}, {"selftest.f4", M + 2 + 16}},
+        {{"selftest.h16", 64}, {"selftest.f4", 16}},
+        {{"selftest.f8", 1 + 24}, {"selftest.h1", 2}},
+    };
+    const char* names[4] = {"selftest.h16", "selftest.h1", "selftest.f8", "selftest.f4"};
+    std::vector<DevBuf> scratch(size_t(s->local) * 4);
+    struct Unregister {          // the scratch images leave the surface cache whatever happens
+        KjSplit* s; const char* const* names;
+        ~Unregister() { for (uint32_t li = 0; li < s->local; ++li) for (int k = 0; k < 4; ++k) s->surfaces.erase({li, names[k]}); }
+    } unregister{s, names};
+    for (uint32_t li = 0; li < s->local; ++li)
+        for (int k = 0; k < 4; ++k) {
+            const SurfInfo* si = info_of(names[k]);
+            const size_t bytes = size_t(si->half ? s->hw : s->W) * si->bytes_per_texel * (si->half ? s->hh : s->H);
+            KJ_TRY_HIP(scratch[li * 4 + k].alloc(bytes, st));
+            s->surfaces[{li, names[k]}] = {(uint8_t*)scratch[li * 4 + k].p, bytes};
+        }
+    auto rows_of = [&](uint32_t rank, bool half) { return half ? half_rows(*s, s->strips[rank]) : s->strips[rank]; };
+    std::vector<uint8_t> host;
+    bool ok = true;
+    for (size_t ri = 0; ri < rounds.size(); ++ri) {
+        for (uint32_t li = 0; li < s->local; ++li)
+            for (size_t ii = 0; ii < rounds[ri].size(); ++ii) {
+                uint8_t* p; uint32_t rb;
+                KJ_SPLIT_TRY(surface_of(*s, s->first + li, rounds[ri][ii].name, &p, &rb));
+                const SurfInfo* si = info_of(rounds[ri][ii].name);
+                const auto own = rows_of(s->first + li, si->half);
+                KJ_TRY_HIP(hipMemsetAsync(p, 0, size_t(rb) * (si->half ? s->hh : s->H), st));
+                KJ_TRY_HIP(hipMemsetAsync(p + size_t(own.first) * rb, int((s->first + li + 1) * 8 + ii) & 0xff, size_t(own.second - own.first) * rb, st));
+            }
+        KJ_SPLIT_TRY(exchange(*s, rounds[ri], st));
+        for (uint32_t li = 0; li < s->local; ++li)
+            for (size_t ii = 0; ii < rounds[ri].size(); ++ii) {
+                uint8_t* p; uint32_t rb;
+                KJ_SPLIT_TRY(surface_of(*s, s->first + li, rounds[ri][ii].name, &p, &rb));
+                const SurfInfo* si = info_of(rounds[ri][ii].name);
+                const uint32_t total = si->half ? s->hh : s->H;
+                host.resize(size_t(rb) * total);
+                KJ_TRY_HIP(hipMemcpyAsync(host.data(), p, host.size(), hipMemcpyDeviceToHost, st));
+                KJ_TRY_HIP(hipStreamSynchronize(st));
+                const auto own = rows_of(s->first + li, si->half);
+                const int halo = rounds[ri][ii].halo;
+                const uint32_t lo = halo < 0 ? 0u : uint32_t(std::max<int64_t>(0, int64_t(own.first) - halo)), hi = halo < 0 ? total : std::min<uint32_t>(total, own.second + uint32_t(halo));
+                for (uint32_t row = 0; row < total && ok; ++row) {
+                    uint32_t owner = 0;
+                    while (owner + 1 < s->world && row >= rows_of(owner, si->half).second) ++owner;
+                    const uint8_t want = row >= lo && row < hi ? uint8_t(((owner + 1) * 8 + ii) & 0xff) : uint8_t(0);
+                    const uint8_t* r = &host[size_t(row) * rb];
+                    for (uint32_t x = 0; x < rb; ++x) if (r[x] != want) { ok = false; break; }
+                }
+            }
+    }
+    // the record lists: rank r contributes r + 1 records of bytes r + 1
+    const size_t RQ = 32;
+    std::vector<uint32_t> n_strip(s->local), all_strip;
+    for (uint32_t li = 0; li < s->local; ++li) {
+        const uint32_t rank = s->first + li;
+        n_strip[li] = rank + 1;
+        if (s->strip_list[li].bytes < size_t(rank + 1) * RQ) KJ_TRY_HIP(s->strip_list[li].alloc(size_t(rank + 1) * RQ, st));
+        KJ_TRY_HIP(hipMemsetAsync(s->strip_list[li].p, int(rank + 1), size_t(rank + 1) * RQ, st));
+        if (!s->counts[li].p) KJ_TRY_HIP(s->counts[li].alloc(8, st));
+        const uint32_t cnt[2] = {rank + 1, 0};
+        KJ_TRY_HIP(hipMemcpyAsync(s->counts[li].p, cnt, 8, hipMemcpyHostToDevice, st));
+        KJ_TRY_HIP(hipStreamSynchronize(st));     // (cnt lives on this stack frame)
+    }
+    KJ_SPLIT_TRY(gather_strip_lists(*s, n_strip, all_strip, st));
+    for (uint32_t li = 0; li < s->local; ++li) {
+        size_t total = 0;
+        KJ_SPLIT_TRY(assemble_lists(*s, li, all_strip, 0, &total, st));
+        ok = ok && total == size_t(s->world) * (s->world + 1) / 2;
+        if (!ok) break;
+        host.resize(total * RQ);
+        KJ_TRY_HIP(hipMemcpyAsync(host.data(), s->merged[li].p, host.size(), hipMemcpyDeviceToHost, st));
+        KJ_TRY_HIP(hipStreamSynchronize(st));
+        size_t off = 0;
+        for (uint32_t r = 0; r < s->world; ++r)
+            for (size_t b = 0; b < size_t(r + 1) * RQ; ++b) ok = ok && host[off++] == uint8_t(r + 1);
+    }
+    *out_passed = ok ? 1u : 0u;
+    return KJ_OK;
 }
 
 // RCCL bootstrap without a link-time dependency: rank 0 makes the id, the caller broadcasts its 128 bytes by whatever means it has

@@ -707,6 +707,26 @@ class NativeSplit:
     def gather_output(self, name="spatial_filtered_tex"):
         klib.check(self.L.kj_split_gather(self.h, name.encode(), klib._stream_ptr()))
 
+    def self_test(self, dist=None):
+        """Start-up check of the compiled transport before frame 0 (kj_split_self_test: every kind of exchange of the frame schedule on scratch
+        images, checked row by row). `dist`: the torch.distributed module of an N-process job -- the ranks' verdicts are combined (MIN), so
+        every rank returns the same answer; a transport ERROR on any rank counts as a failure on all of them instead of raising on one."""
+        passed = C.c_uint32(0)
+        try:
+            klib.check(self.L.kj_split_self_test(self.h, C.byref(passed), klib._stream_ptr()))
+            ok = bool(passed.value)
+        except Exception as e:
+            import sys
+            print(f"[kajiya_amd split self-test] transport error: {e}", file=sys.stderr, flush=True)
+            ok = False
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            import torch
+            on_host = dist.get_backend() == "gloo"
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if on_host else next(iter(self.pipes.values())).depth.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(int(flag.item()))
+        return ok
+
     @staticmethod
     def rccl_comm_from_torch(dist, rank, world, device):
         """An RCCL communicator of the library's own (torch does not hand out its ncclComm_t): rank 0 draws the id, torch.distributed

@@ -24,9 +24,19 @@ def _json_line(out):
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs ROCm's clang++ as the host compiler")
-def test_bench_two_ranks_under_torch_distributed_run():
+@pytest.mark.parametrize("orchestrator", ["python", "compiled", "compiled, damaged transport"])
+def test_bench_two_ranks_under_torch_distributed_run(orchestrator):
+    """orchestrator "compiled": what a real `bench.py --gpus N` does by default -- the compiled orchestrator with a communicator of its own -- with the
+    socket stand-in for RCCL (tests/rccl_stub) as that communicator; "damaged transport": one rank's messages arrive with a flipped byte, the
+    self-test before frame 0 fails on every rank and the job falls back to the Python orchestrator instead of rendering garbage."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, KJ_BENCH_SHARE_GPU0="1", HIP_EMU_WORKERS="4")
+    if orchestrator != "python":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_multigpu_emulated as TM
+        env.update(KJ_SPLIT_NATIVE="1", KJ_RCCL_LIB=TM.build_rccl_stub())
+        if "damaged" in orchestrator:
+            env["KJ_RCCL_STUB_CORRUPT"] = "1"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                         RUN, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + TOY, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -37,6 +47,12 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert j["value"] > 0 and j["ms_per_step"] > 0 and "2-way screen-tile split" in j["config"]["parallelism"]
     assert j["config"]["rays_per_frame"] > 1000                                   # both strips' rays were counted
     assert j["comm_ranks"] == 2                                                    # what the communicator reports, not what --gpus asked for
+    if orchestrator == "compiled":
+        assert "orchestrator: compiled" in j["config"]["parallelism"] and "2 ranks OK" in r.stderr
+    else:
+        assert "orchestrator: python" in j["config"]["parallelism"]
+    if "damaged" in orchestrator:
+        assert "2 ranks FAILED" in r.stderr and "falling back to the Python orchestrator" in r.stderr
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs ROCm's clang++ as the host compiler")

@@ -25,7 +25,18 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, H, frames, packed, q, with_ircache=False, with_ssgi=False):
+def build_rccl_stub():
+    """tests/rccl_stub/rccl_stub.cpp -> tests/_build/rccl_stub/librccl_stub.so: the socket-backed stand-in for RCCL the compiled transport is pointed at (KJ_RCCL_LIB)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "rccl_stub", "rccl_stub.cpp")
+    out = os.path.join(ROOT, "tests", "_build", "rccl_stub", "librccl_stub.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-o", out, src])
+    return out
+
+
+def _worker(rank, world, port, W, H, frames, packed, q, with_ircache=False, with_ssgi=False, native=False):
     try:
         os.environ["KJ_HIP_EMU"] = "fast"
         os.environ.setdefault("HIP_EMU_WORKERS", "4")
@@ -44,7 +55,16 @@ def _worker(rank, world, port, W, H, frames, packed, q, with_ircache=False, with
         pipe = lib.GpuPipeline(dev, scene, W, H, use_ircache=with_ircache)
         if with_ircache:
             ref.ircache_set_deferred(True)      # the single-GPU frame in the same deterministic mode the split puts the replicas in
-        split = multigpu.SplitRtdgi(multigpu.DistComm(dist, rank, world, packed=packed), {rank: pipe}, W, H, motion_halo=8)
+        if native:
+            # the COMPILED orchestrator with its own communicator (csrc/split.cpp's RCCL branch), the communicator being the socket stand-in:
+            # bootstrap exactly as bench.py does (rank 0 draws the id, torch.distributed broadcasts it), self-test, then frames
+            os.environ["KJ_RCCL_LIB"] = build_rccl_stub()
+            comm = multigpu.NativeSplit.rccl_comm_from_torch(dist, rank, world, "cuda:0")
+            split = multigpu.NativeSplit(world, {rank: pipe}, W, H, motion_halo=8, nccl_comm=comm)
+            assert split.self_test(dist) is True
+            split.strips = [split.strip(r) for r in range(world)]
+        else:
+            split = multigpu.SplitRtdgi(multigpu.DistComm(dist, rank, world, packed=packed), {rank: pipe}, W, H, motion_halo=8)
         assert split.consistent_ircache == with_ircache
         worst = 0
         from kajiya_amd import frame as kframe
@@ -84,16 +104,22 @@ def _worker(rank, world, port, W, H, frames, packed, q, with_ircache=False, with
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs ROCm's clang++ as the host compiler")
-@pytest.mark.parametrize("world,packed,with_ircache,with_ssgi", [(2, False, False, False), (3, True, False, True), (2, False, True, False)])
-def test_strip_split_over_gloo_processes_with_the_real_kernels(world, packed, with_ircache, with_ssgi):
+@pytest.mark.parametrize("world,packed,with_ircache,with_ssgi,native", [(2, False, False, False, False), (3, True, False, True, False), (2, False, True, False, False),
+                                                                        (2, False, True, True, True), (3, False, True, False, True)])
+def test_strip_split_over_gloo_processes_with_the_real_kernels(world, packed, with_ircache, with_ssgi, native):
     """with_ircache: the irradiance cache bound on every rank; the strips' recorded cache updates travel through DistComm.all_gather_rows
-    and every replica must stay bit-identical to the single-GPU cache."""
+    and every replica must stay bit-identical to the single-GPU cache.
+    native: the compiled orchestrator (kj_split_*) with a communicator of its own instead of SplitRtdgi + DistComm -- the code path `bench.py --gpus N`
+    takes by default -- its ncclSend / ncclRecv / ncclAllGather calls served by tests/rccl_stub (sockets between the processes). Packing per peer, the
+    message order both ends assume, the all-gather of the record counts and lists, the self-test before frame 0: everything but RCCL itself."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "hip_emu"))
     env_before = os.environ.get("KJ_HIP_EMU")
     os.environ["KJ_HIP_EMU"] = "fast"
     try:
         import build_emu
         build_emu.build()                      # once, before the ranks race for it
+        if native:
+            build_rccl_stub()
     finally:
         if env_before is None:
             os.environ.pop("KJ_HIP_EMU", None)
@@ -103,7 +129,7 @@ def test_strip_split_over_gloo_processes_with_the_real_kernels(world, packed, wi
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, frames, packed, q, with_ircache, with_ssgi)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, frames, packed, q, with_ircache, with_ssgi, native)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=900) for _ in range(world)]
@@ -115,3 +141,59 @@ def test_strip_split_over_gloo_processes_with_the_real_kernels(world, packed, wi
     total = results[0][3]
     assert (sum(r[2][0] for r in results), sum(r[2][1] for r in results)) == tuple(total), results    # the strips' rays add up to the unsplit frame's
     assert results[0][4][0] == 0 and results[-1][4][1] == H
+
+
+def _self_test_worker(rank, world, port, W, H, corrupt, q):
+    try:
+        os.environ["KJ_HIP_EMU"] = "fast"
+        os.environ.setdefault("HIP_EMU_WORKERS", "2")
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        if corrupt is not None:
+            os.environ["KJ_RCCL_STUB_CORRUPT"] = str(corrupt)
+        sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "hip_emu"))
+        import build_emu, cpu_as_cuda
+        cpu_as_cuda.install(build_emu.build())
+        import torch.distributed as dist
+        from kajiya_amd import lib, multigpu
+        import test_gpu_parity as T
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = lib.Device(0)
+        pipe = lib.GpuPipeline(dev, lib.Scene(dev, T._scenes()["cornell"]), W, H, use_ircache=True)
+        os.environ["KJ_RCCL_LIB"] = build_rccl_stub()
+        split = multigpu.NativeSplit(world, {rank: pipe}, W, H, motion_halo=8, nccl_comm=multigpu.NativeSplit.rccl_comm_from_torch(dist, rank, world, "cuda:0"))
+        q.put((rank, split.self_test(dist)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs ROCm's clang++ as the host compiler")
+@pytest.mark.parametrize("world,corrupt", [(3, None), (2, 1), (3, 0)])
+def test_compiled_transport_self_test_notices_a_damaged_message(world, corrupt):
+    """kj_split_self_test over the socket stand-in for RCCL: passes on a sound transport; when ONE rank's received messages arrive with a flipped
+    byte, every rank reports failure (the verdicts are combined), which is what makes bench.py fall back to the Python orchestrator."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hip_emu"))
+    env_before = os.environ.get("KJ_HIP_EMU")
+    os.environ["KJ_HIP_EMU"] = "fast"
+    try:
+        import build_emu
+        build_emu.build()
+        build_rccl_stub()
+    finally:
+        if env_before is None:
+            os.environ.pop("KJ_HIP_EMU", None)
+        else:
+            os.environ["KJ_HIP_EMU"] = env_before
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_self_test_worker, args=(r, world, port, 128, 160, corrupt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(got) == list(range(world))
+    assert all(v is (corrupt is None) for v in got.values()), got
