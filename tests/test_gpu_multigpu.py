@@ -124,6 +124,7 @@ def test_native_split_matches_the_python_orchestrator(gpu, device, n_ranks, W, H
     nat_pipes = {r: gpu.GpuPipeline(device, scene, W, H, use_ircache=with_cache) for r in range(n_ranks)}
     py = multigpu.SplitRtdgi(multigpu.LocalComm(n_ranks), py_pipes, W, H, motion_halo=8)
     nat = multigpu.NativeSplit(n_ranks, nat_pipes, W, H, motion_halo=8)
+    assert nat.self_test() is True      # kj_split_self_test with every rank in this process: the packed exchanges and the record-list gather on scratch images
     assert [nat.strip(r) for r in range(n_ranks)] == py.strips
     fs = frame.FrameState((W, H))
     fs.ircache_enabled = with_cache
