@@ -418,6 +418,9 @@ KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t
  * ray_counter_dev: optional device u64 that receives += rays traced. */
 KjStatus kj_trace_sun_shadow_mask(KjDevice* dev, KjScene* scene, const KjGbufferDepth* gbuffer_depth, void* out_mask_r8,
                                   uint64_t* ray_counter_dev, void* stream);
+/* Rows [row_begin, row_end) of the mask (row_begin a multiple of 8): one strip of the screen-tile split. Nothing outside the strip is read. */
+KjStatus kj_trace_sun_shadow_mask_rows(KjDevice* dev, KjScene* scene, const KjGbufferDepth* gbuffer_depth, void* out_mask_r8, uint32_t row_begin, uint32_t row_end,
+                                       uint64_t* ray_counter_dev, void* stream);
 
 /* ShadowDenoiseRenderer::render(rg, &GbufferDepth, shadow_mask, reprojection_map) -> ReadOnlyHandle<Image>
  *   renderers/shadow_denoise.rs:19-148; shaders/shadow_denoise/{bitpack_shadow_mask,megakernel,spatial_filter}.hlsl over the
@@ -430,6 +433,12 @@ KjStatus kj_shadow_denoise_create(KjDevice* dev, KjShadowDenoise** out);
 void kj_shadow_denoise_destroy(KjShadowDenoise* s);
 KjStatus kj_shadow_denoise_render(KjShadowDenoise* s, const KjGbufferDepth* gbuffer_depth, const void* shadow_mask_r8, const void* reprojection_map,
                                   const void** out_rg16f, void* stream);
+/* The denoised term for rows [row_begin, row_end) only (row_begin a multiple of 16): the screen-tile split's form. The passes over-compute what the next one
+ * reaches into (up to 24 rows either side), so the caller provides the mask on [row_begin - 32, row_end + 32) and the two histories
+ * ("shadow_denoise_moments:<k>", "shadow_denoise_accum:<k>" through kj_shadow_denoise_surface) on the strip +- (motion reach + 26) rows; *out_rg16f is valid on
+ * the strip's rows. kj_split_shadow_frame does exactly that. */
+KjStatus kj_shadow_denoise_render_rows(KjShadowDenoise* s, const KjGbufferDepth* gbuffer_depth, const void* shadow_mask_r8, const void* reprojection_map,
+                                       uint32_t row_begin, uint32_t row_end, const void** out_rg16f, void* stream);
 KjStatus kj_shadow_denoise_surface(KjShadowDenoise* s, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 
 /* light_gbuffer(rg, gbuffer_depth, shadow_mask, rtr, rtdgi, ircache, wrc, temporal_output, output, sky_cube, convolved_sky_cube,
@@ -442,6 +451,10 @@ KjStatus kj_shadow_denoise_surface(KjShadowDenoise* s, const char* name, void** 
 KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gbuffer_depth, const void* shadow_mask, uint32_t shadow_mask_is_rg16f, const void* rtr_tex,
                           const void* rtdgi_tex, const void* unconvolved_sky_cube, uint32_t sky_cube_width, void* out_temporal, void* out,
                           uint32_t debug_shading_mode, void* stream);
+/* Rows [row_begin, row_end) of the combine (row_begin a multiple of 8): every input is read at the pixel itself, a strip needs nothing from outside it. */
+KjStatus kj_light_gbuffer_rows(KjDevice* dev, const KjGbufferDepth* gbuffer_depth, const void* shadow_mask, uint32_t shadow_mask_is_rg16f, const void* rtr_tex,
+                               const void* rtdgi_tex, const void* unconvolved_sky_cube, uint32_t sky_cube_width, void* out_temporal, void* out,
+                               uint32_t debug_shading_mode, uint32_t row_begin, uint32_t row_end, void* stream);
 
 /* ---------------------------------------------------------------------------
  * SSAO / SSGI guide — feeds kernel radii and edge-stopping weights of the rtdgi spatial passes, resolve
@@ -614,6 +627,11 @@ KjStatus kj_split_merge_ircache(KjSplit* split, void* stream);
 /* The SSAO guide of the frame, before kj_split_gi_frame: SsgiRenderer::render strip by strip (kj_ssgi_render_rows) with the halo exchanges of its temporal
  * history and of the finished guide. `ssgi`, `out_ssao_r8`: one entry per LOCAL rank; out_ssao_r8[i] is what frames[i].rtdgi.ssao_tex must point at. */
 KjStatus kj_split_ssgi_frame(KjSplit* split, KjSsgi* const* ssgi, const KjSplitFrame* frames, const void** out_ssao_r8, void* stream);
+/* Sun shadows of the frame strip by strip: trace_sun_shadow_mask (each rank's rays for its own rows, into the caller's R8 image mask_r8[i]) +
+ * ShadowDenoiseRenderer::render (kj_shadow_denoise_render_rows) with the halo exchanges of the denoiser's two histories and of the mask. One entry per LOCAL
+ * rank in every array; out_rg16f[i] is valid on rank i's own rows (what kj_light_gbuffer_rows reads); ray_counters_dev: NULL or optional device u64s. */
+KjStatus kj_split_shadow_frame(KjSplit* split, KjShadowDenoise* const* denoisers, const KjSplitFrame* frames, void* const* mask_r8, uint64_t* const* ray_counters_dev,
+                               const void** out_rg16f, void* stream);
 /* TAA on the GI output of the frame just rendered (exchange I + strip-wise TaaRenderer::render). */
 KjStatus kj_split_taa_frame(KjSplit* split, const KjSplitFrame* frames, void* stream);
 /* Every rank receives the owners' rows of a surface ("spatial_filtered_tex", "TAA/taa:0", ...): result collection. */

@@ -222,13 +222,14 @@ struct LightGbufferArgs {
     const uint2* __restrict__ brdf_fg_lut;
     const float4* __restrict__ sun_color;
     uint32_t debug_shading_mode;
+    int row0, row1;      // rows [row0, row1) of the image
 };
 __global__ void __launch_bounds__(64) k_light_gbuffer(LightGbufferArgs a) {
     const int lane = threadIdx.x;
     const uint2 tb = tile_order<KJ_TILES_PLAIN>();
-    const int x = int(tb.x) * 8 + (lane & 7), y = int(tb.y) * 8 + (lane >> 3);
+    const int x = int(tb.x) * 8 + (lane & 7), y = a.row0 + int(tb.y) * 8 + (lane >> 3);
     const int W = a.output_tex.w, H = a.output_tex.h;
-    if (x >= W || y >= H) return;
+    if (x >= W || y >= a.row1) return;
     const FrameConstants& fc = *a.fc;
     const V4 ots = tex_size4(W, H);
     const V2 uv = get_uv(float(x), float(y), ots);
@@ -286,12 +287,12 @@ __global__ void __launch_bounds__(64) k_light_gbuffer(LightGbufferArgs a) {
 
 // rt/trace_sun_shadow_mask.rgen.hlsl:19-60 (USE_SOFT_SHADOWS 1): one shadow ray per full-res pixel, R8_UNORM mask
 __global__ void __launch_bounds__(64) k_sun_shadow_mask(const FrameConstants* __restrict__ fcp, SceneView sc, const uint32_t* __restrict__ blue_noise, Img<float> depth_tex,
-                                                         Img<uint32_t> geometric_normal_tex, Img<uint8_t> output_tex, unsigned long long* __restrict__ ray_counter) {
+                                                         Img<uint32_t> geometric_normal_tex, Img<uint8_t> output_tex, unsigned long long* __restrict__ ray_counter, int row0, int row1) {
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x;
     const uint2 tb = tile_order<KJ_TILES_PLAIN>();
-    const int x = int(tb.x) * 8 + (lane & 7), y = int(tb.y) * 8 + (lane >> 3);
-    if (x >= output_tex.w || y >= output_tex.h) return;
+    const int x = int(tb.x) * 8 + (lane & 7), y = row0 + int(tb.y) * 8 + (lane >> 3);      // rows [row0, row1): the launch covers just those tiles
+    if (x >= output_tex.w || y >= row1) return;
     const FrameConstants& fc = *fcp;
     const V2 uv{(float(x) + 0.5f) / float(output_tex.w), (float(y) + 0.5f) / float(output_tex.h)};
     const float z_over_w = depth_tex.ld(x, y);
@@ -323,7 +324,15 @@ extern "C" {
 // rtdgi_tex RGBA16F, unconvolved_sky_cube 6 x w x w RGBA16F; outputs RGBA16F.
 KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gd, const void* shadow_mask, uint32_t shadow_mask_is_rg16f, const void* rtr_tex, const void* rtdgi_tex,
                           const void* unconvolved_sky_cube, uint32_t sky_cube_width, void* out_temporal, void* out, uint32_t debug_shading_mode, void* stream) {
+    KJ_REQUIRE(gd, "null argument");
+    return kj_light_gbuffer_rows(dev, gd, shadow_mask, shadow_mask_is_rg16f, rtr_tex, rtdgi_tex, unconvolved_sky_cube, sky_cube_width, out_temporal, out, debug_shading_mode, 0u, gd->height, stream);
+}
+// rows [row_begin, row_end) of the combine (every input is read at the pixel itself: a strip needs nothing from outside it)
+KjStatus kj_light_gbuffer_rows(KjDevice* dev, const KjGbufferDepth* gd, const void* shadow_mask, uint32_t shadow_mask_is_rg16f, const void* rtr_tex, const void* rtdgi_tex,
+                               const void* unconvolved_sky_cube, uint32_t sky_cube_width, void* out_temporal, void* out, uint32_t debug_shading_mode,
+                               uint32_t row_begin, uint32_t row_end, void* stream) {
     KJ_REQUIRE(dev && gd && gd->gbuffer && gd->depth && shadow_mask && rtdgi_tex && unconvolved_sky_cube && out_temporal && out && gd->width && gd->height, "null argument");
+    KJ_REQUIRE(row_begin < row_end && row_end <= gd->height && (row_begin % 8u) == 0u, "rows must be a non-empty range starting on an 8-row boundary");
     KJ_REQUIRE(dev->fc_dev, "kj_frame_begin not called");
     if (debug_shading_mode > 4) { set_last_error("debug_shading_mode %u (ircache view) is not built", debug_shading_mode); return KJ_ERR_UNSUPPORTED; }
     const int W = int(gd->width), H = int(gd->height);
@@ -337,21 +346,28 @@ KjStatus kj_light_gbuffer(KjDevice* dev, const KjGbufferDepth* gd, const void* s
     a.brdf_fg_lut = (const uint2*)dev->brdf_fg_lut.p;
     a.sun_color = (const float4*)dev->sun_color.p + dev->fc_slot;
     a.debug_shading_mode = debug_shading_mode;
-    hipLaunchKernelGGL(k_light_gbuffer, dim3((W + 7) / 8, (H + 7) / 8), dim3(64), 0, (hipStream_t)stream, a);
+    a.row0 = int(row_begin); a.row1 = int(row_end);
+    hipLaunchKernelGGL(k_light_gbuffer, dim3((W + 7) / 8, (row_end - row_begin + 7) / 8), dim3(64), 0, (hipStream_t)stream, a);
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }
 
 // trace_sun_shadow_mask(rg, &GbufferDepth, tlas, bindless_set) -> Handle<Image> (renderers/shadows.rs:10-40)
 KjStatus kj_trace_sun_shadow_mask(KjDevice* dev, KjScene* scene, const KjGbufferDepth* gd, void* out_mask_r8, uint64_t* ray_counter_dev, void* stream) {
+    KJ_REQUIRE(gd, "null argument");
+    return kj_trace_sun_shadow_mask_rows(dev, scene, gd, out_mask_r8, 0u, gd->height, ray_counter_dev, stream);
+}
+// rows [row_begin, row_end) of the mask: one ray per pixel of the strip, nothing read from outside it
+KjStatus kj_trace_sun_shadow_mask_rows(KjDevice* dev, KjScene* scene, const KjGbufferDepth* gd, void* out_mask_r8, uint32_t row_begin, uint32_t row_end, uint64_t* ray_counter_dev, void* stream) {
     KJ_REQUIRE(dev && scene && gd && gd->depth && gd->geometric_normal && out_mask_r8 && gd->width && gd->height, "null argument");
+    KJ_REQUIRE(row_begin < row_end && row_end <= gd->height && (row_begin % 8u) == 0u, "rows must be a non-empty range starting on an 8-row boundary");
     KJ_REQUIRE(dev->fc_dev, "kj_frame_begin not called");
     if (!scene->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
     const SceneView sv = scene_view(*scene);
     const int W = int(gd->width), H = int(gd->height);
-    hipLaunchKernelGGL(k_sun_shadow_mask, dim3((W + 7) / 8, (H + 7) / 8), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, dev->fc_dev, sv,
+    hipLaunchKernelGGL(k_sun_shadow_mask, dim3((W + 7) / 8, (row_end - row_begin + 7) / 8), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, dev->fc_dev, sv,
                        (const uint32_t*)dev->blue_noise.p, img<float>(gd->depth, W, H), img<uint32_t>(gd->geometric_normal, W, H), img<uint8_t>(out_mask_r8, W, H),
-                       (unsigned long long*)ray_counter_dev);
+                       (unsigned long long*)ray_counter_dev, int(row_begin), int(row_end));
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }

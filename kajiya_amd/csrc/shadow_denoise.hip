@@ -13,13 +13,15 @@ typedef Img<float> ImgF32;
 typedef Img<uint8_t> ImgR8;
 
 // whole tile rows per XCD (kj_vec.hpp: tile_order; every tile of these passes costs the same): spatial 37.5 -> 30.6 us per pass at 1440p
+// tile_row0: the first 8-row tile row of the launch (strips of the screen-tile split start there; 0 for the whole image)
 #define TILE_XY()                                                                          \
     const int lane = threadIdx.x;                                                          \
-    const uint2 kj_tb = kj::tile_order<KJ_TILES_ROWS>();                                  \
+    uint2 kj_tb = kj::tile_order<KJ_TILES_ROWS>();                                        \
+    kj_tb.y += uint32_t(tile_row0);                                                        \
     const int x = int(kj_tb.x) * 8 + (lane & 7), y = int(kj_tb.y) * 8 + (lane >> 3);
 
 // "shadow bitpack" (bitpack_shadow_mask.hlsl + ffx prepare): bit (y%4)*8 + x%8 of tile (x/8, y/4) = ray reached the light
-__global__ void __launch_bounds__(64) k_shadow_bitpack(ImgR8 input_tex, ImgU32 output_tex) {
+__global__ void __launch_bounds__(64) k_shadow_bitpack(ImgR8 input_tex, ImgU32 output_tex, int tile_row0) {
     TILE_XY()
     const bool hit = from_unorm8(input_tex.ld(x, y)) > 0.5f;     // OOB = 0 = shadowed, like the shader's OOB load
     const unsigned long long m = __ballot(hit);
@@ -70,6 +72,7 @@ struct ShadowTemporalArgs {
     ImgH4 output_moments_tex; ImgU32 temporal_output_tex /*RG16F*/; ImgU32 meta_output_tex;
     KernelWeights kw;
     int W, H, TW, TH;
+    int tile_row0;
 };
 KJ_D float shadow_horizontal_neighborhood(const ShadowTemporalArgs& a, int dx, int dy) {
     if (dy < 0 || dy >= a.H) return 0.0f;
@@ -90,6 +93,7 @@ KJ_D float shadow_horizontal_neighborhood(const ShadowTemporalArgs& a, int dx, i
 }
 // "shadow temporal" (megakernel.hlsl + ffx tile classification)
 __global__ void __launch_bounds__(64) k_shadow_temporal(ShadowTemporalArgs a) {
+    const int tile_row0 = a.tile_row0;
     TILE_XY()
     const int gx = int(kj_tb.x), gy = int(kj_tb.y);
     // FFX_DNSR_Shadows_SearchSpatialRegion: 3 x 6 masks around the two 8x4 tiles of this block (wave-uniform)
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(64) k_shadow_temporal(ShadowTemporalArgs a) {
 }
 
 // "shadow spatial" (spatial_filter.hlsl + ffx filter): 16x16 LDS tile holding packed halves exactly like the shader
-__global__ void __launch_bounds__(64) k_shadow_spatial(ImgU32 input_tex /*RG16F*/, ImgU32 meta_tex, ImgU32 geometric_normal_tex, ImgF32 depth_tex, ImgU32 output_tex, int stepsize) {
+__global__ void __launch_bounds__(64) k_shadow_spatial(ImgU32 input_tex /*RG16F*/, ImgU32 meta_tex, ImgU32 geometric_normal_tex, ImgF32 depth_tex, ImgU32 output_tex, int stepsize, int tile_row0) {
     TILE_XY()
     const int W = depth_tex.w, H = depth_tex.h;
     const uint32_t meta = meta_tex.ld(int(kj_tb.x), int(kj_tb.y));
@@ -253,8 +257,19 @@ void kj_shadow_denoise_destroy(KjShadowDenoise* t) { delete t; }
 
 // ShadowDenoiseRenderer::render(rg, &GbufferDepth, shadow_mask, reprojection_map) -> ReadOnlyHandle<Image> (shadow_denoise.rs:19-25)
 KjStatus kj_shadow_denoise_render(KjShadowDenoise* t, const KjGbufferDepth* gd, const void* shadow_mask_r8, const void* reprojection_map, const void** out_rg16f, void* stream_) {
+    KJ_REQUIRE(gd, "null argument");
+    return kj_shadow_denoise_render_rows(t, gd, shadow_mask_r8, reprojection_map, 0u, gd->height, out_rg16f, stream_);
+}
+// The denoised term for full-res rows [row_begin, row_end) (row_begin a multiple of 16): the screen-tile split computes it strip by strip. Every pass runs on
+// the rows the next one reaches into, so only the mask (valid on [r0 - 32, r1 + 32)) and the two histories the temporal pass reads through the motion
+// vectors come from outside the strip:
+//   spatial step 4 on [r0, r1) reads step 2's output +-4 rows -> step 2 on [r0 - 8, r1 + 8) reads +-2 -> step 1 on [r0 - 16, r1 + 16) reads the temporal
+//   pass' output +-1 -> temporal (and the tile metadata) on [r0 - 24, r1 + 24) reads the bit-packed mask +-8 rows -> bitpack on [r0 - 32, r1 + 32).
+KjStatus kj_shadow_denoise_render_rows(KjShadowDenoise* t, const KjGbufferDepth* gd, const void* shadow_mask_r8, const void* reprojection_map, uint32_t row_begin, uint32_t row_end,
+                                       const void** out_rg16f, void* stream_) {
     KJ_REQUIRE(t && gd && gd->depth && gd->geometric_normal && shadow_mask_r8 && reprojection_map && out_rg16f && gd->width && gd->height, "null argument");
     KJ_REQUIRE(t->dev->fc_dev, "kj_frame_begin not called");
+    KJ_REQUIRE(row_begin < row_end && row_end <= gd->height && (row_begin % 16u) == 0u, "rows must be a non-empty range starting on a 16-row boundary");
     hipStream_t s = (hipStream_t)stream_;
     const int W = int(gd->width), H = int(gd->height), TW = (W + 7) / 8, TH = (H + 3) / 4, GW = (W + 7) / 8, GH = (H + 7) / 8;
     if (W != t->W || H != t->H) { t->surf.clear(); t->W = W; t->H = H; t->flip_accum = t->flip_moments = false; }
@@ -270,11 +285,17 @@ KjStatus kj_shadow_denoise_render(KjShadowDenoise* t, const KjGbufferDepth* gd, 
     void* metadata = t->get("metadata_image", TB * 4, s);
     void* temp = t->get("temp", FB * 4, s);
     KJ_TRY_HIP(t->err);
-    const dim3 grid(GW, GH), blk(64);
+    const dim3 blk(64);
+    const bool whole = row_begin == 0u && int(row_end) == H;
+    // 8-row tile rows [t0, t1) of a pass that over-computes `grow` pixel rows on either side of the strip
+    const int tr0 = int(row_begin) / 8, tr1 = (int(row_end) + 7) / 8;
+    auto tiles = [&](int grow, int& t0, int& t1) { t0 = whole ? 0 : std::max(0, tr0 - grow / 8); t1 = whole ? GH : std::min(GH, tr1 + grow / 8); };
+    int t0, t1;
     const ImgR8 mask = img<uint8_t>(shadow_mask_r8, W, H);
     const ImgF32 depth = img<float>(gd->depth, W, H);
     const ImgU32 gnormal = img<uint32_t>(gd->geometric_normal, W, H);
-    hipLaunchKernelGGL(k_shadow_bitpack, grid, blk, 0, s, mask, img<uint32_t>(bitpacked, TW, TH));
+    tiles(32, t0, t1);
+    hipLaunchKernelGGL(k_shadow_bitpack, dim3(GW, t1 - t0), blk, 0, s, mask, img<uint32_t>(bitpacked, TW, TH), t0);
     KJ_CHECK_LAUNCH();
     ShadowTemporalArgs a;
     a.fc = t->dev->fc_dev;
@@ -288,14 +309,19 @@ KjStatus kj_shadow_denoise_render(KjShadowDenoise* t, const KjGbufferDepth* gd, 
         for (int c = 0; c <= 8; ++c) a.kw.w[c] = kw(float(c)) * (1.0f / sum);
     }
     a.W = W; a.H = H; a.TW = TW; a.TH = TH;
-    hipLaunchKernelGGL(k_shadow_temporal, grid, blk, 0, s, a);
+    tiles(24, t0, t1);
+    a.tile_row0 = t0;
+    hipLaunchKernelGGL(k_shadow_temporal, dim3(GW, t1 - t0), blk, 0, s, a);
     KJ_CHECK_LAUNCH();
     const ImgU32 meta = img<uint32_t>(metadata, TW, TH);
-    hipLaunchKernelGGL(k_shadow_spatial, grid, blk, 0, s, img<uint32_t>(spatial_input, W, H), meta, gnormal, depth, img<uint32_t>(accum_out, W, H), 1);
+    tiles(16, t0, t1);
+    hipLaunchKernelGGL(k_shadow_spatial, dim3(GW, t1 - t0), blk, 0, s, img<uint32_t>(spatial_input, W, H), meta, gnormal, depth, img<uint32_t>(accum_out, W, H), 1, t0);
     KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_shadow_spatial, grid, blk, 0, s, img<uint32_t>(accum_out, W, H), meta, gnormal, depth, img<uint32_t>(temp, W, H), 2);
+    tiles(8, t0, t1);
+    hipLaunchKernelGGL(k_shadow_spatial, dim3(GW, t1 - t0), blk, 0, s, img<uint32_t>(accum_out, W, H), meta, gnormal, depth, img<uint32_t>(temp, W, H), 2, t0);
     KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_shadow_spatial, grid, blk, 0, s, img<uint32_t>(temp, W, H), meta, gnormal, depth, img<uint32_t>(spatial_input, W, H), 4);
+    tiles(0, t0, t1);
+    hipLaunchKernelGGL(k_shadow_spatial, dim3(GW, t1 - t0), blk, 0, s, img<uint32_t>(temp, W, H), meta, gnormal, depth, img<uint32_t>(spatial_input, W, H), 4, t0);
     KJ_CHECK_LAUNCH();
     *out_rg16f = spatial_input;
     return KJ_OK;

@@ -35,6 +35,7 @@ const std::map<std::string, SurfInfo>& surf_table() {
         {"candidate_hit_tex", {8, true}}, {"temporal_reservoir_packed_tex", {16, true}}, {"reservoir_output_tex0", {8, true}}, {"reservoir_output_tex1", {8, true}},
         {"irradiance_output_tex", {8, false}}, {"temporal_filtered_tex", {8, false}}, {"spatial_filtered_tex", {8, false}}, {"reprojected_history_tex", {8, false}},
         {"SSGI/ssgi", {2, false}}, {"SSGI/filtered_output_tex", {1, false}},
+        {"SHADOW/shadow_denoise_moments", {8, false}}, {"SHADOW/shadow_denoise_accum", {4, false}}, {"SHADOW/mask", {1, false}},      // "SHADOW/mask": the caller's image (kj_split_shadow_frame)
         {"TAA/taa", {8, false}}, {"TAA/taa.velocity", {4, false}}, {"TAA/taa.smooth_var", {8, false}}, {"TAA/this_frame_output_img", {8, false}},
         {"selftest.h16", {16, true}}, {"selftest.h1", {1, true}}, {"selftest.f8", {8, false}}, {"selftest.f4", {4, false}},      // kj_split_self_test's scratch images
     };
@@ -86,6 +87,8 @@ struct KjSplit {
     std::vector<std::pair<uint32_t, uint32_t>> strips;     // full-res rows [r0, r1) of every rank of the job
     uint32_t frame = 0, taa_frames = 0, ssgi_frames = 0;
     std::vector<KjSsgi*> ssgi;                             // the local ranks' SsgiRenderers (kj_split_ssgi_frame)
+    std::vector<KjShadowDenoise*> shadow;                  // the local ranks' ShadowDenoiseRenderers (kj_split_shadow_frame)
+    uint32_t shadow_frames = 0;
     bool consistent_ircache = false;
     std::vector<uint8_t> ircache_was_deferred;             // each local cache's mode before kj_split_create changed it: restored by kj_split_destroy
     void* nccl = nullptr;                                  // ncclComm_t; null: every rank is local
@@ -118,8 +121,10 @@ KjStatus surface_of(KjSplit& s, uint32_t rank, const std::string& name, uint8_t*
     if (it == s.surfaces.end()) {     // renderer surfaces are allocated once per extent: the pointer is stable
         void* p = nullptr; uint64_t bytes = 0;
         KJ_REQUIRE(name.rfind("SSGI/", 0) != 0 || (li < s.ssgi.size() && s.ssgi[li]), "no SsgiRenderer bound to this rank");
+        KJ_REQUIRE(name.rfind("SHADOW/", 0) != 0 || (li < s.shadow.size() && s.shadow[li]), "no ShadowDenoiseRenderer bound to this rank");
         const KjStatus st = name.rfind("TAA/", 0) == 0    ? kj_taa_surface(s.ranks[li].taa, name.c_str() + 4, &p, &bytes)
                             : name.rfind("SSGI/", 0) == 0 ? kj_ssgi_surface(s.ssgi[li], name.c_str() + 5, &p, &bytes)
+                            : name.rfind("SHADOW/", 0) == 0 ? kj_shadow_denoise_surface(s.shadow[li], name.c_str() + 7, &p, &bytes)
                                                           : kj_rtdgi_surface(s.ranks[li].rtdgi, name.c_str(), &p, &bytes);
         if (st != KJ_OK) return st;
         it = s.surfaces.emplace(key, std::make_pair((uint8_t*)p, bytes)).first;
@@ -446,6 +451,38 @@ KjStatus kj_split_ssgi_frame(KjSplit* s, KjSsgi* const* ssgi, const KjSplitFrame
     }
     KJ_SPLIT_TRY(exchange(*s, {{sfx("SSGI/filtered_output_tex", s->ssgi_frames % 2), 144 + 2}}, st));
     ++s->ssgi_frames;
+    return KJ_OK;
+}
+
+// trace_sun_shadow_mask + ShadowDenoiseRenderer::render strip by strip (multigpu.py: SplitRtdgi.shadow_frame; world_render_passes.rs:124-136): the halo of the
+// denoiser's two histories (read through the motion vectors by a temporal pass that over-computes 24 rows either side), every local rank's rays for its own
+// rows into the caller's mask image, the mask's 32-row halo (one byte per pixel: cheaper than tracing the neighbours' rays again), then the denoiser's
+// passes, each over-computing what the next one reaches into (kj_shadow_denoise_render_rows). out_rg16f[li] is valid on the rank's own rows, which is all
+// kj_light_gbuffer_rows reads. `ray_counters_dev`: NULL or one optional device u64 per local rank.
+KjStatus kj_split_shadow_frame(KjSplit* s, KjShadowDenoise* const* denoisers, const KjSplitFrame* frames, void* const* mask_r8, uint64_t* const* ray_counters_dev,
+                               const void** out_rg16f, void* stream) {
+    KJ_REQUIRE(s && denoisers && frames && mask_r8 && out_rg16f, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    s->shadow.assign(denoisers, denoisers + s->local);
+    for (uint32_t li = 0; li < s->local; ++li) {
+        KJ_REQUIRE(s->shadow[li] && mask_r8[li], "null ShadowDenoiseRenderer / mask image");
+        s->surfaces[{li, std::string("SHADOW/mask")}] = {(uint8_t*)mask_r8[li], uint64_t(s->W) * s->H};      // the caller's image: bound anew every frame
+    }
+    if (s->shadow_frames > 0) {
+        const uint32_t h = 1 - s->shadow_frames % 2, halo = s->motion_halo + 3 + 24;
+        KJ_SPLIT_TRY(exchange(*s, {{sfx("SHADOW/shadow_denoise_moments", h), int(halo)}, {sfx("SHADOW/shadow_denoise_accum", h), int(halo)}}, st));
+    }
+    for (uint32_t li = 0; li < s->local; ++li) {
+        const auto own = s->strips[s->first + li];
+        KJ_SPLIT_TRY(kj_trace_sun_shadow_mask_rows(s->ranks[li].scene->dev, s->ranks[li].scene, &frames[li].rtdgi.gbuffer_depth, mask_r8[li], own.first, own.second,
+                                                   ray_counters_dev ? ray_counters_dev[li] : nullptr, st));
+    }
+    KJ_SPLIT_TRY(exchange(*s, {{"SHADOW/mask", 32}}, st));
+    for (uint32_t li = 0; li < s->local; ++li) {
+        const auto own = s->strips[s->first + li];
+        KJ_SPLIT_TRY(kj_shadow_denoise_render_rows(s->shadow[li], &frames[li].rtdgi.gbuffer_depth, mask_r8[li], frames[li].rtdgi.reprojection_map, own.first, own.second, &out_rg16f[li], st));
+    }
+    ++s->shadow_frames;
     return KJ_OK;
 }
 

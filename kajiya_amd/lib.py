@@ -26,13 +26,13 @@ EXPORTS = [
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
     "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts", "kj_ircache_set_deferred_updates", "kj_ircache_begin_requests", "kj_ircache_request_ranges", "kj_ircache_collect_requests", "kj_ircache_apply_requests",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
-    "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_render_rows", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_light_gbuffer",
-    "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_surface",
+    "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_render_rows", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_trace_sun_shadow_mask_rows", "kj_light_gbuffer", "kj_light_gbuffer_rows",
+    "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_render_rows", "kj_shadow_denoise_surface",
     "kj_baked_mesh_view", "kj_baked_image_view", "kj_baked_image_mip", "kj_baked_image_decode_rgba8",
     "kj_rtr_create", "kj_rtr_destroy", "kj_rtr_set_options", "kj_rtr_trace", "kj_rtr_render_specular_lights", "kj_rtr_filter_temporal", "kj_rtr_surface", "kj_rtr_ray_counts",
     "kj_post_create", "kj_post_destroy", "kj_post_render", "kj_post_read_back_histogram", "kj_luminance_histogram_mean_log2", "kj_post_surface", "kj_post_mip_levels",
     "kj_motion_blur_create", "kj_motion_blur_destroy", "kj_motion_blur_render", "kj_motion_blur_surface",
-    "kj_split_create", "kj_split_destroy", "kj_split_strip", "kj_split_gi_frame", "kj_split_merge_ircache", "kj_split_taa_frame", "kj_split_ssgi_frame", "kj_split_gather", "kj_split_self_test",
+    "kj_split_create", "kj_split_destroy", "kj_split_strip", "kj_split_gi_frame", "kj_split_merge_ircache", "kj_split_taa_frame", "kj_split_ssgi_frame", "kj_split_gather", "kj_split_self_test", "kj_split_shadow_frame",
     "kj_split_rccl_unique_id", "kj_split_rccl_comm_create", "kj_split_rccl_comm_destroy",
 ]
 
@@ -112,8 +112,10 @@ def load():
         "kj_taa_render": [vp, vp, u32, u32, vp, vp, u32, u32, C.POINTER(KjTaaOutput), vp],
         "kj_taa_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_light_gbuffer": [vp, C.POINTER(KjGbufferDepth), vp, u32, vp, vp, vp, u32, vp, vp, u32, vp],
+        "kj_light_gbuffer_rows": [vp, C.POINTER(KjGbufferDepth), vp, u32, vp, vp, vp, u32, vp, vp, u32, u32, u32, vp],
         "kj_shadow_denoise_create": [vp, C.POINTER(vp)],
         "kj_shadow_denoise_render": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.POINTER(vp), vp],
+        "kj_shadow_denoise_render_rows": [vp, C.POINTER(KjGbufferDepth), vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp), vp],
         "kj_shadow_denoise_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_rtr_create": [vp, C.POINTER(KjRtrTables), C.POINTER(vp)],
         "kj_rtr_set_options": [vp, u32],
@@ -123,6 +125,7 @@ def load():
         "kj_rtr_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_rtr_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "kj_trace_sun_shadow_mask": [vp, vp, C.POINTER(KjGbufferDepth), vp, vp, vp],
+        "kj_trace_sun_shadow_mask_rows": [vp, vp, C.POINTER(KjGbufferDepth), vp, C.c_uint32, C.c_uint32, vp, vp],
         "kj_post_create": [vp, vp, C.POINTER(vp)],
         "kj_post_render": [vp, vp, u32, u32, u32, C.c_float, C.c_float, C.POINTER(vp), vp],
         "kj_post_read_back_histogram": [vp, C.c_float, C.c_float, C.POINTER(C.c_float), vp],
@@ -146,6 +149,7 @@ def load():
         "kj_split_merge_ircache": [vp, vp],
         "kj_split_gather": [vp, C.c_char_p, vp],
         "kj_split_self_test": [vp, C.POINTER(C.c_uint32), vp],
+        "kj_split_shadow_frame": [vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
         "kj_split_rccl_unique_id": [vp],
         "kj_split_rccl_comm_create": [vp, u32, u32, C.POINTER(vp)],
     }
@@ -499,22 +503,29 @@ class GpuPipeline:
         inp = input_ptr if input_ptr is not None else self.out.screen_irradiance_tex
         check(self.L.kj_taa_render(self.taa, inp, self.W, self.H, self.reprojection_map_ptr, self.depth.data_ptr(), ow, oh, C.byref(self.taa_out), _stream_ptr()))
 
-    def sun_shadow_mask(self, out=None, ray_counter=None):
-        """trace_sun_shadow_mask (renderers/shadows.rs:10-40): R8 mask, one soft-shadow ray per pixel."""
+    def sun_shadow_mask(self, out=None, ray_counter=None, rows=None):
+        """trace_sun_shadow_mask (renderers/shadows.rs:10-40): R8 mask, one soft-shadow ray per pixel. `rows` = (row_begin, row_end): only those
+        rows (the screen-tile split, kj_trace_sun_shadow_mask_rows)."""
         if out is None:
             out = self.torch.zeros((self.H, self.W), dtype=self.torch.uint8, device=self.depth.device)
         g = self.gbuffer_depth()
-        check(self.L.kj_trace_sun_shadow_mask(self.dev.h, self.scene.h, C.byref(g), out.data_ptr(), ray_counter.data_ptr() if ray_counter is not None else None, _stream_ptr()))
+        r0, r1 = rows if rows is not None else (0, self.H)
+        check(self.L.kj_trace_sun_shadow_mask_rows(self.dev.h, self.scene.h, C.byref(g), out.data_ptr(), r0, r1, ray_counter.data_ptr() if ray_counter is not None else None, _stream_ptr()))
         return out
 
-    def shadow_denoise(self, shadow_mask):
-        """ShadowDenoiseRenderer::render (world_render_passes.rs:131-136): returns the RG16F image (H, W, 2) float16, x = shadow term."""
+    def shadow_denoiser(self):
         if getattr(self, "shadow_dn", None) is None:
             self.shadow_dn = C.c_void_p()
             check(self.L.kj_shadow_denoise_create(self.dev.h, C.byref(self.shadow_dn)))
+        return self.shadow_dn
+
+    def shadow_denoise(self, shadow_mask, rows=None):
+        """ShadowDenoiseRenderer::render (world_render_passes.rs:131-136): returns the RG16F image (H, W, 2) float16, x = shadow term. `rows`: the
+        strip form (kj_shadow_denoise_render_rows): the result is valid on those rows only."""
         g = self.gbuffer_depth()
         out = C.c_void_p()
-        check(self.L.kj_shadow_denoise_render(self.shadow_dn, C.byref(g), shadow_mask.data_ptr(), self.reprojection_map_ptr, C.byref(out), _stream_ptr()))
+        r0, r1 = rows if rows is not None else (0, self.H)
+        check(self.L.kj_shadow_denoise_render_rows(self.shadow_denoiser(), C.byref(g), shadow_mask.data_ptr(), self.reprojection_map_ptr, r0, r1, C.byref(out), _stream_ptr()))
         return tensor_from_ptr(out.value, self.W * self.H * 4, self.torch.float16, (self.H, self.W, 2))
 
     def rtr_params(self, pass_mask=63):
@@ -569,16 +580,17 @@ class GpuPipeline:
         check(self.L.kj_shadow_denoise_surface(self.shadow_dn, name.encode(), C.byref(ptr), C.byref(n)))
         return tensor_from_ptr(ptr.value, n.value, dtype, shape)
 
-    def light_gbuffer(self, shadow_mask, rtdgi_ptr=None, rtr_ptr=None, debug_shading_mode=0):
+    def light_gbuffer(self, shadow_mask, rtdgi_ptr=None, rtr_ptr=None, debug_shading_mode=0, rows=None):
         """light_gbuffer (renderers/deferred.rs:6-60): returns (temporal_output, output) RGBA16F images. `shadow_mask`: uint8 (H, W)
-        raw mask or float16 (H, W, 2) denoised image."""
+        raw mask or float16 (H, W, 2) denoised image. `rows`: only those rows (kj_light_gbuffer_rows)."""
         t = self.torch
         if not hasattr(self, "_lit"):
             self._lit = (t.zeros((self.H, self.W, 4), dtype=t.float16, device=self.depth.device), t.zeros((self.H, self.W, 4), dtype=t.float16, device=self.depth.device))
         g = self.gbuffer_depth()
         gi = rtdgi_ptr if rtdgi_ptr is not None else self.out.screen_irradiance_tex
-        check(self.L.kj_light_gbuffer(self.dev.h, C.byref(g), shadow_mask.data_ptr(), 1 if shadow_mask.dtype == t.float16 else 0, rtr_ptr, gi, self.sky64.data_ptr(), 64,
-                                      self._lit[0].data_ptr(), self._lit[1].data_ptr(), debug_shading_mode, _stream_ptr()))
+        r0, r1 = rows if rows is not None else (0, self.H)
+        check(self.L.kj_light_gbuffer_rows(self.dev.h, C.byref(g), shadow_mask.data_ptr(), 1 if shadow_mask.dtype == t.float16 else 0, rtr_ptr, gi, self.sky64.data_ptr(), 64,
+                                           self._lit[0].data_ptr(), self._lit[1].data_ptr(), debug_shading_mode, r0, r1, _stream_ptr()))
         return self._lit
 
     def ssgi_frame(self, rows=None):

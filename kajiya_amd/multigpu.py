@@ -45,6 +45,8 @@ SSGI_SURF = {"ssgi": 2, "filtered_output_tex": 1}
 # rows of the SSAO guide a rank's rtdgi passes reach beyond its strip: the first spatial pass runs on own +- 64 full-res rows and its taps reach another
 # 32 half-res rows (the guide travels inside the half-res G-buffer record extract_half writes), + the half-res subsample offset
 GUIDE_HALO = 144
+# ShadowDenoiseRenderer surfaces the split exchanges (full-res): the temporal pass' two histories (RGBA16F moments, RG16F accumulated term)
+SHADOW_SURF = {"shadow_denoise_moments": 8, "shadow_denoise_accum": 4}
 
 
 def plan_strips(height, n):
@@ -238,7 +240,8 @@ class SplitRtdgi:
       I  before TAA      25 rows of the GI output
     Between D and H nothing is exchanged: spatial pass 0 is over-computed on +-32 half-res rows, pass 1 on +-16, the resolve on
     +-16 full-res rows, which covers every tap of the next pass (restir_spatial.hlsl:89-97,155-157; restir_resolve.hlsl:89-96;
-    temporal_filter.hlsl:69-89). TAA over-computes its intermediates the same way (taa_frame)."""
+    temporal_filter.hlsl:69-89). TAA over-computes its intermediates the same way (taa_frame). Outside gi_frame: the SSAO guide (ssgi_frame: its
+    history's motion halo, the finished guide's halo) and the sun shadows (shadow_frame: the denoiser's histories' motion halos, the mask's halo)."""
 
     def __init__(self, comm, pipes, width, height, motion_halo=8):
         self.comm, self.pipes = comm, pipes
@@ -248,6 +251,7 @@ class SplitRtdgi:
         self.frame = 0
         self.taa_frames = 0
         self.ssgi_frames = 0
+        self.shadow_frames = 0
         self._views = {}
         self._plans = {}
         self._params = {}
@@ -273,6 +277,10 @@ class SplitRtdgi:
                 t = gp.taa_surface(name[4:], torch.uint8, (self.H, self.W * TAA_SURF[name[4:].split(":")[0]]))
             elif name.startswith("SSGI/"):
                 t = gp.ssgi_surface(name[5:], torch.uint8, (self.H, self.W * SSGI_SURF[name[5:].split(":")[0]]))
+            elif name == "SHADOW/mask":
+                return gp.shadow_mask_img            # the caller's image (shadow_frame): not cached, it may change between frames
+            elif name.startswith("SHADOW/"):
+                t = gp.shadow_denoise_surface(name[7:], torch.uint8, (self.H, self.W * SHADOW_SURF[name[7:].split(":")[0]]))
             else:
                 bpt, res = SURF[name.split(":")[0]]
                 w = (self.W + 1) // 2 if res == "h" else self.W
@@ -292,7 +300,7 @@ class SplitRtdgi:
         if prepared is None:
             xfers = []
             for name, halo in items:
-                res = "f" if name.startswith(("TAA/", "SSGI/")) else SURF[name.split(":")[0]][1]
+                res = "f" if name.startswith(("TAA/", "SSGI/", "SHADOW/")) else SURF[name.split(":")[0]][1]
                 xfers += [(src, dst, (name, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H)]
             # renderer surfaces keep their address for a given extent, so the row views can be resolved once per distinct item list
             # (two per exchange point: the ping-pong suffixes alternate)
@@ -444,6 +452,34 @@ class SplitRtdgi:
             self.pipes[r].ssgi_frame(rows=self.strips[r])
         self._exchange([(f"SSGI/filtered_output_tex:{self.ssgi_frames % 2}", GUIDE_HALO + 2)])
         self.ssgi_frames += 1
+
+    def shadow_frame(self, masks=None, ray_counters=None):
+        """trace_sun_shadow_mask + ShadowDenoiseRenderer::render strip by strip (world_render_passes.rs:124-136): the halo of the denoiser's two
+        histories (its temporal pass reads them through the motion vectors and over-computes 24 rows either side), every rank's rays for its OWN
+        rows, the mask's 32-row halo (one byte per pixel -- cheaper than tracing the neighbours' rays again), then the denoiser's passes, each
+        over-computing what the next one reaches into (kj_shadow_denoise_render_rows). Returns {rank: RG16F image valid on the rank's own rows} --
+        all light_gbuffer(rows=strip) reads. `masks`: {rank: uint8 (H, W) image}; made on first use otherwise."""
+        import torch
+        M = self.motion_halo
+        R = self.comm.ranks
+        for r in R:
+            gp = self.pipes[r]
+            gp.shadow_denoiser()
+            if masks is not None:
+                gp.shadow_mask_img = masks[r]
+            elif getattr(gp, "shadow_mask_img", None) is None:
+                gp.shadow_mask_img = torch.zeros((self.H, self.W), dtype=torch.uint8, device=gp.depth.device)
+        if self.shadow_frames > 0:
+            h = f":{1 - self.shadow_frames % 2}"
+            self._exchange([("SHADOW/shadow_denoise_moments" + h, M + 3 + 24), ("SHADOW/shadow_denoise_accum" + h, M + 3 + 24)])
+        for r in R:
+            self.pipes[r].sun_shadow_mask(out=self.pipes[r].shadow_mask_img, ray_counter=ray_counters[r] if ray_counters else None, rows=self.strips[r])
+        if masks is not None:
+            self._plans.pop((("SHADOW/mask", 32),), None)       # the caller's image may be another one than last frame's: resolve its rows anew
+        self._exchange([("SHADOW/mask", 32)])
+        out = {r: self.pipes[r].shadow_denoise(self.pipes[r].shadow_mask_img, rows=self.strips[r]) for r in R}
+        self.shadow_frames += 1
+        return out
 
     def gi_frame(self, ircache_done=False, trace_event=None, defer_merge=False):
         """One rtdgi frame. Unless `ircache_done`, each rank's ircache.prepare + trace_irradiance run here first (serial order).
@@ -681,6 +717,25 @@ class NativeSplit:
         klib.check(self.L.kj_split_ssgi_frame(self.h, handles, self._frames, outs, klib._stream_ptr()))
         for i, r in enumerate(self.ranks):
             self.pipes[r].ssao_ptr = C.c_void_p(outs[i])
+
+    def shadow_frame(self, masks=None, ray_counters=None):
+        """kj_split_shadow_frame: the sun shadow mask + its denoiser strip by strip (SplitRtdgi.shadow_frame is the reference). Returns {rank: RG16F
+        image valid on the rank's own rows}."""
+        import torch
+        n = len(self.ranks)
+        handles, mk, outs, ctr = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+        for i, r in enumerate(self.ranks):
+            gp = self.pipes[r]
+            handles[i] = gp.shadow_denoiser().value
+            if masks is not None:
+                gp.shadow_mask_img = masks[r]
+            elif getattr(gp, "shadow_mask_img", None) is None:
+                gp.shadow_mask_img = torch.zeros((self.H, self.W), dtype=torch.uint8, device=gp.depth.device)
+            mk[i] = gp.shadow_mask_img.data_ptr()
+            ctr[i] = ray_counters[r].data_ptr() if ray_counters else None
+        self._fill()
+        klib.check(self.L.kj_split_shadow_frame(self.h, handles, self._frames, mk, ctr if ray_counters else None, outs, klib._stream_ptr()))
+        return {r: klib.tensor_from_ptr(outs[i], self.W * self.H * 4, torch.float16, (self.H, self.W, 2)) for i, r in enumerate(self.ranks)}
 
     def frame_pipelined(self, next_fc, run_ssgi=False):
         import torch

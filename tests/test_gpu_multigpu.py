@@ -239,3 +239,61 @@ def test_strip_plan_and_transfers():
                     assert so[0] <= a < b <= so[1]
                     got |= set(range(a, b))
             assert got == need
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,W,H", [(2, 256, 160), (3, 320, 208), (8, 192, 256)])
+def test_strip_split_sun_shadows_are_bit_exact(gpu, device, n_ranks, W, H):
+    """trace_sun_shadow_mask + ShadowDenoiseRenderer::render strip by strip (SURVEY 8f-2 under the screen-tile split): both orchestrators
+    (SplitRtdgi.shadow_frame, kj_split_shadow_frame) against the unsplit passes over frames with a moving camera -- on every rank's own rows the
+    mask, the denoised term and both histories of the denoiser bit for bit, and the rays traced add up to one per pixel; then light_gbuffer
+    on each rank's rows against the whole-frame combine."""
+    import torch
+    from kajiya_amd import multigpu, frame
+    desc = T._scenes()["city20k"]
+    scene = gpu.Scene(device, desc)
+    ref = gpu.GpuPipeline(device, scene, W, H, use_ircache=False)
+    py_pipes = {r: gpu.GpuPipeline(device, scene, W, H, use_ircache=False) for r in range(n_ranks)}
+    nat_pipes = {r: gpu.GpuPipeline(device, scene, W, H, use_ircache=False) for r in range(n_ranks)}
+    py = multigpu.SplitRtdgi(multigpu.LocalComm(n_ranks), py_pipes, W, H, motion_halo=8)
+    nat = multigpu.NativeSplit(n_ranks, nat_pipes, W, H, motion_halo=8)
+    fs = frame.FrameState((W, H))
+    fs.ircache_enabled = False
+    counters = {tag: {r: torch.zeros(1, dtype=torch.int64, device=ref.depth.device) for r in range(n_ranks)} for tag in ("python", "native")}
+    ref_counter = torch.zeros(1, dtype=torch.int64, device=ref.depth.device)
+    for fi in range(5):
+        fc = fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.02))
+        fs.retire_frame()
+        ref.render_inputs(fc); ref.reprojection()
+        mask = ref.sun_shadow_mask(ray_counter=ref_counter)
+        dn = ref.shadow_denoise(mask).view(torch.int16)
+        for pipes in (py_pipes, nat_pipes):
+            for r in range(n_ranks):
+                pipes[r].render_inputs(fc)
+                pipes[r].reprojection()
+        outs = {"python": py.shadow_frame(ray_counters=counters["python"]), "native": nat.shadow_frame(ray_counters=counters["native"])}
+        torch.cuda.synchronize()
+        for tag, pipes in (("python", py_pipes), ("native", nat_pipes)):
+            for r in range(n_ranks):
+                a, b = py.strips[r]
+                assert torch.equal(mask[a:b], pipes[r].shadow_mask_img[a:b]), f"frame {fi} rank {r} ({tag}): mask differs"
+                got = outs[tag][r].view(torch.int16)
+                neq = (dn[a:b] != got[a:b]).any(dim=-1)
+                assert not bool(neq.any()), f"frame {fi} rank {r} ({tag}): {int(neq.sum())} denoised texels differ (rows {(torch.nonzero(neq.any(dim=1)).flatten()[:8] + a).tolist()})"
+                for name, words in (("shadow_denoise_moments", 4), ("shadow_denoise_accum", 2)):
+                    x = ref.shadow_denoise_surface(f"{name}:{fi % 2}", torch.int16, (H, W, words))
+                    y = pipes[r].shadow_denoise_surface(f"{name}:{fi % 2}", torch.int16, (H, W, words))
+                    assert torch.equal(x[a:b], y[a:b]), f"frame {fi} rank {r} ({tag}): history {name} differs"
+    for tag in ("python", "native"):
+        assert sum(int(c.item()) for c in counters[tag].values()) == int(ref_counter.item()) > 0, tag       # every ray traced once across the ranks
+    # the deferred combine on a rank's rows (every input read at the pixel itself) against the whole frame
+    ref.gi_frame()
+    dn2 = ref.shadow_denoise(mask)
+    whole2 = [t.clone() for t in ref.light_gbuffer(dn2)]
+    for t in ref._lit:
+        t.zero_()
+    for a, b in py.strips:
+        ref.light_gbuffer(dn2, rows=(a, b))
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(whole2[k].view(torch.int16), ref._lit[k].view(torch.int16)), "light_gbuffer strip by strip differs from the whole-frame combine"

@@ -86,6 +86,10 @@ def _worker(rank, world, port, W, H, frames, packed, q, with_ircache=False, with
             split.gi_frame()
             split.taa_frame()
             ref.taa_frame()
+            if with_ssgi:      # (the cases with the guide also carry the sun shadows: mask + denoiser strip by strip, two more exchanges)
+                dn = ref.shadow_denoise(ref.sun_shadow_mask()).view(torch.int16)
+                a0, b0 = split.strips[rank]
+                worst = max(worst, int((dn[a0:b0] != split.shadow_frame()[rank].view(torch.int16)[a0:b0]).sum()))
             split.gather_output("spatial_filtered_tex")
             split.gather_output(f"TAA/taa:{fi % 2}")
             a, b = ref.surface("spatial_filtered_tex", torch.int16, (H, W, 4)), pipe.surface("spatial_filtered_tex", torch.int16, (H, W, 4))
