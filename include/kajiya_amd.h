@@ -204,6 +204,13 @@ KjStatus kj_scene_set_blas_build_mode(KjScene* scene, uint32_t mode);
  * largest nodes of the instances' top levels become the leaves (opened greedily by world-space surface area, 4 per instance slot on average):
  * large instances that overlap many others -- a terrain -- stop being one box around everything. Same hits either way. */
 KjStatus kj_scene_set_open_instances(KjScene* scene, uint32_t enable);
+/* Who builds the per-commit top tree (the TLAS build of WorldRenderer::build_ray_tracing_top_level_acceleration, world_renderer.rs:836-911): the host
+ * (binned SAH: the better tree, 0.08 ms at 64 instances but 10 ms at 8 k) or the device (a linear BVH over the instances' world boxes, for scenes whose
+ * instance count makes the host build the cost of a per-frame commit). KJ_TOP_BUILD_AUTO: the host below 4096 top-tree leaves, the device from there on. */
+enum { KJ_TOP_BUILD_AUTO = 0u, KJ_TOP_BUILD_HOST = 1u, KJ_TOP_BUILD_DEVICE = 2u };
+KjStatus kj_scene_set_top_build_mode(KjScene* scene, uint32_t mode);
+/* The last commit's top tree: its nodes, the reservation at the head of the world node array, and who built it (1 = the device). */
+KjStatus kj_scene_top_tree_info(KjScene* scene, uint32_t* out_nodes, uint32_t* out_capacity, uint32_t* out_built_on_device);
 
 /* Baked assets (`bin/bake` output, kajiya-asset-pipe/src/lib.rs:38-60): zero-copy, bounds-checked views of
  * `cache/<name>.mesh` (PackedTriMesh::Flat, kajiya-asset/src/mesh.rs:796-807) and `cache/<identity:08x>.image`

@@ -55,6 +55,8 @@ struct DevBuf {
     }
 };
 
+struct LbvhScratch;     // kj_scene_device.hpp
+
 } // namespace kj
 
 struct KjDevice {
@@ -90,6 +92,10 @@ struct KjScene {
     std::vector<std::vector<BlasTopNode>> blas_top;   // one list per mesh, [0] = the root
     bool open_instances = false;                  // kj_scene_set_open_instances / KJ_SCENE_OPEN_INSTANCES=1: top-tree leaves are nodes of the instances' top levels instead of whole instances
     uint32_t blas_nodes_used = 0, obj_tris_used = 0;   // fill of the two device pools every BLAS lives in (d_blas_nodes, d_obj_tris)
+    uint32_t top_build_mode = 0;                  // kj_scene_set_top_build_mode: 0 = host SAH below KJ_TOP_DEVICE_MIN_LEAVES leaves and a device LBVH from there on, 1 = host, 2 = device
+    bool top_built_on_device = false;             // how the last commit built it (kj_scene_stats)
+    kj::DevBuf d_top_boxes, d_top_refs;           // the device build's inputs
+    kj::LbvhScratch* top_scratch = nullptr;       // ... and its working set, kept across commits
     uint32_t blas_build_mode = 0;                 // for meshes added from now on: 0 = SAH on the host (fast trace), 1 = LBVH on the device (fast build), 2 = PLOC on the device
     std::vector<uint8_t> mesh_build_mode;         // per mesh
     // what changed since the last commit

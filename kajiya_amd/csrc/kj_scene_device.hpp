@@ -34,4 +34,9 @@ struct LbvhResult { static constexpr size_t HEAD_NODES = 341; float bounds[6]; u
 struct LbvhScratch { static constexpr int BUFFERS = 14; DevBuf buf[BUFFERS], tmp, queue_len, level_nodes; uint32_t capacity = 0; };   // the build's working set, reused across meshes
 hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s, bool ploc);   // ploc: hierarchy by agglomerative clustering instead of Morton-code splits
 
+// The per-commit top tree built on the device: a linear BVH over the leaves' padded world boxes (six floats each: min xyz, max xyz), every leaf holding one
+// box and becoming the child reference d_leaf_refs[i] (the world node the leaf stands for). For commits with thousands of instances, where the host's SAH
+// build of the top tree is what a per-frame commit costs (profiles/r03_top_tree_build.md). Nodes into d_nodes_out[0 .. node_count); one synchronisation.
+hipError_t build_top_lbvh_device(const float* d_leaf_boxes, const uint32_t* d_leaf_refs, uint32_t leaf_count, Bvh4Node* d_nodes_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s);
+
 }  // namespace kj

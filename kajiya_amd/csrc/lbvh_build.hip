@@ -60,6 +60,14 @@ __global__ void __launch_bounds__(256) k_lbvh_prims(const uint8_t* __restrict__ 
     pbox[i] = b;
     for (int k = 0; k < 3; ++k) { atomicMin(&ob[k], f2o(b.mn[k])); atomicMax(&ob[3 + k], f2o(b.mx[k])); }
 }
+// the top tree's primitives: boxes given as they are (the padded world boxes of the instances' root or opened nodes)
+__global__ void __launch_bounds__(256) k_lbvh_prims_boxes(const Box6* __restrict__ boxes, uint32_t n, Box6* __restrict__ pbox, uint32_t* __restrict__ ob) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Box6 b = boxes[i];
+    pbox[i] = b;
+    for (int k = 0; k < 3; ++k) { atomicMin(&ob[k], f2o(b.mn[k])); atomicMax(&ob[3 + k], f2o(b.mx[k])); }
+}
 // 21 bits per axis -> every third bit of a 63-bit code. (Round 2 used 10 bits per axis: in a 250 k-triangle mesh whole neighbourhoods
 // share one 30-bit code, and triangles with equal codes are split by their POSITION in the sorted array, i.e. arbitrarily in space.)
 typedef unsigned long long MortonCode;
@@ -179,11 +187,13 @@ struct CollapseItem { uint32_t bin, out, depth; };
 // level with a grid that is large enough by construction (<= 4^level items, <= one per triangle) and reads nothing back in between.
 __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __restrict__ children, const uint2* __restrict__ range, const Box6* __restrict__ nbox, const CollapseItem* __restrict__ in,
                                                        uint32_t* __restrict__ queue_len, uint32_t level, CollapseItem* __restrict__ out, uint32_t* __restrict__ counters /*[1]=nodes, [2]=max depth*/,
-                                                       Bvh4Node* __restrict__ nodes, uint32_t node_base, uint32_t* __restrict__ level_nodes, uint32_t* __restrict__ level_done) {
+                                                       Bvh4Node* __restrict__ nodes, uint32_t node_base, uint32_t* __restrict__ level_nodes, uint32_t* __restrict__ level_done,
+                                                       uint32_t max_leaf, const uint32_t* __restrict__ leaf_refs, const uint32_t* __restrict__ sorted_ids) {
+    // leaf_refs (the top tree): every leaf holds ONE primitive and becomes the child reference leaf_refs[primitive] -- a node of an instance's tree -- as it is
     const uint32_t in_count = queue_len[level];
     for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < in_count; w += gridDim.x * 64) {
     const CollapseItem it = in[w];
-    auto is_leaf = [&](uint32_t id) { return id >= uint32_t(n - 1) || range[id].y - range[id].x + 1u <= KJ_BVH_MAX_LEAF_TRIS; };
+    auto is_leaf = [&](uint32_t id) { return id >= uint32_t(n - 1) || range[id].y - range[id].x + 1u <= max_leaf; };
     uint32_t ch[4]; int nch = 0;
     if (n == 1 || is_leaf(it.bin)) ch[nch++] = n == 1 ? 0u : it.bin;    // whole mesh fits one leaf
     else { const uint2 c = children[it.bin]; ch[nch++] = c.x; ch[nch++] = c.y; }
@@ -209,11 +219,11 @@ __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __rest
             continue;
         }
         quantise_child(node, scale, i, cb[i]);
-        if (n == 1) node.child[i] = KJ_BVH_LEAF;
+        if (n == 1) node.child[i] = leaf_refs ? leaf_refs[0] : KJ_BVH_LEAF;
         else if (is_leaf(ch[i])) {
             const uint32_t first = ch[i] >= uint32_t(n - 1) ? ch[i] - uint32_t(n - 1) : range[ch[i]].x;
             const uint32_t cnt = ch[i] >= uint32_t(n - 1) ? 1u : range[ch[i]].y - range[ch[i]].x + 1u;
-            node.child[i] = KJ_BVH_LEAF | ((cnt - 1u) << 28) | first;
+            node.child[i] = leaf_refs ? leaf_refs[sorted_ids[first]] : (KJ_BVH_LEAF | ((cnt - 1u) << 28) | first);
         } else {
             const uint32_t o = atomicAdd(&counters[1], 1u);
             node.child[i] = node_base + o;
@@ -537,9 +547,11 @@ __global__ void __launch_bounds__(64) k_ploc_collapse(uint32_t n, const uint2* _
 namespace kj {
 
 #define KJ_LB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
-hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s, bool ploc) {
-    const uint32_t n = mesh.index_count / 3;
+// One builder, two kinds of primitives: a mesh's triangles (d_boxes == nullptr) or given boxes with a child reference each (the top tree: leaves of one)
+static hipError_t build_lbvh(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, const Box6* d_boxes, const uint32_t* d_leaf_refs, uint32_t n, uint32_t node_base, Bvh4Node* d_nodes_out,
+                             BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s, bool ploc) {
     if (n == 0 || !scratch) return hipErrorInvalidValue;
+    const bool top = d_boxes != nullptr;
     // working set: 15 device buffers, kept by the caller across the meshes of a commit (allocating and freeing them per mesh cost a
     // third of a nine-mesh build: hipFree synchronises the device) and grown when a larger mesh comes along
     if (scratch->capacity < n) {
@@ -576,7 +588,8 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
     KJ_LB(hipMemsetAsync(visits, 0, size_t(n) * 4, s));      // the refit's arrival counters
     const dim3 g((n + 255) / 256), b(256);
     hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, ob);
-    hipLaunchKernelGGL(k_lbvh_prims, g, b, 0, s, d_vertex_buffer, mesh, n, pbox, ob);
+    if (top) hipLaunchKernelGGL(k_lbvh_prims_boxes, g, b, 0, s, d_boxes, n, pbox, ob);
+    else hipLaunchKernelGGL(k_lbvh_prims, g, b, 0, s, d_vertex_buffer, mesh, n, pbox, ob);
     hipLaunchKernelGGL(k_lbvh_morton, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ob, n, codes, ids);
     size_t tmp_bytes = 0;
     KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const MortonCode*)codes, codes2, (const uint32_t*)ids, ids2, int(n), 0, 3 * KJ_MORTON_BITS, s));
@@ -622,7 +635,7 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
         if (ploc) hipLaunchKernelGGL(k_ploc_collapse, cg, dim3(64), 0, s, n, (const uint2*)children, (const uint32_t*)cnt, (const Box6*)nbox, (const uint32_t*)ids2, (const PlocItem*)in, queue_len, level,
                                      (PlocItem*)out, counters, d_nodes_out, node_base, tri_order, level_nodes, level_done);
         else hipLaunchKernelGGL(k_lbvh_collapse, cg, dim3(64), 0, s, int(n), (const uint2*)children, (const uint2*)range, (const Box6*)nbox, (const CollapseItem*)in, queue_len, level, (CollapseItem*)out,
-                                counters, d_nodes_out, node_base, level_nodes, level_done);
+                                counters, d_nodes_out, node_base, level_nodes, level_done, top ? 1u : uint32_t(KJ_BVH_MAX_LEAF_TRIS), d_leaf_refs, (const uint32_t*)ids2);
     };
     KJ_LB(hipMemcpyAsync(counters, init_counters, 16, hipMemcpyHostToDevice, s));
     if (ploc) {
@@ -631,7 +644,7 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
     } else KJ_LB(hipMemcpyAsync(q0, &root, sizeof(root), hipMemcpyHostToDevice, s));
     uint32_t host_counters[4] = {0, 1, 0, 0}, host_levels[KJ_LBVH_BATCH + 2], host_queue[KJ_LBVH_BATCH + 2], hob[8];
     result->level_starts.assign({0u});
-    result->head.resize(std::min<size_t>(size_t(n) + 1, LbvhResult::HEAD_NODES));
+    result->head.resize(top ? 0 : std::min<size_t>(size_t(n) + 1, LbvhResult::HEAD_NODES));
     uint64_t bound = 1;
     uint32_t in_count = 1u, nodes_before = 1u;      // level 0 = the root = node 0
     while (in_count) {
@@ -646,12 +659,12 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
         }
         // everything else the caller needs rides the same read-back: a tree that fits one batch (every mesh so far) costs ONE synchronisation.
         // (The triangles in leaf order: PLOC's order is written by the collapse; if the tree turns out deeper, the last batch emits them again.)
-        hipLaunchKernelGGL(k_lbvh_emit_tris, g, b, 0, s, d_vertex_buffer, mesh, ploc ? (const uint32_t*)tri_order : (const uint32_t*)ids2, n, d_tris_out);
+        if (!top) hipLaunchKernelGGL(k_lbvh_emit_tris, g, b, 0, s, d_vertex_buffer, mesh, ploc ? (const uint32_t*)tri_order : (const uint32_t*)ids2, n, d_tris_out);
         KJ_LB(hipMemcpyAsync(host_levels, level_nodes, sizeof(host_levels), hipMemcpyDeviceToHost, s));
         KJ_LB(hipMemcpyAsync(host_queue, queue_len, sizeof(host_queue), hipMemcpyDeviceToHost, s));
         KJ_LB(hipMemcpyAsync(host_counters, counters, 16, hipMemcpyDeviceToHost, s));
         KJ_LB(hipMemcpyAsync(hob, ob, 24, hipMemcpyDeviceToHost, s));
-        KJ_LB(hipMemcpyAsync(result->head.data(), d_nodes_out, result->head.size() * sizeof(Bvh4Node), hipMemcpyDeviceToHost, s));      // the top levels, for the caller's top-tree build
+        if (!result->head.empty()) KJ_LB(hipMemcpyAsync(result->head.data(), d_nodes_out, result->head.size() * sizeof(Bvh4Node), hipMemcpyDeviceToHost, s));      // the top levels, for the caller's top-tree build
         KJ_LB(hipStreamSynchronize(s));
         for (uint32_t l = 1; l <= KJ_LBVH_BATCH + 1; ++l)
             if (host_levels[l] > result->level_starts.back()) result->level_starts.push_back(host_levels[l]);
@@ -669,6 +682,16 @@ hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh&
     result->node_count = host_counters[1];
     result->max_stack = host_counters[2] > 0 ? host_counters[2] : 1;
     return hipSuccess;
+}
+hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s, bool ploc) {
+    return build_lbvh(d_vertex_buffer, mesh, nullptr, nullptr, mesh.index_count / 3, node_base, d_nodes_out, d_tris_out, result, scratch, s, ploc);
+}
+// The per-commit top tree as a linear BVH over the leaves' world boxes (kj_scene_device.hpp): d_leaf_boxes[i] = {min xyz, max xyz}, d_leaf_refs[i] = the world
+// node that leaf stands for. Nodes into d_nodes_out[0 .. node_count), node_count < max(leaf_count, 2). One synchronisation.
+hipError_t build_top_lbvh_device(const float* d_leaf_boxes, const uint32_t* d_leaf_refs, uint32_t leaf_count, Bvh4Node* d_nodes_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s) {
+    static_assert(sizeof(Box6) == 24, "a box is six floats");
+    if (!d_leaf_boxes || !d_leaf_refs) return hipErrorInvalidValue;
+    return build_lbvh(nullptr, GpuMesh{}, (const Box6*)d_leaf_boxes, d_leaf_refs, leaf_count, 0u, d_nodes_out, nullptr, result, scratch, s, false);
 }
 
 }  // namespace kj

@@ -75,7 +75,10 @@ KjStatus kj_scene_create(KjDevice* dev, KjScene** out) {
     *out = s;
     return KJ_OK;
 }
-void kj_scene_destroy(KjScene* scene) { delete scene; }
+void kj_scene_destroy(KjScene* scene) {
+    if (scene) delete scene->top_scratch;
+    delete scene;
+}
 
 KjStatus kj_scene_add_mesh(KjScene* s, const KjMeshDesc* d, uint32_t* out_mesh) {
     KJ_REQUIRE(s && d && out_mesh, "null argument");
@@ -204,6 +207,8 @@ KjStatus kj_scene_remove_instance(KjScene* s, uint32_t instance) {
 
 // nodes of a BLAS' top levels kept on the host for the top-tree build (root + up to four levels below it)
 #define KJ_BLAS_TOP_NODES 341u
+// from this many top-tree leaves on, the commit builds the top tree on the device (kj_scene_set_top_build_mode overrides)
+#define KJ_TOP_DEVICE_MIN_LEAVES 4096u
 
 // world box of an object-space box under a 3x4 transform (all eight corners), padded for fp32 rounding
 static void world_box(const float* x, const float* ob, float* wb) {
@@ -443,6 +448,12 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     // depends on the number of instance slots only, so the reservation (and with it the layout of the world arrays) is stable across commits.
     // Built, measured (200 k-triangle city, instrumented trace pass: 16.3 -> 16.0 node visits per closest-hit ray, 15.0 -> 15.2 per shadow ray --
     // the terrain's top levels move into a top tree that is one level deeper for it) and therefore NOT the default: kj_scene_set_open_instances.
+    // Who builds the top tree: the host (binned SAH, the better tree) while that is cheap, the device (a linear BVH over the same boxes) once the host's
+    // build would be what a per-frame commit costs -- 1.1 ms at 1 k leaves, 10 ms at 8 k, 46 ms at 32 k against 0.1 ms for the refit of a moved
+    // instance (profiles/r03_top_tree_build.md). kj_scene_set_top_build_mode / KJ_SCENE_TOP_BUILD: 0 = by leaf count, 1 = host, 2 = device.
+    static const int top_env = getenv("KJ_SCENE_TOP_BUILD") ? atoi(getenv("KJ_SCENE_TOP_BUILD")) : -1;
+    const uint32_t top_mode = top_env >= 0 && top_env <= 2 ? uint32_t(top_env) : s->top_build_mode;
+    auto device_top_wanted = [&](uint32_t leaves) { return top_mode == 2u || (top_mode == 0u && leaves >= KJ_TOP_DEVICE_MIN_LEAVES); };
     static const bool open_env = getenv("KJ_SCENE_OPEN_INSTANCES") && atoi(getenv("KJ_SCENE_OPEN_INSTANCES")) != 0;
     const bool open_instances = s->open_instances || open_env;
     const uint32_t top_budget = open_instances ? std::min(4096u, 4u * ni + 16u) : ni;
@@ -497,6 +508,9 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         auto smaller = [](const TopLeaf& a, const TopLeaf& b) { return a.area != b.area ? a.area < b.area : (a.inst != b.inst ? a.inst > b.inst : a.top > b.top); };
         for (TopLeaf& t : top_open) place(t);
         uint32_t leaves = uint32_t(top_open.size());
+        // nothing to open and a device build ahead (it orders the leaves itself, by Morton code): the leaves are the instances as they come -- the
+        // largest-first order below only matters to the host's builder, and popping a heap of n entries is a third of what is left of this stage
+        if (!open_instances && device_top_wanted(leaves)) { top_leaves.swap(top_open); }
         std::make_heap(top_open.begin(), top_open.end(), smaller);
         while (!top_open.empty()) {
             std::pop_heap(top_open.begin(), top_open.end(), smaller);
@@ -519,6 +533,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
             tlas_prims.push_back(t);
         }
     }
+    const bool device_top = !tlas_prims.empty() && device_top_wanted(uint32_t(tlas_prims.size()));
     s->live_tri_count = total_tris;                                                      // what kj_scene_stats reports: triangles a ray can hit
     if (keep_layout) { total_tris = s->tri_count; total_nodes = s->world_nodes; }      // array sizes as laid out, holes included
     KJ_REQUIRE(total_tris > 0, "scene has no triangles");
@@ -532,7 +547,7 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         for (int k = 0; k < 3; ++k) n.exp8[k] = 127;
         tl.nodes.push_back(n);
         tl.max_stack = 1;
-    } else {
+    } else if (!device_top) {
         build_bvh4(tlas_prims, tl, 1);
         for (BvhNode& n : tl.nodes)
             for (int i = 0; i < 4; ++i)
@@ -541,8 +556,11 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
                     n.child[i] = node_base[t.inst] + s->blas_top[s->instances[t.inst].mesh][t.top].node;
                 }
     }
-    KJ_REQUIRE(tl.nodes.size() <= tlas_capacity, "top tree larger than its reservation");
-    KJ_REQUIRE(tl.max_stack + 1 + max_blas_stack <= KJ_BVH_LDS_STACK + KJ_BVH_SPILL_STACK, "BVH too deep for the traversal stack");
+    uint32_t top_node_count = uint32_t(tl.nodes.size()), top_max_stack = tl.max_stack;      // (the device build reports its own below)
+    if (!device_top) {
+        KJ_REQUIRE(top_node_count <= tlas_capacity, "top tree larger than its reservation");
+        KJ_REQUIRE(top_max_stack + 1 + max_blas_stack <= KJ_BVH_LDS_STACK + KJ_BVH_SPILL_STACK, "BVH too deep for the traversal stack");
+    }
     s->last_commit_ms[1] = ms_since(t1);
     const auto t2 = Clock::now();
     // 4. per-commit tables
@@ -558,7 +576,26 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         KJ_TRY_HIP(s->d_nodes.alloc(size_t(total_nodes) * sizeof(BvhNode), stream));
         KJ_TRY_HIP(s->d_node_boxes.alloc(size_t(total_nodes) * 24, stream));
     }
-    KJ_TRY_HIP(hipMemcpyAsync(s->d_nodes.p, tl.nodes.data(), tl.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, stream));
+    if (device_top) {
+        // the same leaves the host build would have been given -- box and the world node each stands for -- as two small uploads; nodes straight into the
+        // world array's reservation. The builder's working set stays with the scene (a per-frame commit must not allocate).
+        std::vector<float> boxes(tlas_prims.size() * 6);
+        std::vector<uint32_t> refs(tlas_prims.size());
+        for (size_t j = 0; j < tlas_prims.size(); ++j) {
+            for (int k = 0; k < 3; ++k) { boxes[j * 6 + k] = tlas_prims[j].v0[k]; boxes[j * 6 + 3 + k] = tlas_prims[j].v1[k]; }
+            refs[j] = node_base[top_leaves[j].inst] + s->blas_top[s->instances[top_leaves[j].inst].mesh][top_leaves[j].top].node;
+        }
+        if (s->d_top_boxes.bytes < boxes.size() * 4) { KJ_TRY_HIP(s->d_top_boxes.alloc(boxes.size() * 4 + boxes.size(), stream)); KJ_TRY_HIP(s->d_top_refs.alloc(refs.size() * 4 + refs.size(), stream)); }
+        KJ_TRY_HIP(hipMemcpyAsync(s->d_top_boxes.p, boxes.data(), boxes.size() * 4, hipMemcpyHostToDevice, stream));
+        KJ_TRY_HIP(hipMemcpyAsync(s->d_top_refs.p, refs.data(), refs.size() * 4, hipMemcpyHostToDevice, stream));
+        if (!s->top_scratch) s->top_scratch = new LbvhScratch();
+        LbvhResult tr;
+        KJ_TRY_HIP(build_top_lbvh_device((const float*)s->d_top_boxes.p, (const uint32_t*)s->d_top_refs.p, uint32_t(refs.size()), (Bvh4Node*)s->d_nodes.p, &tr, s->top_scratch, stream));
+        top_node_count = tr.node_count; top_max_stack = tr.max_stack;
+        KJ_REQUIRE(top_node_count <= tlas_capacity, "top tree larger than its reservation");
+        KJ_REQUIRE(top_max_stack + 1 + max_blas_stack <= KJ_BVH_LDS_STACK + KJ_BVH_SPILL_STACK, "BVH too deep for the traversal stack");
+    } else
+        KJ_TRY_HIP(hipMemcpyAsync(s->d_nodes.p, tl.nodes.data(), tl.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, stream));
     std::vector<InstanceTriJob> jobs, renumber;
     std::vector<InstanceRefitJob> refits;
     uint32_t max_wide = 0;
@@ -596,9 +633,10 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     s->tri_count = total_tris;
     s->node_count = total_nodes;
     s->world_nodes = total_nodes; s->tlas_capacity = tlas_capacity;
-    s->tlas_node_count = uint32_t(tl.nodes.size());
+    s->tlas_node_count = top_node_count;
+    s->top_built_on_device = device_top;
     s->bvh_root = 0;
-    s->bvh_max_depth = tl.max_stack + 1 + max_blas_stack;
+    s->bvh_max_depth = top_max_stack + 1 + max_blas_stack;
     s->light_count = light_count;
     s->meshes_dirty = false; s->instance_set_dirty = false; s->instances_added = false; s->committed_once = true;
     std::fill(s->xform_dirty.begin(), s->xform_dirty.end(), uint8_t(0));
@@ -610,6 +648,17 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
 KjStatus kj_scene_set_open_instances(KjScene* s, uint32_t enable) {
     KJ_REQUIRE(s, "null scene");
     if (s->open_instances != (enable != 0)) { s->open_instances = enable != 0; s->instance_set_dirty = true; s->instances_added = true; s->committed = false; }   // the reservation changes: lay out anew
+    return KJ_OK;
+}
+KjStatus kj_scene_set_top_build_mode(KjScene* s, uint32_t mode) {
+    KJ_REQUIRE(s && mode <= 2, "mode must be KJ_TOP_BUILD_AUTO (0), KJ_TOP_BUILD_HOST (1) or KJ_TOP_BUILD_DEVICE (2)");
+    if (s->top_build_mode != mode) { s->top_build_mode = mode; s->instance_set_dirty = true; s->committed = false; }     // the next commit builds the top tree the new way
+    return KJ_OK;
+}
+KjStatus kj_scene_top_tree_info(KjScene* s, uint32_t* out_nodes, uint32_t* out_capacity, uint32_t* out_built_on_device) {
+    KJ_REQUIRE(s && out_nodes && out_capacity && out_built_on_device, "null argument");
+    if (!s->committed) { set_last_error("scene not committed"); return KJ_ERR_NOT_COMMITTED; }
+    *out_nodes = s->tlas_node_count; *out_capacity = s->tlas_capacity; *out_built_on_device = s->top_built_on_device ? 1u : 0u;
     return KJ_OK;
 }
 KjStatus kj_scene_set_blas_build_mode(KjScene* s, uint32_t mode) {

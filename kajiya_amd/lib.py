@@ -19,7 +19,7 @@ EXPORTS = [
     "kj_last_error", "kj_abi_version", "kj_device_create", "kj_device_destroy", "kj_device_brdf_lut",
     "kj_scene_create", "kj_scene_destroy", "kj_scene_add_mesh", "kj_scene_add_instance", "kj_scene_set_instance_transform",
     "kj_scene_set_instance_emissive_multiplier", "kj_scene_remove_instance", "kj_scene_commit", "kj_scene_triangle_light_count",
-    "kj_scene_stats", "kj_scene_last_commit_ms", "kj_scene_set_blas_build_mode", "kj_scene_set_open_instances", "kj_frame_begin", "kj_trace_closest", "kj_trace_any", "kj_debug_calibration_copy", "kj_raster_gbuffer", "kj_sky_cube_render",
+    "kj_scene_stats", "kj_scene_last_commit_ms", "kj_scene_set_blas_build_mode", "kj_scene_set_open_instances", "kj_scene_set_top_build_mode", "kj_scene_top_tree_info", "kj_frame_begin", "kj_trace_closest", "kj_trace_any", "kj_debug_calibration_copy", "kj_raster_gbuffer", "kj_sky_cube_render",
     "kj_sky_cube_convolve", "kj_reprojection_create", "kj_reprojection_destroy", "kj_calculate_reprojection_map",
     "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_reproject_rows", "kj_rtdgi_render",
     "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_set_ray_pass_form", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
@@ -83,6 +83,8 @@ def load():
         "kj_ircache_apply_requests": [vp, vp, u32, vp],
         "kj_scene_set_blas_build_mode": [vp, u32],
         "kj_scene_set_open_instances": [vp, u32],
+        "kj_scene_set_top_build_mode": [vp, u32],
+        "kj_scene_top_tree_info": [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)],
         "kj_raster_gbuffer": [vp, vp, u32, u32, vp, vp, vp, vp, vp],
         "kj_sky_cube_render": [vp, vp, vp],
         "kj_sky_cube_convolve": [vp, vp, vp, vp],
@@ -203,11 +205,13 @@ class Device:
 class Scene:
     """WorldRenderer scene state: add_mesh / add_instance / commit (builds the software LBVH)."""
 
-    def __init__(self, dev: Device, desc: kscenes.SceneDesc = None, use_lights=False, fast_build=False, open_instances=False):
+    def __init__(self, dev: Device, desc: kscenes.SceneDesc = None, use_lights=False, fast_build=False, open_instances=False, top_build=None):
         L = load()
         self.dev = dev
         self.h = C.c_void_p()
         check(L.kj_scene_create(dev.h, C.byref(self.h)))
+        if top_build is not None:   # who builds the per-commit top tree: "host" / 1, "device" / 2 (default: the host below 4096 leaves, the device from there on)
+            check(L.kj_scene_set_top_build_mode(self.h, {"auto": 0, "host": 1, "device": 2}.get(top_build, top_build)))
         if open_instances:  # top-tree leaves = nodes of the instances' top levels instead of whole instances
             check(L.kj_scene_set_open_instances(self.h, 1))
         if fast_build:      # BLASes built on the device instead of SAH trees built on the host: True / 1 = LBVH, "ploc" / 2 = PLOC
@@ -239,6 +243,12 @@ class Scene:
     def set_instance_transform(self, instance, xform3x4):
         xf = np.ascontiguousarray(xform3x4, np.float32)
         check(load().kj_scene_set_instance_transform(self.h, instance, xf.ctypes.data))
+
+    def top_tree_info(self):
+        """{nodes, capacity, device}: the last commit's top tree and who built it."""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(load().kj_scene_top_tree_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"nodes": a.value, "capacity": b.value, "device": bool(c.value)}
 
     def last_commit_ms(self):
         """[BLAS builds, instance records + TLAS, uploads + device transform, total] of the last commit, host ms."""

@@ -474,7 +474,7 @@ def _blob(rng, n_tris, size=1.0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fast_build", [False, True, "ploc", "open"])
+@pytest.mark.parametrize("fast_build", [False, True, "ploc", "open", "device_top", "open+device_top"])
 def test_instance_trees_under_rotation_mirroring_and_repeated_edits(gpu, oracle, device, fast_build):
     """The per-instance world-space trees (scene_device.hip: refit by node height, four lanes per node) at their corners: meshes of
     1, 4, 5, 17 and 1300 triangles (one-node trees, one refit step, several steps, a step wider than one workgroup pass), instances
@@ -482,7 +482,8 @@ def test_instance_trees_under_rotation_mirroring_and_repeated_edits(gpu, oracle,
     tree), 300 instances of the smallest meshes (a deeper top tree), then three rounds of edits -- move everything, remove some,
     ADD new instances of old meshes and a new mesh -- each followed by a commit. Ray queries stay bit-exact against an oracle scene
     built from scratch in the edited state every time. `fast_build`: every BLAS built on the device (LBVH, or PLOC: the refit walks
-    depth levels instead of node heights)."""
+    depth levels instead of node heights). "device_top": the per-commit top tree built on the device as a linear BVH over the instances' world boxes
+    (kj_scene_set_top_build_mode; what commits with thousands of instances switch to by themselves), also over opened instances."""
     import os
     import torch
     from kajiya_amd import scenes
@@ -505,8 +506,9 @@ def test_instance_trees_under_rotation_mirroring_and_repeated_edits(gpu, oracle,
     for k in range(300):
         live.append((int(rng.randint(0, 4)) if k % 50 else 4, random_xform(k)))
         desc.add_instance(*live[-1])
-    open_instances = fast_build == "open"     # host-built BLASes; top-tree leaves = nodes of the instances' top levels (kj_scene_set_open_instances)
-    gsc = gpu.Scene(device, desc, fast_build=False if open_instances else fast_build, open_instances=open_instances)
+    open_instances = "open" in str(fast_build)     # host-built BLASes; top-tree leaves = nodes of the instances' top levels (kj_scene_set_open_instances)
+    device_top = "device_top" in str(fast_build)
+    gsc = gpu.Scene(device, desc, fast_build=False if (open_instances or device_top) else fast_build, open_instances=open_instances, top_build="device" if device_top else None)
 
     def check(tag):
         cur = scenes.SceneDesc()
@@ -517,6 +519,7 @@ def test_instance_trees_under_rotation_mirroring_and_repeated_edits(gpu, oracle,
                 cur.add_instance(*e)
         osc = oracle.OracleScene(cur)
         assert gsc.stats()["triangles"] == osc.triangle_count, tag
+        assert gsc.top_tree_info()["device"] is device_top, tag
         lo, hi = cur.bounds()
         rays = _random_rays(rng, 40_000, lo.astype(np.float32), hi.astype(np.float32))
         # half of them aimed at an instance (the scene is sparse: uniformly random rays mostly miss)
@@ -622,3 +625,54 @@ def test_light_gbuffer(gpu, oracle, device, mode):
     sky = op.depth == 0
     if sky.any():
         assert np.isfinite(ref_o[sky].astype(np.float32)).all()
+
+
+@pytest.mark.gpu
+def test_thousands_of_instances_get_a_device_built_top_tree(gpu, oracle, device):
+    """A commit with 5000 instances (more than KJ_TOP_DEVICE_MIN_LEAVES) builds its top tree on the device without being told to -- the host's SAH build
+    would cost ~6 ms per commit there -- and ray queries stay bit-exact against the oracle, also after instances moved and a second commit rebuilt it."""
+    import torch
+    from kajiya_amd import scenes
+    rng = np.random.RandomState(7)
+    meshes = [_blob(rng, n) for n in (1, 3, 9)]
+    desc = scenes.SceneDesc()
+    for m in meshes:
+        desc.add_mesh(m)
+    live = []
+    for k in range(5000):
+        r = _rotation(rng.normal(size=3), rng.uniform(0, 2 * np.pi))
+        live.append((k % 3, scenes.affine(r, rng.uniform(3.0, 8.0), rng.uniform(-60, 60, 3))))
+        desc.add_instance(*live[-1])
+    gsc = gpu.Scene(device, desc)
+    L = gpu.load()
+
+    def check(tag):
+        cur = scenes.SceneDesc()
+        for m in meshes:
+            cur.add_mesh(m)
+        for e in live:
+            cur.add_instance(*e)
+        osc = oracle.OracleScene(cur)
+        info = gsc.top_tree_info()
+        assert info["device"] is True and 1 < info["nodes"] < info["capacity"] == 5000, (tag, info)
+        lo, hi = cur.bounds()
+        rays = _random_rays(rng, 30_000, lo.astype(np.float32), hi.astype(np.float32))
+        at = np.array([e[1][:, 3] for e in live], np.float32)[rng.randint(0, len(live), 20_000)]
+        d = at + rng.normal(scale=0.3, size=at.shape).astype(np.float32) - rays[:20_000, 0:3]
+        rays[:20_000, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True); rays[:20_000, 7] = 1e4
+        ref = osc.trace_closest(rays)
+        got = gsc.trace_closest(torch.from_numpy(rays).cuda(), len(rays)).cpu().numpy()
+        bad = (ref.view(np.uint32) != got.view(np.uint32)).any(axis=1)
+        assert not bad.any(), f"{tag}: {int(bad.sum())} of {len(rays)} rays differ"
+        assert (ref[:, 0] < 3e38).mean() > 0.03, tag
+        assert np.array_equal(osc.trace_any(rays), gsc.trace_any(torch.from_numpy(rays).cuda(), len(rays)).cpu().numpy()), tag
+    check("initial")
+    for slot in rng.randint(0, 5000, 400):
+        r = _rotation(rng.normal(size=3), rng.uniform(0, 2 * np.pi))
+        live[slot] = (live[slot][0], scenes.affine(r, rng.uniform(3.0, 8.0), rng.uniform(-60, 60, 3)))
+        gpu.check(L.kj_scene_set_instance_transform(gsc.h, int(slot), live[slot][1].ctypes.data))
+    gsc.commit()
+    check("after moving 400 instances")
+    gpu.check(L.kj_scene_set_top_build_mode(gsc.h, 1))      # ... and back on the host when told to
+    gsc.commit()
+    assert gsc.top_tree_info()["device"] is False
