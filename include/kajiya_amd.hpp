@@ -267,6 +267,7 @@ struct Scene {
     // how the BLAS of meshes added from now on is built (ray_tracing.rs:438 build flags): PREFER_FAST_TRACE = binned SAH on the host,
     // PREFER_FAST_BUILD = linear BVH on the device
     void set_blas_build_mode(uint32_t kj_blas_build_mode) { check(kj_scene_set_blas_build_mode(h, kj_blas_build_mode), "kj_scene_set_blas_build_mode"); }     // KJ_BLAS_BUILD_*
+    void set_top_build_mode(uint32_t kj_top_build_mode) { check(kj_scene_set_top_build_mode(h, kj_top_build_mode), "kj_scene_set_top_build_mode"); }           // KJ_TOP_BUILD_*: who builds the per-frame TLAS
     void set_blas_build_mode(bool prefer_fast_build) { check(kj_scene_set_blas_build_mode(h, prefer_fast_build ? KJ_BLAS_BUILD_FAST_BUILD : KJ_BLAS_BUILD_FAST_TRACE), "kj_scene_set_blas_build_mode"); }
     // host ms of the last build_ray_tracing_top_level_acceleration: {BLAS builds, instance tables + top tree, uploads + device refit, total}
     std::array<double, 4> last_commit_ms() const { std::array<double, 4> t{}; check(kj_scene_last_commit_ms(h, t.data()), "kj_scene_last_commit_ms"); return t; }
