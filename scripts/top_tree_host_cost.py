@@ -2,8 +2,10 @@
 that matter here are HOST milliseconds: stage [1] of kj_scene_last_commit_ms = instance records + top tree; kernels run on the CPU stand-in and their times
 mean nothing) or, on a GPU box, `python scripts/top_tree_host_cost.py` for the device build's real cost in stage [2]."""
 import json
+import os
 import sys
 import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from kajiya_amd import lib, scenes
 
 rng = np.random.default_rng(1)
