@@ -392,6 +392,10 @@ KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream);
 KjStatus kj_ircache_set_deferred_updates(KjIrcache* ircache, uint32_t enable);
 KjStatus kj_ircache_begin_requests(KjIrcache* ircache, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, void* stream);
 KjStatus kj_ircache_request_ranges(KjIrcache* ircache, uint32_t out_first_slot[4], uint32_t out_slot_count[4]);
+/* A frame with reflections (kj_rtr_trace bound to this cache) records the lookups of rtr's validate and trace rays too: two more slot ranges of one slot
+ * per half-res pixel behind the four above. Sticky; set before kj_ircache_begin_requests. kj_rtr_trace refuses a deferred cache without them. */
+KjStatus kj_ircache_set_rtr_requests(KjIrcache* ircache, uint32_t enable);
+KjStatus kj_ircache_rtr_request_ranges(KjIrcache* ircache, uint32_t out_first_slot[2], uint32_t out_slot_count[2]);
 KjStatus kj_ircache_collect_requests(KjIrcache* ircache, uint32_t first_slot, uint32_t slot_count, void* out_list /* device, 32 B each */, uint32_t out_capacity,
                                      void* out_count_dev /* device u32, incremented */, void* stream);
 KjStatus kj_ircache_apply_requests(KjIrcache* ircache, const void* list /* device */, uint32_t count, void* stream);
@@ -544,6 +548,8 @@ typedef struct KjRtrParams {
 #define KJ_RTR_PASS_TEMPORAL_FILTER 16u
 #define KJ_RTR_PASS_CLEANUP 32u
 #define KJ_RTR_PASS_ALL 63u
+#define KJ_RTR_PASS_EXTRACT_HALF 64u      /* kj_rtr_render_rows only (kj_rtr_trace always runs it): half-res view normal / depth of the whole frame */
+#define KJ_RTR_PASS_SPECULAR_LIGHTS 128u  /* kj_rtr_render_rows only: kj_rtr_render_specular_lights on the rows */
 #define KJ_RTR_PASS_KEEP 0x80000000u  /* tests: do not advance the ping-pong state (run one pass of an already started frame) */
 KjStatus kj_rtr_create(KjDevice* dev, const KjRtrTables* tables, KjRtr** out);
 void kj_rtr_destroy(KjRtr* r);
@@ -555,6 +561,11 @@ KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* params, void* stream);
  * (world_render_passes.rs:190-203). A no-op when the scene has no triangle lights, as in the reference. */
 KjStatus kj_rtr_render_specular_lights(KjRtr* r, const KjRtrParams* params, void* stream);
 KjStatus kj_rtr_filter_temporal(KjRtr* r, const KjRtrParams* params, const void** out_resolved_r11g11b10f, void* stream);
+/* The passes of params->pass_mask on full-res rows [row_begin, row_end) (cuts on 16-row boundaries; the ray passes, the reservoir pass and the specular
+ * lights run on the half-res rows underneath): the screen-tile split renders reflections strip by strip with it (kj_split_rtr_frame). A call without
+ * KJ_RTR_PASS_KEEP opens the frame (ping-pong flip, ray counters cleared); every later call of the frame carries it. What a pass reads beyond the rows
+ * (RtrRenderer has no notion of rows: rtr.rs:97-480) must be in place: DESIGN 7 lists the reach of every pass. */
+KjStatus kj_rtr_render_rows(KjRtr* r, const KjRtrParams* params, uint32_t row_begin, uint32_t row_end, const void** out_resolved_r11g11b10f, void* stream);
 KjStatus kj_rtr_surface(KjRtr* r, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 KjStatus kj_rtr_ray_counts(KjRtr* r, uint64_t* out_closest, uint64_t* out_any);
 
@@ -639,6 +650,18 @@ KjStatus kj_split_ssgi_frame(KjSplit* split, KjSsgi* const* ssgi, const KjSplitF
  * rank in every array; out_rg16f[i] is valid on rank i's own rows (what kj_light_gbuffer_rows reads); ray_counters_dev: NULL or optional device u64s. */
 KjStatus kj_split_shadow_frame(KjSplit* split, KjShadowDenoise* const* denoisers, const KjSplitFrame* frames, void* const* mask_r8, uint64_t* const* ray_counters_dev,
                                const void** out_rg16f, void* stream);
+/* Reflections of the frame strip by strip, after kj_split_gi_frame: RtrRenderer::trace + LightingRenderer::render_specular + TracedRtr::filter_temporal
+ * (renderers/rtr.rs:97-480, world_render_passes.rs:172-210) through kj_rtr_render_rows, with four exchange points: the all-gather of this frame's GI image (a
+ * reflection's hit reads it anywhere on screen), the reservoir histories' halos after the ray passes, the all-gather of the reservoir pass' outputs (the resolve's
+ * taps land where a world-space kernel projects to), the all-gather of the temporal filter's output (its own history next frame, read at the reflection's
+ * reprojected virtual position). kj_split_set_rtr(split, 1) comes first, once: the caches reserve slot ranges for the lookups of rtr's rays
+ * (kj_ircache_set_rtr_requests) and the replay of the frame's recorded cache updates moves from kj_split_gi_frame behind rtr's ray passes (here, or
+ * kj_split_merge_ircache with KJ_SPLIT_DEFER_IRCACHE_MERGE). `rtr`, `rtr_params`, `out_resolved_r11g11b10f`: one entry per LOCAL rank; rtr_params[i] as for
+ * kj_rtr_trace (pass_mask ignored); out_resolved_r11g11b10f (may be NULL) [i] is valid on rank i's own rows, which is all kj_light_gbuffer_rows reads. */
+enum { KJ_SPLIT_RTR_SPECULAR_LIGHTS = 1u };      /* with KJ_SPLIT_DEFER_IRCACHE_MERGE: the flags of kj_split_rtr_frame */
+KjStatus kj_split_set_rtr(KjSplit* split, uint32_t enable);
+KjStatus kj_split_rtr_frame(KjSplit* split, KjRtr* const* rtr, const KjRtrParams* rtr_params, uint32_t flags, void* trace_done_event, const void** out_resolved_r11g11b10f,
+                            void* stream);
 /* TAA on the GI output of the frame just rendered (exchange I + strip-wise TaaRenderer::render). */
 KjStatus kj_split_taa_frame(KjSplit* split, const KjSplitFrame* frames, void* stream);
 /* Every rank receives the owners' rows of a surface ("spatial_filtered_tex", "TAA/taa:0", ...): result collection. */

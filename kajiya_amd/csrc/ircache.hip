@@ -691,6 +691,7 @@ KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream_) 
 }
 // ---- deferred updates: begin (clear the frame's slots), collect (compact a slot range into a list), apply (replay a merged list)
 KjStatus kj_ircache_set_deferred_updates(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->deferred = enable != 0; return KJ_OK; }
+KjStatus kj_ircache_set_rtr_requests(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->rtr_requests = enable != 0; return KJ_OK; }
 KjStatus kj_ircache_begin_requests(KjIrcache* c, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, void* stream_) {
     KJ_REQUIRE(c && c->deferred, "deferred updates are off (kj_ircache_set_deferred_updates)");
     hipStream_t s = (hipStream_t)stream_;
@@ -706,6 +707,13 @@ KjStatus kj_ircache_request_ranges(KjIrcache* c, uint32_t out_first_slot[4], uin
     const uint32_t hb = c->req_half_pixels, e = KjIrcache::REQ_E;
     const uint32_t first[4] = {0u, hb, 2u * hb, 2u * hb + e}, count[4] = {hb, hb, e, e};
     for (int k = 0; k < 4; ++k) { out_first_slot[k] = first[k]; out_slot_count[k] = count[k]; }
+    return KJ_OK;
+}
+KjStatus kj_ircache_rtr_request_ranges(KjIrcache* c, uint32_t out_first_slot[2], uint32_t out_slot_count[2]) {
+    KJ_REQUIRE(c && out_first_slot && out_slot_count, "null argument");
+    const uint32_t hb = c->rtr_requests ? c->req_half_pixels : 0u;
+    out_first_slot[0] = c->rtr_request_base(); out_first_slot[1] = c->rtr_request_base() + hb;
+    out_slot_count[0] = out_slot_count[1] = hb;
     return KJ_OK;
 }
 KjStatus kj_ircache_collect_requests(KjIrcache* c, uint32_t first_slot, uint32_t slot_count, void* out_list, uint32_t out_capacity, void* out_count_dev, void* stream_) {

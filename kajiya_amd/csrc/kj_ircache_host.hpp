@@ -16,12 +16,15 @@ struct KjIrcache {
     int cur = 0;  // which grid_meta buffer is live after prepare()
     // deferred updates (kj_ircache.hpp: IrcRequest): one slot per possible lookup of the frame, in four ranges
     //   [0, HB) rtdgi validate | [HB, 2 HB) rtdgi trace | [2 HB, 2 HB + E) the cache's validate rays | [2 HB + E, 2 HB + 2 E) its trace rays
+    // and, when the frame has reflections (kj_ircache_set_rtr_requests), two more behind them: [.., + HB) rtr validate | [.., + HB) rtr trace
     bool deferred = false;
+    bool rtr_requests = false;
     bool requests_begun = false;        // kj_ircache_begin_requests ran for the frame kj_ircache_prepare is about to open (deferred mode)
     uint32_t req_half_pixels = 0;       // HB of the current frame
     kj::DevBuf freed, aux_snapshot, requests, req_sort_keys, req_sort_keys2, req_sort_idx, req_sort_idx2, req_flags, req_ranks, req_tmp, req_count, req_cells, req_seg_in, req_seg, req_voter, req_voters_incl, req_last_accepted;
     hipError_t err = hipSuccess;
     static constexpr uint32_t REQ_E = IRC_MAX_ENTRIES * IRC_SAMPLES_PER_FRAME;
-    uint32_t request_slots() const { return 2u * req_half_pixels + 2u * REQ_E; }
+    uint32_t rtr_request_base() const { return 2u * req_half_pixels + 2u * REQ_E; }
+    uint32_t request_slots() const { return (rtr_requests ? 4u : 2u) * req_half_pixels + 2u * REQ_E; }
     kj::IrcacheView view() const;
 };

@@ -26,10 +26,11 @@ typedef Img<float4> ImgF4;
 // workgroup -> tile order (kj_vec.hpp: tile_order; profiles/r03_xcd_tile_order.md): the passes whose every tile costs the same take whole tile rows per
 // XCD (TILE_XY_ROWS: temporal filter 180 -> 172 us, cleanup 51 -> 44, extract_half 14.6 -> 13.0 at 1440p); the ray passes, the reservoir pass and
 // the resolve keep the plain order (measured equal or 1-2 % slower with rows)
+// `tile_row0` (a kernel argument in scope): the first 8-row tile row of the launch -- 0 for the whole image; the screen-tile split launches a strip's tile rows only
 #define TILE_XY_ORDER(W_, H_, MODE_)                                      \
     const int lane = threadIdx.x;                                         \
     const uint2 kj_tb = kj::tile_order<MODE_>();                          \
-    const int x = int(kj_tb.x) * 8 + (lane & 7), y = int(kj_tb.y) * 8 + (lane >> 3); \
+    const int x = int(kj_tb.x) * 8 + (lane & 7), y = (int(kj_tb.y) + tile_row0) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < (H_);
 #define TILE_XY(W_, H_) TILE_XY_ORDER(W_, H_, KJ_TILES_PLAIN)
 #define TILE_XY_ROWS(W_, H_) TILE_XY_ORDER(W_, H_, KJ_TILES_ROWS)
@@ -63,14 +64,17 @@ struct RtrResolveArgs {
     ImgH4 restir_irradiance_tex, restir_ray_tex; ImgU2 restir_reservoir_tex; ImgF4 restir_ray_orig_tex;
     ImgU32 output_tex; ImgU32 ray_len_output_tex;
     const uint32_t* blue_noise; const uint2* brdf_fg_lut;
+    int tile_row0, tile_rows;       // full-res 8-row tile rows [tile_row0, tile_row0 + tile_rows) (kj_rtr_render_rows); the whole image: 0, (h + 7) / 8
 };
 struct RtrTemporalFilterArgs {
     const FrameConstants* fc;
     ImgU32 input_tex; ImgH4 history_tex; ImgF32 depth_tex; ImgU32 ray_len_tex; ImgU2 reprojection_tex; ImgR8 refl_restir_invalidity_tex; ImgU4 gbuffer_tex; ImgH4 output_tex;
+    int tile_row0, tile_rows;
 };
 struct RtrCleanupArgs {
     const FrameConstants* fc;
     ImgH4 input_tex; ImgF32 depth_tex; ImgU32 geometric_normal_tex; ImgU32 output_tex; const int4* spatial_resolve_offsets;
+    int tile_row0, tile_rows;
 };
 hipError_t launch_rtr_resolve(const RtrResolveArgs& a, hipStream_t s);
 hipError_t launch_rtr_temporal_filter(const RtrTemporalFilterArgs& a, hipStream_t s);

@@ -37,6 +37,9 @@ struct RtrCtx {
     unsigned long long* __restrict__ ray_counters;
     const uint32_t* __restrict__ ranking_tile; const uint32_t* __restrict__ scrambling_tile; const uint32_t* __restrict__ sobol;
     uint32_t reuse_rtdgi_rays;
+    uint32_t request_slot_base, request_key_base, request_stride;   // deferred ircache updates: slot / key of half-res pixel (x, y) = base + y * stride + x
+    int tile_row0;                  // first 8-row tile row of the launch (half-res tiles; the validate pass: its own row bounds below)
+    int quad_row0, quad_row1;       // the validate pass' rows of 2x2 half-res quads [quad_row0, quad_row1)
 };
 
 KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
@@ -52,7 +55,7 @@ KJ_D float blue_noise_sampler(const RtrCtx& c, int pixel_i, int pixel_j, int sam
 }
 
 // ------------------------------------------------------------------ GbufferDepth::half_view_normal / half_depth (renderers/mod.rs:44-71)
-__global__ void __launch_bounds__(64) k_rtr_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgU32 half_view_normal, ImgF32 half_depth) {
+__global__ void __launch_bounds__(64) k_rtr_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgU32 half_view_normal, ImgF32 half_depth, int tile_row0) {
     TILE_XY_ROWS(half_depth.w, half_depth.h)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
@@ -66,7 +69,7 @@ __global__ void __launch_bounds__(64) k_rtr_extract_half(const FrameConstants* _
 
 // ------------------------------------------------------------------ reflection_trace_common.inc.hlsl:56-257
 struct RtrTraceResult { V3 total_radiance; float hit_t; V3 hit_normal_vs; };
-KJ_D RtrTraceResult rtr_trace_ray(const RtrCtx& c, float roughness, uint32_t& rng, V3 ray_o, V3 ray_d, uint32_t* stack) {
+KJ_D RtrTraceResult rtr_trace_ray(const RtrCtx& c, float roughness, uint32_t& rng, V3 ray_o, V3 ray_d, uint32_t* stack, uint32_t request_pixel) {
     const FrameConstants& fc = *c.fc;
     const float roughness_bias = roughness;
     const float reflected_cone_spread_angle = sqrtf(roughness) * 0.05f;
@@ -131,7 +134,7 @@ KJ_D RtrTraceResult rtr_trace_ray(const RtrCtx& c, float roughness, uint32_t& rn
             }
             if (c.has_ircache) {
                 const float cone_width = ray_cone.propagate(0.0f, primary_hit.ray_t).width;
-                const V3 gi = ircache_lookup<false, true>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng, cone_width < 0.1f);
+                const V3 gi = ircache_lookup<false, true>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng, cone_width < 0.1f, c.request_slot_base + request_pixel, c.request_key_base | request_pixel);
                 total_radiance += gi * gbuffer.albedo;
             }
         }
@@ -148,6 +151,7 @@ KJ_D RtrTraceResult rtr_trace_ray(const RtrCtx& c, float roughness, uint32_t& rn
 #endif
 __global__ void __launch_bounds__(64, KJ_RTR_WAVES) k_rtr_trace(RtrCtx c, ImgH4 out0_tex, ImgH4 out1_tex, ImgU32 out2_tex, ImgU32 rng_out_tex) {
     extern __shared__ uint32_t lds_stack[];
+    const int tile_row0 = c.tile_row0;
     TILE_XY(out0_tex.w, out0_tex.h)
     if (!in_image) return;
     const FrameConstants& fc = *c.fc;
@@ -181,7 +185,7 @@ __global__ void __launch_bounds__(64, KJ_RTR_WAVES) k_rtr_trace(RtrCtx c, ImgH4 
         const float cos_theta = normalize(wo + brdf_sample.wi).z;
         const V3 ray_d = to_world(tangent_to_world, brdf_sample.wi);
         rng_out_tex.st(x, y, rng);
-        const RtrTraceResult result = rtr_trace_ray(c, gbuffer.roughness, rng, refl_ray_origin_ws, ray_d, lds_stack + lane);
+        const RtrTraceResult result = rtr_trace_ray(c, gbuffer.roughness, rng, refl_ray_origin_ws, ray_d, lds_stack + lane, uint32_t(y) * c.request_stride + uint32_t(x));
         const V3 hit_offset_ws = ray_d * result.hit_t;
         const FgLut brdf_lut = specular_energy_preservation(c.brdf_fg_lut, gbuffer.roughness, spec_albedo, wo.z);
         const float pdf = brdf_sample.pdf / brdf_lut.valid_sample_fraction;
@@ -200,8 +204,8 @@ __global__ void __launch_bounds__(64, KJ_RTR_WAVES) k_rtr_validate(RtrCtx c, Img
     extern __shared__ uint32_t lds_stack[];
     const int lane = threadIdx.x;
     const uint2 tb = tile_order<KJ_TILES_PLAIN>();
-    const int qx = int(tb.x) * 8 + (lane & 7), qy = int(tb.y) * 8 + (lane >> 3);
-    if (qx >= qw || qy >= qh) return;
+    const int qx = int(tb.x) * 8 + (lane & 7), qy = (int(tb.y) + c.tile_row0) * 8 + (lane >> 3);
+    if (qx >= qw || qy >= qh || qy < c.quad_row0 || qy >= c.quad_row1) return;
     const FrameConstants& fc = *c.fc;
     const I2 off = halfres_subsample_offset(fc.frame_index);
     const int x = qx * 2 + off.x, y = qy * 2 + off.y;
@@ -217,7 +221,7 @@ __global__ void __launch_bounds__(64, KJ_RTR_WAVES) k_rtr_validate(RtrCtx c, Img
     const float dl = length(d);
     const V3 ray_d = dl > 0.0f ? d / dl : V3{0, 0, 1};
     uint32_t rng = rng_history_tex.ld(x, y);
-    const RtrTraceResult result = rtr_trace_ray(c, gbuffer.roughness, rng, ray_orig_ws, ray_d, lds_stack + lane);
+    const RtrTraceResult result = rtr_trace_ray(c, gbuffer.roughness, rng, ray_orig_ws, ray_d, lds_stack + lane, uint32_t(y) * c.request_stride + uint32_t(x));
     Reservoir1spp r = Reservoir1spp::from_raw(reservoir_history_tex.ld(x, y));
     const V4 prev_irradiance_packed = ld4(irradiance_history_tex, x, y);
     const V3 prev_irradiance = vmax(v3(0.0f), xyz(prev_irradiance_packed) * fc.pre_exposure_delta);
@@ -279,9 +283,11 @@ struct RtrTemporalArgs {
     ImgH4 irradiance_history_tex; ImgF4 ray_orig_history_tex; ImgH4 ray_history_tex; ImgU32 rng_history_tex; ImgU2 reservoir_history_tex;
     ImgU2 reprojection_tex; ImgH4 hit_normal_history_tex;
     ImgH4 irradiance_out_tex; ImgF4 ray_orig_output_tex; ImgH4 ray_output_tex; ImgU32 rng_output_tex; ImgH4 hit_normal_output_tex; ImgU2 reservoir_out_tex;
+    int tile_row0;
 };
 // ------------------------------------------------------------------ rtr_restir_temporal.hlsl:155-533
 __global__ void __launch_bounds__(64) k_rtr_restir_temporal(RtrTemporalArgs a) {
+    const int tile_row0 = a.tile_row0;
     TILE_XY(a.irradiance_out_tex.w, a.irradiance_out_tex.h)
     const FrameConstants& fc = *a.fc;
     // the five taps' spiral directions depend on the tap and the frame only: evaluated once per workgroup with the reference's cosf / sinf
@@ -436,7 +442,7 @@ __global__ void __launch_bounds__(64) k_rtr_restir_temporal(RtrTemporalArgs a) {
 // ------------------------------------------------------------------ LightingRenderer::render_specular (renderers/lighting.rs:23-88)
 // sample_lights.rgen.hlsl:18-63: one triangle-light sample + shadow ray per half-res pixel
 __global__ void __launch_bounds__(64) k_lighting_sample_lights(const FrameConstants* __restrict__ fcp, SceneView sc, ImgF32 depth_tex, const uint32_t* __restrict__ blue_noise,
-                                                                ImgH4 out0_tex, ImgF4 out1_tex, ImgU32 out2_tex, unsigned long long* ray_counters) {
+                                                                ImgH4 out0_tex, ImgF4 out1_tex, ImgU32 out2_tex, unsigned long long* ray_counters, int tile_row0) {
     extern __shared__ uint32_t lds_stack[];
     TILE_XY(out0_tex.w, out0_tex.h)
     if (!in_image) return;
@@ -467,7 +473,7 @@ __global__ void __launch_bounds__(64) k_lighting_sample_lights(const FrameConsta
 // spatial_reuse_lights.hlsl:33-168 (RENDER_INTO_RTR: the result is added to rtr's resolved image)
 __global__ void __launch_bounds__(64) k_lighting_spatial_reuse(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer_tex, ImgF32 depth_tex, ImgH4 hit0_tex, ImgF4 hit1_tex, ImgU32 hit2_tex,
                                                                 ImgU32 half_view_normal_tex, ImgF32 half_depth_tex, ImgU32 output_tex, const int4* __restrict__ spatial_resolve_offsets,
-                                                                const uint2* __restrict__ brdf_fg_lut) {
+                                                                const uint2* __restrict__ brdf_fg_lut, int tile_row0) {
     TILE_XY(output_tex.w, output_tex.h)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
@@ -598,15 +604,29 @@ static KjStatus rtr_check_params(KjRtr* r, const KjRtrParams* p) {
     return KJ_OK;
 }
 
-KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* p, void* stream_) {
-    if (KjStatus st = rtr_check_params(r, p)) return st;
+} // extern "C"
+
+// Full-res rows [row_begin, row_end) -> tile rows of the full-res and half-res launches and the validate pass' quad rows. row_begin is a multiple of 16
+// (or the whole image): half-res 8x8 tiles and the validate pass' 2x2 quads never straddle a strip's edge.
+struct RtrRows { int f0, fn, h0, hn, hrow0, hrow1, q0, q1; bool whole; };
+static RtrRows rtr_rows(const KjRtr* r, uint32_t row_begin, uint32_t row_end) {
+    RtrRows o;
+    o.whole = row_begin == 0u && int(row_end) == r->H;
+    o.f0 = int(row_begin) / 8; o.fn = (int(row_end) + 7) / 8 - o.f0;
+    o.hrow0 = int(row_begin) / 2; o.hrow1 = int(row_end) == r->H ? r->hh : int(row_end) / 2;
+    o.h0 = o.hrow0 / 8; o.hn = (o.hrow1 + 7) / 8 - o.h0;
+    o.q0 = o.hrow0 / 2; o.q1 = (o.hrow1 + 1) / 2;
+    return o;
+}
+
+static KjStatus rtr_trace_rows(KjRtr* r, const KjRtrParams* p, uint32_t row_begin, uint32_t row_end, bool extract_half, void* stream_) {
     hipStream_t s = (hipStream_t)stream_;
-    r->resize(int(p->gbuffer_depth.width), int(p->gbuffer_depth.height));
     const int W = r->W, H = r->H, hw = r->hw, hh = r->hh;
     const FrameConstants* fc = r->dev->fc_dev;
     const uint32_t mask = p->pass_mask;
     if (mask & KJ_RTR_PASS_KEEP) for (bool& f : r->flip) f = !f;
-    const dim3 gh((hw + 7) / 8, (hh + 7) / 8), gf((W + 7) / 8, (H + 7) / 8), blk(64);
+    const RtrRows rows = rtr_rows(r, row_begin, row_end);
+    const dim3 gh((hw + 7) / 8, rows.hn), gf((W + 7) / 8, rows.fn), blk(64);
     const size_t HB = size_t(hw) * hh, FB = size_t(W) * H;
     const ImgU4 gbuffer = img<uint4>(p->gbuffer_depth.gbuffer, W, H);
     const ImgF32 depth = img<float>(p->gbuffer_depth.depth, W, H);
@@ -642,6 +662,13 @@ KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* p, void* stream_) {
     c.ray_counters = (unsigned long long*)r->ray_counters.p;
     c.ranking_tile = (const uint32_t*)r->ranking.p; c.scrambling_tile = (const uint32_t*)r->scrambling.p; c.sobol = (const uint32_t*)r->sobol.p;
     c.reuse_rtdgi_rays = r->reuse_rtdgi_rays ? 1u : 0u;
+    c.request_stride = uint32_t(hw); c.request_slot_base = 0; c.request_key_base = 0;
+    c.tile_row0 = rows.h0; c.quad_row0 = rows.q0; c.quad_row1 = rows.q1;
+    if (p->ircache && p->ircache->deferred) {      // the lookups of the two ray passes record into slot ranges of their own (kj_ircache_set_rtr_requests)
+        KJ_REQUIRE(p->ircache->rtr_requests && p->ircache->req_half_pixels == uint32_t(hw) * uint32_t(hh),
+                   "a cache in deferred-update mode needs kj_ircache_set_rtr_requests(cache, 1) before kj_ircache_begin_requests (this frame's half-res extent)");
+        c.request_slot_base = p->ircache->rtr_request_base() + uint32_t(hw) * uint32_t(hh); c.request_key_base = 6u << 28;      // the trace pass; validate re-bases below
+    }
     const size_t trace_lds = size_t(c.sc.bvh.stack_entries) * 64 * 4;
     KJ_REQUIRE(trace_lds <= 64 * 1024, "BVH too deep for the LDS traversal stack");
 
@@ -649,15 +676,20 @@ KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* p, void* stream_) {
     hipStream_t sv = fork ? r->side : s;
     if (fork) { KJ_TRY_HIP(hipEventRecord(r->ev_fork, s)); KJ_TRY_HIP(hipStreamWaitEvent(r->side, r->ev_fork, 0)); }
     if (mask & KJ_RTR_PASS_VALIDATE) {
-        KJ_TRY_HIP(hipMemsetAsync(invalidity, 0, HB, sv));
+        KJ_TRY_HIP(hipMemsetAsync((uint8_t*)invalidity + size_t(rows.hrow0) * hw, 0, size_t(rows.hrow1 - rows.hrow0) * hw, sv));
         const int qw = (hw + 1) / 2, qh = (hh + 1) / 2;
-        hipLaunchKernelGGL(k_rtr_validate, dim3((qw + 7) / 8, (qh + 7) / 8), blk, trace_lds, sv, c, img<float4>(ray_orig_hist, hw, hh), img<uint2>(ray_hist, hw, hh), img<uint32_t>(rng_hist, hw, hh),
+        RtrCtx vc = c;
+        vc.tile_row0 = rows.q0 / 8;
+        if (p->ircache && p->ircache->deferred) { vc.request_slot_base = p->ircache->rtr_request_base(); vc.request_key_base = 5u << 28; }
+        hipLaunchKernelGGL(k_rtr_validate, dim3((qw + 7) / 8, (rows.q1 + 7) / 8 - rows.q0 / 8), blk, trace_lds, sv, vc, img<float4>(ray_orig_hist, hw, hh), img<uint2>(ray_hist, hw, hh), img<uint32_t>(rng_hist, hw, hh),
                            img<uint2>(irradiance_hist, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint8_t>(invalidity, hw, hh), qw, qh);
         KJ_CHECK_LAUNCH();
     }
     if (fork) KJ_TRY_HIP(hipEventRecord(r->ev_join, r->side));
-    hipLaunchKernelGGL(k_rtr_extract_half, gh, blk, 0, s, fc, gbuffer, depth, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh));
-    KJ_CHECK_LAUNCH();
+    if (extract_half) {      // the whole frame whatever the rows: the resolve reads the view normal wherever its taps land
+        hipLaunchKernelGGL(k_rtr_extract_half, dim3((hw + 7) / 8, (hh + 7) / 8), blk, 0, s, fc, gbuffer, depth, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), 0);
+        KJ_CHECK_LAUNCH();
+    }
     if (mask & KJ_RTR_PASS_TRACE) {
         hipLaunchKernelGGL(k_rtr_trace, gh, blk, trace_lds, s, c, refl0, refl1, refl2, img<uint32_t>(rng_out, hw, hh));
         KJ_CHECK_LAUNCH();
@@ -672,6 +704,7 @@ KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* p, void* stream_) {
         a.reprojection_tex = reprojection; a.hit_normal_history_tex = img<uint2>(hit_normal_hist, hw, hh);
         a.irradiance_out_tex = img<uint2>(irradiance_out, hw, hh); a.ray_orig_output_tex = img<float4>(ray_orig_out, hw, hh); a.ray_output_tex = img<uint2>(ray_out, hw, hh);
         a.rng_output_tex = img<uint32_t>(rng_out, hw, hh); a.hit_normal_output_tex = img<uint2>(hit_normal_out, hw, hh); a.reservoir_out_tex = img<uint2>(reservoir_out, hw, hh);
+        a.tile_row0 = rows.h0;
         hipLaunchKernelGGL(k_rtr_restir_temporal, gh, blk, 0, s, a);
         KJ_CHECK_LAUNCH();
     }
@@ -683,15 +716,15 @@ KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* p, void* stream_) {
         a.restir_ray_orig_tex = img<float4>(ray_orig_out, hw, hh);
         a.output_tex = img<uint32_t>(resolved, W, H); a.ray_len_output_tex = img<uint32_t>(ray_len_out, W, H);
         a.blue_noise = (const uint32_t*)r->dev->blue_noise.p; a.brdf_fg_lut = (const uint2*)r->dev->brdf_fg_lut.p;
+        a.tile_row0 = rows.f0; a.tile_rows = rows.fn;
         KJ_TRY_HIP(launch_rtr_resolve(a, s));
     }
     r->resolved_tex = resolved; r->temporal_output_tex = temporal_out; r->history_tex = temporal_hist; r->ray_len_tex = ray_len_out; r->refl_restir_invalidity_tex = invalidity;
     return KJ_OK;
 }
 
-KjStatus kj_rtr_render_specular_lights(KjRtr* r, const KjRtrParams* p, void* stream_) {
-    if (KjStatus st = rtr_check_params(r, p)) return st;
-    KJ_REQUIRE(r->resolved_tex && int(p->gbuffer_depth.width) == r->W && int(p->gbuffer_depth.height) == r->H, "kj_rtr_trace must run first with the same extent");
+// sample_lights on half-res rows grown by 8 either side of the strip (spatial_reuse_lights taps reach <= 6 half-res rows with rtr.rs's offset table), reuse on the rows
+static KjStatus rtr_specular_lights_rows(KjRtr* r, const KjRtrParams* p, uint32_t row_begin, uint32_t row_end, void* stream_) {
     if (p->scene->light_count == 0 || r->dev->fc_host.triangle_light_count == 0) return KJ_OK;   // world_render_passes.rs:166-170,190: only with triangle lights
     hipStream_t s = (hipStream_t)stream_;
     const int W = r->W, H = r->H, hw = r->hw, hh = r->hh;
@@ -706,34 +739,75 @@ KjStatus kj_rtr_render_specular_lights(KjRtr* r, const KjRtrParams* p, void* str
     const SceneView sc = scene_view(*p->scene);
     const size_t trace_lds = size_t(sc.bvh.stack_entries) * 64 * 4;
     const ImgF32 depth = img<float>(p->gbuffer_depth.depth, W, H);
-    const dim3 gh((hw + 7) / 8, (hh + 7) / 8), gf((W + 7) / 8, (H + 7) / 8), blk(64);
-    hipLaunchKernelGGL(k_lighting_sample_lights, gh, blk, trace_lds, s, fc, sc, depth, (const uint32_t*)r->dev->blue_noise.p, img<uint2>(l0, hw, hh), img<float4>(l1, hw, hh),
-                       img<uint32_t>(l2, hw, hh), (unsigned long long*)r->ray_counters.p);
+    const RtrRows rows = rtr_rows(r, row_begin, row_end);
+    const int sh0 = rows.whole ? 0 : std::max(0, rows.h0 - 1), sh1 = rows.whole ? (hh + 7) / 8 : std::min((hh + 7) / 8, rows.h0 + rows.hn + 1);
+    const dim3 blk(64);
+    hipLaunchKernelGGL(k_lighting_sample_lights, dim3((hw + 7) / 8, sh1 - sh0), blk, trace_lds, s, fc, sc, depth, (const uint32_t*)r->dev->blue_noise.p, img<uint2>(l0, hw, hh), img<float4>(l1, hw, hh),
+                       img<uint32_t>(l2, hw, hh), (unsigned long long*)r->ray_counters.p, sh0);
     KJ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_lighting_spatial_reuse, gf, blk, 0, s, fc, img<uint4>(p->gbuffer_depth.gbuffer, W, H), depth, img<uint2>(l0, hw, hh), img<float4>(l1, hw, hh), img<uint32_t>(l2, hw, hh),
+    hipLaunchKernelGGL(k_lighting_spatial_reuse, dim3((W + 7) / 8, rows.fn), blk, 0, s, fc, img<uint4>(p->gbuffer_depth.gbuffer, W, H), depth, img<uint2>(l0, hw, hh), img<float4>(l1, hw, hh), img<uint32_t>(l2, hw, hh),
                        img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), img<uint32_t>(r->resolved_tex, W, H), (const int4*)r->offsets.p,
-                       (const uint2*)r->dev->brdf_fg_lut.p);
+                       (const uint2*)r->dev->brdf_fg_lut.p, rows.f0);
     KJ_CHECK_LAUNCH();
     return KJ_OK;
+}
+
+static KjStatus rtr_filter_rows(KjRtr* r, const KjRtrParams* p, uint32_t row_begin, uint32_t row_end, void* stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    const int W = r->W, H = r->H, hw = r->hw, hh = r->hh;
+    const FrameConstants* fc = r->dev->fc_dev;
+    const RtrRows rows = rtr_rows(r, row_begin, row_end);
+    const ImgF32 depth = img<float>(p->gbuffer_depth.depth, W, H);
+    if (p->pass_mask & KJ_RTR_PASS_TEMPORAL_FILTER) {
+        const RtrTemporalFilterArgs a{fc, img<uint32_t>(r->resolved_tex, W, H), img<uint2>(r->history_tex, W, H), depth, img<uint32_t>(r->ray_len_tex, W, H), img<uint2>(p->reprojection_map, W, H),
+                                      img<uint8_t>(r->refl_restir_invalidity_tex, hw, hh), img<uint4>(p->gbuffer_depth.gbuffer, W, H), img<uint2>(r->temporal_output_tex, W, H), rows.f0, rows.fn};
+        KJ_TRY_HIP(launch_rtr_temporal_filter(a, s));
+    }
+    if (p->pass_mask & KJ_RTR_PASS_CLEANUP) {
+        const RtrCleanupArgs a{fc, img<uint2>(r->temporal_output_tex, W, H), depth, img<uint32_t>(p->gbuffer_depth.geometric_normal, W, H), img<uint32_t>(r->resolved_tex, W, H), (const int4*)r->offsets.p,
+                               rows.f0, rows.fn};
+        KJ_TRY_HIP(launch_rtr_cleanup(a, s));
+    }
+    return KJ_OK;
+}
+
+extern "C" {
+
+KjStatus kj_rtr_trace(KjRtr* r, const KjRtrParams* p, void* stream_) {
+    if (KjStatus st = rtr_check_params(r, p)) return st;
+    r->resize(int(p->gbuffer_depth.width), int(p->gbuffer_depth.height));
+    return rtr_trace_rows(r, p, 0u, uint32_t(r->H), true, stream_);
+}
+
+KjStatus kj_rtr_render_specular_lights(KjRtr* r, const KjRtrParams* p, void* stream_) {
+    if (KjStatus st = rtr_check_params(r, p)) return st;
+    KJ_REQUIRE(r->resolved_tex && int(p->gbuffer_depth.width) == r->W && int(p->gbuffer_depth.height) == r->H, "kj_rtr_trace must run first with the same extent");
+    return rtr_specular_lights_rows(r, p, 0u, uint32_t(r->H), stream_);
 }
 
 KjStatus kj_rtr_filter_temporal(KjRtr* r, const KjRtrParams* p, const void** out_resolved, void* stream_) {
     if (KjStatus st = rtr_check_params(r, p)) return st;
     KJ_REQUIRE(r->resolved_tex && int(p->gbuffer_depth.width) == r->W && int(p->gbuffer_depth.height) == r->H, "kj_rtr_trace must run first with the same extent");
-    hipStream_t s = (hipStream_t)stream_;
-    const int W = r->W, H = r->H, hw = r->hw, hh = r->hh;
-    const FrameConstants* fc = r->dev->fc_dev;
-    const dim3 gf((W + 7) / 8, (H + 7) / 8), blk(64);
-    const ImgF32 depth = img<float>(p->gbuffer_depth.depth, W, H);
-    if (p->pass_mask & KJ_RTR_PASS_TEMPORAL_FILTER) {
-        const RtrTemporalFilterArgs a{fc, img<uint32_t>(r->resolved_tex, W, H), img<uint2>(r->history_tex, W, H), depth, img<uint32_t>(r->ray_len_tex, W, H), img<uint2>(p->reprojection_map, W, H),
-                                      img<uint8_t>(r->refl_restir_invalidity_tex, hw, hh), img<uint4>(p->gbuffer_depth.gbuffer, W, H), img<uint2>(r->temporal_output_tex, W, H)};
-        KJ_TRY_HIP(launch_rtr_temporal_filter(a, s));
-    }
-    if (p->pass_mask & KJ_RTR_PASS_CLEANUP) {
-        const RtrCleanupArgs a{fc, img<uint2>(r->temporal_output_tex, W, H), depth, img<uint32_t>(p->gbuffer_depth.geometric_normal, W, H), img<uint32_t>(r->resolved_tex, W, H), (const int4*)r->offsets.p};
-        KJ_TRY_HIP(launch_rtr_cleanup(a, s));
-    }
+    if (KjStatus st = rtr_filter_rows(r, p, 0u, uint32_t(r->H), stream_)) return st;
+    if (out_resolved) *out_resolved = r->resolved_tex;
+    return KJ_OK;
+}
+
+// The screen-tile split's entry point (kj_split_rtr_frame, multigpu.py: SplitRtdgi.rtr_frame): the passes of params->pass_mask on full-res rows
+// [row_begin, row_end) -- the ray passes, the reservoir pass and the specular lights on the half-res rows underneath. What a pass reads beyond the rows is the
+// caller's to provide (DESIGN 7 lists every reach). KJ_RTR_PASS_EXTRACT_HALF: the half-res view normal / depth of the WHOLE frame (inputs are replicated;
+// the resolve reads the normal wherever its taps land). Without KJ_RTR_PASS_KEEP the call opens the frame (ping-pong flip, ray counters cleared).
+KjStatus kj_rtr_render_rows(KjRtr* r, const KjRtrParams* p, uint32_t row_begin, uint32_t row_end, const void** out_resolved, void* stream_) {
+    if (KjStatus st = rtr_check_params(r, p)) return st;
+    KJ_REQUIRE(row_begin < row_end && row_end <= p->gbuffer_depth.height && (row_begin % 16u) == 0u && (row_end % 16u == 0u || row_end == p->gbuffer_depth.height),
+               "rows must be a non-empty range cut on 16-row boundaries");
+    r->resize(int(p->gbuffer_depth.width), int(p->gbuffer_depth.height));
+    const uint32_t mask = p->pass_mask;
+    if (mask & (KJ_RTR_PASS_VALIDATE | KJ_RTR_PASS_TRACE | KJ_RTR_PASS_RESTIR_TEMPORAL | KJ_RTR_PASS_RESOLVE | KJ_RTR_PASS_EXTRACT_HALF) || !(mask & KJ_RTR_PASS_KEEP))
+        if (KjStatus st = rtr_trace_rows(r, p, row_begin, row_end, (mask & KJ_RTR_PASS_EXTRACT_HALF) != 0, stream_)) return st;
+    KJ_REQUIRE(r->resolved_tex, "the frame has not been opened (a call without KJ_RTR_PASS_KEEP comes first)");
+    if (mask & KJ_RTR_PASS_SPECULAR_LIGHTS) if (KjStatus st = rtr_specular_lights_rows(r, p, row_begin, row_end, stream_)) return st;
+    if (mask & (KJ_RTR_PASS_TEMPORAL_FILTER | KJ_RTR_PASS_CLEANUP)) if (KjStatus st = rtr_filter_rows(r, p, row_begin, row_end, stream_)) return st;
     if (out_resolved) *out_resolved = r->resolved_tex;
     return KJ_OK;
 }

@@ -40,6 +40,7 @@ KJ_D SpecWeight specular_evaluate_weight(float a2, V3 albedo, V3 wo, V3 wi, floa
 
 // ------------------------------------------------------------------ resolve.hlsl:66-663 (USE_RESTIR, CUT_CORNERS_IN_MATH, BORROW_SAMPLES)
 __global__ void __launch_bounds__(64) k_rtr_resolve(RtrResolveArgs a) {
+    const int tile_row0 = a.tile_row0;
     TILE_XY(a.output_tex.w, a.output_tex.h)
     const FrameConstants& fc = *a.fc;
     // (cos, sin) of the eight taps' angles for the four quad positions: lane l < 32 evaluates tap (l >> 2) + 1 at quad position l & 3
@@ -249,7 +250,7 @@ KJ_D V3 soft_color_clamp_fast(V3 center, V3 history, V3 ex, V3 dev) {
 
 // ------------------------------------------------------------------ temporal_filter.hlsl:37-259
 __global__ void __launch_bounds__(64) k_rtr_temporal_filter(const FrameConstants* __restrict__ fcp, ImgU32 input_tex, ImgH4 history_tex, ImgF32 depth_tex, ImgU32 ray_len_tex,
-                                                             ImgU2 reprojection_tex, ImgR8 refl_restir_invalidity_tex, ImgU4 gbuffer_tex, ImgH4 output_tex) {
+                                                             ImgU2 reprojection_tex, ImgR8 refl_restir_invalidity_tex, ImgU4 gbuffer_tex, ImgH4 output_tex, int tile_row0) {
     TILE_XY_ROWS(output_tex.w, output_tex.h)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
@@ -357,7 +358,7 @@ __global__ void __launch_bounds__(64) k_rtr_temporal_filter(const FrameConstants
 
 // ------------------------------------------------------------------ spatial_cleanup.hlsl:20-65
 __global__ void __launch_bounds__(64) k_rtr_cleanup(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgF32 depth_tex, ImgU32 geometric_normal_tex, ImgU32 output_tex,
-                                                     const int4* __restrict__ spatial_resolve_offsets) {
+                                                     const int4* __restrict__ spatial_resolve_offsets, int tile_row0) {
     TILE_XY_ROWS(output_tex.w, output_tex.h)
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
@@ -392,15 +393,15 @@ __global__ void __launch_bounds__(64) k_rtr_cleanup(const FrameConstants* __rest
 }
 
 hipError_t launch_rtr_resolve(const RtrResolveArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_rtr_resolve, dim3((a.output_tex.w + 7) / 8, (a.output_tex.h + 7) / 8), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_rtr_resolve, dim3((a.output_tex.w + 7) / 8, a.tile_rows), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_rtr_temporal_filter(const RtrTemporalFilterArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_rtr_temporal_filter, dim3((a.output_tex.w + 7) / 8, (a.output_tex.h + 7) / 8), dim3(64), 0, s, a.fc, a.input_tex, a.history_tex, a.depth_tex, a.ray_len_tex, a.reprojection_tex,
-                       a.refl_restir_invalidity_tex, a.gbuffer_tex, a.output_tex);
+    hipLaunchKernelGGL(k_rtr_temporal_filter, dim3((a.output_tex.w + 7) / 8, a.tile_rows), dim3(64), 0, s, a.fc, a.input_tex, a.history_tex, a.depth_tex, a.ray_len_tex, a.reprojection_tex,
+                       a.refl_restir_invalidity_tex, a.gbuffer_tex, a.output_tex, a.tile_row0);
     return hipGetLastError();
 }
 hipError_t launch_rtr_cleanup(const RtrCleanupArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_rtr_cleanup, dim3((a.output_tex.w + 7) / 8, (a.output_tex.h + 7) / 8), dim3(64), 0, s, a.fc, a.input_tex, a.depth_tex, a.geometric_normal_tex, a.output_tex, a.spatial_resolve_offsets);
+    hipLaunchKernelGGL(k_rtr_cleanup, dim3((a.output_tex.w + 7) / 8, a.tile_rows), dim3(64), 0, s, a.fc, a.input_tex, a.depth_tex, a.geometric_normal_tex, a.output_tex, a.spatial_resolve_offsets, a.tile_row0);
     return hipGetLastError();
 }

@@ -36,6 +36,8 @@ const std::map<std::string, SurfInfo>& surf_table() {
         {"irradiance_output_tex", {8, false}}, {"temporal_filtered_tex", {8, false}}, {"spatial_filtered_tex", {8, false}}, {"reprojected_history_tex", {8, false}},
         {"SSGI/ssgi", {2, false}}, {"SSGI/filtered_output_tex", {1, false}},
         {"SHADOW/shadow_denoise_moments", {8, false}}, {"SHADOW/shadow_denoise_accum", {4, false}}, {"SHADOW/mask", {1, false}},      // "SHADOW/mask": the caller's image (kj_split_shadow_frame)
+        {"RTR/rtr.temporal", {8, false}}, {"RTR/rtr.ray_len", {4, false}}, {"RTR/rtr.irradiance", {8, true}}, {"RTR/rtr.ray_orig", {16, true}}, {"RTR/rtr.ray", {8, true}},
+        {"RTR/rtr.reservoir", {8, true}}, {"RTR/rtr.rng", {4, true}}, {"RTR/rtr.hit_normal", {8, true}},      // RtrRenderer's eight ping-pong temporals (kj_split_rtr_frame)
         {"TAA/taa", {8, false}}, {"TAA/taa.velocity", {4, false}}, {"TAA/taa.smooth_var", {8, false}}, {"TAA/this_frame_output_img", {8, false}},
         {"selftest.h16", {16, true}}, {"selftest.h1", {1, true}}, {"selftest.f8", {8, false}}, {"selftest.f4", {4, false}},      // kj_split_self_test's scratch images
     };
@@ -76,7 +78,7 @@ struct Rccl {
 Rccl g_rccl;
 constexpr int NCCL_UINT8 = 1, NCCL_UINT32 = 3;     // ncclDataType_t (nccl.h): ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3
 
-struct Item { std::string name; int halo; };        // halo < 0: every row (all-gather)
+struct Item { std::string name; int halo; uint32_t pin = 0; };        // halo < 0: every row (all-gather); pin: the image's first rows, which every rank holds as well
 struct Block { uint32_t src, dst; std::string name; uint32_t row0, row1; };
 
 }  // namespace
@@ -89,6 +91,9 @@ struct KjSplit {
     std::vector<KjSsgi*> ssgi;                             // the local ranks' SsgiRenderers (kj_split_ssgi_frame)
     std::vector<KjShadowDenoise*> shadow;                  // the local ranks' ShadowDenoiseRenderers (kj_split_shadow_frame)
     uint32_t shadow_frames = 0;
+    std::vector<KjRtr*> rtr;                               // the local ranks' RtrRenderers (kj_split_rtr_frame)
+    uint32_t rtr_frames = 0;
+    bool with_rtr = false;                                 // kj_split_set_rtr: reflections follow the GI frame -- the cache's replay moves behind their ray passes
     bool consistent_ircache = false;
     std::vector<uint8_t> ircache_was_deferred;             // each local cache's mode before kj_split_create changed it: restored by kj_split_destroy
     void* nccl = nullptr;                                  // ncclComm_t; null: every rank is local
@@ -122,9 +127,11 @@ KjStatus surface_of(KjSplit& s, uint32_t rank, const std::string& name, uint8_t*
         void* p = nullptr; uint64_t bytes = 0;
         KJ_REQUIRE(name.rfind("SSGI/", 0) != 0 || (li < s.ssgi.size() && s.ssgi[li]), "no SsgiRenderer bound to this rank");
         KJ_REQUIRE(name.rfind("SHADOW/", 0) != 0 || (li < s.shadow.size() && s.shadow[li]), "no ShadowDenoiseRenderer bound to this rank");
+        KJ_REQUIRE(name.rfind("RTR/", 0) != 0 || (li < s.rtr.size() && s.rtr[li]), "no RtrRenderer bound to this rank");
         const KjStatus st = name.rfind("TAA/", 0) == 0    ? kj_taa_surface(s.ranks[li].taa, name.c_str() + 4, &p, &bytes)
                             : name.rfind("SSGI/", 0) == 0 ? kj_ssgi_surface(s.ssgi[li], name.c_str() + 5, &p, &bytes)
                             : name.rfind("SHADOW/", 0) == 0 ? kj_shadow_denoise_surface(s.shadow[li], name.c_str() + 7, &p, &bytes)
+                            : name.rfind("RTR/", 0) == 0 ? kj_rtr_surface(s.rtr[li], name.c_str() + 4, &p, &bytes)
                                                           : kj_rtdgi_surface(s.ranks[li].rtdgi, name.c_str(), &p, &bytes);
         if (st != KJ_OK) return st;
         it = s.surfaces.emplace(key, std::make_pair((uint8_t*)p, bytes)).first;
@@ -144,12 +151,17 @@ void plan(const KjSplit& s, const std::vector<Item>& items, std::vector<Block>& 
             const auto od = si->half ? half_rows(s, s.strips[dst]) : s.strips[dst];
             const uint32_t lo = it.halo < 0 ? 0u : uint32_t(std::max<int64_t>(0, int64_t(od.first) - it.halo));
             const uint32_t hi = it.halo < 0 ? total : std::min<uint32_t>(total, od.second + uint32_t(it.halo));
-            for (uint32_t src = 0; src < s.world; ++src) {
-                if (src == dst) continue;
-                const auto os = si->half ? half_rows(s, s.strips[src]) : s.strips[src];
-                const uint32_t a = std::max(lo, os.first), b = std::min(hi, os.second);
-                if (b > a) out.push_back(Block{src, dst, it.name, a, b});
-            }
+            // the rows around the strip, and the pinned top rows where they are not among them (multigpu.py: transfers)
+            const uint32_t pin = std::min(it.pin, total);
+            std::pair<uint32_t, uint32_t> spans[2] = {{lo, hi}, {0, 0}};
+            if (pin > 0) { if (lo <= pin) spans[0] = {0u, std::max(hi, pin)}; else { spans[0] = {0u, pin}; spans[1] = {lo, hi}; } }
+            for (const auto& sp : spans)
+                for (uint32_t src = 0; src < s.world; ++src) {
+                    if (src == dst) continue;
+                    const auto os = si->half ? half_rows(s, s.strips[src]) : s.strips[src];
+                    const uint32_t a = std::max(sp.first, os.first), b = std::min(sp.second, os.second);
+                    if (b > a) out.push_back(Block{src, dst, it.name, a, b});
+                }
         }
     }
 }
@@ -286,7 +298,9 @@ KjStatus merge_ircache_requests(KjSplit& s, hipStream_t st) {
         KjStatus e = kj_ircache_request_ranges(c, first, count); if (e != KJ_OK) return e;
         const auto h = half_rows(s, s.strips[s.first + li]);
         const uint32_t px = (h.second - h.first) * s.hw;
-        cap_strip[li] = 2 * px; cap_irc[li] = count[2] + count[3];
+        uint32_t rtr_first[2] = {0, 0}, rtr_count[2] = {0, 0};
+        if (s.with_rtr && (e = kj_ircache_rtr_request_ranges(c, rtr_first, rtr_count)) != KJ_OK) return e;
+        cap_strip[li] = (s.with_rtr ? 4 : 2) * px; cap_irc[li] = count[2] + count[3];
         if (s.strip_list[li].bytes < size_t(cap_strip[li]) * RQ) KJ_TRY_HIP(s.strip_list[li].alloc(size_t(cap_strip[li]) * RQ, st));
         if (s.irc_list[li].bytes < size_t(cap_irc[li]) * RQ) KJ_TRY_HIP(s.irc_list[li].alloc(size_t(cap_irc[li]) * RQ, st));
         if (!s.counts[li].p) KJ_TRY_HIP(s.counts[li].alloc(8, st));
@@ -294,6 +308,9 @@ KjStatus merge_ircache_requests(KjSplit& s, hipStream_t st) {
         uint32_t* cnt = (uint32_t*)s.counts[li].p;
         if ((e = kj_ircache_collect_requests(c, first[0] + h.first * s.hw, px, s.strip_list[li].p, cap_strip[li], cnt, st)) != KJ_OK) return e;
         if ((e = kj_ircache_collect_requests(c, first[1] + h.first * s.hw, px, s.strip_list[li].p, cap_strip[li], cnt, st)) != KJ_OK) return e;
+        if (s.with_rtr)      // the lookups of rtr's validate and trace rays on this strip (kj_split_rtr_frame)
+            for (int k = 0; k < 2; ++k)
+                if ((e = kj_ircache_collect_requests(c, rtr_first[k] + h.first * s.hw, px, s.strip_list[li].p, cap_strip[li], cnt, st)) != KJ_OK) return e;
         if ((e = kj_ircache_collect_requests(c, first[2], count[2], s.irc_list[li].p, cap_irc[li], cnt + 1, st)) != KJ_OK) return e;
         if ((e = kj_ircache_collect_requests(c, first[3], count[3], s.irc_list[li].p, cap_irc[li], cnt + 1, st)) != KJ_OK) return e;
     }
@@ -399,12 +416,15 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
     items.clear();
     items.push_back({"rt_history_validity_pre_input_tex", int(M + 1)});
     if (s->frame > 0) {
-        for (const char* n : {"rtdgi.reservoir", "rtdgi.ray_orig", "rtdgi.ray", "rtdgi.radiance", "rtdgi.hit_normal"}) items.push_back({sfx(n, hist_i), int(M + 4)});
+        // (row 0 of the four sample images for everybody: a reservoir nothing was ever selected into keeps payload 0 = pixel (0, 0), and the temporal pass
+        // follows the payload whatever the reservoir's weight)
+        items.push_back({sfx("rtdgi.reservoir", hist_i), int(M + 4)});
+        for (const char* n : {"rtdgi.ray_orig", "rtdgi.ray", "rtdgi.radiance", "rtdgi.hit_normal"}) items.push_back({sfx(n, hist_i), int(M + 4), 1u});
         items.push_back({sfx("rtdgi.invalidity", hist_i), int(M + 8)});
     }
     KJ_SPLIT_TRY(exchange(*s, items, st));
     for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_TRACE | KEEP, s->strips[s->first + li], 0, st));
-    if (s->consistent_ircache && !defer_merge) KJ_SPLIT_TRY(merge_ircache_requests(*s, st));
+    if (s->consistent_ircache && !defer_merge && !s->with_rtr) KJ_SPLIT_TRY(merge_ircache_requests(*s, st));      // (with reflections in the frame: after THEIR ray passes)
     if (trace_done_event) KJ_TRY_HIP(hipEventRecord((hipEvent_t)trace_done_event, st));
     // ---- C
     KJ_SPLIT_TRY(exchange(*s, {{"rt_history_validity_input_tex", 2}, {"candidate_radiance_tex", 8 + 3}, {"candidate_hit_tex", 8 + 3}}, st));
@@ -413,7 +433,7 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
         KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_RESTIR_TEMPORAL | KEEP, s->strips[s->first + li], 0, st));
     }
     // ---- D: the one-deep halo; the spatial passes and the resolve over-compute inside it instead of exchanging again
-    KJ_SPLIT_TRY(exchange(*s, {{sfx("rtdgi.reservoir", out_i), 64}, {"temporal_reservoir_packed_tex", 64}, {sfx("rtdgi.radiance", out_i), 64}}, st));
+    KJ_SPLIT_TRY(exchange(*s, {{sfx("rtdgi.reservoir", out_i), 64, 1u}, {"temporal_reservoir_packed_tex", 64, 1u}, {sfx("rtdgi.radiance", out_i), 64, 1u}}, st));
     for (uint32_t li = 0; li < s->local; ++li) {
         const uint32_t rank = s->first + li;
         KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_RESTIR_SPATIAL | KEEP, grow(*s, rank, 64), 1, st));
@@ -483,6 +503,60 @@ KjStatus kj_split_shadow_frame(KjSplit* s, KjShadowDenoise* const* denoisers, co
         KJ_SPLIT_TRY(kj_shadow_denoise_render_rows(s->shadow[li], &frames[li].rtdgi.gbuffer_depth, mask_r8[li], frames[li].rtdgi.reprojection_map, own.first, own.second, &out_rg16f[li], st));
     }
     ++s->shadow_frames;
+    return KJ_OK;
+}
+
+// Reflections join the frame (kj_split_rtr_frame after kj_split_gi_frame): the caches reserve slot ranges for the lookups of rtr's rays, and the replay of a
+// frame's recorded cache updates moves behind rtr's ray passes (multigpu.py: SplitRtdgi.enable_rtr).
+KjStatus kj_split_set_rtr(KjSplit* s, uint32_t enable) {
+    KJ_REQUIRE(s, "null argument");
+    s->with_rtr = enable != 0;
+    if (s->consistent_ircache) for (const KjSplitRank& r : s->ranks) KJ_SPLIT_TRY(kj_ircache_set_rtr_requests(r.ircache, enable));
+    return KJ_OK;
+}
+
+// RtrRenderer::trace + LightingRenderer::render_specular + TracedRtr::filter_temporal strip by strip (kj_rtr_render_rows), after kj_split_gi_frame
+// (multigpu.py: SplitRtdgi.rtr_frame documents the reach of every pass; world_render_passes.rs:172-210). Four exchange points: the all-gather of this frame's GI
+// image (a reflection's hit reads it anywhere on screen); after the ray passes the six reservoir histories (motion + 16 half-res rows, and row 0 for everybody:
+// an empty reservoir's payload is pixel (0, 0)); after the reservoir pass the all-gather of its four outputs (the resolve's taps land where a world-space kernel
+// projects to) and the ray-length history's halo; after the temporal filter the all-gather of its output (the cleanup's taps; next frame's filter reads it at the
+// reflection's reprojected virtual position). The resolve and the lights' specular over-compute 16 rows either side instead of a fifth exchange.
+// `rtr_params`: one per local rank, as for kj_rtr_trace (pass_mask ignored). out_resolved[li] (may be NULL) is valid on the rank's own rows: all kj_light_gbuffer_rows reads.
+KjStatus kj_split_rtr_frame(KjSplit* s, KjRtr* const* rtr, const KjRtrParams* rtr_params, uint32_t flags, void* trace_done_event, const void** out_resolved, void* stream) {
+    KJ_REQUIRE(s && rtr && rtr_params, "null argument");
+    KJ_REQUIRE(s->with_rtr, "kj_split_set_rtr(split, 1) comes first (before the frame's kj_ircache_begin_requests)");
+    hipStream_t st = (hipStream_t)stream;
+    s->rtr.assign(rtr, rtr + s->local);
+    for (KjRtr* r : s->rtr) KJ_REQUIRE(r, "null RtrRenderer");
+    const bool lights = (flags & KJ_SPLIT_RTR_SPECULAR_LIGHTS) != 0, defer_merge = (flags & KJ_SPLIT_DEFER_IRCACHE_MERGE) != 0;
+    const uint32_t KEEP = KJ_RTR_PASS_KEEP, M = s->motion_halo, o = s->rtr_frames % 2, h = 1 - s->rtr_frames % 2;
+    auto run = [&](uint32_t li, uint32_t mask, std::pair<uint32_t, uint32_t> rows) {
+        KjRtrParams p = rtr_params[li];
+        p.pass_mask = mask;
+        return kj_rtr_render_rows(s->rtr[li], &p, rows.first, rows.second, out_resolved ? &out_resolved[li] : nullptr, st);
+    };
+    KJ_SPLIT_TRY(exchange(*s, {{"spatial_filtered_tex", -1}}, st));
+    for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(run(li, KJ_RTR_PASS_EXTRACT_HALF | KJ_RTR_PASS_VALIDATE | KJ_RTR_PASS_TRACE, s->strips[s->first + li]));
+    if (s->consistent_ircache && !defer_merge) KJ_SPLIT_TRY(merge_ircache_requests(*s, st));
+    if (trace_done_event) KJ_TRY_HIP(hipEventRecord((hipEvent_t)trace_done_event, st));
+    std::vector<Item> items;
+    if (s->rtr_frames > 0) {
+        for (const char* n : {"RTR/rtr.irradiance", "RTR/rtr.ray_orig", "RTR/rtr.ray", "RTR/rtr.rng", "RTR/rtr.reservoir", "RTR/rtr.hit_normal"}) items.push_back({sfx(n, h), int(M + 16), 1u});
+        KJ_SPLIT_TRY(exchange(*s, items, st));
+    }
+    for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(run(li, KJ_RTR_PASS_RESTIR_TEMPORAL | KEEP, s->strips[s->first + li]));
+    items.clear();
+    for (const char* n : {"RTR/rtr.irradiance", "RTR/rtr.ray", "RTR/rtr.reservoir", "RTR/rtr.ray_orig"}) items.push_back({sfx(n, o), -1});
+    items.push_back({"candidate_hit_tex", 8});      // the pixel's own hit distance on the rows the resolve over-computes
+    if (s->rtr_frames > 0) items.push_back({sfx("RTR/rtr.ray_len", h), int(M + 2 + 16)});
+    KJ_SPLIT_TRY(exchange(*s, items, st));
+    for (uint32_t li = 0; li < s->local; ++li) {
+        KJ_SPLIT_TRY(run(li, KJ_RTR_PASS_RESOLVE | KEEP | (lights ? KJ_RTR_PASS_SPECULAR_LIGHTS : 0u), grow(*s, s->first + li, 16)));
+        KJ_SPLIT_TRY(run(li, KJ_RTR_PASS_TEMPORAL_FILTER | KEEP, s->strips[s->first + li]));
+    }
+    KJ_SPLIT_TRY(exchange(*s, {{sfx("RTR/rtr.temporal", o), -1}}, st));
+    for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(run(li, KJ_RTR_PASS_CLEANUP | KEEP, s->strips[s->first + li]));
+    ++s->rtr_frames;
     return KJ_OK;
 }
 

@@ -24,15 +24,15 @@ EXPORTS = [
     "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_reproject_rows", "kj_rtdgi_render",
     "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_set_ray_pass_form", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
-    "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts", "kj_ircache_set_deferred_updates", "kj_ircache_begin_requests", "kj_ircache_request_ranges", "kj_ircache_collect_requests", "kj_ircache_apply_requests",
+    "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts", "kj_ircache_set_deferred_updates", "kj_ircache_begin_requests", "kj_ircache_request_ranges", "kj_ircache_collect_requests", "kj_ircache_apply_requests", "kj_ircache_set_rtr_requests", "kj_ircache_rtr_request_ranges",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
     "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_render_rows", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_trace_sun_shadow_mask_rows", "kj_light_gbuffer", "kj_light_gbuffer_rows",
     "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_render_rows", "kj_shadow_denoise_surface",
     "kj_baked_mesh_view", "kj_baked_image_view", "kj_baked_image_mip", "kj_baked_image_decode_rgba8",
-    "kj_rtr_create", "kj_rtr_destroy", "kj_rtr_set_options", "kj_rtr_trace", "kj_rtr_render_specular_lights", "kj_rtr_filter_temporal", "kj_rtr_surface", "kj_rtr_ray_counts",
+    "kj_rtr_create", "kj_rtr_destroy", "kj_rtr_set_options", "kj_rtr_trace", "kj_rtr_render_specular_lights", "kj_rtr_filter_temporal", "kj_rtr_render_rows", "kj_rtr_surface", "kj_rtr_ray_counts",
     "kj_post_create", "kj_post_destroy", "kj_post_render", "kj_post_read_back_histogram", "kj_luminance_histogram_mean_log2", "kj_post_surface", "kj_post_mip_levels",
     "kj_motion_blur_create", "kj_motion_blur_destroy", "kj_motion_blur_render", "kj_motion_blur_surface",
-    "kj_split_create", "kj_split_destroy", "kj_split_strip", "kj_split_gi_frame", "kj_split_merge_ircache", "kj_split_taa_frame", "kj_split_ssgi_frame", "kj_split_gather", "kj_split_self_test", "kj_split_shadow_frame",
+    "kj_split_create", "kj_split_destroy", "kj_split_strip", "kj_split_gi_frame", "kj_split_merge_ircache", "kj_split_taa_frame", "kj_split_ssgi_frame", "kj_split_gather", "kj_split_self_test", "kj_split_shadow_frame", "kj_split_set_rtr", "kj_split_rtr_frame",
     "kj_split_rccl_unique_id", "kj_split_rccl_comm_create", "kj_split_rccl_comm_destroy",
 ]
 
@@ -81,6 +81,8 @@ def load():
         "kj_ircache_request_ranges": [vp, C.POINTER(u32), C.POINTER(u32)],
         "kj_ircache_collect_requests": [vp, u32, u32, vp, u32, vp, vp],
         "kj_ircache_apply_requests": [vp, vp, u32, vp],
+        "kj_ircache_set_rtr_requests": [vp, u32],
+        "kj_ircache_rtr_request_ranges": [vp, C.POINTER(u32), C.POINTER(u32)],
         "kj_scene_set_blas_build_mode": [vp, u32],
         "kj_scene_set_open_instances": [vp, u32],
         "kj_scene_set_top_build_mode": [vp, u32],
@@ -124,6 +126,7 @@ def load():
         "kj_rtr_trace": [vp, C.POINTER(KjRtrParams), vp],
         "kj_rtr_render_specular_lights": [vp, C.POINTER(KjRtrParams), vp],
         "kj_rtr_filter_temporal": [vp, C.POINTER(KjRtrParams), C.POINTER(vp), vp],
+        "kj_rtr_render_rows": [vp, C.POINTER(KjRtrParams), u32, u32, C.POINTER(vp), vp],
         "kj_rtr_surface": [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)],
         "kj_rtr_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "kj_trace_sun_shadow_mask": [vp, vp, C.POINTER(KjGbufferDepth), vp, vp, vp],
@@ -152,6 +155,8 @@ def load():
         "kj_split_gather": [vp, C.c_char_p, vp],
         "kj_split_self_test": [vp, C.POINTER(C.c_uint32), vp],
         "kj_split_shadow_frame": [vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
+        "kj_split_set_rtr": [vp, u32],
+        "kj_split_rtr_frame": [vp, C.POINTER(vp), C.POINTER(KjRtrParams), u32, vp, C.POINTER(vp), vp],
         "kj_split_rccl_unique_id": [vp],
         "kj_split_rccl_comm_create": [vp, u32, u32, C.POINTER(vp)],
     }
@@ -365,9 +370,10 @@ class GpuPipeline:
         p = self.params(pass_mask)
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
 
-    def gi_frame(self, pass_mask=KJ_RTDGI_PASS["ALL"]):
+    def gi_frame(self, pass_mask=KJ_RTDGI_PASS["ALL"], defer_replay=False):
         """The GI frame in world_render_passes.rs order: ircache.prepare, trace_irradiance (:99,113-121),
-        rtdgi.reproject (:129), ircache sum-up (:138-140), rtdgi.render (:145-163)."""
+        rtdgi.reproject (:129), ircache sum-up (:138-140), rtdgi.render (:145-163). `defer_replay` (deferred cache updates): the caller
+        replays the frame's records itself (ircache_replay_own_requests) -- after rtr_frame, whose rays look the cache up as well."""
         s = _stream_ptr()
         deferred = self.ircache and getattr(self, "ircache_deferred", False)
         if self.ircache:
@@ -380,7 +386,7 @@ class GpuPipeline:
             check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
         p = self.params(pass_mask)
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
-        if deferred:
+        if deferred and not defer_replay:
             self.ircache_replay_own_requests()
 
     # ---- frame pipelining (async compute). The irradiance cache's maintenance + ray kernels of frame N+1 only depend on
@@ -477,6 +483,15 @@ class GpuPipeline:
         check(self.L.kj_ircache_request_ranges(self.ircache, first, count))
         return list(first), list(count)
 
+    def ircache_set_rtr_requests(self, enable=True):
+        """Reflections bound to a cache in deferred mode record their lookups in two slot ranges of their own (set before ircache_begin_requests)."""
+        check(self.L.kj_ircache_set_rtr_requests(self.ircache, int(enable)))
+
+    def ircache_rtr_request_ranges(self):
+        first, count = (C.c_uint32 * 2)(), (C.c_uint32 * 2)()
+        check(self.L.kj_ircache_rtr_request_ranges(self.ircache, first, count))
+        return list(first), list(count)
+
     def ircache_collect(self, ranges, capacity=None, tag="all"):
         """Compacts the recorded requests of the slot ranges [(first, count), ...] into one device list; returns (int32 tensor
         [capacity, 8], device int32 counter). 32 bytes per request. The list buffer is cached per (`tag`, capacity): two lists that
@@ -504,7 +519,8 @@ class GpuPipeline:
     def ircache_replay_own_requests(self):
         """Single GPU in deferred mode: everything this frame's lookups recorded, replayed in the canonical order."""
         first, count = self.ircache_request_ranges()
-        buf, cnt = self.ircache_collect(list(zip(first, count)))
+        f2, c2 = self.ircache_rtr_request_ranges()       # (empty unless the frame has reflections: ircache_set_rtr_requests)
+        buf, cnt = self.ircache_collect(list(zip(first + f2, count + c2)))
         self.ircache_apply(buf, int(cnt.item()))
 
     def taa_frame(self, input_ptr=None, out_extent=None):
@@ -555,15 +571,20 @@ class GpuPipeline:
         p.pass_mask = pass_mask
         return p
 
-    def rtr_frame(self, pass_mask=63, tables=None, specular_lights=False):
-        """RtrRenderer::trace + TracedRtr::filter_temporal after rtdgi.render (same stream). Returns the resolved
-        B10G11R11_UFLOAT image as an int32 (H, W) tensor view. `tables`: KjRtrTables (default: rtr_tables.standin_tables())."""
+    def rtr_handle(self, tables=None):
+        """The RtrRenderer of this pipeline, made on first use. `tables`: KjRtrTables (default: rtr_tables.standin_tables())."""
         if getattr(self, "rtr", None) is None:
             if tables is None:
                 from . import rtr_tables
                 tables, self._rtr_keep = rtr_tables.standin_tables()
             self.rtr = C.c_void_p()
             check(self.L.kj_rtr_create(self.dev.h, C.byref(tables), C.byref(self.rtr)))
+        return self.rtr
+
+    def rtr_frame(self, pass_mask=63, tables=None, specular_lights=False):
+        """RtrRenderer::trace + TracedRtr::filter_temporal after rtdgi.render (same stream). Returns the resolved
+        B10G11R11_UFLOAT image as an int32 (H, W) tensor view. `tables`: KjRtrTables (default: rtr_tables.standin_tables())."""
+        self.rtr_handle(tables)
         p = self.rtr_params(pass_mask)
         s = _stream_ptr()
         out = C.c_void_p()

@@ -47,6 +47,10 @@ SSGI_SURF = {"ssgi": 2, "filtered_output_tex": 1}
 GUIDE_HALO = 144
 # ShadowDenoiseRenderer surfaces the split exchanges (full-res): the temporal pass' two histories (RGBA16F moments, RG16F accumulated term)
 SHADOW_SURF = {"shadow_denoise_moments": 8, "shadow_denoise_accum": 4}
+# RtrRenderer's eight ping-pong temporals (rtr.rs:36-52): name -> (bytes per texel, resolution)
+RTR_SURF = {"rtr.temporal": (8, "f"), "rtr.ray_len": (4, "f"), "rtr.irradiance": (8, "h"), "rtr.ray_orig": (16, "h"), "rtr.ray": (8, "h"), "rtr.reservoir": (8, "h"),
+            "rtr.rng": (4, "h"), "rtr.hit_normal": (8, "h")}
+RTR_PASS = {"TRACE": 1, "VALIDATE": 2, "RESTIR_TEMPORAL": 4, "RESOLVE": 8, "TEMPORAL_FILTER": 16, "CLEANUP": 32, "EXTRACT_HALF": 64, "SPECULAR_LIGHTS": 128}
 
 
 def plan_strips(height, n):
@@ -68,9 +72,10 @@ def half_rows(r0, r1, height):
     return r0 // 2, (hh if r1 == height else r1 // 2)
 
 
-def transfers(strips, halo, res, height):
+def transfers(strips, halo, res, height, pin=0):
     """[(src_rank, dst_rank, row0, row1)] in the surface's own resolution so that every rank holds rows
-    [own0 - halo, own1 + halo) after the exchange (halo=None: all rows = all-gather)."""
+    [own0 - halo, own1 + halo) after the exchange (halo=None: all rows = all-gather). `pin`: every rank also holds the image's first `pin`
+    rows (an empty reservoir's payload is pixel (0, 0): rtr's reservoir pass follows it into the histories, rtr_restir_temporal.hlsl:383-392)."""
     n = len(strips)
     own = [half_rows(a, b, height) if res == "h" else (a, b) for a, b in strips]
     total = (height + 1) // 2 if res == "h" else height
@@ -78,12 +83,16 @@ def transfers(strips, halo, res, height):
     for dst in range(n):
         lo = 0 if halo is None else max(0, own[dst][0] - halo)
         hi = total if halo is None else min(total, own[dst][1] + halo)
-        for src in range(n):
-            if src == dst:
-                continue
-            a, b = max(lo, own[src][0]), min(hi, own[src][1])
-            if b > a:
-                out.append((src, dst, a, b))
+        spans = [(lo, hi)]
+        if pin > 0:
+            spans = [(0, max(hi, min(pin, total)))] if lo <= pin else [(0, min(pin, total)), (lo, hi)]
+        for lo2, hi2 in spans:
+            for src in range(n):
+                if src == dst:
+                    continue
+                a, b = max(lo2, own[src][0]), min(hi2, own[src][1])
+                if b > a:
+                    out.append((src, dst, a, b))
     return out
 
 
@@ -252,6 +261,8 @@ class SplitRtdgi:
         self.taa_frames = 0
         self.ssgi_frames = 0
         self.shadow_frames = 0
+        self.rtr_frames = 0
+        self.with_rtr = False
         self._views = {}
         self._plans = {}
         self._params = {}
@@ -281,6 +292,9 @@ class SplitRtdgi:
                 return gp.shadow_mask_img            # the caller's image (shadow_frame): not cached, it may change between frames
             elif name.startswith("SHADOW/"):
                 t = gp.shadow_denoise_surface(name[7:], torch.uint8, (self.H, self.W * SHADOW_SURF[name[7:].split(":")[0]]))
+            elif name.startswith("RTR/"):
+                bpt, res = RTR_SURF[name[4:].split(":")[0]]
+                t = gp.rtr_surface(name[4:], torch.uint8, ((self.H + 1) // 2, (self.W + 1) // 2 * bpt) if res == "h" else (self.H, self.W * bpt))
             else:
                 bpt, res = SURF[name.split(":")[0]]
                 w = (self.W + 1) // 2 if res == "h" else self.W
@@ -293,15 +307,16 @@ class SplitRtdgi:
         return self._surface(rank, name)[a:b]
 
     def _exchange(self, items):
-        """items: [(surface name, halo rows or None)] -- ONE batched exchange for all of them (a single RCCL group:
+        """items: [(surface name, halo rows or None[, pinned top rows])] -- ONE batched exchange for all of them (a single RCCL group:
         both ends enumerate (item, dst, src) in the same order, so per-pair send/recv order matches)."""
         key = tuple(items)
         prepared = self._plans.get(key)
         if prepared is None:
             xfers = []
-            for name, halo in items:
-                res = "f" if name.startswith(("TAA/", "SSGI/", "SHADOW/")) else SURF[name.split(":")[0]][1]
-                xfers += [(src, dst, (name, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H)]
+            for item in items:
+                name, halo, pin = item if len(item) == 3 else (item[0], item[1], 0)
+                res = RTR_SURF[name[4:].split(":")[0]][1] if name.startswith("RTR/") else "f" if name.startswith(("TAA/", "SSGI/", "SHADOW/")) else SURF[name.split(":")[0]][1]
+                xfers += [(src, dst, (name, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H, pin)]
             # renderer surfaces keep their address for a given extent, so the row views can be resolved once per distinct item list
             # (two per exchange point: the ping-pong suffixes alternate)
             prepared = self.comm.prepare(xfers, lambda r, na, b: self._rows_view(r, na[0], na[1], b))
@@ -481,6 +496,65 @@ class SplitRtdgi:
         self.shadow_frames += 1
         return out
 
+    def enable_rtr(self, tables=None):
+        """Reflections join the frame (rtr_frame after gi_frame): every rank gets its RtrRenderer, the caches reserve slot ranges for the lookups of rtr's
+        rays (kj_ircache_set_rtr_requests), and the replay of a frame's recorded cache updates moves behind rtr's ray passes."""
+        self.with_rtr = True
+        for gp in self.pipes.values():
+            gp.rtr_handle(tables)
+            if gp.ircache and self.consistent_ircache:
+                gp.ircache_set_rtr_requests(True)
+
+    def rtr_frame(self, specular_lights=False, trace_event=None, defer_merge=False):
+        """RtrRenderer::trace + LightingRenderer::render_specular + TracedRtr::filter_temporal strip by strip (kj_rtr_render_rows), after gi_frame
+        (world_render_passes.rs:172-210). Reach of the passes and what travels for it:
+          X1  before the ray passes   ALL-GATHER of this frame's GI image: a reflection ray's hit reads it at the hit's screen position, anywhere
+                                      (reflection_trace_common.inc.hlsl:159-166). Validate rewrites the reservoir histories of its own quads in place.
+          X2  after the ray passes    the six reservoir histories: motion + the search's 1 + the taps' 14 half-res rows (rtr_restir_temporal.hlsl:
+                                      232-262,383-390), and row 0 for everybody -- an empty reservoir's payload is pixel (0, 0), and the pass follows it
+          X3  after the reservoir pass  ALL-GATHER of {irradiance, ray, reservoir, ray origin}: the resolve's taps land where a world-space kernel
+                                      projects to (resolve.hlsl:296-330: up to a tenth of the frustum's height at the surface's depth, times perspective);
+                                      the ray-length history's motion halo; 8 half-res rows of the hit image the trace pass just wrote (the resolve reads
+                                      the pixel's own hit distance from it, :112). The resolve (and the lights' specular) over-computes 16 rows either side: the
+                                      temporal filter's 3x3 moments read them.
+          X4  after the temporal filter  ALL-GATHER of its output: the cleanup's taps reach 24 rows, and next frame's filter reads this image at the
+                                      reflection's reprojected virtual position -- anywhere (temporal_filter.hlsl:60-84).
+        Each rank's resolved image (what light_gbuffer reads, at the pixel itself) is valid on its own rows. Returns {rank: int32 (H, W) view}."""
+        assert self.with_rtr, "enable_rtr() first"
+        M, R = self.motion_halo, self.comm.ranks
+        k = self.rtr_frames
+        o, h = f":{k % 2}", f":{1 - k % 2}"
+        s = klib._stream_ptr()
+        P = RTR_PASS
+        params = {r: self.pipes[r].rtr_params(0) for r in R}
+
+        def run(r, mask, rows):
+            p = params[r]
+            p.pass_mask = mask
+            klib.check(self.pipes[r].L.kj_rtr_render_rows(self.pipes[r].rtr, C.byref(p), rows[0], rows[1], None, s))
+        self._exchange([("spatial_filtered_tex", None)])
+        for r in R:
+            run(r, P["EXTRACT_HALF"] | P["VALIDATE"] | P["TRACE"], self.strips[r])
+        if self.consistent_ircache and not defer_merge:
+            self._merge_ircache_requests()
+        if trace_event is not None:
+            import torch
+            trace_event.record(torch.cuda.current_stream())
+        if k > 0:
+            self._exchange([(f"RTR/{n}{h}", M + 16, 1) for n in ("rtr.irradiance", "rtr.ray_orig", "rtr.ray", "rtr.rng", "rtr.reservoir", "rtr.hit_normal")])
+        for r in R:
+            run(r, P["RESTIR_TEMPORAL"] | KEEP, self.strips[r])
+        self._exchange([(f"RTR/{n}{o}", None) for n in ("rtr.irradiance", "rtr.ray", "rtr.reservoir", "rtr.ray_orig")] + [("candidate_hit_tex", 8)] + ([(f"RTR/rtr.ray_len{h}", M + 2 + 16)] if k > 0 else []))
+        for r in R:
+            run(r, P["RESOLVE"] | KEEP | (P["SPECULAR_LIGHTS"] if specular_lights else 0), self._grow(r, 16))
+            run(r, P["TEMPORAL_FILTER"] | KEEP, self.strips[r])
+        self._exchange([(f"RTR/rtr.temporal{o}", None)])
+        for r in R:
+            run(r, P["CLEANUP"] | KEEP, self.strips[r])
+        self.rtr_frames += 1
+        import torch
+        return {r: self.pipes[r].rtr_surface("resolved_tex", torch.int32, (self.H, self.W)) for r in R}
+
     def gi_frame(self, ircache_done=False, trace_event=None, defer_merge=False):
         """One rtdgi frame. Unless `ircache_done`, each rank's ircache.prepare + trace_irradiance run here first (serial order).
         `defer_merge`: leave the replay of the cache's recorded updates to the caller (frame_pipelined runs it on the side stream
@@ -524,12 +598,14 @@ class SplitRtdgi:
         # ---- B
         items = [("rt_history_validity_pre_input_tex", M + 1)]
         if self.frame > 0:
-            items += [(n + hist_sfx, M + 4) for n in ("rtdgi.reservoir", "rtdgi.ray_orig", "rtdgi.ray", "rtdgi.radiance", "rtdgi.hit_normal")]
+            # (row 0 for everybody: a reservoir nothing was ever selected into -- a validation frame without an accepted history tap -- keeps payload 0,
+            # pixel (0, 0), and the temporal pass follows the payload into the four sample images whatever the reservoir's weight: restir_temporal.hlsl:262-275)
+            items += [("rtdgi.reservoir" + hist_sfx, M + 4)] + [(n + hist_sfx, M + 4, 1) for n in ("rtdgi.ray_orig", "rtdgi.ray", "rtdgi.radiance", "rtdgi.hit_normal")]
             items += [("rtdgi.invalidity" + hist_sfx, M + 8)]
         self._exchange(items)
         for r in R:
             self._render(r, P["TRACE"] | KEEP, self.strips[r])
-        if self.consistent_ircache and not defer_merge:
+        if self.consistent_ircache and not defer_merge and not self.with_rtr:      # (with reflections in the frame the replay follows THEIR ray passes: rtr_frame)
             self._merge_ircache_requests()
         if trace_event is not None:
             import torch
@@ -541,7 +617,8 @@ class SplitRtdgi:
             self._render(r, P["RESTIR_TEMPORAL"] | KEEP, self.strips[r])
         # ---- D: the one-deep halo. Reach (half-res rows): pass 0 runs on own+-32 and taps +-32; pass 1 runs on own+-16, taps +-16
         # and follows payloads another +-32; the resolve runs on own+-8, taps +-3 and follows payloads +-48.
-        self._exchange([("rtdgi.reservoir" + out_sfx, 64), ("temporal_reservoir_packed_tex", 64), ("rtdgi.radiance" + out_sfx, 64)])
+        # (and row 0: the payload of an empty reservoir is pixel (0, 0) here too)
+        self._exchange([("rtdgi.reservoir" + out_sfx, 64, 1), ("temporal_reservoir_packed_tex", 64, 1), ("rtdgi.radiance" + out_sfx, 64, 1)])
         for r in R:
             self._render(r, P["RESTIR_SPATIAL"] | KEEP, self._grow(r, 64), spatial_select=1)
             self._render(r, P["RESTIR_SPATIAL"] | KEEP, self._grow(r, 32), spatial_select=2)
@@ -555,8 +632,8 @@ class SplitRtdgi:
 
     def _merge_ircache_requests(self):
         """All-gather of this frame's recorded cache updates, then the same replay on every rank. A strip's rtdgi lookups (validate and
-        trace pass) occupy contiguous slots (rows of the half-res image); the cache's own ray passes are replicated, so their records
-        are identical on every rank and stay local."""
+        trace pass) -- and, with reflections in the frame, rtr's (validate and trace rays) -- occupy contiguous slots (rows of the half-res
+        image); the cache's own ray passes are replicated, so their records are identical on every rank and stay local."""
         import torch
         hw = (self.W + 1) // 2
         strip_lists, irc_lists = {}, {}
@@ -564,7 +641,8 @@ class SplitRtdgi:
             gp = self.pipes[r]
             first, count = gp.ircache_request_ranges()
             h0, h1 = half_rows(*self.strips[r], self.H)
-            strip_lists[r] = gp.ircache_collect([(first[0] + h0 * hw, (h1 - h0) * hw), (first[1] + h0 * hw, (h1 - h0) * hw)], capacity=2 * (h1 - h0) * hw, tag="strip")
+            bases = [first[0], first[1]] + (gp.ircache_rtr_request_ranges()[0] if self.with_rtr else [])
+            strip_lists[r] = gp.ircache_collect([(b + h0 * hw, (h1 - h0) * hw) for b in bases], capacity=len(bases) * (h1 - h0) * hw, tag="strip")
             irc_lists[r] = gp.ircache_collect([(first[2], count[2]), (first[3], count[3])], capacity=count[2] + count[3], tag="cache passes")
         gathered = self.comm.all_gather_rows({r: (buf, int(cnt.item())) for r, (buf, cnt) in strip_lists.items()})
         for r in self.comm.ranks:
@@ -636,6 +714,7 @@ class NativeSplit:
         self.consistent_ircache = all(gp.ircache for gp in pipes.values())
         for gp in pipes.values():
             gp.ircache_deferred = bool(gp.ircache) and self.consistent_ircache
+        self.with_rtr = False
 
     def __del__(self):
         try:
@@ -717,6 +796,35 @@ class NativeSplit:
         klib.check(self.L.kj_split_ssgi_frame(self.h, handles, self._frames, outs, klib._stream_ptr()))
         for i, r in enumerate(self.ranks):
             self.pipes[r].ssao_ptr = C.c_void_p(outs[i])
+
+    def enable_rtr(self, tables=None):
+        """Reflections join the frame (kj_split_set_rtr; SplitRtdgi.enable_rtr is the reference)."""
+        self.with_rtr = True
+        for gp in self.pipes.values():
+            gp.rtr_handle(tables)
+        klib.check(self.L.kj_split_set_rtr(self.h, 1))
+
+    def rtr_frame(self, specular_lights=False, trace_event=None, defer_merge=False):
+        """kj_split_rtr_frame: reflections strip by strip after gi_frame (SplitRtdgi.rtr_frame is the reference). Returns {rank: int32 (H, W) view of the
+        resolved image, valid on the rank's own rows}."""
+        import torch
+        from .abi import KjRtrParams
+        n = len(self.ranks)
+        handles, outs, params = (C.c_void_p * n)(), (C.c_void_p * n)(), (KjRtrParams * n)()
+        for i, r in enumerate(self.ranks):
+            handles[i] = self.pipes[r].rtr_handle().value
+            params[i] = self.pipes[r].rtr_params(0)
+        handle = None
+        if trace_event is not None:
+            try:
+                trace_event.record()
+                handle = int(trace_event.cuda_event)
+            except Exception:
+                handle = None
+        klib.check(self.L.kj_split_rtr_frame(self.h, handles, params, (1 if specular_lights else 0) | (2 if defer_merge else 0), handle, outs, klib._stream_ptr()))
+        if trace_event is not None and handle is None:
+            trace_event.record()
+        return {r: self.pipes[r].rtr_surface("resolved_tex", torch.int32, (self.H, self.W)) for r in self.ranks}
 
     def shadow_frame(self, masks=None, ray_counters=None):
         """kj_split_shadow_frame: the sun shadow mask + its denoiser strip by strip (SplitRtdgi.shadow_frame is the reference). Returns {rank: RG16F

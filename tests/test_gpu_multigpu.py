@@ -297,3 +297,89 @@ def test_strip_split_sun_shadows_are_bit_exact(gpu, device, n_ranks, W, H):
     torch.cuda.synchronize()
     for k in range(2):
         assert torch.equal(whole2[k].view(torch.int16), ref._lit[k].view(torch.int16)), "light_gbuffer strip by strip differs from the whole-frame combine"
+
+
+RTR_HALF = ("rtr.irradiance", "rtr.ray_orig", "rtr.ray", "rtr.reservoir", "rtr.rng", "rtr.hit_normal")
+RTR_FULL = ("rtr.temporal", "rtr.ray_len")
+
+
+def _rtr_own_rows_equal(ref, gp, strip, fi, H, torch, what):
+    """Every surface of RtrRenderer on a rank's own rows against the unsplit frame: the eight ping-pong outputs of frame `fi`, the
+    invalidity image, the resolved image light_gbuffer reads."""
+    a, b = strip
+    ha, hb = a // 2, ((H + 1) // 2 if b == H else b // 2)
+    hh = (H + 1) // 2
+    for name in RTR_HALF + ("refl_restir_invalidity_tex",):
+        n = name if name.startswith("refl") else f"{name}:{fi % 2}"
+        x, y = ref.rtr_surface(n, torch.uint8, (hh, -1)), gp.rtr_surface(n, torch.uint8, (hh, -1))
+        neq = (x[ha:hb] != y[ha:hb]).any(dim=1)
+        assert not bool(neq.any()), f"{what}: {n} differs on half-res rows {(torch.nonzero(neq).flatten()[:8] + ha).tolist()} of [{ha}, {hb})"
+    for name in RTR_FULL + ("resolved_tex",):
+        n = name if name == "resolved_tex" else f"{name}:{fi % 2}"
+        x, y = ref.rtr_surface(n, torch.uint8, (H, -1)), gp.rtr_surface(n, torch.uint8, (H, -1))
+        neq = (x[a:b] != y[a:b]).any(dim=1)
+        assert not bool(neq.any()), f"{what}: {n} differs on rows {(torch.nonzero(neq).flatten()[:8] + a).tolist()} of [{a}, {b})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,W,H,with_cache,lights", [(2, 256, 160, False, False), (3, 320, 208, True, False), (2, 192, 416, True, True), (8, 192, 256, False, False)])
+def test_strip_split_reflections_are_bit_exact(gpu, device, n_ranks, W, H, with_cache, lights):
+    """RtrRenderer::trace + render_specular + filter_temporal strip by strip (SURVEY 8f-3 under the screen-tile split; VERDICT r2 missing #5): both
+    orchestrators (SplitRtdgi.rtr_frame, kj_split_rtr_frame) against the unsplit passes over frames with a moving camera -- on every rank's own rows all
+    eight ping-pong temporals, the invalidity image and the resolved image bit for bit, the rtdgi candidates the trace pass overwrites, and with the
+    cache bound every cache buffer (rtr's rays record their lookups in slot ranges of their own; the replay follows them). 192x416 on two ranks: strips
+    taller than every halo, with triangle lights (the lights' specular pass)."""
+    import torch
+    from kajiya_amd import multigpu, frame, scenes as S
+    desc = S.glossy_test_scene()
+    scene = gpu.Scene(device, desc, use_lights=lights)
+    ref = gpu.GpuPipeline(device, scene, W, H, use_ircache=with_cache)
+    if with_cache:
+        ref.ircache_set_deferred(True)
+        ref.ircache_set_rtr_requests(True)
+    splits = {}
+    for tag in ("python", "native"):
+        pipes = {r: gpu.GpuPipeline(device, scene, W, H, use_ircache=with_cache) for r in range(n_ranks)}
+        sp = multigpu.SplitRtdgi(multigpu.LocalComm(n_ranks), pipes, W, H, motion_halo=8) if tag == "python" else multigpu.NativeSplit(n_ranks, pipes, W, H, motion_halo=8)
+        sp.enable_rtr()
+        splits[tag] = (sp, pipes)
+    strips = splits["python"][0].strips
+    fs = frame.FrameState((W, H))
+    fs.ircache_enabled = with_cache
+    fs.triangle_light_count = scene.triangle_light_count if lights else 0
+    for fi in range(6):
+        fc = fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 1.5, 0.0), radius=9.0, height=3.5, rate=0.008))
+        fs.retire_frame()
+        ref.render_inputs(fc); ref.reprojection()
+        ref.gi_frame(defer_replay=True)
+        ref.rtr_frame(specular_lights=lights)
+        if with_cache:
+            ref.ircache_replay_own_requests()
+        for tag, (sp, pipes) in splits.items():
+            for r in range(n_ranks):
+                pipes[r].render_inputs(fc)
+                pipes[r].reprojection()
+            sp.gi_frame()
+            sp.rtr_frame(specular_lights=lights)
+        torch.cuda.synchronize()
+        hh = (H + 1) // 2
+        for tag, (sp, pipes) in splits.items():
+            for r in range(n_ranks):
+                # (the GI image first: this scene found the rtdgi split's own row-0 dependence -- a reservoir no history tap was selected into on a
+                # validation frame keeps payload 0, and next frame's temporal pass follows it to pixel (0, 0) of the sample images, which here is geometry)
+                x, y = ref.surface("spatial_filtered_tex", torch.uint8, (H, -1)), pipes[r].surface("spatial_filtered_tex", torch.uint8, (H, -1))
+                assert torch.equal(x[strips[r][0]:strips[r][1]], y[strips[r][0]:strips[r][1]]), f"frame {fi} rank {r} ({tag}): the GI image differs"
+                _rtr_own_rows_equal(ref, pipes[r], strips[r], fi, H, torch, f"frame {fi} rank {r} ({tag})")
+                ha, hb = strips[r][0] // 2, (hh if strips[r][1] == H else strips[r][1] // 2)
+                for n in ("candidate_radiance_tex", "candidate_hit_tex", "candidate_normal_tex"):
+                    x, y = ref.surface(n, torch.uint8, (hh, -1)), pipes[r].surface(n, torch.uint8, (hh, -1))
+                    assert torch.equal(x[ha:hb], y[ha:hb]), f"frame {fi} rank {r} ({tag}): {n} differs"
+                if with_cache:
+                    for name in IRC_BUFS:
+                        x, y = ref.ircache_buffer(name, torch.uint8), pipes[r].ircache_buffer(name, torch.uint8)
+                        assert torch.equal(x, y), f"frame {fi} rank {r} ({tag}): ircache buffer {name} differs in {int((x != y).sum())} bytes"
+    closest, any_hit = ref.rtr_ray_counts()
+    assert closest > 0
+    assert (scene.triangle_light_count > 0) == lights
+    if with_cache:
+        assert ref.ircache_buffer("meta", torch.int32).cpu().numpy()[3] > 20     # the cache did allocate entries
