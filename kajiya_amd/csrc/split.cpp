@@ -601,7 +601,7 @@ KjStatus kj_split_self_test(KjSplit* s, uint32_t* out_passed, void* stream) {
     const int M = int(s->motion_halo);
     const std::vector<std::vector<Item>> rounds = {
         {{"selftest.f8", -1}},
-        {{"selftest.h16", M + 4}, {"selftest.h1", M + 1}, {"selftest.f8", M + 3}, {"selftest.f4", M + 2 + 16}},
+        {{"selftest.h16", M + 4, 1u}, {"selftest.h1", M + 1}, {"selftest.f8", M + 3}, {"selftest.f4", M + 2 + 16}},      // (h16: with row 0 pinned for everybody)
         {{"selftest.h16", 64}, {"selftest.f4", 16}},
         {{"selftest.f8", 1 + 24}, {"selftest.h1", 2}},
     };
@@ -644,10 +644,11 @@ KjStatus kj_split_self_test(KjSplit* s, uint32_t* out_passed, void* stream) {
                 const auto own = rows_of(s->first + li, si->half);
                 const int halo = rounds[ri][ii].halo;
                 const uint32_t lo = halo < 0 ? 0u : uint32_t(std::max<int64_t>(0, int64_t(own.first) - halo)), hi = halo < 0 ? total : std::min<uint32_t>(total, own.second + uint32_t(halo));
+                const uint32_t pin = std::min(rounds[ri][ii].pin, total);
                 for (uint32_t row = 0; row < total && ok; ++row) {
                     uint32_t owner = 0;
                     while (owner + 1 < s->world && row >= rows_of(owner, si->half).second) ++owner;
-                    const uint8_t want = row >= lo && row < hi ? uint8_t(((owner + 1) * 8 + ii) & 0xff) : uint8_t(0);
+                    const uint8_t want = (row >= lo && row < hi) || row < pin ? uint8_t(((owner + 1) * 8 + ii) & 0xff) : uint8_t(0);
                     const uint8_t* r = &host[size_t(row) * rb];
                     for (uint32_t x = 0; x < rb; ++x) if (r[x] != want) { ok = false; break; }
                 }

@@ -338,8 +338,8 @@ class SplitRtdgi:
         n = self.comm.n
         dev = device or next(iter(self.pipes.values())).depth.device
         M = self.motion_halo
-        plans = [("all-gather, full res, 8 B", "f", 8, None), ("motion halo, half res, 16 B", "h", 16, M + 4), ("one-deep halo, half res, 16 B", "h", 16, 64),
-                 ("stencil halo, full res, 8 B", "f", 8, 16), ("TAA input halo, full res, 8 B", "f", 8, 25), ("validity halo, half res, 1 B", "h", 1, M + 1)]
+        plans = [("all-gather, full res, 8 B", "f", 8, None, 0), ("motion halo + row 0 for everybody, half res, 16 B", "h", 16, M + 4, 1), ("one-deep halo, half res, 16 B", "h", 16, 64, 0),
+                 ("stencil halo, full res, 8 B", "f", 8, 16, 0), ("TAA input halo, full res, 8 B", "f", 8, 25, 0), ("validity halo, half res, 1 B", "h", 1, M + 1, 0)]
         ok = True
         owner_of = {}
         for res in ("h", "f"):
@@ -349,7 +349,7 @@ class SplitRtdgi:
                 a2, b2 = half_rows(a, b, self.H) if res == "h" else (a, b)
                 o[a2:b2] = r + 1
             owner_of[res] = o.to(dev)
-        for k, (what, res, bpt, halo) in enumerate(plans):
+        for k, (what, res, bpt, halo, pin) in enumerate(plans):
             h = (self.H + 1) // 2 if res == "h" else self.H
             w = ((self.W + 1) // 2 if res == "h" else self.W) * bpt
             scratch = {}
@@ -359,7 +359,7 @@ class SplitRtdgi:
                 a2, b2 = half_rows(a, b, self.H) if res == "h" else (a, b)
                 t[a2:b2] = (r + 1) * 8 + k            # the owner's pattern; every other row stays 0 until the exchange fills it
                 scratch[r] = t
-            xfers = [(src, dst, (k, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H)]
+            xfers = [(src, dst, (k, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H, pin)]
             self.comm.run_prepared(self.comm.prepare(xfers, lambda r, na, b: scratch[r][na[1]:b]))
             for r in self.comm.ranks:
                 a, b = self.strips[r]
@@ -367,7 +367,9 @@ class SplitRtdgi:
                 lo, hi = (0, h) if halo is None else (max(0, a2 - halo), min(h, b2 + halo))
                 expect = (owner_of[res][lo:hi].to(torch.int32) * 8 + k).to(torch.uint8)
                 good = bool((scratch[r][lo:hi] == expect[:, None]).all().item())
-                outside = bool((scratch[r][:lo] == 0).all().item()) and bool((scratch[r][hi:] == 0).all().item())
+                p0 = min(pin, lo)                      # the pinned top rows, where they are not inside [lo, hi) anyway
+                good = good and bool((scratch[r][:p0] == (owner_of[res][:p0].to(torch.int32) * 8 + k).to(torch.uint8)[:, None]).all().item())
+                outside = bool((scratch[r][p0:lo] == 0).all().item()) and bool((scratch[r][hi:] == 0).all().item())
                 if not (good and outside):
                     ok = False
                     import sys

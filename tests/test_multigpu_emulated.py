@@ -201,3 +201,98 @@ def test_compiled_transport_self_test_notices_a_damaged_message(world, corrupt):
         p.join(timeout=60)
     assert sorted(got) == list(range(world))
     assert all(v is (corrupt is None) for v in got.values()), got
+
+
+def _rtr_worker(rank, world, port, W, H, frames, q, native):
+    try:
+        os.environ["KJ_HIP_EMU"] = "fast"
+        os.environ.setdefault("HIP_EMU_WORKERS", "4")
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "hip_emu"))
+        import build_emu, cpu_as_cuda
+        cpu_as_cuda.install(build_emu.build())
+        import torch
+        import torch.distributed as dist
+        from kajiya_amd import lib, multigpu, scenes as S, frame as kframe
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = lib.Device(0)
+        scene = lib.Scene(dev, S.glossy_test_scene())
+        ref = lib.GpuPipeline(dev, scene, W, H, use_ircache=True)
+        pipe = lib.GpuPipeline(dev, scene, W, H, use_ircache=True)
+        ref.ircache_set_deferred(True)
+        ref.ircache_set_rtr_requests(True)
+        if native:
+            os.environ["KJ_RCCL_LIB"] = build_rccl_stub()
+            comm = multigpu.NativeSplit.rccl_comm_from_torch(dist, rank, world, "cuda:0")
+            split = multigpu.NativeSplit(world, {rank: pipe}, W, H, motion_halo=8, nccl_comm=comm)
+            assert split.self_test(dist) is True
+            own = split.strip(rank)
+        else:
+            split = multigpu.SplitRtdgi(multigpu.DistComm(dist, rank, world), {rank: pipe}, W, H, motion_halo=8)
+            own = split.strips[rank]
+        split.enable_rtr()
+        fs = kframe.FrameState((W, H))
+        fs.ircache_enabled = True
+        worst = 0
+        a, b = own
+        hh = (H + 1) // 2
+        ha, hb = a // 2, (hh if b == H else b // 2)
+        for fi in range(frames):
+            fc = fs.prepare_frame_constants(kframe.orbit_camera(fi, (W, H), center=(0.0, 1.5, 0.0), radius=9.0, height=3.5, rate=0.008))
+            fs.retire_frame()
+            ref.render_inputs(fc); ref.reprojection()
+            ref.gi_frame(defer_replay=True)
+            ref.rtr_frame()
+            ref.ircache_replay_own_requests()
+            pipe.render_inputs(fc); pipe.reprojection()
+            split.gi_frame()
+            split.rtr_frame()
+            x, y = ref.rtr_surface("resolved_tex", torch.int32, (H, W)), pipe.rtr_surface("resolved_tex", torch.int32, (H, W))
+            worst = max(worst, int((x[a:b] != y[a:b]).sum()))
+            for n, rows, lo, hi in ((f"rtr.temporal:{fi % 2}", H, a, b), (f"rtr.reservoir:{fi % 2}", hh, ha, hb), (f"rtr.irradiance:{fi % 2}", hh, ha, hb)):
+                x, y = ref.rtr_surface(n, torch.uint8, (rows, -1)), pipe.rtr_surface(n, torch.uint8, (rows, -1))
+                worst = max(worst, int((x[lo:hi] != y[lo:hi]).sum()))
+            for name in ("meta", "grid_meta", "entry_cell", "irradiance", "life", "pool", "reposition_proposal", "reposition_proposal_count"):
+                worst = max(worst, int((ref.ircache_buffer(name, torch.uint8) != pipe.ircache_buffer(name, torch.uint8)).sum()))
+        q.put((rank, worst, pipe.rtr_ray_counts(), ref.rtr_ray_counts(), own))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None, None))
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs ROCm's clang++ as the host compiler")
+@pytest.mark.parametrize("world,native", [(2, False), (3, True)])
+def test_reflections_split_over_processes_with_the_real_kernels(world, native):
+    """SplitRtdgi.rtr_frame over DistComm / kj_split_rtr_frame over the socket stand-in for RCCL, one process per rank: the three all-gathers, the history
+    halos with their pinned row 0, rtr's cache records in the merged replay. On its own rows every rank holds the unsplit frame's resolved image and
+    reservoir state, every replica of the cache equals the single-GPU cache, and the strips' reflection rays add up to the unsplit frame's."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hip_emu"))
+    env_before = os.environ.get("KJ_HIP_EMU")
+    os.environ["KJ_HIP_EMU"] = "fast"
+    try:
+        import build_emu
+        build_emu.build()
+        if native:
+            build_rccl_stub()
+    finally:
+        if env_before is None:
+            os.environ.pop("KJ_HIP_EMU", None)
+        else:
+            os.environ["KJ_HIP_EMU"] = env_before
+    W, H, frames = 128, 96 if world == 2 else 144, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rtr_worker, args=(r, world, port, W, H, frames, q, native)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert not [r for r in results if r[1] == "error"], "\n".join(str(r[2]) for r in results if r[1] == "error")
+    results.sort()
+    assert [r[1] for r in results] == [0] * world, results
+    total = results[0][3]
+    assert (sum(r[2][0] for r in results), sum(r[2][1] for r in results)) == tuple(total) and total[0] > 0, results      # (ray counters of the LAST frame)

@@ -128,6 +128,17 @@ def test_transfer_plan_is_symmetric_and_minimal():
     assert sum(b - a for _, _, a, b in x) == 16 * 2 * 7
     xa = multigpu.transfers(st, None, "f", 1080)
     assert sum(b - a for _, _, a, b in xa) == 1080 * 7
+    # pinned top rows: everybody but their owner receives them once, whether or not the halo already reaches them
+    xp = multigpu.transfers(st, 16, "f", 1080, pin=1)
+    extra = sorted(set(xp) - set(x))
+    assert extra == [(0, d, 0, 1) for d in range(1, 8)] and set(x) <= set(xp)
+    for d in range(8):
+        rows = sorted(r for s_, d_, a, b in xp if d_ == d for r in range(a, b))
+        assert len(rows) == len(set(rows))                                            # no row travels twice to the same rank
+    hp = multigpu.transfers(multigpu.plan_strips(208, 3), 12, "h", 208, pin=1)
+    assert (0, 2, 0, 1) in hp and (0, 1, 0, 1) in hp and not any(d == 0 and a == 0 for s_, d, a, b in hp)
+    hq = multigpu.transfers(multigpu.plan_strips(64, 2), 15, "h", 64, pin=1)          # strips of 16 half-res rows: the halo reaches row 0 -- one merged span
+    assert [t for t in hq if t[1] == 1] == [(0, 1, 0, 16)]
 
 
 class _StubPipe:
