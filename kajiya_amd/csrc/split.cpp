@@ -17,6 +17,7 @@
 #include "kj_ircache_host.hpp"
 #include <dlfcn.h>
 #include <algorithm>
+#include <cmath>
 #include <map>
 #include <string>
 #include <vector>
@@ -330,6 +331,14 @@ KjStatus merge_ircache_requests(KjSplit& s, hipStream_t st) {
 
 std::string sfx(const char* name, uint32_t k) { return std::string(name) + ":" + std::to_string(k); }
 
+// Half-res rows the taps of rtr's resolve can land beyond the rows it runs on (multigpu.py: rtr_resolve_halo has the derivation), or -1: no useful bound.
+// The same expression in double on both sides: the two ends of an exchange must agree on it.
+int rtr_resolve_halo(uint32_t height, float clip_to_view_11) {
+    const double t = std::fabs(double(clip_to_view_11)), k = std::max(0.1, 4.0 / double(height));
+    if (!(k * t < 0.5)) return -1;
+    return int(std::ceil(k * std::sqrt(1.0 + t * t) / (1.0 - k * t) * double(height) / 4.0)) + 4;
+}
+
 }  // namespace
 
 extern "C" {
@@ -546,7 +555,8 @@ KjStatus kj_split_rtr_frame(KjSplit* s, KjRtr* const* rtr, const KjRtrParams* rt
     }
     for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(run(li, KJ_RTR_PASS_RESTIR_TEMPORAL | KEEP, s->strips[s->first + li]));
     items.clear();
-    for (const char* n : {"RTR/rtr.irradiance", "RTR/rtr.ray", "RTR/rtr.reservoir", "RTR/rtr.ray_orig"}) items.push_back({sfx(n, o), -1});
+    const int reach = rtr_resolve_halo(s->H, s->ranks[0].scene->dev->fc_host.view_constants.clip_to_view[5]);
+    for (const char* n : {"RTR/rtr.irradiance", "RTR/rtr.ray", "RTR/rtr.reservoir", "RTR/rtr.ray_orig"}) items.push_back({sfx(n, o), reach < 0 ? -1 : 8 + reach, 1u});      // (the resolve runs on own +- 16 rows)
     items.push_back({"candidate_hit_tex", 8});      // the pixel's own hit distance on the rows the resolve over-computes
     if (s->rtr_frames > 0) items.push_back({sfx("RTR/rtr.ray_len", h), int(M + 2 + 16)});
     KJ_SPLIT_TRY(exchange(*s, items, st));

@@ -194,6 +194,7 @@ class Device:
 
     def frame_begin(self, fc):
         check(load().kj_frame_begin(self.h, C.byref(fc), _stream_ptr()))
+        self.clip_to_view_11 = float(fc.view_constants.clip_to_view[5])      # tan(vertical fov / 2): the split sizes rtr's resolve halo from it
 
     def brdf_lut_ptr(self):
         p = C.c_void_p()

@@ -67,6 +67,22 @@ def plan_strips(height, n):
     return out
 
 
+def rtr_resolve_halo(height, clip_to_view_11):
+    """Half-res rows the taps of rtr's resolve can land beyond the rows it runs on, or None (no useful bound: all-gather). resolve.hlsl:296-330: a tap is the
+    pixel's reflection-ray origin plus a WORLD-space offset o, |o| <= kernel_size_ws * radius, radius <= 1 (the accumulated radius stays below 8, the
+    multiplier is 8^-0.666), kernel_size_ws <= k * z * t after its two clamps (:268-271), with k = max(0.1, 4 / height), z the origin's view depth and
+    t = clip_to_view[1][1] = tan(vertical fov / 2). A point at view height Y and depth z sits at NDC y = Y / (z t); moving it by (oy, dz) moves y by
+    (oy z - Y dz) / (z (z + dz) t), and with |Y| <= z t (the pixel is on screen) and |(oy, dz)| <= k z t that is at most k sqrt(1 + t^2) / (1 - k t). NDC spans 2
+    over height / 2 half-res rows. + 4 rows for what the derivation leaves out (the biased ray origin, the sub-pixel jitter of the projection, rounding).
+    Same expression, in double, in csrc/split.cpp (rtr_resolve_halo): both ends of an exchange must agree on it."""
+    import math
+    t = abs(float(clip_to_view_11))
+    k = max(0.1, 4.0 / height)
+    if not k * t < 0.5:
+        return None
+    return int(math.ceil(k * math.sqrt(1.0 + t * t) / (1.0 - k * t) * height / 4.0)) + 4
+
+
 def half_rows(r0, r1, height):
     hh = (height + 1) // 2
     return r0 // 2, (hh if r1 == height else r1 // 2)
@@ -514,8 +530,10 @@ class SplitRtdgi:
                                       (reflection_trace_common.inc.hlsl:159-166). Validate rewrites the reservoir histories of its own quads in place.
           X2  after the ray passes    the six reservoir histories: motion + the search's 1 + the taps' 14 half-res rows (rtr_restir_temporal.hlsl:
                                       232-262,383-390), and row 0 for everybody -- an empty reservoir's payload is pixel (0, 0), and the pass follows it
-          X3  after the reservoir pass  ALL-GATHER of {irradiance, ray, reservoir, ray origin}: the resolve's taps land where a world-space kernel
-                                      projects to (resolve.hlsl:296-330: up to a tenth of the frustum's height at the surface's depth, times perspective);
+          X3  after the reservoir pass  {irradiance, ray, reservoir, ray origin}: the resolve's taps land where a WORLD-space kernel projects to
+                                      (resolve.hlsl:296-330: up to a tenth of the frustum's height at the surface's depth, times perspective) -- a halo
+                                      sized from the field of view (rtr_resolve_halo: 8 + 0.12 x height / 4 + 4 half-res rows at 52 degrees), and row 0
+                                      (an empty reservoir's payload; a tap whose kernel basis degenerates at normal incidence);
                                       the ray-length history's motion halo; 8 half-res rows of the hit image the trace pass just wrote (the resolve reads
                                       the pixel's own hit distance from it, :112). The resolve (and the lights' specular) over-computes 16 rows either side: the
                                       temporal filter's 3x3 moments read them.
@@ -546,7 +564,9 @@ class SplitRtdgi:
             self._exchange([(f"RTR/{n}{h}", M + 16, 1) for n in ("rtr.irradiance", "rtr.ray_orig", "rtr.ray", "rtr.rng", "rtr.reservoir", "rtr.hit_normal")])
         for r in R:
             run(r, P["RESTIR_TEMPORAL"] | KEEP, self.strips[r])
-        self._exchange([(f"RTR/{n}{o}", None) for n in ("rtr.irradiance", "rtr.ray", "rtr.reservoir", "rtr.ray_orig")] + [("candidate_hit_tex", 8)] + ([(f"RTR/rtr.ray_len{h}", M + 2 + 16)] if k > 0 else []))
+        reach = rtr_resolve_halo(self.H, self.pipes[R[0]].dev.clip_to_view_11)
+        x3 = None if reach is None else 8 + reach         # (the resolve runs on own +- 16 full-res rows)
+        self._exchange([(f"RTR/{n}{o}", x3, 1) for n in ("rtr.irradiance", "rtr.ray", "rtr.reservoir", "rtr.ray_orig")] + [("candidate_hit_tex", 8)] + ([(f"RTR/rtr.ray_len{h}", M + 2 + 16)] if k > 0 else []))
         for r in R:
             run(r, P["RESOLVE"] | KEEP | (P["SPECULAR_LIGHTS"] if specular_lights else 0), self._grow(r, 16))
             run(r, P["TEMPORAL_FILTER"] | KEEP, self.strips[r])
