@@ -664,6 +664,10 @@ KjStatus kj_split_rtr_frame(KjSplit* split, KjRtr* const* rtr, const KjRtrParams
                             void* stream);
 /* TAA on the GI output of the frame just rendered (exchange I + strip-wise TaaRenderer::render). */
 KjStatus kj_split_taa_frame(KjSplit* split, const KjSplitFrame* frames, void* stream);
+/* The same on images of the caller's -- input_rgba16f[i] (one per LOCAL rank, full res, valid on the rank's own rows; its halo rows are written into it): the
+ * lighting frame resolves the LIT image (world_render_passes.rs:212-291: light_gbuffer's output is what TaaRenderer::render takes), i.e. what
+ * kj_light_gbuffer_rows wrote on each rank's strip. NULL: the GI image (kj_split_taa_frame). */
+KjStatus kj_split_taa_frame_on(KjSplit* split, const KjSplitFrame* frames, void* const* input_rgba16f, void* stream);
 /* Every rank receives the owners' rows of a surface ("spatial_filtered_tex", "TAA/taa:0", ...): result collection. */
 KjStatus kj_split_gather(KjSplit* split, const char* surface_name, void* stream);
 /* Start-up check of the transport, before frame 0: every kind of exchange of the frame schedule (all-gather of an image, mixed surfaces packed into one message

@@ -37,6 +37,7 @@ const std::map<std::string, SurfInfo>& surf_table() {
         {"irradiance_output_tex", {8, false}}, {"temporal_filtered_tex", {8, false}}, {"spatial_filtered_tex", {8, false}}, {"reprojected_history_tex", {8, false}},
         {"SSGI/ssgi", {2, false}}, {"SSGI/filtered_output_tex", {1, false}},
         {"SHADOW/shadow_denoise_moments", {8, false}}, {"SHADOW/shadow_denoise_accum", {4, false}}, {"SHADOW/mask", {1, false}},      // "SHADOW/mask": the caller's image (kj_split_shadow_frame)
+        {"LIT/input", {8, false}},        // the caller's RGBA16F image TAA resolves instead of the GI image (kj_split_taa_frame_on)
         {"RTR/rtr.temporal", {8, false}}, {"RTR/rtr.ray_len", {4, false}}, {"RTR/rtr.irradiance", {8, true}}, {"RTR/rtr.ray_orig", {16, true}}, {"RTR/rtr.ray", {8, true}},
         {"RTR/rtr.reservoir", {8, true}}, {"RTR/rtr.rng", {4, true}}, {"RTR/rtr.hit_normal", {8, true}},      // RtrRenderer's eight ping-pong temporals (kj_split_rtr_frame)
         {"TAA/taa", {8, false}}, {"TAA/taa.velocity", {4, false}}, {"TAA/taa.smooth_var", {8, false}}, {"TAA/this_frame_output_img", {8, false}},
@@ -572,14 +573,24 @@ KjStatus kj_split_rtr_frame(KjSplit* s, KjRtr* const* rtr, const KjRtrParams* rt
 
 // TaaRenderer::render on this frame's GI image, strip by strip (multigpu.py: SplitRtdgi.taa_frame): one exchange (the input's halo;
 // the three histories travelled with exchange A of gi_frame), the intermediates over-computed on up to 32 extra rows per side.
-KjStatus kj_split_taa_frame(KjSplit* s, const KjSplitFrame* frames, void* stream) {
+KjStatus kj_split_taa_frame(KjSplit* s, const KjSplitFrame* frames, void* stream) { return kj_split_taa_frame_on(s, frames, nullptr, stream); }
+
+// The same on images of the caller's: input_rgba16f[li] (full res, valid on the rank's own rows -- e.g. what kj_light_gbuffer_rows wrote: the lighting frame of
+// world_render_passes.rs:212-291 resolves the LIT image) instead of the GI image; NULL: the GI image. The halo rows are written into the caller's images.
+KjStatus kj_split_taa_frame_on(KjSplit* s, const KjSplitFrame* frames, void* const* input_rgba16f, void* stream) {
     KJ_REQUIRE(s && frames, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    KJ_SPLIT_TRY(exchange(*s, {{"spatial_filtered_tex", 1 + 24}}, st));
+    const char* name = input_rgba16f ? "LIT/input" : "spatial_filtered_tex";
+    if (input_rgba16f)
+        for (uint32_t li = 0; li < s->local; ++li) {
+            KJ_REQUIRE(input_rgba16f[li], "null input image");
+            s->surfaces[{li, std::string("LIT/input")}] = {(uint8_t*)input_rgba16f[li], uint64_t(s->W) * s->H * 8};      // the caller's image: bound anew every frame
+        }
+    KJ_SPLIT_TRY(exchange(*s, {{name, 1 + 24}}, st));
     for (uint32_t li = 0; li < s->local; ++li) {
         const uint32_t rank = s->first + li;
         uint8_t* inp; uint32_t rb;
-        KJ_SPLIT_TRY(surface_of(*s, rank, "spatial_filtered_tex", &inp, &rb));
+        KJ_SPLIT_TRY(surface_of(*s, rank, name, &inp, &rb));
         const struct { uint32_t mask, grow; bool keep; } steps[5] = {{1, 32, false}, {2 | 4, 24, true}, {8, 16, true}, {16, 8, true}, {32 | 64, 0, true}};
         for (const auto& stp : steps) {
             const auto rows = grow(*s, rank, stp.grow);

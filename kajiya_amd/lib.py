@@ -32,7 +32,7 @@ EXPORTS = [
     "kj_rtr_create", "kj_rtr_destroy", "kj_rtr_set_options", "kj_rtr_trace", "kj_rtr_render_specular_lights", "kj_rtr_filter_temporal", "kj_rtr_render_rows", "kj_rtr_surface", "kj_rtr_ray_counts",
     "kj_post_create", "kj_post_destroy", "kj_post_render", "kj_post_read_back_histogram", "kj_luminance_histogram_mean_log2", "kj_post_surface", "kj_post_mip_levels",
     "kj_motion_blur_create", "kj_motion_blur_destroy", "kj_motion_blur_render", "kj_motion_blur_surface",
-    "kj_split_create", "kj_split_destroy", "kj_split_strip", "kj_split_gi_frame", "kj_split_merge_ircache", "kj_split_taa_frame", "kj_split_ssgi_frame", "kj_split_gather", "kj_split_self_test", "kj_split_shadow_frame", "kj_split_set_rtr", "kj_split_rtr_frame",
+    "kj_split_create", "kj_split_destroy", "kj_split_strip", "kj_split_gi_frame", "kj_split_merge_ircache", "kj_split_taa_frame", "kj_split_taa_frame_on", "kj_split_ssgi_frame", "kj_split_gather", "kj_split_self_test", "kj_split_shadow_frame", "kj_split_set_rtr", "kj_split_rtr_frame",
     "kj_split_rccl_unique_id", "kj_split_rccl_comm_create", "kj_split_rccl_comm_destroy",
 ]
 
@@ -150,6 +150,7 @@ def load():
         "kj_split_strip": [vp, u32, C.POINTER(u32), C.POINTER(u32)],
         "kj_split_gi_frame": [vp, C.POINTER(KjSplitFrame), u32, vp, vp],
         "kj_split_taa_frame": [vp, C.POINTER(KjSplitFrame), vp],
+        "kj_split_taa_frame_on": [vp, C.POINTER(KjSplitFrame), C.POINTER(vp), vp],
         "kj_split_ssgi_frame": [vp, C.POINTER(vp), C.POINTER(KjSplitFrame), C.POINTER(vp), vp],
         "kj_split_merge_ircache": [vp, vp],
         "kj_split_gather": [vp, C.c_char_p, vp],

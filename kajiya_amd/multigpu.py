@@ -251,6 +251,23 @@ class DistComm:
             t.copy_(h)
 
 
+def _lighting_frame(split, ranks, with_ssgi, specular_lights):
+    """BASELINE configs[2] under the split -- the whole lighting frame of world_render_passes.rs:99-291 strip by strip, for either orchestrator: SSAO guide, sun
+    shadow mask + denoiser, irradiance cache + rtdgi, reflections (enable_rtr() comes first), the deferred combine on each rank's rows (it reads every input
+    at the pixel itself) and TAA on the lit image. Returns {rank: (lit RGBA16F image, valid on the rank's rows)}; the TAA output is TaaRenderer's as usual."""
+    if with_ssgi:
+        split.ssgi_frame()
+    shadows = split.shadow_frame()
+    split.gi_frame()
+    rtr = split.rtr_frame(specular_lights=specular_lights)
+    lit = {}
+    for r in ranks:
+        a, b = split.strips[r]
+        lit[r] = split.pipes[r].light_gbuffer(shadows[r], rtr_ptr=rtr[r].data_ptr(), rows=(a, b))[1]
+    split.taa_frame(inputs=lit)
+    return lit
+
+
 class SplitRtdgi:
     """Drives RtdgiRenderer::{reproject,render} + TaaRenderer::render strip by strip with halo exchanges.
     `pipes`: {rank: GpuPipeline} for the ranks living in this process (one for DistComm, N for LocalComm).
@@ -306,6 +323,8 @@ class SplitRtdgi:
                 t = gp.ssgi_surface(name[5:], torch.uint8, (self.H, self.W * SSGI_SURF[name[5:].split(":")[0]]))
             elif name == "SHADOW/mask":
                 return gp.shadow_mask_img            # the caller's image (shadow_frame): not cached, it may change between frames
+            elif name == "LIT/input":
+                return gp.taa_input_img.view(torch.uint8).view(self.H, self.W * 8)      # the caller's image (taa_frame(inputs=...))
             elif name.startswith("SHADOW/"):
                 t = gp.shadow_denoise_surface(name[7:], torch.uint8, (self.H, self.W * SHADOW_SURF[name[7:].split(":")[0]]))
             elif name.startswith("RTR/"):
@@ -331,7 +350,7 @@ class SplitRtdgi:
             xfers = []
             for item in items:
                 name, halo, pin = item if len(item) == 3 else (item[0], item[1], 0)
-                res = RTR_SURF[name[4:].split(":")[0]][1] if name.startswith("RTR/") else "f" if name.startswith(("TAA/", "SSGI/", "SHADOW/")) else SURF[name.split(":")[0]][1]
+                res = RTR_SURF[name[4:].split(":")[0]][1] if name.startswith("RTR/") else "f" if name.startswith(("TAA/", "SSGI/", "SHADOW/", "LIT/")) else SURF[name.split(":")[0]][1]
                 xfers += [(src, dst, (name, a), b) for (src, dst, a, b) in transfers(self.strips, halo, res, self.H, pin)]
             # renderer surfaces keep their address for a given extent, so the row views can be resolved once per distinct item list
             # (two per exchange point: the ping-pong suffixes alternate)
@@ -675,15 +694,20 @@ class SplitRtdgi:
             gp.ircache_apply(merged, merged.shape[0])
             self._keepalive = merged
 
-    def taa_frame(self):
-        """TaaRenderer::render on this frame's GI image, strip by strip. ONE exchange here (the input's halo; the three
+    def taa_frame(self, inputs=None):
+        """TaaRenderer::render on this frame's GI image -- or on `inputs`: {rank: RGBA16F (H, W, 4) image valid on the rank's own rows}, e.g. the lit image of
+        light_gbuffer(rows=strip) (lighting_frame) -- strip by strip. ONE exchange here (the input's halo; the three
         histories travel with exchange A of gi_frame); the intermediate images are over-computed on up to 32 extra rows per side (8-row tile
         granularity) instead of being exchanged: prob_filter2 reaches +-4 rows of prob_filter, that +-1 of input_prob,
         that +-1 of the filtered history / input and +-2 of the input deviation, those +-1 of the reprojected history /
         input (taa/*.hlsl)."""
         import torch
-        gi_out = "spatial_filtered_tex"
+        gi_out = "spatial_filtered_tex" if inputs is None else "LIT/input"
         stream = klib._stream_ptr()
+        if inputs is not None:
+            for r in self.comm.ranks:
+                self.pipes[r].taa_input_img = inputs[r]
+            self._plans.pop(((gi_out, 1 + 24),), None)       # the caller's images may be others than last frame's: resolve their rows anew
         # ---- I
         self._exchange([(gi_out, 1 + 24)])                   # filter_input runs on +-24 rows
         for r in self.comm.ranks:
@@ -702,6 +726,9 @@ class SplitRtdgi:
             run(16, 8)                     # prob filter (+-1)
             run(32 | 64, 0)                # prob filter 2 (+-4), taa (+-2 reprojected history, +-1 input)
         self.taa_frames += 1
+
+    def lighting_frame(self, with_ssgi=True, specular_lights=False):
+        return _lighting_frame(self, self.comm.ranks, with_ssgi, specular_lights)
 
     def gather_output(self, name="spatial_filtered_tex"):
         """Assemble the full image from every rank's own rows (result collection; not part of the timed frame)."""
@@ -737,6 +764,7 @@ class NativeSplit:
         for gp in pipes.values():
             gp.ircache_deferred = bool(gp.ircache) and self.consistent_ircache
         self.with_rtr = False
+        self.strips = [self.strip(r) for r in range(world)]
 
     def __del__(self):
         try:
@@ -885,9 +913,16 @@ class NativeSplit:
                 klib.check(self.L.kj_split_merge_ircache(self.h, klib._stream_ptr()))
             torch.cuda.current_stream().wait_stream(sd["stream"])
 
-    def taa_frame(self):
+    def taa_frame(self, inputs=None):
         self._fill()
-        klib.check(self.L.kj_split_taa_frame(self.h, self._frames, klib._stream_ptr()))
+        if inputs is None:
+            klib.check(self.L.kj_split_taa_frame(self.h, self._frames, klib._stream_ptr()))
+        else:
+            ptrs = (C.c_void_p * len(self.ranks))(*[inputs[r].data_ptr() for r in self.ranks])
+            klib.check(self.L.kj_split_taa_frame_on(self.h, self._frames, ptrs, klib._stream_ptr()))
+
+    def lighting_frame(self, with_ssgi=True, specular_lights=False):
+        return _lighting_frame(self, self.ranks, with_ssgi, specular_lights)
 
     def gather_output(self, name="spatial_filtered_tex"):
         klib.check(self.L.kj_split_gather(self.h, name.encode(), klib._stream_ptr()))

@@ -388,3 +388,48 @@ def test_strip_split_reflections_are_bit_exact(gpu, device, n_ranks, W, H, with_
     assert (scene.triangle_light_count > 0) == lights
     if with_cache:
         assert ref.ircache_buffer("meta", torch.int32).cpu().numpy()[3] > 20     # the cache did allocate entries
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,W,H,native", [(2, 256, 160, False), (3, 192, 208, True)])
+def test_whole_lighting_frame_under_the_split_is_bit_exact(gpu, device, n_ranks, W, H, native):
+    """BASELINE configs[2] under the split (lighting_frame: SSAO guide, sun shadows + denoiser, irradiance cache + rtdgi, reflections, the deferred combine,
+    TAA on the lit image -- world_render_passes.rs:99-291) against the same frames on one GPU in scripts/config3_bench.py's order: on every rank's own rows the
+    lit image and the TAA output bit for bit, and every replica of the cache."""
+    import torch
+    from kajiya_amd import multigpu, frame, scenes as S
+    scene = gpu.Scene(device, S.glossy_test_scene())
+    ref = gpu.GpuPipeline(device, scene, W, H, use_ircache=True)
+    ref.ircache_set_deferred(True)
+    ref.ircache_set_rtr_requests(True)
+    pipes = {r: gpu.GpuPipeline(device, scene, W, H, use_ircache=True) for r in range(n_ranks)}
+    sp = multigpu.NativeSplit(n_ranks, pipes, W, H, motion_halo=8) if native else multigpu.SplitRtdgi(multigpu.LocalComm(n_ranks), pipes, W, H, motion_halo=8)
+    sp.enable_rtr()
+    fs = frame.FrameState((W, H), sun_size_multiplier=4.0)
+    fs.ircache_enabled = True
+    for fi in range(6):
+        fc = fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 1.5, 0.0), radius=9.0, height=3.5, rate=0.008))
+        fs.retire_frame()
+        ref.render_inputs(fc); ref.reprojection()
+        ref.ssgi_frame()
+        shadow = ref.shadow_denoise(ref.sun_shadow_mask())
+        ref.gi_frame(defer_replay=True)
+        rtr = ref.rtr_frame()
+        ref.ircache_replay_own_requests()
+        lit = ref.light_gbuffer(shadow, rtr_ptr=rtr.data_ptr())[1]
+        ref.taa_frame(input_ptr=lit.data_ptr())
+        for r in range(n_ranks):
+            pipes[r].render_inputs(fc)
+            pipes[r].reprojection()
+        lits = sp.lighting_frame()
+        torch.cuda.synchronize()
+        ta = ref.taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4))
+        for r in range(n_ranks):
+            a, b = sp.strips[r]
+            assert torch.equal(lit.view(torch.int16)[a:b], lits[r].view(torch.int16)[a:b]), f"frame {fi} rank {r}: the lit image differs"
+            neq = (ta[a:b] != pipes[r].taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4))[a:b]).any(dim=-1)
+            assert not bool(neq.any()), f"frame {fi} rank {r}: {int(neq.sum())} TAA texels differ (rows {(torch.nonzero(neq.any(dim=1)).flatten()[:8] + a).tolist()})"
+            for name in IRC_BUFS:
+                x, y = ref.ircache_buffer(name, torch.uint8), pipes[r].ircache_buffer(name, torch.uint8)
+                assert torch.equal(x, y), f"frame {fi} rank {r}: ircache buffer {name} differs"
+    assert float(lit.float().abs().max()) > 0.0
