@@ -65,3 +65,23 @@ def test_bench_single_rank_line_has_roofline_and_cpu_baseline():
     assert set(["bound", "achieved", "peak", "unit", "frac", "traffic"]) <= set(j["roofline"])
     cb = j["cpu_baseline"]
     assert set(["value", "unit", "cores", "kind", "sample"]) <= set(cb) and cb["kind"] in ("port", "reference") and cb["value"] > 0
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs ROCm's clang++ as the host compiler")
+def test_config3_lighting_frame_two_processes_over_the_compiled_transport():
+    """scripts/config3_split_bench.py --check under the driver's kind of launch line: BASELINE configs[2]'s whole lighting frame (SSAO guide, sun shadows,
+    cache + rtdgi, reflections, deferred combine, TAA on the lit image) split over two PROCESSES, the compiled orchestrator's ncclSend / ncclRecv served by the
+    socket stand-in for RCCL -- every rank's rows of the lit image and of the TAA output equal the one-GPU frame's, texel for texel."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_multigpu_emulated as TM
+    env = dict(os.environ, KJ_BENCH_SHARE_GPU0="1", HIP_EMU_WORKERS="4", KJ_SPLIT_NATIVE="1", KJ_RCCL_LIB=TM.build_rccl_stub())
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        RUN, os.path.join(ROOT, "scripts", "config3_split_bench.py"), "--scene", "glossy", "--res", "128x96", "--frames", "2", "--warmup", "2", "--motion-halo", "8", "--check"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"config"' in l]
+    assert len(lines) == 1, r.stdout[-3000:]
+    j = json.loads(lines[0])
+    assert j["ranks"] == 2 and j["processes"] == 2 and j["orchestrator"] == "compiled" and j["mismatching_texels_vs_one_gpu"] == 0 and j["frame_ms_wall"] > 0
+    assert "exchange self-test OK" in r.stderr
