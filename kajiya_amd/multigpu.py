@@ -268,6 +268,37 @@ def _lighting_frame(split, ranks, with_ssgi, specular_lights):
     return lit
 
 
+def _lighting_frame_pipelined(split, ranks, next_fc, with_ssgi, specular_lights):
+    """lighting_frame with every rank's cache replica updated on a side stream, as frame_pipelined does for the GI frame (pipeline_begin(fc) primes it): the
+    replay of this frame's recorded cache updates and the NEXT frame's cache maintenance + its three ray passes start when this frame's reflection rays --
+    the cache's last readers -- are done, and run under the reservoir pass, resolve, filters, deferred combine and TAA. Every launch of this frame is issued
+    before the next frame's constants are uploaded (the host-side order the constants ring needs). Same results as lighting_frame, frame by frame."""
+    import torch
+    sd = split._side
+    i = split.frame & 1
+    main = torch.cuda.current_stream()
+    main.wait_event(sd["fc"][i])
+    if with_ssgi:
+        split.ssgi_frame()
+    shadows = split.shadow_frame()
+    main.wait_event(sd["irc"][i])
+    split.gi_frame(ircache_done=True, defer_merge=True)            # (advances split.frame)
+    rtr = split.rtr_frame(specular_lights=specular_lights, trace_event=sd["trace"][i], defer_merge=True)
+    lit = {}
+    for r in ranks:
+        a, b = split.strips[r]
+        lit[r] = split.pipes[r].light_gbuffer(shadows[r], rtr_ptr=rtr[r].data_ptr(), rows=(a, b))[1]
+    split.taa_frame(inputs=lit)
+    if next_fc is not None:
+        split._enqueue_ircache(next_fc, sd["trace"][i])
+    elif split.consistent_ircache:                                 # last frame: nothing follows on the side stream, replay there all the same
+        with torch.cuda.stream(sd["stream"]):
+            sd["stream"].wait_event(sd["trace"][i])
+            split._replay_recorded_cache_updates()
+        main.wait_stream(sd["stream"])
+    return lit
+
+
 class SplitRtdgi:
     """Drives RtdgiRenderer::{reproject,render} + TaaRenderer::render strip by strip with halo exchanges.
     `pipes`: {rank: GpuPipeline} for the ranks living in this process (one for DistComm, N for LocalComm).
@@ -730,6 +761,12 @@ class SplitRtdgi:
     def lighting_frame(self, with_ssgi=True, specular_lights=False):
         return _lighting_frame(self, self.comm.ranks, with_ssgi, specular_lights)
 
+    def lighting_frame_pipelined(self, next_fc, with_ssgi=True, specular_lights=False):
+        return _lighting_frame_pipelined(self, self.comm.ranks, next_fc, with_ssgi, specular_lights)
+
+    def _replay_recorded_cache_updates(self):
+        self._merge_ircache_requests()
+
     def gather_output(self, name="spatial_filtered_tex"):
         """Assemble the full image from every rank's own rows (result collection; not part of the timed frame)."""
         self._exchange([(name, None)])
@@ -923,6 +960,12 @@ class NativeSplit:
 
     def lighting_frame(self, with_ssgi=True, specular_lights=False):
         return _lighting_frame(self, self.ranks, with_ssgi, specular_lights)
+
+    def lighting_frame_pipelined(self, next_fc, with_ssgi=True, specular_lights=False):
+        return _lighting_frame_pipelined(self, self.ranks, next_fc, with_ssgi, specular_lights)
+
+    def _replay_recorded_cache_updates(self):
+        klib.check(self.L.kj_split_merge_ircache(self.h, klib._stream_ptr()))
 
     def gather_output(self, name="spatial_filtered_tex"):
         klib.check(self.L.kj_split_gather(self.h, name.encode(), klib._stream_ptr()))

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--res", default="2560x1440"); ap.add_argument("--tris", type=int, default=4_000_000); ap.add_argument("--scene", default="ruins")
 ap.add_argument("--frames", type=int, default=30); ap.add_argument("--warmup", type=int, default=12); ap.add_argument("--virtual-ranks", type=int, default=2)
 ap.add_argument("--motion-halo", type=int, default=16); ap.add_argument("--check", action="store_true", help="also render every frame unsplit and compare this rank's rows")
+ap.add_argument("--pipelined", action="store_true", help="lighting_frame_pipelined: the cache's work of frame N+1 and the replay of frame N's updates on a side stream (inputs of all frames pre-generated; no --check)")
 a = ap.parse_args()
 W, H = map(int, a.res.split("x"))
 rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -52,7 +53,35 @@ cam = (lambda i: frame.orbit_camera(i, (W, H), center=(0.0, 1.5, 0.0), radius=9.
       (lambda i: frame.orbit_camera(i, (W, H), center=(0.0, 3.0, 0.0), radius=34.0, height=5.0, rate=0.004))
 mine = sorted(pipes)
 worst, t_acc = 0, 0.0
-for i in range(a.warmup + a.frames):
+if a.pipelined:
+    import ctypes as C
+    assert not a.check, "--check compares serial frames"
+    K = a.warmup + a.frames
+    fcs, inputs = [], []
+    gp0 = pipes[mine[0]]
+    for i in range(K + 1):
+        fc = fs.prepare_frame_constants(cam(i)); fs.retire_frame()
+        gp0.render_inputs(fc); gp0.reprojection()
+        rp = lib.tensor_from_ptr(gp0.reprojection_map_ptr.value, W * H * 8, torch.int16, (H, W, 4)).clone()
+        fcs.append(fc); inputs.append((gp0.geometric_normal.clone(), gp0.gbuffer.clone(), gp0.depth.clone(), rp, gp0.sky16.clone(), gp0.sky64.clone()))
+
+    def bind(i):
+        for r in mine:
+            q = pipes[r]
+            q.geometric_normal, q.gbuffer, q.depth, rp, q.sky16, q.sky64 = inputs[i]
+            q.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+    bind(0); split.pipeline_begin(fcs[0])
+    for i in range(K):
+        if i == a.warmup:
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+        bind(i)
+        split.lighting_frame_pipelined(fcs[i + 1] if i + 1 < K else None)
+    torch.cuda.synchronize()
+    t_acc = time.perf_counter() - t0
+for i in range(0 if a.pipelined else a.warmup + a.frames):
     fc = fs.prepare_frame_constants(cam(i)); fs.retire_frame()
     for r in mine:                       # inputs are replicated: every rank rasterises the whole G-buffer (outside the timed part)
         pipes[r].render_inputs(fc); pipes[r].reprojection()
@@ -81,7 +110,7 @@ if world > 1:
 if rank == 0:
     reach = multigpu.rtr_resolve_halo(H, pipes[mine[0]].dev.clip_to_view_11)
     print(json.dumps({"config": "BASELINE configs[2] under the screen-tile split", "workload": f"{a.scene} @ {W}x{H}", "ranks": n, "processes": world, "orchestrator": "compiled" if native else "python",
-                      "frame_ms_wall": round(ms, 4), "wall_is": "max over ranks, serial issue" if world > 1 else "N virtual ranks' work + host syncs on ONE GPU: not a frame time",
+                      "frame_ms_wall": round(ms, 4), "pipelined": a.pipelined, "wall_is": "max over ranks, " + ("pipelined frames" if a.pipelined else "serial issue") if world > 1 else "N virtual ranks' work + host syncs on ONE GPU: not a frame time",
                       "frames": a.frames, "motion_halo": a.motion_halo, "rtr_resolve_halo_half_rows": reach, "strips": [list(s) for s in split.strips],
                       "mismatching_texels_vs_one_gpu": worst if a.check else None}))
 if world > 1:

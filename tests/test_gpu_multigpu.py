@@ -433,3 +433,63 @@ def test_whole_lighting_frame_under_the_split_is_bit_exact(gpu, device, n_ranks,
                 x, y = ref.ircache_buffer(name, torch.uint8), pipes[r].ircache_buffer(name, torch.uint8)
                 assert torch.equal(x, y), f"frame {fi} rank {r}: ircache buffer {name} differs"
     assert float(lit.float().abs().max()) > 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("native", [False, True])
+def test_pipelined_lighting_frames_match_serial_lighting_frames(gpu, device, native):
+    """lighting_frame_pipelined (BASELINE configs[2] under the split with the cache's work of frame N+1 and the replay of frame N's recorded updates on a side
+    stream, started behind frame N's reflection rays) against the same frames issued serially with lighting_frame: every rank's rows of the lit image and of
+    the TAA output, all of RtrRenderer's temporals on those rows, and every cache buffer, bit for bit. Both orchestrators."""
+    import ctypes as C
+    import torch
+    from kajiya_amd import multigpu, frame, scenes as S
+    W, H, n_ranks, K = 192, 160, 2, 5
+    scene = gpu.Scene(device, S.glossy_test_scene())
+
+    def make():
+        pipes = {r: gpu.GpuPipeline(device, scene, W, H, use_ircache=True) for r in range(n_ranks)}
+        sp = multigpu.NativeSplit(n_ranks, pipes, W, H, motion_halo=8) if native else multigpu.SplitRtdgi(multigpu.LocalComm(n_ranks), pipes, W, H, motion_halo=8)
+        sp.enable_rtr()
+        return pipes, sp
+    fs = frame.FrameState((W, H), sun_size_multiplier=4.0)
+    fs.ircache_enabled = True
+    fcs = []
+    for fi in range(K + 1):
+        fcs.append(fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 1.5, 0.0), radius=9.0, height=3.5, rate=0.008)))
+        fs.retire_frame()
+    gen = gpu.GpuPipeline(device, scene, W, H)
+    inputs = []
+    for fc in fcs:
+        gen.render_inputs(fc)
+        gen.reprojection()
+        rp = gpu.tensor_from_ptr(gen.reprojection_map_ptr.value, W * H * 8, torch.int16, (H, W, 4)).clone()
+        inputs.append((gen.geometric_normal.clone(), gen.gbuffer.clone(), gen.depth.clone(), rp, gen.sky16.clone(), gen.sky64.clone()))
+    torch.cuda.synchronize()
+
+    def bind(pipes, i):
+        gn, gb, d, rp, sky16, sky64 = inputs[i]
+        for q in pipes.values():
+            q.geometric_normal, q.gbuffer, q.depth, q.sky16, q.sky64 = gn, gb, d, sky16, sky64
+            q.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+    ser_pipes, ser = make()
+    for i in range(K):
+        bind(ser_pipes, i)
+        device.frame_begin(fcs[i])
+        ser_lit = {r: t.clone() for r, t in ser.lighting_frame().items()}
+    torch.cuda.synchronize()
+    pip_pipes, pip = make()
+    bind(pip_pipes, 0)
+    pip.pipeline_begin(fcs[0])
+    for i in range(K):
+        bind(pip_pipes, i)
+        pip_lit = pip.lighting_frame_pipelined(fcs[i + 1] if i + 1 < K else None)
+    torch.cuda.synchronize()
+    for r in range(n_ranks):
+        a, b = ser.strips[r]
+        assert torch.equal(ser_lit[r].view(torch.int16)[a:b], pip_lit[r].view(torch.int16)[a:b]), f"rank {r}: lit image"
+        x, y = (p[r].taa_surface(f"taa:{(K - 1) % 2}", torch.int16, (H, W, 4)) for p in (ser_pipes, pip_pipes))
+        assert torch.equal(x[a:b], y[a:b]), f"rank {r}: TAA image"
+        _rtr_own_rows_equal(ser_pipes[r], pip_pipes[r], (a, b), K - 1, H, torch, f"rank {r}")
+        for name in IRC_BUFS:
+            assert torch.equal(ser_pipes[r].ircache_buffer(name, torch.uint8), pip_pipes[r].ircache_buffer(name, torch.uint8)), f"rank {r}: ircache buffer {name}"
