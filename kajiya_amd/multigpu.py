@@ -14,9 +14,14 @@ from their owners:
     restir_spatial.hlsl:89-97, restir_resolve.hlsl:89-96), 16 / 3 rows between the spatial passes, 2 / 16
     full-res rows around the denoiser stencils.
 
-Inputs (G-buffer, depth, reprojection map, sky, BVH) are replicated, as is the world-space irradiance cache
-(each rank updates its replica from its own strip's rays; replicas therefore differ at noise level — with the
-cache unbound the split is bit-identical to the single-GPU frame, which tests/test_gpu_multigpu.py checks).
+The other renderers of the lighting frame split the same way (SplitRtdgi.ssgi_frame / shadow_frame / rtr_frame, whose docstrings list the reach of every pass;
+lighting_frame strings the whole of BASELINE configs[2] together). One dependence is easy to miss: an EMPTY reservoir's payload is pixel (0, 0), and the passes
+that follow payloads do so before they look at the weight -- so row 0 of the payload-followed images travels to every rank (`transfers(..., pin=1)`).
+
+Inputs (G-buffer, depth, reprojection map, sky, BVH) are replicated, as is the world-space irradiance cache: the
+replicas record their lookups' side effects, the records of all strips are all-gathered and every rank replays the
+same merged list (kj_ircache_set_deferred_updates), so that -- cache bound or not -- every rank's rows are
+bit-identical to the single-GPU frame, which tests/test_gpu_multigpu.py checks.
 
 Communication backends: `DistComm` = torch.distributed point-to-point (backend "nccl" = RCCL over xGMI, or
 "gloo" on CPU for the tests); `LocalComm` = N virtual ranks inside one process (single-GPU emulation used by
