@@ -230,6 +230,11 @@ def main():
         rp = lib.tensor_from_ptr(gp.reprojection_map_ptr.value, W * H * 8, torch.int16, (H, W, 4)).clone()
         inputs.append((gp.geometric_normal.clone(), gp.gbuffer.clone(), gp.depth.clone(), rp))
     torch.cuda.synchronize()
+    max_motion_rows = None
+    if not single:      # the split reads histories through the motion vectors: a frame moving further than the halo would be rendered from rows a rank does not hold
+        from kajiya_amd import multigpu as _mg
+        max_motion_rows = max(_mg.max_vertical_motion_rows(t[3], H) for t in inputs)
+        assert max_motion_rows <= args.motion_halo, f"the bench's frames move {max_motion_rows:.1f} rows per frame: more than --motion-halo {args.motion_halo}"
     counters = gp_counters = None
     use_ssgi = not args.no_ssgi
 
@@ -525,6 +530,8 @@ def main():
         "roofline": roofline,
         "roofline_all": roofline_all,
     }
+    if max_motion_rows is not None:
+        out["config"]["max_vertical_motion_rows"] = round(max_motion_rows, 2)      # <= motion halo: checked before the timed region
     out["comm_ranks"] = (dist.get_world_size() if world > 1 else 1)     # what the communicator itself reports: an N > 1 run certifies its rank count
     if rank == 0 and world == 1 and not args.no_also and nsplit <= 1:
         inputs.clear()              # the primary workload's frames: free their HBM before the children build theirs

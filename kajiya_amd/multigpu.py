@@ -88,6 +88,13 @@ def rtr_resolve_halo(height, clip_to_view_11):
     return int(math.ceil(k * math.sqrt(1.0 + t * t) / (1.0 - k * t) * height / 4.0)) + 4
 
 
+def max_vertical_motion_rows(reprojection_map, height):
+    """Largest |vertical screen motion| of a reprojection map (RGBA16_SNORM as an int16 (H, W, 4) tensor; .y = motion in screen heights), in full-res rows:
+    what `motion_halo` has to cover. The split reads histories through these vectors; a frame that moves further than the halo is rendered from rows the
+    rank does not hold -- silently. bench.py checks its frames against it before the timed region."""
+    return float(reprojection_map[..., 1].abs().max().item()) / 32767.0 * height
+
+
 def half_rows(r0, r1, height):
     hh = (height + 1) // 2
     return r0 // 2, (hh if r1 == height else r1 // 2)
@@ -334,6 +341,8 @@ class SplitRtdgi:
         self.with_rtr = False
         self._views = {}
         self._plans = {}
+        self._plan_bytes = {}
+        self.exchange_log = None       # set to [] to record (items, {rank: bytes arriving}) per exchange (scripts/split_exchange_bytes.py)
         self._params = {}
         self._s = None
         self._side = None          # side stream state for pipelined ircache work
@@ -392,7 +401,32 @@ class SplitRtdgi:
             # (two per exchange point: the ping-pong suffixes alternate)
             prepared = self.comm.prepare(xfers, lambda r, na, b: self._rows_view(r, na[0], na[1], b))
             self._plans[key] = prepared
+            into = {}                 # bytes arriving at each rank in this exchange: rows x the surface's row bytes (any rank can tell for all of them)
+            for (src, dst, (name, a), b) in xfers:
+                into[dst] = into.get(dst, 0) + (b - a) * self._row_bytes(name)
+            self._plan_bytes[key] = into
         self.comm.run_prepared(prepared)
+        if self.exchange_log is not None:
+            self.exchange_log.append((key, self._plan_bytes.get(key, {})))
+
+    def _row_bytes(self, name):
+        base = name.split(":")[0]
+        hw = (self.W + 1) // 2
+        if base.startswith("RTR/"):
+            bpt, res = RTR_SURF[base[4:]]
+            return (hw if res == "h" else self.W) * bpt
+        if base.startswith("TAA/"):
+            return self.W * TAA_SURF[base[4:]]
+        if base.startswith("SSGI/"):
+            return self.W * SSGI_SURF[base[5:]]
+        if base == "SHADOW/mask":
+            return self.W
+        if base.startswith("SHADOW/"):
+            return self.W * SHADOW_SURF[base[7:]]
+        if base == "LIT/input":
+            return self.W * 8
+        bpt, res = SURF[base]
+        return (hw if res == "h" else self.W) * bpt
 
     def _grow(self, rank, rows):
         r0, r1 = self.strips[rank]
