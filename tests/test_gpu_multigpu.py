@@ -391,11 +391,12 @@ def test_strip_split_reflections_are_bit_exact(gpu, device, n_ranks, W, H, with_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_ranks,W,H,native", [(2, 256, 160, False), (3, 192, 208, True)])
+@pytest.mark.parametrize("n_ranks,W,H,native", [(2, 256, 160, False), (3, 192, 208, True), (8, 1920, 1080, True)])
 def test_whole_lighting_frame_under_the_split_is_bit_exact(gpu, device, n_ranks, W, H, native):
     """BASELINE configs[2] under the split (lighting_frame: SSAO guide, sun shadows + denoiser, irradiance cache + rtdgi, reflections, the deferred combine,
     TAA on the lit image -- world_render_passes.rs:99-291) against the same frames on one GPU in scripts/config3_bench.py's order: on every rank's own rows the
-    lit image and the TAA output bit for bit, and every replica of the cache."""
+    lit image and the TAA output bit for bit, and every replica of the cache. 1920x1080 on 8 ranks: the halos at the proportions of a real run (135-row strips, the
+    resolve's 36 + 8 half-res rows, motion halo 16) -- too slow for the CPU stand-in's suite, where scripts/config3_split_bench.py --check ran it once (0 texels)."""
     import torch
     from kajiya_amd import multigpu, frame, scenes as S
     scene = gpu.Scene(device, S.glossy_test_scene())
@@ -403,12 +404,13 @@ def test_whole_lighting_frame_under_the_split_is_bit_exact(gpu, device, n_ranks,
     ref.ircache_set_deferred(True)
     ref.ircache_set_rtr_requests(True)
     pipes = {r: gpu.GpuPipeline(device, scene, W, H, use_ircache=True) for r in range(n_ranks)}
-    sp = multigpu.NativeSplit(n_ranks, pipes, W, H, motion_halo=8) if native else multigpu.SplitRtdgi(multigpu.LocalComm(n_ranks), pipes, W, H, motion_halo=8)
+    halo = 8 if H < 1000 else 16
+    sp = multigpu.NativeSplit(n_ranks, pipes, W, H, motion_halo=halo) if native else multigpu.SplitRtdgi(multigpu.LocalComm(n_ranks), pipes, W, H, motion_halo=halo)
     sp.enable_rtr()
     fs = frame.FrameState((W, H), sun_size_multiplier=4.0)
     fs.ircache_enabled = True
     for fi in range(6):
-        fc = fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 1.5, 0.0), radius=9.0, height=3.5, rate=0.008))
+        fc = fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 1.5, 0.0), radius=9.0, height=3.5, rate=0.008 if H < 1000 else 0.004))
         fs.retire_frame()
         ref.render_inputs(fc); ref.reprojection()
         ref.ssgi_frame()
@@ -421,6 +423,7 @@ def test_whole_lighting_frame_under_the_split_is_bit_exact(gpu, device, n_ranks,
         for r in range(n_ranks):
             pipes[r].render_inputs(fc)
             pipes[r].reprojection()
+        assert multigpu.max_vertical_motion_rows(gpu.tensor_from_ptr(ref.reprojection_map_ptr.value, W * H * 8, torch.int16, (H, W, 4)), H) <= halo      # the test's own precondition
         lits = sp.lighting_frame()
         torch.cuda.synchronize()
         ta = ref.taa_surface(f"taa:{fi % 2}", torch.int16, (H, W, 4))
