@@ -391,6 +391,9 @@ KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream);
  * rays), exchange, apply_requests on the merged list. */
 KjStatus kj_ircache_set_deferred_updates(KjIrcache* ircache, uint32_t enable);
 KjStatus kj_ircache_begin_requests(KjIrcache* ircache, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, void* stream);
+/* For a caller whose per-pixel passes run on half-res rows [half_row_begin, half_row_end) only (a rank of the screen-tile split): clears those rows' slots and the
+ * cache's own two ranges instead of the whole slot array (150 MB at 4K, 280 MB with reflections). Lookups recorded outside the rows would survive into next frame. */
+KjStatus kj_ircache_begin_requests_rows(KjIrcache* ircache, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, uint32_t half_row_begin, uint32_t half_row_end, void* stream);
 KjStatus kj_ircache_request_ranges(KjIrcache* ircache, uint32_t out_first_slot[4], uint32_t out_slot_count[4]);
 /* A frame with reflections (kj_rtr_trace bound to this cache) records the lookups of rtr's validate and trace rays too: two more slot ranges of one slot
  * per half-res pixel behind the four above. Sticky; set before kj_ircache_begin_requests. kj_rtr_trace refuses a deferred cache without them. */

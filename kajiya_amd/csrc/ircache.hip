@@ -693,12 +693,30 @@ KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream_) 
 KjStatus kj_ircache_set_deferred_updates(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->deferred = enable != 0; return KJ_OK; }
 KjStatus kj_ircache_set_rtr_requests(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->rtr_requests = enable != 0; return KJ_OK; }
 KjStatus kj_ircache_begin_requests(KjIrcache* c, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, void* stream_) {
+    return kj_ircache_begin_requests_rows(c, rtdgi_half_width, rtdgi_half_height, 0u, rtdgi_half_height, stream_);
+}
+// The same for a caller whose per-pixel passes (rtdgi's and rtr's validate / trace) run on half-res rows [half_row_begin, half_row_end) only -- a rank of the
+// screen-tile split: only those rows of the per-pixel slot ranges are cleared (and the cache's own two ranges): at 4K the slot array is 150 MB, 280 MB with
+// reflections, and clearing all of it every frame was 0.1 ms of every rank's frame whatever the rank count (profiles/r03_split_work_per_rank.md). Slots of other
+// rows stay as the (re)allocation left them: unused.
+KjStatus kj_ircache_begin_requests_rows(KjIrcache* c, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, uint32_t half_row_begin, uint32_t half_row_end, void* stream_) {
     KJ_REQUIRE(c && c->deferred, "deferred updates are off (kj_ircache_set_deferred_updates)");
+    KJ_REQUIRE(half_row_begin <= half_row_end && half_row_end <= rtdgi_half_height, "bad row range");
     hipStream_t s = (hipStream_t)stream_;
     c->req_half_pixels = rtdgi_half_width * rtdgi_half_height;
-    const size_t bytes = size_t(c->request_slots()) * sizeof(IrcRequest);
-    if (c->requests.bytes != bytes) KJ_TRY_HIP(c->requests.alloc(bytes, s));
-    KJ_TRY_HIP(hipMemsetAsync(c->requests.p, 0xff, bytes, s));      // cell = 0xffffffff: unused
+    const size_t RQ = sizeof(IrcRequest), bytes = size_t(c->request_slots()) * RQ;
+    const bool fresh = c->requests.bytes != bytes;
+    if (fresh) KJ_TRY_HIP(c->requests.alloc(bytes, s));
+    uint8_t* const base = (uint8_t*)c->requests.p;
+    if (fresh || (half_row_begin == 0u && half_row_end == rtdgi_half_height)) {
+        KJ_TRY_HIP(hipMemsetAsync(base, 0xff, bytes, s));      // cell = 0xffffffff: unused
+    } else {
+        const size_t hb = c->req_half_pixels, row0 = size_t(half_row_begin) * rtdgi_half_width, n = size_t(half_row_end - half_row_begin) * rtdgi_half_width;
+        size_t firsts[4] = {0, hb, 0, 0}; int ranges = 2;
+        if (c->rtr_requests) { firsts[2] = c->rtr_request_base(); firsts[3] = c->rtr_request_base() + hb; ranges = 4; }
+        if (n) for (int k = 0; k < ranges; ++k) KJ_TRY_HIP(hipMemsetAsync(base + (firsts[k] + row0) * RQ, 0xff, n * RQ, s));
+        KJ_TRY_HIP(hipMemsetAsync(base + 2 * hb * RQ, 0xff, size_t(2u * KjIrcache::REQ_E) * RQ, s));      // the cache's own validate and trace rays
+    }
     c->requests_begun = true;
     return KJ_OK;
 }

@@ -242,7 +242,8 @@ KjStatus render(KjSplit& s, uint32_t li, const KjSplitFrame& fr, uint32_t mask, 
 KjStatus ircache_head(KjSplit& s, uint32_t li, const KjSplitFrame& fr, hipStream_t st) {
     KjIrcache* c = s.ranks[li].ircache;
     KjStatus e;
-    if (s.consistent_ircache && (e = kj_ircache_begin_requests(c, s.hw, s.hh, st)) != KJ_OK) return e;
+    const auto h = half_rows(s, s.strips[s.first + li]);      // this rank's per-pixel passes run on its strip only: only those rows' record slots are cleared
+    if (s.consistent_ircache && (e = kj_ircache_begin_requests_rows(c, s.hw, s.hh, h.first, h.second, st)) != KJ_OK) return e;
     if ((e = kj_ircache_prepare(c, st)) != KJ_OK) return e;
     return kj_ircache_trace_irradiance(c, s.ranks[li].scene, fr.sky_cube16, 16, st);
 }

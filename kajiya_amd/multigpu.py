@@ -510,7 +510,7 @@ class SplitRtdgi:
 
     def _ircache_head(self, gp, s):
         if self.consistent_ircache:
-            gp.ircache_begin_requests()
+            gp.ircache_begin_requests(half_rows=half_rows(*self.strips[next(r for r in self.comm.ranks if self.pipes[r] is gp)], self.H))
         klib.check(gp.L.kj_ircache_prepare(gp.ircache, s))
         klib.check(gp.L.kj_ircache_trace_irradiance(gp.ircache, gp.scene.h, gp.sky16.data_ptr(), 16, s))
 
@@ -901,7 +901,7 @@ class NativeSplit:
                 if gp.ircache:
                     s = klib._stream_ptr()
                     if self.consistent_ircache:
-                        gp.ircache_begin_requests()
+                        gp.ircache_begin_requests(half_rows=half_rows(*self.strips[r], self.H))
                     klib.check(gp.L.kj_ircache_prepare(gp.ircache, s))
                     klib.check(gp.L.kj_ircache_trace_irradiance(gp.ircache, gp.scene.h, gp.sky16.data_ptr(), 16, s))
             if self.on_ircache_traced is not None:
