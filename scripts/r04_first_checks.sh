@@ -8,7 +8,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd); cd "$ROOT"; mkdir -p gpurun_out
 t0=$(date +%s)
 if [ -z "$SKIP_TESTS" ]; then
-  timeout 900 python -m pytest -q -m gpu tests/test_gpu_multigpu.py tests/test_gpu_rtr.py -k "not 2-2048-1024" > gpurun_out/r04_tests.log 2>&1
+  timeout 900 python -m pytest -q -m gpu tests/test_gpu_multigpu.py tests/test_gpu_rtr.py tests/test_zzz_gpu_split_reflections.py -k "not 2-2048-1024" > gpurun_out/r04_tests.log 2>&1
   echo "tests rc=$? $(( $(date +%s) - t0 )) s: $(tail -1 gpurun_out/r04_tests.log)"
 fi
 cd /tmp; export TMPDIR=/tmp
