@@ -520,4 +520,39 @@ struct WorldRenderer {
     }
 };
 
+// ---------------------------------------------------------------- the screen-tile split across the GPUs of a node (no counterpart in the reference: kajiya renders on one
+// GPU). One process per GPU; this process's rank with its renderers and an ncclComm_t made from kj_split_rccl_unique_id / kj_split_rccl_comm_create.
+// Per frame, in world_render_passes.rs order: ssgi_frame, shadow_frame, gi_frame, rtr_frame (after set_rtr once), kj_light_gbuffer_rows on strip(), taa_frame.
+struct ScreenTileSplit {
+    KjSplit* h = nullptr;
+    uint32_t rank;
+    ScreenTileSplit(uint32_t world, uint32_t rank_, RtdgiRenderer& rtdgi, TaaRenderer& taa, IrcacheRenderer* ircache, Scene& scene, uint32_t width, uint32_t height, uint32_t motion_halo,
+                    void* nccl_comm) : rank(rank_) {
+        KjSplitRank me;
+        std::memset(&me, 0, sizeof(me));
+        me.rtdgi = rtdgi.h; me.taa = taa.h; me.ircache = ircache ? ircache->h : nullptr; me.scene = scene.h;
+        check(kj_split_create(world, rank_, 1, &me, width, height, motion_halo, nccl_comm, &h), "kj_split_create");
+    }
+    ~ScreenTileSplit() { kj_split_destroy(h); }
+    ScreenTileSplit(const ScreenTileSplit&) = delete;
+    ScreenTileSplit& operator=(const ScreenTileSplit&) = delete;
+    std::array<uint32_t, 2> strip() const { std::array<uint32_t, 2> r{}; check(kj_split_strip(h, rank, &r[0], &r[1]), "kj_split_strip"); return r; }
+    bool self_test(hipStream_t s) { uint32_t ok = 0; check(kj_split_self_test(h, &ok, s), "kj_split_self_test"); return ok != 0; }      // combine over the ranks by the host's own means
+    const void* ssgi_frame(SsgiRenderer& ssgi, const KjSplitFrame& f, hipStream_t s) { KjSsgi* g = ssgi.h; const void* out = nullptr; check(kj_split_ssgi_frame(h, &g, &f, &out, s), "kj_split_ssgi_frame"); return out; }
+    const void* shadow_frame(ShadowDenoiseRenderer& dn, const KjSplitFrame& f, void* mask_r8, hipStream_t s) {
+        KjShadowDenoise* d = dn.h; const void* out = nullptr;
+        check(kj_split_shadow_frame(h, &d, &f, &mask_r8, nullptr, &out, s), "kj_split_shadow_frame"); return out;
+    }
+    void gi_frame(const KjSplitFrame& f, uint32_t flags, hipEvent_t trace_done, hipStream_t s) { check(kj_split_gi_frame(h, &f, flags, trace_done, s), "kj_split_gi_frame"); }
+    void set_rtr(bool enable) { check(kj_split_set_rtr(h, enable ? 1u : 0u), "kj_split_set_rtr"); }
+    const void* rtr_frame(RtrRenderer& rtr, const KjRtrParams& p, uint32_t flags, hipEvent_t trace_done, hipStream_t s) {
+        KjRtr* r = rtr.h; const void* out = nullptr;
+        check(kj_split_rtr_frame(h, &r, &p, flags, trace_done, &out, s), "kj_split_rtr_frame"); return out;
+    }
+    void merge_ircache(hipStream_t s) { check(kj_split_merge_ircache(h, s), "kj_split_merge_ircache"); }
+    void taa_frame(const KjSplitFrame& f, void* lit_rgba16f, hipStream_t s) {      // lit_rgba16f: the image to resolve (valid on strip()), or nullptr: the GI image
+        if (lit_rgba16f) check(kj_split_taa_frame_on(h, &f, &lit_rgba16f, s), "kj_split_taa_frame_on"); else check(kj_split_taa_frame(h, &f, s), "kj_split_taa_frame");
+    }
+};
+
 }  // namespace kajiya_amd
