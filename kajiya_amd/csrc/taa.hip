@@ -58,11 +58,11 @@ KJ_D V4 catmull_rom_5tap_history(const ImgH4& tex, V2 uv, V2 tex_size, float ped
     const V2 offset12 = w2 / (w1 + w2);
     const V2 p0 = (tex_pos1 - 1.0f) / tex_size, p3 = (tex_pos1 + 2.0f) / tex_size, p12 = (tex_pos1 + offset12) / tex_size;
     V4 result = v4(0.0f);
-    result += taa_history_tap(tex, V2{p12.x, p0.y}, ped) * (w12.x * w0.y);
-    result += taa_history_tap(tex, V2{p0.x, p12.y}, ped) * (w0.x * w12.y);
-    result += taa_history_tap(tex, V2{p12.x, p12.y}, ped) * (w12.x * w12.y);
-    result += taa_history_tap(tex, V2{p3.x, p12.y}, ped) * (w3.x * w12.y);
-    result += taa_history_tap(tex, V2{p12.x, p3.y}, ped) * (w12.x * w3.y);
+    result += taa_history_tap(tex, V2{p12.x, p0.y}, ped) * w12.x * w0.y;
+    result += taa_history_tap(tex, V2{p0.x, p12.y}, ped) * w0.x * w12.y;
+    result += taa_history_tap(tex, V2{p12.x, p12.y}, ped) * w12.x * w12.y;
+    result += taa_history_tap(tex, V2{p3.x, p12.y}, ped) * w3.x * w12.y;
+    result += taa_history_tap(tex, V2{p12.x, p3.y}, ped) * w12.x * w3.y;
     return result / (w12.x * w0.y + w0.x * w12.y + w12.x * w12.y + w3.x * w12.y + w12.x * w3.y);
 }
 

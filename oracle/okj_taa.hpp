@@ -50,11 +50,11 @@ struct Taa {
         const f2 offset12 = w2 / (w1 + w2);
         const f2 p0 = (tex_pos1 - 1.0f) / tex_size, p3 = (tex_pos1 + 2.0f) / tex_size, p12 = (tex_pos1 + offset12) / tex_size;
         f4 result = mk4(0.0f);
-        result += remap(sample_bilinear_clamp(tex, f2{p12.x, p0.y})) * (w12.x * w0.y);
-        result += remap(sample_bilinear_clamp(tex, f2{p0.x, p12.y})) * (w0.x * w12.y);
-        result += remap(sample_bilinear_clamp(tex, f2{p12.x, p12.y})) * (w12.x * w12.y);
-        result += remap(sample_bilinear_clamp(tex, f2{p3.x, p12.y})) * (w3.x * w12.y);
-        result += remap(sample_bilinear_clamp(tex, f2{p12.x, p3.y})) * (w12.x * w3.y);
+        result += remap(sample_bilinear_clamp(tex, f2{p12.x, p0.y})) * w12.x * w0.y;
+        result += remap(sample_bilinear_clamp(tex, f2{p0.x, p12.y})) * w0.x * w12.y;
+        result += remap(sample_bilinear_clamp(tex, f2{p12.x, p12.y})) * w12.x * w12.y;
+        result += remap(sample_bilinear_clamp(tex, f2{p3.x, p12.y})) * w3.x * w12.y;
+        result += remap(sample_bilinear_clamp(tex, f2{p12.x, p3.y})) * w12.x * w3.y;
         return result / (w12.x * w0.y + w0.x * w12.y + w12.x * w12.y + w3.x * w12.y + w12.x * w3.y);
     }
 

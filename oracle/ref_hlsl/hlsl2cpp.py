@@ -52,10 +52,10 @@ APPEND = {
 
 
 class Tok:
-    __slots__ = ("kind", "text")
+    __slots__ = ("kind", "text", "bind")
 
     def __init__(self, kind, text):
-        self.kind, self.text = kind, text
+        self.kind, self.text, self.bind = kind, text, None
 
     def sig(self):
         return self.kind not in ("ws", "lc", "bc")
@@ -117,6 +117,15 @@ class Rewriter:
             i += 1
         raise ValueError("unbalanced %s in %s" % (open_, self.relpath))
 
+    def binding_before(self, i):
+        """(binding, set) of the [[vk::binding]] attribute directly in front of token i, or ("-1", "-1")."""
+        k = i - 1
+        while k >= 0 and not self.toks[k].sig():
+            if self.toks[k].bind:
+                return self.toks[k].bind
+            k -= 1
+        return ("-1", "-1")
+
     def drop(self, a, b):
         for k in range(a, b + 1):
             if self.toks[k].kind != "ws" or "\n" not in self.toks[k].text:
@@ -170,7 +179,10 @@ class Rewriter:
                 j = self.nsig(i)
                 if self.is_(j, "["):                       # [[vk::...]]
                     e = self.match_close(i, "[", "]")
+                    m = re.match(r"\[\[vk::binding\((\w+)(?:,(\w+))?\)\]\]$", re.sub(r"\s+", "", "".join(x.text for x in T[i:e + 1])))
                     self.drop(i, e)
+                    if m:
+                        T[i].bind = (m.group(1), m.group(2) or "0")     # (binding, set); names when the declaration sits in a macro
                     i = e + 1
                     continue
                 jn = self.nsig(j) if j is not None else None
@@ -196,6 +208,7 @@ class Rewriter:
             elif t.kind == "op" and t.text == "}":
                 depth -= 1
             elif t.kind == "id" and t.text == "cbuffer":
+                cb_bind = self.binding_before(i)
                 n = self.nsig(i)
                 b = self.nsig(n) if T[n].kind == "id" else n
                 if self.is_(b, ":"):                          # `cbuffer X : register(b0)`
@@ -215,7 +228,7 @@ class Rewriter:
                         if self.is_(nx, ";") or self.is_(nx, "["):
                             name = T[x].text
                     if name:
-                        T[semi].text = '; static hlsl::ConstReg _creg_%s("%s", &%s, sizeof(%s));' % (name, name, name, name)
+                        T[semi].text = '; static hlsl::ConstReg _creg_%s("%s", &%s, sizeof(%s), %s, %s);' % (name, name, name, name, cb_bind[0], cb_bind[1])
                     k = self.nsig(semi)
                 self.drop(i, b)
                 s = self.nsig(e)
@@ -224,6 +237,7 @@ class Rewriter:
                 continue
             elif t.kind == "id" and (t.text in RESOURCE_TYPES or t.text == "ConstantBuffer"):
                 # TYPE [<...>] NAME [ [..] ] ;   -- only declarations (a NAME then `;`), at any depth inside a macro body or depth 0
+                res_bind = self.binding_before(i)
                 j = self.nsig(i)
                 type_end = i
                 if self.is_(j, "<"):
@@ -234,22 +248,24 @@ class Rewriter:
                 if j is not None and T[j].kind == "id" and depth == 0:
                     name = T[j].text
                     k = self.nsig(j)
-                    if self.is_(k, "["):                     # unbounded / sized arrays of resources (bindless): one slot
+                    if self.is_(k, "["):                     # arrays of resources (bindless tables): hlsl::ResourceArray, slots bound by index
                         ke = self.match_close(k, "[", "]")
+                        type_text = re.sub(r"\s+", "", "".join(x.text for x in T[i:type_end + 1]))
                         self.drop(k, ke)
-                        T[k].text = "[1]"
-                        k = self.nsig(ke)
-                        i = k
+                        T[i].text = "hlsl::ResourceArray<" + T[i].text
+                        T[type_end].text = T[type_end].text + ">"
+                        T[j].text = '%s{hlsl::ResName{"%s", "%s[]", %s, %s}}' % (name, name, type_text, res_bind[0], res_bind[1])
+                        i = self.nsig(ke)
                         continue
                     if self.is_(k, ";"):
                         type_text = "".join(x.text for x in T[i:type_end + 1]).replace('"', "").strip()
                         type_text = re.sub(r"\s+", "", type_text)
                         if t.text == "ConstantBuffer":
-                            T[k].text = '; static hlsl::ConstReg _creg_%s("%s", &%s, sizeof(%s));' % (name, name, name, name)
+                            T[k].text = '; static hlsl::ConstReg _creg_%s("%s", &%s, sizeof(%s), %s, %s);' % (name, name, name, name, res_bind[0], res_bind[1])
                         elif t.text in ("SamplerState", "SamplerComparisonState"):
                             T[j].text = '%s{"%s"}' % (name, name)
                         else:
-                            T[j].text = '%s{hlsl::ResName{"%s", "%s"}}' % (name, name, type_text)
+                            T[j].text = '%s{hlsl::ResName{"%s", "%s", %s, %s}}' % (name, name, type_text, res_bind[0], res_bind[1])
                         i = k
                         continue
             i += 1

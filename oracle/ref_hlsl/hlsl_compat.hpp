@@ -236,7 +236,15 @@ template <class R, class A, class F> static inline vres<R, VT<A>::n> map1(const 
     template <class A, HLSL_REQ(VT<A>::ok)> static inline vres<float, VT<A>::n> name(const A& a_) { return map1<float>(a_, [](typename VT<A>::elem v) { const float x = cv<float>(v); (void)x; return float(expr); }); }
 HLSL_FLOAT1(sqrt, std::sqrt(x)) HLSL_FLOAT1(rsqrt, 1.0f / std::sqrt(x)) HLSL_FLOAT1(rcp, 1.0f / x)
 HLSL_FLOAT1(exp, std::exp(x)) HLSL_FLOAT1(exp2, std::exp2(x)) HLSL_FLOAT1(log, std::log(x)) HLSL_FLOAT1(log2, std::log2(x)) HLSL_FLOAT1(log10, std::log10(x))
-HLSL_FLOAT1(sin, std::sin(x)) HLSL_FLOAT1(cos, std::cos(x)) HLSL_FLOAT1(tan, std::tan(x))
+// sin / cos: range reduction of the hardware the reference ran on (v_sin_f32 / v_cos_f32 take revolutions: x * 1/2pi, fract) -- DESIGN.md §4;
+// it matters for the ~500 rad spiral-tap angles of the denoiser kernels, whose int() taps a last-bit difference moves
+static inline float hw_turns_(float x) { float t = x * 0.15915494309189535f; t = t - std::floor(t); return t * 6.28318530717958647692f; }
+#ifdef HLSL_LIBM_SINCOS
+HLSL_FLOAT1(sin, std::sin(x)) HLSL_FLOAT1(cos, std::cos(x))
+#else
+HLSL_FLOAT1(sin, std::sin(hw_turns_(x))) HLSL_FLOAT1(cos, std::cos(hw_turns_(x)))
+#endif
+HLSL_FLOAT1(tan, std::tan(x))
 HLSL_FLOAT1(asin, std::asin(x)) HLSL_FLOAT1(acos, std::acos(x)) HLSL_FLOAT1(atan, std::atan(x))
 HLSL_FLOAT1(sinh, std::sinh(x)) HLSL_FLOAT1(cosh, std::cosh(x)) HLSL_FLOAT1(tanh, std::tanh(x))
 HLSL_FLOAT1(floor, std::floor(x)) HLSL_FLOAT1(ceil, std::ceil(x)) HLSL_FLOAT1(trunc, std::trunc(x)) HLSL_FLOAT1(round, std::nearbyint(x))

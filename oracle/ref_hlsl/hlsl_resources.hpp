@@ -86,12 +86,13 @@ static inline void store_texel(void* base, size_t index, int fmt, const Texel& t
     }
 }
 
-struct ResName { const char* name; const char* type; };
+struct ResName { const char* name; const char* type; int binding; int set; };       // [[vk::binding(binding, set)]]; -1 when unknown
 struct ResourceBase;
 void hlsl_register_resource(const ResName& n, ResourceBase* r);       // ref_runtime.cpp: into the pass whose wrapper is being initialised
 struct ResourceBase { void* data = nullptr; int w = 0, h = 0, depth = 1; int fmt = 0; size_t bytes = 0;
     ResourceBase() {}
-    explicit ResourceBase(const ResName& n) { hlsl_register_resource(n, this); } };
+    explicit ResourceBase(const ResName& n) { hlsl_register_resource(n, this); }
+    virtual ~ResourceBase() {} };
 #define HLSL_RES_CTORS(Type, Base) Type() {} explicit Type(const ResName& n) : Base(n) {}
 
 // texel <-> shader type T (scalar or vec of float / uint / int)
@@ -263,6 +264,14 @@ template <class D, class V> static inline void InterlockedAnd(D& d, V v) { d = D
 template <class D, class V, class O> static inline void InterlockedExchange(D& d, V v, O& orig) { orig = O(d); d = D(v); }
 template <class D, class C, class V, class O> static inline void InterlockedCompareExchange(D& d, C c, V v, O& orig) { orig = O(d); if (d == D(c)) d = D(v); }
 
+// `Texture2D bindless_textures[];`: a table of views, slots bound by index (ref_bind_slot)
+struct ResourceArrayBase : ResourceBase { ResourceArrayBase() {} explicit ResourceArrayBase(const ResName& n) : ResourceBase(n) {} virtual ResourceBase* slot(uint i) = 0; };
+template <class T> struct ResourceArray : ResourceArrayBase {
+    enum { SLOTS = 1024 }; T slots[SLOTS];
+    HLSL_RES_CTORS(ResourceArray, ResourceArrayBase)
+    T& operator[](uint i) { return slots[i < SLOTS ? i : 0]; }
+    ResourceBase* slot(uint i) override { return i < SLOTS ? &slots[i] : nullptr; } };
+static inline uint NonUniformResourceIndex(uint i) { return i; }
 template <class T> struct ConstantBuffer : T {};
 struct RayDesc { float3 Origin; float TMin; float3 Direction; float TMax; };
 
@@ -308,10 +317,10 @@ static inline void AllMemoryBarrier() {}
 // themselves as they are constructed), then PassEnd. Static initialisation inside a translation unit runs in declaration order.
 void hlsl_pass_begin(const char* name);
 void hlsl_pass_end(const uint nt[3], bool lockstep, void (*invoke)(const LaneInfo&));
-void hlsl_register_constant(const char* name, void* ptr, size_t bytes);
+void hlsl_register_constant(const char* name, void* ptr, size_t bytes, int binding, int set);
 struct PassBegin { explicit PassBegin(const char* name) { hlsl_pass_begin(name); } };
 struct PassEnd { PassEnd(const uint nt[3], bool lockstep, void (*invoke)(const LaneInfo&)) { hlsl_pass_end(nt, lockstep, invoke); } };
-struct ConstReg { ConstReg(const char* name, void* ptr, size_t bytes) { hlsl_register_constant(name, ptr, bytes); } };
+struct ConstReg { ConstReg(const char* name, void* ptr, size_t bytes, int binding = -1, int set = -1) { hlsl_register_constant(name, ptr, bytes, binding, set); } };
 template <class T> static inline T lane_arg(const uint3& v) { return T(v); }          // uint3 -> uint3 / (explicitly truncated) uint2 / int2 ...
 template <> inline uint lane_arg<uint>(const uint3& v) { return v.x; }
 template <> inline int lane_arg<int>(const uint3& v) { return int(v.x); }

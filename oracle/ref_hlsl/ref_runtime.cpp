@@ -9,8 +9,8 @@
 
 namespace hlsl {
 
-struct ResourceSlot { std::string name, type; ResourceBase* res; };
-struct ConstantSlot { std::string name; void* ptr; size_t bytes; };
+struct ResourceSlot { std::string name, type; ResourceBase* res; int binding, set; };
+struct ConstantSlot { std::string name; void* ptr; size_t bytes; int binding, set; };
 struct PassInfo { std::string name_s; const char* name = ""; uint nt[3] = {1, 1, 1}; bool needs_lockstep = false; void (*invoke)(const LaneInfo&) = nullptr;
     std::vector<ResourceSlot> resources; std::vector<ConstantSlot> constants; };
 static std::vector<PassInfo*>& registry() { static std::vector<PassInfo*> r; return r; }
@@ -18,8 +18,8 @@ static PassInfo*& open_pass() { static PassInfo* p = nullptr; return p; }
 void hlsl_pass_begin(const char* name) { PassInfo* p = new PassInfo; p->name_s = name; p->name = p->name_s.c_str(); open_pass() = p; }
 void hlsl_pass_end(const uint nt[3], bool lockstep, void (*invoke)(const LaneInfo&)) {
     PassInfo* p = open_pass(); for (int i = 0; i < 3; ++i) p->nt[i] = nt[i]; p->needs_lockstep = lockstep; p->invoke = invoke; registry().push_back(p); open_pass() = nullptr; }
-void hlsl_register_resource(const ResName& n, ResourceBase* r) { if (open_pass()) open_pass()->resources.push_back(ResourceSlot{n.name, n.type, r}); }
-void hlsl_register_constant(const char* name, void* ptr, size_t bytes) { if (open_pass()) open_pass()->constants.push_back(ConstantSlot{name, ptr, bytes}); }
+void hlsl_register_resource(const ResName& n, ResourceBase* r) { if (open_pass()) open_pass()->resources.push_back(ResourceSlot{n.name, n.type, r, n.binding, n.set}); }
+void hlsl_register_constant(const char* name, void* ptr, size_t bytes, int binding, int set) { if (open_pass()) open_pass()->constants.push_back(ConstantSlot{name, ptr, bytes, binding, set}); }
 
 // ------------------------------------------------------------------------------------------------ lanes
 enum LaneState { LANE_READY = 0, LANE_WAIT_WAVE = 1, LANE_WAIT_GROUP = 2, LANE_DONE = 3 };
@@ -136,6 +136,10 @@ int ref_pass_exists(const char* pass) { return find(pass) != nullptr; }
 int ref_pass_resource_count(const char* pass) { const PassInfo* p = find(pass); return p ? int(p->resources.size()) : -1; }
 const char* ref_pass_resource_name(const char* pass, int i) { return find(pass)->resources[size_t(i)].name.c_str(); }
 const char* ref_pass_resource_type(const char* pass, int i) { return find(pass)->resources[size_t(i)].type.c_str(); }
+int ref_pass_resource_binding(const char* pass, int i) { return find(pass)->resources[size_t(i)].binding; }
+int ref_pass_resource_set(const char* pass, int i) { return find(pass)->resources[size_t(i)].set; }
+int ref_pass_constant_binding(const char* pass, int i) { return find(pass)->constants[size_t(i)].binding; }
+int ref_pass_constant_set(const char* pass, int i) { return find(pass)->constants[size_t(i)].set; }
 int ref_pass_constant_count(const char* pass) { const PassInfo* p = find(pass); return p ? int(p->constants.size()) : -1; }
 const char* ref_pass_constant_name(const char* pass, int i) { return find(pass)->constants[size_t(i)].name.c_str(); }
 int ref_pass_constant_bytes(const char* pass, int i) { return int(find(pass)->constants[size_t(i)].bytes); }
@@ -147,6 +151,15 @@ int ref_bind(const char* pass, const char* name, void* data, int w, int h, int f
     for (size_t i = 0; i < p->resources.size(); ++i) if (p->resources[i].name == name) {
         ResourceBase* r = p->resources[i].res; r->data = data; r->w = w; r->h = h; r->fmt = fmt;
         r->bytes = bytes ? size_t(bytes) : size_t(w) * size_t(h) * size_t(format_bytes(fmt)); return 0; }
+    return -2;
+}
+// one slot of a resource array (`Texture2D bindless_textures[]`)
+int ref_bind_slot(const char* pass, const char* name, unsigned index, void* data, int w, int h, int fmt) {
+    PassInfo* p = find(pass); if (!p) return -1;
+    for (size_t i = 0; i < p->resources.size(); ++i) if (p->resources[i].name == name) {
+        ResourceArrayBase* a = dynamic_cast<ResourceArrayBase*>(p->resources[i].res); if (!a) return -4;
+        ResourceBase* r = a->slot(index); if (!r) return -5;
+        r->data = data; r->w = w; r->h = h; r->fmt = fmt; r->bytes = size_t(w) * size_t(h) * size_t(format_bytes(fmt)); return 0; }
     return -2;
 }
 int ref_set_constant(const char* pass, const char* name, const void* src, unsigned long long bytes) {

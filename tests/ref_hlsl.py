@@ -1,0 +1,126 @@
+"""TEST INFRASTRUCTURE: loader for oracle/_ref/libref_hlsl.so -- the reference's own HLSL text compiled for the CPU (oracle/ref_hlsl/) --
+and a host side for it that binds memory the way kajiya's SimpleRenderPass does: positionally, in `.read()` / `.write()` order, to the
+`[[vk::binding(n)]]` numbers of descriptor set 0, the `.constants((...))` tuple into the cbuffer that follows them."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+LIB_PATH = os.path.join(REF_DIR, "libref_hlsl.so")
+REFERENCE = "/root/reference"
+
+# hlsl_resources.hpp: enum Format
+FMT = dict(r32f=1, rg32f=2, rgba32f=3, r16f=4, rg16f=5, rgba16f=6, r8=7, rgba8=8, r8s=9, rgba8s=10, rgba16s=11, r11g11b10f=12, a2r10g10b10=13,
+           r32ui=14, rg32ui=15, rgba32ui=16, rg16s=17, r16=18, rg8=19,
+           reservoir=15, trp=16)   # parity.py's names for RG32UI reservoirs / the RGBA32UI packed temporal reservoir
+FMT_BYTES = {1: 4, 2: 8, 3: 16, 4: 2, 5: 4, 6: 8, 7: 1, 8: 4, 9: 1, 10: 4, 11: 8, 12: 4, 13: 4, 14: 4, 15: 8, 16: 16, 17: 4, 18: 2, 19: 2}
+
+_LIB = None
+
+
+def available():
+    return os.path.exists(LIB_PATH) or os.path.isdir(os.path.join(REFERENCE, "assets", "shaders"))
+
+
+def build():
+    """Rebuild from the reference checkout when there is one (this container); elsewhere the prebuilt library is what there is."""
+    if os.path.isdir(os.path.join(REFERENCE, "assets", "shaders")):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle", "ref_hlsl")])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        for f in ("ref_pass_name", "ref_pass_resource_name", "ref_pass_resource_type", "ref_pass_constant_name"):
+            getattr(L, f).restype = C.c_char_p
+        L.ref_bind.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ulonglong]
+        L.ref_set_constant.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_ulonglong]
+        L.ref_dispatch.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint]
+        L.ref_bind_slot.argtypes = [C.c_char_p, C.c_char_p, C.c_uint, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def passes():
+    L = lib()
+    return [L.ref_pass_name(i).decode() for i in range(L.ref_pass_count())]
+
+
+class Tex:
+    """A flat row-major image in one of the reference's texel formats, over a numpy byte buffer."""
+
+    def __init__(self, raw, w, h, fmt):
+        self.fmt = FMT[fmt] if isinstance(fmt, str) else fmt
+        self.raw = np.ascontiguousarray(raw).reshape(-1).view(np.uint8)
+        self.w, self.h = int(w), int(h)
+        assert self.raw.size == self.w * self.h * FMT_BYTES[self.fmt], (self.raw.size, w, h, fmt)
+
+    @staticmethod
+    def zeros(w, h, fmt):
+        f = FMT[fmt] if isinstance(fmt, str) else fmt
+        return Tex(np.zeros(int(w) * int(h) * FMT_BYTES[f], np.uint8), w, h, f)
+
+
+class Buf:
+    def __init__(self, raw):
+        self.raw = np.ascontiguousarray(raw).reshape(-1).view(np.uint8)
+
+
+def extent_inv_extent(w, h):
+    """ImageDesc::extent_inv_extent_2d (kajiya-backend image.rs): [w, h, 1/w, 1/h] as f32"""
+    return np.array([w, h, np.float32(1.0) / np.float32(w), np.float32(1.0) / np.float32(h)], np.float32)
+
+
+BINDLESS = {}       # slot -> Tex: descriptor set 1's `bindless_textures[]` (inc/bindless_textures.hlsl: 0 BRDF-FG LUT, 1 blue noise, 2 Bezold-Brucke LUT)
+
+
+def set_bindless(slot, tex):
+    BINDLESS[slot] = tex
+
+
+def run_pass(name, resources, constants, frame_constants, dispatch):
+    """resources: Tex / Buf objects in .read()/.write() order; constants: numpy scalars / arrays in .constants((...)) order;
+    dispatch: the thread extent given to .dispatch([x, y, z])."""
+    L = lib()
+    pn = name.encode()
+    assert L.ref_pass_exists(pn), (name, passes())
+    slots = []
+    for i in range(L.ref_pass_resource_count(pn)):
+        if L.ref_pass_resource_set(pn, i) == 0:
+            slots.append((L.ref_pass_resource_binding(pn, i), L.ref_pass_resource_name(pn, i)))
+    slots.sort()
+    assert [b for b, _ in slots] == list(range(len(slots))), (name, slots)          # set 0 is dense from binding 0, like SimpleRenderPass binds it
+    assert len(slots) == len(resources), (name, [n for _, n in slots], len(resources))
+    keep = []
+    for (_, rn), r in zip(slots, resources):
+        if isinstance(r, Tex):
+            rc = L.ref_bind(pn, rn, r.raw.ctypes.data, r.w, r.h, r.fmt, 0)
+        else:
+            rc = L.ref_bind(pn, rn, r.raw.ctypes.data, 0, 0, 0, r.raw.size)
+        assert rc == 0, (name, rn, rc)
+        keep.append(r)
+    # the cbuffer of set 0 sits right after the resources; members in declaration order = the order of the .constants() tuple
+    cmembers = [i for i in range(L.ref_pass_constant_count(pn)) if L.ref_pass_constant_set(pn, i) == 0]
+    if constants is None:       # a pass recorded without .constants(): whatever cbuffer the shader declares is unbound (and must be unused)
+        constants, cmembers = [], []
+    assert len(cmembers) == len(constants), (name, [L.ref_pass_constant_name(pn, i) for i in cmembers], len(constants))
+    for i, v in zip(cmembers, constants):
+        assert L.ref_pass_constant_binding(pn, i) == len(slots), (name, L.ref_pass_constant_name(pn, i))
+        b = np.ascontiguousarray(v).reshape(-1).view(np.uint8)
+        assert L.ref_set_constant(pn, L.ref_pass_constant_name(pn, i), b.ctypes.data, b.size) == 0, (name, L.ref_pass_constant_name(pn, i), b.size, L.ref_pass_constant_bytes(pn, i))
+    if frame_constants is not None:
+        names = [L.ref_pass_constant_name(pn, i) for i in range(L.ref_pass_constant_count(pn))]
+        if b"frame_constants" in names:
+            assert C.sizeof(frame_constants) == 1216
+            assert L.ref_set_constant(pn, b"frame_constants", C.byref(frame_constants), 1216) == 0
+    for i in range(L.ref_pass_resource_count(pn)):
+        if L.ref_pass_resource_name(pn, i) == b"bindless_textures":
+            for slot, t in BINDLESS.items():
+                assert L.ref_bind_slot(pn, b"bindless_textures", slot, t.raw.ctypes.data, t.w, t.h, t.fmt) == 0
+    d = list(dispatch) + [1] * (3 - len(dispatch))
+    assert L.ref_dispatch(pn, int(d[0]), int(d[1]), int(d[2])) == 0
+    return keep

@@ -1,0 +1,302 @@
+"""The oracle pinned to the reference's own text. oracle/_ref/libref_hlsl.so is kajiya's HLSL -- read in place from
+/root/reference/assets/shaders, rewritten token by token and compiled for the CPU (oracle/ref_hlsl/) -- and these tests run it and the
+hand-written oracle (oracle/okj_*.hpp) on the same inputs:
+
+  phase B  every ray-free compute pass of the GI path, dispatched the way the reference's Rust records it (renderers/rtdgi.rs,
+           taa.rs, reprojection.rs, half_res.rs: binding order, constants tuple, dispatch extent), against the oracle's pass on the
+           oracle's own frame state, under the same bars the GPU-vs-oracle tests use (tests/parity.py: 1e-3 relative L2, <= 0.2 % outliers).
+
+Not GPU tests: this runs wherever the library is (built here, where the reference checkout is; it travels to the GPU box prebuilt)."""
+import ctypes as C
+import numpy as np
+import pytest
+
+import parity as P
+import ref_hlsl as R
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="neither a reference checkout nor a prebuilt oracle/_ref/libref_hlsl.so")
+
+KEEP = 1 << 31
+
+
+def _frame_constants(W, H, n_frames, scene="cornell"):
+    from kajiya_amd import frame
+    fs = frame.FrameState((W, H))
+    out = []
+    for i in range(n_frames):
+        if scene == "cornell":
+            cam = frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.01)
+        else:
+            cam = frame.orbit_camera(i, (W, H), center=(0.0, 6.0, 0.0), radius=60.0, height=14.0, rate=0.004)
+        out.append(fs.prepare_frame_constants(cam))
+        fs.retire_frame()
+    return out
+
+
+def _surfaces(op):
+    out = {}
+    for name in list(P.FORMATS.keys()):
+        if name.startswith("rtr") or name in ("refl_restir_invalidity_tex", "resolved_tex"):
+            continue
+        for suffix in ("", ":0", ":1"):
+            n = name + suffix
+            try:
+                out[n] = op.surface(n, np.uint8, (-1,)).copy()
+            except KeyError:
+                pass
+    return out
+
+
+class _Frame:
+    """The oracle's state around one pass, as named textures for the reference pass: inputs from `before`, outputs into copies."""
+
+    def __init__(self, op, before, frame_no, W, H):
+        self.op, self.before, self.W, self.H = op, before, W, H
+        self.hw, self.hh = (W + 1) // 2, (H + 1) // 2
+        self.out_sfx, self.hist_sfx = (":0", ":1") if frame_no % 2 == 0 else (":1", ":0")      # PingPongTemporalResource (renderers/mod.rs:85-102)
+        self.written = {}
+
+    def _dims(self, name):
+        return (self.W, self.H) if P.base_name(name) in P.FULL_RES else (self.hw, self.hh)
+
+    def rd(self, name):
+        w, h = self._dims(name)
+        return R.Tex(self.before[name].copy(), w, h, P.fmt_of(name))
+
+    def wr(self, name):
+        w, h = self._dims(name)
+        t = R.Tex(self.before[name].copy(), w, h, P.fmt_of(name))
+        self.written[name] = t
+        return t
+
+    def hist(self, key):
+        return self.rd(key + self.hist_sfx)
+
+    def out(self, key):
+        return self.wr(key + self.out_sfx)
+
+    def out_as_input(self, key):
+        return self.rd(key + self.out_sfx)
+
+    # the frame's inputs (not rtdgi surfaces)
+    def depth(self):
+        return R.Tex(self.op.depth, self.W, self.H, "r32f")
+
+    def gbuffer(self):
+        return R.Tex(self.op.gbuffer, self.W, self.H, "rgba32f")
+
+    def geometric_normal(self):
+        return R.Tex(self.op.geometric_normal, self.W, self.H, "a2r10g10b10")
+
+    def reprojection_map(self):
+        return R.Tex(self.op.reprojection_map, self.W, self.H, "rgba16s")
+
+    def ssao(self):
+        return R.Tex(self.op.ssao, self.W, self.H, "r8")
+
+
+def _ref_rtdgi_pass(pname, f, fc, spatial_passes=2, raytraced=False):
+    """Records one rtdgi pass like renderers/rtdgi.rs does. Returns the surfaces it wrote (name -> Tex)."""
+    W, H, hw, hh = f.W, f.H, f.hw, f.hh
+    g, ho = R.extent_inv_extent(W, H), R.extent_inv_extent(hw, hh)
+    if pname == "REPROJECT":                     # rtdgi.rs:143-170
+        R.run_pass("rtdgi/fullres_reproject", [f.hist("rtdgi.temporal2"), f.reprojection_map(), f.wr("reprojected_history_tex")], [g], fc, (W, H, 1))
+    elif pname == "EXTRACT_HALF":                # rtdgi.rs:189-202, half_res.rs:4-44 (no .constants(): the cbuffer is declared and unused)
+        R.run_pass("extract_half_res_ssao", [f.ssao(), f.wr("half_ssao_tex")], None, fc, (hw, hh, 1))
+        R.run_pass("extract_half_res_gbuffer_view_normal_rgba8", [f.gbuffer(), f.wr("half_view_normal_tex")], None, fc, (hw, hh, 1))
+        R.run_pass("extract_half_res_depth", [f.depth(), f.wr("half_depth_tex")], None, fc, (hw, hh, 1))
+    elif pname == "VALIDITY_INTEGRATE":          # rtdgi.rs:352-367
+        R.run_pass("rtdgi/temporal_validity_integrate",
+                   [f.rd("rt_history_validity_input_tex"), f.hist("rtdgi.invalidity"), f.reprojection_map(), f.rd("half_view_normal_tex"), f.rd("half_depth_tex"),
+                    f.out("rtdgi.invalidity")], [g, ho], fc, (hw, hh, 1))
+    elif pname == "RESTIR_TEMPORAL":             # rtdgi.rs:369-397
+        R.run_pass("rtdgi/restir_temporal",
+                   [f.rd("half_view_normal_tex"), f.depth(), f.rd("candidate_radiance_tex"), f.rd("candidate_normal_tex"), f.rd("candidate_hit_tex"),
+                    f.hist("rtdgi.radiance"), f.hist("rtdgi.ray_orig"), f.hist("rtdgi.ray"), f.hist("rtdgi.reservoir"), f.reprojection_map(),
+                    f.hist("rtdgi.hit_normal"), f.hist("rtdgi.candidate"), f.out_as_input("rtdgi.invalidity"),
+                    f.out("rtdgi.radiance"), f.out("rtdgi.ray_orig"), f.out("rtdgi.ray"), f.out("rtdgi.hit_normal"), f.out("rtdgi.reservoir"), f.out("rtdgi.candidate"),
+                    f.wr("temporal_reservoir_packed_tex")], [g], fc, (hw, hh, 1))
+    elif pname == "RESTIR_SPATIAL":              # rtdgi.rs:402-474: two passes, ping-ponging reservoir_output_tex0 / 1
+        names = ["reservoir_output_tex0", "reservoir_output_tex1"]
+        reservoir_in = f.out_as_input("rtdgi.reservoir")
+        bounced_in = R.Tex(f.before["rtdgi.radiance" + f.out_sfx].copy(), hw, hh, "rgba16f")           # `bounced_radiance_input_tex = &radiance_tex` for pass 0
+        for idx in range(spatial_passes):
+            out = f.wr(names[idx & 1])
+            bounced_out = R.Tex.zeros(hw, hh, "r11g11b10f")
+            R.run_pass("rtdgi/restir_spatial",
+                       [reservoir_in, bounced_in, f.rd("half_view_normal_tex"), f.rd("half_depth_tex"), f.depth(), f.rd("half_ssao_tex"),
+                        f.rd("temporal_reservoir_packed_tex"), f.rd("reprojected_history_tex"), out, bounced_out],
+                       [g, ho, np.uint32(idx), np.uint32(1 if idx + 1 == spatial_passes else 0), np.uint32(1 if raytraced else 0)], fc, (hw, hh, 1))
+            reservoir_in, bounced_in = R.Tex(out.raw.copy(), hw, hh, "rg32ui"), bounced_out
+    elif pname == "RESTIR_RESOLVE":              # rtdgi.rs:503-524
+        last = "reservoir_output_tex%d" % ((spatial_passes - 1) & 1) if spatial_passes else "rtdgi.reservoir" + f.out_sfx
+        R.run_pass("rtdgi/restir_resolve",
+                   [f.out_as_input("rtdgi.radiance"), f.rd(last), f.gbuffer(), f.depth(), f.rd("half_view_normal_tex"), f.rd("half_depth_tex"), f.ssao(),
+                    f.rd("candidate_radiance_tex"), f.rd("candidate_hit_tex"), f.rd("temporal_reservoir_packed_tex"), R.Tex.zeros(hw, hh, "r11g11b10f"),
+                    f.wr("irradiance_output_tex")], [g, g], fc, (W, H, 1))
+    elif pname == "TEMPORAL_FILTER":             # rtdgi.rs:71-115
+        R.run_pass("rtdgi/temporal_filter",
+                   [f.rd("irradiance_output_tex"), f.rd("reprojected_history_tex"), f.hist("rtdgi.temporal2_var"), f.reprojection_map(), f.out_as_input("rtdgi.invalidity"),
+                    f.wr("temporal_filtered_tex"), f.out("rtdgi.temporal2"), f.out("rtdgi.temporal2_var")], [g, g], fc, (W, H, 1))
+    elif pname == "SPATIAL_FILTER":              # rtdgi.rs:117-141
+        R.run_pass("rtdgi/spatial_filter",
+                   [f.rd("temporal_filtered_tex"), f.depth(), f.ssao(), f.geometric_normal(), f.wr("spatial_filtered_tex")], [g], fc, (W, H, 1))
+    else:
+        raise KeyError(pname)
+    return f.written
+
+
+RAY_FREE = ["REPROJECT", "EXTRACT_HALF", "VALIDITY_INTEGRATE", "RESTIR_TEMPORAL", "RESTIR_SPATIAL", "RESTIR_RESOLVE", "TEMPORAL_FILTER", "SPATIAL_FILTER"]
+PASS_ORDER = ["EXTRACT_HALF", "VALIDATE", "TRACE", "VALIDITY_INTEGRATE", "RESTIR_TEMPORAL", "RESTIR_SPATIAL", "RESTIR_RESOLVE", "TEMPORAL_FILTER", "SPATIAL_FILTER"]
+
+
+def _check(r, what, pname=""):
+    """The bars of the GPU-vs-oracle tests -- and, on top of them, what this comparison actually delivers: with the oracle and the
+    compiled reference text sharing the definitions of DESIGN.md §4 for everything HLSL leaves to the implementation, the two are
+    the same arithmetic in the same order, and their outputs are byte-identical. A texel that differs is a difference in reading."""
+    assert P.pass_within_bars(pname, r), f"{what}: reference HLSL vs oracle {r}"
+    assert r["differ_frac"] == 0.0, f"{what}: within the bars but not byte-identical: {r}"
+
+
+def _bind_luts(oracle):
+    """Descriptor set 1 (default_world_renderer.rs:20-40): the BRDF-FG LUT and the blue-noise image, the oracle's copies of both."""
+    R.set_bindless(0, R.Tex(oracle.brdf_lut(), 64, 64, "rgba16f"))
+    R.set_bindless(1, R.Tex(oracle.blue_noise(), 256, 256, "rgba8"))
+
+
+def _rtdgi_chain(oracle, scene_name, W, H, n_frames, warmup, report=None, spatial_passes=2, raytraced=False):
+    from kajiya_amd import scenes
+    _bind_luts(oracle)
+    from kajiya_amd.abi import KJ_RTDGI_PASS
+    desc = scenes.cornell_box() if scene_name == "cornell" else scenes.procedural_city(seed=1234, target_tris=20000)
+    op = oracle.OraclePipeline(oracle.OracleScene(desc), W, H)
+    op.L.okj_rtdgi_set_options(op.rtdgi, spatial_passes)
+    op.L.okj_rtdgi_set_raytraced_visibility(op.rtdgi, int(raytraced))
+    fcs = _frame_constants(W, H, n_frames, scene_name)
+    worst = {}
+    for fi, fc in enumerate(fcs):
+        op.render_inputs(fc); op.reprojection(fc)
+        if fi < warmup:
+            op.rtdgi_frame(fc)
+            continue
+        before = _surfaces(op)
+        op.L.okj_rtdgi_reproject(op.rtdgi, C.byref(fc), op.reprojection_map.ctypes.data, W, H)
+        first = True
+        for pname in ["REPROJECT"] + PASS_ORDER:
+            if pname != "REPROJECT":
+                before = _surfaces(op)
+                mask = KJ_RTDGI_PASS[pname] | (0 if first else KEEP)
+                first = False
+                p = op.params(mask)
+                op.L.okj_rtdgi_render(op.rtdgi, C.byref(fc), C.byref(p), C.byref(op.out))
+            if pname not in RAY_FREE:
+                continue
+            after = _surfaces(op)
+            written = _ref_rtdgi_pass(pname, _Frame(op, before, fi, W, H), fc, spatial_passes=spatial_passes, raytraced=raytraced)
+            for n, t in written.items():
+                if raytraced and pname == "RESTIR_SPATIAL" and n == "reservoir_output_tex%d" % ((spatial_passes - 1) & 1):
+                    continue     # the oracle's RESTIR_SPATIAL step ends with "restir check" (rtdgi.rs:478-494), a ray pass, on the last reservoir image
+                r = P.compare(t.raw, after[n], P.fmt_of(n), vector=P.is_vector(n))
+                key = (pname, P.base_name(n))
+                if key not in worst or r["rel_l2"] > worst[key]["rel_l2"]:
+                    worst[key] = r
+                if report is not None:
+                    report.append((fi, pname, n, r))
+                else:
+                    _check(r, f"frame {fi} pass {pname} surface {n}", pname)
+            # and nothing else changed on the oracle's side that the reference pass does not write
+            for n in after:
+                if n not in written and not np.array_equal(after[n], before[n]):
+                    raise AssertionError(f"frame {fi} pass {pname}: the oracle wrote {n}, the reference pass does not")
+    return worst
+
+
+@pytest.mark.parametrize("scene_name,W,H,passes,raytraced", [("cornell", 64, 64, 2, False), ("cornell", 72, 40, 2, False), ("city", 96, 56, 2, False),
+                                                             ("cornell", 40, 40, 1, False), ("cornell", 40, 40, 3, True)])
+def test_rtdgi_ray_free_passes_reference_hlsl_vs_oracle(oracle, scene_name, W, H, passes, raytraced):
+    """fullres_reproject, the half-res extracts, validity integrate, temporal + N x spatial ReSTIR, resolve, temporal and spatial filter:
+    frames 5 (tracing), 6 (validation: frame_index % 3 == 0) and 7 after five warm-up frames. Extents that are not multiples of the
+    8x8 group, a moving camera over a 20 k-triangle city, 1 / 2 / 3 spatial passes, occlusion_raymarch_importance_only on and off."""
+    worst = _rtdgi_chain(oracle, scene_name, W, H, n_frames=8, warmup=5, spatial_passes=passes, raytraced=raytraced)
+    assert len(worst) >= (18 if passes >= 2 and not raytraced else 17), sorted(worst)
+
+
+@pytest.mark.parametrize("scene_name,W,H", [("cornell", 64, 64), ("city", 104, 60)])
+def test_reprojection_map_reference_hlsl_vs_oracle(oracle, scene_name, W, H):
+    """calculate_reprojection_map.hlsl as renderers/reprojection.rs:6-52 records it, on a moving camera, against the oracle's map."""
+    from kajiya_amd import scenes
+    desc = scenes.cornell_box() if scene_name == "cornell" else scenes.procedural_city(seed=1234, target_tris=20000)
+    op = oracle.OraclePipeline(oracle.OracleScene(desc), W, H)
+    for fi, fc in enumerate(_frame_constants(W, H, 4, scene_name)):
+        op.render_inputs(fc)
+        prev_depth = op.prev_depth.copy()
+        op.reprojection(fc)
+        out = R.Tex.zeros(W, H, "rgba16s")
+        out.raw[:] = 0xcd
+        R.run_pass("calculate_reprojection_map", [R.Tex(op.depth, W, H, "r32f"), R.Tex(op.geometric_normal, W, H, "a2r10g10b10"), R.Tex(prev_depth, W, H, "r32f"),
+                                                  R.Tex(op.velocity, W, H, "rgba16f"), out], [R.extent_inv_extent(W, H)], fc, (W, H, 1))
+        a, b = out.raw.view(np.int16).reshape(-1, 4), op.reprojection_map.reshape(-1, 4)
+        assert np.array_equal(a, b), (fi, int((a != b).any(axis=1).sum()), a[(a != b).any(axis=1)][:4], b[(a != b).any(axis=1)][:4])
+
+
+# ---------------------------------------------------------------------------------------------------------------- TAA (renderers/taa.rs:41-191)
+TAA_FORMATS = {"taa": "rgba16f", "taa.velocity": "rg16f", "taa.smooth_var": "rgba16f", "reprojected_history_img": "rgba16f", "closest_velocity_img": "rg16f",
+               "filtered_input_img": "rgba16f", "filtered_input_deviation_img": "rgba16f", "filtered_history_img": "rgba16f", "input_prob_img": "r16f",
+               "prob_filtered1_img": "r16f", "prob_filtered2_img": "r16f", "this_frame_output_img": "rgba16f"}
+
+
+def _taa_surfaces(op):
+    out = {}
+    for name in TAA_FORMATS:
+        for suffix in ("", ":0", ":1"):
+            try:
+                out[name + suffix] = op.taa_surface(name + suffix, np.uint8, (-1,)).copy()
+            except (KeyError, AttributeError):
+                pass
+    return out
+
+
+@pytest.mark.parametrize("W,H", [(64, 64), (72, 40)])
+def test_taa_passes_reference_hlsl_vs_oracle(oracle, W, H):
+    """The seven TAA passes on the GI output, frames 0..5 (frame 0: empty history), each reference pass fed the oracle's surfaces."""
+    from kajiya_amd import scenes
+    _bind_luts(oracle)
+    op = oracle.OraclePipeline(oracle.OracleScene(scenes.cornell_box()), W, H)
+    g = R.extent_inv_extent(W, H)
+    compared = set()
+    for fi, fc in enumerate(_frame_constants(W, H, 6)):
+        op.render_inputs(fc); op.reprojection(fc); op.rtdgi_frame(fc)
+        before = _taa_surfaces(op) if fi else {}
+        op.taa_frame(fc)
+        after = _taa_surfaces(op)
+        out_sfx, hist_sfx = (":0", ":1") if fi % 2 == 0 else (":1", ":0")
+
+        def tex(d, n):
+            raw = d.get(n)
+            if raw is None:
+                raw = np.zeros_like(after[n])          # frame 0: a temporal that does not exist yet is created cleared
+            return R.Tex(raw.copy(), W, H, TAA_FORMATS[n.split(":")[0]])
+        inp = R.Tex(op.surface("spatial_filtered_tex", np.uint8, (-1,)).copy(), W, H, "rgba16f")
+        depth, reproj = R.Tex(op.depth, W, H, "r32f"), R.Tex(op.reprojection_map, W, H, "rgba16s")
+        written = {}
+
+        def wr(n):
+            written[n] = tex(after, n)
+            written[n].raw[:] = 0xcd                     # every texel must be written by the pass
+            return written[n]
+        R.run_pass("taa/reproject_history", [tex(before, "taa" + hist_sfx), reproj, depth, wr("reprojected_history_img"), wr("closest_velocity_img")], [g, g], fc, (W, H, 1))
+        R.run_pass("taa/filter_input", [inp, depth, wr("filtered_input_img"), wr("filtered_input_deviation_img")], None, fc, (W, H, 1))
+        R.run_pass("taa/filter_history", [tex(after, "reprojected_history_img"), wr("filtered_history_img")], [g, g], fc, (W, H, 1))
+        R.run_pass("taa/input_prob", [inp, tex(after, "filtered_input_img"), tex(after, "filtered_input_deviation_img"), tex(after, "reprojected_history_img"),
+                                      tex(after, "filtered_history_img"), reproj, depth, tex(before, "taa.smooth_var" + hist_sfx), tex(before, "taa.velocity" + hist_sfx),
+                                      wr("input_prob_img")], [g], fc, (W, H, 1))
+        R.run_pass("taa/filter_prob", [tex(after, "input_prob_img"), wr("prob_filtered1_img")], None, fc, (W, H, 1))
+        R.run_pass("taa/filter_prob2", [tex(after, "prob_filtered1_img"), wr("prob_filtered2_img")], None, fc, (W, H, 1))
+        R.run_pass("taa/taa", [inp, tex(after, "reprojected_history_img"), reproj, tex(after, "closest_velocity_img"), tex(before, "taa.velocity" + hist_sfx), depth,
+                               tex(before, "taa.smooth_var" + hist_sfx), tex(after, "prob_filtered2_img"),
+                               wr("taa" + out_sfx), wr("this_frame_output_img"), wr("taa.smooth_var" + out_sfx), wr("taa.velocity" + out_sfx)], [g, g], fc, (W, H, 1))
+        for n, t in written.items():
+            r = P.compare(t.raw, after[n], TAA_FORMATS[n.split(":")[0]])
+            _check(r, f"frame {fi} TAA surface {n}")
+            compared.add(n.split(":")[0])
+    assert compared == set(TAA_FORMATS), compared
