@@ -265,9 +265,13 @@ int okj_ircache_buffer(void* p, const char* name, void** out_ptr, uint64_t* out_
     OKJ_BUF("irradiance", ic.irradiance) OKJ_BUF("aux", ic.aux) OKJ_BUF("life", ic.life) OKJ_BUF("pool", ic.pool)
     OKJ_BUF("entry_indirection", ic.entry_indirection) OKJ_BUF("reposition_proposal", ic.reposition_proposal)
     OKJ_BUF("reposition_proposal_count", ic.reposition_proposal_count)
+    OKJ_BUF("grid_meta0", ic.grid_meta[0]) OKJ_BUF("grid_meta1", ic.grid_meta[1]) OKJ_BUF("entry_occupancy", ic.entry_occupancy)   // tests/test_ref_hlsl.py
 #undef OKJ_BUF
     return 1;
 }
+// tests/test_ref_hlsl.py: the host-side state of IrcacheRenderer (ircache.rs:92-100) and the ray-free head of trace_irradiance on its own
+void okj_ircache_host_state(void* p, int32_t* out3) { Ircache& ic = ((OkjIrcache*)p)->ic; out3[0] = ic.parity; out3[1] = ic.initialized ? 1 : 0; out3[2] = ic.cur; }
+void okj_ircache_prepare_and_reset(void* p) { IrcacheTracer::prepare_and_reset(((OkjIrcache*)p)->ic); }
 void okj_ircache_ray_counts(void* p, uint64_t* closest, uint64_t* any) {
     Ircache& ic = ((OkjIrcache*)p)->ic;
     *closest = ic.rays_closest.load(); *any = ic.rays_any.load();

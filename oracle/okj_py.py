@@ -78,6 +78,8 @@ def lib():
         L.okj_ircache_buffer.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_ircache_ray_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.okj_ircache_set_deferred_updates.argtypes = [C.c_void_p, C.c_int]
+        L.okj_ircache_host_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.okj_ircache_prepare_and_reset.argtypes = [C.c_void_p]
         L.okj_ircache_begin_requests.argtypes = [C.c_void_p]
         L.okj_ircache_apply_requests.argtypes = [C.c_void_p]
         L.okj_ircache_request_count.argtypes = [C.c_void_p]; L.okj_ircache_request_count.restype = C.c_uint64

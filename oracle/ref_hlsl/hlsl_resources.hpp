@@ -248,7 +248,12 @@ struct RWByteAddressBuffer : ByteAddressBuffer {
     void InterlockedMax(uint a, uint v, uint& orig) { orig = ld(a); st(a, orig > v ? orig : v); }
     void InterlockedMax(uint a, uint v) { const uint o = ld(a); st(a, o > v ? o : v); }
     void InterlockedOr(uint a, uint v, uint& orig) { orig = ld(a); st(a, orig | v); }
+    void InterlockedOr(uint a, uint v) { st(a, ld(a) | v); }
     void InterlockedAnd(uint a, uint v, uint& orig) { orig = ld(a); st(a, orig & v); }
+    void InterlockedAnd(uint a, uint v) { st(a, ld(a) & v); }
+    void InterlockedMin(uint a, uint v, uint& orig) { orig = ld(a); st(a, orig < v ? orig : v); }
+    void InterlockedMin(uint a, uint v) { const uint o = ld(a); st(a, o < v ? o : v); }
+    void InterlockedExchange(uint a, uint v, uint& orig) { orig = ld(a); st(a, v); }
 };
 // lanes run one at a time (cooperative scheduler), so "atomics" are plain read-modify-writes
 template <class D, class V, class O> static inline void InterlockedAdd(D& d, V v, O& orig) { orig = O(d); d = D(d + D(v)); }

@@ -108,8 +108,22 @@ static void run_group_lockstep(const PassInfo* p, GroupRun& r, uint3 group_id) {
     g_run = nullptr;
 }
 
+// Scheduling choice for passes without lock-step needs: group by group (default), or every thread of the dispatch in ascending
+// (z, y, x) order. Any order is a legal schedule; passes that push onto shared lists with atomics (the irradiance cache's free list)
+// produce those lists in schedule order, and the oracle's loops are the ascending one.
+static bool g_linear_order = false;
 static void dispatch(const PassInfo* p, uint tx, uint ty, uint tz) {
     const uint gx = (tx + p->nt[0] - 1) / p->nt[0], gy = (ty + p->nt[1] - 1) / p->nt[1], gz = (tz + p->nt[2] - 1) / p->nt[2];
+    if (!p->needs_lockstep && g_linear_order) {
+        for (uint z = 0; z < gz * p->nt[2]; ++z) for (uint y = 0; y < gy * p->nt[1]; ++y) for (uint x = 0; x < gx * p->nt[0]; ++x) {
+            LaneInfo& l = g_plain_lane;
+            l.group_id = uint3(x / p->nt[0], y / p->nt[1], z / p->nt[2]); l.group_thread_id = uint3(x % p->nt[0], y % p->nt[1], z % p->nt[2]);
+            l.group_index = l.group_thread_id.x + p->nt[0] * (l.group_thread_id.y + p->nt[1] * l.group_thread_id.z);
+            l.dispatch_thread_id = uint3(x, y, z);
+            p->invoke(l);
+        }
+        return;
+    }
     if (p->needs_lockstep) {
         GroupRun run;
         for (uint z = 0; z < gz; ++z) for (uint y = 0; y < gy; ++y) for (uint x = 0; x < gx; ++x) run_group_lockstep(p, run, uint3(x, y, z));
@@ -170,5 +184,6 @@ int ref_set_constant(const char* pass, const char* name, const void* src, unsign
     return -2;
 }
 // `threads`: the extent kajiya's .dispatch([x, y, z]) is given -- threads, rounded up to whole groups like the backend does
+void ref_set_linear_order(int on) { g_linear_order = on != 0; }
 int ref_dispatch(const char* pass, unsigned tx, unsigned ty, unsigned tz) { const PassInfo* p = find(pass); if (!p) return -1; dispatch(p, tx, ty, tz); return 0; }
 }

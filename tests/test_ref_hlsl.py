@@ -300,3 +300,111 @@ def test_taa_passes_reference_hlsl_vs_oracle(oracle, W, H):
             _check(r, f"frame {fi} TAA surface {n}")
             compared.add(n.split(":")[0])
     assert compared == set(TAA_FORMATS), compared
+
+
+# ---------------------------------------------------------------------------------------------------------------- irradiance cache maintenance
+IRC_BUFFERS = ["meta", "grid_meta0", "grid_meta1", "entry_cell", "spatial", "irradiance", "aux", "life", "pool", "entry_indirection", "reposition_proposal",
+               "reposition_proposal_count", "entry_occupancy"]
+MAX_ENTRIES = 65536
+
+
+def _irc_snapshot(op):
+    s = {n: op.ircache_buffer(n, np.uint8).copy() for n in IRC_BUFFERS}
+    s["entry_occupancy"] = s["entry_occupancy"][:MAX_ENTRIES * 4]      # the oracle pads its copy by one group of 64 it never scans
+    return s
+
+
+def _irc_host_state(op):
+    st = (C.c_int32 * 3)()
+    op.L.okj_ircache_host_state(op.ircache, st)
+    return dict(parity=st[0], initialized=bool(st[1]), cur=st[2])
+
+
+def _irc_diff(got, ref, what):
+    for n in ref:
+        if n in got and not np.array_equal(got[n], ref[n]):
+            a, b = got[n].view(np.uint32), ref[n].view(np.uint32)
+            bad = np.nonzero(a != b)[0]
+            raise AssertionError(f"{what}: buffer {n}: {bad.size} of {a.size} dwords differ, first at {bad[:6]}: {a[bad[:6]]} vs {b[bad[:6]]}")
+
+
+def _ref_ircache_prepare(s, host, fc):
+    """IrcacheRenderer::prepare (renderers/ircache.rs:168-350) recorded on the buffers of snapshot `s` (modified in place)."""
+    B = {n: R.Buf(s[n]) for n in s}
+    a, b = ("grid_meta0", "grid_meta1") if host["parity"] == 0 else ("grid_meta1", "grid_meta0")       # :235-240
+    if not host["initialized"]:
+        R.run_pass("ircache/clear_ircache_pool", [B["pool"], B["life"]], None, fc, (MAX_ENTRIES, 1, 1))
+    else:
+        R.run_pass("ircache/scroll_cascades", [B[a], B[b], B["entry_cell"], B["irradiance"], B["life"], B["pool"], B["meta"]], None, fc, (32, 32, 32 * 12))
+        a, b = b, a
+    args = R.Buf(np.zeros(8, np.uint32))
+    R.run_pass("ircache/prepare_age_dispatch_args", [B["meta"], args], None, fc, (1, 1, 1))
+    groups = args.raw.view(np.uint32)[:3].copy()
+    assert groups[1] == 1 and groups[2] == 1
+    occupancy = R.Buf(np.zeros(MAX_ENTRIES, np.uint32))                      # a transient in the reference: size_of::<u32>() * MAX_ENTRIES (ircache.rs:307-310)
+    R.run_pass("ircache/age_ircache_entries", [B["meta"], B[a], B["entry_cell"], B["life"], B["pool"], B["spatial"], B["reposition_proposal"],
+                                               B["reposition_proposal_count"], B["irradiance"], occupancy], None, fc, (int(groups[0]) * 64, 1, 1))
+    # inclusive_prefix_scan_u32_1m (renderers/prefix_scan.rs:10-42): three passes over 1 Mi elements of a 64 Ki-element buffer
+    SEG = 1024
+    R.run_pass("prefix_scan/inclusive_prefix_scan", [occupancy], None, None, (SEG * SEG // 2, 1, 1))
+    segment_sum = R.Buf(np.zeros(SEG, np.uint32))
+    R.run_pass("prefix_scan/inclusive_prefix_scan_segments", [occupancy, segment_sum], None, None, (SEG // 2, 1, 1))
+    R.run_pass("prefix_scan/inclusive_prefix_scan_merge", [occupancy, segment_sum], None, None, (SEG * SEG // 2, 1, 1))
+    R.run_pass("ircache/ircache_compact_entries", [B["meta"], B["life"], occupancy, B["entry_indirection"]], None, fc, (int(groups[0]) * 64, 1, 1))
+    s["entry_occupancy"] = occupancy.raw
+    return 0 if a == "grid_meta0" else 1
+
+
+def test_ircache_maintenance_reference_hlsl_vs_oracle(oracle):
+    """Every ray-free pass of the irradiance cache -- clear pool / scroll cascades, age, the three-pass prefix scan, compact
+    (IrcacheRenderer::prepare), dispatch args + reset (head of trace_irradiance) and the SH sum-up -- from the reference's text on the
+    oracle's live cache state, frame after frame under a moving camera: every buffer byte for byte. The passes that push onto the
+    free list with atomics run in ascending thread order on both sides (any order is a legal schedule: ref_set_linear_order)."""
+    from kajiya_amd import scenes, frame
+    _bind_luts(oracle)
+    L = R.lib()
+    L.ref_set_linear_order(1)
+    try:
+        W = H = 64
+        op = oracle.OraclePipeline(oracle.OracleScene(scenes.cornell_box()), W, H, use_ircache=True)
+        fs = frame.FrameState((W, H))
+        fs.ircache_enabled = True
+        seen_scroll = 0
+        for fi in range(7):
+            fc = fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.03))
+            seen_scroll += sum(abs(int(v)) for c in range(12) for v in fc.ircache_cascades[c].voxels_scrolled_this_frame[:3]) if fi else 0
+            op.render_inputs(fc); op.reprojection(fc)
+            # --- prepare
+            s0, host = _irc_snapshot(op), _irc_host_state(op)
+            op.L.okj_ircache_prepare(op.ircache, C.byref(fc))
+            s1, host1 = _irc_snapshot(op), _irc_host_state(op)
+            cur = _ref_ircache_prepare(s0, host, fc)
+            assert cur == host1["cur"], (fi, cur, host1)
+            live = "grid_meta%d" % cur
+            # the buffer scrolled OUT of is dead until the next frame overwrites it; everything else must match
+            _irc_diff({n: v for n, v in s0.items() if n != "grid_meta%d" % (1 - cur)}, s1, f"frame {fi} prepare")
+            assert s1["meta"].view(np.uint32)[2] > 0 or fi == 0, "no live entries: the test would be vacuous"
+            # --- head of trace_irradiance: dispatch args + reset (ircache.rs:369-394)
+            s = {n: v.copy() for n, v in s1.items()}
+            B = {n: R.Buf(s[n]) for n in s}
+            args = R.Buf(np.zeros(16, np.uint32))
+            R.run_pass("ircache/prepare_trace_dispatch_args", [B["meta"], args], None, fc, (1, 1, 1))
+            g = args.raw.view(np.uint32)
+            R.run_pass("ircache/reset_entry", [B["life"], B["meta"], B["irradiance"], B["aux"], B["entry_indirection"]], None, fc, (int(g[8]) * 64, 1, 1))
+            op.L.okj_ircache_prepare_and_reset(op.ircache)
+            _irc_diff(s, _irc_snapshot(op), f"frame {fi} dispatch args + reset")
+            # --- the frame's ray work on the oracle, then the sum-up
+            op.L.okj_ircache_trace_irradiance(op.ircache, C.byref(fc), op.scene.h, op.sky16.ctypes.data, 16)
+            op.L.okj_rtdgi_reproject(op.rtdgi, C.byref(fc), op.reprojection_map.ctypes.data, W, H)
+            s = _irc_snapshot(op)
+            B = {n: R.Buf(s[n]) for n in s}
+            # dispatched with the `pending` args buffer written at the head of trace_irradiance (ircache.rs:487-506), not recomputed
+            R.run_pass("ircache/sum_up_irradiance", [B["life"], B["meta"], B["irradiance"], B["aux"], B["entry_indirection"]], None, fc, (int(g[8]) * 64, 1, 1))
+            op.ircache_sum_up(fc)
+            _irc_diff(s, _irc_snapshot(op), f"frame {fi} sum-up")
+            p = op.params()
+            op.L.okj_rtdgi_render(op.rtdgi, C.byref(fc), C.byref(p), C.byref(op.out))      # the lookups that allocate next frame's entries
+            fs.retire_frame()
+        assert seen_scroll > 0, "the camera never crossed a cell: scroll_cascades was not exercised"
+    finally:
+        L.ref_set_linear_order(0)
