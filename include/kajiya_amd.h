@@ -355,8 +355,10 @@ KjStatus kj_rtdgi_traversal_counts(KjRtdgi* r, uint64_t out[6]);
  *     traversals and hit shading (the ray-generation shader's shape)
  *   KJ_RTDGI_RAYS_GROUPED: 256-thread workgroups, hit shading regrouped onto full waves through LDS
  *   KJ_RTDGI_RAYS_STAGED: five launches over dense ray arrays (ray streams)
- *   KJ_RTDGI_RAYS_SPLIT: two launches: closest-hit traversal + everything a miss needs | hit shading on records compacted across tiles */
-enum { KJ_RTDGI_RAYS_GROUPED = 0, KJ_RTDGI_RAYS_FUSED = 1, KJ_RTDGI_RAYS_STAGED = 2, KJ_RTDGI_RAYS_SPLIT = 3 };
+ *   KJ_RTDGI_RAYS_SPLIT: two launches: closest-hit traversal + everything a miss needs | hit shading on records compacted across tiles
+ *   KJ_RTDGI_RAYS_QUAD: the fused kernels with four lanes per pixel (a wave covers 8 x 2 pixels; the traversal's four child tests of a node
+ *     run on the four lanes, the shading code on all of them, the first lane stores) */
+enum { KJ_RTDGI_RAYS_GROUPED = 0, KJ_RTDGI_RAYS_FUSED = 1, KJ_RTDGI_RAYS_STAGED = 2, KJ_RTDGI_RAYS_SPLIT = 3, KJ_RTDGI_RAYS_QUAD = 4 };
 KjStatus kj_rtdgi_set_ray_pass_form(KjRtdgi* r, uint32_t form);
 /* Ray counters of the last kj_rtdgi_render (closest-hit rays, any-hit rays). */
 KjStatus kj_rtdgi_ray_counts(KjRtdgi* r, uint64_t* out_closest, uint64_t* out_any);

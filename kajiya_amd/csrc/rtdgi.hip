@@ -39,6 +39,14 @@ typedef Img<float4> ImgF4;
     const int x = int(kj_tb.x) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
+// four lanes per pixel (the QUAD form of the ray passes): a wave covers 8 x 2 pixels, lane = 4 * pixel slot + k; `lead` = the lane that stores
+#define QUAD_TILE_XY(W_, H_, QUAD_)                                                                                        \
+    const int lane = (QUAD_) ? int(threadIdx.x >> 2) : int(threadIdx.x);                                                   \
+    const bool lead = !(QUAD_) || (threadIdx.x & 3u) == 0u;                                                                \
+    const uint2 kj_tb = kj::tile_order<KJ_TILES_PLAIN>();                                                                  \
+    const int x = int(kj_tb.x) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * ((QUAD_) ? 2 : 8) + (lane >> 3);                \
+    const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
+
 // ------------------------------------------------------------------ extract_half_res_{gbuffer_view_normal_rgba8,depth,ssao}.hlsl (fused)
 // Besides the reference's three half-res images this writes them once more as ONE 8-byte record per pixel
 // {depth bits, view normal snorm8 x3 | ssao snorm8 << 24}: what the resampling passes stage in LDS / fetch per tap (rtdgi_resample.hip).
@@ -151,10 +159,19 @@ KJ_D void count_rays(unsigned long long* counters, int which, bool active) {
 // utilisation (two thirds of the rays leave the scene, and their lanes idle through hit shading and the shadow ray): its rays alone
 // would take 0.13 of its 0.28 ms at the microbench's rates.
 struct TraceResult { V3 out_value; V3 hit_normal_ws; float hit_t; float pdf; bool is_hit; };
+// QUAD form: four lanes per pixel run the same code on the same inputs (kj_bvh.hpp: bvh_trace_quad); the first lane of each quad counts
+KJ_D void count_rays_quad(unsigned long long* counters, int which) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if ((threadIdx.x & 3u) == 0u) atomicAdd(&counter_slot(counters)[which], 1ull);
+    return;
+#endif
+    const unsigned long long m = __ballot(true) & 0x1111111111111111ull;
+    if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
+}
 // Everything diffuse_trace_common.inc.hlsl:80-200 does for a ray that HIT (the divergent part: G-buffer of the hit, the sun's shadow ray,
 // the triangle lights, last frame's GI or the irradiance cache). Shared by the fused and the grouped form of the ray passes so that both
 // sum the radiance terms with the same arithmetic in the same order. Returns the radiance; `hit_normal_ws` = the hit's shading normal.
-template <bool STATS>
+template <bool STATS, bool QUAD = false>
 KJ_D V3 shade_candidate_hit(const TraceCtx& c, uint32_t px, uint32_t py, uint32_t& rng, V3 ray_o, V3 ray_d, const GbufferPathVertex& primary_hit, uint32_t* stack, uint32_t stride,
                             TraverseStats* st_any, V3& hit_normal_ws) {
     const FrameConstants& fc = *c.fc;
@@ -179,8 +196,9 @@ KJ_D V3 shade_candidate_hit(const TraceCtx& c, uint32_t px, uint32_t py, uint32_
     if (sun_radiance.x != 0 || sun_radiance.y != 0 || sun_radiance.z != 0) {
         const V4 bn = blue_noise_for_pixel(c.blue_noise, px, py, rng);
         const V3 to_light_norm = sample_sun_direction(fc, V2{bn.x, bn.y}, false);
-        count_rays(c.ray_counters, 1, true);
-        const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, stride, st_any);
+        if (QUAD) count_rays_quad(c.ray_counters, 1); else count_rays(c.ray_counters, 1, true);
+        const bool is_shadowed = QUAD ? rt_is_shadowed_quad(c.sc, true, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, stride)
+                                      : rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, stride, st_any);
         const V3 wi = to_local(tangent_to_world, to_light_norm);
         const V3 brdf_value = layered_brdf_evaluate(brdf, wo, wi) * fmaxf(0.0f, wi.z);
         total_radiance += brdf_value * (is_shadowed ? v3(0.0f) : sun_radiance);
@@ -202,8 +220,9 @@ KJ_D V3 shade_candidate_hit(const TraceCtx& c, uint32_t px, uint32_t py, uint32_
             const V3 to_light_norm_ws = to_light_ws * (1.0f / sqrtf(dist2));
             const float to_psa_metric = fmaxf(0.0f, dot(to_light_norm_ws, gbuffer.normal)) * fmaxf(0.0f, dot(to_light_norm_ws, -ls.normal)) / dist2;
             if (to_psa_metric > 0.0f) {
-                count_rays(c.ray_counters, 1, true);
-                const bool is_shadowed = rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, stride, st_any);
+                if (QUAD) count_rays_quad(c.ray_counters, 1); else count_rays(c.ray_counters, 1, true);
+                const bool is_shadowed = QUAD ? rt_is_shadowed_quad(c.sc, true, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, stride)
+                                              : rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, stride, st_any);
                 const V3 bounce_albedo = lerp(gbuffer.albedo, v3(1.0f), 0.04f);
                 const V3 brdf_value = bounce_albedo * to_psa_metric / KJ_PI;
                 if (!is_shadowed) total_radiance += V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * brdf_value / ls.pdf;
@@ -211,7 +230,10 @@ KJ_D V3 shade_candidate_hit(const TraceCtx& c, uint32_t px, uint32_t py, uint32_
         }
         if (c.has_ircache) {  // USE_IRCACHE (diffuse_trace_common.inc.hlsl:189-198); unbound => contributes 0 (BASELINE config 1)
             const uint32_t rq = py * c.request_stride + px;
-            const V3 gi = ircache_lookup<false>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng, false, c.request_slot_base + rq, c.request_key_base | rq);
+            V3 gi = v3(0.0f);
+            // the lookup's side effects (atomics, or the recorded request) are the quad's first lane's; the rng is not used after it
+            if (!QUAD || (threadIdx.x & 3u) == 0u) gi = ircache_lookup<false>(c.irc, fc, ray_o, primary_hit.position, gbuffer.normal, 1u, rng, false, c.request_slot_base + rq, c.request_key_base | rq);
+            if (QUAD) gi = quad_broadcast0(gi);
             total_radiance += gi * gbuffer.albedo;
         }
     }
@@ -230,19 +252,21 @@ KJ_D void add_traversal_stats(const TraceCtx& c, const TraverseStats& st_closest
         atomicAdd(&counter_slot(c.ray_counters)[5], (unsigned long long)st_any.tris);
     }
 }
-template <bool STATS>
+template <bool STATS, bool QUAD = false>
 KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3 normal_ws, uint32_t& rng, V3 ray_o, V3 ray_d, float ray_tmax, uint32_t* stack) {
     const FrameConstants& fc = *c.fc;
     V3 total_radiance = v3(0.0f);
     V3 hit_normal_ws = -ray_d;
     float hit_t = ray_tmax;
     const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, ray_d) * 2 * KJ_PI));
-    count_rays(c.ray_counters, 0, true);
+    if (QUAD) count_rays_quad(c.ray_counters, 0); else count_rays(c.ray_counters, 0, true);
     TraverseStats st_closest{0, 0}, st_any{0, 0};
-    const GbufferPathVertex primary_hit = gbuffer_raytrace<STATS>(c.sc, fc, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, 64, &st_closest, candidate_ray_cone(c, ray_o));
+    constexpr uint32_t STRIDE = QUAD ? 16u : 64u;     // LDS stack layout [level][lane] / [level][quad]
+    const GbufferPathVertex primary_hit = QUAD ? gbuffer_raytrace_quad(c.sc, fc, true, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, STRIDE, candidate_ray_cone(c, ray_o))
+                                               : gbuffer_raytrace<STATS>(c.sc, fc, ray_o, ray_d, 0.0f, ray_tmax, 1, false, stack, STRIDE, &st_closest, candidate_ray_cone(c, ray_o));
     if (primary_hit.is_hit) {
         hit_t = primary_hit.ray_t;
-        total_radiance = shade_candidate_hit<STATS>(c, px, py, rng, ray_o, ray_d, primary_hit, stack, 64, &st_any, hit_normal_ws);
+        total_radiance = shade_candidate_hit<STATS, QUAD>(c, px, py, rng, ray_o, ray_d, primary_hit, stack, STRIDE, &st_any, hit_normal_ws);
     } else {
         total_radiance += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
     }
@@ -354,7 +378,7 @@ KJ_D TraceResult trace_candidate_grouped(const TraceCtx& c, bool has_ray, uint32
 }
 
 // ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111
-template <bool STATS>
+template <bool STATS, bool QUAD = false>
 // waves per SIMD the fused ray kernels are compiled for: 4 = 123 VGPRs, no spills; 5 = 96 VGPRs + 20 spilled dwords outside the traversal
 // loop: trace pass -2 %; 6 = 80 VGPRs + 48 dwords: +30 % (measured, same box)
 #ifndef KJ_FUSED_WAVES
@@ -363,11 +387,11 @@ template <bool STATS>
 __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_validate_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
                                                         ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
     extern __shared__ uint32_t lds_stack[];
-    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    QUAD_TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h, QUAD)
     if (!in_image) return;
     const FrameConstants& fc = *c.fc;
     const I2 off = halfres_subsample_offset(fc.frame_index);
-    if (0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y)) { invalidity_out_tex.st(x, y, to_unorm8(1.0f)); return; }
+    if (0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y)) { if (lead) invalidity_out_tex.st(x, y, to_unorm8(1.0f)); return; }
     float invalidity = 0.0f;
     if (is_rtdgi_validation_frame(fc.frame_index)) {
         const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
@@ -377,12 +401,12 @@ __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_validate_fused(Tra
         const V4 prev_radiance_packed = ld4(irradiance_history_tex, x, y);
         const V3 prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
         uint32_t rng = hash3(uint32_t(x), uint32_t(y), 0);
-        const TraceResult result = trace_candidate<STATS>(c, x, y, normal_ws, rng, prev_ray_orig, normalize(prev_hit_pos - prev_ray_orig), SKY_DIST, lds_stack + lane);
+        const TraceResult result = trace_candidate<STATS, QUAD>(c, x, y, normal_ws, rng, prev_ray_orig, normalize(prev_hit_pos - prev_ray_orig), SKY_DIST, lds_stack + lane);
         const V3 new_radiance = vmax(v3(0.0f), result.out_value);
         const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
         invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
         const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
-        if (fabsf(result.hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
+        if (lead && fabsf(result.hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
             st4(irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
             Reservoir1spp r = Reservoir1spp::from_raw(reservoir_tex.ld(x, y));
             const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
@@ -391,24 +415,26 @@ __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_validate_fused(Tra
             reservoir_tex.st(x, y, r.as_raw());
         }
     }
-    invalidity_out_tex.st(x, y, to_unorm8(invalidity));
+    if (lead) invalidity_out_tex.st(x, y, to_unorm8(invalidity));
 }
 
 // ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24
-template <bool STATS>
+template <bool STATS, bool QUAD = false>
 __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
                                                      ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
     extern __shared__ uint32_t lds_stack[];
-    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
+    QUAD_TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h, QUAD)
     if (!in_image) return;
     const FrameConstants& fc = *c.fc;
     const I2 off = halfres_subsample_offset(fc.frame_index);
     const int hx = x * 2 + off.x, hy = y * 2 + off.y;
     const float depth = c.depth.ld(hx, hy);
     if (0.0f == depth) {
-        st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
-        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
-        invalidity_out_tex.st(x, y, 0);
+        if (lead) {
+            st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
+            candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
+            invalidity_out_tex.st(x, y, 0);
+        }
         return;
     }
     const V4 gts = tex_size4(c.depth.w, c.depth.h);
@@ -423,17 +449,19 @@ __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_fused(TraceC
         const V3 outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
         const V3 origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
         uint32_t rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u);
-        TraceResult result = trace_candidate<STATS>(c, x, y, normal_ws, rng, origin, outgoing_dir, tracing_frame ? SKY_DIST : near_field_fade_out_end, lds_stack + lane);
+        TraceResult result = trace_candidate<STATS, QUAD>(c, x, y, normal_ws, rng, origin, outgoing_dir, tracing_frame ? SKY_DIST : near_field_fade_out_end, lds_stack + lane);
         if (!tracing_frame && !result.is_hit) { result.out_value = v3(0.0f); result.hit_t = SKY_DIST; }
         const V3 hit_offset_ws = outgoing_dir * result.hit_t;
         const float cos_theta = dot(normalize(outgoing_dir - vr.dir_ws), normal_ws);
-        st4(candidate_irradiance_out_tex, x, y, v4(result.out_value, 1.0f - cos_theta));
-        st4(candidate_hit_out_tex, x, y, v4(hit_offset_ws, result.pdf * (tracing_frame ? 1.0f : -1.0f)));
-        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, result.hit_normal_ws), 0)));
+        if (lead) {
+            st4(candidate_irradiance_out_tex, x, y, v4(result.out_value, 1.0f - cos_theta));
+            st4(candidate_hit_out_tex, x, y, v4(hit_offset_ws, result.pdf * (tracing_frame ? 1.0f : -1.0f)));
+            candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, result.hit_normal_ws), 0)));
+        }
     }
     const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
     const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
-    invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
+    if (lead) invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
 }
 
 // ---- the two ray passes in the grouped form (trace_candidate_grouped above)
@@ -971,8 +999,12 @@ __global__ void __launch_bounds__(64) k_rtdgi_validate_finish(RayStage st, ImgU2
 
 // ------------------------------------------------------------------ temporal_validity_integrate.hlsl:21-119
 // WaveReadLaneAt(v, lane^k) inside the 8x8 group == __shfl_xor(v, k) on wave64.
-__global__ void __launch_bounds__(64) k_validity_integrate(const FrameConstants* __restrict__ fcp, ImgR8 input_tex, ImgU32 history_tex /*RG16F*/, ImgU2 reprojection_tex,
-                                                            ImgF32 half_depth_tex, ImgU32 output_tex /*RG16F*/, int W, int H, int row0, int row1) {
+struct ValidityIntegrateArgs { const FrameConstants* __restrict__ fc; ImgR8 input_tex; ImgU32 history_tex /*RG16F*/; ImgU2 reprojection_tex; ImgF32 half_depth_tex; ImgU32 output_tex /*RG16F*/; int W, H, row0, row1; };
+KJ_D void validity_integrate_body(const ValidityIntegrateArgs& v) {
+    const FrameConstants* fcp = v.fc;
+    const ImgR8& input_tex = v.input_tex; const ImgU32& history_tex = v.history_tex; const ImgU2& reprojection_tex = v.reprojection_tex;
+    const ImgF32& half_depth_tex = v.half_depth_tex; const ImgU32& output_tex = v.output_tex;
+    const int W = v.W, H = v.H, row0 = v.row0, row1 = v.row1;
     TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     const FrameConstants& fc = *fcp;
     V2 invalid_blurred{0, 0};
@@ -1017,6 +1049,7 @@ __global__ void __launch_bounds__(64) k_validity_integrate(const FrameConstants*
     history /= 8;
     if (in_image) st2h(output_tex, x, y, V2{fmaxf(history * 0.75f, ib), from_unorm8(input_tex.ld(x, y))});
 }
+__global__ void __launch_bounds__(64) k_validity_integrate(ValidityIntegrateArgs v) { validity_integrate_body(v); }
 
 // ------------------------------------------------------------------ restir_temporal.hlsl:83-422
 struct RestirTemporalArgs {
@@ -1028,7 +1061,7 @@ struct RestirTemporalArgs {
     ImgH4 candidate_out_tex; ImgU4 temporal_reservoir_packed_tex;
     int row0, row1;
 };
-__global__ void __launch_bounds__(64) k_restir_temporal(RestirTemporalArgs a) {
+KJ_D void restir_temporal_body(const RestirTemporalArgs& a) {
     const int row0 = a.row0, row1 = a.row1;
     TILE_XY_M(a.reservoir_out_tex.w, a.reservoir_out_tex.h, KJ_TILES_ROWS)
     if (!in_image) return;
@@ -1151,6 +1184,14 @@ __global__ void __launch_bounds__(64) k_restir_temporal(RestirTemporalArgs a) {
     rp.luminance = fmaxf(0.0f, sRGB_to_luminance(radiance_sel));
     rp.hit_normal_ws = xyz(hit_normal_ws_dot);
     a.temporal_reservoir_packed_tex.st(x, y, rp.as_raw());
+}
+__global__ void __launch_bounds__(64) k_restir_temporal(RestirTemporalArgs a) { restir_temporal_body(a); }
+// `validity integrate` + `restir temporal` in ONE launch (the default when a frame runs both): same tiles, same code, one dependent launch
+// less on the frame's critical chain. The temporal pass reads `rt_invalidity_tex[px].y` -- of its own pixel only -- which the same lane
+// has just stored (a thread observes its own earlier stores), so nothing needs to be exchanged between the two halves.
+__global__ void __launch_bounds__(64) k_validity_integrate_restir_temporal(ValidityIntegrateArgs v, RestirTemporalArgs a) {
+    validity_integrate_body(v);
+    restir_temporal_body(a);
 }
 
 // restir_spatial.hlsl + occlusion_raymarch.hlsl: rtdgi_resample.hip (k_restir_spatial<>)
@@ -1278,6 +1319,8 @@ struct KjRtdgi {
     bool count_traversal = false;               // instrumented trace kernels
     uint32_t staged_min_rays = 0xffffffffu;     // ray passes run staged (ray streams) from this many ray slots per launch (KJ_RTDGI_STAGED_MIN_RAYS); default: never, see below
     uint32_t stream_waves_per_cu = 24;          // persistent waves per CU of a ray-stream launch (measured best of 8 / 16 / 24 / 32: scripts/traversal_microbench.py)
+    bool fuse_validity_temporal = true;         // `validity integrate` + `restir temporal` as one launch (KJ_RTDGI_FUSE_VT=0: two)
+    bool quad_rays = false;                     // the fused ray kernels with four lanes per pixel (kj_rtdgi_set_ray_pass_form KJ_RTDGI_RAYS_QUAD)
     bool split_rays = false;                    // the ray passes as two launches each: closest-hit + misses | hit shading on compacted records (kj_rtdgi_set_ray_pass_form)
     bool grouped_rays = false;                  // the ray passes' form when not staged: grouped (hit shading regrouped inside a 256-thread workgroup) or fused (KJ_RTDGI_GROUPED=0)
     uint32_t ray_waves_per_simd = 0;            // 0 = whatever fits
@@ -1322,6 +1365,8 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     if (const char* v = getenv("KJ_RTDGI_STAGED_MIN_RAYS")) r->staged_min_rays = uint32_t(atoll(v));
     if (const char* v = getenv("KJ_RTDGI_GROUPED")) r->grouped_rays = atoi(v) != 0;
     if (const char* v = getenv("KJ_RTDGI_SPLIT")) r->split_rays = atoi(v) != 0;
+    if (const char* v = getenv("KJ_RTDGI_QUAD")) r->quad_rays = atoi(v) != 0;
+    if (const char* v = getenv("KJ_RTDGI_FUSE_VT")) r->fuse_validity_temporal = atoi(v) != 0;
     if (const char* v = getenv("KJ_RTDGI_WAVES_PER_SIMD")) r->ray_waves_per_simd = uint32_t(std::max(0, atoi(v)));
     if (r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
     *out = r;
@@ -1500,7 +1545,21 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(2);
     }
-    if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged && !grouped && !split) {
+    // QUAD form of the fused kernels: four lanes per pixel (bvh_trace_quad), a wave covers 8 x 2 pixels, four times the waves
+    const bool quad = r->quad_rays && !staged && !grouped && !split && !r->count_traversal;
+    const dim3 ghq(gh.x, (uint32_t(hr1 - hr0) + 1) / 2);
+    if ((mask & KJ_RTDGI_PASS_VALIDATE) && quad) {
+        SCOPE_BEGIN(2);
+        if (is_rtdgi_validation_frame(r->dev->fc_host.frame_index))
+            hipLaunchKernelGGL((k_rtdgi_validate_fused<false, true>), ghq, blk, quad_stack_bytes(), s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+                               img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
+        else   // two frames of three the pass only writes the invalidity image
+            hipLaunchKernelGGL(k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+                               img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(2);
+    }
+    if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged && !grouped && !split && !quad) {
         SCOPE_BEGIN(2);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
                            img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
@@ -1524,7 +1583,14 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
     }
-    if ((mask & KJ_RTDGI_PASS_TRACE) && !staged && !grouped && !split) {
+    if ((mask & KJ_RTDGI_PASS_TRACE) && quad) {
+        SCOPE_BEGIN(3);
+        hipLaunchKernelGGL((k_rtdgi_trace_fused<false, true>), ghq, blk, quad_stack_bytes(), s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(3);
+    }
+    if ((mask & KJ_RTDGI_PASS_TRACE) && !staged && !grouped && !split && !quad) {
         SCOPE_BEGIN(3);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
                            img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
@@ -1558,10 +1624,13 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
     }
-    if (mask & KJ_RTDGI_PASS_VALIDITY_INTEGRATE) {
+    const ValidityIntegrateArgs via{fc, img<uint8_t>(validity_in, hw, hh), img<uint32_t>(invalidity_hist, hw, hh), reprojection, img<float>(half_depth, hw, hh),
+                                    img<uint32_t>(invalidity_out, hw, hh), W, H, hr0, hr1};
+    const bool fuse_validity_temporal = r->fuse_validity_temporal && (mask & KJ_RTDGI_PASS_VALIDITY_INTEGRATE) && (mask & KJ_RTDGI_PASS_RESTIR_TEMPORAL);
+    if (fuse_validity_temporal) r->ev_valid[4] = false;
+    if ((mask & KJ_RTDGI_PASS_VALIDITY_INTEGRATE) && !fuse_validity_temporal) {
         SCOPE_BEGIN(4);
-        hipLaunchKernelGGL(k_validity_integrate, gh, blk, 0, s, fc, img<uint8_t>(validity_in, hw, hh), img<uint32_t>(invalidity_hist, hw, hh), reprojection,
-                           img<float>(half_depth, hw, hh), img<uint32_t>(invalidity_out, hw, hh), W, H, hr0, hr1);
+        hipLaunchKernelGGL(k_validity_integrate, gh, blk, 0, s, via);
         KJ_CHECK_LAUNCH();
         SCOPE_END(4);
     }
@@ -1589,7 +1658,8 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         a.temporal_reservoir_packed_tex = img<uint4>(temporal_reservoir_packed, hw, hh);
         SCOPE_BEGIN(5);
         a.row0 = hr0; a.row1 = hr1;
-        hipLaunchKernelGGL(k_restir_temporal, gh, blk, 0, s, a);
+        if (fuse_validity_temporal) hipLaunchKernelGGL(k_validity_integrate_restir_temporal, gh, blk, 0, s, via, a);      // timed as scope 5; scope 4 reads 0
+        else hipLaunchKernelGGL(k_restir_temporal, gh, blk, 0, s, a);
         KJ_CHECK_LAUNCH();
         SCOPE_END(5);
     }
@@ -1678,9 +1748,10 @@ KjStatus kj_rtdgi_set_profiling(KjRtdgi* r, uint32_t enable_pass_timers, uint32_
     return KJ_OK;
 }
 KjStatus kj_rtdgi_set_ray_pass_form(KjRtdgi* r, uint32_t form) {
-    KJ_REQUIRE(r && form <= KJ_RTDGI_RAYS_SPLIT, "null argument / unknown form");
+    KJ_REQUIRE(r && form <= KJ_RTDGI_RAYS_QUAD, "null argument / unknown form");
     r->grouped_rays = form == KJ_RTDGI_RAYS_GROUPED;
     r->split_rays = form == KJ_RTDGI_RAYS_SPLIT;
+    r->quad_rays = form == KJ_RTDGI_RAYS_QUAD;
     r->staged_min_rays = form == KJ_RTDGI_RAYS_STAGED ? 0u : 0xffffffffu;
     return KJ_OK;
 }

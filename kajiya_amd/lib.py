@@ -688,7 +688,7 @@ class GpuPipeline:
     PASS_NAMES = ["rtdgi reproject", "extract half", "rtdgi validate", "rtdgi trace", "validity integrate", "restir temporal",
                   "restir spatial 0", "restir spatial 1", "restir resolve", "rtdgi temporal", "rtdgi spatial"]
 
-    RAY_PASS_FORMS = {"grouped": 0, "fused": 1, "staged": 2, "split": 3}
+    RAY_PASS_FORMS = {"grouped": 0, "fused": 1, "staged": 2, "split": 3, "quad": 4}
 
     def set_ray_pass_form(self, form):
         """How `rtdgi validate` / `rtdgi trace` are scheduled (include/kajiya_amd.h: KJ_RTDGI_RAYS_*); outputs are identical for all."""

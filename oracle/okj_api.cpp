@@ -475,6 +475,15 @@ uint64_t okj_reference_path_trace(const void* scene, const KjFrameConstants* fc,
     if (mpl) in.max_path_length = uint32_t(atoi(mpl));
     return reference_path_trace(*(const FrameConstants*)fc, in, (f4*)output, w, h);
 }
+// the same on rows [row_begin, row_end) of the w x h frame (`output` is the whole frame)
+uint64_t okj_reference_path_trace_rows(const void* scene, const KjFrameConstants* fc, const void* brdf_fg_lut, void* output, uint32_t w, uint32_t h, uint32_t row_begin, uint32_t row_end) {
+    static std::vector<h4> lut;
+    ReferencePtInputs in;
+    in.scene = (const Scene*)scene;
+    if (brdf_fg_lut) in.brdf_fg_lut = (const h4*)brdf_fg_lut;
+    else { if (lut.empty()) { lut.resize(64 * 64); build_brdf_fg_lut(lut.data()); } in.brdf_fg_lut = lut.data(); }
+    return reference_path_trace(*(const FrameConstants*)fc, in, (f4*)output, w, h, row_begin, row_end);
+}
 
 // ---- rtr (RtrRenderer, renderers/rtr.rs). params hold HOST pointers; params->scene / ircache are okj handles.
 struct OkjRtr {

@@ -131,6 +131,8 @@ def lib():
         L.okj_motion_blur_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_reference_path_trace.restype = C.c_uint64
         L.okj_reference_path_trace.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
+        L.okj_reference_path_trace_rows.restype = C.c_uint64
+        L.okj_reference_path_trace_rows.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.okj_set_threads.argtypes = [C.c_int]
         L.okj_get_max_threads.restype = C.c_int
         _LIB = L
@@ -158,6 +160,12 @@ def reference_path_trace(scene, fc, output, first_bounce_mode=0):
     assert output.dtype == np.float32 and output.flags["C_CONTIGUOUS"] and output.shape[2] == 4
     h, w = output.shape[:2]
     return lib().okj_reference_path_trace(scene.h, C.byref(fc), brdf_lut().ctypes.data, output.ctypes.data, w, h, first_bounce_mode)
+
+
+def reference_path_trace_rows(scene, fc, output, row_begin, row_end):
+    """One sample per pixel of rows [row_begin, row_end) of the frame `output` (H, W, 4 float32) belongs to."""
+    h, w = output.shape[:2]
+    return lib().okj_reference_path_trace_rows(scene.h, C.byref(fc), brdf_lut().ctypes.data, output.ctypes.data, w, h, row_begin, row_end)
 
 
 class OracleScene:

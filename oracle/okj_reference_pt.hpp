@@ -137,10 +137,10 @@ static inline bool reference_pt_sample(const FrameConstants& fc, const Reference
 }
 
 // One dispatch: accumulate one sample per pixel into `output` (RGBA32F, a = sample count), :79-87,369-375.
-static inline uint64_t reference_path_trace(const FrameConstants& fc, const ReferencePtInputs& in, f4* output, uint32_t W, uint32_t H) {
+static inline uint64_t reference_path_trace(const FrameConstants& fc, const ReferencePtInputs& in, f4* output, uint32_t W, uint32_t H, uint32_t row_begin = 0, uint32_t row_end = ~0u) {
     uint64_t rays_total = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays_total)
-    for (int y = 0; y < int(H); ++y)
+    for (int y = int(row_begin); y < int(row_end < H ? row_end : H); ++y)      // a band of rows of the W x H frame (tests at 4K): same pixels, same rng
         for (uint32_t x = 0; x < W; ++x) {
             const f4 prev = output[size_t(y) * W + x];
             if (!(prev.w < 1000.0f)) continue;

@@ -61,6 +61,10 @@ IRC_BUFS = ("meta", "grid_meta", "entry_cell", "spatial", "irradiance", "aux", "
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_ranks,W,H", [(2, 256, 160), (3, 320, 208), (2, 2048, 1024)])
 def test_strip_split_with_the_irradiance_cache_is_bit_exact(gpu, device, n_ranks, W, H):
+    strip_split_with_the_irradiance_cache(gpu, device, n_ranks, W, H)
+
+
+def strip_split_with_the_irradiance_cache(gpu, device, n_ranks, W, H, scene_name="city20k", frames=None):
     """with the cache bound every rank keeps a replica; the strips' lookups are recorded, all-gathered and replayed in
     one canonical order on every replica (kj_ircache_apply_requests). The replicas must stay bit-identical to each other AND to a
     single GPU running the same frames in the same (deferred, deterministic) mode: GI image, TAA image and every cache buffer.
@@ -68,7 +72,7 @@ def test_strip_split_with_the_irradiance_cache_is_bit_exact(gpu, device, n_ranks
     2 x 65536 x 4 -- the two used to share one cached buffer)"""
     import torch
     from kajiya_amd import multigpu
-    desc = T._scenes()["city20k"]
+    desc = T._scenes()[scene_name]
     scene = gpu.Scene(device, desc)
     ref = gpu.GpuPipeline(device, scene, W, H, use_ircache=True)
     ref.ircache_set_deferred(True)
@@ -78,8 +82,10 @@ def test_strip_split_with_the_irradiance_cache_is_bit_exact(gpu, device, n_ranks
     from kajiya_amd import frame
     fs = frame.FrameState((W, H))
     fs.ircache_enabled = True
-    for fi in range(8 if W < 1024 else 4):
-        fc = fs.prepare_frame_constants(frame.orbit_camera(fi, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.02))
+    for fi in range(frames or (8 if W < 1024 else 4)):
+        cam = frame.orbit_camera(fi, (W, H), center=(0.0, 3.0, 0.0), radius=34.0, height=5.0, rate=0.004) if scene_name.startswith("ruins") else \
+            frame.orbit_camera(fi, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.02)
+        fc = fs.prepare_frame_constants(cam)
         fs.retire_frame()
         ref.frame(fc)
         for r in range(n_ranks):

@@ -280,17 +280,50 @@ def camera_of(scene_name):
     return scene_name if scene_name in ("cornell", "textured", "pica") else ("ruins" if scene_name.startswith("ruins") else "city")
 
 
-def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced, n_frames=8, warmup=5, after_frame=None):
+def _frame_constants_with_cache(W, H, n_frames, scene):
+    """_frame_constants with the irradiance cache's cascades in the constants (IrcacheRenderer::update_eye_position)."""
+    from kajiya_amd import frame
+    fs = frame.FrameState((W, H))
+    fs.ircache_enabled = True
+    out = []
+    for i in range(n_frames):
+        if scene == "cornell":
+            cam = frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.01)
+        elif scene == "ruins":
+            cam = frame.orbit_camera(i, (W, H), center=(0.0, 3.0, 0.0), radius=34.0, height=5.0, rate=0.004)
+        elif scene == "pica":
+            cam = frame.orbit_camera(i, (W, H), center=(-0.4, 0.5, -0.6), radius=5.0, height=1.6, rate=0.01)
+        else:
+            cam = frame.orbit_camera(i, (W, H), center=(0.0, 2.0, 0.0), radius=30.0, height=6.0, rate=0.004)
+        out.append(fs.prepare_frame_constants(cam))
+        fs.retire_frame()
+    return out
+
+
+def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced, n_frames=8, warmup=5, after_frame=None, with_cache=False):
+    """`with_cache`: the irradiance cache is BOUND, in its deterministic mode on both sides (lookups read, updates are recorded and replayed
+    at the end of the frame): the ray passes then take the branch of `trace_candidate` that reads the cache for hits failing the 5e-3
+    depth gate (diffuse_trace_common.inc.hlsl:85-107). The frame's head (cache maintenance, its three ray passes, reproject, SH sum-up)
+    runs on both sides, the oracle's cache is uploaded, and every rtdgi pass is compared in isolation as without the cache."""
     import torch
     from kajiya_amd.abi import KJ_RTDGI_PASS
     desc = _scenes()[scene_name]
-    op, gp = _make_pipelines(gpu, oracle, device, desc, W, H)
+    if with_cache:
+        import test_gpu_ircache as TI
+        op = oracle.OraclePipeline(oracle.OracleScene(desc), W, H, use_ircache=True)
+        gp = gpu.GpuPipeline(device, gpu.Scene(device, desc), W, H, use_ircache=True)
+        op.ircache_set_deferred(True)
+        gp.ircache_set_deferred(True)
+        fcs = _frame_constants_with_cache(W, H, n_frames, camera_of(scene_name))
+    else:
+        op, gp = _make_pipelines(gpu, oracle, device, desc, W, H)
+        fcs = _frame_constants(W, H, n_frames, camera_of(scene_name))
     op.L.okj_rtdgi_set_options(op.rtdgi, passes)
     op.L.okj_rtdgi_set_raytraced_visibility(op.rtdgi, int(raytraced))
     gpu.check(gp.L.kj_rtdgi_set_options(gp.rtdgi, passes, int(raytraced)))
-    fcs = _frame_constants(W, H, n_frames, camera_of(scene_name))
     repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
     worst = {}
+    cache_lookups = 0
     for fi, fc in enumerate(fcs):
         op.render_inputs(fc); op.reprojection(fc)
         gp.dev.frame_begin(fc)
@@ -299,8 +332,13 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced, n
         gp.reprojection_map_ptr = C.c_void_p(repro_dev.data_ptr())
         if fi < warmup:
             # warm-up frames: run whole frames on both, then force the GPU state to the oracle's
-            op.rtdgi_frame(fc); gp.rtdgi_frame()
-            torch.cuda.synchronize()
+            if with_cache:
+                op.gi_frame(fc); gp.gi_frame()
+                torch.cuda.synchronize()
+                TI._upload_ircache(op, gp, torch)
+            else:
+                op.rtdgi_frame(fc); gp.rtdgi_frame()
+                torch.cuda.synchronize()
             _upload_state(gp, _oracle_surfaces(op), torch)
             if after_frame:
                 after_frame(op, gp, fi, fc)
@@ -308,8 +346,20 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced, n
         # --- pass-by-pass frames (covers a validation frame (fi%3==0) and tracing frames)
         pre = _oracle_surfaces(op)
         _upload_state(gp, pre, torch)
+        if with_cache:      # head of the frame (world_render_passes.rs:99-140) on both sides: requests, cache maintenance + ray passes
+            TI._upload_ircache(op, gp, torch)
+            op.L.okj_ircache_begin_requests(op.ircache)
+            op.ircache_prepare_and_trace(fc)
+            gp.ircache_begin_requests()
+            gpu.check(gp.L.kj_ircache_prepare(gp.ircache, None))
+            gpu.check(gp.L.kj_ircache_trace_irradiance(gp.ircache, gp.scene.h, gp.sky16.data_ptr(), 16, None))
         op.L.okj_rtdgi_reproject(op.rtdgi, C.byref(fc), op.reprojection_map.ctypes.data, W, H)
         gpu.check(gp.L.kj_rtdgi_reproject(gp.rtdgi, gp.reprojection_map_ptr, W, H, None))
+        if with_cache:
+            op.ircache_sum_up(fc)
+            gpu.check(gp.L.kj_ircache_sum_up_irradiance_for_sampling(gp.ircache, None))
+            torch.cuda.synchronize()
+            TI._upload_ircache(op, gp, torch)     # the cache the ray passes look up: the oracle's, on both sides
         first = True
         for pname in ["REPROJECT"] + PASS_ORDER:
             if pname != "REPROJECT":
@@ -317,8 +367,11 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced, n
                 first = False
                 before = _oracle_surfaces(op)
                 _upload_state(gp, before, torch)
+                requests_before = op.L.okj_ircache_request_count(op.ircache) if with_cache else 0
                 p = op.params(mask); op.L.okj_rtdgi_render(op.rtdgi, C.byref(fc), C.byref(p), C.byref(op.out))
                 gpp = gp.params(mask); gpu.check(gp.L.kj_rtdgi_render(gp.rtdgi, C.byref(gpp), C.byref(gp.out), None))
+                if with_cache:
+                    cache_lookups += op.L.okj_ircache_request_count(op.ircache) - requests_before
             torch.cuda.synchronize()
             ref = _oracle_surfaces(op)
             got = _download_state(gp, ref.keys(), torch)
@@ -327,9 +380,18 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced, n
                 key = (pname, P.base_name(n))
                 if key not in worst or r["rel_l2"] > worst[key]["rel_l2"]:
                     worst[key] = r
-                assert P.pass_within_bars(pname, r), f"frame {fi} pass {pname} surface {n}: {r}"
+                assert P.pass_within_bars(pname, r), f"frame {fi} pass {pname}{' (cache bound)' if with_cache else ''} surface {n}: {r}"
+        if with_cache:      # the frame's recorded cache updates, replayed on both sides; then the product continues from the oracle's cache
+            op.L.okj_ircache_apply_requests(op.ircache)
+            gp.ircache_replay_own_requests()
+            torch.cuda.synchronize()
+            TI._upload_ircache(op, gp, torch)
         if after_frame:       # e.g. TAA on the frame the oracle has just finished (tests/test_gpu_headline_sizes.py)
             after_frame(op, gp, fi, fc)
+    if with_cache:
+        hw, hh = (W + 1) // 2, (H + 1) // 2
+        print(f"  cache lookups recorded by the compared ray passes: {cache_lookups}")
+        assert cache_lookups > 0.005 * hw * hh * (n_frames - warmup), f"only {cache_lookups} cache lookups in the compared ray passes: the cache-fed branch was barely exercised"
     for k, v in sorted(worst.items()):
         if v["rel_l2"] > 0:
             print(f"  {k[0]:>20s} {k[1]:<36s} rel_l2={v['rel_l2']:.2e} mismatch={v['mismatch_frac']:.2e}")
@@ -337,9 +399,9 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced, n
 
 @pytest.mark.parametrize("scene_name,W,H,with_cache", [("city20k", 200, 120, True), ("cornell", 123, 77, False)])
 def test_ray_pass_forms_agree(gpu, device, scene_name, W, H, with_cache):
-    """The four schedules of the two ray passes -- fused (one wave per tile does everything), grouped (256-thread workgroups, hit shading
-    regrouped through LDS), split (two launches: closest hit + misses | hit shading on records compacted across tiles) and staged (ray
-    streams) -- run the same functions on the same rays. Over free-running frames (validation and tracing frames, ragged extents):
+    """The five schedules of the two ray passes -- fused (one wave per tile does everything), grouped (256-thread workgroups, hit shading
+    regrouped through LDS), split (two launches: closest hit + misses | hit shading on records compacted across tiles), staged (ray
+    streams) and quad (the fused kernels with four lanes per pixel) -- run the same functions on the same rays. Over free-running frames (validation and tracing frames, ragged extents):
 
       * without the cache every surface is bit-identical, frame after frame;
       * with the cache bound (deterministic mode: the racy one differs from run to run by design) ray counts and the integer cache
@@ -350,7 +412,7 @@ def test_ray_pass_forms_agree(gpu, device, scene_name, W, H, with_cache):
     from kajiya_amd import frame
     scene = gpu.Scene(device, _scenes()[scene_name])
     pipes = {}
-    for form in ("grouped", "fused", "staged", "split"):
+    for form in ("grouped", "fused", "staged", "split", "quad"):
         gp = gpu.GpuPipeline(device, scene, W, H, use_ircache=with_cache)
         gp.set_ray_pass_form(form)
         if with_cache:
@@ -369,7 +431,7 @@ def test_ray_pass_forms_agree(gpu, device, scene_name, W, H, with_cache):
             gp.frame(fc)
         torch.cuda.synchronize()
         ref = pipes["fused"]
-        for form in ("grouped", "staged", "split"):
+        for form in ("grouped", "staged", "split", "quad"):
             q = pipes[form]
             assert ref.ray_counts() == q.ray_counts(), (fi, form, ref.ray_counts(), q.ray_counts())
             for n in names:
