@@ -139,6 +139,55 @@ void okj_trace_any(void* s, const float* rays, uint8_t* out, uint32_t count) {
         out[i] = sc.trace_any(ray) ? 1 : 0;
     }
 }
+// ---- tests/test_ref_hlsl.py: the scene as the reference's ray-tracing shaders see it (oracle/ref_hlsl compiles them from their own text).
+// TraceRay's intersection query -- the Vulkan driver's black box in the reference -- is answered by this scene's tracer;
+// what runs on a hit is the reference's rt/gbuffer.rchit.hlsl reading the tables exported below.
+struct OkjRefHit { int32_t hit; float t, bary_u, bary_v; uint32_t instance_index, instance_id, primitive_index; float object_to_world[12]; };
+void okj_ref_trace_hook(void* scene, const float* r, uint32_t flags, OkjRefHit* out) {
+    const Scene& sc = *(const Scene*)scene;
+    const Ray ray{f3{r[0], r[1], r[2]}, r[3], f3{r[4], r[5], r[6]}, r[7]};
+    memset(out, 0, sizeof(*out));
+    if ((flags & 4u) && (flags & 8u)) { out->hit = sc.trace_any(ray) ? 1 : 0; return; }      // ACCEPT_FIRST_HIT_AND_END_SEARCH | SKIP_CLOSEST_HIT_SHADER: a shadow ray
+    const Hit h = sc.trace_closest(ray, (flags & 0x10u) != 0);                                   // CULL_BACK_FACING_TRIANGLES
+    if (!h.is_hit()) return;
+    const WorldTri& t = sc.tris[h.tri];
+    const Instance& inst = sc.instances[t.inst];
+    out->hit = 1; out->t = h.t; out->bary_u = h.u; out->bary_v = h.v;
+    out->instance_index = t.inst; out->instance_id = inst.mesh;            // instance custom index = mesh index (world_renderer.rs:836-911)
+    out->primitive_index = t.prim;
+    memcpy(out->object_to_world, inst.xform, 48);
+}
+void* okj_ref_trace_hook_ptr() { return (void*)&okj_ref_trace_hook; }
+// `meshes` (inc/bindless.hlsl: StructuredBuffer<Mesh>, seven offsets per mesh) and `vertices` (the byte-addressed buffer). The material
+// records' map indices are indices into this scene's map table; the reference's bindless table holds three LUTs first
+// (inc/bindless_textures.hlsl), so the exported copy has `map_index_bias` added -- the index kajiya's add_image would have handed out.
+uint32_t okj_scene_mesh_count(void* s) { return uint32_t(((Scene*)s)->meshes.size()); }
+uint32_t okj_scene_instance_count(void* s) { return uint32_t(((Scene*)s)->instances.size()); }
+uint32_t okj_scene_map_count(void* s) { return uint32_t(((Scene*)s)->maps.size()); }
+uint64_t okj_scene_vertex_buffer_bytes(void* s) { return ((Scene*)s)->vertex_buffer.size(); }
+void okj_scene_export_tables(void* s, uint32_t* meshes7, uint8_t* vertices, float* instance_emissive_multipliers, const uint32_t* material_counts, uint32_t map_index_bias) {
+    const Scene& sc = *(const Scene*)s;
+    memcpy(vertices, sc.vertex_buffer.data(), sc.vertex_buffer.size());
+    for (size_t i = 0; i < sc.meshes.size(); ++i) {
+        const GpuMesh& m = sc.meshes[i];
+        const uint32_t v[7] = {m.vertex_core_offset, m.vertex_uv_offset, m.vertex_mat_offset, m.vertex_aux_offset, m.vertex_tangent_offset, m.mat_data_offset, m.index_offset};
+        memcpy(meshes7 + i * 7, v, 28);
+        for (uint32_t k = 0; k < material_counts[i]; ++k) {
+            KjMeshMaterial mat;
+            memcpy(&mat, vertices + m.mat_data_offset + size_t(k) * sizeof(KjMeshMaterial), sizeof(mat));
+            for (int j = 0; j < 4; ++j) mat.maps[j] += map_index_bias;
+            memcpy(vertices + m.mat_data_offset + size_t(k) * sizeof(KjMeshMaterial), &mat, sizeof(mat));
+        }
+    }
+    for (size_t i = 0; i < sc.instances.size(); ++i) instance_emissive_multipliers[i] = sc.instances[i].emissive_multiplier;
+}
+// map i: placeholder colour as RGBA8 (what a 1x1 image holds), or its first mip level
+void okj_scene_map_info(void* s, uint32_t i, uint8_t* rgba8_placeholder, uint32_t* w, uint32_t* h, uint32_t* mips, const void** texels) {
+    const Scene::Map& m = ((Scene*)s)->maps[i];
+    rgba8_placeholder[0] = uint8_t(m.color.x * 255.0f + 0.5f); rgba8_placeholder[1] = uint8_t(m.color.y * 255.0f + 0.5f);
+    rgba8_placeholder[2] = uint8_t(m.color.z * 255.0f + 0.5f); rgba8_placeholder[3] = uint8_t(m.color.w * 255.0f + 0.5f);
+    *w = m.width; *h = m.height; *mips = m.mips; *texels = m.texels.empty() ? nullptr : m.texels.data();
+}
 // world-space triangle i -> (inst, prim), for mapping product hits onto oracle triangle ids
 void okj_scene_tri_ids(void* s, uint32_t* out_inst_prim) {
     const Scene& sc = *(Scene*)s;
@@ -272,6 +321,16 @@ int okj_ircache_buffer(void* p, const char* name, void** out_ptr, uint64_t* out_
 // tests/test_ref_hlsl.py: the host-side state of IrcacheRenderer (ircache.rs:92-100) and the ray-free head of trace_irradiance on its own
 void okj_ircache_host_state(void* p, int32_t* out3) { Ircache& ic = ((OkjIrcache*)p)->ic; out3[0] = ic.parity; out3[1] = ic.initialized ? 1 : 0; out3[2] = ic.cur; }
 void okj_ircache_prepare_and_reset(void* p) { IrcacheTracer::prepare_and_reset(((OkjIrcache*)p)->ic); }
+// one of the cache's three ray passes on its own: 0 = trace accessibility, 1 = validate, 2 = trace irradiance (ircache.rs:396-481)
+void okj_ircache_ray_pass(void* p, const KjFrameConstants* fc, void* scene, const void* sky_cube, int sky_cube_width, int which) {
+    OkjIrcache* o = (OkjIrcache*)p;
+    IrcacheTraceInputs in;
+    in.scene = (const Scene*)scene; in.sky_cube = (const h4*)sky_cube; in.sky_cube_width = sky_cube_width; in.brdf_fg_lut = o->brdf_lut.data();
+    const f3 sun_color = sun_color_in_direction(*fc, sun_direction(*fc));
+    if (which == 0) IrcacheTracer::trace_accessibility(o->ic, in);
+    else if (which == 1) IrcacheTracer::validate(o->ic, *fc, in, sun_color);
+    else IrcacheTracer::trace_irradiance(o->ic, *fc, in, sun_color);
+}
 void okj_ircache_ray_counts(void* p, uint64_t* closest, uint64_t* any) {
     Ircache& ic = ((OkjIrcache*)p)->ic;
     *closest = ic.rays_closest.load(); *any = ic.rays_any.load();

@@ -78,8 +78,14 @@ def lib():
         L.okj_ircache_buffer.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_ircache_ray_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.okj_ircache_set_deferred_updates.argtypes = [C.c_void_p, C.c_int]
+        L.okj_ref_trace_hook_ptr.restype = C.c_void_p
+        L.okj_scene_mesh_count.argtypes = [C.c_void_p]; L.okj_scene_instance_count.argtypes = [C.c_void_p]; L.okj_scene_map_count.argtypes = [C.c_void_p]
+        L.okj_scene_vertex_buffer_bytes.argtypes = [C.c_void_p]; L.okj_scene_vertex_buffer_bytes.restype = C.c_uint64
+        L.okj_scene_export_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.okj_scene_map_info.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.okj_ircache_host_state.argtypes = [C.c_void_p, C.c_void_p]
         L.okj_ircache_prepare_and_reset.argtypes = [C.c_void_p]
+        L.okj_ircache_ray_pass.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.okj_ircache_begin_requests.argtypes = [C.c_void_p]
         L.okj_ircache_apply_requests.argtypes = [C.c_void_p]
         L.okj_ircache_request_count.argtypes = [C.c_void_p]; L.okj_ircache_request_count.restype = C.c_uint64

@@ -34,6 +34,7 @@ RESOURCE_TYPES = {"Texture2D", "RWTexture2D", "Texture3D", "RWTexture3D", "Textu
                   "RWByteAddressBuffer", "Buffer", "RWBuffer", "SamplerState", "SamplerComparisonState", "RaytracingAccelerationStructure", "Texture2DArray", "RWTexture2DArray"}
 BUILTIN_TYPES = set("float int uint bool half double min16float".split()) | {t + str(n) for t in ("float", "int", "uint", "bool", "half") for n in (1, 2, 3, 4)} | \
     {"float%dx%d" % (r, c) for r in (2, 3, 4) for c in (2, 3, 4)}
+BRACE_CTOR_TYPES = {t + str(n) for t in ("float", "int", "uint", "bool", "half") for n in (2, 3, 4)} | {"float%dx%d" % (r, c) for r in (2, 3, 4) for c in (2, 3, 4)}
 SEMANTIC_RE = re.compile(r"^(SV_\w+|TEXCOORD\d*|POSITION\d*|COLOR\d*|NORMAL\d*|TANGENT\d*)$")
 CPP_KEYWORD_IDS = {"and": "and_", "or": "or_", "not": "not_", "xor": "xor_", "new": "new_", "delete": "delete_", "register": "register_", "auto": "auto_", "union": "union_",
                    "export": "export_", "friend": "friend_", "mutable": "mutable_", "virtual": "virtual_", "explicit": "explicit_", "near": "near_", "far": "far_", "typeid": "typeid_"}
@@ -280,6 +281,12 @@ class Rewriter:
                 continue
             p = self.nsig(i, -1)
             n = self.nsig(i)
+            if t.kind == "id" and t.text in BRACE_CTOR_TYPES and self.is_(n, "(") and not (p is not None and (T[p].text in (".", "->", "::") or T[p].kind == "id")):
+                # `float2(a(rng), b(rng))`: DXC evaluates constructor arguments left to right and the shaders rely on it (two hash1_mut(rng)
+                # draws in one constructor); a C++ braced-init-list guarantees that order, a parenthesised argument list does not
+                e = self.match_close(n, "(", ")")
+                T[n].text = "{"
+                T[e].text = "}"
             if t.kind == "id":
                 if t.text == "const":
                     if not (p is not None and T[p].text == "static"):
@@ -386,6 +393,8 @@ class Rewriter:
                 raise ValueError("entry point parameter without semantic in %s: %s" % (self.relpath, a))
             c = a.index(":")
             ty, sem = a[0], a[c + 1]
+            if sem in ("SV_RayPayload", "SV_IntersectionAttributes"):
+                return None          # a hit / miss shader: called by TraceRay (hlsl_resources.hpp), not dispatched
             if sem not in LANE_VALUE:
                 raise ValueError("unsupported semantic %s in %s" % (sem, self.relpath))
             out.append("hlsl::lane_arg<%s>(L.%s)" % (ty, LANE_VALUE[sem]))
@@ -411,6 +420,30 @@ def swizzle_members():
     return "\n".join(out) + "\n"
 
 
+RT_WRAPPER = """// generated by oracle/ref_hlsl/hlsl2cpp.py: ray-generation shader {rel} with its hit / miss shaders (text not copied into the repository)
+#include "hlsl_compat.hpp"
+namespace hlsl {{ namespace {{      // internal linkage
+static hlsl::PassBegin _pass_begin("{name}");
+#include "{rel}"
+namespace chit_ns {{
+#include "{chit}"
+}}
+namespace miss0_ns {{
+#include "{miss0}"
+}}
+namespace miss1_ns {{
+#include "{miss1}"
+}}
+static void _chit(void* payload, float bu, float bv) {{ chit_ns::RayHitAttrib a; a.bary = float2(bu, bv); chit_ns::cs_main(*(GbufferRayPayload*)payload, a); }}
+static void _miss0(void* payload) {{ miss0_ns::cs_main(*(GbufferRayPayload*)payload); }}
+static void _miss1(void* payload) {{ miss1_ns::cs_main(*(miss1_ns::ShadowPayload*)payload); }}
+static const hlsl::RtPipeline _rt = {{_chit, {{_miss0, _miss1}}}};
+static void _invoke(const hlsl::LaneInfo& L) {{ hlsl::hlsl_rt_pipeline() = &_rt; cs_main(); }}
+static const hlsl::uint _nt[3] = {{1, 1, 1}};
+static hlsl::PassEnd _pass_end(_nt, false, _invoke);
+}} }}
+"""
+
 WRAPPER = """// generated by oracle/ref_hlsl/hlsl2cpp.py from the reference's {rel} (text not copied into the repository)
 #include "hlsl_compat.hpp"
 namespace hlsl {{ namespace {{      // internal linkage: every pass declares its own `input_tex`, `cs_main`, ...
@@ -431,6 +464,7 @@ def main():
     ap.add_argument("--shaders", default="/root/reference/assets/shaders")
     ap.add_argument("--out", required=True)
     ap.add_argument("--passes", nargs="*", default=[], help="entry files (relative to --shaders) to emit wrappers for")
+    ap.add_argument("--rt-passes", nargs="*", default=[], help="rgen[:chit[:miss0[:miss1]]] (relative to --shaders)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     with open(os.path.join(args.out, "hlsl_swizzles.inc"), "w") as f:
@@ -455,7 +489,16 @@ def main():
         name = rel[:-5] if rel.endswith(".hlsl") else rel
         with open(os.path.join(args.out, "pass_" + name.replace("/", "_").replace(".", "_") + ".cpp"), "w") as f:
             f.write(WRAPPER.format(rel=rel, name=name))
-    print("hlsl2cpp: rewrote %d files into %s, %d pass wrappers" % (n, args.out, len(args.passes)))
+    for spec in args.rt_passes:
+        parts = spec.split(":")
+        rel = parts[0]
+        chit = parts[1] if len(parts) > 1 and parts[1] else "rt/gbuffer.rchit.hlsl"
+        miss0 = parts[2] if len(parts) > 2 and parts[2] else "rt/gbuffer.rmiss.hlsl"
+        miss1 = parts[3] if len(parts) > 3 and parts[3] else "rt/shadow.rmiss.hlsl"
+        name = rel[:-5] if rel.endswith(".hlsl") else rel
+        with open(os.path.join(args.out, "pass_" + name.replace("/", "_").replace(".", "_") + ".cpp"), "w") as f:
+            f.write(RT_WRAPPER.format(rel=rel, name=name, chit=chit, miss0=miss0, miss1=miss1))
+    print("hlsl2cpp: rewrote %d files into %s, %d pass wrappers" % (n, args.out, len(args.passes) + len(args.rt_passes)))
 
 
 if __name__ == "__main__":

@@ -143,6 +143,7 @@ template <class T, class A, class... R> static inline void flatten_(T* out, int 
     template <class B, HLSL_REQ(VT<B>::isvec && VT<B>::n == N), class = void> vec(const B& b) { T t[N]; for (int i = 0; i < N; ++i) t[i] = cv<T>(VT<B>::get(b, i)); for (int i = 0; i < N; ++i) d[i] = t[i]; } \
     template <class B, HLSL_REQ(VT<B>::isvec && (VT<B>::n > N)), class = void, class = void> explicit vec(const B& b) { for (int i = 0; i < N; ++i) d[i] = cv<T>(VT<B>::get(b, i)); } \
     template <class A0, class A1, class... R, HLSL_REQ((all_ok<A0, A1, R...>::v && ncomp<A0, A1, R...>::n == N))> vec(const A0& a0, const A1& a1, const R&... r) { flatten_<T>(d, 0, a0, a1, r...); } \
+    template <class U, HLSL_REQ(is_elem<U>::value)> explicit vec(const U (&a)[N]) { for (int i = 0; i < N; ++i) d[i] = cv<T>(a[i]); }   /* float4(float[4]) */ \
     T& operator[](int i) { return d[i]; } \
     T operator[](int i) const { return d[i]; } \
     T& operator[](uint i) { return d[i]; } \

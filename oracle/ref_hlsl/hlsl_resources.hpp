@@ -232,6 +232,7 @@ struct ByteAddressBuffer : ResourceBase {
     HLSL_RES_CTORS(ByteAddressBuffer, ResourceBase)
     uint ld(uint a) const { if (!data || size_t(a) + 4 > bytes) return 0u; uint v; memcpy(&v, (const uint8_t*)data + a, 4); return v; }
     uint Load(uint a) const { return ld(a); }
+    template <class T> T Load(uint a) const { T t; memset((void*)&t, 0, sizeof(T)); if (data && size_t(a) + sizeof(T) <= bytes) memcpy((void*)&t, (const uint8_t*)data + a, sizeof(T)); return t; }
     uint2 Load2(uint a) const { return uint2(ld(a), ld(a + 4)); }
     uint3 Load3(uint a) const { return uint3(ld(a), ld(a + 4), ld(a + 8)); }
     uint4 Load4(uint a) const { return uint4(ld(a), ld(a + 4), ld(a + 8), ld(a + 12)); }
@@ -316,6 +317,42 @@ static inline void AllMemoryBarrierWithGroupSync() { hlsl_group_barrier(); }
 static inline void DeviceMemoryBarrierWithGroupSync() { hlsl_group_barrier(); }
 static inline void DeviceMemoryBarrier() {}
 static inline void AllMemoryBarrier() {}
+
+// ------------------------------------------------------------------------------------------------ ray tracing
+// TraceRay stands in for VK_KHR_ray_tracing_pipeline: the intersection query goes to a hook the test installs (the oracle's scene: the
+// driver's traversal is a black box in the reference too); the closest-hit and miss shaders that then run are the
+// reference's own text (rt/gbuffer.rchit.hlsl, rt/*.rmiss.hlsl), compiled into the same translation unit by the wrapper.
+enum { RAY_FLAG_NONE = 0, RAY_FLAG_FORCE_OPAQUE = 1, RAY_FLAG_FORCE_NON_OPAQUE = 2, RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH = 4, RAY_FLAG_SKIP_CLOSEST_HIT_SHADER = 8,
+       RAY_FLAG_CULL_BACK_FACING_TRIANGLES = 0x10, RAY_FLAG_CULL_FRONT_FACING_TRIANGLES = 0x20, RAY_FLAG_CULL_OPAQUE = 0x40, RAY_FLAG_CULL_NON_OPAQUE = 0x80 };
+struct RayHitInfo { int hit; float t, bary_u, bary_v; uint instance_index, instance_id, primitive_index; float object_to_world[12]; /* row-major 3x4 */ };
+typedef void (*TraceHook)(void* user, const float* ray8 /* origin, tmin, direction, tmax */, uint flags, RayHitInfo* out);
+struct RtPipeline { void (*closest_hit)(void* payload, float bary_u, float bary_v); void (*miss[2])(void* payload); };
+const RtPipeline*& hlsl_rt_pipeline();
+void hlsl_trace(const float* ray8, uint flags, RayHitInfo* out);
+struct RtHitContext { RayDesc ray; RayHitInfo hit; };
+RtHitContext*& hlsl_rt_hit();
+static inline float3 WorldRayOrigin() { return hlsl_rt_hit()->ray.Origin; }
+static inline float3 WorldRayDirection() { return hlsl_rt_hit()->ray.Direction; }
+static inline float RayTCurrent() { return hlsl_rt_hit()->hit.t; }
+static inline float RayTMin() { return hlsl_rt_hit()->ray.TMin; }
+static inline uint InstanceID() { return hlsl_rt_hit()->hit.instance_id; }
+static inline uint InstanceIndex() { return hlsl_rt_hit()->hit.instance_index; }
+static inline uint PrimitiveIndex() { return hlsl_rt_hit()->hit.primitive_index; }
+static inline float3x4 ObjectToWorld3x4() { const float* m = hlsl_rt_hit()->hit.object_to_world; return float3x4(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11]); }
+static inline uint3 DispatchRaysIndex() { return hlsl_lane().dispatch_thread_id; }
+uint3 hlsl_dispatch_dims();
+static inline uint3 DispatchRaysDimensions() { return hlsl_dispatch_dims(); }
+template <class P> static inline void TraceRay(const RaytracingAccelerationStructure&, uint flags, uint /*mask*/, uint /*sbt offset*/, uint /*sbt stride*/, uint miss_index, const RayDesc& ray, P& payload) {
+    RtHitContext ctx; ctx.ray = ray;
+    const float r8[8] = {ray.Origin.x, ray.Origin.y, ray.Origin.z, ray.TMin, ray.Direction.x, ray.Direction.y, ray.Direction.z, ray.TMax};
+    hlsl_trace(r8, flags, &ctx.hit);
+    const RtPipeline* pl = hlsl_rt_pipeline();
+    if (ctx.hit.hit) {
+        if (!(flags & RAY_FLAG_SKIP_CLOSEST_HIT_SHADER)) { RtHitContext* saved = hlsl_rt_hit(); hlsl_rt_hit() = &ctx; pl->closest_hit((void*)&payload, ctx.hit.bary_u, ctx.hit.bary_v); hlsl_rt_hit() = saved; }
+    } else {
+        pl->miss[miss_index < 2 ? miss_index : 1]((void*)&payload);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ pass registry (filled by the generated wrappers)
 // A wrapper is one translation unit: PassBegin, then the rewritten shader text (whose resource / constant declarations register

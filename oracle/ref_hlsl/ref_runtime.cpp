@@ -21,6 +21,15 @@ void hlsl_pass_end(const uint nt[3], bool lockstep, void (*invoke)(const LaneInf
 void hlsl_register_resource(const ResName& n, ResourceBase* r) { if (open_pass()) open_pass()->resources.push_back(ResourceSlot{n.name, n.type, r, n.binding, n.set}); }
 void hlsl_register_constant(const char* name, void* ptr, size_t bytes, int binding, int set) { if (open_pass()) open_pass()->constants.push_back(ConstantSlot{name, ptr, bytes, binding, set}); }
 
+// ------------------------------------------------------------------------------------------------ ray tracing hooks
+static TraceHook g_trace_hook = nullptr; static void* g_trace_user = nullptr;
+const RtPipeline*& hlsl_rt_pipeline() { static thread_local const RtPipeline* p = nullptr; return p; }
+RtHitContext*& hlsl_rt_hit() { static thread_local RtHitContext* h = nullptr; return h; }
+void hlsl_trace(const float* ray8, uint flags, RayHitInfo* out) {
+    if (!g_trace_hook) { fprintf(stderr, "hlsl_compat: TraceRay without a trace hook (ref_set_trace_hook)\n"); abort(); }
+    g_trace_hook(g_trace_user, ray8, flags, out);
+}
+
 // ------------------------------------------------------------------------------------------------ lanes
 enum LaneState { LANE_READY = 0, LANE_WAIT_WAVE = 1, LANE_WAIT_GROUP = 2, LANE_DONE = 3 };
 struct Lane { ucontext_t ctx; LaneInfo info; int state; };
@@ -112,7 +121,10 @@ static void run_group_lockstep(const PassInfo* p, GroupRun& r, uint3 group_id) {
 // (z, y, x) order. Any order is a legal schedule; passes that push onto shared lists with atomics (the irradiance cache's free list)
 // produce those lists in schedule order, and the oracle's loops are the ascending one.
 static bool g_linear_order = false;
+static uint3 g_dispatch_dims;
+uint3 hlsl_dispatch_dims() { return g_dispatch_dims; }
 static void dispatch(const PassInfo* p, uint tx, uint ty, uint tz) {
+    g_dispatch_dims = uint3(tx, ty, tz);
     const uint gx = (tx + p->nt[0] - 1) / p->nt[0], gy = (ty + p->nt[1] - 1) / p->nt[1], gz = (tz + p->nt[2] - 1) / p->nt[2];
     if (!p->needs_lockstep && g_linear_order) {
         for (uint z = 0; z < gz * p->nt[2]; ++z) for (uint y = 0; y < gy * p->nt[1]; ++y) for (uint x = 0; x < gx * p->nt[0]; ++x) {
@@ -162,28 +174,32 @@ void ref_pass_numthreads(const char* pass, unsigned* out3) { const PassInfo* p =
 // bind memory to a resource of the pass: textures give (w, h, format), buffers give bytes (w = h = 0)
 int ref_bind(const char* pass, const char* name, void* data, int w, int h, int fmt, unsigned long long bytes) {
     const PassInfo* p = find(pass); if (!p) return -1;
+    int found = 0;      // every resource of that name: a hit shader compiled into the same wrapper declares its own copy of some set-1 / set-2 resources
     for (size_t i = 0; i < p->resources.size(); ++i) if (p->resources[i].name == name) {
         ResourceBase* r = p->resources[i].res; r->data = data; r->w = w; r->h = h; r->fmt = fmt;
-        r->bytes = bytes ? size_t(bytes) : size_t(w) * size_t(h) * size_t(format_bytes(fmt)); return 0; }
-    return -2;
+        r->bytes = bytes ? size_t(bytes) : size_t(w) * size_t(h) * size_t(format_bytes(fmt)); ++found; }
+    return found ? 0 : -2;
 }
 // one slot of a resource array (`Texture2D bindless_textures[]`)
 int ref_bind_slot(const char* pass, const char* name, unsigned index, void* data, int w, int h, int fmt) {
     PassInfo* p = find(pass); if (!p) return -1;
+    int found = 0;
     for (size_t i = 0; i < p->resources.size(); ++i) if (p->resources[i].name == name) {
         ResourceArrayBase* a = dynamic_cast<ResourceArrayBase*>(p->resources[i].res); if (!a) return -4;
         ResourceBase* r = a->slot(index); if (!r) return -5;
-        r->data = data; r->w = w; r->h = h; r->fmt = fmt; r->bytes = size_t(w) * size_t(h) * size_t(format_bytes(fmt)); return 0; }
-    return -2;
+        r->data = data; r->w = w; r->h = h; r->fmt = fmt; r->bytes = size_t(w) * size_t(h) * size_t(format_bytes(fmt)); ++found; }
+    return found ? 0 : -2;
 }
 int ref_set_constant(const char* pass, const char* name, const void* src, unsigned long long bytes) {
     const PassInfo* p = find(pass); if (!p) return -1;
+    int found = 0;
     for (size_t i = 0; i < p->constants.size(); ++i) if (p->constants[i].name == name) {
         if (bytes != p->constants[i].bytes) return -3;
-        memcpy(p->constants[i].ptr, src, size_t(bytes)); return 0; }
-    return -2;
+        memcpy(p->constants[i].ptr, src, size_t(bytes)); ++found; }
+    return found ? 0 : -2;
 }
 // `threads`: the extent kajiya's .dispatch([x, y, z]) is given -- threads, rounded up to whole groups like the backend does
+void ref_set_trace_hook(void* fn, void* user) { g_trace_hook = (TraceHook)fn; g_trace_user = user; }
 void ref_set_linear_order(int on) { g_linear_order = on != 0; }
 int ref_dispatch(const char* pass, unsigned tx, unsigned ty, unsigned tz) { const PassInfo* p = find(pass); if (!p) return -1; dispatch(p, tx, ty, tz); return 0; }
 }

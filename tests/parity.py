@@ -16,7 +16,7 @@ FORMATS = {
     "rtr.reservoir": "reservoir", "rtr.rng": "u32", "rtr.hit_normal": "rgba16f", "refl_restir_invalidity_tex": "r8", "resolved_tex": "r11g11b10f",
 }
 FULL_RES = {"rtdgi.temporal2_var", "rtdgi.temporal2", "reprojected_history_tex", "irradiance_output_tex", "temporal_filtered_tex", "spatial_filtered_tex"}
-BYTES_PER_TEXEL = {"r11g11b10f": 4, "u32": 4, "rtr_ray_orig": 16, "rgba16f": 8, "rgba32f": 16, "rg16f": 4, "reservoir": 8, "rgba8s": 4, "trp": 16, "r8": 1, "r8s": 1, "r32f": 4}
+BYTES_PER_TEXEL = {"r16f": 2, "r11g11b10f": 4, "u32": 4, "rtr_ray_orig": 16, "rgba16f": 8, "rgba32f": 16, "rg16f": 4, "reservoir": 8, "rgba8s": 4, "trp": 16, "r8": 1, "r8s": 1, "r32f": 4}
 
 
 def base_name(name):
@@ -41,6 +41,8 @@ def decode(raw_u8, fmt):
         return raw.view(np.float16).astype(np.float32).reshape(-1, 4)
     if fmt == "rg16f":
         return raw.view(np.float16).astype(np.float32).reshape(-1, 2)
+    if fmt == "r16f":
+        return raw.view(np.float16).astype(np.float32).reshape(-1, 1)
     if fmt == "rgba32f":
         return raw.view(np.float32).reshape(-1, 4)
     if fmt == "r32f":

@@ -82,9 +82,23 @@ def set_bindless(slot, tex):
     BINDLESS[slot] = tex
 
 
+NAMED = {}          # name -> Tex / Buf: descriptor sets 1 and 2 (`meshes`, `vertices`, `bindless_texture_sizes`, `instance_dynamic_parameters_dyn`, `triangle_lights_dyn`)
+
+
+def set_named(name, res):
+    NAMED[name] = res
+
+
+def set_trace_hook(fn_ptr, user):
+    """TraceRay's intersection query (the driver's black box in the reference): a C function (user, ray8, flags, RayHitInfo*)."""
+    L = lib()
+    L.ref_set_trace_hook.argtypes = [C.c_void_p, C.c_void_p]
+    L.ref_set_trace_hook(fn_ptr, user)
+
+
 def run_pass(name, resources, constants, frame_constants, dispatch):
     """resources: Tex / Buf objects in .read()/.write() order; constants: numpy scalars / arrays in .constants((...)) order;
-    dispatch: the thread extent given to .dispatch([x, y, z])."""
+    dispatch: the thread extent given to .dispatch([x, y, z]) / .trace_rays(tlas, [x, y, z])."""
     L = lib()
     pn = name.encode()
     assert L.ref_pass_exists(pn), (name, passes())
@@ -92,7 +106,7 @@ def run_pass(name, resources, constants, frame_constants, dispatch):
     for i in range(L.ref_pass_resource_count(pn)):
         if L.ref_pass_resource_set(pn, i) == 0:
             slots.append((L.ref_pass_resource_binding(pn, i), L.ref_pass_resource_name(pn, i)))
-    slots.sort()
+    slots = sorted(set(slots))
     assert [b for b, _ in slots] == list(range(len(slots))), (name, slots)          # set 0 is dense from binding 0, like SimpleRenderPass binds it
     assert len(slots) == len(resources), (name, [n for _, n in slots], len(resources))
     keep = []
@@ -118,6 +132,13 @@ def run_pass(name, resources, constants, frame_constants, dispatch):
             assert C.sizeof(frame_constants) == 1216
             assert L.ref_set_constant(pn, b"frame_constants", C.byref(frame_constants), 1216) == 0
     for i in range(L.ref_pass_resource_count(pn)):
+        rn = L.ref_pass_resource_name(pn, i)
+        if L.ref_pass_resource_set(pn, i) != 0 and rn.decode() in NAMED:
+            r = NAMED[rn.decode()]
+            if isinstance(r, Tex):
+                assert L.ref_bind(pn, rn, r.raw.ctypes.data, r.w, r.h, r.fmt, 0) == 0
+            else:
+                assert L.ref_bind(pn, rn, r.raw.ctypes.data, 0, 0, 0, r.raw.size) == 0
         if L.ref_pass_resource_name(pn, i) == b"bindless_textures":
             for slot, t in BINDLESS.items():
                 assert L.ref_bind_slot(pn, b"bindless_textures", slot, t.raw.ctypes.data, t.w, t.h, t.fmt) == 0

@@ -130,7 +130,8 @@ def config3_lighting_frame_parity(gpu, oracle, device, scene_name, W, H):
             # the whole frame in one go (its passes in isolation: the 4K test above): a candidate whose shadow ray or depth gate flipped
             # (1e-4 of the half-res texels) reaches ~50 full-res neighbours through the resampling chain and the denoiser, each by a
             # little -- the image-level bar holds, the count of slightly-off texels is reported and bounded loosely
-            assert r["rel_l2"] <= P.REL_L2_TOL and r["bad_class"] == 0 and r["mismatch_frac"] <= 2e-2, f"rtdgi whole frame {fi}: {r}"
+            # (measured on MI355X, round 4: 4.5e-3 / 4.1e-4 of the texels at 1440p; the bar is twice the larger one)
+            assert r["rel_l2"] <= P.REL_L2_TOL and r["bad_class"] == 0 and r["mismatch_frac"] <= 9e-3, f"rtdgi whole frame {fi}: {r}"
             T._upload_state(gp, T._oracle_surfaces(op), torch)
             for k, pname in enumerate(TR.RTR_PASS_ORDER):
                 mask = TR.KJ_RTR_PASS[pname] | (0 if k == 0 else TR.KJ_RTR_PASS["KEEP"])
