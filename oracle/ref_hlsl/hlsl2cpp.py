@@ -285,8 +285,9 @@ class Rewriter:
                 # `float2(a(rng), b(rng))`: DXC evaluates constructor arguments left to right and the shaders rely on it (two hash1_mut(rng)
                 # draws in one constructor); a C++ braced-init-list guarantees that order, a parenthesised argument list does not
                 e = self.match_close(n, "(", ")")
+                t.text = "(" + t.text          # parenthesised as a whole: inside a macro argument the commas between braces would split it
                 T[n].text = "{"
-                T[e].text = "}"
+                T[e].text = "})"
             if t.kind == "id":
                 if t.text == "const":
                     if not (p is not None and T[p].text == "static"):

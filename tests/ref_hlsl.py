@@ -17,7 +17,9 @@ FMT = dict(r32f=1, rg32f=2, rgba32f=3, r16f=4, rg16f=5, rgba16f=6, r8=7, rgba8=8
            reservoir=15, trp=16)   # parity.py's names for RG32UI reservoirs / the RGBA32UI packed temporal reservoir
 FMT_BYTES = {1: 4, 2: 8, 3: 16, 4: 2, 5: 4, 6: 8, 7: 1, 8: 4, 9: 1, 10: 4, 11: 8, 12: 4, 13: 4, 14: 4, 15: 8, 16: 16, 17: 4, 18: 2, 19: 2}
 
-_LIB = None
+_LIB = {}
+_VARIANT = "hw"      # which build run_pass() uses: "hw" = sin / cos reduced in revolutions like v_sin_f32, "libm" = libm's
+_HOOK = None
 
 
 def available():
@@ -30,19 +32,37 @@ def build():
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle", "ref_hlsl")])
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        build()
-        L = C.CDLL(LIB_PATH)
+class sincos:
+    """with sincos("libm"): ... -- the passes inside run from the build whose sin / cos are libm's (what the oracle uses outside the five
+    spiral-tap sites of the rtdgi screen passes); the default build reduces the angle in revolutions like the hardware the reference ran on."""
+
+    def __init__(self, variant):
+        self.variant = variant
+
+    def __enter__(self):
+        global _VARIANT
+        self.prev, _VARIANT = _VARIANT, self.variant
+
+    def __exit__(self, *a):
+        global _VARIANT
+        _VARIANT = self.prev
+
+
+def lib(variant=None):
+    variant = variant or _VARIANT
+    if variant not in _LIB:
+        if not _LIB:
+            build()
+        L = C.CDLL(LIB_PATH if variant == "hw" else LIB_PATH.replace(".so", "_libm.so"))
         for f in ("ref_pass_name", "ref_pass_resource_name", "ref_pass_resource_type", "ref_pass_constant_name"):
             getattr(L, f).restype = C.c_char_p
         L.ref_bind.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ulonglong]
         L.ref_set_constant.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_ulonglong]
         L.ref_dispatch.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint]
         L.ref_bind_slot.argtypes = [C.c_char_p, C.c_char_p, C.c_uint, C.c_void_p, C.c_int, C.c_int, C.c_int]
-        _LIB = L
-    return _LIB
+        L.ref_set_trace_hook.argtypes = [C.c_void_p, C.c_void_p]
+        _LIB[variant] = L
+    return _LIB[variant]
 
 
 def passes():
@@ -91,15 +111,16 @@ def set_named(name, res):
 
 def set_trace_hook(fn_ptr, user):
     """TraceRay's intersection query (the driver's black box in the reference): a C function (user, ray8, flags, RayHitInfo*)."""
-    L = lib()
-    L.ref_set_trace_hook.argtypes = [C.c_void_p, C.c_void_p]
-    L.ref_set_trace_hook(fn_ptr, user)
+    global _HOOK
+    _HOOK = (fn_ptr, user)
 
 
 def run_pass(name, resources, constants, frame_constants, dispatch):
     """resources: Tex / Buf objects in .read()/.write() order; constants: numpy scalars / arrays in .constants((...)) order;
     dispatch: the thread extent given to .dispatch([x, y, z]) / .trace_rays(tlas, [x, y, z])."""
     L = lib()
+    if _HOOK:
+        L.ref_set_trace_hook(_HOOK[0], _HOOK[1])
     pn = name.encode()
     assert L.ref_pass_exists(pn), (name, passes())
     slots = []

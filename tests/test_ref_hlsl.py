@@ -19,6 +19,14 @@ pytestmark = pytest.mark.skipif(not R.available(), reason="neither a reference c
 KEEP = 1 << 31
 
 
+@pytest.fixture
+def libm_sincos():
+    """The passes of this test run from the build of the reference's text whose sin / cos are libm's -- the oracle's choice everywhere but
+    the five spiral-tap sites of the rtdgi screen passes, which use the hardware's range reduction (ref_hlsl.sincos)."""
+    with R.sincos("libm"):
+        yield
+
+
 def _frame_constants(W, H, n_frames, scene="cornell"):
     from kajiya_amd import frame
     fs = frame.FrameState((W, H))
@@ -457,7 +465,7 @@ def _empty_ircache():
 
 
 @pytest.mark.parametrize("W,H", [(64, 64), (72, 40)])
-def test_rtdgi_ray_passes_reference_hlsl_vs_oracle(oracle, W, H):
+def test_rtdgi_ray_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, W, H):
     """`rtdgi validate` and `rtdgi trace` from the reference's own text -- diffuse_validate.rgen.hlsl / trace_diffuse.rgen.hlsl with
     diffuse_trace_common.inc.hlsl, candidate_ray_dir.hlsl, inc/rt.hlsl, and on every hit rt/gbuffer.rchit.hlsl reading the scene tables --
     against the oracle's passes on the oracle's frame state. Only the intersection query itself (the driver's in the reference) is the
@@ -516,7 +524,7 @@ def test_rtdgi_ray_passes_reference_hlsl_vs_oracle(oracle, W, H):
     assert len({c[:2] for c in compared}) >= 7, sorted(compared)
 
 
-def test_sun_shadow_mask_and_reference_pt_reference_hlsl_vs_oracle(oracle):
+def test_sun_shadow_mask_and_reference_pt_reference_hlsl_vs_oracle(oracle, libm_sincos):
     """rt/trace_sun_shadow_mask.rgen.hlsl (renderers/shadows.rs:10-40) and rt/reference_path_trace.rgen.hlsl (renderers/reference.rs:8-26; up to
     17 segments per path through rt/gbuffer.rchit.hlsl, the layered BRDF's sampling, Russian roulette, the sun and the sky) from the
     reference's text against the oracle: the mask bit for bit; the path tracer per pixel under the bars of the GPU-vs-oracle test
@@ -564,7 +572,7 @@ def _numbers_equal(a, b):
     return bool(same.all())
 
 
-def test_ircache_ray_passes_and_live_lookups_reference_hlsl_vs_oracle(oracle):
+def test_ircache_ray_passes_and_live_lookups_reference_hlsl_vs_oracle(oracle, libm_sincos):
     """The irradiance cache's three ray passes (trace_accessibility / ircache_validate / trace_irradiance .rgen.hlsl with
     ircache_trace_common.inc.hlsl and the PRECISE ircache/lookup.hlsl inside them) and the rtdgi validate + trace passes with the LIVE cache
     bound (ircache/lookup.hlsl allocating entries, refreshing lives, voting on positions) from the reference's own text, frame after
@@ -616,6 +624,7 @@ def test_ircache_ray_passes_and_live_lookups_reference_hlsl_vs_oracle(oracle):
                         bad = np.nonzero(a != b)[0]
                         frac = bad.size / max(1, a.size)
                         slots_off += bad.size
+                        print(f"frame {fi} {pass_name} {n}: dwords {bad} : {a[bad]} vs {b[bad]}  (as float {a[bad].view(np.float32)} vs {b[bad].view(np.float32)})")
                         assert n in ("aux", "reposition_proposal") and frac <= 2e-3, f"frame {fi} {pass_name}: buffer {n}: {bad.size} of {a.size} dwords differ, first at {bad[:6]}: {a[bad[:6]]} vs {b[bad[:6]]}"
             op.L.okj_rtdgi_reproject(op.rtdgi, C.byref(fc), op.reprojection_map.ctypes.data, W, H)
             op.ircache_sum_up(fc)
@@ -658,3 +667,58 @@ def test_ircache_ray_passes_and_live_lookups_reference_hlsl_vs_oracle(oracle):
     finally:
         L.ref_set_linear_order(0)
         oracle.lib().okj_set_threads(n_threads)
+
+
+# ---------------------------------------------------------------------------------------------------------------- SURVEY 8f rows
+def test_ssao_guide_passes_reference_hlsl_vs_oracle(oracle, libm_sincos):
+    """SsgiRenderer::render + filter_ssgi (renderers/ssgi.rs:25-181): ssgi/{ssgi,spatial_filter,upsample,temporal_filter}.hlsl from the
+    reference's text against the oracle's four stages, six frames of a moving camera over the 20 k-triangle city (USE_AO_ONLY: the
+    previous-radiance input never reaches the output and is bound black)."""
+    from kajiya_amd import scenes
+    _bind_luts(oracle)
+    W, H = 104, 60
+    hw, hh = W // 2, H // 2
+    op = oracle.OraclePipeline(oracle.OracleScene(scenes.procedural_city(seed=1234, target_tris=20000)), W, H)
+    g, ho = R.extent_inv_extent(W, H), R.extent_inv_extent(hw, hh)
+    FM = {"ssgi_tex": "r16f", "spatially_filtered_tex": "r16f", "upsampled_tex": "r16f", "ssgi": "r16f", "filtered_output_tex": "r8", "half_view_normal_tex": "rgba8s", "half_depth_tex": "r32f"}
+    FULL = {"upsampled_tex", "ssgi", "filtered_output_tex"}
+
+    def snap():
+        out = {}
+        for n in FM:
+            for sfx in ("", ":0", ":1"):
+                try:
+                    out[n + sfx] = op.ssgi_surface(n + sfx, np.uint8, (-1,)).copy()
+                except (KeyError, AttributeError):
+                    pass
+        return out
+    for fi, fc in enumerate(_frame_constants(W, H, 6, "city")):
+        op.render_inputs(fc); op.reprojection(fc)
+        before = snap() if fi else {}
+        op.ssgi_frame(fc)
+        after = snap()
+        out_sfx, hist_sfx = (":0", ":1") if fi % 2 == 0 else (":1", ":0")
+
+        def tex(d, n):
+            raw = d.get(n)
+            if raw is None:
+                raw = np.zeros_like(after[n])
+            w, h = (W, H) if n.split(":")[0] in FULL else (hw, hh)
+            return R.Tex(raw.copy(), w, h, FM[n.split(":")[0]])
+        written = {}
+
+        def wr(n):
+            written[n] = tex(after, n)
+            written[n].raw[:] = 0xcd
+            return written[n]
+        gbuffer, depth, reproj = R.Tex(op.gbuffer, W, H, "rgba32f"), R.Tex(op.depth, W, H, "r32f"), R.Tex(op.reprojection_map, W, H, "rgba16s")
+        R.run_pass("ssgi/ssgi", [gbuffer, tex(after, "half_depth_tex"), tex(after, "half_view_normal_tex"), R.Tex.zeros(W, H, "rgba16f"), reproj, wr("ssgi_tex")], [g, ho], fc, (hw, hh, 1))
+        R.run_pass("ssgi/spatial_filter", [tex(after, "ssgi_tex"), tex(after, "half_depth_tex"), tex(after, "half_view_normal_tex"), wr("spatially_filtered_tex")], None, fc, (hw, hh, 1))
+        R.run_pass("ssgi/upsample", [tex(after, "spatially_filtered_tex"), depth, gbuffer, wr("upsampled_tex")], None, fc, (W, H, 1))
+        # the oracle double-buffers the R8 output like the product does (the reference's is a transient): the one written this frame
+        fo = "filtered_output_tex" + (":0" if not np.array_equal(after["filtered_output_tex:0"], before.get("filtered_output_tex:0", None)) else ":1") if fi else \
+            ("filtered_output_tex:0" if after["filtered_output_tex:0"].any() else "filtered_output_tex:1")
+        R.run_pass("ssgi/temporal_filter", [tex(after, "upsampled_tex"), tex(before, "ssgi" + hist_sfx), reproj, wr(fo), wr("ssgi" + out_sfx)], [g], fc, (W, H, 1))
+        for n, t in written.items():
+            r = P.compare(t.raw, after[n], FM[n.split(":")[0]])
+            _check(r, f"frame {fi} SSAO guide surface {n}")
