@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(64) k_shadow_temporal(ShadowTemporalArgs a) {
         local_neighborhood += hn[lx][8 + ly + i] * a.kw.w[i];
     }
     const V4 reproj = ld_reproj(a.reprojection_tex, x, y);
-    const V2 uv{(float(x) + 0.5f) / float(a.W), (float(y) + 0.5f) / float(a.H)};
+    const V2 uv{(float(x) + 0.5f) * (1.0f / float(a.W)), (float(y) + 0.5f) * (1.0f / float(a.H))};     // ffx ...tileclassification.hlsl:351-352: times texel_size (the host's f32 reciprocals)
     const V2 history_uv = uv + V2{reproj.x, reproj.y};
     const float shadow_current = from_unorm8(a.shadow_mask_tex.ld(x, y));
     const uint32_t qv = uint32_t(reproj.z * 15.0f + 0.5f);
@@ -179,7 +179,8 @@ __global__ void __launch_bounds__(64) k_shadow_spatial(ImgU32 input_tex /*RG16F*
     __shared__ float s_depth[16][16];
     for (int i = lane; i < 256; i += 64) {
         const int tx = i & 15, ty = i >> 4;
-        const int px = min(max(int(kj_tb.x) * 8 - 4 + tx, 0), W - 1), py = min(max(int(kj_tb.y) * 8 - 4 + ty, 0), H - 1);
+        // ffx_denoiser_shadows_filter.hlsl:76 clamps an int2 against uint2 dimensions: the comparison is unsigned, a negative coordinate lands on the FAR edge
+        const int px = int(min(uint32_t(int(kj_tb.x) * 8 - 4 + tx), uint32_t(W - 1))), py = int(min(uint32_t(int(kj_tb.y) * 8 - 4 + ty), uint32_t(H - 1)));
         const V3 n = unpack_a2r10g10b10(geometric_normal_tex.ld(px, py)) * 2.0f - 1.0f;
         s_in[ty][tx] = input_tex.ld(px, py);                       // already two packed halves
         s_depth[ty][tx] = depth_tex.ld(px, py);

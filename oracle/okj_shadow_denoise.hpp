@@ -143,7 +143,9 @@ struct ShadowDenoise {
                             local_neighborhood += hn[lx][8 + ly + i] * w;
                         }
                         const f4 reproj = ld_reproj(reprojection_tex, x, y);
-                        const f2 uv{(float(x) + 0.5f) / float(W), (float(y) + 0.5f) / float(H)};
+                        // ffx_denoiser_shadows_tileclassification.hlsl:351-352: (did + 0.5) * texel_size, texel_size = the host's f32 reciprocals (input_tex_size.zw) -- a
+                        // MULTIPLICATION, not a division by the extent (one ulp apart in uv; found by running the reference's own text)
+                        const f2 uv{(float(x) + 0.5f) * (1.0f / float(W)), (float(y) + 0.5f) * (1.0f / float(H))};
                         const f2 history_uv = uv + f2{reproj.x, reproj.y};
                         const float shadow_current = from_unorm8(shadow_mask.ld(x, y));
                         const uint32_t qv = uint32_t(reproj.z * 15.0f + 0.5f);
@@ -213,7 +215,10 @@ struct ShadowDenoise {
                 float s_depth[16][16];
                 for (int ty = 0; ty < 16; ++ty)
                     for (int tx = 0; tx < 16; ++tx) {
-                        const int px = std::min(std::max(gx * 8 - 4 + tx, 0), W - 1), py = std::min(std::max(gy * 8 - 4 + ty, 0), H - 1);
+                        // ffx_denoiser_shadows_filter.hlsl:76: clamp(did, int2(0, 0), FFX_DNSR_Shadows_GetBufferDimensions() - 1) with the dimensions a
+                        // uint2 (shadow_denoise/spatial_filter.hlsl:19-21): int and uint unify to uint, so a NEGATIVE coordinate becomes a huge one
+                        // and clamps to the FAR edge, not to 0 (found by running the reference's own text: tests/test_ref_hlsl.py)
+                        const int px = int(std::min(uint32_t(gx * 8 - 4 + tx), uint32_t(W - 1))), py = int(std::min(uint32_t(gy * 8 - 4 + ty), uint32_t(H - 1)));
                         const f3 n = unpack_a2r10g10b10(geometric_normal_tex.ld(px, py)) * 2.0f - 1.0f;
                         const h2 v = input.ld(px, py);
                         s_in[ty][tx] = pack2(f16_to_f32(v.x), f16_to_f32(v.y));

@@ -39,7 +39,7 @@ SEMANTIC_RE = re.compile(r"^(SV_\w+|TEXCOORD\d*|POSITION\d*|COLOR\d*|NORMAL\d*|T
 CPP_KEYWORD_IDS = {"and": "and_", "or": "or_", "not": "not_", "xor": "xor_", "new": "new_", "delete": "delete_", "register": "register_", "auto": "auto_", "union": "union_",
                    "export": "export_", "friend": "friend_", "mutable": "mutable_", "virtual": "virtual_", "explicit": "explicit_", "near": "near_", "far": "far_", "typeid": "typeid_"}
 LANE_VALUE = {"SV_DispatchThreadID": "dispatch_thread_id", "SV_GroupThreadID": "group_thread_id", "SV_GroupID": "group_id", "SV_GroupIndex": "group_index"}
-LOCKSTEP_IDS = re.compile(r"^(Wave[A-Z]\w*|GroupMemoryBarrierWithGroupSync|AllMemoryBarrierWithGroupSync|DeviceMemoryBarrierWithGroupSync)$")
+LOCKSTEP_IDS = re.compile(r"^(Wave[A-Z]\w*|Quad[A-Z]\w*|GroupMemoryBarrierWithGroupSync|AllMemoryBarrierWithGroupSync|DeviceMemoryBarrierWithGroupSync)$")
 
 # (file relative to assets/shaders) -> [(regex on the REWRITTEN text, replacement, why)]. Each one only names a conversion HLSL performs implicitly.
 PATCHES = {

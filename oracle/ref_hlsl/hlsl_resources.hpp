@@ -311,6 +311,10 @@ template <class T> static inline T WavePrefixSum(const T& v) {
 static inline bool WaveActiveAnyTrue(bool b) { return wave_reduce_(uint(b), [](uint a, uint c) { return a | c; }) != 0; }
 static inline bool WaveActiveAllTrue(bool b) { return wave_reduce_(uint(b), [](uint a, uint c) { return a & c; }) != 0; }
 static inline bool WaveIsFirstLane() { const uint one = 1; const WaveView w = hlsl_wave_publish(&one, 4); for (uint l = 0; l < HLSL_WAVE; ++l) if (w.active[l]) return l == w.lane; return true; }
+// quad intrinsics in a compute shader: a quad = four consecutive lanes; X flips bit 0, Y bit 1, diagonal both
+template <class T> static inline T QuadReadAcrossX(const T& v) { return WaveReadLaneAt(v, WaveGetLaneIndex() ^ 1u); }
+template <class T> static inline T QuadReadAcrossY(const T& v) { return WaveReadLaneAt(v, WaveGetLaneIndex() ^ 2u); }
+template <class T> static inline T QuadReadAcrossDiagonal(const T& v) { return WaveReadLaneAt(v, WaveGetLaneIndex() ^ 3u); }
 static inline void GroupMemoryBarrierWithGroupSync() { hlsl_group_barrier(); }
 static inline void GroupMemoryBarrier() {}
 static inline void AllMemoryBarrierWithGroupSync() { hlsl_group_barrier(); }

@@ -722,3 +722,80 @@ def test_ssao_guide_passes_reference_hlsl_vs_oracle(oracle, libm_sincos):
         for n, t in written.items():
             r = P.compare(t.raw, after[n], FM[n.split(":")[0]])
             _check(r, f"frame {fi} SSAO guide surface {n}")
+
+
+def test_shadow_denoise_passes_reference_hlsl_vs_oracle(oracle, libm_sincos):
+    """ShadowDenoiseRenderer::render (renderers/shadow_denoise.rs:19-149): shadow_denoise/{bitpack_shadow_mask,megakernel,spatial_filter}.hlsl
+    with AMD's ffx_denoiser_shadows_* code they include (wave ballots, quad reads, group-shared tiles: the lock-step scheduler), chained
+    like the host records them -- bit-pack, temporal megakernel, three a-trous passes (step 1, 2, 4) -- against the oracle's frame."""
+    from kajiya_amd import scenes
+    _bind_luts(oracle)
+    W, H = 104, 60
+    TW, TH = (W + 7) // 8, (H + 3) // 4
+    op = oracle.OraclePipeline(oracle.OracleScene(scenes.procedural_city(seed=1234, target_tris=20000)), W, H)
+    g = R.extent_inv_extent(W, H)
+    ext = np.array([TW, TH], np.uint32)
+    FM = {"bitpacked_shadows_image": ("r32ui", TW, TH), "metadata_image": ("r32ui", TW, TH), "spatial_input_image": ("rg16f", W, H), "temp": ("rg16f", W, H),
+          "shadow_denoise_accum": ("rg16f", W, H), "shadow_denoise_moments": ("rgba16f", W, H)}
+
+    def snap():
+        out = {}
+        for n in FM:
+            for sfx in ("", ":0", ":1"):
+                try:
+                    out[n + sfx] = op.shadow_denoise_surface(n + sfx, np.uint8, (-1,)).copy()
+                except (KeyError, AttributeError):
+                    pass
+        return out
+    for fi, fc in enumerate(_frame_constants(W, H, 5, "city")):
+        op.render_inputs(fc); op.reprojection(fc)
+        mask = op.sun_shadow_mask(fc)
+        before = snap() if fi else {}
+        op.shadow_denoise(fc, mask)
+        after = snap()
+        out_sfx, hist_sfx = (":0", ":1") if fi % 2 == 0 else (":1", ":0")
+
+        def tex(d, n):
+            fmt, w, h = FM[n.split(":")[0]]
+            raw = d.get(n)
+            return R.Tex(raw.copy() if raw is not None else np.zeros_like(after[n]), w, h, fmt)
+        mask_t, reproj = R.Tex(mask, W, H, "r8"), R.Tex(op.reprojection_map, W, H, "rgba16s")
+        gn, depth = R.Tex(op.geometric_normal, W, H, "a2r10g10b10"), R.Tex(op.depth, W, H, "r32f")
+        bitpacked, moments, spatial_input, metadata = tex({}, "bitpacked_shadows_image"), tex({}, "shadow_denoise_moments" + out_sfx), tex({}, "spatial_input_image"), tex({}, "metadata_image")
+        accum, temp = tex({}, "shadow_denoise_accum" + out_sfx), tex({}, "temp")
+        R.run_pass("shadow_denoise/bitpack_shadow_mask", [mask_t, bitpacked], [g, ext], fc, (TW * 2, TH, 1))
+        R.run_pass("shadow_denoise/megakernel", [mask_t, bitpacked, tex(before, "shadow_denoise_moments" + hist_sfx), tex(before, "shadow_denoise_accum" + hist_sfx), reproj,
+                                                 moments, spatial_input, metadata], [g, ext], fc, (W, H, 1))
+        for step, (src, dst) in ((1, (spatial_input, accum)), (2, (accum, temp)), (4, (temp, spatial_input))):
+            src_copy = R.Tex(src.raw.copy(), W, H, "rg16f")
+            R.run_pass("shadow_denoise/spatial_filter", [src_copy, metadata, gn, depth, dst], [g, ext, np.uint32(step)], fc, (W, H, 1))
+        for n, t in (("bitpacked_shadows_image", bitpacked), ("metadata_image", metadata), ("shadow_denoise_moments" + out_sfx, moments),
+                     ("shadow_denoise_accum" + out_sfx, accum), ("temp", temp), ("spatial_input_image", spatial_input)):
+            fmt = FM[n.split(":")[0]][0]
+            if fmt == "r32ui":
+                assert np.array_equal(t.raw, after[n]), (fi, n, int((t.raw.view(np.uint32) != after[n].view(np.uint32)).sum()))
+            else:
+                _check(P.compare(t.raw, after[n], fmt), f"frame {fi} shadow denoiser surface {n}")
+        assert 0 < (mask == 0).mean() < 1
+
+
+def test_light_gbuffer_reference_hlsl_vs_oracle(oracle, libm_sincos):
+    """light_gbuffer.hlsl as renderers/deferred.rs:8-46 records it (G-buffer, depth, shadow mask, reflections, GI, the nine cache buffers,
+    the two sky cubes) against the oracle's combine: both outputs, sky pixels with the sun disc included."""
+    from kajiya_amd import scenes
+    _bind_luts(oracle)
+    W, H = 96, 64
+    op = oracle.OraclePipeline(oracle.OracleScene(scenes.cornell_box()), W, H)
+    g = R.extent_inv_extent(W, H)
+    for fi, fc in enumerate(_frame_constants(W, H, 4)):
+        op.render_inputs(fc); op.reprojection(fc); op.rtdgi_frame(fc)
+        mask = op.sun_shadow_mask(fc)
+        gi = op.surface("spatial_filtered_tex", np.float16, (H, W, 4)).copy()
+        rtr = np.zeros((H, W), np.uint32)
+        ref_t, ref_o = op.light_gbuffer(fc, mask, gi, rtr, 0)
+        t_out, o_out = R.Tex.zeros(W, H, "rgba16f"), R.Tex.zeros(W, H, "rgba16f")
+        R.run_pass("light_gbuffer", [R.Tex(op.gbuffer, W, H, "rgba32f"), R.Tex(op.depth, W, H, "r32f"), R.Tex(mask, W, H, "r8"), R.Tex(rtr, W, H, "r11g11b10f"), R.Tex(gi, W, H, "rgba16f")] +
+                   _ircache_bind_set(_empty_ircache(), 0) + [R.Tex.zeros(1, 1, "rgba16f"), t_out, o_out, R.Tex(op.sky64, 64, 64 * 6, "rgba16f"), R.Tex(op.sky16, 16, 16 * 6, "rgba16f")],
+                   [g, np.uint32(0), np.uint32(0)], fc, (W, H, 1))
+        _check(P.compare(t_out.raw, ref_t.view(np.uint8).reshape(-1), "rgba16f"), f"frame {fi} light_gbuffer temporal_output")
+        _check(P.compare(o_out.raw, ref_o.view(np.uint8).reshape(-1), "rgba16f"), f"frame {fi} light_gbuffer output")
