@@ -159,6 +159,13 @@ typedef struct KjReprojection KjReprojection;
 
 const char* kj_last_error(void);
 uint32_t kj_abi_version(void);
+/* sizeof() of the library's own build of every struct that crosses this boundary by value or by pointer, so that a binding in another
+ * language can check its layout at start-up (tests/test_abi.py does, for the ctypes binding and for INTEGRATION.md's `-sys` text).
+ * Returns 0 for an unknown id. */
+enum KjAbiStruct { KJ_ABI_FRAME_CONSTANTS = 0, KJ_ABI_VIEW_CONSTANTS, KJ_ABI_MESH_MATERIAL, KJ_ABI_PACKED_VERTEX, KJ_ABI_MATERIAL_MAP, KJ_ABI_MESH_DESC, KJ_ABI_TRIANGLE_LIGHT,
+                   KJ_ABI_GBUFFER_DEPTH, KJ_ABI_RTDGI_RENDER_PARAMS, KJ_ABI_RTDGI_OUTPUT, KJ_ABI_TAA_OUTPUT, KJ_ABI_RTR_TABLES, KJ_ABI_RTR_PARAMS, KJ_ABI_SPLIT_RANK,
+                   KJ_ABI_SPLIT_FRAME, KJ_ABI_BAKED_MESH_VIEW, KJ_ABI_BAKED_IMAGE_VIEW, KJ_ABI_STRUCT_COUNT };
+uint32_t kj_abi_struct_size(uint32_t id);
 
 /* RenderBackend / WorldRenderer::new analogue (default_world_renderer.rs:14-58):
  * picks the HIP device, builds the BRDF-FG LUT (bindless #0, lut/brdf_fg.hlsl),

@@ -274,109 +274,6 @@ KJ_D TraceResult trace_candidate(const TraceCtx& c, uint32_t px, uint32_t py, V3
     return TraceResult{total_radiance, hit_normal_ws, hit_t, pdf, primary_hit.is_hit};
 }
 
-// ---- grouped form of the two ray passes (built for VERDICT r2 item 3, measured, NOT the default: trace pass 0.282 ms vs 0.273 fused at
-// 1080p, 0.814 vs 0.773 at 4K, same lease; profiles/r03_ray_pass_forms.md): a 256-thread workgroup = four 8x8 tiles (2 x 2). Two thirds of the candidate
-// rays leave the scene, so in the fused form above a wave runs everything after the closest-hit query -- G-buffer of the hit, the sun's
-// shadow-ray traversal, lights, cache lookup -- with a sixth of its lanes (lane utilisation 34 % over the kernel, PMC). Here
-//   1. every pixel traces its closest-hit ray (as before);
-//   2. lanes that hit park a 48-byte record {ray, (t, u, v, triangle), pixel, rng} in LDS, compacted per wave by ballot + prefix count;
-//   3. the workgroup's records are dealt to ceil(n / 64) of its waves, evenly, and THOSE waves run shade_candidate_hit on full(er)
-//      waves -- one shadow-ray traversal for four tiles' hits instead of four mostly empty ones; the other waves sleep at the barrier;
-//   4. results return through LDS to the pixels that own them.
-// Why it loses: the pass is bound by the dependent chain each wave walks (~100 traversal steps of ~1.5-2 us), not by issue slots; a wave
-// parked at the barrier still holds its slot, so four waves waiting for ONE fuller shadow-ray walk (whose chain is the maximum over 44
-// rays instead of 11) cost more slot-time than four short walks side by side.
-// The arithmetic per ray, the order of the radiance sums and the rng streams are those of the fused form (same functions), so the
-// outputs are bit-identical to it. LDS per workgroup: the traversal stacks (16 x 256 dwords) + 256 records (12 KB, reused for the
-// results) = 28 KB -> five workgroups = 20 waves per CU, the fused form's occupancy.
-struct HitRecord { float ox, oy, oz, dx, dy, dz, t, u, v; uint32_t slot, pixel_and_owner, rng; };     // pixel_and_owner = px | py << 12 | owner thread << 24
-#define KJ_GROUP_THREADS 256u
-KJ_HD size_t grouped_lds_bytes(uint32_t stack_entries) { return size_t(stack_entries) * KJ_GROUP_THREADS * 4 + KJ_GROUP_THREADS * sizeof(HitRecord) + 16; }
-// 2 x 2 tiles: wave w covers tile (w & 1, w >> 1) of the 16 x 16 block
-#define GROUP_TILE_XY(W_, H_)                                                                                              \
-    const int lane = int(threadIdx.x & 63u), wave = int(threadIdx.x >> 6);                                                  \
-    const uint2 kj_tb = kj::tile_order<KJ_TILES_PLAIN>();                                                                  \
-    const int x = int(kj_tb.x) * 16 + (wave & 1) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * 16 + (wave >> 1) * 8 + (lane >> 3); \
-    const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
-// Called by ALL threads of the workgroup (barriers inside); `has_ray` false = this pixel traces nothing (sky, outside the image).
-template <bool STATS>
-KJ_D TraceResult trace_candidate_grouped(const TraceCtx& c, bool has_ray, uint32_t px, uint32_t py, V3 normal_ws, uint32_t rng, V3 ray_o, V3 ray_d, float ray_tmax, uint32_t* lds) {
-    const FrameConstants& fc = *c.fc;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t* stack = lds + tid;
-    HitRecord* rec = (HitRecord*)(lds + size_t(c.sc.bvh.stack_entries) * KJ_GROUP_THREADS);
-    uint32_t* counts = (uint32_t*)(rec + KJ_GROUP_THREADS);
-    V3 total_radiance = v3(0.0f);
-    V3 hit_normal_ws = -ray_d;
-    float hit_t = ray_tmax;
-    const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, ray_d) * 2 * KJ_PI));
-    TraverseStats st_closest{0, 0}, st_any{0, 0};
-    RayHit h;
-    h.slot = 0xffffffffu; h.t = 0; h.u = 0; h.v = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    count_rays(c.ray_counters, 0, has_ray);
-#else
-    if (has_ray) atomicAdd(&counter_slot(c.ray_counters)[0], 1ull);
-    if (lane == 0) counts[wave] = 0;
-    __syncthreads();
-#endif
-    if (has_ray) h = bvh_trace<false, STATS>(c.sc.bvh, ray_o, ray_d, 0.0f, ray_tmax, false, stack, KJ_GROUP_THREADS, &st_closest);
-    const bool hit = has_ray && h.slot != 0xffffffffu;
-    if (has_ray && !hit) total_radiance += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
-    // 2. park the hits, compacted per wave
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned long long hm = __ballot(hit);
-    const uint32_t rank = uint32_t(__popcll(hm & ((1ull << lane) - 1ull)));
-    if (lane == 0) counts[wave] = uint32_t(__popcll(hm));
-#else
-    const uint32_t rank = hit ? atomicAdd(&counts[wave], 1u) : 0u;    // the CPU stand-in has no wave votes in multi-wave workgroups
-#endif
-    if (hit) {
-        HitRecord r;
-        r.ox = ray_o.x; r.oy = ray_o.y; r.oz = ray_o.z; r.dx = ray_d.x; r.dy = ray_d.y; r.dz = ray_d.z;
-        r.t = h.t; r.u = h.u; r.v = h.v; r.slot = h.slot; r.pixel_and_owner = px | (py << 12) | (tid << 24); r.rng = rng;
-        rec[wave * 64u + rank] = r;
-    }
-    __syncthreads();
-    // 3. deal the workgroup's records to as few waves as hold them, evenly
-    const uint32_t n0 = counts[0], n1 = counts[1], n2 = counts[2], n3 = counts[3], total = n0 + n1 + n2 + n3;
-    const uint32_t waves_used = (total + 63u) / 64u;
-    const uint32_t per_wave = waves_used ? (total + waves_used - 1u) / waves_used : 0u;
-    const uint32_t first = wave * per_wave;
-    const bool work = wave < waves_used && first + lane < min(total, first + per_wave);
-    HitRecord r;
-    if (work) {
-        uint32_t j = first + lane, sw = 0;
-        if (j >= n0) { j -= n0; sw = 1; if (j >= n1) { j -= n1; sw = 2; if (j >= n2) { j -= n2; sw = 3; } } }
-        r = rec[sw * 64u + j];
-    }
-    __syncthreads();                       // every record is in registers: the area now takes the results
-    float* results = (float*)rec;          // [owner thread][radiance.xyz, hit normal.xyz]
-    if (work) {
-        const V3 o{r.ox, r.oy, r.oz}, d{r.dx, r.dy, r.dz};
-        RayHit rh;
-        rh.t = r.t; rh.u = r.u; rh.v = r.v; rh.slot = r.slot; rh.world_id = 0;
-        GbufferPathVertex pv;
-        pv.is_hit = true; pv.ray_t = r.t;
-        pv.gbuffer_packed = shade_gbuffer_hit(c.sc, fc, d, rh, 1, candidate_ray_cone(c, o).width_at_t(r.t * length(d)));      // GbufferRaytrace::trace, inc/rt.hlsl:112-137
-        pv.position = mad_nc(o, d, r.t);
-        uint32_t rrng = r.rng;
-        V3 n;
-        const V3 rad = shade_candidate_hit<STATS>(c, r.pixel_and_owner & 0xfffu, (r.pixel_and_owner >> 12) & 0xfffu, rrng, o, d, pv, stack, KJ_GROUP_THREADS, &st_any, n);
-        float* dst = results + (r.pixel_and_owner >> 24) * 6u;
-        dst[0] = rad.x; dst[1] = rad.y; dst[2] = rad.z; dst[3] = n.x; dst[4] = n.y; dst[5] = n.z;
-    }
-    __syncthreads();
-    if (hit) {
-        const float* src = results + tid * 6u;
-        total_radiance = V3{src[0], src[1], src[2]};
-        hit_normal_ws = V3{src[3], src[4], src[5]};
-        hit_t = h.t;
-    }
-    add_traversal_stats<STATS>(c, st_closest, st_any);
-    return TraceResult{total_radiance, hit_normal_ws, hit_t, pdf, hit};
-}
-
 // ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111
 template <bool STATS, bool QUAD = false>
 // waves per SIMD the fused ray kernels are compiled for: 4 = 123 VGPRs, no spills; 5 = 96 VGPRs + 20 spilled dwords outside the traversal
@@ -464,538 +361,9 @@ __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_fused(TraceC
     if (lead) invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
 }
 
-// ---- the two ray passes in the grouped form (trace_candidate_grouped above)
-#ifndef KJ_GROUPED_WAVES
-#define KJ_GROUPED_WAVES 5
+#ifdef KJ_RAY_PASS_EXPERIMENTS
+#include "rtdgi_ray_experiments.inc"
 #endif
-template <bool STATS>
-__global__ void __launch_bounds__(KJ_GROUP_THREADS, KJ_GROUPED_WAVES) k_rtdgi_validate_grouped(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
-                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
-    extern __shared__ uint32_t lds_group[];
-    GROUP_TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
-    const FrameConstants& fc = *c.fc;
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    const bool sky = in_image && 0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y);
-    if (!is_rtdgi_validation_frame(fc.frame_index)) {      // uniform: two frames of three the pass only writes the invalidity image
-        if (in_image) invalidity_out_tex.st(x, y, to_unorm8(sky ? 1.0f : 0.0f));
-        return;
-    }
-    const bool has_ray = in_image && !sky;
-    V3 normal_ws = v3(0.0f), prev_ray_orig = v3(0.0f), prev_hit_pos = v3(0.0f), prev_radiance = v3(0.0f), dir = V3{0.0f, 0.0f, 1.0f};
-    V4 prev_radiance_packed = v4(0.0f);
-    if (has_ray) {
-        normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
-        const float4 ro = ray_orig_history_tex.ld(x, y);
-        prev_ray_orig = V3{ro.x, ro.y, ro.z};
-        prev_hit_pos = xyz(ld4(reservoir_ray_history_tex, x, y)) + prev_ray_orig;
-        prev_radiance_packed = ld4(irradiance_history_tex, x, y);
-        prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
-        dir = normalize(prev_hit_pos - prev_ray_orig);
-    }
-    const TraceResult result = trace_candidate_grouped<STATS>(c, has_ray, uint32_t(x), uint32_t(y), normal_ws, hash3(uint32_t(x), uint32_t(y), 0), prev_ray_orig, dir, SKY_DIST, lds_group);
-    if (!in_image) return;
-    if (sky) { invalidity_out_tex.st(x, y, to_unorm8(1.0f)); return; }
-    const V3 new_radiance = vmax(v3(0.0f), result.out_value);
-    const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
-    const float invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
-    const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
-    if (fabsf(result.hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
-        st4(irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
-        Reservoir1spp r = Reservoir1spp::from_raw(reservoir_tex.ld(x, y));
-        const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
-        r.M *= clampf(lum_old / fmaxf(1e-8f, lum_new), 0.03f, 1.0f);
-        r.W *= clampf(lum_old / fmaxf(1e-8f, lum_new) * 10.0f, 0.01f, 1.0f);
-        reservoir_tex.st(x, y, r.as_raw());
-    }
-    invalidity_out_tex.st(x, y, to_unorm8(invalidity));
-}
-template <bool STATS>
-__global__ void __launch_bounds__(KJ_GROUP_THREADS, KJ_GROUPED_WAVES) k_rtdgi_trace_grouped(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
-                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
-    extern __shared__ uint32_t lds_group[];
-    GROUP_TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
-    const FrameConstants& fc = *c.fc;
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
-    const float depth = in_image ? c.depth.ld(hx, hy) : 0.0f;
-    const bool has_ray = in_image && depth != 0.0f;
-    const V4 gts = tex_size4(c.depth.w, c.depth.h);
-    const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
-    V3 normal_ws = v3(0.0f), outgoing_dir = V3{0.0f, 0.0f, 1.0f}, origin = v3(0.0f), view_dir = v3(0.0f);
-    float tmax = SKY_DIST;
-    if (has_ray) {
-        const V2 uv = get_uv(float(hx), float(hy), gts);
-        const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
-        const float near_field_fade_out_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
-        normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
-        const Basis tangent_to_world = build_orthonormal_basis(normal_ws);
-        const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, fc.frame_index);
-        outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
-        origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
-        view_dir = vr.dir_ws;
-        tmax = tracing_frame ? SKY_DIST : near_field_fade_out_end;
-    }
-    TraceResult result = trace_candidate_grouped<STATS>(c, has_ray, uint32_t(x), uint32_t(y), normal_ws, hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u), origin, outgoing_dir, tmax, lds_group);
-    if (!in_image) return;
-    if (!has_ray) {
-        st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
-        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
-        invalidity_out_tex.st(x, y, 0);
-        return;
-    }
-    if (!tracing_frame && !result.is_hit) { result.out_value = v3(0.0f); result.hit_t = SKY_DIST; }
-    const V3 hit_offset_ws = outgoing_dir * result.hit_t;
-    const float cos_theta = dot(normalize(outgoing_dir - view_dir), normal_ws);
-    st4(candidate_irradiance_out_tex, x, y, v4(result.out_value, 1.0f - cos_theta));
-    st4(candidate_hit_out_tex, x, y, v4(hit_offset_ws, result.pdf * (tracing_frame ? 1.0f : -1.0f)));
-    candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, result.hit_normal_ws), 0)));
-    const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
-    const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
-    invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
-}
-
-// ---- split form of the two ray passes (measured, NOT the default: at 1080p the closest-hit launch alone takes 0.188 ms of the fused
-// kernel's 0.268 and the shading launch 0.260 -- 2025 waves on 1024 SIMDs, each a chain of ~130 dependent steps with nothing to hide
-// its latency behind; 0.796 vs 0.750 ms at 4K; profiles/r03_ray_pass_forms.md): TWO launches per pass.
-//   A. one wave per 8x8 tile: ray generation, the closest-hit traversal, everything a pixel whose ray MISSED needs (sky radiance, its
-//      outputs). Lanes that hit append a 64-byte record {ray, (t, u, v, triangle), pixel, rng, what the pixel's epilogue needs} to their
-//      tile's slots of a global array (ballot + prefix count, no atomics) and the wave ends -- its registers and its slot are free
-//      for the next tile while the hits wait.
-//   B. one wave per KJ_SPLIT_TILES tiles: gathers those tiles' records onto its lanes (a sixth of the pixels hit: four tiles fill
-//      a wave to ~70 %), runs shade_candidate_hit -- G-buffer of the hit, ONE shadow-ray traversal for four tiles' hits, lights, cache
-//      lookup -- and writes the hit pixels' outputs.
-// Unlike the grouped form nothing idles holding a wave slot, unlike the staged form there are two launches, not five, and no ray streams;
-// kernel A needs no shading registers, so it is compiled for more waves per SIMD. Same functions, same arithmetic and rng streams as
-// the fused form: bit-identical outputs.
-struct SplitRecord { float ox, oy, oz, t; float dx, dy, dz, u; float v, e0, e1, e2; uint32_t slot, pixel, rng, pad; };    // 64 B; e0..e2: the pass' epilogue inputs
-#define KJ_SPLIT_TILES 4u
-#ifndef KJ_SPLIT_A_WAVES
-#define KJ_SPLIT_A_WAVES 6
-#endif
-struct SplitStage { SplitRecord* __restrict__ records; uint32_t* __restrict__ counts; uint32_t tiles; };
-// A lane that hit parks its record; returns nothing. Called by every lane still in the kernel (wave vote inside).
-KJ_D void split_park(const SplitStage& st, bool hit, const SplitRecord& r) {
-    const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
-    const unsigned long long hm = __ballot(hit);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t rank = uint32_t(__popcll(hm & ((1ull << lane) - 1ull)));
-    if (hit) st.records[size_t(tile) * 64u + rank] = r;
-    if (hm == 0ull || (__ffsll((long long)hm) - 1) == int(lane)) { if (hit || hm == 0ull) st.counts[tile] = uint32_t(__popcll(hm)); }
-}
-template <bool STATS>
-__global__ void __launch_bounds__(64, KJ_SPLIT_A_WAVES) k_rtdgi_trace_closest(TraceCtx c, SplitStage st, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
-                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
-    extern __shared__ uint32_t lds_stack[];
-    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
-    const FrameConstants& fc = *c.fc;
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
-    const float depth = in_image ? c.depth.ld(hx, hy) : 0.0f;
-    const bool has_ray = in_image && depth != 0.0f;
-    count_rays(c.ray_counters, 0, has_ray);
-    if (in_image && !has_ray) {
-        st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
-        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
-        invalidity_out_tex.st(x, y, 0);
-    }
-    bool hit = false;
-    SplitRecord rec{};
-    if (has_ray) {
-        const V4 gts = tex_size4(c.depth.w, c.depth.h);
-        const V2 uv = get_uv(float(hx), float(hy), gts);
-        const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
-        const float near_field_fade_out_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
-        const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
-        const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
-        const Basis tangent_to_world = build_orthonormal_basis(normal_ws);
-        const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, fc.frame_index);
-        const V3 outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
-        const V3 origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
-        const float tmax = tracing_frame ? SKY_DIST : near_field_fade_out_end;
-        const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, outgoing_dir) * 2 * KJ_PI));
-        const float cos_theta = dot(normalize(outgoing_dir - vr.dir_ws), normal_ws);
-        TraverseStats st_closest{0, 0};
-        const RayHit h = bvh_trace<false, STATS>(c.sc.bvh, origin, outgoing_dir, 0.0f, tmax, false, lds_stack + lane, 64, &st_closest);
-        if (STATS) { atomicAdd(&counter_slot(c.ray_counters)[2], (unsigned long long)st_closest.nodes); atomicAdd(&counter_slot(c.ray_counters)[3], (unsigned long long)st_closest.tris); }
-        hit = h.slot != 0xffffffffu;
-        if (hit) {
-            rec.ox = origin.x; rec.oy = origin.y; rec.oz = origin.z; rec.t = h.t; rec.dx = outgoing_dir.x; rec.dy = outgoing_dir.y; rec.dz = outgoing_dir.z; rec.u = h.u; rec.v = h.v;
-            rec.e0 = cos_theta; rec.e1 = pdf; rec.e2 = 0.0f;
-            rec.slot = h.slot; rec.pixel = uint32_t(x) | (uint32_t(y) << 16); rec.rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u); rec.pad = 0;
-        } else {   // the ray left the scene: the sky, or nothing at all inside the near field of a validation frame
-            const V3 out_value = tracing_frame ? xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, outgoing_dir)) : v3(0.0f);
-            const float hit_t = tracing_frame ? tmax : SKY_DIST;
-            st4(candidate_irradiance_out_tex, x, y, v4(out_value, 1.0f - cos_theta));
-            st4(candidate_hit_out_tex, x, y, v4(outgoing_dir * hit_t, pdf * (tracing_frame ? 1.0f : -1.0f)));
-            candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, -outgoing_dir), 0)));
-        }
-        const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
-        const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
-        invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
-    }
-    split_park(st, hit, rec);
-}
-// lane -> record of this wave's KJ_SPLIT_TILES tiles, `batch` = which 64 of them; false = no record for this lane
-KJ_D bool split_fetch(const SplitStage& st, uint32_t batch, SplitRecord& r, uint32_t& total) {
-    const uint32_t t0 = blockIdx.x * KJ_SPLIT_TILES;
-    uint32_t cnt[KJ_SPLIT_TILES];
-    total = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < KJ_SPLIT_TILES; ++k) { cnt[k] = t0 + k < st.tiles ? st.counts[t0 + k] : 0u; total += cnt[k]; }
-    uint32_t j = batch * 64u + (threadIdx.x & 63u);
-    if (j >= total) return false;
-    uint32_t tile = 0;
-#pragma unroll
-    for (uint32_t k = 0; k + 1 < KJ_SPLIT_TILES; ++k) if (tile == k && j >= cnt[k]) { j -= cnt[k]; tile = k + 1; }
-    r = st.records[size_t(t0 + tile) * 64u + j];
-    return true;
-}
-template <bool STATS>
-KJ_D V3 split_shade(const TraceCtx& c, const SplitRecord& r, uint32_t* stack, V3& hit_normal_ws) {
-    const FrameConstants& fc = *c.fc;
-    const V3 o{r.ox, r.oy, r.oz}, d{r.dx, r.dy, r.dz};
-    RayHit rh;
-    rh.t = r.t; rh.u = r.u; rh.v = r.v; rh.slot = r.slot; rh.world_id = 0;
-    GbufferPathVertex pv;
-    pv.is_hit = true; pv.ray_t = r.t;
-    pv.gbuffer_packed = shade_gbuffer_hit(c.sc, fc, d, rh, 1, candidate_ray_cone(c, o).width_at_t(r.t * length(d)));      // GbufferRaytrace::trace, inc/rt.hlsl:112-137
-    pv.position = mad_nc(o, d, r.t);
-    uint32_t rng = r.rng;
-    TraverseStats st_any{0, 0};
-    const V3 rad = shade_candidate_hit<STATS>(c, r.pixel & 0xffffu, r.pixel >> 16, rng, o, d, pv, stack, 64, &st_any, hit_normal_ws);
-    if (STATS) { atomicAdd(&counter_slot(c.ray_counters)[4], (unsigned long long)st_any.nodes); atomicAdd(&counter_slot(c.ray_counters)[5], (unsigned long long)st_any.tris); }
-    return rad;
-}
-template <bool STATS>
-__global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_shade(TraceCtx c, SplitStage st, ImgH4 candidate_irradiance_out_tex, ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex) {
-    extern __shared__ uint32_t lds_stack[];
-    const FrameConstants& fc = *c.fc;
-    const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
-    uint32_t total = 1;
-    for (uint32_t batch = 0; batch * 64u < total; ++batch) {
-        SplitRecord r;
-        if (!split_fetch(st, batch, r, total)) continue;
-        V3 hit_normal_ws;
-        const V3 rad = split_shade<STATS>(c, r, lds_stack + (threadIdx.x & 63u), hit_normal_ws);
-        const int x = int(r.pixel & 0xffffu), y = int(r.pixel >> 16);
-        const V3 d{r.dx, r.dy, r.dz};
-        st4(candidate_irradiance_out_tex, x, y, v4(rad, 1.0f - r.e0));
-        st4(candidate_hit_out_tex, x, y, v4(d * r.t, r.e1 * (tracing_frame ? 1.0f : -1.0f)));
-        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, hit_normal_ws), 0)));
-    }
-}
-// diffuse_validate.rgen.hlsl:46-111 after the re-traced sample's radiance and distance are known
-KJ_D void validate_finish_pixel(int x, int y, V3 out_value, float hit_t, V3 prev_ray_orig, V3 prev_hit_pos, V4 prev_radiance_packed, ImgU2 reservoir_tex, ImgH4 irradiance_history_tex,
-                                ImgR8 invalidity_out_tex) {
-    const V3 prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
-    const V3 new_radiance = vmax(v3(0.0f), out_value);
-    const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
-    const float invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
-    const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
-    if (fabsf(hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
-        st4(irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
-        Reservoir1spp r = Reservoir1spp::from_raw(reservoir_tex.ld(x, y));
-        const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
-        r.M *= clampf(lum_old / fmaxf(1e-8f, lum_new), 0.03f, 1.0f);
-        r.W *= clampf(lum_old / fmaxf(1e-8f, lum_new) * 10.0f, 0.01f, 1.0f);
-        reservoir_tex.st(x, y, r.as_raw());
-    }
-    invalidity_out_tex.st(x, y, to_unorm8(invalidity));
-}
-template <bool STATS>
-__global__ void __launch_bounds__(64, KJ_SPLIT_A_WAVES) k_rtdgi_validate_closest(TraceCtx c, SplitStage st, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
-                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
-    extern __shared__ uint32_t lds_stack[];
-    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
-    const FrameConstants& fc = *c.fc;
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    const bool sky = in_image && 0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y);
-    const bool has_ray = in_image && !sky;
-    count_rays(c.ray_counters, 0, has_ray);
-    if (sky) invalidity_out_tex.st(x, y, to_unorm8(1.0f));
-    bool hit = false;
-    SplitRecord rec{};
-    if (has_ray) {
-        const float4 ro = ray_orig_history_tex.ld(x, y);
-        const V3 prev_ray_orig{ro.x, ro.y, ro.z};
-        const V3 prev_hit_pos = xyz(ld4(reservoir_ray_history_tex, x, y)) + prev_ray_orig;
-        const V3 dir = normalize(prev_hit_pos - prev_ray_orig);
-        TraverseStats st_closest{0, 0};
-        const RayHit h = bvh_trace<false, STATS>(c.sc.bvh, prev_ray_orig, dir, 0.0f, SKY_DIST, false, lds_stack + lane, 64, &st_closest);
-        if (STATS) { atomicAdd(&counter_slot(c.ray_counters)[2], (unsigned long long)st_closest.nodes); atomicAdd(&counter_slot(c.ray_counters)[3], (unsigned long long)st_closest.tris); }
-        hit = h.slot != 0xffffffffu;
-        if (hit) {
-            rec.ox = prev_ray_orig.x; rec.oy = prev_ray_orig.y; rec.oz = prev_ray_orig.z; rec.t = h.t; rec.dx = dir.x; rec.dy = dir.y; rec.dz = dir.z; rec.u = h.u; rec.v = h.v;
-            rec.e0 = prev_hit_pos.x; rec.e1 = prev_hit_pos.y; rec.e2 = prev_hit_pos.z;
-            rec.slot = h.slot; rec.pixel = uint32_t(x) | (uint32_t(y) << 16); rec.rng = hash3(uint32_t(x), uint32_t(y), 0); rec.pad = 0;
-        } else {
-            validate_finish_pixel(x, y, xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, dir)), SKY_DIST, prev_ray_orig, prev_hit_pos, ld4(irradiance_history_tex, x, y), reservoir_tex,
-                                  irradiance_history_tex, invalidity_out_tex);
-        }
-    }
-    split_park(st, hit, rec);
-}
-template <bool STATS>
-__global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_validate_shade(TraceCtx c, SplitStage st, ImgU2 reservoir_tex, ImgH4 irradiance_history_tex, ImgR8 invalidity_out_tex) {
-    extern __shared__ uint32_t lds_stack[];
-    uint32_t total = 1;
-    for (uint32_t batch = 0; batch * 64u < total; ++batch) {
-        SplitRecord r;
-        if (!split_fetch(st, batch, r, total)) continue;
-        V3 hit_normal_ws;
-        const V3 rad = split_shade<STATS>(c, r, lds_stack + (threadIdx.x & 63u), hit_normal_ws);
-        const int x = int(r.pixel & 0xffffu), y = int(r.pixel >> 16);
-        validate_finish_pixel(x, y, rad, r.t, V3{r.ox, r.oy, r.oz}, V3{r.e0, r.e1, r.e2}, ld4(irradiance_history_tex, x, y), reservoir_tex, irradiance_history_tex, invalidity_out_tex);
-    }
-}
-
-// ---- staged form (KJ_RTDGI_STAGED_MIN_RAYS=0 selects it; kept for measurements and for callers that batch rays: its stream
-// kernels are what kj_trace_closest / kj_trace_any run, +28 % rays/s over one ray per lane on 1.6 M incoherent rays).
-// The reference's ray-generation shaders (trace_diffuse.rgen.hlsl, diffuse_validate.rgen.hlsl) run ray generation, traversal,
-// hit shading, the sun's shadow ray and the result's bookkeeping in one invocation per pixel. On gfx950 that is a megakernel
-// whose waves idle three lanes out of four (sky pixels, rays of unequal length, node / triangle steps interleaved, hit vs miss
-// shading). Here a ray pass is five launches over dense per-pixel arrays (ray i = lane i % 64 of 8x8 tile i / 64 of the launch):
-//   1. ray generation          -> rays_a[i]            (k_rtdgi_trace_raygen / k_rtdgi_validate_raygen; "no ray" for sky pixels)
-//   2. closest-hit ray stream  -> hits_a[i]            (kj_bvh.hpp: bvh_trace_stream -- persistent waves, lane refill, block voting)
-//   3. hit shading             -> rays_b[i], state[i]  (k_rtdgi_shade: G-buffer of the hit, sun shadow ray, lights, irradiance cache)
-//   4. occlusion ray stream    -> occl_b[i]
-//   5. finish                  -> the pass's images    (k_rtdgi_trace_finish / k_rtdgi_validate_finish)
-// The arithmetic of diffuse_trace_common.inc.hlsl:38-221 is unchanged, including the order in which the radiance terms are summed
-// (the shade step carries the sum twice, with and without the sun's term, and the finish step picks one).
-struct RayStage {
-    float4* __restrict__ rays_a; float4* __restrict__ hits_a;     // 2 x float4 per ray; (t, u, v, slot bits) per hit
-    float4* __restrict__ rays_b; uint32_t* __restrict__ occl_b;   // sun shadow rays; 1 = blocked
-    float4* __restrict__ state;                                   // 2 x float4 per pixel: (radiance if sun visible, hit_t), (radiance if sun blocked, is_hit)
-};
-#define KJ_NO_RAY -1.0f
-KJ_D uint32_t stage_index(int lane) { return (blockIdx.y * gridDim.x + blockIdx.x) * 64u + uint32_t(lane); }
-KJ_D void put_ray(float4* rays, uint32_t i, V3 o, float tmin, V3 d, float tmax) {
-    rays[size_t(i) * 2] = make_float4(o.x, o.y, o.z, tmin);
-    rays[size_t(i) * 2 + 1] = make_float4(d.x, d.y, d.z, tmax);
-}
-KJ_D void put_no_ray(float4* rays, uint32_t i) { put_ray(rays, i, v3(0.0f), 0.0f, v3(0.0f), KJ_NO_RAY); }
-
-// ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24: ray generation
-__global__ void __launch_bounds__(64) k_rtdgi_trace_raygen(TraceCtx c, RayStage st, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
-                                                            ImgU32 candidate_normal_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
-    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
-    const uint32_t idx = stage_index(lane);
-    const FrameConstants& fc = *c.fc;
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
-    const float depth = in_image ? c.depth.ld(hx, hy) : 0.0f;
-    const bool has_ray = in_image && depth != 0.0f;
-    count_rays(c.ray_counters, 0, has_ray);
-    if (!has_ray) {
-        put_no_ray(st.rays_a, idx);
-        if (in_image) {
-            st4(candidate_irradiance_out_tex, x, y, v4(0.0f));
-            candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
-            invalidity_out_tex.st(x, y, 0);
-        }
-        return;
-    }
-    const V4 gts = tex_size4(c.depth.w, c.depth.h);
-    const V2 uv = get_uv(float(hx), float(hy), gts);
-    const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
-    const float near_field_fade_out_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
-    const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
-    const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
-    const Basis tangent_to_world = build_orthonormal_basis(normal_ws);
-    const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, fc.frame_index);
-    const V3 outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
-    const V3 origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
-    put_ray(st.rays_a, idx, origin, 0.0f, outgoing_dir, tracing_frame ? SKY_DIST : near_field_fade_out_end);
-    const float cos_theta = dot(normalize(outgoing_dir - vr.dir_ws), normal_ws);
-    st4(candidate_irradiance_out_tex, x, y, V4{0, 0, 0, 1.0f - cos_theta});   // rgb: the finish step
-    const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
-    const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
-    invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
-}
-// ------------------------------------------------------------------ diffuse_validate.rgen.hlsl:46-111: ray generation (the kept sample's ray again)
-__global__ void __launch_bounds__(64) k_rtdgi_validate_raygen(TraceCtx c, RayStage st, ImgH4 reservoir_ray_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
-    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
-    const uint32_t idx = stage_index(lane);
-    const FrameConstants& fc = *c.fc;
-    const I2 off = halfres_subsample_offset(fc.frame_index);
-    const bool sky = in_image && 0.0f == c.depth.ld(x * 2 + off.x, y * 2 + off.y);
-    const bool has_ray = in_image && !sky && is_rtdgi_validation_frame(fc.frame_index);
-    count_rays(c.ray_counters, 0, has_ray);
-    if (!has_ray) {
-        put_no_ray(st.rays_a, idx);
-        if (in_image) invalidity_out_tex.st(x, y, to_unorm8(sky ? 1.0f : 0.0f));
-        return;
-    }
-    const float4 ro = ray_orig_history_tex.ld(x, y);
-    const V3 prev_ray_orig{ro.x, ro.y, ro.z};
-    const V3 prev_hit_pos = xyz(ld4(reservoir_ray_history_tex, x, y)) + prev_ray_orig;
-    put_ray(st.rays_a, idx, prev_ray_orig, 0.0f, normalize(prev_hit_pos - prev_ray_orig), SKY_DIST);
-}
-
-// ------------------------------------------------------------------ closest-hit / occlusion streams over a stage's rays
-template <bool ANY_HIT, bool STATS>
-__global__ void __launch_bounds__(64) k_rtdgi_ray_stream(BvhView bvh, const float4* __restrict__ rays, float4* __restrict__ hits, uint32_t* __restrict__ occl, uint32_t count,
-                                                          unsigned long long* __restrict__ ray_counters, StreamTune tune) {
-    extern __shared__ uint32_t lds_stack[];
-    TraverseStats stats{0, 0};
-    bvh_trace_stream<ANY_HIT, STATS>(bvh, rays, count, false, blockIdx.x, gridDim.x, lds_stack + threadIdx.x, 64,
-                                     [&](uint32_t i, const RayHit& h) {
-                                         if (ANY_HIT) occl[i] = h.slot != 0xffffffffu ? 1u : 0u;
-                                         else hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
-                                     }, tune, &stats);
-    if (STATS) {  // instrumentation build only: traversal work per ray type (SURVEY 8d "measured by the instrumented kernel")
-        atomicAdd(&counter_slot(ray_counters)[ANY_HIT ? 4 : 2], (unsigned long long)stats.nodes);
-        atomicAdd(&counter_slot(ray_counters)[ANY_HIT ? 5 : 3], (unsigned long long)stats.tris);
-    }
-}
-
-// ------------------------------------------------------------------ diffuse_trace_common.inc.hlsl:38-221: everything after the closest-hit query
-template <bool VALIDATE>
-__global__ void __launch_bounds__(64) k_rtdgi_shade(TraceCtx c, RayStage st, ImgU32 half_view_normal_tex, ImgU32 candidate_normal_out_tex,
-                                                     ImgH4 candidate_hit_out_tex, int hw, int hh, int row0, int row1) {
-    extern __shared__ uint32_t lds_stack[];
-    TILE_XY(hw, hh)
-    const uint32_t idx = stage_index(lane);
-    const float4 ra = st.rays_a[size_t(idx) * 2], rb = st.rays_a[size_t(idx) * 2 + 1];
-    if (!(rb.w >= 0.0f)) { put_no_ray(st.rays_b, idx); return; }
-    const FrameConstants& fc = *c.fc;
-    const V3 ray_o{ra.x, ra.y, ra.z}, ray_d{rb.x, rb.y, rb.z};
-    const float ray_tmax = rb.w;
-    const float4 hrec = st.hits_a[idx];
-    RayHit h;
-    h.t = hrec.x; h.u = hrec.y; h.v = hrec.z; h.slot = __float_as_uint(hrec.w); h.world_id = 0;
-    const bool is_hit = h.slot != 0xffffffffu;
-    const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(half_view_normal_tex, x, y));
-    uint32_t rng = VALIDATE ? hash3(uint32_t(x), uint32_t(y), 0) : hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u);
-    uint32_t* stack = lds_stack + lane;
-    // the radiance sum, carried twice: `lit` if the sun's shadow ray turns out free, `shadowed` if blocked
-    V3 lit = v3(0.0f), shadowed = v3(0.0f);
-    V3 hit_normal_ws = -ray_d;
-    float hit_t = ray_tmax;
-    bool shadow_ray = false;
-    if (is_hit) {
-        // GbufferRaytrace::trace after the traversal (inc/rt.hlsl:112-137): shade the hit; the reflected cone is the half-res pixel
-        // cone propagated from the eye to the ray origin (diffuse_trace_common.inc.hlsl:68-71)
-        const RayCone ray_cone = pixel_ray_cone_from_image_height(fc, float(c.depth.h) * 0.5f).propagate(0.03f, length(ray_o - get_eye_position(fc)));
-        const uint4 gbuffer_packed = shade_gbuffer_hit(c.sc, fc, ray_d, h, 1, ray_cone.width_at_t(h.t * length(ray_d)));
-        const V3 hit_position = mad_nc(ray_o, ray_d, h.t);
-        hit_t = h.t;
-        GbufferData gbuffer = gbuffer_unpack(gbuffer_packed);
-        hit_normal_ws = gbuffer.normal;
-        const V3 hit_cs = position_world_to_sample(fc, hit_position);
-        const V2 hit_uv = cs_to_uv(V2{hit_cs.x, hit_cs.y});
-        const float screen_depth = sample_nearest_clamp(c.depth, hit_uv);
-        bool is_on_screen = fabsf(hit_cs.x) < 1.0f && fabsf(hit_cs.y) < 1.0f && inverse_depth_relative_diff(hit_cs.z, screen_depth) < 5e-3f;
-        V4 reprojected_radiance = v4(0.0f);
-        if (is_on_screen) {
-            reprojected_radiance = unpack_rgba16f(sample_nearest_clamp(c.reprojected_gi, hit_uv)) * fc.pre_exposure_delta;
-            is_on_screen = reprojected_radiance.w > 0;
-        }
-        gbuffer.roughness = lerp(gbuffer.roughness, 1.0f, ROUGHNESS_BIAS);
-        const Basis tangent_to_world = build_orthonormal_basis(gbuffer.normal);
-        const V3 wo = to_local(tangent_to_world, -ray_d);
-        const LayeredBrdf brdf = layered_brdf_from_gbuffer_ndotv(c.brdf_fg_lut, gbuffer, wo.z);
-        const float4 sc4 = *c.sun_color;
-        const V3 sun_radiance{sc4.x, sc4.y, sc4.z};
-        if (sun_radiance.x != 0 || sun_radiance.y != 0 || sun_radiance.z != 0) {
-            const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, rng);
-            const V3 to_light_norm = sample_sun_direction(fc, V2{bn.x, bn.y}, false);
-            put_ray(st.rays_b, idx, hit_position, 1e-4f, to_light_norm, SKY_DIST);
-            shadow_ray = true;
-            const V3 wi = to_local(tangent_to_world, to_light_norm);
-            const V3 brdf_value = layered_brdf_evaluate(brdf, wo, wi) * fmaxf(0.0f, wi.z);
-            lit += brdf_value * sun_radiance;
-            shadowed += brdf_value * v3(0.0f);
-        }
-        lit += gbuffer.emissive; shadowed += gbuffer.emissive;
-        if (is_on_screen) {
-            const V3 t = xyz(reprojected_radiance) * gbuffer.albedo;
-            lit += t; shadowed += t;
-        } else {
-            V2 urand;
-            urand.x = uint_to_u01_float(hash1_mut(rng));
-            urand.y = uint_to_u01_float(hash1_mut(rng));
-            const uint32_t nl = min(fc.triangle_light_count, c.sc.light_count);
-            for (uint32_t li = 0; li < nl; ++li) {
-                const KjTriangleLight tl = c.sc.lights[li];
-                const V3 v0{tl.verts[0], tl.verts[1], tl.verts[2]}, v1{tl.verts[3], tl.verts[4], tl.verts[5]}, v2{tl.verts[6], tl.verts[7], tl.verts[8]};
-                const LightSampleArea ls = sample_triangle_light(v0, v1 - v0, v2 - v0, urand);
-                const V3 to_light_ws = ls.pos - hit_position;
-                const float dist2 = dot(to_light_ws, to_light_ws);
-                const V3 to_light_norm_ws = to_light_ws * (1.0f / sqrtf(dist2));
-                const float to_psa_metric = fmaxf(0.0f, dot(to_light_norm_ws, gbuffer.normal)) * fmaxf(0.0f, dot(to_light_norm_ws, -ls.normal)) / dist2;
-                if (to_psa_metric > 0.0f) {   // few, short rays of the off-screen minority: traced in place
-                    count_rays(c.ray_counters, 1, true);
-                    const bool is_shadowed = rt_is_shadowed<false>(c.sc, hit_position, to_light_norm_ws, 1e-3f, sqrtf(dist2) - 2e-3f, stack, 64);
-                    const V3 bounce_albedo = lerp(gbuffer.albedo, v3(1.0f), 0.04f);
-                    const V3 brdf_value = bounce_albedo * to_psa_metric / KJ_PI;
-                    if (!is_shadowed) { const V3 t = V3{tl.radiance[0], tl.radiance[1], tl.radiance[2]} * brdf_value / ls.pdf; lit += t; shadowed += t; }
-                }
-            }
-            if (c.has_ircache) {  // USE_IRCACHE (diffuse_trace_common.inc.hlsl:189-198); unbound => contributes 0 (BASELINE config 1)
-                const uint32_t rq = uint32_t(y) * c.request_stride + uint32_t(x);
-                const V3 t = ircache_lookup<false>(c.irc, fc, ray_o, hit_position, gbuffer.normal, 1u, rng, false, c.request_slot_base + rq, c.request_key_base | rq) * gbuffer.albedo;
-                lit += t; shadowed += t;
-            }
-        }
-    } else {
-        const V3 t = xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
-        lit += t; shadowed += t;
-    }
-    count_rays(c.ray_counters, 1, shadow_ray);
-    if (!shadow_ray) put_no_ray(st.rays_b, idx);
-    st.state[size_t(idx) * 2] = make_float4(lit.x, lit.y, lit.z, hit_t);
-    st.state[size_t(idx) * 2 + 1] = make_float4(shadowed.x, shadowed.y, shadowed.z, is_hit ? 1.0f : 0.0f);
-    if (!VALIDATE) {
-        const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
-        const float out_hit_t = (!tracing_frame && !is_hit) ? SKY_DIST : hit_t;
-        const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, ray_d) * 2 * KJ_PI));
-        st4(candidate_hit_out_tex, x, y, v4(ray_d * out_hit_t, pdf * (tracing_frame ? 1.0f : -1.0f)));
-        candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, hit_normal_ws), 0)));
-    }
-}
-
-// ------------------------------------------------------------------ finish: trace_diffuse.rgen.hlsl:103-113
-__global__ void __launch_bounds__(64) k_rtdgi_trace_finish(const FrameConstants* __restrict__ fcp, RayStage st, ImgH4 candidate_irradiance_out_tex, int row0, int row1) {
-    TILE_XY(candidate_irradiance_out_tex.w, candidate_irradiance_out_tex.h)
-    const uint32_t idx = stage_index(lane);
-    if (!in_image || !(st.rays_a[size_t(idx) * 2 + 1].w >= 0.0f)) return;
-    const float4 s0 = st.state[size_t(idx) * 2], s1 = st.state[size_t(idx) * 2 + 1];
-    const bool blocked = st.rays_b[size_t(idx) * 2 + 1].w >= 0.0f && st.occl_b[idx] != 0u;
-    V3 out_value = blocked ? V3{s1.x, s1.y, s1.z} : V3{s0.x, s0.y, s0.z};
-    if (is_rtdgi_validation_frame(fcp->frame_index) && s1.w == 0.0f) out_value = v3(0.0f);
-    const float w = unpack_rgba16f(candidate_irradiance_out_tex.ld(x, y)).w;
-    st4(candidate_irradiance_out_tex, x, y, v4(out_value, w));
-}
-// ------------------------------------------------------------------ finish: diffuse_validate.rgen.hlsl:84-110
-__global__ void __launch_bounds__(64) k_rtdgi_validate_finish(RayStage st, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex, ImgH4 irradiance_history_tex,
-                                                               ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
-    TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h)
-    const uint32_t idx = stage_index(lane);
-    if (!in_image || !(st.rays_a[size_t(idx) * 2 + 1].w >= 0.0f)) return;
-    const float4 s0 = st.state[size_t(idx) * 2], s1 = st.state[size_t(idx) * 2 + 1];
-    const bool blocked = st.rays_b[size_t(idx) * 2 + 1].w >= 0.0f && st.occl_b[idx] != 0u;
-    const V3 out_value = blocked ? V3{s1.x, s1.y, s1.z} : V3{s0.x, s0.y, s0.z};
-    const float result_hit_t = s0.w;
-    const float4 ro = ray_orig_history_tex.ld(x, y);
-    const V3 prev_ray_orig{ro.x, ro.y, ro.z};
-    const V3 prev_hit_pos = xyz(ld4(reservoir_ray_history_tex, x, y)) + prev_ray_orig;
-    const V4 prev_radiance_packed = ld4(irradiance_history_tex, x, y);
-    const V3 prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
-    const V3 new_radiance = vmax(v3(0.0f), out_value);
-    const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
-    const float invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
-    const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
-    if (fabsf(result_hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
-        st4(irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
-        Reservoir1spp r = Reservoir1spp::from_raw(reservoir_tex.ld(x, y));
-        const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
-        r.M *= clampf(lum_old / fmaxf(1e-8f, lum_new), 0.03f, 1.0f);
-        r.W *= clampf(lum_old / fmaxf(1e-8f, lum_new) * 10.0f, 0.01f, 1.0f);
-        reservoir_tex.st(x, y, r.as_raw());
-    }
-    invalidity_out_tex.st(x, y, to_unorm8(invalidity));
-}
 
 // ------------------------------------------------------------------ temporal_validity_integrate.hlsl:21-119
 // WaveReadLaneAt(v, lane^k) inside the 8x8 group == __shfl_xor(v, k) on wave64.
@@ -1490,6 +858,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(1);
     }
+#ifdef KJ_RAY_PASS_EXPERIMENTS
     // the ray passes' stage buffers (dense, one slot per lane of every 8x8 tile of the launch)
     const uint32_t stage_rays = gh.x * gh.y * 64u;
     const size_t stage_full = size_t((hw + 7) / 8) * ((hh + 7) / 8) * 64;
@@ -1624,6 +993,25 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
     }
+#else
+    // The product build carries the fused form of the two ray passes only (one wave per 8x8 tile: ray generation, both traversals, hit shading);
+    // the other forms live behind KJ_RAY_PASS_EXPERIMENTS (rtdgi_ray_experiments.inc)
+    if (mask & KJ_RTDGI_PASS_VALIDATE) {
+        SCOPE_BEGIN(2);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+                           img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(2);
+    }
+    tc.request_slot_base = uint32_t(hw) * uint32_t(hh); tc.request_key_base = 2u << 28;
+    if (mask & KJ_RTDGI_PASS_TRACE) {
+        SCOPE_BEGIN(3);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+                           img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(3);
+    }
+#endif
     const ValidityIntegrateArgs via{fc, img<uint8_t>(validity_in, hw, hh), img<uint32_t>(invalidity_hist, hw, hh), reprojection, img<float>(half_depth, hw, hh),
                                     img<uint32_t>(invalidity_out, hw, hh), W, H, hr0, hr1};
     const bool fuse_validity_temporal = r->fuse_validity_temporal && (mask & KJ_RTDGI_PASS_VALIDITY_INTEGRATE) && (mask & KJ_RTDGI_PASS_RESTIR_TEMPORAL);
@@ -1749,6 +1137,9 @@ KjStatus kj_rtdgi_set_profiling(KjRtdgi* r, uint32_t enable_pass_timers, uint32_
 }
 KjStatus kj_rtdgi_set_ray_pass_form(KjRtdgi* r, uint32_t form) {
     KJ_REQUIRE(r && form <= KJ_RTDGI_RAYS_QUAD, "null argument / unknown form");
+#ifndef KJ_RAY_PASS_EXPERIMENTS
+    KJ_REQUIRE(form == KJ_RTDGI_RAYS_FUSED, "this build carries the fused form only (the others: make EXPERIMENTS=1, -DKJ_RAY_PASS_EXPERIMENTS)");
+#endif
     r->grouped_rays = form == KJ_RTDGI_RAYS_GROUPED;
     r->split_rays = form == KJ_RTDGI_RAYS_SPLIT;
     r->quad_rays = form == KJ_RTDGI_RAYS_QUAD;

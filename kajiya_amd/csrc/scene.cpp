@@ -66,6 +66,13 @@ extern "C" {
 
 const char* kj_last_error(void) { return kj::g_last_error; }
 uint32_t kj_abi_version(void) { return 1; }
+uint32_t kj_abi_struct_size(uint32_t id) {
+    static const uint32_t sizes[KJ_ABI_STRUCT_COUNT] = {
+        sizeof(KjFrameConstants), sizeof(KjViewConstants), sizeof(KjMeshMaterial), sizeof(KjPackedVertex), sizeof(KjMaterialMap), sizeof(KjMeshDesc), sizeof(KjTriangleLight),
+        sizeof(KjGbufferDepth), sizeof(KjRtdgiRenderParams), sizeof(KjRtdgiOutput), sizeof(KjTaaOutput), sizeof(KjRtrTables), sizeof(KjRtrParams), sizeof(KjSplitRank),
+        sizeof(KjSplitFrame), sizeof(KjBakedMeshView), sizeof(KjBakedImageView)};
+    return id < KJ_ABI_STRUCT_COUNT ? sizes[id] : 0u;
+}
 
 KjStatus kj_scene_create(KjDevice* dev, KjScene** out) {
     KJ_REQUIRE(dev && out, "null argument");

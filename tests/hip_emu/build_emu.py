@@ -13,6 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CSRC = os.path.join(ROOT, "kajiya_amd", "csrc")
 # KJ_EMU_DEFINES="-DKJ_BVH_FOLD_INVD ...": build an experiment variant of the product (same switches as scripts/build_variant.sh) into its own directory
 EXTRA = os.environ.get("KJ_EMU_DEFINES", "").split()
+# the CPU stand-in always carries the measured-and-rejected forms of the ray passes too (rtdgi_ray_experiments.inc), so that
+# test_ray_pass_forms_agree keeps holding them to the fused form although the product library no longer compiles them
+ALWAYS = ["-DKJ_RAY_PASS_EXPERIMENTS"]
 # KJ_HIP_EMU=fast: lanes as fibers, workgroups spread over the host cores, -O2, NO sanitizers (tests/hip_emu/hip/hip_runtime.h, fiber mode)
 FAST = os.environ.get("KJ_HIP_EMU") == "fast"
 OUT = os.path.join(ROOT, "tests", "_build", ("emu_fast" if FAST else "emu_all") + ("_" + re.sub(r"[^A-Za-z0-9]+", "_", "".join(EXTRA)) if EXTRA else ""))
@@ -22,9 +25,9 @@ FLAGS = ["-g", "-O1", "-std=c++20", "-fPIC", "-pthread", "-ffp-contract=off", "-
          # float -> int casts of NaN / out-of-range values are DEFINED on the GPU (v_cvt_i32_f32 saturates, NaN -> 0) and the kernels rely on that
          # where the reference's shaders do (e.g. a NaN direction reaching a cube lookup from an empty reservoir, clamped right after): not an error
          "-fno-sanitize=float-cast-overflow",
-         "-I", os.path.join(ROOT, "tests", "hip_emu"), "-I", CSRC, "-D__HIP_PLATFORM_AMD__"] + EXTRA
+         "-I", os.path.join(ROOT, "tests", "hip_emu"), "-I", CSRC, "-D__HIP_PLATFORM_AMD__"] + ALWAYS + EXTRA
 if FAST:
-    FLAGS = ["-g", "-O2", "-std=c++20", "-fPIC", "-pthread", "-ffp-contract=off", "-DHIP_EMU_FIBERS", "-I", os.path.join(ROOT, "tests", "hip_emu"), "-I", CSRC, "-D__HIP_PLATFORM_AMD__"] + EXTRA
+    FLAGS = ["-g", "-O2", "-std=c++20", "-fPIC", "-pthread", "-ffp-contract=off", "-DHIP_EMU_FIBERS", "-I", os.path.join(ROOT, "tests", "hip_emu"), "-I", CSRC, "-D__HIP_PLATFORM_AMD__"] + ALWAYS + EXTRA
 DYNAMIC_LDS = re.compile(r"extern __shared__ ([A-Za-z0-9_]+) ([A-Za-z0-9_]+)\[\];")
 
 
@@ -45,7 +48,10 @@ def build():
         name = os.path.splitext(os.path.basename(src))[0]
         obj = os.path.join(OUT, name + ".o")
         if src.endswith(".hip"):
-            text = DYNAMIC_LDS.sub(r"\1* \2 = (\1*)hip_emu::dynamic_lds();", open(src).read())
+            text = open(src).read()
+            # kernel text kept in a .inc next to the .hip (rtdgi_ray_experiments.inc) is spliced in, so that its dynamic-LDS declarations get rewritten too
+            text = re.sub(r'#include "(\w+\.inc)"', lambda m: open(os.path.join(CSRC, m.group(1))).read() if "experiments" in m.group(1) else m.group(0), text)
+            text = DYNAMIC_LDS.sub(r"\1* \2 = (\1*)hip_emu::dynamic_lds();", text)
             src = os.path.join(OUT, name + ".emu.cpp")
             open(src, "w").write(text)
         subprocess.check_call([CLANG] + FLAGS + ["-x", "c++", "-c", src, "-o", obj])

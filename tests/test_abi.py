@@ -33,6 +33,65 @@ def test_struct_layouts():
     assert C.sizeof(abi.KjPackedVertex) == 16
 
 
+ABI_IDS = ["KjFrameConstants", "KjViewConstants", "KjMeshMaterial", "KjPackedVertex", "KjMaterialMap", "KjMeshDesc", "KjTriangleLight", "KjGbufferDepth", "KjRtdgiRenderParams",
+           "KjRtdgiOutput", "KjTaaOutput", "KjRtrTables", "KjRtrParams", "KjSplitRank", "KjSplitFrame", "KjBakedMeshView", "KjBakedImageView"]     # enum KjAbiStruct, in order
+
+
+def _rust_repr_c_structs(text):
+    """`#[repr(C)] pub struct Name { pub a: T, ... }` blocks of INTEGRATION.md -> {name: [(field, type)]} (opaque `_p: [u8; 0]` handles skipped)."""
+    out = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\s*pub struct (\w+)\s*\{([^{}]*)\}", text, re.S):
+        body = re.sub(r"//[^\n]*", "", m.group(2))
+        fields = re.findall(r"pub\s+(\w+)\s*:\s*([^,}]+?)\s*(?:,|$)", body, re.S)
+        if fields:
+            out[m.group(1)] = [(n, t.strip()) for n, t in fields]
+    return out
+
+
+def _rust_size_align(ty, structs):
+    ty = ty.strip()
+    if ty.startswith("*"):
+        return 8, 8
+    prim = {"u8": 1, "i8": 1, "u16": 2, "i16": 2, "u32": 4, "i32": 4, "f32": 4, "u64": 8, "i64": 8, "f64": 8, "usize": 8}
+    if ty in prim:
+        return prim[ty], prim[ty]
+    m = re.match(r"\[(.+);\s*(\d+)\]$", ty)
+    if m:
+        s, a = _rust_size_align(m.group(1), structs)
+        return s * int(m.group(2)), a
+    off, align = 0, 1
+    for _, ft in structs[ty]:
+        s, a = _rust_size_align(ft, structs)
+        off = (off + a - 1) // a * a + s
+        align = max(align, a)
+    return (off + align - 1) // align * align, align
+
+
+def test_every_struct_of_the_boundary_has_the_library_s_size():
+    """kj_abi_struct_size(id) is sizeof() inside the library. The ctypes binding (kajiya_amd/abi.py) must agree for every struct it declares,
+    and so must every `#[repr(C)]` struct INTEGRATION.md hands a kajiya maintainer -- round 3's text had KjRtdgiRenderParams twelve bytes short."""
+    from kajiya_amd import lib, abi
+    L = lib.load()
+    L.kj_abi_struct_size.restype = C.c_uint32
+    L.kj_abi_struct_size.argtypes = [C.c_uint32]
+    sizes = {name: L.kj_abi_struct_size(i) for i, name in enumerate(ABI_IDS)}
+    assert all(v > 0 for v in sizes.values()) and L.kj_abi_struct_size(len(ABI_IDS)) == 0, sizes
+    hdr = open(os.path.join(ROOT, "include", "kajiya_amd.h")).read()
+    enum = re.search(r"enum KjAbiStruct \{(.*?)\}", hdr, re.S).group(1)
+    assert len(re.findall(r"KJ_ABI_\w+", enum)) == len(ABI_IDS) + 1            # + KJ_ABI_STRUCT_COUNT
+    checked = 0
+    for name, size in sizes.items():
+        if hasattr(abi, name):
+            assert C.sizeof(getattr(abi, name)) == size, (name, C.sizeof(getattr(abi, name)), size)
+            checked += 1
+    assert checked >= 12, checked
+    structs = _rust_repr_c_structs(open(os.path.join(ROOT, "INTEGRATION.md")).read())
+    in_doc = [n for n in sizes if n in structs]
+    assert {"KjGbufferDepth", "KjRtdgiRenderParams", "KjRtdgiOutput"} <= set(in_doc), in_doc
+    for name in in_doc:
+        assert _rust_size_align(name, structs)[0] == sizes[name], (name, _rust_size_align(name, structs)[0], sizes[name], structs[name])
+
+
 def test_error_reporting_without_gpu():
     """No compute calls: only argument validation paths (must not touch a device)."""
     from kajiya_amd import lib
