@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--scene", default="city", choices=["city", "ruins", "cornell", "pica"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-frames", type=int, default=20, help="frames of the CPU oracle in the cpu_baseline leg (at this run's extent)")
+    ap.add_argument("--no-scalar-baseline", action="store_true", help="skip the extra single-thread oracle frame of the cpu_baseline leg (minutes at 4K)")
     ap.add_argument("--no-also", action="store_true", help="skip the two headline-size measurements appended as `also` (4K ruins GI frame; 1440p config-3 lighting frame)")
     ap.add_argument("--profile-frames", type=int, default=12)
     ap.add_argument("--no-ssgi", action="store_true", help="drive rtdgi with the constant SSAO guide instead of running SsgiRenderer each frame")
@@ -70,10 +72,10 @@ def frame_constants_list(W, H, n, cam_args, phase=0.0):
     return out
 
 
-def cpu_baseline(desc, cam_args, cores):
-    """Oracle (CPU restatement, kind='port') on a bounded sample of the same scene/camera."""
+def cpu_baseline(desc, cam_args, cores, W=1920, H=1080, frames=20, scalar=True):
+    """Oracle (CPU restatement, kind='port') on a bounded sample of the same scene/camera: the bench workload itself, fewer frames
+    (~10-30 s of CPU work on 16+ cores: 20 frames at 1080p, 1 frame at 4K)."""
     from oracle import okj_py
-    W, H, frames = 1920, 1080, 20   # the bench workload itself, fewer frames (~10-30 s of CPU work on 16+ cores)
     t_build = time.time()
     osc = okj_py.OracleScene(desc)
     t_build = time.time() - t_build
@@ -90,6 +92,12 @@ def cpu_baseline(desc, cam_args, cores):
         a, b = op.ray_counts()
         c, d = op.ircache_ray_counts()
         rays += a + b + c + d
+    res = {"value": round(rays / t_gi / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "sample": f"oracle ircache + rtdgi (all passes), same scene+camera, {frames} frame(s) at {W}x{H} ({rays} rays in {t_gi:.2f} s; "
+                     f"oracle BVH build {t_build:.1f} s not counted)",
+           "gi_frame_ms_at_sample_res": round(1e3 * t_gi / frames, 2)}
+    if not scalar:
+        return res
     # one more frame on a single thread: the "CPU scalar reference" of SURVEY 8d (the multi-core figure above is the headline)
     okj_py.lib().okj_set_threads(1)
     fc = frame_constants_list(W, H, frames + 1, cam_args)[-1]
@@ -103,11 +111,8 @@ def cpu_baseline(desc, cam_args, cores):
     a, b = op.ray_counts()
     c, d = op.ircache_ray_counts()
     okj_py.lib().okj_set_threads(cores)
-    return {"value": round(rays / t_gi / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"oracle ircache + rtdgi (all passes), same scene+camera, {frames} frames at {W}x{H} ({rays} rays in {t_gi:.2f} s; "
-                      f"oracle BVH build {t_build:.1f} s not counted)",
-            "gi_frame_ms_at_sample_res": round(1e3 * t_gi / frames, 2),
-            "scalar_1core": {"value": round((a + b + c + d) / t_1 / 1e6, 4), "unit": "Mrays/s", "gi_frame_ms": round(1e3 * t_1, 1), "sample": "1 more frame, 1 thread"}}
+    res["scalar_1core"] = {"value": round((a + b + c + d) / t_1 / 1e6, 4), "unit": "Mrays/s", "gi_frame_ms": round(1e3 * t_1, 1), "sample": "1 more frame, 1 thread"}
+    return res
 
 
 def also_measurements():
@@ -119,10 +124,12 @@ def also_measurements():
     out = []
     env = dict(os.environ)
     for label, cmd in (("4K GI frame, ruins ~4M tris (configs[3] on one GPU / north-star target)",
-                        [sys.executable, os.path.join(ROOT, "bench.py"), "--no-also", "--no-cpu-baseline", "--scene", "ruins", "--tris", "4000000", "--width", "3840", "--height", "2160",
-                         "--steps", "36", "--warmup", "12", "--profile-frames", "6"]),
+                        [sys.executable, os.path.join(ROOT, "bench.py"), "--no-also", "--cpu-baseline-frames", "1", "--no-scalar-baseline", "--scene", "ruins", "--tris", "4000000",
+                         "--width", "3840", "--height", "2160", "--steps", "36", "--warmup", "12", "--profile-frames", "6"]),
                        ("1440p full lighting frame, ruins ~4M tris (configs[2])",
-                        [sys.executable, os.path.join(ROOT, "scripts", "config3_bench.py"), "--frames", "36", "--warmup", "12"])):
+                        [sys.executable, os.path.join(ROOT, "scripts", "config3_bench.py"), "--frames", "36", "--warmup", "12"]),
+                       ("reference path tracer, 4K, ruins ~4M tris, N = 1 of configs[4]'s 8-way interleave (ms per sample per pixel pass)",
+                        [sys.executable, os.path.join(ROOT, "scripts", "pt_bench.py"), "8"])):
         t0 = time.time()
         try:
             r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -136,7 +143,11 @@ def also_measurements():
             rf = j.get("roofline") or {}
             e.update({"gi_frame_ms": j["gi_frame_ms"], "fps": round(1000.0 / j["gi_frame_ms"], 1), "mrays_per_s": j["value"], "workload": j["config"]["workload"][:120],
                       "rays_per_frame": j["config"]["rays_per_frame"], "segment_ms": j.get("segment_ms"), "pass_ms": j.get("pass_ms"),
-                      "roofline": {k: rf.get(k) for k in ("kernel", "bound", "limited_by", "avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac")}})
+                      "roofline": {k: rf.get(k) for k in ("kernel", "bound", "bound_measured", "limited_by", "avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac")},
+                      "cpu_baseline": j.get("cpu_baseline")})
+        elif "ms_per_spp" in j:
+            e.update({k: j[k] for k in ("workload", "seconds", "ms_per_spp", "Mrays_per_s", "rays_per_path")})
+            e["spp_64_ms"] = round(64 * j["ms_per_spp"], 1)       # configs[4]: 64 spp at 4K on one GPU; the 8-way interleave deals tiles round-robin (exact: tests/test_gpu_headline_sizes.py)
         else:
             e.update({"frame_ms": j["frame_ms"], "fps": j["fps"], "mrays_per_s": j["mrays_per_s"], "workload": j["workload"], "segment_ms": j["segment_ms"], "rays_per_frame": j["rays_per_frame"],
                       "overlap": j.get("overlap")})
@@ -201,6 +212,8 @@ def main():
                 flag = torch.tensor([1 if created else 0], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else f"cuda:{local_rank}")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if not int(flag.item()):
+                    if split is not None:
+                        split.close()
                     split = None
             if split is not None:
                 passed = split.self_test(dist if world > 1 else None)
@@ -208,6 +221,7 @@ def main():
                 if rank == 0:
                     print(f"[bench] {transport} {nsplit} ranks {'OK' if passed else 'FAILED'}: exchange self-test ({'passed' if passed else 'wrong rows delivered'})", file=sys.stderr, flush=True)
                 if not passed:
+                    split.close()      # explicitly, before the Python orchestrator switches the caches' update mode (not left to __del__)
                     split = None
             if split is None and rank == 0:
                 print("[bench] falling back to the Python orchestrator over torch.distributed", file=sys.stderr, flush=True)
@@ -486,16 +500,17 @@ def main():
             # `bound` names the roofline `achieved` is priced against (the contract's "hbm" | "mfma"; this path has no dense contraction).
             # `limited_by` is what the counters of the same kernel say actually limits it.
             vb, hf, ms_ = e.get("valu_busy_pct"), e.get("hbm_frac"), e.get("mem_unit_stalled_pct")
+            # `bound_measured`: the same verdict as one word ("hbm" | "valu" | "memory unit" | "latency"), next to the contract's `bound`
             if vb is None or hf is None:
-                e["limited_by"] = None
+                e["limited_by"], e["bound_measured"] = None, None
             elif hf >= 0.6:
-                e["limited_by"] = f"hbm bandwidth (traffic at {hf:.2f} of peak)"
+                e["limited_by"], e["bound_measured"] = f"hbm bandwidth (traffic at {hf:.2f} of peak)", "hbm"
             elif vb >= 75.0:
-                e["limited_by"] = f"valu issue (VALUBusy {vb:.0f} %)"
+                e["limited_by"], e["bound_measured"] = f"valu issue (VALUBusy {vb:.0f} %)", "valu"
             elif ms_ is not None and ms_ >= 20.0:
-                e["limited_by"] = f"memory unit (MemUnitStalled {ms_:.0f} %)"
+                e["limited_by"], e["bound_measured"] = f"memory unit (MemUnitStalled {ms_:.0f} %)", "memory unit"
             else:
-                e["limited_by"] = f"latency: neither the VALUs ({vb:.0f} % busy) nor HBM ({hf:.2f} of peak) saturated -- dependent loads / occupancy"
+                e["limited_by"], e["bound_measured"] = f"latency: neither the VALUs ({vb:.0f} % busy) nor HBM ({hf:.2f} of peak) saturated -- dependent loads / occupancy", "latency"
             if note:
                 e["note"] = note
             return e
@@ -548,7 +563,7 @@ def main():
         except Exception:
             pass
         cores = min(cores, 64)
-        out["cpu_baseline"] = cpu_baseline(desc, cam_args, cores)
+        out["cpu_baseline"] = cpu_baseline(desc, cam_args, cores, W, H, args.cpu_baseline_frames, not args.no_scalar_baseline)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

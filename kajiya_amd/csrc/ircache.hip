@@ -654,6 +654,8 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     if (const char* pe = getenv("KJ_IRC_PART")) {
         unsigned pi = 0, pn = 1;
         if (sscanf(pe, "%u/%u", &pi, &pn) == 2 && pn >= 1u && pi < pn) { tc.part_index = pi; tc.part_count = pn; }
+        static bool warned = false;      // a variable left over from a profiling script degrades GI: never silently
+        if (!warned && tc.part_count > 1u) { fprintf(stderr, "kajiya_amd: KJ_IRC_PART=%s is set: the irradiance cache traces only every %u-th entry (a MEASUREMENT switch; results are incomplete)\n", pe, tc.part_count); warned = true; }
     }
     // Default: four lanes per path (kj_bvh.hpp: bvh_trace_quad) -- 16 paths per wave, a ~75-instruction step instead of ~200, four
     // times the waves. KJ_IRC_QUAD=0: one lane per path.

@@ -98,6 +98,8 @@ struct KjSplit {
     bool with_rtr = false;                                 // kj_split_set_rtr: reflections follow the GI frame -- the cache's replay moves behind their ray passes
     bool consistent_ircache = false;
     std::vector<uint8_t> ircache_was_deferred;             // each local cache's mode before kj_split_create changed it: restored by kj_split_destroy
+    bool rtr_requests_set = false;                         // kj_split_set_rtr switched the caches to the four-range slot layout: undone by kj_split_destroy
+    bool merge_pending = false;                            // a frame recorded cache lookups that nobody has replayed yet: the next frame's head requires it clear
     void* nccl = nullptr;                                  // ncclComm_t; null: every rank is local
     std::map<std::pair<uint32_t, std::string>, std::pair<uint8_t*, uint64_t>> surfaces;     // (local index, name) -> base pointer, bytes
     std::vector<DevBuf> send_stage, recv_stage;            // [local rank * world + peer]: the packed rows of one exchange
@@ -117,6 +119,11 @@ const SurfInfo* info_of(const std::string& name) {
     const std::string base = name.substr(0, name.find(':'));
     auto it = surf_table().find(base);
     return it == surf_table().end() ? nullptr : &it->second;
+}
+
+// the cached base pointers of one renderer kind ("SSGI/", "SHADOW/", "RTR/"): dropped when the caller binds other handles than last frame
+void forget_surfaces(KjSplit& s, const char* prefix) {
+    for (auto it = s.surfaces.begin(); it != s.surfaces.end();) it = it->first.second.rfind(prefix, 0) == 0 ? s.surfaces.erase(it) : std::next(it);
 }
 
 KjStatus surface_of(KjSplit& s, uint32_t rank, const std::string& name, uint8_t** out, uint32_t* row_bytes) {
@@ -263,12 +270,14 @@ KjStatus gather_strip_lists(KjSplit& s, const std::vector<uint32_t>& n_strip, st
     for (uint32_t p = 0; p < s.world; ++p)
         if (p != me && s.peer_lists[p].bytes < size_t(all_strip[p]) * RQ) KJ_TRY_HIP(s.peer_lists[p].alloc(size_t(all_strip[p]) * RQ + 4096, st));
     KJ_REQUIRE(g_rccl.GroupStart() == 0, "ncclGroupStart failed");
-    for (uint32_t p = 0; p < s.world; ++p) {
+    bool ok = true;      // an error inside the group must not return before ncclGroupEnd: the peers would block in their receives
+    for (uint32_t p = 0; p < s.world && ok; ++p) {
         if (p == me) continue;
-        if (all_strip[me]) KJ_REQUIRE(g_rccl.Send(s.strip_list[0].p, size_t(all_strip[me]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclSend failed");
-        if (all_strip[p]) KJ_REQUIRE(g_rccl.Recv(s.peer_lists[p].p, size_t(all_strip[p]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclRecv failed");
+        if (all_strip[me]) ok = ok && g_rccl.Send(s.strip_list[0].p, size_t(all_strip[me]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0;
+        if (all_strip[p]) ok = ok && g_rccl.Recv(s.peer_lists[p].p, size_t(all_strip[p]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0;
     }
-    KJ_REQUIRE(g_rccl.GroupEnd() == 0, "ncclGroupEnd failed");
+    const bool ended = g_rccl.GroupEnd() == 0;
+    KJ_REQUIRE(ok && ended, "ncclSend / ncclRecv / ncclGroupEnd failed");
     return KJ_OK;
 }
 
@@ -294,6 +303,7 @@ KjStatus assemble_lists(KjSplit& s, uint32_t li, const std::vector<uint32_t>& al
 // on every rank and stay local. Merged order = every rank's strip records in rank order, then the cache's own (multigpu.py).
 KjStatus merge_ircache_requests(KjSplit& s, hipStream_t st) {
     const size_t RQ = 32;
+    s.merge_pending = false;
     std::vector<uint32_t> n_strip(s.local), n_irc(s.local), cap_strip(s.local), cap_irc(s.local);
     for (uint32_t li = 0; li < s.local; ++li) {
         KjIrcache* c = s.ranks[li].ircache;
@@ -379,7 +389,10 @@ void kj_split_destroy(KjSplit* s) {
     if (!s) return;
     // hand the caches back in the mode they came in: a plain kj_rtdgi_render caller would otherwise keep RECORDING lookups that nobody replays
     for (size_t i = 0; i < s->ranks.size() && i < s->ircache_was_deferred.size(); ++i)
-        if (s->ranks[i].ircache) kj_ircache_set_deferred_updates(s->ranks[i].ircache, s->ircache_was_deferred[i]);
+        if (s->ranks[i].ircache) {
+            kj_ircache_set_deferred_updates(s->ranks[i].ircache, s->ircache_was_deferred[i]);
+            if (s->rtr_requests_set) kj_ircache_set_rtr_requests(s->ranks[i].ircache, 0);      // back to the two-range slot layout a plain kj_rtdgi_render caller expects
+        }
     delete s;
 }
 
@@ -396,6 +409,9 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
     KJ_REQUIRE(s && frames, "null argument");
     const bool ircache_done = (flags & KJ_SPLIT_IRCACHE_DONE) != 0, defer_merge = (flags & KJ_SPLIT_DEFER_IRCACHE_MERGE) != 0;
     hipStream_t st = (hipStream_t)stream;
+    // a frame whose recorded lookups were never replayed (kj_split_rtr_frame / kj_split_merge_ircache left out) would silently stop the caches
+    // from allocating and refreshing entries
+    KJ_REQUIRE(!s->merge_pending, "the previous frame's recorded cache updates were never replayed: call kj_split_rtr_frame or kj_split_merge_ircache before the next kj_split_gi_frame");
     const uint32_t KEEP = KJ_RTDGI_PASS_KEEP_TEMPORALS, M = s->motion_halo;
     const uint32_t out_i = s->frame % 2, hist_i = 1 - s->frame % 2;
     std::vector<Item> items;
@@ -435,6 +451,7 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
     }
     KJ_SPLIT_TRY(exchange(*s, items, st));
     for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_TRACE | KEEP, s->strips[s->first + li], 0, st));
+    if (s->consistent_ircache) s->merge_pending = true;
     if (s->consistent_ircache && !defer_merge && !s->with_rtr) KJ_SPLIT_TRY(merge_ircache_requests(*s, st));      // (with reflections in the frame: after THEIR ray passes)
     if (trace_done_event) KJ_TRY_HIP(hipEventRecord((hipEvent_t)trace_done_event, st));
     // ---- C
@@ -473,6 +490,7 @@ KjStatus kj_split_merge_ircache(KjSplit* s, void* stream) {
 KjStatus kj_split_ssgi_frame(KjSplit* s, KjSsgi* const* ssgi, const KjSplitFrame* frames, const void** out_ssao_r8, void* stream) {
     KJ_REQUIRE(s && ssgi && frames && out_ssao_r8, "null argument");
     hipStream_t st = (hipStream_t)stream;
+    if (s->ssgi.size() != s->local || !std::equal(s->ssgi.begin(), s->ssgi.end(), ssgi)) forget_surfaces(*s, "SSGI/");     // another renderer handle: its surfaces live elsewhere
     s->ssgi.assign(ssgi, ssgi + s->local);
     for (KjSsgi* g : s->ssgi) KJ_REQUIRE(g, "null SsgiRenderer");
     if (s->ssgi_frames > 0) KJ_SPLIT_TRY(exchange(*s, {{sfx("SSGI/ssgi", 1 - s->ssgi_frames % 2), int(s->motion_halo + 2)}}, st));
@@ -494,6 +512,7 @@ KjStatus kj_split_shadow_frame(KjSplit* s, KjShadowDenoise* const* denoisers, co
                                const void** out_rg16f, void* stream) {
     KJ_REQUIRE(s && denoisers && frames && mask_r8 && out_rg16f, "null argument");
     hipStream_t st = (hipStream_t)stream;
+    if (s->shadow.size() != s->local || !std::equal(s->shadow.begin(), s->shadow.end(), denoisers)) forget_surfaces(*s, "SHADOW/");
     s->shadow.assign(denoisers, denoisers + s->local);
     for (uint32_t li = 0; li < s->local; ++li) {
         KJ_REQUIRE(s->shadow[li] && mask_r8[li], "null ShadowDenoiseRenderer / mask image");
@@ -523,6 +542,7 @@ KjStatus kj_split_set_rtr(KjSplit* s, uint32_t enable) {
     KJ_REQUIRE(s, "null argument");
     s->with_rtr = enable != 0;
     if (s->consistent_ircache) for (const KjSplitRank& r : s->ranks) KJ_SPLIT_TRY(kj_ircache_set_rtr_requests(r.ircache, enable));
+    s->rtr_requests_set = s->consistent_ircache && enable != 0;
     return KJ_OK;
 }
 
@@ -537,6 +557,7 @@ KjStatus kj_split_rtr_frame(KjSplit* s, KjRtr* const* rtr, const KjRtrParams* rt
     KJ_REQUIRE(s && rtr && rtr_params, "null argument");
     KJ_REQUIRE(s->with_rtr, "kj_split_set_rtr(split, 1) comes first (before the frame's kj_ircache_begin_requests)");
     hipStream_t st = (hipStream_t)stream;
+    if (s->rtr.size() != s->local || !std::equal(s->rtr.begin(), s->rtr.end(), rtr)) forget_surfaces(*s, "RTR/");
     s->rtr.assign(rtr, rtr + s->local);
     for (KjRtr* r : s->rtr) KJ_REQUIRE(r, "null RtrRenderer");
     const bool lights = (flags & KJ_SPLIT_RTR_SPECULAR_LIGHTS) != 0, defer_merge = (flags & KJ_SPLIT_DEFER_IRCACHE_MERGE) != 0;

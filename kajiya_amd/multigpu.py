@@ -821,9 +821,11 @@ class NativeSplit:
     `pipes`: {rank: GpuPipeline} for the ranks living in this process -- all `world` of them (virtual ranks on one device), or one
     together with `nccl_comm` (an ncclComm_t as an integer: NativeSplit.rccl_comm_from_torch makes one)."""
 
-    def __init__(self, world, pipes, width, height, motion_halo=8, nccl_comm=None):
+    def __init__(self, world, pipes, width, height, motion_halo=8, nccl_comm=None, own_comm=True):
+        """`own_comm`: close() also destroys `nccl_comm` (the usual case: rccl_comm_from_torch made it for this object)."""
         from .abi import KjSplitRank, KjSplitFrame
         self.L = klib.load()
+        self._own_comm = nccl_comm if (own_comm and nccl_comm) else None
         self.pipes = pipes
         self.ranks = sorted(pipes)
         self.W, self.H = width, height
@@ -842,9 +844,23 @@ class NativeSplit:
         self.with_rtr = False
         self.strips = [self.strip(r) for r in range(world)]
 
+    def close(self):
+        """Destroys the orchestrator NOW (kj_split_destroy hands the caches back in the mode they came in) and its RCCL communicator, if this
+        object made one. A caller that falls back to another orchestrator must not leave this to the garbage collector: a late destroy would
+        flip the caches' update mode under the other one's feet."""
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self.L.kj_split_destroy(h)
+        comm, self._own_comm = getattr(self, "_own_comm", None), None
+        if comm:
+            try:
+                self.L.kj_split_rccl_comm_destroy(comm)
+            except Exception:
+                pass
+
     def __del__(self):
         try:
-            self.L.kj_split_destroy(self.h)
+            self.close()
         except Exception:
             pass
 
