@@ -309,6 +309,11 @@ enum {
     KJ_RTDGI_PASS_TEMPORAL_FILTER = 1u << 7,
     KJ_RTDGI_PASS_SPATIAL_FILTER = 1u << 8,
     KJ_RTDGI_PASS_ALL = 0x1ffu,
+    /* Scheduling aids for a host that computes the SSAO guide on another stream while the ray passes run (nothing before `restir spatial`
+     * reads the half-res SSAO): with _NO_SSAO the extract pass leaves the SSAO out; _SSAO_ONLY (its own call, after the guide is done and
+     * before `restir spatial`) adds it. Together they write exactly what KJ_RTDGI_PASS_EXTRACT_HALF alone writes. */
+    KJ_RTDGI_PASS_EXTRACT_HALF_NO_SSAO = 1u << 9,
+    KJ_RTDGI_PASS_EXTRACT_HALF_SSAO_ONLY = 1u << 10,
     /* Debug: re-use the previous call's ping-pong assignment instead of advancing it, so a frame can be
      * executed pass by pass (render-graph debug hook analogue). Never set on the product path. */
     KJ_RTDGI_PASS_KEEP_TEMPORALS = 1u << 31

@@ -50,6 +50,10 @@ typedef Img<float4> ImgF4;
 // ------------------------------------------------------------------ extract_half_res_{gbuffer_view_normal_rgba8,depth,ssao}.hlsl (fused)
 // Besides the reference's three half-res images this writes them once more as ONE 8-byte record per pixel
 // {depth bits, view normal snorm8 x3 | ssao snorm8 << 24}: what the resampling passes stage in LDS / fetch per tap (rtdgi_resample.hip).
+// SSAO_MODE 0: all three (the reference's pass); 1: everything but the SSAO (the record keeps a zero in its SSAO byte); 2: only the SSAO, into
+// the image and the record's byte -- the two halves of a frame whose SSAO guide is still being computed on another stream while the ray
+// passes run (KJ_RTDGI_PASS_EXTRACT_HALF_NO_SSAO / _SSAO_ONLY: nothing before `restir spatial` reads the half-res SSAO)
+template <int SSAO_MODE>
 __global__ void __launch_bounds__(64) k_extract_half(const FrameConstants* __restrict__ fcp, ImgU4 gbuffer, ImgF32 depth, ImgR8 ssao, ImgU32 half_view_normal,
                                                       ImgF32 half_depth, ImgR8S half_ssao, ImgU2 half_gbuf, int row0, int row1) {
     TILE_XY_M(half_depth.w, half_depth.h, KJ_TILES_ROWS)
@@ -57,14 +61,20 @@ __global__ void __launch_bounds__(64) k_extract_half(const FrameConstants* __res
     const FrameConstants& fc = *fcp;
     const I2 off = halfres_subsample_offset(fc.frame_index);
     const int sx = x * 2 + off.x, sy = y * 2 + off.y;
+    if (SSAO_MODE == 2) {
+        const int8_t ao = to_snorm8(from_unorm8(ssao.ld(sx, sy)));
+        half_ssao.st(x, y, ao);
+        ((uint8_t*)half_gbuf.p)[(size_t(y) * half_gbuf.w + x) * 8 + 7] = uint8_t(ao);
+        return;
+    }
     const V3 normal_ws = unpack_normal_11_10_11_no_normalize(gbuffer.ld(sx, sy).y);
     const V3 normal_vs = normalize(xyz(mul44(fc.view_constants.world_to_view, v4(normal_ws, 0))));
     const uint32_t packed_normal = pack_rgba8_snorm(v4(normal_vs, 1.0f));
     const float d = depth.ld(sx, sy);
-    const int8_t ao = to_snorm8(from_unorm8(ssao.ld(sx, sy)));
+    const int8_t ao = SSAO_MODE == 1 ? int8_t(0) : to_snorm8(from_unorm8(ssao.ld(sx, sy)));
     half_view_normal.st(x, y, packed_normal);
     half_depth.st(x, y, d);
-    half_ssao.st(x, y, ao);
+    if (SSAO_MODE == 0) half_ssao.st(x, y, ao);
     half_gbuf.st(x, y, make_uint2(asuint(d), (packed_normal & 0x00ffffffu) | (uint32_t(uint8_t(ao)) << 24)));
 }
 
@@ -852,9 +862,9 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     // out as waves retire instead of all at once (160 KB of LDS per CU, four SIMDs)
     if (r->ray_waves_per_simd) trace_lds = std::max(trace_lds, (size_t(160 * 1024) / (4u * r->ray_waves_per_simd)) & ~size_t(255));
 
-    if (mask & KJ_RTDGI_PASS_EXTRACT_HALF) {
+    if (mask & (KJ_RTDGI_PASS_EXTRACT_HALF | KJ_RTDGI_PASS_EXTRACT_HALF_SSAO_ONLY)) {
         SCOPE_BEGIN(1);
-        hipLaunchKernelGGL(k_extract_half, gh, blk, 0, s, fc, gbuffer, depth, ssao, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), img<int8_t>(half_ssao, hw, hh), img<uint2>(half_gbuf, hw, hh), hr0, hr1);
+        hipLaunchKernelGGL((mask & KJ_RTDGI_PASS_EXTRACT_HALF_SSAO_ONLY) ? k_extract_half<2> : (mask & KJ_RTDGI_PASS_EXTRACT_HALF_NO_SSAO) ? k_extract_half<1> : k_extract_half<0>, gh, blk, 0, s, fc, gbuffer, depth, ssao, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), img<int8_t>(half_ssao, hw, hh), img<uint2>(half_gbuf, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(1);
     }

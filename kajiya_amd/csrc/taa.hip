@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(64) k_taa_reproject(const FrameConstants* __re
 // filter_input.hlsl:33-88. The shader calls filter_input_inner twice over the same 3x3 taps (first with an infinite
 // luma cutoff, then with 1.001x the first pass' luma); here the taps are decoded once and kept in registers, and
 // pow(x, 8) is three squarings.
-__global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32 depth_tex, ImgH4 output_tex, ImgH4 dev_output_tex, int row0, int row1) {
+KJ_D void taa_filter_input_body(const ImgH4& input_tex, const ImgF32& depth_tex, const ImgH4& output_tex, const ImgH4& dev_output_tex, int row0, int row1) {
     TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     // LDS-staged 10x10 tile: .xyz = decoded YCbCr of the input texel, .w = depth (one decode per texel instead of nine)
     __shared__ float4 tile[10 * 10];
@@ -165,6 +165,9 @@ __global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32
     st4(output_tex, x, y, v4(cex, 0.0f));
     st4(dev_output_tex, x, y, v4(vsqrt(var_a), 0.0f));
 }
+__global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32 depth_tex, ImgH4 output_tex, ImgH4 dev_output_tex, int row0, int row1) {
+    taa_filter_input_body(input_tex, depth_tex, output_tex, dev_output_tex, row0, row1);
+}
 
 // filter_history.hlsl:15-61. Same two-pass structure as filter_input; K = 1 unless the history is > 1.75x the input extent.
 template <int K, bool UNCUT>
@@ -184,7 +187,7 @@ KJ_D V3 fh_filter_input(const V3* taps, float luma_cutoff) {
     return iex / iwsum;
 }
 template <int K, bool TILED>
-__global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_history, ImgH4 output_tex, int row0, int row1) {
+KJ_D void taa_filter_history_body(const ImgH4& reprojected_history, const ImgH4& output_tex, int row0, int row1) {
     TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     constexpr int TW = 8 + 2 * K;
     __shared__ float4 tile[TILED ? TW * TW : 1];
@@ -213,6 +216,18 @@ __global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_his
     }
     const float filtered_luma = fh_filter_input<K, true>(taps, 1e10f).x;
     st4(output_tex, x, y, v4(fh_filter_input<K, false>(taps, filtered_luma * 1.001f), 0.0f));
+}
+template <int K, bool TILED>
+__global__ void __launch_bounds__(64) k_taa_filter_history(ImgH4 reprojected_history, ImgH4 output_tex, int row0, int row1) {
+    taa_filter_history_body<K, TILED>(reprojected_history, output_tex, row0, row1);
+}
+// "taa filter input" + "taa filter history" in ONE launch (same extent: both stencils are centred on the wave's tile): two independent
+// passes of the reference's seven on the same tiles -- five launches per TAA frame instead of six; each half is its own function, so
+// the early exit of a lane outside the image leaves only that half.
+__global__ void __launch_bounds__(64) k_taa_filter_input_and_history(ImgH4 input_tex, ImgF32 depth_tex, ImgH4 filtered_input, ImgH4 filtered_input_dev, ImgH4 reprojected_history,
+                                                                      ImgH4 filtered_history, int row0, int row1) {
+    taa_filter_input_body(input_tex, depth_tex, filtered_input, filtered_input_dev, row0, row1);
+    taa_filter_history_body<1, true>(reprojected_history, filtered_history, row0, row1);
 }
 
 // input_prob.hlsl:50-108
@@ -546,11 +561,17 @@ static KjStatus taa_render_impl(KjTaa* t, const void* input_tex, uint32_t input_
         hipLaunchKernelGGL(k_taa_reproject, go, blk, 0, s, fc, img<uint2>(history, OW, OH), reproj, depth, img<uint2>(reprojected_history, OW, OH), img<uint32_t>(closest_velocity, OW, OH), IW, IH, or0, or1);
         KJ_CHECK_LAUNCH();
     }
-    if (mask & 2u) {
+    const bool both_input_filters = t->merge_prob_filters && (mask & 6u) == 6u && OW == IW && OH == IH;     // same extent, both passes: one launch
+    if (both_input_filters) {
+        hipLaunchKernelGGL(k_taa_filter_input_and_history, gi, blk, 0, s, input, depth, img<uint2>(filtered_input, IW, IH), img<uint2>(filtered_input_dev, IW, IH),
+                           img<uint2>(reprojected_history, OW, OH), img<uint2>(filtered_history, IW, IH), ir0, ir1);
+        KJ_CHECK_LAUNCH();
+    }
+    if ((mask & 2u) && !both_input_filters) {
         hipLaunchKernelGGL(k_taa_filter_input, gi, blk, 0, s, input, depth, img<uint2>(filtered_input, IW, IH), img<uint2>(filtered_input_dev, IW, IH), ir0, ir1);
         KJ_CHECK_LAUNCH();
     }
-    if (mask & 4u) {
+    if ((mask & 4u) && !both_input_filters) {
         const ImgH4 rh = img<uint2>(reprojected_history, OW, OH), fh = img<uint2>(filtered_history, IW, IH);
         if (float(OW) / float(IW) > 1.75f) hipLaunchKernelGGL((k_taa_filter_history<2, false>), gi, blk, 0, s, rh, fh, ir0, ir1);
         else if (OW == IW && OH == IH) hipLaunchKernelGGL((k_taa_filter_history<1, true>), gi, blk, 0, s, rh, fh, ir0, ir1);

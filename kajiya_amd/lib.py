@@ -444,12 +444,26 @@ class GpuPipeline:
         # everything that does not read the cache goes first: the wait for the cache stream sits in the frame-to-frame critical
         # cycle (this frame's ray passes -> next frame's cache rays -> next frame's ray passes); measured -1.6 % per frame
         s0.wait_event(self._ev_fc[i])
-        if run_ssgi:
+        # The SSAO guide (VALU-bound, ~0.1 ms at 1080p) on a stream of its own UNDER the ray passes (latency-bound): nothing before
+        # `restir spatial` reads it, so the half-res extract leaves the SSAO out here and adds it behind `restir temporal`
+        # (KJ_RTDGI_PASS_EXTRACT_HALF_NO_SSAO / _SSAO_ONLY). KJ_SSGI_OVERLAP=0: first on the main stream, as until round 3.
+        overlap_ssgi = run_ssgi and os.environ.get("KJ_SSGI_OVERLAP", "1") != "0"
+        if run_ssgi and not overlap_ssgi:
             self.ssgi_frame()
+        if overlap_ssgi:
+            if not hasattr(self, "_s3"):
+                self._s3 = torch.cuda.Stream()
+                self._ev_ssgi = [torch.cuda.Event(), torch.cuda.Event()]
+            with torch.cuda.stream(self._s3):
+                self._s3.wait_event(self._ev_fc[i])
+                if self._pipe_i > 0:
+                    self._s3.wait_event(self._ev_gi[1 - i])      # last frame's resolve / filters have read the guide image this call overwrites... (double-buffered: two frames back)
+                self.ssgi_frame()
+                self._ev_ssgi[i].record(self._s3)
         s = _stream_ptr()
         P = KJ_RTDGI_PASS
         check(self.L.kj_rtdgi_reproject(self.rtdgi, self.reprojection_map_ptr, self.W, self.H, s))
-        p = self.params(P["EXTRACT_HALF"])
+        p = self.params(P["EXTRACT_HALF"] | (P["EXTRACT_HALF_NO_SSAO"] if overlap_ssgi else 0))
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
         s0.wait_event(self._ev_irc[i])
         check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
@@ -459,7 +473,15 @@ class GpuPipeline:
         self._ev_trace[i].record(s0)
         if self._pipe_i > 0:
             s0.wait_event(self._ev_taa[1 - i])           # last frame's spatial filter has consumed temporal_filtered_tex
-        p = self.params((P["ALL"] & ~head & ~P["SPATIAL_FILTER"]) | (1 << 31))
+        if overlap_ssgi:
+            p = self.params(P["VALIDITY_INTEGRATE"] | P["RESTIR_TEMPORAL"] | (1 << 31))
+            check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+            s0.wait_event(self._ev_ssgi[i])
+            p = self.params(P["EXTRACT_HALF_SSAO_ONLY"] | (1 << 31))       # params() picks up this frame's guide pointer (ssgi_frame set it)
+            check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+            p = self.params((P["ALL"] & ~head & ~P["SPATIAL_FILTER"] & ~P["VALIDITY_INTEGRATE"] & ~P["RESTIR_TEMPORAL"]) | (1 << 31))
+        else:
+            p = self.params((P["ALL"] & ~head & ~P["SPATIAL_FILTER"]) | (1 << 31))
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
         self._ev_gi[i].record(s0)
         p = self.params(P["SPATIAL_FILTER"] | (1 << 31))      # captures this frame's inputs (guide N, depth N) now

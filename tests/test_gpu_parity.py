@@ -746,3 +746,26 @@ def test_thousands_of_instances_get_a_device_built_top_tree(gpu, oracle, device)
     gpu.check(L.kj_scene_set_top_build_mode(gsc.h, 1))      # ... and back on the host when told to
     gsc.commit()
     assert gsc.top_tree_info()["device"] is False
+
+
+def test_extract_half_in_two_parts_writes_what_the_single_pass_writes(gpu, device):
+    """KJ_RTDGI_PASS_EXTRACT_HALF_NO_SSAO followed by KJ_RTDGI_PASS_EXTRACT_HALF_SSAO_ONLY (the pipelined frame computes the SSAO guide on its
+    own stream under the ray passes and adds it behind `restir temporal`) == KJ_RTDGI_PASS_EXTRACT_HALF, byte for byte."""
+    import torch
+    from kajiya_amd.abi import KJ_RTDGI_PASS as P
+    W, H = 123, 77
+    desc = _scenes()["city20k"]
+    scene = gpu.Scene(device, desc)
+    a, b = gpu.GpuPipeline(device, scene, W, H), gpu.GpuPipeline(device, scene, W, H)
+    for fc in _frame_constants(W, H, 3, "city"):
+        for gp in (a, b):
+            gp.render_inputs(fc); gp.reprojection(); gp.ssgi_frame()
+            gpu.check(gp.L.kj_rtdgi_reproject(gp.rtdgi, gp.reprojection_map_ptr, W, H, None))
+        pa = a.params(P["EXTRACT_HALF"]); gpu.check(a.L.kj_rtdgi_render(a.rtdgi, C.byref(pa), C.byref(a.out), None))
+        pb = b.params(P["EXTRACT_HALF"] | P["EXTRACT_HALF_NO_SSAO"]); gpu.check(b.L.kj_rtdgi_render(b.rtdgi, C.byref(pb), C.byref(b.out), None))
+        torch.cuda.synchronize()
+        assert not torch.equal(a.surface("half_gbuf", torch.uint8, (-1,)), b.surface("half_gbuf", torch.uint8, (-1,)))      # the guide is not constant: the byte matters
+        pb = b.params(P["EXTRACT_HALF_SSAO_ONLY"] | KEEP); gpu.check(b.L.kj_rtdgi_render(b.rtdgi, C.byref(pb), C.byref(b.out), None))
+        torch.cuda.synchronize()
+        for n in ("half_gbuf", "half_ssao_tex", "half_view_normal_tex", "half_depth_tex"):
+            assert torch.equal(a.surface(n, torch.uint8, (-1,)), b.surface(n, torch.uint8, (-1,))), n
