@@ -446,8 +446,10 @@ class GpuPipeline:
         s0.wait_event(self._ev_fc[i])
         # The SSAO guide (VALU-bound, ~0.1 ms at 1080p) on a stream of its own UNDER the ray passes (latency-bound): nothing before
         # `restir spatial` reads it, so the half-res extract leaves the SSAO out here and adds it behind `restir temporal`
-        # (KJ_RTDGI_PASS_EXTRACT_HALF_NO_SSAO / _SSAO_ONLY). KJ_SSGI_OVERLAP=0: first on the main stream, as until round 3.
-        overlap_ssgi = run_ssgi and os.environ.get("KJ_SSGI_OVERLAP", "1") != "0"
+        # (KJ_RTDGI_PASS_EXTRACT_HALF_NO_SSAO / _SSAO_ONLY). Measured on MI355X (round 4, A/B/A/B in one lease): 1080p 1.002-1.009 ms against
+        # 1.018-1.023 ms with the guide first on the main stream (-1.5 %); at 4K the ray passes are issue-bound (VALUBusy 82 %) and the guide
+        # under them costs 2 % (3.55 vs 3.48 ms). Hence: on up to 1080p-sized frames, off above; KJ_SSGI_OVERLAP=0 / 1 forces it.
+        overlap_ssgi = run_ssgi and os.environ.get("KJ_SSGI_OVERLAP", "1" if self.W * self.H <= 1920 * 1200 else "0") != "0"
         if run_ssgi and not overlap_ssgi:
             self.ssgi_frame()
         if overlap_ssgi:

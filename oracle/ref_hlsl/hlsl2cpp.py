@@ -332,8 +332,13 @@ class Rewriter:
                 if t.text == "." and n is not None and T[n].kind == "id":
                     name = T[n].text
                     m = re.match(r"^_([1-4])([1-4])$", name)
+                    mm = re.match(r"^(?:_m[0-3][0-3]){1,4}$", name) or re.match(r"^(?:_[1-4][1-4]){2,4}$", name)
                     if m:
                         T[n].text = "e(%d, %d)" % (int(m.group(1)) - 1, int(m.group(2)) - 1)
+                    elif mm:          # matrix swizzles: `_m00_m11` (zero-based) / `_11_22` (one-based) -> one element, or a vector of them
+                        zero = name.startswith("_m")
+                        rc = [(int(a) - (0 if zero else 1), int(b) - (0 if zero else 1)) for a, b in re.findall(r"_m?([0-4])([0-4])", name)]
+                        T[n].text = ("e(%d, %d)" % rc[0]) if len(rc) == 1 else "msw%d(%s)" % (len(rc), ", ".join("%d, %d" % x for x in rc))
                     elif re.match(r"^(x{2,4}|r{2,4})$", name) and not (p is not None and T[p].text == "this"):
                         t.text = "->*"
                         T[n].text = "hlsl::_sw%d" % len(name)

@@ -384,6 +384,9 @@ template <int R, int C> struct matrix {
     vec<float, C> operator[](int r) const { vec<float, C> v; for (int c = 0; c < C; ++c) v.d[c] = m[c][r]; return v; }
     float& e(int r, int c) { return m[c][r]; }
     float e(int r, int c) const { return m[c][r]; }
+    vec<float, 2> msw2(int r0, int c0, int r1, int c1) const { return vec<float, 2>(m[c0][r0], m[c1][r1]); }          // M._m00_m11
+    vec<float, 3> msw3(int r0, int c0, int r1, int c1, int r2, int c2) const { return vec<float, 3>(m[c0][r0], m[c1][r1], m[c2][r2]); }
+    vec<float, 4> msw4(int r0, int c0, int r1, int c1, int r2, int c2, int r3, int c3) const { return vec<float, 4>(m[c0][r0], m[c1][r1], m[c2][r2], m[c3][r3]); }
 };
 typedef matrix<2, 2> float2x2; typedef matrix<3, 3> float3x3; typedef matrix<4, 4> float4x4; typedef matrix<3, 4> float3x4; typedef matrix<4, 3> float4x3;
 template <int R, int C, class V, HLSL_REQ(VT<V>::isvec && VT<V>::n == C)> static inline vec<float, R> mul(const matrix<R, C>& M, const V& v_) {
