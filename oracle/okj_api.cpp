@@ -566,6 +566,7 @@ void* okj_rtr_create(const uint8_t* blue_noise_rgba8_256, const void* brdf_fg_lu
 }
 void okj_rtr_destroy(void* p) { delete (OkjRtr*)p; }
 void okj_rtr_set_options(void* p, uint32_t reuse_rtdgi_rays) { ((OkjRtr*)p)->r.reuse_rtdgi_rays = reuse_rtdgi_rays != 0; }
+void okj_rtr_set_literal_own_sample_shadowing(void* p, uint32_t on) { ((OkjRtr*)p)->r.literal_own_sample_shadowing = on != 0; }
 static RtrInputs okj_rtr_inputs(OkjRtr* o, const KjFrameConstants* fc, const KjRtrParams* params) {
     RtrInputs in;
     const int W = params->gbuffer_depth.width, H = params->gbuffer_depth.height, hw = (W + 1) / 2, hh = (H + 1) / 2;

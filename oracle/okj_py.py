@@ -99,6 +99,7 @@ def lib():
         L.okj_rtr_create.restype = C.c_void_p; L.okj_rtr_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(KjRtrTables)]
         L.okj_rtr_destroy.argtypes = [C.c_void_p]
         L.okj_rtr_set_options.argtypes = [C.c_void_p, C.c_uint32]
+        L.okj_rtr_set_literal_own_sample_shadowing.argtypes = [C.c_void_p, C.c_uint32]
         L.okj_rtr_trace.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.POINTER(KjRtrParams)]
         L.okj_rtr_filter_temporal.restype = C.c_void_p; L.okj_rtr_filter_temporal.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.POINTER(KjRtrParams)]
         L.okj_rtr_surface.restype = C.c_int; L.okj_rtr_surface.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]

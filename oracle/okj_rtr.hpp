@@ -81,6 +81,7 @@ struct Rtr {
     int W = 0, H = 0, hw = 0, hh = 0;
     bool flip[8] = {false, false, false, false, false, false, false, false};
     bool reuse_rtdgi_rays = true;                               // rtr.rs:32,70
+    bool literal_own_sample_shadowing = false;                  // test knob (tests/test_ref_hlsl.py): resolve.hlsl:535-540 as written, residues and all (see the header)
     std::atomic<uint64_t> rays_closest{0}, rays_any{0};
     f3 sun_color;
 
@@ -602,7 +603,7 @@ struct Rtr {
                     // gives the shader 0/0 = NaN (comparison false, no rejection), a 1-ulp residue gives it a random direction. Residues are
                     // treated as zero (see the header): real neighbours are >= a pixel footprint (~4e-3 x distance) apart.
                     const float surface_offset_len = length(surface_offset);
-                    if (surface_offset_len > 1e-5f * eye_to_surf_dist &&
+                    if ((literal_own_sample_shadowing || surface_offset_len > 1e-5f * eye_to_surf_dist) &&
                         dot(center_to_hit_vs, normal_vs) * 0.2f / length(center_to_hit_vs) < dot(surface_offset, normal_vs) / surface_offset_len)
                         rejection_bias *= is_center_sample ? 1.0f : 0.0f;
                     const BrdfValue spec = specular_brdf.evaluate(wo, wi);

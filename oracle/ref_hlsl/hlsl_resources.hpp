@@ -27,10 +27,12 @@ static inline float unorm_to_f(uint v, uint maxv) { return float(v) / float(maxv
 static inline uint f_to_unorm(float v, uint maxv) { if (!(v == v)) v = 0.0f; v = std::fmin(std::fmax(v, 0.0f), 1.0f); return uint(std::nearbyint(v * float(maxv))); }
 static inline float snorm_to_f(int v, int maxv) { return std::fmax(float(v) / float(maxv), -1.0f); }
 static inline int f_to_snorm(float v, int maxv) { if (!(v == v)) v = 0.0f; v = std::fmin(std::fmax(v, -1.0f), 1.0f); return int(std::nearbyint(v * float(maxv))); }
-// unsigned small floats (B10G11R11_UFLOAT): stores round to nearest even THROUGH fp16; negative -> 0
-static inline uint f_to_uf(float v, int mbits) { const uint h = f32tof16_(v); if (h & 0x8000u) return 0u; if (h > 0x7c00u) return 0x7c00u >> (10 - mbits);
-    const uint drop = 10 - mbits; uint r = h >> drop; const uint rem = h & ((1u << drop) - 1u), half_ = 1u << (drop - 1);
-    if (rem > half_ || (rem == half_ && (r & 1u))) ++r; return r; }
+// unsigned small floats (B10G11R11_UFLOAT): the format conversion is the API's, not the shaders' text; this is the definition the oracle and the
+// kernels share (okj::f32_to_ufloat): through fp16 (RTE), then the dropped mantissa bits round half up; finite values saturate at
+// the largest finite one, +inf stays inf, negative / zero / NaN -> 0
+static inline uint f_to_uf(float v, int mbits) { if (!(v > 0.0f)) return 0u; const uint h = f32tof16_(v) & 0x7fffu; const uint drop = 10 - mbits;
+    const uint r = (h + (1u << (drop - 1))) >> drop; const uint max_finite = (30u << mbits) | ((1u << mbits) - 1u);
+    if (h >= 0x7c00u) return 31u << mbits; return r > max_finite ? max_finite : r; }
 static inline float uf_to_f(uint v, int mbits) { return f16tof32_(v << (10 - mbits)); }
 
 // Texel <-> four 32-bit lanes. Float formats go through float4, integer formats through uint4; a float view of a 32-bit float
@@ -203,9 +205,10 @@ template <class T> struct TextureCube : ResourceBase {
     template <class D> T SampleLevel(const SamplerState& s, const D& dir_, float) const {
         const float3 d(dir_); const float ax = std::fabs(d.x), ay = std::fabs(d.y), az = std::fabs(d.z);
         int face; float sc, tc, ma;
-        if (ax >= ay && ax >= az) { face = d.x >= 0 ? 0 : 1; sc = d.x >= 0 ? -d.z : d.z; tc = -d.y; ma = ax; }
-        else if (ay >= az) { face = d.y >= 0 ? 2 : 3; sc = d.x; tc = d.y >= 0 ? d.z : -d.z; ma = ay; }
-        else { face = d.z >= 0 ? 4 : 5; sc = d.z >= 0 ? d.x : -d.x; tc = -d.y; ma = az; }
+        // Vulkan "Cube Map Face Selection": on ties rz wins over ry and rx, ry over rx
+        if (az >= ax && az >= ay) { face = d.z >= 0 ? 4 : 5; sc = d.z >= 0 ? d.x : -d.x; tc = -d.y; ma = az; }
+        else if (ay >= ax) { face = d.y >= 0 ? 2 : 3; sc = d.x; tc = d.y >= 0 ? d.z : -d.z; ma = ay; }
+        else { face = d.x >= 0 ? 0 : 1; sc = d.x >= 0 ? -d.z : d.z; tc = -d.y; ma = ax; }
         const float u = 0.5f * (sc / ma + 1.0f), v = 0.5f * (tc / ma + 1.0f);
         Texture2D<T> f; f.data = (uint8_t*)data + size_t(face) * size_t(w) * size_t(w) * size_t(format_bytes(fmt)); f.w = w; f.h = w; f.fmt = fmt;
         SamplerState cl = s; cl.address = 0;

@@ -799,3 +799,152 @@ def test_light_gbuffer_reference_hlsl_vs_oracle(oracle, libm_sincos):
                    [g, np.uint32(0), np.uint32(0)], fc, (W, H, 1))
         _check(P.compare(t_out.raw, ref_t.view(np.uint8).reshape(-1), "rgba16f"), f"frame {fi} light_gbuffer temporal_output")
         _check(P.compare(o_out.raw, ref_o.view(np.uint8).reshape(-1), "rgba16f"), f"frame {fi} light_gbuffer output")
+
+
+# ---------------------------------------------------------------------------------------------------------------- reflections
+RTR_PINGPONG = ["rtr.temporal", "rtr.ray_len", "rtr.irradiance", "rtr.ray_orig", "rtr.ray", "rtr.reservoir", "rtr.rng", "rtr.hit_normal"]
+RTR_NAMES = [n + s for n in RTR_PINGPONG for s in (":0", ":1")] + ["refl_restir_invalidity_tex", "resolved_tex"]
+RTR_CANDIDATES = ["candidate_radiance_tex", "candidate_hit_tex", "candidate_normal_tex"]
+RTR_PASS_ORDER = ["TRACE", "VALIDATE", "RESTIR_TEMPORAL", "RESOLVE", "TEMPORAL_FILTER", "CLEANUP"]
+_RTR_TEX_FMT = {"u32": "r32ui", "rtr_ray_orig": "rgba32f"}       # parity.py's names for the rng image and RtrRestirRayOrigin (RGBA32F, rtr.rs:160-169)
+
+
+def _rtr_state(op):
+    st = {n: op.rtr_surface(n, np.uint8, (-1,)).copy() for n in RTR_NAMES}
+    st.update({n: op.surface(n, np.uint8, (-1,)).copy() for n in RTR_CANDIDATES})
+    return st
+
+
+class _RtrFrame(_Frame):
+    """_Frame over the oracle's reflection state. All eight PingPongTemporalResources of RtrRenderer (rtr.rs:19-27) turn once per frame."""
+
+    def _tex(self, name):
+        w, h = (self.W, self.H) if P.base_name(name) in ("rtr.temporal", "rtr.ray_len", "resolved_tex") else (self.hw, self.hh)
+        fmt = P.fmt_of(name)
+        return R.Tex(self.before[name].copy(), w, h, _RTR_TEX_FMT.get(fmt, fmt))
+
+    def rd(self, name):
+        return self._tex(name)
+
+    def wr(self, name):
+        t = self._tex(name)
+        self.written[name] = t
+        return t
+
+
+@pytest.mark.parametrize("reuse", [1, 0])
+def test_rtr_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, reuse):
+    """RtrRenderer::trace + TracedRtr::filter_temporal (renderers/rtr.rs:97-400,440-480) from the reference's own text -- rtr/reflection.rgen.hlsl
+    and reflection_validate.rgen.hlsl (with reflection_trace_common.inc.hlsl, inc/blue_noise.hlsl's sampler, rt/gbuffer.rchit.hlsl on every hit),
+    rtr_restir_temporal.hlsl, resolve.hlsl, temporal_filter.hlsl, spatial_cleanup.hlsl -- pass by pass against oracle/okj_rtr.hpp on the
+    oracle's frame state, recorded the way rtr.rs records them (binding order, constants, dispatch extents; `reuse_rtdgi_rays` on -- the
+    rough pixels keep rtdgi's candidates, rtr.rs:32 -- and off). The irradiance cache is bound empty (the oracle's null lookup hook). Every surface every pass
+    writes must come out number for number, with the two places where the oracle DEFINES what the text leaves to chance set
+    aside and counted:
+      (a) reflection_validate.rgen.hlsl:88 normalises `ray_hit_ws - ray_orig_ws`; where the history holds no ray yet that is normalize(0) = NaN
+          handed to TraceRay (undefined in the API). The oracle and the kernels trace +Z. Quads whose validation pixel has a zero history ray
+          are left out of the comparison;
+      (b) resolve.hlsl:535-540 divides by |sample origin - pixel origin|, which for the pixel's own half-res sample is the rounding residue of
+          `(origin - eye) + eye`: a direction made of rounding noise, different under any other contraction / association of the same
+          arithmetic. The oracle and the kernels count a residue as zero. Here the oracle runs with that rule switched off (a test knob) --
+          the text as written -- and the texels the rule changes are counted on one frame."""
+    from kajiya_amd import scenes, rtr_tables
+    from kajiya_amd.abi import KJ_RTR_PASS
+    import test_gpu_parity as T
+    _bind_luts(oracle)
+    desc = scenes.glossy_test_scene()
+    osc = oracle.OracleScene(desc)
+    keep = _bind_scene(oracle, osc, desc)
+    W, H = 72, 44
+    hw, hh = (W + 1) // 2, (H + 1) // 2
+    qw, qh = (hw + 1) // 2, (hh + 1) // 2
+    op = oracle.OraclePipeline(osc, W, H)
+    g, ho = R.extent_inv_extent(W, H), R.extent_inv_extent(hw, hh)
+    ranking, scrambling = rtr_tables.ranking_and_scrambling()
+    sampler = [R.Buf(ranking), R.Buf(scrambling), R.Buf(rtr_tables.sobol_256x256())]
+    offsets = rtr_tables.spatial_resolve_offsets()
+    sky = R.Tex(op.sky64, 64, 64 * 6, "rgba16f")
+    wrc = R.Tex.zeros(1, 1, "rgba16f")
+    compared, undefined_quads, own_rule = {}, 0, {}
+    for fi, fc in enumerate(T._frame_constants(W, H, 7, "textured")):
+        op.render_inputs(fc); op.reprojection(fc)
+        op.rtdgi_frame(fc)
+        if fi < 4:
+            op.rtr_frame(fc)
+            op.L.okj_rtr_set_literal_own_sample_shadowing(op.rtr, 1)       # (b) of the docstring
+            op.L.okj_rtr_set_options(op.rtr, reuse)
+            continue
+        rtdgi = R.Tex(np.frombuffer((C.c_uint8 * (W * H * 8)).from_address(op.out.screen_irradiance_tex), np.uint8).copy(), W, H, "rgba16f")
+        for k, pname in enumerate(RTR_PASS_ORDER):
+            before = _rtr_state(op)
+            op.rtr_frame(fc, KJ_RTR_PASS[pname] | (0 if k == 0 else KJ_RTR_PASS["KEEP"]))
+            after = _rtr_state(op)
+            f = _RtrFrame(op, before, fi, W, H)
+            irc = _ircache_bind_set(_empty_ircache(), 0)
+            half_view_normal = R.Tex(op.rtr_surface("half_view_normal_tex", np.uint8, (-1,)).copy(), hw, hh, "rgba8s")
+            half_depth = R.Tex(op.rtr_surface("half_depth_tex", np.uint8, (-1,)).copy(), hw, hh, "r32f")
+            if pname == "TRACE":               # rtr.rs:118-151
+                R.run_pass("rtr/reflection.rgen",
+                           [f.gbuffer(), f.depth()] + sampler + [rtdgi, sky] + irc +
+                           [wrc, f.wr("candidate_radiance_tex"), f.wr("candidate_hit_tex"), f.wr("candidate_normal_tex"), f.out("rtr.rng")],
+                           [g, np.uint32(reuse)], fc, (hw, hh, 1))
+            elif pname == "VALIDATE":          # rtr.rs:207-232: the invalidity image is a fresh transient; half of the half-res extent
+                inval = f.wr("refl_restir_invalidity_tex")
+                inval.raw[:] = 0
+                R.run_pass("rtr/reflection_validate.rgen",
+                           [f.gbuffer(), f.depth(), rtdgi, sky, inval] + irc +
+                           [wrc, f.hist("rtr.ray_orig"), f.hist("rtr.ray"), f.hist("rtr.rng"), f.wr("rtr.irradiance" + f.hist_sfx), f.wr("rtr.reservoir" + f.hist_sfx)],
+                           [g], fc, (qw, qh, 1))
+            elif pname == "RESTIR_TEMPORAL":   # rtr.rs:234-262
+                R.run_pass("rtr/rtr_restir_temporal",
+                           [f.gbuffer(), half_view_normal, f.depth(), f.rd("candidate_radiance_tex"), f.rd("candidate_hit_tex"), f.rd("candidate_normal_tex"),
+                            f.hist("rtr.irradiance"), f.hist("rtr.ray_orig"), f.hist("rtr.ray"), f.hist("rtr.rng"), f.hist("rtr.reservoir"), f.reprojection_map(),
+                            f.hist("rtr.hit_normal"), f.out("rtr.irradiance"), f.out("rtr.ray_orig"), f.out("rtr.ray"), f.out("rtr.rng"), f.out("rtr.hit_normal"),
+                            f.out("rtr.reservoir")], [g], fc, (hw, hh, 1))
+            elif pname == "RESOLVE":           # rtr.rs:290-318
+                R.run_pass("rtr/resolve",
+                           [f.gbuffer(), f.depth(), f.rd("candidate_radiance_tex"), f.rd("candidate_hit_tex"), f.rd("candidate_normal_tex"), f.hist("rtr.temporal"),
+                            f.reprojection_map(), half_view_normal, half_depth, f.hist("rtr.ray_len"), f.out_as_input("rtr.irradiance"), f.out_as_input("rtr.ray"),
+                            f.out_as_input("rtr.reservoir"), f.out_as_input("rtr.ray_orig"), f.out_as_input("rtr.hit_normal"), f.wr("resolved_tex"), f.out("rtr.ray_len")],
+                           [g, offsets], fc, (W, H, 1))
+            elif pname == "TEMPORAL_FILTER":   # rtr.rs:449-465
+                R.run_pass("rtr/temporal_filter",
+                           [f.rd("resolved_tex"), f.hist("rtr.temporal"), f.depth(), f.out_as_input("rtr.ray_len"), f.reprojection_map(), f.rd("refl_restir_invalidity_tex"),
+                            f.gbuffer(), f.out("rtr.temporal")], [g], fc, (W, H, 1))
+            else:                              # rtr.rs:467-477
+                R.run_pass("rtr/spatial_cleanup", [f.out_as_input("rtr.temporal"), f.depth(), f.geometric_normal(), f.wr("resolved_tex")], [offsets], fc, (W, H, 1))
+            if pname == "VALIDATE":            # (a) of the docstring: quads whose validation ray has no direction
+                off = np.array([(0, 0), (1, 1), (1, 0), (0, 1)])[fc.frame_index & 3]
+                ray = P.decode(before["rtr.ray" + f.hist_sfx], "rgba16f").reshape(hh, hw, 4)[off[1]::2, off[0]::2, :3]
+                dead = np.argwhere((ray == 0).all(axis=-1) & (op.depth.reshape(H, W)[2 * off[1]::4, 2 * off[0]::4][:ray.shape[0], :ray.shape[1]] != 0))
+                undefined_quads += len(dead)
+                for n, t in f.written.items():
+                    bpt = t.raw.size // (hw * hh)
+                    a, b = t.raw.reshape(hh, hw, bpt), after[n].reshape(hh, hw, bpt)
+                    for qy, qx in dead:
+                        a[2 * qy:2 * qy + 2, 2 * qx:2 * qx + 2] = b[2 * qy:2 * qy + 2, 2 * qx:2 * qx + 2]
+            if pname == "RESOLVE" and fi == 6:     # (b): what the oracle's own rule changes, on the same inputs
+                op.L.okj_rtr_set_literal_own_sample_shadowing(op.rtr, 0)
+                op.rtr_frame(fc, KJ_RTR_PASS[pname] | KJ_RTR_PASS["KEEP"])
+                ruled = _rtr_state(op)
+                own_rule = {n: int((P.decode(ruled[n], P.fmt_of(n)) != P.decode(after[n], P.fmt_of(n))).any(axis=-1).sum()) for n in f.written}
+                op.L.okj_rtr_set_literal_own_sample_shadowing(op.rtr, 1)
+                op.rtr_frame(fc, KJ_RTR_PASS[pname] | KJ_RTR_PASS["KEEP"])
+                assert all(np.array_equal(v, after[n]) for n, v in _rtr_state(op).items())
+            for n, t in f.written.items():
+                r = P.compare(t.raw, after[n], P.fmt_of(n), vector=P.is_vector(n))
+                ident = _numbers_equal(t.raw, after[n]) if P.fmt_of(n) in ("u32", "reservoir") else r["differ_frac"] == 0.0
+                compared[(pname, P.base_name(n))] = compared.get((pname, P.base_name(n)), True) and bool(ident)
+                if not ident:
+                    a, b = P.decode(t.raw, P.fmt_of(n)), P.decode(after[n], P.fmt_of(n))
+                    bad = np.nonzero((a != b).any(axis=-1))[0]
+                    print(f"frame {fi} {pname} {n}: {bad.size} of {a.shape[0]} texels differ, e.g. texel {bad[:3]}: ref {a[bad[:3]]} oracle {b[bad[:3]]}  {r}")
+            for n in after:
+                if n not in f.written and not np.array_equal(after[n], before[n]):
+                    raise AssertionError(f"frame {fi} pass {pname}: the oracle wrote {n}, the reference pass does not")
+    print(sorted(compared.items()))
+    print(f"validate quads without a ray direction (left out): {undefined_quads} of {3 * qw * qh}; texels the oracle's own-sample rule changes at {W}x{H}: {own_rule}")
+    assert len(compared) >= 17, sorted(compared)
+    assert all(compared.values()), sorted(k for k, v in compared.items() if not v)
+    assert undefined_quads <= 0.02 * 3 * qw * qh
+    assert 0 < own_rule["resolved_tex"] <= 0.05 * W * H and own_rule["rtr.ray_len" + (":0" if 6 % 2 == 0 else ":1")] <= 0.08 * W * H, own_rule
