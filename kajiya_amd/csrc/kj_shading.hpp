@@ -266,7 +266,7 @@ KJ_HD V3 integrate_optical_depth(V3 ray_start, V3 ray_dir) {
     float ray_length = atmosphere_intersection(ray_start, ray_dir).y;
     float step_size = ray_length / 8;
     V3 od = v3(0.0f);
-    for (int i = 0; i < 8; i++) od += atmosphere_density_at(ray_start + ray_dir * ((i + 0.5f) * step_size)) * step_size;
+    for (int i = 0; i < 8; i++) od += atmosphere_density_at(ray_start + ray_dir * (i + 0.5f) * step_size) * step_size;   // left to right, as the shader text associates
     return od;
 }
 KJ_HD V3 atmosphere_absorb(V3 od) {
@@ -295,8 +295,8 @@ KJ_HD V3 integrate_scattering(V3 ray_start, V3 ray_dir, float ray_length, V3 lig
         od += dens * step_size;
         V3 view_t = atmosphere_absorb(od);
         V3 light_t = atmosphere_absorb(integrate_optical_depth(p, light_dir));
-        rayleigh += view_t * light_t * (phase_r * dens.x * step_size);
-        mie += view_t * light_t * (phase_m * dens.y * step_size);
+        rayleigh += view_t * light_t * phase_r * dens.x * step_size;    // left to right, as the shader text associates
+        mie += view_t * light_t * phase_m * dens.y * step_size;
         prev_t = t;
     }
     return (rayleigh * C_R + mie * C_M) * light_color * 20.0f;

@@ -34,7 +34,9 @@ KJ_D V3 blur_fetch(const ImgU32& i, int x, int y) { return unpack_r11g11b10f(i.l
 typedef Img<float4> ImgF4;     // RGBA32F: the reference path tracer's accumulation image (world_render_passes.rs:294-330 feeds it to post as is)
 KJ_D V3 blur_fetch(const ImgF4& i, int x, int y) { const float4 v = i.ld(x, y); return V3{v.x, v.y, v.z}; }
 
-// one blur + 2x downsample pass; VTAPS = 10 for the Rust kernel of mip 0 (`while y < KERNEL_RADIUS * 2`), 11 for blur.hlsl
+// one blur + 2x downsample pass; VTAPS = 10 for the Rust kernel of mip 0 (`while y < KERNEL_RADIUS * 2`), 11 for blur.hlsl. blur.hlsl computes
+// the taps' source coordinates in `uint` (:22,50): a tap left of / above the image sits at 2^32 - k, its weight underflows to 0 (blur.rs: i32).
+template <int VTAPS> KJ_D float blur_src_coord(int s) { return VTAPS == 11 ? float(uint32_t(s)) : float(s); }
 template <typename SRC, int VTAPS>
 __global__ void __launch_bounds__(64) k_post_blur(SRC src, ImgU32 dst) {
     __shared__ float vblur_out[3][138];                       // (group_width + kernel_radius) * 2 columns, SoA: conflict-free
@@ -47,7 +49,7 @@ __global__ void __launch_bounds__(64) k_post_blur(SRC src, ImgU32 dst) {
 #pragma unroll
         for (int yi = 0; yi < VTAPS; ++yi) {
             const int sy = y * 2 - 5 + yi;
-            const float wt = gaussian_wt(float(y), float(sy));
+            const float wt = gaussian_wt(float(y), blur_src_coord<VTAPS>(sy));
             v += blur_fetch(src, sx, sy) * wt;
             vw += wt;
         }
@@ -59,7 +61,7 @@ __global__ void __launch_bounds__(64) k_post_blur(SRC src, ImgU32 dst) {
     float wt_sum = 0.0f;
 #pragma unroll
     for (int xi = 0; xi <= 10; ++xi) {
-        const float wt = gaussian_wt(float(x), float(x * 2 + xi - 5));
+        const float wt = gaussian_wt(float(x), blur_src_coord<VTAPS>(x * 2 + xi - 5));
         const int c = lx * 2 + xi;
         res += V3{vblur_out[0][c], vblur_out[1][c], vblur_out[2][c]} * wt;
         wt_sum += wt;

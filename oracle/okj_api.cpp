@@ -119,6 +119,7 @@ void okj_scene_commit(void* s) { ((Scene*)s)->commit(); }
 void okj_scene_use_bvh(void* s, int v) { ((Scene*)s)->use_bvh = v != 0; }
 uint32_t okj_scene_triangle_count(void* s) { return uint32_t(((Scene*)s)->tris.size()); }
 uint32_t okj_scene_triangle_light_count(void* s) { return uint32_t(((Scene*)s)->triangle_lights.size()); }
+void okj_scene_triangle_lights(void* s, KjTriangleLight* out) { const auto& l = ((Scene*)s)->triangle_lights; if (!l.empty()) memcpy(out, l.data(), l.size() * sizeof(KjTriangleLight)); }
 // rays: {ox,oy,oz,tmin, dx,dy,dz,tmax}; hits: {t,u,v,asfloat(tri)}
 void okj_trace_closest(void* s, const float* rays, float* hits, uint32_t count, int cull_back, int brute) {
     const Scene& sc = *(Scene*)s;

@@ -199,8 +199,13 @@ struct Post {
         const float sigma = 5.0f * 0.5f;
         return expf(-px_off * px_off / (sigma * sigma));
     }
-    // one blur pass: dst (w x h) from a source fetched by `fetch(x, y)` (0 out of bounds); `vtaps` = 10 (Rust mip 0) or 11 (HLSL)
+    // one blur pass: dst (w x h) from a source fetched by `fetch(x, y)` (0 out of bounds); `vtaps` = 10 (Rust mip 0) or 11 (HLSL).
+    // The two texts differ in one more way: blur.rs computes the tap's source coordinate in i32, blur.hlsl in `uint` (`src_px.y + y` with
+    // `uint y`, :22; `px.x * 2 + x - kernel_radius` with all three uint, :50) -- a tap left of / above the image has coordinate 2^32 - k there,
+    // its Gaussian weight underflows to exactly 0, and it does NOT count in the weight sum (in mip 0 it does, with its zero texel).
     template <typename Fetch> static void blur_pass(ImgU32 dst, int vtaps, Fetch fetch) {
+        const bool hlsl = vtaps == 11;
+        auto src_coord = [hlsl](int s) { return hlsl ? float(uint32_t(s)) : float(s); };
         for (int y = 0; y < dst.h; ++y)
             for (int x = 0; x < dst.w; ++x) {
                 f3 res = mk3(0.0f);
@@ -211,12 +216,12 @@ struct Post {
                     float vw = 0.0f;
                     for (int yi = 0; yi < vtaps; ++yi) {
                         const int sy = y * 2 - 5 + yi;
-                        const float wt = gaussian_wt(float(y), float(sy));
+                        const float wt = gaussian_wt(float(y), src_coord(sy));
                         v += fetch(sx, sy) * wt;
                         vw += wt;
                     }
                     v = v / vw;
-                    const float wt = gaussian_wt(float(x), float(sx));
+                    const float wt = gaussian_wt(float(x), src_coord(sx));
                     res += v * wt;
                     wt_sum += wt;
                 }

@@ -405,7 +405,7 @@ static inline f3 integrate_optical_depth(f3 ray_start, f3 ray_dir) {
     float step_size = ray_length / sample_count;
     f3 od = mk3(0.0f);
     for (int i = 0; i < sample_count; i++) {
-        f3 p = ray_start + ray_dir * ((i + 0.5f) * step_size);
+        f3 p = ray_start + ray_dir * (i + 0.5f) * step_size;           // atmosphere_felix.hlsl:133, left to right: (rayDir * (i + 0.5)) * stepSize
         od += atmosphere_density(atmosphere_height(p)) * step_size;
     }
     return od;
@@ -436,8 +436,8 @@ static inline f3 integrate_scattering(f3 ray_start, f3 ray_dir, float ray_length
         od += dens * step_size;
         f3 view_t = absorb(od);
         f3 light_t = absorb(integrate_optical_depth(p, light_dir));
-        rayleigh += view_t * light_t * (phase_r * dens.x * step_size);
-        mie += view_t * light_t * (phase_m * dens.y * step_size);
+        rayleigh += view_t * light_t * phase_r * dens.x * step_size;    // :228-229, left to right: the vector product first, then the three scalars one by one
+        mie += view_t * light_t * phase_m * dens.y * step_size;
         prev_t = t;
     }
     return (rayleigh * C_RAYLEIGH() + mie * C_MIE()) * light_color * 20.0f;

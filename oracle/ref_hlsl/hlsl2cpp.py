@@ -43,6 +43,10 @@ LOCKSTEP_IDS = re.compile(r"^(Wave[A-Z]\w*|Quad[A-Z]\w*|GroupMemoryBarrierWithGr
 
 # (file relative to assets/shaders) -> [(regex on the REWRITTEN text, replacement, why)]. Each one only names a conversion HLSL performs implicitly.
 PATCHES = {
+    "lighting/spatial_reuse_lights.hlsl": [(r"output_tex\[orig_px\]\.rgb \+= out_color;", "{ float4 v_ = output_tex[orig_px]; v_.rgb += out_color; output_tex[orig_px] = v_; }",
+                                            "a swizzled compound assignment to an image texel: load, modify, store")],
+    "lighting/sample_lights.rgen.hlsl": [(r"float4\{select\(is_shadowed, 0, triangle_light\.radiance\(\), 1\)\}", "float4{select(is_shadowed, 0, triangle_light.radiance()), 1}",
+                                          "as shipped the call reads select(c, 0, radiance, 1) inside float4(): one parenthesis late, not a valid select(); what it means is unambiguous")],
     "inc/lights/triangle.hlsl": [(r"res\.packed = p\.packed;", "for (int i_ = 0; i_ < 12; ++i_) res.packed[i_] = p.packed[i_];", "HLSL arrays are values and assign element-wise")],
 }
 # (file) -> text inserted before the file's closing include guard: forwarding overloads that spell out which conversion HLSL's overload

@@ -2,6 +2,7 @@
 // in the reference's texel formats (SURVEY.md App. A / DESIGN.md §2), samplers, atomics, and the lane-scheduler hooks behind the wave
 // intrinsics and group barriers. Fixed-function behaviour (format conversion, filtering, out-of-bounds) follows DESIGN.md §4.
 #pragma once
+#include <vector>
 
 namespace hlsl {
 
@@ -197,6 +198,18 @@ template <class T> struct RWTexture2D : ResourceBase {
     template <class P, HLSL_REQ(VT<P>::isvec && VT<P>::n == 2)> RWTexel<T> operator[](const P& p) {
         const int x = cv<int>(VT<P>::get(p, 0)), y = cv<int>(VT<P>::get(p, 1)); return RWTexel<T>(this, x, y, texel_to<T>(fetch(x, y))); }
     template <class A, class B> void GetDimensions(A& ow, B& oh) const { ow = A(w); oh = B(h); }
+};
+
+// image arrays (the sky cubes as storage images): slices of w x h texels one after another; the slice count follows from the bound size
+template <class T> struct RWTexture2DArray : ResourceBase {
+    HLSL_RES_CTORS(RWTexture2DArray, ResourceBase)
+    std::vector<RWTexture2D<T>> slices;
+    template <class P, HLSL_REQ(VT<P>::isvec && VT<P>::n == 3)> RWTexel<T> operator[](const P& p) {
+        const size_t slice_bytes = size_t(w) * size_t(h) * size_t(format_bytes(fmt)); const size_t n = slice_bytes ? bytes / slice_bytes : 0;
+        if (slices.size() != n + 1) slices.resize(n + 1);                   // [n] stays unbound: out-of-range slices read 0 and drop stores
+        const uint z = cv<uint>(VT<P>::get(p, 2)); RWTexture2D<T>& sl = slices[z < n ? z : n];
+        if (z < n) { sl.data = (uint8_t*)data + size_t(z) * slice_bytes; sl.w = w; sl.h = h; sl.fmt = fmt; sl.bytes = slice_bytes; }
+        return sl[int2(cv<int>(VT<P>::get(p, 0)), cv<int>(VT<P>::get(p, 1)))]; }
 };
 
 // cube maps: six w x w faces, face-major (+X -X +Y -Y +Z -Z), Vulkan face selection, bilinear inside the face with clamped texel coordinates

@@ -127,13 +127,15 @@ def run_pass(name, resources, constants, frame_constants, dispatch):
     for i in range(L.ref_pass_resource_count(pn)):
         if L.ref_pass_resource_set(pn, i) == 0:
             slots.append((L.ref_pass_resource_binding(pn, i), L.ref_pass_resource_name(pn, i)))
+        elif L.ref_pass_resource_set(pn, i) == -1:       # no [[vk::binding]] (blur.hlsl): the compiler numbers them in declaration order
+            slots.append((len(slots), L.ref_pass_resource_name(pn, i)))
     slots = sorted(set(slots))
     assert [b for b, _ in slots] == list(range(len(slots))), (name, slots)          # set 0 is dense from binding 0, like SimpleRenderPass binds it
     assert len(slots) == len(resources), (name, [n for _, n in slots], len(resources))
     keep = []
     for (_, rn), r in zip(slots, resources):
         if isinstance(r, Tex):
-            rc = L.ref_bind(pn, rn, r.raw.ctypes.data, r.w, r.h, r.fmt, 0)
+            rc = L.ref_bind(pn, rn, r.raw.ctypes.data, r.w, r.h, r.fmt, r.raw.size)      # size: an image array's slice count follows from it
         else:
             rc = L.ref_bind(pn, rn, r.raw.ctypes.data, 0, 0, 0, r.raw.size)
         assert rc == 0, (name, rn, rc)

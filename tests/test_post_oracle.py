@@ -56,9 +56,12 @@ def _gaussian_wt(dst_px, src_px):           # blur.rs:18-22
     return math.exp(-px_off * px_off / (sigma * sigma))
 
 
-def _rust_blur(src, dw, dh, vtaps):
+def _rust_blur(src, dw, dh, vtaps, uint_coords=False):
     """blur_cs (rust-shaders/src/blur.rs:41-91): vblur of 138 columns into shared memory, then 11 horizontal taps. `vtaps` = 10 for the
-    Rust text (`while y < KERNEL_RADIUS * 2`), 11 for blur.hlsl (`y <= kernel_radius * 2`). Out-of-range fetches read 0."""
+    Rust text (`while y < KERNEL_RADIUS * 2`), 11 for blur.hlsl (`y <= kernel_radius * 2`). Out-of-range fetches read 0.
+    `uint_coords`: blur.hlsl's other difference -- the tap's source coordinate handed to gaussian_wt is a `uint` expression there (blur.hlsl:22,50;
+    i32 in blur.rs:30,83), so a tap left of / above the image sits at 2^32 - k and weighs exactly 0 instead of counting with a zero texel."""
+    coord = (lambda s: float(s % (1 << 32))) if uint_coords else float
     sh, sw = src.shape[:2]
     pad = np.zeros((sh + 2 * dh + 32, sw + 2 * dw + 32, 3))
     oy, ox = 8, 8
@@ -70,7 +73,7 @@ def _rust_blur(src, dw, dh, vtaps):
         acc, wsum = 0.0, 0.0
         for yi in range(vtaps):
             sy = y * 2 - 5 + yi
-            wt = _gaussian_wt(y, sy)
+            wt = _gaussian_wt(y, coord(sy))
             acc = acc + pad[oy + sy, ox + cols[0]: ox + cols[-1] + 1] * wt
             wsum += wt
         v[y] = acc / wsum
@@ -79,7 +82,7 @@ def _rust_blur(src, dw, dh, vtaps):
         acc, wsum = 0.0, 0.0
         for xi in range(11):
             sx = x * 2 + xi - 5
-            wt = _gaussian_wt(x, sx)
+            wt = _gaussian_wt(x, coord(sx))
             acc = acc + v[:, sx + 5] * wt
             wsum += wt
         out[:, x] = acc / wsum
@@ -104,7 +107,7 @@ def test_blur_pyramid_matches_the_rust_and_hlsl_statements(oracle, W, H):
     # mips 1..: blur.hlsl on the previous (stored) mip
     for l in range(1, levels):
         wl, hl = op.mip_extent(l)
-        _assert_stored(op.mip("blur_pyramid", l), _rust_blur(_unpack(op.mip("blur_pyramid", l - 1)), wl, hl, 11), f"blur mip {l}")
+        _assert_stored(op.mip("blur_pyramid", l), _rust_blur(_unpack(op.mip("blur_pyramid", l - 1)), wl, hl, 11, uint_coords=True), f"blur mip {l}")
 
 
 def _bilinear_clamp(img, u, v):
