@@ -172,6 +172,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from kajiya_amd import lib
+    if os.environ.get("KJ_PRIO_MAIN"):      # A/B knob: the GI chain on a stream of that priority (-1 = high), the side streams stay at KJ_PRIO_* (default 0)
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["KJ_PRIO_MAIN"])))
+        print("[bench] stream priority range", torch.cuda.Stream.priority_range(), "main", os.environ["KJ_PRIO_MAIN"], file=sys.stderr)
 
     W, H = args.width, args.height
     K, Wm = args.steps, args.warmup
@@ -479,8 +482,13 @@ def main():
                 continue
         n_h2, n_f = hw * hh * strip_frac, W * H * strip_frac
         # pass -> (kernel name as rocprofv3 prints it, units per launch, algorithmic bytes per unit [SURVEY 8d table])
-        table = [("rtdgi reproject", "k_fullres_reproject", n_f, 24), ("extract half", "k_extract_half", n_h2, 30), ("validity integrate", "k_validity_integrate", n_h2, 25),
-                 ("restir temporal", "k_restir_temporal", n_h2, 168), ("restir spatial 0", "k_restir_spatial<32, 8, 16, 16, false>", n_h2, 41),
+        # validity integrate + restir temporal are ONE launch by default since round 4 (k_validity_integrate_restir_temporal; KJ_RTDGI_FUSE_VT=0 splits them):
+        # its time is reported under "restir temporal", "validity integrate" reads 0
+        vi_fused = pass_ms[lib.GpuPipeline.PASS_NAMES.index("validity integrate")] == 0.0
+        table = [("rtdgi reproject", "k_fullres_reproject", n_f, 24), ("extract half", "k_extract_half<0>", n_h2, 30)] + \
+                ([("restir temporal", "k_validity_integrate_restir_temporal", n_h2, 25 + 168)] if vi_fused else
+                 [("validity integrate", "k_validity_integrate", n_h2, 25), ("restir temporal", "k_restir_temporal", n_h2, 168)]) + \
+                [("restir spatial 0", "k_restir_spatial<32, 8, 16, 16, false>", n_h2, 41),
                  ("restir spatial 1", "k_restir_spatial<16, 5, 16, 16, false>", n_h2, 41), ("restir resolve", "k_restir_resolve", n_f, 43),
                  ("rtdgi temporal", "k_temporal_filter", n_f, 49), ("rtdgi spatial", "k_spatial_filter", n_f, 25)]
 
@@ -514,7 +522,7 @@ def main():
             if note:
                 e["note"] = note
             return e
-        ray_kernel = "k_rtdgi_trace_fused<false>"
+        ray_kernel = "k_rtdgi_trace_fused<false, false>"
         roofline = entry(ray_kernel, trace_ms, trace_bytes)
         roofline.update({"traffic_source": f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md)" if roofline["traffic"] else None,
                          "nodes_per_closest_ray": round(nodes_per_closest, 2), "tris_per_closest_ray": round(tris_per_closest, 2),
@@ -522,7 +530,7 @@ def main():
         roofline.update(trace_rays_note)
         roofline_all = [roofline] + [entry(kern, pass_ms[lib.GpuPipeline.PASS_NAMES.index(pname)], units * bpu) for pname, kern, units, bpu in table]
         if seg:
-            roofline_all.append(entry("taa (7 kernels)", seg["taa"], W * H * 224, "segment: sum of the seven TAA launches"))
+            roofline_all.append(entry("taa (7 passes, 5 launches)", seg["taa"], W * H * 224, "segment: sum of the TAA launches (the two input filters and the two probability filters share a launch each)"))
         if args.pmc_calibration_copy and single:
             nbytes = 512 << 20
             a_ = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}"); b_ = torch.empty_like(a_)

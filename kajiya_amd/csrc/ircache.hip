@@ -166,12 +166,12 @@ template <bool QUAD> KJ_D void irc_count_path_rays(unsigned long long* counters,
     const uint32_t stride = QUAD ? 16u : 64u;                                                                                       \
     if (slot_ >= per_wave_) return;                                                                                                 \
     const uint32_t own_entries_ = ((entries_) + c.part_count - 1u - c.part_index) / c.part_count;                                   \
-    for (uint32_t local_ = blockIdx.x * per_wave_ + slot_, d = 0; local_ < own_entries_ * (per_entry_) &&                           \
-         ((d = ((local_ / (per_entry_)) * c.part_count + c.part_index) * (per_entry_) + local_ % (per_entry_)), true); local_ += gridDim.x * per_wave_)
+    for (uint32_t local_ = block_ * per_wave_ + slot_, d = 0; local_ < own_entries_ * (per_entry_) &&                               \
+         ((d = ((local_ / (per_entry_)) * c.part_count + c.part_index) * (per_entry_) + local_ % (per_entry_)), true); local_ += nblocks_ * per_wave_)
 // trace_accessibility.rgen.hlsl:21-66
+// (the three passes are device functions over a block range so that one launch can carry all of them: k_irc_ray_passes below)
 template <bool QUAD>
-__global__ void __launch_bounds__(64) k_irc_trace_accessibility(IrcTraceCtx c) {
-    extern __shared__ uint32_t lds_stack[];
+KJ_D void irc_trace_accessibility_blocks(const IrcTraceCtx& c, uint32_t* lds_stack, uint32_t block_, uint32_t nblocks_) {
     const IrcacheView& ic = c.ic;
     IRC_PATH_LOOP(ic.meta[IRC_META_TRACING_ALLOC_COUNT], IRC_OCTA_DIMS2) {
         const uint32_t entry_idx = ic.entry_indirection[d / IRC_OCTA_DIMS2];
@@ -192,6 +192,11 @@ __global__ void __launch_bounds__(64) k_irc_trace_accessibility(IrcTraceCtx c) {
             *dst = make_float2(asfloat(raw.x), asfloat(raw.y));
         }
     }
+}
+template <bool QUAD>
+__global__ void __launch_bounds__(64) k_irc_trace_accessibility(IrcTraceCtx c) {
+    extern __shared__ uint32_t lds_stack[];
+    irc_trace_accessibility_blocks<QUAD>(c, lds_stack, blockIdx.x, gridDim.x);
 }
 
 struct IrcTraceResult { V3 incident_radiance, direction, hit_pos; };
@@ -263,8 +268,7 @@ KJ_D IrcTraceResult ircache_trace(const IrcTraceCtx& c, const IrcVertex& entry, 
 }
 // ircache_validate.rgen.hlsl:44-131
 template <bool QUAD>
-__global__ void __launch_bounds__(64) k_irc_validate(IrcTraceCtx c) {
-    extern __shared__ uint32_t lds_stack[];
+KJ_D void irc_validate_blocks(const IrcTraceCtx& c, uint32_t* lds_stack, uint32_t block_, uint32_t nblocks_) {
     const IrcacheView& ic = c.ic;
     const FrameConstants& fc = *c.fc;
     IRC_PATH_LOOP(ic.meta[IRC_META_TRACING_ALLOC_COUNT], IRC_VALIDATION_SAMPLES_PER_FRAME) {
@@ -296,10 +300,14 @@ __global__ void __launch_bounds__(64) k_irc_validate(IrcTraceCtx c) {
         }
     }
 }
+template <bool QUAD>
+__global__ void __launch_bounds__(64) k_irc_validate(IrcTraceCtx c) {
+    extern __shared__ uint32_t lds_stack[];
+    irc_validate_blocks<QUAD>(c, lds_stack, blockIdx.x, gridDim.x);
+}
 // trace_irradiance.rgen.hlsl:44-145
 template <bool QUAD>
-__global__ void __launch_bounds__(64) k_irc_trace_irradiance(IrcTraceCtx c) {
-    extern __shared__ uint32_t lds_stack[];
+KJ_D void irc_trace_irradiance_blocks(const IrcTraceCtx& c, uint32_t* lds_stack, uint32_t block_, uint32_t nblocks_) {
     const IrcacheView& ic = c.ic;
     const FrameConstants& fc = *c.fc;
     IRC_PATH_LOOP(ic.meta[IRC_META_TRACING_ALLOC_COUNT], IRC_SAMPLES_PER_FRAME) {
@@ -341,6 +349,26 @@ __global__ void __launch_bounds__(64) k_irc_trace_irradiance(IrcTraceCtx c) {
             if (selected_new) ic.aux[output_idx + IRC_OCTA_DIMS2 * 2] = packed_entry;
         }
     }
+}
+template <bool QUAD>
+__global__ void __launch_bounds__(64) k_irc_trace_irradiance(IrcTraceCtx c) {
+    extern __shared__ uint32_t lds_stack[];
+    irc_trace_irradiance_blocks<QUAD>(c, lds_stack, blockIdx.x, gridDim.x);
+}
+// The three ray passes in ONE launch, side by side: blocks [0, n) validate, [n, 2n) trace, [2n, 3n) accessibility (the two long chains are
+// dispatched first). This is the schedule the reference asks for: ircache.rs:396-481 records the three passes with `write_no_sync` on every
+// buffer they share ("if we use `write_no_sync`, we can overlap with the next pass", :411-412), i.e. WITHOUT barriers between them, and each is
+// a few hundred waves -- on any GPU they run concurrently, racing on the aux slots exactly as they race inside one pass. Launched one after
+// the other (each a chain of ~100 dependent traversal steps, ~0.1 ms regardless of its size) they are the longest link of the frame-to-frame
+// cycle: this frame's ray passes -> next frame's cache rays -> next frame's ray passes. Not in the cache's deterministic mode, whose snapshots
+// define an order between the passes (kj_ircache_trace_irradiance).
+template <bool QUAD>
+__global__ void __launch_bounds__(64) k_irc_ray_passes(IrcTraceCtx c, uint32_t blocks_per_pass) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t pass = blockIdx.x / blocks_per_pass, block = blockIdx.x % blocks_per_pass;
+    if (pass == 0u) irc_validate_blocks<QUAD>(c, lds_stack, block, blocks_per_pass);
+    else if (pass == 1u) irc_trace_irradiance_blocks<QUAD>(c, lds_stack, block, blocks_per_pass);
+    else irc_trace_accessibility_blocks<QUAD>(c, lds_stack, block, blocks_per_pass);
 }
 // sum_up_irradiance.hlsl:34-89 — 16 lanes per entry (one per octahedral cell), shuffle-reduced
 __global__ void __launch_bounds__(64) k_irc_sum_up(const FrameConstants* __restrict__ fcp, IrcacheView ic) {
@@ -667,6 +695,17 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     KJ_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_irc_reset, dim3(grid), dim3(64), 0, s, tc.ic);
     KJ_CHECK_LAUNCH();
+    // racy (the reference's) mode, opt-in (KJ_IRC_SIDE_BY_SIDE=1): the three passes side by side in one launch, as the reference's barrier-free
+    // recording lets them run. Measured on MI355X (round 4, profiles/r04_ab_runs.md): the cache's segment 0.40 -> 0.21 ms at 1080p, the PIPELINED
+    // frame unchanged (it is VALU-bound, not waiting for this chain), and the SH sums on identical state move from 1.3e-2 to 5.3e-2 of the
+    // sequential oracle's (tests/test_gpu_ircache.py; bar 5e-2) -- so it is not the default.
+    static const bool side_by_side = getenv("KJ_IRC_SIDE_BY_SIDE") && atoi(getenv("KJ_IRC_SIDE_BY_SIDE")) != 0;
+    if (!c->deferred && side_by_side) {
+        hipLaunchKernelGGL(quad ? k_irc_ray_passes<true> : k_irc_ray_passes<false>, dim3(grid * 3u), dim3(64), lds_rays, s, tc, grid);
+        KJ_CHECK_LAUNCH();
+        c->pending_irradiance_sum = true;
+        return KJ_OK;
+    }
     hipLaunchKernelGGL(quad ? k_irc_trace_accessibility<true> : k_irc_trace_accessibility<false>, dim3(grid), dim3(64), lds_rays, s, tc);
     KJ_CHECK_LAUNCH();
     if (c->deferred) {   // lookups inside the next two passes read other entries' aux while those are rewritten: give them a snapshot

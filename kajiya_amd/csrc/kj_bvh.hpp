@@ -207,19 +207,33 @@ KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
     else KJ_POP(S.cur)
 }
 
-// Test ONE triangle of the leaf S.cur; an occlusion ray that hits is finished.
+// Test the next triangle(s) of the leaf S.cur; an occlusion ray that hits is finished. KJ_TRI_PAIR (experiment, round 4): a leaf with two or
+// more triangles left tests TWO per step -- both fetches issued before the first test -- so a 4-triangle leaf is two dependent round
+// trips instead of four. The closest hit (ties to the lowest world id) does not depend on how many triangles a step takes.
+#ifndef KJ_TRI_PAIR
+#define KJ_TRI_PAIR 0
+#endif
 template <bool ANY_HIT, bool STATS>
 KJ_D void tri_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
     const uint32_t first = S.cur & 0x0fffffffu;
-    const uint32_t rest = (S.cur >> 28) & 7u;      // triangles left after this one
+    uint32_t rest = (S.cur >> 28) & 7u;      // triangles left after this one
     const uint32_t slot = first;
     const float4* __restrict__ tp = (const float4*)bvh.tris + size_t(slot) * 3;
     const float4 a = tp[0], b = tp[1], c = tp[2];
-    if (STATS) stats->tris++;
-    if (intersect_tri(S.wo, S.wd, S.tmin, S.tmax, a, b, c, slot, S.cull_back, S.h)) {
-        if (ANY_HIT) { S.cur = KJ_BVH_NONE; return; }
-    }
-    if (rest) S.cur = KJ_BVH_LEAF | ((rest - 1u) << 28) | (first + 1u);
+#if KJ_TRI_PAIR
+    const uint32_t two = rest != 0u ? 1u : 0u;
+    const float4* __restrict__ tq = tp + two * 3u;      // the same triangle again when there is no second one: the load is always in range
+    const float4 a2 = tq[0], b2 = tq[1], c2 = tq[2];
+#else
+    const uint32_t two = 0u;
+#endif
+    if (STATS) stats->tris += 1u + two;
+    bool hit = intersect_tri(S.wo, S.wd, S.tmin, S.tmax, a, b, c, slot, S.cull_back, S.h);
+#if KJ_TRI_PAIR
+    if (two && !(ANY_HIT && hit)) hit |= intersect_tri(S.wo, S.wd, S.tmin, S.tmax, a2, b2, c2, slot + 1u, S.cull_back, S.h);
+#endif
+    if (ANY_HIT && hit) { S.cur = KJ_BVH_NONE; return; }
+    if (rest > two) S.cur = KJ_BVH_LEAF | ((rest - 1u - two) << 28) | (first + 1u + two);
     else KJ_POP(S.cur)
 }
 

@@ -37,6 +37,43 @@ KJ_HD float sqrt_fast(float x) { return sqrtf(x); }
 KJ_HD float exp2_fast(float x) { return exp2f(x); }
 KJ_HD float log2_fast(float x) { return log2f(x); }
 #endif
+// Division and square root for code that has to keep the reference's results (nearly always) bit for bit and cannot afford the ~11 / ~18
+// instruction IEEE sequences (TAA upstream of its hypersensitive probability stage): the hardware estimate (v_rcp_f32 / v_rsq_f32, 1 ulp) followed
+// by ONE Newton step on the RESULT through an exact fma residual -- e = fma(-d, q, n), q' = fma(e, r, q) -- whose error before the single final rounding
+// is second order (~1e-14 relative): the correctly rounded result except where the exact one lies within ~1e-14 of a rounding boundary (about
+// 1e-7 of operand pairs, then one ulp off). 4 instructions per quotient (3 when the reciprocal is shared by the components of a vector), 5 per root of a positive normal number.
+// The quotient of a zero numerator keeps IEEE's sign. Domain: d finite, normal, non-zero; n finite; results in the normal range (the IEEE sequence's operand scaling and its fix-up of infinities are
+// what is left out). The CPU stand-in (tests/hip_emu) divides and takes the root exactly.
+#if defined(__HIP_DEVICE_COMPILE__)
+KJ_D float div_nr_with(float n, float d, float r) {
+#pragma clang fp contract(off)      // n * r must round by itself: with contraction allowed, a numerator `a - 1.0f` is folded INTO the multiply ((a - 1) r -> fma(a, r, -r): measured)
+    const float q = n * r;
+    // the sign is q's: for n = -0 the refinement ends in (+0) + (-0) = +0 where the quotient is -0, and TAA's luma weights turn on the sign of a zero
+    // (cutoff / -0 = -inf -> weight 0, cutoff / +0 -> 1: the reference's own ill-conditioning; measured: 0.3 % of the history's texels without this)
+    return __builtin_copysignf(__builtin_fmaf(__builtin_fmaf(-d, q, n), r, q), q);
+}
+KJ_D float div_nr(float n, float d) { return div_nr_with(n, d, __builtin_amdgcn_rcpf(d)); }
+KJ_D float sqrt_nr_pos(float x) {        // x a positive, finite, normal number
+#pragma clang fp contract(off)
+    const float y = __builtin_amdgcn_rsqf(x), s = x * y, h = 0.5f * y;
+    return __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+}
+KJ_D float sqrt_nr(float x) {
+    if (x >= FLT_MIN && x < INFINITY) {
+        return sqrt_nr_pos(x);
+    }
+    return sqrtf(x);                     // 0, denormals, negative, NaN, inf: the IEEE sequence
+}
+#else
+KJ_HD float div_nr_with(float n, float d, float) { return n / d; }
+KJ_HD float div_nr(float n, float d) { return n / d; }
+KJ_HD float sqrt_nr(float x) { return sqrtf(x); }
+KJ_HD float sqrt_nr_pos(float x) { return sqrtf(x); }
+#endif
+KJ_HD V2 div_nr(V2 n, float d) { const float r = rcp_fast(d); return V2{div_nr_with(n.x, d, r), div_nr_with(n.y, d, r)}; }
+KJ_HD V3 div_nr(V3 n, float d) { const float r = rcp_fast(d); return V3{div_nr_with(n.x, d, r), div_nr_with(n.y, d, r), div_nr_with(n.z, d, r)}; }
+KJ_HD V4 div_nr(V4 n, float d) { const float r = rcp_fast(d); return V4{div_nr_with(n.x, d, r), div_nr_with(n.y, d, r), div_nr_with(n.z, d, r), div_nr_with(n.w, d, r)}; }
+KJ_HD V2 div_nr(V2 n, V2 d) { return V2{div_nr(n.x, d.x), div_nr(n.y, d.y)}; }
 KJ_HD float length_fast(V3 a) { return sqrt_fast(dot(a, a)); }
 KJ_HD float length_fast(V2 a) { return sqrt_fast(dot(a, a)); }
 KJ_HD V3 normalize_fast(V3 a) { return a * rsq_fast(dot(a, a)); }

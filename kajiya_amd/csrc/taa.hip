@@ -18,7 +18,10 @@ typedef Img<float> ImgF32;
 // One stage is hypersensitive, and that decides what may change where: input_prob divides the squared difference of the filtered
 // input and the filtered history by a variance floored at 1e-6, so ONE fp16 ulp in either image moves a texel's probability by O(1)
 // in flat regions. Everything upstream of it (history reprojection, the input / history filters, their colour decode) therefore
-// keeps the reference's operations bit for bit and only takes transformations that cannot change a result:
+// keeps the reference's operations and (nearly always) their bits, and only takes transformations that cannot change a result, or change one in ~1e-7 of cases by one ulp:
+//  * quotients and square roots go through div_nr / sqrt_nr (kj_screen.hpp: the hardware estimate + one Newton step on the result through an exact fma
+//    residual: correctly rounded except ~1e-7 of operand pairs) wherever the operands are provably in their domain, with the IEEE sequence behind a
+//    branch for black / non-finite texels; a third of this file's instructions were IEEE division sequences (round 4: TAA 0.29 -> 0.2x ms at 1080p);
 //  * exp2 / log2 of arguments whose results stay in the normal range go straight to v_exp_f32 / v_log_f32 (same bits as libm there);
 //  * `pow8(saturate(1e10 / luma))` -- the first of the two passes of the input / history filters -- is 1 for every luma in
 //    [+0, 1e10], decided by one integer compare on the bits; the division runs only for the others.
@@ -33,12 +36,27 @@ typedef Img<float> ImgF32;
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
 // taa_common.hlsl (TAA_NONLINEARITY_TYPE 1, TAA_COLOR_MAPPING_MODE 1)
-KJ_D V3 taa_decode_rgb(V3 v) { const float m = max3(v.x, v.y, v.z); return v * sqrtf(fmaxf(0.0f, m)) / fmaxf(1e-20f, m); }     // (upstream of input_prob: exact)
+#ifndef KJ_TAA_NR_MASK
+#define KJ_TAA_NR_MASK 31
+#endif
+#define NRDIV(bit_, a_, b_) (((KJ_TAA_NR_MASK) & (bit_)) ? div_nr(a_, b_) : ((a_) / (b_)))
+KJ_D V3 taa_decode_rgb(V3 v) {       // v * sqrt(max(0, m)) / max(1e-20, m), m = the largest component (upstream of input_prob: the reference's operations,
+    const float m = max3(v.x, v.y, v.z);     // nearly always its bits -- kj_screen.hpp: div_nr / sqrt_nr), without a branch:
+    if (!((KJ_TAA_NR_MASK) & 1)) return v * sqrtf(fmaxf(0.0f, m)) / fmaxf(1e-20f, m);
+    const V3 q = div_nr(v * sqrt_nr_pos(fmaxf(m, FLT_MIN)), fmaxf(1e-20f, m));
+    // m <= 0 (a black texel): sqrt(max(0, m)) = 0 and the quotient is v * 0 / 1e-20 = a signed zero (NaN for a NaN / infinite component, as v * 0 is);
+    // m = inf or NaN: NaN from both forms. (0 < m < 2^-126 cannot come out of an fp16 image times an exposure ratio; it gives 0 here.)
+    return V3{m >= FLT_MIN ? q.x : v.x * 0.0f, m >= FLT_MIN ? q.y : v.y * 0.0f, m >= FLT_MIN ? q.z : v.z * 0.0f};
+}
 KJ_D V3 taa_encode_rgb(V3 v) { const float m = max3(v.x, v.y, v.z); return v * ((m * m) * rcp_fast(fmaxf(1e-20f, m))); }
 // pow8(saturate(cutoff / luma)) of the input / history filters. cutoff = 1e10 ("no cutoff"): 1 for every luma in [+0, 1e10]
 KJ_D float pow8_(float x) { const float x2 = x * x, x4 = x2 * x2; return x4 * x4; }
 KJ_D float luma_weight_uncut(float luma) { return __float_as_uint(luma) <= __float_as_uint(1e10f) ? 1.0f : pow8_(saturate(1e10f / luma)); }
-KJ_D float luma_weight(float cutoff, float luma) { return pow8_(saturate(cutoff / luma)); }
+// saturate(cutoff / luma) is 1 wherever 0 < luma <= cutoff (a correctly rounded quotient >= 1); above the cutoff luma > 0 and the quotient is in div_nr's domain
+KJ_D float luma_weight(float cutoff, float luma) {
+    if (((KJ_TAA_NR_MASK) & 2) && luma > 0.0f && cutoff > 0.0f) return luma <= cutoff ? 1.0f : pow8_(fminf(div_nr(cutoff, luma), 1.0f));
+    return pow8_(saturate(cutoff / luma));       // black texels / a black neighbourhood (0 / 0 = NaN -> 0), negative lumas: as written
+}
 KJ_D float ld1h(const ImgH1& i, int x, int y) { return f16_to_f32(i.ld(x, y)); }
 
 // image_sample_catmull_rom_5tap (inc/image.hlsl:88-172); the history remap (decode_rgb * pre_exposure_delta) is applied per tap
@@ -55,15 +73,17 @@ KJ_D V4 catmull_rom_5tap_history(const ImgH4& tex, V2 uv, V2 tex_size, float ped
     const V2 w2 = f * (0.5f + f * (2.0f - 1.5f * f));
     const V2 w3 = f * f * (-0.5f + 0.5f * f);
     const V2 w12 = w1 + w2;
-    const V2 offset12 = w2 / (w1 + w2);
-    const V2 p0 = (tex_pos1 - 1.0f) / tex_size, p3 = (tex_pos1 + 2.0f) / tex_size, p12 = (tex_pos1 + offset12) / tex_size;
+    const V2 offset12 = NRDIV(4 | 32, w2, w1 + w2);                                      // w1 + w2 in [0.5, 1.125]
+    const V2 p0 = NRDIV(4 | 64, tex_pos1 - 1.0f, tex_size), p3 = NRDIV(4 | 64, tex_pos1 + 2.0f, tex_size), p12 = NRDIV(4 | 64, tex_pos1 + offset12, tex_size);
     V4 result = v4(0.0f);
     result += taa_history_tap(tex, V2{p12.x, p0.y}, ped) * w12.x * w0.y;
     result += taa_history_tap(tex, V2{p0.x, p12.y}, ped) * w0.x * w12.y;
     result += taa_history_tap(tex, V2{p12.x, p12.y}, ped) * w12.x * w12.y;
     result += taa_history_tap(tex, V2{p3.x, p12.y}, ped) * w3.x * w12.y;
     result += taa_history_tap(tex, V2{p12.x, p3.y}, ped) * w12.x * w3.y;
-    return result / (w12.x * w0.y + w0.x * w12.y + w12.x * w12.y + w3.x * w12.y + w12.x * w3.y);
+    // (this quotient stays on the IEEE sequence: with div_nr here -- bit-exact by itself, scripts/selftest_div_sqrt_nr.py -- the compiler schedules the five
+    // accumulations above differently and channels that are exactly zero come out as -0 instead of +0, which TAA's luma weights turn into 0 against 1: measured)
+    return NRDIV(128, result, w12.x * w0.y + w0.x * w12.y + w12.x * w12.y + w3.x * w12.y + w12.x * w3.y);      // the five weights sum to 0.9 .. 1
 }
 
 // reproject_history.hlsl:42-129
@@ -72,7 +92,7 @@ __global__ void __launch_bounds__(64) k_taa_reproject(const FrameConstants* __re
     const int OW = output_tex.w, OH = output_tex.h;
     TILE_XY_M(OW, OH, KJ_TILES_ROWS)
     const V4 its = tex_size4(IW, IH), ots = tex_size4(OW, OH);
-    const V2 scale{its.x / ots.x, its.y / ots.y};
+    const V2 scale{NRDIV(4 | 256, its.x, ots.x), NRDIV(4 | 256, its.y, ots.y)};
     const int rx = int(uint32_t((float(x) + 0.5f) * scale.x)), ry = int(uint32_t((float(y) + 0.5f) * scale.y));
     V2 vmn, vmx;
     {
@@ -148,9 +168,9 @@ KJ_D void taa_filter_input_body(const ImgH4& input_tex, const ImgF32& depth_tex,
         iex += s[i];
         iex2 += s[i] * s[i];
     }
-    clamped_iex = clamped_iex / clamped_iwsum;
-    iex = iex / 9.0f;
-    iex2 = iex2 / 9.0f;
+    clamped_iex = NRDIV(8, clamped_iex, clamped_iwsum);      // (a zero weight sum -- a neighbourhood of NaNs -- is NaN either way)
+    iex = NRDIV(8, iex, 9.0f);
+    iex2 = NRDIV(8, iex2, 9.0f);
     const V3 var_a = vmax(v3(0.0f), iex2 - iex * iex);
     // pass 2: luma_cutoff = first pass' luma * 1.001
     const float cutoff = clamped_iex.x * 1.001f;
@@ -161,9 +181,9 @@ KJ_D void taa_filter_input_body(const ImgH4& input_tex, const ImgF32& depth_tex,
         cws += w;
         cex += s[i] * w;
     }
-    cex = cex / cws;
+    cex = NRDIV(8, cex, cws);          // (cws = 0 in a black neighbourhood: 0 / 0 = NaN either way)
     st4(output_tex, x, y, v4(cex, 0.0f));
-    st4(dev_output_tex, x, y, v4(vsqrt(var_a), 0.0f));
+    st4(dev_output_tex, x, y, v4(((KJ_TAA_NR_MASK) & 8) ? V3{sqrt_nr(var_a.x), sqrt_nr(var_a.y), sqrt_nr(var_a.z)} : vsqrt(var_a), 0.0f));
 }
 __global__ void __launch_bounds__(64) k_taa_filter_input(ImgH4 input_tex, ImgF32 depth_tex, ImgH4 output_tex, ImgH4 dev_output_tex, int row0, int row1) {
     taa_filter_input_body(input_tex, depth_tex, output_tex, dev_output_tex, row0, row1);
@@ -184,7 +204,7 @@ KJ_D V3 fh_filter_input(const V3* taps, float luma_cutoff) {
             iwsum += w;
             iex += s * w;
         }
-    return iex / iwsum;
+    return NRDIV(8, iex, iwsum);
 }
 template <int K, bool TILED>
 KJ_D void taa_filter_history_body(const ImgH4& reprojected_history, const ImgH4& output_tex, int row0, int row1) {
@@ -331,10 +351,10 @@ __global__ void __launch_bounds__(256) k_taa_filter_prob_both(ImgH1 input_tex, I
 struct Unjittered { V4 color; float coverage; V3 ex, ex2; };
 template <bool TILED>
 KJ_D void sample_image_unjitter_taa2(const ImgH4& img, const float4* tile_cols /* 10x10, centred on this lane */, int opx, int opy, V2 out_size, V2 sample_offset_pixels, float ks_a, float ks_b, Unjittered& ra, Unjittered& rb) {
-    const V2 scale = V2{float(img.w), float(img.h)} / out_size;
+    const V2 scale = NRDIV(16, (V2{float(img.w), float(img.h)}), out_size);
     const int bx = int((float(opx) + 0.5f) * scale.x), by = int((float(opy) + 0.5f) * scale.y);
     const V2 dst_sample_loc{float(opx) + 0.5f, float(opy) + 0.5f};
-    const V2 base_src_sample_loc = V2{float(bx) + 0.5f + sample_offset_pixels.x, float(by) + 0.5f - sample_offset_pixels.y} / scale;
+    const V2 base_src_sample_loc = NRDIV(16, (V2{float(bx) + 0.5f + sample_offset_pixels.x, float(by) + 0.5f - sample_offset_pixels.y}), scale);
     V4 res_a = v4(0.0f), res_b = v4(0.0f);
     V3 ex_a = v3(0.0f), ex2_a = v3(0.0f), ex_b = v3(0.0f), ex2_b = v3(0.0f);
     float dev_wt_sum_a = 0, wt_sum_a = 0, dev_wt_sum_b = 0, wt_sum_b = 0;
@@ -342,7 +362,7 @@ KJ_D void sample_image_unjitter_taa2(const ImgH4& img, const float4* tile_cols /
     for (int yy = -1; yy <= 1; ++yy)
 #pragma unroll
         for (int xx = -1; xx <= 1; ++xx) {
-            const V2 src_sample_loc = base_src_sample_loc + V2{float(xx), float(yy)} / scale;
+            const V2 src_sample_loc = base_src_sample_loc + NRDIV(16, (V2{float(xx), float(yy)}), scale);
             V3 col;
             if (TILED) { const float4 t = tile_cols[yy * 10 + xx]; col = V3{t.x, t.y, t.z}; }
             else col = sRGB_to_YCbCr(taa_decode_rgb(xyz(ld4(img, bx + xx, by + yy))));
@@ -362,8 +382,8 @@ KJ_D void sample_image_unjitter_taa2(const ImgH4& img, const float4* tile_cols /
                 ex_b += col * dev_wt; ex2_b += col * col * dev_wt; dev_wt_sum_b += dev_wt;
             }
         }
-    ra = Unjittered{res_a, wt_sum_a, ex_a / dev_wt_sum_a, ex2_a / dev_wt_sum_a};     // IEEE: a variance is formed from these moments
-    rb = Unjittered{res_b, wt_sum_b, ex_b / dev_wt_sum_b, ex2_b / dev_wt_sum_b};
+    ra = Unjittered{res_a, wt_sum_a, NRDIV(16, ex_a, dev_wt_sum_a), NRDIV(16, ex2_a, dev_wt_sum_a)};     // a variance is formed from these moments: the (nearly always) correctly rounded quotients
+    rb = Unjittered{res_b, wt_sum_b, NRDIV(16, ex_b, dev_wt_sum_b), NRDIV(16, ex2_b, dev_wt_sum_b)};
 }
 
 // taa.hlsl:94-338
@@ -395,7 +415,7 @@ __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
     if (!in_image) return;
     const FrameConstants& fc = *a.fc;
     const V4 ots = tex_size4(OW, OH);
-    const V2 frac_{float(a.input_tex.w) / float(OW), float(a.input_tex.h) / float(OH)};
+    const V2 frac_{NRDIV(16, float(a.input_tex.w), float(OW)), NRDIV(16, float(a.input_tex.h), float(OH))};
     const V2 sop{fc.view_constants.sample_offset_pixels[0], fc.view_constants.sample_offset_pixels[1]};
     const int rx = int(uint32_t((float(x) + 0.5f) * frac_.x)), ry = int(uint32_t((float(y) + 0.5f) * frac_.y));
     const V2 uv = get_uv(float(x), float(y), ots);
@@ -479,7 +499,7 @@ __global__ void __launch_bounds__(64) k_taa(TaaArgs a) {
     }
     float total_coverage = fmaxf(1e-5f, history_coverage + coverage);
     V3 temporal_result = (clamped_history * history_coverage + center) * rcp_fast(total_coverage);
-    total_coverage = fminf(fmaxf(2.0f, 8.0f / (frac_.x * frac_.y)), total_coverage);
+    total_coverage = fminf(fmaxf(2.0f, NRDIV(16, 8.0f, frac_.x * frac_.y)), total_coverage);
     st4(a.smooth_var_output_tex, x, y, v4(smooth_var, 0.0f));
     temporal_result = vmax(v3(0.0f), taa_encode_rgb(YCbCr_to_sRGB(temporal_result)));
     st4(a.temporal_output_tex, x, y, v4(temporal_result, total_coverage));
@@ -632,3 +652,35 @@ KjStatus kj_taa_surface(KjTaa* t, const char* name, void** out_dev_ptr, uint64_t
 }
 
 }  // extern "C"
+
+// ---- self test of kj_screen.hpp's div_nr / sqrt_nr against the IEEE operations, on the device: counts[0] = quotients that differ, counts[1] = roots that
+// differ, counts[2] = quotients off by more than one ulp, counts[3] = roots off by more than one ulp, over `n` pseudo-random operand pairs
+__global__ void __launch_bounds__(256) k_selftest_div_sqrt_nr(uint32_t n, uint32_t seed, unsigned long long* __restrict__ counts) {
+    uint32_t bad_q = 0, bad_s = 0, far_q = 0, far_s = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t h0 = hash1(i ^ seed), h1 = hash1(h0 + 0x9e3779b9u), h2 = hash1(h1 + i);
+        // numerator and denominator: random mantissas, exponents in [-20, 20]; every 8th numerator negative
+        const float num = __uint_as_float(((107u + h2 % 41u) << 23) | (h0 & 0x7fffffu)) * ((h2 >> 8) % 8u == 0u ? -1.0f : 1.0f);
+        const float den = __uint_as_float(((107u + (h2 >> 16) % 41u) << 23) | (h1 & 0x7fffffu));
+        float num_ = num, den_ = den;
+        if (seed & 1u) {         // odd seeds: TAA's own operand classes -- half-integer texel positions over image extents, Catmull-Rom weight ratios
+            if (i & 1u) { num_ = float(int(h0 % 4200u) - 3) + 0.5f + (h2 & 2u ? 0.0f : __uint_as_float(0x3f000000u | (h1 & 0x7fffffu)) - 0.5f); den_ = float(64u + h1 % 4033u); }
+            else { const float f = __uint_as_float(0x3f800000u | (h0 & 0x7fffffu)) - 1.0f; const float w1 = 1.0f + f * f * (-2.5f + 1.5f * f), w2 = f * (0.5f + f * (2.0f - 1.5f * f)); num_ = w2; den_ = w1 + w2; }
+        }
+        if ((h1 >> 23) % 64u == 0u) num_ = (h2 & 4u) ? -0.0f : 0.0f;       // zero numerators of either sign
+        const float q_ieee = num_ / den_, q_nr = div_nr(num_, den_);
+        const float s_ieee = sqrtf(den), s_nr = sqrt_nr(den);
+        if (__float_as_uint(q_ieee) != __float_as_uint(q_nr)) { ++bad_q; if (fabsf(q_ieee - q_nr) > fabsf(q_ieee) * 1.3e-7f) ++far_q; }
+        if (__float_as_uint(s_ieee) != __float_as_uint(s_nr)) { ++bad_s; if (fabsf(s_ieee - s_nr) > fabsf(s_ieee) * 1.3e-7f) ++far_s; }
+    }
+    if (bad_q) atomicAdd(&counts[0], (unsigned long long)bad_q);
+    if (bad_s) atomicAdd(&counts[1], (unsigned long long)bad_s);
+    if (far_q) atomicAdd(&counts[2], (unsigned long long)far_q);
+    if (far_s) atomicAdd(&counts[3], (unsigned long long)far_s);
+}
+extern "C" KjStatus kj_selftest_div_sqrt_nr(uint32_t n, uint32_t seed, void* counts4_u64_device, void* stream) {
+    KJ_REQUIRE(counts4_u64_device, "null argument");
+    hipLaunchKernelGGL(k_selftest_div_sqrt_nr, dim3(1024), dim3(256), 0, (hipStream_t)stream, n, seed, (unsigned long long*)counts4_u64_device);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}

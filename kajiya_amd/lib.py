@@ -402,7 +402,7 @@ class GpuPipeline:
         """Prime the pipeline: upload `fc` and issue the ircache work of the first frame on the side stream."""
         torch = self.torch
         assert self.ircache, "pipelining overlaps the irradiance cache; nothing to do without it"
-        self._s1 = torch.cuda.Stream()
+        self._s1 = torch.cuda.Stream(priority=int(os.environ.get("KJ_PRIO_IRC", "0")))      # stream priorities: A/B knobs (profiles/r04_stream_priorities.md)
         self._ev_irc = [torch.cuda.Event(), torch.cuda.Event()]
         self._ev_fc = [torch.cuda.Event(), torch.cuda.Event()]      # frame constants of frame i are in place (k_frame_begin ran on the side stream)
         self._ev_trace = [torch.cuda.Event(), torch.cuda.Event()]
@@ -438,7 +438,7 @@ class GpuPipeline:
         s0 = torch.cuda.current_stream()
         i = self._pipe_i & 1
         if not hasattr(self, "_s2"):
-            self._s2 = torch.cuda.Stream()
+            self._s2 = torch.cuda.Stream(priority=int(os.environ.get("KJ_PRIO_TAA", "0")))
             self._ev_gi = [torch.cuda.Event(), torch.cuda.Event()]
             self._ev_taa = [torch.cuda.Event(), torch.cuda.Event()]
         # everything that does not read the cache goes first: the wait for the cache stream sits in the frame-to-frame critical
@@ -454,7 +454,7 @@ class GpuPipeline:
             self.ssgi_frame()
         if overlap_ssgi:
             if not hasattr(self, "_s3"):
-                self._s3 = torch.cuda.Stream()
+                self._s3 = torch.cuda.Stream(priority=int(os.environ.get("KJ_PRIO_SSGI", "0")))
                 self._ev_ssgi = [torch.cuda.Event(), torch.cuda.Event()]
             with torch.cuda.stream(self._s3):
                 self._s3.wait_event(self._ev_fc[i])

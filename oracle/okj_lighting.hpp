@@ -1,7 +1,7 @@
 // ORACLE (test infrastructure). LightingRenderer::render_specular restated (renderers/lighting.rs:23-88; shaders/lighting/
 // sample_lights.rgen.hlsl, spatial_reuse_lights.hlsl): specular lighting from the triangle lights — one light sample + shadow ray per
 // half-res pixel, eight-tap ratio-estimator reuse at full res — ADDED into rtr's resolved image (RENDER_INTO_RTR) so both are filtered
-// together (world_render_passes.rs:190-203). Runs only when the scene has triangle lights. Parity unpinned (no reference vectors).
+// together (world_render_passes.rs:190-203). Runs only when the scene has triangle lights. Pinned to the two shaders' own text: tests/test_ref_hlsl.py::test_light_specular_reference_hlsl_vs_oracle.
 #pragma once
 #include "okj_rtr.hpp"
 

@@ -9,7 +9,7 @@ if [ "$WHICH" = "4k" ]; then
 else
   ARGS=""; WL="scene=city,tris=1000000,width=1920,height=1080"; JSON=pmc_kernels.json; TAG=1080p
 fi
-OUT=$ROOT/gpurun_out/pmc_r03_$TAG
+RND=${KJ_ROUND:-4}; OUT=$ROOT/gpurun_out/pmc_r0${RND}_$TAG
 rm -rf $OUT; mkdir -p $OUT
 CMD="python $ROOT/bench.py $ARGS --steps 9 --warmup 6 --profile-frames 3 --no-cpu-baseline --no-also --no-overlap --pmc-calibration-copy"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "VALUBusy VALUUtilization" "MemUnitStalled SQ_WAVES"; do
@@ -17,8 +17,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "VALUBusy VALUUtilization" "MemUnitStalled 
   timeout 600 rocprofv3 --pmc $grp -d $OUT/$tag -o pmc --output-format csv -- $CMD > $OUT/$tag.log 2>&1
 done
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- $CMD > $OUT/stats.log 2>&1
-python $ROOT/scripts/pmc_to_json.py $ROOT/gpurun_out/$JSON --workload $WL --round 3 \
+python $ROOT/scripts/pmc_to_json.py $ROOT/gpurun_out/$JSON --workload $WL --round $RND \
   --calibrate "pmc_calibration_copy:536870912" $OUT/FETCH_SIZE $OUT/WRITE_SIZE $OUT/VALUBusy_VALUUtilization $OUT/MemUnitStalled_SQ_WAVES
-cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $ROOT/gpurun_out/r03_kernel_stats_${TAG}_serial.csv 2>/dev/null
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $ROOT/gpurun_out/r0${RND}_kernel_stats_${TAG}_serial.csv 2>/dev/null
 find $OUT -name "*.csv" -size +2M -delete 2>/dev/null     # the per-dispatch counter tables are large; the summaries above are what is kept
-ls -la $ROOT/gpurun_out/$JSON $ROOT/gpurun_out/r03_kernel_stats_${TAG}_serial.csv
+ls -la $ROOT/gpurun_out/$JSON $ROOT/gpurun_out/r0${RND}_kernel_stats_${TAG}_serial.csv

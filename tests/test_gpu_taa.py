@@ -1,6 +1,7 @@
 """GPU parity for TAA (TaaRenderer::render): every frame both implementations receive the SAME input image,
 reprojection map and depth (the oracle's); all TAA surfaces are compared per frame."""
 import ctypes as C
+import os
 import numpy as np
 import pytest
 
@@ -75,6 +76,11 @@ class TaaStep:
             else:
                 r = P.compare(got, ref, fmt)
             self.worst = max(self.worst, r["rel_l2"])
+            if os.environ.get("KJ_TAA_DEBUG"):      # debugging aid: which surfaces differ from the oracle at all, and how (raw halves of the first texels)
+                g16, r16 = got.view(np.uint16), ref.view(np.uint16)
+                bad = np.nonzero(g16 != r16)[0]
+                print(f"  frame {fi} {name}: {bad.size} of {g16.size} halves differ" + (f", e.g. at {bad[:6]}: got {[hex(v) for v in g16[bad[:6]]]} ref {[hex(v) for v in r16[bad[:6]]]}" if bad.size else ""))
+                continue
             # filter_history.hlsl:37 weights taps by pow8(saturate(cutoff / luma)): where the history is dark (luma ~ 0, freshly disoccluded
             # texels) the quotient is ill-conditioned in the reference itself, so for this image up to 1 % of the texels may be outliers
             # (at most 5e-4 off in absolute terms at 1080p); the image as a whole still has to meet 1e-3. input_prob.hlsl:77-100 divides the

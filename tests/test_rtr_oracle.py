@@ -1,5 +1,5 @@
-"""CPU checks of the rtr restatement (oracle/okj_rtr.hpp). The reference holds no vectors for this path (parity
-unpinned), so the oracle is pinned by properties: B10G11R11 packing known answers, the sampler-table arithmetic, and the
+"""CPU checks of the rtr restatement (oracle/okj_rtr.hpp). The reference holds no vectors for this path; the oracle's six
+passes are held to the reference's shader text in tests/test_ref_hlsl.py, and here to properties: B10G11R11 packing known answers, the sampler-table arithmetic, and the
 physical invariant that a smooth metal mirror under the sky resolves to the sky radiance along the mirrored view direction
 (rtr output is "radiance not scaled by FG", rtr_settings.hlsl:7)."""
 import ctypes as C

@@ -25,14 +25,28 @@ def _fc(W, H, frame_index, pre_exposure):
     return fs.prepare_frame_constants(frame.orbit_camera(0, (W, H)))
 
 
-def _compare(got_words, ref_words, what, max_differ):
+def _compare(got_words, ref_words, what, max_differ, singular_texels=0):
+    """`singular_texels`: how many texels may sit on the display transform's own singularity (the final image only). The second Helmholtz-
+    Kohlrausch evaluation of display_transform.hlsl (inc/color/helmholtz_kohlrausch.hlsl:53-106) maps the hue angle to t = theta / pi * 0.5 + 0.5
+    and indexes its 16 spline samples with uint(floor(t * 16)) % 16; a colour whose CIE LUV v' equals the white point's EXACTLY, on the cyan
+    side, has theta = pi, t = 1.0, index 16 % 16 = 0 and a spline parameter of 16 instead of 0..1: the extrapolated multiplier is 27 instead of
+    1.04 and the pixel comes out 24x darker. With fp32 chromaticities that is ~3e-7 of all colours -- about one pixel of a 1080p frame, in the
+    reference too -- and whether a given texel is on it depends on the last bit of everything upstream (measured on MI355X: 2 of 2 M texels
+    of the 1080p case, one on each side; oracle/okj_post.hpp and post.hip follow the text: DESIGN.md section 4)."""
     a = P.decode(np.ascontiguousarray(got_words).view(np.uint8), "r11g11b10f").astype(np.float64)
     b = P.decode(np.ascontiguousarray(ref_words).view(np.uint8), "r11g11b10f").astype(np.float64)
     assert np.isfinite(a).all() and np.isfinite(b).all(), what
     err = np.abs(a - b)
     tol = np.maximum(np.abs(b), 2.0 ** -14) * STEP
+    beyond = (err > 2.05 * tol + 1e-9).any(-1)
+    if beyond.sum() > singular_texels:
+        bad = np.argwhere(beyond).reshape(-1)
+        w = int(np.argmax((err / tol).max(-1)))
+        raise AssertionError((what, float((err / tol).max()), f"{bad.size} texels beyond two steps, first {bad[:8]}, worst texel {w}: got {a[w]} ref {b[w]}"))
+    if beyond.any():
+        print(f"{what}: {int(beyond.sum())} texel(s) on the display transform's singularity: {np.argwhere(beyond).reshape(-1)[:4]}")
+    err, a, b = err[~beyond], a[~beyond], b[~beyond]
     differ = float((err > 0).any(-1).mean())
-    assert (err <= 2.05 * tol + 1e-9).all(), (what, float((err / tol).max()))
     assert differ <= max_differ, (what, differ)
     return differ
 
@@ -64,7 +78,7 @@ def test_post_matches_oracle(gpu, oracle, device, W, H, frame_index, mult, contr
         for pyr in ("blur_pyramid", "rev_blur_pyramid"):
             g = gp.surface(f"{pyr}:{l}", torch.int32, (h, w)).cpu().numpy().view(np.uint32)
             worst[pyr] = max(worst.get(pyr, 0.0), _compare(g, op.mip(pyr, l), f"{pyr}:{l}", 0.03 if w * h > 500 else 0.2))
-    worst["output"] = _compare(got.cpu().numpy().view(np.uint32), ref, "output", 0.05)
+    worst["output"] = _compare(got.cpu().numpy().view(np.uint32), ref, "output", 0.05, singular_texels=max(1, int(4e-6 * W * H)))
     hist_g = gp.surface("histogram", torch.int32, (256,)).cpu().numpy().view(np.uint32).astype(np.int64)
     hist_o = op.histogram().astype(np.int64)
     assert abs(int(hist_g.sum()) - int(hist_o.sum())) <= 0.002 * hist_o.sum()
