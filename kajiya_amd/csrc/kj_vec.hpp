@@ -197,14 +197,26 @@ KJ_HD V2 r2_sequence(uint32_t i) {
     const float xs = x + 0.5f, ys = y + 0.5f;
     return V2{xs - floorf(xs), ys - floorf(ys)};
 }
+// A texel code divided by its format's maximum (n / 255, / 127, / 1023, / 32767). On the device the IEEE division (11 instructions per channel, and every screen
+// pass decodes the reprojection map, view normals, blue noise) is the constant reciprocal and one Newton step on the quotient through an exact fma residual:
+// the correctly rounded quotient for EVERY code of each format (tests/test_oracle.py::test_texel_code_division_through_the_reciprocal_is_exact walks them all).
+template <int MAXV> KJ_HD float texel_code_div(float n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang fp contract(off)
+    const float d = float(MAXV), r = 1.0f / float(MAXV), q = n * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+#else
+    return n / float(MAXV);
+#endif
+}
 // inc/blue_noise.hlsl:8-15; tex = 256x256 RGBA8 packed as one u32 per texel
 KJ_D V4 blue_noise_for_pixel(const uint32_t* __restrict__ tex, uint32_t px, uint32_t py, uint32_t n) {
     V2 r = r2_sequence(n);
     uint32_t ox = uint32_t(r.x * 256.0f), oy = uint32_t(r.y * 256.0f);
     uint32_t t = tex[((py + oy) & 255u) * 256u + ((px + ox) & 255u)];
     const float s = 255.0f / 256.0f, b = 0.5f / 256.0f;
-    return V4{(float(t & 255u) / 255.0f) * s + b, (float((t >> 8) & 255u) / 255.0f) * s + b,
-              (float((t >> 16) & 255u) / 255.0f) * s + b, (float(t >> 24) / 255.0f) * s + b};
+    return V4{texel_code_div<255>(float(t & 255u)) * s + b, texel_code_div<255>(float((t >> 8) & 255u)) * s + b,
+              texel_code_div<255>(float((t >> 16) & 255u)) * s + b, texel_code_div<255>(float(t >> 24)) * s + b};
 }
 
 // ---- fp16 storage (round-to-nearest-even, both directions exact)
@@ -264,17 +276,17 @@ KJ_HD V3 rgb9e5_to_float3(uint32_t v) {
 
 // ---- typed-format conversions (fixed-function image load/store in the reference; RNE)
 KJ_HD int8_t to_snorm8(float v) { return int8_t(rintf(clampf(v, -1.0f, 1.0f) * 127.0f)); }
-KJ_HD float from_snorm8(int8_t v) { return fmaxf(float(v) / 127.0f, -1.0f); }
+KJ_HD float from_snorm8(int8_t v) { return fmaxf(texel_code_div<127>(float(v)), -1.0f); }
 KJ_HD uint8_t to_unorm8(float v) { return uint8_t(rintf(clampf(v, 0.0f, 1.0f) * 255.0f)); }
-KJ_HD float from_unorm8(uint8_t v) { return float(v) / 255.0f; }
+KJ_HD float from_unorm8(uint8_t v) { return texel_code_div<255>(float(v)); }
 KJ_HD int16_t to_snorm16(float v) { return int16_t(rintf(clampf(v, -1.0f, 1.0f) * 32767.0f)); }
-KJ_HD float from_snorm16(int16_t v) { return fmaxf(float(v) / 32767.0f, -1.0f); }
+KJ_HD float from_snorm16(int16_t v) { return fmaxf(texel_code_div<32767>(float(v)), -1.0f); }
 KJ_HD uint32_t pack_a2r10g10b10(V3 rgb) {
     uint32_t r = uint32_t(rintf(clampf(rgb.x, 0.0f, 1.0f) * 1023.0f)), g = uint32_t(rintf(clampf(rgb.y, 0.0f, 1.0f) * 1023.0f)),
              b = uint32_t(rintf(clampf(rgb.z, 0.0f, 1.0f) * 1023.0f));
     return (r << 20) | (g << 10) | b;
 }
-KJ_HD V3 unpack_a2r10g10b10(uint32_t p) { return V3{float((p >> 20) & 1023u) / 1023.0f, float((p >> 10) & 1023u) / 1023.0f, float(p & 1023u) / 1023.0f}; }
+KJ_HD V3 unpack_a2r10g10b10(uint32_t p) { return V3{texel_code_div<1023>(float((p >> 20) & 1023u)), texel_code_div<1023>(float((p >> 10) & 1023u)), texel_code_div<1023>(float(p & 1023u))}; }
 KJ_HD uint32_t pack_rgba8_snorm(V4 v) {
     return uint32_t(uint8_t(to_snorm8(v.x))) | (uint32_t(uint8_t(to_snorm8(v.y))) << 8) | (uint32_t(uint8_t(to_snorm8(v.z))) << 16) | (uint32_t(uint8_t(to_snorm8(v.w))) << 24);
 }

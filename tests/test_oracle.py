@@ -791,3 +791,21 @@ def test_gbuffer_layout_matches_the_reference_s_rust_statement(oracle):
         assert list(unp[8:11]) == list(rgb)
         # and the round trip is tight: 8-bit sqrt-encoded albedo, 11-bit normal, f16 roughness
         assert np.abs(np.array(unp[0:3]) - albedo).max() < 5e-3 and np.abs(np.array(unp[3:6]) - n).max() < 2e-3 and abs(unp[6] - rough) < 2e-3
+
+
+def test_texel_code_division_through_the_reciprocal_is_exact():
+    """kj_vec.hpp: texel_code_div<MAXV> on the device computes n / MAXV as q = n * r, q' = fma(fma(-MAXV, q, n), r, q) with r = fl(1 / MAXV). For every code
+    of every format that uses it -- UNORM8 (0..255 / 255), SNORM8 (-128..127 / 127), UNORM10 (0..1023 / 1023), SNORM16 (-32768..32767 / 32767) -- that must be
+    the correctly rounded quotient, bit for bit (what the oracle's division gives). libm's fmaf is the exact fma."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.fmaf.restype = C.c_float
+    libm.fmaf.argtypes = [C.c_float] * 3
+    for maxv, lo, hi in ((255, 0, 255), (127, -128, 127), (1023, 0, 1023), (32767, -32768, 32767)):
+        d = np.float32(maxv)
+        r = np.float32(1.0) / d
+        for v in range(lo, hi + 1):
+            n = np.float32(v)
+            q = np.float32(n * r)
+            res = np.float32(libm.fmaf(libm.fmaf(-d, q, n), r, q))
+            assert res.tobytes() == np.float32(n / d).tobytes(), (maxv, v, res, n / d)
