@@ -166,6 +166,10 @@ enum KjAbiStruct { KJ_ABI_FRAME_CONSTANTS = 0, KJ_ABI_VIEW_CONSTANTS, KJ_ABI_MES
                    KJ_ABI_GBUFFER_DEPTH, KJ_ABI_RTDGI_RENDER_PARAMS, KJ_ABI_RTDGI_OUTPUT, KJ_ABI_TAA_OUTPUT, KJ_ABI_RTR_TABLES, KJ_ABI_RTR_PARAMS, KJ_ABI_SPLIT_RANK,
                    KJ_ABI_SPLIT_FRAME, KJ_ABI_BAKED_MESH_VIEW, KJ_ABI_BAKED_IMAGE_VIEW, KJ_ABI_STRUCT_COUNT };
 uint32_t kj_abi_struct_size(uint32_t id);
+/* Device self test (no reference counterpart): the cheap exact division / square root the screen passes use (csrc/kj_screen.hpp: div_nr, sqrt_nr) against the
+ * IEEE operations over `n` pseudo-random operand pairs (odd `seed`s draw TAA's own operand classes). `counts4_u64_device`: four uint64 on the device, ADDED to:
+ * quotients whose bits differ, roots whose bits differ, quotients off by more than an ulp, roots off by more than an ulp. scripts/selftest_div_sqrt_nr.py. */
+KjStatus kj_selftest_div_sqrt_nr(uint32_t n, uint32_t seed, void* counts4_u64_device, void* stream);
 
 /* RenderBackend / WorldRenderer::new analogue (default_world_renderer.rs:14-58):
  * picks the HIP device, builds the BRDF-FG LUT (bindless #0, lut/brdf_fg.hlsl),
