@@ -567,6 +567,7 @@ KjStatus kj_ircache_create(KjDevice* dev, KjIrcache** out) {
     KJ_REQUIRE(dev && out, "null argument");
     KjIrcache* c = new KjIrcache();
     c->dev = dev;
+    c->ray_passes_side_by_side = getenv("KJ_IRC_SIDE_BY_SIDE") && atoi(getenv("KJ_IRC_SIDE_BY_SIDE")) != 0;
     hipError_t e = hipSuccess;
     auto A = [&](kj::DevBuf& b, size_t n) { if (e == hipSuccess) e = b.alloc(n); };
     A(c->meta, 32); A(c->grid_meta[0], size_t(IRC_MAX_GRID_CELLS) * 8); A(c->grid_meta[1], size_t(IRC_MAX_GRID_CELLS) * 8);
@@ -695,12 +696,11 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     KJ_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_irc_reset, dim3(grid), dim3(64), 0, s, tc.ic);
     KJ_CHECK_LAUNCH();
-    // racy (the reference's) mode, opt-in (KJ_IRC_SIDE_BY_SIDE=1): the three passes side by side in one launch, as the reference's barrier-free
+    // racy (the reference's) mode, opt-in (kj_ircache_set_ray_passes_side_by_side, or KJ_IRC_SIDE_BY_SIDE=1 at creation): the three passes side by side in one launch, as the reference's barrier-free
     // recording lets them run. Measured on MI355X (round 4, profiles/r04_ab_runs.md): the cache's segment 0.40 -> 0.21 ms at 1080p, the PIPELINED
     // frame unchanged (it is VALU-bound, not waiting for this chain), and the SH sums on identical state move from 1.3e-2 to 5.3e-2 of the
     // sequential oracle's (tests/test_gpu_ircache.py; bar 5e-2) -- so it is not the default.
-    static const bool side_by_side = getenv("KJ_IRC_SIDE_BY_SIDE") && atoi(getenv("KJ_IRC_SIDE_BY_SIDE")) != 0;
-    if (!c->deferred && side_by_side) {
+    if (!c->deferred && c->ray_passes_side_by_side) {
         hipLaunchKernelGGL(quad ? k_irc_ray_passes<true> : k_irc_ray_passes<false>, dim3(grid * 3u), dim3(64), lds_rays, s, tc, grid);
         KJ_CHECK_LAUNCH();
         c->pending_irradiance_sum = true;
@@ -732,6 +732,7 @@ KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream_) 
 }
 // ---- deferred updates: begin (clear the frame's slots), collect (compact a slot range into a list), apply (replay a merged list)
 KjStatus kj_ircache_set_deferred_updates(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->deferred = enable != 0; return KJ_OK; }
+KjStatus kj_ircache_set_ray_passes_side_by_side(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->ray_passes_side_by_side = enable != 0; return KJ_OK; }
 KjStatus kj_ircache_set_rtr_requests(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->rtr_requests = enable != 0; return KJ_OK; }
 KjStatus kj_ircache_begin_requests(KjIrcache* c, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, void* stream_) {
     return kj_ircache_begin_requests_rows(c, rtdgi_half_width, rtdgi_half_height, 0u, rtdgi_half_height, stream_);

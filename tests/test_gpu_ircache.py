@@ -44,13 +44,21 @@ def test_ircache_maintenance_and_sum_are_exact_on_identical_state(gpu, oracle, d
     one_frame_on_identical_state(gpu, oracle, device, "cornell", 128, 128)
 
 
-def one_frame_on_identical_state(gpu, oracle, device, scene_name, W, H):
+def test_ircache_ray_passes_side_by_side_on_identical_state(gpu, oracle, device):
+    """kj_ircache_set_ray_passes_side_by_side(1): the three ray passes in one launch, racing as the reference's barrier-free recording lets them
+    (ircache.rs:396-481). Same maintenance results bit for bit, same ray counts; the SH sums sit further from the SEQUENTIAL oracle than with
+    three launches (measured 5.3e-2 against 1.3e-2 on this case) -- a different valid schedule, held to a 1e-1 sanity bar and reported."""
+    one_frame_on_identical_state(gpu, oracle, device, "cornell", 128, 128, side_by_side=True)
+
+
+def one_frame_on_identical_state(gpu, oracle, device, scene_name, W, H, side_by_side=False):
     import torch
     desc = T._scenes()[scene_name]
     oracle.lib().okj_set_threads(1)
     try:
         op = oracle.OraclePipeline(oracle.OracleScene(desc), W, H, use_ircache=True)
         gp = gpu.GpuPipeline(device, gpu.Scene(device, desc), W, H, use_ircache=True)
+        gpu.check(gp.L.kj_ircache_set_ray_passes_side_by_side(gp.ircache, int(side_by_side)))
         fcs = _frames(W, H, 8, scene="cornell" if scene_name == "cornell" else "city")
         for fc in fcs[:6]:
             op.frame(fc)
@@ -106,7 +114,7 @@ def one_frame_on_identical_state(gpu, oracle, device, scene_name, W, H):
         # happen to have landed -- the sequential oracle sees all earlier ones, the GPU with four lanes per path and four times the waves in
         # flight sees fewer (measured 1.1e-2 with one lane per path, 2.3e-2 with four, 1080p city). Parity of the cache is held at 1e-3 by
         # the deterministic mode on both sides (deterministic_frames_on_identical_state below).
-        assert num / den < 5e-2
+        assert num / den < (1e-1 if side_by_side else 5e-2)
     finally:
         oracle.lib().okj_set_threads(oracle.lib().okj_get_max_threads())
 

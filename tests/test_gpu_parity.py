@@ -160,6 +160,23 @@ def test_small_batches_walk_four_lanes_per_ray_and_agree_bit_for_bit(gpu, oracle
         assert start <= len(rays)
 
 
+def test_div_nr_and_sqrt_nr_are_the_ieee_operations_bit_for_bit(gpu, device):
+    """kj_screen.hpp: div_nr / sqrt_nr -- the hardware reciprocal / reciprocal square root plus one Newton step on the RESULT through an exact fma residual, which TAA uses
+    upstream of its hypersensitive probability stage in place of the ~11 / ~18 instruction IEEE sequences -- against `/` and sqrtf() on the device: 2 x 2^26 operand pairs
+    (random mantissas over 40 binades, every 8th numerator negative, zero numerators of both signs; odd seeds: TAA's own operand classes -- half-integer texel positions over
+    image extents, Catmull-Rom weight ratios). Not one quotient or root may differ in a single bit. (On the CPU stand-in both sides are the same expression.)"""
+    import os
+    import torch
+    L = gpu.load()
+    L.kj_selftest_div_sqrt_nr.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    counts = torch.zeros(4, dtype=torch.int64, device="cuda")
+    n = 1 << (18 if os.environ.get("KJ_HIP_EMU") else 26)
+    for seed in (12345, 777):
+        gpu.check(L.kj_selftest_div_sqrt_nr(n, seed, counts.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert counts.tolist() == [0, 0, 0, 0], f"quotients / roots differing from IEEE, and by more than an ulp: {counts.tolist()} of {2 * n}"
+
+
 def test_brdf_lut_and_sky(gpu, oracle, device):
     import torch
     lut_ref = oracle.brdf_lut()
