@@ -4,7 +4,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd); cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 T0=$(date +%s)
 if [ -z "$SKIP_TESTS" ]; then
-  timeout 1500 python -m pytest tests -x -q -m gpu -p no:cacheprovider --durations=12 > gpurun_out/r04_gpu_tests.log 2>&1
+  timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider --durations=12 > gpurun_out/r04_gpu_tests.log 2>&1
   echo "gpu tests rc=$? $(( $(date +%s) - T0 )) s: $(tail -1 gpurun_out/r04_gpu_tests.log)"; grep -E "FAILED|^ERROR" gpurun_out/r04_gpu_tests.log | head
   timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r04_smoke.log 2>&1; echo "smoke rc=$? $(( $(date +%s) - T0 )) s: $(tail -1 gpurun_out/r04_smoke.log)"
 fi
