@@ -22,8 +22,56 @@ _VARIANT = "hw"      # which build run_pass() uses: "hw" = sin / cos reduced in 
 _HOOK = None
 
 
-def available():
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden", "ref_hlsl")
+_SCOPE = None       # the recording / replay scope of the running test (golden below)
+
+
+def lib_available():
     return os.path.exists(LIB_PATH) or os.path.isdir(os.path.join(REFERENCE, "assets", "shaders"))
+
+
+def replaying():
+    """No compiled reference text in reach (no checkout, no prebuilt oracle/_ref/libref_hlsl.so) -- or KJ_REF_HLSL_REPLAY=1: run_pass() hands back what the
+    reference's text wrote when scripts/make_ref_hlsl_golden.sh recorded it (tests/golden/ref_hlsl/*.npz), for the test cases that were recorded."""
+    return bool(os.environ.get("KJ_REF_HLSL_REPLAY")) or not lib_available()
+
+
+def available():
+    return lib_available() or os.path.isdir(GOLDEN_DIR)
+
+
+def require_live(why="this case drives the compiled reference text directly"):
+    import pytest
+    if replaying():
+        pytest.skip(f"needs oracle/_ref/libref_hlsl.so ({why}); only recorded cases run without it")
+
+
+class golden:
+    """with golden("name"): ... -- a test case whose reference-side outputs are committed. Live (the library is there): runs the reference's text; with
+    KJ_REF_GOLDEN_RECORD=1 also writes every image / buffer each pass WROTE to tests/golden/ref_hlsl/name.npz. Replaying: run_pass() fills the outputs from that file
+    instead, so the same test -- the oracle against what the reference's text produced -- runs where neither the checkout nor the library exists."""
+
+    def __init__(self, name):
+        self.name = name
+        self.path = os.path.join(GOLDEN_DIR, name + ".npz")
+
+    def __enter__(self):
+        global _SCOPE
+        _SCOPE = {"name": self.name, "seq": 0, "rec": {}, "data": None}
+        if replaying():
+            if not os.path.exists(self.path):
+                import pytest
+                pytest.skip(f"no recorded outputs for {self.name}")
+            _SCOPE["data"] = np.load(self.path)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _SCOPE
+        sc, _SCOPE = _SCOPE, None
+        if et is None and not replaying() and os.environ.get("KJ_REF_GOLDEN_RECORD") and sc["rec"]:
+            os.makedirs(GOLDEN_DIR, exist_ok=True)
+            np.savez_compressed(self.path, **sc["rec"])
+        return False
 
 
 def build():
@@ -49,6 +97,7 @@ class sincos:
 
 
 def lib(variant=None):
+    assert not replaying() or lib_available(), "replay mode has no library: call require_live() first"
     variant = variant or _VARIANT
     if variant not in _LIB:
         if not _LIB:
@@ -118,17 +167,34 @@ def set_trace_hook(fn_ptr, user):
 def run_pass(name, resources, constants, frame_constants, dispatch):
     """resources: Tex / Buf objects in .read()/.write() order; constants: numpy scalars / arrays in .constants((...)) order;
     dispatch: the thread extent given to .dispatch([x, y, z]) / .trace_rays(tlas, [x, y, z])."""
+    if replaying():
+        if _SCOPE is None or _SCOPE["data"] is None:
+            import pytest
+            pytest.skip("no reference checkout and no prebuilt oracle/_ref/libref_hlsl.so; this case has no recorded outputs")
+        seq, data = _SCOPE["seq"], _SCOPE["data"]
+        _SCOPE["seq"] += 1
+        prefix = f"{seq:04d}|{name}|"
+        keys = [k for k in data.files if k.startswith(prefix)]
+        assert keys, f"recorded outputs of {_SCOPE['name']} have no call {prefix}: the test changed since scripts/make_ref_hlsl_golden.sh ran"
+        for k in keys:
+            r = resources[int(k.split("|")[2])]
+            assert r.raw.size == data[k].size, (k, r.raw.size, data[k].size)
+            r.raw[:] = data[k]
+        return list(resources)
     L = lib()
     if _HOOK:
         L.ref_set_trace_hook(_HOOK[0], _HOOK[1])
     pn = name.encode()
     assert L.ref_pass_exists(pn), (name, passes())
-    slots = []
+    slots, types = [], {}
     for i in range(L.ref_pass_resource_count(pn)):
         if L.ref_pass_resource_set(pn, i) == 0:
             slots.append((L.ref_pass_resource_binding(pn, i), L.ref_pass_resource_name(pn, i)))
         elif L.ref_pass_resource_set(pn, i) == -1:       # no [[vk::binding]] (blur.hlsl): the compiler numbers them in declaration order
             slots.append((len(slots), L.ref_pass_resource_name(pn, i)))
+        else:
+            continue
+        types[slots[-1][1]] = L.ref_pass_resource_type(pn, i)
     slots = sorted(set(slots))
     assert [b for b, _ in slots] == list(range(len(slots))), (name, slots)          # set 0 is dense from binding 0, like SimpleRenderPass binds it
     assert len(slots) == len(resources), (name, [n for _, n in slots], len(resources))
@@ -167,4 +233,11 @@ def run_pass(name, resources, constants, frame_constants, dispatch):
                 assert L.ref_bind_slot(pn, b"bindless_textures", slot, t.raw.ctypes.data, t.w, t.h, t.fmt) == 0
     d = list(dispatch) + [1] * (3 - len(dispatch))
     assert L.ref_dispatch(pn, int(d[0]), int(d[1]), int(d[2])) == 0
+    if _SCOPE is not None:
+        seq = _SCOPE["seq"]
+        _SCOPE["seq"] += 1
+        if os.environ.get("KJ_REF_GOLDEN_RECORD"):
+            for idx, ((_, rn), r) in enumerate(zip(slots, resources)):
+                if types[rn].startswith(b"RW"):
+                    _SCOPE["rec"][f"{seq:04d}|{name}|{idx}"] = r.raw.copy()
     return keep

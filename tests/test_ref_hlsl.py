@@ -14,9 +14,26 @@ import pytest
 import parity as P
 import ref_hlsl as R
 
-pytestmark = pytest.mark.skipif(not R.available(), reason="neither a reference checkout nor a prebuilt oracle/_ref/libref_hlsl.so")
+pytestmark = pytest.mark.skipif(not R.available(), reason="no reference checkout, no prebuilt oracle/_ref/libref_hlsl.so and no recorded outputs under tests/golden/ref_hlsl")
 
 KEEP = 1 << 31
+
+
+def recorded_case(select):
+    """One parametrisation of each test has the reference side's outputs COMMITTED (tests/golden/ref_hlsl/<name>.npz: every image / buffer each pass of the
+    reference's text wrote, recorded by scripts/make_ref_hlsl_golden.sh from the live run): there the test -- the oracle against what the reference's text produced --
+    also runs where neither the reference checkout nor the compiled library exists (ref_hlsl.golden / replaying). `select(kwargs)` -> file stem or None."""
+    import contextlib
+    import functools
+
+    def deco(f):
+        @functools.wraps(f)
+        def w(*a, **k):
+            name = select(k)
+            with (R.golden(name) if name else contextlib.nullcontext()):
+                return f(*a, **k)
+        return w
+    return deco
 
 
 @pytest.fixture
@@ -225,6 +242,7 @@ def _rtdgi_chain(oracle, scene_name, W, H, n_frames, warmup, report=None, spatia
 
 @pytest.mark.parametrize("scene_name,W,H,passes,raytraced", [("cornell", 64, 64, 2, False), ("cornell", 72, 40, 2, False), ("city", 96, 56, 2, False),
                                                              ("cornell", 40, 40, 1, False), ("cornell", 40, 40, 3, True)])
+@recorded_case(lambda k: "rtdgi_screen_passes_cornell_64" if (k["scene_name"], k["W"], k["passes"], k["raytraced"]) == ("cornell", 64, 2, False) else None)
 def test_rtdgi_ray_free_passes_reference_hlsl_vs_oracle(oracle, scene_name, W, H, passes, raytraced):
     """fullres_reproject, the half-res extracts, validity integrate, temporal + N x spatial ReSTIR, resolve, temporal and spatial filter:
     frames 5 (tracing), 6 (validation: frame_index % 3 == 0) and 7 after five warm-up frames. Extents that are not multiples of the
@@ -234,6 +252,7 @@ def test_rtdgi_ray_free_passes_reference_hlsl_vs_oracle(oracle, scene_name, W, H
 
 
 @pytest.mark.parametrize("scene_name,W,H", [("cornell", 64, 64), ("city", 104, 60)])
+@recorded_case(lambda k: "reprojection_map_cornell_64" if k["scene_name"] == "cornell" else None)
 def test_reprojection_map_reference_hlsl_vs_oracle(oracle, scene_name, W, H):
     """calculate_reprojection_map.hlsl as renderers/reprojection.rs:6-52 records it, on a moving camera, against the oracle's map."""
     from kajiya_amd import scenes
@@ -269,6 +288,7 @@ def _taa_surfaces(op):
 
 
 @pytest.mark.parametrize("W,H", [(64, 64), (72, 40)])
+@recorded_case(lambda k: "taa_64" if k["W"] == 64 else None)
 def test_taa_passes_reference_hlsl_vs_oracle(oracle, W, H):
     """The seven TAA passes on the GI output, frames 0..5 (frame 0: empty history), each reference pass fed the oracle's surfaces."""
     from kajiya_amd import scenes
@@ -372,6 +392,7 @@ def test_ircache_maintenance_reference_hlsl_vs_oracle(oracle):
     (IrcacheRenderer::prepare), dispatch args + reset (head of trace_irradiance) and the SH sum-up -- from the reference's text on the
     oracle's live cache state, frame after frame under a moving camera: every buffer byte for byte. The passes that push onto the
     free list with atomics run in ascending thread order on both sides (any order is a legal schedule: ref_set_linear_order)."""
+    R.require_live("the cache's buffers are 70 MB per call: not recorded")
     from kajiya_amd import scenes, frame
     _bind_luts(oracle)
     L = R.lib()
@@ -465,6 +486,7 @@ def _empty_ircache():
 
 
 @pytest.mark.parametrize("W,H", [(64, 64), (72, 40)])
+@recorded_case(lambda k: "rtdgi_ray_passes_cornell_64" if k["W"] == 64 else None)
 def test_rtdgi_ray_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, W, H):
     """`rtdgi validate` and `rtdgi trace` from the reference's own text -- diffuse_validate.rgen.hlsl / trace_diffuse.rgen.hlsl with
     diffuse_trace_common.inc.hlsl, candidate_ray_dir.hlsl, inc/rt.hlsl, and on every hit rt/gbuffer.rchit.hlsl reading the scene tables --
@@ -524,6 +546,7 @@ def test_rtdgi_ray_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, W, H):
     assert len({c[:2] for c in compared}) >= 7, sorted(compared)
 
 
+@recorded_case(lambda k: "sun_shadow_mask_and_reference_pt")
 def test_sun_shadow_mask_and_reference_pt_reference_hlsl_vs_oracle(oracle, libm_sincos):
     """rt/trace_sun_shadow_mask.rgen.hlsl (renderers/shadows.rs:10-40) and rt/reference_path_trace.rgen.hlsl (renderers/reference.rs:8-26; up to
     17 segments per path through rt/gbuffer.rchit.hlsl, the layered BRDF's sampling, Russian roulette, the sun and the sky) from the
@@ -579,6 +602,7 @@ def test_ircache_ray_passes_and_live_lookups_reference_hlsl_vs_oracle(oracle, li
     frame, against the oracle on the oracle's cache state -- in the reference's own racy semantics, executed in ascending thread order on
     both sides (one oracle thread; ref_set_linear_order). Every cache buffer and every rtdgi surface must come out equal number for
     number, apart from texels / slots where the two sin / cos range reductions round a sampled direction differently (counted, <= 0.2 %)."""
+    R.require_live("the cache's buffers are 70 MB per call: not recorded")
     from kajiya_amd import scenes, frame
     from kajiya_amd.abi import KJ_RTDGI_PASS
     _bind_luts(oracle)
@@ -670,6 +694,7 @@ def test_ircache_ray_passes_and_live_lookups_reference_hlsl_vs_oracle(oracle, li
 
 
 # ---------------------------------------------------------------------------------------------------------------- SURVEY 8f rows
+@recorded_case(lambda k: "ssao_guide")
 def test_ssao_guide_passes_reference_hlsl_vs_oracle(oracle, libm_sincos):
     """SsgiRenderer::render + filter_ssgi (renderers/ssgi.rs:25-181): ssgi/{ssgi,spatial_filter,upsample,temporal_filter}.hlsl from the
     reference's text against the oracle's four stages, six frames of a moving camera over the 20 k-triangle city (USE_AO_ONLY: the
@@ -724,6 +749,7 @@ def test_ssao_guide_passes_reference_hlsl_vs_oracle(oracle, libm_sincos):
             _check(r, f"frame {fi} SSAO guide surface {n}")
 
 
+@recorded_case(lambda k: "shadow_denoise")
 def test_shadow_denoise_passes_reference_hlsl_vs_oracle(oracle, libm_sincos):
     """ShadowDenoiseRenderer::render (renderers/shadow_denoise.rs:19-149): shadow_denoise/{bitpack_shadow_mask,megakernel,spatial_filter}.hlsl
     with AMD's ffx_denoiser_shadows_* code they include (wave ballots, quad reads, group-shared tiles: the lock-step scheduler), chained
@@ -779,6 +805,7 @@ def test_shadow_denoise_passes_reference_hlsl_vs_oracle(oracle, libm_sincos):
         assert 0 < (mask == 0).mean() < 1
 
 
+@recorded_case(lambda k: "light_gbuffer")
 def test_light_gbuffer_reference_hlsl_vs_oracle(oracle, libm_sincos):
     """light_gbuffer.hlsl as renderers/deferred.rs:8-46 records it (G-buffer, depth, shadow mask, reflections, GI, the nine cache buffers,
     the two sky cubes) against the oracle's combine: both outputs, sky pixels with the sun disc included."""
@@ -833,6 +860,7 @@ class _RtrFrame(_Frame):
 
 
 @pytest.mark.parametrize("reuse", [1, 0])
+@recorded_case(lambda k: "rtr_reuse_rtdgi_rays" if k["reuse"] == 1 else None)
 def test_rtr_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, reuse):
     """RtrRenderer::trace + TracedRtr::filter_temporal (renderers/rtr.rs:97-400,440-480) from the reference's own text -- rtr/reflection.rgen.hlsl
     and reflection_validate.rgen.hlsl (with reflection_trace_common.inc.hlsl, inc/blue_noise.hlsl's sampler, rt/gbuffer.rchit.hlsl on every hit),
@@ -950,6 +978,7 @@ def test_rtr_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, reuse):
     assert 0 < own_rule["resolved_tex"] <= 0.05 * W * H and own_rule["rtr.ray_len" + (":0" if 6 % 2 == 0 else ":1")] <= 0.08 * W * H, own_rule
 
 
+@recorded_case(lambda k: "sky_cubes")
 def test_sky_cubes_reference_hlsl_vs_oracle(oracle, libm_sincos):
     """The two sky cubes every GI pass reads (renderers/sky.rs:4-35): sky/comp_cube.hlsl (64^2 x 6, the atmosphere integrated per texel) and
     convolve_cube.hlsl (16^2 x 6, 512 cone samples of the first through the cube sampler) from the reference's text against the oracle's
@@ -971,6 +1000,7 @@ def test_sky_cubes_reference_hlsl_vs_oracle(oracle, libm_sincos):
         _check(r, f"frame {fi} convolved sky cube")
 
 
+@recorded_case(lambda k: "light_specular")
 def test_light_specular_reference_hlsl_vs_oracle(oracle, libm_sincos):
     """LightingRenderer::render_specular (renderers/lighting.rs:23-88): lighting/sample_lights.rgen.hlsl (one shadow ray per half-res pixel to a
     triangle light picked by the blue-noise image) and lighting/spatial_reuse_lights.hlsl (the rtr resolve kernel's footprint, added INTO
@@ -1013,6 +1043,7 @@ def test_light_specular_reference_hlsl_vs_oracle(oracle, libm_sincos):
 
 
 @pytest.mark.parametrize("W,H,frame_index,mult,contrast,lut_seed", [(160, 90, 3, 1.3, 1.1, 0), (333, 187, 0, 1.0, 1.0, None)])
+@recorded_case(lambda k: "post_160x90" if k["W"] == 160 else None)
 def test_post_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, W, H, frame_index, mult, contrast, lut_seed):
     """PostProcessRenderer::render (renderers/post.rs:10-272), the passes that are HLSL in the reference: blur.hlsl (mips 1.. of the blur pyramid),
     post/luminance_histogram_{clear,calculate,copy}.hlsl and post_combine.hlsl (glare, vignette, the display transform with its Bezold-Brucke
