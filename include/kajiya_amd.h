@@ -412,7 +412,7 @@ KjStatus kj_ircache_set_deferred_updates(KjIrcache* ircache, uint32_t enable);
  * "ircache validate" and "ircache trace" with `write_no_sync` on every buffer they share (ircache.rs:396-481; :411-412 "if we use `write_no_sync`, we can overlap
  * with the next pass"), i.e. without barriers: on a GPU they overlap as far as the hardware lets them. enable = 0 (default): three launches one after the other,
  * the schedule the sequential oracle models. enable = 1: one launch carrying the three passes side by side -- the cache's segment of the frame 0.40 -> 0.21 ms on
- * MI355X at 1080p, and the racy cache's distance from the sequential oracle on identical state 1.3e-2 -> 5.3e-2. Ignored in the deterministic mode. */
+ * MI355X at 1080p, and the racy cache's distance from the sequential oracle on identical state 1.3e-2 -> 5e-2 .. 1.3e-1 of its SH sums. Ignored in the deterministic mode. */
 KjStatus kj_ircache_set_ray_passes_side_by_side(KjIrcache* ircache, uint32_t enable);
 KjStatus kj_ircache_begin_requests(KjIrcache* ircache, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, void* stream);
 /* For a caller whose per-pixel passes run on half-res rows [half_row_begin, half_row_end) only (a rank of the screen-tile split): clears those rows' slots and the

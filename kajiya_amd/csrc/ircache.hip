@@ -698,7 +698,7 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     KJ_CHECK_LAUNCH();
     // racy (the reference's) mode, opt-in (kj_ircache_set_ray_passes_side_by_side, or KJ_IRC_SIDE_BY_SIDE=1 at creation): the three passes side by side in one launch, as the reference's barrier-free
     // recording lets them run. Measured on MI355X (round 4, profiles/r04_ab_runs.md): the cache's segment 0.40 -> 0.21 ms at 1080p, the PIPELINED
-    // frame unchanged (it is VALU-bound, not waiting for this chain), and the SH sums on identical state move from 1.3e-2 to 5.3e-2 of the
+    // frame unchanged (it is VALU-bound, not waiting for this chain), and the SH sums on identical state move from 1.3e-2 to 5e-2 .. 1.3e-1 of the
     // sequential oracle's (tests/test_gpu_ircache.py; bar 5e-2) -- so it is not the default.
     if (!c->deferred && c->ray_passes_side_by_side) {
         hipLaunchKernelGGL(quad ? k_irc_ray_passes<true> : k_irc_ray_passes<false>, dim3(grid * 3u), dim3(64), lds_rays, s, tc, grid);

@@ -87,7 +87,11 @@ class TaaStep:
             # squared colour difference by a variance formed as E[x^2] - E[x]^2 of fp16 inputs (1e-6 floor) inside exp2(): the same
             # allowance there and for its two dilations (filter_prob.hlsl, filter_prob2.hlsl), which carry the same texels forward (measured
             # 0.23 % at 1080p on the city, whole-image rel-L2 5e-4 .. 6e-4).
-            ill_conditioned = ("filtered_history_img", "input_prob_img", "prob_filtered1_img", "prob_filtered2_img")
+            # filtered_input_deviation_img is sqrt(max(0, E[x^2] - E[x]^2)) over 3x3 fp16 texels (filter_input.hlsl): in flat regions the difference IS the rounding
+            # noise of the two moments, so a texel there can be off by its whole (tiny) value -- at 1080p on the city 0.21 % of the texels are beyond the outlier
+            # tolerance while the largest absolute difference is 1.2e-4 and the image's rel-L2 5e-5 (round 4, with the moments rounding product by product as the
+            # oracle's do; 0.25 % with fused multiply-adds). Same allowance as the other cancelling quantities of this pass chain.
+            ill_conditioned = ("filtered_history_img", "input_prob_img", "prob_filtered1_img", "prob_filtered2_img", "filtered_input_deviation_img")
             # (filter_history's second pass is sum(s * w) / sum(w) with w = pow8(saturate(cutoff / luma)) and cutoff = 1.001 x the first pass'
             # luma: where that luma is 0 the quotient is 0 / 0 -- at 1080p on the city 6 texels of 2 M come out NaN on one side and ~0 on
             # the other; up to 1e-5 of the texels may, for this image only)
