@@ -309,6 +309,9 @@ __global__ void __launch_bounds__(64) k_taa_input_prob(const FrameConstants* __r
         }
     output_tex.st(x, y, f32_to_f16(input_prob));
 }
+// ---- from here on (the probability dilations, the final pass): downstream of the hypersensitive stage, tolerant of a last bit -- FMA contraction back on
+// (this file is compiled with -ffp-contract=off: csrc/Makefile)
+#pragma clang fp contract(fast)
 // filter_prob.hlsl, filter_prob2.hlsl
 __global__ void __launch_bounds__(64) k_taa_filter_prob(ImgH1 input_tex, ImgH1 output_tex, int row0, int row1) {
     TILE_XY(output_tex.w, output_tex.h)

@@ -9,7 +9,12 @@ from kajiya_amd import lib, scenes
 
 dev = lib.Device(0)
 desc = scenes.procedural_city(target_tris=1_000_000, seed=1234)
-scene = lib.Scene(dev, desc, fast_build="--fast-build" in sys.argv)   # --fast-build: BLASes as device-built LBVHs
+TOP = ([a.split("=")[1] for a in sys.argv if a.startswith("--top-build=")] or [None])[0]      # --top-build=device|host: force the per-commit top tree's builder
+INST = int(([a.split("=")[1] for a in sys.argv if a.startswith("--instances=")] or [0])[0])       # --instances=N: the city with N instances instead of 64
+if INST:
+    desc = scenes.procedural_city(target_tris=1_000_000, seed=1234, n_instances=INST)
+scene = lib.Scene(dev, desc, fast_build="--fast-build" in sys.argv, **({"top_build": TOP} if TOP else {}))   # --fast-build: BLASes as device-built LBVHs
+print("top tree:", scene.top_tree_info(), flush=True)
 lo, hi = desc.bounds()
 rng = np.random.RandomState(1)
 N = 1 << 21

@@ -82,24 +82,23 @@ class TaaStep:
                 print(f"  frame {fi} {name}: {bad.size} of {g16.size} halves differ" + (f", e.g. at {bad[:6]}: got {[hex(v) for v in g16[bad[:6]]]} ref {[hex(v) for v in r16[bad[:6]]]}" if bad.size else ""))
                 continue
             # filter_history.hlsl:37 weights taps by pow8(saturate(cutoff / luma)): where the history is dark (luma ~ 0, freshly disoccluded
-            # texels) the quotient is ill-conditioned in the reference itself, so for this image up to 1 % of the texels may be outliers
-            # (at most 5e-4 off in absolute terms at 1080p); the image as a whole still has to meet 1e-3. input_prob.hlsl:77-100 divides the
-            # squared colour difference by a variance formed as E[x^2] - E[x]^2 of fp16 inputs (1e-6 floor) inside exp2(): the same
-            # allowance there and for its two dilations (filter_prob.hlsl, filter_prob2.hlsl), which carry the same texels forward (measured
-            # 0.23 % at 1080p on the city, whole-image rel-L2 5e-4 .. 6e-4).
-            # filtered_input_deviation_img is sqrt(max(0, E[x^2] - E[x]^2)) over 3x3 fp16 texels (filter_input.hlsl): in flat regions the difference IS the rounding
-            # noise of the two moments, so a texel there can be off by its whole (tiny) value -- at 1080p on the city 0.21 % of the texels are beyond the outlier
-            # tolerance while the largest absolute difference is 1.2e-4 and the image's rel-L2 5e-5 (round 4, with the moments rounding product by product as the
-            # oracle's do; 0.25 % with fused multiply-adds). Same allowance as the other cancelling quantities of this pass chain.
-            ill_conditioned = ("filtered_history_img", "input_prob_img", "prob_filtered1_img", "prob_filtered2_img", "filtered_input_deviation_img")
+            # texels) the quotient is ill-conditioned in the reference itself. input_prob.hlsl:77-100 divides the squared colour difference by a
+            # variance formed as E[x^2] - E[x]^2 of fp16 inputs (1e-6 floor) inside exp2(); its two dilations (filter_prob.hlsl, filter_prob2.hlsl)
+            # carry the same texels forward. A texel that differs there differs by O(1).
+            # Round 4: taa.hip is compiled WITHOUT FMA contraction upstream of input_prob (csrc/Makefile), i.e. with the oracle's arithmetic operation by operation: at
+            # 1080p on the city the reprojected history and the deviation image are bit-identical to the oracle's, filtered history differs in 348 of 8.3 M halves
+            # (was 64827), input_prob in 408 of 2.1 M (was 19155). What is left comes from v_exp_f32 / v_log_f32 against libm and from the single-instruction
+            # quotients inside input_prob itself. The allowance for these four images is therefore the ordinary outlier count (0.2 %, was 1 %) -- their outliers are
+            # still off by O(1) (a probability of 0 against 1), so the image WITHOUT its outliers has to meet 1e-3 and the whole image 2e-3.
+            ill_conditioned = ("filtered_history_img", "input_prob_img", "prob_filtered1_img", "prob_filtered2_img")
             # (filter_history's second pass is sum(s * w) / sum(w) with w = pow8(saturate(cutoff / luma)) and cutoff = 1.001 x the first pass'
             # luma: where that luma is 0 the quotient is 0 / 0 -- at 1080p on the city 6 texels of 2 M come out NaN on one side and ~0 on
             # the other; up to 1e-5 of the texels may, for this image only)
             # For these four the outlier texels are off by O(1) -- a probability of 0 against 1 -- so a few of them carry the image's L2: the
-            # image WITHOUT its outliers has to meet 1e-3, the outliers are counted (<= 1 %) and the whole image may not exceed 2e-3 (twice
+            # image WITHOUT its outliers has to meet 1e-3, the outliers are counted (<= 0.2 %) and the whole image may not exceed 2e-3 (twice
             # the largest value measured: 1.06e-3 for input_prob_img on the 4K ruins frame with the irradiance cache bound, round 4)
             if name in ill_conditioned:
-                ok = r["rel_l2_inliers"] <= P.REL_L2_TOL and r["mismatch_frac"] <= 1e-2 and r["rel_l2"] <= 2e-3 and \
+                ok = r["rel_l2_inliers"] <= P.REL_L2_TOL and r["mismatch_frac"] <= P.MISMATCH_TOL and r["rel_l2"] <= 2e-3 and \
                     r.get("bad_class", 0) <= (int(1e-5 * r.get("n", 0)) if name == "filtered_history_img" else 0)
             else:
                 ok = P.within_bars(r)
