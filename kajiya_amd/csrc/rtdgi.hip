@@ -602,82 +602,7 @@ __global__ void __launch_bounds__(64) k_restir_check(const FrameConstants* __res
 
 // restir_resolve.hlsl: rtdgi_resample.hip (k_restir_resolve)
 
-// ------------------------------------------------------------------ temporal_filter.hlsl:39-252
-// temporal_filter.hlsl is instruction-bound here (VALUBusy 85 %): its quotients and square roots feed blends and clamp boxes, so they
-// take the single-instruction forms (v_rsq_f32 / v_rcp_f32 / v_sqrt_f32, 1 ulp); the 5x5 weights sum to a compile-time constant.
-KJ_D V4 crunch_fast(V4 v) {      // linear_rgb_to_crunched_luma_chroma: y * sqrt(y.x) / max(1e-8, y.x)
-    const V3 y = sRGB_to_YCbCr(xyz(v));
-    return v4(y * (sqrt_fast(y.x) * rcp_fast(fmaxf(1e-8f, y.x))), v.w);
-}
-__global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __restrict__ fcp, ImgH4 input_tex, ImgH4 history_tex, ImgU32 variance_history_tex /*RG16F*/,
-                                                         ImgU2 reprojection_tex, ImgU32 rt_history_invalidity_tex /*RG16F half*/, ImgH4 output_tex, ImgH4 history_output_tex,
-                                                         ImgU32 variance_history_output_tex, int row0, int row1) {
-    const int W = output_tex.w, H = output_tex.h;
-    TILE_XY_M(W, H, KJ_TILES_ROWS)
-    const FrameConstants& fc = *fcp;
-    const V4 history_mult{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
-    // LDS-staged 12x12 tile (8x8 outputs + the 5x5 stencil's halo): each texel's colour-space conversion is done once per
-    // tile instead of once per tap (25x per texture): .xyz = crunched luma-chroma of the input, .w = crunched history luma.
-    __shared__ float4 tile[12 * 12];
-    {
-        const int tx0 = int(kj_tb.x) * 8 - 2, ty0 = row0 + int(kj_tb.y) * 8 - 2;
-        for (int i = lane; i < 144; i += 64) {
-            const int tx = tx0 + i % 12, ty = ty0 + i / 12;
-            const V4 n = crunch_fast(ld4(input_tex, tx, ty));
-            const V4 hn = crunch_fast(ld4(history_tex, tx, ty) * history_mult);
-            tile[i] = make_float4(n.x, n.y, n.z, hn.x);
-        }
-    }
-    __syncthreads();
-    if (!in_image) return;
-    const V2 uv = get_uv(float(x), float(y), tex_size4(W, H));
-    const V4 center = crunch_fast(ld4(input_tex, x, y));
-    const V4 reproj = ld_reproj(reprojection_tex, x, y);
-    const V4 history = crunch_fast(ld4(history_tex, x, y) * history_mult);
-    V3 vsum = v3(0.0f), vsum2 = v3(0.0f);
-    float wsum = 0, hist_vsum = 0;
-    const int lt = ((lane >> 3) + 2) * 12 + (lane & 7) + 2;
-#pragma unroll
-    for (int dy = -2; dy <= 2; ++dy)
-#pragma unroll
-        for (int dx = -2; dx <= 2; ++dx) {
-            const float4 t = tile[lt + dy * 12 + dx];
-            const V3 neigh{t.x, t.y, t.z};
-            const float hist_luma = t.w;
-            const float w = expf(-3.0f * float(dx * dx + dy * dy) / float((2 + 1.) * (2 + 1.)));
-            vsum += neigh * w;
-            vsum2 += neigh * neigh * w;
-            wsum += w;
-            hist_vsum += hist_luma * w;
-        }
-    const float inv_wsum = 1.0f / wsum;      // (compile-time constant)
-    const V3 ex = vsum * inv_wsum, ex2 = vsum2 * inv_wsum;
-    const V3 var = vmax(v3(0.0f), ex2 - ex * ex);
-    const V3 dev{sqrt_fast(var.x), sqrt_fast(var.y), sqrt_fast(var.z)};
-    hist_vsum *= inv_wsum;
-    const V2 moments_history = sample_bilinear_clamp_rg16f(variance_history_tex.p, W, H, uv + V2{reproj.x, reproj.y}) *
-                               V2{fc.pre_exposure_delta, fc.pre_exposure_delta * fc.pre_exposure_delta};
-    const float center_luma = center.x + (hist_vsum - ex.x);
-    const V2 mo = lerp(moments_history, V2{center_luma, center_luma * center_luma}, 0.25f);
-    st2h(variance_history_output_tex, x, y, V2{fmaxf(0.0f, mo.x), fmaxf(0.0f, mo.y)});
-    const float center_temporal_dev = sqrt_fast(fmaxf(0.0f, moments_history.y - moments_history.x * moments_history.x));
-    const float temporal_change = fabsf(hist_vsum - ex.x) * rcp_fast(fmaxf(1e-8f, hist_vsum + ex.x));
-    const float rt_invalid = saturate(sqrt_fast(ld2h(rt_history_invalidity_tex, x / 2, y / 2).x) * 4);
-    const float current_sample_count = history.w;
-    float clamp_box_size = 1 * lerp(0.25f, 2.0f, 1.0f - rt_invalid) * lerp(0.333f, 1.0f, saturate(reproj.w)) * 2;
-    clamp_box_size = fmaxf(clamp_box_size, 0.5f);
-    const V3 nmin = xyz(center) - dev * clamp_box_size, nmax = xyz(center) + dev * clamp_box_size;
-    const V3 clamped_history = vclamp(xyz(history), nmin, nmax);
-    const float variance_adjusted_temporal_change = smoothstep(0.1f, 1.0f, 0.05f * temporal_change * rcp_fast(center_temporal_dev));
-    float max_sample_count = 32;
-    max_sample_count = lerp(max_sample_count, 4.0f, variance_adjusted_temporal_change);
-    max_sample_count *= lerp(1.0f, 0.5f, rt_invalid);
-    const V3 res = lerp(clamped_history, xyz(center), rcp_fast(1.0f + fminf(max_sample_count, current_sample_count)));
-    const float output_sample_count = fminf(current_sample_count, max_sample_count) + 1;
-    const V4 output = crunched_luma_chroma_to_linear_rgb(v4(res, output_sample_count));
-    st4(history_output_tex, x, y, output);
-    st4(output_tex, x, y, v4(xyz(output), saturate(output_sample_count * lerp(1.0f, 0.5f, rt_invalid) * smoothstep(0.3f, 0.0f, temporal_change) / 32.0f)));
-}
+// temporal_filter.hlsl: rtdgi_resample.hip (k_temporal_filter; approximate by design, it lives with the other instruction-bound screen passes)
 
 // spatial_filter.hlsl: rtdgi_resample.hip (k_spatial_filter)
 
@@ -1095,10 +1020,8 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     }
     if (mask & KJ_RTDGI_PASS_TEMPORAL_FILTER) {
         SCOPE_BEGIN(9);
-        hipLaunchKernelGGL(k_temporal_filter, gf, blk, 0, s, fc, img<uint2>(irradiance, W, H), img<uint2>(r->reprojected_history_tex, W, H), img<uint32_t>(variance_hist, W, H),
-                           reprojection, img<uint32_t>(invalidity_out, hw, hh), img<uint2>(temporal_filtered, W, H), img<uint2>(r->temporal_output_tex, W, H),
-                           img<uint32_t>(variance_out, W, H), fr0, fr1);
-        KJ_CHECK_LAUNCH();
+        KJ_TRY_HIP(launch_temporal_filter(fc, irradiance, r->reprojected_history_tex, variance_hist, reprojection.p, invalidity_out, temporal_filtered, r->temporal_output_tex, variance_out,
+                                          W, H, fr0, fr1, s));
         SCOPE_END(9);
     }
     if (mask & KJ_RTDGI_PASS_SPATIAL_FILTER) {

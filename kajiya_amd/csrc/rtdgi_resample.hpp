@@ -27,6 +27,8 @@ struct ResolveLaunch {
     int W, H, hw, hh, row0, row1;   // rows in full-res pixels, row0 a multiple of 16
 };
 hipError_t launch_restir_resolve(const ResolveLaunch& L, hipStream_t s);
+hipError_t launch_temporal_filter(const KjFrameConstants* fc, const void* input, const void* history, const void* variance_history, const void* reprojection, const void* rt_history_invalidity,
+                                  void* output, void* history_output, void* variance_history_output, int W, int H, int row0, int row1, hipStream_t s);
 hipError_t launch_spatial_filter(const KjFrameConstants* fc, const void* input, const void* depth, const void* ssao, const void* geometric_normal, void* output,
                                  int W, int H, int row0, int row1, hipStream_t s);
 
