@@ -39,21 +39,8 @@ typedef Img<float> ImgF32;
 #ifndef KJ_TAA_NR_MASK
 #define KJ_TAA_NR_MASK 31
 #endif
-#ifndef KJ_TAA_VAR_NC
-#define KJ_TAA_VAR_NC 2
-#endif
-KJ_D V3 mul_nc(V3 a, V3 b) {
-#pragma clang fp contract(off)
-    return V3{a.x * b.x, a.y * b.y, a.z * b.z};
-}
-KJ_D V3 add_nc(V3 a, V3 b) {
-#pragma clang fp contract(off)
-    return V3{a.x + b.x, a.y + b.y, a.z + b.z};
-}
-KJ_D V3 sub_nc3(V3 a, V3 b) {
-#pragma clang fp contract(off)
-    return V3{a.x - b.x, a.y - b.y, a.z - b.z};
-}
+// KJ_TAA_NR_MASK (default: all groups on) switches groups of quotients / roots back to the IEEE sequences: what the round-4 A/B runs and the bisection that found the one
+// site that has to stay IEEE (catmull_rom_5tap_history's last line) were built with (scripts/r04_taa_bisect.sh, profiles/r04_ab_runs.md)
 #define NRDIV(bit_, a_, b_) (((KJ_TAA_NR_MASK) & (bit_)) ? div_nr(a_, b_) : ((a_) / (b_)))
 KJ_D V3 taa_decode_rgb(V3 v) {       // v * sqrt(max(0, m)) / max(1e-20, m), m = the largest component (upstream of input_prob: the reference's operations,
     const float m = max3(v.x, v.y, v.z);     // nearly always its bits -- kj_screen.hpp: div_nr / sqrt_nr), without a branch:
@@ -181,21 +168,14 @@ KJ_D void taa_filter_input_body(const ImgH4& input_tex, const ImgF32& depth_tex,
         clamped_iwsum += w;
         clamped_iex += s[i] * w;
         iex += s[i];
-#if KJ_TAA_VAR_NC >= 2
-        iex2 = add_nc(iex2, mul_nc(s[i], s[i]));
-#else
         iex2 += s[i] * s[i];
-#endif
     }
     clamped_iex = NRDIV(8, clamped_iex, clamped_iwsum);      // (a zero weight sum -- a neighbourhood of NaNs -- is NaN either way)
     iex = NRDIV(8, iex, 9.0f);
     iex2 = NRDIV(8, iex2, 9.0f);
-    // E[x^2] - E[x]^2 cancels: its products and sums round one by one, as in the text (a fused multiply-add moves the deviation image by an fp16 step in 5 % of the texels)
-#if KJ_TAA_VAR_NC >= 1
-    const V3 var_a = vmax(v3(0.0f), sub_nc3(iex2, mul_nc(iex, iex)));
-#else
+    // E[x^2] - E[x]^2 cancels: its products and sums round one by one, as in the text (this file is compiled without FMA contraction: a fused multiply-add here moves
+    // the deviation image by an fp16 step in 5 % of the texels)
     const V3 var_a = vmax(v3(0.0f), iex2 - iex * iex);
-#endif
     // pass 2: luma_cutoff = first pass' luma * 1.001
     const float cutoff = clamped_iex.x * 1.001f;
     V3 cex = v3(0.0f); float cws = 0;
