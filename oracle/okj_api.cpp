@@ -627,4 +627,80 @@ uint64_t okj_lighting_render_specular(const KjFrameConstants* fc, const void* sc
     return l.rays_any.load();
 }
 
+// The twin of oracle/ref_hlsl/probes/inc_functions.hlsl: the restated leaf functions (inc/hash.hlsl, pack_unpack.hlsl, quasi_random.hlsl, math.hlsl, color.hlsl,
+// reservoir.hlsl, brdf.hlsl) on the same inputs, row for row, so that tests/test_ref_hlsl.py can hold each function to the reference's text bit for bit.
+// in4: n x uint4; out4: rows x n x uint4 (row-major by function row). Returns the number of rows.
+uint32_t okj_probe_functions(const uint32_t* in4, uint32_t n, uint32_t* out4) {
+    uint32_t rows = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t ux = in4[i * 4 + 0], uy = in4[i * 4 + 1], uz = in4[i * 4 + 2], uw = in4[i * 4 + 3];
+        const f3 f{asfloat(ux), asfloat(uy), asfloat(uz)};
+        const f3 unit = normalize(f);
+        const f2 urand{uint_to_u01_float(ux), uint_to_u01_float(uy)};
+        const f3 col = vabs(f);
+        const f3 scol{saturate(col.x), saturate(col.y), saturate(col.z)};
+        uint32_t k = 0;
+        auto OUT = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+            uint32_t* o = out4 + (size_t(k++) * n + i) * 4;
+            o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+        };
+        auto U = [](float v) { return asuint(v); };
+        OUT(hash1(ux), hash_combine2(ux, uy), hash2(ux, uy), hash3(ux, uy, uz));
+        OUT(U(uint_to_u01_float(ux)), U(interleaved_gradient_noise(ux & 4095u, uy & 4095u)), 0, 0);
+        OUT(U(unpack_unorm(ux, 8)), pack_unorm(urand.x, 11), U(unpack_unorm(uy, 11)), pack_unorm(urand.y, 10));
+        const uint32_t packed_n = pack_normal_11_10_11(unit);
+        { const f3 v = unpack_normal_11_10_11(packed_n); OUT(packed_n, U(v.x), U(v.y), U(v.z)); }
+        { const f3 v = unpack_normal_11_10_11_no_normalize(uw); OUT(U(v.x), U(v.y), U(v.z), 0); }
+        { const f3 v = unpack_normal_11_10_11_no_normalize(uw); OUT(U(v.x), U(v.y), U(v.z), 0); }     // (the float- and the uint-argument forms are one function here)
+        { const f3 v = unpack_color_888(ux); OUT(pack_color_888(scol), U(v.x), U(v.y), U(v.z)); }
+        { const f2 v = unpack_2x16f_uint(uz); OUT(pack_2x16f_uint(f.x, f.y), U(v.x), U(v.y), 0); }
+        { const f3 v = rgb9e5_to_float3(uy); OUT(float3_to_rgb9e5(col), U(v.x), U(v.y), U(v.z)); }
+        { const f3 v = octa_decode(urand); OUT(U(v.x), U(v.y), U(v.z), 0); }
+        { const f2 v = octa_wrap(urand * 2.0f - 1.0f); OUT(U(v.x), U(v.y), U(max3(f.x, f.y, f.z)), 0); }
+        { const f2 v = hammersley(uy & 1023u, 1024u); OUT(U(radical_inverse_vdc(ux)), U(v.x), U(v.y), 0); }
+        { const f2 v = r2_sequence(uz & 0xffffu); OUT(U(v.x), U(v.y), 0, 0); }
+        const m33 basis = build_orthonormal_basis(unit);
+        const f3 b0 = mul(basis, f3{1, 0, 0}), b1 = mul(basis, f3{0, 1, 0}), b2 = mul(basis, f3{0, 0, 1});
+        OUT(U(b0.x), U(b0.y), U(b0.z), U(b1.x));
+        OUT(U(b1.y), U(b1.z), U(b2.x), U(b2.y));
+        { const f3 v = uniform_sample_cone(urand, 0.5f + 0.5f * urand.x); OUT(U(v.x), U(v.y), U(v.z), U(b2.z)); }
+        { const f3 v = uniform_sample_hemisphere(urand); OUT(U(v.x), U(v.y), U(v.z), U(inverse_depth_relative_diff(fabsf(f.x), fabsf(f.y)))); }
+        OUT(U(Rtr::exponential_squish(fabsf(f.x), urand.y * 8.0f)), U(Rtr::exponential_unsquish(urand.x, 0.25f + urand.y)), 0, 0);
+        { const f3 v = sRGB_to_YCbCr(col); OUT(U(v.x), U(v.y), U(v.z), U(sRGB_to_luminance(col))); }
+        { const f3 v = YCbCr_to_sRGB(f); OUT(U(v.x), U(v.y), U(v.z), 0); }
+        {
+            Reservoir1spp r = Reservoir1spp::from_raw(u2{ux, uy});
+            uint32_t rng = uz;
+            const bool a = r.update(urand.x * 3.0f, uw, rng);
+            const bool b = r.update(urand.y, uw ^ 0x5555u, rng);
+            r.M = fminf(r.M, 500.0f);
+            r.W = fminf(r.W, 1000.0f);
+            const u2 raw = r.as_raw();
+            OUT(raw.x, raw.y, U(r.w_sum), (a ? 1u : 0u) | (b ? 2u : 0u) | (rng << 2));
+            Reservoir1spp s;
+            StreamState st;
+            s.init_with_stream(urand.x, urand.y * 4.0f, st, 17);
+            const bool c = s.update_with_stream(r, urand.y + 0.125f, 0.75f, st, uw, rng);
+            s.finish_stream(st);
+            OUT(U(s.M), U(s.W), U(s.w_sum), s.payload ^ (c ? 0x80000000u : 0u));
+        }
+        {
+            SpecularBrdf brdf{0.02f + 0.96f * urand.x, scol};
+            const f3 wo = uniform_sample_hemisphere(f2{urand.y, urand.x});
+            const f3 wi = uniform_sample_hemisphere(f2{uint_to_u01_float(uz), uint_to_u01_float(uw)});
+            const BrdfValue v = brdf.evaluate(wo, wi);
+            OUT(U(v.value.x), U(v.value.y), U(v.value.z), U(v.pdf));
+            OUT(U(v.value_over_pdf.x), U(v.value_over_pdf.y), U(v.value_over_pdf.z), U(v.transmission_fraction.x));
+            const BrdfSample s = brdf.sample(wo, f2{uint_to_u01_float(uw), uint_to_u01_float(uz)});
+            OUT(U(s.wi.x), U(s.wi.y), U(s.wi.z), U(s.pdf));
+            OUT(U(s.value_over_pdf.x), U(s.value_over_pdf.y), U(s.value_over_pdf.z), U(s.value.y));
+            DiffuseBrdf diffuse{scol};
+            const BrdfSample d = diffuse.sample(wo, urand);
+            OUT(U(d.wi.x), U(d.wi.y), U(d.wi.z), U(diffuse.evaluate(wo, wi).value.z));
+        }
+        rows = k;
+    }
+    return rows;
+}
+
 } // extern "C"

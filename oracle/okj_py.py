@@ -140,6 +140,7 @@ def lib():
         L.okj_reference_path_trace.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
         L.okj_reference_path_trace_rows.restype = C.c_uint64
         L.okj_reference_path_trace_rows.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.okj_probe_functions.restype = C.c_uint32; L.okj_probe_functions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.okj_set_threads.argtypes = [C.c_int]
         L.okj_get_max_threads.restype = C.c_int
         _LIB = L
@@ -160,6 +161,15 @@ def brdf_lut():
         lib().okj_brdf_fg_lut(out.ctypes.data)
         _BRDF_LUT = out
     return _BRDF_LUT
+
+
+def probe_functions(inputs, rows):
+    """The restated leaf functions on `inputs` (n, 4) uint32: (rows, n, 4) uint32, in the row order of oracle/ref_hlsl/probes/inc_functions.hlsl."""
+    inputs = np.ascontiguousarray(inputs, np.uint32)
+    out = np.zeros((rows, inputs.shape[0], 4), np.uint32)
+    got = lib().okj_probe_functions(inputs.ctypes.data, inputs.shape[0], out.ctypes.data)
+    assert got == rows, (got, rows)
+    return out
 
 
 def reference_path_trace(scene, fc, output, first_bounce_mode=0):

@@ -475,6 +475,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--passes", nargs="*", default=[], help="entry files (relative to --shaders) to emit wrappers for")
     ap.add_argument("--rt-passes", nargs="*", default=[], help="rgen[:chit[:miss0[:miss1]]] (relative to --shaders)")
+    ap.add_argument("--probes", default=None, help="a directory of OUR OWN test shaders (oracle/ref_hlsl/probes): rewritten into <out>/probes/, where `../inc/...` is the reference's header")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     with open(os.path.join(args.out, "hlsl_swizzles.inc"), "w") as f:
@@ -495,6 +496,14 @@ def main():
             with open(dst, "w") as f:
                 f.write(text)
             n += 1
+    if args.probes:
+        for fn in sorted(os.listdir(args.probes)):
+            if fn.endswith(".hlsl"):
+                rel = os.path.join("probes", fn)
+                os.makedirs(os.path.join(args.out, "probes"), exist_ok=True)
+                with open(os.path.join(args.out, rel), "w") as f:
+                    f.write(Rewriter(open(os.path.join(args.probes, fn), encoding="utf-8").read(), rel).run())
+                n += 1
     for rel in args.passes:
         name = rel[:-5] if rel.endswith(".hlsl") else rel
         with open(os.path.join(args.out, "pass_" + name.replace("/", "_").replace(".", "_") + ".cpp"), "w") as f:

@@ -1085,3 +1085,80 @@ def test_post_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, W, H, frame_i
     R.run_pass("post_combine", [R.Tex(inp, W, H, "rgba16f"), mip("blur_pyramid", 0), mip("rev_blur_pyramid", 0), tmp, out],
                [R.extent_inv_extent(W, H), np.float32(mult), np.float32(contrast)], fc, (W, H, 1))
     _check(P.compare(out.raw, ref_out.reshape(-1).view(np.uint8), "r11g11b10f"), "post combine")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# phase A: the leaf functions of the reference's headers, one by one
+
+_PROBE_ROWS = [   # (what the row of oracle/ref_hlsl/probes/inc_functions.hlsl holds, which of its four words are floats)
+    ("hash1, hash_combine2, hash2, hash3", ""),
+    ("uint_to_u01_float, interleaved_gradient_noise", "xy"),
+    ("unpack_unorm(8), pack_unorm(11), unpack_unorm(11), pack_unorm(10)", "xz"),
+    ("pack_normal_11_10_11, unpack_normal_11_10_11", "yzw"),
+    ("unpack_normal_11_10_11_no_normalize", "xyz"),
+    ("unpack_normal_11_10_11_uint_no_normalize", "xyz"),
+    ("pack_color_888, unpack_color_888", "yzw"),
+    ("pack_2x16f_uint, unpack_2x16f_uint", "yz"),
+    ("float3_to_rgb9e5, rgb9e5_to_float3", "yzw"),
+    ("octa_decode", "xyz"),
+    ("octa_wrap, max3", "xyz"),
+    ("radical_inverse_vdc, hammersley", "xyz"),
+    ("r2_sequence", "xy"),
+    ("build_orthonormal_basis (column 0, column 1 .x)", "xyzw"),
+    ("build_orthonormal_basis (column 1 .yz, column 2 .xy)", "xyzw"),
+    ("uniform_sample_cone, build_orthonormal_basis (column 2 .z)", "xyzw"),
+    ("uniform_sample_hemisphere, inverse_depth_relative_diff", "xyzw"),
+    ("exponential_squish, exponential_unsquish", "xy"),
+    ("sRGB_to_YCbCr, sRGB_to_luminance", "xyzw"),
+    ("YCbCr_to_sRGB", "xyz"),
+    ("Reservoir1spp::from_raw / update x 2 / as_raw", "z"),
+    ("Reservoir1spp::init_with_stream / update_with_stream / finish_stream", "xyz"),
+    ("SpecularBrdf::evaluate (value, pdf)", "xyzw"),
+    ("SpecularBrdf::evaluate (value_over_pdf, transmission_fraction)", "xyzw"),
+    ("SpecularBrdf::sample (wi, pdf)", "xyzw"),
+    ("SpecularBrdf::sample (value_over_pdf, value)", "xyzw"),
+    ("DiffuseBrdf::sample, DiffuseBrdf::evaluate", "xyzw"),
+]
+
+
+def _probe_inputs(n, seed):
+    """uint4 per probe: three words that read as finite floats of moderate magnitude (2^-20 .. 2^20, either sign, random mantissa) and also serve as raw bits
+    (hash inputs, packed words), one word of arbitrary bits; the first rows are the special values."""
+    rng = np.random.default_rng(seed)
+    u = np.zeros((n, 4), np.uint32)
+    sign = rng.integers(0, 2, (n, 3), dtype=np.uint32) << 31
+    expo = rng.integers(107, 148, (n, 3), dtype=np.uint32) << 23
+    u[:, :3] = sign | expo | rng.integers(0, 1 << 23, (n, 3), dtype=np.uint32)
+    u[:, 3] = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    one, half = 0x3F800000, 0x3F000000
+    special = [(one, 0, 0, 0), (0, one, 0, 0xFFFFFFFF), (0, 0, one, 0x80000000), (0, 0, one | 0x80000000, 1), (one, one, one, 0x7FFFFFFF),
+               (half, half, half, 0x3FF), (one | 0x80000000, half, 0x3E800000, 0xFFE00000), (0x3F7FFFFF, 0x3F7FFFFF, 0x33800000, 0x001FFFFF)]
+    u[:len(special)] = np.array(special, np.uint32)
+    return u
+
+
+@pytest.mark.parametrize("n", [4096, 1 << 18])
+@recorded_case(lambda k: "inc_functions" if k["n"] == 4096 else None)
+def test_inc_functions_reference_hlsl_vs_oracle(oracle, libm_sincos, n):
+    """VERDICT r3 item 1(a), phase A: every leaf function of inc/*.hlsl the oracle restates -- hashes, the pack / unpack family, the quasi-random sequences, the
+    sampling and basis helpers, the colour transforms, Reservoir1spp's methods, the specular and diffuse lobes -- evaluated by the reference's text (a probe pass of ours
+    that includes the headers where they lie) and by the oracle (okj_probe_functions) on the same inputs (4096: recorded; 262144: live only), compared BIT FOR BIT, function by function."""
+    if n != 4096:
+        R.require_live()
+    inp = _probe_inputs(n, 20260922 + n)
+    rows = len(_PROBE_ROWS)
+    out = np.zeros((rows, n, 4), np.uint32)
+    R.run_pass("probes/inc_functions", [R.Buf(inp), R.Buf(out)], [np.uint32(n)], None, (n, 1, 1))
+    ours = oracle.probe_functions(inp, rows)
+    assert out.any(axis=(1, 2)).all(), "a row the probe never wrote"
+    bad = []
+    for r, (what, floats) in enumerate(_PROBE_ROWS):
+        a, b = out[r], ours[r]
+        same = a == b
+        for c in floats:        # a NaN is a NaN whatever its payload
+            ci = "xyzw".index(c)
+            same[:, ci] |= np.isnan(a[:, ci].view(np.float32)) & np.isnan(b[:, ci].view(np.float32))
+        if not same.all():
+            i = int(np.argmin(same.all(axis=1)))
+            bad.append((what, int((~same.all(axis=1)).sum()), i, [hex(v) for v in inp[i]], [hex(v) for v in a[i]], [hex(v) for v in b[i]]))
+    assert not bad, bad
