@@ -170,6 +170,11 @@ uint32_t kj_abi_struct_size(uint32_t id);
  * IEEE operations over `n` pseudo-random operand pairs (odd `seed`s draw TAA's own operand classes). `counts4_u64_device`: four uint64 on the device, ADDED to:
  * quotients whose bits differ, roots whose bits differ, quotients off by more than an ulp, roots off by more than an ulp. scripts/selftest_div_sqrt_nr.py. */
 KjStatus kj_selftest_div_sqrt_nr(uint32_t n, uint32_t seed, void* counts4_u64_device, void* stream);
+/* Device self test (no reference counterpart): the leaf functions of the device headers (hashes, pack / unpack family, quasi-random sequences, basis and samplers,
+ * colour transforms, Reservoir1spp's methods, the specular and diffuse lobes) on `n` inputs (uint4 each, device), one output ROW of n uint4 per function group, in the
+ * row order of oracle/ref_hlsl/probes/inc_functions.hlsl -- the probe that runs the reference's own inc/ headers on the same inputs (csrc/probe.hip;
+ * tests/test_gpu_parity.py compares the rows). `out4_device` holds rows_capacity x n uint4; *out_rows = rows written. */
+KjStatus kj_selftest_probe_functions(const void* in4_device, uint32_t n, void* out4_device, uint32_t rows_capacity, uint32_t* out_rows, void* stream);
 
 /* RenderBackend / WorldRenderer::new analogue (default_world_renderer.rs:14-58):
  * picks the HIP device, builds the BRDF-FG LUT (bindless #0, lut/brdf_fg.hlsl),

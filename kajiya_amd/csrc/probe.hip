@@ -1,0 +1,86 @@
+// Device self test (no reference counterpart): the leaf functions of the device headers -- kj_vec.hpp (inc/hash.hlsl, pack_unpack.hlsl, quasi_random.hlsl, math.hlsl,
+// color.hlsl), kj_reservoir.hpp (inc/reservoir.hlsl), kj_shading.hpp (inc/brdf.hlsl), kj_ircache.hpp (octa_decode), kj_rtr.hpp (exponential_(un)squish) -- evaluated on a
+// buffer of inputs, one output row per function, in the row order of oracle/ref_hlsl/probes/inc_functions.hlsl. That probe runs the reference's own text and
+// tests/test_ref_hlsl.py holds the oracle's restatement to it bit for bit; tests/test_gpu_parity.py holds THESE rows to the oracle's: the chain reference text ->
+// oracle -> device code, function by function instead of pass by pass. Compiled without FMA contraction like the ray passes' units (csrc/Makefile).
+#include "kj_rtr.hpp"
+#include "kj_ircache.hpp"
+
+#define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
+#define KJ_PROBE_ROWS 27u
+
+__global__ void __launch_bounds__(256) k_probe_functions(const uint4* __restrict__ in4, uint32_t n, uint4* __restrict__ out4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 u = in4[i];
+    const V3 f{asfloat(u.x), asfloat(u.y), asfloat(u.z)};
+    const V3 unit = normalize(f);
+    const V2 urand{uint_to_u01_float(u.x), uint_to_u01_float(u.y)};
+    const V3 col = vabs(f);
+    const V3 scol{saturate(col.x), saturate(col.y), saturate(col.z)};
+    uint32_t k = 0;
+    auto OUT = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) { out4[size_t(k++) * n + i] = make_uint4(a, b, c, d); };
+    auto U = [](float v) { return asuint(v); };
+    OUT(hash1(u.x), hash_combine2(u.x, u.y), hash2(u.x, u.y), hash3(u.x, u.y, u.z));
+    OUT(U(uint_to_u01_float(u.x)), U(interleaved_gradient_noise(u.x & 4095u, u.y & 4095u)), 0, 0);
+    OUT(U(unpack_unorm(u.x, 8)), pack_unorm(urand.x, 11), U(unpack_unorm(u.y, 11)), pack_unorm(urand.y, 10));
+    const uint32_t packed_n = pack_normal_11_10_11(unit);
+    { const V3 v = unpack_normal_11_10_11(packed_n); OUT(packed_n, U(v.x), U(v.y), U(v.z)); }
+    { const V3 v = unpack_normal_11_10_11_no_normalize(u.w); OUT(U(v.x), U(v.y), U(v.z), 0); }
+    { const V3 v = unpack_normal_11_10_11_no_normalize(u.w); OUT(U(v.x), U(v.y), U(v.z), 0); }     // (the float- and the uint-argument forms are one function here)
+    { const V3 v = unpack_color_888(u.x); OUT(pack_color_888(scol), U(v.x), U(v.y), U(v.z)); }
+    { const V2 v = unpack_2x16f_uint(u.z); OUT(pack_2x16f_uint(f.x, f.y), U(v.x), U(v.y), 0); }
+    { const V3 v = rgb9e5_to_float3(u.y); OUT(float3_to_rgb9e5(col), U(v.x), U(v.y), U(v.z)); }
+    { const V3 v = octa_decode(urand); OUT(U(v.x), U(v.y), U(v.z), 0); }
+    OUT(0, 0, U(max3(f.x, f.y, f.z)), 0);                                                            // (octa_wrap has no device form: octa_decode inlines it)
+    { const V2 v = hammersley(u.y & 1023u, 1024u); OUT(U(radical_inverse_vdc(u.x)), U(v.x), U(v.y), 0); }
+    { const V2 v = r2_sequence(u.z & 0xffffu); OUT(U(v.x), U(v.y), 0, 0); }
+    const Basis basis = build_orthonormal_basis(unit);
+    const V3 b0 = to_world(basis, V3{1, 0, 0}), b1 = to_world(basis, V3{0, 1, 0}), b2 = to_world(basis, V3{0, 0, 1});
+    OUT(U(b0.x), U(b0.y), U(b0.z), U(b1.x));
+    OUT(U(b1.y), U(b1.z), U(b2.x), U(b2.y));
+    { const V3 v = uniform_sample_cone(urand, 0.5f + 0.5f * urand.x); OUT(U(v.x), U(v.y), U(v.z), U(b2.z)); }
+    { const V3 v = uniform_sample_hemisphere(urand); OUT(U(v.x), U(v.y), U(v.z), U(inverse_depth_relative_diff(fabsf(f.x), fabsf(f.y)))); }
+    OUT(U(exponential_squish(fabsf(f.x), urand.y * 8.0f)), U(exponential_unsquish(urand.x, 0.25f + urand.y)), 0, 0);
+    { const V3 v = sRGB_to_YCbCr(col); OUT(U(v.x), U(v.y), U(v.z), U(sRGB_to_luminance(col))); }
+    { const V3 v = YCbCr_to_sRGB(f); OUT(U(v.x), U(v.y), U(v.z), 0); }
+    {
+        Reservoir1spp r = Reservoir1spp::from_raw(make_uint2(u.x, u.y));
+        uint32_t rng = u.z;
+        const bool a = r.update(urand.x * 3.0f, u.w, rng);
+        const bool b = r.update(urand.y, u.w ^ 0x5555u, rng);
+        r.M = fminf(r.M, 500.0f);
+        r.W = fminf(r.W, 1000.0f);
+        const uint2 raw = r.as_raw();
+        OUT(raw.x, raw.y, U(r.w_sum), (a ? 1u : 0u) | (b ? 2u : 0u) | (rng << 2));
+        Reservoir1spp s = Reservoir1spp::create();
+        StreamState st{0, 0};
+        s.init_with_stream(urand.x, urand.y * 4.0f, st, 17);
+        const bool c = s.update_with_stream(r, urand.y + 0.125f, 0.75f, st, u.w, rng);
+        s.finish_stream(st);
+        OUT(U(s.M), U(s.W), U(s.w_sum), s.payload ^ (c ? 0x80000000u : 0u));
+    }
+    {
+        const float roughness = 0.02f + 0.96f * urand.x;
+        const V3 wo = uniform_sample_hemisphere(V2{urand.y, urand.x});
+        const V3 wi = uniform_sample_hemisphere(V2{uint_to_u01_float(u.z), uint_to_u01_float(u.w)});
+        const BrdfValue v = specular_evaluate(roughness, scol, wo, wi);
+        OUT(U(v.value.x), U(v.value.y), U(v.value.z), U(v.pdf));
+        OUT(U(v.value_over_pdf.x), U(v.value_over_pdf.y), U(v.value_over_pdf.z), U(v.transmission_fraction.x));
+        const BrdfSample s = specular_sample(roughness, scol, wo, V2{uint_to_u01_float(u.w), uint_to_u01_float(u.z)});
+        OUT(U(s.wi.x), U(s.wi.y), U(s.wi.z), U(s.pdf));
+        OUT(U(s.value_over_pdf.x), U(s.value_over_pdf.y), U(s.value_over_pdf.z), U(s.value.y));
+        const BrdfSample d = diffuse_sample(scol, urand);
+        OUT(U(d.wi.x), U(d.wi.y), U(d.wi.z), U(diffuse_evaluate(scol, wi).value.z));
+    }
+}
+
+extern "C" KjStatus kj_selftest_probe_functions(const void* in4_device, uint32_t n, void* out4_device, uint32_t rows_capacity, uint32_t* out_rows, void* stream) {
+    KJ_REQUIRE(in4_device && out4_device && out_rows, "null argument");
+    KJ_REQUIRE(rows_capacity >= KJ_PROBE_ROWS, "the output buffer holds fewer rows than the probe writes");
+    *out_rows = KJ_PROBE_ROWS;
+    if (n == 0) return KJ_OK;
+    hipLaunchKernelGGL(k_probe_functions, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, (const uint4*)in4_device, n, (uint4*)out4_device);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}

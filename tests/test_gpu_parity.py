@@ -177,6 +177,61 @@ def test_div_nr_and_sqrt_nr_are_the_ieee_operations_bit_for_bit(gpu, device):
     assert counts.tolist() == [0, 0, 0, 0], f"quotients / roots differing from IEEE, and by more than an ulp: {counts.tolist()} of {2 * n}"
 
 
+def test_device_leaf_functions_match_the_oracle_row_by_row(gpu, oracle, device):
+    """The chain reference text -> oracle -> device code, FUNCTION BY FUNCTION: csrc/probe.hip evaluates the device headers' leaf functions (hashes, pack / unpack family,
+    quasi-random sequences, basis and samplers, colour transforms, Reservoir1spp's methods, the two lobes) on the inputs and in the row order of
+    oracle/ref_hlsl/probes/inc_functions.hlsl, which tests/test_ref_hlsl.py runs through the reference's own text against the oracle, bit for bit. Here the same rows of
+    the oracle (okj_probe_functions) against the device's. Rows of integer / IEEE arithmetic: bit for bit. Rows through sin / cos / exp2 / log2 / pow (the device's math
+    library against the host's): the samplers and the squish pair within 1e-5; the specular lobe -- whose normal distribution at low roughness amplifies a last-bit
+    difference of cos(theta) by 1 / a2 -- under the bars of the pass tests (tests/parity.py: <= 0.2 % of the inputs off by more than 2e-3, rejected samples included)."""
+    import os
+    import torch
+    import test_ref_hlsl as TR
+    L = gpu.load()
+    L.kj_selftest_probe_functions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+    n = 1 << (12 if os.environ.get("KJ_HIP_EMU") else 18)
+    inp = TR._probe_inputs(n, 424242)
+    rows = len(TR._PROBE_ROWS)
+    ours = oracle.probe_functions(inp, rows)
+    d_in = torch.from_numpy(inp.view(np.int32)).cuda()
+    d_out = torch.zeros((rows, n, 4), dtype=torch.int32, device="cuda")
+    got_rows = C.c_uint32(0)
+    gpu.check(L.kj_selftest_probe_functions(d_in.data_ptr(), n, d_out.data_ptr(), rows, C.byref(got_rows), None))
+    torch.cuda.synchronize()
+    assert got_rows.value == rows
+    got = d_out.cpu().numpy().view(np.uint32)
+    transcendental = {15: (1e-5, 1e-4), 16: (1e-5, 1e-4), 17: (1e-5, 1e-4), 26: (1e-5, 1e-4),      # cone / hemisphere samplers, exponential_(un)squish, the diffuse lobe
+                      22: (2e-3, 2e-3), 23: (2e-3, 2e-3), 24: (2e-3, 2e-3), 25: (2e-3, 2e-3)}       # the specular lobe: (error bar, fraction of the inputs allowed beyond it)
+    device_words = {10: "z"}                                # octa_wrap has no device form (octa_decode inlines it): that row carries max3 only
+    bad, report = [], []
+    for r, (what, floats) in enumerate(TR._PROBE_ROWS):
+        words = ["xyzw".index(c) for c in device_words.get(r, "xyzw")]
+        a, b = got[r][:, words], ours[r][:, words]
+        fl = np.array(["xyzw"[w] in floats for w in words])
+        same = a == b
+        if fl.any():
+            af, bf = a[:, fl].view(np.float32), b[:, fl].view(np.float32)
+            same[:, fl] |= np.isnan(af) & np.isnan(bf)
+        differing = int((~same.all(axis=1)).sum())
+        if r not in transcendental:
+            if differing:
+                i = int(np.argmin(same.all(axis=1)))
+                bad.append((what, differing, [hex(v) for v in inp[i]], [hex(v) for v in a[i]], [hex(v) for v in b[i]]))
+            continue
+        af, bf = a[:, fl].view(np.float32).astype(np.float64), b[:, fl].view(np.float32).astype(np.float64)
+        with np.errstate(invalid="ignore", over="ignore"):
+            err = np.abs(af - bf) / np.maximum(1.0, np.maximum(np.abs(af), np.abs(bf)))
+        err = np.where(np.isfinite(err), err, np.where((af == bf) | (np.isnan(af) & np.isnan(bf)), 0.0, np.inf))
+        tol, frac = transcendental[r]
+        far = (err > tol).any(axis=1)
+        report.append(f"{what}: {differing / n:.2%} of the inputs differ in some bit, {int(far.sum())} by more than {tol:g} (worst {err[np.isfinite(err)].max():.1e})")
+        if far.mean() > frac or not (a[:, ~fl] == b[:, ~fl]).all():
+            i = int(np.argmax(far))
+            bad.append((what, int(far.sum()), [hex(v) for v in inp[i]], af[i].tolist(), bf[i].tolist()))
+    print("\n".join(report))
+    assert not bad, bad
+
+
 def test_brdf_lut_and_sky(gpu, oracle, device):
     import torch
     lut_ref = oracle.brdf_lut()
