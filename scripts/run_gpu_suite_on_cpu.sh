@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs the `-m gpu` parity tests against the product source compiled for the CPU (tests/hip_emu): no GPU needed.
-#   scripts/run_gpu_suite_on_cpu.sh [pytest args]              fiber mode: ~7 min on 8 cores for everything but the full-size / 1080p cases
+#   scripts/run_gpu_suite_on_cpu.sh [pytest args]              fiber mode: ~9 min on 8 cores for everything but the full-size / 1080p cases
 #   scripts/run_gpu_suite_on_cpu.sh --sanitize [pytest args]   one host thread per lane under ASan + UBSan: ~1.5 h; leaves out the slowest tests
 # Never a statement about the hardware or about hipcc's code generation: the same tests on an MI355X are.
 cd "$(dirname "$0")/.."

@@ -68,7 +68,8 @@ int progress(Comm* c) {
             if (ev) { pf.push_back({c->fd[p], ev, 0}); peer.push_back(p); }
         }
         if (pf.empty()) return 0;
-        if (poll(pf.data(), pf.size(), 60000) <= 0) { fprintf(stderr, "[rccl stub] rank %d: no progress for 60 s\n", c->rank); return 1; }
+        static const int patience_ms = getenv("KJ_RCCL_STUB_TIMEOUT_MS") ? atoi(getenv("KJ_RCCL_STUB_TIMEOUT_MS")) : 60000;     // (real RCCL would wait forever)
+        if (poll(pf.data(), pf.size(), patience_ms) <= 0) { fprintf(stderr, "[rccl stub] rank %d: no progress for %d ms\n", c->rank, patience_ms); return 1; }
         for (size_t i = 0; i < pf.size(); ++i) {
             const int p = peer[i];
             if ((pf[i].revents & POLLOUT) && !c->sends[p].empty()) {

@@ -37,6 +37,7 @@ def test_bench_two_ranks_under_torch_distributed_run(orchestrator):
         env.update(KJ_SPLIT_NATIVE="1", KJ_RCCL_LIB=TM.build_rccl_stub())
         if "damaged" in orchestrator:
             env["KJ_RCCL_STUB_CORRUPT"] = "1"
+            env["KJ_RCCL_STUB_TIMEOUT_MS"] = "5000"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                         RUN, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + TOY, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

@@ -154,6 +154,7 @@ def _self_test_worker(rank, world, port, W, H, corrupt, q):
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         if corrupt is not None:
             os.environ["KJ_RCCL_STUB_CORRUPT"] = str(corrupt)
+            os.environ["KJ_RCCL_STUB_TIMEOUT_MS"] = "5000"      # a damaged length field leaves a rank waiting for bytes nobody sends: the stand-in gives up, RCCL would not
         sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "hip_emu"))
         import build_emu, cpu_as_cuda
         cpu_as_cuda.install(build_emu.build())
