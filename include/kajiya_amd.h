@@ -175,6 +175,10 @@ KjStatus kj_selftest_div_sqrt_nr(uint32_t n, uint32_t seed, void* counts4_u64_de
  * row order of oracle/ref_hlsl/probes/inc_functions.hlsl -- the probe that runs the reference's own inc/ headers on the same inputs (csrc/probe.hip;
  * tests/test_gpu_parity.py compares the rows). `out4_device` holds rows_capacity x n uint4; *out_rows = rows written. */
 KjStatus kj_selftest_probe_functions(const void* in4_device, uint32_t n, void* out4_device, uint32_t rows_capacity, uint32_t* out_rows, void* stream);
+/* The same for the second probe (oracle/ref_hlsl/probes/inc_functions_color.hlsl): the display transform's colour science incl. the transform itself, the G-buffer record,
+ * soft_color_clamp, the uv helpers, the sky model. `bezold_brucke_lut_rg16f_device`: the 64-texel RG16F table (256 bytes) on the device. */
+KjStatus kj_selftest_probe_functions_color(const void* in4_device, uint32_t n, const void* bezold_brucke_lut_rg16f_device, void* out4_device, uint32_t rows_capacity,
+                                           uint32_t* out_rows, void* stream);
 
 /* RenderBackend / WorldRenderer::new analogue (default_world_renderer.rs:14-58):
  * picks the HIP device, builds the BRDF-FG LUT (bindless #0, lut/brdf_fg.hlsl),

@@ -122,13 +122,12 @@ KJ_D V3 display_transform_sRGB(const uint32_t* __restrict__ bb_lut, V3 input_sti
     const float chroma_attenuation_t = saturate(
         (compressed_achromatic_luminance - fminf(1.0f, max_intensity_equiv_lum) * chroma_attenuation_start) /
         (1.03f * max_output_scale - fminf(1.0f, max_intensity_equiv_lum) * chroma_attenuation_start));
-    float chroma_attenuation = asinf(chroma_attenuation_t * chroma_attenuation_t * chroma_attenuation_t) / 3.14159265358979323846f * 2.0f;
+    float chroma_attenuation = asinf(powf(chroma_attenuation_t, 3.0f)) / 3.14159265358979323846f * 2.0f;      // pow(), as the text has it (:161)
     {
         const float compressed_achromatic_luminance2 = compress_luminance(0.125f * input_equiv_lum / max_output_scale) * max_output_scale;
         const float chroma_attenuation_t2 = saturate((compressed_achromatic_luminance2 - fminf(1.0f, max_intensity_equiv_lum) * 0.5f) /
                                                      (max_output_scale - fminf(1.0f, max_intensity_equiv_lum) * 0.5f));
-        const float t2sq = chroma_attenuation_t2 * chroma_attenuation_t2;
-        chroma_attenuation = lerp(chroma_attenuation, 1.0f, 1.0f - saturate(1.0f - t2sq * t2sq));
+        chroma_attenuation = lerp(chroma_attenuation, 1.0f, 1.0f - saturate(1.0f - powf(chroma_attenuation_t2, 4.0f)));
     }
     {
         const V3 perceptual_mid = lerp(perceptual, perceptual_white, chroma_attenuation);

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(64) k_post_histogram(const FrameConstants* __r
     const uint32_t bin = min(f2u_sat(t * 256.0f), 255u);
     const V2 uv = V2{float(x) + 0.5f, float(y) + 0.5f} / V2{float(ew), float(eh)};
     const float l = length(uv - V2{0.5f, 0.5f});
-    const float infl = expf(-8.0f * (l * l));
+    const float infl = expf(-8.0f * powf(l, 2.0f));
     atomicAdd(&histogram[bin], f2u_sat(infl * 256.0f));
 }
 
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(64) k_post_combine(const FrameConstants* __res
     col = vmax(v3(0.0f), col);
     col = col * input_multiplier;
     const float l = length(uv - V2{0.5f, 0.5f});
-    col = col * expf(-2.0f * (l * l * l));
+    col = col * expf(-2.0f * powf(l, 3.0f));      // pow(), as the text has it (post_combine.hlsl:156)
     col = display_transform_sRGB(bb_lut, col);
     col = vpow(col, contrast);
     const uint32_t idx = fcp->frame_index;

@@ -5,9 +5,11 @@
 // oracle -> device code, function by function instead of pass by pass. Compiled without FMA contraction like the ray passes' units (csrc/Makefile).
 #include "kj_rtr.hpp"
 #include "kj_ircache.hpp"
+#include "kj_color.hpp"
 
 #define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
 #define KJ_PROBE_ROWS 27u
+#define KJ_PROBE_COLOR_ROWS 26u
 
 __global__ void __launch_bounds__(256) k_probe_functions(const uint4* __restrict__ in4, uint32_t n, uint4* __restrict__ out4) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,6 +83,81 @@ extern "C" KjStatus kj_selftest_probe_functions(const void* in4_device, uint32_t
     *out_rows = KJ_PROBE_ROWS;
     if (n == 0) return KJ_OK;
     hipLaunchKernelGGL(k_probe_functions, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, (const uint4*)in4_device, n, (uint4*)out4_device);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+
+// The second probe (oracle/ref_hlsl/probes/inc_functions_color.hlsl): the display transform's colour science (kj_color.hpp), the G-buffer record, soft_color_clamp, the
+// uv helpers and the sky model (kj_shading.hpp). Words of functions that have no device form of their own (XYZ_to_LAB: unused by the active branch of the transform; the
+// phase functions and the density-by-height, which the device folds into integrate_scattering / atmosphere_density_at) stay 0 and the test leaves them out.
+__global__ void __launch_bounds__(256) k_probe_functions_color(const uint4* __restrict__ in4, uint32_t n, const uint32_t* __restrict__ bb_lut, uint4* __restrict__ out4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 u = in4[i];
+    const V3 f{asfloat(u.x), asfloat(u.y), asfloat(u.z)};
+    const V3 unit = normalize(f);
+    const V3 col = vabs(f);
+    const V3 ucol{uint_to_u01_float(u.x), uint_to_u01_float(u.y), uint_to_u01_float(u.z)};
+    const V2 urand{uint_to_u01_float(u.w), uint_to_u01_float(hash1(u.w))};
+    uint32_t k = 0;
+    auto OUT = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) { out4[size_t(k++) * n + i] = make_uint4(a, b, c, d); };
+    auto U = [](float v) { return asuint(v); };
+    auto OUT3 = [&](V3 v, float w = 0.0f) { OUT(U(v.x), U(v.y), U(v.z), U(w)); };
+    OUT3(col_sRGB_to_XYZ(col));
+    OUT3(col_XYZ_to_sRGB(f));
+    OUT3(CIE_XYZ_to_xyY(col));
+    OUT3(CIE_xyY_to_XYZ(V3{ucol.x * 0.8f + 0.1f, ucol.y * 0.8f + 0.1f, col.z}));
+    OUT3(XYZ_to_IPT(f));
+    OUT3(IPT_to_XYZ(V3{ucol.x, ucol.y - 0.5f, ucol.z - 0.5f}));
+    { const V2 a = CIE_xyY_xy_to_LUV_uv(V2{ucol.x, ucol.y}), b = CIE_XYZ_to_LUV_uv(col); OUT(U(a.x), U(a.y), U(b.x), U(b.y)); }
+    OUT(U(col_catmull_rom(ucol.x, f.x, f.y, f.z, urand.x)), U(compress_luminance(col.x)), 0, 0);
+    {
+        const float hk = hk_from_sRGB(ucol);
+        OUT(U(XYZ_to_hk_luminance_multiplier_custom_g0(col)), U(hk), U(srgb_to_equivalent_luminance(hk, V3{ucol.z, ucol.x, ucol.y})), 0);
+    }
+    OUT(0, 0, 0, U(bb_xy_white_offset_to_lut_coord(V2{ucol.x - 0.5f, ucol.y - 0.5f})));
+    OUT3(bezold_brucke_shift_XYZ_with_lut(bb_lut, col_sRGB_to_XYZ(ucol), urand.x));
+    OUT3(display_transform_sRGB(bb_lut, ucol));
+    OUT3(display_transform_sRGB(bb_lut, ucol * fminf(col.x, 4096.0f)));
+    OUT3(display_transform_sRGB(bb_lut, col));
+    {
+        GbufferData g;
+        g.albedo = ucol; g.normal = unit; g.roughness = urand.x; g.metalness = urand.y; g.emissive = col;
+        const uint4 p = gbuffer_pack(g);
+        OUT(p.x, p.y, p.z, p.w);
+        const GbufferData d = gbuffer_unpack(u);
+        OUT3(d.albedo, d.roughness);
+        OUT3(d.normal, d.metalness);
+        OUT3(d.emissive);
+    }
+    OUT3(soft_color_clamp(ucol, col, V3{ucol.z, ucol.x, ucol.y}, V3{ucol.y, ucol.z, ucol.x} * 0.3f));
+    {
+        const V4 tex_size{1920.0f, 1080.0f, 1.0f / 1920.0f, 1.0f / 1080.0f};
+        const V2 a = get_uv(float(int(u.x & 4095u)), float(int(u.y & 4095u)), tex_size), b = get_uv(col.x, col.y, tex_size);
+        OUT(U(a.x), U(a.y), U(b.x), U(b.y));
+        const V2 c = cs_to_uv(V2{f.x, f.y}), d = uv_to_cs(V2{ucol.x, ucol.y});
+        OUT(U(c.x), U(c.y), U(d.x), U(d.y));
+    }
+    {
+        const V3 start{f.x, col.y * 0.05f, f.z};
+        const V2 s = atmosphere_intersection(start, unit);
+        OUT(U(s.x), U(s.y), 0, 0);
+        OUT(0, 0, 0, 0);
+        OUT3(integrate_optical_depth(start, unit));
+        OUT3(atmosphere_absorb(col));
+        const V3 light_dir = normalize(ucol * 2.0f - 1.0f);
+        OUT3(integrate_scattering(start, unit, INFINITY, light_dir, v3(1.0f)));
+    }
+}
+
+extern "C" KjStatus kj_selftest_probe_functions_color(const void* in4_device, uint32_t n, const void* bezold_brucke_lut_rg16f_device, void* out4_device, uint32_t rows_capacity,
+                                                      uint32_t* out_rows, void* stream) {
+    KJ_REQUIRE(in4_device && bezold_brucke_lut_rg16f_device && out4_device && out_rows, "null argument");
+    KJ_REQUIRE(rows_capacity >= KJ_PROBE_COLOR_ROWS, "the output buffer holds fewer rows than the probe writes");
+    *out_rows = KJ_PROBE_COLOR_ROWS;
+    if (n == 0) return KJ_OK;
+    hipLaunchKernelGGL(k_probe_functions_color, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, (const uint4*)in4_device, n,
+                       (const uint32_t*)bezold_brucke_lut_rg16f_device, (uint4*)out4_device);
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }

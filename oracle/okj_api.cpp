@@ -703,4 +703,74 @@ uint32_t okj_probe_functions(const uint32_t* in4, uint32_t n, uint32_t* out4) {
     return rows;
 }
 
+// The twin of oracle/ref_hlsl/probes/inc_functions_color.hlsl: the colour science of the display transform (inc/color/*.hlsl), the G-buffer record, soft_color_clamp,
+// inc/uv.hlsl and the sky model, row for row. bezold_brucke_lut_rg16f: the 64-texel table the probe pass finds in bindless slot 2. Returns the number of rows.
+uint32_t okj_probe_functions_color(const uint32_t* in4, uint32_t n, const void* bezold_brucke_lut_rg16f, uint32_t* out4) {
+    const h2* lut = (const h2*)bezold_brucke_lut_rg16f;
+    uint32_t rows = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t ux = in4[i * 4 + 0], uy = in4[i * 4 + 1], uz = in4[i * 4 + 2], uw = in4[i * 4 + 3];
+        const f3 f{asfloat(ux), asfloat(uy), asfloat(uz)};
+        const f3 unit = normalize(f);
+        const f3 col = vabs(f);
+        const f3 ucol{uint_to_u01_float(ux), uint_to_u01_float(uy), uint_to_u01_float(uz)};
+        const f2 urand{uint_to_u01_float(uw), uint_to_u01_float(hash1(uw))};
+        uint32_t k = 0;
+        auto OUT = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+            uint32_t* o = out4 + (size_t(k++) * n + i) * 4;
+            o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+        };
+        auto U = [](float v) { return asuint(v); };
+        auto OUT3 = [&](f3 v, float w = 0.0f) { OUT(U(v.x), U(v.y), U(v.z), U(w)); };
+        OUT3(post_sRGB_to_XYZ(col));
+        OUT3(post_XYZ_to_sRGB(f));
+        OUT3(CIE_XYZ_to_xyY(col));
+        OUT3(CIE_xyY_to_XYZ(f3{ucol.x * 0.8f + 0.1f, ucol.y * 0.8f + 0.1f, col.z}));
+        OUT3(XYZ_to_IPT(f));
+        OUT3(IPT_to_XYZ(f3{ucol.x, ucol.y - 0.5f, ucol.z - 0.5f}));
+        { const f2 a = CIE_xyY_xy_to_LUV_uv(f2{ucol.x, ucol.y}), b = CIE_XYZ_to_LUV_uv(col); OUT(U(a.x), U(a.y), U(b.x), U(b.y)); }
+        OUT(U(post_catmull_rom(ucol.x, f.x, f.y, f.z, urand.x)), U(compress_luminance(col.x)), 0, 0);
+        {
+            const float hk = hk_from_sRGB(ucol);
+            OUT(U(XYZ_to_hk_luminance_multiplier_custom_g0(col)), U(hk), U(srgb_to_equivalent_luminance(hk, f3{ucol.z, ucol.x, ucol.y})), 0);
+        }
+        OUT3(XYZ_to_LAB(col), bb_xy_white_offset_to_lut_coord(f2{ucol.x - 0.5f, ucol.y - 0.5f}));
+        OUT3(bezold_brucke_shift_XYZ_with_lut(lut, post_sRGB_to_XYZ(ucol), urand.x));
+        OUT3(display_transform_sRGB(lut, ucol));
+        OUT3(display_transform_sRGB(lut, ucol * fminf(col.x, 4096.0f)));
+        OUT3(display_transform_sRGB(lut, col));
+        {
+            GbufferData g;
+            g.albedo = ucol; g.normal = unit; g.roughness = urand.x; g.metalness = urand.y; g.emissive = col;
+            const u4 p = gbuffer_pack(g);
+            OUT(p.x, p.y, p.z, p.w);
+            const GbufferData d = gbuffer_unpack(u4{ux, uy, uz, uw});
+            OUT3(d.albedo, d.roughness);
+            OUT3(d.normal, d.metalness);
+            OUT3(d.emissive);
+        }
+        OUT3(Rtr::soft_color_clamp(ucol, col, f3{ucol.z, ucol.x, ucol.y}, f3{ucol.y, ucol.z, ucol.x} * 0.3f));
+        {
+            const f4 tex_size{1920.0f, 1080.0f, 1.0f / 1920.0f, 1.0f / 1080.0f};
+            const f2 a = get_uv(float(int(ux & 4095u)), float(int(uy & 4095u)), tex_size), b = get_uv(col.x, col.y, tex_size);
+            OUT(U(a.x), U(a.y), U(b.x), U(b.y));
+            const f2 c = cs_to_uv(f2{f.x, f.y}), d = uv_to_cs(f2{ucol.x, ucol.y});
+            OUT(U(c.x), U(c.y), U(d.x), U(d.y));
+        }
+        {
+            const f3 start{f.x, col.y * 0.05f, f.z};
+            const float costh = ucol.x * 2.0f - 1.0f;
+            const f2 s = atm::sphere_intersection(start, unit, atm::planet_center(), atm::PLANET_RADIUS + atm::ATMOSPHERE_HEIGHT);
+            OUT(U(s.x), U(s.y), U(atm::phase_rayleigh(costh)), U(atm::phase_mie(costh)));
+            OUT3(atm::atmosphere_density(col.x), atm::atmosphere_height(start));
+            OUT3(atm::integrate_optical_depth(start, unit));
+            OUT3(atm::absorb(col));
+            const f3 light_dir = normalize(ucol * 2.0f - 1.0f);
+            OUT3(atm::integrate_scattering(start, unit, INFINITY, light_dir, mk3(1.0f)));
+        }
+        rows = k;
+    }
+    return rows;
+}
+
 } // extern "C"

@@ -146,13 +146,12 @@ static inline f3 display_transform_sRGB(const h2* bb_lut, f3 input_stimulus) {
     const float chroma_attenuation_t = saturate(
         (compressed_achromatic_luminance - fminf(1.0f, max_intensity_equiv_lum) * chroma_attenuation_start) /
         (1.03f * max_output_scale - fminf(1.0f, max_intensity_equiv_lum) * chroma_attenuation_start));
-    float chroma_attenuation = asinf(chroma_attenuation_t * chroma_attenuation_t * chroma_attenuation_t) / M_PI_F * 2.0f;
+    float chroma_attenuation = asinf(powf(chroma_attenuation_t, 3.0f)) / M_PI_F * 2.0f;      // pow(), as the text has it (:161): t * t * t rounds twice and differs in the last bit for a third of the arguments
     {
         const float compressed_achromatic_luminance2 = compress_luminance(0.125f * input_equiv_lum / max_output_scale) * max_output_scale;
         const float chroma_attenuation_t2 = saturate((compressed_achromatic_luminance2 - fminf(1.0f, max_intensity_equiv_lum) * 0.5f) /
                                                      (max_output_scale - fminf(1.0f, max_intensity_equiv_lum) * 0.5f));
-        const float t2sq = chroma_attenuation_t2 * chroma_attenuation_t2;
-        chroma_attenuation = lerp(chroma_attenuation, 1.0f, 1.0f - saturate(1.0f - t2sq * t2sq));
+        chroma_attenuation = lerp(chroma_attenuation, 1.0f, 1.0f - saturate(1.0f - powf(chroma_attenuation_t2, 4.0f)));
     }
     {
         const f3 perceptual_mid = lerp(perceptual, perceptual_white, chroma_attenuation);
@@ -261,7 +260,7 @@ struct Post {
                     const uint32_t bin = std::min(f2u_sat(t * 256.0f), 255u);
                     const f2 uv = f2{float(x) + 0.5f, float(y) + 0.5f} / f2{float(ew), float(eh)};
                     const float l = length(uv - 0.5f);
-                    const float infl = expf(-8.0f * (l * l));
+                    const float infl = expf(-8.0f * powf(l, 2.0f));
                     hist[bin] += f2u_sat(infl * 256.0f);
                 }
             auto& hb = surf["histogram"];
@@ -304,7 +303,7 @@ struct Post {
                 col = vmax(mk3(0.0f), col);
                 col = col * post_exposure_mult;
                 const float l = length(uv - 0.5f);
-                col = col * expf(-2.0f * (l * l * l));
+                col = col * expf(-2.0f * powf(l, 3.0f));      // pow(), as the text has it (post_combine.hlsl:156)
                 col = display_transform_sRGB(bb_lut, col);
                 col = vpow(col, contrast);
                 const uint32_t idx = fc.frame_index;

@@ -141,6 +141,7 @@ def lib():
         L.okj_reference_path_trace_rows.restype = C.c_uint64
         L.okj_reference_path_trace_rows.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.okj_probe_functions.restype = C.c_uint32; L.okj_probe_functions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.okj_probe_functions_color.restype = C.c_uint32; L.okj_probe_functions_color.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.okj_set_threads.argtypes = [C.c_int]
         L.okj_get_max_threads.restype = C.c_int
         _LIB = L
@@ -168,6 +169,16 @@ def probe_functions(inputs, rows):
     inputs = np.ascontiguousarray(inputs, np.uint32)
     out = np.zeros((rows, inputs.shape[0], 4), np.uint32)
     got = lib().okj_probe_functions(inputs.ctypes.data, inputs.shape[0], out.ctypes.data)
+    assert got == rows, (got, rows)
+    return out
+
+
+def probe_functions_color(inputs, rows, bezold_brucke_lut):
+    """The restated colour / G-buffer / sky functions on `inputs` (n, 4) uint32: (rows, n, 4) uint32, in the row order of oracle/ref_hlsl/probes/inc_functions_color.hlsl."""
+    inputs = np.ascontiguousarray(inputs, np.uint32)
+    lut = np.ascontiguousarray(bezold_brucke_lut, np.float16).reshape(64, 2)
+    out = np.zeros((rows, inputs.shape[0], 4), np.uint32)
+    got = lib().okj_probe_functions_color(inputs.ctypes.data, inputs.shape[0], lut.ctypes.data, out.ctypes.data)
     assert got == rows, (got, rows)
     return out
 

@@ -203,9 +203,18 @@ def test_device_leaf_functions_match_the_oracle_row_by_row(gpu, oracle, device):
     transcendental = {15: (1e-5, 1e-4), 16: (1e-5, 1e-4), 17: (1e-5, 1e-4), 26: (1e-5, 1e-4),      # cone / hemisphere samplers, exponential_(un)squish, the diffuse lobe
                       22: (2e-3, 2e-3), 23: (2e-3, 2e-3), 24: (2e-3, 2e-3), 25: (2e-3, 2e-3)}       # the specular lobe: (error bar, fraction of the inputs allowed beyond it)
     device_words = {10: "z"}                                # octa_wrap has no device form (octa_decode inlines it): that row carries max3 only
+    _compare_probe_rows(got, ours, TR._PROBE_ROWS, inp, transcendental, device_words)
+
+
+def _compare_probe_rows(got, ours, rows_desc, inp, transcendental, device_words):
+    """Rows outside `transcendental`: bit for bit (NaN = NaN). Rows in it: {row: (error bar relative to max(1, |value|), fraction of the inputs allowed beyond it)}; their integer
+    words still bit for bit. `device_words`: {row: the words the device writes} where a function has no device form of its own ("" = the whole row is left out)."""
+    n = got.shape[1]
     bad, report = [], []
-    for r, (what, floats) in enumerate(TR._PROBE_ROWS):
+    for r, (what, floats) in enumerate(rows_desc):
         words = ["xyzw".index(c) for c in device_words.get(r, "xyzw")]
+        if not words:
+            continue
         a, b = got[r][:, words], ours[r][:, words]
         fl = np.array(["xyzw"[w] in floats for w in words])
         same = a == b
@@ -230,6 +239,38 @@ def test_device_leaf_functions_match_the_oracle_row_by_row(gpu, oracle, device):
             bad.append((what, int(far.sum()), [hex(v) for v in inp[i]], af[i].tolist(), bf[i].tolist()))
     print("\n".join(report))
     assert not bad, bad
+
+
+def test_device_colour_functions_match_the_oracle_row_by_row(gpu, oracle, device):
+    """The second probe (oracle/ref_hlsl/probes/inc_functions_color.hlsl; tests/test_ref_hlsl.py holds the oracle to the reference's text on it, bit for bit): the display
+    transform's colour science and the transform itself (kj_color.hpp), the G-buffer record, soft_color_clamp, the uv helpers and the sky model on the device against the
+    oracle's rows. Matrix products, chromaticity conversions, LUV, the spline, the G-buffer record, the clamp, uv, the sphere intersection: bit for bit. Rows through pow / exp /
+    atan2 / asin: under the stated bars."""
+    import os
+    import torch
+    import test_ref_hlsl as TR
+    from kajiya_amd import post_tables
+    L = gpu.load()
+    L.kj_selftest_probe_functions_color.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+    n = 1 << (12 if os.environ.get("KJ_HIP_EMU") else 17)
+    inp = TR._probe_inputs(n, 31337)
+    rows = len(TR._COLOR_PROBE_ROWS)
+    lut = np.ascontiguousarray(post_tables.synthetic_bezold_brucke_lut(5), np.float16).reshape(64, 2)
+    ours = oracle.probe_functions_color(inp, rows, lut)
+    d_in = torch.from_numpy(inp.view(np.int32)).cuda()
+    d_lut = torch.from_numpy(lut.view(np.int16).copy()).cuda()
+    d_out = torch.zeros((rows, n, 4), dtype=torch.int32, device="cuda")
+    got_rows = C.c_uint32(0)
+    gpu.check(L.kj_selftest_probe_functions_color(d_in.data_ptr(), n, d_lut.data_ptr(), d_out.data_ptr(), rows, C.byref(got_rows), None))
+    torch.cuda.synchronize()
+    assert got_rows.value == rows
+    got = d_out.cpu().numpy().view(np.uint32)
+    transcendental = {4: (1e-3, 1e-3), 5: (1e-4, 1e-3),                       # IPT: pow(x, 0.43) into a matrix whose rows cancel
+                      7: (1e-5, 1e-4), 8: (1e-4, 1e-3),                       # compress_luminance (pow); the Helmholtz-Kohlrausch multiplier (atan2, pow)
+                      11: (2e-3, 2e-3), 12: (2e-3, 2e-3), 13: (2e-3, 2e-3),   # the display transform: the bars of the pass tests
+                      23: (1e-5, 1e-4), 24: (1e-5, 1e-4), 25: (1e-5, 1e-4)}   # the sky: exp, pow
+    device_words = {9: "w", 21: "xy", 22: ""}       # XYZ_to_LAB, the phase functions and the density-by-height have no device form of their own
+    _compare_probe_rows(got, ours, TR._COLOR_PROBE_ROWS, inp, transcendental, device_words)
 
 
 def test_brdf_lut_and_sky(gpu, oracle, device):

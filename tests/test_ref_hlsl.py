@@ -1162,3 +1162,45 @@ def test_inc_functions_reference_hlsl_vs_oracle(oracle, libm_sincos, n):
             i = int(np.argmin(same.all(axis=1)))
             bad.append((what, int((~same.all(axis=1)).sum()), i, [hex(v) for v in inp[i]], [hex(v) for v in a[i]], [hex(v) for v in b[i]]))
     assert not bad, bad
+
+
+_COLOR_PROBE_ROWS = [
+    ("sRGB_to_XYZ", "xyz"), ("XYZ_to_sRGB", "xyz"), ("CIE_XYZ_to_xyY", "xyz"), ("CIE_xyY_to_XYZ", "xyz"), ("XYZ_to_IPT", "xyz"), ("IPT_to_XYZ", "xyz"),
+    ("CIE_xyY_xy_to_LUV_uv, CIE_XYZ_to_LUV_uv", "xyzw"), ("catmull_rom, compress_luminance", "xy"),
+    ("XYZ_to_hk_luminance_multiplier_custom_g0, hk_from_sRGB, srgb_to_equivalent_luminance", "xyz"), ("XYZ_to_LAB, bb_xy_white_offset_to_lut_coord", "xyzw"),
+    ("bezold_brucke_shift_XYZ_with_lut", "xyz"), ("display_transform_sRGB (a colour in [0, 1))", "xyz"), ("display_transform_sRGB (HDR)", "xyz"), ("display_transform_sRGB (any magnitude)", "xyz"),
+    ("GbufferData::pack", ""), ("GbufferDataPacked::unpack (albedo, roughness)", "xyzw"), ("GbufferDataPacked::unpack (normal, metalness)", "xyzw"),
+    ("GbufferDataPacked::unpack (emissive)", "xyz"), ("soft_color_clamp", "xyz"), ("get_uv (int2), get_uv (float2)", "xyzw"), ("cs_to_uv, uv_to_cs", "xyzw"),
+    ("SphereIntersection, PhaseRayleigh, PhaseMie", "xyzw"), ("AtmosphereDensity, AtmosphereHeight", "xyzw"), ("IntegrateOpticalDepth", "xyz"), ("Absorb", "xyz"),
+    ("IntegrateScattering", "xyz"),
+]
+
+
+@pytest.mark.parametrize("n", [4096, 1 << 17])
+@recorded_case(lambda k: "inc_functions_color" if k["n"] == 4096 else None)
+def test_inc_color_functions_reference_hlsl_vs_oracle(oracle, libm_sincos, n):
+    """Phase A, second probe: the colour science of the display transform (inc/color/{srgb, xyz, ipt, luv, lab, math, helmholtz_kohlrausch, bezold_brucke,
+    display_transform}.hlsl, the transform itself included, with a non-trivial Bezold-Brucke table), the G-buffer record (inc/gbuffer.hlsl), soft_color_clamp, inc/uv.hlsl
+    and the sky model's functions (inc/atmosphere_felix.hlsl) -- the reference's text against the oracle's restatement on the same inputs, bit for bit, function by function."""
+    from kajiya_amd import post_tables
+    if n != 4096:
+        R.require_live()
+    lut = np.ascontiguousarray(post_tables.synthetic_bezold_brucke_lut(5), np.float16).reshape(64, 2)
+    R.set_bindless(2, R.Tex(lut.copy(), 64, 1, "rg16f"))
+    inp = _probe_inputs(n, 777 + n)
+    rows = len(_COLOR_PROBE_ROWS)
+    out = np.zeros((rows, n, 4), np.uint32)
+    R.run_pass("probes/inc_functions_color", [R.Buf(inp), R.Buf(out)], [np.uint32(n)], None, (n, 1, 1))
+    ours = oracle.probe_functions_color(inp, rows, lut)
+    assert out.any(axis=(1, 2)).all(), "a row the probe never wrote"
+    bad = []
+    for r, (what, floats) in enumerate(_COLOR_PROBE_ROWS):
+        a, b = out[r], ours[r]
+        same = a == b
+        for c in floats:        # a NaN is a NaN whatever its payload
+            ci = "xyzw".index(c)
+            same[:, ci] |= np.isnan(a[:, ci].view(np.float32)) & np.isnan(b[:, ci].view(np.float32))
+        if not same.all():
+            i = int(np.argmin(same.all(axis=1)))
+            bad.append((what, int((~same.all(axis=1)).sum()), i, [hex(v) for v in inp[i]], a[i].view(np.float32).tolist(), b[i].view(np.float32).tolist()))
+    assert not bad, bad
