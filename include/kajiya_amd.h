@@ -179,6 +179,11 @@ KjStatus kj_selftest_probe_functions(const void* in4_device, uint32_t n, void* o
  * soft_color_clamp, the uv helpers, the sky model. `bezold_brucke_lut_rg16f_device`: the 64-texel RG16F table (256 bytes) on the device. */
 KjStatus kj_selftest_probe_functions_color(const void* in4_device, uint32_t n, const void* bezold_brucke_lut_rg16f_device, void* out4_device, uint32_t rows_capacity,
                                            uint32_t* out_rows, void* stream);
+/* The same for the third probe (oracle/ref_hlsl/probes/inc_functions_shading.hlsl): the view-ray helpers under `frame_constants` (host pointer), the ray cone, the layered
+ * BRDF and its energy preservation off the device's BRDF table (`brdf_fg_lut_rgba16f_device`: 64 x 64 RGBA16F, e.g. kj_device_brdf_lut), the sun, atmosphere_default, the
+ * triangle-light sampler. */
+KjStatus kj_selftest_probe_functions_shading(const KjFrameConstants* frame_constants, const void* in4_device, uint32_t n, const void* brdf_fg_lut_rgba16f_device,
+                                             void* out4_device, uint32_t rows_capacity, uint32_t* out_rows, void* stream);
 
 /* RenderBackend / WorldRenderer::new analogue (default_world_renderer.rs:14-58):
  * picks the HIP device, builds the BRDF-FG LUT (bindless #0, lut/brdf_fg.hlsl),

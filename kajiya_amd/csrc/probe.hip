@@ -10,6 +10,7 @@
 #define KJ_CHECK_LAUNCH() KJ_TRY_HIP(hipGetLastError())
 #define KJ_PROBE_ROWS 27u
 #define KJ_PROBE_COLOR_ROWS 26u
+#define KJ_PROBE_SHADING_ROWS 29u
 
 __global__ void __launch_bounds__(256) k_probe_functions(const uint4* __restrict__ in4, uint32_t n, uint4* __restrict__ out4) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,6 +159,85 @@ extern "C" KjStatus kj_selftest_probe_functions_color(const void* in4_device, ui
     if (n == 0) return KJ_OK;
     hipLaunchKernelGGL(k_probe_functions_color, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, (const uint4*)in4_device, n,
                        (const uint32_t*)bezold_brucke_lut_rg16f_device, (uint4*)out4_device);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+
+// The third probe (oracle/ref_hlsl/probes/inc_functions_shading.hlsl): the view-ray helpers, the ray cone, the layered BRDF with its energy preservation, the sun,
+// atmosphere_default, the triangle-light sampler (kj_shading.hpp, kj_scene.hpp, kj_rtr.hpp). Words with no device form of their own (ray_dir_vs, the boost factor -- folded
+// into layered_brdf_from_gbuffer_ndotv --, valid_sample_fraction, the measure conversion) stay 0.
+__global__ void __launch_bounds__(256) k_probe_functions_shading(FrameConstants fc, const uint4* __restrict__ in4, uint32_t n, const uint2* __restrict__ fg_lut, uint4* __restrict__ out4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 u = in4[i];
+    const V3 f{asfloat(u.x), asfloat(u.y), asfloat(u.z)};
+    const V3 unit = normalize(f);
+    const V3 ucol{uint_to_u01_float(u.x), uint_to_u01_float(u.y), uint_to_u01_float(u.z)};
+    const V3 urand{uint_to_u01_float(u.w), uint_to_u01_float(hash1(u.w)), uint_to_u01_float(hash1(u.w + 1u))};
+    const float depth = ucol.z * 0.25f + 1e-5f;
+    const V2 uv{ucol.x, ucol.y};
+    uint32_t k = 0;
+    auto OUT = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) { out4[size_t(k++) * n + i] = make_uint4(a, b, c, d); };
+    auto U = [](float v) { return asuint(v); };
+    auto OUT3 = [&](V3 v, float w = 0.0f) { OUT(U(v.x), U(v.y), U(v.z), U(w)); };
+    {
+        const ViewRay v = view_ray_from_uv(fc, uv);
+        OUT3(v.dir_ws);
+        OUT3(v.origin_ws);
+        const ViewRay h = view_ray_from_uv_and_depth(fc, uv, depth);
+        OUT3(h.hit_ws, h.hit_vs.z);
+        OUT3(h.biased_secondary_ray_origin_ws());
+        OUT3(h.biased_secondary_ray_origin_ws_with_normal(unit));
+        OUT3(view_ray_from_uv_and_biased_depth(fc, uv, depth).hit_ws);
+    }
+    OUT3(get_eye_position(fc), depth_to_view_z(fc, depth));
+    OUT3(get_prev_eye_position(fc), pixel_ray_cone_from_image_height(fc, 1080.0f).spread_angle);
+    OUT3(direction_view_to_world(fc, f));
+    OUT3(direction_world_to_view(fc, f));
+    OUT3(position_world_to_view(fc, f));
+    OUT3(position_world_to_clip(fc, f));
+    OUT3(position_world_to_sample(fc, f));
+    {
+        const RayCone c = pixel_ray_cone_from_image_height(fc, 720.0f).propagate(urand.x * 0.1f, fabsf(f.x));
+        OUT(U(c.width), U(c.spread_angle), U(c.width_at_t(fabsf(f.y))), 0);
+    }
+    {
+        GbufferData g;
+        g.albedo = ucol; g.normal = unit; g.roughness = 0.02f + 0.96f * urand.x; g.emissive = v3(0.0f);
+        g.metalness = (u.w & 1u) ? urand.y : float((u.w >> 1) & 1u);
+        const V3 wo = uniform_sample_hemisphere(V2{urand.y, urand.z});
+        const V3 wi = uniform_sample_hemisphere(V2{urand.z, urand.x});
+        OUT(0, 0, 0, 0);
+        const LayeredBrdf brdf = layered_brdf_from_gbuffer_ndotv(fg_lut, g, wo.z);
+        OUT3(brdf.spec_albedo, brdf.roughness);
+        OUT3(brdf.diff_albedo);
+        OUT3(brdf.preintegrated_reflection);
+        OUT3(brdf.preintegrated_reflection_mult);
+        OUT3(brdf.preintegrated_transmission_fraction);
+        OUT3(layered_brdf_evaluate(brdf, wo, wi));
+        OUT3(layered_brdf_evaluate_directional_light(brdf, wo, wi));
+        const BrdfSample s = layered_brdf_sample(brdf, wo, urand);
+        OUT3(s.wi, s.pdf);
+        OUT3(s.value_over_pdf, s.value.x);
+    }
+    OUT3(sample_sun_direction(fc, V2{urand.x, urand.y}, true));
+    OUT3(sun_color_in_direction(fc, V3{unit.x, fabsf(unit.y), unit.z}));
+    OUT3(atmosphere_default(fc, unit, normalize(sun_direction(fc))));
+    {
+        const LightSampleArea l = sample_triangle_light(f, ucol * 4.0f - 2.0f, urand * 4.0f - 2.0f, V2{ucol.y, ucol.x});
+        OUT3(l.pos, l.pdf);
+        OUT3(l.normal);
+    }
+}
+
+extern "C" KjStatus kj_selftest_probe_functions_shading(const KjFrameConstants* frame_constants, const void* in4_device, uint32_t n, const void* brdf_fg_lut_rgba16f_device,
+                                                        void* out4_device, uint32_t rows_capacity, uint32_t* out_rows, void* stream) {
+    KJ_REQUIRE(frame_constants && in4_device && brdf_fg_lut_rgba16f_device && out4_device && out_rows, "null argument");
+    KJ_REQUIRE(rows_capacity >= KJ_PROBE_SHADING_ROWS, "the output buffer holds fewer rows than the probe writes");
+    *out_rows = KJ_PROBE_SHADING_ROWS;
+    if (n == 0) return KJ_OK;
+    hipLaunchKernelGGL(k_probe_functions_shading, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *frame_constants, (const uint4*)in4_device, n,
+                       (const uint2*)brdf_fg_lut_rgba16f_device, (uint4*)out4_device);
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }

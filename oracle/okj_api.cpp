@@ -773,4 +773,78 @@ uint32_t okj_probe_functions_color(const uint32_t* in4, uint32_t n, const void* 
     return rows;
 }
 
+// The twin of oracle/ref_hlsl/probes/inc_functions_shading.hlsl: the view-ray helpers, the ray cone, the layered BRDF with its energy preservation (`brdf_fg_lut`: the 64x64
+// RGBA16F table of bindless slot 0), the sun, atmosphere_default and the triangle-light sampler, row for row. Returns the number of rows.
+uint32_t okj_probe_functions_shading(const KjFrameConstants* fcp, const uint32_t* in4, uint32_t n, const void* brdf_fg_lut, uint32_t* out4) {
+    const FrameConstants& fc = *fcp;
+    const h4* fg = (const h4*)brdf_fg_lut;
+    uint32_t rows = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t ux = in4[i * 4 + 0], uy = in4[i * 4 + 1], uz = in4[i * 4 + 2], uw = in4[i * 4 + 3];
+        const f3 f{asfloat(ux), asfloat(uy), asfloat(uz)};
+        const f3 unit = normalize(f);
+        const f3 ucol{uint_to_u01_float(ux), uint_to_u01_float(uy), uint_to_u01_float(uz)};
+        const f3 urand{uint_to_u01_float(uw), uint_to_u01_float(hash1(uw)), uint_to_u01_float(hash1(uw + 1u))};
+        const float depth = ucol.z * 0.25f + 1e-5f;
+        const f2 uv{ucol.x, ucol.y};
+        uint32_t k = 0;
+        auto OUT = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+            uint32_t* o = out4 + (size_t(k++) * n + i) * 4;
+            o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+        };
+        auto U = [](float v) { return asuint(v); };
+        auto OUT3 = [&](f3 v, float w = 0.0f) { OUT(U(v.x), U(v.y), U(v.z), U(w)); };
+        {
+            const ViewRayContext v = ViewRayContext::from_uv(fc, uv);
+            OUT3(v.ray_dir_ws(), v.ray_dir_vs().z);
+            OUT3(v.ray_origin_ws());
+            const ViewRayContext h = ViewRayContext::from_uv_and_depth(fc, uv, depth);
+            OUT3(h.ray_hit_ws(), h.ray_hit_vs().z);
+            OUT3(h.biased_secondary_ray_origin_ws());
+            OUT3(h.biased_secondary_ray_origin_ws_with_normal(unit));
+            OUT3(ViewRayContext::from_uv_and_biased_depth(fc, uv, depth).ray_hit_ws());
+        }
+        OUT3(get_eye_position(fc), depth_to_view_z(fc, depth));
+        OUT3(get_prev_eye_position(fc), pixel_cone_spread_angle_from_image_height(fc, 1080.0f));
+        OUT3(direction_view_to_world(fc, f));
+        OUT3(direction_world_to_view(fc, f));
+        OUT3(position_world_to_view(fc, f));
+        OUT3(position_world_to_clip(fc, f));
+        OUT3(position_world_to_sample(fc, f));
+        {
+            const RayCone c = pixel_ray_cone_from_image_height(fc, 720.0f).propagate(urand.x * 0.1f, fabsf(f.x));
+            OUT(U(c.width), U(c.spread_angle), U(c.width_at_t(fabsf(f.y))), 0);
+        }
+        {
+            GbufferData g;
+            g.albedo = ucol; g.normal = unit; g.roughness = 0.02f + 0.96f * urand.x;
+            g.metalness = (uw & 1u) ? urand.y : float((uw >> 1) & 1u);
+            const f3 wo = uniform_sample_hemisphere(f2{urand.y, urand.z});
+            const f3 wi = uniform_sample_hemisphere(f2{urand.z, urand.x});
+            OUT3(metalness_albedo_boost(g.metalness, g.albedo));
+            const LayeredBrdf brdf = LayeredBrdf::from_gbuffer_ndotv(fg, g, wo.z);
+            OUT3(brdf.specular_brdf.albedo, brdf.specular_brdf.roughness);
+            OUT3(brdf.diffuse_brdf.albedo, brdf.energy_preservation.valid_sample_fraction);
+            OUT3(brdf.energy_preservation.preintegrated_reflection);
+            OUT3(brdf.energy_preservation.preintegrated_reflection_mult);
+            OUT3(brdf.energy_preservation.preintegrated_transmission_fraction);
+            OUT3(brdf.evaluate(wo, wi));
+            OUT3(brdf.evaluate_directional_light(wo, wi));
+            const BrdfSample s = brdf.sample(wo, urand);
+            OUT3(s.wi, s.pdf);
+            OUT3(s.value_over_pdf, s.value.x);
+        }
+        OUT3(sample_sun_direction(fc, f2{urand.x, urand.y}, true));
+        OUT3(sun_color_in_direction(fc, f3{unit.x, fabsf(unit.y), unit.z}));
+        OUT3(atmosphere_default(fc, unit, normalize(sun_direction(fc))));
+        {
+            const LightSampleArea l = sample_triangle_light(f, ucol * 4.0f - 2.0f, urand * 4.0f - 2.0f, f2{ucol.y, ucol.x});
+            OUT3(l.pos, l.pdf);
+            OUT3(l.normal, l.pdf * fabsf(f.y) / (urand.x + 1e-3f) / (urand.y + 1e-3f));        // to_projected_solid_angle_measure(PdfArea), lights/triangle.hlsl:58-60
+        }
+        rows = k;
+    }
+    return rows;
+}
+
 } // extern "C"

@@ -142,6 +142,7 @@ def lib():
         L.okj_reference_path_trace_rows.argtypes = [C.c_void_p, C.POINTER(KjFrameConstants), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.okj_probe_functions.restype = C.c_uint32; L.okj_probe_functions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.okj_probe_functions_color.restype = C.c_uint32; L.okj_probe_functions_color.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.okj_probe_functions_shading.restype = C.c_uint32; L.okj_probe_functions_shading.argtypes = [C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.okj_set_threads.argtypes = [C.c_int]
         L.okj_get_max_threads.restype = C.c_int
         _LIB = L
@@ -179,6 +180,16 @@ def probe_functions_color(inputs, rows, bezold_brucke_lut):
     lut = np.ascontiguousarray(bezold_brucke_lut, np.float16).reshape(64, 2)
     out = np.zeros((rows, inputs.shape[0], 4), np.uint32)
     got = lib().okj_probe_functions_color(inputs.ctypes.data, inputs.shape[0], lut.ctypes.data, out.ctypes.data)
+    assert got == rows, (got, rows)
+    return out
+
+
+def probe_functions_shading(fc, inputs, rows):
+    """The restated view-ray / layered-BRDF / sun / light-sampling functions on `inputs` (n, 4) uint32 under frame constants `fc`: (rows, n, 4) uint32, in the row order of
+    oracle/ref_hlsl/probes/inc_functions_shading.hlsl."""
+    inputs = np.ascontiguousarray(inputs, np.uint32)
+    out = np.zeros((rows, inputs.shape[0], 4), np.uint32)
+    got = lib().okj_probe_functions_shading(C.byref(fc), inputs.ctypes.data, inputs.shape[0], brdf_lut().ctypes.data, out.ctypes.data)
     assert got == rows, (got, rows)
     return out
 

@@ -273,6 +273,38 @@ def test_device_colour_functions_match_the_oracle_row_by_row(gpu, oracle, device
     _compare_probe_rows(got, ours, TR._COLOR_PROBE_ROWS, inp, transcendental, device_words)
 
 
+def test_device_shading_functions_match_the_oracle_row_by_row(gpu, oracle, device):
+    """The third probe (oracle/ref_hlsl/probes/inc_functions_shading.hlsl): view-ray helpers under a real camera, the ray cone, the layered BRDF with its energy preservation
+    off the ORACLE's BRDF table uploaded (test_brdf_lut_and_sky compares the device's own table with it separately), the sun, atmosphere_default, the triangle-light sampler.
+    The matrix chains, biased origins, ray cone, the lobes' albedos, the light sampler: bit for bit."""
+    import os
+    import torch
+    import test_ref_hlsl as TR
+    L = gpu.load()
+    from kajiya_amd.abi import KjFrameConstants
+    L.kj_selftest_probe_functions_shading.argtypes = [C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+    n = 1 << (12 if os.environ.get("KJ_HIP_EMU") else 17)
+    inp = TR._probe_inputs(n, 271828)
+    rows = len(TR._SHADING_PROBE_ROWS)
+    fc = TR._frame_constants(320, 180, 3, "city")[2]
+    ours = oracle.probe_functions_shading(fc, inp, rows)
+    d_in = torch.from_numpy(inp.view(np.int32)).cuda()
+    d_out = torch.zeros((rows, n, 4), dtype=torch.int32, device="cuda")
+    d_lut = torch.from_numpy(np.ascontiguousarray(oracle.brdf_lut()).view(np.int16).copy()).cuda()
+    got_rows = C.c_uint32(0)
+    gpu.check(L.kj_selftest_probe_functions_shading(C.byref(fc), d_in.data_ptr(), n, d_lut.data_ptr(), d_out.data_ptr(), rows, C.byref(got_rows), None))
+    torch.cuda.synchronize()
+    assert got_rows.value == rows
+    got = d_out.cpu().numpy().view(np.uint32)
+    lobe = (2e-3, 2e-3)
+    transcendental = {7: (1e-6, 0.0), 13: (1e-5, 1e-4),                       # atan of the pixel cone
+                      20: lobe, 21: lobe, 22: lobe, 23: lobe,                 # the specular lobe inside (pow, and sin / cos of the samplers upstream)
+                      15: (1e-5, 1e-4), 16: (1e-5, 1e-4), 17: (1e-4, 1e-3), 18: (1e-4, 1e-3), 19: (1e-4, 1e-3),   # ndotv comes from a sampled direction (cos / sin): the table is read a last bit aside
+                      24: (1e-5, 1e-4), 25: (1e-5, 1e-4), 26: (1e-5, 1e-4)}   # the cone sampler; the sky (exp, pow)
+    device_words = {0: "xyz", 14: "", 16: "xyz", 28: "xyz"}
+    _compare_probe_rows(got, ours, TR._SHADING_PROBE_ROWS, inp, transcendental, device_words)
+
+
 def test_brdf_lut_and_sky(gpu, oracle, device):
     import torch
     lut_ref = oracle.brdf_lut()

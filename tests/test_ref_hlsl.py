@@ -1204,3 +1204,45 @@ def test_inc_color_functions_reference_hlsl_vs_oracle(oracle, libm_sincos, n):
             i = int(np.argmin(same.all(axis=1)))
             bad.append((what, int((~same.all(axis=1)).sum()), i, [hex(v) for v in inp[i]], a[i].view(np.float32).tolist(), b[i].view(np.float32).tolist()))
     assert not bad, bad
+
+
+_SHADING_PROBE_ROWS = [
+    ("ViewRayContext::from_uv: ray_dir_ws, ray_dir_vs", "xyzw"), ("ViewRayContext::ray_origin_ws", "xyz"), ("ViewRayContext::from_uv_and_depth: ray_hit_ws, ray_hit_vs", "xyzw"),
+    ("biased_secondary_ray_origin_ws", "xyz"), ("biased_secondary_ray_origin_ws_with_normal", "xyz"), ("from_uv_and_biased_depth", "xyz"),
+    ("get_eye_position, depth_to_view_z", "xyzw"), ("get_prev_eye_position, pixel_cone_spread_angle_from_image_height", "xyzw"), ("direction_view_to_world", "xyz"),
+    ("direction_world_to_view", "xyz"), ("position_world_to_view", "xyz"), ("position_world_to_clip", "xyz"), ("position_world_to_sample", "xyz"),
+    ("RayCone::propagate, width_at_t", "xyz"), ("metalness_albedo_boost", "xyz"), ("LayeredBrdf::from_gbuffer_ndotv: specular lobe", "xyzw"),
+    ("from_gbuffer_ndotv: diffuse albedo, valid_sample_fraction", "xyzw"), ("SpecularBrdfEnergyPreservation: preintegrated_reflection", "xyz"),
+    ("preintegrated_reflection_mult", "xyz"), ("preintegrated_transmission_fraction", "xyz"), ("LayeredBrdf::evaluate", "xyz"), ("LayeredBrdf::evaluate_directional_light", "xyz"),
+    ("LayeredBrdf::sample (wi, pdf)", "xyzw"), ("LayeredBrdf::sample (value_over_pdf, value)", "xyzw"), ("sample_sun_direction", "xyz"), ("sun_color_in_direction", "xyz"),
+    ("atmosphere_default", "xyz"), ("sample_triangle_light (pos, pdf)", "xyzw"), ("sample_triangle_light (normal), to_projected_solid_angle_measure", "xyzw"),
+]
+
+
+@pytest.mark.parametrize("n", [4096, 1 << 17])
+@recorded_case(lambda k: "inc_functions_shading" if k["n"] == 4096 else None)
+def test_inc_shading_functions_reference_hlsl_vs_oracle(oracle, libm_sincos, n):
+    """Phase A, third probe: the view-ray helpers of inc/frame_constants.hlsl under a real camera (jittered, with a previous frame), inc/ray_cone.hlsl, the layered BRDF and
+    its energy preservation off the BRDF table (inc/layered_brdf.hlsl, inc/brdf_lut.hlsl), inc/sun.hlsl, inc/atmosphere.hlsl and the triangle-light sampler
+    (inc/lights/triangle.hlsl) -- the reference's text against the oracle's restatement, bit for bit, function by function."""
+    if n != 4096:
+        R.require_live()
+    _bind_luts(oracle)
+    fc = _frame_constants(320, 180, 3, "city")[2]
+    inp = _probe_inputs(n, 4242 + n)
+    rows = len(_SHADING_PROBE_ROWS)
+    out = np.zeros((rows, n, 4), np.uint32)
+    R.run_pass("probes/inc_functions_shading", [R.Buf(inp), R.Buf(out)], [np.uint32(n)], fc, (n, 1, 1))
+    ours = oracle.probe_functions_shading(fc, inp, rows)
+    assert out.any(axis=(1, 2)).all(), "a row the probe never wrote"
+    bad = []
+    for r, (what, floats) in enumerate(_SHADING_PROBE_ROWS):
+        a, b = out[r], ours[r]
+        same = a == b
+        for c in floats:        # a NaN is a NaN whatever its payload
+            ci = "xyzw".index(c)
+            same[:, ci] |= np.isnan(a[:, ci].view(np.float32)) & np.isnan(b[:, ci].view(np.float32))
+        if not same.all():
+            i = int(np.argmin(same.all(axis=1)))
+            bad.append((what, int((~same.all(axis=1)).sum()), i, [hex(v) for v in inp[i]], a[i].view(np.float32).tolist(), b[i].view(np.float32).tolist()))
+    assert not bad, bad
