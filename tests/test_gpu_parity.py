@@ -300,7 +300,7 @@ def test_device_shading_functions_match_the_oracle_row_by_row(gpu, oracle, devic
     transcendental = {7: (1e-6, 0.0), 13: (1e-5, 1e-4),                       # atan of the pixel cone
                       20: lobe, 21: lobe, 22: lobe, 23: lobe,                 # the specular lobe inside (pow, and sin / cos of the samplers upstream)
                       15: (1e-5, 1e-4), 16: (1e-5, 1e-4), 17: (1e-4, 1e-3), 18: (1e-4, 1e-3), 19: (1e-4, 1e-3),   # ndotv comes from a sampled direction (cos / sin): the table is read a last bit aside
-                      24: (1e-5, 1e-4), 25: (1e-5, 1e-4), 26: (1e-5, 1e-4)}   # the cone sampler; the sky (exp, pow)
+                      24: (1e-5, 1e-4), 25: (1e-5, 1e-4), 26: (1e-4, 1e-4)}   # the cone sampler; the sky (exp, pow; measured: 8 of 131 072 beyond 1e-5, worst 2.3e-5)
     device_words = {0: "xyz", 14: "", 16: "xyz", 28: "xyz"}
     _compare_probe_rows(got, ours, TR._SHADING_PROBE_ROWS, inp, transcendental, device_words)
 
