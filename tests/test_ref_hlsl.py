@@ -8,6 +8,7 @@ hand-written oracle (oracle/okj_*.hpp) on the same inputs:
 
 Not GPU tests: this runs wherever the library is (built here, where the reference checkout is; it travels to the GPU box prebuilt)."""
 import ctypes as C
+import os
 import numpy as np
 import pytest
 
@@ -17,6 +18,14 @@ import ref_hlsl as R
 pytestmark = pytest.mark.skipif(not R.available(), reason="no reference checkout, no prebuilt oracle/_ref/libref_hlsl.so and no recorded outputs under tests/golden/ref_hlsl")
 
 KEEP = 1 << 31
+# KJ_REF_HLSL_SCALE=k: every frame extent of the pass-level cases below times k (live runs only; the recorded cases are the unscaled ones). The stored formats are 16 bits
+# or fewer for most surfaces, so a last-bit difference in the fp32 arithmetic shows in about one texel in ten thousand: the small extents of the default run find reading
+# differences of association and evaluation order, the scaled run (scripts/ref_hlsl_at_scale.sh) is what has the power for rarer ones.
+SCALE = int(os.environ.get("KJ_REF_HLSL_SCALE", "1"))
+
+
+def _scaled(w, h):
+    return w * SCALE, h * SCALE
 
 
 def recorded_case(select):
@@ -247,6 +256,7 @@ def test_rtdgi_ray_free_passes_reference_hlsl_vs_oracle(oracle, scene_name, W, H
     """fullres_reproject, the half-res extracts, validity integrate, temporal + N x spatial ReSTIR, resolve, temporal and spatial filter:
     frames 5 (tracing), 6 (validation: frame_index % 3 == 0) and 7 after five warm-up frames. Extents that are not multiples of the
     8x8 group, a moving camera over a 20 k-triangle city, 1 / 2 / 3 spatial passes, occlusion_raymarch_importance_only on and off."""
+    W, H = _scaled(W, H)
     worst = _rtdgi_chain(oracle, scene_name, W, H, n_frames=8, warmup=5, spatial_passes=passes, raytraced=raytraced)
     assert len(worst) >= (18 if passes >= 2 else 17), sorted(worst)
 
@@ -255,6 +265,7 @@ def test_rtdgi_ray_free_passes_reference_hlsl_vs_oracle(oracle, scene_name, W, H
 @recorded_case(lambda k: "reprojection_map_cornell_64" if k["scene_name"] == "cornell" else None)
 def test_reprojection_map_reference_hlsl_vs_oracle(oracle, scene_name, W, H):
     """calculate_reprojection_map.hlsl as renderers/reprojection.rs:6-52 records it, on a moving camera, against the oracle's map."""
+    W, H = _scaled(W, H)
     from kajiya_amd import scenes
     desc = scenes.cornell_box() if scene_name == "cornell" else scenes.procedural_city(seed=1234, target_tris=20000)
     op = oracle.OraclePipeline(oracle.OracleScene(desc), W, H)
@@ -291,6 +302,7 @@ def _taa_surfaces(op):
 @recorded_case(lambda k: "taa_64" if k["W"] == 64 else None)
 def test_taa_passes_reference_hlsl_vs_oracle(oracle, W, H):
     """The seven TAA passes on the GI output, frames 0..5 (frame 0: empty history), each reference pass fed the oracle's surfaces."""
+    W, H = _scaled(W, H)
     from kajiya_amd import scenes
     _bind_luts(oracle)
     op = oracle.OraclePipeline(oracle.OracleScene(scenes.cornell_box()), W, H)
@@ -492,6 +504,7 @@ def test_rtdgi_ray_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, W, H):
     diffuse_trace_common.inc.hlsl, candidate_ray_dir.hlsl, inc/rt.hlsl, and on every hit rt/gbuffer.rchit.hlsl reading the scene tables --
     against the oracle's passes on the oracle's frame state. Only the intersection query itself (the driver's in the reference) is the
     oracle's. The irradiance cache is bound empty, as the oracle's null lookup hook models it (BASELINE configs[0])."""
+    W, H = _scaled(W, H)
     from kajiya_amd import scenes
     from kajiya_amd.abi import KJ_RTDGI_PASS
     _bind_luts(oracle)
@@ -558,7 +571,7 @@ def test_sun_shadow_mask_and_reference_pt_reference_hlsl_vs_oracle(oracle, libm_
     desc = scenes.cornell_box()
     osc = oracle.OracleScene(desc)
     keep = _bind_scene(oracle, osc, desc)
-    W, H = 64, 48
+    W, H = _scaled(64, 48)
     op = oracle.OraclePipeline(osc, W, H)
     acc_ref, acc_o = R.Tex.zeros(W, H, "rgba32f"), np.zeros((H, W, 4), np.float32)
     worst = 0.0
@@ -611,7 +624,7 @@ def test_ircache_ray_passes_and_live_lookups_reference_hlsl_vs_oracle(oracle, li
     n_threads = oracle.lib().okj_get_max_threads()
     oracle.lib().okj_set_threads(1)
     try:
-        W, H = 64, 48
+        W, H = _scaled(64, 48)
         hw, hh = W // 2, H // 2
         desc = scenes.cornell_box()
         osc = oracle.OracleScene(desc)
@@ -701,7 +714,7 @@ def test_ssao_guide_passes_reference_hlsl_vs_oracle(oracle, libm_sincos):
     previous-radiance input never reaches the output and is bound black)."""
     from kajiya_amd import scenes
     _bind_luts(oracle)
-    W, H = 104, 60
+    W, H = _scaled(104, 60)
     hw, hh = W // 2, H // 2
     op = oracle.OraclePipeline(oracle.OracleScene(scenes.procedural_city(seed=1234, target_tris=20000)), W, H)
     g, ho = R.extent_inv_extent(W, H), R.extent_inv_extent(hw, hh)
@@ -756,7 +769,7 @@ def test_shadow_denoise_passes_reference_hlsl_vs_oracle(oracle, libm_sincos):
     like the host records them -- bit-pack, temporal megakernel, three a-trous passes (step 1, 2, 4) -- against the oracle's frame."""
     from kajiya_amd import scenes
     _bind_luts(oracle)
-    W, H = 104, 60
+    W, H = _scaled(104, 60)
     TW, TH = (W + 7) // 8, (H + 3) // 4
     op = oracle.OraclePipeline(oracle.OracleScene(scenes.procedural_city(seed=1234, target_tris=20000)), W, H)
     g = R.extent_inv_extent(W, H)
@@ -811,7 +824,7 @@ def test_light_gbuffer_reference_hlsl_vs_oracle(oracle, libm_sincos):
     the two sky cubes) against the oracle's combine: both outputs, sky pixels with the sun disc included."""
     from kajiya_amd import scenes
     _bind_luts(oracle)
-    W, H = 96, 64
+    W, H = _scaled(96, 64)
     op = oracle.OraclePipeline(oracle.OracleScene(scenes.cornell_box()), W, H)
     g = R.extent_inv_extent(W, H)
     for fi, fc in enumerate(_frame_constants(W, H, 4)):
@@ -883,7 +896,7 @@ def test_rtr_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, reuse):
     desc = scenes.glossy_test_scene()
     osc = oracle.OracleScene(desc)
     keep = _bind_scene(oracle, osc, desc)
-    W, H = 72, 44
+    W, H = _scaled(72, 44)
     hw, hh = (W + 1) // 2, (H + 1) // 2
     qw, qh = (hw + 1) // 2, (hh + 1) // 2
     op = oracle.OraclePipeline(osc, W, H)
@@ -942,9 +955,10 @@ def test_rtr_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, reuse):
             else:                              # rtr.rs:467-477
                 R.run_pass("rtr/spatial_cleanup", [f.out_as_input("rtr.temporal"), f.depth(), f.geometric_normal(), f.wr("resolved_tex")], [offsets], fc, (W, H, 1))
             if pname == "VALIDATE":            # (a) of the docstring: quads whose validation ray has no direction
-                off = np.array([(0, 0), (1, 1), (1, 0), (0, 1)])[fc.frame_index & 3]
+                off = np.array([(1, 1), (1, 0), (0, 0), (0, 1)])[fc.frame_index & 3]           # hi_px_subpixels (inc/frame_constants.hlsl:235-240)
                 ray = P.decode(before["rtr.ray" + f.hist_sfx], "rgba16f").reshape(hh, hw, 4)[off[1]::2, off[0]::2, :3]
-                dead = np.argwhere((ray == 0).all(axis=-1) & (op.depth.reshape(H, W)[2 * off[1]::4, 2 * off[0]::4][:ray.shape[0], :ray.shape[1]] != 0))
+                # a zero-length ray where the quad's own pixel (hi_px = (2 q + off) * 2 + off, reflection_validate.rgen.hlsl:49-54) sees geometry
+                dead = np.argwhere((ray == 0).all(axis=-1) & (op.depth.reshape(H, W)[3 * off[1]::4, 3 * off[0]::4][:ray.shape[0], :ray.shape[1]] != 0))
                 undefined_quads += len(dead)
                 for n, t in f.written.items():
                     bpt = t.raw.size // (hw * hh)
@@ -1016,7 +1030,7 @@ def test_light_specular_reference_hlsl_vs_oracle(oracle, libm_sincos):
     lights = np.zeros(n_lights * 12, np.float32)
     oracle.lib().okj_scene_triangle_lights(C.c_void_p(osc.h), C.c_void_p(lights.ctypes.data))
     R.set_named("triangle_lights_dyn", R.Buf(lights))
-    W, H = 72, 44
+    W, H = _scaled(72, 44)
     hw, hh = (W + 1) // 2, (H + 1) // 2
     op = oracle.OraclePipeline(osc, W, H)
     g = R.extent_inv_extent(W, H)
@@ -1049,6 +1063,7 @@ def test_post_passes_reference_hlsl_vs_oracle(oracle, libm_sincos, W, H, frame_i
     post/luminance_histogram_{clear,calculate,copy}.hlsl and post_combine.hlsl (glare, vignette, the display transform with its Bezold-Brucke
     LUT, contrast, dither), each on the oracle's own inputs to that pass, against the oracle. Mip 0 of the blur pyramid and the reverse pyramid
     are Rust kernels in the reference (rust-shaders/src/{blur,rev_blur}.rs; tests/test_post_oracle.py holds the oracle to their text)."""
+    W, H = _scaled(W, H)
     from kajiya_amd import frame, post_tables
     _bind_luts(oracle)
     lut = post_tables.zero_bezold_brucke_lut() if lut_seed is None else post_tables.synthetic_bezold_brucke_lut(lut_seed)
