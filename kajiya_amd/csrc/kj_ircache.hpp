@@ -111,7 +111,10 @@ KJ_HD IrcCoord irc_ws_pos_to_coord(const FrameConstants& fc, V3 pos, V3 normal, 
     const int32_t* org = fc.ircache_cascades[cascade].origin;
     const V3 q = (pos + normal * cell_diameter * 0.5f) / cell_diameter;
     const int cx = int(floorf(q.x)) - org[0], cy = int(floorf(q.y)) - org[1], cz = int(floorf(q.z)) - org[2];
-    return IrcCoord{uint32_t(min(max(cx, 0), 31)), uint32_t(min(max(cy, 0), 31)), uint32_t(min(max(cz, 0), 31)), cascade};
+    // clamp(coord, (0).xxx, (IRCACHE_CASCADE_SIZE - 1).xxx) with a uint constant (ircache_grid.hlsl:7,73): int and uint unify to uint -- a coordinate below the cascade's
+    // first cell wraps and lands on its LAST cell
+    const uint32_t ux = uint32_t(cx), uy = uint32_t(cy), uz = uint32_t(cz);
+    return IrcCoord{ux < 31u ? ux : 31u, uy < 31u ? uy : 31u, uz < 31u ? uz : 31u, cascade};
 }
 
 #ifdef __HIPCC__

@@ -847,4 +847,53 @@ uint32_t okj_probe_functions_shading(const KjFrameConstants* fcp, const uint32_t
     return rows;
 }
 
+// The twin of oracle/ref_hlsl/probes/inc_functions_misc.hlsl: taa_common's colour mapping, get_bilinear_filter, TemporalReservoirOutput, the cache's SampleParams and
+// ws_pos_to_ircache_coord under the frame's cascades, row for row. Returns the number of rows.
+uint32_t okj_probe_functions_misc(const KjFrameConstants* fcp, const uint32_t* in4, uint32_t n, uint32_t* out4) {
+    const FrameConstants& fc = *fcp;
+    uint32_t rows = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t ux = in4[i * 4 + 0], uy = in4[i * 4 + 1], uz = in4[i * 4 + 2], uw = in4[i * 4 + 3];
+        const f3 f{asfloat(ux), asfloat(uy), asfloat(uz)};
+        const f3 unit = normalize(f);
+        const f3 col = vabs(f);
+        const f3 ucol{uint_to_u01_float(ux), uint_to_u01_float(uy), uint_to_u01_float(uz)};
+        uint32_t k = 0;
+        auto OUT = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+            uint32_t* o = out4 + (size_t(k++) * n + i) * 4;
+            o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+        };
+        auto U = [](float v) { return asuint(v); };
+        { const f3 v = taa_decode_rgb(col); OUT(U(v.x), U(v.y), U(v.z), 0); }
+        { const f3 v = taa_encode_rgb(col); OUT(U(v.x), U(v.y), U(v.z), 0); }
+        {
+            const Bilinear b = get_bilinear_filter(f2{ucol.x * 1.25f - 0.125f, ucol.y * 1.25f - 0.125f}, f2{1920.0f, 1080.0f});
+            OUT(U(b.origin.x), U(b.origin.y), U(b.weights.x), U(b.weights.y));
+        }
+        {
+            const TemporalReservoirOutput t = TemporalReservoirOutput::from_raw(u4{ux, uy, uz, uw});
+            const u4 r = t.as_raw();
+            OUT(r.x, r.y, r.z, r.w);
+            OUT(U(t.depth), U(t.ray_hit_offset_ws.x), U(t.ray_hit_offset_ws.y), U(t.ray_hit_offset_ws.z));
+            OUT(U(t.luminance), U(t.hit_normal_ws.x), U(t.hit_normal_ws.y), U(t.hit_normal_ws.z));
+        }
+        {
+            const SampleParams s = SampleParams::from_spf_entry_sample_frame(4, ux & 0xffffu, uy & 3u, uz & 0xffffu);
+            const f2 uv = s.octa_uv();
+            OUT(s.value, s.rng(), U(uv.x), U(uv.y));
+            const f3 d = s.direction();
+            OUT(U(d.x), U(d.y), U(d.z), s.octa_idx());
+        }
+        {
+            const f3 center{fc.ircache_grid_center[0], fc.ircache_grid_center[1], fc.ircache_grid_center[2]};
+            const f3 pos = center + f * 0.01f;
+            const Ircache::Coord c = Ircache::ws_pos_to_ircache_coord(fc, pos, unit, ucol - 0.5f);
+            OUT(c.x, c.y, c.z, c.cascade);
+            OUT(c.cell(), Ircache::ws_local_pos_to_cascade_idx(f * 0.01f, 1), U(IRCACHE_GRID_CELL_DIAMETER * float(1u << (uw % 12u))), 0);
+        }
+        rows = k;
+    }
+    return rows;
+}
+
 } // extern "C"

@@ -164,7 +164,9 @@ struct Ircache {
         const f3 cell_offset = normal * cell_diameter * 0.5f;
         const f3 q = (pos + cell_offset) / cell_diameter;
         const int cx = int(floorf(q.x)) - org[0], cy = int(floorf(q.y)) - org[1], cz = int(floorf(q.z)) - org[2];
-        auto cl = [](int v) { return uint32_t(std::min(std::max(v, 0), 31)); };
+        // clamp(coord, (0).xxx, (IRCACHE_CASCADE_SIZE - 1).xxx) with IRCACHE_CASCADE_SIZE a uint (ircache_grid.hlsl:7,73): int and uint unify to uint, so a coordinate
+        // below the cascade's first cell wraps and lands on its LAST cell, not on cell 0
+        auto cl = [](int v) { return std::min(uint32_t(v), 31u); };
         return Coord{cl(cx), cl(cy), cl(cz), cascade};
     }
 

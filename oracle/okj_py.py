@@ -143,6 +143,7 @@ def lib():
         L.okj_probe_functions.restype = C.c_uint32; L.okj_probe_functions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.okj_probe_functions_color.restype = C.c_uint32; L.okj_probe_functions_color.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.okj_probe_functions_shading.restype = C.c_uint32; L.okj_probe_functions_shading.argtypes = [C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.okj_probe_functions_misc.restype = C.c_uint32; L.okj_probe_functions_misc.argtypes = [C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_void_p]
         L.okj_set_threads.argtypes = [C.c_int]
         L.okj_get_max_threads.restype = C.c_int
         _LIB = L
@@ -190,6 +191,16 @@ def probe_functions_shading(fc, inputs, rows):
     inputs = np.ascontiguousarray(inputs, np.uint32)
     out = np.zeros((rows, inputs.shape[0], 4), np.uint32)
     got = lib().okj_probe_functions_shading(C.byref(fc), inputs.ctypes.data, inputs.shape[0], brdf_lut().ctypes.data, out.ctypes.data)
+    assert got == rows, (got, rows)
+    return out
+
+
+def probe_functions_misc(fc, inputs, rows):
+    """taa_common / bilinear / TemporalReservoirOutput / SampleParams / ws_pos_to_ircache_coord on `inputs` (n, 4) uint32 under `fc`: (rows, n, 4) uint32, in the row order
+    of oracle/ref_hlsl/probes/inc_functions_misc.hlsl."""
+    inputs = np.ascontiguousarray(inputs, np.uint32)
+    out = np.zeros((rows, inputs.shape[0], 4), np.uint32)
+    got = lib().okj_probe_functions_misc(C.byref(fc), inputs.ctypes.data, inputs.shape[0], out.ctypes.data)
     assert got == rows, (got, rows)
     return out
 

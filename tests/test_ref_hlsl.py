@@ -1261,3 +1261,44 @@ def test_inc_shading_functions_reference_hlsl_vs_oracle(oracle, libm_sincos, n):
             i = int(np.argmin(same.all(axis=1)))
             bad.append((what, int((~same.all(axis=1)).sum()), i, [hex(v) for v in inp[i]], a[i].view(np.float32).tolist(), b[i].view(np.float32).tolist()))
     assert not bad, bad
+
+
+_MISC_PROBE_ROWS = [
+    ("taa decode_rgb", "xyz"), ("taa encode_rgb", "xyz"), ("get_bilinear_filter", "xyzw"), ("TemporalReservoirOutput::from_raw -> as_raw", ""),
+    ("TemporalReservoirOutput: depth, ray_hit_offset_ws", "xyzw"), ("TemporalReservoirOutput: luminance, hit_normal_ws", "xyzw"),
+    ("SampleParams: raw, rng, octa_uv", "zw"), ("SampleParams::direction, octa_idx", "xyz"), ("ws_pos_to_ircache_coord", ""),
+    ("IrcacheCoord::cell_idx, ws_local_pos_to_cascade_idx, ircache_grid_cell_diameter_in_cascade", "z"),
+]
+
+
+@pytest.mark.parametrize("n", [4096, 1 << 17])
+@recorded_case(lambda k: "inc_functions_misc" if k["n"] == 4096 else None)
+def test_misc_functions_reference_hlsl_vs_oracle(oracle, libm_sincos, n):
+    """Phase A, fourth probe: the helpers that live next to the passes -- taa/taa_common.hlsl, inc/bilinear.hlsl, rtdgi/rtdgi_common.hlsl, the cache's sample parameters and
+    its grid addressing under a frame's cascades (positions from centimetres to kilometres around the grid centre) -- reference text against oracle, bit for bit."""
+    if n != 4096:
+        R.require_live()
+    fc = _frame_constants(320, 180, 3, "city")[2]
+    inp = _probe_inputs(n, 1234 + n)
+    rows = len(_MISC_PROBE_ROWS)
+    out = np.zeros((rows, n, 4), np.uint32)
+    R.run_pass("probes/inc_functions_misc", [R.Buf(inp), R.Buf(out)], [np.uint32(n)], fc, (n, 1, 1))
+    ours = oracle.probe_functions_misc(fc, inp, rows)
+    assert out.any(axis=(1, 2)).all(), "a row the probe never wrote"
+    bad = []
+    for r, (what, floats) in enumerate(_MISC_PROBE_ROWS):
+        a, b = out[r], ours[r]
+        same = a == b
+        if r == 3:              # words y, z are pairs of halves that went half -> float -> half: a NaN half stays a NaN, its payload is the conversion's business
+            ha, hb = a[:, 1:3].copy().view(np.uint16), b[:, 1:3].copy().view(np.uint16)
+            nan = lambda h: ((h & 0x7c00) == 0x7c00) & ((h & 0x3ff) != 0)
+            ok = (ha == hb) | (nan(ha) & nan(hb))
+            same[:, 1:3] = ok.reshape(-1, 2, 2).all(axis=2)
+        for c in floats:        # a NaN is a NaN whatever its payload
+            ci = "xyzw".index(c)
+            same[:, ci] |= np.isnan(a[:, ci].view(np.float32)) & np.isnan(b[:, ci].view(np.float32))
+        if not same.all():
+            i = int(np.argmin(same.all(axis=1)))
+            bad.append((what, int((~same.all(axis=1)).sum()), i, [hex(v) for v in inp[i]], [hex(v) for v in a[i]], [hex(v) for v in b[i]]))
+    assert not bad, bad
+    assert len(np.unique(out[8][:, 3])) >= 10, "the positions reach fewer than ten of the twelve cascades"

@@ -16,5 +16,5 @@ def test_recorded_reference_outputs_replay_against_the_oracle():
     tail = r.stdout[-2500:] + r.stderr[-1500:]
     assert r.returncode == 0, tail
     m = re.search(r"(\d+) passed", r.stdout)
-    assert m and int(m.group(1)) >= 15 and " failed" not in r.stdout, tail
-    assert len([f for f in os.listdir(os.path.join(ROOT, "tests", "golden", "ref_hlsl")) if f.endswith(".npz")]) >= 15
+    assert m and int(m.group(1)) >= 16 and " failed" not in r.stdout, tail
+    assert len([f for f in os.listdir(os.path.join(ROOT, "tests", "golden", "ref_hlsl")) if f.endswith(".npz")]) >= 16
