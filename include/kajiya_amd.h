@@ -184,6 +184,10 @@ KjStatus kj_selftest_probe_functions_color(const void* in4_device, uint32_t n, c
  * triangle-light sampler. */
 KjStatus kj_selftest_probe_functions_shading(const KjFrameConstants* frame_constants, const void* in4_device, uint32_t n, const void* brdf_fg_lut_rgba16f_device,
                                              void* out4_device, uint32_t rows_capacity, uint32_t* out_rows, void* stream);
+/* The same for the fourth probe (oracle/ref_hlsl/probes/inc_functions_misc.hlsl): TemporalReservoirOutput, the irradiance cache's sample parameters and its grid
+ * addressing (ws_pos_to_ircache_coord under `frame_constants`' cascades). */
+KjStatus kj_selftest_probe_functions_misc(const KjFrameConstants* frame_constants, const void* in4_device, uint32_t n, void* out4_device, uint32_t rows_capacity,
+                                          uint32_t* out_rows, void* stream);
 
 /* RenderBackend / WorldRenderer::new analogue (default_world_renderer.rs:14-58):
  * picks the HIP device, builds the BRDF-FG LUT (bindless #0, lut/brdf_fg.hlsl),

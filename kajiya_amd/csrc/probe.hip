@@ -11,6 +11,7 @@
 #define KJ_PROBE_ROWS 27u
 #define KJ_PROBE_COLOR_ROWS 26u
 #define KJ_PROBE_SHADING_ROWS 29u
+#define KJ_PROBE_MISC_ROWS 10u
 
 __global__ void __launch_bounds__(256) k_probe_functions(const uint4* __restrict__ in4, uint32_t n, uint4* __restrict__ out4) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -238,6 +239,53 @@ extern "C" KjStatus kj_selftest_probe_functions_shading(const KjFrameConstants* 
     if (n == 0) return KJ_OK;
     hipLaunchKernelGGL(k_probe_functions_shading, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *frame_constants, (const uint4*)in4_device, n,
                        (const uint2*)brdf_fg_lut_rgba16f_device, (uint4*)out4_device);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+
+// The fourth probe (oracle/ref_hlsl/probes/inc_functions_misc.hlsl): TemporalReservoirOutput (kj_reservoir.hpp), the cache's sample parameters and grid addressing
+// (kj_ircache.hpp). Rows of functions that are local to a kernel's translation unit on the device (taa's colour mapping, the bilinear helper) stay 0.
+__global__ void __launch_bounds__(256) k_probe_functions_misc(FrameConstants fc, const uint4* __restrict__ in4, uint32_t n, uint4* __restrict__ out4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 u = in4[i];
+    const V3 f{asfloat(u.x), asfloat(u.y), asfloat(u.z)};
+    const V3 unit = normalize(f);
+    const V3 ucol{uint_to_u01_float(u.x), uint_to_u01_float(u.y), uint_to_u01_float(u.z)};
+    uint32_t k = 0;
+    auto OUT = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) { out4[size_t(k++) * n + i] = make_uint4(a, b, c, d); };
+    auto U = [](float v) { return asuint(v); };
+    OUT(0, 0, 0, 0);
+    OUT(0, 0, 0, 0);
+    OUT(0, 0, 0, 0);
+    {
+        const TemporalReservoirOutput t = TemporalReservoirOutput::from_raw(u);
+        const uint4 r = t.as_raw();
+        OUT(r.x, r.y, r.z, r.w);
+        OUT(U(t.depth), U(t.ray_hit_offset_ws.x), U(t.ray_hit_offset_ws.y), U(t.ray_hit_offset_ws.z));
+        OUT(U(t.luminance), U(t.hit_normal_ws.x), U(t.hit_normal_ws.y), U(t.hit_normal_ws.z));
+    }
+    {
+        const uint32_t s = irc_sample_params(4, u.x & 0xffffu, u.y & 3u, u.z & 0xffffu);
+        OUT(s, hash1(s >> 4u), 0, 0);
+        const V3 d = irc_sample_direction(s);
+        OUT(U(d.x), U(d.y), U(d.z), s % IRC_OCTA_DIMS2);
+    }
+    {
+        const V3 center{fc.ircache_grid_center[0], fc.ircache_grid_center[1], fc.ircache_grid_center[2]};
+        const IrcCoord c = irc_ws_pos_to_coord<true>(fc, center + f * 0.01f, unit, ucol - 0.5f);
+        OUT(c.x, c.y, c.z, c.cascade);
+        OUT(irc_cell_idx(c.x, c.y, c.z, c.cascade), irc_cascade_idx(f * 0.01f, 1u), 0, 0);
+    }
+}
+
+extern "C" KjStatus kj_selftest_probe_functions_misc(const KjFrameConstants* frame_constants, const void* in4_device, uint32_t n, void* out4_device, uint32_t rows_capacity,
+                                                     uint32_t* out_rows, void* stream) {
+    KJ_REQUIRE(frame_constants && in4_device && out4_device && out_rows, "null argument");
+    KJ_REQUIRE(rows_capacity >= KJ_PROBE_MISC_ROWS, "the output buffer holds fewer rows than the probe writes");
+    *out_rows = KJ_PROBE_MISC_ROWS;
+    if (n == 0) return KJ_OK;
+    hipLaunchKernelGGL(k_probe_functions_misc, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *frame_constants, (const uint4*)in4_device, n, (uint4*)out4_device);
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }

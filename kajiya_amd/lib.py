@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KJ_AMD_LIB") or os.path.join(HERE, "libkajiya_amd.so")   # KJ_AMD_LIB: A/B a differently built library
 
 EXPORTS = [
-    "kj_abi_struct_size", "kj_selftest_div_sqrt_nr", "kj_selftest_probe_functions", "kj_selftest_probe_functions_color", "kj_selftest_probe_functions_shading",
+    "kj_abi_struct_size", "kj_selftest_div_sqrt_nr", "kj_selftest_probe_functions", "kj_selftest_probe_functions_color", "kj_selftest_probe_functions_shading", "kj_selftest_probe_functions_misc",
     "kj_last_error", "kj_abi_version", "kj_device_create", "kj_device_destroy", "kj_device_brdf_lut",
     "kj_scene_create", "kj_scene_destroy", "kj_scene_add_mesh", "kj_scene_add_instance", "kj_scene_set_instance_transform",
     "kj_scene_set_instance_emissive_multiplier", "kj_scene_remove_instance", "kj_scene_commit", "kj_scene_triangle_light_count",

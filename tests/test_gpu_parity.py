@@ -305,6 +305,37 @@ def test_device_shading_functions_match_the_oracle_row_by_row(gpu, oracle, devic
     _compare_probe_rows(got, ours, TR._SHADING_PROBE_ROWS, inp, transcendental, device_words)
 
 
+def test_device_cache_addressing_and_reservoir_record_match_the_oracle_row_by_row(gpu, oracle, device):
+    """The fourth probe (oracle/ref_hlsl/probes/inc_functions_misc.hlsl): TemporalReservoirOutput's pack / unpack, the irradiance cache's sample parameters and directions,
+    and ws_pos_to_ircache_coord for positions from centimetres to kilometres around the grid centre -- incl. the ones below a cascade's first cell, which the text's unsigned
+    clamp sends to its last. Everything but the octahedral direction is integer / IEEE arithmetic: bit for bit."""
+    import os
+    import torch
+    import test_ref_hlsl as TR
+    from kajiya_amd.abi import KjFrameConstants
+    L = gpu.load()
+    L.kj_selftest_probe_functions_misc.argtypes = [C.POINTER(KjFrameConstants), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+    n = 1 << (12 if os.environ.get("KJ_HIP_EMU") else 17)
+    inp = TR._probe_inputs(n, 161803)
+    rows = len(TR._MISC_PROBE_ROWS)
+    fc = TR._frame_constants(320, 180, 3, "city")[2]
+    ours = oracle.probe_functions_misc(fc, inp, rows)
+    d_in = torch.from_numpy(inp.view(np.int32)).cuda()
+    d_out = torch.zeros((rows, n, 4), dtype=torch.int32, device="cuda")
+    got_rows = C.c_uint32(0)
+    gpu.check(L.kj_selftest_probe_functions_misc(C.byref(fc), d_in.data_ptr(), n, d_out.data_ptr(), rows, C.byref(got_rows), None))
+    torch.cuda.synchronize()
+    assert got_rows.value == rows
+    got = d_out.cpu().numpy().view(np.uint32)
+    # the record's y / z words are pairs of halves that went half -> float -> half: a NaN half stays a NaN, its payload is the conversion's business
+    for side in (got, ours):
+        h = side[3][:, 1:3].copy().view(np.uint16)
+        h[((h & 0x7c00) == 0x7c00) & ((h & 0x3ff) != 0)] = 0x7e00
+        side[3][:, 1:3] = h.view(np.uint32)
+    assert (ours[8][:, :3] == 31).any() and (ours[8][:, :3] == 0).any()
+    _compare_probe_rows(got, ours, TR._MISC_PROBE_ROWS, inp, {}, {0: "", 1: "", 2: "", 6: "xy", 9: "xy"})
+
+
 def test_brdf_lut_and_sky(gpu, oracle, device):
     import torch
     lut_ref = oracle.brdf_lut()
