@@ -391,9 +391,15 @@ KjStatus kj_rtdgi_traversal_counts(KjRtdgi* r, uint64_t out[6]);
  *   KJ_RTDGI_RAYS_STAGED: five launches over dense ray arrays (ray streams)
  *   KJ_RTDGI_RAYS_SPLIT: two launches: closest-hit traversal + everything a miss needs | hit shading on records compacted across tiles
  *   KJ_RTDGI_RAYS_QUAD: the fused kernels with four lanes per pixel (a wave covers 8 x 2 pixels; the traversal's four child tests of a node
- *     run on the four lanes, the shading code on all of them, the first lane stores) */
-enum { KJ_RTDGI_RAYS_GROUPED = 0, KJ_RTDGI_RAYS_FUSED = 1, KJ_RTDGI_RAYS_STAGED = 2, KJ_RTDGI_RAYS_SPLIT = 3, KJ_RTDGI_RAYS_QUAD = 4 };
+ *     run on the four lanes, the shading code on all of them, the first lane stores)
+ *   KJ_RTDGI_RAYS_POOL (round 5): a few persistent waves per SIMD; a lane holds one pixel's job (ray generation -> closest-hit walk -> hit shading ->
+ *     shadow walk -> the rest of the shading), free lanes are refilled from the wave's tile list while its other rays still walk, closest-hit and
+ *     occlusion rays share traversal steps, and the shading blocks wait for enough lanes (kj_rtdgi_set_pool_tune) */
+enum { KJ_RTDGI_RAYS_GROUPED = 0, KJ_RTDGI_RAYS_FUSED = 1, KJ_RTDGI_RAYS_STAGED = 2, KJ_RTDGI_RAYS_SPLIT = 3, KJ_RTDGI_RAYS_QUAD = 4, KJ_RTDGI_RAYS_POOL = 5 };
 KjStatus kj_rtdgi_set_ray_pass_form(KjRtdgi* r, uint32_t form);
+/* Scheduling of the pool form: persistent waves per SIMD (1 .. 4), the lane counts that must be waiting before the refill / first / second shading
+ * block is issued while other lanes still walk (1 .. 64), and whether tiles are handed out by a device counter (1) or by stride (0). Results do not depend on any of them. */
+KjStatus kj_rtdgi_set_pool_tune(KjRtdgi* r, uint32_t waves_per_simd, uint32_t refill_min, uint32_t shade_a_min, uint32_t shade_b_min, uint32_t dynamic_tiles);
 /* Ray counters of the last kj_rtdgi_render (closest-hit rays, any-hit rays). */
 KjStatus kj_rtdgi_ray_counts(KjRtdgi* r, uint64_t* out_closest, uint64_t* out_any);
 

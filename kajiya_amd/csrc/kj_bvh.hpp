@@ -237,6 +237,21 @@ KJ_D void tri_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t st
     else KJ_POP(S.cur)
 }
 
+// The same step for a wave that carries closest-hit and occlusion rays side by side (the pool form of the rtdgi ray passes): `any_hit` is the lane's.
+// (Such a wave visits every node's children nearest first, node_step<false>: an occlusion ray's answer does not depend on the order.)
+template <bool STATS>
+KJ_D void tri_step_mixed(const BvhView& bvh, RayState& S, bool any_hit, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
+    const uint32_t first = S.cur & 0x0fffffffu;
+    const uint32_t rest = (S.cur >> 28) & 7u;
+    const float4* __restrict__ tp = (const float4*)bvh.tris + size_t(first) * 3;
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    if (STATS) stats->tris += 1u;
+    const bool hit = intersect_tri(S.wo, S.wd, S.tmin, S.tmax, a, b, c, first, S.cull_back, S.h);
+    if (any_hit && hit) { S.cur = KJ_BVH_NONE; return; }
+    if (rest != 0u) S.cur = KJ_BVH_LEAF | ((rest - 1u) << 28) | (first + 1u);
+    else KJ_POP(S.cur)
+}
+
 // One ray per lane, start to finish, inside a caller's kernel. The lanes of the wave that are in the call step together: each
 // wave step issues EITHER the node block or the triangle block, whichever more lanes are waiting for (triangle lanes count
 // double: their block is the cheaper one), instead of a mixed wave paying for both blocks in every iteration. Per-ray results do

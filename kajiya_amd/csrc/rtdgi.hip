@@ -181,9 +181,11 @@ KJ_D void count_rays_quad(unsigned long long* counters, int which) {
 // Everything diffuse_trace_common.inc.hlsl:80-200 does for a ray that HIT (the divergent part: G-buffer of the hit, the sun's shadow ray,
 // the triangle lights, last frame's GI or the irradiance cache). Shared by the fused and the grouped form of the ray passes so that both
 // sum the radiance terms with the same arithmetic in the same order. Returns the radiance; `hit_normal_ws` = the hit's shading normal.
-template <bool STATS, bool QUAD = false>
-KJ_D V3 shade_candidate_hit(const TraceCtx& c, uint32_t px, uint32_t py, uint32_t& rng, V3 ray_o, V3 ray_d, const GbufferPathVertex& primary_hit, uint32_t* stack, uint32_t stride,
-                            TraverseStats* st_any, V3& hit_normal_ws) {
+// `sun_shadowed(position, to_light_norm)` answers the sun's shadow ray: the fused form walks it on the spot; the pool form (k_rtdgi_rays_pool) has walked it already, among
+// the other rays of its wave, and hands the answer in.
+template <bool STATS, bool QUAD = false, typename SunShadowed>
+KJ_D V3 shade_candidate_hit_with(const TraceCtx& c, uint32_t px, uint32_t py, uint32_t& rng, V3 ray_o, V3 ray_d, const GbufferPathVertex& primary_hit, uint32_t* stack, uint32_t stride,
+                                 TraverseStats* st_any, V3& hit_normal_ws, SunShadowed sun_shadowed) {
     const FrameConstants& fc = *c.fc;
     V3 total_radiance = v3(0.0f);
     GbufferData gbuffer = gbuffer_unpack(primary_hit.gbuffer_packed);
@@ -206,9 +208,7 @@ KJ_D V3 shade_candidate_hit(const TraceCtx& c, uint32_t px, uint32_t py, uint32_
     if (sun_radiance.x != 0 || sun_radiance.y != 0 || sun_radiance.z != 0) {
         const V4 bn = blue_noise_for_pixel(c.blue_noise, px, py, rng);
         const V3 to_light_norm = sample_sun_direction(fc, V2{bn.x, bn.y}, false);
-        if (QUAD) count_rays_quad(c.ray_counters, 1); else count_rays(c.ray_counters, 1, true);
-        const bool is_shadowed = QUAD ? rt_is_shadowed_quad(c.sc, true, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, stride)
-                                      : rt_is_shadowed<STATS>(c.sc, primary_hit.position, to_light_norm, 1e-4f, SKY_DIST, stack, stride, st_any);
+        const bool is_shadowed = sun_shadowed(primary_hit.position, to_light_norm);
         const V3 wi = to_local(tangent_to_world, to_light_norm);
         const V3 brdf_value = layered_brdf_evaluate(brdf, wo, wi) * fmaxf(0.0f, wi.z);
         total_radiance += brdf_value * (is_shadowed ? v3(0.0f) : sun_radiance);
@@ -248,6 +248,15 @@ KJ_D V3 shade_candidate_hit(const TraceCtx& c, uint32_t px, uint32_t py, uint32_
         }
     }
     return total_radiance;
+}
+template <bool STATS, bool QUAD = false>
+KJ_D V3 shade_candidate_hit(const TraceCtx& c, uint32_t px, uint32_t py, uint32_t& rng, V3 ray_o, V3 ray_d, const GbufferPathVertex& primary_hit, uint32_t* stack, uint32_t stride,
+                            TraverseStats* st_any, V3& hit_normal_ws) {
+    return shade_candidate_hit_with<STATS, QUAD>(c, px, py, rng, ray_o, ray_d, primary_hit, stack, stride, st_any, hit_normal_ws, [&](V3 position, V3 to_light_norm) -> bool {
+        if (QUAD) count_rays_quad(c.ray_counters, 1); else count_rays(c.ray_counters, 1, true);
+        return QUAD ? rt_is_shadowed_quad(c.sc, true, position, to_light_norm, 1e-4f, SKY_DIST, stack, stride)
+                    : rt_is_shadowed<STATS>(c.sc, position, to_light_norm, 1e-4f, SKY_DIST, stack, stride, st_any);
+    });
 }
 // diffuse_trace_common.inc.hlsl:68-71: reflected cone = the half-res pixel cone propagated from the eye to the ray origin
 KJ_D RayCone candidate_ray_cone(const TraceCtx& c, V3 ray_o) {
@@ -369,6 +378,249 @@ __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_fused(TraceC
     const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
     const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
     if (lead) invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
+}
+
+// ------------------------------------------------------------------ the POOL form of the two ray passes (round 5)
+// The fused kernels above give every 8x8 tile a wave that lives as long as its slowest pixel: sky pixels never start, two rays of three leave the scene after
+// a short walk, a sixth of the lanes shade a hit and walk a shadow ray -- 34 % of the lanes of an issued instruction do work (PMC, rounds 2-4). Here a launch is a few
+// PERSISTENT waves per SIMD, each working through a strided list of tiles, and a lane is a slot that holds one pixel's job in one of four states:
+//     idle -> [raygen] -> closest-hit walk -> miss: [retire: sky, outputs] -> idle
+//                                         -> hit : [shade A: G-buffer of the hit, the sun's shadow ray] -> occlusion walk -> [shade B: the rest of
+//                                                  diffuse_trace_common.inc.hlsl:80-200, outputs] -> idle
+// Every iteration the wave votes (ballots) on ONE block to issue: refill (retire misses + ray generation for the free lanes, from the tile list), shade A, shade B, or
+// a traversal step (node or triangle block, by majority, as in bvh_trace) in which closest-hit and occlusion rays of different pixels walk side by side. A shading
+// block waits until enough lanes want it (tunable thresholds), so hit shading runs on fuller waves; free lanes are refilled before the wave's other rays have finished.
+// Each pixel's arithmetic is that of the fused kernels, expression for expression (same device functions, same rng streams, FP contraction off in this unit), so every
+// output is bit-identical to theirs -- tests/test_gpu_parity.py::test_ray_pass_forms_agree -- and only the interleaving differs; with the racy cache the order of the
+// lookups' atomics differs, as it does from run to run of the fused form.
+// LDS per wave: the traversal stacks ([level][lane]) + KJ_POOL_REC dwords per lane ([field][lane]) for what a job carries across its shadow walk.
+#define KJ_POOL_REC 13u           // ray origin 3, direction 3, hit t, packed G-buffer 4 | written at ray generation: pdf, 1 - cos(theta)
+#ifndef KJ_POOL_WAVES
+#define KJ_POOL_WAVES 4           // waves per SIMD the kernel is compiled for (its VGPR budget); the launch picks how many it actually starts
+#endif
+struct PoolArgs {
+    ImgU32 half_view_normal_tex;
+    ImgU2 reprojection_tex; ImgH4 candidate_irradiance_out_tex; ImgU32 candidate_normal_out_tex; ImgH4 candidate_hit_out_tex; ImgR8 invalidity_in_tex;     // trace pass
+    ImgU2 reservoir_tex; ImgH4 reservoir_ray_history_tex; ImgH4 irradiance_history_tex; ImgF4 ray_orig_history_tex;                                      // validate pass
+    ImgR8 invalidity_out_tex;
+    int row0, row1;
+    uint32_t tiles_x, tiles_y;
+    uint32_t refill_min, shade_a_min, shade_b_min;     // lanes that must be waiting before the block is issued (while other lanes still walk)
+    uint32_t* tile_counter;                            // non-null: tiles beyond a wave's first are handed out by this counter instead of by stride
+};
+enum : uint32_t { KJ_PH_IDLE = 0u, KJ_PH_CLOSEST = 1u, KJ_PH_SHADOW = 2u, KJ_PH_NOSUN = 3u };
+KJ_D uint32_t pool_first_lane(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
+#else
+    return __shfl(v, 0);
+#endif
+}
+KJ_HD size_t pool_lds_bytes(uint32_t stack_entries) { return (size_t(stack_entries) + KJ_POOL_REC) * 64u * 4u; }
+
+// what trace_diffuse.rgen.hlsl:103-118 stores for a pixel whose candidate is known
+KJ_D void pool_finish_trace(const FrameConstants& fc, const PoolArgs& a, int x, int y, bool tracing_frame, V3 outgoing_dir, V3 out_value, V3 hit_normal_ws, float hit_t, float pdf, float one_minus_cos) {
+    const V3 hit_offset_ws = outgoing_dir * hit_t;
+    st4(a.candidate_irradiance_out_tex, x, y, v4(out_value, one_minus_cos));
+    st4(a.candidate_hit_out_tex, x, y, v4(hit_offset_ws, pdf * (tracing_frame ? 1.0f : -1.0f)));
+    a.candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, hit_normal_ws), 0)));
+}
+// diffuse_validate.rgen.hlsl:84-110 for a pixel whose re-traced radiance is known
+KJ_D void pool_finish_validate(const PoolArgs& a, int x, int y, V3 out_value, float hit_t) {
+    const float4 ro = a.ray_orig_history_tex.ld(x, y);
+    const V3 prev_ray_orig{ro.x, ro.y, ro.z};
+    const V3 prev_hit_pos = xyz(ld4(a.reservoir_ray_history_tex, x, y)) + prev_ray_orig;
+    const V4 prev_radiance_packed = ld4(a.irradiance_history_tex, x, y);
+    const V3 prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
+    const V3 new_radiance = vmax(v3(0.0f), out_value);
+    const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
+    const float invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
+    const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
+    if (fabsf(hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
+        st4(a.irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
+        Reservoir1spp r = Reservoir1spp::from_raw(a.reservoir_tex.ld(x, y));
+        const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
+        r.M *= clampf(lum_old / fmaxf(1e-8f, lum_new), 0.03f, 1.0f);
+        r.W *= clampf(lum_old / fmaxf(1e-8f, lum_new) * 10.0f, 0.01f, 1.0f);
+        a.reservoir_tex.st(x, y, r.as_raw());
+    }
+    a.invalidity_out_tex.st(x, y, to_unorm8(invalidity));
+}
+
+template <bool VALIDATE, bool STATS>
+__global__ void __launch_bounds__(64, KJ_POOL_WAVES) k_rtdgi_rays_pool(TraceCtx c, PoolArgs a) {
+    extern __shared__ uint32_t lds_pool[];
+    const uint32_t NONE = KJ_BVH_NONE;
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lane_bit = 1ull << lane;
+    uint32_t* stack = lds_pool + lane;
+    uint32_t* rec = lds_pool + c.sc.bvh.stack_entries * 64u + lane;
+    const FrameConstants& fc = *c.fc;
+    const I2 off = halfres_subsample_offset(fc.frame_index);
+    const bool tracing_frame = !is_rtdgi_validation_frame(fc.frame_index);
+    const int W = a.invalidity_out_tex.w, H = a.invalidity_out_tex.h;
+    const int y_end = H < a.row1 ? H : a.row1;
+    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
+    uint32_t tile = blockIdx.x, cursor = 0;
+    bool exhausted = tile >= n_tiles;
+    RayState S;
+    S.cur = NONE; S.sp = 0; S.cull_back = false;
+    S.h.t = FLT_MAX; S.h.u = S.h.v = 0; S.h.slot = S.h.world_id = 0xffffffffu;
+    S.wo = S.wd = S.binv = v3(0.0f); S.tmin = S.tmax = 0.0f;
+    uint32_t spill[KJ_BVH_SPILL_STACK];
+    uint32_t phase = KJ_PH_IDLE, pix = 0, rng = 0;
+    uint32_t n_closest = 0, n_any = 0;      // wave-uniform ray counts, added to the device counters once
+    TraverseStats st_closest{0, 0}, st_any{0, 0};
+    for (;;) {
+        const bool walking = S.cur != NONE;
+        const bool want_node = walking && !(S.cur & KJ_BVH_LEAF), want_tri = walking && (S.cur & KJ_BVH_LEAF) != 0u;
+        const bool done_closest = phase == KJ_PH_CLOSEST && !walking;
+        const bool is_miss = done_closest && S.h.slot == 0xffffffffu, wait_a = done_closest && S.h.slot != 0xffffffffu;
+        const bool wait_b = (phase == KJ_PH_SHADOW || phase == KJ_PH_NOSUN) && !walking;
+        const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
+        const uint32_t n_miss = uint32_t(__popcll(__ballot(is_miss))), n_free = n_miss + uint32_t(__popcll(__ballot(phase == KJ_PH_IDLE)));
+        const uint32_t n_a = uint32_t(__popcll(__ballot(wait_a))), n_b = uint32_t(__popcll(__ballot(wait_b)));
+        const uint32_t n_walk = nn + nt;
+        // in the tail (no tiles left) a shading block goes as soon as its lanes are as many as the walking ones
+        const uint32_t floor_ = n_walk > 1u ? n_walk : 1u;
+        const uint32_t thr_a = exhausted ? (a.shade_a_min < floor_ ? a.shade_a_min : floor_) : a.shade_a_min;
+        const uint32_t thr_b = exhausted ? (a.shade_b_min < floor_ ? a.shade_b_min : floor_) : a.shade_b_min;
+        int block;      // 0 refill, 1 shade A, 2 shade B, 3 walk
+        if (!exhausted && n_free >= a.refill_min) block = 0;
+        else if (n_b != 0u && n_b >= thr_b) block = 2;
+        else if (n_a != 0u && n_a >= thr_a) block = 1;
+        else if (n_walk != 0u) block = 3;
+        else if (n_b != 0u) block = 2;
+        else if (n_a != 0u) block = 1;
+        else if (n_miss != 0u || (!exhausted && n_free != 0u)) block = 0;
+        else break;
+
+        if (block == 3) {
+            TraverseStats* st = phase == KJ_PH_CLOSEST ? &st_closest : &st_any;
+            if (nt == 0u || (nn != 0u && nn >= nt * 2u)) { if (want_node) node_step<false, STATS>(c.sc.bvh, S, stack, 64, spill, st); }
+            else { if (want_tri) tri_step_mixed<STATS>(c.sc.bvh, S, phase != KJ_PH_CLOSEST, stack, 64, spill, st); }
+        } else if (block == 0) {
+            if (is_miss) {      // diffuse_trace_common.inc.hlsl:201-207: the sky
+                const int x = int(pix & 0xffffu), y = int(pix >> 16);
+                const V3 ray_d = S.wd;
+                V3 total_radiance = v3(0.0f);
+                total_radiance += xyz(sample_cube_rgba16f(c.sky_cube, c.sky_cube_width, ray_d));
+                if (VALIDATE) pool_finish_validate(a, x, y, total_radiance, SKY_DIST);
+                else {
+                    if (!tracing_frame) total_radiance = v3(0.0f);
+                    pool_finish_trace(fc, a, x, y, tracing_frame, ray_d, total_radiance, -ray_d, SKY_DIST, __uint_as_float(rec[11u * 64u]), __uint_as_float(rec[12u * 64u]));
+                }
+                phase = KJ_PH_IDLE;
+            }
+            if (!exhausted) {
+                const unsigned long long im = __ballot(phase == KJ_PH_IDLE);
+                const uint32_t n_idle = uint32_t(__popcll(im)), left = 64u - cursor;
+                const uint32_t take = n_idle < left ? n_idle : left;
+                const uint32_t rank = uint32_t(__popcll(im & (lane_bit - 1ull)));
+                bool started = false;
+                if (phase == KJ_PH_IDLE && rank < take) {
+                    const uint32_t p = cursor + rank, ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+                    const int x = int(tx * 8u + (p & 7u)), y = a.row0 + int(ty * 8u + (p >> 3));
+                    if (x < W && y < y_end) {
+                        const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+                        const float depth = c.depth.ld(hx, hy);
+                        if (VALIDATE) {
+                            if (0.0f == depth) a.invalidity_out_tex.st(x, y, to_unorm8(1.0f));
+                            else {
+                                const float4 ro = a.ray_orig_history_tex.ld(x, y);
+                                const V3 prev_ray_orig{ro.x, ro.y, ro.z};
+                                const V3 prev_hit_pos = xyz(ld4(a.reservoir_ray_history_tex, x, y)) + prev_ray_orig;
+                                rng = hash3(uint32_t(x), uint32_t(y), 0);
+                                ray_begin<false>(S, prev_ray_orig, normalize(prev_hit_pos - prev_ray_orig), 0.0f, SKY_DIST, false);
+                                started = true;
+                            }
+                        } else if (0.0f == depth) {
+                            st4(a.candidate_irradiance_out_tex, x, y, v4(0.0f));
+                            a.candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
+                            a.invalidity_out_tex.st(x, y, 0);
+                        } else {
+                            const V4 gts = tex_size4(c.depth.w, c.depth.h);
+                            const V2 uv = get_uv(float(hx), float(hy), gts);
+                            const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, uv, depth);
+                            const float near_field_fade_out_end = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
+                            const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(a.half_view_normal_tex, x, y));
+                            const Basis tangent_to_world = build_orthonormal_basis(normal_ws);
+                            const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, fc.frame_index);
+                            const V3 outgoing_dir = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
+                            const V3 origin = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
+                            rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u);
+                            const float pdf = fmaxf(0.0f, 1.0f / (dot(normal_ws, outgoing_dir) * 2 * KJ_PI));
+                            const float cos_theta = dot(normalize(outgoing_dir - vr.dir_ws), normal_ws);
+                            rec[11u * 64u] = __float_as_uint(pdf);
+                            rec[12u * 64u] = __float_as_uint(1.0f - cos_theta);
+                            ray_begin<false>(S, origin, outgoing_dir, 0.0f, tracing_frame ? SKY_DIST : near_field_fade_out_end, false);
+                            started = true;
+                            const V4 reproj = ld_reproj(a.reprojection_tex, hx, hy);
+                            const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
+                            a.invalidity_out_tex.st(x, y, a.invalidity_in_tex.ld(rx, ry));
+                        }
+                        if (started) { pix = uint32_t(x) | (uint32_t(y) << 16); phase = KJ_PH_CLOSEST; }
+                    }
+                }
+                n_closest += uint32_t(__popcll(__ballot(started)));
+                cursor += take;
+                if (cursor == 64u) {
+                    cursor = 0;
+                    if (a.tile_counter) {
+                        uint32_t t = 0;
+                        if (lane == 0u) t = atomicAdd(a.tile_counter, 1u) + gridDim.x;
+                        tile = pool_first_lane(t);
+                    } else tile += gridDim.x;
+                    exhausted = tile >= n_tiles;
+                }
+            }
+        } else if (block == 1) {
+            bool sun_ray = false;
+            if (wait_a) {       // rt/gbuffer.rchit.hlsl + diffuse_trace_common.inc.hlsl:80-130 up to the sun's shadow ray
+                const int x = int(pix & 0xffffu), y = int(pix >> 16);
+                const V3 ray_o = S.wo, ray_d = S.wd;
+                const RayHit h = S.h;
+                const uint4 gp = shade_gbuffer_hit(c.sc, fc, ray_d, h, 1, candidate_ray_cone(c, ray_o).width_at_t(h.t * length(ray_d)));
+                const V3 position = mad_nc(ray_o, ray_d, h.t);
+                rec[0u * 64u] = __float_as_uint(ray_o.x); rec[1u * 64u] = __float_as_uint(ray_o.y); rec[2u * 64u] = __float_as_uint(ray_o.z);
+                rec[3u * 64u] = __float_as_uint(ray_d.x); rec[4u * 64u] = __float_as_uint(ray_d.y); rec[5u * 64u] = __float_as_uint(ray_d.z);
+                rec[6u * 64u] = __float_as_uint(h.t);
+                rec[7u * 64u] = gp.x; rec[8u * 64u] = gp.y; rec[9u * 64u] = gp.z; rec[10u * 64u] = gp.w;
+                const float4 sc4 = *c.sun_color;
+                if (sc4.x != 0 || sc4.y != 0 || sc4.z != 0) {
+                    const V4 bn = blue_noise_for_pixel(c.blue_noise, uint32_t(x), uint32_t(y), rng);
+                    const V3 to_light_norm = sample_sun_direction(fc, V2{bn.x, bn.y}, false);
+                    ray_begin<true>(S, position, to_light_norm, 1e-4f, SKY_DIST, false);
+                    phase = KJ_PH_SHADOW;
+                    sun_ray = true;
+                } else { S.cur = NONE; phase = KJ_PH_NOSUN; }
+            }
+            n_any += uint32_t(__popcll(__ballot(sun_ray)));
+        } else {
+            if (wait_b) {       // the rest of diffuse_trace_common.inc.hlsl:80-200 with the shadow ray's answer, then the pass' stores
+                const int x = int(pix & 0xffffu), y = int(pix >> 16);
+                const bool sun_is_shadowed = S.h.slot != 0xffffffffu;
+                const V3 ray_o{__uint_as_float(rec[0u * 64u]), __uint_as_float(rec[1u * 64u]), __uint_as_float(rec[2u * 64u])};
+                const V3 ray_d{__uint_as_float(rec[3u * 64u]), __uint_as_float(rec[4u * 64u]), __uint_as_float(rec[5u * 64u])};
+                GbufferPathVertex pv;
+                pv.is_hit = true;
+                pv.ray_t = __uint_as_float(rec[6u * 64u]);
+                pv.gbuffer_packed = make_uint4(rec[7u * 64u], rec[8u * 64u], rec[9u * 64u], rec[10u * 64u]);
+                pv.position = mad_nc(ray_o, ray_d, pv.ray_t);
+                V3 hit_normal_ws;
+                const V3 radiance = shade_candidate_hit_with<STATS>(c, uint32_t(x), uint32_t(y), rng, ray_o, ray_d, pv, stack, 64, &st_any, hit_normal_ws,
+                                                                    [&](V3, V3) -> bool { return sun_is_shadowed; });
+                if (VALIDATE) pool_finish_validate(a, x, y, radiance, pv.ray_t);
+                else pool_finish_trace(fc, a, x, y, tracing_frame, ray_d, radiance, hit_normal_ws, pv.ray_t, __uint_as_float(rec[11u * 64u]), __uint_as_float(rec[12u * 64u]));
+                phase = KJ_PH_IDLE;
+            }
+        }
+    }
+    if (lane == 0u) {
+        if (n_closest) atomicAdd(&counter_slot(c.ray_counters)[0], (unsigned long long)n_closest);
+        if (n_any) atomicAdd(&counter_slot(c.ray_counters)[1], (unsigned long long)n_any);
+    }
+    add_traversal_stats<STATS>(c, st_closest, st_any);
 }
 
 #ifdef KJ_RAY_PASS_EXPERIMENTS
@@ -627,6 +879,9 @@ struct KjRtdgi {
     bool split_rays = false;                    // the ray passes as two launches each: closest-hit + misses | hit shading on compacted records (kj_rtdgi_set_ray_pass_form)
     bool grouped_rays = false;                  // the ray passes' form when not staged: grouped (hit shading regrouped inside a 256-thread workgroup) or fused (KJ_RTDGI_GROUPED=0)
     uint32_t ray_waves_per_simd = 0;            // 0 = whatever fits
+    bool pool_rays = false;                     // the ray passes as persistent waves over a pool of pixel jobs (k_rtdgi_rays_pool; kj_rtdgi_set_ray_pass_form KJ_RTDGI_RAYS_POOL)
+    uint32_t pool_waves_per_simd = 3, pool_refill_min = 16, pool_shade_a_min = 16, pool_shade_b_min = 16, pool_dynamic_tiles = 0;   // kj_rtdgi_set_pool_tune
+    kj::DevBuf pool_tile_counters;              // two u32 (validate, trace), zeroed with the ray counters
     int resample_variant = 2;                   // spatial reuse: 2 = per-tap gathers (fastest measured), 0 / 1 = LDS-staged tiles (KJ_RTDGI_RESAMPLE_VARIANT; rtdgi_resample.hpp)
     static const int NUM_SCOPES = 11;
     hipEvent_t ev[NUM_SCOPES][2] = {};
@@ -671,6 +926,13 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     if (const char* v = getenv("KJ_RTDGI_QUAD")) r->quad_rays = atoi(v) != 0;
     if (const char* v = getenv("KJ_RTDGI_FUSE_VT")) r->fuse_validity_temporal = atoi(v) != 0;
     if (const char* v = getenv("KJ_RTDGI_WAVES_PER_SIMD")) r->ray_waves_per_simd = uint32_t(std::max(0, atoi(v)));
+    if (const char* v = getenv("KJ_RTDGI_POOL")) r->pool_rays = atoi(v) != 0;      // A/B runs of bench.py: the pool form of the ray passes on / off
+    if (const char* v = getenv("KJ_RTDGI_POOL_TUNE")) {                             // "waves,refill,shade_a,shade_b,dynamic"
+        unsigned w = 0, f = 0, a = 0, b = 0, d = 0;
+        if (sscanf(v, "%u,%u,%u,%u,%u", &w, &f, &a, &b, &d) == 5 && w >= 1 && w <= KJ_POOL_WAVES && f >= 1 && f <= 64 && a >= 1 && a <= 64 && b >= 1 && b <= 64) {
+            r->pool_waves_per_simd = w; r->pool_refill_min = f; r->pool_shade_a_min = a; r->pool_shade_b_min = b; r->pool_dynamic_tiles = d ? 1u : 0u;
+        } else fprintf(stderr, "kajiya_amd: KJ_RTDGI_POOL_TUNE=%s ignored (want \"waves,refill,shade_a,shade_b,dynamic\")\n", v);
+    }
     if (r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
     *out = r;
     return KJ_OK;
@@ -793,6 +1055,30 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(1);
     }
+    // the pool form of the ray passes (k_rtdgi_rays_pool): persistent waves over the launch's tiles
+    PoolArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.half_view_normal_tex = img<uint32_t>(half_view_normal, hw, hh);
+    pa.reprojection_tex = reprojection; pa.candidate_irradiance_out_tex = img<uint2>(candidate_radiance, hw, hh); pa.candidate_normal_out_tex = img<uint32_t>(candidate_normal, hw, hh);
+    pa.candidate_hit_out_tex = img<uint2>(candidate_hit, hw, hh); pa.invalidity_in_tex = img<uint8_t>(validity_pre, hw, hh);
+    pa.reservoir_tex = img<uint2>(reservoir_hist, hw, hh); pa.reservoir_ray_history_tex = img<uint2>(ray_hist, hw, hh); pa.irradiance_history_tex = img<uint2>(radiance_hist, hw, hh);
+    pa.ray_orig_history_tex = img<float4>(ray_orig_hist, hw, hh);
+    pa.row0 = hr0; pa.row1 = hr1; pa.tiles_x = gh.x; pa.tiles_y = gh.y;
+    pa.refill_min = std::max(1u, std::min(64u, r->pool_refill_min)); pa.shade_a_min = std::max(1u, std::min(64u, r->pool_shade_a_min)); pa.shade_b_min = std::max(1u, std::min(64u, r->pool_shade_b_min));
+    const bool pool = r->pool_rays;
+    const size_t pool_lds = pool_lds_bytes(tc.sc.bvh.stack_entries);
+    const uint32_t pool_grid = std::max(1u, std::min(uint32_t(gh.x * gh.y), uint32_t(r->dev->num_cus) * 4u * std::max(1u, std::min(uint32_t(KJ_POOL_WAVES), r->pool_waves_per_simd))));
+    if (pool && r->pool_dynamic_tiles) {
+        if (!r->pool_tile_counters.p) KJ_TRY_HIP(r->pool_tile_counters.alloc(8));
+        KJ_TRY_HIP(hipMemsetAsync(r->pool_tile_counters.p, 0, 8, s));
+    }
+    auto launch_pool = [&](bool validate) {
+        PoolArgs q = pa;
+        if (validate) q.invalidity_out_tex = img<uint8_t>(validity_pre, hw, hh); else q.invalidity_out_tex = img<uint8_t>(validity_in, hw, hh);
+        q.tile_counter = r->pool_dynamic_tiles ? (uint32_t*)r->pool_tile_counters.p + (validate ? 0 : 1) : nullptr;
+        if (validate) hipLaunchKernelGGL((r->count_traversal ? k_rtdgi_rays_pool<true, true> : k_rtdgi_rays_pool<true, false>), dim3(pool_grid), blk, pool_lds, s, tc, q);
+        else hipLaunchKernelGGL((r->count_traversal ? k_rtdgi_rays_pool<false, true> : k_rtdgi_rays_pool<false, false>), dim3(pool_grid), blk, pool_lds, s, tc, q);
+    };
 #ifdef KJ_RAY_PASS_EXPERIMENTS
     // the ray passes' stage buffers (dense, one slot per lane of every 8x8 tile of the launch)
     const uint32_t stage_rays = gh.x * gh.y * 64u;
@@ -865,7 +1151,8 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     }
     if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged && !grouped && !split && !quad) {
         SCOPE_BEGIN(2);
-        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+        if (pool && is_rtdgi_validation_frame(r->dev->fc_host.frame_index)) launch_pool(true);
+        else hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
                            img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(2);
@@ -896,7 +1183,8 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     }
     if ((mask & KJ_RTDGI_PASS_TRACE) && !staged && !grouped && !split && !quad) {
         SCOPE_BEGIN(3);
-        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+        if (pool) launch_pool(false);
+        else hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
                            img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
@@ -933,7 +1221,8 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     // the other forms live behind KJ_RAY_PASS_EXPERIMENTS (rtdgi_ray_experiments.inc)
     if (mask & KJ_RTDGI_PASS_VALIDATE) {
         SCOPE_BEGIN(2);
-        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+        if (pool && is_rtdgi_validation_frame(r->dev->fc_host.frame_index)) launch_pool(true);    // two frames of three the pass only writes the invalidity image: the fused kernel does just that
+        else hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
                            img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(2);
@@ -941,7 +1230,8 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     tc.request_slot_base = uint32_t(hw) * uint32_t(hh); tc.request_key_base = 2u << 28;
     if (mask & KJ_RTDGI_PASS_TRACE) {
         SCOPE_BEGIN(3);
-        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+        if (pool) launch_pool(false);
+        else hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
                            img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
@@ -1069,14 +1359,22 @@ KjStatus kj_rtdgi_set_profiling(KjRtdgi* r, uint32_t enable_pass_timers, uint32_
     return KJ_OK;
 }
 KjStatus kj_rtdgi_set_ray_pass_form(KjRtdgi* r, uint32_t form) {
-    KJ_REQUIRE(r && form <= KJ_RTDGI_RAYS_QUAD, "null argument / unknown form");
+    KJ_REQUIRE(r && form <= KJ_RTDGI_RAYS_POOL, "null argument / unknown form");
 #ifndef KJ_RAY_PASS_EXPERIMENTS
-    KJ_REQUIRE(form == KJ_RTDGI_RAYS_FUSED, "this build carries the fused form only (the others: make EXPERIMENTS=1, -DKJ_RAY_PASS_EXPERIMENTS)");
+    KJ_REQUIRE(form == KJ_RTDGI_RAYS_FUSED || form == KJ_RTDGI_RAYS_POOL, "this build carries the fused and the pool form only (the others: make EXPERIMENTS=1, -DKJ_RAY_PASS_EXPERIMENTS)");
 #endif
+    r->pool_rays = form == KJ_RTDGI_RAYS_POOL;
     r->grouped_rays = form == KJ_RTDGI_RAYS_GROUPED;
     r->split_rays = form == KJ_RTDGI_RAYS_SPLIT;
     r->quad_rays = form == KJ_RTDGI_RAYS_QUAD;
     r->staged_min_rays = form == KJ_RTDGI_RAYS_STAGED ? 0u : 0xffffffffu;
+    return KJ_OK;
+}
+KjStatus kj_rtdgi_set_pool_tune(KjRtdgi* r, uint32_t waves_per_simd, uint32_t refill_min, uint32_t shade_a_min, uint32_t shade_b_min, uint32_t dynamic_tiles) {
+    KJ_REQUIRE(r, "null argument");
+    KJ_REQUIRE(waves_per_simd >= 1 && waves_per_simd <= KJ_POOL_WAVES, "waves_per_simd out of range (1 .. the kernel's compiled occupancy)");
+    KJ_REQUIRE(refill_min >= 1 && refill_min <= 64 && shade_a_min >= 1 && shade_a_min <= 64 && shade_b_min >= 1 && shade_b_min <= 64, "thresholds are lane counts (1 .. 64)");
+    r->pool_waves_per_simd = waves_per_simd; r->pool_refill_min = refill_min; r->pool_shade_a_min = shade_a_min; r->pool_shade_b_min = shade_b_min; r->pool_dynamic_tiles = dynamic_tiles ? 1u : 0u;
     return KJ_OK;
 }
 KjStatus kj_rtdgi_pass_times_ms(KjRtdgi* r, float* out_ms, uint32_t count) {

@@ -23,7 +23,7 @@ EXPORTS = [
     "kj_scene_stats", "kj_scene_last_commit_ms", "kj_scene_set_blas_build_mode", "kj_scene_set_open_instances", "kj_scene_set_top_build_mode", "kj_scene_top_tree_info", "kj_frame_begin", "kj_trace_closest", "kj_trace_any", "kj_debug_calibration_copy", "kj_raster_gbuffer", "kj_sky_cube_render",
     "kj_sky_cube_convolve", "kj_reprojection_create", "kj_reprojection_destroy", "kj_calculate_reprojection_map",
     "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_reproject_rows", "kj_rtdgi_render",
-    "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_set_ray_pass_form", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
+    "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_set_ray_pass_form", "kj_rtdgi_set_pool_tune", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
     "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts", "kj_ircache_set_deferred_updates", "kj_ircache_set_ray_passes_side_by_side", "kj_ircache_begin_requests", "kj_ircache_begin_requests_rows", "kj_ircache_request_ranges", "kj_ircache_collect_requests", "kj_ircache_apply_requests", "kj_ircache_set_rtr_requests", "kj_ircache_rtr_request_ranges",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
@@ -103,6 +103,7 @@ def load():
         "kj_rtdgi_ray_counts": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "kj_rtdgi_set_profiling": [vp, u32, u32],
         "kj_rtdgi_set_ray_pass_form": [vp, u32],
+        "kj_rtdgi_set_pool_tune": [vp, u32, u32, u32, u32, u32],
         "kj_rtdgi_pass_times_ms": [vp, C.POINTER(C.c_float), u32],
         "kj_rtdgi_traversal_counts": [vp, C.POINTER(C.c_uint64)],
         "kj_ircache_create": [vp, C.POINTER(vp)],
@@ -713,11 +714,15 @@ class GpuPipeline:
     PASS_NAMES = ["rtdgi reproject", "extract half", "rtdgi validate", "rtdgi trace", "validity integrate", "restir temporal",
                   "restir spatial 0", "restir spatial 1", "restir resolve", "rtdgi temporal", "rtdgi spatial"]
 
-    RAY_PASS_FORMS = {"grouped": 0, "fused": 1, "staged": 2, "split": 3, "quad": 4}
+    RAY_PASS_FORMS = {"grouped": 0, "fused": 1, "staged": 2, "split": 3, "quad": 4, "pool": 5}
 
     def set_ray_pass_form(self, form):
         """How `rtdgi validate` / `rtdgi trace` are scheduled (include/kajiya_amd.h: KJ_RTDGI_RAYS_*); outputs are identical for all."""
         check(self.L.kj_rtdgi_set_ray_pass_form(self.rtdgi, self.RAY_PASS_FORMS[form]))
+
+    def set_pool_tune(self, waves_per_simd=3, refill_min=16, shade_a_min=16, shade_b_min=16, dynamic_tiles=False):
+        """Scheduling knobs of the pool form of the ray passes (kj_rtdgi_set_pool_tune); results do not depend on them."""
+        check(self.L.kj_rtdgi_set_pool_tune(self.rtdgi, waves_per_simd, refill_min, shade_a_min, shade_b_min, int(dynamic_tiles)))
 
     def set_profiling(self, pass_timers=True, count_traversal=False):
         check(self.L.kj_rtdgi_set_profiling(self.rtdgi, int(pass_timers), int(count_traversal)))

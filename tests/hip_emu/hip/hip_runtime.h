@@ -220,6 +220,19 @@ template <typename T> inline T __shfl_xor(T v, int lane_mask) {
     hip_emu::barrier_wait();
     return r;
 }
+template <typename T> inline T __shfl(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "hip_emu: __shfl of a type wider than 8 bytes");
+    hip_emu::require_one_wave();
+    const unsigned l = hip_emu::lane(), n = blockDim.x * blockDim.y * blockDim.z;
+    memcpy(&hip_emu::g_exchange[l], &v, sizeof(T));
+    hip_emu::barrier_wait();
+    unsigned src = unsigned(src_lane) < n ? unsigned(src_lane) : l;
+    if (!hip_emu::g_lane_active[src]) src = l;
+    T r;
+    memcpy(&r, &hip_emu::g_exchange[src], sizeof(T));
+    hip_emu::barrier_wait();
+    return r;
+}
 inline unsigned long long __ballot(int predicate) {
     hip_emu::require_one_wave();
     const unsigned l = hip_emu::lane(), n = blockDim.x * blockDim.y * blockDim.z;

@@ -575,7 +575,8 @@ def _per_pass_parity(gpu, oracle, device, scene_name, W, H, passes, raytraced, n
 
 @pytest.mark.parametrize("scene_name,W,H,with_cache", [("city20k", 200, 120, True), ("cornell", 123, 77, False)])
 def test_ray_pass_forms_agree(gpu, device, scene_name, W, H, with_cache):
-    """The five schedules of the two ray passes -- fused (one wave per tile does everything), grouped (256-thread workgroups, hit shading
+    """The six schedules of the two ray passes -- fused (one wave per tile does everything), pool (persistent waves whose lanes are refilled with
+    pixel jobs while the wave's other rays still walk, round 5; twice, with different scheduling knobs), grouped (256-thread workgroups, hit shading
     regrouped through LDS), split (two launches: closest hit + misses | hit shading on records compacted across tiles), staged (ray
     streams) and quad (the fused kernels with four lanes per pixel) -- run the same functions on the same rays. Over free-running frames (validation and tracing frames, ragged extents):
 
@@ -588,14 +589,21 @@ def test_ray_pass_forms_agree(gpu, device, scene_name, W, H, with_cache):
     from kajiya_amd import frame
     scene = gpu.Scene(device, _scenes()[scene_name])
     pipes = {}
-    for form in ("grouped", "fused", "staged", "split", "quad"):
+    for form in ("grouped", "fused", "staged", "split", "quad", "pool", "pool-eager"):
         gp = gpu.GpuPipeline(device, scene, W, H, use_ircache=with_cache)
+        if form == "pool-eager":      # the pool form once more with other scheduling knobs: every block as soon as one lane wants it, tiles by counter
+            gp.set_ray_pass_form("pool")
+            gp.set_pool_tune(waves_per_simd=1, refill_min=1, shade_a_min=1, shade_b_min=1, dynamic_tiles=True)
+            if with_cache:
+                gp.ircache_set_deferred(True)
+            pipes[form] = gp
+            continue
         try:
             gp.set_ray_pass_form(form)
         except Exception:
             # the product library carries the fused form only; the others are compiled with -DKJ_RAY_PASS_EXPERIMENTS (make EXPERIMENTS=1;
             # the CPU stand-in of tests/hip_emu always builds them, so the CPU suite keeps holding them to the fused form)
-            assert form != "fused"
+            assert form not in ("fused", "pool")     # the product library carries these two
             continue
         if with_cache:
             gp.ircache_set_deferred(True)
@@ -613,9 +621,9 @@ def test_ray_pass_forms_agree(gpu, device, scene_name, W, H, with_cache):
             gp.frame(fc)
         torch.cuda.synchronize()
         ref = pipes["fused"]
-        if len(pipes) == 1:
-            pytest.skip("this build of the library carries the fused form of the ray passes only")
-        for form in ("grouped", "staged", "split", "quad"):
+        for form in ("grouped", "staged", "split", "quad", "pool", "pool-eager"):
+            if form not in pipes:
+                continue
             q = pipes[form]
             assert ref.ray_counts() == q.ray_counts(), (fi, form, ref.ray_counts(), q.ray_counts())
             for n in names:
