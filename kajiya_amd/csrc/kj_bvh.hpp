@@ -81,7 +81,7 @@ KJ_D bool intersect_tri(V3 o, V3 d, float tmin, float tmax, const float4 a, cons
 }
 
 // stack: LDS base for this lane; entries at stack[level * stride]
-struct TraverseStats { uint32_t nodes, tris; };
+struct TraverseStats { uint32_t nodes, tris; uint32_t wave_node_steps = 0, wave_tri_steps = 0; };   // wave_*: steps the WAVE issued (counted by one lane of it): lane utilisation of the walk = (nodes + tris) / (64 * steps)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 KJ_D float q8(uint32_t packed, int i) { return float((packed >> (8 * i)) & 0xffu); }   // v_cvt_f32_ubyte<i>
@@ -132,20 +132,38 @@ KJ_D void ray_begin(RayState& S, V3 o, V3 d, float tmin, float tmax, bool cull_b
 // so the LDS footprint (4 KB / wave) does not cap occupancy the way a bound-sized LDS stack did (11 KB / wave).
 #define KJ_PUSH(v_) { const uint32_t pv_ = (v_); if (S.sp < KJ_BVH_LDS_STACK) stack[S.sp * stride] = pv_; else spill[S.sp - KJ_BVH_LDS_STACK] = pv_; S.sp++; }
 // next reference off the stack
+// (KJ_POP_DS, round 5: the LDS part is read unconditionally and the rare deep entries from the spill copy afterwards. Selecting between an LDS and a private POINTER
+// made the load a flat_load -- generic address, counted on both memory counters -- in the middle of every step's dependent chain; this way it is a ds_read.)
+#ifndef KJ_POP_DS
+#define KJ_POP_DS 0      // measured on MI355X: the ds_read form is 4-5 % SLOWER on the rtdgi trace pass (0.290-0.295 against 0.275-0.281 ms at 1080p, 0.819 against 0.785 at 4K; profiles/r05_ray_pass_experiments.md)
+#endif
+#ifndef KJ_WALK_UNIFIED
+#define KJ_WALK_UNIFIED 0    // measured: 24 % fewer iterations per wave and the trace pass 18 % SLOWER (0.317 against 0.268 ms at 1080p, 0.938 against 0.790 at 4K): what these kernels pay for is issued instructions
+#endif
+#ifndef KJ_BVH_FOLD_INVD
+#define KJ_BVH_FOLD_INVD 0
+#endif
 KJ_D void pop_next(RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill) {
     if (S.sp == 0) { S.cur = KJ_BVH_NONE; return; }
     --S.sp;
+#if KJ_POP_DS && defined(__HIP_DEVICE_COMPILE__)
+    // (an explicit LDS pointer and a compiler barrier on the value: left to itself the optimiser merges the two loads back into one flat_load of a selected address)
+    uint32_t v = *((const __attribute__((address_space(3))) uint32_t*)stack + (S.sp < KJ_BVH_LDS_STACK ? S.sp : KJ_BVH_LDS_STACK - 1u) * stride);
+    asm volatile("" : "+v"(v));
+    if (S.sp >= KJ_BVH_LDS_STACK) v = spill[S.sp - KJ_BVH_LDS_STACK];
+    S.cur = v;
+#else
     S.cur = S.sp < KJ_BVH_LDS_STACK ? stack[S.sp * stride] : spill[S.sp - KJ_BVH_LDS_STACK];
+#endif
 }
 #define KJ_POP(dst_) pop_next(S, stack, stride, spill);
 // Visit the 4-wide node S.cur: test its four quantised child boxes, continue with the nearest hit child, push the others.
 KJ_D bool wants_node_step(const RayState& S) { return S.cur != KJ_BVH_NONE && !(S.cur & KJ_BVH_LEAF); }
 KJ_D bool wants_tri_step(const RayState& S) { return S.cur != KJ_BVH_NONE && (S.cur & KJ_BVH_LEAF); }
+// (node_step_data / tri_step_data: the step on a node / triangle whose 64 / 48 bytes are in registers already; node_step / tri_step fetch them first)
 template <bool ANY_HIT, bool STATS>
-KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
+KJ_D void node_step_data(RayState& S, const float4 n0, const uint4 ch, const uint4 qa, const uint2 qb, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
     const uint32_t NONE = KJ_BVH_NONE;
-    const float4* __restrict__ n = (const float4*)bvh.nodes + size_t(S.cur) * 4;
-    const float4 n0 = n[0]; const uint4 ch = *(const uint4*)(n + 1), qa = *(const uint4*)(n + 2); const uint2 qb = *(const uint2*)(n + 3);
     if (STATS) stats->nodes++;
     const V3 o = S.wo, inv_d = S.binv;
     const float tmin = S.tmin;
@@ -161,6 +179,31 @@ KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
     const uint32_t nqx = neg_x ? qa.w : qa.x, fqx = neg_x ? qa.x : qa.w;
     const uint32_t nqy = neg_y ? qb.x : qa.y, fqy = neg_y ? qa.y : qb.x;
     const uint32_t nqz = neg_z ? qb.y : qa.z, fqz = neg_z ? qa.z : qb.y;
+#if KJ_BVH_FOLD_INVD
+    // the reciprocal direction folded into the decode: t = fma(q, step / d, (origin - o) / d) -- six multiplies per node instead of one per plane (experiment, round 5)
+    const float sxi = sx * inv_d.x, syi = sy * inv_d.y, szi = sz * inv_d.z;
+    const float bx = (n0.x - o.x) * inv_d.x, by = (n0.y - o.y) * inv_d.y, bz = (n0.z - o.z) * inv_d.z;
+    uint32_t key[4];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const int i0 = pr * 2, i1 = pr * 2 + 1;
+        const f32x2 tnx = __builtin_elementwise_fma(f32x2{q8(nqx, i0), q8(nqx, i1)}, f32x2{sxi, sxi}, f32x2{bx, bx});
+        const f32x2 tny = __builtin_elementwise_fma(f32x2{q8(nqy, i0), q8(nqy, i1)}, f32x2{syi, syi}, f32x2{by, by});
+        const f32x2 tnz = __builtin_elementwise_fma(f32x2{q8(nqz, i0), q8(nqz, i1)}, f32x2{szi, szi}, f32x2{bz, bz});
+        const f32x2 tfx = __builtin_elementwise_fma(f32x2{q8(fqx, i0), q8(fqx, i1)}, f32x2{sxi, sxi}, f32x2{bx, bx});
+        const f32x2 tfy = __builtin_elementwise_fma(f32x2{q8(fqy, i0), q8(fqy, i1)}, f32x2{syi, syi}, f32x2{by, by});
+        const f32x2 tfz = __builtin_elementwise_fma(f32x2{q8(fqz, i0), q8(fqz, i1)}, f32x2{szi, szi}, f32x2{bz, bz});
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = pr * 2 + k;
+            const float tn = fmaxf(fmaxf(fmaxf(tnx[k], tny[k]), tnz[k]), tmin);
+            const float tf = fminf(fminf(fminf(tfx[k], tfy[k]), tfz[k]), tlimit);
+            const uint32_t c = i == 0 ? ch.x : (i == 1 ? ch.y : (i == 2 ? ch.z : ch.w));
+            const bool hit = (tn <= tf * 1.000001f + 1e-30f) && c != NONE;
+            key[i] = hit ? __float_as_uint(tn) : NONE;
+        }
+    }
+#else
     const float bx = n0.x - o.x, by = n0.y - o.y, bz = n0.z - o.z;
     const float fx = bx, fy = by, fz = bz;
     uint32_t key[4];
@@ -184,6 +227,7 @@ KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
             key[i] = hit ? __float_as_uint(tn) : NONE;   // tn >= tmin >= 0: float order == integer order
         }
     }
+#endif
     // Branch-free tail: (key, reference) pairs go through a 5-comparator network as selects and the three farther children are
     // stored to the LDS stack unconditionally, the stack pointer advancing only for hits (sorted order puts the hits first; a
     // non-hit's store is overwritten by the next push or ignored).
@@ -204,6 +248,21 @@ KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
         if (key[1] != NONE) KJ_PUSH(ref[1])
     }
     if (key[0] != NONE) S.cur = ref[0];
+    else KJ_POP(S.cur)
+}
+template <bool ANY_HIT, bool STATS>
+KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
+    const float4* __restrict__ n = (const float4*)bvh.nodes + size_t(S.cur) * 4;
+    const float4 n0 = n[0]; const uint4 ch = *(const uint4*)(n + 1), qa = *(const uint4*)(n + 2); const uint2 qb = *(const uint2*)(n + 3);
+    node_step_data<ANY_HIT, STATS>(S, n0, ch, qa, qb, stack, stride, spill, stats);
+}
+template <bool ANY_HIT, bool STATS>
+KJ_D void tri_step_data(RayState& S, const float4 a, const float4 b, const float4 c, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
+    const uint32_t first = S.cur & 0x0fffffffu, rest = (S.cur >> 28) & 7u;
+    if (STATS) stats->tris += 1u;
+    const bool hit = intersect_tri(S.wo, S.wd, S.tmin, S.tmax, a, b, c, first, S.cull_back, S.h);
+    if (ANY_HIT && hit) { S.cur = KJ_BVH_NONE; return; }
+    if (rest != 0u) S.cur = KJ_BVH_LEAF | ((rest - 1u) << 28) | (first + 1u);
     else KJ_POP(S.cur)
 }
 
@@ -261,14 +320,37 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
     RayState S;
     ray_begin<ANY_HIT>(S, o, d, tmin, tmax, cull_back);
     uint32_t spill[KJ_BVH_SPILL_STACK];
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && KJ_WALK_UNIFIED
+    // KJ_WALK_UNIFIED (round 5): every lane with a ray advances in EVERY iteration -- ONE fetch serves both kinds of lanes (a node's 64 bytes or a triangle's 48 from
+    // the lane's own address), then the node block runs for the lanes at a node and the triangle block for the lanes at a leaf. An iteration issues both blocks (when
+    // both kinds of lanes exist) but a wave needs max over its lanes of (nodes + triangles) iterations instead of the sum of the two votes' rounds: for launches that
+    // are a single round of waves bound by their dependent chain, not by issue. Per-ray results are unchanged (same steps in the same order for each ray).
+    uint32_t it_node = 0;
+    for (;;) {
+        const bool want_node = wants_node_step(S), want_tri = wants_tri_step(S);
+        if (__ballot(want_node | want_tri) == 0ull) break;
+        if (STATS) it_node++;
+        if (want_node | want_tri) {
+            const float4* __restrict__ p = want_node ? (const float4*)bvh.nodes + size_t(S.cur) * 4 : (const float4*)bvh.tris + size_t(S.cur & 0x0fffffffu) * 3;
+            const float4 d0 = p[0], d1 = p[1], d2 = p[2];
+            if (want_node) {
+                const uint2 qb = *(const uint2*)(p + 3);
+                node_step_data<ANY_HIT, STATS>(S, d0, make_uint4(__float_as_uint(d1.x), __float_as_uint(d1.y), __float_as_uint(d1.z), __float_as_uint(d1.w)),
+                                               make_uint4(__float_as_uint(d2.x), __float_as_uint(d2.y), __float_as_uint(d2.z), __float_as_uint(d2.w)), qb, stack, stride, spill, stats);
+            } else tri_step_data<ANY_HIT, STATS>(S, d0, d1, d2, stack, stride, spill, stats);
+        }
+    }
+    if (STATS && (__ffsll((long long)__ballot(true)) - 1) == int(__lane_id())) stats->wave_node_steps += it_node;
+#elif defined(__HIP_DEVICE_COMPILE__)
+    uint32_t it_node = 0, it_tri = 0;
     for (;;) {
         const bool want_node = wants_node_step(S), want_tri = wants_tri_step(S);
         const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
         if (nn + nt == 0u) break;
-        if (nt == 0u || (nn != 0u && nn >= nt * 2u)) { if (want_node) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
-        else { if (want_tri) tri_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
+        if (nt == 0u || (nn != 0u && nn >= nt * 2u)) { if (STATS) it_node++; if (want_node) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
+        else { if (STATS) it_tri++; if (want_tri) tri_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
     }
+    if (STATS && (__ffsll((long long)__ballot(true)) - 1) == int(__lane_id())) { stats->wave_node_steps += it_node; stats->wave_tri_steps += it_tri; }
 #else
     while (S.cur != KJ_BVH_NONE) {
         if (wants_node_step(S)) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);

@@ -269,6 +269,9 @@ KJ_D void add_traversal_stats(const TraceCtx& c, const TraverseStats& st_closest
         atomicAdd(&counter_slot(c.ray_counters)[3], (unsigned long long)st_closest.tris);
         atomicAdd(&counter_slot(c.ray_counters)[4], (unsigned long long)st_any.nodes);
         atomicAdd(&counter_slot(c.ray_counters)[5], (unsigned long long)st_any.tris);
+        // steps the waves issued (one lane of a wave holds its count): [6], [7] node / triangle steps of closest-hit walks, [8], [9] of occlusion walks
+        if (st_closest.wave_node_steps | st_closest.wave_tri_steps) { atomicAdd(&counter_slot(c.ray_counters)[6], (unsigned long long)st_closest.wave_node_steps); atomicAdd(&counter_slot(c.ray_counters)[7], (unsigned long long)st_closest.wave_tri_steps); }
+        if (st_any.wave_node_steps | st_any.wave_tri_steps) { atomicAdd(&counter_slot(c.ray_counters)[8], (unsigned long long)st_any.wave_node_steps); atomicAdd(&counter_slot(c.ray_counters)[9], (unsigned long long)st_any.wave_tri_steps); }
     }
 }
 template <bool STATS, bool QUAD = false>
@@ -471,6 +474,7 @@ __global__ void __launch_bounds__(64, KJ_POOL_WAVES) k_rtdgi_rays_pool(TraceCtx 
     uint32_t phase = KJ_PH_IDLE, pix = 0, rng = 0;
     uint32_t n_closest = 0, n_any = 0;      // wave-uniform ray counts, added to the device counters once
     TraverseStats st_closest{0, 0}, st_any{0, 0};
+    uint32_t it_node = 0, it_tri = 0, it_refill = 0, it_a = 0, it_b = 0, lanes_a = 0, lanes_b = 0;      // STATS: blocks this wave issued, lanes that worked in the shading blocks
     for (;;) {
         const bool walking = S.cur != NONE;
         const bool want_node = walking && !(S.cur & KJ_BVH_LEAF), want_tri = walking && (S.cur & KJ_BVH_LEAF) != 0u;
@@ -497,9 +501,10 @@ __global__ void __launch_bounds__(64, KJ_POOL_WAVES) k_rtdgi_rays_pool(TraceCtx 
 
         if (block == 3) {
             TraverseStats* st = phase == KJ_PH_CLOSEST ? &st_closest : &st_any;
-            if (nt == 0u || (nn != 0u && nn >= nt * 2u)) { if (want_node) node_step<false, STATS>(c.sc.bvh, S, stack, 64, spill, st); }
-            else { if (want_tri) tri_step_mixed<STATS>(c.sc.bvh, S, phase != KJ_PH_CLOSEST, stack, 64, spill, st); }
+            if (nt == 0u || (nn != 0u && nn >= nt * 2u)) { if (STATS) it_node++; if (want_node) node_step<false, STATS>(c.sc.bvh, S, stack, 64, spill, st); }
+            else { if (STATS) it_tri++; if (want_tri) tri_step_mixed<STATS>(c.sc.bvh, S, phase != KJ_PH_CLOSEST, stack, 64, spill, st); }
         } else if (block == 0) {
+            if (STATS) it_refill++;
             if (is_miss) {      // diffuse_trace_common.inc.hlsl:201-207: the sky
                 const int x = int(pix & 0xffffu), y = int(pix >> 16);
                 const V3 ray_d = S.wd;
@@ -575,6 +580,7 @@ __global__ void __launch_bounds__(64, KJ_POOL_WAVES) k_rtdgi_rays_pool(TraceCtx 
                 }
             }
         } else if (block == 1) {
+            if (STATS) { it_a++; lanes_a += n_a; }
             bool sun_ray = false;
             if (wait_a) {       // rt/gbuffer.rchit.hlsl + diffuse_trace_common.inc.hlsl:80-130 up to the sun's shadow ray
                 const int x = int(pix & 0xffffu), y = int(pix >> 16);
@@ -597,6 +603,7 @@ __global__ void __launch_bounds__(64, KJ_POOL_WAVES) k_rtdgi_rays_pool(TraceCtx 
             }
             n_any += uint32_t(__popcll(__ballot(sun_ray)));
         } else {
+            if (STATS) { it_b++; lanes_b += n_b; }
             if (wait_b) {       // the rest of diffuse_trace_common.inc.hlsl:80-200 with the shadow ray's answer, then the pass' stores
                 const int x = int(pix & 0xffffu), y = int(pix >> 16);
                 const bool sun_is_shadowed = S.h.slot != 0xffffffffu;
@@ -619,6 +626,12 @@ __global__ void __launch_bounds__(64, KJ_POOL_WAVES) k_rtdgi_rays_pool(TraceCtx 
     if (lane == 0u) {
         if (n_closest) atomicAdd(&counter_slot(c.ray_counters)[0], (unsigned long long)n_closest);
         if (n_any) atomicAdd(&counter_slot(c.ray_counters)[1], (unsigned long long)n_any);
+        if (STATS) {    // [6], [7]: node / triangle steps this wave issued (closest-hit and occlusion rays walk together here); [10..14]: refill / shade A / shade B blocks, lanes in A, lanes in B
+            atomicAdd(&counter_slot(c.ray_counters)[6], (unsigned long long)it_node); atomicAdd(&counter_slot(c.ray_counters)[7], (unsigned long long)it_tri);
+            atomicAdd(&counter_slot(c.ray_counters)[10], (unsigned long long)it_refill); atomicAdd(&counter_slot(c.ray_counters)[11], (unsigned long long)it_a);
+            atomicAdd(&counter_slot(c.ray_counters)[12], (unsigned long long)it_b); atomicAdd(&counter_slot(c.ray_counters)[13], (unsigned long long)lanes_a);
+            atomicAdd(&counter_slot(c.ray_counters)[14], (unsigned long long)lanes_b);
+        }
     }
     add_traversal_stats<STATS>(c, st_closest, st_any);
 }
@@ -929,7 +942,7 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     if (const char* v = getenv("KJ_RTDGI_POOL")) r->pool_rays = atoi(v) != 0;      // A/B runs of bench.py: the pool form of the ray passes on / off
     if (const char* v = getenv("KJ_RTDGI_POOL_TUNE")) {                             // "waves,refill,shade_a,shade_b,dynamic"
         unsigned w = 0, f = 0, a = 0, b = 0, d = 0;
-        if (sscanf(v, "%u,%u,%u,%u,%u", &w, &f, &a, &b, &d) == 5 && w >= 1 && w <= KJ_POOL_WAVES && f >= 1 && f <= 64 && a >= 1 && a <= 64 && b >= 1 && b <= 64) {
+        if (sscanf(v, "%u,%u,%u,%u,%u", &w, &f, &a, &b, &d) == 5 && w <= KJ_POOL_WAVES && f >= 1 && f <= 64 && a >= 1 && a <= 64 && b >= 1 && b <= 64) {
             r->pool_waves_per_simd = w; r->pool_refill_min = f; r->pool_shade_a_min = a; r->pool_shade_b_min = b; r->pool_dynamic_tiles = d ? 1u : 0u;
         } else fprintf(stderr, "kajiya_amd: KJ_RTDGI_POOL_TUNE=%s ignored (want \"waves,refill,shade_a,shade_b,dynamic\")\n", v);
     }
@@ -1067,7 +1080,8 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     pa.refill_min = std::max(1u, std::min(64u, r->pool_refill_min)); pa.shade_a_min = std::max(1u, std::min(64u, r->pool_shade_a_min)); pa.shade_b_min = std::max(1u, std::min(64u, r->pool_shade_b_min));
     const bool pool = r->pool_rays;
     const size_t pool_lds = pool_lds_bytes(tc.sc.bvh.stack_entries);
-    const uint32_t pool_grid = std::max(1u, std::min(uint32_t(gh.x * gh.y), uint32_t(r->dev->num_cus) * 4u * std::max(1u, std::min(uint32_t(KJ_POOL_WAVES), r->pool_waves_per_simd))));
+    // waves_per_simd = 0: one wave per tile (no persistence: the pool only interleaves a tile's own closest-hit and shadow walks)
+    const uint32_t pool_grid = r->pool_waves_per_simd == 0u ? uint32_t(gh.x * gh.y) : std::max(1u, std::min(uint32_t(gh.x * gh.y), uint32_t(r->dev->num_cus) * 4u * std::min(uint32_t(KJ_POOL_WAVES), r->pool_waves_per_simd)));
     if (pool && r->pool_dynamic_tiles) {
         if (!r->pool_tile_counters.p) KJ_TRY_HIP(r->pool_tile_counters.alloc(8));
         KJ_TRY_HIP(hipMemsetAsync(r->pool_tile_counters.p, 0, 8, s));
@@ -1372,7 +1386,7 @@ KjStatus kj_rtdgi_set_ray_pass_form(KjRtdgi* r, uint32_t form) {
 }
 KjStatus kj_rtdgi_set_pool_tune(KjRtdgi* r, uint32_t waves_per_simd, uint32_t refill_min, uint32_t shade_a_min, uint32_t shade_b_min, uint32_t dynamic_tiles) {
     KJ_REQUIRE(r, "null argument");
-    KJ_REQUIRE(waves_per_simd >= 1 && waves_per_simd <= KJ_POOL_WAVES, "waves_per_simd out of range (1 .. the kernel's compiled occupancy)");
+    KJ_REQUIRE(waves_per_simd <= KJ_POOL_WAVES, "waves_per_simd out of range (0 = one wave per tile, else 1 .. the kernel's compiled occupancy)");
     KJ_REQUIRE(refill_min >= 1 && refill_min <= 64 && shade_a_min >= 1 && shade_a_min <= 64 && shade_b_min >= 1 && shade_b_min <= 64, "thresholds are lane counts (1 .. 64)");
     r->pool_waves_per_simd = waves_per_simd; r->pool_refill_min = refill_min; r->pool_shade_a_min = shade_a_min; r->pool_shade_b_min = shade_b_min; r->pool_dynamic_tiles = dynamic_tiles ? 1u : 0u;
     return KJ_OK;

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--tile-waves", action="store_true", help="only the one-wave-per-tile launches of the pool form (waves_per_simd = 0): thresholds of the two shading blocks")
     args = ap.parse_args()
     import torch
     from kajiya_amd import lib
@@ -74,7 +75,9 @@ def main():
     gp.set_ray_pass_form("fused")
     results.append(measure("fused"))
     gp.set_ray_pass_form("pool")
-    if args.quick:
+    if args.tile_waves:
+        grid = [(0, 64, a, b, 0) for a, b in ((64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (1, 1), (16, 64), (64, 16), (8, 32), (32, 8))]
+    elif args.quick:
         grid = [(3, 16, 16, 16, 0), (2, 16, 16, 16, 0), (4, 16, 16, 16, 0), (3, 8, 16, 16, 0), (3, 24, 24, 24, 0), (3, 16, 16, 16, 1)]
     else:
         grid = []
