@@ -437,7 +437,17 @@ KjStatus kj_ircache_set_deferred_updates(KjIrcache* ircache, uint32_t enable);
  * with the next pass"), i.e. without barriers: on a GPU they overlap as far as the hardware lets them. enable = 0 (default): three launches one after the other,
  * the schedule the sequential oracle models. enable = 1: one launch carrying the three passes side by side -- the cache's segment of the frame 0.40 -> 0.21 ms on
  * MI355X at 1080p, and the racy cache's distance from the sequential oracle on identical state 1.3e-2 -> 5e-2 .. 1.3e-1 of its SH sums. Ignored in the deterministic mode. */
-KjStatus kj_ircache_set_ray_passes_side_by_side(KjIrcache* ircache, uint32_t enable);
+KjStatus kj_ircache_set_ray_passes_side_by_side(KjIrcache* ircache, uint32_t enable);      /* = kj_ircache_set_ray_pass_schedule(enable ? KJ_IRC_PASSES_SIDE_BY_SIDE : KJ_IRC_PASSES_SEQUENTIAL) */
+/* The schedule of the three ray passes, in full (round 5):
+ *   KJ_IRC_PASSES_CHAIN (default): ONE launch in which every aux slot still sees its own passes in recording order -- accessibility, validation, the new sample --
+ *     while the three rays of a slot walk side by side (validation's and the new sample's path on two quads of the same wave; the slot's values go from one to the
+ *     other through lane shuffles, as the packed values the sequential passes would have stored). Own-slot results are those of three launches; what a pass sees of
+ *     OTHER entries (the lookups' reads) is unordered in the racy mode, as it is inside a pass, and in the deterministic mode it is the snapshot taken before the
+ *     XX
+ *   KJ_IRC_PASSES_SEQUENTIAL: three launches one after the other (rounds 1-4), a snapshot between validation and tracing in the deterministic mode.
+ *   KJ_IRC_PASSES_SIDE_BY_SIDE: one launch, the passes racing on their shared slots (racy mode only; the deterministic mode runs the chain instead). */
+enum { KJ_IRC_PASSES_SEQUENTIAL = 0, KJ_IRC_PASSES_SIDE_BY_SIDE = 1, KJ_IRC_PASSES_CHAIN = 2 };
+KjStatus kj_ircache_set_ray_pass_schedule(KjIrcache* ircache, uint32_t schedule);
 KjStatus kj_ircache_begin_requests(KjIrcache* ircache, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, void* stream);
 /* For a caller whose per-pixel passes run on half-res rows [half_row_begin, half_row_end) only (a rank of the screen-tile split): clears those rows' slots and the
  * cache's own two ranges instead of the whole slot array (150 MB at 4K, 280 MB with reflections). Lookups recorded outside the rows would survive into next frame. */

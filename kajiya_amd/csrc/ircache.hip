@@ -154,6 +154,10 @@ struct IrcTraceCtx {
 };
 // one count per path: in the QUAD form the four lanes of a path run the same code, lane 0 counts
 template <bool QUAD> KJ_D void irc_count_path_rays(unsigned long long* counters, int which) {
+#if !defined(__HIP_DEVICE_COMPILE__)      // the tests' CPU stand-in for HIP has no votes in divergent code: one atomic per path
+    if (!QUAD || (threadIdx.x & 3u) == 0u) atomicAdd(&counter_slot(counters)[which], 1ull);
+    return;
+#endif
     const unsigned long long m = __ballot(true) & (QUAD ? 0x1111111111111111ull : ~0ull);
     if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
 }
@@ -370,6 +374,171 @@ __global__ void __launch_bounds__(64) k_irc_ray_passes(IrcTraceCtx c, uint32_t b
     else if (pass == 1u) irc_trace_irradiance_blocks<QUAD>(c, lds_stack, block, blocks_per_pass);
     else irc_trace_accessibility_blocks<QUAD>(c, lds_stack, block, blocks_per_pass);
 }
+// ---- the CHAIN schedule of the three ray passes (round 5; the default with four lanes per path): ONE launch in which every aux slot still sees its own passes in the
+// reference's recording order -- accessibility, then validation, then the new sample (ircache.rs:396-481) -- while the RAYS of the three run side by side.
+// The passes of one frame meet on the same slots: validation and tracing both work on the four octahedral cells irc_sample_params() picks for the frame (same formula,
+// same count), accessibility on all sixteen. Per slot the dependency is only in the arithmetic at the END of each pass (the reservoir's M after accessibility feeds
+// validation's clamp; validation's reservoir and radiance feed the new sample's merge); the three rays themselves depend on nothing the others write. So:
+//   * a CHAIN item = one (entry, sample) = one slot, on EIGHT lanes: quad A walks the accessibility ray, then validation's path (closest hit + shadow rays + lookup);
+//     quad B walks the new sample's path at the same time (same instruction stream, its own arguments); A's results go to B through lane shuffles -- as the packed
+//     values the sequential passes would have stored and re-read -- and B merges and stores. A's own stores would be overwritten by B's: they are not made.
+//   * the twelve slots of an entry that neither validation nor tracing touch this frame get their accessibility ray from a plain quad (second block range).
+// Own-slot results are those of the three launches. What differs is what a pass sees of OTHER entries while it runs (the lookups' reads of contributions and, in the
+// racy mode, their atomics): with the three launches tracing's lookups see every validation update of the frame; here they see whichever have happened. The racy
+// mode races on these inside a pass anyway; the deterministic mode defines them: lookups of validation AND tracing read the snapshot taken before the launch (one
+// snapshot instead of two; oracle: okj_ircache_set_chain_schedule). The launch is as long as its longest path chain instead of the sum of three.
+KJ_D uint32_t irc_octa_swizzle(uint32_t xy) { return xy ^ ((xy & 4u) >> 2u); }       // irc_sample_params()'s cell order
+KJ_D void irc_count_quads(unsigned long long* counters, int which, bool active) {     // one count per active quad; called in wave-uniform control flow
+#if !defined(__HIP_DEVICE_COMPILE__)      // the tests' CPU stand-in for HIP: its lanes are not in lockstep after a divergent section, a vote here would mix call sites
+    if (active && (threadIdx.x & 3u) == 0u) atomicAdd(&counter_slot(counters)[which], 1ull);
+    return;
+#endif
+    const unsigned long long m = __ballot(active) & 0x1111111111111111ull;
+    if (m != 0ull && (__ffsll((long long)m) - 1) == int(__lane_id())) atomicAdd(&counter_slot(counters)[which], (unsigned long long)__popcll(m));
+}
+KJ_D void irc_chain_blocks(const IrcTraceCtx& c, uint32_t* lds_stack, uint32_t block, uint32_t nblocks) {
+    const IrcacheView& ic = c.ic;
+    const FrameConstants& fc = *c.fc;
+    const uint32_t octet = threadIdx.x >> 3, half = (threadIdx.x >> 2) & 1u;
+    const bool lead = (threadIdx.x & 3u) == 0u;
+    const int a_lead_lane = int(threadIdx.x & ~7u);
+    uint32_t* const stack = lds_stack + (threadIdx.x >> 2);
+    const uint32_t stride = 16u;
+    const uint32_t n_items = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME;
+    static_assert(IRC_SAMPLES_PER_FRAME == IRC_VALIDATION_SAMPLES_PER_FRAME, "validation and tracing work on the same slots of a frame");
+#if !defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t emu_mail[8][8];
+    __shared__ uint32_t emu_read[8];
+    if (int(threadIdx.x) == a_lead_lane) { emu_mail[octet][6] = 0u; emu_read[octet] = 0u; }
+    __syncthreads();
+#endif
+    for (uint32_t base = block * 8u; base < n_items; base += nblocks * 8u) {       // wave-uniform trip count
+        const uint32_t d = base + octet;
+        const bool item = d < n_items;
+        const uint32_t entry_idx = item ? ic.entry_indirection[d / IRC_SAMPLES_PER_FRAME] : 0u;
+        const uint32_t sample_idx = d % IRC_SAMPLES_PER_FRAME;
+        const uint32_t life = ic.life[entry_idx];
+        const float4 packed_entry = ic.spatial[entry_idx];
+        const IrcVertex entry = irc_unpack_vertex(packed_entry);
+        const uint32_t sp = irc_sample_params(IRC_SAMPLES_PER_FRAME, entry_idx, sample_idx, fc.frame_index);
+        const size_t output_idx = size_t(entry_idx) * IRC_AUX_STRIDE + (sp % IRC_OCTA_DIMS2);
+        const float4 r0 = ic.aux[output_idx];
+        uint2 raw = make_uint2(asuint(r0.x), asuint(r0.y));
+        float4 value = ic.aux[output_idx + IRC_OCTA_DIMS2];
+        const IrcVertex prev_entry = irc_unpack_vertex(ic.aux[output_idx + IRC_OCTA_DIMS2 * 2]);
+        // ---- quad A: trace_accessibility.rgen.hlsl:21-66 on this slot
+        const bool acc = item && half == 0u && irc_life_valid(life);
+        irc_count_quads(c.ray_counters, 1, acc);
+        const bool blocked = rt_is_shadowed_quad(c.sc, acc, entry.position, prev_entry.position - entry.position, 0.001f, 0.999f, stack, stride);
+        if (acc && blocked) { Reservoir1spp r = Reservoir1spp::from_raw(raw); r.M *= 0.8f; raw = r.as_raw(); }
+        // ---- both quads: one path each (ircache_trace_common.inc.hlsl) -- A re-traces the slot's stored sample from where it was taken, B the frame's new sample
+        Reservoir1spp rv = Reservoir1spp::from_raw(raw);
+        const bool validate = item && half == 0u && rv.M > 0;
+        const bool active = item && (half == 1u || validate);
+        IrcTraceResult traced;
+        traced.incident_radiance = traced.direction = traced.hit_pos = v3(0.0f);
+        if (active)
+            traced = half == 0u ? ircache_trace<true>(c, prev_entry, rv.payload, life, stack, stride, c.request_slot_base + d, (3u << 28) | d)
+                                : ircache_trace<true>(c, entry, sp, life, stack, stride, c.request_slot_base + KjIrcache::REQ_E + d, (4u << 28) | d);
+        // ---- quad A: ircache_validate.rgen.hlsl:96-128
+        if (validate) {
+            const V3 b{value.x * fc.pre_exposure_delta, value.y * fc.pre_exposure_delta, value.z * fc.pre_exposure_delta};
+            const float limiter = lerp(0.5f, 1.0f, smoothstep(-0.1f, 0.0f, dot(traced.direction, prev_entry.normal)));
+            const V3 a = traced.incident_radiance * limiter;
+            const V3 dist3 = vabs(a - b) / (a + b);
+            const float dist = fmaxf(dist3.x, fmaxf(dist3.y, dist3.z));
+            const float invalidity = smoothstep(0.1f, 0.5f, dist);
+            rv.M = fmaxf(0.0f, fminf(rv.M, exp2f(log2f(float(IRC_RESTIR_M_CLAMP)) * (1.0f - invalidity))));
+            raw = rv.as_raw();
+            value = make_float4(a.x, a.y, a.z, value.w);
+        }
+        // ---- A -> B: the slot as the sequential passes would have left it in memory (packed reservoir, radiance)
+#if defined(__HIP_DEVICE_COMPILE__)
+        raw.x = __shfl(raw.x, a_lead_lane); raw.y = __shfl(raw.y, a_lead_lane);
+        value.x = __shfl(value.x, a_lead_lane); value.y = __shfl(value.y, a_lead_lane); value.z = __shfl(value.z, a_lead_lane); value.w = __shfl(value.w, a_lead_lane);
+#else
+        {   // the tests' CPU stand-in for HIP runs lanes as fibers that are NOT in lockstep after a divergent section: hand the values over through a mailbox with a
+            // sequence number; the poster waits until the previous item's eight readers are through
+            const uint32_t seq = base / (nblocks * 8u) + 1u;
+            if (int(threadIdx.x) == a_lead_lane) {
+                while (emu_read[octet] != 8u * (seq - 1u)) __syncthreads();
+                emu_mail[octet][0] = raw.x; emu_mail[octet][1] = raw.y; emu_mail[octet][2] = asuint(value.x); emu_mail[octet][3] = asuint(value.y); emu_mail[octet][4] = asuint(value.z); emu_mail[octet][5] = asuint(value.w);
+                emu_mail[octet][6] = seq;
+            }
+            while (emu_mail[octet][6] != seq) __syncthreads();
+            raw.x = emu_mail[octet][0]; raw.y = emu_mail[octet][1]; value = make_float4(asfloat(emu_mail[octet][2]), asfloat(emu_mail[octet][3]), asfloat(emu_mail[octet][4]), asfloat(emu_mail[octet][5]));
+            emu_read[octet] += 1u;
+        }
+#endif
+        // ---- quad B: trace_irradiance.rgen.hlsl:75-143
+        if (item && half == 1u) {
+            uint32_t rng = hash1(hash1(entry_idx) + fc.frame_index);
+            const float limiter = lerp(0.5f, 1.0f, smoothstep(-0.1f, 0.0f, dot(traced.direction, entry.normal)));
+            const V3 new_value = traced.incident_radiance * limiter;
+            StreamState stream_state{0, 0};
+            Reservoir1spp reservoir = Reservoir1spp::create();
+            reservoir.init_with_stream(sRGB_to_luminance(new_value), 1.0f, stream_state, sp);
+            const V3 prev_value{value.x * fc.pre_exposure_delta, value.y * fc.pre_exposure_delta, value.z * fc.pre_exposure_delta};
+            V3 val_sel = new_value;
+            bool selected_new = true;
+            {
+                Reservoir1spp r = Reservoir1spp::from_raw(raw);
+                if (r.M > 0) {
+                    r.M = fminf(r.M, 30.0f);
+                    if (reservoir.update_with_stream(r, sRGB_to_luminance(prev_value), 1.0f, stream_state, r.payload, rng)) {
+                        val_sel = prev_value;
+                        selected_new = false;
+                    }
+                }
+            }
+            reservoir.finish_stream(stream_state);
+            if (lead) {
+                const uint2 out_raw = reservoir.as_raw();
+                float2* dst = (float2*)&ic.aux[output_idx];
+                *dst = make_float2(asfloat(out_raw.x), asfloat(out_raw.y));
+                ic.aux[output_idx + IRC_OCTA_DIMS2] = make_float4(val_sel.x, val_sel.y, val_sel.z, reservoir.W);
+                if (selected_new) ic.aux[output_idx + IRC_OCTA_DIMS2 * 2] = packed_entry;
+            }
+        }
+    }
+}
+// accessibility rays of the slots the frame's validation / tracing do not touch: twelve per entry, one quad each
+KJ_D void irc_accessibility_rest_blocks(const IrcTraceCtx& c, uint32_t* lds_stack, uint32_t block, uint32_t nblocks) {
+    const IrcacheView& ic = c.ic;
+    const uint32_t quad = threadIdx.x >> 2;
+    const bool lead = (threadIdx.x & 3u) == 0u;
+    uint32_t* const stack = lds_stack + quad;
+    const uint32_t period = IRC_OCTA_DIMS2 / IRC_SAMPLES_PER_FRAME, rest = period - 1u;       // 4 cells per sample group, 3 of them untouched
+    const uint32_t per_entry = IRC_SAMPLES_PER_FRAME * rest;
+    const uint32_t n_items = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * per_entry;
+    const uint32_t phase = c.fc->frame_index % period;
+    for (uint32_t base = block * 16u; base < n_items; base += nblocks * 16u) {
+        const uint32_t d = base + quad;
+        const bool item = d < n_items;
+        const uint32_t entry_idx = item ? ic.entry_indirection[d / per_entry] : 0u;
+        const uint32_t j = d % per_entry;
+        const uint32_t octa_idx = irc_octa_swizzle((j / rest) * period + (phase + 1u + j % rest) % period);
+        const bool acc = item && irc_life_valid(ic.life[entry_idx]);
+        const IrcVertex entry = irc_unpack_vertex(ic.spatial[entry_idx]);
+        const size_t output_idx = size_t(entry_idx) * IRC_AUX_STRIDE + octa_idx;
+        const float4 r0 = ic.aux[output_idx];
+        Reservoir1spp r = Reservoir1spp::from_raw(make_uint2(asuint(r0.x), asuint(r0.y)));
+        const IrcVertex prev_entry = irc_unpack_vertex(ic.aux[output_idx + IRC_OCTA_DIMS2 * 2]);
+        irc_count_quads(c.ray_counters, 1, acc);
+        const bool blocked = rt_is_shadowed_quad(c.sc, acc, entry.position, prev_entry.position - entry.position, 0.001f, 0.999f, stack, 16u);
+        if (acc && blocked && lead) {
+            r.M *= 0.8f;
+            const uint2 raw = r.as_raw();
+            float2* dst = (float2*)&ic.aux[output_idx];
+            *dst = make_float2(asfloat(raw.x), asfloat(raw.y));
+        }
+    }
+}
+__global__ void __launch_bounds__(64) k_irc_ray_chain(IrcTraceCtx c, uint32_t chain_blocks) {
+    extern __shared__ uint32_t lds_stack[];
+    if (blockIdx.x < chain_blocks) irc_chain_blocks(c, lds_stack, blockIdx.x, chain_blocks);
+    else irc_accessibility_rest_blocks(c, lds_stack, blockIdx.x - chain_blocks, gridDim.x - chain_blocks);
+}
 // sum_up_irradiance.hlsl:34-89 — 16 lanes per entry (one per octahedral cell), shuffle-reduced
 __global__ void __launch_bounds__(64) k_irc_sum_up(const FrameConstants* __restrict__ fcp, IrcacheView ic) {
     const uint32_t alloc_count = ic.meta[IRC_META_TRACING_ALLOC_COUNT];
@@ -567,7 +736,8 @@ KjStatus kj_ircache_create(KjDevice* dev, KjIrcache** out) {
     KJ_REQUIRE(dev && out, "null argument");
     KjIrcache* c = new KjIrcache();
     c->dev = dev;
-    c->ray_passes_side_by_side = getenv("KJ_IRC_SIDE_BY_SIDE") && atoi(getenv("KJ_IRC_SIDE_BY_SIDE")) != 0;
+    if (getenv("KJ_IRC_SIDE_BY_SIDE") && atoi(getenv("KJ_IRC_SIDE_BY_SIDE")) != 0) c->ray_pass_schedule = KJ_IRC_PASSES_SIDE_BY_SIDE;
+    if (const char* v = getenv("KJ_IRC_SCHEDULE")) { const int k = atoi(v); if (k >= 0 && k <= 2) c->ray_pass_schedule = uint32_t(k); }      // A/B runs
     hipError_t e = hipSuccess;
     auto A = [&](kj::DevBuf& b, size_t n) { if (e == hipSuccess) e = b.alloc(n); };
     A(c->meta, 32); A(c->grid_meta[0], size_t(IRC_MAX_GRID_CELLS) * 8); A(c->grid_meta[1], size_t(IRC_MAX_GRID_CELLS) * 8);
@@ -700,7 +870,19 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     // recording lets them run. Measured on MI355X (round 4, profiles/r04_ab_runs.md): the cache's segment 0.40 -> 0.21 ms at 1080p, the PIPELINED
     // frame unchanged (it is VALU-bound, not waiting for this chain), and the SH sums on identical state move from 1.3e-2 to 5e-2 .. 1.3e-1 of the
     // sequential oracle's (tests/test_gpu_ircache.py; bar 5e-2) -- so it is not the default.
-    if (!c->deferred && c->ray_passes_side_by_side) {
+    // the chain (default): one launch, own-slot order kept (k_irc_ray_chain). Needs the four-lanes-per-path form; a partitioned measurement run takes the three launches
+    if (quad && tc.part_count == 1u && (c->ray_pass_schedule == KJ_IRC_PASSES_CHAIN || (c->deferred && c->ray_pass_schedule == KJ_IRC_PASSES_SIDE_BY_SIDE))) {
+        if (c->deferred) {   // what validation's and tracing's lookups read of other entries: the state before the launch
+            if (c->aux_snapshot.bytes != c->aux.bytes) KJ_TRY_HIP(c->aux_snapshot.alloc(c->aux.bytes, s));
+            tc.ic.aux_read = (const float4*)c->aux_snapshot.p;
+            hipLaunchKernelGGL(k_irc_snapshot_aux, dim3(c->dev->num_cus * 4), dim3(256), 0, s, (const uint32_t*)c->meta.p, (const float4*)c->aux.p, (float4*)c->aux_snapshot.p);
+        }
+        hipLaunchKernelGGL(k_irc_ray_chain, dim3(grid * 2u), dim3(64), lds_rays, s, tc, grid);
+        KJ_CHECK_LAUNCH();
+        c->pending_irradiance_sum = true;
+        return KJ_OK;
+    }
+    if (!c->deferred && c->ray_pass_schedule == KJ_IRC_PASSES_SIDE_BY_SIDE) {
         hipLaunchKernelGGL(quad ? k_irc_ray_passes<true> : k_irc_ray_passes<false>, dim3(grid * 3u), dim3(64), lds_rays, s, tc, grid);
         KJ_CHECK_LAUNCH();
         c->pending_irradiance_sum = true;
@@ -732,7 +914,8 @@ KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream_) 
 }
 // ---- deferred updates: begin (clear the frame's slots), collect (compact a slot range into a list), apply (replay a merged list)
 KjStatus kj_ircache_set_deferred_updates(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->deferred = enable != 0; return KJ_OK; }
-KjStatus kj_ircache_set_ray_passes_side_by_side(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->ray_passes_side_by_side = enable != 0; return KJ_OK; }
+KjStatus kj_ircache_set_ray_passes_side_by_side(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->ray_pass_schedule = enable ? KJ_IRC_PASSES_SIDE_BY_SIDE : KJ_IRC_PASSES_SEQUENTIAL; return KJ_OK; }
+KjStatus kj_ircache_set_ray_pass_schedule(KjIrcache* c, uint32_t schedule) { KJ_REQUIRE(c && schedule <= KJ_IRC_PASSES_CHAIN, "null argument / unknown schedule"); c->ray_pass_schedule = schedule; return KJ_OK; }
 KjStatus kj_ircache_set_rtr_requests(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->rtr_requests = enable != 0; return KJ_OK; }
 KjStatus kj_ircache_begin_requests(KjIrcache* c, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, void* stream_) {
     return kj_ircache_begin_requests_rows(c, rtdgi_half_width, rtdgi_half_height, 0u, rtdgi_half_height, stream_);

@@ -18,7 +18,7 @@ struct KjIrcache {
     //   [0, HB) rtdgi validate | [HB, 2 HB) rtdgi trace | [2 HB, 2 HB + E) the cache's validate rays | [2 HB + E, 2 HB + 2 E) its trace rays
     // and, when the frame has reflections (kj_ircache_set_rtr_requests), two more behind them: [.., + HB) rtr validate | [.., + HB) rtr trace
     bool deferred = false;
-    bool ray_passes_side_by_side = false;     // kj_ircache_set_ray_passes_side_by_side (default: env KJ_IRC_SIDE_BY_SIDE at creation, else off)
+    uint32_t ray_pass_schedule = 2;           // KJ_IRC_PASSES_*: kj_ircache_set_ray_pass_schedule (default: the chain; env KJ_IRC_SCHEDULE / KJ_IRC_SIDE_BY_SIDE at creation)
     bool rtr_requests = false;
     bool requests_begun = false;        // kj_ircache_begin_requests ran for the frame kj_ircache_prepare is about to open (deferred mode)
     uint32_t req_half_pixels = 0;       // HB of the current frame

@@ -25,7 +25,7 @@ EXPORTS = [
     "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_reproject_rows", "kj_rtdgi_render",
     "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_set_ray_pass_form", "kj_rtdgi_set_pool_tune", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
-    "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts", "kj_ircache_set_deferred_updates", "kj_ircache_set_ray_passes_side_by_side", "kj_ircache_begin_requests", "kj_ircache_begin_requests_rows", "kj_ircache_request_ranges", "kj_ircache_collect_requests", "kj_ircache_apply_requests", "kj_ircache_set_rtr_requests", "kj_ircache_rtr_request_ranges",
+    "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts", "kj_ircache_set_deferred_updates", "kj_ircache_set_ray_passes_side_by_side", "kj_ircache_set_ray_pass_schedule", "kj_ircache_begin_requests", "kj_ircache_begin_requests_rows", "kj_ircache_request_ranges", "kj_ircache_collect_requests", "kj_ircache_apply_requests", "kj_ircache_set_rtr_requests", "kj_ircache_rtr_request_ranges",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
     "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_render_rows", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_trace_sun_shadow_mask_rows", "kj_light_gbuffer", "kj_light_gbuffer_rows",
     "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_render_rows", "kj_shadow_denoise_surface",
@@ -77,7 +77,7 @@ def load():
         "kj_trace_any": [vp, vp, vp, u32, vp],
         "kj_debug_calibration_copy": [vp, vp, C.c_uint64, vp],
         "kj_scene_last_commit_ms": [vp, C.POINTER(C.c_double)],
-        "kj_ircache_set_deferred_updates": [vp, u32], "kj_ircache_set_ray_passes_side_by_side": [vp, u32],
+        "kj_ircache_set_deferred_updates": [vp, u32], "kj_ircache_set_ray_passes_side_by_side": [vp, u32], "kj_ircache_set_ray_pass_schedule": [vp, u32],
         "kj_ircache_begin_requests": [vp, u32, u32, vp],
         "kj_ircache_begin_requests_rows": [vp, u32, u32, u32, u32, vp],
         "kj_ircache_request_ranges": [vp, C.POINTER(u32), C.POINTER(u32)],
@@ -503,6 +503,12 @@ class GpuPipeline:
     def ircache_set_deferred(self, enable=True):
         check(self.L.kj_ircache_set_deferred_updates(self.ircache, int(enable)))
         self.ircache_deferred = bool(enable)
+
+    IRC_PASS_SCHEDULES = {"sequential": 0, "side_by_side": 1, "chain": 2}
+
+    def ircache_set_ray_pass_schedule(self, schedule):
+        """How the cache's three ray passes are scheduled (include/kajiya_amd.h: KJ_IRC_PASSES_*); "chain" is the default."""
+        check(self.L.kj_ircache_set_ray_pass_schedule(self.ircache, self.IRC_PASS_SCHEDULES[schedule]))
 
     def ircache_begin_requests(self, half_rows=None):
         """`half_rows`: (begin, end) -- this pipeline's per-pixel passes only run on those half-res rows (a rank of the split): only their slots are cleared."""

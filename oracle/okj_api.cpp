@@ -272,6 +272,7 @@ void okj_rtdgi_ray_counts(void* p, uint64_t* closest, uint64_t* any) {
 struct OkjIrcache {
     Ircache ic;
     std::vector<h4> brdf_lut;
+    bool chain_schedule = true;      // okj_ircache_set_chain_schedule: the deterministic mode under the product's default schedule of the three ray passes (include/kajiya_amd.h: KJ_IRC_PASSES_CHAIN)
 };
 void* okj_ircache_create(const void* brdf_fg_lut) {
     OkjIrcache* o = new OkjIrcache();
@@ -297,12 +298,15 @@ void okj_ircache_trace_irradiance(void* p, const KjFrameConstants* fc, void* sce
     o->ic.read_aux_snapshot = o->ic.deferred;
     if (o->ic.deferred) o->ic.snapshot_aux();
     IrcacheTracer::validate(o->ic, *fc, in, sun_color);
-    if (o->ic.deferred) o->ic.snapshot_aux();
+    // the product's default schedule (KJ_IRC_PASSES_CHAIN: one launch, every slot's own passes in order, the three rays side by side) defines what tracing's lookups read
+    // of OTHER entries as the state before the launch -- the snapshot above (accessibility does not touch what lookups read); the three-launch schedule refreshes it here
+    if (o->ic.deferred && !o->chain_schedule) o->ic.snapshot_aux();
     IrcacheTracer::trace_irradiance(o->ic, *fc, in, sun_color);
     o->ic.read_aux_snapshot = false;
 }
 // deterministic mode (okj_ircache.hpp header): record-then-replay of the lookups' side effects
 void okj_ircache_set_deferred_updates(void* p, int enable) { ((OkjIrcache*)p)->ic.deferred = enable != 0; }
+void okj_ircache_set_chain_schedule(void* p, int enable) { ((OkjIrcache*)p)->chain_schedule = enable != 0; }
 void okj_ircache_begin_requests(void* p) { ((OkjIrcache*)p)->ic.begin_requests(); }
 uint64_t okj_ircache_request_count(void* p) { return ((OkjIrcache*)p)->ic.requests.size(); }
 void okj_ircache_apply_requests(void* p) { ((OkjIrcache*)p)->ic.apply_requests(); }

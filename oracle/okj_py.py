@@ -78,6 +78,7 @@ def lib():
         L.okj_ircache_buffer.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.okj_ircache_ray_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.okj_ircache_set_deferred_updates.argtypes = [C.c_void_p, C.c_int]
+        L.okj_ircache_set_chain_schedule.argtypes = [C.c_void_p, C.c_int]
         L.okj_ref_trace_hook_ptr.restype = C.c_void_p
         L.okj_scene_mesh_count.argtypes = [C.c_void_p]; L.okj_scene_instance_count.argtypes = [C.c_void_p]; L.okj_scene_map_count.argtypes = [C.c_void_p]
         L.okj_scene_vertex_buffer_bytes.argtypes = [C.c_void_p]; L.okj_scene_vertex_buffer_bytes.restype = C.c_uint64
@@ -346,6 +347,11 @@ class OraclePipeline:
         kj_ircache_set_deferred_updates, so that cache state can be compared under the deterministic passes' bars."""
         self.L.okj_ircache_set_deferred_updates(self.ircache, int(enable))
         self.ircache_deferred = bool(enable)
+
+    def ircache_set_chain_schedule(self, enable=True):
+        """Deterministic mode only: which schedule of the cache's three ray passes the oracle restates -- the product's default (KJ_IRC_PASSES_CHAIN: tracing's lookups read
+        the state before the passes, on by default here too) or three launches with a snapshot between validation and tracing (kj_ircache_set_ray_pass_schedule(SEQUENTIAL))."""
+        self.L.okj_ircache_set_chain_schedule(self.ircache, int(enable))
 
     def taa_frame(self, fc, input_ptr=None, out_extent=None):
         """TaaRenderer::render on `input_ptr` (default: this frame's rtdgi screen_irradiance_tex)."""

@@ -44,23 +44,30 @@ def test_ircache_maintenance_and_sum_are_exact_on_identical_state(gpu, oracle, d
     one_frame_on_identical_state(gpu, oracle, device, "cornell", 128, 128)
 
 
+def test_ircache_ray_passes_three_launches_on_identical_state(gpu, oracle, device):
+    """kj_ircache_set_ray_pass_schedule(KJ_IRC_PASSES_SEQUENTIAL): the three ray passes as three launches (the default of rounds 1-4), against the same sequential oracle
+    and the same statistical bar as the default chain schedule above."""
+    one_frame_on_identical_state(gpu, oracle, device, "cornell", 128, 128, schedule="sequential")
+
+
 def test_ircache_ray_passes_side_by_side_on_identical_state(gpu, oracle, device):
     """kj_ircache_set_ray_passes_side_by_side(1): the three ray passes in one launch, racing as the reference's barrier-free recording lets them
     (ircache.rs:396-481). Same maintenance results bit for bit, same ray counts; the SH sums sit much further from the SEQUENTIAL oracle than with
     three launches (measured 5.3e-2 and 1.25e-1 in two runs on MI355X against 1.3e-2 on this case: which pass's update of a slot a lookup or the next
     pass sees is decided by the race) -- a different valid schedule of a racy algorithm, not a parity claim: this test exercises the path (maintenance
     exact, ray counts equal) and holds the sums to a 0.3 sanity bar."""
-    one_frame_on_identical_state(gpu, oracle, device, "cornell", 128, 128, side_by_side=True)
+    one_frame_on_identical_state(gpu, oracle, device, "cornell", 128, 128, schedule="side_by_side")
 
 
-def one_frame_on_identical_state(gpu, oracle, device, scene_name, W, H, side_by_side=False):
+def one_frame_on_identical_state(gpu, oracle, device, scene_name, W, H, schedule="chain"):
+    side_by_side = schedule == "side_by_side"
     import torch
     desc = T._scenes()[scene_name]
     oracle.lib().okj_set_threads(1)
     try:
         op = oracle.OraclePipeline(oracle.OracleScene(desc), W, H, use_ircache=True)
         gp = gpu.GpuPipeline(device, gpu.Scene(device, desc), W, H, use_ircache=True)
-        gpu.check(gp.L.kj_ircache_set_ray_passes_side_by_side(gp.ircache, int(side_by_side)))
+        gp.ircache_set_ray_pass_schedule(schedule)      # "chain" = the library's default (one launch, own-slot order kept); the oracle is the sequential one for all three
         fcs = _frames(W, H, 8, scene="cornell" if scene_name == "cornell" else "city")
         for fc in fcs[:6]:
             op.frame(fc)
@@ -281,7 +288,7 @@ def assert_cache_parity(a, b, what, flip_cells=8, flip_tol=P.MISMATCH_TOL, verbo
     return exact_layout
 
 
-def deterministic_frames_on_identical_state(gpu, oracle, device, scene_name, W, H, warmup=5, frames=3):
+def deterministic_frames_on_identical_state(gpu, oracle, device, scene_name, W, H, warmup=5, frames=3, schedule="chain"):
     """Whole GI frames (cache maintenance, its three ray passes, rtdgi with its cache lookups, the replay of the recorded updates) in the
     cache's deterministic mode, each from IDENTICAL state: before every compared frame the oracle's cache buffers, rtdgi surfaces and
     G-buffer are uploaded to the product. Compared after each frame: the whole cache per cell, and the GI output."""
@@ -291,6 +298,10 @@ def deterministic_frames_on_identical_state(gpu, oracle, device, scene_name, W, 
     gp = gpu.GpuPipeline(device, gpu.Scene(device, desc), W, H, use_ircache=True)
     op.ircache_set_deferred(True)
     gp.ircache_set_deferred(True)
+    # the schedule of the cache's three ray passes: the library's default chain (one launch; lookups of validation and tracing read the state before it) or three
+    # launches (a snapshot between validation and tracing); the oracle restates whichever the product runs
+    gp.ircache_set_ray_pass_schedule(schedule)
+    op.ircache_set_chain_schedule(schedule == "chain")
     fcs = _frames(W, H, warmup + frames, scene="cornell" if scene_name == "cornell" else "city")
     repro_dev = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
     get_g = lambda name, dt: gp.ircache_buffer(name, torch.uint8).cpu().numpy().view(dt)
@@ -327,6 +338,11 @@ def test_ircache_deterministic_mode_parity(gpu, oracle, device):
     """with deferred, canonically ordered updates on BOTH sides the cache meets the 1e-3 bar (a12 / a13 were
     'statistical')."""
     deterministic_frames_on_identical_state(gpu, oracle, device, "cornell", 128, 128)
+
+
+def test_ircache_deterministic_mode_parity_three_launches(gpu, oracle, device):
+    """The same with the three ray passes as three launches on both sides (kj_ircache_set_ray_pass_schedule(SEQUENTIAL) / okj_ircache_set_chain_schedule(0))."""
+    deterministic_frames_on_identical_state(gpu, oracle, device, "cornell", 128, 128, schedule="sequential")
 
 
 def test_ircache_deterministic_free_running(gpu, oracle, device):
