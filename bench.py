@@ -206,7 +206,7 @@ def main():
         if want_native:
             try:
                 nccl = multigpu.NativeSplit.rccl_comm_from_torch(dist, rank, world, f"cuda:{local_rank}") if world > 1 else None
-                split = multigpu.NativeSplit(nsplit, split_pipes, W, H, motion_halo=args.motion_halo, nccl_comm=nccl)
+                split = multigpu.NativeSplit(nsplit, split_pipes, W, H, motion_halo=args.motion_halo, nccl_comm=nccl, own_comm=True)
                 created = True
             except Exception as e:
                 print(f"[bench] rank {rank}: compiled split orchestrator unavailable ({e})", file=sys.stderr, flush=True)

@@ -379,6 +379,7 @@ KjStatus kj_rtdgi_surface(KjRtdgi* r, const char* name, void** out_dev_ptr, uint
  * instrumented build (nodes visited / triangles tested per ray type) — never timed. */
 #define KJ_RTDGI_NUM_SCOPES 11
 KjStatus kj_rtdgi_set_profiling(KjRtdgi* r, uint32_t enable_pass_timers, uint32_t count_traversal);
+/* (`validity integrate` reads 0 while it shares `restir temporal`'s launch, the default; a frame that issues the half-res extract in two parts reports the first, the bulk, as `extract half`.) */
 KjStatus kj_rtdgi_pass_times_ms(KjRtdgi* r, float* out_ms, uint32_t count);
 /* out[6] = closest rays, any-hit rays, nodes (closest), tris (closest), nodes (any), tris (any) */
 KjStatus kj_rtdgi_traversal_counts(KjRtdgi* r, uint64_t out[6]);

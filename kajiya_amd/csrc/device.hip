@@ -440,17 +440,17 @@ KjStatus kj_raster_gbuffer(KjDevice* dev, KjScene* scene, uint32_t W, uint32_t H
 
 // waves + scheduling knobs of a ray-stream launch: enough waves to fill the chip (KJ_STREAM_WAVES_PER_CU per CU, default 24); knobs overridable for measurements
 static StreamTune stream_launch(const KjDevice* dev, uint32_t count, uint32_t* waves) {
-    const uint32_t per_cu = getenv("KJ_STREAM_WAVES_PER_CU") ? uint32_t(atoi(getenv("KJ_STREAM_WAVES_PER_CU"))) : 24u;
+    const uint32_t per_cu = kj_debug_getenv("KJ_STREAM_WAVES_PER_CU") ? uint32_t(atoi(kj_debug_getenv("KJ_STREAM_WAVES_PER_CU"))) : 24u;
     StreamTune t = stream_tune_for(count, dev->num_cus * per_cu, waves);
-    if (const char* v = getenv("KJ_STREAM_REFILL")) t.refill_threshold = uint32_t(atoi(v));
-    if (const char* v = getenv("KJ_STREAM_NODE_WEIGHT")) t.node_weight = uint32_t(atoi(v));
-    if (const char* v = getenv("KJ_STREAM_TRI_WEIGHT")) t.tri_weight = uint32_t(atoi(v));
+    if (const char* v = kj_debug_getenv("KJ_STREAM_REFILL")) t.refill_threshold = uint32_t(atoi(v));
+    if (const char* v = kj_debug_getenv("KJ_STREAM_NODE_WEIGHT")) t.node_weight = uint32_t(atoi(v));
+    if (const char* v = kj_debug_getenv("KJ_STREAM_TRI_WEIGHT")) t.tri_weight = uint32_t(atoi(v));
     return t;
 }
 // Batches too small to fill the chip with one ray per lane (fewer rays than ~4 waves per SIMD would hold) walk with four lanes per ray
 // (kj_bvh.hpp: bvh_trace_quad). KJ_TRACE_QUAD_MAX_RAYS overrides the threshold (0 = never).
 static uint32_t quad_max_rays(const KjDevice* dev) {
-    const long env = getenv("KJ_TRACE_QUAD_MAX_RAYS") ? atol(getenv("KJ_TRACE_QUAD_MAX_RAYS")) : -1;
+    const long env = kj_debug_getenv("KJ_TRACE_QUAD_MAX_RAYS") ? atol(kj_debug_getenv("KJ_TRACE_QUAD_MAX_RAYS")) : -1;
     return env >= 0 ? uint32_t(env) : dev->num_cus * 4u * 4u * 16u;      // 4 SIMDs x 4 waves x 16 rays per CU: 65536 on MI355X
 }
 KjStatus kj_trace_closest(KjScene* scene, const void* rays, void* hits, uint32_t count, uint32_t cull_back_faces, void* stream) {
@@ -460,7 +460,7 @@ KjStatus kj_trace_closest(KjScene* scene, const void* rays, void* hits, uint32_t
     const SceneView sv = scene_view(*scene);
     if (count <= quad_max_rays(scene->dev))
         hipLaunchKernelGGL(k_trace_closest_quad, dim3((count + 15) / 16), dim3(64), quad_stack_bytes(), (hipStream_t)stream, sv, (const float4*)rays, (float4*)hits, count, int(cull_back_faces));
-    else if (getenv("KJ_TRACE_PER_RAY"))
+    else if (kj_debug_getenv("KJ_TRACE_PER_RAY"))
         hipLaunchKernelGGL(k_trace_closest, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (float4*)hits, count, int(cull_back_faces));
     else {
         uint32_t waves; const StreamTune tune = stream_launch(scene->dev, count, &waves);
@@ -476,7 +476,7 @@ KjStatus kj_trace_any(KjScene* scene, const void* rays, void* out_u8, uint32_t c
     const SceneView sv = scene_view(*scene);
     if (count <= quad_max_rays(scene->dev))
         hipLaunchKernelGGL(k_trace_any_quad, dim3((count + 15) / 16), dim3(64), quad_stack_bytes(), (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count);
-    else if (getenv("KJ_TRACE_PER_RAY"))
+    else if (kj_debug_getenv("KJ_TRACE_PER_RAY"))
         hipLaunchKernelGGL(k_trace_any, dim3((count + 63) / 64), dim3(64), sv.bvh.stack_entries * 64 * 4, (hipStream_t)stream, sv, (const float4*)rays, (uint8_t*)out_u8, count);
     else {
         uint32_t waves; const StreamTune tune = stream_launch(scene->dev, count, &waves);

@@ -736,8 +736,8 @@ KjStatus kj_ircache_create(KjDevice* dev, KjIrcache** out) {
     KJ_REQUIRE(dev && out, "null argument");
     KjIrcache* c = new KjIrcache();
     c->dev = dev;
-    if (getenv("KJ_IRC_SIDE_BY_SIDE") && atoi(getenv("KJ_IRC_SIDE_BY_SIDE")) != 0) c->ray_pass_schedule = KJ_IRC_PASSES_SIDE_BY_SIDE;
-    if (const char* v = getenv("KJ_IRC_SCHEDULE")) { const int k = atoi(v); if (k >= 0 && k <= 2) c->ray_pass_schedule = uint32_t(k); }      // A/B runs
+    if (kj_debug_getenv("KJ_IRC_SIDE_BY_SIDE") && atoi(kj_debug_getenv("KJ_IRC_SIDE_BY_SIDE")) != 0) c->ray_pass_schedule = KJ_IRC_PASSES_SIDE_BY_SIDE;
+    if (const char* v = kj_debug_getenv("KJ_IRC_SCHEDULE")) { const int k = atoi(v); if (k >= 0 && k <= 2) c->ray_pass_schedule = uint32_t(k); }      // A/B runs
     hipError_t e = hipSuccess;
     auto A = [&](kj::DevBuf& b, size_t n) { if (e == hipSuccess) e = b.alloc(n); };
     A(c->meta, 32); A(c->grid_meta[0], size_t(IRC_MAX_GRID_CELLS) * 8); A(c->grid_meta[1], size_t(IRC_MAX_GRID_CELLS) * 8);
@@ -845,12 +845,12 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     // wave, the other lanes idle -- which measured -2.5 % per frame at n = 8 (each wave's step count is the maximum over fewer
     // divergent paths). Not the default: with 8x as many waves in flight a lookup sees fewer of the same pass' updates, which moves the
     // racy passes further from the sequential oracle (SH rel-L2 on identical state, 1080p city: 1.1e-2 at 64, 2.3e-2 at 8; bar 2e-2).
-    static const uint32_t lanes_env = getenv("KJ_IRC_LANES") ? uint32_t(atoi(getenv("KJ_IRC_LANES"))) : 0u;
+    static const uint32_t lanes_env = kj_debug_getenv("KJ_IRC_LANES") ? uint32_t(atoi(kj_debug_getenv("KJ_IRC_LANES"))) : 0u;
     tc.lanes = lanes_env >= 1u && lanes_env <= 64u ? lanes_env : 64u;
     // KJ_IRC_PART="i/n" (a measurement switch, scripts/ircache_partition_probe.sh): the three ray passes take every n-th entry only -- what
     // one rank of n would trace if the cache's own rays were dealt out across ranks. Results are then incomplete by construction.
     tc.part_index = 0u; tc.part_count = 1u;
-    if (const char* pe = getenv("KJ_IRC_PART")) {
+    if (const char* pe = kj_debug_getenv("KJ_IRC_PART")) {
         unsigned pi = 0, pn = 1;
         if (sscanf(pe, "%u/%u", &pi, &pn) == 2 && pn >= 1u && pi < pn) { tc.part_index = pi; tc.part_count = pn; }
         static bool warned = false;      // a variable left over from a profiling script degrades GI: never silently
@@ -858,7 +858,7 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     }
     // Default: four lanes per path (kj_bvh.hpp: bvh_trace_quad) -- 16 paths per wave, a ~75-instruction step instead of ~200, four
     // times the waves. KJ_IRC_QUAD=0: one lane per path.
-    static const bool quad = !(getenv("KJ_IRC_QUAD") && atoi(getenv("KJ_IRC_QUAD")) == 0);
+    static const bool quad = !(kj_debug_getenv("KJ_IRC_QUAD") && atoi(kj_debug_getenv("KJ_IRC_QUAD")) == 0);
     const uint32_t grid = c->dev->num_cus * (quad ? 32u : (tc.lanes < 64u ? 32u : 8u));
     const size_t lds_rays = quad ? quad_stack_bytes() : lds;
     KJ_TRY_HIP(hipMemsetAsync(c->ray_counters.p, 0, KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8, s));

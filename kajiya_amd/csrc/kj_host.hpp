@@ -9,6 +9,21 @@
 #include <vector>
 #include "../../include/kajiya_amd.h"
 #include "kj_scene_types.hpp"
+#include <cstdlib>
+
+// MEASUREMENT SWITCHES (A/B runs of bench.py and the scripts under scripts/): environment variables that change what the library runs are honoured only when
+// KJ_DEBUG_ENV=1 is set as well; a set switch without the gate is ignored with one line on stderr. What a host may configure goes through the C-ABI
+// (kj_*_set_*); the ungated variables left are diagnostics (KJ_BVH_TIMING, KJ_SCENE_DEBUG), the host build's thread count (KJ_BVH_THREADS) and the RCCL library path (KJ_RCCL_LIB).
+inline const char* kj_debug_getenv(const char* name) {
+    static const bool gate = [] { const char* g = getenv("KJ_DEBUG_ENV"); return g && atoi(g) != 0; }();
+    const char* v = getenv(name);
+    if (v && !gate) {
+        static bool warned = false;
+        if (!warned) { fprintf(stderr, "kajiya_amd: %s is set but ignored: measurement switches need KJ_DEBUG_ENV=1 (this line is printed once)\n", name); warned = true; }
+        return nullptr;
+    }
+    return v;
+}
 
 namespace kj {
 

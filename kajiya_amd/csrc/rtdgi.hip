@@ -932,20 +932,26 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     KJ_REQUIRE(dev && out, "null argument");
     KjRtdgi* r = new KjRtdgi();
     r->dev = dev;
-    if (const char* v = getenv("KJ_RTDGI_RESAMPLE_VARIANT")) r->resample_variant = atoi(v);
-    if (const char* v = getenv("KJ_RTDGI_STAGED_MIN_RAYS")) r->staged_min_rays = uint32_t(atoll(v));
-    if (const char* v = getenv("KJ_RTDGI_GROUPED")) r->grouped_rays = atoi(v) != 0;
-    if (const char* v = getenv("KJ_RTDGI_SPLIT")) r->split_rays = atoi(v) != 0;
-    if (const char* v = getenv("KJ_RTDGI_QUAD")) r->quad_rays = atoi(v) != 0;
-    if (const char* v = getenv("KJ_RTDGI_FUSE_VT")) r->fuse_validity_temporal = atoi(v) != 0;
-    if (const char* v = getenv("KJ_RTDGI_WAVES_PER_SIMD")) r->ray_waves_per_simd = uint32_t(std::max(0, atoi(v)));
-    if (const char* v = getenv("KJ_RTDGI_POOL")) r->pool_rays = atoi(v) != 0;      // A/B runs of bench.py: the pool form of the ray passes on / off
-    if (const char* v = getenv("KJ_RTDGI_POOL_TUNE")) {                             // "waves,refill,shade_a,shade_b,dynamic"
+    if (const char* v = kj_debug_getenv("KJ_RTDGI_RESAMPLE_VARIANT")) r->resample_variant = atoi(v);
+    if (const char* v = kj_debug_getenv("KJ_RTDGI_STAGED_MIN_RAYS")) r->staged_min_rays = uint32_t(atoll(v));
+    if (const char* v = kj_debug_getenv("KJ_RTDGI_GROUPED")) r->grouped_rays = atoi(v) != 0;
+    if (const char* v = kj_debug_getenv("KJ_RTDGI_SPLIT")) r->split_rays = atoi(v) != 0;
+    if (const char* v = kj_debug_getenv("KJ_RTDGI_QUAD")) r->quad_rays = atoi(v) != 0;
+    if (const char* v = kj_debug_getenv("KJ_RTDGI_FUSE_VT")) r->fuse_validity_temporal = atoi(v) != 0;
+    if (const char* v = kj_debug_getenv("KJ_RTDGI_WAVES_PER_SIMD")) r->ray_waves_per_simd = uint32_t(std::max(0, atoi(v)));
+    if (const char* v = kj_debug_getenv("KJ_RTDGI_POOL")) r->pool_rays = atoi(v) != 0;      // A/B runs of bench.py: the pool form of the ray passes on / off
+    if (const char* v = kj_debug_getenv("KJ_RTDGI_POOL_TUNE")) {                             // "waves,refill,shade_a,shade_b,dynamic"
         unsigned w = 0, f = 0, a = 0, b = 0, d = 0;
         if (sscanf(v, "%u,%u,%u,%u,%u", &w, &f, &a, &b, &d) == 5 && w <= KJ_POOL_WAVES && f >= 1 && f <= 64 && a >= 1 && a <= 64 && b >= 1 && b <= 64) {
             r->pool_waves_per_simd = w; r->pool_refill_min = f; r->pool_shade_a_min = a; r->pool_shade_b_min = b; r->pool_dynamic_tiles = d ? 1u : 0u;
         } else fprintf(stderr, "kajiya_amd: KJ_RTDGI_POOL_TUNE=%s ignored (want \"waves,refill,shade_a,shade_b,dynamic\")\n", v);
     }
+#ifndef KJ_RAY_PASS_EXPERIMENTS
+    if (r->grouped_rays || r->split_rays || r->quad_rays || r->staged_min_rays != 0xffffffffu) {      // this build carries the fused and the pool form only: say so instead of measuring the same kernel twice
+        fprintf(stderr, "kajiya_amd: KJ_RTDGI_GROUPED / _SPLIT / _QUAD / _STAGED_MIN_RAYS ask for a form of the ray passes this build does not carry (make EXPERIMENTS=1): the fused form runs\n");
+        r->grouped_rays = r->split_rays = r->quad_rays = false; r->staged_min_rays = 0xffffffffu;
+    }
+#endif
     if (r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
     *out = r;
     return KJ_OK;
@@ -1063,10 +1069,13 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     if (r->ray_waves_per_simd) trace_lds = std::max(trace_lds, (size_t(160 * 1024) / (4u * r->ray_waves_per_simd)) & ~size_t(255));
 
     if (mask & (KJ_RTDGI_PASS_EXTRACT_HALF | KJ_RTDGI_PASS_EXTRACT_HALF_SSAO_ONLY)) {
-        SCOPE_BEGIN(1);
+        // (a frame that splits the extract in two -- everything but the SSAO early, the SSAO byte behind `restir temporal` -- times the first, the bulk, as `extract half`;
+        // the SSAO-only launch, ~2 us, is not timed: both in one scope would report the last one only)
+        const bool timed_extract = !(mask & KJ_RTDGI_PASS_EXTRACT_HALF_SSAO_ONLY);
+        if (timed_extract) SCOPE_BEGIN(1);
         hipLaunchKernelGGL((mask & KJ_RTDGI_PASS_EXTRACT_HALF_SSAO_ONLY) ? k_extract_half<2> : (mask & KJ_RTDGI_PASS_EXTRACT_HALF_NO_SSAO) ? k_extract_half<1> : k_extract_half<0>, gh, blk, 0, s, fc, gbuffer, depth, ssao, img<uint32_t>(half_view_normal, hw, hh), img<float>(half_depth, hw, hh), img<int8_t>(half_ssao, hw, hh), img<uint2>(half_gbuf, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
-        SCOPE_END(1);
+        if (timed_extract) SCOPE_END(1);
     }
     // the pool form of the ray passes (k_rtdgi_rays_pool): persistent waves over the launch's tiles
     PoolArgs pa;

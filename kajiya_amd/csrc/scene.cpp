@@ -458,10 +458,10 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     // Who builds the top tree: the host (binned SAH, the better tree) while that is cheap, the device (a linear BVH over the same boxes) once the host's
     // build would be what a per-frame commit costs -- 1.1 ms at 1 k leaves, 10 ms at 8 k, 46 ms at 32 k against 0.1 ms for the refit of a moved
     // instance (profiles/r03_top_tree_build.md). kj_scene_set_top_build_mode / KJ_SCENE_TOP_BUILD: 0 = by leaf count, 1 = host, 2 = device.
-    static const int top_env = getenv("KJ_SCENE_TOP_BUILD") ? atoi(getenv("KJ_SCENE_TOP_BUILD")) : -1;
+    static const int top_env = kj_debug_getenv("KJ_SCENE_TOP_BUILD") ? atoi(kj_debug_getenv("KJ_SCENE_TOP_BUILD")) : -1;
     const uint32_t top_mode = top_env >= 0 && top_env <= 2 ? uint32_t(top_env) : s->top_build_mode;
     auto device_top_wanted = [&](uint32_t leaves) { return top_mode == 2u || (top_mode == 0u && leaves >= KJ_TOP_DEVICE_MIN_LEAVES); };
-    static const bool open_env = getenv("KJ_SCENE_OPEN_INSTANCES") && atoi(getenv("KJ_SCENE_OPEN_INSTANCES")) != 0;
+    static const bool open_env = kj_debug_getenv("KJ_SCENE_OPEN_INSTANCES") && atoi(kj_debug_getenv("KJ_SCENE_OPEN_INSTANCES")) != 0;
     const bool open_instances = s->open_instances || open_env;
     const uint32_t top_budget = open_instances ? std::min(4096u, 4u * ni + 16u) : ni;
     const uint32_t tlas_capacity = std::max(1u, top_budget);     // a 4-wide tree over n single-node leaves has fewer than n nodes

@@ -40,7 +40,7 @@ typedef Img<float> ImgF32;
 #define KJ_TAA_NR_MASK 31
 #endif
 // KJ_TAA_NR_MASK (default: all groups on) switches groups of quotients / roots back to the IEEE sequences: what the round-4 A/B runs and the bisection that found the one
-// site that has to stay IEEE (catmull_rom_5tap_history's last line) were built with (scripts/r04_taa_bisect.sh, profiles/r04_ab_runs.md)
+// site that has to stay IEEE (catmull_rom_5tap_history's last line) were built with (scripts/archive/r04_taa_bisect.sh, profiles/r04_ab_runs.md)
 #define NRDIV(bit_, a_, b_) (((KJ_TAA_NR_MASK) & (bit_)) ? div_nr(a_, b_) : ((a_) / (b_)))
 KJ_D V3 taa_decode_rgb(V3 v) {       // v * sqrt(max(0, m)) / max(1e-20, m), m = the largest component (upstream of input_prob: the reference's operations,
     const float m = max3(v.x, v.y, v.z);     // nearly always its bits -- kj_screen.hpp: div_nr / sqrt_nr), without a branch:
@@ -56,7 +56,7 @@ KJ_D float pow8_(float x) { const float x2 = x * x, x4 = x2 * x2; return x4 * x4
 KJ_D float luma_weight_uncut(float luma) { return __float_as_uint(luma) <= __float_as_uint(1e10f) ? 1.0f : pow8_(saturate(1e10f / luma)); }
 // saturate(cutoff / luma) is 1 wherever 0 < luma <= cutoff (a correctly rounded quotient >= 1); above the cutoff luma > 0 and the quotient is in div_nr's domain
 KJ_D float luma_weight(float cutoff, float luma) {
-    if (((KJ_TAA_NR_MASK) & 2) && luma > 0.0f && cutoff > 0.0f) return luma <= cutoff ? 1.0f : pow8_(fminf(div_nr(cutoff, luma), 1.0f));
+    if (((KJ_TAA_NR_MASK) & 2) && luma > 0.0f && luma < INFINITY && cutoff > 0.0f && cutoff < INFINITY) return luma <= cutoff ? 1.0f : pow8_(fminf(div_nr(cutoff, luma), 1.0f));     // finite operands: div_nr's domain
     return pow8_(saturate(cutoff / luma));       // black texels / a black neighbourhood (0 / 0 = NaN -> 0), negative lumas: as written
 }
 KJ_D float ld1h(const ImgH1& i, int x, int y) { return f16_to_f32(i.ld(x, y)); }
@@ -544,7 +544,7 @@ KjStatus kj_taa_create(KjDevice* dev, KjTaa** out) {
     KJ_REQUIRE(dev && out, "null argument");
     KjTaa* t = new KjTaa();
     t->dev = dev;
-    if (const char* v = getenv("KJ_TAA_MERGE_PROB")) t->merge_prob_filters = atoi(v) != 0;
+    if (const char* v = kj_debug_getenv("KJ_TAA_MERGE_PROB")) t->merge_prob_filters = atoi(v) != 0;
     *out = t;
     return KJ_OK;
 }

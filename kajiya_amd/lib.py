@@ -458,6 +458,7 @@ class GpuPipeline:
                 self._s3 = torch.cuda.Stream(priority=int(os.environ.get("KJ_PRIO_SSGI", "0")))
                 self._ev_ssgi = [torch.cuda.Event(), torch.cuda.Event()]
             with torch.cuda.stream(self._s3):
+                self._s3.wait_stream(s0)                         # the caller's work on the current stream up to here: this frame's G-buffer, depth and reprojection map
                 self._s3.wait_event(self._ev_fc[i])
                 if self._pipe_i > 0:
                     self._s3.wait_event(self._ev_gi[1 - i])      # last frame's resolve / filters have read the guide image this call overwrites... (double-buffered: two frames back)

@@ -821,8 +821,9 @@ class NativeSplit:
     `pipes`: {rank: GpuPipeline} for the ranks living in this process -- all `world` of them (virtual ranks on one device), or one
     together with `nccl_comm` (an ncclComm_t as an integer: NativeSplit.rccl_comm_from_torch makes one)."""
 
-    def __init__(self, world, pipes, width, height, motion_halo=8, nccl_comm=None, own_comm=True):
-        """`own_comm`: close() also destroys `nccl_comm` (the usual case: rccl_comm_from_torch made it for this object)."""
+    def __init__(self, world, pipes, width, height, motion_halo=8, nccl_comm=None, own_comm=False):
+        """`own_comm`: close() -- an explicit call, never the garbage collector -- also destroys `nccl_comm`. Off by default: a communicator the caller made and may keep
+        using is the caller's; bench.py, which makes one with rccl_comm_from_torch for this object alone, passes True."""
         from .abi import KjSplitRank, KjSplitFrame
         self.L = klib.load()
         self._own_comm = nccl_comm if (own_comm and nccl_comm) else None
@@ -859,6 +860,8 @@ class NativeSplit:
                 pass
 
     def __del__(self):
+        # the orchestrator handle only: ncclCommDestroy from a finaliser can block on peers at interpreter shutdown, and the communicator may not be ours
+        self._own_comm = None
         try:
             self.close()
         except Exception:

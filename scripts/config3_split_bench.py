@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[2] under the screen-tile split: the whole lighting frame of scripts/config3_bench.py (SSAO guide, sun shadows + denoiser, irradiance cache +
 rtdgi, reflections, deferred combine, TAA on the lit image) strip by strip through multigpu.lighting_frame -- N virtual ranks on one GPU (--virtual-ranks N:
-for rocprofv3, sum of kernel + copy durations / frames / N = the GPU work of one rank, as scripts/r03_virtual_split_gpu_time.sh does for the GI frame) or one
+for rocprofv3, sum of kernel + copy durations / frames / N = the GPU work of one rank, as scripts/archive/r03_virtual_split_gpu_time.sh does for the GI frame) or one
 process per GPU under `python -m torch.distributed.run --nproc-per-node N ... scripts/config3_split_bench.py` (the compiled orchestrator over RCCL, certified
 by its self-test before frame 0; KJ_SPLIT_NATIVE=0: the Python orchestrator over torch.distributed). Frames are issued serially (no cache pipelining): the wall time of
 a virtual-rank run is N ranks' work plus their host syncs on one GPU and says nothing; of an N-process run it is the frame time (max over ranks).
