@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--profile-frames", type=int, default=12)
     ap.add_argument("--no-ssgi", action="store_true", help="drive rtdgi with the constant SSAO guide instead of running SsgiRenderer each frame")
     ap.add_argument("--no-overlap", action="store_true", help="serial frames: do not overlap the next frame's ircache work with this frame's screen-space tail")
+    ap.add_argument("--deterministic-cache", action="store_true", help="the irradiance cache in its deterministic mode (deferred, canonically ordered updates: the mode the 1e-3 cache parity is "
+                    "tested in and the mode every screen-tile split runs) for the timed region; serial frames (implies --no-overlap)")
     ap.add_argument("--virtual-ranks", type=int, default=0, help="debug: run the N-way screen-tile split on ONE GPU (LocalComm)")
     ap.add_argument("--pmc-calibration-copy", action="store_true", help="after the timed region, copy 512 MiB with the library's `pmc_calibration_copy` kernel: a known byte count for scripts/pmc_collect.sh")
     ap.add_argument("--motion-halo", type=int, default=16, help="rows of history exchanged beyond the stencil (>= max |screen motion| per frame)")
@@ -143,6 +145,7 @@ def also_measurements():
             rf = j.get("roofline") or {}
             e.update({"gi_frame_ms": j["gi_frame_ms"], "fps": round(1000.0 / j["gi_frame_ms"], 1), "mrays_per_s": j["value"], "workload": j["config"]["workload"][:120],
                       "rays_per_frame": j["config"]["rays_per_frame"], "segment_ms": j.get("segment_ms"), "pass_ms": j.get("pass_ms"),
+                      "deterministic_cache": j.get("deterministic_cache"),
                       "roofline": {k: rf.get(k) for k in ("kernel", "bound", "bound_measured", "limited_by", "avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac")},
                       "cpu_baseline": j.get("cpu_baseline")})
         elif "ms_per_spp" in j:
@@ -282,7 +285,9 @@ def main():
     irc_counters = [q.ircache_buffer("ray_counters", torch.int64).view(64, 16) for q in all_pipes]
     ray_log = torch.zeros((n_frames + 1, 6), dtype=torch.int64, device=f"cuda:{local_rank}")
     irc_log = torch.zeros((n_frames + 1, 2), dtype=torch.int64, device=f"cuda:{local_rank}")
-    overlap = not args.no_overlap
+    overlap = not args.no_overlap and not args.deterministic_cache
+    if args.deterministic_cache and single:
+        gp.ircache_set_deferred(True)
     serial_step = step
     if overlap:
         # frame pipelining (GpuPipeline.frame_pipelined / SplitRtdgi.frame_pipelined): frame i+1's ircache maintenance + rays run
@@ -537,6 +542,26 @@ def main():
             lib.check(gp.L.kj_debug_calibration_copy(b_.data_ptr(), a_.data_ptr(), nbytes, lib._stream_ptr()))
             torch.cuda.synchronize()
 
+    # ---- the cache's two modes side by side: `value` above times the reference's racy cache (pipelined frames); the 1e-3 cache parity, smoke's second leg
+    # and every screen-tile split run the DETERMINISTIC mode (lookups record, one sorted replay per frame). Same process, same inputs (replayed: timing only), serial frames.
+    det_leg = None
+    if single and world == 1 and not args.deterministic_cache:
+        def serial_ms(nf):
+            torch.cuda.synchronize(); t_ = time.perf_counter()
+            for k_ in range(nf):
+                serial_step(Wm + (k_ % max(1, K)))
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t_) / nf
+        nf = min(24, K)
+        serial_ms(6)
+        racy_serial = serial_ms(nf)
+        gp.ircache_set_deferred(True)
+        serial_ms(6)
+        det_serial = serial_ms(nf)
+        gp.ircache_set_deferred(False)
+        det_leg = {"frames": nf, "serial_racy_ms": round(racy_serial, 4), "serial_deterministic_ms": round(det_serial, 4),
+                   "note": "serial frames on one stream, this run's own inputs replayed; deterministic = kj_ircache_set_deferred_updates(1): lookups record 32-byte requests, one collect + "
+                           "sort + replay per frame (one host read-back of the record count). An N > 1 line (screen-tile split) runs this mode on every rank: compare it with serial_deterministic_ms, not with `value`"}
     ms_per_step = 1e3 * elapsed / K
     out = {
         "metric": "gi_mrays_per_s", "value": round(total_rays_all / elapsed / 1e6, 3), "unit": "Mrays/s",
@@ -549,6 +574,8 @@ def main():
                    "rays_per_frame": round(total_rays / K, 1), "ircache_rays_per_frame": round(irc_rays / K, 1), "parallelism": ("single GPU, 3 HIP streams: next frame's ircache rays (side stream) and this frame's spatial filter + TAA (third stream) overlap the main stream's ray passes" if overlap else "single GPU, serial frames") if nsplit <= 1 else f"{nsplit}-way screen-tile split (16-row-aligned strips; 6 batched halo exchanges per frame incl. the temporal2 all-gather, over "
                                   + (("gloo, host-staged (debug)" if os.environ.get("KJ_BENCH_SHARE_GPU0") and "compiled" not in transport else "RCCL P2P") if world > 1 else "virtual ranks on one GPU") + f"; orchestrator: {'compiled (kj_split_*)' if 'compiled' in transport else 'python (multigpu.SplitRtdgi)'}" + f"; motion halo {args.motion_halo} rows; irradiance cache replicated per rank"
                                   + ("; next frame's ircache work overlapped on a second stream)" if overlap else ")")},
+        "ircache_mode": "deterministic (deferred, canonically ordered updates)" if (args.deterministic_cache or nsplit > 1) else "racy (the reference's atomics)",
+        "deterministic_cache": det_leg,
         "segment_ms": seg,
         "pass_ms": {n: round(v, 4) for n, v in zip(lib.GpuPipeline.PASS_NAMES, pass_ms)} if pass_ms else None,
         "roofline": roofline,

@@ -463,7 +463,8 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
     auto device_top_wanted = [&](uint32_t leaves) { return top_mode == 2u || (top_mode == 0u && leaves >= KJ_TOP_DEVICE_MIN_LEAVES); };
     static const bool open_env = kj_debug_getenv("KJ_SCENE_OPEN_INSTANCES") && atoi(kj_debug_getenv("KJ_SCENE_OPEN_INSTANCES")) != 0;
     const bool open_instances = s->open_instances || open_env;
-    const uint32_t top_budget = open_instances ? std::min(4096u, 4u * ni + 16u) : ni;
+    static const uint32_t budget_env = kj_debug_getenv("KJ_SCENE_OPEN_BUDGET") ? uint32_t(std::max(0, atoi(kj_debug_getenv("KJ_SCENE_OPEN_BUDGET")))) : 0u;      // measurement switch: leaves of the top tree when instances are opened
+    const uint32_t top_budget = open_instances ? (budget_env ? std::max(ni, std::min(32768u, budget_env)) : std::min(4096u, 4u * ni + 16u)) : ni;
     const uint32_t tlas_capacity = std::max(1u, top_budget);     // a 4-wide tree over n single-node leaves has fewer than n nodes
     uint32_t total_tris = 0, total_nodes = tlas_capacity, max_blas_stack = 1;
     // A commit that only REMOVED instances (or moved some) keeps the layout of the world arrays: the removed instance's triangles and

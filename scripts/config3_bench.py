@@ -14,9 +14,13 @@ ap.add_argument("--res", default="2560x1440"); ap.add_argument("--tris", type=in
 ap.add_argument("--frames", type=int, default=60); ap.add_argument("--warmup", type=int, default=24)
 a = ap.parse_args()
 W, H = map(int, a.res.split("x"))
+import time as _t
+_t0 = _t.time()
+def _stage(what): print(f"[config3_bench] {what}: {_t.time() - _t0:.1f} s since start", file=sys.stderr, flush=True)
 dev = lib.Device(0)
 desc = scenes.procedural_ruins(target_tris=a.tris, seed=5678)
 gp = lib.GpuPipeline(dev, lib.Scene(dev, desc), W, H, use_ircache=True)
+_stage("scene + pipeline built")
 fs = frame.FrameState((W, H), sun_size_multiplier=4.0); fs.ircache_enabled = True
 SEG = ["ssgi", "sun shadows + denoise", "ircache + rtdgi", "rtr", "light_gbuffer", "taa"]
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(SEG) + 1)]
@@ -40,6 +44,7 @@ for i in range(a.warmup + SERIAL):
             acc[k] += ev[k].elapsed_time(ev[k + 1])
         for name, fn in (("rtdgi", gp.ray_counts), ("ircache", gp.ircache_ray_counts), ("rtr", gp.rtr_ray_counts)):
             c, s = fn(); rays[name][0] += c; rays[name][1] += s
+_stage("warm-up + serial frames done")
 n = SERIAL
 seg = {k: round(v / n, 4) for k, v in zip(SEG, acc)}
 serial_total = sum(seg.values())
@@ -57,6 +62,7 @@ for i in range(K0, K0 + K + 7):
     rp = lib.tensor_from_ptr(gp.reprojection_map_ptr.value, W * H * 8, torch.int16, (H, W, 4)).clone()
     fcs.append(fc); inputs.append((gp.geometric_normal.clone(), gp.gbuffer.clone(), gp.depth.clone(), rp))
 torch.cuda.synchronize()
+_stage("inputs of the overlapped frames generated")
 main, side, tail = torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()
 ev_fc, ev_irc, ev_rtr, ev_lit, ev_taa = ([torch.cuda.Event(), torch.cuda.Event()] for _ in range(5))
 L = gp.L
@@ -106,6 +112,7 @@ for j in range(6, 6 + K):
     overlapped_frame(j)
 torch.cuda.synchronize()
 total = 1e3 * (time.perf_counter() - t0) / K
+_stage("overlapped frames done")
 shadow_rays = W * H
 all_rays = sum(v[0] + v[1] for v in rays.values()) / n + shadow_rays
 print(json.dumps({"config": "BASELINE configs[2]", "workload": f"procedural_ruins {a.tris} tris (Ruins stand-in) @ {W}x{H}", "frame_ms": round(total, 4), "fps": round(1000.0 / total, 1),
