@@ -589,6 +589,12 @@ __global__ void __launch_bounds__(64) k_irc_sum_up(const FrameConstants* __restr
 //   * a cell nobody occupies is allocated by its first lookup that may allocate; new cells take pool entries in cell order;
 //   * an occupied cell's lookups run through lookup.hlsl:287-301 one after the other: life refresh (min), then the position vote --
 //     accepted with probability 1 / (votes so far + 1), using the random number the lookup drew when it ran.
+// begin of a frame's records: the cache's OWN two slot ranges (validation's and tracing's lookups, slot = path index) hold records only below last frame's
+// path count -- clear those, not the whole 2 x 8 MB (the fills were 0.14 ms of every rank's frame whatever the rank count: profiles/r04_split_work_per_rank.md)
+__global__ void __launch_bounds__(256) k_irc_clear_own_requests(const uint32_t* __restrict__ meta, IrcRequest* __restrict__ own, uint32_t slots_per_range) {
+    const uint32_t used = min(meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME, slots_per_range);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < used; i += gridDim.x * 256u) { own[i].cell = 0xffffffffu; own[slots_per_range + i].cell = 0xffffffffu; }
+}
 __global__ void __launch_bounds__(256) k_irc_collect_requests(const IrcRequest* __restrict__ slots, uint32_t n, IrcRequest* __restrict__ out, uint32_t capacity, uint32_t* __restrict__ count) {
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t i = base + threadIdx.x;
@@ -933,14 +939,19 @@ KjStatus kj_ircache_begin_requests_rows(KjIrcache* c, uint32_t rtdgi_half_width,
     const bool fresh = c->requests.bytes != bytes;
     if (fresh) KJ_TRY_HIP(c->requests.alloc(bytes, s));
     uint8_t* const base = (uint8_t*)c->requests.p;
-    if (fresh || (half_row_begin == 0u && half_row_end == rtdgi_half_height)) {
+    const size_t own_first = 2 * size_t(c->req_half_pixels);
+    if (fresh) {
         KJ_TRY_HIP(hipMemsetAsync(base, 0xff, bytes, s));      // cell = 0xffffffff: unused
+    } else if (half_row_begin == 0u && half_row_end == rtdgi_half_height) {      // every per-pixel slot; of the cache's own ranges what last frame can have written
+        KJ_TRY_HIP(hipMemsetAsync(base, 0xff, own_first * RQ, s));
+        if (c->rtr_requests) KJ_TRY_HIP(hipMemsetAsync(base + size_t(c->rtr_request_base()) * RQ, 0xff, 2 * size_t(c->req_half_pixels) * RQ, s));
+        hipLaunchKernelGGL(k_irc_clear_own_requests, dim3(c->dev->num_cus), dim3(256), 0, s, (const uint32_t*)c->meta.p, (IrcRequest*)base + own_first, KjIrcache::REQ_E);
     } else {
         const size_t hb = c->req_half_pixels, row0 = size_t(half_row_begin) * rtdgi_half_width, n = size_t(half_row_end - half_row_begin) * rtdgi_half_width;
         size_t firsts[4] = {0, hb, 0, 0}; int ranges = 2;
         if (c->rtr_requests) { firsts[2] = c->rtr_request_base(); firsts[3] = c->rtr_request_base() + hb; ranges = 4; }
         if (n) for (int k = 0; k < ranges; ++k) KJ_TRY_HIP(hipMemsetAsync(base + (firsts[k] + row0) * RQ, 0xff, n * RQ, s));
-        KJ_TRY_HIP(hipMemsetAsync(base + 2 * hb * RQ, 0xff, size_t(2u * KjIrcache::REQ_E) * RQ, s));      // the cache's own validate and trace rays
+        hipLaunchKernelGGL(k_irc_clear_own_requests, dim3(c->dev->num_cus), dim3(256), 0, s, (const uint32_t*)c->meta.p, (IrcRequest*)base + own_first, KjIrcache::REQ_E);      // the cache's own validate and trace rays
     }
     c->requests_begun = true;
     return KJ_OK;
