@@ -595,7 +595,10 @@ __global__ void __launch_bounds__(256) k_irc_clear_own_requests(const uint32_t* 
     const uint32_t used = min(meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME, slots_per_range);
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < used; i += gridDim.x * 256u) { own[i].cell = 0xffffffffu; own[slots_per_range + i].cell = 0xffffffffu; }
 }
-__global__ void __launch_bounds__(256) k_irc_collect_requests(const IrcRequest* __restrict__ slots, uint32_t n, IrcRequest* __restrict__ out, uint32_t capacity, uint32_t* __restrict__ count) {
+// `used_paths` (may be null): the range is one of the cache's OWN two (slot = path index): only the first *used_paths * IRC_SAMPLES_PER_FRAME slots can hold a record
+__global__ void __launch_bounds__(256) k_irc_collect_requests(const IrcRequest* __restrict__ slots, uint32_t n, IrcRequest* __restrict__ out, uint32_t capacity, uint32_t* __restrict__ count,
+                                                              const uint32_t* __restrict__ used_paths) {
+    if (used_paths) n = min(n, *used_paths * IRC_SAMPLES_PER_FRAME);
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t i = base + threadIdx.x;
         const bool valid = i < n && slots[i].cell != 0xffffffffu;
@@ -974,8 +977,11 @@ KjStatus kj_ircache_collect_requests(KjIrcache* c, uint32_t first_slot, uint32_t
     KJ_REQUIRE(c && c->deferred && out_list && out_count_dev && c->requests.p, "null argument / no requests recorded");
     KJ_REQUIRE(uint64_t(first_slot) + slot_count <= c->request_slots(), "slot range out of bounds");
     if (slot_count == 0) return KJ_OK;
+    // the cache's own two ranges (validation's and tracing's lookups, slot = path index) are scanned up to this frame's path count only, not all 2 x 262 144 slots
+    const uint32_t own0 = 2u * c->req_half_pixels, own1 = own0 + KjIrcache::REQ_E;
+    const bool own = slot_count <= KjIrcache::REQ_E && (first_slot == own0 || first_slot == own1);
     hipLaunchKernelGGL(k_irc_collect_requests, dim3(std::min(4096u, (slot_count + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream_, (const IrcRequest*)c->requests.p + first_slot, slot_count,
-                       (IrcRequest*)out_list, out_capacity, (uint32_t*)out_count_dev);
+                       (IrcRequest*)out_list, out_capacity, (uint32_t*)out_count_dev, own ? (const uint32_t*)c->meta.p + IRC_META_TRACING_ALLOC_COUNT : (const uint32_t*)nullptr);
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }
