@@ -591,17 +591,19 @@ __global__ void __launch_bounds__(64) k_irc_sum_up(const FrameConstants* __restr
 //     accepted with probability 1 / (votes so far + 1), using the random number the lookup drew when it ran.
 // begin of a frame's records: the cache's OWN two slot ranges (validation's and tracing's lookups, slot = path index) hold records only below last frame's
 // path count -- clear those, not the whole 2 x 8 MB (the fills were 0.14 ms of every rank's frame whatever the rank count: profiles/r04_split_work_per_rank.md)
-__global__ void __launch_bounds__(256) k_irc_clear_own_requests(const uint32_t* __restrict__ meta, IrcRequest* __restrict__ own, uint32_t slots_per_range) {
+__global__ void __launch_bounds__(256) k_irc_clear_own_requests(const uint32_t* __restrict__ meta, uint32_t* __restrict__ own_cells, uint32_t slots_per_range) {
     const uint32_t used = min(meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME, slots_per_range);
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < used; i += gridDim.x * 256u) { own[i].cell = 0xffffffffu; own[slots_per_range + i].cell = 0xffffffffu; }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < used; i += gridDim.x * 256u) { own_cells[i] = 0xffffffffu; own_cells[slots_per_range + i] = 0xffffffffu; }
 }
 // `used_paths` (may be null): the range is one of the cache's OWN two (slot = path index): only the first *used_paths * IRC_SAMPLES_PER_FRAME slots can hold a record
-__global__ void __launch_bounds__(256) k_irc_collect_requests(const IrcRequest* __restrict__ slots, uint32_t n, IrcRequest* __restrict__ out, uint32_t capacity, uint32_t* __restrict__ count,
-                                                              const uint32_t* __restrict__ used_paths) {
+// (`cells`: the 4-byte-per-slot copy of the records' cell field -- the scan reads those, and a record's 32 bytes only where there is one: the slot array is 66 MB per
+// range at 4K and a few percent of its slots hold a record)
+__global__ void __launch_bounds__(256) k_irc_collect_requests(const IrcRequest* __restrict__ slots, const uint32_t* __restrict__ cells, uint32_t n, IrcRequest* __restrict__ out, uint32_t capacity,
+                                                              uint32_t* __restrict__ count, const uint32_t* __restrict__ used_paths) {
     if (used_paths) n = min(n, *used_paths * IRC_SAMPLES_PER_FRAME);
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t i = base + threadIdx.x;
-        const bool valid = i < n && slots[i].cell != 0xffffffffu;
+        const bool valid = i < n && cells[i] != 0xffffffffu;
 #if defined(__HIP_DEVICE_COMPILE__)
         const unsigned long long m = __ballot(valid);        // one atomic per wave (a counter hit by every lane serialises in L2)
         const uint32_t lane = threadIdx.x & 63u;
@@ -734,6 +736,7 @@ IrcacheView KjIrcache::view() const {
     v.reposition_proposal_count = (uint32_t*)reposition_proposal_count.p;
     v.entry_indirection = (const uint32_t*)entry_indirection.p;
     v.requests = deferred ? (IrcRequest*)requests.p : nullptr;
+    v.request_cells = deferred ? (uint32_t*)request_cells.p : nullptr;
     return v;
 }
 
@@ -938,23 +941,24 @@ KjStatus kj_ircache_begin_requests_rows(KjIrcache* c, uint32_t rtdgi_half_width,
     KJ_REQUIRE(half_row_begin <= half_row_end && half_row_end <= rtdgi_half_height, "bad row range");
     hipStream_t s = (hipStream_t)stream_;
     c->req_half_pixels = rtdgi_half_width * rtdgi_half_height;
-    const size_t RQ = sizeof(IrcRequest), bytes = size_t(c->request_slots()) * RQ;
+    const size_t RQ = sizeof(IrcRequest), bytes = size_t(c->request_slots()) * RQ, CB = 4, cell_bytes = size_t(c->request_slots()) * CB;
     const bool fresh = c->requests.bytes != bytes;
-    if (fresh) KJ_TRY_HIP(c->requests.alloc(bytes, s));
-    uint8_t* const base = (uint8_t*)c->requests.p;
+    if (fresh) { KJ_TRY_HIP(c->requests.alloc(bytes, s)); KJ_TRY_HIP(c->request_cells.alloc(cell_bytes, s)); }
+    // what is cleared (and what a collect scans) is the 4-byte cell copy of every slot, 0xffffffff = no record; the 32-byte records themselves are only ever read where a cell says so
+    uint8_t* const base = (uint8_t*)c->request_cells.p;
     const size_t own_first = 2 * size_t(c->req_half_pixels);
     if (fresh) {
-        KJ_TRY_HIP(hipMemsetAsync(base, 0xff, bytes, s));      // cell = 0xffffffff: unused
+        KJ_TRY_HIP(hipMemsetAsync(base, 0xff, cell_bytes, s));
     } else if (half_row_begin == 0u && half_row_end == rtdgi_half_height) {      // every per-pixel slot; of the cache's own ranges what last frame can have written
-        KJ_TRY_HIP(hipMemsetAsync(base, 0xff, own_first * RQ, s));
-        if (c->rtr_requests) KJ_TRY_HIP(hipMemsetAsync(base + size_t(c->rtr_request_base()) * RQ, 0xff, 2 * size_t(c->req_half_pixels) * RQ, s));
-        hipLaunchKernelGGL(k_irc_clear_own_requests, dim3(c->dev->num_cus), dim3(256), 0, s, (const uint32_t*)c->meta.p, (IrcRequest*)base + own_first, KjIrcache::REQ_E);
+        KJ_TRY_HIP(hipMemsetAsync(base, 0xff, own_first * CB, s));
+        if (c->rtr_requests) KJ_TRY_HIP(hipMemsetAsync(base + size_t(c->rtr_request_base()) * CB, 0xff, 2 * size_t(c->req_half_pixels) * CB, s));
+        hipLaunchKernelGGL(k_irc_clear_own_requests, dim3(c->dev->num_cus), dim3(256), 0, s, (const uint32_t*)c->meta.p, (uint32_t*)base + own_first, KjIrcache::REQ_E);
     } else {
         const size_t hb = c->req_half_pixels, row0 = size_t(half_row_begin) * rtdgi_half_width, n = size_t(half_row_end - half_row_begin) * rtdgi_half_width;
         size_t firsts[4] = {0, hb, 0, 0}; int ranges = 2;
         if (c->rtr_requests) { firsts[2] = c->rtr_request_base(); firsts[3] = c->rtr_request_base() + hb; ranges = 4; }
-        if (n) for (int k = 0; k < ranges; ++k) KJ_TRY_HIP(hipMemsetAsync(base + (firsts[k] + row0) * RQ, 0xff, n * RQ, s));
-        hipLaunchKernelGGL(k_irc_clear_own_requests, dim3(c->dev->num_cus), dim3(256), 0, s, (const uint32_t*)c->meta.p, (IrcRequest*)base + own_first, KjIrcache::REQ_E);      // the cache's own validate and trace rays
+        if (n) for (int k = 0; k < ranges; ++k) KJ_TRY_HIP(hipMemsetAsync(base + (firsts[k] + row0) * CB, 0xff, n * CB, s));
+        hipLaunchKernelGGL(k_irc_clear_own_requests, dim3(c->dev->num_cus), dim3(256), 0, s, (const uint32_t*)c->meta.p, (uint32_t*)base + own_first, KjIrcache::REQ_E);      // the cache's own validate and trace rays
     }
     c->requests_begun = true;
     return KJ_OK;
@@ -980,7 +984,7 @@ KjStatus kj_ircache_collect_requests(KjIrcache* c, uint32_t first_slot, uint32_t
     // the cache's own two ranges (validation's and tracing's lookups, slot = path index) are scanned up to this frame's path count only, not all 2 x 262 144 slots
     const uint32_t own0 = 2u * c->req_half_pixels, own1 = own0 + KjIrcache::REQ_E;
     const bool own = slot_count <= KjIrcache::REQ_E && (first_slot == own0 || first_slot == own1);
-    hipLaunchKernelGGL(k_irc_collect_requests, dim3(std::min(4096u, (slot_count + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream_, (const IrcRequest*)c->requests.p + first_slot, slot_count,
+    hipLaunchKernelGGL(k_irc_collect_requests, dim3(std::min(4096u, (slot_count + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream_, (const IrcRequest*)c->requests.p + first_slot, (const uint32_t*)c->request_cells.p + first_slot, slot_count,
                        (IrcRequest*)out_list, out_capacity, (uint32_t*)out_count_dev, own ? (const uint32_t*)c->meta.p + IRC_META_TRACING_ALLOC_COUNT : (const uint32_t*)nullptr);
     KJ_CHECK_LAUNCH();
     return KJ_OK;

@@ -47,6 +47,7 @@ struct IrcacheView {
     // it records what it WOULD have done (allocate the cell, refresh the entry's life, vote for its position) in its own slot
     // requests[request_slot], and kj_ircache_apply_requests replays the merged records of all ranks in one canonical order.
     struct IrcRequest* requests;
+    uint32_t* request_cells;      // requests[i].cell once more, 4 bytes per slot: what a frame's begin clears and its collects scan (0xffffffff = no record) instead of the 32-byte records
 };
 // One lookup's side effects. `cell` = 0xffffffff marks an unused slot. 32 bytes.
 struct IrcRequest {
@@ -173,6 +174,7 @@ KJ_D V3 ircache_lookup(const IrcacheView& ic, const FrameConstants& fc, V3 query
             rq.dart = uint_to_u01_float(hash1_mut(rng));
             rq.proposal = irc_pack_vertex(irc_reposition_proposal(query_from_ws, pt_ws, normal_ws, IRC_GRID_CELL_DIAMETER * float(1u << rc.cascade)));
             ic.requests[request_slot] = rq;
+            ic.request_cells[request_slot] = cell;
             if ((entry_flags & IRC_META_OCCUPIED) == 0 || just_allocated) return v3(0.0f);
         } else
         if (!skip_allocation && (entry_flags & IRC_META_OCCUPIED) == 0) {

@@ -22,7 +22,7 @@ struct KjIrcache {
     bool rtr_requests = false;
     bool requests_begun = false;        // kj_ircache_begin_requests ran for the frame kj_ircache_prepare is about to open (deferred mode)
     uint32_t req_half_pixels = 0;       // HB of the current frame
-    kj::DevBuf freed, aux_snapshot, requests, req_sort_keys, req_sort_keys2, req_sort_idx, req_sort_idx2, req_flags, req_ranks, req_tmp, req_count, req_cells, req_seg_in, req_seg, req_voter, req_voters_incl, req_last_accepted;
+    kj::DevBuf freed, aux_snapshot, requests, request_cells, req_sort_keys, req_sort_keys2, req_sort_idx, req_sort_idx2, req_flags, req_ranks, req_tmp, req_count, req_cells, req_seg_in, req_seg, req_voter, req_voters_incl, req_last_accepted;
     hipError_t err = hipSuccess;
     static constexpr uint32_t REQ_E = IRC_MAX_ENTRIES * IRC_SAMPLES_PER_FRAME;
     uint32_t rtr_request_base() const { return 2u * req_half_pixels + 2u * REQ_E; }
