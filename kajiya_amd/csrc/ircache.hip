@@ -598,24 +598,45 @@ __global__ void __launch_bounds__(256) k_irc_clear_own_requests(const uint32_t* 
 // `used_paths` (may be null): the range is one of the cache's OWN two (slot = path index): only the first *used_paths * IRC_SAMPLES_PER_FRAME slots can hold a record
 // (`cells`: the 4-byte-per-slot copy of the records' cell field -- the scan reads those, and a record's 32 bytes only where there is one: the slot array is 66 MB per
 // range at 4K and a few percent of its slots hold a record)
+// One atomic per 2048 slots: a thread scans eight consecutive cells, the workgroup's counts meet in a wave scan + four LDS words, and ONE lane reserves the block's range of the
+// output list (round 5: with an atomic per wave of 64 slots a 2 M-slot range at 4K cost 64 us -- ~10 k atomics on one address -- for 8 MB of cells).
+#define KJ_COLLECT_PER_THREAD 8u
 __global__ void __launch_bounds__(256) k_irc_collect_requests(const IrcRequest* __restrict__ slots, const uint32_t* __restrict__ cells, uint32_t n, IrcRequest* __restrict__ out, uint32_t capacity,
                                                               uint32_t* __restrict__ count, const uint32_t* __restrict__ used_paths) {
     if (used_paths) n = min(n, *used_paths * IRC_SAMPLES_PER_FRAME);
-    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
-        const uint32_t i = base + threadIdx.x;
-        const bool valid = i < n && cells[i] != 0xffffffffu;
+    const uint32_t per_block = 256u * KJ_COLLECT_PER_THREAD;
 #if defined(__HIP_DEVICE_COMPILE__)
-        const unsigned long long m = __ballot(valid);        // one atomic per wave (a counter hit by every lane serialises in L2)
-        const uint32_t lane = threadIdx.x & 63u;
-        const int leader = m ? __ffsll((long long)m) - 1 : 0;
-        uint32_t wave_base = 0;
-        if (m != 0ull && int(lane) == leader) wave_base = atomicAdd(count, uint32_t(__popcll(m)));
-        wave_base = __shfl(wave_base, leader);
-        const uint32_t o = wave_base + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
-#else
-        const uint32_t o = valid ? atomicAdd(count, 1u) : 0u;
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #endif
-        if (valid && o < capacity) out[o] = slots[i];
+    for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {      // the same trip count for every thread of the block
+        const uint32_t i0 = base + threadIdx.x * KJ_COLLECT_PER_THREAD;
+        uint32_t valid = 0, cnt = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < KJ_COLLECT_PER_THREAD; ++k) {
+            const bool v = i0 + k < n && cells[i0 + k] != 0xffffffffu;
+            valid |= v ? (1u << k) : 0u; cnt += v ? 1u : 0u;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t incl = cnt;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0u) { const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]; s_base = tot ? atomicAdd(count, tot) : 0u; }
+        __syncthreads();
+        uint32_t o = s_base + incl - cnt;
+        for (uint32_t w = 0; w < wave; ++w) o += s_wave[w];
+#else
+        uint32_t o = cnt ? atomicAdd(count, cnt) : 0u;
+#endif
+#pragma unroll
+        for (uint32_t k = 0; k < KJ_COLLECT_PER_THREAD; ++k)
+            if (valid & (1u << k)) { if (o < capacity) out[o] = slots[i0 + k]; ++o; }
+#if defined(__HIP_DEVICE_COMPILE__)
+        __syncthreads();      // s_wave / s_base are rewritten by the next round
+#endif
     }
 }
 __global__ void __launch_bounds__(256) k_irc_request_keys(const IrcRequest* __restrict__ rq, uint32_t n, unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx) {
@@ -984,7 +1005,7 @@ KjStatus kj_ircache_collect_requests(KjIrcache* c, uint32_t first_slot, uint32_t
     // the cache's own two ranges (validation's and tracing's lookups, slot = path index) are scanned up to this frame's path count only, not all 2 x 262 144 slots
     const uint32_t own0 = 2u * c->req_half_pixels, own1 = own0 + KjIrcache::REQ_E;
     const bool own = slot_count <= KjIrcache::REQ_E && (first_slot == own0 || first_slot == own1);
-    hipLaunchKernelGGL(k_irc_collect_requests, dim3(std::min(4096u, (slot_count + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream_, (const IrcRequest*)c->requests.p + first_slot, (const uint32_t*)c->request_cells.p + first_slot, slot_count,
+    hipLaunchKernelGGL(k_irc_collect_requests, dim3(std::min(4096u, (slot_count + 2047u) / 2048u)), dim3(256), 0, (hipStream_t)stream_, (const IrcRequest*)c->requests.p + first_slot, (const uint32_t*)c->request_cells.p + first_slot, slot_count,
                        (IrcRequest*)out_list, out_capacity, (uint32_t*)out_count_dev, own ? (const uint32_t*)c->meta.p + IRC_META_TRACING_ALLOC_COUNT : (const uint32_t*)nullptr);
     KJ_CHECK_LAUNCH();
     return KJ_OK;
