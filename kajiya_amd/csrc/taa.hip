@@ -272,18 +272,52 @@ __global__ void __launch_bounds__(64) k_taa_filter_input_and_history(ImgH4 input
     taa_filter_history_body<1, true>(reprojected_history, filtered_history, row0, row1);
 }
 
+#ifndef KJ_TAA_PROB_TILE
+#define KJ_TAA_PROB_TILE 1
+#endif
 // input_prob.hlsl:50-108
 __global__ void __launch_bounds__(64) k_taa_input_prob(const FrameConstants* __restrict__ fc, ImgH4 filtered_input_tex, ImgH4 filtered_input_dev_tex, ImgH4 filtered_history_tex,
                                                         ImgH4 reprojection_tex, ImgH4 smooth_var_history_tex, ImgH2 velocity_history_tex, ImgH1 output_tex, int row0, int row1) {
     const int IW = output_tex.w, IH = output_tex.h;
     TILE_XY_M(IW, IH, KJ_TILES_ROWS)
+#if KJ_TAA_PROB_TILE
+    // Round 5: the 3x3 taps of the filtered input and of the reprojection map come from a 10x10 LDS tile decoded once per texel (same decode, same values)
+    // instead of nine times per pixel
+    __shared__ float4 in_tile[10 * 10];
+    __shared__ float2 rv_tile[10 * 10];
+    __shared__ float4 dev_tile[12 * 12];      // the deviation image's stride-2 3x3 taps reach two texels either side
+    {
+        const int dx0 = int(kj_tb.x) * 8 - 2, dy0 = row0 + int(kj_tb.y) * 8 - 2;
+        for (int i = lane; i < 144; i += 64) {
+            const V3 d = xyz(ld4(filtered_input_dev_tex, dx0 + i % 12, dy0 + i / 12));
+            dev_tile[i] = make_float4(d.x, d.y, d.z, 0.0f);
+        }
+        const int tx0 = int(kj_tb.x) * 8 - 1, ty0 = row0 + int(kj_tb.y) * 8 - 1;
+        for (int i = lane; i < 100; i += 64) {
+            const int tx = tx0 + i % 10, ty = ty0 + i / 10;
+            const V3 c = xyz(ld4(filtered_input_tex, tx, ty));
+            const V4 r = ld_reproj(reprojection_tex, tx, ty);
+            in_tile[i] = make_float4(c.x, c.y, c.z, 0.0f);
+            rv_tile[i] = make_float2(r.x, r.y);
+        }
+    }
+    __syncthreads();
+    const int lt = ((lane >> 3) + 1) * 10 + (lane & 7) + 1;
+#endif
     if (!in_image) return;
     const V4 its = tex_size4(IW, IH);
     V3 ivar = v3(0.0f);
 #pragma unroll
     for (int oy = -1; oy <= 1; ++oy)
 #pragma unroll
-        for (int ox = -1; ox <= 1; ++ox) ivar = vmax(ivar, xyz(ld4(filtered_input_dev_tex, x + ox * 2, y + oy * 2)));
+        for (int ox = -1; ox <= 1; ++ox) {
+#if KJ_TAA_PROB_TILE
+            const float4 td = dev_tile[((lane >> 3) + 2 + oy * 2) * 12 + (lane & 7) + 2 + ox * 2];
+            ivar = vmax(ivar, V3{td.x, td.y, td.z});
+#else
+            ivar = vmax(ivar, xyz(ld4(filtered_input_dev_tex, x + ox * 2, y + oy * 2)));
+#endif
+        }
     ivar = ivar * ivar;
     const V2 input_uv{(float(x) + fc->view_constants.sample_offset_pixels[0]) * its.z, (float(y) + fc->view_constants.sample_offset_pixels[1]) * its.w};
     const V4 closest_history = unpack_rgba16f(sample_nearest_clamp(filtered_history_tex, input_uv));
@@ -298,8 +332,14 @@ __global__ void __launch_bounds__(64) k_taa_input_prob(const FrameConstants* __r
     for (int oy = -1; oy <= 1; ++oy)
 #pragma unroll
         for (int ox = -1; ox <= 1; ++ox) {
+#if KJ_TAA_PROB_TILE
+            const float4 ti = in_tile[lt + oy * 10 + ox]; const float2 tr = rv_tile[lt + oy * 10 + ox];
+            const V3 idiff = V3{ti.x, ti.y, ti.z} - xyz(closest_history);
+            const V2 rv{tr.x, tr.y};
+#else
             const V3 idiff = xyz(ld4(filtered_input_tex, x + ox, y + oy)) - xyz(closest_history);
             const V4 rv = ld_reproj(reprojection_tex, x + ox, y + oy);
+#endif
             const V2 q{(rv.x - closest_vel.x) * rcp_fast(fmaxf(1.0f, fabsf(rv.x + closest_vel.x))), (rv.y - closest_vel.y) * rcp_fast(fmaxf(1.0f, fabsf(rv.y + closest_vel.y)))};
             // (results below 2^-126 come out as 0: the image is fp16)
             const float prob = exp2_fast(-1.0f * length_fast(idiff * idiff * inv_var) - 1000.0f * length_fast(q));
