@@ -37,7 +37,7 @@ typedef Img<float> ImgF32;
 
 // taa_common.hlsl (TAA_NONLINEARITY_TYPE 1, TAA_COLOR_MAPPING_MODE 1)
 #ifndef KJ_TAA_NR_MASK
-#define KJ_TAA_NR_MASK 31
+#define KJ_TAA_NR_MASK (31 | 512)
 #endif
 // KJ_TAA_NR_MASK (default: all groups on) switches groups of quotients / roots back to the IEEE sequences: what the round-4 A/B runs and the bisection that found the one
 // site that has to stay IEEE (catmull_rom_5tap_history's last line) were built with (scripts/archive/r04_taa_bisect.sh, profiles/r04_ab_runs.md)
@@ -173,7 +173,9 @@ KJ_D void taa_filter_input_body(const ImgH4& input_tex, const ImgF32& depth_tex,
             const float4 t = tile[lt + yy * 10 + xx];
             s[i] = V3{t.x, t.y, t.z};
             float w = 1;
-            w *= exp2_fast(-fminf(16.0f, depth_scale * inverse_depth_relative_diff(center_depth, t.w)));     // >= 2^-16: same bits as exp2f
+            // inverse_depth_relative_diff(center, tap): both operands are >= 1e-20 and finite, the quotient is a normal number: div_nr's domain (round 5; 9 IEEE sequences per pixel before)
+            const float depth_diff = ((KJ_TAA_NR_MASK) & 512) ? fabsf(div_nr(fmaxf(1e-20f, center_depth), fmaxf(1e-20f, t.w)) - 1.0f) : inverse_depth_relative_diff(center_depth, t.w);
+            w *= exp2_fast(-fminf(16.0f, depth_scale * depth_diff));     // >= 2^-16: same bits as exp2f
             w *= distance_w;
             wd[i] = w;
         }
@@ -379,6 +381,7 @@ __global__ void __launch_bounds__(64) k_taa_filter_prob2(ImgH1 input_tex, ImgH1 
 __global__ void __launch_bounds__(256) k_taa_filter_prob_both(ImgH1 input_tex, ImgH1 prob1_tex, ImgH1 output_tex) {
     __shared__ float s_in[26 * 26];
     __shared__ float s_p1[24 * 24];
+    __shared__ float s_e1[24 * 24];      // exp2(-clamp(10 p, 0, 100)) of every staged probability, once per texel instead of once per tap (25 taps read each texel; round 5)
     const int W = output_tex.w, H = output_tex.h;
     const int tid = int(threadIdx.x);
     const uint2 tb = tile_order<KJ_TILES_ROWS>();
@@ -397,6 +400,7 @@ __global__ void __launch_bounds__(256) k_taa_filter_prob_both(ImgH1 input_tex, I
                 for (int ox = -1; ox <= 1; ++ox) prob = fmaxf(prob, s_in[(ty + 1 + oy) * 26 + tx + 1 + ox]);
         }
         s_p1[i] = prob;
+        s_e1[i] = exp2_fast(-clampf(10.0f * prob, 0.0f, 100.0f));
     }
     __syncthreads();
     const int lx = tid & 15, ly = tid >> 4;
@@ -407,7 +411,7 @@ __global__ void __launch_bounds__(256) k_taa_filter_prob_both(ImgH1 input_tex, I
 #pragma unroll
     for (int oy = -2; oy <= 2; ++oy)
 #pragma unroll
-        for (int ox = -2; ox <= 2; ++ox) weighted += V2{exp2_fast(-clampf(10.0f * s_p1[(ly + 4 + oy * 2) * 24 + lx + 4 + ox * 2], 0.0f, 100.0f)), 1.0f};
+        for (int ox = -2; ox <= 2; ++ox) weighted += V2{s_e1[(ly + 4 + oy * 2) * 24 + lx + 4 + ox * 2], 1.0f};
     output_tex.st(x, y, f32_to_f16(fmaxf(0.0f, -1.0f / 10.0f * log2_fast(1e-30f + weighted.x / weighted.y))));
 }
 
