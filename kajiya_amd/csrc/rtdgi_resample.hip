@@ -432,7 +432,6 @@ __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __
     // LDS-staged 12x12 tile (8x8 outputs + the 5x5 stencil's halo): each texel's colour-space conversion is done once per
     // tile instead of once per tap (25x per texture): .xyz = crunched luma-chroma of the input, .w = crunched history luma.
     __shared__ float4 tile[12 * 12];
-    __shared__ float4 tile_sq[12 * 12];      // the texel's squares, for the second moment: once per texel instead of once per tap (round 5; same products, same order)
     {
         const int tx0 = int(kj_tb.x) * 8 - 2, ty0 = row0 + int(kj_tb.y) * 8 - 2;
         for (int i = lane; i < 144; i += 64) {
@@ -440,7 +439,6 @@ __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __
             const V4 n = crunch_fast(ld4(input_tex, tx, ty));
             const V4 hn = crunch_fast(ld4(history_tex, tx, ty) * history_mult);
             tile[i] = make_float4(n.x, n.y, n.z, hn.x);
-            tile_sq[i] = make_float4(n.x * n.x, n.y * n.y, n.z * n.z, 0.0f);
         }
     }
     __syncthreads();
@@ -460,9 +458,8 @@ __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __
             const V3 neigh{t.x, t.y, t.z};
             const float hist_luma = t.w;
             const float w = expf(-3.0f * float(dx * dx + dy * dy) / float((2 + 1.) * (2 + 1.)));
-            const float4 tq = tile_sq[lt + dy * 12 + dx];
             vsum += neigh * w;
-            vsum2 += V3{tq.x, tq.y, tq.z} * w;
+            vsum2 += neigh * neigh * w;      // (the squares from a second LDS tile, once per texel: measured 51 -> 75 us at 1080p, round 5 -- the kernel is LDS-bound on its 25 tile reads; reverted)
             wsum += w;
             hist_vsum += hist_luma * w;
         }
