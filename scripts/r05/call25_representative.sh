@@ -7,7 +7,7 @@ python bench.py --no-also --no-cpu-baseline --steps 20 --warmup 10 > $O/probe.js
 TAA=$(python -c "import json; print(json.loads(open('$O/probe.json').read().strip().split(chr(10))[-1])['segment_ms']['taa'])")
 echo "probe: taa segment $TAA ms"
 python - <<PY || exit 0
-import sys; sys.exit(0 if float("$TAA") < 0.262 else 1)
+import sys; sys.exit(0 if float("$TAA") < 0.27 else 1)
 PY
 ( time python bench.py ) > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --no-also --no-cpu-baseline --no-overlap > $O/bench_1080p_serial.json 2> /dev/null
