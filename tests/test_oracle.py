@@ -809,3 +809,38 @@ def test_texel_code_division_through_the_reciprocal_is_exact():
             q = np.float32(n * r)
             res = np.float32(libm.fmaf(libm.fmaf(-d, q, n), r, q))
             assert res.tobytes() == np.float32(n / d).tobytes(), (maxv, v, res, n / d)
+
+
+def test_ircache_chain_schedule_differs_from_three_launches_only_in_cross_entry_reads(oracle):
+    """The two deterministic schedules of the cache's three ray passes the oracle restates (okj_ircache_set_chain_schedule; product: kj_ircache_set_ray_pass_schedule):
+    the chain -- one launch, every slot's own passes in order, lookups of validation AND tracing read the state before the passes -- and three launches with a snapshot
+    refreshed between validation and tracing. Everything that does not go through a lookup's read of ANOTHER entry's radiance is the same in both: which cells are
+    occupied, by which entries, the rays traced. The SH sums differ by what tracing's lookups saw of this frame's validation, a second-order term."""
+    import ctypes as C
+    from kajiya_amd import frame, scenes
+    W = H = 64
+    desc = scenes.cornell_box()
+    pipes = []
+    for chain in (True, False):
+        op = oracle.OraclePipeline(oracle.OracleScene(desc), W, H, use_ircache=True)
+        op.ircache_set_deferred(True)
+        op.ircache_set_chain_schedule(chain)
+        pipes.append(op)
+    fs = frame.FrameState((W, H))
+    fs.ircache_enabled = True
+    for i in range(8):
+        fc = fs.prepare_frame_constants(frame.orbit_camera(i, (W, H), center=(0.0, 1.0, 0.0), radius=6.5, height=0.0, rate=0.02))
+        fs.retire_frame()
+        for op in pipes:
+            op.render_inputs(fc); op.reprojection(fc); op.gi_frame(fc)
+        a, b = pipes
+        assert a.ircache_ray_counts()[0] == b.ircache_ray_counts()[0], i
+        for name in ("grid_meta0", "grid_meta1", "entry_cell", "life", "meta"):
+            assert np.array_equal(a.ircache_buffer(name, np.uint8), b.ircache_buffer(name, np.uint8)), (i, name)
+    irr_a = pipes[0].ircache_buffer("irradiance", np.float32).astype(np.float64)
+    irr_b = pipes[1].ircache_buffer("irradiance", np.float32).astype(np.float64)
+    alloc = int(pipes[0].ircache_buffer("meta", np.uint32)[3])
+    assert alloc > 30
+    rel = float(np.sqrt(((irr_a - irr_b) ** 2).sum() / max(1e-30, (irr_b ** 2).sum())))
+    print(f"chain vs three-launch schedule after 8 frames: {alloc} entries, SH rel-L2 {rel:.3e}")
+    assert 0.0 < rel < 0.1, rel      # not identical (tracing's lookups read different snapshots), and close
