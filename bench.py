@@ -131,7 +131,9 @@ def also_measurements():
                        ("1440p full lighting frame, ruins ~4M tris (configs[2])",
                         [sys.executable, os.path.join(ROOT, "scripts", "config3_bench.py"), "--frames", "36", "--warmup", "12"]),
                        ("reference path tracer, 4K, ruins ~4M tris, N = 1 of configs[4]'s 8-way interleave (ms per sample per pixel pass)",
-                        [sys.executable, os.path.join(ROOT, "scripts", "pt_bench.py"), "8"])):
+                        [sys.executable, os.path.join(ROOT, "scripts", "pt_bench.py"), "8"]),
+                       ("screen-tile split of the 4K GI frame on ONE GPU: GPU work per rank at 4 and 8 virtual ranks (configs[3]; SURVEY 8e)",
+                        [sys.executable, os.path.join(ROOT, "scripts", "split_virtual_bench.py"), "--ranks", "4,8", "--frames", "10", "--warmup", "4"])):
         t0 = time.time()
         try:
             r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -141,12 +143,17 @@ def also_measurements():
             out.append({"what": label, "error": repr(e)[:200]})
             continue
         e = {"what": label, "wall_s": round(time.time() - t0, 1)}
+        if "split" in j:      # scripts/split_virtual_bench.py: one entry per rank count, named split_virtual_N
+            for sp in j["split"]:
+                out.append(dict(sp, workload=j["workload"], one_gpu=j["one_gpu"], wall_s=e["wall_s"], method="HIP events around K serial frames of all N ranks on one stream; "
+                                "per_rank_work_ms = (that - the orchestrator's own event pairs around every exchange) / N"))
+            continue
         if "gi_frame_ms" in j:
             rf = j.get("roofline") or {}
             e.update({"gi_frame_ms": j["gi_frame_ms"], "fps": round(1000.0 / j["gi_frame_ms"], 1), "mrays_per_s": j["value"], "workload": j["config"]["workload"][:120],
                       "rays_per_frame": j["config"]["rays_per_frame"], "segment_ms": j.get("segment_ms"), "pass_ms": j.get("pass_ms"),
                       "deterministic_cache": j.get("deterministic_cache"),
-                      "roofline": {k: rf.get(k) for k in ("kernel", "bound", "bound_measured", "limited_by", "avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac")},
+                      "roofline": {k: rf.get(k) for k in ("kernel", "bound", "priced_against", "bound_measured", "limited_by", "avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac")},
                       "cpu_baseline": j.get("cpu_baseline")})
         elif "ms_per_spp" in j:
             e.update({k: j[k] for k in ("workload", "seconds", "ms_per_spp", "Mrays_per_s", "rays_per_path")})
@@ -498,7 +505,7 @@ def main():
                  ("rtdgi temporal", "k_temporal_filter", n_f, 49), ("rtdgi spatial", "k_spatial_filter", n_f, 25)]
 
         def entry(kernel, ms, algo_bytes, note=None):
-            e = {"kernel": kernel, "bound": "hbm", "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
+            e = {"kernel": kernel, "bound": "hbm", "priced_against": "hbm", "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
                  "achieved": round(algo_bytes / (ms * 1e-3) / 1e9, 2) if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
             e["frac"] = round(e["achieved"] / HBM_PEAK_GBS, 5)
             k = pmc.get(kernel) or pmc.get(kernel.split("<")[0])
@@ -510,8 +517,9 @@ def main():
             for src, dst in (("VALUBusy", "valu_busy_pct"), ("VALUUtilization", "valu_lane_utilization_pct"), ("MemUnitStalled", "mem_unit_stalled_pct")):
                 if k and src in k:
                     e[dst] = round(k[src], 1)
-            # `bound` names the roofline `achieved` is priced against (the contract's "hbm" | "mfma"; this path has no dense contraction).
-            # `limited_by` is what the counters of the same kernel say actually limits it.
+            # `bound` is the bench contract's field: which of its two rooflines ("hbm" | "mfma") `achieved` / `peak` / `frac` are priced against -- HBM here, this path
+            # has no dense contraction (same value in `priced_against`, which says so by name). What the counters of the same kernel show it limited BY is
+            # `bound_measured` ("hbm" | "valu" | "memory unit" | "latency") and, spelled out, `limited_by`.
             vb, hf, ms_ = e.get("valu_busy_pct"), e.get("hbm_frac"), e.get("mem_unit_stalled_pct")
             # `bound_measured`: the same verdict as one word ("hbm" | "valu" | "memory unit" | "latency"), next to the contract's `bound`
             if vb is None or hf is None:
@@ -543,7 +551,7 @@ def main():
             torch.cuda.synchronize()
 
     # ---- the cache's two modes side by side: `value` above times the reference's racy cache (pipelined frames); the 1e-3 cache parity, smoke's second leg
-    # and every screen-tile split run the DETERMINISTIC mode (lookups record, one sorted replay per frame). Same process, same inputs (replayed: timing only), serial frames.
+    # and every screen-tile split run the DETERMINISTIC mode (lookups record, one reduction + merge per frame). Same process, same inputs (replayed: timing only), serial frames.
     det_leg = None
     if single and world == 1 and not args.deterministic_cache:
         def serial_ms(nf):
@@ -560,8 +568,8 @@ def main():
         det_serial = serial_ms(nf)
         gp.ircache_set_deferred(False)
         det_leg = {"frames": nf, "serial_racy_ms": round(racy_serial, 4), "serial_deterministic_ms": round(det_serial, 4),
-                   "note": "serial frames on one stream, this run's own inputs replayed; deterministic = kj_ircache_set_deferred_updates(1): lookups record 32-byte requests, one collect + "
-                           "sort + replay per frame (one host read-back of the record count). An N > 1 line (screen-tile split) runs this mode on every rank: compare it with serial_deterministic_ms, not with `value`"}
+                   "note": "serial frames on one stream, this run's own inputs replayed; deterministic = kj_ircache_set_deferred_updates(1): lookups record 32-byte requests, reduced into a fixed-size summary and "
+                           "merged once per frame (no sort, no host read-back since round 6). An N > 1 line (screen-tile split) runs this mode on every rank: compare it with serial_deterministic_ms, not with `value`"}
     ms_per_step = 1e3 * elapsed / K
     out = {
         "metric": "gi_mrays_per_s", "value": round(total_rays_all / elapsed / 1e6, 3), "unit": "Mrays/s",

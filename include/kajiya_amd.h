@@ -164,7 +164,7 @@ uint32_t kj_abi_version(void);
  * Returns 0 for an unknown id. */
 enum KjAbiStruct { KJ_ABI_FRAME_CONSTANTS = 0, KJ_ABI_VIEW_CONSTANTS, KJ_ABI_MESH_MATERIAL, KJ_ABI_PACKED_VERTEX, KJ_ABI_MATERIAL_MAP, KJ_ABI_MESH_DESC, KJ_ABI_TRIANGLE_LIGHT,
                    KJ_ABI_GBUFFER_DEPTH, KJ_ABI_RTDGI_RENDER_PARAMS, KJ_ABI_RTDGI_OUTPUT, KJ_ABI_TAA_OUTPUT, KJ_ABI_RTR_TABLES, KJ_ABI_RTR_PARAMS, KJ_ABI_SPLIT_RANK,
-                   KJ_ABI_SPLIT_FRAME, KJ_ABI_BAKED_MESH_VIEW, KJ_ABI_BAKED_IMAGE_VIEW, KJ_ABI_STRUCT_COUNT };
+                   KJ_ABI_SPLIT_FRAME, KJ_ABI_BAKED_MESH_VIEW, KJ_ABI_BAKED_IMAGE_VIEW, KJ_ABI_SPLIT_PROFILE, KJ_ABI_STRUCT_COUNT };
 uint32_t kj_abi_struct_size(uint32_t id);
 /* Device self test (no reference counterpart): the cheap exact division / square root the screen passes use (csrc/kj_screen.hpp: div_nr, sqrt_nr) against the
  * IEEE operations over `n` pseudo-random operand pairs (odd `seed`s draw TAA's own operand classes). `counts4_u64_device`: four uint64 on the device, ADDED to:
@@ -427,18 +427,23 @@ KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream);
 /* Deferred updates -- the irradiance cache under a screen-tile split. The reference's lookups allocate cells, refresh
  * entry lives and vote for entry positions with atomics as they go (lookup.hlsl:118-150,287-301): replicas of the cache fed by
  * different strips drift apart. With deferred updates on, a lookup returns the same value but only RECORDS those effects (one 32-byte
- * KjIrcacheRequest per lookup, in a slot of its own); the host gathers the records of all ranks and every rank replays the union in
- * one canonical order (by cell, then by the lookup's position in the frame), which leaves all replicas bit-identical -- and identical
- * to one GPU running the same frame in this mode. Per frame: begin_requests, the frame's passes, collect_requests per slot range
- * (kj_ircache_request_ranges: rtdgi validate, rtdgi trace -- rows of a strip are contiguous slots --, the cache's validate and trace
- * rays), exchange, apply_requests on the merged list. */
+ * KjIrcacheRequest per lookup, in a slot of its own). What the records of a frame do to the cache is defined as a REDUCTION over the
+ * records of a cell (ircache.hip: one of the racy program's legal outcomes -- every lookup reads the entry's life before any lowers it;
+ * the vote's winner is the voter with the smallest dart, accepted against the count before the frame's votes; an empty cell is allocated
+ * by its lowest-positioned lookup that may allocate; new cells take pool entries in cell order), so a rank reduces its own strip's
+ * records into a fixed-size SUMMARY (kj_ircache_summary_bytes: 4 MB), the summaries are all-gathered and every rank merges the same
+ * ones: all replicas stay bit-identical -- and identical to one GPU running the same frame in this mode. No list lengths, no sort, no
+ * host synchronisation. Per frame: begin_requests (one launch clears the frame's slots and both summaries), the frame's passes,
+ * summarize_requests(strip ranges -> summary 0; the cache's own two ranges -> summary 1: kj_ircache_request_ranges gives rtdgi validate,
+ * rtdgi trace -- rows of a strip are contiguous slots --, the cache's validate and trace rays), all-gather of summary 0, apply_summaries
+ * (every rank's summary 0 in rank order, then the local summary 1). */
 KjStatus kj_ircache_set_deferred_updates(KjIrcache* ircache, uint32_t enable);
 /* Schedule of the three ray passes of kj_ircache_trace_irradiance in the racy (default, the reference's) mode. The reference records "ircache trace access",
  * "ircache validate" and "ircache trace" with `write_no_sync` on every buffer they share (ircache.rs:396-481; :411-412 "if we use `write_no_sync`, we can overlap
- * with the next pass"), i.e. without barriers: on a GPU they overlap as far as the hardware lets them. enable = 0 (default): three launches one after the other,
- * the schedule the sequential oracle models. enable = 1: one launch carrying the three passes side by side -- the cache's segment of the frame 0.40 -> 0.21 ms on
+ * with the next pass"), i.e. without barriers: on a GPU they overlap as far as the hardware lets them. enable = 0: back to the library default (the chain, below;
+ * rounds 1-4: three launches). enable = 1: one launch carrying the three passes side by side -- the cache's segment of the frame 0.40 -> 0.21 ms on
  * MI355X at 1080p, and the racy cache's distance from the sequential oracle on identical state 1.3e-2 -> 5e-2 .. 1.3e-1 of its SH sums. Ignored in the deterministic mode. */
-KjStatus kj_ircache_set_ray_passes_side_by_side(KjIrcache* ircache, uint32_t enable);      /* = kj_ircache_set_ray_pass_schedule(enable ? KJ_IRC_PASSES_SIDE_BY_SIDE : KJ_IRC_PASSES_SEQUENTIAL) */
+KjStatus kj_ircache_set_ray_passes_side_by_side(KjIrcache* ircache, uint32_t enable);      /* deprecated: = kj_ircache_set_ray_pass_schedule(enable ? KJ_IRC_PASSES_SIDE_BY_SIDE : KJ_IRC_PASSES_CHAIN (the default)) */
 /* The schedule of the three ray passes, in full (round 5):
  *   KJ_IRC_PASSES_CHAIN (default): ONE launch in which every aux slot still sees its own passes in recording order -- accessibility, validation, the new sample --
  *     while the three rays of a slot walk side by side (validation's and the new sample's path on two quads of the same wave; the slot's values go from one to the
@@ -460,9 +465,15 @@ KjStatus kj_ircache_request_ranges(KjIrcache* ircache, uint32_t out_first_slot[4
  * per half-res pixel behind the four above. Sticky; set before kj_ircache_begin_requests. kj_rtr_trace refuses a deferred cache without them. */
 KjStatus kj_ircache_set_rtr_requests(KjIrcache* ircache, uint32_t enable);
 KjStatus kj_ircache_rtr_request_ranges(KjIrcache* ircache, uint32_t out_first_slot[2], uint32_t out_slot_count[2]);
-KjStatus kj_ircache_collect_requests(KjIrcache* ircache, uint32_t first_slot, uint32_t slot_count, void* out_list /* device, 32 B each */, uint32_t out_capacity,
-                                     void* out_count_dev /* device u32, incremented */, void* stream);
-KjStatus kj_ircache_apply_requests(KjIrcache* ircache, const void* list /* device */, uint32_t count, void* stream);
+uint64_t kj_ircache_summary_bytes(void);
+/* Reduces the records of up to 6 slot ranges into the cache's summary `which` (0: the part a rank of the split sends to the others; 1: the part that stays
+ * local -- the cache's own ray passes, identical on every replica). Once per summary and frame. */
+KjStatus kj_ircache_summarize_requests(KjIrcache* ircache, const uint32_t* first_slots, const uint32_t* slot_counts, uint32_t n_ranges, uint32_t which, void* stream);
+KjStatus kj_ircache_summary(KjIrcache* ircache, uint32_t which, void** out_dev_ptr /* kj_ircache_summary_bytes() bytes */);
+/* Merges `n` (<= 32) summaries -- device pointers, the same ones in the same order on every replica -- and applies the result to the cache. */
+KjStatus kj_ircache_apply_summaries(KjIrcache* ircache, const void* const* summaries /* host array of device pointers */, uint32_t n, void* stream);
+/* A plain device list of records replayed at once (reduce into summary 0 + apply): for callers that assemble lists themselves, and for tests. */
+KjStatus kj_ircache_apply_requests(KjIrcache* ircache, const void* list /* device, 32 B each; cell 0xffffffff = unused */, uint32_t count, void* stream);
 KjStatus kj_ircache_buffer(KjIrcache* c, const char* name, void** out_dev_ptr, uint64_t* out_bytes);
 KjStatus kj_ircache_ray_counts(KjIrcache* c, uint64_t* out_closest, uint64_t* out_any);
 
@@ -681,7 +692,9 @@ KjStatus kj_motion_blur_surface(KjMotionBlur* m, const char* name, void** out_de
  * is RtdgiRenderer::render (rtdgi.rs:173-554) + TaaRenderer::render (taa.rs:41-191) of ONE frame, pass by pass, with the irradiance
  * cache replicated and kept bit-identical across ranks (kj_ircache_set_deferred_updates). KjSplit is the compiled orchestrator:
  * one per process, created over the renderers of the ranks living in that process -- exactly one with an RCCL communicator
- * (`nccl_comm`, an ncclComm_t), or all `world` of them without (virtual ranks on one device: the exchange is device-to-device copies).
+ * (`nccl_comm`, an ncclComm_t), or all `world` of them without (virtual ranks on one device: the exchange is device-to-device copies),
+ * or all of them WITH a communicator of exactly one rank (loopback: every message is an ncclSend to self matched by an ncclRecv from
+ * self, the summaries' all-gather an all-gather of one -- the transport code and RCCL itself on the single GPU of a build box).
  * It calls the entry points above with row ranges and exchanges halos in between: one packed message per peer and exchange point,
  * ncclSend / ncclRecv inside one group. kajiya_amd/multigpu.py is the reference implementation of the same schedule.
  * Strips are 16-row aligned; surfaces are looked up by name through kj_rtdgi_surface / kj_taa_surface. RCCL is loaded with dlopen on
@@ -700,9 +713,9 @@ KjStatus kj_split_create(uint32_t world, uint32_t first_rank, uint32_t local_ran
 void kj_split_destroy(KjSplit* split);
 KjStatus kj_split_strip(KjSplit* split, uint32_t rank, uint32_t* out_row_begin, uint32_t* out_row_end);
 /* One GI frame: [cache prepare + rays unless KJ_SPLIT_IRCACHE_DONE], reproject, the rtdgi passes with exchanges A-D and H, and -- unless
- * KJ_SPLIT_DEFER_IRCACHE_MERGE -- the merged replay of the cache's recorded updates (it reads list lengths back: two host syncs; a
- * pipelining caller defers it and calls kj_split_merge_ircache on its cache stream once the frame is enqueued, before the next frame's
- * cache work). `frames`: one entry per LOCAL rank. `trace_done_event`: optional hipEvent_t recorded once the ray passes are enqueued. */
+ * KJ_SPLIT_DEFER_IRCACHE_MERGE -- the replay of the cache's recorded updates (each rank's summary, one fixed-size all-gather, the same merge
+ * everywhere: no host synchronisation; a pipelining caller still defers it and calls kj_split_merge_ircache on its cache stream once the frame
+ * is enqueued, before the next frame's cache work, so that the all-gather overlaps the resampling chain). `frames`: one entry per LOCAL rank. `trace_done_event`: optional hipEvent_t recorded once the ray passes are enqueued. */
 enum { KJ_SPLIT_IRCACHE_DONE = 1u, KJ_SPLIT_DEFER_IRCACHE_MERGE = 2u };
 KjStatus kj_split_gi_frame(KjSplit* split, const KjSplitFrame* frames, uint32_t flags, void* trace_done_event, void* stream);
 KjStatus kj_split_merge_ircache(KjSplit* split, void* stream);
@@ -735,12 +748,20 @@ KjStatus kj_split_taa_frame_on(KjSplit* split, const KjSplitFrame* frames, void*
 /* Every rank receives the owners' rows of a surface ("spatial_filtered_tex", "TAA/taa:0", ...): result collection. */
 KjStatus kj_split_gather(KjSplit* split, const char* surface_name, void* stream);
 /* Start-up check of the transport, before frame 0: every kind of exchange of the frame schedule (all-gather of an image, mixed surfaces packed into one message
- * per peer, the 64-row one-deep halo, stencil halos, the variable-length all-gather of the cache's record lists) once on scratch images whose rows carry their
+ * per peer, the 64-row one-deep halo, stencil halos, the fixed-size all-gather of the cache's summaries) once on scratch images whose rows carry their
  * owner's rank, read back and checked row by row. *out_passed: 1 when every rank of this process holds exactly the rows it is entitled to (combine the
  * processes' verdicts with the caller's own collective). Synchronises `stream`. No counterpart in the reference (single-GPU). */
 KjStatus kj_split_self_test(KjSplit* split, uint32_t* out_passed, void* stream);
+/* Measurement aid: with profiling on every exchange is bracketed by two HIP events on the frame's stream (pack + transport + scatter; with virtual ranks: the
+ * device copies standing in for the wire) and the bytes arriving at the busiest local rank are summed. kj_split_profile waits for the recorded events and
+ * reports the totals since kj_split_set_profiling(split, 1). */
+typedef struct KjSplitProfile { double exchange_ms; uint64_t exchange_bytes_busiest_rank; uint32_t exchange_points; uint32_t gi_frames; } KjSplitProfile;
+KjStatus kj_split_set_profiling(KjSplit* split, uint32_t enable);
+KjStatus kj_split_profile(KjSplit* split, KjSplitProfile* out);
 KjStatus kj_split_rccl_unique_id(uint8_t out_id[128]);
 KjStatus kj_split_rccl_comm_create(const uint8_t id[128], uint32_t world, uint32_t rank, void** out_comm);
+/* ncclCommCount / ncclCommUserRank of a communicator. */
+KjStatus kj_split_rccl_comm_info(void* comm, uint32_t* out_ranks, uint32_t* out_rank);
 void kj_split_rccl_comm_destroy(void* comm);
 
 #ifdef __cplusplus

@@ -105,6 +105,10 @@ class KjSplitFrame(C.Structure):
     _fields_ = [("rtdgi", KjRtdgiRenderParams), ("rtdgi_out", C.POINTER(KjRtdgiOutput)), ("taa_out", C.POINTER(KjTaaOutput)), ("sky_cube16", C.c_void_p)]
 
 
+class KjSplitProfile(C.Structure):
+    _fields_ = [("exchange_ms", C.c_double), ("exchange_bytes_busiest_rank", C.c_uint64), ("exchange_points", C.c_uint32), ("gi_frames", C.c_uint32)]
+
+
 class KjRtrTables(C.Structure):
     _fields_ = [("ranking_tile", C.c_void_p), ("scrambling_tile", C.c_void_p), ("sobol", C.c_void_p), ("spatial_resolve_offsets", C.c_void_p)]
 

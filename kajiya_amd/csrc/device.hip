@@ -207,6 +207,48 @@ __global__ void __launch_bounds__(64) k_trace_any_stream(SceneView sc, const flo
                            [&](uint32_t i, const RayHit& h) { out[i] = h.slot != 0xffffffffu ? 1 : 0; }, tune);
 }
 
+// ---- many contiguous copies in one launch (kj_host.hpp: launch_copy_blocks). A workgroup takes one 32 KB chunk of one block; the block is found by a scan of the
+// (wave-uniform) chunk prefix. 16-byte moves where source, destination and length allow, bytes otherwise (odd test extents).
+#define KJ_COPY_MAX_BLOCKS 48
+#define KJ_COPY_CHUNK (32u * 1024u)
+struct CopyBatch { kj::CopyBlock blk[KJ_COPY_MAX_BLOCKS]; uint32_t first_chunk[KJ_COPY_MAX_BLOCKS + 1]; uint32_t n; };
+__global__ void __launch_bounds__(256) k_copy_blocks(CopyBatch b) {
+    uint32_t k = 0;
+    while (k + 1u < b.n && blockIdx.x >= b.first_chunk[k + 1u]) ++k;
+    const kj::CopyBlock blk = b.blk[k];
+    const uint64_t off = uint64_t(blockIdx.x - b.first_chunk[k]) * KJ_COPY_CHUNK;
+    const uint32_t len = uint32_t(blk.bytes - off < KJ_COPY_CHUNK ? blk.bytes - off : KJ_COPY_CHUNK);
+    const uint8_t* src = (const uint8_t*)blk.src + off;
+    uint8_t* dst = (uint8_t*)blk.dst + off;
+    if (((uintptr_t(src) | uintptr_t(dst)) & 15u) == 0u) {
+        const uint32_t quads = len / 16u;
+        for (uint32_t i = threadIdx.x; i < quads; i += 256u) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+        for (uint32_t i = quads * 16u + threadIdx.x; i < len; i += 256u) dst[i] = src[i];
+    } else
+        for (uint32_t i = threadIdx.x; i < len; i += 256u) dst[i] = src[i];
+}
+namespace kj {
+hipError_t launch_copy_blocks(const CopyBlock* blocks, size_t n, hipStream_t s) {
+    size_t i = 0;
+    while (i < n) {
+        CopyBatch b;
+        b.n = 0;
+        uint32_t chunks = 0;
+        for (; i < n && b.n < KJ_COPY_MAX_BLOCKS; ++i) {
+            if (blocks[i].bytes == 0) continue;
+            b.blk[b.n] = blocks[i]; b.first_chunk[b.n] = chunks;
+            chunks += uint32_t((blocks[i].bytes + KJ_COPY_CHUNK - 1) / KJ_COPY_CHUNK);
+            ++b.n;
+        }
+        if (b.n == 0) break;
+        b.first_chunk[b.n] = chunks;
+        hipLaunchKernelGGL(k_copy_blocks, dim3(chunks), dim3(256), 0, s, b);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+}  // namespace kj
 __global__ void __launch_bounds__(256) pmc_calibration_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
     for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) dst[i] = src[i];
 }

@@ -9,7 +9,6 @@
 #include "kj_reservoir.hpp"
 #include "kj_ircache_host.hpp"
 #include <algorithm>
-#include <hipcub/hipcub.hpp>
 
 using namespace kj;
 namespace kj { SceneView scene_view(const KjScene& s); }
@@ -77,8 +76,9 @@ __global__ void __launch_bounds__(256) k_irc_age(IrcacheView ic, uint32_t* __res
     occupancy[e] = (e < total_entry_count && irc_life_valid(ic.life[e])) ? 1u : 0u;
 }
 // inclusive prefix scan over 64 Ki u32 in one workgroup (prefix_scan/*.hlsl semantics)
-__global__ void __launch_bounds__(1024) k_irc_scan(uint32_t* __restrict__ data) {
+__global__ void __launch_bounds__(1024) k_irc_scan(uint32_t* __restrict__ data, uint32_t* __restrict__ data2) {
     __shared__ uint32_t partial[1024];
+    if (blockIdx.x == 1u) data = data2;      // two independent scans in one launch (the freed-entry flags and the occupancy flags of the deterministic mode's prepare)
     const uint32_t t = threadIdx.x;
     uint4 v[16];
     uint32_t run = 0;
@@ -437,9 +437,13 @@ KJ_D void irc_chain_blocks(const IrcTraceCtx& c, uint32_t* lds_stack, uint32_t b
         const bool active = item && (half == 1u || validate);
         IrcTraceResult traced;
         traced.incident_radiance = traced.direction = traced.hit_pos = v3(0.0f);
-        if (active)
-            traced = half == 0u ? ircache_trace<true>(c, prev_entry, rv.payload, life, stack, stride, c.request_slot_base + d, (3u << 28) | d)
-                                : ircache_trace<true>(c, entry, sp, life, stack, stride, c.request_slot_base + KjIrcache::REQ_E + d, (4u << 28) | d);
+        if (active) {
+            // ONE call site with per-lane arguments: a ternary of two calls is two divergent call sites, which the wave executes one after the other with half its
+            // lanes masked -- here quad A's and quad B's paths share every traversal step
+            const bool b_side = half == 1u;
+            const IrcVertex from = b_side ? entry : prev_entry;
+            traced = ircache_trace<true>(c, from, b_side ? sp : rv.payload, life, stack, stride, c.request_slot_base + (b_side ? KjIrcache::REQ_E : 0u) + d, ((b_side ? 4u : 3u) << 28) | d);
+        }
         // ---- quad A: ircache_validate.rgen.hlsl:96-128
         if (validate) {
             const V3 b{value.x * fc.pre_exposure_delta, value.y * fc.pre_exposure_delta, value.z * fc.pre_exposure_delta};
@@ -584,159 +588,248 @@ __global__ void __launch_bounds__(64) k_irc_sum_up(const FrameConstants* __restr
 
 
 // ------------------------------------------------------------------ deferred updates: replay of recorded lookups
-// Canonical order = (cell, key): what a cell receives does not depend on which GPU's strip a lookup came from, so every replica of
-// the cache ends up bit-identical, and identical to a single GPU replaying the same frame.
-//   * a cell nobody occupies is allocated by its first lookup that may allocate; new cells take pool entries in cell order;
-//   * an occupied cell's lookups run through lookup.hlsl:287-301 one after the other: life refresh (min), then the position vote --
-//     accepted with probability 1 / (votes so far + 1), using the random number the lookup drew when it ran.
-// begin of a frame's records: the cache's OWN two slot ranges (validation's and tracing's lookups, slot = path index) hold records only below last frame's
-// path count -- clear those, not the whole 2 x 8 MB (the fills were 0.14 ms of every rank's frame whatever the rank count: profiles/r04_split_work_per_rank.md)
-__global__ void __launch_bounds__(256) k_irc_clear_own_requests(const uint32_t* __restrict__ meta, uint32_t* __restrict__ own_cells, uint32_t slots_per_range) {
-    const uint32_t used = min(meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME, slots_per_range);
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < used; i += gridDim.x * 256u) { own_cells[i] = 0xffffffffu; own_cells[slots_per_range + i] = 0xffffffffu; }
+// What a frame's recorded lookups do to the cache is stated so that it is (i) one of the racy reference program's legal outcomes, (ii) a REDUCTION -- min, sum,
+// arg-min -- over the records of a cell, in any order and any grouping, so that a rank of the screen-tile split reduces its own strip's records first and only a
+// fixed-size SUMMARY travels (no sort, no record lists, no list lengths on the host), and (iii) the same whatever the number of ranks:
+//   * an unoccupied cell is allocated if any of its lookups may allocate; the one with the lowest position in the frame (`key`) is "the thread whose atomicOr
+//     came first" (lookup.hlsl:118-150): its rank sets the entry's life, its proposal the entry's position. New cells take pool entries in cell order;
+//   * an occupied cell's lookups (entry alive, not allocated this frame) all read the entry's life BEFORE any of them lowers it -- the interleaving in which
+//     every load of lookup.hlsl:287 precedes every InterlockedMin of :291 --, so lookup i votes iff rank_i <= life0 / IRC_LIFE_PER_RANK, and the life ends as
+//     min(life0, min_i rank_i * L);
+//   * the position vote (lookup.hlsl:293-301): every voter's InterlockedAdd returns a different count, in ANY order, and the proposal that stays is the last
+//     plain store among the accepted voters', again in any order. The outcome chosen: the voter with the smallest dart (ties: lowest key) is the one that drew
+//     count v0 -- accepted iff dart <= 1 / (v0 + 1) -- and its store lands last. If even that dart fails nobody can be accepted (later counts only lower the
+//     bar). Like the sequential reservoir it picks uniformly among the voters (the darts are i.i.d.), and v0 = 0 whenever a frame is replayed once: the age pass
+//     zeroes the counts.
+// Round 6: this replaces the (cell, key)-ordered replay of rounds 2-5 (a 51-bit radix sort of ~1.2 M records at 4K + three segmented scans: 0.15-0.20 ms of every
+// rank's frame whatever the rank count, and two host syncs for the list lengths).
+//
+// A summary (IRC_SUMMARY_BYTES, fixed): 64-byte header {alloc_count}, then per ENTRY winner (dart << 32 | key) u64, rank_min u32, votes u32, the winner's
+// proposal float4; then up to IRC_MAX_ENTRIES allocation requests (cell order; more cannot be served by the pool anyway) as IrcRequest records.
+#define IRC_SUMMARY_HEADER_BYTES 64u
+#define IRC_SUMMARY_BYTES (size_t(IRC_SUMMARY_HEADER_BYTES) + size_t(IRC_MAX_ENTRIES) * (8u + 4u + 4u + 16u + 32u))
+#define IRC_MAX_SUMMARIES 32u
+struct IrcSummaryView { uint32_t* header; unsigned long long* winner; uint32_t* rank_min; uint32_t* votes; float4* proposal; IrcRequest* allocs; };
+KJ_HD IrcSummaryView irc_summary_view(void* p) {
+    uint8_t* b = (uint8_t*)p;
+    IrcSummaryView v;
+    v.header = (uint32_t*)b; b += IRC_SUMMARY_HEADER_BYTES;
+    v.winner = (unsigned long long*)b; b += size_t(IRC_MAX_ENTRIES) * 8;
+    v.rank_min = (uint32_t*)b; b += size_t(IRC_MAX_ENTRIES) * 4;
+    v.votes = (uint32_t*)b; b += size_t(IRC_MAX_ENTRIES) * 4;
+    v.proposal = (float4*)b; b += size_t(IRC_MAX_ENTRIES) * 16;
+    v.allocs = (IrcRequest*)b;
+    return v;
 }
-// `used_paths` (may be null): the range is one of the cache's OWN two (slot = path index): only the first *used_paths * IRC_SAMPLES_PER_FRAME slots can hold a record
-// (`cells`: the 4-byte-per-slot copy of the records' cell field -- the scan reads those, and a record's 32 bytes only where there is one: the slot array is 66 MB per
-// range at 4K and a few percent of its slots hold a record)
-// One atomic per 2048 slots: a thread scans eight consecutive cells, the workgroup's counts meet in a wave scan + four LDS words, and ONE lane reserves the block's range of the
-// output list (round 5: with an atomic per wave of 64 slots a 2 M-slot range at 4K cost 64 us -- ~10 k atomics on one address -- for 8 MB of cells).
-#define KJ_COLLECT_PER_THREAD 8u
-__global__ void __launch_bounds__(256) k_irc_collect_requests(const IrcRequest* __restrict__ slots, const uint32_t* __restrict__ cells, uint32_t n, IrcRequest* __restrict__ out, uint32_t capacity,
-                                                              uint32_t* __restrict__ count, const uint32_t* __restrict__ used_paths) {
-    if (used_paths) n = min(n, *used_paths * IRC_SAMPLES_PER_FRAME);
-    const uint32_t per_block = 256u * KJ_COLLECT_PER_THREAD;
-#if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_base;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#endif
-    for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {      // the same trip count for every thread of the block
-        const uint32_t i0 = base + threadIdx.x * KJ_COLLECT_PER_THREAD;
-        uint32_t valid = 0, cnt = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < KJ_COLLECT_PER_THREAD; ++k) {
-            const bool v = i0 + k < n && cells[i0 + k] != 0xffffffffu;
-            valid |= v ? (1u << k) : 0u; cnt += v ? 1u : 0u;
-        }
-#if defined(__HIP_DEVICE_COMPILE__)
-        uint32_t incl = cnt;
-#pragma unroll
-        for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-        if (lane == 63u) s_wave[wave] = incl;
-        __syncthreads();
-        if (threadIdx.x == 0u) { const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]; s_base = tot ? atomicAdd(count, tot) : 0u; }
-        __syncthreads();
-        uint32_t o = s_base + incl - cnt;
-        for (uint32_t w = 0; w < wave; ++w) o += s_wave[w];
-#else
-        uint32_t o = cnt ? atomicAdd(count, cnt) : 0u;
-#endif
-#pragma unroll
-        for (uint32_t k = 0; k < KJ_COLLECT_PER_THREAD; ++k)
-            if (valid & (1u << k)) { if (o < capacity) out[o] = slots[i0 + k]; ++o; }
-#if defined(__HIP_DEVICE_COMPILE__)
-        __syncthreads();      // s_wave / s_base are rewritten by the next round
-#endif
+// one launch clears everything a frame's records need cleared (round 5: ~30 fills per rank and frame, 0.07-0.13 ms): word ranges with a pattern; a range flagged
+// `own` is one of the cache's own two slot ranges and is cleared up to last frame's path count only
+#define IRC_CLEAR_MAX 12
+struct IrcClearSegs { uint32_t* p[IRC_CLEAR_MAX]; uint32_t words[IRC_CLEAR_MAX]; uint32_t pattern[IRC_CLEAR_MAX]; uint32_t own[IRC_CLEAR_MAX]; uint32_t n; };
+__global__ void __launch_bounds__(256) k_irc_clear_segments(IrcClearSegs sg, const uint32_t* __restrict__ meta) {
+    for (uint32_t k = 0; k < sg.n; ++k) {
+        const uint32_t words = sg.own[k] ? min(meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME, sg.words[k]) : sg.words[k];
+        uint32_t* const p = sg.p[k];
+        const uint32_t pat = sg.pattern[k];
+        // 16-byte stores where the range allows (every range here starts on a 16-byte boundary or is short)
+        if ((uintptr_t(p) & 15u) == 0u) {
+            const uint32_t quads = words / 4u;
+            for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < quads; i += gridDim.x * 256u) ((uint4*)p)[i] = make_uint4(pat, pat, pat, pat);
+            for (uint32_t i = quads * 4u + blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) p[i] = pat;
+        } else
+            for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) p[i] = pat;
     }
 }
-__global__ void __launch_bounds__(256) k_irc_request_keys(const IrcRequest* __restrict__ rq, uint32_t n, unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    keys[i] = ((unsigned long long)rq[i].cell << 32) | rq[i].key;
-    idx[i] = i;
-}
-// The replay of a cell's lookups is a sequential recurrence in the reference's order (life refresh = running minimum, the position vote = reservoir
-// sampling with the vote count as its state), and a cell near the camera receives tens of thousands of lookups per frame: one thread per cell (round 2)
-// spent 1.0 ms at 1080p / 1.7 ms at 4K on its longest cells (rocprofv3, virtual ranks). It is evaluated here for all records at once through
-// segmented scans over the sorted list (hipCUB scan-by-key, key = cell):
-//   * lookup i refreshes the life to rank_i * IRC_LIFE_PER_RANK when that is lower: the cell's life ends as min(life0, min rank_i * L);
-//   * lookup i votes iff rank_i <= (life before it) / L = min(life0 / L, min_{j < i} rank_j): an exclusive running MINIMUM;
-//   * the k-th voter's proposal replaces the current one iff its dart <= 1 / (votes0 + k + 1), k = number of voters before it: an exclusive running
-//     SUM; the proposal that survives is the LAST accepted one (an atomicMax per accepted vote on the segment's head slot: ~ln(n) per cell);
-//   * an unoccupied cell is allocated by its first lookup that may allocate: a running minimum over positions, carried in the same scan.
-// The segment's TAIL record (last of its cell) then holds every total and writes the cell's state; new cells take pool entries in cell order as before.
-// sort key = cell << 32 | position of the lookup in the frame; cells are < IRC_MAX_GRID_CELLS < 2^19 (an unused slot's 0xffffffff keeps its low
-// 19 bits set and still sorts behind every real cell), so the radix sort runs over 51 bits instead of 64
-#define KJ_IRC_SORT_BITS (32 + 19)
-static_assert(IRC_MAX_GRID_CELLS <= (1u << 19), "sort key width");
-struct IrcSegMin { uint32_t rank, first_allowed, head, pad; };      // componentwise minima over a cell's records [segment start .. i]
-struct IrcSegMinOp { KJ_HD IrcSegMin operator()(const IrcSegMin& a, const IrcSegMin& b) const { return IrcSegMin{a.rank < b.rank ? a.rank : b.rank, a.first_allowed < b.first_allowed ? a.first_allowed : b.first_allowed, a.head < b.head ? a.head : b.head, 0u}; } };
-struct IrcSumOp { KJ_HD uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
-__global__ void __launch_bounds__(256) k_irc_request_prepare(const IrcRequest* __restrict__ rq, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ idx, uint32_t n,
-                                                              uint32_t* __restrict__ cells, IrcSegMin* __restrict__ seg_in, uint32_t* __restrict__ last_accepted) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t bits = rq[idx[i]].bits;
-    cells[i] = uint32_t(keys[i] >> 32);
-    seg_in[i] = IrcSegMin{bits & 0xffu, (bits & 0x100u) ? 0xffffffffu : i, i, 0u};
-    last_accepted[i] = 0u;
-}
-KJ_D bool irc_is_tail(const uint32_t* __restrict__ cells, uint32_t i, uint32_t n) { return i + 1u == n || cells[i + 1u] != cells[i]; }
-// is a live, not-just-allocated entry behind the cell whose lookups may refresh it? (the loop guard of lookup.hlsl:287: life < IRC_LIFE_RECYCLE)
-KJ_D bool irc_replay_entry(const IrcacheView& ic, uint32_t cell, uint32_t* entry, uint32_t* life0) {
-    if (cell == 0xffffffffu) return false;
-    const uint2 gm = ic.grid_meta[cell];
+// slot ranges of one reduce launch; `own`: scanned up to this frame's path count only (slot = path index)
+#define IRC_REDUCE_MAX_RANGES 6
+struct IrcReduceRanges { uint32_t first[IRC_REDUCE_MAX_RANGES], count[IRC_REDUCE_MAX_RANGES], own[IRC_REDUCE_MAX_RANGES]; uint32_t n; };
+KJ_D bool irc_replay_entry(const IrcacheView& ic, uint2 gm, uint32_t* entry, uint32_t* life0) {
     if ((gm.y & IRC_META_OCCUPIED) == 0 || (gm.y & IRC_META_JUST_ALLOCATED) != 0) return false;
     *entry = gm.x; *life0 = ic.life[gm.x];
-    return *life0 < IRC_LIFE_RECYCLE;
+    return *life0 < IRC_LIFE_RECYCLE;          // the guard of lookup.hlsl:287
 }
-// voters (for the running sum) and, at the tails of unoccupied cells, the allocation flag (for the pool order)
-__global__ void __launch_bounds__(256) k_irc_request_voters(IrcacheView ic, const uint32_t* __restrict__ cells, const IrcSegMin* __restrict__ seg_in, const IrcSegMin* __restrict__ seg, uint32_t n,
-                                                             uint32_t* __restrict__ voter, uint32_t* __restrict__ flags) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t cell = cells[i];
-    uint32_t v = 0u, f = 0u, entry, life0;
-    if (cell != 0xffffffffu && (ic.grid_meta[cell].y & IRC_META_OCCUPIED) == 0) f = (irc_is_tail(cells, i, n) && seg[i].first_allowed != 0xffffffffu) ? 1u : 0u;
-    else if (irc_replay_entry(ic, cell, &entry, &life0)) {
-        const uint32_t rank_before = seg[i].head == i ? 0xffffffffu : seg[i - 1u].rank;      // minimum over the cell's earlier lookups
-        v = seg_in[i].rank <= min(rank_before, life0 / IRC_LIFE_PER_RANK) ? 1u : 0u;
+// Records -> per-entry (rank_min, votes, winner) and per-cell allocation winner (key << 32 | record index). A workgroup first reduces into an LDS hash table
+// keyed by cell (a cell near the camera receives tens of thousands of lookups per frame: ~6 ns per same-address device atomic would serialise to 0.3 ms), then
+// flushes one device atomic per touched cell and field. `cells`: the 4-byte-per-slot copy of the records' cell field (0xffffffff = no record), or null for a
+// plain list (then rq[i].cell itself).
+#define IRC_RED_SLOTS 1024u
+#define IRC_RED_PER_THREAD 8u
+__global__ void __launch_bounds__(256) k_irc_reduce_requests(IrcacheView ic, const IrcRequest* __restrict__ rq, const uint32_t* __restrict__ cells, IrcReduceRanges rr, IrcSummaryView sum,
+                                                              unsigned long long* __restrict__ alloc_min) {
+    __shared__ uint32_t h_cell[IRC_RED_SLOTS], h_rank[IRC_RED_SLOTS], h_votes[IRC_RED_SLOTS];
+    __shared__ unsigned long long h_win[IRC_RED_SLOTS], h_alloc[IRC_RED_SLOTS];
+    for (uint32_t t = threadIdx.x; t < IRC_RED_SLOTS; t += 256u) { h_cell[t] = 0xffffffffu; h_rank[t] = 0xffffffffu; h_votes[t] = 0u; h_win[t] = ~0ull; h_alloc[t] = ~0ull; }
+    __syncthreads();
+    const uint32_t per_block = 256u * IRC_RED_PER_THREAD;
+    const uint32_t used_paths = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME;
+    uint32_t chunk0 = 0;      // chunks (of per_block slots) of the ranges before range k
+    for (uint32_t k = 0; k < rr.n; ++k) {
+        const uint32_t n = rr.own[k] ? min(rr.count[k], used_paths) : rr.count[k];
+        const uint32_t chunks = (n + per_block - 1u) / per_block;
+        // chunk c of this range belongs to block (chunk0 + c) % gridDim.x
+        for (uint32_t c = (blockIdx.x + gridDim.x - chunk0 % gridDim.x) % gridDim.x; c < chunks; c += gridDim.x) {
+            const uint32_t i0 = c * per_block + threadIdx.x;
+            for (uint32_t j = 0; j < IRC_RED_PER_THREAD; ++j) {
+                const uint32_t li = i0 + j * 256u;      // coalesced over the workgroup
+                if (li >= n) break;
+                const uint32_t i = rr.first[k] + li;
+                const uint32_t cell = cells ? cells[i] : rq[i].cell;
+                if (cell == 0xffffffffu) continue;
+                const uint2 gm = ic.grid_meta[cell];
+                const uint32_t key = rq[i].key, bits = rq[i].bits;
+                uint32_t entry = 0, life0 = 0;
+                const bool unoccupied = (gm.y & IRC_META_OCCUPIED) == 0;
+                const bool may_alloc = unoccupied && (bits & 0x100u) == 0u;
+                const bool replay = !unoccupied && irc_replay_entry(ic, gm, &entry, &life0);
+                if (!may_alloc && !replay) continue;
+                const uint32_t rank = bits & 0xffu;
+                const bool voter = replay && rank <= life0 / IRC_LIFE_PER_RANK;
+                const unsigned long long win = ((unsigned long long)asuint(rq[i].dart) << 32) | key, alc = ((unsigned long long)key << 32) | i;
+                // find or claim the cell's slot in the workgroup's table
+                uint32_t h = (cell * 2654435761u) >> 22, slot = 0xffffffffu;
+                for (uint32_t probe = 0; probe < 16u; ++probe) {
+                    const uint32_t old = atomicCAS(&h_cell[h], 0xffffffffu, cell);
+                    if (old == 0xffffffffu || old == cell) { slot = h; break; }
+                    h = (h + 1u) & (IRC_RED_SLOTS - 1u);
+                }
+                if (slot != 0xffffffffu) {
+                    if (may_alloc) atomicMin(&h_alloc[slot], alc);
+                    else { atomicMin(&h_rank[slot], rank); if (voter) { atomicAdd(&h_votes[slot], 1u); atomicMin(&h_win[slot], win); } }
+                } else if (may_alloc) atomicMin(&alloc_min[cell], alc);      // table full around this hash: straight to memory
+                else { atomicMin(&sum.rank_min[entry], rank); if (voter) { atomicAdd(&sum.votes[entry], 1u); atomicMin(&sum.winner[entry], win); } }
+            }
+        }
+        chunk0 += chunks;
     }
-    voter[i] = v; flags[i] = f;
-}
-__global__ void __launch_bounds__(256) k_irc_request_accept(IrcacheView ic, const IrcRequest* __restrict__ rq, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ cells,
-                                                             const IrcSegMin* __restrict__ seg, const uint32_t* __restrict__ voter, const uint32_t* __restrict__ voters_incl, uint32_t n,
-                                                             uint32_t* __restrict__ last_accepted) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || !voter[i]) return;
-    const uint32_t entry = ic.grid_meta[cells[i]].x;
-    const uint32_t votes_before = ic.reposition_proposal_count[entry] + (voters_incl[i] - 1u);
-    if (rq[idx[i]].dart <= 1.0f / (float(votes_before) + 1.0f)) atomicMax(&last_accepted[seg[i].head], i + 1u);
-}
-// the tail record of every cell writes the cell's new state
-__global__ void __launch_bounds__(256) k_irc_request_apply(IrcacheView ic, const IrcRequest* __restrict__ rq, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ cells,
-                                                            const IrcSegMin* __restrict__ seg, const uint32_t* __restrict__ voters_incl, const uint32_t* __restrict__ last_accepted, uint32_t n,
-                                                            const uint32_t* __restrict__ flags, const uint32_t* __restrict__ ranks) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t cell = cells[i];
-    if (cell == 0xffffffffu || !irc_is_tail(cells, i, n)) return;
-    const IrcSegMin m = seg[i];
-    const uint2 gm = ic.grid_meta[cell];
-    if ((gm.y & IRC_META_OCCUPIED) == 0) {
-        if (!flags[i]) return;
-        const uint32_t alloc_idx = ic.meta[IRC_META_ALLOC_COUNT] + ranks[i];
-        if (alloc_idx >= IRC_MAX_ENTRIES) return;                                           // pool exhausted: the cell stays empty
-        const IrcRequest a = rq[idx[m.first_allowed]];                                      // the first lookup allowed to allocate
-        const uint32_t entry_idx = ic.pool[alloc_idx];
-        atomicMax(&ic.meta[IRC_META_ENTRY_COUNT], entry_idx + 1u);
-        ic.life[entry_idx] = (a.bits & 0xffu) * IRC_LIFE_PER_RANK;
-        ic.entry_cell[entry_idx] = cell;
-        ic.grid_meta[cell] = make_uint2(entry_idx, gm.y | IRC_META_OCCUPIED | IRC_META_JUST_ALLOCATED);
-        ic.reposition_proposal[entry_idx] = a.proposal;
-        return;
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < IRC_RED_SLOTS; t += 256u) {
+        const uint32_t cell = h_cell[t];
+        if (cell == 0xffffffffu) continue;
+        if (h_alloc[t] != ~0ull) atomicMin(&alloc_min[cell], h_alloc[t]);
+        if (h_rank[t] != 0xffffffffu) {
+            const uint32_t entry = ic.grid_meta[cell].x;
+            atomicMin(&sum.rank_min[entry], h_rank[t]);
+            if (h_votes[t]) { atomicAdd(&sum.votes[entry], h_votes[t]); atomicMin(&sum.winner[entry], h_win[t]); }
+        }
     }
-    uint32_t entry, life0;
-    if (!irc_replay_entry(ic, cell, &entry, &life0)) return;
-    ic.life[entry] = min(life0, m.rank * IRC_LIFE_PER_RANK);
-    ic.reposition_proposal_count[entry] += voters_incl[i];
-    const uint32_t la = last_accepted[m.head];
-    if (la) ic.reposition_proposal[entry] = rq[idx[la - 1u]].proposal;
 }
-__global__ void k_irc_request_finish(IrcacheView ic, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ ranks, uint32_t n) {
-    const uint32_t allocated = ranks[n - 1] + flags[n - 1];
-    const uint32_t before = ic.meta[IRC_META_ALLOC_COUNT];
-    ic.meta[IRC_META_ALLOC_COUNT] = min(before + allocated, uint32_t(IRC_MAX_ENTRIES));
+// second pass over the records: the one whose (dart, key) won its entry's vote leaves its proposal in the summary
+__global__ void __launch_bounds__(256) k_irc_reduce_winners(IrcacheView ic, const IrcRequest* __restrict__ rq, const uint32_t* __restrict__ cells, IrcReduceRanges rr, IrcSummaryView sum) {
+    const uint32_t used_paths = ic.meta[IRC_META_TRACING_ALLOC_COUNT] * IRC_SAMPLES_PER_FRAME;
+    for (uint32_t k = 0; k < rr.n; ++k) {
+        const uint32_t n = rr.own[k] ? min(rr.count[k], used_paths) : rr.count[k];
+        for (uint32_t li = blockIdx.x * 256u + threadIdx.x; li < n; li += gridDim.x * 256u) {
+            const uint32_t i = rr.first[k] + li;
+            const uint32_t cell = cells ? cells[i] : rq[i].cell;
+            if (cell == 0xffffffffu) continue;
+            const uint2 gm = ic.grid_meta[cell];
+            if ((gm.y & IRC_META_OCCUPIED) == 0 || (gm.y & IRC_META_JUST_ALLOCATED) != 0) continue;
+            const unsigned long long w = sum.winner[gm.x];
+            if (uint32_t(w) != rq[i].key || uint32_t(w >> 32) != asuint(rq[i].dart)) continue;      // keys are unique in a frame: at most one record matches
+            sum.proposal[gm.x] = rq[i].proposal;
+        }
+    }
+}
+// ---- cells with an allocation winner, in cell order: count per 1024-cell block, then every block sums the counts in front of it and emits
+#define IRC_CELL_BLOCKS (IRC_MAX_GRID_CELLS / 1024u)
+static_assert(IRC_MAX_GRID_CELLS % 1024u == 0, "cell blocks");
+__global__ void __launch_bounds__(256) k_irc_alloc_count(const unsigned long long* __restrict__ alloc_min, uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0u) s_cnt = 0u;
+    __syncthreads();
+    const uint32_t c0 = blockIdx.x * 1024u + threadIdx.x * 4u;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) cnt += alloc_min[c0 + k] != ~0ull ? 1u : 0u;
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0u) block_counts[blockIdx.x] = s_cnt;
+}
+static_assert((IRC_CELL_BLOCKS + 4u) % 2u == 0u, "the source table behind the block counts must be 8-byte aligned");
+struct IrcSummarySources { const void* p[IRC_MAX_SUMMARIES]; uint32_t n; };
+// the merge kernels index the sources by a run-time number: from a table in memory (indexing a by-value kernel argument makes every thread copy the whole struct
+// to scratch first: k_irc_alloc_emit<true> took 33 us against 5 us for its list-writing twin, round 6). One 32-thread launch stores the table.
+__global__ void k_irc_store_sources(IrcSummarySources src, const void** __restrict__ table) { if (threadIdx.x < IRC_MAX_SUMMARIES) table[threadIdx.x] = threadIdx.x < src.n ? src.p[threadIdx.x] : nullptr; }
+// APPLY = false: this rank's winners -> the summary's allocation list (cell order, truncated to IRC_MAX_ENTRIES: the pool cannot serve more, and the lowest
+// cells are the ones that get entries), records read from `rq`. APPLY = true: the merged winners take pool entries (locator = source << 16 | index in that
+// source's list). Both leave alloc_min all-ones behind.
+template <bool APPLY>
+__global__ void __launch_bounds__(256) k_irc_alloc_emit(IrcacheView ic, unsigned long long* __restrict__ alloc_min, const uint32_t* __restrict__ block_counts, const IrcRequest* __restrict__ rq,
+                                                         IrcSummaryView sum, const void* const* __restrict__ src, uint32_t* __restrict__ out_total) {
+    __shared__ uint32_t s_scan[256], s_base, s_total;
+    // the counts in front of this block (and all of them): IRC_CELL_BLOCKS = 384 words, two per thread
+    uint32_t before = 0, all = 0;
+    for (uint32_t b = threadIdx.x; b < IRC_CELL_BLOCKS; b += 256u) { const uint32_t v = block_counts[b]; all += v; if (b < blockIdx.x) before += v; }
+    if (threadIdx.x == 0u) { s_base = 0u; s_total = 0u; }
+    __syncthreads();
+    if (before) atomicAdd(&s_base, before);
+    if (all) atomicAdd(&s_total, all);
+    const uint32_t c0 = blockIdx.x * 1024u + threadIdx.x * 4u;
+    unsigned long long v[4];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) { v[k] = alloc_min[c0 + k]; cnt += v[k] != ~0ull ? 1u : 0u; }
+    s_scan[threadIdx.x] = cnt;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256u; off <<= 1) {
+        const uint32_t add = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_scan[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (s_total == 0u) { if (blockIdx.x == 0u && threadIdx.x == 0u) { if (APPLY) *out_total = 0u; else sum.header[0] = 0u; } return; }
+    uint32_t r = s_base + s_scan[threadIdx.x] - cnt;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) { if (APPLY) *out_total = s_total; else sum.header[0] = min(s_total, uint32_t(IRC_MAX_ENTRIES)); }
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        if (v[k] == ~0ull) continue;
+        const uint32_t cell = c0 + k, loc = uint32_t(v[k]);
+        alloc_min[cell] = ~0ull;
+        if (!APPLY) {
+            if (r < IRC_MAX_ENTRIES) { IrcRequest a = rq[loc]; a.cell = cell; a.dart = 0.0f; sum.allocs[r] = a; }
+        } else {
+            const uint32_t alloc_idx = ic.meta[IRC_META_ALLOC_COUNT] + r;
+            if (alloc_idx < IRC_MAX_ENTRIES) {                                           // else: pool exhausted, the cell stays empty
+                const IrcRequest a = irc_summary_view((void*)src[loc >> 16]).allocs[loc & 0xffffu];
+                const uint32_t entry_idx = ic.pool[alloc_idx];
+                atomicMax(&ic.meta[IRC_META_ENTRY_COUNT], entry_idx + 1u);
+                ic.life[entry_idx] = (a.bits & 0xffu) * IRC_LIFE_PER_RANK;
+                ic.entry_cell[entry_idx] = cell;
+                ic.grid_meta[cell] = make_uint2(entry_idx, ic.grid_meta[cell].y | IRC_META_OCCUPIED | IRC_META_JUST_ALLOCATED);
+                ic.reposition_proposal[entry_idx] = a.proposal;
+            }
+        }
+        ++r;
+    }
+}
+// ---- apply: the merge of every source's summary
+__global__ void __launch_bounds__(256) k_irc_merge_entries(IrcacheView ic, const void* const* __restrict__ src, uint32_t n_src) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= IRC_MAX_ENTRIES) return;
+    uint32_t rank_min = 0xffffffffu, votes = 0u, win_src = 0u;
+    unsigned long long win = ~0ull;
+    for (uint32_t s = 0; s < n_src; ++s) {
+        const IrcSummaryView v = irc_summary_view((void*)src[s]);
+        rank_min = min(rank_min, v.rank_min[e]);
+        votes += v.votes[e];
+        const unsigned long long w = v.winner[e];
+        if (w < win) { win = w; win_src = s; }
+    }
+    if (rank_min == 0xffffffffu) return;      // no replayable lookup reached this entry
+    ic.life[e] = min(ic.life[e], rank_min * IRC_LIFE_PER_RANK);
+    if (votes) {
+        const uint32_t v0 = ic.reposition_proposal_count[e];
+        ic.reposition_proposal_count[e] = v0 + votes;
+        if (asfloat(uint32_t(win >> 32)) <= 1.0f / (float(v0) + 1.0f)) ic.reposition_proposal[e] = irc_summary_view((void*)src[win_src]).proposal[e];
+    }
+}
+__global__ void __launch_bounds__(256) k_irc_merge_allocs(const void* const* __restrict__ src, unsigned long long* __restrict__ alloc_min) {
+    const uint32_t s = blockIdx.y, i = blockIdx.x * 256u + threadIdx.x;
+    const IrcSummaryView v = irc_summary_view((void*)src[s]);
+    if (i >= min(v.header[0], uint32_t(IRC_MAX_ENTRIES))) return;
+    atomicMin(&alloc_min[v.allocs[i].cell], ((unsigned long long)v.allocs[i].key << 32) | (s << 16) | i);
+}
+__global__ void k_irc_request_finish(IrcacheView ic, const uint32_t* __restrict__ total) {
+    ic.meta[IRC_META_ALLOC_COUNT] = min(ic.meta[IRC_META_ALLOC_COUNT] + *total, uint32_t(IRC_MAX_ENTRIES));
 }
 
 // ================================================================== host
@@ -824,8 +917,8 @@ KjStatus kj_ircache_prepare(KjIrcache* c, void* stream_) {
     if (c->parity == 1) std::swap(a, b);
     uint32_t* freed = nullptr;
     if (c->deferred) {
-        if (c->freed.bytes != IRC_MAX_ENTRIES * 4) KJ_TRY_HIP(c->freed.alloc(IRC_MAX_ENTRIES * 4, s));
-        KJ_TRY_HIP(hipMemsetAsync(c->freed.p, 0, IRC_MAX_ENTRIES * 4, s));
+        if (c->freed.bytes != IRC_MAX_ENTRIES * 4) { KJ_TRY_HIP(c->freed.alloc(IRC_MAX_ENTRIES * 4, s)); c->begin_cleared_frame_state = false; }
+        if (!c->begin_cleared_frame_state) KJ_TRY_HIP(hipMemsetAsync(c->freed.p, 0, IRC_MAX_ENTRIES * 4, s));      // (normally part of kj_ircache_begin_requests' one clear launch)
         freed = (uint32_t*)c->freed.p;
     }
     if (!c->initialized) {
@@ -843,14 +936,15 @@ KjStatus kj_ircache_prepare(KjIrcache* c, void* stream_) {
     const IrcacheView v = c->view();
     hipLaunchKernelGGL(k_irc_age, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, v, (uint32_t*)c->occupancy.p, freed);
     KJ_CHECK_LAUNCH();
-    if (freed) {
-        hipLaunchKernelGGL(k_irc_scan, dim3(1), dim3(1024), 0, s, freed);
+    if (freed) {      // both inclusive scans -- the freed-entry flags and the occupancy flags -- in one launch of two workgroups
+        hipLaunchKernelGGL(k_irc_scan, dim3(2), dim3(1024), 0, s, freed, (uint32_t*)c->occupancy.p);
         hipLaunchKernelGGL(k_irc_push_freed, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, (const uint32_t*)freed, (uint32_t*)c->pool.p, (uint32_t*)c->meta.p);
         hipLaunchKernelGGL(k_irc_pop_freed_count, dim3(1), dim3(1), 0, s, (const uint32_t*)freed, (uint32_t*)c->meta.p);
         KJ_CHECK_LAUNCH();
+    } else {
+        hipLaunchKernelGGL(k_irc_scan, dim3(1), dim3(1024), 0, s, (uint32_t*)c->occupancy.p, (uint32_t*)nullptr);
+        KJ_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_irc_scan, dim3(1), dim3(1024), 0, s, (uint32_t*)c->occupancy.p);
-    KJ_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_irc_compact, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, (const uint32_t*)c->meta.p, (const uint32_t*)c->life.p, (const uint32_t*)c->occupancy.p,
                        (uint32_t*)c->entry_indirection.p);
     KJ_CHECK_LAUNCH();
@@ -894,7 +988,8 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
     static const bool quad = !(kj_debug_getenv("KJ_IRC_QUAD") && atoi(kj_debug_getenv("KJ_IRC_QUAD")) == 0);
     const uint32_t grid = c->dev->num_cus * (quad ? 32u : (tc.lanes < 64u ? 32u : 8u));
     const size_t lds_rays = quad ? quad_stack_bytes() : lds;
-    KJ_TRY_HIP(hipMemsetAsync(c->ray_counters.p, 0, KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8, s));
+    if (!c->begin_cleared_frame_state) KJ_TRY_HIP(hipMemsetAsync(c->ray_counters.p, 0, KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8, s));
+    c->begin_cleared_frame_state = false;
     hipLaunchKernelGGL(k_irc_prepare_trace, dim3(1), dim3(1), 0, s, (uint32_t*)c->meta.p);
     KJ_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_irc_reset, dim3(grid), dim3(64), 0, s, tc.ic);
@@ -945,42 +1040,72 @@ KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream_) 
     c->pending_irradiance_sum = false;
     return KJ_OK;
 }
-// ---- deferred updates: begin (clear the frame's slots), collect (compact a slot range into a list), apply (replay a merged list)
-KjStatus kj_ircache_set_deferred_updates(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->deferred = enable != 0; return KJ_OK; }
-KjStatus kj_ircache_set_ray_passes_side_by_side(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->ray_pass_schedule = enable ? KJ_IRC_PASSES_SIDE_BY_SIDE : KJ_IRC_PASSES_SEQUENTIAL; return KJ_OK; }
+// ---- deferred updates: begin (clear the frame's slots and summaries), summarize (reduce slot ranges into a fixed-size summary), apply (merge summaries)
+KjStatus kj_ircache_set_deferred_updates(KjIrcache* c, uint32_t enable) {
+    KJ_REQUIRE(c, "null argument");
+    // racy frames in between overwrite the path count the own-range clears are bounded by: the next begin clears every slot
+    if (enable && !c->deferred) c->req_clear_all = true;
+    c->deferred = enable != 0;
+    return KJ_OK;
+}
+KjStatus kj_ircache_set_ray_passes_side_by_side(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->ray_pass_schedule = enable ? KJ_IRC_PASSES_SIDE_BY_SIDE : KJ_IRC_PASSES_CHAIN; return KJ_OK; }
 KjStatus kj_ircache_set_ray_pass_schedule(KjIrcache* c, uint32_t schedule) { KJ_REQUIRE(c && schedule <= KJ_IRC_PASSES_CHAIN, "null argument / unknown schedule"); c->ray_pass_schedule = schedule; return KJ_OK; }
 KjStatus kj_ircache_set_rtr_requests(KjIrcache* c, uint32_t enable) { KJ_REQUIRE(c, "null argument"); c->rtr_requests = enable != 0; return KJ_OK; }
 KjStatus kj_ircache_begin_requests(KjIrcache* c, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, void* stream_) {
     return kj_ircache_begin_requests_rows(c, rtdgi_half_width, rtdgi_half_height, 0u, rtdgi_half_height, stream_);
 }
+static hipError_t irc_summary_buffers(KjIrcache* c, hipStream_t s) {
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 2 && e == hipSuccess; ++k)
+        if (c->summary[k].bytes != IRC_SUMMARY_BYTES) { e = c->summary[k].alloc(IRC_SUMMARY_BYTES, s); c->summary_fresh = true; }
+    if (e == hipSuccess && c->alloc_min.bytes != size_t(IRC_MAX_GRID_CELLS) * 8) {
+        e = c->alloc_min.alloc(size_t(IRC_MAX_GRID_CELLS) * 8, s);
+        if (e == hipSuccess) e = hipMemsetAsync(c->alloc_min.p, 0xff, size_t(IRC_MAX_GRID_CELLS) * 8, s);      // every emit leaves it all-ones again
+    }
+    if (e == hipSuccess && c->req_scratch.bytes != (IRC_CELL_BLOCKS + 4u) * 4u + IRC_MAX_SUMMARIES * 8u) e = c->req_scratch.alloc((IRC_CELL_BLOCKS + 4u) * 4u + IRC_MAX_SUMMARIES * 8u, s);
+    return e;
+}
+// what a summary needs cleared before records are reduced into it: header + winner + rank_min -> all-ones, votes -> 0 (the proposals are only read where a winner is)
+static void irc_summary_clear_segments(void* summary, IrcClearSegs& sg) {
+    const IrcSummaryView v = irc_summary_view(summary);
+    sg.p[sg.n] = v.header; sg.words[sg.n] = (IRC_SUMMARY_HEADER_BYTES + IRC_MAX_ENTRIES * 12u) / 4u; sg.pattern[sg.n] = 0xffffffffu; sg.own[sg.n] = 0u; ++sg.n;
+    sg.p[sg.n] = v.votes; sg.words[sg.n] = IRC_MAX_ENTRIES; sg.pattern[sg.n] = 0u; sg.own[sg.n] = 0u; ++sg.n;
+}
 // The same for a caller whose per-pixel passes (rtdgi's and rtr's validate / trace) run on half-res rows [half_row_begin, half_row_end) only -- a rank of the
-// screen-tile split: only those rows of the per-pixel slot ranges are cleared (and the cache's own two ranges): at 4K the slot array is 150 MB, 280 MB with
-// reflections, and clearing all of it every frame was 0.1 ms of every rank's frame whatever the rank count (profiles/r03_split_work_per_rank.md). Slots of other
-// rows stay as the (re)allocation left them: unused.
+// screen-tile split: only those rows of the per-pixel slot ranges are cleared (and the cache's own two ranges up to last frame's path count): at 4K the slot array
+// is 150 MB, 280 MB with reflections. Slots of other rows stay as the (re)allocation left them: unused. ONE launch clears the cell words of every range and both
+// summaries (round 5: 6-8 fills here, ~30 per rank and frame overall).
 KjStatus kj_ircache_begin_requests_rows(KjIrcache* c, uint32_t rtdgi_half_width, uint32_t rtdgi_half_height, uint32_t half_row_begin, uint32_t half_row_end, void* stream_) {
     KJ_REQUIRE(c && c->deferred, "deferred updates are off (kj_ircache_set_deferred_updates)");
     KJ_REQUIRE(half_row_begin <= half_row_end && half_row_end <= rtdgi_half_height, "bad row range");
     hipStream_t s = (hipStream_t)stream_;
     c->req_half_pixels = rtdgi_half_width * rtdgi_half_height;
     const size_t RQ = sizeof(IrcRequest), bytes = size_t(c->request_slots()) * RQ, CB = 4, cell_bytes = size_t(c->request_slots()) * CB;
-    const bool fresh = c->requests.bytes != bytes;
-    if (fresh) { KJ_TRY_HIP(c->requests.alloc(bytes, s)); KJ_TRY_HIP(c->request_cells.alloc(cell_bytes, s)); }
-    // what is cleared (and what a collect scans) is the 4-byte cell copy of every slot, 0xffffffff = no record; the 32-byte records themselves are only ever read where a cell says so
-    uint8_t* const base = (uint8_t*)c->request_cells.p;
+    const bool fresh = c->requests.bytes != bytes || c->req_clear_all;
+    if (c->requests.bytes != bytes) { KJ_TRY_HIP(c->requests.alloc(bytes, s)); KJ_TRY_HIP(c->request_cells.alloc(cell_bytes, s)); }
+    KJ_TRY_HIP(irc_summary_buffers(c, s));
+    // what is cleared (and what a reduce scans) is the 4-byte cell copy of every slot, 0xffffffff = no record; the 32-byte records themselves are only ever read where a cell says so
+    uint32_t* const base = (uint32_t*)c->request_cells.p;
     const size_t own_first = 2 * size_t(c->req_half_pixels);
-    if (fresh) {
-        KJ_TRY_HIP(hipMemsetAsync(base, 0xff, cell_bytes, s));
-    } else if (half_row_begin == 0u && half_row_end == rtdgi_half_height) {      // every per-pixel slot; of the cache's own ranges what last frame can have written
-        KJ_TRY_HIP(hipMemsetAsync(base, 0xff, own_first * CB, s));
-        if (c->rtr_requests) KJ_TRY_HIP(hipMemsetAsync(base + size_t(c->rtr_request_base()) * CB, 0xff, 2 * size_t(c->req_half_pixels) * CB, s));
-        hipLaunchKernelGGL(k_irc_clear_own_requests, dim3(c->dev->num_cus), dim3(256), 0, s, (const uint32_t*)c->meta.p, (uint32_t*)base + own_first, KjIrcache::REQ_E);
-    } else {
+    IrcClearSegs sg{};
+    auto seg = [&](size_t first, size_t n, uint32_t own) { if (n) { sg.p[sg.n] = base + first; sg.words[sg.n] = uint32_t(n); sg.pattern[sg.n] = 0xffffffffu; sg.own[sg.n] = own; ++sg.n; } };
+    if (fresh) seg(0, c->request_slots(), 0u);
+    else {
         const size_t hb = c->req_half_pixels, row0 = size_t(half_row_begin) * rtdgi_half_width, n = size_t(half_row_end - half_row_begin) * rtdgi_half_width;
-        size_t firsts[4] = {0, hb, 0, 0}; int ranges = 2;
-        if (c->rtr_requests) { firsts[2] = c->rtr_request_base(); firsts[3] = c->rtr_request_base() + hb; ranges = 4; }
-        if (n) for (int k = 0; k < ranges; ++k) KJ_TRY_HIP(hipMemsetAsync(base + (firsts[k] + row0) * CB, 0xff, n * CB, s));
-        hipLaunchKernelGGL(k_irc_clear_own_requests, dim3(c->dev->num_cus), dim3(256), 0, s, (const uint32_t*)c->meta.p, (uint32_t*)base + own_first, KjIrcache::REQ_E);      // the cache's own validate and trace rays
+        seg(row0, n, 0u); seg(hb + row0, n, 0u);
+        if (c->rtr_requests) { seg(c->rtr_request_base() + row0, n, 0u); seg(c->rtr_request_base() + hb + row0, n, 0u); }
+        seg(own_first, KjIrcache::REQ_E, 1u); seg(own_first + KjIrcache::REQ_E, KjIrcache::REQ_E, 1u);      // the cache's own validate and trace rays: what last frame can have written
     }
+    irc_summary_clear_segments(c->summary[0].p, sg); irc_summary_clear_segments(c->summary[1].p, sg);
+    // the frame's other two clears ride along: the freed-entry flags of kj_ircache_prepare and the ray counters of kj_ircache_trace_irradiance
+    c->begin_cleared_frame_state = c->freed.bytes == IRC_MAX_ENTRIES * 4 && sg.n + 2u <= IRC_CLEAR_MAX;
+    if (c->begin_cleared_frame_state) {
+        sg.p[sg.n] = (uint32_t*)c->freed.p; sg.words[sg.n] = IRC_MAX_ENTRIES; sg.pattern[sg.n] = 0u; sg.own[sg.n] = 0u; ++sg.n;
+        sg.p[sg.n] = (uint32_t*)c->ray_counters.p; sg.words[sg.n] = KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 2u; sg.pattern[sg.n] = 0u; sg.own[sg.n] = 0u; ++sg.n;
+    }
+    hipLaunchKernelGGL(k_irc_clear_segments, dim3(c->dev->num_cus * 4), dim3(256), 0, s, sg, (const uint32_t*)c->meta.p);
+    KJ_CHECK_LAUNCH();
+    c->req_clear_all = false;
     c->requests_begun = true;
     return KJ_OK;
 }
@@ -998,59 +1123,84 @@ KjStatus kj_ircache_rtr_request_ranges(KjIrcache* c, uint32_t out_first_slot[2],
     out_slot_count[0] = out_slot_count[1] = hb;
     return KJ_OK;
 }
-KjStatus kj_ircache_collect_requests(KjIrcache* c, uint32_t first_slot, uint32_t slot_count, void* out_list, uint32_t out_capacity, void* out_count_dev, void* stream_) {
-    KJ_REQUIRE(c && c->deferred && out_list && out_count_dev && c->requests.p, "null argument / no requests recorded");
-    KJ_REQUIRE(uint64_t(first_slot) + slot_count <= c->request_slots(), "slot range out of bounds");
-    if (slot_count == 0) return KJ_OK;
-    // the cache's own two ranges (validation's and tracing's lookups, slot = path index) are scanned up to this frame's path count only, not all 2 x 262 144 slots
-    const uint32_t own0 = 2u * c->req_half_pixels, own1 = own0 + KjIrcache::REQ_E;
-    const bool own = slot_count <= KjIrcache::REQ_E && (first_slot == own0 || first_slot == own1);
-    hipLaunchKernelGGL(k_irc_collect_requests, dim3(std::min(4096u, (slot_count + 2047u) / 2048u)), dim3(256), 0, (hipStream_t)stream_, (const IrcRequest*)c->requests.p + first_slot, (const uint32_t*)c->request_cells.p + first_slot, slot_count,
-                       (IrcRequest*)out_list, out_capacity, (uint32_t*)out_count_dev, own ? (const uint32_t*)c->meta.p + IRC_META_TRACING_ALLOC_COUNT : (const uint32_t*)nullptr);
+uint64_t kj_ircache_summary_bytes(void) { return IRC_SUMMARY_BYTES; }
+// records (rq / cells, ranges rr) -> summary: reduce, winners' proposals, the allocation list in cell order
+static KjStatus irc_summarize(KjIrcache* c, const IrcRequest* rq, const uint32_t* cells, const IrcReduceRanges& rr, void* summary, hipStream_t s) {
+    IrcacheView v = c->view();
+    v.requests = nullptr;
+    const IrcSummaryView sum = irc_summary_view(summary);
+    uint64_t slots = 0;
+    for (uint32_t k = 0; k < rr.n; ++k) slots += rr.count[k];
+    const uint32_t per_block = 256u * IRC_RED_PER_THREAD;
+    const uint32_t grid = uint32_t(std::min<uint64_t>(std::max<uint64_t>(1, (slots + per_block - 1) / per_block), uint64_t(c->dev->num_cus) * 8));
+    unsigned long long* const alloc_min = (unsigned long long*)c->alloc_min.p;
+    uint32_t* const block_counts = (uint32_t*)c->req_scratch.p;
+    hipLaunchKernelGGL(k_irc_reduce_requests, dim3(grid), dim3(256), 0, s, v, rq, cells, rr, sum, alloc_min);
+    hipLaunchKernelGGL(k_irc_reduce_winners, dim3(grid), dim3(256), 0, s, v, rq, cells, rr, sum);
+    hipLaunchKernelGGL(k_irc_alloc_count, dim3(IRC_CELL_BLOCKS), dim3(256), 0, s, (const unsigned long long*)alloc_min, block_counts);
+    hipLaunchKernelGGL(k_irc_alloc_emit<false>, dim3(IRC_CELL_BLOCKS), dim3(256), 0, s, v, alloc_min, (const uint32_t*)block_counts, rq, sum, (const void* const*)nullptr, (uint32_t*)nullptr);
     KJ_CHECK_LAUNCH();
     return KJ_OK;
 }
+// Reduces the records of up to 6 slot ranges into the cache's summary `which` (0: what a rank of the split sends to the others -- its strip's per-pixel lookups;
+// 1: what stays local -- the cache's own ray passes, identical on every replica). Once per summary and frame (kj_ircache_begin_requests clears both).
+KjStatus kj_ircache_summarize_requests(KjIrcache* c, const uint32_t* first_slots, const uint32_t* slot_counts, uint32_t n_ranges, uint32_t which, void* stream_) {
+    KJ_REQUIRE(c && c->deferred && c->requests.p && c->summary[0].p, "null argument / no requests recorded (kj_ircache_begin_requests)");
+    KJ_REQUIRE(which < 2u && n_ranges <= IRC_REDUCE_MAX_RANGES && (n_ranges == 0 || (first_slots && slot_counts)), "bad range list / summary index");
+    IrcReduceRanges rr{};
+    const uint32_t own0 = 2u * c->req_half_pixels, own1 = own0 + KjIrcache::REQ_E;
+    for (uint32_t k = 0; k < n_ranges; ++k) {
+        KJ_REQUIRE(uint64_t(first_slots[k]) + slot_counts[k] <= c->request_slots(), "slot range out of bounds");
+        // the cache's own two ranges (validation's and tracing's lookups, slot = path index) are scanned up to this frame's path count only
+        rr.first[k] = first_slots[k]; rr.count[k] = slot_counts[k]; rr.own[k] = slot_counts[k] <= KjIrcache::REQ_E && (first_slots[k] == own0 || first_slots[k] == own1) ? 1u : 0u;
+    }
+    rr.n = n_ranges;
+    return irc_summarize(c, (const IrcRequest*)c->requests.p, (const uint32_t*)c->request_cells.p, rr, c->summary[which].p, (hipStream_t)stream_);
+}
+KjStatus kj_ircache_summary(KjIrcache* c, uint32_t which, void** out_dev_ptr) {
+    KJ_REQUIRE(c && which < 2u && out_dev_ptr && c->summary[which].p, "null argument / no summary yet (kj_ircache_begin_requests)");
+    *out_dev_ptr = c->summary[which].p;
+    return KJ_OK;
+}
+// The replay: merges `n` summaries (device pointers; every replica passes the same ones in the same order -- the ranks' strip summaries in rank order, then
+// its own local one) and applies the result. No host synchronisation, nothing sized by a count the host would have to read.
+KjStatus kj_ircache_apply_summaries(KjIrcache* c, const void* const* summaries, uint32_t n, void* stream_) {
+    KJ_REQUIRE(c && summaries && n >= 1u && n <= IRC_MAX_SUMMARIES, "null argument / too many summaries (32)");
+    hipStream_t s = (hipStream_t)stream_;
+    KJ_TRY_HIP(irc_summary_buffers(c, s));
+    IrcacheView v = c->view();
+    v.requests = nullptr;
+    IrcSummarySources src{};
+    for (uint32_t k = 0; k < n; ++k) { KJ_REQUIRE(summaries[k], "null summary"); src.p[k] = summaries[k]; }
+    src.n = n;
+    unsigned long long* const alloc_min = (unsigned long long*)c->alloc_min.p;
+    uint32_t* const block_counts = (uint32_t*)c->req_scratch.p; uint32_t* const total = block_counts + IRC_CELL_BLOCKS;
+    const void** const table = (const void**)(total + 4);      // 8-byte aligned: req_scratch = 384 counts + 4 words + the table
+    hipLaunchKernelGGL(k_irc_store_sources, dim3(1), dim3(32), 0, s, src, table);
+    hipLaunchKernelGGL(k_irc_merge_entries, dim3(IRC_MAX_ENTRIES / 256), dim3(256), 0, s, v, (const void* const*)table, n);
+    hipLaunchKernelGGL(k_irc_merge_allocs, dim3(IRC_MAX_ENTRIES / 256, n), dim3(256), 0, s, (const void* const*)table, alloc_min);
+    hipLaunchKernelGGL(k_irc_alloc_count, dim3(IRC_CELL_BLOCKS), dim3(256), 0, s, (const unsigned long long*)alloc_min, block_counts);
+    hipLaunchKernelGGL(k_irc_alloc_emit<true>, dim3(IRC_CELL_BLOCKS), dim3(256), 0, s, v, alloc_min, (const uint32_t*)block_counts, (const IrcRequest*)nullptr, IrcSummaryView{}, (const void* const*)table, total);
+    hipLaunchKernelGGL(k_irc_request_finish, dim3(1), dim3(1), 0, s, v, (const uint32_t*)total);
+    KJ_CHECK_LAUNCH();
+    return KJ_OK;
+}
+// A plain list of records (32 bytes each; cell 0xffffffff = unused) replayed at once: reduce into summary 0, apply it. For callers that assemble lists themselves
+// and for tests; the frame path is begin_requests -> summarize_requests -> (exchange) -> apply_summaries.
 KjStatus kj_ircache_apply_requests(KjIrcache* c, const void* list, uint32_t count, void* stream_) {
     KJ_REQUIRE(c && (list || count == 0), "null argument");
     if (count == 0) return KJ_OK;
     hipStream_t s = (hipStream_t)stream_;
-    IrcacheView v = c->view();
-    v.requests = nullptr;
-    const IrcRequest* rq = (const IrcRequest*)list;
-    auto A = [&](kj::DevBuf& b, size_t n) { if (b.bytes < n) { hipError_t e = b.alloc(n, s); if (e != hipSuccess) c->err = e; } };
-    A(c->req_sort_keys, size_t(count) * 8); A(c->req_sort_keys2, size_t(count) * 8); A(c->req_sort_idx, size_t(count) * 4); A(c->req_sort_idx2, size_t(count) * 4);
-    A(c->req_flags, size_t(count) * 4); A(c->req_ranks, size_t(count) * 4); A(c->req_count, 16);
-    A(c->req_cells, size_t(count) * 4); A(c->req_seg_in, size_t(count) * sizeof(IrcSegMin)); A(c->req_seg, size_t(count) * sizeof(IrcSegMin));
-    A(c->req_voter, size_t(count) * 4); A(c->req_voters_incl, size_t(count) * 4); A(c->req_last_accepted, size_t(count) * 4);
-    KJ_TRY_HIP(c->err);
-    const dim3 g((count + 255) / 256), b(256);
-    unsigned long long* const keys = (unsigned long long*)c->req_sort_keys.p; unsigned long long* const keys_sorted = (unsigned long long*)c->req_sort_keys2.p;
-    uint32_t* const idx = (uint32_t*)c->req_sort_idx.p; uint32_t* const idx_sorted = (uint32_t*)c->req_sort_idx2.p;
-    uint32_t* const cells = (uint32_t*)c->req_cells.p;
-    IrcSegMin* const seg_in = (IrcSegMin*)c->req_seg_in.p; IrcSegMin* const seg = (IrcSegMin*)c->req_seg.p;
-    uint32_t* const voter = (uint32_t*)c->req_voter.p; uint32_t* const voters_incl = (uint32_t*)c->req_voters_incl.p; uint32_t* const last_accepted = (uint32_t*)c->req_last_accepted.p;
-    uint32_t* const flags = (uint32_t*)c->req_flags.p; uint32_t* const ranks = (uint32_t*)c->req_ranks.p;
-    hipLaunchKernelGGL(k_irc_request_keys, g, b, 0, s, rq, count, keys, idx);
-    size_t sort_bytes = 0, scan_bytes = 0, seg_bytes = 0, sum_bytes = 0;
-    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)keys, keys_sorted, (const uint32_t*)idx, idx_sorted, int(count), 0, KJ_IRC_SORT_BITS, s));
-    KJ_TRY_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)flags, ranks, int(count), s));
-    KJ_TRY_HIP(hipcub::DeviceScan::InclusiveScanByKey(nullptr, seg_bytes, (const uint32_t*)cells, (const IrcSegMin*)seg_in, seg, IrcSegMinOp(), count, hipcub::Equality(), s));
-    KJ_TRY_HIP(hipcub::DeviceScan::InclusiveScanByKey(nullptr, sum_bytes, (const uint32_t*)cells, (const uint32_t*)voter, voters_incl, IrcSumOp(), count, hipcub::Equality(), s));
-    const size_t tmp_bytes = std::max(std::max(sort_bytes, scan_bytes), std::max(seg_bytes, sum_bytes));
-    A(c->req_tmp, tmp_bytes + 16);
-    KJ_TRY_HIP(c->err);
-    KJ_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(c->req_tmp.p, sort_bytes, (const unsigned long long*)keys, keys_sorted, (const uint32_t*)idx, idx_sorted, int(count), 0, KJ_IRC_SORT_BITS, s));
-    hipLaunchKernelGGL(k_irc_request_prepare, g, b, 0, s, rq, (const unsigned long long*)keys_sorted, (const uint32_t*)idx_sorted, count, cells, seg_in, last_accepted);
-    KJ_TRY_HIP(hipcub::DeviceScan::InclusiveScanByKey(c->req_tmp.p, seg_bytes, (const uint32_t*)cells, (const IrcSegMin*)seg_in, seg, IrcSegMinOp(), count, hipcub::Equality(), s));
-    hipLaunchKernelGGL(k_irc_request_voters, g, b, 0, s, v, (const uint32_t*)cells, (const IrcSegMin*)seg_in, (const IrcSegMin*)seg, count, voter, flags);
-    KJ_TRY_HIP(hipcub::DeviceScan::InclusiveScanByKey(c->req_tmp.p, sum_bytes, (const uint32_t*)cells, (const uint32_t*)voter, voters_incl, IrcSumOp(), count, hipcub::Equality(), s));
-    KJ_TRY_HIP(hipcub::DeviceScan::ExclusiveSum(c->req_tmp.p, scan_bytes, (const uint32_t*)flags, ranks, int(count), s));
-    hipLaunchKernelGGL(k_irc_request_accept, g, b, 0, s, v, rq, (const uint32_t*)idx_sorted, (const uint32_t*)cells, (const IrcSegMin*)seg, (const uint32_t*)voter, (const uint32_t*)voters_incl, count, last_accepted);
-    hipLaunchKernelGGL(k_irc_request_apply, g, b, 0, s, v, rq, (const uint32_t*)idx_sorted, (const uint32_t*)cells, (const IrcSegMin*)seg, (const uint32_t*)voters_incl, (const uint32_t*)last_accepted, count,
-                       (const uint32_t*)flags, (const uint32_t*)ranks);
-    hipLaunchKernelGGL(k_irc_request_finish, dim3(1), dim3(1), 0, s, v, (const uint32_t*)c->req_flags.p, (const uint32_t*)c->req_ranks.p, count);
-    KJ_CHECK_LAUNCH();
-    return KJ_OK;
+    KJ_TRY_HIP(irc_summary_buffers(c, s));
+    IrcClearSegs sg{};
+    irc_summary_clear_segments(c->summary[0].p, sg);
+    hipLaunchKernelGGL(k_irc_clear_segments, dim3(c->dev->num_cus), dim3(256), 0, s, sg, (const uint32_t*)c->meta.p);
+    IrcReduceRanges rr{};
+    rr.first[0] = 0u; rr.count[0] = count; rr.own[0] = 0u; rr.n = 1u;
+    const KjStatus e = irc_summarize(c, (const IrcRequest*)list, nullptr, rr, c->summary[0].p, s);
+    if (e != KJ_OK) return e;
+    const void* one[1] = {c->summary[0].p};
+    return kj_ircache_apply_summaries(c, one, 1u, s);
 }
 KjStatus kj_ircache_buffer(KjIrcache* c, const char* name, void** out_dev_ptr, uint64_t* out_bytes) {
     KJ_REQUIRE(c && name && out_dev_ptr && out_bytes, "null argument");

@@ -72,6 +72,11 @@ struct DevBuf {
 
 struct LbvhScratch;     // kj_scene_device.hpp
 
+// Many contiguous device-to-device copies in ONE launch (device.hip: k_copy_blocks): the pack and the scatter of a halo exchange (split.cpp) are dozens of row
+// blocks of a few hundred KB each -- as hipMemcpyAsync calls each is a launch of its own (~10 us apiece on the device, 128 per rank and frame: round 6).
+struct CopyBlock { const void* src; void* dst; uint64_t bytes; };
+hipError_t launch_copy_blocks(const CopyBlock* blocks, size_t n, hipStream_t s);
+
 } // namespace kj
 
 struct KjDevice {

@@ -22,7 +22,12 @@ struct KjIrcache {
     bool rtr_requests = false;
     bool requests_begun = false;        // kj_ircache_begin_requests ran for the frame kj_ircache_prepare is about to open (deferred mode)
     uint32_t req_half_pixels = 0;       // HB of the current frame
-    kj::DevBuf freed, aux_snapshot, requests, request_cells, req_sort_keys, req_sort_keys2, req_sort_idx, req_sort_idx2, req_flags, req_ranks, req_tmp, req_count, req_cells, req_seg_in, req_seg, req_voter, req_voters_incl, req_last_accepted;
+    kj::DevBuf freed, aux_snapshot, requests, request_cells;
+    // the reduction of a frame's records (ircache.hip: IRC_SUMMARY_BYTES each): [0] what a rank of the split sends -- its strip's per-pixel lookups --, [1] what stays local (the cache's own
+    // ray passes); alloc_min: per cell, the allocation winner (key << 32 | locator), all-ones between uses; req_scratch: 384 block counts + the total
+    kj::DevBuf summary[2], alloc_min, req_scratch;
+    bool summary_fresh = false, req_clear_all = false;
+    bool begin_cleared_frame_state = false;      // this frame's kj_ircache_begin_requests also cleared `freed` and the ray counters (one launch instead of three)
     hipError_t err = hipSuccess;
     static constexpr uint32_t REQ_E = IRC_MAX_ENTRIES * IRC_SAMPLES_PER_FRAME;
     uint32_t rtr_request_base() const { return 2u * req_half_pixels + 2u * REQ_E; }

@@ -383,6 +383,7 @@ __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_fused(TraceC
     if (lead) invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
 }
 
+#ifdef KJ_RAY_PASS_EXPERIMENTS      // measured-and-rejected forms of the ray passes (make EXPERIMENTS=1): the pool form below (1.4-1.9x slower than the fused form: profiles/r05_ray_pass_experiments.md) and rtdgi_ray_experiments.inc
 // ------------------------------------------------------------------ the POOL form of the two ray passes (round 5)
 // The fused kernels above give every 8x8 tile a wave that lives as long as its slowest pixel: sky pixels never start, two rays of three leave the scene after
 // a short walk, a sixth of the lanes shade a hit and walk a shadow ray -- 34 % of the lanes of an issued instruction do work (PMC, rounds 2-4). Here a launch is a few
@@ -636,7 +637,6 @@ __global__ void __launch_bounds__(64, KJ_POOL_WAVES) k_rtdgi_rays_pool(TraceCtx 
     add_traversal_stats<STATS>(c, st_closest, st_any);
 }
 
-#ifdef KJ_RAY_PASS_EXPERIMENTS
 #include "rtdgi_ray_experiments.inc"
 #endif
 
@@ -872,6 +872,9 @@ __global__ void __launch_bounds__(64) k_restir_check(const FrameConstants* __res
 // spatial_filter.hlsl: rtdgi_resample.hip (k_spatial_filter)
 
 // ================================================================== host side
+#ifndef KJ_POOL_WAVES
+#define KJ_POOL_WAVES 4
+#endif
 struct KjRtdgi {
     KjDevice* dev = nullptr;
     uint32_t spatial_reuse_pass_count = 2;      // rtdgi.rs:43-44
@@ -947,9 +950,9 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
         } else fprintf(stderr, "kajiya_amd: KJ_RTDGI_POOL_TUNE=%s ignored (want \"waves,refill,shade_a,shade_b,dynamic\")\n", v);
     }
 #ifndef KJ_RAY_PASS_EXPERIMENTS
-    if (r->grouped_rays || r->split_rays || r->quad_rays || r->staged_min_rays != 0xffffffffu) {      // this build carries the fused and the pool form only: say so instead of measuring the same kernel twice
-        fprintf(stderr, "kajiya_amd: KJ_RTDGI_GROUPED / _SPLIT / _QUAD / _STAGED_MIN_RAYS ask for a form of the ray passes this build does not carry (make EXPERIMENTS=1): the fused form runs\n");
-        r->grouped_rays = r->split_rays = r->quad_rays = false; r->staged_min_rays = 0xffffffffu;
+    if (r->grouped_rays || r->split_rays || r->quad_rays || r->pool_rays || r->staged_min_rays != 0xffffffffu) {      // this build carries the fused form only: say so instead of measuring the same kernel twice
+        fprintf(stderr, "kajiya_amd: KJ_RTDGI_GROUPED / _SPLIT / _QUAD / _POOL / _STAGED_MIN_RAYS ask for a form of the ray passes this build does not carry (make EXPERIMENTS=1): the fused form runs\n");
+        r->grouped_rays = r->split_rays = r->quad_rays = r->pool_rays = false; r->staged_min_rays = 0xffffffffu;
     }
 #endif
     if (r->ray_counters.alloc(KJ_COUNTER_SLOTS * KJ_COUNTER_STRIDE * 8) != hipSuccess) { delete r; set_last_error("out of device memory"); return KJ_ERR_OUT_OF_MEMORY; }
@@ -1077,6 +1080,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         if (timed_extract) SCOPE_END(1);
     }
+#ifdef KJ_RAY_PASS_EXPERIMENTS
     // the pool form of the ray passes (k_rtdgi_rays_pool): persistent waves over the launch's tiles
     PoolArgs pa;
     memset(&pa, 0, sizeof(pa));
@@ -1102,7 +1106,6 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         if (validate) hipLaunchKernelGGL((r->count_traversal ? k_rtdgi_rays_pool<true, true> : k_rtdgi_rays_pool<true, false>), dim3(pool_grid), blk, pool_lds, s, tc, q);
         else hipLaunchKernelGGL((r->count_traversal ? k_rtdgi_rays_pool<false, true> : k_rtdgi_rays_pool<false, false>), dim3(pool_grid), blk, pool_lds, s, tc, q);
     };
-#ifdef KJ_RAY_PASS_EXPERIMENTS
     // the ray passes' stage buffers (dense, one slot per lane of every 8x8 tile of the launch)
     const uint32_t stage_rays = gh.x * gh.y * 64u;
     const size_t stage_full = size_t((hw + 7) / 8) * ((hh + 7) / 8) * 64;
@@ -1244,8 +1247,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     // the other forms live behind KJ_RAY_PASS_EXPERIMENTS (rtdgi_ray_experiments.inc)
     if (mask & KJ_RTDGI_PASS_VALIDATE) {
         SCOPE_BEGIN(2);
-        if (pool && is_rtdgi_validation_frame(r->dev->fc_host.frame_index)) launch_pool(true);    // two frames of three the pass only writes the invalidity image: the fused kernel does just that
-        else hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
                            img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(2);
@@ -1253,8 +1255,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     tc.request_slot_base = uint32_t(hw) * uint32_t(hh); tc.request_key_base = 2u << 28;
     if (mask & KJ_RTDGI_PASS_TRACE) {
         SCOPE_BEGIN(3);
-        if (pool) launch_pool(false);
-        else hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
                            img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
@@ -1384,7 +1385,7 @@ KjStatus kj_rtdgi_set_profiling(KjRtdgi* r, uint32_t enable_pass_timers, uint32_
 KjStatus kj_rtdgi_set_ray_pass_form(KjRtdgi* r, uint32_t form) {
     KJ_REQUIRE(r && form <= KJ_RTDGI_RAYS_POOL, "null argument / unknown form");
 #ifndef KJ_RAY_PASS_EXPERIMENTS
-    KJ_REQUIRE(form == KJ_RTDGI_RAYS_FUSED || form == KJ_RTDGI_RAYS_POOL, "this build carries the fused and the pool form only (the others: make EXPERIMENTS=1, -DKJ_RAY_PASS_EXPERIMENTS)");
+    KJ_REQUIRE(form == KJ_RTDGI_RAYS_FUSED, "this build carries the fused form only (the measured-and-rejected others, the pool form included: make EXPERIMENTS=1, -DKJ_RAY_PASS_EXPERIMENTS)");
 #endif
     r->pool_rays = form == KJ_RTDGI_RAYS_POOL;
     r->grouped_rays = form == KJ_RTDGI_RAYS_GROUPED;

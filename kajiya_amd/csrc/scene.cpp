@@ -70,7 +70,7 @@ uint32_t kj_abi_struct_size(uint32_t id) {
     static const uint32_t sizes[KJ_ABI_STRUCT_COUNT] = {
         sizeof(KjFrameConstants), sizeof(KjViewConstants), sizeof(KjMeshMaterial), sizeof(KjPackedVertex), sizeof(KjMaterialMap), sizeof(KjMeshDesc), sizeof(KjTriangleLight),
         sizeof(KjGbufferDepth), sizeof(KjRtdgiRenderParams), sizeof(KjRtdgiOutput), sizeof(KjTaaOutput), sizeof(KjRtrTables), sizeof(KjRtrParams), sizeof(KjSplitRank),
-        sizeof(KjSplitFrame), sizeof(KjBakedMeshView), sizeof(KjBakedImageView)};
+        sizeof(KjSplitFrame), sizeof(KjBakedMeshView), sizeof(KjBakedImageView), sizeof(KjSplitProfile)};
     return id < KJ_ABI_STRUCT_COUNT ? sizes[id] : 0u;
 }
 

@@ -58,6 +58,8 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool load() {
         if (lib) return true;
@@ -74,11 +76,12 @@ struct Rccl {
         Send = (decltype(Send))sym("ncclSend"); Recv = (decltype(Recv))sym("ncclRecv"); AllGather = (decltype(AllGather))sym("ncclAllGather");
         GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId"); CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy"); GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        CommCount = (decltype(CommCount))sym("ncclCommCount"); CommUserRank = (decltype(CommUserRank))sym("ncclCommUserRank");
         return GroupStart && GroupEnd && Send && Recv && AllGather && GetUniqueId && CommInitRank && CommDestroy;
     }
 };
 Rccl g_rccl;
-constexpr int NCCL_UINT8 = 1, NCCL_UINT32 = 3;     // ncclDataType_t (nccl.h): ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3
+constexpr int NCCL_UINT8 = 1;     // ncclDataType_t (nccl.h): ncclInt8 0, ncclUint8 1
 
 struct Item { std::string name; int halo; uint32_t pin = 0; };        // halo < 0: every row (all-gather); pin: the image's first rows, which every rank holds as well
 struct Block { uint32_t src, dst; std::string name; uint32_t row0, row1; };
@@ -101,12 +104,22 @@ struct KjSplit {
     bool rtr_requests_set = false;                         // kj_split_set_rtr switched the caches to the four-range slot layout: undone by kj_split_destroy
     bool merge_pending = false;                            // a frame recorded cache lookups that nobody has replayed yet: the next frame's head requires it clear
     void* nccl = nullptr;                                  // ncclComm_t; null: every rank is local
+    bool loopback = false;                                 // every rank is local AND a one-rank communicator is the wire: each message is an ncclSend to self matched by an ncclRecv from self
+                                                           // (the transport code and RCCL itself on the one GPU a build box has; tests/test_gpu_rccl_one_rank.py)
     std::map<std::pair<uint32_t, std::string>, std::pair<uint8_t*, uint64_t>> surfaces;     // (local index, name) -> base pointer, bytes
     std::vector<DevBuf> send_stage, recv_stage;            // [local rank * world + peer]: the packed rows of one exchange
-    // the cache's recorded updates of a frame
-    std::vector<DevBuf> strip_list, irc_list, merged, counts;   // per local rank; counts = two device dwords {strip, cache passes}
-    DevBuf all_counts;                                     // RCCL: every rank's strip count
-    std::vector<DevBuf> peer_lists;                        // RCCL: the other ranks' strip lists
+    // the cache's recorded updates of a frame: every rank's strip summary (kj_ircache_summarize_requests), all-gathered -- RCCL only; virtual ranks read each other's
+    DevBuf gathered;
+    DevBuf selftest_gather[2];                             // kj_split_self_test's fixed-size all-gather
+    // kj_split_set_profiling: HIP events around every exchange (pack + transport + scatter), bytes arriving at the busiest local rank
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+    std::vector<hipEvent_t> ev_free;
+    double exchange_ms = 0.0;
+    uint64_t exchange_bytes = 0;
+    uint32_t exchange_points = 0, frames_profiled = 0;
+    hipEvent_t take_event() { hipEvent_t e = nullptr; if (!ev_free.empty()) { e = ev_free.back(); ev_free.pop_back(); } else if (hipEventCreate(&e) != hipSuccess) e = nullptr; return e; }
+    ~KjSplit() { for (auto& p : ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); } for (hipEvent_t e : ev_free) (void)hipEventDestroy(e); }
 };
 
 namespace {
@@ -195,41 +208,70 @@ KjStatus exchange(KjSplit& s, const std::vector<Item>& items, hipStream_t st) {
             if (sb.bytes < send_bytes[li][p]) KJ_TRY_HIP(sb.alloc(send_bytes[li][p] + send_bytes[li][p] / 4, st));
             if (rbuf.bytes < recv_bytes[li][p]) KJ_TRY_HIP(rbuf.alloc(recv_bytes[li][p] + recv_bytes[li][p] / 4, st));
         }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (s.profiling) {
+        size_t busiest = 0;
+        for (uint32_t li = 0; li < s.local; ++li) { size_t n = 0; for (uint32_t p = 0; p < s.world; ++p) n += recv_bytes[li][p]; busiest = std::max(busiest, n); }
+        s.exchange_bytes += busiest; ++s.exchange_points;
+        ev0 = s.take_event(); ev1 = s.take_event();
+        if (ev0) KJ_TRY_HIP(hipEventRecord(ev0, st));
+    }
     std::vector<std::vector<size_t>> off(s.local, std::vector<size_t>(s.world, 0));
+    std::vector<CopyBlock> copies;       // the row blocks of a step, moved by ONE launch (kj_host.hpp: launch_copy_blocks) instead of one hipMemcpyAsync each
     for (const Block& b : blocks) {      // pack: the blocks bound for a peer, in plan order
         if (!is_local(s, b.src)) continue;
         const uint32_t li = b.src - s.first;
         uint8_t* ps; uint32_t rb;
         const KjStatus e = surface_of(s, b.src, b.name, &ps, &rb); if (e != KJ_OK) return e;
         const size_t n = size_t(b.row1 - b.row0) * rb;
-        KJ_TRY_HIP(hipMemcpyAsync((uint8_t*)s.send_stage[li * s.world + b.dst].p + off[li][b.dst], ps + size_t(b.row0) * rb, n, hipMemcpyDeviceToDevice, st));
+        copies.push_back(CopyBlock{ps + size_t(b.row0) * rb, (uint8_t*)s.send_stage[li * s.world + b.dst].p + off[li][b.dst], n});
         off[li][b.dst] += n;
     }
-    if (s.nccl) {       // one message per peer, all of them in one group
+    KJ_TRY_HIP(launch_copy_blocks(copies.data(), copies.size(), st));
+    if (s.nccl && s.loopback) {       // every rank lives here, the wire is RCCL all the same: one send to self + the matching receive per (source, destination), in one group
         KJ_REQUIRE(g_rccl.GroupStart() == 0, "ncclGroupStart failed");
-        for (uint32_t p = 0; p < s.world; ++p) {
-            if (send_bytes[0][p]) KJ_REQUIRE(g_rccl.Send(s.send_stage[p].p, send_bytes[0][p], NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclSend failed");
-            if (recv_bytes[0][p]) KJ_REQUIRE(g_rccl.Recv(s.recv_stage[p].p, recv_bytes[0][p], NCCL_UINT8, int(p), s.nccl, st) == 0, "ncclRecv failed");
+        bool ok = true;      // an error inside the group must not return before ncclGroupEnd
+        for (uint32_t src = 0; src < s.world && ok; ++src)
+            for (uint32_t dst = 0; dst < s.world && ok; ++dst)
+                if (send_bytes[src][dst]) {
+                    ok = ok && send_bytes[src][dst] == recv_bytes[dst][src];
+                    ok = ok && g_rccl.Send(s.send_stage[src * s.world + dst].p, send_bytes[src][dst], NCCL_UINT8, 0, s.nccl, st) == 0;
+                    ok = ok && g_rccl.Recv(s.recv_stage[dst * s.world + src].p, send_bytes[src][dst], NCCL_UINT8, 0, s.nccl, st) == 0;
+                }
+        const bool ended = g_rccl.GroupEnd() == 0;
+        KJ_REQUIRE(ok && ended, "ncclSend / ncclRecv to self / ncclGroupEnd failed");
+    } else if (s.nccl) {       // one message per peer, all of them in one group
+        KJ_REQUIRE(g_rccl.GroupStart() == 0, "ncclGroupStart failed");
+        bool ok = true;
+        for (uint32_t p = 0; p < s.world && ok; ++p) {
+            if (send_bytes[0][p]) ok = ok && g_rccl.Send(s.send_stage[p].p, send_bytes[0][p], NCCL_UINT8, int(p), s.nccl, st) == 0;
+            if (recv_bytes[0][p]) ok = ok && g_rccl.Recv(s.recv_stage[p].p, recv_bytes[0][p], NCCL_UINT8, int(p), s.nccl, st) == 0;
         }
-        KJ_REQUIRE(g_rccl.GroupEnd() == 0, "ncclGroupEnd failed");
+        const bool ended = g_rccl.GroupEnd() == 0;
+        KJ_REQUIRE(ok && ended, "ncclSend / ncclRecv / ncclGroupEnd failed");
     } else {            // every rank lives here: the "wire" is a copy from the sender's staging buffer to the receiver's
+        copies.clear();
         for (uint32_t src = 0; src < s.world; ++src)
             for (uint32_t dst = 0; dst < s.world; ++dst)
                 if (send_bytes[src][dst]) {
                     KJ_REQUIRE(send_bytes[src][dst] == recv_bytes[dst][src], "packed sizes disagree between the two ends of an exchange");
-                    KJ_TRY_HIP(hipMemcpyAsync(s.recv_stage[dst * s.world + src].p, s.send_stage[src * s.world + dst].p, send_bytes[src][dst], hipMemcpyDeviceToDevice, st));
+                    copies.push_back(CopyBlock{s.send_stage[src * s.world + dst].p, s.recv_stage[dst * s.world + src].p, send_bytes[src][dst]});
                 }
+        KJ_TRY_HIP(launch_copy_blocks(copies.data(), copies.size(), st));
     }
     for (auto& o : off) std::fill(o.begin(), o.end(), 0);
+    copies.clear();
     for (const Block& b : blocks) {      // scatter, in the same order
         if (!is_local(s, b.dst)) continue;
         const uint32_t li = b.dst - s.first;
         uint8_t* pd; uint32_t rb;
         const KjStatus e = surface_of(s, b.dst, b.name, &pd, &rb); if (e != KJ_OK) return e;
         const size_t n = size_t(b.row1 - b.row0) * rb;
-        KJ_TRY_HIP(hipMemcpyAsync(pd + size_t(b.row0) * rb, (const uint8_t*)s.recv_stage[li * s.world + b.src].p + off[li][b.src], n, hipMemcpyDeviceToDevice, st));
+        copies.push_back(CopyBlock{(const uint8_t*)s.recv_stage[li * s.world + b.src].p + off[li][b.src], pd + size_t(b.row0) * rb, n});
         off[li][b.src] += n;
     }
+    KJ_TRY_HIP(launch_copy_blocks(copies.data(), copies.size(), st));
+    if (ev0 && ev1) { KJ_TRY_HIP(hipEventRecord(ev1, st)); s.ev_pending.push_back({ev0, ev1}); }
     return KJ_OK;
 }
 
@@ -255,56 +297,15 @@ KjStatus ircache_head(KjSplit& s, uint32_t li, const KjSplitFrame& fr, hipStream
     return kj_ircache_trace_irradiance(c, s.ranks[li].scene, fr.sky_cube16, 16, st);
 }
 
-// The transport of the merge: every rank's strip list (strip_list[li], n_strip[li] records of 32 bytes; counts[li]'s first dword holds the same
-// number on the device) reaches every rank. Virtual ranks: nothing moves. RCCL: all-gather of the counts, then one send / receive per peer.
-KjStatus gather_strip_lists(KjSplit& s, const std::vector<uint32_t>& n_strip, std::vector<uint32_t>& all_strip, hipStream_t st) {
-    const size_t RQ = 32;
-    all_strip.assign(s.world, 0);
-    if (!s.nccl) { for (uint32_t li = 0; li < s.local; ++li) all_strip[li] = n_strip[li]; return KJ_OK; }
-    if (!s.all_counts.p) KJ_TRY_HIP(s.all_counts.alloc(size_t(s.world) * 4, st));
-    KJ_REQUIRE(g_rccl.AllGather(s.counts[0].p, s.all_counts.p, 1, NCCL_UINT32, s.nccl, st) == 0, "ncclAllGather failed");
-    KJ_TRY_HIP(hipMemcpyAsync(all_strip.data(), s.all_counts.p, size_t(s.world) * 4, hipMemcpyDeviceToHost, st));
-    KJ_TRY_HIP(hipStreamSynchronize(st));
-    const uint32_t me = s.first;
-    KJ_REQUIRE(all_strip[me] == n_strip[0], "the all-gathered record count of this rank is not the one it contributed");
-    for (uint32_t p = 0; p < s.world; ++p)
-        if (p != me && s.peer_lists[p].bytes < size_t(all_strip[p]) * RQ) KJ_TRY_HIP(s.peer_lists[p].alloc(size_t(all_strip[p]) * RQ + 4096, st));
-    KJ_REQUIRE(g_rccl.GroupStart() == 0, "ncclGroupStart failed");
-    bool ok = true;      // an error inside the group must not return before ncclGroupEnd: the peers would block in their receives
-    for (uint32_t p = 0; p < s.world && ok; ++p) {
-        if (p == me) continue;
-        if (all_strip[me]) ok = ok && g_rccl.Send(s.strip_list[0].p, size_t(all_strip[me]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0;
-        if (all_strip[p]) ok = ok && g_rccl.Recv(s.peer_lists[p].p, size_t(all_strip[p]) * RQ, NCCL_UINT8, int(p), s.nccl, st) == 0;
-    }
-    const bool ended = g_rccl.GroupEnd() == 0;
-    KJ_REQUIRE(ok && ended, "ncclSend / ncclRecv / ncclGroupEnd failed");
-    return KJ_OK;
-}
-
-// merged[li] = every rank's strip records in rank order, then local rank li's own n_irc records (irc_list[li])
-KjStatus assemble_lists(KjSplit& s, uint32_t li, const std::vector<uint32_t>& all_strip, uint32_t n_irc, size_t* out_total, hipStream_t st) {
-    const size_t RQ = 32;
-    size_t total = n_irc;
-    for (uint32_t p = 0; p < s.world; ++p) total += all_strip[p];
-    if (s.merged[li].bytes < std::max<size_t>(total, 1) * RQ) KJ_TRY_HIP(s.merged[li].alloc(std::max<size_t>(total, 1) * RQ + total * RQ / 4, st));
-    size_t off = 0;
-    for (uint32_t p = 0; p < s.world; ++p) {
-        const void* src = is_local(s, p) ? s.strip_list[p - s.first].p : s.peer_lists[p].p;
-        if (all_strip[p]) KJ_TRY_HIP(hipMemcpyAsync((uint8_t*)s.merged[li].p + off, src, size_t(all_strip[p]) * RQ, hipMemcpyDeviceToDevice, st));
-        off += size_t(all_strip[p]) * RQ;
-    }
-    if (n_irc) KJ_TRY_HIP(hipMemcpyAsync((uint8_t*)s.merged[li].p + off, s.irc_list[li].p, size_t(n_irc) * RQ, hipMemcpyDeviceToDevice, st));
-    *out_total = total;
-    return KJ_OK;
-}
-
-// All-gather of this frame's recorded cache updates, then the same replay on every rank. A strip's rtdgi lookups (validate and trace
-// pass) occupy contiguous slots (rows of the half-res image); the cache's own ray passes are replicated, so their records are identical
-// on every rank and stay local. Merged order = every rank's strip records in rank order, then the cache's own (multigpu.py).
+// This frame's recorded cache updates: every local rank reduces its strip's per-pixel lookups (rtdgi's validate and trace pass -- rows of the half-res image are
+// contiguous slots --, and rtr's two with reflections in the frame) into its cache's summary 0 and the cache's own ray passes' (replicated: identical on every
+// rank) into summary 1; the strip summaries are all-gathered -- ONE fixed-size ncclAllGather; virtual ranks read each other's buffers -- and every rank merges
+// the same summaries in rank order plus its local one (ircache.hip: a reduction whose result does not depend on the number of ranks). Nothing is read back:
+// no list lengths, no host synchronisation (rounds 2-5: two hipStreamSynchronize per split frame for the record counts, a sort of the merged records).
 KjStatus merge_ircache_requests(KjSplit& s, hipStream_t st) {
-    const size_t RQ = 32;
     s.merge_pending = false;
-    std::vector<uint32_t> n_strip(s.local), n_irc(s.local), cap_strip(s.local), cap_irc(s.local);
+    const size_t SB = size_t(kj_ircache_summary_bytes());
+    std::vector<void*> strip_sum(s.local, nullptr), own_sum(s.local, nullptr);
     for (uint32_t li = 0; li < s.local; ++li) {
         KjIrcache* c = s.ranks[li].ircache;
         uint32_t first[4], count[4];
@@ -313,30 +314,25 @@ KjStatus merge_ircache_requests(KjSplit& s, hipStream_t st) {
         const uint32_t px = (h.second - h.first) * s.hw;
         uint32_t rtr_first[2] = {0, 0}, rtr_count[2] = {0, 0};
         if (s.with_rtr && (e = kj_ircache_rtr_request_ranges(c, rtr_first, rtr_count)) != KJ_OK) return e;
-        cap_strip[li] = (s.with_rtr ? 4 : 2) * px; cap_irc[li] = count[2] + count[3];
-        if (s.strip_list[li].bytes < size_t(cap_strip[li]) * RQ) KJ_TRY_HIP(s.strip_list[li].alloc(size_t(cap_strip[li]) * RQ, st));
-        if (s.irc_list[li].bytes < size_t(cap_irc[li]) * RQ) KJ_TRY_HIP(s.irc_list[li].alloc(size_t(cap_irc[li]) * RQ, st));
-        if (!s.counts[li].p) KJ_TRY_HIP(s.counts[li].alloc(8, st));
-        KJ_TRY_HIP(hipMemsetAsync(s.counts[li].p, 0, 8, st));
-        uint32_t* cnt = (uint32_t*)s.counts[li].p;
-        if ((e = kj_ircache_collect_requests(c, first[0] + h.first * s.hw, px, s.strip_list[li].p, cap_strip[li], cnt, st)) != KJ_OK) return e;
-        if ((e = kj_ircache_collect_requests(c, first[1] + h.first * s.hw, px, s.strip_list[li].p, cap_strip[li], cnt, st)) != KJ_OK) return e;
-        if (s.with_rtr)      // the lookups of rtr's validate and trace rays on this strip (kj_split_rtr_frame)
-            for (int k = 0; k < 2; ++k)
-                if ((e = kj_ircache_collect_requests(c, rtr_first[k] + h.first * s.hw, px, s.strip_list[li].p, cap_strip[li], cnt, st)) != KJ_OK) return e;
-        if ((e = kj_ircache_collect_requests(c, first[2], count[2], s.irc_list[li].p, cap_irc[li], cnt + 1, st)) != KJ_OK) return e;
-        if ((e = kj_ircache_collect_requests(c, first[3], count[3], s.irc_list[li].p, cap_irc[li], cnt + 1, st)) != KJ_OK) return e;
+        const uint32_t sf[4] = {first[0] + h.first * s.hw, first[1] + h.first * s.hw, rtr_first[0] + h.first * s.hw, rtr_first[1] + h.first * s.hw}, sc[4] = {px, px, px, px};
+        if ((e = kj_ircache_summarize_requests(c, sf, sc, s.with_rtr ? 4u : 2u, 0u, st)) != KJ_OK) return e;
+        if ((e = kj_ircache_summarize_requests(c, first + 2, count + 2, 2u, 1u, st)) != KJ_OK) return e;
+        if ((e = kj_ircache_summary(c, 0u, &strip_sum[li])) != KJ_OK || (e = kj_ircache_summary(c, 1u, &own_sum[li])) != KJ_OK) return e;
     }
-    std::vector<uint32_t> host(size_t(s.local) * 2);
-    for (uint32_t li = 0; li < s.local; ++li) KJ_TRY_HIP(hipMemcpyAsync(&host[li * 2], s.counts[li].p, 8, hipMemcpyDeviceToHost, st));
-    KJ_TRY_HIP(hipStreamSynchronize(st));      // the list lengths are needed on the host (as in the reference orchestrator)
-    for (uint32_t li = 0; li < s.local; ++li) { n_strip[li] = host[li * 2]; n_irc[li] = host[li * 2 + 1]; }
-    std::vector<uint32_t> all_strip;
-    KjStatus e = gather_strip_lists(s, n_strip, all_strip, st); if (e != KJ_OK) return e;
+    std::vector<const void*> src(size_t(s.world) + 1);
+    if (s.profiling) { s.exchange_bytes += SB * (s.world - 1u); ++s.exchange_points; }      // what the all-gather delivers to every rank (virtual ranks read in place)
+    if (s.nccl) {
+        if (s.gathered.bytes < SB * s.world) KJ_TRY_HIP(s.gathered.alloc(SB * s.world, st));
+        if (s.loopback)      // a one-rank communicator: every virtual rank's summary goes through an all-gather of one
+            for (uint32_t p = 0; p < s.world; ++p) KJ_REQUIRE(g_rccl.AllGather(strip_sum[p], (uint8_t*)s.gathered.p + size_t(p) * SB, SB, NCCL_UINT8, s.nccl, st) == 0, "ncclAllGather failed");
+        else KJ_REQUIRE(g_rccl.AllGather(strip_sum[0], s.gathered.p, SB, NCCL_UINT8, s.nccl, st) == 0, "ncclAllGather failed");
+        for (uint32_t p = 0; p < s.world; ++p) src[p] = (const uint8_t*)s.gathered.p + size_t(p) * SB;
+    } else
+        for (uint32_t p = 0; p < s.world; ++p) src[p] = strip_sum[p];
     for (uint32_t li = 0; li < s.local; ++li) {
-        size_t total = 0;
-        if ((e = assemble_lists(s, li, all_strip, n_irc[li], &total, st)) != KJ_OK) return e;
-        if ((e = kj_ircache_apply_requests(s.ranks[li].ircache, s.merged[li].p, uint32_t(total), st)) != KJ_OK) return e;
+        src[s.world] = own_sum[li];
+        const KjStatus e = kj_ircache_apply_summaries(s.ranks[li].ircache, src.data(), s.world + 1u, st);
+        if (e != KJ_OK) return e;
     }
     return KJ_OK;
 }
@@ -358,12 +354,18 @@ extern "C" {
 KjStatus kj_split_create(uint32_t world, uint32_t first_rank, uint32_t local_ranks, const KjSplitRank* ranks, uint32_t width, uint32_t height, uint32_t motion_halo,
                          void* nccl_comm, KjSplit** out) {
     KJ_REQUIRE(out && ranks && world >= 1 && local_ranks >= 1 && first_rank + local_ranks <= world, "bad rank layout");
-    KJ_REQUIRE(nccl_comm ? local_ranks == 1 : local_ranks == world, "without a communicator every rank must live in this process; with one, exactly one does");
+    KJ_REQUIRE(nccl_comm ? (local_ranks == 1 || local_ranks == world) : local_ranks == world,
+               "without a communicator every rank must live in this process; with one, exactly one does -- or all of them over a ONE-rank communicator (loopback)");
     KJ_REQUIRE(width >= 16 && height >= 16 * world, "image too small for this many strips");
     if (nccl_comm) KJ_REQUIRE(g_rccl.load(), "librccl.so could not be loaded");
+    const bool loopback = nccl_comm && local_ranks == world && world > 1;
+    if (loopback) {
+        int n = 0;
+        KJ_REQUIRE(g_rccl.CommCount && g_rccl.CommCount(nccl_comm, &n) == 0 && n == 1, "loopback (every rank local, RCCL as the wire) needs a communicator of exactly one rank");
+    }
     KjSplit* s = new KjSplit();
     s->world = world; s->first = first_rank; s->local = local_ranks; s->W = width; s->H = height; s->hw = (width + 1) / 2; s->hh = (height + 1) / 2;
-    s->motion_halo = motion_halo; s->nccl = nccl_comm;
+    s->motion_halo = motion_halo; s->nccl = nccl_comm; s->loopback = loopback;
     s->ranks.assign(ranks, ranks + local_ranks);
     // 16-aligned cuts, as even as possible (multigpu.py: plan_strips)
     const uint32_t units = (height + 15) / 16, base = units / world, extra = units % world;
@@ -380,8 +382,8 @@ KjStatus kj_split_create(uint32_t world, uint32_t first_rank, uint32_t local_ran
         s->ircache_was_deferred.push_back(r.ircache && r.ircache->deferred ? 1 : 0);
         if (r.ircache) { const KjStatus e = kj_ircache_set_deferred_updates(r.ircache, all_cached ? 1u : 0u); if (e != KJ_OK) { delete s; return e; } }
     }
-    s->send_stage = std::vector<DevBuf>(size_t(local_ranks) * world); s->recv_stage = std::vector<DevBuf>(size_t(local_ranks) * world); s->peer_lists = std::vector<DevBuf>(world);
-    s->strip_list = std::vector<DevBuf>(local_ranks); s->irc_list = std::vector<DevBuf>(local_ranks); s->merged = std::vector<DevBuf>(local_ranks); s->counts = std::vector<DevBuf>(local_ranks);
+    KJ_REQUIRE(world + 1u <= 32u || !all_cached, "the cache's replay merges at most 32 summaries (31 ranks)");
+    s->send_stage = std::vector<DevBuf>(size_t(local_ranks) * world); s->recv_stage = std::vector<DevBuf>(size_t(local_ranks) * world);
     *out = s;
     return KJ_OK;
 }
@@ -473,12 +475,13 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
     KJ_SPLIT_TRY(exchange(*s, {{"temporal_filtered_tex", 16}}, st));
     for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_SPATIAL_FILTER | KEEP, s->strips[s->first + li], 0, st));
     s->frame++;
+    if (s->profiling) ++s->frames_profiled;
     return KJ_OK;
 }
 
-// The replay a frame issued with KJ_SPLIT_DEFER_IRCACHE_MERGE left out: all-gather of the frame's recorded cache updates + the same
-// replay on every rank. It reads the list lengths back (two host syncs on `stream`), which is why a pipelining caller runs it on its cache
-// stream after the whole frame is enqueued -- before the next frame's kj_ircache_prepare.
+// The replay a frame issued with KJ_SPLIT_DEFER_IRCACHE_MERGE left out: all-gather of the ranks' summaries of the frame's recorded cache updates + the same
+// merge on every rank (no host synchronisation since round 6). A pipelining caller runs it on its cache stream -- before the next frame's kj_ircache_prepare --
+// so that the all-gather overlaps the main stream's resampling chain.
 KjStatus kj_split_merge_ircache(KjSplit* s, void* stream) {
     KJ_REQUIRE(s, "null argument");
     return s->consistent_ircache ? merge_ircache_requests(*s, (hipStream_t)stream) : KJ_OK;
@@ -632,8 +635,8 @@ KjStatus kj_split_gather(KjSplit* s, const char* surface_name, void* stream) {
 
 // Start-up check of the transport, before frame 0 (multigpu.py: SplitRtdgi.self_test is the same check of the Python orchestrator's): every kind of exchange the
 // frame schedule uses -- the all-gather of a full-res image, several surfaces of different texel sizes and halos packed into one message per peer, the 64-row
-// one-deep halo, stencil halos, and the variable-length all-gather of the cache's record lists -- runs once on scratch images whose rows carry their OWNER's
-// rank, through exchange() / gather_strip_lists() themselves; each local rank's images are then read back and every row it is entitled to must hold the
+// one-deep halo, stencil halos, and the fixed-size all-gather of the cache's summaries -- runs once on scratch images whose rows carry their OWNER's
+// rank, through exchange() (and the fixed-size ncclAllGather the cache's summaries travel by) itself; each local rank's images are then read back and every row it is entitled to must hold the
 // owner's pattern, every other row must be untouched. *out_passed = 1 when all local ranks passed; the caller combines the ranks' verdicts (bench.py:
 // all-reduce MIN) -- a transport error is returned as an error. Synchronises `stream`; not for use inside a frame.
 KjStatus kj_split_self_test(KjSplit* s, uint32_t* out_passed, void* stream) {
@@ -697,33 +700,47 @@ KjStatus kj_split_self_test(KjSplit* s, uint32_t* out_passed, void* stream) {
                 }
             }
     }
-    // the record lists: rank r contributes r + 1 records of bytes r + 1
-    const size_t RQ = 32;
-    std::vector<uint32_t> n_strip(s->local), all_strip;
-    for (uint32_t li = 0; li < s->local; ++li) {
-        const uint32_t rank = s->first + li;
-        n_strip[li] = rank + 1;
-        if (s->strip_list[li].bytes < size_t(rank + 1) * RQ) KJ_TRY_HIP(s->strip_list[li].alloc(size_t(rank + 1) * RQ, st));
-        KJ_TRY_HIP(hipMemsetAsync(s->strip_list[li].p, int(rank + 1), size_t(rank + 1) * RQ, st));
-        if (!s->counts[li].p) KJ_TRY_HIP(s->counts[li].alloc(8, st));
-        const uint32_t cnt[2] = {rank + 1, 0};
-        KJ_TRY_HIP(hipMemcpyAsync(s->counts[li].p, cnt, 8, hipMemcpyHostToDevice, st));
-        KJ_TRY_HIP(hipStreamSynchronize(st));     // (cnt lives on this stack frame)
-    }
-    KJ_SPLIT_TRY(gather_strip_lists(*s, n_strip, all_strip, st));
-    for (uint32_t li = 0; li < s->local; ++li) {
-        size_t total = 0;
-        KJ_SPLIT_TRY(assemble_lists(*s, li, all_strip, 0, &total, st));
-        ok = ok && total == size_t(s->world) * (s->world + 1) / 2;
-        if (!ok) break;
-        host.resize(total * RQ);
-        KJ_TRY_HIP(hipMemcpyAsync(host.data(), s->merged[li].p, host.size(), hipMemcpyDeviceToHost, st));
+    // the fixed-size all-gather the cache's summaries travel by: rank r contributes 4 KB of bytes r + 1 (plain virtual ranks read each other's buffers: nothing to test)
+    if (s->nccl && ok) {
+        const size_t N = 4096;
+        KJ_TRY_HIP(s->selftest_gather[0].alloc(N * s->local, st)); KJ_TRY_HIP(s->selftest_gather[1].alloc(N * s->world, st));
+        for (uint32_t li = 0; li < s->local; ++li) KJ_TRY_HIP(hipMemsetAsync((uint8_t*)s->selftest_gather[0].p + N * li, int(s->first + li + 1), N, st));
+        KJ_TRY_HIP(hipMemsetAsync(s->selftest_gather[1].p, 0, N * s->world, st));
+        if (s->loopback)
+            for (uint32_t p = 0; p < s->world; ++p)
+                KJ_REQUIRE(g_rccl.AllGather((uint8_t*)s->selftest_gather[0].p + N * p, (uint8_t*)s->selftest_gather[1].p + N * p, N, NCCL_UINT8, s->nccl, st) == 0, "ncclAllGather failed");
+        else KJ_REQUIRE(g_rccl.AllGather(s->selftest_gather[0].p, s->selftest_gather[1].p, N, NCCL_UINT8, s->nccl, st) == 0, "ncclAllGather failed");
+        host.resize(N * s->world);
+        KJ_TRY_HIP(hipMemcpyAsync(host.data(), s->selftest_gather[1].p, host.size(), hipMemcpyDeviceToHost, st));
         KJ_TRY_HIP(hipStreamSynchronize(st));
-        size_t off = 0;
         for (uint32_t r = 0; r < s->world; ++r)
-            for (size_t b = 0; b < size_t(r + 1) * RQ; ++b) ok = ok && host[off++] == uint8_t(r + 1);
+            for (size_t b = 0; b < N; ++b) ok = ok && host[size_t(r) * N + b] == uint8_t(r + 1);
     }
     *out_passed = ok ? 1u : 0u;
+    return KJ_OK;
+}
+
+// Measurement aid (bench.py's split_virtual_* lines, scripts/split_virtual_bench.py): with profiling on, every exchange is bracketed by two HIP events on the frame's
+// stream (pack + transport + scatter: with virtual ranks the device copies that stand in for the wire) and the bytes arriving at the busiest local rank are summed.
+// kj_split_profile waits for the recorded events and reports the totals since profiling was switched on.
+KjStatus kj_split_set_profiling(KjSplit* s, uint32_t enable) {
+    KJ_REQUIRE(s, "null argument");
+    for (auto& p : s->ev_pending) { s->ev_free.push_back(p.first); s->ev_free.push_back(p.second); }
+    s->ev_pending.clear();
+    s->profiling = enable != 0; s->exchange_ms = 0.0; s->exchange_bytes = 0; s->exchange_points = 0; s->frames_profiled = 0;
+    return KJ_OK;
+}
+KjStatus kj_split_profile(KjSplit* s, KjSplitProfile* out) {
+    KJ_REQUIRE(s && out, "null argument");
+    for (auto& p : s->ev_pending) {
+        KJ_TRY_HIP(hipEventSynchronize(p.second));
+        float ms = 0.0f;
+        KJ_TRY_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+        s->exchange_ms += double(ms);
+        s->ev_free.push_back(p.first); s->ev_free.push_back(p.second);
+    }
+    s->ev_pending.clear();
+    out->exchange_ms = s->exchange_ms; out->exchange_bytes_busiest_rank = s->exchange_bytes; out->exchange_points = s->exchange_points; out->gi_frames = s->frames_profiled;
     return KJ_OK;
 }
 
@@ -740,6 +757,15 @@ KjStatus kj_split_rccl_comm_create(const uint8_t id[128], uint32_t world, uint32
     KJ_REQUIRE(g_rccl.load(), "librccl.so could not be loaded");
     Rccl::Id128 v; memcpy(v.b, id, 128);
     KJ_REQUIRE(g_rccl.CommInitRank(out_comm, int(world), v, int(rank)) == 0, "ncclCommInitRank failed");
+    return KJ_OK;
+}
+// What the communicator itself says about its size and this process' place in it (ncclCommCount / ncclCommUserRank).
+KjStatus kj_split_rccl_comm_info(void* comm, uint32_t* out_ranks, uint32_t* out_rank) {
+    KJ_REQUIRE(comm && out_ranks && out_rank, "null argument");
+    KJ_REQUIRE(g_rccl.load() && g_rccl.CommCount && g_rccl.CommUserRank, "librccl.so could not be loaded");
+    int n = 0, r = 0;
+    KJ_REQUIRE(g_rccl.CommCount(comm, &n) == 0 && g_rccl.CommUserRank(comm, &r) == 0, "ncclCommCount / ncclCommUserRank failed");
+    *out_ranks = uint32_t(n); *out_rank = uint32_t(r);
     return KJ_OK;
 }
 void kj_split_rccl_comm_destroy(void* comm) { if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm); }

@@ -25,7 +25,7 @@ EXPORTS = [
     "kj_rtdgi_create", "kj_rtdgi_destroy", "kj_rtdgi_set_options", "kj_rtdgi_reproject", "kj_rtdgi_reproject_rows", "kj_rtdgi_render",
     "kj_rtdgi_surface", "kj_rtdgi_ray_counts", "kj_rtdgi_set_profiling", "kj_rtdgi_set_ray_pass_form", "kj_rtdgi_set_pool_tune", "kj_rtdgi_pass_times_ms", "kj_rtdgi_traversal_counts",
     "kj_ircache_create", "kj_ircache_destroy", "kj_ircache_update_eye_position", "kj_ircache_constants", "kj_ircache_set_enable_scroll",
-    "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts", "kj_ircache_set_deferred_updates", "kj_ircache_set_ray_passes_side_by_side", "kj_ircache_set_ray_pass_schedule", "kj_ircache_begin_requests", "kj_ircache_begin_requests_rows", "kj_ircache_request_ranges", "kj_ircache_collect_requests", "kj_ircache_apply_requests", "kj_ircache_set_rtr_requests", "kj_ircache_rtr_request_ranges",
+    "kj_ircache_prepare", "kj_ircache_trace_irradiance", "kj_ircache_sum_up_irradiance_for_sampling", "kj_ircache_buffer", "kj_ircache_ray_counts", "kj_ircache_set_deferred_updates", "kj_ircache_set_ray_passes_side_by_side", "kj_ircache_set_ray_pass_schedule", "kj_ircache_begin_requests", "kj_ircache_begin_requests_rows", "kj_ircache_request_ranges", "kj_ircache_summary_bytes", "kj_ircache_summarize_requests", "kj_ircache_summary", "kj_ircache_apply_summaries", "kj_ircache_apply_requests", "kj_ircache_set_rtr_requests", "kj_ircache_rtr_request_ranges",
     "kj_taa_create", "kj_taa_destroy", "kj_taa_render", "kj_taa_render_rows", "kj_taa_surface", "kj_reference_path_trace",
     "kj_ssgi_create", "kj_ssgi_destroy", "kj_ssgi_render", "kj_ssgi_render_rows", "kj_ssgi_surface", "kj_trace_sun_shadow_mask", "kj_trace_sun_shadow_mask_rows", "kj_light_gbuffer", "kj_light_gbuffer_rows",
     "kj_shadow_denoise_create", "kj_shadow_denoise_destroy", "kj_shadow_denoise_render", "kj_shadow_denoise_render_rows", "kj_shadow_denoise_surface",
@@ -34,7 +34,7 @@ EXPORTS = [
     "kj_post_create", "kj_post_destroy", "kj_post_render", "kj_post_read_back_histogram", "kj_luminance_histogram_mean_log2", "kj_post_surface", "kj_post_mip_levels",
     "kj_motion_blur_create", "kj_motion_blur_destroy", "kj_motion_blur_render", "kj_motion_blur_surface",
     "kj_split_create", "kj_split_destroy", "kj_split_strip", "kj_split_gi_frame", "kj_split_merge_ircache", "kj_split_taa_frame", "kj_split_taa_frame_on", "kj_split_ssgi_frame", "kj_split_gather", "kj_split_self_test", "kj_split_shadow_frame", "kj_split_set_rtr", "kj_split_rtr_frame",
-    "kj_split_rccl_unique_id", "kj_split_rccl_comm_create", "kj_split_rccl_comm_destroy",
+    "kj_split_set_profiling", "kj_split_profile", "kj_split_rccl_unique_id", "kj_split_rccl_comm_create", "kj_split_rccl_comm_info", "kj_split_rccl_comm_destroy",
 ]
 
 _LIB = None
@@ -60,6 +60,8 @@ def load():
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
     L.kj_last_error.restype = C.c_char_p
     L.kj_abi_version.restype = u32
+    L.kj_ircache_summary_bytes.argtypes = []
+    L.kj_ircache_summary_bytes.restype = C.c_uint64
     sig = {
         "kj_device_create": [i32, vp, C.POINTER(vp)],
         "kj_device_brdf_lut": [vp, C.POINTER(vp)],
@@ -81,7 +83,9 @@ def load():
         "kj_ircache_begin_requests": [vp, u32, u32, vp],
         "kj_ircache_begin_requests_rows": [vp, u32, u32, u32, u32, vp],
         "kj_ircache_request_ranges": [vp, C.POINTER(u32), C.POINTER(u32)],
-        "kj_ircache_collect_requests": [vp, u32, u32, vp, u32, vp, vp],
+        "kj_ircache_summarize_requests": [vp, C.POINTER(u32), C.POINTER(u32), u32, u32, vp],
+        "kj_ircache_summary": [vp, u32, C.POINTER(vp)],
+        "kj_ircache_apply_summaries": [vp, C.POINTER(vp), u32, vp],
         "kj_ircache_apply_requests": [vp, vp, u32, vp],
         "kj_ircache_set_rtr_requests": [vp, u32],
         "kj_ircache_rtr_request_ranges": [vp, C.POINTER(u32), C.POINTER(u32)],
@@ -161,8 +165,11 @@ def load():
         "kj_split_shadow_frame": [vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
         "kj_split_set_rtr": [vp, u32],
         "kj_split_rtr_frame": [vp, C.POINTER(vp), C.POINTER(KjRtrParams), u32, vp, C.POINTER(vp), vp],
+        "kj_split_set_profiling": [vp, u32],
+        "kj_split_profile": [vp, vp],
         "kj_split_rccl_unique_id": [vp],
         "kj_split_rccl_comm_create": [vp, u32, u32, C.POINTER(vp)],
+        "kj_split_rccl_comm_info": [vp, C.POINTER(u32), C.POINTER(u32)],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -531,36 +538,35 @@ class GpuPipeline:
         check(self.L.kj_ircache_rtr_request_ranges(self.ircache, first, count))
         return list(first), list(count)
 
-    def ircache_collect(self, ranges, capacity=None, tag="all"):
-        """Compacts the recorded requests of the slot ranges [(first, count), ...] into one device list; returns (int32 tensor
-        [capacity, 8], device int32 counter). 32 bytes per request. The list buffer is cached per (`tag`, capacity): two lists that
-        are alive at the same time (a strip's and the cache passes' in the split) must carry different tags -- with equal
-        capacities (2 x 262144 half-res pixels == 2 x IRC_MAX_ENTRIES x 4) they would otherwise share one buffer."""
-        torch = self.torch
-        capacity = capacity or sum(c for _, c in ranges)
-        key = ("_req_list", tag, capacity)
-        buf = getattr(self, "_req_bufs", {}).get(key)
-        if buf is None:
-            buf = torch.empty((max(1, capacity), 8), dtype=torch.int32, device=self.depth.device)
-            self._req_bufs = getattr(self, "_req_bufs", {})
-            self._req_bufs[key] = buf
-        cnt = torch.zeros(1, dtype=torch.int32, device=self.depth.device)
-        s = _stream_ptr()
-        for first, count in ranges:
-            if count:
-                check(self.L.kj_ircache_collect_requests(self.ircache, first, count, buf.data_ptr(), capacity, cnt.data_ptr(), s))
-        return buf, cnt
+    def ircache_summarize(self, ranges, which=0):
+        """Reduces the recorded lookups of the slot ranges [(first, count), ...] into the cache's fixed-size summary `which` (0: the part a rank of the
+        split sends to the others; 1: the part that stays local) and returns it as a uint8 device tensor (include/kajiya_amd.h: kj_ircache_summarize_requests)."""
+        ranges = [(f, c) for f, c in ranges if c]
+        first = (C.c_uint32 * max(1, len(ranges)))(*[f for f, _ in ranges])
+        count = (C.c_uint32 * max(1, len(ranges)))(*[c for _, c in ranges])
+        check(self.L.kj_ircache_summarize_requests(self.ircache, first, count, len(ranges), which, _stream_ptr()))
+        return self.ircache_summary(which)
+
+    def ircache_summary(self, which=0):
+        p = C.c_void_p()
+        check(self.L.kj_ircache_summary(self.ircache, which, C.byref(p)))
+        return tensor_from_ptr(p.value, int(self.L.kj_ircache_summary_bytes()), self.torch.uint8, (-1,))
+
+    def ircache_apply_summaries(self, summaries):
+        """The replay: merges the summaries (uint8 device tensors; the same ones in the same order on every replica) and applies the result."""
+        ptrs = (C.c_void_p * len(summaries))(*[t.data_ptr() for t in summaries])
+        check(self.L.kj_ircache_apply_summaries(self.ircache, ptrs, len(summaries), _stream_ptr()))
 
     def ircache_apply(self, requests, count):
+        """A plain device list of 32-byte records replayed at once (kj_ircache_apply_requests)."""
         if count:
             check(self.L.kj_ircache_apply_requests(self.ircache, requests.data_ptr(), int(count), _stream_ptr()))
 
     def ircache_replay_own_requests(self):
-        """Single GPU in deferred mode: everything this frame's lookups recorded, replayed in the canonical order."""
+        """Single GPU in deferred mode: everything this frame's lookups recorded, reduced and replayed."""
         first, count = self.ircache_request_ranges()
         f2, c2 = self.ircache_rtr_request_ranges()       # (empty unless the frame has reflections: ircache_set_rtr_requests)
-        buf, cnt = self.ircache_collect(list(zip(first + f2, count + c2)))
-        self.ircache_apply(buf, int(cnt.item()))
+        self.ircache_apply_summaries([self.ircache_summarize(list(zip(first + f2, count + c2)))])
 
     def taa_frame(self, input_ptr=None, out_extent=None):
         """TaaRenderer::render on `input_ptr` (default: this frame's rtdgi screen_irradiance_tex)."""

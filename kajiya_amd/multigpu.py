@@ -144,15 +144,10 @@ class LocalComm:
         for (_, dst), data in zip(pairs, staged):
             dst.copy_(data)
 
-    def all_gather_rows(self, parts):
-        """parts: {rank: (tensor [capacity, k], valid row count)} -> {rank: every rank's valid rows, concatenated in rank order}."""
-        return _local_all_gather_rows(parts, self.ranks)
-
-
-def _local_all_gather_rows(parts, ranks):
-    import torch
-    cat = torch.cat([parts[r][0][:parts[r][1]] for r in sorted(parts)], dim=0)
-    return {r: cat for r in ranks}
+    def all_gather_fixed(self, parts):
+        """parts: {rank: tensor} (the same shape on every rank) -> {rank: [every rank's tensor, in rank order]}. Virtual ranks: nothing moves."""
+        every = [parts[r] for r in sorted(parts)]
+        return {r: every for r in self.ranks}
 
 
 class DistComm:
@@ -221,26 +216,20 @@ class DistComm:
         for w in d.batch_isend_irecv(ops):
             w.wait()
 
-    def all_gather_rows(self, parts):
-        """Variable-length all-gather: the row counts first (one small all_gather), then the rows padded to the largest count."""
+    def all_gather_fixed(self, parts):
+        """All-gather of one fixed-size tensor per rank (the irradiance cache's summaries: no counts, nothing the host has to read)."""
         import torch
         d = self.dist
-        buf, n = parts[self.rank]
-        dev = buf.device
+        mine = parts[self.rank]
+        dev = mine.device
         stage = self.stage or d.get_backend() == "gloo" and dev.type != "cpu"
-        counts = torch.zeros(self.n, dtype=torch.int64, device="cpu" if stage else dev)
-        mine = torch.tensor([n], dtype=torch.int64, device=counts.device)
-        d.all_gather_into_tensor(counts, mine)
-        counts = [int(c) for c in counts.tolist()]
-        m = max(counts)
-        if m == 0:
-            return {self.rank: buf[:0]}
-        send = torch.zeros((m, buf.shape[1]), dtype=buf.dtype, device="cpu" if stage else dev)
-        send[:n].copy_(buf[:n])
-        recv = torch.empty((self.n * m, buf.shape[1]), dtype=buf.dtype, device=send.device)
+        send = (mine.cpu() if stage else mine).contiguous().reshape(-1)
+        recv = torch.empty(self.n * send.numel(), dtype=send.dtype, device=send.device)      # (flat: gloo's all-gather takes no leading rank dimension)
         d.all_gather_into_tensor(recv, send)
-        rows = torch.cat([recv[i * m:i * m + counts[i]] for i in range(self.n)], dim=0).to(dev)
-        return {self.rank: rows}
+        if stage:
+            recv = recv.to(dev)
+        self._keep_gathered = recv
+        return {self.rank: [recv[i * send.numel():(i + 1) * send.numel()].reshape(mine.shape) for i in range(self.n)]}
 
     def run(self, xfers, get_rows):
         ops, landing = [], []
@@ -434,9 +423,9 @@ class SplitRtdgi:
 
     def self_test(self, device=None):
         """Start-up check of the transport, before frame 0: every kind of exchange the frame schedule uses -- the all-gather of a
-        full-res image, motion halos, the 64-row one-deep halo of half-res records, full-res stencil halos, the variable-length
-        all-gather of cache records -- runs once on scratch images whose rows carry their OWNER's rank, through the same
-        `comm.prepare` / `run_prepared` / `all_gather_rows` code (incl. the packed mode), and each rank then checks on the device that
+        full-res image, motion halos, the 64-row one-deep halo of half-res records, full-res stencil halos, the fixed-size
+        all-gather of the cache's summaries -- runs once on scratch images whose rows carry their OWNER's rank, through the same
+        `comm.prepare` / `run_prepared` / `all_gather_fixed` code (incl. the packed mode), and each rank then checks on the device that
         every row it is entitled to holds the owner's pattern. Returns True when every rank passed (collective); the first N > 1 run on
         real hardware certifies its own communicator this way (bench.py prints "RCCL <n> ranks OK")."""
         import torch
@@ -479,15 +468,11 @@ class SplitRtdgi:
                     ok = False
                     import sys
                     print(f"[kajiya_amd split self-test] rank {r}: exchange '{what}' delivered wrong rows", file=sys.stderr, flush=True)
-        # the variable-length all-gather of cache records: rank r contributes r + 1 rows of value r + 1
-        parts = {}
+        # the fixed-size all-gather of the cache's summaries: rank r contributes 4 KB of value r + 1
+        parts = {r: torch.full((4096,), r + 1, dtype=torch.uint8, device=dev) for r in self.comm.ranks}
+        got = self.comm.all_gather_fixed(parts)
         for r in self.comm.ranks:
-            buf = torch.full((n + 3, 8), r + 1, dtype=torch.int32, device=dev)
-            parts[r] = (buf, r + 1)
-        got = self.comm.all_gather_rows(parts)
-        want = torch.cat([torch.full((q + 1, 8), q + 1, dtype=torch.int32) for q in range(n)], dim=0).to(dev)
-        for r in self.comm.ranks:
-            if got[r].shape != want.shape or not bool((got[r] == want).all().item()):
+            if len(got[r]) != n or not all(bool((got[r][q] == q + 1).all().item()) for q in range(n)):
                 ok = False
         if isinstance(self.comm, DistComm):
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if (self.comm.stage or self.comm.dist.get_backend() == "gloo") else dev)
@@ -742,27 +727,22 @@ class SplitRtdgi:
         self.frame += 1
 
     def _merge_ircache_requests(self):
-        """All-gather of this frame's recorded cache updates, then the same replay on every rank. A strip's rtdgi lookups (validate and
-        trace pass) -- and, with reflections in the frame, rtr's (validate and trace rays) -- occupy contiguous slots (rows of the half-res
-        image); the cache's own ray passes are replicated, so their records are identical on every rank and stay local."""
-        import torch
+        """This frame's recorded cache updates: every rank reduces its strip's rtdgi lookups (validate and trace pass) -- and, with reflections in the
+        frame, rtr's (validate and trace rays); contiguous slots: rows of the half-res image -- into a fixed-size summary, the summaries are all-gathered
+        and every rank merges the same ones plus the summary of the cache's own ray passes (replicated: identical on every rank, it stays local).
+        No list lengths, nothing read back (include/kajiya_amd.h: kj_ircache_summarize_requests / kj_ircache_apply_summaries)."""
         hw = (self.W + 1) // 2
-        strip_lists, irc_lists = {}, {}
+        strip_sums, own_sums = {}, {}
         for r in self.comm.ranks:
             gp = self.pipes[r]
             first, count = gp.ircache_request_ranges()
             h0, h1 = half_rows(*self.strips[r], self.H)
             bases = [first[0], first[1]] + (gp.ircache_rtr_request_ranges()[0] if self.with_rtr else [])
-            strip_lists[r] = gp.ircache_collect([(b + h0 * hw, (h1 - h0) * hw) for b in bases], capacity=len(bases) * (h1 - h0) * hw, tag="strip")
-            irc_lists[r] = gp.ircache_collect([(first[2], count[2]), (first[3], count[3])], capacity=count[2] + count[3], tag="cache passes")
-        gathered = self.comm.all_gather_rows({r: (buf, int(cnt.item())) for r, (buf, cnt) in strip_lists.items()})
+            strip_sums[r] = gp.ircache_summarize([(b + h0 * hw, (h1 - h0) * hw) for b in bases], which=0)
+            own_sums[r] = gp.ircache_summarize([(first[2], count[2]), (first[3], count[3])], which=1)
+        gathered = self.comm.all_gather_fixed(strip_sums)
         for r in self.comm.ranks:
-            gp = self.pipes[r]
-            buf, cnt = irc_lists[r]
-            n = int(cnt.item())
-            merged = torch.cat([gathered[r], buf[:n]], dim=0).contiguous()
-            gp.ircache_apply(merged, merged.shape[0])
-            self._keepalive = merged
+            self.pipes[r].ircache_apply_summaries(list(gathered[r]) + [own_sums[r]])
 
     def taa_frame(self, inputs=None):
         """TaaRenderer::render on this frame's GI image -- or on `inputs`: {rank: RGBA16F (H, W, 4) image valid on the rank's own rows}, e.g. the lit image of
@@ -1063,3 +1043,16 @@ class NativeSplit:
         comm = C.c_void_p()
         klib.check(L.kj_split_rccl_comm_create(ident, world, rank, C.byref(comm)))
         return comm.value
+
+    @staticmethod
+    def rccl_one_rank_comm():
+        """A communicator of ONE rank (ncclGetUniqueId -> ncclCommInitRank(nranks = 1)) for the loopback mode: NativeSplit(world, all pipes, ..., nccl_comm=this)
+        sends every message of the schedule to self through RCCL. Returns (ncclComm_t as an integer, ranks and rank as the communicator reports them)."""
+        L = klib.load()
+        ident = (C.c_uint8 * 128)()
+        klib.check(L.kj_split_rccl_unique_id(ident))
+        comm = C.c_void_p()
+        klib.check(L.kj_split_rccl_comm_create(ident, 1, 0, C.byref(comm)))
+        n, r = C.c_uint32(), C.c_uint32()
+        klib.check(L.kj_split_rccl_comm_info(comm, C.byref(n), C.byref(r)))
+        return comm.value, n.value, r.value

@@ -10,6 +10,8 @@
 // snapshot of `aux` taken before the pass. Every outcome is one the racy reference program can produce; none depends on thread
 // interleaving, so GPU-vs-oracle comparisons of the cache can be held to the same bars as the deterministic passes.
 #pragma once
+#include <map>
+#include <cstring>
 #include "okj_scene.hpp"
 #include "okj_reservoir.hpp"
 #include <atomic>
@@ -314,54 +316,66 @@ struct Ircache {
         const size_t n = size_t(meta[META_ENTRY_COUNT]) * 32;
         for (size_t i = 0; i < n; ++i) { const size_t o = (i >> 5) * IRCACHE_AUX_STRIDE + (i & 31u); aux_snapshot[o] = aux[o]; }
     }
-    // Replay of the frame's recorded lookups in the canonical order (cell, key):
-    //   * a cell nobody occupies is allocated by its first lookup that may allocate; new cells take pool entries in cell order;
-    //   * an occupied cell's lookups run through lookup.hlsl:287-301 one after the other: life refresh (min), then the position vote --
-    //     accepted with probability 1 / (votes so far + 1), using the random number the lookup drew when it ran.
+    // Replay of the frame's recorded lookups: a reduction over the records of a cell, so that a rank of the screen-tile split can reduce its own strip first and
+    // the result does not depend on the number of ranks. One of the racy program's legal outcomes (lookup.hlsl:118-150, 287-301):
+    //   * a cell nobody occupies is allocated by the lookup with the lowest position in the frame among those that may allocate ("the thread whose
+    //     InterlockedOr came first"); new cells take pool entries in cell order;
+    //   * an occupied cell's lookups all read the entry's life before any of them lowers it (every load of :287 before every InterlockedMin of :291):
+    //     lookup i votes iff rank_i <= life0 / LIFE_PER_RANK; the life ends as min(life0, min_i rank_i * LIFE_PER_RANK);
+    //   * the position vote: the voter with the smallest dart (ties: lowest key) is the one whose InterlockedAdd returned the count before the frame's
+    //     votes -- accepted iff dart <= 1 / (v0 + 1) -- and its store lands last; if that dart fails no voter can be accepted.
     void apply_requests() {
         std::vector<Request>& rq = requests;
-        std::sort(rq.begin(), rq.end(), [](const Request& a, const Request& b) { return a.cell != b.cell ? a.cell < b.cell : a.key < b.key; });
         const size_t n = rq.size();
-        const uint32_t alloc_before = meta[META_ALLOC_COUNT];
-        uint32_t allocated = 0;
-        for (size_t i = 0; i < n;) {
-            size_t e = i;
-            while (e < n && rq[e].cell == rq[i].cell) ++e;
+        // per cell: the allocation winner; per entry: rank minimum, voters, vote winner
+        std::map<uint32_t, size_t> alloc_winner;
+        struct Acc { uint32_t rank_min = 0xffffffffu, votes = 0; uint64_t win = ~0ull; size_t win_idx = 0; };
+        std::map<uint32_t, Acc> acc;
+        for (size_t i = 0; i < n; ++i) {
             const uint32_t cell = rq[i].cell;
+            if (cell == 0xffffffffu) continue;
             const u2 m = gm()[cell];
             if ((m.y & IRCACHE_ENTRY_META_OCCUPIED) == 0) {
-                size_t j = i;
-                while (j < e && (rq[j].bits & 0x100u)) ++j;                 // the first lookup allowed to allocate
-                if (j < e) {
-                    const uint32_t alloc_idx = alloc_before + allocated++;
-                    if (alloc_idx < IRCACHE_MAX_ENTRIES) {                    // else: pool exhausted, the cell stays empty
-                        const uint32_t entry_idx = pool[alloc_idx];
-                        meta[META_ENTRY_COUNT] = std::max(meta[META_ENTRY_COUNT], entry_idx + 1);
-                        life[entry_idx] = ircache_entry_life_for_rank(rq[j].bits & 0xffu);
-                        entry_cell[entry_idx] = cell;
-                        gm()[cell] = u2{entry_idx, m.y | IRCACHE_ENTRY_META_OCCUPIED | IRCACHE_ENTRY_META_JUST_ALLOCATED};
-                        reposition_proposal[entry_idx] = rq[j].proposal;
-                    }
-                }
+                if (rq[i].bits & 0x100u) continue;
+                auto it = alloc_winner.find(cell);
+                if (it == alloc_winner.end() || rq[i].key < rq[it->second].key) alloc_winner[cell] = i;
             } else if ((m.y & IRCACHE_ENTRY_META_JUST_ALLOCATED) == 0) {
-                const uint32_t entry_idx = m.x;
-                uint32_t lf = life[entry_idx], votes = reposition_proposal_count[entry_idx];
-                for (size_t j = i; j < e; ++j) {
-                    const uint32_t query_rank = rq[j].bits & 0xffu;
-                    if (lf < IRCACHE_ENTRY_LIFE_RECYCLE) {
-                        const uint32_t prev_life = lf;
-                        const uint32_t new_life = ircache_entry_life_for_rank(query_rank);
-                        if (new_life < prev_life) lf = new_life;
-                        if (query_rank <= ircache_entry_life_to_rank(prev_life)) {
-                            if (rq[j].dart <= 1.0f / (float(votes) + 1.0f)) reposition_proposal[entry_idx] = rq[j].proposal;
-                            ++votes;
-                        }
-                    }
+                const uint32_t entry_idx = m.x, life0 = life[entry_idx];
+                if (!(life0 < IRCACHE_ENTRY_LIFE_RECYCLE)) continue;
+                const uint32_t query_rank = rq[i].bits & 0xffu;
+                Acc& a = acc[entry_idx];
+                a.rank_min = std::min(a.rank_min, query_rank);
+                if (query_rank <= ircache_entry_life_to_rank(life0)) {
+                    uint32_t dart_bits; memcpy(&dart_bits, &rq[i].dart, 4);
+                    const uint64_t w = (uint64_t(dart_bits) << 32) | rq[i].key;
+                    ++a.votes;
+                    if (w < a.win) { a.win = w; a.win_idx = i; }
                 }
-                life[entry_idx] = lf;
-                reposition_proposal_count[entry_idx] = votes;
             }
-            i = e;
+        }
+        for (const auto& kv : acc) {
+            const uint32_t entry_idx = kv.first;
+            const Acc& a = kv.second;
+            life[entry_idx] = std::min(life[entry_idx], ircache_entry_life_for_rank(a.rank_min));
+            if (a.votes) {
+                const uint32_t v0 = reposition_proposal_count[entry_idx];
+                reposition_proposal_count[entry_idx] = v0 + a.votes;
+                if (rq[a.win_idx].dart <= 1.0f / (float(v0) + 1.0f)) reposition_proposal[entry_idx] = rq[a.win_idx].proposal;
+            }
+        }
+        const uint32_t alloc_before = meta[META_ALLOC_COUNT];
+        uint32_t allocated = 0;
+        for (const auto& kv : alloc_winner) {          // std::map: ascending cell order
+            const uint32_t cell = kv.first;
+            const Request& w = rq[kv.second];
+            const uint32_t alloc_idx = alloc_before + allocated++;
+            if (alloc_idx >= IRCACHE_MAX_ENTRIES) continue;                    // pool exhausted, the cell stays empty
+            const uint32_t entry_idx = pool[alloc_idx];
+            meta[META_ENTRY_COUNT] = std::max(meta[META_ENTRY_COUNT], entry_idx + 1);
+            life[entry_idx] = ircache_entry_life_for_rank(w.bits & 0xffu);
+            entry_cell[entry_idx] = cell;
+            gm()[cell] = u2{entry_idx, gm()[cell].y | IRCACHE_ENTRY_META_OCCUPIED | IRCACHE_ENTRY_META_JUST_ALLOCATED};
+            reposition_proposal[entry_idx] = w.proposal;
         }
         meta[META_ALLOC_COUNT] = std::min(alloc_before + allocated, IRCACHE_MAX_ENTRIES);
         requests.clear();

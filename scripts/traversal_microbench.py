@@ -45,6 +45,7 @@ def measure(label):
 
 # the C-ABI reads these switches at every call (device.hip: stream_waves / stream_tune / KJ_TRACE_PER_RAY)
 KNOBS = ("KJ_TRACE_QUAD_MAX_RAYS", "KJ_TRACE_PER_RAY", "KJ_STREAM_WAVES_PER_CU", "KJ_STREAM_REFILL", "KJ_STREAM_NODE_WEIGHT", "KJ_STREAM_TRI_WEIGHT")
+os.environ["KJ_DEBUG_ENV"] = "1"      # the library reads measurement switches only behind this gate (kj_host.hpp: kj_debug_getenv)
 os.environ["KJ_TRACE_QUAD_MAX_RAYS"] = "0"
 configs = [dict(KJ_TRACE_PER_RAY="1", KJ_TRACE_QUAD_MAX_RAYS="0"), dict(KJ_TRACE_QUAD_MAX_RAYS="0")]
 if "--sweep" in sys.argv:

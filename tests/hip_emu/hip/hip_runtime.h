@@ -259,6 +259,7 @@ inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, 
 inline unsigned atomicAnd(unsigned* p, unsigned v) { return __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; while (o < v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
 inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; while (o > v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
+inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; while (o > v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
 inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicCAS(unsigned* p, unsigned cmp, unsigned v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); return cmp; }
 inline float __fmul_rn(float a, float b) { return a * b; }     // the emulation builds with -ffp-contract=off: every product rounds once anyway

@@ -34,7 +34,7 @@ def test_struct_layouts():
 
 
 ABI_IDS = ["KjFrameConstants", "KjViewConstants", "KjMeshMaterial", "KjPackedVertex", "KjMaterialMap", "KjMeshDesc", "KjTriangleLight", "KjGbufferDepth", "KjRtdgiRenderParams",
-           "KjRtdgiOutput", "KjTaaOutput", "KjRtrTables", "KjRtrParams", "KjSplitRank", "KjSplitFrame", "KjBakedMeshView", "KjBakedImageView"]     # enum KjAbiStruct, in order
+           "KjRtdgiOutput", "KjTaaOutput", "KjRtrTables", "KjRtrParams", "KjSplitRank", "KjSplitFrame", "KjBakedMeshView", "KjBakedImageView", "KjSplitProfile"]     # enum KjAbiStruct, in order
 
 
 def _rust_repr_c_structs(text):

@@ -369,63 +369,64 @@ def test_ircache_deterministic_free_running(gpu, oracle, device):
 
 
 def _sequential_replay(state, req):
-    """The recurrence kj_ircache_apply_requests evaluates with segmented scans, stated the slow way (lookup.hlsl:118-150, 287-301 in the canonical
-    order: by cell, then by the lookup's position in the frame). `state`: dict of numpy arrays (modified in place); `req`: [n, 8] uint32 records
-    {cell, key, bits, dart, proposal x4}."""
+    """What kj_ircache_apply_requests computes by reduction (ircache.hip), stated the slow way: one of the legal outcomes of lookup.hlsl:118-150, 287-301 that
+    does not depend on how the records are grouped -- an empty cell is allocated by its lowest-positioned lookup that may allocate (pool entries in cell order);
+    an occupied cell's lookups all see the life from before the frame's refreshes (vote iff rank <= life0 / 4; the life ends as the minimum); the vote's winner is
+    the voter with the smallest (dart, key), accepted against the count before the frame's votes. `state`: dict of numpy arrays (modified in place); `req`:
+    [n, 8] uint32 records {cell, key, bits, dart, proposal x4}."""
     LIFE_PER_RANK, LIFE_RECYCLE, MAX_ENTRIES, OCC, JUST = 4, 0x8000000, 65536, 1, 2
-    order = sorted(range(len(req)), key=lambda i: (int(req[i, 0]), int(req[i, 1])))
     gm, life, votes, prop, pool, meta, ecell = state["grid_meta"], state["life"], state["reposition_proposal_count"], state["reposition_proposal"], state["pool"], state["meta"], state["entry_cell"]
-    alloc0 = int(meta[3])
-    new_cells = 0
-    i = 0
-    while i < len(order):
-        cell = int(req[order[i], 0])
-        j = i
-        while j < len(order) and int(req[order[j], 0]) == cell:
-            j += 1
-        seg = [order[k] for k in range(i, j)]
-        i = j
+    alloc_winner, acc = {}, {}
+    for i in range(len(req)):
+        cell = int(req[i, 0])
         if cell == 0xffffffff:
             continue
         flags = int(gm[cell, 1])
         if not (flags & OCC):
-            first = next((k for k in seg if not (int(req[k, 2]) & 0x100)), None)
-            if first is None:
+            if int(req[i, 2]) & 0x100:
                 continue
-            alloc_idx = alloc0 + new_cells
-            new_cells += 1
-            if alloc_idx >= MAX_ENTRIES:
+            if cell not in alloc_winner or int(req[i, 1]) < int(req[alloc_winner[cell], 1]):
+                alloc_winner[cell] = i
+        elif not (flags & JUST):
+            e = int(gm[cell, 0])
+            life0 = int(life[e])
+            if life0 >= LIFE_RECYCLE:
                 continue
-            e = int(pool[alloc_idx])
-            meta[2] = max(int(meta[2]), e + 1)
-            life[e] = (int(req[first, 2]) & 0xff) * LIFE_PER_RANK
-            ecell[e] = cell
-            gm[cell] = (e, flags | OCC | JUST)
-            prop[e] = req[first, 4:8]
+            rank = int(req[i, 2]) & 0xff
+            a = acc.setdefault(e, {"rank_min": 0xffffffff, "votes": 0, "win": None})
+            a["rank_min"] = min(a["rank_min"], rank)
+            if rank <= life0 // LIFE_PER_RANK:
+                a["votes"] += 1
+                w = (int(req[i, 3]), int(req[i, 1]), i)      # darts are in [0, 1): their bit patterns order like the floats
+                if a["win"] is None or w < a["win"]:
+                    a["win"] = w
+    for e, a in acc.items():
+        life[e] = min(int(life[e]), a["rank_min"] * LIFE_PER_RANK)
+        if a["votes"]:
+            v0 = int(votes[e])
+            votes[e] = v0 + a["votes"]
+            k = a["win"][2]
+            if req[k, 3:4].view(np.float32)[0] <= np.float32(1.0) / (np.float32(v0) + np.float32(1.0)):
+                prop[e] = req[k, 4:8]
+    alloc0 = int(meta[3])
+    for n_new, cell in enumerate(sorted(alloc_winner)):
+        alloc_idx = alloc0 + n_new
+        if alloc_idx >= MAX_ENTRIES:
             continue
-        if flags & JUST:
-            continue
-        e = int(gm[cell, 0])
-        cur_life, cur_votes = int(life[e]), int(votes[e])
-        for k in seg:
-            rank = int(req[k, 2]) & 0xff
-            if cur_life < LIFE_RECYCLE:
-                prev = cur_life
-                if rank * LIFE_PER_RANK < prev:
-                    cur_life = rank * LIFE_PER_RANK
-                if rank <= prev // LIFE_PER_RANK:
-                    dart = req[k, 3:4].view(np.float32)[0]
-                    if dart <= np.float32(1.0) / (np.float32(cur_votes) + np.float32(1.0)):
-                        prop[e] = req[k, 4:8]
-                    cur_votes += 1
-        life[e], votes[e] = cur_life, cur_votes
-    meta[3] = min(alloc0 + new_cells, MAX_ENTRIES)
+        first = alloc_winner[cell]
+        e = int(pool[alloc_idx])
+        meta[2] = max(int(meta[2]), e + 1)
+        life[e] = (int(req[first, 2]) & 0xff) * LIFE_PER_RANK
+        ecell[e] = cell
+        gm[cell] = (e, int(gm[cell, 1]) | OCC | JUST)
+        prop[e] = req[first, 4:8]
+    meta[3] = min(alloc0 + len(alloc_winner), MAX_ENTRIES)
 
 
 @pytest.mark.parametrize("case", ["random", "one hot cell", "nobody may allocate", "recycled and fresh"])
 def test_replay_of_recorded_lookups_equals_the_sequential_recurrence(gpu, device, case):
-    """kj_ircache_apply_requests on synthetic record lists against `_sequential_replay`, every touched buffer bit for bit: 60 k records over occupied
-    and empty cells; 40 k records on ONE cell (the case that took a thread a millisecond before the scans); lists whose lookups may not allocate;
+    """kj_ircache_apply_requests (reduce into a summary + merge) on synthetic record lists against `_sequential_replay`, every touched buffer bit for bit: 60 k records
+    over occupied and empty cells; 40 k records on ONE cell (every workgroup's LDS table holds one hot slot); lists whose lookups may not allocate;
     entries past IRC_LIFE_RECYCLE and cells allocated this frame (both left alone)."""
     import torch
     W = H = 96
