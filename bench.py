@@ -497,11 +497,12 @@ def main():
         # validity integrate + restir temporal are ONE launch by default since round 4 (k_validity_integrate_restir_temporal; KJ_RTDGI_FUSE_VT=0 splits them):
         # its time is reported under "restir temporal", "validity integrate" reads 0
         vi_fused = pass_ms[lib.GpuPipeline.PASS_NAMES.index("validity integrate")] == 0.0
+        tile_order = 2 if (hw + 15) // 16 >= 96 else 3      # rtdgi_resample.hip: resample_tile_order (column bands from 96 tiles across, 4 x 4 super-tiles below)
         table = [("rtdgi reproject", "k_fullres_reproject", n_f, 24), ("extract half", "k_extract_half<0>", n_h2, 30)] + \
                 ([("restir temporal", "k_validity_integrate_restir_temporal", n_h2, 25 + 168)] if vi_fused else
                  [("validity integrate", "k_validity_integrate", n_h2, 25), ("restir temporal", "k_restir_temporal", n_h2, 168)]) + \
-                [("restir spatial 0", "k_restir_spatial<32, 8, 16, 16, false>", n_h2, 41),
-                 ("restir spatial 1", "k_restir_spatial<16, 5, 16, 16, false>", n_h2, 41), ("restir resolve", "k_restir_resolve", n_f, 43),
+                [("restir spatial 0", f"k_restir_spatial<32, 8, 16, 16, false, {tile_order}>", n_h2, 41),
+                 ("restir spatial 1", f"k_restir_spatial<16, 5, 16, 16, false, {tile_order}>", n_h2, 41), ("restir resolve", f"k_restir_resolve<{tile_order}>", n_f, 43),
                  ("rtdgi temporal", "k_temporal_filter", n_f, 49), ("rtdgi spatial", "k_spatial_filter", n_f, 25)]
 
         def entry(kernel, ms, algo_bytes, note=None):

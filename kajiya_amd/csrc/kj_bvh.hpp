@@ -81,7 +81,7 @@ KJ_D bool intersect_tri(V3 o, V3 d, float tmin, float tmax, const float4 a, cons
 }
 
 // stack: LDS base for this lane; entries at stack[level * stride]
-struct TraverseStats { uint32_t nodes, tris; uint32_t wave_node_steps = 0, wave_tri_steps = 0; };   // wave_*: steps the WAVE issued (counted by one lane of it): lane utilisation of the walk = (nodes + tris) / (64 * steps)
+struct TraverseStats { uint32_t nodes, tris; uint32_t wave_node_steps = 0, wave_tri_steps = 0; uint32_t live_hist[4] = {0, 0, 0, 0}; };   // live_hist: wave steps by the number of lanes still walking (1-8, 9-16, 17-32, 33-64), counted by one lane (round 6: profiles/r06_walk.md)   // wave_*: steps the WAVE issued (counted by one lane of it): lane utilisation of the walk = (nodes + tris) / (64 * steps)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 KJ_D float q8(uint32_t packed, int i) { return float((packed >> (8 * i)) & 0xffu); }   // v_cvt_f32_ubyte<i>
@@ -311,6 +311,65 @@ KJ_D void tri_step_mixed(const BvhView& bvh, RayState& S, bool any_hit, uint32_t
     else KJ_POP(S.cur)
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+template <bool ANY_HIT, bool STATS, uint32_t CAP>
+KJ_D void quad_walk(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats);      // below: four lanes per ray
+#endif
+// KJ_WALK_TAIL_QUAD (round 6 experiment, profiles/r06_walk.md): 54 % of the wave steps of the closest-hit walks and 68 % of the occlusion walks' run with at most 16 of
+// the wave's 64 lanes still holding a ray. With the switch on, a wave whose live rays have dropped to KJ_WALK_TAIL_LANES or fewer (and whose stacks are all within
+// their LDS columns) hands each of them to a QUAD of lanes -- state broadcast from the ray's lane, the quad working on that lane's LDS stack column -- finishes them
+// with the four-lanes-per-ray step (one child box / one triangle per lane: ~75 instructions instead of ~200, a leaf per step instead of a triangle), and returns
+// the hits to the rays' lanes. Same steps per ray as far as results go: the closest hit with ties to the lowest world triangle id does not depend on visiting order.
+#ifndef KJ_WALK_TAIL_QUAD
+#define KJ_WALK_TAIL_QUAD 0
+#endif
+#ifndef KJ_WALK_TAIL_LANES
+#define KJ_WALK_TAIL_LANES 16u
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// bit 4q of the result is set when all four lanes of quad q are in the call (a caller's sky pixels have left the kernel, a shadow ray is traced under `if (hit)`:
+// only whole quads can carry a ray)
+KJ_D unsigned long long walk_full_quads() {
+    const unsigned long long act = __ballot(true);
+    return act & (act >> 1) & (act >> 2) & (act >> 3) & 0x1111111111111111ull;
+}
+KJ_D int walk_nth_set_bit(unsigned long long m, uint32_t n) {      // position of the n-th (0-based) set bit of m, or -1
+    for (uint32_t i = 0; i < n; ++i) m &= m - 1ull;
+    return m ? __ffsll((long long)m) - 1 : -1;
+}
+template <bool ANY_HIT, bool STATS>
+KJ_D void walk_tail_on_quads(const BvhView& bvh, RayState& S, bool alive, unsigned long long fq, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
+    const uint32_t lane = __lane_id() & 63u, q = lane >> 2;
+    const unsigned long long m = __ballot(alive);
+    // this lane's quad, if whole, is the qr-th whole quad and serves the qr-th live ray
+    const bool whole = ((fq >> (4u * q)) & 1ull) != 0ull;
+    const uint32_t qr = uint32_t(__popcll(fq & ((1ull << (4u * q)) - 1ull)));
+    const int src_ = whole ? walk_nth_set_bit(m, qr) : -1;
+    const bool has = src_ >= 0;
+    const int src = has ? src_ : int(lane);
+    RayState T;
+    T.wo = V3{__shfl(S.wo.x, src), __shfl(S.wo.y, src), __shfl(S.wo.z, src)};
+    T.wd = V3{__shfl(S.wd.x, src), __shfl(S.wd.y, src), __shfl(S.wd.z, src)};
+    T.binv = V3{__shfl(S.binv.x, src), __shfl(S.binv.y, src), __shfl(S.binv.z, src)};
+    T.tmin = __shfl(S.tmin, src); T.tmax = __shfl(S.tmax, src);
+    T.h.t = __shfl(S.h.t, src); T.h.u = __shfl(S.h.u, src); T.h.v = __shfl(S.h.v, src); T.h.slot = __shfl(S.h.slot, src); T.h.world_id = __shfl(S.h.world_id, src);
+    T.sp = __shfl(S.sp, src); T.cur = __shfl(S.cur, src);
+    T.cull_back = __shfl(uint32_t(S.cull_back ? 1u : 0u), src) != 0u;
+    const uint32_t lo = uint32_t(uintptr_t(stack)), hi = uint32_t(uintptr_t(stack) >> 32);
+    uint32_t* const col = (uint32_t*)(uintptr_t(__shfl(lo, src)) | (uintptr_t(__shfl(hi, src)) << 32));      // the ray's own stack column
+    if (!has) T.cur = KJ_BVH_NONE;
+    // (`spill`, the caller's: only entries pushed from here on can land in it -- every live stack was within its LDS column at the hand-over)
+    quad_walk<ANY_HIT, STATS, KJ_BVH_LDS_STACK>(bvh, T, col, stride, spill, stats);
+    // the hits go back to the rays' lanes: live lane L, the r-th live one, was served by the r-th whole quad
+    const uint32_t r = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+    const int from_ = alive ? walk_nth_set_bit(fq, r) : -1;
+    const int from = from_ >= 0 ? from_ : int(lane);
+    const float ht = __shfl(T.h.t, from), hu = __shfl(T.h.u, from), hv = __shfl(T.h.v, from);
+    const uint32_t hs = __shfl(T.h.slot, from), hw = __shfl(T.h.world_id, from);
+    if (alive) { S.h.t = ht; S.h.u = hu; S.h.v = hv; S.h.slot = hs; S.h.world_id = hw; S.cur = KJ_BVH_NONE; S.sp = 0; }
+}
+#endif
+
 // One ray per lane, start to finish, inside a caller's kernel. The lanes of the wave that are in the call step together: each
 // wave step issues EITHER the node block or the triangle block, whichever more lanes are waiting for (triangle lanes count
 // double: their block is the cheaper one), instead of a mixed wave paying for both blocks in every iteration. Per-ray results do
@@ -343,14 +402,30 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
     if (STATS && (__ffsll((long long)__ballot(true)) - 1) == int(__lane_id())) stats->wave_node_steps += it_node;
 #elif defined(__HIP_DEVICE_COMPILE__)
     uint32_t it_node = 0, it_tri = 0;
+    uint32_t live_hist[4] = {0, 0, 0, 0};
     for (;;) {
         const bool want_node = wants_node_step(S), want_tri = wants_tri_step(S);
         const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
         if (nn + nt == 0u) break;
+#if KJ_WALK_TAIL_QUAD
+        if (nn + nt <= KJ_WALK_TAIL_LANES) {
+            const bool alive = want_node | want_tri;
+            const unsigned long long fq = walk_full_quads();
+            // every live ray needs a whole quad of lanes that are in this call; a live ray whose stack has spilled to private memory cannot move (try again once it has popped back)
+            if (nn + nt <= uint32_t(__popcll(fq)) && __ballot(alive && S.sp > KJ_BVH_LDS_STACK) == 0ull) {
+                walk_tail_on_quads<ANY_HIT, STATS>(bvh, S, alive, fq, stack, stride, spill, stats);
+                break;
+            }
+        }
+#endif
+        if (STATS) { const uint32_t live = nn + nt; live_hist[live <= 8u ? 0 : (live <= 16u ? 1 : (live <= 32u ? 2 : 3))]++; }
         if (nt == 0u || (nn != 0u && nn >= nt * 2u)) { if (STATS) it_node++; if (want_node) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
         else { if (STATS) it_tri++; if (want_tri) tri_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
     }
-    if (STATS && (__ffsll((long long)__ballot(true)) - 1) == int(__lane_id())) { stats->wave_node_steps += it_node; stats->wave_tri_steps += it_tri; }
+    if (STATS && (__ffsll((long long)__ballot(true)) - 1) == int(__lane_id())) {
+        stats->wave_node_steps += it_node; stats->wave_tri_steps += it_tri;
+        for (int b = 0; b < 4; ++b) stats->live_hist[b] += live_hist[b];
+    }
 #else
     while (S.cur != KJ_BVH_NONE) {
         if (wants_node_step(S)) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);
@@ -386,27 +461,20 @@ KJ_D uint32_t quad_broadcast0(uint32_t v) { return v; }
 KJ_D V3 quad_broadcast0(V3 v) { return V3{quad_broadcast0(v.x), quad_broadcast0(v.y), quad_broadcast0(v.z)}; }
 
 // next reference off a quad's stack: the LDS part is read unconditionally (one ds_read, no generic pointer), the rare deep entries from the spill copy
+template <uint32_t CAP = KJ_QUAD_LDS_STACK>
 KJ_D void quad_pop(RayState& S, const uint32_t* stack, uint32_t stride, const uint32_t* spill) {
     if (S.sp == 0) { S.cur = KJ_BVH_NONE; return; }
     --S.sp;
-    uint32_t v = stack[(S.sp < KJ_QUAD_LDS_STACK ? S.sp : KJ_QUAD_LDS_STACK - 1u) * stride];
-    if (S.sp >= KJ_QUAD_LDS_STACK) v = spill[S.sp - KJ_QUAD_LDS_STACK];
+    uint32_t v = stack[(S.sp < CAP ? S.sp : CAP - 1u) * stride];
+    if (S.sp >= CAP) v = spill[S.sp - CAP];
     S.cur = v;
 }
-// `stack`: LDS base of this QUAD's stack (entries at stack[level * stride]); all four lanes pass the same ray and the same `active`.
-template <bool ANY_HIT, bool STATS = false>
-KJ_D RayHit bvh_trace_quad(const BvhView& bvh, bool active, V3 o, V3 d, float tmin, float tmax, bool cull_back, uint32_t* stack, uint32_t stride, TraverseStats* stats = nullptr) {
-#if !defined(__HIP_DEVICE_COMPILE__)
-    if (!active) { RayHit h; h.t = FLT_MAX; h.u = h.v = 0; h.slot = h.world_id = 0xffffffffu; return h; }
-    uint32_t own[KJ_BVH_LDS_STACK];      // the stand-in's lanes run one after the other: each walks the ray alone, on a private stack
-    return bvh_trace<ANY_HIT, STATS>(bvh, o, d, tmin, tmax, cull_back, own, 1, stats);
-#else
+#if defined(__HIP_DEVICE_COMPILE__)
+// The walk of a ray carried by the four lanes 4q .. 4q+3 (identical S in all four; `stack`: the LDS column of its stack, CAP levels deep; deeper entries in `spill`).
+template <bool ANY_HIT, bool STATS, uint32_t CAP>
+KJ_D void quad_walk(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
     const uint32_t NONE = KJ_BVH_NONE;
     const uint32_t k = __lane_id() & 3u;
-    RayState S;
-    ray_begin<ANY_HIT>(S, o, d, tmin, tmax, cull_back);
-    if (!active) S.cur = NONE;
-    uint32_t spill[KJ_BVH_SPILL_STACK];   // identical in the four lanes (every lane pushes every entry)
     const V3 inv_d = S.binv;
     const bool neg_x = inv_d.x < 0.0f, neg_y = inv_d.y < 0.0f, neg_z = inv_d.z < 0.0f;
     for (;;) {
@@ -443,7 +511,7 @@ KJ_D RayHit bvh_trace_quad(const BvhView& bvh, bool active, V3 o, V3 d, float tm
                 KJ_QSWAP(s0, s1, r0, r1) KJ_QSWAP(s2, s3, r2, r3) KJ_QSWAP(s0, s2, r0, r2) KJ_QSWAP(s1, s3, r1, r3) KJ_QSWAP(s1, s2, r1, r2)
 #undef KJ_QSWAP
                 const uint32_t pushes = (s1 != NONE ? 1u : 0u) + (s2 != NONE ? 1u : 0u) + (s3 != NONE ? 1u : 0u);      // hits sort first: s0 is a hit when any is
-                if (S.sp + 3u <= KJ_QUAD_LDS_STACK) {
+                if (S.sp + 3u <= CAP) {
                     // lane j (1..3) stores the j-th nearest child, the farthest deepest; a non-hit's slot lies beyond the new stack pointer
                     const uint32_t mine = k == 1u ? r1 : (k == 2u ? r2 : r3);
                     if ((k != 0u) & (k <= pushes)) stack[(S.sp + pushes - k) * stride] = mine;
@@ -454,12 +522,12 @@ KJ_D RayHit bvh_trace_quad(const BvhView& bvh, bool active, V3 o, V3 d, float tm
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
                         if (okey[j] != NONE) {
-                            if (S.sp < KJ_QUAD_LDS_STACK) { if (k == 0u) stack[S.sp * stride] = oref[j]; } else spill[S.sp - KJ_QUAD_LDS_STACK] = oref[j];
+                            if (S.sp < CAP) { if (k == 0u) stack[S.sp * stride] = oref[j]; } else spill[S.sp - CAP] = oref[j];
                             S.sp++;
                         }
                 }
                 if (s0 != NONE) S.cur = r0;
-                else quad_pop(S, stack, stride, spill);
+                else quad_pop<CAP>(S, stack, stride, spill);
             }
         } else if (want_tri) {
             const uint32_t first = S.cur & 0x0fffffffu;
@@ -483,10 +551,25 @@ KJ_D RayHit bvh_trace_quad(const BvhView& bvh, bool active, V3 o, V3 d, float tm
             KJ_QMIN(KJ_QP_XOR1) KJ_QMIN(KJ_QP_ROT2)
 #undef KJ_QMIN
             if (ANY_HIT && S.h.slot != 0xffffffffu) S.cur = NONE;
-            else quad_pop(S, stack, stride, spill);
+            else quad_pop<CAP>(S, stack, stride, spill);
             (void)any;
         }
     }
+}
+#endif
+// `stack`: LDS base of this QUAD's stack (entries at stack[level * stride]); all four lanes pass the same ray and the same `active`.
+template <bool ANY_HIT, bool STATS = false>
+KJ_D RayHit bvh_trace_quad(const BvhView& bvh, bool active, V3 o, V3 d, float tmin, float tmax, bool cull_back, uint32_t* stack, uint32_t stride, TraverseStats* stats = nullptr) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (!active) { RayHit h; h.t = FLT_MAX; h.u = h.v = 0; h.slot = h.world_id = 0xffffffffu; return h; }
+    uint32_t own[KJ_BVH_LDS_STACK];      // the stand-in's lanes run one after the other: each walks the ray alone, on a private stack
+    return bvh_trace<ANY_HIT, STATS>(bvh, o, d, tmin, tmax, cull_back, own, 1, stats);
+#else
+    RayState S;
+    ray_begin<ANY_HIT>(S, o, d, tmin, tmax, cull_back);
+    if (!active) S.cur = KJ_BVH_NONE;
+    uint32_t spill[KJ_BVH_SPILL_STACK];   // identical in the four lanes (every lane pushes every entry)
+    quad_walk<ANY_HIT, STATS, KJ_QUAD_LDS_STACK>(bvh, S, stack, stride, spill, stats);
     return S.h;
 #endif
 }

@@ -355,6 +355,9 @@ KJ_D unsigned long long* counter_slot(unsigned long long* base) {
 //                   eight rows in flight at any time are adjacent;
 //   KJ_TILES_BANDS  column bands ~8 tiles wide and as tall as the launch, dealt round-robin: neighbours in both directions share an
 //                   L2 except across band edges, and every XCD sees the image top to bottom (sky and ground alike);
+//   KJ_TILES_SUPER  (round 6) SUPER-TILES of S x S tiles dealt round-robin in row-major order: XCD k works through super-tiles k, k + 8, ... -- a tile's
+//                   neighbours inside its super-tile share its L2 (a 16-px reach around 64 x 64 px costs 2.25x the tile's own texels instead of every XCD
+//                   pulling the whole image), and each XCD's super-tiles are scattered over the whole frame, so sky and geometry reach every XCD alike;
 //   KJ_TILES_PLAIN  blockIdx as is.
 // Which one a kernel uses is a measured choice per kernel (profiles/r03_xcd_tile_order.md): passes whose work per tile is uniform
 // gain 3-17 % from sharing an L2 with their neighbours; passes that skip sky tiles (the ray passes, the resampling passes, the
@@ -365,8 +368,9 @@ KJ_D unsigned long long* counter_slot(unsigned long long* base) {
 #define KJ_TILES_PLAIN 0
 #define KJ_TILES_ROWS 1
 #define KJ_TILES_BANDS 2
+#define KJ_TILES_SUPER 3
 #ifdef __HIPCC__
-template <int MODE_>
+template <int MODE_, int S_ = 4>
 KJ_D uint2 tile_order() {
 #ifdef KJ_TILES_ALL
     constexpr int MODE = KJ_TILES_ALL;          // experiment builds: one order for every kernel
@@ -374,6 +378,30 @@ KJ_D uint2 tile_order() {
     constexpr int MODE = MODE_;
 #endif
     const uint32_t gx = gridDim.x, gy = gridDim.y, id = blockIdx.y * gx + blockIdx.x;
+    if (MODE == KJ_TILES_SUPER) {
+        constexpr uint32_t S = uint32_t(S_), SS = S * S;
+        const uint32_t sgx = gx / S, sgy = gy / S;                 // whole super-tiles
+        const uint32_t n_super = sgx * sgy, n_super8 = n_super & ~7u;
+        const uint32_t n_a = n_super8 * SS;                         // tiles of the super-tiles dealt eight at a time
+        if (id < n_a) {
+            const uint32_t xcd = id & 7u, k = id >> 3;              // the k-th workgroup this XCD receives
+            const uint32_t j = k / SS, w = k - j * SS;              // its j-th super-tile = super-tile j * 8 + xcd, tile w inside it
+            const uint32_t q = j * 8u + xcd, sy = q / sgx, sx = q - sy * sgx, wy = w / S;
+            return make_uint2(sx * S + (w - wy * S), sy * S + wy);
+        }
+        uint32_t r = id - n_a;
+        const uint32_t n_left = (n_super - n_super8) * SS;          // the < 8 super-tiles left over, one after the other
+        if (r < n_left) {
+            const uint32_t q = n_super8 + r / SS, w = r % SS, sy = q / sgx, sx = q - sy * sgx, wy = w / S;
+            return make_uint2(sx * S + (w - wy * S), sy * S + wy);
+        }
+        r -= n_left;
+        const uint32_t rw = gx - sgx * S;                           // the columns right of the super-tiles, every row
+        if (r < rw * gy) { const uint32_t ry = r / rw; return make_uint2(sgx * S + (r - ry * rw), ry); }
+        r -= rw * gy;
+        const uint32_t bw = sgx * S, by = r / (bw ? bw : 1u);       // the rows below them
+        return make_uint2(r - by * bw, sgy * S + by);
+    }
     if (MODE == KJ_TILES_ROWS) {
         const uint32_t n_full = (gy & ~7u) * gx;                    // tiles in whole groups of eight rows
         if (id >= n_full) return make_uint2(blockIdx.x, blockIdx.y);

@@ -272,6 +272,10 @@ KJ_D void add_traversal_stats(const TraceCtx& c, const TraverseStats& st_closest
         // steps the waves issued (one lane of a wave holds its count): [6], [7] node / triangle steps of closest-hit walks, [8], [9] of occlusion walks
         if (st_closest.wave_node_steps | st_closest.wave_tri_steps) { atomicAdd(&counter_slot(c.ray_counters)[6], (unsigned long long)st_closest.wave_node_steps); atomicAdd(&counter_slot(c.ray_counters)[7], (unsigned long long)st_closest.wave_tri_steps); }
         if (st_any.wave_node_steps | st_any.wave_tri_steps) { atomicAdd(&counter_slot(c.ray_counters)[8], (unsigned long long)st_any.wave_node_steps); atomicAdd(&counter_slot(c.ray_counters)[9], (unsigned long long)st_any.wave_tri_steps); }
+        // [10..13]: wave steps of the closest-hit walks by lanes still walking (1-8, 9-16, 17-32, 33-64); [14], [15]: of the occlusion walks (<= 16, > 16)
+        for (int b = 0; b < 4; ++b) if (st_closest.live_hist[b]) atomicAdd(&counter_slot(c.ray_counters)[10 + b], (unsigned long long)st_closest.live_hist[b]);
+        if (st_any.live_hist[0] | st_any.live_hist[1]) atomicAdd(&counter_slot(c.ray_counters)[14], (unsigned long long)(st_any.live_hist[0] + st_any.live_hist[1]));
+        if (st_any.live_hist[2] | st_any.live_hist[3]) atomicAdd(&counter_slot(c.ray_counters)[15], (unsigned long long)(st_any.live_hist[2] + st_any.live_hist[3]));
     }
 }
 template <bool STATS, bool QUAD = false>

@@ -25,6 +25,12 @@ using namespace kj;
 #define RESTIR_RESERVOIR_W_CLAMP 10.0f
 #define SSGI_NEAR_FIELD_RADIUS 80.0f
 
+// workgroup -> tile order of the resampling passes (kj_vec.hpp: tile_order), chosen per launch by its width in tiles (round 6, profiles/r06_screen_passes.md): with
+// the plain order every XCD's L2 pulled the whole working set (restir spatial: 148 / 96 MB per 1080p launch for 21 MB of algorithmic bytes). Column bands cut that
+// 4-7x and are faster where there are at least two bands per XCD (4K: -10 % / -4 % for the second spatial pass / the resolve) but slower at 1080p (one band per
+// XCD: the busiest band sets the pace); 4 x 4 super-tiles dealt round-robin cut it 3-4x at equal time there. -DKJ_SPATIAL_TILES=n / -DKJ_RESOLVE_TILES=n force one order.
+KJ_HD int resample_tile_order(int tiles_x) { return tiles_x >= 96 ? KJ_TILES_BANDS : KJ_TILES_SUPER; }
+
 namespace {
 
 KJ_D V3 unpack_view_normal(uint32_t p) {   // RGBA8_SNORM xyz
@@ -63,7 +69,7 @@ struct SpatialArgs {
 
 // R = reach of the pass in half-res pixels (32: first pass, 16: later passes), SAMPLES = 8 / 5, BW x BH = workgroup in pixels
 // (multiples of 8: one wave per 8x8 block), TILE = stage the G-buffer records in LDS (else gather them from HBM/L2).
-template <int R, int SAMPLES, int BW, int BH, bool TILE>
+template <int R, int SAMPLES, int BW, int BH, bool TILE, int ORDER>
 __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
     constexpr int TW = BW + 2 * R, TH = BH + 2 * R;
     __shared__ uint2 tile[TILE ? TW * TH : 1];
@@ -71,7 +77,7 @@ __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
     const FrameDerived& fd = frame_derived(a.fc);
     const int hw = a.reservoir_output_tex.w, hh = a.reservoir_output_tex.h;
     const int tid = int(threadIdx.x), wave = tid >> 6, lane = tid & 63;
-    const uint2 tb = tile_order<KJ_TILES_PLAIN>();
+    const uint2 tb = tile_order<ORDER, 4>();
     const int bx0 = int(tb.x) * BW, by0 = a.row0 + int(tb.y) * BH;
     const int tx0 = bx0 - R, ty0 = by0 - R;
     if (TILE) {
@@ -251,6 +257,7 @@ struct ResolveArgs2 {
 };
 KJ_D float ggx_ndf_unnorm_fast(float a2, float cos_theta) { const float d = cos_theta * cos_theta * (a2 - 1.0f) + 1.0f; return a2 * rcp_fast(d * d); }
 
+template <int ORDER>
 __global__ void __launch_bounds__(256) k_restir_resolve(ResolveArgs2 a) {
     constexpr int TW = 14, HALO = 3;
     __shared__ float4 t_hit[TW * TW];    // candidate hit point (world) , half-res depth
@@ -261,7 +268,7 @@ __global__ void __launch_bounds__(256) k_restir_resolve(ResolveArgs2 a) {
     const FrameDerived& fd = frame_derived(a.fc);
     const int W = a.irradiance_output_tex.w, H = a.irradiance_output_tex.h;
     const int tid = int(threadIdx.x), wave = tid >> 6, lane = tid & 63;
-    const uint2 tb = tile_order<KJ_TILES_PLAIN>();
+    const uint2 tb = tile_order<ORDER, 4>();
     const int bx0 = int(tb.x) * 16, by0 = a.row0 + int(tb.y) * 16;
     const int hx0 = (bx0 >> 1) - HALO, hy0 = (by0 >> 1) - HALO;
     const I2 off = halfres_subsample_offset(fc.frame_index);
@@ -365,8 +372,52 @@ __global__ void __launch_bounds__(256) k_restir_resolve(ResolveArgs2 a) {
 // reduced polynomial, v_exp_f32 weights, and the tap radii are constants (pow(si, 0.666) for si = 1..7).
 KJ_D V3 crunch(V3 v) { return v * rcp_fast(max3(v.x, v.y, v.z) + 1.0f); }
 KJ_D V3 uncrunch(V3 v) { return v * rcp_fast(1.0f - max3(v.x, v.y, v.z)); }
-__global__ void __launch_bounds__(64) k_spatial_filter(const FrameConstants* __restrict__ fcp, Img<uint2> input_tex, Img<float> depth_tex, Img<uint8_t> ssao_tex,
+// -DKJ_SPATIAL_FILTER_TILED=1 (round 6, measured and REJECTED: 47 -> 73 us at 1080p, 195 -> 307 us at 4K, profiles/r06_screen_passes.md): a 16x16-pixel workgroup
+// stages its pixels + the taps' 16-px reach (48 x 48 texels: crunched value, depth, ssao) in LDS and every tap is two LDS reads. Bit-identical, and slower: most
+// pixels of a converged image take ONE tap (sample_count = 2 for validity near 1), so nine staged texels per pixel replace one or two gathers.
+#ifndef KJ_SPATIAL_FILTER_TILED
+#define KJ_SPATIAL_FILTER_TILED 0
+#endif
+#define KJ_SF_B 16
+#define KJ_SF_R 16
+#define KJ_SF_T (KJ_SF_B + 2 * KJ_SF_R)
+__global__ void __launch_bounds__(KJ_SPATIAL_FILTER_TILED ? 256 : 64) k_spatial_filter(const FrameConstants* __restrict__ fcp, Img<uint2> input_tex, Img<float> depth_tex, Img<uint8_t> ssao_tex,
                                                         Img<uint32_t> geometric_normal_tex, Img<uint2> output_tex, int row0, int row1) {
+#if KJ_SPATIAL_FILTER_TILED
+    __shared__ float4 t_val[KJ_SF_T * KJ_SF_T];      // crunched rgb, depth
+    __shared__ uint8_t t_ssao[KJ_SF_T * KJ_SF_T];
+    const int tid = int(threadIdx.x), wave = tid >> 6, lane = tid & 63;
+    const uint2 tb = tile_order<KJ_TILES_BANDS>();
+    const int bx0 = int(tb.x) * KJ_SF_B, by0 = row0 + int(tb.y) * KJ_SF_B;
+    const int tx0 = bx0 - KJ_SF_R, ty0 = by0 - KJ_SF_R;
+    const int x = bx0 + (wave & 1) * 8 + (lane & 7), y = by0 + (wave >> 1) * 8 + (lane >> 3);
+    const bool in_image = x < output_tex.w && y < (output_tex.h < row1 ? output_tex.h : row1);
+    // a workgroup whose every pixel is fully converged (or outside the image) copies its centres and leaves: no tile
+    const V4 c = in_image ? ld4(input_tex, x, y) : v4(0.0f, 0.0f, 0.0f, 1.0f);
+    const float center_validity = c.w;
+    __shared__ int s_any;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    if (in_image && center_validity != 1) s_any = 1;
+    __syncthreads();
+    if (s_any) {
+        for (int i = tid; i < KJ_SF_T * KJ_SF_T; i += 256) {
+            const int ty = i / KJ_SF_T, tx = i - ty * KJ_SF_T;
+            const float d = depth_tex.ld(tx0 + tx, ty0 + ty);
+            const V3 cv = crunch(xyz(ld4(input_tex, tx0 + tx, ty0 + ty)));
+            t_val[i] = make_float4(cv.x, cv.y, cv.z, d);
+            t_ssao[i] = ssao_tex.ld(tx0 + tx, ty0 + ty);
+        }
+        __syncthreads();
+    }
+    if (!in_image) return;
+    const FrameConstants& fc = *fcp;
+    const V3 center_value = xyz(c);
+    if (center_validity == 1) { st4(output_tex, x, y, v4(center_value, 1.0f)); return; }
+    const int lt = (y - ty0) * KJ_SF_T + (x - tx0);
+    const float center_depth = t_val[lt].w;
+    const float center_ssao = from_unorm8(t_ssao[lt]);
+#else
     const int lane = threadIdx.x;
     const uint2 tb = tile_order<KJ_TILES_BANDS>();
     const int x = int(tb.x) * 8 + (lane & 7), y = row0 + int(tb.y) * 8 + (lane >> 3);
@@ -378,6 +429,7 @@ __global__ void __launch_bounds__(64) k_spatial_filter(const FrameConstants* __r
     if (center_validity == 1) { st4(output_tex, x, y, v4(center_value, 1.0f)); return; }
     const float center_depth = depth_tex.ld(x, y);
     const float center_ssao = from_unorm8(ssao_tex.ld(x, y));
+#endif
     const float center_nz = unpack_a2r10g10b10(geometric_normal_tex.ld(x, y)).z * 2.0f - 1.0f;
     const float ang_off = float((fc.frame_index * 23u) % 32u) * KJ_TAU + interleaved_gradient_noise(x, y) * KJ_PI;
     const float MAX_RADIUS_PX = sqrtf(lerp(16.0f * 16.0f, 2.0f * 2.0f, center_validity));
@@ -393,6 +445,18 @@ __global__ void __launch_bounds__(64) k_spatial_filter(const FrameConstants* __r
         if (!wave_any(si < sample_count)) break;       // sample_count is per pixel; the wave stops at its largest
         const V2 so = cos_sin_turns_fast((float(si) + ang_off) * KJ_GOLDEN_ANGLE) * (tap_pow[si] * RADIUS_SAMPLE_MULT);
         const int sx = int(float(x) + so.x), sy = int(float(y) + so.y);
+#if KJ_SPATIAL_FILTER_TILED
+        // |so| <= 16 px: inside the staged tile (clamped for safety: a tap cannot leave it by more than rounding)
+        const int ti = min(max(sy - ty0, 0), KJ_SF_T - 1) * KJ_SF_T + min(max(sx - tx0, 0), KJ_SF_T - 1);
+        const float4 tv = t_val[ti];
+        const float sample_depth = tv.w;
+        if (sample_depth != 0 && si < sample_count) {
+            const float sample_ssao = from_unorm8(t_ssao[ti]);
+            float wt = exp2_fast(-fabsf(depth_scale * (center_depth * rcp_fast(sample_depth) - 1.0f)));
+            wt *= exp2_fast(-20.0f * fabsf(sample_ssao - center_ssao));
+            sum += v4(V3{tv.x, tv.y, tv.z}, 1.0f) * wt;
+        }
+#else
         const float sample_depth = depth_tex.ld(sx, sy);
         if (sample_depth != 0 && si < sample_count) {
             const V3 sample_val = xyz(ld4(input_tex, sx, sy));
@@ -401,6 +465,7 @@ __global__ void __launch_bounds__(64) k_spatial_filter(const FrameConstants* __r
             wt *= exp2_fast(-20.0f * fabsf(sample_ssao - center_ssao));
             sum += v4(crunch(sample_val), 1.0f) * wt;
         }
+#endif
     }
     const float norm_factor = rcp_fast(fmaxf(1e-5f, sum.w));
     st4(output_tex, x, y, v4(uncrunch(xyz(sum) * norm_factor), 1.0f));
@@ -517,7 +582,14 @@ hipError_t launch_restir_spatial(const SpatialLaunch& L, hipStream_t s) {
     a.pass_idx = L.pass_idx; a.perform_occlusion_raymarch = L.perform_occlusion_raymarch; a.occlusion_raymarch_importance_only = L.occlusion_raymarch_importance_only;
     a.row0 = L.row0; a.row1 = L.row1;
     const int rows = L.row1 - L.row0;
-#define KJ_SPATIAL(R_, S_, BW_, BH_, T_) hipLaunchKernelGGL((k_restir_spatial<R_, S_, BW_, BH_, T_>), dim3((L.hw + BW_ - 1) / BW_, (rows + BH_ - 1) / BH_), dim3(BW_ * BH_), 0, s, a)
+#ifdef KJ_SPATIAL_TILES
+    const int order = KJ_SPATIAL_TILES;
+#else
+    const int order = resample_tile_order((L.hw + 15) / 16);
+#endif
+#define KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, O_) hipLaunchKernelGGL((k_restir_spatial<R_, S_, BW_, BH_, T_, O_>), dim3((L.hw + BW_ - 1) / BW_, (rows + BH_ - 1) / BH_), dim3(BW_ * BH_), 0, s, a)
+#define KJ_SPATIAL(R_, S_, BW_, BH_, T_) do { if (order == KJ_TILES_BANDS) KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, KJ_TILES_BANDS); else if (order == KJ_TILES_SUPER) KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, KJ_TILES_SUPER); \
+                                              else KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, KJ_TILES_PLAIN); } while (0)
     if (L.pass_idx == 0) {
         if (L.variant == 0) KJ_SPATIAL(32, 8, 32, 32, true);
         else if (L.variant == 1) KJ_SPATIAL(32, 8, 16, 16, true);
@@ -526,6 +598,7 @@ hipError_t launch_restir_spatial(const SpatialLaunch& L, hipStream_t s) {
         if (L.variant == 0 || L.variant == 1) KJ_SPATIAL(16, 5, 16, 16, true);
         else KJ_SPATIAL(16, 5, 16, 16, false);
     }
+#undef KJ_SPATIAL_O
 #undef KJ_SPATIAL
     return hipGetLastError();
 }
@@ -545,14 +618,27 @@ hipError_t launch_restir_resolve(const ResolveLaunch& L, hipStream_t s) {
     a.irradiance_output_tex = img<uint2>(L.irradiance_output, L.W, L.H);
     a.blue_noise = (const uint32_t*)L.blue_noise;
     a.row0 = L.row0; a.row1 = L.row1;
-    hipLaunchKernelGGL(k_restir_resolve, dim3((L.W + 15) / 16, (L.row1 - L.row0 + 15) / 16), dim3(256), 0, s, a);
+#ifdef KJ_RESOLVE_TILES
+    const int order = KJ_RESOLVE_TILES;
+#else
+    const int order = resample_tile_order((L.W + 15) / 16);
+#endif
+    const dim3 grid((L.W + 15) / 16, (L.row1 - L.row0 + 15) / 16);
+    if (order == KJ_TILES_BANDS) hipLaunchKernelGGL(k_restir_resolve<KJ_TILES_BANDS>, grid, dim3(256), 0, s, a);
+    else if (order == KJ_TILES_SUPER) hipLaunchKernelGGL(k_restir_resolve<KJ_TILES_SUPER>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_restir_resolve<KJ_TILES_PLAIN>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_spatial_filter(const KjFrameConstants* fc, const void* input, const void* depth, const void* ssao, const void* geometric_normal, void* output,
                                  int W, int H, int row0, int row1, hipStream_t s) {
+#if KJ_SPATIAL_FILTER_TILED
+    hipLaunchKernelGGL(k_spatial_filter, dim3((W + KJ_SF_B - 1) / KJ_SF_B, (row1 - row0 + KJ_SF_B - 1) / KJ_SF_B), dim3(256), 0, s, fc, img<uint2>(input, W, H), img<float>(depth, W, H), img<uint8_t>(ssao, W, H),
+                       img<uint32_t>(geometric_normal, W, H), img<uint2>(output, W, H), row0, row1);
+#else
     hipLaunchKernelGGL(k_spatial_filter, dim3((W + 7) / 8, (row1 - row0 + 7) / 8), dim3(64), 0, s, fc, img<uint2>(input, W, H), img<float>(depth, W, H), img<uint8_t>(ssao, W, H),
                        img<uint32_t>(geometric_normal, W, H), img<uint2>(output, W, H), row0, row1);
+#endif
     return hipGetLastError();
 }
 

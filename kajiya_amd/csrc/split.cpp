@@ -417,15 +417,10 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
     const uint32_t KEEP = KJ_RTDGI_PASS_KEEP_TEMPORALS, M = s->motion_halo;
     const uint32_t out_i = s->frame % 2, hist_i = 1 - s->frame % 2;
     std::vector<Item> items;
-    // ---- A: last frame's denoised GI and its variance are read through the motion vectors only (fullres_reproject: a 4x4 footprint around the
-    // reprojected pixel; temporal_filter: a bilinear tap): halos, like TAA's histories. What the trace pass reads ANYWHERE on screen is the
-    // reprojected image: every rank reprojects its own strip and the strips are all-gathered (A').
-    if (s->frame > 0) { items.push_back({sfx("rtdgi.temporal2", hist_i), int(M + 3)}); items.push_back({sfx("rtdgi.temporal2_var", hist_i), int(M + 2)}); }
-    if (s->taa_frames > 0) {
-        const uint32_t th = 1 - s->taa_frames % 2;
-        items.push_back({sfx("TAA/taa", th), int(M + 4 + 32)}); items.push_back({sfx("TAA/taa.velocity", th), int(M + 2 + 16)}); items.push_back({sfx("TAA/taa.smooth_var", th), int(M + 2 + 16)});
-    }
-    KJ_SPLIT_TRY(exchange(*s, items, st));
+    // ---- A (gone since round 6): last frame's denoised GI and its variance are read through the motion vectors only (fullres_reproject: a 4x4 footprint around
+    // the reprojected pixel; temporal_filter: a bilinear tap) -- halos, like TAA's histories. They are final when their frame's temporal filter / taa pass has run, so
+    // they travel THEN, with exchange H of that frame and with kj_split_taa_frame's closing exchange, instead of in an exchange point of their own at the start of this
+    // one. What the trace pass reads ANYWHERE on screen is the reprojected image: every rank reprojects its own strip and the strips are all-gathered (A').
     for (uint32_t li = 0; li < s->local; ++li) {
         const KjSplitRank& r = s->ranks[li];
         if (r.ircache && !ircache_done) KJ_SPLIT_TRY(ircache_head(*s, li, frames[li], st));
@@ -471,9 +466,10 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
         KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_RESTIR_RESOLVE | KEEP, grow(*s, rank, 16), 0, st));
         KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_TEMPORAL_FILTER | KEEP, s->strips[rank], 0, st));
     }
-    // ---- H
-    KJ_SPLIT_TRY(exchange(*s, {{"temporal_filtered_tex", 16}}, st));
-    for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_SPATIAL_FILTER | KEEP, s->strips[s->first + li], 0, st));
+    // ---- H: the spatial filter's 16-row reach, 32 rows further because it over-computes what TAA's first passes read around the strip (TAA's input halo is
+    // 25 rows: no exchange point of its own), and next frame's history halos of the temporal filter's two outputs
+    KJ_SPLIT_TRY(exchange(*s, {{"temporal_filtered_tex", 16 + 32}, {sfx("rtdgi.temporal2", out_i), int(M + 3)}, {sfx("rtdgi.temporal2_var", out_i), int(M + 2)}}, st));
+    for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_SPATIAL_FILTER | KEEP, grow(*s, s->first + li, 32), 0, st));
     s->frame++;
     if (s->profiling) ++s->frames_profiled;
     return KJ_OK;
@@ -496,12 +492,13 @@ KjStatus kj_split_ssgi_frame(KjSplit* s, KjSsgi* const* ssgi, const KjSplitFrame
     if (s->ssgi.size() != s->local || !std::equal(s->ssgi.begin(), s->ssgi.end(), ssgi)) forget_surfaces(*s, "SSGI/");     // another renderer handle: its surfaces live elsewhere
     s->ssgi.assign(ssgi, ssgi + s->local);
     for (KjSsgi* g : s->ssgi) KJ_REQUIRE(g, "null SsgiRenderer");
-    if (s->ssgi_frames > 0) KJ_SPLIT_TRY(exchange(*s, {{sfx("SSGI/ssgi", 1 - s->ssgi_frames % 2), int(s->motion_halo + 2)}}, st));
     for (uint32_t li = 0; li < s->local; ++li) {
         const auto own = s->strips[s->first + li];
         KJ_SPLIT_TRY(kj_ssgi_render_rows(ssgi[li], &frames[li].rtdgi.gbuffer_depth, frames[li].rtdgi.reprojection_map, nullptr, own.first, own.second, &out_ssao_r8[li], st));
     }
-    KJ_SPLIT_TRY(exchange(*s, {{sfx("SSGI/filtered_output_tex", s->ssgi_frames % 2), 144 + 2}}, st));
+    // ONE exchange: the finished guide's halo and, for next frame's temporal pass, the halo of the history this frame has just written (round 5: a second exchange
+    // point at the start of the next frame)
+    KJ_SPLIT_TRY(exchange(*s, {{sfx("SSGI/filtered_output_tex", s->ssgi_frames % 2), 144 + 2}, {sfx("SSGI/ssgi", s->ssgi_frames % 2), int(s->motion_halo + 2)}}, st));
     ++s->ssgi_frames;
     return KJ_OK;
 }
@@ -596,8 +593,9 @@ KjStatus kj_split_rtr_frame(KjSplit* s, KjRtr* const* rtr, const KjRtrParams* rt
     return KJ_OK;
 }
 
-// TaaRenderer::render on this frame's GI image, strip by strip (multigpu.py: SplitRtdgi.taa_frame): one exchange (the input's halo;
-// the three histories travelled with exchange A of gi_frame), the intermediates over-computed on up to 32 extra rows per side.
+// TaaRenderer::render on this frame's GI image, strip by strip (multigpu.py: SplitRtdgi.taa_frame): the GI image arrives with its halo (kj_split_gi_frame's spatial
+// filter over-computes it), the intermediates are over-computed on up to 32 extra rows per side, and ONE exchange closes the frame: the three histories' halos for the
+// next frame, final now.
 KjStatus kj_split_taa_frame(KjSplit* s, const KjSplitFrame* frames, void* stream) { return kj_split_taa_frame_on(s, frames, nullptr, stream); }
 
 // The same on images of the caller's: input_rgba16f[li] (full res, valid on the rank's own rows -- e.g. what kj_light_gbuffer_rows wrote: the lighting frame of
@@ -611,7 +609,8 @@ KjStatus kj_split_taa_frame_on(KjSplit* s, const KjSplitFrame* frames, void* con
             KJ_REQUIRE(input_rgba16f[li], "null input image");
             s->surfaces[{li, std::string("LIT/input")}] = {(uint8_t*)input_rgba16f[li], uint64_t(s->W) * s->H * 8};      // the caller's image: bound anew every frame
         }
-    KJ_SPLIT_TRY(exchange(*s, {{name, 1 + 24}}, st));
+    // the GI image arrives with its halo already (kj_split_gi_frame's spatial filter over-computes 32 rows either side); a caller's image needs the exchange
+    if (input_rgba16f) KJ_SPLIT_TRY(exchange(*s, {{name, 1 + 24}}, st));
     for (uint32_t li = 0; li < s->local; ++li) {
         const uint32_t rank = s->first + li;
         uint8_t* inp; uint32_t rb;
@@ -622,6 +621,10 @@ KjStatus kj_split_taa_frame_on(KjSplit* s, const KjSplitFrame* frames, void* con
             KJ_SPLIT_TRY(kj_taa_render_rows(s->ranks[li].taa, inp, s->W, s->H, frames[li].rtdgi.reprojection_map, frames[li].rtdgi.gbuffer_depth.depth, s->W, s->H, frames[li].taa_out, st,
                                             stp.mask | (stp.keep ? KJ_RTDGI_PASS_KEEP_TEMPORALS : 0u), rows.first, rows.second));
         }
+    }
+    {   // next frame's history halos (read through the motion vectors by reproject / input_prob / taa), sent now that they are final
+        const uint32_t M = s->motion_halo, to = s->taa_frames % 2;
+        KJ_SPLIT_TRY(exchange(*s, {{sfx("TAA/taa", to), int(M + 4 + 32)}, {sfx("TAA/taa.velocity", to), int(M + 2 + 16)}, {sfx("TAA/taa.smooth_var", to), int(M + 2 + 16)}}, st));
     }
     s->taa_frames++;
     return KJ_OK;

@@ -304,14 +304,16 @@ class SplitRtdgi:
     """Drives RtdgiRenderer::{reproject,render} + TaaRenderer::render strip by strip with halo exchanges.
     `pipes`: {rank: GpuPipeline} for the ranks living in this process (one for DistComm, N for LocalComm).
 
-    Six exchange points per frame (each ONE batched send/recv group):
-      A  frame start     last frame's rtdgi.temporal2 (+variance) and TAA's three histories: motion halos
+    Exchange points per GI + TAA frame (each ONE batched send/recv group; round 6 took three away: a history's halo for the NEXT frame travels with the
+    exchange that follows the pass which makes it final, and TAA's input halo is over-computed by the spatial filter instead of exchanged):
       A' after reproject all-gather of the reprojected GI history (the trace pass reads it at the hit's screen position, anywhere)
       B  after validate  the five reservoir histories (validate rewrites them in place), invalidity, validity_pre
       C  after trace     validity_in (2), candidate radiance / hit (11)
       D  after temporal  reservoir, packed reservoir, radiance: 64 half-res rows (the "one-deep" exchange of SURVEY 8e-2)
-      H  after the temporal filter   16 full-res rows for the spatial filter's taps
-      I  before TAA      25 rows of the GI output
+      H  after the temporal filter   16 + 32 full-res rows for the spatial filter's taps (it over-computes +-32 rows: what TAA's first passes read
+                         around the strip) and the motion halos of rtdgi.temporal2 (+variance) for next frame's reproject / temporal filter
+      T  after TAA       TAA's three histories: motion halos for next frame
+      M  the cache's summaries: one fixed-size all-gather (_merge_ircache_requests)
     Between D and H nothing is exchanged: spatial pass 0 is over-computed on +-32 half-res rows, pass 1 on +-16, the resolve on
     +-16 full-res rows, which covers every tap of the next pass (restir_spatial.hlsl:89-97,155-157; restir_resolve.hlsl:89-96;
     temporal_filter.hlsl:69-89). TAA over-computes its intermediates the same way (taa_frame). Outside gi_frame: the SSAO guide (ssgi_frame: its
@@ -553,11 +555,10 @@ class SplitRtdgi:
         finished guide's halo is exchanged: rtdgi's passes read it up to GUIDE_HALO rows beyond the strip (gi_frame runs extract_half on those
         rows). Round 2 computed the whole frame's guide on every rank: 0.25 ms of replicated work per rank at 4K."""
         M = self.motion_halo
-        if self.ssgi_frames > 0:
-            self._exchange([(f"SSGI/ssgi:{1 - self.ssgi_frames % 2}", M + 2)])
         for r in self.comm.ranks:
             self.pipes[r].ssgi_frame(rows=self.strips[r])
-        self._exchange([(f"SSGI/filtered_output_tex:{self.ssgi_frames % 2}", GUIDE_HALO + 2)])
+        # ONE exchange (round 6): the finished guide's halo and, for next frame's temporal pass, the halo of the history this frame has just written
+        self._exchange([(f"SSGI/filtered_output_tex:{self.ssgi_frames % 2}", GUIDE_HALO + 2), (f"SSGI/ssgi:{self.ssgi_frames % 2}", M + 2)])
         self.ssgi_frames += 1
 
     def shadow_frame(self, masks=None, ray_counters=None):
@@ -661,19 +662,10 @@ class SplitRtdgi:
         R = self.comm.ranks
         self._s = klib._stream_ptr()
         self._params = {r: self.pipes[r].params(0) for r in R}
-        # ---- A
-        items = []
-        if self.frame > 0:
-            # last frame's denoised GI and its variance are read through the motion vectors only (fullres_reproject: a 4x4 footprint around the
-            # reprojected pixel; temporal_filter: a bilinear tap): halos. What the trace pass reads ANYWHERE on screen is the REPROJECTED image,
-            # all-gathered below after every rank has reprojected its own strip (round 2 all-gathered both histories and reprojected the
-            # whole frame on every rank: 99 MB in and 0.10 ms of replicated work per rank at 4K)
-            items += [("rtdgi.temporal2" + hist_sfx, M + 3), ("rtdgi.temporal2_var" + hist_sfx, M + 2)]
-        if self.taa_frames > 0:
-            th = f":{1 - self.taa_frames % 2}"
-            items += [("TAA/taa" + th, M + 4 + 32), ("TAA/taa.velocity" + th, M + 2 + 16), ("TAA/taa.smooth_var" + th, M + 2 + 16)]
-        if items:
-            self._exchange(items)
+        # ---- A (gone since round 6): last frame's denoised GI and its variance are read through the motion vectors only (fullres_reproject: a 4x4 footprint
+        # around the reprojected pixel; temporal_filter: a bilinear tap): halos, like TAA's histories. They are final once their frame's temporal filter / taa pass has
+        # run, so they travel THEN -- with exchange H of that frame, with taa_frame's closing exchange -- instead of in an exchange point of their own here. What the
+        # trace pass reads ANYWHERE on screen is the REPROJECTED image, all-gathered below after every rank has reprojected its own strip.
         for r in R:
             gp = self.pipes[r]
             s = self._s
@@ -720,10 +712,11 @@ class SplitRtdgi:
             self._render(r, P["RESTIR_SPATIAL"] | KEEP, self._grow(r, 32), spatial_select=2)
             self._render(r, P["RESTIR_RESOLVE"] | KEEP, self._grow(r, 16))
             self._render(r, P["TEMPORAL_FILTER"] | KEEP, self.strips[r])
-        # ---- H
-        self._exchange([("temporal_filtered_tex", 16)])
+        # ---- H: the spatial filter's 16-row reach + the 32 rows it over-computes either side for TAA's first passes (their input halo is 25 rows: no exchange
+        # point of its own), and next frame's history halos of the temporal filter's two outputs
+        self._exchange([("temporal_filtered_tex", 16 + 32), ("rtdgi.temporal2" + out_sfx, M + 3), ("rtdgi.temporal2_var" + out_sfx, M + 2)])
         for r in R:
-            self._render(r, P["SPATIAL_FILTER"] | KEEP, self.strips[r])
+            self._render(r, P["SPATIAL_FILTER"] | KEEP, self._grow(r, 32))
         self.frame += 1
 
     def _merge_ircache_requests(self):
@@ -746,8 +739,8 @@ class SplitRtdgi:
 
     def taa_frame(self, inputs=None):
         """TaaRenderer::render on this frame's GI image -- or on `inputs`: {rank: RGBA16F (H, W, 4) image valid on the rank's own rows}, e.g. the lit image of
-        light_gbuffer(rows=strip) (lighting_frame) -- strip by strip. ONE exchange here (the input's halo; the three
-        histories travel with exchange A of gi_frame); the intermediate images are over-computed on up to 32 extra rows per side (8-row tile
+        light_gbuffer(rows=strip) (lighting_frame) -- strip by strip. Exchanges: a caller's image's halo first (the GI image arrives with its halo), the three
+        histories' halos for the NEXT frame at the end; the intermediate images are over-computed on up to 32 extra rows per side (8-row tile
         granularity) instead of being exchanged: prob_filter2 reaches +-4 rows of prob_filter, that +-1 of input_prob,
         that +-1 of the filtered history / input and +-2 of the input deviation, those +-1 of the reprojected history /
         input (taa/*.hlsl)."""
@@ -758,8 +751,9 @@ class SplitRtdgi:
             for r in self.comm.ranks:
                 self.pipes[r].taa_input_img = inputs[r]
             self._plans.pop(((gi_out, 1 + 24),), None)       # the caller's images may be others than last frame's: resolve their rows anew
-        # ---- I
-        self._exchange([(gi_out, 1 + 24)])                   # filter_input runs on +-24 rows
+        # ---- I: a caller's image needs its halo (filter_input runs on +-24 rows); the GI image has it already -- gi_frame's spatial filter over-computes 32 rows either side
+        if inputs is not None:
+            self._exchange([(gi_out, 1 + 24)])
         for r in self.comm.ranks:
             gp = self.pipes[r]
             r0, r1 = self.strips[r]
@@ -775,6 +769,9 @@ class SplitRtdgi:
             run(8, 16)                     # input prob (+-2 deviation, +-1 filtered input / history)
             run(16, 8)                     # prob filter (+-1)
             run(32 | 64, 0)                # prob filter 2 (+-4), taa (+-2 reprojected history, +-1 input)
+        # next frame's history halos (read through the motion vectors by reproject / input_prob / taa), sent now that they are final
+        M, to = self.motion_halo, f":{self.taa_frames % 2}"
+        self._exchange([("TAA/taa" + to, M + 4 + 32), ("TAA/taa.velocity" + to, M + 2 + 16), ("TAA/taa.smooth_var" + to, M + 2 + 16)])
         self.taa_frames += 1
 
     def lighting_frame(self, with_ssgi=True, specular_lights=False):

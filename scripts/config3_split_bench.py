@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--res", default="2560x1440"); ap.add_argument("--tris", type=int, default=4_000_000); ap.add_argument("--scene", default="ruins")
 ap.add_argument("--frames", type=int, default=30); ap.add_argument("--warmup", type=int, default=12); ap.add_argument("--virtual-ranks", type=int, default=2)
 ap.add_argument("--motion-halo", type=int, default=16); ap.add_argument("--check", action="store_true", help="also render every frame unsplit and compare this rank's rows")
+ap.add_argument("--work", action="store_true", help="GPU work per rank (virtual ranks, compiled orchestrator): all frames issued serially without a wait, HIP events around them, minus the orchestrator's own event pairs around every exchange (kj_split_set_profiling), / N; and the same frames on one GPU")
 ap.add_argument("--pipelined", action="store_true", help="lighting_frame_pipelined: the cache's work of frame N+1 and the replay of frame N's updates on a side stream (inputs of all frames pre-generated; no --check)")
 a = ap.parse_args()
 W, H = map(int, a.res.split("x"))
@@ -53,6 +54,65 @@ cam = (lambda i: frame.orbit_camera(i, (W, H), center=(0.0, 1.5, 0.0), radius=9.
       (lambda i: frame.orbit_camera(i, (W, H), center=(0.0, 3.0, 0.0), radius=34.0, height=5.0, rate=0.004))
 mine = sorted(pipes)
 worst, t_acc = 0, 0.0
+if a.work:
+    import ctypes as C
+    from kajiya_amd.abi import KjSplitProfile
+    assert world == 1 and native and not a.check and not a.pipelined, "--work: virtual ranks, compiled orchestrator"
+    K = a.warmup + a.frames
+    fcs, inputs = [], []
+    gp0 = pipes[mine[0]]
+    for i in range(K):
+        fc = fs.prepare_frame_constants(cam(i)); fs.retire_frame()
+        gp0.render_inputs(fc); gp0.reprojection()
+        rp = lib.tensor_from_ptr(gp0.reprojection_map_ptr.value, W * H * 8, torch.int16, (H, W, 4)).clone()
+        fcs.append(fc); inputs.append((gp0.geometric_normal.clone(), gp0.gbuffer.clone(), gp0.depth.clone(), rp, gp0.sky16.clone(), gp0.sky64.clone()))
+
+    def bind_to(qs, i):
+        for q in qs:
+            q.geometric_normal, q.gbuffer, q.depth, rp, q.sky16, q.sky64 = inputs[i]
+            q.reprojection_map_ptr = C.c_void_p(rp.data_ptr())
+
+    def timed(step):
+        for i in range(a.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); e0.record()
+        for i in range(a.warmup, K):
+            step(i)
+        e1.record(); issue = 1e3 * (time.perf_counter() - t0) / a.frames
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / a.frames, issue
+    one = mk(); one.ircache_set_rtr_requests(True)
+
+    def one_step(i):      # scripts/config3_bench.py's order, serial, the reference's racy cache
+        dev.frame_begin(fcs[i]); bind_to([one], i)
+        one.ssgi_frame(); sh = one.shadow_denoise(one.sun_shadow_mask()); one.gi_frame(); rt = one.rtr_frame()
+        lit = one.light_gbuffer(sh, rtr_ptr=rt.data_ptr())[1]; one.taa_frame(input_ptr=lit.data_ptr())
+    one_ms, _ = timed(one_step)
+
+    def split_step(i):
+        dev.frame_begin(fcs[i]); bind_to(pipes.values(), i)
+        split.lighting_frame()
+    for i in range(a.warmup):
+        split_step(i)
+    torch.cuda.synchronize()
+    lib.check(split.L.kj_split_set_profiling(split.h, 1))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for i in range(a.warmup, K):
+        split_step(i)
+    e1.record(); issue = 1e3 * (time.perf_counter() - t0) / a.frames
+    torch.cuda.synchronize()
+    all_ms = e0.elapsed_time(e1) / a.frames
+    prof = KjSplitProfile(); lib.check(split.L.kj_split_profile(split.h, C.byref(prof)))
+    ex = prof.exchange_ms / a.frames
+    work = (all_ms - ex) / n
+    print(json.dumps({"config": "BASELINE configs[2] under the screen-tile split: GPU work per rank", "workload": f"{a.scene} @ {W}x{H}", "ranks": n, "one_gpu_serial_frame_ms": round(one_ms, 4),
+                      "all_ranks_frame_gpu_ms": round(all_ms, 4), "exchange_ms_per_rank": round(ex / n, 4), "per_rank_work_ms": round(work, 4), "speedup_on_work_alone": round(one_ms / work, 3),
+                      "exchange_points_per_frame": round(prof.exchange_points / a.frames, 2), "exchange_MB_arriving_at_busiest_rank_per_frame": round(prof.exchange_bytes_busiest_rank / a.frames / 1e6, 2),
+                      "host_issue_ms_per_frame_all_ranks": round(issue, 3), "host_ran_ahead": bool(issue < 0.8 * all_ms)}))
+    sys.exit(0)
 if a.pipelined:
     import ctypes as C
     assert not a.check, "--check compares serial frames"
