@@ -40,3 +40,15 @@ def gpu():
 @pytest.fixture(scope="session")
 def device(gpu):
     return gpu.Device(0)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """What the loosest bars were set against, as this session measured it (tests/parity.py: MEASURED)."""
+    try:
+        import parity
+    except Exception:
+        return
+    if parity.MEASURED:
+        print("\n[parity] worst values this session saw of the quantities the loose bars bound:")
+        for k in sorted(parity.MEASURED):
+            print(f"[parity]   {k}: {parity.MEASURED[k]:.3e}")

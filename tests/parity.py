@@ -142,6 +142,13 @@ def compare_decoded(a, b, atol=0.0, vector=False, exact=False, rtol=1e-3):
                 rel_l2_inliers=float(np.sqrt((din * din).sum()) / den) if den > 0 else float(np.sqrt((din * din).sum())))
 
 
+MEASURED = {}          # label -> the worst value a session saw of a quantity some bar bounds (printed by tests/conftest.py: pytest_sessionfinish)
+
+
+def measured(label, value):
+    MEASURED[label] = max(MEASURED.get(label, 0.0), float(value))
+
+
 REL_L2_TOL = 1e-3      # north-star tolerance (BASELINE.json) for deterministic passes on identical inputs
 MISMATCH_TOL = 2e-3    # fraction of texels allowed to be off by more than 1e-3 relative (discrete flips: a reservoir pick, an int() tap)
 
@@ -161,6 +168,10 @@ def within_bars_with_flips(r, flip_tol=MISMATCH_TOL, outlier_cap=1e-2):
     either (<= 1e-2)."""
     few = r["mismatch_frac"] * r["n"] <= 8.5          # a handful of texels: on a small image ONE bright flipped texel is > 1e-2 of the image's L2
     flip_tol = max(flip_tol, 8.0 / max(1, r["n"]))
+    # what the bars are set against (tests/conftest.py prints these at the end of a session: VERDICT r5 weak #4 "bars at 2x measured")
+    MEASURED["flip passes: worst rel_l2 beyond a handful of outliers (cap %g)" % outlier_cap] = max(MEASURED.get("flip passes: worst rel_l2 beyond a handful of outliers (cap %g)" % outlier_cap, 0.0), 0.0 if few else r["rel_l2"])
+    MEASURED["flip passes: worst outlier fraction on images of >= 1e5 texels (tol %g)" % MISMATCH_TOL] = max(MEASURED.get("flip passes: worst outlier fraction on images of >= 1e5 texels (tol %g)" % MISMATCH_TOL, 0.0), r["mismatch_frac"] if r["n"] >= 100000 else 0.0)
+    MEASURED["flip passes: worst inlier rel_l2 (tol %g)" % REL_L2_TOL] = max(MEASURED.get("flip passes: worst inlier rel_l2 (tol %g)" % REL_L2_TOL, 0.0), r["rel_l2_inliers"])
     return r["rel_l2_inliers"] <= REL_L2_TOL and r["mismatch_frac"] <= flip_tol and (few or r["rel_l2"] <= outlier_cap) and r.get("bad_class", 0) == 0
 
 
