@@ -433,7 +433,11 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
     for (uint32_t li = 0; li < s->local; ++li) {
         const KjSplitRank& r = s->ranks[li];
         if (r.ircache) KJ_SPLIT_TRY(kj_ircache_sum_up_irradiance_for_sampling(r.ircache, st));
-        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_EXTRACT_HALF, {0, 0}, 0, st));      // replicated inputs: full frame, cheap
+        // the half-res images and G-buffer records for the WHOLE frame, from replicated inputs (27 us per rank at 4K). Not only on own +- 64 half-res rows (tried in round 6:
+        // the wide-angle reflections case of the bit-exactness tests fails): the second spatial pass' occlusion march walks from the pixel towards the sample's HIT point for up to
+        // three times the screen distance of the sample's pixel (occlusion_raymarch.hlsl via restir_spatial.hlsl:235-262) and reads the half-res depth along the way -- well beyond
+        // the halo of everything else under a grazing, wide field of view.
+        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_EXTRACT_HALF, {0, 0}, 0, st));
         KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_VALIDATE | KEEP, s->strips[s->first + li], 0, st));
     }
     // ---- B: validate rewrites the reservoir histories in place

@@ -679,8 +679,10 @@ class SplitRtdgi:
             if gp.ircache:
                 klib.check(gp.L.kj_ircache_sum_up_irradiance_for_sampling(gp.ircache, s))
             # the half-res images and G-buffer records for the WHOLE frame (replicated inputs, cheap): the resolve reads the view normal at every
-            # reservoir's sample pixel, and an empty reservoir's payload is pixel (0, 0) -- rows far outside the strip. With the strip-wise guide
-            # (self.ssgi_frame) the records' ssao byte is only meaningful on own +- GUIDE_HALO rows, which is where it is read.
+            # reservoir's sample pixel, an empty reservoir's payload is pixel (0, 0), and the second spatial pass' occlusion march reads the half-res depth
+            # along a screen-space ray up to three times as long as the sample pixel is far (round 6 tried own +- 64 half-res rows + row 0: the wide-angle
+            # reflections case of the bit-exactness tests fails). With the strip-wise guide (self.ssgi_frame) the records' ssao byte is only meaningful
+            # on own +- GUIDE_HALO rows, which is where it is read.
             self._render(r, P["EXTRACT_HALF"])
             self._render(r, P["VALIDATE"] | KEEP, self.strips[r])
         # ---- B
