@@ -652,7 +652,9 @@ KJ_D bool irc_replay_entry(const IrcacheView& ic, uint2 gm, uint32_t* entry, uin
 // flushes one device atomic per touched cell and field. `cells`: the 4-byte-per-slot copy of the records' cell field (0xffffffff = no record), or null for a
 // plain list (then rq[i].cell itself).
 #define IRC_RED_SLOTS 1024u
+#ifndef IRC_RED_PER_THREAD
 #define IRC_RED_PER_THREAD 8u
+#endif
 __global__ void __launch_bounds__(256) k_irc_reduce_requests(IrcacheView ic, const IrcRequest* __restrict__ rq, const uint32_t* __restrict__ cells, IrcReduceRanges rr, IrcSummaryView sum,
                                                               unsigned long long* __restrict__ alloc_min) {
     __shared__ uint32_t h_cell[IRC_RED_SLOTS], h_rank[IRC_RED_SLOTS], h_votes[IRC_RED_SLOTS];
@@ -763,6 +765,9 @@ __global__ void __launch_bounds__(256) k_irc_alloc_emit(IrcacheView ic, unsigned
     __syncthreads();
     if (before) atomicAdd(&s_base, before);
     if (all) atomicAdd(&s_total, all);
+    __syncthreads();
+    // nothing to hand out anywhere (most frames of a settled cache, every summary of the cache's own passes): leave before touching the 3 MB of winners
+    if (s_total == 0u) { if (blockIdx.x == 0u && threadIdx.x == 0u) { if (APPLY) *out_total = 0u; else sum.header[0] = 0u; } return; }
     const uint32_t c0 = blockIdx.x * 1024u + threadIdx.x * 4u;
     unsigned long long v[4];
     uint32_t cnt = 0;
@@ -776,7 +781,6 @@ __global__ void __launch_bounds__(256) k_irc_alloc_emit(IrcacheView ic, unsigned
         s_scan[threadIdx.x] += add;
         __syncthreads();
     }
-    if (s_total == 0u) { if (blockIdx.x == 0u && threadIdx.x == 0u) { if (APPLY) *out_total = 0u; else sum.header[0] = 0u; } return; }
     uint32_t r = s_base + s_scan[threadIdx.x] - cnt;
     if (blockIdx.x == 0u && threadIdx.x == 0u) { if (APPLY) *out_total = s_total; else sum.header[0] = min(s_total, uint32_t(IRC_MAX_ENTRIES)); }
     __shared__ uint32_t s_entry_max;      // APPLY: the highest entry index this block hands out + 1 -- ONE device atomic per block (an atomicMax per new cell on the one
@@ -1041,7 +1045,10 @@ KjStatus kj_ircache_trace_irradiance(KjIrcache* c, KjScene* scene, const void* s
 KjStatus kj_ircache_sum_up_irradiance_for_sampling(KjIrcache* c, void* stream_) {
     KJ_REQUIRE(c && c->dev->fc_dev, "null argument");
     KJ_REQUIRE(c->pending_irradiance_sum, "trace_irradiance must run first (ircache.rs:492 assert)");
-    hipLaunchKernelGGL(k_irc_sum_up, dim3(c->dev->num_cus * 4), dim3(64), 0, (hipStream_t)stream_, c->dev->fc_dev, c->view());
+#ifndef KJ_IRC_SUMUP_GRID
+#define KJ_IRC_SUMUP_GRID 4
+#endif
+    hipLaunchKernelGGL(k_irc_sum_up, dim3(c->dev->num_cus * KJ_IRC_SUMUP_GRID), dim3(64), 0, (hipStream_t)stream_, c->dev->fc_dev, c->view());
     KJ_CHECK_LAUNCH();
     c->pending_irradiance_sum = false;
     return KJ_OK;

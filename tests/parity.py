@@ -163,10 +163,14 @@ def within_bars_with_flips(r, flip_tol=MISMATCH_TOL, outlier_cap=1e-2):
     """For the outputs of passes that take DISCRETE decisions on float comparisons -- a shadow ray grazing an edge, the 5e-3 depth
     gate that picks last frame's radiance or the irradiance cache for a hit (diffuse_trace_common.inc.hlsl:85-107), a reservoir's
     `w / w_sum >= dart` -- a last-bit difference replaces a texel's whole value, and with radiance spanning decades ONE such texel
-    in 10^5 moves the whole-image L2 past 1e-3. There the outlier texels are counted and capped (<= 0.2 %, or 8 texels on a tiny
-    image), every other texel meets the 1e-3 bar as an image, and beyond a handful (8) the outliers may not dominate the image
+    in 10^5 moves the whole-image L2 past 1e-3. There the outlier texels are counted and capped (<= 0.05 % of an image of 1e5 texels or more, <= 0.2 % or 8 texels
+    of a smaller one), every other texel meets the 1e-3 bar as an image, and beyond a handful (8) the outliers may not dominate the image
     either (<= 1e-2)."""
     few = r["mismatch_frac"] * r["n"] <= 8.5          # a handful of texels: on a small image ONE bright flipped texel is > 1e-2 of the image's L2
+    # images of 1e5 texels and more (where a fraction is a statistic): 5e-4, 3.4x the worst the whole GPU suite measured in round 6 (1.45e-4; the outlier cap of 1e-2 is 2x
+    # its 4.98e-3: profiles/r06_gpu_tests_summary.txt); smaller images keep the 2e-3 / eight-texel rule
+    if flip_tol == MISMATCH_TOL and r["n"] >= 100000:
+        flip_tol = 5e-4
     flip_tol = max(flip_tol, 8.0 / max(1, r["n"]))
     # what the bars are set against (tests/conftest.py prints these at the end of a session: VERDICT r5 weak #4 "bars at 2x measured")
     MEASURED["flip passes: worst rel_l2 beyond a handful of outliers (cap %g)" % outlier_cap] = max(MEASURED.get("flip passes: worst rel_l2 beyond a handful of outliers (cap %g)" % outlier_cap, 0.0), 0.0 if few else r["rel_l2"])

@@ -130,9 +130,10 @@ def config3_lighting_frame_parity(gpu, oracle, device, scene_name, W, H):
             # the whole frame in one go (its passes in isolation: the 4K test above): a candidate whose shadow ray or depth gate flipped
             # (1e-4 of the half-res texels) reaches ~50 full-res neighbours through the resampling chain and the denoiser, each by a
             # little -- the image-level bar holds, the count of slightly-off texels is reported and bounded loosely
-            # (measured on MI355X, round 4: 4.5e-3 / 4.1e-4 of the texels at 1440p; the bar is twice the larger one)
-            P.measured("1440p whole rtdgi frame: mismatch fraction (bar 9e-3)", r["mismatch_frac"])
-            assert r["rel_l2"] <= P.REL_L2_TOL and r["bad_class"] == 0 and r["mismatch_frac"] <= 9e-3, f"rtdgi whole frame {fi}: {r}"
+            # (measured on MI355X: round 4 4.5e-3 / 4.1e-4 of the texels at 1440p; round 6, with the ray passes and TAA compiled without FMA contraction since, 8.6e-4 at worst
+            # (profiles/r06_gpu_tests_summary.txt): the bar is twice that, rounded up)
+            P.measured("1440p whole rtdgi frame: mismatch fraction (bar 2e-3)", r["mismatch_frac"])
+            assert r["rel_l2"] <= P.REL_L2_TOL and r["bad_class"] == 0 and r["mismatch_frac"] <= 2e-3, f"rtdgi whole frame {fi}: {r}"
             T._upload_state(gp, T._oracle_surfaces(op), torch)
             for k, pname in enumerate(TR.RTR_PASS_ORDER):
                 mask = TR.KJ_RTR_PASS[pname] | (0 if k == 0 else TR.KJ_RTR_PASS["KEEP"])

@@ -327,9 +327,10 @@ def deterministic_frames_on_identical_state(gpu, oracle, device, scene_name, W, 
         print(f"  GI output: rel-L2 {r['rel_l2']:.2e}, outliers {r['mismatch_frac']:.2e}")
         # one flipped slot of THIS frame's cache passes moves its entry's SH by a percent, and every pixel whose ray ends in that cell
         # reads it: the image-level bar holds; the count of slightly-off texels is reported and bounded loosely
-        # measured on MI355X (round 4): 3.5e-3 / 2.0e-3 of the texels at 1080p, 133 / 0 / 0 texels at 128^2; the bar is twice that
-        P.measured("GI output behind the deterministic cache, n = %d: mismatch fraction (bar max(7e-3, 270 / n))" % r["n"], r["mismatch_frac"])
-        assert r["rel_l2"] <= P.REL_L2_TOL and r["bad_class"] == 0 and r["mismatch_frac"] <= max(7e-3, 270.0 / r["n"]), f"GI output: {r}"
+        # measured on MI355X: round 4 3.5e-3 / 2.0e-3 of the texels at 1080p, 133 / 0 / 0 texels at 128^2; round 6 1.4e-3 at 1080p, 114 texels at 128^2
+        # (profiles/r06_gpu_tests_summary.txt): the bar is twice the round-6 values, rounded up
+        P.measured("GI output behind the deterministic cache, n = %d: mismatch fraction (bar max(3e-3, 270 / n))" % r["n"], r["mismatch_frac"])
+        assert r["rel_l2"] <= P.REL_L2_TOL and r["bad_class"] == 0 and r["mismatch_frac"] <= max(3e-3, 270.0 / r["n"]), f"GI output: {r}"
         oc, oa = op.ircache_ray_counts(); gc, ga = gp.ircache_ray_counts()
         assert oc == gc and abs(oa - ga) <= 0.002 * oa + 4, (oc, oa, gc, ga)
     return exact
