@@ -653,7 +653,7 @@ KJ_D bool irc_replay_entry(const IrcacheView& ic, uint2 gm, uint32_t* entry, uin
 // plain list (then rq[i].cell itself).
 #define IRC_RED_SLOTS 1024u
 #ifndef IRC_RED_PER_THREAD
-#define IRC_RED_PER_THREAD 8u
+#define IRC_RED_PER_THREAD 4u      // slots per thread and chunk: 1024-slot chunks (8: 22 us per reduce of a 4K strip, 4: 18.7, 2: 18.0; round 6)
 #endif
 __global__ void __launch_bounds__(256) k_irc_reduce_requests(IrcacheView ic, const IrcRequest* __restrict__ rq, const uint32_t* __restrict__ cells, IrcReduceRanges rr, IrcSummaryView sum,
                                                               unsigned long long* __restrict__ alloc_min) {
