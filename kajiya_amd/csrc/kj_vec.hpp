@@ -438,6 +438,12 @@ template <typename T> struct Img {
         const T v = p[in ? size_t(y) * w + x : size_t(0)];
         return in ? v : T();
     }
+    // the same load with the select left to the caller (`in` false: the value is texel 0's, to be replaced by T()): kernels that put many gathers in flight before
+    // using any of them keep the selects -- the first USE of each loaded value -- out of the issue sequence
+    KJ_D T ld_raw(int x, int y, bool& in) const {
+        in = inb(x, y);
+        return p[in ? size_t(y) * w + x : size_t(0)];
+    }
     KJ_D T ldc(int x, int y) const {  // clamp-to-edge
         x = x < 0 ? 0 : (x >= w ? w - 1 : x); y = y < 0 ? 0 : (y >= h ? h - 1 : y);
         return p[size_t(y) * w + x];

@@ -100,14 +100,16 @@ __global__ void __launch_bounds__(64) k_fullres_reproject(ImgH4 input_tex, ImgU2
         // GatherBlue(sampler_nnc, uv + 0.5*sign(prev_uv)*texel): validity of the 2x2 footprint
         const V2 guv = uv + 0.5f * V2{float((prev_uv.x > 0) - (prev_uv.x < 0)), float((prev_uv.y > 0) - (prev_uv.y < 0))} * V2{ts.z, ts.w};
         const int ox = int(floorf(guv.x * float(W) - 0.5f)), oy = int(floorf(guv.y * float(H) - 0.5f));
+        // (round 6: the four texels of the footprint are requested together -- `&&` between them made every load wait for the previous one's answer)
+        uint2 fp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sx = min(max(ox + (i & 1), 0), W - 1), sy = min(max(oy + (i >> 1), 0), H - 1);
+            fp[i] = reprojection_tex.p[size_t(sy) * W + sx];      // clamped: in bounds
+        }
         bool all_valid = true;
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const int sx = min(max(ox + dx, 0), W - 1), sy = min(max(oy + dy, 0), H - 1);
-                all_valid = all_valid && (uint32_t(ld_reproj(reprojection_tex, sx, sy).z * 15.0f + 0.5f) == 15u);
-            }
+        for (int i = 0; i < 4; ++i) all_valid = all_valid & (uint32_t(from_snorm16(int16_t(fp[i].y & 0xffff)) * 15.0f + 0.5f) == 15u);
         if (all_valid) {
             const V2 pixel = prev_uv * V2{float(W), float(H)} + 0.5f;
             const V2 frc{frac(pixel.x), frac(pixel.y)};
@@ -677,7 +679,8 @@ KJ_D void validity_integrate_body(const ValidityIntegrateArgs& v) {
         for (int ox = 1; ox <= 2; ++ox) {
             const V4 reproj = ld_reproj(reprojection_tex, x * 2 + ox, y * 2 + oy);
             const float sample_depth = half_depth_tex.ld(x + ox / 2, y + oy / 2);
-            edge_ok = edge_ok && !(reproj.w < 0 || inverse_depth_relative_diff(center_depth, sample_depth) > 0.1f) && (reproj.z == 0 && sample_depth != 0);
+            // (`&`, not `&&`: a short-circuit makes every texel's loads wait for the previous texel's verdict)
+            edge_ok = edge_ok & !((reproj.w < 0) | (inverse_depth_relative_diff(center_depth, sample_depth) > 0.1f)) & ((reproj.z == 0) & (sample_depth != 0));
         }
     float edge = edge_ok ? 1.0f : 0.0f;
     edge = fmaxf(edge, __shfl_xor(edge, 1));
@@ -687,12 +690,16 @@ KJ_D void validity_integrate_body(const ValidityIntegrateArgs& v) {
     const V2 reproj_px{float(x) + float(W) * reproj.x / 2 + 0.5f, float(y) + float(H) * reproj.y / 2 + 0.5f};
     float history = 0;
     const float ang_off = uint_to_u01_float(hash3(uint32_t(x), uint32_t(y), fc.frame_index)) * KJ_PI * 2;
+    uint32_t hist_raw[8]; bool hist_in[8];
+#pragma unroll
     for (uint32_t si = 0; si < 8u; ++si) {
         const float ang = (float(si) + ang_off) * KJ_GOLDEN_ANGLE;
         const float radius = float(si) * 1.0f;
         const V2 so = cos_sin_turns_fast(ang) * radius;      // same reduction in revolutions, < 1 ulp (kj_screen.hpp): libm's sinf + cosf are 235 instructions per tap
-        history += ld2h(history_tex, int(reproj_px.x + so.x), int(reproj_px.y + so.y)).x;
+        hist_raw[si] = history_tex.ld_raw(int(reproj_px.x + so.x), int(reproj_px.y + so.y), hist_in[si]);      // the eight taps in flight together
     }
+#pragma unroll
+    for (uint32_t si = 0; si < 8u; ++si) history += unpack_2x16f_uint(hist_in[si] ? hist_raw[si] : 0u).x;
     history /= 8;
     if (in_image) st2h(output_tex, x, y, V2{fmaxf(history * 0.75f, ib), from_unorm8(input_tex.ld(x, y))});
 }
@@ -769,37 +776,48 @@ KJ_D void restir_temporal_body(const RestirTemporalArgs& a) {
             rpx_offset = I2{oa.x + ob.x, oa.y + ob.y};
             if (rpx_offset.x == 0 && rpx_offset.y == 0) continue;
         }
-        const V4 reproj = ld_reproj(a.reprojection_tex, hx + rpx_offset.x * 2, hy + rpx_offset.y * 2);
+        // (round 6: a tap's gathers leave in three groups instead of one by one: [reprojection, neighbour depth, neighbour normal] -- the last two depend on the tap's
+        // position only --, [the reprojected reservoir], [the four histories at the pixel the reservoir points at]; the rejection tests follow in the text's order.)
         const V2 base = sample_i == 0 ? V2{float(x), float(y)} : V2{float(uint32_t(x + rpx_offset.x) ^ pxv_x), float(uint32_t(y + rpx_offset.y) ^ pxv_y)};
-        const int prx = f2i_sat(floorf(base.x + gts.x * reproj.x * 0.5f + 0.0f + 0.5f)), pry = f2i_sat(floorf(base.y + gts.y * reproj.y * 0.5f + 0.0f + 0.5f));
-        const I2 rpx{wrap_add(prx, rpx_offset.x), wrap_add(pry, rpx_offset.y)};
         const int pnx = f2i_sat(floorf(base.x + 0.5f)), pny = f2i_sat(floorf(base.y + 0.5f));
         const I2 neighbor_px{wrap_add(pnx, rpx_offset.x), wrap_add(pny, rpx_offset.y)};
         const int nhx = wrap_mul2_add(neighbor_px.x, off.x), nhy = wrap_mul2_add(neighbor_px.y, off.y);
+        bool in_rp, in_d, in_n, in_h;
+        const uint2 reproj_raw = a.reprojection_tex.ld_raw(hx + rpx_offset.x * 2, hy + rpx_offset.y * 2, in_rp);
+        const float sample_depth_raw = a.depth_tex.ld_raw(nhx, nhy, in_d);
+        const uint32_t sample_normal_raw = a.half_view_normal_tex.ld_raw(neighbor_px.x, neighbor_px.y, in_n);
+        const uint2 rpr = in_rp ? reproj_raw : make_uint2(0u, 0u);
+        const V4 reproj{from_snorm16(int16_t(rpr.x & 0xffff)), from_snorm16(int16_t(rpr.x >> 16)), from_snorm16(int16_t(rpr.y & 0xffff)), from_snorm16(int16_t(rpr.y >> 16))};
+        const int prx = f2i_sat(floorf(base.x + gts.x * reproj.x * 0.5f + 0.0f + 0.5f)), pry = f2i_sat(floorf(base.y + gts.y * reproj.y * 0.5f + 0.0f + 0.5f));
+        const I2 rpx{wrap_add(prx, rpx_offset.x), wrap_add(pry, rpx_offset.y)};
         Reservoir1spp r = Reservoir1spp::from_raw(a.reservoir_history_tex.ld(rpx.x, rpx.y));
         const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
         float relevance = 1;
-        const float sample_depth = a.depth_tex.ld(nhx, nhy);
-        const float4 pro = a.ray_orig_history_tex.ld(spx_x, spx_y);
+        const float sample_depth = in_d ? sample_depth_raw : 0.0f;
+        const float4 pro_raw = a.ray_orig_history_tex.ld_raw(spx_x, spx_y, in_h);      // (the four histories share the half-res extent)
+        const uint2 rh_raw = a.ray_history_tex.ld_raw(spx_x, spx_y, in_h);
+        const uint2 hn_raw = a.hit_normal_history_tex.ld_raw(spx_x, spx_y, in_h);
+        const uint2 prad_raw = a.radiance_history_tex.ld_raw(spx_x, spx_y, in_h);
+        const float4 pro = in_h ? pro_raw : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         const V3 prev_ray_orig{pro.x, pro.y, pro.z};
         if (length(prev_ray_orig - refl_ray_origin_ws) > 0.1f * -vr.hit_vs.z) continue;
         if (0 == sample_depth) continue;
         if (reproj.z == 0) continue;
         relevance *= 1 - smoothstep_fast(0.0f, 0.1f, fabsf(fmaxf(1e-20f, depth) * rcp_fast(fmaxf(1e-20f, sample_depth)) - 1.0f));
-        const V3 sample_normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, neighbor_px.x, neighbor_px.y);
+        const V3 sample_normal_vs = xyz(unpack_rgba8_snorm(in_n ? sample_normal_raw : 0u));
         const float normal_similarity_dot = fmaxf(0.0f, dot(sample_normal_vs, normal_vs));
         if (sample_i != 0 && normal_similarity_dot < 0.2f) continue;
         relevance *= square(square(normal_similarity_dot));
-        const V4 rh = ld4(a.ray_history_tex, spx_x, spx_y);
+        const V4 rh = unpack_rgba16f(in_h ? rh_raw : make_uint2(0u, 0u));
         const V3 sample_hit_ws = xyz(rh) + prev_ray_orig;
         const float prev_dist = rh.w;
-        const V4 hn = ld4(a.hit_normal_history_tex, spx_x, spx_y);
+        const V4 hn = unpack_rgba16f(in_h ? hn_raw : make_uint2(0u, 0u));
         const V4 sample_hit_normal_ws_dot{hn.x * 2 - 1, hn.y * 2 - 1, hn.z * 2 - 1, hn.w};
         const V3 dir_to_sample_hit_unnorm = sample_hit_ws - refl_ray_origin_ws;
         const float inv_dist_to_sample_hit = rsq_fast(dot(dir_to_sample_hit_unnorm, dir_to_sample_hit_unnorm));
         const V3 dir_to_sample_hit = dir_to_sample_hit_unnorm * inv_dist_to_sample_hit;
         const float center_to_hit_vis = -dot(xyz(sample_hit_normal_ws_dot), dir_to_sample_hit);
-        const V4 prev_rad = ld4(a.radiance_history_tex, spx_x, spx_y) * V4{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
+        const V4 prev_rad = unpack_rgba16f(in_h ? prad_raw : make_uint2(0u, 0u)) * V4{fc.pre_exposure_delta, fc.pre_exposure_delta, fc.pre_exposure_delta, 1};
         r.M = fmaxf(0.0f, fminf(r.M, M_clamp_now));
         const float p_q = 1 * fmaxf(0.0f, sRGB_to_luminance(xyz(prev_rad))) * stepf(0.0f, dot(dir_to_sample_hit, normal_ws));
         float jacobian = 1;

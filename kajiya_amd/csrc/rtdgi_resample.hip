@@ -69,6 +69,9 @@ struct SpatialArgs {
 
 // R = reach of the pass in half-res pixels (32: first pass, 16: later passes), SAMPLES = 8 / 5, BW x BH = workgroup in pixels
 // (multiples of 8: one wave per 8x8 block), TILE = stage the G-buffer records in LDS (else gather them from HBM/L2).
+#ifndef KJ_SPATIAL_BATCH
+#define KJ_SPATIAL_BATCH 0      // taps of restir spatial whose gathers are in flight together: 0 = the measured choice per pass (below), 1 = the shader text's order everywhere
+#endif
 template <int R, int SAMPLES, int BW, int BH, bool TILE, int ORDER>
 __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
     constexpr int TW = BW + 2 * R, TH = BH + 2 * R;
@@ -144,25 +147,15 @@ __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
     const float ang_offset = uint_to_u01_float(hash3(uint32_t(x) >> shift, uint32_t(y) >> shift, ang_seed)) * KJ_PI * 2;
 #endif
 
-#pragma unroll
-    for (int sample_i = 0; sample_i < SAMPLES; ++sample_i) {
-#if KJ_WAVE_SHARED
-        const V2 cs_ang{tap_cos[sample_i], tap_sin[sample_i]};
-#else
-        const V2 cs_ang = cos_sin_turns_fast((float(sample_i) + ang_offset) * KJ_GOLDEN_ANGLE);
-#endif
+    // One tap of the text's loop once its three gathers are known: the neighbour's reservoir (non-empty), its G-buffer record (not sky) and the packed sample the
+    // reservoir points at. Everything the shader does with them, in its order; a `return` is the shader's `continue`.
+    auto tap = [&](const int sample_i, const int rx, const int ry, const uint2 reservoir_raw, const uint2 rg, const uint4 sp_raw) {
         const bool is_center_sample = sample_i == 0;
-        const V2 radius = is_center_sample ? V2{0, 0} : sqrt_fast((float(sample_i) + sample_radius_offset) * (1.0f / float(SAMPLES))) * kernel_radius;
-        const int rx = x + int(cs_ang.x * radius.x), ry = y + int(cs_ang.y * radius.y);
-        const uint2 reservoir_raw = a.reservoir_input_tex.ld(rx, ry);
-        if (0 == reservoir_raw.x) continue;
-        const uint2 rg = gbuf_at(rx, ry);
         const float rpx_depth = asfloat(rg.x);
-        if (rpx_depth == 0.0f) continue;
         Reservoir1spp r = Reservoir1spp::from_raw(reservoir_raw);
         r.M = fminf(r.M, 500.0f);
         const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
-        const PackedSample sp = unpack_sample(a.temporal_reservoir_packed_tex.ld(spx_x, spx_y));
+        const PackedSample sp = unpack_sample(sp_raw);
         float relevance = 1;
         relevance *= normal_influence(dot(unpack_view_normal(rg.y), center_normal_vs), 0.5f) * (1.0f / 1.125f);
         relevance *= 1 - fabsf(from_snorm8(int8_t(rg.y >> 24)) - center_ssao);
@@ -178,7 +171,7 @@ __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
             relevance *= 1 - smoothstep_fast(0.0f, depth_gate, depth_diff);
         }
         float p_q = sp.luminance * fmaxf(0.0f, dot(dir_to_sample_hit, center_normal_ws));
-        if (!(p_q >= 0)) continue;
+        if (!(p_q >= 0)) return;
         r.M *= relevance;
         float jacobian = 1;
         if (!is_center_sample) {
@@ -202,6 +195,7 @@ __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
                 const float depth_step_per_z = (end_cs.z - depth) * rcp_fast(length_fast(V2{end_cs.x - c_cs.x, end_cs.y - c_cs.y}));
                 const float t_step = rcp_fast(float(k_count));
                 float t = 0.5f * t_step;
+#pragma unroll 1
                 for (int k = 0; k < 6; ++k) {
                     const bool active = k < k_count;
                     if (!wave_any(active)) break;
@@ -235,6 +229,69 @@ __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
         reservoir.M += 1;
         const float dart = uint_to_u01_float(hash1_mut(rng));
         if (w * rcp_fast(reservoir.w_sum) >= dart) { reservoir.payload = r.payload; stream_state.p_q_sel = p_q; }
+    };
+    auto tap_pixel = [&](const int sample_i, int& rx, int& ry) {
+#if KJ_WAVE_SHARED
+        const V2 cs_ang{tap_cos[sample_i], tap_sin[sample_i]};
+#else
+        const V2 cs_ang = cos_sin_turns_fast((float(sample_i) + ang_offset) * KJ_GOLDEN_ANGLE);
+#endif
+        const V2 radius = sample_i == 0 ? V2{0, 0} : sqrt_fast((float(sample_i) + sample_radius_offset) * (1.0f / float(SAMPLES))) * kernel_radius;
+        rx = x + int(cs_ang.x * radius.x); ry = y + int(cs_ang.y * radius.y);
+    };
+    // Memory-level parallelism (round 6, profiles/r06_screen_passes.md): a tap is a chain of three dependent gathers, and the loop as the shader text has it issues
+    // them one at a time with a `continue` between them: 24 round trips to memory for the 8 taps of the first pass. With BATCH > 1 the taps of a batch put their loads
+    // in flight TOGETHER -- every tap's reservoir + record (their addresses depend on nothing loaded), then every packed sample -- and the arithmetic follows tap by tap
+    // in the text's order: same operations on the same values. Measured (MI355X, profiles/r06/gathers_in_flight_call11_summary.txt): the first pass (8 taps, no march) in
+    // batches of 4 -- 121 VGPRs, four waves per SIMD instead of five -- 32.9 -> 26.7 us at 1080p, 97.3 -> 86.5 us at 4K; batches of 8 (155 VGPRs) 39.8 us; the second
+    // pass, whose taps spend their time in the occlusion march, loses 7-9 % with any batching and keeps the text's order (BATCH = 1).
+    constexpr int BATCH = KJ_SPATIAL_BATCH == 0 ? (SAMPLES == 8 ? 4 : 1) : (SAMPLES < KJ_SPATIAL_BATCH ? SAMPLES : KJ_SPATIAL_BATCH);
+    if (BATCH == 1) {
+#pragma unroll
+        for (int sample_i = 0; sample_i < SAMPLES; ++sample_i) {
+            int rx, ry;
+            tap_pixel(sample_i, rx, ry);
+            const uint2 reservoir_raw = a.reservoir_input_tex.ld(rx, ry);
+            if (0 == reservoir_raw.x) continue;
+            const uint2 rg = gbuf_at(rx, ry);
+            if (asfloat(rg.x) == 0.0f) continue;
+            tap(sample_i, rx, ry, reservoir_raw, rg, a.temporal_reservoir_packed_tex.ld(int(reservoir_raw.x & 0xffff), int(reservoir_raw.x >> 16)));
+        }
+    } else {
+#pragma unroll
+        for (int base = 0; base < SAMPLES; base += BATCH) {
+            uint32_t tap_xy[BATCH];      // rx + 0x8000 | (ry + 0x8000) << 16
+            uint2 tap_res[BATCH], tap_g[BATCH];
+            uint4 tap_sp[BATCH];
+            bool tap_in[BATCH], tap_sp_in[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                if (base + j >= SAMPLES) break;
+                int rx, ry;
+                tap_pixel(base + j, rx, ry);
+                tap_xy[j] = uint32_t(rx + 0x8000) | (uint32_t(ry + 0x8000) << 16);
+                tap_res[j] = a.reservoir_input_tex.ld_raw(rx, ry, tap_in[j]);
+                if (TILE) tap_g[j] = gbuf_at(rx, ry);
+                else { bool in_; tap_g[j] = a.half_gbuf.ld_raw(rx, ry, in_); }      // (same extent as the reservoir image: one in-bounds flag serves both)
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                if (base + j >= SAMPLES) break;
+                if (!tap_in[j]) { tap_res[j] = make_uint2(0u, 0u); if (!TILE) tap_g[j] = make_uint2(0u, 0u); }
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                if (base + j >= SAMPLES) break;
+                const uint32_t payload = tap_res[j].x;      // an empty reservoir's payload is pixel (0, 0): a valid address; the value is not used
+                tap_sp[j] = a.temporal_reservoir_packed_tex.ld_raw(int(payload & 0xffff), int(payload >> 16), tap_sp_in[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                if (base + j >= SAMPLES) break;
+                if (0 == tap_res[j].x || asfloat(tap_g[j].x) == 0.0f) continue;
+                tap(base + j, int(tap_xy[j] & 0xffffu) - 0x8000, int(tap_xy[j] >> 16) - 0x8000, tap_res[j], tap_g[j], tap_sp_in[j] ? tap_sp[j] : make_uint4(0u, 0u, 0u, 0u));
+            }
+        }
     }
     reservoir.finish_stream(stream_state);
     reservoir.W = fminf(reservoir.W, RESTIR_RESERVOIR_W_CLAMP);
@@ -273,30 +330,43 @@ __global__ void __launch_bounds__(256) k_restir_resolve(ResolveArgs2 a) {
     const int hx0 = (bx0 >> 1) - HALO, hy0 = (by0 >> 1) - HALO;
     const I2 off = halfres_subsample_offset(fc.frame_index);
     const HalfPxToCs px_to_cs = HalfPxToCs::make(W, H, off);
+    // (round 6: every load of the prologue -- this pixel's own depth / G-buffer / ssao and the staged texel's five images -- is issued before the first one is used:
+    // one round trip to memory instead of eight; the out-of-bounds selects of Img::ld follow the loads. Same values, same arithmetic.)
+    const int x = bx0 + (wave & 1) * 8 + (lane & 7), y = by0 + (wave >> 1) * 8 + (lane >> 3);
+    bool c_in_d, c_in_g, c_in_s;
+    const float depth_raw = a.depth_tex.ld_raw(x, y, c_in_d);
+    const uint4 gbuffer_raw = a.gbuffer_tex.ld_raw(x, y, c_in_g);
+    const uint8_t ssao_raw = a.ssao_tex.ld_raw(x, y, c_in_s);
     if (tid < TW * TW) {
         const int ty = tid / TW, tx = tid - ty * TW;
         const int px = hx0 + tx, py = hy0 + ty;
-        const uint2 g = a.half_gbuf.ld(px, py);
+        bool in_h, in_f;      // the half-res images share one extent, the full-res ssao has its own
+        uint2 g = a.half_gbuf.ld_raw(px, py, in_h);
+        uint2 ch = a.candidate_hit_tex.ld_raw(px, py, in_h);
+        uint2 cr = a.candidate_radiance_tex.ld_raw(px, py, in_h);
+        uint2 rs = a.reservoir_input_tex.ld_raw(px, py, in_h);
+        uint8_t ao = a.ssao_tex.ld_raw(px * 2 + off.x, py * 2 + off.y, in_f);
+        if (!in_h) { g = make_uint2(0u, 0u); ch = make_uint2(0u, 0u); cr = make_uint2(0u, 0u); rs = make_uint2(0u, 0u); }
+        if (!in_f) ao = 0;
         const float d = asfloat(g.x);
         const V3 pos = hit_ws_from_cs(fd, px_to_cs(px, py), d);
-        const V3 hit = xyz(ld4(a.candidate_hit_tex, px, py)) + pos;
+        const V3 hit = xyz(unpack_rgba16f(ch)) + pos;
         t_hit[tid] = make_float4(hit.x, hit.y, hit.z, d);
-        t_rad[tid] = a.candidate_radiance_tex.ld(px, py);
-        t_res[tid] = a.reservoir_input_tex.ld(px, py);
-        t_nrm[tid] = (g.y & 0x00ffffffu) | (uint32_t(a.ssao_tex.ld(px * 2 + off.x, py * 2 + off.y)) << 24);
+        t_rad[tid] = cr;
+        t_res[tid] = rs;
+        t_nrm[tid] = (g.y & 0x00ffffffu) | (uint32_t(ao) << 24);
     }
     __syncthreads();
-    const int x = bx0 + (wave & 1) * 8 + (lane & 7), y = by0 + (wave >> 1) * 8 + (lane >> 3);
     if (!(x < W && y < (H < a.row1 ? H : a.row1))) return;
-    const float depth = a.depth_tex.ld(x, y);
+    const float depth = c_in_d ? depth_raw : 0.0f;
     if (0 == depth) { st4(a.irradiance_output_tex, x, y, v4(0.0f)); return; }
     const V4 gts = tex_size4(W, H);
     const V2 c_cs = uv_to_cs(get_uv(float(x), float(y), gts));
     const V3 c_ws = hit_ws_from_cs(fd, c_cs, depth);
     const float c_vs_z = hit_vs_from_cs(fc, c_cs, depth).z;
-    const V3 center_normal_ws = normalize_fast(unpack_normal_11_10_11_no_normalize(a.gbuffer_tex.ld(x, y).y));
+    const V3 center_normal_ws = normalize_fast(unpack_normal_11_10_11_no_normalize(c_in_g ? gbuffer_raw.y : 0u));
     const V3 center_normal_vs = rotate_world_to_view(fc, center_normal_ws);
-    const float center_ssao = from_unorm8(a.ssao_tex.ld(x, y));
+    const float center_ssao = from_unorm8(c_in_s ? ssao_raw : uint8_t(0));
     const uint32_t px_idx_in_quad = (((uint32_t(x) & 1u) | (uint32_t(y) & 1u) * 2u) + hash1(fc.frame_index)) & 3u;
     const float blue_x = blue_noise_for_pixel(a.blue_noise, x, y, fc.frame_index).x * KJ_TAU;
     const float near_end = -c_vs_z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);
@@ -338,23 +408,36 @@ __global__ void __launch_bounds__(256) k_restir_resolve(ResolveArgs2 a) {
         float w_sum = 0;
         V3 weighted = v3(0.0f);
         const float kernel_scale = sharpen_gi_kernel ? 0.5f : 1.0f;
+        // the three gathers at each tap's sample pixel: all twelve in flight before the first is used (round 6)
+        int tap_ti[4];
+        uint4 tap_sp[4]; uint2 tap_rad[4], tap_g[4];
+        bool tap_in[4];      // (the three images share the half-res extent)
 #pragma unroll
         for (int si = 0; si < 4; ++si) {
             const V2 rpo = tap_dir[si] * (tap_radius[si] * kernel_scale);
             const int rx = int(floorf(hxf + rpo.x)), ry = int(floorf(hyf + rpo.y));
-            const int ti = (ry - hy0) * TW + (rx - hx0);
+            tap_ti[si] = (ry - hy0) * TW + (rx - hx0);
+            const uint32_t payload = t_res[tap_ti[si]].x;
+            const int spx_x = int(payload & 0xffff), spx_y = int(payload >> 16);
+            tap_sp[si] = a.temporal_reservoir_packed_tex.ld_raw(spx_x, spx_y, tap_in[si]);
+            tap_rad[si] = a.radiance_tex.ld_raw(spx_x, spx_y, tap_in[si]);
+            tap_g[si] = a.half_gbuf.ld_raw(spx_x, spx_y, tap_in[si]);
+        }
+#pragma unroll
+        for (int si = 0; si < 4; ++si) {
+            const int ti = tap_ti[si];
             const Reservoir1spp r = Reservoir1spp::from_raw(t_res[ti]);
             const int spx_x = int(r.payload & 0xffff), spx_y = int(r.payload >> 16);
-            const PackedSample sp = unpack_sample(a.temporal_reservoir_packed_tex.ld(spx_x, spx_y));
+            const PackedSample sp = unpack_sample(tap_in[si] ? tap_sp[si] : make_uint4(0u, 0u, 0u, 0u));
             const V3 hit_ws = sp.hit_offset_ws + hit_ws_from_cs(fd, px_to_cs(spx_x, spx_y), sp.depth);
             const V3 sample_offset = hit_ws - c_ws;
             const float d2 = dot(sample_offset, sample_offset);
             const float inv_d = rsq_fast(d2), sample_dist = d2 * inv_d;
             const float geometric_term = 2 * fmaxf(0.0f, dot(center_normal_ws, sample_offset) * inv_d);
-            V3 radiance = xyz(ld4(a.radiance_tex, spx_x, spx_y));
+            V3 radiance = xyz(unpack_rgba16f(tap_in[si] ? tap_rad[si] : make_uint2(0u, 0u)));
             radiance *= lerp(1.0f, smoothstep_fast(near_start, near_end, sample_dist), center_ssao);
             const V3 contribution = radiance * geometric_term * r.W;
-            const V3 sample_normal_vs = unpack_view_normal(a.half_gbuf.ld(spx_x, spx_y).y);
+            const V3 sample_normal_vs = unpack_view_normal(tap_in[si] ? tap_g[si].y : 0u);
             const uint32_t tn = t_nrm[ti];
             float w = ggx_ndf_unnorm_fast(0.01f, saturate(dot(center_normal_vs, sample_normal_vs)));
             w *= exp2_fast(-fabsf(inv_depth_scale * (depth * rcp_fast(t_hit[ti].w) - 1.0f)));
@@ -497,21 +580,41 @@ __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __
     // LDS-staged 12x12 tile (8x8 outputs + the 5x5 stencil's halo): each texel's colour-space conversion is done once per
     // tile instead of once per tap (25x per texture): .xyz = crunched luma-chroma of the input, .w = crunched history luma.
     __shared__ float4 tile[12 * 12];
+    // (round 6: the pixel's own four texels and the up to three staged texels' two images are requested together, before the first is used, and the moments' bilinear
+    // footprint as soon as the reprojection is known -- under the tile's staging instead of behind the 5x5 loop: three round trips to memory instead of seven)
+    bool c_in, c_in_inv;      // (x, y) lies in all three full-res images
+    const uint2 center_raw = input_tex.ld_raw(x, y, c_in);
+    const uint2 reproj_raw = reprojection_tex.ld_raw(x, y, c_in);
+    const uint2 history_raw = history_tex.ld_raw(x, y, c_in);
+    const uint32_t rt_inv_raw = rt_history_invalidity_tex.ld_raw(x / 2, y / 2, c_in_inv);
     {
         const int tx0 = int(kj_tb.x) * 8 - 2, ty0 = row0 + int(kj_tb.y) * 8 - 2;
-        for (int i = lane; i < 144; i += 64) {
+        uint2 sn[3], sh[3]; bool s_in[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = lane + 64 * k;
             const int tx = tx0 + i % 12, ty = ty0 + i / 12;
-            const V4 n = crunch_fast(ld4(input_tex, tx, ty));
-            const V4 hn = crunch_fast(ld4(history_tex, tx, ty) * history_mult);
-            tile[i] = make_float4(n.x, n.y, n.z, hn.x);
+            sn[k] = input_tex.ld_raw(tx, ty, s_in[k]);
+            sh[k] = history_tex.ld_raw(tx, ty, s_in[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = lane + 64 * k;
+            if (i < 144) {
+                const V4 n = crunch_fast(unpack_rgba16f(s_in[k] ? sn[k] : make_uint2(0u, 0u)));
+                const V4 hn = crunch_fast(unpack_rgba16f(s_in[k] ? sh[k] : make_uint2(0u, 0u)) * history_mult);
+                tile[i] = make_float4(n.x, n.y, n.z, hn.x);
+            }
         }
     }
+    const uint2 rpr = c_in ? reproj_raw : make_uint2(0u, 0u);
+    const V4 reproj{from_snorm16(int16_t(rpr.x & 0xffff)), from_snorm16(int16_t(rpr.x >> 16)), from_snorm16(int16_t(rpr.y & 0xffff)), from_snorm16(int16_t(rpr.y >> 16))};
+    const V2 uv = get_uv(float(x), float(y), tex_size4(W, H));
+    const V2 moments_history_raw = sample_bilinear_clamp_rg16f(variance_history_tex.p, W, H, uv + V2{reproj.x, reproj.y});      // (clamped addresses: safe for the lanes outside the image too)
     __syncthreads();
     if (!in_image) return;
-    const V2 uv = get_uv(float(x), float(y), tex_size4(W, H));
-    const V4 center = crunch_fast(ld4(input_tex, x, y));
-    const V4 reproj = ld_reproj(reprojection_tex, x, y);
-    const V4 history = crunch_fast(ld4(history_tex, x, y) * history_mult);
+    const V4 center = crunch_fast(unpack_rgba16f(c_in ? center_raw : make_uint2(0u, 0u)));
+    const V4 history = crunch_fast(unpack_rgba16f(c_in ? history_raw : make_uint2(0u, 0u)) * history_mult);
     V3 vsum = v3(0.0f), vsum2 = v3(0.0f);
     float wsum = 0, hist_vsum = 0;
     const int lt = ((lane >> 3) + 2) * 12 + (lane & 7) + 2;
@@ -533,14 +636,13 @@ __global__ void __launch_bounds__(64) k_temporal_filter(const FrameConstants* __
     const V3 var = vmax(v3(0.0f), ex2 - ex * ex);
     const V3 dev{sqrt_fast(var.x), sqrt_fast(var.y), sqrt_fast(var.z)};
     hist_vsum *= inv_wsum;
-    const V2 moments_history = sample_bilinear_clamp_rg16f(variance_history_tex.p, W, H, uv + V2{reproj.x, reproj.y}) *
-                               V2{fc.pre_exposure_delta, fc.pre_exposure_delta * fc.pre_exposure_delta};
+    const V2 moments_history = moments_history_raw * V2{fc.pre_exposure_delta, fc.pre_exposure_delta * fc.pre_exposure_delta};
     const float center_luma = center.x + (hist_vsum - ex.x);
     const V2 mo = lerp(moments_history, V2{center_luma, center_luma * center_luma}, 0.25f);
     st2h(variance_history_output_tex, x, y, V2{fmaxf(0.0f, mo.x), fmaxf(0.0f, mo.y)});
     const float center_temporal_dev = sqrt_fast(fmaxf(0.0f, moments_history.y - moments_history.x * moments_history.x));
     const float temporal_change = fabsf(hist_vsum - ex.x) * rcp_fast(fmaxf(1e-8f, hist_vsum + ex.x));
-    const float rt_invalid = saturate(sqrt_fast(ld2h(rt_history_invalidity_tex, x / 2, y / 2).x) * 4);
+    const float rt_invalid = saturate(sqrt_fast(unpack_2x16f_uint(c_in_inv ? rt_inv_raw : 0u).x) * 4);
     const float current_sample_count = history.w;
     float clamp_box_size = 1 * lerp(0.25f, 2.0f, 1.0f - rt_invalid) * lerp(0.333f, 1.0f, saturate(reproj.w)) * 2;
     clamp_box_size = fmaxf(clamp_box_size, 0.5f);

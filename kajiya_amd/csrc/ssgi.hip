@@ -122,6 +122,17 @@ __global__ void __launch_bounds__(64) k_ssgi(const FrameConstants* __restrict__ 
     float theta_cos_max2 = cos_sin_turns_fast(n_angle + 1.57079632679f).x;
     int pc0x = x, pc0y = y, pc1x = x, pc1y = y;
     const V2 hit_cs{vrc.hit_cs.x, vrc.hit_cs.y};
+    // (round 6: the twelve depths along the slice depend on the geometry only: requested together, then the two marches run on registers in the text's order --
+    // the loop as the text has it is twelve round trips to memory one after the other)
+    float md[12]; bool md_in[12];
+#pragma unroll
+    for (uint32_t i = 0; i < 6; ++i) {
+        const float t0 = float(i) + rand_offset, t1 = float(i) + (1.0f - rand_offset);
+        const V2 suv0 = cs_to_uv(V2{hit_cs.x - cs_slice_dir.x * t0, hit_cs.y - cs_slice_dir.y * t0}), suv1 = cs_to_uv(V2{hit_cs.x + cs_slice_dir.x * t1, hit_cs.y + cs_slice_dir.y * t1});
+        md[2 * i] = half_depth.ld_raw(int(output_tex_size.x * suv0.x), int(output_tex_size.y * suv0.y), md_in[2 * i]);
+        md[2 * i + 1] = half_depth.ld_raw(int(output_tex_size.x * suv1.x), int(output_tex_size.y * suv1.y), md_in[2 * i + 1]);
+    }
+#pragma unroll
     for (uint32_t i = 0; i < 6; ++i) {
         {
             const float t = float(i) + rand_offset;
@@ -130,7 +141,7 @@ __global__ void __launch_bounds__(64) k_ssgi(const FrameConstants* __restrict__ 
             const int spx = int(output_tex_size.x * suv.x), spy = int(output_tex_size.y * suv.y);
             if (spx != pc0x || spy != pc0y) {
                 pc0x = spx; pc0y = spy;
-                sample_cs.z = half_depth.ld(spx, spy);
+                sample_cs.z = md_in[2 * i] ? md[2 * i] : 0.0f;
                 theta_cos_max1 = ssgi_process_sample(fc, sample_cs, center_vs, v_vs, kernel_radius_ws, theta_cos_max1);
             }
         }
@@ -141,7 +152,7 @@ __global__ void __launch_bounds__(64) k_ssgi(const FrameConstants* __restrict__ 
             const int spx = int(output_tex_size.x * suv.x), spy = int(output_tex_size.y * suv.y);
             if (spx != pc1x || spy != pc1y) {
                 pc1x = spx; pc1y = spy;
-                sample_cs.z = half_depth.ld(spx, spy);
+                sample_cs.z = md_in[2 * i + 1] ? md[2 * i + 1] : 0.0f;
                 theta_cos_max2 = ssgi_process_sample(fc, sample_cs, center_vs, v_vs, kernel_radius_ws, theta_cos_max2);
             }
         }
@@ -160,20 +171,32 @@ __global__ void __launch_bounds__(64) k_ssgi_spatial(ImgH1 ssgi_tex, ImgF32 half
     TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     if (!in_image) return;
     float result = 0, w_sum = 0;
-    const float center_depth = half_depth.ld(x, y);
+    // (round 6: the 3 x 3 neighbourhood's {depth, value, normal} -- one in-bounds flag per texel, the three images share the half-res extent -- requested together:
+    // 27 loads in flight instead of up to 19 round trips one after the other)
+    bool t_in[9];
+    float d_raw[9]; uint16_t s_raw[9]; uint32_t n_raw[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int sx = x + (i % 3 - 1), sy = y + (i / 3 - 1);
+        d_raw[i] = half_depth.ld_raw(sx, sy, t_in[i]);
+        s_raw[i] = ssgi_tex.ld_raw(sx, sy, t_in[i]);
+        n_raw[i] = half_view_normal.ld_raw(sx, sy, t_in[i]);
+    }
+    const float center_depth = t_in[4] ? d_raw[4] : 0.0f;
     if (center_depth != 0.0f) {
-        const V3 center_normal = ld_nrm_snorm8(half_view_normal, x, y);
+        const V3 center_normal = xyz(unpack_rgba8_snorm(t_in[4] ? n_raw[4] : 0u));
         w_sum = 1.0f;
-        result = f16_to_f32(ssgi_tex.ld(x, y));
+        result = f16_to_f32(t_in[4] ? s_raw[4] : uint16_t(0));
 #pragma unroll
         for (int yy = -1; yy <= 1; ++yy)
 #pragma unroll
             for (int xx = -1; xx <= 1; ++xx) {
                 if (xx == 0 && yy == 0) continue;
-                const float sdp = half_depth.ld(x + xx, y + yy);
+                const int i = (yy + 1) * 3 + (xx + 1);
+                const float sdp = t_in[i] ? d_raw[i] : 0.0f;
                 if (sdp == 0.0f) continue;
-                const float s = f16_to_f32(ssgi_tex.ld(x + xx, y + yy));
-                const V3 n = ld_nrm_snorm8(half_view_normal, x + xx, y + yy);
+                const float s = f16_to_f32(t_in[i] ? s_raw[i] : uint16_t(0));
+                const V3 n = xyz(unpack_rgba8_snorm(t_in[i] ? n_raw[i] : 0u));
                 const float depth_diff = 1.0f - (center_depth / sdp);
                 const float depth_factor = exp2f(-200.0f * fabsf(depth_diff));
                 float nf = fmaxf(0.0f, dot(n, center_normal));
@@ -193,16 +216,27 @@ __global__ void __launch_bounds__(64) k_ssgi_upsample(ImgH1 ssgi_tex, ImgF32 dep
     TILE_XY_M(output_tex.w, output_tex.h, KJ_TILES_ROWS)
     if (!in_image) return;
     float result = 0, w_sum = 0;
-    const float center_depth = depth.ld(x, y);
+    // (round 6: the pixel's depth and its nine taps' {depth, value} are requested together -- the loop as the text has it waits for a tap's depth before it asks for its
+    // value, 19 round trips to memory one after the other; same values, same arithmetic)
+    bool c_in, d_in[9], s_in[9];
+    const float center_raw = depth.ld_raw(x, y, c_in);
+    float d_raw[9]; uint16_t s_raw[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int sx = x / 2 + (i % 3 - 1), sy = y / 2 + (i / 3 - 1);
+        d_raw[i] = depth.ld_raw(sx * 2, sy * 2, d_in[i]);
+        s_raw[i] = ssgi_tex.ld_raw(sx, sy, s_in[i]);
+    }
+    const float center_depth = c_in ? center_raw : 0.0f;
     if (center_depth != 0.0f) {
 #pragma unroll
         for (int yy = -1; yy <= 1; ++yy)
 #pragma unroll
             for (int xx = -1; xx <= 1; ++xx) {
-                const int sx = x / 2 + xx, sy = y / 2 + yy;
-                const float sdp = depth.ld(sx * 2, sy * 2);
+                const int i = (yy + 1) * 3 + (xx + 1);
+                const float sdp = d_in[i] ? d_raw[i] : 0.0f;
                 if (sdp == 0.0f) continue;
-                const float s = f16_to_f32(ssgi_tex.ld(sx, sy));
+                const float s = f16_to_f32(s_in[i] ? s_raw[i] : uint16_t(0));
                 const float depth_diff = 1.0f - (center_depth / sdp);
                 float w = 1;
                 w *= exp2f(-200.0f * fabsf(depth_diff));
@@ -212,7 +246,7 @@ __global__ void __launch_bounds__(64) k_ssgi_upsample(ImgH1 ssgi_tex, ImgF32 dep
             }
     }
     if (w_sum > 1e-6f) output_tex.st(x, y, f32_to_f16(result / w_sum));
-    else output_tex.st(x, y, ssgi_tex.ld(x / 2, y / 2));
+    else output_tex.st(x, y, s_in[4] ? s_raw[4] : uint16_t(0));      // ssgi_tex at (x / 2, y / 2): the centre tap
 }
 
 // "ssao temporal" (temporal_filter.hlsl), full res; history R16F, final R8_UNORM
