@@ -54,9 +54,33 @@ KJ_D V3 mad_nc(V3 o, V3 d, float t) {
     return V3{o.x + x, o.y + y, o.z + z};
 }
 // Returns true when the triangle is a closer hit (and updates h).
+#ifndef KJ_TRI_BRANCHFREE
+#define KJ_TRI_BRANCHFREE 0      // 1 (round 6 experiment): every lane evaluates the whole test and the hit record is updated by selects -- no nested exec masks, no PHI copies
+#endif
 KJ_D bool intersect_tri(V3 o, V3 d, float tmin, float tmax, const float4 a, const float4 b, const float4 c, uint32_t slot, bool cull_back, RayHit& h) {
 #pragma clang fp contract(off)
     const V3 v0{a.x, a.y, a.z}, v1{b.x, b.y, b.z}, v2{c.x, c.y, c.z};
+#if KJ_TRI_BRANCHFREE && defined(__HIP_DEVICE_COMPILE__)
+    {
+        const V3 e1 = sub_nc(v1, v0);
+        const V3 e2 = sub_nc(v2, v0);
+        const V3 pvec = cross_nc(d, e2);
+        const float det = dot_nc(e1, pvec);
+        const bool ok_det = cull_back ? (det > 0.0f) : (det != 0.0f);
+        const float inv_det = 1.0f / det;
+        const V3 tvec = sub_nc(o, v0);
+        const float u = dot_nc(tvec, pvec) * inv_det;
+        const V3 qvec = cross_nc(tvec, e1);
+        const float v = dot_nc(d, qvec) * inv_det;
+        const float upv = u + v;
+        const float t = dot_nc(e2, qvec) * inv_det;
+        const uint32_t wid = __float_as_uint(a.w);
+        const bool ok = ok_det & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (upv <= 1.0f) & (t > tmin) & (t < tmax);
+        const bool closer = ok & ((t < h.t) | ((t == h.t) & (wid < h.world_id)));
+        h.t = closer ? t : h.t; h.u = closer ? u : h.u; h.v = closer ? v : h.v; h.slot = closer ? slot : h.slot; h.world_id = closer ? wid : h.world_id;
+        return closer;
+    }
+#endif
     const V3 e1 = sub_nc(v1, v0);
     const V3 e2 = sub_nc(v2, v0);
     const V3 pvec = cross_nc(d, e2);
