@@ -114,12 +114,23 @@ __global__ void __launch_bounds__(64) k_taa_reproject(const FrameConstants* __re
     const V4 its = tex_size4(IW, IH), ots = tex_size4(OW, OH);
     const V2 scale{NRDIV(4 | 256, its.x, ots.x), NRDIV(4 | 256, its.y, ots.y)};
     const int rx = int(uint32_t((float(x) + 0.5f) * scale.x)), ry = int(uint32_t((float(y) + 0.5f) * scale.y));
+    // (round 6: the four corner texels and the pixel's own reprojection -- the one the history is fetched with unless the velocity gets dilated -- are requested
+    // together; the text's order is two round trips for the corners, the dilation's, then one more for the velocity before the history's twelve texels can be asked for)
     V2 vmn, vmx;
+    uint2 rc_raw;
     {
-        V4 r = ld_reproj(reprojection_tex, rx - 1, ry - 1); vmn = vmx = V2{r.x, r.y};
-        r = ld_reproj(reprojection_tex, rx + 1, ry - 1); vmn = vmin(vmn, V2{r.x, r.y}); vmx = V2{fmaxf(vmx.x, r.x), fmaxf(vmx.y, r.y)};
-        r = ld_reproj(reprojection_tex, rx - 1, ry + 1); vmn = vmin(vmn, V2{r.x, r.y}); vmx = V2{fmaxf(vmx.x, r.x), fmaxf(vmx.y, r.y)};
-        r = ld_reproj(reprojection_tex, rx + 1, ry + 1); vmn = vmin(vmn, V2{r.x, r.y}); vmx = V2{fmaxf(vmx.x, r.x), fmaxf(vmx.y, r.y)};
+        bool in_[5]; uint2 q[5];
+        q[0] = reprojection_tex.ld_raw(rx - 1, ry - 1, in_[0]); q[1] = reprojection_tex.ld_raw(rx + 1, ry - 1, in_[1]);
+        q[2] = reprojection_tex.ld_raw(rx - 1, ry + 1, in_[2]); q[3] = reprojection_tex.ld_raw(rx + 1, ry + 1, in_[3]);
+        q[4] = reprojection_tex.ld_raw(rx, ry, in_[4]);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) if (!in_[i]) q[i] = make_uint2(0u, 0u);
+        auto xy = [](uint2 p_) { return V2{from_snorm16(int16_t(p_.x & 0xffff)), from_snorm16(int16_t(p_.x >> 16))}; };
+        V2 r = xy(q[0]); vmn = vmx = r;
+        r = xy(q[1]); vmn = vmin(vmn, r); vmx = V2{fmaxf(vmx.x, r.x), fmaxf(vmx.y, r.y)};
+        r = xy(q[2]); vmn = vmin(vmn, r); vmx = V2{fmaxf(vmx.x, r.x), fmaxf(vmx.y, r.y)};
+        r = xy(q[3]); vmn = vmin(vmn, r); vmx = V2{fmaxf(vmx.x, r.x), fmaxf(vmx.y, r.y)};
+        rc_raw = q[4];
     }
     const V2 d = vmx - vmn, s = vmx + vmn;
     int should_dilate = (d.x > 0.1f * fmaxf(its.z, fabsf(s.x)) || d.y > 0.1f * fmaxf(its.w, fabsf(s.y))) ? 1 : 0;
@@ -134,8 +145,8 @@ __global__ void __launch_bounds__(64) k_taa_reproject(const FrameConstants* __re
                 if (dd > reproj_depth) { reproj_depth = dd; cx = rx + ox; cy = ry + oy; }
             }
     }
-    const V4 rr = ld_reproj(reprojection_tex, cx, cy);
-    const V2 reproj_xy{rr.x, rr.y};
+    if (cx != rx || cy != ry) rc_raw = reprojection_tex.ld(cx, cy);
+    const V2 reproj_xy{from_snorm16(int16_t(rc_raw.x & 0xffff)), from_snorm16(int16_t(rc_raw.x >> 16))};
     if (!in_image) return;  // after the wave vote
     st2h(closest_velocity_output, x, y, reproj_xy);
     const V2 uv = get_uv(float(x), float(y), ots);
