@@ -139,18 +139,26 @@ __global__ void __launch_bounds__(64) k_rtr_resolve(RtrResolveArgs a) {
             sample_px_y = int(floorf(sample_uv.y * ots.y / 2.0f));
         }
         float rejection_bias = 1.0f;
-        const V3 sample_normal_vs = ld_nrm_snorm8(a.half_view_normal_tex, sample_px_x, sample_px_y);
+        // (round 6: a tap's gathers leave in two groups -- [normal, reservoir] at the tap's pixel, then [ray origin, ray, irradiance] at the pixel the reservoir points
+        // at -- instead of one by one with the rejection test between them; the tap's position depends on the taps before it, so taps cannot share a round trip)
+        bool in_t, in_s;      // (the half-res images share one extent)
+        const uint32_t normal_raw = a.half_view_normal_tex.ld_raw(sample_px_x, sample_px_y, in_t);
+        const uint2 reservoir_raw_ = a.restir_reservoir_tex.ld_raw(sample_px_x, sample_px_y, in_t);
+        const V3 sample_normal_vs = xyz(unpack_rgba8_snorm(in_t ? normal_raw : 0u));
         float pdf0_mult = 1.0f, pdf1_mult = 1.0f;
-        const uint2 reservoir_raw = a.restir_reservoir_tex.ld(sample_px_x, sample_px_y);
+        const uint2 reservoir_raw = in_t ? reservoir_raw_ : make_uint2(0u, 0u);
         const Reservoir1spp r = Reservoir1spp::from_raw(reservoir_raw);
         const int spx = int(r.payload & 0xffffu), spy = int(r.payload >> 16);
-        const RtrRestirRayOrigin sample_origin = ray_origin_from_raw(a.restir_ray_orig_tex.ld(spx, spy));
+        const auto origin_raw = a.restir_ray_orig_tex.ld_raw(spx, spy, in_s);
+        const uint2 ray_raw = a.restir_ray_tex.ld_raw(spx, spy, in_s);
+        const uint2 irr_raw = a.restir_irradiance_tex.ld_raw(spx, spy, in_s);
+        const RtrRestirRayOrigin sample_origin = ray_origin_from_raw(in_s ? origin_raw : decltype(origin_raw)());
         const V3 sample_origin_ws = sample_origin.ray_origin_eye_offset_ws + eye;
         if (reservoir_raw.x == 0u || sample_origin.roughness > gbuffer.roughness * 2.0f) continue;
-        const V4 restir_ray = ld4(a.restir_ray_tex, spx, spy);
+        const V4 restir_ray = unpack_rgba16f(in_s ? ray_raw : make_uint2(0u, 0u));
         const V3 sample_hit_ws = xyz(restir_ray) + sample_origin_ws;
         const V3 sample_origin_vs = position_world_to_view(fc, sample_origin_ws);
-        const V4 restir_irr = ld4(a.restir_irradiance_tex, spx, spy);
+        const V4 restir_irr = unpack_rgba16f(in_s ? irr_raw : make_uint2(0u, 0u));
         const V3 sample_radiance = xyz(restir_irr);
         const float sample_ray_pdf = restir_ray.w;
         const float inv_neighbor_sampling_pdf = r.W;      // 1 / neighbor_sampling_pdf
@@ -255,11 +263,24 @@ __global__ void __launch_bounds__(64) k_rtr_temporal_filter(const FrameConstants
     if (!in_image) return;
     const FrameConstants& fc = *fcp;
     const V4 ots = tex_size4(output_tex.w, output_tex.h);
-    auto ld_in = [&](int sx, int sy) { return input_tex.inb(sx, sy) ? v4(unpack_r11g11b10f(input_tex.ld(sx, sy)), 1.0f) : v4(0.0f); };
-    const V4 center = crunch_fast(ld_in(x, y));
-    const float refl_ray_length = clampf(ld2h(ray_len_tex, x, y).x, 0.0f, 1e3f);
+    // (round 6: everything whose address is known up front -- the pixel's own six texels and the 3x3 neighbourhood's {input, depth} -- is requested before the first
+    // value is used; the moments' loop as the text has it is 18 round trips to memory one after the other)
+    bool nb_in[9]; uint32_t nb_c[9]; float nb_d[9];      // (input and depth share the extent)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        nb_c[i] = input_tex.ld_raw(x + i % 3 - 1, y + i / 3 - 1, nb_in[i]);
+        nb_d[i] = depth_tex.ld_raw(x + i % 3 - 1, y + i / 3 - 1, nb_in[i]);
+    }
+    bool c_in, c_in_h;
+    const uint32_t ray_len_raw = ray_len_tex.ld_raw(x, y, c_in);
+    const uint2 reproj_raw = reprojection_tex.ld_raw(x, y, c_in);
+    const uint4 gbuffer_raw = gbuffer_tex.ld_raw(x, y, c_in);
+    const uint8_t restir_inv_raw = refl_restir_invalidity_tex.ld_raw(x / 2, y / 2, c_in_h);
+    auto ld_in = [&](int i) { return nb_in[i] ? v4(unpack_r11g11b10f(nb_c[i]), 1.0f) : v4(0.0f); };
+    const V4 center = crunch_fast(ld_in(4));
+    const float refl_ray_length = clampf(unpack_2x16f_uint(c_in ? ray_len_raw : 0u).x, 0.0f, 1e3f);
     const V2 uv = get_uv(float(x), float(y), ots);
-    const float center_depth = depth_tex.ld(x, y);
+    const float center_depth = nb_in[4] ? nb_d[4] : 0.0f;
     const ViewRay vr = view_ray_from_uv_and_depth(fc, uv, center_depth);
     V3 ray_dir_vs;
     {
@@ -274,7 +295,8 @@ __global__ void __launch_bounds__(64) k_rtr_temporal_filter(const FrameConstants
     const V4 prev_reflector_cs = mul44(fc.view_constants.clip_to_prev_clip, v4(vr.hit_cs, 1.0f));
     const float inv_prw = rcp_fast(prev_reflector_cs.w);
     const V2 reflector_prev_uv = cs_to_uv(V2{prev_reflector_cs.x * inv_prw, prev_reflector_cs.y * inv_prw});
-    const V4 reproj = ld_reproj(reprojection_tex, x, y);
+    const uint2 rpr = c_in ? reproj_raw : make_uint2(0u, 0u);
+    const V4 reproj{from_snorm16(int16_t(rpr.x & 0xffff)), from_snorm16(int16_t(rpr.x >> 16)), from_snorm16(int16_t(rpr.y & 0xffff)), from_snorm16(int16_t(rpr.y >> 16))};
     const V2 rmv = reflector_prev_uv - uv;
     const float reflector_move_rate = fminf(1.0f, sqrt_fast(reproj.x * reproj.x + reproj.y * reproj.y) * rsq_fast(dot(rmv, rmv)));
     hit_prev_uv = lerp(uv, hit_prev_uv, reflector_move_rate);
@@ -308,10 +330,13 @@ __global__ void __launch_bounds__(64) k_rtr_temporal_filter(const FrameConstants
     const float history1_valid = quad_reproj_valid_packed == 15u ? 1.0f : 0.0f;
     V4 vsum = v4(0.0f), vsum2 = v4(0.0f);
     float wsum = 0.0f;
+#pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
-            const float sample_depth = depth_tex.ld(x + dx, y + dy);
-            const V4 neigh = linear_rgb_to_crunched_luma_chroma(ld_in(x + dx, y + dy));
+            const int i = (dy + 1) * 3 + (dx + 1);
+            const float sample_depth = nb_in[i] ? nb_d[i] : 0.0f;
+            const V4 neigh = linear_rgb_to_crunched_luma_chroma(ld_in(i));
             const float w = exp2_fast(-200.0f * fabsf(center_depth * rcp_fast(sample_depth) - 1.0f));
             vsum = vsum + neigh * w;
             vsum2 = vsum2 + neigh * neigh * w;
@@ -320,8 +345,8 @@ __global__ void __launch_bounds__(64) k_rtr_temporal_filter(const FrameConstants
     const V4 ex = vsum / wsum, ex2 = vsum2 / wsum;      // the moments stay IEEE: their difference below is a variance (cancellation amplifies an ulp)
     const V4 dvar = vmax(v4(0.0f), ex2 - ex * ex);
     const V4 dev{sqrt_fast(dvar.x), sqrt_fast(dvar.y), sqrt_fast(dvar.z), sqrt_fast(dvar.w)};
-    const GbufferData gbuffer = gbuffer_unpack(gbuffer_tex.ld(x, y));
-    const float restir_invalidity = from_unorm8(refl_restir_invalidity_tex.ld(x / 2, y / 2));
+    const GbufferData gbuffer = gbuffer_unpack(c_in ? gbuffer_raw : make_uint4(0u, 0u, 0u, 0u));
+    const float restir_invalidity = from_unorm8(c_in_h ? restir_inv_raw : uint8_t(0));
     const float n_deviations = lerp(reproj.z > 0.0f ? 2.0f : 1.25f, 0.625f, restir_invalidity);
     float wo_similarity;
     {

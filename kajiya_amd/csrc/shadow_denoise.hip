@@ -74,12 +74,19 @@ struct ShadowTemporalArgs {
     int W, H, TW, TH;
     int tile_row0;
 };
-KJ_D float shadow_horizontal_neighborhood(const ShadowTemporalArgs& a, int dx, int dy) {
+// (round 6: the three mask words of a row are fetched by the caller -- nine loads in flight for the three rows of a block instead of nine round trips; `lcr` holds what
+// bitpacked_tex.ld returns at (tix - 1, tiy), (tix, tiy), (tix + 1, tiy): zero outside the image)
+KJ_D void shadow_neighborhood_masks(const ShadowTemporalArgs& a, int dx, int dy, uint32_t lcr[3], bool in_[3]) {
+    const int tix = dx / 8, tiy = (dy < 0 ? 0 : dy) / 4;      // (rows above the image are rejected by the consumer)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lcr[k] = a.bitpacked_tex.ld_raw(tix - 1 + k, tiy, in_[k]);
+}
+KJ_D float shadow_horizontal_neighborhood(const ShadowTemporalArgs& a, int dx, int dy, const uint32_t lcr[3], const bool in_[3]) {
     if (dy < 0 || dy >= a.H) return 0.0f;
-    const int tix = dx / 8, tiy = dy / 4;
-    const uint32_t left_tile = tix == 0 ? 0u : a.bitpacked_tex.ld(tix - 1, tiy);
-    const uint32_t center_tile = a.bitpacked_tex.ld(tix, tiy);
-    const uint32_t right_tile = tix == a.TW - 1 ? 0u : a.bitpacked_tex.ld(tix + 1, tiy);
+    const int tix = dx / 8;
+    const uint32_t left_tile = (tix == 0 || !in_[0]) ? 0u : lcr[0];
+    const uint32_t center_tile = in_[1] ? lcr[1] : 0u;
+    const uint32_t right_tile = (tix == a.TW - 1 || !in_[2]) ? 0u : lcr[2];
     const uint32_t row = uint32_t(dy % 4) * 8u;
     uint32_t nb = ((left_tile >> row) & 0xFFu) | (((center_tile >> row) & 0xFFu) << 8) | (((right_tile >> row) & 0xFFu) << 16);
     nb >>= uint32_t(dx % 8);
@@ -114,9 +121,14 @@ __global__ void __launch_bounds__(64) k_shadow_temporal(ShadowTemporalArgs a) {
     if (lane == 0) a.meta_output_tex.st(gx, gy, 0u);
     __shared__ float hn[8][24];
     const int lx = lane & 7, ly = lane >> 3;
-    hn[lx][ly] = shadow_horizontal_neighborhood(a, x, y - 8);
-    hn[lx][ly + 8] = shadow_horizontal_neighborhood(a, x, y);
-    hn[lx][ly + 16] = shadow_horizontal_neighborhood(a, x, y + 8);
+    uint32_t m0[3], m1[3], m2[3]; bool i0[3], i1[3], i2[3];
+    shadow_neighborhood_masks(a, x, y - 8, m0, i0); shadow_neighborhood_masks(a, x, y, m1, i1); shadow_neighborhood_masks(a, x, y + 8, m2, i2);
+    bool c_in;      // the pixel's own reprojection and mask texels: requested with the masks, used behind the barrier
+    const uint2 reproj_raw = a.reprojection_tex.ld_raw(x, y, c_in);
+    const uint8_t mask_raw = a.shadow_mask_tex.ld_raw(x, y, c_in);
+    hn[lx][ly] = shadow_horizontal_neighborhood(a, x, y - 8, m0, i0);
+    hn[lx][ly + 8] = shadow_horizontal_neighborhood(a, x, y, m1, i1);
+    hn[lx][ly + 16] = shadow_horizontal_neighborhood(a, x, y + 8, m2, i2);
     __syncthreads();
     float local_neighborhood = 0;
     local_neighborhood += hn[lx][ly + 8] * a.kw.w[0];
@@ -127,10 +139,11 @@ __global__ void __launch_bounds__(64) k_shadow_temporal(ShadowTemporalArgs a) {
         local_neighborhood += hn[lx][8 + ly - i] * a.kw.w[i];
         local_neighborhood += hn[lx][8 + ly + i] * a.kw.w[i];
     }
-    const V4 reproj = ld_reproj(a.reprojection_tex, x, y);
+    const uint2 rpr = c_in ? reproj_raw : make_uint2(0u, 0u);
+    const V4 reproj{from_snorm16(int16_t(rpr.x & 0xffff)), from_snorm16(int16_t(rpr.x >> 16)), from_snorm16(int16_t(rpr.y & 0xffff)), from_snorm16(int16_t(rpr.y >> 16))};
     const V2 uv{(float(x) + 0.5f) * (1.0f / float(a.W)), (float(y) + 0.5f) * (1.0f / float(a.H))};     // ffx ...tileclassification.hlsl:351-352: times texel_size (the host's f32 reciprocals)
     const V2 history_uv = uv + V2{reproj.x, reproj.y};
-    const float shadow_current = from_unorm8(a.shadow_mask_tex.ld(x, y));
+    const float shadow_current = from_unorm8(c_in ? mask_raw : uint8_t(0));
     const uint32_t qv = uint32_t(reproj.z * 15.0f + 0.5f);
     const bool is_disoccluded = ((qv & 1u) + ((qv >> 1) & 1u) + ((qv >> 2) & 1u) + ((qv >> 3) & 1u)) < 4u;
     V4 previous_moments = v4(0.0f);
@@ -177,20 +190,31 @@ __global__ void __launch_bounds__(64) k_shadow_spatial(ImgU32 input_tex /*RG16F*
     }
     __shared__ uint32_t s_in[16][16], s_nxy[16][16], s_nzw[16][16];
     __shared__ float s_depth[16][16];
-    for (int i = lane; i < 256; i += 64) {
-        const int tx = i & 15, ty = i >> 4;
+    // (round 6: a lane's four staged texels x three images and its own depth are requested together: the rolled loop was four round trips of three loads each)
+    bool d_in;
+    const float depth_raw = depth_tex.ld_raw(x, y, d_in);
+    uint32_t st_n[4], st_i[4]; float st_d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k, tx = i & 15, ty = i >> 4;
         // ffx_denoiser_shadows_filter.hlsl:76 clamps an int2 against uint2 dimensions: the comparison is unsigned, a negative coordinate lands on the FAR edge
         const int px = int(min(uint32_t(int(kj_tb.x) * 8 - 4 + tx), uint32_t(W - 1))), py = int(min(uint32_t(int(kj_tb.y) * 8 - 4 + ty), uint32_t(H - 1)));
-        const V3 n = unpack_a2r10g10b10(geometric_normal_tex.ld(px, py)) * 2.0f - 1.0f;
-        s_in[ty][tx] = input_tex.ld(px, py);                       // already two packed halves
-        s_depth[ty][tx] = depth_tex.ld(px, py);
+        const size_t at = size_t(py) * W + px;      // clamped: in bounds (the three images share the extent)
+        st_n[k] = geometric_normal_tex.p[at]; st_i[k] = input_tex.p[at]; st_d[k] = depth_tex.p[at];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k, tx = i & 15, ty = i >> 4;
+        const V3 n = unpack_a2r10g10b10(st_n[k]) * 2.0f - 1.0f;
+        s_in[ty][tx] = st_i[k];                       // already two packed halves
+        s_depth[ty][tx] = st_d[k];
         s_nxy[ty][tx] = pack_2x16f_uint(n.x, n.y);
         s_nzw[ty][tx] = pack_2x16f_uint(n.z, 0.0f);
     }
     __syncthreads();
     float weight_sum = 1.0f;
     V2 shadow_sum{0, 0};
-    const float depth = depth_tex.ld(x, y);
+    const float depth = d_in ? depth_raw : 0.0f;
     if (depth != 0.0f) {
         const int cx = (lane & 7) + 4, cy = (lane >> 3) + 4;
         const V2 shadow_center = unpack_2x16f_uint(s_in[cy][cx]);
