@@ -384,6 +384,11 @@ def main():
             pass_ms = [a + b for a, b in zip(pass_ms, t)]
             trace_ms_list.append(t[3])
         pass_ms = [p / max(1, args.profile_frames) for p in pass_ms]
+        # `rtdgi trace` = k_rtdgi_trace_fused's launches: on a validation frame (one in three) the two ray passes are ONE launch since round 6
+        # (k_rtdgi_validate_and_trace, timed under `rtdgi validate`; `rtdgi trace` reads 0 for such a frame): the mean is over the frames that have the launch
+        trace_launches = [t_ for t_ in trace_ms_list if t_ > 0.0]
+        if trace_launches and len(trace_launches) < len(trace_ms_list):
+            pass_ms[3] = sum(trace_launches) / len(trace_launches)
         gp.set_profiling(False, False)
         # ---- segment timers (torch events on the launch stream): ircache / rtdgi / taa
         seg = {"ssgi": 0.0, "ircache": 0.0, "rtdgi": 0.0, "taa": 0.0}
@@ -421,7 +426,7 @@ def main():
         # The frame is issued in two parts so that the TRACE kernel's own rays can be told from the validate kernel's (the per-frame ray
         # counters cover both): everything up to the validate pass, read the counters, the rest, read them again.
         gp.set_profiling(False, True)
-        trav, trace_only = None, None
+        trav, trace_only, n_trace_only = None, None, 0
         Pm = lib.KJ_RTDGI_PASS
         head_mask = Pm["EXTRACT_HALF"] | Pm["VALIDATE"]
         for i in range(base + args.profile_frames, base + args.profile_frames + 3):
@@ -441,7 +446,9 @@ def main():
                 torch.cuda.synchronize()
                 c = gp.traversal_counts()
                 t_only = {k: c[k] - a[k] for k in c}
-                trace_only = t_only if trace_only is None else {k: trace_only[k] + t_only[k] for k in c}
+                if int(fcs[i].frame_index) % 3 != 0 or not trace_launches or len(trace_launches) == len(trace_ms_list):      # (the trace kernel's launches the timer above averages over)
+                    trace_only = t_only if trace_only is None else {k: trace_only[k] + t_only[k] for k in c}
+                    n_trace_only += 1
             else:
                 step(i)
                 torch.cuda.synchronize()
@@ -466,8 +473,9 @@ def main():
         strip_frac = 1.0 / max(1, nsplit)
         if trace_only is not None:      # the trace kernel's own rays and its own nodes / triangles, counted (3 instrumented frames)
             ray_bytes = (trace_only["closest_nodes"] + trace_only["any_nodes"]) * 64 + (trace_only["closest_tris"] + trace_only["any_tris"]) * 48 + trace_only["closest_rays"] * 232
-            trace_bytes = hw * hh * 38 * strip_frac + ray_bytes / 3.0
-            trace_rays_note = {"trace_kernel_closest_rays_per_launch": round(trace_only["closest_rays"] / 3.0, 1), "trace_kernel_any_rays_per_launch": round(trace_only["any_rays"] / 3.0, 1)}
+            trace_bytes = hw * hh * 38 * strip_frac + ray_bytes / float(max(1, n_trace_only))
+            trace_rays_note = {"trace_kernel_closest_rays_per_launch": round(trace_only["closest_rays"] / float(max(1, n_trace_only)), 1), "trace_kernel_any_rays_per_launch": round(trace_only["any_rays"] / float(max(1, n_trace_only)), 1),
+                               "trace_kernel_launches_counted": n_trace_only}
         else:                           # split runs: the validate kernel traces about a third as many rays per frame as the trace kernel
             trace_share = 1.0 / (1.0 + 1.0 / 3.0)
             bytes_per_closest = nodes_per_closest * 64 + tris_per_closest * 48 + 232

@@ -39,12 +39,12 @@ typedef Img<float4> ImgF4;
     const int x = int(kj_tb.x) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * 8 + (lane >> 3); \
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
-// four lanes per pixel (the QUAD form of the ray passes): a wave covers 8 x 2 pixels, lane = 4 * pixel slot + k; `lead` = the lane that stores
-#define QUAD_TILE_XY(W_, H_, QUAD_)                                                                                        \
+// (the QUAD form of the ray passes -- experiments builds: four lanes per pixel, a wave covers 8 x 2 pixels, lane = 4 * pixel slot + k; `lead` = the lane that stores)
+// the two fused ray kernels' pixel of a lane, given the tile (the one-launch form of a validation frame's two passes hands each workgroup its tile)
+#define RAY_TILE_XY(W_, H_, QUAD_, TB_)                                                                                    \
     const int lane = (QUAD_) ? int(threadIdx.x >> 2) : int(threadIdx.x);                                                   \
     const bool lead = !(QUAD_) || (threadIdx.x & 3u) == 0u;                                                                \
-    const uint2 kj_tb = kj::tile_order<KJ_TILES_PLAIN>();                                                                  \
-    const int x = int(kj_tb.x) * 8 + (lane & 7), y = row0 + int(kj_tb.y) * ((QUAD_) ? 2 : 8) + (lane >> 3);                \
+    const int x = int((TB_).x) * 8 + (lane & 7), y = row0 + int((TB_).y) * ((QUAD_) ? 2 : 8) + (lane >> 3);                \
     const bool in_image = x < (W_) && y < ((H_) < row1 ? (H_) : row1);
 
 // ------------------------------------------------------------------ extract_half_res_{gbuffer_view_normal_rgba8,depth,ssao}.hlsl (fused)
@@ -309,10 +309,9 @@ template <bool STATS, bool QUAD = false>
 #ifndef KJ_FUSED_WAVES
 #define KJ_FUSED_WAVES 5
 #endif
-__global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_validate_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
-                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
-    extern __shared__ uint32_t lds_stack[];
-    QUAD_TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h, QUAD)
+KJ_D void rtdgi_validate_tile(const TraceCtx& c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
+                              ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1, uint2 kj_tb, uint32_t* lds_stack) {
+    RAY_TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h, QUAD, kj_tb)
     if (!in_image) return;
     const FrameConstants& fc = *c.fc;
     const I2 off = halfres_subsample_offset(fc.frame_index);
@@ -342,13 +341,21 @@ __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_validate_fused(Tra
     }
     if (lead) invalidity_out_tex.st(x, y, to_unorm8(invalidity));
 }
+template <bool STATS, bool QUAD = false>
+__global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_validate_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reservoir_tex, ImgH4 reservoir_ray_history_tex,
+                                                        ImgH4 irradiance_history_tex, ImgF4 ray_orig_history_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+    extern __shared__ uint32_t lds_stack[];
+    rtdgi_validate_tile<STATS, QUAD>(c, half_view_normal_tex, reservoir_tex, reservoir_ray_history_tex, irradiance_history_tex, ray_orig_history_tex, invalidity_out_tex, row0, row1,
+                                     kj::tile_order<KJ_TILES_PLAIN>(), lds_stack);
+}
 
 // ------------------------------------------------------------------ trace_diffuse.rgen.hlsl:49-120 + candidate_ray_dir.hlsl:1-24
-template <bool STATS, bool QUAD = false>
-__global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
-                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
-    extern __shared__ uint32_t lds_stack[];
-    QUAD_TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h, QUAD)
+// COPY_VALIDITY false: the pass' last statement -- rt_history_validity_input_tex[px] = the validate pass' output at the reprojected pixel -- is left to
+// k_rtdgi_validity_reproject (the one-launch form of the two ray passes on a validation frame, below: the validate pass' tiles are still in flight)
+template <bool STATS, bool QUAD = false, bool COPY_VALIDITY = true>
+KJ_D void rtdgi_trace_tile(const TraceCtx& c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
+                           ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1, uint2 kj_tb, uint32_t* lds_stack) {
+    RAY_TILE_XY(invalidity_out_tex.w, invalidity_out_tex.h, QUAD, kj_tb)
     if (!in_image) return;
     const FrameConstants& fc = *c.fc;
     const I2 off = halfres_subsample_offset(fc.frame_index);
@@ -384,9 +391,56 @@ __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_fused(TraceC
             candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, result.hit_normal_ws), 0)));
         }
     }
+    if (COPY_VALIDITY) {
+        const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
+        const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
+        if (lead) invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
+    }
+}
+template <bool STATS, bool QUAD = false>
+__global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_trace_fused(TraceCtx c, ImgU32 half_view_normal_tex, ImgU2 reprojection_tex, ImgH4 candidate_irradiance_out_tex,
+                                                     ImgU32 candidate_normal_out_tex, ImgH4 candidate_hit_out_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+    extern __shared__ uint32_t lds_stack[];
+    rtdgi_trace_tile<STATS, QUAD, true>(c, half_view_normal_tex, reprojection_tex, candidate_irradiance_out_tex, candidate_normal_out_tex, candidate_hit_out_tex, invalidity_in_tex, invalidity_out_tex,
+                                        row0, row1, kj::tile_order<KJ_TILES_PLAIN>(), lds_stack);
+}
+
+// The two ray passes of a VALIDATION frame as ONE launch (round 6). On such a frame (one in three) `rtdgi validate` re-traces every reservoir's path with full-length rays and
+// `rtdgi trace` walks short near-field rays; at 1080p each launch lasts exactly as long as its slowest wave (289 us and 181 us against 140 / 74 us of wave time per slot:
+// profiles/r06_ray_tile_order.md) and runs its second half on a nearly empty chip. The passes do not depend on one another except for the trace pass' last statement, the copy of the
+// validate pass' output at the reprojected pixel, which moves into a small launch behind both (k_rtdgi_validity_reproject). Here the validate tiles are dispatched first (the long
+// chains), the trace tiles fill the slots they leave: rows [0, tiles_y) of the grid are validate tiles, [tiles_y, 2 tiles_y) trace tiles. Same functions on the same inputs, same
+// outputs; with the racy cache the two passes' lookups race with one another as each pass' lookups already do among themselves.
+struct ValidateTraceArgs {
+    ImgU32 half_view_normal_tex;
+    ImgU2 reservoir_tex; ImgH4 reservoir_ray_history_tex, irradiance_history_tex; ImgF4 ray_orig_history_tex; ImgR8 validity_pre_tex;                       // validate
+    ImgU2 reprojection_tex; ImgH4 candidate_irradiance_out_tex; ImgU32 candidate_normal_out_tex; ImgH4 candidate_hit_out_tex; ImgR8 validity_in_tex;    // trace
+    int row0, row1;
+    uint32_t tiles_y, trace_request_slot_base, trace_request_key_base;
+};
+template <bool STATS>
+__global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_validate_and_trace(TraceCtx c, ValidateTraceArgs a) {
+    extern __shared__ uint32_t lds_stack[];
+    if (blockIdx.y < a.tiles_y) {
+        rtdgi_validate_tile<STATS, false>(c, a.half_view_normal_tex, a.reservoir_tex, a.reservoir_ray_history_tex, a.irradiance_history_tex, a.ray_orig_history_tex, a.validity_pre_tex, a.row0, a.row1,
+                                          make_uint2(blockIdx.x, blockIdx.y), lds_stack);
+    } else {
+        c.request_slot_base = a.trace_request_slot_base; c.request_key_base = a.trace_request_key_base;
+        rtdgi_trace_tile<STATS, false, false>(c, a.half_view_normal_tex, a.reprojection_tex, a.candidate_irradiance_out_tex, a.candidate_normal_out_tex, a.candidate_hit_out_tex, a.validity_pre_tex,
+                                              a.validity_in_tex, a.row0, a.row1, make_uint2(blockIdx.x, blockIdx.y - a.tiles_y), lds_stack);
+    }
+}
+// trace_diffuse.rgen.hlsl:119: rt_history_validity_input_tex[px] = rt_history_validity_pre_input_tex[reprojected px], for the pixels whose trace pass left it out (sky pixels hold the 0 the pass stored)
+__global__ void __launch_bounds__(64) k_rtdgi_validity_reproject(const FrameConstants* __restrict__ fcp, ImgF32 depth_tex, ImgU2 reprojection_tex, ImgR8 invalidity_in_tex, ImgR8 invalidity_out_tex, int row0, int row1) {
+    TILE_XY_M(invalidity_out_tex.w, invalidity_out_tex.h, KJ_TILES_ROWS)
+    if (!in_image) return;
+    const I2 off = halfres_subsample_offset(fcp->frame_index);
+    const int hx = x * 2 + off.x, hy = y * 2 + off.y;
+    if (0.0f == depth_tex.ld(hx, hy)) return;
+    const V4 gts = tex_size4(depth_tex.w, depth_tex.h);
     const V4 reproj = ld_reproj(reprojection_tex, hx, hy);
     const int rx = int(floorf(float(x) + gts.x * reproj.x / 2 + 0.5f)), ry = int(floorf(float(y) + gts.y * reproj.y / 2 + 0.5f));
-    if (lead) invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
+    invalidity_out_tex.st(x, y, invalidity_in_tex.ld(rx, ry));
 }
 
 #ifdef KJ_RAY_PASS_EXPERIMENTS      // measured-and-rejected forms of the ray passes (make EXPERIMENTS=1): the pool form below (1.4-1.9x slower than the fused form: profiles/r05_ray_pass_experiments.md) and rtdgi_ray_experiments.inc
@@ -913,6 +967,7 @@ struct KjRtdgi {
     uint32_t staged_min_rays = 0xffffffffu;     // ray passes run staged (ray streams) from this many ray slots per launch (KJ_RTDGI_STAGED_MIN_RAYS); default: never, see below
     uint32_t stream_waves_per_cu = 24;          // persistent waves per CU of a ray-stream launch (measured best of 8 / 16 / 24 / 32: scripts/traversal_microbench.py)
     bool fuse_validity_temporal = true;         // `validity integrate` + `restir temporal` as one launch (KJ_RTDGI_FUSE_VT=0: two)
+    bool fuse_validate_trace = true;            // a validation frame's `rtdgi validate` + `rtdgi trace` as one launch (k_rtdgi_validate_and_trace; KJ_RTDGI_FUSE_RAYS=0: two)
     bool quad_rays = false;                     // the fused ray kernels with four lanes per pixel (kj_rtdgi_set_ray_pass_form KJ_RTDGI_RAYS_QUAD)
     bool split_rays = false;                    // the ray passes as two launches each: closest-hit + misses | hit shading on compacted records (kj_rtdgi_set_ray_pass_form)
     bool grouped_rays = false;                  // the ray passes' form when not staged: grouped (hit shading regrouped inside a 256-thread workgroup) or fused (KJ_RTDGI_GROUPED=0)
@@ -963,6 +1018,7 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     if (const char* v = kj_debug_getenv("KJ_RTDGI_SPLIT")) r->split_rays = atoi(v) != 0;
     if (const char* v = kj_debug_getenv("KJ_RTDGI_QUAD")) r->quad_rays = atoi(v) != 0;
     if (const char* v = kj_debug_getenv("KJ_RTDGI_FUSE_VT")) r->fuse_validity_temporal = atoi(v) != 0;
+    if (const char* v = kj_debug_getenv("KJ_RTDGI_FUSE_RAYS")) r->fuse_validate_trace = atoi(v) != 0;
     if (const char* v = kj_debug_getenv("KJ_RTDGI_WAVES_PER_SIMD")) r->ray_waves_per_simd = uint32_t(std::max(0, atoi(v)));
     if (const char* v = kj_debug_getenv("KJ_RTDGI_POOL")) r->pool_rays = atoi(v) != 0;      // A/B runs of bench.py: the pool form of the ray passes on / off
     if (const char* v = kj_debug_getenv("KJ_RTDGI_POOL_TUNE")) {                             // "waves,refill,shade_a,shade_b,dynamic"
@@ -1102,6 +1158,27 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         if (timed_extract) SCOPE_END(1);
     }
+    // A validation frame's two ray passes as one launch (k_rtdgi_validate_and_trace) when the call runs both: the pass timers then report the launch (and the small
+    // launch that completes rt_history_validity_input_tex behind it) as `rtdgi validate`; `rtdgi trace` reads 0 for that frame.
+    const bool rays_in_one_launch = r->fuse_validate_trace && is_rtdgi_validation_frame(r->dev->fc_host.frame_index) && (mask & KJ_RTDGI_PASS_VALIDATE) && (mask & KJ_RTDGI_PASS_TRACE);
+    auto launch_validate_and_trace = [&]() -> KjStatus {
+        ValidateTraceArgs a;
+        a.half_view_normal_tex = img<uint32_t>(half_view_normal, hw, hh);
+        a.reservoir_tex = img<uint2>(reservoir_hist, hw, hh); a.reservoir_ray_history_tex = img<uint2>(ray_hist, hw, hh); a.irradiance_history_tex = img<uint2>(radiance_hist, hw, hh);
+        a.ray_orig_history_tex = img<float4>(ray_orig_hist, hw, hh); a.validity_pre_tex = img<uint8_t>(validity_pre, hw, hh);
+        a.reprojection_tex = reprojection; a.candidate_irradiance_out_tex = img<uint2>(candidate_radiance, hw, hh); a.candidate_normal_out_tex = img<uint32_t>(candidate_normal, hw, hh);
+        a.candidate_hit_out_tex = img<uint2>(candidate_hit, hw, hh); a.validity_in_tex = img<uint8_t>(validity_in, hw, hh);
+        a.row0 = hr0; a.row1 = hr1; a.tiles_y = gh.y;
+        a.trace_request_slot_base = uint32_t(hw) * uint32_t(hh); a.trace_request_key_base = 2u << 28;      // (tc holds the validate pass' bases)
+        SCOPE_BEGIN(2);
+        hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_and_trace<true> : k_rtdgi_validate_and_trace<false>, dim3(gh.x, gh.y * 2u), blk, trace_lds, s, tc, a);
+        KJ_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_rtdgi_validity_reproject, gh, blk, 0, s, fc, depth, reprojection, img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(2);
+        r->ev_valid[3] = false;
+        return KJ_OK;
+    };
 #ifdef KJ_RAY_PASS_EXPERIMENTS
     // the pool form of the ray passes (k_rtdgi_rays_pool): persistent waves over the launch's tiles
     PoolArgs pa;
@@ -1197,7 +1274,9 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(2);
     }
-    if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged && !grouped && !split && !quad) {
+    const bool fused_default = !staged && !grouped && !split && !quad && !pool;      // the product's form of the ray passes
+    if (fused_default && rays_in_one_launch) { const KjStatus st_ = launch_validate_and_trace(); if (st_ != KJ_OK) return st_; }
+    if ((mask & KJ_RTDGI_PASS_VALIDATE) && !staged && !grouped && !split && !quad && !(fused_default && rays_in_one_launch)) {
         SCOPE_BEGIN(2);
         if (pool && is_rtdgi_validation_frame(r->dev->fc_host.frame_index)) launch_pool(true);
         else hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
@@ -1229,7 +1308,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         KJ_CHECK_LAUNCH();
         SCOPE_END(3);
     }
-    if ((mask & KJ_RTDGI_PASS_TRACE) && !staged && !grouped && !split && !quad) {
+    if ((mask & KJ_RTDGI_PASS_TRACE) && !staged && !grouped && !split && !quad && !(fused_default && rays_in_one_launch)) {
         SCOPE_BEGIN(3);
         if (pool) launch_pool(false);
         else hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
@@ -1267,7 +1346,8 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
 #else
     // The product build carries the fused form of the two ray passes only (one wave per 8x8 tile: ray generation, both traversals, hit shading);
     // the other forms live behind KJ_RAY_PASS_EXPERIMENTS (rtdgi_ray_experiments.inc)
-    if (mask & KJ_RTDGI_PASS_VALIDATE) {
+    if (rays_in_one_launch) { const KjStatus st_ = launch_validate_and_trace(); if (st_ != KJ_OK) return st_; }
+    if ((mask & KJ_RTDGI_PASS_VALIDATE) && !rays_in_one_launch) {
         SCOPE_BEGIN(2);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_fused<true> : k_rtdgi_validate_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), img<uint2>(reservoir_hist, hw, hh), img<uint2>(ray_hist, hw, hh),
                            img<uint2>(radiance_hist, hw, hh), img<float4>(ray_orig_hist, hw, hh), img<uint8_t>(validity_pre, hw, hh), hr0, hr1);
@@ -1275,7 +1355,7 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         SCOPE_END(2);
     }
     tc.request_slot_base = uint32_t(hw) * uint32_t(hh); tc.request_key_base = 2u << 28;
-    if (mask & KJ_RTDGI_PASS_TRACE) {
+    if ((mask & KJ_RTDGI_PASS_TRACE) && !rays_in_one_launch) {
         SCOPE_BEGIN(3);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_trace_fused<true> : k_rtdgi_trace_fused<false>, gh, blk, trace_lds, s, tc, img<uint32_t>(half_view_normal, hw, hh), reprojection, img<uint2>(candidate_radiance, hw, hh),
                            img<uint32_t>(candidate_normal, hw, hh), img<uint2>(candidate_hit, hw, hh), img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
