@@ -336,6 +336,12 @@ enum {
      * before `restir spatial`) adds it. Together they write exactly what KJ_RTDGI_PASS_EXTRACT_HALF alone writes. */
     KJ_RTDGI_PASS_EXTRACT_HALF_NO_SSAO = 1u << 9,
     KJ_RTDGI_PASS_EXTRACT_HALF_SSAO_ONLY = 1u << 10,
+    /* For a host that has to do something between `rtdgi validate` and the LAST statement of `rtdgi trace` (trace_diffuse.rgen.hlsl:119 reads the validate pass' output at the
+     * reprojected pixel: in the screen-tile split that is a halo exchange; nothing else of the trace pass reads what validate writes). A call with VALIDATE | TRACE | _TRACE_MAY_DEFER
+     * runs the trace pass without that statement where the library has the two passes as one launch (validation frames), and leaves the trace pass out altogether otherwise;
+     * a later call with _TRACE_FINISH alone runs what is left (the statement, or the whole pass). Same images as VALIDATE then TRACE. */
+    KJ_RTDGI_PASS_TRACE_MAY_DEFER = 1u << 11,
+    KJ_RTDGI_PASS_TRACE_FINISH = 1u << 12,
     /* Debug: re-use the previous call's ping-pong assignment instead of advancing it, so a frame can be
      * executed pass by pass (render-graph debug hook analogue). Never set on the product path. */
     KJ_RTDGI_PASS_KEEP_TEMPORALS = 1u << 31

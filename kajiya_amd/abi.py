@@ -88,7 +88,7 @@ class KjRtdgiOutput(C.Structure):
 
 
 KJ_RTDGI_PASS = dict(
-    EXTRACT_HALF_NO_SSAO=1 << 9, EXTRACT_HALF_SSAO_ONLY=1 << 10,
+    EXTRACT_HALF_NO_SSAO=1 << 9, EXTRACT_HALF_SSAO_ONLY=1 << 10, TRACE_MAY_DEFER=1 << 11, TRACE_FINISH=1 << 12,
     EXTRACT_HALF=1 << 0, VALIDATE=1 << 1, TRACE=1 << 2, VALIDITY_INTEGRATE=1 << 3, RESTIR_TEMPORAL=1 << 4,
     RESTIR_SPATIAL=1 << 5, RESTIR_RESOLVE=1 << 6, TEMPORAL_FILTER=1 << 7, SPATIAL_FILTER=1 << 8, ALL=0x1ff)
 

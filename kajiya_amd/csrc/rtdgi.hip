@@ -416,18 +416,22 @@ struct ValidateTraceArgs {
     ImgU2 reservoir_tex; ImgH4 reservoir_ray_history_tex, irradiance_history_tex; ImgF4 ray_orig_history_tex; ImgR8 validity_pre_tex;                       // validate
     ImgU2 reprojection_tex; ImgH4 candidate_irradiance_out_tex; ImgU32 candidate_normal_out_tex; ImgH4 candidate_hit_out_tex; ImgR8 validity_in_tex;    // trace
     int row0, row1;
-    uint32_t tiles_y, trace_request_slot_base, trace_request_key_base;
+    uint32_t tiles_y, trace_request_slot_base, trace_request_key_base, order;
 };
 template <bool STATS>
 __global__ void __launch_bounds__(64, KJ_FUSED_WAVES) k_rtdgi_validate_and_trace(TraceCtx c, ValidateTraceArgs a) {
     extern __shared__ uint32_t lds_stack[];
-    if (blockIdx.y < a.tiles_y) {
+    // dispatch order (workgroups are handed out x-fastest, then y): 0 = every validate tile, then every trace tile (the default); 1 = row by row, validate row then trace row;
+    // 2 = the trace tiles first (KJ_RTDGI_FUSE_ORDER, measured: profiles/r06_ray_tile_order.md)
+    const bool validate = a.order == 1u ? (blockIdx.y & 1u) == 0u : a.order == 2u ? blockIdx.y >= a.tiles_y : blockIdx.y < a.tiles_y;
+    const uint32_t tile_row = a.order == 1u ? blockIdx.y >> 1 : blockIdx.y >= a.tiles_y ? blockIdx.y - a.tiles_y : blockIdx.y;
+    if (validate) {
         rtdgi_validate_tile<STATS, false>(c, a.half_view_normal_tex, a.reservoir_tex, a.reservoir_ray_history_tex, a.irradiance_history_tex, a.ray_orig_history_tex, a.validity_pre_tex, a.row0, a.row1,
-                                          make_uint2(blockIdx.x, blockIdx.y), lds_stack);
+                                          make_uint2(blockIdx.x, tile_row), lds_stack);
     } else {
         c.request_slot_base = a.trace_request_slot_base; c.request_key_base = a.trace_request_key_base;
         rtdgi_trace_tile<STATS, false, false>(c, a.half_view_normal_tex, a.reprojection_tex, a.candidate_irradiance_out_tex, a.candidate_normal_out_tex, a.candidate_hit_out_tex, a.validity_pre_tex,
-                                              a.validity_in_tex, a.row0, a.row1, make_uint2(blockIdx.x, blockIdx.y - a.tiles_y), lds_stack);
+                                              a.validity_in_tex, a.row0, a.row1, make_uint2(blockIdx.x, tile_row), lds_stack);
     }
 }
 // trace_diffuse.rgen.hlsl:119: rt_history_validity_input_tex[px] = rt_history_validity_pre_input_tex[reprojected px], for the pixels whose trace pass left it out (sky pixels hold the 0 the pass stored)
@@ -967,6 +971,8 @@ struct KjRtdgi {
     uint32_t staged_min_rays = 0xffffffffu;     // ray passes run staged (ray streams) from this many ray slots per launch (KJ_RTDGI_STAGED_MIN_RAYS); default: never, see below
     uint32_t stream_waves_per_cu = 24;          // persistent waves per CU of a ray-stream launch (measured best of 8 / 16 / 24 / 32: scripts/traversal_microbench.py)
     bool fuse_validity_temporal = true;         // `validity integrate` + `restir temporal` as one launch (KJ_RTDGI_FUSE_VT=0: two)
+    bool trace_deferred = false, validity_copy_pending = false;      // an open KJ_RTDGI_PASS_TRACE_MAY_DEFER call: the whole trace pass / its last statement is left to KJ_RTDGI_PASS_TRACE_FINISH
+    uint32_t fuse_order = 0;                    // k_rtdgi_validate_and_trace's dispatch order (KJ_RTDGI_FUSE_ORDER)
     bool fuse_validate_trace = true;            // a validation frame's `rtdgi validate` + `rtdgi trace` as one launch (k_rtdgi_validate_and_trace; KJ_RTDGI_FUSE_RAYS=0: two)
     bool quad_rays = false;                     // the fused ray kernels with four lanes per pixel (kj_rtdgi_set_ray_pass_form KJ_RTDGI_RAYS_QUAD)
     bool split_rays = false;                    // the ray passes as two launches each: closest-hit + misses | hit shading on compacted records (kj_rtdgi_set_ray_pass_form)
@@ -1019,6 +1025,7 @@ KjStatus kj_rtdgi_create(KjDevice* dev, KjRtdgi** out) {
     if (const char* v = kj_debug_getenv("KJ_RTDGI_QUAD")) r->quad_rays = atoi(v) != 0;
     if (const char* v = kj_debug_getenv("KJ_RTDGI_FUSE_VT")) r->fuse_validity_temporal = atoi(v) != 0;
     if (const char* v = kj_debug_getenv("KJ_RTDGI_FUSE_RAYS")) r->fuse_validate_trace = atoi(v) != 0;
+    if (const char* v = kj_debug_getenv("KJ_RTDGI_FUSE_ORDER")) r->fuse_order = uint32_t(std::max(0, atoi(v)));
     if (const char* v = kj_debug_getenv("KJ_RTDGI_WAVES_PER_SIMD")) r->ray_waves_per_simd = uint32_t(std::max(0, atoi(v)));
     if (const char* v = kj_debug_getenv("KJ_RTDGI_POOL")) r->pool_rays = atoi(v) != 0;      // A/B runs of bench.py: the pool form of the ray passes on / off
     if (const char* v = kj_debug_getenv("KJ_RTDGI_POOL_TUNE")) {                             // "waves,refill,shade_a,shade_b,dynamic"
@@ -1081,7 +1088,25 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     hipStream_t s = (hipStream_t)stream_;
     const int W = r->W, H = r->H, hw = r->hw, hh = r->hh;
     const FrameConstants* fc = r->dev->fc_dev;
-    const uint32_t mask = p->pass_mask;
+    uint32_t mask = p->pass_mask;
+    // KJ_RTDGI_PASS_TRACE_MAY_DEFER / KJ_RTDGI_PASS_TRACE_FINISH (include/kajiya_amd.h; the screen-tile split: `rtdgi validate`'s output needs a halo exchange before the trace pass'
+    // LAST statement reads it at the reprojected pixel, and nothing else of the trace pass reads what `rtdgi validate` writes). A call with VALIDATE | TRACE | TRACE_MAY_DEFER either runs
+    // both passes as one launch without that statement (a validation frame in the product's form of the ray passes) or leaves the trace pass out altogether; the TRACE_FINISH call
+    // behind the exchange runs what is left: the statement alone (k_rtdgi_validity_reproject) or the whole pass.
+    bool trace_without_copy = false, validity_copy_only = false;
+    if (mask & KJ_RTDGI_PASS_TRACE_FINISH) {
+        KJ_REQUIRE(!(mask & KJ_RTDGI_PASS_TRACE) && (r->trace_deferred || r->validity_copy_pending), "KJ_RTDGI_PASS_TRACE_FINISH completes a call with KJ_RTDGI_PASS_TRACE | KJ_RTDGI_PASS_TRACE_MAY_DEFER (none is open)");
+        if (r->trace_deferred) mask |= KJ_RTDGI_PASS_TRACE; else validity_copy_only = true;
+    }
+    if ((mask & KJ_RTDGI_PASS_TRACE_MAY_DEFER) && (mask & KJ_RTDGI_PASS_TRACE) && !(mask & KJ_RTDGI_PASS_TRACE_FINISH)) {
+        KJ_REQUIRE(!r->trace_deferred && !r->validity_copy_pending, "the previous KJ_RTDGI_PASS_TRACE_MAY_DEFER call was never completed (KJ_RTDGI_PASS_TRACE_FINISH)");
+        bool product_form = true;
+#ifdef KJ_RAY_PASS_EXPERIMENTS
+        product_form = !(r->quad_rays || r->split_rays || r->grouped_rays || r->pool_rays || r->staged_min_rays != 0xffffffffu);
+#endif
+        if (product_form && r->fuse_validate_trace && is_rtdgi_validation_frame(r->dev->fc_host.frame_index) && (mask & KJ_RTDGI_PASS_VALIDATE)) trace_without_copy = true;
+        else mask &= ~uint32_t(KJ_RTDGI_PASS_TRACE);
+    }
     // rows of this call (screen-tile split): full-res [fr0, fr1), half-res [hr0, hr1); 0,0 = whole image
     int fr0 = 0, fr1 = H;
     if (p->row_end > p->row_begin) {
@@ -1093,6 +1118,8 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
     // every argument check is above: from here on the ping-pong state may change (an early return after this point would leave
     // output and history swapped for the next call)
     if (mask & KJ_RTDGI_PASS_KEEP_TEMPORALS) for (bool& f : r->flip) f = !f;
+    if (p->pass_mask & KJ_RTDGI_PASS_TRACE_FINISH) r->trace_deferred = r->validity_copy_pending = false;
+    else if ((p->pass_mask & KJ_RTDGI_PASS_TRACE_MAY_DEFER) && (p->pass_mask & KJ_RTDGI_PASS_TRACE)) { r->trace_deferred = !trace_without_copy; r->validity_copy_pending = trace_without_copy; }
     const int hr0 = fr0 / 2, hr1 = fr1 == H ? hh : fr1 / 2;
     const dim3 gh((hw + 7) / 8, (hr1 - hr0 + 7) / 8), gf((W + 7) / 8, (fr1 - fr0 + 7) / 8), blk(64);
     const size_t HB = size_t(hw) * hh, FB = size_t(W) * H;
@@ -1168,17 +1195,25 @@ KjStatus kj_rtdgi_render(KjRtdgi* r, const KjRtdgiRenderParams* p, KjRtdgiOutput
         a.ray_orig_history_tex = img<float4>(ray_orig_hist, hw, hh); a.validity_pre_tex = img<uint8_t>(validity_pre, hw, hh);
         a.reprojection_tex = reprojection; a.candidate_irradiance_out_tex = img<uint2>(candidate_radiance, hw, hh); a.candidate_normal_out_tex = img<uint32_t>(candidate_normal, hw, hh);
         a.candidate_hit_out_tex = img<uint2>(candidate_hit, hw, hh); a.validity_in_tex = img<uint8_t>(validity_in, hw, hh);
-        a.row0 = hr0; a.row1 = hr1; a.tiles_y = gh.y;
+        a.row0 = hr0; a.row1 = hr1; a.tiles_y = gh.y; a.order = r->fuse_order;
         a.trace_request_slot_base = uint32_t(hw) * uint32_t(hh); a.trace_request_key_base = 2u << 28;      // (tc holds the validate pass' bases)
         SCOPE_BEGIN(2);
         hipLaunchKernelGGL(r->count_traversal ? k_rtdgi_validate_and_trace<true> : k_rtdgi_validate_and_trace<false>, dim3(gh.x, gh.y * 2u), blk, trace_lds, s, tc, a);
         KJ_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_rtdgi_validity_reproject, gh, blk, 0, s, fc, depth, reprojection, img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
-        KJ_CHECK_LAUNCH();
+        if (!trace_without_copy) {
+            hipLaunchKernelGGL(k_rtdgi_validity_reproject, gh, blk, 0, s, fc, depth, reprojection, img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+            KJ_CHECK_LAUNCH();
+        }
         SCOPE_END(2);
         r->ev_valid[3] = false;
         return KJ_OK;
     };
+    if (validity_copy_only) {      // KJ_RTDGI_PASS_TRACE_FINISH behind a one-launch call: the trace pass' last statement
+        SCOPE_BEGIN(3);
+        hipLaunchKernelGGL(k_rtdgi_validity_reproject, gh, blk, 0, s, fc, depth, reprojection, img<uint8_t>(validity_pre, hw, hh), img<uint8_t>(validity_in, hw, hh), hr0, hr1);
+        KJ_CHECK_LAUNCH();
+        SCOPE_END(3);
+    }
 #ifdef KJ_RAY_PASS_EXPERIMENTS
     // the pool form of the ray passes (k_rtdgi_rays_pool): persistent waves over the launch's tiles
     PoolArgs pa;

@@ -438,7 +438,9 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
         // three times the screen distance of the sample's pixel (occlusion_raymarch.hlsl via restir_spatial.hlsl:235-262) and reads the half-res depth along the way -- well beyond
         // the halo of everything else under a grazing, wide field of view.
         KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_EXTRACT_HALF, {0, 0}, 0, st));
-        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_VALIDATE | KEEP, s->strips[s->first + li], 0, st));
+        // `rtdgi validate`, and with it -- where the library has the two ray passes of a validation frame as ONE launch (k_rtdgi_validate_and_trace: a strip's launch of either pass
+        // lasts as long as its slowest waves) -- `rtdgi trace` without its last statement, the one read of the validate pass' output (at the reprojected pixel: exchange B's halo)
+        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_VALIDATE | KJ_RTDGI_PASS_TRACE | KJ_RTDGI_PASS_TRACE_MAY_DEFER | KEEP, s->strips[s->first + li], 0, st));
     }
     // ---- B: validate rewrites the reservoir histories in place
     items.clear();
@@ -451,7 +453,7 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
         items.push_back({sfx("rtdgi.invalidity", hist_i), int(M + 8)});
     }
     KJ_SPLIT_TRY(exchange(*s, items, st));
-    for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_TRACE | KEEP, s->strips[s->first + li], 0, st));
+    for (uint32_t li = 0; li < s->local; ++li) KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_TRACE_FINISH | KEEP, s->strips[s->first + li], 0, st));      // the rest of `rtdgi trace`: that statement, or the whole pass
     if (s->consistent_ircache) s->merge_pending = true;
     if (s->consistent_ircache && !defer_merge && !s->with_rtr) KJ_SPLIT_TRY(merge_ircache_requests(*s, st));      // (with reflections in the frame: after THEIR ray passes)
     if (trace_done_event) KJ_TRY_HIP(hipEventRecord((hipEvent_t)trace_done_event, st));

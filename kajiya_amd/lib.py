@@ -13,6 +13,9 @@ from .abi import (KjFrameConstants, KjMeshDesc, KjGbufferDepth, KjRtdgiRenderPar
 from . import scenes as kscenes
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# KJ_MEASURE_SKIP=taa,irc_rays (measurement only, behind KJ_DEBUG_ENV=1 like the library's switches: what a piece of the PIPELINED frame costs at the margin -- the frame's images are
+# wrong without it): frame_pipelined leaves out TAA / the cache's ray launch
+_MEASURE_SKIP = set(filter(None, os.environ.get("KJ_MEASURE_SKIP", "").split(","))) if os.environ.get("KJ_DEBUG_ENV") == "1" else set()
 LIB_PATH = os.environ.get("KJ_AMD_LIB") or os.path.join(HERE, "libkajiya_amd.so")   # KJ_AMD_LIB: A/B a differently built library
 
 EXPORTS = [
@@ -426,7 +429,8 @@ class GpuPipeline:
             self._ev_fc[self._pipe_i & 1].record(self._s1)
             s = _stream_ptr()
             check(self.L.kj_ircache_prepare(self.ircache, s))
-            check(self.L.kj_ircache_trace_irradiance(self.ircache, self.scene.h, self.sky16.data_ptr(), 16, s))
+            if "irc_rays" not in _MEASURE_SKIP:
+                check(self.L.kj_ircache_trace_irradiance(self.ircache, self.scene.h, self.sky16.data_ptr(), 16, s))
             if self.on_ircache_traced is not None:
                 self.on_ircache_traced()          # e.g. the bench logs the cache's ray counters, stream-ordered
             self._ev_irc[self._pipe_i & 1].record(self._s1)
@@ -477,7 +481,8 @@ class GpuPipeline:
         p = self.params(P["EXTRACT_HALF"] | (P["EXTRACT_HALF_NO_SSAO"] if overlap_ssgi else 0))
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
         s0.wait_event(self._ev_irc[i])
-        check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
+        if "irc_rays" not in _MEASURE_SKIP:
+            check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
         head = P["EXTRACT_HALF"] | P["VALIDATE"] | P["TRACE"]
         p = self.params(P["VALIDATE"] | P["TRACE"] | (1 << 31))
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
@@ -499,7 +504,8 @@ class GpuPipeline:
         with torch.cuda.stream(self._s2):
             self._s2.wait_event(self._ev_gi[i])
             check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), _stream_ptr()))
-            self.taa_frame()
+            if "taa" not in _MEASURE_SKIP:
+                self.taa_frame()
             self._ev_taa[i].record(self._s2)
         self._pipe_i += 1
         if next_fc is not None:
