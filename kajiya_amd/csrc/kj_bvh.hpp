@@ -105,6 +105,15 @@ KJ_D bool intersect_tri(V3 o, V3 d, float tmin, float tmax, const float4 a, cons
 }
 
 // stack: LDS base for this lane; entries at stack[level * stride]
+// KJ_WALK_PREFETCH (round 6 experiment): in a wave's TAIL -- at most KJ_WALK_PREFETCH_LANES live rays, where every step is one dependent round trip to L2 / the Infinity Cache
+// on a nearly idle SIMD -- a node step requests the first bytes of the SECOND nearest child it pushes (the next thing popped when the nearest child's subtree is done), so that
+// its line is in the L2 by then. The value is never used.
+#ifndef KJ_WALK_PREFETCH
+#define KJ_WALK_PREFETCH 0
+#endif
+#ifndef KJ_WALK_PREFETCH_LANES
+#define KJ_WALK_PREFETCH_LANES 16u
+#endif
 struct TraverseStats { uint32_t nodes, tris; uint32_t wave_node_steps = 0, wave_tri_steps = 0; uint32_t live_hist[4] = {0, 0, 0, 0}; };   // live_hist: wave steps by the number of lanes still walking (1-8, 9-16, 17-32, 33-64), counted by one lane (round 6: profiles/r06_walk.md)   // wave_*: steps the WAVE issued (counted by one lane of it): lane utilisation of the walk = (nodes + tris) / (64 * steps)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -123,6 +132,11 @@ struct RayState {
     RayHit h;
     uint32_t sp, cur;
     bool cull_back;
+#if KJ_WALK_PREFETCH
+    uint32_t pf_prev = 0u, pf_acc = 0u;      // KJ_WALK_PREFETCH: the last requested word (never used), and where it ends up
+    uint32_t pf_ref = 0xffffffffu;           // what the node step just taken wants requested
+    bool pf_on = false;                      // wave-uniform: the wave is in its tail (few live rays: the step's round trip is what it waits for)
+#endif
 };
 // reciprocal direction for the slab tests (v_rcp_f32: the boxes are conservative by several ulps, the triangles never see this)
 KJ_D float rcp_box(float x) {
@@ -273,12 +287,26 @@ KJ_D void node_step_data(RayState& S, const float4 n0, const uint4 ch, const uin
     }
     if (key[0] != NONE) S.cur = ref[0];
     else KJ_POP(S.cur)
+#if KJ_WALK_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
+    S.pf_ref = (S.pf_on && key[1] != NONE) ? ref[1] : NONE;
+#endif
 }
 template <bool ANY_HIT, bool STATS>
 KJ_D void node_step(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
     const float4* __restrict__ n = (const float4*)bvh.nodes + size_t(S.cur) * 4;
-    const float4 n0 = n[0]; const uint4 ch = *(const uint4*)(n + 1), qa = *(const uint4*)(n + 2); const uint2 qb = *(const uint2*)(n + 3);
+    float4 n0 = n[0]; const uint4 ch = *(const uint4*)(n + 1), qa = *(const uint4*)(n + 2); const uint2 qb = *(const uint2*)(n + 3);
+#if KJ_WALK_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(S.pf_prev), "+v"(n0.x));      // the previous request is consumed behind this node's own (younger) loads: loads return in order
+    S.pf_acc ^= S.pf_prev;
+#endif
     node_step_data<ANY_HIT, STATS>(S, n0, ch, qa, qb, stack, stride, spill, stats);
+#if KJ_WALK_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
+    if (S.pf_ref != KJ_BVH_NONE) {
+        const uint32_t c = S.pf_ref;
+        const uintptr_t pfp = (c & KJ_BVH_LEAF) ? uintptr_t(bvh.tris) + size_t(c & 0x0fffffffu) * 48u : uintptr_t(bvh.nodes) + size_t(c) * 64u;
+        S.pf_prev = *(const __attribute__((address_space(1))) uint32_t*)pfp;
+    }
+#endif
 }
 template <bool ANY_HIT, bool STATS>
 KJ_D void tri_step_data(RayState& S, const float4 a, const float4 b, const float4 c, uint32_t* stack, uint32_t stride, uint32_t* spill, TraverseStats* stats) {
@@ -443,6 +471,9 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
         }
 #endif
         if (STATS) { const uint32_t live = nn + nt; live_hist[live <= 8u ? 0 : (live <= 16u ? 1 : (live <= 32u ? 2 : 3))]++; }
+#if KJ_WALK_PREFETCH
+        S.pf_on = nn + nt <= KJ_WALK_PREFETCH_LANES;
+#endif
         if (nt == 0u || (nn != 0u && nn >= nt * 2u)) { if (STATS) it_node++; if (want_node) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
         else { if (STATS) it_tri++; if (want_tri) tri_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats); }
     }
@@ -450,6 +481,10 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
         stats->wave_node_steps += it_node; stats->wave_tri_steps += it_tri;
         for (int b = 0; b < 4; ++b) stats->live_hist[b] += live_hist[b];
     }
+#if KJ_WALK_PREFETCH
+    S.pf_acc ^= S.pf_prev;
+    if (S.pf_acc == 0x9e3779b9u && __float_as_uint(S.tmax) == 0xffffffffu) S.h.u = 2.0f;      // never true: keeps the requests from being optimised away
+#endif
 #else
     while (S.cur != KJ_BVH_NONE) {
         if (wants_node_step(S)) node_step<ANY_HIT, STATS>(bvh, S, stack, stride, spill, stats);
@@ -466,6 +501,9 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
 // rays instead of 64, and the launch has four times the waves. The caller runs its shading code on all four lanes (same inputs, same
 // results) and lets lane 0 of each quad perform the side effects. Per-ray results are those of bvh_trace(): the closest hit with
 // equal-t ties going to the lowest world triangle id does not depend on the order boxes and triangles are visited in.
+#ifndef KJ_QUAD_PREFETCH
+#define KJ_QUAD_PREFETCH 0
+#endif
 #define KJ_QUAD_LDS_STACK 32u     // stack entries per quad kept in LDS ([level][quad]: 16 quads x 32 levels x 4 B = 2 KB per wave); deeper ones spill
 KJ_HD size_t quad_stack_bytes() { return size_t(KJ_QUAD_LDS_STACK) * 16u * 4u; }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -501,6 +539,9 @@ KJ_D void quad_walk(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
     const uint32_t k = __lane_id() & 3u;
     const V3 inv_d = S.binv;
     const bool neg_x = inv_d.x < 0.0f, neg_y = inv_d.y < 0.0f, neg_z = inv_d.z < 0.0f;
+#if KJ_QUAD_PREFETCH
+    uint32_t pf_prev = 0u, pf_acc = 0u;
+#endif
     for (;;) {
         const bool want_node = wants_node_step(S), want_tri = wants_tri_step(S);
         const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
@@ -508,7 +549,12 @@ KJ_D void quad_walk(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
         if (nt == 0u || (nn != 0u && nn >= nt * 2u)) {
             if (want_node) {
                 const float4* __restrict__ n = (const float4*)bvh.nodes + size_t(S.cur) * 4;
-                const float4 n0 = n[0]; const uint4 ch = *(const uint4*)(n + 1), qa = *(const uint4*)(n + 2); const uint2 qb = *(const uint2*)(n + 3);
+                float4 n0 = n[0]; const uint4 ch = *(const uint4*)(n + 1), qa = *(const uint4*)(n + 2); const uint2 qb = *(const uint2*)(n + 3);
+#if KJ_QUAD_PREFETCH
+                // the previous step's request is consumed HERE, behind this node's own (younger) loads: loads return in order, so the wait for n0 has covered it
+                asm volatile("" : "+v"(pf_prev), "+v"(n0.x));
+                pf_acc ^= pf_prev;
+#endif
                 if (STATS && k == 0u) stats->nodes++;
                 const float tlimit = ANY_HIT ? S.tmax : fminf(S.h.t, S.tmax);
                 const uint32_t e = __float_as_uint(n0.w);
@@ -525,6 +571,15 @@ KJ_D void quad_walk(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
                 uint32_t c = ch.x;
                 c = k == 1u ? ch.y : c; c = k == 2u ? ch.z : c; c = k == 3u ? ch.w : c;
                 const bool hit = (tn <= tf * 1.000001f + 1e-30f) & (c != NONE);
+#if KJ_QUAD_PREFETCH
+                // KJ_QUAD_PREFETCH (round 6): a lane whose child the ray enters requests the child's first bytes NOW -- the node, or a leaf's first triangle --, before the
+                // sort and the pushes: these launches are lone waves bound by the round trip of every step's dependent load; the nearest child's line is then on its way (or there)
+                // when the next step asks for it, the pushed ones' when they are popped. The value is never used (xor-ed into a word nothing reads out).
+                if (hit) {
+                    const uintptr_t pfp = (c & KJ_BVH_LEAF) ? uintptr_t(bvh.tris) + size_t(c & 0x0fffffffu) * 48u : uintptr_t(bvh.nodes) + size_t(c) * 64u;
+                    pf_prev = *(const __attribute__((address_space(1))) uint32_t*)pfp;      // (a global_load: a generic pointer would make it a flat_load, counted on the LDS counter too)
+                }
+#endif
                 // key = entry distance with the child index in its two low bits (all four keys distinct; tn >= tmin >= 0: float order ==
                 // integer order); occlusion rays take the children in slot order. (key, reference) pairs of the four lanes travel
                 // through quad rotations and a 5-comparator network of selects: every lane ends up with the same sorted list.
@@ -579,6 +634,10 @@ KJ_D void quad_walk(const BvhView& bvh, RayState& S, uint32_t* stack, uint32_t s
             (void)any;
         }
     }
+#if KJ_QUAD_PREFETCH
+    pf_acc ^= pf_prev;
+    if (pf_acc == 0x9e3779b9u && __float_as_uint(S.tmax) == 0xffffffffu) S.h.u = 2.0f;      // never true (tmax is a finite distance): keeps the requests from being optimised away
+#endif
 }
 #endif
 // `stack`: LDS base of this QUAD's stack (entries at stack[level * stride]); all four lanes pass the same ray and the same `active`.
