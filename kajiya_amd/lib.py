@@ -16,6 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # KJ_MEASURE_SKIP=taa,irc_rays (measurement only, behind KJ_DEBUG_ENV=1 like the library's switches: what a piece of the PIPELINED frame costs at the margin -- the frame's images are
 # wrong without it): frame_pipelined leaves out TAA / the cache's ray launch
 _MEASURE_SKIP = set(filter(None, os.environ.get("KJ_MEASURE_SKIP", "").split(","))) if os.environ.get("KJ_DEBUG_ENV") == "1" else set()
+# where the pipelined frame runs the cache's SH sum-up (IrcacheRenderState::sum_up_irradiance_for_sampling): behind the cache's rays on the cache stream (1) or on the main stream behind
+# its wait for them (0, rounds 1-5)
+_SUMUP_ON_CACHE_STREAM = os.environ.get("KJ_SUMUP_ON_CACHE_STREAM", "0") != "0"
 LIB_PATH = os.environ.get("KJ_AMD_LIB") or os.path.join(HERE, "libkajiya_amd.so")   # KJ_AMD_LIB: A/B a differently built library
 
 EXPORTS = [
@@ -433,6 +436,9 @@ class GpuPipeline:
                 check(self.L.kj_ircache_trace_irradiance(self.ircache, self.scene.h, self.sky16.data_ptr(), 16, s))
             if self.on_ircache_traced is not None:
                 self.on_ircache_traced()          # e.g. the bench logs the cache's ray counters, stream-ordered
+            # the SH sum-up behind the rays on THIS stream (KJ_SUMUP_ON_CACHE_STREAM, see frame_pipelined): 0.03 ms off the main stream's chain between two trace passes
+            if _SUMUP_ON_CACHE_STREAM and "irc_rays" not in _MEASURE_SKIP:
+                check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
             self._ev_irc[self._pipe_i & 1].record(self._s1)
 
     def frame_pipelined(self, next_fc, run_ssgi=False):
@@ -481,7 +487,7 @@ class GpuPipeline:
         p = self.params(P["EXTRACT_HALF"] | (P["EXTRACT_HALF_NO_SSAO"] if overlap_ssgi else 0))
         check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
         s0.wait_event(self._ev_irc[i])
-        if "irc_rays" not in _MEASURE_SKIP:
+        if "irc_rays" not in _MEASURE_SKIP and not _SUMUP_ON_CACHE_STREAM:
             check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
         head = P["EXTRACT_HALF"] | P["VALIDATE"] | P["TRACE"]
         p = self.params(P["VALIDATE"] | P["TRACE"] | (1 << 31))
