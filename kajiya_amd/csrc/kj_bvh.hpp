@@ -502,7 +502,7 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
 // results) and lets lane 0 of each quad perform the side effects. Per-ray results are those of bvh_trace(): the closest hit with
 // equal-t ties going to the lowest world triangle id does not depend on the order boxes and triangles are visited in.
 #ifndef KJ_QUAD_PREFETCH
-#define KJ_QUAD_PREFETCH 0
+#define KJ_QUAD_PREFETCH 1      // measured on MI355X (round 6, profiles/r06_walk.md): k_irc_ray_chain 152.9 -> 145.3 us on the 4 M-triangle scene (-5 %), the frames unchanged
 #endif
 #define KJ_QUAD_LDS_STACK 32u     // stack entries per quad kept in LDS ([level][quad]: 16 quads x 32 levels x 4 B = 2 KB per wave); deeper ones spill
 KJ_HD size_t quad_stack_bytes() { return size_t(KJ_QUAD_LDS_STACK) * 16u * 4u; }

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _MEASURE_SKIP = set(filter(None, os.environ.get("KJ_MEASURE_SKIP", "").split(","))) if os.environ.get("KJ_DEBUG_ENV") == "1" else set()
 # where the pipelined frame runs the cache's SH sum-up (IrcacheRenderState::sum_up_irradiance_for_sampling): behind the cache's rays on the cache stream (1) or on the main stream behind
 # its wait for them (0, rounds 1-5)
-_SUMUP_ON_CACHE_STREAM = os.environ.get("KJ_SUMUP_ON_CACHE_STREAM", "0") != "0"
+_SUMUP_ON_CACHE_STREAM = os.environ.get("KJ_SUMUP_ON_CACHE_STREAM", "1") != "0"
 LIB_PATH = os.environ.get("KJ_AMD_LIB") or os.path.join(HERE, "libkajiya_amd.so")   # KJ_AMD_LIB: A/B a differently built library
 
 EXPORTS = [
