@@ -178,6 +178,9 @@ KJ_D void ray_begin(RayState& S, V3 o, V3 d, float tmin, float tmax, bool cull_b
 #ifndef KJ_WALK_UNIFIED
 #define KJ_WALK_UNIFIED 0    // measured: 24 % fewer iterations per wave and the trace pass 18 % SLOWER (0.317 against 0.268 ms at 1080p, 0.938 against 0.790 at 4K): what these kernels pay for is issued instructions
 #endif
+#ifndef KJ_WALK_UNIFIED_TAIL
+#define KJ_WALK_UNIFIED_TAIL 0
+#endif
 #ifndef KJ_BVH_FOLD_INVD
 #define KJ_BVH_FOLD_INVD 0
 #endif
@@ -439,9 +442,18 @@ KJ_D RayHit bvh_trace(const BvhView& bvh, V3 o, V3 d, float tmin, float tmax, bo
     uint32_t it_node = 0;
     for (;;) {
         const bool want_node = wants_node_step(S), want_tri = wants_tri_step(S);
+#if KJ_WALK_UNIFIED_TAIL
+        // KJ_WALK_UNIFIED_TAIL = n (round 6 experiment): the per-wave vote (one kind of step per iteration) while more than n rays are alive, every live lane in every iteration below
+        const uint32_t nn = uint32_t(__popcll(__ballot(want_node))), nt = uint32_t(__popcll(__ballot(want_tri)));
+        if (nn + nt == 0u) break;
+        const bool vote_node = nt == 0u || (nn != 0u && nn >= nt * 2u);
+        const bool go = nn + nt <= uint32_t(KJ_WALK_UNIFIED_TAIL) ? (want_node | want_tri) : (vote_node ? want_node : want_tri);
+#else
         if (__ballot(want_node | want_tri) == 0ull) break;
+        const bool go = want_node | want_tri;
+#endif
         if (STATS) it_node++;
-        if (want_node | want_tri) {
+        if (go) {
             const float4* __restrict__ p = want_node ? (const float4*)bvh.nodes + size_t(S.cur) * 4 : (const float4*)bvh.tris + size_t(S.cur & 0x0fffffffu) * 3;
             const float4 d0 = p[0], d1 = p[1], d2 = p[2];
             if (want_node) {
