@@ -460,8 +460,8 @@ KjStatus kj_split_gi_frame(KjSplit* s, const KjSplitFrame* frames, uint32_t flag
     // ---- C
     KJ_SPLIT_TRY(exchange(*s, {{"rt_history_validity_input_tex", 2}, {"candidate_radiance_tex", 8 + 3}, {"candidate_hit_tex", 8 + 3}}, st));
     for (uint32_t li = 0; li < s->local; ++li) {
-        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_VALIDITY_INTEGRATE | KEEP, s->strips[s->first + li], 0, st));
-        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_RESTIR_TEMPORAL | KEEP, s->strips[s->first + li], 0, st));
+        // (one call: the library has the two passes as one launch -- a pixel's integrated validity is read by that pixel alone)
+        KJ_SPLIT_TRY(render(*s, li, frames[li], KJ_RTDGI_PASS_VALIDITY_INTEGRATE | KJ_RTDGI_PASS_RESTIR_TEMPORAL | KEEP, s->strips[s->first + li], 0, st));
     }
     // ---- D: the one-deep halo; the spatial passes and the resolve over-compute inside it instead of exchanging again
     KJ_SPLIT_TRY(exchange(*s, {{sfx("rtdgi.reservoir", out_i), 64, 1u}, {"temporal_reservoir_packed_tex", 64, 1u}, {sfx("rtdgi.radiance", out_i), 64, 1u}}, st));
