@@ -418,88 +418,12 @@ struct ValidateTraceArgs {
     int row0, row1;
     uint32_t tiles_y, trace_request_slot_base, trace_request_key_base, order;
 };
-#ifndef KJ_FUSED_SHARED_WALK
-#define KJ_FUSED_SHARED_WALK 0
-#endif
 #ifndef KJ_FUSED_BOTH_WAVES
 #define KJ_FUSED_BOTH_WAVES KJ_FUSED_WAVES
 #endif
 template <bool STATS>
 __global__ void __launch_bounds__(64, KJ_FUSED_BOTH_WAVES) k_rtdgi_validate_and_trace(TraceCtx c, ValidateTraceArgs a) {
     extern __shared__ uint32_t lds_stack[];
-#if KJ_FUSED_SHARED_WALK
-    // KJ_FUSED_SHARED_WALK (round 6 experiment): ONE call site of trace_candidate for both kinds of tiles -- each kind sets the ray up and finishes its own way around it (half the code of two
-    // inlined copies; what a tile keeps across the walk is re-read / re-derived behind it). Same operations on the same values as rtdgi_validate_tile / rtdgi_trace_tile.
-    {
-        const bool is_validate = a.order == 1u ? (blockIdx.y & 1u) == 0u : a.order == 2u ? blockIdx.y >= a.tiles_y : blockIdx.y < a.tiles_y;
-        const uint2 kj_tb = make_uint2(blockIdx.x, a.order == 1u ? blockIdx.y >> 1 : blockIdx.y >= a.tiles_y ? blockIdx.y - a.tiles_y : blockIdx.y);
-        const int row0 = a.row0, row1 = a.row1;
-        RAY_TILE_XY(a.validity_pre_tex.w, a.validity_pre_tex.h, false, kj_tb)
-        if (!in_image) return;
-        const FrameConstants& fc = *c.fc;
-        const I2 off = halfres_subsample_offset(fc.frame_index);
-        const int hx = x * 2 + off.x, hy = y * 2 + off.y;
-        const float depth = c.depth.ld(hx, hy);
-        if (0.0f == depth) {
-            if (is_validate) a.validity_pre_tex.st(x, y, to_unorm8(1.0f));
-            else {
-                st4(a.candidate_irradiance_out_tex, x, y, v4(0.0f));
-                a.candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(V4{0, 0, 1, 0}));
-                a.validity_in_tex.st(x, y, 0);
-            }
-            return;
-        }
-        if (!is_validate) { c.request_slot_base = a.trace_request_slot_base; c.request_key_base = a.trace_request_key_base; }
-        const V3 normal_ws = direction_view_to_world(fc, ld_nrm_snorm8(a.half_view_normal_tex, x, y));
-        V3 ray_o, ray_d; float ray_tmax; uint32_t rng;
-        if (is_validate) {
-            const float4 ro = a.ray_orig_history_tex.ld(x, y);
-            const V3 prev_ray_orig{ro.x, ro.y, ro.z};
-            const V3 prev_hit_pos = xyz(ld4(a.reservoir_ray_history_tex, x, y)) + prev_ray_orig;
-            ray_o = prev_ray_orig; ray_d = normalize(prev_hit_pos - prev_ray_orig); ray_tmax = SKY_DIST; rng = hash3(uint32_t(x), uint32_t(y), 0);
-        } else {
-            const V4 gts = tex_size4(c.depth.w, c.depth.h);
-            const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, get_uv(float(hx), float(hy), gts), depth);
-            const Basis tangent_to_world = build_orthonormal_basis(normal_ws);
-            const V4 bn = blue_noise_for_pixel(c.blue_noise, x, y, fc.frame_index);
-            ray_d = to_world(tangent_to_world, uniform_sample_hemisphere(V2{bn.x, bn.y}));
-            ray_o = vr.biased_secondary_ray_origin_ws_with_normal(normal_ws);
-            ray_tmax = -vr.hit_vs.z * (SSGI_NEAR_FIELD_RADIUS * gts.w * 0.5f);      // (a validation frame: the near field only)
-            rng = hash3(uint32_t(x), uint32_t(y), fc.frame_index & 31u);
-        }
-        TraceResult result = trace_candidate<STATS, false>(c, x, y, normal_ws, rng, ray_o, ray_d, ray_tmax, lds_stack + lane);
-        if (is_validate) {
-            const float4 ro = a.ray_orig_history_tex.ld(x, y);
-            const V3 prev_ray_orig{ro.x, ro.y, ro.z};
-            const V3 prev_hit_pos = xyz(ld4(a.reservoir_ray_history_tex, x, y)) + prev_ray_orig;
-            const V4 prev_radiance_packed = ld4(a.irradiance_history_tex, x, y);
-            const V3 prev_radiance = vmax(v3(0.0f), xyz(prev_radiance_packed));
-            const V3 new_radiance = vmax(v3(0.0f), result.out_value);
-            const float rad_diff = length(vabs(prev_radiance - new_radiance) / vmax(v3(1e-3f), prev_radiance + new_radiance));
-            const float invalidity = smoothstep(0.1f, 0.5f, rad_diff / length(v3(1.0f)));
-            const float prev_hit_dist = length(prev_hit_pos - prev_ray_orig);
-            if (fabsf(result.hit_t - prev_hit_dist) / (prev_hit_dist + prev_hit_dist) < 0.2f) {
-                st4(a.irradiance_history_tex, x, y, v4(new_radiance, prev_radiance_packed.w));
-                Reservoir1spp r = Reservoir1spp::from_raw(a.reservoir_tex.ld(x, y));
-                const float lum_old = sRGB_to_luminance(prev_radiance), lum_new = sRGB_to_luminance(new_radiance);
-                r.M *= clampf(lum_old / fmaxf(1e-8f, lum_new), 0.03f, 1.0f);
-                r.W *= clampf(lum_old / fmaxf(1e-8f, lum_new) * 10.0f, 0.01f, 1.0f);
-                a.reservoir_tex.st(x, y, r.as_raw());
-            }
-            a.validity_pre_tex.st(x, y, to_unorm8(invalidity));
-        } else {
-            const V4 gts = tex_size4(c.depth.w, c.depth.h);
-            const ViewRay vr = view_ray_from_uv_and_biased_depth(fc, get_uv(float(hx), float(hy), gts), depth);
-            if (!result.is_hit) { result.out_value = v3(0.0f); result.hit_t = SKY_DIST; }
-            const V3 hit_offset_ws = ray_d * result.hit_t;
-            const float cos_theta = dot(normalize(ray_d - vr.dir_ws), normal_ws);
-            st4(a.candidate_irradiance_out_tex, x, y, v4(result.out_value, 1.0f - cos_theta));
-            st4(a.candidate_hit_out_tex, x, y, v4(hit_offset_ws, result.pdf * -1.0f));
-            a.candidate_normal_out_tex.st(x, y, pack_rgba8_snorm(v4(direction_world_to_view(fc, result.hit_normal_ws), 0)));
-        }
-        return;
-    }
-#endif
     // dispatch order (workgroups are handed out x-fastest, then y): 0 = every validate tile, then every trace tile (the default); 1 = row by row, validate row then trace row;
     // 2 = the trace tiles first (KJ_RTDGI_FUSE_ORDER, measured: profiles/r06_ray_tile_order.md)
     const bool validate = a.order == 1u ? (blockIdx.y & 1u) == 0u : a.order == 2u ? blockIdx.y >= a.tiles_y : blockIdx.y < a.tiles_y;

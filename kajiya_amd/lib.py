@@ -19,6 +19,8 @@ _MEASURE_SKIP = set(filter(None, os.environ.get("KJ_MEASURE_SKIP", "").split(","
 # where the pipelined frame runs the cache's SH sum-up (IrcacheRenderState::sum_up_irradiance_for_sampling): behind the cache's rays on the cache stream (1) or on the main stream behind
 # its wait for them (0, rounds 1-5)
 _SUMUP_ON_CACHE_STREAM = os.environ.get("KJ_SUMUP_ON_CACHE_STREAM", "1") != "0"
+# the pipelined frame's half-res extract on the SSAO guide's stream beside `rtdgi reproject` (1) or behind it on the main stream (0, rounds 1-6)
+_EXTRACT_BESIDE_REPROJECT = os.environ.get("KJ_EXTRACT_BESIDE_REPROJECT", "0") != "0"
 LIB_PATH = os.environ.get("KJ_AMD_LIB") or os.path.join(HERE, "libkajiya_amd.so")   # KJ_AMD_LIB: A/B a differently built library
 
 EXPORTS = [
@@ -474,18 +476,30 @@ class GpuPipeline:
             if not hasattr(self, "_s3"):
                 self._s3 = torch.cuda.Stream(priority=int(os.environ.get("KJ_PRIO_SSGI", "0")))
                 self._ev_ssgi = [torch.cuda.Event(), torch.cuda.Event()]
+                self._ev_extract = [torch.cuda.Event(), torch.cuda.Event()]
             with torch.cuda.stream(self._s3):
                 self._s3.wait_stream(s0)                         # the caller's work on the current stream up to here: this frame's G-buffer, depth and reprojection map
                 self._s3.wait_event(self._ev_fc[i])
                 if self._pipe_i > 0:
                     self._s3.wait_event(self._ev_gi[1 - i])      # last frame's resolve / filters have read the guide image this call overwrites... (double-buffered: two frames back)
+                if _EXTRACT_BESIDE_REPROJECT:
+                    # the half-res extract (G-buffer inputs only) at the head of THIS stream, beside the main stream's `rtdgi reproject` instead of behind it: everything of last frame
+                    # that reads the half-res images is on the main stream ahead of the wait_stream above
+                    P = KJ_RTDGI_PASS
+                    check(self.L.kj_rtdgi_reproject(self.rtdgi, self.reprojection_map_ptr, self.W, self.H, C.c_void_p(s0.cuda_stream)))      # (host side first: the frame's first rtdgi call; its launch goes to the main stream)
+                    p = self.params(P["EXTRACT_HALF"] | P["EXTRACT_HALF_NO_SSAO"])
+                    check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), _stream_ptr()))
+                    self._ev_extract[i].record(self._s3)
                 self.ssgi_frame()
                 self._ev_ssgi[i].record(self._s3)
         s = _stream_ptr()
         P = KJ_RTDGI_PASS
-        check(self.L.kj_rtdgi_reproject(self.rtdgi, self.reprojection_map_ptr, self.W, self.H, s))
-        p = self.params(P["EXTRACT_HALF"] | (P["EXTRACT_HALF_NO_SSAO"] if overlap_ssgi else 0))
-        check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+        if overlap_ssgi and _EXTRACT_BESIDE_REPROJECT:
+            s0.wait_event(self._ev_extract[i])
+        else:
+            check(self.L.kj_rtdgi_reproject(self.rtdgi, self.reprojection_map_ptr, self.W, self.H, s))
+            p = self.params(P["EXTRACT_HALF"] | (P["EXTRACT_HALF_NO_SSAO"] if overlap_ssgi else 0))
+            check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
         s0.wait_event(self._ev_irc[i])
         if "irc_rays" not in _MEASURE_SKIP and not _SUMUP_ON_CACHE_STREAM:
             check(self.L.kj_ircache_sum_up_irradiance_for_sampling(self.ircache, s))
