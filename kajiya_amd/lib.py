@@ -19,8 +19,8 @@ _MEASURE_SKIP = set(filter(None, os.environ.get("KJ_MEASURE_SKIP", "").split(","
 # where the pipelined frame runs the cache's SH sum-up (IrcacheRenderState::sum_up_irradiance_for_sampling): behind the cache's rays on the cache stream (1) or on the main stream behind
 # its wait for them (0, rounds 1-5)
 _SUMUP_ON_CACHE_STREAM = os.environ.get("KJ_SUMUP_ON_CACHE_STREAM", "1") != "0"
-# the pipelined frame's half-res extract on the SSAO guide's stream beside `rtdgi reproject` (1) or behind it on the main stream (0, rounds 1-6)
-_EXTRACT_BESIDE_REPROJECT = os.environ.get("KJ_EXTRACT_BESIDE_REPROJECT", "0") != "0"
+# the pipelined frame's half-res extract on the SSAO guide's stream beside `rtdgi reproject` (1: -1.3 % per 1080p frame, round 6) or behind it on the main stream (0)
+_EXTRACT_BESIDE_REPROJECT = os.environ.get("KJ_EXTRACT_BESIDE_REPROJECT", "1") != "0"
 LIB_PATH = os.environ.get("KJ_AMD_LIB") or os.path.join(HERE, "libkajiya_amd.so")   # KJ_AMD_LIB: A/B a differently built library
 
 EXPORTS = [
@@ -491,6 +491,9 @@ class GpuPipeline:
                     check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), _stream_ptr()))
                     self._ev_extract[i].record(self._s3)
                 self.ssgi_frame()
+                if _EXTRACT_BESIDE_REPROJECT:      # ... and the guide's half-res copy right behind the guide, on this stream (its readers, `restir spatial` onwards, wait for _ev_ssgi)
+                    p = self.params(KJ_RTDGI_PASS["EXTRACT_HALF_SSAO_ONLY"] | (1 << 31))
+                    check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), _stream_ptr()))
                 self._ev_ssgi[i].record(self._s3)
         s = _stream_ptr()
         P = KJ_RTDGI_PASS
@@ -513,8 +516,9 @@ class GpuPipeline:
             p = self.params(P["VALIDITY_INTEGRATE"] | P["RESTIR_TEMPORAL"] | (1 << 31))
             check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
             s0.wait_event(self._ev_ssgi[i])
-            p = self.params(P["EXTRACT_HALF_SSAO_ONLY"] | (1 << 31))       # params() picks up this frame's guide pointer (ssgi_frame set it)
-            check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
+            if not _EXTRACT_BESIDE_REPROJECT:
+                p = self.params(P["EXTRACT_HALF_SSAO_ONLY"] | (1 << 31))       # params() picks up this frame's guide pointer (ssgi_frame set it)
+                check(self.L.kj_rtdgi_render(self.rtdgi, C.byref(p), C.byref(self.out), s))
             p = self.params((P["ALL"] & ~head & ~P["SPATIAL_FILTER"] & ~P["VALIDITY_INTEGRATE"] & ~P["RESTIR_TEMPORAL"]) | (1 << 31))
         else:
             p = self.params((P["ALL"] & ~head & ~P["SPATIAL_FILTER"]) | (1 << 31))
