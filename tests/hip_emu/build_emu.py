@@ -38,7 +38,15 @@ def sanitizer_preload():
 
 
 def build():
+    """One build at a time: the ranks of a torch.distributed.run launch all come here, and a stale library must not be rebuilt by two of them into the same files."""
+    import fcntl
     os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked()
+
+
+def _build_locked():
     deps = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
         glob.glob(os.path.join(ROOT, "tests", "hip_emu", "hip", "*.h")) + glob.glob(os.path.join(ROOT, "tests", "hip_emu", "hipcub", "*.hpp")) + [os.path.join(ROOT, "include", "kajiya_amd.h"), os.path.abspath(__file__)]
     if os.path.exists(SO) and os.path.getmtime(SO) >= max(os.path.getmtime(d) for d in deps):
