@@ -31,7 +31,16 @@ hipError_t launch_instance_refit(const Bvh4Node* blas_nodes, const uint2* steps,
 // A mesh's BLAS built on the device as a linear BVH (lbvh_build.hip): nodes into d_nodes_out[0 .. node_count) with child node
 // indices offset by node_base, object-space triangles in leaf order into d_tris_out[0 .. index_count / 3). Synchronises the stream.
 struct LbvhResult { static constexpr size_t HEAD_NODES = 341; float bounds[6]; uint32_t node_count, max_stack; std::vector<uint32_t> level_starts; std::vector<Bvh4Node> head; /* the first nodes (the tree is laid out level by level) */ };   // level d (0 = the root) = nodes [level_starts[d], level_starts[d + 1])
-struct LbvhScratch { static constexpr int BUFFERS = 14; DevBuf buf[BUFFERS], tmp, queue_len, level_nodes; uint32_t capacity = 0; };   // the build's working set, reused across meshes
+// The build's working set, reused across meshes: ONE allocation carved into the builder's buffers (round 6: they were 17 allocations, and as many hipFree calls -- each a
+// device synchronisation -- when the commit's scratch went out of scope).
+struct LbvhScratch {
+    static constexpr int BUFFERS = 14, SLOTS = BUFFERS + 4;      // + the sort's temporary storage, the two level arrays, the read-back block
+    DevBuf arena, tmp_extra;
+    void* slot[SLOTS] = {};
+    size_t slot_bytes[SLOTS] = {};
+    uint32_t capacity = 0;
+    std::vector<uint32_t> readback;                             // host copy of the read-back block
+};
 hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s, bool ploc);   // ploc: hierarchy by agglomerative clustering instead of Morton-code splits
 
 // The per-commit top tree built on the device: a linear BVH over the leaves' padded world boxes (six floats each: min xyz, max xyz), every leaf holding one

@@ -47,26 +47,38 @@ __global__ void k_lbvh_init(uint32_t* __restrict__ ob) {   // ordered-uint bound
     if (threadIdx.x < 3) ob[threadIdx.x] = 0xffffffffu;
     else if (threadIdx.x < 6) ob[threadIdx.x] = 0u;
 }
+// (Round 6: the mesh bounds are reduced in LDS first and leave the workgroup as six atomics -- they were six global atomics per TRIANGLE on the same six words:
+// 45 us per 110 k triangles, profiles/r06_blas_builds.md)
+KJ_D void lbvh_bounds_reduce(bool valid, const Box6& b, uint32_t* __restrict__ ob) {
+    __shared__ uint32_t ob_l[6];
+    if (threadIdx.x < 6) ob_l[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+    __syncthreads();
+    if (valid) for (int k = 0; k < 3; ++k) { atomicMin(&ob_l[k], f2o(b.mn[k])); atomicMax(&ob_l[3 + k], f2o(b.mx[k])); }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&ob[threadIdx.x], ob_l[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&ob[threadIdx.x], ob_l[threadIdx.x]);
+}
 __global__ void __launch_bounds__(256) k_lbvh_prims(const uint8_t* __restrict__ vb, GpuMesh m, uint32_t n, Box6* __restrict__ pbox, uint32_t* __restrict__ ob) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     Box6 b;
     for (int k = 0; k < 3; ++k) { b.mn[k] = FLT_MAX; b.mx[k] = -FLT_MAX; }
-    for (int v = 0; v < 3; ++v) {
-        const uint32_t idx = *(const uint32_t*)(vb + m.index_offset + (size_t(i) * 3 + v) * 4);
-        const float* p = (const float*)(vb + m.vertex_core_offset + size_t(idx) * 16);
-        for (int k = 0; k < 3; ++k) { b.mn[k] = fminf(b.mn[k], p[k]); b.mx[k] = fmaxf(b.mx[k], p[k]); }
+    if (i < n) {
+        for (int v = 0; v < 3; ++v) {
+            const uint32_t idx = *(const uint32_t*)(vb + m.index_offset + (size_t(i) * 3 + v) * 4);
+            const float* p = (const float*)(vb + m.vertex_core_offset + size_t(idx) * 16);
+            for (int k = 0; k < 3; ++k) { b.mn[k] = fminf(b.mn[k], p[k]); b.mx[k] = fmaxf(b.mx[k], p[k]); }
+        }
+        pbox[i] = b;
     }
-    pbox[i] = b;
-    for (int k = 0; k < 3; ++k) { atomicMin(&ob[k], f2o(b.mn[k])); atomicMax(&ob[3 + k], f2o(b.mx[k])); }
+    lbvh_bounds_reduce(i < n, b, ob);
 }
 // the top tree's primitives: boxes given as they are (the padded world boxes of the instances' root or opened nodes)
 __global__ void __launch_bounds__(256) k_lbvh_prims_boxes(const Box6* __restrict__ boxes, uint32_t n, Box6* __restrict__ pbox, uint32_t* __restrict__ ob) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const Box6 b = boxes[i];
-    pbox[i] = b;
-    for (int k = 0; k < 3; ++k) { atomicMin(&ob[k], f2o(b.mn[k])); atomicMax(&ob[3 + k], f2o(b.mx[k])); }
+    Box6 b;
+    for (int k = 0; k < 3; ++k) { b.mn[k] = FLT_MAX; b.mx[k] = -FLT_MAX; }
+    if (i < n) { b = boxes[i]; pbox[i] = b; }
+    lbvh_bounds_reduce(i < n, b, ob);
 }
 // 21 bits per axis -> every third bit of a 63-bit code. (Round 2 used 10 bits per axis: in a 250 k-triangle mesh whole neighbourhoods
 // share one 30-bit code, and triangles with equal codes are split by their POSITION in the sorted array, i.e. arbitrarily in space.)
@@ -134,30 +146,68 @@ __global__ void __launch_bounds__(256) k_lbvh_hierarchy(const MortonCode* __rest
     parent[right] = uint32_t(i);
     if (i == 0) parent[0] = 0xffffffffu;
 }
-__global__ void __launch_bounds__(256) k_lbvh_refit(const Box6* __restrict__ pbox, const uint32_t* __restrict__ ids, int n, const uint2* __restrict__ children,
-                                                     const uint32_t* __restrict__ parent, uint32_t* __restrict__ visits, Box6* __restrict__ nbox) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+// Node boxes, bottom-up: a thread per leaf climbs; at every node the first arrival stops and the second, which finds both children's boxes, goes on.
+// Round 6: the climb is local to the workgroup as far as it can be. Internal node i of the radix tree has i as one end of its range of leaves, so the nodes whose
+// range lies inside the workgroup's KJ_REFIT_BLOCK consecutive leaves are the workgroup's own: their links are staged in LDS, their arrival counters and boxes
+// live there, and the climb through them is LDS traffic under workgroup-scope fences. Only the nodes that span workgroups -- ~log2(n / KJ_REFIT_BLOCK) levels, a
+// few arrivals per workgroup -- go through the global counters with device-scope fences, with the links fetched alongside the arrival atomic and the climber's own
+// box kept in registers (only the sibling's is read). Every node of a tree was a chain of global atomics and three device fences per step before:
+// 232 us per 110 k triangles, a quarter of a device build (profiles/r06_blas_builds.md). Same boxes: min / max in the same (left, right) order.
+#define KJ_REFIT_BLOCK 512u
+__global__ void __launch_bounds__(KJ_REFIT_BLOCK) k_lbvh_refit(const Box6* __restrict__ pbox, const uint32_t* __restrict__ ids, int n_, const uint2* __restrict__ children, const uint2* __restrict__ range,
+                                                                const uint32_t* __restrict__ parent, uint32_t* __restrict__ visits, Box6* __restrict__ nbox) {
+    constexpr uint32_t B = KJ_REFIT_BLOCK, NONE = 0xffffffffu;
+    __shared__ Box6 leaf_l[B], node_l[B];      // boxes of leaf base + t / of internal node base + t
+    __shared__ uint2 child_l[B];
+    __shared__ uint32_t parent_l[B], visits_l[B];
+    __shared__ uint8_t own_l[B];               // internal node base + t has its whole range inside this workgroup
+    const uint32_t n = uint32_t(n_), nint = n - 1u, t = threadIdx.x, base = blockIdx.x * B, k = base + t;
+    Box6 mine;
+    uint32_t me = nint + k, cur = NONE;
+    if (k < n) { mine = pbox[ids[k]]; leaf_l[t] = mine; nbox[me] = mine; cur = parent[me]; }
+    visits_l[t] = 0u;
+    own_l[t] = 0;
+    if (k < nint) {
+        const uint2 r = range[k];
+        child_l[t] = children[k]; parent_l[t] = parent[k];
+        own_l[t] = uint8_t(r.x / B == blockIdx.x && r.y / B == blockIdx.x);
+    }
+    __syncthreads();
     if (k >= n) return;
-    nbox[n - 1 + k] = pbox[ids[k]];
-    __threadfence();
-    uint32_t cur = parent[n - 1 + k];
-    while (cur != 0xffffffffu) {
-        if (atomicAdd(&visits[cur], 1u) == 0u) return;     // the first arrival stops; the second has both children's boxes
-        __threadfence();
+    auto unite = [](const Box6& a, const Box6& b) { Box6 u; for (int q = 0; q < 3; ++q) { u.mn[q] = fminf(a.mn[q], b.mn[q]); u.mx[q] = fmaxf(a.mx[q], b.mx[q]); } return u; };
+    // the workgroup's own nodes (cur - base wraps for a node below the block: not ours either)
+    while (cur != NONE && cur - base < B && own_l[cur - base]) {
+        const uint32_t l = cur - base;
+        __threadfence_block();                                   // my box is in LDS before my arrival is
+        if (atomicAdd(&visits_l[l], 1u) == 0u) return;
+        __threadfence_block();
+        const uint2 c = child_l[l];                              // both children lie inside the node's range: leaves / nodes of this workgroup
+        const Box6 a = c.x >= nint ? leaf_l[c.x - nint - base] : node_l[c.x - base];
+        const Box6 b = c.y >= nint ? leaf_l[c.y - nint - base] : node_l[c.y - base];
+        mine = unite(a, b);
+        node_l[l] = mine; nbox[cur] = mine;
+        me = cur; cur = parent_l[l];
+    }
+    // nodes that span workgroups
+    while (cur != NONE) {
         const uint2 c = children[cur];
-        const Box6 a = nbox[c.x], b = nbox[c.y];
-        Box6 u;
-        for (int q = 0; q < 3; ++q) { u.mn[q] = fminf(a.mn[q], b.mn[q]); u.mx[q] = fmaxf(a.mx[q], b.mx[q]); }
-        nbox[cur] = u;
-        __threadfence();
-        cur = parent[cur];
+        const uint32_t up = parent[cur];
+        __threadfence();                                         // release: nbox[me]
+        if (atomicAdd(&visits[cur], 1u) == 0u) return;
+        __threadfence();                                         // acquire: the sibling's box was written before its climber's arrival
+        const bool left = c.x == me;
+        const Box6 sib = nbox[left ? c.y : c.x];
+        mine = left ? unite(mine, sib) : unite(sib, mine);
+        nbox[cur] = mine;
+        me = cur; cur = up;
     }
 }
 // The frame of a 4-wide node (origin + power-of-two step per axis around its children's boxes) ...
 KJ_D void node_frame(const Box6* cb, int nch, Bvh4Node& node, float scale[3]) {
     Box6 frame;
     for (int k = 0; k < 3; ++k) { frame.mn[k] = FLT_MAX; frame.mx[k] = -FLT_MAX; }
-    for (int i = 0; i < nch; ++i) for (int k = 0; k < 3; ++k) { frame.mn[k] = fminf(frame.mn[k], cb[i].mn[k]); frame.mx[k] = fmaxf(frame.mx[k], cb[i].mx[k]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i < nch) for (int k = 0; k < 3; ++k) { frame.mn[k] = fminf(frame.mn[k], cb[i].mn[k]); frame.mx[k] = fmaxf(frame.mx[k], cb[i].mx[k]); }
     memset(&node, 0, sizeof(node));
     for (int k = 0; k < 3; ++k) {
         node.origin[k] = frame.mn[k];
@@ -190,28 +240,62 @@ __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __rest
                                                        Bvh4Node* __restrict__ nodes, uint32_t node_base, uint32_t* __restrict__ level_nodes, uint32_t* __restrict__ level_done,
                                                        uint32_t max_leaf, const uint32_t* __restrict__ leaf_refs, const uint32_t* __restrict__ sorted_ids) {
     // leaf_refs (the top tree): every leaf holds ONE primitive and becomes the child reference leaf_refs[primitive] -- a node of an instance's tree -- as it is
+    // Round 6: everything a binary node contributes -- links, range, box -- is requested in ONE round per opened node (`fetch`), and the choice of the node to
+    // open works on registers. (The text of the selection is unchanged; as written before, is_leaf -> box -> links were three dependent round trips per candidate
+    // and a level cost ~11 of them, ~21 us however few items it had: 14 levels x 9 meshes = a third of a device build, profiles/r06_blas_builds.md.)
     const uint32_t in_count = queue_len[level];
+    struct Bin { uint2 c, r; Box6 b; bool leaf; };
+    auto fetch = [&](uint32_t id) {
+        Bin f;
+        const bool internal = id < uint32_t(n - 1);
+        f.b = nbox[id];
+        f.c = internal ? children[id] : make_uint2(0u, 0u);
+        f.r = internal ? range[id] : make_uint2(0u, 0u);
+        f.leaf = !internal || f.r.y - f.r.x + 1u <= max_leaf;
+        return f;
+    };
     for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < in_count; w += gridDim.x * 64) {
     const CollapseItem it = in[w];
-    auto is_leaf = [&](uint32_t id) { return id >= uint32_t(n - 1) || range[id].y - range[id].x + 1u <= max_leaf; };
-    uint32_t ch[4]; int nch = 0;
-    if (n == 1 || is_leaf(it.bin)) ch[nch++] = n == 1 ? 0u : it.bin;    // whole mesh fits one leaf
-    else { const uint2 c = children[it.bin]; ch[nch++] = c.x; ch[nch++] = c.y; }
-    while (nch < 4) {
-        int best = -1; float ba = -1.0f;
-        for (int i = 0; i < nch; ++i)
-            if (!is_leaf(ch[i])) { const float a = half_area(nbox[ch[i]]); if (a > ba) { ba = a; best = i; } }
-        if (best < 0) break;
-        const uint2 c = children[ch[best]];
-        ch[best] = c.x; ch[nch++] = c.y;
+    uint32_t ch[4] = {0u, 0u, 0u, 0u}; Bin fi[4]; int nch = 0;
+    if (n == 1) { ch[0] = 0u; fi[0].b = nbox[0]; fi[0].leaf = true; fi[0].c = fi[0].r = make_uint2(0u, 0u); nch = 1; }    // whole mesh fits one leaf
+    else {
+        const Bin root = fetch(it.bin);
+        if (root.leaf) { ch[0] = it.bin; fi[0] = root; nch = 1; }
+        else { ch[0] = root.c.x; ch[1] = root.c.y; fi[0] = fetch(ch[0]); fi[1] = fetch(ch[1]); nch = 2; }
+        while (nch < 4) {
+            int best = -1; float ba = -1.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < nch && !fi[i].leaf) { const float a = half_area(fi[i].b); if (a > ba) { ba = a; best = i; } }
+            if (best < 0) break;
+            uint2 c = make_uint2(0u, 0u);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) if (i == best) c = fi[i].c;
+            const Bin fx = fetch(c.x), fy = fetch(c.y);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i == best) { ch[i] = c.x; fi[i] = fx; }
+                if (i == nch) { ch[i] = c.y; fi[i] = fy; }
+            }
+            ++nch;
+        }
     }
     Box6 cb[4];
-    for (int i = 0; i < nch; ++i) cb[i] = nbox[n == 1 ? 0 : ch[i]];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cb[i] = fi[i < nch ? i : 0].b;
     Bvh4Node node;
     float scale[3];
     node_frame(cb, nch, node, scale);
     node.exp8[3] = uint8_t(nch);
     atomicMax(&counters[2], it.depth + uint32_t(nch));     // stack entries below this node + what its visit can push, + 1
+    // node indices and queue places of the children that go on: ONE request each per item (they were a returning atomic per child, one after the other: up to eight
+    // dependent round trips, half of what a level of few items took). Which index a node gets inside its level was never defined; now a node's children are neighbours.
+    uint32_t inner = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) inner += (n != 1 && i < nch && !fi[i].leaf) ? 1u : 0u;
+    uint32_t o = 0u, place = 0u;
+    if (inner) { o = atomicAdd(&counters[1], inner); place = atomicAdd(&queue_len[level + 1], inner); }
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i >= nch) {
             node.child[i] = 0xffffffffu;
@@ -220,24 +304,27 @@ __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __rest
         }
         quantise_child(node, scale, i, cb[i]);
         if (n == 1) node.child[i] = leaf_refs ? leaf_refs[0] : KJ_BVH_LEAF;
-        else if (is_leaf(ch[i])) {
-            const uint32_t first = ch[i] >= uint32_t(n - 1) ? ch[i] - uint32_t(n - 1) : range[ch[i]].x;
-            const uint32_t cnt = ch[i] >= uint32_t(n - 1) ? 1u : range[ch[i]].y - range[ch[i]].x + 1u;
+        else if (fi[i].leaf) {
+            const uint32_t first = ch[i] >= uint32_t(n - 1) ? ch[i] - uint32_t(n - 1) : fi[i].r.x;
+            const uint32_t cnt = ch[i] >= uint32_t(n - 1) ? 1u : fi[i].r.y - fi[i].r.x + 1u;
             node.child[i] = leaf_refs ? leaf_refs[sorted_ids[first]] : (KJ_BVH_LEAF | ((cnt - 1u) << 28) | first);
         } else {
-            const uint32_t o = atomicAdd(&counters[1], 1u);
             node.child[i] = node_base + o;
-            out[atomicAdd(&queue_len[level + 1], 1u)] = CollapseItem{ch[i], o, it.depth + uint32_t(nch - 1)};
+            out[place++] = CollapseItem{ch[i], o++, it.depth + uint32_t(nch - 1)};
         }
     }
     nodes[it.out] = node;
     }
     // the last workgroup of the level to finish records how many nodes exist now: where the next level's nodes start (the levels of a tree are
     // contiguous runs, which the per-instance refit walks deepest first). It was a launch of its own per level.
+    // (Round 6: only the workgroups that had items take part -- the grid is sized by the bound 4^level, and every one of the 3 900 workgroups of a deep, EMPTY level
+    // of a 250 k-triangle mesh queued up at this one counter: 71 us per level.)
+    const uint32_t with_items = min(gridDim.x, max(1u, (in_count + 63u) / 64u));
+    if (blockIdx.x >= with_items) return;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(&level_done[level], 1u) + 1u == gridDim.x) level_nodes[level + 2] = atomicAdd(&counters[1], 0u);
+        if (atomicAdd(&level_done[level], 1u) + 1u == with_items) level_nodes[level + 2] = atomicAdd(&counters[1], 0u);
     }
 }
 __global__ void __launch_bounds__(256) k_lbvh_emit_tris(const uint8_t* __restrict__ vb, GpuMesh m, const uint32_t* __restrict__ ids, uint32_t n, BvhTri* __restrict__ out) {
@@ -453,8 +540,24 @@ __global__ void __launch_bounds__(PLOC_TAIL) k_ploc_tail(uint32_t* __restrict__ 
         const bool mutual = i < m && best_j != PLOC_NONE && ln[best_j] == i;
         const bool makes = mutual && i < best_j, leaves = mutual && i > best_j;
         uint32_t total_made, total_valid;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // both counts of a round from wave votes + sixteen wave totals: two barriers (round 6; the two LDS scans below were forty, half of k_ploc_tail's 314 us per mesh)
+        uint32_t my_node, my_place;
+        {
+            const uint32_t wave = i >> 6, lane = i & 63u;
+            const unsigned long long below = (1ull << lane) - 1ull, bm = __ballot(makes), bv = __ballot(i < m && !leaves);
+            if (lane == 0u) scan[wave] = uint32_t(__popcll(bm)) | (uint32_t(__popcll(bv)) << 16);
+            __syncthreads();
+            uint32_t before = 0u, total = 0u;
+            for (uint32_t w = 0; w < PLOC_TAIL / 64u; ++w) { const uint32_t v = scan[w]; total += v; before += w < wave ? v : 0u; }
+            __syncthreads();
+            my_node = uint32_t(__popcll(bm & below)) + (before & 0xffffu); my_place = uint32_t(__popcll(bv & below)) + (before >> 16);
+            total_made = total & 0xffffu; total_valid = total >> 16;
+        }
+#else
         const uint32_t my_node = tail_exclusive_scan(makes ? 1u : 0u, scan, &total_made);
         const uint32_t my_place = tail_exclusive_scan((i < m && !leaves) ? 1u : 0u, scan, &total_valid);
+#endif
         uint32_t keep = i < m ? lc[i] : PLOC_NONE;
         Box6 kb = i < m ? lb[i] : Box6{};
         if (makes) {
@@ -485,28 +588,54 @@ __global__ void __launch_bounds__(64) k_ploc_collapse(uint32_t n, const uint2* _
                                                        const PlocItem* __restrict__ in, uint32_t* __restrict__ queue_len, uint32_t level, PlocItem* __restrict__ out, uint32_t* __restrict__ counters,
                                                        Bvh4Node* __restrict__ nodes, uint32_t node_base, uint32_t* __restrict__ tri_order, uint32_t* __restrict__ level_nodes, uint32_t* __restrict__ level_done) {
     const uint32_t in_count = queue_len[level];
+    // (round 6: as in k_lbvh_collapse, one round of requests per opened node)
+    struct Bin { uint2 c; uint32_t cnt; Box6 b; bool leaf; };
+    auto fetch = [&](uint32_t id) {
+        Bin f;
+        f.b = nbox[id];
+        f.cnt = cnt[id];
+        f.c = id >= n ? children[id - n] : make_uint2(0u, 0u);
+        f.leaf = (f.cnt & PLOC_LEAF_FLAG) != 0u;
+        return f;
+    };
     for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < in_count; w += gridDim.x * 64) {
         const PlocItem it = in[w];
-        auto is_leaf = [&](uint32_t id) { return (cnt[id] & PLOC_LEAF_FLAG) != 0u; };
-        uint32_t ch[4]; int nch = 0;
-        if (is_leaf(it.bin)) ch[nch++] = it.bin;          // the whole mesh fits one leaf
-        else { const uint2 c = children[it.bin - n]; ch[nch++] = c.x; ch[nch++] = c.y; }
+        uint32_t ch[4] = {0u, 0u, 0u, 0u}; Bin fi[4]; int nch = 0;
+        const Bin root = fetch(it.bin);
+        if (root.leaf) { ch[0] = it.bin; fi[0] = root; nch = 1; }          // the whole mesh fits one leaf
+        else { ch[0] = root.c.x; ch[1] = root.c.y; fi[0] = fetch(ch[0]); fi[1] = fetch(ch[1]); nch = 2; }
         while (nch < 4) {
             int best = -1; float ba = -1.0f;
-            for (int i = 0; i < nch; ++i)
-                if (!is_leaf(ch[i])) { const float a = half_area(nbox[ch[i]]); if (a > ba) { ba = a; best = i; } }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < nch && !fi[i].leaf) { const float a = half_area(fi[i].b); if (a > ba) { ba = a; best = i; } }
             if (best < 0) break;
-            const uint2 c = children[ch[best] - n];
-            ch[best] = c.x; ch[nch++] = c.y;
+            uint2 c = make_uint2(0u, 0u);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) if (i == best) c = fi[i].c;
+            const Bin fx = fetch(c.x), fy = fetch(c.y);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i == best) { ch[i] = c.x; fi[i] = fx; }
+                if (i == nch) { ch[i] = c.y; fi[i] = fy; }
+            }
+            ++nch;
         }
         Box6 cb[4];
-        for (int i = 0; i < nch; ++i) cb[i] = nbox[ch[i]];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cb[i] = fi[i < nch ? i : 0].b;
         Bvh4Node node;
         float scale[3];
         node_frame(cb, nch, node, scale);
         node.exp8[3] = uint8_t(nch);
         atomicMax(&counters[2], it.depth + uint32_t(nch));
         uint32_t first = it.first;
+        uint32_t inner = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) inner += (i < nch && !fi[i].leaf) ? 1u : 0u;
+        uint32_t o = 0u, place = 0u;
+        if (inner) { o = atomicAdd(&counters[1], inner); place = atomicAdd(&queue_len[level + 1], inner); }
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i >= nch) {
                 node.child[i] = 0xffffffffu;
@@ -514,8 +643,8 @@ __global__ void __launch_bounds__(64) k_ploc_collapse(uint32_t n, const uint2* _
                 continue;
             }
             quantise_child(node, scale, i, cb[i]);
-            const uint32_t count = cnt[ch[i]] & ~PLOC_LEAF_FLAG;
-            if (is_leaf(ch[i])) {
+            const uint32_t count = fi[i].cnt & ~PLOC_LEAF_FLAG;
+            if (fi[i].leaf) {
                 node.child[i] = KJ_BVH_LEAF | ((count - 1u) << 28) | first;
                 uint32_t stack[KJ_BVH_MAX_LEAF_TRIS + 1]; int sp = 0; uint32_t o = first;      // the leaf's triangles, left to right
                 stack[sp++] = ch[i];
@@ -525,9 +654,8 @@ __global__ void __launch_bounds__(64) k_ploc_collapse(uint32_t n, const uint2* _
                     else { const uint2 c = children[id - n]; stack[sp++] = c.y; stack[sp++] = c.x; }
                 }
             } else {
-                const uint32_t o = atomicAdd(&counters[1], 1u);
                 node.child[i] = node_base + o;
-                out[atomicAdd(&queue_len[level + 1], 1u)] = PlocItem{ch[i], o, it.depth + uint32_t(nch - 1), first};
+                out[place++] = PlocItem{ch[i], o++, it.depth + uint32_t(nch - 1), first};
             }
             first += count;
         }
@@ -535,11 +663,27 @@ __global__ void __launch_bounds__(64) k_ploc_collapse(uint32_t n, const uint2* _
     }
     // the last workgroup of the level to finish records how many nodes exist now: where the next level's nodes start (the levels of a tree are
     // contiguous runs, which the per-instance refit walks deepest first). It was a launch of its own per level.
+    // (Round 6: only the workgroups that had items take part -- the grid is sized by the bound 4^level, and every one of the 3 900 workgroups of a deep, EMPTY level
+    // of a 250 k-triangle mesh queued up at this one counter: 71 us per level.)
+    const uint32_t with_items = min(gridDim.x, max(1u, (in_count + 63u) / 64u));
+    if (blockIdx.x >= with_items) return;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(&level_done[level], 1u) + 1u == gridDim.x) level_nodes[level + 2] = atomicAdd(&counters[1], 0u);
+        if (atomicAdd(&level_done[level], 1u) + 1u == with_items) level_nodes[level + 2] = atomicAdd(&counters[1], 0u);
     }
+}
+
+// What the host reads after a batch of levels, gathered into one block: [levels | queue lengths | counters[4] | bounds[8] | the tree's first nodes]
+#define KJ_LBVH_READBACK_HEAD (2u * (KJ_LBVH_BATCH + 2u) + 4u + 8u)
+#define KJ_LBVH_READBACK_DWORDS (KJ_LBVH_READBACK_HEAD + uint32_t(kj::LbvhResult::HEAD_NODES * sizeof(kj::Bvh4Node) / 4))
+__global__ void __launch_bounds__(256) k_lbvh_pack_results(const uint32_t* __restrict__ level_nodes, const uint32_t* __restrict__ queue_len, const uint32_t* __restrict__ counters,
+                                                            const uint32_t* __restrict__ ob, const uint32_t* __restrict__ head, uint32_t head_dwords, uint32_t* __restrict__ out) {
+    const uint32_t t = threadIdx.x, L = KJ_LBVH_BATCH + 2u;
+    if (t < L) { out[t] = level_nodes[t]; out[L + t] = queue_len[t]; }
+    if (t < 4u) out[2u * L + t] = counters[t];
+    if (t < 8u) out[2u * L + 4u + t] = t < 6u ? ob[t] : 0u;
+    for (uint32_t i = t; i < head_dwords; i += 256u) out[KJ_LBVH_READBACK_HEAD + i] = head[i];
 }
 
 }  // namespace
@@ -556,26 +700,33 @@ static hipError_t build_lbvh(const uint8_t* d_vertex_buffer, const GpuMesh& mesh
     // third of a nine-mesh build: hipFree synchronises the device) and grown when a larger mesh comes along
     if (scratch->capacity < n) {
         const size_t c = size_t(n) + n / 4;
-        const size_t sizes[LbvhScratch::BUFFERS] = {c * sizeof(Box6), 32, c * 8, c * 4, c * 8, c * 4, c * 8, c * 8, 2 * c * 4, c * 4, 2 * c * sizeof(Box6),
-                                                    (c + 1) * sizeof(PlocItem), (c + 1) * sizeof(PlocItem), 64};
-        for (int k = 0; k < LbvhScratch::BUFFERS; ++k) KJ_LB(scratch->buf[k].alloc(sizes[k], s));
+        size_t sort_bytes = 0;
+        KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const MortonCode*)nullptr, (MortonCode*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, int(c), 0, 3 * KJ_MORTON_BITS, s));
+        const size_t sizes[LbvhScratch::SLOTS] = {c * sizeof(Box6), 32, c * 8, c * 4, c * 8, c * 4, c * 8, c * 8, 2 * c * 4, c * 4, 2 * c * sizeof(Box6),
+                                                  (c + 1) * sizeof(PlocItem), (c + 1) * sizeof(PlocItem), 64,
+                                                  std::max<size_t>(sort_bytes, 16), (KJ_LBVH_BATCH + 2) * 4, (2 * KJ_LBVH_BATCH + 4) * 4, KJ_LBVH_READBACK_DWORDS * 4};
+        size_t total = 0;
+        for (int k = 0; k < LbvhScratch::SLOTS; ++k) total += (sizes[k] + 255) & ~size_t(255);
+        KJ_LB(scratch->arena.alloc(total, s));
+        size_t at = 0;
+        for (int k = 0; k < LbvhScratch::SLOTS; ++k) { scratch->slot[k] = (uint8_t*)scratch->arena.p + at; scratch->slot_bytes[k] = sizes[k]; at += (sizes[k] + 255) & ~size_t(255); }
         scratch->capacity = uint32_t(c);
     }
     // typed views of the working set (a buffer serves several stages: what PLOC clusters in is what the sort is done with)
-    Box6* const pbox = (Box6*)scratch->buf[0].p;
-    uint32_t* const ob = (uint32_t*)scratch->buf[1].p;
-    MortonCode* const codes = (MortonCode*)scratch->buf[2].p;
-    uint32_t* const ids = (uint32_t*)scratch->buf[3].p;
-    MortonCode* const codes2 = (MortonCode*)scratch->buf[4].p;
-    uint32_t* const ids2 = (uint32_t*)scratch->buf[5].p;            // triangle ids in Morton order
-    uint2* const children = (uint2*)scratch->buf[6].p;
-    uint2* const range = (uint2*)scratch->buf[7].p;
-    uint32_t* const parent = (uint32_t*)scratch->buf[8].p;
-    uint32_t* const visits = (uint32_t*)scratch->buf[9].p;
-    Box6* const nbox = (Box6*)scratch->buf[10].p;
-    void* const q0 = scratch->buf[11].p; void* const q1 = scratch->buf[12].p;
-    uint32_t* const counters = (uint32_t*)scratch->buf[13].p;
-    DevBuf& tmp = scratch->tmp;
+    void* const* const slot = scratch->slot;
+    Box6* const pbox = (Box6*)slot[0];
+    uint32_t* const ob = (uint32_t*)slot[1];
+    MortonCode* const codes = (MortonCode*)slot[2];
+    uint32_t* const ids = (uint32_t*)slot[3];
+    MortonCode* const codes2 = (MortonCode*)slot[4];
+    uint32_t* const ids2 = (uint32_t*)slot[5];            // triangle ids in Morton order
+    uint2* const children = (uint2*)slot[6];
+    uint2* const range = (uint2*)slot[7];
+    uint32_t* const parent = (uint32_t*)slot[8];
+    uint32_t* const visits = (uint32_t*)slot[9];
+    Box6* const nbox = (Box6*)slot[10];
+    void* const q0 = slot[11]; void* const q1 = slot[12];
+    uint32_t* const counters = (uint32_t*)slot[13];
     const uint32_t cap = scratch->capacity;
     uint32_t* const clusters = (uint32_t*)codes;              // PLOC: the cluster list, ...
     uint32_t* const merged = (uint32_t*)codes + cap;          // ... its next state before compaction,
@@ -593,8 +744,12 @@ static hipError_t build_lbvh(const uint8_t* d_vertex_buffer, const GpuMesh& mesh
     hipLaunchKernelGGL(k_lbvh_morton, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ob, n, codes, ids);
     size_t tmp_bytes = 0;
     KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const MortonCode*)codes, codes2, (const uint32_t*)ids, ids2, int(n), 0, 3 * KJ_MORTON_BITS, s));
-    if (tmp.bytes < (tmp_bytes ? tmp_bytes : 16)) KJ_LB(tmp.alloc(tmp_bytes ? tmp_bytes : 16, s));
-    KJ_LB(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (const MortonCode*)codes, codes2, (const uint32_t*)ids, ids2, int(n), 0, 3 * KJ_MORTON_BITS, s));
+    void* sort_tmp = slot[LbvhScratch::BUFFERS];
+    if (tmp_bytes > scratch->slot_bytes[LbvhScratch::BUFFERS]) {      // (the reservation was sized for the capacity: a smaller mesh asking for more is not expected)
+        if (scratch->tmp_extra.bytes < tmp_bytes) KJ_LB(scratch->tmp_extra.alloc(tmp_bytes, s));
+        sort_tmp = scratch->tmp_extra.p;
+    }
+    KJ_LB(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tmp_bytes, (const MortonCode*)codes, codes2, (const uint32_t*)ids, ids2, int(n), 0, 3 * KJ_MORTON_BITS, s));
     if (ploc) {
         KJ_LB(hipMemsetAsync(counters, 0, 64, s));
         hipLaunchKernelGGL(k_ploc_init, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ids2, n, nbox, cnt, cost, clusters, mcount);
@@ -616,15 +771,16 @@ static hipError_t build_lbvh(const uint8_t* d_vertex_buffer, const GpuMesh& mesh
     } else {
         if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, g, b, 0, s, (const MortonCode*)codes2, int(n), children, range, parent);
         else KJ_LB(hipMemsetAsync(parent, 0xff, 8, s));
-        hipLaunchKernelGGL(k_lbvh_refit, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ids2, int(n), (const uint2*)children, (const uint32_t*)parent, visits, nbox);
+        hipLaunchKernelGGL(k_lbvh_refit, dim3((n + KJ_REFIT_BLOCK - 1) / KJ_REFIT_BLOCK), dim3(KJ_REFIT_BLOCK), 0, s, (const Box6*)pbox, (const uint32_t*)ids2, int(n), (const uint2*)children, (const uint2*)range,
+                           (const uint32_t*)parent, visits, nbox);
     }
     // collapse, level by level: counters = {-, nodes allocated, max stack}; queue_len[l] = items of level l (the kernel of level l appends to
     // queue_len[l + 1]); level_nodes[l] = nodes allocated before level l's children (a level's nodes are one contiguous run). Levels are
     // issued KJ_LBVH_BATCH at a time without looking at the queues -- every launch is sized by the bound 4^level, <= one item per triangle --,
     // then ONE read-back says whether the tree goes deeper (a 250 k-triangle mesh has ~13 levels; many coincident centroids make deep ones).
-    KJ_LB(scratch->queue_len.alloc((KJ_LBVH_BATCH + 2) * 4, s)); KJ_LB(scratch->level_nodes.alloc((2 * KJ_LBVH_BATCH + 4) * 4, s));      // (no-ops after the first mesh)
-    uint32_t* const queue_len = (uint32_t*)scratch->queue_len.p;
-    uint32_t* const level_nodes = (uint32_t*)scratch->level_nodes.p;       // [0 .. BATCH + 2): nodes before each level; then one arrival counter per level
+    uint32_t* const queue_len = (uint32_t*)slot[LbvhScratch::BUFFERS + 1];
+    uint32_t* const level_nodes = (uint32_t*)slot[LbvhScratch::BUFFERS + 2];       // [0 .. BATCH + 2): nodes before each level; then one arrival counter per level
+    uint32_t* const readback = (uint32_t*)slot[LbvhScratch::BUFFERS + 3];
     uint32_t* const level_done = level_nodes + KJ_LBVH_BATCH + 2;
     const uint32_t init_counters[4] = {0u, 1u, 0u, 0u};
     const CollapseItem root{0u, 0u, 0u};
@@ -660,12 +816,20 @@ static hipError_t build_lbvh(const uint8_t* d_vertex_buffer, const GpuMesh& mesh
         // everything else the caller needs rides the same read-back: a tree that fits one batch (every mesh so far) costs ONE synchronisation.
         // (The triangles in leaf order: PLOC's order is written by the collapse; if the tree turns out deeper, the last batch emits them again.)
         if (!top) hipLaunchKernelGGL(k_lbvh_emit_tris, g, b, 0, s, d_vertex_buffer, mesh, ploc ? (const uint32_t*)tri_order : (const uint32_t*)ids2, n, d_tris_out);
-        KJ_LB(hipMemcpyAsync(host_levels, level_nodes, sizeof(host_levels), hipMemcpyDeviceToHost, s));
-        KJ_LB(hipMemcpyAsync(host_queue, queue_len, sizeof(host_queue), hipMemcpyDeviceToHost, s));
-        KJ_LB(hipMemcpyAsync(host_counters, counters, 16, hipMemcpyDeviceToHost, s));
-        KJ_LB(hipMemcpyAsync(hob, ob, 24, hipMemcpyDeviceToHost, s));
-        if (!result->head.empty()) KJ_LB(hipMemcpyAsync(result->head.data(), d_nodes_out, result->head.size() * sizeof(Bvh4Node), hipMemcpyDeviceToHost, s));      // the top levels, for the caller's top-tree build
+        // (round 6: ONE copy -- the five pieces are gathered into a block on the device first; five copies into pageable memory were ~100 us of idle GPU per mesh)
+        const uint32_t head_count = uint32_t(result->head.size());      // the top levels, for the caller's top-tree build
+        hipLaunchKernelGGL(k_lbvh_pack_results, dim3(1), dim3(256), 0, s, (const uint32_t*)level_nodes, (const uint32_t*)queue_len, (const uint32_t*)counters, (const uint32_t*)ob,
+                           (const uint32_t*)d_nodes_out, head_count * uint32_t(sizeof(Bvh4Node) / 4), readback);
+        const size_t rb_dwords = KJ_LBVH_READBACK_HEAD + size_t(head_count) * (sizeof(Bvh4Node) / 4);
+        scratch->readback.resize(KJ_LBVH_READBACK_DWORDS);
+        KJ_LB(hipMemcpyAsync(scratch->readback.data(), readback, rb_dwords * 4, hipMemcpyDeviceToHost, s));
         KJ_LB(hipStreamSynchronize(s));
+        {
+            const uint32_t* rb = scratch->readback.data();
+            memcpy(host_levels, rb, sizeof(host_levels)); memcpy(host_queue, rb + (KJ_LBVH_BATCH + 2), sizeof(host_queue));
+            memcpy(host_counters, rb + 2 * (KJ_LBVH_BATCH + 2), 16); memcpy(hob, rb + 2 * (KJ_LBVH_BATCH + 2) + 4, 24);
+            if (head_count) memcpy(result->head.data(), rb + KJ_LBVH_READBACK_HEAD, size_t(head_count) * sizeof(Bvh4Node));
+        }
         for (uint32_t l = 1; l <= KJ_LBVH_BATCH + 1; ++l)
             if (host_levels[l] > result->level_starts.back()) result->level_starts.push_back(host_levels[l]);
         in_count = host_queue[KJ_LBVH_BATCH];

@@ -331,6 +331,15 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         return e;
     };
     LbvhScratch lbvh_scratch;     // device-side builds of this commit share their working buffers
+    {   // the pools grow ONCE for all device-side builds of the commit (at most one node per triangle): a reallocation per mesh was a hipMalloc + copy + hipFree between two builds
+        size_t more_nodes = 0, more_tris = 0;
+        for (uint32_t mi = 0; mi < s->meshes.size(); ++mi)
+            if (!s->blas[mi].built && s->mesh_build_mode[mi] != 0) { const size_t ntri = s->meshes[mi].index_count / 3; more_nodes += ntri + 1; more_tris += ntri; }
+        if (more_nodes) {
+            KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), (size_t(s->blas_nodes_used) + more_nodes) * sizeof(BvhNode)));
+            KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), (size_t(s->obj_tris_used) + more_tris) * sizeof(BvhTri)));
+        }
+    }
     // host SAH builds of all new meshes run concurrently (a small mesh builds on one thread: nine of them one after the other were
     // half of a first commit); each result is the same tree whatever runs beside it
     auto host_build = [s](uint32_t mi) {
