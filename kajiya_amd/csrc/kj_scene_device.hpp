@@ -31,16 +31,14 @@ hipError_t launch_instance_refit(const Bvh4Node* blas_nodes, const uint2* steps,
 // A mesh's BLAS built on the device as a linear BVH (lbvh_build.hip): nodes into d_nodes_out[0 .. node_count) with child node
 // indices offset by node_base, object-space triangles in leaf order into d_tris_out[0 .. index_count / 3). Synchronises the stream.
 struct LbvhResult { static constexpr size_t HEAD_NODES = 341; float bounds[6]; uint32_t node_count, max_stack; std::vector<uint32_t> level_starts; std::vector<Bvh4Node> head; /* the first nodes (the tree is laid out level by level) */ };   // level d (0 = the root) = nodes [level_starts[d], level_starts[d + 1])
-// The build's working set, reused across meshes: ONE allocation carved into the builder's buffers (round 6: they were 17 allocations, and as many hipFree calls -- each a
-// device synchronisation -- when the commit's scratch went out of scope).
-struct LbvhScratch {
-    static constexpr int BUFFERS = 14, SLOTS = BUFFERS + 4;      // + the sort's temporary storage, the two level arrays, the read-back block
-    DevBuf arena, tmp_extra;
-    void* slot[SLOTS] = {};
-    size_t slot_bytes[SLOTS] = {};
-    uint32_t capacity = 0;
-    std::vector<uint32_t> readback;                             // host copy of the read-back block
-};
+// The builder's working set: ONE allocation, grown when a call needs more and carved into the call's buffers (round 6: it was 17 allocations per commit, and as many
+// hipFree calls -- each a device synchronisation -- when the commit's scratch went out of scope).
+struct LbvhScratch { DevBuf arena; std::vector<uint32_t> readback; /* host copy of the builder's read-back block */ };
+// The meshes of a commit as ONE batch: the per-mesh stages one after the other, the 4-wide collapse level by level for all meshes together, one read-back.
+struct LbvhBatchMesh { GpuMesh mesh; uint32_t node_base; Bvh4Node* nodes_out; BvhTri* tris_out; LbvhResult* result; };
+// nodes[0 .. count) of a tree with mesh-relative child indices -> dst, inner child indices + node_base
+hipError_t launch_blas_place_nodes(const Bvh4Node* src, Bvh4Node* dst, uint32_t count, uint32_t node_base, hipStream_t s);
+hipError_t build_blas_lbvh_device_batch(const uint8_t* d_vertex_buffer, const LbvhBatchMesh* batch, uint32_t count, LbvhScratch* scratch, hipStream_t s, bool ploc);
 hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s, bool ploc);   // ploc: hierarchy by agglomerative clustering instead of Morton-code splits
 
 // The per-commit top tree built on the device: a linear BVH over the leaves' padded world boxes (six floats each: min xyz, max xyz), every leaf holding one

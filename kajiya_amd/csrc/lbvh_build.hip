@@ -26,6 +26,7 @@
 #include "kj_scene_device.hpp"
 #include "kj_vec.hpp"
 #include <cfloat>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 
@@ -43,9 +44,9 @@ KJ_D float half_area(const Box6& b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-__global__ void k_lbvh_init(uint32_t* __restrict__ ob) {   // ordered-uint bounds: min = +inf, max = -inf
-    if (threadIdx.x < 3) ob[threadIdx.x] = 0xffffffffu;
-    else if (threadIdx.x < 6) ob[threadIdx.x] = 0u;
+__global__ void __launch_bounds__(64) k_lbvh_init(uint32_t* __restrict__ ob, uint32_t meshes) {   // ordered-uint bounds of every mesh of the batch (8 dwords each): min = +inf, max = -inf
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i < meshes * 8u) ob[i] = (i & 7u) < 3u ? 0xffffffffu : 0u;
 }
 // (Round 6: the mesh bounds are reduced in LDS first and leave the workgroup as six atomics -- they were six global atomics per TRIANGLE on the same six words:
 // 45 us per 110 k triangles, profiles/r06_blas_builds.md)
@@ -58,8 +59,9 @@ KJ_D void lbvh_bounds_reduce(bool valid, const Box6& b, uint32_t* __restrict__ o
     if (threadIdx.x < 3) atomicMin(&ob[threadIdx.x], ob_l[threadIdx.x]);
     else if (threadIdx.x < 6) atomicMax(&ob[threadIdx.x], ob_l[threadIdx.x]);
 }
-__global__ void __launch_bounds__(256) k_lbvh_prims(const uint8_t* __restrict__ vb, GpuMesh m, uint32_t n, Box6* __restrict__ pbox, uint32_t* __restrict__ ob) {
+__global__ void __launch_bounds__(256) k_lbvh_prims(const uint8_t* __restrict__ vb, GpuMesh m, uint32_t n, Box6* __restrict__ pbox, uint32_t* __restrict__ ob, uint32_t* __restrict__ visits) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) visits[i] = 0u;      // the refit's arrival counters (was a fill of its own)
     Box6 b;
     for (int k = 0; k < 3; ++k) { b.mn[k] = FLT_MAX; b.mx[k] = -FLT_MAX; }
     if (i < n) {
@@ -73,8 +75,9 @@ __global__ void __launch_bounds__(256) k_lbvh_prims(const uint8_t* __restrict__ 
     lbvh_bounds_reduce(i < n, b, ob);
 }
 // the top tree's primitives: boxes given as they are (the padded world boxes of the instances' root or opened nodes)
-__global__ void __launch_bounds__(256) k_lbvh_prims_boxes(const Box6* __restrict__ boxes, uint32_t n, Box6* __restrict__ pbox, uint32_t* __restrict__ ob) {
+__global__ void __launch_bounds__(256) k_lbvh_prims_boxes(const Box6* __restrict__ boxes, uint32_t n, Box6* __restrict__ pbox, uint32_t* __restrict__ ob, uint32_t* __restrict__ visits) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) visits[i] = 0u;
     Box6 b;
     for (int k = 0; k < 3; ++k) { b.mn[k] = FLT_MAX; b.mx[k] = -FLT_MAX; }
     if (i < n) { b = boxes[i]; pbox[i] = b; }
@@ -231,20 +234,34 @@ KJ_D void quantise_child(Bvh4Node& node, const float scale[3], int i, const Box6
         node.qlo[k][i] = uint8_t(lo); node.qhi[k][i] = uint8_t(hi);
     }
 }
-// One level of the 4-wide tree. item = (binary internal node, output node index, depth).
-struct CollapseItem { uint32_t bin, out, depth; };
+// One level of the 4-wide trees of ALL meshes of a batch. item = (binary internal node, output node index, depth, mesh).
+// Round 6: the collapse is batched over the meshes of a commit -- a level is one launch for all of them. A level of a small mesh is a chain of ~8 dependent round
+// trips whatever its item count (14-25 us), and nine meshes one after the other paid it nine times per level: half of a device build (profiles/r06_blas_builds.md).
+struct CollapseMesh {
+    uint32_t n, node_base, max_leaf, head_dwords;
+    const uint2* children; const uint2* range; const uint32_t* cnt; const Box6* nbox; const uint32_t* sorted_ids; const uint32_t* leaf_refs;
+    const uint32_t* root_cluster; const uint32_t* ob;
+    Bvh4Node* nodes; uint32_t* tri_order; uint32_t* counters /*[1] = nodes, [2] = max depth*/; uint32_t* level_nodes;
+};
+struct CollapseItem { uint32_t bin, out, depth, mesh; };
 // The level's queue length lives on the device (queue_len[level]; the kernel appends to queue_len[level + 1]): the host launches every
-// level with a grid that is large enough by construction (<= 4^level items, <= one per triangle) and reads nothing back in between.
-__global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __restrict__ children, const uint2* __restrict__ range, const Box6* __restrict__ nbox, const CollapseItem* __restrict__ in,
-                                                       uint32_t* __restrict__ queue_len, uint32_t level, CollapseItem* __restrict__ out, uint32_t* __restrict__ counters /*[1]=nodes, [2]=max depth*/,
-                                                       Bvh4Node* __restrict__ nodes, uint32_t node_base, uint32_t* __restrict__ level_nodes, uint32_t* __restrict__ level_done,
-                                                       uint32_t max_leaf, const uint32_t* __restrict__ leaf_refs, const uint32_t* __restrict__ sorted_ids) {
+// level with a grid that is large enough by construction (<= 4^level items per mesh, <= one per triangle) and reads nothing back in between.
+__global__ void __launch_bounds__(64) k_lbvh_collapse(const CollapseMesh* __restrict__ meshes, const CollapseItem* __restrict__ in, uint32_t* __restrict__ queue_len, uint32_t level,
+                                                       CollapseItem* __restrict__ out) {
     // leaf_refs (the top tree): every leaf holds ONE primitive and becomes the child reference leaf_refs[primitive] -- a node of an instance's tree -- as it is
     // Round 6: everything a binary node contributes -- links, range, box -- is requested in ONE round per opened node (`fetch`), and the choice of the node to
     // open works on registers. (The text of the selection is unchanged; as written before, is_leaf -> box -> links were three dependent round trips per candidate
     // and a level cost ~11 of them, ~21 us however few items it had: 14 levels x 9 meshes = a third of a device build, profiles/r06_blas_builds.md.)
     const uint32_t in_count = queue_len[level];
     struct Bin { uint2 c, r; Box6 b; bool leaf; };
+    for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < in_count; w += gridDim.x * 64) {
+    const CollapseItem it = in[w];
+    const CollapseMesh& M = meshes[it.mesh];
+    const int n = int(M.n);
+    const uint2* __restrict__ children = M.children; const uint2* __restrict__ range = M.range; const Box6* __restrict__ nbox = M.nbox;
+    const uint32_t* __restrict__ leaf_refs = M.leaf_refs; const uint32_t* __restrict__ sorted_ids = M.sorted_ids;
+    uint32_t* const counters = M.counters; Bvh4Node* const nodes = M.nodes;
+    const uint32_t max_leaf = M.max_leaf, node_base = M.node_base;
     auto fetch = [&](uint32_t id) {
         Bin f;
         const bool internal = id < uint32_t(n - 1);
@@ -254,8 +271,6 @@ __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __rest
         f.leaf = !internal || f.r.y - f.r.x + 1u <= max_leaf;
         return f;
     };
-    for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < in_count; w += gridDim.x * 64) {
-    const CollapseItem it = in[w];
     uint32_t ch[4] = {0u, 0u, 0u, 0u}; Bin fi[4]; int nch = 0;
     if (n == 1) { ch[0] = 0u; fi[0].b = nbox[0]; fi[0].leaf = true; fi[0].c = fi[0].r = make_uint2(0u, 0u); nch = 1; }    // whole mesh fits one leaf
     else {
@@ -310,22 +325,16 @@ __global__ void __launch_bounds__(64) k_lbvh_collapse(int n, const uint2* __rest
             node.child[i] = leaf_refs ? leaf_refs[sorted_ids[first]] : (KJ_BVH_LEAF | ((cnt - 1u) << 28) | first);
         } else {
             node.child[i] = node_base + o;
-            out[place++] = CollapseItem{ch[i], o++, it.depth + uint32_t(nch - 1)};
+            out[place++] = CollapseItem{ch[i], o++, it.depth + uint32_t(nch - 1), it.mesh};
         }
     }
     nodes[it.out] = node;
     }
-    // the last workgroup of the level to finish records how many nodes exist now: where the next level's nodes start (the levels of a tree are
-    // contiguous runs, which the per-instance refit walks deepest first). It was a launch of its own per level.
-    // (Round 6: only the workgroups that had items take part -- the grid is sized by the bound 4^level, and every one of the 3 900 workgroups of a deep, EMPTY level
-    // of a 250 k-triangle mesh queued up at this one counter: 71 us per level.)
-    const uint32_t with_items = min(gridDim.x, max(1u, (in_count + 63u) / 64u));
-    if (blockIdx.x >= with_items) return;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&level_done[level], 1u) + 1u == with_items) level_nodes[level + 2] = atomicAdd(&counters[1], 0u);
-    }
+}
+// After a level: where every mesh's next level starts (the levels of a tree are contiguous runs, which the per-instance refit walks deepest first).
+__global__ void __launch_bounds__(64) k_collapse_record_level(const CollapseMesh* __restrict__ meshes, uint32_t nmesh, uint32_t level) {
+    const uint32_t m = blockIdx.x * 64 + threadIdx.x;
+    if (m < nmesh) meshes[m].level_nodes[level + 2] = meshes[m].counters[1];
 }
 __global__ void __launch_bounds__(256) k_lbvh_emit_tris(const uint8_t* __restrict__ vb, GpuMesh m, const uint32_t* __restrict__ ids, uint32_t n, BvhTri* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -581,25 +590,26 @@ __global__ void __launch_bounds__(PLOC_TAIL) k_ploc_tail(uint32_t* __restrict__ 
     }
     if (i == 0) { clusters[0] = lc[0]; mcount[0] = 1u; mcount[1] = made; }
 }
-struct PlocItem { uint32_t bin, out, depth, first; };
-__global__ void k_ploc_root(const uint32_t* __restrict__ clusters, PlocItem* __restrict__ q) { q[0] = PlocItem{clusters[0], 0u, 0u, 0u}; }
-// One level of the 4-wide tree over the PLOC hierarchy: as k_lbvh_collapse, plus the top-down hand-out of triangle slots.
-__global__ void __launch_bounds__(64) k_ploc_collapse(uint32_t n, const uint2* __restrict__ children, const uint32_t* __restrict__ cnt, const Box6* __restrict__ nbox, const uint32_t* __restrict__ sorted_ids,
-                                                       const PlocItem* __restrict__ in, uint32_t* __restrict__ queue_len, uint32_t level, PlocItem* __restrict__ out, uint32_t* __restrict__ counters,
-                                                       Bvh4Node* __restrict__ nodes, uint32_t node_base, uint32_t* __restrict__ tri_order, uint32_t* __restrict__ level_nodes, uint32_t* __restrict__ level_done) {
+struct PlocItem { uint32_t bin, out, depth, first, mesh; };
+// One level of the 4-wide trees over the PLOC hierarchies of a batch: as k_lbvh_collapse, plus the top-down hand-out of triangle slots.
+__global__ void __launch_bounds__(64) k_ploc_collapse(const CollapseMesh* __restrict__ meshes, const PlocItem* __restrict__ in, uint32_t* __restrict__ queue_len, uint32_t level, PlocItem* __restrict__ out) {
     const uint32_t in_count = queue_len[level];
     // (round 6: as in k_lbvh_collapse, one round of requests per opened node)
     struct Bin { uint2 c; uint32_t cnt; Box6 b; bool leaf; };
-    auto fetch = [&](uint32_t id) {
-        Bin f;
-        f.b = nbox[id];
-        f.cnt = cnt[id];
-        f.c = id >= n ? children[id - n] : make_uint2(0u, 0u);
-        f.leaf = (f.cnt & PLOC_LEAF_FLAG) != 0u;
-        return f;
-    };
     for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < in_count; w += gridDim.x * 64) {
         const PlocItem it = in[w];
+        const CollapseMesh& M = meshes[it.mesh];
+        const uint32_t n = M.n, node_base = M.node_base;
+        const uint2* __restrict__ children = M.children; const uint32_t* __restrict__ cnt = M.cnt; const Box6* __restrict__ nbox = M.nbox; const uint32_t* __restrict__ sorted_ids = M.sorted_ids;
+        uint32_t* const counters = M.counters; uint32_t* const tri_order = M.tri_order; Bvh4Node* const nodes = M.nodes;
+        auto fetch = [&](uint32_t id) {
+            Bin f;
+            f.b = nbox[id];
+            f.cnt = cnt[id];
+            f.c = id >= n ? children[id - n] : make_uint2(0u, 0u);
+            f.leaf = (f.cnt & PLOC_LEAF_FLAG) != 0u;
+            return f;
+        };
         uint32_t ch[4] = {0u, 0u, 0u, 0u}; Bin fi[4]; int nch = 0;
         const Bin root = fetch(it.bin);
         if (root.leaf) { ch[0] = it.bin; fi[0] = root; nch = 1; }          // the whole mesh fits one leaf
@@ -655,35 +665,57 @@ __global__ void __launch_bounds__(64) k_ploc_collapse(uint32_t n, const uint2* _
                 }
             } else {
                 node.child[i] = node_base + o;
-                out[place++] = PlocItem{ch[i], o++, it.depth + uint32_t(nch - 1), first};
+                out[place++] = PlocItem{ch[i], o++, it.depth + uint32_t(nch - 1), first, it.mesh};
             }
             first += count;
         }
         nodes[it.out] = node;
     }
-    // the last workgroup of the level to finish records how many nodes exist now: where the next level's nodes start (the levels of a tree are
-    // contiguous runs, which the per-instance refit walks deepest first). It was a launch of its own per level.
-    // (Round 6: only the workgroups that had items take part -- the grid is sized by the bound 4^level, and every one of the 3 900 workgroups of a deep, EMPTY level
-    // of a 250 k-triangle mesh queued up at this one counter: 71 us per level.)
-    const uint32_t with_items = min(gridDim.x, max(1u, (in_count + 63u) / 64u));
-    if (blockIdx.x >= with_items) return;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&level_done[level], 1u) + 1u == with_items) level_nodes[level + 2] = atomicAdd(&counters[1], 0u);
-    }
 }
 
-// What the host reads after a batch of levels, gathered into one block: [levels | queue lengths | counters[4] | bounds[8] | the tree's first nodes]
-#define KJ_LBVH_READBACK_HEAD (2u * (KJ_LBVH_BATCH + 2u) + 4u + 8u)
-#define KJ_LBVH_READBACK_DWORDS (KJ_LBVH_READBACK_HEAD + uint32_t(kj::LbvhResult::HEAD_NODES * sizeof(kj::Bvh4Node) / 4))
-__global__ void __launch_bounds__(256) k_lbvh_pack_results(const uint32_t* __restrict__ level_nodes, const uint32_t* __restrict__ queue_len, const uint32_t* __restrict__ counters,
-                                                            const uint32_t* __restrict__ ob, const uint32_t* __restrict__ head, uint32_t head_dwords, uint32_t* __restrict__ out) {
-    const uint32_t t = threadIdx.x, L = KJ_LBVH_BATCH + 2u;
-    if (t < L) { out[t] = level_nodes[t]; out[L + t] = queue_len[t]; }
-    if (t < 4u) out[2u * L + t] = counters[t];
-    if (t < 8u) out[2u * L + 4u + t] = t < 6u ? ob[t] : 0u;
-    for (uint32_t i = t; i < head_dwords; i += 256u) out[KJ_LBVH_READBACK_HEAD + i] = head[i];
+#define KJ_NODE_CHILD_DWORD 4u
+static_assert(offsetof(kj::Bvh4Node, child) == KJ_NODE_CHILD_DWORD * 4 && sizeof(kj::Bvh4Node) == 64, "k_blas_place_nodes walks a node as sixteen dwords");
+// A tree moves to its place in the pool: dword by dword; the four child references of a node (dwords 4..7 of its 16: Bvh4Node::child) that name inner nodes get the base
+__global__ void __launch_bounds__(256) k_blas_place_nodes(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t dwords, uint32_t node_base) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= dwords) return;
+    uint32_t v = src[i];
+    const uint32_t w = i & 15u;
+    if (w >= KJ_NODE_CHILD_DWORD && w < KJ_NODE_CHILD_DWORD + 4u && v != 0xffffffffu && !(v & KJ_BVH_LEAF)) v += node_base;
+    dst[i] = v;
+}
+// What the host reads after a batch of levels, gathered into one block on the device and fetched with ONE copy (five copies into pageable memory per mesh were
+// ~100 us of idle GPU each time): [queue lengths] then per mesh [levels | counters[4] | bounds[8] | the tree's first nodes].
+#define KJ_LBVH_RB_LEVELS (KJ_LBVH_BATCH + 2u)
+#define KJ_LBVH_RB_MESH_HEAD (KJ_LBVH_RB_LEVELS + 4u + 8u)
+#define KJ_LBVH_RB_MESH_DWORDS (KJ_LBVH_RB_MESH_HEAD + uint32_t(kj::LbvhResult::HEAD_NODES * sizeof(kj::Bvh4Node) / 4))
+__global__ void __launch_bounds__(256) k_collapse_pack_results(const CollapseMesh* __restrict__ meshes, const uint32_t* __restrict__ queue_len, uint32_t* __restrict__ out) {
+    const uint32_t t = threadIdx.x, L = KJ_LBVH_RB_LEVELS;
+    const CollapseMesh& M = meshes[blockIdx.x];
+    if (blockIdx.x == 0 && t < L) out[t] = queue_len[t];
+    uint32_t* const o = out + L + size_t(blockIdx.x) * KJ_LBVH_RB_MESH_DWORDS;
+    if (t < L) o[t] = M.level_nodes[t];
+    if (t < 4u) o[L + t] = M.counters[t];
+    if (t < 8u) o[L + 4u + t] = t < 6u ? M.ob[t] : 0u;
+    const uint32_t* __restrict__ head = (const uint32_t*)M.nodes;
+    for (uint32_t i = t; i < M.head_dwords; i += 256u) o[KJ_LBVH_RB_MESH_HEAD + i] = head[i];
+}
+// Start of a batch of levels. first: every mesh's root item, counters = {-, 1 node (the root), 0}; otherwise the items left by the previous batch go on.
+template <typename Item>
+__global__ void __launch_bounds__(64) k_collapse_begin(const CollapseMesh* __restrict__ meshes, uint32_t nmesh, uint32_t* __restrict__ queue_len, Item* __restrict__ q0, int first, int ploc) {
+    const uint32_t m = blockIdx.x * 64 + threadIdx.x;
+    if (m < nmesh) {
+        const CollapseMesh& M = meshes[m];
+        if (first) { M.counters[0] = 0u; M.counters[1] = 1u; M.counters[2] = 0u; M.counters[3] = 0u; }
+        for (uint32_t l = 0; l < KJ_LBVH_RB_LEVELS; ++l) M.level_nodes[l] = 0u;
+        M.level_nodes[1] = first ? 1u : M.counters[1];
+        if (first) { Item it{}; it.bin = ploc ? M.root_cluster[0] : 0u; it.mesh = m; q0[m] = it; }
+    }
+    if (m == 0) {
+        const uint32_t carry = first ? nmesh : queue_len[KJ_LBVH_BATCH];
+        for (uint32_t l = 0; l < KJ_LBVH_RB_LEVELS; ++l) queue_len[l] = 0u;
+        queue_len[0] = carry;
+    }
 }
 
 }  // namespace
@@ -691,171 +723,203 @@ __global__ void __launch_bounds__(256) k_lbvh_pack_results(const uint32_t* __res
 namespace kj {
 
 #define KJ_LB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
-// One builder, two kinds of primitives: a mesh's triangles (d_boxes == nullptr) or given boxes with a child reference each (the top tree: leaves of one)
-static hipError_t build_lbvh(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, const Box6* d_boxes, const uint32_t* d_leaf_refs, uint32_t n, uint32_t node_base, Bvh4Node* d_nodes_out,
-                             BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s, bool ploc) {
-    if (n == 0 || !scratch) return hipErrorInvalidValue;
-    const bool top = d_boxes != nullptr;
-    // working set: 15 device buffers, kept by the caller across the meshes of a commit (allocating and freeing them per mesh cost a
-    // third of a nine-mesh build: hipFree synchronises the device) and grown when a larger mesh comes along
-    if (scratch->capacity < n) {
-        const size_t c = size_t(n) + n / 4;
-        size_t sort_bytes = 0;
-        KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const MortonCode*)nullptr, (MortonCode*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, int(c), 0, 3 * KJ_MORTON_BITS, s));
-        const size_t sizes[LbvhScratch::SLOTS] = {c * sizeof(Box6), 32, c * 8, c * 4, c * 8, c * 4, c * 8, c * 8, 2 * c * 4, c * 4, 2 * c * sizeof(Box6),
-                                                  (c + 1) * sizeof(PlocItem), (c + 1) * sizeof(PlocItem), 64,
-                                                  std::max<size_t>(sort_bytes, 16), (KJ_LBVH_BATCH + 2) * 4, (2 * KJ_LBVH_BATCH + 4) * 4, KJ_LBVH_READBACK_DWORDS * 4};
-        size_t total = 0;
-        for (int k = 0; k < LbvhScratch::SLOTS; ++k) total += (sizes[k] + 255) & ~size_t(255);
-        KJ_LB(scratch->arena.alloc(total, s));
-        size_t at = 0;
-        for (int k = 0; k < LbvhScratch::SLOTS; ++k) { scratch->slot[k] = (uint8_t*)scratch->arena.p + at; scratch->slot_bytes[k] = sizes[k]; at += (sizes[k] + 255) & ~size_t(255); }
-        scratch->capacity = uint32_t(c);
+// One builder, two kinds of primitives: a mesh's triangles (boxes == nullptr) or given boxes with a child reference each (the top tree: leaves of one).
+// A call builds a BATCH of meshes: the per-mesh stages (boxes, codes, sort, hierarchy / clustering, node boxes) one mesh after the other, the collapse into 4-wide
+// nodes level by level for all of them together, one read-back at the end.
+// (The per-mesh stages of a batch on up to four side streams between two events on the caller's stream: measured, city 2.6 -> 2.2 ms, ruins 8.7 -> 8.1 ms per commit -- the
+// stages are bound by the host's launch rate, ~17 launches per mesh -- against 16 ms once for creating the streams, and a commit with several new meshes is a scene load:
+// not kept. profiles/r06_blas_builds.md)
+struct LbvhJob { const uint8_t* vb; GpuMesh mesh; const Box6* boxes; const uint32_t* leaf_refs; uint32_t n, node_base; Bvh4Node* nodes_out; BvhTri* tris_out; LbvhResult* result; };
+static hipError_t build_lbvh_batch(const LbvhJob* jobs, uint32_t njobs, LbvhScratch* scratch, hipStream_t s, bool ploc) {
+    if (!njobs || !scratch) return hipErrorInvalidValue;
+    for (uint32_t j = 0; j < njobs; ++j) if (jobs[j].n == 0) return hipErrorInvalidValue;
+    // working set: ONE allocation (grown when a commit needs more), carved into the shared pieces and every job's own buffers
+    enum { PBOX, CODES, IDS, CODES2, IDS2, CHILDREN, RANGE, PARENT, VISITS, NBOX, COUNTERS, LEVELS, JOB_SLOTS };
+    enum { Q0, Q1, QLEN, TABLE, READBACK, SORT_TMP, BOUNDS, SHARED_SLOTS };
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    size_t total_n = 0, sort_bytes = 16;
+    for (uint32_t j = 0; j < njobs; ++j) {
+        total_n += jobs[j].n;
+        size_t b = 0;
+        KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const MortonCode*)nullptr, (MortonCode*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, int(jobs[j].n), 0, 3 * KJ_MORTON_BITS, s));
+        sort_bytes = std::max(sort_bytes, b);
     }
-    // typed views of the working set (a buffer serves several stages: what PLOC clusters in is what the sort is done with)
-    void* const* const slot = scratch->slot;
-    Box6* const pbox = (Box6*)slot[0];
-    uint32_t* const ob = (uint32_t*)slot[1];
-    MortonCode* const codes = (MortonCode*)slot[2];
-    uint32_t* const ids = (uint32_t*)slot[3];
-    MortonCode* const codes2 = (MortonCode*)slot[4];
-    uint32_t* const ids2 = (uint32_t*)slot[5];            // triangle ids in Morton order
-    uint2* const children = (uint2*)slot[6];
-    uint2* const range = (uint2*)slot[7];
-    uint32_t* const parent = (uint32_t*)slot[8];
-    uint32_t* const visits = (uint32_t*)slot[9];
-    Box6* const nbox = (Box6*)slot[10];
-    void* const q0 = slot[11]; void* const q1 = slot[12];
-    uint32_t* const counters = (uint32_t*)slot[13];
-    const uint32_t cap = scratch->capacity;
-    uint32_t* const clusters = (uint32_t*)codes;              // PLOC: the cluster list, ...
-    uint32_t* const merged = (uint32_t*)codes + cap;          // ... its next state before compaction,
-    uint32_t* const nearest = ids;                            // every cluster's nearest neighbour,
-    uint32_t* const cnt = parent;                             // per node: triangles below (bit 31: emitted as one leaf)
-    float* const cost = (float*)range;                        // per node: SAH cost of the subtree
-    uint32_t* const block_valid = visits;                     // survivors per block, then their offsets
-    uint32_t* const mcount = counters + 4;                    // {clusters, inner nodes made, next round's clusters, blocks done}
-    uint32_t* const tri_order = (uint32_t*)codes2;            // triangle ids in leaf order (the collapse writes it)
-    KJ_LB(hipMemsetAsync(visits, 0, size_t(n) * 4, s));      // the refit's arrival counters
-    const dim3 g((n + 255) / 256), b(256);
-    hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(64), 0, s, ob);
-    if (top) hipLaunchKernelGGL(k_lbvh_prims_boxes, g, b, 0, s, d_boxes, n, pbox, ob);
-    else hipLaunchKernelGGL(k_lbvh_prims, g, b, 0, s, d_vertex_buffer, mesh, n, pbox, ob);
-    hipLaunchKernelGGL(k_lbvh_morton, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ob, n, codes, ids);
-    size_t tmp_bytes = 0;
-    KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const MortonCode*)codes, codes2, (const uint32_t*)ids, ids2, int(n), 0, 3 * KJ_MORTON_BITS, s));
-    void* sort_tmp = slot[LbvhScratch::BUFFERS];
-    if (tmp_bytes > scratch->slot_bytes[LbvhScratch::BUFFERS]) {      // (the reservation was sized for the capacity: a smaller mesh asking for more is not expected)
-        if (scratch->tmp_extra.bytes < tmp_bytes) KJ_LB(scratch->tmp_extra.alloc(tmp_bytes, s));
-        sort_tmp = scratch->tmp_extra.p;
-    }
-    KJ_LB(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tmp_bytes, (const MortonCode*)codes, codes2, (const uint32_t*)ids, ids2, int(n), 0, 3 * KJ_MORTON_BITS, s));
-    if (ploc) {
-        KJ_LB(hipMemsetAsync(counters, 0, 64, s));
-        hipLaunchKernelGGL(k_ploc_init, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ids2, n, nbox, cnt, cost, clusters, mcount);
-        uint32_t m = n, rounds = 0;
-        while (m > PLOC_TAIL) {
-            const dim3 gr((m + PLOC_BLOCK - 1) / PLOC_BLOCK);
-            for (int k = 0; k < 4; ++k) {      // four rounds on the last known count (it only shrinks; blocks past the end leave at once)
-                hipLaunchKernelGGL(k_ploc_nearest, gr, dim3(PLOC_BLOCK), 0, s, (const uint32_t*)clusters, (const Box6*)nbox, (const uint32_t*)mcount, nearest);
-                hipLaunchKernelGGL(k_ploc_merge, gr, dim3(PLOC_BLOCK), 0, s, (const uint32_t*)clusters, (const uint32_t*)nearest, n, mcount, nbox, children, cnt, cost, merged, block_valid);
-                hipLaunchKernelGGL(k_ploc_block_offsets, dim3(1), dim3(1024), 0, s, block_valid, mcount);
-                hipLaunchKernelGGL(k_ploc_compact, gr, dim3(PLOC_BLOCK), 0, s, (const uint32_t*)merged, (const uint32_t*)block_valid, mcount, clusters, mcount + 3);
-            }
-            KJ_LB(hipMemcpyAsync(&m, mcount, 4, hipMemcpyDeviceToHost, s));
-            KJ_LB(hipStreamSynchronize(s));
-            if (++rounds > n) return hipErrorUnknown;      // every round merges at least one pair
-            if (getenv("KJ_BVH_TIMING")) fprintf(stderr, "[ploc] after %u rounds: %u clusters\n", rounds * 4u, m);
+    const size_t rb_dwords = KJ_LBVH_RB_LEVELS + size_t(njobs) * KJ_LBVH_RB_MESH_DWORDS;
+    const size_t shared_bytes[SHARED_SLOTS] = {(total_n + njobs) * sizeof(PlocItem), (total_n + njobs) * sizeof(PlocItem), KJ_LBVH_RB_LEVELS * 4, njobs * sizeof(CollapseMesh), rb_dwords * 4, sort_bytes, size_t(njobs) * 32};
+    auto job_bytes = [&](uint32_t n, int k) -> size_t {
+        const size_t c = n;
+        switch (k) {
+            case PBOX: return c * sizeof(Box6); case CODES: return c * 8; case IDS: return c * 4; case CODES2: return c * 8; case IDS2: return c * 4;
+            case CHILDREN: return c * 8; case RANGE: return c * 8; case PARENT: return 2 * c * 4; case VISITS: return c * 4; case NBOX: return 2 * c * sizeof(Box6);
+            case COUNTERS: return 64; default: return KJ_LBVH_RB_LEVELS * 4;
         }
-        if (m > 1u) hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(PLOC_TAIL), 0, s, clusters, n, mcount, nbox, children, cnt, cost);
-    } else {
-        if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, g, b, 0, s, (const MortonCode*)codes2, int(n), children, range, parent);
-        else KJ_LB(hipMemsetAsync(parent, 0xff, 8, s));
-        hipLaunchKernelGGL(k_lbvh_refit, dim3((n + KJ_REFIT_BLOCK - 1) / KJ_REFIT_BLOCK), dim3(KJ_REFIT_BLOCK), 0, s, (const Box6*)pbox, (const uint32_t*)ids2, int(n), (const uint2*)children, (const uint2*)range,
-                           (const uint32_t*)parent, visits, nbox);
-    }
-    // collapse, level by level: counters = {-, nodes allocated, max stack}; queue_len[l] = items of level l (the kernel of level l appends to
-    // queue_len[l + 1]); level_nodes[l] = nodes allocated before level l's children (a level's nodes are one contiguous run). Levels are
-    // issued KJ_LBVH_BATCH at a time without looking at the queues -- every launch is sized by the bound 4^level, <= one item per triangle --,
-    // then ONE read-back says whether the tree goes deeper (a 250 k-triangle mesh has ~13 levels; many coincident centroids make deep ones).
-    uint32_t* const queue_len = (uint32_t*)slot[LbvhScratch::BUFFERS + 1];
-    uint32_t* const level_nodes = (uint32_t*)slot[LbvhScratch::BUFFERS + 2];       // [0 .. BATCH + 2): nodes before each level; then one arrival counter per level
-    uint32_t* const readback = (uint32_t*)slot[LbvhScratch::BUFFERS + 3];
-    uint32_t* const level_done = level_nodes + KJ_LBVH_BATCH + 2;
-    const uint32_t init_counters[4] = {0u, 1u, 0u, 0u};
-    const CollapseItem root{0u, 0u, 0u};
-    void* qin = q0; void* qout = q1;
-    auto collapse = [&](uint32_t items, uint32_t level) {
-        const dim3 cg(std::min(4096u, (items + 63) / 64));
-        const void* in = qin; void* out = qout;
-        if (ploc) hipLaunchKernelGGL(k_ploc_collapse, cg, dim3(64), 0, s, n, (const uint2*)children, (const uint32_t*)cnt, (const Box6*)nbox, (const uint32_t*)ids2, (const PlocItem*)in, queue_len, level,
-                                     (PlocItem*)out, counters, d_nodes_out, node_base, tri_order, level_nodes, level_done);
-        else hipLaunchKernelGGL(k_lbvh_collapse, cg, dim3(64), 0, s, int(n), (const uint2*)children, (const uint2*)range, (const Box6*)nbox, (const CollapseItem*)in, queue_len, level, (CollapseItem*)out,
-                                counters, d_nodes_out, node_base, level_nodes, level_done, top ? 1u : uint32_t(KJ_BVH_MAX_LEAF_TRIS), d_leaf_refs, (const uint32_t*)ids2);
     };
-    KJ_LB(hipMemcpyAsync(counters, init_counters, 16, hipMemcpyHostToDevice, s));
-    if (ploc) {
-        hipLaunchKernelGGL(k_ploc_root, dim3(1), dim3(1), 0, s, (const uint32_t*)clusters, (PlocItem*)q0);
-        KJ_LB(hipMemsetAsync(tri_order, 0, size_t(n) * 4, s));      // slots a deep tree has not reached after the first batch must still name a triangle (emit below)
-    } else KJ_LB(hipMemcpyAsync(q0, &root, sizeof(root), hipMemcpyHostToDevice, s));
-    uint32_t host_counters[4] = {0, 1, 0, 0}, host_levels[KJ_LBVH_BATCH + 2], host_queue[KJ_LBVH_BATCH + 2], hob[8];
-    result->level_starts.assign({0u});
-    result->head.resize(top ? 0 : std::min<size_t>(size_t(n) + 1, LbvhResult::HEAD_NODES));
-    uint64_t bound = 1;
-    uint32_t in_count = 1u, nodes_before = 1u;      // level 0 = the root = node 0
+    size_t total = 0;
+    for (int k = 0; k < SHARED_SLOTS; ++k) total += up(shared_bytes[k]);
+    for (uint32_t j = 0; j < njobs; ++j) for (int k = 0; k < JOB_SLOTS; ++k) total += up(job_bytes(jobs[j].n, k));
+    if (scratch->arena.bytes < total) KJ_LB(scratch->arena.alloc(total + total / 4, s));
+    uint8_t* at = (uint8_t*)scratch->arena.p;
+    void* shared[SHARED_SLOTS];
+    for (int k = 0; k < SHARED_SLOTS; ++k) { shared[k] = at; at += up(shared_bytes[k]); }
+    std::vector<void*> slots(size_t(njobs) * JOB_SLOTS);
+    for (uint32_t j = 0; j < njobs; ++j) for (int k = 0; k < JOB_SLOTS; ++k) { slots[size_t(j) * JOB_SLOTS + k] = at; at += up(job_bytes(jobs[j].n, k)); }
+    uint32_t* const queue_len = (uint32_t*)shared[QLEN];
+    CollapseMesh* const d_table = (CollapseMesh*)shared[TABLE];
+    uint32_t* const readback = (uint32_t*)shared[READBACK];
+    std::vector<CollapseMesh> table(njobs);
+
+    // ---- per mesh: primitive boxes, Morton codes, sort, the binary hierarchy with its node boxes
+    for (uint32_t j = 0; j < njobs; ++j) {
+        const LbvhJob& job = jobs[j];
+        const uint32_t n = job.n;
+        void* const sort_tmp = shared[SORT_TMP];
+        const bool top = job.boxes != nullptr;
+        void* const* const slot = &slots[size_t(j) * JOB_SLOTS];
+        // typed views of the working set (a buffer serves several stages: what PLOC clusters in is what the sort is done with)
+        Box6* const pbox = (Box6*)slot[PBOX];
+        uint32_t* const ob = (uint32_t*)shared[BOUNDS] + size_t(j) * 8;
+        MortonCode* const codes = (MortonCode*)slot[CODES];
+        uint32_t* const ids = (uint32_t*)slot[IDS];
+        MortonCode* const codes2 = (MortonCode*)slot[CODES2];
+        uint32_t* const ids2 = (uint32_t*)slot[IDS2];            // triangle ids in Morton order
+        uint2* const children = (uint2*)slot[CHILDREN];
+        uint2* const range = (uint2*)slot[RANGE];
+        uint32_t* const parent = (uint32_t*)slot[PARENT];
+        uint32_t* const visits = (uint32_t*)slot[VISITS];
+        Box6* const nbox = (Box6*)slot[NBOX];
+        uint32_t* const counters = (uint32_t*)slot[COUNTERS];
+        uint32_t* const clusters = (uint32_t*)codes;              // PLOC: the cluster list, ...
+        uint32_t* const merged = (uint32_t*)codes + n;            // ... its next state before compaction,
+        uint32_t* const nearest = ids;                            // every cluster's nearest neighbour,
+        uint32_t* const cnt = parent;                             // per node: triangles below (bit 31: emitted as one leaf)
+        float* const cost = (float*)range;                        // per node: SAH cost of the subtree
+        uint32_t* const block_valid = visits;                     // survivors per block, then their offsets
+        uint32_t* const mcount = counters + 4;                    // {clusters, inner nodes made, next round's clusters, blocks done}
+        uint32_t* const tri_order = (uint32_t*)codes2;            // triangle ids in leaf order (the collapse writes it)
+        const dim3 g((n + 255) / 256), b(256);
+        if (j == 0) hipLaunchKernelGGL(k_lbvh_init, dim3((njobs * 8 + 63) / 64), dim3(64), 0, s, (uint32_t*)shared[BOUNDS], njobs);
+        if (top) hipLaunchKernelGGL(k_lbvh_prims_boxes, g, b, 0, s, job.boxes, n, pbox, ob, visits);
+        else hipLaunchKernelGGL(k_lbvh_prims, g, b, 0, s, job.vb, job.mesh, n, pbox, ob, visits);
+        hipLaunchKernelGGL(k_lbvh_morton, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ob, n, codes, ids);
+        size_t tmp_bytes = 0;
+        KJ_LB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const MortonCode*)codes, codes2, (const uint32_t*)ids, ids2, int(n), 0, 3 * KJ_MORTON_BITS, s));
+        if (tmp_bytes > sort_bytes) return hipErrorUnknown;
+        KJ_LB(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tmp_bytes, (const MortonCode*)codes, codes2, (const uint32_t*)ids, ids2, int(n), 0, 3 * KJ_MORTON_BITS, s));
+        if (ploc) {
+            KJ_LB(hipMemsetAsync(counters, 0, 64, s));
+            hipLaunchKernelGGL(k_ploc_init, g, b, 0, s, (const Box6*)pbox, (const uint32_t*)ids2, n, nbox, cnt, cost, clusters, mcount);
+            uint32_t m = n, rounds = 0;
+            while (m > PLOC_TAIL) {
+                const dim3 gr((m + PLOC_BLOCK - 1) / PLOC_BLOCK);
+                for (int k = 0; k < 4; ++k) {      // four rounds on the last known count (it only shrinks; blocks past the end leave at once)
+                    hipLaunchKernelGGL(k_ploc_nearest, gr, dim3(PLOC_BLOCK), 0, s, (const uint32_t*)clusters, (const Box6*)nbox, (const uint32_t*)mcount, nearest);
+                    hipLaunchKernelGGL(k_ploc_merge, gr, dim3(PLOC_BLOCK), 0, s, (const uint32_t*)clusters, (const uint32_t*)nearest, n, mcount, nbox, children, cnt, cost, merged, block_valid);
+                    hipLaunchKernelGGL(k_ploc_block_offsets, dim3(1), dim3(1024), 0, s, block_valid, mcount);
+                    hipLaunchKernelGGL(k_ploc_compact, gr, dim3(PLOC_BLOCK), 0, s, (const uint32_t*)merged, (const uint32_t*)block_valid, mcount, clusters, mcount + 3);
+                }
+                KJ_LB(hipMemcpyAsync(&m, mcount, 4, hipMemcpyDeviceToHost, s));
+                KJ_LB(hipStreamSynchronize(s));
+                if (++rounds > n) return hipErrorUnknown;      // every round merges at least one pair
+                if (getenv("KJ_BVH_TIMING")) fprintf(stderr, "[ploc] after %u rounds: %u clusters\n", rounds * 4u, m);
+            }
+            if (m > 1u) hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(PLOC_TAIL), 0, s, clusters, n, mcount, nbox, children, cnt, cost);
+            KJ_LB(hipMemsetAsync(tri_order, 0, size_t(n) * 4, s));      // slots a deep tree has not reached after the first batch must still name a triangle (emit below)
+        } else {
+            if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, g, b, 0, s, (const MortonCode*)codes2, int(n), children, range, parent);
+            else KJ_LB(hipMemsetAsync(parent, 0xff, 8, s));
+            hipLaunchKernelGGL(k_lbvh_refit, dim3((n + KJ_REFIT_BLOCK - 1) / KJ_REFIT_BLOCK), dim3(KJ_REFIT_BLOCK), 0, s, (const Box6*)pbox, (const uint32_t*)ids2, int(n), (const uint2*)children, (const uint2*)range,
+                               (const uint32_t*)parent, visits, nbox);
+            if (!top) hipLaunchKernelGGL(k_lbvh_emit_tris, g, b, 0, s, job.vb, job.mesh, (const uint32_t*)ids2, n, job.tris_out);      // the triangles in leaf order = in Morton order
+        }
+        job.result->level_starts.assign({0u});
+        job.result->head.resize(top ? 0 : std::min<size_t>(size_t(n) + 1, LbvhResult::HEAD_NODES));
+        CollapseMesh& M = table[j];
+        M.n = n; M.node_base = job.node_base; M.max_leaf = top ? 1u : uint32_t(KJ_BVH_MAX_LEAF_TRIS); M.head_dwords = uint32_t(job.result->head.size() * (sizeof(Bvh4Node) / 4));
+        M.children = children; M.range = range; M.cnt = cnt; M.nbox = nbox; M.sorted_ids = ids2; M.leaf_refs = job.leaf_refs; M.root_cluster = clusters; M.ob = ob;
+        M.nodes = job.nodes_out; M.tri_order = tri_order; M.counters = counters; M.level_nodes = (uint32_t*)slot[LEVELS];
+    }
+    // ---- the collapse, level by level, all meshes together: counters = {-, nodes allocated, max stack} per mesh; queue_len[l] = items of level l (the kernel of level l
+    // appends to queue_len[l + 1]); level_nodes[l] = a mesh's nodes allocated before level l's children (a level's nodes are one contiguous run). Levels are issued
+    // KJ_LBVH_BATCH at a time without looking at the queues -- every launch is sized by the bound 4^level per mesh, <= one item per triangle --, then ONE read-back
+    // says whether a tree goes deeper (a 250 k-triangle mesh has ~13 levels; many coincident centroids make deep ones).
+    KJ_LB(hipMemcpyAsync(d_table, table.data(), njobs * sizeof(CollapseMesh), hipMemcpyHostToDevice, s));
+    void* qin = shared[Q0]; void* qout = shared[Q1];
+    const dim3 mg((njobs + 63) / 64);
+    if (ploc) hipLaunchKernelGGL(k_collapse_begin<PlocItem>, mg, dim3(64), 0, s, (const CollapseMesh*)d_table, njobs, queue_len, (PlocItem*)qin, 1, 1);
+    else hipLaunchKernelGGL(k_collapse_begin<CollapseItem>, mg, dim3(64), 0, s, (const CollapseMesh*)d_table, njobs, queue_len, (CollapseItem*)qin, 1, 0);
+    scratch->readback.resize(rb_dwords);
+    uint64_t per_mesh_bound = 1, carried = 0;      // items of the next level: <= per_mesh_bound per mesh (first batch), <= carried (later batches), <= a mesh's triangles
+    uint32_t in_count = njobs;
+    size_t batches = 0;
     while (in_count) {
-        uint32_t queue_head[KJ_LBVH_BATCH + 2] = {}, level_head[2 * KJ_LBVH_BATCH + 4] = {};
-        queue_head[0] = in_count; level_head[1] = nodes_before;
-        KJ_LB(hipMemcpyAsync(queue_len, queue_head, sizeof(queue_head), hipMemcpyHostToDevice, s));
-        KJ_LB(hipMemcpyAsync(level_nodes, level_head, sizeof(level_head), hipMemcpyHostToDevice, s));
         for (uint32_t level = 0; level < KJ_LBVH_BATCH; ++level) {
-            collapse(uint32_t(std::min<uint64_t>(std::max<uint64_t>(bound, in_count), n)), level);
-            bound = std::min<uint64_t>(std::max<uint64_t>(bound, in_count) * 4, uint64_t(n));
+            uint64_t items = 0;
+            if (carried) items = std::min<uint64_t>(carried, total_n);
+            else for (uint32_t j = 0; j < njobs; ++j) items += std::min<uint64_t>(per_mesh_bound, jobs[j].n);
+            const dim3 cg(uint32_t(std::min<uint64_t>(4096u, (items + 63) / 64)));
+            if (ploc) hipLaunchKernelGGL(k_ploc_collapse, cg, dim3(64), 0, s, (const CollapseMesh*)d_table, (const PlocItem*)qin, queue_len, level, (PlocItem*)qout);
+            else hipLaunchKernelGGL(k_lbvh_collapse, cg, dim3(64), 0, s, (const CollapseMesh*)d_table, (const CollapseItem*)qin, queue_len, level, (CollapseItem*)qout);
+            hipLaunchKernelGGL(k_collapse_record_level, mg, dim3(64), 0, s, (const CollapseMesh*)d_table, njobs, level);
+            if (carried) carried = std::min<uint64_t>(carried * 4, total_n); else per_mesh_bound = std::min<uint64_t>(per_mesh_bound * 4, uint64_t(1) << 40);
             std::swap(qin, qout);
         }
-        // everything else the caller needs rides the same read-back: a tree that fits one batch (every mesh so far) costs ONE synchronisation.
-        // (The triangles in leaf order: PLOC's order is written by the collapse; if the tree turns out deeper, the last batch emits them again.)
-        if (!top) hipLaunchKernelGGL(k_lbvh_emit_tris, g, b, 0, s, d_vertex_buffer, mesh, ploc ? (const uint32_t*)tri_order : (const uint32_t*)ids2, n, d_tris_out);
-        // (round 6: ONE copy -- the five pieces are gathered into a block on the device first; five copies into pageable memory were ~100 us of idle GPU per mesh)
-        const uint32_t head_count = uint32_t(result->head.size());      // the top levels, for the caller's top-tree build
-        hipLaunchKernelGGL(k_lbvh_pack_results, dim3(1), dim3(256), 0, s, (const uint32_t*)level_nodes, (const uint32_t*)queue_len, (const uint32_t*)counters, (const uint32_t*)ob,
-                           (const uint32_t*)d_nodes_out, head_count * uint32_t(sizeof(Bvh4Node) / 4), readback);
-        const size_t rb_dwords = KJ_LBVH_READBACK_HEAD + size_t(head_count) * (sizeof(Bvh4Node) / 4);
-        scratch->readback.resize(KJ_LBVH_READBACK_DWORDS);
+        // PLOC's triangle order is written by the collapse; if a tree turns out deeper, the next batch emits its triangles again
+        if (ploc) for (uint32_t j = 0; j < njobs; ++j)
+            if (!jobs[j].boxes) hipLaunchKernelGGL(k_lbvh_emit_tris, dim3((jobs[j].n + 255) / 256), dim3(256), 0, s, jobs[j].vb, jobs[j].mesh, (const uint32_t*)table[j].tri_order, jobs[j].n, jobs[j].tris_out);
+        hipLaunchKernelGGL(k_collapse_pack_results, dim3(njobs), dim3(256), 0, s, (const CollapseMesh*)d_table, (const uint32_t*)queue_len, readback);
         KJ_LB(hipMemcpyAsync(scratch->readback.data(), readback, rb_dwords * 4, hipMemcpyDeviceToHost, s));
         KJ_LB(hipStreamSynchronize(s));
-        {
-            const uint32_t* rb = scratch->readback.data();
-            memcpy(host_levels, rb, sizeof(host_levels)); memcpy(host_queue, rb + (KJ_LBVH_BATCH + 2), sizeof(host_queue));
-            memcpy(host_counters, rb + 2 * (KJ_LBVH_BATCH + 2), 16); memcpy(hob, rb + 2 * (KJ_LBVH_BATCH + 2) + 4, 24);
-            if (head_count) memcpy(result->head.data(), rb + KJ_LBVH_READBACK_HEAD, size_t(head_count) * sizeof(Bvh4Node));
+        const uint32_t* rb = scratch->readback.data();
+        in_count = rb[KJ_LBVH_BATCH];
+        for (uint32_t j = 0; j < njobs; ++j) {
+            LbvhResult* r = jobs[j].result;
+            const uint32_t* o = rb + KJ_LBVH_RB_LEVELS + size_t(j) * KJ_LBVH_RB_MESH_DWORDS;
+            for (uint32_t l = 1; l <= KJ_LBVH_BATCH + 1; ++l)
+                if (o[l] > r->level_starts.back()) r->level_starts.push_back(o[l]);
+            if (r->level_starts.size() > 4096) return hipErrorUnknown;
+            if (in_count) continue;
+            const uint32_t* host_counters = o + KJ_LBVH_RB_LEVELS; const uint32_t* hob = host_counters + 4;
+            for (int k = 0; k < 6; ++k) {
+                const uint32_t ov = hob[k];
+                const uint32_t u = (ov & 0x80000000u) ? (ov & 0x7fffffffu) : ~ov;
+                memcpy(&r->bounds[k], &u, 4);
+            }
+            r->head.resize(std::min<size_t>(r->head.size(), host_counters[1]));
+            if (!r->head.empty()) memcpy(r->head.data(), o + KJ_LBVH_RB_MESH_HEAD, r->head.size() * sizeof(Bvh4Node));
+            r->node_count = host_counters[1];
+            r->max_stack = host_counters[2] > 0 ? host_counters[2] : 1;
         }
-        for (uint32_t l = 1; l <= KJ_LBVH_BATCH + 1; ++l)
-            if (host_levels[l] > result->level_starts.back()) result->level_starts.push_back(host_levels[l]);
-        in_count = host_queue[KJ_LBVH_BATCH];
-        nodes_before = host_counters[1];
-        if (result->level_starts.size() > 4096) return hipErrorUnknown;
+        if (in_count) {
+            carried = in_count;
+            if (ploc) hipLaunchKernelGGL(k_collapse_begin<PlocItem>, mg, dim3(64), 0, s, (const CollapseMesh*)d_table, njobs, queue_len, (PlocItem*)qin, 0, 1);
+            else hipLaunchKernelGGL(k_collapse_begin<CollapseItem>, mg, dim3(64), 0, s, (const CollapseMesh*)d_table, njobs, queue_len, (CollapseItem*)qin, 0, 0);
+        }
+        if (++batches > 4096) return hipErrorUnknown;
     }
     KJ_LB(hipGetLastError());
-    for (int k = 0; k < 6; ++k) {
-        const uint32_t o = hob[k];
-        const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-        memcpy(&result->bounds[k], &u, 4);
-    }
-    result->head.resize(std::min<size_t>(result->head.size(), host_counters[1]));
-    result->node_count = host_counters[1];
-    result->max_stack = host_counters[2] > 0 ? host_counters[2] : 1;
     return hipSuccess;
 }
 hipError_t build_blas_lbvh_device(const uint8_t* d_vertex_buffer, const GpuMesh& mesh, uint32_t node_base, Bvh4Node* d_nodes_out, BvhTri* d_tris_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s, bool ploc) {
-    return build_lbvh(d_vertex_buffer, mesh, nullptr, nullptr, mesh.index_count / 3, node_base, d_nodes_out, d_tris_out, result, scratch, s, ploc);
+    const LbvhJob job{d_vertex_buffer, mesh, nullptr, nullptr, mesh.index_count / 3, node_base, d_nodes_out, d_tris_out, result};
+    return build_lbvh_batch(&job, 1, scratch, s, ploc);
+}
+// The meshes of a commit in one go. Nodes of mesh j into batch[j].nodes_out[0 .. node_count) -- at most one per triangle + 1 --, child node indices offset by batch[j].node_base.
+hipError_t build_blas_lbvh_device_batch(const uint8_t* d_vertex_buffer, const LbvhBatchMesh* batch, uint32_t count, LbvhScratch* scratch, hipStream_t s, bool ploc) {
+    std::vector<LbvhJob> jobs(count);
+    for (uint32_t j = 0; j < count; ++j) jobs[j] = LbvhJob{d_vertex_buffer, batch[j].mesh, nullptr, nullptr, batch[j].mesh.index_count / 3, batch[j].node_base, batch[j].nodes_out, batch[j].tris_out, batch[j].result};
+    return build_lbvh_batch(jobs.data(), count, scratch, s, ploc);
+}
+hipError_t launch_blas_place_nodes(const Bvh4Node* src, Bvh4Node* dst, uint32_t count, uint32_t node_base, hipStream_t s) {
+    if (count) hipLaunchKernelGGL(k_blas_place_nodes, dim3((count * 16u + 255u) / 256u), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, count * 16u, node_base);
+    return hipGetLastError();
 }
 // The per-commit top tree as a linear BVH over the leaves' world boxes (kj_scene_device.hpp): d_leaf_boxes[i] = {min xyz, max xyz}, d_leaf_refs[i] = the world
 // node that leaf stands for. Nodes into d_nodes_out[0 .. node_count), node_count < max(leaf_count, 2). One synchronisation.
 hipError_t build_top_lbvh_device(const float* d_leaf_boxes, const uint32_t* d_leaf_refs, uint32_t leaf_count, Bvh4Node* d_nodes_out, LbvhResult* result, LbvhScratch* scratch, hipStream_t s) {
     static_assert(sizeof(Box6) == 24, "a box is six floats");
     if (!d_leaf_boxes || !d_leaf_refs) return hipErrorInvalidValue;
-    return build_lbvh(nullptr, GpuMesh{}, (const Box6*)d_leaf_boxes, d_leaf_refs, leaf_count, 0u, d_nodes_out, nullptr, result, scratch, s, false);
+    const LbvhJob job{nullptr, GpuMesh{}, (const Box6*)d_leaf_boxes, d_leaf_refs, leaf_count, 0u, d_nodes_out, nullptr, result};
+    return build_lbvh_batch(&job, 1, scratch, s, false);
 }
 
 }  // namespace kj

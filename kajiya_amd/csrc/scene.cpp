@@ -331,13 +331,33 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         return e;
     };
     LbvhScratch lbvh_scratch;     // device-side builds of this commit share their working buffers
-    {   // the pools grow ONCE for all device-side builds of the commit (at most one node per triangle): a reallocation per mesh was a hipMalloc + copy + hipFree between two builds
-        size_t more_nodes = 0, more_tris = 0;
-        for (uint32_t mi = 0; mi < s->meshes.size(); ++mi)
-            if (!s->blas[mi].built && s->mesh_build_mode[mi] != 0) { const size_t ntri = s->meshes[mi].index_count / 3; more_nodes += ntri + 1; more_tris += ntri; }
-        if (more_nodes) {
-            KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), (size_t(s->blas_nodes_used) + more_nodes) * sizeof(BvhNode)));
-            KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), (size_t(s->obj_tris_used) + more_tris) * sizeof(BvhTri)));
+    // Device-side builds (LBVH / PLOC) of ALL new meshes of the commit as one batch per builder (round 6: per-mesh stages one after the other, the 4-wide collapse level
+    // by level for all meshes together, one read-back -- lbvh_build.hip). A tree's node count is known only afterwards, so the batch writes every tree with
+    // mesh-relative child indices into a scratch area (one node per triangle + 1 reserved) and the loop below moves each into the pool at its final, dense place.
+    std::map<uint32_t, LbvhResult> device_built;
+    std::map<uint32_t, size_t> device_nodes_at;      // mesh -> first node of its tree in blas_tmp_nodes
+    kj::DevBuf blas_tmp_nodes;
+    {
+        size_t tmp_nodes = 0, tris_after = s->obj_tris_used, nodes_after = s->blas_nodes_used;
+        std::vector<uint32_t> tri_base_of(s->meshes.size(), 0u);
+        for (uint32_t mi = 0; mi < s->meshes.size(); ++mi) {
+            if (s->blas[mi].built) continue;
+            const size_t ntri = s->meshes[mi].index_count / 3;
+            tri_base_of[mi] = uint32_t(tris_after); tris_after += ntri;
+            if (s->mesh_build_mode[mi] != 0) { device_nodes_at[mi] = tmp_nodes; tmp_nodes += ntri + 1; }
+        }
+        if (tmp_nodes) {
+            KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), tris_after * sizeof(BvhTri)));      // the pools grow ONCE per commit, not per mesh
+            KJ_TRY_HIP(blas_tmp_nodes.alloc(tmp_nodes * sizeof(BvhNode), stream));
+            for (int mode = 1; mode <= 2; ++mode) {
+                std::vector<LbvhBatchMesh> batch;
+                for (auto& kv : device_nodes_at)
+                    if (s->mesh_build_mode[kv.first] == mode)
+                        batch.push_back(LbvhBatchMesh{s->meshes[kv.first], 0u, (Bvh4Node*)blas_tmp_nodes.p + kv.second, (BvhTri*)s->d_obj_tris.p + tri_base_of[kv.first], &device_built[kv.first]});
+                if (!batch.empty()) KJ_TRY_HIP(build_blas_lbvh_device_batch((const uint8_t*)s->d_vertex_buffer.p, batch.data(), uint32_t(batch.size()), &lbvh_scratch, stream, mode == 2));
+            }
+            for (auto& kv : device_built) nodes_after += kv.second.node_count;
+            KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), nodes_after * sizeof(BvhNode)));
         }
     }
     // host SAH builds of all new meshes run concurrently (a small mesh builds on one thread: nine of them one after the other were
@@ -387,17 +407,16 @@ KjStatus kj_scene_commit(KjScene* s, void* stream_) {
         const uint32_t ntri = m.index_count / 3;
         bl.node_base = s->blas_nodes_used; bl.tri_base = s->obj_tris_used; bl.tri_count = ntri;
         std::vector<uint32_t> steps;          // {first, end} node of every step of the refit's bottom-up order
-        if (s->mesh_build_mode[mi] != 0) {   // on the device (LBVH or PLOC), straight into the pools (at most one node per triangle)
-            KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), size_t(s->blas_nodes_used + ntri + 1) * sizeof(BvhNode)));
-            KJ_TRY_HIP(grow_pool(s->d_obj_tris, size_t(s->obj_tris_used) * sizeof(BvhTri), size_t(s->obj_tris_used + ntri) * sizeof(BvhTri)));
-            LbvhResult lr;
-            KJ_TRY_HIP(build_blas_lbvh_device((const uint8_t*)s->d_vertex_buffer.p, m, bl.node_base, (Bvh4Node*)s->d_blas_nodes.p + bl.node_base, (BvhTri*)s->d_obj_tris.p + bl.tri_base, &lr, &lbvh_scratch, stream, s->mesh_build_mode[mi] == 2));
+        if (s->mesh_build_mode[mi] != 0) {   // built on the device above (LBVH or PLOC): the tree moves from the batch's scratch area to its place in the pool
+            const LbvhResult& lr = device_built[mi];
             bl.node_count = lr.node_count; bl.max_stack = lr.max_stack;
+            KJ_TRY_HIP(grow_pool(s->d_blas_nodes, size_t(s->blas_nodes_used) * sizeof(BvhNode), size_t(s->blas_nodes_used + bl.node_count) * sizeof(BvhNode)));      // (a no-op unless host builds came in between)
+            KJ_TRY_HIP(launch_blas_place_nodes((const Bvh4Node*)blas_tmp_nodes.p + device_nodes_at[mi], (Bvh4Node*)s->d_blas_nodes.p + bl.node_base, bl.node_count, bl.node_base, stream));
             memcpy(bl.bounds, lr.bounds, 24);
             // laid out by depth on the device: the refit walks the levels deepest first, the root is node 0
             for (size_t d = lr.level_starts.size() - 1; d-- > 0;) { steps.push_back(lr.level_starts[d]); steps.push_back(lr.level_starts[d + 1]); }
             bl.root = 0;
-            extract_blas_top(lr.head.data(), uint32_t(lr.head.size()), bl.node_base, 0u, bl.bounds, KJ_BLAS_TOP_NODES, s->blas_top[mi]);      // its top levels, read back with the build's own results
+            extract_blas_top(lr.head.data(), uint32_t(lr.head.size()), 0u, 0u, bl.bounds, KJ_BLAS_TOP_NODES, s->blas_top[mi]);      // its top levels (mesh-relative child indices), read back with the build's own results
         } else {                              // binned SAH on the host
             if (!host_builds.count(mi)) {      // not started yet (the in-flight limit): start it now, alone if need be
                 try { host_builds[mi] = std::async(std::launch::async, host_build, mi); }
