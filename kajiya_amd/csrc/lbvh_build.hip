@@ -234,6 +234,12 @@ KJ_D void quantise_child(Bvh4Node& node, const float scale[3], int i, const Box6
         node.qlo[k][i] = uint8_t(lo); node.qhi[k][i] = uint8_t(hi);
     }
 }
+#ifndef KJ_LBVH_BATCH
+#define KJ_LBVH_BATCH 14u      // collapse levels issued between two read-backs (tests build a variant with 3 to walk the continuation)
+#endif
+#define KJ_LBVH_RB_LEVELS (KJ_LBVH_BATCH + 2u)
+#define KJ_LBVH_RB_MESH_HEAD (KJ_LBVH_RB_LEVELS + 4u + 8u)
+#define KJ_LBVH_RB_MESH_DWORDS (KJ_LBVH_RB_MESH_HEAD + uint32_t(kj::LbvhResult::HEAD_NODES * sizeof(kj::Bvh4Node) / 4))
 // One level of the 4-wide trees of ALL meshes of a batch. item = (binary internal node, output node index, depth, mesh).
 // Round 6: the collapse is batched over the meshes of a commit -- a level is one launch for all of them. A level of a small mesh is a chain of ~8 dependent round
 // trips whatever its item count (14-25 us), and nine meshes one after the other paid it nine times per level: half of a device build (profiles/r06_blas_builds.md).
@@ -241,7 +247,9 @@ struct CollapseMesh {
     uint32_t n, node_base, max_leaf, head_dwords;
     const uint2* children; const uint2* range; const uint32_t* cnt; const Box6* nbox; const uint32_t* sorted_ids; const uint32_t* leaf_refs;
     const uint32_t* root_cluster; const uint32_t* ob;
-    Bvh4Node* nodes; uint32_t* tri_order; uint32_t* counters /*[1] = nodes, [2] = max depth*/; uint32_t* level_nodes;
+    Bvh4Node* nodes; uint32_t* tri_order; uint32_t* counters /*[1] = nodes, [2] = max depth*/;
+    uint32_t* level_nodes;      // [1] = nodes before the batch's first level; [KJ_LBVH_RB_LEVELS + l] = nodes level l of the batch allocated (the levels of a tree are contiguous runs,
+                                // which the per-instance refit walks deepest first; where each starts is summed up from these in k_collapse_pack_results -- it was a launch per level)
 };
 struct CollapseItem { uint32_t bin, out, depth, mesh; };
 // The level's queue length lives on the device (queue_len[level]; the kernel appends to queue_len[level + 1]): the host launches every
@@ -309,7 +317,7 @@ __global__ void __launch_bounds__(64) k_lbvh_collapse(const CollapseMesh* __rest
 #pragma unroll
     for (int i = 0; i < 4; ++i) inner += (n != 1 && i < nch && !fi[i].leaf) ? 1u : 0u;
     uint32_t o = 0u, place = 0u;
-    if (inner) { o = atomicAdd(&counters[1], inner); place = atomicAdd(&queue_len[level + 1], inner); }
+    if (inner) { o = atomicAdd(&counters[1], inner); place = atomicAdd(&queue_len[level + 1], inner); atomicAdd(&M.level_nodes[KJ_LBVH_RB_LEVELS + level], inner); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i >= nch) {
@@ -330,11 +338,6 @@ __global__ void __launch_bounds__(64) k_lbvh_collapse(const CollapseMesh* __rest
     }
     nodes[it.out] = node;
     }
-}
-// After a level: where every mesh's next level starts (the levels of a tree are contiguous runs, which the per-instance refit walks deepest first).
-__global__ void __launch_bounds__(64) k_collapse_record_level(const CollapseMesh* __restrict__ meshes, uint32_t nmesh, uint32_t level) {
-    const uint32_t m = blockIdx.x * 64 + threadIdx.x;
-    if (m < nmesh) meshes[m].level_nodes[level + 2] = meshes[m].counters[1];
 }
 __global__ void __launch_bounds__(256) k_lbvh_emit_tris(const uint8_t* __restrict__ vb, GpuMesh m, const uint32_t* __restrict__ ids, uint32_t n, BvhTri* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -503,9 +506,6 @@ __global__ void __launch_bounds__(PLOC_BLOCK) k_ploc_compact(const uint32_t* __r
 // boxes and nearest neighbours in LDS, a barrier where the multi-launch rounds have a kernel boundary. (The tail is where rounds are
 // many and small: a 2 k-triangle mesh takes 36 rounds, a 250 k-triangle one ~50, the last ~25 of them on fewer than a thousand clusters.)
 #define PLOC_TAIL 1024
-#ifndef KJ_LBVH_BATCH
-#define KJ_LBVH_BATCH 14u      // collapse levels issued between two read-backs (tests build a variant with 3 to walk the continuation)
-#endif
 KJ_D uint32_t tail_exclusive_scan(uint32_t v, uint32_t* lds /*[PLOC_TAIL]*/, uint32_t* total) {
     const uint32_t t = threadIdx.x;
     lds[t] = v;
@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(64) k_ploc_collapse(const CollapseMesh* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) inner += (i < nch && !fi[i].leaf) ? 1u : 0u;
         uint32_t o = 0u, place = 0u;
-        if (inner) { o = atomicAdd(&counters[1], inner); place = atomicAdd(&queue_len[level + 1], inner); }
+        if (inner) { o = atomicAdd(&counters[1], inner); place = atomicAdd(&queue_len[level + 1], inner); atomicAdd(&M.level_nodes[KJ_LBVH_RB_LEVELS + level], inner); }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i >= nch) {
@@ -686,15 +686,16 @@ __global__ void __launch_bounds__(256) k_blas_place_nodes(const uint32_t* __rest
 }
 // What the host reads after a batch of levels, gathered into one block on the device and fetched with ONE copy (five copies into pageable memory per mesh were
 // ~100 us of idle GPU each time): [queue lengths] then per mesh [levels | counters[4] | bounds[8] | the tree's first nodes].
-#define KJ_LBVH_RB_LEVELS (KJ_LBVH_BATCH + 2u)
-#define KJ_LBVH_RB_MESH_HEAD (KJ_LBVH_RB_LEVELS + 4u + 8u)
-#define KJ_LBVH_RB_MESH_DWORDS (KJ_LBVH_RB_MESH_HEAD + uint32_t(kj::LbvhResult::HEAD_NODES * sizeof(kj::Bvh4Node) / 4))
 __global__ void __launch_bounds__(256) k_collapse_pack_results(const CollapseMesh* __restrict__ meshes, const uint32_t* __restrict__ queue_len, uint32_t* __restrict__ out) {
     const uint32_t t = threadIdx.x, L = KJ_LBVH_RB_LEVELS;
     const CollapseMesh& M = meshes[blockIdx.x];
     if (blockIdx.x == 0 && t < L) out[t] = queue_len[t];
     uint32_t* const o = out + L + size_t(blockIdx.x) * KJ_LBVH_RB_MESH_DWORDS;
-    if (t < L) o[t] = M.level_nodes[t];
+    if (t == 0) {      // nodes before every level of the batch
+        uint32_t acc = M.level_nodes[1];
+        o[0] = 0u; o[1] = acc;
+        for (uint32_t l = 0; l < KJ_LBVH_BATCH; ++l) { acc += M.level_nodes[L + l]; o[l + 2] = acc; }
+    }
     if (t < 4u) o[L + t] = M.counters[t];
     if (t < 8u) o[L + 4u + t] = t < 6u ? M.ob[t] : 0u;
     const uint32_t* __restrict__ head = (const uint32_t*)M.nodes;
@@ -707,7 +708,7 @@ __global__ void __launch_bounds__(64) k_collapse_begin(const CollapseMesh* __res
     if (m < nmesh) {
         const CollapseMesh& M = meshes[m];
         if (first) { M.counters[0] = 0u; M.counters[1] = 1u; M.counters[2] = 0u; M.counters[3] = 0u; }
-        for (uint32_t l = 0; l < KJ_LBVH_RB_LEVELS; ++l) M.level_nodes[l] = 0u;
+        for (uint32_t l = 0; l < 2u * KJ_LBVH_RB_LEVELS; ++l) M.level_nodes[l] = 0u;
         M.level_nodes[1] = first ? 1u : M.counters[1];
         if (first) { Item it{}; it.bin = ploc ? M.root_cluster[0] : 0u; it.mesh = m; q0[m] = it; }
     }
@@ -751,7 +752,7 @@ static hipError_t build_lbvh_batch(const LbvhJob* jobs, uint32_t njobs, LbvhScra
         switch (k) {
             case PBOX: return c * sizeof(Box6); case CODES: return c * 8; case IDS: return c * 4; case CODES2: return c * 8; case IDS2: return c * 4;
             case CHILDREN: return c * 8; case RANGE: return c * 8; case PARENT: return 2 * c * 4; case VISITS: return c * 4; case NBOX: return 2 * c * sizeof(Box6);
-            case COUNTERS: return 64; default: return KJ_LBVH_RB_LEVELS * 4;
+            case COUNTERS: return 64; default: return 2 * KJ_LBVH_RB_LEVELS * 4;
         }
     };
     size_t total = 0;
@@ -859,7 +860,6 @@ static hipError_t build_lbvh_batch(const LbvhJob* jobs, uint32_t njobs, LbvhScra
             const dim3 cg(uint32_t(std::min<uint64_t>(4096u, (items + 63) / 64)));
             if (ploc) hipLaunchKernelGGL(k_ploc_collapse, cg, dim3(64), 0, s, (const CollapseMesh*)d_table, (const PlocItem*)qin, queue_len, level, (PlocItem*)qout);
             else hipLaunchKernelGGL(k_lbvh_collapse, cg, dim3(64), 0, s, (const CollapseMesh*)d_table, (const CollapseItem*)qin, queue_len, level, (CollapseItem*)qout);
-            hipLaunchKernelGGL(k_collapse_record_level, mg, dim3(64), 0, s, (const CollapseMesh*)d_table, njobs, level);
             if (carried) carried = std::min<uint64_t>(carried * 4, total_n); else per_mesh_bound = std::min<uint64_t>(per_mesh_bound * 4, uint64_t(1) << 40);
             std::swap(qin, qout);
         }
