@@ -234,8 +234,8 @@ KjStatus kj_scene_set_blas_build_mode(KjScene* scene, uint32_t mode);
  * large instances that overlap many others -- a terrain -- stop being one box around everything. Same hits either way. */
 KjStatus kj_scene_set_open_instances(KjScene* scene, uint32_t enable);
 /* Who builds the per-commit top tree (the TLAS build of WorldRenderer::build_ray_tracing_top_level_acceleration, world_renderer.rs:836-911): the host
- * (binned SAH: the better tree, 0.08 ms at 64 instances but 10 ms at 8 k) or the device (a linear BVH over the instances' world boxes, for scenes whose
- * instance count makes the host build the cost of a per-frame commit). KJ_TOP_BUILD_AUTO: the host below 4096 top-tree leaves, the device from there on. */
+ * (binned SAH: the better tree, 0.06 ms per commit at 64 instances but 2.6 ms at 4 k and 24 ms at 32 k) or the device (a linear BVH over the instances' world boxes:
+ * 0.2-0.5 ms up to 4 k, 1.7 ms at 32 k; closest-hit rays within 2 % of the host tree's rate, measured). KJ_TOP_BUILD_AUTO: the host below 1024 top-tree leaves, the device from there on. */
 enum { KJ_TOP_BUILD_AUTO = 0u, KJ_TOP_BUILD_HOST = 1u, KJ_TOP_BUILD_DEVICE = 2u };
 KjStatus kj_scene_set_top_build_mode(KjScene* scene, uint32_t mode);
 /* The last commit's top tree: its nodes, the reservation at the head of the world node array, and who built it (1 = the device). */

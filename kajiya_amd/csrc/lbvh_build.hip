@@ -521,8 +521,10 @@ KJ_D uint32_t tail_exclusive_scan(uint32_t v, uint32_t* lds /*[PLOC_TAIL]*/, uin
     __syncthreads();
     return incl - v;
 }
-__global__ void __launch_bounds__(PLOC_TAIL) k_ploc_tail(uint32_t* __restrict__ clusters, uint32_t n, uint32_t* __restrict__ mcount, Box6* __restrict__ nbox, uint2* __restrict__ children,
-                                                          uint32_t* __restrict__ cnt, float* __restrict__ cost) {
+// (Round 6: ONE launch for the tails of all meshes of a batch, a workgroup each -- nine tails one after the other, each a single workgroup on an otherwise idle chip, were 2.2 ms of a city commit.)
+struct PlocTailJob { uint32_t* clusters; uint32_t* mcount; Box6* nbox; uint2* children; uint32_t* cnt; float* cost; uint32_t n, pad; };
+KJ_D void ploc_tail_body(uint32_t* __restrict__ clusters, uint32_t n, uint32_t* __restrict__ mcount, Box6* __restrict__ nbox, uint2* __restrict__ children,
+                         uint32_t* __restrict__ cnt, float* __restrict__ cost) {
     __shared__ Box6 lb[PLOC_TAIL];
     __shared__ uint32_t lc[PLOC_TAIL], ln[PLOC_TAIL], scan[PLOC_TAIL];
     const uint32_t i = threadIdx.x;
@@ -589,6 +591,10 @@ __global__ void __launch_bounds__(PLOC_TAIL) k_ploc_tail(uint32_t* __restrict__ 
         __syncthreads();
     }
     if (i == 0) { clusters[0] = lc[0]; mcount[0] = 1u; mcount[1] = made; }
+}
+__global__ void __launch_bounds__(PLOC_TAIL) k_ploc_tail(const PlocTailJob* __restrict__ jobs) {
+    const PlocTailJob J = jobs[blockIdx.x];
+    ploc_tail_body(J.clusters, J.n, J.mcount, J.nbox, J.children, J.cnt, J.cost);
 }
 struct PlocItem { uint32_t bin, out, depth, first, mesh; };
 // One level of the 4-wide trees over the PLOC hierarchies of a batch: as k_lbvh_collapse, plus the top-down hand-out of triangle slots.
@@ -736,7 +742,7 @@ static hipError_t build_lbvh_batch(const LbvhJob* jobs, uint32_t njobs, LbvhScra
     for (uint32_t j = 0; j < njobs; ++j) if (jobs[j].n == 0) return hipErrorInvalidValue;
     // working set: ONE allocation (grown when a commit needs more), carved into the shared pieces and every job's own buffers
     enum { PBOX, CODES, IDS, CODES2, IDS2, CHILDREN, RANGE, PARENT, VISITS, NBOX, COUNTERS, LEVELS, JOB_SLOTS };
-    enum { Q0, Q1, QLEN, TABLE, READBACK, SORT_TMP, BOUNDS, SHARED_SLOTS };
+    enum { Q0, Q1, QLEN, TABLE, READBACK, SORT_TMP, BOUNDS, TAILS, SHARED_SLOTS };
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     size_t total_n = 0, sort_bytes = 16;
     for (uint32_t j = 0; j < njobs; ++j) {
@@ -746,7 +752,7 @@ static hipError_t build_lbvh_batch(const LbvhJob* jobs, uint32_t njobs, LbvhScra
         sort_bytes = std::max(sort_bytes, b);
     }
     const size_t rb_dwords = KJ_LBVH_RB_LEVELS + size_t(njobs) * KJ_LBVH_RB_MESH_DWORDS;
-    const size_t shared_bytes[SHARED_SLOTS] = {(total_n + njobs) * sizeof(PlocItem), (total_n + njobs) * sizeof(PlocItem), KJ_LBVH_RB_LEVELS * 4, njobs * sizeof(CollapseMesh), rb_dwords * 4, sort_bytes, size_t(njobs) * 32};
+    const size_t shared_bytes[SHARED_SLOTS] = {(total_n + njobs) * sizeof(PlocItem), (total_n + njobs) * sizeof(PlocItem), KJ_LBVH_RB_LEVELS * 4, njobs * sizeof(CollapseMesh), rb_dwords * 4, sort_bytes, size_t(njobs) * 32, njobs * sizeof(PlocTailJob)};
     auto job_bytes = [&](uint32_t n, int k) -> size_t {
         const size_t c = n;
         switch (k) {
@@ -768,6 +774,7 @@ static hipError_t build_lbvh_batch(const LbvhJob* jobs, uint32_t njobs, LbvhScra
     CollapseMesh* const d_table = (CollapseMesh*)shared[TABLE];
     uint32_t* const readback = (uint32_t*)shared[READBACK];
     std::vector<CollapseMesh> table(njobs);
+    std::vector<PlocTailJob> tails(ploc ? njobs : 0);
 
     // ---- per mesh: primitive boxes, Morton codes, sort, the binary hierarchy with its node boxes
     for (uint32_t j = 0; j < njobs; ++j) {
@@ -823,7 +830,7 @@ static hipError_t build_lbvh_batch(const LbvhJob* jobs, uint32_t njobs, LbvhScra
                 if (++rounds > n) return hipErrorUnknown;      // every round merges at least one pair
                 if (getenv("KJ_BVH_TIMING")) fprintf(stderr, "[ploc] after %u rounds: %u clusters\n", rounds * 4u, m);
             }
-            if (m > 1u) hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(PLOC_TAIL), 0, s, clusters, n, mcount, nbox, children, cnt, cost);
+            tails[j] = PlocTailJob{clusters, mcount, nbox, children, cnt, cost, n, 0u};      // the last <= PLOC_TAIL clusters: all meshes' tails in one launch below
             KJ_LB(hipMemsetAsync(tri_order, 0, size_t(n) * 4, s));      // slots a deep tree has not reached after the first batch must still name a triangle (emit below)
         } else {
             if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, g, b, 0, s, (const MortonCode*)codes2, int(n), children, range, parent);
@@ -843,6 +850,10 @@ static hipError_t build_lbvh_batch(const LbvhJob* jobs, uint32_t njobs, LbvhScra
     // appends to queue_len[l + 1]); level_nodes[l] = a mesh's nodes allocated before level l's children (a level's nodes are one contiguous run). Levels are issued
     // KJ_LBVH_BATCH at a time without looking at the queues -- every launch is sized by the bound 4^level per mesh, <= one item per triangle --, then ONE read-back
     // says whether a tree goes deeper (a 250 k-triangle mesh has ~13 levels; many coincident centroids make deep ones).
+    if (ploc) {
+        KJ_LB(hipMemcpyAsync(shared[TAILS], tails.data(), njobs * sizeof(PlocTailJob), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_ploc_tail, dim3(njobs), dim3(PLOC_TAIL), 0, s, (const PlocTailJob*)shared[TAILS]);
+    }
     KJ_LB(hipMemcpyAsync(d_table, table.data(), njobs * sizeof(CollapseMesh), hipMemcpyHostToDevice, s));
     void* qin = shared[Q0]; void* qout = shared[Q1];
     const dim3 mg((njobs + 63) / 64);

@@ -214,8 +214,10 @@ KjStatus kj_scene_remove_instance(KjScene* s, uint32_t instance) {
 
 // nodes of a BLAS' top levels kept on the host for the top-tree build (root + up to four levels below it)
 #define KJ_BLAS_TOP_NODES 341u
-// from this many top-tree leaves on, the commit builds the top tree on the device (kj_scene_set_top_build_mode overrides)
-#define KJ_TOP_DEVICE_MIN_LEAVES 4096u
+// from this many top-tree leaves on, the commit builds the top tree on the device (kj_scene_set_top_build_mode overrides). Measured on MI355X (round 6,
+// profiles/r06_blas_builds.md): a commit with one moved instance costs 0.14 ms (host) / 0.22 ms (device) at 256 instances, 0.63 / 0.32 ms at 1024, 2.6 / 0.47 ms at 4096,
+// 23.6 / 1.7 ms at 32 k; closest-hit rays under the device's linear tree run within 2 % of the host's SAH tree at every count, occlusion rays 0-11 % slower.
+#define KJ_TOP_DEVICE_MIN_LEAVES 1024u
 
 // world box of an object-space box under a 3x4 transform (all eight corners), padded for fp32 rounding
 static void world_box(const float* x, const float* ob, float* wb) {
