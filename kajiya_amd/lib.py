@@ -235,7 +235,7 @@ class Scene:
         self.dev = dev
         self.h = C.c_void_p()
         check(L.kj_scene_create(dev.h, C.byref(self.h)))
-        if top_build is not None:   # who builds the per-commit top tree: "host" / 1, "device" / 2 (default: the host below 4096 leaves, the device from there on)
+        if top_build is not None:   # who builds the per-commit top tree: "host" / 1, "device" / 2 (default: the host below 1024 leaves, the device from there on)
             check(L.kj_scene_set_top_build_mode(self.h, {"auto": 0, "host": 1, "device": 2}.get(top_build, top_build)))
         if open_instances:  # top-tree leaves = nodes of the instances' top levels instead of whole instances
             check(L.kj_scene_set_open_instances(self.h, 1))

@@ -764,7 +764,7 @@ def test_instance_trees_under_rotation_mirroring_and_repeated_edits(gpu, oracle,
         desc.add_instance(*live[-1])
     open_instances = "open" in str(fast_build)     # host-built BLASes; top-tree leaves = nodes of the instances' top levels (kj_scene_set_open_instances)
     device_top = "device_top" in str(fast_build)
-    gsc = gpu.Scene(device, desc, fast_build=False if (open_instances or device_top) else fast_build, open_instances=open_instances, top_build="device" if device_top else None)
+    gsc = gpu.Scene(device, desc, fast_build=False if (open_instances or device_top) else fast_build, open_instances=open_instances, top_build="device" if device_top else "host")      # (KJ_TOP_BUILD_AUTO would pick the device for the opened variants: > 1024 top-tree leaves)
 
     def check(tag):
         cur = scenes.SceneDesc()
