@@ -69,6 +69,9 @@ struct SpatialArgs {
 
 // R = reach of the pass in half-res pixels (32: first pass, 16: later passes), SAMPLES = 8 / 5, BW x BH = workgroup in pixels
 // (multiples of 8: one wave per 8x8 block), TILE = stage the G-buffer records in LDS (else gather them from HBM/L2).
+#ifndef KJ_MARCH_BATCH
+#define KJ_MARCH_BATCH 0
+#endif
 #ifndef KJ_SPATIAL_BATCH
 #define KJ_SPATIAL_BATCH 0      // taps of restir spatial whose gathers are in flight together: 0 = the measured choice per pass (below), 1 = the shader text's order everywhere
 #endif
@@ -195,6 +198,41 @@ __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
                 const float depth_step_per_z = (end_cs.z - depth) * rcp_fast(length_fast(V2{end_cs.x - c_cs.x, end_cs.y - c_cs.y}));
                 const float t_step = rcp_fast(float(k_count));
                 float t = 0.5f * t_step;
+#if KJ_MARCH_BATCH
+                // -DKJ_MARCH_BATCH=N (round 6, measured and NOT adopted): the march's depth taps -- their addresses depend on nothing loaded -- requested N at a time, the
+                // text's arithmetic behind them in the text's order (a lane past its k_count reads texel 0 and ignores it). 94 -> 101 / 105 / 117 VGPRs (five -> four waves per
+                // SIMD); N = 6: 41.0 -> 40.0 us at 1080p, 129 -> 123.5 us at 4K for the pass, nothing on the rtdgi segment or the frame (profiles/r06_screen_passes.md)
+                if (!TILE) {
+#pragma unroll
+                    for (int k0 = 0; k0 < 6; k0 += KJ_MARCH_BATCH) {
+                        if (!wave_any(k0 < k_count)) break;
+                        float m_depth[KJ_MARCH_BATCH], m_iz[KJ_MARCH_BATCH], m_bz[KJ_MARCH_BATCH]; bool m_in[KJ_MARCH_BATCH];
+#pragma unroll
+                        for (int j = 0; j < KJ_MARCH_BATCH; ++j) if (k0 + j < 6) {
+                            const V3 interp_cs = lerp(V3{c_cs.x, c_cs.y, depth}, end_cs, t);
+                            const V2 uv_at = cs_to_uv(V2{interp_cs.x, interp_cs.y});
+                            const float fpx = floorf(uv_at.x * fullres.x - float(off.x)), fpy = floorf(uv_at.y * fullres.y - float(off.y));
+                            const uint32_t ux = fpx > 0 ? uint32_t(fpx) : 0u, uy = fpy > 0 ? uint32_t(fpy) : 0u;
+                            const uint32_t pxi = (ux & ~1u) + uint32_t(off.x), pyi = (uy & ~1u) + uint32_t(off.y);
+                            const int hx = int(pxi >> 1u), hy = int(pyi >> 1u);
+                            m_in[j] = k0 + j < k_count && a.half_depth_tex.inb(hx, hy);
+                            m_depth[j] = a.half_depth_tex.p[m_in[j] ? size_t(hy) * a.half_depth_tex.w + hx : size_t(0)];
+                            const V2 qcs = uv_to_cs(V2{(float(pxi) + 0.5f) * gts.z, (float(pyi) + 0.5f) * gts.w});
+                            m_bz[j] = depth + depth_step_per_z * length_fast(qcs - c_cs);
+                            m_iz[j] = interp_cs.z;
+                            t += t_step;
+                        }
+#pragma unroll
+                        for (int j = 0; j < KJ_MARCH_BATCH; ++j) if (k0 + j < 6) {
+                            const float depth_at = m_in[j] ? m_depth[j] : 0.0f;
+                            if (k0 + j < k_count && depth_at > m_bz[j]) {
+                                const float depth_diff = fabsf(fmaxf(1e-20f, m_iz[j]) * rcp_fast(fmaxf(1e-20f, depth_at)) - 1.0f);
+                                visibility *= 1 - smoothstep_fast(0.05f, 0.025f, depth_diff);
+                            }
+                        }
+                    }
+                } else
+#endif
 #pragma unroll 1
                 for (int k = 0; k < 6; ++k) {
                     const bool active = k < k_count;
@@ -461,6 +499,12 @@ KJ_D V3 uncrunch(V3 v) { return v * rcp_fast(1.0f - max3(v.x, v.y, v.z)); }
 #ifndef KJ_SPATIAL_FILTER_TILED
 #define KJ_SPATIAL_FILTER_TILED 0
 #endif
+#ifndef KJ_SF_BATCH
+#define KJ_SF_BATCH 1      // 0: one tap at a time, as the shader text has the loop
+#endif
+#ifndef KJ_SF_SIZES
+#define KJ_SF_SIZES 1, 6
+#endif
 #define KJ_SF_B 16
 #define KJ_SF_R 16
 #define KJ_SF_T (KJ_SF_B + 2 * KJ_SF_R)
@@ -523,6 +567,46 @@ __global__ void __launch_bounds__(KJ_SPATIAL_FILTER_TILED ? 256 : 64) k_spatial_
     const float depth_scale = -100.0f * center_nz;
     const float tap_pow[8] = {0.0f, powf(1.0f, KERNEL_SHARPNESS), powf(2.0f, KERNEL_SHARPNESS), powf(3.0f, KERNEL_SHARPNESS), powf(4.0f, KERNEL_SHARPNESS),
                               powf(5.0f, KERNEL_SHARPNESS), powf(6.0f, KERNEL_SHARPNESS), powf(7.0f, KERNEL_SHARPNESS)};
+#if KJ_SF_BATCH && !KJ_SPATIAL_FILTER_TILED
+    // The seven taps in batches (round 6): a batch's depth gathers are requested together, then the value + ssao gathers of the taps that pass the text's test (the
+    // others read texel 0: no branch between the requests), then the text's arithmetic in the text's order -- same operations on the same values; a batch no lane of the
+    // wave reaches is skipped. sample_count is 2 (tap 1 only) wherever validity > 0.5, hence a first batch of one, then the other six: 14 round trips to memory become 4.
+    // MI355X (profiles/r06_screen_passes.md): 44.0 -> 39.8 us at 1080p, 178 -> 161 us at 4K; {1,3,3} 40.2 / 165, {3,4} 40.7 / 164, {7} 40.9 / 165.
+    constexpr int sf_sizes[] = {KJ_SF_SIZES};
+    constexpr int sf_batches = int(sizeof(sf_sizes) / sizeof(int));
+    uint32_t b = 1;
+#pragma unroll
+    for (int bi = 0; bi < sf_batches; ++bi) {
+        if (!wave_any(b < sample_count)) break;
+        constexpr int NB = 7;      // largest batch
+        int t_idx[NB]; float t_depth[NB]; bool t_use[NB]; uint2 t_v[NB]; uint32_t t_s[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) if (k < sf_sizes[bi]) {
+            const uint32_t si = b + k;
+            const V2 so = cos_sin_turns_fast((float(si) + ang_off) * KJ_GOLDEN_ANGLE) * (tap_pow[si & 7u] * RADIUS_SAMPLE_MULT);
+            const int sx = int(float(x) + so.x), sy = int(float(y) + so.y);
+            t_idx[k] = (si < sample_count && depth_tex.inb(sx, sy)) ? sy * depth_tex.w + sx : -1;
+            t_depth[k] = depth_tex.p[t_idx[k] < 0 ? 0 : t_idx[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) if (k < sf_sizes[bi]) {
+            t_use[k] = t_idx[k] >= 0 && t_depth[k] != 0;
+            t_v[k] = input_tex.p[t_use[k] ? t_idx[k] : 0];
+            t_s[k] = ssao_tex.p[t_use[k] ? t_idx[k] : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) if (k < sf_sizes[bi]) {
+            if (t_use[k]) {
+                const V3 sample_val = xyz(unpack_rgba16f(t_v[k]));
+                const float sample_ssao = from_unorm8(uint8_t(t_s[k]));
+                float wt = exp2_fast(-fabsf(depth_scale * (center_depth * rcp_fast(t_depth[k]) - 1.0f)));
+                wt *= exp2_fast(-20.0f * fabsf(sample_ssao - center_ssao));
+                sum += v4(crunch(sample_val), 1.0f) * wt;
+            }
+        }
+        b += sf_sizes[bi];
+    }
+#else
 #pragma unroll
     for (uint32_t si = 1; si < 8u; ++si) {
         if (!wave_any(si < sample_count)) break;       // sample_count is per pixel; the wave stops at its largest
@@ -550,6 +634,7 @@ __global__ void __launch_bounds__(KJ_SPATIAL_FILTER_TILED ? 256 : 64) k_spatial_
         }
 #endif
     }
+#endif
     const float norm_factor = rcp_fast(fmaxf(1e-5f, sum.w));
     st4(output_tex, x, y, v4(uncrunch(xyz(sum) * norm_factor), 1.0f));
 }
