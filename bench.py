@@ -509,8 +509,8 @@ def main():
         table = [("rtdgi reproject", "k_fullres_reproject", n_f, 24), ("extract half", "k_extract_half<0>", n_h2, 30)] + \
                 ([("restir temporal", "k_validity_integrate_restir_temporal", n_h2, 25 + 168)] if vi_fused else
                  [("validity integrate", "k_validity_integrate", n_h2, 25), ("restir temporal", "k_restir_temporal", n_h2, 168)]) + \
-                [("restir spatial 0", f"k_restir_spatial<32, 8, 16, 16, false, {tile_order}>", n_h2, 41),
-                 ("restir spatial 1", f"k_restir_spatial<16, 5, 16, 16, false, {tile_order}>", n_h2, 41), ("restir resolve", f"k_restir_resolve<{2 if (W + 15) // 16 >= 96 else 3}>", n_f, 43),
+                [("restir spatial 0", f"k_restir_spatial<32, 8, 16, 16, false, {tile_order}, false>", n_h2, 41),
+                 ("restir spatial 1", f"k_restir_spatial<16, 5, 16, 16, false, {tile_order}, true>", n_h2, 41), ("restir resolve", f"k_restir_resolve<{2 if (W + 15) // 16 >= 96 else 3}>", n_f, 43),
                  ("rtdgi temporal", "k_temporal_filter", n_f, 49), ("rtdgi spatial", "k_spatial_filter", n_f, 25)]
 
         def entry(kernel, ms, algo_bytes, note=None):

@@ -70,12 +70,13 @@ struct SpatialArgs {
 // R = reach of the pass in half-res pixels (32: first pass, 16: later passes), SAMPLES = 8 / 5, BW x BH = workgroup in pixels
 // (multiples of 8: one wave per 8x8 block), TILE = stage the G-buffer records in LDS (else gather them from HBM/L2).
 #ifndef KJ_MARCH_BATCH
-#define KJ_MARCH_BATCH 0
+#define KJ_MARCH_BATCH 6      // the second pass' march: its six depth taps requested together (0: the rolled loop)
 #endif
 #ifndef KJ_SPATIAL_BATCH
 #define KJ_SPATIAL_BATCH 0      // taps of restir spatial whose gathers are in flight together: 0 = the measured choice per pass (below), 1 = the shader text's order everywhere
 #endif
-template <int R, int SAMPLES, int BW, int BH, bool TILE, int ORDER>
+// MARCH: the launch performs the occlusion march (the last spatial pass). A pass that does not is built without the march's code and registers (KJ_SPATIAL_MARCH_SPLIT).
+template <int R, int SAMPLES, int BW, int BH, bool TILE, int ORDER, bool MARCH>
 __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
     constexpr int TW = BW + 2 * R, TH = BH + 2 * R;
     __shared__ uint2 tile[TILE ? TW * TH : 1];
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
             jacobian = sqrt_fast(dist_ratio * dist_ratio * clampf(center_to_hit_vis * rcp_fast(reused_to_hit_vis), 0.0f, 1e4f));
         }
         float visibility = 1;
-        if (a.perform_occlusion_raymarch) {
+        if (MARCH && a.perform_occlusion_raymarch) {
             // the march only scales this sample's weight: skipped (wave-wide when possible) for samples whose weight is zero anyway
             const bool contributes = p_q > 0 && r.M != 0 && r.W != 0;
             if (wave_any(contributes)) {
@@ -199,10 +200,11 @@ __global__ void __launch_bounds__(BW * BH) k_restir_spatial(SpatialArgs a) {
                 const float t_step = rcp_fast(float(k_count));
                 float t = 0.5f * t_step;
 #if KJ_MARCH_BATCH
-                // -DKJ_MARCH_BATCH=N (round 6, measured and NOT adopted): the march's depth taps -- their addresses depend on nothing loaded -- requested N at a time, the
-                // text's arithmetic behind them in the text's order (a lane past its k_count reads texel 0 and ignores it). 94 -> 101 / 105 / 117 VGPRs (five -> four waves per
-                // SIMD); N = 6: 41.0 -> 40.0 us at 1080p, 129 -> 123.5 us at 4K for the pass, nothing on the rtdgi segment or the frame (profiles/r06_screen_passes.md)
-                if (!TILE) {
+                // The march's depth taps -- their addresses depend on nothing loaded -- requested KJ_MARCH_BATCH at a time, the text's arithmetic behind them in the text's
+                // order (a lane past its k_count reads texel 0 and ignores it). In the 5-tap kernel without LDS tile only (94 -> 117 VGPRs, four waves per SIMD): pass 1
+                // 41.1 -> 39.9 us at 1080p, 129 -> 123.6 us at 4K. While every build carried the march this cost the FIRST pass a wave and was not adopted; with the march
+                // out of the first pass' build (MARCH, above: 121 -> 86 VGPRs, 26.2 -> 25.6 us / 85.0 -> 79.0 us) it pays (profiles/r06_screen_passes.md).
+                if (!TILE && SAMPLES == 5) {
 #pragma unroll
                     for (int k0 = 0; k0 < 6; k0 += KJ_MARCH_BATCH) {
                         if (!wave_any(k0 < k_count)) break;
@@ -774,18 +776,24 @@ hipError_t launch_restir_spatial(const SpatialLaunch& L, hipStream_t s) {
 #else
     const int order = resample_tile_order((L.hw + 15) / 16);
 #endif
-#define KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, O_) hipLaunchKernelGGL((k_restir_spatial<R_, S_, BW_, BH_, T_, O_>), dim3((L.hw + BW_ - 1) / BW_, (rows + BH_ - 1) / BH_), dim3(BW_ * BH_), 0, s, a)
-#define KJ_SPATIAL(R_, S_, BW_, BH_, T_) do { if (order == KJ_TILES_BANDS) KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, KJ_TILES_BANDS); else if (order == KJ_TILES_SUPER) KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, KJ_TILES_SUPER); \
-                                              else KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, KJ_TILES_PLAIN); } while (0)
+#ifndef KJ_SPATIAL_MARCH_SPLIT
+#define KJ_SPATIAL_MARCH_SPLIT 1      // 0: every kernel carries the march (one build per shape)
+#endif
+#define KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, O_, M_) hipLaunchKernelGGL((k_restir_spatial<R_, S_, BW_, BH_, T_, O_, M_>), dim3((L.hw + BW_ - 1) / BW_, (rows + BH_ - 1) / BH_), dim3(BW_ * BH_), 0, s, a)
+#define KJ_SPATIAL_M(R_, S_, BW_, BH_, T_, M_) do { if (order == KJ_TILES_BANDS) KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, KJ_TILES_BANDS, M_); else if (order == KJ_TILES_SUPER) KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, KJ_TILES_SUPER, M_); \
+                                                   else KJ_SPATIAL_O(R_, S_, BW_, BH_, T_, KJ_TILES_PLAIN, M_); } while (0)
+    // the first pass of the default two does not march: its kernel is built without the march; any later pass uses the build that has it (the run-time flag decides)
+#define KJ_SPATIAL(R_, S_, BW_, BH_, T_) do { if (KJ_SPATIAL_MARCH_SPLIT && L.pass_idx == 0 && !L.perform_occlusion_raymarch) KJ_SPATIAL_M(R_, S_, BW_, BH_, T_, false); else KJ_SPATIAL_M(R_, S_, BW_, BH_, T_, true); } while (0)
     if (L.pass_idx == 0) {
         if (L.variant == 0) KJ_SPATIAL(32, 8, 32, 32, true);
         else if (L.variant == 1) KJ_SPATIAL(32, 8, 16, 16, true);
         else KJ_SPATIAL(32, 8, 16, 16, false);
     } else {
-        if (L.variant == 0 || L.variant == 1) KJ_SPATIAL(16, 5, 16, 16, true);
-        else KJ_SPATIAL(16, 5, 16, 16, false);
+        if (L.variant == 0 || L.variant == 1) KJ_SPATIAL_M(16, 5, 16, 16, true, true);
+        else KJ_SPATIAL_M(16, 5, 16, 16, false, true);
     }
 #undef KJ_SPATIAL_O
+#undef KJ_SPATIAL_M
 #undef KJ_SPATIAL
     return hipGetLastError();
 }
